@@ -1,0 +1,187 @@
+/* p3r.h - C ABI of the MI355X-native batch-STARK prover for the p3-recursion
+ * `prove_next_layer` hot path.
+ *
+ * The reference (Plonky3/Plonky3-recursion) is pure Rust and exposes NO FFI for a device
+ * backend; the seam this library replaces is
+ *
+ *   BatchStarkProver::prove_all_tables      circuit-prover/src/batch_stark_prover.rs:1203-1222
+ *     -> prove::<EF,D>                       circuit-prover/src/batch_stark_prover.rs:1275-1642
+ *       -> p3_batch_stark::prove_batch       call site batch_stark_prover.rs:1595
+ *   ProverData::from_airs_and_degrees        call sites recursion/src/recursion.rs:376,487,737,859
+ *
+ * plus the finer unit seams a Rust integrator can bind one at a time:
+ *
+ *   TableProver::batch_instance_d4 (Poseidon2 table)   batch_stark_prover/dynamic_air.rs:324-419
+ *     -> Poseidon2CircuitAir::generate_trace_rows       poseidon2-circuit-air/src/air.rs:280-520
+ *   Mmcs::commit / open_batch (MerkleTreeMmcs)          circuit-prover/src/config.rs:56-63,129
+ *   TwoAdicSubgroupDft::coset_lde_batch                 circuit-prover/src/config.rs:55,131
+ *   CryptographicPermutation<[F;16]>::permute           circuit-prover/src/config.rs:126-136
+ *
+ * Conventions (mirroring the reference's Result<_, String> stringification at
+ * recursion/src/recursion.rs:34-36):
+ *   - every int-returning call returns 0 on success and a negative P3R_E* code on failure;
+ *     p3r_last_error(ctx) then returns a human-readable message (ctx may be NULL for
+ *     failures of p3r_create itself);
+ *   - one p3r_ctx per GPU, NOT thread-safe, one call in flight per ctx (RecursionOutput is
+ *     !Send in the reference: recursion/src/recursion.rs:117-139);
+ *   - every field element crossing this ABI is a CANONICAL u32 (< p); matrices are
+ *     ROW-MAJOR exactly like p3_matrix::dense::RowMajorMatrix; extension-field elements are
+ *     4 consecutive base coefficients (basis 1,x,x^2,x^3);
+ *   - the caller owns all host buffers; the ctx owns all device memory;
+ *   - there is NO CPU fallback: without a usable gfx950 device p3r_create fails.
+ */
+#ifndef P3R_H
+#define P3R_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3R_ABI_VERSION 1
+
+enum {
+  P3R_OK = 0,
+  P3R_EINVAL = -1,   /* bad argument / shape (reference: InvalidProofShape-style errors) */
+  P3R_ENODEV = -2,   /* no usable HIP device */
+  P3R_EHIP = -3,     /* HIP runtime error */
+  P3R_ENOMEM = -4,
+  P3R_EUNSUPPORTED = -5, /* reference: BatchStarkProverError::UnsupportedDegree */
+  P3R_EBUFFER = -6   /* caller buffer too small */
+};
+
+enum { P3R_FIELD_KOALA_BEAR = 0, P3R_FIELD_BABY_BEAR = 1 };
+
+/* Mirrors the FRI/PCS parameters the examples build
+ * (recursion/examples/common/mod.rs:464-486, recursive_fibonacci.rs:71-147) plus the
+ * field selection of circuit-prover/src/config.rs:180-183. */
+typedef struct p3r_config {
+  uint32_t abi_version;        /* P3R_ABI_VERSION */
+  uint32_t field;              /* P3R_FIELD_* */
+  uint32_t ext_degree;         /* 4 (binomial x^4 = W) */
+  uint32_t log_blowup;
+  uint32_t max_log_arity;
+  uint32_t cap_height;
+  uint32_t log_final_poly_len;
+  uint32_t commit_pow_bits;
+  uint32_t query_pow_bits;
+  uint32_t num_queries;
+  int32_t device;              /* HIP device ordinal */
+  /* Poseidon2 width-16 round constants, canonical, flat:
+   *   [4][16] external-initial | [partial_rounds] internal | [4][16] external-final
+   * (the p3_{koala,baby}_bear::*_POSEIDON2_RC_16_* statics a Rust caller passes through,
+   * poseidon2-circuit-air/src/public_types.rs:48-54,220-226).  NULL selects the library's
+   * built-in table, which is self-generated and NOT pinned to upstream. */
+  const uint32_t* poseidon2_rc;
+  uint32_t poseidon2_rc_len;
+} p3r_config;
+
+typedef struct p3r_ctx p3r_ctx;
+typedef struct p3r_dmat p3r_dmat; /* device-resident matrix (power-of-two height) */
+typedef struct p3r_tree p3r_tree; /* device-resident MMCS prover data */
+
+/* ---- context ---- */
+p3r_ctx* p3r_create(const p3r_config* cfg);
+void p3r_destroy(p3r_ctx* ctx);
+const char* p3r_last_error(const p3r_ctx* ctx);
+/* Width of the Poseidon2 circuit-table main trace (166 KoalaBear / 300 BabyBear), i.e.
+ * BaseAir::width of Poseidon2CircuitAir (poseidon2-circuit-air/src/air.rs:561-585). */
+uint32_t p3r_poseidon2_trace_width(const p3r_ctx* ctx);
+/* Number of round constants the configured field expects (148 / 141). */
+uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx);
+/* Blocks until all work queued on the ctx's stream has completed. */
+int p3r_sync(p3r_ctx* ctx);
+
+/* ---- device matrices (inputs stay resident in HBM between calls) ---- */
+p3r_dmat* p3r_dmat_upload(p3r_ctx* ctx, const uint32_t* rowmajor, size_t height, size_t width);
+p3r_dmat* p3r_dmat_alloc(p3r_ctx* ctx, size_t height, size_t width);
+int p3r_dmat_download(p3r_ctx* ctx, const p3r_dmat* m, uint32_t* rowmajor_out);
+size_t p3r_dmat_height(const p3r_dmat* m);
+size_t p3r_dmat_width(const p3r_dmat* m);
+void p3r_dmat_free(p3r_ctx* ctx, p3r_dmat* m);
+
+/* ---- K3: Poseidon2 (CryptographicPermutation + circuit-table trace fill) ---- */
+
+/* n independent width-16 permutations; in/out are n x 16 row-major. */
+int p3r_poseidon2_permute_batch(p3r_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);
+/* Device-resident form: states is an n x 16 matrix permuted in place. */
+int p3r_poseidon2_permute_dmat(p3r_ctx* ctx, p3r_dmat* states);
+
+/* Flattened Vec<Poseidon2CircuitRow<F>> (circuit/src/ops/poseidon2_perm/trace.rs:94-125),
+ * already padded to a power of two by the caller exactly as Poseidon2Prover does
+ * (circuit-prover/src/batch_stark_prover/poseidon2.rs:1125-1140). Only the fields the
+ * main trace depends on are carried; the CTL fields feed the preprocessed trace. */
+typedef struct p3r_p2_rows {
+  size_t n;                       /* power of two */
+  const uint32_t* input_values;   /* n x 16 row-major */
+  const uint8_t* new_start;       /* n */
+  const uint8_t* merkle_path;     /* n */
+  const uint8_t* mmcs_bit;        /* n */
+  const uint32_t* mmcs_index_sum; /* n */
+} p3r_p2_rows;
+
+/* Poseidon2CircuitAir::generate_trace_rows: trace_out is n x p3r_poseidon2_trace_width(). */
+int p3r_poseidon2_trace_fill(p3r_ctx* ctx, const p3r_p2_rows* rows, uint32_t* trace_out);
+/* Same, leaving the trace in HBM. */
+p3r_dmat* p3r_poseidon2_trace_fill_dmat(p3r_ctx* ctx, const p3r_p2_rows* rows);
+/* Rows kept resident in HBM (so a prove can start from device-resident inputs). */
+typedef struct p3r_p2_dev p3r_p2_dev;
+p3r_p2_dev* p3r_p2_rows_upload(p3r_ctx* ctx, const p3r_p2_rows* rows);
+void p3r_p2_rows_free(p3r_ctx* ctx, p3r_p2_dev* rows);
+p3r_dmat* p3r_poseidon2_trace_fill_dev(p3r_ctx* ctx, const p3r_p2_dev* rows);
+
+/* ---- K5: coset low-degree extension (TwoAdicSubgroupDft::coset_lde_batch followed by
+ * bit_reverse_rows, as TwoAdicFriPcs::commit applies it) ----
+ * evals: h x w evaluations over the size-h subgroup (natural order).
+ * out  : (h << added_bits) x w, row i = evaluation at shift * w_{h<<added_bits}^{bitrev(i)}. */
+int p3r_coset_lde(p3r_ctx* ctx, const uint32_t* evals, size_t h, size_t w, uint32_t added_bits,
+                  uint32_t shift, uint32_t* out);
+p3r_dmat* p3r_coset_lde_dmat(p3r_ctx* ctx, const p3r_dmat* evals, uint32_t added_bits,
+                             uint32_t shift);
+
+/* ---- K6: MMCS (MerkleTreeMmcs<PaddingFreeSponge<Perm,16,8,8>, TruncatedPermutation<Perm,2,8,16>>) ---- */
+
+typedef struct p3r_matrix {
+  const uint32_t* values; /* height x width row-major */
+  size_t height;          /* power of two */
+  size_t width;
+} p3r_matrix;
+
+/* Mmcs::commit over host matrices of mixed heights; cap_out receives (8 << cap_height)
+ * elements; *tree_out (optional, may be NULL) receives the prover data for p3r_mmcs_open. */
+int p3r_mmcs_commit(p3r_ctx* ctx, const p3r_matrix* mats, size_t n_mats, uint32_t* cap_out,
+                    p3r_tree** tree_out);
+/* Same over device-resident matrices; the tree borrows (does not own) the matrices. */
+int p3r_mmcs_commit_dmat(p3r_ctx* ctx, const p3r_dmat* const* mats, size_t n_mats,
+                         uint32_t* cap_out, p3r_tree** tree_out);
+/* Mmcs::open_batch(index): writes, for each committed matrix in commit order, its row
+ * (index >> (log_max_height - log_height)) into opened_values (concatenated, sum of widths
+ * elements), and the sibling digests bottom-up into proof_out
+ * ((log_max_height - cap_height) x 8 elements). */
+int p3r_mmcs_open(p3r_ctx* ctx, const p3r_tree* tree, size_t index, uint32_t* opened_values,
+                  uint32_t* proof_out);
+size_t p3r_tree_log_max_height(const p3r_tree* tree);
+size_t p3r_tree_total_width(const p3r_tree* tree);
+void p3r_tree_free(p3r_ctx* ctx, p3r_tree* tree);
+
+/* ---- measurement support (bench.py): run `iters` back-to-back launches of one kernel
+ * family on resident data and return the mean per-launch time measured with HIP events
+ * on the ctx's own stream. ---- */
+int p3r_time_permute_dmat(p3r_ctx* ctx, p3r_dmat* states, int iters, double* ms_per_launch);
+
+/* Per-kernel-family timers: while enabled, every launch of a hot kernel is bracketed by HIP
+ * events on the ctx's stream; p3r_profile_read sums them per family since the last enable. */
+typedef struct p3r_profile_entry {
+  char name[32];
+  double total_ms;
+  uint64_t launches;
+} p3r_profile_entry;
+int p3r_profile_enable(p3r_ctx* ctx, int on);
+int p3r_profile_read(p3r_ctx* ctx, p3r_profile_entry* out, size_t cap, size_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3R_H */

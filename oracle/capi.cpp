@@ -1,0 +1,216 @@
+// ORACLE (test infrastructure): extern "C" entry points so tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg can drive the CPU restatement through ctypes.
+// Nothing in the product (plonky3_recursion_amd/) may link or load this library.
+// PARITY UNPINNED (see field.hpp).
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "dft.hpp"
+#include "hash.hpp"
+#include "tables.hpp"
+
+using namespace orc;
+
+namespace {
+thread_local std::string g_err;
+template <class Fn>
+int guard(Fn&& fn) {
+  try {
+    fn();
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+template <class FP>
+Matrix<FP> mat_from(const uint32_t* v, size_t h, size_t w) {
+  Matrix<FP> m(h, w);
+  for (size_t i = 0; i < h * w; ++i) {
+    if (v[i] >= FP::P) throw std::runtime_error("non-canonical input element");
+    m.v[i] = Fe<FP>(v[i]);
+  }
+  return m;
+}
+template <class FP>
+void mat_to(const Matrix<FP>& m, uint32_t* out) {
+  for (size_t i = 0; i < m.v.size(); ++i) out[i] = m.v[i].v;
+}
+
+struct TreeBase {
+  virtual ~TreeBase() = default;
+  virtual void open(size_t index, uint32_t* opened, uint32_t* proof) const = 0;
+  virtual size_t total_width() const = 0;
+  virtual int log_max_h() const = 0;
+};
+template <class FP>
+struct TreeImpl : TreeBase {
+  std::vector<std::unique_ptr<Matrix<FP>>> owned;
+  MerkleTree<FP> tree;
+  void open(size_t index, uint32_t* opened, uint32_t* proof) const override {
+    std::vector<std::vector<Fe<FP>>> ov;
+    std::vector<typename MerkleTree<FP>::Digest> pf;
+    tree.open(index, ov, pf);
+    for (auto& r : ov) for (auto x : r) *opened++ = x.v;
+    for (auto& d : pf) for (auto x : d) *proof++ = x.v;
+  }
+  size_t total_width() const override {
+    size_t t = 0;
+    for (auto& m : owned) t += m->w;
+    return t;
+  }
+  int log_max_h() const override { return tree.log_max_h; }
+};
+
+#define FIELD_SWITCH(field, fn, ...)                                  \
+  do {                                                                \
+    if ((field) == 0) fn<KoalaBear>(__VA_ARGS__);                     \
+    else if ((field) == 1) fn<BabyBear>(__VA_ARGS__);                 \
+    else throw std::runtime_error("unknown field id");                \
+  } while (0)
+
+template <class FP>
+void do_permute(const uint32_t* rc, const uint32_t* in, uint32_t* out, size_t n) {
+  Poseidon2<FP> p2(rc);
+  for (size_t i = 0; i < n; ++i) {
+    std::array<Fe<FP>, WIDTH> s;
+    for (int k = 0; k < WIDTH; ++k) s[k] = Fe<FP>(in[i * WIDTH + k]);
+    p2.permute(s);
+    for (int k = 0; k < WIDTH; ++k) out[i * WIDTH + k] = s[k].v;
+  }
+}
+
+template <class FP>
+void do_trace_rows(const uint32_t* rc, size_t n, const uint32_t* inputs, const uint8_t* new_start,
+                   const uint8_t* merkle_path, const uint8_t* mmcs_bit, const uint32_t* index_sum,
+                   uint32_t* out) {
+  Poseidon2<FP> p2(rc);
+  std::vector<P2Row<FP>> rows(n);
+  for (size_t i = 0; i < n; ++i) {
+    rows[i].new_start = new_start[i];
+    rows[i].merkle_path = merkle_path[i];
+    rows[i].mmcs_bit = mmcs_bit[i];
+    rows[i].mmcs_index_sum = Fe<FP>(index_sum[i]);
+    for (int k = 0; k < WIDTH; ++k) rows[i].input[k] = Fe<FP>(inputs[i * WIDTH + k]);
+  }
+  mat_to(p2_generate_trace_rows<FP>(p2, rows), out);
+}
+
+template <class FP>
+void do_lde(const uint32_t* evals, size_t h, size_t w, uint32_t added_bits, uint32_t shift,
+            uint32_t* out) {
+  mat_to(coset_lde_bitrev<FP>(mat_from<FP>(evals, h, w), (int)added_bits, Fe<FP>(shift)), out);
+}
+
+template <class FP>
+void do_commit(const uint32_t* rc, size_t n_mats, const uint32_t* const* values, const size_t* heights,
+               const size_t* widths, int cap_height, uint32_t* cap_out, void** tree_out) {
+  Poseidon2<FP> p2(rc);
+  auto t = std::make_unique<TreeImpl<FP>>();
+  std::vector<const Matrix<FP>*> ptrs;
+  for (size_t i = 0; i < n_mats; ++i) {
+    t->owned.push_back(std::make_unique<Matrix<FP>>(mat_from<FP>(values[i], heights[i], widths[i])));
+    ptrs.push_back(t->owned.back().get());
+  }
+  t->tree = MerkleTree<FP>::commit(p2, ptrs, cap_height);
+  for (auto& d : t->tree.cap()) for (auto x : d) *cap_out++ = x.v;
+  if (tree_out) *tree_out = static_cast<TreeBase*>(t.release());
+}
+
+template <class FP>
+void do_verify(const uint32_t* rc, const uint32_t* cap, int cap_height, size_t n_mats,
+               const size_t* heights, const size_t* widths, size_t index, const uint32_t* opened,
+               const uint32_t* proof, size_t proof_len, int* ok) {
+  Poseidon2<FP> p2(rc);
+  using Digest = typename MerkleTree<FP>::Digest;
+  std::vector<Digest> capd(size_t(1) << cap_height);
+  for (auto& d : capd) for (auto& x : d) x = Fe<FP>(*cap++);
+  std::vector<std::pair<size_t, size_t>> dims;
+  std::vector<std::vector<Fe<FP>>> ov;
+  for (size_t i = 0; i < n_mats; ++i) {
+    dims.emplace_back(heights[i], widths[i]);
+    std::vector<Fe<FP>> r(widths[i]);
+    for (auto& x : r) x = Fe<FP>(*opened++);
+    ov.push_back(r);
+  }
+  std::vector<Digest> pf(proof_len);
+  for (auto& d : pf) for (auto& x : d) x = Fe<FP>(*proof++);
+  *ok = MerkleTree<FP>::verify(p2, capd, cap_height, dims, index, ov, pf) ? 1 : 0;
+}
+
+template <class FP>
+void do_challenger_script(const uint32_t* rc, const int32_t* ops, size_t n_ops, const uint32_t* args,
+                          uint32_t* out, size_t* n_out) {
+  // ops: 0 observe(arg) ; 1 sample -> out ; 2 sample_ext -> 4 outs ; 3 sample_bits(arg) -> out ;
+  //      4 grind(arg) -> witness ; 5 observe_base_as_ext(arg)
+  Poseidon2<FP> p2(rc);
+  Challenger<FP> ch(&p2);
+  size_t o = 0;
+  for (size_t i = 0; i < n_ops; ++i) {
+    switch (ops[i]) {
+      case 0: ch.observe(Fe<FP>(args[i])); break;
+      case 1: out[o++] = ch.sample().v; break;
+      case 2: { auto e = ch.sample_ext(); for (auto c : e.c) out[o++] = c.v; break; }
+      case 3: out[o++] = ch.sample_bits((int)args[i]); break;
+      case 4: out[o++] = ch.grind((int)args[i]).v; break;
+      case 5: ch.observe_base_as_ext(Fe<FP>(args[i])); break;
+      default: throw std::runtime_error("bad challenger op");
+    }
+  }
+  *n_out = o;
+}
+
+template <class FP>
+void do_ext_ops(const uint32_t* a, const uint32_t* b, uint32_t* mul, uint32_t* inv) {
+  Fe4<FP> x, y;
+  for (int i = 0; i < 4; ++i) { x.c[i] = Fe<FP>(a[i]); y.c[i] = Fe<FP>(b[i]); }
+  auto m = x * y;
+  auto iv = x.inv();
+  for (int i = 0; i < 4; ++i) { mul[i] = m.c[i].v; inv[i] = iv.c[i].v; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+int orc_p2_trace_width(int field) { return field == 0 ? Poseidon2<KoalaBear>::perm_cols() + 2 : Poseidon2<BabyBear>::perm_cols() + 2; }
+int orc_p2_num_constants(int field) { return field == 0 ? Poseidon2<KoalaBear>::num_constants() : Poseidon2<BabyBear>::num_constants(); }
+
+int orc_p2_permute(int field, const uint32_t* rc, const uint32_t* in, uint32_t* out, size_t n) {
+  return guard([&] { FIELD_SWITCH(field, do_permute, rc, in, out, n); });
+}
+int orc_p2_trace_rows(int field, const uint32_t* rc, size_t n, const uint32_t* inputs,
+                      const uint8_t* new_start, const uint8_t* merkle_path, const uint8_t* mmcs_bit,
+                      const uint32_t* index_sum, uint32_t* out) {
+  return guard([&] { FIELD_SWITCH(field, do_trace_rows, rc, n, inputs, new_start, merkle_path, mmcs_bit, index_sum, out); });
+}
+int orc_coset_lde(int field, const uint32_t* evals, size_t h, size_t w, uint32_t added_bits,
+                  uint32_t shift, uint32_t* out) {
+  return guard([&] { FIELD_SWITCH(field, do_lde, evals, h, w, added_bits, shift, out); });
+}
+int orc_mmcs_commit(int field, const uint32_t* rc, size_t n_mats, const uint32_t* const* values,
+                    const size_t* heights, const size_t* widths, int cap_height, uint32_t* cap_out,
+                    void** tree_out) {
+  return guard([&] { FIELD_SWITCH(field, do_commit, rc, n_mats, values, heights, widths, cap_height, cap_out, tree_out); });
+}
+int orc_mmcs_open(const void* tree, size_t index, uint32_t* opened, uint32_t* proof) {
+  return guard([&] { static_cast<const TreeBase*>(tree)->open(index, opened, proof); });
+}
+void orc_tree_free(void* tree) { delete static_cast<TreeBase*>(tree); }
+int orc_mmcs_verify(int field, const uint32_t* rc, const uint32_t* cap, int cap_height, size_t n_mats,
+                    const size_t* heights, const size_t* widths, size_t index, const uint32_t* opened,
+                    const uint32_t* proof, size_t proof_len, int* ok) {
+  return guard([&] { FIELD_SWITCH(field, do_verify, rc, cap, cap_height, n_mats, heights, widths, index, opened, proof, proof_len, ok); });
+}
+int orc_challenger_script(int field, const uint32_t* rc, const int32_t* ops, size_t n_ops,
+                          const uint32_t* args, uint32_t* out, size_t* n_out) {
+  return guard([&] { FIELD_SWITCH(field, do_challenger_script, rc, ops, n_ops, args, out, n_out); });
+}
+int orc_ext_ops(int field, const uint32_t* a, const uint32_t* b, uint32_t* mul, uint32_t* inv) {
+  return guard([&] { FIELD_SWITCH(field, do_ext_ops, a, b, mul, inv); });
+}
+
+}  // extern "C"

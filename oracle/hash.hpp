@@ -1,0 +1,297 @@
+// ORACLE (test infrastructure): Poseidon2 width-16, PaddingFreeSponge<_,16,8,8>,
+// TruncatedPermutation<_,2,8,16>, DuplexChallenger<_,_,16,8> and MerkleTreeMmcs.
+// PARITY UNPINNED (see field.hpp).  Each function cites the in-tree restatement it follows.
+#pragma once
+#include <algorithm>
+#include <numeric>
+
+#include "field.hpp"
+
+namespace orc {
+
+constexpr int WIDTH = 16, RATE = 8, DIGEST = 8, HALF_FULL = 4;
+
+template <class FP>
+struct Poseidon2 {
+  using F = Fe<FP>;
+  // flat: [4][16] external-initial | [PARTIAL] internal | [4][16] external-final
+  // (poseidon2-circuit-air/src/public_types.rs:48-54,220-226 name the upstream statics)
+  std::vector<F> rc;
+  std::array<F, WIDTH> diag;            // internal diagonal v_i
+  std::array<std::array<F, WIDTH>, WIDTH> ext;  // external matrix circ(2*M4, M4, M4, M4)
+
+  static constexpr int num_constants() { return 2 * HALF_FULL * WIDTH + FP::PARTIAL; }
+  // Poseidon2Cols width: inputs | 4x{sbox[16][R], post[16]} | P x {sbox[R], post_sbox} | 4x{..}
+  static constexpr int perm_cols() {
+    return WIDTH + 2 * HALF_FULL * (WIDTH * FP::SBOX_REGS + WIDTH) + FP::PARTIAL * (FP::SBOX_REGS + 1);
+  }
+
+  explicit Poseidon2(const uint32_t* rc_canonical) {
+    rc.resize(num_constants());
+    for (int i = 0; i < num_constants(); ++i) rc[i] = F(rc_canonical[i]);
+    static const int M4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+    for (int i = 0; i < WIDTH; ++i)
+      for (int j = 0; j < WIDTH; ++j)
+        ext[i][j] = F((uint64_t)M4[i % 4][j % 4] * ((i / 4 == j / 4) ? 2 : 1));
+    // SURVEY.md appendix A (upstream p3-{koala,baby}-bear internal diagonals)
+    auto inv2k = [](int k) { return F(uint64_t(1) << k).inv(); };
+    const F two(2), three(3), four(4);
+    if (FP::P == 0x7f000001u) {
+      diag = {-two, F::one(), two, inv2k(1), three, four, -inv2k(1), -three, -four, inv2k(8),
+              inv2k(3), inv2k(24), -inv2k(8), -inv2k(3), -inv2k(4), -inv2k(24)};
+    } else {
+      diag = {-two, F::one(), two, inv2k(1), three, four, -inv2k(1), -three, -four, inv2k(8),
+              inv2k(2), inv2k(3), inv2k(27), -inv2k(8), -inv2k(4), -inv2k(27)};
+    }
+  }
+
+  void external(std::array<F, WIDTH>& s) const {
+    std::array<F, WIDTH> o{};
+    for (int i = 0; i < WIDTH; ++i)
+      for (int j = 0; j < WIDTH; ++j) o[i] += ext[i][j] * s[j];
+    s = o;
+  }
+  void internal(std::array<F, WIDTH>& s) const {
+    F sum = F::zero();
+    for (auto& x : s) sum += x;
+    for (int i = 0; i < WIDTH; ++i) s[i] = s[i] * diag[i] + sum;
+  }
+  static F sbox(F x) { return x.pow(FP::SBOX_DEGREE); }
+
+  // Permutation; when `cells` is non-null every committed trace cell is appended in
+  // Poseidon2Cols order (p3_poseidon2_air::generate_trace_rows_for_perm, called at
+  // poseidon2-circuit-air/src/air.rs:497-505).
+  void permute(std::array<F, WIDTH>& s, std::vector<F>* cells = nullptr) const {
+    if (cells) for (auto& x : s) cells->push_back(x);
+    external(s);
+    int k = 0;
+    auto full = [&]() {
+      for (int i = 0; i < WIDTH; ++i) {
+        F x = s[i] + rc[k + i];
+        if (FP::SBOX_REGS == 1 && cells) cells->push_back(x * x * x);
+        s[i] = sbox(x);
+      }
+      k += WIDTH;
+      external(s);
+      if (cells) for (auto& x : s) cells->push_back(x);
+    };
+    for (int r = 0; r < HALF_FULL; ++r) full();
+    for (int r = 0; r < FP::PARTIAL; ++r) {
+      F x = s[0] + rc[k++];
+      if (FP::SBOX_REGS == 1 && cells) cells->push_back(x * x * x);
+      s[0] = sbox(x);
+      if (cells) cells->push_back(s[0]);
+      internal(s);
+    }
+    for (int r = 0; r < HALF_FULL; ++r) full();
+  }
+
+  // PaddingFreeSponge<Perm,16,8,8>::hash_iter, overwrite mode
+  // (recursion/src/pcs/mmcs.rs:17-26 and the chunk loop :75-172).
+  std::array<F, DIGEST> hash(const std::vector<F>& in) const {
+    std::array<F, WIDTH> s{};
+    size_t i = 0;
+    while (i < in.size()) {
+      size_t take = std::min<size_t>(RATE, in.size() - i);
+      for (size_t j = 0; j < take; ++j) s[j] = in[i + j];
+      permute(s);
+      i += take;
+    }
+    std::array<F, DIGEST> d;
+    std::copy(s.begin(), s.begin() + DIGEST, d.begin());
+    return d;
+  }
+  // TruncatedPermutation<Perm,2,8,16>: perm(left || right)[0..8]
+  // (circuit/src/ops/mmcs.rs:117-160).
+  std::array<F, DIGEST> compress(const std::array<F, DIGEST>& l, const std::array<F, DIGEST>& r) const {
+    std::array<F, WIDTH> s;
+    std::copy(l.begin(), l.end(), s.begin());
+    std::copy(r.begin(), r.end(), s.begin() + DIGEST);
+    permute(s);
+    std::array<F, DIGEST> d;
+    std::copy(s.begin(), s.begin() + DIGEST, d.begin());
+    return d;
+  }
+};
+
+// DuplexChallenger<F, Perm, 16, 8> with the 0.6 prefix-free padding
+// (recursion/src/challenger/circuit.rs:97-156 duplexing, :337-364 observe/sample,
+//  :366-386 extension elements, :388-430 sample_bits / PoW).
+template <class FP>
+struct Challenger {
+  using F = Fe<FP>;
+  using EF = Fe4<FP>;
+  const Poseidon2<FP>* perm;
+  std::array<F, WIDTH> state{};
+  std::vector<F> in_buf, out_buf;
+  explicit Challenger(const Poseidon2<FP>* p) : perm(p) {}
+
+  void duplexing() {
+    size_t n = in_buf.size();
+    for (size_t i = 0; i < n; ++i) state[i] = in_buf[i];
+    in_buf.clear();
+    if (n > 0) {
+      for (size_t i = n; i < RATE; ++i) state[i] = F::zero();
+      state[RATE] += F((uint64_t)n);
+    }
+    perm->permute(state);
+    out_buf.assign(state.begin(), state.begin() + RATE);
+  }
+  void observe(F x) {
+    out_buf.clear();
+    in_buf.push_back(x);
+    if (in_buf.size() == RATE) duplexing();
+  }
+  void observe_slice(const std::vector<F>& xs) { for (auto x : xs) observe(x); }
+  template <size_t N> void observe_arr(const std::array<F, N>& xs) { for (auto x : xs) observe(x); }
+  void observe_ext(const EF& x) { for (auto c : x.c) observe(c); }
+  // observe_base_as_algebra_element: [v,0,0,0] (recursion/src/verifier/batch_stark.rs:521-523)
+  void observe_base_as_ext(F v) { observe_ext(EF(v)); }
+  F sample() {
+    if (!in_buf.empty() || out_buf.empty()) duplexing();
+    F x = out_buf.back();
+    out_buf.pop_back();
+    return x;
+  }
+  EF sample_ext() {
+    EF e;
+    for (int i = 0; i < 4; ++i) e.c[i] = sample();
+    return e;
+  }
+  uint32_t sample_bits(int bits) { return sample().v & ((bits >= 32) ? ~0u : ((1u << bits) - 1)); }
+  bool check_witness(int bits, F witness) {
+    if (bits == 0) return true;
+    observe(witness);
+    return sample_bits(bits) == 0;
+  }
+  // Deterministic grind: smallest canonical witness (upstream searches in parallel and may
+  // return any valid witness - SURVEY.md appendix A "PoW"; DESIGN.md states this choice).
+  F grind(int bits) {
+    if (bits == 0) return F::zero();
+    for (uint32_t w = 0; w < FP::P; ++w) {
+      Challenger c = *this;
+      if (c.check_witness(bits, F(w))) {
+        check_witness(bits, F(w));
+        return F(w);
+      }
+    }
+    throw std::runtime_error("grind failed");
+  }
+};
+
+// Row-major matrix of base elements.
+template <class FP>
+struct Matrix {
+  using F = Fe<FP>;
+  size_t h = 0, w = 0;
+  std::vector<F> v;
+  Matrix() = default;
+  Matrix(size_t h_, size_t w_) : h(h_), w(w_), v(h_ * w_) {}
+  F& at(size_t r, size_t c) { return v[r * w + c]; }
+  const F& at(size_t r, size_t c) const { return v[r * w + c]; }
+  std::vector<F> row(size_t r) const { return std::vector<F>(v.begin() + r * w, v.begin() + (r + 1) * w); }
+};
+
+// MerkleTreeMmcs over mixed-height matrices (recursion/src/pcs/mmcs.rs:355-425: group
+// same-height matrices, tallest first, stable; concatenate their rows into one leaf
+// preimage; circuit/src/ops/mmcs.rs:19-70,112-185: after compressing a level, if shorter
+// matrices have that height, digest = compress(digest, hash(rows))).
+template <class FP>
+struct MerkleTree {
+  using F = Fe<FP>;
+  using Digest = std::array<F, DIGEST>;
+  std::vector<const Matrix<FP>*> mats;  // commit order
+  std::vector<std::vector<Digest>> layers;
+  int log_max_h = 0, cap_height = 0;
+
+  std::vector<Digest> cap() const { return layers.back(); }
+
+  static MerkleTree commit(const Poseidon2<FP>& p2, const std::vector<const Matrix<FP>*>& mats,
+                           int cap_height) {
+    MerkleTree t;
+    t.mats = mats;
+    t.cap_height = cap_height;
+    std::vector<size_t> order(mats.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](size_t a, size_t b) { return mats[a]->h > mats[b]->h; });
+    size_t hmax = mats[order[0]]->h;
+    t.log_max_h = log2_strict(hmax);
+    auto rows_at = [&](size_t h, size_t i) {
+      std::vector<F> cat;
+      for (size_t k : order)
+        if (mats[k]->h == h) {
+          auto r = mats[k]->row(i);
+          cat.insert(cat.end(), r.begin(), r.end());
+        }
+      return cat;
+    };
+    auto any_at = [&](size_t h) {
+      for (auto* m : mats) if (m->h == h) return true;
+      return false;
+    };
+    std::vector<Digest> cur(hmax);
+    for (size_t i = 0; i < hmax; ++i) cur[i] = p2.hash(rows_at(hmax, i));
+    t.layers.push_back(cur);
+    while (cur.size() > (size_t(1) << cap_height)) {
+      size_t nn = cur.size() / 2;
+      std::vector<Digest> nxt(nn);
+      bool inj = any_at(nn);
+      for (size_t i = 0; i < nn; ++i) {
+        nxt[i] = p2.compress(cur[2 * i], cur[2 * i + 1]);
+        if (inj) nxt[i] = p2.compress(nxt[i], p2.hash(rows_at(nn, i)));
+      }
+      t.layers.push_back(nxt);
+      cur = nxt;
+    }
+    return t;
+  }
+
+  // open_batch(index): rows (index >> (log_max_h - log_h)) of every matrix in commit order,
+  // sibling digests bottom-up.
+  void open(size_t index, std::vector<std::vector<F>>& opened, std::vector<Digest>& proof) const {
+    opened.clear();
+    proof.clear();
+    for (auto* m : mats) opened.push_back(m->row(index >> (log_max_h - log2_strict(m->h))));
+    for (int l = 0; l < log_max_h - cap_height; ++l) proof.push_back(layers[l][(index >> l) ^ 1]);
+  }
+
+  // verify_batch (recursion/src/pcs/mmcs.rs:319-426): dims = (height, width) per matrix in
+  // commit order.
+  static bool verify(const Poseidon2<FP>& p2, const std::vector<Digest>& cap, int cap_height,
+                     const std::vector<std::pair<size_t, size_t>>& dims, size_t index,
+                     const std::vector<std::vector<F>>& opened, const std::vector<Digest>& proof) {
+    std::vector<size_t> order(dims.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](size_t a, size_t b) { return dims[a].first > dims[b].first; });
+    size_t hmax = dims[order[0]].first;
+    int log_max = log2_strict(hmax);
+    if ((int)proof.size() != log_max - cap_height) return false;
+    auto cat_at = [&](size_t h, bool& any) {
+      std::vector<F> cat;
+      any = false;
+      for (size_t k : order)
+        if (dims[k].first == h) {
+          any = true;
+          if (opened[k].size() != dims[k].second) throw std::runtime_error("opened width mismatch");
+          cat.insert(cat.end(), opened[k].begin(), opened[k].end());
+        }
+      return cat;
+    };
+    bool any;
+    Digest d = p2.hash(cat_at(hmax, any));
+    size_t idx = index;
+    size_t h = hmax;
+    for (auto& sib : proof) {
+      d = (idx & 1) ? p2.compress(sib, d) : p2.compress(d, sib);
+      idx >>= 1;
+      h >>= 1;
+      auto cat = cat_at(h, any);
+      if (any) d = p2.compress(d, p2.hash(cat));
+    }
+    return idx < cap.size() && cap[idx] == d;
+  }
+};
+
+}  // namespace orc

@@ -1,0 +1,9 @@
+"""MI355X-native batch-STARK prover for the p3-recursion `prove_next_layer` hot path.
+
+Host-side mirror of the reference's interface for this path over the C ABI in include/p3r.h.
+The HIP library is mandatory: importing the package is cheap, but any compute entry point
+raises if `libp3r_hip.so` has not been built (no CPU fallback).
+"""
+from .device import Context, DeviceMatrix, MerkleTree, P3rError  # noqa: F401
+
+__all__ = ["Context", "DeviceMatrix", "MerkleTree", "P3rError"]

@@ -1,0 +1,111 @@
+"""ctypes loader for the C-ABI shared library (include/p3r.h).
+
+The product has no CPU fallback: if the HIP library is missing this module raises, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp3r_hip.so")
+
+P3R_ABI_VERSION = 1
+FIELD_KOALA_BEAR = 0
+FIELD_BABY_BEAR = 1
+
+
+class P3rConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("field", C.c_uint32),
+        ("ext_degree", C.c_uint32),
+        ("log_blowup", C.c_uint32),
+        ("max_log_arity", C.c_uint32),
+        ("cap_height", C.c_uint32),
+        ("log_final_poly_len", C.c_uint32),
+        ("commit_pow_bits", C.c_uint32),
+        ("query_pow_bits", C.c_uint32),
+        ("num_queries", C.c_uint32),
+        ("device", C.c_int32),
+        ("poseidon2_rc", C.POINTER(C.c_uint32)),
+        ("poseidon2_rc_len", C.c_uint32),
+    ]
+
+
+class P3rP2Rows(C.Structure):
+    _fields_ = [
+        ("n", C.c_size_t),
+        ("input_values", C.POINTER(C.c_uint32)),
+        ("new_start", C.POINTER(C.c_uint8)),
+        ("merkle_path", C.POINTER(C.c_uint8)),
+        ("mmcs_bit", C.POINTER(C.c_uint8)),
+        ("mmcs_index_sum", C.POINTER(C.c_uint32)),
+    ]
+
+
+class P3rMatrix(C.Structure):
+    _fields_ = [("values", C.POINTER(C.c_uint32)), ("height", C.c_size_t), ("width", C.c_size_t)]
+
+
+class P3rProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_uint64)]
+
+
+u32p = C.POINTER(C.c_uint32)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/p3r.h declares must appear here
+# (tests/test_abi.py checks header <-> table <-> .so agreement).
+SIGNATURES = {
+    "p3r_create": (vp, [C.POINTER(P3rConfig)]),
+    "p3r_destroy": (None, [vp]),
+    "p3r_last_error": (C.c_char_p, [vp]),
+    "p3r_poseidon2_trace_width": (C.c_uint32, [vp]),
+    "p3r_poseidon2_num_constants": (C.c_uint32, [vp]),
+    "p3r_sync": (C.c_int, [vp]),
+    "p3r_dmat_upload": (vp, [vp, u32p, C.c_size_t, C.c_size_t]),
+    "p3r_dmat_alloc": (vp, [vp, C.c_size_t, C.c_size_t]),
+    "p3r_dmat_download": (C.c_int, [vp, vp, u32p]),
+    "p3r_dmat_height": (C.c_size_t, [vp]),
+    "p3r_dmat_width": (C.c_size_t, [vp]),
+    "p3r_dmat_free": (None, [vp, vp]),
+    "p3r_poseidon2_permute_batch": (C.c_int, [vp, u32p, u32p, C.c_size_t]),
+    "p3r_poseidon2_permute_dmat": (C.c_int, [vp, vp]),
+    "p3r_poseidon2_trace_fill": (C.c_int, [vp, C.POINTER(P3rP2Rows), u32p]),
+    "p3r_poseidon2_trace_fill_dmat": (vp, [vp, C.POINTER(P3rP2Rows)]),
+    "p3r_p2_rows_upload": (vp, [vp, C.POINTER(P3rP2Rows)]),
+    "p3r_p2_rows_free": (None, [vp, vp]),
+    "p3r_poseidon2_trace_fill_dev": (vp, [vp, vp]),
+    "p3r_coset_lde": (C.c_int, [vp, u32p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, u32p]),
+    "p3r_coset_lde_dmat": (vp, [vp, vp, C.c_uint32, C.c_uint32]),
+    "p3r_mmcs_commit": (C.c_int, [vp, C.POINTER(P3rMatrix), C.c_size_t, u32p, C.POINTER(vp)]),
+    "p3r_mmcs_commit_dmat": (C.c_int, [vp, C.POINTER(vp), C.c_size_t, u32p, C.POINTER(vp)]),
+    "p3r_mmcs_open": (C.c_int, [vp, vp, C.c_size_t, u32p, u32p]),
+    "p3r_tree_log_max_height": (C.c_size_t, [vp]),
+    "p3r_tree_total_width": (C.c_size_t, [vp]),
+    "p3r_tree_free": (None, [vp, vp]),
+    "p3r_time_permute_dmat": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_double)]),
+    "p3r_profile_enable": (C.c_int, [vp, C.c_int]),
+    "p3r_profile_read": (C.c_int, [vp, C.POINTER(P3rProfileEntry), C.c_size_t, C.POINTER(C.c_size_t)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libp3r_hip.so (built by __graft_entry__.build()). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "plonky3_recursion_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

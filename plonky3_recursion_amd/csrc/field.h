@@ -1,0 +1,241 @@
+// 31-bit Montgomery prime fields (KoalaBear, BabyBear) and their degree-4 binomial
+// extension, shared by host orchestration code and gfx950 device kernels.
+//
+// Reference anchors (the arithmetic itself lives in the un-vendored p3-monty-31 /
+// p3-koala-bear / p3-baby-bear 0.6 crates):
+//   moduli                      circuit-prover/src/batch_stark_prover.rs:76-78
+//   x^4 = W binomial extension   circuit-prover/src/air/alu_air.rs:715-733,
+//                                circuit-prover/src/field_params.rs:46-53
+//   coset shift = F::GENERATOR   recursion/src/pcs/fri/verifier.rs:960
+//
+// Device representation: Montgomery form x*2^32 mod P held in a u32 in [0, P).
+// Everything that crosses the C ABI is canonical (see include/p3r.h).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define P3R_HD __host__ __device__ __forceinline__
+#else
+#define P3R_HD inline
+#endif
+
+namespace p3r {
+
+constexpr uint32_t inv_mod_2_32(uint32_t p) {
+  // Newton iteration: x <- x*(2 - p*x); doubles the number of correct low bits.
+  uint32_t x = 1;
+  for (int i = 0; i < 6; ++i) x *= 2u - p * x;
+  return x;
+}
+constexpr uint32_t pow_mod(uint32_t b, uint64_t e, uint32_t p) {
+  uint64_t r = 1, x = b % p;
+  while (e) {
+    if (e & 1) r = r * x % p;
+    x = x * x % p;
+    e >>= 1;
+  }
+  return (uint32_t)r;
+}
+
+// Field parameter packs. GEN is the multiplicative generator upstream uses as the
+// LDE coset shift; the 2-adic generator is GEN^((P-1)/2^TWO_ADICITY), which
+// reproduces the upstream tables (0x6ac49f88 for KoalaBear, 0x1a427a41 for BabyBear).
+struct KoalaBearParams {
+  static constexpr uint32_t P = 0x7f000001u;  // 2^31 - 2^24 + 1
+  static constexpr uint32_t GEN = 3;
+  static constexpr int TWO_ADICITY = 24;
+  static constexpr uint32_t EXT_W = 3;  // x^4 = 3
+  static constexpr int SBOX_DEGREE = 3;
+  static constexpr int SBOX_REGISTERS = 0;
+  static constexpr int PARTIAL_ROUNDS = 20;
+  static constexpr int FIELD_ID = 0;
+};
+struct BabyBearParams {
+  static constexpr uint32_t P = 0x78000001u;  // 2^31 - 2^27 + 1
+  static constexpr uint32_t GEN = 31;
+  static constexpr int TWO_ADICITY = 27;
+  static constexpr uint32_t EXT_W = 11;  // x^4 = 11
+  static constexpr int SBOX_DEGREE = 7;
+  static constexpr int SBOX_REGISTERS = 1;
+  static constexpr int PARTIAL_ROUNDS = 13;
+  static constexpr int FIELD_ID = 1;
+};
+
+template <class PP>
+struct Fp {
+  using Params = PP;
+  static constexpr uint32_t P = PP::P;
+  static constexpr uint32_t MU = inv_mod_2_32(PP::P);          // P*MU == 1 mod 2^32
+  static constexpr uint32_t R1 = (uint32_t)((1ull << 32) % PP::P);  // mont(1)
+  static constexpr uint32_t R2 = (uint32_t)((uint64_t)R1 * R1 % PP::P);
+
+  uint32_t v;  // Montgomery form, < P
+
+  static P3R_HD uint32_t mulhi(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+  }
+  // x < P*2^32  ->  x * 2^-32 mod P
+  static P3R_HD uint32_t reduce(uint32_t lo, uint32_t hi) {
+    uint32_t t = lo * MU;
+    uint32_t u = mulhi(t, P);
+    uint32_t r = hi - u;
+    return hi < u ? r + P : r;
+  }
+  static P3R_HD Fp raw(uint32_t m) { Fp r; r.v = m; return r; }
+  static P3R_HD Fp zero() { return raw(0); }
+  static P3R_HD Fp one() { return raw(R1); }
+  static P3R_HD Fp from_canonical(uint32_t x) {  // x < P
+    uint32_t lo = x * R2;
+    uint32_t hi = mulhi(x, R2);
+    return raw(reduce(lo, hi));
+  }
+  static P3R_HD Fp from_u64(uint64_t x) { return from_canonical((uint32_t)(x % P)); }
+  P3R_HD uint32_t to_canonical() const { return reduce(v, 0); }
+
+  friend P3R_HD Fp operator+(Fp a, Fp b) {
+    uint32_t s = a.v + b.v;
+    return raw(s >= P ? s - P : s);
+  }
+  friend P3R_HD Fp operator-(Fp a, Fp b) {
+    uint32_t d = a.v - b.v;
+    return raw(a.v < b.v ? d + P : d);
+  }
+  friend P3R_HD Fp operator*(Fp a, Fp b) {
+    uint32_t lo = a.v * b.v;
+    uint32_t hi = mulhi(a.v, b.v);
+    return raw(reduce(lo, hi));
+  }
+  P3R_HD Fp operator-() const { return raw(v ? P - v : 0); }
+  P3R_HD Fp& operator+=(Fp o) { *this = *this + o; return *this; }
+  P3R_HD Fp& operator-=(Fp o) { *this = *this - o; return *this; }
+  P3R_HD Fp& operator*=(Fp o) { *this = *this * o; return *this; }
+  P3R_HD bool operator==(Fp o) const { return v == o.v; }
+  P3R_HD bool operator!=(Fp o) const { return v != o.v; }
+  P3R_HD Fp dbl() const { return *this + *this; }
+  P3R_HD Fp sqr() const { return *this * *this; }
+  P3R_HD Fp halve() const {
+    // (v + (v odd ? P : 0)) / 2; Montgomery form is linear so halving commutes.
+    uint32_t t = (v & 1) ? v + P : v;  // < 2^32 since P < 2^31
+    return raw(t >> 1);
+  }
+  P3R_HD Fp pow(uint64_t e) const {
+    Fp r = one(), b = *this;
+    while (e) {
+      if (e & 1) r *= b;
+      b = b.sqr();
+      e >>= 1;
+    }
+    return r;
+  }
+  P3R_HD Fp inv() const { return pow((uint64_t)P - 2); }
+
+  static P3R_HD Fp generator() { return from_canonical(PP::GEN); }
+  // Generator of the order-2^bits subgroup (upstream two_adic_generator(bits)).
+  static P3R_HD Fp two_adic_generator(int bits) {
+    Fp g = from_canonical(PP::GEN).pow(((uint64_t)P - 1) >> PP::TWO_ADICITY);
+    for (int i = PP::TWO_ADICITY; i > bits; --i) g = g.sqr();
+    return g;
+  }
+};
+
+// Degree-4 binomial extension F[x]/(x^4 - W), basis 1,x,x^2,x^3, flattened in that
+// order wherever an extension element is stored as 4 base elements.
+template <class PP>
+struct Fp4 {
+  using F = Fp<PP>;
+  F c[4];
+
+  static P3R_HD Fp4 zero() { Fp4 r; r.c[0] = r.c[1] = r.c[2] = r.c[3] = F::zero(); return r; }
+  static P3R_HD Fp4 one() { Fp4 r = zero(); r.c[0] = F::one(); return r; }
+  static P3R_HD Fp4 from_base(F b) { Fp4 r = zero(); r.c[0] = b; return r; }
+  static P3R_HD F w() { return F::from_canonical(PP::EXT_W); }
+
+  friend P3R_HD Fp4 operator+(Fp4 a, Fp4 b) {
+    Fp4 r;
+    for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] + b.c[i];
+    return r;
+  }
+  friend P3R_HD Fp4 operator-(Fp4 a, Fp4 b) {
+    Fp4 r;
+    for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] - b.c[i];
+    return r;
+  }
+  P3R_HD Fp4 operator-() const {
+    Fp4 r;
+    for (int i = 0; i < 4; ++i) r.c[i] = -c[i];
+    return r;
+  }
+  friend P3R_HD Fp4 operator*(Fp4 a, Fp4 b) {
+    const F W = w();
+    Fp4 r;
+    r.c[0] = a.c[0] * b.c[0] + W * (a.c[1] * b.c[3] + a.c[2] * b.c[2] + a.c[3] * b.c[1]);
+    r.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0] + W * (a.c[2] * b.c[3] + a.c[3] * b.c[2]);
+    r.c[2] = a.c[0] * b.c[2] + a.c[1] * b.c[1] + a.c[2] * b.c[0] + W * (a.c[3] * b.c[3]);
+    r.c[3] = a.c[0] * b.c[3] + a.c[1] * b.c[2] + a.c[2] * b.c[1] + a.c[3] * b.c[0];
+    return r;
+  }
+  friend P3R_HD Fp4 operator*(Fp4 a, F b) {
+    Fp4 r;
+    for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * b;
+    return r;
+  }
+  P3R_HD Fp4& operator+=(Fp4 o) { *this = *this + o; return *this; }
+  P3R_HD Fp4& operator-=(Fp4 o) { *this = *this - o; return *this; }
+  P3R_HD Fp4& operator*=(Fp4 o) { *this = *this * o; return *this; }
+  P3R_HD bool operator==(const Fp4& o) const {
+    return c[0] == o.c[0] && c[1] == o.c[1] && c[2] == o.c[2] && c[3] == o.c[3];
+  }
+  P3R_HD bool is_zero() const { return (c[0].v | c[1].v | c[2].v | c[3].v) == 0; }
+  P3R_HD Fp4 sqr() const { return *this * *this; }
+  P3R_HD Fp4 pow(uint64_t e) const {
+    Fp4 r = one(), b = *this;
+    while (e) {
+      if (e & 1) r *= b;
+      b = b.sqr();
+      e >>= 1;
+    }
+    return r;
+  }
+  // Inverse through the norm to the quadratic subfield F[y]/(y^2 - W), y = x^2:
+  // a = A + x*B with A = a0 + a2*y, B = a1 + a3*y; a^-1 = (A - x*B) / (A^2 - y*B^2).
+  P3R_HD Fp4 inv() const {
+    const F W = w();
+    // A^2 = (a0^2 + W a2^2) + (2 a0 a2) y ; B^2 = (a1^2 + W a3^2) + (2 a1 a3) y
+    F A0 = c[0] * c[0] + W * (c[2] * c[2]);
+    F A1 = (c[0] * c[2]).dbl();
+    F B0 = c[1] * c[1] + W * (c[3] * c[3]);
+    F B1 = (c[1] * c[3]).dbl();
+    // N = A^2 - y*B^2 = (A0 - W*B1) + (A1 - B0) y
+    F n0 = A0 - W * B1;
+    F n1 = A1 - B0;
+    // 1/N = (n0 - n1 y) / (n0^2 - W n1^2)
+    F d = (n0 * n0 - W * (n1 * n1)).inv();
+    F i0 = n0 * d;
+    F i1 = -(n1 * d);
+    // (A - xB) * (i0 + i1 y):  A*(i0+i1 y) = (a0 i0 + W a2 i1) + (a0 i1 + a2 i0) y
+    Fp4 r;
+    r.c[0] = c[0] * i0 + W * (c[2] * i1);
+    r.c[2] = c[0] * i1 + c[2] * i0;
+    r.c[1] = -(c[1] * i0 + W * (c[3] * i1));
+    r.c[3] = -(c[1] * i1 + c[3] * i0);
+    return r;
+  }
+};
+
+P3R_HD uint32_t bit_reverse(uint32_t x, int bits) {
+  if (bits == 0) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(x) >> (32 - bits);
+#else
+  uint32_t r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1u) << (bits - 1 - i);
+  return r;
+#endif
+}
+
+}  // namespace p3r

@@ -1,0 +1,728 @@
+// C ABI (include/p3r.h): context, device matrices, Poseidon2 (K3), coset LDE (K5), MMCS (K6).
+// Host orchestration only; all arithmetic on data runs in the gfx950 kernels of kernels.cuh.
+#include "context.h"
+#include "kernels.cuh"
+#include "poseidon2_rc_default.inc"
+#include "profile.h"
+
+#include <algorithm>
+#include <numeric>
+
+using namespace p3r;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <class Fn>
+int guard(p3r_ctx* ctx, Fn&& fn) {
+  try {
+    fn();
+    return P3R_OK;
+  } catch (const Error& e) {
+    if (ctx) ctx->err = e.what(); else g_create_error = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    if (ctx) ctx->err = e.what(); else g_create_error = e.what();
+    return P3R_EINVAL;
+  }
+}
+
+#define P3R_FIELD_CALL(ctx, fn, ...)                                              \
+  ((ctx)->cfg.field == P3R_FIELD_KOALA_BEAR ? fn<KoalaBearParams>(__VA_ARGS__)    \
+                                            : fn<BabyBearParams>(__VA_ARGS__))
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// ------------------------------------------------------------------ matrices
+template <class PP>
+std::unique_ptr<p3r_dmat> upload(p3r_ctx* ctx, const uint32_t* rowmajor, size_t h, size_t w) {
+  log2_exact(h, "matrix height");
+  if (w == 0) fail(P3R_EINVAL, "matrix width must be positive");
+  auto m = std::make_unique<p3r_dmat>();
+  m->buf.alloc(h * w);
+  m->d = m->buf.p;
+  m->h = h;
+  m->w = w;
+  DevBuf stage(h * w);
+  P3R_HIP(hipMemcpyAsync(stage.p, rowmajor, h * w * 4, hipMemcpyHostToDevice, ctx->stream));
+  dim3 grid((unsigned)((h + 63) / 64), (unsigned)((w + 63) / 64));
+  hipLaunchKernelGGL(k_rowmajor_to_colmajor<PP>, grid, dim3(kBlock), 0, ctx->stream, stage.p,
+                     m->d, (uint32_t)h, (uint32_t)w, 1);
+  P3R_HIP(hipGetLastError());
+  P3R_HIP(hipStreamSynchronize(ctx->stream));  // stage dies here
+  return m;
+}
+
+template <class PP>
+void download(p3r_ctx* ctx, const p3r_dmat* m, uint32_t* rowmajor_out) {
+  DevBuf stage(m->h * m->w);
+  dim3 grid((unsigned)((m->h + 63) / 64), (unsigned)((m->w + 63) / 64));
+  hipLaunchKernelGGL(k_colmajor_to_rowmajor<PP>, grid, dim3(kBlock), 0, ctx->stream, m->d,
+                     stage.p, (uint32_t)m->h, (uint32_t)m->w, 1);
+  P3R_HIP(hipGetLastError());
+  P3R_HIP(hipMemcpyAsync(rowmajor_out, stage.p, m->h * m->w * 4, hipMemcpyDeviceToHost,
+                         ctx->stream));
+  P3R_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+std::unique_ptr<p3r_dmat> dmat_alloc(size_t h, size_t w) {
+  log2_exact(h, "matrix height");
+  auto m = std::make_unique<p3r_dmat>();
+  m->buf.alloc(h * w);
+  m->d = m->buf.p;
+  m->h = h;
+  m->w = w;
+  return m;
+}
+
+// ------------------------------------------------------------------ Poseidon2
+template <class PP>
+void permute_dmat(p3r_ctx* ctx, p3r_dmat* s) {
+  if (s->w != P2_WIDTH) fail(P3R_EINVAL, "state matrix must have width 16, got %zu", s->w);
+  ProfScope ps(ctx, "p2_permute_batch");
+  hipLaunchKernelGGL(k_p2_permute_batch<PP>, dim3(blocks_for(s->h)), dim3(kBlock), 0, ctx->stream,
+                     s->d, s->d, s->h, ctx->rc.p);
+  P3R_HIP(hipGetLastError());
+}
+
+// Device-resident Poseidon2CircuitRow batch (inputs column-major Montgomery, flags as bytes).
+template <class PP>
+std::unique_ptr<p3r_p2_dev> p2_rows_upload(p3r_ctx* ctx, const p3r_p2_rows* rows) {
+  const size_t n = rows->n;
+  log2_exact(n, "Poseidon2 row count (callers pad to a power of two)");
+  if (!rows->input_values || !rows->new_start || !rows->merkle_path || !rows->mmcs_bit ||
+      !rows->mmcs_index_sum)
+    fail(P3R_EINVAL, "p3r_p2_rows has a NULL field");
+  auto d = std::make_unique<p3r_p2_dev>();
+  d->n = n;
+  d->flags.alloc((3 * n + 3) / 4 + 1);
+  uint8_t* f8 = reinterpret_cast<uint8_t*>(d->flags.p);
+  P3R_HIP(hipMemcpyAsync(f8, rows->new_start, n, hipMemcpyHostToDevice, ctx->stream));
+  P3R_HIP(hipMemcpyAsync(f8 + n, rows->merkle_path, n, hipMemcpyHostToDevice, ctx->stream));
+  P3R_HIP(hipMemcpyAsync(f8 + 2 * n, rows->mmcs_bit, n, hipMemcpyHostToDevice, ctx->stream));
+  d->seed.alloc(n);
+  P3R_HIP(hipMemcpyAsync(d->seed.p, rows->mmcs_index_sum, n * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_convert_inplace<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream,
+                     d->seed.p, n, 1);
+  P3R_HIP(hipGetLastError());
+  d->inputs = upload<PP>(ctx, rows->input_values, n, P2_WIDTH);  // syncs the stream
+  return d;
+}
+
+template <class PP>
+std::unique_ptr<p3r_dmat> trace_fill(p3r_ctx* ctx, const p3r_p2_dev* rows) {
+  const size_t n = rows->n;
+  const uint8_t* f8 = reinterpret_cast<const uint8_t*>(rows->flags.p);
+  DevBuf acc(n);
+  const size_t n_blocks = (n + kScanTile - 1) / kScanTile;
+  DevBuf agg(2 * n_blocks);
+  {
+    ProfScope ps(ctx, "p2_acc_scan");
+    hipLaunchKernelGGL(k_p2_acc_scan<PP>, dim3((unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, 0,
+                       n, f8, f8 + n, f8 + 2 * n, rows->seed.p, agg.p, n_blocks, acc.p);
+    hipLaunchKernelGGL(k_p2_acc_scan<PP>, dim3(1), dim3(kBlock), 0, ctx->stream, 1, n, f8, f8 + n,
+                       f8 + 2 * n, rows->seed.p, agg.p, n_blocks, acc.p);
+    hipLaunchKernelGGL(k_p2_acc_scan<PP>, dim3((unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, 2,
+                       n, f8, f8 + n, f8 + 2 * n, rows->seed.p, agg.p, n_blocks, acc.p);
+  }
+  const size_t width = p2_perm_cols<PP>() + 2;
+  auto trace = dmat_alloc(n, width);
+  {
+    ProfScope ps(ctx, "p2_trace_fill");
+    hipLaunchKernelGGL(k_p2_trace_fill<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream,
+                       rows->inputs->d, f8 + 2 * n, acc.p, trace->d, n, ctx->rc.p);
+  }
+  P3R_HIP(hipGetLastError());
+  P3R_HIP(hipStreamSynchronize(ctx->stream));  // temporaries die here
+  return trace;
+}
+
+// ------------------------------------------------------------------ NTT tables
+template <class PP>
+const uint32_t* get_tw_sub(p3r_ctx* ctx, int log_r, int inverse) {
+  auto key = std::make_pair(log_r, inverse);
+  auto it = ctx->tw_sub.find(key);
+  if (it != ctx->tw_sub.end()) return it->second.p;
+  using F = Fp<PP>;
+  size_t half = log_r ? (size_t(1) << (log_r - 1)) : 1;
+  std::vector<uint32_t> t(half);
+  F root = F::two_adic_generator(log_r);
+  if (inverse) root = root.inv();
+  F x = F::one();
+  for (size_t i = 0; i < half; ++i) {
+    t[i] = x.v;
+    x *= root;
+  }
+  DevBuf d(half);
+  P3R_HIP(hipMemcpy(d.p, t.data(), half * 4, hipMemcpyHostToDevice));
+  return ctx->tw_sub.emplace(key, std::move(d)).first->second.p;
+}
+
+template <class PP>
+std::pair<const uint32_t*, const uint32_t*> get_tw4(p3r_ctx* ctx, int log_n, int inverse) {
+  auto key = std::make_pair(log_n, inverse);
+  auto it = ctx->tw4.find(key);
+  if (it == ctx->tw4.end()) {
+    using F = Fp<PP>;
+    F root = F::two_adic_generator(log_n);
+    if (inverse) root = root.inv();
+    size_t n_hi = log_n > 10 ? (size_t(1) << (log_n - 10)) : 1;
+    std::vector<uint32_t> lo(1024), hi(n_hi);
+    F x = F::one();
+    for (size_t i = 0; i < 1024; ++i) {
+      lo[i] = x.v;
+      x *= root;
+    }
+    F step = x;  // root^1024
+    x = F::one();
+    for (size_t i = 0; i < n_hi; ++i) {
+      hi[i] = x.v;
+      x *= step;
+    }
+    DevBuf dlo(1024), dhi(n_hi);
+    P3R_HIP(hipMemcpy(dlo.p, lo.data(), 1024 * 4, hipMemcpyHostToDevice));
+    P3R_HIP(hipMemcpy(dhi.p, hi.data(), n_hi * 4, hipMemcpyHostToDevice));
+    it = ctx->tw4.emplace(key, std::make_pair(std::move(dlo), std::move(dhi))).first;
+  }
+  return {it->second.first.p, it->second.second.p};
+}
+
+// Per-coset input scaling for the forward pass: output block z of the bit-reversed LDE is
+// the coset shift * w_{N<<b}^{bitrev_b(z)} * <w_N>, so cell k of the coefficient vector is
+// multiplied by s_z^k = s_z^{N2*n1} * s_z^{n2}.
+template <class PP>
+std::pair<const uint32_t*, const uint32_t*> get_pre(p3r_ctx* ctx, int log_n, int log_n1,
+                                                    int log_n2, int added_bits, uint32_t shift) {
+  auto key = std::make_tuple(log_n, added_bits, shift);
+  auto it = ctx->pre.find(key);
+  if (it == ctx->pre.end()) {
+    using F = Fp<PP>;
+    const size_t B = size_t(1) << added_bits, N1 = size_t(1) << log_n1, N2 = size_t(1) << log_n2;
+    std::vector<uint32_t> a(B * N1), b(B * N2);
+    F wbig = F::two_adic_generator(log_n + added_bits);
+    for (size_t z = 0; z < B; ++z) {
+      F s = F::from_canonical(shift) * wbig.pow(bit_reverse((uint32_t)z, added_bits));
+      F x = F::one();
+      for (size_t i = 0; i < N2; ++i) {
+        b[z * N2 + i] = x.v;
+        x *= s;
+      }
+      F step = x;  // s^N2
+      x = F::one();
+      for (size_t i = 0; i < N1; ++i) {
+        a[z * N1 + i] = x.v;
+        x *= step;
+      }
+    }
+    DevBuf da(a.size()), db(b.size());
+    P3R_HIP(hipMemcpy(da.p, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+    P3R_HIP(hipMemcpy(db.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    it = ctx->pre.emplace(key, std::make_pair(std::move(da), std::move(db))).first;
+  }
+  return {it->second.first.p, it->second.second.p};
+}
+
+template <class PP>
+void launch_ntt(p3r_ctx* ctx, NttPass a, size_t ncols, size_t ncosets, const char* name) {
+  const int log_r = a.sub_dim == 0 ? a.log_n1 : a.log_n2;
+  const int log_lines = a.sub_dim == 0 ? a.log_n2 : a.log_n1;
+  int log_t = std::max(0, 14 - log_r);
+  if (a.sub_dim == 0 && log_t > 5) log_t = 5;  // 128-byte segments are enough when strided
+  log_t = std::min(log_t, log_lines);
+  a.log_t = log_t;
+  const size_t R = size_t(1) << log_r, T = size_t(1) << log_t;
+  size_t lds = (R * (T + 1) + (R >> 5) + 1 + (R >> 1) + 1) * sizeof(uint32_t);
+  if (lds > 160 * 1024) fail(P3R_EUNSUPPORTED, "NTT tile of 2^%d rows does not fit LDS", log_r);
+  dim3 grid((unsigned)(size_t(1) << (log_lines - log_t)), (unsigned)ncols, (unsigned)ncosets);
+  ProfScope ps(ctx, name);
+  hipLaunchKernelGGL(k_ntt_tile<PP>, grid, dim3(kBlock), lds, ctx->stream, a);
+  P3R_HIP(hipGetLastError());
+}
+
+// K5. in: h x w evaluations over the subgroup (natural order, column-major Montgomery).
+// Returns (h << added_bits) x w, rows in bit-reversed order over shift * <w_{h<<added_bits}>.
+template <class PP>
+std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_bits,
+                                    uint32_t shift) {
+  using F = Fp<PP>;
+  const int log_n = log2_exact(in->h, "LDE input height");
+  if (log_n + added_bits > PP::TWO_ADICITY)
+    fail(P3R_EINVAL, "LDE of 2^%d rows exceeds the field's two-adicity (%d)", log_n + added_bits,
+         PP::TWO_ADICITY);
+  if (shift == 0 || shift >= PP::P) fail(P3R_EINVAL, "coset shift must be a non-zero canonical element");
+  const size_t N = in->h, B = size_t(1) << added_bits, w = in->w;
+  auto out = dmat_alloc(N * B, w);
+  DevBuf coef(N * w);
+  const uint32_t inv_n = F::from_canonical((uint32_t)(N % PP::P)).inv().v;
+
+  NttPass p{};
+  if (log_n <= 11) {
+    // single pass each way: whole polynomial in one LDS tile
+    p = NttPass{};
+    p.in = in->d; p.out = coef.p;
+    p.in_col_stride = N; p.out_col_stride = N; p.out_coset_stride = 0;
+    p.log_n1 = 0; p.log_n2 = log_n; p.sub_dim = 1; p.out_mode = 1;
+    p.tw_sub = get_tw_sub<PP>(ctx, log_n, 1);
+    p.scale = inv_n; p.use_scale = 1;
+    launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
+    auto pre = get_pre<PP>(ctx, log_n, 0, log_n, added_bits, shift);
+    p = NttPass{};
+    p.in = coef.p; p.out = out->d;
+    p.in_col_stride = N; p.out_col_stride = N * B; p.out_coset_stride = N;
+    p.log_n1 = 0; p.log_n2 = log_n; p.sub_dim = 1; p.out_mode = 0;
+    p.tw_sub = get_tw_sub<PP>(ctx, log_n, 0);
+    p.pre_a = pre.first; p.pre_b = pre.second;
+    launch_ntt<PP>(ctx, p, w, B, "ntt_forward");
+  } else {
+    const int la = log_n / 2, lb = log_n - la;  // N1 = 2^la (strided dim), N2 = 2^lb
+    DevBuf tmp(N * w);
+    auto tw4i = get_tw4<PP>(ctx, log_n, 1);
+    // inverse pass 1: size-N1 transforms along n1, twiddle, transposed store tmp[n2*N1 + k1]
+    p = NttPass{};
+    p.in = in->d; p.out = tmp.p;
+    p.in_col_stride = N; p.out_col_stride = N;
+    p.log_n1 = la; p.log_n2 = lb; p.sub_dim = 0; p.out_mode = 2;
+    p.tw_sub = get_tw_sub<PP>(ctx, la, 1);
+    p.tw4_lo = tw4i.first; p.tw4_hi = tw4i.second;
+    launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
+    // inverse pass 2: tmp viewed as [N2][N1]; size-N2 transforms along its first dim,
+    // natural row order -> coefficient k1 + N1*k2 lands at k2*N1 + k1
+    p = NttPass{};
+    p.in = tmp.p; p.out = coef.p;
+    p.in_col_stride = N; p.out_col_stride = N;
+    p.log_n1 = lb; p.log_n2 = la; p.sub_dim = 0; p.out_mode = 1;
+    p.tw_sub = get_tw_sub<PP>(ctx, lb, 1);
+    p.scale = inv_n; p.use_scale = 1;
+    launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
+    // forward pass 1 (all cosets): scale by s_z^k, size-N1 transforms along n1, twiddle, in place rows
+    auto pre = get_pre<PP>(ctx, log_n, la, lb, added_bits, shift);
+    auto tw4f = get_tw4<PP>(ctx, log_n, 0);
+    p = NttPass{};
+    p.in = coef.p; p.out = out->d;
+    p.in_col_stride = N; p.out_col_stride = N * B; p.out_coset_stride = N;
+    p.log_n1 = la; p.log_n2 = lb; p.sub_dim = 0; p.out_mode = 0;
+    p.tw_sub = get_tw_sub<PP>(ctx, la, 0);
+    p.tw4_lo = tw4f.first; p.tw4_hi = tw4f.second;
+    p.pre_a = pre.first; p.pre_b = pre.second;
+    launch_ntt<PP>(ctx, p, w, B, "ntt_forward");
+    // forward pass 2: contiguous size-N2 transforms, in place, bit-reversed rows kept.
+    // The B cosets of a column are contiguous, so they are just B*N1 lines of N2 cells.
+    p = NttPass{};
+    p.in = out->d; p.out = out->d;
+    p.in_col_stride = N * B; p.out_col_stride = N * B;
+    p.log_n1 = la + added_bits; p.log_n2 = lb; p.sub_dim = 1; p.out_mode = 0;
+    p.tw_sub = get_tw_sub<PP>(ctx, lb, 0);
+    launch_ntt<PP>(ctx, p, w, 1, "ntt_forward");
+    P3R_HIP(hipStreamSynchronize(ctx->stream));  // tmp dies here
+  }
+  P3R_HIP(hipStreamSynchronize(ctx->stream));  // coef dies here
+  return out;
+}
+
+// ------------------------------------------------------------------ MMCS
+template <class PP>
+void hash_rows(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats, size_t h, uint32_t* dig) {
+  std::vector<const uint32_t*> cols;
+  for (const p3r_dmat* m : mats)
+    for (size_t c = 0; c < m->w; ++c) cols.push_back(m->d + c * m->h);
+  const uint32_t** dcols = nullptr;
+  P3R_HIP(hipMalloc((void**)&dcols, cols.size() * sizeof(void*)));
+  hipError_t e = hipMemcpyAsync(dcols, cols.data(), cols.size() * sizeof(void*),
+                                hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    ProfScope ps(ctx, "mmcs_hash_rows");
+    hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream,
+                       (const uint32_t* const*)dcols, (int)cols.size(), h, dig, ctx->rc.p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dcols);
+  P3R_HIP(e);
+}
+
+template <class PP>
+void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
+  using F = Fp<PP>;
+  const auto& mats = tree->mats;
+  if (mats.empty()) fail(P3R_EINVAL, "MMCS commit needs at least one matrix");
+  // tallest first, stable (recursion/src/pcs/mmcs.rs:355-425)
+  std::vector<size_t> order(mats.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](size_t a, size_t b) { return mats[a]->h > mats[b]->h; });
+  const size_t hmax = mats[order[0]]->h;
+  tree->log_max_h = log2_exact(hmax, "matrix height");
+  tree->cap_height = (int)ctx->cfg.cap_height;
+  if (tree->cap_height > tree->log_max_h)
+    fail(P3R_EINVAL, "cap_height %d exceeds log2 of the tallest matrix (%d)", tree->cap_height,
+         tree->log_max_h);
+  tree->total_width = 0;
+  for (auto* m : mats) tree->total_width += m->w;
+
+  auto at_height = [&](size_t h) {
+    std::vector<const p3r_dmat*> v;
+    for (size_t i : order)
+      if (mats[i]->h == h) v.push_back(mats[i]);
+    return v;
+  };
+  tree->layers.clear();
+  tree->layers.emplace_back(P2_DIGEST * hmax);
+  hash_rows<PP>(ctx, at_height(hmax), hmax, tree->layers[0].p);
+  size_t n = hmax;
+  const size_t cap_n = size_t(1) << tree->cap_height;
+  while (n > cap_n) {
+    const size_t nn = n / 2;
+    DevBuf next(P2_DIGEST * nn);
+    const uint32_t* prev = tree->layers.back().p;
+    {
+      ProfScope ps(ctx, "mmcs_compress");
+      hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(nn)), dim3(kBlock), 0, ctx->stream,
+                         prev, n, 2, 0, prev, n, 2, 1, next.p, nn, ctx->rc.p);
+    }
+    P3R_HIP(hipGetLastError());
+    auto inj = at_height(nn);
+    if (!inj.empty()) {
+      DevBuf idig(P2_DIGEST * nn);
+      hash_rows<PP>(ctx, inj, nn, idig.p);
+      {
+        ProfScope ps(ctx, "mmcs_compress");
+        hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(nn)), dim3(kBlock), 0, ctx->stream,
+                           next.p, nn, 1, 0, idig.p, nn, 1, 0, next.p, nn, ctx->rc.p);
+      }
+      P3R_HIP(hipGetLastError());
+      P3R_HIP(hipStreamSynchronize(ctx->stream));  // idig dies here
+    }
+    tree->layers.push_back(std::move(next));
+    n = nn;
+  }
+  // cap: digest-major canonical
+  std::vector<uint32_t> soa(P2_DIGEST * cap_n);
+  P3R_HIP(hipMemcpyAsync(soa.data(), tree->layers.back().p, soa.size() * 4, hipMemcpyDeviceToHost,
+                         ctx->stream));
+  P3R_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t j = 0; j < cap_n; ++j)
+    for (int k = 0; k < P2_DIGEST; ++k)
+      cap_out[j * P2_DIGEST + k] = F::raw(soa[(size_t)k * cap_n + j]).to_canonical();
+}
+
+template <class PP>
+void mmcs_open(p3r_ctx* ctx, const p3r_tree* tree, size_t index, uint32_t* opened, uint32_t* proof) {
+  using F = Fp<PP>;
+  if (index >> tree->log_max_h) fail(P3R_EINVAL, "open index %zu out of range", index);
+  size_t off = 0;
+  for (const p3r_dmat* m : tree->mats) {
+    int lh = log2_exact(m->h, "matrix height");
+    size_t row = index >> (tree->log_max_h - lh);
+    // strided gather of one row: w scattered 4-byte cells
+    P3R_HIP(hipMemcpy2DAsync(opened + off, 4, m->d + row, m->h * 4, 4, m->w, hipMemcpyDeviceToHost,
+                             ctx->stream));
+    off += m->w;
+  }
+  const int depth = tree->log_max_h - tree->cap_height;
+  for (int l = 0; l < depth; ++l) {
+    size_t n = size_t(1) << (tree->log_max_h - l);
+    size_t sib = (index >> l) ^ 1;
+    P3R_HIP(hipMemcpy2DAsync(proof + (size_t)l * P2_DIGEST, 4, tree->layers[l].p + sib, n * 4, 4,
+                             P2_DIGEST, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  P3R_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < off; ++i) opened[i] = F::raw(opened[i]).to_canonical();
+  for (size_t i = 0; i < (size_t)depth * P2_DIGEST; ++i) proof[i] = F::raw(proof[i]).to_canonical();
+}
+
+template <class PP>
+void init_ctx(p3r_ctx* ctx) {
+  using F = Fp<PP>;
+  const size_t nrc = p2_num_constants<PP>();
+  const uint32_t* src = ctx->cfg.poseidon2_rc;
+  if (src) {
+    if (ctx->cfg.poseidon2_rc_len != nrc)
+      fail(P3R_EINVAL, "poseidon2_rc_len is %u, the field needs %zu constants",
+           ctx->cfg.poseidon2_rc_len, nrc);
+  } else {
+    src = PP::FIELD_ID == 0 ? kDefaultRc_koala_bear : kDefaultRc_baby_bear;
+  }
+  ctx->rc_canonical.assign(src, src + nrc);
+  std::vector<uint32_t> mont(nrc);
+  for (size_t i = 0; i < nrc; ++i) {
+    if (src[i] >= PP::P) fail(P3R_EINVAL, "round constant %zu is not canonical", i);
+    mont[i] = F::from_canonical(src[i]).v;
+  }
+  ctx->rc.alloc(nrc);
+  P3R_HIP(hipMemcpy(ctx->rc.p, mont.data(), nrc * 4, hipMemcpyHostToDevice));
+  ctx->partial_rounds = PP::PARTIAL_ROUNDS;
+  ctx->cfg.poseidon2_rc = nullptr;  // caller's pointer is not retained
+  P3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_tile<PP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+p3r_ctx* p3r_create(const p3r_config* cfg) {
+  p3r_ctx* ctx = nullptr;
+  int rc = guard(nullptr, [&] {
+    if (!cfg) fail(P3R_EINVAL, "cfg is NULL");
+    if (cfg->abi_version != P3R_ABI_VERSION)
+      fail(P3R_EINVAL, "abi_version %u != %u", cfg->abi_version, P3R_ABI_VERSION);
+    if (cfg->field != P3R_FIELD_KOALA_BEAR && cfg->field != P3R_FIELD_BABY_BEAR)
+      fail(P3R_EUNSUPPORTED, "unsupported field id %u", cfg->field);
+    if (cfg->ext_degree != 4)
+      fail(P3R_EUNSUPPORTED, "unsupported extension degree %u (only D=4)", cfg->ext_degree);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+      fail(P3R_ENODEV, "no HIP device available (%s); this library has no CPU fallback",
+           e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+      fail(P3R_ENODEV, "device %d out of range (%d devices)", cfg->device, ndev);
+    P3R_HIP(hipSetDevice(cfg->device));
+    auto c = std::make_unique<p3r_ctx>();
+    c->cfg = *cfg;
+    P3R_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    P3R_FIELD_CALL(c, init_ctx, c.get());
+    ctx = c.release();
+  });
+  return rc == P3R_OK ? ctx : nullptr;
+}
+
+void p3r_destroy(p3r_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->cfg.device);
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_clear(ctx);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* p3r_last_error(const p3r_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+uint32_t p3r_poseidon2_trace_width(const p3r_ctx* ctx) {
+  return ctx->cfg.field == P3R_FIELD_KOALA_BEAR ? p2_perm_cols<KoalaBearParams>() + 2
+                                                : p2_perm_cols<BabyBearParams>() + 2;
+}
+uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx) {
+  return ctx->cfg.field == P3R_FIELD_KOALA_BEAR ? p2_num_constants<KoalaBearParams>()
+                                                : p2_num_constants<BabyBearParams>();
+}
+
+int p3r_sync(p3r_ctx* ctx) {
+  return guard(ctx, [&] { P3R_HIP(hipStreamSynchronize(ctx->stream)); });
+}
+
+p3r_dmat* p3r_dmat_upload(p3r_ctx* ctx, const uint32_t* rowmajor, size_t h, size_t w) {
+  p3r_dmat* out = nullptr;
+  guard(ctx, [&] {
+    if (!rowmajor) fail(P3R_EINVAL, "rowmajor is NULL");
+    out = P3R_FIELD_CALL(ctx, upload, ctx, rowmajor, h, w).release();
+  });
+  return out;
+}
+p3r_dmat* p3r_dmat_alloc(p3r_ctx* ctx, size_t h, size_t w) {
+  p3r_dmat* out = nullptr;
+  guard(ctx, [&] { out = dmat_alloc(h, w).release(); });
+  return out;
+}
+int p3r_dmat_download(p3r_ctx* ctx, const p3r_dmat* m, uint32_t* out) {
+  return guard(ctx, [&] {
+    if (!m || !out) fail(P3R_EINVAL, "NULL argument");
+    P3R_FIELD_CALL(ctx, download, ctx, m, out);
+  });
+}
+size_t p3r_dmat_height(const p3r_dmat* m) { return m->h; }
+size_t p3r_dmat_width(const p3r_dmat* m) { return m->w; }
+void p3r_dmat_free(p3r_ctx* ctx, p3r_dmat* m) {
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  delete m;
+}
+
+int p3r_poseidon2_permute_dmat(p3r_ctx* ctx, p3r_dmat* states) {
+  return guard(ctx, [&] {
+    if (!states) fail(P3R_EINVAL, "states is NULL");
+    P3R_FIELD_CALL(ctx, permute_dmat, ctx, states);
+  });
+}
+
+int p3r_poseidon2_permute_batch(p3r_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n) {
+  return guard(ctx, [&] {
+    if (!in || !out) fail(P3R_EINVAL, "NULL argument");
+    if (n == 0) return;
+    // pad the batch to a power of two of lanes; the tail rows are zeros and are dropped
+    size_t np = 1;
+    while (np < n) np <<= 1;
+    std::vector<uint32_t> padded;
+    const uint32_t* src = in;
+    if (np != n) {
+      padded.assign(np * P2_WIDTH, 0);
+      memcpy(padded.data(), in, n * P2_WIDTH * 4);
+      src = padded.data();
+    }
+    auto m = P3R_FIELD_CALL(ctx, upload, ctx, src, np, (size_t)P2_WIDTH);
+    P3R_FIELD_CALL(ctx, permute_dmat, ctx, m.get());
+    if (np != n) {
+      P3R_FIELD_CALL(ctx, download, ctx, m.get(), padded.data());
+      memcpy(out, padded.data(), n * P2_WIDTH * 4);
+    } else {
+      P3R_FIELD_CALL(ctx, download, ctx, m.get(), out);
+    }
+  });
+}
+
+p3r_p2_dev* p3r_p2_rows_upload(p3r_ctx* ctx, const p3r_p2_rows* rows) {
+  p3r_p2_dev* out = nullptr;
+  guard(ctx, [&] {
+    if (!rows) fail(P3R_EINVAL, "rows is NULL");
+    out = P3R_FIELD_CALL(ctx, p2_rows_upload, ctx, rows).release();
+  });
+  return out;
+}
+void p3r_p2_rows_free(p3r_ctx* ctx, p3r_p2_dev* rows) {
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  delete rows;
+}
+p3r_dmat* p3r_poseidon2_trace_fill_dev(p3r_ctx* ctx, const p3r_p2_dev* rows) {
+  p3r_dmat* out = nullptr;
+  guard(ctx, [&] {
+    if (!rows) fail(P3R_EINVAL, "rows is NULL");
+    out = P3R_FIELD_CALL(ctx, trace_fill, ctx, rows).release();
+  });
+  return out;
+}
+p3r_dmat* p3r_poseidon2_trace_fill_dmat(p3r_ctx* ctx, const p3r_p2_rows* rows) {
+  p3r_dmat* out = nullptr;
+  guard(ctx, [&] {
+    if (!rows) fail(P3R_EINVAL, "rows is NULL");
+    auto d = P3R_FIELD_CALL(ctx, p2_rows_upload, ctx, rows);
+    out = P3R_FIELD_CALL(ctx, trace_fill, ctx, d.get()).release();
+  });
+  return out;
+}
+
+int p3r_poseidon2_trace_fill(p3r_ctx* ctx, const p3r_p2_rows* rows, uint32_t* trace_out) {
+  return guard(ctx, [&] {
+    if (!rows || !trace_out) fail(P3R_EINVAL, "NULL argument");
+    auto d = P3R_FIELD_CALL(ctx, p2_rows_upload, ctx, rows);
+    auto t = P3R_FIELD_CALL(ctx, trace_fill, ctx, d.get());
+    P3R_FIELD_CALL(ctx, download, ctx, t.get(), trace_out);
+  });
+}
+
+p3r_dmat* p3r_coset_lde_dmat(p3r_ctx* ctx, const p3r_dmat* evals, uint32_t added_bits,
+                             uint32_t shift) {
+  p3r_dmat* out = nullptr;
+  guard(ctx, [&] {
+    if (!evals) fail(P3R_EINVAL, "evals is NULL");
+    out = P3R_FIELD_CALL(ctx, coset_lde, ctx, evals, (int)added_bits, shift).release();
+  });
+  return out;
+}
+
+int p3r_coset_lde(p3r_ctx* ctx, const uint32_t* evals, size_t h, size_t w, uint32_t added_bits,
+                  uint32_t shift, uint32_t* out) {
+  return guard(ctx, [&] {
+    if (!evals || !out) fail(P3R_EINVAL, "NULL argument");
+    auto in = P3R_FIELD_CALL(ctx, upload, ctx, evals, h, w);
+    auto lde = P3R_FIELD_CALL(ctx, coset_lde, ctx, in.get(), (int)added_bits, shift);
+    P3R_FIELD_CALL(ctx, download, ctx, lde.get(), out);
+  });
+}
+
+int p3r_mmcs_commit_dmat(p3r_ctx* ctx, const p3r_dmat* const* mats, size_t n_mats,
+                         uint32_t* cap_out, p3r_tree** tree_out) {
+  return guard(ctx, [&] {
+    if (!mats || !cap_out || n_mats == 0) fail(P3R_EINVAL, "bad arguments");
+    auto tree = std::make_unique<p3r_tree>();
+    tree->mats.assign(mats, mats + n_mats);
+    P3R_FIELD_CALL(ctx, mmcs_commit, ctx, tree.get(), cap_out);
+    if (tree_out) *tree_out = tree.release();
+  });
+}
+
+int p3r_mmcs_commit(p3r_ctx* ctx, const p3r_matrix* mats, size_t n_mats, uint32_t* cap_out,
+                    p3r_tree** tree_out) {
+  return guard(ctx, [&] {
+    if (!mats || !cap_out || n_mats == 0) fail(P3R_EINVAL, "bad arguments");
+    auto tree = std::make_unique<p3r_tree>();
+    for (size_t i = 0; i < n_mats; ++i) {
+      if (!mats[i].values) fail(P3R_EINVAL, "matrix %zu has NULL values", i);
+      tree->owned.push_back(
+          P3R_FIELD_CALL(ctx, upload, ctx, mats[i].values, mats[i].height, mats[i].width));
+      tree->mats.push_back(tree->owned.back().get());
+    }
+    P3R_FIELD_CALL(ctx, mmcs_commit, ctx, tree.get(), cap_out);
+    if (tree_out) *tree_out = tree.release();
+  });
+}
+
+int p3r_mmcs_open(p3r_ctx* ctx, const p3r_tree* tree, size_t index, uint32_t* opened_values,
+                  uint32_t* proof_out) {
+  return guard(ctx, [&] {
+    if (!tree || !opened_values || !proof_out) fail(P3R_EINVAL, "NULL argument");
+    P3R_FIELD_CALL(ctx, mmcs_open, ctx, tree, index, opened_values, proof_out);
+  });
+}
+size_t p3r_tree_log_max_height(const p3r_tree* t) { return (size_t)t->log_max_h; }
+size_t p3r_tree_total_width(const p3r_tree* t) { return t->total_width; }
+void p3r_tree_free(p3r_ctx* ctx, p3r_tree* tree) {
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  delete tree;
+}
+
+int p3r_time_permute_dmat(p3r_ctx* ctx, p3r_dmat* states, int iters, double* ms_per_launch) {
+  return guard(ctx, [&] {
+    if (!states || !ms_per_launch || iters <= 0) fail(P3R_EINVAL, "bad arguments");
+    hipEvent_t a, b;
+    P3R_HIP(hipEventCreate(&a));
+    P3R_HIP(hipEventCreate(&b));
+    P3R_FIELD_CALL(ctx, permute_dmat, ctx, states);  // warm-up
+    P3R_HIP(hipEventRecord(a, ctx->stream));
+    for (int i = 0; i < iters; ++i) P3R_FIELD_CALL(ctx, permute_dmat, ctx, states);
+    P3R_HIP(hipEventRecord(b, ctx->stream));
+    P3R_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    P3R_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_per_launch = (double)ms / iters;
+  });
+}
+
+int p3r_profile_enable(p3r_ctx* ctx, int on) {
+  return guard(ctx, [&] {
+    P3R_HIP(hipStreamSynchronize(ctx->stream));
+    prof_clear(ctx);
+    ctx->prof_enabled = on != 0;
+  });
+}
+
+int p3r_profile_read(p3r_ctx* ctx, p3r_profile_entry* out, size_t cap, size_t* n_out) {
+  return guard(ctx, [&] {
+    if (!out || !n_out) fail(P3R_EINVAL, "NULL argument");
+    P3R_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<p3r_profile_entry> acc;
+    for (auto& r : ctx->prof) {
+      float ms = 0;
+      P3R_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+      auto it = std::find_if(acc.begin(), acc.end(),
+                             [&](const p3r_profile_entry& e) { return !strcmp(e.name, r.name); });
+      if (it == acc.end()) {
+        p3r_profile_entry e{};
+        strncpy(e.name, r.name, sizeof e.name - 1);
+        acc.push_back(e);
+        it = acc.end() - 1;
+      }
+      it->total_ms += ms;
+      it->launches += 1;
+    }
+    if (acc.size() > cap) fail(P3R_EBUFFER, "need room for %zu profile entries", acc.size());
+    std::copy(acc.begin(), acc.end(), out);
+    *n_out = acc.size();
+  });
+}
+
+}  // extern "C"

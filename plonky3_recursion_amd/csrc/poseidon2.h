@@ -1,0 +1,181 @@
+// Poseidon2 width-16 permutation for KoalaBear (x^3, 4+20+4 rounds) and BabyBear
+// (x^7, 4+13+4 rounds), as one host/device template.
+//
+// Reference anchors:
+//   round structure / S-box degrees  circuit/src/ops/poseidon2_perm/config.rs:56-122
+//   round-constant sources            poseidon2-circuit-air/src/public_types.rs:48-54,220-226
+//   sponge / compression use          recursion/src/pcs/mmcs.rs:17-26,75-172,
+//                                     circuit/src/ops/mmcs.rs:117-160
+// The linear layers (external 4x4 circulant-of-M4, internal diagonal) are those of the
+// un-vendored p3-poseidon2 / p3-{koala,baby}-bear 0.6 crates.
+//
+// The round constants are DATA supplied through p3r_config (include/p3r.h): a flat table
+//   [4][16] external-initial | [PARTIAL] internal | [4][16] external-final
+// in Montgomery form on the device.  Nothing in this file bakes in constant values.
+#pragma once
+#include "field.h"
+
+namespace p3r {
+
+constexpr int P2_WIDTH = 16;
+constexpr int P2_RATE = 8;
+constexpr int P2_DIGEST = 8;
+constexpr int P2_HALF_FULL = 4;
+
+template <class PP>
+constexpr int p2_num_constants() { return 2 * P2_HALF_FULL * P2_WIDTH + PP::PARTIAL_ROUNDS; }
+
+// Number of columns of the upstream Poseidon2Cols<.., WIDTH=16, ..> struct:
+// inputs | 4 x {sbox regs[16][R], post[16]} | PARTIAL x {sbox regs[R], post_sbox} | 4 x {...}.
+template <class PP>
+constexpr int p2_perm_cols() {
+  return P2_WIDTH + 2 * P2_HALF_FULL * (P2_WIDTH * PP::SBOX_REGISTERS + P2_WIDTH) +
+         PP::PARTIAL_ROUNDS * (PP::SBOX_REGISTERS + 1);
+}
+
+// y = M4 * x with M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]].
+template <class F>
+P3R_HD void p2_mat4(F& x0, F& x1, F& x2, F& x3) {
+  F t01 = x0 + x1, t23 = x2 + x3;
+  F t0123 = t01 + t23;
+  F t01123 = t0123 + x1;
+  F t01233 = t0123 + x3;
+  F n3 = t01233 + x0.dbl();  // 3x0 + x1 + x2 + 2x3
+  F n1 = t01123 + x2.dbl();  // x0 + 2x1 + 3x2 + x3
+  F n0 = t01123 + t01;       // 2x0 + 3x1 + x2 + x3
+  F n2 = t01233 + t23;       // x0 + x1 + 2x2 + 3x3
+  x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+}
+
+template <class F>
+P3R_HD void p2_external_linear(F* s) {
+#pragma unroll
+  for (int i = 0; i < P2_WIDTH; i += 4) p2_mat4(s[i], s[i + 1], s[i + 2], s[i + 3]);
+  F sum[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sum[k] = s[k] + s[4 + k] + s[8 + k] + s[12 + k];
+#pragma unroll
+  for (int i = 0; i < P2_WIDTH; ++i) s[i] += sum[i & 3];
+}
+
+// Multiply a Montgomery-form value by 2^-k with one reduction: feed x * 2^(32-k) to REDC.
+template <class F>
+P3R_HD F p2_div_2exp(F x, int k) {
+  uint32_t lo = x.v << (32 - k);
+  uint32_t hi = x.v >> k;
+  return F::raw(F::reduce(lo, hi));
+}
+
+// s_i <- v_i * s_i + sum(s), diagonal v per field:
+//  KoalaBear: [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/8, 1/2^24, -1/2^8, -1/8, -1/16, -1/2^24]
+//  BabyBear : [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/4, 1/8, 1/2^27, -1/2^8, -1/16, -1/2^27]
+template <class PP, class F>
+P3R_HD void p2_internal_linear(F* s) {
+  F part = s[1];
+#pragma unroll
+  for (int i = 2; i < P2_WIDTH; ++i) part += s[i];
+  F sum = part + s[0];
+  s[0] = part - s[0];  // -2*s0 + sum
+  s[1] = s[1] + sum;
+  s[2] = s[2].dbl() + sum;
+  s[3] = s[3].halve() + sum;
+  s[4] = s[4].dbl() + s[4] + sum;
+  s[5] = s[5].dbl().dbl() + sum;
+  s[6] = sum - s[6].halve();
+  s[7] = sum - (s[7].dbl() + s[7]);
+  s[8] = sum - s[8].dbl().dbl();
+  s[9] = p2_div_2exp(s[9], 8) + sum;
+  if (PP::FIELD_ID == 0) {
+    s[10] = p2_div_2exp(s[10], 3) + sum;
+    s[11] = p2_div_2exp(s[11], 24) + sum;
+    s[12] = sum - p2_div_2exp(s[12], 8);
+    s[13] = sum - p2_div_2exp(s[13], 3);
+    s[14] = sum - p2_div_2exp(s[14], 4);
+    s[15] = sum - p2_div_2exp(s[15], 24);
+  } else {
+    s[10] = p2_div_2exp(s[10], 2) + sum;
+    s[11] = p2_div_2exp(s[11], 3) + sum;
+    s[12] = p2_div_2exp(s[12], 27) + sum;
+    s[13] = sum - p2_div_2exp(s[13], 8);
+    s[14] = sum - p2_div_2exp(s[14], 4);
+    s[15] = sum - p2_div_2exp(s[15], 27);
+  }
+}
+
+template <class PP, class F>
+P3R_HD F p2_sbox(F x) {
+  F x2 = x.sqr();
+  F x3 = x2 * x;
+  if (PP::SBOX_DEGREE == 3) return x3;
+  return x3.sqr() * x;  // x^7
+}
+
+// Trace sink used by the circuit-table fill (K3): receives every committed cell in
+// Poseidon2Cols order. NullSink turns the same code into the plain permutation.
+struct P2NullSink {
+  template <class F> P3R_HD void put(F) {}
+};
+
+// Full permutation; `rc` is the flat constant table in Montgomery form.
+// Emits, in Poseidon2Cols order after the inputs: per full round [sbox regs x16][post x16],
+// per partial round [sbox reg][post_sbox].
+template <class PP, class F, class Sink>
+P3R_HD void p2_permute_traced(F* s, const uint32_t* __restrict__ rc, Sink& sink) {
+  p2_external_linear(s);
+  int k = 0;
+  for (int r = 0; r < P2_HALF_FULL; ++r) {
+#pragma unroll
+    for (int i = 0; i < P2_WIDTH; ++i) {
+      F x = s[i] + F::raw(rc[k + i]);
+      if (PP::SBOX_REGISTERS == 1) {
+        F x3 = x.sqr() * x;
+        sink.put(x3);
+        s[i] = x3.sqr() * x;
+      } else {
+        s[i] = p2_sbox<PP>(x);
+      }
+    }
+    k += P2_WIDTH;
+    p2_external_linear(s);
+#pragma unroll
+    for (int i = 0; i < P2_WIDTH; ++i) sink.put(s[i]);
+  }
+  for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
+    F x = s[0] + F::raw(rc[k + r]);
+    if (PP::SBOX_REGISTERS == 1) {
+      F x3 = x.sqr() * x;
+      sink.put(x3);
+      s[0] = x3.sqr() * x;
+    } else {
+      s[0] = p2_sbox<PP>(x);
+    }
+    sink.put(s[0]);
+    p2_internal_linear<PP>(s);
+  }
+  k += PP::PARTIAL_ROUNDS;
+  for (int r = 0; r < P2_HALF_FULL; ++r) {
+#pragma unroll
+    for (int i = 0; i < P2_WIDTH; ++i) {
+      F x = s[i] + F::raw(rc[k + i]);
+      if (PP::SBOX_REGISTERS == 1) {
+        F x3 = x.sqr() * x;
+        sink.put(x3);
+        s[i] = x3.sqr() * x;
+      } else {
+        s[i] = p2_sbox<PP>(x);
+      }
+    }
+    k += P2_WIDTH;
+    p2_external_linear(s);
+#pragma unroll
+    for (int i = 0; i < P2_WIDTH; ++i) sink.put(s[i]);
+  }
+}
+
+template <class PP, class F>
+P3R_HD void p2_permute(F* s, const uint32_t* __restrict__ rc) {
+  P2NullSink sink;
+  p2_permute_traced<PP>(s, rc, sink);
+}
+
+}  // namespace p3r

@@ -1,0 +1,258 @@
+"""Thin object layer over the C ABI: context, device matrices, Poseidon2, LDE, MMCS.
+
+Names follow the reference's traits where one exists:
+  Context               StarkConfig built by circuit-prover/src/config.rs:92-137 /
+                        recursion/examples/common/mod.rs:464-486 (FRI params + Poseidon2 perms)
+  MerkleTree.commit/open_batch   p3_commit::Mmcs::{commit, open_batch}
+  coset_lde_batch       p3_dft::TwoAdicSubgroupDft::coset_lde_batch (+ bit_reverse_rows)
+  permute_batch         CryptographicPermutation<[F;16]>::permute over a batch
+  generate_trace_rows   Poseidon2CircuitAir::generate_trace_rows (poseidon2-circuit-air/src/air.rs:280)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FIELD_IDS = {"koala-bear": _lib.FIELD_KOALA_BEAR, "baby-bear": _lib.FIELD_BABY_BEAR}
+MODULUS = {"koala-bear": 0x7F000001, "baby-bear": 0x78000001}
+GENERATOR = {"koala-bear": 3, "baby-bear": 31}
+
+
+class P3rError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"p3r error {code}: {msg}")
+        self.code = code
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(_lib.u32p)
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+class Context:
+    """One per GPU; not thread-safe; one call in flight (include/p3r.h)."""
+
+    def __init__(self, field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
+                 log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
+                 device=0, poseidon2_rc=None):
+        self.lib = _lib.load()
+        self.field = field
+        self.p = MODULUS[field]
+        cfg = _lib.P3rConfig()
+        cfg.abi_version = _lib.P3R_ABI_VERSION
+        cfg.field = FIELD_IDS[field]
+        cfg.ext_degree = 4
+        cfg.log_blowup = log_blowup
+        cfg.max_log_arity = max_log_arity
+        cfg.cap_height = cap_height
+        cfg.log_final_poly_len = log_final_poly_len
+        cfg.commit_pow_bits = commit_pow_bits
+        cfg.query_pow_bits = query_pow_bits
+        cfg.num_queries = num_queries
+        cfg.device = device
+        if poseidon2_rc is not None:
+            rc, ptr = _u32(poseidon2_rc)
+            cfg.poseidon2_rc = ptr
+            cfg.poseidon2_rc_len = rc.size
+        self.cfg = cfg
+        self.cap_height = cap_height
+        self.log_blowup = log_blowup
+        self.h = self.lib.p3r_create(C.byref(cfg))
+        if not self.h:
+            raise P3rError(-2, self.lib.p3r_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.p3r_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != 0:
+            raise P3rError(rc, self.lib.p3r_last_error(self.h).decode())
+
+    def ptr(self, p):
+        if not p:
+            raise P3rError(-1, self.lib.p3r_last_error(self.h).decode())
+        return p
+
+    def sync(self):
+        self.check(self.lib.p3r_sync(self.h))
+
+    @property
+    def poseidon2_trace_width(self):
+        return self.lib.p3r_poseidon2_trace_width(self.h)
+
+    # ---- matrices
+    def upload(self, rowmajor):
+        a, p = _u32(rowmajor)
+        assert a.ndim == 2
+        return DeviceMatrix(self, self.ptr(self.lib.p3r_dmat_upload(self.h, p, a.shape[0], a.shape[1])))
+
+    # ---- Poseidon2
+    def permute_batch(self, states):
+        a, p = _u32(states)
+        assert a.ndim == 2 and a.shape[1] == 16
+        out = np.empty_like(a)
+        self.check(self.lib.p3r_poseidon2_permute_batch(self.h, p, out.ctypes.data_as(_lib.u32p), a.shape[0]))
+        return out
+
+    def _p2_rows(self, inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum):
+        keep = []
+        rows = _lib.P3rP2Rows()
+        a, rows.input_values = _u32(inputs)
+        keep.append(a)
+        rows.n = a.shape[0]
+        for name, v in (("new_start", new_start), ("merkle_path", merkle_path), ("mmcs_bit", mmcs_bit)):
+            b, p = _u8(v)
+            keep.append(b)
+            setattr(rows, name, p)
+        b, rows.mmcs_index_sum = _u32(mmcs_index_sum)
+        keep.append(b)
+        return rows, keep
+
+    def generate_trace_rows(self, inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum):
+        rows, keep = self._p2_rows(inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum)
+        out = np.empty((rows.n, self.poseidon2_trace_width), dtype=np.uint32)
+        self.check(self.lib.p3r_poseidon2_trace_fill(self.h, C.byref(rows), out.ctypes.data_as(_lib.u32p)))
+        return out
+
+    def generate_trace_rows_device(self, inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum):
+        rows, keep = self._p2_rows(inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum)
+        return DeviceMatrix(self, self.ptr(self.lib.p3r_poseidon2_trace_fill_dmat(self.h, C.byref(rows))))
+
+    def upload_p2_rows(self, inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum):
+        rows, keep = self._p2_rows(inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum)
+        return DeviceP2Rows(self, self.ptr(self.lib.p3r_p2_rows_upload(self.h, C.byref(rows))))
+
+    def generate_trace_rows_resident(self, dev_rows):
+        return DeviceMatrix(self, self.ptr(self.lib.p3r_poseidon2_trace_fill_dev(self.h, dev_rows.h)))
+
+    # ---- LDE
+    def coset_lde_batch(self, evals, added_bits, shift):
+        a, p = _u32(evals)
+        out = np.empty((a.shape[0] << added_bits, a.shape[1]), dtype=np.uint32)
+        self.check(self.lib.p3r_coset_lde(self.h, p, a.shape[0], a.shape[1], added_bits, shift,
+                                          out.ctypes.data_as(_lib.u32p)))
+        return out
+
+    def coset_lde_batch_device(self, dmat, added_bits, shift):
+        return DeviceMatrix(self, self.ptr(self.lib.p3r_coset_lde_dmat(self.h, dmat.h, added_bits, shift)))
+
+    # ---- MMCS
+    def commit(self, mats):
+        """Mmcs::commit over host matrices (list of 2-D uint32 arrays). Returns (cap, tree)."""
+        keep = []
+        arr = (_lib.P3rMatrix * len(mats))()
+        for i, m in enumerate(mats):
+            a, p = _u32(m)
+            keep.append(a)
+            arr[i].values, arr[i].height, arr[i].width = p, a.shape[0], a.shape[1]
+        cap = np.empty((1 << self.cap_height, 8), dtype=np.uint32)
+        tree = C.c_void_p()
+        self.check(self.lib.p3r_mmcs_commit(self.h, arr, len(mats), cap.ctypes.data_as(_lib.u32p), C.byref(tree)))
+        return cap, MerkleTree(self, tree.value, [])
+
+    def commit_device(self, dmats):
+        arr = (C.c_void_p * len(dmats))(*[d.h for d in dmats])
+        cap = np.empty((1 << self.cap_height, 8), dtype=np.uint32)
+        tree = C.c_void_p()
+        self.check(self.lib.p3r_mmcs_commit_dmat(self.h, arr, len(dmats), cap.ctypes.data_as(_lib.u32p), C.byref(tree)))
+        return cap, MerkleTree(self, tree.value, list(dmats))
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        self.check(self.lib.p3r_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        buf = (_lib.P3rProfileEntry * 64)()
+        n = C.c_size_t()
+        self.check(self.lib.p3r_profile_read(self.h, buf, 64, C.byref(n)))
+        return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n.value)}
+
+    def time_permute(self, dmat, iters):
+        ms = C.c_double()
+        self.check(self.lib.p3r_time_permute_dmat(self.h, dmat.h, iters, C.byref(ms)))
+        return ms.value
+
+
+class DeviceMatrix:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def shape(self):
+        return (self.ctx.lib.p3r_dmat_height(self.h), self.ctx.lib.p3r_dmat_width(self.h))
+
+    def download(self):
+        out = np.empty(self.shape, dtype=np.uint32)
+        self.ctx.check(self.ctx.lib.p3r_dmat_download(self.ctx.h, self.h, out.ctypes.data_as(_lib.u32p)))
+        return out
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.p3r_dmat_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceP2Rows:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.p3r_p2_rows_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MerkleTree:
+    def __init__(self, ctx, handle, borrowed):
+        self.ctx, self.h, self._borrowed = ctx, handle, borrowed
+
+    @property
+    def log_max_height(self):
+        return self.ctx.lib.p3r_tree_log_max_height(self.h)
+
+    def open_batch(self, index):
+        """Returns (opened_values concatenated in commit order, proof[(depth, 8)])."""
+        w = self.ctx.lib.p3r_tree_total_width(self.h)
+        depth = self.log_max_height - self.ctx.cap_height
+        opened = np.empty(w, dtype=np.uint32)
+        proof = np.empty((depth, 8), dtype=np.uint32)
+        self.ctx.check(self.ctx.lib.p3r_mmcs_open(self.ctx.h, self.h, index, opened.ctypes.data_as(_lib.u32p),
+                                                  proof.ctypes.data_as(_lib.u32p)))
+        return opened, proof
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.p3r_tree_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

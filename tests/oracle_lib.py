@@ -1,0 +1,146 @@
+"""ctypes view of the CPU oracle (oracle/libp3r_oracle.so). Test infrastructure only."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "libp3r_oracle.so")
+
+FIELD_NAMES = {"koala-bear": "koala_bear", "baby-bear": "baby_bear"}
+FIELD_IDS = {"koala-bear": 0, "baby-bear": 1}
+MODULUS = {"koala-bear": 0x7F000001, "baby-bear": 0x78000001}
+GENERATOR = {"koala-bear": 3, "baby-bear": 31}
+
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+
+
+def build():
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+        return
+    subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(u32p)
+
+
+def default_rc(field):
+    with open(os.path.join(ROOT, "tests/golden/poseidon2_rc_default.json")) as fh:
+        return np.array(json.load(fh)[FIELD_NAMES[field]], dtype=np.uint32)
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        self.lib = C.CDLL(LIB)
+        self.lib.orc_last_error.restype = C.c_char_p
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError("oracle: " + self.lib.orc_last_error().decode())
+
+    def trace_width(self, field):
+        return self.lib.orc_p2_trace_width(FIELD_IDS[field])
+
+    def permute(self, field, states, rc=None):
+        rc = default_rc(field) if rc is None else rc
+        a, p = _u32(states)
+        out = np.empty_like(a)
+        r, rp = _u32(rc)
+        self._ck(self.lib.orc_p2_permute(FIELD_IDS[field], rp, p, out.ctypes.data_as(u32p), C.c_size_t(a.shape[0])))
+        return out
+
+    def trace_rows(self, field, inputs, new_start, merkle_path, mmcs_bit, index_sum, rc=None):
+        rc = default_rc(field) if rc is None else rc
+        a, p = _u32(inputs)
+        n = a.shape[0]
+        fl = [np.ascontiguousarray(x, dtype=np.uint8) for x in (new_start, merkle_path, mmcs_bit)]
+        s, sp = _u32(index_sum)
+        r, rp = _u32(rc)
+        out = np.empty((n, self.trace_width(field)), dtype=np.uint32)
+        self._ck(self.lib.orc_p2_trace_rows(FIELD_IDS[field], rp, C.c_size_t(n), p,
+                                            fl[0].ctypes.data_as(u8p), fl[1].ctypes.data_as(u8p),
+                                            fl[2].ctypes.data_as(u8p), sp, out.ctypes.data_as(u32p)))
+        return out
+
+    def coset_lde(self, field, evals, added_bits, shift):
+        a, p = _u32(evals)
+        out = np.empty((a.shape[0] << added_bits, a.shape[1]), dtype=np.uint32)
+        self._ck(self.lib.orc_coset_lde(FIELD_IDS[field], p, C.c_size_t(a.shape[0]), C.c_size_t(a.shape[1]),
+                                        C.c_uint32(added_bits), C.c_uint32(shift), out.ctypes.data_as(u32p)))
+        return out
+
+    def commit(self, field, mats, cap_height=0, rc=None):
+        rc = default_rc(field) if rc is None else rc
+        arrs = [np.ascontiguousarray(m, dtype=np.uint32) for m in mats]
+        n = len(arrs)
+        vals = (u32p * n)(*[a.ctypes.data_as(u32p) for a in arrs])
+        hs = (C.c_size_t * n)(*[a.shape[0] for a in arrs])
+        ws = (C.c_size_t * n)(*[a.shape[1] for a in arrs])
+        cap = np.empty((1 << cap_height, 8), dtype=np.uint32)
+        tree = C.c_void_p()
+        r, rp = _u32(rc)
+        self._ck(self.lib.orc_mmcs_commit(FIELD_IDS[field], rp, C.c_size_t(n), vals, hs, ws, cap_height,
+                                          cap.ctypes.data_as(u32p), C.byref(tree)))
+        return cap, OracleTree(self, tree, arrs, cap_height)
+
+    def verify(self, field, cap, dims, index, opened, proof, rc=None):
+        rc = default_rc(field) if rc is None else rc
+        n = len(dims)
+        hs = (C.c_size_t * n)(*[d[0] for d in dims])
+        ws = (C.c_size_t * n)(*[d[1] for d in dims])
+        c, cp = _u32(cap)
+        cap_height = int(np.log2(c.shape[0]))
+        o, op = _u32(opened)
+        pf, pp = _u32(proof)
+        r, rp = _u32(rc)
+        ok = C.c_int()
+        self._ck(self.lib.orc_mmcs_verify(FIELD_IDS[field], rp, cp, cap_height, C.c_size_t(n), hs, ws,
+                                          C.c_size_t(index), op, pp, C.c_size_t(pf.shape[0]), C.byref(ok)))
+        return bool(ok.value)
+
+    def challenger_script(self, field, ops, args, rc=None):
+        rc = default_rc(field) if rc is None else rc
+        o = np.ascontiguousarray(ops, dtype=np.int32)
+        a, ap = _u32(args)
+        out = np.empty(4 * len(ops) + 4, dtype=np.uint32)
+        n = C.c_size_t()
+        r, rp = _u32(rc)
+        self._ck(self.lib.orc_challenger_script(FIELD_IDS[field], rp, o.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                C.c_size_t(len(ops)), ap, out.ctypes.data_as(u32p), C.byref(n)))
+        return out[: n.value]
+
+    def ext_ops(self, field, a, b):
+        x, xp = _u32(a)
+        y, yp = _u32(b)
+        mul = np.empty(4, dtype=np.uint32)
+        inv = np.empty(4, dtype=np.uint32)
+        self._ck(self.lib.orc_ext_ops(FIELD_IDS[field], xp, yp, mul.ctypes.data_as(u32p), inv.ctypes.data_as(u32p)))
+        return mul, inv
+
+
+class OracleTree:
+    def __init__(self, orc, handle, arrs, cap_height):
+        self.orc, self.h, self.arrs, self.cap_height = orc, handle, arrs, cap_height
+        self.log_max_h = int(np.log2(max(a.shape[0] for a in arrs)))
+
+    def open(self, index):
+        w = sum(a.shape[1] for a in self.arrs)
+        opened = np.empty(w, dtype=np.uint32)
+        proof = np.empty((self.log_max_h - self.cap_height, 8), dtype=np.uint32)
+        self.orc._ck(self.orc.lib.orc_mmcs_open(self.h, C.c_size_t(index), opened.ctypes.data_as(u32p),
+                                                proof.ctypes.data_as(u32p)))
+        return opened, proof
+
+    def __del__(self):
+        try:
+            self.orc.lib.orc_tree_free(self.h)
+        except Exception:
+            pass
