@@ -175,6 +175,7 @@ void do_ext_ops(const uint32_t* a, const uint32_t* b, uint32_t* mul, uint32_t* i
 extern "C" {
 
 const char* orc_last_error() { return g_err.c_str(); }
+void orc_set_error(const char* s) { g_err = s; }
 
 int orc_p2_trace_width(int field) { return field == 0 ? Poseidon2<KoalaBear>::perm_cols() + 2 : Poseidon2<BabyBear>::perm_cols() + 2; }
 int orc_p2_num_constants(int field) { return field == 0 ? Poseidon2<KoalaBear>::num_constants() : Poseidon2<BabyBear>::num_constants(); }

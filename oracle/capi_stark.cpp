@@ -1,0 +1,233 @@
+// ORACLE (test infrastructure): extern "C" entry points for the full batch-STARK restatement:
+// build the five table instances of a recursion layer from flattened Traces, prove, verify,
+// (de)serialise.  PARITY UNPINNED (see field.hpp).
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "proof_io.hpp"
+#include "stark.hpp"
+#include "tables.hpp"
+
+using namespace orc;
+
+extern "C" {
+
+// Flattened `Traces<EF>` + per-op preprocessed data of one recursion layer, as the
+// reference's prove_all_tables consumes them (circuit/src/tables/mod.rs:49-62;
+// circuit-prover/src/common.rs:198-368 for the preprocessed conventions). All canonical u32.
+typedef struct orc_workload {
+  size_t n_const;  const uint32_t* const_values;  /* n x 4 */ const uint32_t* const_prep;  /* n x 2: mult, idx */
+  size_t n_public; const uint32_t* public_values; /* n x 4 */ const uint32_t* public_prep; /* n x 2 */
+  size_t n_alu;    const uint32_t* alu_values;    /* n x 16 */ const uint32_t* alu_prep13;  /* n x 13 */
+  size_t n_p2;     const uint32_t* p2_inputs;     /* n x 16 */
+  const uint32_t* p2_flags;          /* n x 4: new_start, merkle_path, mmcs_bit, mmcs_ctl_enabled */
+  const uint32_t* p2_mmcs_index_sum; /* n */
+  const uint32_t* p2_in_ctl;         /* n x 4 */
+  const uint32_t* p2_input_indices;  /* n x 4 (witness ids, unscaled) */
+  const uint32_t* p2_out_ctl;        /* n x 2 (multiplicity) */
+  const uint32_t* p2_output_indices; /* n x 2 */
+  const uint32_t* p2_mmcs_index_sum_idx; /* n */
+  size_t n_recompose; const uint32_t* recompose_values; /* n x 4 */ const uint32_t* recompose_prep; /* n x 2: idx, mult */
+  /* TablePacking (circuit-prover/src/batch_stark_prover/packing.rs:10-27) */
+  uint32_t public_lanes, alu_lanes, horner_packed_steps, recompose_lanes, min_trace_height;
+} orc_workload;
+
+typedef struct orc_params {
+  uint32_t log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits,
+      num_queries;
+} orc_params;
+
+const char* orc_last_error();
+}
+
+namespace {
+thread_local std::string g_err2;
+void set_err(const std::string& e);
+
+struct LayerBase {
+  virtual ~LayerBase() = default;
+  virtual size_t num_tables() const = 0;
+  virtual void info(size_t i, uint32_t* out6) const = 0;
+  virtual void get(size_t i, int which, uint32_t* out) const = 0;
+  virtual void prep_commit(const orc_params& p, uint32_t* cap_out) = 0;
+  virtual std::vector<uint8_t> prove(const orc_params& p, int enc) = 0;
+  virtual void verify(const orc_params& p, const uint32_t* prep_cap, const uint8_t* bytes, size_t n, int enc) const = 0;
+};
+
+StarkParams to_sp(const orc_params& p) {
+  StarkParams s;
+  s.log_blowup = p.log_blowup; s.max_log_arity = p.max_log_arity; s.cap_height = p.cap_height;
+  s.log_final_poly_len = p.log_final_poly_len; s.commit_pow_bits = p.commit_pow_bits;
+  s.query_pow_bits = p.query_pow_bits; s.num_queries = p.num_queries;
+  return s;
+}
+
+template <class FP>
+struct Layer : LayerBase {
+  using F = Fe<FP>;
+  Poseidon2<FP> p2;
+  std::vector<Instance<FP>> insts;
+  std::unique_ptr<ProverData<FP>> pd;
+  explicit Layer(const uint32_t* rc) : p2(rc) {}
+
+  static std::vector<F> vec(const uint32_t* p, size_t n) {
+    std::vector<F> v(n);
+    for (size_t i = 0; i < n; ++i) {
+      if (p[i] >= FP::P) throw std::runtime_error("non-canonical workload element");
+      v[i] = F(p[i]);
+    }
+    return v;
+  }
+
+  // order [Const, Public, Alu, Poseidon2, Recompose]
+  // (circuit-prover/src/batch_stark_prover.rs:1493-1519; backend/fri.rs:693-721)
+  void build(const orc_workload& w) {
+    const size_t mh = w.min_trace_height;
+    {
+      Instance<FP> in;
+      in.air.kind = AIR_CONST; in.air.lanes = 1;
+      in.main = lanes_trace_to_matrix<FP>(vec(w.const_values, w.n_const * 4), 1, mh);
+      in.prep = lanes_prep_to_matrix<FP>(vec(w.const_prep, w.n_const * 2), 2, 1, mh);
+      insts.push_back(std::move(in));
+    }
+    {
+      Instance<FP> in;
+      in.air.kind = AIR_PUBLIC; in.air.lanes = (int)w.public_lanes;
+      in.main = lanes_trace_to_matrix<FP>(vec(w.public_values, w.n_public * 4), in.air.lanes, mh);
+      in.prep = lanes_prep_to_matrix<FP>(vec(w.public_prep, w.n_public * 2), 2, in.air.lanes, mh);
+      insts.push_back(std::move(in));
+    }
+    {
+      Instance<FP> in;
+      in.air.kind = AIR_ALU; in.air.lanes = (int)w.alu_lanes; in.air.horner_k = (int)w.horner_packed_steps;
+      auto values = vec(w.alu_values, w.n_alu * 16);
+      auto prep = vec(w.alu_prep13, w.n_alu * 13);
+      in.main = alu_trace_to_matrix<FP>(in.air, values, prep, mh);
+      in.prep = alu_preprocessed_trace<FP>(in.air, prep, mh);
+      if (in.main.h != in.prep.h) throw std::runtime_error("ALU main/prep height mismatch");
+      insts.push_back(std::move(in));
+    }
+    {
+      Instance<FP> in;
+      in.air.kind = AIR_POSEIDON2;
+      // pad the op list to a power of two >= min height with filler rows
+      // (new_start = true, zero state: batch_stark_prover/poseidon2.rs:1125-1140)
+      size_t n = 1;
+      while (n < std::max(w.n_p2, mh)) n <<= 1;
+      std::vector<P2Row<FP>> rows(n);
+      std::vector<P2CtlRow<FP>> ctl(w.n_p2);
+      for (size_t r = 0; r < n; ++r) {
+        if (r < w.n_p2) {
+          rows[r].new_start = w.p2_flags[r * 4 + 0]; rows[r].merkle_path = w.p2_flags[r * 4 + 1];
+          rows[r].mmcs_bit = w.p2_flags[r * 4 + 2];
+          rows[r].mmcs_index_sum = F(w.p2_mmcs_index_sum[r]);
+          for (int k = 0; k < 16; ++k) rows[r].input[k] = F(w.p2_inputs[r * 16 + k]);
+          auto& c = ctl[r];
+          c.new_start = rows[r].new_start; c.merkle_path = rows[r].merkle_path;
+          c.mmcs_ctl_enabled = w.p2_flags[r * 4 + 3];
+          for (int l = 0; l < 4; ++l) { c.in_ctl[l] = w.p2_in_ctl[r * 4 + l]; c.input_indices[l] = w.p2_input_indices[r * 4 + l]; }
+          for (int l = 0; l < 2; ++l) { c.out_ctl[l] = F(w.p2_out_ctl[r * 2 + l]); c.output_indices[l] = w.p2_output_indices[r * 2 + l]; }
+          c.mmcs_index_sum_idx = w.p2_mmcs_index_sum_idx[r];
+        } else {
+          rows[r].new_start = true;
+        }
+      }
+      in.main = p2_generate_trace_rows<FP>(p2, rows);
+      in.prep = p2_preprocessed_trace<FP>(ctl, n);
+      insts.push_back(std::move(in));
+    }
+    {
+      Instance<FP> in;
+      in.air.kind = AIR_RECOMPOSE; in.air.lanes = (int)w.recompose_lanes; in.air.coeff_lookups = 0;
+      in.main = lanes_trace_to_matrix<FP>(vec(w.recompose_values, w.n_recompose * 4), in.air.lanes, mh);
+      in.prep = lanes_prep_to_matrix<FP>(vec(w.recompose_prep, w.n_recompose * 2), 2, in.air.lanes, mh);
+      // RecomposeAir::trace_to_matrix pads only to a power of two; the prover then pads dynamic
+      // tables to min_height (batch_stark_prover.rs:1515): same result as padding here.
+      insts.push_back(std::move(in));
+    }
+    for (auto& in : insts)
+      if (in.main.h != in.prep.h) throw std::runtime_error("main/preprocessed height mismatch");
+  }
+
+  size_t num_tables() const override { return insts.size(); }
+  void info(size_t i, uint32_t* o) const override {
+    const auto& in = insts.at(i);
+    o[0] = in.air.kind; o[1] = in.air.lanes; o[2] = in.air.horner_k; o[3] = (uint32_t)in.main.h;
+    o[4] = (uint32_t)in.main.w; o[5] = (uint32_t)in.prep.w;
+  }
+  void get(size_t i, int which, uint32_t* out) const override {
+    const auto& m = which == 0 ? insts.at(i).main : insts.at(i).prep;
+    for (size_t k = 0; k < m.v.size(); ++k) out[k] = m.v[k].v;
+  }
+  void ensure_pd(const orc_params& p) {
+    if (!pd) pd = std::make_unique<ProverData<FP>>(make_prover_data<FP>(p2, to_sp(p), insts));
+  }
+  void prep_commit(const orc_params& p, uint32_t* cap_out) override {
+    ensure_pd(p);
+    for (auto& d : pd->prep.cap) for (auto x : d) *cap_out++ = x.v;
+  }
+  std::vector<uint8_t> prove(const orc_params& p, int enc) override {
+    ensure_pd(p);
+    auto proof = prove_batch<FP>(p2, to_sp(p), insts, *pd);
+    return serialize_proof<FP>(proof, enc);
+  }
+  void verify(const orc_params& p, const uint32_t* prep_cap, const uint8_t* bytes, size_t n, int enc) const override {
+    auto proof = deserialize_proof<FP>(bytes, n, enc);
+    std::vector<InstanceShape> shapes;
+    for (auto& in : insts) shapes.push_back({in.air});
+    typename BatchProof<FP>::Cap cap(size_t(1) << p.cap_height);
+    for (auto& d : cap) for (auto& x : d) x = F(*prep_cap++);
+    verify_batch<FP>(p2, to_sp(p), shapes, cap, proof);
+  }
+};
+
+template <class Fn>
+int guard2(Fn&& fn) {
+  try { fn(); return 0; } catch (const std::exception& e) { set_err(e.what()); return -1; }
+}
+}  // namespace
+
+// error string shared with capi.cpp through a tiny setter
+extern "C" void orc_set_error(const char* s);
+namespace { void set_err(const std::string& e) { orc_set_error(e.c_str()); } }
+
+extern "C" {
+
+void* orc_layer_build(int field, const uint32_t* rc, const orc_workload* w) {
+  LayerBase* out = nullptr;
+  guard2([&] {
+    if (field == 0) { auto l = std::make_unique<Layer<KoalaBear>>(rc); l->build(*w); out = l.release(); }
+    else if (field == 1) { auto l = std::make_unique<Layer<BabyBear>>(rc); l->build(*w); out = l.release(); }
+    else throw std::runtime_error("unknown field id");
+  });
+  return out;
+}
+void orc_layer_free(void* h) { delete static_cast<LayerBase*>(h); }
+size_t orc_layer_num_tables(const void* h) { return static_cast<const LayerBase*>(h)->num_tables(); }
+int orc_layer_table_info(const void* h, size_t i, uint32_t* out6) {
+  return guard2([&] { static_cast<const LayerBase*>(h)->info(i, out6); });
+}
+int orc_layer_get_matrix(const void* h, size_t i, int which, uint32_t* out) {
+  return guard2([&] { static_cast<const LayerBase*>(h)->get(i, which, out); });
+}
+int orc_layer_prep_commit(void* h, const orc_params* p, uint32_t* cap_out) {
+  return guard2([&] { static_cast<LayerBase*>(h)->prep_commit(*p, cap_out); });
+}
+// proves; *bytes_out is malloc'd (free with orc_bytes_free)
+int orc_layer_prove(void* h, const orc_params* p, int field_encoding, uint8_t** bytes_out, size_t* len_out) {
+  return guard2([&] {
+    auto v = static_cast<LayerBase*>(h)->prove(*p, field_encoding);
+    *bytes_out = (uint8_t*)malloc(v.size());
+    memcpy(*bytes_out, v.data(), v.size());
+    *len_out = v.size();
+  });
+}
+void orc_bytes_free(uint8_t* b) { free(b); }
+// verify_batch against this layer's AIR shapes; returns 0 iff the proof is accepted
+int orc_layer_verify(const void* h, const orc_params* p, const uint32_t* prep_cap, const uint8_t* bytes,
+                     size_t len, int field_encoding) {
+  return guard2([&] { static_cast<const LayerBase*>(h)->verify(*p, prep_cap, bytes, len, field_encoding); });
+}
+
+}  // extern "C"

@@ -1,0 +1,921 @@
+// ORACLE (test infrastructure): CPU restatement of p3_batch_stark::prove_batch /
+// verify_batch over TwoAdicFriPcs<MerkleTreeMmcs<Poseidon2>> with the LogUp lookup argument,
+// for the five recursion tables.  PARITY UNPINNED (see field.hpp): the prover body lives in
+// un-vendored p3-* 0.6 crates; the statement, transcript order and every check below are
+// pinned by the in-tree circuit verifier, cited per step:
+//
+//   transcript order            recursion/src/verifier/batch_stark.rs:521-627
+//   domains, rounds, points     recursion/src/verifier/batch_stark.rs:629-852
+//   opened-value observation    recursion/src/verifier/batch_stark.rs:1114-1276
+//   per-AIR quotient identity   recursion/src/verifier/batch_stark.rs:886-1021
+//   LogUp challenge layout      recursion/src/verifier/batch_stark.rs:1026-1112
+//   quotient recomposition      recursion/src/verifier/quotient.rs:60-140
+//   selectors                   recursion/src/pcs/fri/targets.rs:868-908
+//   constraint folding          recursion/src/traits/air.rs:162-182
+//   FRI                         recursion/src/pcs/fri/targets.rs:748-866, verifier.rs:424-1838
+//
+// Choices that upstream leaves un-pinned and that DESIGN.md section "EXT choices" lists:
+// LogUp per-row constraint polynomials and same-bus packing rule, FRI arity schedule rule,
+// smallest-witness grinding.
+#pragma once
+#include <map>
+
+#include "air.hpp"
+#include "dft.hpp"
+
+namespace orc {
+
+struct StarkParams {
+  int log_blowup = 2, max_log_arity = 2, cap_height = 0, log_final_poly_len = 5;
+  int commit_pow_bits = 0, query_pow_bits = 15, num_queries = 54;
+};
+
+template <class FP>
+struct Instance {
+  AirDesc air;
+  Matrix<FP> main;  // height = padded trace height
+  Matrix<FP> prep;  // BaseAir::preprocessed_trace(), same height
+};
+
+// ------------------------------------------------------------------ proof containers
+template <class FP>
+struct BatchOpening {
+  std::vector<std::vector<Fe<FP>>> opened_values;          // per matrix of the batch
+  std::vector<std::array<Fe<FP>, DIGEST>> opening_proof;   // sibling digests bottom-up
+};
+template <class FP>
+struct CommitPhaseStep {
+  uint8_t log_arity = 1;
+  std::vector<Fe4<FP>> sibling_values;
+  std::vector<std::array<Fe<FP>, DIGEST>> opening_proof;
+};
+template <class FP>
+struct QueryProof {
+  std::vector<BatchOpening<FP>> input_proof;               // one per round
+  std::vector<CommitPhaseStep<FP>> commit_phase_openings;
+};
+template <class FP>
+struct FriProof {
+  using Cap = std::vector<std::array<Fe<FP>, DIGEST>>;
+  std::vector<Cap> commit_phase_commits;
+  std::vector<Fe<FP>> commit_pow_witnesses;
+  std::vector<QueryProof<FP>> query_proofs;
+  std::vector<Fe4<FP>> final_poly;
+  Fe<FP> query_pow_witness;
+};
+template <class FP>
+struct OpenedValues {
+  using EF = Fe4<FP>;
+  std::vector<EF> trace_local;
+  bool has_trace_next = false;
+  std::vector<EF> trace_next;
+  std::vector<EF> preprocessed_local, preprocessed_next;   // always present for circuit tables
+  std::vector<std::vector<EF>> quotient_chunks;
+  std::vector<EF> permutation_local, permutation_next;     // flattened aux columns (aux_width * 4)
+};
+template <class FP>
+struct BatchProof {
+  using Cap = std::vector<std::array<Fe<FP>, DIGEST>>;
+  Cap main_commit, permutation_commit, quotient_commit;
+  bool has_permutation = false;
+  std::vector<OpenedValues<FP>> opened;                    // per instance
+  FriProof<FP> fri;
+  std::vector<bool> has_terminal;
+  std::vector<Fe4<FP>> lookup_terminals;                   // per instance (valid iff has_terminal)
+  std::vector<size_t> degree_bits;
+};
+
+// ------------------------------------------------------------------ LogUp
+// Multiplicity degrees per interaction, in push order (for the packing degree rule).
+inline std::vector<int> interaction_mult_degrees(const AirDesc& a) {
+  std::vector<int> d;
+  switch (a.kind) {
+    case AIR_CONST: d = {1}; break;
+    case AIR_PUBLIC: d.assign(a.lanes, 1); break;
+    case AIR_RECOMPOSE: d.assign(a.lanes * (1 + (a.coeff_lookups ? D : 0)), 1); break;
+    case AIR_ALU:
+      for (int l = 0; l < a.lanes; ++l) { d.push_back(2); d.push_back(1); d.push_back(2); d.push_back(1); }
+      for (int t = 1; t < a.horner_k; ++t) { d.push_back(1); d.push_back(1); }
+      break;
+    case AIR_POSEIDON2: d = {2, 2, 2, 2, 1, 1, 2}; break;
+  }
+  return d;
+}
+// Maximum degree of the AIR's own (base) constraints under upstream's accounting
+// (preprocessed/main columns 1, is_transition 0, is_first/is_last 1).
+template <class FP>
+int air_base_constraint_degree(const AirDesc& a) {
+  switch (a.kind) {
+    case AIR_ALU: return 3;
+    case AIR_POSEIDON2: return 3;
+    default: return 0;
+  }
+}
+inline int group_degree(const std::vector<int>& mult_deg, const std::vector<int>& members) {
+  int K = (int)members.size();
+  int deg = 1 + K;  // fraction column times every denominator
+  for (int m : members) deg = std::max(deg, mult_deg[m] + K - 1);
+  return deg;
+}
+inline int log2_ceil(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+struct LookupLayout {
+  std::vector<std::vector<int>> groups;  // each group -> interaction indices sharing one aux column
+  int log_quotient_chunks = 0;
+  int aux_width() const { return groups.empty() ? 0 : (int)groups.size() + 1; }
+};
+// Lookups::from_air + get_log_num_quotient_chunks + pack_same_bus(budget = 2^log_chunks + 1)
+// (circuit-prover/src/batch_stark_prover.rs:925-941).  Packing rule: greedy in declaration
+// order while the packed constraint degree stays within the budget.
+template <class FP>
+LookupLayout lookup_layout(const AirDesc& a) {
+  LookupLayout L;
+  auto md = interaction_mult_degrees(a);
+  int max_deg = std::max(air_base_constraint_degree<FP>(a), 2);
+  for (size_t i = 0; i < md.size(); ++i) max_deg = std::max(max_deg, group_degree(md, {(int)i}));
+  L.log_quotient_chunks = log2_ceil(max_deg - 1);
+  const int budget = (1 << L.log_quotient_chunks) + 1;
+  std::vector<int> cur;
+  for (size_t i = 0; i < md.size(); ++i) {
+    auto trial = cur;
+    trial.push_back((int)i);
+    if (!cur.empty() && group_degree(md, trial) > budget) {
+      L.groups.push_back(cur);
+      cur = {(int)i};
+    } else {
+      cur = trial;
+    }
+  }
+  if (!cur.empty()) L.groups.push_back(cur);
+  return L;
+}
+
+template <class FP>
+struct LookupChallenges {
+  Fe4<FP> prefix;  // alpha + gamma for bus 0 ("WitnessChecks"), gamma = beta^W
+  Fe4<FP> beta;
+};
+// get_perm_challenges (verifier/batch_stark.rs:1026-1112): one (alpha, beta) pair; every
+// lookup is on the single global bus "WitnessChecks" (bus id 0); W = widest tuple = 1 + D.
+template <class FP>
+LookupChallenges<FP> sample_lookup_challenges(Challenger<FP>& ch) {
+  Fe4<FP> alpha = ch.sample_ext(), beta = ch.sample_ext();
+  Fe4<FP> gamma = beta;
+  for (int i = 1; i < 1 + D; ++i) gamma *= beta;
+  return {alpha + gamma, beta};
+}
+
+// denominator prefix + sum_j beta^j * field_j, generic over value type
+template <class FP, class V>
+Fe4<FP> lookup_denominator(const LookupChallenges<FP>& c, const std::vector<V>& fields);
+template <class FP>
+Fe4<FP> lookup_denom_f(const LookupChallenges<FP>& c, const std::vector<Fe<FP>>& fields) {
+  Fe4<FP> d = c.prefix, bp = Fe4<FP>::one();
+  for (auto& f : fields) { d += bp * f; bp *= c.beta; }
+  return d;
+}
+template <class FP>
+Fe4<FP> lookup_denom_e(const LookupChallenges<FP>& c, const std::vector<Fe4<FP>>& fields) {
+  Fe4<FP> d = c.prefix, bp = Fe4<FP>::one();
+  for (auto& f : fields) { d += bp * f; bp *= c.beta; }
+  return d;
+}
+
+// LogUp constraints for one row, appended after the AIR's base constraints:
+//   per group g:   f_g * prod_k d_k - sum_k m_k * prod_{l != k} d_l
+//   is_first * s ;  is_transition * (s' - s - sum_g f_g) ;  is_last * (s + sum_g f_g - T)
+template <class FP>
+void logup_constraints(const LookupLayout& L, const std::vector<Fe4<FP>>& denoms,
+                       const std::vector<Fe4<FP>>& mults, const std::vector<Fe4<FP>>& aux_local,
+                       const std::vector<Fe4<FP>>& aux_next, Fe4<FP> is_first, Fe4<FP> is_last,
+                       Fe4<FP> is_transition, Fe4<FP> terminal, std::vector<Fe4<FP>>& out) {
+  using EF = Fe4<FP>;
+  EF sum_f = EF::zero();
+  for (size_t g = 0; g < L.groups.size(); ++g) {
+    const auto& mem = L.groups[g];
+    EF f = aux_local[g + 1];
+    EF prod = EF::one();
+    for (int k : mem) prod *= denoms[k];
+    EF rhs = EF::zero();
+    for (size_t a = 0; a < mem.size(); ++a) {
+      EF t = mults[mem[a]];
+      for (size_t bb = 0; bb < mem.size(); ++bb)
+        if (bb != a) t *= denoms[mem[bb]];
+      rhs += t;
+    }
+    out.push_back(f * prod - rhs);
+    sum_f += f;
+  }
+  out.push_back(is_first * aux_local[0]);
+  out.push_back(is_transition * (aux_next[0] - aux_local[0] - sum_f));
+  out.push_back(is_last * (aux_local[0] + sum_f - terminal));
+}
+
+// ------------------------------------------------------------------ helpers
+template <class FP>
+Matrix<FP> rows_bitrev(const Matrix<FP>& m) {
+  Matrix<FP> o(m.h, m.w);
+  int l = log2_strict(m.h);
+  for (size_t i = 0; i < m.h; ++i)
+    std::copy(m.v.begin() + i * m.w, m.v.begin() + (i + 1) * m.w, o.v.begin() + bitrev((uint32_t)i, l) * m.w);
+  return o;
+}
+template <class FP>
+Fe4<FP> horner_ext(const std::vector<Fe<FP>>& coeffs, Fe4<FP> x) {
+  Fe4<FP> acc = Fe4<FP>::zero();
+  for (size_t i = coeffs.size(); i-- > 0;) acc = acc * x + Fe4<FP>(coeffs[i]);
+  return acc;
+}
+// Evaluate every column of `evals` (given over the coset `dshift * <w_h>`, natural order) at z.
+template <class FP>
+std::vector<Fe4<FP>> open_matrix(const Matrix<FP>& evals, Fe<FP> dshift, Fe4<FP> z) {
+  std::vector<Fe4<FP>> out(evals.w);
+  Fe4<FP> zz = z * dshift.inv();
+  for (size_t c = 0; c < evals.w; ++c) {
+    std::vector<Fe<FP>> col(evals.h);
+    for (size_t r = 0; r < evals.h; ++r) col[r] = evals.at(r, c);
+    out[c] = horner_ext<FP>(idft<FP>(col), zz);
+  }
+  return out;
+}
+
+template <class FP>
+struct Selectors {
+  Fe4<FP> is_first, is_last, is_transition, inv_vanishing;
+};
+// selectors of the trace domain <w_n> at an arbitrary point (fri/targets.rs:868-908)
+template <class FP>
+Selectors<FP> selectors_at(int log_n, Fe4<FP> x) {
+  using EF = Fe4<FP>;
+  Fe<FP> ginv = Fe<FP>::two_adic_generator(log_n).inv();
+  EF zh = x.pow(uint64_t(1) << log_n) - EF::one();
+  Selectors<FP> s;
+  s.is_first = zh * (x - EF::one()).inv();
+  s.is_last = zh * (x - EF(ginv)).inv();
+  s.is_transition = x - EF(ginv);
+  s.inv_vanishing = zh.inv();
+  return s;
+}
+
+// One committed batch on the prover side.
+template <class FP>
+struct Committed {
+  std::vector<Matrix<FP>> ldes;  // bit-reversed LDEs
+  MerkleTree<FP> tree;
+  typename BatchProof<FP>::Cap cap;
+};
+template <class FP>
+Committed<FP> commit_ldes(const Poseidon2<FP>& p2, std::vector<Matrix<FP>> ldes, int cap_height) {
+  Committed<FP> c;
+  c.ldes = std::move(ldes);
+  std::vector<const Matrix<FP>*> ptrs;
+  for (auto& m : c.ldes) ptrs.push_back(&m);
+  c.tree = MerkleTree<FP>::commit(p2, ptrs, cap_height);
+  c.cap = c.tree.cap();
+  return c;
+}
+
+// Preprocessed commitment shared by every proof of a circuit shape
+// (ProverData::from_airs_and_degrees; recursion/src/recursion.rs:376).
+template <class FP>
+struct ProverData {
+  Committed<FP> prep;
+};
+template <class FP>
+ProverData<FP> make_prover_data(const Poseidon2<FP>& p2, const StarkParams& sp,
+                                const std::vector<Instance<FP>>& insts) {
+  std::vector<Matrix<FP>> ldes;
+  for (auto& in : insts) ldes.push_back(coset_lde_bitrev<FP>(in.prep, sp.log_blowup, Fe<FP>::generator()));
+  return {commit_ldes<FP>(p2, std::move(ldes), sp.cap_height)};
+}
+
+// ------------------------------------------------------------------ FRI
+template <class FP>
+struct FriInput {
+  int log_height;
+  std::vector<Fe4<FP>> ro;  // reduced openings in committed (bit-reversed) order
+};
+
+template <class FP>
+Fe4<FP> fold2(Fe4<FP> e0, Fe4<FP> e1, Fe4<FP> beta, Fe<FP> x0) {
+  // e0 + (beta - x0)(e1 - e0) * (-1/2)/x0   (fri/verifier.rs:562-577)
+  Fe<FP> inv = (-(Fe<FP>(2).inv())) * x0.inv();
+  return e0 + (beta - Fe4<FP>(x0)) * (e1 - e0) * inv;
+}
+// Fold one row of 2^la sibling evaluations (fri/verifier.rs:587-781): la sequential arity-2
+// folds with beta, beta^2, ...; `row` is the index of the folded element at the NEW height.
+template <class FP>
+Fe4<FP> fold_row(std::vector<Fe4<FP>> e, size_t row, int log_new_height, int la, Fe4<FP> beta) {
+  using F = Fe<FP>;
+  F ss = F::two_adic_generator(log_new_height + la).pow(bitrev((uint32_t)row, log_new_height));
+  F omega = F::two_adic_generator(la);
+  Fe4<FP> b = beta;
+  for (int step = 0; step < la; ++step) {
+    int log_dom = la - step;
+    F om_s = omega.pow(uint64_t(1) << step);
+    size_t pairs = e.size() / 2;
+    for (size_t j = 0; j < pairs; ++j) {
+      F x0 = ss * om_s.pow(bitrev((uint32_t)(2 * j), log_dom));
+      e[j] = fold2<FP>(e[2 * j], e[2 * j + 1], b, x0);
+    }
+    e.resize(pairs);
+    ss = ss * ss;
+    b = b * b;
+  }
+  return e[0];
+}
+// Arity schedule: fold as far as max_log_arity allows without skipping the next roll-in
+// height or the final height (upstream rule un-pinned).
+inline int choose_log_arity(int log_cur, int log_final, int max_log_arity, int log_next_input) {
+  int la = std::min(max_log_arity, log_cur - log_final);
+  if (log_next_input >= 0 && log_next_input < log_cur) la = std::min(la, log_cur - log_next_input);
+  return std::max(la, 1);
+}
+
+template <class FP>
+struct FriProverState {
+  std::vector<Matrix<FP>> leaves;  // per phase: rows x (arity*4)
+  std::vector<MerkleTree<FP>> trees;
+  std::vector<int> log_arities;
+};
+
+template <class FP>
+void fri_commit_phase(const Poseidon2<FP>& p2, const StarkParams& sp, std::vector<FriInput<FP>> inputs,
+                      Challenger<FP>& ch, FriProof<FP>& proof, FriProverState<FP>& st) {
+  using EF = Fe4<FP>;
+  using F = Fe<FP>;
+  std::sort(inputs.begin(), inputs.end(), [](auto& a, auto& b) { return a.log_height > b.log_height; });
+  const int log_final = sp.log_final_poly_len + sp.log_blowup;
+  std::vector<EF> folded = inputs[0].ro;
+  size_t next = 1;
+  int log_cur = inputs[0].log_height;
+  while (log_cur > log_final) {
+    int log_next = next < inputs.size() ? inputs[next].log_height : -1;
+    int la = choose_log_arity(log_cur, log_final, sp.max_log_arity, log_next);
+    size_t arity = size_t(1) << la, rows = folded.size() >> la;
+    Matrix<FP> leaves(rows, arity * 4);
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t j = 0; j < arity; ++j)
+        for (int k = 0; k < 4; ++k) leaves.at(r, j * 4 + k) = folded[r * arity + j].c[k];
+    st.leaves.push_back(leaves);
+    std::vector<const Matrix<FP>*> ptr{&st.leaves.back()};
+    st.trees.push_back(MerkleTree<FP>::commit(p2, ptr, sp.cap_height));
+    // the tree keeps a pointer to the matrix: re-point it at the stored copy after push_back moves
+    st.log_arities.push_back(la);
+    auto cap = st.trees.back().cap();
+    proof.commit_phase_commits.push_back(cap);
+    for (auto& d : cap) ch.observe_arr(d);
+    proof.commit_pow_witnesses.push_back(ch.grind(sp.commit_pow_bits));
+    EF beta = ch.sample_ext();
+    std::vector<EF> nf(rows);
+    for (size_t r = 0; r < rows; ++r) {
+      std::vector<EF> e(folded.begin() + r * arity, folded.begin() + (r + 1) * arity);
+      nf[r] = fold_row<FP>(e, r, log_cur - la, la, beta);
+    }
+    log_cur -= la;
+    if (next < inputs.size() && inputs[next].log_height == log_cur) {
+      EF bp = beta.pow(arity);
+      for (size_t i = 0; i < rows; ++i) nf[i] += bp * inputs[next].ro[i];
+      ++next;
+    }
+    folded = nf;
+  }
+  if (next != inputs.size()) throw std::runtime_error("FRI: an input height was never rolled in");
+  // final polynomial: natural-order evaluations over the (unshifted) subgroup -> coefficients
+  size_t m = folded.size();
+  int lm = log2_strict(m);
+  std::vector<EF> nat(m);
+  for (size_t i = 0; i < m; ++i) nat[bitrev((uint32_t)i, lm)] = folded[i];
+  // inverse DFT coefficient-wise on the 4 base coordinates
+  std::vector<EF> coeffs(m);
+  for (int k = 0; k < 4; ++k) {
+    std::vector<F> col(m);
+    for (size_t i = 0; i < m; ++i) col[i] = nat[i].c[k];
+    auto cc = idft<FP>(col);
+    for (size_t i = 0; i < m; ++i) coeffs[i].c[k] = cc[i];
+  }
+  size_t flen = size_t(1) << sp.log_final_poly_len;
+  for (size_t i = flen; i < m; ++i)
+    if (!coeffs[i].is_zero()) throw std::runtime_error("FRI: final polynomial degree too high (constraints unsatisfied?)");
+  coeffs.resize(flen);
+  proof.final_poly = coeffs;
+  for (auto& c : coeffs) ch.observe_ext(c);
+  for (int la : st.log_arities) ch.observe(F((uint64_t)la));
+  proof.query_pow_witness = ch.grind(sp.query_pow_bits);
+}
+
+// ------------------------------------------------------------------ prove_batch
+template <class FP>
+struct AuxTrace {
+  Matrix<FP> flat;  // n x (aux_width*4)
+  Fe4<FP> terminal;
+};
+
+template <class FP>
+BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
+                           const std::vector<Instance<FP>>& insts, const ProverData<FP>& pd) {
+  using F = Fe<FP>;
+  using EF = Fe4<FP>;
+  const size_t ni = insts.size();
+  const F gen = F::generator();
+  BatchProof<FP> proof;
+  Challenger<FP> ch(&p2);
+  std::vector<int> log_n(ni);
+  std::vector<LookupLayout> layouts(ni);
+  for (size_t i = 0; i < ni; ++i) {
+    log_n[i] = log2_strict(insts[i].main.h);
+    if ((int)insts[i].main.w != air_width<FP>(insts[i].air)) throw std::runtime_error("main width mismatch");
+    if ((int)insts[i].prep.w != air_prep_width(insts[i].air) || insts[i].prep.h != insts[i].main.h)
+      throw std::runtime_error("preprocessed shape mismatch");
+    layouts[i] = lookup_layout<FP>(insts[i].air);
+    proof.degree_bits.push_back(log_n[i]);
+  }
+  // 1. commit main traces (one MMCS over all instances)
+  std::vector<Matrix<FP>> main_ldes;
+  for (auto& in : insts) main_ldes.push_back(coset_lde_bitrev<FP>(in.main, sp.log_blowup, gen));
+  auto main_c = commit_ldes<FP>(p2, std::move(main_ldes), sp.cap_height);
+  proof.main_commit = main_c.cap;
+  // 2. transcript head (batch_stark.rs:521-578)
+  ch.observe_base_as_ext(F((uint64_t)ni));
+  for (size_t i = 0; i < ni; ++i) {
+    ch.observe_base_as_ext(F((uint64_t)log_n[i]));  // ext degree bits (no ZK)
+    ch.observe_base_as_ext(F((uint64_t)log_n[i]));  // base degree bits
+    ch.observe_base_as_ext(F((uint64_t)insts[i].main.w));
+    ch.observe_base_as_ext(F(uint64_t(1) << layouts[i].log_quotient_chunks));
+  }
+  for (auto& d : proof.main_commit) ch.observe_arr(d);
+  // (public values: the circuit tables have none)
+  for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(F((uint64_t)insts[i].prep.w));
+  for (auto& d : pd.prep.cap) ch.observe_arr(d);
+  // 3. LogUp challenges, permutation traces
+  bool any_lookup = false;
+  for (auto& L : layouts) any_lookup |= !L.groups.empty();
+  LookupChallenges<FP> lc{};
+  if (any_lookup) lc = sample_lookup_challenges<FP>(ch);
+  std::vector<AuxTrace<FP>> aux(ni);
+  proof.has_terminal.assign(ni, false);
+  proof.lookup_terminals.assign(ni, EF::zero());
+  std::vector<int> perm_insts;
+  for (size_t i = 0; i < ni; ++i) {
+    const auto& L = layouts[i];
+    if (L.groups.empty()) continue;
+    const auto& in = insts[i];
+    const size_t n = in.main.h;
+    const int aw = L.aux_width();
+    aux[i].flat = Matrix<FP>(n, aw * 4);
+    EF run = EF::zero();
+    for (size_t r = 0; r < n; ++r) {
+      EvalCtx<FP, F> b;
+      size_t rn = (r + 1) % n;
+      b.local = &in.main.v[r * in.main.w]; b.next = &in.main.v[rn * in.main.w];
+      b.prep_local = &in.prep.v[r * in.prep.w]; b.prep_next = &in.prep.v[rn * in.prep.w];
+      b.record_constraints = false;
+      b.is_first = b.is_last = b.is_transition = F::zero();
+      eval_air<FP, F>(in.air, p2, b);
+      for (int k = 0; k < 4; ++k) aux[i].flat.at(r, k) = run.c[k];
+      for (size_t g = 0; g < L.groups.size(); ++g) {
+        EF f = EF::zero();
+        for (int m : L.groups[g]) {
+          const auto& it = b.interactions[m];
+          if (it.mult.v != 0) f += lookup_denom_f<FP>(lc, it.fields).inv() * it.mult;
+        }
+        for (int k = 0; k < 4; ++k) aux[i].flat.at(r, (g + 1) * 4 + k) = f.c[k];
+        run += f;
+      }
+    }
+    aux[i].terminal = run;
+    proof.has_terminal[i] = true;
+    proof.lookup_terminals[i] = run;
+    perm_insts.push_back((int)i);
+  }
+  Committed<FP> perm_c;
+  if (any_lookup) {
+    std::vector<Matrix<FP>> ldes;
+    for (int i : perm_insts) ldes.push_back(coset_lde_bitrev<FP>(aux[i].flat, sp.log_blowup, gen));
+    perm_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height);
+    proof.has_permutation = true;
+    proof.permutation_commit = perm_c.cap;
+    for (auto& d : perm_c.cap) ch.observe_arr(d);
+    for (size_t i = 0; i < ni; ++i)
+      if (proof.has_terminal[i]) ch.observe_ext(proof.lookup_terminals[i]);
+  }
+  // 4. constraint-folding challenge, quotients
+  EF alpha = ch.sample_ext();
+  std::vector<Matrix<FP>> q_chunk_evals;   // per (instance, chunk): n x 4 over its chunk coset
+  std::vector<F> q_chunk_shift;
+  std::vector<std::pair<int, int>> q_chunk_owner;
+  for (size_t i = 0; i < ni; ++i) {
+    const auto& in = insts[i];
+    const auto& L = layouts[i];
+    const int lq = L.log_quotient_chunks, C = 1 << lq;
+    const size_t n = in.main.h, qn = n << lq;
+    if (lq > sp.log_blowup) throw std::runtime_error("quotient domain larger than the LDE");
+    // evaluations on the quotient coset gen*<w_qn>, natural order = first qn rows of the
+    // bit-reversed LDE, un-reversed (Pcs::get_evaluations_on_domain)
+    auto on_q = [&](const Matrix<FP>& lde) {
+      Matrix<FP> head(qn, lde.w);
+      std::copy(lde.v.begin(), lde.v.begin() + qn * lde.w, head.v.begin());
+      return rows_bitrev<FP>(head);
+    };
+    Matrix<FP> mq = on_q(main_c.ldes[i]), pq = on_q(pd.prep.ldes[i]), aq;
+    int perm_pos = -1;
+    for (size_t k = 0; k < perm_insts.size(); ++k) if (perm_insts[k] == (int)i) perm_pos = (int)k;
+    if (perm_pos >= 0) aq = on_q(perm_c.ldes[perm_pos]);
+    Matrix<FP> qflat(qn, 4);
+    const F wq = F::two_adic_generator(log_n[i] + lq);
+    F x = gen;
+    const int aw = L.aux_width();
+    for (size_t r = 0; r < qn; ++r, x *= wq) {
+      size_t rn = (r + C) % qn;
+      EvalCtx<FP, F> b;
+      b.local = &mq.v[r * mq.w]; b.next = &mq.v[rn * mq.w];
+      b.prep_local = &pq.v[r * pq.w]; b.prep_next = &pq.v[rn * pq.w];
+      auto sel = selectors_at<FP>(log_n[i], EF(x));
+      b.is_first = sel.is_first.c[0]; b.is_last = sel.is_last.c[0]; b.is_transition = sel.is_transition.c[0];
+      eval_air<FP, F>(in.air, p2, b);
+      std::vector<EF> ext_cons;
+      if (aw) {
+        std::vector<EF> al(aw), an(aw), den, mul;
+        for (int c = 0; c < aw; ++c)
+          for (int k = 0; k < 4; ++k) { al[c].c[k] = aq.at(r, c * 4 + k); an[c].c[k] = aq.at(rn, c * 4 + k); }
+        for (auto& it : b.interactions) { den.push_back(lookup_denom_f<FP>(lc, it.fields)); mul.push_back(EF(it.mult)); }
+        logup_constraints<FP>(L, den, mul, al, an, sel.is_first, sel.is_last, sel.is_transition,
+                              proof.lookup_terminals[i], ext_cons);
+      }
+      EF acc = EF::zero();
+      for (auto& c : b.constraints) acc = acc * alpha + EF(c);
+      for (auto& c : ext_cons) acc = acc * alpha + c;
+      EF q = acc * sel.inv_vanishing;
+      for (int k = 0; k < 4; ++k) qflat.at(r, k) = q.c[k];
+    }
+    // split_evals: chunk c = rows c, c+C, ... ; split_domains: shift gen * wq^c
+    for (int c = 0; c < C; ++c) {
+      Matrix<FP> ce(n, 4);
+      for (size_t r = 0; r < n; ++r)
+        for (int k = 0; k < 4; ++k) ce.at(r, k) = qflat.at(r * C + c, k);
+      q_chunk_evals.push_back(ce);
+      q_chunk_shift.push_back(gen * wq.pow(c));
+      q_chunk_owner.emplace_back((int)i, c);
+    }
+  }
+  std::vector<Matrix<FP>> q_ldes;
+  for (size_t k = 0; k < q_chunk_evals.size(); ++k)
+    q_ldes.push_back(coset_lde_bitrev<FP>(q_chunk_evals[k], sp.log_blowup, gen * q_chunk_shift[k].inv()));
+  auto quot_c = commit_ldes<FP>(p2, std::move(q_ldes), sp.cap_height);
+  proof.quotient_commit = quot_c.cap;
+  for (auto& d : quot_c.cap) ch.observe_arr(d);
+  EF zeta = ch.sample_ext();
+
+  // 5. open (rounds: main, quotient, preprocessed, permutation); observe in round/matrix/point order
+  proof.opened.resize(ni);
+  struct OpenItem { int round, mat, log_h; EF z; std::vector<EF> vals; };
+  std::vector<OpenItem> items;  // in reduced-opening order
+  for (size_t i = 0; i < ni; ++i) {
+    EF zn = zeta * F::two_adic_generator(log_n[i]);
+    auto& ov = proof.opened[i];
+    ov.trace_local = open_matrix<FP>(insts[i].main, F::one(), zeta);
+    items.push_back({0, (int)i, log_n[i], zeta, ov.trace_local});
+    ov.has_trace_next = air_uses_next(insts[i].air);
+    if (ov.has_trace_next) {
+      ov.trace_next = open_matrix<FP>(insts[i].main, F::one(), zn);
+      items.push_back({0, (int)i, log_n[i], zn, ov.trace_next});
+    }
+  }
+  for (size_t k = 0; k < q_chunk_evals.size(); ++k) {
+    int i = q_chunk_owner[k].first;
+    auto v = open_matrix<FP>(q_chunk_evals[k], q_chunk_shift[k], zeta);
+    proof.opened[i].quotient_chunks.push_back(v);
+    items.push_back({1, (int)k, log_n[i], zeta, v});
+  }
+  for (size_t i = 0; i < ni; ++i) {
+    EF zn = zeta * F::two_adic_generator(log_n[i]);
+    auto& ov = proof.opened[i];
+    ov.preprocessed_local = open_matrix<FP>(insts[i].prep, F::one(), zeta);
+    ov.preprocessed_next = open_matrix<FP>(insts[i].prep, F::one(), zn);
+    items.push_back({2, (int)i, log_n[i], zeta, ov.preprocessed_local});
+    items.push_back({2, (int)i, log_n[i], zn, ov.preprocessed_next});
+  }
+  for (size_t k = 0; k < perm_insts.size(); ++k) {
+    int i = perm_insts[k];
+    EF zn = zeta * F::two_adic_generator(log_n[i]);
+    auto& ov = proof.opened[i];
+    ov.permutation_local = open_matrix<FP>(aux[i].flat, F::one(), zeta);
+    ov.permutation_next = open_matrix<FP>(aux[i].flat, F::one(), zn);
+    items.push_back({3, (int)k, log_n[i], zeta, ov.permutation_local});
+    items.push_back({3, (int)k, log_n[i], zn, ov.permutation_next});
+  }
+  for (auto& it : items) for (auto& v : it.vals) ch.observe_ext(v);
+
+  // 6. FRI: batching challenge, per-height reduced openings
+  EF fri_alpha = ch.sample_ext();
+  const Committed<FP>* rounds[4] = {&main_c, &quot_c, &pd.prep, &perm_c};
+  std::map<int, std::pair<EF, std::vector<EF>>> ros;  // log_height -> (alpha_pow, ro)
+  for (auto& it : items) {
+    const Matrix<FP>& lde = rounds[it.round]->ldes[it.mat];
+    int lh = it.log_h + sp.log_blowup;
+    auto& e = ros[lh];
+    if (e.second.empty()) { e.first = EF::one(); e.second.assign(lde.h, EF::zero()); }
+    const F wl = F::two_adic_generator(lh);
+    for (size_t r = 0; r < lde.h; ++r) {
+      F x = gen * wl.pow(bitrev((uint32_t)r, lh));
+      EF inv = (it.z - EF(x)).inv();
+      EF ap = e.first, acc = EF::zero();
+      for (size_t c = 0; c < lde.w; ++c) {
+        acc += ap * (it.vals[c] - EF(lde.at(r, c)));
+        ap *= fri_alpha;
+      }
+      e.second[r] += acc * inv;
+    }
+    e.first *= fri_alpha.pow(lde.w);
+  }
+  std::vector<FriInput<FP>> inputs;
+  for (auto& kv : ros) inputs.push_back({kv.first, kv.second.second});
+  FriProverState<FP> st;
+  st.leaves.reserve(64); st.trees.reserve(64);
+  fri_commit_phase<FP>(p2, sp, inputs, ch, proof.fri, st);
+  // the Merkle trees hold pointers into st.leaves (reserved above, so no reallocation)
+  int log_max = 0;
+  for (auto& in : inputs) log_max = std::max(log_max, in.log_height);
+  for (int q = 0; q < sp.num_queries; ++q) {
+    size_t index = ch.sample_bits(log_max);
+    QueryProof<FP> qp;
+    for (int r = 0; r < 4; ++r) {
+      if (r == 3 && !any_lookup) continue;
+      const auto& cm = *rounds[r];
+      BatchOpening<FP> bo;
+      size_t ridx = index >> (log_max - cm.tree.log_max_h);
+      cm.tree.open(ridx, bo.opened_values, bo.opening_proof);
+      qp.input_proof.push_back(bo);
+    }
+    size_t idx = index;
+    for (size_t p = 0; p < st.trees.size(); ++p) {
+      int la = st.log_arities[p];
+      size_t row = idx >> la, pos = idx & ((size_t(1) << la) - 1);
+      CommitPhaseStep<FP> step;
+      step.log_arity = (uint8_t)la;
+      for (size_t j = 0; j < (size_t(1) << la); ++j) {
+        if (j == pos) continue;
+        EF e;
+        for (int k = 0; k < 4; ++k) e.c[k] = st.leaves[p].at(row, j * 4 + k);
+        step.sibling_values.push_back(e);
+      }
+      std::vector<std::vector<F>> ov;
+      st.trees[p].open(row, ov, step.opening_proof);
+      qp.commit_phase_openings.push_back(step);
+      idx = row;
+    }
+    proof.fri.query_proofs.push_back(qp);
+  }
+  return proof;
+}
+
+// ------------------------------------------------------------------ verify_batch
+// Shape of one instance as the verifier knows it.
+struct InstanceShape {
+  AirDesc air;
+};
+
+template <class FP>
+void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vector<InstanceShape>& shapes,
+                  const typename BatchProof<FP>::Cap& prep_commit, const BatchProof<FP>& proof) {
+  using F = Fe<FP>;
+  using EF = Fe4<FP>;
+  auto fail = [](const std::string& m) { throw std::runtime_error("verify: " + m); };
+  const size_t ni = shapes.size();
+  if (proof.opened.size() != ni || proof.degree_bits.size() != ni) fail("instance count mismatch");
+  const F gen = F::generator();
+  std::vector<LookupLayout> layouts(ni);
+  std::vector<int> log_n(ni);
+  bool any_lookup = false;
+  for (size_t i = 0; i < ni; ++i) {
+    layouts[i] = lookup_layout<FP>(shapes[i].air);
+    log_n[i] = (int)proof.degree_bits[i];
+    any_lookup |= !layouts[i].groups.empty();
+    const auto& ov = proof.opened[i];
+    const int w = air_width<FP>(shapes[i].air), pw = air_prep_width(shapes[i].air);
+    if ((int)ov.trace_local.size() != w) fail("trace width");
+    if (ov.has_trace_next != air_uses_next(shapes[i].air)) fail("trace_next presence");
+    if (ov.has_trace_next && (int)ov.trace_next.size() != w) fail("trace_next width");
+    if ((int)ov.preprocessed_local.size() != pw || (int)ov.preprocessed_next.size() != pw) fail("prep width");
+    if ((int)ov.quotient_chunks.size() != (1 << layouts[i].log_quotient_chunks)) fail("chunk count");
+    for (auto& c : ov.quotient_chunks) if (c.size() != 4) fail("chunk width");
+    const size_t aflat = (size_t)layouts[i].aux_width() * 4;
+    if (ov.permutation_local.size() != aflat || ov.permutation_next.size() != aflat) fail("permutation width");
+    if (proof.has_terminal[i] != !layouts[i].groups.empty()) fail("terminal presence");
+  }
+  if (proof.has_permutation != any_lookup) fail("permutation commitment presence");
+  Challenger<FP> ch(&p2);
+  ch.observe_base_as_ext(F((uint64_t)ni));
+  for (size_t i = 0; i < ni; ++i) {
+    ch.observe_base_as_ext(F((uint64_t)log_n[i]));
+    ch.observe_base_as_ext(F((uint64_t)log_n[i]));
+    ch.observe_base_as_ext(F((uint64_t)air_width<FP>(shapes[i].air)));
+    ch.observe_base_as_ext(F(uint64_t(1) << layouts[i].log_quotient_chunks));
+  }
+  for (auto& d : proof.main_commit) ch.observe_arr(d);
+  for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(F((uint64_t)air_prep_width(shapes[i].air)));
+  for (auto& d : prep_commit) ch.observe_arr(d);
+  LookupChallenges<FP> lc{};
+  if (any_lookup) {
+    lc = sample_lookup_challenges<FP>(ch);
+    for (auto& d : proof.permutation_commit) ch.observe_arr(d);
+    for (size_t i = 0; i < ni; ++i) if (proof.has_terminal[i]) ch.observe_ext(proof.lookup_terminals[i]);
+  }
+  EF alpha = ch.sample_ext();
+  for (auto& d : proof.quotient_commit) ch.observe_arr(d);
+  EF zeta = ch.sample_ext();
+
+  // rounds: (commitment cap, matrices (log_height, points(z, values)))
+  struct MatOpen { int log_h; std::vector<std::pair<EF, const std::vector<EF>*>> pts; };
+  struct Round { const typename BatchProof<FP>::Cap* cap; std::vector<MatOpen> mats; };
+  std::vector<Round> rounds;
+  {
+    Round r{&proof.main_commit, {}};
+    for (size_t i = 0; i < ni; ++i) {
+      MatOpen m{log_n[i], {{zeta, &proof.opened[i].trace_local}}};
+      if (proof.opened[i].has_trace_next)
+        m.pts.push_back({zeta * F::two_adic_generator(log_n[i]), &proof.opened[i].trace_next});
+      r.mats.push_back(m);
+    }
+    rounds.push_back(r);
+  }
+  {
+    Round r{&proof.quotient_commit, {}};
+    for (size_t i = 0; i < ni; ++i)
+      for (auto& c : proof.opened[i].quotient_chunks) r.mats.push_back({log_n[i], {{zeta, &c}}});
+    rounds.push_back(r);
+  }
+  {
+    Round r{&prep_commit, {}};
+    for (size_t i = 0; i < ni; ++i) {
+      EF zn = zeta * F::two_adic_generator(log_n[i]);
+      r.mats.push_back({log_n[i], {{zeta, &proof.opened[i].preprocessed_local}, {zn, &proof.opened[i].preprocessed_next}}});
+    }
+    rounds.push_back(r);
+  }
+  if (any_lookup) {
+    Round r{&proof.permutation_commit, {}};
+    for (size_t i = 0; i < ni; ++i) {
+      if (proof.opened[i].permutation_local.empty()) continue;
+      EF zn = zeta * F::two_adic_generator(log_n[i]);
+      r.mats.push_back({log_n[i], {{zeta, &proof.opened[i].permutation_local}, {zn, &proof.opened[i].permutation_next}}});
+    }
+    rounds.push_back(r);
+  }
+  for (auto& r : rounds) for (auto& m : r.mats) for (auto& pt : m.pts) for (auto& v : *pt.second) ch.observe_ext(v);
+
+  // FRI challenges (fri/targets.rs:748-814)
+  const auto& fp = proof.fri;
+  EF fri_alpha = ch.sample_ext();
+  std::vector<int> log_arities;
+  if (!fp.query_proofs.empty())
+    for (auto& s : fp.query_proofs[0].commit_phase_openings) log_arities.push_back(s.log_arity);
+  if (fp.commit_phase_commits.size() != log_arities.size() || fp.commit_pow_witnesses.size() != log_arities.size())
+    fail("FRI phase count");
+  std::vector<EF> betas;
+  for (size_t p = 0; p < fp.commit_phase_commits.size(); ++p) {
+    for (auto& d : fp.commit_phase_commits[p]) ch.observe_arr(d);
+    if (!ch.check_witness(sp.commit_pow_bits, fp.commit_pow_witnesses[p])) fail("commit PoW");
+    betas.push_back(ch.sample_ext());
+  }
+  if (fp.final_poly.size() != (size_t(1) << sp.log_final_poly_len)) fail("final poly length");
+  for (auto& c : fp.final_poly) ch.observe_ext(c);
+  for (int la : log_arities) ch.observe(F((uint64_t)la));
+  if (!ch.check_witness(sp.query_pow_bits, fp.query_pow_witness)) fail("query PoW");
+  int total_red = 0;
+  for (int la : log_arities) total_red += la;
+  const int log_max = total_red + sp.log_final_poly_len + sp.log_blowup;
+  if ((int)fp.query_proofs.size() != sp.num_queries) fail("query count");
+
+  for (auto& qp : fp.query_proofs) {
+    size_t index = ch.sample_bits(log_max);
+    if (qp.input_proof.size() != rounds.size()) fail("input proof round count");
+    std::map<int, std::pair<EF, EF>> ro;  // log_height -> (alpha_pow, ro)
+    for (size_t r = 0; r < rounds.size(); ++r) {
+      const auto& rd = rounds[r];
+      const auto& bo = qp.input_proof[r];
+      if (bo.opened_values.size() != rd.mats.size()) fail("opened matrix count");
+      int batch_max = 0;
+      std::vector<std::pair<size_t, size_t>> dims;
+      for (size_t m = 0; m < rd.mats.size(); ++m) {
+        batch_max = std::max(batch_max, rd.mats[m].log_h + sp.log_blowup);
+        dims.emplace_back(size_t(1) << (rd.mats[m].log_h + sp.log_blowup), bo.opened_values[m].size());
+      }
+      size_t ridx = index >> (log_max - batch_max);
+      if (!MerkleTree<FP>::verify(p2, *rd.cap, sp.cap_height, dims, ridx, bo.opened_values, bo.opening_proof))
+        fail("input MMCS opening");
+      for (size_t m = 0; m < rd.mats.size(); ++m) {
+        int lh = rd.mats[m].log_h + sp.log_blowup;
+        // x = GENERATOR * g_lh^{rev(index >> (log_max - lh))}   (fri/verifier.rs:921-981)
+        size_t ih = index >> (log_max - lh);
+        F x = gen * F::two_adic_generator(lh).pow(bitrev((uint32_t)ih, lh));
+        auto it = ro.find(lh);
+        if (it == ro.end()) it = ro.emplace(lh, std::make_pair(EF::one(), EF::zero())).first;
+        for (auto& pt : rd.mats[m].pts) {
+          if (pt.second->size() != bo.opened_values[m].size()) fail("opened width vs point values");
+          EF inv = (pt.first - EF(x)).inv();
+          for (size_t c = 0; c < pt.second->size(); ++c) {
+            it->second.second += it->second.first * ((*pt.second)[c] - EF(bo.opened_values[m][c])) * inv;
+            it->second.first *= fri_alpha;
+          }
+        }
+      }
+    }
+    if (ro.count(sp.log_blowup) && !ro[sp.log_blowup].second.is_zero()) fail("height-1 reduced opening");
+    if (!ro.count(log_max)) fail("no reduced opening at the maximum height");
+    EF folded = ro[log_max].second;
+    size_t idx = index;
+    int log_cur = log_max;
+    if (qp.commit_phase_openings.size() != log_arities.size()) fail("commit phase opening count");
+    for (size_t p = 0; p < log_arities.size(); ++p) {
+      const auto& step = qp.commit_phase_openings[p];
+      int la = step.log_arity;
+      if (la != log_arities[p] || la < 1 || la > sp.max_log_arity) fail("log_arity");
+      size_t arity = size_t(1) << la, pos = idx & (arity - 1), row = idx >> la;
+      if (step.sibling_values.size() != arity - 1) fail("sibling count");
+      std::vector<EF> evals(arity);
+      size_t s = 0;
+      for (size_t j = 0; j < arity; ++j) evals[j] = (j == pos) ? folded : step.sibling_values[s++];
+      std::vector<F> flat;
+      for (auto& e : evals) for (auto c : e.c) flat.push_back(c);
+      std::vector<std::pair<size_t, size_t>> dims{{size_t(1) << (log_cur - la), arity * 4}};
+      if (!MerkleTree<FP>::verify(p2, fp.commit_phase_commits[p], sp.cap_height, dims, row, {flat}, step.opening_proof))
+        fail("commit-phase MMCS opening");
+      folded = fold_row<FP>(evals, row, log_cur - la, la, betas[p]);
+      log_cur -= la;
+      idx = row;
+      if (log_cur < log_max && ro.count(log_cur)) folded += betas[p].pow(arity) * ro[log_cur].second;
+    }
+    for (auto& kv : ro)
+      if (kv.first < log_cur && kv.first != sp.log_blowup) fail("reduced opening below the final height");
+    // final polynomial at g^{rev(idx)} of the final domain (fri/verifier.rs:887-915)
+    F xf = F::two_adic_generator(log_cur).pow(bitrev((uint32_t)idx, log_cur));
+    EF ev = EF::zero();
+    for (size_t i = fp.final_poly.size(); i-- > 0;) ev = ev * EF(xf) + fp.final_poly[i];
+    if (ev != folded) fail("final polynomial mismatch");
+  }
+
+  // per-AIR quotient identity (batch_stark.rs:886-1017) and terminal sum (:1019-1021)
+  EF tsum = EF::zero();
+  for (size_t i = 0; i < ni; ++i) {
+    const auto& L = layouts[i];
+    const auto& ov = proof.opened[i];
+    const int lq = L.log_quotient_chunks, C = 1 << lq;
+    // recompose quotient(zeta) from chunks (verifier/quotient.rs:60-140)
+    const F wq = F::two_adic_generator(log_n[i] + lq);
+    std::vector<F> shifts(C);
+    for (int c = 0; c < C; ++c) shifts[c] = gen * wq.pow(c);
+    auto zh_coset = [&](F shift, EF x) { return (x * shift.inv()).pow(uint64_t(1) << log_n[i]) - EF::one(); };
+    EF quotient = EF::zero();
+    for (int c = 0; c < C; ++c) {
+      EF zp = EF::one();
+      for (int j = 0; j < C; ++j) {
+        if (j == c) continue;
+        zp *= zh_coset(shifts[j], zeta) * zh_coset(shifts[j], EF(shifts[c])).inv();
+      }
+      EF val = EF::zero();
+      for (int e = 0; e < 4; ++e) {
+        EF basis = EF::zero();
+        basis.c[e] = F::one();
+        val += basis * ov.quotient_chunks[c][e];
+      }
+      quotient += zp * val;
+    }
+    auto sel = selectors_at<FP>(log_n[i], zeta);
+    EvalCtx<FP, EF> b;
+    std::vector<EF> zeros(ov.trace_local.size(), EF::zero());
+    b.local = ov.trace_local.data();
+    b.next = ov.has_trace_next ? ov.trace_next.data() : zeros.data();
+    b.prep_local = ov.preprocessed_local.data();
+    b.prep_next = ov.preprocessed_next.data();
+    b.is_first = sel.is_first; b.is_last = sel.is_last; b.is_transition = sel.is_transition;
+    eval_air<FP, EF>(shapes[i].air, p2, b);
+    std::vector<EF> ext_cons;
+    const int aw = L.aux_width();
+    if (aw) {
+      auto recompose = [&](const std::vector<EF>& flat) {
+        std::vector<EF> out(aw, EF::zero());
+        for (int c = 0; c < aw; ++c)
+          for (int e = 0; e < 4; ++e) {
+            EF basis = EF::zero();
+            basis.c[e] = F::one();
+            out[c] += basis * flat[c * 4 + e];
+          }
+        return out;
+      };
+      auto al = recompose(ov.permutation_local), an = recompose(ov.permutation_next);
+      std::vector<EF> den, mul;
+      for (auto& it : b.interactions) { den.push_back(lookup_denom_e<FP>(lc, it.fields)); mul.push_back(it.mult); }
+      logup_constraints<FP>(L, den, mul, al, an, sel.is_first, sel.is_last, sel.is_transition,
+                            proof.lookup_terminals[i], ext_cons);
+      tsum += proof.lookup_terminals[i];
+    }
+    EF acc = EF::zero();
+    for (auto& c : b.constraints) acc = acc * alpha + c;
+    for (auto& c : ext_cons) acc = acc * alpha + c;
+    if (acc * sel.inv_vanishing != quotient) fail("constraints do not match the quotient for instance " + std::to_string(i));
+  }
+  if (any_lookup && !tsum.is_zero()) fail("lookup terminals do not sum to zero");
+}
+
+}  // namespace orc

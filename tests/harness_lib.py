@@ -1,0 +1,55 @@
+"""ctypes view of the synthetic-workload generator (harness/libp3r_synth.so)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDIR = os.path.join(ROOT, "harness")
+LIB = os.path.join(HDIR, "libp3r_synth.so")
+FIELD_IDS = {"koala-bear": 0, "baby-bear": 1}
+u32p = C.POINTER(C.c_uint32)
+
+ARRAYS = ["const_values", "const_prep", "public_values", "public_prep", "alu_values", "alu_prep13",
+          "p2_inputs", "p2_flags", "p2_mmcs_index_sum", "p2_in_ctl", "p2_input_indices", "p2_out_ctl",
+          "p2_output_indices", "p2_mmcs_index_sum_idx", "recompose_values", "recompose_prep", "counts"]
+
+
+def build():
+    src = os.path.join(HDIR, "synth.cpp")
+    if os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(src):
+        return
+    subprocess.run(["make", "-C", HDIR], check=True, capture_output=True)
+
+
+def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None):
+    """Returns dict name -> np.uint32 array (see harness/synth.cpp)."""
+    build()
+    lib = C.CDLL(LIB)
+    lib.syn_generate.restype = C.c_void_p
+    lib.syn_generate.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, u32p]
+    lib.syn_error.restype = C.c_char_p
+    lib.syn_error.argtypes = [C.c_void_p]
+    lib.syn_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(u32p), C.POINTER(C.c_size_t)]
+    lib.syn_free.argtypes = [C.c_void_p]
+    if rc is None:
+        import oracle_lib
+        rc = oracle_lib.default_rc(field)
+    rc = np.ascontiguousarray(rc, dtype=np.uint32)
+    h = lib.syn_generate(FIELD_IDS[field], log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth,
+                         rc.ctypes.data_as(u32p))
+    try:
+        err = lib.syn_error(h)
+        if err:
+            raise RuntimeError("synth: " + err.decode())
+        out = {}
+        for name in ARRAYS:
+            p = u32p()
+            n = C.c_size_t()
+            if lib.syn_get(h, name.encode(), C.byref(p), C.byref(n)) != 0:
+                raise KeyError(name)
+            out[name] = np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+        return out
+    finally:
+        lib.syn_free(h)

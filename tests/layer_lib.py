@@ -1,0 +1,129 @@
+"""Oracle-side recursion layer: table building, prove_batch, verify_batch (ctypes)."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_lib
+
+u32p = C.POINTER(C.c_uint32)
+KINDS = ["const", "public", "alu", "poseidon2", "recompose"]
+
+
+class OrcWorkload(C.Structure):
+    _fields_ = [
+        ("n_const", C.c_size_t), ("const_values", u32p), ("const_prep", u32p),
+        ("n_public", C.c_size_t), ("public_values", u32p), ("public_prep", u32p),
+        ("n_alu", C.c_size_t), ("alu_values", u32p), ("alu_prep13", u32p),
+        ("n_p2", C.c_size_t), ("p2_inputs", u32p), ("p2_flags", u32p), ("p2_mmcs_index_sum", u32p),
+        ("p2_in_ctl", u32p), ("p2_input_indices", u32p), ("p2_out_ctl", u32p), ("p2_output_indices", u32p),
+        ("p2_mmcs_index_sum_idx", u32p),
+        ("n_recompose", C.c_size_t), ("recompose_values", u32p), ("recompose_prep", u32p),
+        ("public_lanes", C.c_uint32), ("alu_lanes", C.c_uint32), ("horner_packed_steps", C.c_uint32),
+        ("recompose_lanes", C.c_uint32), ("min_trace_height", C.c_uint32),
+    ]
+
+
+class OrcParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("log_blowup", "max_log_arity", "cap_height", "log_final_poly_len",
+                                          "commit_pow_bits", "query_pow_bits", "num_queries")]
+
+
+def params(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0,
+           query_pow_bits=15, num_queries=54):
+    return OrcParams(log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits,
+                     num_queries)
+
+
+def min_trace_height(p):
+    # TablePacking::with_fri_params (packing.rs:100-106)
+    return 1 << (p.log_final_poly_len + p.log_blowup + 1)
+
+
+def fill_workload(wl_struct, arrays, packing, keep):
+    def ptr(name):
+        a = np.ascontiguousarray(arrays[name], dtype=np.uint32)
+        keep.append(a)
+        return a.ctypes.data_as(u32p)
+    c = arrays["counts"]
+    wl_struct.n_const, wl_struct.n_public, wl_struct.n_alu, wl_struct.n_p2, wl_struct.n_recompose = (int(x) for x in c[:5])
+    for name in ("const_values", "const_prep", "public_values", "public_prep", "alu_values", "alu_prep13",
+                 "p2_inputs", "p2_flags", "p2_mmcs_index_sum", "p2_in_ctl", "p2_input_indices", "p2_out_ctl",
+                 "p2_output_indices", "p2_mmcs_index_sum_idx", "recompose_values", "recompose_prep"):
+        setattr(wl_struct, name, ptr(name))
+    wl_struct.public_lanes = packing.get("public_lanes", 1)
+    wl_struct.alu_lanes = packing.get("alu_lanes", 3)
+    wl_struct.horner_packed_steps = packing.get("horner_packed_steps", 4)
+    wl_struct.recompose_lanes = packing.get("recompose_lanes", 1)
+    wl_struct.min_trace_height = packing["min_trace_height"]
+
+
+class OracleLayer:
+    """The five table instances of one recursion layer + prover data, on the CPU oracle."""
+
+    def __init__(self, orc, field, arrays, prm, packing=None, rc=None):
+        self.orc, self.field, self.prm = orc, field, prm
+        lib = orc.lib
+        lib.orc_layer_build.restype = C.c_void_p
+        lib.orc_layer_build.argtypes = [C.c_int, u32p, C.POINTER(OrcWorkload)]
+        lib.orc_layer_free.argtypes = [C.c_void_p]
+        lib.orc_layer_num_tables.restype = C.c_size_t
+        lib.orc_layer_num_tables.argtypes = [C.c_void_p]
+        lib.orc_layer_table_info.argtypes = [C.c_void_p, C.c_size_t, u32p]
+        lib.orc_layer_get_matrix.argtypes = [C.c_void_p, C.c_size_t, C.c_int, u32p]
+        lib.orc_layer_prep_commit.argtypes = [C.c_void_p, C.POINTER(OrcParams), u32p]
+        lib.orc_layer_prove.argtypes = [C.c_void_p, C.POINTER(OrcParams), C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                        C.POINTER(C.c_size_t)]
+        lib.orc_bytes_free.argtypes = [C.POINTER(C.c_uint8)]
+        lib.orc_layer_verify.argtypes = [C.c_void_p, C.POINTER(OrcParams), u32p, C.POINTER(C.c_uint8), C.c_size_t,
+                                         C.c_int]
+        packing = dict(packing or {})
+        packing.setdefault("min_trace_height", min_trace_height(prm))
+        self.packing = packing
+        wl = OrcWorkload()
+        self._keep = []
+        fill_workload(wl, arrays, packing, self._keep)
+        self.rc = oracle_lib.default_rc(field) if rc is None else np.ascontiguousarray(rc, dtype=np.uint32)
+        self.h = lib.orc_layer_build(oracle_lib.FIELD_IDS[field], self.rc.ctypes.data_as(u32p), C.byref(wl))
+        if not self.h:
+            raise RuntimeError("oracle: " + lib.orc_last_error().decode())
+
+    def tables(self):
+        out = []
+        lib = self.orc.lib
+        for i in range(lib.orc_layer_num_tables(self.h)):
+            info = (C.c_uint32 * 6)()
+            self.orc._ck(lib.orc_layer_table_info(self.h, i, info))
+            kind, lanes, k, h, w, pw = (int(x) for x in info)
+            main = np.empty((h, w), dtype=np.uint32)
+            prep = np.empty((h, pw), dtype=np.uint32)
+            self.orc._ck(lib.orc_layer_get_matrix(self.h, i, 0, main.ctypes.data_as(u32p)))
+            self.orc._ck(lib.orc_layer_get_matrix(self.h, i, 1, prep.ctypes.data_as(u32p)))
+            out.append(dict(kind=KINDS[kind], kind_id=kind, lanes=lanes, horner_k=k, main=main, prep=prep))
+        return out
+
+    def prep_commit(self):
+        cap = np.empty((1 << self.prm.cap_height, 8), dtype=np.uint32)
+        self.orc._ck(self.orc.lib.orc_layer_prep_commit(self.h, C.byref(self.prm), cap.ctypes.data_as(u32p)))
+        return cap
+
+    def prove(self, field_encoding=0):
+        buf = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        self.orc._ck(self.orc.lib.orc_layer_prove(self.h, C.byref(self.prm), field_encoding, C.byref(buf), C.byref(n)))
+        try:
+            return bytes(C.string_at(buf, n.value))
+        finally:
+            self.orc.lib.orc_bytes_free(buf)
+
+    def verify(self, proof_bytes, prep_cap=None, field_encoding=0):
+        """Raises RuntimeError with the verifier's reason if the proof is rejected."""
+        cap = self.prep_commit() if prep_cap is None else np.ascontiguousarray(prep_cap, dtype=np.uint32)
+        b = (C.c_uint8 * len(proof_bytes)).from_buffer_copy(proof_bytes)
+        self.orc._ck(self.orc.lib.orc_layer_verify(self.h, C.byref(self.prm), cap.ctypes.data_as(u32p), b,
+                                                    len(proof_bytes), field_encoding))
+
+    def __del__(self):
+        try:
+            self.orc.lib.orc_layer_free(self.h)
+        except Exception:
+            pass
