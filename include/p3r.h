@@ -166,6 +166,50 @@ size_t p3r_tree_log_max_height(const p3r_tree* tree);
 size_t p3r_tree_total_width(const p3r_tree* tree);
 void p3r_tree_free(p3r_ctx* ctx, p3r_tree* tree);
 
+/* ---- batch-STARK proving (the chosen drop-in seam) ----
+ *
+ * p3r_prep_create  == ProverData::from_airs_and_degrees + CircuitProverData::new as called by
+ *                     build_next_layer_prep (recursion/src/recursion.rs:342-394): LDE and one
+ *                     global MMCS commitment of every AIR's preprocessed trace, kept in HBM.
+ * p3r_prove_batch  == p3_batch_stark::prove_batch(&config, &instances, &prover_data)
+ *                     (circuit-prover/src/batch_stark_prover.rs:1543-1595): takes the per-table
+ *                     main traces in instance order [Const, Public, Alu, dynamic...]
+ *                     (batch_stark_prover.rs:1493-1519) and writes the postcard bytes of
+ *                     BatchProof (recursion/src/types/proof.rs:403-409).
+ */
+enum { P3R_AIR_CONST = 0, P3R_AIR_PUBLIC = 1, P3R_AIR_ALU = 2, P3R_AIR_POSEIDON2 = 3, P3R_AIR_RECOMPOSE = 4 };
+
+/* One CircuitTableAir (circuit-prover/src/common.rs:90-100) of extension degree D = 4. */
+typedef struct p3r_air_desc {
+  uint32_t kind;                /* P3R_AIR_* */
+  uint32_t lanes;               /* TablePacking lanes of this table (packing.rs:10-27) */
+  uint32_t horner_packed_steps; /* ALU only: TablePacking::horner_packed_steps, 2..8 */
+  uint32_t coeff_lookups;       /* Recompose only: challenger.d() != D (backend/fri.rs:693-721) */
+} p3r_air_desc;
+
+typedef struct p3r_prep p3r_prep;
+
+/* prep_mats[i] = BaseAir::preprocessed_trace() of instance i (row-major, padded height).
+ * commit_out receives the global preprocessed commitment (8 << cap_height elements). */
+p3r_prep* p3r_prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, const p3r_matrix* prep_mats,
+                          size_t n_instances, uint32_t* commit_out);
+void p3r_prep_free(p3r_ctx* ctx, p3r_prep* prep);
+
+#define P3R_PROVE_CANONICAL_FIELD_ENCODING 1u /* flags: write canonical u32 instead of the
+                                               * Montgomery word p3-monty-31's serde emits */
+
+/* Main traces resident in HBM (n_instances device matrices, instance order). On success
+ * *proof_len bytes of proof_buf hold the serialized BatchProof; P3R_EBUFFER reports the
+ * needed size through *proof_len. P3R_EINVAL with "do not satisfy the constraints" is the
+ * counterpart of prove_batch's internal-inconsistency panic. */
+int p3r_prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* main_traces,
+                    size_t n_instances, uint32_t flags, uint8_t* proof_buf, size_t proof_cap,
+                    size_t* proof_len);
+/* Same from host matrices (row-major canonical). */
+int p3r_prove_batch_host(p3r_ctx* ctx, const p3r_prep* prep, const p3r_matrix* main_traces,
+                         size_t n_instances, uint32_t flags, uint8_t* proof_buf, size_t proof_cap,
+                         size_t* proof_len);
+
 /* ---- measurement support (bench.py): run `iters` back-to-back launches of one kernel
  * family on resident data and return the mean per-launch time measured with HIP events
  * on the ctx's own stream. ---- */

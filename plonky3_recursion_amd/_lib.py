@@ -46,6 +46,11 @@ class P3rMatrix(C.Structure):
     _fields_ = [("values", C.POINTER(C.c_uint32)), ("height", C.c_size_t), ("width", C.c_size_t)]
 
 
+class P3rAirDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("lanes", C.c_uint32), ("horner_packed_steps", C.c_uint32),
+                ("coeff_lookups", C.c_uint32)]
+
+
 class P3rProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_uint64)]
 
@@ -83,6 +88,12 @@ SIGNATURES = {
     "p3r_tree_log_max_height": (C.c_size_t, [vp]),
     "p3r_tree_total_width": (C.c_size_t, [vp]),
     "p3r_tree_free": (None, [vp, vp]),
+    "p3r_prep_create": (vp, [vp, C.POINTER(P3rAirDesc), C.POINTER(P3rMatrix), C.c_size_t, u32p]),
+    "p3r_prep_free": (None, [vp, vp]),
+    "p3r_prove_batch": (C.c_int, [vp, vp, C.POINTER(vp), C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t,
+                                  C.POINTER(C.c_size_t)]),
+    "p3r_prove_batch_host": (C.c_int, [vp, vp, C.POINTER(P3rMatrix), C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8),
+                                       C.c_size_t, C.POINTER(C.c_size_t)]),
     "p3r_time_permute_dmat": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_double)]),
     "p3r_profile_enable": (C.c_int, [vp, C.c_int]),
     "p3r_profile_read": (C.c_int, [vp, C.POINTER(P3rProfileEntry), C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -1,0 +1,165 @@
+// Host-side serial pieces of the prover: DuplexChallenger, LogUp lookup layout, postcard writer.
+// They are tiny and strictly sequential in the reference too.
+//
+//   DuplexChallenger<F, Perm, 16, 8> + 0.6 prefix-free padding
+//        recursion/src/challenger/circuit.rs:97-156 (duplexing), :337-364 (observe / sample),
+//        :366-386 (extension elements), :388-430 (sample_bits, PoW check)
+//   lookup packing budget      circuit-prover/src/batch_stark_prover.rs:925-941
+//   proof field order          recursion/src/types/proof.rs:403-409,452-457,527-534,585-589,
+//                              recursion/src/pcs/fri/targets.rs:104-110
+#pragma once
+#include <vector>
+
+#include "air_device.cuh"
+#include "context.h"
+
+namespace p3r {
+
+template <class PP>
+struct HostChallenger {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const uint32_t* rc;  // Montgomery
+  F state[P2_WIDTH];
+  std::vector<F> in_buf, out_buf;
+  explicit HostChallenger(const uint32_t* rc_) : rc(rc_) {
+    for (auto& s : state) s = F::zero();
+  }
+  void duplexing() {
+    size_t n = in_buf.size();
+    for (size_t i = 0; i < n; ++i) state[i] = in_buf[i];
+    in_buf.clear();
+    if (n > 0) {
+      for (size_t i = n; i < (size_t)P2_RATE; ++i) state[i] = F::zero();
+      state[P2_RATE] += F::from_canonical((uint32_t)n);
+    }
+    p2_permute<PP>(state, rc);
+    out_buf.assign(state, state + P2_RATE);
+  }
+  void observe(F x) {
+    out_buf.clear();
+    in_buf.push_back(x);
+    if (in_buf.size() == (size_t)P2_RATE) duplexing();
+  }
+  void observe_ext(const E& e) { for (int i = 0; i < 4; ++i) observe(e.c[i]); }
+  void observe_base_as_ext(uint64_t v) { observe_ext(E::from_base(F::from_u64(v))); }
+  void observe_digest_canonical(const uint32_t* d) { for (int i = 0; i < P2_DIGEST; ++i) observe(F::from_canonical(d[i])); }
+  F sample() {
+    if (!in_buf.empty() || out_buf.empty()) duplexing();
+    F x = out_buf.back();
+    out_buf.pop_back();
+    return x;
+  }
+  E sample_ext() {
+    E e;
+    for (int i = 0; i < 4; ++i) e.c[i] = sample();
+    return e;
+  }
+  uint32_t sample_bits(int bits) { return sample().to_canonical() & ((1u << bits) - 1); }
+  bool check_witness(int bits, F w) {
+    if (bits == 0) return true;
+    observe(w);
+    return sample_bits(bits) == 0;
+  }
+};
+
+// ---- lookup layout (same rule as DESIGN.md "LogUp"): greedy same-bus packing under the
+// degree budget 2^log_chunks + 1.
+inline std::vector<int> interaction_mult_degrees(const AirParams& a) {
+  std::vector<int> d;
+  switch (a.kind) {
+    case AIR_CONST: d = {1}; break;
+    case AIR_PUBLIC: d.assign(a.lanes, 1); break;
+    case AIR_RECOMPOSE: d.assign(a.lanes * (1 + (a.coeff_lookups ? 4 : 0)), 1); break;
+    case AIR_ALU:
+      for (int l = 0; l < a.lanes; ++l) { d.push_back(2); d.push_back(1); d.push_back(2); d.push_back(1); }
+      for (int t = 1; t < a.horner_k; ++t) { d.push_back(1); d.push_back(1); }
+      break;
+    case AIR_POSEIDON2: d = {2, 2, 2, 2, 1, 1, 2}; break;
+  }
+  return d;
+}
+struct LookupLayout {
+  int n_interactions = 0, n_groups = 0, pair = 0, log_chunks = 0;
+  int aux_width() const { return n_groups ? n_groups + 1 : 0; }
+};
+inline LookupLayout lookup_layout(const AirParams& a) {
+  auto md = interaction_mult_degrees(a);
+  auto gdeg = [&](int first, int K) {
+    int deg = 1 + K;
+    for (int k = 0; k < K; ++k) deg = std::max(deg, md[first + k] + K - 1);
+    return deg;
+  };
+  int max_deg = 2;
+  if (a.kind == AIR_ALU || a.kind == AIR_POSEIDON2) max_deg = 3;
+  for (size_t i = 0; i < md.size(); ++i) max_deg = std::max(max_deg, gdeg((int)i, 1));
+  LookupLayout L;
+  L.n_interactions = (int)md.size();
+  while ((1 << L.log_chunks) < max_deg - 1) ++L.log_chunks;
+  const int budget = (1 << L.log_chunks) + 1;
+  // greedy packing; the device kernels support the two shapes it produces for these AIRs
+  std::vector<int> sizes;
+  int first = 0, K = 0;
+  for (int i = 0; i < (int)md.size(); ++i) {
+    if (K > 0 && gdeg(first, K + 1) > budget) { sizes.push_back(K); first = i; K = 1; }
+    else { if (K == 0) first = i; ++K; }
+  }
+  if (K) sizes.push_back(K);
+  L.n_groups = (int)sizes.size();
+  bool all1 = true, pairs = true;
+  for (size_t g = 0; g < sizes.size(); ++g) {
+    all1 = all1 && sizes[g] == 1;
+    pairs = pairs && (sizes[g] == 2 || (g + 1 == sizes.size() && sizes[g] == 1));
+  }
+  if (all1) L.pair = 0;
+  else if (pairs) L.pair = 1;
+  else fail(P3R_EUNSUPPORTED, "lookup packing shape not supported by the device kernels");
+  return L;
+}
+
+inline int air_width_of(const AirParams& a, int p2_width) {
+  switch (a.kind) {
+    case AIR_CONST: return 4;
+    case AIR_PUBLIC: return a.lanes * 4;
+    case AIR_ALU: return a.lanes * 16 + ((a.horner_k - 1) / 2 + 2 * (a.horner_k - 1) + 1) * 4;
+    case AIR_POSEIDON2: return p2_width;
+    case AIR_RECOMPOSE: return a.lanes * 4;
+  }
+  return 0;
+}
+inline int air_prep_width_of(const AirParams& a) {
+  switch (a.kind) {
+    case AIR_CONST: return 2;
+    case AIR_PUBLIC: return a.lanes * 2;
+    case AIR_ALU: return a.lanes * 13 + 7 * (a.horner_k - 1);
+    case AIR_POSEIDON2: return 24;
+    case AIR_RECOMPOSE: return a.lanes * (2 + (a.coeff_lookups ? 8 : 0));
+  }
+  return 0;
+}
+inline bool air_uses_next(const AirParams& a) { return a.kind == AIR_ALU || a.kind == AIR_POSEIDON2; }
+
+// ---- postcard writer. Field elements are written as the Montgomery word by default
+// (p3-monty-31's serde form), or canonical when `canonical` is set.
+template <class PP>
+struct ProofWriter {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  std::vector<uint8_t> out;
+  bool canonical = false;
+  void byte(uint8_t b) { out.push_back(b); }
+  void varint(uint64_t v) {
+    while (v >= 0x80) { out.push_back((uint8_t)(v | 0x80)); v >>= 7; }
+    out.push_back((uint8_t)v);
+  }
+  void fe(F x) { varint(canonical ? x.to_canonical() : x.v); }
+  void ef(const E& e) { for (int i = 0; i < 4; ++i) fe(e.c[i]); }
+  void vec_ef(const std::vector<E>& v) { varint(v.size()); for (auto& e : v) ef(e); }
+  void digest_mont(const uint32_t* d) { for (int i = 0; i < P2_DIGEST; ++i) fe(F::raw(d[i])); }
+  void cap_mont(const std::vector<uint32_t>& cap) {
+    varint(cap.size() / P2_DIGEST);
+    for (size_t i = 0; i < cap.size(); i += P2_DIGEST) digest_mont(&cap[i]);
+  }
+};
+
+}  // namespace p3r

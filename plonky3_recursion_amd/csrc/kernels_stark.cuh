@@ -1,0 +1,539 @@
+// gfx950 kernels for the proving stages after the main-trace commit:
+//   K7  LogUp auxiliary (permutation) trace       k_logup_aux, k_ef_scan
+//   K8  quotient evaluation                        k_quotient
+//   K9  openings at zeta / zeta*g                   k_bary_weights, k_open_dot, k_open_reduce
+//   K10 FRI reduced openings, folds, grinding       k_fri_reduce, k_fri_fold, k_grind
+//   query answers                                   k_gather
+// Protocol anchors are listed in p3r_prove.hip next to the host code that sequences them.
+#pragma once
+#include "air_device.cuh"
+#include "kernels.cuh"
+
+namespace p3r {
+
+// Extension elements travel to kernels by value as 4 Montgomery words.
+struct E4 {
+  uint32_t c[4];
+};
+template <class PP>
+__host__ __device__ __forceinline__ Fp4<PP> e4_load(const E4& e) {
+  Fp4<PP> r;
+  for (int i = 0; i < 4; ++i) r.c[i] = Fp<PP>::raw(e.c[i]);
+  return r;
+}
+template <class PP>
+__host__ __device__ __forceinline__ E4 e4_store(const Fp4<PP>& e) {
+  E4 r;
+  for (int i = 0; i < 4; ++i) r.c[i] = e.c[i].v;
+  return r;
+}
+
+// LogUp challenges: denominator = prefix + sum_j beta^j * field_j, tuple = (idx, v0..v3)
+// (recursion/src/verifier/batch_stark.rs:1086-1100).
+struct LookupCh {
+  E4 prefix;
+  E4 beta_pow[5];
+};
+template <class PP>
+__device__ __forceinline__ Fp4<PP> lookup_denom(const LookupCh& lc, Fp<PP> idx, const V4<Fp<PP>>& v) {
+  Fp4<PP> d = e4_load<PP>(lc.prefix) + e4_load<PP>(lc.beta_pow[0]) * idx;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) d += e4_load<PP>(lc.beta_pow[j + 1]) * v.c[j];
+  return d;
+}
+
+// ------------------------------------------------------------------ K7: aux trace
+// One lane per trace row: fraction columns f_g = sum_{k in g} m_k / d_k for each packed
+// lookup group (groups are consecutive pairs when `pair` else singletons - the host checks
+// that the packing computed from the degree budget has this shape), plus the row total.
+template <class PP>
+struct AuxSink {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const LookupCh& lc;
+  uint32_t* aux;  // [4*aw][n]
+  size_t n, row;
+  int pair;
+  int cnt = 0;
+  E cur, total;
+  __device__ AuxSink(const LookupCh& l, uint32_t* a, size_t n_, size_t r, int p)
+      : lc(l), aux(a), n(n_), row(r), pair(p), cur(E::zero()), total(E::zero()) {}
+  __device__ __forceinline__ void flush() {
+    int g = pair ? (cnt - 1) / 2 : cnt - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aux[(size_t)((g + 1) * 4 + k) * n + row] = cur.c[k].v;
+    total += cur;
+    cur = E::zero();
+  }
+  __device__ __forceinline__ void add(F idx, const V4<F>& v, F mult) {
+    if (mult.v != 0) cur += lookup_denom<PP>(lc, idx, v).inv() * mult;
+    ++cnt;
+    if (!pair || (cnt & 1) == 0) flush();
+  }
+  __device__ __forceinline__ void finish() {
+    if (pair && (cnt & 1)) flush();
+  }
+};
+
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_logup_aux(AirParams air, const uint32_t* __restrict__ main, const uint32_t* __restrict__ prep, size_t n,
+            LookupCh lc, int pair, uint32_t* __restrict__ aux, uint32_t* __restrict__ rowsum /* [4][n] */) {
+  size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n) return;
+  RowView<PP> v{main, prep, n, r, r + 1 == n ? 0 : r + 1};
+  AuxSink<PP> sink(lc, aux, n, r, pair);
+  air_interactions<PP>(air, v, sink);
+  sink.finish();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rowsum[(size_t)k * n + r] = sink.total.c[k].v;
+}
+
+// Exclusive prefix sum of extension elements (running LogUp sum, aux column 0).
+// mode 0: block totals -> agg; mode 1: exclusive scan of agg (one block), grand total -> total;
+// mode 2: write exclusive prefixes.
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_ef_scan(int mode, size_t n, const uint32_t* __restrict__ in /* [4][n] */, uint32_t* __restrict__ agg,
+          size_t n_blocks, uint32_t* __restrict__ out /* [4][n] planes, stride n */,
+          uint32_t* __restrict__ total) {
+  using E = Fp4<PP>;
+  using F = Fp<PP>;
+  __shared__ uint32_t sh[4][kBlock];
+  const int tid = threadIdx.x;
+  E loc[kScanItems];
+  E run = E::zero();
+  if (mode == 1) {
+    size_t per = (n_blocks + kBlock - 1) / kBlock;
+    size_t lo = (size_t)tid * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    for (size_t j = lo; j < hi; ++j) {
+      E m;
+      for (int k = 0; k < 4; ++k) m.c[k] = F::raw(agg[4 * j + k]);
+      run += m;
+    }
+  } else {
+    size_t base = (size_t)blockIdx.x * kScanTile + (size_t)tid * kScanItems;
+#pragma unroll
+    for (int q = 0; q < kScanItems; ++q) {
+      size_t i = base + q;
+      loc[q] = E::zero();
+      if (i < n)
+        for (int k = 0; k < 4; ++k) loc[q].c[k] = F::raw(in[(size_t)k * n + i]);
+      run += loc[q];
+    }
+  }
+  for (int k = 0; k < 4; ++k) sh[k][tid] = run.c[k].v;
+  __syncthreads();
+  for (int off = 1; off < kBlock; off <<= 1) {
+    E prev = E::zero(), cur;
+    bool has = tid >= off;
+    for (int k = 0; k < 4; ++k) {
+      if (has) prev.c[k] = F::raw(sh[k][tid - off]);
+      cur.c[k] = F::raw(sh[k][tid]);
+    }
+    __syncthreads();
+    if (has) {
+      cur += prev;
+      for (int k = 0; k < 4; ++k) sh[k][tid] = cur.c[k].v;
+    }
+    __syncthreads();
+  }
+  E excl = E::zero();
+  if (tid > 0)
+    for (int k = 0; k < 4; ++k) excl.c[k] = F::raw(sh[k][tid - 1]);
+  if (mode == 0) {
+    if (tid == kBlock - 1)
+      for (int k = 0; k < 4; ++k) agg[4 * (size_t)blockIdx.x + k] = sh[k][tid];
+  } else if (mode == 1) {
+    size_t per = (n_blocks + kBlock - 1) / kBlock;
+    size_t lo = (size_t)tid * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    E p = excl;
+    for (size_t j = lo; j < hi; ++j) {
+      E m;
+      for (int k = 0; k < 4; ++k) m.c[k] = F::raw(agg[4 * j + k]);
+      for (int k = 0; k < 4; ++k) agg[4 * j + k] = p.c[k].v;
+      p += m;
+    }
+    if (tid == kBlock - 1)
+      for (int k = 0; k < 4; ++k) total[k] = sh[k][tid];
+  } else {
+    E p;
+    for (int k = 0; k < 4; ++k) p.c[k] = F::raw(agg[4 * (size_t)blockIdx.x + k]);
+    p += excl;
+    size_t base = (size_t)blockIdx.x * kScanTile + (size_t)tid * kScanItems;
+#pragma unroll
+    for (int q = 0; q < kScanItems; ++q) {
+      size_t i = base + q;
+      if (i < n)
+        for (int k = 0; k < 4; ++k) out[(size_t)k * n + i] = p.c[k].v;
+      p += loc[q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K8: quotient
+struct QuotientArgs {
+  AirParams air;
+  const uint32_t* main;   // bit-reversed LDEs, height lde_h
+  const uint32_t* prep;
+  const uint32_t* aux;    // nullable
+  size_t lde_h;
+  int log_n;              // trace height
+  int log_chunks;         // log2 of quotient chunks C
+  const uint32_t* apow;   // alpha^(N-1-k) as 4 words each, k = 0..N-1 (base constraints first)
+  int n_base, n_groups, pair;
+  LookupCh lc;
+  E4 terminal;
+  uint32_t gen;           // coset shift (Montgomery)
+  uint32_t w_q;           // generator of the quotient domain (size n*C)
+  uint32_t g_inv;         // inverse trace-domain generator
+  uint32_t zh[4];         // Z_H on the C cosets:  gen^n * w_C^c - 1
+  uint32_t zh_inv[4];
+  const uint32_t* rc;
+  uint32_t* out;          // [C][4][n] chunk evaluations, natural order
+};
+
+template <class PP>
+struct BaseFold {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const uint32_t* apow;
+  int k = 0;
+  E acc;
+  __device__ BaseFold(const uint32_t* a) : apow(a), acc(E::zero()) {}
+  __device__ __forceinline__ E pw() {
+    E p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p.c[i] = F::raw(apow[4 * k + i]);
+    ++k;
+    return p;
+  }
+  __device__ __forceinline__ void base(F c) { acc += pw() * c; }
+  __device__ __forceinline__ void ext(const E& c) { acc += pw() * c; }
+};
+
+// Collects the LogUp group constraints:  f_g * prod d_k - sum_k m_k prod_{l!=k} d_l.
+template <class PP>
+struct QuotSink {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const QuotientArgs& q;
+  BaseFold<PP>& fold;
+  size_t row;
+  int cnt = 0;
+  E d0, sum_f;
+  F m0;
+  __device__ QuotSink(const QuotientArgs& q_, BaseFold<PP>& f, size_t r)
+      : q(q_), fold(f), row(r), d0(E::zero()), sum_f(E::zero()), m0(F::zero()) {}
+  __device__ __forceinline__ E aux_at(int col, size_t r) const {
+    E e;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.c[k] = F::raw(q.aux[(size_t)(col * 4 + k) * q.lde_h + r]);
+    return e;
+  }
+  __device__ __forceinline__ void add(F idx, const V4<F>& v, F mult) {
+    E d = lookup_denom<PP>(q.lc, idx, v);
+    ++cnt;
+    if (!q.pair) {
+      E f = aux_at(cnt, row);
+      fold.ext(f * d - E::from_base(mult));
+      sum_f += f;
+    } else if (cnt & 1) {
+      d0 = d;
+      m0 = mult;
+    } else {
+      E f = aux_at(cnt / 2, row);
+      fold.ext(f * d0 * d - (d * m0 + d0 * mult));
+      sum_f += f;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    if (q.pair && (cnt & 1)) {
+      E f = aux_at((cnt + 1) / 2, row);
+      fold.ext(f * d0 - E::from_base(m0));
+      sum_f += f;
+    }
+  }
+};
+
+template <class PP>
+__global__ void __launch_bounds__(kBlock) k_quotient(QuotientArgs q) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const int lq = q.log_n + q.log_chunks;
+  const size_t qn = size_t(1) << lq, C = size_t(1) << q.log_chunks;
+  size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;  // LDE row
+  if (j >= qn) return;
+  const uint32_t i = bit_reverse((uint32_t)j, lq);        // natural index on the quotient coset
+  const uint32_t i_next = (uint32_t)((i + C) & (qn - 1));
+  RowView<PP> v{q.main, q.prep, q.lde_h, j, bit_reverse(i_next, lq)};
+  const F x = F::raw(q.gen) * F::raw(q.w_q).pow(i);
+  const uint32_t c = i & (uint32_t)(C - 1);
+  const F zh = F::raw(q.zh[c]), g_inv = F::raw(q.g_inv);
+  const F is_transition = x - g_inv;
+  BaseFold<PP> fold(q.apow);
+  if (q.air.kind == AIR_ALU) alu_constraints<PP>(q.air, v, fold);
+  else if (q.air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, q.rc, fold);
+  if (q.aux) {
+    const F is_first = zh * (x - F::one()).inv();
+    const F is_last = zh * is_transition.inv();
+    QuotSink<PP> sink(q, fold, j);
+    air_interactions<PP>(q.air, v, sink);
+    sink.finish();
+    E s = sink.aux_at(0, j), s_next = sink.aux_at(0, v.nxt);
+    fold.ext(s * is_first);
+    fold.ext((s_next - s - sink.sum_f) * is_transition);
+    fold.ext((s + sink.sum_f - e4_load<PP>(q.terminal)) * is_last);
+  }
+  E quot = fold.acc * F::raw(q.zh_inv[c]);
+  const size_t n = size_t(1) << q.log_n, r = i >> q.log_chunks;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q.out[((size_t)c * 4 + k) * n + r] = quot.c[k].v;
+}
+
+// ------------------------------------------------------------------ K9: openings
+// Barycentric weights over the trace subgroup:  L_i(z) = w^i (z^n - 1) / (n (z - w^i)).
+// `scale` = (z^n - 1)/n is supplied by the host.
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_bary_weights(size_t n, uint32_t w_n, E4 z, E4 scale, uint32_t* __restrict__ out /* [4][n] */) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  F wi = F::raw(w_n).pow(i);
+  E r = (e4_load<PP>(z) - E::from_base(wi)).inv() * e4_load<PP>(scale) * wi;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[(size_t)k * n + i] = r.c[k].v;
+}
+
+constexpr int kOpenCols = 8;      // matrix columns sharing one pass over the weights
+constexpr int kOpenRows = 8192;   // rows per block
+// partial[p][chunk][col] = sum over the chunk's rows of weights_p[row] * M[col][row]
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_open_dot(const uint32_t* __restrict__ mat, size_t n, int w, const uint32_t* __restrict__ wt0,
+           const uint32_t* __restrict__ wt1, uint32_t* __restrict__ partial, int n_chunks) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  __shared__ uint32_t sh[kBlock][4];
+  const int c0 = blockIdx.x * kOpenCols, chunk = blockIdx.y;
+  const int P = wt1 ? 2 : 1;
+  size_t r0 = (size_t)chunk * kOpenRows, r1 = r0 + kOpenRows < n ? r0 + kOpenRows : n;
+  E acc[2][kOpenCols];
+  for (int p = 0; p < 2; ++p)
+    for (int c = 0; c < kOpenCols; ++c) acc[p][c] = E::zero();
+  for (size_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
+    E wa, wb = E::zero();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wa.c[k] = F::raw(wt0[(size_t)k * n + r]);
+    if (P == 2)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wb.c[k] = F::raw(wt1[(size_t)k * n + r]);
+#pragma unroll
+    for (int c = 0; c < kOpenCols; ++c) {
+      if (c0 + c < w) {
+        F m = F::raw(mat[(size_t)(c0 + c) * n + r]);
+        acc[0][c] += wa * m;
+        if (P == 2) acc[1][c] += wb * m;
+      }
+    }
+  }
+  for (int p = 0; p < P; ++p)
+    for (int c = 0; c < kOpenCols; ++c) {
+      if (c0 + c >= w) break;
+      for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] = acc[p][c].c[k].v;
+      __syncthreads();
+      for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+          for (int k = 0; k < 4; ++k)
+            sh[threadIdx.x][k] = (F::raw(sh[threadIdx.x][k]) + F::raw(sh[threadIdx.x + off][k])).v;
+        __syncthreads();
+      }
+      if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k)
+          partial[(((size_t)p * n_chunks + chunk) * w + c0 + c) * 4 + k] = sh[0][k];
+      __syncthreads();
+    }
+}
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_open_reduce(const uint32_t* __restrict__ partial, int P, int n_chunks, int w, uint32_t* __restrict__ out) {
+  using F = Fp<PP>;
+  int t = blockIdx.x * kBlock + threadIdx.x;  // over P*w*4 outputs
+  if (t >= P * w * 4) return;
+  int p = t / (w * 4), rem = t % (w * 4);
+  F s = F::zero();
+  for (int ch = 0; ch < n_chunks; ++ch) s += F::raw(partial[((size_t)p * n_chunks + ch) * w * 4 + rem]);
+  out[t] = s.v;
+}
+
+// ------------------------------------------------------------------ K10: FRI
+// ro[r] += sum_p off_p * (V_p - S[r]) / (z_p - x_r),  S[r] = sum_c alpha^c M[c][r],
+// x_r = gen * w^{bitrev(r)}   (recursion/src/pcs/fri/verifier.rs:1122-1345, :921-981)
+struct FriReduceArgs {
+  const uint32_t* mat;  // bit-reversed LDE [w][h]
+  size_t h;
+  int w, log_h;
+  const uint32_t* apow;  // alpha^c, 4 words each
+  int n_points;
+  E4 z[2], v[2], off[2];
+  uint32_t gen, w_h;
+  uint32_t* ro;          // [4][h], accumulated in place
+};
+template <class PP>
+__global__ void __launch_bounds__(kBlock) k_fri_reduce(FriReduceArgs a) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= a.h) return;
+  E S = E::zero();
+  for (int c = 0; c < a.w; ++c) {
+    E ap;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ap.c[k] = F::raw(a.apow[4 * c + k]);
+    S += ap * F::raw(a.mat[(size_t)c * a.h + r]);
+  }
+  F x = F::raw(a.gen) * F::raw(a.w_h).pow(bit_reverse((uint32_t)r, a.log_h));
+  E acc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc.c[k] = F::raw(a.ro[(size_t)k * a.h + r]);
+  for (int p = 0; p < a.n_points; ++p) {
+    E inv = (e4_load<PP>(a.z[p]) - E::from_base(x)).inv();
+    acc += e4_load<PP>(a.off[p]) * (e4_load<PP>(a.v[p]) - S) * inv;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a.ro[(size_t)k * a.h + r] = acc.c[k].v;
+}
+
+// One commit-phase fold of arity 2^la: la sequential arity-2 folds with beta, beta^2, ...
+// (recursion/src/pcs/fri/verifier.rs:562-781), then the roll-in  + beta^{2^la} * ro.
+struct FriFoldArgs {
+  const uint32_t* in;   // [4][rows << la]
+  uint32_t* out;        // [4][rows]
+  size_t rows;
+  int la, log_rows;
+  E4 beta, beta_pow;    // beta and beta^{2^la}
+  const uint32_t* roll; // nullable [4][rows]
+  uint32_t w_inv;       // inverse generator of the domain of size rows << la
+  uint32_t tw_inv[3][4];  // tw_inv[s][j] = (w_arity^{2^s})^{-bitrev(2j, la - s)}
+  uint32_t neg_half;
+};
+template <class PP>
+__global__ void __launch_bounds__(kBlock) k_fri_fold(FriFoldArgs a) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= a.rows) return;
+  const size_t n_in = a.rows << a.la;
+  E e[8];
+  const int arity = 1 << a.la;
+  for (int j = 0; j < arity; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[j].c[k] = F::raw(a.in[(size_t)k * n_in + (r << a.la) + j]);
+  F ss_inv = F::raw(a.w_inv).pow(bit_reverse((uint32_t)r, a.log_rows));
+  E b = e4_load<PP>(a.beta);
+  const F nh = F::raw(a.neg_half);
+  int len = arity;
+  for (int s = 0; s < a.la; ++s) {
+    for (int j = 0; j < len / 2; ++j) {
+      F x0_inv = ss_inv * F::raw(a.tw_inv[s][j]);
+      // e0 + (beta - x0)(e1 - e0)(-1/2)/x0  =  e0 + (beta/x0 - 1)(e1 - e0)(-1/2)
+      E t = b * x0_inv - E::one();
+      e[j] = e[2 * j] + t * (e[2 * j + 1] - e[2 * j]) * nh;
+    }
+    len /= 2;
+    ss_inv = ss_inv.sqr();
+    b = b.sqr();
+  }
+  E res = e[0];
+  if (a.roll) {
+    E ro;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ro.c[k] = F::raw(a.roll[(size_t)k * a.rows + r]);
+    res += e4_load<PP>(a.beta_pow) * ro;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a.out[(size_t)k * a.rows + r] = res.c[k].v;
+}
+
+// Leaf hashing for column sets that are strided views (FRI commit-phase leaves are the
+// rows of the `rows x (arity*4)` matrix laid over the folded vector).
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_mmcs_hash_rows_strided(const uint32_t* const* __restrict__ cols, int wtot, size_t h, size_t stride,
+                         uint32_t* __restrict__ dig, const uint32_t* __restrict__ rc) {
+  using F = Fp<PP>;
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= h) return;
+  F s[P2_WIDTH];
+#pragma unroll
+  for (int k = 0; k < P2_WIDTH; ++k) s[k] = F::zero();
+  int g = 0;
+  for (; g + P2_RATE <= wtot; g += P2_RATE) {
+#pragma unroll
+    for (int j = 0; j < P2_RATE; ++j) s[j] = F::raw(cols[g + j][i * stride]);
+    p2_permute<PP>(s, rc);
+  }
+  int rem = wtot - g;
+  if (rem > 0) {
+#pragma unroll
+    for (int j = 0; j < P2_RATE; ++j)
+      if (j < rem) s[j] = F::raw(cols[g + j][i * stride]);
+    p2_permute<PP>(s, rc);
+  }
+#pragma unroll
+  for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * h + i] = s[k].v;
+}
+
+// Proof-of-work grinding: candidate witness w = base + tid; smallest valid one wins
+// (check = low `bits` bits of the next sample are zero, recursion/src/challenger/circuit.rs:409-430).
+struct GrindArgs {
+  uint32_t state[16];   // sponge state before the witness is observed (Montgomery)
+  uint32_t pending[8];  // buffered, not yet absorbed inputs (Montgomery)
+  int n_pending;
+  int bits;
+  uint32_t base;
+  const uint32_t* rc;
+  uint32_t* result;     // atomicMin target, initialised to 0xFFFFFFFF
+};
+template <class PP>
+__global__ void __launch_bounds__(kBlock) k_grind(GrindArgs a) {
+  using F = Fp<PP>;
+  uint32_t cand = a.base + blockIdx.x * kBlock + threadIdx.x;
+  if (cand >= PP::P) return;
+  F s[P2_WIDTH];
+#pragma unroll
+  for (int k = 0; k < P2_WIDTH; ++k) s[k] = F::raw(a.state[k]);
+  const int n_abs = a.n_pending + 1;
+#pragma unroll
+  for (int k = 0; k < P2_RATE; ++k) {
+    if (k < a.n_pending) s[k] = F::raw(a.pending[k]);
+    else if (k == a.n_pending) s[k] = F::from_canonical(cand);
+    else s[k] = F::zero();
+  }
+  s[P2_RATE] += F::from_canonical((uint32_t)n_abs);
+  p2_permute<PP>(s, a.rc);
+  uint32_t sample = s[P2_RATE - 1].to_canonical();
+  if ((sample & ((1u << a.bits) - 1)) == 0) atomicMin(a.result, cand);
+}
+
+// Query answers: copy `count` strided cells into a contiguous staging buffer.
+struct GatherDesc {
+  const uint32_t* src;
+  uint64_t stride;
+  uint32_t count;
+  uint32_t dst;
+};
+template <class PP>
+__global__ void __launch_bounds__(64)
+k_gather(const GatherDesc* __restrict__ descs, uint32_t* __restrict__ out, int to_canonical) {
+  using F = Fp<PP>;
+  GatherDesc d = descs[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < d.count; i += 64) {
+    uint32_t v = d.src[(size_t)i * d.stride];
+    out[d.dst + i] = to_canonical ? F::raw(v).to_canonical() : v;
+  }
+}
+
+}  // namespace p3r

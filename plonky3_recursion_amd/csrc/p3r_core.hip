@@ -459,6 +459,8 @@ void init_ctx(p3r_ctx* ctx) {
 
 }  // namespace
 
+#include "prove_impl.cuh"
+
 // =============================================================================== C ABI
 extern "C" {
 
@@ -689,6 +691,63 @@ int p3r_time_permute_dmat(p3r_ctx* ctx, p3r_dmat* states, int iters, double* ms_
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     *ms_per_launch = (double)ms / iters;
+  });
+}
+
+p3r_prep* p3r_prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, const p3r_matrix* prep_mats,
+                          size_t n_instances, uint32_t* commit_out) {
+  p3r_prep* out = nullptr;
+  guard(ctx, [&] {
+    if (!airs || !prep_mats || !commit_out || n_instances == 0) fail(P3R_EINVAL, "bad arguments");
+    for (size_t i = 0; i < n_instances; ++i)
+      if (!prep_mats[i].values) fail(P3R_EINVAL, "preprocessed matrix %zu has NULL values", i);
+    auto prep = P3R_FIELD_CALL(ctx, prep_create, ctx, airs, prep_mats, n_instances);
+    std::copy(prep->cap_canonical.begin(), prep->cap_canonical.end(), commit_out);
+    out = prep.release();
+  });
+  return out;
+}
+void p3r_prep_free(p3r_ctx* ctx, p3r_prep* prep) {
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  delete prep;
+}
+
+static int emit_proof(std::vector<uint8_t>&& bytes, uint8_t* buf, size_t cap, size_t* len) {
+  *len = bytes.size();
+  if (bytes.size() > cap) fail(P3R_EBUFFER, "proof needs %zu bytes, buffer holds %zu", bytes.size(), cap);
+  memcpy(buf, bytes.data(), bytes.size());
+  return 0;
+}
+
+int p3r_prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* main_traces,
+                    size_t n_instances, uint32_t flags, uint8_t* proof_buf, size_t proof_cap,
+                    size_t* proof_len) {
+  return guard(ctx, [&] {
+    if (!prep || !main_traces || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
+    for (size_t i = 0; i < n_instances; ++i)
+      if (!main_traces[i]) fail(P3R_EINVAL, "main trace %zu is NULL", i);
+    auto bytes = P3R_FIELD_CALL(ctx, prove_batch, ctx, prep, main_traces, n_instances,
+                                (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
+    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+  });
+}
+
+int p3r_prove_batch_host(p3r_ctx* ctx, const p3r_prep* prep, const p3r_matrix* main_traces,
+                         size_t n_instances, uint32_t flags, uint8_t* proof_buf, size_t proof_cap,
+                         size_t* proof_len) {
+  return guard(ctx, [&] {
+    if (!prep || !main_traces || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
+    std::vector<std::unique_ptr<p3r_dmat>> owned;
+    std::vector<const p3r_dmat*> ptrs;
+    for (size_t i = 0; i < n_instances; ++i) {
+      if (!main_traces[i].values) fail(P3R_EINVAL, "main trace %zu has NULL values", i);
+      owned.push_back(P3R_FIELD_CALL(ctx, upload, ctx, main_traces[i].values, main_traces[i].height,
+                                     main_traces[i].width));
+      ptrs.push_back(owned.back().get());
+    }
+    auto bytes = P3R_FIELD_CALL(ctx, prove_batch, ctx, prep, ptrs.data(), n_instances,
+                                (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
+    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
   });
 }
 

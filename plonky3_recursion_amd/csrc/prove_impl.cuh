@@ -1,0 +1,665 @@
+// prove_batch on the GPU: the body the reference delegates to p3_batch_stark::prove_batch
+// (call site circuit-prover/src/batch_stark_prover.rs:1595).  Included into p3r_core.hip.
+//
+// Stage order and transcript are pinned by the in-tree circuit verifier:
+//   transcript head, commitments, challenges   recursion/src/verifier/batch_stark.rs:521-627
+//   rounds / opening points                     recursion/src/verifier/batch_stark.rs:645-852
+//   opened-value observation order              recursion/src/verifier/batch_stark.rs:1114-1276
+//   quotient domain / chunks                    recursion/src/verifier/batch_stark.rs:701-717,
+//                                               recursion/src/verifier/quotient.rs:60-140
+//   FRI challenges, arities, PoW, queries       recursion/src/pcs/fri/targets.rs:748-866
+//   reduced openings / folding / final poly     recursion/src/pcs/fri/verifier.rs:562-781,887-915,1068-1356
+// All matrices stay resident in HBM; only commitments, opened values, the final polynomial
+// and the query answers cross to the host.
+#include "host_transcript.h"
+#include "kernels_stark.cuh"
+
+struct p3r_prep {
+  std::vector<p3r::AirParams> airs;
+  std::vector<std::unique_ptr<p3r_dmat>> traces;  // preprocessed traces (K7 and openings read them)
+  std::vector<std::unique_ptr<p3r_dmat>> ldes;    // their bit-reversed LDEs (K8, FRI)
+  std::vector<size_t> heights;
+  std::unique_ptr<p3r_tree> tree;
+  std::vector<uint32_t> cap_canonical;
+};
+
+namespace {
+
+template <class PP>
+E4 to_e4(const Fp4<PP>& e) { return e4_store<PP>(e); }
+
+template <class PP>
+std::vector<Fp4<PP>> download_ef(p3r_ctx* ctx, const uint32_t* dev, size_t count) {
+  std::vector<uint32_t> raw(count * 4);
+  P3R_HIP(hipMemcpyAsync(raw.data(), dev, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  P3R_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<Fp4<PP>> out(count);
+  for (size_t i = 0; i < count; ++i)
+    for (int k = 0; k < 4; ++k) out[i].c[k] = Fp<PP>::raw(raw[i * 4 + k]);
+  return out;
+}
+
+// Open every column of `mat` (n x w evaluations over shift*<w_n>, natural order) at up to two
+// points; returns values [point][col].
+template <class PP>
+std::vector<std::vector<Fp4<PP>>> open_matrix(p3r_ctx* ctx, const uint32_t* mat, size_t n, int w,
+                                              Fp<PP> dshift, const std::vector<Fp4<PP>>& points) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const int log_n = log2_exact(n, "trace height");
+  const int P = (int)points.size();
+  DevBuf wts((size_t)P * 4 * n);
+  const F w_n = F::two_adic_generator(log_n);
+  const F n_inv = F::from_u64(n).inv();
+  for (int p = 0; p < P; ++p) {
+    E z = points[p] * dshift.inv();
+    E scale = (z.pow(n) - E::one()) * n_inv;
+    ProfScope ps(ctx, "open_weights");
+    hipLaunchKernelGGL(k_bary_weights<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, w_n.v,
+                       to_e4<PP>(z), to_e4<PP>(scale), wts.p + (size_t)p * 4 * n);
+  }
+  const int n_chunks = (int)((n + kOpenRows - 1) / kOpenRows);
+  DevBuf partial((size_t)P * n_chunks * w * 4), out((size_t)P * w * 4);
+  {
+    ProfScope ps(ctx, "open_dot");
+    dim3 grid((w + kOpenCols - 1) / kOpenCols, n_chunks);
+    hipLaunchKernelGGL(k_open_dot<PP>, grid, dim3(kBlock), 0, ctx->stream, mat, n, w, wts.p,
+                       P == 2 ? wts.p + 4 * n : (const uint32_t*)nullptr, partial.p, n_chunks);
+    hipLaunchKernelGGL(k_open_reduce<PP>, dim3(blocks_for((size_t)P * w * 4)), dim3(kBlock), 0, ctx->stream,
+                       partial.p, P, n_chunks, w, out.p);
+  }
+  P3R_HIP(hipGetLastError());
+  auto flat = download_ef<PP>(ctx, out.p, (size_t)P * w);
+  std::vector<std::vector<E>> res(P);
+  for (int p = 0; p < P; ++p) res[p].assign(flat.begin() + (size_t)p * w, flat.begin() + (size_t)(p + 1) * w);
+  return res;
+}
+
+// Merkle layers above a leaf-digest layer (no injections): used by the FRI commit phase.
+template <class PP>
+void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves) {
+  size_t n = n_leaves;
+  const size_t cap_n = size_t(1) << tree->cap_height;
+  while (n > cap_n) {
+    const size_t nn = n / 2;
+    DevBuf next(P2_DIGEST * nn);
+    const uint32_t* prev = tree->layers.back().p;
+    ProfScope ps(ctx, "mmcs_compress");
+    hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(nn)), dim3(kBlock), 0, ctx->stream, prev, n, 2, 0,
+                       prev, n, 2, 1, next.p, nn, ctx->rc.p);
+    tree->layers.push_back(std::move(next));
+    n = nn;
+  }
+  P3R_HIP(hipGetLastError());
+}
+
+template <class PP>
+std::vector<uint32_t> download_cap_mont(p3r_ctx* ctx, const p3r_tree* tree) {
+  const size_t cap_n = size_t(1) << tree->cap_height;
+  std::vector<uint32_t> soa(P2_DIGEST * cap_n), cap(P2_DIGEST * cap_n);
+  P3R_HIP(hipMemcpyAsync(soa.data(), tree->layers.back().p, soa.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  P3R_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t j = 0; j < cap_n; ++j)
+    for (int k = 0; k < P2_DIGEST; ++k) cap[j * P2_DIGEST + k] = soa[(size_t)k * cap_n + j];
+  return cap;
+}
+
+template <class PP>
+std::unique_ptr<p3r_tree> commit_dmats(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats,
+                                       std::vector<uint32_t>& cap_mont) {
+  auto tree = std::make_unique<p3r_tree>();
+  tree->mats = mats;
+  std::vector<uint32_t> cap_canon((size_t)P2_DIGEST << ctx->cfg.cap_height);
+  mmcs_commit<PP>(ctx, tree.get(), cap_canon.data());
+  cap_mont.resize(cap_canon.size());
+  for (size_t i = 0; i < cap_canon.size(); ++i) cap_mont[i] = Fp<PP>::from_canonical(cap_canon[i]).v;
+  return tree;
+}
+
+template <class PP>
+std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, const p3r_matrix* mats, size_t n) {
+  using F = Fp<PP>;
+  auto prep = std::make_unique<p3r_prep>();
+  std::vector<const p3r_dmat*> ptrs;
+  for (size_t i = 0; i < n; ++i) {
+    AirParams a{(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups};
+    if (a.kind < 0 || a.kind > AIR_RECOMPOSE) fail(P3R_EINVAL, "instance %zu: unknown AIR kind %d", i, a.kind);
+    if (a.lanes < 1) fail(P3R_EINVAL, "instance %zu: lanes must be positive", i);
+    if (a.kind == AIR_ALU && (a.horner_k < 2 || a.horner_k > 8))
+      fail(P3R_EINVAL, "instance %zu: horner_packed_steps must be in 2..8", i);
+    if ((int)mats[i].width != air_prep_width_of(a))
+      fail(P3R_EINVAL, "instance %zu: preprocessed width %zu, the AIR expects %d", i, mats[i].width,
+           air_prep_width_of(a));
+    (void)lookup_layout(a);
+    prep->airs.push_back(a);
+    prep->heights.push_back(mats[i].height);
+    auto m = upload<PP>(ctx, mats[i].values, mats[i].height, mats[i].width);
+    prep->ldes.push_back(coset_lde<PP>(ctx, m.get(), (int)ctx->cfg.log_blowup, PP::GEN));
+    prep->traces.push_back(std::move(m));
+    ptrs.push_back(prep->ldes.back().get());
+  }
+  std::vector<uint32_t> cap_mont;
+  prep->tree = commit_dmats<PP>(ctx, ptrs, cap_mont);
+  prep->cap_canonical.resize(cap_mont.size());
+  for (size_t i = 0; i < cap_mont.size(); ++i) prep->cap_canonical[i] = F::raw(cap_mont[i]).to_canonical();
+  return prep;
+}
+
+struct RoundTrees {
+  const p3r_tree* tree;
+};
+
+template <class PP>
+std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* mains, size_t ni,
+                                 bool canonical_encoding) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const p3r_config& cfg = ctx->cfg;
+  const int log_blowup = (int)cfg.log_blowup;
+  if (ni != prep->airs.size()) fail(P3R_EINVAL, "%zu traces for %zu preprocessed instances", ni, prep->airs.size());
+  const int p2w = p2_perm_cols<PP>() + 2;
+  std::vector<LookupLayout> layouts(ni);
+  std::vector<int> log_n(ni);
+  for (size_t i = 0; i < ni; ++i) {
+    const AirParams& a = prep->airs[i];
+    if (mains[i]->h != prep->heights[i])
+      fail(P3R_EINVAL, "instance %zu: trace height %zu != preprocessed height %zu", i, mains[i]->h, prep->heights[i]);
+    if ((int)mains[i]->w != air_width_of(a, p2w))
+      fail(P3R_EINVAL, "instance %zu: trace width %zu, the AIR expects %d", i, mains[i]->w, air_width_of(a, p2w));
+    log_n[i] = log2_exact(mains[i]->h, "trace height");
+    layouts[i] = lookup_layout(a);
+    if (layouts[i].log_chunks > log_blowup) fail(P3R_EINVAL, "quotient domain larger than the LDE");
+  }
+  const F gen = F::generator();
+  std::vector<F> rc_host(ctx->rc_canonical.size());
+  std::vector<uint32_t> rc_mont(ctx->rc_canonical.size());
+  for (size_t i = 0; i < rc_mont.size(); ++i) rc_mont[i] = F::from_canonical(ctx->rc_canonical[i]).v;
+  HostChallenger<PP> ch(rc_mont.data());
+  ProofWriter<PP> W;
+  W.canonical = canonical_encoding;
+
+  // ---- 1. main LDEs + commitment
+  std::vector<std::unique_ptr<p3r_dmat>> main_lde(ni);
+  std::vector<const p3r_dmat*> ptrs;
+  for (size_t i = 0; i < ni; ++i) {
+    main_lde[i] = coset_lde<PP>(ctx, mains[i], log_blowup, PP::GEN);
+    ptrs.push_back(main_lde[i].get());
+  }
+  std::vector<uint32_t> main_cap, perm_cap, quot_cap;
+  auto main_tree = commit_dmats<PP>(ctx, ptrs, main_cap);
+
+  // ---- 2. transcript head
+  ch.observe_base_as_ext(ni);
+  for (size_t i = 0; i < ni; ++i) {
+    ch.observe_base_as_ext(log_n[i]);
+    ch.observe_base_as_ext(log_n[i]);
+    ch.observe_base_as_ext(mains[i]->w);
+    ch.observe_base_as_ext(uint64_t(1) << layouts[i].log_chunks);
+  }
+  for (uint32_t v : main_cap) ch.observe(F::raw(v));
+  for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(air_prep_width_of(prep->airs[i]));
+  for (uint32_t v : prep->cap_canonical) ch.observe(F::from_canonical(v));
+
+  // ---- 3. LogUp: challenges, aux traces, commitment, terminals
+  bool any_lookup = false;
+  for (auto& L : layouts) any_lookup |= L.n_groups > 0;
+  LookupCh lc{};
+  if (any_lookup) {
+    E alpha_l = ch.sample_ext(), beta_l = ch.sample_ext();
+    E bp = E::one();
+    for (int j = 0; j < 5; ++j) { lc.beta_pow[j] = to_e4<PP>(bp); bp *= beta_l; }
+    lc.prefix = to_e4<PP>(alpha_l + bp);  // alpha + beta^5, bus id 0
+  }
+  std::vector<std::unique_ptr<p3r_dmat>> aux(ni), aux_lde(ni);
+  std::vector<E> terminals(ni, E::zero());
+  std::vector<int> perm_insts;
+  std::unique_ptr<p3r_tree> perm_tree;
+  if (any_lookup) {
+    for (size_t i = 0; i < ni; ++i) {
+      const auto& L = layouts[i];
+      if (!L.n_groups) continue;
+      const size_t n = mains[i]->h;
+      aux[i] = dmat_alloc(n, (size_t)L.aux_width() * 4);
+      DevBuf rowsum(4 * n), total(4);
+      const size_t n_blocks = (n + kScanTile - 1) / kScanTile;
+      DevBuf agg(4 * n_blocks);
+      // the preprocessed TRACE is not retained; its first n*... rows are not the trace either,
+      // so K7 reads the trace-domain preprocessed columns from the caller-provided copy.
+      {
+        ProfScope ps(ctx, "logup_aux");
+        hipLaunchKernelGGL(k_logup_aux<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, prep->airs[i],
+                           mains[i]->d, prep->traces[i]->d, n, lc, L.pair, aux[i]->d, rowsum.p);
+        hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, 0, n, rowsum.p,
+                           agg.p, n_blocks, aux[i]->d, total.p);
+        hipLaunchKernelGGL(k_ef_scan<PP>, dim3(1), dim3(kBlock), 0, ctx->stream, 1, n, rowsum.p, agg.p, n_blocks,
+                           aux[i]->d, total.p);
+        hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, 2, n, rowsum.p,
+                           agg.p, n_blocks, aux[i]->d, total.p);
+      }
+      P3R_HIP(hipGetLastError());
+      terminals[i] = download_ef<PP>(ctx, total.p, 1)[0];
+      aux_lde[i] = coset_lde<PP>(ctx, aux[i].get(), log_blowup, PP::GEN);
+      perm_insts.push_back((int)i);
+    }
+    ptrs.clear();
+    for (int i : perm_insts) ptrs.push_back(aux_lde[i].get());
+    perm_tree = commit_dmats<PP>(ctx, ptrs, perm_cap);
+    for (uint32_t v : perm_cap) ch.observe(F::raw(v));
+    for (int i : perm_insts) ch.observe_ext(terminals[i]);
+  }
+
+  // ---- 4. alpha, quotient chunks, commitment
+  const E alpha = ch.sample_ext();
+  struct Chunk { int inst; F shift; std::unique_ptr<p3r_dmat> evals, lde; };
+  std::vector<Chunk> chunks;
+  std::vector<std::unique_ptr<p3r_dmat>> chunk_bufs_keep;
+  for (size_t i = 0; i < ni; ++i) {
+    const AirParams& a = prep->airs[i];
+    const auto& L = layouts[i];
+    const int lq = L.log_chunks, C = 1 << lq;
+    const size_t n = mains[i]->h;
+    const int n_base = air_num_base_constraints<PP>(a);
+    const int n_ext = L.n_groups ? L.n_groups + 3 : 0;
+    const int N = n_base + n_ext;
+    std::vector<uint32_t> apow((size_t)std::max(N, 1) * 4);
+    {
+      E p = E::one();
+      for (int k = N - 1; k >= 0; --k) {
+        for (int c = 0; c < 4; ++c) apow[4 * k + c] = p.c[c].v;
+        p *= alpha;
+      }
+    }
+    DevBuf d_apow(apow.size());
+    P3R_HIP(hipMemcpyAsync(d_apow.p, apow.data(), apow.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    QuotientArgs q{};
+    q.air = a;
+    q.main = main_lde[i]->d;
+    q.prep = prep->ldes[i]->d;
+    q.aux = L.n_groups ? aux_lde[i]->d : nullptr;
+    q.lde_h = main_lde[i]->h;
+    q.log_n = log_n[i];
+    q.log_chunks = lq;
+    q.apow = d_apow.p;
+    q.n_base = n_base; q.n_groups = L.n_groups; q.pair = L.pair;
+    q.lc = lc;
+    q.terminal = to_e4<PP>(terminals[i]);
+    q.gen = gen.v;
+    const F wq = F::two_adic_generator(log_n[i] + lq);
+    q.w_q = wq.v;
+    q.g_inv = F::two_adic_generator(log_n[i]).inv().v;
+    const F gen_n = gen.pow(n), w_c = F::two_adic_generator(lq);
+    for (int c = 0; c < C; ++c) {
+      F zh = gen_n * w_c.pow(c) - F::one();
+      q.zh[c] = zh.v;
+      q.zh_inv[c] = zh.inv().v;
+    }
+    q.rc = ctx->rc.p;
+    auto chunk_buf = dmat_alloc(n, (size_t)4 * C);  // [C][4][n]
+    q.out = chunk_buf->d;
+    {
+      ProfScope ps(ctx, "quotient");
+      hipLaunchKernelGGL(k_quotient<PP>, dim3(blocks_for(n << lq)), dim3(kBlock), 0, ctx->stream, q);
+    }
+    P3R_HIP(hipGetLastError());
+    for (int c = 0; c < C; ++c) {
+      Chunk ck;
+      ck.inst = (int)i;
+      ck.shift = gen * wq.pow(c);
+      ck.evals = std::make_unique<p3r_dmat>();
+      ck.evals->d = chunk_buf->d + (size_t)c * 4 * n;  // view: n x 4 column-major
+      ck.evals->h = n;
+      ck.evals->w = 4;
+      // commit evaluates the chunk polynomial on gen*<w>: shift = GENERATOR / domain shift
+      ck.lde = coset_lde<PP>(ctx, ck.evals.get(), log_blowup, (gen * ck.shift.inv()).to_canonical());
+      chunks.push_back(std::move(ck));
+    }
+    P3R_HIP(hipStreamSynchronize(ctx->stream));  // d_apow dies here
+    chunk_bufs_keep.push_back(std::move(chunk_buf));
+  }
+  ptrs.clear();
+  for (auto& ck : chunks) ptrs.push_back(ck.lde.get());
+  auto quot_tree = commit_dmats<PP>(ctx, ptrs, quot_cap);
+  for (uint32_t v : quot_cap) ch.observe(F::raw(v));
+  const E zeta = ch.sample_ext();
+
+  // ---- 5. openings, observed in round / matrix / point order
+  struct Item { int round, mat; const p3r_dmat* lde; int log_h; std::vector<E> z; std::vector<std::vector<E>> vals; };
+  std::vector<Item> items;
+  std::vector<std::vector<std::vector<E>>> o_main(ni), o_prep(ni), o_perm(ni);
+  std::vector<std::vector<E>> o_chunks(chunks.size());
+  for (size_t i = 0; i < ni; ++i) {
+    std::vector<E> pts{zeta};
+    if (air_uses_next(prep->airs[i])) pts.push_back(zeta * F::two_adic_generator(log_n[i]));
+    o_main[i] = open_matrix<PP>(ctx, mains[i]->d, mains[i]->h, (int)mains[i]->w, F::one(), pts);
+    items.push_back({0, (int)i, main_lde[i].get(), log_n[i], pts, o_main[i]});
+  }
+  for (size_t k = 0; k < chunks.size(); ++k) {
+    auto& ck = chunks[k];
+    auto v = open_matrix<PP>(ctx, ck.evals->d, ck.evals->h, 4, ck.shift, {zeta});
+    o_chunks[k] = v[0];
+    items.push_back({1, (int)k, ck.lde.get(), log_n[ck.inst], {zeta}, v});
+  }
+  for (size_t i = 0; i < ni; ++i) {
+    std::vector<E> pts{zeta, zeta * F::two_adic_generator(log_n[i])};
+    const p3r_dmat* pt = prep->traces[i].get();
+    o_prep[i] = open_matrix<PP>(ctx, pt->d, pt->h, (int)pt->w, F::one(), pts);
+    items.push_back({2, (int)i, prep->ldes[i].get(), log_n[i], pts, o_prep[i]});
+  }
+  for (size_t k = 0; k < perm_insts.size(); ++k) {
+    int i = perm_insts[k];
+    std::vector<E> pts{zeta, zeta * F::two_adic_generator(log_n[i])};
+    o_perm[i] = open_matrix<PP>(ctx, aux[i]->d, aux[i]->h, (int)aux[i]->w, F::one(), pts);
+    items.push_back({3, (int)k, aux_lde[i].get(), log_n[i], pts, o_perm[i]});
+  }
+  for (auto& it : items)
+    for (auto& pv : it.vals)
+      for (auto& v : pv) ch.observe_ext(v);
+
+  // ---- 6. FRI batching challenge and per-height reduced openings
+  const E fri_alpha = ch.sample_ext();
+  size_t max_w = 1;
+  for (auto& it : items) max_w = std::max(max_w, it.lde->w);
+  std::vector<E> fa_pow(max_w + 1);
+  fa_pow[0] = E::one();
+  for (size_t c = 1; c <= max_w; ++c) fa_pow[c] = fa_pow[c - 1] * fri_alpha;
+  DevBuf d_fapow(max_w * 4);
+  {
+    std::vector<uint32_t> h(max_w * 4);
+    for (size_t c = 0; c < max_w; ++c)
+      for (int k = 0; k < 4; ++k) h[c * 4 + k] = fa_pow[c].c[k].v;
+    P3R_HIP(hipMemcpyAsync(d_fapow.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    P3R_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  std::map<int, std::pair<E, DevBuf>> ros;  // log_height -> (alpha power, ro planes [4][h])
+  for (auto& it : items) {
+    const int lh = it.log_h + log_blowup;
+    auto f = ros.find(lh);
+    if (f == ros.end()) {
+      DevBuf b((size_t)4 << lh);
+      P3R_HIP(hipMemsetAsync(b.p, 0, ((size_t)16) << lh, ctx->stream));
+      f = ros.emplace(lh, std::make_pair(E::one(), std::move(b))).first;
+    }
+    FriReduceArgs a{};
+    a.mat = it.lde->d; a.h = it.lde->h; a.w = (int)it.lde->w; a.log_h = lh;
+    a.apow = d_fapow.p;
+    a.n_points = (int)it.z.size();
+    E ap = f->second.first;
+    for (size_t p = 0; p < it.z.size(); ++p) {
+      E V = E::zero();
+      for (size_t c = 0; c < it.vals[p].size(); ++c) V += fa_pow[c] * it.vals[p][c];
+      a.z[p] = to_e4<PP>(it.z[p]);
+      a.v[p] = to_e4<PP>(V);
+      a.off[p] = to_e4<PP>(ap);
+      ap *= fa_pow[it.lde->w];
+    }
+    f->second.first = ap;
+    a.gen = gen.v;
+    a.w_h = F::two_adic_generator(lh).v;
+    a.ro = f->second.second.p;
+    ProfScope ps(ctx, "fri_reduce");
+    hipLaunchKernelGGL(k_fri_reduce<PP>, dim3(blocks_for(a.h)), dim3(kBlock), 0, ctx->stream, a);
+  }
+  P3R_HIP(hipGetLastError());
+
+  // ---- 7. FRI commit phase
+  std::vector<int> heights;
+  for (auto& kv : ros) heights.push_back(kv.first);
+  std::sort(heights.rbegin(), heights.rend());
+  const int log_max = heights[0];
+  const int log_final = (int)cfg.log_final_poly_len + log_blowup;
+  struct Phase { int la; size_t rows; DevBuf folded_in; std::unique_ptr<p3r_tree> tree; std::vector<uint32_t> cap; };
+  std::vector<Phase> phases;
+  DevBuf folded = std::move(ros[log_max].second);
+  size_t next_h = 1;
+  int log_cur = log_max;
+  std::vector<F> commit_pow_witnesses;
+  while (log_cur > log_final) {
+    int log_next = next_h < heights.size() ? heights[next_h] : -1;
+    int la = std::min((int)cfg.max_log_arity, log_cur - log_final);
+    if (log_next >= 0 && log_next < log_cur) la = std::min(la, log_cur - log_next);
+    la = std::max(la, 1);
+    if (la > 3) fail(P3R_EUNSUPPORTED, "max_log_arity > 3 is not supported");
+    const size_t arity = size_t(1) << la, rows = (size_t(1) << log_cur) >> la, n_in = size_t(1) << log_cur;
+    Phase ph;
+    ph.la = la;
+    ph.rows = rows;
+    // leaves: row r = the 2^la sibling evaluations, EF flattened -> column (j*4+k) = plane k, offset j, stride arity
+    ph.tree = std::make_unique<p3r_tree>();
+    ph.tree->cap_height = (int)cfg.cap_height;
+    ph.tree->log_max_h = log_cur - la;
+    ph.tree->layers.emplace_back(P2_DIGEST * rows);
+    {
+      std::vector<const uint32_t*> cols;
+      for (size_t j = 0; j < arity; ++j)
+        for (int k = 0; k < 4; ++k) cols.push_back(folded.p + (size_t)k * n_in + j);
+      const uint32_t** dcols = nullptr;
+      P3R_HIP(hipMalloc((void**)&dcols, cols.size() * sizeof(void*)));
+      P3R_HIP(hipMemcpyAsync(dcols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+      {
+        ProfScope ps(ctx, "mmcs_hash_rows");
+        hipLaunchKernelGGL(k_mmcs_hash_rows_strided<PP>, dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream,
+                           (const uint32_t* const*)dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p,
+                           ctx->rc.p);
+      }
+      hipError_t e = hipStreamSynchronize(ctx->stream);
+      (void)hipFree(dcols);
+      P3R_HIP(e);
+    }
+    build_plain_layers<PP>(ctx, ph.tree.get(), rows);
+    ph.cap = download_cap_mont<PP>(ctx, ph.tree.get());
+    for (uint32_t v : ph.cap) ch.observe(F::raw(v));
+    if (cfg.commit_pow_bits) fail(P3R_EUNSUPPORTED, "commit_pow_bits > 0 is not supported yet");
+    commit_pow_witnesses.push_back(F::zero());
+    const E beta = ch.sample_ext();
+    DevBuf out(4 * rows);
+    FriFoldArgs fa{};
+    fa.in = folded.p; fa.out = out.p; fa.rows = rows; fa.la = la; fa.log_rows = log_cur - la;
+    fa.beta = to_e4<PP>(beta);
+    fa.beta_pow = to_e4<PP>(beta.pow(arity));
+    const bool roll = next_h < heights.size() && heights[next_h] == log_cur - la;
+    fa.roll = roll ? ros[heights[next_h]].second.p : nullptr;
+    fa.w_inv = F::two_adic_generator(log_cur).inv().v;
+    const F omega = F::two_adic_generator(la);
+    for (int s = 0; s < la; ++s) {
+      F om_s = omega.pow(uint64_t(1) << s);
+      for (int j = 0; j < (int)(arity >> (s + 1)); ++j)
+        fa.tw_inv[s][j] = om_s.pow(bit_reverse(2 * j, la - s)).inv().v;
+    }
+    fa.neg_half = (-(F::from_canonical(2).inv())).v;
+    {
+      ProfScope ps(ctx, "fri_fold");
+      hipLaunchKernelGGL(k_fri_fold<PP>, dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream, fa);
+    }
+    P3R_HIP(hipGetLastError());
+    if (roll) ++next_h;
+    ph.folded_in = std::move(folded);
+    folded = std::move(out);
+    log_cur -= la;
+    phases.push_back(std::move(ph));
+  }
+  if (next_h != heights.size()) fail(P3R_EINVAL, "FRI: an input height was never rolled in");
+  // final polynomial (host: <= 2^(log_final) extension elements)
+  std::vector<E> final_poly;
+  {
+    const size_t m = size_t(1) << log_cur;
+    std::vector<uint32_t> raw(4 * m);
+    P3R_HIP(hipMemcpyAsync(raw.data(), folded.p, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    P3R_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<E> nat(m);
+    for (size_t i = 0; i < m; ++i)
+      for (int k = 0; k < 4; ++k) nat[bit_reverse((uint32_t)i, log_cur)].c[k] = F::raw(raw[(size_t)k * m + i]);
+    const F w_inv = F::two_adic_generator(log_cur).inv(), m_inv = F::from_u64(m).inv();
+    std::vector<E> coeffs(m);
+    for (size_t kk = 0; kk < m; ++kk) {
+      E acc = E::zero();
+      F wk = w_inv.pow(kk), x = F::one();
+      for (size_t nn = 0; nn < m; ++nn) { acc += nat[nn] * x; x *= wk; }
+      coeffs[kk] = acc * m_inv;
+    }
+    const size_t flen = size_t(1) << cfg.log_final_poly_len;
+    for (size_t i = flen; i < m; ++i)
+      if (!coeffs[i].is_zero())
+        fail(P3R_EINVAL, "FRI final polynomial has degree >= 2^%u: the traces do not satisfy the constraints",
+             cfg.log_final_poly_len);
+    final_poly.assign(coeffs.begin(), coeffs.begin() + flen);
+  }
+  for (auto& c : final_poly) ch.observe_ext(c);
+  for (auto& ph : phases) ch.observe(F::from_canonical((uint32_t)ph.la));
+  // query proof of work: smallest witness (device search)
+  F query_pow_witness = F::zero();
+  if (cfg.query_pow_bits) {
+    GrindArgs g{};
+    for (int k = 0; k < 16; ++k) g.state[k] = ch.state[k].v;
+    g.n_pending = (int)ch.in_buf.size();
+    for (int k = 0; k < g.n_pending; ++k) g.pending[k] = ch.in_buf[k].v;
+    g.bits = (int)cfg.query_pow_bits;
+    g.rc = ctx->rc.p;
+    DevBuf res(1);
+    g.result = res.p;
+    uint32_t found = 0xFFFFFFFFu;
+    const uint32_t batch = 1u << std::min<uint32_t>(cfg.query_pow_bits + 3, 24);
+    for (uint64_t base = 0; base < PP::P && found == 0xFFFFFFFFu; base += batch) {
+      P3R_HIP(hipMemsetAsync(res.p, 0xFF, 4, ctx->stream));
+      g.base = (uint32_t)base;
+      ProfScope ps(ctx, "grind");
+      hipLaunchKernelGGL(k_grind<PP>, dim3(batch / kBlock), dim3(kBlock), 0, ctx->stream, g);
+      P3R_HIP(hipMemcpyAsync(&found, res.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+      P3R_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (found == 0xFFFFFFFFu) fail(P3R_EINVAL, "proof-of-work search exhausted the field");
+    query_pow_witness = F::from_canonical(found);
+    if (!ch.check_witness((int)cfg.query_pow_bits, query_pow_witness)) fail(P3R_EHIP, "device PoW witness rejected on host");
+  }
+
+  // ---- 8. queries: one gather launch for every opened row / sibling of every query
+  const p3r_tree* round_trees[4] = {main_tree.get(), quot_tree.get(), prep->tree.get(), perm_tree.get()};
+  const int n_rounds = any_lookup ? 4 : 3;
+  std::vector<size_t> indices(cfg.num_queries);
+  for (auto& ix : indices) ix = ch.sample_bits(log_max);
+  std::vector<GatherDesc> descs;
+  uint32_t cursor = 0;
+  auto push = [&](const uint32_t* src, uint64_t stride, uint32_t count) {
+    descs.push_back({src, stride, count, cursor});
+    uint32_t at = cursor;
+    cursor += count;
+    return at;
+  };
+  struct QRound { std::vector<std::pair<uint32_t, uint32_t>> rows; uint32_t proof_at; int depth; };
+  struct QPhase { uint32_t sib_at[8][4]; uint32_t proof_at; int depth; size_t pos; };
+  std::vector<std::vector<QRound>> qrounds(indices.size());
+  std::vector<std::vector<QPhase>> qphases(indices.size());
+  for (size_t qi = 0; qi < indices.size(); ++qi) {
+    const size_t index = indices[qi];
+    for (int r = 0; r < n_rounds; ++r) {
+      const p3r_tree* t = round_trees[r];
+      size_t ridx = index >> (log_max - t->log_max_h);
+      QRound qr;
+      for (const p3r_dmat* m : t->mats) {
+        int lh = log2_exact(m->h, "height");
+        size_t row = ridx >> (t->log_max_h - lh);
+        qr.rows.emplace_back(push(m->d + row, m->h, (uint32_t)m->w), (uint32_t)m->w);
+      }
+      qr.depth = t->log_max_h - t->cap_height;
+      qr.proof_at = cursor;
+      for (int l = 0; l < qr.depth; ++l)
+        push(t->layers[l].p + ((ridx >> l) ^ 1), size_t(1) << (t->log_max_h - l), P2_DIGEST);
+      qrounds[qi].push_back(qr);
+    }
+    size_t idx = index;
+    for (auto& ph : phases) {
+      const size_t arity = size_t(1) << ph.la, row = idx >> ph.la, n_in = ph.rows << ph.la;
+      QPhase qp;
+      qp.pos = idx & (arity - 1);
+      for (size_t j = 0; j < arity; ++j)
+        for (int k = 0; k < 4; ++k) qp.sib_at[j][k] = push(ph.folded_in.p + (size_t)k * n_in + row * arity + j, 1, 1);
+      qp.depth = ph.tree->log_max_h - ph.tree->cap_height;
+      qp.proof_at = cursor;
+      for (int l = 0; l < qp.depth; ++l)
+        push(ph.tree->layers[l].p + ((row >> l) ^ 1), size_t(1) << (ph.tree->log_max_h - l), P2_DIGEST);
+      qphases[qi].push_back(qp);
+      idx = row;
+    }
+  }
+  std::vector<uint32_t> gathered(cursor);
+  {
+    GatherDesc* d_descs = nullptr;
+    P3R_HIP(hipMalloc((void**)&d_descs, descs.size() * sizeof(GatherDesc)));
+    DevBuf d_out(cursor);
+    hipError_t e = hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(GatherDesc), hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e == hipSuccess) {
+      ProfScope ps(ctx, "query_gather");
+      hipLaunchKernelGGL(k_gather<PP>, dim3((unsigned)descs.size()), dim3(64), 0, ctx->stream, d_descs, d_out.p, 0);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(gathered.data(), d_out.p, (size_t)cursor * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_descs);
+    P3R_HIP(e);
+  }
+
+  // ---- 9. serialise BatchProof (field order: host_transcript.h)
+  W.cap_mont(main_cap);
+  if (any_lookup) { W.byte(1); W.cap_mont(perm_cap); } else W.byte(0);
+  W.cap_mont(quot_cap);
+  W.byte(0);  // random commitment (ZK): none
+  W.varint(ni);
+  {
+    size_t ck = 0;
+    for (size_t i = 0; i < ni; ++i) {
+      W.vec_ef(o_main[i][0]);
+      if (o_main[i].size() == 2) { W.byte(1); W.vec_ef(o_main[i][1]); } else W.byte(0);
+      W.byte(1); W.vec_ef(o_prep[i][0]);
+      W.byte(1); W.vec_ef(o_prep[i][1]);
+      const size_t C = size_t(1) << layouts[i].log_chunks;
+      W.varint(C);
+      for (size_t c = 0; c < C; ++c) W.vec_ef(o_chunks[ck++]);
+      W.byte(0);  // random opened values: none
+      if (!o_perm[i].empty()) { W.vec_ef(o_perm[i][0]); W.vec_ef(o_perm[i][1]); }
+      else { W.varint(0); W.varint(0); }
+    }
+  }
+  W.varint(phases.size());
+  for (auto& ph : phases) W.cap_mont(ph.cap);
+  W.varint(commit_pow_witnesses.size());
+  for (auto& w : commit_pow_witnesses) W.fe(w);
+  W.varint(indices.size());
+  for (size_t qi = 0; qi < indices.size(); ++qi) {
+    W.varint(qrounds[qi].size());
+    for (auto& qr : qrounds[qi]) {
+      W.varint(qr.rows.size());
+      for (auto& rw : qr.rows) {
+        W.varint(rw.second);
+        for (uint32_t c = 0; c < rw.second; ++c) W.fe(F::raw(gathered[rw.first + c]));
+      }
+      W.varint(qr.depth);
+      for (int l = 0; l < qr.depth; ++l) W.digest_mont(&gathered[qr.proof_at + (size_t)l * P2_DIGEST]);
+    }
+    W.varint(qphases[qi].size());
+    for (size_t p = 0; p < phases.size(); ++p) {
+      auto& qp = qphases[qi][p];
+      const size_t arity = size_t(1) << phases[p].la;
+      W.byte((uint8_t)phases[p].la);
+      W.varint(arity - 1);
+      for (size_t j = 0; j < arity; ++j) {
+        if (j == qp.pos) continue;
+        for (int k = 0; k < 4; ++k) W.fe(F::raw(gathered[qp.sib_at[j][k]]));
+      }
+      W.varint(qp.depth);
+      for (int l = 0; l < qp.depth; ++l) W.digest_mont(&gathered[qp.proof_at + (size_t)l * P2_DIGEST]);
+    }
+  }
+  W.vec_ef(final_poly);
+  W.fe(query_pow_witness);
+  W.varint(ni);
+  for (size_t i = 0; i < ni; ++i) {
+    if (layouts[i].n_groups) { W.byte(1); W.ef(terminals[i]); } else W.byte(0);
+  }
+  W.varint(ni);
+  for (size_t i = 0; i < ni; ++i) W.varint(log_n[i]);
+  P3R_HIP(hipStreamSynchronize(ctx->stream));
+  return std::move(W.out);
+}
+
+}  // namespace

@@ -171,6 +171,53 @@ class Context:
         self.check(self.lib.p3r_mmcs_commit_dmat(self.h, arr, len(dmats), cap.ctypes.data_as(_lib.u32p), C.byref(tree)))
         return cap, MerkleTree(self, tree.value, list(dmats))
 
+    # ---- batch-STARK proving
+    def prep_create(self, airs, prep_mats):
+        """airs: list of dicts(kind, lanes, horner_packed_steps, coeff_lookups); prep_mats: 2-D arrays.
+        Returns (commitment, ProverData)."""
+        n = len(airs)
+        descs = (_lib.P3rAirDesc * n)()
+        arr = (_lib.P3rMatrix * n)()
+        keep = []
+        for i, (a, m) in enumerate(zip(airs, prep_mats)):
+            descs[i].kind = a["kind"]
+            descs[i].lanes = a.get("lanes", 1)
+            descs[i].horner_packed_steps = a.get("horner_packed_steps", 2)
+            descs[i].coeff_lookups = a.get("coeff_lookups", 0)
+            x, p = _u32(m)
+            keep.append(x)
+            arr[i].values, arr[i].height, arr[i].width = p, x.shape[0], x.shape[1]
+        cap = np.empty((1 << self.cap_height, 8), dtype=np.uint32)
+        h = self.ptr(self.lib.p3r_prep_create(self.h, descs, arr, n, cap.ctypes.data_as(_lib.u32p)))
+        return cap, ProverData(self, h)
+
+    def _proof_call(self, fn, *args):
+        cap = 1 << 20
+        while True:
+            buf = (C.c_uint8 * cap)()
+            n = C.c_size_t()
+            rc = fn(*args, buf, cap, C.byref(n))
+            if rc == -6 and n.value > cap:  # P3R_EBUFFER
+                cap = n.value
+                continue
+            self.check(rc)
+            return bytes(buf[: n.value])
+
+    def prove_batch(self, prover_data, main_traces, canonical_field_encoding=False):
+        """main_traces: DeviceMatrix list (resident) or 2-D uint32 arrays (host)."""
+        flags = 1 if canonical_field_encoding else 0
+        n = len(main_traces)
+        if all(isinstance(m, DeviceMatrix) for m in main_traces):
+            arr = (C.c_void_p * n)(*[m.h for m in main_traces])
+            return self._proof_call(self.lib.p3r_prove_batch, self.h, prover_data.h, arr, n, flags)
+        arr = (_lib.P3rMatrix * n)()
+        keep = []
+        for i, m in enumerate(main_traces):
+            x, p = _u32(m)
+            keep.append(x)
+            arr[i].values, arr[i].height, arr[i].width = p, x.shape[0], x.shape[1]
+        return self._proof_call(self.lib.p3r_prove_batch_host, self.h, prover_data.h, arr, n, flags)
+
     # ---- profiling
     def profile_enable(self, on=True):
         self.check(self.lib.p3r_profile_enable(self.h, 1 if on else 0))
@@ -203,6 +250,24 @@ class DeviceMatrix:
     def free(self):
         if self.h and self.ctx.h:
             self.ctx.lib.p3r_dmat_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ProverData:
+    """Device-resident preprocessed LDEs + commitment (ProverData::from_airs_and_degrees)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.p3r_prep_free(self.ctx.h, self.h)
         self.h = None
 
     def __del__(self):
