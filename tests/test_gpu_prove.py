@@ -1,0 +1,77 @@
+"""GPU parity for the full prove_batch: proof BYTES from the HIP path equal the CPU oracle's on
+the same synthetic recursion layer, and the oracle's verifier (a restatement of the in-tree
+circuit verifier) accepts them."""
+import numpy as np
+import pytest
+
+import harness_lib
+import layer_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def make_ctx(field, prm):
+    import plonky3_recursion_amd as p3r
+    return p3r.Context(field=field, log_blowup=prm.log_blowup, max_log_arity=prm.max_log_arity,
+                       cap_height=prm.cap_height, log_final_poly_len=prm.log_final_poly_len,
+                       commit_pow_bits=prm.commit_pow_bits, query_pow_bits=prm.query_pow_bits,
+                       num_queries=prm.num_queries)
+
+
+def airs_of(tables):
+    return [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"], coeff_lookups=0)
+            for t in tables]
+
+
+CASES = [
+    ("koala-bear", 5, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=0, query_pow_bits=3, num_queries=4)),
+    ("koala-bear", 7, dict(log_blowup=2, max_log_arity=3, log_final_poly_len=2, query_pow_bits=5, num_queries=6)),
+    ("koala-bear", 8, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=3, cap_height=2, query_pow_bits=4, num_queries=5)),
+    ("baby-bear", 6, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=4, num_queries=5)),
+    ("baby-bear", 8, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=6, num_queries=4)),
+    ("koala-bear", 10, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=5, query_pow_bits=8, num_queries=8)),
+]
+
+
+@pytest.mark.parametrize("field,log_h,kw", CASES)
+def test_prove_batch_bytes_equal_oracle(oracle, field, log_h, kw):
+    arrs = harness_lib.generate(field, log_h, seed=100 + log_h, horner_chain_len=20, sponge_chain_len=3, merkle_depth=5)
+    prm = layer_lib.params(**kw)
+    L = layer_lib.OracleLayer(oracle, field, arrs, prm)
+    tables = L.tables()
+    ctx = make_ctx(field, prm)
+    cap, pd = ctx.prep_create(airs_of(tables), [t["prep"] for t in tables])
+    assert np.array_equal(cap, L.prep_commit())
+    got = ctx.prove_batch(pd, [t["main"] for t in tables])
+    L.verify(got)  # the oracle verifier accepts the GPU proof
+    want = L.prove()
+    assert len(got) == len(want)
+    assert got == want
+    # canonical field encoding switch
+    got_c = ctx.prove_batch(pd, [t["main"] for t in tables], canonical_field_encoding=True)
+    assert got_c == L.prove(field_encoding=1)
+    pd.free()
+    ctx.close()
+
+
+def test_prove_rejects_unsatisfied_trace(oracle):
+    import plonky3_recursion_amd as p3r
+    field = "koala-bear"
+    arrs = harness_lib.generate(field, 6, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=4)
+    L = layer_lib.OracleLayer(oracle, field, arrs, prm)
+    tables = L.tables()
+    ctx = make_ctx(field, prm)
+    cap, pd = ctx.prep_create(airs_of(tables), [t["prep"] for t in tables])
+    mains = [t["main"].copy() for t in tables]
+    mains[2][3, 5] = (int(mains[2][3, 5]) + 1) % 0x7F000001  # break one ALU cell
+    bad = ctx.prove_batch(pd, mains)
+    with pytest.raises(RuntimeError):
+        L.verify(bad)
+    # shape errors are reported, not crashed on
+    with pytest.raises(p3r.P3rError):
+        ctx.prove_batch(pd, mains[:3])
+    with pytest.raises(p3r.P3rError):
+        ctx.prove_batch(pd, [m[:, :-1] for m in mains])
+    pd.free()
+    ctx.close()
