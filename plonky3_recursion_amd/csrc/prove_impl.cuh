@@ -517,8 +517,10 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     DevBuf res(1);
     g.result = res.p;
     uint32_t found = 0xFFFFFFFFu;
-    const uint32_t batch = 1u << std::min<uint32_t>(cfg.query_pow_bits + 3, 24);
-    for (uint64_t base = 0; base < PP::P && found == 0xFFFFFFFFu; base += batch) {
+    const uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(cfg.query_pow_bits + 3, 12), 24);
+    // 2^(bits+10) candidates miss with probability e^-1024; stop there instead of sweeping the field
+    const uint64_t limit = std::min<uint64_t>(PP::P, (uint64_t(1) << std::min<uint32_t>(cfg.query_pow_bits + 10, 31)) + batch);
+    for (uint64_t base = 0; base < limit && found == 0xFFFFFFFFu; base += batch) {
       P3R_HIP(hipMemsetAsync(res.p, 0xFF, 4, ctx->stream));
       g.base = (uint32_t)base;
       ProfScope ps(ctx, "grind");
