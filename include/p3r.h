@@ -210,6 +210,73 @@ int p3r_prove_batch_host(p3r_ctx* ctx, const p3r_prep* prep, const p3r_matrix* m
                          size_t n_instances, uint32_t flags, uint8_t* proof_buf, size_t proof_cap,
                          size_t* proof_len);
 
+/* ---- prove_all_tables: the recursion layer as the reference sees it ----
+ *
+ * p3r_layer_create == build_next_layer_prep (recursion/src/recursion.rs:342-394): everything
+ *   that depends only on the verifier-circuit shape - get_airs_and_degrees_with_prep's
+ *   preprocessed op lists (circuit-prover/src/common.rs:127-390), the ALU lane schedule
+ *   (circuit-prover/src/air/alu_air.rs:349-463), the preprocessed traces and their commitment.
+ *   It is the object NextLayerPrepCache caches (recursion.rs:295-298).
+ * p3r_prove_all_tables == BatchStarkProver::prove_all_tables(&traces, &circuit_prover_data)
+ *   (circuit-prover/src/batch_stark_prover.rs:1203-1222): builds the five main traces in
+ *   instance order [Const, Public, Alu, Poseidon2, Recompose] (K1-K3) and proves them.
+ *   It returns the inner BatchProof bytes; the Rust shim wraps them with the metadata fields
+ *   of BatchStarkProof (batch_stark_prover.rs:1631-1641), which it already owns.
+ */
+typedef struct p3r_layer_desc_counts {
+  size_t n_const, n_public, n_alu, n_p2, n_recompose; /* ops / rows before padding */
+} p3r_layer_desc_counts;
+
+typedef struct p3r_layer_desc {
+  p3r_layer_desc_counts counts;
+  /* TablePacking (circuit-prover/src/batch_stark_prover/packing.rs:10-27) */
+  uint32_t public_lanes, alu_lanes, horner_packed_steps, recompose_lanes, min_trace_height;
+  /* per-op preprocessed data exactly as get_airs_and_degrees_with_prep leaves it */
+  const uint32_t* const_prep;     /* n_const x 2: [ext_mult, D*witness_idx]   (common.rs:353-368) */
+  const uint32_t* public_prep;    /* n_public x 2                              (common.rs:324-351) */
+  const uint32_t* alu_prep13;     /* n_alu x 13: AluPrepLaneCols               (common.rs:198-323) */
+  const uint32_t* recompose_prep; /* n_recompose x 2: [D*output_idx, out_mult] */
+  /* Poseidon2CircuitRow CTL fields after poseidon_preprocess_for_prover
+   * (circuit-prover/src/batch_stark_prover.rs:97-246); witness ids are NOT yet D-scaled */
+  const uint8_t* p2_new_start;        /* n_p2 */
+  const uint8_t* p2_merkle_path;      /* n_p2 */
+  const uint8_t* p2_mmcs_ctl_enabled; /* n_p2 */
+  const uint8_t* p2_in_ctl;           /* n_p2 x 4 */
+  const uint32_t* p2_input_indices;   /* n_p2 x 4 */
+  const uint32_t* p2_out_ctl;         /* n_p2 x 2, multiplicity as a canonical field element */
+  const uint32_t* p2_output_indices;  /* n_p2 x 2 */
+  const uint32_t* p2_mmcs_index_sum_idx; /* n_p2 */
+} p3r_layer_desc;
+
+/* Flattened Traces<EF> (circuit/src/tables/mod.rs:49-62), D = 4, canonical. */
+typedef struct p3r_traces {
+  size_t n_const;     const uint32_t* const_values;     /* n x 4 */
+  size_t n_public;    const uint32_t* public_values;    /* n x 4 */
+  size_t n_alu;       const uint32_t* alu_values;       /* n x 16: AluTrace.values [a,b,c,out] */
+  p3r_p2_rows p2;     /* n = un-padded Poseidon2 row count (any n, padding is done here) */
+  size_t n_recompose; const uint32_t* recompose_values; /* n x 4 */
+} p3r_traces;
+
+typedef struct p3r_layer p3r_layer;
+typedef struct p3r_dtraces p3r_dtraces;
+
+p3r_layer* p3r_layer_create(p3r_ctx* ctx, const p3r_layer_desc* desc, uint32_t* commit_out);
+void p3r_layer_free(p3r_ctx* ctx, p3r_layer* layer);
+/* Padded heights of the five tables, in instance order. */
+int p3r_layer_table_heights(const p3r_layer* layer, size_t heights_out[5]);
+
+/* Per-proof inputs made resident in HBM once; a prove can then be repeated without PCIe. */
+p3r_dtraces* p3r_traces_upload(p3r_ctx* ctx, const p3r_layer* layer, const p3r_traces* traces);
+void p3r_traces_free(p3r_ctx* ctx, p3r_dtraces* traces);
+
+int p3r_prove_all_tables(p3r_ctx* ctx, const p3r_layer* layer, const p3r_traces* traces, uint32_t flags,
+                         uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
+int p3r_prove_all_tables_resident(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
+                                  uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
+/* K1-K3 only: the main trace of table `table` (0..4) as a device matrix (parity tests). */
+p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
+                                     uint32_t table);
+
 /* ---- measurement support (bench.py): run `iters` back-to-back launches of one kernel
  * family on resident data and return the mean per-launch time measured with HIP events
  * on the ctx's own stream. ---- */

@@ -51,6 +51,34 @@ class P3rAirDesc(C.Structure):
                 ("coeff_lookups", C.c_uint32)]
 
 
+class P3rLayerCounts(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("n_const", "n_public", "n_alu", "n_p2", "n_recompose")]
+
+
+class P3rLayerDesc(C.Structure):
+    _fields_ = [
+        ("counts", P3rLayerCounts),
+        ("public_lanes", C.c_uint32), ("alu_lanes", C.c_uint32), ("horner_packed_steps", C.c_uint32),
+        ("recompose_lanes", C.c_uint32), ("min_trace_height", C.c_uint32),
+        ("const_prep", C.POINTER(C.c_uint32)), ("public_prep", C.POINTER(C.c_uint32)),
+        ("alu_prep13", C.POINTER(C.c_uint32)), ("recompose_prep", C.POINTER(C.c_uint32)),
+        ("p2_new_start", C.POINTER(C.c_uint8)), ("p2_merkle_path", C.POINTER(C.c_uint8)),
+        ("p2_mmcs_ctl_enabled", C.POINTER(C.c_uint8)), ("p2_in_ctl", C.POINTER(C.c_uint8)),
+        ("p2_input_indices", C.POINTER(C.c_uint32)), ("p2_out_ctl", C.POINTER(C.c_uint32)),
+        ("p2_output_indices", C.POINTER(C.c_uint32)), ("p2_mmcs_index_sum_idx", C.POINTER(C.c_uint32)),
+    ]
+
+
+class P3rTraces(C.Structure):
+    _fields_ = [
+        ("n_const", C.c_size_t), ("const_values", C.POINTER(C.c_uint32)),
+        ("n_public", C.c_size_t), ("public_values", C.POINTER(C.c_uint32)),
+        ("n_alu", C.c_size_t), ("alu_values", C.POINTER(C.c_uint32)),
+        ("p2", P3rP2Rows),
+        ("n_recompose", C.c_size_t), ("recompose_values", C.POINTER(C.c_uint32)),
+    ]
+
+
 class P3rProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_uint64)]
 
@@ -94,6 +122,16 @@ SIGNATURES = {
                                   C.POINTER(C.c_size_t)]),
     "p3r_prove_batch_host": (C.c_int, [vp, vp, C.POINTER(P3rMatrix), C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8),
                                        C.c_size_t, C.POINTER(C.c_size_t)]),
+    "p3r_layer_create": (vp, [vp, C.POINTER(P3rLayerDesc), u32p]),
+    "p3r_layer_free": (None, [vp, vp]),
+    "p3r_layer_table_heights": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "p3r_traces_upload": (vp, [vp, vp, C.POINTER(P3rTraces)]),
+    "p3r_traces_free": (None, [vp, vp]),
+    "p3r_prove_all_tables": (C.c_int, [vp, vp, C.POINTER(P3rTraces), C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t,
+                                       C.POINTER(C.c_size_t)]),
+    "p3r_prove_all_tables_resident": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t,
+                                                C.POINTER(C.c_size_t)]),
+    "p3r_layer_build_main_trace": (vp, [vp, vp, vp, C.c_uint32]),
     "p3r_time_permute_dmat": (C.c_int, [vp, vp, C.c_int, C.POINTER(C.c_double)]),
     "p3r_profile_enable": (C.c_int, [vp, C.c_int]),
     "p3r_profile_read": (C.c_int, [vp, C.POINTER(P3rProfileEntry), C.c_size_t, C.POINTER(C.c_size_t)]),

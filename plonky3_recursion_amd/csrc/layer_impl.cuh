@@ -1,0 +1,391 @@
+// prove_all_tables on the GPU (included into p3r_core.hip): Traces -> per-table matrices
+// (K1, K2, K3) -> prove_batch, plus the cached per-circuit-shape setup (K4).
+//
+//   BatchStarkProver::prove_all_tables / prove     circuit-prover/src/batch_stark_prover.rs:1203-1222,1275-1642
+//   build_next_layer_prep / NextLayerPrepCache      recursion/src/recursion.rs:295-298,342-394
+//   get_airs_and_degrees_with_prep                  circuit-prover/src/common.rs:127-390
+//   AluAir::compute_schedule / trace_to_matrix /
+//          build_scheduled_preprocessed_trace       circuit-prover/src/air/alu_air.rs:349-463,497-608,613-677
+//   ConstAir / WitnessSendAir / RecomposeAir trace_to_matrix
+//                                                   const_air.rs:88-127, public_air.rs:127-169, recompose_air.rs:96-119
+//   Poseidon2 preprocessed rows + padding           poseidon2-circuit-air/src/air.rs:613-649,697-794
+//   Poseidon2 filler rows                           circuit-prover/src/batch_stark_prover/poseidon2.rs:1125-1140
+//
+// The ALU lane schedule depends only on the preprocessed op list, so it is computed once on
+// the host at setup and kept in HBM as a scatter plan; building the ALU main trace from the
+// per-proof values is then one fully parallel kernel (a packed-Horner row's previous lane-0
+// output is itself a trace value, so there is no sequential dependency between rows).
+
+namespace {
+
+// plan entry kinds
+enum { PLAN_SEP = 0, PLAN_OP = 1, PLAN_PACKED = 2 };
+
+struct AluPlanEntry {
+  uint32_t first;  // op index
+  uint8_t kind, k;
+  uint16_t pad;
+};
+
+// K1: one lane per trace row.
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_alu_trace(const AluPlanEntry* __restrict__ plan, const uint32_t* __restrict__ prev_src /* per row */,
+            const uint32_t* __restrict__ values /* [n_ops][16] Montgomery */, size_t rows, size_t h, int lanes,
+            int k_max, uint32_t* __restrict__ out /* [width][h] */) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (row >= rows) return;
+  auto val = [&](uint32_t op, int operand) {
+    E e;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) e.c[d] = F::raw(values[(size_t)op * 16 + operand * 4 + d]);
+    return e;
+  };
+  auto put = [&](int col, const E& e) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) out[(size_t)(col + d) * h + row] = e.c[d].v;
+  };
+  const int num_int = (k_max - 1) / 2;
+  for (int lane = 0; lane < lanes; ++lane) {
+    AluPlanEntry en = plan[row * lanes + lane];
+    const int base = lane * 16;
+    if (en.kind == PLAN_OP) {
+      for (int o = 0; o < 4; ++o) put(base + o * 4, val(en.first, o));
+    } else if (en.kind == PLAN_PACKED) {
+      const int k = en.k;
+      for (int o = 0; o < 3; ++o) put(base + o * 4, val(en.first, o));
+      put(base + 12, val(en.first + k - 1, 3));
+      if (lane == 0) {
+        const int extra = lanes * 16;
+        const uint32_t ps = prev_src[row];
+        E acc = ps == 0xFFFFFFFFu ? E::zero() : val(ps, 3);
+        const E b = val(en.first, 1);
+        int step = 0;
+        for (int s = 0; s < num_int; ++s) {
+          uint32_t i0 = en.first + step;
+          if (step + 1 < k) {
+            E o0 = acc * b + val(i0, 2) - val(i0, 0);
+            acc = o0 * b + val(i0 + 1, 2) - val(i0 + 1, 0);
+            step += 2;
+          } else {
+            acc = acc * b + val(i0, 2) - val(i0, 0);
+            step += 1;
+          }
+          put(extra + s * 4, acc);
+        }
+        const int ac_base = extra + num_int * 4;
+        for (int t = 1; t < k; ++t) {
+          put(ac_base + 8 * (t - 1), val(en.first + t, 0));
+          put(ac_base + 8 * (t - 1) + 4, val(en.first + t, 2));
+        }
+        put(ac_base + 8 * (k_max - 1), b * b);
+      }
+    }
+  }
+}
+
+// K2: flat per-op values (row-major, `w` cells per row) -> zero-padded column-major matrix.
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_flat_to_colmajor(const uint32_t* __restrict__ src, size_t n_flat, uint32_t* __restrict__ dst, size_t h, int w) {
+  size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= h * (size_t)w) return;
+  size_t c = t / h, r = t % h;
+  size_t s = r * w + c;
+  dst[t] = s < n_flat ? src[s] : 0u;
+}
+
+struct HostAluSchedule {
+  std::vector<AluPlanEntry> entries;  // rows * lanes
+  std::vector<uint32_t> prev_src;     // per row
+  size_t rows = 0;
+};
+
+// AluAir::compute_schedule (alu_air.rs:349-463); prep13 canonical, 13 cells per op.
+inline HostAluSchedule alu_schedule(const uint32_t* prep13, size_t n_ops, int lanes, int pack_k) {
+  HostAluSchedule S;
+  auto is_h = [&](size_t i) { return prep13[i * 13 + 4] == 1; };
+  bool any = false;
+  for (size_t i = 0; i < n_ops; ++i) any = any || is_h(i);
+  std::vector<AluPlanEntry>& sched = S.entries;
+  if (!any) {
+    for (size_t i = 0; i < n_ops; ++i) sched.push_back({(uint32_t)i, PLAN_OP, 1, 0});
+  } else {
+    std::vector<std::vector<size_t>> chains;
+    std::vector<size_t> cur, non_chain;
+    for (size_t i = 0; i < n_ops; ++i) {
+      if (is_h(i)) cur.push_back(i);
+      else { if (!cur.empty()) { chains.push_back(cur); cur.clear(); } non_chain.push_back(i); }
+    }
+    if (!cur.empty()) chains.push_back(cur);
+    size_t nc = 0;
+    auto fill_row = [&]() {
+      while (sched.size() % lanes != 0) {
+        if (nc < non_chain.size()) sched.push_back({(uint32_t)non_chain[nc++], PLAN_OP, 1, 0});
+        else sched.push_back({0, PLAN_SEP, 1, 0});
+      }
+    };
+    sched.push_back({0, PLAN_SEP, 1, 0});
+    fill_row();
+    for (size_t ci = 0; ci < chains.size(); ++ci) {
+      const auto& chain = chains[ci];
+      if (ci > 0) { fill_row(); sched.push_back({0, PLAN_SEP, 1, 0}); fill_row(); }
+      size_t i = 0;
+      while (i < chain.size()) {
+        size_t k_try = std::min<size_t>(chain.size() - i, (size_t)pack_k), best = 1;
+        for (size_t k = k_try; k >= 2; --k) {
+          bool ok = true;
+          for (size_t j = 1; j < k && ok; ++j) ok = chain[i + j] == chain[i] + j;
+          for (size_t j = 1; j < k && ok; ++j) ok = prep13[chain[i + j] * 13 + 6] == prep13[chain[i] * 13 + 6];
+          if (ok) { best = k; break; }
+        }
+        if (best >= 2) { sched.push_back({(uint32_t)chain[i], PLAN_PACKED, (uint8_t)best, 0}); i += best; }
+        else { sched.push_back({(uint32_t)chain[i], PLAN_OP, 1, 0}); i += 1; }
+        fill_row();
+      }
+    }
+    fill_row();
+    while (nc < non_chain.size()) sched.push_back({(uint32_t)non_chain[nc++], PLAN_OP, 1, 0});
+    fill_row();
+  }
+  while (sched.size() % lanes != 0) sched.push_back({0, PLAN_SEP, 1, 0});  // unscheduled tail: zero cells
+  S.rows = std::max<size_t>(sched.size() / lanes, 1);
+  sched.resize(S.rows * lanes, AluPlanEntry{0, PLAN_SEP, 1, 0});
+  // previous lane-0 output feeding each row's packed-Horner accumulator (alu_air.rs:513-589)
+  S.prev_src.assign(S.rows, 0xFFFFFFFFu);
+  uint32_t prev = 0xFFFFFFFFu;
+  for (size_t r = 0; r < S.rows; ++r) {
+    S.prev_src[r] = prev;
+    const AluPlanEntry& e = sched[r * lanes];
+    if (!any) continue;  // unscheduled traces never use it
+    if (e.kind == PLAN_OP) prev = e.first;
+    else if (e.kind == PLAN_PACKED) prev = e.first + e.k - 1;
+    else prev = 0xFFFFFFFFu;
+  }
+  return S;
+}
+
+inline size_t padded_height(size_t rows, size_t min_height) {
+  size_t h = 1;
+  while (h < std::max<size_t>(rows, 1)) h <<= 1;
+  size_t mh = 1;
+  while (mh < min_height) mh <<= 1;
+  return std::max(h, mh);
+}
+
+}  // namespace
+
+// Everything that depends only on the circuit shape (CircuitProverData + the ALU schedule).
+struct p3r_layer {
+  p3r_layer_desc_counts counts{};
+  uint32_t public_lanes = 1, alu_lanes = 1, horner_k = 2, recompose_lanes = 1, min_height = 1;
+  size_t h_const = 0, h_public = 0, h_alu = 0, h_p2 = 0, h_recompose = 0, alu_rows = 0;
+  std::unique_ptr<p3r_prep> prep;
+  p3r::DevBuf alu_plan, alu_prev_src;
+};
+
+// Per-proof inputs resident in HBM (flattened Traces<EF>).
+struct p3r_dtraces {
+  p3r::DevBuf const_values, public_values, alu_values, recompose_values;  // Montgomery, row-major
+  size_t n_const = 0, n_public = 0, n_alu = 0, n_recompose = 0;
+  std::unique_ptr<p3r_p2_dev> p2;  // padded to the table height with filler rows
+};
+
+namespace {
+
+template <class PP>
+std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, uint32_t* commit_out) {
+  const uint32_t P = PP::P;
+  auto L = std::make_unique<p3r_layer>();
+  L->counts = d->counts;
+  L->public_lanes = d->public_lanes; L->alu_lanes = d->alu_lanes; L->horner_k = d->horner_packed_steps;
+  L->recompose_lanes = d->recompose_lanes; L->min_height = d->min_trace_height;
+  if (!L->public_lanes || !L->alu_lanes || !L->recompose_lanes) fail(P3R_EINVAL, "lane counts must be positive");
+  if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
+  const auto& c = d->counts;
+  auto check = [&](const uint32_t* p, size_t n, const char* what) {
+    if (n && !p) fail(P3R_EINVAL, "%s is NULL", what);
+    for (size_t i = 0; i < n; ++i)
+      if (p[i] >= P) fail(P3R_EINVAL, "%s[%zu] is not canonical", what, i);
+  };
+  check(d->const_prep, c.n_const * 2, "const_prep");
+  check(d->public_prep, c.n_public * 2, "public_prep");
+  check(d->alu_prep13, c.n_alu * 13, "alu_prep13");
+  check(d->recompose_prep, c.n_recompose * 2, "recompose_prep");
+  check(d->p2_out_ctl, c.n_p2 * 2, "p2_out_ctl");
+  const size_t mh = L->min_height;
+  auto lanes_prep = [&](const uint32_t* prep, size_t n_ops, int per_op, int lanes, size_t& h_out) {
+    size_t rows = std::max<size_t>((n_ops + lanes - 1) / lanes, 1);
+    h_out = padded_height(rows, mh);
+    std::vector<uint32_t> m(h_out * (size_t)lanes * per_op, 0);
+    std::copy(prep, prep + n_ops * per_op, m.begin());
+    return m;
+  };
+  std::vector<std::vector<uint32_t>> mats(5);
+  p3r_air_desc airs[5] = {{P3R_AIR_CONST, 1, 2, 0},
+                          {P3R_AIR_PUBLIC, L->public_lanes, 2, 0},
+                          {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
+                          {P3R_AIR_POSEIDON2, 1, 2, 0},
+                          {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 0}};
+  mats[0] = lanes_prep(d->const_prep, c.n_const, 2, 1, L->h_const);
+  mats[1] = lanes_prep(d->public_prep, c.n_public, 2, (int)L->public_lanes, L->h_public);
+  // ALU: schedule + scheduled preprocessed trace (alu_air.rs:613-677)
+  {
+    const int lanes = (int)L->alu_lanes, k_max = (int)L->horner_k, pw = lanes * 13 + 7 * (k_max - 1);
+    HostAluSchedule S = alu_schedule(d->alu_prep13, c.n_alu, lanes, k_max);
+    L->alu_rows = S.rows;
+    L->h_alu = padded_height(S.rows, mh);
+    std::vector<uint32_t>& m = mats[2];
+    m.assign(L->h_alu * (size_t)pw, 0);
+    auto mulmod = [&](uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)a * b % P); };
+    for (size_t pos = 0; pos < S.entries.size(); ++pos) {
+      const auto& en = S.entries[pos];
+      size_t row = pos / lanes, lane = pos % lanes, base = row * pw + lane * 13;
+      if (en.kind == PLAN_OP) {
+        std::copy(d->alu_prep13 + (size_t)en.first * 13, d->alu_prep13 + (size_t)en.first * 13 + 13, m.begin() + base);
+      } else if (en.kind == PLAN_PACKED && lane == 0) {
+        const int k = en.k;
+        const uint32_t* src0 = d->alu_prep13 + (size_t)en.first * 13;
+        const uint32_t* last = d->alu_prep13 + (size_t)(en.first + k - 1) * 13;
+        std::copy(src0, src0 + 13, m.begin() + base);
+        m[base + 8] = last[8];
+        m[base + 10] = last[10];
+        m[base + 9] = mulmod(m[base + 9], (uint32_t)k);
+        const uint32_t mult_a = m[base];
+        size_t extra = row * pw + (size_t)lanes * 13;
+        m[extra + (k - 2)] = 1;
+        for (int t = 1; t < k; ++t) {
+          const uint32_t* st = d->alu_prep13 + (size_t)(en.first + t) * 13;
+          size_t p = extra + (k_max - 1) + 6 * (t - 1);
+          m[p] = st[5]; m[p + 1] = st[7]; m[p + 2] = st[11]; m[p + 3] = st[12];
+          m[p + 4] = mulmod(mult_a, st[11]);
+          m[p + 5] = mulmod(mult_a, st[12]);
+        }
+      }
+    }
+    L->alu_plan.alloc((S.entries.size() * sizeof(AluPlanEntry) + 3) / 4);
+    P3R_HIP(hipMemcpy(L->alu_plan.p, S.entries.data(), S.entries.size() * sizeof(AluPlanEntry), hipMemcpyHostToDevice));
+    L->alu_prev_src.alloc(S.prev_src.size());
+    P3R_HIP(hipMemcpy(L->alu_prev_src.p, S.prev_src.data(), S.prev_src.size() * 4, hipMemcpyHostToDevice));
+  }
+  // Poseidon2 preprocessed rows (air.rs:697-794, non-compact D=4 layout) + padding (:613-649)
+  {
+    L->h_p2 = padded_height(c.n_p2, mh);
+    std::vector<uint32_t>& m = mats[3];
+    m.assign(L->h_p2 * 24, 0);
+    auto scaled = [&](uint32_t wid) { return (uint32_t)((uint64_t)wid * 4 % P); };
+    for (size_t r = 0; r < c.n_p2; ++r) {
+      uint32_t* o = &m[r * 24];
+      const bool ns = d->p2_new_start[r], mp = d->p2_merkle_path[r], en = d->p2_mmcs_ctl_enabled[r];
+      for (int l = 0; l < 4; ++l) {
+        const bool ctl = d->p2_in_ctl[r * 4 + l];
+        o[l * 4] = scaled(d->p2_input_indices[r * 4 + l]);
+        o[l * 4 + 1] = ctl;
+        o[l * 4 + 2] = !ns && !mp && !ctl;
+        o[l * 4 + 3] = !ns && mp && !ctl;
+      }
+      for (int l = 0; l < 2; ++l) {
+        o[16 + 2 * l] = scaled(d->p2_output_indices[r * 2 + l]);
+        o[17 + 2 * l] = d->p2_out_ctl[r * 2 + l];
+      }
+      o[20] = scaled(d->p2_mmcs_index_sum_idx[r]);
+      o[21] = en && mp;
+      o[22] = ns;
+      o[23] = mp;
+    }
+    if (L->h_p2 > c.n_p2) m[c.n_p2 * 24 + 22] = 1;
+  }
+  mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, 2, (int)L->recompose_lanes, L->h_recompose);
+  const int widths[5] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1), 24,
+                         (int)L->recompose_lanes * 2};
+  const size_t heights[5] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose};
+  p3r_matrix pm[5];
+  for (int i = 0; i < 5; ++i) pm[i] = {mats[i].data(), heights[i], (size_t)widths[i]};
+  L->prep = prep_create<PP>(ctx, airs, pm, 5);
+  std::copy(L->prep->cap_canonical.begin(), L->prep->cap_canonical.end(), commit_out);
+  return L;
+}
+
+template <class PP>
+DevBuf upload_mont(p3r_ctx* ctx, const uint32_t* host, size_t n, const char* what) {
+  DevBuf b(std::max<size_t>(n, 1));
+  if (n) {
+    if (!host) fail(P3R_EINVAL, "%s is NULL", what);
+    P3R_HIP(hipMemcpyAsync(b.p, host, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_convert_inplace<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, b.p, n, 1);
+    P3R_HIP(hipGetLastError());
+    P3R_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return b;
+}
+
+template <class PP>
+std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, const p3r_traces* t) {
+  const auto& c = L->counts;
+  if (t->n_const != c.n_const || t->n_public != c.n_public || t->n_alu != c.n_alu || t->p2.n != c.n_p2 ||
+      t->n_recompose != c.n_recompose)
+    fail(P3R_EINVAL, "trace row counts do not match the prepared circuit shape");
+  auto d = std::make_unique<p3r_dtraces>();
+  d->n_const = c.n_const; d->n_public = c.n_public; d->n_alu = c.n_alu; d->n_recompose = c.n_recompose;
+  d->const_values = upload_mont<PP>(ctx, t->const_values, c.n_const * 4, "const_values");
+  d->public_values = upload_mont<PP>(ctx, t->public_values, c.n_public * 4, "public_values");
+  d->alu_values = upload_mont<PP>(ctx, t->alu_values, c.n_alu * 16, "alu_values");
+  d->recompose_values = upload_mont<PP>(ctx, t->recompose_values, c.n_recompose * 4, "recompose_values");
+  // Poseidon2 rows padded with fillers: new_start = true, zero state (poseidon2.rs:1125-1140)
+  const size_t h = L->h_p2, n = c.n_p2;
+  std::vector<uint32_t> in(h * 16, 0), idx(h, 0);
+  std::vector<uint8_t> ns(h, 1), mp(h, 0), bit(h, 0);
+  if (n) {
+    if (!t->p2.input_values || !t->p2.new_start || !t->p2.merkle_path || !t->p2.mmcs_bit || !t->p2.mmcs_index_sum)
+      fail(P3R_EINVAL, "Poseidon2 rows have a NULL field");
+    std::copy(t->p2.input_values, t->p2.input_values + n * 16, in.begin());
+    std::copy(t->p2.mmcs_index_sum, t->p2.mmcs_index_sum + n, idx.begin());
+    std::copy(t->p2.new_start, t->p2.new_start + n, ns.begin());
+    std::copy(t->p2.merkle_path, t->p2.merkle_path + n, mp.begin());
+    std::copy(t->p2.mmcs_bit, t->p2.mmcs_bit + n, bit.begin());
+  }
+  p3r_p2_rows rows{h, in.data(), ns.data(), mp.data(), bit.data(), idx.data()};
+  d->p2 = p2_rows_upload<PP>(ctx, &rows);
+  return d;
+}
+
+// K1 + K2 + K3: the five main-trace matrices in instance order.
+template <class PP>
+std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t) {
+  std::vector<std::unique_ptr<p3r_dmat>> m(5);
+  auto flat = [&](const DevBuf& src, size_t n_ops, size_t h, int w) {
+    auto out = dmat_alloc(h, (size_t)w);
+    ProfScope ps(ctx, "trace_to_matrix");
+    hipLaunchKernelGGL(k_flat_to_colmajor<PP>, dim3(blocks_for(h * w)), dim3(kBlock), 0, ctx->stream, src.p,
+                       n_ops * 4, out->d, h, w);
+    return out;
+  };
+  m[0] = flat(t->const_values, t->n_const, L->h_const, 4);
+  m[1] = flat(t->public_values, t->n_public, L->h_public, (int)L->public_lanes * 4);
+  {
+    const int lanes = (int)L->alu_lanes, k = (int)L->horner_k;
+    const int width = lanes * 16 + ((k - 1) / 2 + 2 * (k - 1) + 1) * 4;
+    m[2] = dmat_alloc(L->h_alu, (size_t)width);
+    P3R_HIP(hipMemsetAsync(m[2]->d, 0, L->h_alu * (size_t)width * 4, ctx->stream));
+    ProfScope ps(ctx, "alu_trace");
+    hipLaunchKernelGGL(k_alu_trace<PP>, dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<const AluPlanEntry*>(L->alu_plan.p), L->alu_prev_src.p, t->alu_values.p,
+                       L->alu_rows, L->h_alu, lanes, k, m[2]->d);
+  }
+  m[3] = trace_fill<PP>(ctx, t->p2.get());
+  m[4] = flat(t->recompose_values, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * 4);
+  P3R_HIP(hipGetLastError());
+  return m;
+}
+
+template <class PP>
+std::vector<uint8_t> prove_all_tables(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, bool canonical) {
+  auto mains = build_main_traces<PP>(ctx, L, t);
+  const p3r_dmat* ptrs[5];
+  for (int i = 0; i < 5; ++i) ptrs[i] = mains[i].get();
+  return prove_batch<PP>(ctx, L->prep.get(), ptrs, 5, canonical);
+}
+
+}  // namespace

@@ -460,6 +460,7 @@ void init_ctx(p3r_ctx* ctx) {
 }  // namespace
 
 #include "prove_impl.cuh"
+#include "layer_impl.cuh"
 
 // =============================================================================== C ABI
 extern "C" {
@@ -749,6 +750,66 @@ int p3r_prove_batch_host(p3r_ctx* ctx, const p3r_prep* prep, const p3r_matrix* m
                                 (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
     emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
   });
+}
+
+p3r_layer* p3r_layer_create(p3r_ctx* ctx, const p3r_layer_desc* desc, uint32_t* commit_out) {
+  p3r_layer* out = nullptr;
+  guard(ctx, [&] {
+    if (!desc || !commit_out) fail(P3R_EINVAL, "NULL argument");
+    out = P3R_FIELD_CALL(ctx, layer_create, ctx, desc, commit_out).release();
+  });
+  return out;
+}
+void p3r_layer_free(p3r_ctx* ctx, p3r_layer* layer) {
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  delete layer;
+}
+int p3r_layer_table_heights(const p3r_layer* L, size_t h[5]) {
+  if (!L || !h) return P3R_EINVAL;
+  h[0] = L->h_const; h[1] = L->h_public; h[2] = L->h_alu; h[3] = L->h_p2; h[4] = L->h_recompose;
+  return P3R_OK;
+}
+p3r_dtraces* p3r_traces_upload(p3r_ctx* ctx, const p3r_layer* layer, const p3r_traces* traces) {
+  p3r_dtraces* out = nullptr;
+  guard(ctx, [&] {
+    if (!layer || !traces) fail(P3R_EINVAL, "NULL argument");
+    out = P3R_FIELD_CALL(ctx, traces_upload, ctx, layer, traces).release();
+  });
+  return out;
+}
+void p3r_traces_free(p3r_ctx* ctx, p3r_dtraces* t) {
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  delete t;
+}
+int p3r_prove_all_tables_resident(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
+                                  uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {
+  return guard(ctx, [&] {
+    if (!layer || !traces || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
+    auto bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, layer, traces,
+                                (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
+    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+  });
+}
+int p3r_prove_all_tables(p3r_ctx* ctx, const p3r_layer* layer, const p3r_traces* traces, uint32_t flags,
+                         uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {
+  return guard(ctx, [&] {
+    if (!layer || !traces || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
+    auto d = P3R_FIELD_CALL(ctx, traces_upload, ctx, layer, traces);
+    auto bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, layer, d.get(),
+                                (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
+    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+  });
+}
+p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
+                                     uint32_t table) {
+  p3r_dmat* out = nullptr;
+  guard(ctx, [&] {
+    if (!layer || !traces || table > 4) fail(P3R_EINVAL, "bad arguments");
+    auto m = P3R_FIELD_CALL(ctx, build_main_traces, ctx, layer, traces);
+    P3R_HIP(hipStreamSynchronize(ctx->stream));
+    out = m[table].release();
+  });
+  return out;
 }
 
 int p3r_profile_enable(p3r_ctx* ctx, int on) {
