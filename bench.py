@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
-"""bench.py - one JSON line for the driver (see DESIGN.md "Measurement").
+"""bench.py - one JSON line for the driver (DESIGN.md "Measurement").
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already
-resident in HBM.  Multi-GPU: independent proofs shard one per rank with no data-path
+A "step" is one `prove_all_tables` (the body of `prove_next_layer` after the verifier circuit has
+run) over the synthetic KoalaBear 2^20-row recursion layer of SURVEY.md section 8d, with the
+Traces and the cached preprocessed data (NextLayerPrepCache) already resident in HBM.  It covers
+K1-K3 trace building, main/permutation/quotient LDE + MMCS commits, LogUp, quotient evaluation,
+openings, FRI commit/fold/grind/queries and proof serialisation.
+
+Multi-GPU: independent proofs (aggregation-tree nodes) shard one per rank with no data-path
 collective - weak scaling; only the barrier / max-over-ranks timing
 crosses ranks.
 """
@@ -18,87 +23,72 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-P = {"koala-bear": 0x7F000001, "baby-bear": 0x78000001}
-GEN = {"koala-bear": 3, "baby-bear": 31}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
-# Synthetic recursion-layer table mix: heights as
-# fractions of H, main widths at D=4, alu_lanes=3, K=4.
-def table_shapes(field, log_h):
-    h = 1 << log_h
-    p2w = 166 if field == "koala-bear" else 300
-    return [("const", max(h // 16, 1), 4), ("public", h // 2, 4), ("alu", h, 80),
-            ("poseidon2", h // 2, p2w), ("recompose", h // 4, 4)]
+FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0,
+           query_pow_bits=15, num_queries=54)  # recursive_fibonacci.rs:71-147, examples/common/mod.rs:472
+GEN_KNOBS = dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
 
 
-def synth_inputs(field, log_h, seed):
-    rng = np.random.default_rng(seed)
-    p = P[field]
-    mats = {}
-    for name, hh, w in table_shapes(field, log_h):
-        if name == "poseidon2":
-            continue
-        mats[name] = rng.integers(0, p, size=(hh, w), dtype=np.uint32)
-    n = (1 << log_h) // 2
-    rows = dict(
-        inputs=rng.integers(0, p, size=(n, 16), dtype=np.uint32),
-        new_start=(rng.random(n) < 0.05).astype(np.uint8),
-        merkle_path=(rng.random(n) < 0.7).astype(np.uint8),
-        mmcs_bit=rng.integers(0, 2, size=n, dtype=np.uint8),
-        mmcs_index_sum=rng.integers(0, p, size=n, dtype=np.uint32),
-    )
-    return mats, rows
+def lookup_aux_widths(alu_lanes, horner_k):
+    """(aux EF columns, quotient chunks) per table, DESIGN.md 'LogUp' packing rule."""
+    alu_lookups = 4 * alu_lanes + 2 * (horner_k - 1)
+    return {"const": (2, 1), "public": (2, 1), "alu": ((alu_lookups + 1) // 2 + 1, 2), "poseidon2": (5, 2),
+            "recompose": (2, 1)}
 
 
-def perms_in_commit(field, log_h, log_blowup):
-    """Poseidon2 permutations one commit-phase step executes (trace fill + leaves + tree)."""
-    total = 0
-    shapes = table_shapes(field, log_h)
-    total += (1 << log_h) // 2  # K3: one per Poseidon2-table row
-    by_h = {}
-    for _, hh, w in shapes:
-        by_h.setdefault(hh << log_blowup, 0)
-        by_h[hh << log_blowup] += w
-    hmax = max(by_h)
-    for hh, w in by_h.items():
-        total += hh * ((w + 7) // 8)  # leaf / injected-row sponges
-        if hh != hmax:
-            total += hh  # injection compress
-    total += hmax - 1  # 2-to-1 compressions
-    return total, by_h
+def workload_model(field, heights, widths, packing):
+    """Analytic per-prove counts: Poseidon2 permutations and algorithmic bytes of the hash kernel."""
+    names = ["const", "public", "alu", "poseidon2", "recompose"]
+    aux = lookup_aux_widths(packing.alu_lanes, packing.horner_packed_steps)
+    B = 1 << FRI["log_blowup"]
+    perms = heights[3]  # K3: one per Poseidon2-table row
+    hash_cells = 0
+    hash_rows = 0
+
+    def commit(mats):
+        nonlocal perms, hash_cells, hash_rows
+        by_h = {}
+        for h, w in mats:
+            by_h[h] = by_h.get(h, 0) + w
+        hmax = max(by_h)
+        for h, w in by_h.items():
+            perms += h * ((w + 7) // 8)
+            hash_cells += h * w
+            hash_rows += h
+            if h != hmax:
+                perms += h
+        perms += hmax - 1
+
+    commit([(heights[i] * B, widths[i]) for i in range(5)])                       # main
+    commit([(heights[i] * B, aux[n][0] * 4) for i, n in enumerate(names)])        # permutation
+    commit([(heights[i] * B, 4) for i, n in enumerate(names) for _ in range(aux[n][1])])  # quotient chunks
+    # FRI commit phase: arity-4 folds from the tallest LDE down to 2^(log_final_poly_len+log_blowup)
+    h = max(heights) * B
+    final = 1 << (FRI["log_final_poly_len"] + FRI["log_blowup"])
+    while h > final:
+        la = min(FRI["max_log_arity"], (h // final).bit_length() - 1)
+        rows = h >> la
+        perms += rows * (((4 << la) + 7) // 8) + rows - 1
+        hash_cells += rows * (4 << la)
+        hash_rows += rows
+        h = rows
+    return perms, 4 * hash_cells + 32 * hash_rows
 
 
-def commit_phase_step(ctx, d_mats, d_rows, log_blowup, gen):
-    """K3 trace fill + K5 LDE of every main table + K6 one MMCS over all of them."""
-    tr = ctx.generate_trace_rows_resident(d_rows)
-    order = ["const", "public", "alu", "poseidon2", "recompose"]
-    srcs = dict(d_mats)
-    srcs["poseidon2"] = tr
-    ldes = [ctx.coset_lde_batch_device(srcs[k], log_blowup, gen) for k in order]
-    cap, tree = ctx.commit_device(ldes)
-    tree.free()
-    for m in ldes:
-        m.free()
-    tr.free()
-    return cap
-
-
-def cpu_baseline(field, log_h_sample, log_blowup):
-    """The oracle (kind "port", 1 thread) on a bounded sample of the same workload."""
+def cpu_baseline(field, log_h):
+    """The CPU oracle (kind 'port', single thread) proving the same table mix at a bounded size."""
+    import harness_lib
+    import layer_lib
     import oracle_lib
     orc = oracle_lib.Oracle()
-    mats, rows = synth_inputs(field, log_h_sample, 1)
+    arrs = harness_lib.generate(field, log_h, seed=1, **GEN_KNOBS)
+    prm = layer_lib.params(**FRI)
+    L = layer_lib.OracleLayer(orc, field, arrs, prm)
+    L.prep_commit()  # preprocessed commitment is cached in the reference too (NextLayerPrepCache)
     t0 = time.perf_counter()
-    tr = orc.trace_rows(field, rows["inputs"], rows["new_start"], rows["merkle_path"], rows["mmcs_bit"],
-                        rows["mmcs_index_sum"])
-    srcs = dict(mats)
-    srcs["poseidon2"] = tr
-    ldes = [orc.coset_lde(field, srcs[k], log_blowup, GEN[field])
-            for k in ["const", "public", "alu", "poseidon2", "recompose"]]
-    orc.commit(field, ldes, 0)
-    dt = time.perf_counter() - t0
-    nperm, _ = perms_in_commit(field, log_h_sample, log_blowup)
-    return dt, nperm
+    L.prove()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -109,10 +99,13 @@ def main():
     ap.add_argument("--log-height", type=int, default=20)
     ap.add_argument("--field", default="koala-bear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-log-height", type=int, default=11)
     args = ap.parse_args()
 
     import torch
+    import harness_lib
     import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import workload as wl
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -123,13 +116,16 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    field, log_h, log_blowup = args.field, args.log_height, 2
-    ctx = p3r.Context(field=field, device=local_rank, log_blowup=log_blowup)
-    mats, rows = synth_inputs(field, log_h, 0x5EED0000 + rank)
-    d_mats = {k: ctx.upload(v) for k, v in mats.items()}
-    d_rows = ctx.upload_p2_rows(rows["inputs"], rows["new_start"], rows["merkle_path"], rows["mmcs_bit"],
-                                rows["mmcs_index_sum"])
-    del mats, rows
+    field, log_h = args.field, args.log_height
+    ctx = p3r.Context(field=field, device=local_rank, **FRI)
+    arrs = harness_lib.generate(field, log_h, seed=0x5EED0000 + rank, **GEN_KNOBS)
+    packing = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    cache = p3r.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), p3r.FriRecursionBackend(),
+                                      p3r.ProveNextLayerParams(table_packing=packing))
+    cpd = cache.circuit_prover_data
+    resident = p3r.ResidentTraces(ctx, cpd, wl.traces_from_arrays(arrs))
+    counts = [int(x) for x in arrs["counts"]]
+    del arrs
 
     def barrier():
         ctx.sync()
@@ -137,13 +133,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    proof_len = 0
     for _ in range(args.warmup):
-        commit_phase_step(ctx, d_mats, d_rows, log_blowup, GEN[field])
+        proof_len = len(cache.prover.prove_all_tables(resident, cpd).proof)
     ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        commit_phase_step(ctx, d_mats, d_rows, log_blowup, GEN[field])
+        proof_len = len(cache.prover.prove_all_tables(resident, cpd).proof)
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
@@ -156,16 +153,17 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     if rank == 0:
-        nperm, by_h = perms_in_commit(field, log_h, log_blowup)
-        # dominant kernel: MMCS leaf hashing. Algorithmic bytes per launch = every LDE cell
-        # read once (4 B) + 8 digest words written per row (DESIGN.md "K6").
+        p2w = ctx.poseidon2_trace_width
+        k = packing.horner_packed_steps
+        widths = [4, 4 * packing.public_lanes, 16 * packing.alu_lanes + ((k - 1) // 2 + 2 * (k - 1) + 1) * 4, p2w,
+                  4 * packing.recompose_lanes]
+        perms, hash_bytes = workload_model(field, cpd.table_heights, widths, packing)
+        kernel_ms = {kk: v[0] / args.steps for kk, v in prof.items()}
+        dominant = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
         hash_ms, hash_launches = prof.get("mmcs_hash_rows", (0.0, 0))
-        cells = sum(hh * w for hh, w in by_h.items())
-        rows_hashed = sum(by_h)
-        alg_bytes_per_step = 4 * cells + 32 * rows_hashed
         launches_per_step = hash_launches / args.steps if args.steps else 0
         avg_launch_ms = hash_ms / hash_launches if hash_launches else float("nan")
-        achieved = (alg_bytes_per_step / launches_per_step) / (avg_launch_ms * 1e-3) / 1e9 if hash_launches else None
+        achieved = (hash_bytes / launches_per_step) / (avg_launch_ms * 1e-3) / 1e9 if hash_launches else None
         line = {
             "metric": "prove_next_layer ms + Poseidon2 perms/s, KoalaBear 2^20-row circuit, 1/8 GPU",
             "value": ms_per_step,
@@ -177,20 +175,22 @@ def main():
             "higher_is_better": False,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (31-bit Montgomery prime field)",
+            "dtype": "u32 (31-bit Montgomery prime field, degree-4 extension)",
             "data": "synthetic",
             "config": {
-                "workload": f"PARTIAL hot path: main-trace commit phase only (K3 Poseidon2 trace fill + K5 coset LDE + "
-                            f"K6 MMCS commit) of the synthetic {field} 2^{log_h}-row recursion layer "
-                            f"(tables const/public/alu/poseidon2/recompose, blowup 4); quotient/FRI not yet in the timed region",
-                "field": field, "log_height": log_h, "log_blowup": log_blowup,
-                "independent_proofs": world,
+                "workload": f"prove_all_tables (prove_next_layer after the verifier-circuit run) of the synthetic "
+                            f"{field} 2^{log_h}-row recursion layer: tables const/public/alu/poseidon2/recompose, "
+                            f"FRI blowup 4, arity<=4, 54 queries, 15-bit PoW; Traces + NextLayerPrepCache resident in HBM",
+                "field": field, "log_height": log_h, "table_heights": cpd.table_heights, "table_widths": widths,
+                "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose", "witnesses"], counts)),
+                "fri": FRI, "independent_proofs": world, "proof_bytes": proof_len,
             },
-            "poseidon2_perms_per_s": nperm * world / (ms_per_step * 1e-3),
-            "poseidon2_perms_per_step": nperm,
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "poseidon2_perms_per_s": perms * world / (ms_per_step * 1e-3),
+            "poseidon2_perms_per_step": perms,
+            "kernel_ms_per_step": kernel_ms,
+            "dominant_kernel_family": dominant,
             "roofline": {
-                "kernel": "k_mmcs_hash_rows",
+                "kernel": "k_mmcs_hash_rows (+ strided variant)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -198,21 +198,23 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": None,
                 "avg_launch_ms": avg_launch_ms,
-                "algorithmic_bytes_per_launch": alg_bytes_per_step / launches_per_step if launches_per_step else None,
-                "note": "Poseidon2 hashing is integer-VALU bound, not HBM bound (616 modmul per 32 B absorbed); "
-                        "see DESIGN.md for the VALU ceiling next to this HBM figure",
+                "algorithmic_bytes_per_launch": hash_bytes / launches_per_step if launches_per_step else None,
+                "note": "MMCS leaf hashing is integer-VALU bound (one Poseidon2 permutation per 32 B absorbed), "
+                        "not HBM bound; DESIGN.md gives the VALU ceiling next to this HBM figure",
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            sample_log_h = 11
-            cdt, cperm = cpu_baseline(field, sample_log_h, log_blowup)
+            lh = args.cpu_baseline_log_height
+            cdt = cpu_baseline(field, lh)
             line["cpu_baseline"] = {
                 "value": cdt * 1e3, "unit": "ms", "cores": 1, "kind": "port",
-                "sample": f"same commit phase on the same table mix at 2^{sample_log_h} rows "
-                          f"(1/{1 << (log_h - sample_log_h)} of the workload), oracle/ C++ restatement, 1 thread",
-                "poseidon2_perms_per_s": cperm / cdt,
+                "sample": f"same prove (same table mix, same FRI parameters) at 2^{lh} rows = 1/{1 << (log_h - lh)} "
+                          f"of the workload, oracle/ C++ restatement, 1 thread",
             }
         print(json.dumps(line))
+    resident.free()
+    cpd.free()
+    ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 
