@@ -40,7 +40,64 @@ struct Error : std::runtime_error {
                   #expr, hipGetErrorString(e_));                                        \
   } while (0)
 
-// RAII device buffer of u32 cells.
+// Device memory pool.  A prove allocates and drops dozens of multi-hundred-MB temporaries;
+// hipMalloc/hipFree each cost a device-wide synchronisation plus page-table work, so freed
+// blocks are kept in exact-size free lists and reused.  Safe without extra synchronisation
+// because every user of a ctx enqueues on ONE stream: a block handed out again is only
+// touched by work ordered after the work that used it before.  (Blocking copies therefore
+// go through h2d_sync below, never through the NULL stream.)
+struct DevPool {
+  std::map<size_t, std::vector<void*>> free_lists;
+  size_t cached_bytes = 0;
+  static size_t round_up(size_t bytes) {
+    const size_t g = bytes < (size_t(1) << 20) ? 256 : (size_t(1) << 20);
+    return (bytes + g - 1) / g * g;
+  }
+  void* get(size_t bytes) {
+    bytes = round_up(bytes);
+    auto it = free_lists.find(bytes);
+    if (it != free_lists.end() && !it->second.empty()) {
+      void* p = it->second.back();
+      it->second.pop_back();
+      cached_bytes -= bytes;
+      return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory && cached_bytes) {
+      trim();
+      e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess)
+      fail(e == hipErrorOutOfMemory ? P3R_ENOMEM : P3R_EHIP, "hipMalloc(%zu bytes) failed: %s", bytes,
+           hipGetErrorString(e));
+    return p;
+  }
+  void put(void* p, size_t bytes) {
+    bytes = round_up(bytes);
+    free_lists[bytes].push_back(p);
+    cached_bytes += bytes;
+  }
+  void trim() {
+    for (auto& kv : free_lists)
+      for (void* p : kv.second) (void)hipFree(p);
+    free_lists.clear();
+    cached_bytes = 0;
+  }
+};
+inline DevPool& dev_pool() {
+  static DevPool pool;
+  return pool;
+}
+
+// Blocking host->device / device->host copy ordered on the ctx stream.
+inline hipError_t copy_sync(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);
+}
+
+// RAII device buffer of u32 cells (pooled).
 struct DevBuf {
   uint32_t* p = nullptr;
   size_t n = 0;
@@ -56,11 +113,11 @@ struct DevBuf {
   ~DevBuf() { release(); }
   void alloc(size_t cells) {
     release();
-    if (cells) P3R_HIP(hipMalloc((void**)&p, cells * sizeof(uint32_t)));
+    if (cells) p = static_cast<uint32_t*>(dev_pool().get(cells * sizeof(uint32_t)));
     n = cells;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_pool().put(p, n * sizeof(uint32_t));
     p = nullptr;
     n = 0;
   }

@@ -266,9 +266,9 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
       }
     }
     L->alu_plan.alloc((S.entries.size() * sizeof(AluPlanEntry) + 3) / 4);
-    P3R_HIP(hipMemcpy(L->alu_plan.p, S.entries.data(), S.entries.size() * sizeof(AluPlanEntry), hipMemcpyHostToDevice));
+    P3R_HIP(copy_sync(ctx->stream, L->alu_plan.p, S.entries.data(), S.entries.size() * sizeof(AluPlanEntry), hipMemcpyHostToDevice));
     L->alu_prev_src.alloc(S.prev_src.size());
-    P3R_HIP(hipMemcpy(L->alu_prev_src.p, S.prev_src.data(), S.prev_src.size() * 4, hipMemcpyHostToDevice));
+    P3R_HIP(copy_sync(ctx->stream, L->alu_prev_src.p, S.prev_src.data(), S.prev_src.size() * 4, hipMemcpyHostToDevice));
   }
   // Poseidon2 preprocessed rows (air.rs:697-794, non-compact D=4 layout) + padding (:613-649)
   {

@@ -50,7 +50,6 @@ std::unique_ptr<p3r_dmat> upload(p3r_ctx* ctx, const uint32_t* rowmajor, size_t 
   hipLaunchKernelGGL(k_rowmajor_to_colmajor<PP>, grid, dim3(kBlock), 0, ctx->stream, stage.p,
                      m->d, (uint32_t)h, (uint32_t)w, 1);
   P3R_HIP(hipGetLastError());
-  P3R_HIP(hipStreamSynchronize(ctx->stream));  // stage dies here
   return m;
 }
 
@@ -134,7 +133,6 @@ std::unique_ptr<p3r_dmat> trace_fill(p3r_ctx* ctx, const p3r_p2_dev* rows) {
                        rows->inputs->d, f8 + 2 * n, acc.p, trace->d, n, ctx->rc.p);
   }
   P3R_HIP(hipGetLastError());
-  P3R_HIP(hipStreamSynchronize(ctx->stream));  // temporaries die here
   return trace;
 }
 
@@ -155,7 +153,7 @@ const uint32_t* get_tw_sub(p3r_ctx* ctx, int log_r, int inverse) {
     x *= root;
   }
   DevBuf d(half);
-  P3R_HIP(hipMemcpy(d.p, t.data(), half * 4, hipMemcpyHostToDevice));
+  P3R_HIP(copy_sync(ctx->stream, d.p, t.data(), half * 4, hipMemcpyHostToDevice));
   return ctx->tw_sub.emplace(key, std::move(d)).first->second.p;
 }
 
@@ -181,8 +179,8 @@ std::pair<const uint32_t*, const uint32_t*> get_tw4(p3r_ctx* ctx, int log_n, int
       x *= step;
     }
     DevBuf dlo(1024), dhi(n_hi);
-    P3R_HIP(hipMemcpy(dlo.p, lo.data(), 1024 * 4, hipMemcpyHostToDevice));
-    P3R_HIP(hipMemcpy(dhi.p, hi.data(), n_hi * 4, hipMemcpyHostToDevice));
+    P3R_HIP(copy_sync(ctx->stream, dlo.p, lo.data(), 1024 * 4, hipMemcpyHostToDevice));
+    P3R_HIP(copy_sync(ctx->stream, dhi.p, hi.data(), n_hi * 4, hipMemcpyHostToDevice));
     it = ctx->tw4.emplace(key, std::make_pair(std::move(dlo), std::move(dhi))).first;
   }
   return {it->second.first.p, it->second.second.p};
@@ -216,8 +214,8 @@ std::pair<const uint32_t*, const uint32_t*> get_pre(p3r_ctx* ctx, int log_n, int
       }
     }
     DevBuf da(a.size()), db(b.size());
-    P3R_HIP(hipMemcpy(da.p, a.data(), a.size() * 4, hipMemcpyHostToDevice));
-    P3R_HIP(hipMemcpy(db.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    P3R_HIP(copy_sync(ctx->stream, da.p, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+    P3R_HIP(copy_sync(ctx->stream, db.p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     it = ctx->pre.emplace(key, std::make_pair(std::move(da), std::move(db))).first;
   }
   return {it->second.first.p, it->second.second.p};
@@ -314,9 +312,7 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
     p.log_n1 = la + added_bits; p.log_n2 = lb; p.sub_dim = 1; p.out_mode = 0;
     p.tw_sub = get_tw_sub<PP>(ctx, lb, 0);
     launch_ntt<PP>(ctx, p, w, 1, "ntt_forward");
-    P3R_HIP(hipStreamSynchronize(ctx->stream));  // tmp dies here
   }
-  P3R_HIP(hipStreamSynchronize(ctx->stream));  // coef dies here
   return out;
 }
 
@@ -326,19 +322,13 @@ void hash_rows(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats, size_t h,
   std::vector<const uint32_t*> cols;
   for (const p3r_dmat* m : mats)
     for (size_t c = 0; c < m->w; ++c) cols.push_back(m->d + c * m->h);
-  const uint32_t** dcols = nullptr;
-  P3R_HIP(hipMalloc((void**)&dcols, cols.size() * sizeof(void*)));
-  hipError_t e = hipMemcpyAsync(dcols, cols.data(), cols.size() * sizeof(void*),
-                                hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) {
-    ProfScope ps(ctx, "mmcs_hash_rows");
-    hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream,
-                       (const uint32_t* const*)dcols, (int)cols.size(), h, dig, ctx->rc.p);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(dcols);
-  P3R_HIP(e);
+  DevBuf dcols_buf(cols.size() * sizeof(void*) / sizeof(uint32_t));
+  const uint32_t** dcols = reinterpret_cast<const uint32_t**>(dcols_buf.p);
+  P3R_HIP(copy_sync(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice));
+  ProfScope ps(ctx, "mmcs_hash_rows");
+  hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream,
+                     (const uint32_t* const*)dcols, (int)cols.size(), h, dig, ctx->rc.p);
+  P3R_HIP(hipGetLastError());
 }
 
 template <class PP>
@@ -391,7 +381,6 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
                            next.p, nn, 1, 0, idig.p, nn, 1, 0, next.p, nn, ctx->rc.p);
       }
       P3R_HIP(hipGetLastError());
-      P3R_HIP(hipStreamSynchronize(ctx->stream));  // idig dies here
     }
     tree->layers.push_back(std::move(next));
     n = nn;
@@ -450,7 +439,7 @@ void init_ctx(p3r_ctx* ctx) {
     mont[i] = F::from_canonical(src[i]).v;
   }
   ctx->rc.alloc(nrc);
-  P3R_HIP(hipMemcpy(ctx->rc.p, mont.data(), nrc * 4, hipMemcpyHostToDevice));
+  P3R_HIP(copy_sync(ctx->stream, ctx->rc.p, mont.data(), nrc * 4, hipMemcpyHostToDevice));
   ctx->partial_rounds = PP::PARTIAL_ROUNDS;
   ctx->cfg.poseidon2_rc = nullptr;  // caller's pointer is not retained
   P3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_tile<PP>),
@@ -499,6 +488,7 @@ void p3r_destroy(p3r_ctx* ctx) {
   prof_clear(ctx);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  dev_pool().trim();
 }
 
 const char* p3r_last_error(const p3r_ctx* ctx) {

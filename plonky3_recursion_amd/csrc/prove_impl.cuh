@@ -313,7 +313,6 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       ck.lde = coset_lde<PP>(ctx, ck.evals.get(), log_blowup, (gen * ck.shift.inv()).to_canonical());
       chunks.push_back(std::move(ck));
     }
-    P3R_HIP(hipStreamSynchronize(ctx->stream));  // d_apow dies here
     chunk_bufs_keep.push_back(std::move(chunk_buf));
   }
   ptrs.clear();
@@ -432,18 +431,16 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       std::vector<const uint32_t*> cols;
       for (size_t j = 0; j < arity; ++j)
         for (int k = 0; k < 4; ++k) cols.push_back(folded.p + (size_t)k * n_in + j);
-      const uint32_t** dcols = nullptr;
-      P3R_HIP(hipMalloc((void**)&dcols, cols.size() * sizeof(void*)));
-      P3R_HIP(hipMemcpyAsync(dcols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+      DevBuf dcols_buf(cols.size() * sizeof(void*) / sizeof(uint32_t));
+      const uint32_t** dcols = reinterpret_cast<const uint32_t**>(dcols_buf.p);
+      P3R_HIP(copy_sync(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice));
       {
         ProfScope ps(ctx, "mmcs_hash_rows");
         hipLaunchKernelGGL(k_mmcs_hash_rows_strided<PP>, dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream,
                            (const uint32_t* const*)dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p,
                            ctx->rc.p);
       }
-      hipError_t e = hipStreamSynchronize(ctx->stream);
-      (void)hipFree(dcols);
-      P3R_HIP(e);
+      P3R_HIP(hipGetLastError());
     }
     build_plain_layers<PP>(ctx, ph.tree.get(), rows);
     ph.cap = download_cap_mont<PP>(ctx, ph.tree.get());
@@ -584,8 +581,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   }
   std::vector<uint32_t> gathered(cursor);
   {
-    GatherDesc* d_descs = nullptr;
-    P3R_HIP(hipMalloc((void**)&d_descs, descs.size() * sizeof(GatherDesc)));
+    DevBuf descs_buf((descs.size() * sizeof(GatherDesc) + 3) / 4);
+    GatherDesc* d_descs = reinterpret_cast<GatherDesc*>(descs_buf.p);
     DevBuf d_out(cursor);
     hipError_t e = hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(GatherDesc), hipMemcpyHostToDevice,
                                   ctx->stream);
@@ -597,7 +594,6 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     if (e == hipSuccess)
       e = hipMemcpyAsync(gathered.data(), d_out.p, (size_t)cursor * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_descs);
     P3R_HIP(e);
   }
 
