@@ -341,14 +341,67 @@ struct NttPass {
   const uint32_t* pre_b;
   uint32_t scale;           // Montgomery; multiplied into every output when use_scale
   int use_scale;
+  int inverse;              // direction (selects root16)
+  uint32_t root16[8];       // w_16^k (or its inverse), k < 8: constants of the register radix-16
 };
 
 __device__ __forceinline__ uint32_t lds_addr(uint32_t r, uint32_t t, uint32_t T) {
   return r * (T + 1) + (r >> 5) + t;
 }
 
+constexpr int kNttBlock = 1024;  // one radix-16 group per lane per stage group at 2^14-cell tiles
+// LOGM consecutive DIF stages (s .. s+LOGM-1) of the size-R sub-NTT done in registers: a lane
+// owns the 2^LOGM rows r0 + j*q (q = R >> (s+LOGM)) of one tile column.  Stage s+u pairs
+// (j, j + M/2^(u+1)) with twiddle w_R^{(i << (s+u))}, i = row mod half, which factors into
+// w_M^{jj << u} (a 16th root of unity, `root16`) times (w_R^{low << s})^{2^u}.
+template <class PP, int LOGM>
+__device__ __forceinline__ void ntt_stage_group(uint32_t* tile, const uint32_t* tws, const uint32_t* root16,
+                                                int s, int log_r, int log_t, uint32_t tid) {
+  using F = Fp<PP>;
+  constexpr int M = 1 << LOGM;
+  const uint32_t T = 1u << log_t;
+  const int lq = log_r - s - LOGM;
+  const uint32_t q = 1u << lq;
+  const uint32_t items = (1u << (log_r - LOGM)) << log_t;
+  for (uint32_t e = tid; e < items; e += kNttBlock) {
+    const uint32_t t = e & (T - 1), b = e >> log_t;
+    const uint32_t low = b & (q - 1), high = b >> lq;
+    const uint32_t r0 = (high << (lq + LOGM)) | low;
+    F x[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) x[j] = F::raw(tile[lds_addr(r0 + j * q, t, T)]);
+    F wu = F::raw(tws[low << s]);
+#pragma unroll
+    for (int u = 0; u < LOGM; ++u) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int half = M >> (u + 1);
+      F tw[M / 2];
+      tw[0] = wu;
+#pragma unroll
+      for (int jj = 1; jj < M / 2; ++jj)
+        if (jj < half) tw[jj] = wu * F::raw(root16[(jj << u) << (4 - LOGM)]);
+#pragma unroll
+      for (int blk = 0; blk < M; blk += 2 * half) {
+#pragma unroll
+        for (int jj = 0; jj < M / 2; ++jj) {
+          if (jj < half) {
+            F p = x[blk + jj], c = x[blk + jj + half];
+            x[blk + jj] = p + c;
+            x[blk + jj + half] = (p - c) * tw[jj];
+          }
+        }
+      }
+      wu = wu.sqr();
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) tile[lds_addr(r0 + j * q, t, T)] = x[j].v;
+  }
+  __syncthreads();
+}
+
 template <class PP>
-__global__ void __launch_bounds__(kBlock) k_ntt_tile(NttPass a) {
+__global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
   using F = Fp<PP>;
   extern __shared__ uint32_t lds[];
   const uint32_t tid = threadIdx.x;
@@ -364,11 +417,11 @@ __global__ void __launch_bounds__(kBlock) k_ntt_tile(NttPass a) {
   const uint32_t* pre_a = a.pre_a ? a.pre_a + (size_t)blockIdx.z * N1 : nullptr;
   const uint32_t* pre_b = a.pre_b ? a.pre_b + (size_t)blockIdx.z * N2 : nullptr;
 
-  for (uint32_t i = tid; i < (R >> 1); i += kBlock) tws[i] = a.tw_sub[i];
+  for (uint32_t i = tid; i < (R >> 1); i += kNttBlock) tws[i] = a.tw_sub[i];
 
   const uint32_t E = R << a.log_t;
   // ---- load (lanes run along the unit-stride global dimension) ----
-  for (uint32_t e = tid; e < E; e += kBlock) {
+  for (uint32_t e = tid; e < E; e += kNttBlock) {
     uint32_t r, t, n1, n2;
     if (a.sub_dim == 0) {
       t = e & (T - 1); r = e >> a.log_t; n1 = r; n2 = line0 + t;
@@ -380,25 +433,17 @@ __global__ void __launch_bounds__(kBlock) k_ntt_tile(NttPass a) {
     tile[lds_addr(r, t, T)] = v.v;
   }
   __syncthreads();
-  // ---- DIF butterflies: stage s pairs rows (r0, r0 + half), twiddle w_R^{i << s} ----
-  const uint32_t nb = E >> 1;
-  for (int s = 0; s < log_r; ++s) {
-    const uint32_t log_half = log_r - 1 - s;
-    const uint32_t half = 1u << log_half;
-    for (uint32_t e = tid; e < nb; e += kBlock) {
-      uint32_t t = e & (T - 1), q = e >> a.log_t;
-      uint32_t i = q & (half - 1), blk = q >> log_half;
-      uint32_t r0 = (blk << (log_half + 1)) + i;
-      uint32_t a0 = lds_addr(r0, t, T), a1 = lds_addr(r0 + half, t, T);
-      F x = F::raw(tile[a0]), y = F::raw(tile[a1]);
-      tile[a0] = (x + y).v;
-      tile[a1] = ((x - y) * F::raw(tws[i << s])).v;
-    }
-    __syncthreads();
+  // ---- DIF butterflies, up to four stages per LDS round trip (register radix-16) ----
+  {
+    int s = 0;
+    while (log_r - s >= 4) { ntt_stage_group<PP, 4>(tile, tws, a.root16, s, log_r, a.log_t, tid); s += 4; }
+    if (log_r - s == 3) ntt_stage_group<PP, 3>(tile, tws, a.root16, s, log_r, a.log_t, tid);
+    else if (log_r - s == 2) ntt_stage_group<PP, 2>(tile, tws, a.root16, s, log_r, a.log_t, tid);
+    else if (log_r - s == 1) ntt_stage_group<PP, 1>(tile, tws, a.root16, s, log_r, a.log_t, tid);
   }
   // ---- store ----
   const F scale = F::raw(a.scale);
-  for (uint32_t e = tid; e < E; e += kBlock) {
+  for (uint32_t e = tid; e < E; e += kNttBlock) {
     uint32_t rho, t;  // rho: row index in the OUTPUT geometry
     bool lanes_along_t = (a.sub_dim == 0 && a.out_mode != 2);
     if (lanes_along_t) {

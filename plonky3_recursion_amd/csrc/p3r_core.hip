@@ -229,12 +229,19 @@ void launch_ntt(p3r_ctx* ctx, NttPass a, size_t ncols, size_t ncosets, const cha
   if (a.sub_dim == 0 && log_t > 5) log_t = 5;  // 128-byte segments are enough when strided
   log_t = std::min(log_t, log_lines);
   a.log_t = log_t;
+  {
+    using F = Fp<PP>;
+    F w16 = F::two_adic_generator(4);
+    if (a.inverse) w16 = w16.inv();
+    F x = F::one();
+    for (int k = 0; k < 8; ++k) { a.root16[k] = x.v; x *= w16; }
+  }
   const size_t R = size_t(1) << log_r, T = size_t(1) << log_t;
   size_t lds = (R * (T + 1) + (R >> 5) + 1 + (R >> 1) + 1) * sizeof(uint32_t);
   if (lds > 160 * 1024) fail(P3R_EUNSUPPORTED, "NTT tile of 2^%d rows does not fit LDS", log_r);
   dim3 grid((unsigned)(size_t(1) << (log_lines - log_t)), (unsigned)ncols, (unsigned)ncosets);
   ProfScope ps(ctx, name);
-  hipLaunchKernelGGL(k_ntt_tile<PP>, grid, dim3(kBlock), lds, ctx->stream, a);
+  hipLaunchKernelGGL(k_ntt_tile<PP>, grid, dim3(kNttBlock), lds, ctx->stream, a);
   P3R_HIP(hipGetLastError());
 }
 
@@ -261,7 +268,7 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
     p.in = in->d; p.out = coef.p;
     p.in_col_stride = N; p.out_col_stride = N; p.out_coset_stride = 0;
     p.log_n1 = 0; p.log_n2 = log_n; p.sub_dim = 1; p.out_mode = 1;
-    p.tw_sub = get_tw_sub<PP>(ctx, log_n, 1);
+    p.tw_sub = get_tw_sub<PP>(ctx, log_n, 1); p.inverse = 1;
     p.scale = inv_n; p.use_scale = 1;
     launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
     auto pre = get_pre<PP>(ctx, log_n, 0, log_n, added_bits, shift);
@@ -281,7 +288,7 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
     p.in = in->d; p.out = tmp.p;
     p.in_col_stride = N; p.out_col_stride = N;
     p.log_n1 = la; p.log_n2 = lb; p.sub_dim = 0; p.out_mode = 2;
-    p.tw_sub = get_tw_sub<PP>(ctx, la, 1);
+    p.tw_sub = get_tw_sub<PP>(ctx, la, 1); p.inverse = 1;
     p.tw4_lo = tw4i.first; p.tw4_hi = tw4i.second;
     launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
     // inverse pass 2: tmp viewed as [N2][N1]; size-N2 transforms along its first dim,
@@ -290,7 +297,7 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
     p.in = tmp.p; p.out = coef.p;
     p.in_col_stride = N; p.out_col_stride = N;
     p.log_n1 = lb; p.log_n2 = la; p.sub_dim = 0; p.out_mode = 1;
-    p.tw_sub = get_tw_sub<PP>(ctx, lb, 1);
+    p.tw_sub = get_tw_sub<PP>(ctx, lb, 1); p.inverse = 1;
     p.scale = inv_n; p.use_scale = 1;
     launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
     // forward pass 1 (all cosets): scale by s_z^k, size-N1 transforms along n1, twiddle, in place rows
