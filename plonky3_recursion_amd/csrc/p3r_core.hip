@@ -2,6 +2,7 @@
 // Host orchestration only; all arithmetic on data runs in the gfx950 kernels of kernels.cuh.
 #include "context.h"
 #include "kernels.cuh"
+#include "kernels_stark.cuh"
 #include "poseidon2_rc_default.inc"
 #include "profile.h"
 
@@ -338,6 +339,25 @@ void hash_rows(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats, size_t h,
   P3R_HIP(hipGetLastError());
 }
 
+// Remaining plain layers (no injections) below a layer of n <= kTreeTopMax digests, one launch.
+template <class PP>
+void tree_top(p3r_ctx* ctx, p3r_tree* tree, size_t n) {
+  const size_t cap_n = size_t(1) << tree->cap_height;
+  if (n <= cap_n) return;
+  const uint32_t* top = tree->layers.back().p;
+  TreeTopLayers tl{};
+  int l = 0;
+  for (size_t m = n / 2; m >= cap_n; m /= 2) {
+    tree->layers.emplace_back(P2_DIGEST * m);
+    tl.p[l++] = tree->layers.back().p;
+    if (m == 1) break;
+  }
+  ProfScope ps(ctx, "mmcs_compress");
+  hipLaunchKernelGGL(k_mmcs_tree_top<PP>, dim3(1), dim3(1024), 0, ctx->stream, top, (int)n, (int)cap_n, tl,
+                     ctx->rc.p);
+  P3R_HIP(hipGetLastError());
+}
+
 template <class PP>
 void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   using F = Fp<PP>;
@@ -368,7 +388,13 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   hash_rows<PP>(ctx, at_height(hmax), hmax, tree->layers[0].p);
   size_t n = hmax;
   const size_t cap_n = size_t(1) << tree->cap_height;
+  size_t min_h = hmax;
+  for (auto* m : mats) min_h = std::min(min_h, m->h);
   while (n > cap_n) {
+    if (n <= (size_t)kTreeTopMax && min_h >= n) {  // nothing left to inject below this layer
+      tree_top<PP>(ctx, tree, n);
+      break;
+    }
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;

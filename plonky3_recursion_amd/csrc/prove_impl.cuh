@@ -81,6 +81,10 @@ void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves) {
   size_t n = n_leaves;
   const size_t cap_n = size_t(1) << tree->cap_height;
   while (n > cap_n) {
+    if (n <= (size_t)kTreeTopMax) {
+      tree_top<PP>(ctx, tree, n);
+      break;
+    }
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;
