@@ -1,0 +1,112 @@
+"""2-to-1 aggregation tree across the GPUs of one node.
+
+Reference: `prove_aggregation_layer` (recursion/src/recursion.rs:656-762) proves one tree node;
+the tree driver is the serial `for pair_idx` loop of recursion/examples/recursive_aggregation.rs:423-476,
+which the book calls embarrassingly parallel (book/src/user_guide/aggregation.md).  Nodes of one
+level are independent, so they shard over ranks with NO data-path collective; the only exchange is
+moving finished child proofs (hundreds of kB) to the rank that proves the parent, and the final
+root hand-off to rank 0.  One process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+What is NOT here: running the parent's verifier circuit over the two child proofs.  That is the
+reference's CPU `CircuitRunner` (out of scope); the scheduler takes it as
+the `make_traces(level, node, child_proofs)` callback that returns the parent's `Traces`.
+"""
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import numpy as np
+
+
+@dataclass
+class TreePlan:
+    """Static placement: node i of level l runs on rank (i * stride_l) % world, stride_l = 2^l,
+    so a parent lives where its LEFT child lived and only the right child's proof moves."""
+    n_leaves: int
+    world: int
+
+    def __post_init__(self):
+        if self.n_leaves < 1 or self.n_leaves & (self.n_leaves - 1):
+            raise ValueError("n_leaves must be a power of two")
+
+    @property
+    def levels(self):
+        return self.n_leaves.bit_length()  # leaves are level 0, root is level log2(n)
+
+    def nodes(self, level):
+        return self.n_leaves >> level
+
+    def owner(self, level, node):
+        return (node << level) % self.world
+
+    def my_nodes(self, level, rank):
+        return [i for i in range(self.nodes(level)) if self.owner(level, i) == rank]
+
+
+def _send_bytes(dist, payload: bytes, dst: int, device):
+    import torch
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    dist.send(n, dst)
+    buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    dist.send(buf, dst)
+
+
+def _recv_bytes(dist, src: int, device) -> bytes:
+    import torch
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.recv(n, src)
+    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=device)
+    dist.recv(buf, src)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], bytes],
+                         prove_parent: Callable[[int, int, bytes, bytes], bytes], dist=None,
+                         device="cpu") -> Optional[bytes]:
+    """Proves every node this rank owns, level by level; returns the root proof on rank 0.
+
+    prove_leaf(i) -> proof bytes of leaf i.
+    prove_parent(level, node, left_proof, right_proof) -> proof bytes (the caller runs the verifier
+    circuit over the two children and calls `prove_aggregation_layer`'s GPU part).
+    `dist` is torch.distributed (None for a single process)."""
+    proofs = {i: prove_leaf(i) for i in plan.my_nodes(0, rank)}
+    for level in range(1, plan.levels):
+        nxt = {}
+        # ship right children to the parent's owner (left child already lives there)
+        for node in range(plan.nodes(level)):
+            parent_rank = plan.owner(level, node)
+            right = 2 * node + 1
+            right_rank = plan.owner(level - 1, right)
+            if right_rank == parent_rank:
+                continue
+            if rank == right_rank:
+                _send_bytes(dist, proofs[right], parent_rank, device)
+            elif rank == parent_rank:
+                proofs[right] = _recv_bytes(dist, right_rank, device)
+        for node in plan.my_nodes(level, rank):
+            nxt[node] = prove_parent(level, node, proofs[2 * node], proofs[2 * node + 1])
+        proofs = nxt
+    # final root hand-off to rank 0
+    root_level = plan.levels - 1
+    root_rank = plan.owner(root_level, 0)
+    if root_rank == 0:
+        return proofs.get(0) if rank == 0 else None
+    if rank == root_rank:
+        _send_bytes(dist, proofs[0], 0, device)
+        return None
+    if rank == 0:
+        return _recv_bytes(dist, root_rank, device)
+    return None
+
+
+def gather_proofs_to_root(proof: bytes, dist, rank: int, world: int, device="cpu") -> Optional[List[bytes]]:
+    """Independent proofs (one per rank) handed to rank 0: used by bench.py's weak-scaling run."""
+    if dist is None or world == 1:
+        return [proof]
+    if rank == 0:
+        out = [proof]
+        for src in range(1, world):
+            out.append(_recv_bytes(dist, src, device))
+        return out
+    _send_bytes(dist, proof, 0, device)
+    return None
