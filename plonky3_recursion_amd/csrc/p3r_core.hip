@@ -18,6 +18,8 @@ thread_local std::string g_create_error;
 template <class Fn>
 int guard(p3r_ctx* ctx, Fn&& fn) {
   try {
+    // the calling thread's current device may have been changed by the embedding framework
+    if (ctx) (void)hipSetDevice(ctx->cfg.device);
     fn();
     return P3R_OK;
   } catch (const Error& e) {

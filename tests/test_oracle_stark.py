@@ -1,0 +1,95 @@
+"""CPU: the oracle's batch-STARK prover against its own verifier (a restatement of the in-tree
+circuit verifier, recursion/src/verifier/batch_stark.rs + pcs/fri/verifier.rs) on synthetic
+recursion layers; prove -> verify round trips and the reference's negative-test patterns
+(tampered proof bytes, unsatisfied trace, unbalanced lookup: circuit-prover/src/batch_stark_prover/tests.rs,
+recursion/tests/test_lookups.rs)."""
+import numpy as np
+import pytest
+
+import harness_lib
+import layer_lib
+
+SMALL = dict(horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+
+
+@pytest.mark.parametrize("field", ["koala-bear", "baby-bear"])
+@pytest.mark.parametrize("log_h,kw", [
+    (5, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=0)),
+    (7, dict(log_blowup=2, max_log_arity=3, log_final_poly_len=2)),
+    (7, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, cap_height=2)),
+])
+def test_prove_verify_roundtrip(oracle, field, log_h, kw):
+    arrs = harness_lib.generate(field, log_h, seed=log_h, **SMALL)
+    prm = layer_lib.params(query_pow_bits=3, num_queries=5, **kw)
+    L = layer_lib.OracleLayer(oracle, field, arrs, prm)
+    pf = L.prove()
+    L.verify(pf)
+    assert L.prove() == pf  # deterministic (smallest PoW witness)
+    # canonical field encoding round trip
+    L.verify(L.prove(field_encoding=1), field_encoding=1)
+    # every 97th byte flipped must be rejected
+    for pos in range(7, len(pf), max(len(pf) // 40, 1)):
+        bad = bytearray(pf)
+        bad[pos] ^= 1
+        with pytest.raises(RuntimeError):
+            L.verify(bytes(bad))
+
+
+def test_table_shapes_follow_reference_formulas(oracle):
+    arrs = harness_lib.generate("koala-bear", 6, **SMALL)
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=3)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm)
+    t = {x["kind"]: x for x in L.tables()}
+    # SURVEY.md appendix B / shape_golden.rs: D=4, alu_lanes=3, K=4
+    assert t["const"]["main"].shape[1] == 4 and t["const"]["prep"].shape[1] == 2
+    assert t["alu"]["main"].shape[1] == 3 * 16 + (1 + 6 + 1) * 4 == 80
+    assert t["alu"]["prep"].shape[1] == 3 * 13 + 7 * 3 == 60
+    assert t["poseidon2"]["main"].shape[1] == 166 and t["poseidon2"]["prep"].shape[1] == 24
+    assert t["recompose"]["main"].shape[1] == 4 and t["recompose"]["prep"].shape[1] == 2
+    mh = layer_lib.min_trace_height(prm)  # packing.rs:100-106
+    assert all(x["main"].shape[0] >= mh and x["main"].shape[0] == x["prep"].shape[0] for x in L.tables())
+    # preprocessed padding rule of the Poseidon2 table (air.rs:644-646)
+    n_p2 = int(arrs["counts"][3])
+    prep = t["poseidon2"]["prep"]
+    if prep.shape[0] > n_p2:
+        assert prep[n_p2, 22] == 1 and not prep[n_p2 + 1:].any()
+
+
+@pytest.mark.parametrize("packing", [dict(alu_lanes=1, horner_packed_steps=2), dict(alu_lanes=2, horner_packed_steps=3, public_lanes=2),
+                                     dict(alu_lanes=4, horner_packed_steps=6, recompose_lanes=2)])
+def test_lane_and_pack_variants(oracle, packing):
+    arrs = harness_lib.generate("koala-bear", 6, seed=3, horner_chain_len=17, sponge_chain_len=3, merkle_depth=4)
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=3)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=packing)
+    L.verify(L.prove())
+
+
+def test_unsatisfied_trace_is_rejected(oracle):
+    arrs = harness_lib.generate("koala-bear", 6, **SMALL)
+    arrs["alu_values"][5] = (int(arrs["alu_values"][5]) + 1) % 0x7F000001
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=4)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm)
+    with pytest.raises(RuntimeError, match="constraints do not match|final polynomial"):
+        L.verify(L.prove())
+
+
+def test_unbalanced_lookup_is_rejected(oracle):
+    arrs = harness_lib.generate("koala-bear", 6, **SMALL)
+    arrs["const_prep"][2] = int(arrs["const_prep"][2]) + 1  # one extra read that nobody performs
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=4)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm)
+    with pytest.raises(RuntimeError, match="terminals do not sum to zero"):
+        L.verify(L.prove())
+
+
+def test_poseidon2_chain_break_is_rejected(oracle):
+    arrs = harness_lib.generate("koala-bear", 6, **SMALL)
+    fl = arrs["p2_flags"].reshape(-1, 4)
+    # find a sponge continuation row and corrupt a chained (non-CTL) capacity input
+    rows = [r for r in range(1, len(fl)) if not fl[r, 0] and not fl[r, 1]]
+    assert rows
+    arrs["p2_inputs"][rows[0] * 16 + 12] = (int(arrs["p2_inputs"][rows[0] * 16 + 12]) + 1) % 0x7F000001
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=4)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm)
+    with pytest.raises(RuntimeError):
+        L.verify(L.prove())
