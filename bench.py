@@ -137,7 +137,6 @@ def main():
     last_proof = b""
     for _ in range(args.warmup):
         proof_len = len(cache.prover.prove_all_tables(resident, cpd).proof)
-    ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -159,6 +158,12 @@ def main():
                 assert len(got) == world
         except Exception as e:  # never let the hand-off demo break the measurement
             handoff_ms = f"failed: {e}"
+    # per-kernel-family times come from two EXTRA steps with HIP-event bracketing switched on, so
+    # the event overhead is not inside `value`
+    prof_steps = 2
+    ctx.profile_enable(True)
+    for _ in range(prof_steps):
+        cache.prover.prove_all_tables(resident, cpd)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
 
@@ -174,10 +179,10 @@ def main():
         widths = [4, 4 * packing.public_lanes, 16 * packing.alu_lanes + ((k - 1) // 2 + 2 * (k - 1) + 1) * 4, p2w,
                   4 * packing.recompose_lanes]
         perms, hash_bytes = workload_model(field, cpd.table_heights, widths, packing)
-        kernel_ms = {kk: v[0] / args.steps for kk, v in prof.items()}
+        kernel_ms = {kk: v[0] / prof_steps for kk, v in prof.items()}
         dominant = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
         hash_ms, hash_launches = prof.get("mmcs_hash_rows", (0.0, 0))
-        launches_per_step = hash_launches / args.steps if args.steps else 0
+        launches_per_step = hash_launches / prof_steps
         avg_launch_ms = hash_ms / hash_launches if hash_launches else float("nan")
         achieved = (hash_bytes / launches_per_step) / (avg_launch_ms * 1e-3) / 1e9 if hash_launches else None
         line = {

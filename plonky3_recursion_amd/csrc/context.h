@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>

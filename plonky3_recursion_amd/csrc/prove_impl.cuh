@@ -13,6 +13,8 @@
 // and the query answers cross to the host.
 #include "host_transcript.h"
 #include "kernels_stark.cuh"
+#include "kernels_fri_reduce.cuh"
+#include "open_impl.cuh"
 
 struct p3r_prep {
   std::vector<p3r::AirParams> airs;
@@ -326,33 +328,43 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   const E zeta = ch.sample_ext();
 
   // ---- 5. openings, observed in round / matrix / point order
-  struct Item { int round, mat; const p3r_dmat* lde; int log_h; std::vector<E> z; std::vector<std::vector<E>> vals; };
+  struct Item { int round, mat; const p3r_dmat* lde; int log_h; std::vector<E> z; std::vector<std::vector<E>> vals; size_t job; };
   std::vector<Item> items;
   std::vector<std::vector<std::vector<E>>> o_main(ni), o_prep(ni), o_perm(ni);
   std::vector<std::vector<E>> o_chunks(chunks.size());
-  for (size_t i = 0; i < ni; ++i) {
-    std::vector<E> pts{zeta};
-    if (air_uses_next(prep->airs[i])) pts.push_back(zeta * F::two_adic_generator(log_n[i]));
-    o_main[i] = open_matrix<PP>(ctx, mains[i]->d, mains[i]->h, (int)mains[i]->w, F::one(), pts);
-    items.push_back({0, (int)i, main_lde[i].get(), log_n[i], pts, o_main[i]});
-  }
-  for (size_t k = 0; k < chunks.size(); ++k) {
-    auto& ck = chunks[k];
-    auto v = open_matrix<PP>(ctx, ck.evals->d, ck.evals->h, 4, ck.shift, {zeta});
-    o_chunks[k] = v[0];
-    items.push_back({1, (int)k, ck.lde.get(), log_n[ck.inst], {zeta}, v});
-  }
-  for (size_t i = 0; i < ni; ++i) {
-    std::vector<E> pts{zeta, zeta * F::two_adic_generator(log_n[i])};
-    const p3r_dmat* pt = prep->traces[i].get();
-    o_prep[i] = open_matrix<PP>(ctx, pt->d, pt->h, (int)pt->w, F::one(), pts);
-    items.push_back({2, (int)i, prep->ldes[i].get(), log_n[i], pts, o_prep[i]});
-  }
-  for (size_t k = 0; k < perm_insts.size(); ++k) {
-    int i = perm_insts[k];
-    std::vector<E> pts{zeta, zeta * F::two_adic_generator(log_n[i])};
-    o_perm[i] = open_matrix<PP>(ctx, aux[i]->d, aux[i]->h, (int)aux[i]->w, F::one(), pts);
-    items.push_back({3, (int)k, aux_lde[i].get(), log_n[i], pts, o_perm[i]});
+  {
+    Opener<PP> op(ctx);
+    for (size_t i = 0; i < ni; ++i) {
+      std::vector<E> pts{zeta};
+      if (air_uses_next(prep->airs[i])) pts.push_back(zeta * F::two_adic_generator(log_n[i]));
+      size_t j = op.open(mains[i]->d, mains[i]->h, (int)mains[i]->w, F::one(), pts);
+      items.push_back({0, (int)i, main_lde[i].get(), log_n[i], pts, {}, j});
+    }
+    for (size_t k = 0; k < chunks.size(); ++k) {
+      auto& ck = chunks[k];
+      size_t j = op.open(ck.evals->d, ck.evals->h, 4, ck.shift, {zeta});
+      items.push_back({1, (int)k, ck.lde.get(), log_n[ck.inst], {zeta}, {}, j});
+    }
+    for (size_t i = 0; i < ni; ++i) {
+      std::vector<E> pts{zeta, zeta * F::two_adic_generator(log_n[i])};
+      const p3r_dmat* pt = prep->traces[i].get();
+      size_t j = op.open(pt->d, pt->h, (int)pt->w, F::one(), pts);
+      items.push_back({2, (int)i, prep->ldes[i].get(), log_n[i], pts, {}, j});
+    }
+    for (size_t k = 0; k < perm_insts.size(); ++k) {
+      int i = perm_insts[k];
+      std::vector<E> pts{zeta, zeta * F::two_adic_generator(log_n[i])};
+      size_t j = op.open(aux[i]->d, aux[i]->h, (int)aux[i]->w, F::one(), pts);
+      items.push_back({3, (int)k, aux_lde[i].get(), log_n[i], pts, {}, j});
+    }
+    auto all = op.finish();
+    for (auto& it : items) {
+      it.vals = all[it.job];
+      if (it.round == 0) o_main[it.mat] = it.vals;
+      else if (it.round == 1) o_chunks[it.mat] = it.vals[0];
+      else if (it.round == 2) o_prep[it.mat] = it.vals;
+      else o_perm[perm_insts[it.mat]] = it.vals;
+    }
   }
   for (auto& it : items)
     for (auto& pv : it.vals)
@@ -374,6 +386,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     P3R_HIP(hipStreamSynchronize(ctx->stream));
   }
   std::map<int, std::pair<E, DevBuf>> ros;  // log_height -> (alpha power, ro planes [4][h])
+  std::map<std::array<uint64_t, 3>, DevBuf> inv_cache;  // (log_height, z) -> 1/(z - x_r)
   for (auto& it : items) {
     const int lh = it.log_h + log_blowup;
     auto f = ros.find(lh);
@@ -382,25 +395,33 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       P3R_HIP(hipMemsetAsync(b.p, 0, ((size_t)16) << lh, ctx->stream));
       f = ros.emplace(lh, std::make_pair(E::one(), std::move(b))).first;
     }
-    FriReduceArgs a{};
-    a.mat = it.lde->d; a.h = it.lde->h; a.w = (int)it.lde->w; a.log_h = lh;
+    FriReducePreArgs a{};
+    a.mat = it.lde->d; a.h = it.lde->h; a.w = (int)it.lde->w;
     a.apow = d_fapow.p;
     a.n_points = (int)it.z.size();
     E ap = f->second.first;
     for (size_t p = 0; p < it.z.size(); ++p) {
       E V = E::zero();
       for (size_t c = 0; c < it.vals[p].size(); ++c) V += fa_pow[c] * it.vals[p][c];
-      a.z[p] = to_e4<PP>(it.z[p]);
+      std::array<uint64_t, 3> key{(uint64_t)lh, ((uint64_t)it.z[p].c[0].v << 32) | it.z[p].c[1].v,
+                                  ((uint64_t)it.z[p].c[2].v << 32) | it.z[p].c[3].v};
+      auto iv = inv_cache.find(key);
+      if (iv == inv_cache.end()) {
+        DevBuf b((size_t)4 << lh);
+        ProfScope ps(ctx, "fri_inv_points");
+        hipLaunchKernelGGL(k_fri_inv_points<PP>, dim3(blocks_for(size_t(1) << lh)), dim3(kBlock), 0, ctx->stream,
+                           size_t(1) << lh, lh, gen.v, F::two_adic_generator(lh).v, to_e4<PP>(it.z[p]), b.p);
+        iv = inv_cache.emplace(key, std::move(b)).first;
+      }
+      a.inv[p] = iv->second.p;
       a.v[p] = to_e4<PP>(V);
       a.off[p] = to_e4<PP>(ap);
       ap *= fa_pow[it.lde->w];
     }
     f->second.first = ap;
-    a.gen = gen.v;
-    a.w_h = F::two_adic_generator(lh).v;
     a.ro = f->second.second.p;
     ProfScope ps(ctx, "fri_reduce");
-    hipLaunchKernelGGL(k_fri_reduce<PP>, dim3(blocks_for(a.h)), dim3(kBlock), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_fri_reduce_pre<PP>, dim3(blocks_for(a.h)), dim3(kBlock), 0, ctx->stream, a);
   }
   P3R_HIP(hipGetLastError());
 
