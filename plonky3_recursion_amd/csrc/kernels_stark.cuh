@@ -309,52 +309,64 @@ k_bary_weights(size_t n, uint32_t w_n, E4 z, E4 scale, uint32_t* __restrict__ ou
 
 constexpr int kOpenCols = 8;      // matrix columns sharing one pass over the weights
 constexpr int kOpenRows = 8192;   // rows per block
-// partial[p][chunk][col] = sum over the chunk's rows of weights_p[row] * M[col][row]
-template <class PP>
+// partial[p][chunk][col] = sum over the chunk's rows of weights_p[row] * M[col][row].
+// All accumulator indexing is compile-time (register resident); the block reduction is a
+// wave shuffle tree followed by a 4-wave LDS combine.
+template <class PP, int P>
 __global__ void __launch_bounds__(kBlock)
-k_open_dot(const uint32_t* __restrict__ mat, size_t n, int w, const uint32_t* __restrict__ wt0,
-           const uint32_t* __restrict__ wt1, uint32_t* __restrict__ partial, int n_chunks) {
+k_open_dot_t(const uint32_t* __restrict__ mat, size_t n, int w, const uint32_t* __restrict__ wt0,
+             const uint32_t* __restrict__ wt1, uint32_t* __restrict__ partial, int n_chunks) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
-  __shared__ uint32_t sh[kBlock][4];
+  constexpr int NV = P * kOpenCols * 4;
+  __shared__ uint32_t sh[kBlock / 64][NV];
   const int c0 = blockIdx.x * kOpenCols, chunk = blockIdx.y;
-  const int P = wt1 ? 2 : 1;
   size_t r0 = (size_t)chunk * kOpenRows, r1 = r0 + kOpenRows < n ? r0 + kOpenRows : n;
-  E acc[2][kOpenCols];
-  for (int p = 0; p < 2; ++p)
+  E acc[P][kOpenCols];
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+#pragma unroll
     for (int c = 0; c < kOpenCols; ++c) acc[p][c] = E::zero();
   for (size_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
-    E wa, wb = E::zero();
+    E wv[P];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wa.c[k] = F::raw(wt0[(size_t)k * n + r]);
+    for (int k = 0; k < 4; ++k) wv[0].c[k] = F::raw(wt0[(size_t)k * n + r]);
     if (P == 2)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) wb.c[k] = F::raw(wt1[(size_t)k * n + r]);
+      for (int k = 0; k < 4; ++k) wv[P - 1].c[k] = F::raw(wt1[(size_t)k * n + r]);
 #pragma unroll
     for (int c = 0; c < kOpenCols; ++c) {
-      if (c0 + c < w) {
-        F m = F::raw(mat[(size_t)(c0 + c) * n + r]);
-        acc[0][c] += wa * m;
-        if (P == 2) acc[1][c] += wb * m;
-      }
+      F m = c0 + c < w ? F::raw(mat[(size_t)(c0 + c) * n + r]) : F::zero();
+#pragma unroll
+      for (int p = 0; p < P; ++p) acc[p][c] += wv[p] * m;
     }
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
   for (int p = 0; p < P; ++p)
-    for (int c = 0; c < kOpenCols; ++c) {
-      if (c0 + c >= w) break;
-      for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] = acc[p][c].c[k].v;
-      __syncthreads();
-      for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-          for (int k = 0; k < 4; ++k)
-            sh[threadIdx.x][k] = (F::raw(sh[threadIdx.x][k]) + F::raw(sh[threadIdx.x + off][k])).v;
-        __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kOpenCols; ++c)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        F v = acc[p][c].c[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += F::raw(__shfl_down(v.v, off));
+        if (lane == 0) sh[wave][(p * kOpenCols + c) * 4 + k] = v.v;
       }
-      if (threadIdx.x == 0)
-        for (int k = 0; k < 4; ++k)
-          partial[(((size_t)p * n_chunks + chunk) * w + c0 + c) * 4 + k] = sh[0][k];
-      __syncthreads();
-    }
+  __syncthreads();
+  if ((int)threadIdx.x < NV) {
+    F s = F::zero();
+#pragma unroll
+    for (int wv = 0; wv < kBlock / 64; ++wv) s += F::raw(sh[wv][threadIdx.x]);
+    const int p = threadIdx.x / (kOpenCols * 4), rem = threadIdx.x % (kOpenCols * 4), c = rem / 4, k = rem % 4;
+    if (c0 + c < w) partial[(((size_t)p * n_chunks + chunk) * w + c0 + c) * 4 + k] = s.v;
+  }
+}
+template <class PP>
+void launch_open_dot(hipStream_t stream, dim3 grid, const uint32_t* mat, size_t n, int w, const uint32_t* wt0,
+                     const uint32_t* wt1, uint32_t* partial, int n_chunks) {
+  if (wt1) hipLaunchKernelGGL((k_open_dot_t<PP, 2>), grid, dim3(kBlock), 0, stream, mat, n, w, wt0, wt1, partial, n_chunks);
+  else hipLaunchKernelGGL((k_open_dot_t<PP, 1>), grid, dim3(kBlock), 0, stream, mat, n, w, wt0, wt1, partial, n_chunks);
 }
 template <class PP>
 __global__ void __launch_bounds__(kBlock)

@@ -44,7 +44,7 @@ struct Opener {
     DevBuf partial((size_t)P * n_chunks * w * 4);
     ProfScope ps(ctx, "open_dot");
     dim3 grid((w + kOpenCols - 1) / kOpenCols, n_chunks);
-    hipLaunchKernelGGL(k_open_dot<PP>, grid, dim3(kBlock), 0, ctx->stream, mat, n, w, w0, w1, partial.p, n_chunks);
+    launch_open_dot<PP>(ctx->stream, grid, mat, n, w, w0, w1, partial.p, n_chunks);
     hipLaunchKernelGGL(k_open_reduce<PP>, dim3(blocks_for((size_t)P * w * 4)), dim3(kBlock), 0, ctx->stream,
                        partial.p, P, n_chunks, w, out.p + used * 4);
     P3R_HIP(hipGetLastError());

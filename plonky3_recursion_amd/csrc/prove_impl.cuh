@@ -41,42 +41,6 @@ std::vector<Fp4<PP>> download_ef(p3r_ctx* ctx, const uint32_t* dev, size_t count
   return out;
 }
 
-// Open every column of `mat` (n x w evaluations over shift*<w_n>, natural order) at up to two
-// points; returns values [point][col].
-template <class PP>
-std::vector<std::vector<Fp4<PP>>> open_matrix(p3r_ctx* ctx, const uint32_t* mat, size_t n, int w,
-                                              Fp<PP> dshift, const std::vector<Fp4<PP>>& points) {
-  using F = Fp<PP>;
-  using E = Fp4<PP>;
-  const int log_n = log2_exact(n, "trace height");
-  const int P = (int)points.size();
-  DevBuf wts((size_t)P * 4 * n);
-  const F w_n = F::two_adic_generator(log_n);
-  const F n_inv = F::from_u64(n).inv();
-  for (int p = 0; p < P; ++p) {
-    E z = points[p] * dshift.inv();
-    E scale = (z.pow(n) - E::one()) * n_inv;
-    ProfScope ps(ctx, "open_weights");
-    hipLaunchKernelGGL(k_bary_weights<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n, w_n.v,
-                       to_e4<PP>(z), to_e4<PP>(scale), wts.p + (size_t)p * 4 * n);
-  }
-  const int n_chunks = (int)((n + kOpenRows - 1) / kOpenRows);
-  DevBuf partial((size_t)P * n_chunks * w * 4), out((size_t)P * w * 4);
-  {
-    ProfScope ps(ctx, "open_dot");
-    dim3 grid((w + kOpenCols - 1) / kOpenCols, n_chunks);
-    hipLaunchKernelGGL(k_open_dot<PP>, grid, dim3(kBlock), 0, ctx->stream, mat, n, w, wts.p,
-                       P == 2 ? wts.p + 4 * n : (const uint32_t*)nullptr, partial.p, n_chunks);
-    hipLaunchKernelGGL(k_open_reduce<PP>, dim3(blocks_for((size_t)P * w * 4)), dim3(kBlock), 0, ctx->stream,
-                       partial.p, P, n_chunks, w, out.p);
-  }
-  P3R_HIP(hipGetLastError());
-  auto flat = download_ef<PP>(ctx, out.p, (size_t)P * w);
-  std::vector<std::vector<E>> res(P);
-  for (int p = 0; p < P; ++p) res[p].assign(flat.begin() + (size_t)p * w, flat.begin() + (size_t)(p + 1) * w);
-  return res;
-}
-
 // Merkle layers above a leaf-digest layer (no injections): used by the FRI commit phase.
 template <class PP>
 void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves) {
