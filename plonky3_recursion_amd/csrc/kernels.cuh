@@ -334,7 +334,7 @@ struct NttPass {
   int log_t;     // lines per tile
   int out_mode;  // 0 keep LDS row order (bit-reversed); 1 natural order, same geometry;
                  // 2 natural order, transposed: out[n2*N1 + k1] (sub_dim 0 only)
-  const uint32_t* tw_sub;   // w_R^i for i < R/2 (forward or inverse root)
+  const uint32_t* tw_sub;   // Shoup pairs (w_R^i canonical, floor(w*2^32/P)) for i < R/2
   const uint32_t* tw4_lo;   // optional 4-step twiddles: w_N^x = hi[x >> 10] * lo[x & 1023]
   const uint32_t* tw4_hi;
   const uint32_t* pre_a;    // optional per-coset input scaling pre_a[z][n1] * pre_b[z][n2]
@@ -350,13 +350,23 @@ __device__ __forceinline__ uint32_t lds_addr(uint32_t r, uint32_t t, uint32_t T)
 }
 
 constexpr int kNttBlock = 1024;  // one radix-16 group per lane per stage group at 2^14-cell tiles
+// Shoup product: a (any u32) times a fixed w < P given w' = floor(w * 2^32 / P); 3 multiplies.
+// The data stays in Montgomery form (x*R) while w is canonical: (x*R)*w = (x*w)*R.
+template <class PP>
+__device__ __forceinline__ Fp<PP> shoup_mul(uint32_t a, uint32_t w, uint32_t wp) {
+  uint32_t q = __umulhi(a, wp);
+  uint32_t r = a * w - q * PP::P;  // in [0, 2P)
+  uint32_t r2 = r - PP::P;
+  return Fp<PP>::raw(r < r2 ? r : r2);
+}
+
 // LOGM consecutive DIF stages (s .. s+LOGM-1) of the size-R sub-NTT done in registers: a lane
 // owns the 2^LOGM rows r0 + j*q (q = R >> (s+LOGM)) of one tile column.  Stage s+u pairs
-// (j, j + M/2^(u+1)) with twiddle w_R^{(i << (s+u))}, i = row mod half, which factors into
-// w_M^{jj << u} (a 16th root of unity, `root16`) times (w_R^{low << s})^{2^u}.
+// (j, j + M/2^(u+1)) with twiddle w_R^{i << (s+u)}, i = jj*q + low, read as a (w, w') Shoup pair
+// from the LDS copy of the twiddle table.
 template <class PP, int LOGM>
-__device__ __forceinline__ void ntt_stage_group(uint32_t* tile, const uint32_t* tws, const uint32_t* root16,
-                                                int s, int log_r, int log_t, uint32_t tid) {
+__device__ __forceinline__ void ntt_stage_group(uint32_t* tile, const uint32_t* tws, int s, int log_r, int log_t,
+                                                uint32_t tid) {
   using F = Fp<PP>;
   constexpr int M = 1 << LOGM;
   const uint32_t T = 1u << log_t;
@@ -370,29 +380,23 @@ __device__ __forceinline__ void ntt_stage_group(uint32_t* tile, const uint32_t* 
     F x[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) x[j] = F::raw(tile[lds_addr(r0 + j * q, t, T)]);
-    F wu = F::raw(tws[low << s]);
 #pragma unroll
     for (int u = 0; u < LOGM; ++u) {
-      constexpr int dummy = 0;
-      (void)dummy;
       const int half = M >> (u + 1);
-      F tw[M / 2];
-      tw[0] = wu;
+      const uint32_t base_idx = low << (s + u);
 #pragma unroll
-      for (int jj = 1; jj < M / 2; ++jj)
-        if (jj < half) tw[jj] = wu * F::raw(root16[(jj << u) << (4 - LOGM)]);
+      for (int jj = 0; jj < M / 2; ++jj) {
+        if (jj < half) {
+          const uint32_t idx = base_idx + ((uint32_t)jj << (lq + s + u));
+          const uint2 tw = *reinterpret_cast<const uint2*>(&tws[2 * idx]);
 #pragma unroll
-      for (int blk = 0; blk < M; blk += 2 * half) {
-#pragma unroll
-        for (int jj = 0; jj < M / 2; ++jj) {
-          if (jj < half) {
+          for (int blk = 0; blk < M; blk += 2 * half) {
             F p = x[blk + jj], c = x[blk + jj + half];
             x[blk + jj] = p + c;
-            x[blk + jj + half] = (p - c) * tw[jj];
+            x[blk + jj + half] = shoup_mul<PP>(p.v + (PP::P - c.v), tw.x, tw.y);
           }
         }
       }
-      wu = wu.sqr();
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) tile[lds_addr(r0 + j * q, t, T)] = x[j].v;
@@ -409,7 +413,7 @@ __global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
   const uint32_t R = 1u << log_r, T = 1u << a.log_t;
   const uint32_t N1 = 1u << a.log_n1, N2 = 1u << a.log_n2;
   uint32_t* tile = lds;
-  uint32_t* tws = lds + (R * (T + 1) + (R >> 5) + 1);
+  uint32_t* tws = lds + ((R * (T + 1) + (R >> 5) + 2) & ~1u);  // 8-byte aligned (w, w') pairs
   const uint32_t line0 = blockIdx.x * T;  // first line of the tile (n2 for sub_dim 0, n1 for 1)
   const uint32_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
   uint32_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride +
@@ -417,7 +421,7 @@ __global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
   const uint32_t* pre_a = a.pre_a ? a.pre_a + (size_t)blockIdx.z * N1 : nullptr;
   const uint32_t* pre_b = a.pre_b ? a.pre_b + (size_t)blockIdx.z * N2 : nullptr;
 
-  for (uint32_t i = tid; i < (R >> 1); i += kNttBlock) tws[i] = a.tw_sub[i];
+  for (uint32_t i = tid; i < R; i += kNttBlock) tws[i] = a.tw_sub[i];
 
   const uint32_t E = R << a.log_t;
   // ---- load (lanes run along the unit-stride global dimension) ----
@@ -436,10 +440,10 @@ __global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
   // ---- DIF butterflies, up to four stages per LDS round trip (register radix-16) ----
   {
     int s = 0;
-    while (log_r - s >= 4) { ntt_stage_group<PP, 4>(tile, tws, a.root16, s, log_r, a.log_t, tid); s += 4; }
-    if (log_r - s == 3) ntt_stage_group<PP, 3>(tile, tws, a.root16, s, log_r, a.log_t, tid);
-    else if (log_r - s == 2) ntt_stage_group<PP, 2>(tile, tws, a.root16, s, log_r, a.log_t, tid);
-    else if (log_r - s == 1) ntt_stage_group<PP, 1>(tile, tws, a.root16, s, log_r, a.log_t, tid);
+    while (log_r - s >= 4) { ntt_stage_group<PP, 4>(tile, tws, s, log_r, a.log_t, tid); s += 4; }
+    if (log_r - s == 3) ntt_stage_group<PP, 3>(tile, tws, s, log_r, a.log_t, tid);
+    else if (log_r - s == 2) ntt_stage_group<PP, 2>(tile, tws, s, log_r, a.log_t, tid);
+    else if (log_r - s == 1) ntt_stage_group<PP, 1>(tile, tws, s, log_r, a.log_t, tid);
   }
   // ---- store ----
   const F scale = F::raw(a.scale);

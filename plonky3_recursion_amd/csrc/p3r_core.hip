@@ -53,6 +53,8 @@ std::unique_ptr<p3r_dmat> upload(p3r_ctx* ctx, const uint32_t* rowmajor, size_t 
   hipLaunchKernelGGL(k_rowmajor_to_colmajor<PP>, grid, dim3(kBlock), 0, ctx->stream, stage.p,
                      m->d, (uint32_t)h, (uint32_t)w, 1);
   P3R_HIP(hipGetLastError());
+  // the caller's (pageable) host buffer must be fully consumed before we return
+  P3R_HIP(hipStreamSynchronize(ctx->stream));
   return m;
 }
 
@@ -147,16 +149,18 @@ const uint32_t* get_tw_sub(p3r_ctx* ctx, int log_r, int inverse) {
   if (it != ctx->tw_sub.end()) return it->second.p;
   using F = Fp<PP>;
   size_t half = log_r ? (size_t(1) << (log_r - 1)) : 1;
-  std::vector<uint32_t> t(half);
+  std::vector<uint32_t> t(2 * half);
   F root = F::two_adic_generator(log_r);
   if (inverse) root = root.inv();
   F x = F::one();
   for (size_t i = 0; i < half; ++i) {
-    t[i] = x.v;
+    const uint32_t w = x.to_canonical();
+    t[2 * i] = w;
+    t[2 * i + 1] = (uint32_t)(((uint64_t)w << 32) / PP::P);
     x *= root;
   }
-  DevBuf d(half);
-  P3R_HIP(copy_sync(ctx->stream, d.p, t.data(), half * 4, hipMemcpyHostToDevice));
+  DevBuf d(2 * half);
+  P3R_HIP(copy_sync(ctx->stream, d.p, t.data(), 2 * half * 4, hipMemcpyHostToDevice));
   return ctx->tw_sub.emplace(key, std::move(d)).first->second.p;
 }
 
@@ -240,7 +244,7 @@ void launch_ntt(p3r_ctx* ctx, NttPass a, size_t ncols, size_t ncosets, const cha
     for (int k = 0; k < 8; ++k) { a.root16[k] = x.v; x *= w16; }
   }
   const size_t R = size_t(1) << log_r, T = size_t(1) << log_t;
-  size_t lds = (R * (T + 1) + (R >> 5) + 1 + (R >> 1) + 1) * sizeof(uint32_t);
+  size_t lds = (R * (T + 1) + (R >> 5) + 2 + R + 2) * sizeof(uint32_t);
   if (lds > 160 * 1024) fail(P3R_EUNSUPPORTED, "NTT tile of 2^%d rows does not fit LDS", log_r);
   dim3 grid((unsigned)(size_t(1) << (log_lines - log_t)), (unsigned)ncols, (unsigned)ncosets);
   ProfScope ps(ctx, name);
