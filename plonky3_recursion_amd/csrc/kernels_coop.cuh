@@ -1,0 +1,89 @@
+// Lane-cooperative Poseidon2 for LATENCY-bound work (small Merkle layers): one state element per
+// lane, 16 lanes (one DPP "row") per permutation, 4 permutations per wavefront.  The one-state-
+// per-lane kernels of kernels.cuh are ~9 k dependent instructions (~25 us) per layer however few
+// nodes the layer has; here a permutation is ~1.3 k dependent instructions because the S-boxes of
+// a round run in parallel and the linear layers are DPP rotations:
+//   external:  M4 is circulant, y_i = 2 x_i + 3 x_{i+1} + x_{i+2} + x_{i+3} inside a quad
+//              (quad_perm), then the 4 quads are summed with row_ror:4 / row_ror:8;
+//   internal:  sum over the row with row_ror:8,4,2,1, then s_i <- d_i * s_i + sum.
+// Same arithmetic as poseidon2.h (Montgomery form), so results are bit-identical.
+#pragma once
+#include "kernels.cuh"
+
+namespace p3r {
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+constexpr int DPP_QUAD_NEXT1 = 0x39;  // quad_perm:[1,2,3,0]
+constexpr int DPP_QUAD_NEXT2 = 0x4E;  // quad_perm:[2,3,0,1]
+constexpr int DPP_QUAD_NEXT3 = 0x93;  // quad_perm:[3,0,1,2]
+constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+
+template <class F>
+__device__ __forceinline__ F coop_external(F x) {
+  F b = F::raw(dpp<DPP_QUAD_NEXT1>(x.v)), c = F::raw(dpp<DPP_QUAD_NEXT2>(x.v)), d = F::raw(dpp<DPP_QUAD_NEXT3>(x.v));
+  F ab = x + b;
+  F y = ab.dbl() + b + (c + d);  // 2x + 3b + c + d
+  F t = y + F::raw(dpp<DPP_ROW_ROR4>(y.v));
+  t = t + F::raw(dpp<DPP_ROW_ROR8>(t.v));  // sum of the 4 quads at this quad position
+  return y + t;
+}
+template <class F>
+__device__ __forceinline__ F coop_row_sum(F x) {
+  F t = x + F::raw(dpp<DPP_ROW_ROR8>(x.v));
+  t = t + F::raw(dpp<DPP_ROW_ROR4>(t.v));
+  t = t + F::raw(dpp<DPP_ROW_ROR2>(t.v));
+  return t + F::raw(dpp<DPP_ROW_ROR1>(t.v));
+}
+
+// `s`: this lane's state element (lane & 15 = element index).  `diag`: Montgomery internal
+// diagonal of this lane.  Round constants `rc` as in poseidon2.h.
+template <class PP>
+__device__ __forceinline__ Fp<PP> coop_permute(Fp<PP> s, int elem, Fp<PP> diag, const uint32_t* __restrict__ rc) {
+  using F = Fp<PP>;
+  s = coop_external(s);
+  int k = 0;
+  for (int r = 0; r < P2_HALF_FULL; ++r) {
+    s = p2_sbox<PP>(s + F::raw(rc[k + elem]));
+    k += P2_WIDTH;
+    s = coop_external(s);
+  }
+  for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
+    F sb = p2_sbox<PP>(s + F::raw(rc[k + r]));
+    s = elem == 0 ? sb : s;
+    F sum = coop_row_sum(s);
+    s = s * diag + sum;
+  }
+  k += PP::PARTIAL_ROUNDS;
+  for (int r = 0; r < P2_HALF_FULL; ++r) {
+    s = p2_sbox<PP>(s + F::raw(rc[k + elem]));
+    k += P2_WIDTH;
+    s = coop_external(s);
+  }
+  return s;
+}
+
+// Same contract as k_mmcs_compress (kernels.cuh), 16 lanes per node.
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_mmcs_compress_coop(const uint32_t* __restrict__ L, size_t nl, int lmul, int ladd, const uint32_t* __restrict__ R,
+                     size_t nr, int rmul, int radd, uint32_t* __restrict__ out, size_t n,
+                     const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+  using F = Fp<PP>;
+  const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t node = gid >> 4;
+  const int elem = (int)(gid & 15);
+  // whole rows are active or inactive together (n*16 need not fill the last wave)
+  const bool live = node < n;
+  F s = F::zero();
+  if (live) {
+    s = elem < P2_DIGEST ? F::raw(L[(size_t)elem * nl + node * lmul + ladd])
+                         : F::raw(R[(size_t)(elem - P2_DIGEST) * nr + node * rmul + radd]);
+  }
+  s = coop_permute<PP>(s, elem, F::raw(diag[elem]), rc);
+  if (live && elem < P2_DIGEST) out[(size_t)elem * n + node] = s.v;
+}
+
+}  // namespace p3r

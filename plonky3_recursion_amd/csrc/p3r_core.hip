@@ -3,6 +3,7 @@
 #include "context.h"
 #include "kernels.cuh"
 #include "kernels_stark.cuh"
+#include "kernels_coop.cuh"
 #include "poseidon2_rc_default.inc"
 #include "profile.h"
 
@@ -345,6 +346,22 @@ void hash_rows(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats, size_t h,
   P3R_HIP(hipGetLastError());
 }
 
+// One 2-to-1 layer.  Layers too small to fill the chip with one-permutation-per-lane work are
+// latency-bound, so they use the 16-lanes-per-node kernel instead.
+constexpr size_t kCoopMaxNodes = 32768;
+template <class PP>
+void launch_compress(p3r_ctx* ctx, const uint32_t* L, size_t nl, int lmul, int ladd, const uint32_t* R, size_t nr,
+                     int rmul, int radd, uint32_t* out, size_t n) {
+  ProfScope ps(ctx, "mmcs_compress");
+  if (n <= kCoopMaxNodes)
+    hipLaunchKernelGGL(k_mmcs_compress_coop<PP>, dim3(blocks_for(n * 16)), dim3(kBlock), 0, ctx->stream, L, nl, lmul,
+                       ladd, R, nr, rmul, radd, out, n, ctx->rc.p, ctx->p2_diag.p);
+  else
+    hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, L, nl, lmul, ladd, R,
+                       nr, rmul, radd, out, n, ctx->rc.p);
+  P3R_HIP(hipGetLastError());
+}
+
 // Remaining plain layers (no injections) below a layer of n <= kTreeTopMax digests, one launch.
 template <class PP>
 void tree_top(p3r_ctx* ctx, p3r_tree* tree, size_t n) {
@@ -397,29 +414,15 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   size_t min_h = hmax;
   for (auto* m : mats) min_h = std::min(min_h, m->h);
   while (n > cap_n) {
-    if (n <= (size_t)kTreeTopMax && min_h >= n) {  // nothing left to inject below this layer
-      tree_top<PP>(ctx, tree, n);
-      break;
-    }
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;
-    {
-      ProfScope ps(ctx, "mmcs_compress");
-      hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(nn)), dim3(kBlock), 0, ctx->stream,
-                         prev, n, 2, 0, prev, n, 2, 1, next.p, nn, ctx->rc.p);
-    }
-    P3R_HIP(hipGetLastError());
+    launch_compress<PP>(ctx, prev, n, 2, 0, prev, n, 2, 1, next.p, nn);
     auto inj = at_height(nn);
     if (!inj.empty()) {
       DevBuf idig(P2_DIGEST * nn);
       hash_rows<PP>(ctx, inj, nn, idig.p);
-      {
-        ProfScope ps(ctx, "mmcs_compress");
-        hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(nn)), dim3(kBlock), 0, ctx->stream,
-                           next.p, nn, 1, 0, idig.p, nn, 1, 0, next.p, nn, ctx->rc.p);
-      }
-      P3R_HIP(hipGetLastError());
+      launch_compress<PP>(ctx, next.p, nn, 1, 0, idig.p, nn, 1, 0, next.p, nn);
     }
     tree->layers.push_back(std::move(next));
     n = nn;
@@ -479,6 +482,21 @@ void init_ctx(p3r_ctx* ctx) {
   }
   ctx->rc.alloc(nrc);
   P3R_HIP(copy_sync(ctx->stream, ctx->rc.p, mont.data(), nrc * 4, hipMemcpyHostToDevice));
+  {
+    auto inv2k = [](int k) { return F::from_u64(uint64_t(1) << k).inv(); };
+    const F two = F::from_canonical(2), three = F::from_canonical(3), four = F::from_canonical(4);
+    F d[16] = {-two, F::one(), two, inv2k(1), three, four, -inv2k(1), -three, -four, inv2k(8), inv2k(3), inv2k(24),
+               -inv2k(8), -inv2k(3), -inv2k(4), -inv2k(24)};
+    if (PP::FIELD_ID == 1) {
+      F b[16] = {-two, F::one(), two, inv2k(1), three, four, -inv2k(1), -three, -four, inv2k(8), inv2k(2), inv2k(3),
+                 inv2k(27), -inv2k(8), -inv2k(4), -inv2k(27)};
+      for (int i = 0; i < 16; ++i) d[i] = b[i];
+    }
+    uint32_t dm[16];
+    for (int i = 0; i < 16; ++i) dm[i] = d[i].v;
+    ctx->p2_diag.alloc(16);
+    P3R_HIP(copy_sync(ctx->stream, ctx->p2_diag.p, dm, sizeof dm, hipMemcpyHostToDevice));
+  }
   ctx->partial_rounds = PP::PARTIAL_ROUNDS;
   ctx->cfg.poseidon2_rc = nullptr;  // caller's pointer is not retained
   P3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_tile<PP>),

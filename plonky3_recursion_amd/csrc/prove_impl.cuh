@@ -47,20 +47,13 @@ void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves) {
   size_t n = n_leaves;
   const size_t cap_n = size_t(1) << tree->cap_height;
   while (n > cap_n) {
-    if (n <= (size_t)kTreeTopMax) {
-      tree_top<PP>(ctx, tree, n);
-      break;
-    }
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;
-    ProfScope ps(ctx, "mmcs_compress");
-    hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(nn)), dim3(kBlock), 0, ctx->stream, prev, n, 2, 0,
-                       prev, n, 2, 1, next.p, nn, ctx->rc.p);
+    launch_compress<PP>(ctx, prev, n, 2, 0, prev, n, 2, 1, next.p, nn);
     tree->layers.push_back(std::move(next));
     n = nn;
   }
-  P3R_HIP(hipGetLastError());
 }
 
 template <class PP>
