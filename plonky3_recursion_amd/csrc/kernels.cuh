@@ -349,7 +349,7 @@ __device__ __forceinline__ uint32_t lds_addr(uint32_t r, uint32_t t, uint32_t T)
   return r * (T + 1) + (r >> 5) + t;
 }
 
-constexpr int kNttBlock = 1024;  // one radix-16 group per lane per stage group at 2^14-cell tiles
+constexpr int kNttBlock = 1024;  // upper bound; launches use tile_cells/16 lanes (one radix-16 group per lane)
 // Shoup product: a (any u32) times a fixed w < P given w' = floor(w * 2^32 / P); 3 multiplies.
 // The data stays in Montgomery form (x*R) while w is canonical: (x*R)*w = (x*w)*R.
 template <class PP>
@@ -373,7 +373,7 @@ __device__ __forceinline__ void ntt_stage_group(uint32_t* tile, const uint32_t* 
   const int lq = log_r - s - LOGM;
   const uint32_t q = 1u << lq;
   const uint32_t items = (1u << (log_r - LOGM)) << log_t;
-  for (uint32_t e = tid; e < items; e += kNttBlock) {
+  for (uint32_t e = tid; e < items; e += blockDim.x) {
     const uint32_t t = e & (T - 1), b = e >> log_t;
     const uint32_t low = b & (q - 1), high = b >> lq;
     const uint32_t r0 = (high << (lq + LOGM)) | low;
@@ -421,11 +421,11 @@ __global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
   const uint32_t* pre_a = a.pre_a ? a.pre_a + (size_t)blockIdx.z * N1 : nullptr;
   const uint32_t* pre_b = a.pre_b ? a.pre_b + (size_t)blockIdx.z * N2 : nullptr;
 
-  for (uint32_t i = tid; i < R; i += kNttBlock) tws[i] = a.tw_sub[i];
+  for (uint32_t i = tid; i < R; i += blockDim.x) tws[i] = a.tw_sub[i];
 
   const uint32_t E = R << a.log_t;
   // ---- load (lanes run along the unit-stride global dimension) ----
-  for (uint32_t e = tid; e < E; e += kNttBlock) {
+  for (uint32_t e = tid; e < E; e += blockDim.x) {
     uint32_t r, t, n1, n2;
     if (a.sub_dim == 0) {
       t = e & (T - 1); r = e >> a.log_t; n1 = r; n2 = line0 + t;
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
   }
   // ---- store ----
   const F scale = F::raw(a.scale);
-  for (uint32_t e = tid; e < E; e += kNttBlock) {
+  for (uint32_t e = tid; e < E; e += blockDim.x) {
     uint32_t rho, t;  // rho: row index in the OUTPUT geometry
     bool lanes_along_t = (a.sub_dim == 0 && a.out_mode != 2);
     if (lanes_along_t) {

@@ -233,7 +233,8 @@ template <class PP>
 void launch_ntt(p3r_ctx* ctx, NttPass a, size_t ncols, size_t ncosets, const char* name) {
   const int log_r = a.sub_dim == 0 ? a.log_n1 : a.log_n2;
   const int log_lines = a.sub_dim == 0 ? a.log_n2 : a.log_n1;
-  int log_t = std::max(0, 14 - log_r);
+  static const int log_tile = getenv("P3R_NTT_LOG_TILE") ? atoi(getenv("P3R_NTT_LOG_TILE")) : 13;  // 2^13 cells, 512 lanes: 4 tiles per CU overlap their phases
+  int log_t = std::max(0, log_tile - log_r);
   if (a.sub_dim == 0 && log_t > 5) log_t = 5;  // 128-byte segments are enough when strided
   log_t = std::min(log_t, log_lines);
   a.log_t = log_t;
@@ -249,7 +250,8 @@ void launch_ntt(p3r_ctx* ctx, NttPass a, size_t ncols, size_t ncosets, const cha
   if (lds > 160 * 1024) fail(P3R_EUNSUPPORTED, "NTT tile of 2^%d rows does not fit LDS", log_r);
   dim3 grid((unsigned)(size_t(1) << (log_lines - log_t)), (unsigned)ncols, (unsigned)ncosets);
   ProfScope ps(ctx, name);
-  hipLaunchKernelGGL(k_ntt_tile<PP>, grid, dim3(kNttBlock), lds, ctx->stream, a);
+  const unsigned threads = (unsigned)std::min<size_t>(kNttBlock, std::max<size_t>(64, (R * T) >> 4));
+  hipLaunchKernelGGL(k_ntt_tile<PP>, grid, dim3(threads), lds, ctx->stream, a);
   P3R_HIP(hipGetLastError());
 }
 
