@@ -179,7 +179,8 @@ def main():
         widths = [4, 4 * packing.public_lanes, 16 * packing.alu_lanes + ((k - 1) // 2 + 2 * (k - 1) + 1) * 4, p2w,
                   4 * packing.recompose_lanes]
         perms, hash_bytes = workload_model(field, cpd.table_heights, widths, packing)
-        kernel_ms = {kk: v[0] / prof_steps for kk, v in prof.items()}
+        kernel_ms = {kk: v[0] / prof_steps for kk, v in prof.items() if not kk.startswith("stage:")}
+        stage_ms = {kk[6:]: v[0] / prof_steps for kk, v in prof.items() if kk.startswith("stage:")}
         dominant = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
         hash_ms, hash_launches = prof.get("mmcs_hash_rows", (0.0, 0))
         launches_per_step = hash_launches / prof_steps
@@ -211,6 +212,7 @@ def main():
             "poseidon2_perms_per_s": perms * world / (ms_per_step * 1e-3),
             "poseidon2_perms_per_step": perms,
             "kernel_ms_per_step": kernel_ms,
+            "stage_wall_ms_per_step": stage_ms,
             "dominant_kernel_family": dominant,
             "roofline": {
                 "kernel": "k_mmcs_hash_rows (+ strided variant)",

@@ -170,6 +170,10 @@ struct p3r_ctx {
   p3r_config cfg{};
   bool prof_enabled = false;
   std::vector<p3r::ProfRec> prof;
+  // wall-clock per prove stage (only while profiling; each mark synchronises the stream)
+  std::vector<std::pair<std::string, double>> stage_ms;
+  std::string cur_stage;
+  double cur_stage_t0 = 0;
   int partial_rounds = 0;
   hipStream_t stream = nullptr;
   p3r::DevBuf rc;  // Poseidon2 constants, Montgomery

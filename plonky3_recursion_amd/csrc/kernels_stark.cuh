@@ -550,53 +550,3 @@ k_gather(const GatherDesc* __restrict__ descs, uint32_t* __restrict__ out, int t
 
 }  // namespace p3r
 
-namespace p3r {
-
-// Top of a Merkle tree in ONE launch: starting from a layer of n_top <= kTreeTopMax digests,
-// every remaining 2-to-1 layer down to the cap is computed by a single workgroup that keeps
-// the current layer in LDS (the per-layer launches of k_mmcs_compress are launch-latency
-// bound once a layer is smaller than the chip).  Each computed layer is also written to its
-// own buffer (`layers[l]`, digests SoA) because query openings read siblings from them.
-constexpr int kTreeTopMax = 2048;
-struct TreeTopLayers {
-  uint32_t* p[12];
-};
-template <class PP>
-__global__ void __launch_bounds__(1024)
-k_mmcs_tree_top(const uint32_t* __restrict__ top, int n_top, int n_cap, TreeTopLayers layers,
-                const uint32_t* __restrict__ rc) {
-  using F = Fp<PP>;
-  __shared__ uint32_t cur[P2_DIGEST][kTreeTopMax];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < n_top; i += 1024)
-#pragma unroll
-    for (int k = 0; k < P2_DIGEST; ++k) cur[k][i] = top[(size_t)k * n_top + i];
-  __syncthreads();
-  int n = n_top, l = 0;
-  while (n > n_cap) {
-    const int nn = n >> 1;
-    F s[P2_WIDTH];
-    if (tid < nn) {
-#pragma unroll
-      for (int k = 0; k < P2_DIGEST; ++k) {
-        s[k] = F::raw(cur[k][2 * tid]);
-        s[P2_DIGEST + k] = F::raw(cur[k][2 * tid + 1]);
-      }
-      p2_permute<PP>(s, rc);
-    }
-    __syncthreads();
-    if (tid < nn) {
-      uint32_t* out = layers.p[l];
-#pragma unroll
-      for (int k = 0; k < P2_DIGEST; ++k) {
-        cur[k][tid] = s[k].v;
-        out[(size_t)k * nn + tid] = s[k].v;
-      }
-    }
-    __syncthreads();
-    n = nn;
-    ++l;
-  }
-}
-
-}  // namespace p3r

@@ -382,6 +382,7 @@ std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r
 
 template <class PP>
 std::vector<uint8_t> prove_all_tables(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, bool canonical) {
+  prof_stage(ctx, "build_traces");
   auto mains = build_main_traces<PP>(ctx, L, t);
   const p3r_dmat* ptrs[5];
   for (int i = 0; i < 5; ++i) ptrs[i] = mains[i].get();

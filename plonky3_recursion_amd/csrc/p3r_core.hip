@@ -364,25 +364,6 @@ void launch_compress(p3r_ctx* ctx, const uint32_t* L, size_t nl, int lmul, int l
   P3R_HIP(hipGetLastError());
 }
 
-// Remaining plain layers (no injections) below a layer of n <= kTreeTopMax digests, one launch.
-template <class PP>
-void tree_top(p3r_ctx* ctx, p3r_tree* tree, size_t n) {
-  const size_t cap_n = size_t(1) << tree->cap_height;
-  if (n <= cap_n) return;
-  const uint32_t* top = tree->layers.back().p;
-  TreeTopLayers tl{};
-  int l = 0;
-  for (size_t m = n / 2; m >= cap_n; m /= 2) {
-    tree->layers.emplace_back(P2_DIGEST * m);
-    tl.p[l++] = tree->layers.back().p;
-    if (m == 1) break;
-  }
-  ProfScope ps(ctx, "mmcs_compress");
-  hipLaunchKernelGGL(k_mmcs_tree_top<PP>, dim3(1), dim3(1024), 0, ctx->stream, top, (int)n, (int)cap_n, tl,
-                     ctx->rc.p);
-  P3R_HIP(hipGetLastError());
-}
-
 template <class PP>
 void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   using F = Fp<PP>;
@@ -413,8 +394,6 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   hash_rows<PP>(ctx, at_height(hmax), hmax, tree->layers[0].p);
   size_t n = hmax;
   const size_t cap_n = size_t(1) << tree->cap_height;
-  size_t min_h = hmax;
-  for (auto* m : mats) min_h = std::min(min_h, m->h);
   while (n > cap_n) {
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
@@ -887,6 +866,12 @@ int p3r_profile_read(p3r_ctx* ctx, p3r_profile_entry* out, size_t cap, size_t* n
       }
       it->total_ms += ms;
       it->launches += 1;
+    }
+    for (auto& kv : ctx->stage_ms) {
+      p3r_profile_entry e{};
+      snprintf(e.name, sizeof e.name, "stage:%s", kv.first.c_str());
+      e.total_ms = kv.second;
+      acc.push_back(e);
     }
     if (acc.size() > cap) fail(P3R_EBUFFER, "need room for %zu profile entries", acc.size());
     std::copy(acc.begin(), acc.end(), out);

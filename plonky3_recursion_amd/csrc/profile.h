@@ -1,6 +1,8 @@
 // Per-kernel-family timing with HIP events on the ctx's own stream (bench.py's
 // `roofline.achieved` is derived from these; torch.cuda.Event would not see this stream).
 #pragma once
+#include <chrono>
+
 #include "context.h"
 
 namespace p3r {
@@ -11,6 +13,24 @@ inline void prof_clear(p3r_ctx* ctx) {
     (void)hipEventDestroy(r.b);
   }
   ctx->prof.clear();
+  ctx->stage_ms.clear();
+  ctx->cur_stage.clear();
+}
+
+// Stage marks: `prof_stage(ctx, "name")` closes the previous stage and opens a new one;
+// `prof_stage(ctx, nullptr)` closes the last.  No-ops unless profiling is enabled.
+inline void prof_stage(p3r_ctx* ctx, const char* name) {
+  if (!ctx->prof_enabled) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  if (!ctx->cur_stage.empty()) {
+    bool found = false;
+    for (auto& kv : ctx->stage_ms)
+      if (kv.first == ctx->cur_stage) { kv.second += now - ctx->cur_stage_t0; found = true; }
+    if (!found) ctx->stage_ms.emplace_back(ctx->cur_stage, now - ctx->cur_stage_t0);
+  }
+  ctx->cur_stage = name ? name : "";
+  ctx->cur_stage_t0 = now;
 }
 
 struct ProfScope {

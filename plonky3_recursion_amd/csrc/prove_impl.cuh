@@ -141,6 +141,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   ProofWriter<PP> W;
   W.canonical = canonical_encoding;
 
+  prof_stage(ctx, "main_lde_commit");
   // ---- 1. main LDEs + commitment
   std::vector<std::unique_ptr<p3r_dmat>> main_lde(ni);
   std::vector<const p3r_dmat*> ptrs;
@@ -151,6 +152,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<uint32_t> main_cap, perm_cap, quot_cap;
   auto main_tree = commit_dmats<PP>(ctx, ptrs, main_cap);
 
+  prof_stage(ctx, "transcript_head");
   // ---- 2. transcript head
   ch.observe_base_as_ext(ni);
   for (size_t i = 0; i < ni; ++i) {
@@ -163,6 +165,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(air_prep_width_of(prep->airs[i]));
   for (uint32_t v : prep->cap_canonical) ch.observe(F::from_canonical(v));
 
+  prof_stage(ctx, "logup_aux_commit");
   // ---- 3. LogUp: challenges, aux traces, commitment, terminals
   bool any_lookup = false;
   for (auto& L : layouts) any_lookup |= L.n_groups > 0;
@@ -211,6 +214,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     for (int i : perm_insts) ch.observe_ext(terminals[i]);
   }
 
+  prof_stage(ctx, "quotient_commit");
   // ---- 4. alpha, quotient chunks, commitment
   const E alpha = ch.sample_ext();
   struct Chunk { int inst; F shift; std::unique_ptr<p3r_dmat> evals, lde; };
@@ -284,6 +288,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   for (uint32_t v : quot_cap) ch.observe(F::raw(v));
   const E zeta = ch.sample_ext();
 
+  prof_stage(ctx, "openings");
   // ---- 5. openings, observed in round / matrix / point order
   struct Item { int round, mat; const p3r_dmat* lde; int log_h; std::vector<E> z; std::vector<std::vector<E>> vals; size_t job; };
   std::vector<Item> items;
@@ -327,6 +332,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     for (auto& pv : it.vals)
       for (auto& v : pv) ch.observe_ext(v);
 
+  prof_stage(ctx, "fri_reduce");
   // ---- 6. FRI batching challenge and per-height reduced openings
   const E fri_alpha = ch.sample_ext();
   size_t max_w = 1;
@@ -382,6 +388,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   }
   P3R_HIP(hipGetLastError());
 
+  prof_stage(ctx, "fri_commit_phase");
   // ---- 7. FRI commit phase
   std::vector<int> heights;
   for (auto& kv : ros) heights.push_back(kv.first);
@@ -512,6 +519,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     if (!ch.check_witness((int)cfg.query_pow_bits, query_pow_witness)) fail(P3R_EHIP, "device PoW witness rejected on host");
   }
 
+  prof_stage(ctx, "queries");
   // ---- 8. queries: one gather launch for every opened row / sibling of every query
   const p3r_tree* round_trees[4] = {main_tree.get(), quot_tree.get(), prep->tree.get(), perm_tree.get()};
   const int n_rounds = any_lookup ? 4 : 3;
@@ -579,6 +587,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     P3R_HIP(e);
   }
 
+  prof_stage(ctx, "serialize");
   // ---- 9. serialise BatchProof (field order: host_transcript.h)
   W.cap_mont(main_cap);
   if (any_lookup) { W.byte(1); W.cap_mont(perm_cap); } else W.byte(0);
@@ -639,6 +648,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   W.varint(ni);
   for (size_t i = 0; i < ni; ++i) W.varint(log_n[i]);
   P3R_HIP(hipStreamSynchronize(ctx->stream));
+  prof_stage(ctx, nullptr);
   return std::move(W.out);
 }
 
