@@ -76,6 +76,17 @@ def workload_model(field, heights, widths, packing):
     return perms, 4 * hash_cells + 32 * hash_rows
 
 
+def pmc_traffic_bytes(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (collected with rocprofv3 in
+    separate --pmc passes; it cannot be collected from inside this process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+            k = json.load(fh)["kernels"][kernel]
+        return (k["fetch_kb_per_launch"] + k["write_kb_per_launch"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(field, log_h):
     """The CPU oracle (kind 'port', single thread) proving the same table mix at a bounded size."""
     import harness_lib
@@ -221,7 +232,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes("k_mmcs_hash_rows") if (field, log_h) == ("koala-bear", 20) else None,
+                "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "same command; bytes per launch)",
                 "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": hash_bytes / launches_per_step if launches_per_step else None,
                 "note": "MMCS leaf hashing is integer-VALU bound (one Poseidon2 permutation per 32 B absorbed), "
