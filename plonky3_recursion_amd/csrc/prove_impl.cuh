@@ -79,6 +79,39 @@ std::unique_ptr<p3r_tree> commit_dmats(p3r_ctx* ctx, const std::vector<const p3r
   return tree;
 }
 
+// Proof-of-work grinding on the device: the smallest witness w such that, after observing w, the
+// low `bits` bits of the next sample are zero (recursion/src/challenger/circuit.rs:409-430).
+// Leaves the host challenger in the post-check state.  bits == 0: witness 0, transcript untouched.
+template <class PP>
+Fp<PP> grind_witness(p3r_ctx* ctx, HostChallenger<PP>& ch, int bits) {
+  using F = Fp<PP>;
+  if (bits == 0) return F::zero();
+  if (bits > 30) fail(P3R_EINVAL, "proof-of-work bits must be <= 30");
+  GrindArgs g{};
+  for (int k = 0; k < 16; ++k) g.state[k] = ch.state[k].v;
+  g.n_pending = (int)ch.in_buf.size();
+  for (int k = 0; k < g.n_pending; ++k) g.pending[k] = ch.in_buf[k].v;
+  g.bits = bits;
+  g.rc = ctx->rc.p;
+  DevBuf res(1);
+  g.result = res.p;
+  uint32_t found = 0xFFFFFFFFu;
+  const uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(bits + 3, 12), 24);
+  // 2^(bits+10) candidates all miss with probability e^-1024; stop there instead of sweeping the field
+  const uint64_t limit = std::min<uint64_t>(PP::P, (uint64_t(1) << std::min<uint32_t>(bits + 10, 31)) + batch);
+  for (uint64_t base = 0; base < limit && found == 0xFFFFFFFFu; base += batch) {
+    P3R_HIP(hipMemsetAsync(res.p, 0xFF, 4, ctx->stream));
+    g.base = (uint32_t)base;
+    ProfScope ps(ctx, "grind");
+    hipLaunchKernelGGL(k_grind<PP>, dim3(batch / kBlock), dim3(kBlock), 0, ctx->stream, g);
+    P3R_HIP(copy_sync(ctx->stream, &found, res.p, 4, hipMemcpyDeviceToHost));
+  }
+  if (found == 0xFFFFFFFFu) fail(P3R_EINVAL, "proof-of-work search found no witness");
+  const F w = F::from_canonical(found);
+  if (!ch.check_witness(bits, w)) fail(P3R_EHIP, "device PoW witness rejected on host");
+  return w;
+}
+
 template <class PP>
 std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, const p3r_matrix* mats, size_t n) {
   using F = Fp<PP>;
@@ -434,8 +467,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     build_plain_layers<PP>(ctx, ph.tree.get(), rows);
     ph.cap = download_cap_mont<PP>(ctx, ph.tree.get());
     for (uint32_t v : ph.cap) ch.observe(F::raw(v));
-    if (cfg.commit_pow_bits) fail(P3R_EUNSUPPORTED, "commit_pow_bits > 0 is not supported yet");
-    commit_pow_witnesses.push_back(F::zero());
+    commit_pow_witnesses.push_back(grind_witness<PP>(ctx, ch, (int)cfg.commit_pow_bits));
     const E beta = ch.sample_ext();
     DevBuf out(4 * rows);
     FriFoldArgs fa{};
@@ -492,32 +524,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   for (auto& c : final_poly) ch.observe_ext(c);
   for (auto& ph : phases) ch.observe(F::from_canonical((uint32_t)ph.la));
   // query proof of work: smallest witness (device search)
-  F query_pow_witness = F::zero();
-  if (cfg.query_pow_bits) {
-    GrindArgs g{};
-    for (int k = 0; k < 16; ++k) g.state[k] = ch.state[k].v;
-    g.n_pending = (int)ch.in_buf.size();
-    for (int k = 0; k < g.n_pending; ++k) g.pending[k] = ch.in_buf[k].v;
-    g.bits = (int)cfg.query_pow_bits;
-    g.rc = ctx->rc.p;
-    DevBuf res(1);
-    g.result = res.p;
-    uint32_t found = 0xFFFFFFFFu;
-    const uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(cfg.query_pow_bits + 3, 12), 24);
-    // 2^(bits+10) candidates miss with probability e^-1024; stop there instead of sweeping the field
-    const uint64_t limit = std::min<uint64_t>(PP::P, (uint64_t(1) << std::min<uint32_t>(cfg.query_pow_bits + 10, 31)) + batch);
-    for (uint64_t base = 0; base < limit && found == 0xFFFFFFFFu; base += batch) {
-      P3R_HIP(hipMemsetAsync(res.p, 0xFF, 4, ctx->stream));
-      g.base = (uint32_t)base;
-      ProfScope ps(ctx, "grind");
-      hipLaunchKernelGGL(k_grind<PP>, dim3(batch / kBlock), dim3(kBlock), 0, ctx->stream, g);
-      P3R_HIP(hipMemcpyAsync(&found, res.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-      P3R_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    if (found == 0xFFFFFFFFu) fail(P3R_EINVAL, "proof-of-work search exhausted the field");
-    query_pow_witness = F::from_canonical(found);
-    if (!ch.check_witness((int)cfg.query_pow_bits, query_pow_witness)) fail(P3R_EHIP, "device PoW witness rejected on host");
-  }
+  const F query_pow_witness = grind_witness<PP>(ctx, ch, (int)cfg.query_pow_bits);
 
   prof_stage(ctx, "queries");
   // ---- 8. queries: one gather launch for every opened row / sibling of every query

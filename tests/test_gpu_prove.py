@@ -30,6 +30,9 @@ CASES = [
     ("baby-bear", 6, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=4, num_queries=5)),
     ("baby-bear", 8, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=6, num_queries=4)),
     ("koala-bear", 10, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=5, query_pow_bits=8, num_queries=8)),
+    # commit-phase proof of work (one grind per FRI phase) and no query PoW
+    ("koala-bear", 7, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, commit_pow_bits=4, query_pow_bits=0, num_queries=5)),
+    ("baby-bear", 7, dict(log_blowup=1, max_log_arity=3, log_final_poly_len=0, commit_pow_bits=3, query_pow_bits=5, num_queries=4)),
 ]
 
 
