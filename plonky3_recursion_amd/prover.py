@@ -186,18 +186,96 @@ def _traces_struct(tr: Traces):
     return t, keep
 
 
+def _varint(v: int) -> bytes:
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _pc_str(s: str) -> bytes:
+    b = s.encode()
+    return _varint(len(b)) + b
+
+
+AIR_VARIANT_BASELINE, AIR_VARIANT_OPTIMIZED = 0, 1
+
+
+@dataclass
+class NonPrimitiveTableEntry:
+    """circuit-prover/src/batch_stark_prover.rs:272-290."""
+    op_type: str
+    rows: int
+    lanes: int = 1
+    public_values: tuple = ()
+    air_variant: int = AIR_VARIANT_BASELINE
+
+
 @dataclass
 class BatchStarkProof:
-    """`proof` holds the postcard bytes of the inner `BatchProof<SC>`; the remaining fields are the
-    metadata the reference stores next to it (batch_stark_prover.rs:610-636)."""
+    """`proof` holds the postcard bytes of the inner `BatchProof<SC>` (what the GPU computes); the
+    remaining fields are the metadata the reference stores next to it
+    (circuit-prover/src/batch_stark_prover.rs:610-636, populated at :1598-1641)."""
     proof: bytes
     table_packing: TablePacking
-    rows: dict
+    rows: tuple                      # RowCounts([const, public, alu]) - op counts, padded to >= 1
+    alu_variant: int = AIR_VARIANT_OPTIMIZED   # BatchStarkProver::new default (:1106-1114)
     ext_degree: int = 4
     w_binomial: Optional[int] = None
     alu_quintic_trinomial: bool = False
-    non_primitives: tuple = ("poseidon2_perm", "recompose")
+    non_primitives: tuple = ()
+    # stark_common: the preprocessed binding (serde_stark_common, :582-607)
     preprocessed_commitment: Optional[np.ndarray] = None
+    preprocessed_widths: tuple = ()
+    degree_bits: tuple = ()
+    monty_r: int = 0                 # 2^32 mod p when field elements serialise in Montgomery form, else 0
+    modulus: int = 0
+
+    def _fe(self, x: int) -> bytes:
+        return _varint((x << 32) % self.modulus if self.monty_r else x)
+
+    def to_postcard(self) -> bytes:
+        """postcard bytes of the whole `BatchStarkProof<SC>`, field order = the serde derives of
+        batch_stark_prover.rs:610-636, packing.rs:9-27, :459-460 (RowCounts), :272-290,
+        :505-511 (SerializedStarkCommon), :495-500."""
+        tp = self.table_packing
+        out = bytearray(self.proof)
+        # TablePacking { public_lanes, alu_lanes, npo_lanes: Vec<(NpoTypeId, usize)>, min_trace_height, horner_packed_steps }
+        out += _varint(tp.public_lanes) + _varint(tp.alu_lanes)
+        npo = [(e.op_type, e.lanes) for e in self.non_primitives if e.lanes != 1]
+        out += _varint(len(npo))
+        for name, lanes in npo:
+            out += _pc_str(name) + _varint(lanes)
+        out += _varint(tp.min_trace_height) + _varint(tp.horner_packed_steps)
+        # RowCounts([usize; 3]) - fixed-size array: no length prefix
+        for r in self.rows:
+            out += _varint(max(int(r), 1))
+        out += _varint(self.alu_variant)               # unit-variant enum -> variant index
+        out += _varint(self.ext_degree)
+        out += (b"\x01" + self._fe(self.w_binomial)) if self.w_binomial is not None else b"\x00"
+        out += b"\x01" if self.alu_quintic_trinomial else b"\x00"
+        out += _varint(len(self.non_primitives))
+        for e in self.non_primitives:
+            out += _pc_str(e.op_type) + _varint(e.rows) + _varint(e.lanes)
+            out += _varint(len(e.public_values)) + b"".join(self._fe(int(v)) for v in e.public_values)
+            out += _varint(e.air_variant)
+        # stark_common: Option<SerializedStarkCommon { commitment, instances: Vec<Option<meta>>, matrix_to_instance }>
+        if self.preprocessed_commitment is None:
+            out += b"\x00"
+        else:
+            cap = np.asarray(self.preprocessed_commitment, dtype=np.uint64).reshape(-1, 8)
+            out += b"\x01" + _varint(cap.shape[0])
+            for d in cap:
+                out += b"".join(self._fe(int(v)) for v in d)
+            out += _varint(len(self.preprocessed_widths))
+            for i, (w, db) in enumerate(zip(self.preprocessed_widths, self.degree_bits)):
+                out += b"\x01" + _varint(i) + _varint(w) + _varint(db)
+            out += _varint(len(self.preprocessed_widths))
+            for i in range(len(self.preprocessed_widths)):
+                out += _varint(i)
+        return bytes(out)
 
 
 W_BINOMIAL = {"koala-bear": 3, "baby-bear": 11}
@@ -222,9 +300,23 @@ class BatchStarkProver:
         else:
             t, keep = _traces_struct(traces)
             raw = self._call(ctx.lib.p3r_prove_all_tables, ctx.h, circuit_prover_data.h, C.byref(t), flags)
-        return BatchStarkProof(proof=raw, table_packing=circuit_prover_data.packing, rows=dict(circuit_prover_data.rows),
-                               w_binomial=W_BINOMIAL[ctx.field],
-                               preprocessed_commitment=circuit_prover_data.preprocessed_commitment)
+        cpd = circuit_prover_data
+        tp = cpd.packing
+        p2_name = "poseidon2_perm/%s_d4_w16" % ctx.field.replace("-", "_")   # circuit/src/ops/npo.rs:38
+        k = tp.horner_packed_steps
+        prep_widths = (2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24, 2 * tp.recompose_lanes)
+        return BatchStarkProof(
+            proof=raw, table_packing=tp,
+            rows=(cpd.rows["const"], cpd.rows["public"], cpd.rows["alu"]),
+            w_binomial=W_BINOMIAL[ctx.field],
+            non_primitives=(
+                # Poseidon2Prover reports the PADDED row count (poseidon2.rs:1449), RecomposeProver the op count (recompose.rs:125)
+                NonPrimitiveTableEntry(op_type=p2_name, rows=cpd.table_heights[3], lanes=1),
+                NonPrimitiveTableEntry(op_type="recompose", rows=cpd.rows["recompose"], lanes=tp.recompose_lanes),
+            ),
+            preprocessed_commitment=cpd.preprocessed_commitment, preprocessed_widths=prep_widths,
+            degree_bits=tuple(int(h).bit_length() - 1 for h in cpd.table_heights),
+            monty_r=0 if canonical_field_encoding else 1, modulus=ctx.p)
 
     def build_main_trace(self, resident: ResidentTraces, cpd: CircuitProverData, table: int) -> DeviceMatrix:
         return DeviceMatrix(self.ctx, self.ctx.ptr(

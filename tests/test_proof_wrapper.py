@@ -1,0 +1,74 @@
+"""CPU: postcard encoding of the outer BatchStarkProof metadata (in-tree serde derives:
+circuit-prover/src/batch_stark_prover.rs:610-636 and the structs it nests)."""
+import numpy as np
+
+from plonky3_recursion_amd import prover as pv
+
+
+def varints(b, n):
+    out, i = [], 0
+    for _ in range(n):
+        v = s = 0
+        while True:
+            x = b[i]; i += 1
+            v |= (x & 0x7F) << s; s += 7
+            if not x & 0x80:
+                break
+        out.append(v)
+    return out, b[i:]
+
+
+def test_wrapper_layout_canonical_encoding():
+    tp = pv.TablePacking(public_lanes=1, alu_lanes=3, horner_packed_steps=4, recompose_lanes=2, min_trace_height=256)
+    cap = np.arange(1, 9, dtype=np.uint32).reshape(1, 8)
+    p = pv.BatchStarkProof(
+        proof=b"\xAA\xBB", table_packing=tp, rows=(70000, 0, 300), w_binomial=3,
+        non_primitives=(pv.NonPrimitiveTableEntry("poseidon2_perm/koala_bear_d4_w16", 1024, 1),
+                        pv.NonPrimitiveTableEntry("recompose", 17, 2)),
+        preprocessed_commitment=cap, preprocessed_widths=(2, 2, 60, 24, 4), degree_bits=(8, 9, 10, 10, 8),
+        monty_r=0, modulus=0x7F000001)
+    b = p.to_postcard()
+    assert b[:2] == b"\xAA\xBB"
+    rest = b[2:]
+    (pl, al, n_npo), rest = varints(rest, 3)
+    assert (pl, al, n_npo) == (1, 3, 1)                      # only non-default NPO lanes are listed
+    (ln,), rest = varints(rest, 1)
+    assert rest[:ln] == b"recompose"
+    (lanes, mth, hk), rest = varints(rest[ln:], 3)
+    assert (lanes, mth, hk) == (2, 256, 4)
+    (r0, r1, r2, alu_variant, ext_deg), rest = varints(rest, 5)
+    assert (r0, r1, r2) == (70000, 1, 300)                   # zero row counts are padded to 1 (:1613-1617)
+    assert (alu_variant, ext_deg) == (pv.AIR_VARIANT_OPTIMIZED, 4)
+    assert rest[0] == 1                                      # Some(w_binomial)
+    (w,), rest = varints(rest[1:], 1)
+    assert w == 3 and rest[0] == 0                           # alu_quintic_trinomial = false
+    (n_np, l0), rest = varints(rest[1:], 2)
+    assert n_np == 2 and rest[:l0] == b"poseidon2_perm/koala_bear_d4_w16"
+    (rows, lanes, n_pv, variant), rest = varints(rest[l0:], 4)
+    assert (rows, lanes, n_pv, variant) == (1024, 1, 0, 0)
+    (l1,), rest = varints(rest, 1)
+    assert rest[:l1] == b"recompose"
+    (rows, lanes, n_pv, variant), rest = varints(rest[l1:], 4)
+    assert (rows, lanes, n_pv, variant) == (17, 2, 0, 0)
+    assert rest[0] == 1                                      # Some(stark_common)
+    (n_cap,), rest = varints(rest[1:], 1)
+    cap_vals, rest = varints(rest, 8)
+    assert n_cap == 1 and cap_vals == list(range(1, 9))
+    (n_inst,), rest = varints(rest, 1)
+    assert n_inst == 5
+    for i, (w_, db) in enumerate(zip((2, 2, 60, 24, 4), (8, 9, 10, 10, 8))):
+        assert rest[0] == 1
+        (mi, ww, d), rest = varints(rest[1:], 3)
+        assert (mi, ww, d) == (i, w_, db)
+    (n_m2i,), rest = varints(rest, 1)
+    m2i, rest = varints(rest, n_m2i)
+    assert m2i == [0, 1, 2, 3, 4] and rest == b""
+
+
+def test_wrapper_montgomery_field_encoding():
+    tp = pv.TablePacking(min_trace_height=4)
+    p = pv.BatchStarkProof(proof=b"", table_packing=tp, rows=(1, 1, 1), w_binomial=11, monty_r=1, modulus=0x78000001)
+    b = p.to_postcard()
+    # ... w_binomial is written as 11 * 2^32 mod p
+    want = (11 << 32) % 0x78000001
+    assert pv._varint(want) in b
