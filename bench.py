@@ -45,15 +45,17 @@ def workload_model(field, heights, widths, packing):
     perms = heights[3]  # K3: one per Poseidon2-table row
     hash_cells = 0
     hash_rows = 0
+    hash_perms = 0
 
     def commit(mats):
-        nonlocal perms, hash_cells, hash_rows
+        nonlocal perms, hash_cells, hash_rows, hash_perms
         by_h = {}
         for h, w in mats:
             by_h[h] = by_h.get(h, 0) + w
         hmax = max(by_h)
         for h, w in by_h.items():
             perms += h * ((w + 7) // 8)
+            hash_perms += h * ((w + 7) // 8)
             hash_cells += h * w
             hash_rows += h
             if h != hmax:
@@ -70,10 +72,11 @@ def workload_model(field, heights, widths, packing):
         la = min(FRI["max_log_arity"], (h // final).bit_length() - 1)
         rows = h >> la
         perms += rows * (((4 << la) + 7) // 8) + rows - 1
+        hash_perms += rows * (((4 << la) + 7) // 8)
         hash_cells += rows * (4 << la)
         hash_rows += rows
         h = rows
-    return perms, 4 * hash_cells + 32 * hash_rows
+    return perms, hash_perms, 4 * hash_cells + 32 * hash_rows
 
 
 def pmc_traffic_bytes(kernel):
@@ -189,7 +192,7 @@ def main():
         k = packing.horner_packed_steps
         widths = [4, 4 * packing.public_lanes, 16 * packing.alu_lanes + ((k - 1) // 2 + 2 * (k - 1) + 1) * 4, p2w,
                   4 * packing.recompose_lanes]
-        perms, hash_bytes = workload_model(field, cpd.table_heights, widths, packing)
+        perms, hash_perms, hash_bytes = workload_model(field, cpd.table_heights, widths, packing)
         kernel_ms = {kk: v[0] / prof_steps for kk, v in prof.items() if not kk.startswith("stage:")}
         stage_ms = {kk[6:]: v[0] / prof_steps for kk, v in prof.items() if kk.startswith("stage:")}
         dominant = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
@@ -241,6 +244,17 @@ def main():
                         "not HBM bound; DESIGN.md gives the VALU ceiling next to this HBM figure",
             },
         }
+        # The dominant kernel is integer-VALU bound, so next to the HBM roofline the contract asks for
+        # we price it against the measured issue rate of the chip (tools/microbench/int_rates.hip:
+        # 54.5 T simple lane-ops/s sustained) and the ~9.0 k instructions of one KoalaBear permutation
+        # (8 full rounds x 520 + 20 partial rounds x 222 + ~300, from the gfx950 ISA of the kernel).
+        hash_total_ms = kernel_ms.get("mmcs_hash_rows", 0.0)
+        if field == "koala-bear" and hash_total_ms:
+            peak = 54.5e12 / 9.0e3
+            ach = hash_perms / (hash_total_ms * 1e-3)
+            line["valu_roofline"] = {"kernel": "k_mmcs_hash_rows (+ strided variant)", "bound": "int-valu",
+                                     "achieved": ach, "peak": peak, "unit": "Poseidon2 perms/s", "frac": ach / peak,
+                                     "perms_per_step_in_kernel": hash_perms}
         if not args.no_cpu_baseline and world == 1:
             lh = args.cpu_baseline_log_height
             cdt = cpu_baseline(field, lh)

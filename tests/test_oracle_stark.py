@@ -93,3 +93,29 @@ def test_poseidon2_chain_break_is_rejected(oracle):
     L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm)
     with pytest.raises(RuntimeError):
         L.verify(L.prove())
+
+
+@pytest.mark.parametrize("lanes,want", [(1, (28, 20)), (2, (44, 33))])
+def test_alu_widths_match_reference_shape_goldens(oracle, lanes, want):
+    """The only literal goldens in the reference: circuit-prover/src/air/shape_golden.rs:48-61
+    (D=4, default horner pack K=2): (main_width, preprocessed_width) = (28, 20) / (44, 33)."""
+    arrs = harness_lib.generate("koala-bear", 5, seed=2, horner_chain_len=6, sponge_chain_len=2, merkle_depth=3)
+    prm = layer_lib.params(log_blowup=1, max_log_arity=1, log_final_poly_len=0, query_pow_bits=1, num_queries=2)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(alu_lanes=lanes, horner_packed_steps=2))
+    alu = [t for t in L.tables() if t["kind"] == "alu"][0]
+    assert (alu["main"].shape[1], alu["prep"].shape[1]) == want
+    const, public = L.tables()[0], L.tables()[1]
+    assert (const["main"].shape[1], const["prep"].shape[1]) == (4, 2)     # shape_golden.rs: D4 const/public
+    assert (public["main"].shape[1], public["prep"].shape[1]) == (4, 2)
+    L.verify(L.prove())
+
+
+def test_field_moduli_match_reference_constants():
+    # circuit-prover/src/batch_stark_prover.rs:76-78, tests.rs:694-733
+    assert oracle_lib_moduli() == {"koala-bear": 0x7F000001, "baby-bear": 0x78000001}
+    assert 0x7F000001 == 2**31 - 2**24 + 1 and 0x78000001 == 2**31 - 2**27 + 1
+
+
+def oracle_lib_moduli():
+    import oracle_lib
+    return dict(oracle_lib.MODULUS)
