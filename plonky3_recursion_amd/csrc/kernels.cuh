@@ -10,6 +10,7 @@
 #pragma once
 #include "field.h"
 #include "poseidon2.h"
+#include "kernels_ntt.cuh"
 
 namespace p3r {
 
@@ -315,163 +316,6 @@ k_mmcs_compress(const uint32_t* __restrict__ L, size_t nl, int lmul, int ladd,
   p2_permute<PP>(s, rc);
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) out[(size_t)k * n + i] = s[k].v;
-}
-
-// ---------------------------------------------------------------------------------
-// K5: radix-2 NTT as LDS-staged tiles (DESIGN.md "NTT / LDE").
-// A polynomial of N = N1*N2 cells is viewed as [N1][N2] (idx = n1*N2 + n2).  One launch
-// transforms along ONE of the two dimensions for a tile of T lines; the size-R sub-NTT
-// runs decimation-in-frequency inside LDS (result k lands in LDS row bitrev(k)).
-// ---------------------------------------------------------------------------------
-struct NttPass {
-  const uint32_t* in;
-  uint32_t* out;
-  uint64_t in_col_stride;    // cells between consecutive polynomials (grid.y)
-  uint64_t out_col_stride;
-  uint64_t out_coset_stride; // cells between consecutive cosets (grid.z)
-  int log_n1, log_n2;
-  int sub_dim;   // 0: transform along n1 (stride-N2 lines), 1: along n2 (contiguous lines)
-  int log_t;     // lines per tile
-  int out_mode;  // 0 keep LDS row order (bit-reversed); 1 natural order, same geometry;
-                 // 2 natural order, transposed: out[n2*N1 + k1] (sub_dim 0 only)
-  const uint32_t* tw_sub;   // Shoup pairs (w_R^i canonical, floor(w*2^32/P)) for i < R/2
-  const uint32_t* tw4_lo;   // optional 4-step twiddles: w_N^x = hi[x >> 10] * lo[x & 1023]
-  const uint32_t* tw4_hi;
-  const uint32_t* pre_a;    // optional per-coset input scaling pre_a[z][n1] * pre_b[z][n2]
-  const uint32_t* pre_b;
-  uint32_t scale;           // Montgomery; multiplied into every output when use_scale
-  int use_scale;
-  int inverse;              // direction (selects root16)
-  uint32_t root16[8];       // w_16^k (or its inverse), k < 8: constants of the register radix-16
-};
-
-__device__ __forceinline__ uint32_t lds_addr(uint32_t r, uint32_t t, uint32_t T) {
-  return r * (T + 1) + (r >> 5) + t;
-}
-
-constexpr int kNttBlock = 1024;  // upper bound; launches use tile_cells/16 lanes (one radix-16 group per lane)
-// Shoup product: a (any u32) times a fixed w < P given w' = floor(w * 2^32 / P); 3 multiplies.
-// The data stays in Montgomery form (x*R) while w is canonical: (x*R)*w = (x*w)*R.
-template <class PP>
-__device__ __forceinline__ Fp<PP> shoup_mul(uint32_t a, uint32_t w, uint32_t wp) {
-  uint32_t q = __umulhi(a, wp);
-  uint32_t r = a * w - q * PP::P;  // in [0, 2P)
-  uint32_t r2 = r - PP::P;
-  return Fp<PP>::raw(r < r2 ? r : r2);
-}
-
-// LOGM consecutive DIF stages (s .. s+LOGM-1) of the size-R sub-NTT done in registers: a lane
-// owns the 2^LOGM rows r0 + j*q (q = R >> (s+LOGM)) of one tile column.  Stage s+u pairs
-// (j, j + M/2^(u+1)) with twiddle w_R^{i << (s+u)}, i = jj*q + low, read as a (w, w') Shoup pair
-// from the LDS copy of the twiddle table.
-template <class PP, int LOGM>
-__device__ __forceinline__ void ntt_stage_group(uint32_t* tile, const uint32_t* tws, int s, int log_r, int log_t,
-                                                uint32_t tid) {
-  using F = Fp<PP>;
-  constexpr int M = 1 << LOGM;
-  const uint32_t T = 1u << log_t;
-  const int lq = log_r - s - LOGM;
-  const uint32_t q = 1u << lq;
-  const uint32_t items = (1u << (log_r - LOGM)) << log_t;
-  for (uint32_t e = tid; e < items; e += blockDim.x) {
-    const uint32_t t = e & (T - 1), b = e >> log_t;
-    const uint32_t low = b & (q - 1), high = b >> lq;
-    const uint32_t r0 = (high << (lq + LOGM)) | low;
-    F x[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) x[j] = F::raw(tile[lds_addr(r0 + j * q, t, T)]);
-#pragma unroll
-    for (int u = 0; u < LOGM; ++u) {
-      const int half = M >> (u + 1);
-      const uint32_t base_idx = low << (s + u);
-#pragma unroll
-      for (int jj = 0; jj < M / 2; ++jj) {
-        if (jj < half) {
-          const uint32_t idx = base_idx + ((uint32_t)jj << (lq + s + u));
-          const uint2 tw = *reinterpret_cast<const uint2*>(&tws[2 * idx]);
-#pragma unroll
-          for (int blk = 0; blk < M; blk += 2 * half) {
-            F p = x[blk + jj], c = x[blk + jj + half];
-            x[blk + jj] = p + c;
-            x[blk + jj + half] = shoup_mul<PP>(p.v + (PP::P - c.v), tw.x, tw.y);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < M; ++j) tile[lds_addr(r0 + j * q, t, T)] = x[j].v;
-  }
-  __syncthreads();
-}
-
-template <class PP>
-__global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
-  using F = Fp<PP>;
-  extern __shared__ uint32_t lds[];
-  const uint32_t tid = threadIdx.x;
-  const int log_r = a.sub_dim == 0 ? a.log_n1 : a.log_n2;
-  const uint32_t R = 1u << log_r, T = 1u << a.log_t;
-  const uint32_t N1 = 1u << a.log_n1, N2 = 1u << a.log_n2;
-  uint32_t* tile = lds;
-  uint32_t* tws = lds + ((R * (T + 1) + (R >> 5) + 2) & ~1u);  // 8-byte aligned (w, w') pairs
-  const uint32_t line0 = blockIdx.x * T;  // first line of the tile (n2 for sub_dim 0, n1 for 1)
-  const uint32_t* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
-  uint32_t* out = a.out + (size_t)blockIdx.y * a.out_col_stride +
-                  (size_t)blockIdx.z * a.out_coset_stride;
-  const uint32_t* pre_a = a.pre_a ? a.pre_a + (size_t)blockIdx.z * N1 : nullptr;
-  const uint32_t* pre_b = a.pre_b ? a.pre_b + (size_t)blockIdx.z * N2 : nullptr;
-
-  for (uint32_t i = tid; i < R; i += blockDim.x) tws[i] = a.tw_sub[i];
-
-  const uint32_t E = R << a.log_t;
-  // ---- load (lanes run along the unit-stride global dimension) ----
-  for (uint32_t e = tid; e < E; e += blockDim.x) {
-    uint32_t r, t, n1, n2;
-    if (a.sub_dim == 0) {
-      t = e & (T - 1); r = e >> a.log_t; n1 = r; n2 = line0 + t;
-    } else {
-      r = e & (R - 1); t = e >> log_r; n1 = line0 + t; n2 = r;
-    }
-    F v = F::raw(in[(size_t)n1 * N2 + n2]);
-    if (pre_a) v = v * (F::raw(pre_a[n1]) * F::raw(pre_b[n2]));
-    tile[lds_addr(r, t, T)] = v.v;
-  }
-  __syncthreads();
-  // ---- DIF butterflies, up to four stages per LDS round trip (register radix-16) ----
-  {
-    int s = 0;
-    while (log_r - s >= 4) { ntt_stage_group<PP, 4>(tile, tws, s, log_r, a.log_t, tid); s += 4; }
-    if (log_r - s == 3) ntt_stage_group<PP, 3>(tile, tws, s, log_r, a.log_t, tid);
-    else if (log_r - s == 2) ntt_stage_group<PP, 2>(tile, tws, s, log_r, a.log_t, tid);
-    else if (log_r - s == 1) ntt_stage_group<PP, 1>(tile, tws, s, log_r, a.log_t, tid);
-  }
-  // ---- store ----
-  const F scale = F::raw(a.scale);
-  for (uint32_t e = tid; e < E; e += blockDim.x) {
-    uint32_t rho, t;  // rho: row index in the OUTPUT geometry
-    bool lanes_along_t = (a.sub_dim == 0 && a.out_mode != 2);
-    if (lanes_along_t) {
-      t = e & (T - 1); rho = e >> a.log_t;
-    } else {
-      rho = e & (R - 1); t = e >> log_r;
-    }
-    uint32_t r = a.out_mode == 0 ? rho : bit_reverse(rho, log_r);  // LDS row
-    uint32_t k = a.out_mode == 0 ? bit_reverse(rho, log_r) : rho;  // sub-NTT output index
-    F v = F::raw(tile[lds_addr(r, t, T)]);
-    uint32_t line = line0 + t;
-    if (a.tw4_lo) {
-      uint32_t x = k * line;  // < N
-      v = v * (F::raw(a.tw4_hi[x >> 10]) * F::raw(a.tw4_lo[x & 1023]));
-    }
-    if (a.use_scale) v = v * scale;
-    size_t o;
-    if (a.sub_dim == 0) {
-      o = a.out_mode == 2 ? (size_t)line * N1 + rho : (size_t)rho * N2 + line;
-    } else {
-      o = (size_t)line * N2 + rho;
-    }
-    out[o] = v.v;
-  }
 }
 
 }  // namespace p3r

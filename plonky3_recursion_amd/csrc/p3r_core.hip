@@ -238,13 +238,6 @@ void launch_ntt(p3r_ctx* ctx, NttPass a, size_t ncols, size_t ncosets, const cha
   if (a.sub_dim == 0 && log_t > 5) log_t = 5;  // 128-byte segments are enough when strided
   log_t = std::min(log_t, log_lines);
   a.log_t = log_t;
-  {
-    using F = Fp<PP>;
-    F w16 = F::two_adic_generator(4);
-    if (a.inverse) w16 = w16.inv();
-    F x = F::one();
-    for (int k = 0; k < 8; ++k) { a.root16[k] = x.v; x *= w16; }
-  }
   const size_t R = size_t(1) << log_r, T = size_t(1) << log_t;
   size_t lds = (R * (T + 1) + (R >> 5) + 2 + R + 2) * sizeof(uint32_t);
   if (lds > 160 * 1024) fail(P3R_EUNSUPPORTED, "NTT tile of 2^%d rows does not fit LDS", log_r);
