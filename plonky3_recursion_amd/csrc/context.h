@@ -85,10 +85,14 @@ struct DevPool {
     free_lists.clear();
     cached_bytes = 0;
   }
+  ~DevPool() { trim(); }
 };
-inline DevPool& dev_pool() {
-  static DevPool pool;
-  return pool;
+// One pool per ctx (a ctx owns one stream, which is what makes reuse safe).  The pool in use is
+// selected per API call (thread-local); a buffer remembers the pool it came from and keeps it
+// alive, so objects may outlive the call - and even the ctx - that created them.
+inline std::shared_ptr<DevPool>& tls_pool() {
+  thread_local std::shared_ptr<DevPool> p;
+  return p;
 }
 
 // Blocking host->device / device->host copy ordered on the ctx stream.
@@ -102,25 +106,31 @@ inline hipError_t copy_sync(hipStream_t s, void* dst, const void* src, size_t by
 struct DevBuf {
   uint32_t* p = nullptr;
   size_t n = 0;
+  std::shared_ptr<DevPool> pool;
   DevBuf() = default;
   explicit DevBuf(size_t cells) { alloc(cells); }
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), pool(std::move(o.pool)) { o.p = nullptr; o.n = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    if (this != &o) { release(); p = o.p; n = o.n; pool = std::move(o.pool); o.p = nullptr; o.n = 0; }
     return *this;
   }
   ~DevBuf() { release(); }
   void alloc(size_t cells) {
     release();
-    if (cells) p = static_cast<uint32_t*>(dev_pool().get(cells * sizeof(uint32_t)));
+    if (cells) {
+      pool = tls_pool();
+      if (!pool) fail(P3R_EINVAL, "device allocation outside a p3r API call");
+      p = static_cast<uint32_t*>(pool->get(cells * sizeof(uint32_t)));
+    }
     n = cells;
   }
   void release() {
-    if (p) dev_pool().put(p, n * sizeof(uint32_t));
+    if (p) pool->put(p, n * sizeof(uint32_t));
     p = nullptr;
     n = 0;
+    pool.reset();
   }
 };
 
@@ -168,6 +178,7 @@ struct ProfRec {
 
 struct p3r_ctx {
   p3r_config cfg{};
+  std::shared_ptr<p3r::DevPool> pool = std::make_shared<p3r::DevPool>();
   bool prof_enabled = false;
   std::vector<p3r::ProfRec> prof;
   // wall-clock per prove stage (only while profiling; each mark synchronises the stream)

@@ -20,7 +20,10 @@ template <class Fn>
 int guard(p3r_ctx* ctx, Fn&& fn) {
   try {
     // the calling thread's current device may have been changed by the embedding framework
-    if (ctx) (void)hipSetDevice(ctx->cfg.device);
+    if (ctx) {
+      (void)hipSetDevice(ctx->cfg.device);
+      tls_pool() = ctx->pool;
+    }
     fn();
     return P3R_OK;
   } catch (const Error& e) {
@@ -505,6 +508,7 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
     P3R_HIP(hipSetDevice(cfg->device));
     auto c = std::make_unique<p3r_ctx>();
     c->cfg = *cfg;
+    tls_pool() = c->pool;
     P3R_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     P3R_FIELD_CALL(c, init_ctx, c.get());
     ctx = c.release();
@@ -518,8 +522,10 @@ void p3r_destroy(p3r_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   prof_clear(ctx);
   (void)hipStreamDestroy(ctx->stream);
+  std::shared_ptr<DevPool> pool = ctx->pool;
   delete ctx;
-  dev_pool().trim();
+  pool->trim();  // cached blocks go back to the driver; blocks still owned by live objects follow later
+  if (tls_pool() == pool) tls_pool().reset();
 }
 
 const char* p3r_last_error(const p3r_ctx* ctx) {
