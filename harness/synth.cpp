@@ -43,11 +43,16 @@ struct Workload {
   std::string err;
 };
 
+// shape knobs for the reference's edge cases: non-primitive tables without rows are left out of the
+// batch, Public / ALU tables holding at most the dummy op run with one lane
+// (batch_stark_prover.rs:1305-1318, tables/alu.rs:69-73)
+enum { SYN_NO_POSEIDON2 = 1, SYN_NO_RECOMPOSE = 2, SYN_SINGLE_PUBLIC = 4, SYN_NO_ALU = 8 };
+
 enum { OP_ADD = 0, OP_MUL = 1, OP_BOOL = 2, OP_MULADD = 3, OP_HORNER = 4 };
 
 template <class PP>
 void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int sponge_chain_len,
-              int merkle_depth, const uint32_t* rc_canonical) {
+              int merkle_depth, const uint32_t* rc_canonical, uint32_t flags) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
   const uint32_t P = PP::P;
@@ -67,7 +72,10 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   auto put_e = [&](std::vector<uint32_t>& dst, const E& e) { for (int i = 0; i < 4; ++i) dst.push_back(e.c[i].to_canonical()); };
 
   // ---- Const (H/16 rows) and Public (H/2 ops) ----
-  const size_t n_const = std::max<size_t>(H / 16, 2), n_public = std::max<size_t>(H / 2, 2);
+  if ((flags & SYN_SINGLE_PUBLIC) && !(flags & SYN_NO_POSEIDON2))
+    throw std::runtime_error("SYN_SINGLE_PUBLIC needs SYN_NO_POSEIDON2 (Merkle accumulators are public inputs)");
+  const size_t n_const = std::max<size_t>(H / 16, 2);
+  const size_t n_public = (flags & SYN_SINGLE_PUBLIC) ? 1 : std::max<size_t>(H / 2, 2);
   std::vector<uint32_t> const_w, public_w;
   {
     // witness 0 is the zero constant, witness 1 is one (handy for bool ops)
@@ -77,7 +85,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   }
 
   // ---- Poseidon2 chain plan first (its accumulator values need Public witnesses) ----
-  const size_t n_p2 = std::max<size_t>(H / 2, 4);
+  const size_t n_p2 = (flags & SYN_NO_POSEIDON2) ? 0 : std::max<size_t>(H / 2, 4);
   struct P2Plan { bool new_start, merkle, bit, mmcs_ctl; uint32_t acc; };
   std::vector<P2Plan> plan;
   {
@@ -117,7 +125,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   while (public_w.size() < n_public) public_w.push_back(create(re()));
 
   // ---- Recompose (H/4 rows): creates an extension witness from 4 base coefficients ----
-  const size_t n_rec = std::max<size_t>(H / 4, 2);
+  const size_t n_rec = (flags & SYN_NO_RECOMPOSE) ? 0 : std::max<size_t>(H / 4, 2);
   std::vector<uint32_t> rec_w;
   for (size_t i = 0; i < n_rec; ++i) rec_w.push_back(create(re()));
 
@@ -218,7 +226,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
       size_t fill = 2 * chain_rows;
       return chain_rows + (nonchain > fill ? (nonchain - fill + lanes - 1) / lanes : 0);
     };
-    const size_t target = H > 16 ? H - 4 : H - 1;
+    const size_t target = (flags & SYN_NO_ALU) ? 0 : (H > 16 ? H - 4 : H - 1);
     while (rows_now() < target) {
       double u = rng.unit();
       if (u < p_chain) {
@@ -277,6 +285,13 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
                         1u, o.c_rd ? 1u : 0u};
     alu_prep.insert(alu_prep.end(), row, row + 13);
   }
+  if (ops.empty()) {
+    // AluTrace::from_records / get_airs_and_degrees_with_prep add one all-zero dummy op
+    // (tables/alu.rs:69-73, common.rs:283-286)
+    alu_prep.insert(alu_prep.end(), 13, 0u);
+    alu_values.insert(alu_values.end(), 16, 0u);
+    ops.push_back({OP_ADD, 0, 0, 0, 0, false});
+  }
   W.arr["counts"] = {(uint32_t)const_w.size(), (uint32_t)public_w.size(), (uint32_t)ops.size(),
                      (uint32_t)n_p2, (uint32_t)rec_w.size(), (uint32_t)wval.size()};
 }
@@ -286,11 +301,11 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
 extern "C" {
 
 void* syn_generate(int field, int log_h, uint64_t seed, int horner_chain_len, int sponge_chain_len,
-                   int merkle_depth, const uint32_t* rc_canonical) {
+                   int merkle_depth, const uint32_t* rc_canonical, uint32_t flags) {
   auto* W = new Workload();
   try {
-    if (field == 0) generate<KoalaBearParams>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical);
-    else if (field == 1) generate<BabyBearParams>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical);
+    if (field == 0) generate<KoalaBearParams>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (field == 1) generate<BabyBearParams>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else throw std::runtime_error("unknown field");
   } catch (const std::exception& e) {
     W->err = e.what();

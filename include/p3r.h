@@ -262,8 +262,14 @@ typedef struct p3r_dtraces p3r_dtraces;
 
 p3r_layer* p3r_layer_create(p3r_ctx* ctx, const p3r_layer_desc* desc, uint32_t* commit_out);
 void p3r_layer_free(p3r_ctx* ctx, p3r_layer* layer);
-/* Padded heights of the five tables, in instance order. */
+/* Padded heights of [Const, Public, ALU, Poseidon2, Recompose]; 0 = the table is not part of the
+ * batch: a non-primitive table with no rows is left out, as `batch_instance_*` returning None does
+ * (batch_stark_prover/poseidon2.rs:1089-1092, recompose.rs:77-80). */
 int p3r_layer_table_heights(const p3r_layer* layer, size_t heights_out[5]);
+/* The packing the proof was made with: Public / ALU lanes fall back to 1 when the table holds at
+ * most the dummy op (reduce_lanes_if_dummy, batch_stark_prover.rs:1305-1318); BatchStarkProof
+ * stores this effective packing (:1617-1622). */
+int p3r_layer_effective_lanes(const p3r_layer* layer, uint32_t* public_lanes, uint32_t* alu_lanes);
 
 /* Per-proof inputs made resident in HBM once; a prove can then be repeated without PCIe. */
 p3r_dtraces* p3r_traces_upload(p3r_ctx* ctx, const p3r_layer* layer, const p3r_traces* traces);

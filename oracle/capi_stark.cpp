@@ -82,8 +82,13 @@ struct Layer : LayerBase {
 
   // order [Const, Public, Alu, Poseidon2, Recompose]
   // (circuit-prover/src/batch_stark_prover.rs:1493-1519; backend/fri.rs:693-721)
+  // Lanes of a Public / ALU table holding at most the dummy op fall back to 1
+  // (reduce_lanes_if_dummy, batch_stark_prover.rs:1305-1318); a non-primitive table with no
+  // rows is not part of the batch (batch_stark_prover/poseidon2.rs:1089-1092, recompose.rs:77-80).
   void build(const orc_workload& w) {
     const size_t mh = w.min_trace_height;
+    const int public_lanes = w.n_public <= 1 ? 1 : (int)w.public_lanes;
+    const int alu_lanes = w.n_alu <= 1 ? 1 : (int)w.alu_lanes;
     {
       Instance<FP> in;
       in.air.kind = AIR_CONST; in.air.lanes = 1;
@@ -93,14 +98,14 @@ struct Layer : LayerBase {
     }
     {
       Instance<FP> in;
-      in.air.kind = AIR_PUBLIC; in.air.lanes = (int)w.public_lanes;
+      in.air.kind = AIR_PUBLIC; in.air.lanes = public_lanes;
       in.main = lanes_trace_to_matrix<FP>(vec(w.public_values, w.n_public * 4), in.air.lanes, mh);
       in.prep = lanes_prep_to_matrix<FP>(vec(w.public_prep, w.n_public * 2), 2, in.air.lanes, mh);
       insts.push_back(std::move(in));
     }
     {
       Instance<FP> in;
-      in.air.kind = AIR_ALU; in.air.lanes = (int)w.alu_lanes; in.air.horner_k = (int)w.horner_packed_steps;
+      in.air.kind = AIR_ALU; in.air.lanes = alu_lanes; in.air.horner_k = (int)w.horner_packed_steps;
       auto values = vec(w.alu_values, w.n_alu * 16);
       auto prep = vec(w.alu_prep13, w.n_alu * 13);
       in.main = alu_trace_to_matrix<FP>(in.air, values, prep, mh);
@@ -108,7 +113,7 @@ struct Layer : LayerBase {
       if (in.main.h != in.prep.h) throw std::runtime_error("ALU main/prep height mismatch");
       insts.push_back(std::move(in));
     }
-    {
+    if (w.n_p2 > 0) {
       Instance<FP> in;
       in.air.kind = AIR_POSEIDON2;
       // pad the op list to a power of two >= min height with filler rows
@@ -137,7 +142,7 @@ struct Layer : LayerBase {
       in.prep = p2_preprocessed_trace<FP>(ctl, n);
       insts.push_back(std::move(in));
     }
-    {
+    if (w.n_recompose > 0) {
       Instance<FP> in;
       in.air.kind = AIR_RECOMPOSE; in.air.lanes = (int)w.recompose_lanes; in.air.coeff_lookups = 0;
       in.main = lanes_trace_to_matrix<FP>(vec(w.recompose_values, w.n_recompose * 4), in.air.lanes, mh);

@@ -125,6 +125,7 @@ SIGNATURES = {
     "p3r_layer_create": (vp, [vp, C.POINTER(P3rLayerDesc), u32p]),
     "p3r_layer_free": (None, [vp, vp]),
     "p3r_layer_table_heights": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "p3r_layer_effective_lanes": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "p3r_traces_upload": (vp, [vp, vp, C.POINTER(P3rTraces)]),
     "p3r_traces_free": (None, [vp, vp]),
     "p3r_prove_all_tables": (C.c_int, [vp, vp, C.POINTER(P3rTraces), C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t,

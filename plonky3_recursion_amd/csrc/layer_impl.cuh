@@ -182,6 +182,14 @@ struct p3r_layer {
   p3r_layer_desc_counts counts{};
   uint32_t public_lanes = 1, alu_lanes = 1, horner_k = 2, recompose_lanes = 1, min_height = 1;
   size_t h_const = 0, h_public = 0, h_alu = 0, h_p2 = 0, h_recompose = 0, alu_rows = 0;
+  // A non-primitive table with no rows is not part of the batch (poseidon2.rs:1089-1092,
+  // recompose.rs:77-80: `batch_instance_*` returns None); the primitive three always are.
+  bool has_p2 = true, has_recompose = true;
+  int slot_of(int table) const {  // position of table 0..4 among the proved instances, -1 if absent
+    if (table < 3) return table;
+    if (table == 3) return has_p2 ? 3 : -1;
+    return has_recompose ? (has_p2 ? 4 : 3) : -1;
+  }
   std::unique_ptr<p3r_prep> prep;
   p3r::DevBuf alu_plan, alu_prev_src;
 };
@@ -203,6 +211,12 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   L->public_lanes = d->public_lanes; L->alu_lanes = d->alu_lanes; L->horner_k = d->horner_packed_steps;
   L->recompose_lanes = d->recompose_lanes; L->min_height = d->min_trace_height;
   if (!L->public_lanes || !L->alu_lanes || !L->recompose_lanes) fail(P3R_EINVAL, "lane counts must be positive");
+  // reduce_lanes_if_dummy (batch_stark_prover.rs:1305-1318, common.rs:150-160): a Public / ALU table
+  // that holds at most the dummy op is proved with one lane, and the proof records that packing.
+  if (d->counts.n_public <= 1) L->public_lanes = 1;
+  if (d->counts.n_alu <= 1) L->alu_lanes = 1;
+  L->has_p2 = d->counts.n_p2 > 0;
+  L->has_recompose = d->counts.n_recompose > 0;
   if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
   const auto& c = d->counts;
   auto check = [&](const uint32_t* p, size_t n, const char* what) {
@@ -271,7 +285,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     P3R_HIP(copy_sync(ctx->stream, L->alu_prev_src.p, S.prev_src.data(), S.prev_src.size() * 4, hipMemcpyHostToDevice));
   }
   // Poseidon2 preprocessed rows (air.rs:697-794, non-compact D=4 layout) + padding (:613-649)
-  {
+  if (L->has_p2) {
     L->h_p2 = padded_height(c.n_p2, mh);
     std::vector<uint32_t>& m = mats[3];
     m.assign(L->h_p2 * 24, 0);
@@ -297,13 +311,20 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     }
     if (L->h_p2 > c.n_p2) m[c.n_p2 * 24 + 22] = 1;
   }
-  mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, 2, (int)L->recompose_lanes, L->h_recompose);
+  if (L->has_recompose)
+    mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, 2, (int)L->recompose_lanes, L->h_recompose);
   const int widths[5] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1), 24,
                          (int)L->recompose_lanes * 2};
   const size_t heights[5] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose};
   p3r_matrix pm[5];
-  for (int i = 0; i < 5; ++i) pm[i] = {mats[i].data(), heights[i], (size_t)widths[i]};
-  L->prep = prep_create<PP>(ctx, airs, pm, 5);
+  p3r_air_desc present_airs[5];
+  size_t n_present = 0;
+  for (int i = 0; i < 5; ++i) {
+    if (L->slot_of(i) < 0) continue;
+    present_airs[n_present] = airs[i];
+    pm[n_present++] = {mats[i].data(), heights[i], (size_t)widths[i]};
+  }
+  L->prep = prep_create<PP>(ctx, present_airs, pm, n_present);
   std::copy(L->prep->cap_canonical.begin(), L->prep->cap_canonical.end(), commit_out);
   return L;
 }
@@ -333,6 +354,7 @@ std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, con
   d->public_values = upload_mont<PP>(ctx, t->public_values, c.n_public * 4, "public_values");
   d->alu_values = upload_mont<PP>(ctx, t->alu_values, c.n_alu * 16, "alu_values");
   d->recompose_values = upload_mont<PP>(ctx, t->recompose_values, c.n_recompose * 4, "recompose_values");
+  if (!L->has_p2) return d;
   // Poseidon2 rows padded with fillers: new_start = true, zero state (poseidon2.rs:1125-1140)
   const size_t h = L->h_p2, n = c.n_p2;
   std::vector<uint32_t> in(h * 16, 0), idx(h, 0);
@@ -351,7 +373,7 @@ std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, con
   return d;
 }
 
-// K1 + K2 + K3: the five main-trace matrices in instance order.
+// K1 + K2 + K3: the main-trace matrices, indexed by table 0..4 (absent tables stay null).
 template <class PP>
 std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t) {
   std::vector<std::unique_ptr<p3r_dmat>> m(5);
@@ -374,8 +396,8 @@ std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r
                        reinterpret_cast<const AluPlanEntry*>(L->alu_plan.p), L->alu_prev_src.p, t->alu_values.p,
                        L->alu_rows, L->h_alu, lanes, k, m[2]->d);
   }
-  m[3] = trace_fill<PP>(ctx, t->p2.get());
-  m[4] = flat(t->recompose_values, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * 4);
+  if (L->has_p2) m[3] = trace_fill<PP>(ctx, t->p2.get());
+  if (L->has_recompose) m[4] = flat(t->recompose_values, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * 4);
   P3R_HIP(hipGetLastError());
   return m;
 }
@@ -385,8 +407,10 @@ std::vector<uint8_t> prove_all_tables(p3r_ctx* ctx, const p3r_layer* L, const p3
   prof_stage(ctx, "build_traces");
   auto mains = build_main_traces<PP>(ctx, L, t);
   const p3r_dmat* ptrs[5];
-  for (int i = 0; i < 5; ++i) ptrs[i] = mains[i].get();
-  return prove_batch<PP>(ctx, L->prep.get(), ptrs, 5, canonical);
+  size_t n = 0;
+  for (int i = 0; i < 5; ++i)
+    if (mains[i]) ptrs[n++] = mains[i].get();
+  return prove_batch<PP>(ctx, L->prep.get(), ptrs, n, canonical);
 }
 
 }  // namespace

@@ -22,6 +22,7 @@ verifier circuit (`build_next_layer_circuit`, `CircuitRunner::run`).  `Recursion
 carries the `Traces` that run produced; everything from there to the proof bytes is on the GPU.
 """
 import ctypes as C
+import dataclasses
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -125,7 +126,11 @@ class CircuitProverData:
                                                   self.preprocessed_commitment.ctypes.data_as(_lib.u32p)))
         hs = (C.c_size_t * 5)()
         ctx.check(ctx.lib.p3r_layer_table_heights(self.h, hs))
-        self.table_heights = [int(x) for x in hs]
+        self.table_heights = [int(x) for x in hs]   # 0 = table absent from the batch
+        pl, al = C.c_uint32(), C.c_uint32()
+        ctx.check(ctx.lib.p3r_layer_effective_lanes(self.h, C.byref(pl), C.byref(al)))
+        # reduce_lanes_if_dummy (batch_stark_prover.rs:1305-1318): what the proof records (:1617-1622)
+        self.effective_packing = dataclasses.replace(packing, public_lanes=pl.value, alu_lanes=al.value)
 
     def free(self):
         if self.h and self.ctx.h:
@@ -301,21 +306,27 @@ class BatchStarkProver:
             t, keep = _traces_struct(traces)
             raw = self._call(ctx.lib.p3r_prove_all_tables, ctx.h, circuit_prover_data.h, C.byref(t), flags)
         cpd = circuit_prover_data
-        tp = cpd.packing
+        tp = cpd.effective_packing
         p2_name = "poseidon2_perm/%s_d4_w16" % ctx.field.replace("-", "_")   # circuit/src/ops/npo.rs:38
         k = tp.horner_packed_steps
+        present = [h > 0 for h in cpd.table_heights]
         prep_widths = (2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24, 2 * tp.recompose_lanes)
+        # non-primitive tables without rows are not proved (poseidon2.rs:1089-1092, recompose.rs:77-80)
+        npo = []
+        if present[3]:
+            # Poseidon2Prover reports the PADDED row count (poseidon2.rs:1449)
+            npo.append(NonPrimitiveTableEntry(op_type=p2_name, rows=cpd.table_heights[3], lanes=1))
+        if present[4]:
+            # RecomposeProver reports the op count (recompose.rs:125)
+            npo.append(NonPrimitiveTableEntry(op_type="recompose", rows=cpd.rows["recompose"], lanes=tp.recompose_lanes))
         return BatchStarkProof(
             proof=raw, table_packing=tp,
             rows=(cpd.rows["const"], cpd.rows["public"], cpd.rows["alu"]),
             w_binomial=W_BINOMIAL[ctx.field],
-            non_primitives=(
-                # Poseidon2Prover reports the PADDED row count (poseidon2.rs:1449), RecomposeProver the op count (recompose.rs:125)
-                NonPrimitiveTableEntry(op_type=p2_name, rows=cpd.table_heights[3], lanes=1),
-                NonPrimitiveTableEntry(op_type="recompose", rows=cpd.rows["recompose"], lanes=tp.recompose_lanes),
-            ),
-            preprocessed_commitment=cpd.preprocessed_commitment, preprocessed_widths=prep_widths,
-            degree_bits=tuple(int(h).bit_length() - 1 for h in cpd.table_heights),
+            non_primitives=tuple(npo),
+            preprocessed_commitment=cpd.preprocessed_commitment,
+            preprocessed_widths=tuple(w for w, ok in zip(prep_widths, present) if ok),
+            degree_bits=tuple(int(h).bit_length() - 1 for h in cpd.table_heights if h > 0),
             monty_r=0 if canonical_field_encoding else 1, modulus=ctx.p)
 
     def build_main_trace(self, resident: ResidentTraces, cpd: CircuitProverData, table: int) -> DeviceMatrix:

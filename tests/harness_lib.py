@@ -23,12 +23,16 @@ def build():
     subprocess.run(["make", "-C", HDIR], check=True, capture_output=True)
 
 
-def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None):
+NO_POSEIDON2, NO_RECOMPOSE, SINGLE_PUBLIC, NO_ALU = 1, 2, 4, 8
+
+
+def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None,
+             flags=0):
     """Returns dict name -> np.uint32 array (see harness/synth.cpp)."""
     build()
     lib = C.CDLL(LIB)
     lib.syn_generate.restype = C.c_void_p
-    lib.syn_generate.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, u32p]
+    lib.syn_generate.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, u32p, C.c_uint32]
     lib.syn_error.restype = C.c_char_p
     lib.syn_error.argtypes = [C.c_void_p]
     lib.syn_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(u32p), C.POINTER(C.c_size_t)]
@@ -38,7 +42,7 @@ def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_le
         rc = oracle_lib.default_rc(field)
     rc = np.ascontiguousarray(rc, dtype=np.uint32)
     h = lib.syn_generate(FIELD_IDS[field], log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth,
-                         rc.ctypes.data_as(u32p))
+                         rc.ctypes.data_as(u32p), flags)
     try:
         err = lib.syn_error(h)
         if err:

@@ -92,3 +92,47 @@ def test_row_count_mismatch_is_reported(oracle):
         cache.prover.prove_all_tables(traces, cache.circuit_prover_data)
     cache.circuit_prover_data.free()
     ctx.close()
+
+
+EDGE_SHAPES = [
+    harness_lib.NO_POSEIDON2,
+    harness_lib.NO_RECOMPOSE,
+    harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC,
+    harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU,
+]
+
+
+@pytest.mark.parametrize("flags", EDGE_SHAPES)
+def test_absent_tables_and_dummy_lane_reduction(oracle, flags):
+    """Tables without rows are left out of the batch, dummy-only Public / ALU tables use one lane
+    (batch_stark_prover.rs:1305-1318, poseidon2.rs:1089-1092, recompose.rs:77-80); the effective
+    packing is what the proof wrapper records (:1617-1622)."""
+    from plonky3_recursion_amd import prover as pv
+    arrs, L, ctx, cache, traces = setup(oracle, "koala-bear", 6,
+                                        dict(log_blowup=1, log_final_poly_len=1, query_pow_bits=3, num_queries=4),
+                                        dict(public_lanes=2, alu_lanes=3), horner_chain_len=8, flags=flags)
+    tables = L.tables()
+    cpd = cache.circuit_prover_data
+    assert [h for h in cpd.table_heights if h] == [t["main"].shape[0] for t in tables]
+    assert [i for i, h in enumerate(cpd.table_heights) if h] == [t["kind_id"] for t in tables]
+    assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
+    res = pv.ResidentTraces(ctx, cpd, traces)
+    for t in tables:
+        got = cache.prover.build_main_trace(res, cpd, t["kind_id"]).download()
+        assert np.array_equal(got, t["main"]), t["kind"]
+    for absent in set(range(5)) - {t["kind_id"] for t in tables}:
+        with pytest.raises(pv.P3rError):
+            cache.prover.build_main_trace(res, cpd, absent)
+    out = cache.prover.prove_all_tables(res, cpd)
+    assert out.proof == L.prove()
+    L.verify(out.proof)
+    by_kind = {t["kind"]: t for t in tables}
+    assert out.table_packing.public_lanes == by_kind["public"]["lanes"]
+    assert out.table_packing.alu_lanes == by_kind["alu"]["lanes"]
+    assert len(out.non_primitives) == len(tables) - 3
+    assert len(out.degree_bits) == len(out.preprocessed_widths) == len(tables)
+    assert out.preprocessed_widths == tuple(t["prep"].shape[1] for t in tables)
+    out.to_postcard()
+    res.free()
+    cpd.free()
+    ctx.close()

@@ -119,3 +119,33 @@ def test_field_moduli_match_reference_constants():
 def oracle_lib_moduli():
     import oracle_lib
     return dict(oracle_lib.MODULUS)
+
+
+EDGE_SHAPES = [
+    (harness_lib.NO_POSEIDON2, ["const", "public", "alu", "recompose"]),
+    (harness_lib.NO_RECOMPOSE, ["const", "public", "alu", "poseidon2"]),
+    (harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC, ["const", "public", "alu"]),
+    (harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU, ["const", "public", "alu", "recompose"]),
+]
+
+
+@pytest.mark.parametrize("flags,kinds", EDGE_SHAPES)
+def test_absent_tables_and_dummy_lane_reduction(oracle, flags, kinds):
+    """Non-primitive tables without rows are left out of the batch (poseidon2.rs:1089-1092,
+    recompose.rs:77-80); Public / ALU tables holding at most the dummy op use one lane
+    (batch_stark_prover.rs:1305-1318)."""
+    arrs = harness_lib.generate("koala-bear", 6, seed=9, horner_chain_len=8, sponge_chain_len=3, merkle_depth=4,
+                                flags=flags)
+    prm = layer_lib.params(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(public_lanes=2, alu_lanes=3))
+    tables = L.tables()
+    assert [t["kind"] for t in tables] == kinds
+    by_kind = {t["kind"]: t for t in tables}
+    assert by_kind["public"]["lanes"] == (1 if flags & harness_lib.SINGLE_PUBLIC else 2)
+    assert by_kind["alu"]["lanes"] == (1 if flags & harness_lib.NO_ALU else 3)
+    proof = L.prove()
+    L.verify(proof)
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    with pytest.raises(RuntimeError):
+        L.verify(bytes(bad))
