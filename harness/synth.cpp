@@ -50,6 +50,11 @@ enum { SYN_NO_POSEIDON2 = 1, SYN_NO_RECOMPOSE = 2, SYN_SINGLE_PUBLIC = 4, SYN_NO
 
 enum { OP_ADD = 0, OP_MUL = 1, OP_BOOL = 2, OP_MULADD = 3, OP_HORNER = 4 };
 
+// circuit op kinds of include/p3r.h (p3r_op_kind)
+enum : uint32_t { C_CONST = 0, C_PUBLIC = 1, C_ADD = 2, C_MUL = 3, C_BOOL = 4, C_MULADD = 5, C_HORNER = 6,
+                  C_HINT_EXT = 7, C_HINT_BIN = 8, C_P2 = 9, C_RECOMPOSE = 10 };
+constexpr uint32_t NO_W = 0xFFFFFFFFu;
+
 template <class PP>
 void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int sponge_chain_len,
               int merkle_depth, const uint32_t* rc_canonical, uint32_t flags) {
@@ -64,24 +69,45 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   std::vector<uint32_t> rc_m(p2_num_constants<PP>());
   for (size_t i = 0; i < rc_m.size(); ++i) rc_m[i] = F::from_canonical(rc_canonical[i]).v;
 
+  // ---- the circuit being built (flattened Circuit<EF>, include/p3r.h) ----
+  auto& c_ops = W.arr["ops"];   // n x 8: kind, a, b, c, out, aux, ext_off, ext_len
+  auto& c_ext = W.arr["ext"];
+  auto push_op = [&](uint32_t kind, uint32_t a, uint32_t b, uint32_t c, uint32_t out, uint32_t aux,
+                     const std::vector<uint32_t>& ext) {
+    const uint32_t off = (uint32_t)c_ext.size();
+    c_ext.insert(c_ext.end(), ext.begin(), ext.end());
+    const uint32_t row[8] = {kind, a, b, c, out, aux, off, (uint32_t)ext.size()};
+    c_ops.insert(c_ops.end(), row, row + 8);
+  };
+  uint32_t next_npo_id = 0;
+
   // witness table
   std::vector<E> wval;
   std::vector<uint32_t> reads;
   auto create = [&](const E& v) { wval.push_back(v); reads.push_back(0); return (uint32_t)(wval.size() - 1); };
   auto pick = [&]() { uint32_t w = rng.below((uint32_t)wval.size()); reads[w]++; return w; };
   auto put_e = [&](std::vector<uint32_t>& dst, const E& e) { for (int i = 0; i < 4; ++i) dst.push_back(e.c[i].to_canonical()); };
+  auto canon4 = [&](const E& e) { std::vector<uint32_t> v; put_e(v, e); return v; };
 
   // ---- Const (H/16 rows) and Public (H/2 ops) ----
   if ((flags & SYN_SINGLE_PUBLIC) && !(flags & SYN_NO_POSEIDON2))
     throw std::runtime_error("SYN_SINGLE_PUBLIC needs SYN_NO_POSEIDON2 (Merkle accumulators are public inputs)");
-  const size_t n_const = std::max<size_t>(H / 16, 2);
+  const size_t n_const = std::max<size_t>(H / 16, 8);
   const size_t n_public = (flags & SYN_SINGLE_PUBLIC) ? 1 : std::max<size_t>(H / 2, 2);
-  std::vector<uint32_t> const_w, public_w;
+  std::vector<uint32_t> const_w, public_w, base_valued;
   {
-    // witness 0 is the zero constant, witness 1 is one (handy for bool ops)
+    // witness 0 is the zero constant (the lowerer's ExprId::ZERO), witness 1 is one; every other
+    // constant alternates between a base-field value (coefficients of Recompose ops) and a full
+    // extension value
     const_w.push_back(create(E::zero()));
     const_w.push_back(create(E::one()));
-    while (const_w.size() < n_const) const_w.push_back(create(re()));
+    while (const_w.size() < n_const) {
+      const bool base = const_w.size() & 1;
+      uint32_t w = create(base ? E::from_base(rf()) : re());
+      if (base) base_valued.push_back(w);
+      const_w.push_back(w);
+    }
+    for (uint32_t w : const_w) push_op(C_CONST, 0, 0, 0, w, 0, canon4(wval[w]));
   }
 
   // ---- Poseidon2 chain plan first (its accumulator values need Public witnesses) ----
@@ -89,7 +115,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   struct P2Plan { bool new_start, merkle, bit, mmcs_ctl; uint32_t acc; };
   std::vector<P2Plan> plan;
   {
-    // leave room for the trailing partial chain; ~70% Merkle rows, ~30% sponge rows
+    // ~70% Merkle rows, ~30% sponge rows
     while (plan.size() < n_p2) {
       bool merkle = rng.unit() < 0.7;
       size_t len = merkle ? (size_t)merkle_depth : (size_t)sponge_chain_len;
@@ -111,7 +137,6 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   // ends of Merkle chains with mmcs_ctl: the row sends (idx, acc); it is followed by a
   // new_start row (or by the table padding, whose first row carries new_start = 1).
   std::vector<int64_t> acc_wid(n_p2, -1);
-  std::vector<uint32_t> public_vals_w;
   for (size_t r = 0; r < n_p2; ++r) {
     bool last_of_chain = (r + 1 == n_p2) || plan[r + 1].new_start;
     if (plan[r].merkle && plan[r].mmcs_ctl && last_of_chain) {
@@ -123,101 +148,183 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     }
   }
   while (public_w.size() < n_public) public_w.push_back(create(re()));
+  auto& public_rows = W.arr["public_rows"]; auto& in_public = W.arr["in_public_values"];
+  for (size_t i = 0; i < public_w.size(); ++i) {
+    push_op(C_PUBLIC, 0, 0, 0, public_w[i], (uint32_t)i, {});
+    public_rows.push_back(public_w[i]);
+    put_e(in_public, wval[public_w[i]]);
+  }
 
-  // ---- Recompose (H/4 rows): creates an extension witness from 4 base coefficients ----
+  // ---- private inputs: set before the run, claimed on the bus by their first ALU use
+  // (circuit.rs:247-250,351-359) ----
+  const size_t n_private = (flags & SYN_NO_ALU) ? 0 : std::max<size_t>(H / 64, 2);
+  std::vector<uint32_t> private_w;
+  auto& private_rows = W.arr["private_rows"]; auto& in_private = W.arr["in_private_values"];
+  for (size_t i = 0; i < n_private; ++i) {
+    uint32_t w = create(re());
+    private_w.push_back(w);
+    private_rows.push_back(w);
+    put_e(in_private, wval[w]);
+  }
+  // witnesses other tables may read right now (private inputs only after an ALU op claimed them)
+  std::vector<uint32_t> pickable;
+  for (uint32_t w : const_w) pickable.push_back(w);
+  for (uint32_t w : public_w) pickable.push_back(w);
+  auto pickp_noread = [&]() { return pickable[rng.below((uint32_t)pickable.size())]; };
+  auto pickp = [&]() { uint32_t w = pickp_noread(); reads[w]++; return w; };
+
+  // ---- Recompose (H/4 rows): packs 4 base-field witnesses into one extension witness
+  // (ops/recompose.rs:115-170; the coefficient witnesses are not looked up without coeff_lookups) ----
   const size_t n_rec = (flags & SYN_NO_RECOMPOSE) ? 0 : std::max<size_t>(H / 4, 2);
   std::vector<uint32_t> rec_w;
-  for (size_t i = 0; i < n_rec; ++i) rec_w.push_back(create(re()));
+  auto& rec_values = W.arr["recompose_values"];
+  for (size_t i = 0; i < n_rec; ++i) {
+    std::vector<uint32_t> ins(4);
+    E v;
+    for (int k = 0; k < 4; ++k) {
+      ins[k] = base_valued[rng.below((uint32_t)base_valued.size())];
+      v.c[k] = wval[ins[k]].c[0];
+      rec_values.push_back(v.c[k].to_canonical());
+    }
+    uint32_t w = create(v);
+    rec_w.push_back(w);
+    pickable.push_back(w);
+    push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, 0, ins);
+  }
 
-  // ---- Poseidon2 rows ----
+  // ---- Poseidon2 rows (executor semantics: ops/poseidon_perm/executor.rs:921-972) ----
   auto& p2_inputs = W.arr["p2_inputs"];      // n x 16
   auto& p2_flags = W.arr["p2_flags"];        // n x 4: new_start, merkle_path, mmcs_bit, mmcs_ctl_enabled
   auto& p2_index_sum = W.arr["p2_mmcs_index_sum"];
   auto& p2_in_ctl = W.arr["p2_in_ctl"];      // n x 4
   auto& p2_in_idx = W.arr["p2_input_indices"];
-  auto& p2_out_ctl = W.arr["p2_out_ctl"];    // n x 2, canonical multiplicity (n_reads)
+  auto& p2_out_ctl = W.arr["p2_out_ctl"];    // n x 2, canonical multiplicity
   auto& p2_out_idx = W.arr["p2_output_indices"];
   auto& p2_acc_idx = W.arr["p2_mmcs_index_sum_idx"];
+  auto& pd_ids = W.arr["pd_op_ids"]; auto& pd_sib = W.arr["pd_siblings"];
   struct OutFix { size_t row; int limb; uint32_t wid; };
   std::vector<OutFix> out_fix;
   {
     F state[16];
     for (auto& x : state) x = F::zero();
+    // The outputs of some one-row sponges land on witnesses a Public op already defined with the
+    // same value: such an output is a READER on the bus (out_ctl = -1; circuit.rs:464-491,
+    // dup_npo_outputs; batch_stark_prover.rs:225-238)
     for (size_t r = 0; r < n_p2; ++r) {
       const auto& p = plan[r];
+      const bool last_of_chain = (r + 1 == n_p2) || plan[r + 1].new_start;
       F in[16];
       uint32_t in_ctl[4] = {0, 0, 0, 0}, in_idx[4] = {0, 0, 0, 0};
+      std::vector<uint32_t> ext(7, NO_W);
+      const bool onto_public = !p.merkle && last_of_chain && rng.unit() < 0.2;
       if (p.new_start) {
         for (auto& x : in) x = F::zero();
-        if (p.merkle) {
-          for (auto& x : in) x = rf();  // leaf digest + sibling: private data, no CTL on Merkle rows
-        } else {
-          for (int l = 0; l < 2; ++l) {  // rate limbs fed from the witness bus
-            uint32_t w = pick();
-            in_ctl[l] = 1; in_idx[l] = w;
-            for (int d = 0; d < 4; ++d) in[l * 4 + d] = wval[w].c[d];
-          }
+        for (int l = 0; l < 2; ++l) {
+          // sponge: rate limbs read from the witness bus; Merkle: the leaf digest is named by
+          // witness index without a bus read (executor.rs:786-790)
+          uint32_t w = pickp_noread();
+          if (!p.merkle) reads[w]++;
+          in_ctl[l] = 1; in_idx[l] = w; ext[l] = w;
+          for (int d = 0; d < 4; ++d) in[l * 4 + d] = wval[w].c[d];
         }
       } else if (!p.merkle) {
         for (int i = 0; i < 16; ++i) in[i] = state[i];  // full previous output carried
         for (int l = 0; l < 2; ++l) {
           if (rng.unit() < 0.5) {
-            uint32_t w = pick();
-            in_ctl[l] = 1; in_idx[l] = w;
+            uint32_t w = pickp();
+            in_ctl[l] = 1; in_idx[l] = w; ext[l] = w;
             for (int d = 0; d < 4; ++d) in[l * 4 + d] = wval[w].c[d];
           }
         }
       } else {
-        // previous digest (limbs 0..1) placed left or right of a fresh sibling
-        F sib[8];
-        for (auto& x : sib) x = rf();
-        for (int i = 0; i < 8; ++i) {
-          in[p.bit ? 8 + i : i] = state[i];
-          in[p.bit ? i : 8 + i] = sib[i];
-        }
+        for (int i = 0; i < 8; ++i) in[i] = state[i];  // previous digest carried in the rate limbs
+        for (int i = 8; i < 16; ++i) in[i] = F::zero();
       }
+      if (p.merkle) {
+        // sibling = private data in the capacity limbs, then the direction bit swaps the halves
+        // (executor.rs:166-234); the bit itself is the zero / one constant witness
+        pd_ids.push_back(next_npo_id);
+        for (int i = 8; i < 16; ++i) { in[i] = rf(); pd_sib.push_back(in[i].to_canonical()); }
+        if (p.bit) for (int i = 0; i < 8; ++i) std::swap(in[i], in[8 + i]);
+        ext[5] = p.bit ? 1u : 0u;
+      }
+      if (acc_wid[r] >= 0) ext[4] = (uint32_t)acc_wid[r];
       for (int i = 0; i < 16; ++i) p2_inputs.push_back(in[i].to_canonical());
       for (int i = 0; i < 16; ++i) state[i] = in[i];
       p2_permute<PP>(state, rc_m.data());
-      bool last_of_chain = (r + 1 == n_p2) || plan[r + 1].new_start;
+      const bool en = acc_wid[r] >= 0;
       p2_flags.push_back(p.new_start); p2_flags.push_back(p.merkle); p2_flags.push_back(p.bit);
-      p2_flags.push_back(p.mmcs_ctl);
-      p2_index_sum.push_back(p.merkle ? p.acc : 0u);
+      p2_flags.push_back(en);
+      p2_index_sum.push_back(en ? p.acc : 0u);
       for (int l = 0; l < 4; ++l) { p2_in_ctl.push_back(in_ctl[l]); p2_in_idx.push_back(in_idx[l]); }
+      ext[6] = 2;
       for (int l = 0; l < 2; ++l) {
-        if (last_of_chain) {
+        if (onto_public) {
           E v; for (int d = 0; d < 4; ++d) v.c[d] = state[l * 4 + d];
           uint32_t w = create(v);
+          push_op(C_PUBLIC, 0, 0, 0, w, (uint32_t)public_w.size(), {});
+          public_w.push_back(w);
+          public_rows.push_back(w);
+          put_e(in_public, v);
+          reads[w]++;
+          pickable.push_back(w);
+          p2_out_idx.push_back(w);
+          p2_out_ctl.push_back(P - 1);
+          ext.push_back(w);
+        } else if (last_of_chain) {
+          E v; for (int d = 0; d < 4; ++d) v.c[d] = state[l * 4 + d];
+          uint32_t w = create(v);
+          pickable.push_back(w);
           out_fix.push_back({r, l, w});
           p2_out_idx.push_back(w);
+          p2_out_ctl.push_back(0);  // patched below once read counts are known
+          ext.push_back(w);
         } else {
           p2_out_idx.push_back(0);
+          p2_out_ctl.push_back(0);
+          ext.push_back(NO_W);
         }
-        p2_out_ctl.push_back(0);  // patched below once read counts are known
       }
-      p2_acc_idx.push_back(acc_wid[r] >= 0 ? (uint32_t)acc_wid[r] : 0u);
+      p2_acc_idx.push_back(en ? (uint32_t)acc_wid[r] : 0u);
+      push_op(C_P2, next_npo_id++, 0, 0, 0, (p.new_start ? 1u : 0u) | (p.merkle ? 2u : 0u), ext);
     }
   }
 
   // ---- ALU ops: 3 lanes x ~H rows; Horner chains ride lane 0 (alu_air.rs:349-463) ----
   // Op mix: 45% Add, 30% Mul, 10% MulAdd, 14% HornerAcc (chains of
-  // length U{4..horner_chain_len}), 1% BoolCheck.  Only the LAST output of a Horner run is
-  // ever read by another op: intermediate outputs of packed rows never reach the bus
-  // (alu_air.rs:630-667), so they are created non-pickable.
+  // length U{4..horner_chain_len}), 1% BoolCheck; a few percent of the Add / Mul ops run
+  // backwards (the runner solves for b, runner.rs:341-385), claim a private input or consume
+  // hint outputs.  Only the LAST output of a Horner run is ever read by another op:
+  // intermediate outputs of packed rows never reach the bus (alu_air.rs:630-667).
   auto& alu_values = W.arr["alu_values"];  // n x 16 (a,b,c,out)
-  struct AluOp { int kind; uint32_t a, b, c, out; bool c_rd; };
+  // a_state / c_state: 0 skip, 1 reader, 2 creator (circuit.rs:341-379)
+  struct AluOp { int kind; uint32_t a, b, c, out; uint8_t a_state, c_state; bool b_creator, out_creator, has_c; };
   std::vector<AluOp> ops;
+  std::vector<uint32_t> bool_w = {0, 1};
   {
     const size_t lanes = 3;
-    std::vector<uint32_t> pickable(wval.size());
-    for (size_t i = 0; i < pickable.size(); ++i) pickable[i] = (uint32_t)i;
-    auto pickp = [&]() { uint32_t w = pickable[rng.below((uint32_t)pickable.size())]; reads[w]++; return w; };
-    auto emit = [&](int kind, uint32_t a, uint32_t b, uint32_t c, const E& outv, bool c_rd, bool out_pickable) {
+    auto emit = [&](int kind, uint32_t a, uint32_t b, uint32_t c, uint32_t out, uint32_t aux, uint8_t a_state,
+                    uint8_t c_state, bool b_creator, bool out_creator) {
+      const bool has_c = c != NO_W;
+      if (!b_creator) reads[b]++;
+      if (!out_creator) reads[out]++;
+      if (a_state == 1) reads[a]++;
+      if (c_state == 1) reads[c]++;
+      ops.push_back({kind, a, b, has_c ? c : 0u, out, a_state, c_state, b_creator, out_creator, has_c});
+      // AluOpRecord values (runner.rs:317-453)
+      E av = wval[a], bv = wval[b], cv = E::zero(), ov = wval[out];
+      if (kind == OP_BOOL) { bv = E::zero(); cv = av; }
+      else if (kind == OP_MULADD || kind == OP_HORNER) cv = has_c ? wval[c] : E::zero();
+      put_e(alu_values, av); put_e(alu_values, bv); put_e(alu_values, cv); put_e(alu_values, ov);
+      static const uint32_t kinds[5] = {C_ADD, C_MUL, C_BOOL, C_MULADD, C_HORNER};
+      push_op(kinds[kind], a, b, c, out, aux, {});
+    };
+    // forward op with already-defined operands
+    auto fwd = [&](int kind, uint32_t a, uint32_t b, uint32_t c, const E& outv, bool out_pickable, uint32_t aux = NO_W) {
       uint32_t o = create(outv);
+      emit(kind, a, b, c, o, aux, 1, c != NO_W ? 1 : 0, false, true);
       if (out_pickable) pickable.push_back(o);
-      ops.push_back({kind, a, b, c, o, c_rd});
-      put_e(alu_values, wval[a]); put_e(alu_values, wval[b]);
-      put_e(alu_values, c_rd ? wval[c] : E::zero()); put_e(alu_values, outv);
+      return o;
     };
     const double avg_len = horner_chain_len > 4 ? (4 + horner_chain_len) / 2.0 : horner_chain_len;
     const double p_chain = horner_chain_len > 0 ? 0.14 / (avg_len * 0.86 + 0.14) : 0.0;
@@ -227,45 +334,128 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
       return chain_rows + (nonchain > fill ? (nonchain - fill + lanes - 1) / lanes : 0);
     };
     const size_t target = (flags & SYN_NO_ALU) ? 0 : (H > 16 ? H - 4 : H - 1);
+    size_t next_private = 0;
     while (rows_now() < target) {
       double u = rng.unit();
       if (u < p_chain) {
         int len = horner_chain_len > 4 ? 4 + (int)rng.below((uint32_t)horner_chain_len - 3) : horner_chain_len;
         size_t need = (size_t)(len + 3) / 4 + 1;
         if (rows_now() + need + 1 >= target) { len = 2; need = 2; }
-        uint32_t b = pickp();
-        reads[b] += (uint32_t)len - 1;
+        uint32_t b = pickp_noread();
         E acc = E::zero();
+        uint32_t acc_w = 0;  // the zero constant seeds the accumulator
         for (int j = 0; j < len; ++j) {
-          uint32_t a = pickp(), c = pickp();
+          uint32_t a = pickp_noread(), c = pickp_noread();
           acc = acc * wval[b] + wval[c] - wval[a];
-          emit(OP_HORNER, a, b, c, acc, true, j == len - 1);
+          acc_w = fwd(OP_HORNER, a, b, c, acc, j == len - 1, acc_w);
         }
         chain_rows += need;
         // a non-Horner op ends the run so the next chain is a separate chain
-        uint32_t a = pickp(), bb = pickp();
-        emit(OP_ADD, a, bb, 0, wval[a] + wval[bb], false, true);
+        uint32_t a = pickp_noread(), bb = pickp_noread();
+        fwd(OP_ADD, a, bb, NO_W, wval[a] + wval[bb], true);
         nonchain += 1;
         continue;
       }
       double v = rng.unit();
-      if (v < 0.45 / 0.86) {
-        uint32_t a = pickp(), b = pickp();
-        emit(OP_ADD, a, b, 0, wval[a] + wval[b], false, true);
+      if (v < 0.03 && next_private < private_w.size()) {
+        // a private input is claimed by its first ALU use: as `a` (a_state = creator), as `b` of
+        // a forward op (b_is_private_creator) or as `c` of a MulAdd (c_state = creator)
+        uint32_t pw = private_w[next_private++];
+        int role = (int)rng.below(3);
+        if (role == 0) {
+          uint32_t b = pickp_noread();
+          uint32_t o = create(wval[pw] + wval[b]);
+          emit(OP_ADD, pw, b, NO_W, o, NO_W, 2, 0, false, true);
+          pickable.push_back(o);
+        } else if (role == 1) {
+          uint32_t a = pickp_noread();
+          uint32_t o = create(wval[a] * wval[pw]);
+          emit(OP_MUL, a, pw, NO_W, o, NO_W, 1, 0, true, true);
+          pickable.push_back(o);
+        } else {
+          uint32_t a = pickp_noread(), b = pickp_noread();
+          uint32_t o = create(wval[a] * wval[b] + wval[pw]);
+          emit(OP_MULADD, a, b, pw, o, NO_W, 1, 2, false, true);
+          pickable.push_back(o);
+        }
+        pickable.push_back(pw);
+      } else if (v < 0.06) {
+        // backward op (the lowering of sub / div): a and out are known, the runner solves for b
+        uint32_t a = pickp_noread(), o = pickp_noread();
+        const bool mul = rng.unit() < 0.5 && !(wval[a] == E::zero());
+        uint32_t b = create(mul ? wval[o] * wval[a].inv() : wval[o] - wval[a]);
+        emit(mul ? OP_MUL : OP_ADD, a, b, NO_W, o, NO_W, 1, 0, true, false);
+        pickable.push_back(b);
+      } else if (v < 0.07) {
+        // ExtDecompositionHint: 4 hint outputs, each claimed by the Add that first uses it
+        uint32_t src = pickp_noread();
+        std::vector<uint32_t> outs(4);
+        for (int i = 0; i < 4; ++i) outs[i] = create(E::from_base(wval[src].c[i]));
+        push_op(C_HINT_EXT, src, 0, 0, 0, 0, outs);
+        for (int i = 0; i < 4; ++i) {
+          uint32_t b = pickp_noread();
+          uint32_t o = create(wval[outs[i]] + wval[b]);
+          emit(OP_ADD, outs[i], b, NO_W, o, NO_W, 2, 0, false, true);
+          pickable.push_back(o);
+          pickable.push_back(outs[i]);
+          base_valued.push_back(outs[i]);
+          nonchain += 1;
+        }
+        continue;
+      } else if (v < 0.075) {
+        // BinaryDecompositionHint of the low coefficient: 8 bits, each bool-checked the way the
+        // lowerer emits it (a = c = bit, b = zero constant; lowerer/state.rs:336-351)
+        uint32_t src = pickp_noread();
+        std::vector<uint32_t> outs(8);
+        const uint32_t val = wval[src].c[0].to_canonical();
+        for (int i = 0; i < 8; ++i) outs[i] = create(E::from_base(F::from_canonical((val >> i) & 1)));
+        push_op(C_HINT_BIN, src, 0, 0, 0, 0, outs);
+        for (int i = 0; i < 8; ++i) {
+          // an Add claims the hint output first (a_state = creator); the lowerer-style BoolCheck
+          // then reads it twice (a and c)
+          uint32_t z = pickp_noread();
+          uint32_t o1 = create(wval[outs[i]] + wval[z]);
+          emit(OP_ADD, outs[i], z, NO_W, o1, NO_W, 2, 0, false, true);
+          pickable.push_back(o1);
+          uint32_t o = create(wval[outs[i]]);
+          emit(OP_BOOL, outs[i], 0, outs[i], o, NO_W, 1, 1, false, true);
+          pickable.push_back(o);
+          bool_w.push_back(o);
+          nonchain += 2;
+        }
+        continue;
+      } else if (v < 0.45 / 0.86) {
+        uint32_t a = pickp_noread(), b = pickp_noread();
+        fwd(OP_ADD, a, b, NO_W, wval[a] + wval[b], true);
       } else if (v < 0.75 / 0.86) {
-        uint32_t a = pickp(), b = pickp();
-        emit(OP_MUL, a, b, 0, wval[a] * wval[b], false, true);
+        uint32_t a = pickp_noread(), b = pickp_noread();
+        fwd(OP_MUL, a, b, NO_W, wval[a] * wval[b], true);
       } else if (v < 0.85 / 0.86) {
-        uint32_t a = pickp(), b = pickp(), c = pickp();
-        emit(OP_MULADD, a, b, c, wval[a] * wval[b] + wval[c], true, true);
+        uint32_t a = pickp_noread(), b = pickp_noread(), c = pickp_noread();
+        // one MulAdd in four keeps the witness of the fused a*b product (intermediate_out)
+        uint32_t io = rng.unit() < 0.25 ? create(wval[a] * wval[b]) : NO_W;
+        fwd(OP_MULADD, a, b, c, wval[a] * wval[b] + wval[c], true, io);
       } else {
-        uint32_t a = rng.below(2);  // witness 0 (zero) or 1 (one)
-        reads[a]++;
-        uint32_t b = pickp();
-        emit(OP_BOOL, a, b, 0, E::zero(), false, true);
+        uint32_t a = bool_w[rng.below((uint32_t)bool_w.size())];
+        uint32_t o = fwd(OP_BOOL, a, 0, a, wval[a], true);
+        bool_w.push_back(o);
       }
       nonchain += 1;
     }
+    // private inputs nobody claimed yet (UnclaimedPrivateInput otherwise, circuit.rs:497-503)
+    while (next_private < private_w.size()) {
+      uint32_t pw = private_w[next_private++], b = pickp_noread();
+      uint32_t o = create(wval[pw] + wval[b]);
+      emit(OP_ADD, pw, b, NO_W, o, NO_W, 2, 0, false, true);
+      pickable.push_back(o);
+    }
+  }
+  // ALU-dedup leftovers: duplicates the runner fills from their canonical witness at the end
+  auto& rewrite = W.arr["rewrite"];
+  for (size_t i = 0; i < std::max<size_t>(H / 256, 1) && !(flags & SYN_NO_ALU); ++i) {
+    uint32_t canon = pickp_noread();
+    uint32_t dup = create(wval[canon]);
+    rewrite.push_back(dup); rewrite.push_back(canon);
   }
 
   // ---- emit tables ----
@@ -273,16 +463,19 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   for (uint32_t w : const_w) { put_e(const_values, wval[w]); const_prep.push_back(reads[w]); const_prep.push_back(w * 4); }
   auto& public_values = W.arr["public_values"]; auto& public_prep = W.arr["public_prep"];
   for (uint32_t w : public_w) { put_e(public_values, wval[w]); public_prep.push_back(reads[w]); public_prep.push_back(w * 4); }
-  auto& rec_values = W.arr["recompose_values"]; auto& rec_prep = W.arr["recompose_prep"];
-  for (uint32_t w : rec_w) { put_e(rec_values, wval[w]); rec_prep.push_back(w * 4); rec_prep.push_back(reads[w]); }
+  auto& rec_prep = W.arr["recompose_prep"];
+  for (uint32_t w : rec_w) { rec_prep.push_back(w * 4); rec_prep.push_back(reads[w]); }
   for (auto& f : out_fix) p2_out_ctl[f.row * 2 + f.limb] = reads[f.wid];
-  // ALU per-op preprocessed, 13 columns (AluPrepLaneCols, alu_columns.rs:9-46)
+  // ALU per-op preprocessed, 13 columns (AluPrepLaneCols, alu_columns.rs:9-46; common.rs:198-281)
   auto& alu_prep = W.arr["alu_prep13"];
   const uint32_t neg1 = P - 1;
+  auto neg = [&](uint32_t x) { return (P - x % P) % P; };
   for (auto& o : ops) {
+    const uint32_t a_col = o.a_state == 1 ? 1u : o.a_state == 2 ? neg(reads[o.a]) : 0u;
+    const uint32_t c_col = o.c_state == 1 ? 1u : o.c_state == 2 ? neg(reads[o.c]) : 0u;
     uint32_t row[13] = {neg1, o.kind == OP_ADD, o.kind == OP_BOOL, o.kind == OP_MULADD, o.kind == OP_HORNER,
-                        o.a * 4, o.b * 4, (o.c_rd ? o.c : 0) * 4, o.out * 4, neg1, reads[o.out] % P,
-                        1u, o.c_rd ? 1u : 0u};
+                        o.a * 4, o.b * 4, o.c * 4, o.out * 4,
+                        o.b_creator ? reads[o.b] % P : neg1, o.out_creator ? reads[o.out] % P : neg1, a_col, c_col};
     alu_prep.insert(alu_prep.end(), row, row + 13);
   }
   if (ops.empty()) {
@@ -290,9 +483,8 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     // (tables/alu.rs:69-73, common.rs:283-286)
     alu_prep.insert(alu_prep.end(), 13, 0u);
     alu_values.insert(alu_values.end(), 16, 0u);
-    ops.push_back({OP_ADD, 0, 0, 0, 0, false});
   }
-  W.arr["counts"] = {(uint32_t)const_w.size(), (uint32_t)public_w.size(), (uint32_t)ops.size(),
+  W.arr["counts"] = {(uint32_t)const_w.size(), (uint32_t)public_w.size(), (uint32_t)std::max<size_t>(ops.size(), 1),
                      (uint32_t)n_p2, (uint32_t)rec_w.size(), (uint32_t)wval.size()};
 }
 

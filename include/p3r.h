@@ -283,6 +283,99 @@ int p3r_prove_all_tables_resident(p3r_ctx* ctx, const p3r_layer* layer, const p3
 p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
                                      uint32_t table);
 
+/* ---- the caller side of prove_next_layer: the circuit itself ------------------------------------
+ * `prove_next_layer` (recursion/src/recursion.rs:401-502) receives a `Circuit<EF>`, sets its public
+ * inputs and the Merkle-sibling private data, RUNS it (`CircuitRunner::run`,
+ * circuit/src/tables/runner.rs:195-253) and proves the resulting `Traces`.  The entry points below
+ * take the flattened `Circuit<EF>` (circuit/src/circuit.rs:152-181) instead of pre-computed
+ * `Traces` + preprocessed columns:
+ *   p3r_circuit_create  == Circuit::generate_preprocessed_columns::<4> (circuit.rs:237-510)
+ *                          + get_airs_and_degrees_with_prep (circuit-prover/src/common.rs:127-390)
+ *                          + poseidon_preprocess_for_prover (batch_stark_prover.rs:97-246)
+ *                          + recompose_preprocess_for_op (batch_stark_prover/recompose.rs:294-358)
+ *                          + ProverData::from_airs_and_degrees            (build_next_layer_prep)
+ *   p3r_circuit_run     == set_public_inputs / set_private_inputs / set_private_data + run()
+ *                          (runner.rs:83-253) with the witness table and the Traces kept in HBM
+ *   p3r_prove_next_layer== run + prove_all_tables
+ * D = 4 (extension-field witnesses), Poseidon2 D4 width 16, Recompose without coefficient lookups:
+ * the tables FriRecursionBackend registers (recursion/src/backend/fri.rs:693-721). */
+#define P3R_NO_WITNESS 0xFFFFFFFFu
+
+enum p3r_op_kind {               /* circuit/src/ops/op.rs `Op`, AluOpKind */
+  P3R_OP_CONST = 0,              /* out; ext[ext_off..+4] = value coefficients (canonical) */
+  P3R_OP_PUBLIC = 1,             /* out; aux = public_pos */
+  P3R_OP_ALU_ADD = 2,            /* a, b, out                    (c = aux = P3R_NO_WITNESS) */
+  P3R_OP_ALU_MUL = 3,
+  P3R_OP_ALU_BOOL_CHECK = 4,     /* a, b, out */
+  P3R_OP_ALU_MUL_ADD = 5,        /* a, b, c or NO_WITNESS, out; aux = intermediate_out or NO_WITNESS */
+  P3R_OP_ALU_HORNER_ACC = 6,     /* a, b, c, out; aux = acc (intermediate_out) */
+  P3R_OP_HINT_EXT_DECOMPOSITION = 7,    /* a = input; ext = 4 output witnesses
+                                           (circuit/src/builder/circuit_builder.rs:1659-1728) */
+  P3R_OP_HINT_BINARY_DECOMPOSITION = 8, /* a = input; ext = ext_len output witnesses (:1750-1810) */
+  P3R_OP_POSEIDON2_PERM = 9,     /* a = NonPrimitiveOpId; aux = flags (bit 0 new_start, bit 1 merkle_path);
+                                    ext = [in0..in3, mmcs_index_sum, mmcs_bit, n_out (2 or 4), out0..];
+                                    empty slots are P3R_NO_WITNESS (poseidon_perm/executor.rs:921-972) */
+  P3R_OP_RECOMPOSE = 10          /* a = NonPrimitiveOpId; out; ext = 4 coefficient witnesses
+                                    (circuit/src/ops/recompose.rs:115-170) */
+};
+
+typedef struct p3r_op {
+  uint32_t kind;
+  uint32_t a, b, c, out, aux;
+  uint32_t ext_off, ext_len; /* slice of p3r_circuit_desc.ext */
+} p3r_op;
+
+typedef struct p3r_circuit_desc {
+  uint32_t witness_count;
+  size_t n_ops;     const p3r_op* ops;                     /* execution order */
+  size_t n_ext;     const uint32_t* ext;
+  size_t n_public;  const uint32_t* public_rows;           /* witness of public input i */
+  size_t n_private; const uint32_t* private_input_rows;
+  size_t n_rewrite; const uint32_t* witness_rewrite;       /* pairs (duplicate, canonical) */
+  uint32_t public_lanes, alu_lanes, horner_packed_steps, recompose_lanes, min_trace_height;
+} p3r_circuit_desc;
+
+typedef struct p3r_circuit_inputs {
+  const uint32_t* public_values;   /* n_public x 4, canonical */
+  const uint32_t* private_values;  /* n_private x 4 */
+  size_t n_private_data;                 /* set_private_data: Poseidon2PermPrivateData { sibling } */
+  const uint32_t* private_data_op_ids;   /* n_private_data NonPrimitiveOpIds */
+  const uint32_t* private_data_siblings; /* n_private_data x 8: two extension limbs */
+} p3r_circuit_inputs;
+
+typedef struct p3r_circuit p3r_circuit;
+
+/* Fails (NULL + p3r_last_error) on a malformed circuit, an unclaimed private input
+ * (circuit.rs:497-503) or an op the three-table backend has no table for. */
+p3r_circuit* p3r_circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* desc, uint32_t* commit_out);
+void p3r_circuit_free(p3r_ctx* ctx, p3r_circuit* circuit);
+/* The CircuitProverData the circuit was prepared into (owned by the circuit). */
+const p3r_layer* p3r_circuit_layer(const p3r_circuit* circuit);
+/* Op counts of the five tables, i.e. the sizes of the arrays p3r_dtraces_get returns. */
+int p3r_circuit_counts(const p3r_circuit* circuit, p3r_layer_desc_counts* out);
+/* Levels of the execution schedule (ops of one level have no dependencies on each other). */
+int p3r_circuit_levels(const p3r_circuit* circuit, size_t* n_levels);
+
+/* CircuitRunner::run on the device.  Errors mirror CircuitError: a witness conflict
+ * (runner.rs:473-510), DivisionByZero (:378), a non-boolean mmcs_bit
+ * (poseidon_perm/executor.rs:305-335), a witness that is never set (:218-221). */
+p3r_dtraces* p3r_circuit_run(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs);
+int p3r_prove_next_layer(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs,
+                         uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
+
+/* Read back one array of device-resident Traces (canonical), for parity tests / inspection. */
+enum p3r_traces_array {
+  P3R_TRACES_CONST_VALUES = 0,    /* n_const x 4 */
+  P3R_TRACES_PUBLIC_VALUES = 1,   /* n_public x 4 */
+  P3R_TRACES_ALU_VALUES = 2,      /* n_alu x 16 */
+  P3R_TRACES_P2_INPUT_VALUES = 3, /* n_p2 x 16 */
+  P3R_TRACES_P2_FLAGS = 4,        /* n_p2 x 3: new_start, merkle_path, mmcs_bit */
+  P3R_TRACES_P2_MMCS_INDEX_SUM = 5, /* n_p2 */
+  P3R_TRACES_RECOMPOSE_VALUES = 6 /* n_recompose x 4 */
+};
+int p3r_dtraces_get(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces, uint32_t which,
+                    uint32_t* out, size_t out_len);
+
 /* ---- measurement support (bench.py): run `iters` back-to-back launches of one kernel
  * family on resident data and return the mean per-launch time measured with HIP events
  * on the ctx's own stream. ---- */

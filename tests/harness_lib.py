@@ -13,7 +13,10 @@ u32p = C.POINTER(C.c_uint32)
 
 ARRAYS = ["const_values", "const_prep", "public_values", "public_prep", "alu_values", "alu_prep13",
           "p2_inputs", "p2_flags", "p2_mmcs_index_sum", "p2_in_ctl", "p2_input_indices", "p2_out_ctl",
-          "p2_output_indices", "p2_mmcs_index_sum_idx", "recompose_values", "recompose_prep", "counts"]
+          "p2_output_indices", "p2_mmcs_index_sum_idx", "recompose_values", "recompose_prep", "counts",
+          # the circuit the arrays above were derived from (flattened Circuit<EF>, include/p3r.h) and its inputs
+          "ops", "ext", "public_rows", "in_public_values", "private_rows", "in_private_values", "pd_op_ids",
+          "pd_siblings", "rewrite"]
 
 
 def build():
@@ -52,7 +55,8 @@ def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_le
             p = u32p()
             n = C.c_size_t()
             if lib.syn_get(h, name.encode(), C.byref(p), C.byref(n)) != 0:
-                raise KeyError(name)
+                out[name] = np.zeros(0, np.uint32)   # array never touched by this shape
+                continue
             out[name] = np.ctypeslib.as_array(p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
         return out
     finally:

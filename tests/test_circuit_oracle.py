@@ -1,0 +1,120 @@
+"""CPU: the oracle's circuit-side restatement (oracle/circuit.hpp).
+
+1. generate_preprocessed_columns and the runner against the literal expectations of the
+   reference's own unit tests (tests/golden/reference_unit_tests.json, each case cites file:line);
+2. preprocessing + run of the synthetic circuits against the harness's own, independently kept
+   bookkeeping of the same workload (values, indices, signed multiplicities);
+3. the runner's error paths (CircuitError variants of circuit/src/tables/runner.rs)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import circuit_lib as cl
+import harness_lib
+import layer_lib
+import oracle_lib
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_unit_tests.json")))
+KIND = dict(const=cl.OP_CONST, public=cl.OP_PUBLIC, add=cl.OP_ADD, mul=cl.OP_MUL, bool=cl.OP_BOOL,
+            muladd=cl.OP_MULADD, horner=cl.OP_HORNER)
+BABYBEAR = 0x78000001
+
+
+def build(case):
+    ops, ext = [], []
+    for o in case["ops"]:
+        e = list(o["ext"])
+        if o["kind"] == "const":
+            e = e + [0, 0, 0]   # a base-field constant embedded in the extension
+        ops.append([KIND[o["kind"]], o["a"], o["b"], o["c"], o["out"], o["aux"], len(ext), len(e)])
+        ext += e
+    return cl.Circuit(case["witness_count"], ops, ext, case.get("public_rows", ()), case.get("private_rows", ()))
+
+
+@pytest.mark.parametrize("case", GOLD["preprocessed_columns"], ids=lambda c: c["source"].split()[-1])
+def test_preprocessed_columns_match_reference_unit_tests(oracle, case):
+    oc = cl.OracleCircuit(oracle, build(case)).preprocess(BABYBEAR, case["D"])
+    for name, want in case["expect"].items():
+        assert oc.get(name).tolist() == want, name
+
+
+@pytest.mark.parametrize("case", GOLD["runner"], ids=lambda c: c["source"].split()[1])
+def test_runner_matches_reference_unit_tests(oracle, case):
+    emb = lambda vals: [x for v in vals for x in (v, 0, 0, 0)]
+    oc = cl.OracleCircuit(oracle, build(case))
+    oc.run("baby-bear", cl.Inputs(emb(case["public_values"]), emb(case["private_values"])))
+    e = case["expect"]
+    for name in ("witness", "const_values", "public_values"):
+        got = oc.get(name).reshape(-1, 4)
+        assert got[:, 0].tolist() == e[name], name
+        assert not got[:, 1:].any(), name
+    alu = oc.get("alu_values").reshape(-1, 4, 4)
+    assert alu[:, :, 0].tolist() == e["alu_values"]
+    assert not alu[:, :, 1:].any()
+
+
+SHAPES = [0, harness_lib.NO_POSEIDON2, harness_lib.NO_RECOMPOSE,
+          harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC,
+          harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU]
+
+
+@pytest.mark.parametrize("field", ["koala-bear", "baby-bear"])
+@pytest.mark.parametrize("flags", SHAPES)
+def test_circuit_path_reproduces_harness_bookkeeping(oracle, field, flags):
+    a = harness_lib.generate(field, 8, seed=21, horner_chain_len=16, sponge_chain_len=3, merkle_depth=5, flags=flags)
+    oc = cl.OracleCircuit(oracle, cl.Circuit.from_arrays(a)).preprocess(oracle_lib.MODULUS[field])
+    oc.run(field, cl.Inputs.from_arrays(a))
+    w = oc.workload_arrays()
+    for k in w:
+        assert np.array_equal(w[k], a[k]), k
+    if flags == 0:
+        kinds = np.bincount(a["ops"].reshape(-1, 8)[:, 0], minlength=11)
+        assert kinds.all()   # every op kind is exercised
+        assert len(a["private_rows"]) and len(a["rewrite"]) and (a["p2_out_ctl"] == oracle_lib.MODULUS[field] - 1).any()
+
+
+def test_circuit_path_proof_verifies(oracle):
+    """Traces + preprocessed columns derived from the circuit prove and verify (LogUp balanced
+    under the reference's creator / reader multiplicity rules, every AIR satisfied)."""
+    field = "koala-bear"
+    a = harness_lib.generate(field, 7, seed=4, horner_chain_len=10, sponge_chain_len=3, merkle_depth=4)
+    oc = cl.OracleCircuit(oracle, cl.Circuit.from_arrays(a)).preprocess(oracle_lib.MODULUS[field])
+    oc.run(field, cl.Inputs.from_arrays(a))
+    prm = layer_lib.params(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+    L = layer_lib.OracleLayer(oracle, field, oc.workload_arrays(), prm)
+    L.verify(L.prove())
+
+
+def small_circuit():
+    # w0 = 0, w1 = 5 (const), w2 public, w3 = w2 + w1, w4 private
+    ops = [[cl.OP_CONST, 0, 0, cl.NO_W, 0, cl.NO_W, 0, 4], [cl.OP_CONST, 0, 0, cl.NO_W, 1, cl.NO_W, 4, 4],
+           [cl.OP_PUBLIC, 0, 0, cl.NO_W, 2, 0, 0, 0], [cl.OP_ADD, 2, 1, cl.NO_W, 3, cl.NO_W, 0, 0]]
+    return ops, [0, 0, 0, 0, 5, 0, 0, 0]
+
+
+def test_runner_error_paths(oracle):
+    ops, ext = small_circuit()
+    ok = cl.Circuit(4, ops, ext, [2])
+    cl.OracleCircuit(oracle, ok).run("koala-bear", cl.Inputs([3, 0, 0, 0]))
+    # WitnessConflict: out already holds a different value (runner.rs:473-510)
+    bad = cl.Circuit(4, ops + [[cl.OP_ADD, 1, 1, cl.NO_W, 3, cl.NO_W, 0, 0]], ext, [2])
+    with pytest.raises(RuntimeError, match="WitnessConflict"):
+        cl.OracleCircuit(oracle, bad).run("koala-bear", cl.Inputs([3, 0, 0, 0]))
+    # ... but an equal value is accepted
+    same = cl.Circuit(4, ops + [[cl.OP_ADD, 1, 2, cl.NO_W, 3, cl.NO_W, 0, 0]], ext, [2])
+    cl.OracleCircuit(oracle, same).run("koala-bear", cl.Inputs([3, 0, 0, 0]))
+    # DivisionByZero: backward Mul with a = 0 (runner.rs:376-379)
+    div = cl.Circuit(5, ops + [[cl.OP_MUL, 0, 4, cl.NO_W, 3, cl.NO_W, 0, 0]], ext, [2])
+    with pytest.raises(RuntimeError, match="DivisionByZero"):
+        cl.OracleCircuit(oracle, div).run("koala-bear", cl.Inputs([3, 0, 0, 0]))
+    # WitnessNotSet (a operand) and WitnessNotSetForIndex (never written)
+    with pytest.raises(RuntimeError, match="WitnessNotSet"):
+        cl.OracleCircuit(oracle, cl.Circuit(6, ops + [[cl.OP_ADD, 5, 1, cl.NO_W, 4, cl.NO_W, 0, 0]], ext, [2])).run(
+            "koala-bear", cl.Inputs([3, 0, 0, 0]))
+    with pytest.raises(RuntimeError, match="WitnessNotSetForIndex"):
+        cl.OracleCircuit(oracle, cl.Circuit(5, ops, ext, [2])).run("koala-bear", cl.Inputs([3, 0, 0, 0]))
+    # UnclaimedPrivateInput at preprocessing (circuit.rs:497-503)
+    with pytest.raises(RuntimeError, match="UnclaimedPrivateInput"):
+        cl.OracleCircuit(oracle, cl.Circuit(5, ops, ext, [2], [4])).preprocess(0x7F000001)
