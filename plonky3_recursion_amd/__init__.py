@@ -5,8 +5,8 @@ The HIP library is mandatory: importing the package is cheap, but any compute en
 raises if `libp3r_hip.so` has not been built (no CPU fallback).
 """
 from .device import Context, DeviceMatrix, MerkleTree, P3rError  # noqa: F401
-from .prover import (BatchStarkProof, BatchStarkProver, CircuitPrep, CircuitProverData,  # noqa: F401
-                     FriRecursionBackend, FriRecursionConfig, NextLayerPrepCache, ProveNextLayerParams,
+from .prover import (BatchStarkProof, BatchStarkProver, Circuit, CircuitInputs, CircuitPrep,  # noqa: F401
+                     CircuitProverData, CircuitRunner, PreparedCircuit, FriRecursionBackend, FriRecursionConfig, NextLayerPrepCache, ProveNextLayerParams,
                      RecursionInput, RecursionOutput, ResidentTraces, TablePacking, Traces,
                      build_next_layer_prep, prove_next_layer)
 

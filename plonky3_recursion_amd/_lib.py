@@ -79,6 +79,31 @@ class P3rTraces(C.Structure):
     ]
 
 
+class P3rOp(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("kind", "a", "b", "c", "out", "aux", "ext_off", "ext_len")]
+
+
+class P3rCircuitDesc(C.Structure):
+    _fields_ = [
+        ("witness_count", C.c_uint32),
+        ("n_ops", C.c_size_t), ("ops", C.POINTER(P3rOp)),
+        ("n_ext", C.c_size_t), ("ext", C.POINTER(C.c_uint32)),
+        ("n_public", C.c_size_t), ("public_rows", C.POINTER(C.c_uint32)),
+        ("n_private", C.c_size_t), ("private_input_rows", C.POINTER(C.c_uint32)),
+        ("n_rewrite", C.c_size_t), ("witness_rewrite", C.POINTER(C.c_uint32)),
+        ("public_lanes", C.c_uint32), ("alu_lanes", C.c_uint32), ("horner_packed_steps", C.c_uint32),
+        ("recompose_lanes", C.c_uint32), ("min_trace_height", C.c_uint32),
+    ]
+
+
+class P3rCircuitInputs(C.Structure):
+    _fields_ = [
+        ("public_values", C.POINTER(C.c_uint32)), ("private_values", C.POINTER(C.c_uint32)),
+        ("n_private_data", C.c_size_t), ("private_data_op_ids", C.POINTER(C.c_uint32)),
+        ("private_data_siblings", C.POINTER(C.c_uint32)),
+    ]
+
+
 class P3rProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_uint64)]
 
@@ -126,6 +151,15 @@ SIGNATURES = {
     "p3r_layer_free": (None, [vp, vp]),
     "p3r_layer_table_heights": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "p3r_layer_effective_lanes": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "p3r_circuit_create": (vp, [vp, C.POINTER(P3rCircuitDesc), u32p]),
+    "p3r_circuit_free": (None, [vp, vp]),
+    "p3r_circuit_layer": (vp, [vp]),
+    "p3r_circuit_counts": (C.c_int, [vp, C.POINTER(P3rLayerCounts)]),
+    "p3r_circuit_levels": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "p3r_circuit_run": (vp, [vp, vp, C.POINTER(P3rCircuitInputs)]),
+    "p3r_prove_next_layer": (C.c_int, [vp, vp, C.POINTER(P3rCircuitInputs), C.c_uint32, C.POINTER(C.c_uint8),
+                                       C.c_size_t, C.POINTER(C.c_size_t)]),
+    "p3r_dtraces_get": (C.c_int, [vp, vp, vp, C.c_uint32, u32p, C.c_size_t]),
     "p3r_traces_upload": (vp, [vp, vp, C.POINTER(P3rTraces)]),
     "p3r_traces_free": (None, [vp, vp]),
     "p3r_prove_all_tables": (C.c_int, [vp, vp, C.POINTER(P3rTraces), C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t,

@@ -1,0 +1,902 @@
+// The caller side of prove_next_layer on the GPU (included into p3r_core.hip): a flattened
+// Circuit<EF> is prepared once (preprocessed columns + execution schedule) and then RUN in HBM:
+// the witness table and the resulting Traces never leave the device before prove_all_tables.
+//
+//   Circuit::generate_preprocessed_columns::<4>      circuit/src/circuit.rs:237-510
+//   NPO executors' preprocess()                      circuit/src/ops/poseidon_perm/executor.rs:770-920,
+//                                                    circuit/src/ops/recompose.rs:172-192
+//   get_airs_and_degrees_with_prep                   circuit-prover/src/common.rs:127-390
+//   poseidon_preprocess_for_prover                   circuit-prover/src/batch_stark_prover.rs:97-246
+//   recompose_preprocess_for_op                      circuit-prover/src/batch_stark_prover/recompose.rs:294-358
+//   CircuitRunner::{set_public_inputs, set_private_inputs, set_private_data, execute_all, run}
+//                                                    circuit/src/tables/runner.rs:83-510
+//   PoseidonPermExecutor::execute (D=4, width 16)    circuit/src/ops/poseidon_perm/executor.rs:921-972
+//   RecomposeExecutor::execute                       circuit/src/ops/recompose.rs:115-170
+//   Ext / BinaryDecompositionHint                    circuit/src/builder/circuit_builder.rs:1659-1810
+//
+// The reference runner is a sequential interpreter.  Which witnesses are set when an op runs
+// is a property of the circuit, not of the inputs, so everything the interpreter decides at
+// run time - the direction of an Add / Mul (forward, or solving for `b`), whether a write
+// lands on a fresh slot or must equal the value already there - is decided here once, at
+// setup.  Ops are then levelised (an op's level = 1 + the highest level among the ops that
+// produce what it reads, including the Poseidon2 chaining through the previous permutation of
+// the same mode) and every level runs as one launch: one lane per ALU / hint / recompose op,
+// sixteen lanes per Poseidon2 permutation (kernels_coop.cuh).  Ops write their trace records
+// (AluOpRecord, Poseidon2CircuitRow, RecomposeCircuitRow) as they execute.
+
+namespace {
+
+constexpr uint32_t kNoW = P3R_NO_WITNESS;
+
+// ---------------------------------------------------------------- preprocessing (host, once)
+struct CircuitTables {
+  p3r_layer_desc_counts counts{};
+  std::vector<uint32_t> const_prep, public_prep, alu_prep13, recompose_prep;
+  std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_ctl_enabled, p2_in_ctl;
+  std::vector<uint32_t> p2_input_indices, p2_out_ctl, p2_output_indices, p2_mmcs_index_sum_idx;
+};
+
+struct HostCircuit {
+  uint32_t witness_count = 0;
+  std::vector<p3r_op> ops;
+  std::vector<uint32_t> ext, public_rows, private_rows, rewrite;
+  const uint32_t* ext_of(const p3r_op& op) const { return ext.data() + op.ext_off; }
+};
+
+inline bool op_is_alu(uint32_t k) { return k >= P3R_OP_ALU_ADD && k <= P3R_OP_ALU_HORNER_ACC; }
+
+inline void validate_circuit(const HostCircuit& c) {
+  const uint32_t nw = c.witness_count;
+  auto wid = [&](uint32_t w, size_t i, const char* what) {
+    if (w >= nw) fail(P3R_EINVAL, "op %zu: %s witness %u out of bounds (witness_count %u)", i, what, w, nw);
+  };
+  auto opt = [&](uint32_t w, size_t i, const char* what) { if (w != kNoW) wid(w, i, what); };
+  for (size_t i = 0; i < c.ops.size(); ++i) {
+    const p3r_op& op = c.ops[i];
+    if ((size_t)op.ext_off + op.ext_len > c.ext.size()) fail(P3R_EINVAL, "op %zu: ext slice out of range", i);
+    const uint32_t* e = c.ext_of(op);
+    switch (op.kind) {
+      case P3R_OP_CONST:
+        wid(op.out, i, "out");
+        if (op.ext_len != 4) fail(P3R_EINVAL, "op %zu: a constant carries 4 coefficients", i);
+        break;
+      case P3R_OP_PUBLIC: wid(op.out, i, "out"); break;
+      case P3R_OP_ALU_ADD: case P3R_OP_ALU_MUL: case P3R_OP_ALU_BOOL_CHECK: case P3R_OP_ALU_MUL_ADD:
+      case P3R_OP_ALU_HORNER_ACC:
+        wid(op.a, i, "a"); wid(op.b, i, "b"); wid(op.out, i, "out"); opt(op.c, i, "c"); opt(op.aux, i, "intermediate_out");
+        if (op.kind == P3R_OP_ALU_HORNER_ACC && (op.c == kNoW || op.aux == kNoW))
+          fail(P3R_EINVAL, "op %zu: HornerAcc requires c and the accumulator witness", i);
+        break;
+      case P3R_OP_HINT_EXT_DECOMPOSITION:
+        wid(op.a, i, "input");
+        if (op.ext_len != 4) fail(P3R_EINVAL, "op %zu: ExtDecompositionHint expects 4 outputs, got %u", i, op.ext_len);
+        for (uint32_t k = 0; k < op.ext_len; ++k) wid(e[k], i, "hint output");
+        break;
+      case P3R_OP_HINT_BINARY_DECOMPOSITION:
+        wid(op.a, i, "input");
+        if (op.ext_len > 31 * 4) fail(P3R_EINVAL, "op %zu: BinaryDecompositionTooManyBits (%u > 124)", i, op.ext_len);
+        for (uint32_t k = 0; k < op.ext_len; ++k) wid(e[k], i, "hint output");
+        break;
+      case P3R_OP_POSEIDON2_PERM: {
+        if (op.ext_len < 7 || (e[6] != 2 && e[6] != 4) || op.ext_len != 7 + e[6])
+          fail(P3R_EINVAL, "op %zu: Poseidon2 perm expects 4 input limbs, mmcs_index_sum, mmcs_bit and 2 or 4 outputs", i);
+        for (uint32_t k = 0; k < 6; ++k) opt(e[k], i, "poseidon2 input");
+        for (uint32_t k = 0; k < e[6]; ++k) opt(e[7 + k], i, "poseidon2 output");
+        if ((op.aux & 2) && e[5] == kNoW)
+          fail(P3R_EINVAL, "op %zu: mmcs_bit must be provided when merkle_path=true", i);
+        break;
+      }
+      case P3R_OP_RECOMPOSE:
+        wid(op.out, i, "out");
+        if (op.ext_len != 4) fail(P3R_EINVAL, "op %zu: recompose expects 1 input group with 4 witnesses", i);
+        for (uint32_t k = 0; k < 4; ++k) wid(e[k], i, "coefficient");
+        break;
+      default: fail(P3R_EUNSUPPORTED, "op %zu: kind %u has no table in this backend", i, op.kind);
+    }
+  }
+  for (uint32_t w : c.public_rows) if (w >= nw) fail(P3R_EINVAL, "public row witness %u out of bounds", w);
+  for (uint32_t w : c.private_rows) if (w >= nw) fail(P3R_EINVAL, "private row witness %u out of bounds", w);
+  for (uint32_t w : c.rewrite) if (w >= nw) fail(P3R_EINVAL, "witness_rewrite entry %u out of bounds", w);
+}
+
+// Bus roles of one ALU op (circuit.rs:337-391): 0 skip / 1 reader / 2 creator for a and c.
+struct AluRoles { uint8_t a_state, c_state, b_creator, out_creator; };
+
+template <class PP>
+CircuitTables circuit_tables(const HostCircuit& c) {
+  constexpr uint32_t P = PP::P, D = 4, NEG1 = P - 1;
+  auto scaled = [&](uint32_t w) { return (uint32_t)(((uint64_t)w * D) % P); };
+  CircuitTables T;
+  std::vector<uint32_t> reads(c.witness_count, 0);
+  std::vector<uint8_t> defined(c.witness_count, 0), is_private(c.witness_count, 0), is_hint(c.witness_count, 0);
+  std::vector<uint8_t> dup_p2(c.witness_count, 0), dup_rec(c.witness_count, 0);
+  for (uint32_t w : c.private_rows) is_private[w] = 1;
+  {
+    // hint outputs not also produced by a Const / Public op (circuit.rs:263-284)
+    std::vector<uint8_t> cp(c.witness_count, 0);
+    for (auto& op : c.ops)
+      if (op.kind == P3R_OP_CONST || op.kind == P3R_OP_PUBLIC) cp[op.out] = 1;
+    for (auto& op : c.ops)
+      if (op.kind == P3R_OP_HINT_EXT_DECOMPOSITION || op.kind == P3R_OP_HINT_BINARY_DECOMPOSITION)
+        for (uint32_t k = 0; k < op.ext_len; ++k) {
+          const uint32_t w = c.ext_of(op)[k];
+          if (!cp[w]) is_hint[w] = 1;
+        }
+  }
+  // pass 1: who creates, who reads
+  std::vector<AluRoles> roles;
+  std::vector<const p3r_op*> consts, publics, alus, p2s, recs;
+  for (auto& op : c.ops) {
+    switch (op.kind) {
+      case P3R_OP_CONST: consts.push_back(&op); defined[op.out] = 1; break;
+      case P3R_OP_PUBLIC: publics.push_back(&op); defined[op.out] = 1; break;
+      case P3R_OP_HINT_EXT_DECOMPOSITION: case P3R_OP_HINT_BINARY_DECOMPOSITION: break;
+      case P3R_OP_POSEIDON2_PERM: {
+        const uint32_t* e = c.ext_of(op);
+        const bool merkle = op.aux & 2;
+        for (int l = 0; l < 4; ++l)
+          if (e[l] != kNoW && !merkle) reads[e[l]]++;  // Merkle rows name the limb without a bus read
+        for (int l = 0; l < 2; ++l) {
+          const uint32_t w = e[7 + l];
+          if (w == kNoW) continue;
+          if (defined[w]) { dup_p2[w] = 1; reads[w]++; } else defined[w] = 1;
+        }
+        p2s.push_back(&op);
+        break;
+      }
+      case P3R_OP_RECOMPOSE:
+        if (defined[op.out]) { dup_rec[op.out] = 1; reads[op.out]++; } else defined[op.out] = 1;
+        recs.push_back(&op);
+        break;
+      default: {  // ALU
+        const bool out_def = defined[op.out], b_def = defined[op.b];
+        auto state_of = [&](uint32_t w) -> uint8_t {
+          if (defined[w]) return 1;
+          return ((is_private[w] || is_hint[w]) && !(!out_def && w == op.out)) ? 2 : 0;
+        };
+        AluRoles r{};
+        r.a_state = state_of(op.a);
+        r.c_state = op.c != kNoW ? state_of(op.c) : 0;
+        const bool out_backward = out_def || is_hint[op.out];
+        r.out_creator = !out_def;
+        r.b_creator = (!b_def && is_private[op.b]) || (out_backward && !b_def);
+        if (!r.b_creator) reads[op.b]++;
+        if (!r.out_creator) reads[op.out]++;
+        if (r.a_state == 1) reads[op.a]++;
+        if (r.c_state == 1) reads[op.c]++;
+        if (r.out_creator) defined[op.out] = 1;
+        if (r.b_creator) defined[op.b] = 1;
+        if (r.a_state == 2) defined[op.a] = 1;
+        if (r.c_state == 2) defined[op.c] = 1;
+        roles.push_back(r);
+        alus.push_back(&op);
+      }
+    }
+  }
+  for (uint32_t w : c.private_rows)
+    if (!defined[w]) fail(P3R_EINVAL, "UnclaimedPrivateInput { witness_id: WitnessId(%u) }", w);
+  // the accumulator of a Merkle chain is read when the row is followed by a chain boundary
+  // (the first padding row counts as one: batch_stark_prover.rs:149-176)
+  {
+    const size_t n = p2s.size();
+    size_t h = 1;
+    while (h < n) h <<= 1;
+    for (size_t r = 0; r < n; ++r) {
+      const uint32_t* e = c.ext_of(*p2s[r]);
+      if (e[4] == kNoW || !(p2s[r]->aux & 2)) continue;
+      const bool next_ns = r + 1 < n ? (p2s[r + 1]->aux & 1) : (h > n ? true : (p2s[0]->aux & 1));
+      if (next_ns) reads[e[4]]++;
+    }
+  }
+  // pass 2: signed multiplicities
+  auto mult = [&](uint32_t w) { return reads[w] % P; };
+  T.counts.n_const = consts.size();
+  for (auto* op : consts) { T.const_prep.push_back(mult(op->out)); T.const_prep.push_back(scaled(op->out)); }
+  T.counts.n_public = publics.size();
+  for (auto* op : publics) { T.public_prep.push_back(mult(op->out)); T.public_prep.push_back(scaled(op->out)); }
+  T.counts.n_alu = std::max<size_t>(alus.size(), 1);
+  for (size_t i = 0; i < alus.size(); ++i) {
+    const p3r_op& op = *alus[i];
+    const AluRoles& r = roles[i];
+    const uint32_t c_w = op.c != kNoW ? op.c : 0;
+    auto reader_col = [&](uint8_t st, uint32_t w) { return st == 1 ? 1u : st == 2 ? (P - mult(w)) % P : 0u; };
+    const uint32_t row[13] = {NEG1,
+                              op.kind == P3R_OP_ALU_ADD, op.kind == P3R_OP_ALU_BOOL_CHECK,
+                              op.kind == P3R_OP_ALU_MUL_ADD, op.kind == P3R_OP_ALU_HORNER_ACC,
+                              scaled(op.a), scaled(op.b), scaled(c_w), scaled(op.out),
+                              r.b_creator ? mult(op.b) : NEG1, r.out_creator ? mult(op.out) : NEG1,
+                              reader_col(r.a_state, op.a), reader_col(r.c_state, c_w)};
+    T.alu_prep13.insert(T.alu_prep13.end(), row, row + 13);
+  }
+  if (alus.empty()) T.alu_prep13.assign(13, 0);  // the dummy row of an empty ALU table (common.rs:283-286)
+  T.counts.n_p2 = p2s.size();
+  for (auto* op : p2s) {
+    const uint32_t* e = c.ext_of(*op);
+    T.p2_new_start.push_back(op->aux & 1);
+    T.p2_merkle_path.push_back((op->aux >> 1) & 1);
+    T.p2_mmcs_ctl_enabled.push_back(e[4] != kNoW);
+    for (int l = 0; l < 4; ++l) {
+      T.p2_in_ctl.push_back(e[l] != kNoW);
+      T.p2_input_indices.push_back(e[l] != kNoW ? e[l] : 0);
+    }
+    for (int l = 0; l < 2; ++l) {
+      const uint32_t w = e[7 + l];
+      T.p2_output_indices.push_back(w != kNoW ? w : 0);
+      T.p2_out_ctl.push_back(w == kNoW ? 0 : dup_p2[w] ? NEG1 : mult(w));
+    }
+    T.p2_mmcs_index_sum_idx.push_back(e[4] != kNoW ? e[4] : 0);
+  }
+  T.counts.n_recompose = recs.size();
+  for (auto* op : recs) {
+    T.recompose_prep.push_back(scaled(op->out));
+    T.recompose_prep.push_back(dup_rec[op->out] ? NEG1 : mult(op->out));
+  }
+  return T;
+}
+
+// ---------------------------------------------------------------- execution schedule (host, once)
+enum : uint32_t {
+  RUN_BACKWARD = 1u << 8,    // Add / Mul solving for b (runner.rs:341-385)
+  RUN_CHECK_OUT = 1u << 9,   // `out` already holds a value: compare instead of write (set_witness, :473-510)
+  RUN_CHECK_AUX = 1u << 10,  // same for MulAdd's intermediate_out
+  RUN_CHECK_BIT = 1u << 31,  // on a hint-output entry of the device ext array
+};
+
+struct RunOp {  // ALU / hint / recompose / const-check ops, one lane each
+  uint32_t kind_flags;  // bits 0-7 p3r_op_kind, 8-10 RUN_*, 16-23 ext_len
+  uint32_t a, b, c, out, aux;
+  uint32_t rec;      // ALU record / recompose row this op fills
+  uint32_t ext_off;  // into the device ext array
+  uint32_t op_idx;   // position in the circuit (error reports)
+  uint32_t pad;
+};
+
+struct RunP2 {  // one Poseidon2 permutation, sixteen lanes
+  uint32_t in[4], idx_w, bit_w, out[4];
+  uint32_t flags;  // bit 0 new_start, 1 merkle_path, 4-7 output is a check, 8-10 number of outputs
+  uint32_t row, prev_row, op_idx;
+};
+
+enum : uint32_t { RUN_ERR_CONFLICT = 1, RUN_ERR_DIV0 = 2, RUN_ERR_MMCS_BIT = 3, RUN_ERR_INDEX_SUM = 4 };
+
+struct RunSchedule {
+  std::vector<RunOp> light;
+  std::vector<RunP2> p2;
+  std::vector<uint32_t> light_off, p2_off;  // per level, size levels + 1
+  std::vector<uint32_t> dev_ext;
+  std::vector<uint32_t> const_rows;         // const op -> witness, in table order (static Const trace)
+  std::vector<uint32_t> public_out;         // public table row -> witness
+  std::vector<uint32_t> rewrite_pairs;      // (dst, src, check) triples applied after the last level
+  std::vector<uint32_t> p2_row_of_op_id;    // NonPrimitiveOpId -> Poseidon2 row (or kNoW)
+  std::vector<uint8_t> p2_row_merkle;
+  std::string deferred_error;               // what run() reports for a circuit that cannot complete
+  size_t levels = 0;
+};
+
+inline RunSchedule build_schedule(const HostCircuit& c) {
+  RunSchedule S;
+  const uint32_t nw = c.witness_count;
+  std::vector<uint8_t> set(nw, 0);
+  std::vector<uint32_t> wlevel(nw, 0);
+  for (uint32_t w : c.public_rows) set[w] = 1;
+  for (uint32_t w : c.private_rows) set[w] = 1;
+  auto defer = [&](const char* fmt, auto... args) {
+    if (!S.deferred_error.empty()) return;
+    char buf[256];
+    snprintf(buf, sizeof buf, fmt, args...);
+    S.deferred_error = buf;
+  };
+  struct Tmp { uint32_t level; bool is_p2; uint32_t idx; };
+  std::vector<Tmp> order;
+  std::vector<RunOp> light;
+  std::vector<RunP2> p2;
+  uint32_t n_alu = 0, n_rec = 0, n_pub = 0;
+  uint32_t last_normal = kNoW, last_merkle = kNoW, last_normal_level = 0, last_merkle_level = 0;
+  uint32_t max_op_id = 0;
+  bool any_npo = false;
+  for (auto& op : c.ops)
+    if (op.kind == P3R_OP_POSEIDON2_PERM || op.kind == P3R_OP_RECOMPOSE) { max_op_id = std::max(max_op_id, op.a); any_npo = true; }
+  if (any_npo) S.p2_row_of_op_id.assign((size_t)max_op_id + 1, kNoW);
+
+  for (size_t i = 0; i < c.ops.size(); ++i) {
+    const p3r_op& op = c.ops[i];
+    const uint32_t* e = c.ext_of(op);
+    uint32_t lvl = 0;
+    auto need = [&](uint32_t w) {  // read of a witness that must already be set
+      if (!set[w]) defer("WitnessNotSet { witness_id: WitnessId(%u) } at op %zu", w, i);
+      lvl = std::max(lvl, wlevel[w]);
+    };
+    // a write: fresh slot, or a comparison against what is there (then the op also depends on it)
+    auto put = [&](uint32_t w) -> bool {
+      if (set[w]) { lvl = std::max(lvl, wlevel[w]); return true; }
+      return false;
+    };
+    RunOp r{};
+    r.kind_flags = op.kind;
+    r.a = op.a; r.b = op.b; r.c = op.c; r.out = op.out; r.aux = op.aux; r.op_idx = (uint32_t)i;
+    std::vector<uint32_t> written;
+    switch (op.kind) {
+      case P3R_OP_CONST:
+        S.const_rows.push_back(op.out);
+        r.ext_off = (uint32_t)S.dev_ext.size();
+        S.dev_ext.insert(S.dev_ext.end(), e, e + 4);
+        if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
+        break;
+      case P3R_OP_PUBLIC:
+        if (!set[op.out]) defer("PublicInputNotSet { witness_id: WitnessId(%u) }", op.out);
+        S.public_out.push_back(op.out);
+        ++n_pub;
+        continue;  // nothing to execute
+      case P3R_OP_ALU_ADD: case P3R_OP_ALU_MUL:
+        need(op.a);
+        if (set[op.b]) {
+          need(op.b);
+          if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
+        } else {
+          need(op.out);
+          r.kind_flags |= RUN_BACKWARD;
+          written.push_back(op.b);
+        }
+        r.rec = n_alu++;
+        break;
+      case P3R_OP_ALU_BOOL_CHECK:
+        need(op.a);
+        if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
+        r.rec = n_alu++;
+        break;
+      case P3R_OP_ALU_MUL_ADD:
+        need(op.a); need(op.b);
+        if (op.aux != kNoW) { if (put(op.aux)) r.kind_flags |= RUN_CHECK_AUX; else written.push_back(op.aux); }
+        if (op.c != kNoW && op.c != op.aux) need(op.c);
+        // `out` may be the witness intermediate_out just wrote
+        if (op.aux != kNoW && op.out == op.aux) r.kind_flags |= RUN_CHECK_OUT;
+        else if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
+        r.rec = n_alu++;
+        break;
+      case P3R_OP_ALU_HORNER_ACC:
+        need(op.aux); need(op.a); need(op.b); need(op.c);
+        if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
+        r.rec = n_alu++;
+        break;
+      case P3R_OP_HINT_EXT_DECOMPOSITION: case P3R_OP_HINT_BINARY_DECOMPOSITION:
+        need(op.a);
+        r.ext_off = (uint32_t)S.dev_ext.size();
+        r.kind_flags |= op.ext_len << 16;
+        for (uint32_t k = 0; k < op.ext_len; ++k) {
+          uint32_t w = e[k];
+          bool dup_in_op = false;
+          for (uint32_t j = 0; j < k; ++j) dup_in_op |= e[j] == w;
+          if (dup_in_op || put(w)) S.dev_ext.push_back(w | RUN_CHECK_BIT); else { S.dev_ext.push_back(w); written.push_back(w); }
+        }
+        break;
+      case P3R_OP_RECOMPOSE:
+        for (int k = 0; k < 4; ++k) need(e[k]);
+        r.ext_off = (uint32_t)S.dev_ext.size();
+        S.dev_ext.insert(S.dev_ext.end(), e, e + 4);
+        if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
+        r.rec = n_rec++;
+        break;
+      case P3R_OP_POSEIDON2_PERM: {
+        RunP2 q{};
+        const bool new_start = op.aux & 1, merkle = op.aux & 2;
+        q.flags = (op.aux & 3) | (e[6] << 8);
+        q.op_idx = (uint32_t)i;
+        q.row = (uint32_t)p2.size();
+        for (int l = 0; l < 4; ++l) { q.in[l] = e[l]; if (e[l] != kNoW) need(e[l]); }
+        q.idx_w = e[4]; if (e[4] != kNoW) need(e[4]);
+        q.bit_w = e[5]; if (e[5] != kNoW) need(e[5]);
+        q.prev_row = kNoW;
+        if (!new_start) {
+          const uint32_t prev = merkle ? last_merkle : last_normal;
+          if (prev == kNoW) defer("Poseidon2ChainMissingPreviousState { operation_index: NonPrimitiveOpId(%u) }", op.a);
+          q.prev_row = prev;
+          lvl = std::max(lvl, merkle ? last_merkle_level : last_normal_level);
+        }
+        for (uint32_t l = 0; l < 4; ++l) {
+          q.out[l] = l < e[6] ? e[7 + l] : kNoW;
+          if (q.out[l] == kNoW) continue;
+          bool earlier = false;
+          for (uint32_t j = 0; j < l; ++j) earlier |= q.out[j] == q.out[l];
+          if (earlier || put(q.out[l])) q.flags |= 1u << (4 + l); else written.push_back(q.out[l]);
+        }
+        if (S.p2_row_of_op_id[op.a] != kNoW) fail(P3R_EINVAL, "duplicate NonPrimitiveOpId(%u)", op.a);
+        S.p2_row_of_op_id[op.a] = q.row;
+        S.p2_row_merkle.push_back(merkle);
+        lvl += 1;
+        if (merkle) { last_merkle = q.row; last_merkle_level = lvl; } else { last_normal = q.row; last_normal_level = lvl; }
+        for (uint32_t w : written) { set[w] = 1; wlevel[w] = lvl; }
+        order.push_back({lvl, true, (uint32_t)p2.size()});
+        p2.push_back(q);
+        continue;
+      }
+      default: fail(P3R_EUNSUPPORTED, "op %zu: unsupported kind %u", i, op.kind);
+    }
+    lvl += 1;
+    for (uint32_t w : written) { set[w] = 1; wlevel[w] = lvl; }
+    order.push_back({lvl, false, (uint32_t)light.size()});
+    light.push_back(r);
+  }
+  // ALU-dedup leftovers (runner.rs:199-216)
+  uint32_t max_level = 0;
+  for (auto& t : order) max_level = std::max(max_level, t.level);
+  for (size_t k = 0; k + 1 < c.rewrite.size(); k += 2) {
+    const uint32_t dup = c.rewrite[k];
+    uint32_t cur = c.rewrite[k + 1];
+    for (size_t guard = 0; guard <= c.rewrite.size(); ++guard) {
+      bool moved = false;
+      for (size_t j = 0; j + 1 < c.rewrite.size(); j += 2)
+        if (c.rewrite[j] == cur) { cur = c.rewrite[j + 1]; moved = true; break; }
+      if (!moved) break;
+    }
+    if (!set[cur]) continue;
+    S.rewrite_pairs.insert(S.rewrite_pairs.end(), {dup, cur, (uint32_t)set[dup]});
+    set[dup] = 1;
+  }
+  for (uint32_t w = 0; w < nw; ++w)
+    if (!set[w]) { defer("WitnessNotSetForIndex { index: %u }", w); break; }
+  // sort by level (stable: circuit order inside a level)
+  S.levels = max_level;
+  S.light_off.assign(max_level + 2, 0);
+  S.p2_off.assign(max_level + 2, 0);
+  for (auto& t : order) (t.is_p2 ? S.p2_off : S.light_off)[t.level + 1]++;
+  for (size_t l = 1; l < S.light_off.size(); ++l) { S.light_off[l] += S.light_off[l - 1]; S.p2_off[l] += S.p2_off[l - 1]; }
+  S.light.resize(light.size());
+  S.p2.resize(p2.size());
+  std::vector<uint32_t> lp(S.light_off.begin(), S.light_off.end() - 1), pp(S.p2_off.begin(), S.p2_off.end() - 1);
+  for (auto& t : order) {
+    if (t.is_p2) S.p2[pp[t.level]++] = p2[t.idx];
+    else S.light[lp[t.level]++] = light[t.idx];
+  }
+  (void)n_pub;
+  return S;
+}
+
+// ---------------------------------------------------------------- kernels
+template <class PP>
+__device__ __forceinline__ Fp4<PP> w_load(const uint32_t* __restrict__ w, uint32_t id) {
+  const uint4 v = *reinterpret_cast<const uint4*>(w + (size_t)id * 4);
+  Fp4<PP> e;
+  e.c[0] = Fp<PP>::raw(v.x); e.c[1] = Fp<PP>::raw(v.y); e.c[2] = Fp<PP>::raw(v.z); e.c[3] = Fp<PP>::raw(v.w);
+  return e;
+}
+template <class PP>
+__device__ __forceinline__ void w_store(uint32_t* __restrict__ w, uint32_t id, const Fp4<PP>& e) {
+  *reinterpret_cast<uint4*>(w + (size_t)id * 4) = make_uint4(e.c[0].v, e.c[1].v, e.c[2].v, e.c[3].v);
+}
+__device__ __forceinline__ void run_error(uint32_t* err, uint32_t op_idx, uint32_t code) {
+  // the runner stops at the FIRST failing op of the sequence: keep the smallest op index
+  atomicMin(err, (op_idx << 3) | code);
+}
+template <class PP>
+__device__ __forceinline__ void w_put(uint32_t* __restrict__ w, uint32_t id, const Fp4<PP>& e, bool check, uint32_t* err,
+                                      uint32_t op_idx) {
+  if (check) {
+    if (!(w_load<PP>(w, id) == e)) run_error(err, op_idx, RUN_ERR_CONFLICT);
+  } else {
+    w_store<PP>(w, id, e);
+  }
+}
+
+// One level of the schedule: blocks [0, light_blocks) run one ALU / hint / recompose / const op per
+// lane, the remaining blocks one Poseidon2 permutation per 16 lanes.
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_run_level(const RunOp* __restrict__ light, uint32_t n_light, uint32_t light_blocks,
+            const RunP2* __restrict__ p2, uint32_t n_p2, uint32_t* __restrict__ w,
+            const uint32_t* __restrict__ ext, uint32_t* __restrict__ alu_values, uint32_t* __restrict__ rec_values,
+            uint32_t* __restrict__ p2_inputs, size_t p2_h, uint8_t* __restrict__ p2_flags, uint32_t* __restrict__ p2_seed,
+            uint32_t* __restrict__ p2_out, const int32_t* __restrict__ pd_slot, const uint32_t* __restrict__ siblings,
+            const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag, uint32_t* __restrict__ err) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  if (blockIdx.x < light_blocks) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_light) return;
+    const RunOp op = light[i];
+    const uint32_t kind = op.kind_flags & 0xFF;
+    const bool chk_out = op.kind_flags & RUN_CHECK_OUT;
+    auto record = [&](const E& a, const E& b, const E& c, const E& o) {  // AluOpRecord (runner.rs:317-453)
+      uint4* dst = reinterpret_cast<uint4*>(alu_values + (size_t)op.rec * 16);
+      dst[0] = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
+      dst[1] = make_uint4(b.c[0].v, b.c[1].v, b.c[2].v, b.c[3].v);
+      dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
+      dst[3] = make_uint4(o.c[0].v, o.c[1].v, o.c[2].v, o.c[3].v);
+    };
+    switch (kind) {
+      case P3R_OP_CONST: {
+        E v;
+        for (int k = 0; k < 4; ++k) v.c[k] = F::raw(ext[op.ext_off + k]);  // stored in Montgomery form
+        w_put<PP>(w, op.out, v, chk_out, err, op.op_idx);
+        break;
+      }
+      case P3R_OP_ALU_ADD: case P3R_OP_ALU_MUL: {
+        const E a = w_load<PP>(w, op.a);
+        E b, o;
+        if (op.kind_flags & RUN_BACKWARD) {
+          o = w_load<PP>(w, op.out);
+          if (kind == P3R_OP_ALU_ADD) b = o - a;
+          else {
+            if (a == E::zero()) { run_error(err, op.op_idx, RUN_ERR_DIV0); b = E::zero(); }
+            else b = o * a.inv();
+          }
+          w_store<PP>(w, op.b, b);
+        } else {
+          b = w_load<PP>(w, op.b);
+          o = kind == P3R_OP_ALU_ADD ? a + b : a * b;
+          w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+        }
+        record(a, b, E::zero(), o);
+        break;
+      }
+      case P3R_OP_ALU_BOOL_CHECK: {
+        const E a = w_load<PP>(w, op.a);
+        w_put<PP>(w, op.out, a, chk_out, err, op.op_idx);
+        record(a, E::zero(), a, a);
+        break;
+      }
+      case P3R_OP_ALU_MUL_ADD: {
+        const E a = w_load<PP>(w, op.a), b = w_load<PP>(w, op.b), ab = a * b;
+        if (op.aux != kNoW) w_put<PP>(w, op.aux, ab, op.kind_flags & RUN_CHECK_AUX, err, op.op_idx);
+        const E c = op.c != kNoW ? (op.c == op.aux ? ab : w_load<PP>(w, op.c)) : E::zero();
+        const E o = ab + c;
+        if (op.aux != kNoW && op.out == op.aux) { if (!(o == ab)) run_error(err, op.op_idx, RUN_ERR_CONFLICT); }
+        else w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+        record(a, b, c, o);
+        break;
+      }
+      case P3R_OP_ALU_HORNER_ACC: {
+        const E acc = w_load<PP>(w, op.aux), a = w_load<PP>(w, op.a), b = w_load<PP>(w, op.b), c = w_load<PP>(w, op.c);
+        const E o = acc * b + c - a;
+        w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+        record(a, b, c, o);
+        break;
+      }
+      case P3R_OP_HINT_EXT_DECOMPOSITION: {
+        const E v = w_load<PP>(w, op.a);
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t t = ext[op.ext_off + k];
+          w_put<PP>(w, t & ~RUN_CHECK_BIT, E::from_base(v.c[k]), t & RUN_CHECK_BIT, err, op.op_idx);
+        }
+        break;
+      }
+      case P3R_OP_HINT_BINARY_DECOMPOSITION: {
+        const E v = w_load<PP>(w, op.a);
+        const uint32_t n_out = (op.kind_flags >> 16) & 0xFF;
+        uint32_t o = 0;
+        for (int k = 0; k < 4 && o < n_out; ++k) {
+          const uint32_t val = v.c[k].to_canonical();
+          for (int bit = 0; bit < 31 && o < n_out; ++bit, ++o) {
+            const uint32_t t = ext[op.ext_off + o];
+            const E e = ((val >> bit) & 1) ? E::one() : E::zero();
+            w_put<PP>(w, t & ~RUN_CHECK_BIT, e, t & RUN_CHECK_BIT, err, op.op_idx);
+          }
+        }
+        break;
+      }
+      case P3R_OP_RECOMPOSE: {
+        E v;
+        for (int k = 0; k < 4; ++k) {
+          v.c[k] = w_load<PP>(w, ext[op.ext_off + k]).c[0];
+          rec_values[(size_t)op.rec * 4 + k] = v.c[k].v;
+        }
+        w_put<PP>(w, op.out, v, chk_out, err, op.op_idx);
+        break;
+      }
+      default: break;
+    }
+    return;
+  }
+  // ---- Poseidon2 permutations: lane j of a 16-lane group owns state element j (limb j/4, coeff j%4)
+  const uint32_t g = (blockIdx.x - light_blocks) * kBlock + threadIdx.x;
+  const uint32_t i = g >> 4;
+  const int j = (int)(g & 15);
+  const bool live = i < n_p2;
+  F s = F::zero();
+  RunP2 q{};
+  bool bit = false;
+  if (live) {
+    q = p2[i];
+    const bool new_start = q.flags & 1, merkle = q.flags & 2;
+    // init_chain_state (executor.rs:103-139): Merkle rows carry the rate limbs only
+    if (!new_start && (!merkle || j < 8)) s = F::raw(p2_out[(size_t)q.prev_row * 16 + j]);
+    // fill_sibling_data (:166-201): private sibling in the capacity limbs
+    const int32_t slot = pd_slot[q.row];
+    if (merkle && slot >= 0 && j >= 8) s = F::raw(siblings[(size_t)slot * 8 + (j - 8)]);
+    // apply_witness_values (:207-219)
+    const uint32_t in_w = q.in[j >> 2];
+    if (in_w != kNoW) s = F::raw(w[(size_t)in_w * 4 + (j & 3)]);
+    // resolve_mmcs_bit (:283-338)
+    if (q.bit_w != kNoW) {
+      const E v = w_load<PP>(w, q.bit_w);
+      if (v == E::one()) bit = true;
+      else if (!(v == E::zero()) && j == 0) run_error(err, q.op_idx, RUN_ERR_MMCS_BIT);
+    }
+  }
+  // apply_merkle_swap (:227-234): the two halves trade places
+  {
+    const uint32_t other = __shfl_xor(s.v, 8);
+    if (live && (q.flags & 2) && bit) s = F::raw(other);
+  }
+  if (live) {
+    // Poseidon2CircuitRow (build_trace_row :364-417, trace.rs:188-233)
+    p2_inputs[(size_t)j * p2_h + q.row] = s.v;
+    if (j == 0) {
+      p2_flags[q.row] = q.flags & 1;
+      p2_flags[p2_h + q.row] = (q.flags >> 1) & 1;
+      p2_flags[2 * p2_h + q.row] = bit;
+      uint32_t seed = 0;
+      if (q.idx_w != kNoW) {
+        const E v = w_load<PP>(w, q.idx_w);
+        if (v.c[1].v | v.c[2].v | v.c[3].v) run_error(err, q.op_idx, RUN_ERR_INDEX_SUM);
+        seed = v.c[0].v;
+      }
+      p2_seed[q.row] = seed;
+    }
+  }
+  s = coop_permute<PP>(s, j, F::raw(diag[j]), rc);
+  if (live) {
+    p2_out[(size_t)q.row * 16 + j] = s.v;
+    const uint32_t n_out = (q.flags >> 8) & 7;
+    const uint32_t l = (uint32_t)j >> 2;
+    if (l < n_out && q.out[l] != kNoW) {
+      uint32_t* slot = w + (size_t)q.out[l] * 4 + (j & 3);
+      if (q.flags & (1u << (4 + l))) { if (*slot != s.v) run_error(err, q.op_idx, RUN_ERR_CONFLICT); }
+      else *slot = s.v;
+    }
+  }
+}
+
+// witness[rows[i]] = values[i]  (set_public_inputs / set_private_inputs, runner.rs:83-122)
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_run_scatter(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ values, size_t n, uint32_t* __restrict__ w) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n * 4) return;
+  w[(size_t)rows[i >> 2] * 4 + (i & 3)] = values[i];
+}
+// out[i] = witness[rows[i]]  (PublicTraceBuilder, tables/public.rs:44-62)
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_run_gather(const uint32_t* __restrict__ rows, size_t n, const uint32_t* __restrict__ w, uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n * 4) return;
+  out[i] = w[(size_t)rows[i >> 2] * 4 + (i & 3)];
+}
+// duplicates left behind by ALU deduplication take the value of their canonical witness
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_run_rewrite(const uint32_t* __restrict__ triples, size_t n, uint32_t* __restrict__ w, uint32_t* __restrict__ err) {
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t dst = triples[3 * i], src = triples[3 * i + 1];
+  w_put<PP>(w, dst, w_load<PP>(w, src), triples[3 * i + 2] != 0, err, 0x1FFFFFFFu);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- the prepared circuit
+struct p3r_circuit {
+  HostCircuit host;
+  RunSchedule sched;
+  p3r_layer_desc_counts counts{};
+  std::unique_ptr<p3r_layer> layer;
+  p3r::DevBuf d_light, d_p2, d_ext, d_const_values, d_public_rows, d_private_rows, d_public_out, d_rewrite;
+};
+
+namespace {
+
+template <class PP>
+std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* d, uint32_t* commit_out) {
+  auto C = std::make_unique<p3r_circuit>();
+  HostCircuit& h = C->host;
+  auto need = [&](const void* p, size_t n, const char* what) { if (n && !p) fail(P3R_EINVAL, "%s is NULL", what); };
+  need(d->ops, d->n_ops, "ops"); need(d->ext, d->n_ext, "ext"); need(d->public_rows, d->n_public, "public_rows");
+  need(d->private_input_rows, d->n_private, "private_input_rows"); need(d->witness_rewrite, d->n_rewrite, "witness_rewrite");
+  h.witness_count = d->witness_count;
+  h.ops.assign(d->ops, d->ops + d->n_ops);
+  h.ext.assign(d->ext, d->ext + d->n_ext);
+  h.public_rows.assign(d->public_rows, d->public_rows + d->n_public);
+  h.private_rows.assign(d->private_input_rows, d->private_input_rows + d->n_private);
+  h.rewrite.assign(d->witness_rewrite, d->witness_rewrite + 2 * d->n_rewrite);
+  validate_circuit(h);
+  for (auto& op : h.ops)
+    if (op.kind == P3R_OP_CONST)
+      for (int k = 0; k < 4; ++k)
+        if (h.ext_of(op)[k] >= PP::P) fail(P3R_EINVAL, "constant of witness %u is not canonical", op.out);
+
+  // CircuitProverData: preprocessed columns -> LDE + commitment (build_next_layer_prep)
+  CircuitTables T = circuit_tables<PP>(h);
+  C->counts = T.counts;
+  p3r_layer_desc ld{};
+  ld.counts = T.counts;
+  ld.public_lanes = d->public_lanes; ld.alu_lanes = d->alu_lanes; ld.horner_packed_steps = d->horner_packed_steps;
+  ld.recompose_lanes = d->recompose_lanes; ld.min_trace_height = d->min_trace_height;
+  ld.const_prep = T.const_prep.data(); ld.public_prep = T.public_prep.data(); ld.alu_prep13 = T.alu_prep13.data();
+  ld.recompose_prep = T.recompose_prep.data();
+  ld.p2_new_start = T.p2_new_start.data(); ld.p2_merkle_path = T.p2_merkle_path.data();
+  ld.p2_mmcs_ctl_enabled = T.p2_mmcs_ctl_enabled.data(); ld.p2_in_ctl = T.p2_in_ctl.data();
+  ld.p2_input_indices = T.p2_input_indices.data(); ld.p2_out_ctl = T.p2_out_ctl.data();
+  ld.p2_output_indices = T.p2_output_indices.data(); ld.p2_mmcs_index_sum_idx = T.p2_mmcs_index_sum_idx.data();
+  C->layer = layer_create<PP>(ctx, &ld, commit_out);
+
+  // execution schedule
+  C->sched = build_schedule(h);
+  RunSchedule& S = C->sched;
+  // constants travel in Montgomery form; hint output lists keep their flag bit
+  std::vector<uint32_t> ext_m = S.dev_ext;
+  std::vector<uint32_t> const_vals;
+  for (auto& r : S.light)
+    if ((r.kind_flags & 0xFF) == P3R_OP_CONST)
+      for (int k = 0; k < 4; ++k) ext_m[r.ext_off + k] = Fp<PP>::from_canonical(S.dev_ext[r.ext_off + k]).v;
+  for (auto& op : h.ops)
+    if (op.kind == P3R_OP_CONST)
+      for (int k = 0; k < 4; ++k) const_vals.push_back(Fp<PP>::from_canonical(h.ext_of(op)[k]).v);
+  auto up = [&](DevBuf& b, const void* src, size_t bytes) {
+    b.alloc(std::max<size_t>((bytes + 3) / 4, 1));
+    if (bytes) P3R_HIP(copy_sync(ctx->stream, b.p, src, bytes, hipMemcpyHostToDevice));
+  };
+  up(C->d_light, S.light.data(), S.light.size() * sizeof(RunOp));
+  up(C->d_p2, S.p2.data(), S.p2.size() * sizeof(RunP2));
+  up(C->d_ext, ext_m.data(), ext_m.size() * 4);
+  up(C->d_const_values, const_vals.data(), const_vals.size() * 4);
+  up(C->d_public_rows, h.public_rows.data(), h.public_rows.size() * 4);
+  up(C->d_private_rows, h.private_rows.data(), h.private_rows.size() * 4);
+  up(C->d_public_out, S.public_out.data(), S.public_out.size() * 4);
+  up(C->d_rewrite, S.rewrite_pairs.data(), S.rewrite_pairs.size() * 4);
+  return C;
+}
+
+inline const char* run_error_text(uint32_t code) {
+  switch (code) {
+    case RUN_ERR_CONFLICT: return "WitnessConflict";
+    case RUN_ERR_DIV0: return "DivisionByZero";
+    case RUN_ERR_MMCS_BIT: return "IncorrectNonPrimitiveOpPrivateData: expected boolean mmcs_bit (0 or 1)";
+    case RUN_ERR_INDEX_SUM: return "IncorrectNonPrimitiveOpPrivateData: expected base field mmcs_index_sum";
+    default: return "unknown";
+  }
+}
+
+// CircuitRunner::run: returns the Traces (HBM-resident) of one execution.
+template <class PP>
+std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, const p3r_circuit_inputs* in,
+                                         DevBuf* witness_out = nullptr) {
+  const HostCircuit& h = C->host;
+  const RunSchedule& S = C->sched;
+  const p3r_layer* L = C->layer.get();
+  if (!S.deferred_error.empty()) fail(P3R_EINVAL, "%s", S.deferred_error.c_str());
+  if (h.public_rows.size() && !in->public_values) fail(P3R_EINVAL, "PublicInputLengthMismatch: public_values is NULL");
+  if (h.private_rows.size() && !in->private_values) fail(P3R_EINVAL, "PrivateInputLengthMismatch: private_values is NULL");
+  // set_private_data (runner.rs:124-176)
+  const size_t n_p2 = C->counts.n_p2;
+  std::vector<int32_t> pd_slot(std::max<size_t>(n_p2, 1), -1);
+  for (size_t k = 0; k < in->n_private_data; ++k) {
+    const uint32_t id = in->private_data_op_ids[k];
+    if (id >= S.p2_row_of_op_id.size() || S.p2_row_of_op_id[id] == kNoW)
+      fail(P3R_EINVAL, "NonPrimitiveOpIdOutOfRange { op_id: %u, max_ops: %zu }", id, S.p2_row_of_op_id.size());
+    const uint32_t row = S.p2_row_of_op_id[id];
+    if (pd_slot[row] >= 0) fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data already set for NonPrimitiveOpId(%u)", id);
+    if (!S.p2_row_merkle[row])
+      fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data provided for non-Merkle operation NonPrimitiveOpId(%u)", id);
+    pd_slot[row] = (int32_t)k;
+  }
+  prof_stage(ctx, "run_circuit");
+  auto T = std::make_unique<p3r_dtraces>();
+  const auto& cn = C->counts;
+  T->n_const = cn.n_const; T->n_public = cn.n_public; T->n_alu = cn.n_alu; T->n_recompose = cn.n_recompose;
+  DevBuf w((size_t)std::max<uint32_t>(h.witness_count, 1) * 4);
+  DevBuf err(1), d_pub, d_priv, d_sib, d_slot, p2_out(std::max<size_t>(n_p2, 1) * 16);
+  P3R_HIP(hipMemsetAsync(err.p, 0xFF, 4, ctx->stream));
+  d_pub = upload_mont<PP>(ctx, in->public_values, h.public_rows.size() * 4, "public_values");
+  d_priv = upload_mont<PP>(ctx, in->private_values, h.private_rows.size() * 4, "private_values");
+  d_sib = upload_mont<PP>(ctx, in->private_data_siblings, in->n_private_data * 8, "private_data_siblings");
+  d_slot.alloc(pd_slot.size());
+  P3R_HIP(copy_sync(ctx->stream, d_slot.p, pd_slot.data(), pd_slot.size() * 4, hipMemcpyHostToDevice));
+  if (h.public_rows.size())
+    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(h.public_rows.size() * 4)), dim3(kBlock), 0, ctx->stream,
+                       C->d_public_rows.p, d_pub.p, h.public_rows.size(), w.p);
+  if (h.private_rows.size())
+    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(h.private_rows.size() * 4)), dim3(kBlock), 0, ctx->stream,
+                       C->d_private_rows.p, d_priv.p, h.private_rows.size(), w.p);
+  // trace buffers
+  T->const_values.alloc(std::max<size_t>(cn.n_const * 4, 1));
+  if (cn.n_const)
+    P3R_HIP(hipMemcpyAsync(T->const_values.p, C->d_const_values.p, cn.n_const * 16, hipMemcpyDeviceToDevice, ctx->stream));
+  T->public_values.alloc(std::max<size_t>(cn.n_public * 4, 1));
+  T->alu_values.alloc(std::max<size_t>(cn.n_alu * 16, 1));
+  P3R_HIP(hipMemsetAsync(T->alu_values.p, 0, T->alu_values.n * 4, ctx->stream));  // the dummy op of an empty table
+  T->recompose_values.alloc(std::max<size_t>(cn.n_recompose * 4, 1));
+  uint32_t* p2_inputs = nullptr; uint8_t* p2_flags = nullptr; uint32_t* p2_seed = nullptr;
+  size_t p2_h = 0;
+  if (L->has_p2) {
+    // padded with fillers: new_start = 1, zero state (poseidon2.rs:1125-1140)
+    p2_h = L->h_p2;
+    auto d = std::make_unique<p3r_p2_dev>();
+    d->n = p2_h;
+    d->inputs = dmat_alloc(p2_h, P2_WIDTH);
+    P3R_HIP(hipMemsetAsync(d->inputs->d, 0, p2_h * P2_WIDTH * 4, ctx->stream));
+    d->flags.alloc((3 * p2_h + 3) / 4 + 1);
+    p2_flags = reinterpret_cast<uint8_t*>(d->flags.p);
+    P3R_HIP(hipMemsetAsync(p2_flags, 1, p2_h, ctx->stream));
+    P3R_HIP(hipMemsetAsync(p2_flags + p2_h, 0, 2 * p2_h, ctx->stream));
+    d->seed.alloc(p2_h);
+    P3R_HIP(hipMemsetAsync(d->seed.p, 0, p2_h * 4, ctx->stream));
+    p2_inputs = d->inputs->d; p2_seed = d->seed.p;
+    T->p2 = std::move(d);
+  }
+  {
+    ProfScope ps(ctx, "run_levels");
+    const RunOp* light = reinterpret_cast<const RunOp*>(C->d_light.p);
+    const RunP2* p2 = reinterpret_cast<const RunP2*>(C->d_p2.p);
+    for (size_t l = 1; l <= S.levels; ++l) {
+      const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2_off[l + 1] - S.p2_off[l];
+      if (!nl && !np) continue;
+      const uint32_t lb = (nl + kBlock - 1) / kBlock, pb = (np * 16 + kBlock - 1) / kBlock;
+      hipLaunchKernelGGL(k_run_level<PP>, dim3(lb + pb), dim3(kBlock), 0, ctx->stream, light + S.light_off[l], nl, lb,
+                         p2 + S.p2_off[l], np, w.p, C->d_ext.p, T->alu_values.p, T->recompose_values.p, p2_inputs, p2_h,
+                         p2_flags, p2_seed, p2_out.p, reinterpret_cast<const int32_t*>(d_slot.p), d_sib.p, ctx->rc.p,
+                         ctx->p2_diag.p, err.p);
+    }
+    if (!S.rewrite_pairs.empty())
+      hipLaunchKernelGGL(k_run_rewrite<PP>, dim3(blocks_for(S.rewrite_pairs.size() / 3)), dim3(kBlock), 0, ctx->stream,
+                         C->d_rewrite.p, S.rewrite_pairs.size() / 3, w.p, err.p);
+    if (cn.n_public)
+      hipLaunchKernelGGL(k_run_gather<PP>, dim3(blocks_for(cn.n_public * 4)), dim3(kBlock), 0, ctx->stream,
+                         C->d_public_out.p, cn.n_public, w.p, T->public_values.p);
+    P3R_HIP(hipGetLastError());
+  }
+  uint32_t e = 0;
+  P3R_HIP(copy_sync(ctx->stream, &e, err.p, 4, hipMemcpyDeviceToHost));
+  if (e != 0xFFFFFFFFu) {
+    const uint32_t idx = e >> 3;
+    if (idx == 0x1FFFFFFFu) fail(P3R_EINVAL, "WitnessConflict while applying witness_rewrite");
+    fail(P3R_EINVAL, "%s at op %u", run_error_text(e & 7), idx);
+  }
+  if (witness_out) *witness_out = std::move(w);
+  return T;
+}
+
+template <class PP>
+void dtraces_get(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, uint32_t which, uint32_t* out, size_t out_len) {
+  const auto& c = L->counts;
+  auto plain = [&](const DevBuf& src, size_t n) {
+    if (out_len != n) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", n, out_len);
+    if (!n) return;
+    DevBuf tmp(n);
+    P3R_HIP(hipMemcpyAsync(tmp.p, src.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_convert_inplace<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, tmp.p, n, 0);
+    P3R_HIP(copy_sync(ctx->stream, out, tmp.p, n * 4, hipMemcpyDeviceToHost));
+  };
+  switch (which) {
+    case P3R_TRACES_CONST_VALUES: plain(t->const_values, c.n_const * 4); break;
+    case P3R_TRACES_PUBLIC_VALUES: plain(t->public_values, c.n_public * 4); break;
+    case P3R_TRACES_ALU_VALUES: plain(t->alu_values, c.n_alu * 16); break;
+    case P3R_TRACES_RECOMPOSE_VALUES: plain(t->recompose_values, c.n_recompose * 4); break;
+    case P3R_TRACES_P2_INPUT_VALUES: {
+      if (out_len != c.n_p2 * 16) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2 * 16, out_len);
+      if (!c.n_p2) break;
+      std::vector<uint32_t> full(t->p2->n * 16);
+      download<PP>(ctx, t->p2->inputs.get(), full.data());  // row-major [h][16], canonical
+      std::copy(full.begin(), full.begin() + c.n_p2 * 16, out);
+      break;
+    }
+    case P3R_TRACES_P2_FLAGS: {
+      if (out_len != c.n_p2 * 3) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2 * 3, out_len);
+      if (!c.n_p2) break;
+      const size_t h = t->p2->n;
+      std::vector<uint8_t> f(3 * h);
+      P3R_HIP(copy_sync(ctx->stream, f.data(), t->p2->flags.p, 3 * h, hipMemcpyDeviceToHost));
+      for (size_t r = 0; r < c.n_p2; ++r)
+        for (int k = 0; k < 3; ++k) out[r * 3 + k] = f[k * h + r];
+      break;
+    }
+    case P3R_TRACES_P2_MMCS_INDEX_SUM: {
+      if (out_len != c.n_p2) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2, out_len);
+      if (!c.n_p2) break;
+      plain(t->p2->seed, c.n_p2);
+      break;
+    }
+    default: fail(P3R_EINVAL, "unknown traces array %u", which);
+  }
+}
+
+}  // namespace

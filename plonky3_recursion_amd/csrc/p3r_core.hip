@@ -484,6 +484,7 @@ void init_ctx(p3r_ctx* ctx) {
 
 #include "prove_impl.cuh"
 #include "layer_impl.cuh"
+#include "circuit_impl.cuh"
 
 // =============================================================================== C ABI
 extern "C" {
@@ -844,6 +845,56 @@ p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const
     out = m[table].release();
   });
   return out;
+}
+
+// ---- circuit boundary (circuit_impl.cuh) ----
+p3r_circuit* p3r_circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* desc, uint32_t* commit_out) {
+  p3r_circuit* out = nullptr;
+  guard(ctx, [&] {
+    if (!desc || !commit_out) fail(P3R_EINVAL, "NULL argument");
+    out = P3R_FIELD_CALL(ctx, circuit_create, ctx, desc, commit_out).release();
+  });
+  return out;
+}
+void p3r_circuit_free(p3r_ctx* ctx, p3r_circuit* circuit) {
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  delete circuit;
+}
+const p3r_layer* p3r_circuit_layer(const p3r_circuit* circuit) { return circuit ? circuit->layer.get() : nullptr; }
+int p3r_circuit_counts(const p3r_circuit* circuit, p3r_layer_desc_counts* out) {
+  if (!circuit || !out) return P3R_EINVAL;
+  *out = circuit->counts;
+  return P3R_OK;
+}
+int p3r_circuit_levels(const p3r_circuit* circuit, size_t* n_levels) {
+  if (!circuit || !n_levels) return P3R_EINVAL;
+  *n_levels = circuit->sched.levels;
+  return P3R_OK;
+}
+p3r_dtraces* p3r_circuit_run(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs) {
+  p3r_dtraces* out = nullptr;
+  guard(ctx, [&] {
+    if (!circuit || !inputs) fail(P3R_EINVAL, "NULL argument");
+    out = P3R_FIELD_CALL(ctx, circuit_run, ctx, circuit, inputs).release();
+  });
+  return out;
+}
+int p3r_prove_next_layer(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs,
+                         uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {
+  return guard(ctx, [&] {
+    if (!circuit || !inputs || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
+    auto t = P3R_FIELD_CALL(ctx, circuit_run, ctx, circuit, inputs);
+    auto bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, circuit->layer.get(), t.get(),
+                                (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
+    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+  });
+}
+int p3r_dtraces_get(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces, uint32_t which,
+                    uint32_t* out, size_t out_len) {
+  return guard(ctx, [&] {
+    if (!layer || !traces || (!out && out_len)) fail(P3R_EINVAL, "NULL argument");
+    P3R_FIELD_CALL(ctx, dtraces_get, ctx, layer, traces, which, out, out_len);
+  });
 }
 
 int p3r_profile_enable(p3r_ctx* ctx, int on) {

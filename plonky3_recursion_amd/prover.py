@@ -92,6 +92,7 @@ class CircuitProverData:
     def __init__(self, ctx: Context, prep: CircuitPrep, packing: TablePacking):
         packing.validate()
         self.ctx, self.packing = ctx, packing
+        self._borrowed = False
         d = _lib.P3rLayerDesc()
         keep = []
 
@@ -124,6 +125,19 @@ class CircuitProverData:
         self.preprocessed_commitment = np.empty((1 << ctx.cap_height, 8), dtype=np.uint32)
         self.h = ctx.ptr(ctx.lib.p3r_layer_create(ctx.h, C.byref(d),
                                                   self.preprocessed_commitment.ctypes.data_as(_lib.u32p)))
+        self._read_shape()
+
+    @classmethod
+    def _borrow(cls, ctx: Context, handle, packing: TablePacking, rows: dict, commitment: np.ndarray):
+        """View of the CircuitProverData a prepared circuit owns (p3r_circuit_layer)."""
+        self = cls.__new__(cls)
+        self.ctx, self.packing, self.h, self.rows = ctx, packing, handle, rows
+        self.preprocessed_commitment, self._borrowed = commitment, True
+        self._read_shape()
+        return self
+
+    def _read_shape(self):
+        ctx, packing = self.ctx, self.packing
         hs = (C.c_size_t * 5)()
         ctx.check(ctx.lib.p3r_layer_table_heights(self.h, hs))
         self.table_heights = [int(x) for x in hs]   # 0 = table absent from the batch
@@ -133,7 +147,7 @@ class CircuitProverData:
         self.effective_packing = dataclasses.replace(packing, public_lanes=pl.value, alu_lanes=al.value)
 
     def free(self):
-        if self.h and self.ctx.h:
+        if self.h and self.ctx.h and not self._borrowed:
             self.ctx.lib.p3r_layer_free(self.ctx.h, self.h)
         self.h = None
 
@@ -144,13 +158,32 @@ class CircuitProverData:
             pass
 
 
+TRACES_ARRAYS = dict(const_values=(0, "const", 4), public_values=(1, "public", 4), alu_values=(2, "alu", 16),
+                     p2_input_values=(3, "poseidon2", 16), p2_flags=(4, "poseidon2", 3),
+                     p2_mmcs_index_sum=(5, "poseidon2", 1), recompose_values=(6, "recompose", 4))
+
+
 class ResidentTraces:
     """`Traces` uploaded to HBM once (so a prove starts from device-resident inputs)."""
 
     def __init__(self, ctx: Context, cpd: CircuitProverData, traces: Traces):
-        self.ctx = ctx
+        self.ctx, self.cpd = ctx, cpd
         t, self._keep = _traces_struct(traces)
         self.h = ctx.ptr(ctx.lib.p3r_traces_upload(ctx.h, cpd.h, C.byref(t)))
+
+    @classmethod
+    def _adopt(cls, ctx: Context, cpd: CircuitProverData, handle):
+        self = cls.__new__(cls)
+        self.ctx, self.cpd, self.h, self._keep = ctx, cpd, handle, None
+        return self
+
+    def download(self, name: str) -> np.ndarray:
+        """One array of the device-resident Traces, canonical (see TRACES_ARRAYS)."""
+        which, table, width = TRACES_ARRAYS[name]
+        out = np.empty((self.cpd.rows[table], width), dtype=np.uint32)
+        self.ctx.check(self.ctx.lib.p3r_dtraces_get(self.ctx.h, self.cpd.h, self.h, which,
+                                                    out.ctypes.data_as(_lib.u32p), out.size))
+        return out
 
     def free(self):
         if self.h and self.ctx.h:
@@ -334,6 +367,152 @@ class BatchStarkProver:
             self.ctx.lib.p3r_layer_build_main_trace(self.ctx.h, cpd.h, resident.h, table)))
 
 
+# ----------------------------------------------------------------------------- circuit boundary
+NO_WITNESS = 0xFFFFFFFF
+(OP_CONST, OP_PUBLIC, OP_ALU_ADD, OP_ALU_MUL, OP_ALU_BOOL_CHECK, OP_ALU_MUL_ADD, OP_ALU_HORNER_ACC,
+ OP_HINT_EXT_DECOMPOSITION, OP_HINT_BINARY_DECOMPOSITION, OP_POSEIDON2_PERM, OP_RECOMPOSE) = range(11)
+
+
+@dataclass
+class Circuit:
+    """Flattened `Circuit<EF>` (circuit/src/circuit.rs:152-181).  `ops` is (n, 8) uint32 in execution
+    order: [kind, a, b, c, out, aux, ext_off, ext_len], see `p3r_op_kind` in include/p3r.h."""
+    witness_count: int
+    ops: np.ndarray
+    ext: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
+    public_rows: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
+    private_input_rows: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
+    witness_rewrite: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.uint32))
+
+    @property
+    def public_flat_len(self):
+        return len(np.asarray(self.public_rows).reshape(-1))
+
+    @property
+    def private_flat_len(self):
+        return len(np.asarray(self.private_input_rows).reshape(-1))
+
+    def runner(self, prepared: "PreparedCircuit") -> "CircuitRunner":
+        return CircuitRunner(prepared)
+
+
+@dataclass
+class CircuitInputs:
+    public_values: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.uint32))
+    private_values: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.uint32))
+    private_data_op_ids: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
+    private_data_siblings: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.uint32))
+
+
+def _flat32(a):
+    x = np.ascontiguousarray(np.asarray(a, dtype=np.uint32).reshape(-1))
+    return x, x.ctypes.data_as(_lib.u32p)
+
+
+class PreparedCircuit:
+    """A circuit prepared for repeated proving: preprocessed columns (generate_preprocessed_columns +
+    get_airs_and_degrees_with_prep), their commitment, and the levelised execution schedule."""
+
+    def __init__(self, ctx: Context, circuit: Circuit, packing: TablePacking):
+        packing.validate()
+        self.ctx, self.circuit, self.packing = ctx, circuit, packing
+        d = _lib.P3rCircuitDesc()
+        ops, _ = _flat32(circuit.ops)
+        if ops.size % 8:
+            raise ValueError("ops must be (n, 8)")
+        keep = [ops]
+        d.witness_count = circuit.witness_count
+        d.n_ops, d.ops = ops.size // 8, C.cast(ops.ctypes.data_as(_lib.u32p), C.POINTER(_lib.P3rOp))
+        for name, attr in (("ext", "ext"), ("public", "public_rows"), ("private", "private_input_rows"),
+                           ("rewrite", "witness_rewrite")):
+            x, ptr = _flat32(getattr(circuit, attr))
+            keep.append(x)
+            n = x.size // 2 if name == "rewrite" else x.size
+            setattr(d, "n_" + name, n)
+            setattr(d, {"ext": "ext", "public": "public_rows", "private": "private_input_rows",
+                        "rewrite": "witness_rewrite"}[name], ptr)
+        d.public_lanes, d.alu_lanes = packing.public_lanes, packing.alu_lanes
+        d.horner_packed_steps, d.recompose_lanes = packing.horner_packed_steps, packing.recompose_lanes
+        d.min_trace_height = packing.min_trace_height
+        commit = np.empty((1 << ctx.cap_height, 8), dtype=np.uint32)
+        self.h = ctx.ptr(ctx.lib.p3r_circuit_create(ctx.h, C.byref(d), commit.ctypes.data_as(_lib.u32p)))
+        cn = _lib.P3rLayerCounts()
+        ctx.check(ctx.lib.p3r_circuit_counts(self.h, C.byref(cn)))
+        rows = dict(const=cn.n_const, public=cn.n_public, alu=cn.n_alu, poseidon2=cn.n_p2, recompose=cn.n_recompose)
+        lv = C.c_size_t()
+        ctx.check(ctx.lib.p3r_circuit_levels(self.h, C.byref(lv)))
+        self.levels = lv.value
+        self.circuit_prover_data = CircuitProverData._borrow(ctx, ctx.lib.p3r_circuit_layer(self.h), packing, rows,
+                                                             commit)
+
+    @staticmethod
+    def _inputs_struct(circuit: Circuit, inputs: CircuitInputs):
+        t = _lib.P3rCircuitInputs()
+        pub, t.public_values = _flat32(inputs.public_values)
+        prv, t.private_values = _flat32(inputs.private_values)
+        # set_public_inputs / set_private_inputs length checks (runner.rs:84-90,107-113)
+        if pub.size != 4 * circuit.public_flat_len:
+            raise P3rError(-1, "PublicInputLengthMismatch { expected: %d, got: %d }" % (circuit.public_flat_len, pub.size // 4))
+        if prv.size != 4 * circuit.private_flat_len:
+            raise P3rError(-1, "PrivateInputLengthMismatch { expected: %d, got: %d }" % (circuit.private_flat_len, prv.size // 4))
+        ids, t.private_data_op_ids = _flat32(inputs.private_data_op_ids)
+        sib, t.private_data_siblings = _flat32(inputs.private_data_siblings)
+        if sib.size != 8 * ids.size:
+            raise ValueError("private_data_siblings must hold two extension limbs (8 values) per op id")
+        t.n_private_data = ids.size
+        return t, (pub, prv, ids, sib)
+
+    def run(self, inputs: CircuitInputs) -> ResidentTraces:
+        """`CircuitRunner::run` on the device (circuit/src/tables/runner.rs:195-253)."""
+        t, keep = self._inputs_struct(self.circuit, inputs)
+        h = self.ctx.ptr(self.ctx.lib.p3r_circuit_run(self.ctx.h, self.h, C.byref(t)))
+        return ResidentTraces._adopt(self.ctx, self.circuit_prover_data, h)
+
+    def prove(self, inputs: CircuitInputs, canonical_field_encoding=False) -> bytes:
+        t, keep = self._inputs_struct(self.circuit, inputs)
+        return self.ctx._proof_call(self.ctx.lib.p3r_prove_next_layer, self.ctx.h, self.h, C.byref(t),
+                                    1 if canonical_field_encoding else 0)
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.circuit_prover_data.h = None
+            self.ctx.lib.p3r_circuit_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class CircuitRunner:
+    """The reference's runner surface (circuit/src/tables/runner.rs:22-253) over a prepared circuit."""
+
+    def __init__(self, prepared: PreparedCircuit):
+        self.prepared = prepared
+        self._inputs = CircuitInputs()
+        self._pd = {}
+
+    def set_public_inputs(self, values):
+        self._inputs.public_values = np.asarray(values, dtype=np.uint32).reshape(-1, 4)
+
+    def set_private_inputs(self, values):
+        self._inputs.private_values = np.asarray(values, dtype=np.uint32).reshape(-1, 4)
+
+    def set_private_data(self, op_id: int, sibling):
+        if op_id in self._pd:
+            raise P3rError(-1, "IncorrectNonPrimitiveOpPrivateData: private data already set for NonPrimitiveOpId(%d)" % op_id)
+        self._pd[op_id] = np.asarray(sibling, dtype=np.uint32).reshape(8)
+
+    def run(self) -> ResidentTraces:
+        ids = np.array(list(self._pd.keys()), dtype=np.uint32)
+        self._inputs.private_data_op_ids = ids
+        self._inputs.private_data_siblings = (np.stack([self._pd[int(i)] for i in ids]) if len(ids)
+                                              else np.zeros((0, 8), np.uint32))
+        return self.prepared.run(self._inputs)
+
+
 # ----------------------------------------------------------------------------- recursion API
 @dataclass
 class FriRecursionConfig:
@@ -367,10 +546,12 @@ class ProveNextLayerParams:
 
 @dataclass
 class RecursionInput:
-    """What `prove_next_layer` proves: the traces of the verifier circuit run over `prev`.
-    (`prev` itself - a UniStark or BatchStark proof - is consumed by the Rust-side circuit runner.)"""
-    traces: Traces
+    """What `prove_next_layer` proves.  Either the inputs of the verifier circuit (public inputs +
+    the Merkle siblings `set_fri_private_data` extracts from `prev`, recursion.rs:455-476), in which
+    case the circuit is run on the device, or already-computed `Traces`."""
+    traces: Optional[Traces] = None
     prev_proof: Optional[BatchStarkProof] = None
+    circuit_inputs: Optional[CircuitInputs] = None
 
 
 @dataclass
@@ -386,13 +567,20 @@ class RecursionOutput:
 class NextLayerPrepCache:
     prover: BatchStarkProver
     circuit_prover_data: CircuitProverData
+    prepared_circuit: Optional[PreparedCircuit] = None
 
 
-def build_next_layer_prep(ctx: Context, circuit_prep: CircuitPrep, backend: FriRecursionBackend,
+def build_next_layer_prep(ctx: Context, circuit, backend: FriRecursionBackend,
                           params: ProveNextLayerParams) -> NextLayerPrepCache:
+    """recursion.rs:342-394.  `circuit` is a `Circuit` (preprocessed columns are derived here, as
+    get_airs_and_degrees_with_prep does) or an already-flattened `CircuitPrep`."""
     backend.non_primitive_provers(4)
-    cpd = CircuitProverData(ctx, circuit_prep, params.table_packing)
-    return NextLayerPrepCache(prover=BatchStarkProver(ctx, params.table_packing), circuit_prover_data=cpd)
+    prover = BatchStarkProver(ctx, params.table_packing)
+    if isinstance(circuit, Circuit):
+        pc = PreparedCircuit(ctx, circuit, params.table_packing)
+        return NextLayerPrepCache(prover=prover, circuit_prover_data=pc.circuit_prover_data, prepared_circuit=pc)
+    cpd = CircuitProverData(ctx, circuit, params.table_packing)
+    return NextLayerPrepCache(prover=prover, circuit_prover_data=cpd)
 
 
 def prove_next_layer(inp: RecursionInput, ctx: Context, backend: FriRecursionBackend, params: ProveNextLayerParams,
@@ -402,7 +590,13 @@ def prove_next_layer(inp: RecursionInput, ctx: Context, backend: FriRecursionBac
     computed; without it the preprocessed commitment is rebuilt first (recursion.rs:452-501)."""
     if prep is None:
         if circuit_prep is None:
-            raise ValueError("prove_next_layer needs either a NextLayerPrepCache or the CircuitPrep to build one")
+            raise ValueError("prove_next_layer needs either a NextLayerPrepCache or the circuit to build one")
         prep = build_next_layer_prep(ctx, circuit_prep, backend, params)
-    proof = prep.prover.prove_all_tables(inp.traces, prep.circuit_prover_data)
+    if inp.traces is not None:
+        traces = inp.traces
+    else:
+        if prep.prepared_circuit is None or inp.circuit_inputs is None:
+            raise ValueError("without Traces, prove_next_layer needs a prepared Circuit and its inputs")
+        traces = prep.prepared_circuit.run(inp.circuit_inputs)   # runner.run() (recursion.rs:478)
+    proof = prep.prover.prove_all_tables(traces, prep.circuit_prover_data)
     return RecursionOutput(proof=proof, circuit_prover_data=prep.circuit_prover_data)

@@ -1,7 +1,7 @@
 """Adapters from the synthetic-workload arrays (harness/synth.cpp) to the prover's input types."""
 import numpy as np
 
-from .prover import CircuitPrep, Traces
+from .prover import Circuit, CircuitInputs, CircuitPrep, Traces
 
 
 def traces_from_arrays(a) -> Traces:
@@ -35,3 +35,15 @@ def circuit_prep_from_arrays(a) -> CircuitPrep:
         p2_output_indices=a["p2_output_indices"].reshape(-1, 2),
         p2_mmcs_index_sum_idx=a["p2_mmcs_index_sum_idx"],
     )
+
+
+def circuit_from_arrays(a) -> Circuit:
+    return Circuit(witness_count=int(a["counts"][5]), ops=a["ops"].reshape(-1, 8), ext=a["ext"],
+                   public_rows=a["public_rows"], private_input_rows=a["private_rows"],
+                   witness_rewrite=a["rewrite"].reshape(-1, 2))
+
+
+def circuit_inputs_from_arrays(a) -> CircuitInputs:
+    return CircuitInputs(public_values=a["in_public_values"].reshape(-1, 4),
+                         private_values=a["in_private_values"].reshape(-1, 4),
+                         private_data_op_ids=a["pd_op_ids"], private_data_siblings=a["pd_siblings"].reshape(-1, 8))
