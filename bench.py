@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py - one JSON line for the driver (DESIGN.md "Measurement").
 
-A "step" is one `prove_all_tables` (the body of `prove_next_layer` after the verifier circuit has
-run) over the synthetic KoalaBear 2^20-row recursion layer of SURVEY.md section 8d, with the
-Traces and the cached preprocessed data (NextLayerPrepCache) already resident in HBM.  It covers
-K1-K3 trace building, main/permutation/quotient LDE + MMCS commits, LogUp, quotient evaluation,
-openings, FRI commit/fold/grind/queries and proof serialisation.
+A "step" is one `prove_next_layer` (recursion/src/recursion.rs:401-502 with a NextLayerPrepCache):
+the verifier circuit is RUN on the device (CircuitRunner::run, levelised) and its tables are proved
+(`prove_all_tables`), over the synthetic KoalaBear 2^20-row recursion layer of SURVEY.md section 8d,
+with the circuit inputs (public values, Merkle siblings) and the cached preprocessed data already
+resident in HBM.  It covers the witness fill, K1-K3 trace building, main/permutation/quotient
+LDE + MMCS commits, LogUp, quotient evaluation, openings, FRI commit/fold/grind/queries and proof
+serialisation.
 
 Multi-GPU: independent proofs (aggregation-tree nodes) shard one per rank with no data-path
 collective - weak scaling; only the barrier / max-over-ranks timing
@@ -91,18 +93,25 @@ def pmc_traffic_bytes(kernel):
 
 
 def cpu_baseline(field, log_h):
-    """The CPU oracle (kind 'port', single thread) proving the same table mix at a bounded size."""
+    """The CPU oracle (kind 'port', single thread): run the circuit, prove its tables, same table
+    mix at a bounded size."""
+    import circuit_lib
     import harness_lib
     import layer_lib
     import oracle_lib
     orc = oracle_lib.Oracle()
     arrs = harness_lib.generate(field, log_h, seed=1, **GEN_KNOBS)
     prm = layer_lib.params(**FRI)
-    L = layer_lib.OracleLayer(orc, field, arrs, prm)
+    oc = circuit_lib.OracleCircuit(orc, circuit_lib.Circuit.from_arrays(arrs)).preprocess(oracle_lib.MODULUS[field])
+    inputs = circuit_lib.Inputs.from_arrays(arrs)
+    t0 = time.perf_counter()
+    oc.run(field, inputs)
+    run_s = time.perf_counter() - t0
+    L = layer_lib.OracleLayer(orc, field, oc.workload_arrays(), prm)
     L.prep_commit()  # preprocessed commitment is cached in the reference too (NextLayerPrepCache)
     t0 = time.perf_counter()
     L.prove()
-    return time.perf_counter() - t0
+    return run_s + (time.perf_counter() - t0), run_s
 
 
 def main():
@@ -134,11 +143,11 @@ def main():
     ctx = p3r.Context(field=field, device=local_rank, **FRI)
     arrs = harness_lib.generate(field, log_h, seed=0x5EED0000 + rank, **GEN_KNOBS)
     packing = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
-    cache = p3r.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), p3r.FriRecursionBackend(),
+    cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(arrs), p3r.FriRecursionBackend(),
                                       p3r.ProveNextLayerParams(table_packing=packing))
-    cpd = cache.circuit_prover_data
-    resident = p3r.ResidentTraces(ctx, cpd, wl.traces_from_arrays(arrs))
-    counts = [int(x) for x in arrs["counts"]]
+    cpd, pc = cache.circuit_prover_data, cache.prepared_circuit
+    resident = pc.upload_inputs(wl.circuit_inputs_from_arrays(arrs))
+    counts = [int(x) for x in arrs["counts"]] + [len(arrs["ops"]) // 8]
     del arrs
 
     def barrier():
@@ -150,11 +159,11 @@ def main():
     proof_len = 0
     last_proof = b""
     for _ in range(args.warmup):
-        proof_len = len(cache.prover.prove_all_tables(resident, cpd).proof)
+        proof_len = len(pc.prove(resident))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        last_proof = cache.prover.prove_all_tables(resident, cpd).proof
+        last_proof = pc.prove(resident)
         proof_len = len(last_proof)
     barrier()
     dt = time.perf_counter() - t0
@@ -177,7 +186,7 @@ def main():
     prof_steps = 2
     ctx.profile_enable(True)
     for _ in range(prof_steps):
-        cache.prover.prove_all_tables(resident, cpd)
+        pc.prove(resident)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
 
@@ -214,11 +223,13 @@ def main():
             "dtype": "u32 (31-bit Montgomery prime field, degree-4 extension)",
             "data": "synthetic",
             "config": {
-                "workload": f"prove_all_tables (prove_next_layer after the verifier-circuit run) of the synthetic "
+                "workload": f"prove_next_layer (verifier-circuit run on the device + prove_all_tables) of the synthetic "
                             f"{field} 2^{log_h}-row recursion layer: tables const/public/alu/poseidon2/recompose, "
-                            f"FRI blowup 4, arity<=4, 54 queries, 15-bit PoW; Traces + NextLayerPrepCache resident in HBM",
+                            f"FRI blowup 4, arity<=4, 54 queries, 15-bit PoW; circuit inputs + NextLayerPrepCache "
+                            f"resident in HBM",
+                "circuit_levels": pc.levels,
                 "field": field, "log_height": log_h, "table_heights": cpd.table_heights, "table_widths": widths,
-                "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose", "witnesses"], counts)),
+                "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose", "witnesses", "circuit_ops"], counts)),
                 "fri": FRI, "independent_proofs": world, "proof_bytes": proof_len,
                 "parallelism": f"{world} independent proofs, one per GPU, no data-path collective",
             },
@@ -257,15 +268,16 @@ def main():
                                      "perms_per_step_in_kernel": hash_perms}
         if not args.no_cpu_baseline and world == 1:
             lh = args.cpu_baseline_log_height
-            cdt = cpu_baseline(field, lh)
+            cdt, crun = cpu_baseline(field, lh)
             line["cpu_baseline"] = {
                 "value": cdt * 1e3, "unit": "ms", "cores": 1, "kind": "port",
-                "sample": f"same prove (same table mix, same FRI parameters) at 2^{lh} rows = 1/{1 << (log_h - lh)} "
-                          f"of the workload, oracle/ C++ restatement, 1 thread",
+                "sample": f"same prove_next_layer (circuit run + prove, same table mix, same FRI parameters) at 2^{lh} "
+                          f"rows = 1/{1 << (log_h - lh)} of the workload, oracle/ C++ restatement, 1 thread",
+                "circuit_run_ms": crun * 1e3,
             }
         print(json.dumps(line))
     resident.free()
-    cpd.free()
+    pc.free()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -363,6 +363,15 @@ p3r_dtraces* p3r_circuit_run(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r
 int p3r_prove_next_layer(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs,
                          uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
 
+/* Inputs made resident in HBM once (set_public_inputs / set_private_inputs / set_private_data with
+ * their checks, runner.rs:83-176); a run or a prove can then be repeated without PCIe. */
+typedef struct p3r_dinputs p3r_dinputs;
+p3r_dinputs* p3r_circuit_inputs_upload(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs);
+void p3r_circuit_inputs_free(p3r_ctx* ctx, p3r_dinputs* inputs);
+p3r_dtraces* p3r_circuit_run_resident(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_dinputs* inputs);
+int p3r_prove_next_layer_resident(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_dinputs* inputs,
+                                  uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
+
 /* Read back one array of device-resident Traces (canonical), for parity tests / inspection. */
 enum p3r_traces_array {
   P3R_TRACES_CONST_VALUES = 0,    /* n_const x 4 */

@@ -159,6 +159,11 @@ SIGNATURES = {
     "p3r_circuit_run": (vp, [vp, vp, C.POINTER(P3rCircuitInputs)]),
     "p3r_prove_next_layer": (C.c_int, [vp, vp, C.POINTER(P3rCircuitInputs), C.c_uint32, C.POINTER(C.c_uint8),
                                        C.c_size_t, C.POINTER(C.c_size_t)]),
+    "p3r_circuit_inputs_upload": (vp, [vp, vp, C.POINTER(P3rCircuitInputs)]),
+    "p3r_circuit_inputs_free": (None, [vp, vp]),
+    "p3r_circuit_run_resident": (vp, [vp, vp, vp]),
+    "p3r_prove_next_layer_resident": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t,
+                                                C.POINTER(C.c_size_t)]),
     "p3r_dtraces_get": (C.c_int, [vp, vp, vp, C.c_uint32, u32p, C.c_size_t]),
     "p3r_traces_upload": (vp, [vp, vp, C.POINTER(P3rTraces)]),
     "p3r_traces_free": (None, [vp, vp]),

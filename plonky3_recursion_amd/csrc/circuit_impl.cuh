@@ -271,6 +271,17 @@ struct RunSchedule {
   std::vector<uint8_t> p2_row_merkle;
   std::string deferred_error;               // what run() reports for a circuit that cannot complete
   size_t levels = 0;
+  // launches: a wide level each, or a run of consecutive narrow levels [l0, l1) in one workgroup
+  struct Segment { uint32_t l0, l1; bool narrow; uint32_t chunk_begin, n_chunks; };
+  std::vector<Segment> segments;
+  std::vector<uint32_t> chunk_bounds;       // per narrow segment: n_chunks + 1 level boundaries
+  // Horner chains: runs of consecutive HornerAcc ops threaded through the accumulator with one
+  // shared multiplier b are an affine recurrence acc <- acc*b + (c - a); each run is ONE scan
+  // (k_run_chains) at one level instead of one level per step.
+  struct ChainSeg { uint32_t first, n, acc_w, b_w; };
+  std::vector<RunOp> chain_ops;             // steps of all chains, chain by chain
+  std::vector<ChainSeg> chains;             // sorted by level
+  std::vector<uint32_t> chain_off;          // per level
 };
 
 inline RunSchedule build_schedule(const HostCircuit& c) {
@@ -288,6 +299,9 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
   };
   struct Tmp { uint32_t level; bool is_p2; uint32_t idx; };
   std::vector<Tmp> order;
+  struct OpenChain { uint32_t level, first, n, acc_w, b_w, last_out; size_t last_op; };
+  std::vector<OpenChain> chains;     // closed + (last one possibly) open
+  bool chain_open = false;
   std::vector<RunOp> light;
   std::vector<RunP2> p2;
   uint32_t n_alu = 0, n_rec = 0, n_pub = 0;
@@ -353,11 +367,34 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
         else if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
         r.rec = n_alu++;
         break;
-      case P3R_OP_ALU_HORNER_ACC:
+      case P3R_OP_ALU_HORNER_ACC: {
+        const bool ready = set[op.aux] && set[op.a] && set[op.b] && set[op.c] && !set[op.out] &&
+                           op.out != op.a && op.out != op.b && op.out != op.c && op.out != op.aux;
+        if (ready) {
+          r.rec = n_alu++;
+          // extend the open chain when this step continues it and its operands are ready in time
+          if (chain_open) {
+            OpenChain& ch = chains.back();
+            if (ch.last_op + 1 == i && op.aux == ch.last_out && op.b == ch.b_w &&
+                std::max(wlevel[op.a], wlevel[op.c]) < ch.level) {
+              ch.n++; ch.last_out = op.out; ch.last_op = i;
+              S.chain_ops.push_back(r);
+              set[op.out] = 1; wlevel[op.out] = ch.level;
+              continue;
+            }
+          }
+          const uint32_t l = 1 + std::max(std::max(wlevel[op.aux], wlevel[op.b]), std::max(wlevel[op.a], wlevel[op.c]));
+          chains.push_back({l, (uint32_t)S.chain_ops.size(), 1, op.aux, op.b, op.out, i});
+          chain_open = true;
+          S.chain_ops.push_back(r);
+          set[op.out] = 1; wlevel[op.out] = l;
+          continue;
+        }
         need(op.aux); need(op.a); need(op.b); need(op.c);
         if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
         r.rec = n_alu++;
         break;
+      }
       case P3R_OP_HINT_EXT_DECOMPOSITION: case P3R_OP_HINT_BINARY_DECOMPOSITION:
         need(op.a);
         r.ext_off = (uint32_t)S.dev_ext.size();
@@ -419,6 +456,7 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
   // ALU-dedup leftovers (runner.rs:199-216)
   uint32_t max_level = 0;
   for (auto& t : order) max_level = std::max(max_level, t.level);
+  for (auto& ch : chains) max_level = std::max(max_level, ch.level);
   for (size_t k = 0; k + 1 < c.rewrite.size(); k += 2) {
     const uint32_t dup = c.rewrite[k];
     uint32_t cur = c.rewrite[k + 1];
@@ -448,6 +486,38 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
     else S.light[lp[t.level]++] = light[t.idx];
   }
   (void)n_pub;
+  S.chain_off.assign(max_level + 2, 0);
+  for (auto& ch : chains) S.chain_off[ch.level + 1]++;
+  for (size_t l = 1; l < S.chain_off.size(); ++l) S.chain_off[l] += S.chain_off[l - 1];
+  S.chains.resize(chains.size());
+  {
+    std::vector<uint32_t> cp(S.chain_off.begin(), S.chain_off.end() - 1);
+    for (auto& ch : chains) S.chains[cp[ch.level]++] = {ch.first, ch.n, ch.acc_w, ch.b_w};
+  }
+  for (uint32_t l = 1; l <= max_level; ++l) {
+    const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2_off[l + 1] - S.p2_off[l];
+    const uint32_t nc = S.chain_off[l + 1] - S.chain_off[l];
+    if (!nl && !np && !nc) continue;
+    const bool narrow = nl <= 1024 && np <= 64 && !nc;
+    if (narrow && !S.segments.empty() && S.segments.back().narrow && S.segments.back().l1 == l) S.segments.back().l1 = l + 1;
+    else S.segments.push_back({l, l + 1, narrow, 0, 0});
+  }
+  for (auto& seg : S.segments) {
+    if (!seg.narrow) continue;
+    seg.chunk_begin = (uint32_t)S.chunk_bounds.size();
+    uint32_t start = seg.l0;
+    S.chunk_bounds.push_back(start);
+    for (uint32_t l = seg.l0; l < seg.l1; ++l) {
+      // records of levels [start, l + 1) must fit the LDS staging buffers (kNarrowLightCap / kNarrowP2Cap)
+      if (S.light_off[l + 1] - S.light_off[start] > 1400 || S.p2_off[l + 1] - S.p2_off[start] > 128) {
+        S.chunk_bounds.push_back(l);
+        start = l;
+        seg.n_chunks++;
+      }
+    }
+    S.chunk_bounds.push_back(seg.l1);
+    seg.n_chunks++;
+  }
   return S;
 }
 
@@ -477,131 +547,147 @@ __device__ __forceinline__ void w_put(uint32_t* __restrict__ w, uint32_t id, con
   }
 }
 
-// One level of the schedule: blocks [0, light_blocks) run one ALU / hint / recompose / const op per
-// lane, the remaining blocks one Poseidon2 permutation per 16 lanes.
+struct RunArgs {
+  const RunOp* light;   // sorted by level
+  const RunP2* p2;
+  uint32_t* w;          // witness table, [witness_count][4] Montgomery
+  const uint32_t* ext;
+  uint32_t* alu_values;
+  uint32_t* rec_values;
+  uint32_t* p2_inputs;
+  size_t p2_h;
+  uint8_t* p2_flags;
+  uint32_t* p2_seed;
+  uint32_t* p2_out;     // permutation outputs by row (chain state)
+  const int32_t* pd_slot;
+  const uint32_t* siblings;
+  const uint32_t* rc;
+  const uint32_t* diag;
+  uint32_t* err;
+  const uint32_t* light_off;  // per level, device copies of the schedule offsets
+  const uint32_t* p2_off;
+};
+
+// One ALU / hint / recompose / const op.
 template <class PP>
-__global__ void __launch_bounds__(kBlock)
-k_run_level(const RunOp* __restrict__ light, uint32_t n_light, uint32_t light_blocks,
-            const RunP2* __restrict__ p2, uint32_t n_p2, uint32_t* __restrict__ w,
-            const uint32_t* __restrict__ ext, uint32_t* __restrict__ alu_values, uint32_t* __restrict__ rec_values,
-            uint32_t* __restrict__ p2_inputs, size_t p2_h, uint8_t* __restrict__ p2_flags, uint32_t* __restrict__ p2_seed,
-            uint32_t* __restrict__ p2_out, const int32_t* __restrict__ pd_slot, const uint32_t* __restrict__ siblings,
-            const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag, uint32_t* __restrict__ err) {
+__device__ __forceinline__ void run_light_op(const RunArgs& A, const RunOp& op) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
-  if (blockIdx.x < light_blocks) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_light) return;
-    const RunOp op = light[i];
-    const uint32_t kind = op.kind_flags & 0xFF;
-    const bool chk_out = op.kind_flags & RUN_CHECK_OUT;
-    auto record = [&](const E& a, const E& b, const E& c, const E& o) {  // AluOpRecord (runner.rs:317-453)
-      uint4* dst = reinterpret_cast<uint4*>(alu_values + (size_t)op.rec * 16);
-      dst[0] = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
-      dst[1] = make_uint4(b.c[0].v, b.c[1].v, b.c[2].v, b.c[3].v);
-      dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
-      dst[3] = make_uint4(o.c[0].v, o.c[1].v, o.c[2].v, o.c[3].v);
-    };
-    switch (kind) {
-      case P3R_OP_CONST: {
-        E v;
-        for (int k = 0; k < 4; ++k) v.c[k] = F::raw(ext[op.ext_off + k]);  // stored in Montgomery form
-        w_put<PP>(w, op.out, v, chk_out, err, op.op_idx);
-        break;
-      }
-      case P3R_OP_ALU_ADD: case P3R_OP_ALU_MUL: {
-        const E a = w_load<PP>(w, op.a);
-        E b, o;
-        if (op.kind_flags & RUN_BACKWARD) {
-          o = w_load<PP>(w, op.out);
-          if (kind == P3R_OP_ALU_ADD) b = o - a;
-          else {
-            if (a == E::zero()) { run_error(err, op.op_idx, RUN_ERR_DIV0); b = E::zero(); }
-            else b = o * a.inv();
-          }
-          w_store<PP>(w, op.b, b);
-        } else {
-          b = w_load<PP>(w, op.b);
-          o = kind == P3R_OP_ALU_ADD ? a + b : a * b;
-          w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
-        }
-        record(a, b, E::zero(), o);
-        break;
-      }
-      case P3R_OP_ALU_BOOL_CHECK: {
-        const E a = w_load<PP>(w, op.a);
-        w_put<PP>(w, op.out, a, chk_out, err, op.op_idx);
-        record(a, E::zero(), a, a);
-        break;
-      }
-      case P3R_OP_ALU_MUL_ADD: {
-        const E a = w_load<PP>(w, op.a), b = w_load<PP>(w, op.b), ab = a * b;
-        if (op.aux != kNoW) w_put<PP>(w, op.aux, ab, op.kind_flags & RUN_CHECK_AUX, err, op.op_idx);
-        const E c = op.c != kNoW ? (op.c == op.aux ? ab : w_load<PP>(w, op.c)) : E::zero();
-        const E o = ab + c;
-        if (op.aux != kNoW && op.out == op.aux) { if (!(o == ab)) run_error(err, op.op_idx, RUN_ERR_CONFLICT); }
-        else w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
-        record(a, b, c, o);
-        break;
-      }
-      case P3R_OP_ALU_HORNER_ACC: {
-        const E acc = w_load<PP>(w, op.aux), a = w_load<PP>(w, op.a), b = w_load<PP>(w, op.b), c = w_load<PP>(w, op.c);
-        const E o = acc * b + c - a;
-        w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
-        record(a, b, c, o);
-        break;
-      }
-      case P3R_OP_HINT_EXT_DECOMPOSITION: {
-        const E v = w_load<PP>(w, op.a);
-        for (int k = 0; k < 4; ++k) {
-          const uint32_t t = ext[op.ext_off + k];
-          w_put<PP>(w, t & ~RUN_CHECK_BIT, E::from_base(v.c[k]), t & RUN_CHECK_BIT, err, op.op_idx);
-        }
-        break;
-      }
-      case P3R_OP_HINT_BINARY_DECOMPOSITION: {
-        const E v = w_load<PP>(w, op.a);
-        const uint32_t n_out = (op.kind_flags >> 16) & 0xFF;
-        uint32_t o = 0;
-        for (int k = 0; k < 4 && o < n_out; ++k) {
-          const uint32_t val = v.c[k].to_canonical();
-          for (int bit = 0; bit < 31 && o < n_out; ++bit, ++o) {
-            const uint32_t t = ext[op.ext_off + o];
-            const E e = ((val >> bit) & 1) ? E::one() : E::zero();
-            w_put<PP>(w, t & ~RUN_CHECK_BIT, e, t & RUN_CHECK_BIT, err, op.op_idx);
-          }
-        }
-        break;
-      }
-      case P3R_OP_RECOMPOSE: {
-        E v;
-        for (int k = 0; k < 4; ++k) {
-          v.c[k] = w_load<PP>(w, ext[op.ext_off + k]).c[0];
-          rec_values[(size_t)op.rec * 4 + k] = v.c[k].v;
-        }
-        w_put<PP>(w, op.out, v, chk_out, err, op.op_idx);
-        break;
-      }
-      default: break;
+  uint32_t* __restrict__ w = A.w;
+  const uint32_t* __restrict__ ext = A.ext;
+  uint32_t* err = A.err;
+  const uint32_t kind = op.kind_flags & 0xFF;
+  const bool chk_out = op.kind_flags & RUN_CHECK_OUT;
+  auto record = [&](const E& a, const E& b, const E& c, const E& o) {  // AluOpRecord (runner.rs:317-453)
+    uint4* dst = reinterpret_cast<uint4*>(A.alu_values + (size_t)op.rec * 16);
+    dst[0] = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
+    dst[1] = make_uint4(b.c[0].v, b.c[1].v, b.c[2].v, b.c[3].v);
+    dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
+    dst[3] = make_uint4(o.c[0].v, o.c[1].v, o.c[2].v, o.c[3].v);
+  };
+  switch (kind) {
+    case P3R_OP_CONST: {
+      E v;
+      for (int k = 0; k < 4; ++k) v.c[k] = F::raw(ext[op.ext_off + k]);  // stored in Montgomery form
+      w_put<PP>(w, op.out, v, chk_out, err, op.op_idx);
+      break;
     }
-    return;
+    case P3R_OP_ALU_ADD: case P3R_OP_ALU_MUL: {
+      const E a = w_load<PP>(w, op.a);
+      E b, o;
+      if (op.kind_flags & RUN_BACKWARD) {
+        o = w_load<PP>(w, op.out);
+        if (kind == P3R_OP_ALU_ADD) b = o - a;
+        else {
+          if (a == E::zero()) { run_error(err, op.op_idx, RUN_ERR_DIV0); b = E::zero(); }
+          else b = o * a.inv();
+        }
+        w_store<PP>(w, op.b, b);
+      } else {
+        b = w_load<PP>(w, op.b);
+        o = kind == P3R_OP_ALU_ADD ? a + b : a * b;
+        w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+      }
+      record(a, b, E::zero(), o);
+      break;
+    }
+    case P3R_OP_ALU_BOOL_CHECK: {
+      const E a = w_load<PP>(w, op.a);
+      w_put<PP>(w, op.out, a, chk_out, err, op.op_idx);
+      record(a, E::zero(), a, a);
+      break;
+    }
+    case P3R_OP_ALU_MUL_ADD: {
+      const E a = w_load<PP>(w, op.a), b = w_load<PP>(w, op.b), ab = a * b;
+      if (op.aux != kNoW) w_put<PP>(w, op.aux, ab, op.kind_flags & RUN_CHECK_AUX, err, op.op_idx);
+      const E c = op.c != kNoW ? (op.c == op.aux ? ab : w_load<PP>(w, op.c)) : E::zero();
+      const E o = ab + c;
+      if (op.aux != kNoW && op.out == op.aux) { if (!(o == ab)) run_error(err, op.op_idx, RUN_ERR_CONFLICT); }
+      else w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+      record(a, b, c, o);
+      break;
+    }
+    case P3R_OP_ALU_HORNER_ACC: {
+      const E acc = w_load<PP>(w, op.aux), a = w_load<PP>(w, op.a), b = w_load<PP>(w, op.b), c = w_load<PP>(w, op.c);
+      const E o = acc * b + c - a;
+      w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+      record(a, b, c, o);
+      break;
+    }
+    case P3R_OP_HINT_EXT_DECOMPOSITION: {
+      const E v = w_load<PP>(w, op.a);
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t t = ext[op.ext_off + k];
+        w_put<PP>(w, t & ~RUN_CHECK_BIT, E::from_base(v.c[k]), t & RUN_CHECK_BIT, err, op.op_idx);
+      }
+      break;
+    }
+    case P3R_OP_HINT_BINARY_DECOMPOSITION: {
+      const E v = w_load<PP>(w, op.a);
+      const uint32_t n_out = (op.kind_flags >> 16) & 0xFF;
+      uint32_t o = 0;
+      for (int k = 0; k < 4 && o < n_out; ++k) {
+        const uint32_t val = v.c[k].to_canonical();
+        for (int bit = 0; bit < 31 && o < n_out; ++bit, ++o) {
+          const uint32_t t = ext[op.ext_off + o];
+          const E e = ((val >> bit) & 1) ? E::one() : E::zero();
+          w_put<PP>(w, t & ~RUN_CHECK_BIT, e, t & RUN_CHECK_BIT, err, op.op_idx);
+        }
+      }
+      break;
+    }
+    case P3R_OP_RECOMPOSE: {
+      E v;
+      for (int k = 0; k < 4; ++k) {
+        v.c[k] = w_load<PP>(w, ext[op.ext_off + k]).c[0];
+        A.rec_values[(size_t)op.rec * 4 + k] = v.c[k].v;
+      }
+      w_put<PP>(w, op.out, v, chk_out, err, op.op_idx);
+      break;
+    }
+    default: break;
   }
-  // ---- Poseidon2 permutations: lane j of a 16-lane group owns state element j (limb j/4, coeff j%4)
-  const uint32_t g = (blockIdx.x - light_blocks) * kBlock + threadIdx.x;
-  const uint32_t i = g >> 4;
-  const int j = (int)(g & 15);
-  const bool live = i < n_p2;
+}
+
+// One Poseidon2 permutation: lane j of a 16-lane group owns state element j (limb j/4, coeff j%4).
+// Whole waves must call this together (DPP inside coop_permute); `live` masks the tail.
+template <class PP>
+__device__ __forceinline__ void run_p2_op(const RunArgs& A, const RunP2* src, int j, bool live) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  uint32_t* __restrict__ w = A.w;
+  uint32_t* err = A.err;
   F s = F::zero();
   RunP2 q{};
   bool bit = false;
   if (live) {
-    q = p2[i];
+    q = *src;
     const bool new_start = q.flags & 1, merkle = q.flags & 2;
     // init_chain_state (executor.rs:103-139): Merkle rows carry the rate limbs only
-    if (!new_start && (!merkle || j < 8)) s = F::raw(p2_out[(size_t)q.prev_row * 16 + j]);
+    if (!new_start && (!merkle || j < 8)) s = F::raw(A.p2_out[(size_t)q.prev_row * 16 + j]);
     // fill_sibling_data (:166-201): private sibling in the capacity limbs
-    const int32_t slot = pd_slot[q.row];
-    if (merkle && slot >= 0 && j >= 8) s = F::raw(siblings[(size_t)slot * 8 + (j - 8)]);
+    const int32_t slot = A.pd_slot[q.row];
+    if (merkle && slot >= 0 && j >= 8) s = F::raw(A.siblings[(size_t)slot * 8 + (j - 8)]);
     // apply_witness_values (:207-219)
     const uint32_t in_w = q.in[j >> 2];
     if (in_w != kNoW) s = F::raw(w[(size_t)in_w * 4 + (j & 3)]);
@@ -619,29 +705,135 @@ k_run_level(const RunOp* __restrict__ light, uint32_t n_light, uint32_t light_bl
   }
   if (live) {
     // Poseidon2CircuitRow (build_trace_row :364-417, trace.rs:188-233)
-    p2_inputs[(size_t)j * p2_h + q.row] = s.v;
+    A.p2_inputs[(size_t)j * A.p2_h + q.row] = s.v;
     if (j == 0) {
-      p2_flags[q.row] = q.flags & 1;
-      p2_flags[p2_h + q.row] = (q.flags >> 1) & 1;
-      p2_flags[2 * p2_h + q.row] = bit;
+      A.p2_flags[q.row] = q.flags & 1;
+      A.p2_flags[A.p2_h + q.row] = (q.flags >> 1) & 1;
+      A.p2_flags[2 * A.p2_h + q.row] = bit;
       uint32_t seed = 0;
       if (q.idx_w != kNoW) {
         const E v = w_load<PP>(w, q.idx_w);
         if (v.c[1].v | v.c[2].v | v.c[3].v) run_error(err, q.op_idx, RUN_ERR_INDEX_SUM);
         seed = v.c[0].v;
       }
-      p2_seed[q.row] = seed;
+      A.p2_seed[q.row] = seed;
     }
   }
-  s = coop_permute<PP>(s, j, F::raw(diag[j]), rc);
+  s = coop_permute<PP>(s, j, F::raw(A.diag[j]), A.rc);
   if (live) {
-    p2_out[(size_t)q.row * 16 + j] = s.v;
+    A.p2_out[(size_t)q.row * 16 + j] = s.v;
     const uint32_t n_out = (q.flags >> 8) & 7;
     const uint32_t l = (uint32_t)j >> 2;
     if (l < n_out && q.out[l] != kNoW) {
       uint32_t* slot = w + (size_t)q.out[l] * 4 + (j & 3);
       if (q.flags & (1u << (4 + l))) { if (*slot != s.v) run_error(err, q.op_idx, RUN_ERR_CONFLICT); }
       else *slot = s.v;
+    }
+  }
+}
+
+// One WIDE level of the schedule: blocks [0, light_blocks) run one light op per lane, the
+// remaining blocks one Poseidon2 permutation per 16 lanes.
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_run_level(RunArgs A, uint32_t light_begin, uint32_t n_light, uint32_t light_blocks, uint32_t p2_begin, uint32_t n_p2) {
+  if (blockIdx.x < light_blocks) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_light) run_light_op<PP>(A, A.light[light_begin + i]);
+    return;
+  }
+  const uint32_t g = (blockIdx.x - light_blocks) * kBlock + threadIdx.x;
+  run_p2_op<PP>(A, A.p2 + p2_begin + (g >> 4), (int)(g & 15), (g >> 4) < n_p2);
+}
+
+// Horner chains of one level: one WAVE per chain evaluates acc_j = acc_{j-1}*b + (c_j - a_j) as an
+// affine scan - every lane folds its slice locally, the slice maps (b^len, value) are combined
+// with a shuffle scan across the wave, then every lane replays its slice from its incoming
+// accumulator, writing the outputs and the AluOpRecords (runner.rs:430-453).
+constexpr int kChainBlock = 256;  // four chains per workgroup
+template <class PP>
+__global__ void __launch_bounds__(kChainBlock)
+k_run_chains(RunArgs A, const RunOp* __restrict__ steps, const RunSchedule::ChainSeg* __restrict__ segs, uint32_t n_segs) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const uint32_t chain = blockIdx.x * (kChainBlock / 64) + (threadIdx.x >> 6);
+  if (chain >= n_segs) return;  // whole waves leave together
+  const RunSchedule::ChainSeg seg = segs[chain];
+  const uint32_t t = threadIdx.x & 63;
+  uint32_t* __restrict__ w = A.w;
+  const E b = w_load<PP>(w, seg.b_w);
+  const uint32_t per = (seg.n + 63) / 64;
+  const uint32_t i0 = min(t * per, seg.n), i1 = min(i0 + per, seg.n);
+  // local fold from a zero accumulator: value V, multiplier M = b^(i1 - i0)
+  E M = E::one(), V = E::zero();
+  for (uint32_t i = i0; i < i1; ++i) {
+    const RunOp op = steps[seg.first + i];
+    V = V * b + w_load<PP>(w, op.c) - w_load<PP>(w, op.a);
+    M = M * b;
+  }
+  auto up = [&](const E& e, int d) { E r; for (int k = 0; k < 4; ++k) r.c[k] = F::raw(__shfl_up(e.c[k].v, d)); return r; };
+  // inclusive scan of the maps x -> x*M + V (composition: the earlier slice is applied first)
+  for (int d = 1; d < 64; d <<= 1) {
+    const E pm = up(M, d), pv = up(V, d);
+    if ((int)t >= d) {
+      V = pv * M + V;
+      M = pm * M;
+    }
+  }
+  // incoming accumulator of this slice = (maps of all earlier slices)(acc0)
+  E acc = w_load<PP>(w, seg.acc_w);
+  {
+    const E pm = up(M, 1), pv = up(V, 1);
+    if (t > 0) acc = acc * pm + pv;
+  }
+  for (uint32_t i = i0; i < i1; ++i) {
+    const RunOp op = steps[seg.first + i];
+    const E a = w_load<PP>(w, op.a), c = w_load<PP>(w, op.c);
+    acc = acc * b + c - a;
+    w_store<PP>(w, op.out, acc);
+    uint4* dst = reinterpret_cast<uint4*>(A.alu_values + (size_t)op.rec * 16);
+    dst[0] = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
+    dst[1] = make_uint4(b.c[0].v, b.c[1].v, b.c[2].v, b.c[3].v);
+    dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
+    dst[3] = make_uint4(acc.c[0].v, acc.c[1].v, acc.c[2].v, acc.c[3].v);
+  }
+}
+
+// Runs of NARROW levels (each at most kNarrowBlock light ops and kNarrowBlock/16 permutations)
+// inside ONE workgroup: the level barrier is a __syncthreads() instead of a kernel boundary.
+// All waves of a workgroup share the CU's vector L1, so workgroup-scope ordering is enough for
+// the witness table and the chain state to be seen by the next level.  The op records of a
+// chunk of levels (they are contiguous: the schedule is sorted by level) are staged in LDS by
+// one coalesced copy, so a level does not start with a cold HBM read of its own ops.
+constexpr int kNarrowBlock = 1024;
+constexpr uint32_t kNarrowLightCap = 1400, kNarrowP2Cap = 128;  // records per chunk (63 KB of LDS)
+template <class PP>
+__global__ void __launch_bounds__(kNarrowBlock)
+k_run_levels_narrow(RunArgs A, const uint32_t* __restrict__ chunk_bounds, uint32_t n_chunks) {
+  __shared__ RunOp s_light[kNarrowLightCap];
+  __shared__ RunP2 s_p2[kNarrowP2Cap];
+  const uint32_t t = threadIdx.x;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const uint32_t l0 = chunk_bounds[c], l1 = chunk_bounds[c + 1];
+    const uint32_t lb0 = A.light_off[l0], pb0 = A.p2_off[l0];
+    {
+      const uint32_t nw = (A.light_off[l1] - lb0) * (uint32_t)(sizeof(RunOp) / 4);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(A.light + lb0);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(s_light);
+      for (uint32_t i = t; i < nw; i += kNarrowBlock) dst[i] = src[i];
+      const uint32_t np_w = (A.p2_off[l1] - pb0) * (uint32_t)(sizeof(RunP2) / 4);
+      const uint32_t* psrc = reinterpret_cast<const uint32_t*>(A.p2 + pb0);
+      uint32_t* pdst = reinterpret_cast<uint32_t*>(s_p2);
+      for (uint32_t i = t; i < np_w; i += kNarrowBlock) pdst[i] = psrc[i];
+    }
+    __syncthreads();
+    for (uint32_t l = l0; l < l1; ++l) {
+      const uint32_t lb = A.light_off[l], nl = A.light_off[l + 1] - lb;
+      const uint32_t pb = A.p2_off[l], np = A.p2_off[l + 1] - pb;
+      if (t < nl) run_light_op<PP>(A, s_light[lb - lb0 + t]);
+      // whole waves enter together; waves with no live group skip the permutation
+      if ((t & ~63u) < np * 16) run_p2_op<PP>(A, s_p2 + (pb - pb0) + (t >> 4), (int)(t & 15), (t >> 4) < np);
+      __syncthreads();
     }
   }
 }
@@ -681,6 +873,12 @@ struct p3r_circuit {
   p3r_layer_desc_counts counts{};
   std::unique_ptr<p3r_layer> layer;
   p3r::DevBuf d_light, d_p2, d_ext, d_const_values, d_public_rows, d_private_rows, d_public_out, d_rewrite;
+  p3r::DevBuf d_light_off, d_p2_off, d_chunk_bounds, d_chain_ops, d_chains;
+};
+
+// Inputs of one run made resident in HBM (public / private values, Merkle siblings).
+struct p3r_dinputs {
+  p3r::DevBuf pub, priv, sib, slot;
 };
 
 namespace {
@@ -743,6 +941,11 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   up(C->d_private_rows, h.private_rows.data(), h.private_rows.size() * 4);
   up(C->d_public_out, S.public_out.data(), S.public_out.size() * 4);
   up(C->d_rewrite, S.rewrite_pairs.data(), S.rewrite_pairs.size() * 4);
+  up(C->d_light_off, S.light_off.data(), S.light_off.size() * 4);
+  up(C->d_p2_off, S.p2_off.data(), S.p2_off.size() * 4);
+  up(C->d_chunk_bounds, S.chunk_bounds.data(), S.chunk_bounds.size() * 4);
+  up(C->d_chain_ops, S.chain_ops.data(), S.chain_ops.size() * sizeof(RunOp));
+  up(C->d_chains, S.chains.data(), S.chains.size() * sizeof(RunSchedule::ChainSeg));
   return C;
 }
 
@@ -756,17 +959,13 @@ inline const char* run_error_text(uint32_t code) {
   }
 }
 
-// CircuitRunner::run: returns the Traces (HBM-resident) of one execution.
+// set_public_inputs / set_private_inputs / set_private_data (runner.rs:83-176): validate, upload.
 template <class PP>
-std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, const p3r_circuit_inputs* in,
-                                         DevBuf* witness_out = nullptr) {
+std::unique_ptr<p3r_dinputs> circuit_inputs_upload(p3r_ctx* ctx, const p3r_circuit* C, const p3r_circuit_inputs* in) {
   const HostCircuit& h = C->host;
   const RunSchedule& S = C->sched;
-  const p3r_layer* L = C->layer.get();
-  if (!S.deferred_error.empty()) fail(P3R_EINVAL, "%s", S.deferred_error.c_str());
   if (h.public_rows.size() && !in->public_values) fail(P3R_EINVAL, "PublicInputLengthMismatch: public_values is NULL");
   if (h.private_rows.size() && !in->private_values) fail(P3R_EINVAL, "PrivateInputLengthMismatch: private_values is NULL");
-  // set_private_data (runner.rs:124-176)
   const size_t n_p2 = C->counts.n_p2;
   std::vector<int32_t> pd_slot(std::max<size_t>(n_p2, 1), -1);
   for (size_t k = 0; k < in->n_private_data; ++k) {
@@ -779,18 +978,31 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
       fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data provided for non-Merkle operation NonPrimitiveOpId(%u)", id);
     pd_slot[row] = (int32_t)k;
   }
+  auto D = std::make_unique<p3r_dinputs>();
+  D->pub = upload_mont<PP>(ctx, in->public_values, h.public_rows.size() * 4, "public_values");
+  D->priv = upload_mont<PP>(ctx, in->private_values, h.private_rows.size() * 4, "private_values");
+  D->sib = upload_mont<PP>(ctx, in->private_data_siblings, in->n_private_data * 8, "private_data_siblings");
+  D->slot.alloc(pd_slot.size());
+  P3R_HIP(copy_sync(ctx->stream, D->slot.p, pd_slot.data(), pd_slot.size() * 4, hipMemcpyHostToDevice));
+  return D;
+}
+
+// CircuitRunner::run: returns the Traces (HBM-resident) of one execution.
+template <class PP>
+std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, const p3r_dinputs* in) {
+  const HostCircuit& h = C->host;
+  const RunSchedule& S = C->sched;
+  const p3r_layer* L = C->layer.get();
+  if (!S.deferred_error.empty()) fail(P3R_EINVAL, "%s", S.deferred_error.c_str());
+  const size_t n_p2 = C->counts.n_p2;
   prof_stage(ctx, "run_circuit");
   auto T = std::make_unique<p3r_dtraces>();
   const auto& cn = C->counts;
   T->n_const = cn.n_const; T->n_public = cn.n_public; T->n_alu = cn.n_alu; T->n_recompose = cn.n_recompose;
   DevBuf w((size_t)std::max<uint32_t>(h.witness_count, 1) * 4);
-  DevBuf err(1), d_pub, d_priv, d_sib, d_slot, p2_out(std::max<size_t>(n_p2, 1) * 16);
+  DevBuf err(1), p2_out(std::max<size_t>(n_p2, 1) * 16);
+  const DevBuf &d_pub = in->pub, &d_priv = in->priv, &d_sib = in->sib, &d_slot = in->slot;
   P3R_HIP(hipMemsetAsync(err.p, 0xFF, 4, ctx->stream));
-  d_pub = upload_mont<PP>(ctx, in->public_values, h.public_rows.size() * 4, "public_values");
-  d_priv = upload_mont<PP>(ctx, in->private_values, h.private_rows.size() * 4, "private_values");
-  d_sib = upload_mont<PP>(ctx, in->private_data_siblings, in->n_private_data * 8, "private_data_siblings");
-  d_slot.alloc(pd_slot.size());
-  P3R_HIP(copy_sync(ctx->stream, d_slot.p, pd_slot.data(), pd_slot.size() * 4, hipMemcpyHostToDevice));
   if (h.public_rows.size())
     hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(h.public_rows.size() * 4)), dim3(kBlock), 0, ctx->stream,
                        C->d_public_rows.p, d_pub.p, h.public_rows.size(), w.p);
@@ -825,16 +1037,31 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
   }
   {
     ProfScope ps(ctx, "run_levels");
-    const RunOp* light = reinterpret_cast<const RunOp*>(C->d_light.p);
-    const RunP2* p2 = reinterpret_cast<const RunP2*>(C->d_p2.p);
-    for (size_t l = 1; l <= S.levels; ++l) {
+    RunArgs A{};
+    A.light = reinterpret_cast<const RunOp*>(C->d_light.p);
+    A.p2 = reinterpret_cast<const RunP2*>(C->d_p2.p);
+    A.w = w.p; A.ext = C->d_ext.p; A.alu_values = T->alu_values.p; A.rec_values = T->recompose_values.p;
+    A.p2_inputs = p2_inputs; A.p2_h = p2_h; A.p2_flags = p2_flags; A.p2_seed = p2_seed; A.p2_out = p2_out.p;
+    A.pd_slot = reinterpret_cast<const int32_t*>(d_slot.p); A.siblings = d_sib.p;
+    A.rc = ctx->rc.p; A.diag = ctx->p2_diag.p; A.err = err.p;
+    A.light_off = C->d_light_off.p; A.p2_off = C->d_p2_off.p;
+    for (const auto& seg : S.segments) {
+      if (seg.narrow) {
+        hipLaunchKernelGGL(k_run_levels_narrow<PP>, dim3(1), dim3(kNarrowBlock), 0, ctx->stream, A,
+                           C->d_chunk_bounds.p + seg.chunk_begin, seg.n_chunks);
+        continue;
+      }
+      const uint32_t l = seg.l0;
       const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2_off[l + 1] - S.p2_off[l];
-      if (!nl && !np) continue;
       const uint32_t lb = (nl + kBlock - 1) / kBlock, pb = (np * 16 + kBlock - 1) / kBlock;
-      hipLaunchKernelGGL(k_run_level<PP>, dim3(lb + pb), dim3(kBlock), 0, ctx->stream, light + S.light_off[l], nl, lb,
-                         p2 + S.p2_off[l], np, w.p, C->d_ext.p, T->alu_values.p, T->recompose_values.p, p2_inputs, p2_h,
-                         p2_flags, p2_seed, p2_out.p, reinterpret_cast<const int32_t*>(d_slot.p), d_sib.p, ctx->rc.p,
-                         ctx->p2_diag.p, err.p);
+      if (lb + pb)
+        hipLaunchKernelGGL(k_run_level<PP>, dim3(lb + pb), dim3(kBlock), 0, ctx->stream, A, S.light_off[l], nl, lb,
+                           S.p2_off[l], np);
+      const uint32_t nc = S.chain_off[l + 1] - S.chain_off[l];
+      if (nc)
+        hipLaunchKernelGGL(k_run_chains<PP>, dim3((nc + 3) / 4), dim3(kChainBlock), 0, ctx->stream, A,
+                           reinterpret_cast<const RunOp*>(C->d_chain_ops.p),
+                           reinterpret_cast<const RunSchedule::ChainSeg*>(C->d_chains.p) + S.chain_off[l], nc);
     }
     if (!S.rewrite_pairs.empty())
       hipLaunchKernelGGL(k_run_rewrite<PP>, dim3(blocks_for(S.rewrite_pairs.size() / 3)), dim3(kBlock), 0, ctx->stream,
@@ -851,7 +1078,6 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     if (idx == 0x1FFFFFFFu) fail(P3R_EINVAL, "WitnessConflict while applying witness_rewrite");
     fail(P3R_EINVAL, "%s at op %u", run_error_text(e & 7), idx);
   }
-  if (witness_out) *witness_out = std::move(w);
   return T;
 }
 

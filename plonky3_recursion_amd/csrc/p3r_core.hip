@@ -871,7 +871,19 @@ int p3r_circuit_levels(const p3r_circuit* circuit, size_t* n_levels) {
   *n_levels = circuit->sched.levels;
   return P3R_OK;
 }
-p3r_dtraces* p3r_circuit_run(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs) {
+p3r_dinputs* p3r_circuit_inputs_upload(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs) {
+  p3r_dinputs* out = nullptr;
+  guard(ctx, [&] {
+    if (!circuit || !inputs) fail(P3R_EINVAL, "NULL argument");
+    out = P3R_FIELD_CALL(ctx, circuit_inputs_upload, ctx, circuit, inputs).release();
+  });
+  return out;
+}
+void p3r_circuit_inputs_free(p3r_ctx* ctx, p3r_dinputs* inputs) {
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  delete inputs;
+}
+p3r_dtraces* p3r_circuit_run_resident(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_dinputs* inputs) {
   p3r_dtraces* out = nullptr;
   guard(ctx, [&] {
     if (!circuit || !inputs) fail(P3R_EINVAL, "NULL argument");
@@ -879,14 +891,35 @@ p3r_dtraces* p3r_circuit_run(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r
   });
   return out;
 }
+p3r_dtraces* p3r_circuit_run(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs) {
+  p3r_dtraces* out = nullptr;
+  guard(ctx, [&] {
+    if (!circuit || !inputs) fail(P3R_EINVAL, "NULL argument");
+    auto d = P3R_FIELD_CALL(ctx, circuit_inputs_upload, ctx, circuit, inputs);
+    out = P3R_FIELD_CALL(ctx, circuit_run, ctx, circuit, d.get()).release();
+  });
+  return out;
+}
+static void prove_next_layer_impl(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_dinputs* d, uint32_t flags,
+                                  uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {
+  auto t = P3R_FIELD_CALL(ctx, circuit_run, ctx, circuit, d);
+  auto bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, circuit->layer.get(), t.get(),
+                              (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
+  emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+}
 int p3r_prove_next_layer(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs,
                          uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {
   return guard(ctx, [&] {
     if (!circuit || !inputs || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
-    auto t = P3R_FIELD_CALL(ctx, circuit_run, ctx, circuit, inputs);
-    auto bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, circuit->layer.get(), t.get(),
-                                (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
-    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+    auto d = P3R_FIELD_CALL(ctx, circuit_inputs_upload, ctx, circuit, inputs);
+    prove_next_layer_impl(ctx, circuit, d.get(), flags, proof_buf, proof_cap, proof_len);
+  });
+}
+int p3r_prove_next_layer_resident(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_dinputs* inputs,
+                                  uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {
+  return guard(ctx, [&] {
+    if (!circuit || !inputs || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
+    prove_next_layer_impl(ctx, circuit, inputs, flags, proof_buf, proof_cap, proof_len);
   });
 }
 int p3r_dtraces_get(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces, uint32_t which,

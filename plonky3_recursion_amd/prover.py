@@ -462,21 +462,51 @@ class PreparedCircuit:
         t.n_private_data = ids.size
         return t, (pub, prv, ids, sib)
 
-    def run(self, inputs: CircuitInputs) -> ResidentTraces:
-        """`CircuitRunner::run` on the device (circuit/src/tables/runner.rs:195-253)."""
-        t, keep = self._inputs_struct(self.circuit, inputs)
-        h = self.ctx.ptr(self.ctx.lib.p3r_circuit_run(self.ctx.h, self.h, C.byref(t)))
+    def upload_inputs(self, inputs: CircuitInputs) -> "ResidentInputs":
+        return ResidentInputs(self, inputs)
+
+    def run(self, inputs) -> ResidentTraces:
+        """`CircuitRunner::run` on the device (circuit/src/tables/runner.rs:195-253).
+        inputs: `CircuitInputs` (host) or `ResidentInputs` (already in HBM)."""
+        if isinstance(inputs, ResidentInputs):
+            h = self.ctx.ptr(self.ctx.lib.p3r_circuit_run_resident(self.ctx.h, self.h, inputs.h))
+        else:
+            t, keep = self._inputs_struct(self.circuit, inputs)
+            h = self.ctx.ptr(self.ctx.lib.p3r_circuit_run(self.ctx.h, self.h, C.byref(t)))
         return ResidentTraces._adopt(self.ctx, self.circuit_prover_data, h)
 
-    def prove(self, inputs: CircuitInputs, canonical_field_encoding=False) -> bytes:
+    def prove(self, inputs, canonical_field_encoding=False) -> bytes:
+        """Run + prove_all_tables in one call (the inner BatchProof bytes)."""
+        flags = 1 if canonical_field_encoding else 0
+        if isinstance(inputs, ResidentInputs):
+            return self.ctx._proof_call(self.ctx.lib.p3r_prove_next_layer_resident, self.ctx.h, self.h, inputs.h, flags)
         t, keep = self._inputs_struct(self.circuit, inputs)
-        return self.ctx._proof_call(self.ctx.lib.p3r_prove_next_layer, self.ctx.h, self.h, C.byref(t),
-                                    1 if canonical_field_encoding else 0)
+        return self.ctx._proof_call(self.ctx.lib.p3r_prove_next_layer, self.ctx.h, self.h, C.byref(t), flags)
 
     def free(self):
         if self.h and self.ctx.h:
             self.circuit_prover_data.h = None
             self.ctx.lib.p3r_circuit_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ResidentInputs:
+    """`CircuitInputs` uploaded to HBM once."""
+
+    def __init__(self, prepared: PreparedCircuit, inputs: CircuitInputs):
+        self.ctx = prepared.ctx
+        t, keep = PreparedCircuit._inputs_struct(prepared.circuit, inputs)
+        self.h = self.ctx.ptr(self.ctx.lib.p3r_circuit_inputs_upload(self.ctx.h, prepared.h, C.byref(t)))
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.p3r_circuit_inputs_free(self.ctx.h, self.h)
         self.h = None
 
     def __del__(self):
