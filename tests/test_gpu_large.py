@@ -72,3 +72,45 @@ def test_five_chained_layers_reuse_one_prep(oracle):
     L.verify(proofs[-1], prep_cap=cap)
     cache.circuit_prover_data.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("field,log_h,gen", [
+    ("koala-bear", 15, dict()),
+    # config-2 style knobs: Horner chains of thousands of steps (one scan each), 330-deep sponge chains
+    ("koala-bear", 15, dict(horner_chain_len=2600, sponge_chain_len=330)),
+    ("baby-bear", 13, dict(horner_chain_len=300, sponge_chain_len=40)),
+])
+def test_circuit_run_and_prove_at_scale(oracle, field, log_h, gen):
+    """prove_next_layer from the circuit: the device runner's Traces equal the oracle's sequential
+    run (wide levels, long chain scans, fused narrow levels), the proof is accepted by the oracle
+    verifier against the GPU's own preprocessed commitment."""
+    import circuit_lib as cl
+    import oracle_lib
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import workload as wl
+    gen = dict(dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20), **gen)
+    a = harness_lib.generate(field, log_h, seed=77, **gen)
+    oc = cl.OracleCircuit(oracle, cl.Circuit.from_arrays(a)).preprocess(oracle_lib.MODULUS[field])
+    oc.run(field, cl.Inputs.from_arrays(a))
+    want = oc.workload_arrays()
+    ctx = p3r.Context(field=field, **FRI)
+    tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(a), p3r.FriRecursionBackend(),
+                                      p3r.ProveNextLayerParams(table_packing=tp))
+    pc = cache.prepared_circuit
+    inputs = pc.upload_inputs(wl.circuit_inputs_from_arrays(a))
+    res = pc.run(inputs)
+    for name, key in (("const_values", "const_values"), ("public_values", "public_values"), ("alu_values", "alu_values"),
+                      ("recompose_values", "recompose_values"), ("p2_input_values", "p2_inputs"),
+                      ("p2_mmcs_index_sum", "p2_mmcs_index_sum")):
+        assert np.array_equal(res.download(name).reshape(-1), want[key]), name
+    assert np.array_equal(res.download("p2_flags"), want["p2_flags"].reshape(-1, 4)[:, :3])
+    res.free()
+    out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=inputs), ctx, p3r.FriRecursionBackend(),
+                               p3r.ProveNextLayerParams(table_packing=tp), prep=cache)
+    assert pc.prove(inputs) == out.proof.proof
+    L = layer_lib.OracleLayer(oracle, field, want, layer_lib.params(**FRI))
+    L.verify(out.proof.proof, prep_cap=cache.circuit_prover_data.preprocessed_commitment)
+    inputs.free()
+    pc.free()
+    ctx.close()
