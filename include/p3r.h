@@ -283,6 +283,18 @@ int p3r_prove_all_tables_resident(p3r_ctx* ctx, const p3r_layer* layer, const p3
 p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
                                      uint32_t table);
 
+/* ---- verification -------------------------------------------------------------------------------
+ * `p3_batch_stark::verify_batch(&config, &airs, &proof, &public_values, &common)` as
+ * `BatchStarkProver::verify_all_tables` calls it (circuit-prover/src/batch_stark_prover.rs:1230-1268,
+ * 1649-1727), for proofs made with the same p3r_config.  `airs` are the proved tables in instance
+ * order, `preprocessed_commitment` the (1 << cap_height) x 8 canonical digests of the
+ * CircuitProverData.  Host code, no device and no p3r_ctx needed.  Returns P3R_OK when the proof
+ * is accepted; otherwise an error code and the reason in err_buf (the analogue of
+ * BatchStarkProverError::Verify(String)). */
+int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_airs,
+                     const uint32_t* preprocessed_commitment, const uint8_t* proof, size_t proof_len, uint32_t flags,
+                     char* err_buf, size_t err_cap);
+
 /* ---- the caller side of prove_next_layer: the circuit itself ------------------------------------
  * `prove_next_layer` (recursion/src/recursion.rs:401-502) receives a `Circuit<EF>`, sets its public
  * inputs and the Merkle-sibling private data, RUNS it (`CircuitRunner::run`,

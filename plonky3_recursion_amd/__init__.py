@@ -4,10 +4,10 @@ Host-side mirror of the reference's interface for this path over the C ABI in in
 The HIP library is mandatory: importing the package is cheap, but any compute entry point
 raises if `libp3r_hip.so` has not been built (no CPU fallback).
 """
-from .device import Context, DeviceMatrix, MerkleTree, P3rError  # noqa: F401
+from .device import Context, DeviceMatrix, MerkleTree, P3rError, make_config, verify_batch  # noqa: F401
 from .prover import (BatchStarkProof, BatchStarkProver, Circuit, CircuitInputs, CircuitPrep,  # noqa: F401
                      CircuitProverData, CircuitRunner, PreparedCircuit, FriRecursionBackend, FriRecursionConfig, NextLayerPrepCache, ProveNextLayerParams,
                      RecursionInput, RecursionOutput, ResidentTraces, TablePacking, Traces,
-                     build_next_layer_prep, prove_next_layer)
+                     build_next_layer_prep, prove_next_layer, verify_all_tables)
 
 __all__ = ["Context", "DeviceMatrix", "MerkleTree", "P3rError"]

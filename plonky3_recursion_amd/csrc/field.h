@@ -192,6 +192,8 @@ struct Fp4 {
   }
   P3R_HD bool is_zero() const { return (c[0].v | c[1].v | c[2].v | c[3].v) == 0; }
   P3R_HD Fp4 sqr() const { return *this * *this; }
+  P3R_HD Fp4 dbl() const { Fp4 r; for (int i = 0; i < 4; ++i) r.c[i] = c[i].dbl(); return r; }
+  P3R_HD Fp4 halve() const { Fp4 r; for (int i = 0; i < 4; ++i) r.c[i] = c[i].halve(); return r; }
   P3R_HD Fp4 pow(uint64_t e) const {
     Fp4 r = one(), b = *this;
     while (e) {
@@ -226,6 +228,12 @@ struct Fp4 {
     return r;
   }
 };
+
+// Embedding of a base-field constant into the value type a generic routine computes in
+// (the base field itself for the prover's kernels, the extension for evaluations at zeta).
+template <class V> struct Lift;
+template <class PP> struct Lift<Fp<PP>> { static P3R_HD Fp<PP> of(Fp<PP> x) { return x; } };
+template <class PP> struct Lift<Fp4<PP>> { static P3R_HD Fp4<PP> of(Fp<PP> x) { return Fp4<PP>::from_base(x); } };
 
 P3R_HD uint32_t bit_reverse(uint32_t x, int bits) {
   if (bits == 0) return 0;

@@ -485,6 +485,7 @@ void init_ctx(p3r_ctx* ctx) {
 #include "prove_impl.cuh"
 #include "layer_impl.cuh"
 #include "circuit_impl.cuh"
+#include "verify_impl.h"
 
 // =============================================================================== C ABI
 extern "C" {
@@ -845,6 +846,47 @@ p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const
     out = m[table].release();
   });
   return out;
+}
+
+// ---- native verifier (verify_impl.h): host code, no device needed ----
+int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_airs,
+                     const uint32_t* preprocessed_commitment, const uint8_t* proof, size_t proof_len, uint32_t flags,
+                     char* err_buf, size_t err_cap) {
+  auto report = [&](const char* msg) {
+    if (err_buf && err_cap) snprintf(err_buf, err_cap, "%s", msg);
+  };
+  try {
+    if (!cfg || !airs || !preprocessed_commitment || (!proof && proof_len)) { report("NULL argument"); return P3R_EINVAL; }
+    if (cfg->abi_version != P3R_ABI_VERSION) { report("ABI version mismatch"); return P3R_EINVAL; }
+    if (cfg->ext_degree != 4) { report("UnsupportedDegree"); return P3R_EUNSUPPORTED; }
+    p3r::VerifyParams prm{(int)cfg->log_blowup, (int)cfg->max_log_arity, (int)cfg->cap_height, (int)cfg->log_final_poly_len,
+                          (int)cfg->commit_pow_bits, (int)cfg->query_pow_bits, (int)cfg->num_queries};
+    std::vector<p3r::AirParams> a(n_airs);
+    for (size_t i = 0; i < n_airs; ++i) {
+      if (airs[i].kind > P3R_AIR_RECOMPOSE || !airs[i].lanes) { report("bad AIR descriptor"); return P3R_EINVAL; }
+      a[i] = {(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups};
+    }
+    const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
+    std::vector<uint32_t> cap(preprocessed_commitment, preprocessed_commitment + ((size_t)P2_DIGEST << cfg->cap_height));
+    auto run = [&](auto tag) {
+      using PP = decltype(tag);
+      const size_t nrc = p2_num_constants<PP>();
+      const uint32_t* src = cfg->poseidon2_rc;
+      if (src && cfg->poseidon2_rc_len != nrc) p3r::vfail("poseidon2_rc_len is %u, the field needs %zu constants", cfg->poseidon2_rc_len, nrc);
+      if (!src) src = PP::FIELD_ID == 0 ? kDefaultRc_koala_bear : kDefaultRc_baby_bear;
+      p3r::verify_batch<PP>(prm, std::vector<uint32_t>(src, src + nrc), a, cap, proof, proof_len, canonical);
+    };
+    if (cfg->field == P3R_FIELD_KOALA_BEAR) run(p3r::KoalaBearParams{});
+    else if (cfg->field == P3R_FIELD_BABY_BEAR) run(p3r::BabyBearParams{});
+    else { report("unknown field"); return P3R_EINVAL; }
+    return P3R_OK;
+  } catch (const p3r::VerifyFailure& e) {
+    report(e.what());
+    return P3R_EINVAL;
+  } catch (const std::exception& e) {
+    report(e.what());
+    return P3R_EINVAL;
+  }
 }
 
 // ---- circuit boundary (circuit_impl.cuh) ----

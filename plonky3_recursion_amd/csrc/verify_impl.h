@@ -1,0 +1,597 @@
+// Native verifier for the proofs prove_impl.cuh produces: `verify_batch` behind
+// `BatchStarkProver::verify_all_tables` (circuit-prover/src/batch_stark_prover.rs:1230-1268,
+// 1649-1727).  Host code: verification is a few thousand permutations and is serial in the
+// reference too.  It replays the prover's transcript and checks, following the in-tree circuit
+// verifier (the only in-tree statement of what p3-batch-stark / p3-fri 0.6 verify):
+//   transcript order, domains, opening points      recursion/src/verifier/batch_stark.rs:521-852
+//   folded constraints * 1/Z_H == quotient(zeta)   :886-1021, recursion/src/verifier/quotient.rs:60-
+//   selectors at zeta                               recursion/src/pcs/fri/targets.rs:868-908
+//   LogUp constraints, global sum of terminals      batch_stark.rs:1026-1112
+//   MMCS openings (mixed heights, injection, cap)   recursion/src/pcs/mmcs.rs:319-426, circuit/src/ops/mmcs.rs:81-209
+//   FRI: reduced openings, folds, roll-ins, final polynomial, proofs of work
+//                                                   recursion/src/pcs/fri/verifier.rs:424-465,562-781,887-981,1068-1356
+// The AIR statements are the ones the quotient kernel evaluates (air_device.cuh), instantiated
+// over the extension field at zeta.
+#pragma once
+#include <array>
+#include <cstdarg>
+#include <map>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "host_transcript.h"
+
+namespace p3r {
+
+struct VerifyFailure : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+[[noreturn]] inline void vfail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw VerifyFailure(buf);
+}
+
+// ---- postcard reader (mirror of ProofWriter)
+template <class PP>
+struct ProofReader {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const uint8_t* p;
+  const uint8_t* end;
+  bool canonical;
+  uint8_t byte() {
+    if (p >= end) vfail("proof truncated");
+    return *p++;
+  }
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      uint8_t b = byte();
+      v |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    vfail("malformed varint");
+  }
+  size_t len(size_t max) {
+    uint64_t v = varint();
+    if (v > max) vfail("length %llu exceeds the bound %zu", (unsigned long long)v, max);
+    return (size_t)v;
+  }
+  F fe() {
+    uint64_t v = varint();
+    if (v >= PP::P) vfail("field element out of range");
+    return canonical ? F::from_canonical((uint32_t)v) : F::raw((uint32_t)v);
+  }
+  E ef() { E e; for (int i = 0; i < 4; ++i) e.c[i] = fe(); return e; }
+  std::vector<E> vec_ef(size_t max = 1u << 16) {
+    std::vector<E> v(len(max));
+    for (auto& e : v) e = ef();
+    return v;
+  }
+  using Digest = std::array<F, P2_DIGEST>;
+  Digest digest() { Digest d; for (auto& x : d) x = fe(); return d; }
+  std::vector<Digest> cap() {
+    std::vector<Digest> c(len(1u << 16));
+    for (auto& d : c) d = digest();
+    return c;
+  }
+};
+
+template <class PP>
+struct ParsedProof {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  using Digest = std::array<F, P2_DIGEST>;
+  using Cap = std::vector<Digest>;
+  Cap main_cap, quot_cap;
+  std::optional<Cap> perm_cap;
+  struct Inst {
+    std::vector<E> main_local, prep_local, prep_next, perm_local, perm_next;
+    std::optional<std::vector<E>> main_next;
+    std::vector<std::vector<E>> chunks;
+  };
+  std::vector<Inst> insts;
+  std::vector<Cap> commit_caps;
+  std::vector<F> commit_pow;
+  struct QRound { std::vector<std::vector<F>> rows; std::vector<Digest> path; };
+  struct QPhase { int la; std::vector<E> sibs; std::vector<Digest> path; };
+  struct Query { std::vector<QRound> rounds; std::vector<QPhase> phases; };
+  std::vector<Query> queries;
+  std::vector<E> final_poly;
+  F query_pow;
+  std::vector<std::optional<E>> terminals;
+  std::vector<int> degree_bits;
+};
+
+template <class PP>
+ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical) {
+  ProofReader<PP> R{bytes, bytes + n, canonical};
+  ParsedProof<PP> P;
+  P.main_cap = R.cap();
+  if (R.byte()) P.perm_cap = R.cap();
+  P.quot_cap = R.cap();
+  if (R.byte()) vfail("proof carries a random (ZK) commitment: not supported");
+  P.insts.resize(R.len(64));
+  for (auto& in : P.insts) {
+    in.main_local = R.vec_ef();
+    if (R.byte()) in.main_next = R.vec_ef();
+    if (!R.byte()) vfail("preprocessed_local missing");
+    in.prep_local = R.vec_ef();
+    if (!R.byte()) vfail("preprocessed_next missing");
+    in.prep_next = R.vec_ef();
+    in.chunks.resize(R.len(8));
+    for (auto& c : in.chunks) c = R.vec_ef();
+    if (R.byte()) vfail("proof carries random opened values: not supported");
+    in.perm_local = R.vec_ef();
+    in.perm_next = R.vec_ef();
+  }
+  P.commit_caps.resize(R.len(64));
+  for (auto& c : P.commit_caps) c = R.cap();
+  P.commit_pow.resize(R.len(64));
+  for (auto& w : P.commit_pow) w = R.fe();
+  P.queries.resize(R.len(1024));
+  for (auto& q : P.queries) {
+    q.rounds.resize(R.len(8));
+    for (auto& r : q.rounds) {
+      r.rows.resize(R.len(256));
+      for (auto& row : r.rows) {
+        row.resize(R.len(1u << 16));
+        for (auto& x : row) x = R.fe();
+      }
+      r.path.resize(R.len(64));
+      for (auto& d : r.path) d = R.digest();
+    }
+    q.phases.resize(R.len(64));
+    for (auto& ph : q.phases) {
+      ph.la = R.byte();
+      ph.sibs.resize(R.len(16));
+      for (auto& e : ph.sibs) e = R.ef();
+      ph.path.resize(R.len(64));
+      for (auto& d : ph.path) d = R.digest();
+    }
+  }
+  P.final_poly = R.vec_ef();
+  P.query_pow = R.fe();
+  P.terminals.resize(R.len(64));
+  for (auto& t : P.terminals)
+    if (R.byte()) t = R.ef();
+  P.degree_bits.resize(R.len(64));
+  for (auto& d : P.degree_bits) d = (int)R.len(40);
+  if (R.p != R.end) vfail("%zu trailing bytes after the proof", (size_t)(R.end - R.p));
+  return P;
+}
+
+// ---- the opened values of one instance as an AIR view over the extension field
+template <class PP>
+struct ZetaView {
+  using V = Fp4<PP>;
+  const std::vector<V>*ml, *mn, *pl, *pn;
+  V L(int c) const { return (*ml).at(c); }
+  V N(int c) const { return (*mn).at(c); }
+  V PL(int c) const { return (*pl).at(c); }
+  V PN(int c) const { return (*pn).at(c); }
+};
+
+// acc <- acc * alpha + c over every constraint, base-field constraints first
+// (recursion/src/traits/air.rs:162-182)
+template <class PP>
+struct ZetaFold {
+  using E = Fp4<PP>;
+  E alpha, acc = E::zero();
+  int count = 0;
+  void base(const E& c) { acc = acc * alpha + c; ++count; }
+  void ext(const E& c) { base(c); }
+};
+
+// LogUp group constraints at zeta: f_g * prod d_k - sum_k m_k prod_{l != k} d_l (same grouping as QuotSink)
+template <class PP>
+struct ZetaLookupSink {
+  using E = Fp4<PP>;
+  E prefix;
+  E beta_pow[5];
+  const std::vector<E>& aux;  // EF aux columns at zeta: [0] running sum, [g + 1] fraction of group g
+  ZetaFold<PP>& fold;
+  int pair, cnt = 0;
+  E d0 = E::zero(), m0 = E::zero(), sum_f = E::zero();
+  E denom(const E& idx, const V4<E>& v) const {
+    E d = prefix + beta_pow[0] * idx;
+    for (int j = 0; j < 4; ++j) d += beta_pow[j + 1] * v.c[j];
+    return d;
+  }
+  void add(const E& idx, const V4<E>& v, const E& mult) {
+    const E d = denom(idx, v);
+    ++cnt;
+    if (!pair) {
+      const E f = aux.at(cnt);
+      fold.ext(f * d - mult);
+      sum_f += f;
+    } else if (cnt & 1) {
+      d0 = d; m0 = mult;
+    } else {
+      const E f = aux.at(cnt / 2);
+      fold.ext(f * d0 * d - (d * m0 + d0 * mult));
+      sum_f += f;
+    }
+  }
+  void finish() {
+    if (pair && (cnt & 1)) {
+      const E f = aux.at((cnt + 1) / 2);
+      fold.ext(f * d0 - m0);
+      sum_f += f;
+    }
+  }
+};
+
+// ---- MMCS
+template <class PP>
+std::array<Fp<PP>, P2_DIGEST> sponge_hash(const std::vector<Fp<PP>>& row, const uint32_t* rc) {
+  using F = Fp<PP>;
+  F s[P2_WIDTH];
+  for (auto& x : s) x = F::zero();
+  size_t g = 0;
+  // overwrite-mode PaddingFreeSponge, rate 8 (recursion/src/pcs/mmcs.rs:38-179)
+  for (; g < row.size(); g += P2_RATE) {
+    for (size_t j = 0; j < (size_t)P2_RATE && g + j < row.size(); ++j) s[j] = row[g + j];
+    p2_permute<PP>(s, rc);
+  }
+  std::array<F, P2_DIGEST> d;
+  for (int k = 0; k < P2_DIGEST; ++k) d[k] = s[k];
+  return d;
+}
+template <class PP>
+std::array<Fp<PP>, P2_DIGEST> compress2(const std::array<Fp<PP>, P2_DIGEST>& l, const std::array<Fp<PP>, P2_DIGEST>& r,
+                                        const uint32_t* rc) {
+  Fp<PP> s[P2_WIDTH];
+  for (int k = 0; k < P2_DIGEST; ++k) { s[k] = l[k]; s[P2_DIGEST + k] = r[k]; }
+  p2_permute<PP>(s, rc);
+  std::array<Fp<PP>, P2_DIGEST> d;
+  for (int k = 0; k < P2_DIGEST; ++k) d[k] = s[k];
+  return d;
+}
+
+// verify_batch of one commitment: `log_heights[m]` / rows[m] in COMMIT order; index addresses the
+// tallest matrix.  (recursion/src/pcs/mmcs.rs:319-426)
+template <class PP>
+void mmcs_verify(const std::vector<std::array<Fp<PP>, P2_DIGEST>>& cap, int cap_height, const std::vector<int>& log_heights,
+                 const std::vector<std::vector<Fp<PP>>>& rows, size_t index,
+                 const std::vector<std::array<Fp<PP>, P2_DIGEST>>& path, const uint32_t* rc, const char* what) {
+  using F = Fp<PP>;
+  if (rows.size() != log_heights.size()) vfail("%s: %zu opened rows for %zu matrices", what, rows.size(), log_heights.size());
+  int log_max = 0;
+  for (int lh : log_heights) log_max = std::max(log_max, lh);
+  if (cap_height > log_max || cap.size() != (size_t(1) << cap_height)) vfail("%s: bad cap", what);
+  if ((int)path.size() != log_max - cap_height) vfail("%s: opening proof has %zu siblings, expected %d", what, path.size(), log_max - cap_height);
+  if (index >> log_max) vfail("%s: index out of range", what);
+  auto concat = [&](int lh) {
+    std::vector<F> r;
+    for (size_t m = 0; m < rows.size(); ++m)
+      if (log_heights[m] == lh) r.insert(r.end(), rows[m].begin(), rows[m].end());
+    return r;
+  };
+  auto any_at = [&](int lh) {
+    for (int x : log_heights) if (x == lh) return true;
+    return false;
+  };
+  auto node = sponge_hash<PP>(concat(log_max), rc);
+  size_t idx = index;
+  for (int lvl = 0; lvl < log_max - cap_height; ++lvl) {
+    node = (idx & 1) ? compress2<PP>(path[lvl], node, rc) : compress2<PP>(node, path[lvl], rc);
+    idx >>= 1;
+    const int lh = log_max - lvl - 1;
+    if (any_at(lh)) node = compress2<PP>(node, sponge_hash<PP>(concat(lh), rc), rc);  // injection
+  }
+  if (node != cap.at(idx)) vfail("%s: Merkle root mismatch", what);
+}
+
+// ---- the whole verification
+struct VerifyParams {
+  int log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits, num_queries;
+};
+
+template <class PP>
+void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canonical, const std::vector<AirParams>& airs,
+                  const std::vector<uint32_t>& prep_cap_canonical, const uint8_t* bytes, size_t n_bytes, bool canonical) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  using Digest = std::array<F, P2_DIGEST>;
+  const ParsedProof<PP> P = parse_proof<PP>(bytes, n_bytes, canonical);
+  const size_t ni = airs.size();
+  if (rc_canonical.size() != (size_t)p2_num_constants<PP>()) vfail("wrong number of round constants");
+  std::vector<uint32_t> rc(rc_canonical.size());
+  for (size_t i = 0; i < rc.size(); ++i) rc[i] = F::from_canonical(rc_canonical[i]).v;
+  const int p2w = p2_perm_cols<PP>() + 2;
+  if (P.insts.size() != ni || P.degree_bits.size() != ni || P.terminals.size() != ni)
+    vfail("proof has %zu instances, the verifier was given %zu AIRs", P.insts.size(), ni);
+  const int cap_h = prm.cap_height, lb = prm.log_blowup;
+  std::vector<Digest> prep_cap(size_t(1) << cap_h);
+  if (prep_cap_canonical.size() != prep_cap.size() * P2_DIGEST) vfail("preprocessed commitment has the wrong size");
+  for (size_t j = 0; j < prep_cap.size(); ++j)
+    for (int k = 0; k < P2_DIGEST; ++k) prep_cap[j][k] = F::from_canonical(prep_cap_canonical[j * P2_DIGEST + k]);
+
+  // ---- shapes
+  std::vector<LookupLayout> layouts(ni);
+  std::vector<int> log_n(ni), width(ni), prep_w(ni);
+  bool any_lookup = false;
+  std::vector<int> perm_insts;
+  for (size_t i = 0; i < ni; ++i) {
+    const auto& in = P.insts[i];
+    layouts[i] = lookup_layout(airs[i]);
+    log_n[i] = P.degree_bits[i];
+    if (log_n[i] + lb > PP::TWO_ADICITY) vfail("instance %zu: degree too large", i);
+    width[i] = air_width_of(airs[i], p2w);
+    prep_w[i] = air_prep_width_of(airs[i]);
+    const size_t aw = (size_t)layouts[i].aux_width() * 4, C = size_t(1) << layouts[i].log_chunks;
+    if (in.main_local.size() != (size_t)width[i]) vfail("instance %zu: %zu main openings, the AIR has %d columns", i, in.main_local.size(), width[i]);
+    if (air_uses_next(airs[i]) != in.main_next.has_value()) vfail("instance %zu: main next-row openings do not match the AIR", i);
+    if (in.main_next && in.main_next->size() != (size_t)width[i]) vfail("instance %zu: bad main next width", i);
+    if (in.prep_local.size() != (size_t)prep_w[i] || in.prep_next.size() != (size_t)prep_w[i]) vfail("instance %zu: bad preprocessed opening width", i);
+    if (in.perm_local.size() != aw || in.perm_next.size() != aw) vfail("instance %zu: bad permutation opening width", i);
+    if (in.chunks.size() != C) vfail("instance %zu: %zu quotient chunks, expected %zu", i, in.chunks.size(), C);
+    for (auto& c : in.chunks) if (c.size() != 4) vfail("instance %zu: bad quotient chunk width", i);
+    if ((layouts[i].n_groups > 0) != P.terminals[i].has_value()) vfail("instance %zu: lookup terminal presence mismatch", i);
+    if (layouts[i].n_groups) { any_lookup = true; perm_insts.push_back((int)i); }
+  }
+  if (any_lookup != P.perm_cap.has_value()) vfail("permutation commitment presence mismatch");
+
+  // ---- transcript (same order as prove_batch)
+  HostChallenger<PP> ch(rc.data());
+  auto observe_cap = [&](const std::vector<Digest>& cap) { for (auto& d : cap) for (auto x : d) ch.observe(x); };
+  ch.observe_base_as_ext(ni);
+  for (size_t i = 0; i < ni; ++i) {
+    ch.observe_base_as_ext(log_n[i]);
+    ch.observe_base_as_ext(log_n[i]);
+    ch.observe_base_as_ext(width[i]);
+    ch.observe_base_as_ext(uint64_t(1) << layouts[i].log_chunks);
+  }
+  observe_cap(P.main_cap);
+  for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(prep_w[i]);
+  observe_cap(prep_cap);
+  E l_prefix = E::zero(), l_beta_pow[5];
+  for (auto& b : l_beta_pow) b = E::zero();
+  if (any_lookup) {
+    const E alpha_l = ch.sample_ext(), beta_l = ch.sample_ext();
+    E bp = E::one();
+    for (int j = 0; j < 5; ++j) { l_beta_pow[j] = bp; bp *= beta_l; }
+    l_prefix = alpha_l + bp;
+    observe_cap(*P.perm_cap);
+    for (int i : perm_insts) ch.observe_ext(*P.terminals[i]);
+  }
+  const E alpha = ch.sample_ext();
+  observe_cap(P.quot_cap);
+  const E zeta = ch.sample_ext();
+  for (size_t i = 0; i < ni; ++i) {
+    for (auto& v : P.insts[i].main_local) ch.observe_ext(v);
+    if (P.insts[i].main_next) for (auto& v : *P.insts[i].main_next) ch.observe_ext(v);
+  }
+  for (size_t i = 0; i < ni; ++i)
+    for (auto& c : P.insts[i].chunks) for (auto& v : c) ch.observe_ext(v);
+  for (size_t i = 0; i < ni; ++i) {
+    for (auto& v : P.insts[i].prep_local) ch.observe_ext(v);
+    for (auto& v : P.insts[i].prep_next) ch.observe_ext(v);
+  }
+  for (int i : perm_insts) {
+    for (auto& v : P.insts[i].perm_local) ch.observe_ext(v);
+    for (auto& v : P.insts[i].perm_next) ch.observe_ext(v);
+  }
+
+  // ---- constraints at zeta
+  const F gen = F::generator();
+  E terminal_sum = E::zero();
+  for (size_t i = 0; i < ni; ++i) {
+    const auto& in = P.insts[i];
+    const auto& L = layouts[i];
+    const size_t n = size_t(1) << log_n[i];
+    const F g = F::two_adic_generator(log_n[i]), g_inv = g.inv();
+    // selectors on the (unshifted) trace domain: Z_H = zeta^n - 1 (pcs/fri/targets.rs:868-908)
+    const E zh = zeta.pow(n) - E::one();
+    if (zh.is_zero()) vfail("zeta lies in the trace domain");
+    const E is_transition = zeta - E::from_base(g_inv);
+    const E is_first = zh * (zeta - E::one()).inv();
+    const E is_last = zh * is_transition.inv();
+    static const std::vector<E> none;
+    ZetaView<PP> v{&in.main_local, in.main_next ? &*in.main_next : &none, &in.prep_local, &in.prep_next};
+    ZetaFold<PP> fold;
+    fold.alpha = alpha;
+    if (airs[i].kind == AIR_ALU) alu_constraints<PP>(airs[i], v, fold);
+    else if (airs[i].kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc.data(), fold);
+    if (fold.count != air_num_base_constraints<PP>(airs[i])) vfail("instance %zu: constraint count mismatch", i);
+    if (L.n_groups) {
+      // EF aux columns from their 4 base-column openings: sum_k x^k * col_k(zeta)
+      auto ef_cols = [&](const std::vector<E>& flat) {
+        std::vector<E> out(flat.size() / 4, E::zero());
+        for (size_t c = 0; c < out.size(); ++c)
+          for (int k = 0; k < 4; ++k) {
+            E basis = E::zero();
+            basis.c[k] = F::one();
+            out[c] += basis * flat[c * 4 + k];
+          }
+        return out;
+      };
+      const std::vector<E> aux_l = ef_cols(in.perm_local), aux_n = ef_cols(in.perm_next);
+      ZetaLookupSink<PP> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4]},
+                              aux_l, fold, L.pair};
+      air_interactions<PP>(airs[i], v, sink);
+      sink.finish();
+      if (sink.cnt != L.n_interactions) vfail("instance %zu: interaction count mismatch", i);
+      const E s = aux_l[0], s_next = aux_n[0], terminal = *P.terminals[i];
+      fold.ext(s * is_first);
+      fold.ext((s_next - s - sink.sum_f) * is_transition);
+      fold.ext((s + sink.sum_f - terminal) * is_last);
+      terminal_sum += terminal;
+    }
+    // quotient(zeta) = sum_c L_c(zeta) * Q_c(zeta) over the 2^log_chunks cosets of the quotient domain
+    // (recursion/src/verifier/quotient.rs:60-)
+    const int lq = L.log_chunks;
+    const size_t C = size_t(1) << lq;
+    const F wq = F::two_adic_generator(log_n[i] + lq);
+    std::vector<F> shifts(C);
+    for (size_t c = 0; c < C; ++c) shifts[c] = gen * wq.pow(c);
+    E quotient = E::zero();
+    for (size_t c = 0; c < C; ++c) {
+      // vanishing polynomial of coset c' at x: (x / shift_c')^n - 1
+      E num = E::one();
+      F den = F::one();
+      for (size_t o = 0; o < C; ++o) {
+        if (o == c) continue;
+        num *= (zeta * shifts[o].inv()).pow(n) - E::one();
+        den *= (shifts[c] * shifts[o].inv()).pow(n) - F::one();
+      }
+      E qc = E::zero();
+      for (int k = 0; k < 4; ++k) {
+        E basis = E::zero();
+        basis.c[k] = F::one();
+        qc += basis * in.chunks[c][k];
+      }
+      quotient += num * den.inv() * qc;
+    }
+    if (!(fold.acc * zh.inv() == quotient)) vfail("instance %zu: constraints do not match the quotient at zeta (OodEvaluationMismatch)", i);
+  }
+  if (any_lookup && !terminal_sum.is_zero()) vfail("global lookup sum is not zero");
+
+  // ---- FRI transcript
+  const E fri_alpha = ch.sample_ext();
+  // input batches in round order: matrices (log LDE height, width), points and claimed values
+  struct Mat { int log_h; int w; std::vector<E> z; std::vector<const std::vector<E>*> vals; };
+  std::vector<std::vector<Mat>> rounds(any_lookup ? 4 : 3);
+  for (size_t i = 0; i < ni; ++i) {
+    Mat m{log_n[i] + lb, width[i], {zeta}, {&P.insts[i].main_local}};
+    if (P.insts[i].main_next) { m.z.push_back(zeta * F::two_adic_generator(log_n[i])); m.vals.push_back(&*P.insts[i].main_next); }
+    rounds[0].push_back(m);
+  }
+  for (size_t i = 0; i < ni; ++i)
+    for (auto& c : P.insts[i].chunks) rounds[1].push_back({log_n[i] + lb, 4, {zeta}, {&c}});
+  for (size_t i = 0; i < ni; ++i)
+    rounds[2].push_back({log_n[i] + lb, prep_w[i], {zeta, zeta * F::two_adic_generator(log_n[i])},
+                         {&P.insts[i].prep_local, &P.insts[i].prep_next}});
+  for (int i : perm_insts)
+    rounds[3].push_back({log_n[i] + lb, layouts[i].aux_width() * 4, {zeta, zeta * F::two_adic_generator(log_n[i])},
+                         {&P.insts[i].perm_local, &P.insts[i].perm_next}});
+  const std::vector<Digest>* round_caps[4] = {&P.main_cap, &P.quot_cap, &prep_cap, any_lookup ? &*P.perm_cap : nullptr};
+  int log_max = 0;
+  std::vector<int> heights;
+  for (auto& r : rounds) for (auto& m : r) { log_max = std::max(log_max, m.log_h); heights.push_back(m.log_h); }
+  std::sort(heights.rbegin(), heights.rend());
+  heights.erase(std::unique(heights.begin(), heights.end()), heights.end());
+  const int log_final = prm.log_final_poly_len + lb;
+  // the arity schedule the prover must have used (the FRI prover's rule, prove_impl.cuh step 7)
+  std::vector<int> las;
+  {
+    size_t next_h = 1;
+    int cur = log_max;
+    while (cur > log_final) {
+      int log_next = next_h < heights.size() ? heights[next_h] : -1;
+      int la = std::min(prm.max_log_arity, cur - log_final);
+      if (log_next >= 0 && log_next < cur) la = std::min(la, cur - log_next);
+      la = std::max(la, 1);
+      if (next_h < heights.size() && heights[next_h] == cur - la) ++next_h;
+      cur -= la;
+      las.push_back(la);
+    }
+    if (next_h != heights.size()) vfail("FRI: an input height is never rolled in");
+    if (cur != log_final) vfail("FRI: fold schedule does not end at the final polynomial length");
+  }
+  if (P.commit_caps.size() != las.size() || P.commit_pow.size() != las.size()) vfail("FRI: %zu commit phases, expected %zu", P.commit_caps.size(), las.size());
+  if (P.final_poly.size() != (size_t(1) << prm.log_final_poly_len)) vfail("FRI: final polynomial has the wrong length");
+  std::vector<E> betas;
+  for (size_t p = 0; p < las.size(); ++p) {
+    observe_cap(P.commit_caps[p]);
+    if (!ch.check_witness(prm.commit_pow_bits, P.commit_pow[p])) vfail("FRI: invalid commit-phase proof of work");
+    betas.push_back(ch.sample_ext());
+  }
+  for (auto& c : P.final_poly) ch.observe_ext(c);
+  for (int la : las) ch.observe(F::from_canonical((uint32_t)la));
+  if (!ch.check_witness(prm.query_pow_bits, P.query_pow)) vfail("FRI: invalid query proof of work");
+  if ((int)P.queries.size() != prm.num_queries) vfail("FRI: %zu queries, expected %d", P.queries.size(), prm.num_queries);
+
+  // ---- queries
+  size_t max_w = 1;
+  for (auto& r : rounds) for (auto& m : r) max_w = std::max(max_w, (size_t)m.w);
+  std::vector<E> fa_pow(max_w + 1);
+  fa_pow[0] = E::one();
+  for (size_t c = 1; c <= max_w; ++c) fa_pow[c] = fa_pow[c - 1] * fri_alpha;
+  for (size_t qi = 0; qi < P.queries.size(); ++qi) {
+    const auto& Q = P.queries[qi];
+    const size_t index = ch.sample_bits(log_max);
+    if (Q.rounds.size() != rounds.size()) vfail("query %zu: %zu input batches, expected %zu", qi, Q.rounds.size(), rounds.size());
+    // reduced openings per height, alpha powers restart per height (pcs/fri/verifier.rs:1068-1356)
+    std::map<int, std::pair<E, E>> ro;  // log_h -> (next alpha power, value)
+    for (size_t r = 0; r < rounds.size(); ++r) {
+      std::vector<int> lhs;
+      for (auto& m : rounds[r]) lhs.push_back(m.log_h);
+      int r_max = 0;
+      for (int x : lhs) r_max = std::max(r_max, x);
+      const auto& qr = Q.rounds[r];
+      if (qr.rows.size() != rounds[r].size()) vfail("query %zu: batch %zu opens %zu matrices, expected %zu", qi, r, qr.rows.size(), rounds[r].size());
+      for (size_t m = 0; m < rounds[r].size(); ++m)
+        if (qr.rows[m].size() != (size_t)rounds[r][m].w) vfail("query %zu: batch %zu matrix %zu has the wrong width", qi, r, m);
+      mmcs_verify<PP>(*round_caps[r], cap_h, lhs, qr.rows, index >> (log_max - r_max), qr.path, rc.data(), "input batch");
+      for (size_t m = 0; m < rounds[r].size(); ++m) {
+        const Mat& M = rounds[r][m];
+        auto it = ro.find(M.log_h);
+        if (it == ro.end()) it = ro.emplace(M.log_h, std::make_pair(E::one(), E::zero())).first;
+        const size_t ridx = index >> (log_max - M.log_h);
+        const F x = gen * F::two_adic_generator(M.log_h).pow(bit_reverse((uint32_t)ridx, M.log_h));  // verifier.rs:921-981
+        E S = E::zero();
+        for (int c = 0; c < M.w; ++c) S += fa_pow[c] * qr.rows[m][c];
+        for (size_t p = 0; p < M.z.size(); ++p) {
+          E Vp = E::zero();
+          for (int c = 0; c < M.w; ++c) Vp += fa_pow[c] * (*M.vals[p])[c];
+          it->second.second += it->second.first * (Vp - S) * (M.z[p] - E::from_base(x)).inv();
+          it->second.first *= fa_pow[M.w];
+        }
+      }
+    }
+    // fold chain (pcs/fri/verifier.rs:562-781)
+    if (Q.phases.size() != las.size()) vfail("query %zu: %zu commit-phase openings, expected %zu", qi, Q.phases.size(), las.size());
+    if (!ro.count(log_max)) vfail("query %zu: no reduced opening at the maximum height", qi);
+    E folded = ro[log_max].second;
+    size_t idx = index;
+    int cur = log_max;
+    const F neg_half = -(F::from_canonical(2).inv());
+    for (size_t p = 0; p < las.size(); ++p) {
+      const auto& ph = Q.phases[p];
+      const int la = las[p];
+      const size_t arity = size_t(1) << la, pos = idx & (arity - 1), row = idx >> la;
+      if (ph.la != la || ph.sibs.size() != arity - 1) vfail("query %zu phase %zu: wrong arity", qi, p);
+      std::vector<E> e(arity);
+      for (size_t j = 0, s = 0; j < arity; ++j) e[j] = j == pos ? folded : ph.sibs[s++];
+      // the leaf is the row of 2^la sibling evaluations, extension elements flattened
+      std::vector<F> leaf;
+      for (auto& x : e) for (int k = 0; k < 4; ++k) leaf.push_back(x.c[k]);
+      mmcs_verify<PP>(P.commit_caps[p], cap_h, {cur - la}, {leaf}, row, ph.path, rc.data(), "FRI commit phase");
+      F ss_inv = F::two_adic_generator(cur).inv().pow(bit_reverse((uint32_t)row, cur - la));
+      E b = betas[p];
+      const F omega = F::two_adic_generator(la);
+      size_t len = arity;
+      for (int s = 0; s < la; ++s) {
+        const F om_s = omega.pow(uint64_t(1) << s);
+        for (size_t j = 0; j < len / 2; ++j) {
+          const F x0_inv = ss_inv * om_s.pow(bit_reverse((uint32_t)(2 * j), la - s)).inv();
+          const E t = b * x0_inv - E::one();  // arity2_fold_at_point: e0 + (beta - x0)(e1 - e0)(-1/2)/x0
+          e[j] = e[2 * j] + t * (e[2 * j + 1] - e[2 * j]) * neg_half;
+        }
+        len /= 2;
+        ss_inv = ss_inv.sqr();
+        b = b.sqr();
+      }
+      folded = e[0];
+      cur -= la;
+      idx = row;
+      auto it = ro.find(cur);
+      if (it != ro.end() && cur != log_max) folded += betas[p].pow(arity) * it->second.second;  // roll-in
+    }
+    // final polynomial at x = w^{bitrev(idx)} of the size-2^cur domain (verifier.rs:887-915)
+    const F x = F::two_adic_generator(cur).pow(bit_reverse((uint32_t)idx, cur));
+    E eval = E::zero();
+    for (size_t k = P.final_poly.size(); k-- > 0;) eval = eval * x + P.final_poly[k];
+    if (!(eval == folded)) vfail("query %zu: final polynomial mismatch", qi);
+  }
+}
+
+}  // namespace p3r

@@ -35,6 +35,50 @@ def _u8(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_uint8))
 
 
+def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5,
+                commit_pow_bits=0, query_pow_bits=15, num_queries=54, device=0, poseidon2_rc=None):
+    """A `p3r_config` (+ the array it points into, which must stay alive with it)."""
+    cfg = _lib.P3rConfig()
+    cfg.abi_version = _lib.P3R_ABI_VERSION
+    cfg.field = FIELD_IDS[field]
+    cfg.ext_degree = 4
+    cfg.log_blowup = log_blowup
+    cfg.max_log_arity = max_log_arity
+    cfg.cap_height = cap_height
+    cfg.log_final_poly_len = log_final_poly_len
+    cfg.commit_pow_bits = commit_pow_bits
+    cfg.query_pow_bits = query_pow_bits
+    cfg.num_queries = num_queries
+    cfg.device = device
+    rc = None
+    if poseidon2_rc is not None:
+        rc, ptr = _u32(poseidon2_rc)
+        cfg.poseidon2_rc = ptr
+        cfg.poseidon2_rc_len = rc.size
+    return cfg, rc
+
+
+def verify_batch(cfg, airs, preprocessed_commitment, proof: bytes, canonical_field_encoding=False):
+    """`verify_batch` behind `verify_all_tables` (batch_stark_prover.rs:1649-1727): host code in the
+    C-ABI library, no GPU needed.  `cfg` is a `p3r_config` (e.g. `Context.cfg`), `airs` a list of
+    dicts(kind, lanes, horner_packed_steps, coeff_lookups).  Raises P3rError with the verifier's
+    reason when the proof is rejected."""
+    lib = _lib.load()
+    arr = (_lib.P3rAirDesc * len(airs))()
+    for i, a in enumerate(airs):
+        arr[i].kind, arr[i].lanes = a["kind"], a.get("lanes", 1)
+        arr[i].horner_packed_steps, arr[i].coeff_lookups = a.get("horner_packed_steps", 2), a.get("coeff_lookups", 0)
+    cap, cap_p = _u32(preprocessed_commitment)
+    if cap.size != 8 << cfg.cap_height:
+        raise P3rError(-1, "preprocessed commitment must hold %d digests" % (1 << cfg.cap_height))
+    buf = (C.c_uint8 * max(len(proof), 1)).from_buffer_copy(proof if proof else b"\0")
+    err = C.create_string_buffer(512)
+    rc = lib.p3r_verify_batch(C.byref(cfg), arr, len(airs), cap_p, buf, len(proof), 1 if canonical_field_encoding else 0,
+                              err, len(err))
+    if rc != 0:
+        raise P3rError(rc, err.value.decode())
+
+
 class Context:
     """One per GPU; not thread-safe; one call in flight (include/p3r.h)."""
 
@@ -44,22 +88,8 @@ class Context:
         self.lib = _lib.load()
         self.field = field
         self.p = MODULUS[field]
-        cfg = _lib.P3rConfig()
-        cfg.abi_version = _lib.P3R_ABI_VERSION
-        cfg.field = FIELD_IDS[field]
-        cfg.ext_degree = 4
-        cfg.log_blowup = log_blowup
-        cfg.max_log_arity = max_log_arity
-        cfg.cap_height = cap_height
-        cfg.log_final_poly_len = log_final_poly_len
-        cfg.commit_pow_bits = commit_pow_bits
-        cfg.query_pow_bits = query_pow_bits
-        cfg.num_queries = num_queries
-        cfg.device = device
-        if poseidon2_rc is not None:
-            rc, ptr = _u32(poseidon2_rc)
-            cfg.poseidon2_rc = ptr
-            cfg.poseidon2_rc_len = rc.size
+        cfg, self._rc_keep = make_config(field, log_blowup, max_log_arity, cap_height, log_final_poly_len,
+                                         commit_pow_bits, query_pow_bits, num_queries, device, poseidon2_rc)
         self.cfg = cfg
         self.cap_height = cap_height
         self.log_blowup = log_blowup

@@ -29,7 +29,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from .device import Context, DeviceMatrix, P3rError, _u32, _u8
+from .device import Context, DeviceMatrix, P3rError, _u32, _u8, make_config, verify_batch
 
 
 @dataclass
@@ -274,6 +274,40 @@ class BatchStarkProof:
     def _fe(self, x: int) -> bytes:
         return _varint((x << 32) % self.modulus if self.monty_r else x)
 
+    def validate(self):
+        """Structural invariants `#[derive(Deserialize)]` can bypass (batch_stark_prover.rs:666-681,
+        RowCounts :459-480, packing.rs:140-161, NonPrimitiveTableEntry :272-300)."""
+        if self.ext_degree not in (1, 2, 4, 5, 6, 8):
+            raise P3rError(-1, "UnsupportedExtDegree(%d)" % self.ext_degree)
+        if len(self.rows) != 3 or any(int(r) < 0 for r in self.rows):
+            raise P3rError(-1, "bad RowCounts")
+        tp = self.table_packing
+        if tp.public_lanes == 0:
+            raise P3rError(-1, 'ZeroLanes("public_lanes")')
+        if tp.alu_lanes == 0:
+            raise P3rError(-1, 'ZeroLanes("alu_lanes")')
+        for e in self.non_primitives:
+            if e.lanes == 0:
+                raise P3rError(-1, "ZeroNpoLanes(%s)" % e.op_type)
+        if tp.min_trace_height == 0 or tp.min_trace_height & (tp.min_trace_height - 1):
+            raise P3rError(-1, "BadMinTraceHeight(%d)" % tp.min_trace_height)
+        if tp.horner_packed_steps < 2:
+            raise P3rError(-1, "BadHornerPackedSteps(%d)" % tp.horner_packed_steps)
+
+    def airs(self):
+        """The proved tables in instance order, from the metadata the proof carries."""
+        tp = self.table_packing
+        out = [dict(kind=0, lanes=1), dict(kind=1, lanes=tp.public_lanes),
+               dict(kind=2, lanes=tp.alu_lanes, horner_packed_steps=tp.horner_packed_steps)]
+        for e in self.non_primitives:
+            if e.op_type.startswith("poseidon2_perm/"):
+                out.append(dict(kind=3, lanes=1))
+            elif e.op_type == "recompose":
+                out.append(dict(kind=4, lanes=e.lanes))
+            else:
+                raise P3rError(-5, "MissingTableProver(%s)" % e.op_type)
+        return out
+
     def to_postcard(self) -> bytes:
         """postcard bytes of the whole `BatchStarkProof<SC>`, field order = the serde derives of
         batch_stark_prover.rs:610-636, packing.rs:9-27, :459-460 (RowCounts), :272-290,
@@ -319,6 +353,15 @@ class BatchStarkProof:
 W_BINOMIAL = {"koala-bear": 3, "baby-bear": 11}
 
 
+def verify_all_tables(cfg, proof: BatchStarkProof, canonical_field_encoding=None):
+    """Verify a `BatchStarkProof` against the preprocessed commitment it binds itself to
+    (stark_common); `cfg` is the `p3r_config` the proof was made with.  No GPU needed."""
+    if proof.preprocessed_commitment is None:
+        raise P3rError(-1, "proof carries no preprocessed commitment (stark_common)")
+    canonical = (proof.monty_r == 0) if canonical_field_encoding is None else canonical_field_encoding
+    verify_batch(cfg, proof.airs(), proof.preprocessed_commitment, proof.proof, canonical)
+
+
 class BatchStarkProver:
     def __init__(self, ctx: Context, table_packing: Optional[TablePacking] = None):
         self.ctx = ctx
@@ -361,6 +404,13 @@ class BatchStarkProver:
             preprocessed_widths=tuple(w for w, ok in zip(prep_widths, present) if ok),
             degree_bits=tuple(int(h).bit_length() - 1 for h in cpd.table_heights if h > 0),
             monty_r=0 if canonical_field_encoding else 1, modulus=ctx.p)
+
+    def verify_all_tables(self, proof: BatchStarkProof, canonical_field_encoding=None):
+        """circuit-prover/src/batch_stark_prover.rs:1230-1268: re-check the proof metadata, rebuild the
+        AIR list from it and run `verify_batch` (native host code, include/p3r.h).  Raises P3rError
+        with the reason on rejection."""
+        proof.validate()
+        verify_all_tables(self.ctx.cfg, proof, canonical_field_encoding)
 
     def build_main_trace(self, resident: ResidentTraces, cpd: CircuitProverData, table: int) -> DeviceMatrix:
         return DeviceMatrix(self.ctx, self.ctx.ptr(

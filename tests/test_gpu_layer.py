@@ -136,3 +136,31 @@ def test_absent_tables_and_dummy_lane_reduction(oracle, flags):
     res.free()
     cpd.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("field,log_h,kw,packing", CASES[:3])
+def test_prove_then_verify_all_tables_natively(oracle, field, log_h, kw, packing):
+    """The reference's own test pattern (prove_all_tables -> verify_all_tables,
+    circuit-prover/src/batch_stark_prover/tests.rs) with the product's native verifier; a tampered
+    proof and tampered metadata are rejected."""
+    import dataclasses
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    arrs, L, ctx, cache, traces = setup(oracle, field, log_h, kw, packing)
+    proof = cache.prover.prove_all_tables(traces, cache.circuit_prover_data)
+    cache.prover.verify_all_tables(proof)
+    canon = cache.prover.prove_all_tables(traces, cache.circuit_prover_data, canonical_field_encoding=True)
+    cache.prover.verify_all_tables(canon)
+    p3r.verify_all_tables(ctx.cfg, proof)   # free function: no prover object, no GPU work
+    bad = bytearray(proof.proof)
+    bad[len(bad) // 2] ^= 2
+    with pytest.raises(p3r.P3rError):
+        cache.prover.verify_all_tables(dataclasses.replace(proof, proof=bytes(bad)))
+    with pytest.raises(p3r.P3rError, match="BadHornerPackedSteps"):
+        cache.prover.verify_all_tables(dataclasses.replace(
+            proof, table_packing=dataclasses.replace(proof.table_packing, horner_packed_steps=1)))
+    with pytest.raises(p3r.P3rError):   # a different lane count is a different statement
+        cache.prover.verify_all_tables(dataclasses.replace(
+            proof, table_packing=dataclasses.replace(proof.table_packing, alu_lanes=proof.table_packing.alu_lanes + 1)))
+    cache.circuit_prover_data.free()
+    ctx.close()
