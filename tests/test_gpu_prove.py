@@ -67,7 +67,9 @@ def test_prove_rejects_unsatisfied_trace(oracle):
     ctx = make_ctx(field, prm)
     cap, pd = ctx.prep_create(airs_of(tables), [t["prep"] for t in tables])
     mains = [t["main"].copy() for t in tables]
-    mains[2][3, 5] = (int(mains[2][3, 5]) + 1) % 0x7F000001  # break one ALU cell
+    # break the output of an Add op in lane 0 (preprocessed column 1 = sel_add): a + b != out
+    row = int(np.nonzero(tables[2]["prep"][:, 1] == 1)[0][0])
+    mains[2][row, 12] = (int(mains[2][row, 12]) + 1) % 0x7F000001
     bad = ctx.prove_batch(pd, mains)
     with pytest.raises(RuntimeError):
         L.verify(bad)
