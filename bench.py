@@ -134,10 +134,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # P3R_BENCH_BACKEND=gloo exercises the multi-rank path where the ranks cannot have a GPU each
+    # (several ranks share device 0); the driver's runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("P3R_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     field, log_h = args.field, args.log_height
     ctx = p3r.Context(field=field, device=local_rank, **FRI)
@@ -174,7 +183,7 @@ def main():
         try:
             from plonky3_recursion_amd.aggregation import gather_proofs_to_root
             h0 = time.perf_counter()
-            got = gather_proofs_to_root(last_proof, dist, rank, world, device=torch.device("cuda", local_rank))
+            got = gather_proofs_to_root(last_proof, dist, rank, world, device=coll_device)
             torch.cuda.synchronize()
             handoff_ms = (time.perf_counter() - h0) * 1e3
             if rank == 0:
@@ -191,7 +200,7 @@ def main():
     ctx.profile_enable(False)
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

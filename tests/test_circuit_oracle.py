@@ -118,3 +118,25 @@ def test_runner_error_paths(oracle):
     # UnclaimedPrivateInput at preprocessing (circuit.rs:497-503)
     with pytest.raises(RuntimeError, match="UnclaimedPrivateInput"):
         cl.OracleCircuit(oracle, cl.Circuit(5, ops, ext, [2], [4])).preprocess(0x7F000001)
+
+
+@pytest.mark.parametrize("case", GOLD["table_matrices"], ids=lambda c: c["source"].split()[1])
+def test_const_public_matrices_match_reference_unit_tests(oracle, case):
+    """ConstAir / PublicAir trace_to_matrix + preprocessed_trace for D = 4 (reference literals)."""
+    z32 = np.zeros(0, np.uint32)
+    vals = np.array(case["values"], np.uint32).reshape(-1)
+    prep = np.array(case["prep"], np.uint32).reshape(-1)
+    n = len(case["values"])
+    is_const = case["table"] == "const"
+    one_const = (np.array([0, 0, 0, 0], np.uint32), np.array([0, 0], np.uint32))
+    arrs = {k: z32 for k in harness_lib.ARRAYS}
+    arrs.update(const_values=vals if is_const else one_const[0], const_prep=prep if is_const else one_const[1],
+                public_values=z32 if is_const else vals, public_prep=z32 if is_const else prep,
+                alu_values=np.zeros(16, np.uint32), alu_prep13=np.zeros(13, np.uint32),
+                counts=np.array([n if is_const else 1, 0 if is_const else n, 1, 0, 0, 0], np.uint32))
+    prm = layer_lib.params(log_blowup=1, max_log_arity=1, log_final_poly_len=0, query_pow_bits=0, num_queries=1)
+    L = layer_lib.OracleLayer(oracle, "baby-bear", arrs, prm,
+                              packing=dict(public_lanes=case["lanes"], min_trace_height=case["min_trace_height"]))
+    t = {x["kind"]: x for x in L.tables()}[case["table"]]
+    assert t["main"].tolist() == case["expect_main"]
+    assert t["prep"].tolist() == case["expect_prep"]
