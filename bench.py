@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--log-height", type=int, default=20)
     ap.add_argument("--field", default="koala-bear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-log-height", type=int, default=11)
+    ap.add_argument("--cpu-baseline-log-height", type=int, default=13)
     args = ap.parse_args()
 
     import torch
