@@ -45,12 +45,13 @@ def workload_model(field, heights, widths, packing):
     aux = lookup_aux_widths(packing.alu_lanes, packing.horner_packed_steps)
     B = 1 << FRI["log_blowup"]
     perms = heights[3]  # K3: one per Poseidon2-table row
-    hash_cells = 0
+    hash_cells = 0      # k_mmcs_hash_rows only (the committed LDEs); FRI leaves use the strided variant
     hash_rows = 0
     hash_perms = 0
+    hash_launches = 0
 
     def commit(mats):
-        nonlocal perms, hash_cells, hash_rows, hash_perms
+        nonlocal perms, hash_cells, hash_rows, hash_perms, hash_launches
         by_h = {}
         for h, w in mats:
             by_h[h] = by_h.get(h, 0) + w
@@ -60,6 +61,7 @@ def workload_model(field, heights, widths, packing):
             hash_perms += h * ((w + 7) // 8)
             hash_cells += h * w
             hash_rows += h
+            hash_launches += 1
             if h != hmax:
                 perms += h
         perms += hmax - 1
@@ -74,11 +76,8 @@ def workload_model(field, heights, widths, packing):
         la = min(FRI["max_log_arity"], (h // final).bit_length() - 1)
         rows = h >> la
         perms += rows * (((4 << la) + 7) // 8) + rows - 1
-        hash_perms += rows * (((4 << la) + 7) // 8)
-        hash_cells += rows * (4 << la)
-        hash_rows += rows
         h = rows
-    return perms, hash_perms, 4 * hash_cells + 32 * hash_rows
+    return perms, hash_perms, 4 * hash_cells + 32 * hash_rows, hash_launches
 
 
 def pmc_traffic_bytes(kernel):
@@ -87,7 +86,11 @@ def pmc_traffic_bytes(kernel):
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
             k = json.load(fh)["kernels"][kernel]
-        return (k["fetch_kb_per_launch"] + k["write_kb_per_launch"]) * 1024.0
+        # gfx950: FETCH_SIZE tallies the 128-B requests of a coalesced streaming read at 64 B
+        # (/opt/skills/guides/MI355X_MICROARCH.md, HBM section) - doubled before comparing with bytes.
+        # Calibration on this access pattern (4 B per lane, every LDE cell read exactly once):
+        # reported 161 MB against 332 MB that must be read per launch = 0.49.
+        return (2.0 * k["fetch_kb_per_launch"] + k["write_kb_per_launch"]) * 1024.0
     except Exception:
         return None
 
@@ -210,12 +213,15 @@ def main():
         k = packing.horner_packed_steps
         widths = [4, 4 * packing.public_lanes, 16 * packing.alu_lanes + ((k - 1) // 2 + 2 * (k - 1) + 1) * 4, p2w,
                   4 * packing.recompose_lanes]
-        perms, hash_perms, hash_bytes = workload_model(field, cpd.table_heights, widths, packing)
+        perms, hash_perms, hash_bytes, model_launches = workload_model(field, cpd.table_heights, widths, packing)
         kernel_ms = {kk: v[0] / prof_steps for kk, v in prof.items() if not kk.startswith("stage:")}
         stage_ms = {kk[6:]: v[0] / prof_steps for kk, v in prof.items() if kk.startswith("stage:")}
         dominant = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
         hash_ms, hash_launches = prof.get("mmcs_hash_rows", (0.0, 0))
         launches_per_step = hash_launches / prof_steps
+        if launches_per_step != model_launches:
+            print(f"bench: {launches_per_step} k_mmcs_hash_rows launches per step, the model expects {model_launches}",
+                  file=sys.stderr)
         avg_launch_ms = hash_ms / hash_launches if hash_launches else float("nan")
         achieved = (hash_bytes / launches_per_step) / (avg_launch_ms * 1e-3) / 1e9 if hash_launches else None
         line = {
@@ -249,7 +255,7 @@ def main():
             "stage_wall_ms_per_step": stage_ms,
             "dominant_kernel_family": dominant,
             "roofline": {
-                "kernel": "k_mmcs_hash_rows (+ strided variant)",
+                "kernel": "k_mmcs_hash_rows",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -257,7 +263,8 @@ def main():
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": pmc_traffic_bytes("k_mmcs_hash_rows") if (field, log_h) == ("koala-bear", 20) else None,
                 "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "same command; bytes per launch)",
+                                  "same command; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of "
+                                  "the microarchitecture guide)",
                 "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": hash_bytes / launches_per_step if launches_per_step else None,
                 "note": "MMCS leaf hashing is integer-VALU bound (one Poseidon2 permutation per 32 B absorbed), "
@@ -272,7 +279,7 @@ def main():
         if field == "koala-bear" and hash_total_ms:
             peak = 54.5e12 / 9.0e3
             ach = hash_perms / (hash_total_ms * 1e-3)
-            line["valu_roofline"] = {"kernel": "k_mmcs_hash_rows (+ strided variant)", "bound": "int-valu",
+            line["valu_roofline"] = {"kernel": "k_mmcs_hash_rows", "bound": "int-valu",
                                      "achieved": ach, "peak": peak, "unit": "Poseidon2 perms/s", "frac": ach / peak,
                                      "perms_per_step_in_kernel": hash_perms}
         if not args.no_cpu_baseline and world == 1:

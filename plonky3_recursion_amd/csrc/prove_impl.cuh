@@ -457,7 +457,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       const uint32_t** dcols = reinterpret_cast<const uint32_t**>(dcols_buf.p);
       P3R_HIP(copy_sync(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice));
       {
-        ProfScope ps(ctx, "mmcs_hash_rows");
+        ProfScope ps(ctx, "mmcs_hash_rows_strided");
         hipLaunchKernelGGL(k_mmcs_hash_rows_strided<PP>, dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream,
                            (const uint32_t* const*)dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p,
                            ctx->rc.p);
