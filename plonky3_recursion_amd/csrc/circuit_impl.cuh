@@ -47,6 +47,9 @@ inline bool op_is_alu(uint32_t k) { return k >= P3R_OP_ALU_ADD && k <= P3R_OP_AL
 
 inline void validate_circuit(const HostCircuit& c) {
   const uint32_t nw = c.witness_count;
+  // bit 31 of a stored witness id and the top bits of the error word are used as flags
+  if (nw >= (1u << 31)) fail(P3R_EINVAL, "witness_count %u is too large", nw);
+  if (c.ops.size() >= (size_t(1) << 28)) fail(P3R_EINVAL, "%zu ops is too many", c.ops.size());
   auto wid = [&](uint32_t w, size_t i, const char* what) {
     if (w >= nw) fail(P3R_EINVAL, "op %zu: %s witness %u out of bounds (witness_count %u)", i, what, w, nw);
   };
@@ -84,10 +87,12 @@ inline void validate_circuit(const HostCircuit& c) {
         for (uint32_t k = 0; k < e[6]; ++k) opt(e[7 + k], i, "poseidon2 output");
         if ((op.aux & 2) && e[5] == kNoW)
           fail(P3R_EINVAL, "op %zu: mmcs_bit must be provided when merkle_path=true", i);
+        if (op.a >= c.ops.size()) fail(P3R_EINVAL, "op %zu: NonPrimitiveOpId(%u) out of range", i, op.a);
         break;
       }
       case P3R_OP_RECOMPOSE:
         wid(op.out, i, "out");
+        if (op.a >= c.ops.size()) fail(P3R_EINVAL, "op %zu: NonPrimitiveOpId(%u) out of range", i, op.a);
         if (op.ext_len != 4) fail(P3R_EINVAL, "op %zu: recompose expects 1 input group with 4 witnesses", i);
         for (uint32_t k = 0; k < 4; ++k) wid(e[k], i, "coefficient");
         break;
@@ -457,14 +462,16 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
   uint32_t max_level = 0;
   for (auto& t : order) max_level = std::max(max_level, t.level);
   for (auto& ch : chains) max_level = std::max(max_level, ch.level);
+  std::unordered_map<uint32_t, uint32_t> canon_of;
+  for (size_t k = 0; k + 1 < c.rewrite.size(); k += 2) canon_of.emplace(c.rewrite[k], c.rewrite[k + 1]);
   for (size_t k = 0; k + 1 < c.rewrite.size(); k += 2) {
     const uint32_t dup = c.rewrite[k];
     uint32_t cur = c.rewrite[k + 1];
-    for (size_t guard = 0; guard <= c.rewrite.size(); ++guard) {
-      bool moved = false;
-      for (size_t j = 0; j + 1 < c.rewrite.size(); j += 2)
-        if (c.rewrite[j] == cur) { cur = c.rewrite[j + 1]; moved = true; break; }
-      if (!moved) break;
+    // follow the chain to its root (WitnessId::resolve, circuit/src/types.rs:20-27); a cycle never ends there either
+    for (size_t hops = 0; hops <= canon_of.size(); ++hops) {
+      auto it = canon_of.find(cur);
+      if (it == canon_of.end()) break;
+      cur = it->second;
     }
     if (!set[cur]) continue;
     S.rewrite_pairs.insert(S.rewrite_pairs.end(), {dup, cur, (uint32_t)set[dup]});

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <unordered_map>
 
 using namespace p3r;
 
