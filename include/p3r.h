@@ -295,6 +295,11 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
                      const uint32_t* preprocessed_commitment, const uint8_t* proof, size_t proof_len, uint32_t flags,
                      char* err_buf, size_t err_cap);
 
+/* Length of the postcard-encoded `BatchProof` at the head of `bytes` (what p3r_prove_* return; the
+ * serialised `BatchStarkProof` continues with its metadata, batch_stark_prover.rs:610-636). */
+int p3r_batch_proof_len(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags, size_t* proof_len,
+                        char* err_buf, size_t err_cap);
+
 /* ---- the caller side of prove_next_layer: the circuit itself ------------------------------------
  * `prove_next_layer` (recursion/src/recursion.rs:401-502) receives a `Circuit<EF>`, sets its public
  * inputs and the Merkle-sibling private data, RUNS it (`CircuitRunner::run`,

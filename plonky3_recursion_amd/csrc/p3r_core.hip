@@ -890,6 +890,21 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
   }
 }
 
+int p3r_batch_proof_len(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags, size_t* proof_len,
+                        char* err_buf, size_t err_cap) {
+  try {
+    if (!bytes || !proof_len) throw std::runtime_error("NULL argument");
+    const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
+    if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len);
+    else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len);
+    else throw std::runtime_error("unknown field");
+    return P3R_OK;
+  } catch (const std::exception& e) {
+    if (err_buf && err_cap) snprintf(err_buf, err_cap, "%s", e.what());
+    return P3R_EINVAL;
+  }
+}
+
 // ---- circuit boundary (circuit_impl.cuh) ----
 p3r_circuit* p3r_circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* desc, uint32_t* commit_out) {
   p3r_circuit* out = nullptr;

@@ -109,8 +109,10 @@ struct ParsedProof {
   std::vector<int> degree_bits;
 };
 
+// `consumed`: when given, trailing bytes are allowed and the length of the BatchProof is returned
+// (the outer BatchStarkProof appends its metadata after it, batch_stark_prover.rs:610-636).
 template <class PP>
-ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical) {
+ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size_t* consumed = nullptr) {
   ProofReader<PP> R{bytes, bytes + n, canonical};
   ParsedProof<PP> P;
   P.main_cap = R.cap();
@@ -163,7 +165,8 @@ ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical) {
     if (R.byte()) t = R.ef();
   P.degree_bits.resize(R.len(64));
   for (auto& d : P.degree_bits) d = (int)R.len(40);
-  if (R.p != R.end) vfail("%zu trailing bytes after the proof", (size_t)(R.end - R.p));
+  if (consumed) *consumed = (size_t)(R.p - bytes);
+  else if (R.p != R.end) vfail("%zu trailing bytes after the proof", (size_t)(R.end - R.p));
   return P;
 }
 

@@ -308,6 +308,91 @@ class BatchStarkProof:
                 raise P3rError(-5, "MissingTableProver(%s)" % e.op_type)
         return out
 
+    @classmethod
+    def from_postcard(cls, data: bytes, field: str, canonical_field_encoding=False) -> "BatchStarkProof":
+        """Inverse of `to_postcard`: the inner `BatchProof` is delimited with the C-ABI parser
+        (p3r_batch_proof_len), the metadata that follows is decoded here and `validate()`d."""
+        from .device import FIELD_IDS, MODULUS
+        lib = _lib.load()
+        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+        n, err = C.c_size_t(), C.create_string_buffer(256)
+        rc = lib.p3r_batch_proof_len(FIELD_IDS[field], buf, len(data), 1 if canonical_field_encoding else 0,
+                                     C.byref(n), err, len(err))
+        if rc != 0:
+            raise P3rError(rc, err.value.decode())
+        p, pos = MODULUS[field], [n.value]
+        r_inv = pow(1 << 32, -1, p)
+
+        def byte():
+            if pos[0] >= len(data):
+                raise P3rError(-1, "proof metadata truncated")
+            pos[0] += 1
+            return data[pos[0] - 1]
+
+        def varint():
+            v = shift = 0
+            while True:
+                b = byte()
+                v |= (b & 0x7F) << shift
+                if not b & 0x80:
+                    return v
+                shift += 7
+                if shift > 63:
+                    raise P3rError(-1, "malformed varint")
+
+        def fe():
+            v = varint()
+            if v >= p:
+                raise P3rError(-1, "field element out of range")
+            return v if canonical_field_encoding else v * r_inv % p
+
+        def string():
+            k = varint()
+            if pos[0] + k > len(data):
+                raise P3rError(-1, "proof metadata truncated")
+            pos[0] += k
+            return data[pos[0] - k:pos[0]].decode()
+
+        public_lanes, alu_lanes = varint(), varint()
+        npo_lanes = {}
+        for _ in range(varint()):
+            name = string()
+            npo_lanes[name] = varint()
+        min_h, horner_k = varint(), varint()
+        rows = (varint(), varint(), varint())
+        alu_variant, ext_degree = varint(), varint()
+        w_binomial = fe() if byte() else None
+        quintic = bool(byte())
+        entries = []
+        for _ in range(varint()):
+            op_type, n_rows, lanes = string(), varint(), varint()
+            pv = tuple(fe() for _ in range(varint()))
+            entries.append(NonPrimitiveTableEntry(op_type=op_type, rows=n_rows, lanes=lanes, public_values=pv,
+                                                  air_variant=varint()))
+        commitment, widths, degree_bits = None, (), ()
+        if byte():
+            commitment = np.array([[fe() for _ in range(8)] for _ in range(varint())], dtype=np.uint32)
+            widths, degree_bits = [], []
+            for _ in range(varint()):
+                if byte():
+                    varint()          # matrix index
+                    widths.append(varint())
+                    degree_bits.append(varint())
+            for _ in range(varint()):
+                varint()              # matrix_to_instance
+        if pos[0] != len(data):
+            raise P3rError(-1, "%d trailing bytes after the proof metadata" % (len(data) - pos[0]))
+        recompose_lanes = next((e.lanes for e in entries if e.op_type == "recompose"), npo_lanes.get("recompose", 1))
+        out = cls(proof=data[:n.value],
+                  table_packing=TablePacking(public_lanes=public_lanes, alu_lanes=alu_lanes, horner_packed_steps=horner_k,
+                                             recompose_lanes=recompose_lanes, min_trace_height=min_h),
+                  rows=rows, alu_variant=alu_variant, ext_degree=ext_degree, w_binomial=w_binomial,
+                  alu_quintic_trinomial=quintic, non_primitives=tuple(entries), preprocessed_commitment=commitment,
+                  preprocessed_widths=tuple(widths), degree_bits=tuple(degree_bits),
+                  monty_r=0 if canonical_field_encoding else 1, modulus=p)
+        out.validate()
+        return out
+
     def to_postcard(self) -> bytes:
         """postcard bytes of the whole `BatchStarkProof<SC>`, field order = the serde derives of
         batch_stark_prover.rs:610-636, packing.rs:9-27, :459-460 (RowCounts), :272-290,

@@ -91,3 +91,44 @@ def test_native_verifier_rejects_unsatisfied_trace_and_unbalanced_lookup(oracle)
         prm, tables, cap, proof = corrupt_and_prove(oracle, mutate)
         with pytest.raises(p3r.P3rError, match=why):
             verify("koala-bear", prm, tables, cap, proof)
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_batch_stark_proof_wire_round_trip_and_verify(oracle, canonical):
+    """BatchStarkProof -> postcard bytes -> BatchStarkProof (metadata validated,
+    batch_stark_prover.rs:666-681) -> verify_all_tables, with the inner BatchProof made by the oracle."""
+    import dataclasses
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    field = "koala-bear"
+    arrs = harness_lib.generate(field, 6, seed=8, **SMALL)
+    prm = layer_lib.params(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+    packing = dict(public_lanes=2, alu_lanes=3, horner_packed_steps=4, recompose_lanes=2)
+    L = layer_lib.OracleLayer(oracle, field, arrs, prm, packing=packing)
+    tables, cap = L.tables(), L.prep_commit()
+    inner = L.prove(field_encoding=1 if canonical else 0)
+    tp = pv.TablePacking(min_trace_height=layer_lib.min_trace_height(prm), **packing)
+    counts = [int(x) for x in arrs["counts"]]
+    proof = pv.BatchStarkProof(
+        proof=inner, table_packing=tp, rows=tuple(counts[:3]), w_binomial=3,
+        non_primitives=(pv.NonPrimitiveTableEntry("poseidon2_perm/koala_bear_d4_w16", tables[3]["main"].shape[0], 1),
+                        pv.NonPrimitiveTableEntry("recompose", counts[4], 2)),
+        preprocessed_commitment=cap, preprocessed_widths=tuple(t["prep"].shape[1] for t in tables),
+        degree_bits=tuple(t["main"].shape[0].bit_length() - 1 for t in tables),
+        monty_r=0 if canonical else 1, modulus=0x7F000001)
+    wire = proof.to_postcard()
+    back = pv.BatchStarkProof.from_postcard(wire, field, canonical_field_encoding=canonical)
+    assert back.proof == inner and back.to_postcard() == wire
+    assert back.table_packing == tp and back.rows == proof.rows and back.non_primitives == proof.non_primitives
+    assert np.array_equal(back.preprocessed_commitment, cap)
+    cfg, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries)
+    p3r.verify_all_tables(cfg, back)
+    # metadata tampering: a zero lane count is refused at decode time, trailing bytes too
+    bad_tp = dataclasses.replace(tp, alu_lanes=0)
+    with pytest.raises(p3r.P3rError, match="ZeroLanes"):
+        pv.BatchStarkProof.from_postcard(dataclasses.replace(proof, table_packing=bad_tp).to_postcard(), field, canonical)
+    with pytest.raises(p3r.P3rError, match="trailing"):
+        pv.BatchStarkProof.from_postcard(wire + b"\x00", field, canonical)
+    with pytest.raises(p3r.P3rError):
+        pv.BatchStarkProof.from_postcard(wire[:len(inner) + 3], field, canonical)
