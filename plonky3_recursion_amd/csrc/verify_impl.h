@@ -49,12 +49,20 @@ struct ProofReader {
     if (p >= end) vfail("proof truncated");
     return *p++;
   }
+  bool flag() {  // Option / bool tag: postcard admits 0 and 1 only
+    const uint8_t b = byte();
+    if (b > 1) vfail("invalid option tag %u", b);
+    return b != 0;
+  }
   uint64_t varint() {
     uint64_t v = 0;
     for (int shift = 0; shift < 64; shift += 7) {
       uint8_t b = byte();
       v |= (uint64_t)(b & 0x7F) << shift;
-      if (!(b & 0x80)) return v;
+      if (!(b & 0x80)) {
+        if (b == 0 && shift > 0) vfail("non-canonical varint");
+        return v;
+      }
     }
     vfail("malformed varint");
   }
@@ -116,20 +124,20 @@ ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size
   ProofReader<PP> R{bytes, bytes + n, canonical};
   ParsedProof<PP> P;
   P.main_cap = R.cap();
-  if (R.byte()) P.perm_cap = R.cap();
+  if (R.flag()) P.perm_cap = R.cap();
   P.quot_cap = R.cap();
-  if (R.byte()) vfail("proof carries a random (ZK) commitment: not supported");
+  if (R.flag()) vfail("proof carries a random (ZK) commitment: not supported");
   P.insts.resize(R.len(64));
   for (auto& in : P.insts) {
     in.main_local = R.vec_ef();
-    if (R.byte()) in.main_next = R.vec_ef();
-    if (!R.byte()) vfail("preprocessed_local missing");
+    if (R.flag()) in.main_next = R.vec_ef();
+    if (!R.flag()) vfail("preprocessed_local missing");
     in.prep_local = R.vec_ef();
-    if (!R.byte()) vfail("preprocessed_next missing");
+    if (!R.flag()) vfail("preprocessed_next missing");
     in.prep_next = R.vec_ef();
     in.chunks.resize(R.len(8));
     for (auto& c : in.chunks) c = R.vec_ef();
-    if (R.byte()) vfail("proof carries random opened values: not supported");
+    if (R.flag()) vfail("proof carries random opened values: not supported");
     in.perm_local = R.vec_ef();
     in.perm_next = R.vec_ef();
   }
@@ -162,7 +170,7 @@ ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size
   P.query_pow = R.fe();
   P.terminals.resize(R.len(64));
   for (auto& t : P.terminals)
-    if (R.byte()) t = R.ef();
+    if (R.flag()) t = R.ef();
   P.degree_bits.resize(R.len(64));
   for (auto& d : P.degree_bits) d = (int)R.len(40);
   if (consumed) *consumed = (size_t)(R.p - bytes);

@@ -132,3 +132,33 @@ def test_batch_stark_proof_wire_round_trip_and_verify(oracle, canonical):
         pv.BatchStarkProof.from_postcard(wire + b"\x00", field, canonical)
     with pytest.raises(p3r.P3rError):
         pv.BatchStarkProof.from_postcard(wire[:len(inner) + 3], field, canonical)
+
+
+def test_native_verifier_parser_survives_mutations(oracle):
+    """Random byte edits, truncations and insertions: always a clean rejection (bounded lengths,
+    strict option tags and varints), never an acceptance of different bytes."""
+    import random
+    import plonky3_recursion_amd as p3r
+    arrs = harness_lib.generate("koala-bear", 5, seed=8, horner_chain_len=8, sponge_chain_len=3, merkle_depth=3)
+    prm = layer_lib.params(log_blowup=1, max_log_arity=2, log_final_poly_len=0, query_pow_bits=2, num_queries=3)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm)
+    tables, cap, proof = L.tables(), L.prep_commit(), L.prove()
+    verify("koala-bear", prm, tables, cap, proof)
+    rng = random.Random(1)
+    for _ in range(600):
+        b = bytearray(proof)
+        k = rng.random()
+        if k < 0.4:
+            for _ in range(rng.randint(1, 4)):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+        elif k < 0.6:
+            b = b[:rng.randrange(len(b))]
+        elif k < 0.8:
+            i = rng.randrange(len(b))
+            b[i:i] = bytes(rng.randrange(256) for _ in range(rng.randint(1, 8)))
+        else:
+            b[rng.randrange(min(len(b), 400))] = 0xFF
+        if bytes(b) == proof:
+            continue
+        with pytest.raises(p3r.P3rError):
+            verify("koala-bear", prm, tables, cap, bytes(b))
