@@ -1,0 +1,112 @@
+// prove_next_layer from C++ through include/p3r.hpp: the shape of
+// recursion/examples/recursive_fibonacci.rs (build the prep cache once, prove layers against it,
+// verify) with the synthetic verifier circuit of harness/synth.cpp standing in for
+// build_next_layer_circuit, which is out of scope.
+//
+//   prove_next_layer <field: koala-bear|baby-bear> <log_height> <proof_out_file> [layers]
+//
+// Prints one line per layer; writes the postcard bytes of the inner BatchProof of the last layer.
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+#include "p3r.hpp"
+
+namespace {
+struct Synth {  // harness/libp3r_synth.so
+  void* lib;
+  void* (*generate)(int, int, uint64_t, int, int, int, const uint32_t*, uint32_t);
+  const char* (*error)(void*);
+  int (*get)(void*, const char*, const uint32_t**, size_t*);
+  void (*release)(void*);
+  explicit Synth(const std::string& path) {
+    lib = dlopen(path.c_str(), RTLD_NOW);
+    if (!lib) throw std::runtime_error(dlerror());
+    generate = reinterpret_cast<decltype(generate)>(dlsym(lib, "syn_generate"));
+    error = reinterpret_cast<decltype(error)>(dlsym(lib, "syn_error"));
+    get = reinterpret_cast<decltype(get)>(dlsym(lib, "syn_get"));
+    release = reinterpret_cast<decltype(release)>(dlsym(lib, "syn_free"));
+  }
+};
+std::vector<uint32_t> arr(const Synth& s, void* h, const char* name) {
+  const uint32_t* p = nullptr;
+  size_t n = 0;
+  if (s.get(h, name, &p, &n) != 0) return {};
+  return std::vector<uint32_t>(p, p + n);
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 4) { std::fprintf(stderr, "usage: %s <field> <log_height> <proof_out> [layers]\n", argv[0]); return 2; }
+  try {
+    const p3r::Field field = std::string(argv[1]) == "baby-bear" ? p3r::Field::BabyBear : p3r::Field::KoalaBear;
+    const int log_h = std::atoi(argv[2]);
+    const int layers = argc > 4 ? std::atoi(argv[4]) : 2;
+    std::string self = argv[0];
+    const std::string root = self.substr(0, self.rfind('/')) + "/..";
+
+    p3r::FriParams fri;  // the examples' defaults: blow-up 4, 54 queries, 15 bits of query PoW
+    p3r::Context ctx(field, fri);
+    std::vector<uint32_t> rc(p3r_poseidon2_num_constants(ctx.raw()));
+    ctx.check(p3r_poseidon2_round_constants(ctx.raw(), rc.data()));
+
+    // the verifier circuit + its inputs
+    Synth synth(root + "/harness/libp3r_synth.so");
+    void* w = synth.generate((int)field, log_h, 0x5EED0000, 64, 8, 20, rc.data(), 0);
+    if (*synth.error(w)) throw std::runtime_error(synth.error(w));
+    p3r::Circuit circuit;
+    circuit.witness_count = arr(synth, w, "counts")[5];
+    const auto ops = arr(synth, w, "ops");
+    circuit.ops.resize(ops.size() / 8);
+    std::memcpy(circuit.ops.data(), ops.data(), ops.size() * 4);
+    circuit.ext = arr(synth, w, "ext");
+    circuit.public_rows = arr(synth, w, "public_rows");
+    circuit.private_input_rows = arr(synth, w, "private_rows");
+    circuit.witness_rewrite = arr(synth, w, "rewrite");
+    p3r::CircuitInputs inputs{arr(synth, w, "in_public_values"), arr(synth, w, "in_private_values"), arr(synth, w, "pd_op_ids"),
+                              arr(synth, w, "pd_siblings")};
+    synth.release(w);
+
+    const p3r::FriRecursionBackend backend;
+    p3r::ProveNextLayerParams params;
+    params.table_packing = p3r::TablePacking::create(1, 3).with_fri_params(fri.log_final_poly_len, fri.log_blowup);
+    const size_t n_ops = circuit.ops.size();
+    auto t0 = std::chrono::steady_clock::now();
+    p3r::NextLayerPrepCache prep = p3r::build_next_layer_prep(ctx, std::move(circuit), backend, params);
+    ctx.sync();
+    std::printf("build_next_layer_prep: %zu ops, %zu schedule levels, %.1f ms\n", n_ops, prep.prepared_circuit->levels(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+
+    p3r::RecursionInput input;
+    input.circuit_inputs = &inputs;
+    p3r::RecursionOutput out;
+    for (int l = 0; l < layers; ++l) {
+      t0 = std::chrono::steady_clock::now();
+      out = p3r::prove_next_layer(input, ctx, backend, params, prep);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      prep.prover->verify_all_tables(out.proof);
+      std::printf("layer %d: prove_next_layer %.1f ms, proof %zu bytes (%zu with metadata), verify_all_tables ok\n", l, ms,
+                  out.proof.proof.size(), out.proof.to_postcard().size());
+    }
+    // negative checks: tampered bytes and tampered metadata are refused
+    p3r::BatchStarkProof bad = out.proof;
+    bad.proof[bad.proof.size() / 2] ^= 1;
+    bool rejected = false;
+    try { prep.prover->verify_all_tables(bad); } catch (const p3r::Error&) { rejected = true; }
+    if (!rejected) throw std::runtime_error("a tampered proof was accepted");
+    bad = out.proof;
+    bad.table_packing.horner_packed_steps = 1;
+    rejected = false;
+    try { prep.prover->verify_all_tables(bad); } catch (const p3r::Error& e) { rejected = std::string(e.what()).find("BadHornerPackedSteps") != std::string::npos; }
+    if (!rejected) throw std::runtime_error("tampered metadata was accepted");
+    std::ofstream(argv[3], std::ios::binary).write(reinterpret_cast<const char*>(out.proof.proof.data()), (std::streamsize)out.proof.proof.size());
+    std::printf("ok\n");
+    return 0;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+}

@@ -91,6 +91,9 @@ const char* p3r_last_error(const p3r_ctx* ctx);
 uint32_t p3r_poseidon2_trace_width(const p3r_ctx* ctx);
 /* Number of round constants the configured field expects (148 / 141). */
 uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx);
+/* The round constants in use (canonical, the flat layout of p3r_config.poseidon2_rc); `out` holds
+ * p3r_poseidon2_num_constants values. */
+int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out);
 /* Blocks until all work queued on the ctx's stream has completed. */
 int p3r_sync(p3r_ctx* ctx);
 

@@ -1,0 +1,483 @@
+// Host-side C++ mirror of the reference's interface for the prove_next_layer path, over the C ABI
+// of p3r.h.  Header-only, C++17, no HIP or torch types: link against libp3r_hip.so.
+//
+// The reference is compiled Rust; a Rust caller binds p3r.h directly.  This header
+// is the same surface for C++ callers, with the reference's names, argument meaning and error
+// behaviour (errors are exceptions carrying the reference's error text):
+//   TablePacking                 circuit-prover/src/batch_stark_prover/packing.rs:10-161
+//   Traces<EF> (flattened)       circuit/src/tables/mod.rs:49-62
+//   CircuitProverData            circuit-prover/src/batch_stark_prover.rs:314-341
+//   NonPrimitiveTableEntry       :272-290        BatchStarkProof  :610-636 (+ validate :666-681)
+//   BatchStarkProver::{prove_all_tables, verify_all_tables}   :1203-1268
+//   Circuit<EF> / CircuitRunner  circuit/src/circuit.rs:152-181, circuit/src/tables/runner.rs:22-253
+//   FriRecursionBackend          recursion/src/backend/fri.rs:113-128
+//   ProveNextLayerParams, RecursionInput, RecursionOutput, NextLayerPrepCache,
+//   build_next_layer_prep, prove_next_layer                   recursion/src/recursion.rs:96-139,221-234,295-298,342-502
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "p3r.h"
+
+namespace p3r {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+enum class Field : uint32_t { KoalaBear = P3R_FIELD_KOALA_BEAR, BabyBear = P3R_FIELD_BABY_BEAR };
+inline uint32_t modulus(Field f) { return f == Field::KoalaBear ? 0x7f000001u : 0x78000001u; }
+inline uint32_t binomial_w(Field f) { return f == Field::KoalaBear ? 3u : 11u; }
+
+// FRI / PCS parameters (recursion/examples/common/mod.rs:464-486)
+struct FriParams {
+  uint32_t log_blowup = 2, max_log_arity = 2, cap_height = 0, log_final_poly_len = 5, commit_pow_bits = 0,
+           query_pow_bits = 15, num_queries = 54;
+};
+
+inline p3r_config make_config(Field field, const FriParams& p, int device = 0, const std::vector<uint32_t>* rc = nullptr) {
+  p3r_config c{};
+  c.abi_version = P3R_ABI_VERSION;
+  c.field = (uint32_t)field;
+  c.ext_degree = 4;
+  c.log_blowup = p.log_blowup; c.max_log_arity = p.max_log_arity; c.cap_height = p.cap_height;
+  c.log_final_poly_len = p.log_final_poly_len; c.commit_pow_bits = p.commit_pow_bits;
+  c.query_pow_bits = p.query_pow_bits; c.num_queries = p.num_queries;
+  c.device = device;
+  if (rc) { c.poseidon2_rc = rc->data(); c.poseidon2_rc_len = (uint32_t)rc->size(); }
+  return c;
+}
+
+// One per GPU, not thread-safe, one call in flight (the reference's RecursionOutput is !Send).
+class Context {
+ public:
+  Context(Field field, const FriParams& fri, int device = 0, std::vector<uint32_t> poseidon2_rc = {})
+      : field_(field), fri_(fri), rc_(std::move(poseidon2_rc)) {
+    cfg_ = make_config(field, fri, device, rc_.empty() ? nullptr : &rc_);
+    h_ = p3r_create(&cfg_);
+    if (!h_) throw Error(P3R_ENODEV, p3r_last_error(nullptr));
+  }
+  ~Context() { if (h_) p3r_destroy(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  p3r_ctx* raw() const { return h_; }
+  const p3r_config& config() const { return cfg_; }
+  Field field() const { return field_; }
+  const FriParams& fri() const { return fri_; }
+  void check(int rc) const { if (rc != P3R_OK) throw Error(rc, p3r_last_error(h_)); }
+  template <class T> T* ptr(T* p) const { if (!p) throw Error(P3R_EINVAL, p3r_last_error(h_)); return p; }
+  void sync() const { check(p3r_sync(h_)); }
+
+ private:
+  Field field_;
+  FriParams fri_;
+  std::vector<uint32_t> rc_;
+  p3r_config cfg_{};
+  p3r_ctx* h_ = nullptr;
+};
+
+struct TablePacking {
+  uint32_t public_lanes = 1, alu_lanes = 3, horner_packed_steps = 4, recompose_lanes = 1, min_trace_height = 1;
+  static TablePacking create(uint32_t public_lanes, uint32_t alu_lanes) {  // TablePacking::new
+    TablePacking t;
+    t.public_lanes = public_lanes; t.alu_lanes = alu_lanes;
+    return t;
+  }
+  // FRI needs log_height > log_final_poly_len + log_blowup (packing.rs:100-106)
+  TablePacking& with_fri_params(uint32_t log_final_poly_len, uint32_t log_blowup) {
+    min_trace_height = 1u << (log_final_poly_len + log_blowup + 1);
+    return *this;
+  }
+  void validate() const {  // packing.rs:140-161
+    if (!public_lanes) throw Error(P3R_EINVAL, "ZeroLanes(\"public_lanes\")");
+    if (!alu_lanes) throw Error(P3R_EINVAL, "ZeroLanes(\"alu_lanes\")");
+    if (!recompose_lanes) throw Error(P3R_EINVAL, "ZeroNpoLanes(recompose)");
+    if (!min_trace_height || (min_trace_height & (min_trace_height - 1)))
+      throw Error(P3R_EINVAL, "BadMinTraceHeight(" + std::to_string(min_trace_height) + ")");
+    if (horner_packed_steps < 2) throw Error(P3R_EINVAL, "BadHornerPackedSteps(" + std::to_string(horner_packed_steps) + ")");
+  }
+};
+
+// Flattened Traces<EF>, D = 4, canonical u32.
+struct Traces {
+  std::vector<uint32_t> const_values, public_values;  // n x 4
+  std::vector<uint32_t> alu_values;                   // n x 16: [a, b, c, out]
+  std::vector<uint32_t> p2_input_values;              // n x 16
+  std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_bit;
+  std::vector<uint32_t> p2_mmcs_index_sum;
+  std::vector<uint32_t> recompose_values;             // n x 4
+};
+
+// Per-op preprocessed data as get_airs_and_degrees_with_prep leaves it (see p3r_layer_desc).
+struct CircuitPrep {
+  std::vector<uint32_t> const_prep, public_prep, alu_prep13, recompose_prep;
+  std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_ctl_enabled, p2_in_ctl;
+  std::vector<uint32_t> p2_input_indices, p2_out_ctl, p2_output_indices, p2_mmcs_index_sum_idx;
+};
+
+struct Circuit {  // flattened Circuit<EF>
+  uint32_t witness_count = 0;
+  std::vector<p3r_op> ops;
+  std::vector<uint32_t> ext, public_rows, private_input_rows, witness_rewrite /* pairs */;
+};
+
+struct CircuitInputs {
+  std::vector<uint32_t> public_values, private_values;                  // x 4 each
+  std::vector<uint32_t> private_data_op_ids, private_data_siblings;     // siblings x 8
+};
+
+class CircuitProverData {
+ public:
+  CircuitProverData(const Context& ctx, const CircuitPrep& prep, const TablePacking& packing) : ctx_(&ctx), packing_(packing) {
+    packing.validate();
+    p3r_layer_desc d{};
+    d.counts.n_const = prep.const_prep.size() / 2; d.counts.n_public = prep.public_prep.size() / 2;
+    d.counts.n_alu = prep.alu_prep13.size() / 13; d.counts.n_p2 = prep.p2_new_start.size();
+    d.counts.n_recompose = prep.recompose_prep.size() / 2;
+    d.public_lanes = packing.public_lanes; d.alu_lanes = packing.alu_lanes;
+    d.horner_packed_steps = packing.horner_packed_steps; d.recompose_lanes = packing.recompose_lanes;
+    d.min_trace_height = packing.min_trace_height;
+    d.const_prep = prep.const_prep.data(); d.public_prep = prep.public_prep.data();
+    d.alu_prep13 = prep.alu_prep13.data(); d.recompose_prep = prep.recompose_prep.data();
+    d.p2_new_start = prep.p2_new_start.data(); d.p2_merkle_path = prep.p2_merkle_path.data();
+    d.p2_mmcs_ctl_enabled = prep.p2_mmcs_ctl_enabled.data(); d.p2_in_ctl = prep.p2_in_ctl.data();
+    d.p2_input_indices = prep.p2_input_indices.data(); d.p2_out_ctl = prep.p2_out_ctl.data();
+    d.p2_output_indices = prep.p2_output_indices.data(); d.p2_mmcs_index_sum_idx = prep.p2_mmcs_index_sum_idx.data();
+    rows_ = d.counts;
+    preprocessed_commitment.resize(size_t(8) << ctx.fri().cap_height);
+    owned_ = ctx.ptr(p3r_layer_create(ctx.raw(), &d, preprocessed_commitment.data()));
+    layer_ = owned_;
+    read_shape();
+  }
+  // view of the data a prepared circuit owns
+  CircuitProverData(const Context& ctx, const p3r_layer* borrowed, const TablePacking& packing, p3r_layer_desc_counts rows,
+                    std::vector<uint32_t> commitment)
+      : preprocessed_commitment(std::move(commitment)), ctx_(&ctx), packing_(packing), rows_(rows), layer_(borrowed) {
+    read_shape();
+  }
+  ~CircuitProverData() { if (owned_) p3r_layer_free(ctx_->raw(), owned_); }
+  CircuitProverData(const CircuitProverData&) = delete;
+  CircuitProverData& operator=(const CircuitProverData&) = delete;
+  const p3r_layer* raw() const { return layer_; }
+  const TablePacking& packing() const { return packing_; }
+  const TablePacking& effective_packing() const { return effective_; }  // reduce_lanes_if_dummy applied
+  const p3r_layer_desc_counts& rows() const { return rows_; }
+  std::vector<uint32_t> preprocessed_commitment;  // (1 << cap_height) x 8, canonical
+  std::array<size_t, 5> table_heights{};          // 0 = table absent from the batch
+
+ private:
+  void read_shape() {
+    ctx_->check(p3r_layer_table_heights(layer_, table_heights.data()));
+    effective_ = packing_;
+    ctx_->check(p3r_layer_effective_lanes(layer_, &effective_.public_lanes, &effective_.alu_lanes));
+  }
+  const Context* ctx_;
+  TablePacking packing_, effective_;
+  p3r_layer_desc_counts rows_{};
+  p3r_layer* owned_ = nullptr;
+  const p3r_layer* layer_ = nullptr;
+};
+
+struct NonPrimitiveTableEntry {
+  std::string op_type;
+  size_t rows = 0, lanes = 1;
+  std::vector<uint32_t> public_values;
+  uint32_t air_variant = 0;  // AirVariant::Baseline
+};
+
+struct BatchStarkProof {
+  std::vector<uint8_t> proof;  // postcard bytes of the inner BatchProof<SC>
+  TablePacking table_packing;  // the EFFECTIVE packing (batch_stark_prover.rs:1617-1622)
+  std::array<size_t, 3> rows{};
+  uint32_t alu_variant = 1;    // AirVariant::Optimized (:1106-1114)
+  uint32_t ext_degree = 4;
+  std::optional<uint32_t> w_binomial;
+  bool alu_quintic_trinomial = false;
+  std::vector<NonPrimitiveTableEntry> non_primitives;
+  std::vector<uint32_t> preprocessed_commitment;  // stark_common
+  std::vector<uint32_t> preprocessed_widths, degree_bits;
+  bool montgomery_field_encoding = true;
+  uint32_t modulus = 0;
+
+  void validate() const {  // batch_stark_prover.rs:666-681
+    switch (ext_degree) { case 1: case 2: case 4: case 5: case 6: case 8: break;
+      default: throw Error(P3R_EINVAL, "UnsupportedExtDegree(" + std::to_string(ext_degree) + ")"); }
+    table_packing.validate();
+    for (auto& e : non_primitives) if (!e.lanes) throw Error(P3R_EINVAL, "ZeroNpoLanes(" + e.op_type + ")");
+  }
+  // the proved tables in instance order
+  std::vector<p3r_air_desc> airs() const {
+    std::vector<p3r_air_desc> a = {{P3R_AIR_CONST, 1, 2, 0}, {P3R_AIR_PUBLIC, table_packing.public_lanes, 2, 0},
+                                   {P3R_AIR_ALU, table_packing.alu_lanes, table_packing.horner_packed_steps, 0}};
+    for (auto& e : non_primitives) {
+      if (e.op_type.rfind("poseidon2_perm/", 0) == 0) a.push_back({P3R_AIR_POSEIDON2, 1, 2, 0});
+      else if (e.op_type == "recompose") a.push_back({P3R_AIR_RECOMPOSE, (uint32_t)e.lanes, 2, 0});
+      else throw Error(P3R_EUNSUPPORTED, "MissingTableProver(" + e.op_type + ")");
+    }
+    return a;
+  }
+  // postcard bytes of the whole BatchStarkProof<SC> (serde derives of :610-636, packing.rs:9-27,
+  // RowCounts :459-460, NonPrimitiveTableEntry :272-290, SerializedStarkCommon :495-511)
+  std::vector<uint8_t> to_postcard() const {
+    std::vector<uint8_t> out = proof;
+    auto varint = [&](uint64_t v) { while (v >= 0x80) { out.push_back((uint8_t)(v | 0x80)); v >>= 7; } out.push_back((uint8_t)v); };
+    auto str = [&](const std::string& s) { varint(s.size()); out.insert(out.end(), s.begin(), s.end()); };
+    auto fe = [&](uint32_t x) { varint(montgomery_field_encoding ? (uint32_t)(((uint64_t)x << 32) % modulus) : x); };
+    varint(table_packing.public_lanes); varint(table_packing.alu_lanes);
+    size_t n_npo = 0;
+    for (auto& e : non_primitives) n_npo += e.lanes != 1;
+    varint(n_npo);
+    for (auto& e : non_primitives) if (e.lanes != 1) { str(e.op_type); varint(e.lanes); }
+    varint(table_packing.min_trace_height); varint(table_packing.horner_packed_steps);
+    for (size_t r : rows) varint(r ? r : 1);
+    varint(alu_variant); varint(ext_degree);
+    if (w_binomial) { out.push_back(1); fe(*w_binomial); } else out.push_back(0);
+    out.push_back(alu_quintic_trinomial);
+    varint(non_primitives.size());
+    for (auto& e : non_primitives) {
+      str(e.op_type); varint(e.rows); varint(e.lanes);
+      varint(e.public_values.size());
+      for (uint32_t v : e.public_values) fe(v);
+      varint(e.air_variant);
+    }
+    if (preprocessed_commitment.empty()) { out.push_back(0); return out; }
+    out.push_back(1);
+    varint(preprocessed_commitment.size() / 8);
+    for (uint32_t v : preprocessed_commitment) fe(v);
+    varint(preprocessed_widths.size());
+    for (size_t i = 0; i < preprocessed_widths.size(); ++i) { out.push_back(1); varint(i); varint(preprocessed_widths[i]); varint(degree_bits[i]); }
+    varint(preprocessed_widths.size());
+    for (size_t i = 0; i < preprocessed_widths.size(); ++i) varint(i);
+    return out;
+  }
+};
+
+// verify_batch behind verify_all_tables: host code, no device needed.
+inline void verify_all_tables(const p3r_config& cfg, const BatchStarkProof& proof) {
+  proof.validate();
+  if (proof.preprocessed_commitment.empty()) throw Error(P3R_EINVAL, "proof carries no preprocessed commitment (stark_common)");
+  auto airs = proof.airs();
+  char err[512] = {0};
+  int rc = p3r_verify_batch(&cfg, airs.data(), airs.size(), proof.preprocessed_commitment.data(), proof.proof.data(),
+                            proof.proof.size(), proof.montgomery_field_encoding ? 0 : P3R_PROVE_CANONICAL_FIELD_ENCODING, err,
+                            sizeof err);
+  if (rc != P3R_OK) throw Error(rc, std::string("Verify(") + err + ")");
+}
+
+namespace detail {
+template <class Fn>
+std::vector<uint8_t> proof_call(const Context& ctx, Fn&& fn) {
+  std::vector<uint8_t> buf(size_t(1) << 20);
+  size_t n = 0;
+  int rc = fn(buf.data(), buf.size(), &n);
+  if (rc == P3R_EBUFFER && n > buf.size()) { buf.resize(n); rc = fn(buf.data(), buf.size(), &n); }
+  ctx.check(rc);
+  buf.resize(n);
+  return buf;
+}
+inline p3r_traces traces_struct(const Traces& t) {
+  p3r_traces s{};
+  s.n_const = t.const_values.size() / 4; s.const_values = t.const_values.data();
+  s.n_public = t.public_values.size() / 4; s.public_values = t.public_values.data();
+  s.n_alu = t.alu_values.size() / 16; s.alu_values = t.alu_values.data();
+  s.p2.n = t.p2_input_values.size() / 16; s.p2.input_values = t.p2_input_values.data();
+  s.p2.new_start = t.p2_new_start.data(); s.p2.merkle_path = t.p2_merkle_path.data(); s.p2.mmcs_bit = t.p2_mmcs_bit.data();
+  s.p2.mmcs_index_sum = t.p2_mmcs_index_sum.data();
+  s.n_recompose = t.recompose_values.size() / 4; s.recompose_values = t.recompose_values.data();
+  return s;
+}
+}  // namespace detail
+
+// Traces kept in HBM (uploaded, or produced there by the device CircuitRunner).
+class ResidentTraces {
+ public:
+  ResidentTraces(const Context& ctx, p3r_dtraces* h) : ctx_(&ctx), h_(h) {}
+  ResidentTraces(const Context& ctx, const CircuitProverData& cpd, const Traces& t) : ctx_(&ctx) {
+    p3r_traces s = detail::traces_struct(t);
+    h_ = ctx.ptr(p3r_traces_upload(ctx.raw(), cpd.raw(), &s));
+  }
+  ~ResidentTraces() { if (h_) p3r_traces_free(ctx_->raw(), h_); }
+  ResidentTraces(ResidentTraces&& o) noexcept : ctx_(o.ctx_), h_(o.h_) { o.h_ = nullptr; }
+  ResidentTraces(const ResidentTraces&) = delete;
+  const p3r_dtraces* raw() const { return h_; }
+  std::vector<uint32_t> download(const CircuitProverData& cpd, p3r_traces_array which, size_t len) const {
+    std::vector<uint32_t> out(len);
+    ctx_->check(p3r_dtraces_get(ctx_->raw(), cpd.raw(), h_, which, out.data(), len));
+    return out;
+  }
+
+ private:
+  const Context* ctx_;
+  p3r_dtraces* h_ = nullptr;
+};
+
+// A circuit prepared once: preprocessed columns + commitment + the levelised execution schedule.
+class PreparedCircuit {
+ public:
+  PreparedCircuit(const Context& ctx, Circuit circuit, const TablePacking& packing) : ctx_(&ctx), circuit_(std::move(circuit)) {
+    packing.validate();
+    p3r_circuit_desc d{};
+    d.witness_count = circuit_.witness_count;
+    d.n_ops = circuit_.ops.size(); d.ops = circuit_.ops.data();
+    d.n_ext = circuit_.ext.size(); d.ext = circuit_.ext.data();
+    d.n_public = circuit_.public_rows.size(); d.public_rows = circuit_.public_rows.data();
+    d.n_private = circuit_.private_input_rows.size(); d.private_input_rows = circuit_.private_input_rows.data();
+    d.n_rewrite = circuit_.witness_rewrite.size() / 2; d.witness_rewrite = circuit_.witness_rewrite.data();
+    d.public_lanes = packing.public_lanes; d.alu_lanes = packing.alu_lanes; d.horner_packed_steps = packing.horner_packed_steps;
+    d.recompose_lanes = packing.recompose_lanes; d.min_trace_height = packing.min_trace_height;
+    std::vector<uint32_t> commit(size_t(8) << ctx.fri().cap_height);
+    h_ = ctx.ptr(p3r_circuit_create(ctx.raw(), &d, commit.data()));
+    p3r_layer_desc_counts counts{};
+    ctx.check(p3r_circuit_counts(h_, &counts));
+    ctx.check(p3r_circuit_levels(h_, &levels_));
+    cpd_ = std::make_unique<CircuitProverData>(ctx, p3r_circuit_layer(h_), packing, counts, std::move(commit));
+  }
+  ~PreparedCircuit() { cpd_.reset(); if (h_) p3r_circuit_free(ctx_->raw(), h_); }
+  PreparedCircuit(const PreparedCircuit&) = delete;
+  const Circuit& circuit() const { return circuit_; }
+  const CircuitProverData& circuit_prover_data() const { return *cpd_; }
+  size_t levels() const { return levels_; }
+  // CircuitRunner::{set_public_inputs, set_private_inputs, set_private_data, run} on the device
+  ResidentTraces run(const CircuitInputs& in) const {
+    p3r_circuit_inputs s = inputs_struct(in);
+    return ResidentTraces(*ctx_, ctx_->ptr(p3r_circuit_run(ctx_->raw(), h_, &s)));
+  }
+  std::vector<uint8_t> prove(const CircuitInputs& in, bool canonical_field_encoding = false) const {
+    p3r_circuit_inputs s = inputs_struct(in);
+    const uint32_t flags = canonical_field_encoding ? P3R_PROVE_CANONICAL_FIELD_ENCODING : 0;
+    return detail::proof_call(*ctx_, [&](uint8_t* b, size_t cap, size_t* n) { return p3r_prove_next_layer(ctx_->raw(), h_, &s, flags, b, cap, n); });
+  }
+
+ private:
+  p3r_circuit_inputs inputs_struct(const CircuitInputs& in) const {
+    // set_public_inputs / set_private_inputs length checks (runner.rs:84-90,107-113)
+    if (in.public_values.size() != 4 * circuit_.public_rows.size())
+      throw Error(P3R_EINVAL, "PublicInputLengthMismatch { expected: " + std::to_string(circuit_.public_rows.size()) + ", got: " +
+                                  std::to_string(in.public_values.size() / 4) + " }");
+    if (in.private_values.size() != 4 * circuit_.private_input_rows.size())
+      throw Error(P3R_EINVAL, "PrivateInputLengthMismatch { expected: " + std::to_string(circuit_.private_input_rows.size()) +
+                                  ", got: " + std::to_string(in.private_values.size() / 4) + " }");
+    if (in.private_data_siblings.size() != 8 * in.private_data_op_ids.size())
+      throw Error(P3R_EINVAL, "private_data_siblings must hold two extension limbs per op id");
+    p3r_circuit_inputs s{};
+    s.public_values = in.public_values.data(); s.private_values = in.private_values.data();
+    s.n_private_data = in.private_data_op_ids.size(); s.private_data_op_ids = in.private_data_op_ids.data();
+    s.private_data_siblings = in.private_data_siblings.data();
+    return s;
+  }
+  const Context* ctx_;
+  Circuit circuit_;
+  p3r_circuit* h_ = nullptr;
+  size_t levels_ = 0;
+  std::unique_ptr<CircuitProverData> cpd_;
+};
+
+class BatchStarkProver {
+ public:
+  BatchStarkProver(const Context& ctx, const TablePacking& packing) : ctx_(&ctx), table_packing_(packing) {}
+  BatchStarkProof prove_all_tables(const Traces& traces, const CircuitProverData& cpd, bool canonical_field_encoding = false) const {
+    p3r_traces s = detail::traces_struct(traces);
+    const uint32_t flags = canonical_field_encoding ? P3R_PROVE_CANONICAL_FIELD_ENCODING : 0;
+    auto bytes = detail::proof_call(*ctx_, [&](uint8_t* b, size_t cap, size_t* n) { return p3r_prove_all_tables(ctx_->raw(), cpd.raw(), &s, flags, b, cap, n); });
+    return wrap(std::move(bytes), cpd, canonical_field_encoding);
+  }
+  BatchStarkProof prove_all_tables(const ResidentTraces& traces, const CircuitProverData& cpd, bool canonical_field_encoding = false) const {
+    const uint32_t flags = canonical_field_encoding ? P3R_PROVE_CANONICAL_FIELD_ENCODING : 0;
+    auto bytes = detail::proof_call(*ctx_, [&](uint8_t* b, size_t cap, size_t* n) { return p3r_prove_all_tables_resident(ctx_->raw(), cpd.raw(), traces.raw(), flags, b, cap, n); });
+    return wrap(std::move(bytes), cpd, canonical_field_encoding);
+  }
+  void verify_all_tables(const BatchStarkProof& proof) const { p3r::verify_all_tables(ctx_->config(), proof); }
+
+ private:
+  // metadata as batch_stark_prover.rs:1598-1641 assembles it
+  BatchStarkProof wrap(std::vector<uint8_t> bytes, const CircuitProverData& cpd, bool canonical) const {
+    BatchStarkProof p;
+    p.proof = std::move(bytes);
+    const TablePacking& tp = cpd.effective_packing();
+    p.table_packing = tp;
+    p.rows = {cpd.rows().n_const, cpd.rows().n_public, cpd.rows().n_alu};
+    p.w_binomial = binomial_w(ctx_->field());
+    const uint32_t k = tp.horner_packed_steps;
+    const uint32_t widths[5] = {2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24, 2 * tp.recompose_lanes};
+    for (int i = 0; i < 5; ++i) {
+      if (!cpd.table_heights[i]) continue;
+      p.preprocessed_widths.push_back(widths[i]);
+      uint32_t db = 0;
+      while ((size_t(1) << db) < cpd.table_heights[i]) ++db;
+      p.degree_bits.push_back(db);
+    }
+    if (cpd.table_heights[3])  // Poseidon2Prover reports the PADDED row count (poseidon2.rs:1449)
+      p.non_primitives.push_back({ctx_->field() == Field::KoalaBear ? "poseidon2_perm/koala_bear_d4_w16" : "poseidon2_perm/baby_bear_d4_w16",
+                                  cpd.table_heights[3], 1, {}, 0});
+    if (cpd.table_heights[4])  // RecomposeProver reports the op count (recompose.rs:125)
+      p.non_primitives.push_back({"recompose", cpd.rows().n_recompose, tp.recompose_lanes, {}, 0});
+    p.preprocessed_commitment = cpd.preprocessed_commitment;
+    p.montgomery_field_encoding = !canonical;
+    p.modulus = modulus(ctx_->field());
+    return p;
+  }
+  const Context* ctx_;
+  TablePacking table_packing_;
+};
+
+// ---- recursion API (recursion/src/recursion.rs)
+struct FriRecursionBackend {  // registers the Poseidon2 + Recompose table provers for D = 4 (backend/fri.rs:693-721)
+  void non_primitive_provers(size_t ext_degree) const {
+    if (ext_degree != 4) throw Error(P3R_EUNSUPPORTED, "UnsupportedDegree(" + std::to_string(ext_degree) + ")");
+  }
+};
+struct ProveNextLayerParams { TablePacking table_packing; };
+
+struct NextLayerPrepCache {
+  std::unique_ptr<BatchStarkProver> prover;
+  std::unique_ptr<PreparedCircuit> prepared_circuit;          // when built from a Circuit
+  std::unique_ptr<CircuitProverData> owned_prover_data;       // when built from flattened preprocessed columns
+  const CircuitProverData& circuit_prover_data() const { return prepared_circuit ? prepared_circuit->circuit_prover_data() : *owned_prover_data; }
+};
+
+inline NextLayerPrepCache build_next_layer_prep(const Context& ctx, Circuit circuit, const FriRecursionBackend& backend,
+                                                const ProveNextLayerParams& params) {
+  backend.non_primitive_provers(4);
+  NextLayerPrepCache c;
+  c.prover = std::make_unique<BatchStarkProver>(ctx, params.table_packing);
+  c.prepared_circuit = std::make_unique<PreparedCircuit>(ctx, std::move(circuit), params.table_packing);
+  return c;
+}
+inline NextLayerPrepCache build_next_layer_prep(const Context& ctx, const CircuitPrep& prep, const FriRecursionBackend& backend,
+                                                const ProveNextLayerParams& params) {
+  backend.non_primitive_provers(4);
+  NextLayerPrepCache c;
+  c.prover = std::make_unique<BatchStarkProver>(ctx, params.table_packing);
+  c.owned_prover_data = std::make_unique<CircuitProverData>(ctx, prep, params.table_packing);
+  return c;
+}
+
+// What prove_next_layer proves: the inputs of the verifier circuit (run on the device), or Traces.
+struct RecursionInput {
+  const CircuitInputs* circuit_inputs = nullptr;
+  const Traces* traces = nullptr;
+};
+struct RecursionOutput {
+  BatchStarkProof proof;
+};
+
+inline RecursionOutput prove_next_layer(const RecursionInput& input, const Context& ctx, const FriRecursionBackend& backend,
+                                        const ProveNextLayerParams&, const NextLayerPrepCache& prep) {
+  backend.non_primitive_provers(4);
+  (void)ctx;
+  if (input.traces) return {prep.prover->prove_all_tables(*input.traces, prep.circuit_prover_data())};
+  if (!input.circuit_inputs || !prep.prepared_circuit)
+    throw Error(P3R_EINVAL, "without Traces, prove_next_layer needs a prepared Circuit and its inputs");
+  ResidentTraces t = prep.prepared_circuit->run(*input.circuit_inputs);  // runner.run() (recursion.rs:478)
+  return {prep.prover->prove_all_tables(t, prep.circuit_prover_data())};
+}
+
+}  // namespace p3r

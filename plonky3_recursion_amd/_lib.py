@@ -119,6 +119,7 @@ SIGNATURES = {
     "p3r_last_error": (C.c_char_p, [vp]),
     "p3r_poseidon2_trace_width": (C.c_uint32, [vp]),
     "p3r_poseidon2_num_constants": (C.c_uint32, [vp]),
+    "p3r_poseidon2_round_constants": (C.c_int, [vp, u32p]),
     "p3r_sync": (C.c_int, [vp]),
     "p3r_dmat_upload": (vp, [vp, u32p, C.c_size_t, C.c_size_t]),
     "p3r_dmat_alloc": (vp, [vp, C.c_size_t, C.c_size_t]),

@@ -543,6 +543,11 @@ uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx) {
   return ctx->cfg.field == P3R_FIELD_KOALA_BEAR ? p2_num_constants<KoalaBearParams>()
                                                 : p2_num_constants<BabyBearParams>();
 }
+int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out) {
+  if (!ctx || !out) return P3R_EINVAL;
+  std::copy(ctx->rc_canonical.begin(), ctx->rc_canonical.end(), out);
+  return P3R_OK;
+}
 
 int p3r_sync(p3r_ctx* ctx) {
   return guard(ctx, [&] { P3R_HIP(hipStreamSynchronize(ctx->stream)); });
