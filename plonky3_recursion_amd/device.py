@@ -222,16 +222,17 @@ class Context:
         return cap, ProverData(self, h)
 
     def _proof_call(self, fn, *args):
-        cap = 1 << 20
+        buf = getattr(self, "_proof_buf", None)
+        if buf is None:
+            buf = self._proof_buf = C.create_string_buffer(1 << 20)
         while True:
-            buf = (C.c_uint8 * cap)()
             n = C.c_size_t()
-            rc = fn(*args, buf, cap, C.byref(n))
-            if rc == -6 and n.value > cap:  # P3R_EBUFFER
-                cap = n.value
+            rc = fn(*args, C.cast(buf, C.POINTER(C.c_uint8)), len(buf), C.byref(n))
+            if rc == -6 and n.value > len(buf):  # P3R_EBUFFER
+                buf = self._proof_buf = C.create_string_buffer(n.value)
                 continue
             self.check(rc)
-            return bytes(buf[: n.value])
+            return C.string_at(buf, n.value)   # one memcpy (slicing a ctypes array builds a list first)
 
     def prove_batch(self, prover_data, main_traces, canonical_field_encoding=False):
         """main_traces: DeviceMatrix list (resident) or 2-D uint32 arrays (host)."""
