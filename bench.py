@@ -30,6 +30,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0,
            query_pow_bits=15, num_queries=54)  # recursive_fibonacci.rs:71-147, examples/common/mod.rs:472
 GEN_KNOBS = dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
+# BASELINE config 2 (layer 1 over a uni-stark Keccak proof): same table mix,
+# Horner chains of ~2600 steps and sponge chains of ~330 permutations
+CONFIG2_KNOBS = dict(horner_chain_len=2600, sponge_chain_len=330, merkle_depth=20)
 
 
 def lookup_aux_widths(alu_lanes, horner_k):
@@ -126,6 +129,8 @@ def main():
     ap.add_argument("--field", default="koala-bear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-log-height", type=int, default=13)
+    ap.add_argument("--no-config2", action="store_true",
+                    help="skip the secondary measurement with BASELINE config 2's chain-length knobs")
     args = ap.parse_args()
 
     import torch
@@ -291,9 +296,39 @@ def main():
                           f"rows = 1/{1 << (log_h - lh)} of the workload, oracle/ C++ restatement, 1 thread",
                 "circuit_run_ms": crun * 1e3,
             }
+        if not args.no_config2 and world == 1:
+            # secondary, on rank 0 at N = 1 only: the same step over a circuit with config 2's knobs
+            # (the prover's work is the same, the circuit run is deeper)
+            resident.free()
+            pc.free()
+            arrs2 = harness_lib.generate(field, log_h, seed=0x5EED0000, **CONFIG2_KNOBS)
+            pc2 = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(arrs2), packing)
+            res2 = pc2.upload_inputs(wl.circuit_inputs_from_arrays(arrs2))
+            n_ops2 = len(arrs2["ops"]) // 8
+            del arrs2
+            pc2.prove(res2)
+            ctx.sync()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                pc2.prove(res2)
+            ctx.sync()
+            ms2 = (time.perf_counter() - t2) / 3 * 1e3
+            ctx.profile_enable(True)
+            pc2.prove(res2)
+            prof2 = ctx.profile_read()
+            ctx.profile_enable(False)
+            line["config2_keccak_layer1_knobs"] = {
+                "ms_per_step": ms2, "steps": 3, "circuit_ops": n_ops2, "circuit_levels": pc2.levels,
+                "run_circuit_ms": prof2.get("stage:run_circuit", (None,))[0],
+                "workload": f"same step, synthetic {field} 2^{log_h}-row layer with Horner chains up to 2600 steps and "
+                            f"sponge chains of 330 permutations (BASELINE config 2)"}
+            res2.free()
+            pc2.free()
+            resident = pc = None
         print(json.dumps(line))
-    resident.free()
-    pc.free()
+    if resident is not None:
+        resident.free()
+        pc.free()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -266,8 +266,13 @@ enum : uint32_t { RUN_ERR_CONFLICT = 1, RUN_ERR_DIV0 = 2, RUN_ERR_MMCS_BIT = 3, 
 
 struct RunSchedule {
   std::vector<RunOp> light;
-  std::vector<RunP2> p2;
-  std::vector<uint32_t> light_off, p2_off;  // per level, size levels + 1
+  // Poseidon2 permutations: a run of rows chained through the sponge / Merkle state whose witness
+  // inputs are all ready when the run starts is ONE segment, executed row after row by one 16-lane
+  // group with the state kept in registers (no launch, barrier or memory round trip per row)
+  struct P2Seg { uint32_t first, n; };
+  std::vector<RunP2> p2;                    // rows, segment by segment
+  std::vector<P2Seg> p2segs;                // sorted by level
+  std::vector<uint32_t> light_off, p2seg_off;  // per level, size levels + 1
   std::vector<uint32_t> dev_ext;
   std::vector<uint32_t> const_rows;         // const op -> witness, in table order (static Const trace)
   std::vector<uint32_t> public_out;         // public table row -> witness
@@ -285,8 +290,9 @@ struct RunSchedule {
   // (k_run_chains) at one level instead of one level per step.
   struct ChainSeg { uint32_t first, n, acc_w, b_w; };
   std::vector<RunOp> chain_ops;             // steps of all chains, chain by chain
-  std::vector<ChainSeg> chains;             // sorted by level
+  std::vector<ChainSeg> chains;             // sorted by level; within a level the long ones first
   std::vector<uint32_t> chain_off;          // per level
+  std::vector<uint32_t> chain_long;         // per level: how many of its chains get a whole workgroup
 };
 
 inline RunSchedule build_schedule(const HostCircuit& c) {
@@ -304,13 +310,16 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
   };
   struct Tmp { uint32_t level; bool is_p2; uint32_t idx; };
   std::vector<Tmp> order;
+  struct OpenP2 { uint32_t level; std::vector<RunP2> rows; };
+  std::vector<OpenP2> p2open;        // every segment; open_normal / open_merkle index the growing ones
+  int open_normal = -1, open_merkle = -1;
+  uint32_t n_p2_rows = 0;
   struct OpenChain { uint32_t level, first, n, acc_w, b_w, last_out; size_t last_op; };
   std::vector<OpenChain> chains;     // closed + (last one possibly) open
   bool chain_open = false;
   std::vector<RunOp> light;
-  std::vector<RunP2> p2;
   uint32_t n_alu = 0, n_rec = 0, n_pub = 0;
-  uint32_t last_normal = kNoW, last_merkle = kNoW, last_normal_level = 0, last_merkle_level = 0;
+  uint32_t last_normal = kNoW, last_merkle = kNoW;
   uint32_t max_op_id = 0;
   bool any_npo = false;
   for (auto& op : c.ops)
@@ -423,16 +432,16 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
         const bool new_start = op.aux & 1, merkle = op.aux & 2;
         q.flags = (op.aux & 3) | (e[6] << 8);
         q.op_idx = (uint32_t)i;
-        q.row = (uint32_t)p2.size();
+        q.row = n_p2_rows++;
         for (int l = 0; l < 4; ++l) { q.in[l] = e[l]; if (e[l] != kNoW) need(e[l]); }
         q.idx_w = e[4]; if (e[4] != kNoW) need(e[4]);
         q.bit_w = e[5]; if (e[5] != kNoW) need(e[5]);
         q.prev_row = kNoW;
+        int& open = merkle ? open_merkle : open_normal;
         if (!new_start) {
           const uint32_t prev = merkle ? last_merkle : last_normal;
           if (prev == kNoW) defer("Poseidon2ChainMissingPreviousState { operation_index: NonPrimitiveOpId(%u) }", op.a);
           q.prev_row = prev;
-          lvl = std::max(lvl, merkle ? last_merkle_level : last_normal_level);
         }
         for (uint32_t l = 0; l < 4; ++l) {
           q.out[l] = l < e[6] ? e[7 + l] : kNoW;
@@ -444,11 +453,17 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
         if (S.p2_row_of_op_id[op.a] != kNoW) fail(P3R_EINVAL, "duplicate NonPrimitiveOpId(%u)", op.a);
         S.p2_row_of_op_id[op.a] = q.row;
         S.p2_row_merkle.push_back(merkle);
-        lvl += 1;
-        if (merkle) { last_merkle = q.row; last_merkle_level = lvl; } else { last_normal = q.row; last_normal_level = lvl; }
-        for (uint32_t w : written) { set[w] = 1; wlevel[w] = lvl; }
-        order.push_back({lvl, true, (uint32_t)p2.size()});
-        p2.push_back(q);
+        // `lvl` = highest level among the witnesses this row reads (or compares against)
+        if (!new_start && open >= 0 && q.prev_row != kNoW && lvl < p2open[open].level) {
+          p2open[open].rows.push_back(q);  // continues the open run of its mode
+        } else {
+          uint32_t seg_level = lvl + 1;
+          if (!new_start && open >= 0) seg_level = std::max(seg_level, p2open[open].level + 1);
+          p2open.push_back({seg_level, {q}});
+          open = (int)p2open.size() - 1;
+        }
+        if (merkle) last_merkle = q.row; else last_normal = q.row;
+        for (uint32_t w : written) { set[w] = 1; wlevel[w] = p2open[open].level; }
         continue;
       }
       default: fail(P3R_EUNSUPPORTED, "op %zu: unsupported kind %u", i, op.kind);
@@ -462,6 +477,7 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
   uint32_t max_level = 0;
   for (auto& t : order) max_level = std::max(max_level, t.level);
   for (auto& ch : chains) max_level = std::max(max_level, ch.level);
+  for (auto& sg : p2open) max_level = std::max(max_level, sg.level);
   std::unordered_map<uint32_t, uint32_t> canon_of;
   for (size_t k = 0; k + 1 < c.rewrite.size(); k += 2) canon_of.emplace(c.rewrite[k], c.rewrite[k + 1]);
   for (size_t k = 0; k + 1 < c.rewrite.size(); k += 2) {
@@ -482,27 +498,41 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
   // sort by level (stable: circuit order inside a level)
   S.levels = max_level;
   S.light_off.assign(max_level + 2, 0);
-  S.p2_off.assign(max_level + 2, 0);
-  for (auto& t : order) (t.is_p2 ? S.p2_off : S.light_off)[t.level + 1]++;
-  for (size_t l = 1; l < S.light_off.size(); ++l) { S.light_off[l] += S.light_off[l - 1]; S.p2_off[l] += S.p2_off[l - 1]; }
+  S.p2seg_off.assign(max_level + 2, 0);
+  for (auto& t : order) S.light_off[t.level + 1]++;
+  for (auto& sg : p2open) S.p2seg_off[sg.level + 1]++;
+  for (size_t l = 1; l < S.light_off.size(); ++l) { S.light_off[l] += S.light_off[l - 1]; S.p2seg_off[l] += S.p2seg_off[l - 1]; }
   S.light.resize(light.size());
-  S.p2.resize(p2.size());
-  std::vector<uint32_t> lp(S.light_off.begin(), S.light_off.end() - 1), pp(S.p2_off.begin(), S.p2_off.end() - 1);
-  for (auto& t : order) {
-    if (t.is_p2) S.p2[pp[t.level]++] = p2[t.idx];
-    else S.light[lp[t.level]++] = light[t.idx];
+  {
+    std::vector<uint32_t> lp(S.light_off.begin(), S.light_off.end() - 1);
+    for (auto& t : order) S.light[lp[t.level]++] = light[t.idx];
+  }
+  {
+    // rows of a segment contiguous, segments in level order
+    std::vector<uint32_t> by_level(p2open.size());
+    std::iota(by_level.begin(), by_level.end(), 0u);
+    std::stable_sort(by_level.begin(), by_level.end(), [&](uint32_t x, uint32_t y) { return p2open[x].level < p2open[y].level; });
+    for (uint32_t k : by_level) {
+      S.p2segs.push_back({(uint32_t)S.p2.size(), (uint32_t)p2open[k].rows.size()});
+      S.p2.insert(S.p2.end(), p2open[k].rows.begin(), p2open[k].rows.end());
+    }
   }
   (void)n_pub;
   S.chain_off.assign(max_level + 2, 0);
   for (auto& ch : chains) S.chain_off[ch.level + 1]++;
   for (size_t l = 1; l < S.chain_off.size(); ++l) S.chain_off[l] += S.chain_off[l - 1];
   S.chains.resize(chains.size());
+  S.chain_long.assign(max_level + 2, 0);
   {
+    // a chain longer than kLongChain steps is scanned by a whole workgroup, the others by one wave
     std::vector<uint32_t> cp(S.chain_off.begin(), S.chain_off.end() - 1);
-    for (auto& ch : chains) S.chains[cp[ch.level]++] = {ch.first, ch.n, ch.acc_w, ch.b_w};
+    for (auto& ch : chains)
+      if (ch.n > 128) { S.chains[cp[ch.level]++] = {ch.first, ch.n, ch.acc_w, ch.b_w}; S.chain_long[ch.level]++; }
+    for (auto& ch : chains)
+      if (ch.n <= 128) S.chains[cp[ch.level]++] = {ch.first, ch.n, ch.acc_w, ch.b_w};
   }
   for (uint32_t l = 1; l <= max_level; ++l) {
-    const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2_off[l + 1] - S.p2_off[l];
+    const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2seg_off[l + 1] - S.p2seg_off[l];
     const uint32_t nc = S.chain_off[l + 1] - S.chain_off[l];
     if (!nl && !np && !nc) continue;
     const bool narrow = nl <= 1024 && np <= 64 && !nc;
@@ -515,8 +545,8 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
     uint32_t start = seg.l0;
     S.chunk_bounds.push_back(start);
     for (uint32_t l = seg.l0; l < seg.l1; ++l) {
-      // records of levels [start, l + 1) must fit the LDS staging buffers (kNarrowLightCap / kNarrowP2Cap)
-      if (S.light_off[l + 1] - S.light_off[start] > 1400 || S.p2_off[l + 1] - S.p2_off[start] > 128) {
+      // light-op records of levels [start, l + 1) must fit the LDS staging buffer (kNarrowLightCap)
+      if (S.light_off[l + 1] - S.light_off[start] > 1400) {
         S.chunk_bounds.push_back(l);
         start = l;
         seg.n_chunks++;
@@ -572,7 +602,8 @@ struct RunArgs {
   const uint32_t* diag;
   uint32_t* err;
   const uint32_t* light_off;  // per level, device copies of the schedule offsets
-  const uint32_t* p2_off;
+  const RunSchedule::P2Seg* p2segs;
+  const uint32_t* p2seg_off;
 };
 
 // One ALU / hint / recompose / const op.
@@ -676,22 +707,25 @@ __device__ __forceinline__ void run_light_op(const RunArgs& A, const RunOp& op) 
   }
 }
 
-// One Poseidon2 permutation: lane j of a 16-lane group owns state element j (limb j/4, coeff j%4).
-// Whole waves must call this together (DPP inside coop_permute); `live` masks the tail.
+// One segment of chained Poseidon2 permutations: lane j of a 16-lane group owns state element j
+// (limb j/4, coefficient j%4) and walks the rows of the segment with the state in a register.
+// Whole 16-lane groups call this together (DPP inside coop_permute); `live` masks the tail groups.
 template <class PP>
-__device__ __forceinline__ void run_p2_op(const RunArgs& A, const RunP2* src, int j, bool live) {
+__device__ __forceinline__ void run_p2_segment(const RunArgs& A, RunSchedule::P2Seg seg, int j, bool live) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
   uint32_t* __restrict__ w = A.w;
   uint32_t* err = A.err;
-  F s = F::zero();
-  RunP2 q{};
-  bool bit = false;
-  if (live) {
-    q = *src;
+  if (!live) seg.n = 0;
+  F carried = F::zero();  // output of the previous row of this segment
+  RunP2 next = seg.n ? A.p2[seg.first] : RunP2{};
+  for (uint32_t k = 0; k < seg.n; ++k) {
+    const RunP2 q = next;
+    if (k + 1 < seg.n) next = A.p2[seg.first + k + 1];  // in flight while this row is permuted
     const bool new_start = q.flags & 1, merkle = q.flags & 2;
     // init_chain_state (executor.rs:103-139): Merkle rows carry the rate limbs only
-    if (!new_start && (!merkle || j < 8)) s = F::raw(A.p2_out[(size_t)q.prev_row * 16 + j]);
+    F s = F::zero();
+    if (!new_start && (!merkle || j < 8)) s = k ? carried : F::raw(A.p2_out[(size_t)q.prev_row * 16 + j]);
     // fill_sibling_data (:166-201): private sibling in the capacity limbs
     const int32_t slot = A.pd_slot[q.row];
     if (merkle && slot >= 0 && j >= 8) s = F::raw(A.siblings[(size_t)slot * 8 + (j - 8)]);
@@ -699,18 +733,17 @@ __device__ __forceinline__ void run_p2_op(const RunArgs& A, const RunP2* src, in
     const uint32_t in_w = q.in[j >> 2];
     if (in_w != kNoW) s = F::raw(w[(size_t)in_w * 4 + (j & 3)]);
     // resolve_mmcs_bit (:283-338)
+    bool bit = false;
     if (q.bit_w != kNoW) {
       const E v = w_load<PP>(w, q.bit_w);
       if (v == E::one()) bit = true;
       else if (!(v == E::zero()) && j == 0) run_error(err, q.op_idx, RUN_ERR_MMCS_BIT);
     }
-  }
-  // apply_merkle_swap (:227-234): the two halves trade places
-  {
-    const uint32_t other = __shfl_xor(s.v, 8);
-    if (live && (q.flags & 2) && bit) s = F::raw(other);
-  }
-  if (live) {
+    // apply_merkle_swap (:227-234): the two halves trade places
+    {
+      const uint32_t other = __shfl_xor(s.v, 8);
+      if (merkle && bit) s = F::raw(other);
+    }
     // Poseidon2CircuitRow (build_trace_row :364-417, trace.rs:188-233)
     A.p2_inputs[(size_t)j * A.p2_h + q.row] = s.v;
     if (j == 0) {
@@ -725,16 +758,15 @@ __device__ __forceinline__ void run_p2_op(const RunArgs& A, const RunP2* src, in
       }
       A.p2_seed[q.row] = seed;
     }
-  }
-  s = coop_permute<PP>(s, j, F::raw(A.diag[j]), A.rc);
-  if (live) {
+    s = coop_permute<PP>(s, j, F::raw(A.diag[j]), A.rc);
+    carried = s;
     A.p2_out[(size_t)q.row * 16 + j] = s.v;
     const uint32_t n_out = (q.flags >> 8) & 7;
     const uint32_t l = (uint32_t)j >> 2;
     if (l < n_out && q.out[l] != kNoW) {
-      uint32_t* slot = w + (size_t)q.out[l] * 4 + (j & 3);
-      if (q.flags & (1u << (4 + l))) { if (*slot != s.v) run_error(err, q.op_idx, RUN_ERR_CONFLICT); }
-      else *slot = s.v;
+      uint32_t* slot_w = w + (size_t)q.out[l] * 4 + (j & 3);
+      if (q.flags & (1u << (4 + l))) { if (*slot_w != s.v) run_error(err, q.op_idx, RUN_ERR_CONFLICT); }
+      else *slot_w = s.v;
     }
   }
 }
@@ -750,7 +782,8 @@ k_run_level(RunArgs A, uint32_t light_begin, uint32_t n_light, uint32_t light_bl
     return;
   }
   const uint32_t g = (blockIdx.x - light_blocks) * kBlock + threadIdx.x;
-  run_p2_op<PP>(A, A.p2 + p2_begin + (g >> 4), (int)(g & 15), (g >> 4) < n_p2);
+  const bool live = (g >> 4) < n_p2;
+  run_p2_segment<PP>(A, live ? A.p2segs[p2_begin + (g >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(g & 15), live);
 }
 
 // Horner chains of one level: one WAVE per chain evaluates acc_j = acc_{j-1}*b + (c_j - a_j) as an
@@ -806,40 +839,103 @@ k_run_chains(RunArgs A, const RunOp* __restrict__ steps, const RunSchedule::Chai
   }
 }
 
+// Long chains: the same scan with a whole workgroup per chain - slices are folded per lane, combined
+// by a shuffle scan inside each wave, the sixteen wave totals by one more shuffle scan through LDS.
+constexpr int kLongChainBlock = 1024;
+template <class PP>
+__global__ void __launch_bounds__(kLongChainBlock)
+k_run_chains_block(RunArgs A, const RunOp* __restrict__ steps, const RunSchedule::ChainSeg* __restrict__ segs) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  constexpr int kWaves = kLongChainBlock / 64;
+  __shared__ uint32_t s_m[kWaves][4], s_v[kWaves][4];
+  const RunSchedule::ChainSeg seg = segs[blockIdx.x];
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  uint32_t* __restrict__ w = A.w;
+  const E b = w_load<PP>(w, seg.b_w);
+  const uint32_t per = (seg.n + kLongChainBlock - 1) / kLongChainBlock;
+  const uint32_t i0 = min(t * per, seg.n), i1 = min(i0 + per, seg.n);
+  E M = E::one(), V = E::zero();
+  for (uint32_t i = i0; i < i1; ++i) {
+    const RunOp op = steps[seg.first + i];
+    V = V * b + w_load<PP>(w, op.c) - w_load<PP>(w, op.a);
+    M = M * b;
+  }
+  auto up = [&](const E& e, int d) { E r; for (int k = 0; k < 4; ++k) r.c[k] = F::raw(__shfl_up(e.c[k].v, d)); return r; };
+  for (int d = 1; d < 64; d <<= 1) {  // inclusive scan inside the wave
+    const E pm = up(M, d), pv = up(V, d);
+    if ((int)lane >= d) { V = pv * M + V; M = pm * M; }
+  }
+  if (lane == 63)
+    for (int k = 0; k < 4; ++k) { s_m[wave][k] = M.c[k].v; s_v[wave][k] = V.c[k].v; }
+  __syncthreads();
+  if (wave == 0) {  // inclusive scan of the wave totals, kept as EXCLUSIVE prefixes per wave
+    E tm = E::one(), tv = E::zero();
+    if (lane < kWaves)
+      for (int k = 0; k < 4; ++k) { tm.c[k] = F::raw(s_m[lane][k]); tv.c[k] = F::raw(s_v[lane][k]); }
+    for (int d = 1; d < kWaves; d <<= 1) {
+      const E pm = up(tm, d), pv = up(tv, d);
+      if ((int)lane >= d) { tv = pv * tm + tv; tm = pm * tm; }
+    }
+    const E em = up(tm, 1), ev = up(tv, 1);
+    if (lane < kWaves)
+      for (int k = 0; k < 4; ++k) {
+        s_m[lane][k] = lane ? em.c[k].v : E::one().c[k].v;
+        s_v[lane][k] = lane ? ev.c[k].v : 0u;
+      }
+  }
+  __syncthreads();
+  // incoming accumulator: acc0 through the earlier waves, then through the earlier lanes of this wave
+  E acc = w_load<PP>(w, seg.acc_w);
+  {
+    E wm, wv;
+    for (int k = 0; k < 4; ++k) { wm.c[k] = F::raw(s_m[wave][k]); wv.c[k] = F::raw(s_v[wave][k]); }
+    acc = acc * wm + wv;
+    const E pm = up(M, 1), pv = up(V, 1);
+    if (lane > 0) acc = acc * pm + pv;
+  }
+  for (uint32_t i = i0; i < i1; ++i) {
+    const RunOp op = steps[seg.first + i];
+    const E a = w_load<PP>(w, op.a), c = w_load<PP>(w, op.c);
+    acc = acc * b + c - a;
+    w_store<PP>(w, op.out, acc);
+    uint4* dst = reinterpret_cast<uint4*>(A.alu_values + (size_t)op.rec * 16);
+    dst[0] = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
+    dst[1] = make_uint4(b.c[0].v, b.c[1].v, b.c[2].v, b.c[3].v);
+    dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
+    dst[3] = make_uint4(acc.c[0].v, acc.c[1].v, acc.c[2].v, acc.c[3].v);
+  }
+}
+
 // Runs of NARROW levels (each at most kNarrowBlock light ops and kNarrowBlock/16 permutations)
 // inside ONE workgroup: the level barrier is a __syncthreads() instead of a kernel boundary.
 // All waves of a workgroup share the CU's vector L1, so workgroup-scope ordering is enough for
-// the witness table and the chain state to be seen by the next level.  The op records of a
-// chunk of levels (they are contiguous: the schedule is sorted by level) are staged in LDS by
+// the witness table and the chain state to be seen by the next level.  The light-op records of
+// a chunk of levels (they are contiguous: the schedule is sorted by level) are staged in LDS by
 // one coalesced copy, so a level does not start with a cold HBM read of its own ops.
 constexpr int kNarrowBlock = 1024;
-constexpr uint32_t kNarrowLightCap = 1400, kNarrowP2Cap = 128;  // records per chunk (63 KB of LDS)
+constexpr uint32_t kNarrowLightCap = 1400;  // light-op records per chunk (56 KB of LDS)
 template <class PP>
 __global__ void __launch_bounds__(kNarrowBlock)
 k_run_levels_narrow(RunArgs A, const uint32_t* __restrict__ chunk_bounds, uint32_t n_chunks) {
   __shared__ RunOp s_light[kNarrowLightCap];
-  __shared__ RunP2 s_p2[kNarrowP2Cap];
   const uint32_t t = threadIdx.x;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     const uint32_t l0 = chunk_bounds[c], l1 = chunk_bounds[c + 1];
-    const uint32_t lb0 = A.light_off[l0], pb0 = A.p2_off[l0];
+    const uint32_t lb0 = A.light_off[l0];
     {
       const uint32_t nw = (A.light_off[l1] - lb0) * (uint32_t)(sizeof(RunOp) / 4);
       const uint32_t* src = reinterpret_cast<const uint32_t*>(A.light + lb0);
       uint32_t* dst = reinterpret_cast<uint32_t*>(s_light);
       for (uint32_t i = t; i < nw; i += kNarrowBlock) dst[i] = src[i];
-      const uint32_t np_w = (A.p2_off[l1] - pb0) * (uint32_t)(sizeof(RunP2) / 4);
-      const uint32_t* psrc = reinterpret_cast<const uint32_t*>(A.p2 + pb0);
-      uint32_t* pdst = reinterpret_cast<uint32_t*>(s_p2);
-      for (uint32_t i = t; i < np_w; i += kNarrowBlock) pdst[i] = psrc[i];
     }
     __syncthreads();
     for (uint32_t l = l0; l < l1; ++l) {
       const uint32_t lb = A.light_off[l], nl = A.light_off[l + 1] - lb;
-      const uint32_t pb = A.p2_off[l], np = A.p2_off[l + 1] - pb;
+      const uint32_t pb = A.p2seg_off[l], np = A.p2seg_off[l + 1] - pb;
       if (t < nl) run_light_op<PP>(A, s_light[lb - lb0 + t]);
-      // whole waves enter together; waves with no live group skip the permutation
-      if ((t & ~63u) < np * 16) run_p2_op<PP>(A, s_p2 + (pb - pb0) + (t >> 4), (int)(t & 15), (t >> 4) < np);
+      const bool live = (t >> 4) < np;
+      if (__any(live)) run_p2_segment<PP>(A, live ? A.p2segs[pb + (t >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(t & 15), live);
       __syncthreads();
     }
   }
@@ -880,7 +976,7 @@ struct p3r_circuit {
   p3r_layer_desc_counts counts{};
   std::unique_ptr<p3r_layer> layer;
   p3r::DevBuf d_light, d_p2, d_ext, d_const_values, d_public_rows, d_private_rows, d_public_out, d_rewrite;
-  p3r::DevBuf d_light_off, d_p2_off, d_chunk_bounds, d_chain_ops, d_chains;
+  p3r::DevBuf d_light_off, d_p2seg_off, d_p2segs, d_chunk_bounds, d_chain_ops, d_chains;
 };
 
 // Inputs of one run made resident in HBM (public / private values, Merkle siblings).
@@ -949,7 +1045,8 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   up(C->d_public_out, S.public_out.data(), S.public_out.size() * 4);
   up(C->d_rewrite, S.rewrite_pairs.data(), S.rewrite_pairs.size() * 4);
   up(C->d_light_off, S.light_off.data(), S.light_off.size() * 4);
-  up(C->d_p2_off, S.p2_off.data(), S.p2_off.size() * 4);
+  up(C->d_p2seg_off, S.p2seg_off.data(), S.p2seg_off.size() * 4);
+  up(C->d_p2segs, S.p2segs.data(), S.p2segs.size() * sizeof(RunSchedule::P2Seg));
   up(C->d_chunk_bounds, S.chunk_bounds.data(), S.chunk_bounds.size() * 4);
   up(C->d_chain_ops, S.chain_ops.data(), S.chain_ops.size() * sizeof(RunOp));
   up(C->d_chains, S.chains.data(), S.chains.size() * sizeof(RunSchedule::ChainSeg));
@@ -1051,7 +1148,8 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     A.p2_inputs = p2_inputs; A.p2_h = p2_h; A.p2_flags = p2_flags; A.p2_seed = p2_seed; A.p2_out = p2_out.p;
     A.pd_slot = reinterpret_cast<const int32_t*>(d_slot.p); A.siblings = d_sib.p;
     A.rc = ctx->rc.p; A.diag = ctx->p2_diag.p; A.err = err.p;
-    A.light_off = C->d_light_off.p; A.p2_off = C->d_p2_off.p;
+    A.light_off = C->d_light_off.p; A.p2seg_off = C->d_p2seg_off.p;
+    A.p2segs = reinterpret_cast<const RunSchedule::P2Seg*>(C->d_p2segs.p);
     for (const auto& seg : S.segments) {
       if (seg.narrow) {
         hipLaunchKernelGGL(k_run_levels_narrow<PP>, dim3(1), dim3(kNarrowBlock), 0, ctx->stream, A,
@@ -1059,16 +1157,19 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
         continue;
       }
       const uint32_t l = seg.l0;
-      const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2_off[l + 1] - S.p2_off[l];
+      const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2seg_off[l + 1] - S.p2seg_off[l];
       const uint32_t lb = (nl + kBlock - 1) / kBlock, pb = (np * 16 + kBlock - 1) / kBlock;
       if (lb + pb)
         hipLaunchKernelGGL(k_run_level<PP>, dim3(lb + pb), dim3(kBlock), 0, ctx->stream, A, S.light_off[l], nl, lb,
-                           S.p2_off[l], np);
-      const uint32_t nc = S.chain_off[l + 1] - S.chain_off[l];
-      if (nc)
-        hipLaunchKernelGGL(k_run_chains<PP>, dim3((nc + 3) / 4), dim3(kChainBlock), 0, ctx->stream, A,
-                           reinterpret_cast<const RunOp*>(C->d_chain_ops.p),
-                           reinterpret_cast<const RunSchedule::ChainSeg*>(C->d_chains.p) + S.chain_off[l], nc);
+                           S.p2seg_off[l], np);
+      const uint32_t nc = S.chain_off[l + 1] - S.chain_off[l], n_long = S.chain_long[l];
+      const RunOp* steps = reinterpret_cast<const RunOp*>(C->d_chain_ops.p);
+      const RunSchedule::ChainSeg* segs = reinterpret_cast<const RunSchedule::ChainSeg*>(C->d_chains.p) + S.chain_off[l];
+      if (n_long)
+        hipLaunchKernelGGL(k_run_chains_block<PP>, dim3(n_long), dim3(kLongChainBlock), 0, ctx->stream, A, steps, segs);
+      if (nc > n_long)
+        hipLaunchKernelGGL(k_run_chains<PP>, dim3((nc - n_long + 3) / 4), dim3(kChainBlock), 0, ctx->stream, A, steps,
+                           segs + n_long, nc - n_long);
     }
     if (!S.rewrite_pairs.empty())
       hipLaunchKernelGGL(k_run_rewrite<PP>, dim3(blocks_for(S.rewrite_pairs.size() / 3)), dim3(kBlock), 0, ctx->stream,
