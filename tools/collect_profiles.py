@@ -35,7 +35,7 @@ kern = {k: {"launches": len(fe.get(k, [])),
             "write_kb_per_launch": sum(wr.get(k, [0])) / max(len(wr.get(k, [])), 1)} for k in sorted(set(fe) | set(wr))}
 json.dump({
     "provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
-                  "`python3 bench.py --no-cpu-baseline --steps 1 --warmup 0` (tools/profile_round.sh), MI355X, round 1 "
+                  "`python3 bench.py --no-cpu-baseline --no-config2 --steps 1 --warmup 0` (tools/profile_round.sh), MI355X, round 1 "
                   "final; counter unit KB; averages over every launch of the kernel in the run (circuit preparation + "
                   "3 prove_next_layer)",
     "note": "raw counter values. gfx950 tallies the 128-B requests of a coalesced streaming read at 64 B, so FETCH_SIZE is "
