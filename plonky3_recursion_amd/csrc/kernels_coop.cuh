@@ -38,6 +38,15 @@ __device__ __forceinline__ F coop_row_sum(F x) {
   return t + F::raw(dpp<DPP_ROW_ROR1>(t.v));
 }
 
+// Value of row-lane 0 on every lane of the row; `x0` must be zero on lanes 1..15, so the three
+// combining steps are plain ORs (no modular reduction on this dependent path).
+constexpr int DPP_QUAD_BCAST0 = 0x00;  // quad_perm:[0,0,0,0]
+__device__ __forceinline__ uint32_t coop_bcast0(uint32_t x0) {
+  uint32_t q = dpp<DPP_QUAD_BCAST0>(x0);  // lanes 0..3 (the other quads read their own zero)
+  q |= dpp<DPP_ROW_ROR4>(q);
+  return q | dpp<DPP_ROW_ROR8>(q);
+}
+
 // `s`: this lane's state element (lane & 15 = element index).  `diag`: Montgomery internal
 // diagonal of this lane.  Round constants `rc` as in poseidon2.h.
 template <class PP>
@@ -51,10 +60,12 @@ __device__ __forceinline__ Fp<PP> coop_permute(Fp<PP> s, int elem, Fp<PP> diag, 
     s = coop_external(s);
   }
   for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
-    F sb = p2_sbox<PP>(s + F::raw(rc[k + r]));
-    s = elem == 0 ? sb : s;
-    F sum = coop_row_sum(s);
-    s = s * diag + sum;
+    // sum(s') = S-box output of element 0 + the sum of the other fifteen: the latter and the
+    // products d_i * s_i do not wait for the S-box, only its broadcast and two additions do
+    const F rest = coop_row_sum(elem == 0 ? F::zero() : s);
+    const F sb = p2_sbox<PP>(s + F::raw(rc[k + r]));
+    const F sum = rest + F::raw(coop_bcast0(elem == 0 ? sb.v : 0u));
+    s = (elem == 0 ? sb : s) * diag + sum;
   }
   k += PP::PARTIAL_ROUNDS;
   for (int r = 0; r < P2_HALF_FULL; ++r) {
