@@ -23,6 +23,18 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed) {
       if (OP == 5) d[i] = __builtin_fma(d[i], 1.0000001, 0.5);        // v_fma_f64
       if (OP == 6) { uint32_t t = a[i] + a[(i + 1) & 15]; a[i] = min(t, t - 0x7f000001u); }                   // add, sub, min
       if (OP == 7) { uint32_t lo = a[i] * b, hi = __umulhi(a[i], b); uint32_t t = lo * 0x81000001u; uint32_t u = __umulhi(t, 0x7f000001u); uint32_t r = hi - u; a[i] = hi < u ? r + 0x7f000001u : r; }  // Montgomery product
+      if (OP == 9) {  // Shoup product by a fixed w (w' = floor(w 2^32 / P)): 1 mul_hi + 2 mul_lo
+        uint32_t q = __umulhi(a[i], 0x9A3C5E71u);
+        uint32_t r = a[i] * b - q * 0x7f000001u;
+        a[i] = min(r, r - 0x7f000001u) + i;
+      }
+      if (OP == 8) {  // Montgomery product through two 64-bit multiply-adds: x = a*b; y = q*P + x; r = y >> 32
+        uint64_t x = (uint64_t)a[i] * b;
+        uint32_t q = (uint32_t)x * 0x7EFFFFFFu;
+        uint64_t y = (uint64_t)q * 0x7f000001u + x;
+        uint32_t r = (uint32_t)(y >> 32);
+        a[i] = min(r, r - 0x7f000001u);
+      }
     }
   }
   uint32_t s = 0;
@@ -58,5 +70,7 @@ int main() {
   run<5>(out, "v_fma_f64", 1);
   run<6>(out, "modular add (add,sub,min)", 1);
   run<7>(out, "Montgomery product", 1);
+  run<8>(out, "Montgomery via mad_u64_u32", 1);
+  run<9>(out, "Shoup product (+add)", 1);
   return 0;
 }
