@@ -28,7 +28,7 @@ struct NttPass {
   int log_t;     // lines per tile
   int out_mode;  // 0 keep row order (bit-reversed); 1 natural order, same geometry;
                  // 2 natural order, transposed: out[n2*N1 + k1] (sub_dim 0 only)
-  const uint32_t* tw_sub;   // Shoup pairs (w_R^i canonical, floor(w*2^32/P)) for i < R/2
+  const uint32_t* tw_sub;   // w_R^i in Montgomery form, i < R/2
   const uint32_t* tw4_lo;   // optional 4-step twiddles: w_N^x = hi[x >> 10] * lo[x & 1023]
   const uint32_t* tw4_hi;
   const uint32_t* pre_a;    // optional per-coset input scaling pre_a[z][n1] * pre_b[z][n2]
@@ -127,12 +127,13 @@ __device__ __forceinline__ void ntt_stage_group(uint32_t* tile, const uint32_t* 
       for (int jj = 0; jj < M / 2; ++jj) {
         if (jj < half) {
           const uint32_t idx = base_idx + ((uint32_t)jj << (lq + s + u));
-          const uint2 tw = *reinterpret_cast<const uint2*>(&tws[2 * idx]);
+          const uint32_t tw = tws[idx];
 #pragma unroll
           for (int blk = 0; blk < M; blk += 2 * half) {
             F p = x[blk + jj], c = x[blk + jj + half];
             x[blk + jj] = p + c;
-            x[blk + jj + half] = shoup_mul<PP>(p.v + (PP::P - c.v), tw.x, tw.y);
+            // (p - c + P) < 2P < 2^32 times a Montgomery twiddle < P: within REDC's input range
+            x[blk + jj + half] = F::raw(F::reduce64((uint64_t)(p.v + (PP::P - c.v)) * tw));
           }
         }
       }
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
                    a.pre_a ? a.pre_a + (size_t)blockIdx.z * N1 : nullptr,
                    a.pre_b ? a.pre_b + (size_t)blockIdx.z * N2 : nullptr,
                    blockIdx.x * T, N1, N2, log_r};
-  for (uint32_t i = tid; i < R; i += blockDim.x) tws[i] = a.tw_sub[i];
+  for (uint32_t i = tid; i < R / 2; i += blockDim.x) tws[i] = a.tw_sub[i];
   __syncthreads();
   const uint32_t E = R << a.log_t;
 

@@ -154,18 +154,16 @@ const uint32_t* get_tw_sub(p3r_ctx* ctx, int log_r, int inverse) {
   if (it != ctx->tw_sub.end()) return it->second.p;
   using F = Fp<PP>;
   size_t half = log_r ? (size_t(1) << (log_r - 1)) : 1;
-  std::vector<uint32_t> t(2 * half);
+  std::vector<uint32_t> t(half);
   F root = F::two_adic_generator(log_r);
   if (inverse) root = root.inv();
   F x = F::one();
   for (size_t i = 0; i < half; ++i) {
-    const uint32_t w = x.to_canonical();
-    t[2 * i] = w;
-    t[2 * i + 1] = (uint32_t)(((uint64_t)w << 32) / PP::P);
+    t[i] = x.v;  // Montgomery form
     x *= root;
   }
-  DevBuf d(2 * half);
-  P3R_HIP(copy_sync(ctx->stream, d.p, t.data(), 2 * half * 4, hipMemcpyHostToDevice));
+  DevBuf d(half);
+  P3R_HIP(copy_sync(ctx->stream, d.p, t.data(), half * 4, hipMemcpyHostToDevice));
   return ctx->tw_sub.emplace(key, std::move(d)).first->second.p;
 }
 
