@@ -305,14 +305,18 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
     p.tw_sub = get_tw_sub<PP>(ctx, lb, 1); p.inverse = 1;
     p.scale = inv_n; p.use_scale = 1;
     launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
-    // forward pass 1 (all cosets): scale by s_z^k, size-N1 transforms along n1, twiddle, in place rows
-    auto pre = get_pre<PP>(ctx, log_n, la, lb, added_bits, shift);
+    // forward pass 1 (all cosets): scale by s_z^k, size-N1 transforms along n1, twiddle, in place rows.
+    // The forward transform has its own split: its strided pass wants few rows per tile (long
+    // contiguous segments per row), its second pass is contiguous whatever N2 is.
+    static const int fwd_la_cap = getenv("P3R_NTT_FWD_LOG_N1") ? atoi(getenv("P3R_NTT_FWD_LOG_N1")) : 8;
+    const int la_f = std::max(log_n - 13, std::min(log_n / 2, fwd_la_cap)), lb_f = log_n - la_f;
+    auto pre = get_pre<PP>(ctx, log_n, la_f, lb_f, added_bits, shift);
     auto tw4f = get_tw4<PP>(ctx, log_n, 0);
     p = NttPass{};
     p.in = coef.p; p.out = out->d;
     p.in_col_stride = N; p.out_col_stride = N * B; p.out_coset_stride = N;
-    p.log_n1 = la; p.log_n2 = lb; p.sub_dim = 0; p.out_mode = 0;
-    p.tw_sub = get_tw_sub<PP>(ctx, la, 0);
+    p.log_n1 = la_f; p.log_n2 = lb_f; p.sub_dim = 0; p.out_mode = 0;
+    p.tw_sub = get_tw_sub<PP>(ctx, la_f, 0);
     p.tw4_lo = tw4f.first; p.tw4_hi = tw4f.second;
     p.pre_a = pre.first; p.pre_b = pre.second;
     launch_ntt<PP>(ctx, p, w, B, "ntt_forward");
@@ -321,8 +325,8 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
     p = NttPass{};
     p.in = out->d; p.out = out->d;
     p.in_col_stride = N * B; p.out_col_stride = N * B;
-    p.log_n1 = la + added_bits; p.log_n2 = lb; p.sub_dim = 1; p.out_mode = 0;
-    p.tw_sub = get_tw_sub<PP>(ctx, lb, 0);
+    p.log_n1 = la_f + added_bits; p.log_n2 = lb_f; p.sub_dim = 1; p.out_mode = 0;
+    p.tw_sub = get_tw_sub<PP>(ctx, lb_f, 0);
     launch_ntt<PP>(ctx, p, w, 1, "ntt_forward");
   }
   return out;
