@@ -99,6 +99,26 @@ struct Fp {
 #endif
   }
   static P3R_HD uint32_t reduce(uint32_t lo, uint32_t hi) { return reduce64(((uint64_t)hi << 32) | lo); }
+  // REDC without the final conditional subtraction: a value in [0, 2P) congruent to x * 2^-32.
+  // Usable wherever the next operation is a product with a fully reduced factor (2P * P < P * 2^32).
+  static P3R_HD uint32_t reduce64_lazy(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t q = (uint32_t)x * NEG_MU;
+    return (uint32_t)(((uint64_t)q * P + x) >> 32);
+#else
+    return reduce64(x);
+#endif
+  }
+  // (a * a) * x with the square left unreduced in between
+  P3R_HD Fp sqr_times(Fp x) const {
+    const uint32_t sq = reduce64_lazy((uint64_t)v * v);
+    return raw(reduce64((uint64_t)sq * x.v));
+  }
+  // a * a * a with the square left unreduced in between
+  P3R_HD Fp cube() const {
+    const uint32_t sq = reduce64_lazy((uint64_t)v * v);
+    return raw(reduce64((uint64_t)sq * v));
+  }
   static P3R_HD Fp raw(uint32_t m) { Fp r; r.v = m; return r; }
   static P3R_HD Fp zero() { return raw(0); }
   static P3R_HD Fp one() { return raw(R1); }

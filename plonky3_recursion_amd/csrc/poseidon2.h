@@ -111,10 +111,9 @@ P3R_HD void p2_internal_linear(F* s) {
 
 template <class PP, class F>
 P3R_HD F p2_sbox(F x) {
-  F x2 = x.sqr();
-  F x3 = x2 * x;
+  F x3 = x.cube();
   if (PP::SBOX_DEGREE == 3) return x3;
-  return x3.sqr() * x;  // x^7
+  return x3.sqr_times(x);  // x^7
 }
 
 // Trace sink used by the circuit-table fill (K3): receives every committed cell in
@@ -135,9 +134,9 @@ P3R_HD void p2_permute_traced(F* s, const uint32_t* __restrict__ rc, Sink& sink)
     for (int i = 0; i < P2_WIDTH; ++i) {
       F x = s[i] + F::raw(rc[k + i]);
       if (PP::SBOX_REGISTERS == 1) {
-        F x3 = x.sqr() * x;
+        F x3 = x.cube();
         sink.put(x3);
-        s[i] = x3.sqr() * x;
+        s[i] = x3.sqr_times(x);
       } else {
         s[i] = p2_sbox<PP>(x);
       }
@@ -150,9 +149,9 @@ P3R_HD void p2_permute_traced(F* s, const uint32_t* __restrict__ rc, Sink& sink)
   for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
     F x = s[0] + F::raw(rc[k + r]);
     if (PP::SBOX_REGISTERS == 1) {
-      F x3 = x.sqr() * x;
+      F x3 = x.cube();
       sink.put(x3);
-      s[0] = x3.sqr() * x;
+      s[0] = x3.sqr_times(x);
     } else {
       s[0] = p2_sbox<PP>(x);
     }
@@ -165,9 +164,9 @@ P3R_HD void p2_permute_traced(F* s, const uint32_t* __restrict__ rc, Sink& sink)
     for (int i = 0; i < P2_WIDTH; ++i) {
       F x = s[i] + F::raw(rc[k + i]);
       if (PP::SBOX_REGISTERS == 1) {
-        F x3 = x.sqr() * x;
+        F x3 = x.cube();
         sink.put(x3);
-        s[i] = x3.sqr() * x;
+        s[i] = x3.sqr_times(x);
       } else {
         s[i] = p2_sbox<PP>(x);
       }
