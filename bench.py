@@ -278,11 +278,12 @@ def main():
         }
         # The dominant kernel is integer-VALU bound, so next to the HBM roofline the contract asks for
         # we price it against the measured issue rate of the chip (tools/microbench/int_rates.hip:
-        # 54.5 T simple lane-ops/s sustained) and the ~9.0 k instructions of one KoalaBear permutation
-        # (8 full rounds x 520 + 20 partial rounds x 222 + ~300, from the gfx950 ISA of the kernel).
+        # 54.5 T simple lane-ops/s sustained) and the ~7.8 k instructions of one KoalaBear permutation
+        # (gfx950 ISA of the kernel: 4 x 406 + 4 x 432 for the full rounds, 20 x 207 for the partial
+        # rounds, 319 around them; a Montgomery product is v_mad_u64_u32 + v_mul_lo_u32 + v_mad_u64_u32).
         hash_total_ms = kernel_ms.get("mmcs_hash_rows", 0.0)
         if field == "koala-bear" and hash_total_ms:
-            peak = 54.5e12 / 9.0e3
+            peak = 54.5e12 / 7.8e3
             ach = hash_perms / (hash_total_ms * 1e-3)
             line["valu_roofline"] = {"kernel": "k_mmcs_hash_rows", "bound": "int-valu",
                                      "achieved": ach, "peak": peak, "unit": "Poseidon2 perms/s", "frac": ach / peak,
