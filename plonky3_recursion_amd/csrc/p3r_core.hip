@@ -309,7 +309,9 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
     // The forward transform has its own split: its strided pass wants few rows per tile (long
     // contiguous segments per row), its second pass is contiguous whatever N2 is.
     static const int fwd_la_cap = getenv("P3R_NTT_FWD_LOG_N1") ? atoi(getenv("P3R_NTT_FWD_LOG_N1")) : 8;
-    const int la_f = std::max(log_n - 13, std::min(log_n / 2, fwd_la_cap)), lb_f = log_n - la_f;
+    // (measured: 2^8 x 2^12 beats 2^10 x 2^10 at n = 2^20; past 2^12 contiguous points per line the
+    // balanced split is better again)
+    const int la_f = log_n - fwd_la_cap <= 12 ? std::min(log_n / 2, fwd_la_cap) : log_n / 2, lb_f = log_n - la_f;
     auto pre = get_pre<PP>(ctx, log_n, la_f, lb_f, added_bits, shift);
     auto tw4f = get_tw4<PP>(ctx, log_n, 0);
     p = NttPass{};
