@@ -58,12 +58,25 @@ P3R_HD void p2_external_linear(F* s) {
   for (int i = 0; i < P2_WIDTH; ++i) s[i] += sum[i & 3];
 }
 
-// Multiply a Montgomery-form value by 2^-k with one reduction: feed x * 2^(32-k) to REDC.
+// Multiply a Montgomery-form value by 2^-k.  Both primes are c*2^m + 1 (KoalaBear 127*2^24 + 1,
+// BabyBear 15*2^27 + 1), so 2^-m = -c and, for k <= m,
+//     x / 2^k  =  (x >> k)  -  c * ((x mod 2^k) << (m - k))      (mod P),
+// with both terms below P: shifts, one small multiply, one conditional correction - no REDC.
+// (Montgomery form is linear, so the same map applies to the representative.)
 template <class F>
 P3R_HD F p2_div_2exp(F x, int k) {
-  uint32_t lo = x.v << (32 - k);
-  uint32_t hi = x.v >> k;
-  return F::raw(F::reduce(lo, hi));
+  using PP = typename F::Params;
+  constexpr int M = PP::TWO_ADICITY;                 // 24 / 27
+  constexpr uint32_t C = (PP::P - 1) >> M;           // 127 / 15
+  const uint32_t hi = x.v >> k;
+  const uint32_t t = (x.v << (32 - k)) >> (32 - M);  // (x mod 2^k) << (M - k), below 2^M
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t m = M <= 24 ? __umul24(t, C) : (t << 4) - t;  // C = 15 = 2^4 - 1 when M = 27
+#else
+  const uint32_t m = t * C;
+#endif
+  const uint32_t d = hi - m, d2 = d + PP::P;
+  return F::raw(d < d2 ? d : d2);
 }
 
 template <class PP>
