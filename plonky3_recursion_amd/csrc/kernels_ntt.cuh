@@ -38,7 +38,7 @@ struct NttPass {
   int inverse;
 };
 
-constexpr int kNttBlock = 1024;  // upper bound; launches use tile_cells/16 lanes
+constexpr int kNttBlock = 512;  // launches use tile_cells/16 lanes (2^13-cell tiles)
 
 __device__ __forceinline__ uint32_t lds_addr(uint32_t r, uint32_t t, uint32_t T) {
   return r * (T + 1) + (r >> 5) + t;
@@ -159,7 +159,7 @@ __device__ __forceinline__ void ntt_group_dispatch(int logm, uint32_t* tile, con
 }
 
 template <class PP>
-__global__ void __launch_bounds__(kNttBlock) k_ntt_tile(NttPass a) {
+__global__ void __launch_bounds__(kNttBlock, 8) k_ntt_tile(NttPass a) {
   using F = Fp<PP>;
   extern __shared__ uint32_t lds[];
   const uint32_t tid = threadIdx.x;

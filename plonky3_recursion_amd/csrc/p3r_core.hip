@@ -236,7 +236,7 @@ void launch_ntt(p3r_ctx* ctx, NttPass a, size_t ncols, size_t ncosets, const cha
   const int log_r = a.sub_dim == 0 ? a.log_n1 : a.log_n2;
   const int log_lines = a.sub_dim == 0 ? a.log_n2 : a.log_n1;
   static const int log_tile = getenv("P3R_NTT_LOG_TILE") ? atoi(getenv("P3R_NTT_LOG_TILE")) : 13;  // 2^13 cells, 512 lanes: 4 tiles per CU overlap their phases
-  int log_t = std::max(0, log_tile - log_r);
+  int log_t = std::max(0, std::min(log_tile, 13) - log_r);
   if (a.sub_dim == 0 && log_t > 5) log_t = 5;  // 128-byte segments are enough when strided
   log_t = std::min(log_t, log_lines);
   a.log_t = log_t;
