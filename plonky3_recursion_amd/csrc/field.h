@@ -137,6 +137,11 @@ struct Fp {
     return raw(a.v < b.v ? d + P : d);
   }
   friend P3R_HD Fp operator*(Fp a, Fp b) { return raw(reduce64((uint64_t)a.v * b.v)); }
+  // a1*b1 + a2*b2 with ONE reduction: 2*P^2 < P*2^32, so the sum of two products is still inside
+  // REDC's input range (inner products and constraint folds pair their terms)
+  static P3R_HD Fp dot2(Fp a1, Fp b1, Fp a2, Fp b2) {
+    return raw(reduce64((uint64_t)a1.v * b1.v + (uint64_t)a2.v * b2.v));
+  }
   P3R_HD Fp operator-() const { return raw(v ? P - v : 0); }
   P3R_HD Fp& operator+=(Fp o) { *this = *this + o; return *this; }
   P3R_HD Fp& operator-=(Fp o) { *this = *this - o; return *this; }
@@ -209,6 +214,12 @@ struct Fp4 {
   friend P3R_HD Fp4 operator*(Fp4 a, F b) {
     Fp4 r;
     for (int i = 0; i < 4; ++i) r.c[i] = a.c[i] * b;
+    return r;
+  }
+  // a1*b1 + a2*b2 for extension a's and base b's, one reduction per coefficient
+  static P3R_HD Fp4 dot2_base(const Fp4& a1, F b1, const Fp4& a2, F b2) {
+    Fp4 r;
+    for (int i = 0; i < 4; ++i) r.c[i] = F::dot2(a1.c[i], b1, a2.c[i], b2);
     return r;
   }
   P3R_HD Fp4& operator+=(Fp4 o) { *this = *this + o; return *this; }

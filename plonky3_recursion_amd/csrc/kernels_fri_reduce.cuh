@@ -38,12 +38,16 @@ __global__ void __launch_bounds__(kBlock) k_fri_reduce_pre(FriReducePreArgs a) {
   size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= a.h) return;
   E S = E::zero();
-  for (int c = 0; c < a.w; ++c) {
+  auto apow = [&](int c) {
     E ap;
 #pragma unroll
     for (int k = 0; k < 4; ++k) ap.c[k] = F::raw(a.apow[4 * c + k]);
-    S += ap * F::raw(a.mat[(size_t)c * a.h + r]);
-  }
+    return ap;
+  };
+  int c = 0;
+  for (; c + 1 < a.w; c += 2)  // two columns per reduction
+    S += E::dot2_base(apow(c), F::raw(a.mat[(size_t)c * a.h + r]), apow(c + 1), F::raw(a.mat[(size_t)(c + 1) * a.h + r]));
+  if (c < a.w) S += apow(c) * F::raw(a.mat[(size_t)c * a.h + r]);
   E acc;
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc.c[k] = F::raw(a.ro[(size_t)k * a.h + r]);

@@ -327,18 +327,29 @@ k_open_dot_t(const uint32_t* __restrict__ mat, size_t n, int w, const uint32_t* 
   for (int p = 0; p < P; ++p)
 #pragma unroll
     for (int c = 0; c < kOpenCols; ++c) acc[p][c] = E::zero();
-  for (size_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
-    E wv[P];
+  // two rows per step: their products share one reduction per coefficient
+  for (size_t r = r0 + threadIdx.x; r < r1; r += 2 * kBlock) {
+    const size_t rb = r + kBlock;
+    const bool has_b = rb < r1;
+    E wa[P], wb[P];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) wv[0].c[k] = F::raw(wt0[(size_t)k * n + r]);
+    for (int k = 0; k < 4; ++k) {
+      wa[0].c[k] = F::raw(wt0[(size_t)k * n + r]);
+      wb[0].c[k] = has_b ? F::raw(wt0[(size_t)k * n + rb]) : F::zero();
+    }
     if (P == 2)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) wv[P - 1].c[k] = F::raw(wt1[(size_t)k * n + r]);
+      for (int k = 0; k < 4; ++k) {
+        wa[P - 1].c[k] = F::raw(wt1[(size_t)k * n + r]);
+        wb[P - 1].c[k] = has_b ? F::raw(wt1[(size_t)k * n + rb]) : F::zero();
+      }
 #pragma unroll
     for (int c = 0; c < kOpenCols; ++c) {
-      F m = c0 + c < w ? F::raw(mat[(size_t)(c0 + c) * n + r]) : F::zero();
+      const bool col = c0 + c < w;
+      const F ma = col ? F::raw(mat[(size_t)(c0 + c) * n + r]) : F::zero();
+      const F mb = col && has_b ? F::raw(mat[(size_t)(c0 + c) * n + rb]) : F::zero();
 #pragma unroll
-      for (int p = 0; p < P; ++p) acc[p][c] += wv[p] * m;
+      for (int p = 0; p < P; ++p) acc[p][c] += E::dot2_base(wa[p], ma, wb[p], mb);
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
