@@ -228,7 +228,8 @@ P3R_HD void poseidon2_constraints(const View& v, typename View::V is_transition,
   for (int l = 0; l < 4; ++l) {
     F gate = is_transition * v.PN(l * 4 + 2);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) fold.base(gate * (v.N(l * 4 + d) - v.L(out_col + l * 4 + d)));
+    for (int d = 0; d < 4; d += 2)
+      fold.base2(gate * (v.N(l * 4 + d) - v.L(out_col + l * 4 + d)), gate * (v.N(l * 4 + d + 1) - v.L(out_col + l * 4 + d + 1)));
   }
   // Merkle chaining, left then right placement
   F is_left = one - next_bit;
@@ -265,10 +266,11 @@ P3R_HD void poseidon2_constraints(const View& v, typename View::V is_transition,
     col += P2_WIDTH * R;
     p2_external_linear(s);
 #pragma unroll
-    for (int i = 0; i < P2_WIDTH; ++i) {
-      F post = v.L(col + i);
-      fold.base(s[i] - post);
-      s[i] = post;
+    for (int i = 0; i < P2_WIDTH; i += 2) {
+      F post0 = v.L(col + i), post1 = v.L(col + i + 1);
+      fold.base2(s[i] - post0, s[i + 1] - post1);
+      s[i] = post0;
+      s[i + 1] = post1;
     }
     col += P2_WIDTH;
   };

@@ -209,6 +209,11 @@ struct BaseFold {
     return p;
   }
   __device__ __forceinline__ void base(F c) { acc += pw() * c; }
+  // two consecutive base constraints: their products share one reduction per coefficient
+  __device__ __forceinline__ void base2(F c0, F c1) {
+    const E p0 = pw(), p1 = pw();
+    acc += E::dot2_base(p0, c0, p1, c1);
+  }
   __device__ __forceinline__ void ext(const E& c) { acc += pw() * c; }
 };
 

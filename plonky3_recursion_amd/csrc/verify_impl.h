@@ -197,6 +197,7 @@ struct ZetaFold {
   E alpha, acc = E::zero();
   int count = 0;
   void base(const E& c) { acc = acc * alpha + c; ++count; }
+  void base2(const E& c0, const E& c1) { base(c0); base(c1); }
   void ext(const E& c) { base(c); }
 };
 
