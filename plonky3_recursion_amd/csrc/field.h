@@ -203,12 +203,14 @@ struct Fp4 {
     return r;
   }
   friend P3R_HD Fp4 operator*(Fp4 a, Fp4 b) {
+    // W folded into a's high coefficients, then every output coefficient is two paired products
     const F W = w();
+    const F wa1 = W * a.c[1], wa2 = W * a.c[2], wa3 = W * a.c[3];
     Fp4 r;
-    r.c[0] = a.c[0] * b.c[0] + W * (a.c[1] * b.c[3] + a.c[2] * b.c[2] + a.c[3] * b.c[1]);
-    r.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0] + W * (a.c[2] * b.c[3] + a.c[3] * b.c[2]);
-    r.c[2] = a.c[0] * b.c[2] + a.c[1] * b.c[1] + a.c[2] * b.c[0] + W * (a.c[3] * b.c[3]);
-    r.c[3] = a.c[0] * b.c[3] + a.c[1] * b.c[2] + a.c[2] * b.c[1] + a.c[3] * b.c[0];
+    r.c[0] = F::dot2(a.c[0], b.c[0], wa1, b.c[3]) + F::dot2(wa2, b.c[2], wa3, b.c[1]);
+    r.c[1] = F::dot2(a.c[0], b.c[1], a.c[1], b.c[0]) + F::dot2(wa2, b.c[3], wa3, b.c[2]);
+    r.c[2] = F::dot2(a.c[0], b.c[2], a.c[1], b.c[1]) + F::dot2(a.c[2], b.c[0], wa3, b.c[3]);
+    r.c[3] = F::dot2(a.c[0], b.c[3], a.c[1], b.c[2]) + F::dot2(a.c[2], b.c[1], a.c[3], b.c[0]);
     return r;
   }
   friend P3R_HD Fp4 operator*(Fp4 a, F b) {
