@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp3r_hip.so")
+# P3R_LIB_PATH: A/B runs of two builds of the library on one box (development only)
+LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so")
 
 P3R_ABI_VERSION = 1
 FIELD_KOALA_BEAR = 0
