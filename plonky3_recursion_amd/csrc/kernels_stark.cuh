@@ -313,20 +313,20 @@ k_bary_weights(size_t n, uint32_t w_n, E4 z, E4 scale, uint32_t* __restrict__ ou
 }
 
 constexpr int kOpenCols = 8;      // matrix columns sharing one pass over the weights
-constexpr int kOpenRows = 8192;   // rows per block
+constexpr int kOpenRows = 8192;   // rows per block for tall matrices (the host shrinks it for short ones)
 // partial[p][chunk][col] = sum over the chunk's rows of weights_p[row] * M[col][row].
 // All accumulator indexing is compile-time (register resident); the block reduction is a
 // wave shuffle tree followed by a 4-wave LDS combine.
 template <class PP, int P>
 __global__ void __launch_bounds__(kBlock)
 k_open_dot_t(const uint32_t* __restrict__ mat, size_t n, int w, const uint32_t* __restrict__ wt0,
-             const uint32_t* __restrict__ wt1, uint32_t* __restrict__ partial, int n_chunks) {
+             const uint32_t* __restrict__ wt1, uint32_t* __restrict__ partial, int n_chunks, int rows_per_block) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
   constexpr int NV = P * kOpenCols * 4;
   __shared__ uint32_t sh[kBlock / 64][NV];
   const int c0 = blockIdx.x * kOpenCols, chunk = blockIdx.y;
-  size_t r0 = (size_t)chunk * kOpenRows, r1 = r0 + kOpenRows < n ? r0 + kOpenRows : n;
+  size_t r0 = (size_t)chunk * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
   E acc[P][kOpenCols];
 #pragma unroll
   for (int p = 0; p < P; ++p)
@@ -380,9 +380,9 @@ k_open_dot_t(const uint32_t* __restrict__ mat, size_t n, int w, const uint32_t* 
 }
 template <class PP>
 void launch_open_dot(hipStream_t stream, dim3 grid, const uint32_t* mat, size_t n, int w, const uint32_t* wt0,
-                     const uint32_t* wt1, uint32_t* partial, int n_chunks) {
-  if (wt1) hipLaunchKernelGGL((k_open_dot_t<PP, 2>), grid, dim3(kBlock), 0, stream, mat, n, w, wt0, wt1, partial, n_chunks);
-  else hipLaunchKernelGGL((k_open_dot_t<PP, 1>), grid, dim3(kBlock), 0, stream, mat, n, w, wt0, wt1, partial, n_chunks);
+                     const uint32_t* wt1, uint32_t* partial, int n_chunks, int rows_per_block) {
+  if (wt1) hipLaunchKernelGGL((k_open_dot_t<PP, 2>), grid, dim3(kBlock), 0, stream, mat, n, w, wt0, wt1, partial, n_chunks, rows_per_block);
+  else hipLaunchKernelGGL((k_open_dot_t<PP, 1>), grid, dim3(kBlock), 0, stream, mat, n, w, wt0, wt1, partial, n_chunks, rows_per_block);
 }
 template <class PP>
 __global__ void __launch_bounds__(kBlock)

@@ -40,11 +40,19 @@ struct Opener {
     const F inv_shift = dshift.inv();
     const uint32_t* w0 = weights(n, points[0] * inv_shift);
     const uint32_t* w1 = P == 2 ? weights(n, points[1] * inv_shift) : nullptr;
-    const int n_chunks = (int)((n + kOpenRows - 1) / kOpenRows);
+    // rows per block: 8192 for tall matrices, fewer for short ones so the launch still has
+    // ~1000 workgroups (a 2^16-row table would otherwise occupy a third of the chip)
+    const size_t col_groups = (w + kOpenCols - 1) / kOpenCols;
+    size_t rows_per_block = kOpenRows;
+    // (at most 64 chunks: the final reduction walks them serially)
+    while (rows_per_block > 2 * kBlock && (n + rows_per_block - 1) / rows_per_block < 64 &&
+           col_groups * ((n + rows_per_block - 1) / rows_per_block) < 1024)
+      rows_per_block /= 2;
+    const int n_chunks = (int)((n + rows_per_block - 1) / rows_per_block);
     DevBuf partial((size_t)P * n_chunks * w * 4);
     ProfScope ps(ctx, "open_dot");
     dim3 grid((w + kOpenCols - 1) / kOpenCols, n_chunks);
-    launch_open_dot<PP>(ctx->stream, grid, mat, n, w, w0, w1, partial.p, n_chunks);
+    launch_open_dot<PP>(ctx->stream, grid, mat, n, w, w0, w1, partial.p, n_chunks, (int)rows_per_block);
     hipLaunchKernelGGL(k_open_reduce<PP>, dim3(blocks_for((size_t)P * w * 4)), dim3(kBlock), 0, ctx->stream,
                        partial.p, P, n_chunks, w, out.p + used * 4);
     P3R_HIP(hipGetLastError());
