@@ -164,3 +164,37 @@ def test_prove_then_verify_all_tables_natively(oracle, field, log_h, kw, packing
             proof, table_packing=dataclasses.replace(proof.table_packing, alu_lanes=proof.table_packing.alu_lanes + 1)))
     cache.circuit_prover_data.free()
     ctx.close()
+
+
+def test_concurrent_contexts_on_one_gpu(oracle):
+    """Several p3r_ctx (own stream, own memory pool) driven from separate host threads at the same
+    time: every proof equals the single-threaded one (aggregation leaves sharing a GPU)."""
+    import threading
+    from plonky3_recursion_amd import prover as pv
+    jobs = []
+    for i, (field, log_h) in enumerate([("koala-bear", 9), ("baby-bear", 8), ("koala-bear", 10), ("koala-bear", 8)]):
+        arrs, L, ctx, cache, traces = setup(oracle, field, log_h, dict(log_final_poly_len=2, query_pow_bits=6, num_queries=8),
+                                            None)
+        want = cache.prover.prove_all_tables(traces, cache.circuit_prover_data).proof
+        assert want == L.prove()
+        jobs.append((ctx, cache, traces, want))
+    errors = []
+
+    def run(job):
+        ctx, cache, traces, want = job
+        try:
+            for _ in range(12):
+                if cache.prover.prove_all_tables(traces, cache.circuit_prover_data).proof != want:
+                    errors.append("proof changed under concurrency")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for ctx, cache, traces, want in jobs:
+        cache.circuit_prover_data.free()
+        ctx.close()
