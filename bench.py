@@ -151,10 +151,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        import datetime
+        limit = datetime.timedelta(seconds=300)   # a lost rank aborts the run instead of hanging it
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     field, log_h = args.field, args.log_height
     ctx = p3r.Context(field=field, device=local_rank, **FRI)
