@@ -102,6 +102,40 @@ inline hipError_t copy_sync(hipStream_t s, void* dst, const void* src, size_t by
   return hipStreamSynchronize(s);
 }
 
+// Pinned staging ring for small host->device uploads (pointer tables, challenge powers, job
+// descriptors) that must not stall the host: the source is copied into pinned memory, the
+// transfer is enqueued on the ctx stream and the caller moves on.  A region is handed out again
+// only after the ring wraps, and wrapping waits for the stream first.
+struct HostStage {
+  static constexpr size_t kBytes = size_t(1) << 20;
+  char* base = nullptr;
+  size_t off = 0;
+  HostStage() = default;
+  HostStage(const HostStage&) = delete;
+  HostStage& operator=(const HostStage&) = delete;
+  ~HostStage() {
+    if (base) (void)hipHostFree(base);
+  }
+  hipError_t upload(hipStream_t s, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes > kBytes / 4) return copy_sync(s, dst, src, bytes, hipMemcpyHostToDevice);
+    if (!base) {
+      hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&base), kBytes, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+    }
+    const size_t need = (bytes + 63) & ~size_t(63);
+    if (off + need > kBytes) {
+      hipError_t e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return e;
+      off = 0;
+    }
+    std::memcpy(base + off, src, bytes);
+    hipError_t e = hipMemcpyAsync(dst, base + off, bytes, hipMemcpyHostToDevice, s);
+    off += need;
+    return e;
+  }
+};
+
 // RAII device buffer of u32 cells (pooled).
 struct DevBuf {
   uint32_t* p = nullptr;
@@ -191,6 +225,7 @@ struct p3r_ctx {
   p3r::DevBuf p2_diag;  // internal-layer diagonal, Montgomery (lane-cooperative kernels)
   std::vector<uint32_t> rc_canonical;
   std::string err;
+  p3r::HostStage stage;  // small uploads that do not wait (see HostStage)
 
   // NTT table caches (device), keyed by log size / direction / shift.
   std::map<std::pair<int, int>, p3r::DevBuf> tw_sub;                 // (log_r, inverse)

@@ -97,4 +97,49 @@ k_mmcs_compress_coop(const uint32_t* __restrict__ L, size_t nl, int lmul, int la
   if (live && elem < P2_DIGEST) out[(size_t)elem * n + node] = s.v;
 }
 
+// The last levels of a Merkle tree in ONE workgroup: from a layer of at most kTailNodes digests
+// down to the cap, a barrier per level instead of a launch (each of these levels is a single
+// permutation latency; the launches between them cost more than the work).  Every level is
+// written to its own layer buffer - queries read siblings from them - and handed to the next
+// level through LDS.  Plain 2-to-1 levels only: the host uses it below the last injection.
+constexpr int kTailBlock = 1024;  // 64 nodes in flight
+constexpr int kTailNodes = 256;
+constexpr int kTailLevels = 8;
+struct TreeTailArgs {
+  const uint32_t* in;  // [8][n_in]
+  uint32_t n_in;       // power of two, <= kTailNodes
+  int n_levels;        // <= kTailLevels
+  uint32_t* out[kTailLevels];  // out[l]: [8][n_in >> (l+1)]
+};
+template <class PP>
+__global__ void __launch_bounds__(kTailBlock)
+k_mmcs_tree_tail(TreeTailArgs a, const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+  using F = Fp<PP>;
+  __shared__ uint32_t buf[2][P2_DIGEST * kTailNodes / 2];
+  const int elem = threadIdx.x & 15;
+  const uint32_t group = threadIdx.x >> 4, k = elem & 7;
+  const F d = F::raw(diag[elem]);
+  uint32_t n = a.n_in;
+#pragma unroll
+  for (int l = 0; l < kTailLevels; ++l) {
+    if (l < a.n_levels) {
+      const uint32_t nn = n / 2;
+      const uint32_t* cur = buf[(l + 1) & 1];
+      uint32_t* nxt = buf[l & 1];
+      // a 16-lane row works on one node: lanes 0..7 hold the left child, 8..15 the right one
+      for (uint32_t node = group; node < nn; node += kTailBlock / 16) {
+        const uint32_t child = 2 * node + (elem >> 3);
+        F s = F::raw(l == 0 ? a.in[k * n + child] : cur[k * n + child]);
+        s = coop_permute<PP>(s, elem, d, rc);
+        if (elem < P2_DIGEST) {
+          nxt[k * nn + node] = s.v;
+          a.out[l][k * nn + node] = s.v;
+        }
+      }
+      __syncthreads();
+      n = nn;
+    }
+  }
+}
+
 }  // namespace p3r

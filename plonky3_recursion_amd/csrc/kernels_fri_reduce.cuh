@@ -8,57 +8,83 @@
 
 namespace p3r {
 
-template <class PP>
-__global__ void __launch_bounds__(kBlock)
-k_fri_inv_points(size_t h, int log_h, uint32_t gen, uint32_t w_h, E4 z, uint32_t* __restrict__ inv /* [4][h] */) {
-  using F = Fp<PP>;
-  using E = Fp4<PP>;
-  size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= h) return;
-  F x = F::raw(gen) * F::raw(w_h).pow(bit_reverse((uint32_t)r, log_h));
-  E v = (e4_load<PP>(z) - E::from_base(x)).inv();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) inv[(size_t)k * h + r] = v.c[k].v;
-}
-
-struct FriReducePreArgs {
-  const uint32_t* mat;  // bit-reversed LDE [w][h]
-  size_t h;
-  int w;
-  const uint32_t* apow;  // alpha^c, 4 words each
-  int n_points;
-  const uint32_t* inv[2];  // [4][h] each
-  E4 v[2], off[2];
-  uint32_t* ro;  // [4][h], accumulated in place
+// Both kernels run once per proof over job lists (one job per distinct (height, point), resp. per
+// height); a block finds its job by walking the list of first-block indices.
+struct FriInvJob {
+  uint32_t* inv;  // [4][h]
+  uint64_t h;
+  int log_h;
+  uint32_t w_h;
+  E4 z;
+  uint32_t block0;
 };
 template <class PP>
-__global__ void __launch_bounds__(kBlock) k_fri_reduce_pre(FriReducePreArgs a) {
+__global__ void __launch_bounds__(kBlock)
+k_fri_inv_points(const FriInvJob* __restrict__ jobs, int n_jobs, uint32_t gen) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
-  size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= a.h) return;
-  E S = E::zero();
+  int j = 0;
+  while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
+  const FriInvJob& job = jobs[j];
+  const size_t h = job.h, r = (size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x;
+  if (r >= h) return;
+  F x = F::raw(gen) * F::raw(job.w_h).pow(bit_reverse((uint32_t)r, job.log_h));
+  E v = (e4_load<PP>(job.z) - E::from_base(x)).inv();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) job.inv[(size_t)k * h + r] = v.c[k].v;
+}
+
+// One committed matrix and its opening points.
+struct FriReduceMat {
+  const uint32_t* mat;  // bit-reversed LDE [w][h]
+  int w, n_points;
+  const uint32_t* inv[2];  // [4][h] each
+  E4 v[2], off[2];
+};
+// All matrices of one height: lane r owns ro[r] and adds every matrix's term to it, so ro is
+// written once and needs no zero fill.
+struct FriReduceJob {
+  uint32_t* ro;  // [4][h]
+  uint64_t h;
+  uint32_t mat0, n_mats;  // range in the matrix list
+  uint32_t block0;
+};
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriReduceMat* __restrict__ mats,
+                 const uint32_t* __restrict__ apow_tab /* alpha^c, 4 words each */) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  int j = 0;
+  while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
+  const FriReduceJob job = jobs[j];
+  const size_t h = job.h, r = (size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x;
+  if (r >= h) return;
   auto apow = [&](int c) {
     E ap;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ap.c[k] = F::raw(a.apow[4 * c + k]);
+    for (int k = 0; k < 4; ++k) ap.c[k] = F::raw(apow_tab[4 * c + k]);
     return ap;
   };
-  int c = 0;
-  for (; c + 1 < a.w; c += 2)  // two columns per reduction
-    S += E::dot2_base(apow(c), F::raw(a.mat[(size_t)c * a.h + r]), apow(c + 1), F::raw(a.mat[(size_t)(c + 1) * a.h + r]));
-  if (c < a.w) S += apow(c) * F::raw(a.mat[(size_t)c * a.h + r]);
-  E acc;
+  E acc = E::zero();
+  for (uint32_t m = 0; m < job.n_mats; ++m) {
+    const FriReduceMat& a = mats[job.mat0 + m];
+    const uint32_t* __restrict__ mat = a.mat;
+    const int w = a.w;
+    E S = E::zero();
+    int c = 0;
+    for (; c + 1 < w; c += 2)  // two columns per reduction
+      S += E::dot2_base(apow(c), F::raw(mat[(size_t)c * h + r]), apow(c + 1), F::raw(mat[(size_t)(c + 1) * h + r]));
+    if (c < w) S += apow(c) * F::raw(mat[(size_t)c * h + r]);
+    for (int p = 0; p < a.n_points; ++p) {
+      E inv;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) acc.c[k] = F::raw(a.ro[(size_t)k * a.h + r]);
-  for (int p = 0; p < a.n_points; ++p) {
-    E inv;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) inv.c[k] = F::raw(a.inv[p][(size_t)k * a.h + r]);
-    acc += e4_load<PP>(a.off[p]) * (e4_load<PP>(a.v[p]) - S) * inv;
+      for (int k = 0; k < 4; ++k) inv.c[k] = F::raw(a.inv[p][(size_t)k * h + r]);
+      acc += e4_load<PP>(a.off[p]) * (e4_load<PP>(a.v[p]) - S) * inv;
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) a.ro[(size_t)k * a.h + r] = acc.c[k].v;
+  for (int k = 0; k < 4; ++k) job.ro[(size_t)k * h + r] = acc.c[k].v;
 }
 
 }  // namespace p3r

@@ -2,7 +2,7 @@
 //   K7  LogUp auxiliary (permutation) trace       k_logup_aux, k_ef_scan
 //   K8  quotient evaluation                        k_quotient
 //   K9  openings at zeta / zeta*g                   k_bary_weights, k_open_dot, k_open_reduce
-//   K10 FRI reduced openings, folds, grinding       k_fri_reduce, k_fri_fold, k_grind
+//   K10 FRI reduced openings, folds, grinding       k_fri_fold, k_grind (reduced openings: kernels_fri_reduce.cuh)
 //   query answers                                   k_gather
 // Protocol anchors are listed in p3r_prove.hip next to the host code that sequences them.
 #pragma once
@@ -297,36 +297,60 @@ __global__ void __launch_bounds__(kBlock) k_quotient(QuotientArgs q) {
 }
 
 // ------------------------------------------------------------------ K9: openings
+// All openings of one proof run as three launches over job lists (a recursion layer opens ~20
+// matrices at 1-2 points each; per-matrix launches are latency-bound for 2^14..2^16-row layers).
+// A block finds its job by walking the (short) list of first-block indices.
+//
 // Barycentric weights over the trace subgroup:  L_i(z) = w^i (z^n - 1) / (n (z - w^i)).
 // `scale` = (z^n - 1)/n is supplied by the host.
+struct BaryJob {
+  uint32_t* out;  // [4][n]
+  uint64_t n;
+  uint32_t w_n;
+  E4 z, scale;
+  uint32_t block0;  // first block of this job
+};
 template <class PP>
-__global__ void __launch_bounds__(kBlock)
-k_bary_weights(size_t n, uint32_t w_n, E4 z, E4 scale, uint32_t* __restrict__ out /* [4][n] */) {
+__global__ void __launch_bounds__(kBlock) k_bary_weights(const BaryJob* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
-  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  F wi = F::raw(w_n).pow(i);
-  E r = (e4_load<PP>(z) - E::from_base(wi)).inv() * e4_load<PP>(scale) * wi;
+  int j = 0;
+  while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
+  const BaryJob& b = jobs[j];
+  const size_t i = (size_t)(blockIdx.x - b.block0) * kBlock + threadIdx.x;
+  if (i >= b.n) return;
+  F wi = F::raw(b.w_n).pow(i);
+  E r = (e4_load<PP>(b.z) - E::from_base(wi)).inv() * e4_load<PP>(b.scale) * wi;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) out[(size_t)k * n + i] = r.c[k].v;
+  for (int k = 0; k < 4; ++k) b.out[(size_t)k * b.n + i] = r.c[k].v;
 }
 
 constexpr int kOpenCols = 8;      // matrix columns sharing one pass over the weights
 constexpr int kOpenRows = 8192;   // rows per block for tall matrices (the host shrinks it for short ones)
+struct OpenJob {
+  const uint32_t* mat;  // [w][n] column-major, natural order
+  const uint32_t *wt0, *wt1;  // weights per point ([4][n]); wt1 null for a single point
+  uint32_t* partial;    // [P][n_chunks][w][4]
+  uint64_t n;
+  int w, n_chunks, rows_per_block, col_groups;
+  uint32_t block0;      // first block of this job in the dot launch
+  uint32_t out0;        // first output word of this job ([P][w][4]) in the reduce launch
+};
 // partial[p][chunk][col] = sum over the chunk's rows of weights_p[row] * M[col][row].
 // All accumulator indexing is compile-time (register resident); the block reduction is a
 // wave shuffle tree followed by a 4-wave LDS combine.
 template <class PP, int P>
-__global__ void __launch_bounds__(kBlock)
-k_open_dot_t(const uint32_t* __restrict__ mat, size_t n, int w, const uint32_t* __restrict__ wt0,
-             const uint32_t* __restrict__ wt1, uint32_t* __restrict__ partial, int n_chunks, int rows_per_block) {
+__device__ __forceinline__ void open_dot_block(const OpenJob& job, int col_group, int chunk,
+                                               uint32_t (*sh)[2 * kOpenCols * 4]) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
   constexpr int NV = P * kOpenCols * 4;
-  __shared__ uint32_t sh[kBlock / 64][NV];
-  const int c0 = blockIdx.x * kOpenCols, chunk = blockIdx.y;
-  size_t r0 = (size_t)chunk * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  const uint32_t* __restrict__ mat = job.mat;
+  const uint32_t* __restrict__ wt0 = job.wt0;
+  const uint32_t* __restrict__ wt1 = job.wt1;
+  const size_t n = job.n;
+  const int w = job.w, c0 = col_group * kOpenCols;
+  size_t r0 = (size_t)chunk * job.rows_per_block, r1 = r0 + job.rows_per_block < n ? r0 + job.rows_per_block : n;
   E acc[P][kOpenCols];
 #pragma unroll
   for (int p = 0; p < P; ++p)
@@ -375,65 +399,39 @@ k_open_dot_t(const uint32_t* __restrict__ mat, size_t n, int w, const uint32_t* 
 #pragma unroll
     for (int wv = 0; wv < kBlock / 64; ++wv) s += F::raw(sh[wv][threadIdx.x]);
     const int p = threadIdx.x / (kOpenCols * 4), rem = threadIdx.x % (kOpenCols * 4), c = rem / 4, k = rem % 4;
-    if (c0 + c < w) partial[(((size_t)p * n_chunks + chunk) * w + c0 + c) * 4 + k] = s.v;
+    if (c0 + c < w) job.partial[(((size_t)p * job.n_chunks + chunk) * w + c0 + c) * 4 + k] = s.v;
   }
 }
 template <class PP>
-void launch_open_dot(hipStream_t stream, dim3 grid, const uint32_t* mat, size_t n, int w, const uint32_t* wt0,
-                     const uint32_t* wt1, uint32_t* partial, int n_chunks, int rows_per_block) {
-  if (wt1) hipLaunchKernelGGL((k_open_dot_t<PP, 2>), grid, dim3(kBlock), 0, stream, mat, n, w, wt0, wt1, partial, n_chunks, rows_per_block);
-  else hipLaunchKernelGGL((k_open_dot_t<PP, 1>), grid, dim3(kBlock), 0, stream, mat, n, w, wt0, wt1, partial, n_chunks, rows_per_block);
+__global__ void __launch_bounds__(kBlock) k_open_dot(const OpenJob* __restrict__ jobs, int n_jobs) {
+  __shared__ uint32_t sh[kBlock / 64][2 * kOpenCols * 4];
+  int j = 0;
+  while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
+  const OpenJob job = jobs[j];
+  const int local = (int)(blockIdx.x - job.block0);
+  const int col_group = local % job.col_groups, chunk = local / job.col_groups;
+  if (job.wt1) open_dot_block<PP, 2>(job, col_group, chunk, sh);
+  else open_dot_block<PP, 1>(job, col_group, chunk, sh);
 }
+// out[out0 + (p*w + c)*4 + k] = sum over chunks of partial[p][chunk][c][k]
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
-k_open_reduce(const uint32_t* __restrict__ partial, int P, int n_chunks, int w, uint32_t* __restrict__ out) {
+k_open_reduce(const OpenJob* __restrict__ jobs, int n_jobs, uint32_t total, uint32_t* __restrict__ out) {
   using F = Fp<PP>;
-  int t = blockIdx.x * kBlock + threadIdx.x;  // over P*w*4 outputs
-  if (t >= P * w * 4) return;
-  int p = t / (w * 4), rem = t % (w * 4);
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= total) return;
+  int j = 0;
+  while (j + 1 < n_jobs && t >= jobs[j + 1].out0) ++j;
+  const OpenJob& job = jobs[j];
+  const uint32_t local = t - job.out0;
+  const uint32_t per_point = (uint32_t)job.w * 4, p = local / per_point, rem = local % per_point;
   F s = F::zero();
-  for (int ch = 0; ch < n_chunks; ++ch) s += F::raw(partial[((size_t)p * n_chunks + ch) * w * 4 + rem]);
+  for (int ch = 0; ch < job.n_chunks; ++ch)
+    s += F::raw(job.partial[((size_t)p * job.n_chunks + ch) * per_point + rem]);
   out[t] = s.v;
 }
 
 // ------------------------------------------------------------------ K10: FRI
-// ro[r] += sum_p off_p * (V_p - S[r]) / (z_p - x_r),  S[r] = sum_c alpha^c M[c][r],
-// x_r = gen * w^{bitrev(r)}   (recursion/src/pcs/fri/verifier.rs:1122-1345, :921-981)
-struct FriReduceArgs {
-  const uint32_t* mat;  // bit-reversed LDE [w][h]
-  size_t h;
-  int w, log_h;
-  const uint32_t* apow;  // alpha^c, 4 words each
-  int n_points;
-  E4 z[2], v[2], off[2];
-  uint32_t gen, w_h;
-  uint32_t* ro;          // [4][h], accumulated in place
-};
-template <class PP>
-__global__ void __launch_bounds__(kBlock) k_fri_reduce(FriReduceArgs a) {
-  using F = Fp<PP>;
-  using E = Fp4<PP>;
-  size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= a.h) return;
-  E S = E::zero();
-  for (int c = 0; c < a.w; ++c) {
-    E ap;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ap.c[k] = F::raw(a.apow[4 * c + k]);
-    S += ap * F::raw(a.mat[(size_t)c * a.h + r]);
-  }
-  F x = F::raw(a.gen) * F::raw(a.w_h).pow(bit_reverse((uint32_t)r, a.log_h));
-  E acc;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) acc.c[k] = F::raw(a.ro[(size_t)k * a.h + r]);
-  for (int p = 0; p < a.n_points; ++p) {
-    E inv = (e4_load<PP>(a.z[p]) - E::from_base(x)).inv();
-    acc += e4_load<PP>(a.off[p]) * (e4_load<PP>(a.v[p]) - S) * inv;
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) a.ro[(size_t)k * a.h + r] = acc.c[k].v;
-}
-
 // One commit-phase fold of arity 2^la: la sequential arity-2 folds with beta, beta^2, ...
 // (recursion/src/pcs/fri/verifier.rs:562-781), then the roll-in  + beta^{2^la} * ro.
 struct FriFoldArgs {

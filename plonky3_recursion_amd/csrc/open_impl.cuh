@@ -11,59 +11,94 @@ struct Opener {
   using F = Fp<PP>;
   using E = Fp4<PP>;
   p3r_ctx* ctx;
-  DevBuf out;
-  size_t used = 0;
+  size_t used = 0;  // opened values so far (extension-field elements)
   struct Job { size_t off; int P, w; };
   std::vector<Job> jobs;
-  std::map<std::array<uint64_t, 3>, DevBuf> wcache;
+  std::vector<OpenJob> dot_jobs;
+  std::vector<BaryJob> bary_jobs;
+  std::vector<DevBuf> keep;  // weights and partial sums, alive until finish()
+  std::map<std::array<uint64_t, 3>, const uint32_t*> wcache;
+  uint32_t bary_blocks = 0, dot_blocks = 0;
 
-  explicit Opener(p3r_ctx* c, size_t capacity_ef = 8192) : ctx(c), out(capacity_ef * 4) {}
+  explicit Opener(p3r_ctx* c) : ctx(c) {}
 
   // L_i(z) = w^i (z^n - 1) / (n (z - w^i)) over the size-n subgroup
   const uint32_t* weights(size_t n, const E& z) {
     std::array<uint64_t, 3> key{n, ((uint64_t)z.c[0].v << 32) | z.c[1].v, ((uint64_t)z.c[2].v << 32) | z.c[3].v};
     auto it = wcache.find(key);
-    if (it != wcache.end()) return it->second.p;
+    if (it != wcache.end()) return it->second;
     const int log_n = log2_exact(n, "trace height");
-    DevBuf b(4 * n);
-    E scale = (z.pow(n) - E::one()) * F::from_u64(n).inv();
-    ProfScope ps(ctx, "open_weights");
-    hipLaunchKernelGGL(k_bary_weights<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, n,
-                       F::two_adic_generator(log_n).v, e4_store<PP>(z), e4_store<PP>(scale), b.p);
-    return wcache.emplace(key, std::move(b)).first->second.p;
+    keep.emplace_back(4 * n);
+    BaryJob b{};
+    b.out = keep.back().p;
+    b.n = n;
+    b.w_n = F::two_adic_generator(log_n).v;
+    b.z = e4_store<PP>(z);
+    b.scale = e4_store<PP>((z.pow(n) - E::one()) * F::from_u64(n).inv());
+    b.block0 = bary_blocks;
+    bary_blocks += blocks_for(n);
+    bary_jobs.push_back(b);
+    return wcache.emplace(key, b.out).first->second;
   }
 
-  // `mat`: n x w evaluations over dshift*<w_n> (natural order).  Returns a job id.
+  // `mat`: n x w evaluations over dshift*<w_n> (natural order).  Returns a job id; nothing is
+  // launched before finish().
   size_t open(const uint32_t* mat, size_t n, int w, F dshift, const std::vector<E>& points) {
     const int P = (int)points.size();
-    if (used + (size_t)P * w > out.n / 4) fail(P3R_EINVAL, "too many opened values for the staging buffer");
     const F inv_shift = dshift.inv();
-    const uint32_t* w0 = weights(n, points[0] * inv_shift);
-    const uint32_t* w1 = P == 2 ? weights(n, points[1] * inv_shift) : nullptr;
-    // rows per block: 8192 for tall matrices, fewer for short ones so the launch still has
+    OpenJob j{};
+    j.mat = mat;
+    j.wt0 = weights(n, points[0] * inv_shift);
+    j.wt1 = P == 2 ? weights(n, points[1] * inv_shift) : nullptr;
+    j.n = n;
+    j.w = w;
+    // rows per block: 8192 for tall matrices, fewer for short ones so the job still has
     // ~1000 workgroups (a 2^16-row table would otherwise occupy a third of the chip)
-    const size_t col_groups = (w + kOpenCols - 1) / kOpenCols;
+    j.col_groups = (w + kOpenCols - 1) / kOpenCols;
     size_t rows_per_block = kOpenRows;
     // (at most 64 chunks: the final reduction walks them serially)
     while (rows_per_block > 2 * kBlock && (n + rows_per_block - 1) / rows_per_block < 64 &&
-           col_groups * ((n + rows_per_block - 1) / rows_per_block) < 1024)
+           j.col_groups * ((n + rows_per_block - 1) / rows_per_block) < 1024)
       rows_per_block /= 2;
-    const int n_chunks = (int)((n + rows_per_block - 1) / rows_per_block);
-    DevBuf partial((size_t)P * n_chunks * w * 4);
-    ProfScope ps(ctx, "open_dot");
-    dim3 grid((w + kOpenCols - 1) / kOpenCols, n_chunks);
-    launch_open_dot<PP>(ctx->stream, grid, mat, n, w, w0, w1, partial.p, n_chunks, (int)rows_per_block);
-    hipLaunchKernelGGL(k_open_reduce<PP>, dim3(blocks_for((size_t)P * w * 4)), dim3(kBlock), 0, ctx->stream,
-                       partial.p, P, n_chunks, w, out.p + used * 4);
-    P3R_HIP(hipGetLastError());
+    j.rows_per_block = (int)rows_per_block;
+    j.n_chunks = (int)((n + rows_per_block - 1) / rows_per_block);
+    keep.emplace_back((size_t)P * j.n_chunks * w * 4);
+    j.partial = keep.back().p;
+    j.block0 = dot_blocks;
+    dot_blocks += (uint32_t)(j.col_groups * j.n_chunks);
+    j.out0 = (uint32_t)(used * 4);
+    dot_jobs.push_back(j);
     jobs.push_back({used, P, w});
     used += (size_t)P * w;
     return jobs.size() - 1;
   }
 
+  template <class T>
+  const T* upload_jobs(const std::vector<T>& v) {
+    keep.emplace_back((v.size() * sizeof(T) + 3) / 4);
+    P3R_HIP(ctx->stage.upload(ctx->stream, keep.back().p, v.data(), v.size() * sizeof(T)));
+    return reinterpret_cast<const T*>(keep.back().p);
+  }
+
   // values[job][point][col]
   std::vector<std::vector<std::vector<E>>> finish() {
     std::vector<uint32_t> raw(used * 4);
+    if (jobs.empty()) return {};
+    DevBuf out(used * 4);
+    {
+      const BaryJob* d_bary = upload_jobs(bary_jobs);
+      const OpenJob* d_jobs = upload_jobs(dot_jobs);
+      {
+        ProfScope ps(ctx, "open_weights");
+        hipLaunchKernelGGL(k_bary_weights<PP>, dim3(bary_blocks), dim3(kBlock), 0, ctx->stream, d_bary,
+                           (int)bary_jobs.size());
+      }
+      ProfScope ps(ctx, "open_dot");
+      hipLaunchKernelGGL(k_open_dot<PP>, dim3(dot_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)dot_jobs.size());
+      hipLaunchKernelGGL(k_open_reduce<PP>, dim3(blocks_for(used * 4)), dim3(kBlock), 0, ctx->stream, d_jobs,
+                         (int)dot_jobs.size(), (uint32_t)(used * 4), out.p);
+      P3R_HIP(hipGetLastError());
+    }
     P3R_HIP(copy_sync(ctx->stream, raw.data(), out.p, raw.size() * 4, hipMemcpyDeviceToHost));
     std::vector<std::vector<std::vector<E>>> res(jobs.size());
     for (size_t j = 0; j < jobs.size(); ++j) {

@@ -342,7 +342,7 @@ void hash_rows(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats, size_t h,
     for (size_t c = 0; c < m->w; ++c) cols.push_back(m->d + c * m->h);
   DevBuf dcols_buf(cols.size() * sizeof(void*) / sizeof(uint32_t));
   const uint32_t** dcols = reinterpret_cast<const uint32_t**>(dcols_buf.p);
-  P3R_HIP(copy_sync(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice));
+  P3R_HIP(ctx->stage.upload(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*)));
   ProfScope ps(ctx, "mmcs_hash_rows");
   hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream,
                      (const uint32_t* const*)dcols, (int)cols.size(), h, dig, ctx->rc.p);
@@ -363,6 +363,25 @@ void launch_compress(p3r_ctx* ctx, const uint32_t* L, size_t nl, int lmul, int l
     hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, L, nl, lmul, ladd, R,
                        nr, rmul, radd, out, n, ctx->rc.p);
   P3R_HIP(hipGetLastError());
+}
+
+// Levels from the `n`-digest layer at the back of `tree->layers` down to the cap, when they fit
+// the single-workgroup kernel; the caller guarantees that nothing is injected below `n`.
+template <class PP>
+bool mmcs_tree_tail(p3r_ctx* ctx, p3r_tree* tree, size_t n) {
+  const size_t cap_n = size_t(1) << tree->cap_height;
+  if (n > (size_t)kTailNodes || n <= cap_n) return false;
+  TreeTailArgs a{};
+  a.in = tree->layers.back().p;
+  a.n_in = (uint32_t)n;
+  for (size_t nn = n / 2; nn >= cap_n; nn /= 2) {  // cap_n >= 1 ends it
+    tree->layers.emplace_back(P2_DIGEST * nn);
+    a.out[a.n_levels++] = tree->layers.back().p;
+  }
+  ProfScope ps(ctx, "mmcs_compress");
+  hipLaunchKernelGGL(k_mmcs_tree_tail<PP>, dim3(1), dim3(kTailBlock), 0, ctx->stream, a, ctx->rc.p, ctx->p2_diag.p);
+  P3R_HIP(hipGetLastError());
+  return true;
 }
 
 template <class PP>
@@ -395,7 +414,10 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   hash_rows<PP>(ctx, at_height(hmax), hmax, tree->layers[0].p);
   size_t n = hmax;
   const size_t cap_n = size_t(1) << tree->cap_height;
+  size_t min_h = hmax;
+  for (auto* m : mats) min_h = std::min(min_h, m->h);
   while (n > cap_n) {
+    if (n <= min_h && mmcs_tree_tail<PP>(ctx, tree, n)) break;
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;

@@ -47,6 +47,7 @@ void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves) {
   size_t n = n_leaves;
   const size_t cap_n = size_t(1) << tree->cap_height;
   while (n > cap_n) {
+    if (mmcs_tree_tail<PP>(ctx, tree, n)) break;
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;
@@ -214,12 +215,15 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<int> perm_insts;
   std::unique_ptr<p3r_tree> perm_tree;
   if (any_lookup) {
+    DevBuf totals(4 * ni);
+    P3R_HIP(hipMemsetAsync(totals.p, 0, 16 * ni, ctx->stream));
     for (size_t i = 0; i < ni; ++i) {
       const auto& L = layouts[i];
       if (!L.n_groups) continue;
       const size_t n = mains[i]->h;
       aux[i] = dmat_alloc(n, (size_t)L.aux_width() * 4);
-      DevBuf rowsum(4 * n), total(4);
+      DevBuf rowsum(4 * n);
+      uint32_t* total = totals.p + 4 * i;
       const size_t n_blocks = (n + kScanTile - 1) / kScanTile;
       DevBuf agg(4 * n_blocks);
       // the preprocessed TRACE is not retained; its first n*... rows are not the trace either,
@@ -229,20 +233,24 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         hipLaunchKernelGGL(k_logup_aux<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, prep->airs[i],
                            mains[i]->d, prep->traces[i]->d, n, lc, L.pair, aux[i]->d, rowsum.p);
         hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, 0, n, rowsum.p,
-                           agg.p, n_blocks, aux[i]->d, total.p);
+                           agg.p, n_blocks, aux[i]->d, total);
         hipLaunchKernelGGL(k_ef_scan<PP>, dim3(1), dim3(kBlock), 0, ctx->stream, 1, n, rowsum.p, agg.p, n_blocks,
-                           aux[i]->d, total.p);
+                           aux[i]->d, total);
         hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, 2, n, rowsum.p,
-                           agg.p, n_blocks, aux[i]->d, total.p);
+                           agg.p, n_blocks, aux[i]->d, total);
       }
       P3R_HIP(hipGetLastError());
-      terminals[i] = download_ef<PP>(ctx, total.p, 1)[0];
       aux_lde[i] = coset_lde<PP>(ctx, aux[i].get(), log_blowup, PP::GEN);
       perm_insts.push_back((int)i);
     }
     ptrs.clear();
     for (int i : perm_insts) ptrs.push_back(aux_lde[i].get());
     perm_tree = commit_dmats<PP>(ctx, ptrs, perm_cap);
+    {
+      // every table's global sum in one transfer
+      auto all = download_ef<PP>(ctx, totals.p, ni);
+      for (int i : perm_insts) terminals[i] = all[i];
+    }
     for (uint32_t v : perm_cap) ch.observe(F::raw(v));
     for (int i : perm_insts) ch.observe_ext(terminals[i]);
   }
@@ -270,7 +278,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       }
     }
     DevBuf d_apow(apow.size());
-    P3R_HIP(hipMemcpyAsync(d_apow.p, apow.data(), apow.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    P3R_HIP(ctx->stage.upload(ctx->stream, d_apow.p, apow.data(), apow.size() * 4));
     QuotientArgs q{};
     q.air = a;
     q.main = main_lde[i]->d;
@@ -378,48 +386,87 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     std::vector<uint32_t> h(max_w * 4);
     for (size_t c = 0; c < max_w; ++c)
       for (int k = 0; k < 4; ++k) h[c * 4 + k] = fa_pow[c].c[k].v;
-    P3R_HIP(hipMemcpyAsync(d_fapow.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    P3R_HIP(hipStreamSynchronize(ctx->stream));
+    P3R_HIP(ctx->stage.upload(ctx->stream, d_fapow.p, h.data(), h.size() * 4));
   }
+  // One pass per height over all its matrices (kernels_fri_reduce.cuh); alpha powers restart per
+  // height and run on across that height's matrices and points in `items` order.
   std::map<int, std::pair<E, DevBuf>> ros;  // log_height -> (alpha power, ro planes [4][h])
-  std::map<std::array<uint64_t, 3>, DevBuf> inv_cache;  // (log_height, z) -> 1/(z - x_r)
-  for (auto& it : items) {
-    const int lh = it.log_h + log_blowup;
-    auto f = ros.find(lh);
-    if (f == ros.end()) {
-      DevBuf b((size_t)4 << lh);
-      P3R_HIP(hipMemsetAsync(b.p, 0, ((size_t)16) << lh, ctx->stream));
-      f = ros.emplace(lh, std::make_pair(E::one(), std::move(b))).first;
-    }
-    FriReducePreArgs a{};
-    a.mat = it.lde->d; a.h = it.lde->h; a.w = (int)it.lde->w;
-    a.apow = d_fapow.p;
-    a.n_points = (int)it.z.size();
-    E ap = f->second.first;
-    for (size_t p = 0; p < it.z.size(); ++p) {
-      E V = E::zero();
-      for (size_t c = 0; c < it.vals[p].size(); ++c) V += fa_pow[c] * it.vals[p][c];
-      std::array<uint64_t, 3> key{(uint64_t)lh, ((uint64_t)it.z[p].c[0].v << 32) | it.z[p].c[1].v,
-                                  ((uint64_t)it.z[p].c[2].v << 32) | it.z[p].c[3].v};
-      auto iv = inv_cache.find(key);
-      if (iv == inv_cache.end()) {
-        DevBuf b((size_t)4 << lh);
-        ProfScope ps(ctx, "fri_inv_points");
-        hipLaunchKernelGGL(k_fri_inv_points<PP>, dim3(blocks_for(size_t(1) << lh)), dim3(kBlock), 0, ctx->stream,
-                           size_t(1) << lh, lh, gen.v, F::two_adic_generator(lh).v, to_e4<PP>(it.z[p]), b.p);
-        iv = inv_cache.emplace(key, std::move(b)).first;
+  {
+    std::map<int, std::vector<FriReduceMat>> by_height;
+    std::map<std::array<uint64_t, 3>, uint32_t*> inv_cache;  // (log_height, z) -> 1/(z - x_r)
+    std::vector<FriInvJob> inv_jobs;
+    std::vector<DevBuf> keep;
+    uint32_t inv_blocks = 0;
+    for (auto& it : items) {
+      const int lh = it.log_h + log_blowup;
+      auto f = ros.find(lh);
+      if (f == ros.end()) f = ros.emplace(lh, std::make_pair(E::one(), DevBuf((size_t)4 << lh))).first;
+      FriReduceMat a{};
+      a.mat = it.lde->d;
+      a.w = (int)it.lde->w;
+      a.n_points = (int)it.z.size();
+      E ap = f->second.first;
+      for (size_t p = 0; p < it.z.size(); ++p) {
+        E V = E::zero();
+        for (size_t c = 0; c < it.vals[p].size(); ++c) V += fa_pow[c] * it.vals[p][c];
+        std::array<uint64_t, 3> key{(uint64_t)lh, ((uint64_t)it.z[p].c[0].v << 32) | it.z[p].c[1].v,
+                                    ((uint64_t)it.z[p].c[2].v << 32) | it.z[p].c[3].v};
+        auto iv = inv_cache.find(key);
+        if (iv == inv_cache.end()) {
+          keep.emplace_back((size_t)4 << lh);
+          FriInvJob j{};
+          j.inv = keep.back().p;
+          j.h = uint64_t(1) << lh;
+          j.log_h = lh;
+          j.w_h = F::two_adic_generator(lh).v;
+          j.z = to_e4<PP>(it.z[p]);
+          j.block0 = inv_blocks;
+          inv_blocks += blocks_for(size_t(1) << lh);
+          inv_jobs.push_back(j);
+          iv = inv_cache.emplace(key, j.inv).first;
+        }
+        a.inv[p] = iv->second;
+        a.v[p] = to_e4<PP>(V);
+        a.off[p] = to_e4<PP>(ap);
+        ap *= fa_pow[it.lde->w];
       }
-      a.inv[p] = iv->second.p;
-      a.v[p] = to_e4<PP>(V);
-      a.off[p] = to_e4<PP>(ap);
-      ap *= fa_pow[it.lde->w];
+      f->second.first = ap;
+      by_height[lh].push_back(a);
     }
-    f->second.first = ap;
-    a.ro = f->second.second.p;
-    ProfScope ps(ctx, "fri_reduce");
-    hipLaunchKernelGGL(k_fri_reduce_pre<PP>, dim3(blocks_for(a.h)), dim3(kBlock), 0, ctx->stream, a);
+    std::vector<FriReduceMat> mats;
+    std::vector<FriReduceJob> jobs;
+    uint32_t blocks = 0;
+    for (auto& kv : by_height) {
+      FriReduceJob j{};
+      j.ro = ros[kv.first].second.p;
+      j.h = uint64_t(1) << kv.first;
+      j.mat0 = (uint32_t)mats.size();
+      j.n_mats = (uint32_t)kv.second.size();
+      j.block0 = blocks;
+      blocks += blocks_for(size_t(1) << kv.first);
+      jobs.push_back(j);
+      mats.insert(mats.end(), kv.second.begin(), kv.second.end());
+    }
+    auto upload = [&](const void* src, size_t bytes) {
+      keep.emplace_back((bytes + 3) / 4);
+      P3R_HIP(ctx->stage.upload(ctx->stream, keep.back().p, src, bytes));
+      return keep.back().p;
+    };
+    const auto* d_inv = reinterpret_cast<const FriInvJob*>(upload(inv_jobs.data(), inv_jobs.size() * sizeof(FriInvJob)));
+    const auto* d_mats = reinterpret_cast<const FriReduceMat*>(upload(mats.data(), mats.size() * sizeof(FriReduceMat)));
+    const auto* d_jobs = reinterpret_cast<const FriReduceJob*>(upload(jobs.data(), jobs.size() * sizeof(FriReduceJob)));
+    {
+      ProfScope ps(ctx, "fri_inv_points");
+      hipLaunchKernelGGL(k_fri_inv_points<PP>, dim3(inv_blocks), dim3(kBlock), 0, ctx->stream, d_inv,
+                         (int)inv_jobs.size(), gen.v);
+    }
+    {
+      ProfScope ps(ctx, "fri_reduce");
+      hipLaunchKernelGGL(k_fri_reduce_pre<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(),
+                         d_mats, d_fapow.p);
+    }
+    P3R_HIP(hipGetLastError());
   }
-  P3R_HIP(hipGetLastError());
 
   prof_stage(ctx, "fri_commit_phase");
   // ---- 7. FRI commit phase
@@ -455,7 +502,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         for (int k = 0; k < 4; ++k) cols.push_back(folded.p + (size_t)k * n_in + j);
       DevBuf dcols_buf(cols.size() * sizeof(void*) / sizeof(uint32_t));
       const uint32_t** dcols = reinterpret_cast<const uint32_t**>(dcols_buf.p);
-      P3R_HIP(copy_sync(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*), hipMemcpyHostToDevice));
+      P3R_HIP(ctx->stage.upload(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*)));
       {
         ProfScope ps(ctx, "mmcs_hash_rows_strided");
         hipLaunchKernelGGL(k_mmcs_hash_rows_strided<PP>, dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream,
@@ -581,8 +628,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     DevBuf descs_buf((descs.size() * sizeof(GatherDesc) + 3) / 4);
     GatherDesc* d_descs = reinterpret_cast<GatherDesc*>(descs_buf.p);
     DevBuf d_out(cursor);
-    hipError_t e = hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(GatherDesc), hipMemcpyHostToDevice,
-                                  ctx->stream);
+    hipError_t e = ctx->stage.upload(ctx->stream, d_descs, descs.data(), descs.size() * sizeof(GatherDesc));
     if (e == hipSuccess) {
       ProfScope ps(ctx, "query_gather");
       hipLaunchKernelGGL(k_gather<PP>, dim3((unsigned)descs.size()), dim3(64), 0, ctx->stream, d_descs, d_out.p, 0);
