@@ -64,9 +64,9 @@ def workload_model(field, heights, widths, packing):
             hash_perms += h * ((w + 7) // 8)
             hash_cells += h * w
             hash_rows += h
-            hash_launches += 1
             if h != hmax:
                 perms += h
+        hash_launches += 1  # one job-list launch per commit covers every height class
         perms += hmax - 1
 
     commit([(heights[i] * B, widths[i]) for i in range(5)])                       # main

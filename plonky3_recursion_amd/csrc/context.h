@@ -226,6 +226,10 @@ struct p3r_ctx {
   std::vector<uint32_t> rc_canonical;
   std::string err;
   p3r::HostStage stage;  // small uploads that do not wait (see HostStage)
+  // Small read-only device tables (column pointers and job lists of the row-hash kernels),
+  // keyed by their content: the pool hands the same addresses to the same allocation sequence,
+  // so after the first proof of a shape every table is already on the device.
+  std::map<std::string, p3r::DevBuf> const_tables;
 
   // NTT table caches (device), keyed by log size / direction / shift.
   std::map<std::pair<int, int>, p3r::DevBuf> tw_sub;                 // (log_r, inverse)

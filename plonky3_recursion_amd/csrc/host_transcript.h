@@ -8,6 +8,7 @@
 //   proof field order          recursion/src/types/proof.rs:403-409,452-457,527-534,585-589,
 //                              recursion/src/pcs/fri/targets.rs:104-110
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "air_device.cuh"
@@ -145,14 +146,38 @@ template <class PP>
 struct ProofWriter {
   using F = Fp<PP>;
   using E = Fp4<PP>;
+  // `out` is grown in large steps and written through a cursor (a proof is ~10^5 varints; a
+  // push_back per byte made serialisation a visible part of small proofs); take() trims it.
   std::vector<uint8_t> out;
+  size_t len = 0;
   bool canonical = false;
-  void byte(uint8_t b) { out.push_back(b); }
-  void varint(uint64_t v) {
-    while (v >= 0x80) { out.push_back((uint8_t)(v | 0x80)); v >>= 7; }
-    out.push_back((uint8_t)v);
+  uint8_t* room(size_t n) {
+    if (len + n > out.size()) out.resize(std::max(out.size() * 2, len + n + 4096));
+    return out.data() + len;
   }
-  void fe(F x) { varint(canonical ? x.to_canonical() : x.v); }
+  void byte(uint8_t b) { *room(1) = b; ++len; }
+  void varint(uint64_t v) {
+    uint8_t* p = room(10);
+    size_t i = 0;
+    while (v >= 0x80) { p[i++] = (uint8_t)(v | 0x80); v >>= 7; }
+    p[i++] = (uint8_t)v;
+    len += i;
+  }
+  std::vector<uint8_t> take() {
+    out.resize(len);
+    return std::move(out);
+  }
+  void fe(F x) {
+    const uint32_t v = canonical ? x.to_canonical() : x.v;
+    if (v < (1u << 28)) return varint(v);
+    uint8_t* p = room(5);  // 7 of 8 field elements: five bytes, no loop
+    p[0] = (uint8_t)(v | 0x80);
+    p[1] = (uint8_t)((v >> 7) | 0x80);
+    p[2] = (uint8_t)((v >> 14) | 0x80);
+    p[3] = (uint8_t)((v >> 21) | 0x80);
+    p[4] = (uint8_t)(v >> 28);
+    len += 5;
+  }
   void ef(const E& e) { for (int i = 0; i < 4; ++i) fe(e.c[i]); }
   void vec_ef(const std::vector<E>& v) { varint(v.size()); for (auto& e : v) ef(e); }
   void digest_mont(const uint32_t* d) { for (int i = 0; i < P2_DIGEST; ++i) fe(F::raw(d[i])); }

@@ -268,12 +268,27 @@ k_p2_trace_fill(const uint32_t* __restrict__ inputs /* [16][n] mont */,
 // mode: a chunk of k<=8 cells overwrites state[0..k]; an exact multiple of 8 does not
 // trigger an extra permutation; the digest is state[0..8].
 // `cols[g]` is the device address of concatenated column g (length h).
+// A commit hashes the rows of every height class in ONE launch (job list, widest rows first): the
+// short tables of a layer do not fill the chip on their own, and for 2^14..2^16-row layers each
+// launch saved is a visible fraction of the proof.
+struct HashRowsJob {
+  const uint32_t* const* cols;
+  uint32_t* dig;  // [8][h]
+  uint64_t h;
+  int wtot;
+  uint32_t block0;  // first block of this job
+};
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
-k_mmcs_hash_rows(const uint32_t* const* __restrict__ cols, int wtot, size_t h,
-                 uint32_t* __restrict__ dig /* [8][h] */, const uint32_t* __restrict__ rc) {
+k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const uint32_t* __restrict__ rc) {
   using F = Fp<PP>;
-  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const uint32_t* const* __restrict__ cols = jobs[jb].cols;
+  uint32_t* __restrict__ dig = jobs[jb].dig;
+  const size_t h = jobs[jb].h;
+  const int wtot = jobs[jb].wtot;
+  size_t i = (size_t)(blockIdx.x - jobs[jb].block0) * kBlock + threadIdx.x;
   if (i >= h) return;
   F s[P2_WIDTH];
 #pragma unroll

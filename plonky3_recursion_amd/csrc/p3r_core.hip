@@ -335,17 +335,52 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
 }
 
 // ------------------------------------------------------------------ MMCS
+// Device copy of a small read-only table (see p3r_ctx::const_tables).
+inline const void* const_table(p3r_ctx* ctx, const void* data, size_t bytes) {
+  std::string key(static_cast<const char*>(data), bytes);
+  auto it = ctx->const_tables.find(key);
+  if (it == ctx->const_tables.end()) {
+    if (ctx->const_tables.size() >= 1024) ctx->const_tables.clear();  // shapes changed: start over
+    DevBuf b((bytes + 3) / 4);
+    P3R_HIP(ctx->stage.upload(ctx->stream, b.p, data, bytes));
+    it = ctx->const_tables.emplace(std::move(key), std::move(b)).first;
+  }
+  return it->second.p;
+}
+inline const uint32_t* const* col_table(p3r_ctx* ctx, const std::vector<const uint32_t*>& cols) {
+  return static_cast<const uint32_t* const*>(const_table(ctx, cols.data(), cols.size() * sizeof(void*)));
+}
+
+// Row digests of several height classes in one launch: classes[c] = the matrices of one height
+// (their rows are concatenated in the given order), digs[c] = [8][h_c].
 template <class PP>
-void hash_rows(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats, size_t h, uint32_t* dig) {
-  std::vector<const uint32_t*> cols;
-  for (const p3r_dmat* m : mats)
-    for (size_t c = 0; c < m->w; ++c) cols.push_back(m->d + c * m->h);
-  DevBuf dcols_buf(cols.size() * sizeof(void*) / sizeof(uint32_t));
-  const uint32_t** dcols = reinterpret_cast<const uint32_t**>(dcols_buf.p);
-  P3R_HIP(ctx->stage.upload(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*)));
+void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& classes,
+               const std::vector<uint32_t*>& digs) {
+  std::vector<HashRowsJob> jobs;
+  for (size_t c = 0; c < classes.size(); ++c) {
+    std::vector<const uint32_t*> cols;
+    for (const p3r_dmat* m : classes[c])
+      for (size_t k = 0; k < m->w; ++k) cols.push_back(m->d + k * m->h);
+    HashRowsJob j{};
+    j.cols = col_table(ctx, cols);
+    j.dig = digs[c];
+    j.h = classes[c][0]->h;
+    j.wtot = (int)cols.size();
+    jobs.push_back(j);
+  }
+  // widest rows first: their blocks run longest
+  std::stable_sort(jobs.begin(), jobs.end(),
+                   [](const HashRowsJob& a, const HashRowsJob& b) { return a.wtot > b.wtot; });
+  uint32_t blocks = 0;
+  for (auto& j : jobs) {
+    j.block0 = blocks;
+    blocks += blocks_for(j.h);
+  }
+  const auto* d_jobs =
+      static_cast<const HashRowsJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(HashRowsJob)));
   ProfScope ps(ctx, "mmcs_hash_rows");
-  hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream,
-                     (const uint32_t* const*)dcols, (int)cols.size(), h, dig, ctx->rc.p);
+  hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(),
+                     ctx->rc.p);
   P3R_HIP(hipGetLastError());
 }
 
@@ -409,25 +444,35 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
       if (mats[i]->h == h) v.push_back(mats[i]);
     return v;
   };
+  // leaf digests of every height class up front, in one launch
+  std::vector<size_t> class_h;
+  for (size_t i : order)
+    if (class_h.empty() || class_h.back() != mats[i]->h) class_h.push_back(mats[i]->h);
   tree->layers.clear();
   tree->layers.emplace_back(P2_DIGEST * hmax);
-  hash_rows<PP>(ctx, at_height(hmax), hmax, tree->layers[0].p);
+  std::map<size_t, DevBuf> inject;  // height -> digests of the matrices of that height
+  {
+    std::vector<std::vector<const p3r_dmat*>> classes;
+    std::vector<uint32_t*> digs;
+    for (size_t h : class_h) {
+      classes.push_back(at_height(h));
+      if (h == hmax) digs.push_back(tree->layers[0].p);
+      else digs.push_back(inject.emplace(h, DevBuf(P2_DIGEST * h)).first->second.p);
+    }
+    hash_rows<PP>(ctx, classes, digs);
+  }
   size_t n = hmax;
   const size_t cap_n = size_t(1) << tree->cap_height;
-  size_t min_h = hmax;
-  for (auto* m : mats) min_h = std::min(min_h, m->h);
+  const size_t min_h = class_h.back();
   while (n > cap_n) {
     if (n <= min_h && mmcs_tree_tail<PP>(ctx, tree, n)) break;
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;
     launch_compress<PP>(ctx, prev, n, 2, 0, prev, n, 2, 1, next.p, nn);
-    auto inj = at_height(nn);
-    if (!inj.empty()) {
-      DevBuf idig(P2_DIGEST * nn);
-      hash_rows<PP>(ctx, inj, nn, idig.p);
-      launch_compress<PP>(ctx, next.p, nn, 1, 0, idig.p, nn, 1, 0, next.p, nn);
-    }
+    auto inj = inject.find(nn);
+    if (inj != inject.end())
+      launch_compress<PP>(ctx, next.p, nn, 1, 0, inj->second.p, nn, 1, 0, next.p, nn);
     tree->layers.push_back(std::move(next));
     n = nn;
   }

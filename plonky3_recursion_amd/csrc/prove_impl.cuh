@@ -500,14 +500,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       std::vector<const uint32_t*> cols;
       for (size_t j = 0; j < arity; ++j)
         for (int k = 0; k < 4; ++k) cols.push_back(folded.p + (size_t)k * n_in + j);
-      DevBuf dcols_buf(cols.size() * sizeof(void*) / sizeof(uint32_t));
-      const uint32_t** dcols = reinterpret_cast<const uint32_t**>(dcols_buf.p);
-      P3R_HIP(ctx->stage.upload(ctx->stream, dcols, cols.data(), cols.size() * sizeof(void*)));
+      const uint32_t* const* dcols = col_table(ctx, cols);
       {
         ProfScope ps(ctx, "mmcs_hash_rows_strided");
         hipLaunchKernelGGL(k_mmcs_hash_rows_strided<PP>, dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream,
-                           (const uint32_t* const*)dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p,
-                           ctx->rc.p);
+                           dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p, ctx->rc.p);
       }
       P3R_HIP(hipGetLastError());
     }
@@ -702,7 +699,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   for (size_t i = 0; i < ni; ++i) W.varint(log_n[i]);
   P3R_HIP(hipStreamSynchronize(ctx->stream));
   prof_stage(ctx, nullptr);
-  return std::move(W.out);
+  return W.take();
 }
 
 }  // namespace
