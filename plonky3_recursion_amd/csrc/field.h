@@ -22,6 +22,19 @@
 
 namespace p3r {
 
+#if defined(__HIPCC__)
+// A pointer that a kernel reads out of a job list in memory is a generic ("flat") address to the
+// compiler: 64-bit vector addresses and flat loads.  Kernel-argument pointers are known to be
+// global; as_global() says the same about a loaded one (every buffer here is hipMalloc'ed), which
+// gives scalar-base addressing back.
+template <class T>
+using gptr = T __attribute__((address_space(1)))*;
+template <class T>
+__device__ __forceinline__ gptr<T> as_global(T* p) {
+  return (gptr<T>)p;
+}
+#endif
+
 constexpr uint32_t inv_mod_2_32(uint32_t p) {
   // Newton iteration: x <- x*(2 - p*x); doubles the number of correct low bits.
   uint32_t x = 1;

@@ -284,8 +284,8 @@ k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const uint32_
   using F = Fp<PP>;
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
-  const uint32_t* const* __restrict__ cols = jobs[jb].cols;
-  uint32_t* __restrict__ dig = jobs[jb].dig;
+  const gptr<const uint32_t* const> cols = as_global(jobs[jb].cols);
+  const gptr<uint32_t> dig = as_global(jobs[jb].dig);
   const size_t h = jobs[jb].h;
   const int wtot = jobs[jb].wtot;
   size_t i = (size_t)(blockIdx.x - jobs[jb].block0) * kBlock + threadIdx.x;
@@ -296,14 +296,14 @@ k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const uint32_
   int g = 0;
   for (; g + P2_RATE <= wtot; g += P2_RATE) {
 #pragma unroll
-    for (int j = 0; j < P2_RATE; ++j) s[j] = F::raw(cols[g + j][i]);
+    for (int j = 0; j < P2_RATE; ++j) s[j] = F::raw(as_global(cols[g + j])[i]);
     p2_permute<PP>(s, rc);
   }
   int rem = wtot - g;
   if (rem > 0) {
 #pragma unroll
     for (int j = 0; j < P2_RATE; ++j)
-      if (j < rem) s[j] = F::raw(cols[g + j][i]);
+      if (j < rem) s[j] = F::raw(as_global(cols[g + j])[i]);
     p2_permute<PP>(s, rc);
   }
 #pragma unroll

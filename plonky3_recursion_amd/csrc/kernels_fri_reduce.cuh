@@ -30,8 +30,9 @@ k_fri_inv_points(const FriInvJob* __restrict__ jobs, int n_jobs, uint32_t gen) {
   if (r >= h) return;
   F x = F::raw(gen) * F::raw(job.w_h).pow(bit_reverse((uint32_t)r, job.log_h));
   E v = (e4_load<PP>(job.z) - E::from_base(x)).inv();
+  const gptr<uint32_t> inv = as_global(job.inv);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) job.inv[(size_t)k * h + r] = v.c[k].v;
+  for (int k = 0; k < 4; ++k) inv[(size_t)k * h + r] = v.c[k].v;
 }
 
 // One committed matrix and its opening points.
@@ -69,7 +70,7 @@ k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriRed
   E acc = E::zero();
   for (uint32_t m = 0; m < job.n_mats; ++m) {
     const FriReduceMat& a = mats[job.mat0 + m];
-    const uint32_t* __restrict__ mat = a.mat;
+    const gptr<const uint32_t> mat = as_global(a.mat);
     const int w = a.w;
     E S = E::zero();
     int c = 0;
@@ -79,12 +80,12 @@ k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriRed
     for (int p = 0; p < a.n_points; ++p) {
       E inv;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) inv.c[k] = F::raw(a.inv[p][(size_t)k * h + r]);
+      for (int k = 0; k < 4; ++k) inv.c[k] = F::raw(as_global(a.inv[p])[(size_t)k * h + r]);
       acc += e4_load<PP>(a.off[p]) * (e4_load<PP>(a.v[p]) - S) * inv;
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) job.ro[(size_t)k * h + r] = acc.c[k].v;
+  for (int k = 0; k < 4; ++k) as_global(job.ro)[(size_t)k * h + r] = acc.c[k].v;
 }
 
 }  // namespace p3r

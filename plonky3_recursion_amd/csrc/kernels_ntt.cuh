@@ -3,7 +3,7 @@
 // A polynomial of N = N1*N2 cells is viewed as [N1][N2] (idx = n1*N2 + n2).  One launch
 // transforms along ONE of the two dimensions for a tile of T lines; the size-R sub-NTT runs
 // decimation-in-frequency (result k lands in row bitrev(k)), up to four stages at a time in
-// registers (radix-16), with Shoup-form twiddles read from an LDS copy of the table.
+// registers (radix-16), with Montgomery twiddles read from an LDS copy of the table.
 //   * the FIRST stage group reads its 16 cells straight from global memory (with the optional
 //     coset pre-scaling) and the LAST one, for strided passes, writes straight back (with the
 //     optional four-step twiddle / scaling), so a 2^10-point sub-NTT makes only two LDS round
@@ -36,6 +36,10 @@ struct NttPass {
   uint32_t scale;           // Montgomery; multiplied into every output when use_scale
   int use_scale;
   int inverse;
+  // position in a job-list launch: this pass owns (polynomials << (log_gx + log_gz)) blocks
+  // starting at block0; 2^log_gx tiles per polynomial and coset, 2^log_gz cosets
+  uint32_t block0;
+  int log_gx, log_gz;
 };
 
 constexpr int kNttBlock = 512;  // launches use tile_cells/16 lanes (2^13-cell tiles)
@@ -44,26 +48,18 @@ __device__ __forceinline__ uint32_t lds_addr(uint32_t r, uint32_t t, uint32_t T)
   return r * (T + 1) + (r >> 5) + t;
 }
 
-// Shoup product: a (any u32) times a fixed w < P given w' = floor(w * 2^32 / P); 3 multiplies.
-// The data stays in Montgomery form (x*R) while w is canonical: (x*R)*w = (x*w)*R.
-template <class PP>
-__device__ __forceinline__ Fp<PP> shoup_mul(uint32_t a, uint32_t w, uint32_t wp) {
-  uint32_t q = __umulhi(a, wp);
-  uint32_t r = a * w - q * PP::P;  // in [0, 2P)
-  uint32_t r2 = r - PP::P;
-  return Fp<PP>::raw(r < r2 ? r : r2);
-}
-
 // Per-block view of the pass: where a tile cell lives in global memory and what is applied to
 // it on the way in and out.
 template <class PP>
 struct NttTileIo {
   using F = Fp<PP>;
   const NttPass& a;
-  const uint32_t* in;
-  uint32_t* out;
-  const uint32_t* pre_a;
-  const uint32_t* pre_b;
+  gptr<const uint32_t> in;
+  gptr<uint32_t> out;
+  gptr<const uint32_t> pre_a;
+  gptr<const uint32_t> pre_b;
+  gptr<const uint32_t> tw4_lo;
+  gptr<const uint32_t> tw4_hi;
   uint32_t line0, N1, N2;
   int log_r;
   __device__ __forceinline__ F load(uint32_t r, uint32_t t) const {
@@ -78,9 +74,9 @@ struct NttTileIo {
     const uint32_t k = bit_reverse(r, log_r);
     const uint32_t rho = a.out_mode == 0 ? r : k;
     const uint32_t line = line0 + t;
-    if (a.tw4_lo) {
+    if (tw4_lo) {
       uint32_t x = k * line;  // < N
-      v = v * (F::raw(a.tw4_hi[x >> 10]) * F::raw(a.tw4_lo[x & 1023]));
+      v = v * (F::raw(tw4_hi[x >> 10]) * F::raw(tw4_lo[x & 1023]));
     }
     if (a.use_scale) v = v * F::raw(a.scale);
     size_t o;
@@ -158,10 +154,21 @@ __device__ __forceinline__ void ntt_group_dispatch(int logm, uint32_t* tile, con
   }
 }
 
+// One launch runs the same pass of SEVERAL matrices (all tables of a commit): `jobs` lists them,
+// a block finds its pass by walking the first-block indices.  The loops below stride by
+// blockDim, so a pass may get more lanes than its tile has 16-cell items.
 template <class PP>
-__global__ void __launch_bounds__(kNttBlock, 8) k_ntt_tile(NttPass a) {
+__global__ void __launch_bounds__(kNttBlock, 8) k_ntt_tile(const NttPass* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
   extern __shared__ uint32_t lds[];
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const NttPass a = jobs[jb];
+  // tile (x) fastest, then coset (z), then polynomial (y); x and z counts are powers of two
+  const uint32_t local = blockIdx.x - a.block0;
+  const uint32_t bx = local & ((1u << a.log_gx) - 1);
+  const uint32_t bz = (local >> a.log_gx) & ((1u << a.log_gz) - 1);
+  const uint32_t by = local >> (a.log_gx + a.log_gz);
   const uint32_t tid = threadIdx.x;
   const int log_r = a.sub_dim == 0 ? a.log_n1 : a.log_n2;
   const uint32_t R = 1u << log_r, T = 1u << a.log_t;
@@ -169,12 +176,14 @@ __global__ void __launch_bounds__(kNttBlock, 8) k_ntt_tile(NttPass a) {
   uint32_t* tile = lds;
   uint32_t* tws = lds + ((R * (T + 1) + (R >> 5) + 2) & ~1u);  // 8-byte aligned (w, w') pairs
   NttTileIo<PP> io{a,
-                   a.in + (size_t)blockIdx.y * a.in_col_stride,
-                   a.out + (size_t)blockIdx.y * a.out_col_stride + (size_t)blockIdx.z * a.out_coset_stride,
-                   a.pre_a ? a.pre_a + (size_t)blockIdx.z * N1 : nullptr,
-                   a.pre_b ? a.pre_b + (size_t)blockIdx.z * N2 : nullptr,
-                   blockIdx.x * T, N1, N2, log_r};
-  for (uint32_t i = tid; i < R / 2; i += blockDim.x) tws[i] = a.tw_sub[i];
+                   as_global(a.in) + (size_t)by * a.in_col_stride,
+                   as_global(a.out) + (size_t)by * a.out_col_stride + (size_t)bz * a.out_coset_stride,
+                   a.pre_a ? as_global(a.pre_a) + (size_t)bz * N1 : nullptr,
+                   a.pre_b ? as_global(a.pre_b) + (size_t)bz * N2 : nullptr,
+                   as_global(a.tw4_lo), as_global(a.tw4_hi),
+                   bx * T, N1, N2, log_r};
+  const gptr<const uint32_t> tw_sub = as_global(a.tw_sub);
+  for (uint32_t i = tid; i < R / 2; i += blockDim.x) tws[i] = tw_sub[i];
   __syncthreads();
   const uint32_t E = R << a.log_t;
 

@@ -321,8 +321,9 @@ __global__ void __launch_bounds__(kBlock) k_bary_weights(const BaryJob* __restri
   if (i >= b.n) return;
   F wi = F::raw(b.w_n).pow(i);
   E r = (e4_load<PP>(b.z) - E::from_base(wi)).inv() * e4_load<PP>(b.scale) * wi;
+  const gptr<uint32_t> out = as_global(b.out);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) b.out[(size_t)k * b.n + i] = r.c[k].v;
+  for (int k = 0; k < 4; ++k) out[(size_t)k * b.n + i] = r.c[k].v;
 }
 
 constexpr int kOpenCols = 8;      // matrix columns sharing one pass over the weights
@@ -345,9 +346,9 @@ __device__ __forceinline__ void open_dot_block(const OpenJob& job, int col_group
   using F = Fp<PP>;
   using E = Fp4<PP>;
   constexpr int NV = P * kOpenCols * 4;
-  const uint32_t* __restrict__ mat = job.mat;
-  const uint32_t* __restrict__ wt0 = job.wt0;
-  const uint32_t* __restrict__ wt1 = job.wt1;
+  const gptr<const uint32_t> mat = as_global(job.mat);
+  const gptr<const uint32_t> wt0 = as_global(job.wt0);
+  const gptr<const uint32_t> wt1 = as_global(job.wt1);
   const size_t n = job.n;
   const int w = job.w, c0 = col_group * kOpenCols;
   size_t r0 = (size_t)chunk * job.rows_per_block, r1 = r0 + job.rows_per_block < n ? r0 + job.rows_per_block : n;
@@ -399,7 +400,7 @@ __device__ __forceinline__ void open_dot_block(const OpenJob& job, int col_group
 #pragma unroll
     for (int wv = 0; wv < kBlock / 64; ++wv) s += F::raw(sh[wv][threadIdx.x]);
     const int p = threadIdx.x / (kOpenCols * 4), rem = threadIdx.x % (kOpenCols * 4), c = rem / 4, k = rem % 4;
-    if (c0 + c < w) job.partial[(((size_t)p * job.n_chunks + chunk) * w + c0 + c) * 4 + k] = s.v;
+    if (c0 + c < w) as_global(job.partial)[(((size_t)p * job.n_chunks + chunk) * w + c0 + c) * 4 + k] = s.v;
   }
 }
 template <class PP>
@@ -426,8 +427,9 @@ k_open_reduce(const OpenJob* __restrict__ jobs, int n_jobs, uint32_t total, uint
   const uint32_t local = t - job.out0;
   const uint32_t per_point = (uint32_t)job.w * 4, p = local / per_point, rem = local % per_point;
   F s = F::zero();
+  const gptr<const uint32_t> partial = as_global(job.partial);
   for (int ch = 0; ch < job.n_chunks; ++ch)
-    s += F::raw(job.partial[((size_t)p * job.n_chunks + ch) * per_point + rem]);
+    s += F::raw(partial[((size_t)p * job.n_chunks + ch) * per_point + rem]);
   out[t] = s.v;
 }
 

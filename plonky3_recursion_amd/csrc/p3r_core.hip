@@ -231,110 +231,6 @@ std::pair<const uint32_t*, const uint32_t*> get_pre(p3r_ctx* ctx, int log_n, int
   return {it->second.first.p, it->second.second.p};
 }
 
-template <class PP>
-void launch_ntt(p3r_ctx* ctx, NttPass a, size_t ncols, size_t ncosets, const char* name) {
-  const int log_r = a.sub_dim == 0 ? a.log_n1 : a.log_n2;
-  const int log_lines = a.sub_dim == 0 ? a.log_n2 : a.log_n1;
-  static const int log_tile = getenv("P3R_NTT_LOG_TILE") ? atoi(getenv("P3R_NTT_LOG_TILE")) : 13;  // 2^13 cells, 512 lanes: 4 tiles per CU overlap their phases
-  int log_t = std::max(0, std::min(log_tile, 13) - log_r);
-  if (a.sub_dim == 0 && log_t > 5) log_t = 5;  // 128-byte segments are enough when strided
-  log_t = std::min(log_t, log_lines);
-  a.log_t = log_t;
-  const size_t R = size_t(1) << log_r, T = size_t(1) << log_t;
-  size_t lds = (R * (T + 1) + (R >> 5) + 2 + R + 2) * sizeof(uint32_t);
-  if (lds > 160 * 1024) fail(P3R_EUNSUPPORTED, "NTT tile of 2^%d rows does not fit LDS", log_r);
-  dim3 grid((unsigned)(size_t(1) << (log_lines - log_t)), (unsigned)ncols, (unsigned)ncosets);
-  ProfScope ps(ctx, name);
-  const unsigned threads = (unsigned)std::min<size_t>(kNttBlock, std::max<size_t>(64, (R * T) >> 4));
-  hipLaunchKernelGGL(k_ntt_tile<PP>, grid, dim3(threads), lds, ctx->stream, a);
-  P3R_HIP(hipGetLastError());
-}
-
-// K5. in: h x w evaluations over the subgroup (natural order, column-major Montgomery).
-// Returns (h << added_bits) x w, rows in bit-reversed order over shift * <w_{h<<added_bits}>.
-template <class PP>
-std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_bits,
-                                    uint32_t shift) {
-  using F = Fp<PP>;
-  const int log_n = log2_exact(in->h, "LDE input height");
-  if (log_n + added_bits > PP::TWO_ADICITY)
-    fail(P3R_EINVAL, "LDE of 2^%d rows exceeds the field's two-adicity (%d)", log_n + added_bits,
-         PP::TWO_ADICITY);
-  if (shift == 0 || shift >= PP::P) fail(P3R_EINVAL, "coset shift must be a non-zero canonical element");
-  const size_t N = in->h, B = size_t(1) << added_bits, w = in->w;
-  auto out = dmat_alloc(N * B, w);
-  DevBuf coef(N * w);
-  const uint32_t inv_n = F::from_canonical((uint32_t)(N % PP::P)).inv().v;
-
-  NttPass p{};
-  if (log_n <= 11) {
-    // single pass each way: whole polynomial in one LDS tile
-    p = NttPass{};
-    p.in = in->d; p.out = coef.p;
-    p.in_col_stride = N; p.out_col_stride = N; p.out_coset_stride = 0;
-    p.log_n1 = 0; p.log_n2 = log_n; p.sub_dim = 1; p.out_mode = 1;
-    p.tw_sub = get_tw_sub<PP>(ctx, log_n, 1); p.inverse = 1;
-    p.scale = inv_n; p.use_scale = 1;
-    launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
-    auto pre = get_pre<PP>(ctx, log_n, 0, log_n, added_bits, shift);
-    p = NttPass{};
-    p.in = coef.p; p.out = out->d;
-    p.in_col_stride = N; p.out_col_stride = N * B; p.out_coset_stride = N;
-    p.log_n1 = 0; p.log_n2 = log_n; p.sub_dim = 1; p.out_mode = 0;
-    p.tw_sub = get_tw_sub<PP>(ctx, log_n, 0);
-    p.pre_a = pre.first; p.pre_b = pre.second;
-    launch_ntt<PP>(ctx, p, w, B, "ntt_forward");
-  } else {
-    const int la = log_n / 2, lb = log_n - la;  // N1 = 2^la (strided dim), N2 = 2^lb
-    DevBuf tmp(N * w);
-    auto tw4i = get_tw4<PP>(ctx, log_n, 1);
-    // inverse pass 1: size-N1 transforms along n1, twiddle, transposed store tmp[n2*N1 + k1]
-    p = NttPass{};
-    p.in = in->d; p.out = tmp.p;
-    p.in_col_stride = N; p.out_col_stride = N;
-    p.log_n1 = la; p.log_n2 = lb; p.sub_dim = 0; p.out_mode = 2;
-    p.tw_sub = get_tw_sub<PP>(ctx, la, 1); p.inverse = 1;
-    p.tw4_lo = tw4i.first; p.tw4_hi = tw4i.second;
-    launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
-    // inverse pass 2: tmp viewed as [N2][N1]; size-N2 transforms along its first dim,
-    // natural row order -> coefficient k1 + N1*k2 lands at k2*N1 + k1
-    p = NttPass{};
-    p.in = tmp.p; p.out = coef.p;
-    p.in_col_stride = N; p.out_col_stride = N;
-    p.log_n1 = lb; p.log_n2 = la; p.sub_dim = 0; p.out_mode = 1;
-    p.tw_sub = get_tw_sub<PP>(ctx, lb, 1); p.inverse = 1;
-    p.scale = inv_n; p.use_scale = 1;
-    launch_ntt<PP>(ctx, p, w, 1, "ntt_inverse");
-    // forward pass 1 (all cosets): scale by s_z^k, size-N1 transforms along n1, twiddle, in place rows.
-    // The forward transform has its own split: its strided pass wants few rows per tile (long
-    // contiguous segments per row), its second pass is contiguous whatever N2 is.
-    static const int fwd_la_cap = getenv("P3R_NTT_FWD_LOG_N1") ? atoi(getenv("P3R_NTT_FWD_LOG_N1")) : 8;
-    // (measured: 2^8 x 2^12 beats 2^10 x 2^10 at n = 2^20; past 2^12 contiguous points per line the
-    // balanced split is better again)
-    const int la_f = log_n - fwd_la_cap <= 12 ? std::min(log_n / 2, fwd_la_cap) : log_n / 2, lb_f = log_n - la_f;
-    auto pre = get_pre<PP>(ctx, log_n, la_f, lb_f, added_bits, shift);
-    auto tw4f = get_tw4<PP>(ctx, log_n, 0);
-    p = NttPass{};
-    p.in = coef.p; p.out = out->d;
-    p.in_col_stride = N; p.out_col_stride = N * B; p.out_coset_stride = N;
-    p.log_n1 = la_f; p.log_n2 = lb_f; p.sub_dim = 0; p.out_mode = 0;
-    p.tw_sub = get_tw_sub<PP>(ctx, la_f, 0);
-    p.tw4_lo = tw4f.first; p.tw4_hi = tw4f.second;
-    p.pre_a = pre.first; p.pre_b = pre.second;
-    launch_ntt<PP>(ctx, p, w, B, "ntt_forward");
-    // forward pass 2: contiguous size-N2 transforms, in place, bit-reversed rows kept.
-    // The B cosets of a column are contiguous, so they are just B*N1 lines of N2 cells.
-    p = NttPass{};
-    p.in = out->d; p.out = out->d;
-    p.in_col_stride = N * B; p.out_col_stride = N * B;
-    p.log_n1 = la_f + added_bits; p.log_n2 = lb_f; p.sub_dim = 1; p.out_mode = 0;
-    p.tw_sub = get_tw_sub<PP>(ctx, lb_f, 0);
-    launch_ntt<PP>(ctx, p, w, 1, "ntt_forward");
-  }
-  return out;
-}
-
-// ------------------------------------------------------------------ MMCS
 // Device copy of a small read-only table (see p3r_ctx::const_tables).
 inline const void* const_table(p3r_ctx* ctx, const void* data, size_t bytes) {
   std::string key(static_cast<const char*>(data), bytes);
@@ -351,6 +247,156 @@ inline const uint32_t* const* col_table(p3r_ctx* ctx, const std::vector<const ui
   return static_cast<const uint32_t* const*>(const_table(ctx, cols.data(), cols.size() * sizeof(void*)));
 }
 
+// One pass of one matrix inside a job-list launch.
+struct NttJob {
+  NttPass pass;
+  size_t ncols, ncosets;
+};
+// Runs the listed passes in ONE launch (they must be independent of each other).
+template <class PP>
+void launch_ntt(p3r_ctx* ctx, std::vector<NttJob>& jobs, const char* name) {
+  if (jobs.empty()) return;
+  static const int log_tile = getenv("P3R_NTT_LOG_TILE") ? atoi(getenv("P3R_NTT_LOG_TILE")) : 13;  // 2^13 cells, 512 lanes: 4 tiles per CU overlap their phases
+  std::vector<NttPass> passes;
+  size_t lds_max = 0;
+  unsigned threads_max = 64;
+  uint64_t blocks = 0;
+  for (NttJob& j : jobs) {
+    NttPass& a = j.pass;
+    const int log_r = a.sub_dim == 0 ? a.log_n1 : a.log_n2;
+    const int log_lines = a.sub_dim == 0 ? a.log_n2 : a.log_n1;
+    int log_t = std::max(0, std::min(log_tile, 13) - log_r);
+    if (a.sub_dim == 0 && log_t > 5) log_t = 5;  // 128-byte segments are enough when strided
+    log_t = std::min(log_t, log_lines);
+    a.log_t = log_t;
+    const size_t R = size_t(1) << log_r, T = size_t(1) << log_t;
+    const size_t lds = (R * (T + 1) + (R >> 5) + 2 + R + 2) * sizeof(uint32_t);
+    if (lds > 160 * 1024) fail(P3R_EUNSUPPORTED, "NTT tile of 2^%d rows does not fit LDS", log_r);
+    lds_max = std::max(lds_max, lds);
+    threads_max = std::max(threads_max, (unsigned)std::min<size_t>(kNttBlock, (R * T) >> 4));
+    a.block0 = (uint32_t)blocks;
+    a.log_gx = log_lines - log_t;
+    a.log_gz = log2_exact(j.ncosets, "coset count");
+    blocks += (uint64_t)j.ncols << (a.log_gx + a.log_gz);
+    passes.push_back(a);
+  }
+  if (blocks >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "NTT launch of %llu tiles", (unsigned long long)blocks);
+  const auto* d_jobs = static_cast<const NttPass*>(const_table(ctx, passes.data(), passes.size() * sizeof(NttPass)));
+  ProfScope ps(ctx, name);
+  hipLaunchKernelGGL(k_ntt_tile<PP>, dim3((unsigned)blocks), dim3(threads_max), lds_max, ctx->stream, d_jobs,
+                     (int)passes.size());
+  P3R_HIP(hipGetLastError());
+}
+
+// K5 for a batch of matrices (all tables of a commit): every matrix goes through the same passes,
+// and pass k of all of them is one launch.
+// in: h x w evaluations over the subgroup (natural order, column-major Montgomery).
+// Returns (h << added_bits) x w, rows in bit-reversed order over shift * <w_{h<<added_bits}>.
+struct LdeItem {
+  const p3r_dmat* in;
+  uint32_t shift;  // canonical coset shift
+};
+template <class PP>
+std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::vector<LdeItem>& items,
+                                                       int added_bits) {
+  using F = Fp<PP>;
+  const size_t B = size_t(1) << added_bits;
+  std::vector<std::unique_ptr<p3r_dmat>> outs;
+  std::vector<DevBuf> scratch;  // coefficient vectors and transposition buffers
+  // phase 1/2: inverse transform (small matrices: 1 = inverse, 2 = forward); 3/4: forward of the rest
+  std::vector<NttJob> phase[4];
+  static const int fwd_la_cap = getenv("P3R_NTT_FWD_LOG_N1") ? atoi(getenv("P3R_NTT_FWD_LOG_N1")) : 8;
+  for (const LdeItem& it : items) {
+    const p3r_dmat* in = it.in;
+    const uint32_t shift = it.shift;
+    const int log_n = log2_exact(in->h, "LDE input height");
+    if (log_n + added_bits > PP::TWO_ADICITY)
+      fail(P3R_EINVAL, "LDE of 2^%d rows exceeds the field's two-adicity (%d)", log_n + added_bits,
+           PP::TWO_ADICITY);
+    if (shift == 0 || shift >= PP::P) fail(P3R_EINVAL, "coset shift must be a non-zero canonical element");
+    const size_t N = in->h, w = in->w;
+    outs.push_back(dmat_alloc(N * B, w));
+    p3r_dmat* out = outs.back().get();
+    scratch.emplace_back(N * w);
+    uint32_t* coef = scratch.back().p;
+    const uint32_t inv_n = F::from_canonical((uint32_t)(N % PP::P)).inv().v;
+
+    NttPass p{};
+    if (log_n <= 11) {
+      // single pass each way: whole polynomial in one LDS tile
+      p.in = in->d; p.out = coef;
+      p.in_col_stride = N; p.out_col_stride = N; p.out_coset_stride = 0;
+      p.log_n1 = 0; p.log_n2 = log_n; p.sub_dim = 1; p.out_mode = 1;
+      p.tw_sub = get_tw_sub<PP>(ctx, log_n, 1); p.inverse = 1;
+      p.scale = inv_n; p.use_scale = 1;
+      phase[0].push_back({p, w, 1});
+      auto pre = get_pre<PP>(ctx, log_n, 0, log_n, added_bits, shift);
+      p = NttPass{};
+      p.in = coef; p.out = out->d;
+      p.in_col_stride = N; p.out_col_stride = N * B; p.out_coset_stride = N;
+      p.log_n1 = 0; p.log_n2 = log_n; p.sub_dim = 1; p.out_mode = 0;
+      p.tw_sub = get_tw_sub<PP>(ctx, log_n, 0);
+      p.pre_a = pre.first; p.pre_b = pre.second;
+      phase[1].push_back({p, w, B});
+      continue;
+    }
+    const int la = log_n / 2, lb = log_n - la;  // N1 = 2^la (strided dim), N2 = 2^lb
+    scratch.emplace_back(N * w);
+    uint32_t* tmp = scratch.back().p;
+    auto tw4i = get_tw4<PP>(ctx, log_n, 1);
+    // inverse pass 1: size-N1 transforms along n1, twiddle, transposed store tmp[n2*N1 + k1]
+    p.in = in->d; p.out = tmp;
+    p.in_col_stride = N; p.out_col_stride = N;
+    p.log_n1 = la; p.log_n2 = lb; p.sub_dim = 0; p.out_mode = 2;
+    p.tw_sub = get_tw_sub<PP>(ctx, la, 1); p.inverse = 1;
+    p.tw4_lo = tw4i.first; p.tw4_hi = tw4i.second;
+    phase[0].push_back({p, w, 1});
+    // inverse pass 2: tmp viewed as [N2][N1]; size-N2 transforms along its first dim,
+    // natural row order -> coefficient k1 + N1*k2 lands at k2*N1 + k1
+    p = NttPass{};
+    p.in = tmp; p.out = coef;
+    p.in_col_stride = N; p.out_col_stride = N;
+    p.log_n1 = lb; p.log_n2 = la; p.sub_dim = 0; p.out_mode = 1;
+    p.tw_sub = get_tw_sub<PP>(ctx, lb, 1); p.inverse = 1;
+    p.scale = inv_n; p.use_scale = 1;
+    phase[1].push_back({p, w, 1});
+    // forward pass 1 (all cosets): scale by s_z^k, size-N1 transforms along n1, twiddle, in place rows.
+    // The forward transform has its own split: its strided pass wants few rows per tile (long
+    // contiguous segments per row), its second pass is contiguous whatever N2 is.
+    // (measured: 2^8 x 2^12 beats 2^10 x 2^10 at n = 2^20; past 2^12 contiguous points per line the
+    // balanced split is better again)
+    const int la_f = log_n - fwd_la_cap <= 12 ? std::min(log_n / 2, fwd_la_cap) : log_n / 2, lb_f = log_n - la_f;
+    auto pre = get_pre<PP>(ctx, log_n, la_f, lb_f, added_bits, shift);
+    auto tw4f = get_tw4<PP>(ctx, log_n, 0);
+    p = NttPass{};
+    p.in = coef; p.out = out->d;
+    p.in_col_stride = N; p.out_col_stride = N * B; p.out_coset_stride = N;
+    p.log_n1 = la_f; p.log_n2 = lb_f; p.sub_dim = 0; p.out_mode = 0;
+    p.tw_sub = get_tw_sub<PP>(ctx, la_f, 0);
+    p.tw4_lo = tw4f.first; p.tw4_hi = tw4f.second;
+    p.pre_a = pre.first; p.pre_b = pre.second;
+    phase[2].push_back({p, w, B});
+    // forward pass 2: contiguous size-N2 transforms, in place, bit-reversed rows kept.
+    // The B cosets of a column are contiguous, so they are just B*N1 lines of N2 cells.
+    p = NttPass{};
+    p.in = out->d; p.out = out->d;
+    p.in_col_stride = N * B; p.out_col_stride = N * B;
+    p.log_n1 = la_f + added_bits; p.log_n2 = lb_f; p.sub_dim = 1; p.out_mode = 0;
+    p.tw_sub = get_tw_sub<PP>(ctx, lb_f, 0);
+    phase[3].push_back({p, w, 1});
+  }
+  launch_ntt<PP>(ctx, phase[0], "ntt_inverse");
+  launch_ntt<PP>(ctx, phase[1], "ntt_inverse");
+  launch_ntt<PP>(ctx, phase[2], "ntt_forward");
+  launch_ntt<PP>(ctx, phase[3], "ntt_forward");
+  return outs;
+}
+template <class PP>
+std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_bits, uint32_t shift) {
+  return std::move(coset_lde_batch<PP>(ctx, {{in, shift}}, added_bits)[0]);
+}
+
+// ------------------------------------------------------------------ MMCS
 // Row digests of several height classes in one launch: classes[c] = the matrices of one height
 // (their rows are concatenated in the given order), digs[c] = [8][h_c].
 template <class PP>

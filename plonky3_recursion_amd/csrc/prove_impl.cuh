@@ -177,12 +177,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
 
   prof_stage(ctx, "main_lde_commit");
   // ---- 1. main LDEs + commitment
-  std::vector<std::unique_ptr<p3r_dmat>> main_lde(ni);
+  std::vector<LdeItem> lde_items;
+  for (size_t i = 0; i < ni; ++i) lde_items.push_back({mains[i], PP::GEN});
+  std::vector<std::unique_ptr<p3r_dmat>> main_lde = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
   std::vector<const p3r_dmat*> ptrs;
-  for (size_t i = 0; i < ni; ++i) {
-    main_lde[i] = coset_lde<PP>(ctx, mains[i], log_blowup, PP::GEN);
-    ptrs.push_back(main_lde[i].get());
-  }
+  for (size_t i = 0; i < ni; ++i) ptrs.push_back(main_lde[i].get());
   std::vector<uint32_t> main_cap, perm_cap, quot_cap;
   auto main_tree = commit_dmats<PP>(ctx, ptrs, main_cap);
 
@@ -240,11 +239,16 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
                            agg.p, n_blocks, aux[i]->d, total);
       }
       P3R_HIP(hipGetLastError());
-      aux_lde[i] = coset_lde<PP>(ctx, aux[i].get(), log_blowup, PP::GEN);
       perm_insts.push_back((int)i);
     }
+    lde_items.clear();
+    for (int i : perm_insts) lde_items.push_back({aux[i].get(), PP::GEN});
+    auto ldes = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
     ptrs.clear();
-    for (int i : perm_insts) ptrs.push_back(aux_lde[i].get());
+    for (size_t k = 0; k < perm_insts.size(); ++k) {
+      aux_lde[perm_insts[k]] = std::move(ldes[k]);
+      ptrs.push_back(aux_lde[perm_insts[k]].get());
+    }
     perm_tree = commit_dmats<PP>(ctx, ptrs, perm_cap);
     {
       // every table's global sum in one transfer
@@ -317,11 +321,16 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       ck.evals->d = chunk_buf->d + (size_t)c * 4 * n;  // view: n x 4 column-major
       ck.evals->h = n;
       ck.evals->w = 4;
-      // commit evaluates the chunk polynomial on gen*<w>: shift = GENERATOR / domain shift
-      ck.lde = coset_lde<PP>(ctx, ck.evals.get(), log_blowup, (gen * ck.shift.inv()).to_canonical());
       chunks.push_back(std::move(ck));
     }
     chunk_bufs_keep.push_back(std::move(chunk_buf));
+  }
+  {
+    // commit evaluates each chunk polynomial on gen*<w>: shift = GENERATOR / domain shift
+    lde_items.clear();
+    for (auto& ck : chunks) lde_items.push_back({ck.evals.get(), (gen * ck.shift.inv()).to_canonical()});
+    auto ldes = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
+    for (size_t k = 0; k < chunks.size(); ++k) chunks[k].lde = std::move(ldes[k]);
   }
   ptrs.clear();
   for (auto& ck : chunks) ptrs.push_back(ck.lde.get());
