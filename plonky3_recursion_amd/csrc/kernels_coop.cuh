@@ -76,68 +76,57 @@ __device__ __forceinline__ Fp<PP> coop_permute(Fp<PP> s, int elem, Fp<PP> diag, 
   return s;
 }
 
-// Same contract as k_mmcs_compress (kernels.cuh), 16 lanes per node.
-template <class PP>
-__global__ void __launch_bounds__(kBlock)
-k_mmcs_compress_coop(const uint32_t* __restrict__ L, size_t nl, int lmul, int ladd, const uint32_t* __restrict__ R,
-                     size_t nr, int rmul, int radd, uint32_t* __restrict__ out, size_t n,
-                     const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
-  using F = Fp<PP>;
-  const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  const size_t node = gid >> 4;
-  const int elem = (int)(gid & 15);
-  // whole rows are active or inactive together (n*16 need not fill the last wave)
-  const bool live = node < n;
-  F s = F::zero();
-  if (live) {
-    s = elem < P2_DIGEST ? F::raw(L[(size_t)elem * nl + node * lmul + ladd])
-                         : F::raw(R[(size_t)(elem - P2_DIGEST) * nr + node * rmul + radd]);
-  }
-  s = coop_permute<PP>(s, elem, F::raw(diag[elem]), rc);
-  if (live && elem < P2_DIGEST) out[(size_t)elem * n + node] = s.v;
-}
-
-// The last levels of a Merkle tree in ONE workgroup: from a layer of at most kTailNodes digests
-// down to the cap, a barrier per level instead of a launch (each of these levels is a single
-// permutation latency; the launches between them cost more than the work).  Every level is
-// written to its own layer buffer - queries read siblings from them - and handed to the next
-// level through LDS.  Plain 2-to-1 levels only: the host uses it below the last injection.
-constexpr int kTailBlock = 1024;  // 64 nodes in flight
-constexpr int kTailNodes = 256;
-constexpr int kTailLevels = 8;
-struct TreeTailArgs {
+// Up to eight levels of a Merkle tree per launch.  A workgroup owns kSubtreeNodes consecutive
+// digests of the input layer and everything above them: a barrier per level instead of a launch
+// (each of these levels is one permutation latency; the launches between them cost more than the
+// work), LDS hand-off between levels.  Every level is also written to its own layer buffer -
+// queries read siblings from them.  A level may carry an injection (digests of the shorter
+// matrices of the commit, circuit/src/ops/mmcs.rs:117-160): node = compress(compress(l, r), inj).
+// Used for layers of at most kCoopMaxNodes nodes; the last launch of a tree is a single workgroup.
+constexpr int kSubtreeBlock = 1024;  // 64 nodes in flight
+constexpr int kSubtreeNodes = 256;
+constexpr int kSubtreeLevels = 8;
+struct SubtreeArgs {
   const uint32_t* in;  // [8][n_in]
-  uint32_t n_in;       // power of two, <= kTailNodes
-  int n_levels;        // <= kTailLevels
-  uint32_t* out[kTailLevels];  // out[l]: [8][n_in >> (l+1)]
+  uint32_t n_in;       // power of two; a multiple of kSubtreeNodes, or smaller (one workgroup)
+  int n_levels;        // <= kSubtreeLevels, <= log2(min(n_in, kSubtreeNodes))
+  uint32_t* out[kSubtreeLevels];        // out[l]: [8][n_in >> (l+1)]
+  const uint32_t* inj[kSubtreeLevels];  // inj[l]: [8][n_in >> (l+1)] or null
 };
 template <class PP>
-__global__ void __launch_bounds__(kTailBlock)
-k_mmcs_tree_tail(TreeTailArgs a, const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+__global__ void __launch_bounds__(kSubtreeBlock)
+k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
   using F = Fp<PP>;
-  __shared__ uint32_t buf[2][P2_DIGEST * kTailNodes / 2];
+  __shared__ uint32_t buf[2][P2_DIGEST * kSubtreeNodes / 2];
   const int elem = threadIdx.x & 15;
   const uint32_t group = threadIdx.x >> 4, k = elem & 7;
   const F d = F::raw(diag[elem]);
-  uint32_t n = a.n_in;
+  uint32_t n = a.n_in < (uint32_t)kSubtreeNodes ? a.n_in : (uint32_t)kSubtreeNodes;  // local nodes
+  uint32_t n_glob = a.n_in, first = blockIdx.x * n;  // layer size, this workgroup's first node
 #pragma unroll
-  for (int l = 0; l < kTailLevels; ++l) {
+  for (int l = 0; l < kSubtreeLevels; ++l) {
     if (l < a.n_levels) {
-      const uint32_t nn = n / 2;
+      const uint32_t nn = n / 2, nn_glob = n_glob / 2, first_out = first / 2;
       const uint32_t* cur = buf[(l + 1) & 1];
       uint32_t* nxt = buf[l & 1];
       // a 16-lane row works on one node: lanes 0..7 hold the left child, 8..15 the right one
-      for (uint32_t node = group; node < nn; node += kTailBlock / 16) {
+      for (uint32_t node = group; node < nn; node += kSubtreeBlock / 16) {
         const uint32_t child = 2 * node + (elem >> 3);
-        F s = F::raw(l == 0 ? a.in[k * n + child] : cur[k * n + child]);
+        F s = F::raw(l == 0 ? a.in[(size_t)k * n_glob + first + child] : cur[k * n + child]);
         s = coop_permute<PP>(s, elem, d, rc);
+        if (a.inj[l]) {
+          if (elem >= P2_DIGEST) s = F::raw(a.inj[l][(size_t)k * nn_glob + first_out + node]);
+          s = coop_permute<PP>(s, elem, d, rc);
+        }
         if (elem < P2_DIGEST) {
           nxt[k * nn + node] = s.v;
-          a.out[l][k * nn + node] = s.v;
+          a.out[l][(size_t)k * nn_glob + first_out + node] = s.v;
         }
       }
       __syncthreads();
       n = nn;
+      n_glob = nn_glob;
+      first = first_out;
     }
   }
 }

@@ -430,39 +430,47 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
   P3R_HIP(hipGetLastError());
 }
 
-// One 2-to-1 layer.  Layers too small to fill the chip with one-permutation-per-lane work are
-// latency-bound, so they use the 16-lanes-per-node kernel instead.
+// One 2-to-1 layer, one permutation per lane: for layers large enough to fill the chip.  Smaller
+// ones are latency-bound and go through mmcs_subtree below (16 lanes per node, 8 levels per launch).
 constexpr size_t kCoopMaxNodes = 32768;
 template <class PP>
 void launch_compress(p3r_ctx* ctx, const uint32_t* L, size_t nl, int lmul, int ladd, const uint32_t* R, size_t nr,
                      int rmul, int radd, uint32_t* out, size_t n) {
   ProfScope ps(ctx, "mmcs_compress");
-  if (n <= kCoopMaxNodes)
-    hipLaunchKernelGGL(k_mmcs_compress_coop<PP>, dim3(blocks_for(n * 16)), dim3(kBlock), 0, ctx->stream, L, nl, lmul,
-                       ladd, R, nr, rmul, radd, out, n, ctx->rc.p, ctx->p2_diag.p);
-  else
-    hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, L, nl, lmul, ladd, R,
-                       nr, rmul, radd, out, n, ctx->rc.p);
+  hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, L, nl, lmul, ladd, R,
+                     nr, rmul, radd, out, n, ctx->rc.p);
   P3R_HIP(hipGetLastError());
 }
 
-// Levels from the `n`-digest layer at the back of `tree->layers` down to the cap, when they fit
-// the single-workgroup kernel; the caller guarantees that nothing is injected below `n`.
+// Up to eight levels above the `n`-digest layer at the back of `tree->layers` in one launch
+// (k_mmcs_subtree), for layers small enough to be latency-bound.  `inject`: height -> digests to
+// fold in at that height (may be null).  Returns the size of the new back layer, or `n` when
+// the layer is too large for this path.
 template <class PP>
-bool mmcs_tree_tail(p3r_ctx* ctx, p3r_tree* tree, size_t n) {
+size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_t, DevBuf>* inject) {
   const size_t cap_n = size_t(1) << tree->cap_height;
-  if (n > (size_t)kTailNodes || n <= cap_n) return false;
-  TreeTailArgs a{};
+  if (n / 2 > kCoopMaxNodes || n <= cap_n) return n;
+  SubtreeArgs a{};
   a.in = tree->layers.back().p;
   a.n_in = (uint32_t)n;
-  for (size_t nn = n / 2; nn >= cap_n; nn /= 2) {  // cap_n >= 1 ends it
+  const size_t local = std::min<size_t>(n, kSubtreeNodes);
+  size_t nn = n, shrink = local;
+  while (shrink > 1 && nn > cap_n && a.n_levels < kSubtreeLevels) {
+    nn /= 2;
+    shrink /= 2;
     tree->layers.emplace_back(P2_DIGEST * nn);
-    a.out[a.n_levels++] = tree->layers.back().p;
+    a.out[a.n_levels] = tree->layers.back().p;
+    if (inject) {
+      auto it = inject->find(nn);
+      if (it != inject->end()) a.inj[a.n_levels] = it->second.p;
+    }
+    ++a.n_levels;
   }
   ProfScope ps(ctx, "mmcs_compress");
-  hipLaunchKernelGGL(k_mmcs_tree_tail<PP>, dim3(1), dim3(kTailBlock), 0, ctx->stream, a, ctx->rc.p, ctx->p2_diag.p);
+  hipLaunchKernelGGL(k_mmcs_subtree<PP>, dim3((unsigned)(n / local)), dim3(kSubtreeBlock), 0, ctx->stream, a,
+                     ctx->rc.p, ctx->p2_diag.p);
   P3R_HIP(hipGetLastError());
-  return true;
+  return nn;
 }
 
 template <class PP>
@@ -509,9 +517,12 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   }
   size_t n = hmax;
   const size_t cap_n = size_t(1) << tree->cap_height;
-  const size_t min_h = class_h.back();
   while (n > cap_n) {
-    if (n <= min_h && mmcs_tree_tail<PP>(ctx, tree, n)) break;
+    const size_t after = mmcs_subtree<PP>(ctx, tree, n, &inject);
+    if (after != n) {
+      n = after;
+      continue;
+    }
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;

@@ -47,7 +47,11 @@ void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves) {
   size_t n = n_leaves;
   const size_t cap_n = size_t(1) << tree->cap_height;
   while (n > cap_n) {
-    if (mmcs_tree_tail<PP>(ctx, tree, n)) break;
+    const size_t after = mmcs_subtree<PP>(ctx, tree, n, nullptr);
+    if (after != n) {
+      n = after;
+      continue;
+    }
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;
