@@ -31,8 +31,8 @@ struct AirParams {
 template <class PP>
 struct RowView {
   using F = Fp<PP>;
-  const uint32_t* main;
-  const uint32_t* prep;
+  gptr<const uint32_t> main;  // (global address space: see as_global, field.h)
+  gptr<const uint32_t> prep;
   size_t h;         // matrix height (trace height for K7, LDE height for K8)
   size_t row, nxt;  // local row and "next" row (already wrapped / bit-reverse mapped)
   using V = F;

@@ -287,7 +287,7 @@ struct RunSchedule {
   std::vector<uint32_t> chunk_bounds;       // per narrow segment: n_chunks + 1 level boundaries
   // Horner chains: runs of consecutive HornerAcc ops threaded through the accumulator with one
   // shared multiplier b are an affine recurrence acc <- acc*b + (c - a); each run is ONE scan
-  // (k_run_chains) at one level instead of one level per step.
+  // (run_chains) at one level instead of one level per step.
   struct ChainSeg { uint32_t first, n, acc_w, b_w; };
   std::vector<RunOp> chain_ops;             // steps of all chains, chain by chain
   std::vector<ChainSeg> chains;             // sorted by level; within a level the long ones first
@@ -771,32 +771,18 @@ __device__ __forceinline__ void run_p2_segment(const RunArgs& A, RunSchedule::P2
   }
 }
 
-// One WIDE level of the schedule: blocks [0, light_blocks) run one light op per lane, the
-// remaining blocks one Poseidon2 permutation per 16 lanes.
-template <class PP>
-__global__ void __launch_bounds__(kBlock)
-k_run_level(RunArgs A, uint32_t light_begin, uint32_t n_light, uint32_t light_blocks, uint32_t p2_begin, uint32_t n_p2) {
-  if (blockIdx.x < light_blocks) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n_light) run_light_op<PP>(A, A.light[light_begin + i]);
-    return;
-  }
-  const uint32_t g = (blockIdx.x - light_blocks) * kBlock + threadIdx.x;
-  const bool live = (g >> 4) < n_p2;
-  run_p2_segment<PP>(A, live ? A.p2segs[p2_begin + (g >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(g & 15), live);
-}
-
 // Horner chains of one level: one WAVE per chain evaluates acc_j = acc_{j-1}*b + (c_j - a_j) as an
 // affine scan - every lane folds its slice locally, the slice maps (b^len, value) are combined
 // with a shuffle scan across the wave, then every lane replays its slice from its incoming
 // accumulator, writing the outputs and the AluOpRecords (runner.rs:430-453).
-constexpr int kChainBlock = 256;  // four chains per workgroup
+// `block`: index among the chain blocks of the launch, four chains (waves) per block.
 template <class PP>
-__global__ void __launch_bounds__(kChainBlock)
-k_run_chains(RunArgs A, const RunOp* __restrict__ steps, const RunSchedule::ChainSeg* __restrict__ segs, uint32_t n_segs) {
+__device__ __forceinline__ void run_chains(const RunArgs& A, const RunOp* __restrict__ steps,
+                                           const RunSchedule::ChainSeg* __restrict__ segs, uint32_t n_segs,
+                                           uint32_t block) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
-  const uint32_t chain = blockIdx.x * (kChainBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t chain = block * (kBlock / 64) + (threadIdx.x >> 6);
   if (chain >= n_segs) return;  // whole waves leave together
   const RunSchedule::ChainSeg seg = segs[chain];
   const uint32_t t = threadIdx.x & 63;
@@ -837,6 +823,27 @@ k_run_chains(RunArgs A, const RunOp* __restrict__ steps, const RunSchedule::Chai
     dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
     dst[3] = make_uint4(acc.c[0].v, acc.c[1].v, acc.c[2].v, acc.c[3].v);
   }
+}
+
+// One WIDE level of the schedule in one launch, longest-running blocks first: a Poseidon2
+// permutation segment per 16 lanes, then a short Horner chain per wave, then one light op per lane.
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_run_level(RunArgs A, uint32_t p2_begin, uint32_t n_p2, uint32_t p2_blocks, const RunOp* __restrict__ chain_steps,
+            const RunSchedule::ChainSeg* __restrict__ chains, uint32_t n_chains, uint32_t chain_blocks,
+            uint32_t light_begin, uint32_t n_light) {
+  if (blockIdx.x < p2_blocks) {
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = (g >> 4) < n_p2;
+    run_p2_segment<PP>(A, live ? A.p2segs[p2_begin + (g >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(g & 15), live);
+    return;
+  }
+  if (blockIdx.x < p2_blocks + chain_blocks) {
+    run_chains<PP>(A, chain_steps, chains, n_chains, blockIdx.x - p2_blocks);
+    return;
+  }
+  const uint32_t i = (blockIdx.x - p2_blocks - chain_blocks) * kBlock + threadIdx.x;
+  if (i < n_light) run_light_op<PP>(A, A.light[light_begin + i]);
 }
 
 // Long chains: the same scan with a whole workgroup per chain - slices are folded per lane, combined
@@ -1159,17 +1166,16 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
       const uint32_t l = seg.l0;
       const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2seg_off[l + 1] - S.p2seg_off[l];
       const uint32_t lb = (nl + kBlock - 1) / kBlock, pb = (np * 16 + kBlock - 1) / kBlock;
-      if (lb + pb)
-        hipLaunchKernelGGL(k_run_level<PP>, dim3(lb + pb), dim3(kBlock), 0, ctx->stream, A, S.light_off[l], nl, lb,
-                           S.p2seg_off[l], np);
       const uint32_t nc = S.chain_off[l + 1] - S.chain_off[l], n_long = S.chain_long[l];
       const RunOp* steps = reinterpret_cast<const RunOp*>(C->d_chain_ops.p);
       const RunSchedule::ChainSeg* segs = reinterpret_cast<const RunSchedule::ChainSeg*>(C->d_chains.p) + S.chain_off[l];
+      const uint32_t n_short = nc - n_long, cb = (n_short + kBlock / 64 - 1) / (kBlock / 64);
+      // chains only read operands of lower levels, so they share the launch with the level's other ops
+      if (lb + pb + cb)
+        hipLaunchKernelGGL(k_run_level<PP>, dim3(pb + cb + lb), dim3(kBlock), 0, ctx->stream, A, S.p2seg_off[l], np, pb,
+                           steps, segs + n_long, n_short, cb, S.light_off[l], nl);
       if (n_long)
         hipLaunchKernelGGL(k_run_chains_block<PP>, dim3(n_long), dim3(kLongChainBlock), 0, ctx->stream, A, steps, segs);
-      if (nc > n_long)
-        hipLaunchKernelGGL(k_run_chains<PP>, dim3((nc - n_long + 3) / 4), dim3(kChainBlock), 0, ctx->stream, A, steps,
-                           segs + n_long, nc - n_long);
     }
     if (!S.rewrite_pairs.empty())
       hipLaunchKernelGGL(k_run_rewrite<PP>, dim3(blocks_for(S.rewrite_pairs.size() / 3)), dim3(kBlock), 0, ctx->stream,

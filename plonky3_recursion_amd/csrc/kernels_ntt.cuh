@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(kNttBlock, 8) k_ntt_tile(const NttPass* __rest
   const uint32_t R = 1u << log_r, T = 1u << a.log_t;
   const uint32_t N1 = 1u << a.log_n1, N2 = 1u << a.log_n2;
   uint32_t* tile = lds;
-  uint32_t* tws = lds + ((R * (T + 1) + (R >> 5) + 2) & ~1u);  // 8-byte aligned (w, w') pairs
+  uint32_t* tws = lds + ((R * (T + 1) + (R >> 5) + 2) & ~1u);  // twiddle copy, after the padded tile
   NttTileIo<PP> io{a,
                    as_global(a.in) + (size_t)by * a.in_col_stride,
                    as_global(a.out) + (size_t)by * a.out_col_stride + (size_t)bz * a.out_coset_stride,

@@ -51,12 +51,12 @@ struct AuxSink {
   using F = Fp<PP>;
   using E = Fp4<PP>;
   const LookupCh& lc;
-  uint32_t* aux;  // [4*aw][n]
+  gptr<uint32_t> aux;  // [4*aw][n]
   size_t n, row;
   int pair;
   int cnt = 0;
   E cur, total;
-  __device__ AuxSink(const LookupCh& l, uint32_t* a, size_t n_, size_t r, int p)
+  __device__ AuxSink(const LookupCh& l, gptr<uint32_t> a, size_t n_, size_t r, int p)
       : lc(l), aux(a), n(n_), row(r), pair(p), cur(E::zero()), total(E::zero()) {}
   __device__ __forceinline__ void flush() {
     int g = pair ? (cnt - 1) / 2 : cnt - 1;
@@ -75,32 +75,57 @@ struct AuxSink {
   }
 };
 
+// The LogUp pass of every table of a proof is one launch of each kernel below over this job list.
+struct LogupJob {
+  AirParams air;
+  const uint32_t* main;  // trace [w][n]
+  const uint32_t* prep;  // preprocessed trace [w_prep][n]
+  uint32_t* aux;         // [4*aux_w][n]: column 0 = running sum, then the fraction columns
+  uint32_t* rowsum;      // [4][n] scratch: sum of the row's fractions
+  uint32_t* agg;         // [n_tiles][4] scratch of the scan
+  uint32_t* total;       // [4]: the table's global sum
+  uint64_t n;
+  int pair;
+  uint32_t n_tiles;      // scan tiles of kScanTile rows
+  uint32_t block0;       // first block in the row launch (k_logup_aux)
+  uint32_t tile0;        // first block in the tile launches (k_ef_scan modes 0 and 2)
+};
+
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
-k_logup_aux(AirParams air, const uint32_t* __restrict__ main, const uint32_t* __restrict__ prep, size_t n,
-            LookupCh lc, int pair, uint32_t* __restrict__ aux, uint32_t* __restrict__ rowsum /* [4][n] */) {
-  size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
+k_logup_aux(const LogupJob* __restrict__ jobs, int n_jobs, LookupCh lc) {
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const LogupJob& job = jobs[jb];
+  const size_t n = job.n, r = (size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x;
   if (r >= n) return;
-  RowView<PP> v{main, prep, n, r, r + 1 == n ? 0 : r + 1};
-  AuxSink<PP> sink(lc, aux, n, r, pair);
-  air_interactions<PP>(air, v, sink);
+  RowView<PP> v{as_global(job.main), as_global(job.prep), n, r, r + 1 == n ? 0 : r + 1};
+  AuxSink<PP> sink(lc, as_global(job.aux), n, r, job.pair);
+  air_interactions<PP>(job.air, v, sink);
   sink.finish();
+  const gptr<uint32_t> rowsum = as_global(job.rowsum);
 #pragma unroll
   for (int k = 0; k < 4; ++k) rowsum[(size_t)k * n + r] = sink.total.c[k].v;
 }
 
-// Exclusive prefix sum of extension elements (running LogUp sum, aux column 0).
-// mode 0: block totals -> agg; mode 1: exclusive scan of agg (one block), grand total -> total;
-// mode 2: write exclusive prefixes.
+// Exclusive prefix sum of extension elements (running LogUp sum, aux column 0) per job.
+// mode 0: tile totals -> agg; mode 1: exclusive scan of agg (one block per job), grand total ->
+// total; mode 2: write exclusive prefixes.
 template <class PP>
-__global__ void __launch_bounds__(kBlock)
-k_ef_scan(int mode, size_t n, const uint32_t* __restrict__ in /* [4][n] */, uint32_t* __restrict__ agg,
-          size_t n_blocks, uint32_t* __restrict__ out /* [4][n] planes, stride n */,
-          uint32_t* __restrict__ total) {
+__global__ void __launch_bounds__(kBlock) k_ef_scan(int mode, const LogupJob* __restrict__ jobs, int n_jobs) {
   using E = Fp4<PP>;
   using F = Fp<PP>;
   __shared__ uint32_t sh[4][kBlock];
   const int tid = threadIdx.x;
+  int jb = 0;
+  if (mode == 1) jb = blockIdx.x;
+  else
+    while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].tile0) ++jb;
+  const size_t n = jobs[jb].n, n_blocks = jobs[jb].n_tiles;
+  const uint32_t tile = mode == 1 ? 0 : blockIdx.x - jobs[jb].tile0;
+  const gptr<const uint32_t> in = as_global(jobs[jb].rowsum);
+  const gptr<uint32_t> agg = as_global(jobs[jb].agg), out = as_global(jobs[jb].aux),
+                       total = as_global(jobs[jb].total);
   E loc[kScanItems];
   E run = E::zero();
   if (mode == 1) {
@@ -112,7 +137,7 @@ k_ef_scan(int mode, size_t n, const uint32_t* __restrict__ in /* [4][n] */, uint
       run += m;
     }
   } else {
-    size_t base = (size_t)blockIdx.x * kScanTile + (size_t)tid * kScanItems;
+    size_t base = (size_t)tile * kScanTile + (size_t)tid * kScanItems;
 #pragma unroll
     for (int q = 0; q < kScanItems; ++q) {
       size_t i = base + q;
@@ -143,7 +168,7 @@ k_ef_scan(int mode, size_t n, const uint32_t* __restrict__ in /* [4][n] */, uint
     for (int k = 0; k < 4; ++k) excl.c[k] = F::raw(sh[k][tid - 1]);
   if (mode == 0) {
     if (tid == kBlock - 1)
-      for (int k = 0; k < 4; ++k) agg[4 * (size_t)blockIdx.x + k] = sh[k][tid];
+      for (int k = 0; k < 4; ++k) agg[4 * (size_t)tile + k] = sh[k][tid];
   } else if (mode == 1) {
     size_t per = (n_blocks + kBlock - 1) / kBlock;
     size_t lo = (size_t)tid * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
@@ -158,9 +183,9 @@ k_ef_scan(int mode, size_t n, const uint32_t* __restrict__ in /* [4][n] */, uint
       for (int k = 0; k < 4; ++k) total[k] = sh[k][tid];
   } else {
     E p;
-    for (int k = 0; k < 4; ++k) p.c[k] = F::raw(agg[4 * (size_t)blockIdx.x + k]);
+    for (int k = 0; k < 4; ++k) p.c[k] = F::raw(agg[4 * (size_t)tile + k]);
     p += excl;
-    size_t base = (size_t)blockIdx.x * kScanTile + (size_t)tid * kScanItems;
+    size_t base = (size_t)tile * kScanTile + (size_t)tid * kScanItems;
 #pragma unroll
     for (int q = 0; q < kScanItems; ++q) {
       size_t i = base + q;
@@ -271,7 +296,7 @@ __global__ void __launch_bounds__(kBlock) k_quotient(QuotientArgs q) {
   if (j >= qn) return;
   const uint32_t i = bit_reverse((uint32_t)j, lq);        // natural index on the quotient coset
   const uint32_t i_next = (uint32_t)((i + C) & (qn - 1));
-  RowView<PP> v{q.main, q.prep, q.lde_h, j, bit_reverse(i_next, lq)};
+  RowView<PP> v{as_global(q.main), as_global(q.prep), q.lde_h, j, bit_reverse(i_next, lq)};
   const F x = F::raw(q.gen) * F::raw(q.w_q).pow(i);
   const uint32_t c = i & (uint32_t)(C - 1);
   const F zh = F::raw(q.zh[c]), g_inv = F::raw(q.g_inv);

@@ -220,30 +220,47 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   if (any_lookup) {
     DevBuf totals(4 * ni);
     P3R_HIP(hipMemsetAsync(totals.p, 0, 16 * ni, ctx->stream));
+    // aux traces of all tables: fractions per row, then the running sum as a three-phase scan
+    std::vector<LogupJob> jobs;
+    std::vector<DevBuf> scratch;
+    uint32_t row_blocks = 0, tiles = 0;
     for (size_t i = 0; i < ni; ++i) {
       const auto& L = layouts[i];
       if (!L.n_groups) continue;
       const size_t n = mains[i]->h;
       aux[i] = dmat_alloc(n, (size_t)L.aux_width() * 4);
-      DevBuf rowsum(4 * n);
-      uint32_t* total = totals.p + 4 * i;
-      const size_t n_blocks = (n + kScanTile - 1) / kScanTile;
-      DevBuf agg(4 * n_blocks);
-      // the preprocessed TRACE is not retained; its first n*... rows are not the trace either,
-      // so K7 reads the trace-domain preprocessed columns from the caller-provided copy.
-      {
-        ProfScope ps(ctx, "logup_aux");
-        hipLaunchKernelGGL(k_logup_aux<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, prep->airs[i],
-                           mains[i]->d, prep->traces[i]->d, n, lc, L.pair, aux[i]->d, rowsum.p);
-        hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, 0, n, rowsum.p,
-                           agg.p, n_blocks, aux[i]->d, total);
-        hipLaunchKernelGGL(k_ef_scan<PP>, dim3(1), dim3(kBlock), 0, ctx->stream, 1, n, rowsum.p, agg.p, n_blocks,
-                           aux[i]->d, total);
-        hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, 2, n, rowsum.p,
-                           agg.p, n_blocks, aux[i]->d, total);
-      }
-      P3R_HIP(hipGetLastError());
+      LogupJob j{};
+      j.air = prep->airs[i];
+      j.main = mains[i]->d;
+      // the preprocessed TRACE (not the LDE): kept from preparation for this pass and the openings
+      j.prep = prep->traces[i]->d;
+      j.aux = aux[i]->d;
+      j.n = n;
+      j.pair = L.pair;
+      j.n_tiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
+      scratch.emplace_back(4 * n);
+      j.rowsum = scratch.back().p;
+      scratch.emplace_back(4 * (size_t)j.n_tiles);
+      j.agg = scratch.back().p;
+      j.total = totals.p + 4 * i;
+      j.block0 = row_blocks;
+      j.tile0 = tiles;
+      row_blocks += blocks_for(n);
+      tiles += j.n_tiles;
+      jobs.push_back(j);
       perm_insts.push_back((int)i);
+    }
+    {
+      scratch.emplace_back((jobs.size() * sizeof(LogupJob) + 3) / 4);
+      const auto* d_jobs = reinterpret_cast<const LogupJob*>(scratch.back().p);
+      P3R_HIP(ctx->stage.upload(ctx->stream, scratch.back().p, jobs.data(), jobs.size() * sizeof(LogupJob)));
+      const int nj = (int)jobs.size();
+      ProfScope ps(ctx, "logup_aux");
+      hipLaunchKernelGGL(k_logup_aux<PP>, dim3(row_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, nj, lc);
+      hipLaunchKernelGGL(k_ef_scan<PP>, dim3(tiles), dim3(kBlock), 0, ctx->stream, 0, d_jobs, nj);
+      hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)nj), dim3(kBlock), 0, ctx->stream, 1, d_jobs, nj);
+      hipLaunchKernelGGL(k_ef_scan<PP>, dim3(tiles), dim3(kBlock), 0, ctx->stream, 2, d_jobs, nj);
+      P3R_HIP(hipGetLastError());
     }
     lde_items.clear();
     for (int i : perm_insts) lde_items.push_back({aux[i].get(), PP::GEN});
