@@ -265,6 +265,7 @@ struct RunP2 {  // one Poseidon2 permutation, sixteen lanes
 enum : uint32_t { RUN_ERR_CONFLICT = 1, RUN_ERR_DIV0 = 2, RUN_ERR_MMCS_BIT = 3, RUN_ERR_INDEX_SUM = 4 };
 
 struct RunSchedule {
+  uint32_t n_alu_records = 0;  // AluOpRecords the run writes (0: the ALU table holds its dummy op only)
   std::vector<RunOp> light;
   // Poseidon2 permutations: a run of rows chained through the sponge / Merkle state whose witness
   // inputs are all ready when the run starts is ONE segment, executed row after row by one 16-lane
@@ -555,6 +556,7 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
     S.chunk_bounds.push_back(seg.l1);
     seg.n_chunks++;
   }
+  S.n_alu_records = n_alu;
   return S;
 }
 
@@ -1126,7 +1128,8 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     P3R_HIP(hipMemcpyAsync(T->const_values.p, C->d_const_values.p, cn.n_const * 16, hipMemcpyDeviceToDevice, ctx->stream));
   T->public_values.alloc(std::max<size_t>(cn.n_public * 4, 1));
   T->alu_values.alloc(std::max<size_t>(cn.n_alu * 16, 1));
-  P3R_HIP(hipMemsetAsync(T->alu_values.p, 0, T->alu_values.n * 4, ctx->stream));  // the dummy op of an empty table
+  if (S.n_alu_records == 0)  // the dummy op of an empty table; otherwise every record is written by its op
+    P3R_HIP(hipMemsetAsync(T->alu_values.p, 0, T->alu_values.n * 4, ctx->stream));
   T->recompose_values.alloc(std::max<size_t>(cn.n_recompose * 4, 1));
   uint32_t* p2_inputs = nullptr; uint8_t* p2_flags = nullptr; uint32_t* p2_seed = nullptr;
   size_t p2_h = 0;
