@@ -24,6 +24,9 @@ int guard(p3r_ctx* ctx, Fn&& fn) {
     if (ctx) {
       (void)hipSetDevice(ctx->cfg.device);
       tls_pool() = ctx->pool;
+      // the table cache is only trimmed here, between API calls: a call keeps device pointers into
+      // it while it assembles its launches (e.g. column tables referenced from a job list)
+      if (ctx->const_tables.size() > 4096) ctx->const_tables.clear();
     }
     fn();
     return P3R_OK;
@@ -236,7 +239,6 @@ inline const void* const_table(p3r_ctx* ctx, const void* data, size_t bytes) {
   std::string key(static_cast<const char*>(data), bytes);
   auto it = ctx->const_tables.find(key);
   if (it == ctx->const_tables.end()) {
-    if (ctx->const_tables.size() >= 1024) ctx->const_tables.clear();  // shapes changed: start over
     DevBuf b((bytes + 3) / 4);
     P3R_HIP(ctx->stage.upload(ctx->stream, b.p, data, bytes));
     it = ctx->const_tables.emplace(std::move(key), std::move(b)).first;

@@ -399,6 +399,39 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       else o_perm[perm_insts[it.mat]] = it.vals;
     }
   }
+  // 1/(zeta - x) vectors of the reduced openings depend on the opening points only: the device
+  // computes them while the host absorbs the opened values into the transcript
+  std::map<std::array<uint64_t, 3>, uint32_t*> inv_cache;  // (log_height, z) -> 1/(z - x_r)
+  std::vector<DevBuf> inv_keep;
+  {
+    std::vector<FriInvJob> inv_jobs;
+    uint32_t inv_blocks = 0;
+    for (auto& it : items) {
+      const int lh = it.log_h + log_blowup;
+      for (size_t p = 0; p < it.z.size(); ++p) {
+        std::array<uint64_t, 3> key{(uint64_t)lh, ((uint64_t)it.z[p].c[0].v << 32) | it.z[p].c[1].v,
+                                    ((uint64_t)it.z[p].c[2].v << 32) | it.z[p].c[3].v};
+        if (inv_cache.count(key)) continue;
+        inv_keep.emplace_back((size_t)4 << lh);
+        FriInvJob j{};
+        j.inv = inv_keep.back().p;
+        j.h = uint64_t(1) << lh;
+        j.log_h = lh;
+        j.w_h = F::two_adic_generator(lh).v;
+        j.z = to_e4<PP>(it.z[p]);
+        j.block0 = inv_blocks;
+        inv_blocks += blocks_for(size_t(1) << lh);
+        inv_jobs.push_back(j);
+        inv_cache.emplace(key, j.inv);
+      }
+    }
+    inv_keep.emplace_back((inv_jobs.size() * sizeof(FriInvJob) + 3) / 4);
+    P3R_HIP(ctx->stage.upload(ctx->stream, inv_keep.back().p, inv_jobs.data(), inv_jobs.size() * sizeof(FriInvJob)));
+    ProfScope ps(ctx, "fri_inv_points");
+    hipLaunchKernelGGL(k_fri_inv_points<PP>, dim3(inv_blocks), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<const FriInvJob*>(inv_keep.back().p), (int)inv_jobs.size(), gen.v);
+    P3R_HIP(hipGetLastError());
+  }
   for (auto& it : items)
     for (auto& pv : it.vals)
       for (auto& v : pv) ch.observe_ext(v);
@@ -423,10 +456,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::map<int, std::pair<E, DevBuf>> ros;  // log_height -> (alpha power, ro planes [4][h])
   {
     std::map<int, std::vector<FriReduceMat>> by_height;
-    std::map<std::array<uint64_t, 3>, uint32_t*> inv_cache;  // (log_height, z) -> 1/(z - x_r)
-    std::vector<FriInvJob> inv_jobs;
     std::vector<DevBuf> keep;
-    uint32_t inv_blocks = 0;
     for (auto& it : items) {
       const int lh = it.log_h + log_blowup;
       auto f = ros.find(lh);
@@ -441,21 +471,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         for (size_t c = 0; c < it.vals[p].size(); ++c) V += fa_pow[c] * it.vals[p][c];
         std::array<uint64_t, 3> key{(uint64_t)lh, ((uint64_t)it.z[p].c[0].v << 32) | it.z[p].c[1].v,
                                     ((uint64_t)it.z[p].c[2].v << 32) | it.z[p].c[3].v};
-        auto iv = inv_cache.find(key);
-        if (iv == inv_cache.end()) {
-          keep.emplace_back((size_t)4 << lh);
-          FriInvJob j{};
-          j.inv = keep.back().p;
-          j.h = uint64_t(1) << lh;
-          j.log_h = lh;
-          j.w_h = F::two_adic_generator(lh).v;
-          j.z = to_e4<PP>(it.z[p]);
-          j.block0 = inv_blocks;
-          inv_blocks += blocks_for(size_t(1) << lh);
-          inv_jobs.push_back(j);
-          iv = inv_cache.emplace(key, j.inv).first;
-        }
-        a.inv[p] = iv->second;
+        a.inv[p] = inv_cache.at(key);
         a.v[p] = to_e4<PP>(V);
         a.off[p] = to_e4<PP>(ap);
         ap *= fa_pow[it.lde->w];
@@ -482,14 +498,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       P3R_HIP(ctx->stage.upload(ctx->stream, keep.back().p, src, bytes));
       return keep.back().p;
     };
-    const auto* d_inv = reinterpret_cast<const FriInvJob*>(upload(inv_jobs.data(), inv_jobs.size() * sizeof(FriInvJob)));
     const auto* d_mats = reinterpret_cast<const FriReduceMat*>(upload(mats.data(), mats.size() * sizeof(FriReduceMat)));
     const auto* d_jobs = reinterpret_cast<const FriReduceJob*>(upload(jobs.data(), jobs.size() * sizeof(FriReduceJob)));
-    {
-      ProfScope ps(ctx, "fri_inv_points");
-      hipLaunchKernelGGL(k_fri_inv_points<PP>, dim3(inv_blocks), dim3(kBlock), 0, ctx->stream, d_inv,
-                         (int)inv_jobs.size(), gen.v);
-    }
     {
       ProfScope ps(ctx, "fri_reduce");
       hipLaunchKernelGGL(k_fri_reduce_pre<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(),
