@@ -107,7 +107,7 @@ inline hipError_t copy_sync(hipStream_t s, void* dst, const void* src, size_t by
 // transfer is enqueued on the ctx stream and the caller moves on.  A region is handed out again
 // only after the ring wraps, and wrapping waits for the stream first.
 struct HostStage {
-  static constexpr size_t kBytes = size_t(1) << 20;
+  static constexpr size_t kBytes = size_t(4) << 20;  // the largest client is the query gather list (~0.4 MB)
   char* base = nullptr;
   size_t off = 0;
   HostStage() = default;

@@ -617,6 +617,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<size_t> indices(cfg.num_queries);
   for (auto& ix : indices) ix = ch.sample_bits(log_max);
   std::vector<GatherDesc> descs;
+  descs.reserve(indices.size() * 512);
   uint32_t cursor = 0;
   auto push = [&](const uint32_t* src, uint64_t stride, uint32_t count) {
     descs.push_back({src, stride, count, cursor});
