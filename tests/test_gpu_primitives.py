@@ -152,6 +152,28 @@ def test_mmcs_vs_oracle(oracle, cap_height, ctx):
     c.close()
 
 
+@pytest.mark.parametrize("cap_height", [0, 1])
+def test_mmcs_tall_mixed_heights(oracle, cap_height, ctx):
+    """A tree tall enough for every layer regime: one permutation per lane above 32 K nodes (with an
+    injection there), several workgroups of the 8-levels-per-launch kernel (injection inside), and
+    the single-workgroup tail (injection inside, cap above the root)."""
+    import plonky3_recursion_amd as p3r
+    c = p3r.Context(field=ctx.field, cap_height=cap_height)
+    rng = np.random.default_rng(35)
+    shapes = [(1 << 17, 3), (1 << 16, 9), (1 << 12, 2), (1 << 17, 6), (32, 5), (1 << 12, 8)]
+    mats = [rand(rng, ctx.field, s) for s in shapes]
+    cap, tree = c.commit(mats)
+    ocap, otree = oracle.commit(ctx.field, mats, cap_height)
+    assert np.array_equal(cap, ocap)
+    for index in (0, 1, 4097, 77777, (1 << 17) - 1):
+        opened, proof = tree.open_batch(index)
+        oo, op = otree.open(index)
+        assert np.array_equal(opened, oo) and np.array_equal(proof, op)
+        assert oracle.verify(ctx.field, cap, shapes, index, opened, proof)
+    tree.free()
+    c.close()
+
+
 def test_mmcs_golden_sponge(ctx, golden):
     g = golden["prim"][key_of(ctx)]
     for kat in g["sponge"]:
