@@ -35,12 +35,55 @@ k_fri_inv_points(const FriInvJob* __restrict__ jobs, int n_jobs, uint32_t gen) {
   for (int k = 0; k < 4; ++k) inv[(size_t)k * h + r] = v.c[k].v;
 }
 
+// V = sum_c alpha^c * value_c over the opened values of one (matrix, point): one workgroup per
+// job, straight from the device copy of the opened values (the host never forms these sums).
+struct FriVsumJob {
+  const uint32_t* vals;  // [w][4]
+  uint32_t* out;         // [4]
+  int w;
+};
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_fri_vsum(const FriVsumJob* __restrict__ jobs, const uint32_t* __restrict__ apow_tab /* alpha^c, 4 words each */) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  __shared__ uint32_t sh[kBlock / 64][4];
+  const FriVsumJob job = jobs[blockIdx.x];
+  const gptr<const uint32_t> vals = as_global(job.vals);
+  E acc = E::zero();
+  for (int c = threadIdx.x; c < job.w; c += kBlock) {
+    E ap, v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ap.c[k] = F::raw(apow_tab[4 * c + k]);
+      v.c[k] = F::raw(vals[4 * c + k]);
+    }
+    acc += ap * v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    F x = acc.c[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += F::raw(__shfl_down(x.v, off));
+    if (lane == 0) sh[wave][k] = x.v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    F x = F::zero();
+#pragma unroll
+    for (int wv = 0; wv < kBlock / 64; ++wv) x += F::raw(sh[wv][threadIdx.x]);
+    as_global(job.out)[threadIdx.x] = x.v;
+  }
+}
+
 // One committed matrix and its opening points.
 struct FriReduceMat {
   const uint32_t* mat;  // bit-reversed LDE [w][h]
   int w, n_points;
   const uint32_t* inv[2];  // [4][h] each
-  E4 v[2], off[2];
+  const uint32_t* v[2];    // [4]: the k_fri_vsum result of this matrix and point
+  E4 off[2];
 };
 // All matrices of one height: lane r owns ro[r] and adds every matrix's term to it, so ro is
 // written once and needs no zero fill.
@@ -81,7 +124,10 @@ k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriRed
       E inv;
 #pragma unroll
       for (int k = 0; k < 4; ++k) inv.c[k] = F::raw(as_global(a.inv[p])[(size_t)k * h + r]);
-      acc += e4_load<PP>(a.off[p]) * (e4_load<PP>(a.v[p]) - S) * inv;
+      E V;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) V.c[k] = F::raw(as_global(a.v[p])[k]);
+      acc += e4_load<PP>(a.off[p]) * (V - S) * inv;
     }
   }
 #pragma unroll

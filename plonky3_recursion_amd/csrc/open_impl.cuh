@@ -17,6 +17,7 @@ struct Opener {
   std::vector<OpenJob> dot_jobs;
   std::vector<BaryJob> bary_jobs;
   std::vector<DevBuf> keep;  // weights and partial sums, alive until finish()
+  DevBuf out;                // the opened values on the device: [job][point][col][4]
   std::map<std::array<uint64_t, 3>, const uint32_t*> wcache;
   uint32_t bary_blocks = 0, dot_blocks = 0;
 
@@ -80,11 +81,16 @@ struct Opener {
     return reinterpret_cast<const T*>(keep.back().p);
   }
 
+  // device address of the opened values of one job and point ([w][4]), valid after finish()
+  const uint32_t* values_dev(size_t job, int point) const {
+    return out.p + (jobs[job].off + (size_t)point * jobs[job].w) * 4;
+  }
+
   // values[job][point][col]
   std::vector<std::vector<std::vector<E>>> finish() {
     std::vector<uint32_t> raw(used * 4);
     if (jobs.empty()) return {};
-    DevBuf out(used * 4);
+    out.alloc(used * 4);
     {
       const BaryJob* d_bary = upload_jobs(bary_jobs);
       const OpenJob* d_jobs = upload_jobs(dot_jobs);
@@ -100,6 +106,7 @@ struct Opener {
       P3R_HIP(hipGetLastError());
     }
     P3R_HIP(copy_sync(ctx->stream, raw.data(), out.p, raw.size() * 4, hipMemcpyDeviceToHost));
+    keep.clear();  // `out` stays for the reduced openings (values_dev)
     std::vector<std::vector<std::vector<E>>> res(jobs.size());
     for (size_t j = 0; j < jobs.size(); ++j) {
       res[j].resize(jobs[j].P);

@@ -365,8 +365,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<Item> items;
   std::vector<std::vector<std::vector<E>>> o_main(ni), o_prep(ni), o_perm(ni);
   std::vector<std::vector<E>> o_chunks(chunks.size());
+  Opener<PP> op(ctx);  // keeps the opened values on the device for the reduced openings
   {
-    Opener<PP> op(ctx);
     for (size_t i = 0; i < ni; ++i) {
       std::vector<E> pts{zeta};
       if (air_uses_next(prep->airs[i])) pts.push_back(zeta * F::two_adic_generator(log_n[i]));
@@ -457,6 +457,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   {
     std::map<int, std::vector<FriReduceMat>> by_height;
     std::vector<DevBuf> keep;
+    std::vector<FriVsumJob> vsum_jobs;
+    DevBuf vsums(8 * items.size());
     for (auto& it : items) {
       const int lh = it.log_h + log_blowup;
       auto f = ros.find(lh);
@@ -467,12 +469,12 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       a.n_points = (int)it.z.size();
       E ap = f->second.first;
       for (size_t p = 0; p < it.z.size(); ++p) {
-        E V = E::zero();
-        for (size_t c = 0; c < it.vals[p].size(); ++c) V += fa_pow[c] * it.vals[p][c];
         std::array<uint64_t, 3> key{(uint64_t)lh, ((uint64_t)it.z[p].c[0].v << 32) | it.z[p].c[1].v,
                                     ((uint64_t)it.z[p].c[2].v << 32) | it.z[p].c[3].v};
         a.inv[p] = inv_cache.at(key);
-        a.v[p] = to_e4<PP>(V);
+        // V = sum_c alpha^c * opened value c, formed on the device (k_fri_vsum)
+        a.v[p] = vsums.p + 4 * vsum_jobs.size();
+        vsum_jobs.push_back({op.values_dev(it.job, (int)p), vsums.p + 4 * vsum_jobs.size(), (int)it.vals[p].size()});
         a.off[p] = to_e4<PP>(ap);
         ap *= fa_pow[it.lde->w];
       }
@@ -500,8 +502,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     };
     const auto* d_mats = reinterpret_cast<const FriReduceMat*>(upload(mats.data(), mats.size() * sizeof(FriReduceMat)));
     const auto* d_jobs = reinterpret_cast<const FriReduceJob*>(upload(jobs.data(), jobs.size() * sizeof(FriReduceJob)));
+    const auto* d_vsum = reinterpret_cast<const FriVsumJob*>(upload(vsum_jobs.data(), vsum_jobs.size() * sizeof(FriVsumJob)));
     {
       ProfScope ps(ctx, "fri_reduce");
+      hipLaunchKernelGGL(k_fri_vsum<PP>, dim3((unsigned)vsum_jobs.size()), dim3(kBlock), 0, ctx->stream, d_vsum,
+                         d_fapow.p);
       hipLaunchKernelGGL(k_fri_reduce_pre<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(),
                          d_mats, d_fapow.p);
     }
@@ -587,17 +592,25 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     std::vector<uint32_t> raw(4 * m);
     P3R_HIP(hipMemcpyAsync(raw.data(), folded.p, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     P3R_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<E> nat(m);
-    for (size_t i = 0; i < m; ++i)
-      for (int k = 0; k < 4; ++k) nat[bit_reverse((uint32_t)i, log_cur)].c[k] = F::raw(raw[(size_t)k * m + i]);
-    const F w_inv = F::two_adic_generator(log_cur).inv(), m_inv = F::from_u64(m).inv();
+    // inverse DFT, decimation in time: the rows are already in bit-reversed order, the
+    // coefficients come out in natural order
     std::vector<E> coeffs(m);
-    for (size_t kk = 0; kk < m; ++kk) {
-      E acc = E::zero();
-      F wk = w_inv.pow(kk), x = F::one();
-      for (size_t nn = 0; nn < m; ++nn) { acc += nat[nn] * x; x *= wk; }
-      coeffs[kk] = acc * m_inv;
+    for (size_t i = 0; i < m; ++i)
+      for (int k = 0; k < 4; ++k) coeffs[i].c[k] = F::raw(raw[(size_t)k * m + i]);
+    const F w_inv = F::two_adic_generator(log_cur).inv(), m_inv = F::from_u64(m).inv();
+    for (size_t len = 2; len <= m; len <<= 1) {
+      const F w_len = w_inv.pow(m / len);
+      for (size_t i = 0; i < m; i += len) {
+        F x = F::one();
+        for (size_t j = 0; j < len / 2; ++j) {
+          const E u = coeffs[i + j], v = coeffs[i + j + len / 2] * x;
+          coeffs[i + j] = u + v;
+          coeffs[i + j + len / 2] = u - v;
+          x *= w_len;
+        }
+      }
     }
+    for (auto& c : coeffs) c = c * m_inv;
     const size_t flen = size_t(1) << cfg.log_final_poly_len;
     for (size_t i = flen; i < m; ++i)
       if (!coeffs[i].is_zero())
