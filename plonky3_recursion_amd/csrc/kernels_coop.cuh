@@ -131,4 +131,26 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
   }
 }
 
+// One step of the FRI commit-phase transcript on the device (DuplexChallenger<F, Perm, 16, 8>,
+// recursion/src/challenger/circuit.rs:97-156,337-386) for cap_height 0 and no commit-phase proof
+// of work: observe the 8 words of the phase's Merkle root (a full rate block: overwrite
+// state[0..8], state[8] += 8, permute), then sample the folding challenge (an extension element
+// pops state[7], [6], [5], [4]).  Keeps the commit phase free of host round trips; the host
+// replays the same steps on its own transcript afterwards from `cap_out`.
+template <class PP>
+__global__ void __launch_bounds__(64)
+k_fri_transcript_step(const uint32_t* __restrict__ root /* [8] */, uint32_t* __restrict__ state /* [16] */,
+                      uint32_t* __restrict__ beta_out /* [4] */, uint32_t* __restrict__ cap_out /* [8] */,
+                      const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+  using F = Fp<PP>;
+  const int j = threadIdx.x;
+  if (j >= P2_WIDTH) return;  // one 16-lane row
+  F s = j < P2_RATE ? F::raw(root[j]) : F::raw(state[j]);
+  if (j < P2_RATE) cap_out[j] = s.v;
+  if (j == P2_RATE) s += F::from_canonical(P2_RATE);
+  s = coop_permute<PP>(s, j, F::raw(diag[j]), rc);
+  state[j] = s.v;
+  if (j >= 4 && j < P2_RATE) beta_out[7 - j] = s.v;
+}
+
 }  // namespace p3r

@@ -466,7 +466,8 @@ struct FriFoldArgs {
   uint32_t* out;        // [4][rows]
   size_t rows;
   int la, log_rows;
-  E4 beta, beta_pow;    // beta and beta^{2^la}
+  const uint32_t* beta; // the phase's folding challenge, 4 words on the device (written by the
+                        // device-side transcript step, or uploaded by the host)
   const uint32_t* roll; // nullable [4][rows]
   uint32_t w_inv;       // inverse generator of the domain of size rows << la
   uint32_t tw_inv[3][4];  // tw_inv[s][j] = (w_arity^{2^s})^{-bitrev(2j, la - s)}
@@ -485,7 +486,9 @@ __global__ void __launch_bounds__(kBlock) k_fri_fold(FriFoldArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) e[j].c[k] = F::raw(a.in[(size_t)k * n_in + (r << a.la) + j]);
   F ss_inv = F::raw(a.w_inv).pow(bit_reverse((uint32_t)r, a.log_rows));
-  E b = e4_load<PP>(a.beta);
+  E b;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b.c[k] = F::raw(a.beta[k]);
   const F nh = F::raw(a.neg_half);
   int len = arity;
   for (int s = 0; s < a.la; ++s) {
@@ -504,7 +507,7 @@ __global__ void __launch_bounds__(kBlock) k_fri_fold(FriFoldArgs a) {
     E ro;
 #pragma unroll
     for (int k = 0; k < 4; ++k) ro.c[k] = F::raw(a.roll[(size_t)k * a.rows + r]);
-    res += e4_load<PP>(a.beta_pow) * ro;
+    res += b * ro;  // b is beta^(2^la) after the la squarings above
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) a.out[(size_t)k * a.rows + r] = res.c[k].v;

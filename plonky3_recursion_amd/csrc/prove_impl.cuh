@@ -526,6 +526,17 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   size_t next_h = 1;
   int log_cur = log_max;
   std::vector<F> commit_pow_witnesses;
+  // The folding challenges stay on the device.  With a one-digest cap and no commit-phase proof of
+  // work the transcript steps between the phases run there too (k_fri_transcript_step), so the whole
+  // commit phase is enqueued without a host round trip; the host replays them afterwards.
+  const bool device_transcript = cfg.cap_height == 0 && cfg.commit_pow_bits == 0 && ch.in_buf.empty();
+  constexpr size_t kMaxPhases = 32;
+  DevBuf d_tstate(P2_WIDTH), d_betas(4 * kMaxPhases), d_caps(P2_DIGEST * kMaxPhases);
+  if (device_transcript) {
+    uint32_t st[P2_WIDTH];
+    for (int k = 0; k < P2_WIDTH; ++k) st[k] = ch.state[k].v;
+    P3R_HIP(ctx->stage.upload(ctx->stream, d_tstate.p, st, sizeof st));
+  }
   while (log_cur > log_final) {
     int log_next = next_h < heights.size() ? heights[next_h] : -1;
     int la = std::min((int)cfg.max_log_arity, log_cur - log_final);
@@ -554,15 +565,24 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       P3R_HIP(hipGetLastError());
     }
     build_plain_layers<PP>(ctx, ph.tree.get(), rows);
-    ph.cap = download_cap_mont<PP>(ctx, ph.tree.get());
-    for (uint32_t v : ph.cap) ch.observe(F::raw(v));
-    commit_pow_witnesses.push_back(grind_witness<PP>(ctx, ch, (int)cfg.commit_pow_bits));
-    const E beta = ch.sample_ext();
+    const size_t pi = phases.size();
+    if (pi >= kMaxPhases) fail(P3R_EUNSUPPORTED, "more than %zu FRI commit phases", kMaxPhases);
+    if (device_transcript) {
+      hipLaunchKernelGGL(k_fri_transcript_step<PP>, dim3(1), dim3(64), 0, ctx->stream, ph.tree->layers.back().p,
+                         d_tstate.p, d_betas.p + 4 * pi, d_caps.p + P2_DIGEST * pi, ctx->rc.p, ctx->p2_diag.p);
+    } else {
+      ph.cap = download_cap_mont<PP>(ctx, ph.tree.get());
+      for (uint32_t v : ph.cap) ch.observe(F::raw(v));
+      commit_pow_witnesses.push_back(grind_witness<PP>(ctx, ch, (int)cfg.commit_pow_bits));
+      const E beta = ch.sample_ext();
+      uint32_t bw[4];
+      for (int k = 0; k < 4; ++k) bw[k] = beta.c[k].v;
+      P3R_HIP(ctx->stage.upload(ctx->stream, d_betas.p + 4 * pi, bw, sizeof bw));
+    }
     DevBuf out(4 * rows);
     FriFoldArgs fa{};
     fa.in = folded.p; fa.out = out.p; fa.rows = rows; fa.la = la; fa.log_rows = log_cur - la;
-    fa.beta = to_e4<PP>(beta);
-    fa.beta_pow = to_e4<PP>(beta.pow(arity));
+    fa.beta = d_betas.p + 4 * pi;
     const bool roll = next_h < heights.size() && heights[next_h] == log_cur - la;
     fa.roll = roll ? ros[heights[next_h]].second.p : nullptr;
     fa.w_inv = F::two_adic_generator(log_cur).inv().v;
@@ -589,9 +609,24 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<E> final_poly;
   {
     const size_t m = size_t(1) << log_cur;
-    std::vector<uint32_t> raw(4 * m);
+    std::vector<uint32_t> raw(4 * m), caps(P2_DIGEST * phases.size()), betas(4 * phases.size());
     P3R_HIP(hipMemcpyAsync(raw.data(), folded.p, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (device_transcript && !phases.empty()) {
+      P3R_HIP(hipMemcpyAsync(caps.data(), d_caps.p, caps.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+      P3R_HIP(hipMemcpyAsync(betas.data(), d_betas.p, betas.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     P3R_HIP(hipStreamSynchronize(ctx->stream));
+    if (device_transcript) {
+      // replay the commit phase on the host transcript; the challenges must be the device's
+      for (size_t pi = 0; pi < phases.size(); ++pi) {
+        phases[pi].cap.assign(caps.begin() + P2_DIGEST * pi, caps.begin() + P2_DIGEST * (pi + 1));
+        for (uint32_t v : phases[pi].cap) ch.observe(F::raw(v));
+        commit_pow_witnesses.push_back(grind_witness<PP>(ctx, ch, 0));
+        const E beta = ch.sample_ext();
+        for (int k = 0; k < 4; ++k)
+          if (beta.c[k].v != betas[4 * pi + k]) fail(P3R_EHIP, "internal: device and host FRI transcripts disagree");
+      }
+    }
     // inverse DFT, decimation in time: the rows are already in bit-reversed order, the
     // coefficients come out in natural order
     std::vector<E> coeffs(m);
