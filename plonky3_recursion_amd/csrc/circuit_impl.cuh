@@ -1100,9 +1100,22 @@ std::unique_ptr<p3r_dinputs> circuit_inputs_upload(p3r_ctx* ctx, const p3r_circu
   return D;
 }
 
+// Decodes the error word of a run (first failing op in circuit order, or all ones).
+inline void run_raise_error(uint32_t e) {
+  if (e != 0xFFFFFFFFu) {
+    const uint32_t idx = e >> 3;
+    if (idx == 0x1FFFFFFFu) fail(P3R_EINVAL, "WitnessConflict while applying witness_rewrite");
+    fail(P3R_EINVAL, "%s at op %u", run_error_text(e & 7), idx);
+  }
+}
+
 // CircuitRunner::run: returns the Traces (HBM-resident) of one execution.
+// `deferred_err`: when given, the run is only enqueued; its error word travels to that pinned host
+// word behind it on the stream, and the caller passes it to run_raise_error after its next
+// synchronisation, before trusting anything derived from the traces.
 template <class PP>
-std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, const p3r_dinputs* in) {
+std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, const p3r_dinputs* in,
+                                         uint32_t* deferred_err = nullptr) {
   const HostCircuit& h = C->host;
   const RunSchedule& S = C->sched;
   const p3r_layer* L = C->layer.get();
@@ -1188,12 +1201,12 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
                          C->d_public_out.p, cn.n_public, w.p, T->public_values.p);
     P3R_HIP(hipGetLastError());
   }
-  uint32_t e = 0;
-  P3R_HIP(copy_sync(ctx->stream, &e, err.p, 4, hipMemcpyDeviceToHost));
-  if (e != 0xFFFFFFFFu) {
-    const uint32_t idx = e >> 3;
-    if (idx == 0x1FFFFFFFu) fail(P3R_EINVAL, "WitnessConflict while applying witness_rewrite");
-    fail(P3R_EINVAL, "%s at op %u", run_error_text(e & 7), idx);
+  if (deferred_err) {
+    P3R_HIP(hipMemcpyAsync(deferred_err, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    uint32_t e = 0;
+    P3R_HIP(copy_sync(ctx->stream, &e, err.p, 4, hipMemcpyDeviceToHost));
+    run_raise_error(e);
   }
   return T;
 }

@@ -116,18 +116,31 @@ struct HostStage {
   ~HostStage() {
     if (base) (void)hipHostFree(base);
   }
+  static constexpr size_t kWordBytes = 64;  // head of the ring: words() below, never reused by uploads
+  hipError_t ensure() {
+    if (base) return hipSuccess;
+    off = kWordBytes;
+    return hipHostMalloc(reinterpret_cast<void**>(&base), kBytes, hipHostMallocDefault);
+  }
+  // A few pinned words for small device->host results that are fetched asynchronously and read
+  // after a later synchronisation of the stream (the circuit run's error word).
+  hipError_t words(uint32_t** out) {
+    hipError_t e = ensure();
+    *out = reinterpret_cast<uint32_t*>(base);
+    return e;
+  }
   hipError_t upload(hipStream_t s, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return hipSuccess;
     if (bytes > kBytes / 4) return copy_sync(s, dst, src, bytes, hipMemcpyHostToDevice);
-    if (!base) {
-      hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&base), kBytes, hipHostMallocDefault);
+    {
+      hipError_t e = ensure();
       if (e != hipSuccess) return e;
     }
     const size_t need = (bytes + 63) & ~size_t(63);
     if (off + need > kBytes) {
       hipError_t e = hipStreamSynchronize(s);
       if (e != hipSuccess) return e;
-      off = 0;
+      off = kWordBytes;
     }
     std::memcpy(base + off, src, bytes);
     hipError_t e = hipMemcpyAsync(dst, base + off, bytes, hipMemcpyHostToDevice, s);

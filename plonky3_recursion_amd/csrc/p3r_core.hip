@@ -1095,9 +1095,23 @@ p3r_dtraces* p3r_circuit_run(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r
 }
 static void prove_next_layer_impl(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_dinputs* d, uint32_t flags,
                                   uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {
-  auto t = P3R_FIELD_CALL(ctx, circuit_run, ctx, circuit, d);
-  auto bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, circuit->layer.get(), t.get(),
-                              (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
+  // The run is enqueued, not awaited: proving starts behind it on the stream, and the run's error
+  // word lands in a pinned host word that is read once the proof is done.  (A failed run leaves
+  // garbage VALUES in the traces, never a bad address, so proving over them is harmless; its error
+  // takes precedence over whatever the prover made of the garbage.)
+  uint32_t* run_err = nullptr;
+  P3R_HIP(ctx->stage.words(&run_err));
+  *run_err = 0xFFFFFFFFu;
+  auto t = P3R_FIELD_CALL(ctx, circuit_run, ctx, circuit, d, run_err);
+  std::vector<uint8_t> bytes;
+  try {
+    bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, circuit->layer.get(), t.get(),
+                           (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
+  } catch (...) {
+    if (hipStreamSynchronize(ctx->stream) == hipSuccess) run_raise_error(*run_err);
+    throw;
+  }
+  run_raise_error(*run_err);  // prove_all_tables returns with the stream drained
   emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
 }
 int p3r_prove_next_layer(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs,

@@ -94,6 +94,11 @@ def test_runner_surface_and_errors(oracle):
     bad.public_values[pos, 0] = (int(bad.public_values[pos, 0]) + 1) % P
     with pytest.raises(p3r.P3rError, match="WitnessConflict"):
         pc.run(bad)
+    # the same through prove_next_layer, where the run is not awaited before proving starts: the
+    # run's error is what the caller sees, and the prover is usable afterwards
+    with pytest.raises(p3r.P3rError, match="WitnessConflict"):
+        pc.prove(bad)
+    assert pc.prove(inputs) == pc.prove(inputs)
     with pytest.raises(RuntimeError, match="WitnessConflict"):
         cl.OracleCircuit(oracle, cl.Circuit.from_arrays(a)).run("koala-bear", cl.Inputs(
             bad.public_values, bad.private_values, bad.private_data_op_ids, bad.private_data_siblings))
