@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <cstdarg>
 #include <cstdio>
@@ -149,6 +150,34 @@ struct HostStage {
   }
 };
 
+// Pinned landing area for the larger device->host results of a proof (opened values, query
+// answers): the transfer goes straight into it and the host reads it in place.  A fetch waits for
+// the stream; its result is valid until the next fetch.
+struct HostLanding {
+  char* base = nullptr;
+  size_t cap = 0;
+  HostLanding() = default;
+  HostLanding(const HostLanding&) = delete;
+  HostLanding& operator=(const HostLanding&) = delete;
+  ~HostLanding() {
+    if (base) (void)hipHostFree(base);
+  }
+  hipError_t fetch(hipStream_t s, const void* dev, size_t bytes, const uint32_t** out) {
+    if (bytes > cap) {
+      if (base) (void)hipHostFree(base);
+      base = nullptr;
+      cap = 0;
+      const size_t want = std::max(bytes * 2, size_t(1) << 20);
+      hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&base), want, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      cap = want;
+    }
+    *out = reinterpret_cast<const uint32_t*>(base);
+    if (bytes == 0) return hipStreamSynchronize(s);
+    return copy_sync(s, base, dev, bytes, hipMemcpyDeviceToHost);
+  }
+};
+
 // RAII device buffer of u32 cells (pooled).
 struct DevBuf {
   uint32_t* p = nullptr;
@@ -239,6 +268,7 @@ struct p3r_ctx {
   std::vector<uint32_t> rc_canonical;
   std::string err;
   p3r::HostStage stage;  // small uploads that do not wait (see HostStage)
+  p3r::HostLanding landing;  // device->host results read in place (see HostLanding)
   // Small read-only device tables (column pointers and job lists of the row-hash kernels),
   // keyed by their content: the pool hands the same addresses to the same allocation sequence,
   // so after the first proof of a shape every table is already on the device.

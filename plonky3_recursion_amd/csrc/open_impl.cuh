@@ -88,7 +88,6 @@ struct Opener {
 
   // values[job][point][col]
   std::vector<std::vector<std::vector<E>>> finish() {
-    std::vector<uint32_t> raw(used * 4);
     if (jobs.empty()) return {};
     out.alloc(used * 4);
     {
@@ -105,7 +104,8 @@ struct Opener {
                          (int)dot_jobs.size(), (uint32_t)(used * 4), out.p);
       P3R_HIP(hipGetLastError());
     }
-    P3R_HIP(copy_sync(ctx->stream, raw.data(), out.p, raw.size() * 4, hipMemcpyDeviceToHost));
+    const uint32_t* raw = nullptr;
+    P3R_HIP(ctx->landing.fetch(ctx->stream, out.p, used * 16, &raw));
     keep.clear();  // `out` stays for the reduced openings (values_dev)
     std::vector<std::vector<std::vector<E>>> res(jobs.size());
     for (size_t j = 0; j < jobs.size(); ++j) {

@@ -101,7 +101,9 @@ Fp<PP> grind_witness(p3r_ctx* ctx, HostChallenger<PP>& ch, int bits) {
   DevBuf res(1);
   g.result = res.p;
   uint32_t found = 0xFFFFFFFFu;
-  const uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(bits + 3, 12), 24);
+  // 4x the expected number of tries per launch: a miss (e^-4) costs one more round trip, while a
+  // larger batch makes every proof pay for permutations past the witness
+  const uint32_t batch = 1u << std::min<uint32_t>(std::max<uint32_t>(bits + 2, 12), 24);
   // 2^(bits+10) candidates all miss with probability e^-1024; stop there instead of sweeping the field
   const uint64_t limit = std::min<uint64_t>(PP::P, (uint64_t(1) << std::min<uint32_t>(bits + 10, 31)) + batch);
   for (uint64_t base = 0; base < limit && found == 0xFFFFFFFFu; base += batch) {
@@ -709,7 +711,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       idx = row;
     }
   }
-  std::vector<uint32_t> gathered(cursor);
+  const uint32_t* gathered = nullptr;  // in the ctx's pinned landing area, read in place below
   {
     DevBuf descs_buf((descs.size() * sizeof(GatherDesc) + 3) / 4);
     GatherDesc* d_descs = reinterpret_cast<GatherDesc*>(descs_buf.p);
@@ -720,9 +722,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       hipLaunchKernelGGL(k_gather<PP>, dim3((unsigned)descs.size()), dim3(64), 0, ctx->stream, d_descs, d_out.p, 0);
       e = hipGetLastError();
     }
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(gathered.data(), d_out.p, (size_t)cursor * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ctx->landing.fetch(ctx->stream, d_out.p, (size_t)cursor * 4, &gathered);
     P3R_HIP(e);
   }
 
