@@ -380,6 +380,8 @@ int p3r_circuit_levels(const p3r_circuit* circuit, size_t* n_levels);
  * (runner.rs:473-510), DivisionByZero (:378), a non-boolean mmcs_bit
  * (poseidon_perm/executor.rs:305-335), a witness that is never set (:218-221). */
 p3r_dtraces* p3r_circuit_run(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs);
+/* run + prove_all_tables in one call.  A CircuitError of the run is what the caller gets (same code
+ * and text as p3r_circuit_run), never an error the prover derived from the failed run's traces. */
 int p3r_prove_next_layer(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs,
                          uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
 
