@@ -205,7 +205,8 @@ struct QuotientArgs {
   size_t lde_h;
   int log_n;              // trace height
   int log_chunks;         // log2 of quotient chunks C
-  const uint32_t* apow;   // alpha^(N-1-k) as 4 words each, k = 0..N-1 (base constraints first)
+  const uint32_t* apow;   // alpha^j as 4 words each, j = 0..: one table for all AIRs of a proof
+  int n_constraints;      // N: constraint k (base constraints first) is weighted alpha^(N-1-k)
   int n_base, n_groups, pair;
   LookupCh lc;
   E4 terminal;
@@ -222,15 +223,15 @@ template <class PP>
 struct BaseFold {
   using F = Fp<PP>;
   using E = Fp4<PP>;
-  const uint32_t* apow;
-  int k = 0;
+  const uint32_t* apow;  // alpha^j, ascending
+  int k;                 // exponent of the next constraint's weight: N-1, N-2, ...
   E acc;
-  __device__ BaseFold(const uint32_t* a) : apow(a), acc(E::zero()) {}
+  __device__ BaseFold(const uint32_t* a, int n) : apow(a), k(n - 1), acc(E::zero()) {}
   __device__ __forceinline__ E pw() {
     E p;
 #pragma unroll
     for (int i = 0; i < 4; ++i) p.c[i] = F::raw(apow[4 * k + i]);
-    ++k;
+    --k;
     return p;
   }
   __device__ __forceinline__ void base(F c) { acc += pw() * c; }
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(kBlock) k_quotient(QuotientArgs q) {
   const uint32_t c = i & (uint32_t)(C - 1);
   const F zh = F::raw(q.zh[c]), g_inv = F::raw(q.g_inv);
   const F is_transition = x - g_inv;
-  BaseFold<PP> fold(q.apow);
+  BaseFold<PP> fold(q.apow, q.n_constraints);
   if (q.air.kind == AIR_ALU) alu_constraints<PP>(q.air, v, fold);
   else if (q.air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, q.rc, fold);
   if (q.aux) {

@@ -288,25 +288,30 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   struct Chunk { int inst; F shift; std::unique_ptr<p3r_dmat> evals, lde; };
   std::vector<Chunk> chunks;
   std::vector<std::unique_ptr<p3r_dmat>> chunk_bufs_keep;
+  // one table of alpha powers for all AIRs: constraint k of N is weighted alpha^(N-1-k)
+  auto n_constraints = [&](size_t i) {
+    return air_num_base_constraints<PP>(prep->airs[i]) + (layouts[i].n_groups ? layouts[i].n_groups + 3 : 0);
+  };
+  int n_max = 1;
+  for (size_t i = 0; i < ni; ++i) n_max = std::max(n_max, n_constraints(i));
+  DevBuf d_apow((size_t)n_max * 4);
+  {
+    std::vector<uint32_t> apow((size_t)n_max * 4);
+    E p = E::one();
+    for (int k = 0; k < n_max; ++k) {
+      for (int c = 0; c < 4; ++c) apow[4 * k + c] = p.c[c].v;
+      p *= alpha;
+    }
+    P3R_HIP(ctx->stage.upload(ctx->stream, d_apow.p, apow.data(), apow.size() * 4));
+  }
   for (size_t i = 0; i < ni; ++i) {
     const AirParams& a = prep->airs[i];
     const auto& L = layouts[i];
     const int lq = L.log_chunks, C = 1 << lq;
     const size_t n = mains[i]->h;
     const int n_base = air_num_base_constraints<PP>(a);
-    const int n_ext = L.n_groups ? L.n_groups + 3 : 0;
-    const int N = n_base + n_ext;
-    std::vector<uint32_t> apow((size_t)std::max(N, 1) * 4);
-    {
-      E p = E::one();
-      for (int k = N - 1; k >= 0; --k) {
-        for (int c = 0; c < 4; ++c) apow[4 * k + c] = p.c[c].v;
-        p *= alpha;
-      }
-    }
-    DevBuf d_apow(apow.size());
-    P3R_HIP(ctx->stage.upload(ctx->stream, d_apow.p, apow.data(), apow.size() * 4));
     QuotientArgs q{};
+    q.n_constraints = n_constraints(i);
     q.air = a;
     q.main = main_lde[i]->d;
     q.prep = prep->ldes[i]->d;
@@ -497,14 +502,20 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       jobs.push_back(j);
       mats.insert(mats.end(), kv.second.begin(), kv.second.end());
     }
-    auto upload = [&](const void* src, size_t bytes) {
-      keep.emplace_back((bytes + 3) / 4);
-      P3R_HIP(ctx->stage.upload(ctx->stream, keep.back().p, src, bytes));
-      return keep.back().p;
-    };
-    const auto* d_mats = reinterpret_cast<const FriReduceMat*>(upload(mats.data(), mats.size() * sizeof(FriReduceMat)));
-    const auto* d_jobs = reinterpret_cast<const FriReduceJob*>(upload(jobs.data(), jobs.size() * sizeof(FriReduceJob)));
-    const auto* d_vsum = reinterpret_cast<const FriVsumJob*>(upload(vsum_jobs.data(), vsum_jobs.size() * sizeof(FriVsumJob)));
+    // the three job lists travel in one transfer
+    const size_t b_mats = mats.size() * sizeof(FriReduceMat), b_jobs = jobs.size() * sizeof(FriReduceJob),
+                 b_vsum = vsum_jobs.size() * sizeof(FriVsumJob);
+    const size_t o_jobs = (b_mats + 15) & ~size_t(15), o_vsum = (o_jobs + b_jobs + 15) & ~size_t(15);
+    std::vector<unsigned char> blob(o_vsum + b_vsum);
+    std::memcpy(blob.data(), mats.data(), b_mats);
+    std::memcpy(blob.data() + o_jobs, jobs.data(), b_jobs);
+    std::memcpy(blob.data() + o_vsum, vsum_jobs.data(), b_vsum);
+    keep.emplace_back((blob.size() + 3) / 4);
+    unsigned char* d_blob = reinterpret_cast<unsigned char*>(keep.back().p);
+    P3R_HIP(ctx->stage.upload(ctx->stream, d_blob, blob.data(), blob.size()));
+    const auto* d_mats = reinterpret_cast<const FriReduceMat*>(d_blob);
+    const auto* d_jobs = reinterpret_cast<const FriReduceJob*>(d_blob + o_jobs);
+    const auto* d_vsum = reinterpret_cast<const FriVsumJob*>(d_blob + o_vsum);
     {
       ProfScope ps(ctx, "fri_reduce");
       hipLaunchKernelGGL(k_fri_vsum<PP>, dim3((unsigned)vsum_jobs.size()), dim3(kBlock), 0, ctx->stream, d_vsum,
@@ -533,7 +544,9 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   // commit phase is enqueued without a host round trip; the host replays them afterwards.
   const bool device_transcript = cfg.cap_height == 0 && cfg.commit_pow_bits == 0 && ch.in_buf.empty();
   constexpr size_t kMaxPhases = 32;
-  DevBuf d_tstate(P2_WIDTH), d_betas(4 * kMaxPhases), d_caps(P2_DIGEST * kMaxPhases);
+  DevBuf d_tstate(P2_WIDTH), d_phase((4 + P2_DIGEST) * kMaxPhases);  // challenges, then roots
+  uint32_t* const d_betas = d_phase.p;
+  uint32_t* const d_caps = d_phase.p + 4 * kMaxPhases;
   if (device_transcript) {
     uint32_t st[P2_WIDTH];
     for (int k = 0; k < P2_WIDTH; ++k) st[k] = ch.state[k].v;
@@ -571,7 +584,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     if (pi >= kMaxPhases) fail(P3R_EUNSUPPORTED, "more than %zu FRI commit phases", kMaxPhases);
     if (device_transcript) {
       hipLaunchKernelGGL(k_fri_transcript_step<PP>, dim3(1), dim3(64), 0, ctx->stream, ph.tree->layers.back().p,
-                         d_tstate.p, d_betas.p + 4 * pi, d_caps.p + P2_DIGEST * pi, ctx->rc.p, ctx->p2_diag.p);
+                         d_tstate.p, d_betas + 4 * pi, d_caps + P2_DIGEST * pi, ctx->rc.p, ctx->p2_diag.p);
     } else {
       ph.cap = download_cap_mont<PP>(ctx, ph.tree.get());
       for (uint32_t v : ph.cap) ch.observe(F::raw(v));
@@ -579,12 +592,12 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       const E beta = ch.sample_ext();
       uint32_t bw[4];
       for (int k = 0; k < 4; ++k) bw[k] = beta.c[k].v;
-      P3R_HIP(ctx->stage.upload(ctx->stream, d_betas.p + 4 * pi, bw, sizeof bw));
+      P3R_HIP(ctx->stage.upload(ctx->stream, d_betas + 4 * pi, bw, sizeof bw));
     }
     DevBuf out(4 * rows);
     FriFoldArgs fa{};
     fa.in = folded.p; fa.out = out.p; fa.rows = rows; fa.la = la; fa.log_rows = log_cur - la;
-    fa.beta = d_betas.p + 4 * pi;
+    fa.beta = d_betas + 4 * pi;
     const bool roll = next_h < heights.size() && heights[next_h] == log_cur - la;
     fa.roll = roll ? ros[heights[next_h]].second.p : nullptr;
     fa.w_inv = F::two_adic_generator(log_cur).inv().v;
@@ -611,17 +624,17 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<E> final_poly;
   {
     const size_t m = size_t(1) << log_cur;
-    std::vector<uint32_t> raw(4 * m), caps(P2_DIGEST * phases.size()), betas(4 * phases.size());
+    std::vector<uint32_t> raw(4 * m), phase_words(d_phase.n);
     P3R_HIP(hipMemcpyAsync(raw.data(), folded.p, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (device_transcript && !phases.empty()) {
-      P3R_HIP(hipMemcpyAsync(caps.data(), d_caps.p, caps.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-      P3R_HIP(hipMemcpyAsync(betas.data(), d_betas.p, betas.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    if (device_transcript && !phases.empty())
+      P3R_HIP(hipMemcpyAsync(phase_words.data(), d_phase.p, phase_words.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     P3R_HIP(hipStreamSynchronize(ctx->stream));
+    const uint32_t* betas = phase_words.data();
+    const uint32_t* caps = betas + 4 * kMaxPhases;
     if (device_transcript) {
       // replay the commit phase on the host transcript; the challenges must be the device's
       for (size_t pi = 0; pi < phases.size(); ++pi) {
-        phases[pi].cap.assign(caps.begin() + P2_DIGEST * pi, caps.begin() + P2_DIGEST * (pi + 1));
+        phases[pi].cap.assign(caps + P2_DIGEST * pi, caps + P2_DIGEST * (pi + 1));
         for (uint32_t v : phases[pi].cap) ch.observe(F::raw(v));
         commit_pow_witnesses.push_back(grind_witness<PP>(ctx, ch, 0));
         const E beta = ch.sample_ext();
