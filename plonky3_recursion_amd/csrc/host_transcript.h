@@ -13,6 +13,7 @@
 
 #include "air_device.cuh"
 #include "context.h"
+#include "host_poseidon2_simd.h"
 
 namespace p3r {
 
@@ -34,7 +35,7 @@ struct HostChallenger {
       for (size_t i = n; i < (size_t)P2_RATE; ++i) state[i] = F::zero();
       state[P2_RATE] += F::from_canonical((uint32_t)n);
     }
-    p2_permute<PP>(state, rc);
+    host_permute<PP>(state, rc);
     out_buf.assign(state, state + P2_RATE);
   }
   void observe(F x) {

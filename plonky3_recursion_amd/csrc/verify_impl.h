@@ -250,7 +250,7 @@ std::array<Fp<PP>, P2_DIGEST> sponge_hash(const std::vector<Fp<PP>>& row, const 
   // overwrite-mode PaddingFreeSponge, rate 8 (recursion/src/pcs/mmcs.rs:38-179)
   for (; g < row.size(); g += P2_RATE) {
     for (size_t j = 0; j < (size_t)P2_RATE && g + j < row.size(); ++j) s[j] = row[g + j];
-    p2_permute<PP>(s, rc);
+    host_permute<PP>(s, rc);
   }
   std::array<F, P2_DIGEST> d;
   for (int k = 0; k < P2_DIGEST; ++k) d[k] = s[k];
@@ -261,7 +261,7 @@ std::array<Fp<PP>, P2_DIGEST> compress2(const std::array<Fp<PP>, P2_DIGEST>& l, 
                                         const uint32_t* rc) {
   Fp<PP> s[P2_WIDTH];
   for (int k = 0; k < P2_DIGEST; ++k) { s[k] = l[k]; s[P2_DIGEST + k] = r[k]; }
-  p2_permute<PP>(s, rc);
+  host_permute<PP>(s, rc);
   std::array<Fp<PP>, P2_DIGEST> d;
   for (int k = 0; k < P2_DIGEST; ++k) d[k] = s[k];
   return d;
