@@ -772,7 +772,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       W.varint(qr.rows.size());
       for (auto& rw : qr.rows) {
         W.varint(rw.second);
-        for (uint32_t c = 0; c < rw.second; ++c) W.fe(F::raw(gathered[rw.first + c]));
+        W.words(&gathered[rw.first], rw.second);
       }
       W.varint(qr.depth);
       for (int l = 0; l < qr.depth; ++l) W.digest_mont(&gathered[qr.proof_at + (size_t)l * P2_DIGEST]);
