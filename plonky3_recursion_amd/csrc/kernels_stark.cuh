@@ -576,21 +576,30 @@ __global__ void __launch_bounds__(kBlock) k_grind(GrindArgs a) {
 }
 
 // Query answers: copy `count` strided cells into a contiguous staging buffer.
-struct GatherDesc {
-  const uint32_t* src;
-  uint64_t stride;
-  uint32_t count;
-  uint32_t dst;
+// Query answers.  What a query opens is the same for every query of a proof - one row of every
+// committed matrix, one sibling digest per tree level, the sibling evaluations and the Merkle path
+// of every FRI phase - and only WHERE depends on the query index, through a shift and (for tree
+// siblings) a flipped low bit.  The item list is therefore static per proof shape (it stays on the
+// device, content-keyed); a proof uploads its query indices and launches (items x queries) blocks.
+struct QueryItem {
+  const uint32_t* base;
+  uint64_t stride;   // words between consecutive elements of the item
+  uint32_t count;    // elements
+  uint32_t dst;      // offset inside a query's block of the output
+  uint32_t shift;    // position = ((index >> shift) ^ flip) * mul
+  uint32_t flip;     // 1 for tree siblings
+  uint32_t mul;
 };
 template <class PP>
 __global__ void __launch_bounds__(64)
-k_gather(const GatherDesc* __restrict__ descs, uint32_t* __restrict__ out, int to_canonical) {
-  using F = Fp<PP>;
-  GatherDesc d = descs[blockIdx.x];
-  for (uint32_t i = threadIdx.x; i < d.count; i += 64) {
-    uint32_t v = d.src[(size_t)i * d.stride];
-    out[d.dst + i] = to_canonical ? F::raw(v).to_canonical() : v;
-  }
+k_gather(const QueryItem* __restrict__ items, const uint32_t* __restrict__ indices, uint32_t words_per_query,
+         uint32_t* __restrict__ out) {
+  const QueryItem it = items[blockIdx.x];
+  const uint32_t q = blockIdx.y;
+  const size_t pos = (size_t)((indices[q] >> it.shift) ^ it.flip) * it.mul;
+  const gptr<const uint32_t> src = as_global(it.base) + pos;
+  uint32_t* dst = out + (size_t)q * words_per_query + it.dst;
+  for (uint32_t i = threadIdx.x; i < it.count; i += 64) dst[i] = src[(size_t)i * it.stride];
 }
 
 }  // namespace p3r

@@ -679,63 +679,65 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   const int n_rounds = any_lookup ? 4 : 3;
   std::vector<size_t> indices(cfg.num_queries);
   for (auto& ix : indices) ix = ch.sample_bits(log_max);
-  std::vector<GatherDesc> descs;
-  descs.reserve(indices.size() * 512);
+  // the item list is the same for every query (kernels_stark.cuh, k_gather); offsets are relative
+  // to a query's block of `words_per_query` words in the output
+  std::vector<QueryItem> q_items;
   uint32_t cursor = 0;
-  auto push = [&](const uint32_t* src, uint64_t stride, uint32_t count) {
-    descs.push_back({src, stride, count, cursor});
-    uint32_t at = cursor;
+  auto push = [&](const uint32_t* base, uint64_t stride, uint32_t count, uint32_t shift, uint32_t flip, uint32_t mul) {
+    q_items.push_back({base, stride, count, cursor, shift, flip, mul});
+    const uint32_t at = cursor;
     cursor += count;
     return at;
   };
   struct QRound { std::vector<std::pair<uint32_t, uint32_t>> rows; uint32_t proof_at; int depth; };
-  struct QPhase { uint32_t sib_at[8][4]; uint32_t proof_at; int depth; size_t pos; };
-  std::vector<std::vector<QRound>> qrounds(indices.size());
-  std::vector<std::vector<QPhase>> qphases(indices.size());
-  for (size_t qi = 0; qi < indices.size(); ++qi) {
-    const size_t index = indices[qi];
-    for (int r = 0; r < n_rounds; ++r) {
-      const p3r_tree* t = round_trees[r];
-      size_t ridx = index >> (log_max - t->log_max_h);
-      QRound qr;
-      for (const p3r_dmat* m : t->mats) {
-        int lh = log2_exact(m->h, "height");
-        size_t row = ridx >> (t->log_max_h - lh);
-        qr.rows.emplace_back(push(m->d + row, m->h, (uint32_t)m->w), (uint32_t)m->w);
-      }
-      qr.depth = t->log_max_h - t->cap_height;
-      qr.proof_at = cursor;
-      for (int l = 0; l < qr.depth; ++l)
-        push(t->layers[l].p + ((ridx >> l) ^ 1), size_t(1) << (t->log_max_h - l), P2_DIGEST);
-      qrounds[qi].push_back(qr);
+  struct QPhase { uint32_t sib_at[8]; uint32_t proof_at; int depth; int shift; };
+  std::vector<QRound> qrounds;
+  std::vector<QPhase> qphases;
+  for (int r = 0; r < n_rounds; ++r) {
+    const p3r_tree* t = round_trees[r];
+    const uint32_t tree_shift = (uint32_t)(log_max - t->log_max_h);  // tree index = query index >> tree_shift
+    QRound qr;
+    for (const p3r_dmat* m : t->mats) {
+      const int lh = log2_exact(m->h, "height");
+      qr.rows.emplace_back(push(m->d, m->h, (uint32_t)m->w, (uint32_t)(log_max - lh), 0, 1), (uint32_t)m->w);
     }
-    size_t idx = index;
+    qr.depth = t->log_max_h - t->cap_height;
+    qr.proof_at = cursor;
+    for (int l = 0; l < qr.depth; ++l)
+      push(t->layers[l].p, size_t(1) << (t->log_max_h - l), P2_DIGEST, tree_shift + l, 1, 1);
+    qrounds.push_back(std::move(qr));
+  }
+  {
+    int shift = 0;  // the phase's index = query index >> shift
     for (auto& ph : phases) {
-      const size_t arity = size_t(1) << ph.la, row = idx >> ph.la, n_in = ph.rows << ph.la;
+      const size_t arity = size_t(1) << ph.la, n_in = ph.rows << ph.la;
       QPhase qp;
-      qp.pos = idx & (arity - 1);
+      qp.shift = shift;
+      // sibling j of the row: the four planes of one extension element, at row * arity + j
       for (size_t j = 0; j < arity; ++j)
-        for (int k = 0; k < 4; ++k) qp.sib_at[j][k] = push(ph.folded_in.p + (size_t)k * n_in + row * arity + j, 1, 1);
+        qp.sib_at[j] = push(ph.folded_in.p + j, n_in, 4, (uint32_t)(shift + ph.la), 0, (uint32_t)arity);
       qp.depth = ph.tree->log_max_h - ph.tree->cap_height;
       qp.proof_at = cursor;
       for (int l = 0; l < qp.depth; ++l)
-        push(ph.tree->layers[l].p + ((row >> l) ^ 1), size_t(1) << (ph.tree->log_max_h - l), P2_DIGEST);
-      qphases[qi].push_back(qp);
-      idx = row;
+        push(ph.tree->layers[l].p, size_t(1) << (ph.tree->log_max_h - l), P2_DIGEST, (uint32_t)(shift + ph.la + l), 1, 1);
+      qphases.push_back(qp);
+      shift += ph.la;
     }
   }
+  const uint32_t words_per_query = cursor;
   const uint32_t* gathered = nullptr;  // in the ctx's pinned landing area, read in place below
   {
-    DevBuf descs_buf((descs.size() * sizeof(GatherDesc) + 3) / 4);
-    GatherDesc* d_descs = reinterpret_cast<GatherDesc*>(descs_buf.p);
-    DevBuf d_out(cursor);
-    hipError_t e = ctx->stage.upload(ctx->stream, d_descs, descs.data(), descs.size() * sizeof(GatherDesc));
+    const auto* d_items = static_cast<const QueryItem*>(const_table(ctx, q_items.data(), q_items.size() * sizeof(QueryItem)));
+    std::vector<uint32_t> idx32(indices.begin(), indices.end());
+    DevBuf d_idx(idx32.size()), d_out((size_t)words_per_query * indices.size());
+    hipError_t e = ctx->stage.upload(ctx->stream, d_idx.p, idx32.data(), idx32.size() * 4);
     if (e == hipSuccess) {
       ProfScope ps(ctx, "query_gather");
-      hipLaunchKernelGGL(k_gather<PP>, dim3((unsigned)descs.size()), dim3(64), 0, ctx->stream, d_descs, d_out.p, 0);
+      hipLaunchKernelGGL(k_gather<PP>, dim3((unsigned)q_items.size(), (unsigned)indices.size()), dim3(64), 0, ctx->stream,
+                         d_items, d_idx.p, words_per_query, d_out.p);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = ctx->landing.fetch(ctx->stream, d_out.p, (size_t)cursor * 4, &gathered);
+    if (e == hipSuccess) e = ctx->landing.fetch(ctx->stream, d_out.p, d_out.n * 4, &gathered);
     P3R_HIP(e);
   }
 
@@ -767,28 +769,28 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   for (auto& w : commit_pow_witnesses) W.fe(w);
   W.varint(indices.size());
   for (size_t qi = 0; qi < indices.size(); ++qi) {
-    W.varint(qrounds[qi].size());
-    for (auto& qr : qrounds[qi]) {
+    const uint32_t* g = gathered + (size_t)qi * words_per_query;  // this query's answers
+    W.varint(qrounds.size());
+    for (auto& qr : qrounds) {
       W.varint(qr.rows.size());
       for (auto& rw : qr.rows) {
         W.varint(rw.second);
-        W.words(&gathered[rw.first], rw.second);
+        W.words(g + rw.first, rw.second);
       }
       W.varint(qr.depth);
-      for (int l = 0; l < qr.depth; ++l) W.digest_mont(&gathered[qr.proof_at + (size_t)l * P2_DIGEST]);
+      W.words(g + qr.proof_at, (size_t)qr.depth * P2_DIGEST);
     }
-    W.varint(qphases[qi].size());
+    W.varint(qphases.size());
     for (size_t p = 0; p < phases.size(); ++p) {
-      auto& qp = qphases[qi][p];
+      auto& qp = qphases[p];
       const size_t arity = size_t(1) << phases[p].la;
+      const size_t pos = (indices[qi] >> qp.shift) & (arity - 1);  // the query's own position in the row
       W.byte((uint8_t)phases[p].la);
       W.varint(arity - 1);
-      for (size_t j = 0; j < arity; ++j) {
-        if (j == qp.pos) continue;
-        for (int k = 0; k < 4; ++k) W.fe(F::raw(gathered[qp.sib_at[j][k]]));
-      }
+      for (size_t j = 0; j < arity; ++j)
+        if (j != pos) W.words(g + qp.sib_at[j], 4);
       W.varint(qp.depth);
-      for (int l = 0; l < qp.depth; ++l) W.digest_mont(&gathered[qp.proof_at + (size_t)l * P2_DIGEST]);
+      W.words(g + qp.proof_at, (size_t)qp.depth * P2_DIGEST);
     }
   }
   W.vec_ef(final_poly);
