@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -75,9 +76,14 @@ struct DevPool {
            hipGetErrorString(e));
     return p;
   }
+  // Free lists are kept sorted (lowest address at the back, handed out first): the same sequence of
+  // allocations and releases then yields the same addresses proof after proof whatever the release
+  // order was, which is what lets the job lists and pointer tables of a proof shape stay cached on
+  // the device (p3r_ctx::const_tables) instead of being rebuilt and uploaded every time.
   void put(void* p, size_t bytes) {
     bytes = round_up(bytes);
-    free_lists[bytes].push_back(p);
+    auto& v = free_lists[bytes];
+    v.insert(std::lower_bound(v.begin(), v.end(), p, std::greater<void*>()), p);
     cached_bytes += bytes;
   }
   void trim() {
