@@ -208,25 +208,24 @@ struct QuotientArgs {
   const uint32_t* apow;   // alpha^j as 4 words each, j = 0..: one table for all AIRs of a proof
   int n_constraints;      // N: constraint k (base constraints first) is weighted alpha^(N-1-k)
   int n_base, n_groups, pair;
-  LookupCh lc;
   E4 terminal;
   uint32_t gen;           // coset shift (Montgomery)
   uint32_t w_q;           // generator of the quotient domain (size n*C)
   uint32_t g_inv;         // inverse trace-domain generator
   uint32_t zh[4];         // Z_H on the C cosets:  gen^n * w_C^c - 1
   uint32_t zh_inv[4];
-  const uint32_t* rc;
   uint32_t* out;          // [C][4][n] chunk evaluations, natural order
+  uint32_t block0;        // first block of this table in the launch (all tables of a proof share it)
 };
 
 template <class PP>
 struct BaseFold {
   using F = Fp<PP>;
   using E = Fp4<PP>;
-  const uint32_t* apow;  // alpha^j, ascending
-  int k;                 // exponent of the next constraint's weight: N-1, N-2, ...
+  gptr<const uint32_t> apow;  // alpha^j, ascending
+  int k;                      // exponent of the next constraint's weight: N-1, N-2, ...
   E acc;
-  __device__ BaseFold(const uint32_t* a, int n) : apow(a), k(n - 1), acc(E::zero()) {}
+  __device__ BaseFold(gptr<const uint32_t> a, int n) : apow(a), k(n - 1), acc(E::zero()) {}
   __device__ __forceinline__ E pw() {
     E p;
 #pragma unroll
@@ -249,21 +248,23 @@ struct QuotSink {
   using F = Fp<PP>;
   using E = Fp4<PP>;
   const QuotientArgs& q;
+  const LookupCh& lc;
+  gptr<const uint32_t> aux;
   BaseFold<PP>& fold;
   size_t row;
   int cnt = 0;
   E d0, sum_f;
   F m0;
-  __device__ QuotSink(const QuotientArgs& q_, BaseFold<PP>& f, size_t r)
-      : q(q_), fold(f), row(r), d0(E::zero()), sum_f(E::zero()), m0(F::zero()) {}
+  __device__ QuotSink(const QuotientArgs& q_, const LookupCh& lc_, BaseFold<PP>& f, size_t r)
+      : q(q_), lc(lc_), aux(as_global(q_.aux)), fold(f), row(r), d0(E::zero()), sum_f(E::zero()), m0(F::zero()) {}
   __device__ __forceinline__ E aux_at(int col, size_t r) const {
     E e;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e.c[k] = F::raw(q.aux[(size_t)(col * 4 + k) * q.lde_h + r]);
+    for (int k = 0; k < 4; ++k) e.c[k] = F::raw(aux[(size_t)(col * 4 + k) * q.lde_h + r]);
     return e;
   }
   __device__ __forceinline__ void add(F idx, const V4<F>& v, F mult) {
-    E d = lookup_denom<PP>(q.lc, idx, v);
+    E d = lookup_denom<PP>(lc, idx, v);
     ++cnt;
     if (!q.pair) {
       E f = aux_at(cnt, row);
@@ -287,13 +288,19 @@ struct QuotSink {
   }
 };
 
+// One launch for all tables of a proof: `jobs` lists them, a block finds its table by walking the
+// first-block indices.  The LogUp challenges and the round constants are the same for every table.
 template <class PP>
-__global__ void __launch_bounds__(kBlock) k_quotient(QuotientArgs q) {
+__global__ void __launch_bounds__(kBlock)
+k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const uint32_t* __restrict__ rc) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const QuotientArgs& q = jobs[jb];
   const int lq = q.log_n + q.log_chunks;
   const size_t qn = size_t(1) << lq, C = size_t(1) << q.log_chunks;
-  size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x;  // LDE row
+  size_t j = (size_t)(blockIdx.x - q.block0) * kBlock + threadIdx.x;  // LDE row
   if (j >= qn) return;
   const uint32_t i = bit_reverse((uint32_t)j, lq);        // natural index on the quotient coset
   const uint32_t i_next = (uint32_t)((i + C) & (qn - 1));
@@ -302,13 +309,13 @@ __global__ void __launch_bounds__(kBlock) k_quotient(QuotientArgs q) {
   const uint32_t c = i & (uint32_t)(C - 1);
   const F zh = F::raw(q.zh[c]), g_inv = F::raw(q.g_inv);
   const F is_transition = x - g_inv;
-  BaseFold<PP> fold(q.apow, q.n_constraints);
+  BaseFold<PP> fold(as_global(q.apow), q.n_constraints);
   if (q.air.kind == AIR_ALU) alu_constraints<PP>(q.air, v, fold);
-  else if (q.air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, q.rc, fold);
+  else if (q.air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc, fold);
   if (q.aux) {
     const F is_first = zh * (x - F::one()).inv();
     const F is_last = zh * is_transition.inv();
-    QuotSink<PP> sink(q, fold, j);
+    QuotSink<PP> sink(q, lc, fold, j);
     air_interactions<PP>(q.air, v, sink);
     sink.finish();
     E s = sink.aux_at(0, j), s_next = sink.aux_at(0, v.nxt);
@@ -319,7 +326,7 @@ __global__ void __launch_bounds__(kBlock) k_quotient(QuotientArgs q) {
   E quot = fold.acc * F::raw(q.zh_inv[c]);
   const size_t n = size_t(1) << q.log_n, r = i >> q.log_chunks;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) q.out[((size_t)c * 4 + k) * n + r] = quot.c[k].v;
+  for (int k = 0; k < 4; ++k) as_global(q.out)[((size_t)c * 4 + k) * n + r] = quot.c[k].v;
 }
 
 // ------------------------------------------------------------------ K9: openings

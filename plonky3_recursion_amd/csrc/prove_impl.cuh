@@ -304,6 +304,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     }
     P3R_HIP(ctx->stage.upload(ctx->stream, d_apow.p, apow.data(), apow.size() * 4));
   }
+  std::vector<QuotientArgs> quot_jobs;  // every table's quotient in one launch
+  uint32_t quot_blocks = 0;
   for (size_t i = 0; i < ni; ++i) {
     const AirParams& a = prep->airs[i];
     const auto& L = layouts[i];
@@ -321,7 +323,6 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     q.log_chunks = lq;
     q.apow = d_apow.p;
     q.n_base = n_base; q.n_groups = L.n_groups; q.pair = L.pair;
-    q.lc = lc;
     q.terminal = to_e4<PP>(terminals[i]);
     q.gen = gen.v;
     const F wq = F::two_adic_generator(log_n[i] + lq);
@@ -333,14 +334,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       q.zh[c] = zh.v;
       q.zh_inv[c] = zh.inv().v;
     }
-    q.rc = ctx->rc.p;
     auto chunk_buf = dmat_alloc(n, (size_t)4 * C);  // [C][4][n]
     q.out = chunk_buf->d;
-    {
-      ProfScope ps(ctx, "quotient");
-      hipLaunchKernelGGL(k_quotient<PP>, dim3(blocks_for(n << lq)), dim3(kBlock), 0, ctx->stream, q);
-    }
-    P3R_HIP(hipGetLastError());
+    q.block0 = quot_blocks;
+    quot_blocks += blocks_for(n << lq);
+    quot_jobs.push_back(q);
     for (int c = 0; c < C; ++c) {
       Chunk ck;
       ck.inst = (int)i;
@@ -352,6 +350,14 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       chunks.push_back(std::move(ck));
     }
     chunk_bufs_keep.push_back(std::move(chunk_buf));
+  }
+  {
+    DevBuf d_quot((quot_jobs.size() * sizeof(QuotientArgs) + 3) / 4);
+    P3R_HIP(ctx->stage.upload(ctx->stream, d_quot.p, quot_jobs.data(), quot_jobs.size() * sizeof(QuotientArgs)));
+    ProfScope ps(ctx, "quotient");
+    hipLaunchKernelGGL(k_quotient<PP>, dim3(quot_blocks), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc, ctx->rc.p);
+    P3R_HIP(hipGetLastError());
   }
   {
     // commit evaluates each chunk polynomial on gen*<w>: shift = GENERATOR / domain shift
