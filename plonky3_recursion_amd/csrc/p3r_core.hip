@@ -448,8 +448,15 @@ void launch_compress(p3r_ctx* ctx, const uint32_t* L, size_t nl, int lmul, int l
 // (k_mmcs_subtree), for layers small enough to be latency-bound.  `inject`: height -> digests to
 // fold in at that height (may be null).  Returns the size of the new back layer, or `n` when
 // the layer is too large for this path.
+// `step`: FRI commit phase only - when this launch ends at the root (one workgroup, cap of one
+// digest) the transcript step runs inside it and `step->done` is set.
+struct TranscriptStep {
+  uint32_t *state, *beta, *cap;
+  bool done = false;
+};
 template <class PP>
-size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_t, DevBuf>* inject) {
+size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_t, DevBuf>* inject,
+                    TranscriptStep* step = nullptr) {
   const size_t cap_n = size_t(1) << tree->cap_height;
   if (n / 2 > kCoopMaxNodes || n <= cap_n) return n;
   SubtreeArgs a{};
@@ -467,6 +474,12 @@ size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_
       if (it != inject->end()) a.inj[a.n_levels] = it->second.p;
     }
     ++a.n_levels;
+  }
+  if (step && nn == 1 && n == local) {
+    a.t_state = step->state;
+    a.t_beta = step->beta;
+    a.t_cap = step->cap;
+    step->done = true;
   }
   ProfScope ps(ctx, "mmcs_compress");
   hipLaunchKernelGGL(k_mmcs_subtree<PP>, dim3((unsigned)(n / local)), dim3(kSubtreeBlock), 0, ctx->stream, a,

@@ -43,11 +43,11 @@ std::vector<Fp4<PP>> download_ef(p3r_ctx* ctx, const uint32_t* dev, size_t count
 
 // Merkle layers above a leaf-digest layer (no injections): used by the FRI commit phase.
 template <class PP>
-void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves) {
+void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves, TranscriptStep* step = nullptr) {
   size_t n = n_leaves;
   const size_t cap_n = size_t(1) << tree->cap_height;
   while (n > cap_n) {
-    const size_t after = mmcs_subtree<PP>(ctx, tree, n, nullptr);
+    const size_t after = mmcs_subtree<PP>(ctx, tree, n, nullptr, step);
     if (after != n) {
       n = after;
       continue;
@@ -585,12 +585,14 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       }
       P3R_HIP(hipGetLastError());
     }
-    build_plain_layers<PP>(ctx, ph.tree.get(), rows);
     const size_t pi = phases.size();
     if (pi >= kMaxPhases) fail(P3R_EUNSUPPORTED, "more than %zu FRI commit phases", kMaxPhases);
+    TranscriptStep step{d_tstate.p, d_betas + 4 * pi, d_caps + P2_DIGEST * pi};
+    build_plain_layers<PP>(ctx, ph.tree.get(), rows, device_transcript ? &step : nullptr);
     if (device_transcript) {
-      hipLaunchKernelGGL(k_fri_transcript_step<PP>, dim3(1), dim3(64), 0, ctx->stream, ph.tree->layers.back().p,
-                         d_tstate.p, d_betas + 4 * pi, d_caps + P2_DIGEST * pi, ctx->rc.p, ctx->p2_diag.p);
+      if (!step.done)  // a tree whose root is not produced by a single-workgroup launch (one leaf)
+        hipLaunchKernelGGL(k_fri_transcript_step<PP>, dim3(1), dim3(64), 0, ctx->stream, ph.tree->layers.back().p,
+                           step.state, step.beta, step.cap, ctx->rc.p, ctx->p2_diag.p);
     } else {
       ph.cap = download_cap_mont<PP>(ctx, ph.tree.get());
       for (uint32_t v : ph.cap) ch.observe(F::raw(v));
