@@ -76,6 +76,30 @@ __device__ __forceinline__ Fp<PP> coop_permute(Fp<PP> s, int elem, Fp<PP> diag, 
   return s;
 }
 
+// Leaf hashing of a SMALL strided matrix (FRI commit-phase leaves of the later phases), sixteen
+// lanes per row: a row is only 1-4 permutations, so with one row per lane the launch is one
+// permutation latency of the 7.8 k-instruction kind (25 us) however few rows there are; the
+// lane-cooperative permutation brings it to a few microseconds.  Same overwrite-mode sponge as
+// k_mmcs_hash_rows_strided (kernels_stark.cuh).
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_mmcs_hash_rows_strided_coop(const uint32_t* const* __restrict__ cols, int wtot, size_t h, size_t stride,
+                              uint32_t* __restrict__ dig, const uint32_t* __restrict__ rc,
+                              const uint32_t* __restrict__ diag) {
+  using F = Fp<PP>;
+  const size_t gid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t row = gid >> 4;
+  const int e = (int)(gid & 15);
+  const bool live = row < h;  // whole 16-lane rows are live or not
+  const F d = F::raw(diag[e]);
+  F s = F::zero();
+  for (int g = 0; g < wtot; g += P2_RATE) {
+    if (live && e < P2_RATE && g + e < wtot) s = F::raw(cols[g + e][row * stride]);
+    s = coop_permute<PP>(s, e, d, rc);
+  }
+  if (live && e < P2_DIGEST) dig[(size_t)e * h + row] = s.v;
+}
+
 // Up to eight levels of a Merkle tree per launch.  A workgroup owns kSubtreeNodes consecutive
 // digests of the input layer and everything above them: a barrier per level instead of a launch
 // (each of these levels is one permutation latency; the launches between them cost more than the
