@@ -186,8 +186,8 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
   }
 }
 
-// The same step as a launch of its own (trees whose last launch is not a single workgroup ending
-// at the root do not exist today; kept for a cap layer that is not the root of one workgroup).
+// The same step as a launch of its own, for a phase whose tree has no level above its single leaf
+// (the root is the leaf digest, no k_mmcs_subtree launch to ride on).
 template <class PP>
 __global__ void __launch_bounds__(64)
 k_fri_transcript_step(const uint32_t* __restrict__ root /* [8] */, uint32_t* __restrict__ state /* [16] */,
