@@ -83,6 +83,39 @@ def workload_model(field, heights, widths, packing):
     return perms, hash_perms, 4 * hash_cells + 32 * hash_rows, hash_launches
 
 
+def hbm_families(heights, widths, packing, kernel_ms):
+    """Achieved HBM rate of the streaming kernel families: algorithmic bytes / measured family time.
+    NTT (K5): 16 B per cell for the inverse transform, 4 + 4B + 8B = 52 B per cell for the four-coset
+    forward one (B = 4). Reduced openings (K10): every committed LDE cell once (4 B) plus, per LDE row,
+    the 16-B inverse vector of each opening point and the 16-B accumulator. Openings (K9): every trace
+    cell once plus a 16-B weight per row, point and group of 8 columns."""
+    names = ["const", "public", "alu", "poseidon2", "recompose"]
+    aux = lookup_aux_widths(packing.alu_lanes, packing.horner_packed_steps)
+    B = 1 << FRI["log_blowup"]
+    prep_w = [2, 2 * packing.public_lanes, 13 * packing.alu_lanes + 7 * (packing.horner_packed_steps - 1), 24,
+              2 * packing.recompose_lanes]
+    ntt = fri = opn = 0
+    for i, n in enumerate(names):
+        h = heights[i]
+        if not h:
+            continue
+        w_main, w_aux, w_q = widths[i], aux[n][0] * 4, aux[n][1] * 4
+        ntt += h * (w_main + w_aux + w_q) * (16 + 4 + 4 * B + 8 * B)
+        for w, pts in ((w_main, 2 if n in ("alu", "poseidon2") else 1), (prep_w[i], 2), (w_aux, 2), (w_q, 1)):
+            fri += h * B * (4 * w + 16 * pts)
+            opn += h * (4 * w + 16 * pts * ((w + 7) // 8))
+        fri += h * B * 16
+    out = {}
+    for fam, nbytes, keys in (("ntt", ntt, ("ntt_inverse", "ntt_forward")), ("fri_reduced_openings", fri, ("fri_reduce",)),
+                              ("openings", opn, ("open_dot",))):
+        ms = sum(kernel_ms.get(k, 0.0) for k in keys)
+        if ms:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            out[fam] = {"algorithmic_bytes": nbytes, "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS}
+    return out
+
+
 def pmc_traffic_bytes(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary (collected with rocprofv3 in
     separate --pmc passes; it cannot be collected from inside this process)."""
@@ -290,6 +323,8 @@ def main():
             line["valu_roofline"] = {"kernel": "k_mmcs_hash_rows", "bound": "int-valu",
                                      "achieved": ach, "peak": peak, "unit": "Poseidon2 perms/s", "frac": ach / peak,
                                      "perms_per_step_in_kernel": hash_perms}
+        # The streaming families against HBM, from the same algorithmic byte counts as DESIGN.md §3/§7.
+        line["hbm_families"] = hbm_families(cpd.table_heights, widths, packing, kernel_ms)
         if not args.no_cpu_baseline and world == 1:
             lh = args.cpu_baseline_log_height
             cdt, crun = cpu_baseline(field, lh)
