@@ -258,20 +258,33 @@ struct Fp4 {
   }
   // Inverse through the norm to the quadratic subfield F[y]/(y^2 - W), y = x^2:
   // a = A + x*B with A = a0 + a2*y, B = a1 + a3*y; a^-1 = (A - x*B) / (A^2 - y*B^2).
-  P3R_HD Fp4 inv() const {
+  // The inverse in two halves, so that callers inverting many elements can share ONE base-field
+  // inversion among them (Montgomery's trick on the norms): norm() is the element's norm down to
+  // the base field, inv_given(1/norm()) finishes.  inv() = inv_given(norm().inv()).
+  struct Norm { F n0, n1, d; };
+  P3R_HD Norm norm() const {
     const F W = w();
     // A^2 = (a0^2 + W a2^2) + (2 a0 a2) y ; B^2 = (a1^2 + W a3^2) + (2 a1 a3) y
     F A0 = c[0] * c[0] + W * (c[2] * c[2]);
     F A1 = (c[0] * c[2]).dbl();
     F B0 = c[1] * c[1] + W * (c[3] * c[3]);
     F B1 = (c[1] * c[3]).dbl();
-    // N = A^2 - y*B^2 = (A0 - W*B1) + (A1 - B0) y
-    F n0 = A0 - W * B1;
-    F n1 = A1 - B0;
+    // N = A^2 - y*B^2 = (A0 - W*B1) + (A1 - B0) y ;  norm of N down to F:  n0^2 - W n1^2
+    Norm r;
+    r.n0 = A0 - W * B1;
+    r.n1 = A1 - B0;
+    r.d = r.n0 * r.n0 - W * (r.n1 * r.n1);
+    return r;
+  }
+  P3R_HD Fp4 inv() const {
+    const Norm nm = norm();
+    return inv_given(nm, nm.d.inv());
+  }
+  P3R_HD Fp4 inv_given(const Norm& nm, F d) const {
+    const F W = w();
     // 1/N = (n0 - n1 y) / (n0^2 - W n1^2)
-    F d = (n0 * n0 - W * (n1 * n1)).inv();
-    F i0 = n0 * d;
-    F i1 = -(n1 * d);
+    F i0 = nm.n0 * d;
+    F i1 = -(nm.n1 * d);
     // (A - xB) * (i0 + i1 y):  A*(i0+i1 y) = (a0 i0 + W a2 i1) + (a0 i1 + a2 i0) y
     Fp4 r;
     r.c[0] = c[0] * i0 + W * (c[2] * i1);

@@ -15,8 +15,9 @@ struct FriInvJob {
   uint64_t h;
   int log_h;
   uint32_t w_h;
+  uint32_t w_4;     // primitive 4th root of unity w_h^(h/4) (h >= 4)
   E4 z;
-  uint32_t block0;
+  uint32_t block0;  // first block; a lane owns four consecutive rows
 };
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
@@ -26,13 +27,26 @@ k_fri_inv_points(const FriInvJob* __restrict__ jobs, int n_jobs, uint32_t gen) {
   int j = 0;
   while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
   const FriInvJob& job = jobs[j];
-  const size_t h = job.h, r = (size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x;
-  if (r >= h) return;
-  F x = F::raw(gen) * F::raw(job.w_h).pow(bit_reverse((uint32_t)r, job.log_h));
-  E v = (e4_load<PP>(job.z) - E::from_base(x)).inv();
+  // four consecutive rows per lane: their inversions share one base-field inversion (inv4)
+  const size_t h = job.h, r0 = ((size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x) * 4;
+  if (r0 >= h) return;
+  const E z = e4_load<PP>(job.z);
+  E x[4], v[4];
+  // rows r0..r0+3 differ in their two low bits, i.e. in the two HIGH bits of the bit-reversed
+  // exponent: x, -x, ix, -ix with i = w_h^(h/4)   (h >= 4, r0 a multiple of 4)
+  const F x0 = F::raw(gen) * F::raw(job.w_h).pow(bit_reverse((uint32_t)r0, job.log_h));
+  const F x2 = x0 * F::raw(job.w_4);
+  x[0] = z - E::from_base(x0);
+  x[1] = z + E::from_base(x0);
+  x[2] = z - E::from_base(x2);
+  x[3] = z + E::from_base(x2);
+  inv4<PP>(x, v);
   const gptr<uint32_t> inv = as_global(job.inv);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) inv[(size_t)k * h + r] = v.c[k].v;
+  for (int m = 0; m < 4; ++m)
+    if (r0 + m < h)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) inv[(size_t)k * h + r0 + m] = v[m].c[k].v;
 }
 
 // V = sum_c alpha^c * value_c over the opened values of one (matrix, point): one workgroup per

@@ -334,6 +334,34 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const
 // matrices at 1-2 points each; per-matrix launches are latency-bound for 2^14..2^16-row layers).
 // A block finds its job by walking the (short) list of first-block indices.
 //
+// Inverses of four extension elements with ONE base-field inversion (Montgomery's trick on their
+// norms): the tower inverse costs ~25 products plus a ~56-product exponentiation in the base
+// field, and the latter is what the four share.  A zero among them (never, for z outside the base
+// field) falls back to separate inversions so that it cannot poison its neighbours.
+template <class PP>
+__device__ __forceinline__ void inv4(const Fp4<PP> (&x)[4], Fp4<PP> (&out)[4]) {
+  using F = Fp<PP>;
+  typename Fp4<PP>::Norm nm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nm[i] = x[i].norm();
+  const F p01 = nm[0].d * nm[1].d, p012 = p01 * nm[2].d, p0123 = p012 * nm[3].d;
+  if (p0123.v == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = x[i].inv();
+    return;
+  }
+  F t = p0123.inv();
+  const F i3 = t * p012;
+  t = t * nm[3].d;
+  const F i2 = t * p01;
+  t = t * nm[2].d;
+  const F i1 = t * nm[0].d, i0 = t * nm[1].d;
+  out[0] = x[0].inv_given(nm[0], i0);
+  out[1] = x[1].inv_given(nm[1], i1);
+  out[2] = x[2].inv_given(nm[2], i2);
+  out[3] = x[3].inv_given(nm[3], i3);
+}
+
 // Barycentric weights over the trace subgroup:  L_i(z) = w^i (z^n - 1) / (n (z - w^i)).
 // `scale` = (z^n - 1)/n is supplied by the host.
 struct BaryJob {
@@ -350,13 +378,28 @@ __global__ void __launch_bounds__(kBlock) k_bary_weights(const BaryJob* __restri
   int j = 0;
   while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
   const BaryJob& b = jobs[j];
-  const size_t i = (size_t)(blockIdx.x - b.block0) * kBlock + threadIdx.x;
-  if (i >= b.n) return;
-  F wi = F::raw(b.w_n).pow(i);
-  E r = (e4_load<PP>(b.z) - E::from_base(wi)).inv() * e4_load<PP>(b.scale) * wi;
+  // four consecutive points per lane: their inversions share one base-field inversion (inv4)
+  const size_t i0 = ((size_t)(blockIdx.x - b.block0) * kBlock + threadIdx.x) * 4;
+  if (i0 >= b.n) return;
+  const F w1 = F::raw(b.w_n);
+  const E z = e4_load<PP>(b.z), scale = e4_load<PP>(b.scale);
+  F wi[4];
+  E x[4], inv[4];
+  wi[0] = w1.pow(i0);
+#pragma unroll
+  for (int m = 1; m < 4; ++m) wi[m] = wi[m - 1] * w1;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) x[m] = z - E::from_base(wi[m]);
+  inv4<PP>(x, inv);
   const gptr<uint32_t> out = as_global(b.out);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) out[(size_t)k * b.n + i] = r.c[k].v;
+  for (int m = 0; m < 4; ++m) {
+    if (i0 + m < b.n) {
+      const E r = inv[m] * scale * wi[m];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[(size_t)k * b.n + i0 + m] = r.c[k].v;
+    }
+  }
 }
 
 constexpr int kOpenCols = 8;      // matrix columns sharing one pass over the weights

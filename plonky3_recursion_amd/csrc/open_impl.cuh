@@ -37,7 +37,7 @@ struct Opener {
     b.z = e4_store<PP>(z);
     b.scale = e4_store<PP>((z.pow(n) - E::one()) * F::from_u64(n).inv());
     b.block0 = bary_blocks;
-    bary_blocks += blocks_for(n);
+    bary_blocks += blocks_for((n + 3) / 4);  // a lane owns four consecutive points
     bary_jobs.push_back(b);
     return wcache.emplace(key, b.out).first->second;
   }

@@ -430,10 +430,12 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         j.inv = inv_keep.back().p;
         j.h = uint64_t(1) << lh;
         j.log_h = lh;
+        if (lh < 2) fail(P3R_EINVAL, "FRI: an LDE of fewer than four rows");
         j.w_h = F::two_adic_generator(lh).v;
+        j.w_4 = F::two_adic_generator(2).v;
         j.z = to_e4<PP>(it.z[p]);
         j.block0 = inv_blocks;
-        inv_blocks += blocks_for(size_t(1) << lh);
+        inv_blocks += blocks_for((size_t(1) << lh) / 4);
         inv_jobs.push_back(j);
         inv_cache.emplace(key, j.inv);
       }
