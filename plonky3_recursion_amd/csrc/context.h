@@ -270,6 +270,8 @@ struct p3r_ctx {
   int partial_rounds = 0;
   hipStream_t stream = nullptr;
   p3r::DevBuf rc;  // Poseidon2 constants, Montgomery
+  p3r::DevBuf rc_f64;  // the same constants as canonical doubles (poseidon2_f64.cuh)
+  const double* rcd() const { return reinterpret_cast<const double*>(rc_f64.p); }
   p3r::DevBuf p2_diag;  // internal-layer diagonal, Montgomery (lane-cooperative kernels)
   std::vector<uint32_t> rc_canonical;
   std::string err;

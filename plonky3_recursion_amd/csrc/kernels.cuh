@@ -10,6 +10,7 @@
 #pragma once
 #include "field.h"
 #include "poseidon2.h"
+#include "poseidon2_f64.cuh"
 #include "kernels_ntt.cuh"
 
 namespace p3r {
@@ -77,19 +78,19 @@ k_convert_inplace(uint32_t* __restrict__ d, size_t n, int to_monty) {
 // ---------------------------------------------------------------------------------
 
 // Plain batch permutation: states column-major [16][n] in and out (the perms/s metric).
+// FP64 form (poseidon2_f64.cuh): `rcd` = the constants as canonical doubles.
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
 k_p2_permute_batch(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
-                   const uint32_t* __restrict__ rc) {
-  using F = Fp<PP>;
+                   const double* __restrict__ rcd) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  F s[P2_WIDTH];
+  double s[P2_WIDTH];
 #pragma unroll
-  for (int k = 0; k < P2_WIDTH; ++k) s[k] = F::raw(in[(size_t)k * n + i]);
-  p2_permute<PP>(s, rc);
+  for (int k = 0; k < P2_WIDTH; ++k) s[k] = p2f_load<PP>(in[(size_t)k * n + i]);
+  p2f_permute<PP>(s, rcd);
 #pragma unroll
-  for (int k = 0; k < P2_WIDTH; ++k) out[(size_t)k * n + i] = s[k].v;
+  for (int k = 0; k < P2_WIDTH; ++k) out[(size_t)k * n + i] = p2f_store<PP>(s[k]);
 }
 
 // K3 pass 1: the MMCS index accumulator is the segmented affine recurrence
@@ -280,8 +281,7 @@ struct HashRowsJob {
 };
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
-k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const uint32_t* __restrict__ rc) {
-  using F = Fp<PP>;
+k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const double* __restrict__ rcd) {
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
   const gptr<const uint32_t* const> cols = as_global(jobs[jb].cols);
@@ -290,47 +290,54 @@ k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const uint32_
   const int wtot = jobs[jb].wtot;
   size_t i = (size_t)(blockIdx.x - jobs[jb].block0) * kBlock + threadIdx.x;
   if (i >= h) return;
-  F s[P2_WIDTH];
+  // the sponge state lives in FP64 between permutations (poseidon2_f64.cuh): absorbed cells are
+  // converted on the way in, the capacity half is carried unreduced, the digest is reduced once
+  double s[P2_WIDTH];
 #pragma unroll
-  for (int k = 0; k < P2_WIDTH; ++k) s[k] = F::zero();
+  for (int k = 0; k < P2_WIDTH; ++k) s[k] = 0.0;
   int g = 0;
   for (; g + P2_RATE <= wtot; g += P2_RATE) {
 #pragma unroll
-    for (int j = 0; j < P2_RATE; ++j) s[j] = F::raw(as_global(cols[g + j])[i]);
-    p2_permute<PP>(s, rc);
+    for (int j = 0; j < P2_RATE; ++j) s[j] = p2f_load<PP>(as_global(cols[g + j])[i]);
+    p2f_permute<PP>(s, rcd);
   }
   int rem = wtot - g;
   if (rem > 0) {
 #pragma unroll
     for (int j = 0; j < P2_RATE; ++j)
-      if (j < rem) s[j] = F::raw(as_global(cols[g + j])[i]);
-    p2_permute<PP>(s, rc);
+      if (j < rem) s[j] = p2f_load<PP>(as_global(cols[g + j])[i]);
+    p2f_permute<PP>(s, rcd);
   }
 #pragma unroll
-  for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * h + i] = s[k].v;
+  for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * h + i] = p2f_store<PP>(s[k]);
 }
 
 // K6 tree layers: TruncatedPermutation<Perm,2,8,16>: perm(left || right)[0..8]
-// (circuit/src/ops/mmcs.rs:117-160).  left digest i = L[k*nl + i*lmul + ladd], same for right:
-//   plain layer        L = R = prev, lmul = rmul = 2, ladd = 0, radd = 1
-//   injection          L = compressed layer, R = digests of the shorter matrices, mul 1
+// (circuit/src/ops/mmcs.rs:117-160).  Node i of the new layer = compress(prev[2i], prev[2i+1]); when
+// the commit has matrices of this layer's height their row digests `inj` are folded in by the same
+// lane, node = compress(compress(l, r), inj[i]) - the intermediate digest never leaves registers.
+// prev: [8][2n], inj: [8][n] or null, out: [8][n].
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
-k_mmcs_compress(const uint32_t* __restrict__ L, size_t nl, int lmul, int ladd,
-                const uint32_t* __restrict__ R, size_t nr, int rmul, int radd,
-                uint32_t* __restrict__ out, size_t n, const uint32_t* __restrict__ rc) {
-  using F = Fp<PP>;
+k_mmcs_compress(const uint32_t* __restrict__ prev, const uint32_t* __restrict__ inj, uint32_t* __restrict__ out,
+                size_t n, const double* __restrict__ rcd) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  F s[P2_WIDTH];
+  double s[P2_WIDTH];
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) {
-    s[k] = F::raw(L[(size_t)k * nl + i * lmul + ladd]);
-    s[P2_DIGEST + k] = F::raw(R[(size_t)k * nr + i * rmul + radd]);
+    const uint2 lr = *reinterpret_cast<const uint2*>(prev + (size_t)k * 2 * n + 2 * i);  // siblings are adjacent
+    s[k] = p2f_load<PP>(lr.x);
+    s[P2_DIGEST + k] = p2f_load<PP>(lr.y);
   }
-  p2_permute<PP>(s, rc);
+  p2f_permute<PP>(s, rcd);
+  if (inj) {
 #pragma unroll
-  for (int k = 0; k < P2_DIGEST; ++k) out[(size_t)k * n + i] = s[k].v;
+    for (int k = 0; k < P2_DIGEST; ++k) s[P2_DIGEST + k] = p2f_load<PP>(inj[(size_t)k * n + i]);
+    p2f_permute<PP>(s, rcd);
+  }
+#pragma unroll
+  for (int k = 0; k < P2_DIGEST; ++k) out[(size_t)k * n + i] = p2f_store<PP>(s[k]);
 }
 
 }  // namespace p3r

@@ -569,28 +569,27 @@ __global__ void __launch_bounds__(kBlock) k_fri_fold(FriFoldArgs a) {
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
 k_mmcs_hash_rows_strided(const uint32_t* const* __restrict__ cols, int wtot, size_t h, size_t stride,
-                         uint32_t* __restrict__ dig, const uint32_t* __restrict__ rc) {
-  using F = Fp<PP>;
+                         uint32_t* __restrict__ dig, const double* __restrict__ rcd) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= h) return;
-  F s[P2_WIDTH];
+  double s[P2_WIDTH];
 #pragma unroll
-  for (int k = 0; k < P2_WIDTH; ++k) s[k] = F::zero();
+  for (int k = 0; k < P2_WIDTH; ++k) s[k] = 0.0;
   int g = 0;
   for (; g + P2_RATE <= wtot; g += P2_RATE) {
 #pragma unroll
-    for (int j = 0; j < P2_RATE; ++j) s[j] = F::raw(cols[g + j][i * stride]);
-    p2_permute<PP>(s, rc);
+    for (int j = 0; j < P2_RATE; ++j) s[j] = p2f_load<PP>(cols[g + j][i * stride]);
+    p2f_permute<PP>(s, rcd);
   }
   int rem = wtot - g;
   if (rem > 0) {
 #pragma unroll
     for (int j = 0; j < P2_RATE; ++j)
-      if (j < rem) s[j] = F::raw(cols[g + j][i * stride]);
-    p2_permute<PP>(s, rc);
+      if (j < rem) s[j] = p2f_load<PP>(cols[g + j][i * stride]);
+    p2f_permute<PP>(s, rcd);
   }
 #pragma unroll
-  for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * h + i] = s[k].v;
+  for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * h + i] = p2f_store<PP>(s[k]);
 }
 
 // Proof-of-work grinding: candidate witness w = base + tid; smallest valid one wins

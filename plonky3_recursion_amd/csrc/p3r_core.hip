@@ -94,7 +94,7 @@ void permute_dmat(p3r_ctx* ctx, p3r_dmat* s) {
   if (s->w != P2_WIDTH) fail(P3R_EINVAL, "state matrix must have width 16, got %zu", s->w);
   ProfScope ps(ctx, "p2_permute_batch");
   hipLaunchKernelGGL(k_p2_permute_batch<PP>, dim3(blocks_for(s->h)), dim3(kBlock), 0, ctx->stream,
-                     s->d, s->d, s->h, ctx->rc.p);
+                     s->d, s->d, s->h, ctx->rcd());
   P3R_HIP(hipGetLastError());
 }
 
@@ -428,7 +428,7 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
       static_cast<const HashRowsJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(HashRowsJob)));
   ProfScope ps(ctx, "mmcs_hash_rows");
   hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(),
-                     ctx->rc.p);
+                     ctx->rcd());
   P3R_HIP(hipGetLastError());
 }
 
@@ -436,11 +436,10 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
 // ones are latency-bound and go through mmcs_subtree below (16 lanes per node, 8 levels per launch).
 constexpr size_t kCoopMaxNodes = 32768;
 template <class PP>
-void launch_compress(p3r_ctx* ctx, const uint32_t* L, size_t nl, int lmul, int ladd, const uint32_t* R, size_t nr,
-                     int rmul, int radd, uint32_t* out, size_t n) {
+void launch_compress(p3r_ctx* ctx, const uint32_t* prev, const uint32_t* inj, uint32_t* out, size_t n) {
   ProfScope ps(ctx, "mmcs_compress");
-  hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, L, nl, lmul, ladd, R,
-                     nr, rmul, radd, out, n, ctx->rc.p);
+  hipLaunchKernelGGL(k_mmcs_compress<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, prev, inj, out, n,
+                     ctx->rcd());
   P3R_HIP(hipGetLastError());
 }
 
@@ -541,10 +540,8 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;
-    launch_compress<PP>(ctx, prev, n, 2, 0, prev, n, 2, 1, next.p, nn);
     auto inj = inject.find(nn);
-    if (inj != inject.end())
-      launch_compress<PP>(ctx, next.p, nn, 1, 0, inj->second.p, nn, 1, 0, next.p, nn);
+    launch_compress<PP>(ctx, prev, inj != inject.end() ? inj->second.p : nullptr, next.p, nn);
     tree->layers.push_back(std::move(next));
     n = nn;
   }
@@ -603,6 +600,9 @@ void init_ctx(p3r_ctx* ctx) {
   }
   ctx->rc.alloc(nrc);
   P3R_HIP(copy_sync(ctx->stream, ctx->rc.p, mont.data(), nrc * 4, hipMemcpyHostToDevice));
+  std::vector<double> rcd(src, src + nrc);
+  ctx->rc_f64.alloc(2 * nrc);
+  P3R_HIP(copy_sync(ctx->stream, ctx->rc_f64.p, rcd.data(), nrc * 8, hipMemcpyHostToDevice));
   {
     auto inv2k = [](int k) { return F::from_u64(uint64_t(1) << k).inv(); };
     const F two = F::from_canonical(2), three = F::from_canonical(3), four = F::from_canonical(4);

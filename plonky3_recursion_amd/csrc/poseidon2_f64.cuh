@@ -1,0 +1,184 @@
+// Poseidon2 width-16 permutation in FP64, device only: the throughput form used by MMCS leaf
+// hashing and the wide 2-to-1 layers (one permutation per lane).
+//
+// Why FP64 for an integer permutation.  gfx950 issues v_add_f64 / v_mul_f64 / v_fma_f64 at the
+// full DP rate (tools/microbench: profiles/r02/op_rates.txt), and an integer-valued double holds
+// 53 bits, so the linear layers need NO modular reduction: a field addition is ONE instruction
+// instead of three (add, sub, min on a 31-bit modulus in a 32-bit word has one bit of headroom),
+// `d*s + sum` with a small integer d is one FMA, and the multiplications by 2^-k of the internal
+// diagonal are three instructions (below).  Only the S-box reduces, and its reduction also
+// absorbs whatever the linear layers accumulated.  Same round structure and constants as
+// poseidon2.h; values are exact integers throughout, so the result is the same field element.
+//
+// Representation: a state element is a double holding an INTEGER congruent to the CANONICAL value
+// (not the Montgomery form: the plain product of two Montgomery forms is not one), of either sign,
+// magnitude < 2^53.  p2f_load / p2f_store convert from / to the Montgomery u32 of field.h.
+//
+// Exactness (every step below is exact integer arithmetic, |.| < 2^53):
+//   mulmod(a, b):   h = fl(a*b); l = fma(a, b, -h) is the exact residual (an integer);
+//                   q = rint(h / P) (as h/P + 1.5 2^52 - 1.5 2^52); r = fma(-q, P, h) is exact because h - q*P is an integer of
+//                   magnitude < P; r + l is the product reduced to |.| < 0.7 P.  Holds for
+//                   |a*b| < 2^82 (the error of q stays below 1/4).
+//   x / 2^k:        for 2^k | P - 1 and ANY integer x:  x / 2^k  =  t - frac(t) * P  with t = x * 2^-k
+//                   (x = 2^k F + low  =>  x / 2^k = F - low (P-1) / 2^k  mod P,  frac(t) = low / 2^k):
+//                   v_mul_f64, v_fract_f64, v_fma_f64.  |result| <= |x| / 2^k + P.
+//   growth:         the sum of a partial round is reduced (3 instructions), so a round adds at most
+//                   0.7 P to a lane after its diagonal factor (|d| <= 4); the lanes with |d| >= 2 are
+//                   reduced every 5 partial rounds (4^5 = 2^10 on top of 2^36).
+#pragma once
+#include "poseidon2.h"
+
+namespace p3r {
+
+template <class PP>
+struct P2F64 {
+  static constexpr double P = (double)PP::P;
+  static constexpr double INVP = 1.0 / (double)PP::P;
+  // x + MAGIC - MAGIC = x rounded to the nearest integer for |x| < 2^51: two full-rate instructions
+  // (the first one fused with the product that forms x); v_rndne_f64 issues at half the DP rate.
+  static constexpr double MAGIC = 0x1.8p52;
+};
+#pragma clang fp contract(off)
+
+template <class PP>
+__device__ __forceinline__ double p2f_quot(double x) {
+  return __builtin_fma(x, P2F64<PP>::INVP, P2F64<PP>::MAGIC) - P2F64<PP>::MAGIC;
+}
+
+// a * b mod P, |result| < 0.7 P
+template <class PP>
+__device__ __forceinline__ double p2f_mulmod(double a, double b) {
+  const double h = a * b;
+  const double l = __builtin_fma(a, b, -h);
+  const double q = p2f_quot<PP>(h);
+  const double r = __builtin_fma(-q, P2F64<PP>::P, h);
+  return r + l;
+}
+// x mod P, |result| <= 0.5 P (+ rounding slack)
+template <class PP>
+__device__ __forceinline__ double p2f_reduce(double x) {
+  const double q = p2f_quot<PP>(x);
+  return __builtin_fma(-q, P2F64<PP>::P, x);
+}
+// x * m mod P where m = +-2^-k, 2^k | P - 1
+template <class PP>
+__device__ __forceinline__ double p2f_mul_2exp_neg(double x, double m) {
+  const double t = x * m;
+  const double f = __builtin_amdgcn_fract(t);
+  return __builtin_fma(-f, P2F64<PP>::P, t);
+}
+
+template <class PP>
+__device__ __forceinline__ double p2f_sbox(double x) {
+  const double x2 = p2f_mulmod<PP>(x, x);
+  const double x3 = p2f_mulmod<PP>(x2, x);
+  if (PP::SBOX_DEGREE == 3) return x3;
+  const double x6 = p2f_mulmod<PP>(x3, x3);
+  return p2f_mulmod<PP>(x6, x);
+}
+
+__device__ __forceinline__ void p2f_mat4(double& x0, double& x1, double& x2, double& x3) {
+  const double t01 = x0 + x1, t23 = x2 + x3;
+  const double t0123 = t01 + t23;
+  const double t01123 = t0123 + x1;
+  const double t01233 = t0123 + x3;
+  const double n3 = __builtin_fma(x0, 2.0, t01233);
+  const double n1 = __builtin_fma(x2, 2.0, t01123);
+  const double n0 = t01123 + t01;
+  const double n2 = t01233 + t23;
+  x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+}
+// |out| <= 35 max|in|
+__device__ __forceinline__ void p2f_external_linear(double* s) {
+#pragma unroll
+  for (int i = 0; i < P2_WIDTH; i += 4) p2f_mat4(s[i], s[i + 1], s[i + 2], s[i + 3]);
+  double sum[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sum[k] = (s[k] + s[4 + k]) + (s[8 + k] + s[12 + k]);
+#pragma unroll
+  for (int i = 0; i < P2_WIDTH; ++i) s[i] += sum[i & 3];
+}
+
+// Diagonal of the internal layer as FP64 factors (poseidon2.h: p2_internal_linear); entries that
+// are integers are applied by one FMA, the 2^-k ones by p2f_mul_2exp_neg.
+template <class PP>
+__device__ __forceinline__ void p2f_internal_linear(double* s, bool reduce_wide) {
+  if (reduce_wide) {
+    s[2] = p2f_reduce<PP>(s[2]);
+    s[4] = p2f_reduce<PP>(s[4]);
+    s[5] = p2f_reduce<PP>(s[5]);
+    s[7] = p2f_reduce<PP>(s[7]);
+    s[8] = p2f_reduce<PP>(s[8]);
+  }
+  double part = ((s[1] + s[2]) + (s[3] + s[4])) + ((s[5] + s[6]) + (s[7] + s[8]));
+  part += ((s[9] + s[10]) + (s[11] + s[12])) + ((s[13] + s[14]) + s[15]);
+  const double sum = p2f_reduce<PP>(part + s[0]);
+  s[0] = __builtin_fma(s[0], -2.0, sum);
+  s[1] = s[1] + sum;
+  s[2] = __builtin_fma(s[2], 2.0, sum);
+  s[3] = p2f_mul_2exp_neg<PP>(s[3], 0.5) + sum;
+  s[4] = __builtin_fma(s[4], 3.0, sum);
+  s[5] = __builtin_fma(s[5], 4.0, sum);
+  s[6] = p2f_mul_2exp_neg<PP>(s[6], -0.5) + sum;
+  s[7] = __builtin_fma(s[7], -3.0, sum);
+  s[8] = __builtin_fma(s[8], -4.0, sum);
+  s[9] = p2f_mul_2exp_neg<PP>(s[9], 0x1p-8) + sum;
+  if (PP::FIELD_ID == 0) {
+    s[10] = p2f_mul_2exp_neg<PP>(s[10], 0x1p-3) + sum;
+    s[11] = p2f_mul_2exp_neg<PP>(s[11], 0x1p-24) + sum;
+    s[12] = p2f_mul_2exp_neg<PP>(s[12], -0x1p-8) + sum;
+    s[13] = p2f_mul_2exp_neg<PP>(s[13], -0x1p-3) + sum;
+    s[14] = p2f_mul_2exp_neg<PP>(s[14], -0x1p-4) + sum;
+    s[15] = p2f_mul_2exp_neg<PP>(s[15], -0x1p-24) + sum;
+  } else {
+    s[10] = p2f_mul_2exp_neg<PP>(s[10], 0x1p-2) + sum;
+    s[11] = p2f_mul_2exp_neg<PP>(s[11], 0x1p-3) + sum;
+    s[12] = p2f_mul_2exp_neg<PP>(s[12], 0x1p-27) + sum;
+    s[13] = p2f_mul_2exp_neg<PP>(s[13], -0x1p-8) + sum;
+    s[14] = p2f_mul_2exp_neg<PP>(s[14], -0x1p-4) + sum;
+    s[15] = p2f_mul_2exp_neg<PP>(s[15], -0x1p-27) + sum;
+  }
+}
+
+// `rc`: the flat constant table of poseidon2.h as CANONICAL doubles.
+// In: integers of magnitude < 2^36.  Out: integers of magnitude < 2^36 (35 * 0.7 P), not reduced.
+template <class PP>
+__device__ __forceinline__ void p2f_permute(double* s, const double* __restrict__ rc) {
+  p2f_external_linear(s);
+  int k = 0;
+  for (int r = 0; r < P2_HALF_FULL; ++r) {
+#pragma unroll
+    for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i]);
+    k += P2_WIDTH;
+    p2f_external_linear(s);
+  }
+  for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
+    s[0] = p2f_sbox<PP>(s[0] + rc[k + r]);
+    p2f_internal_linear<PP>(s, r % 5 == 0);
+  }
+  k += PP::PARTIAL_ROUNDS;
+  for (int r = 0; r < P2_HALF_FULL; ++r) {
+#pragma unroll
+    for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i]);
+    k += P2_WIDTH;
+    p2f_external_linear(s);
+  }
+}
+
+// Montgomery u32 (field.h) -> canonical integer in a double: one REDC, one conversion.
+template <class PP>
+__device__ __forceinline__ double p2f_load(uint32_t mont) {
+  using F = Fp<PP>;
+  return (double)F::reduce64_lazy((uint64_t)mont);
+}
+// Any state element (|x| < 2^40) -> fully reduced Montgomery u32: x * 2^32 mod P.
+template <class PP>
+__device__ __forceinline__ uint32_t p2f_store(double x) {
+  const double r = p2f_reduce<PP>(x * 0x1p32);
+  const int32_t v = (int32_t)r;
+  return (uint32_t)(v + ((v >> 31) & (int32_t)PP::P));
+}
+
+#pragma clang fp contract(fast)
+
+}  // namespace p3r

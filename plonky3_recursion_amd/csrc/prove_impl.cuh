@@ -55,7 +55,7 @@ void build_plain_layers(p3r_ctx* ctx, p3r_tree* tree, size_t n_leaves, Transcrip
     const size_t nn = n / 2;
     DevBuf next(P2_DIGEST * nn);
     const uint32_t* prev = tree->layers.back().p;
-    launch_compress<PP>(ctx, prev, n, 2, 0, prev, n, 2, 1, next.p, nn);
+    launch_compress<PP>(ctx, prev, nullptr, next.p, nn);
     tree->layers.push_back(std::move(next));
     n = nn;
   }
@@ -588,7 +588,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
                              ctx->p2_diag.p);
         else
           hipLaunchKernelGGL(k_mmcs_hash_rows_strided<PP>, dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream,
-                             dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p, ctx->rc.p);
+                             dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p, ctx->rcd());
       }
       P3R_HIP(hipGetLastError());
     }
