@@ -132,8 +132,9 @@ def pmc_traffic_bytes(kernel):
 
 
 def cpu_baseline(field, log_h):
-    """The CPU oracle (kind 'port', single thread): run the circuit, prove its tables, same table
-    mix at a bounded size."""
+    """The CPU oracle (kind 'port', OpenMP over the host cores: rows of a commit, columns of an LDE,
+    rows of the LogUp / quotient / reduced-opening passes): run the circuit, prove its tables, same
+    table mix at a bounded size.  Returns (seconds, circuit-run seconds, threads)."""
     import circuit_lib
     import harness_lib
     import layer_lib
@@ -150,7 +151,38 @@ def cpu_baseline(field, log_h):
     L.prep_commit()  # preprocessed commitment is cached in the reference too (NextLayerPrepCache)
     t0 = time.perf_counter()
     L.prove()
-    return run_s + (time.perf_counter() - t0), run_s
+    return run_s + (time.perf_counter() - t0), run_s, int(orc.lib.orc_num_threads())
+
+
+def small_layers(ctx, p3r, wl, packing, field, sizes=(14, 15, 16), steps=20):
+    """The reference's real verifier circuits have 2^14..2^16 rows:
+    the same step at those sizes, each proof verified natively."""
+    import harness_lib
+    out = {}
+    for lh in sizes:
+        arrs = harness_lib.generate(field, lh, seed=0x5EED0000, **GEN_KNOBS)
+        cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(arrs), p3r.FriRecursionBackend(),
+                                          p3r.ProveNextLayerParams(table_packing=packing))
+        pc = cache.prepared_circuit
+        res = pc.upload_inputs(wl.circuit_inputs_from_arrays(arrs))
+        proof = pc.prove(res)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            proof = pc.prove(res)
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        try:
+            cache.prover.verify_all_tables(cache.prover.wrap_proof(proof, pc.circuit_prover_data))
+            ok = True
+        except Exception as e:
+            print(f"bench: small layer 2^{lh}: proof rejected: {e}", file=sys.stderr)
+            ok = False
+        out[str(lh)] = {"ms_per_step": ms, "steps": steps, "proof_bytes": len(proof), "proof_verified": ok,
+                        "table_heights": pc.circuit_prover_data.table_heights}
+        res.free()
+        pc.free()
+    return out
 
 
 def main():
@@ -161,7 +193,8 @@ def main():
     ap.add_argument("--log-height", type=int, default=20)
     ap.add_argument("--field", default="koala-bear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-log-height", type=int, default=13)
+    ap.add_argument("--cpu-baseline-log-height", type=int, default=16)
+    ap.add_argument("--no-small-layers", action="store_true", help="skip the 2^14/2^15/2^16-row layers")
     ap.add_argument("--no-config2", action="store_true",
                     help="skip the secondary measurement with BASELINE config 2's chain-length knobs")
     args = ap.parse_args()
@@ -200,7 +233,6 @@ def main():
     cpd, pc = cache.circuit_prover_data, cache.prepared_circuit
     resident = pc.upload_inputs(wl.circuit_inputs_from_arrays(arrs))
     counts = [int(x) for x in arrs["counts"]] + [len(arrs["ops"]) // 8]
-    del arrs
 
     def barrier():
         ctx.sync()
@@ -233,6 +265,33 @@ def main():
                 assert len(got) == world
         except Exception as e:  # never let the hand-off demo break the measurement
             handoff_ms = f"failed: {e}"
+    # What was timed is checked: the last proof of the timed region goes through verify_all_tables
+    # (batch_stark_prover.rs:1230-1268; native host verifier of the C-ABI library), as every layer
+    # does in recursion/examples/recursive_fibonacci.rs:444-454.  A rejected proof fails the run.
+    import hashlib
+    proof_sha256 = hashlib.sha256(last_proof).hexdigest()
+    v0 = time.perf_counter()
+    try:
+        cache.prover.verify_all_tables(cache.prover.wrap_proof(last_proof, cpd))
+        proof_verified = True
+    except Exception as e:
+        print(f"bench: rank {rank}: the timed proof was REJECTED by verify_all_tables: {e}", file=sys.stderr)
+        proof_verified = False
+    verify_ms = (time.perf_counter() - v0) * 1e3
+    # the same step with the circuit inputs handed over from host memory (public values + Merkle
+    # siblings cross PCIe inside the call) - not `value`, reported next to it
+    host_inputs = wl.circuit_inputs_from_arrays(arrs)
+    same = pc.prove(host_inputs) == last_proof
+    ctx.sync()
+    h0 = time.perf_counter()
+    for _ in range(3):
+        pc.prove(host_inputs)
+    ctx.sync()
+    incl_h2d_ms = (time.perf_counter() - h0) / 3 * 1e3
+    if not same:
+        print("bench: host-input proof differs from the resident-input proof", file=sys.stderr)
+        proof_verified = False
+    del host_inputs
     # per-kernel-family times come from two EXTRA steps with HIP-event bracketing switched on, so
     # the event overhead is not inside `value`
     prof_steps = 2
@@ -243,10 +302,34 @@ def main():
     ctx.profile_enable(False)
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
+        t = torch.tensor([dt, 0.0 if proof_verified else 1.0], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        proof_verified = proof_verified and float(t[1].item()) == 0.0
     ms_per_step = dt / args.steps * 1e3
+
+    # prep-cache miss (recursion.rs:452-501, prep=None): preprocessed columns + LDE + commitment are
+    # rebuilt from the circuit before the proof; once, on rank 0 at N = 1
+    prep_miss_ms = None
+    small = {}
+    if rank == 0 and world == 1:
+        circ = wl.circuit_from_arrays(arrs)
+        hin = wl.circuit_inputs_from_arrays(arrs)
+        ctx.sync()
+        m0 = time.perf_counter()
+        cache2 = p3r.build_next_layer_prep(ctx, circ, p3r.FriRecursionBackend(),
+                                           p3r.ProveNextLayerParams(table_packing=packing))
+        miss_proof = cache2.prepared_circuit.prove(hin)
+        ctx.sync()
+        prep_miss_ms = (time.perf_counter() - m0) * 1e3
+        if miss_proof != last_proof:
+            print("bench: prep-miss proof differs from the cached-prep proof", file=sys.stderr)
+            proof_verified = False
+        cache2.prepared_circuit.free()
+        del circ, hin, cache2
+        if not args.no_small_layers:
+            small = small_layers(ctx, p3r, wl, packing, field)
+    del arrs
 
     if rank == 0:
         p2w = ctx.poseidon2_trace_width
@@ -288,6 +371,12 @@ def main():
                 "fri": FRI, "independent_proofs": world, "proof_bytes": proof_len,
                 "parallelism": f"{world} independent proofs, one per GPU, no data-path collective",
             },
+            "proof_verified": proof_verified,
+            "proof_sha256": proof_sha256,
+            "proof_verify_ms": verify_ms,
+            "value_incl_h2d_ms": incl_h2d_ms,
+            "prep_miss_ms": prep_miss_ms,
+            "small_layers": small or None,
             "root_handoff_ms": handoff_ms,
             "poseidon2_perms_per_s": perms * world / (ms_per_step * 1e-3),
             "poseidon2_perms_per_step": perms,
@@ -327,12 +416,14 @@ def main():
         line["hbm_families"] = hbm_families(cpd.table_heights, widths, packing, kernel_ms)
         if not args.no_cpu_baseline and world == 1:
             lh = args.cpu_baseline_log_height
-            cdt, crun = cpu_baseline(field, lh)
+            cdt, crun, cores = cpu_baseline(field, lh)
             line["cpu_baseline"] = {
-                "value": cdt * 1e3, "unit": "ms", "cores": 1, "kind": "port",
-                "sample": f"same prove_next_layer (circuit run + prove, same table mix, same FRI parameters) at 2^{lh} "
-                          f"rows = 1/{1 << (log_h - lh)} of the workload, oracle/ C++ restatement, 1 thread",
+                "value": cdt * 1e3, "unit": "ms", "cores": cores, "kind": "port",
+                "sample": f"same prove_next_layer (circuit run + prove, same table mix, same FRI parameters, same "
+                          f"synthetic generator) at 2^{lh} rows = 1/{1 << (log_h - lh)} of the workload, oracle/ C++ "
+                          f"restatement, OpenMP on {cores} threads (the circuit run is sequential, as in the reference)",
                 "circuit_run_ms": crun * 1e3,
+                "gpu_ms_same_sample": small.get(str(lh), {}).get("ms_per_step") if small else None,
             }
         if not args.no_config2 and world == 1:
             # secondary, on rank 0 at N = 1 only: the same step over a circuit with config 2's knobs
@@ -370,6 +461,8 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if not proof_verified:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -291,12 +291,15 @@ p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const
  * `BatchStarkProver::verify_all_tables` calls it (circuit-prover/src/batch_stark_prover.rs:1230-1268,
  * 1649-1727), for proofs made with the same p3r_config.  `airs` are the proved tables in instance
  * order, `preprocessed_commitment` the (1 << cap_height) x 8 canonical digests of the
- * CircuitProverData.  Host code, no device and no p3r_ctx needed.  Returns P3R_OK when the proof
+ * CircuitProverData, `degree_bits[i]` the log2 trace height the verifier's preprocessed metadata
+ * holds for instance i (CommonData.preprocessed.instances[i].degree_bits): a proof declaring any
+ * other degree is rejected as recursion/src/verifier/batch_stark.rs:793 does (InvalidProofShape) -
+ * the prover must not choose the domains.  Host code, no device and no p3r_ctx needed.  Returns P3R_OK when the proof
  * is accepted; otherwise an error code and the reason in err_buf (the analogue of
  * BatchStarkProverError::Verify(String)). */
 int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_airs,
-                     const uint32_t* preprocessed_commitment, const uint8_t* proof, size_t proof_len, uint32_t flags,
-                     char* err_buf, size_t err_cap);
+                     const uint32_t* preprocessed_commitment, const uint32_t* degree_bits, const uint8_t* proof,
+                     size_t proof_len, uint32_t flags, char* err_buf, size_t err_cap);
 
 /* Length of the postcard-encoded `BatchProof` at the head of `bytes` (what p3r_prove_* return; the
  * serialised `BatchStarkProof` continues with its metadata, batch_stark_prover.rs:610-636). */

@@ -264,9 +264,19 @@ struct BatchStarkProof {
 inline void verify_all_tables(const p3r_config& cfg, const BatchStarkProof& proof) {
   proof.validate();
   if (proof.preprocessed_commitment.empty()) throw Error(P3R_EINVAL, "proof carries no preprocessed commitment (stark_common)");
+  // the proof's extension metadata must be the verifier's (batch_stark_prover.rs:1245-1263)
+  if (proof.ext_degree != 4)
+    throw Error(P3R_EINVAL, "ExtDegreeMismatch: proof has ext_degree " + std::to_string(proof.ext_degree) + ", the verifier expects 4");
+  const uint32_t want_w = cfg.field == P3R_FIELD_KOALA_BEAR ? 3u : 11u;
+  if (!proof.w_binomial || *proof.w_binomial != want_w) throw Error(P3R_EINVAL, "BinomialWMismatch");
+  if (proof.alu_quintic_trinomial) throw Error(P3R_EINVAL, "QuinticReductionMismatch");
   auto airs = proof.airs();
+  if (proof.degree_bits.size() != airs.size() || proof.preprocessed_widths.size() != airs.size())
+    throw Error(P3R_EINVAL, "InvalidProofShape: AIR list and stark_common metadata differ in length");
+  std::vector<uint32_t> degree_bits(proof.degree_bits.begin(), proof.degree_bits.end());
   char err[512] = {0};
-  int rc = p3r_verify_batch(&cfg, airs.data(), airs.size(), proof.preprocessed_commitment.data(), proof.proof.data(),
+  int rc = p3r_verify_batch(&cfg, airs.data(), airs.size(), proof.preprocessed_commitment.data(), degree_bits.data(),
+                            proof.proof.data(),
                             proof.proof.size(), proof.montgomery_field_encoding ? 0 : P3R_PROVE_CANONICAL_FIELD_ENCODING, err,
                             sizeof err);
   if (rc != P3R_OK) throw Error(rc, std::string("Verify(") + err + ")");

@@ -2,6 +2,8 @@
 // and bench.py's cpu_baseline leg can drive the CPU restatement through ctypes.
 // Nothing in the product (plonky3_recursion_amd/) may link or load this library.
 // PARITY UNPINNED (see field.hpp).
+#include <omp.h>
+
 #include <cstring>
 #include <memory>
 #include <string>
@@ -175,6 +177,8 @@ void do_ext_ops(const uint32_t* a, const uint32_t* b, uint32_t* mul, uint32_t* i
 extern "C" {
 
 const char* orc_last_error() { return g_err.c_str(); }
+// threads the OpenMP loops of the oracle run on (cpu_baseline.cores in bench.py)
+int orc_num_threads() { return omp_get_max_threads(); }
 void orc_set_error(const char* s) { g_err = s; }
 
 int orc_p2_trace_width(int field) { return field == 0 ? Poseidon2<KoalaBear>::perm_cols() + 2 : Poseidon2<BabyBear>::perm_cols() + 2; }

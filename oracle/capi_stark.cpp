@@ -230,6 +230,35 @@ int orc_layer_prove(void* h, const orc_params* p, int field_encoding, uint8_t** 
 }
 void orc_bytes_free(uint8_t* b) { free(b); }
 // verify_batch against this layer's AIR shapes; returns 0 iff the proof is accepted
+// verify_batch from the statement alone (AIR descriptors, no tables): what a verifier holds.
+// airs4[i] = {kind, lanes, horner_packed_steps, coeff_lookups}.  Used for layers whose tables the
+// CPU would take minutes to rebuild (2^20 / 2^22 rows).
+int orc_verify_batch(int field, const uint32_t* rc, const orc_params* p, size_t n_airs, const uint32_t* airs4,
+                     const uint32_t* prep_cap, const uint8_t* bytes, size_t len, int field_encoding) {
+  return guard2([&] {
+    auto run = [&](auto tag) {
+      using FP = decltype(tag);
+      using F = Fe<FP>;
+      Poseidon2<FP> p2(rc);
+      auto proof = deserialize_proof<FP>(bytes, len, field_encoding);
+      std::vector<InstanceShape> shapes;
+      for (size_t i = 0; i < n_airs; ++i) {
+        AirDesc a;
+        a.kind = (int)airs4[4 * i]; a.lanes = (int)airs4[4 * i + 1]; a.horner_k = (int)airs4[4 * i + 2];
+        a.coeff_lookups = (int)airs4[4 * i + 3];
+        shapes.push_back({a});
+      }
+      typename BatchProof<FP>::Cap cap(size_t(1) << p->cap_height);
+      const uint32_t* c = prep_cap;
+      for (auto& d : cap) for (auto& x : d) x = F(*c++);
+      verify_batch<FP>(p2, to_sp(*p), shapes, cap, proof);
+    };
+    if (field == 0) run(KoalaBear{});
+    else if (field == 1) run(BabyBear{});
+    else throw std::runtime_error("unknown field id");
+  });
+}
+
 int orc_layer_verify(const void* h, const orc_params* p, const uint32_t* prep_cap, const uint8_t* bytes,
                      size_t len, int field_encoding) {
   return guard2([&] { static_cast<const LayerBase*>(h)->verify(*p, prep_cap, bytes, len, field_encoding); });

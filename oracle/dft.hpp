@@ -73,6 +73,7 @@ Matrix<FP> coset_lde_bitrev(const Matrix<FP>& evals, int added_bits, Fe<FP> shif
   const size_t h = evals.h, m = h << added_bits;
   const int lm = log2_strict(m);
   Matrix<FP> out(m, evals.w);
+#pragma omp parallel for schedule(dynamic) if (h >= 1024)
   for (size_t c = 0; c < evals.w; ++c) {
     std::vector<F> col(h);
     for (size_t r = 0; r < h; ++r) col[r] = evals.at(r, c);

@@ -231,12 +231,15 @@ struct MerkleTree {
       return false;
     };
     std::vector<Digest> cur(hmax);
+    // rows and nodes of one layer are independent: OpenMP over them (cpu_baseline, bench.py)
+#pragma omp parallel for schedule(static) if (hmax >= 1024)
     for (size_t i = 0; i < hmax; ++i) cur[i] = p2.hash(rows_at(hmax, i));
     t.layers.push_back(cur);
     while (cur.size() > (size_t(1) << cap_height)) {
       size_t nn = cur.size() / 2;
       std::vector<Digest> nxt(nn);
       bool inj = any_at(nn);
+#pragma omp parallel for schedule(static) if (nn >= 1024)
       for (size_t i = 0; i < nn; ++i) {
         nxt[i] = p2.compress(cur[2 * i], cur[2 * i + 1]);
         if (inj) nxt[i] = p2.compress(nxt[i], p2.hash(rows_at(nn, i)));

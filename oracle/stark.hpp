@@ -231,6 +231,7 @@ template <class FP>
 std::vector<Fe4<FP>> open_matrix(const Matrix<FP>& evals, Fe<FP> dshift, Fe4<FP> z) {
   std::vector<Fe4<FP>> out(evals.w);
   Fe4<FP> zz = z * dshift.inv();
+#pragma omp parallel for schedule(dynamic) if (evals.h >= 1024)
   for (size_t c = 0; c < evals.w; ++c) {
     std::vector<Fe<FP>> col(evals.h);
     for (size_t r = 0; r < evals.h; ++r) col[r] = evals.at(r, c);
@@ -368,6 +369,7 @@ void fri_commit_phase(const Poseidon2<FP>& p2, const StarkParams& sp, std::vecto
     proof.commit_pow_witnesses.push_back(ch.grind(sp.commit_pow_bits));
     EF beta = ch.sample_ext();
     std::vector<EF> nf(rows);
+#pragma omp parallel for schedule(static) if (rows >= 1024)
     for (size_t r = 0; r < rows; ++r) {
       std::vector<EF> e(folded.begin() + r * arity, folded.begin() + (r + 1) * arity);
       nf[r] = fold_row<FP>(e, r, log_cur - la, la, beta);
@@ -463,7 +465,8 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     const size_t n = in.main.h;
     const int aw = L.aux_width();
     aux[i].flat = Matrix<FP>(n, aw * 4);
-    EF run = EF::zero();
+    // the fractions of a row depend on that row only (parallel); the running sum is a serial prefix
+#pragma omp parallel for schedule(static) if (n >= 1024)
     for (size_t r = 0; r < n; ++r) {
       EvalCtx<FP, F> b;
       size_t rn = (r + 1) % n;
@@ -472,7 +475,6 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
       b.record_constraints = false;
       b.is_first = b.is_last = b.is_transition = F::zero();
       eval_air<FP, F>(in.air, p2, b);
-      for (int k = 0; k < 4; ++k) aux[i].flat.at(r, k) = run.c[k];
       for (size_t g = 0; g < L.groups.size(); ++g) {
         EF f = EF::zero();
         for (int m : L.groups[g]) {
@@ -480,6 +482,14 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
           if (it.mult.v != 0) f += lookup_denom_f<FP>(lc, it.fields).inv() * it.mult;
         }
         for (int k = 0; k < 4; ++k) aux[i].flat.at(r, (g + 1) * 4 + k) = f.c[k];
+      }
+    }
+    EF run = EF::zero();
+    for (size_t r = 0; r < n; ++r) {
+      for (int k = 0; k < 4; ++k) aux[i].flat.at(r, k) = run.c[k];
+      for (size_t g = 0; g < L.groups.size(); ++g) {
+        EF f;
+        for (int k = 0; k < 4; ++k) f.c[k] = aux[i].flat.at(r, (g + 1) * 4 + k);
         run += f;
       }
     }
@@ -523,9 +533,15 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     if (perm_pos >= 0) aq = on_q(perm_c.ldes[perm_pos]);
     Matrix<FP> qflat(qn, 4);
     const F wq = F::two_adic_generator(log_n[i] + lq);
-    F x = gen;
     const int aw = L.aux_width();
-    for (size_t r = 0; r < qn; ++r, x *= wq) {
+    std::vector<F> xs(qn);
+    {
+      F x = gen;
+      for (size_t r = 0; r < qn; ++r, x *= wq) xs[r] = x;
+    }
+#pragma omp parallel for schedule(static) if (qn >= 1024)
+    for (size_t r = 0; r < qn; ++r) {
+      const F x = xs[r];
       size_t rn = (r + C) % qn;
       EvalCtx<FP, F> b;
       b.local = &mq.v[r * mq.w]; b.next = &mq.v[rn * mq.w];
@@ -616,6 +632,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     auto& e = ros[lh];
     if (e.second.empty()) { e.first = EF::one(); e.second.assign(lde.h, EF::zero()); }
     const F wl = F::two_adic_generator(lh);
+#pragma omp parallel for schedule(static) if (lde.h >= 1024)
     for (size_t r = 0; r < lde.h; ++r) {
       F x = gen * wl.pow(bitrev((uint32_t)r, lh));
       EF inv = (it.z - EF(x)).inv();

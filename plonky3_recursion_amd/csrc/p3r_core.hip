@@ -999,13 +999,13 @@ p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const
 
 // ---- native verifier (verify_impl.h): host code, no device needed ----
 int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_airs,
-                     const uint32_t* preprocessed_commitment, const uint8_t* proof, size_t proof_len, uint32_t flags,
-                     char* err_buf, size_t err_cap) {
+                     const uint32_t* preprocessed_commitment, const uint32_t* degree_bits, const uint8_t* proof,
+                     size_t proof_len, uint32_t flags, char* err_buf, size_t err_cap) {
   auto report = [&](const char* msg) {
     if (err_buf && err_cap) snprintf(err_buf, err_cap, "%s", msg);
   };
   try {
-    if (!cfg || !airs || !preprocessed_commitment || (!proof && proof_len)) { report("NULL argument"); return P3R_EINVAL; }
+    if (!cfg || !airs || !preprocessed_commitment || !degree_bits || (!proof && proof_len)) { report("NULL argument"); return P3R_EINVAL; }
     if (cfg->abi_version != P3R_ABI_VERSION) { report("ABI version mismatch"); return P3R_EINVAL; }
     if (cfg->ext_degree != 4) { report("UnsupportedDegree"); return P3R_EUNSUPPORTED; }
     p3r::VerifyParams prm{(int)cfg->log_blowup, (int)cfg->max_log_arity, (int)cfg->cap_height, (int)cfg->log_final_poly_len,
@@ -1017,13 +1017,14 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     }
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     std::vector<uint32_t> cap(preprocessed_commitment, preprocessed_commitment + ((size_t)P2_DIGEST << cfg->cap_height));
+    const std::vector<uint32_t> want_db(degree_bits, degree_bits + n_airs);
     auto run = [&](auto tag) {
       using PP = decltype(tag);
       const size_t nrc = p2_num_constants<PP>();
       const uint32_t* src = cfg->poseidon2_rc;
       if (src && cfg->poseidon2_rc_len != nrc) p3r::vfail("poseidon2_rc_len is %u, the field needs %zu constants", cfg->poseidon2_rc_len, nrc);
       if (!src) src = PP::FIELD_ID == 0 ? kDefaultRc_koala_bear : kDefaultRc_baby_bear;
-      p3r::verify_batch<PP>(prm, std::vector<uint32_t>(src, src + nrc), a, cap, proof, proof_len, canonical);
+      p3r::verify_batch<PP>(prm, std::vector<uint32_t>(src, src + nrc), a, cap, want_db, proof, proof_len, canonical);
     };
     if (cfg->field == P3R_FIELD_KOALA_BEAR) run(p3r::KoalaBearParams{});
     else if (cfg->field == P3R_FIELD_BABY_BEAR) run(p3r::BabyBearParams{});

@@ -308,7 +308,8 @@ struct VerifyParams {
 
 template <class PP>
 void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canonical, const std::vector<AirParams>& airs,
-                  const std::vector<uint32_t>& prep_cap_canonical, const uint8_t* bytes, size_t n_bytes, bool canonical) {
+                  const std::vector<uint32_t>& prep_cap_canonical, const std::vector<uint32_t>& expected_degree_bits,
+                  const uint8_t* bytes, size_t n_bytes, bool canonical) {
   using F = Fp<PP>;
   using E = Fp4<PP>;
   using Digest = std::array<F, P2_DIGEST>;
@@ -335,6 +336,10 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
     const auto& in = P.insts[i];
     layouts[i] = lookup_layout(airs[i]);
     log_n[i] = P.degree_bits[i];
+    // the domains are the verifier's, not the prover's: recursion/src/verifier/batch_stark.rs:793
+    if (expected_degree_bits.size() != ni || (uint32_t)log_n[i] != expected_degree_bits[i])
+      vfail("InvalidProofShape: instance %zu declares degree_bits %d, the preprocessed metadata has %u", i, log_n[i],
+            i < expected_degree_bits.size() ? expected_degree_bits[i] : 0u);
     if (log_n[i] + lb > PP::TWO_ADICITY) vfail("instance %zu: degree too large", i);
     width[i] = air_width_of(airs[i], p2w);
     prep_w[i] = air_prep_width_of(airs[i]);

@@ -58,10 +58,11 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
     return cfg, rc
 
 
-def verify_batch(cfg, airs, preprocessed_commitment, proof: bytes, canonical_field_encoding=False):
+def verify_batch(cfg, airs, preprocessed_commitment, degree_bits, proof: bytes, canonical_field_encoding=False):
     """`verify_batch` behind `verify_all_tables` (batch_stark_prover.rs:1649-1727): host code in the
     C-ABI library, no GPU needed.  `cfg` is a `p3r_config` (e.g. `Context.cfg`), `airs` a list of
-    dicts(kind, lanes, horner_packed_steps, coeff_lookups).  Raises P3rError with the verifier's
+    dicts(kind, lanes, horner_packed_steps, coeff_lookups), `degree_bits` the verifier-side log2 trace
+    height of every instance (the proof must declare the same).  Raises P3rError with the verifier's
     reason when the proof is rejected."""
     lib = _lib.load()
     arr = (_lib.P3rAirDesc * len(airs))()
@@ -71,9 +72,12 @@ def verify_batch(cfg, airs, preprocessed_commitment, proof: bytes, canonical_fie
     cap, cap_p = _u32(preprocessed_commitment)
     if cap.size != 8 << cfg.cap_height:
         raise P3rError(-1, "preprocessed commitment must hold %d digests" % (1 << cfg.cap_height))
+    if len(degree_bits) != len(airs):
+        raise P3rError(-1, "degree_bits must have one entry per AIR (%d given, %d AIRs)" % (len(degree_bits), len(airs)))
+    db, db_p = _u32(list(degree_bits) or [0])
     buf = (C.c_uint8 * max(len(proof), 1)).from_buffer_copy(proof if proof else b"\0")
     err = C.create_string_buffer(512)
-    rc = lib.p3r_verify_batch(C.byref(cfg), arr, len(airs), cap_p, buf, len(proof), 1 if canonical_field_encoding else 0,
+    rc = lib.p3r_verify_batch(C.byref(cfg), arr, len(airs), cap_p, db_p, buf, len(proof), 1 if canonical_field_encoding else 0,
                               err, len(err))
     if rc != 0:
         raise P3rError(rc, err.value.decode())

@@ -438,13 +438,26 @@ class BatchStarkProof:
 W_BINOMIAL = {"koala-bear": 3, "baby-bear": 11}
 
 
-def verify_all_tables(cfg, proof: BatchStarkProof, canonical_field_encoding=None):
-    """Verify a `BatchStarkProof` against the preprocessed commitment it binds itself to
-    (stark_common); `cfg` is the `p3r_config` the proof was made with.  No GPU needed."""
+def verify_all_tables(cfg, proof: BatchStarkProof, canonical_field_encoding=None, field=None):
+    """Verify a `BatchStarkProof` against the preprocessed commitment and per-instance metadata it binds
+    itself to (stark_common); `cfg` is the `p3r_config` the proof was made with.  No GPU needed.
+    The proof's extension metadata must be the verifier's (batch_stark_prover.rs:1245-1263:
+    ExtDegreeMismatch, BinomialWMismatch, QuinticReductionMismatch)."""
     if proof.preprocessed_commitment is None:
         raise P3rError(-1, "proof carries no preprocessed commitment (stark_common)")
+    if proof.ext_degree != 4:
+        raise P3rError(-1, "ExtDegreeMismatch: proof has ext_degree %d, the verifier expects 4" % proof.ext_degree)
+    field = field or {0: "koala-bear", 1: "baby-bear"}[int(cfg.field)]
+    if proof.w_binomial != W_BINOMIAL[field]:
+        raise P3rError(-1, "BinomialWMismatch: proof has W = %r, the verifier expects %d" % (proof.w_binomial, W_BINOMIAL[field]))
+    if proof.alu_quintic_trinomial:
+        raise P3rError(-1, "QuinticReductionMismatch: the D = 4 verifier has no quintic reduction")
+    airs = proof.airs()
+    if len(proof.preprocessed_widths) != len(airs) or len(proof.degree_bits) != len(airs):
+        raise P3rError(-1, "InvalidProofShape: %d AIRs, %d preprocessed widths, %d degree_bits"
+                       % (len(airs), len(proof.preprocessed_widths), len(proof.degree_bits)))
     canonical = (proof.monty_r == 0) if canonical_field_encoding is None else canonical_field_encoding
-    verify_batch(cfg, proof.airs(), proof.preprocessed_commitment, proof.proof, canonical)
+    verify_batch(cfg, airs, proof.preprocessed_commitment, proof.degree_bits, proof.proof, canonical)
 
 
 class BatchStarkProver:
@@ -466,7 +479,12 @@ class BatchStarkProver:
         else:
             t, keep = _traces_struct(traces)
             raw = self._call(ctx.lib.p3r_prove_all_tables, ctx.h, circuit_prover_data.h, C.byref(t), flags)
-        cpd = circuit_prover_data
+        return self.wrap_proof(raw, circuit_prover_data, canonical_field_encoding)
+
+    def wrap_proof(self, raw: bytes, cpd: CircuitProverData, canonical_field_encoding=False) -> BatchStarkProof:
+        """The `BatchStarkProof` around the inner `BatchProof` bytes of a layer: the metadata fields the
+        reference fills next to `proof` (batch_stark_prover.rs:610-636, 1597-1641)."""
+        ctx = self.ctx
         tp = cpd.effective_packing
         p2_name = "poseidon2_perm/%s_d4_w16" % ctx.field.replace("-", "_")   # circuit/src/ops/npo.rs:38
         k = tp.horner_packed_steps

@@ -42,7 +42,7 @@ def test_fibonacci_base_circuit_tables_prove_and_verify(oracle):
     L.verify(proof)
     cfg, keep = p3r.make_config(field, **{k: FRI[k] for k in FRI})
     airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
-    p3r.verify_batch(cfg, airs, L.prep_commit(), proof)
+    p3r.verify_batch(cfg, airs, L.prep_commit(), [int(t["main"].shape[0]).bit_length() - 1 for t in tables], proof)
     # the wrong expected_result is a WitnessConflict at run time (connect is enforced by the runner)
     bad = cl.Inputs(public_values=[(fib + 1) % P, 0, 0, 0])
     with pytest.raises(RuntimeError, match="WitnessConflict"):

@@ -13,12 +13,14 @@ import layer_lib
 SMALL = dict(horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
 
 
-def verify(field, prm, tables, cap, proof, canonical=False):
+def verify(field, prm, tables, cap, proof, canonical=False, degree_bits=None):
     import plonky3_recursion_amd as p3r
+    if degree_bits is None:  # the verifier's own metadata: log2 of every table's (padded) height
+        degree_bits = [int(t["main"].shape[0]).bit_length() - 1 for t in tables]
     cfg, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
                                 prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries)
     airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
-    p3r.verify_batch(cfg, airs, cap, proof, canonical)
+    p3r.verify_batch(cfg, airs, cap, degree_bits, proof, canonical)
 
 
 CASES = [
@@ -68,6 +70,17 @@ def test_native_verifier_accepts_oracle_proofs_and_rejects_tampering(oracle, fie
     prm2 = layer_lib.params(**dict(kw, num_queries=kw["num_queries"] + 1))
     with pytest.raises(p3r.P3rError):
         verify(field, prm2, tables, cap, proof)
+    # the trace domains are the verifier's (recursion/src/verifier/batch_stark.rs:793): a proof whose
+    # degree_bits differ from the preprocessed metadata is InvalidProofShape, whatever else it holds
+    db = [int(t["main"].shape[0]).bit_length() - 1 for t in tables]
+    for i in range(len(db)):
+        for delta in (1, -1):
+            other_db = list(db)
+            other_db[i] += delta
+            with pytest.raises(p3r.P3rError, match="InvalidProofShape"):
+                verify(field, prm, tables, cap, proof, degree_bits=other_db)
+    with pytest.raises(p3r.P3rError):
+        verify(field, prm, tables, cap, proof, degree_bits=db[:-1])
 
 
 def corrupt_and_prove(oracle, mutate):
@@ -124,6 +137,18 @@ def test_batch_stark_proof_wire_round_trip_and_verify(oracle, canonical):
     cfg, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
                                 prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries)
     p3r.verify_all_tables(cfg, back)
+    # the extension metadata must be the verifier's (batch_stark_prover.rs:1245-1263) and the
+    # stark_common degree_bits are what the inner proof has to declare
+    with pytest.raises(p3r.P3rError, match="ExtDegreeMismatch"):
+        p3r.verify_all_tables(cfg, dataclasses.replace(back, ext_degree=2))
+    with pytest.raises(p3r.P3rError, match="BinomialWMismatch"):
+        p3r.verify_all_tables(cfg, dataclasses.replace(back, w_binomial=11))
+    with pytest.raises(p3r.P3rError, match="QuinticReductionMismatch"):
+        p3r.verify_all_tables(cfg, dataclasses.replace(back, alu_quintic_trinomial=True))
+    with pytest.raises(p3r.P3rError, match="InvalidProofShape"):
+        p3r.verify_all_tables(cfg, dataclasses.replace(back, degree_bits=(back.degree_bits[0] + 1,) + tuple(back.degree_bits[1:])))
+    with pytest.raises(p3r.P3rError, match="InvalidProofShape"):
+        p3r.verify_all_tables(cfg, dataclasses.replace(back, degree_bits=tuple(back.degree_bits[:-1])))
     # metadata tampering: a zero lane count is refused at decode time, trailing bytes too
     bad_tp = dataclasses.replace(tp, alu_lanes=0)
     with pytest.raises(p3r.P3rError, match="ZeroLanes"):
