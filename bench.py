@@ -202,7 +202,7 @@ def main():
     import torch
     import harness_lib
     import plonky3_recursion_amd as p3r
-    from plonky3_recursion_amd import workload as wl
+    import harness_adapters as wl
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -18,10 +18,9 @@
 #include <string>
 #include <vector>
 
-#include "../plonky3_recursion_amd/csrc/field.h"
-#include "../plonky3_recursion_amd/csrc/poseidon2.h"
+#include "arith.h"  // the generator's own arithmetic: independent of the product and of the oracle
 
-using namespace p3r;
+using namespace syn;
 
 namespace {
 
@@ -66,8 +65,6 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   auto rf = [&]() { return F::from_canonical((uint32_t)(rng.next() % P)); };
   auto re = [&]() { E e; for (int i = 0; i < 4; ++i) e.c[i] = rf(); return e; };
 
-  std::vector<uint32_t> rc_m(p2_num_constants<PP>());
-  for (size_t i = 0; i < rc_m.size(); ++i) rc_m[i] = F::from_canonical(rc_canonical[i]).v;
 
   // ---- the circuit being built (flattened Circuit<EF>, include/p3r.h) ----
   auto& c_ops = W.arr["ops"];   // n x 8: kind, a, b, c, out, aux, ext_off, ext_len
@@ -252,7 +249,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
       if (acc_wid[r] >= 0) ext[4] = (uint32_t)acc_wid[r];
       for (int i = 0; i < 16; ++i) p2_inputs.push_back(in[i].to_canonical());
       for (int i = 0; i < 16; ++i) state[i] = in[i];
-      p2_permute<PP>(state, rc_m.data());
+      p2_permute<PP>(state, rc_canonical);
       const bool en = acc_wid[r] >= 0;
       p2_flags.push_back(p.new_start); p2_flags.push_back(p.merkle); p2_flags.push_back(p.bit);
       p2_flags.push_back(en);

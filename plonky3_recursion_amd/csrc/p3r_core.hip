@@ -598,6 +598,7 @@ void init_ctx(p3r_ctx* ctx) {
     if (src[i] >= PP::P) fail(P3R_EINVAL, "round constant %zu is not canonical", i);
     mont[i] = F::from_canonical(src[i]).v;
   }
+  ctx->rc_mont_host = mont;
   ctx->rc.alloc(nrc);
   P3R_HIP(copy_sync(ctx->stream, ctx->rc.p, mont.data(), nrc * 4, hipMemcpyHostToDevice));
   std::vector<double> rcd(src, src + nrc);
@@ -626,10 +627,10 @@ void init_ctx(p3r_ctx* ctx) {
 
 }  // namespace
 
+#include "verify_impl.h"
 #include "prove_impl.cuh"
 #include "layer_impl.cuh"
 #include "circuit_impl.cuh"
-#include "verify_impl.h"
 
 // =============================================================================== C ABI
 extern "C" {

@@ -450,6 +450,35 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   for (auto& it : items)
     for (auto& pv : it.vals)
       for (auto& v : pv) ch.observe_ext(v);
+  // Self-check before anything is serialised: the opened values must satisfy the verifier's
+  // out-of-domain identity, folded constraints(zeta) / Z_H(zeta) == quotient(zeta), per instance
+  // (the same routine the native verifier runs).  Traces that violate a constraint or unbalance a
+  // lookup fail it with overwhelming probability: P3R_EINVAL instead of an unverifiable proof -
+  // the counterpart of prove_batch's internal constraint check (include/p3r.h).  Host work of a few
+  // extension-field evaluations per table, done while the device computes the 1/(z - x) vectors.
+  {
+    E l_beta_pow[5];
+    for (int j = 0; j < 5; ++j) l_beta_pow[j] = e4_load<PP>(lc.beta_pow[j]);
+    const E l_prefix = e4_load<PP>(lc.prefix);
+    std::vector<std::vector<std::vector<E>>> inst_chunks(ni);
+    for (size_t k = 0; k < chunks.size(); ++k) inst_chunks[chunks[k].inst].push_back(o_chunks[k]);
+    static const std::vector<E> empty;
+    for (size_t i = 0; i < ni; ++i) {
+      const bool lk = layouts[i].n_groups > 0;
+      ZetaInstance<PP> zi{&o_main[i][0], o_main[i].size() > 1 ? &o_main[i][1] : nullptr, &o_prep[i][0], &o_prep[i][1],
+                          lk ? &o_perm[i][0] : &empty, lk ? &o_perm[i][1] : &empty, &inst_chunks[i],
+                          lk ? &terminals[i] : nullptr};
+      try {
+        check_instance_at_zeta<PP>(prep->airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow,
+                                   ctx->rc_mont_host.data(), i);
+      } catch (const VerifyFailure& e) {
+        fail(P3R_EINVAL, "the traces do not satisfy the constraints (%s)", e.what());
+      }
+    }
+    E tsum = E::zero();
+    for (int i : perm_insts) tsum += terminals[i];
+    if (!tsum.is_zero()) fail(P3R_EINVAL, "the traces do not satisfy the constraints (global lookup sum is not zero)");
+  }
 
   prof_stage(ctx, "fri_reduce");
   // ---- 6. FRI batching challenge and per-height reduced openings

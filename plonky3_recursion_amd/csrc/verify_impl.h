@@ -301,6 +301,97 @@ void mmcs_verify(const std::vector<std::array<Fp<PP>, P2_DIGEST>>& cap, int cap_
   if (node != cap.at(idx)) vfail("%s: Merkle root mismatch", what);
 }
 
+// ---- the out-of-domain identity of one instance: folded constraints(zeta) / Z_H(zeta) == quotient(zeta)
+// (recursion/src/verifier/batch_stark.rs:886-1017, verifier/quotient.rs:60-140).  Shared by the
+// verifier and by the prover's self-check before it serialises a proof (prove_impl.cuh): the
+// counterpart of prove_batch's debug constraint check, at the cost of one evaluation per table.
+template <class PP>
+struct ZetaInstance {
+  using E = Fp4<PP>;
+  const std::vector<E>* main_local;
+  const std::vector<E>* main_next;  // null when the AIR reads no next row
+  const std::vector<E>* prep_local;
+  const std::vector<E>* prep_next;
+  const std::vector<E>* perm_local;
+  const std::vector<E>* perm_next;
+  const std::vector<std::vector<E>>* chunks;
+  const E* terminal;  // null without lookups
+};
+template <class PP>
+void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log_n_i, const ZetaInstance<PP>& in,
+                            Fp4<PP> alpha, Fp4<PP> zeta, Fp4<PP> l_prefix, const Fp4<PP>* l_beta_pow,
+                            const uint32_t* rc_mont, size_t i) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  const F gen = F::generator();
+  {
+    const size_t n = size_t(1) << log_n_i;
+    const F g = F::two_adic_generator(log_n_i), g_inv = g.inv();
+    // selectors on the (unshifted) trace domain: Z_H = zeta^n - 1 (pcs/fri/targets.rs:868-908)
+    const E zh = zeta.pow(n) - E::one();
+    if (zh.is_zero()) vfail("zeta lies in the trace domain");
+    const E is_transition = zeta - E::from_base(g_inv);
+    const E is_first = zh * (zeta - E::one()).inv();
+    const E is_last = zh * is_transition.inv();
+    static const std::vector<E> none;
+    ZetaView<PP> v{in.main_local, in.main_next ? in.main_next : &none, in.prep_local, in.prep_next};
+    ZetaFold<PP> fold;
+    fold.alpha = alpha;
+    if (air.kind == AIR_ALU) alu_constraints<PP>(air, v, fold);
+    else if (air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc_mont, fold);
+    if (fold.count != air_num_base_constraints<PP>(air)) vfail("instance %zu: constraint count mismatch", i);
+    if (L.n_groups) {
+      // EF aux columns from their 4 base-column openings: sum_k x^k * col_k(zeta)
+      auto ef_cols = [&](const std::vector<E>& flat) {
+        std::vector<E> out(flat.size() / 4, E::zero());
+        for (size_t c = 0; c < out.size(); ++c)
+          for (int k = 0; k < 4; ++k) {
+            E basis = E::zero();
+            basis.c[k] = F::one();
+            out[c] += basis * flat[c * 4 + k];
+          }
+        return out;
+      };
+      const std::vector<E> aux_l = ef_cols(*in.perm_local), aux_n = ef_cols(*in.perm_next);
+      ZetaLookupSink<PP> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4]},
+                              aux_l, fold, L.pair};
+      air_interactions<PP>(air, v, sink);
+      sink.finish();
+      if (sink.cnt != L.n_interactions) vfail("instance %zu: interaction count mismatch", i);
+      const E s = aux_l[0], s_next = aux_n[0], terminal = *in.terminal;
+      fold.ext(s * is_first);
+      fold.ext((s_next - s - sink.sum_f) * is_transition);
+      fold.ext((s + sink.sum_f - terminal) * is_last);
+    }
+    // quotient(zeta) = sum_c L_c(zeta) * Q_c(zeta) over the 2^log_chunks cosets of the quotient domain
+    // (recursion/src/verifier/quotient.rs:60-)
+    const int lq = L.log_chunks;
+    const size_t C = size_t(1) << lq;
+    const F wq = F::two_adic_generator(log_n_i + lq);
+    std::vector<F> shifts(C);
+    for (size_t c = 0; c < C; ++c) shifts[c] = gen * wq.pow(c);
+    E quotient = E::zero();
+    for (size_t c = 0; c < C; ++c) {
+      // vanishing polynomial of coset c' at x: (x / shift_c')^n - 1
+      E num = E::one();
+      F den = F::one();
+      for (size_t o = 0; o < C; ++o) {
+        if (o == c) continue;
+        num *= (zeta * shifts[o].inv()).pow(n) - E::one();
+        den *= (shifts[c] * shifts[o].inv()).pow(n) - F::one();
+      }
+      E qc = E::zero();
+      for (int k = 0; k < 4; ++k) {
+        E basis = E::zero();
+        basis.c[k] = F::one();
+        qc += basis * (*in.chunks)[c][k];
+      }
+      quotient += num * den.inv() * qc;
+    }
+    if (!(fold.acc * zh.inv() == quotient)) vfail("instance %zu: constraints do not match the quotient at zeta (OodEvaluationMismatch)", i);
+  }
+}
+
 // ---- the whole verification
 struct VerifyParams {
   int log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits, num_queries;
@@ -402,72 +493,10 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   E terminal_sum = E::zero();
   for (size_t i = 0; i < ni; ++i) {
     const auto& in = P.insts[i];
-    const auto& L = layouts[i];
-    const size_t n = size_t(1) << log_n[i];
-    const F g = F::two_adic_generator(log_n[i]), g_inv = g.inv();
-    // selectors on the (unshifted) trace domain: Z_H = zeta^n - 1 (pcs/fri/targets.rs:868-908)
-    const E zh = zeta.pow(n) - E::one();
-    if (zh.is_zero()) vfail("zeta lies in the trace domain");
-    const E is_transition = zeta - E::from_base(g_inv);
-    const E is_first = zh * (zeta - E::one()).inv();
-    const E is_last = zh * is_transition.inv();
-    static const std::vector<E> none;
-    ZetaView<PP> v{&in.main_local, in.main_next ? &*in.main_next : &none, &in.prep_local, &in.prep_next};
-    ZetaFold<PP> fold;
-    fold.alpha = alpha;
-    if (airs[i].kind == AIR_ALU) alu_constraints<PP>(airs[i], v, fold);
-    else if (airs[i].kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc.data(), fold);
-    if (fold.count != air_num_base_constraints<PP>(airs[i])) vfail("instance %zu: constraint count mismatch", i);
-    if (L.n_groups) {
-      // EF aux columns from their 4 base-column openings: sum_k x^k * col_k(zeta)
-      auto ef_cols = [&](const std::vector<E>& flat) {
-        std::vector<E> out(flat.size() / 4, E::zero());
-        for (size_t c = 0; c < out.size(); ++c)
-          for (int k = 0; k < 4; ++k) {
-            E basis = E::zero();
-            basis.c[k] = F::one();
-            out[c] += basis * flat[c * 4 + k];
-          }
-        return out;
-      };
-      const std::vector<E> aux_l = ef_cols(in.perm_local), aux_n = ef_cols(in.perm_next);
-      ZetaLookupSink<PP> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4]},
-                              aux_l, fold, L.pair};
-      air_interactions<PP>(airs[i], v, sink);
-      sink.finish();
-      if (sink.cnt != L.n_interactions) vfail("instance %zu: interaction count mismatch", i);
-      const E s = aux_l[0], s_next = aux_n[0], terminal = *P.terminals[i];
-      fold.ext(s * is_first);
-      fold.ext((s_next - s - sink.sum_f) * is_transition);
-      fold.ext((s + sink.sum_f - terminal) * is_last);
-      terminal_sum += terminal;
-    }
-    // quotient(zeta) = sum_c L_c(zeta) * Q_c(zeta) over the 2^log_chunks cosets of the quotient domain
-    // (recursion/src/verifier/quotient.rs:60-)
-    const int lq = L.log_chunks;
-    const size_t C = size_t(1) << lq;
-    const F wq = F::two_adic_generator(log_n[i] + lq);
-    std::vector<F> shifts(C);
-    for (size_t c = 0; c < C; ++c) shifts[c] = gen * wq.pow(c);
-    E quotient = E::zero();
-    for (size_t c = 0; c < C; ++c) {
-      // vanishing polynomial of coset c' at x: (x / shift_c')^n - 1
-      E num = E::one();
-      F den = F::one();
-      for (size_t o = 0; o < C; ++o) {
-        if (o == c) continue;
-        num *= (zeta * shifts[o].inv()).pow(n) - E::one();
-        den *= (shifts[c] * shifts[o].inv()).pow(n) - F::one();
-      }
-      E qc = E::zero();
-      for (int k = 0; k < 4; ++k) {
-        E basis = E::zero();
-        basis.c[k] = F::one();
-        qc += basis * in.chunks[c][k];
-      }
-      quotient += num * den.inv() * qc;
-    }
-    if (!(fold.acc * zh.inv() == quotient)) vfail("instance %zu: constraints do not match the quotient at zeta (OodEvaluationMismatch)", i);
+    ZetaInstance<PP> zi{&in.main_local, in.main_next ? &*in.main_next : nullptr, &in.prep_local, &in.prep_next,
+                        &in.perm_local, &in.perm_next, &in.chunks, P.terminals[i] ? &*P.terminals[i] : nullptr};
+    check_instance_at_zeta<PP>(airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow, rc.data(), i);
+    if (layouts[i].n_groups) terminal_sum += *P.terminals[i];
   }
   if (any_lookup && !terminal_sum.is_zero()) vfail("global lookup sum is not zero");
 

@@ -1,7 +1,7 @@
 """Adapters from the synthetic-workload arrays (harness/synth.cpp) to the prover's input types."""
 import numpy as np
 
-from .prover import Circuit, CircuitInputs, CircuitPrep, Traces
+from plonky3_recursion_amd.prover import Circuit, CircuitInputs, CircuitPrep, Traces
 
 
 def traces_from_arrays(a) -> Traces:

@@ -16,7 +16,7 @@ FRI = dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3
 
 def setup(oracle, field, log_h, flags=0, packing=None, **gen):
     import plonky3_recursion_amd as p3r
-    from plonky3_recursion_amd import workload as wl
+    import harness_adapters as wl
     gen.setdefault("horner_chain_len", 16)
     gen.setdefault("sponge_chain_len", 3)
     gen.setdefault("merkle_depth", 5)

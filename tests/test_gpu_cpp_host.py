@@ -20,7 +20,7 @@ EXE = os.path.join(ROOT, "examples", "prove_next_layer")
 @pytest.mark.parametrize("field,log_h", [("koala-bear", 12), ("baby-bear", 11)])
 def test_cpp_host_matches_python_binding(oracle, tmp_path, field, log_h):
     import plonky3_recursion_amd as p3r
-    from plonky3_recursion_amd import workload as wl
+    import harness_adapters as wl
     if not os.path.exists(EXE):
         subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True)
     out_file = str(tmp_path / "proof.bin")

@@ -21,7 +21,7 @@ GEN = dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
 @pytest.mark.parametrize("field,log_h", [("koala-bear", 20), ("baby-bear", 22)])
 def test_headline_layer_proves_and_both_verifiers_accept(oracle, field, log_h):
     import plonky3_recursion_amd as p3r
-    from plonky3_recursion_amd import workload as wl
+    import harness_adapters as wl
     arrs = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN)   # the bench workload
     ctx = p3r.Context(field=field, **FRI)
     tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])

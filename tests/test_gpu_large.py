@@ -15,7 +15,7 @@ FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, co
 
 def prove_on_gpu(field, log_h, seed=11, **gen):
     import plonky3_recursion_amd as p3r
-    from plonky3_recursion_amd import workload as wl
+    import harness_adapters as wl
     gen.setdefault("horner_chain_len", 64)
     gen.setdefault("sponge_chain_len", 8)
     gen.setdefault("merkle_depth", 20)
@@ -56,7 +56,7 @@ def test_keccak_like_mix_long_chains(oracle):
 def test_five_chained_layers_reuse_one_prep(oracle):
     """Config 3: successive proves over one NextLayerPrepCache (recursive_fibonacci.rs:413-440)."""
     import plonky3_recursion_amd as p3r
-    from plonky3_recursion_amd import workload as wl
+    import harness_adapters as wl
     field, log_h = "koala-bear", 12
     arrs, ctx, cache, out = prove_on_gpu(field, log_h)
     L = layer_lib.OracleLayer(oracle, field, arrs, layer_lib.params(**FRI))
@@ -87,7 +87,7 @@ def test_circuit_run_and_prove_at_scale(oracle, field, log_h, gen):
     import circuit_lib as cl
     import oracle_lib
     import plonky3_recursion_amd as p3r
-    from plonky3_recursion_amd import workload as wl
+    import harness_adapters as wl
     gen = dict(dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20), **gen)
     a = harness_lib.generate(field, log_h, seed=77, **gen)
     oc = cl.OracleCircuit(oracle, cl.Circuit.from_arrays(a)).preprocess(oracle_lib.MODULUS[field])

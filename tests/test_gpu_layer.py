@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 def setup(oracle, field, log_h, kw, packing=None, **gen):
     import plonky3_recursion_amd as p3r
     from plonky3_recursion_amd import prover as pv
-    from plonky3_recursion_amd import workload as wl
+    import harness_adapters as wl
     gen.setdefault("horner_chain_len", 20)
     gen.setdefault("sponge_chain_len", 3)
     gen.setdefault("merkle_depth", 5)

@@ -70,9 +70,20 @@ def test_prove_rejects_unsatisfied_trace(oracle):
     # break the output of an Add op in lane 0 (preprocessed column 1 = sel_add): a + b != out
     row = int(np.nonzero(tables[2]["prep"][:, 1] == 1)[0][0])
     mains[2][row, 12] = (int(mains[2][row, 12]) + 1) % 0x7F000001
-    bad = ctx.prove_batch(pd, mains)
-    with pytest.raises(RuntimeError):
-        L.verify(bad)
+    # the prover checks the out-of-domain identity on its own opened values before it serialises
+    # anything (include/p3r.h: P3R_EINVAL "do not satisfy the constraints", the counterpart of
+    # prove_batch's internal constraint check): no unverifiable proof leaves the library
+    with pytest.raises(p3r.P3rError, match="do not satisfy the constraints"):
+        ctx.prove_batch(pd, mains)
+    # an unbalanced lookup (a multiplicity off by one in the preprocessed data) is caught the same way
+    preps = [t["prep"].copy() for t in tables]
+    preps[0][3, 0] = (int(preps[0][3, 0]) + 1) % 0x7F000001
+    cap2, pd2 = ctx.prep_create(airs_of(tables), preps)
+    with pytest.raises(p3r.P3rError, match="do not satisfy the constraints"):
+        ctx.prove_batch(pd2, [t["main"] for t in tables])
+    pd2.free()
+    # the satisfied traces still prove and verify
+    L.verify(ctx.prove_batch(pd, [t["main"] for t in tables]))
     # shape errors are reported, not crashed on
     with pytest.raises(p3r.P3rError):
         ctx.prove_batch(pd, mains[:3])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turn the raw output of tools/profile_round.sh (gpurun_out/final/) into the committed summaries
-under profiles/r01/: the bench line, rocprofv3's kernel stats and the per-kernel PMC traffic."""
+under profiles/<round>/: the bench line, rocprofv3's kernel stats, the per-kernel PMC traffic and SQ
+instruction counters, the microbenchmark outputs.   usage: python tools/collect_profiles.py r02"""
 import collections
 import csv
 import glob
@@ -8,28 +9,43 @@ import json
 import os
 import re
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, OUT = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles", "r01")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC, OUT = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles", ROUND)
+os.makedirs(OUT, exist_ok=True)
 
 
 def newest(pattern):
     return sorted(glob.glob(pattern), key=os.path.getmtime)[-1]
 
 
-def pmc(path, counter):
+def kname(full):
+    m = re.search(r"(k_[a-z0-9_]+)", full)
+    return m.group(1) if m else full[:40]
+
+
+def pmc(counter):
+    """kernel -> list of per-launch counter values, in launch order"""
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(newest(path + "/*/*_counter_collection.csv"))):
+    try:
+        path = newest(SRC + "/pmc_%s/*/*_counter_collection.csv" % counter)
+    except IndexError:
+        return acc
+    for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            m = re.search(r"(k_[a-z0-9_]+)", r["Kernel_Name"])
-            acc[m.group(1) if m else r["Kernel_Name"][:40]].append(float(r["Counter_Value"]))
+            acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return acc
 
 
 line = json.load(open(os.path.join(SRC, "bench_line.json")))
 json.dump(line, open(os.path.join(OUT, "bench_line_final.json"), "w"), indent=1)
 shutil.copy(newest(SRC + "/stats/*/*_kernel_stats.csv"), os.path.join(OUT, "prove_next_layer_final_kernel_stats.csv"))
-fe, wr = pmc(SRC + "/pmc_fetch", "FETCH_SIZE"), pmc(SRC + "/pmc_write", "WRITE_SIZE")
+for f in ("int_rates.txt", "perm_f64.txt"):
+    if os.path.exists(os.path.join(SRC, f)):
+        shutil.copy(os.path.join(SRC, f), os.path.join(OUT, "microbench_" + f))
+fe, wr = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
 # k_mmcs_hash_rows runs once per commit; its first launch of the run is the preprocessed commit of
 # the circuit preparation, which is not part of a prove_next_layer: keep the proofs' launches only.
 for acc in (fe, wr):
@@ -39,23 +55,41 @@ kern = {k: {"launches": len(fe.get(k, [])),
             "write_kb_per_launch": sum(wr.get(k, [0])) / max(len(wr.get(k, [])), 1)} for k in sorted(set(fe) | set(wr))}
 json.dump({
     "provenance": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) over "
-                  "`python3 bench.py --no-cpu-baseline --no-config2 --steps 1 --warmup 0` (tools/profile_round.sh), MI355X, round 1 "
-                  "final; counter unit KB; averages over every launch of the kernel in the run (circuit preparation + "
-                  "3 prove_next_layer), except k_mmcs_hash_rows: the 9 launches of the 3 proofs (main / LogUp / quotient "
-                  "commit each), without the preprocessed commit of the preparation",
+                  "`python3 bench.py --no-cpu-baseline --no-config2 --no-small-layers --steps 1 --warmup 0` "
+                  "(tools/profile_round.sh), MI355X, round %s; counter unit KB; averages over every launch of the "
+                  "kernel in the run, except k_mmcs_hash_rows: without the preprocessed commit of the preparation" % ROUND,
     "note": "raw counter values. gfx950 tallies the 128-B requests of a coalesced streaming read at 64 B, so FETCH_SIZE is "
-            "doubled before it is compared with bytes (MI355X_MICROARCH.md, HBM section). k_mmcs_hash_rows reads every "
-            "LDE cell of a commit exactly once (4 B per lane) and writes one 32-B digest per row: per proof "
-            "2 x FETCH + WRITE summed over its three launches is compared with 4*cells + 32*rows in bench.py.",
+            "doubled before it is compared with bytes (MI355X_MICROARCH.md, HBM section).",
     "kernels": kern}, open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
-h = kern["k_mmcs_hash_rows"]
+
+# SQ counters: totals per kernel over the run (one pass per counter)
+sq_names = ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+            "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INST_CYCLES_VMEM",
+            "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT"]
+sq = {c: pmc(c) for c in sq_names}
+kernels = sorted(set().union(*[set(v) for v in sq.values()]))
+table = {}
+for k in kernels:
+    row = {c: sum(sq[c].get(k, [])) for c in sq_names if k in sq[c]}
+    row["launches"] = len(sq["SQ_WAVES"].get(k, [])) or len(next(iter(sq.values())).get(k, []))
+    if row.get("SQ_WAVES"):
+        row["valu_insts_per_wave"] = row.get("SQ_INSTS_VALU", 0) / row["SQ_WAVES"]
+        row["lds_insts_per_wave"] = row.get("SQ_INSTS_LDS", 0) / row["SQ_WAVES"]
+    table[k] = row
+json.dump({"provenance": "rocprofv3 --pmc <counter> --kernel-trace, one pass per counter, same command as pmc_traffic.json; "
+                         "sums over every launch of the kernel in the run (1 preparation + 3 prove_next_layer)",
+           "kernels": table}, open(os.path.join(OUT, "pmc_sq.json"), "w"), indent=1)
+
+h = kern.get("k_mmcs_hash_rows", {})
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(OUT, "prove_next_layer_final_kernel_stats.csv")))}
 hs = next(v for k, v in stats.items() if "k_mmcs_hash_rows<" in k and "strided" not in k)
 print("value ms", line["value"], "| hash PMC MB/launch (2*FETCH + WRITE)",
-      (2 * h["fetch_kb_per_launch"] + h["write_kb_per_launch"]) * 1024 / 1e6,
+      (2 * h.get("fetch_kb_per_launch", 0) + h.get("write_kb_per_launch", 0)) * 1024 / 1e6,
       "| bench avg_launch_ms", line["roofline"]["avg_launch_ms"], "| rocprof avg ms", float(hs["AverageNs"]) / 1e6, "calls", hs["Calls"])
-print("roofline", {k: line["roofline"][k] for k in ("achieved", "frac", "traffic", "algorithmic_bytes_per_launch")})
+print("roofline", {k: line["roofline"].get(k) for k in ("achieved", "frac", "traffic", "algorithmic_bytes_per_launch")})
 print("valu", line.get("valu_roofline"))
 print("kernel_ms", {k: round(v, 2) for k, v in line["kernel_ms_per_step"].items()})
 print("stage_ms", {k: round(v, 2) for k, v in line["stage_wall_ms_per_step"].items()})
 print("cpu", line.get("cpu_baseline"))
+for k in ("k_mmcs_hash_rows", "k_ntt_tile", "k_mmcs_compress"):
+    print(k, table.get(k))

@@ -4,7 +4,7 @@ import sys, time, threading
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import harness_lib
 import plonky3_recursion_amd as p3r
-from plonky3_recursion_amd import workload as wl
+import harness_adapters as wl
 FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54)
 LOG_H = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 REPS = 40

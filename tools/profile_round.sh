@@ -1,10 +1,15 @@
+# usage (on the GPU box, via gpurun): bash tools/profile_round.sh [tag]
+# Raw output goes to gpurun_out/final/; tools/collect_profiles.py <round> turns it into profiles/<round>/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
-timeout 900 python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench_err.log
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 bench.py --no-cpu-baseline --no-config2 > gpurun_out/final/stats_run.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/final/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-config2 --steps 1 --warmup 0 > gpurun_out/final/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/final/pmc_write -- python3 bench.py --no-cpu-baseline --no-config2 --steps 1 --warmup 0 > gpurun_out/final/pmc_write.log 2>&1
-find gpurun_out/final -name "*.csv" | head -20
+(cd tools/microbench && ./int_rates > ../../gpurun_out/final/int_rates.txt 2>&1; ./perm_f64 > ../../gpurun_out/final/perm_f64.txt 2>&1)
+timeout 1200 python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench_err.log
+ARGS="bench.py --no-cpu-baseline --no-config2 --no-small-layers"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 $ARGS > gpurun_out/final/stats_run.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT; do
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/final/pmc_$C -- python3 $ARGS --steps 1 --warmup 0 > gpurun_out/final/pmc_$C.log 2>&1
+done
 # keep the merge small: drop the per-dispatch traces except counter collection + stats
-find gpurun_out/final/stats -name "*kernel_trace.csv" -delete
-ls -la gpurun_out/final/*
+find gpurun_out/final -name "*kernel_trace.csv" -delete
+find gpurun_out/final -name "*agent_info.csv" -delete
+du -sh gpurun_out/final

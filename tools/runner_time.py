@@ -3,7 +3,7 @@ sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
 import harness_lib
 import plonky3_recursion_amd as p3r
-from plonky3_recursion_amd import workload as wl
+import harness_adapters as wl
 FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54)
 CASES = [(16, {}), (20, {}), (18, dict(horner_chain_len=2600, sponge_chain_len=330)),
          (20, dict(horner_chain_len=2600, sponge_chain_len=330))]

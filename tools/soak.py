@@ -2,7 +2,7 @@ import sys, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import harness_lib, torch
 import plonky3_recursion_amd as p3r
-from plonky3_recursion_amd import workload as wl
+import harness_adapters as wl
 FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54)
 a = harness_lib.generate("koala-bear", 16, seed=3)
 ctx = p3r.Context(field="koala-bear", **FRI)
