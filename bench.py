@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--field", default="koala-bear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-log-height", type=int, default=16)
+    ap.add_argument("--spans", action="store_true",
+                    help="print the per-stage timers as tracing-forest spans under the reference's span names (stderr)")
     ap.add_argument("--no-small-layers", action="store_true", help="skip the 2^14/2^15/2^16-row layers")
     ap.add_argument("--no-config2", action="store_true",
                     help="skip the secondary measurement with BASELINE config 2's chain-length knobs")
@@ -300,6 +302,9 @@ def main():
         pc.prove(resident)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
+    if args.spans and rank == 0:
+        # the reference's tracing-forest view of the same step (scripts/benchmark.sh:87-101 parses it)
+        print(p3r.span_report(prof, prof_steps), file=sys.stderr)
 
     if dist is not None:
         t = torch.tensor([dt, 0.0 if proof_verified else 1.0], dtype=torch.float64, device=coll_device)

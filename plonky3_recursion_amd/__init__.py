@@ -8,6 +8,6 @@ from .device import Context, DeviceMatrix, MerkleTree, P3rError, make_config, ve
 from .prover import (BatchStarkProof, BatchStarkProver, Circuit, CircuitInputs, CircuitPrep,  # noqa: F401
                      CircuitProverData, CircuitRunner, PreparedCircuit, FriRecursionBackend, FriRecursionConfig, NextLayerPrepCache, ProveNextLayerParams,
                      RecursionInput, RecursionOutput, ResidentTraces, TablePacking, Traces,
-                     build_next_layer_prep, prove_next_layer, verify_all_tables)
+                     build_next_layer_prep, prove_next_layer, span_report, verify_all_tables)
 
 __all__ = ["Context", "DeviceMatrix", "MerkleTree", "P3rError"]

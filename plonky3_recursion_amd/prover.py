@@ -783,3 +783,67 @@ def prove_next_layer(inp: RecursionInput, ctx: Context, backend: FriRecursionBac
         traces = prep.prepared_circuit.run(inp.circuit_inputs)   # runner.run() (recursion.rs:478)
     proof = prep.prover.prove_all_tables(traces, prep.circuit_prover_data)
     return RecursionOutput(proof=proof, circuit_prover_data=prep.circuit_prover_data)
+
+
+# ----------------------------------------------------------------------------- tracing spans
+# The reference instruments its hot path with `tracing` spans named after the functions
+# (`#[instrument(skip_all)]`: recursion.rs:400 `prove_next_layer`, batch_stark_prover.rs:1202
+# `prove_all_tables`, tables/runner.rs:194 `run`, and the per-AIR trace builders alu_air.rs:496,
+# const_air.rs:90, public_air.rs:127, recompose_air.rs:94, poseidon2-circuit-air air.rs:279); the
+# examples print them with tracing_forest as `name [ 109ms | 100.00% ]` and scripts/benchmark.sh:87-101
+# parses those lines.  span_report() renders the ctx's stage / kernel timers in the same shape under
+# the same names; the stages inside prove_batch (an un-vendored crate) keep descriptive names.
+_SPAN_TREE = (
+    ("run", ("stage", "run_circuit"), ()),
+    ("prove_all_tables", None, (
+        ("AluAir::trace_to_matrix", ("kernel", "alu_trace"), ()),
+        ("ConstAir::build_trace + WitnessSendAir::build_trace + RecomposeAir::build_trace", ("kernel", "trace_to_matrix"), ()),
+        ("Poseidon2CircuitAir::build_trace", ("kernel", "p2_acc_scan", "p2_trace_fill"), ()),
+        ("prove_batch", None, (
+            ("commit to main traces", ("stage", "main_lde_commit"), ()),
+            ("observe instance shapes and commitments", ("stage", "transcript_head"), ()),
+            ("LogUp permutation traces and commit", ("stage", "logup_aux_commit"), ()),
+            ("compute and commit quotient", ("stage", "quotient_commit"), ()),
+            ("open", ("stage", "openings"), ()),
+            ("FRI reduced openings", ("stage", "fri_reduce"), ()),
+            ("FRI commit phase", ("stage", "fri_commit_phase"), ()),
+            ("FRI query phase", ("stage", "queries"), ()),
+            ("serialize proof", ("stage", "serialize"), ()),
+        )),
+    )),
+)
+
+
+def span_report(profile: dict, steps: int = 1, root: str = "prove_next_layer") -> str:
+    """`profile` = Context.profile_read() after `steps` profiled prove_next_layer calls."""
+    def own(src):
+        if src is None:
+            return None
+        kind, names = src[0], src[1:]
+        return sum(profile.get(("stage:" + n) if kind == "stage" else n, (0.0, 0))[0] for n in names) / steps
+
+    def total(node):
+        name, src, kids = node
+        t = own(src)
+        return t if t is not None else sum(total(k) for k in kids)
+
+    whole = sum(total(n) for n in _SPAN_TREE) or 1e-12
+    lines = ["%s [ %s | 100.00%% ]" % (root, _fmt_ms(whole))]
+
+    def emit(nodes, prefix):
+        for i, node in enumerate(nodes):
+            last = i == len(nodes) - 1
+            t = total(node)
+            lines.append("%s%s %s [ %s | %.2f%% ]" % (prefix, "\u2515\u2501" if last else "\u251d\u2501", node[0], _fmt_ms(t),
+                                                   100.0 * t / whole))
+            emit(node[2], prefix + ("   " if last else "\u2502  "))
+    emit(_SPAN_TREE, "")
+    return "\n".join(lines)
+
+
+def _fmt_ms(ms: float) -> str:
+    if ms >= 1000.0:
+        return "%.2fs" % (ms / 1000.0)
+    if ms >= 1.0:
+        return "%.2fms" % ms
+    return "%.0f\u00b5s" % (ms * 1000.0)

@@ -72,3 +72,27 @@ def test_wrapper_montgomery_field_encoding():
     # ... w_binomial is written as 11 * 2^32 mod p
     want = (11 << 32) % 0x78000001
     assert pv._varint(want) in b
+
+
+def test_span_report_uses_reference_span_names_and_parses_like_benchmark_sh():
+    """The stage timers are reported under the reference's span names (recursion.rs:400,
+    batch_stark_prover.rs:1202, tables/runner.rs:194, the per-AIR builders) in tracing-forest shape;
+    scripts/benchmark.sh:87-101 picks the `prove_next_layer` line and reads `[ <t>ms`."""
+    import re
+    import plonky3_recursion_amd as p3r
+    prof = {"stage:run_circuit": (3.0, 0), "stage:build_traces": (0.8, 0), "stage:main_lde_commit": (34.0, 0),
+            "stage:logup_aux_commit": (14.0, 0), "stage:quotient_commit": (8.0, 0), "stage:openings": (2.0, 0),
+            "stage:fri_reduce": (2.6, 0), "stage:fri_commit_phase": (4.6, 0), "stage:queries": (0.2, 0),
+            "stage:serialize": (0.4, 0), "stage:transcript_head": (0.02, 0),
+            "alu_trace": (0.24, 2), "trace_to_matrix": (0.06, 6), "p2_acc_scan": (0.04, 6), "p2_trace_fill": (0.24, 2)}
+    text = p3r.span_report(prof, steps=2)
+    lines = text.split("\n")
+    for name in ("prove_next_layer", "run", "prove_all_tables", "AluAir::trace_to_matrix", "ConstAir::build_trace",
+                 "WitnessSendAir::build_trace", "RecomposeAir::build_trace", "Poseidon2CircuitAir::build_trace"):
+        assert any(name in ln for ln in lines), name
+    root = [ln for ln in lines if re.search(r"\bprove_next_layer\b", ln)]
+    assert len(root) == 1
+    m = re.search(r"\[\s*([0-9]+(?:\.[0-9]+)?)\s*(ms|s)\b", root[0])   # benchmark.sh's own pattern
+    total = sum(v[0] for k, v in prof.items() if k.startswith("stage:") and k != "stage:build_traces") / 2 \
+        + (0.24 + 0.06 + 0.04 + 0.24) / 2
+    assert m and m.group(2) == "ms" and abs(float(m.group(1)) - total) < 0.01
