@@ -185,6 +185,134 @@ def small_layers(ctx, p3r, wl, packing, field, sizes=(14, 15, 16), steps=20):
     return out
 
 
+def run_tree(args, torch, dist, rank, world, local_rank, coll_device):
+    """BASELINE config 4: a 2-to-1 aggregation tree of `--tree-leaves` leaf proofs -> 1 root over the
+    ranks (one GPU each).  Leaves are prove_next_layer over the synthetic layer at 2^leaf_log_height
+    rows, every aggregation node is prove_aggregation_layer (recursion.rs:656-762) over the synthetic
+    layer at TWICE the Poseidon2 / ALU counts, with one AggregationPrepCache per
+    rank.  A parent starts when both children's proofs are on its rank (TreePlan: it sits where its left
+    child was; the right child's bytes move by send/recv), parses them (p3r_batch_proof_len: the host
+    work of packing the verifier inputs is proportional to the proof size) and - with
+    --tree-verify-children - verifies them natively first.  The synthetic node circuit's VALUES do not
+    depend on the children (building verifier circuits is the reference's CPU front end, out of
+    scope); its SCHEDULE does.  Strong scaling: the tree is the same whatever the world size."""
+    import harness_lib
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd.aggregation import TreePlan, run_aggregation_tree
+    field, lh = args.field, args.leaf_log_height
+    ctx = p3r.Context(field=field, device=local_rank, **FRI)
+    packing = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    params = p3r.ProveNextLayerParams(table_packing=packing)
+    backend = p3r.FriRecursionBackend()
+    plan = TreePlan(args.tree_leaves, world)
+    # leaf layer (every rank proves the same leaf circuit: one NextLayerPrepCache per rank)
+    la = harness_lib.generate(field, lh, seed=0x5EED0000, **GEN_KNOBS)
+    leaf_cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(la), backend, params)
+    leaf_inputs = leaf_cache.prepared_circuit.upload_inputs(wl.circuit_inputs_from_arrays(la))
+    del la
+    # aggregation node: twice the counts
+    na = harness_lib.generate(field, lh + 1, seed=0x5EED0001, **GEN_KNOBS)
+    node_circuit = wl.circuit_from_arrays(na)
+    n_left, n_right, left_ops = wl.split_aggregation_inputs(wl.circuit_inputs_from_arrays(na))
+    del na
+    agg_cache = [None]
+    stats = {"leaf_ms": [], "node_ms": [], "child_parse_ms": [], "child_verify_ms": []}
+
+    def prove_leaf(i):
+        t0 = time.perf_counter()
+        out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=leaf_inputs), ctx, backend, params, prep=leaf_cache)
+        stats["leaf_ms"].append((time.perf_counter() - t0) * 1e3)
+        return out.proof.to_postcard()
+
+    def prove_parent(level, node, lbytes, rbytes):
+        t0 = time.perf_counter()
+        children = [p3r.BatchStarkProof.from_postcard(b, field) for b in (lbytes, rbytes)]   # parse + metadata rules
+        stats["child_parse_ms"].append((time.perf_counter() - t0) * 1e3)
+        if args.tree_verify_children:
+            t1 = time.perf_counter()
+            for c in children:
+                p3r.verify_all_tables(ctx.cfg, c)
+            stats["child_verify_ms"].append((time.perf_counter() - t1) * 1e3)
+        t1 = time.perf_counter()
+        out = p3r.prove_aggregation_layer(
+            p3r.RecursionInput(prev_proof=children[0], circuit_inputs=n_left),
+            p3r.RecursionInput(prev_proof=children[1], circuit_inputs=n_right),
+            node_circuit, ctx, backend, params, prep_cache=agg_cache, left_non_primitive_ops=left_ops)
+        stats["node_ms"].append((time.perf_counter() - t1) * 1e3)
+        return out.proof.to_postcard()
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    level_ms = []
+
+    def on_level(level, seconds):
+        level_ms.append(seconds * 1e3)
+
+    # warm-up: one leaf and one node per rank (fills the AggregationPrepCache, the pools, the job tables)
+    w = prove_leaf(0)
+    prove_parent(1, 0, w, w)
+    for v in stats.values():
+        v.clear()
+    times = []
+    root = None
+    for _ in range(args.warmup + args.steps):
+        barrier()
+        level_ms.clear()
+        t0 = time.perf_counter()
+        root = run_aggregation_tree(plan, rank, prove_leaf, prove_parent, dist=dist, device=coll_device,
+                                    on_level=on_level, level_barrier=barrier if args.tree_level_barriers else None)
+        barrier()
+        times.append(time.perf_counter() - t0)
+    times = times[args.warmup:]
+    dt = sum(times)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = True
+    if rank == 0:
+        import hashlib
+        rp = p3r.BatchStarkProof.from_postcard(root, field)
+        try:
+            p3r.verify_all_tables(ctx.cfg, rp)
+        except Exception as e:
+            print(f"bench: the ROOT proof was rejected: {e}", file=sys.stderr)
+            ok = False
+        n_nodes = 2 * args.tree_leaves - 1
+        ms_tree = dt / args.steps * 1e3
+        mean = lambda v: (sum(v) / len(v)) if v else None
+        print(json.dumps({
+            "metric": "aggregation tree wall ms (8 leaf proofs -> 1 root, prove_aggregation_layer per node), KoalaBear",
+            "value": ms_tree, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_tree, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32 (31-bit Montgomery prime field, degree-4 extension)", "data": "synthetic",
+            "config": {"workload": f"2-to-1 aggregation tree, {args.tree_leaves} leaves (prove_next_layer, synthetic {field} "
+                                   f"2^{lh}-row layer) -> {args.tree_leaves - 1} nodes (prove_aggregation_layer, 2^{lh + 1}-row "
+                                   f"layer = twice the Poseidon2 / ALU counts), one rank per GPU, parent on its left child's rank",
+                       "field": field, "leaf_log_height": lh, "node_log_height": lh + 1, "leaves": args.tree_leaves,
+                       "nodes": n_nodes, "fri": FRI, "parallelism": f"tree nodes over {world} ranks, send/recv of child proofs only"},
+            "proofs_per_s": n_nodes / (ms_tree * 1e-3),
+            "root_verified": ok, "root_sha256": hashlib.sha256(root).hexdigest(), "root_bytes": len(root),
+            "rank0": {"leaf_ms": mean(stats["leaf_ms"]), "node_ms": mean(stats["node_ms"]),
+                      "child_parse_ms": mean(stats["child_parse_ms"]), "child_verify_ms": mean(stats["child_verify_ms"]),
+                      "level_wall_ms_last_step": list(level_ms)},
+        }))
+    leaf_inputs.free()
+    leaf_cache.prepared_circuit.free()
+    if agg_cache[0] is not None:
+        agg_cache[0].prepared_circuit.free()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +322,14 @@ def main():
     ap.add_argument("--field", default="koala-bear")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-log-height", type=int, default=16)
+    ap.add_argument("--tree", action="store_true",
+                    help="BASELINE config 4: prove a 2-to-1 aggregation tree (leaves -> root) over the ranks instead of "
+                         "independent layers")
+    ap.add_argument("--tree-leaves", type=int, default=8)
+    ap.add_argument("--leaf-log-height", type=int, default=15,
+                    help="rows of a leaf layer (nodes have twice as many); the reference's real verifier circuits have 2^14..2^16")
+    ap.add_argument("--tree-verify-children", action="store_true", help="verify both children natively before proving a node")
+    ap.add_argument("--tree-level-barriers", action="store_true", help="barrier between levels (per-level wall times)")
     ap.add_argument("--spans", action="store_true",
                     help="print the per-stage timers as tracing-forest spans under the reference's span names (stderr)")
     ap.add_argument("--no-small-layers", action="store_true", help="skip the 2^14/2^15/2^16-row layers")
@@ -225,6 +361,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
             dist.init_process_group(backend, timeout=limit)
+
+    if args.tree:
+        return run_tree(args, torch, dist, rank, world, local_rank, coll_device)
 
     field, log_h = args.field, args.log_height
     ctx = p3r.Context(field=field, device=local_rank, **FRI)

@@ -5,9 +5,10 @@ The HIP library is mandatory: importing the package is cheap, but any compute en
 raises if `libp3r_hip.so` has not been built (no CPU fallback).
 """
 from .device import Context, DeviceMatrix, MerkleTree, P3rError, make_config, verify_batch  # noqa: F401
-from .prover import (BatchStarkProof, BatchStarkProver, Circuit, CircuitInputs, CircuitPrep,  # noqa: F401
+from .prover import (AggregationCircuitFingerprint, AggregationPrepCache, BatchStarkProof, BatchStarkProver, Circuit, CircuitInputs, CircuitPrep,  # noqa: F401
                      CircuitProverData, CircuitRunner, PreparedCircuit, FriRecursionBackend, FriRecursionConfig, NextLayerPrepCache, ProveNextLayerParams,
                      RecursionInput, RecursionOutput, ResidentTraces, TablePacking, Traces,
-                     build_next_layer_prep, prove_next_layer, span_report, verify_all_tables)
+                     aggregation_circuit_fingerprint, build_next_layer_prep, pack_aggregation_inputs, prove_aggregation_layer,
+                     prove_next_layer, span_report, verify_all_tables)
 
 __all__ = ["Context", "DeviceMatrix", "MerkleTree", "P3rError"]

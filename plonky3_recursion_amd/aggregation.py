@@ -8,9 +8,11 @@ moving finished child proofs (hundreds of kB) to the rank that proves the parent
 root hand-off to rank 0.  One process per GPU, `torch.distributed`
 (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 
-What is NOT here: running the parent's verifier circuit over the two child proofs.  That is the
-reference's CPU `CircuitRunner` (out of scope); the scheduler takes it as
-the `make_traces(level, node, child_proofs)` callback that returns the parent's `Traces`.
+The node prover itself is `prove_aggregation_layer` (prover.py: AggregationPrepCache keyed by the
+circuit fingerprint, the verifier circuit run on the device); `bench.py --tree` drives this
+scheduler with real proofs, `tests/test_gpu_aggregation.py` checks the root.  What is NOT here:
+BUILDING the parent's verifier circuit from the two child proofs - the reference's symbolic CPU
+front end (out of scope): callers pass the circuit and its inputs.
 """
 from dataclasses import dataclass
 from typing import Callable, List, Optional
@@ -62,15 +64,25 @@ def _recv_bytes(dist, src: int, device) -> bytes:
 
 def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], bytes],
                          prove_parent: Callable[[int, int, bytes, bytes], bytes], dist=None,
-                         device="cpu") -> Optional[bytes]:
+                         device="cpu", on_level: Optional[Callable[[int, float], None]] = None,
+                         level_barrier: Optional[Callable[[], None]] = None) -> Optional[bytes]:
     """Proves every node this rank owns, level by level; returns the root proof on rank 0.
 
     prove_leaf(i) -> proof bytes of leaf i.
     prove_parent(level, node, left_proof, right_proof) -> proof bytes (the caller runs the verifier
     circuit over the two children and calls `prove_aggregation_layer`'s GPU part).
-    `dist` is torch.distributed (None for a single process)."""
+    `dist` is torch.distributed (None for a single process).  `on_level(level, seconds)` receives this
+    rank's wall time per level; with `level_barrier` the levels are separated by that barrier, so
+    the times are the level's wall time across ranks."""
+    import time
+    t0 = time.perf_counter()
     proofs = {i: prove_leaf(i) for i in plan.my_nodes(0, rank)}
+    if level_barrier:
+        level_barrier()
+    if on_level:
+        on_level(0, time.perf_counter() - t0)
     for level in range(1, plan.levels):
+        t0 = time.perf_counter()
         nxt = {}
         # ship right children to the parent's owner (left child already lives there)
         for node in range(plan.nodes(level)):
@@ -86,6 +98,10 @@ def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], 
         for node in plan.my_nodes(level, rank):
             nxt[node] = prove_parent(level, node, proofs[2 * node], proofs[2 * node + 1])
         proofs = nxt
+        if level_barrier:
+            level_barrier()
+        if on_level:
+            on_level(level, time.perf_counter() - t0)
     # final root hand-off to rank 0
     root_level = plan.levels - 1
     root_rank = plan.owner(root_level, 0)

@@ -780,9 +780,88 @@ def prove_next_layer(inp: RecursionInput, ctx: Context, backend: FriRecursionBac
     else:
         if prep.prepared_circuit is None or inp.circuit_inputs is None:
             raise ValueError("without Traces, prove_next_layer needs a prepared Circuit and its inputs")
-        traces = prep.prepared_circuit.run(inp.circuit_inputs)   # runner.run() (recursion.rs:478)
+        # runner.run() (recursion.rs:478) + prove_all_tables as ONE call (p3r_prove_next_layer): the
+        # prover is enqueued behind the circuit run without waiting for it
+        raw = prep.prepared_circuit.prove(inp.circuit_inputs)
+        return RecursionOutput(proof=prep.prover.wrap_proof(raw, prep.circuit_prover_data),
+                               circuit_prover_data=prep.circuit_prover_data)
     proof = prep.prover.prove_all_tables(traces, prep.circuit_prover_data)
     return RecursionOutput(proof=proof, circuit_prover_data=prep.circuit_prover_data)
+
+
+
+# ----------------------------------------------------------------------------- 2-to-1 aggregation
+@dataclass(frozen=True)
+class AggregationCircuitFingerprint:
+    """recursion.rs:72-93: rejects `AggregationPrepCache` hits when a later aggregation step compiles to
+    a different verification circuit even though params and config match."""
+    witness_count: int
+    public_flat_len: int
+    private_flat_len: int
+    ops_len: int
+
+
+def aggregation_circuit_fingerprint(circuit: Circuit) -> AggregationCircuitFingerprint:
+    return AggregationCircuitFingerprint(
+        witness_count=int(circuit.witness_count),
+        public_flat_len=int(np.asarray(circuit.public_rows).size),
+        private_flat_len=int(np.asarray(circuit.private_input_rows).size),
+        ops_len=int(np.asarray(circuit.ops).reshape(-1, 8).shape[0]))
+
+
+@dataclass
+class AggregationPrepCache:
+    """recursion.rs:95-99 (+ the prepared circuit: the levelised schedule of the device runner)."""
+    circuit_fingerprint: AggregationCircuitFingerprint
+    circuit_prover_data: CircuitProverData
+    prover: BatchStarkProver
+    prepared_circuit: PreparedCircuit
+
+
+def pack_aggregation_inputs(left: CircuitInputs, right: CircuitInputs, left_non_primitive_ops: int) -> CircuitInputs:
+    """The inputs of the aggregation circuit from the two halves it verifies: the left proof's public /
+    private values and Merkle siblings first, then the right proof's, whose non-primitive op ids are
+    offset by the number of non-primitive ops the left verifier contributes - the packing
+    `run_aggregation_verification_circuit` does for the two `VerifierResult`s (recursion.rs:596-640)."""
+    def cat(a, b, w):
+        return np.concatenate([np.asarray(a, np.uint32).reshape(-1, w), np.asarray(b, np.uint32).reshape(-1, w)])
+    ids = np.concatenate([np.asarray(left.private_data_op_ids, np.uint32).reshape(-1),
+                          np.asarray(right.private_data_op_ids, np.uint32).reshape(-1) + np.uint32(left_non_primitive_ops)])
+    return CircuitInputs(public_values=cat(left.public_values, right.public_values, 4),
+                         private_values=cat(left.private_values, right.private_values, 4),
+                         private_data_op_ids=ids,
+                         private_data_siblings=cat(left.private_data_siblings, right.private_data_siblings, 8))
+
+
+def prove_aggregation_layer(left: RecursionInput, right: RecursionInput, verification_circuit: Circuit, ctx: Context,
+                            backend: FriRecursionBackend, params: ProveNextLayerParams,
+                            prep_cache: Optional[list] = None, left_non_primitive_ops: int = 0) -> RecursionOutput:
+    """recursion.rs:656-762: one node of the 2-to-1 tree.  `verification_circuit` verifies both inputs;
+    `left.circuit_inputs` / `right.circuit_inputs` are each side's share of its inputs (what the
+    verifier results pack from the two proofs).  `prep_cache` is the reference's
+    `Option<&mut Option<AggregationPrepCache>>` as a one-element list: pass `[None]` on the first call,
+    the slot is filled and reused while the circuit fingerprint stays the same, and ignored (then
+    replaced) when it changes."""
+    if left.circuit_inputs is None or right.circuit_inputs is None:
+        raise ValueError("prove_aggregation_layer needs the circuit inputs of both sides")
+    fp = aggregation_circuit_fingerprint(verification_circuit)
+    inputs = pack_aggregation_inputs(left.circuit_inputs, right.circuit_inputs, left_non_primitive_ops)
+    cached = prep_cache[0] if prep_cache else None
+    if cached is not None and cached.circuit_fingerprint == fp:
+        # run + prove_all_tables as one call: the prover does not wait for the circuit run
+        proof = cached.prover.wrap_proof(cached.prepared_circuit.prove(inputs), cached.circuit_prover_data)
+        return RecursionOutput(proof=proof, circuit_prover_data=cached.circuit_prover_data)
+    backend.non_primitive_provers(4)
+    prover = BatchStarkProver(ctx, params.table_packing)
+    pc = PreparedCircuit(ctx, verification_circuit, params.table_packing)   # get_airs_and_degrees_with_prep + ProverData
+    proof = prover.wrap_proof(pc.prove(inputs), pc.circuit_prover_data)
+    if prep_cache is not None:
+        if not prep_cache:
+            prep_cache.append(None)
+        if prep_cache[0] is not None:
+            prep_cache[0].prepared_circuit.free()
+        prep_cache[0] = AggregationPrepCache(fp, pc.circuit_prover_data, prover, pc)
+    return RecursionOutput(proof=proof, circuit_prover_data=pc.circuit_prover_data)
 
 
 # ----------------------------------------------------------------------------- tracing spans

@@ -47,3 +47,23 @@ def circuit_inputs_from_arrays(a) -> CircuitInputs:
     return CircuitInputs(public_values=a["in_public_values"].reshape(-1, 4),
                          private_values=a["in_private_values"].reshape(-1, 4),
                          private_data_op_ids=a["pd_op_ids"], private_data_siblings=a["pd_siblings"].reshape(-1, 8))
+
+
+def split_aggregation_inputs(inputs: CircuitInputs):
+    """A synthetic aggregation circuit verifies two proofs; its inputs split into the share of the left
+    and of the right proof (first / second half of the public and private values; Merkle siblings by
+    non-primitive op id, the right half's ids relative to the left verifier's op count).  Returns
+    (left, right, left_non_primitive_ops) with pack_aggregation_inputs(left, right, n) == inputs."""
+    pub = np.asarray(inputs.public_values, np.uint32).reshape(-1, 4)
+    prv = np.asarray(inputs.private_values, np.uint32).reshape(-1, 4)
+    ids = np.asarray(inputs.private_data_op_ids, np.uint32).reshape(-1)
+    sib = np.asarray(inputs.private_data_siblings, np.uint32).reshape(-1, 8)
+    hp, hv = pub.shape[0] // 2, prv.shape[0] // 2
+    hs = ids.shape[0] // 2
+    n_left = int(ids[hs]) if hs < ids.shape[0] else 0   # ids are ascending: everything below belongs to the left
+    hs = int(np.searchsorted(ids, n_left))
+    left = CircuitInputs(public_values=pub[:hp], private_values=prv[:hv], private_data_op_ids=ids[:hs],
+                         private_data_siblings=sib[:hs])
+    right = CircuitInputs(public_values=pub[hp:], private_values=prv[hv:],
+                          private_data_op_ids=ids[hs:] - np.uint32(n_left), private_data_siblings=sib[hs:])
+    return left, right, n_left
