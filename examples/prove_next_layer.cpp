@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
     p3r::ProveNextLayerParams params;
     params.table_packing = p3r::TablePacking::create(1, 3).with_fri_params(fri.log_final_poly_len, fri.log_blowup);
     const size_t n_ops = circuit.ops.size();
+    const p3r::Circuit node_circuit = circuit;  // the same circuit again as a 2-to-1 aggregation node, below
     auto t0 = std::chrono::steady_clock::now();
     p3r::NextLayerPrepCache prep = p3r::build_next_layer_prep(ctx, std::move(circuit), backend, params);
     ctx.sync();
@@ -90,6 +91,38 @@ int main(int argc, char** argv) {
       prep.prover->verify_all_tables(out.proof);
       std::printf("layer %d: prove_next_layer %.1f ms, proof %zu bytes (%zu with metadata), verify_all_tables ok\n", l, ms,
                   out.proof.proof.size(), out.proof.to_postcard().size());
+    }
+    // prove_aggregation_layer (recursion.rs:656-762): the circuit's inputs arrive as the shares of the two
+    // proofs it verifies; the AggregationPrepCache slot is filled by the first call and reused by the second
+    {
+      const size_t hp = inputs.public_values.size() / 8 * 4, hv = inputs.private_values.size() / 8 * 4;
+      const size_t hs = inputs.private_data_op_ids.size() / 2;
+      const uint32_t n_left = hs < inputs.private_data_op_ids.size() ? inputs.private_data_op_ids[hs] : 0;
+      size_t cut = 0;
+      while (cut < inputs.private_data_op_ids.size() && inputs.private_data_op_ids[cut] < n_left) ++cut;
+      p3r::CircuitInputs l, r;
+      l.public_values.assign(inputs.public_values.begin(), inputs.public_values.begin() + hp);
+      r.public_values.assign(inputs.public_values.begin() + hp, inputs.public_values.end());
+      l.private_values.assign(inputs.private_values.begin(), inputs.private_values.begin() + hv);
+      r.private_values.assign(inputs.private_values.begin() + hv, inputs.private_values.end());
+      l.private_data_op_ids.assign(inputs.private_data_op_ids.begin(), inputs.private_data_op_ids.begin() + cut);
+      for (size_t i = cut; i < inputs.private_data_op_ids.size(); ++i) r.private_data_op_ids.push_back(inputs.private_data_op_ids[i] - n_left);
+      l.private_data_siblings.assign(inputs.private_data_siblings.begin(), inputs.private_data_siblings.begin() + cut * 8);
+      r.private_data_siblings.assign(inputs.private_data_siblings.begin() + cut * 8, inputs.private_data_siblings.end());
+      p3r::RecursionInput li, ri;
+      li.circuit_inputs = &l;
+      ri.circuit_inputs = &r;
+      std::unique_ptr<p3r::AggregationPrepCache> slot;
+      p3r::RecursionOutput a1 = p3r::prove_aggregation_layer(li, ri, node_circuit, ctx, backend, params, &slot, n_left);
+      const p3r::AggregationPrepCache* filled = slot.get();
+      t0 = std::chrono::steady_clock::now();
+      p3r::RecursionOutput a2 = p3r::prove_aggregation_layer(li, ri, node_circuit, ctx, backend, params, &slot, n_left);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (!filled || slot.get() != filled) throw std::runtime_error("AggregationPrepCache was not reused");
+      if (a1.proof.proof != out.proof.proof || a2.proof.proof != out.proof.proof)
+        throw std::runtime_error("prove_aggregation_layer bytes differ from prove_next_layer of the same circuit");
+      slot->prover->verify_all_tables(a2.proof);
+      std::printf("prove_aggregation_layer (cached prep) %.1f ms, same bytes, verify_all_tables ok\n", ms);
     }
     // negative checks: tampered bytes and tampered metadata are refused
     p3r::BatchStarkProof bad = out.proof;

@@ -490,4 +490,58 @@ inline RecursionOutput prove_next_layer(const RecursionInput& input, const Conte
   return {prep.prover->prove_all_tables(t, prep.circuit_prover_data())};
 }
 
+// ---- 2-to-1 aggregation (recursion/src/recursion.rs:72-99, 656-762)
+struct AggregationCircuitFingerprint {
+  uint32_t witness_count = 0;
+  size_t public_flat_len = 0, private_flat_len = 0, ops_len = 0;
+  bool operator==(const AggregationCircuitFingerprint& o) const {
+    return witness_count == o.witness_count && public_flat_len == o.public_flat_len && private_flat_len == o.private_flat_len &&
+           ops_len == o.ops_len;
+  }
+};
+inline AggregationCircuitFingerprint aggregation_circuit_fingerprint(const Circuit& c) {
+  return {c.witness_count, c.public_rows.size(), c.private_input_rows.size(), c.ops.size()};
+}
+struct AggregationPrepCache {
+  AggregationCircuitFingerprint circuit_fingerprint;
+  std::unique_ptr<BatchStarkProver> prover;
+  std::unique_ptr<PreparedCircuit> prepared_circuit;  // owns the CircuitProverData
+};
+// The inputs of the aggregation circuit from the two halves it verifies: left first, the right proof's
+// non-primitive op ids offset by the left verifier's op count (recursion.rs:596-640).
+inline CircuitInputs pack_aggregation_inputs(const CircuitInputs& l, const CircuitInputs& r, uint32_t left_non_primitive_ops) {
+  CircuitInputs o = l;
+  o.public_values.insert(o.public_values.end(), r.public_values.begin(), r.public_values.end());
+  o.private_values.insert(o.private_values.end(), r.private_values.begin(), r.private_values.end());
+  for (uint32_t id : r.private_data_op_ids) o.private_data_op_ids.push_back(id + left_non_primitive_ops);
+  o.private_data_siblings.insert(o.private_data_siblings.end(), r.private_data_siblings.begin(), r.private_data_siblings.end());
+  return o;
+}
+// `prep_cache` is the reference's Option<&mut Option<AggregationPrepCache>>: null = no caching; an
+// empty slot is filled; a filled slot is used while the circuit fingerprint matches and replaced
+// when it does not.
+inline RecursionOutput prove_aggregation_layer(const RecursionInput& left, const RecursionInput& right, const Circuit& verification_circuit,
+                                               const Context& ctx, const FriRecursionBackend& backend, const ProveNextLayerParams& params,
+                                               std::unique_ptr<AggregationPrepCache>* prep_cache = nullptr,
+                                               uint32_t left_non_primitive_ops = 0) {
+  if (!left.circuit_inputs || !right.circuit_inputs)
+    throw Error(P3R_EINVAL, "prove_aggregation_layer needs the circuit inputs of both sides");
+  backend.non_primitive_provers(4);
+  const AggregationCircuitFingerprint fp = aggregation_circuit_fingerprint(verification_circuit);
+  const CircuitInputs inputs = pack_aggregation_inputs(*left.circuit_inputs, *right.circuit_inputs, left_non_primitive_ops);
+  if (prep_cache && *prep_cache && (*prep_cache)->circuit_fingerprint == fp) {
+    AggregationPrepCache& c = **prep_cache;
+    ResidentTraces t = c.prepared_circuit->run(inputs);
+    return {c.prover->prove_all_tables(t, c.prepared_circuit->circuit_prover_data())};
+  }
+  auto fresh = std::make_unique<AggregationPrepCache>();
+  fresh->circuit_fingerprint = fp;
+  fresh->prover = std::make_unique<BatchStarkProver>(ctx, params.table_packing);
+  fresh->prepared_circuit = std::make_unique<PreparedCircuit>(ctx, verification_circuit, params.table_packing);
+  ResidentTraces t = fresh->prepared_circuit->run(inputs);
+  RecursionOutput out{fresh->prover->prove_all_tables(t, fresh->prepared_circuit->circuit_prover_data())};
+  if (prep_cache) *prep_cache = std::move(fresh);
+  return out;
+}
+
 }  // namespace p3r
