@@ -106,7 +106,7 @@ def hbm_families(heights, widths, packing, kernel_ms):
             opn += h * (4 * w + 16 * pts * ((w + 7) // 8))
         fri += h * B * 16
     out = {}
-    for fam, nbytes, keys in (("ntt", ntt, ("ntt_inverse", "ntt_forward")), ("fri_reduced_openings", fri, ("fri_reduce",)),
+    for fam, nbytes, keys in (("ntt", ntt, ("ntt_inverse_1", "ntt_inverse_2", "ntt_forward_1", "ntt_forward_2")), ("fri_reduced_openings", fri, ("fri_reduce",)),
                               ("openings", opn, ("open_dot",))):
         ms = sum(kernel_ms.get(k, 0.0) for k in keys)
         if ms:

@@ -1,0 +1,265 @@
+// K5, lean form of the two FORWARD passes of a coset LDE (the bulk of the NTT work: 4 cosets):
+//   k_ntt_fwd_col   pass 1: size-R1 transforms along the strided dimension of the coefficient
+//                   vector, all cosets, input scaled by the coset shift powers, output multiplied
+//                   by the four-step twiddles, rows left in bit-reversed order;
+//   k_ntt_fwd_line  pass 2: contiguous size-R2 transforms in place, rows left in bit-reversed order.
+// Same arithmetic and data movement as k_ntt_tile (kernels_ntt.cuh) - identical outputs - but the
+// geometry is a template parameter: one 16-cell item per lane and stage group, every shift and
+// stride a compile-time constant, the twiddles of the last stage group immediates, no per-cell
+// 64-bit address arithmetic.  (rocprof, round 2: k_ntt_tile spends 10.7 VALU instructions per cell
+// and stage where the butterfly itself needs 5; profiles/r02/pmc_sq.json.)
+//
+// Tile: 2^13 cells = 512 lanes x 16 cells, four tiles per CU.
+#pragma once
+#include "kernels_ntt.cuh"
+
+namespace p3r {
+
+constexpr int kNtt2LogTile = 13;
+constexpr int kNtt2Lanes = 512;
+
+// w_{2^log_r}^idx in Montgomery form, at compile time (the twiddles of a last stage group are the
+// 16th roots of unity and their squares: immediates instead of LDS reads)
+template <class PP>
+constexpr uint32_t ntt2_root_mont(int log_r, uint32_t idx) {
+  const uint32_t g = pow_mod(PP::GEN, ((uint64_t)PP::P - 1) >> log_r, PP::P);
+  const uint64_t w = pow_mod(g, idx, PP::P);
+  return (uint32_t)((w << 32) % PP::P);
+}
+
+// twiddles of a LAST stage group (S .. S+ML-1, q = 1): v[u][jj] = w_R^(jj << (S+u))
+template <class PP, int LOG_R, int S, int ML>
+struct Ntt2LastTw {
+  uint32_t v[4][8];
+  constexpr Ntt2LastTw() : v() {
+    for (int u = 0; u < ML; ++u)
+      for (int jj = 0; jj < ((1 << ML) >> (u + 1)); ++jj) v[u][jj] = ntt2_root_mont<PP>(LOG_R, (uint32_t)jj << (S + u));
+  }
+};
+
+// DIF butterfly: (p, c) <- (p + c, (p - c) * tw)
+template <class PP>
+__device__ __forceinline__ void ntt2_bfly(Fp<PP>& p, Fp<PP>& c, uint32_t tw) {
+  using F = Fp<PP>;
+  const F s = p + c;
+  // (p - c + P) < 2P < 2^32 times a Montgomery twiddle < P: within REDC's input range
+  c = F::raw(F::reduce64((uint64_t)(p.v + (PP::P - c.v)) * tw));
+  p = s;
+}
+template <class PP>
+__device__ __forceinline__ void ntt2_bfly_one(Fp<PP>& p, Fp<PP>& c) {  // twiddle 1
+  const Fp<PP> s = p + c, d = p - c;
+  p = s;
+  c = d;
+}
+
+// ML stages (S .. S+ML-1) of a size-2^LOG_R DIF transform on the 16 registers of a lane.
+// M = 2^ML cells form an item (rows r0 + j*q, q = 2^(LOG_R-S-ML)); a lane holds 16/M items in
+// x[i*M + j].  LAST (q == 1): the twiddles are compile-time constants; otherwise `tws` is the
+// table w_R^i (i < R/2) and `low` the item's position below q.
+template <class PP, int LOG_R, int S, int ML, bool LAST>
+__device__ __forceinline__ void ntt2_stages(Fp<PP>* x, const uint32_t* tws, uint32_t low) {
+  constexpr int M = 1 << ML;
+  constexpr int LQ = LOG_R - S - ML;
+  static_assert(!LAST || LQ == 0, "the last group ends the transform");
+  constexpr Ntt2LastTw<PP, LOG_R, S, ML> kLast{};
+#pragma unroll
+  for (int u = 0; u < ML; ++u) {
+    const int half = M >> (u + 1);
+#pragma unroll
+    for (int jj = 0; jj < M / 2; ++jj) {
+      if (jj < half) {
+        uint32_t tw = 0;
+        const bool one = LAST && jj == 0;
+        if constexpr (!LAST) tw = tws[(low << (S + u)) + ((uint32_t)jj << (LQ + S + u))];
+#pragma unroll
+        for (int it = 0; it < 16 / M; ++it) {
+#pragma unroll
+          for (int blk = 0; blk < M; blk += 2 * half) {
+            Fp<PP>& p = x[it * M + blk + jj];
+            Fp<PP>& c = x[it * M + blk + jj + half];
+            if (LAST) {
+              if (one) ntt2_bfly_one<PP>(p, c);
+              else ntt2_bfly<PP>(p, c, kLast.v[u][jj]);
+            } else {
+              ntt2_bfly<PP>(p, c, tw);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ pass 2: contiguous lines, in place
+// data: consecutive lines of R = 2^LOG_R cells; a tile is 2^13 consecutive cells (2^(13-LOG_R) lines).
+// LDS position of cell r of line t: t*LINE + r + (r >> 4): one pad word per 16 cells, so that the
+// last group (16 consecutive cells per lane) and the strided groups are both conflict-free.
+template <int LOG_R>
+__device__ __forceinline__ uint32_t ntt2_line_pos(uint32_t t, uint32_t r) {
+  constexpr uint32_t LINE = (1u << LOG_R) + (1u << (LOG_R > 4 ? LOG_R - 4 : 0));
+  return t * LINE + r + (r >> 4);
+}
+
+struct NttLineJob {
+  uint32_t* data;     // in place
+  const uint32_t* tw; // w_R^i, i < R/2, Montgomery
+  uint32_t block0;    // first block of this job; a job owns cells/2^13 blocks
+};
+
+template <class PP, int LOG_R>
+__global__ void __launch_bounds__(kNtt2Lanes, 2) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
+  using F = Fp<PP>;
+  static_assert(LOG_R >= 5 && LOG_R <= 12, "line length");
+  constexpr uint32_t R = 1u << LOG_R;
+  constexpr int LOG_T = kNtt2LogTile - LOG_R;
+  constexpr uint32_t LINE = R + R / 16;
+  constexpr int G = (LOG_R + 3) / 4;             // stage groups: 4, 4, ..., remainder last
+  constexpr int ML_LAST = LOG_R - 4 * (G - 1);
+  __shared__ uint32_t tile[(LINE << LOG_T)];
+  __shared__ uint32_t tws[R / 2];
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const gptr<uint32_t> data = as_global(jobs[jb].data) + ((size_t)(blockIdx.x - jobs[jb].block0) << kNtt2LogTile);
+  const gptr<const uint32_t> twg = as_global(jobs[jb].tw);
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < R / 2; i += kNtt2Lanes) tws[i] = twg[i];
+  F x[16];
+  // ---- group 0 (stages 0..3) straight from global memory: item b of line t = cells b + j*(R/16)
+  {
+    constexpr int LQ = LOG_R - 4;  // q = R/16 items per line
+    const uint32_t b = tid & ((1u << LQ) - 1), t = tid >> LQ;
+    const gptr<uint32_t> src = data + (t << LOG_R) + b;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = F::raw(src[(uint32_t)j << LQ]);
+    __syncthreads();  // twiddle table
+    ntt2_stages<PP, LOG_R, 0, 4, LOG_R == 4>(x, tws, b);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[ntt2_line_pos<LOG_R>(t, b + ((uint32_t)j << LQ))] = x[j].v;
+  }
+  __syncthreads();
+  // ---- middle groups
+  if constexpr (G >= 3) {
+    constexpr int S = 4;
+    constexpr int LQ = LOG_R - S - 4;
+    const uint32_t it = tid & ((R / 16) - 1), t = tid >> (LOG_R - 4);
+    const uint32_t low = it & ((1u << LQ) - 1), high = it >> LQ;
+    const uint32_t r0 = (high << (LQ + 4)) | low;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[ntt2_line_pos<LOG_R>(t, r0 + ((uint32_t)j << LQ))]);
+    ntt2_stages<PP, LOG_R, S, 4, false>(x, tws, low);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[ntt2_line_pos<LOG_R>(t, r0 + ((uint32_t)j << LQ))] = x[j].v;
+    __syncthreads();
+  }
+  // ---- last group: 16 consecutive cells per lane, constant twiddles
+  {
+    constexpr int S = 4 * (G - 1);
+    const uint32_t it = tid & ((R / 16) - 1), t = tid >> (LOG_R - 4);
+    const uint32_t r0 = it << 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[ntt2_line_pos<LOG_R>(t, r0 + j)]);
+    ntt2_stages<PP, LOG_R, S, ML_LAST, true>(x, nullptr, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[ntt2_line_pos<LOG_R>(t, r0 + j)] = x[j].v;
+  }
+  __syncthreads();
+  // ---- copy out, lanes along the line
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t cell = tid + (uint32_t)j * kNtt2Lanes;
+    data[cell] = tile[ntt2_line_pos<LOG_R>(cell >> LOG_R, cell & (R - 1))];
+  }
+}
+
+// ------------------------------------------------------------------ pass 1: strided dimension, all cosets
+// Coefficients c[n1][n2] (index n1*N2 + n2) of one column; a tile is [R rows n1][T = 2^13/R columns n2].
+// out[z][r][n2] = w_N^(k1*n2) * sum_n1 (s_z^(N2*n1 + n2) c[n1][n2]) w_R^(n1*k1),  k1 = bitrev(r).
+struct NttColJob {
+  const uint32_t* in;
+  uint32_t* out;
+  const uint32_t* tw;      // w_R^i, i < R/2
+  const uint32_t* tw4_lo;  // w_N^x = hi[x >> 10] * lo[x & 1023]
+  const uint32_t* tw4_hi;
+  const uint32_t* pre_a;   // [cosets][N1]: s_z^(N2*n1)
+  const uint32_t* pre_b;   // [cosets][N2]: s_z^n2
+  uint64_t in_col_stride, out_col_stride, out_coset_stride;
+  int log_n2, log_cosets;
+  uint32_t block0;  // tile fastest, then coset, then column
+};
+
+template <class PP, int LOG_R>
+__global__ void __launch_bounds__(kNtt2Lanes, 2) k_ntt_fwd_col(const NttColJob* __restrict__ jobs, int n_jobs) {
+  using F = Fp<PP>;
+  static_assert(LOG_R >= 5 && LOG_R <= 12, "sub-transform size");
+  constexpr uint32_t R = 1u << LOG_R;
+  constexpr int LOG_T = kNtt2LogTile - LOG_R;
+  constexpr uint32_t T = 1u << LOG_T;
+  constexpr int G = (LOG_R + 3) / 4;
+  constexpr int ML_LAST = LOG_R - 4 * (G - 1);
+  __shared__ uint32_t tile[R * (T + 1) + (R >> 5) + 2];
+  __shared__ uint32_t tws[R / 2];
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const NttColJob& a = jobs[jb];
+  const int log_gx = a.log_n2 - LOG_T;
+  const uint32_t local = blockIdx.x - a.block0;
+  const uint32_t bx = local & ((1u << log_gx) - 1);
+  const uint32_t bz = (local >> log_gx) & ((1u << a.log_cosets) - 1);
+  const uint32_t by = local >> (log_gx + a.log_cosets);
+  const uint32_t N2 = 1u << a.log_n2;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t t = tid & (T - 1), it = tid >> LOG_T;  // column inside the tile, 16-row item
+  const uint32_t n2 = (bx << LOG_T) + t;
+  const gptr<const uint32_t> twg = as_global(a.tw);
+  for (uint32_t i = tid; i < R / 2; i += kNtt2Lanes) tws[i] = twg[i];
+  F x[16];
+  // ---- group 0 from global memory: rows it + j*(R/16), scaled by the coset shift powers
+  {
+    constexpr int LQ = LOG_R - 4;
+    const gptr<const uint32_t> src = as_global(a.in) + (size_t)by * a.in_col_stride + n2;
+    const gptr<const uint32_t> pa = as_global(a.pre_a) + ((size_t)bz << LOG_R);
+    const F pb = F::raw(as_global(a.pre_b)[((size_t)bz << a.log_n2) + n2]);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t n1 = it + ((uint32_t)j << LQ);
+      x[j] = F::raw(src[(size_t)n1 << a.log_n2]) * (F::raw(pa[n1]) * pb);
+    }
+    __syncthreads();  // twiddle table
+    ntt2_stages<PP, LOG_R, 0, 4, false>(x, tws, it);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[lds_addr(it + ((uint32_t)j << LQ), t, T)] = x[j].v;
+  }
+  __syncthreads();
+  if constexpr (G >= 3) {
+    constexpr int S = 4;
+    constexpr int LQ = LOG_R - S - 4;
+    const uint32_t low = it & ((1u << LQ) - 1), high = it >> LQ;
+    const uint32_t r0 = (high << (LQ + 4)) | low;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + ((uint32_t)j << LQ), t, T)]);
+    ntt2_stages<PP, LOG_R, S, 4, false>(x, tws, low);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[lds_addr(r0 + ((uint32_t)j << LQ), t, T)] = x[j].v;
+    __syncthreads();
+  }
+  // ---- last group: rows 16*it .. 16*it+15, straight to global memory with the four-step twiddle
+  {
+    constexpr int S = 4 * (G - 1);
+    const uint32_t r0 = it << 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + j, t, T)]);
+    ntt2_stages<PP, LOG_R, S, ML_LAST, true>(x, nullptr, 0);
+    const gptr<uint32_t> dst = as_global(a.out) + (size_t)by * a.out_col_stride + (size_t)bz * a.out_coset_stride + n2;
+    const gptr<const uint32_t> lo = as_global(a.tw4_lo), hi = as_global(a.tw4_hi);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t r = r0 + j;
+      const uint32_t xk = bit_reverse(r, LOG_R) * n2;  // < N
+      const F tw = F::raw(hi[xk >> 10]) * F::raw(lo[xk & 1023]);
+      dst[(size_t)r << a.log_n2] = (x[j] * tw).v;
+    }
+  }
+}
+
+}  // namespace p3r

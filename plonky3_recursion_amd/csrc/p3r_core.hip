@@ -4,6 +4,7 @@
 #include "kernels.cuh"
 #include "kernels_stark.cuh"
 #include "kernels_coop.cuh"
+#include "kernels_ntt2.cuh"
 #include "poseidon2_rc_default.inc"
 #include "profile.h"
 
@@ -290,6 +291,61 @@ void launch_ntt(p3r_ctx* ctx, std::vector<NttJob>& jobs, const char* name) {
   P3R_HIP(hipGetLastError());
 }
 
+// The lean forward passes (kernels_ntt2.cuh): jobs grouped by the compile-time sub-transform size.
+template <class PP, int LOG_R>
+void launch_fwd_col_r(p3r_ctx* ctx, std::vector<NttColJob>& jobs, uint32_t blocks) {
+  const auto* d = static_cast<const NttColJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(NttColJob)));
+  ProfScope ps(ctx, "ntt_forward_1");
+  hipLaunchKernelGGL((k_ntt_fwd_col<PP, LOG_R>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
+  P3R_HIP(hipGetLastError());
+}
+template <class PP, int LOG_R>
+void launch_fwd_line_r(p3r_ctx* ctx, std::vector<NttLineJob>& jobs, uint32_t blocks) {
+  const auto* d = static_cast<const NttLineJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(NttLineJob)));
+  ProfScope ps(ctx, "ntt_forward_2");
+  hipLaunchKernelGGL((k_ntt_fwd_line<PP, LOG_R>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
+  P3R_HIP(hipGetLastError());
+}
+constexpr int kNtt2MinLogR = 5, kNtt2MaxLogR = 12;
+template <class PP>
+void launch_fwd_col(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttColJob>, uint64_t>>& by_r) {
+  for (auto& kv : by_r) {
+    auto& jobs = kv.second.first;
+    if (kv.second.second >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "NTT launch of %llu tiles", (unsigned long long)kv.second.second);
+    const uint32_t blocks = (uint32_t)kv.second.second;
+    switch (kv.first) {
+      case 5: launch_fwd_col_r<PP, 5>(ctx, jobs, blocks); break;
+      case 6: launch_fwd_col_r<PP, 6>(ctx, jobs, blocks); break;
+      case 7: launch_fwd_col_r<PP, 7>(ctx, jobs, blocks); break;
+      case 8: launch_fwd_col_r<PP, 8>(ctx, jobs, blocks); break;
+      case 9: launch_fwd_col_r<PP, 9>(ctx, jobs, blocks); break;
+      case 10: launch_fwd_col_r<PP, 10>(ctx, jobs, blocks); break;
+      case 11: launch_fwd_col_r<PP, 11>(ctx, jobs, blocks); break;
+      case 12: launch_fwd_col_r<PP, 12>(ctx, jobs, blocks); break;
+      default: fail(P3R_EUNSUPPORTED, "forward NTT column pass of 2^%d rows", kv.first);
+    }
+  }
+}
+template <class PP>
+void launch_fwd_line(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttLineJob>, uint64_t>>& by_r) {
+  for (auto& kv : by_r) {
+    auto& jobs = kv.second.first;
+    if (kv.second.second >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "NTT launch of %llu tiles", (unsigned long long)kv.second.second);
+    const uint32_t blocks = (uint32_t)kv.second.second;
+    switch (kv.first) {
+      case 5: launch_fwd_line_r<PP, 5>(ctx, jobs, blocks); break;
+      case 6: launch_fwd_line_r<PP, 6>(ctx, jobs, blocks); break;
+      case 7: launch_fwd_line_r<PP, 7>(ctx, jobs, blocks); break;
+      case 8: launch_fwd_line_r<PP, 8>(ctx, jobs, blocks); break;
+      case 9: launch_fwd_line_r<PP, 9>(ctx, jobs, blocks); break;
+      case 10: launch_fwd_line_r<PP, 10>(ctx, jobs, blocks); break;
+      case 11: launch_fwd_line_r<PP, 11>(ctx, jobs, blocks); break;
+      case 12: launch_fwd_line_r<PP, 12>(ctx, jobs, blocks); break;
+      default: fail(P3R_EUNSUPPORTED, "forward NTT line pass of 2^%d cells", kv.first);
+    }
+  }
+}
+
 // K5 for a batch of matrices (all tables of a commit): every matrix goes through the same passes,
 // and pass k of all of them is one launch.
 // in: h x w evaluations over the subgroup (natural order, column-major Montgomery).
@@ -307,6 +363,9 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
   std::vector<DevBuf> scratch;  // coefficient vectors and transposition buffers
   // phase 1/2: inverse transform (small matrices: 1 = inverse, 2 = forward); 3/4: forward of the rest
   std::vector<NttJob> phase[4];
+  std::map<int, std::pair<std::vector<NttColJob>, uint64_t>> fwd_col;    // sub-transform size -> (jobs, blocks)
+  std::map<int, std::pair<std::vector<NttLineJob>, uint64_t>> fwd_line;
+  static const bool lean_fwd = !getenv("P3R_NTT_OLD");
   static const int fwd_la_cap = getenv("P3R_NTT_FWD_LOG_N1") ? atoi(getenv("P3R_NTT_FWD_LOG_N1")) : 8;
   for (const LdeItem& it : items) {
     const p3r_dmat* in = it.in;
@@ -370,6 +429,29 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
     const int la_f = log_n - fwd_la_cap <= 12 ? std::min(log_n / 2, fwd_la_cap) : log_n / 2, lb_f = log_n - la_f;
     auto pre = get_pre<PP>(ctx, log_n, la_f, lb_f, added_bits, shift);
     auto tw4f = get_tw4<PP>(ctx, log_n, 0);
+    if (lean_fwd && la_f >= kNtt2MinLogR && la_f <= kNtt2MaxLogR && lb_f >= kNtt2MinLogR && lb_f <= kNtt2MaxLogR &&
+        lb_f >= kNtt2LogTile - la_f) {
+      // lean kernels (kernels_ntt2.cuh): the same two passes with compile-time geometry
+      NttColJob cj{};
+      cj.in = coef; cj.out = out->d;
+      cj.tw = get_tw_sub<PP>(ctx, la_f, 0);
+      cj.tw4_lo = tw4f.first; cj.tw4_hi = tw4f.second;
+      cj.pre_a = pre.first; cj.pre_b = pre.second;
+      cj.in_col_stride = N; cj.out_col_stride = N * B; cj.out_coset_stride = N;
+      cj.log_n2 = lb_f; cj.log_cosets = added_bits;
+      auto& fc = fwd_col[la_f];
+      cj.block0 = (uint32_t)fc.second;
+      fc.second += (uint64_t)w << (lb_f - (kNtt2LogTile - la_f) + added_bits);
+      fc.first.push_back(cj);
+      NttLineJob lj{};
+      lj.data = out->d;
+      lj.tw = get_tw_sub<PP>(ctx, lb_f, 0);
+      auto& fl = fwd_line[lb_f];
+      lj.block0 = (uint32_t)fl.second;
+      fl.second += ((uint64_t)w * N * B) >> kNtt2LogTile;
+      fl.first.push_back(lj);
+      continue;
+    }
     p = NttPass{};
     p.in = coef; p.out = out->d;
     p.in_col_stride = N; p.out_col_stride = N * B; p.out_coset_stride = N;
@@ -387,10 +469,12 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
     p.tw_sub = get_tw_sub<PP>(ctx, lb_f, 0);
     phase[3].push_back({p, w, 1});
   }
-  launch_ntt<PP>(ctx, phase[0], "ntt_inverse");
-  launch_ntt<PP>(ctx, phase[1], "ntt_inverse");
-  launch_ntt<PP>(ctx, phase[2], "ntt_forward");
-  launch_ntt<PP>(ctx, phase[3], "ntt_forward");
+  launch_ntt<PP>(ctx, phase[0], "ntt_inverse_1");
+  launch_ntt<PP>(ctx, phase[1], "ntt_inverse_2");
+  launch_ntt<PP>(ctx, phase[2], "ntt_forward_1");
+  launch_fwd_col<PP>(ctx, fwd_col);
+  launch_ntt<PP>(ctx, phase[3], "ntt_forward_2");
+  launch_fwd_line<PP>(ctx, fwd_line);
   return outs;
 }
 template <class PP>
