@@ -57,8 +57,8 @@ __device__ __forceinline__ void ntt2_bfly_one(Fp<PP>& p, Fp<PP>& c) {  // twiddl
 // M = 2^ML cells form an item (rows r0 + j*q, q = 2^(LOG_R-S-ML)); a lane holds 16/M items in
 // x[i*M + j].  LAST (q == 1): the twiddles are compile-time constants; otherwise `tws` is the
 // table w_R^i (i < R/2) and `low` the item's position below q.
-template <class PP, int LOG_R, int S, int ML, bool LAST>
-__device__ __forceinline__ void ntt2_stages(Fp<PP>* x, const uint32_t* tws, uint32_t low) {
+template <class PP, int LOG_R, int S, int ML, bool LAST, class TW>
+__device__ __forceinline__ void ntt2_stages(Fp<PP>* x, TW tws, uint32_t low) {
   constexpr int M = 1 << ML;
   constexpr int LQ = LOG_R - S - ML;
   static_assert(!LAST || LQ == 0, "the last group ends the transform");
@@ -108,7 +108,7 @@ struct NttLineJob {
 };
 
 template <class PP, int LOG_R>
-__global__ void __launch_bounds__(kNtt2Lanes, 2) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
+__global__ void __launch_bounds__(kNtt2Lanes, 6) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
   static_assert(LOG_R >= 5 && LOG_R <= 12, "line length");
   constexpr uint32_t R = 1u << LOG_R;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kNtt2Lanes, 2) k_ntt_fwd_line(const NttLineJob
   constexpr int G = (LOG_R + 3) / 4;             // stage groups: 4, 4, ..., remainder last
   constexpr int ML_LAST = LOG_R - 4 * (G - 1);
   __shared__ uint32_t tile[(LINE << LOG_T)];
-  __shared__ uint32_t tws[R / 2];
+  __shared__ uint32_t tws[R / 2];  // (reading the table through L1 instead frees LDS for a fourth tile per CU but measured 25 % slower)
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
   const gptr<uint32_t> data = as_global(jobs[jb].data) + ((size_t)(blockIdx.x - jobs[jb].block0) << kNtt2LogTile);
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(kNtt2Lanes, 2) k_ntt_fwd_line(const NttLineJob
     const uint32_t r0 = it << 4;
 #pragma unroll
     for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[ntt2_line_pos<LOG_R>(t, r0 + j)]);
-    ntt2_stages<PP, LOG_R, S, ML_LAST, true>(x, nullptr, 0);
+    ntt2_stages<PP, LOG_R, S, ML_LAST, true>(x, (const uint32_t*)nullptr, 0);
 #pragma unroll
     for (int j = 0; j < 16; ++j) tile[ntt2_line_pos<LOG_R>(t, r0 + j)] = x[j].v;
   }
@@ -189,7 +189,7 @@ struct NttColJob {
 };
 
 template <class PP, int LOG_R>
-__global__ void __launch_bounds__(kNtt2Lanes, 2) k_ntt_fwd_col(const NttColJob* __restrict__ jobs, int n_jobs) {
+__global__ void __launch_bounds__(kNtt2Lanes, 8) k_ntt_fwd_col(const NttColJob* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
   static_assert(LOG_R >= 5 && LOG_R <= 12, "sub-transform size");
   constexpr uint32_t R = 1u << LOG_R;
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kNtt2Lanes, 2) k_ntt_fwd_col(const NttColJob* 
     const uint32_t r0 = it << 4;
 #pragma unroll
     for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + j, t, T)]);
-    ntt2_stages<PP, LOG_R, S, ML_LAST, true>(x, nullptr, 0);
+    ntt2_stages<PP, LOG_R, S, ML_LAST, true>(x, (const uint32_t*)nullptr, 0);
     const gptr<uint32_t> dst = as_global(a.out) + (size_t)by * a.out_col_stride + (size_t)bz * a.out_coset_stride + n2;
     const gptr<const uint32_t> lo = as_global(a.tw4_lo), hi = as_global(a.tw4_hi);
 #pragma unroll
