@@ -21,19 +21,20 @@ constexpr int kNtt2Lanes = 512;
 // w_{2^log_r}^idx in Montgomery form, at compile time (the twiddles of a last stage group are the
 // 16th roots of unity and their squares: immediates instead of LDS reads)
 template <class PP>
-constexpr uint32_t ntt2_root_mont(int log_r, uint32_t idx) {
-  const uint32_t g = pow_mod(PP::GEN, ((uint64_t)PP::P - 1) >> log_r, PP::P);
+constexpr uint32_t ntt2_root_mont(int log_r, uint32_t idx, bool inverse) {
+  uint32_t g = pow_mod(PP::GEN, ((uint64_t)PP::P - 1) >> log_r, PP::P);
+  if (inverse) g = pow_mod(g, (uint64_t)PP::P - 2, PP::P);
   const uint64_t w = pow_mod(g, idx, PP::P);
   return (uint32_t)((w << 32) % PP::P);
 }
 
 // twiddles of a LAST stage group (S .. S+ML-1, q = 1): v[u][jj] = w_R^(jj << (S+u))
-template <class PP, int LOG_R, int S, int ML>
+template <class PP, int LOG_R, int S, int ML, bool INV>
 struct Ntt2LastTw {
   uint32_t v[4][8];
   constexpr Ntt2LastTw() : v() {
     for (int u = 0; u < ML; ++u)
-      for (int jj = 0; jj < ((1 << ML) >> (u + 1)); ++jj) v[u][jj] = ntt2_root_mont<PP>(LOG_R, (uint32_t)jj << (S + u));
+      for (int jj = 0; jj < ((1 << ML) >> (u + 1)); ++jj) v[u][jj] = ntt2_root_mont<PP>(LOG_R, (uint32_t)jj << (S + u), INV);
   }
 };
 
@@ -56,13 +57,14 @@ __device__ __forceinline__ void ntt2_bfly_one(Fp<PP>& p, Fp<PP>& c) {  // twiddl
 // ML stages (S .. S+ML-1) of a size-2^LOG_R DIF transform on the 16 registers of a lane.
 // M = 2^ML cells form an item (rows r0 + j*q, q = 2^(LOG_R-S-ML)); a lane holds 16/M items in
 // x[i*M + j].  LAST (q == 1): the twiddles are compile-time constants; otherwise `tws` is the
-// table w_R^i (i < R/2) and `low` the item's position below q.
-template <class PP, int LOG_R, int S, int ML, bool LAST, class TW>
+// table w_R^i (i < R/2) and `low` the item's position below q.  INV: the constants are powers of w_R^-1
+// (the table is the caller's, already inverse).
+template <class PP, int LOG_R, int S, int ML, bool LAST, bool INV = false, class TW = const uint32_t*>
 __device__ __forceinline__ void ntt2_stages(Fp<PP>* x, TW tws, uint32_t low) {
   constexpr int M = 1 << ML;
   constexpr int LQ = LOG_R - S - ML;
   static_assert(!LAST || LQ == 0, "the last group ends the transform");
-  constexpr Ntt2LastTw<PP, LOG_R, S, ML> kLast{};
+  constexpr Ntt2LastTw<PP, LOG_R, S, ML, INV> kLast{};
 #pragma unroll
   for (int u = 0; u < ML; ++u) {
     const int half = M >> (u + 1);
@@ -172,26 +174,35 @@ __global__ void __launch_bounds__(kNtt2Lanes, 6) k_ntt_fwd_line(const NttLineJob
   }
 }
 
-// ------------------------------------------------------------------ pass 1: strided dimension, all cosets
-// Coefficients c[n1][n2] (index n1*N2 + n2) of one column; a tile is [R rows n1][T = 2^13/R columns n2].
-// out[z][r][n2] = w_N^(k1*n2) * sum_n1 (s_z^(N2*n1 + n2) c[n1][n2]) w_R^(n1*k1),  k1 = bitrev(r).
+// ------------------------------------------------------------------ column passes (strided dimension)
+// One column is viewed as [N1 rows][N2] (index n1*N2 + n2); a tile is [R = N1 rows][T = 2^13/R columns n2]
+// and the size-R transform runs along the rows (DIF: tile row r ends up holding output k1 = bitrev(r)).
+//   NTT2_FWD   forward pass 1 of the LDE, every coset z: input scaled by s_z^(N2*n1 + n2), output times
+//              the four-step twiddle w_N^(k1*n2), stored at row r (bit-reversed order kept):
+//              out[z][r*N2 + n2]
+//   NTT2_INV1  inverse pass 1: output times w_N^-(k1*n2), stored TRANSPOSED in natural order,
+//              out[n2*N1 + k1] (through LDS, so that lanes run along k1)
+//   NTT2_INV2  inverse pass 2: output times `scale` (1/N), natural order, out[k1*N2 + n2]
+enum { NTT2_FWD = 0, NTT2_INV1 = 1, NTT2_INV2 = 2 };
 struct NttColJob {
   const uint32_t* in;
   uint32_t* out;
-  const uint32_t* tw;      // w_R^i, i < R/2
-  const uint32_t* tw4_lo;  // w_N^x = hi[x >> 10] * lo[x & 1023]
+  const uint32_t* tw;      // w_R^(+-i), i < R/2
+  const uint32_t* tw4_lo;  // w_N^(+-x) = hi[x >> 10] * lo[x & 1023]
   const uint32_t* tw4_hi;
   const uint32_t* pre_a;   // [cosets][N1]: s_z^(N2*n1)
   const uint32_t* pre_b;   // [cosets][N2]: s_z^n2
   uint64_t in_col_stride, out_col_stride, out_coset_stride;
   int log_n2, log_cosets;
+  uint32_t scale;   // Montgomery (NTT2_INV2)
   uint32_t block0;  // tile fastest, then coset, then column
 };
 
-template <class PP, int LOG_R>
-__global__ void __launch_bounds__(kNtt2Lanes, 8) k_ntt_fwd_col(const NttColJob* __restrict__ jobs, int n_jobs) {
+template <class PP, int LOG_R, int MODE>
+__global__ void __launch_bounds__(kNtt2Lanes, 8) k_ntt_col(const NttColJob* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
   static_assert(LOG_R >= 5 && LOG_R <= 12, "sub-transform size");
+  constexpr bool INV = MODE != NTT2_FWD;
   constexpr uint32_t R = 1u << LOG_R;
   constexpr int LOG_T = kNtt2LogTile - LOG_R;
   constexpr uint32_t T = 1u << LOG_T;
@@ -207,26 +218,31 @@ __global__ void __launch_bounds__(kNtt2Lanes, 8) k_ntt_fwd_col(const NttColJob* 
   const uint32_t bx = local & ((1u << log_gx) - 1);
   const uint32_t bz = (local >> log_gx) & ((1u << a.log_cosets) - 1);
   const uint32_t by = local >> (log_gx + a.log_cosets);
-  const uint32_t N2 = 1u << a.log_n2;
   const uint32_t tid = threadIdx.x;
   const uint32_t t = tid & (T - 1), it = tid >> LOG_T;  // column inside the tile, 16-row item
   const uint32_t n2 = (bx << LOG_T) + t;
   const gptr<const uint32_t> twg = as_global(a.tw);
   for (uint32_t i = tid; i < R / 2; i += kNtt2Lanes) tws[i] = twg[i];
   F x[16];
-  // ---- group 0 from global memory: rows it + j*(R/16), scaled by the coset shift powers
+  // ---- group 0 from global memory: rows it + j*(R/16)
   {
     constexpr int LQ = LOG_R - 4;
     const gptr<const uint32_t> src = as_global(a.in) + (size_t)by * a.in_col_stride + n2;
-    const gptr<const uint32_t> pa = as_global(a.pre_a) + ((size_t)bz << LOG_R);
-    const F pb = F::raw(as_global(a.pre_b)[((size_t)bz << a.log_n2) + n2]);
+    if constexpr (MODE == NTT2_FWD) {  // scaled by the coset shift powers
+      const gptr<const uint32_t> pa = as_global(a.pre_a) + ((size_t)bz << LOG_R);
+      const F pb = F::raw(as_global(a.pre_b)[((size_t)bz << a.log_n2) + n2]);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t n1 = it + ((uint32_t)j << LQ);
-      x[j] = F::raw(src[(size_t)n1 << a.log_n2]) * (F::raw(pa[n1]) * pb);
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t n1 = it + ((uint32_t)j << LQ);
+        // the inner product stays in [0, 2P): the outer REDC takes one unreduced factor (2P * P < P * 2^32)
+        x[j] = F::raw(src[(size_t)n1 << a.log_n2]) * F::raw(F::reduce64_lazy((uint64_t)pa[n1] * pb.v));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = F::raw(src[(size_t)(it + ((uint32_t)j << LQ)) << a.log_n2]);
     }
     __syncthreads();  // twiddle table
-    ntt2_stages<PP, LOG_R, 0, 4, false>(x, tws, it);
+    ntt2_stages<PP, LOG_R, 0, 4, false, INV>(x, tws, it);
 #pragma unroll
     for (int j = 0; j < 16; ++j) tile[lds_addr(it + ((uint32_t)j << LQ), t, T)] = x[j].v;
   }
@@ -238,26 +254,51 @@ __global__ void __launch_bounds__(kNtt2Lanes, 8) k_ntt_fwd_col(const NttColJob* 
     const uint32_t r0 = (high << (LQ + 4)) | low;
 #pragma unroll
     for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + ((uint32_t)j << LQ), t, T)]);
-    ntt2_stages<PP, LOG_R, S, 4, false>(x, tws, low);
+    ntt2_stages<PP, LOG_R, S, 4, false, INV>(x, tws, low);
 #pragma unroll
     for (int j = 0; j < 16; ++j) tile[lds_addr(r0 + ((uint32_t)j << LQ), t, T)] = x[j].v;
     __syncthreads();
   }
-  // ---- last group: rows 16*it .. 16*it+15, straight to global memory with the four-step twiddle
-  {
-    constexpr int S = 4 * (G - 1);
-    const uint32_t r0 = it << 4;
+  // ---- last group: rows 16*it .. 16*it+15
+  constexpr int S_LAST = 4 * (G - 1);
+  const uint32_t r0 = it << 4;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + j, t, T)]);
-    ntt2_stages<PP, LOG_R, S, ML_LAST, true>(x, (const uint32_t*)nullptr, 0);
-    const gptr<uint32_t> dst = as_global(a.out) + (size_t)by * a.out_col_stride + (size_t)bz * a.out_coset_stride + n2;
+  for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + j, t, T)]);
+  ntt2_stages<PP, LOG_R, S_LAST, ML_LAST, true, INV>(x, (const uint32_t*)nullptr, 0);
+  const gptr<uint32_t> dst = as_global(a.out) + (size_t)by * a.out_col_stride + (size_t)bz * a.out_coset_stride;
+  if constexpr (MODE == NTT2_FWD) {
+    // straight to global memory with the four-step twiddle, rows in place
     const gptr<const uint32_t> lo = as_global(a.tw4_lo), hi = as_global(a.tw4_hi);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const uint32_t r = r0 + j;
       const uint32_t xk = bit_reverse(r, LOG_R) * n2;  // < N
-      const F tw = F::raw(hi[xk >> 10]) * F::raw(lo[xk & 1023]);
-      dst[(size_t)r << a.log_n2] = (x[j] * tw).v;
+      const F tw = F::raw(F::reduce64_lazy((uint64_t)hi[xk >> 10] * lo[xk & 1023]));
+      dst[((size_t)r << a.log_n2) + n2] = (x[j] * tw).v;
+    }
+  } else if constexpr (MODE == NTT2_INV2) {
+    // natural row order, scaled: row k1 = bitrev(r)
+    const F sc = F::raw(a.scale);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t k1 = bit_reverse(r0 + j, LOG_R);
+      dst[((size_t)k1 << a.log_n2) + n2] = (x[j] * sc).v;
+    }
+  } else {
+    // transposed: back through LDS so that consecutive lanes write consecutive k1
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[lds_addr(r0 + j, t, T)] = x[j].v;
+    __syncthreads();
+    const gptr<const uint32_t> lo = as_global(a.tw4_lo), hi = as_global(a.tw4_hi);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const uint32_t e = tid + (uint32_t)j * kNtt2Lanes;
+      const uint32_t k1 = e & (R - 1), tt = e >> LOG_R;
+      const uint32_t col = (bx << LOG_T) + tt;
+      const uint32_t xk = k1 * col;
+      const F tw = F::raw(F::reduce64_lazy((uint64_t)hi[xk >> 10] * lo[xk & 1023]));
+      const F v = F::raw(tile[lds_addr(bit_reverse(k1, LOG_R), tt, T)]);
+      dst[((size_t)col << LOG_R) + k1] = (v * tw).v;
     }
   }
 }

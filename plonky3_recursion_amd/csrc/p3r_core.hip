@@ -292,11 +292,11 @@ void launch_ntt(p3r_ctx* ctx, std::vector<NttJob>& jobs, const char* name) {
 }
 
 // The lean forward passes (kernels_ntt2.cuh): jobs grouped by the compile-time sub-transform size.
-template <class PP, int LOG_R>
-void launch_fwd_col_r(p3r_ctx* ctx, std::vector<NttColJob>& jobs, uint32_t blocks) {
+template <class PP, int LOG_R, int MODE>
+void launch_col_r(p3r_ctx* ctx, std::vector<NttColJob>& jobs, uint32_t blocks) {
   const auto* d = static_cast<const NttColJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(NttColJob)));
-  ProfScope ps(ctx, "ntt_forward_1");
-  hipLaunchKernelGGL((k_ntt_fwd_col<PP, LOG_R>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
+  ProfScope ps(ctx, MODE == NTT2_FWD ? "ntt_forward_1" : MODE == NTT2_INV1 ? "ntt_inverse_1" : "ntt_inverse_2");
+  hipLaunchKernelGGL((k_ntt_col<PP, LOG_R, MODE>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
   P3R_HIP(hipGetLastError());
 }
 template <class PP, int LOG_R>
@@ -307,22 +307,22 @@ void launch_fwd_line_r(p3r_ctx* ctx, std::vector<NttLineJob>& jobs, uint32_t blo
   P3R_HIP(hipGetLastError());
 }
 constexpr int kNtt2MinLogR = 5, kNtt2MaxLogR = 12;
-template <class PP>
-void launch_fwd_col(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttColJob>, uint64_t>>& by_r) {
+template <class PP, int MODE>
+void launch_col(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttColJob>, uint64_t>>& by_r) {
   for (auto& kv : by_r) {
     auto& jobs = kv.second.first;
     if (kv.second.second >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "NTT launch of %llu tiles", (unsigned long long)kv.second.second);
     const uint32_t blocks = (uint32_t)kv.second.second;
     switch (kv.first) {
-      case 5: launch_fwd_col_r<PP, 5>(ctx, jobs, blocks); break;
-      case 6: launch_fwd_col_r<PP, 6>(ctx, jobs, blocks); break;
-      case 7: launch_fwd_col_r<PP, 7>(ctx, jobs, blocks); break;
-      case 8: launch_fwd_col_r<PP, 8>(ctx, jobs, blocks); break;
-      case 9: launch_fwd_col_r<PP, 9>(ctx, jobs, blocks); break;
-      case 10: launch_fwd_col_r<PP, 10>(ctx, jobs, blocks); break;
-      case 11: launch_fwd_col_r<PP, 11>(ctx, jobs, blocks); break;
-      case 12: launch_fwd_col_r<PP, 12>(ctx, jobs, blocks); break;
-      default: fail(P3R_EUNSUPPORTED, "forward NTT column pass of 2^%d rows", kv.first);
+      case 5: launch_col_r<PP, 5, MODE>(ctx, jobs, blocks); break;
+      case 6: launch_col_r<PP, 6, MODE>(ctx, jobs, blocks); break;
+      case 7: launch_col_r<PP, 7, MODE>(ctx, jobs, blocks); break;
+      case 8: launch_col_r<PP, 8, MODE>(ctx, jobs, blocks); break;
+      case 9: launch_col_r<PP, 9, MODE>(ctx, jobs, blocks); break;
+      case 10: launch_col_r<PP, 10, MODE>(ctx, jobs, blocks); break;
+      case 11: launch_col_r<PP, 11, MODE>(ctx, jobs, blocks); break;
+      case 12: launch_col_r<PP, 12, MODE>(ctx, jobs, blocks); break;
+      default: fail(P3R_EUNSUPPORTED, "NTT column pass of 2^%d rows", kv.first);
     }
   }
 }
@@ -365,6 +365,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
   std::vector<NttJob> phase[4];
   std::map<int, std::pair<std::vector<NttColJob>, uint64_t>> fwd_col;    // sub-transform size -> (jobs, blocks)
   std::map<int, std::pair<std::vector<NttLineJob>, uint64_t>> fwd_line;
+  std::map<int, std::pair<std::vector<NttColJob>, uint64_t>> inv1, inv2;
   static const bool lean_fwd = !getenv("P3R_NTT_OLD");
   static const int fwd_la_cap = getenv("P3R_NTT_FWD_LOG_N1") ? atoi(getenv("P3R_NTT_FWD_LOG_N1")) : 8;
   for (const LdeItem& it : items) {
@@ -405,6 +406,29 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
     scratch.emplace_back(N * w);
     uint32_t* tmp = scratch.back().p;
     auto tw4i = get_tw4<PP>(ctx, log_n, 1);
+    const bool lean_inv = lean_fwd && la >= kNtt2MinLogR && lb <= kNtt2MaxLogR && la >= kNtt2LogTile - lb && lb >= kNtt2LogTile - la;
+    if (lean_inv) {
+      NttColJob j1{};
+      j1.in = in->d; j1.out = tmp;
+      j1.tw = get_tw_sub<PP>(ctx, la, 1);
+      j1.tw4_lo = tw4i.first; j1.tw4_hi = tw4i.second;
+      j1.in_col_stride = N; j1.out_col_stride = N;
+      j1.log_n2 = lb;
+      auto& q1 = inv1[la];
+      j1.block0 = (uint32_t)q1.second;
+      q1.second += (uint64_t)w << (lb - (kNtt2LogTile - la));
+      q1.first.push_back(j1);
+      NttColJob j2{};   // tmp viewed as [N2 rows][N1]: size-N2 transforms along the rows
+      j2.in = tmp; j2.out = coef;
+      j2.tw = get_tw_sub<PP>(ctx, lb, 1);
+      j2.in_col_stride = N; j2.out_col_stride = N;
+      j2.log_n2 = la;
+      j2.scale = inv_n;
+      auto& q2 = inv2[lb];
+      j2.block0 = (uint32_t)q2.second;
+      q2.second += (uint64_t)w << (la - (kNtt2LogTile - lb));
+      q2.first.push_back(j2);
+    } else {
     // inverse pass 1: size-N1 transforms along n1, twiddle, transposed store tmp[n2*N1 + k1]
     p.in = in->d; p.out = tmp;
     p.in_col_stride = N; p.out_col_stride = N;
@@ -421,6 +445,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
     p.tw_sub = get_tw_sub<PP>(ctx, lb, 1); p.inverse = 1;
     p.scale = inv_n; p.use_scale = 1;
     phase[1].push_back({p, w, 1});
+    }
     // forward pass 1 (all cosets): scale by s_z^k, size-N1 transforms along n1, twiddle, in place rows.
     // The forward transform has its own split: its strided pass wants few rows per tile (long
     // contiguous segments per row), its second pass is contiguous whatever N2 is.
@@ -470,9 +495,11 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
     phase[3].push_back({p, w, 1});
   }
   launch_ntt<PP>(ctx, phase[0], "ntt_inverse_1");
+  launch_col<PP, NTT2_INV1>(ctx, inv1);
   launch_ntt<PP>(ctx, phase[1], "ntt_inverse_2");
+  launch_col<PP, NTT2_INV2>(ctx, inv2);
   launch_ntt<PP>(ctx, phase[2], "ntt_forward_1");
-  launch_fwd_col<PP>(ctx, fwd_col);
+  launch_col<PP, NTT2_FWD>(ctx, fwd_col);
   launch_ntt<PP>(ctx, phase[3], "ntt_forward_2");
   launch_fwd_line<PP>(ctx, fwd_line);
   return outs;

@@ -67,6 +67,14 @@ __device__ __forceinline__ double p2f_mul_2exp_neg(double x, double m) {
   const double f = __builtin_amdgcn_fract(t);
   return __builtin_fma(-f, P2F64<PP>::P, t);
 }
+// x * m + a mod P for k <= 8 and an INTEGER a with |a| < 2^40: the addend rides in the first FMA
+// (a + x * 2^-k has at most 40 + 8 significant bits, so it is exact and frac(t) is unchanged)
+template <class PP>
+__device__ __forceinline__ double p2f_mul_2exp_neg_add(double x, double m, double a) {
+  const double t = __builtin_fma(x, m, a);
+  const double f = __builtin_amdgcn_fract(t);
+  return __builtin_fma(-f, P2F64<PP>::P, t);
+}
 
 template <class PP>
 __device__ __forceinline__ double p2f_sbox(double x) {
@@ -116,26 +124,26 @@ __device__ __forceinline__ void p2f_internal_linear(double* s, bool reduce_wide)
   s[0] = __builtin_fma(s[0], -2.0, sum);
   s[1] = s[1] + sum;
   s[2] = __builtin_fma(s[2], 2.0, sum);
-  s[3] = p2f_mul_2exp_neg<PP>(s[3], 0.5) + sum;
+  s[3] = p2f_mul_2exp_neg_add<PP>(s[3], 0.5, sum);
   s[4] = __builtin_fma(s[4], 3.0, sum);
   s[5] = __builtin_fma(s[5], 4.0, sum);
-  s[6] = p2f_mul_2exp_neg<PP>(s[6], -0.5) + sum;
+  s[6] = p2f_mul_2exp_neg_add<PP>(s[6], -0.5, sum);
   s[7] = __builtin_fma(s[7], -3.0, sum);
   s[8] = __builtin_fma(s[8], -4.0, sum);
-  s[9] = p2f_mul_2exp_neg<PP>(s[9], 0x1p-8) + sum;
+  s[9] = p2f_mul_2exp_neg_add<PP>(s[9], 0x1p-8, sum);
   if (PP::FIELD_ID == 0) {
-    s[10] = p2f_mul_2exp_neg<PP>(s[10], 0x1p-3) + sum;
+    s[10] = p2f_mul_2exp_neg_add<PP>(s[10], 0x1p-3, sum);
     s[11] = p2f_mul_2exp_neg<PP>(s[11], 0x1p-24) + sum;
-    s[12] = p2f_mul_2exp_neg<PP>(s[12], -0x1p-8) + sum;
-    s[13] = p2f_mul_2exp_neg<PP>(s[13], -0x1p-3) + sum;
-    s[14] = p2f_mul_2exp_neg<PP>(s[14], -0x1p-4) + sum;
+    s[12] = p2f_mul_2exp_neg_add<PP>(s[12], -0x1p-8, sum);
+    s[13] = p2f_mul_2exp_neg_add<PP>(s[13], -0x1p-3, sum);
+    s[14] = p2f_mul_2exp_neg_add<PP>(s[14], -0x1p-4, sum);
     s[15] = p2f_mul_2exp_neg<PP>(s[15], -0x1p-24) + sum;
   } else {
-    s[10] = p2f_mul_2exp_neg<PP>(s[10], 0x1p-2) + sum;
-    s[11] = p2f_mul_2exp_neg<PP>(s[11], 0x1p-3) + sum;
+    s[10] = p2f_mul_2exp_neg_add<PP>(s[10], 0x1p-2, sum);
+    s[11] = p2f_mul_2exp_neg_add<PP>(s[11], 0x1p-3, sum);
     s[12] = p2f_mul_2exp_neg<PP>(s[12], 0x1p-27) + sum;
-    s[13] = p2f_mul_2exp_neg<PP>(s[13], -0x1p-8) + sum;
-    s[14] = p2f_mul_2exp_neg<PP>(s[14], -0x1p-4) + sum;
+    s[13] = p2f_mul_2exp_neg_add<PP>(s[13], -0x1p-8, sum);
+    s[14] = p2f_mul_2exp_neg_add<PP>(s[14], -0x1p-4, sum);
     s[15] = p2f_mul_2exp_neg<PP>(s[15], -0x1p-27) + sum;
   }
 }
