@@ -37,6 +37,8 @@ struct P2F64 {
   // x + MAGIC - MAGIC = x rounded to the nearest integer for |x| < 2^51: two full-rate instructions
   // (the first one fused with the product that forms x); v_rndne_f64 issues at half the DP rate.
   static constexpr double MAGIC = 0x1.8p52;
+  // P = P_HI + 1 with P_HI = c * 2^m (127 * 2^24, 15 * 2^27): q * P_HI is an exact double for q < 2^46
+  static constexpr double P_HI = (double)(PP::P - 1);
 };
 #pragma clang fp contract(off)
 
@@ -76,13 +78,35 @@ __device__ __forceinline__ double p2f_mul_2exp_neg_add(double x, double m, doubl
   return __builtin_fma(-f, P2F64<PP>::P, t);
 }
 
+// a * b mod P given c = b / P (rounded): five instructions, and c is shared by every product with
+// the same b (the S-box multiplies by x twice or three times).
+//   q = rint(a * c);  e = fma(a, b, -q * P_HI) = (a b - q P) + q exactly (an integer below 2^47, because
+//   q * P_HI is exact);  result = e - q.  Needs |a b| < 2^76 (q < 2^46); |result| < 0.7 P.
 template <class PP>
+__device__ __forceinline__ double p2f_mulmod_c(double a, double b, double c) {
+  const double q = __builtin_fma(a, c, P2F64<PP>::MAGIC) - P2F64<PP>::MAGIC;
+  const double t = q * P2F64<PP>::P_HI;
+  const double e = __builtin_fma(a, b, -t);
+  return e - q;
+}
+
+// WIDE: |x| may reach 2^41 (first full round of a sponge permutation: unreduced capacity carried
+// through the initial linear layer); otherwise |x| < 2^37.
+template <class PP, bool WIDE = false>
 __device__ __forceinline__ double p2f_sbox(double x) {
-  const double x2 = p2f_mulmod<PP>(x, x);
-  const double x3 = p2f_mulmod<PP>(x2, x);
+  if (WIDE) {
+    const double x2 = p2f_mulmod<PP>(x, x);
+    const double x3 = p2f_mulmod<PP>(x2, x);
+    if (PP::SBOX_DEGREE == 3) return x3;
+    const double x6 = p2f_mulmod<PP>(x3, x3);
+    return p2f_mulmod<PP>(x6, x);
+  }
+  const double c = x * P2F64<PP>::INVP;
+  const double x2 = p2f_mulmod_c<PP>(x, x, c);
+  const double x3 = p2f_mulmod_c<PP>(x2, x, c);
   if (PP::SBOX_DEGREE == 3) return x3;
-  const double x6 = p2f_mulmod<PP>(x3, x3);
-  return p2f_mulmod<PP>(x6, x);
+  const double x6 = p2f_mulmod_c<PP>(x3, x3, x3 * P2F64<PP>::INVP);
+  return p2f_mulmod_c<PP>(x6, x, c);
 }
 
 __device__ __forceinline__ void p2f_mat4(double& x0, double& x1, double& x2, double& x3) {
@@ -154,7 +178,12 @@ template <class PP>
 __device__ __forceinline__ void p2f_permute(double* s, const double* __restrict__ rc) {
   p2f_external_linear(s);
   int k = 0;
-  for (int r = 0; r < P2_HALF_FULL; ++r) {
+  // the first full round sees the widest inputs (see p2f_sbox)
+#pragma unroll
+  for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP, true>(s[i] + rc[k + i]);
+  k += P2_WIDTH;
+  p2f_external_linear(s);
+  for (int r = 1; r < P2_HALF_FULL; ++r) {
 #pragma unroll
     for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i]);
     k += P2_WIDTH;
@@ -165,7 +194,15 @@ __device__ __forceinline__ void p2f_permute(double* s, const double* __restrict_
     p2f_internal_linear<PP>(s, r % 5 == 0);
   }
   k += PP::PARTIAL_ROUNDS;
-  for (int r = 0; r < P2_HALF_FULL; ++r) {
+  // the lanes with |d| >= 2 leave the partial rounds unreduced (up to 4^5 * 2^31): wide S-box once
+#pragma unroll
+  for (int i = 0; i < P2_WIDTH; ++i) {
+    const bool wide = i == 2 || i == 4 || i == 5 || i == 7 || i == 8;
+    s[i] = wide ? p2f_sbox<PP, true>(s[i] + rc[k + i]) : p2f_sbox<PP>(s[i] + rc[k + i]);
+  }
+  k += P2_WIDTH;
+  p2f_external_linear(s);
+  for (int r = 1; r < P2_HALF_FULL; ++r) {
 #pragma unroll
     for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i]);
     k += P2_WIDTH;
