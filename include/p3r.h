@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3R_ABI_VERSION 1
+#define P3R_ABI_VERSION 2
 
 enum {
   P3R_OK = 0,
@@ -76,7 +76,21 @@ typedef struct p3r_config {
    * built-in table, which is self-generated and NOT pinned to upstream. */
   const uint32_t* poseidon2_rc;
   uint32_t poseidon2_rc_len;
+  /* Protocol details the in-tree reference does not pin (they live in un-vendored p3-* crates, DESIGN.md
+   * section 4) are selectable, so that a run of tools/rust_pin against upstream is a configuration
+   * change and not a code change:
+   *   ext_choices      P3R_EXT_* bits below
+   *   fri_log_arities  optional explicit FRI folding schedule (one log2 arity per commit phase, tallest
+   *                    first); NULL selects the rule min(max_log_arity, distance to the final height,
+   *                    distance to the next roll-in height).  Must reach every input height and the
+   *                    final height exactly.  Prover and verifier must be given the same schedule. */
+  uint32_t ext_choices;
+  const uint8_t* fri_log_arities;
+  uint32_t fri_log_arities_len;
 } p3r_config;
+/* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
+ * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
+#define P3R_EXT_LOOKUP_UNPACKED 1u
 
 typedef struct p3r_ctx p3r_ctx;
 typedef struct p3r_dmat p3r_dmat; /* device-resident matrix (power-of-two height) */

@@ -36,6 +36,10 @@ typedef struct orc_workload {
 typedef struct orc_params {
   uint32_t log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits,
       num_queries;
+  // twins of p3r_config.ext_choices (bit 0: unpacked lookups) and p3r_config.fri_log_arities
+  uint32_t ext_choices;
+  uint32_t n_fri_log_arities;
+  uint8_t fri_log_arities[32];
 } orc_params;
 
 const char* orc_last_error();
@@ -60,6 +64,8 @@ StarkParams to_sp(const orc_params& p) {
   s.log_blowup = p.log_blowup; s.max_log_arity = p.max_log_arity; s.cap_height = p.cap_height;
   s.log_final_poly_len = p.log_final_poly_len; s.commit_pow_bits = p.commit_pow_bits;
   s.query_pow_bits = p.query_pow_bits; s.num_queries = p.num_queries;
+  s.lookup_unpacked = (p.ext_choices & 1u) != 0;
+  for (uint32_t i = 0; i < p.n_fri_log_arities && i < 32; ++i) s.fri_log_arities.push_back(p.fri_log_arities[i]);
   return s;
 }
 

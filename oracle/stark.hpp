@@ -28,6 +28,10 @@ namespace orc {
 struct StarkParams {
   int log_blowup = 2, max_log_arity = 2, cap_height = 0, log_final_poly_len = 5;
   int commit_pow_bits = 0, query_pow_bits = 15, num_queries = 54;
+  // selectable details the in-tree reference does not pin (twins of p3r_config.ext_choices /
+  // fri_log_arities, include/p3r.h)
+  bool lookup_unpacked = false;
+  std::vector<int> fri_log_arities;
 };
 
 template <class FP>
@@ -128,7 +132,7 @@ struct LookupLayout {
 // (circuit-prover/src/batch_stark_prover.rs:925-941).  Packing rule: greedy in declaration
 // order while the packed constraint degree stays within the budget.
 template <class FP>
-LookupLayout lookup_layout(const AirDesc& a) {
+LookupLayout lookup_layout(const AirDesc& a, bool unpacked = false) {
   LookupLayout L;
   auto md = interaction_mult_degrees(a);
   int max_deg = std::max(air_base_constraint_degree<FP>(a), 2);
@@ -139,7 +143,7 @@ LookupLayout lookup_layout(const AirDesc& a) {
   for (size_t i = 0; i < md.size(); ++i) {
     auto trial = cur;
     trial.push_back((int)i);
-    if (!cur.empty() && group_degree(md, trial) > budget) {
+    if (!cur.empty() && (unpacked || group_degree(md, trial) > budget)) {
       L.groups.push_back(cur);
       cur = {(int)i};
     } else {
@@ -353,6 +357,14 @@ void fri_commit_phase(const Poseidon2<FP>& p2, const StarkParams& sp, std::vecto
   while (log_cur > log_final) {
     int log_next = next < inputs.size() ? inputs[next].log_height : -1;
     int la = choose_log_arity(log_cur, log_final, sp.max_log_arity, log_next);
+    if (!sp.fri_log_arities.empty()) {  // explicit schedule: must be legal (reach every roll-in and the final height)
+      const size_t ph = st.log_arities.size();
+      int limit = log_cur - log_final;
+      if (log_next >= 0 && log_next < log_cur) limit = std::min(limit, log_cur - log_next);
+      if (ph >= sp.fri_log_arities.size() || sp.fri_log_arities[ph] < 1 || sp.fri_log_arities[ph] > limit)
+        throw std::runtime_error("fri_log_arities does not fit the proof");
+      la = sp.fri_log_arities[ph];
+    }
     size_t arity = size_t(1) << la, rows = folded.size() >> la;
     Matrix<FP> leaves(rows, arity * 4);
     for (size_t r = 0; r < rows; ++r)
@@ -429,7 +441,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     if ((int)insts[i].main.w != air_width<FP>(insts[i].air)) throw std::runtime_error("main width mismatch");
     if ((int)insts[i].prep.w != air_prep_width(insts[i].air) || insts[i].prep.h != insts[i].main.h)
       throw std::runtime_error("preprocessed shape mismatch");
-    layouts[i] = lookup_layout<FP>(insts[i].air);
+    layouts[i] = lookup_layout<FP>(insts[i].air, sp.lookup_unpacked);
     proof.degree_bits.push_back(log_n[i]);
   }
   // 1. commit main traces (one MMCS over all instances)
@@ -705,7 +717,7 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
   std::vector<int> log_n(ni);
   bool any_lookup = false;
   for (size_t i = 0; i < ni; ++i) {
-    layouts[i] = lookup_layout<FP>(shapes[i].air);
+    layouts[i] = lookup_layout<FP>(shapes[i].air, sp.lookup_unpacked);
     log_n[i] = (int)proof.degree_bits[i];
     any_lookup |= !layouts[i].groups.empty();
     const auto& ov = proof.opened[i];

@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # P3R_LIB_PATH: A/B runs of two builds of the library on one box (development only)
 LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so")
 
-P3R_ABI_VERSION = 1
+P3R_ABI_VERSION = 2
+P3R_EXT_LOOKUP_UNPACKED = 1
 FIELD_KOALA_BEAR = 0
 FIELD_BABY_BEAR = 1
 
@@ -29,6 +30,9 @@ class P3rConfig(C.Structure):
         ("device", C.c_int32),
         ("poseidon2_rc", C.POINTER(C.c_uint32)),
         ("poseidon2_rc_len", C.c_uint32),
+        ("ext_choices", C.c_uint32),
+        ("fri_log_arities", C.POINTER(C.c_uint8)),
+        ("fri_log_arities_len", C.c_uint32),
     ]
 
 

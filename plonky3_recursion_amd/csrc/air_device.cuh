@@ -25,6 +25,7 @@ struct AirParams {
   int lanes;
   int horner_k;
   int coeff_lookups;
+  int lookup_unpacked = 0;  // p3r_config.ext_choices & P3R_EXT_LOOKUP_UNPACKED
 };
 
 // Row window over column-major main / preprocessed matrices of a common height.

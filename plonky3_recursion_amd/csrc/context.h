@@ -274,6 +274,7 @@ struct p3r_ctx {
   const double* rcd() const { return reinterpret_cast<const double*>(rc_f64.p); }
   p3r::DevBuf p2_diag;  // internal-layer diagonal, Montgomery (lane-cooperative kernels)
   std::vector<uint32_t> rc_canonical;
+  std::vector<uint8_t> fri_log_arities;  // copy of p3r_config.fri_log_arities (empty: the rule)
   std::vector<uint32_t> rc_mont_host;  // Montgomery copy on the host (the prover's out-of-domain self-check)
   std::string err;
   p3r::HostStage stage;  // small uploads that do not wait (see HostStage)

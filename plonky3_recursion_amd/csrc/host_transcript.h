@@ -103,7 +103,7 @@ inline LookupLayout lookup_layout(const AirParams& a) {
   std::vector<int> sizes;
   int first = 0, K = 0;
   for (int i = 0; i < (int)md.size(); ++i) {
-    if (K > 0 && gdeg(first, K + 1) > budget) { sizes.push_back(K); first = i; K = 1; }
+    if (K > 0 && (a.lookup_unpacked || gdeg(first, K + 1) > budget)) { sizes.push_back(K); first = i; K = 1; }
     else { if (K == 0) first = i; ++K; }
   }
   if (K) sizes.push_back(K);
@@ -117,6 +117,19 @@ inline LookupLayout lookup_layout(const AirParams& a) {
   else if (pairs) L.pair = 1;
   else fail(P3R_EUNSUPPORTED, "lookup packing shape not supported by the device kernels");
   return L;
+}
+
+// FRI folding schedule: log2 arity of commit phase `phase` at height 2^log_cur.  Rule (no override):
+// fold as far as max_log_arity allows without passing the next roll-in height or the final height.
+// With an explicit schedule (p3r_config.fri_log_arities) the entry is used if it is legal; -1 otherwise.
+inline int fri_log_arity(const std::vector<uint8_t>& schedule, size_t phase, int max_log_arity, int log_cur, int log_final,
+                         int log_next_input) {
+  int limit = log_cur - log_final;
+  if (log_next_input >= 0 && log_next_input < log_cur) limit = std::min(limit, log_cur - log_next_input);
+  if (schedule.empty()) return std::max(std::min(max_log_arity, limit), 1);
+  if (phase >= schedule.size()) return -1;
+  const int la = schedule[phase];
+  return (la >= 1 && la <= limit) ? la : -1;
 }
 
 inline int air_width_of(const AirParams& a, int p2_width) {

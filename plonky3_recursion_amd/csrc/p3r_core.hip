@@ -732,6 +732,8 @@ void init_ctx(p3r_ctx* ctx) {
   }
   ctx->partial_rounds = PP::PARTIAL_ROUNDS;
   ctx->cfg.poseidon2_rc = nullptr;  // caller's pointer is not retained
+  if (ctx->cfg.fri_log_arities) ctx->fri_log_arities.assign(ctx->cfg.fri_log_arities, ctx->cfg.fri_log_arities + ctx->cfg.fri_log_arities_len);
+  ctx->cfg.fri_log_arities = nullptr;
   P3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_tile<PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
@@ -1121,11 +1123,13 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     if (cfg->abi_version != P3R_ABI_VERSION) { report("ABI version mismatch"); return P3R_EINVAL; }
     if (cfg->ext_degree != 4) { report("UnsupportedDegree"); return P3R_EUNSUPPORTED; }
     p3r::VerifyParams prm{(int)cfg->log_blowup, (int)cfg->max_log_arity, (int)cfg->cap_height, (int)cfg->log_final_poly_len,
-                          (int)cfg->commit_pow_bits, (int)cfg->query_pow_bits, (int)cfg->num_queries};
+                          (int)cfg->commit_pow_bits, (int)cfg->query_pow_bits, (int)cfg->num_queries, {}};
+    if (cfg->fri_log_arities) prm.fri_log_arities.assign(cfg->fri_log_arities, cfg->fri_log_arities + cfg->fri_log_arities_len);
     std::vector<p3r::AirParams> a(n_airs);
     for (size_t i = 0; i < n_airs; ++i) {
       if (airs[i].kind > P3R_AIR_RECOMPOSE || !airs[i].lanes) { report("bad AIR descriptor"); return P3R_EINVAL; }
-      a[i] = {(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups};
+      a[i] = {(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
+              (cfg->ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0};
     }
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     std::vector<uint32_t> cap(preprocessed_commitment, preprocessed_commitment + ((size_t)P2_DIGEST << cfg->cap_height));

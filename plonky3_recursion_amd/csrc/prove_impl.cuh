@@ -125,7 +125,8 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
   auto prep = std::make_unique<p3r_prep>();
   std::vector<const p3r_dmat*> ptrs;
   for (size_t i = 0; i < n; ++i) {
-    AirParams a{(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups};
+    AirParams a{(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
+                (ctx->cfg.ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0};
     if (a.kind < 0 || a.kind > AIR_RECOMPOSE) fail(P3R_EINVAL, "instance %zu: unknown AIR kind %d", i, a.kind);
     if (a.lanes < 1) fail(P3R_EINVAL, "instance %zu: lanes must be positive", i);
     if (a.kind == AIR_ALU && (a.horner_k < 2 || a.horner_k > 8))
@@ -591,9 +592,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   }
   while (log_cur > log_final) {
     int log_next = next_h < heights.size() ? heights[next_h] : -1;
-    int la = std::min((int)cfg.max_log_arity, log_cur - log_final);
-    if (log_next >= 0 && log_next < log_cur) la = std::min(la, log_cur - log_next);
-    la = std::max(la, 1);
+    int la = fri_log_arity(ctx->fri_log_arities, phases.size(), (int)cfg.max_log_arity, log_cur, log_final, log_next);
+    if (la < 0) fail(P3R_EINVAL, "fri_log_arities does not fit the proof: phase %zu at height 2^%d", phases.size(), log_cur);
     if (la > 3) fail(P3R_EUNSUPPORTED, "max_log_arity > 3 is not supported");
     const size_t arity = size_t(1) << la, rows = (size_t(1) << log_cur) >> la, n_in = size_t(1) << log_cur;
     Phase ph;

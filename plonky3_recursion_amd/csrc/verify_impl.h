@@ -395,6 +395,7 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
 // ---- the whole verification
 struct VerifyParams {
   int log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits, num_queries;
+  std::vector<uint8_t> fri_log_arities;  // explicit folding schedule (p3r_config), empty: the rule
 };
 
 template <class PP>
@@ -532,9 +533,8 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
     int cur = log_max;
     while (cur > log_final) {
       int log_next = next_h < heights.size() ? heights[next_h] : -1;
-      int la = std::min(prm.max_log_arity, cur - log_final);
-      if (log_next >= 0 && log_next < cur) la = std::min(la, cur - log_next);
-      la = std::max(la, 1);
+      const int la = fri_log_arity(prm.fri_log_arities, las.size(), prm.max_log_arity, cur, log_final, log_next);
+      if (la < 0) vfail("FRI: the configured folding schedule does not fit the proof (phase %zu)", las.size());
       if (next_h < heights.size() && heights[next_h] == cur - la) ++next_h;
       cur -= la;
       las.push_back(la);

@@ -187,3 +187,37 @@ def test_native_verifier_parser_survives_mutations(oracle):
             continue
         with pytest.raises(p3r.P3rError):
             verify("koala-bear", prm, tables, cap, bytes(b))
+
+
+@pytest.mark.parametrize("ext_choices,arities", [(1, None), (0, [1, 1, 1, 1, 1]), (1, [1, 1, 1, 1, 1])])
+def test_selectable_protocol_details_oracle_and_native_verifier_agree(oracle, ext_choices, arities):
+    """The [EXT] switches (include/p3r.h: ext_choices, fri_log_arities): LogUp
+    without same-bus packing and an explicit FRI folding schedule.  The oracle proves under the
+    switched rules, both verifiers accept under the same rules and reject under the default ones."""
+    import plonky3_recursion_amd as p3r
+    field, log_h = "koala-bear", 6
+    arrs = harness_lib.generate(field, log_h, seed=91, **SMALL)
+    kw = dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+    base = layer_lib.params(**kw)
+    prm = layer_lib.params(ext_choices=ext_choices, fri_log_arities=arities, **kw)
+    L = layer_lib.OracleLayer(oracle, field, arrs, prm)
+    tables, cap = L.tables(), L.prep_commit()
+    proof = L.prove()
+    L.verify(proof)
+    db = [int(t["main"].shape[0]).bit_length() - 1 for t in tables]
+    airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
+
+    def native(ext, ar):
+        cfg, keep = p3r.make_config(field, base.log_blowup, base.max_log_arity, base.cap_height, base.log_final_poly_len,
+                                    base.commit_pow_bits, base.query_pow_bits, base.num_queries, ext_choices=ext,
+                                    fri_log_arities=ar)
+        p3r.verify_batch(cfg, airs, cap, db, proof)
+
+    native(ext_choices, arities)
+    default_proof = layer_lib.OracleLayer(oracle, field, arrs, base).prove()
+    assert default_proof != proof
+    with pytest.raises(p3r.P3rError):      # the default rules describe a different proof shape
+        native(0, None)
+    if arities is not None:
+        with pytest.raises(p3r.P3rError):  # a schedule that skips the final height is refused
+            native(ext_choices, [2, 2, 2, 2])
