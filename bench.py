@@ -116,11 +116,16 @@ def hbm_families(heights, widths, packing, kernel_ms):
     return out
 
 
+PROFILE_ROUND = "r02"   # profiles/<round>/ holds the rocprofv3 summaries the roofline numbers refer to
+
+
 def pmc_traffic_bytes(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary (collected with rocprofv3 in
-    separate --pmc passes; it cannot be collected from inside this process)."""
+    separate --pmc passes by tools/profile_round.sh; it cannot be collected from inside this process).
+    The kernel's HBM traffic is its input cells and output digests whatever arithmetic hashes them, so
+    the figure only goes stale when the table mix changes - `traffic_source` names the file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")) as fh:
             k = json.load(fh)["kernels"][kernel]
         # gfx950: FETCH_SIZE tallies the 128-B requests of a coalesced streaming read at 64 B
         # (/opt/skills/guides/MI355X_MICROARCH.md, HBM section) - doubled before comparing with bytes.
@@ -535,27 +540,37 @@ def main():
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                 "traffic": pmc_traffic_bytes("k_mmcs_hash_rows") if (field, log_h) == ("koala-bear", 20) else None,
-                "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "same command; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of "
-                                  "the microarchitecture guide)",
+                "traffic_source": f"profiles/{PROFILE_ROUND}/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "same command, tools/profile_round.sh; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, the "
+                                  "gfx950 correction of the microarchitecture guide - the factor 2 for 4-B-per-lane reads is "
+                                  "calibrated on this kernel's known byte count)",
                 "avg_launch_ms": avg_launch_ms,
                 "algorithmic_bytes_per_launch": hash_bytes / launches_per_step if launches_per_step else None,
-                "note": "MMCS leaf hashing is integer-VALU bound (one Poseidon2 permutation per 32 B absorbed), "
-                        "not HBM bound; DESIGN.md gives the VALU ceiling next to this HBM figure",
+                "note": "MMCS leaf hashing is VALU bound (one Poseidon2 permutation per 32 B absorbed), not HBM bound; "
+                        "valu_roofline prices it against the FP64 issue rate",
             },
         }
-        # The dominant kernel is integer-VALU bound, so next to the HBM roofline the contract asks for
-        # we price it against the measured issue rate of the chip (tools/microbench/int_rates.hip:
-        # 54.5 T simple lane-ops/s sustained) and the ~7.8 k instructions of one KoalaBear permutation
-        # (gfx950 ISA of the kernel: 4 x 406 + 4 x 432 for the full rounds, 20 x 207 for the partial
-        # rounds, 319 around them; a Montgomery product is v_mad_u64_u32 + v_mul_lo_u32 + v_mad_u64_u32).
+        # The dominant kernel is VALU bound.  Since round 2 the permutation runs in FP64 (exact integer
+        # arithmetic in doubles, csrc/poseidon2_f64.cuh): its price is FP64 instructions per permutation x
+        # the FP64 issue rate.  Instructions per permutation: dynamic count from the SQ counters
+        # (profiles/r02/pmc_sq.json: SQ_INSTS_VALU x 64 lanes / permutations of the run) - 3.9 k with the
+        # loads and conversions of the sponge around the ~3.5 k of the permutation itself (static histogram:
+        # profiles/r02/isa_histograms.txt).  Peaks: the measured v_fma_f64 rate of this chip
+        # (profiles/r02/microbench_int_rates.txt: 36.7 T lane-ops/s) and the guide's FP64 vector peak
+        # (78.6 TFLOP/s = 39.3 T FMA/s, /opt/skills/guides/MI355X_MICROARCH.md).
         hash_total_ms = kernel_ms.get("mmcs_hash_rows", 0.0)
-        if field == "koala-bear" and hash_total_ms:
-            peak = 54.5e12 / 7.8e3
+        if hash_total_ms:
+            insts = {"koala-bear": 3.9e3, "baby-bear": 5.0e3}[field]
             ach = hash_perms / (hash_total_ms * 1e-3)
-            line["valu_roofline"] = {"kernel": "k_mmcs_hash_rows", "bound": "int-valu",
-                                     "achieved": ach, "peak": peak, "unit": "Poseidon2 perms/s", "frac": ach / peak,
-                                     "perms_per_step_in_kernel": hash_perms}
+            line["valu_roofline"] = {"kernel": "k_mmcs_hash_rows", "bound": "fp64-valu",
+                                     "achieved": ach, "unit": "Poseidon2 perms/s",
+                                     "valu_insts_per_perm": insts,
+                                     "peak_measured": 36.7e12 / insts, "frac_measured": ach * insts / 36.7e12,
+                                     "peak_guide": 39.3e12 / insts, "frac_guide": ach * insts / 39.3e12,
+                                     "peak": 36.7e12 / insts, "frac": ach * insts / 36.7e12,
+                                     "perms_per_step_in_kernel": hash_perms,
+                                     "sources": f"profiles/{PROFILE_ROUND}/pmc_sq.json, microbench_int_rates.txt, "
+                                                "microbench_perm_f64.txt, isa_histograms.txt"}
         # The streaming families against HBM, from the same algorithmic byte counts as DESIGN.md §3/§7.
         line["hbm_families"] = hbm_families(cpd.table_heights, widths, packing, kernel_ms)
         if not args.no_cpu_baseline and world == 1:

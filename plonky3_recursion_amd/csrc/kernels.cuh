@@ -280,7 +280,7 @@ struct HashRowsJob {
   uint32_t block0;  // first block of this job
 };
 template <class PP>
-__global__ void __launch_bounds__(kBlock, 6)
+__global__ void __launch_bounds__(kBlock, 5)
 k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const double* __restrict__ rcd) {
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
