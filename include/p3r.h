@@ -110,6 +110,11 @@ uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx);
 int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out);
 /* Blocks until all work queued on the ctx's stream has completed. */
 int p3r_sync(p3r_ctx* ctx);
+/* Device memory a ctx has released stays in its pool for reuse (a 2^20-row prove keeps several GB
+ * cached between proofs; context.h::DevPool).  p3r_trim returns the cached blocks of this ctx to the
+ * driver and reports how many bytes that was; an allocation that fails with out-of-memory trims the
+ * pools of EVERY ctx of the process before it is reported as P3R_ENOMEM. */
+int p3r_trim(p3r_ctx* ctx, uint64_t* freed_bytes);
 
 /* ---- device matrices (inputs stay resident in HBM between calls) ---- */
 p3r_dmat* p3r_dmat_upload(p3r_ctx* ctx, const uint32_t* rowmajor, size_t height, size_t width);

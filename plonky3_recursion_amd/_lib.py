@@ -126,6 +126,7 @@ SIGNATURES = {
     "p3r_poseidon2_num_constants": (C.c_uint32, [vp]),
     "p3r_poseidon2_round_constants": (C.c_int, [vp, u32p]),
     "p3r_sync": (C.c_int, [vp]),
+    "p3r_trim": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "p3r_dmat_upload": (vp, [vp, u32p, C.c_size_t, C.c_size_t]),
     "p3r_dmat_alloc": (vp, [vp, C.c_size_t, C.c_size_t]),
     "p3r_dmat_download": (C.c_int, [vp, vp, u32p]),

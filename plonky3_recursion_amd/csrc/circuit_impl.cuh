@@ -1002,6 +1002,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   auto need = [&](const void* p, size_t n, const char* what) { if (n && !p) fail(P3R_EINVAL, "%s is NULL", what); };
   need(d->ops, d->n_ops, "ops"); need(d->ext, d->n_ext, "ext"); need(d->public_rows, d->n_public, "public_rows");
   need(d->private_input_rows, d->n_private, "private_input_rows"); need(d->witness_rewrite, d->n_rewrite, "witness_rewrite");
+  prof_stage(ctx, "prep_validate");
   h.witness_count = d->witness_count;
   h.ops.assign(d->ops, d->ops + d->n_ops);
   h.ext.assign(d->ext, d->ext + d->n_ext);
@@ -1015,6 +1016,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
         if (h.ext_of(op)[k] >= PP::P) fail(P3R_EINVAL, "constant of witness %u is not canonical", op.out);
 
   // CircuitProverData: preprocessed columns -> LDE + commitment (build_next_layer_prep)
+  prof_stage(ctx, "prep_circuit_tables");
   CircuitTables T = circuit_tables<PP>(h);
   C->counts = T.counts;
   p3r_layer_desc ld{};
@@ -1027,10 +1029,13 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   ld.p2_mmcs_ctl_enabled = T.p2_mmcs_ctl_enabled.data(); ld.p2_in_ctl = T.p2_in_ctl.data();
   ld.p2_input_indices = T.p2_input_indices.data(); ld.p2_out_ctl = T.p2_out_ctl.data();
   ld.p2_output_indices = T.p2_output_indices.data(); ld.p2_mmcs_index_sum_idx = T.p2_mmcs_index_sum_idx.data();
+  prof_stage(ctx, "prep_layer_create");
   C->layer = layer_create<PP>(ctx, &ld, commit_out);
 
   // execution schedule
+  prof_stage(ctx, "prep_build_schedule");
   C->sched = build_schedule(h);
+  prof_stage(ctx, "prep_upload_schedule");
   RunSchedule& S = C->sched;
   // constants travel in Montgomery form; hint output lists keep their flag bit
   std::vector<uint32_t> ext_m = S.dev_ext;
@@ -1059,6 +1064,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   up(C->d_chunk_bounds, S.chunk_bounds.data(), S.chunk_bounds.size() * 4);
   up(C->d_chain_ops, S.chain_ops.data(), S.chain_ops.size() * sizeof(RunOp));
   up(C->d_chains, S.chains.data(), S.chains.size() * sizeof(RunSchedule::ChainSeg));
+  prof_stage(ctx, nullptr);
   return C;
 }
 

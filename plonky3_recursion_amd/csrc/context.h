@@ -10,6 +10,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -49,26 +50,54 @@ struct Error : std::runtime_error {
 // because every user of a ctx enqueues on ONE stream: a block handed out again is only
 // touched by work ordered after the work that used it before.  (Blocking copies therefore
 // go through h2d_sync below, never through the NULL stream.)
+struct DevPool;
+// Every live pool of the process: a ctx that runs out of device memory trims the caches of ALL of them
+// before giving up (several contexts on one GPU - concurrent provers, aggregation nodes - each keep
+// their freed blocks; one must not fail with P3R_ENOMEM while its siblings hold unused gigabytes).
+struct PoolRegistry {
+  std::mutex mu;
+  std::vector<DevPool*> pools;
+  static PoolRegistry& get() {
+    static PoolRegistry r;
+    return r;
+  }
+};
+
 struct DevPool {
   std::map<size_t, std::vector<void*>> free_lists;
   size_t cached_bytes = 0;
+  std::mutex mu;  // a sibling pool's OOM path may trim this one from another thread
+  DevPool() {
+    std::lock_guard<std::mutex> g(PoolRegistry::get().mu);
+    PoolRegistry::get().pools.push_back(this);
+  }
+  DevPool(const DevPool&) = delete;
+  DevPool& operator=(const DevPool&) = delete;
+  static void trim_all() {
+    std::lock_guard<std::mutex> g(PoolRegistry::get().mu);
+    for (DevPool* p : PoolRegistry::get().pools) p->trim();
+  }
   static size_t round_up(size_t bytes) {
     const size_t g = bytes < (size_t(1) << 20) ? 256 : (size_t(1) << 20);
     return (bytes + g - 1) / g * g;
   }
   void* get(size_t bytes) {
     bytes = round_up(bytes);
-    auto it = free_lists.find(bytes);
-    if (it != free_lists.end() && !it->second.empty()) {
-      void* p = it->second.back();
-      it->second.pop_back();
-      cached_bytes -= bytes;
-      return p;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto it = free_lists.find(bytes);
+      if (it != free_lists.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        cached_bytes -= bytes;
+        return p;
+      }
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipErrorOutOfMemory && cached_bytes) {
-      trim();
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError();
+      trim_all();  // this pool's cache and every sibling's
       e = hipMalloc(&p, bytes);
     }
     if (e != hipSuccess)
@@ -82,17 +111,28 @@ struct DevPool {
   // the device (p3r_ctx::const_tables) instead of being rebuilt and uploaded every time.
   void put(void* p, size_t bytes) {
     bytes = round_up(bytes);
+    std::lock_guard<std::mutex> g(mu);
     auto& v = free_lists[bytes];
     v.insert(std::lower_bound(v.begin(), v.end(), p, std::greater<void*>()), p);
     cached_bytes += bytes;
   }
+  // Frees every cached block.  Blocks are only cached after the work that used them was enqueued on the
+  // owner's stream; hipFree synchronises the device, so freeing them here is safe from any thread.
   void trim() {
+    std::lock_guard<std::mutex> g(mu);
     for (auto& kv : free_lists)
       for (void* p : kv.second) (void)hipFree(p);
     free_lists.clear();
     cached_bytes = 0;
   }
-  ~DevPool() { trim(); }
+  ~DevPool() {
+    {
+      std::lock_guard<std::mutex> g(PoolRegistry::get().mu);
+      auto& v = PoolRegistry::get().pools;
+      v.erase(std::remove(v.begin(), v.end(), this), v.end());
+    }
+    trim();
+  }
 };
 // One pool per ctx (a ctx owns one stream, which is what makes reuse safe).  The pool in use is
 // selected per API call (thread-local); a buffer remembers the pool it came from and keeps it

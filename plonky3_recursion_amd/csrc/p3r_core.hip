@@ -806,6 +806,16 @@ int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out) {
   return P3R_OK;
 }
 
+int p3r_trim(p3r_ctx* ctx, uint64_t* freed_bytes) {
+  if (!ctx) return P3R_EINVAL;
+  return guard(ctx, [&] {
+    P3R_HIP(hipStreamSynchronize(ctx->stream));
+    if (freed_bytes) *freed_bytes = ctx->pool->cached_bytes;
+    ctx->pool->trim();
+    ctx->const_tables.clear();  // the job lists were keyed to the addresses the pool handed out
+  });
+}
+
 int p3r_sync(p3r_ctx* ctx) {
   return guard(ctx, [&] { P3R_HIP(hipStreamSynchronize(ctx->stream)); });
 }

@@ -266,6 +266,12 @@ class Context:
     def profile_enable(self, on=True):
         self.check(self.lib.p3r_profile_enable(self.h, 1 if on else 0))
 
+    def trim(self):
+        """Return this ctx's cached device memory to the driver; returns the number of bytes released."""
+        n = C.c_uint64()
+        self.check(self.lib.p3r_trim(self.h, C.byref(n)))
+        return n.value
+
     def profile_read(self):
         buf = (_lib.P3rProfileEntry * 64)()
         n = C.c_size_t()

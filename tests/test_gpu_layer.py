@@ -198,3 +198,30 @@ def test_concurrent_contexts_on_one_gpu(oracle):
     for ctx, cache, traces, want in jobs:
         cache.circuit_prover_data.free()
         ctx.close()
+
+
+def test_trim_releases_the_pool_and_proofs_stay_identical(oracle):
+    """p3r_trim (include/p3r.h): cached device memory goes back to the driver; the next proof
+    re-allocates and produces the same bytes."""
+    import plonky3_recursion_amd as p3r
+    import harness_adapters as wl
+    field = "koala-bear"
+    fri = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=2, commit_pow_bits=0, query_pow_bits=4,
+               num_queries=6)
+    a = harness_lib.generate(field, 10, seed=4, horner_chain_len=20, sponge_chain_len=4, merkle_depth=6)
+    ctx = p3r.Context(field=field, **fri)
+    tp = p3r.TablePacking().with_fri_params(fri["log_final_poly_len"], fri["log_blowup"])
+    pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
+    inputs = wl.circuit_inputs_from_arrays(a)
+    first = pc.prove(inputs)
+    freed = ctx.trim()
+    assert freed > 0
+    assert ctx.trim() < freed          # nothing (or only the dropped job tables) left to release
+    assert pc.prove(inputs) == first
+    other = p3r.Context(field=field, **fri)   # a sibling ctx on the same GPU keeps working
+    pc2 = p3r.PreparedCircuit(other, wl.circuit_from_arrays(a), tp)
+    assert pc2.prove(inputs) == first
+    pc2.free()
+    other.close()
+    pc.free()
+    ctx.close()
