@@ -327,6 +327,10 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
     if (op.kind == P3R_OP_POSEIDON2_PERM || op.kind == P3R_OP_RECOMPOSE) { max_op_id = std::max(max_op_id, op.a); any_npo = true; }
   if (any_npo) S.p2_row_of_op_id.assign((size_t)max_op_id + 1, kNoW);
 
+  std::vector<uint32_t> written;
+  light.reserve(c.ops.size());
+  order.reserve(c.ops.size());
+  S.dev_ext.reserve(c.ext.size());
   for (size_t i = 0; i < c.ops.size(); ++i) {
     const p3r_op& op = c.ops[i];
     const uint32_t* e = c.ext_of(op);
@@ -343,7 +347,7 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
     RunOp r{};
     r.kind_flags = op.kind;
     r.a = op.a; r.b = op.b; r.c = op.c; r.out = op.out; r.aux = op.aux; r.op_idx = (uint32_t)i;
-    std::vector<uint32_t> written;
+    written.clear();  // (one vector for the whole walk: a heap allocation per op was a third of this function)
     switch (op.kind) {
       case P3R_OP_CONST:
         S.const_rows.push_back(op.out);

@@ -102,3 +102,19 @@ def test_tree_of_real_proofs_root_verifies(world, leaves):
     assert line["config"]["nodes"] == 2 * leaves - 1
     assert len(line["rank0"]["level_wall_ms_last_step"]) == leaves.bit_length()
     assert line["rank0"]["child_verify_ms"] is not None
+
+
+def test_default_bench_line_two_ranks_over_gloo():
+    """The driver's multi-GPU launch of bench.py (independent layers, one per rank, weak scaling, proofs
+    handed to rank 0) with two ranks sharing the test box's one GPU: gloo for the transport instead of
+    nccl, everything else as the driver runs it.  Every rank's timed proof is verified."""
+    env = dict(os.environ, P3R_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-height", "12",
+           "--no-cpu-baseline", "--no-config2", "--no-small-layers"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["proof_verified"] is True
+    assert line["config"]["independent_proofs"] == 2
+    assert isinstance(line["root_handoff_ms"], float)
