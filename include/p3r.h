@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3R_ABI_VERSION 2
+#define P3R_ABI_VERSION 3
 
 enum {
   P3R_OK = 0,
@@ -87,6 +87,11 @@ typedef struct p3r_config {
   uint32_t ext_choices;
   const uint8_t* fri_log_arities;
   uint32_t fri_log_arities_len;
+  /*   proof_layout     optional order of the fields of the postcard-serialised structs: 18 bytes, three
+   *                    permutations batch[5] | fri[5] | opened[8] (csrc/host_transcript.h::ProofLayout
+   *                    lists the fields); NULL = the order read off the in-tree destructuring patterns. */
+  const uint8_t* proof_layout;
+  uint32_t proof_layout_len;
 } p3r_config;
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
@@ -324,6 +329,9 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
  * serialised `BatchStarkProof` continues with its metadata, batch_stark_prover.rs:610-636). */
 int p3r_batch_proof_len(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags, size_t* proof_len,
                         char* err_buf, size_t err_cap);
+/* Same for proofs written with a non-default p3r_config.proof_layout (18 bytes, or NULL). */
+int p3r_batch_proof_len_layout(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags,
+                               const uint8_t* proof_layout, size_t* proof_len, char* err_buf, size_t err_cap);
 
 /* ---- the caller side of prove_next_layer: the circuit itself ------------------------------------
  * `prove_next_layer` (recursion/src/recursion.rs:401-502) receives a `Circuit<EF>`, sets its public

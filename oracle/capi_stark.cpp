@@ -40,6 +40,7 @@ typedef struct orc_params {
   uint32_t ext_choices;
   uint32_t n_fri_log_arities;
   uint8_t fri_log_arities[32];
+  uint8_t proof_layout[18];   // twin of p3r_config.proof_layout; all zero = identity
 } orc_params;
 
 const char* orc_last_error();
@@ -59,6 +60,16 @@ struct LayerBase {
   virtual void verify(const orc_params& p, const uint32_t* prep_cap, const uint8_t* bytes, size_t n, int enc) const = 0;
 };
 
+Layout to_layout(const orc_params& p) {
+  Layout L;
+  bool any = false;
+  for (int i = 0; i < 18; ++i) any |= p.proof_layout[i] != 0;
+  if (!any) return L;
+  std::memcpy(L.batch, p.proof_layout, 5);
+  std::memcpy(L.fri, p.proof_layout + 5, 5);
+  std::memcpy(L.opened, p.proof_layout + 10, 8);
+  return L;
+}
 StarkParams to_sp(const orc_params& p) {
   StarkParams s;
   s.log_blowup = p.log_blowup; s.max_log_arity = p.max_log_arity; s.cap_height = p.cap_height;
@@ -181,10 +192,10 @@ struct Layer : LayerBase {
   std::vector<uint8_t> prove(const orc_params& p, int enc) override {
     ensure_pd(p);
     auto proof = prove_batch<FP>(p2, to_sp(p), insts, *pd);
-    return serialize_proof<FP>(proof, enc);
+    return serialize_proof<FP>(proof, enc, to_layout(p));
   }
   void verify(const orc_params& p, const uint32_t* prep_cap, const uint8_t* bytes, size_t n, int enc) const override {
-    auto proof = deserialize_proof<FP>(bytes, n, enc);
+    auto proof = deserialize_proof<FP>(bytes, n, enc, to_layout(p));
     std::vector<InstanceShape> shapes;
     for (auto& in : insts) shapes.push_back({in.air});
     typename BatchProof<FP>::Cap cap(size_t(1) << p.cap_height);
@@ -246,7 +257,7 @@ int orc_verify_batch(int field, const uint32_t* rc, const orc_params* p, size_t 
       using FP = decltype(tag);
       using F = Fe<FP>;
       Poseidon2<FP> p2(rc);
-      auto proof = deserialize_proof<FP>(bytes, len, field_encoding);
+      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p));
       std::vector<InstanceShape> shapes;
       for (size_t i = 0; i < n_airs; ++i) {
         AirDesc a;

@@ -38,59 +38,92 @@ struct Writer {
   void none() { byte(0); }
 };
 
+// Field order of the serialised structs (twin of p3r_config.proof_layout): three permutations,
+// BatchProof {0 commitments, 1 opened_values, 2 opening_proof, 3 global_lookup_data, 4 degree_bits},
+// FriProof {0 commit_phase_commits, 1 commit_pow_witnesses, 2 query_proofs, 3 final_poly, 4 query_pow_witness},
+// OpenedValues {0 trace_local, 1 trace_next, 2 preprocessed_local, 3 preprocessed_next, 4 quotient_chunks,
+// 5 random, 6 permutation_local, 7 permutation_next}.  Identity = the order of the in-tree destructuring
+// patterns (recursion/src/types/proof.rs:403-409,452-457,527-534,585-589, pcs/fri/targets.rs:104-110).
+struct Layout {
+  uint8_t batch[5] = {0, 1, 2, 3, 4};
+  uint8_t fri[5] = {0, 1, 2, 3, 4};
+  uint8_t opened[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+};
+
 template <class FP>
-std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_ENCODING_MONTY) {
+std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_ENCODING_MONTY, const Layout& L = Layout{}) {
   Writer<FP> w;
   w.enc = enc;
-  // commitments { main, permutation?, quotient_chunks, random? }
-  w.cap(p.main_commit);
-  if (p.has_permutation) { w.some(); w.cap(p.permutation_commit); } else w.none();
-  w.cap(p.quotient_commit);
-  w.none();
-  // opened_values { instances: Vec<OpenedValuesWithLookups> }
-  w.varint(p.opened.size());
-  for (auto& ov : p.opened) {
-    w.vec_ef(ov.trace_local);
-    if (ov.has_trace_next) { w.some(); w.vec_ef(ov.trace_next); } else w.none();
-    w.some(); w.vec_ef(ov.preprocessed_local);
-    w.some(); w.vec_ef(ov.preprocessed_next);
-    w.varint(ov.quotient_chunks.size());
-    for (auto& c : ov.quotient_chunks) w.vec_ef(c);
-    w.none();  // random
-    w.vec_ef(ov.permutation_local);
-    w.vec_ef(ov.permutation_next);
-  }
-  // opening_proof: FriProof
+  auto commitments = [&] {  // { main, permutation?, quotient_chunks, random? }
+    w.cap(p.main_commit);
+    if (p.has_permutation) { w.some(); w.cap(p.permutation_commit); } else w.none();
+    w.cap(p.quotient_commit);
+    w.none();
+  };
+  auto opened = [&] {  // { instances: Vec<OpenedValuesWithLookups> }
+    w.varint(p.opened.size());
+    for (auto& ov : p.opened)
+      for (int k = 0; k < 8; ++k) switch (L.opened[k]) {
+        case 0: w.vec_ef(ov.trace_local); break;
+        case 1: if (ov.has_trace_next) { w.some(); w.vec_ef(ov.trace_next); } else w.none(); break;
+        case 2: w.some(); w.vec_ef(ov.preprocessed_local); break;
+        case 3: w.some(); w.vec_ef(ov.preprocessed_next); break;
+        case 4:
+          w.varint(ov.quotient_chunks.size());
+          for (auto& c : ov.quotient_chunks) w.vec_ef(c);
+          break;
+        case 5: w.none(); break;  // random
+        case 6: w.vec_ef(ov.permutation_local); break;
+        default: w.vec_ef(ov.permutation_next); break;
+      }
+  };
   const auto& f = p.fri;
-  w.varint(f.commit_phase_commits.size());
-  for (auto& c : f.commit_phase_commits) w.cap(c);
-  w.vec_fe(f.commit_pow_witnesses);
-  w.varint(f.query_proofs.size());
-  for (auto& q : f.query_proofs) {
-    w.varint(q.input_proof.size());
-    for (auto& bo : q.input_proof) {
-      w.varint(bo.opened_values.size());
-      for (auto& r : bo.opened_values) w.vec_fe(r);
-      w.varint(bo.opening_proof.size());
-      for (auto& d : bo.opening_proof) w.digest(d);
+  auto queries = [&] {
+    w.varint(f.query_proofs.size());
+    for (auto& q : f.query_proofs) {
+      w.varint(q.input_proof.size());
+      for (auto& bo : q.input_proof) {
+        w.varint(bo.opened_values.size());
+        for (auto& r : bo.opened_values) w.vec_fe(r);
+        w.varint(bo.opening_proof.size());
+        for (auto& d : bo.opening_proof) w.digest(d);
+      }
+      w.varint(q.commit_phase_openings.size());
+      for (auto& s : q.commit_phase_openings) {
+        w.byte(s.log_arity);
+        w.vec_ef(s.sibling_values);
+        w.varint(s.opening_proof.size());
+        for (auto& d : s.opening_proof) w.digest(d);
+      }
     }
-    w.varint(q.commit_phase_openings.size());
-    for (auto& s : q.commit_phase_openings) {
-      w.byte(s.log_arity);
-      w.vec_ef(s.sibling_values);
-      w.varint(s.opening_proof.size());
-      for (auto& d : s.opening_proof) w.digest(d);
+  };
+  auto fri = [&] {  // opening_proof: FriProof
+    for (int k = 0; k < 5; ++k) switch (L.fri[k]) {
+      case 0:
+        w.varint(f.commit_phase_commits.size());
+        for (auto& c : f.commit_phase_commits) w.cap(c);
+        break;
+      case 1: w.vec_fe(f.commit_pow_witnesses); break;
+      case 2: queries(); break;
+      case 3: w.vec_ef(f.final_poly); break;
+      default: w.fe(f.query_pow_witness); break;
     }
+  };
+  for (int k = 0; k < 5; ++k) switch (L.batch[k]) {
+    case 0: commitments(); break;
+    case 1: opened(); break;
+    case 2: fri(); break;
+    case 3:  // lookup_terminals: Vec<Option<EF>>
+      w.varint(p.has_terminal.size());
+      for (size_t i = 0; i < p.has_terminal.size(); ++i) {
+        if (p.has_terminal[i]) { w.some(); w.ef(p.lookup_terminals[i]); } else w.none();
+      }
+      break;
+    default:  // degree_bits: Vec<usize>
+      w.varint(p.degree_bits.size());
+      for (auto d : p.degree_bits) w.varint(d);
+      break;
   }
-  w.vec_ef(f.final_poly);
-  w.fe(f.query_pow_witness);
-  // lookup_terminals: Vec<Option<EF>>, degree_bits: Vec<usize>
-  w.varint(p.has_terminal.size());
-  for (size_t i = 0; i < p.has_terminal.size(); ++i) {
-    if (p.has_terminal[i]) { w.some(); w.ef(p.lookup_terminals[i]); } else w.none();
-  }
-  w.varint(p.degree_bits.size());
-  for (auto d : p.degree_bits) w.varint(d);
   return w.out;
 }
 
@@ -129,68 +162,96 @@ struct Reader {
 };
 
 template <class FP>
-BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_ENCODING_MONTY) {
+BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_ENCODING_MONTY, const Layout& L = Layout{}) {
   Reader<FP> r{data, data + n, enc};
   BatchProof<FP> p;
-  p.main_commit = r.cap();
-  p.has_permutation = r.option();
-  if (p.has_permutation) p.permutation_commit = r.cap();
-  p.quotient_commit = r.cap();
-  if (r.option()) throw std::runtime_error("random commitment present (ZK unsupported)");
-  size_t ni = r.len();
-  p.opened.resize(ni);
-  for (auto& ov : p.opened) {
-    ov.trace_local = r.vec_ef();
-    ov.has_trace_next = r.option();
-    if (ov.has_trace_next) ov.trace_next = r.vec_ef();
-    if (r.option()) ov.preprocessed_local = r.vec_ef();
-    if (r.option()) ov.preprocessed_next = r.vec_ef();
-    size_t nc = r.len();
-    ov.quotient_chunks.resize(nc);
-    for (auto& c : ov.quotient_chunks) c = r.vec_ef();
-    if (r.option()) throw std::runtime_error("random opened values present (ZK unsupported)");
-    ov.permutation_local = r.vec_ef();
-    ov.permutation_next = r.vec_ef();
-  }
+  auto commitments = [&] {
+    p.main_commit = r.cap();
+    p.has_permutation = r.option();
+    if (p.has_permutation) p.permutation_commit = r.cap();
+    p.quotient_commit = r.cap();
+    if (r.option()) throw std::runtime_error("random commitment present (ZK unsupported)");
+  };
+  auto opened = [&] {
+    size_t ni = r.len();
+    p.opened.resize(ni);
+    for (auto& ov : p.opened)
+      for (int k = 0; k < 8; ++k) switch (L.opened[k]) {
+        case 0: ov.trace_local = r.vec_ef(); break;
+        case 1: ov.has_trace_next = r.option(); if (ov.has_trace_next) ov.trace_next = r.vec_ef(); break;
+        case 2: if (r.option()) ov.preprocessed_local = r.vec_ef(); break;
+        case 3: if (r.option()) ov.preprocessed_next = r.vec_ef(); break;
+        case 4: {
+          size_t nc = r.len();
+          ov.quotient_chunks.resize(nc);
+          for (auto& c : ov.quotient_chunks) c = r.vec_ef();
+          break;
+        }
+        case 5: if (r.option()) throw std::runtime_error("random opened values present (ZK unsupported)"); break;
+        case 6: ov.permutation_local = r.vec_ef(); break;
+        default: ov.permutation_next = r.vec_ef(); break;
+      }
+  };
   auto& f = p.fri;
-  size_t np = r.len();
-  f.commit_phase_commits.resize(np);
-  for (auto& c : f.commit_phase_commits) c = r.cap();
-  f.commit_pow_witnesses = r.vec_fe();
-  size_t nq = r.len();
-  f.query_proofs.resize(nq);
-  for (auto& q : f.query_proofs) {
-    size_t nb = r.len();
-    q.input_proof.resize(nb);
-    for (auto& bo : q.input_proof) {
-      size_t nm = r.len();
-      bo.opened_values.resize(nm);
-      for (auto& row : bo.opened_values) row = r.vec_fe();
-      size_t nd = r.len();
-      bo.opening_proof.resize(nd);
-      for (auto& d : bo.opening_proof) d = r.digest();
+  auto queries = [&] {
+    size_t nq = r.len();
+    f.query_proofs.resize(nq);
+    for (auto& q : f.query_proofs) {
+      size_t nb = r.len();
+      q.input_proof.resize(nb);
+      for (auto& bo : q.input_proof) {
+        size_t nm = r.len();
+        bo.opened_values.resize(nm);
+        for (auto& row : bo.opened_values) row = r.vec_fe();
+        size_t nd = r.len();
+        bo.opening_proof.resize(nd);
+        for (auto& d : bo.opening_proof) d = r.digest();
+      }
+      size_t ns = r.len();
+      q.commit_phase_openings.resize(ns);
+      for (auto& s : q.commit_phase_openings) {
+        s.log_arity = r.byte();
+        s.sibling_values = r.vec_ef();
+        size_t nd = r.len();
+        s.opening_proof.resize(nd);
+        for (auto& d : s.opening_proof) d = r.digest();
+      }
     }
-    size_t ns = r.len();
-    q.commit_phase_openings.resize(ns);
-    for (auto& s : q.commit_phase_openings) {
-      s.log_arity = r.byte();
-      s.sibling_values = r.vec_ef();
+  };
+  auto fri = [&] {
+    for (int k = 0; k < 5; ++k) switch (L.fri[k]) {
+      case 0: {
+        size_t np = r.len();
+        f.commit_phase_commits.resize(np);
+        for (auto& c : f.commit_phase_commits) c = r.cap();
+        break;
+      }
+      case 1: f.commit_pow_witnesses = r.vec_fe(); break;
+      case 2: queries(); break;
+      case 3: f.final_poly = r.vec_ef(); break;
+      default: f.query_pow_witness = r.fe(); break;
+    }
+  };
+  for (int k = 0; k < 5; ++k) switch (L.batch[k]) {
+    case 0: commitments(); break;
+    case 1: opened(); break;
+    case 2: fri(); break;
+    case 3: {
+      size_t nt = r.len();
+      p.has_terminal.assign(nt, false);
+      p.lookup_terminals.assign(nt, Fe4<FP>::zero());
+      for (size_t i = 0; i < nt; ++i) {
+        p.has_terminal[i] = r.option();
+        if (p.has_terminal[i]) p.lookup_terminals[i] = r.ef();
+      }
+      break;
+    }
+    default: {
       size_t nd = r.len();
-      s.opening_proof.resize(nd);
-      for (auto& d : s.opening_proof) d = r.digest();
+      for (size_t i = 0; i < nd; ++i) p.degree_bits.push_back((size_t)r.varint());
+      break;
     }
   }
-  f.final_poly = r.vec_ef();
-  f.query_pow_witness = r.fe();
-  size_t nt = r.len();
-  p.has_terminal.assign(nt, false);
-  p.lookup_terminals.assign(nt, Fe4<FP>::zero());
-  for (size_t i = 0; i < nt; ++i) {
-    p.has_terminal[i] = r.option();
-    if (p.has_terminal[i]) p.lookup_terminals[i] = r.ef();
-  }
-  size_t nd = r.len();
-  for (size_t i = 0; i < nd; ++i) p.degree_bits.push_back((size_t)r.varint());
   if (r.p != r.end) throw std::runtime_error("trailing bytes after proof");
   return p;
 }

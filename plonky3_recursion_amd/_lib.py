@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # P3R_LIB_PATH: A/B runs of two builds of the library on one box (development only)
 LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so")
 
-P3R_ABI_VERSION = 2
+P3R_ABI_VERSION = 3
 P3R_EXT_LOOKUP_UNPACKED = 1
 FIELD_KOALA_BEAR = 0
 FIELD_BABY_BEAR = 1
@@ -33,6 +33,8 @@ class P3rConfig(C.Structure):
         ("ext_choices", C.c_uint32),
         ("fri_log_arities", C.POINTER(C.c_uint8)),
         ("fri_log_arities_len", C.c_uint32),
+        ("proof_layout", C.POINTER(C.c_uint8)),
+        ("proof_layout_len", C.c_uint32),
     ]
 
 
@@ -162,6 +164,8 @@ SIGNATURES = {
                                    C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, C.c_char_p, C.c_size_t]),
     "p3r_batch_proof_len": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t),
                                       C.c_char_p, C.c_size_t]),
+    "p3r_batch_proof_len_layout": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8),
+                                             C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
     "p3r_circuit_create": (vp, [vp, C.POINTER(P3rCircuitDesc), u32p]),
     "p3r_circuit_free": (None, [vp, vp]),
     "p3r_circuit_layer": (vp, [vp]),

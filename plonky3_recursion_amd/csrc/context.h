@@ -19,6 +19,7 @@
 #include "../../include/p3r.h"
 #include "field.h"
 #include "poseidon2.h"
+#include "proof_layout.h"
 
 namespace p3r {
 
@@ -315,6 +316,7 @@ struct p3r_ctx {
   p3r::DevBuf p2_diag;  // internal-layer diagonal, Montgomery (lane-cooperative kernels)
   std::vector<uint32_t> rc_canonical;
   std::vector<uint8_t> fri_log_arities;  // copy of p3r_config.fri_log_arities (empty: the rule)
+  p3r::ProofLayout proof_layout;         // from p3r_config.proof_layout (identity by default)
   std::vector<uint32_t> rc_mont_host;  // Montgomery copy on the host (the prover's out-of-domain self-check)
   std::string err;
   p3r::HostStage stage;  // small uploads that do not wait (see HostStage)

@@ -8,6 +8,8 @@
 //   proof field order          recursion/src/types/proof.rs:403-409,452-457,527-534,585-589,
 //                              recursion/src/pcs/fri/targets.rs:104-110
 #pragma once
+#include "proof_layout.h"
+#include <cstring>
 #include <algorithm>
 #include <vector>
 

@@ -734,6 +734,9 @@ void init_ctx(p3r_ctx* ctx) {
   ctx->cfg.poseidon2_rc = nullptr;  // caller's pointer is not retained
   if (ctx->cfg.fri_log_arities) ctx->fri_log_arities.assign(ctx->cfg.fri_log_arities, ctx->cfg.fri_log_arities + ctx->cfg.fri_log_arities_len);
   ctx->cfg.fri_log_arities = nullptr;
+  if (!ctx->proof_layout.set(ctx->cfg.proof_layout, ctx->cfg.proof_layout_len))
+    fail(P3R_EINVAL, "proof_layout must be 18 bytes: three permutations batch[5] | fri[5] | opened[8]");
+  ctx->cfg.proof_layout = nullptr;
   P3R_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_tile<PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 }
@@ -1135,6 +1138,7 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     p3r::VerifyParams prm{(int)cfg->log_blowup, (int)cfg->max_log_arity, (int)cfg->cap_height, (int)cfg->log_final_poly_len,
                           (int)cfg->commit_pow_bits, (int)cfg->query_pow_bits, (int)cfg->num_queries, {}};
     if (cfg->fri_log_arities) prm.fri_log_arities.assign(cfg->fri_log_arities, cfg->fri_log_arities + cfg->fri_log_arities_len);
+    if (!prm.layout.set(cfg->proof_layout, cfg->proof_layout_len)) { report("proof_layout must be 18 bytes: three permutations"); return P3R_EINVAL; }
     std::vector<p3r::AirParams> a(n_airs);
     for (size_t i = 0; i < n_airs; ++i) {
       if (airs[i].kind > P3R_AIR_RECOMPOSE || !airs[i].lanes) { report("bad AIR descriptor"); return P3R_EINVAL; }
@@ -1167,11 +1171,17 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
 
 int p3r_batch_proof_len(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags, size_t* proof_len,
                         char* err_buf, size_t err_cap) {
+  return p3r_batch_proof_len_layout(field, bytes, len, flags, nullptr, proof_len, err_buf, err_cap);
+}
+int p3r_batch_proof_len_layout(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags,
+                               const uint8_t* proof_layout, size_t* proof_len, char* err_buf, size_t err_cap) {
   try {
     if (!bytes || !proof_len) throw std::runtime_error("NULL argument");
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
-    if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len);
-    else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len);
+    p3r::ProofLayout PL;
+    if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
+    if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len, PL);
+    else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len, PL);
     else throw std::runtime_error("unknown field");
     return P3R_OK;
   } catch (const std::exception& e) {

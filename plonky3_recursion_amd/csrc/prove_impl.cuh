@@ -786,65 +786,99 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   }
 
   prof_stage(ctx, "serialize");
-  // ---- 9. serialise BatchProof (field order: host_transcript.h)
-  W.cap_mont(main_cap);
-  if (any_lookup) { W.byte(1); W.cap_mont(perm_cap); } else W.byte(0);
-  W.cap_mont(quot_cap);
-  W.byte(0);  // random commitment (ZK): none
-  W.varint(ni);
-  {
+  // ---- 9. serialise BatchProof; the order of the fields of each struct is ctx->proof_layout
+  // (host_transcript.h::ProofLayout, identity by default)
+  const ProofLayout& PL = ctx->proof_layout;
+  auto write_commitments = [&] {
+    W.cap_mont(main_cap);
+    if (any_lookup) { W.byte(1); W.cap_mont(perm_cap); } else W.byte(0);
+    W.cap_mont(quot_cap);
+    W.byte(0);  // random commitment (ZK): none
+  };
+  auto write_opened = [&] {
+    W.varint(ni);
     size_t ck = 0;
     for (size_t i = 0; i < ni; ++i) {
-      W.vec_ef(o_main[i][0]);
-      if (o_main[i].size() == 2) { W.byte(1); W.vec_ef(o_main[i][1]); } else W.byte(0);
-      W.byte(1); W.vec_ef(o_prep[i][0]);
-      W.byte(1); W.vec_ef(o_prep[i][1]);
       const size_t C = size_t(1) << layouts[i].log_chunks;
-      W.varint(C);
-      for (size_t c = 0; c < C; ++c) W.vec_ef(o_chunks[ck++]);
-      W.byte(0);  // random opened values: none
-      if (!o_perm[i].empty()) { W.vec_ef(o_perm[i][0]); W.vec_ef(o_perm[i][1]); }
-      else { W.varint(0); W.varint(0); }
-    }
-  }
-  W.varint(phases.size());
-  for (auto& ph : phases) W.cap_mont(ph.cap);
-  W.varint(commit_pow_witnesses.size());
-  for (auto& w : commit_pow_witnesses) W.fe(w);
-  W.varint(indices.size());
-  for (size_t qi = 0; qi < indices.size(); ++qi) {
-    const uint32_t* g = gathered + (size_t)qi * words_per_query;  // this query's answers
-    W.varint(qrounds.size());
-    for (auto& qr : qrounds) {
-      W.varint(qr.rows.size());
-      for (auto& rw : qr.rows) {
-        W.varint(rw.second);
-        W.words(g + rw.first, rw.second);
+      for (int f = 0; f < 8; ++f) {
+        switch (PL.opened[f]) {
+          case 0: W.vec_ef(o_main[i][0]); break;
+          case 1: if (o_main[i].size() == 2) { W.byte(1); W.vec_ef(o_main[i][1]); } else W.byte(0); break;
+          case 2: W.byte(1); W.vec_ef(o_prep[i][0]); break;
+          case 3: W.byte(1); W.vec_ef(o_prep[i][1]); break;
+          case 4:
+            W.varint(C);
+            for (size_t c = 0; c < C; ++c) W.vec_ef(o_chunks[ck++]);
+            break;
+          case 5: W.byte(0); break;  // random opened values: none
+          case 6: if (!o_perm[i].empty()) W.vec_ef(o_perm[i][0]); else W.varint(0); break;
+          default: if (!o_perm[i].empty()) W.vec_ef(o_perm[i][1]); else W.varint(0); break;
+        }
       }
-      W.varint(qr.depth);
-      W.words(g + qr.proof_at, (size_t)qr.depth * P2_DIGEST);
     }
-    W.varint(qphases.size());
-    for (size_t p = 0; p < phases.size(); ++p) {
-      auto& qp = qphases[p];
-      const size_t arity = size_t(1) << phases[p].la;
-      const size_t pos = (indices[qi] >> qp.shift) & (arity - 1);  // the query's own position in the row
-      W.byte((uint8_t)phases[p].la);
-      W.varint(arity - 1);
-      for (size_t j = 0; j < arity; ++j)
-        if (j != pos) W.words(g + qp.sib_at[j], 4);
-      W.varint(qp.depth);
-      W.words(g + qp.proof_at, (size_t)qp.depth * P2_DIGEST);
+  };
+  auto write_queries = [&] {
+    W.varint(indices.size());
+    for (size_t qi = 0; qi < indices.size(); ++qi) {
+      const uint32_t* g = gathered + (size_t)qi * words_per_query;  // this query's answers
+      W.varint(qrounds.size());
+      for (auto& qr : qrounds) {
+        W.varint(qr.rows.size());
+        for (auto& rw : qr.rows) {
+          W.varint(rw.second);
+          W.words(g + rw.first, rw.second);
+        }
+        W.varint(qr.depth);
+        W.words(g + qr.proof_at, (size_t)qr.depth * P2_DIGEST);
+      }
+      W.varint(qphases.size());
+      for (size_t p = 0; p < phases.size(); ++p) {
+        auto& qp = qphases[p];
+        const size_t arity = size_t(1) << phases[p].la;
+        const size_t pos = (indices[qi] >> qp.shift) & (arity - 1);  // the query's own position in the row
+        W.byte((uint8_t)phases[p].la);
+        W.varint(arity - 1);
+        for (size_t j = 0; j < arity; ++j)
+          if (j != pos) W.words(g + qp.sib_at[j], 4);
+        W.varint(qp.depth);
+        W.words(g + qp.proof_at, (size_t)qp.depth * P2_DIGEST);
+      }
+    }
+  };
+  auto write_fri = [&] {
+    for (int f = 0; f < 5; ++f) {
+      switch (PL.fri[f]) {
+        case 0:
+          W.varint(phases.size());
+          for (auto& ph : phases) W.cap_mont(ph.cap);
+          break;
+        case 1:
+          W.varint(commit_pow_witnesses.size());
+          for (auto& w : commit_pow_witnesses) W.fe(w);
+          break;
+        case 2: write_queries(); break;
+        case 3: W.vec_ef(final_poly); break;
+        default: W.fe(query_pow_witness); break;
+      }
+    }
+  };
+  for (int f = 0; f < 5; ++f) {
+    switch (PL.batch[f]) {
+      case 0: write_commitments(); break;
+      case 1: write_opened(); break;
+      case 2: write_fri(); break;
+      case 3:
+        W.varint(ni);
+        for (size_t i = 0; i < ni; ++i) {
+          if (layouts[i].n_groups) { W.byte(1); W.ef(terminals[i]); } else W.byte(0);
+        }
+        break;
+      default:
+        W.varint(ni);
+        for (size_t i = 0; i < ni; ++i) W.varint(log_n[i]);
+        break;
     }
   }
-  W.vec_ef(final_poly);
-  W.fe(query_pow_witness);
-  W.varint(ni);
-  for (size_t i = 0; i < ni; ++i) {
-    if (layouts[i].n_groups) { W.byte(1); W.ef(terminals[i]); } else W.byte(0);
-  }
-  W.varint(ni);
-  for (size_t i = 0; i < ni; ++i) W.varint(log_n[i]);
   P3R_HIP(hipStreamSynchronize(ctx->stream));
   prof_stage(ctx, nullptr);
   return W.take();

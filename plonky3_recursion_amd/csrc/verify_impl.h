@@ -120,59 +120,92 @@ struct ParsedProof {
 // `consumed`: when given, trailing bytes are allowed and the length of the BatchProof is returned
 // (the outer BatchStarkProof appends its metadata after it, batch_stark_prover.rs:610-636).
 template <class PP>
-ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size_t* consumed = nullptr) {
+ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size_t* consumed = nullptr,
+                            const ProofLayout& PL = ProofLayout{}) {
   ProofReader<PP> R{bytes, bytes + n, canonical};
   ParsedProof<PP> P;
-  P.main_cap = R.cap();
-  if (R.flag()) P.perm_cap = R.cap();
-  P.quot_cap = R.cap();
-  if (R.flag()) vfail("proof carries a random (ZK) commitment: not supported");
-  P.insts.resize(R.len(64));
-  for (auto& in : P.insts) {
-    in.main_local = R.vec_ef();
-    if (R.flag()) in.main_next = R.vec_ef();
-    if (!R.flag()) vfail("preprocessed_local missing");
-    in.prep_local = R.vec_ef();
-    if (!R.flag()) vfail("preprocessed_next missing");
-    in.prep_next = R.vec_ef();
-    in.chunks.resize(R.len(8));
-    for (auto& c : in.chunks) c = R.vec_ef();
-    if (R.flag()) vfail("proof carries random opened values: not supported");
-    in.perm_local = R.vec_ef();
-    in.perm_next = R.vec_ef();
-  }
-  P.commit_caps.resize(R.len(64));
-  for (auto& c : P.commit_caps) c = R.cap();
-  P.commit_pow.resize(R.len(64));
-  for (auto& w : P.commit_pow) w = R.fe();
-  P.queries.resize(R.len(1024));
-  for (auto& q : P.queries) {
-    q.rounds.resize(R.len(8));
-    for (auto& r : q.rounds) {
-      r.rows.resize(R.len(256));
-      for (auto& row : r.rows) {
-        row.resize(R.len(1u << 16));
-        for (auto& x : row) x = R.fe();
+  auto read_commitments = [&] {
+    P.main_cap = R.cap();
+    if (R.flag()) P.perm_cap = R.cap();
+    P.quot_cap = R.cap();
+    if (R.flag()) vfail("proof carries a random (ZK) commitment: not supported");
+  };
+  auto read_opened = [&] {
+    P.insts.resize(R.len(64));
+    for (auto& in : P.insts) {
+      for (int f = 0; f < 8; ++f) {
+        switch (PL.opened[f]) {
+          case 0: in.main_local = R.vec_ef(); break;
+          case 1: if (R.flag()) in.main_next = R.vec_ef(); break;
+          case 2: if (!R.flag()) vfail("preprocessed_local missing"); in.prep_local = R.vec_ef(); break;
+          case 3: if (!R.flag()) vfail("preprocessed_next missing"); in.prep_next = R.vec_ef(); break;
+          case 4:
+            in.chunks.resize(R.len(8));
+            for (auto& c : in.chunks) c = R.vec_ef();
+            break;
+          case 5: if (R.flag()) vfail("proof carries random opened values: not supported"); break;
+          case 6: in.perm_local = R.vec_ef(); break;
+          default: in.perm_next = R.vec_ef(); break;
+        }
       }
-      r.path.resize(R.len(64));
-      for (auto& d : r.path) d = R.digest();
     }
-    q.phases.resize(R.len(64));
-    for (auto& ph : q.phases) {
-      ph.la = R.byte();
-      ph.sibs.resize(R.len(16));
-      for (auto& e : ph.sibs) e = R.ef();
-      ph.path.resize(R.len(64));
-      for (auto& d : ph.path) d = R.digest();
+  };
+  auto read_queries = [&] {
+    P.queries.resize(R.len(1024));
+    for (auto& q : P.queries) {
+      q.rounds.resize(R.len(8));
+      for (auto& r : q.rounds) {
+        r.rows.resize(R.len(256));
+        for (auto& row : r.rows) {
+          row.resize(R.len(1u << 16));
+          for (auto& x : row) x = R.fe();
+        }
+        r.path.resize(R.len(64));
+        for (auto& d : r.path) d = R.digest();
+      }
+      q.phases.resize(R.len(64));
+      for (auto& ph : q.phases) {
+        ph.la = R.byte();
+        ph.sibs.resize(R.len(16));
+        for (auto& e : ph.sibs) e = R.ef();
+        ph.path.resize(R.len(64));
+        for (auto& d : ph.path) d = R.digest();
+      }
+    }
+  };
+  auto read_fri = [&] {
+    for (int f = 0; f < 5; ++f) {
+      switch (PL.fri[f]) {
+        case 0:
+          P.commit_caps.resize(R.len(64));
+          for (auto& c : P.commit_caps) c = R.cap();
+          break;
+        case 1:
+          P.commit_pow.resize(R.len(64));
+          for (auto& w : P.commit_pow) w = R.fe();
+          break;
+        case 2: read_queries(); break;
+        case 3: P.final_poly = R.vec_ef(); break;
+        default: P.query_pow = R.fe(); break;
+      }
+    }
+  };
+  for (int f = 0; f < 5; ++f) {
+    switch (PL.batch[f]) {
+      case 0: read_commitments(); break;
+      case 1: read_opened(); break;
+      case 2: read_fri(); break;
+      case 3:
+        P.terminals.resize(R.len(64));
+        for (auto& t : P.terminals)
+          if (R.flag()) t = R.ef();
+        break;
+      default:
+        P.degree_bits.resize(R.len(64));
+        for (auto& d : P.degree_bits) d = (int)R.len(40);
+        break;
     }
   }
-  P.final_poly = R.vec_ef();
-  P.query_pow = R.fe();
-  P.terminals.resize(R.len(64));
-  for (auto& t : P.terminals)
-    if (R.flag()) t = R.ef();
-  P.degree_bits.resize(R.len(64));
-  for (auto& d : P.degree_bits) d = (int)R.len(40);
   if (consumed) *consumed = (size_t)(R.p - bytes);
   else if (R.p != R.end) vfail("%zu trailing bytes after the proof", (size_t)(R.end - R.p));
   return P;
@@ -396,6 +429,7 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
 struct VerifyParams {
   int log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits, num_queries;
   std::vector<uint8_t> fri_log_arities;  // explicit folding schedule (p3r_config), empty: the rule
+  ProofLayout layout;                    // field order of the serialised structs (p3r_config.proof_layout)
 };
 
 template <class PP>
@@ -405,7 +439,7 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   using F = Fp<PP>;
   using E = Fp4<PP>;
   using Digest = std::array<F, P2_DIGEST>;
-  const ParsedProof<PP> P = parse_proof<PP>(bytes, n_bytes, canonical);
+  const ParsedProof<PP> P = parse_proof<PP>(bytes, n_bytes, canonical, nullptr, prm.layout);
   const size_t ni = airs.size();
   if (rc_canonical.size() != (size_t)p2_num_constants<PP>()) vfail("wrong number of round constants");
   std::vector<uint32_t> rc(rc_canonical.size());

@@ -37,7 +37,7 @@ def _u8(a):
 
 def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5,
                 commit_pow_bits=0, query_pow_bits=15, num_queries=54, device=0, poseidon2_rc=None, ext_choices=0,
-                fri_log_arities=None):
+                fri_log_arities=None, proof_layout=None):
     """A `p3r_config` (+ the arrays it points into, which must stay alive with it).  `ext_choices` /
     `fri_log_arities`: the selectable protocol details of include/p3r.h."""
     cfg = _lib.P3rConfig()
@@ -63,7 +63,12 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
         ar, aptr = _u8(fri_log_arities)
         cfg.fri_log_arities = aptr
         cfg.fri_log_arities_len = ar.size
-    return cfg, (rc, ar)
+    pl = None
+    if proof_layout is not None:
+        pl, pptr = _u8(proof_layout)
+        cfg.proof_layout = pptr
+        cfg.proof_layout_len = pl.size
+    return cfg, (rc, ar, pl)
 
 
 def verify_batch(cfg, airs, preprocessed_commitment, degree_bits, proof: bytes, canonical_field_encoding=False):
@@ -96,13 +101,13 @@ class Context:
 
     def __init__(self, field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
                  log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
-                 device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None):
+                 device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None, proof_layout=None):
         self.lib = _lib.load()
         self.field = field
         self.p = MODULUS[field]
         cfg, self._rc_keep = make_config(field, log_blowup, max_log_arity, cap_height, log_final_poly_len,
                                          commit_pow_bits, query_pow_bits, num_queries, device, poseidon2_rc, ext_choices,
-                                         fri_log_arities)
+                                         fri_log_arities, proof_layout)
         self.cfg = cfg
         self.cap_height = cap_height
         self.log_blowup = log_blowup

@@ -309,15 +309,21 @@ class BatchStarkProof:
         return out
 
     @classmethod
-    def from_postcard(cls, data: bytes, field: str, canonical_field_encoding=False) -> "BatchStarkProof":
+    def from_postcard(cls, data: bytes, field: str, canonical_field_encoding=False, proof_layout=None) -> "BatchStarkProof":
         """Inverse of `to_postcard`: the inner `BatchProof` is delimited with the C-ABI parser
-        (p3r_batch_proof_len), the metadata that follows is decoded here and `validate()`d."""
+        (p3r_batch_proof_len), the metadata that follows is decoded here and `validate()`d.
+        `proof_layout`: the 18 bytes of `p3r_config.proof_layout` when the proof was written with one."""
         from .device import FIELD_IDS, MODULUS
         lib = _lib.load()
         buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
         n, err = C.c_size_t(), C.create_string_buffer(256)
-        rc = lib.p3r_batch_proof_len(FIELD_IDS[field], buf, len(data), 1 if canonical_field_encoding else 0,
-                                     C.byref(n), err, len(err))
+        if proof_layout is None:
+            rc = lib.p3r_batch_proof_len(FIELD_IDS[field], buf, len(data), 1 if canonical_field_encoding else 0,
+                                         C.byref(n), err, len(err))
+        else:
+            lay = (C.c_uint8 * 18)(*[int(v) for v in proof_layout])
+            rc = lib.p3r_batch_proof_len_layout(FIELD_IDS[field], buf, len(data), 1 if canonical_field_encoding else 0, lay,
+                                                C.byref(n), err, len(err))
         if rc != 0:
             raise P3rError(rc, err.value.decode())
         p, pos = MODULUS[field], [n.value]

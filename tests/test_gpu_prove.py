@@ -93,18 +93,22 @@ def test_prove_rejects_unsatisfied_trace(oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("ext_choices,arities", [(1, None), (0, [1, 1, 1, 1, 1, 1]), (1, [1, 1, 1, 1, 1, 1])])
-def test_selectable_protocol_details_bit_exact(oracle, ext_choices, arities):
+LAYOUT = [4, 0, 2, 1, 3] + [3, 4, 0, 2, 1] + [0, 2, 3, 1, 6, 7, 4, 5]
+
+
+@pytest.mark.parametrize("ext_choices,arities,layout", [(1, None, None), (0, [1, 1, 1, 1, 1, 1], None),
+                                                        (1, [1, 1, 1, 1, 1, 1], LAYOUT), (0, None, LAYOUT)])
+def test_selectable_protocol_details_bit_exact(oracle, ext_choices, arities, layout):
     """ext_choices / fri_log_arities of p3r_config (the [EXT] switches of DESIGN.md section 4): the HIP
     prover under the switched rules produces the oracle's bytes under the same rules."""
     import plonky3_recursion_amd as p3r
     field = "koala-bear"
     arrs = harness_lib.generate(field, 7, seed=17, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
     kw = dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=5)
-    prm = layer_lib.params(ext_choices=ext_choices, fri_log_arities=arities, **kw)
+    prm = layer_lib.params(ext_choices=ext_choices, fri_log_arities=arities, proof_layout=layout, **kw)
     L = layer_lib.OracleLayer(oracle, field, arrs, prm)
     tables = L.tables()
-    ctx = p3r.Context(field=field, ext_choices=ext_choices, fri_log_arities=arities, **kw)
+    ctx = p3r.Context(field=field, ext_choices=ext_choices, fri_log_arities=arities, proof_layout=layout, **kw)
     cap, pd = ctx.prep_create(airs_of(tables), [t["prep"] for t in tables])
     assert np.array_equal(cap, L.prep_commit())
     got = ctx.prove_batch(pd, [t["main"] for t in tables])

@@ -189,8 +189,12 @@ def test_native_verifier_parser_survives_mutations(oracle):
             verify("koala-bear", prm, tables, cap, bytes(b))
 
 
-@pytest.mark.parametrize("ext_choices,arities", [(1, None), (0, [1, 1, 1, 1, 1]), (1, [1, 1, 1, 1, 1])])
-def test_selectable_protocol_details_oracle_and_native_verifier_agree(oracle, ext_choices, arities):
+LAYOUT = [4, 0, 2, 1, 3] + [3, 4, 0, 2, 1] + [0, 2, 3, 1, 6, 7, 4, 5]   # some other order of every struct's fields
+
+
+@pytest.mark.parametrize("ext_choices,arities,layout", [(1, None, None), (0, [1, 1, 1, 1, 1], None), (1, [1, 1, 1, 1, 1], LAYOUT),
+                                                        (0, None, LAYOUT)])
+def test_selectable_protocol_details_oracle_and_native_verifier_agree(oracle, ext_choices, arities, layout):
     """The [EXT] switches (include/p3r.h: ext_choices, fri_log_arities): LogUp
     without same-bus packing and an explicit FRI folding schedule.  The oracle proves under the
     switched rules, both verifiers accept under the same rules and reject under the default ones."""
@@ -199,7 +203,7 @@ def test_selectable_protocol_details_oracle_and_native_verifier_agree(oracle, ex
     arrs = harness_lib.generate(field, log_h, seed=91, **SMALL)
     kw = dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
     base = layer_lib.params(**kw)
-    prm = layer_lib.params(ext_choices=ext_choices, fri_log_arities=arities, **kw)
+    prm = layer_lib.params(ext_choices=ext_choices, fri_log_arities=arities, proof_layout=layout, **kw)
     L = layer_lib.OracleLayer(oracle, field, arrs, prm)
     tables, cap = L.tables(), L.prep_commit()
     proof = L.prove()
@@ -207,17 +211,31 @@ def test_selectable_protocol_details_oracle_and_native_verifier_agree(oracle, ex
     db = [int(t["main"].shape[0]).bit_length() - 1 for t in tables]
     airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
 
-    def native(ext, ar):
+    def native(ext, ar, lay=layout):
         cfg, keep = p3r.make_config(field, base.log_blowup, base.max_log_arity, base.cap_height, base.log_final_poly_len,
                                     base.commit_pow_bits, base.query_pow_bits, base.num_queries, ext_choices=ext,
-                                    fri_log_arities=ar)
+                                    fri_log_arities=ar, proof_layout=lay)
         p3r.verify_batch(cfg, airs, cap, db, proof)
 
     native(ext_choices, arities)
     default_proof = layer_lib.OracleLayer(oracle, field, arrs, base).prove()
     assert default_proof != proof
+    if layout is not None:
+        assert sorted(default_proof) == sorted(proof) or ext_choices or arities   # same content, other order
     with pytest.raises(p3r.P3rError):      # the default rules describe a different proof shape
-        native(0, None)
+        native(0, None, None)
+    if layout is not None:
+        from plonky3_recursion_amd import prover as pv
+        n = pv.BatchStarkProof  # the wire parser finds the end of the inner proof under the same layout
+        import ctypes as C
+        from plonky3_recursion_amd import _lib
+        lib = _lib.load()
+        buf = (C.c_uint8 * (len(proof) + 3)).from_buffer_copy(proof + b"xyz")
+        got, err = C.c_size_t(), C.create_string_buffer(256)
+        lay = (C.c_uint8 * 18)(*layout)
+        assert lib.p3r_batch_proof_len_layout(0, buf, len(proof) + 3, 0, lay, C.byref(got), err, 256) == 0 and got.value == len(proof)
+        bad = (C.c_uint8 * 18)(*([0] * 18))
+        assert lib.p3r_batch_proof_len_layout(0, buf, len(proof) + 3, 0, bad, C.byref(got), err, 256) != 0
     if arities is not None:
         with pytest.raises(p3r.P3rError):  # a schedule that skips the final height is refused
             native(ext_choices, [2, 2, 2, 2])
