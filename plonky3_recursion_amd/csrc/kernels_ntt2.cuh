@@ -103,6 +103,23 @@ __device__ __forceinline__ uint32_t ntt2_line_pos(uint32_t t, uint32_t r) {
   return t * LINE + r + (r >> 4);
 }
 
+// one middle stage group (stages S..S+3) of the line pass, LDS to LDS
+template <class PP, int LOG_R, int S>
+__device__ __forceinline__ void ntt2_line_middle(uint32_t* tile, const uint32_t* tws, Fp<PP>* x, uint32_t tid) {
+  using F = Fp<PP>;
+  constexpr uint32_t R = 1u << LOG_R;
+  constexpr int LQ = LOG_R - S - 4;
+  const uint32_t it = tid & ((R / 16) - 1), t = tid >> (LOG_R - 4);
+  const uint32_t low = it & ((1u << LQ) - 1), high = it >> LQ;
+  const uint32_t r0 = (high << (LQ + 4)) | low;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[ntt2_line_pos<LOG_R>(t, r0 + ((uint32_t)j << LQ))]);
+  ntt2_stages<PP, LOG_R, S, 4, false>(x, tws, low);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tile[ntt2_line_pos<LOG_R>(t, r0 + ((uint32_t)j << LQ))] = x[j].v;
+  __syncthreads();
+}
+
 struct NttLineJob {
   uint32_t* data;     // in place
   const uint32_t* tw; // w_R^i, i < R/2, Montgomery
@@ -112,7 +129,7 @@ struct NttLineJob {
 template <class PP, int LOG_R>
 __global__ void __launch_bounds__(kNtt2Lanes, 6) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
-  static_assert(LOG_R >= 5 && LOG_R <= 12, "line length");
+  static_assert(LOG_R >= 5 && LOG_R <= 13, "line length");
   constexpr uint32_t R = 1u << LOG_R;
   constexpr int LOG_T = kNtt2LogTile - LOG_R;
   constexpr uint32_t LINE = R + R / 16;
@@ -140,20 +157,9 @@ __global__ void __launch_bounds__(kNtt2Lanes, 6) k_ntt_fwd_line(const NttLineJob
     for (int j = 0; j < 16; ++j) tile[ntt2_line_pos<LOG_R>(t, b + ((uint32_t)j << LQ))] = x[j].v;
   }
   __syncthreads();
-  // ---- middle groups
-  if constexpr (G >= 3) {
-    constexpr int S = 4;
-    constexpr int LQ = LOG_R - S - 4;
-    const uint32_t it = tid & ((R / 16) - 1), t = tid >> (LOG_R - 4);
-    const uint32_t low = it & ((1u << LQ) - 1), high = it >> LQ;
-    const uint32_t r0 = (high << (LQ + 4)) | low;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[ntt2_line_pos<LOG_R>(t, r0 + ((uint32_t)j << LQ))]);
-    ntt2_stages<PP, LOG_R, S, 4, false>(x, tws, low);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) tile[ntt2_line_pos<LOG_R>(t, r0 + ((uint32_t)j << LQ))] = x[j].v;
-    __syncthreads();
-  }
+  // ---- middle groups (stages 4..7, and 8..11 for 2^13-cell lines)
+  if constexpr (G >= 3) ntt2_line_middle<PP, LOG_R, 4>(tile, tws, x, tid);
+  if constexpr (G >= 4) ntt2_line_middle<PP, LOG_R, 8>(tile, tws, x, tid);
   // ---- last group: 16 consecutive cells per lane, constant twiddles
   {
     constexpr int S = 4 * (G - 1);

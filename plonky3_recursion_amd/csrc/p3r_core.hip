@@ -306,7 +306,7 @@ void launch_fwd_line_r(p3r_ctx* ctx, std::vector<NttLineJob>& jobs, uint32_t blo
   hipLaunchKernelGGL((k_ntt_fwd_line<PP, LOG_R>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
   P3R_HIP(hipGetLastError());
 }
-constexpr int kNtt2MinLogR = 5, kNtt2MaxLogR = 12;
+constexpr int kNtt2MinLogR = 5, kNtt2MaxLogR = 12, kNtt2MaxLineLogR = 13;
 template <class PP, int MODE>
 void launch_col(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttColJob>, uint64_t>>& by_r) {
   for (auto& kv : by_r) {
@@ -341,6 +341,7 @@ void launch_fwd_line(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttLineJo
       case 10: launch_fwd_line_r<PP, 10>(ctx, jobs, blocks); break;
       case 11: launch_fwd_line_r<PP, 11>(ctx, jobs, blocks); break;
       case 12: launch_fwd_line_r<PP, 12>(ctx, jobs, blocks); break;
+      case 13: launch_fwd_line_r<PP, 13>(ctx, jobs, blocks); break;
       default: fail(P3R_EUNSUPPORTED, "forward NTT line pass of 2^%d cells", kv.first);
     }
   }
@@ -451,10 +452,15 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
     // contiguous segments per row), its second pass is contiguous whatever N2 is.
     // (measured: 2^8 x 2^12 beats 2^10 x 2^10 at n = 2^20; past 2^12 contiguous points per line the
     // balanced split is better again)
-    const int la_f = log_n - fwd_la_cap <= 12 ? std::min(log_n / 2, fwd_la_cap) : log_n / 2, lb_f = log_n - la_f;
+    // With the lean kernels the contiguous pass takes lines of up to 2^13 cells (one tile), so the strided
+    // pass keeps 2^8 rows (128-byte segments) up to 2^21 rows and grows only beyond that (2^22: 2^9 rows,
+    // 64-byte segments; the balanced 2^11 x 2^11 split moved 16-byte segments).
+    const int la_f = lean_fwd ? std::max(std::min(log_n / 2, fwd_la_cap), log_n - kNtt2MaxLineLogR)
+                              : (log_n - fwd_la_cap <= 12 ? std::min(log_n / 2, fwd_la_cap) : log_n / 2);
+    const int lb_f = log_n - la_f;
     auto pre = get_pre<PP>(ctx, log_n, la_f, lb_f, added_bits, shift);
     auto tw4f = get_tw4<PP>(ctx, log_n, 0);
-    if (lean_fwd && la_f >= kNtt2MinLogR && la_f <= kNtt2MaxLogR && lb_f >= kNtt2MinLogR && lb_f <= kNtt2MaxLogR &&
+    if (lean_fwd && la_f >= kNtt2MinLogR && la_f <= kNtt2MaxLogR && lb_f >= kNtt2MinLogR && lb_f <= kNtt2MaxLineLogR &&
         lb_f >= kNtt2LogTile - la_f) {
       // lean kernels (kernels_ntt2.cuh): the same two passes with compile-time geometry
       NttColJob cj{};
