@@ -204,14 +204,19 @@ struct NttColJob {
   uint32_t block0;  // tile fastest, then coset, then column
 };
 
-template <class PP, int LOG_R, int MODE>
-__global__ void __launch_bounds__(kNtt2Lanes, 8) k_ntt_col(const NttColJob* __restrict__ jobs, int n_jobs) {
+// LOG_TILE: 13 (one 16-row item per lane and stage group) or 14 (two items per lane: twice the
+// columns per tile, i.e. twice the contiguous bytes per row - what the inverse passes of tall
+// matrices need, whose 2^10 / 2^11-row tiles are only 8 / 4 columns wide at 2^13 cells).
+template <class PP, int LOG_R, int MODE, int LOG_TILE = kNtt2LogTile>
+__global__ void __launch_bounds__(kNtt2Lanes, LOG_TILE == 13 ? 8 : 4) k_ntt_col(const NttColJob* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
   static_assert(LOG_R >= 5 && LOG_R <= 12, "sub-transform size");
+  static_assert(LOG_TILE == 13 || LOG_TILE == 14, "tile size");
   constexpr bool INV = MODE != NTT2_FWD;
   constexpr uint32_t R = 1u << LOG_R;
-  constexpr int LOG_T = kNtt2LogTile - LOG_R;
+  constexpr int LOG_T = LOG_TILE - LOG_R;
   constexpr uint32_t T = 1u << LOG_T;
+  constexpr int ITEMS = 1 << (LOG_TILE - kNtt2LogTile);
   constexpr int G = (LOG_R + 3) / 4;
   constexpr int ML_LAST = LOG_R - 4 * (G - 1);
   __shared__ uint32_t tile[R * (T + 1) + (R >> 5) + 2];
@@ -225,13 +230,15 @@ __global__ void __launch_bounds__(kNtt2Lanes, 8) k_ntt_col(const NttColJob* __re
   const uint32_t bz = (local >> log_gx) & ((1u << a.log_cosets) - 1);
   const uint32_t by = local >> (log_gx + a.log_cosets);
   const uint32_t tid = threadIdx.x;
-  const uint32_t t = tid & (T - 1), it = tid >> LOG_T;  // column inside the tile, 16-row item
-  const uint32_t n2 = (bx << LOG_T) + t;
   const gptr<const uint32_t> twg = as_global(a.tw);
   for (uint32_t i = tid; i < R / 2; i += kNtt2Lanes) tws[i] = twg[i];
   F x[16];
   // ---- group 0 from global memory: rows it + j*(R/16)
-  {
+#pragma unroll
+  for (int item = 0; item < ITEMS; ++item) {
+    const uint32_t e = tid + (uint32_t)item * kNtt2Lanes;
+    const uint32_t t = e & (T - 1), it = e >> LOG_T;  // column inside the tile, 16-row item
+    const uint32_t n2 = (bx << LOG_T) + t;
     constexpr int LQ = LOG_R - 4;
     const gptr<const uint32_t> src = as_global(a.in) + (size_t)by * a.in_col_stride + n2;
     if constexpr (MODE == NTT2_FWD) {  // scaled by the coset shift powers
@@ -247,57 +254,70 @@ __global__ void __launch_bounds__(kNtt2Lanes, 8) k_ntt_col(const NttColJob* __re
 #pragma unroll
       for (int j = 0; j < 16; ++j) x[j] = F::raw(src[(size_t)(it + ((uint32_t)j << LQ)) << a.log_n2]);
     }
-    __syncthreads();  // twiddle table
+    if (item == 0) __syncthreads();  // twiddle table
     ntt2_stages<PP, LOG_R, 0, 4, false, INV>(x, tws, it);
 #pragma unroll
     for (int j = 0; j < 16; ++j) tile[lds_addr(it + ((uint32_t)j << LQ), t, T)] = x[j].v;
   }
   __syncthreads();
   if constexpr (G >= 3) {
-    constexpr int S = 4;
-    constexpr int LQ = LOG_R - S - 4;
-    const uint32_t low = it & ((1u << LQ) - 1), high = it >> LQ;
-    const uint32_t r0 = (high << (LQ + 4)) | low;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + ((uint32_t)j << LQ), t, T)]);
-    ntt2_stages<PP, LOG_R, S, 4, false, INV>(x, tws, low);
+    for (int item = 0; item < ITEMS; ++item) {
+      const uint32_t e = tid + (uint32_t)item * kNtt2Lanes;
+      const uint32_t t = e & (T - 1), it = e >> LOG_T;
+      constexpr int S = 4;
+      constexpr int LQ = LOG_R - S - 4;
+      const uint32_t low = it & ((1u << LQ) - 1), high = it >> LQ;
+      const uint32_t r0 = (high << (LQ + 4)) | low;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) tile[lds_addr(r0 + ((uint32_t)j << LQ), t, T)] = x[j].v;
+      for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + ((uint32_t)j << LQ), t, T)]);
+      ntt2_stages<PP, LOG_R, S, 4, false, INV>(x, tws, low);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tile[lds_addr(r0 + ((uint32_t)j << LQ), t, T)] = x[j].v;
+    }
     __syncthreads();
   }
   // ---- last group: rows 16*it .. 16*it+15
   constexpr int S_LAST = 4 * (G - 1);
-  const uint32_t r0 = it << 4;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + j, t, T)]);
-  ntt2_stages<PP, LOG_R, S_LAST, ML_LAST, true, INV>(x, (const uint32_t*)nullptr, 0);
   const gptr<uint32_t> dst = as_global(a.out) + (size_t)by * a.out_col_stride + (size_t)bz * a.out_coset_stride;
-  if constexpr (MODE == NTT2_FWD) {
-    // straight to global memory with the four-step twiddle, rows in place
-    const gptr<const uint32_t> lo = as_global(a.tw4_lo), hi = as_global(a.tw4_hi);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t r = r0 + j;
-      const uint32_t xk = bit_reverse(r, LOG_R) * n2;  // < N
-      const F tw = F::raw(F::reduce64_lazy((uint64_t)hi[xk >> 10] * lo[xk & 1023]));
-      dst[((size_t)r << a.log_n2) + n2] = (x[j] * tw).v;
+  for (int item = 0; item < ITEMS; ++item) {
+    const uint32_t e = tid + (uint32_t)item * kNtt2Lanes;
+    const uint32_t t = e & (T - 1), it = e >> LOG_T;
+    const uint32_t n2 = (bx << LOG_T) + t;
+    const uint32_t r0 = it << 4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = F::raw(tile[lds_addr(r0 + j, t, T)]);
+    ntt2_stages<PP, LOG_R, S_LAST, ML_LAST, true, INV>(x, (const uint32_t*)nullptr, 0);
+    if constexpr (MODE == NTT2_FWD) {
+      // straight to global memory with the four-step twiddle, rows in place
+      const gptr<const uint32_t> lo = as_global(a.tw4_lo), hi = as_global(a.tw4_hi);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t r = r0 + j;
+        const uint32_t xk = bit_reverse(r, LOG_R) * n2;  // < N
+        const F tw = F::raw(F::reduce64_lazy((uint64_t)hi[xk >> 10] * lo[xk & 1023]));
+        dst[((size_t)r << a.log_n2) + n2] = (x[j] * tw).v;
+      }
+    } else if constexpr (MODE == NTT2_INV2) {
+      // natural row order, scaled: row k1 = bitrev(r)
+      const F sc = F::raw(a.scale);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t k1 = bit_reverse(r0 + j, LOG_R);
+        dst[((size_t)k1 << a.log_n2) + n2] = (x[j] * sc).v;
+      }
+    } else {
+      // transposed: back through LDS so that consecutive lanes write consecutive k1
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tile[lds_addr(r0 + j, t, T)] = x[j].v;
     }
-  } else if constexpr (MODE == NTT2_INV2) {
-    // natural row order, scaled: row k1 = bitrev(r)
-    const F sc = F::raw(a.scale);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t k1 = bit_reverse(r0 + j, LOG_R);
-      dst[((size_t)k1 << a.log_n2) + n2] = (x[j] * sc).v;
-    }
-  } else {
-    // transposed: back through LDS so that consecutive lanes write consecutive k1
-#pragma unroll
-    for (int j = 0; j < 16; ++j) tile[lds_addr(r0 + j, t, T)] = x[j].v;
+  }
+  if constexpr (MODE == NTT2_INV1) {
     __syncthreads();
     const gptr<const uint32_t> lo = as_global(a.tw4_lo), hi = as_global(a.tw4_hi);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 16 * ITEMS; ++j) {
       const uint32_t e = tid + (uint32_t)j * kNtt2Lanes;
       const uint32_t k1 = e & (R - 1), tt = e >> LOG_R;
       const uint32_t col = (bx << LOG_T) + tt;

@@ -292,11 +292,11 @@ void launch_ntt(p3r_ctx* ctx, std::vector<NttJob>& jobs, const char* name) {
 }
 
 // The lean forward passes (kernels_ntt2.cuh): jobs grouped by the compile-time sub-transform size.
-template <class PP, int LOG_R, int MODE>
+template <class PP, int LOG_R, int MODE, int LOG_TILE>
 void launch_col_r(p3r_ctx* ctx, std::vector<NttColJob>& jobs, uint32_t blocks) {
   const auto* d = static_cast<const NttColJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(NttColJob)));
   ProfScope ps(ctx, MODE == NTT2_FWD ? "ntt_forward_1" : MODE == NTT2_INV1 ? "ntt_inverse_1" : "ntt_inverse_2");
-  hipLaunchKernelGGL((k_ntt_col<PP, LOG_R, MODE>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
+  hipLaunchKernelGGL((k_ntt_col<PP, LOG_R, MODE, LOG_TILE>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
   P3R_HIP(hipGetLastError());
 }
 template <class PP, int LOG_R>
@@ -307,23 +307,25 @@ void launch_fwd_line_r(p3r_ctx* ctx, std::vector<NttLineJob>& jobs, uint32_t blo
   P3R_HIP(hipGetLastError());
 }
 constexpr int kNtt2MinLogR = 5, kNtt2MaxLogR = 12, kNtt2MaxLineLogR = 13;
+// jobs grouped by (sub-transform size, tile size): key = log_r * 2 + (log_tile - 13)
 template <class PP, int MODE>
 void launch_col(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttColJob>, uint64_t>>& by_r) {
   for (auto& kv : by_r) {
     auto& jobs = kv.second.first;
     if (kv.second.second >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "NTT launch of %llu tiles", (unsigned long long)kv.second.second);
     const uint32_t blocks = (uint32_t)kv.second.second;
-    switch (kv.first) {
-      case 5: launch_col_r<PP, 5, MODE>(ctx, jobs, blocks); break;
-      case 6: launch_col_r<PP, 6, MODE>(ctx, jobs, blocks); break;
-      case 7: launch_col_r<PP, 7, MODE>(ctx, jobs, blocks); break;
-      case 8: launch_col_r<PP, 8, MODE>(ctx, jobs, blocks); break;
-      case 9: launch_col_r<PP, 9, MODE>(ctx, jobs, blocks); break;
-      case 10: launch_col_r<PP, 10, MODE>(ctx, jobs, blocks); break;
-      case 11: launch_col_r<PP, 11, MODE>(ctx, jobs, blocks); break;
-      case 12: launch_col_r<PP, 12, MODE>(ctx, jobs, blocks); break;
-      default: fail(P3R_EUNSUPPORTED, "NTT column pass of 2^%d rows", kv.first);
+    const int log_r = kv.first >> 1, big = kv.first & 1;
+#define P3R_COL_CASE(R)                                                                         \
+  case R:                                                                                       \
+    if (MODE != NTT2_FWD && big) launch_col_r<PP, R, MODE == NTT2_FWD ? NTT2_INV1 : MODE, 14>(ctx, jobs, blocks); \
+    else launch_col_r<PP, R, MODE, 13>(ctx, jobs, blocks);                                      \
+    break;
+    switch (log_r) {
+      P3R_COL_CASE(5) P3R_COL_CASE(6) P3R_COL_CASE(7) P3R_COL_CASE(8) P3R_COL_CASE(9) P3R_COL_CASE(10) P3R_COL_CASE(11)
+      P3R_COL_CASE(12)
+      default: fail(P3R_EUNSUPPORTED, "NTT column pass of 2^%d rows", log_r);
     }
+#undef P3R_COL_CASE
   }
 }
 template <class PP>
@@ -415,9 +417,11 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       j1.tw4_lo = tw4i.first; j1.tw4_hi = tw4i.second;
       j1.in_col_stride = N; j1.out_col_stride = N;
       j1.log_n2 = lb;
-      auto& q1 = inv1[la];
+      // 2^14-cell tiles (two items per lane) when the 2^13 tile would be narrower than 16 columns
+      const int big1 = (kNtt2LogTile - la < 4 && lb >= kNtt2LogTile + 1 - la) ? 1 : 0;
+      auto& q1 = inv1[la * 2 + big1];
       j1.block0 = (uint32_t)q1.second;
-      q1.second += (uint64_t)w << (lb - (kNtt2LogTile - la));
+      q1.second += (uint64_t)w << (lb - (kNtt2LogTile + big1 - la));
       q1.first.push_back(j1);
       NttColJob j2{};   // tmp viewed as [N2 rows][N1]: size-N2 transforms along the rows
       j2.in = tmp; j2.out = coef;
@@ -425,9 +429,10 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       j2.in_col_stride = N; j2.out_col_stride = N;
       j2.log_n2 = la;
       j2.scale = inv_n;
-      auto& q2 = inv2[lb];
+      const int big2 = (kNtt2LogTile - lb < 4 && la >= kNtt2LogTile + 1 - lb) ? 1 : 0;
+      auto& q2 = inv2[lb * 2 + big2];
       j2.block0 = (uint32_t)q2.second;
-      q2.second += (uint64_t)w << (la - (kNtt2LogTile - lb));
+      q2.second += (uint64_t)w << (la - (kNtt2LogTile + big2 - lb));
       q2.first.push_back(j2);
     } else {
     // inverse pass 1: size-N1 transforms along n1, twiddle, transposed store tmp[n2*N1 + k1]
@@ -470,7 +475,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       cj.pre_a = pre.first; cj.pre_b = pre.second;
       cj.in_col_stride = N; cj.out_col_stride = N * B; cj.out_coset_stride = N;
       cj.log_n2 = lb_f; cj.log_cosets = added_bits;
-      auto& fc = fwd_col[la_f];
+      auto& fc = fwd_col[la_f * 2];
       cj.block0 = (uint32_t)fc.second;
       fc.second += (uint64_t)w << (lb_f - (kNtt2LogTile - la_f) + added_bits);
       fc.first.push_back(cj);
