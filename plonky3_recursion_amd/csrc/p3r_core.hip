@@ -317,7 +317,7 @@ void launch_col(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttColJob>, ui
     const int log_r = kv.first >> 1, big = kv.first & 1;
 #define P3R_COL_CASE(R)                                                                         \
   case R:                                                                                       \
-    if (MODE != NTT2_FWD && big) launch_col_r<PP, R, MODE == NTT2_FWD ? NTT2_INV1 : MODE, 14>(ctx, jobs, blocks); \
+    if (big) launch_col_r<PP, R, MODE, 14>(ctx, jobs, blocks); \
     else launch_col_r<PP, R, MODE, 13>(ctx, jobs, blocks);                                      \
     break;
     switch (log_r) {
@@ -475,9 +475,12 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       cj.pre_a = pre.first; cj.pre_b = pre.second;
       cj.in_col_stride = N; cj.out_col_stride = N * B; cj.out_coset_stride = N;
       cj.log_n2 = lb_f; cj.log_cosets = added_bits;
-      auto& fc = fwd_col[la_f * 2];
+      // 2^14-cell tiles when the 2^13 tile would be narrower than 32 columns (measured: slower at 2^8 rows
+      // x 32 columns, faster from 2^9 rows on)
+      const int bigf = (kNtt2LogTile - la_f < 5 && lb_f >= kNtt2LogTile + 1 - la_f) ? 1 : 0;
+      auto& fc = fwd_col[la_f * 2 + bigf];
       cj.block0 = (uint32_t)fc.second;
-      fc.second += (uint64_t)w << (lb_f - (kNtt2LogTile - la_f) + added_bits);
+      fc.second += (uint64_t)w << (lb_f - (kNtt2LogTile + bigf - la_f) + added_bits);
       fc.first.push_back(cj);
       NttLineJob lj{};
       lj.data = out->d;
