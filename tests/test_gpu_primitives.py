@@ -98,7 +98,8 @@ def test_lde_golden(ctx, golden):
                                             (12, 3, 2), (13, 2, 1), (14, 2, 2), (15, 1, 2),
                                             # every sub-transform size of the lean NTT kernels (kernels_ntt2.cuh): forward
                                             # 2^6..2^8 x 2^6..2^11, inverse 2^6..2^10 column passes; 1, 2, 4, 8 cosets
-                                            (12, 2, 0), (13, 3, 3), (16, 2, 2), (16, 1, 3), (17, 1, 2), (18, 1, 2), (19, 1, 1)])
+                                            (12, 2, 0), (13, 3, 3), (16, 2, 2), (16, 1, 3), (17, 1, 2), (18, 1, 2), (19, 1, 1), (20, 1, 1),
+                                            (21, 1, 2)])
 def test_lde_vs_oracle(ctx, oracle, log_h, w, added):
     rng = np.random.default_rng(log_h * 31 + w)
     a = rand(rng, ctx.field, (1 << log_h, w))
