@@ -201,7 +201,7 @@ macro_rules! field_module {
                 let traces = runner.run().unwrap();
                 let prover = BatchStarkProver::new(cfg).with_table_packing(packing);
                 let proof: BatchStarkProof<MyConfig> = prover.prove_all_tables(&traces, &cpd).unwrap();
-                prover.verify_all_tables::<F>(&proof).unwrap();
+                prover.verify_all_tables::<Challenge>(&proof).unwrap();  // EF = the expected trace element field (D = 4)
                 let outer = postcard::to_allocvec(&proof).unwrap();
                 let inner = postcard::to_allocvec(&proof.proof).unwrap();
                 json!({
