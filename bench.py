@@ -206,49 +206,72 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device):
     import plonky3_recursion_amd as p3r
     from plonky3_recursion_amd.aggregation import TreePlan, run_aggregation_tree
     field, lh = args.field, args.leaf_log_height
-    ctx = p3r.Context(field=field, device=local_rank, **FRI)
+    import queue
     packing = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
     params = p3r.ProveNextLayerParams(table_packing=packing)
     backend = p3r.FriRecursionBackend()
     plan = TreePlan(args.tree_leaves, world)
-    # leaf layer (every rank proves the same leaf circuit: one NextLayerPrepCache per rank)
     la = harness_lib.generate(field, lh, seed=0x5EED0000, **GEN_KNOBS)
-    leaf_cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(la), backend, params)
-    leaf_inputs = leaf_cache.prepared_circuit.upload_inputs(wl.circuit_inputs_from_arrays(la))
+    leaf_circuit, leaf_host_inputs = wl.circuit_from_arrays(la), wl.circuit_inputs_from_arrays(la)
     del la
-    # aggregation node: twice the counts
-    na = harness_lib.generate(field, lh + 1, seed=0x5EED0001, **GEN_KNOBS)
+    na = harness_lib.generate(field, lh + 1, seed=0x5EED0001, **GEN_KNOBS)   # aggregation node: twice the counts
     node_circuit = wl.circuit_from_arrays(na)
     n_left, n_right, left_ops = wl.split_aggregation_inputs(wl.circuit_inputs_from_arrays(na))
     del na
-    agg_cache = [None]
+    # one worker = one p3r_ctx (HIP stream + memory pool) with its own NextLayerPrepCache /
+    # AggregationPrepCache; --tree-workers > 1 proves the nodes a rank owns at one level concurrently
+    workers = queue.Queue()
+    all_workers = []
+    for _ in range(max(1, args.tree_workers)):
+        wctx = p3r.Context(field=field, device=local_rank, **FRI)
+        lc = p3r.build_next_layer_prep(wctx, leaf_circuit, backend, params)
+        wk = dict(ctx=wctx, leaf_cache=lc, leaf_inputs=lc.prepared_circuit.upload_inputs(leaf_host_inputs), agg_cache=[None])
+        workers.put(wk)
+        all_workers.append(wk)
+    ctx = all_workers[0]["ctx"]
+    import threading
+    stats_lock = threading.Lock()
     stats = {"leaf_ms": [], "node_ms": [], "child_parse_ms": [], "child_verify_ms": []}
 
+    def note(key, ms):
+        with stats_lock:
+            stats[key].append(ms)
+
     def prove_leaf(i):
-        t0 = time.perf_counter()
-        out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=leaf_inputs), ctx, backend, params, prep=leaf_cache)
-        stats["leaf_ms"].append((time.perf_counter() - t0) * 1e3)
-        return out.proof.to_postcard()
+        wk = workers.get()
+        try:
+            t0 = time.perf_counter()
+            out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=wk["leaf_inputs"]), wk["ctx"], backend, params,
+                                       prep=wk["leaf_cache"])
+            note("leaf_ms", (time.perf_counter() - t0) * 1e3)
+            return out.proof.to_postcard()
+        finally:
+            workers.put(wk)
 
     def prove_parent(level, node, lbytes, rbytes):
-        t0 = time.perf_counter()
-        children = [p3r.BatchStarkProof.from_postcard(b, field) for b in (lbytes, rbytes)]   # parse + metadata rules
-        stats["child_parse_ms"].append((time.perf_counter() - t0) * 1e3)
-        if args.tree_verify_children:
+        wk = workers.get()
+        try:
+            t0 = time.perf_counter()
+            children = [p3r.BatchStarkProof.from_postcard(b, field) for b in (lbytes, rbytes)]   # parse + metadata rules
+            note("child_parse_ms", (time.perf_counter() - t0) * 1e3)
+            if args.tree_verify_children:
+                t1 = time.perf_counter()
+                for c in children:
+                    p3r.verify_all_tables(wk["ctx"].cfg, c)
+                note("child_verify_ms", (time.perf_counter() - t1) * 1e3)
             t1 = time.perf_counter()
-            for c in children:
-                p3r.verify_all_tables(ctx.cfg, c)
-            stats["child_verify_ms"].append((time.perf_counter() - t1) * 1e3)
-        t1 = time.perf_counter()
-        out = p3r.prove_aggregation_layer(
-            p3r.RecursionInput(prev_proof=children[0], circuit_inputs=n_left),
-            p3r.RecursionInput(prev_proof=children[1], circuit_inputs=n_right),
-            node_circuit, ctx, backend, params, prep_cache=agg_cache, left_non_primitive_ops=left_ops)
-        stats["node_ms"].append((time.perf_counter() - t1) * 1e3)
-        return out.proof.to_postcard()
+            out = p3r.prove_aggregation_layer(
+                p3r.RecursionInput(prev_proof=children[0], circuit_inputs=n_left),
+                p3r.RecursionInput(prev_proof=children[1], circuit_inputs=n_right),
+                node_circuit, wk["ctx"], backend, params, prep_cache=wk["agg_cache"], left_non_primitive_ops=left_ops)
+            note("node_ms", (time.perf_counter() - t1) * 1e3)
+            return out.proof.to_postcard()
+        finally:
+            workers.put(wk)
 
     def barrier():
-        ctx.sync()
+        for wk in all_workers:
+            wk["ctx"].sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -258,9 +281,11 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device):
     def on_level(level, seconds):
         level_ms.append(seconds * 1e3)
 
-    # warm-up: one leaf and one node per rank (fills the AggregationPrepCache, the pools, the job tables)
-    w = prove_leaf(0)
-    prove_parent(1, 0, w, w)
+    # warm-up: one leaf and one node per worker (fills the AggregationPrepCache, the pools, the job tables)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(all_workers)) as ex:
+        warm = list(ex.map(prove_leaf, range(len(all_workers))))
+        list(ex.map(lambda w: prove_parent(1, 0, w, w), warm))
     for v in stats.values():
         v.clear()
     times = []
@@ -270,7 +295,8 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device):
         level_ms.clear()
         t0 = time.perf_counter()
         root = run_aggregation_tree(plan, rank, prove_leaf, prove_parent, dist=dist, device=coll_device,
-                                    on_level=on_level, level_barrier=barrier if args.tree_level_barriers else None)
+                                    on_level=on_level, level_barrier=barrier if args.tree_level_barriers else None,
+                                    workers=len(all_workers))
         barrier()
         times.append(time.perf_counter() - t0)
     times = times[args.warmup:]
@@ -300,18 +326,21 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device):
                                    f"2^{lh}-row layer) -> {args.tree_leaves - 1} nodes (prove_aggregation_layer, 2^{lh + 1}-row "
                                    f"layer = twice the Poseidon2 / ALU counts), one rank per GPU, parent on its left child's rank",
                        "field": field, "leaf_log_height": lh, "node_log_height": lh + 1, "leaves": args.tree_leaves,
-                       "nodes": n_nodes, "fri": FRI, "parallelism": f"tree nodes over {world} ranks, send/recv of child proofs only"},
+                       "nodes": n_nodes, "fri": FRI, "workers_per_rank": len(all_workers),
+                       "parallelism": f"tree nodes over {world} ranks ({len(all_workers)} concurrent provers = HIP streams per rank), "
+                                      f"send/recv of child proofs only"},
             "proofs_per_s": n_nodes / (ms_tree * 1e-3),
             "root_verified": ok, "root_sha256": hashlib.sha256(root).hexdigest(), "root_bytes": len(root),
             "rank0": {"leaf_ms": mean(stats["leaf_ms"]), "node_ms": mean(stats["node_ms"]),
                       "child_parse_ms": mean(stats["child_parse_ms"]), "child_verify_ms": mean(stats["child_verify_ms"]),
                       "level_wall_ms_last_step": list(level_ms)},
         }))
-    leaf_inputs.free()
-    leaf_cache.prepared_circuit.free()
-    if agg_cache[0] is not None:
-        agg_cache[0].prepared_circuit.free()
-    ctx.close()
+    for wk in all_workers:
+        wk["leaf_inputs"].free()
+        wk["leaf_cache"].prepared_circuit.free()
+        if wk["agg_cache"][0] is not None:
+            wk["agg_cache"][0].prepared_circuit.free()
+        wk["ctx"].close()
     if dist is not None:
         dist.destroy_process_group()
     if not ok:
@@ -333,6 +362,9 @@ def main():
     ap.add_argument("--tree-leaves", type=int, default=8)
     ap.add_argument("--leaf-log-height", type=int, default=15,
                     help="rows of a leaf layer (nodes have twice as many); the reference's real verifier circuits have 2^14..2^16")
+    ap.add_argument("--tree-workers", type=int, default=1,
+                    help="concurrent provers (one p3r_ctx = one HIP stream each) per rank: layers of this size do not fill an "
+                         "MI355X on their own")
     ap.add_argument("--tree-verify-children", action="store_true", help="verify both children natively before proving a node")
     ap.add_argument("--tree-level-barriers", action="store_true", help="barrier between levels (per-level wall times)")
     ap.add_argument("--spans", action="store_true",

@@ -65,7 +65,7 @@ def _recv_bytes(dist, src: int, device) -> bytes:
 def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], bytes],
                          prove_parent: Callable[[int, int, bytes, bytes], bytes], dist=None,
                          device="cpu", on_level: Optional[Callable[[int, float], None]] = None,
-                         level_barrier: Optional[Callable[[], None]] = None) -> Optional[bytes]:
+                         level_barrier: Optional[Callable[[], None]] = None, workers: int = 1) -> Optional[bytes]:
     """Proves every node this rank owns, level by level; returns the root proof on rank 0.
 
     prove_leaf(i) -> proof bytes of leaf i.
@@ -73,10 +73,23 @@ def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], 
     circuit over the two children and calls `prove_aggregation_layer`'s GPU part).
     `dist` is torch.distributed (None for a single process).  `on_level(level, seconds)` receives this
     rank's wall time per level; with `level_barrier` the levels are separated by that barrier, so
-    the times are the level's wall time across ranks."""
+    the times are the level's wall time across ranks.  `workers` > 1: the nodes this rank owns at one
+    level are proved concurrently by that many host threads (the callbacks must then be thread-safe,
+    e.g. one p3r_ctx = one HIP stream per thread: layers of 2^14..2^16 rows do not fill an MI355X on
+    their own, tools/concurrent_small.py)."""
     import time
+    pool = None
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=workers)
+
+    def run_all(fn, keys):
+        if pool is None or len(keys) < 2:
+            return {k: fn(k) for k in keys}
+        return dict(zip(keys, pool.map(fn, keys)))
+
     t0 = time.perf_counter()
-    proofs = {i: prove_leaf(i) for i in plan.my_nodes(0, rank)}
+    proofs = run_all(prove_leaf, plan.my_nodes(0, rank))
     if level_barrier:
         level_barrier()
     if on_level:
@@ -95,13 +108,15 @@ def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], 
                 _send_bytes(dist, proofs[right], parent_rank, device)
             elif rank == parent_rank:
                 proofs[right] = _recv_bytes(dist, right_rank, device)
-        for node in plan.my_nodes(level, rank):
-            nxt[node] = prove_parent(level, node, proofs[2 * node], proofs[2 * node + 1])
+        prev = proofs
+        nxt = run_all(lambda node: prove_parent(level, node, prev[2 * node], prev[2 * node + 1]), plan.my_nodes(level, rank))
         proofs = nxt
         if level_barrier:
             level_barrier()
         if on_level:
             on_level(level, time.perf_counter() - t0)
+    if pool is not None:
+        pool.shutdown()
     # final root hand-off to rank 0
     root_level = plan.levels - 1
     root_rank = plan.owner(root_level, 0)

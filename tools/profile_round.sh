@@ -16,4 +16,5 @@ du -sh gpurun_out/final
 # BASELINE config 5 (BabyBear, 2^22 rows) and config 4 (aggregation tree on one GPU): builder-run lines
 timeout 900 python bench.py --field baby-bear --log-height 22 --steps 3 --no-cpu-baseline --no-config2 --no-small-layers > gpurun_out/final/bench_line_babybear_2p22.json 2> gpurun_out/final/bench_babybear_err.log
 timeout 600 python bench.py --tree --steps 3 --warmup 1 > gpurun_out/final/bench_line_tree_1gpu.json 2> gpurun_out/final/bench_tree_err.log
+timeout 600 python bench.py --tree --tree-workers 4 --steps 3 --warmup 1 > gpurun_out/final/bench_line_tree_1gpu_4workers.json 2>> gpurun_out/final/bench_tree_err.log
 timeout 300 python bench.py --steps 3 --no-cpu-baseline --no-config2 --no-small-layers --spans > /dev/null 2> gpurun_out/final/spans.txt
