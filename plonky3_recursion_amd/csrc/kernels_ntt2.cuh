@@ -201,7 +201,8 @@ struct NttColJob {
   uint64_t in_col_stride, out_col_stride, out_coset_stride;
   int log_n2, log_cosets;
   uint32_t scale;   // Montgomery (NTT2_INV2)
-  uint32_t block0;  // tile fastest, then coset, then column
+  uint32_t block0;  // tile fastest, then coset, then column - or, with xcd_map, see k_ntt_col
+  uint32_t xcd_map; // the cosets of one tile on blocks b, b+8, b+16, ...: one XCD, one L2
 };
 
 // LOG_TILE: 13 (one 16-row item per lane and stage group) or 14 (two items per lane: twice the
@@ -226,9 +227,21 @@ __global__ void __launch_bounds__(kNtt2Lanes, LOG_TILE == 13 ? 8 : 4) k_ntt_col(
   const NttColJob& a = jobs[jb];
   const int log_gx = a.log_n2 - LOG_T;
   const uint32_t local = blockIdx.x - a.block0;
-  const uint32_t bx = local & ((1u << log_gx) - 1);
-  const uint32_t bz = (local >> log_gx) & ((1u << a.log_cosets) - 1);
-  const uint32_t by = local >> (log_gx + a.log_cosets);
+  uint32_t bx, bz, by;
+  if (a.xcd_map) {
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its
+    // own L2): the 2^log_cosets cosets of a tile read the SAME coefficient tile, so they are placed on
+    // blocks 8 apart - the tile comes from HBM once and from that XCD's L2 for the other cosets.
+    const uint32_t xcd = local & 7, slot = local >> 3;
+    bz = slot & ((1u << a.log_cosets) - 1);
+    const uint32_t tile_lin = ((slot >> a.log_cosets) << 3) | xcd;
+    bx = tile_lin & ((1u << log_gx) - 1);
+    by = tile_lin >> log_gx;
+  } else {
+    bx = local & ((1u << log_gx) - 1);
+    bz = (local >> log_gx) & ((1u << a.log_cosets) - 1);
+    by = local >> (log_gx + a.log_cosets);
+  }
   const uint32_t tid = threadIdx.x;
   const gptr<const uint32_t> twg = as_global(a.tw);
   for (uint32_t i = tid; i < R / 2; i += kNtt2Lanes) tws[i] = twg[i];

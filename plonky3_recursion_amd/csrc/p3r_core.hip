@@ -480,6 +480,11 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       const int bigf = (kNtt2LogTile - la_f < 5 && lb_f >= kNtt2LogTile + 1 - la_f) ? 1 : 0;
       auto& fc = fwd_col[la_f * 2 + bigf];
       cj.block0 = (uint32_t)fc.second;
+      {
+        static const bool no_xcd = getenv("P3R_NTT_NO_XCD_MAP") != nullptr;
+        const uint64_t tiles = (uint64_t)w << (lb_f - (kNtt2LogTile + bigf - la_f));
+        cj.xcd_map = (!no_xcd && added_bits > 0 && (cj.block0 & 7) == 0 && (tiles & 7) == 0) ? 1 : 0;
+      }
       fc.second += (uint64_t)w << (lb_f - (kNtt2LogTile + bigf - la_f) + added_bits);
       fc.first.push_back(cj);
       NttLineJob lj{};
