@@ -321,7 +321,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device):
             "metric": "aggregation tree wall ms (8 leaf proofs -> 1 root, prove_aggregation_layer per node), KoalaBear",
             "value": ms_tree, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_tree, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32 (31-bit Montgomery prime field, degree-4 extension)", "data": "synthetic",
+            "dtype": "u32 Montgomery (31-bit prime field, degree-4 extension); Poseidon2 hashing as exact integers in f64", "data": "synthetic",
             "config": {"workload": f"2-to-1 aggregation tree, {args.tree_leaves} leaves (prove_next_layer, synthetic {field} "
                                    f"2^{lh}-row layer) -> {args.tree_leaves - 1} nodes (prove_aggregation_layer, 2^{lh + 1}-row "
                                    f"layer = twice the Poseidon2 / ALU counts), one rank per GPU, parent on its left child's rank",
@@ -548,7 +548,7 @@ def main():
             "higher_is_better": False,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (31-bit Montgomery prime field, degree-4 extension)",
+            "dtype": "u32 Montgomery (31-bit prime field, degree-4 extension); Poseidon2 hashing as exact integers in f64",
             "data": "synthetic",
             "config": {
                 "workload": f"prove_next_layer (verifier-circuit run on the device + prove_all_tables) of the synthetic "

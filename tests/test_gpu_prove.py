@@ -117,3 +117,11 @@ def test_selectable_protocol_details_bit_exact(oracle, ext_choices, arities, lay
     assert got != layer_lib.OracleLayer(oracle, field, arrs, layer_lib.params(**kw)).prove()
     pd.free()
     ctx.close()
+
+
+def test_bad_selectable_details_are_refused():
+    import plonky3_recursion_amd as p3r
+    with pytest.raises(p3r.P3rError, match="proof_layout"):
+        p3r.Context(field="koala-bear", proof_layout=[0] * 18)            # not three permutations
+    with pytest.raises(p3r.P3rError, match="proof_layout"):
+        p3r.Context(field="koala-bear", proof_layout=list(range(5)))       # wrong length
