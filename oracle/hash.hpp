@@ -217,6 +217,7 @@ struct MerkleTree {
                      [&](size_t a, size_t b) { return mats[a]->h > mats[b]->h; });
     size_t hmax = mats[order[0]]->h;
     t.log_max_h = log2_strict(hmax);
+    if (cap_height > t.log_max_h) throw std::runtime_error("cap_height exceeds log2 of the tallest matrix");
     auto rows_at = [&](size_t h, size_t i) {
       std::vector<F> cat;
       for (size_t k : order)

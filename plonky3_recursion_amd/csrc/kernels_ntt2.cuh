@@ -126,12 +126,13 @@ struct NttLineJob {
   uint32_t block0;    // first block of this job; a job owns cells/2^13 blocks
 };
 
-template <class PP, int LOG_R>
-__global__ void __launch_bounds__(kNtt2Lanes, 6) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
+template <class PP, int LOG_R, int LOG_TILE = kNtt2LogTile>
+__global__ void __launch_bounds__(1 << (LOG_TILE - 4)) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
-  static_assert(LOG_R >= 5 && LOG_R <= 13, "line length");
+  static_assert(LOG_R >= 5 && LOG_R <= LOG_TILE && LOG_TILE <= 13, "line length");
   constexpr uint32_t R = 1u << LOG_R;
-  constexpr int LOG_T = kNtt2LogTile - LOG_R;
+  constexpr uint32_t LANES = 1u << (LOG_TILE - 4);
+  constexpr int LOG_T = LOG_TILE - LOG_R;
   constexpr uint32_t LINE = R + R / 16;
   constexpr int G = (LOG_R + 3) / 4;             // stage groups: 4, 4, ..., remainder last
   constexpr int ML_LAST = LOG_R - 4 * (G - 1);
@@ -139,10 +140,10 @@ __global__ void __launch_bounds__(kNtt2Lanes, 6) k_ntt_fwd_line(const NttLineJob
   __shared__ uint32_t tws[R / 2];  // (reading the table through L1 instead frees LDS for a fourth tile per CU but measured 25 % slower)
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
-  const gptr<uint32_t> data = as_global(jobs[jb].data) + ((size_t)(blockIdx.x - jobs[jb].block0) << kNtt2LogTile);
+  const gptr<uint32_t> data = as_global(jobs[jb].data) + ((size_t)(blockIdx.x - jobs[jb].block0) << LOG_TILE);
   const gptr<const uint32_t> twg = as_global(jobs[jb].tw);
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < R / 2; i += kNtt2Lanes) tws[i] = twg[i];
+  for (uint32_t i = tid; i < R / 2; i += LANES) tws[i] = twg[i];
   F x[16];
   // ---- group 0 (stages 0..3) straight from global memory: item b of line t = cells b + j*(R/16)
   {
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(kNtt2Lanes, 6) k_ntt_fwd_line(const NttLineJob
   // ---- copy out, lanes along the line
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const uint32_t cell = tid + (uint32_t)j * kNtt2Lanes;
+    const uint32_t cell = tid + (uint32_t)j * LANES;
     data[cell] = tile[ntt2_line_pos<LOG_R>(cell >> LOG_R, cell & (R - 1))];
   }
 }

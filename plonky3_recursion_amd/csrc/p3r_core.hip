@@ -299,11 +299,11 @@ void launch_col_r(p3r_ctx* ctx, std::vector<NttColJob>& jobs, uint32_t blocks) {
   hipLaunchKernelGGL((k_ntt_col<PP, LOG_R, MODE, LOG_TILE>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
   P3R_HIP(hipGetLastError());
 }
-template <class PP, int LOG_R>
+template <class PP, int LOG_R, int LOG_TILE>
 void launch_fwd_line_r(p3r_ctx* ctx, std::vector<NttLineJob>& jobs, uint32_t blocks) {
   const auto* d = static_cast<const NttLineJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(NttLineJob)));
   ProfScope ps(ctx, "ntt_forward_2");
-  hipLaunchKernelGGL((k_ntt_fwd_line<PP, LOG_R>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)jobs.size());
+  hipLaunchKernelGGL((k_ntt_fwd_line<PP, LOG_R, LOG_TILE>), dim3(blocks), dim3(1u << (LOG_TILE - 4)), 0, ctx->stream, d, (int)jobs.size());
   P3R_HIP(hipGetLastError());
 }
 constexpr int kNtt2MinLogR = 5, kNtt2MaxLogR = 12, kNtt2MaxLineLogR = 13;
@@ -334,18 +334,19 @@ void launch_fwd_line(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttLineJo
     auto& jobs = kv.second.first;
     if (kv.second.second >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "NTT launch of %llu tiles", (unsigned long long)kv.second.second);
     const uint32_t blocks = (uint32_t)kv.second.second;
-    switch (kv.first) {
-      case 5: launch_fwd_line_r<PP, 5>(ctx, jobs, blocks); break;
-      case 6: launch_fwd_line_r<PP, 6>(ctx, jobs, blocks); break;
-      case 7: launch_fwd_line_r<PP, 7>(ctx, jobs, blocks); break;
-      case 8: launch_fwd_line_r<PP, 8>(ctx, jobs, blocks); break;
-      case 9: launch_fwd_line_r<PP, 9>(ctx, jobs, blocks); break;
-      case 10: launch_fwd_line_r<PP, 10>(ctx, jobs, blocks); break;
-      case 11: launch_fwd_line_r<PP, 11>(ctx, jobs, blocks); break;
-      case 12: launch_fwd_line_r<PP, 12>(ctx, jobs, blocks); break;
-      case 13: launch_fwd_line_r<PP, 13>(ctx, jobs, blocks); break;
-      default: fail(P3R_EUNSUPPORTED, "forward NTT line pass of 2^%d cells", kv.first);
+    const int log_r = kv.first >> 1, small = kv.first & 1;
+#define P3R_LINE_CASE(R)                                            \
+  case R:                                                           \
+    if (small) launch_fwd_line_r<PP, R, 12>(ctx, jobs, blocks);     \
+    else launch_fwd_line_r<PP, R, 13>(ctx, jobs, blocks);           \
+    break;
+    switch (log_r) {
+      P3R_LINE_CASE(5) P3R_LINE_CASE(6) P3R_LINE_CASE(7) P3R_LINE_CASE(8) P3R_LINE_CASE(9) P3R_LINE_CASE(10)
+      P3R_LINE_CASE(11) P3R_LINE_CASE(12)
+      case 13: launch_fwd_line_r<PP, 13, 13>(ctx, jobs, blocks); break;
+      default: fail(P3R_EUNSUPPORTED, "forward NTT line pass of 2^%d cells", log_r);
     }
+#undef P3R_LINE_CASE
   }
 }
 
@@ -490,9 +491,14 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       NttLineJob lj{};
       lj.data = out->d;
       lj.tw = get_tw_sub<PP>(ctx, lb_f, 0);
-      auto& fl = fwd_line[lb_f];
+      // lines of up to 2^12 cells on 2^12-cell tiles (256 lanes, six workgroups per CU): measured 10 % faster
+      // than 2^13-cell tiles at the same waves per CU - the pass is VALU-bound (it does not slow down with
+      // a third fewer waves) and smaller workgroups wait less at their barriers.  P3R_NTT_LINE_LOG_TILE=13: tuning
+      static const int line_log_tile = getenv("P3R_NTT_LINE_LOG_TILE") ? atoi(getenv("P3R_NTT_LINE_LOG_TILE")) : 12;
+      const int small = (line_log_tile == 12 && lb_f <= 12) ? 1 : 0;
+      auto& fl = fwd_line[lb_f * 2 + small];
       lj.block0 = (uint32_t)fl.second;
-      fl.second += ((uint64_t)w * N * B) >> kNtt2LogTile;
+      fl.second += ((uint64_t)w * N * B) >> (kNtt2LogTile - small);
       fl.first.push_back(lj);
       continue;
     }

@@ -603,6 +603,9 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     ph.tree = std::make_unique<p3r_tree>();
     ph.tree->cap_height = (int)cfg.cap_height;
     ph.tree->log_max_h = log_cur - la;
+    if (ph.tree->cap_height > ph.tree->log_max_h)
+      fail(P3R_EINVAL, "cap_height %d exceeds the height of FRI commit phase %zu (2^%d rows)", ph.tree->cap_height,
+           phases.size(), ph.tree->log_max_h);
     ph.tree->layers.emplace_back(P2_DIGEST * rows);
     {
       std::vector<const uint32_t*> cols;

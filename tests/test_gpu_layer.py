@@ -94,6 +94,21 @@ def test_row_count_mismatch_is_reported(oracle):
     ctx.close()
 
 
+def test_cap_taller_than_a_fri_commit_phase_tree_is_refused(oracle):
+    """A FRI commit-phase tree of 4 leaves has no 8-digest cap: prover and oracle both refuse the
+    configuration (found by tools/prove_sweep.py; the prover used to read past the tree)."""
+    import plonky3_recursion_amd as p3r
+    kw = dict(log_blowup=2, max_log_arity=3, cap_height=3, log_final_poly_len=0, commit_pow_bits=0, query_pow_bits=2,
+              num_queries=2)
+    arrs, L, ctx, cache, traces = setup(oracle, "koala-bear", 5, kw, None)
+    with pytest.raises(RuntimeError, match="cap_height"):
+        L.prove()
+    with pytest.raises(p3r.P3rError, match="cap_height"):
+        cache.prover.prove_all_tables(traces, cache.circuit_prover_data)
+    cache.circuit_prover_data.free()
+    ctx.close()
+
+
 EDGE_SHAPES = [
     harness_lib.NO_POSEIDON2,
     harness_lib.NO_RECOMPOSE,
