@@ -83,7 +83,8 @@ typedef struct p3r_config {
    *   fri_log_arities  optional explicit FRI folding schedule (one log2 arity per commit phase, tallest
    *                    first); NULL selects the rule min(max_log_arity, distance to the final height,
    *                    distance to the next roll-in height).  Must reach every input height and the
-   *                    final height exactly.  Prover and verifier must be given the same schedule. */
+   *                    final height exactly, and no entry may exceed max_log_arity (the verifier's
+   *                    bound on a step's arity).  Prover and verifier must be given the same schedule. */
   uint32_t ext_choices;
   const uint8_t* fri_log_arities;
   uint32_t fri_log_arities_len;

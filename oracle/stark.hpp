@@ -361,7 +361,8 @@ void fri_commit_phase(const Poseidon2<FP>& p2, const StarkParams& sp, std::vecto
       const size_t ph = st.log_arities.size();
       int limit = log_cur - log_final;
       if (log_next >= 0 && log_next < log_cur) limit = std::min(limit, log_cur - log_next);
-      if (ph >= sp.fri_log_arities.size() || sp.fri_log_arities[ph] < 1 || sp.fri_log_arities[ph] > limit)
+      if (ph >= sp.fri_log_arities.size() || sp.fri_log_arities[ph] < 1 || sp.fri_log_arities[ph] > limit ||
+          sp.fri_log_arities[ph] > sp.max_log_arity)
         throw std::runtime_error("fri_log_arities does not fit the proof");
       la = sp.fri_log_arities[ph];
     }

@@ -1019,6 +1019,14 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
       for (int k = 0; k < 4; ++k)
         if (h.ext_of(op)[k] >= PP::P) fail(P3R_EINVAL, "constant of witness %u is not canonical", op.out);
 
+  // the execution schedule depends on the circuit alone (host vectors only, no device work): it is built
+  // on a second host thread while this one builds and commits the preprocessed columns
+  std::future<RunSchedule> sched_job = std::async(std::launch::async, [&h] { return build_schedule(h); });
+  struct JoinOnUnwind {  // an error below must not leave the worker reading `h` after it is gone
+    std::future<RunSchedule>& f;
+    ~JoinOnUnwind() { if (f.valid()) f.wait(); }
+  } join_on_unwind{sched_job};
+
   // CircuitProverData: preprocessed columns -> LDE + commitment (build_next_layer_prep)
   prof_stage(ctx, "prep_circuit_tables");
   CircuitTables T = circuit_tables<PP>(h);
@@ -1037,8 +1045,8 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   C->layer = layer_create<PP>(ctx, &ld, commit_out);
 
   // execution schedule
-  prof_stage(ctx, "prep_build_schedule");
-  C->sched = build_schedule(h);
+  prof_stage(ctx, "prep_build_schedule");  // = what is left of it when the commitment is done
+  C->sched = sched_job.get();
   prof_stage(ctx, "prep_upload_schedule");
   RunSchedule& S = C->sched;
   // constants travel in Montgomery form; hint output lists keep their flag bit

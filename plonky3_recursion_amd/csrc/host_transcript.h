@@ -131,7 +131,7 @@ inline int fri_log_arity(const std::vector<uint8_t>& schedule, size_t phase, int
   if (schedule.empty()) return std::max(std::min(max_log_arity, limit), 1);
   if (phase >= schedule.size()) return -1;
   const int la = schedule[phase];
-  return (la >= 1 && la <= limit) ? la : -1;
+  return (la >= 1 && la <= limit && la <= max_log_arity) ? la : -1;
 }
 
 inline int air_width_of(const AirParams& a, int p2_width) {

@@ -9,6 +9,7 @@
 #include "profile.h"
 
 #include <algorithm>
+#include <future>
 #include <numeric>
 #include <unordered_map>
 

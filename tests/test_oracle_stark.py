@@ -149,3 +149,18 @@ def test_absent_tables_and_dummy_lane_reduction(oracle, flags, kinds):
     bad[len(bad) // 2] ^= 1
     with pytest.raises(RuntimeError):
         L.verify(bytes(bad))
+
+
+@pytest.mark.parametrize("kw,msg", [
+    # a FRI commit-phase tree of 4 leaves has no 8-digest cap
+    (dict(log_blowup=2, max_log_arity=3, cap_height=3, log_final_poly_len=0, query_pow_bits=2, num_queries=2), "cap_height"),
+    # an explicit folding step above max_log_arity: the verifier's bound on a step's arity
+    (dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=1, num_queries=2,
+          fri_log_arities=[1, 1, 3, 1, 1, 1, 1, 1]), "fri_log_arities"),
+])
+def test_configurations_without_a_proof_are_refused(oracle, kw, msg):
+    """Found by tools/prove_sweep.py: these used to yield bytes the verifier then rejected."""
+    arrs = harness_lib.generate("koala-bear", 5, seed=11, horner_chain_len=8, sponge_chain_len=2, merkle_depth=3)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, layer_lib.params(**kw))
+    with pytest.raises(RuntimeError, match=msg):
+        L.prove()

@@ -3,7 +3,7 @@ cap heights, proof-of-work bits, folding schedules and the selectable protocol d
 combinations than tests/test_gpu_layer.py and tests/test_gpu_prove.py run.  For every draw the proof
 bytes of the HIP prover must equal the oracle's, and both verifiers must accept them.
 
-usage: python tools/prove_sweep.py [first_seed] [count] [max_log_h]     (needs a GPU; oracle = checker)
+usage: python tools/prove_sweep.py [first_seed] [count] [max_log_h] [min_log_h]     (needs a GPU; oracle = checker)
 """
 import random
 import sys
@@ -23,17 +23,26 @@ from plonky3_recursion_amd import prover as pv
 P3R_EXT_LOOKUP_UNPACKED = 1
 
 
-def draw(rng, max_log_h):
+def draw(rng, max_log_h, min_log_h=5):
     log_blowup = rng.choice([1, 1, 2, 2, 3])
     log_final = rng.randint(0, 3)
     # the smallest table is 2^(log_final + log_blowup + 1) rows; the layer's largest table 2^log_h
-    log_h = rng.randint(max(5, log_final + log_blowup + 2), max_log_h)
+    log_h = rng.randint(max(min_log_h, log_final + log_blowup + 2), max_log_h)
     max_log_arity = rng.randint(1, 3)
     kw = dict(log_blowup=log_blowup, max_log_arity=max_log_arity, cap_height=rng.randint(0, 3),
               log_final_poly_len=log_final, commit_pow_bits=rng.choice([0, 0, 2, 5]),
               query_pow_bits=rng.randint(0, 7), num_queries=rng.randint(1, 9))
     if rng.random() < 0.3:
         kw["ext_choices"] = P3R_EXT_LOOKUP_UNPACKED
+    r = rng.random()
+    if r < 0.08:
+        # an explicit folding schedule drawn blindly: one that does not fit the proof must be refused by both sides
+        kw["fri_log_arities"] = [rng.randint(1, 3) for _ in range(rng.randint(1, 8))]
+    elif r < 0.35:
+        kw["fri_log_arities"] = "fitting"   # replaced in one() by a random schedule that fits the table heights
+    if rng.random() < 0.25:
+        # serialisation order of the proof's fields: a permutation per struct (batch 5, fri 5, opened values 8)
+        kw["proof_layout"] = sum((rng.sample(range(n), n) for n in (5, 5, 8)), [])
     packing = dict(public_lanes=rng.randint(1, 3), alu_lanes=rng.randint(1, 4),
                    horner_packed_steps=rng.randint(2, 5), recompose_lanes=rng.randint(1, 2))
     gen = dict(horner_chain_len=rng.choice([0, 5, 20, 60]), sponge_chain_len=rng.randint(1, 6),
@@ -42,10 +51,34 @@ def draw(rng, max_log_h):
     return field, log_h, kw, packing, gen
 
 
-def one(oracle, seed, max_log_h):
+def fitting_schedule(rng, oracle, field, arrs, kw, packing):
+    """A random folding schedule that reaches every roll-in height and the final height (the rule of
+    include/p3r.h: each step at most max_log_arity, the distance to the next input height and to the end)."""
+    base = {k: v for k, v in kw.items() if k not in ("fri_log_arities", "proof_layout")}
+    L = layer_lib.OracleLayer(oracle, field, arrs, layer_lib.params(**base), packing=dict(packing))
+    lb = kw["log_blowup"]
+    # FRI inputs: the LDEs of the trace domains and of the quotient chunks all live at log2(h) + log_blowup
+    hs = sorted({int(np.log2(t["main"].shape[0])) + lb for t in L.tables()}, reverse=True)
+    log_final = kw["log_final_poly_len"] + lb
+    cur, out, nxt = hs[0], [], 1
+    while cur > log_final:
+        limit = cur - log_final
+        if nxt < len(hs):
+            limit = min(limit, cur - hs[nxt])
+        la = rng.randint(1, max(1, min(kw["max_log_arity"], limit)))
+        cur -= la
+        if nxt < len(hs) and hs[nxt] == cur:
+            nxt += 1
+        out.append(la)
+    return out
+
+
+def one(oracle, seed, max_log_h, min_log_h=5):
     rng = random.Random(seed)
-    field, log_h, kw, packing, gen = draw(rng, max_log_h)
+    field, log_h, kw, packing, gen = draw(rng, max_log_h, min_log_h)
     arrs = harness_lib.generate(field, log_h, seed=seed, **gen)
+    if kw.get("fri_log_arities") == "fitting":
+        kw["fri_log_arities"] = fitting_schedule(rng, oracle, field, arrs, kw, packing)
     prm = layer_lib.params(**kw)
     desc = f"seed {seed}: {field} 2^{log_h} {kw} {packing} {gen}"
     L = layer_lib.OracleLayer(oracle, field, arrs, prm, packing=dict(packing))
@@ -53,17 +86,19 @@ def one(oracle, seed, max_log_h):
         want_cap, want = L.prep_commit(), L.prove()
     except RuntimeError as e:       # a configuration the protocol has no proof for: the prover must refuse it too
         want_cap, want = None, str(e)
-    ctx = p3r.Context(field=field, **kw)
     tp = pv.TablePacking(**packing)
     tp.with_fri_params(prm.log_final_poly_len, prm.log_blowup)
+    ctx = None
     try:
+        ctx = p3r.Context(field=field, **kw)
         cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), pv.FriRecursionBackend(),
                                          pv.ProveNextLayerParams(table_packing=tp))
         cpd = cache.circuit_prover_data
         out = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs), cpd)
     except p3r.P3rError as e:
         assert want_cap is None, "prover refused (%s) what the oracle proves: %s" % (e, desc)
-        ctx.close()
+        if ctx is not None:
+            ctx.close()
         return desc + "  [refused by both: " + want + "]", 0
     assert want_cap is not None, "prover accepted what the oracle refuses (%s): %s" % (want, desc)
     assert np.array_equal(cpd.preprocessed_commitment, want_cap), "prep commitment: " + desc
@@ -79,10 +114,11 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     max_log_h = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+    min_log_h = int(sys.argv[4]) if len(sys.argv) > 4 else 5
     oracle = oracle_lib.Oracle()
     t0 = time.time()
     for seed in range(first, first + count):
-        desc, n = one(oracle, seed, max_log_h)
+        desc, n = one(oracle, seed, max_log_h, min_log_h)
         print(f"ok  {desc}  ({n} B)", flush=True)
     print(f"{count} draws agree with the oracle byte for byte ({time.time() - t0:.0f} s)", flush=True)
 
