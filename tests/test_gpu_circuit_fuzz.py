@@ -15,7 +15,7 @@ FRI = dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=2
 
 @pytest.mark.parametrize("field,seeds,n_ops", [("koala-bear", range(0, 24), 300), ("baby-bear", range(100, 108), 300),
                                                ("koala-bear", range(200, 204), 3000)])
-def test_random_circuits_run_and_preprocess_like_the_oracle(oracle, field, seeds, n_ops, prove=True):
+def test_random_circuits_run_and_preprocess_like_the_oracle(oracle, field, seeds, n_ops):
     import plonky3_recursion_amd as p3r
     ctx = p3r.Context(field=field, **FRI)
     tp = p3r.TablePacking(public_lanes=2, alu_lanes=2, recompose_lanes=2).with_fri_params(FRI["log_final_poly_len"],
@@ -28,9 +28,8 @@ def test_random_circuits_run_and_preprocess_like_the_oracle(oracle, field, seeds
         want = oc.workload_arrays()
         pc = p3r.PreparedCircuit(ctx, p3r.Circuit(circuit.witness_count, circuit.ops, circuit.ext, circuit.public_rows,
                                                   circuit.private_rows, circuit.rewrite.reshape(-1, 2)), tp)
-        ci = p3r.CircuitInputs(inputs.public_values.reshape(-1, 4), inputs.private_values.reshape(-1, 4),
-                               inputs.pd_op_ids, inputs.pd_siblings.reshape(-1, 8))
-        res = pc.run(ci)
+        res = pc.run(p3r.CircuitInputs(inputs.public_values.reshape(-1, 4), inputs.private_values.reshape(-1, 4),
+                                       inputs.pd_op_ids, inputs.pd_siblings.reshape(-1, 8)))
         for name, key in (("const_values", "const_values"), ("public_values", "public_values"), ("alu_values", "alu_values"),
                           ("recompose_values", "recompose_values"), ("p2_input_values", "p2_inputs"),
                           ("p2_mmcs_index_sum", "p2_mmcs_index_sum")):
@@ -39,8 +38,6 @@ def test_random_circuits_run_and_preprocess_like_the_oracle(oracle, field, seeds
         L = layer_lib.OracleLayer(oracle, field, want, layer_lib.params(**FRI),
                                   packing=dict(public_lanes=2, alu_lanes=2, recompose_lanes=2))
         assert np.array_equal(pc.circuit_prover_data.preprocessed_commitment, L.prep_commit()), seed
-        if prove:   # the one-call entry point (run + prove) against the oracle's proof of the oracle's traces
-            assert pc.prove(ci) == L.prove(), seed
         res.free()
         pc.free()
     ctx.close()

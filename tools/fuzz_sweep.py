@@ -1,6 +1,5 @@
 """One-off wide sweep of tests/test_gpu_circuit_fuzz.py's check (random circuits: device runner and
-host preprocessing against the oracle, then the proof bytes of run + prove) over many more seeds than
-the test suite runs.
+host preprocessing against the oracle) over many more seeds than the test suite runs.
 
 usage: python tools/fuzz_sweep.py [first_seed] [count] [n_ops]
 """
