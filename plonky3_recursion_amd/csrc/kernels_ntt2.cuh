@@ -123,25 +123,27 @@ __device__ __forceinline__ void ntt2_line_middle(uint32_t* tile, const uint32_t*
 struct NttLineJob {
   uint32_t* data;     // in place
   const uint32_t* tw; // w_R^i, i < R/2, Montgomery
-  uint32_t block0;    // first block of this job; a job owns cells/2^13 blocks
+  uint32_t block0;    // first block of this job; a job owns cells / tile blocks
+  uint32_t log_r;     // line length (read by the mixed-length launch only)
 };
 
-template <class PP, int LOG_R, int LOG_TILE = kNtt2LogTile>
-__global__ void __launch_bounds__(1 << (LOG_TILE - 4)) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
+// words of LDS a line tile needs (data with one pad word per 16 cells; the twiddle table is R/2 more)
+constexpr uint32_t ntt2_line_tile_words(int log_r, int log_tile) {
+  return ((1u << log_r) + (1u << (log_r - 4))) << (log_tile - log_r);
+}
+
+// the work of one workgroup: tile `local` of job `job` (tile / tws: LDS of at least
+// ntt2_line_tile_words(LOG_R, LOG_TILE) / R/2 words)
+template <class PP, int LOG_R, int LOG_TILE>
+__device__ __forceinline__ void ntt2_line_body(const NttLineJob& job, uint32_t local, uint32_t* tile, uint32_t* tws) {
   using F = Fp<PP>;
   static_assert(LOG_R >= 5 && LOG_R <= LOG_TILE && LOG_TILE <= 13, "line length");
   constexpr uint32_t R = 1u << LOG_R;
   constexpr uint32_t LANES = 1u << (LOG_TILE - 4);
-  constexpr int LOG_T = LOG_TILE - LOG_R;
-  constexpr uint32_t LINE = R + R / 16;
   constexpr int G = (LOG_R + 3) / 4;             // stage groups: 4, 4, ..., remainder last
   constexpr int ML_LAST = LOG_R - 4 * (G - 1);
-  __shared__ uint32_t tile[(LINE << LOG_T)];
-  __shared__ uint32_t tws[R / 2];  // (reading the table through L1 instead frees LDS for a fourth tile per CU but measured 25 % slower)
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
-  const gptr<uint32_t> data = as_global(jobs[jb].data) + ((size_t)(blockIdx.x - jobs[jb].block0) << LOG_TILE);
-  const gptr<const uint32_t> twg = as_global(jobs[jb].tw);
+  const gptr<uint32_t> data = as_global(job.data) + ((size_t)local << LOG_TILE);
+  const gptr<const uint32_t> twg = as_global(job.tw);
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < R / 2; i += LANES) tws[i] = twg[i];
   F x[16];
@@ -181,6 +183,38 @@ __global__ void __launch_bounds__(1 << (LOG_TILE - 4)) k_ntt_fwd_line(const NttL
   }
 }
 
+template <class PP, int LOG_R, int LOG_TILE = kNtt2LogTile>
+__global__ void __launch_bounds__(1 << (LOG_TILE - 4)) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
+  __shared__ uint32_t tile[ntt2_line_tile_words(LOG_R, LOG_TILE)];
+  __shared__ uint32_t tws[(1u << LOG_R) / 2];  // (reading the table through L1 instead frees LDS for another tile per CU but measured 25 % slower)
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  ntt2_line_body<PP, LOG_R, LOG_TILE>(jobs[jb], blockIdx.x - jobs[jb].block0, tile, tws);
+}
+
+// Lines of different lengths (2^5 .. 2^12 cells, 2^12-cell tiles) in ONE launch: the tables of a small
+// layer have four different heights, and at 2^14..2^16 rows a pass per height is a launch of a few
+// dozen workgroups that costs more to start than to run.  Used below kNtt2MixedMaxBlocks workgroups.
+template <class PP>
+__global__ void __launch_bounds__(256) k_ntt_fwd_line_mixed(const NttLineJob* __restrict__ jobs, int n_jobs) {
+  __shared__ uint32_t tile[ntt2_line_tile_words(12, 12)];  // the same for every line length
+  __shared__ uint32_t tws[(1u << 12) / 2];
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const NttLineJob& job = jobs[jb];
+  const uint32_t local = blockIdx.x - job.block0;
+  switch (job.log_r) {
+    case 5: ntt2_line_body<PP, 5, 12>(job, local, tile, tws); break;
+    case 6: ntt2_line_body<PP, 6, 12>(job, local, tile, tws); break;
+    case 7: ntt2_line_body<PP, 7, 12>(job, local, tile, tws); break;
+    case 8: ntt2_line_body<PP, 8, 12>(job, local, tile, tws); break;
+    case 9: ntt2_line_body<PP, 9, 12>(job, local, tile, tws); break;
+    case 10: ntt2_line_body<PP, 10, 12>(job, local, tile, tws); break;
+    case 11: ntt2_line_body<PP, 11, 12>(job, local, tile, tws); break;
+    default: ntt2_line_body<PP, 12, 12>(job, local, tile, tws); break;
+  }
+}
+
 // ------------------------------------------------------------------ column passes (strided dimension)
 // One column is viewed as [N1 rows][N2] (index n1*N2 + n2); a tile is [R = N1 rows][T = 2^13/R columns n2]
 // and the size-R transform runs along the rows (DIF: tile row r ends up holding output k1 = bitrev(r)).
@@ -201,6 +235,7 @@ struct NttColJob {
   const uint32_t* pre_b;   // [cosets][N2]: s_z^n2
   uint64_t in_col_stride, out_col_stride, out_coset_stride;
   int log_n2, log_cosets;
+  int log_r;        // sub-transform size (read by the mixed-size launch only)
   uint32_t scale;   // Montgomery (NTT2_INV2)
   uint32_t block0;  // tile fastest, then coset, then column - or, with xcd_map, see k_ntt_col
   uint32_t xcd_map; // the cosets of one tile on blocks b, b+8, b+16, ...: one XCD, one L2
@@ -209,8 +244,14 @@ struct NttColJob {
 // LOG_TILE: 13 (one 16-row item per lane and stage group) or 14 (two items per lane: twice the
 // columns per tile, i.e. twice the contiguous bytes per row - what the inverse passes of tall
 // matrices need, whose 2^10 / 2^11-row tiles are only 8 / 4 columns wide at 2^13 cells).
-template <class PP, int LOG_R, int MODE, int LOG_TILE = kNtt2LogTile>
-__global__ void __launch_bounds__(kNtt2Lanes, LOG_TILE == 13 ? 8 : 4) k_ntt_col(const NttColJob* __restrict__ jobs, int n_jobs) {
+constexpr uint32_t ntt2_col_tile_words(int log_r, int log_tile) {
+  return (1u << log_r) * ((1u << (log_tile - log_r)) + 1) + ((1u << log_r) >> 5) + 2;
+}
+
+// the work of one workgroup: tile `local` of job `a` (tile / tws: LDS of at least
+// ntt2_col_tile_words(LOG_R, LOG_TILE) / R/2 words)
+template <class PP, int LOG_R, int MODE, int LOG_TILE>
+__device__ __forceinline__ void ntt2_col_body(const NttColJob& a, uint32_t local, uint32_t* tile, uint32_t* tws) {
   using F = Fp<PP>;
   static_assert(LOG_R >= 5 && LOG_R <= 12, "sub-transform size");
   static_assert(LOG_TILE == 13 || LOG_TILE == 14, "tile size");
@@ -221,13 +262,7 @@ __global__ void __launch_bounds__(kNtt2Lanes, LOG_TILE == 13 ? 8 : 4) k_ntt_col(
   constexpr int ITEMS = 1 << (LOG_TILE - kNtt2LogTile);
   constexpr int G = (LOG_R + 3) / 4;
   constexpr int ML_LAST = LOG_R - 4 * (G - 1);
-  __shared__ uint32_t tile[R * (T + 1) + (R >> 5) + 2];
-  __shared__ uint32_t tws[R / 2];
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
-  const NttColJob& a = jobs[jb];
   const int log_gx = a.log_n2 - LOG_T;
-  const uint32_t local = blockIdx.x - a.block0;
   uint32_t bx, bz, by;
   if (a.xcd_map) {
     // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its
@@ -358,6 +393,38 @@ __global__ void __launch_bounds__(kNtt2Lanes, LOG_TILE == 13 ? 8 : 4) k_ntt_col(
       const F v = F::raw(tile[lds_addr(bit_reverse(k1, LOG_R), tt, T)]);
       dst[((size_t)col << LOG_R) + k1] = (v * tw).v;
     }
+  }
+}
+
+template <class PP, int LOG_R, int MODE, int LOG_TILE = kNtt2LogTile>
+__global__ void __launch_bounds__(kNtt2Lanes, LOG_TILE == 13 ? 8 : 4) k_ntt_col(const NttColJob* __restrict__ jobs, int n_jobs) {
+  __shared__ uint32_t tile[ntt2_col_tile_words(LOG_R, LOG_TILE)];
+  __shared__ uint32_t tws[(1u << LOG_R) / 2];
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  ntt2_col_body<PP, LOG_R, MODE, LOG_TILE>(jobs[jb], blockIdx.x - jobs[jb].block0, tile, tws);
+}
+
+// Column passes of different sub-transform sizes (2^13-cell tiles) in ONE launch, for small layers
+// (see k_ntt_fwd_line_mixed).
+constexpr uint32_t kNtt2MixedMaxBlocks = 2048;
+template <class PP, int MODE>
+__global__ void __launch_bounds__(kNtt2Lanes) k_ntt_col_mixed(const NttColJob* __restrict__ jobs, int n_jobs) {
+  __shared__ uint32_t tile[ntt2_col_tile_words(12, 13)];  // the largest: 2^12 rows x 2 columns
+  __shared__ uint32_t tws[(1u << 12) / 2];
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const NttColJob& a = jobs[jb];
+  const uint32_t local = blockIdx.x - a.block0;
+  switch (a.log_r) {
+    case 5: ntt2_col_body<PP, 5, MODE, 13>(a, local, tile, tws); break;
+    case 6: ntt2_col_body<PP, 6, MODE, 13>(a, local, tile, tws); break;
+    case 7: ntt2_col_body<PP, 7, MODE, 13>(a, local, tile, tws); break;
+    case 8: ntt2_col_body<PP, 8, MODE, 13>(a, local, tile, tws); break;
+    case 9: ntt2_col_body<PP, 9, MODE, 13>(a, local, tile, tws); break;
+    case 10: ntt2_col_body<PP, 10, MODE, 13>(a, local, tile, tws); break;
+    case 11: ntt2_col_body<PP, 11, MODE, 13>(a, local, tile, tws); break;
+    default: ntt2_col_body<PP, 12, MODE, 13>(a, local, tile, tws); break;
   }
 }
 

@@ -309,8 +309,42 @@ void launch_fwd_line_r(p3r_ctx* ctx, std::vector<NttLineJob>& jobs, uint32_t blo
 }
 constexpr int kNtt2MinLogR = 5, kNtt2MaxLogR = 12, kNtt2MaxLineLogR = 13;
 // jobs grouped by (sub-transform size, tile size): key = log_r * 2 + (log_tile - 13)
+// Several sub-transform sizes, all on 2^13-cell tiles and few workgroups in total (the tables of a small
+// layer): one launch of the mixed-size kernel instead of one per size.
+template <class JOB>
+bool merge_small_launches(std::map<int, std::pair<std::vector<JOB>, uint64_t>>& by_r, std::vector<JOB>& all, uint32_t& blocks) {
+  static const bool off = getenv("P3R_NTT_NO_MIXED") != nullptr;
+  if (off || by_r.size() < 2) return false;
+  uint64_t total = 0;
+  for (auto& kv : by_r) {
+    if (kv.first & 1) return false;  // a 2^14-cell column tile / a 2^13-cell line tile: own launch
+    total += kv.second.second;
+  }
+  if (total > kNtt2MixedMaxBlocks) return false;
+  uint32_t base = 0;
+  for (auto& kv : by_r) {
+    for (JOB j : kv.second.first) {
+      j.block0 += base;
+      all.push_back(j);
+    }
+    base += (uint32_t)kv.second.second;
+  }
+  blocks = base;
+  return true;
+}
 template <class PP, int MODE>
 void launch_col(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttColJob>, uint64_t>>& by_r) {
+  {
+    std::vector<NttColJob> all;
+    uint32_t blocks = 0;
+    if (merge_small_launches(by_r, all, blocks)) {
+      const auto* d = static_cast<const NttColJob*>(const_table(ctx, all.data(), all.size() * sizeof(NttColJob)));
+      ProfScope ps(ctx, MODE == NTT2_FWD ? "ntt_forward_1" : MODE == NTT2_INV1 ? "ntt_inverse_1" : "ntt_inverse_2");
+      hipLaunchKernelGGL((k_ntt_col_mixed<PP, MODE>), dim3(blocks), dim3(kNtt2Lanes), 0, ctx->stream, d, (int)all.size());
+      P3R_HIP(hipGetLastError());
+      return;
+    }
+  }
   for (auto& kv : by_r) {
     auto& jobs = kv.second.first;
     if (kv.second.second >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "NTT launch of %llu tiles", (unsigned long long)kv.second.second);
@@ -331,6 +365,24 @@ void launch_col(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttColJob>, ui
 }
 template <class PP>
 void launch_fwd_line(p3r_ctx* ctx, std::map<int, std::pair<std::vector<NttLineJob>, uint64_t>>& by_r) {
+  {
+    // the line map's low key bit is set for 2^12-cell tiles (the mixed kernel's), clear for 2^13-cell ones
+    std::map<int, std::pair<std::vector<NttLineJob>, uint64_t>> flipped;
+    bool all_small = true;
+    for (auto& kv : by_r) all_small = all_small && (kv.first & 1);
+    std::vector<NttLineJob> all;
+    uint32_t blocks = 0;
+    if (all_small) {
+      for (auto& kv : by_r) flipped[kv.first ^ 1] = kv.second;
+      if (merge_small_launches(flipped, all, blocks)) {
+        const auto* d = static_cast<const NttLineJob*>(const_table(ctx, all.data(), all.size() * sizeof(NttLineJob)));
+        ProfScope ps(ctx, "ntt_forward_2");
+        hipLaunchKernelGGL((k_ntt_fwd_line_mixed<PP>), dim3(blocks), dim3(256), 0, ctx->stream, d, (int)all.size());
+        P3R_HIP(hipGetLastError());
+        return;
+      }
+    }
+  }
   for (auto& kv : by_r) {
     auto& jobs = kv.second.first;
     if (kv.second.second >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "NTT launch of %llu tiles", (unsigned long long)kv.second.second);
@@ -418,7 +470,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       j1.tw = get_tw_sub<PP>(ctx, la, 1);
       j1.tw4_lo = tw4i.first; j1.tw4_hi = tw4i.second;
       j1.in_col_stride = N; j1.out_col_stride = N;
-      j1.log_n2 = lb;
+      j1.log_n2 = lb; j1.log_r = la;
       // 2^14-cell tiles (two items per lane) when the 2^13 tile would be narrower than 16 columns
       const int big1 = (kNtt2LogTile - la < 4 && lb >= kNtt2LogTile + 1 - la) ? 1 : 0;
       auto& q1 = inv1[la * 2 + big1];
@@ -429,7 +481,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       j2.in = tmp; j2.out = coef;
       j2.tw = get_tw_sub<PP>(ctx, lb, 1);
       j2.in_col_stride = N; j2.out_col_stride = N;
-      j2.log_n2 = la;
+      j2.log_n2 = la; j2.log_r = lb;
       j2.scale = inv_n;
       const int big2 = (kNtt2LogTile - lb < 4 && la >= kNtt2LogTile + 1 - lb) ? 1 : 0;
       auto& q2 = inv2[lb * 2 + big2];
@@ -476,7 +528,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       cj.tw4_lo = tw4f.first; cj.tw4_hi = tw4f.second;
       cj.pre_a = pre.first; cj.pre_b = pre.second;
       cj.in_col_stride = N; cj.out_col_stride = N * B; cj.out_coset_stride = N;
-      cj.log_n2 = lb_f; cj.log_cosets = added_bits;
+      cj.log_n2 = lb_f; cj.log_cosets = added_bits; cj.log_r = la_f;
       // 2^14-cell tiles when the 2^13 tile would be narrower than 32 columns (measured: slower at 2^8 rows
       // x 32 columns, faster from 2^9 rows on)
       const int bigf = (kNtt2LogTile - la_f < 5 && lb_f >= kNtt2LogTile + 1 - la_f) ? 1 : 0;
@@ -492,6 +544,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       NttLineJob lj{};
       lj.data = out->d;
       lj.tw = get_tw_sub<PP>(ctx, lb_f, 0);
+      lj.log_r = (uint32_t)lb_f;
       // lines of up to 2^12 cells on 2^12-cell tiles (256 lanes, six workgroups per CU): measured 10 % faster
       // than 2^13-cell tiles at the same waves per CU - the pass is VALU-bound (it does not slow down with
       // a third fewer waves) and smaller workgroups wait less at their barriers.  P3R_NTT_LINE_LOG_TILE=13: tuning
