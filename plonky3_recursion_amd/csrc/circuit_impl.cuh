@@ -723,6 +723,8 @@ __device__ __forceinline__ void run_p2_segment(const RunArgs& A, RunSchedule::P2
   uint32_t* __restrict__ w = A.w;
   uint32_t* err = A.err;
   if (!live) seg.n = 0;
+  const CoopRc<PP> rcs = coop_load_rc<PP>(A.rc, j);
+  const F diag_j = F::raw(A.diag[j]);
   F carried = F::zero();  // output of the previous row of this segment
   RunP2 next = seg.n ? A.p2[seg.first] : RunP2{};
   for (uint32_t k = 0; k < seg.n; ++k) {
@@ -764,7 +766,7 @@ __device__ __forceinline__ void run_p2_segment(const RunArgs& A, RunSchedule::P2
       }
       A.p2_seed[q.row] = seed;
     }
-    s = coop_permute<PP>(s, j, F::raw(A.diag[j]), A.rc);
+    s = coop_permute<PP>(s, j, diag_j, rcs);
     carried = s;
     A.p2_out[(size_t)q.row * 16 + j] = s.v;
     const uint32_t n_out = (q.flags >> 8) & 7;

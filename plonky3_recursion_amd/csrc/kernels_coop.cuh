@@ -47,30 +47,51 @@ __device__ __forceinline__ uint32_t coop_bcast0(uint32_t x0) {
   return q | dpp<DPP_ROW_ROR8>(q);
 }
 
-// `s`: this lane's state element (lane & 15 = element index).  `diag`: Montgomery internal
-// diagonal of this lane.  Round constants `rc` as in poseidon2.h.
+// The round constants one lane of a row needs, loaded ONCE per kernel: its own element of the eight
+// full rounds (vector registers) and the partial rounds' single constants (uniform: scalar registers).
+// Loaded inside the round loops they were a dependent memory read per round - 28 cache latencies per
+// permutation, most of the time of a latency-bound Merkle level.
 template <class PP>
-__device__ __forceinline__ Fp<PP> coop_permute(Fp<PP> s, int elem, Fp<PP> diag, const uint32_t* __restrict__ rc) {
+struct CoopRc {
+  uint32_t full[2 * P2_HALF_FULL];
+  uint32_t part[PP::PARTIAL_ROUNDS];
+};
+template <class PP>
+__device__ __forceinline__ CoopRc<PP> coop_load_rc(const uint32_t* __restrict__ rc, int elem) {
+  CoopRc<PP> c;
+#pragma unroll
+  for (int r = 0; r < P2_HALF_FULL; ++r) c.full[r] = rc[r * P2_WIDTH + elem];
+#pragma unroll
+  for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) c.part[r] = rc[P2_HALF_FULL * P2_WIDTH + r];
+#pragma unroll
+  for (int r = 0; r < P2_HALF_FULL; ++r)
+    c.full[P2_HALF_FULL + r] = rc[P2_HALF_FULL * P2_WIDTH + PP::PARTIAL_ROUNDS + r * P2_WIDTH + elem];
+  return c;
+}
+
+// `s`: this lane's state element (lane & 15 = element index).  `diag`: Montgomery internal
+// diagonal of this lane.  Round constants as loaded by coop_load_rc (layout of poseidon2.h).
+template <class PP>
+__device__ __forceinline__ Fp<PP> coop_permute(Fp<PP> s, int elem, Fp<PP> diag, const CoopRc<PP>& rc) {
   using F = Fp<PP>;
   s = coop_external(s);
-  int k = 0;
+#pragma unroll
   for (int r = 0; r < P2_HALF_FULL; ++r) {
-    s = p2_sbox<PP>(s + F::raw(rc[k + elem]));
-    k += P2_WIDTH;
+    s = p2_sbox<PP>(s + F::raw(rc.full[r]));
     s = coop_external(s);
   }
+#pragma unroll
   for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
     // sum(s') = S-box output of element 0 + the sum of the other fifteen: the latter and the
     // products d_i * s_i do not wait for the S-box, only its broadcast and two additions do
     const F rest = coop_row_sum(elem == 0 ? F::zero() : s);
-    const F sb = p2_sbox<PP>(s + F::raw(rc[k + r]));
+    const F sb = p2_sbox<PP>(s + F::raw(rc.part[r]));
     const F sum = rest + F::raw(coop_bcast0(elem == 0 ? sb.v : 0u));
     s = (elem == 0 ? sb : s) * diag + sum;
   }
-  k += PP::PARTIAL_ROUNDS;
+#pragma unroll
   for (int r = 0; r < P2_HALF_FULL; ++r) {
-    s = p2_sbox<PP>(s + F::raw(rc[k + elem]));
-    k += P2_WIDTH;
+    s = p2_sbox<PP>(s + F::raw(rc.full[P2_HALF_FULL + r]));
     s = coop_external(s);
   }
   return s;
@@ -92,10 +113,11 @@ k_mmcs_hash_rows_strided_coop(const uint32_t* const* __restrict__ cols, int wtot
   const int e = (int)(gid & 15);
   const bool live = row < h;  // whole 16-lane rows are live or not
   const F d = F::raw(diag[e]);
+  const CoopRc<PP> rcs = coop_load_rc<PP>(rc, e);
   F s = F::zero();
   for (int g = 0; g < wtot; g += P2_RATE) {
     if (live && e < P2_RATE && g + e < wtot) s = F::raw(cols[g + e][row * stride]);
-    s = coop_permute<PP>(s, e, d, rc);
+    s = coop_permute<PP>(s, e, d, rcs);
   }
   if (live && e < P2_DIGEST) dig[(size_t)e * h + row] = s.v;
 }
@@ -133,7 +155,7 @@ struct SubtreeArgs {
 template <class PP>
 __device__ __forceinline__ void fri_transcript_step(int j, uint32_t root_word, uint32_t* __restrict__ state,
                                                     uint32_t* __restrict__ beta_out, uint32_t* __restrict__ cap_out,
-                                                    const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+                                                    const CoopRc<PP>& rc, const uint32_t* __restrict__ diag) {
   using F = Fp<PP>;
   F s = j < P2_RATE ? F::raw(root_word) : F::raw(state[j]);
   if (j < P2_RATE) cap_out[j] = s.v;
@@ -150,6 +172,7 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
   const int elem = threadIdx.x & 15;
   const uint32_t group = threadIdx.x >> 4, k = elem & 7;
   const F d = F::raw(diag[elem]);
+  const CoopRc<PP> rcs = coop_load_rc<PP>(rc, elem);
   uint32_t n = a.n_in < (uint32_t)kSubtreeNodes ? a.n_in : (uint32_t)kSubtreeNodes;  // local nodes
   uint32_t n_glob = a.n_in, first = blockIdx.x * n;  // layer size, this workgroup's first node
 #pragma unroll
@@ -162,10 +185,10 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
       for (uint32_t node = group; node < nn; node += kSubtreeBlock / 16) {
         const uint32_t child = 2 * node + (elem >> 3);
         F s = F::raw(l == 0 ? a.in[(size_t)k * n_glob + first + child] : cur[k * n + child]);
-        s = coop_permute<PP>(s, elem, d, rc);
+        s = coop_permute<PP>(s, elem, d, rcs);
         if (a.inj[l]) {
           if (elem >= P2_DIGEST) s = F::raw(a.inj[l][(size_t)k * nn_glob + first_out + node]);
-          s = coop_permute<PP>(s, elem, d, rc);
+          s = coop_permute<PP>(s, elem, d, rcs);
         }
         if (elem < P2_DIGEST) {
           nxt[k * nn + node] = s.v;
@@ -182,7 +205,7 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
     // the root is the single node of the last level: word k at buf[(n_levels - 1) & 1][k]
     const uint32_t* root = buf[(a.n_levels - 1) & 1];
     fri_transcript_step<PP>((int)threadIdx.x, threadIdx.x < P2_RATE ? root[threadIdx.x] : 0u, a.t_state, a.t_beta,
-                            a.t_cap, rc, diag);
+                            a.t_cap, rcs, diag);
   }
 }
 
@@ -195,7 +218,7 @@ k_fri_transcript_step(const uint32_t* __restrict__ root /* [8] */, uint32_t* __r
                       const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
   const int j = threadIdx.x;
   if (j >= P2_WIDTH) return;  // one 16-lane row
-  fri_transcript_step<PP>(j, j < P2_RATE ? root[j] : 0u, state, beta_out, cap_out, rc, diag);
+  fri_transcript_step<PP>(j, j < P2_RATE ? root[j] : 0u, state, beta_out, cap_out, coop_load_rc<PP>(rc, j), diag);
 }
 
 }  // namespace p3r
