@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -225,6 +226,67 @@ struct HostLanding {
   }
 };
 
+// Small device->host results that the host transcript waits for (a commitment cap, the final
+// polynomial, a proof-of-work witness): a one-workgroup kernel on the ctx stream stores the words
+// straight into coherent pinned host memory and then a sequence number; the host polls that word
+// instead of going through a copy engine and hipStreamSynchronize (29 us per fetch measured with
+// tools/microbench/d2h_latency.py - more than the Merkle levels of a small layer's commitment).
+// The stream is NOT synchronised when post() returns: only this kernel's stores are known to be done.
+__global__ void __launch_bounds__(256) k_post_small(uint32_t* host_dst, const uint32_t* __restrict__ src, uint32_t n,
+                                                    uint32_t* flag, uint32_t seq) {
+  for (uint32_t i = threadIdx.x; i < n; i += 256) host_dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct HostPost {
+  static constexpr size_t kWords = 16384;  // 64 KB of results + the sequence word behind them
+  uint32_t* host = nullptr;
+  uint32_t* dev = nullptr;
+  uint32_t seq = 0;
+  HostPost() = default;
+  HostPost(const HostPost&) = delete;
+  HostPost& operator=(const HostPost&) = delete;
+  ~HostPost() {
+    if (host) (void)hipHostFree(host);
+  }
+  static bool enabled() {
+    static const bool off = getenv("P3R_NO_POLLED_FETCH") != nullptr;
+    return !off;
+  }
+  // `words` <= kWords cells from `src` (device) -> *out (valid until the next post)
+  hipError_t post(hipStream_t s, const uint32_t* src, size_t words, const uint32_t** out) {
+    if (!host) {
+      hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&host), (kWords + 16) * 4,
+                                   hipHostMallocMapped | hipHostMallocCoherent);
+      if (e != hipSuccess) return e;
+      e = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0);
+      if (e != hipSuccess) return e;
+      host[kWords] = 0;
+    }
+    *out = host;
+    ++seq;
+    hipLaunchKernelGGL(k_post_small, dim3(1), dim3(256), 0, s, dev, src, (uint32_t)words, dev + kWords, seq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    volatile uint32_t* flag = host + kWords;
+    for (uint64_t spins = 0;; ++spins) {
+      if (*flag == seq) break;
+      if ((spins & 0xFFF) == 0xFFF) {
+        // a fault upstream would leave the flag unset for ever: ask the stream now and then
+        e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) {
+          if (e != hipSuccess) return e;
+          if (*flag == seq) break;
+          return hipStreamSynchronize(s);  // idle stream without the store: cannot happen; do not spin on it
+        }
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return hipSuccess;
+  }
+};
+
 // RAII device buffer of u32 cells (pooled).
 struct DevBuf {
   uint32_t* p = nullptr;
@@ -321,6 +383,7 @@ struct p3r_ctx {
   std::string err;
   p3r::HostStage stage;  // small uploads that do not wait (see HostStage)
   p3r::HostLanding landing;  // device->host results read in place (see HostLanding)
+  p3r::HostPost post;        // small device->host results the host polls for (see HostPost)
   // Small read-only device tables (column pointers and job lists of the row-hash kernels),
   // keyed by their content: the pool hands the same addresses to the same allocation sequence,
   // so after the first proof of a shape every table is already on the device.
@@ -331,3 +394,17 @@ struct p3r_ctx {
   std::map<std::pair<int, int>, std::pair<p3r::DevBuf, p3r::DevBuf>> tw4;  // (log_n, inverse) -> (lo, hi)
   std::map<std::tuple<int, int, uint32_t>, std::pair<p3r::DevBuf, p3r::DevBuf>> pre;  // (log_n, added_bits, shift)
 };
+
+// `words` cells from device memory into `dst` (host), for results the host transcript waits on.
+inline hipError_t fetch_small(p3r_ctx* ctx, const uint32_t* src, size_t words, uint32_t* dst) {
+  if (words == 0) return hipSuccess;
+  if (p3r::HostPost::enabled() && words <= p3r::HostPost::kWords) {
+    const uint32_t* got = nullptr;
+    hipError_t e = ctx->post.post(ctx->stream, src, words, &got);
+    if (e != hipSuccess) return e;
+    std::memcpy(dst, got, words * 4);
+    return hipSuccess;
+  }
+  return p3r::copy_sync(ctx->stream, dst, src, words * 4, hipMemcpyDeviceToHost);
+}
+

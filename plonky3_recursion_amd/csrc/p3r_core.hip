@@ -737,9 +737,7 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   }
   // cap: digest-major canonical
   std::vector<uint32_t> soa(P2_DIGEST * cap_n);
-  P3R_HIP(hipMemcpyAsync(soa.data(), tree->layers.back().p, soa.size() * 4, hipMemcpyDeviceToHost,
-                         ctx->stream));
-  P3R_HIP(hipStreamSynchronize(ctx->stream));
+  P3R_HIP(fetch_small(ctx, tree->layers.back().p, soa.size(), soa.data()));
   for (size_t j = 0; j < cap_n; ++j)
     for (int k = 0; k < P2_DIGEST; ++k)
       cap_out[j * P2_DIGEST + k] = F::raw(soa[(size_t)k * cap_n + j]).to_canonical();

@@ -33,8 +33,7 @@ E4 to_e4(const Fp4<PP>& e) { return e4_store<PP>(e); }
 template <class PP>
 std::vector<Fp4<PP>> download_ef(p3r_ctx* ctx, const uint32_t* dev, size_t count) {
   std::vector<uint32_t> raw(count * 4);
-  P3R_HIP(hipMemcpyAsync(raw.data(), dev, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-  P3R_HIP(hipStreamSynchronize(ctx->stream));
+  P3R_HIP(fetch_small(ctx, dev, raw.size(), raw.data()));
   std::vector<Fp4<PP>> out(count);
   for (size_t i = 0; i < count; ++i)
     for (int k = 0; k < 4; ++k) out[i].c[k] = Fp<PP>::raw(raw[i * 4 + k]);
@@ -65,8 +64,7 @@ template <class PP>
 std::vector<uint32_t> download_cap_mont(p3r_ctx* ctx, const p3r_tree* tree) {
   const size_t cap_n = size_t(1) << tree->cap_height;
   std::vector<uint32_t> soa(P2_DIGEST * cap_n), cap(P2_DIGEST * cap_n);
-  P3R_HIP(hipMemcpyAsync(soa.data(), tree->layers.back().p, soa.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-  P3R_HIP(hipStreamSynchronize(ctx->stream));
+  P3R_HIP(fetch_small(ctx, tree->layers.back().p, soa.size(), soa.data()));
   for (size_t j = 0; j < cap_n; ++j)
     for (int k = 0; k < P2_DIGEST; ++k) cap[j * P2_DIGEST + k] = soa[(size_t)k * cap_n + j];
   return cap;
@@ -111,7 +109,7 @@ Fp<PP> grind_witness(p3r_ctx* ctx, HostChallenger<PP>& ch, int bits) {
     g.base = (uint32_t)base;
     ProfScope ps(ctx, "grind");
     hipLaunchKernelGGL(k_grind<PP>, dim3(batch / kBlock), dim3(kBlock), 0, ctx->stream, g);
-    P3R_HIP(copy_sync(ctx->stream, &found, res.p, 4, hipMemcpyDeviceToHost));
+    P3R_HIP(fetch_small(ctx, res.p, 1, &found));
   }
   if (found == 0xFFFFFFFFu) fail(P3R_EINVAL, "proof-of-work search found no witness");
   const F w = F::from_canonical(found);
@@ -672,10 +670,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   {
     const size_t m = size_t(1) << log_cur;
     std::vector<uint32_t> raw(4 * m), phase_words(d_phase.n);
-    P3R_HIP(hipMemcpyAsync(raw.data(), folded.p, raw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (device_transcript && !phases.empty())
-      P3R_HIP(hipMemcpyAsync(phase_words.data(), d_phase.p, phase_words.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    P3R_HIP(hipStreamSynchronize(ctx->stream));
+    if (device_transcript && !phases.empty()) P3R_HIP(fetch_small(ctx, d_phase.p, phase_words.size(), phase_words.data()));
+    P3R_HIP(fetch_small(ctx, folded.p, raw.size(), raw.data()));
     const uint32_t* betas = phase_words.data();
     const uint32_t* caps = betas + 4 * kMaxPhases;
     if (device_transcript) {
