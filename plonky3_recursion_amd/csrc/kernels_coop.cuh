@@ -134,8 +134,10 @@ constexpr int kSubtreeNodes = 256;
 constexpr int kSubtreeLevels = 8;
 struct SubtreeArgs {
   const uint32_t* in;  // [8][n_in]
-  uint32_t n_in;       // power of two; a multiple of kSubtreeNodes, or smaller (one workgroup)
-  int n_levels;        // <= kSubtreeLevels, <= log2(min(n_in, kSubtreeNodes))
+  uint32_t n_in;       // power of two; a multiple of `local`, or smaller (one workgroup)
+  uint32_t local;      // digests of the input layer per workgroup (power of two <= kSubtreeNodes);
+                       // launched with 8 * local lanes (at least a wave): one 16-lane row per level-0 node
+  int n_levels;        // <= kSubtreeLevels, <= log2(min(n_in, local))
   uint32_t* out[kSubtreeLevels];        // out[l]: [8][n_in >> (l+1)]
   const uint32_t* inj[kSubtreeLevels];  // inj[l]: [8][n_in >> (l+1)] or null
   // Optional (FRI commit phase, single-workgroup launch that ends at the root): the transcript step
@@ -173,7 +175,7 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
   const uint32_t group = threadIdx.x >> 4, k = elem & 7;
   const F d = F::raw(diag[elem]);
   const CoopRc<PP> rcs = coop_load_rc<PP>(rc, elem);
-  uint32_t n = a.n_in < (uint32_t)kSubtreeNodes ? a.n_in : (uint32_t)kSubtreeNodes;  // local nodes
+  uint32_t n = a.n_in < a.local ? a.n_in : a.local;  // local nodes
   uint32_t n_glob = a.n_in, first = blockIdx.x * n;  // layer size, this workgroup's first node
 #pragma unroll
   for (int l = 0; l < kSubtreeLevels; ++l) {
@@ -182,7 +184,7 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
       const uint32_t* cur = buf[(l + 1) & 1];
       uint32_t* nxt = buf[l & 1];
       // a 16-lane row works on one node: lanes 0..7 hold the left child, 8..15 the right one
-      for (uint32_t node = group; node < nn; node += kSubtreeBlock / 16) {
+      for (uint32_t node = group; node < nn; node += blockDim.x / 16) {
         const uint32_t child = 2 * node + (elem >> 3);
         F s = F::raw(l == 0 ? a.in[(size_t)k * n_glob + first + child] : cur[k * n + child]);
         s = coop_permute<PP>(s, elem, d, rcs);

@@ -624,7 +624,25 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
 
 // One 2-to-1 layer, one permutation per lane: for layers large enough to fill the chip.  Smaller
 // ones are latency-bound and go through mmcs_subtree below (16 lanes per node, 8 levels per launch).
-constexpr size_t kCoopMaxNodes = 32768;
+// A lane-cooperative permutation costs 16 lanes x ~1.2 k instructions against ~3.9 k FP64 operations of one
+// lane: it is the faster way through a level only while the level is latency-bound, i.e. up to about
+// one 16-lane row per SIMD and pass (4096 nodes a pass on 256 CUs; a pass is ~2.7 us, a launch of the
+// one-permutation-per-lane kernel ~11 us whatever its size).  P3R_COOP_MAX_NODES / _LEAF_ROWS: tuning.
+inline size_t coop_max_nodes() {
+  static const size_t v = getenv("P3R_COOP_MAX_NODES") ? (size_t)atol(getenv("P3R_COOP_MAX_NODES")) : 16384;
+  return v;
+}
+inline size_t coop_max_leaf_rows() {
+  static const size_t v = getenv("P3R_COOP_MAX_LEAF_ROWS") ? (size_t)atol(getenv("P3R_COOP_MAX_LEAF_ROWS")) : 8192;
+  return v;
+}
+// Digests per workgroup of a k_mmcs_subtree launch: with 32, level 0 is one pass of 16 rows - one wave
+// per SIMD - and the five levels of the launch are all latency-bound; with 256 (eight levels per launch)
+// levels 0 and 1 queued 8 and 4 waves per SIMD on the few CUs that had a workgroup.
+inline size_t subtree_nodes() {
+  static const size_t v = getenv("P3R_SUBTREE_NODES") ? (size_t)atol(getenv("P3R_SUBTREE_NODES")) : 32;
+  return std::min<size_t>(std::max<size_t>(v, 2), kSubtreeNodes);
+}
 template <class PP>
 void launch_compress(p3r_ctx* ctx, const uint32_t* prev, const uint32_t* inj, uint32_t* out, size_t n) {
   ProfScope ps(ctx, "mmcs_compress");
@@ -647,11 +665,12 @@ template <class PP>
 size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_t, DevBuf>* inject,
                     TranscriptStep* step = nullptr) {
   const size_t cap_n = size_t(1) << tree->cap_height;
-  if (n / 2 > kCoopMaxNodes || n <= cap_n) return n;
+  if (n / 2 > coop_max_nodes() || n <= cap_n) return n;
   SubtreeArgs a{};
   a.in = tree->layers.back().p;
   a.n_in = (uint32_t)n;
-  const size_t local = std::min<size_t>(n, kSubtreeNodes);
+  const size_t local = std::min<size_t>(n, subtree_nodes());
+  a.local = (uint32_t)local;
   size_t nn = n, shrink = local;
   while (shrink > 1 && nn > cap_n && a.n_levels < kSubtreeLevels) {
     nn /= 2;
@@ -671,7 +690,8 @@ size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_
     step->done = true;
   }
   ProfScope ps(ctx, "mmcs_compress");
-  hipLaunchKernelGGL(k_mmcs_subtree<PP>, dim3((unsigned)(n / local)), dim3(kSubtreeBlock), 0, ctx->stream, a,
+  const unsigned lanes = (unsigned)std::min<size_t>(std::max<size_t>(local * 8, 64), kSubtreeBlock);
+  hipLaunchKernelGGL(k_mmcs_subtree<PP>, dim3((unsigned)(n / local)), dim3(lanes), 0, ctx->stream, a,
                      ctx->rc.p, ctx->p2_diag.p);
   P3R_HIP(hipGetLastError());
   return nn;

@@ -612,7 +612,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       const uint32_t* const* dcols = col_table(ctx, cols);
       {
         ProfScope ps(ctx, "mmcs_hash_rows_strided");
-        if (rows <= kCoopMaxNodes)  // latency-bound: sixteen lanes per row
+        if (rows <= coop_max_leaf_rows())  // latency-bound: sixteen lanes per row
           hipLaunchKernelGGL(k_mmcs_hash_rows_strided_coop<PP>, dim3(blocks_for(rows * 16)), dim3(kBlock), 0,
                              ctx->stream, dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p, ctx->rc.p,
                              ctx->p2_diag.p);
