@@ -14,6 +14,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -273,6 +274,7 @@ struct HostPost {
     for (uint64_t spins = 0;; ++spins) {
       if (*flag == seq) break;
       if ((spins & 0xFFF) == 0xFFF) {
+        if (spins > (uint64_t(1) << 18)) std::this_thread::yield();  // a long wait (big kernels ahead): give the core away
         // a fault upstream would leave the flag unset for ever: ask the stream now and then
         e = hipStreamQuery(s);
         if (e != hipErrorNotReady) {

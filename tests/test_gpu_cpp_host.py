@@ -43,3 +43,25 @@ def test_cpp_host_matches_python_binding(oracle, tmp_path, field, log_h):
     L.verify(got, prep_cap=pc.circuit_prover_data.preprocessed_commitment)
     pc.free()
     ctx.close()
+
+
+def test_fallback_paths_give_the_same_proof(tmp_path):
+    """The tuning switches of the library are read once per process: the paths they select (copy-engine
+    fetches instead of polled ones, one NTT launch per sub-transform size, 256-digest Merkle workgroups,
+    2^13-cell line tiles, the pre-round-2 NTT kernels) must stay alive and byte-identical."""
+    if not os.path.exists(EXE):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True)
+
+    def proof(name, **env):
+        out_file = str(tmp_path / (name + ".bin"))
+        r = subprocess.run([EXE, "koala-bear", "13", out_file, "1"], capture_output=True, text=True, timeout=300,
+                           env={**os.environ, **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+        return open(out_file, "rb").read()
+
+    want = proof("default")
+    assert proof("unpolled", P3R_NO_POLLED_FETCH="1") == want
+    assert proof("unmixed", P3R_NTT_NO_MIXED="1", P3R_NTT_LINE_LOG_TILE="13") == want
+    assert proof("wide_subtrees", P3R_SUBTREE_NODES="256", P3R_COOP_MAX_NODES="32768",
+                 P3R_COOP_MAX_LEAF_ROWS="32768") == want
+    assert proof("old_ntt", P3R_NTT_OLD="1") == want
