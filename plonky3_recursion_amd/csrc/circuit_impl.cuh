@@ -193,13 +193,48 @@ CircuitTables circuit_tables(const HostCircuit& c) {
       if (next_ns) reads[e[4]]++;
     }
   }
-  // pass 2: signed multiplicities
+  // pass 2: signed multiplicities.  The tables are independent of each other once the read counts are
+  // known: the Poseidon2 / Recompose / Const / Public rows are filled on a second host thread while this
+  // one fills the ALU rows (the largest table).
   auto mult = [&](uint32_t w) { return reads[w] % P; };
   T.counts.n_const = consts.size();
-  for (auto* op : consts) { T.const_prep.push_back(mult(op->out)); T.const_prep.push_back(scaled(op->out)); }
   T.counts.n_public = publics.size();
-  for (auto* op : publics) { T.public_prep.push_back(mult(op->out)); T.public_prep.push_back(scaled(op->out)); }
   T.counts.n_alu = std::max<size_t>(alus.size(), 1);
+  T.counts.n_p2 = p2s.size();
+  T.counts.n_recompose = recs.size();
+  auto small_tables = std::async(std::launch::async, [&] {
+    T.const_prep.reserve(2 * consts.size());
+    for (auto* op : consts) { T.const_prep.push_back(mult(op->out)); T.const_prep.push_back(scaled(op->out)); }
+    T.public_prep.reserve(2 * publics.size());
+    for (auto* op : publics) { T.public_prep.push_back(mult(op->out)); T.public_prep.push_back(scaled(op->out)); }
+    const size_t np = p2s.size();
+    T.p2_new_start.resize(np); T.p2_merkle_path.resize(np); T.p2_mmcs_ctl_enabled.resize(np);
+    T.p2_in_ctl.resize(4 * np); T.p2_input_indices.resize(4 * np);
+    T.p2_output_indices.resize(2 * np); T.p2_out_ctl.resize(2 * np); T.p2_mmcs_index_sum_idx.resize(np);
+    for (size_t r = 0; r < np; ++r) {
+      const p3r_op* op = p2s[r];
+      const uint32_t* e = c.ext_of(*op);
+      T.p2_new_start[r] = op->aux & 1;
+      T.p2_merkle_path[r] = (op->aux >> 1) & 1;
+      T.p2_mmcs_ctl_enabled[r] = e[4] != kNoW;
+      for (int l = 0; l < 4; ++l) {
+        T.p2_in_ctl[4 * r + l] = e[l] != kNoW;
+        T.p2_input_indices[4 * r + l] = e[l] != kNoW ? e[l] : 0;
+      }
+      for (int l = 0; l < 2; ++l) {
+        const uint32_t w = e[7 + l];
+        T.p2_output_indices[2 * r + l] = w != kNoW ? w : 0;
+        T.p2_out_ctl[2 * r + l] = w == kNoW ? 0 : dup_p2[w] ? NEG1 : mult(w);
+      }
+      T.p2_mmcs_index_sum_idx[r] = e[4] != kNoW ? e[4] : 0;
+    }
+    T.recompose_prep.reserve(2 * recs.size());
+    for (auto* op : recs) {
+      T.recompose_prep.push_back(scaled(op->out));
+      T.recompose_prep.push_back(dup_rec[op->out] ? NEG1 : mult(op->out));
+    }
+  });
+  T.alu_prep13.resize(13 * alus.size());
   for (size_t i = 0; i < alus.size(); ++i) {
     const p3r_op& op = *alus[i];
     const AluRoles& r = roles[i];
@@ -211,31 +246,10 @@ CircuitTables circuit_tables(const HostCircuit& c) {
                               scaled(op.a), scaled(op.b), scaled(c_w), scaled(op.out),
                               r.b_creator ? mult(op.b) : NEG1, r.out_creator ? mult(op.out) : NEG1,
                               reader_col(r.a_state, op.a), reader_col(r.c_state, c_w)};
-    T.alu_prep13.insert(T.alu_prep13.end(), row, row + 13);
+    std::copy(row, row + 13, T.alu_prep13.begin() + 13 * i);
   }
   if (alus.empty()) T.alu_prep13.assign(13, 0);  // the dummy row of an empty ALU table (common.rs:283-286)
-  T.counts.n_p2 = p2s.size();
-  for (auto* op : p2s) {
-    const uint32_t* e = c.ext_of(*op);
-    T.p2_new_start.push_back(op->aux & 1);
-    T.p2_merkle_path.push_back((op->aux >> 1) & 1);
-    T.p2_mmcs_ctl_enabled.push_back(e[4] != kNoW);
-    for (int l = 0; l < 4; ++l) {
-      T.p2_in_ctl.push_back(e[l] != kNoW);
-      T.p2_input_indices.push_back(e[l] != kNoW ? e[l] : 0);
-    }
-    for (int l = 0; l < 2; ++l) {
-      const uint32_t w = e[7 + l];
-      T.p2_output_indices.push_back(w != kNoW ? w : 0);
-      T.p2_out_ctl.push_back(w == kNoW ? 0 : dup_p2[w] ? NEG1 : mult(w));
-    }
-    T.p2_mmcs_index_sum_idx.push_back(e[4] != kNoW ? e[4] : 0);
-  }
-  T.counts.n_recompose = recs.size();
-  for (auto* op : recs) {
-    T.recompose_prep.push_back(scaled(op->out));
-    T.recompose_prep.push_back(dup_rec[op->out] ? NEG1 : mult(op->out));
-  }
+  small_tables.get();
   return T;
 }
 

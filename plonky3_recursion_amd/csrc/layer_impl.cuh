@@ -224,11 +224,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     for (size_t i = 0; i < n; ++i)
       if (p[i] >= P) fail(P3R_EINVAL, "%s[%zu] is not canonical", what, i);
   };
-  check(d->const_prep, c.n_const * 2, "const_prep");
-  check(d->public_prep, c.n_public * 2, "public_prep");
   check(d->alu_prep13, c.n_alu * 13, "alu_prep13");
-  check(d->recompose_prep, c.n_recompose * 2, "recompose_prep");
-  check(d->p2_out_ctl, c.n_p2 * 2, "p2_out_ctl");
   const size_t mh = L->min_height;
   auto lanes_prep = [&](const uint32_t* prep, size_t n_ops, int per_op, int lanes, size_t& h_out) {
     size_t rows = std::max<size_t>((n_ops + lanes - 1) / lanes, 1);
@@ -243,8 +239,44 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
                           {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
                           {P3R_AIR_POSEIDON2, 1, 2, 0},
                           {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 0}};
-  mats[0] = lanes_prep(d->const_prep, c.n_const, 2, 1, L->h_const);
-  mats[1] = lanes_prep(d->public_prep, c.n_public, 2, (int)L->public_lanes, L->h_public);
+  // every table but the ALU one on a second host thread (they share nothing with it)
+  auto other_tables = std::async(std::launch::async, [&] {
+    check(d->const_prep, c.n_const * 2, "const_prep");
+    check(d->public_prep, c.n_public * 2, "public_prep");
+    check(d->recompose_prep, c.n_recompose * 2, "recompose_prep");
+    check(d->p2_out_ctl, c.n_p2 * 2, "p2_out_ctl");
+    mats[0] = lanes_prep(d->const_prep, c.n_const, 2, 1, L->h_const);
+    mats[1] = lanes_prep(d->public_prep, c.n_public, 2, (int)L->public_lanes, L->h_public);
+    // Poseidon2 preprocessed rows (air.rs:697-794, non-compact D=4 layout) + padding (:613-649)
+    if (L->has_p2) {
+      L->h_p2 = padded_height(c.n_p2, mh);
+      std::vector<uint32_t>& m = mats[3];
+      m.assign(L->h_p2 * 24, 0);
+      auto scaled = [&](uint32_t wid) { return (uint32_t)((uint64_t)wid * 4 % P); };
+      for (size_t r = 0; r < c.n_p2; ++r) {
+        uint32_t* o = &m[r * 24];
+        const bool ns = d->p2_new_start[r], mp = d->p2_merkle_path[r], en = d->p2_mmcs_ctl_enabled[r];
+        for (int l = 0; l < 4; ++l) {
+          const bool ctl = d->p2_in_ctl[r * 4 + l];
+          o[l * 4] = scaled(d->p2_input_indices[r * 4 + l]);
+          o[l * 4 + 1] = ctl;
+          o[l * 4 + 2] = !ns && !mp && !ctl;
+          o[l * 4 + 3] = !ns && mp && !ctl;
+        }
+        for (int l = 0; l < 2; ++l) {
+          o[16 + 2 * l] = scaled(d->p2_output_indices[r * 2 + l]);
+          o[17 + 2 * l] = d->p2_out_ctl[r * 2 + l];
+        }
+        o[20] = scaled(d->p2_mmcs_index_sum_idx[r]);
+        o[21] = en && mp;
+        o[22] = ns;
+        o[23] = mp;
+      }
+      if (L->h_p2 > c.n_p2) m[c.n_p2 * 24 + 22] = 1;
+    }
+    if (L->has_recompose)
+      mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, 2, (int)L->recompose_lanes, L->h_recompose);
+  });
   // ALU: schedule + scheduled preprocessed trace (alu_air.rs:613-677)
   {
     const int lanes = (int)L->alu_lanes, k_max = (int)L->horner_k, pw = lanes * 13 + 7 * (k_max - 1);
@@ -284,35 +316,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     L->alu_prev_src.alloc(S.prev_src.size());
     P3R_HIP(copy_sync(ctx->stream, L->alu_prev_src.p, S.prev_src.data(), S.prev_src.size() * 4, hipMemcpyHostToDevice));
   }
-  // Poseidon2 preprocessed rows (air.rs:697-794, non-compact D=4 layout) + padding (:613-649)
-  if (L->has_p2) {
-    L->h_p2 = padded_height(c.n_p2, mh);
-    std::vector<uint32_t>& m = mats[3];
-    m.assign(L->h_p2 * 24, 0);
-    auto scaled = [&](uint32_t wid) { return (uint32_t)((uint64_t)wid * 4 % P); };
-    for (size_t r = 0; r < c.n_p2; ++r) {
-      uint32_t* o = &m[r * 24];
-      const bool ns = d->p2_new_start[r], mp = d->p2_merkle_path[r], en = d->p2_mmcs_ctl_enabled[r];
-      for (int l = 0; l < 4; ++l) {
-        const bool ctl = d->p2_in_ctl[r * 4 + l];
-        o[l * 4] = scaled(d->p2_input_indices[r * 4 + l]);
-        o[l * 4 + 1] = ctl;
-        o[l * 4 + 2] = !ns && !mp && !ctl;
-        o[l * 4 + 3] = !ns && mp && !ctl;
-      }
-      for (int l = 0; l < 2; ++l) {
-        o[16 + 2 * l] = scaled(d->p2_output_indices[r * 2 + l]);
-        o[17 + 2 * l] = d->p2_out_ctl[r * 2 + l];
-      }
-      o[20] = scaled(d->p2_mmcs_index_sum_idx[r]);
-      o[21] = en && mp;
-      o[22] = ns;
-      o[23] = mp;
-    }
-    if (L->h_p2 > c.n_p2) m[c.n_p2 * 24 + 22] = 1;
-  }
-  if (L->has_recompose)
-    mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, 2, (int)L->recompose_lanes, L->h_recompose);
+  other_tables.get();
   const int widths[5] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1), 24,
                          (int)L->recompose_lanes * 2};
   const size_t heights[5] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose};
