@@ -122,14 +122,15 @@ k_mmcs_hash_rows_strided_coop(const uint32_t* const* __restrict__ cols, int wtot
   if (live && e < P2_DIGEST) dig[(size_t)e * h + row] = s.v;
 }
 
-// Up to eight levels of a Merkle tree per launch.  A workgroup owns kSubtreeNodes consecutive
-// digests of the input layer and everything above them: a barrier per level instead of a launch
+// Several levels of a Merkle tree per launch.  A workgroup owns `local` consecutive digests of the
+// input layer (32 by default, at most kSubtreeNodes; p3r_core.hip::subtree_nodes says why) and
+// everything above them: a barrier per level instead of a launch
 // (each of these levels is one permutation latency; the launches between them cost more than the
 // work), LDS hand-off between levels.  Every level is also written to its own layer buffer -
 // queries read siblings from them.  A level may carry an injection (digests of the shorter
 // matrices of the commit, circuit/src/ops/mmcs.rs:117-160): node = compress(compress(l, r), inj).
-// Used for layers of at most kCoopMaxNodes nodes; the last launch of a tree is a single workgroup.
-constexpr int kSubtreeBlock = 1024;  // 64 nodes in flight
+// Used for layers of at most coop_max_nodes() nodes; the last launch of a tree is a single workgroup.
+constexpr int kSubtreeBlock = 1024;  // the largest workgroup: 64 nodes in flight
 constexpr int kSubtreeNodes = 256;
 constexpr int kSubtreeLevels = 8;
 struct SubtreeArgs {

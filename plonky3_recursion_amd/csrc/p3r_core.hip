@@ -623,7 +623,7 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
 }
 
 // One 2-to-1 layer, one permutation per lane: for layers large enough to fill the chip.  Smaller
-// ones are latency-bound and go through mmcs_subtree below (16 lanes per node, 8 levels per launch).
+// ones are latency-bound and go through mmcs_subtree below (16 lanes per node, several levels per launch).
 // A lane-cooperative permutation costs 16 lanes x ~1.2 k instructions against ~3.9 k FP64 operations of one
 // lane: it is the faster way through a level only while the level is latency-bound, i.e. up to about
 // one 16-lane row per SIMD and pass (4096 nodes a pass on 256 CUs; a pass is ~2.7 us, a launch of the
@@ -651,7 +651,7 @@ void launch_compress(p3r_ctx* ctx, const uint32_t* prev, const uint32_t* inj, ui
   P3R_HIP(hipGetLastError());
 }
 
-// Up to eight levels above the `n`-digest layer at the back of `tree->layers` in one launch
+// log2(subtree_nodes()) levels above the `n`-digest layer at the back of `tree->layers` in one launch
 // (k_mmcs_subtree), for layers small enough to be latency-bound.  `inject`: height -> digests to
 // fold in at that height (may be null).  Returns the size of the new back layer, or `n` when
 // the layer is too large for this path.
