@@ -190,6 +190,44 @@ def small_layers(ctx, p3r, wl, packing, field, sizes=(14, 15, 16), steps=20):
     return out
 
 
+def small_layer_throughput(p3r, wl, packing, field, log_h=15, provers=4, reps=20):
+    """Independent proofs of production-size layers on ONE GPU: `provers` host threads, each with its own
+    p3r context (HIP stream + memory pool) - what a recursion service runs, since one 2^15-row proof does
+    not fill the chip (the Merkle tops and the circuit-run chains are latency-bound).  Every proof must be
+    the same bytes as the single-prover one."""
+    import threading
+    import harness_lib
+    arrs = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN_KNOBS)
+    workers = []
+    for _ in range(provers):
+        c = p3r.Context(field=field, **FRI)
+        pc = p3r.PreparedCircuit(c, wl.circuit_from_arrays(arrs), packing)
+        res = pc.upload_inputs(wl.circuit_inputs_from_arrays(arrs))
+        workers.append((c, pc, res, pc.prove(res)))
+    ok = all(w[3] == workers[0][3] for w in workers)
+    bad = []
+
+    def run(w):
+        _, pc, res, ref = w
+        for _ in range(reps):
+            if pc.prove(res) != ref:
+                bad.append(1)
+
+    ts = [threading.Thread(target=run, args=(w,)) for w in workers]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    for c, pc, res, _ in workers:
+        res.free()
+        pc.free()
+        c.close()
+    return {"log_height": log_h, "provers": provers, "proofs": provers * reps, "proofs_per_s": provers * reps / dt,
+            "ms_per_proof_amortised": dt / (provers * reps) * 1e3, "all_proofs_identical": ok and not bad}
+
+
 def run_tree(args, torch, dist, rank, world, local_rank, coll_device):
     """BASELINE config 4: a 2-to-1 aggregation tree of `--tree-leaves` leaf proofs -> 1 root over the
     ranks (one GPU each).  Leaves are prove_next_layer over the synthetic layer at 2^leaf_log_height
@@ -494,6 +532,7 @@ def main():
     prep_miss_ms = None
     prep_breakdown = None
     small = {}
+    small_tput = None
     if rank == 0 and world == 1:
         circ = wl.circuit_from_arrays(arrs)
         hin = wl.circuit_inputs_from_arrays(arrs)
@@ -519,6 +558,7 @@ def main():
         del circ, hin, cache2
         if not args.no_small_layers:
             small = small_layers(ctx, p3r, wl, packing, field)
+            small_tput = small_layer_throughput(p3r, wl, packing, field)
     del arrs
 
     if rank == 0:
@@ -568,6 +608,7 @@ def main():
             "prep_miss_ms": prep_miss_ms,
             "prep_miss_breakdown_ms": prep_breakdown,
             "small_layers": small or None,
+            "small_layer_throughput": small_tput,
             "root_handoff_ms": handoff_ms,
             "poseidon2_perms_per_s": perms * world / (ms_per_step * 1e-3),
             "poseidon2_perms_per_step": perms,
