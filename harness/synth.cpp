@@ -45,7 +45,11 @@ struct Workload {
 // shape knobs for the reference's edge cases: non-primitive tables without rows are left out of the
 // batch, Public / ALU tables holding at most the dummy op run with one lane
 // (batch_stark_prover.rs:1305-1318, tables/alu.rs:69-73)
-enum { SYN_NO_POSEIDON2 = 1, SYN_NO_RECOMPOSE = 2, SYN_SINGLE_PUBLIC = 4, SYN_NO_ALU = 8 };
+enum { SYN_NO_POSEIDON2 = 1, SYN_NO_RECOMPOSE = 2, SYN_SINGLE_PUBLIC = 4, SYN_NO_ALU = 8,
+       // sponge rows read only witnesses that no permutation produced: the sponge chains are independent of each
+       // other (the leaf hashes of a verifier circuit: one chain per opened row), Merkle chains may still start
+       // from a sponge's digest
+       SYN_INDEPENDENT_SPONGES = 16 };
 
 enum { OP_ADD = 0, OP_MUL = 1, OP_BOOL = 2, OP_MULADD = 3, OP_HORNER = 4 };
 
@@ -205,6 +209,12 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   {
     F state[16];
     for (auto& x : state) x = F::zero();
+    const uint32_t sponge_pick_limit = (uint32_t)pickable.size();
+    auto sponge_pick = [&](bool count_read) {
+      const uint32_t w = (flags & SYN_INDEPENDENT_SPONGES) ? pickable[rng.below(sponge_pick_limit)] : pickp_noread();
+      if (count_read) reads[w]++;
+      return w;
+    };
     // The outputs of some one-row sponges land on witnesses a Public op already defined with the
     // same value: such an output is a READER on the bus (out_ctl = -1; circuit.rs:464-491,
     // dup_npo_outputs; batch_stark_prover.rs:225-238)
@@ -220,8 +230,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
         for (int l = 0; l < 2; ++l) {
           // sponge: rate limbs read from the witness bus; Merkle: the leaf digest is named by
           // witness index without a bus read (executor.rs:786-790)
-          uint32_t w = pickp_noread();
-          if (!p.merkle) reads[w]++;
+          uint32_t w = p.merkle ? pickp_noread() : sponge_pick(true);
           in_ctl[l] = 1; in_idx[l] = w; ext[l] = w;
           for (int d = 0; d < 4; ++d) in[l * 4 + d] = wval[w].c[d];
         }
@@ -229,7 +238,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
         for (int i = 0; i < 16; ++i) in[i] = state[i];  // full previous output carried
         for (int l = 0; l < 2; ++l) {
           if (rng.unit() < 0.5) {
-            uint32_t w = pickp();
+            uint32_t w = sponge_pick(true);
             in_ctl[l] = 1; in_idx[l] = w; ext[l] = w;
             for (int d = 0; d < 4; ++d) in[l * 4 + d] = wval[w].c[d];
           }

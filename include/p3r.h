@@ -334,6 +334,46 @@ int p3r_batch_proof_len(uint32_t field, const uint8_t* bytes, size_t len, uint32
 int p3r_batch_proof_len_layout(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags,
                                const uint8_t* proof_layout, size_t* proof_len, char* err_buf, size_t err_cap);
 
+/* The whole serialised `BatchStarkProof` (what `to_postcard` / the Rust `postcard::to_allocvec(&proof)` emits):
+ * the inner `BatchProof` followed by the metadata fields of batch_stark_prover.rs:610-636 (TablePacking
+ * packing.rs:9-27, RowCounts :459-460, NonPrimitiveTableEntry :272-290, SerializedStarkCommon :505-511).
+ * p3r_batch_stark_proof_parse walks the bytes once without building containers (framing, every field
+ * element in range), decodes the metadata into `out` (field elements canonical) and applies the structural
+ * rules a `#[derive(Deserialize)]` bypasses (batch_stark_prover.rs:666-681, packing.rs:140-161).  It is what
+ * a parent node of the aggregation tree runs on each child before proving (recursion.rs:656-762 receives the
+ * children already deserialised): host code, no device, no p3r_ctx. */
+#define P3R_META_MAX_NPO 8
+#define P3R_META_MAX_INSTANCES 16
+#define P3R_META_MAX_CAP 64
+typedef struct p3r_npo_table_entry {
+  char op_type[64];        /* NpoTypeId(String), NUL-terminated */
+  uint64_t rows;
+  uint32_t lanes;
+  uint32_t air_variant;    /* 0 Baseline, 1 Optimized */
+  uint32_t n_public_values;
+  uint32_t public_values[8];
+} p3r_npo_table_entry;
+typedef struct p3r_batch_stark_meta {
+  uint64_t proof_len;      /* length of the inner BatchProof at the head of the bytes */
+  uint32_t public_lanes, alu_lanes, min_trace_height, horner_packed_steps;
+  uint32_t n_npo_lanes;    /* TablePacking.npo_lanes: Vec<(NpoTypeId, usize)> */
+  struct { char op_type[64]; uint32_t lanes; } npo_lanes[P3R_META_MAX_NPO];
+  uint64_t rows[3];        /* RowCounts([const, public, alu]) */
+  uint32_t alu_variant, ext_degree;
+  uint32_t has_w_binomial, w_binomial, alu_quintic_trinomial;
+  uint32_t n_non_primitives;
+  p3r_npo_table_entry non_primitives[P3R_META_MAX_NPO];
+  uint32_t has_stark_common;
+  uint32_t cap_len;        /* digests of the preprocessed commitment */
+  uint32_t commitment[8 * P3R_META_MAX_CAP];
+  uint32_t n_instances;    /* SerializedStarkCommon.instances (Some entries, in order) */
+  uint32_t preprocessed_widths[P3R_META_MAX_INSTANCES];
+  uint32_t degree_bits[P3R_META_MAX_INSTANCES];
+} p3r_batch_stark_meta;
+int p3r_batch_stark_proof_parse(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags,
+                                const uint8_t* proof_layout, p3r_batch_stark_meta* out, char* err_buf,
+                                size_t err_cap);
+
 /* ---- the caller side of prove_next_layer: the circuit itself ------------------------------------
  * `prove_next_layer` (recursion/src/recursion.rs:401-502) receives a `Circuit<EF>`, sets its public
  * inputs and the Merkle-sibling private data, RUNS it (`CircuitRunner::run`,

@@ -494,13 +494,34 @@ inline RecursionOutput prove_next_layer(const RecursionInput& input, const Conte
 struct AggregationCircuitFingerprint {
   uint32_t witness_count = 0;
   size_t public_flat_len = 0, private_flat_len = 0, ops_len = 0;
+  // The reference keys the slot by the four lengths and runs the NEW circuit against the cached prover data.
+  // A hit here also reuses the cached execution schedule, so the key additionally binds the circuit's content.
+  uint64_t content_digest[2] = {0, 0};
   bool operator==(const AggregationCircuitFingerprint& o) const {
     return witness_count == o.witness_count && public_flat_len == o.public_flat_len && private_flat_len == o.private_flat_len &&
-           ops_len == o.ops_len;
+           ops_len == o.ops_len && content_digest[0] == o.content_digest[0] && content_digest[1] == o.content_digest[1];
   }
 };
+namespace detail {
+// two independent 64-bit multiply-xorshift streams over the words of the circuit arrays
+inline void digest_words(uint64_t h[2], const uint32_t* w, size_t n) {
+  uint64_t a = h[0] ^ (0x9E3779B97F4A7C15ull * (n + 1)), b = h[1] + 0xC2B2AE3D27D4EB4Full * (n + 1);
+  for (size_t i = 0; i < n; ++i) {
+    a = (a ^ w[i]) * 0xFF51AFD7ED558CCDull; a ^= a >> 32;
+    b = (b + w[i]) * 0xC4CEB9FE1A85EC53ull; b ^= b >> 29;
+  }
+  h[0] = a; h[1] = b;
+}
+}  // namespace detail
 inline AggregationCircuitFingerprint aggregation_circuit_fingerprint(const Circuit& c) {
-  return {c.witness_count, c.public_rows.size(), c.private_input_rows.size(), c.ops.size()};
+  AggregationCircuitFingerprint fp{c.witness_count, c.public_rows.size(), c.private_input_rows.size(), c.ops.size(), {0, 0}};
+  static_assert(sizeof(p3r_op) == 8 * sizeof(uint32_t), "p3r_op is eight words");
+  detail::digest_words(fp.content_digest, reinterpret_cast<const uint32_t*>(c.ops.data()), c.ops.size() * 8);
+  detail::digest_words(fp.content_digest, c.ext.data(), c.ext.size());
+  detail::digest_words(fp.content_digest, c.public_rows.data(), c.public_rows.size());
+  detail::digest_words(fp.content_digest, c.private_input_rows.data(), c.private_input_rows.size());
+  detail::digest_words(fp.content_digest, c.witness_rewrite.data(), c.witness_rewrite.size());
+  return fp;
 }
 struct AggregationPrepCache {
   AggregationCircuitFingerprint circuit_fingerprint;

@@ -111,6 +111,30 @@ class P3rCircuitInputs(C.Structure):
     ]
 
 
+class P3rNpoTableEntry(C.Structure):
+    _fields_ = [("op_type", C.c_char * 64), ("rows", C.c_uint64), ("lanes", C.c_uint32), ("air_variant", C.c_uint32),
+                ("n_public_values", C.c_uint32), ("public_values", C.c_uint32 * 8)]
+
+
+class P3rNpoLanes(C.Structure):
+    _fields_ = [("op_type", C.c_char * 64), ("lanes", C.c_uint32)]
+
+
+class P3rBatchStarkMeta(C.Structure):
+    _fields_ = [
+        ("proof_len", C.c_uint64),
+        ("public_lanes", C.c_uint32), ("alu_lanes", C.c_uint32), ("min_trace_height", C.c_uint32),
+        ("horner_packed_steps", C.c_uint32),
+        ("n_npo_lanes", C.c_uint32), ("npo_lanes", P3rNpoLanes * 8),
+        ("rows", C.c_uint64 * 3),
+        ("alu_variant", C.c_uint32), ("ext_degree", C.c_uint32),
+        ("has_w_binomial", C.c_uint32), ("w_binomial", C.c_uint32), ("alu_quintic_trinomial", C.c_uint32),
+        ("n_non_primitives", C.c_uint32), ("non_primitives", P3rNpoTableEntry * 8),
+        ("has_stark_common", C.c_uint32), ("cap_len", C.c_uint32), ("commitment", C.c_uint32 * (8 * 64)),
+        ("n_instances", C.c_uint32), ("preprocessed_widths", C.c_uint32 * 16), ("degree_bits", C.c_uint32 * 16),
+    ]
+
+
 class P3rProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_uint64)]
 
@@ -166,6 +190,8 @@ SIGNATURES = {
                                       C.c_char_p, C.c_size_t]),
     "p3r_batch_proof_len_layout": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8),
                                              C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
+    "p3r_batch_stark_proof_parse": (C.c_int, [C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint8),
+                                              C.POINTER(P3rBatchStarkMeta), C.c_char_p, C.c_size_t]),
     "p3r_circuit_create": (vp, [vp, C.POINTER(P3rCircuitDesc), u32p]),
     "p3r_circuit_free": (None, [vp, vp]),
     "p3r_circuit_layer": (vp, [vp]),

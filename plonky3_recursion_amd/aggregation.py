@@ -22,10 +22,13 @@ import numpy as np
 
 @dataclass
 class TreePlan:
-    """Static placement: node i of level l runs on rank (i * stride_l) % world, stride_l = 2^l,
-    so a parent lives where its LEFT child lived and only the right child's proof moves."""
+    """Static placement: node i of level l runs on rank (i * 2^l + offset) % world, so a parent lives where
+    its LEFT child lived and only the right child's proof moves.  `offset` rotates the placement: with K
+    trees in flight tree t takes offset t, so the rank that proves the upper levels (and receives the
+    root) differs from tree to tree and every rank ends up with the same number of proofs."""
     n_leaves: int
     world: int
+    offset: int = 0
 
     def __post_init__(self):
         if self.n_leaves < 1 or self.n_leaves & (self.n_leaves - 1):
@@ -39,7 +42,7 @@ class TreePlan:
         return self.n_leaves >> level
 
     def owner(self, level, node):
-        return (node << level) % self.world
+        return ((node << level) + self.offset) % self.world
 
     def my_nodes(self, level, rank):
         return [i for i in range(self.nodes(level)) if self.owner(level, i) == rank]
@@ -88,6 +91,15 @@ def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], 
             return {k: fn(k) for k in keys}
         return dict(zip(keys, pool.map(fn, keys)))
 
+    try:
+        return _run_levels(plan, rank, prove_leaf, prove_parent, dist, device, on_level, level_barrier, run_all)
+    finally:
+        if pool is not None:
+            pool.shutdown()
+
+
+def _run_levels(plan, rank, prove_leaf, prove_parent, dist, device, on_level, level_barrier, run_all):
+    import time
     t0 = time.perf_counter()
     proofs = run_all(prove_leaf, plan.my_nodes(0, rank))
     if level_barrier:
@@ -115,8 +127,6 @@ def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], 
             level_barrier()
         if on_level:
             on_level(level, time.perf_counter() - t0)
-    if pool is not None:
-        pool.shutdown()
     # final root hand-off to rank 0
     root_level = plan.levels - 1
     root_rank = plan.owner(root_level, 0)
@@ -128,6 +138,125 @@ def run_aggregation_tree(plan: TreePlan, rank: int, prove_leaf: Callable[[int], 
     if rank == 0:
         return _recv_bytes(dist, root_rank, device)
     return None
+
+
+def run_aggregation_forest(plans, rank: int, prove_leaf: Callable[[int, int], bytes],
+                           prove_parent: Callable[[int, int, int, bytes, bytes], bytes], dist=None, device="cpu",
+                           workers: int = 1, on_node: Optional[Callable[[int, int, int, float], None]] = None) -> Optional[List[bytes]]:
+    """Dependency-driven scheduler for one or more 2-to-1 trees in flight (`plans`: one TreePlan per tree, all
+    over the same world).  A parent is proved as soon as ITS two children are on its rank - there is no level
+    barrier - by a pool of `workers` host threads (callbacks must be thread-safe for workers > 1: one p3r_ctx
+    = one HIP stream per thread).  The reference's driver is the serial pair loop of
+    recursive_aggregation.rs:447-475; the nodes it proves one after the other are independent.
+
+    prove_leaf(tree, i) -> proof bytes; prove_parent(tree, level, node, left, right) -> proof bytes.
+    Child proofs that must change rank, and each tree's root on its way to rank 0, are moved by ONE
+    communication thread per rank that walks the (level, tree, node)-sorted list of this rank's messages:
+    both ends of a message reach it after the same earlier messages, so blocking send/recv pairs match
+    without tags (RCCL has none) and cannot deadlock.  Returns the root proofs (tree order) on rank 0.
+    `on_node(tree, level, node, seconds_since_start)` is called when a node this rank proved completes."""
+    import threading
+    import time
+    from concurrent.futures import Future, ThreadPoolExecutor
+    n_trees = len(plans)
+    L = plans[0].levels
+    fut = {}                       # (tree, level, node) -> Future[bytes], for every proof this rank holds at some point
+    pending = {}                   # parent key -> number of children still missing
+    lock = threading.Lock()
+    errors = []
+    t_start = time.perf_counter()
+    pool = ThreadPoolExecutor(max_workers=max(1, workers))
+
+    def future_of(key):
+        with lock:
+            f = fut.get(key)
+            if f is None:
+                f = fut[key] = Future()
+            return f
+
+    def run_node(key, fn, *args):
+        f = future_of(key)
+        try:
+            out = fn(*args)
+            if on_node:
+                on_node(key[0], key[1], key[2], time.perf_counter() - t_start)
+            f.set_result(out)
+        except BaseException as e:  # noqa: BLE001 - handed to the waiting thread
+            errors.append(e)
+            f.set_exception(e)
+
+    def child_done(parent_key, _f):
+        with lock:
+            pending[parent_key] -= 1
+            ready = pending[parent_key] == 0
+        if not ready:
+            return
+        t, level, node = parent_key
+        lf, rf = fut[(t, level - 1, 2 * node)], fut[(t, level - 1, 2 * node + 1)]
+        if lf.exception() or rf.exception():
+            future_of(parent_key).set_exception(lf.exception() or rf.exception())
+            return
+        pool.submit(run_node, parent_key, prove_parent, t, level, node, lf.result(), rf.result())
+
+    messages = []                  # (level of the RECEIVING node, tree, node, src, dst, key of the proof that moves)
+    for t, plan in enumerate(plans):
+        for level in range(1, L):
+            for node in range(plan.nodes(level)):
+                dst, src = plan.owner(level, node), plan.owner(level - 1, 2 * node + 1)
+                if dst == rank:
+                    key = (t, level, node)
+                    pending[key] = 2
+                    for child in (2 * node, 2 * node + 1):
+                        future_of((t, level - 1, child)).add_done_callback(lambda f, k=key: child_done(k, f))
+                if src != dst:
+                    messages.append((level, t, node, src, dst, (t, level - 1, 2 * node + 1)))
+        root_rank = plan.owner(L - 1, 0)
+        if root_rank != 0:
+            messages.append((L, t, 0, root_rank, 0, (t, L - 1, 0)))
+    messages.sort(key=lambda m: m[:3])
+    mine = [m for m in messages if rank in (m[3], m[4])]
+
+    def comm():
+        done = 0
+        try:
+            if getattr(device, "type", None) == "cuda":   # the current device is per thread
+                import torch
+                torch.cuda.set_device(device)
+            for _, _, _, src, dst, key in mine:
+                if src == rank:
+                    _send_bytes(dist, future_of(key).result(), dst, device)
+                else:
+                    future_of(key).set_result(_recv_bytes(dist, src, device))
+                done += 1
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            for _, _, _, src, _, key in mine[done:]:   # nobody may wait for a proof that will not arrive
+                if src != rank and not future_of(key).done():
+                    future_of(key).set_exception(e)
+
+    comm_thread = threading.Thread(target=comm, name="p3r-tree-comm") if mine else None
+    try:
+        if comm_thread:
+            comm_thread.start()
+        for t, plan in enumerate(plans):
+            for i in plan.my_nodes(0, rank):
+                pool.submit(run_node, (t, 0, i), prove_leaf, t, i)
+        roots = None
+        if rank == 0:
+            roots = [future_of((t, L - 1, 0)).result() for t in range(n_trees)]
+        else:
+            # this rank is done when everything it proves is proved and everything it sends is sent
+            for t, plan in enumerate(plans):
+                for level in range(L):
+                    for node in plan.my_nodes(level, rank):
+                        future_of((t, level, node)).result()
+        if comm_thread:
+            comm_thread.join()
+        if errors:
+            raise errors[0]
+        return roots
+    finally:
+        pool.shutdown(wait=True)
 
 
 def gather_proofs_to_root(proof: bytes, dist, rank: int, world: int, device="cpu") -> Optional[List[bytes]]:

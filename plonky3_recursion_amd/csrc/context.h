@@ -11,6 +11,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <chrono>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -262,7 +263,12 @@ struct HostPost {
                                    hipHostMallocMapped | hipHostMallocCoherent);
       if (e != hipSuccess) return e;
       e = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0);
-      if (e != hipSuccess) return e;
+      if (e != hipSuccess) {  // never leave a half-initialised pair behind: the next call would launch with dev == NULL
+        (void)hipHostFree(host);
+        host = nullptr;
+        dev = nullptr;
+        return e;
+      }
       host[kWords] = 0;
     }
     *out = host;
@@ -273,8 +279,13 @@ struct HostPost {
     volatile uint32_t* flag = host + kWords;
     for (uint64_t spins = 0;; ++spins) {
       if (*flag == seq) break;
+      // the store normally lands within a few microseconds; past ~50 us of polling there are kernels queued ahead
+      // (large layers, or sibling provers on the same GPU): stop burning the core - yield, then sleep in short naps
+      if (spins > (uint64_t(1) << 14) && (spins & 0x3F) == 0x3F) {
+        if (spins > (uint64_t(1) << 17)) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        else std::this_thread::yield();
+      }
       if ((spins & 0xFFF) == 0xFFF) {
-        if (spins > (uint64_t(1) << 18)) std::this_thread::yield();  // a long wait (big kernels ahead): give the core away
         // a fault upstream would leave the flag unset for ever: ask the stream now and then
         e = hipStreamQuery(s);
         if (e != hipErrorNotReady) {

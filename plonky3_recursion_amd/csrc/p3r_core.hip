@@ -628,20 +628,28 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
 // lane: it is the faster way through a level only while the level is latency-bound, i.e. up to about
 // one 16-lane row per SIMD and pass (4096 nodes a pass on 256 CUs; a pass is ~2.7 us, a launch of the
 // one-permutation-per-lane kernel ~11 us whatever its size).  P3R_COOP_MAX_NODES / _LEAF_ROWS: tuning.
+// (tuning knobs are rounded down to a power of two: the kernels index by shifts and halvings)
+inline size_t env_pow2(const char* name, size_t dflt, size_t lo, size_t hi) {
+  const char* e = getenv(name);
+  size_t v = e ? (size_t)atol(e) : dflt;
+  v = std::min(std::max(v, lo), hi);
+  while (v & (v - 1)) v &= v - 1;
+  return v;
+}
 inline size_t coop_max_nodes() {
-  static const size_t v = getenv("P3R_COOP_MAX_NODES") ? (size_t)atol(getenv("P3R_COOP_MAX_NODES")) : 16384;
+  static const size_t v = env_pow2("P3R_COOP_MAX_NODES", 16384, 1, size_t(1) << 30);
   return v;
 }
 inline size_t coop_max_leaf_rows() {
-  static const size_t v = getenv("P3R_COOP_MAX_LEAF_ROWS") ? (size_t)atol(getenv("P3R_COOP_MAX_LEAF_ROWS")) : 8192;
+  static const size_t v = env_pow2("P3R_COOP_MAX_LEAF_ROWS", 8192, 1, size_t(1) << 30);
   return v;
 }
 // Digests per workgroup of a k_mmcs_subtree launch: with 32, level 0 is one pass of 16 rows - one wave
 // per SIMD - and the five levels of the launch are all latency-bound; with 256 (eight levels per launch)
 // levels 0 and 1 queued 8 and 4 waves per SIMD on the few CUs that had a workgroup.
 inline size_t subtree_nodes() {
-  static const size_t v = getenv("P3R_SUBTREE_NODES") ? (size_t)atol(getenv("P3R_SUBTREE_NODES")) : 32;
-  return std::min<size_t>(std::max<size_t>(v, 2), kSubtreeNodes);
+  static const size_t v = env_pow2("P3R_SUBTREE_NODES", 32, 2, kSubtreeNodes);
+  return v;
 }
 template <class PP>
 void launch_compress(p3r_ctx* ctx, const uint32_t* prev, const uint32_t* inj, uint32_t* out, size_t n) {
@@ -910,7 +918,10 @@ int p3r_trim(p3r_ctx* ctx, uint64_t* freed_bytes) {
   if (!ctx) return P3R_EINVAL;
   return guard(ctx, [&] {
     P3R_HIP(hipStreamSynchronize(ctx->stream));
-    if (freed_bytes) *freed_bytes = ctx->pool->cached_bytes;
+    if (freed_bytes) {
+      std::lock_guard<std::mutex> g(ctx->pool->mu);  // a sibling's out-of-memory path may be trimming this pool
+      *freed_bytes = ctx->pool->cached_bytes;
+    }
     ctx->pool->trim();
     ctx->const_tables.clear();  // the job lists were keyed to the addresses the pool handed out
   });
@@ -1279,6 +1290,24 @@ int p3r_batch_proof_len_layout(uint32_t field, const uint8_t* bytes, size_t len,
     if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
     if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len, PL);
     else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len, PL);
+    else throw std::runtime_error("unknown field");
+    return P3R_OK;
+  } catch (const std::exception& e) {
+    if (err_buf && err_cap) snprintf(err_buf, err_cap, "%s", e.what());
+    return P3R_EINVAL;
+  }
+}
+
+int p3r_batch_stark_proof_parse(uint32_t field, const uint8_t* bytes, size_t len, uint32_t flags,
+                                const uint8_t* proof_layout, p3r_batch_stark_meta* out, char* err_buf,
+                                size_t err_cap) {
+  try {
+    if (!bytes || !out) throw std::runtime_error("NULL argument");
+    const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
+    p3r::ProofLayout PL;
+    if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
+    if (field == P3R_FIELD_KOALA_BEAR) p3r::parse_batch_stark_meta<p3r::KoalaBearParams>(bytes, len, canonical, PL, out);
+    else if (field == P3R_FIELD_BABY_BEAR) p3r::parse_batch_stark_meta<p3r::BabyBearParams>(bytes, len, canonical, PL, out);
     else throw std::runtime_error("unknown field");
     return P3R_OK;
   } catch (const std::exception& e) {

@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/p3r.h"
 #include "host_transcript.h"
 
 namespace p3r {
@@ -209,6 +210,232 @@ ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size
   if (consumed) *consumed = (size_t)(R.p - bytes);
   else if (R.p != R.end) vfail("%zu trailing bytes after the proof", (size_t)(R.end - R.p));
   return P;
+}
+
+// ---- framing-only walk of a BatchProof: what a parent node of the aggregation tree needs before it can
+// hand a child to its verifier circuit (the postcard framing is sound, every field element is in range) -
+// no containers are built.  Runs of field elements take the five-byte fast path (a Montgomery word is
+// >= 2^28 fifteen times out of sixteen): one 8-byte load, one bit-extract, one compare.
+template <class PP>
+struct ProofSkimmer {
+  const uint8_t* p;
+  const uint8_t* end;
+  uint8_t byte() {
+    if (p >= end) vfail("proof truncated");
+    return *p++;
+  }
+  bool flag() {
+    const uint8_t b = byte();
+    if (b > 1) vfail("invalid option tag %u", b);
+    return b != 0;
+  }
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      uint8_t b = byte();
+      v |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) {
+        if (b == 0 && shift > 0) vfail("non-canonical varint");
+        return v;
+      }
+    }
+    vfail("malformed varint");
+  }
+  size_t len(size_t max) {
+    uint64_t v = varint();
+    if (v > max) vfail("length %llu exceeds the bound %zu", (unsigned long long)v, max);
+    return (size_t)v;
+  }
+  void fes_scalar(size_t k) {
+    for (size_t i = 0; i < k; ++i)
+      if (varint() >= PP::P) vfail("field element out of range");
+  }
+#if defined(P3R_HOST_AVX512)
+  __attribute__((target("bmi2"))) void fes_bmi2(size_t k) {
+    const uint8_t* q = p;
+    size_t i = 0;
+    constexpr uint64_t M = 0x8080808080ull, T = 0x0080808080ull, X = 0x7F7F7F7F7Full;
+    while (i < k) {
+      // four at a time while all four are five-byte words (their positions are then known up front)
+      while (i + 4 <= k && q + 23 <= end) {
+        uint64_t x0, x1, x2, x3;
+        std::memcpy(&x0, q, 8); std::memcpy(&x1, q + 5, 8); std::memcpy(&x2, q + 10, 8); std::memcpy(&x3, q + 15, 8);
+        const bool five = ((x0 & M) == T) & ((x1 & M) == T) & ((x2 & M) == T) & ((x3 & M) == T) &
+                          (((x0 >> 32) & 0x7F) != 0) & (((x1 >> 32) & 0x7F) != 0) & (((x2 >> 32) & 0x7F) != 0) &
+                          (((x3 >> 32) & 0x7F) != 0);
+        if (!five) break;
+        if ((_pext_u64(x0, X) >= PP::P) | (_pext_u64(x1, X) >= PP::P) | (_pext_u64(x2, X) >= PP::P) |
+            (_pext_u64(x3, X) >= PP::P))
+          vfail("field element out of range");
+        q += 20;
+        i += 4;
+      }
+      // a shorter word among the next four (one word in sixteen is below 2^28): one at a time, then retry
+      for (int j = 0; j < 4 && i < k; ++j, ++i) {
+        uint64_t x = 0;
+        if (q + 8 <= end) std::memcpy(&x, q, 8);
+        if ((x & M) == T && ((x >> 32) & 0x7F)) {  // five bytes, canonical
+          if (_pext_u64(x, X) >= PP::P) vfail("field element out of range");
+          q += 5;
+        } else {
+          p = q;
+          if (varint() >= PP::P) vfail("field element out of range");
+          q = p;
+        }
+      }
+    }
+    p = q;
+  }
+#endif
+  void fes(size_t k) {
+#if defined(P3R_HOST_AVX512)
+    static const bool bmi2 = __builtin_cpu_supports("bmi2") && !(getenv("P3R_HOST_SIMD") && getenv("P3R_HOST_SIMD")[0] == '0');
+    if (bmi2) return fes_bmi2(k);
+#endif
+    fes_scalar(k);
+  }
+  void vec_ef(size_t max = 1u << 16) { fes(4 * len(max)); }
+  void cap() { fes(P2_DIGEST * len(1u << 16)); }
+};
+
+// Same grammar as parse_proof; returns the length of the BatchProof at the head of `bytes`.
+template <class PP>
+size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofLayout{}) {
+  ProofSkimmer<PP> R{bytes, bytes + n};
+  auto opened = [&] {
+    const size_t ni = R.len(64);
+    for (size_t i = 0; i < ni; ++i)
+      for (int f = 0; f < 8; ++f) {
+        switch (PL.opened[f]) {
+          case 0: R.vec_ef(); break;
+          case 1: if (R.flag()) R.vec_ef(); break;
+          case 2: if (!R.flag()) vfail("preprocessed_local missing"); R.vec_ef(); break;
+          case 3: if (!R.flag()) vfail("preprocessed_next missing"); R.vec_ef(); break;
+          case 4: { const size_t nc = R.len(8); for (size_t c = 0; c < nc; ++c) R.vec_ef(); break; }
+          case 5: if (R.flag()) vfail("proof carries random opened values: not supported"); break;
+          default: R.vec_ef(); break;
+        }
+      }
+  };
+  auto queries = [&] {
+    const size_t nq = R.len(1024);
+    for (size_t q = 0; q < nq; ++q) {
+      const size_t nr = R.len(8);
+      for (size_t r = 0; r < nr; ++r) {
+        const size_t rows = R.len(256);
+        for (size_t k = 0; k < rows; ++k) R.fes(R.len(1u << 16));
+        R.fes(P2_DIGEST * R.len(64));
+      }
+      const size_t nph = R.len(64);
+      for (size_t k = 0; k < nph; ++k) {
+        (void)R.byte();
+        R.fes(4 * R.len(16));
+        R.fes(P2_DIGEST * R.len(64));
+      }
+    }
+  };
+  auto fri = [&] {
+    for (int f = 0; f < 5; ++f) {
+      switch (PL.fri[f]) {
+        case 0: { const size_t nc = R.len(64); for (size_t c = 0; c < nc; ++c) R.cap(); break; }
+        case 1: R.fes(R.len(64)); break;
+        case 2: queries(); break;
+        case 3: R.vec_ef(); break;
+        default: R.fes(1); break;
+      }
+    }
+  };
+  for (int f = 0; f < 5; ++f) {
+    switch (PL.batch[f]) {
+      case 0:
+        R.cap();
+        if (R.flag()) R.cap();
+        R.cap();
+        if (R.flag()) vfail("proof carries a random (ZK) commitment: not supported");
+        break;
+      case 1: opened(); break;
+      case 2: fri(); break;
+      case 3: { const size_t nt = R.len(64); for (size_t t = 0; t < nt; ++t) if (R.flag()) R.fes(4); break; }
+      default: { const size_t nd = R.len(64); for (size_t d = 0; d < nd; ++d) (void)R.len(40); break; }
+    }
+  }
+  return (size_t)(R.p - bytes);
+}
+
+// The metadata fields that follow the inner BatchProof (BatchStarkProof, batch_stark_prover.rs:610-636).
+template <class PP>
+void parse_batch_stark_meta(const uint8_t* bytes, size_t len, bool canonical, const ProofLayout& PL,
+                            p3r_batch_stark_meta* M) {
+  std::memset(M, 0, sizeof *M);
+  M->proof_len = skim_proof<PP>(bytes, len, PL);
+  ProofSkimmer<PP> R{bytes + M->proof_len, bytes + len};
+  auto u32 = [&](const char* what) {
+    const uint64_t v = R.varint();
+    if (v > 0xFFFFFFFFull) vfail("%s does not fit 32 bits", what);
+    return (uint32_t)v;
+  };
+  auto fe = [&]() -> uint32_t {
+    const uint64_t v = R.varint();
+    if (v >= PP::P) vfail("field element out of range");
+    return canonical ? (uint32_t)v : Fp<PP>::raw((uint32_t)v).to_canonical();
+  };
+  auto str = [&](char (&dst)[64]) {
+    const size_t k = R.len(63);
+    if ((size_t)(R.end - R.p) < k) vfail("proof metadata truncated");
+    std::memcpy(dst, R.p, k);
+    dst[k] = 0;
+    R.p += k;
+  };
+  // TablePacking { public_lanes, alu_lanes, npo_lanes, min_trace_height, horner_packed_steps } (packing.rs:9-27)
+  M->public_lanes = u32("public_lanes");
+  M->alu_lanes = u32("alu_lanes");
+  M->n_npo_lanes = (uint32_t)R.len(P3R_META_MAX_NPO);
+  for (uint32_t i = 0; i < M->n_npo_lanes; ++i) { str(M->npo_lanes[i].op_type); M->npo_lanes[i].lanes = u32("npo lanes"); }
+  M->min_trace_height = u32("min_trace_height");
+  M->horner_packed_steps = u32("horner_packed_steps");
+  for (int i = 0; i < 3; ++i) M->rows[i] = R.varint();  // RowCounts([usize; 3]): no length prefix
+  M->alu_variant = u32("alu_variant");
+  if (M->alu_variant > 1) vfail("unknown AirVariant %u", M->alu_variant);
+  M->ext_degree = u32("ext_degree");
+  M->has_w_binomial = R.flag();
+  if (M->has_w_binomial) M->w_binomial = fe();
+  M->alu_quintic_trinomial = R.flag();
+  M->n_non_primitives = (uint32_t)R.len(P3R_META_MAX_NPO);
+  for (uint32_t i = 0; i < M->n_non_primitives; ++i) {
+    p3r_npo_table_entry& e = M->non_primitives[i];
+    str(e.op_type);
+    e.rows = R.varint();
+    e.lanes = u32("npo lanes");
+    e.n_public_values = (uint32_t)R.len(8);
+    for (uint32_t k = 0; k < e.n_public_values; ++k) e.public_values[k] = fe();
+    e.air_variant = u32("air_variant");
+    if (e.air_variant > 1) vfail("unknown AirVariant %u", e.air_variant);
+  }
+  M->has_stark_common = R.flag();
+  if (M->has_stark_common) {
+    M->cap_len = (uint32_t)R.len(P3R_META_MAX_CAP);
+    for (uint32_t i = 0; i < 8 * M->cap_len; ++i) M->commitment[i] = fe();
+    const size_t n_inst = R.len(P3R_META_MAX_INSTANCES);
+    for (size_t i = 0; i < n_inst; ++i) {
+      if (!R.flag()) continue;
+      (void)R.varint();  // matrix index
+      M->preprocessed_widths[M->n_instances] = u32("preprocessed width");
+      M->degree_bits[M->n_instances] = (uint32_t)R.len(40);
+      M->n_instances++;
+    }
+    const size_t n_map = R.len(P3R_META_MAX_INSTANCES);
+    for (size_t i = 0; i < n_map; ++i) (void)R.varint();  // matrix_to_instance
+  }
+  if (R.p != R.end) vfail("%zu trailing bytes after the proof metadata", (size_t)(R.end - R.p));
+  // structural invariants a derived Deserialize bypasses (batch_stark_prover.rs:666-681, packing.rs:140-161)
+  const uint32_t d = M->ext_degree;
+  if (!(d == 1 || d == 2 || d == 4 || d == 5 || d == 6 || d == 8)) vfail("UnsupportedExtDegree(%u)", d);
+  if (!M->public_lanes) vfail("ZeroLanes(\"public_lanes\")");
+  if (!M->alu_lanes) vfail("ZeroLanes(\"alu_lanes\")");
+  for (uint32_t i = 0; i < M->n_non_primitives; ++i)
+    if (!M->non_primitives[i].lanes) vfail("ZeroNpoLanes(%s)", M->non_primitives[i].op_type);
+  if (!M->min_trace_height || (M->min_trace_height & (M->min_trace_height - 1))) vfail("BadMinTraceHeight(%u)", M->min_trace_height);
+  if (M->horner_packed_steps < 2) vfail("BadHornerPackedSteps(%u)", M->horner_packed_steps);
 }
 
 // ---- the opened values of one instance as an AIR view over the extension field

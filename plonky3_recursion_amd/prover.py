@@ -92,7 +92,7 @@ class CircuitProverData:
     def __init__(self, ctx: Context, prep: CircuitPrep, packing: TablePacking):
         packing.validate()
         self.ctx, self.packing = ctx, packing
-        self._borrowed = False
+        self._borrowed, self._owner = False, None
         d = _lib.P3rLayerDesc()
         keep = []
 
@@ -128,11 +128,13 @@ class CircuitProverData:
         self._read_shape()
 
     @classmethod
-    def _borrow(cls, ctx: Context, handle, packing: TablePacking, rows: dict, commitment: np.ndarray):
-        """View of the CircuitProverData a prepared circuit owns (p3r_circuit_layer)."""
+    def _borrow(cls, ctx: Context, handle, packing: TablePacking, rows: dict, commitment: np.ndarray, owner=None):
+        """View of the CircuitProverData a prepared circuit owns (p3r_circuit_layer).  The view keeps its
+        owner alive - the reference hands out an Rc<CircuitProverData> that outlives the cache slot it came
+        from (recursion.rs:748-761) - and is invalidated only by an explicit PreparedCircuit.free()."""
         self = cls.__new__(cls)
         self.ctx, self.packing, self.h, self.rows = ctx, packing, handle, rows
-        self.preprocessed_commitment, self._borrowed = commitment, True
+        self.preprocessed_commitment, self._borrowed, self._owner = commitment, True, owner
         self._read_shape()
         return self
 
@@ -310,94 +312,40 @@ class BatchStarkProof:
 
     @classmethod
     def from_postcard(cls, data: bytes, field: str, canonical_field_encoding=False, proof_layout=None) -> "BatchStarkProof":
-        """Inverse of `to_postcard`: the inner `BatchProof` is delimited with the C-ABI parser
-        (p3r_batch_proof_len), the metadata that follows is decoded here and `validate()`d.
+        """Inverse of `to_postcard`: one pass of the C-ABI parser (p3r_batch_stark_proof_parse: framing of the
+        inner `BatchProof`, the metadata that follows it, and the `validate()` rules) - a parent node of the
+        aggregation tree runs this on each child, so it is native host code, not a Python loop.
         `proof_layout`: the 18 bytes of `p3r_config.proof_layout` when the proof was written with one."""
         from .device import FIELD_IDS, MODULUS
         lib = _lib.load()
-        buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
-        n, err = C.c_size_t(), C.create_string_buffer(256)
-        if proof_layout is None:
-            rc = lib.p3r_batch_proof_len(FIELD_IDS[field], buf, len(data), 1 if canonical_field_encoding else 0,
-                                         C.byref(n), err, len(err))
-        else:
-            lay = (C.c_uint8 * 18)(*[int(v) for v in proof_layout])
-            rc = lib.p3r_batch_proof_len_layout(FIELD_IDS[field], buf, len(data), 1 if canonical_field_encoding else 0, lay,
-                                                C.byref(n), err, len(err))
+        m, err = _lib.P3rBatchStarkMeta(), C.create_string_buffer(256)
+        lay = None if proof_layout is None else (C.c_uint8 * 18)(*[int(v) for v in proof_layout])
+        data = bytes(data)
+        rc = lib.p3r_batch_stark_proof_parse(FIELD_IDS[field], data, len(data), 1 if canonical_field_encoding else 0, lay,
+                                             C.byref(m), err, len(err))
         if rc != 0:
             raise P3rError(rc, err.value.decode())
-        p, pos = MODULUS[field], [n.value]
-        r_inv = pow(1 << 32, -1, p)
-
-        def byte():
-            if pos[0] >= len(data):
-                raise P3rError(-1, "proof metadata truncated")
-            pos[0] += 1
-            return data[pos[0] - 1]
-
-        def varint():
-            v = shift = 0
-            while True:
-                b = byte()
-                v |= (b & 0x7F) << shift
-                if not b & 0x80:
-                    return v
-                shift += 7
-                if shift > 63:
-                    raise P3rError(-1, "malformed varint")
-
-        def fe():
-            v = varint()
-            if v >= p:
-                raise P3rError(-1, "field element out of range")
-            return v if canonical_field_encoding else v * r_inv % p
-
-        def string():
-            k = varint()
-            if pos[0] + k > len(data):
-                raise P3rError(-1, "proof metadata truncated")
-            pos[0] += k
-            return data[pos[0] - k:pos[0]].decode()
-
-        public_lanes, alu_lanes = varint(), varint()
-        npo_lanes = {}
-        for _ in range(varint()):
-            name = string()
-            npo_lanes[name] = varint()
-        min_h, horner_k = varint(), varint()
-        rows = (varint(), varint(), varint())
-        alu_variant, ext_degree = varint(), varint()
-        w_binomial = fe() if byte() else None
-        quintic = bool(byte())
-        entries = []
-        for _ in range(varint()):
-            op_type, n_rows, lanes = string(), varint(), varint()
-            pv = tuple(fe() for _ in range(varint()))
-            entries.append(NonPrimitiveTableEntry(op_type=op_type, rows=n_rows, lanes=lanes, public_values=pv,
-                                                  air_variant=varint()))
-        commitment, widths, degree_bits = None, (), ()
-        if byte():
-            commitment = np.array([[fe() for _ in range(8)] for _ in range(varint())], dtype=np.uint32)
-            widths, degree_bits = [], []
-            for _ in range(varint()):
-                if byte():
-                    varint()          # matrix index
-                    widths.append(varint())
-                    degree_bits.append(varint())
-            for _ in range(varint()):
-                varint()              # matrix_to_instance
-        if pos[0] != len(data):
-            raise P3rError(-1, "%d trailing bytes after the proof metadata" % (len(data) - pos[0]))
+        entries = tuple(NonPrimitiveTableEntry(op_type=e.op_type.decode(), rows=int(e.rows), lanes=int(e.lanes),
+                                               public_values=tuple(e.public_values[:e.n_public_values]),
+                                               air_variant=int(e.air_variant))
+                        for e in m.non_primitives[:m.n_non_primitives])
+        npo_lanes = {e.op_type.decode(): int(e.lanes) for e in m.npo_lanes[:m.n_npo_lanes]}
         recompose_lanes = next((e.lanes for e in entries if e.op_type == "recompose"), npo_lanes.get("recompose", 1))
-        out = cls(proof=data[:n.value],
-                  table_packing=TablePacking(public_lanes=public_lanes, alu_lanes=alu_lanes, horner_packed_steps=horner_k,
-                                             recompose_lanes=recompose_lanes, min_trace_height=min_h),
-                  rows=rows, alu_variant=alu_variant, ext_degree=ext_degree, w_binomial=w_binomial,
-                  alu_quintic_trinomial=quintic, non_primitives=tuple(entries), preprocessed_commitment=commitment,
-                  preprocessed_widths=tuple(widths), degree_bits=tuple(degree_bits),
-                  monty_r=0 if canonical_field_encoding else 1, modulus=p)
-        out.validate()
-        return out
+        commitment = None
+        if m.has_stark_common:
+            commitment = np.frombuffer(m, dtype=np.uint32, count=8 * m.cap_len,
+                                       offset=_lib.P3rBatchStarkMeta.commitment.offset).reshape(-1, 8).copy()
+        return cls(proof=data[:m.proof_len],
+                   table_packing=TablePacking(public_lanes=m.public_lanes, alu_lanes=m.alu_lanes,
+                                              horner_packed_steps=m.horner_packed_steps, recompose_lanes=recompose_lanes,
+                                              min_trace_height=m.min_trace_height),
+                   rows=tuple(int(r) for r in m.rows), alu_variant=int(m.alu_variant), ext_degree=int(m.ext_degree),
+                   w_binomial=int(m.w_binomial) if m.has_w_binomial else None,
+                   alu_quintic_trinomial=bool(m.alu_quintic_trinomial), non_primitives=entries,
+                   preprocessed_commitment=commitment,
+                   preprocessed_widths=tuple(m.preprocessed_widths[:m.n_instances]) if m.has_stark_common else (),
+                   degree_bits=tuple(m.degree_bits[:m.n_instances]) if m.has_stark_common else (),
+                   monty_r=0 if canonical_field_encoding else 1, modulus=MODULUS[field])
 
     def to_postcard(self) -> bytes:
         """postcard bytes of the whole `BatchStarkProof<SC>`, field order = the serde derives of
@@ -601,8 +549,22 @@ class PreparedCircuit:
         lv = C.c_size_t()
         ctx.check(ctx.lib.p3r_circuit_levels(self.h, C.byref(lv)))
         self.levels = lv.value
-        self.circuit_prover_data = CircuitProverData._borrow(ctx, ctx.lib.p3r_circuit_layer(self.h), packing, rows,
-                                                             commit)
+        self._cpd_args = (ctx.lib.p3r_circuit_layer(self.h), packing, rows, commit)
+        self._cpd_view = None
+
+    @property
+    def circuit_prover_data(self) -> CircuitProverData:
+        """The CircuitProverData this circuit was prepared into.  Views hold a reference to the prepared circuit
+        (not the other way round: no reference cycle), so the device data lives exactly as long as the circuit,
+        a cache slot or any RecursionOutput / CircuitProverData handed out still refers to it."""
+        import weakref
+        view = self._cpd_view() if self._cpd_view is not None else None
+        if view is None:
+            if not self.h:
+                raise P3rError(-1, "the prepared circuit has been freed")
+            view = CircuitProverData._borrow(self.ctx, *self._cpd_args, owner=self)
+            self._cpd_view = weakref.ref(view)
+        return view
 
     @staticmethod
     def _inputs_struct(circuit: Circuit, inputs: CircuitInputs):
@@ -643,8 +605,11 @@ class PreparedCircuit:
         return self.ctx._proof_call(self.ctx.lib.p3r_prove_next_layer, self.ctx.h, self.h, C.byref(t), flags)
 
     def free(self):
+        """Explicit release (device memory is returned now): outstanding CircuitProverData views become invalid."""
+        view = self._cpd_view() if getattr(self, "_cpd_view", None) is not None else None
+        if view is not None:
+            view.h = None
         if self.h and self.ctx.h:
-            self.circuit_prover_data.h = None
             self.ctx.lib.p3r_circuit_free(self.ctx.h, self.h)
         self.h = None
 
@@ -805,6 +770,35 @@ class AggregationCircuitFingerprint:
     public_flat_len: int
     private_flat_len: int
     ops_len: int
+    # The reference keys the slot by the four lengths and then runs the NEW circuit against the cached prover
+    # data (a same-shape, different-content circuit fails to verify there).  Here a hit also reuses the cached
+    # execution schedule, so the key additionally binds the circuit's content.
+    content_digest: bytes = b""
+
+
+def _circuit_content_digest(circuit: Circuit) -> bytes:
+    """128-bit digest of ops / ext / public_rows / private_input_rows / witness_rewrite (cached on the object)."""
+    cached = getattr(circuit, "_content_digest", None)
+    arrays = [np.ascontiguousarray(np.asarray(getattr(circuit, n), dtype=np.uint32).reshape(-1))
+              for n in ("ops", "ext", "public_rows", "private_input_rows", "witness_rewrite")]
+    key = tuple((a.__array_interface__["data"][0], a.size) for a in arrays)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    try:
+        import xxhash
+        h = xxhash.xxh3_128()
+    except ImportError:  # pragma: no cover - xxhash ships with the image
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        h.update(np.uint64(a.size).tobytes())
+        h.update(memoryview(a).cast("B"))
+    d = h.digest()
+    try:
+        object.__setattr__(circuit, "_content_digest", (key, d))
+    except Exception:
+        pass
+    return d
 
 
 def aggregation_circuit_fingerprint(circuit: Circuit) -> AggregationCircuitFingerprint:
@@ -812,7 +806,8 @@ def aggregation_circuit_fingerprint(circuit: Circuit) -> AggregationCircuitFinge
         witness_count=int(circuit.witness_count),
         public_flat_len=int(np.asarray(circuit.public_rows).size),
         private_flat_len=int(np.asarray(circuit.private_input_rows).size),
-        ops_len=int(np.asarray(circuit.ops).reshape(-1, 8).shape[0]))
+        ops_len=int(np.asarray(circuit.ops).reshape(-1, 8).shape[0]),
+        content_digest=_circuit_content_digest(circuit))
 
 
 @dataclass
@@ -861,13 +856,14 @@ def prove_aggregation_layer(left: RecursionInput, right: RecursionInput, verific
     prover = BatchStarkProver(ctx, params.table_packing)
     pc = PreparedCircuit(ctx, verification_circuit, params.table_packing)   # get_airs_and_degrees_with_prep + ProverData
     proof = prover.wrap_proof(pc.prove(inputs), pc.circuit_prover_data)
+    cpd = pc.circuit_prover_data
     if prep_cache is not None:
         if not prep_cache:
             prep_cache.append(None)
-        if prep_cache[0] is not None:
-            prep_cache[0].prepared_circuit.free()
-        prep_cache[0] = AggregationPrepCache(fp, pc.circuit_prover_data, prover, pc)
-    return RecursionOutput(proof=proof, circuit_prover_data=pc.circuit_prover_data)
+        # the replaced entry is NOT freed here: RecursionOutputs returned earlier may still hold its
+        # CircuitProverData (an Rc in the reference); it is released when the last of them goes away
+        prep_cache[0] = AggregationPrepCache(fp, cpd, prover, pc)
+    return RecursionOutput(proof=proof, circuit_prover_data=cpd)
 
 
 # ----------------------------------------------------------------------------- tracing spans

@@ -26,7 +26,7 @@ def build():
     subprocess.run(["make", "-C", HDIR], check=True, capture_output=True)
 
 
-NO_POSEIDON2, NO_RECOMPOSE, SINGLE_PUBLIC, NO_ALU = 1, 2, 4, 8
+NO_POSEIDON2, NO_RECOMPOSE, SINGLE_PUBLIC, NO_ALU, INDEPENDENT_SPONGES = 1, 2, 4, 8, 16
 
 
 def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None,

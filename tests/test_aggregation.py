@@ -34,6 +34,84 @@ dist.destroy_process_group()
 '''
 
 
+FOREST_WORKER = r'''
+import hashlib, os, sys, time
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from plonky3_recursion_amd.aggregation import TreePlan, run_aggregation_forest
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+n_leaves, n_trees, workers = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+plans = [TreePlan(n_leaves, world, offset=t) for t in range(n_trees)]
+def leaf(t, i):
+    time.sleep(0.001 * ((7 * i + 3 * t + rank) %% 5))                  # completion order differs from submission order
+    return (b"tree%%d-leaf%%d|" %% (t, i)) * (1000 + i)
+def parent(t, lvl, node, l, r):
+    return hashlib.sha256(l).digest() + hashlib.sha256(r).digest() + b"|%%d.%%d.%%d" %% (t, lvl, node)
+seen = []
+roots = run_aggregation_forest(plans, rank, leaf, parent, dist=dist, workers=workers,
+                               on_node=lambda t, lvl, node, s: seen.append((t, lvl, node)))
+mine = sum(len(p.my_nodes(l, rank)) for p in plans for l in range(p.levels))
+assert len(seen) == mine, (len(seen), mine)
+if rank == 0:
+    for t, r in enumerate(roots):
+        print("ROOT", t, r.hex())
+else:
+    assert roots is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def expected_forest_root(t, n_leaves):
+    level = [(b"tree%d-leaf%d|" % (t, i)) * (1000 + i) for i in range(n_leaves)]
+    lvl = 1
+    while len(level) > 1:
+        level = [hashlib.sha256(level[2 * j]).digest() + hashlib.sha256(level[2 * j + 1]).digest() + b"|%d.%d.%d" % (t, lvl, j)
+                 for j in range(len(level) // 2)]
+        lvl += 1
+    return level[0].hex()
+
+
+@pytest.mark.parametrize("world,n_leaves,n_trees,workers", [(2, 8, 1, 1), (4, 8, 4, 2), (2, 4, 3, 3), (3, 4, 2, 1)])
+def test_forest_over_gloo(tmp_path, world, n_leaves, n_trees, workers):
+    """Dependency-driven scheduler: K trees in flight with rotated placement, no level barrier, one comm
+    thread per rank; every tree's root reaches rank 0 and equals the serial evaluation."""
+    script = tmp_path / "forest_worker.py"
+    script.write_text(FOREST_WORKER % {"root": ROOT})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(n_leaves), str(n_trees),
+           str(workers)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for t in range(n_trees):
+        assert f"ROOT {t} {expected_forest_root(t, n_leaves)}" in out.stdout
+
+
+def test_forest_single_process_and_errors():
+    from plonky3_recursion_amd.aggregation import TreePlan, run_aggregation_forest
+    leaf = lambda t, i: (b"tree%d-leaf%d|" % (t, i)) * (1000 + i)
+    parent = lambda t, lvl, node, l, r: hashlib.sha256(l).digest() + hashlib.sha256(r).digest() + b"|%d.%d.%d" % (t, lvl, node)
+    roots = run_aggregation_forest([TreePlan(8, 1, offset=t) for t in range(3)], 0, leaf, parent, workers=4)
+    assert [r.hex() for r in roots] == [expected_forest_root(t, 8) for t in range(3)]
+
+    def bad_parent(t, lvl, node, l, r):
+        if (lvl, node) == (2, 1):
+            raise RuntimeError("node failed")
+        return parent(t, lvl, node, l, r)
+    with pytest.raises(RuntimeError, match="node failed"):     # the failure reaches the caller, the pool is shut down
+        run_aggregation_forest([TreePlan(8, 1)], 0, leaf, bad_parent, workers=2)
+
+
+def test_rotated_placement_balances_the_forest():
+    from plonky3_recursion_amd.aggregation import TreePlan
+    world = 8
+    plans = [TreePlan(8, world, offset=t) for t in range(world)]
+    load = [sum(len(p.my_nodes(l, r)) for p in plans for l in range(p.levels)) for r in range(world)]
+    assert load == [15] * world                                  # 8 trees x 15 proofs over 8 ranks
+    assert sorted(p.owner(p.levels - 1, 0) for p in plans) == list(range(world))
+
+
 def expected_root(n_leaves):
     level = [(b"leaf%d|" % i) * (1000 + i) for i in range(n_leaves)]
     lvl = 1

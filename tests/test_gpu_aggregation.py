@@ -77,6 +77,50 @@ def test_prove_aggregation_layer_cache_and_fingerprint(oracle):
     ctx.close()
 
 
+def test_aggregation_output_outlives_its_cache_slot_and_content_is_part_of_the_key():
+    """The CircuitProverData of a RecursionOutput stays valid without a cache and after its slot is replaced
+    (the reference returns an Rc, recursion.rs:748-761), and a circuit with the same four lengths but other
+    content is NOT served from the slot."""
+    import gc
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    field = "koala-bear"
+    ctx = p3r.Context(field=field, **FRI)
+    tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    params, backend = p3r.ProveNextLayerParams(table_packing=tp), p3r.FriRecursionBackend()
+    na = harness_lib.generate(field, 8, seed=31, **GEN)
+    circuit = wl.circuit_from_arrays(na)
+    left, right, n_left = wl.split_aggregation_inputs(wl.circuit_inputs_from_arrays(na))
+    L, R = (p3r.RecursionInput(circuit_inputs=x) for x in (left, right))
+    out = p3r.prove_aggregation_layer(L, R, circuit, ctx, backend, params, prep_cache=None, left_non_primitive_ops=n_left)
+    gc.collect()
+    assert out.circuit_prover_data.h, "circuit_prover_data died with the local prepared circuit"
+    assert out.circuit_prover_data.table_heights[2] > 0
+    p3r.BatchStarkProver(ctx, tp).verify_all_tables(out.proof)
+    slot = [None]
+    out1 = p3r.prove_aggregation_layer(L, R, circuit, ctx, backend, params, prep_cache=slot, left_non_primitive_ops=n_left)
+    first = slot[0]
+    # same lengths, different content: flip the value of one constant
+    import copy
+    c2 = copy.deepcopy(circuit)
+    ops = np.asarray(c2.ops).reshape(-1, 8)
+    k = int(np.nonzero(ops[:, 0] == p3r.prover.OP_CONST)[0][3])
+    c2.ext = np.array(c2.ext, copy=True)
+    c2.ext[ops[k, 6]] ^= 1
+    assert p3r.aggregation_circuit_fingerprint(c2) != first.circuit_fingerprint
+    fp1, fp2 = first.circuit_fingerprint, p3r.aggregation_circuit_fingerprint(c2)
+    assert (fp1.witness_count, fp1.public_flat_len, fp1.private_flat_len, fp1.ops_len) == \
+           (fp2.witness_count, fp2.public_flat_len, fp2.private_flat_len, fp2.ops_len)
+    try:
+        p3r.prove_aggregation_layer(L, R, c2, ctx, backend, params, prep_cache=slot, left_non_primitive_ops=n_left)
+    except p3r.P3rError:
+        pass                                    # the changed constant may conflict with the inputs: a run error, not a stale hit
+    assert slot[0] is first or slot[0].circuit_fingerprint == fp2
+    gc.collect()
+    assert out1.circuit_prover_data.h            # the replaced / kept entry is still usable from the older output
+    ctx.close()
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -102,6 +146,33 @@ def test_tree_of_real_proofs_root_verifies(world, leaves):
     assert line["config"]["nodes"] == 2 * leaves - 1
     assert len(line["rank0"]["level_wall_ms_last_step"]) == leaves.bit_length()
     assert line["rank0"]["child_verify_ms"] is not None
+
+
+def test_plain_bench_entry_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns the two ranks (before it touches a
+    device), the line reports what the collective layer saw; a launcher whose WORLD_SIZE disagrees is an error."""
+    env = dict(os.environ, P3R_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-height", "12",
+           "--no-cpu-baseline", "--no-config2", "--no-small-layers"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["proof_verified"] is True
+    assert line["ranks"]["world_size"] == 2 and line["ranks"]["backend"] == "gloo" and len(line["ranks"]["devices"]) == 2
+    # the forest form through the same plain entry: one tree per rank, rotated placement, every root verified
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--tree", "--trees", "0", "--tree-leaves", "4", "--leaf-log-height", "10",
+           "--steps", "1", "--warmup", "0", "--tree-workers", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["trees"] == 2 and line["roots_verified"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["scheduler"] == "dependency-driven" and line["ranks"]["world_size"] == 2
+    assert line["rank0"]["child_parse_ms"] is not None
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=ROOT,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
 
 
 def test_default_bench_line_two_ranks_over_gloo():

@@ -9,6 +9,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/f
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/final/pmc_$C -- python3 $ARGS --steps 1 --warmup 0 > gpurun_out/final/pmc_$C.log 2>&1
 done
+# instructions per permutation of the dominant kernel: N launches over a matrix of known shape (tools/pmc_hash_rows.py)
+for F in koala-bear baby-bear; do
+  for C in SQ_INSTS_VALU SQ_WAVES; do
+    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/final/hashrows_${F}_$C -- python3 tools/pmc_hash_rows.py $F > gpurun_out/final/hashrows_${F}_$C.log 2>&1
+  done
+done
 # keep the merge small: drop the per-dispatch traces except counter collection + stats
 find gpurun_out/final -name "*kernel_trace.csv" -delete
 find gpurun_out/final -name "*agent_info.csv" -delete
@@ -17,4 +23,8 @@ du -sh gpurun_out/final
 timeout 900 python bench.py --field baby-bear --log-height 22 --steps 3 --no-cpu-baseline --no-config2 --no-small-layers > gpurun_out/final/bench_line_babybear_2p22.json 2> gpurun_out/final/bench_babybear_err.log
 timeout 600 python bench.py --tree --steps 3 --warmup 1 > gpurun_out/final/bench_line_tree_1gpu.json 2> gpurun_out/final/bench_tree_err.log
 timeout 600 python bench.py --tree --tree-workers 4 --steps 3 --warmup 1 > gpurun_out/final/bench_line_tree_1gpu_4workers.json 2>> gpurun_out/final/bench_tree_err.log
+timeout 600 python bench.py --tree --tree-workers 4 --trees 4 --steps 3 --warmup 1 > gpurun_out/final/bench_line_forest_1gpu_4trees.json 2>> gpurun_out/final/bench_tree_err.log
+# the plain multi-rank entry (the parent spawns the ranks; two ranks share the box's one GPU over gloo)
+P3R_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 3 --no-cpu-baseline --no-config2 --no-small-layers > gpurun_out/final/bench_line_2ranks_gloo.json 2> gpurun_out/final/bench_2ranks_err.log
+P3R_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --tree --trees 0 --tree-workers 2 --steps 3 > gpurun_out/final/bench_line_forest_2ranks_gloo.json 2>> gpurun_out/final/bench_2ranks_err.log
 timeout 300 python bench.py --steps 3 --no-cpu-baseline --no-config2 --no-small-layers --spans > /dev/null 2> gpurun_out/final/spans.txt
