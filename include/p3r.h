@@ -446,6 +446,10 @@ const p3r_layer* p3r_circuit_layer(const p3r_circuit* circuit);
 int p3r_circuit_counts(const p3r_circuit* circuit, p3r_layer_desc_counts* out);
 /* Levels of the execution schedule (ops of one level have no dependencies on each other). */
 int p3r_circuit_levels(const p3r_circuit* circuit, size_t* n_levels);
+/* 1: the circuit was prepared on the device (preprocessed columns, ALU lane schedule and execution schedule built
+ * in HBM from the uploaded op list); 0: by the host restatement of the same steps (P3R_PREP_HOST=1, or a circuit
+ * the device pass handed over).  Both give the same commitment, schedule and proofs. */
+int p3r_circuit_prepared_on_device(const p3r_circuit* circuit);
 
 /* CircuitRunner::run on the device.  Errors mirror CircuitError: a witness conflict
  * (runner.rs:473-510), DivisionByZero (:378), a non-boolean mmcs_bit

@@ -197,6 +197,7 @@ SIGNATURES = {
     "p3r_circuit_layer": (vp, [vp]),
     "p3r_circuit_counts": (C.c_int, [vp, C.POINTER(P3rLayerCounts)]),
     "p3r_circuit_levels": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "p3r_circuit_prepared_on_device": (C.c_int, [vp]),
     "p3r_circuit_run": (vp, [vp, vp, C.POINTER(P3rCircuitInputs)]),
     "p3r_prove_next_layer": (C.c_int, [vp, vp, C.POINTER(P3rCircuitInputs), C.c_uint32, C.POINTER(C.c_uint8),
                                        C.c_size_t, C.POINTER(C.c_size_t)]),

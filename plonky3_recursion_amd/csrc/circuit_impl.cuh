@@ -26,7 +26,6 @@
 
 namespace {
 
-constexpr uint32_t kNoW = P3R_NO_WITNESS;
 
 // ---------------------------------------------------------------- preprocessing (host, once)
 struct CircuitTables {
@@ -254,62 +253,7 @@ CircuitTables circuit_tables(const HostCircuit& c) {
 }
 
 // ---------------------------------------------------------------- execution schedule (host, once)
-enum : uint32_t {
-  RUN_BACKWARD = 1u << 8,    // Add / Mul solving for b (runner.rs:341-385)
-  RUN_CHECK_OUT = 1u << 9,   // `out` already holds a value: compare instead of write (set_witness, :473-510)
-  RUN_CHECK_AUX = 1u << 10,  // same for MulAdd's intermediate_out
-  RUN_CHECK_BIT = 1u << 31,  // on a hint-output entry of the device ext array
-};
-
-struct RunOp {  // ALU / hint / recompose / const-check ops, one lane each
-  uint32_t kind_flags;  // bits 0-7 p3r_op_kind, 8-10 RUN_*, 16-23 ext_len
-  uint32_t a, b, c, out, aux;
-  uint32_t rec;      // ALU record / recompose row this op fills
-  uint32_t ext_off;  // into the device ext array
-  uint32_t op_idx;   // position in the circuit (error reports)
-  uint32_t pad;
-};
-
-struct RunP2 {  // one Poseidon2 permutation, sixteen lanes
-  uint32_t in[4], idx_w, bit_w, out[4];
-  uint32_t flags;  // bit 0 new_start, 1 merkle_path, 4-7 output is a check, 8-10 number of outputs
-  uint32_t row, prev_row, op_idx;
-};
-
-enum : uint32_t { RUN_ERR_CONFLICT = 1, RUN_ERR_DIV0 = 2, RUN_ERR_MMCS_BIT = 3, RUN_ERR_INDEX_SUM = 4 };
-
-struct RunSchedule {
-  uint32_t n_alu_records = 0;  // AluOpRecords the run writes (0: the ALU table holds its dummy op only)
-  std::vector<RunOp> light;
-  // Poseidon2 permutations: a run of rows chained through the sponge / Merkle state whose witness
-  // inputs are all ready when the run starts is ONE segment, executed row after row by one 16-lane
-  // group with the state kept in registers (no launch, barrier or memory round trip per row)
-  struct P2Seg { uint32_t first, n; };
-  std::vector<RunP2> p2;                    // rows, segment by segment
-  std::vector<P2Seg> p2segs;                // sorted by level
-  std::vector<uint32_t> light_off, p2seg_off;  // per level, size levels + 1
-  std::vector<uint32_t> dev_ext;
-  std::vector<uint32_t> const_rows;         // const op -> witness, in table order (static Const trace)
-  std::vector<uint32_t> public_out;         // public table row -> witness
-  std::vector<uint32_t> rewrite_pairs;      // (dst, src, check) triples applied after the last level
-  std::vector<uint32_t> p2_row_of_op_id;    // NonPrimitiveOpId -> Poseidon2 row (or kNoW)
-  std::vector<uint8_t> p2_row_merkle;
-  std::string deferred_error;               // what run() reports for a circuit that cannot complete
-  size_t levels = 0;
-  // launches: a wide level each, or a run of consecutive narrow levels [l0, l1) in one workgroup
-  struct Segment { uint32_t l0, l1; bool narrow; uint32_t chunk_begin, n_chunks; };
-  std::vector<Segment> segments;
-  std::vector<uint32_t> chunk_bounds;       // per narrow segment: n_chunks + 1 level boundaries
-  // Horner chains: runs of consecutive HornerAcc ops threaded through the accumulator with one
-  // shared multiplier b are an affine recurrence acc <- acc*b + (c - a); each run is ONE scan
-  // (run_chains) at one level instead of one level per step.
-  struct ChainSeg { uint32_t first, n, acc_w, b_w; };
-  std::vector<RunOp> chain_ops;             // steps of all chains, chain by chain
-  std::vector<ChainSeg> chains;             // sorted by level; within a level the long ones first
-  std::vector<uint32_t> chain_off;          // per level
-  std::vector<uint32_t> chain_long;         // per level: how many of its chains get a whole workgroup
-};
-
+// (RunOp / RunP2 / RunSchedule: run_schedule.h, shared with the device-side preparation)
 inline RunSchedule build_schedule(const HostCircuit& c) {
   RunSchedule S;
   const uint32_t nw = c.witness_count;
@@ -550,30 +494,7 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
     for (auto& ch : chains)
       if (ch.n <= 128) S.chains[cp[ch.level]++] = {ch.first, ch.n, ch.acc_w, ch.b_w};
   }
-  for (uint32_t l = 1; l <= max_level; ++l) {
-    const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2seg_off[l + 1] - S.p2seg_off[l];
-    const uint32_t nc = S.chain_off[l + 1] - S.chain_off[l];
-    if (!nl && !np && !nc) continue;
-    const bool narrow = nl <= 1024 && np <= 64 && !nc;
-    if (narrow && !S.segments.empty() && S.segments.back().narrow && S.segments.back().l1 == l) S.segments.back().l1 = l + 1;
-    else S.segments.push_back({l, l + 1, narrow, 0, 0});
-  }
-  for (auto& seg : S.segments) {
-    if (!seg.narrow) continue;
-    seg.chunk_begin = (uint32_t)S.chunk_bounds.size();
-    uint32_t start = seg.l0;
-    S.chunk_bounds.push_back(start);
-    for (uint32_t l = seg.l0; l < seg.l1; ++l) {
-      // light-op records of levels [start, l + 1) must fit the LDS staging buffer (kNarrowLightCap)
-      if (S.light_off[l + 1] - S.light_off[start] > 1400) {
-        S.chunk_bounds.push_back(l);
-        start = l;
-        seg.n_chunks++;
-      }
-    }
-    S.chunk_bounds.push_back(seg.l1);
-    seg.n_chunks++;
-  }
+  finish_segments(S);
   S.n_alu_records = n_alu;
   return S;
 }
@@ -1000,12 +921,18 @@ k_run_rewrite(const uint32_t* __restrict__ triples, size_t n, uint32_t* __restri
 
 // ---------------------------------------------------------------- the prepared circuit
 struct p3r_circuit {
-  HostCircuit host;
+  // `sched` always holds the per-level offsets, the launch plan and the counts; its large arrays (light ops,
+  // permutation rows, chain steps) are only populated by the host-side preparation, which uploads them - the
+  // device-side preparation (prep_device.hip) builds them in HBM
   RunSchedule sched;
+  uint32_t witness_count = 0;
+  bool prepared_on_device = false;
+  size_t n_public_rows = 0, n_private_rows = 0, n_rewrite = 0, n_op_ids = 0;
   p3r_layer_desc_counts counts{};
   std::unique_ptr<p3r_layer> layer;
   p3r::DevBuf d_light, d_p2, d_ext, d_const_values, d_public_rows, d_private_rows, d_public_out, d_rewrite;
   p3r::DevBuf d_light_off, d_p2seg_off, d_p2segs, d_chunk_bounds, d_chain_ops, d_chains;
+  p3r::DevBuf d_row_of_op_id;  // NonPrimitiveOpId -> Poseidon2 row, bit 31 = Merkle row; kNoW: no permutation
 };
 
 // Inputs of one run made resident in HBM (public / private values, Merkle siblings).
@@ -1018,10 +945,39 @@ namespace {
 template <class PP>
 std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* d, uint32_t* commit_out) {
   auto C = std::make_unique<p3r_circuit>();
-  HostCircuit& h = C->host;
+  HostCircuit h;
   auto need = [&](const void* p, size_t n, const char* what) { if (n && !p) fail(P3R_EINVAL, "%s is NULL", what); };
   need(d->ops, d->n_ops, "ops"); need(d->ext, d->n_ext, "ext"); need(d->public_rows, d->n_public, "public_rows");
   need(d->private_input_rows, d->n_private, "private_input_rows"); need(d->witness_rewrite, d->n_rewrite, "witness_rewrite");
+  C->witness_count = d->witness_count;
+  C->n_public_rows = d->n_public;
+  C->n_private_rows = d->n_private;
+  // Device-side preparation (prep_device.hip): the op list crosses PCIe once; preprocessed columns, ALU lane
+  // schedule and execution schedule are built in HBM.  A circuit it flags (malformed, unclaimed private input,
+  // a witness nobody sets ...) goes through the host restatement below, which raises the reference's error.
+  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr;  // read per call: the equality tests flip it
+  if (!host_prep) {
+    prof_stage(ctx, "prep_device");
+    DevPrep R;
+    if (devprep_circuit(ctx, d, R)) {
+      prof_stage(ctx, "prep_layer_create");
+      C->counts = R.counts;
+      C->layer = layer_from_device<PP>(ctx, R, d, commit_out);
+      C->sched = std::move(R.sched);
+      C->n_rewrite = R.n_rewrite;
+      C->n_op_ids = R.n_op_ids;
+      C->d_light = std::move(R.d_light); C->d_p2 = std::move(R.d_p2); C->d_ext = std::move(R.d_ext);
+      C->d_const_values = std::move(R.d_const_values); C->d_public_rows = std::move(R.d_public_rows);
+      C->d_private_rows = std::move(R.d_private_rows); C->d_public_out = std::move(R.d_public_out);
+      C->d_rewrite = std::move(R.d_rewrite); C->d_light_off = std::move(R.d_light_off);
+      C->d_p2seg_off = std::move(R.d_p2seg_off); C->d_p2segs = std::move(R.d_p2segs);
+      C->d_chunk_bounds = std::move(R.d_chunk_bounds); C->d_chain_ops = std::move(R.d_chain_ops);
+      C->d_chains = std::move(R.d_chains); C->d_row_of_op_id = std::move(R.d_row_of_op_id);
+      C->prepared_on_device = true;
+      prof_stage(ctx, nullptr);
+      return C;
+    }
+  }
   prof_stage(ctx, "prep_validate");
   h.witness_count = d->witness_count;
   h.ops.assign(d->ops, d->ops + d->n_ops);
@@ -1092,6 +1048,16 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   up(C->d_chunk_bounds, S.chunk_bounds.data(), S.chunk_bounds.size() * 4);
   up(C->d_chain_ops, S.chain_ops.data(), S.chain_ops.size() * sizeof(RunOp));
   up(C->d_chains, S.chains.data(), S.chains.size() * sizeof(RunSchedule::ChainSeg));
+  {
+    std::vector<uint32_t> ids(S.p2_row_of_op_id);
+    for (auto& v : ids)
+      if (v != kNoW && S.p2_row_merkle[v]) v |= 1u << 31;
+    C->n_op_ids = ids.size();
+    up(C->d_row_of_op_id, ids.data(), ids.size() * 4);
+  }
+  C->n_rewrite = S.rewrite_pairs.size() / 3;
+  // the large host arrays are on the device now
+  S.light = {}; S.p2 = {}; S.chain_ops = {}; S.dev_ext = {}; S.p2_row_of_op_id = {}; S.p2_row_merkle = {};
   prof_stage(ctx, nullptr);
   return C;
 }
@@ -1106,31 +1072,63 @@ inline const char* run_error_text(uint32_t code) {
   }
 }
 
+// set_private_data (runner.rs:124-176) against the device-resident NonPrimitiveOpId -> row table: pass 1 claims the
+// row for the smallest position k naming it, pass 2 reports, per position, what the sequential loop would have
+// said; the smallest failing position wins.
+__global__ void __launch_bounds__(kBlock)
+k_pd_claim(const uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ row_of_id, size_t n_ids, uint32_t* __restrict__ slot) {
+  const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t id = ids[k];
+  if (id >= n_ids) return;
+  const uint32_t v = row_of_id[id];
+  if (v == kNoW) return;
+  atomicMin(&slot[v & 0x7FFFFFFFu], (uint32_t)k);
+}
+__global__ void __launch_bounds__(kBlock)
+k_pd_check(const uint32_t* __restrict__ ids, size_t n, const uint32_t* __restrict__ row_of_id, size_t n_ids,
+           const uint32_t* __restrict__ slot, uint32_t* __restrict__ err) {
+  const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t id = ids[k];
+  uint32_t code = 0;
+  if (id >= n_ids || row_of_id[id] == kNoW) code = 1;          // NonPrimitiveOpIdOutOfRange
+  else if (slot[row_of_id[id] & 0x7FFFFFFFu] != k) code = 2;   // private data already set
+  else if (!(row_of_id[id] >> 31)) code = 3;                   // not a Merkle row
+  if (code) atomicMin(err, ((uint32_t)k << 2) | code);
+}
+
 // set_public_inputs / set_private_inputs / set_private_data (runner.rs:83-176): validate, upload.
 template <class PP>
 std::unique_ptr<p3r_dinputs> circuit_inputs_upload(p3r_ctx* ctx, const p3r_circuit* C, const p3r_circuit_inputs* in) {
-  const HostCircuit& h = C->host;
-  const RunSchedule& S = C->sched;
-  if (h.public_rows.size() && !in->public_values) fail(P3R_EINVAL, "PublicInputLengthMismatch: public_values is NULL");
-  if (h.private_rows.size() && !in->private_values) fail(P3R_EINVAL, "PrivateInputLengthMismatch: private_values is NULL");
-  const size_t n_p2 = C->counts.n_p2;
-  std::vector<int32_t> pd_slot(std::max<size_t>(n_p2, 1), -1);
-  for (size_t k = 0; k < in->n_private_data; ++k) {
-    const uint32_t id = in->private_data_op_ids[k];
-    if (id >= S.p2_row_of_op_id.size() || S.p2_row_of_op_id[id] == kNoW)
-      fail(P3R_EINVAL, "NonPrimitiveOpIdOutOfRange { op_id: %u, max_ops: %zu }", id, S.p2_row_of_op_id.size());
-    const uint32_t row = S.p2_row_of_op_id[id];
-    if (pd_slot[row] >= 0) fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data already set for NonPrimitiveOpId(%u)", id);
-    if (!S.p2_row_merkle[row])
-      fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data provided for non-Merkle operation NonPrimitiveOpId(%u)", id);
-    pd_slot[row] = (int32_t)k;
-  }
+  if (C->n_public_rows && !in->public_values) fail(P3R_EINVAL, "PublicInputLengthMismatch: public_values is NULL");
+  if (C->n_private_rows && !in->private_values) fail(P3R_EINVAL, "PrivateInputLengthMismatch: private_values is NULL");
+  const size_t n_p2 = C->counts.n_p2, n_pd = in->n_private_data;
+  if (n_pd && (!in->private_data_op_ids || !in->private_data_siblings)) fail(P3R_EINVAL, "private data arrays are NULL");
   auto D = std::make_unique<p3r_dinputs>();
-  D->pub = upload_mont<PP>(ctx, in->public_values, h.public_rows.size() * 4, "public_values");
-  D->priv = upload_mont<PP>(ctx, in->private_values, h.private_rows.size() * 4, "private_values");
-  D->sib = upload_mont<PP>(ctx, in->private_data_siblings, in->n_private_data * 8, "private_data_siblings");
-  D->slot.alloc(pd_slot.size());
-  P3R_HIP(copy_sync(ctx->stream, D->slot.p, pd_slot.data(), pd_slot.size() * 4, hipMemcpyHostToDevice));
+  D->pub = upload_mont<PP>(ctx, in->public_values, C->n_public_rows * 4, "public_values");
+  D->priv = upload_mont<PP>(ctx, in->private_values, C->n_private_rows * 4, "private_values");
+  D->sib = upload_mont<PP>(ctx, in->private_data_siblings, n_pd * 8, "private_data_siblings");
+  D->slot.alloc(std::max<size_t>(n_p2, 1));
+  P3R_HIP(hipMemsetAsync(D->slot.p, 0xFF, std::max<size_t>(n_p2, 1) * 4, ctx->stream));  // -1: no private data
+  if (n_pd) {
+    DevBuf ids(n_pd), err(1);
+    P3R_HIP(hipMemcpyAsync(ids.p, in->private_data_op_ids, n_pd * 4, hipMemcpyHostToDevice, ctx->stream));
+    P3R_HIP(hipMemsetAsync(err.p, 0xFF, 4, ctx->stream));
+    hipLaunchKernelGGL(k_pd_claim, dim3(blocks_for(n_pd)), dim3(kBlock), 0, ctx->stream, ids.p, n_pd, C->d_row_of_op_id.p, C->n_op_ids, D->slot.p);
+    hipLaunchKernelGGL(k_pd_check, dim3(blocks_for(n_pd)), dim3(kBlock), 0, ctx->stream, ids.p, n_pd, C->d_row_of_op_id.p, C->n_op_ids, D->slot.p,
+                       err.p);
+    uint32_t e = 0;
+    P3R_HIP(copy_sync(ctx->stream, &e, err.p, 4, hipMemcpyDeviceToHost));
+    if (e != 0xFFFFFFFFu) {
+      const uint32_t id = in->private_data_op_ids[e >> 2];
+      switch (e & 3) {
+        case 1: fail(P3R_EINVAL, "NonPrimitiveOpIdOutOfRange { op_id: %u, max_ops: %zu }", id, C->n_op_ids);
+        case 2: fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data already set for NonPrimitiveOpId(%u)", id);
+        default: fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data provided for non-Merkle operation NonPrimitiveOpId(%u)", id);
+      }
+    }
+  }
   return D;
 }
 
@@ -1150,7 +1148,6 @@ inline void run_raise_error(uint32_t e) {
 template <class PP>
 std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, const p3r_dinputs* in,
                                          uint32_t* deferred_err = nullptr) {
-  const HostCircuit& h = C->host;
   const RunSchedule& S = C->sched;
   const p3r_layer* L = C->layer.get();
   if (!S.deferred_error.empty()) fail(P3R_EINVAL, "%s", S.deferred_error.c_str());
@@ -1159,16 +1156,16 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
   auto T = std::make_unique<p3r_dtraces>();
   const auto& cn = C->counts;
   T->n_const = cn.n_const; T->n_public = cn.n_public; T->n_alu = cn.n_alu; T->n_recompose = cn.n_recompose;
-  DevBuf w((size_t)std::max<uint32_t>(h.witness_count, 1) * 4);
+  DevBuf w((size_t)std::max<uint32_t>(C->witness_count, 1) * 4);
   DevBuf err(1), p2_out(std::max<size_t>(n_p2, 1) * 16);
   const DevBuf &d_pub = in->pub, &d_priv = in->priv, &d_sib = in->sib, &d_slot = in->slot;
   P3R_HIP(hipMemsetAsync(err.p, 0xFF, 4, ctx->stream));
-  if (h.public_rows.size())
-    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(h.public_rows.size() * 4)), dim3(kBlock), 0, ctx->stream,
-                       C->d_public_rows.p, d_pub.p, h.public_rows.size(), w.p);
-  if (h.private_rows.size())
-    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(h.private_rows.size() * 4)), dim3(kBlock), 0, ctx->stream,
-                       C->d_private_rows.p, d_priv.p, h.private_rows.size(), w.p);
+  if (C->n_public_rows)
+    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(C->n_public_rows * 4)), dim3(kBlock), 0, ctx->stream,
+                       C->d_public_rows.p, d_pub.p, C->n_public_rows, w.p);
+  if (C->n_private_rows)
+    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(C->n_private_rows * 4)), dim3(kBlock), 0, ctx->stream,
+                       C->d_private_rows.p, d_priv.p, C->n_private_rows, w.p);
   // trace buffers
   T->const_values.alloc(std::max<size_t>(cn.n_const * 4, 1));
   if (cn.n_const)
@@ -1227,9 +1224,9 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
       if (n_long)
         hipLaunchKernelGGL(k_run_chains_block<PP>, dim3(n_long), dim3(kLongChainBlock), 0, ctx->stream, A, steps, segs);
     }
-    if (!S.rewrite_pairs.empty())
-      hipLaunchKernelGGL(k_run_rewrite<PP>, dim3(blocks_for(S.rewrite_pairs.size() / 3)), dim3(kBlock), 0, ctx->stream,
-                         C->d_rewrite.p, S.rewrite_pairs.size() / 3, w.p, err.p);
+    if (C->n_rewrite)
+      hipLaunchKernelGGL(k_run_rewrite<PP>, dim3(blocks_for(C->n_rewrite)), dim3(kBlock), 0, ctx->stream,
+                         C->d_rewrite.p, C->n_rewrite, w.p, err.p);
     if (cn.n_public)
       hipLaunchKernelGGL(k_run_gather<PP>, dim3(blocks_for(cn.n_public * 4)), dim3(kBlock), 0, ctx->stream,
                          C->d_public_out.p, cn.n_public, w.p, T->public_values.p);

@@ -234,7 +234,7 @@ struct HostLanding {
 // instead of going through a copy engine and hipStreamSynchronize (29 us per fetch measured with
 // tools/microbench/d2h_latency.py - more than the Merkle levels of a small layer's commitment).
 // The stream is NOT synchronised when post() returns: only this kernel's stores are known to be done.
-__global__ void __launch_bounds__(256) k_post_small(uint32_t* host_dst, const uint32_t* __restrict__ src, uint32_t n,
+static __global__ void __launch_bounds__(256) k_post_small(uint32_t* host_dst, const uint32_t* __restrict__ src, uint32_t n,
                                                     uint32_t* flag, uint32_t seq) {
   for (uint32_t i = threadIdx.x; i < n; i += 256) host_dst[i] = src[i];
   __threadfence_system();

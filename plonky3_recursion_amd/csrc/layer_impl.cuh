@@ -18,14 +18,7 @@
 
 namespace {
 
-// plan entry kinds
-enum { PLAN_SEP = 0, PLAN_OP = 1, PLAN_PACKED = 2 };
-
-struct AluPlanEntry {
-  uint32_t first;  // op index
-  uint8_t kind, k;
-  uint16_t pad;
-};
+// (AluPlanEntry / PLAN_*: run_schedule.h)
 
 // K1: one lane per trace row.
 template <class PP>
@@ -329,6 +322,40 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     pm[n_present++] = {mats[i].data(), heights[i], (size_t)widths[i]};
   }
   L->prep = prep_create<PP>(ctx, present_airs, pm, n_present);
+  std::copy(L->prep->cap_canonical.begin(), L->prep->cap_canonical.end(), commit_out);
+  return L;
+}
+
+// The same object from the device-side preparation (prep_device.hip): the preprocessed traces and the ALU scatter
+// plan are already in HBM; what is left is their LDE and commitment.
+template <class PP>
+std::unique_ptr<p3r_layer> layer_from_device(p3r_ctx* ctx, DevPrep& R, const p3r_circuit_desc* d, uint32_t* commit_out) {
+  auto L = std::make_unique<p3r_layer>();
+  L->counts = R.counts;
+  L->public_lanes = R.public_lanes; L->alu_lanes = R.alu_lanes; L->horner_k = d->horner_packed_steps;
+  L->recompose_lanes = d->recompose_lanes; L->min_height = d->min_trace_height;
+  if (!d->public_lanes || !d->alu_lanes || !d->recompose_lanes) fail(P3R_EINVAL, "lane counts must be positive");
+  if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
+  L->has_p2 = R.counts.n_p2 > 0;
+  L->has_recompose = R.counts.n_recompose > 0;
+  L->h_const = R.h[0]; L->h_public = R.h[1]; L->h_alu = R.h[2]; L->h_p2 = R.h[3]; L->h_recompose = R.h[4];
+  L->alu_rows = R.alu_rows;
+  L->alu_plan = std::move(R.alu_plan);
+  L->alu_prev_src = std::move(R.alu_prev_src);
+  const p3r_air_desc airs[5] = {{P3R_AIR_CONST, 1, 2, 0},
+                                {P3R_AIR_PUBLIC, L->public_lanes, 2, 0},
+                                {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
+                                {P3R_AIR_POSEIDON2, 1, 2, 0},
+                                {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 0}};
+  p3r_air_desc present[5];
+  std::vector<std::unique_ptr<p3r_dmat>> traces;
+  size_t n = 0;
+  for (int i = 0; i < 5; ++i) {
+    if (L->slot_of(i) < 0) continue;
+    present[n++] = airs[i];
+    traces.push_back(std::move(R.prep[i]));
+  }
+  L->prep = prep_create<PP>(ctx, present, nullptr, n, &traces);
   std::copy(L->prep->cap_canonical.begin(), L->prep->cap_canonical.end(), commit_out);
   return L;
 }

@@ -7,6 +7,8 @@
 #include "kernels_ntt2.cuh"
 #include "poseidon2_rc_default.inc"
 #include "profile.h"
+#include "run_schedule.h"
+#include "prep_device.h"
 
 #include <algorithm>
 #include <future>
@@ -1340,6 +1342,7 @@ int p3r_circuit_levels(const p3r_circuit* circuit, size_t* n_levels) {
   *n_levels = circuit->sched.levels;
   return P3R_OK;
 }
+int p3r_circuit_prepared_on_device(const p3r_circuit* circuit) { return circuit && circuit->prepared_on_device ? 1 : 0; }
 p3r_dinputs* p3r_circuit_inputs_upload(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs) {
   p3r_dinputs* out = nullptr;
   guard(ctx, [&] {

@@ -117,11 +117,15 @@ Fp<PP> grind_witness(p3r_ctx* ctx, HostChallenger<PP>& ch, int bits) {
   return w;
 }
 
+// `dev_traces`: the preprocessed traces already in HBM (column-major, Montgomery: the device-side preparation
+// writes them there); otherwise they are uploaded from the host matrices `mats`.
 template <class PP>
-std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, const p3r_matrix* mats, size_t n) {
+std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, const p3r_matrix* mats, size_t n,
+                                      std::vector<std::unique_ptr<p3r_dmat>>* dev_traces = nullptr) {
   using F = Fp<PP>;
   auto prep = std::make_unique<p3r_prep>();
   std::vector<const p3r_dmat*> ptrs;
+  std::vector<LdeItem> items;
   for (size_t i = 0; i < n; ++i) {
     AirParams a{(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
                 (ctx->cfg.ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0};
@@ -129,17 +133,18 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
     if (a.lanes < 1) fail(P3R_EINVAL, "instance %zu: lanes must be positive", i);
     if (a.kind == AIR_ALU && (a.horner_k < 2 || a.horner_k > 8))
       fail(P3R_EINVAL, "instance %zu: horner_packed_steps must be in 2..8", i);
-    if ((int)mats[i].width != air_prep_width_of(a))
-      fail(P3R_EINVAL, "instance %zu: preprocessed width %zu, the AIR expects %d", i, mats[i].width,
-           air_prep_width_of(a));
+    const size_t width = dev_traces ? (*dev_traces)[i]->w : mats[i].width, height = dev_traces ? (*dev_traces)[i]->h : mats[i].height;
+    if ((int)width != air_prep_width_of(a))
+      fail(P3R_EINVAL, "instance %zu: preprocessed width %zu, the AIR expects %d", i, width, air_prep_width_of(a));
     (void)lookup_layout(a);
     prep->airs.push_back(a);
-    prep->heights.push_back(mats[i].height);
-    auto m = upload<PP>(ctx, mats[i].values, mats[i].height, mats[i].width);
-    prep->ldes.push_back(coset_lde<PP>(ctx, m.get(), (int)ctx->cfg.log_blowup, PP::GEN));
+    prep->heights.push_back(height);
+    auto m = dev_traces ? std::move((*dev_traces)[i]) : upload<PP>(ctx, mats[i].values, mats[i].height, mats[i].width);
+    items.push_back({m.get(), PP::GEN});
     prep->traces.push_back(std::move(m));
-    ptrs.push_back(prep->ldes.back().get());
   }
+  prep->ldes = coset_lde_batch<PP>(ctx, items, (int)ctx->cfg.log_blowup);
+  for (auto& l : prep->ldes) ptrs.push_back(l.get());
   std::vector<uint32_t> cap_mont;
   prep->tree = commit_dmats<PP>(ctx, ptrs, cap_mont);
   prep->cap_canonical.resize(cap_mont.size());

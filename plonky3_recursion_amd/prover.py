@@ -549,6 +549,7 @@ class PreparedCircuit:
         lv = C.c_size_t()
         ctx.check(ctx.lib.p3r_circuit_levels(self.h, C.byref(lv)))
         self.levels = lv.value
+        self.prepared_on_device = bool(ctx.lib.p3r_circuit_prepared_on_device(self.h))
         self._cpd_args = (ctx.lib.p3r_circuit_layer(self.h), packing, rows, commit)
         self._cpd_view = None
 

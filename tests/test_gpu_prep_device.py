@@ -1,0 +1,161 @@
+"""GPU: the device-side circuit preparation (csrc/prep_device.hip: preprocessed columns, ALU lane schedule and the
+execution schedule built in HBM) against the host restatement of the same steps (P3R_PREP_HOST=1): same
+preprocessed commitment, same schedule depth, same run traces, same proof bytes - on the synthetic layers
+(every table shape, lane counts, Horner pack sizes, long chains), on random circuits of arbitrary dependency
+structure, and on circuits the device pass must hand to the host path for its error."""
+import os
+
+import numpy as np
+import pytest
+
+import circuit_fuzz
+import harness_lib
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+FRI = dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+ARRAYS = ("const_values", "public_values", "alu_values", "recompose_values", "p2_input_values", "p2_flags", "p2_mmcs_index_sum")
+
+
+def both_ways(ctx, circuit, tp, inputs):
+    """(commitment, levels, traces, proof) with the device-side and with the host-side preparation."""
+    import plonky3_recursion_amd as p3r
+    out = []
+    for host in (False, True):
+        if host:
+            os.environ["P3R_PREP_HOST"] = "1"
+        try:
+            pc = p3r.PreparedCircuit(ctx, circuit, tp)
+        finally:
+            os.environ.pop("P3R_PREP_HOST", None)
+        assert pc.prepared_on_device == (not host)
+        res = pc.run(inputs)
+        cpd = pc.circuit_prover_data
+        traces = {k: res.download(k) for k in ARRAYS if cpd.rows[p3r.prover.TRACES_ARRAYS[k][1]]}
+        out.append((cpd.preprocessed_commitment.copy(), pc.levels, traces, pc.prove(inputs), list(cpd.table_heights),
+                    cpd.effective_packing))
+        res.free()
+        pc.free()
+    return out
+
+
+def check_same(dev, host, what):
+    assert np.array_equal(dev[0], host[0]), (what, "preprocessed commitment")
+    assert dev[1] == host[1], (what, "schedule levels", dev[1], host[1])
+    assert dev[4] == host[4] and dev[5] == host[5], (what, "table heights / effective packing")
+    for k in host[2]:
+        assert np.array_equal(dev[2][k], host[2][k]), (what, k)
+    assert dev[3] == host[3], (what, "proof bytes")
+
+
+SHAPES = [0, harness_lib.NO_POSEIDON2, harness_lib.NO_RECOMPOSE,
+          harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC,
+          harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU, harness_lib.INDEPENDENT_SPONGES]
+PACKINGS = [None, dict(public_lanes=2, alu_lanes=1, horner_packed_steps=2, recompose_lanes=2),
+            dict(public_lanes=3, alu_lanes=4, horner_packed_steps=5, recompose_lanes=1),
+            dict(alu_lanes=2, horner_packed_steps=3)]
+
+
+@pytest.mark.parametrize("field,log_h,flags,packing,gen", [
+    *[("koala-bear", 7, f, None, {}) for f in SHAPES],
+    *[("koala-bear", 8, 0, p, {}) for p in PACKINGS[1:]],
+    ("baby-bear", 8, 0, None, {}),
+    ("koala-bear", 10, 0, PACKINGS[2], dict(horner_chain_len=300, sponge_chain_len=70, merkle_depth=9)),
+    ("koala-bear", 12, harness_lib.INDEPENDENT_SPONGES, None, dict(horner_chain_len=2600, sponge_chain_len=330, merkle_depth=20)),
+    ("baby-bear", 13, 0, PACKINGS[3], dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)),
+])
+def test_device_preparation_equals_host_preparation(field, log_h, flags, packing, gen):
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    gen = dict(dict(horner_chain_len=16, sponge_chain_len=3, merkle_depth=5), **gen)
+    a = harness_lib.generate(field, log_h, seed=77 + log_h, flags=flags, **gen)
+    ctx = p3r.Context(field=field, **FRI)
+    tp = p3r.TablePacking(**(packing or {})).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    dev, host = both_ways(ctx, wl.circuit_from_arrays(a), tp, wl.circuit_inputs_from_arrays(a))
+    check_same(dev, host, (field, log_h, flags, packing))
+    ctx.close()
+
+
+@pytest.mark.parametrize("field,seeds,n_ops", [("koala-bear", range(300, 340), 300), ("baby-bear", range(400, 410), 300),
+                                               ("koala-bear", range(500, 506), 3000)])
+def test_device_preparation_on_random_circuits(field, seeds, n_ops):
+    import plonky3_recursion_amd as p3r
+    ctx = p3r.Context(field=field, **FRI)
+    P = oracle_lib.MODULUS[field]
+    for k, seed in enumerate(seeds):
+        tp = p3r.TablePacking(public_lanes=1 + k % 3, alu_lanes=1 + k % 4, horner_packed_steps=2 + k % 4,
+                              recompose_lanes=1 + k % 2).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+        c, i = circuit_fuzz.random_circuit(seed, n_ops=n_ops, modulus=P)
+        circuit = p3r.Circuit(c.witness_count, c.ops, c.ext, c.public_rows, c.private_rows, c.rewrite.reshape(-1, 2))
+        inputs = p3r.CircuitInputs(i.public_values.reshape(-1, 4), i.private_values.reshape(-1, 4), i.pd_op_ids,
+                                   i.pd_siblings.reshape(-1, 8))
+        # random circuits need not satisfy the AIRs: compare everything up to the traces, not proofs
+        import plonky3_recursion_amd.prover as pv
+        res = []
+        for host in (False, True):
+            if host:
+                os.environ["P3R_PREP_HOST"] = "1"
+            try:
+                pc = p3r.PreparedCircuit(ctx, circuit, tp)
+            finally:
+                os.environ.pop("P3R_PREP_HOST", None)
+            assert pc.prepared_on_device == (not host), seed
+            r = pc.run(inputs)
+            cpd = pc.circuit_prover_data
+            res.append((cpd.preprocessed_commitment.copy(), pc.levels, list(cpd.table_heights),
+                        {n: r.download(n) for n in ARRAYS if cpd.rows[pv.TRACES_ARRAYS[n][1]]}))
+            r.free()
+            pc.free()
+        dev, host = res
+        assert np.array_equal(dev[0], host[0]), (seed, "preprocessed commitment")
+        assert dev[1] == host[1] and dev[2] == host[2], (seed, dev[1], host[1], dev[2], host[2])
+        for n in host[3]:
+            assert np.array_equal(dev[3][n], host[3][n]), (seed, n)
+    ctx.close()
+
+
+def test_flagged_circuits_get_the_host_paths_error():
+    """What the device pass cannot describe it hands over: the error text is the host restatement's."""
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    field = "koala-bear"
+    ctx = p3r.Context(field=field, **FRI)
+    tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    a = harness_lib.generate(field, 7, seed=5, horner_chain_len=16, sponge_chain_len=3, merkle_depth=5)
+    good = wl.circuit_from_arrays(a)
+
+    def broken(edit):
+        import copy
+        c = copy.deepcopy(good)
+        c.ops = np.array(c.ops, copy=True).reshape(-1, 8)
+        c.ext = np.array(c.ext, copy=True)
+        edit(c)
+        return c
+
+    def messages(c):
+        got = []
+        for host in (False, True):
+            if host:
+                os.environ["P3R_PREP_HOST"] = "1"
+            try:
+                with pytest.raises(p3r.P3rError) as e:
+                    pc = p3r.PreparedCircuit(ctx, c, tp)
+                    pc.run(wl.circuit_inputs_from_arrays(a))   # deferred errors are reported by run, as the reference does
+                got.append(str(e.value))
+            finally:
+                os.environ.pop("P3R_PREP_HOST", None)
+        assert got[0] == got[1], got
+        return got[0]
+
+    ops = np.asarray(good.ops).reshape(-1, 8)
+    k_alu = int(np.nonzero(ops[:, 0] == p3r.prover.OP_ALU_ADD)[0][5])
+    k_const = int(np.nonzero(ops[:, 0] == p3r.prover.OP_CONST)[0][2])
+    assert "out of bounds" in messages(broken(lambda c: c.ops.__setitem__((k_alu, 1), good.witness_count + 7)))
+    assert "not canonical" in messages(broken(lambda c: c.ext.__setitem__(int(ops[k_const, 6]), 0x7F000001)))
+    assert "kind" in messages(broken(lambda c: c.ops.__setitem__((k_alu, 0), 99)))
+    # a private input nobody claims
+    c = broken(lambda c: None)
+    c.private_input_rows = np.concatenate([np.asarray(c.private_input_rows, np.uint32), [np.uint32(good.witness_count)]])
+    c.witness_count = good.witness_count + 1
+    assert "UnclaimedPrivateInput" in messages(c)
+    ctx.close()
