@@ -113,3 +113,78 @@ def test_hip_prover_reproduces_the_rust_proof(oracle, field, key):
     assert got == bytes.fromhex(g["batch_proof_postcard_hex"])
     pc.free()
     ctx.close()
+
+
+# ---- the tables the Fibonacci circuit does not reach (Poseidon2, Recompose, Mul / MulAdd, packed HornerAcc) --------
+TABLE_OF = {"const": 0, "public": 1, "alu": 2, "poseidon2": 3, "recompose": 4}
+
+
+def _npo_layer(oracle, field, key):
+    import circuit_lib as cl
+    import layer_lib
+    import oracle_lib
+    g = load(f"rust_npo_layer_{key}.json")
+    rc = np.array(g["rc"], dtype=np.uint32)
+    c = g["circuit"]
+    circuit = cl.Circuit(c["witness_count"], np.array(c["ops"], dtype=np.uint32), c["ext"], c["public_rows"], c["private_rows"],
+                         c["rewrite"])
+    pd = g["inputs"]["private_data"]
+    inputs = cl.Inputs(np.array(g["inputs"]["public_values"], dtype=np.uint32).reshape(-1), (),
+                       [d["op_id"] for d in pd], np.array([d["sibling"] for d in pd], dtype=np.uint32).reshape(-1))
+    oc = cl.OracleCircuit(oracle, circuit).preprocess(oracle_lib.MODULUS[field])
+    return g, rc, circuit, inputs, oc, layer_lib.params(**g["fri"])
+
+
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_rust_npo_layer_localises_every_table(oracle, field, key):
+    """Stage by stage against the reference's own run of the NPO circuit, so that a mismatch names one choice
+    (tools/rust_pin/README.md has the table): preprocessed columns -> runner -> per-table main traces ->
+    preprocessed commitment -> native verifier on the Rust proof -> proof bytes."""
+    import layer_lib
+    import plonky3_recursion_amd as p3r
+    g, rc, circuit, inputs, oc, prm = _npo_layer(oracle, field, key)
+    want = g["preprocessed_columns"]
+    # get_airs_and_degrees_with_prep: [const, public, alu] primitive columns, then the NPO maps
+    prim = want["primitive"]
+    assert oc.get("const_prep").tolist() == prim[0], "Const preprocessed columns (ext_mult, D*idx)"
+    assert oc.get("public_prep").tolist() == prim[1], "Public preprocessed columns"
+    assert oc.get("alu_prep13").tolist() == prim[2], "ALU preprocessed columns: bus roles and signed multiplicities"
+    oc.run(field, inputs)
+    got = oc.workload_arrays()
+    assert got["alu_values"].reshape(-1, 16).tolist() == g["alu_trace_values"], "CircuitRunner: AluOpRecords"
+    L = layer_lib.OracleLayer(oracle, field, got, prm, packing=dict(g["packing"]), rc=rc)
+    tables = L.tables()
+    mains = {m["table"]: m for m in g["main_traces"]}
+    for t in tables:
+        name = next((n for n in mains if n.lower().startswith(t["kind"])), None)   # "poseidon2_perm/..." for the permutation table
+        assert name is not None, (t["kind"], list(mains))
+        ref = np.array(mains[name]["values"], dtype=np.uint32).reshape(-1, mains[name]["width"])
+        assert t["main"].shape == ref.shape, (t["kind"], "main trace shape", t["main"].shape, ref.shape)
+        assert np.array_equal(t["main"], ref), (t["kind"], "main trace: column order (Poseidon2Cols interior order for the "
+                                                "permutation table, lane schedule and packed-Horner columns for the ALU)")
+    assert [int(t["main"].shape[0]).bit_length() - 1 for t in tables] == g["degree_bits"], "table heights"
+    inner = bytes.fromhex(g["batch_proof_postcard_hex"])
+    outer = bytes.fromhex(g["batch_stark_proof_postcard_hex"])
+    proof = p3r.BatchStarkProof.from_postcard(outer, field)
+    assert proof.proof == inner and proof.to_postcard() == outer, "BatchStarkProof postcard layout (npo_lanes, non_primitives)"
+    assert np.array_equal(proof.preprocessed_commitment, L.prep_commit()), \
+        "preprocessed commitment: Poseidon2 24-column layout / scheduled ALU preprocessed trace"
+    cfg, keep = p3r.make_config(field, poseidon2_rc=rc, **g["fri"])
+    p3r.verify_all_tables(cfg, proof)     # constraint order of the inner permutation AIR, CTL + packed-Horner lookups, LogUp packing
+    L.verify(inner)
+    assert L.prove() == inner, "prove_batch bytes"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_hip_prover_reproduces_the_rust_npo_proof(oracle, field, key):
+    import plonky3_recursion_amd as p3r
+    g, rc, circuit, inputs, oc, prm = _npo_layer(oracle, field, key)
+    ctx = p3r.Context(field=field, poseidon2_rc=rc, **g["fri"])
+    tp = p3r.TablePacking(**g["packing"]).with_fri_params(g["fri"]["log_final_poly_len"], g["fri"]["log_blowup"])
+    pc = p3r.PreparedCircuit(ctx, p3r.Circuit(circuit.witness_count, circuit.ops, circuit.ext, circuit.public_rows), tp)
+    got = pc.prove(p3r.CircuitInputs(public_values=inputs.public_values.reshape(-1, 4), private_data_op_ids=inputs.pd_op_ids,
+                                     private_data_siblings=inputs.pd_siblings.reshape(-1, 8)))
+    assert got == bytes.fromhex(g["batch_proof_postcard_hex"])
+    pc.free()
+    ctx.close()

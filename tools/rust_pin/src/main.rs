@@ -12,6 +12,17 @@
 //!       the preprocessed commitment, degree bits.  tests/test_rust_pins.py verifies these bytes with
 //!       the native verifier and compares them with the oracle's and the HIP prover's bytes.
 //!
+//!   tests/golden/rust_npo_layer_<field>.json
+//!       a second circuit built with the reference's own builder ops, covering the tables the Fibonacci circuit
+//!       does not reach (SURVEY appendix A's largest risks): Poseidon2 permutation rows (a sponge chain, a Merkle
+//!       path with mmcs_bit and an exposed mmcs_index_sum), a Recompose op, Mul / MulAdd ops and a packed
+//!       HornerAcc run, proved with prove_all_tables under TablePacking::new(1, 3) (horner_packed_steps = 4).
+//!       Next to the proof bytes it holds the LOWERED circuit in this repo's flat op format (so the tests do not
+//!       have to reproduce the builder's lowering), the circuit inputs, the preprocessed columns of
+//!       get_airs_and_degrees_with_prep, the Traces of the run and, per table, the main trace matrix the
+//!       registered TableProvers build - a mismatch localises to
+//!       (bus roles / multiplicities | runner | Poseidon2Cols interior order | constraint order | LogUp packing).
+//!
 //! Written against the API the reference itself uses (recursion/examples/common/mod.rs:192-207,
 //! 464-486; circuit-prover/src/batch_stark_prover/tests.rs:1031-1099).  It has NOT been compiled in
 //! this repo's build image (no cargo there): expect to fix an import or two on first use.
@@ -57,8 +68,12 @@ fn from_json<F: PrimeCharacteristicRing>(v: &Value) -> Vec<F> {
     v.as_array().unwrap().iter().map(|x| F::from_u64(x.as_u64().unwrap())).collect()
 }
 
+// NOTE on `main_traces_for_pinning`: prove() builds the per-table matrices internally (batch_stark_prover.rs:1366-1415:
+// AluAir::trace_to_matrix, ConstAir / PublicAir builders, every registered TableProver::batch_instance_d4).  The kit needs
+// them from outside; the three-line accessor to add to BatchStarkProver for that is in README.md ("main trace dump").
 macro_rules! field_module {
-    ($modname:ident, $F:ty, $Perm:ty, $default_perm:path, $rc_ei:path, $rc_int:path, $rc_ef:path, $key:literal) => {
+    ($modname:ident, $F:ty, $Perm:ty, $default_perm:path, $rc_ei:path, $rc_int:path, $rc_ef:path, $key:literal,
+     $p2_params:ty, $p2_config:expr) => {
         mod $modname {
             use super::*;
             pub type F = $F;
@@ -216,8 +231,206 @@ macro_rules! field_module {
                     "batch_proof_postcard_hex": hex(&inner),
                 })
             }
+
+            /// The tables the Fibonacci circuit does not reach: Poseidon2 (sponge chain + Merkle path), Recompose,
+            /// Mul / MulAdd and a packed HornerAcc run (circuit-prover/examples/poseidon2_perm_merkle.rs is the
+            /// model for the permutation rows).
+            pub fn npo_layer() -> Value {
+                use p3_circuit::ops::{Poseidon2PermCall, Poseidon2PermPrivateData, NpoPrivateData, generate_poseidon2_trace,
+                                      generate_recompose_trace};
+                use p3_circuit_prover::batch_stark_prover::{poseidon2_air_builders, recompose_air_builders, Poseidon2Preprocessor,
+                                                            RecomposePreprocessor};
+                use p3_circuit_prover::common::NpoPreprocessor;
+                let perm: Perm = $default_perm();
+                let p2cfg = $p2_config;
+                let ef = |v: u64| Challenge::from(F::from_u64(v));
+                let ef4 = |a: u64| Challenge::from_basis_coefficients_fn(|i| F::from_u64(a + 7 * i as u64));
+                let mut builder = CircuitBuilder::<Challenge>::new();
+                builder.enable_poseidon2_perm::<$p2_params, _>(generate_poseidon2_trace::<Challenge, $p2_params>, perm.clone());
+                builder.enable_recompose::<F>(generate_recompose_trace::<F, Challenge>);
+                // ---- ALU: Add, Mul, MulAdd, a HornerAcc run of six steps with one alpha (packs as 4 + 2 at K = 4)
+                let x = builder.public_input();
+                let y = builder.public_input();
+                let alpha = builder.public_input();
+                let s = builder.add(x, y);
+                let m = builder.mul(s, y);
+                let ma = builder.mul_add(m, x, s);
+                let mut acc = builder.alloc_const(Challenge::ZERO, "acc0");
+                let mut horner_inputs = Vec::new();
+                for k in 0..6u64 {
+                    let pz = builder.alloc_const(ef4(100 + k), "p_at_z");
+                    let px = builder.alloc_const(ef4(200 + k), "p_at_x");
+                    horner_inputs.push((100 + k, 200 + k));
+                    acc = builder.horner_acc_step(acc, alpha, pz, px);
+                }
+                let folded = builder.mul(acc, ma);
+                // ---- Recompose: four base-field witnesses into one extension witness
+                let coeffs: Vec<_> = (0..4u64).map(|i| builder.alloc_const(ef(11 + i), "coeff")).collect();
+                let packed = builder.recompose_base_coeffs_to_ext::<F>(&coeffs).unwrap();
+                let pr = builder.mul(packed, folded);
+                // ---- Poseidon2: a two-row sponge (absorb x, y; then absorb pr), digest exposed
+                let (_, row0) = builder.add_poseidon2_perm(&Poseidon2PermCall {
+                    config: p2cfg, new_start: true, merkle_path: false, mmcs_bit: None, mmcs_bit2: None,
+                    inputs: vec![Some(x), Some(y), None, None], out_ctl: vec![false, false], return_all_outputs: false,
+                    mmcs_index_sum: None }).unwrap();
+                let _ = row0;
+                let (_, row1) = builder.add_poseidon2_perm(&Poseidon2PermCall {
+                    config: p2cfg, new_start: false, merkle_path: false, mmcs_bit: None, mmcs_bit2: None,
+                    inputs: vec![Some(pr), None, None, None], out_ctl: vec![true, true], return_all_outputs: false,
+                    mmcs_index_sum: None }).unwrap();
+                let (d0, d1) = (row1[0].unwrap(), row1[1].unwrap());
+                // ---- Poseidon2: a Merkle path of three rows from that digest (bits 1, 0 -> index sum 2)
+                let bit0 = builder.alloc_const(Challenge::ZERO, "bit0");
+                let bit1 = builder.alloc_const(Challenge::ONE, "bit1");
+                let idx_sum = builder.public_input();
+                let root0 = builder.public_input();
+                let root1 = builder.public_input();
+                let (leaf_id, _) = builder.add_poseidon2_perm(&Poseidon2PermCall {
+                    config: p2cfg, new_start: true, merkle_path: true, mmcs_bit: Some(bit0), mmcs_bit2: None,
+                    inputs: vec![Some(d0), Some(d1), None, None], out_ctl: vec![false, false], return_all_outputs: false,
+                    mmcs_index_sum: None }).unwrap();
+                let (mid_id, _) = builder.add_poseidon2_perm(&Poseidon2PermCall {
+                    config: p2cfg, new_start: false, merkle_path: true, mmcs_bit: Some(bit1), mmcs_bit2: None,
+                    inputs: vec![None; 4], out_ctl: vec![false, false], return_all_outputs: false, mmcs_index_sum: None }).unwrap();
+                let (top_id, top) = builder.add_poseidon2_perm(&Poseidon2PermCall {
+                    config: p2cfg, new_start: false, merkle_path: true, mmcs_bit: Some(bit0), mmcs_bit2: None,
+                    inputs: vec![None; 4], out_ctl: vec![true, true], return_all_outputs: false, mmcs_index_sum: Some(idx_sum) }).unwrap();
+                builder.connect(top[0].unwrap(), root0);
+                builder.connect(top[1].unwrap(), root1);
+                let circuit = builder.build().unwrap();
+
+                // ---- native evaluation of the public inputs the circuit checks (digest of the Merkle path)
+                let xv = ef4(3); let yv = ef4(5); let av = ef4(9);
+                let sv = xv + yv; let mv = sv * yv; let mav = mv * xv + sv;
+                let mut accv = Challenge::ZERO;
+                for (pz, px) in &horner_inputs { accv = accv * av + ef4(*pz) - ef4(*px); }
+                let prv = Challenge::from_basis_coefficients_fn(|i| F::from_u64(11 + i as u64)) * (accv * mav);
+                let flat = |l: &[Challenge]| -> Vec<F> { l.iter().flat_map(|e| e.as_basis_coefficients_slice().to_vec()).collect() };
+                let mut st = [F::ZERO; WIDTH];
+                st[..8].copy_from_slice(&flat(&[xv, yv]));
+                let mut st = perm.permute(st);
+                st[..4].copy_from_slice(&flat(&[prv]));
+                let st = perm.permute(st);
+                let sib = |k: u64| [ef4(1000 + k), ef4(2000 + k)];
+                // leaf row: digest limbs + sibling in the capacity limbs, bit 0
+                let mut row = [F::ZERO; WIDTH];
+                row[..8].copy_from_slice(&st[..8]);
+                row[8..].copy_from_slice(&flat(&sib(0)));
+                let out = perm.permute(row);
+                // bit 1: the running digest is the right child
+                let mut row = [F::ZERO; WIDTH];
+                row[..8].copy_from_slice(&flat(&sib(1)));
+                row[8..].copy_from_slice(&out[..8]);
+                let out = perm.permute(row);
+                let mut row = [F::ZERO; WIDTH];
+                row[..8].copy_from_slice(&out[..8]);
+                row[8..].copy_from_slice(&flat(&sib(2)));
+                let out = perm.permute(row);
+                let limb = |k: usize| Challenge::from_basis_coefficients_slice(&out[4 * k..4 * k + 4]).unwrap();
+                let publics = vec![xv, yv, av, ef(2), limb(0), limb(1)];
+
+                let packing = TablePacking::new(1, 3).with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
+                let cfg = config();
+                let npo_prep: Vec<Box<dyn NpoPreprocessor<F>>> = vec![Box::new(Poseidon2Preprocessor), Box::new(RecomposePreprocessor::default())];
+                let mut air_builders = poseidon2_air_builders::<_, 4>();
+                air_builders.extend(recompose_air_builders(1, false));
+                let (airs_degrees, primitive_columns, non_primitive_columns) =
+                    get_airs_and_degrees_with_prep::<MyConfig, Challenge, 4>(&circuit, &packing, &npo_prep, &air_builders, ConstraintProfile::Standard).unwrap();
+                let (airs, log_degrees): (Vec<_>, Vec<usize>) = airs_degrees.into_iter().unzip();
+                let prep_json = json!({
+                    "primitive": primitive_columns.iter().map(|c| u32s(c)).collect::<Vec<_>>(),
+                    "non_primitive": non_primitive_columns.iter().map(|(k, c)| (k.to_string(), u32s(c))).collect::<std::collections::BTreeMap<_, _>>(),
+                });
+                let prover_data = ProverData::from_airs_and_degrees(&cfg, &airs, &log_degrees);
+                let cpd = CircuitProverData::new(prover_data, primitive_columns, non_primitive_columns);
+                let mut runner = circuit.runner();
+                runner.set_public_inputs(&publics).unwrap();
+                let mut private_data = Vec::new();
+                for (k, id) in [leaf_id, mid_id, top_id].into_iter().enumerate() {
+                    let s2 = sib(k as u64);
+                    runner.set_private_data(id, NpoPrivateData::new(Poseidon2PermPrivateData { sibling: s2.to_vec() })).unwrap();
+                    private_data.push(json!({"op_id": id.0, "sibling": u32s(&flat(&s2))}));
+                }
+                let traces = runner.run().unwrap();
+                let mut prover = BatchStarkProver::new(cfg).with_table_packing(packing.clone());
+                prover.register_poseidon2_table::<4>(p2cfg);
+                prover.register_recompose_table::<4>(false);
+                // the main trace matrix of every table, as prove() builds them (batch_stark_prover.rs:1366-1415)
+                let mains: Vec<Value> = prover.main_traces_for_pinning::<Challenge, 4>(&traces, &cpd).into_iter()
+                    .map(|(name, m)| json!({"table": name, "width": m.width(), "values": u32s(&m.values)})).collect();
+                let proof: BatchStarkProof<MyConfig> = prover.prove_all_tables(&traces, &cpd).unwrap();
+                prover.verify_all_tables::<Challenge>(&proof).unwrap();
+                let outer = postcard::to_allocvec(&proof).unwrap();
+                let inner = postcard::to_allocvec(&proof.proof).unwrap();
+                let (ops, ext) = flatten_circuit::<F, Challenge>(&circuit);
+                json!({
+                    "field": $key,
+                    "fri": {"log_blowup": LOG_BLOWUP, "max_log_arity": MAX_LOG_ARITY, "cap_height": CAP_HEIGHT,
+                            "log_final_poly_len": LOG_FINAL_POLY_LEN, "commit_pow_bits": COMMIT_POW_BITS,
+                            "query_pow_bits": QUERY_POW_BITS, "num_queries": NUM_QUERIES},
+                    "packing": {"public_lanes": 1, "alu_lanes": 3, "horner_packed_steps": 4, "recompose_lanes": 1},
+                    "rc": round_constants(),
+                    "circuit": {"witness_count": circuit.witness_count, "ops": ops, "ext": ext,
+                                "public_rows": circuit.public_rows.iter().map(|w| w.0).collect::<Vec<_>>(),
+                                "private_rows": Vec::<u32>::new(), "rewrite": Vec::<u32>::new()},
+                    "inputs": {"public_values": publics.iter().map(|e| u32s(e.as_basis_coefficients_slice())).collect::<Vec<_>>(),
+                               "private_data": private_data},
+                    "preprocessed_columns": prep_json,
+                    "alu_trace_values": traces.alu_trace.values.iter().map(|r| r.iter().flat_map(|e| u32s(e.as_basis_coefficients_slice())).collect::<Vec<u32>>()).collect::<Vec<_>>(),
+                    "main_traces": mains,
+                    "degree_bits": log_degrees,
+                    "batch_stark_proof_postcard_hex": hex(&outer),
+                    "batch_proof_postcard_hex": hex(&inner),
+                })
+            }
         }
     };
+}
+
+const NO_W: u32 = u32::MAX;
+
+/// `Circuit<EF>` (circuit/src/circuit.rs:152-181) -> rows [kind, a, b, c, out, aux, ext_off, ext_len] + ext[]:
+/// the flat op format of include/p3r.h (`p3r_op`), as INTEGRATION.md section 3b's shim produces it.
+fn flatten_circuit<F: PrimeField32, EF: BasedVectorSpace<F> + Field>(c: &p3_circuit::Circuit<EF>) -> (Vec<[u32; 8]>, Vec<u32>) {
+    use p3_circuit::ops::Op;
+    let (mut ops, mut ext) = (Vec::new(), Vec::<u32>::new());
+    let w = |x: &Option<p3_circuit::WitnessId>| x.map_or(NO_W, |w| w.0);
+    let slot = |v: &Vec<p3_circuit::WitnessId>| v.first().map_or(NO_W, |w| w.0);
+    for op in &c.ops {
+        let off = ext.len() as u32;
+        match op {
+            Op::Const { out, val } => {
+                ext.extend(val.as_basis_coefficients_slice().iter().map(|x| x.as_canonical_u32()));
+                ops.push([0, 0, 0, NO_W, out.0, NO_W, off, 4]);
+            }
+            Op::Public { out, public_pos } => ops.push([1, 0, 0, NO_W, out.0, *public_pos as u32, off, 0]),
+            Op::Alu { kind, a, b, c, out, intermediate_out } =>
+                ops.push([2 + *kind as u32, a.0, b.0, w(c), out.0, w(intermediate_out), off, 0]),
+            Op::Hint { inputs, outputs, .. } => {
+                // ExtDecompositionHint has exactly D outputs, BinaryDecompositionHint any number of bits
+                ext.extend(outputs.iter().map(|w| w.0));
+                let kind = if outputs.len() == 4 { 7 } else { 8 };
+                ops.push([kind, inputs[0].0, 0, NO_W, 0, NO_W, off, outputs.len() as u32]);
+            }
+            Op::NonPrimitiveOpWithExecutor { inputs, outputs, executor, op_id } => {
+                let ty = executor.op_type().to_string();
+                if ty.starts_with("poseidon2_perm") {
+                    // inputs: 4 limbs, mmcs_index_sum, mmcs_bit; new_start / merkle_path live on the executor
+                    // (circuit/src/ops/poseidon_perm/executor.rs:45-52) and are read off its Debug form here
+                    let dbg = format!("{executor:?}");
+                    let flag = |name: &str| dbg.contains(&format!("{name}: true")) as u32;
+                    ext.extend(inputs[..6].iter().map(slot));
+                    ext.push(outputs.len() as u32);
+                    ext.extend(outputs.iter().map(slot));
+                    ops.push([9, op_id.0 as u32, 0, NO_W, 0, flag("new_start") | flag("merkle_path") << 1, off, 7 + outputs.len() as u32]);
+                } else {
+                    ext.extend(inputs[0].iter().map(|w| w.0));  // Recompose (circuit/src/ops/recompose.rs:115-170)
+                    ops.push([10, op_id.0 as u32, 0, NO_W, outputs[0][0].0, NO_W, off, 4]);
+                }
+            }
+        }
+    }
+    (ops, ext)
 }
 
 fn hex(b: &[u8]) -> String {
@@ -226,10 +439,12 @@ fn hex(b: &[u8]) -> String {
 
 field_module!(koala, p3_koala_bear::KoalaBear, p3_koala_bear::Poseidon2KoalaBear<16>, p3_koala_bear::default_koalabear_poseidon2_16,
               p3_koala_bear::KOALABEAR_POSEIDON2_RC_16_EXTERNAL_INITIAL, p3_koala_bear::KOALABEAR_POSEIDON2_RC_16_INTERNAL,
-              p3_koala_bear::KOALABEAR_POSEIDON2_RC_16_EXTERNAL_FINAL, "koala_bear");
+              p3_koala_bear::KOALABEAR_POSEIDON2_RC_16_EXTERNAL_FINAL, "koala_bear",
+              p3_poseidon2_circuit_air::KoalaBearD4Width16, p3_circuit::ops::Poseidon2Config::KOALA_BEAR_D4_W16);
 field_module!(baby, p3_baby_bear::BabyBear, p3_baby_bear::Poseidon2BabyBear<16>, p3_baby_bear::default_babybear_poseidon2_16,
               p3_baby_bear::BABYBEAR_POSEIDON2_RC_16_EXTERNAL_INITIAL, p3_baby_bear::BABYBEAR_POSEIDON2_RC_16_INTERNAL,
-              p3_baby_bear::BABYBEAR_POSEIDON2_RC_16_EXTERNAL_FINAL, "baby_bear");
+              p3_baby_bear::BABYBEAR_POSEIDON2_RC_16_EXTERNAL_FINAL, "baby_bear",
+              p3_poseidon2_circuit_air::BabyBearD4Width16, p3_circuit::ops::Poseidon2Config::BABY_BEAR_D4_W16);
 
 fn main() {
     let golden = concat!(env!("CARGO_MANIFEST_DIR"), "/../../tests/golden");
@@ -244,5 +459,7 @@ fn main() {
     fs::write(format!("{golden}/rust_primitives.json"), serde_json::to_string(&out).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_fibonacci_layer_koala_bear.json"), serde_json::to_string(&koala::fibonacci_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_fibonacci_layer_baby_bear.json"), serde_json::to_string(&baby::fibonacci_layer()).unwrap()).unwrap();
-    println!("wrote rust_primitives.json and rust_fibonacci_layer_*.json under {golden}");
+    fs::write(format!("{golden}/rust_npo_layer_koala_bear.json"), serde_json::to_string(&koala::npo_layer()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_npo_layer_baby_bear.json"), serde_json::to_string(&baby::npo_layer()).unwrap()).unwrap();
+    println!("wrote rust_primitives.json, rust_fibonacci_layer_*.json and rust_npo_layer_*.json under {golden}");
 }
