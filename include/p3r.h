@@ -355,6 +355,7 @@ typedef struct p3r_npo_table_entry {
 } p3r_npo_table_entry;
 typedef struct p3r_batch_stark_meta {
   uint64_t proof_len;      /* length of the inner BatchProof at the head of the bytes */
+  uint64_t parse_ns;       /* time this call spent (steady clock): what a parent node pays per child */
   uint32_t public_lanes, alu_lanes, min_trace_height, horner_packed_steps;
   uint32_t n_npo_lanes;    /* TablePacking.npo_lanes: Vec<(NpoTypeId, usize)> */
   struct { char op_type[64]; uint32_t lanes; } npo_lanes[P3R_META_MAX_NPO];

@@ -122,7 +122,7 @@ class P3rNpoLanes(C.Structure):
 
 class P3rBatchStarkMeta(C.Structure):
     _fields_ = [
-        ("proof_len", C.c_uint64),
+        ("proof_len", C.c_uint64), ("parse_ns", C.c_uint64),
         ("public_lanes", C.c_uint32), ("alu_lanes", C.c_uint32), ("min_trace_height", C.c_uint32),
         ("horner_packed_steps", C.c_uint32),
         ("n_npo_lanes", C.c_uint32), ("npo_lanes", P3rNpoLanes * 8),

@@ -1305,12 +1305,14 @@ int p3r_batch_stark_proof_parse(uint32_t field, const uint8_t* bytes, size_t len
                                 size_t err_cap) {
   try {
     if (!bytes || !out) throw std::runtime_error("NULL argument");
+    const auto t0 = std::chrono::steady_clock::now();
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     p3r::ProofLayout PL;
     if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
     if (field == P3R_FIELD_KOALA_BEAR) p3r::parse_batch_stark_meta<p3r::KoalaBearParams>(bytes, len, canonical, PL, out);
     else if (field == P3R_FIELD_BABY_BEAR) p3r::parse_batch_stark_meta<p3r::BabyBearParams>(bytes, len, canonical, PL, out);
     else throw std::runtime_error("unknown field");
+    out->parse_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return P3R_OK;
   } catch (const std::exception& e) {
     if (err_buf && err_cap) snprintf(err_buf, err_cap, "%s", e.what());

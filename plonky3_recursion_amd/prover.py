@@ -272,6 +272,7 @@ class BatchStarkProof:
     degree_bits: tuple = ()
     monty_r: int = 0                 # 2^32 mod p when field elements serialise in Montgomery form, else 0
     modulus: int = 0
+    parse_ns: int = field(default=0, compare=False)   # from_postcard: time spent in the native parser (p3r_batch_stark_proof_parse)
 
     def _fe(self, x: int) -> bytes:
         return _varint((x << 32) % self.modulus if self.monty_r else x)
@@ -345,7 +346,7 @@ class BatchStarkProof:
                    preprocessed_commitment=commitment,
                    preprocessed_widths=tuple(m.preprocessed_widths[:m.n_instances]) if m.has_stark_common else (),
                    degree_bits=tuple(m.degree_bits[:m.n_instances]) if m.has_stark_common else (),
-                   monty_r=0 if canonical_field_encoding else 1, modulus=MODULUS[field])
+                   monty_r=0 if canonical_field_encoding else 1, modulus=MODULUS[field], parse_ns=int(m.parse_ns))
 
     def to_postcard(self) -> bytes:
         """postcard bytes of the whole `BatchStarkProof<SC>`, field order = the serde derives of

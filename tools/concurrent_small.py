@@ -9,7 +9,7 @@ FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, co
 LOG_H = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 REPS = 40
 a = harness_lib.generate("koala-bear", LOG_H, seed=3)
-for n_ctx in (1, 2, 4, 8):
+for n_ctx in (tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 2, 4, 8)):
     workers = []
     for i in range(n_ctx):
         ctx = p3r.Context(field="koala-bear", **FRI)
