@@ -332,17 +332,24 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
             out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=wk["leaf_inputs"]), wk["ctx"], backend, params,
                                        prep=wk["leaf_cache"])
             note("leaf_ms", (time.perf_counter() - t0) * 1e3)
-            return out.proof.to_postcard()
+            return out.proof
         finally:
             workers.put(wk)
 
-    def prove_parent(_tree, level, node, lbytes, rbytes):
+    def decode(data):
+        """A child proof off the wire (or, in the level-synchronous mode, any child): native parse + metadata rules."""
+        t0 = time.perf_counter()
+        proof = p3r.BatchStarkProof.from_postcard(data, field)
+        note("child_parse_ms", (time.perf_counter() - t0) * 1e3)
+        note("child_parse_native_ms", proof.parse_ns * 1e-6)
+        return proof
+
+    def prove_parent(_tree, level, node, left, right):
         wk = workers.get()
         try:
-            t0 = time.perf_counter()
-            children = [p3r.BatchStarkProof.from_postcard(b, field) for b in (lbytes, rbytes)]   # native parse + metadata rules
-            note("child_parse_ms", (time.perf_counter() - t0) * 1e3)
-            note("child_parse_native_ms", sum(c.parse_ns for c in children) * 1e-6)
+            # children proved on this rank arrive as the BatchStarkProof their prover returned; only proofs that changed
+            # rank were serialised, and those were parsed on receipt by the communication thread (decode)
+            children = [c if isinstance(c, p3r.BatchStarkProof) else decode(c) for c in (left, right)]
             if args.tree_verify_children:
                 t1 = time.perf_counter()
                 for c in children:
@@ -354,7 +361,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
                 p3r.RecursionInput(prev_proof=children[1], circuit_inputs=n_right),
                 node_circuit, wk["ctx"], backend, params, prep_cache=wk["agg_cache"], left_non_primitive_ops=left_ops)
             note("node_ms", (time.perf_counter() - t1) * 1e3)
-            return out.proof.to_postcard()
+            return out.proof
         finally:
             workers.put(wk)
 
@@ -376,6 +383,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
     with ThreadPoolExecutor(max_workers=len(all_workers)) as ex:
         warm = list(ex.map(lambda i: prove_leaf(0, i), range(len(all_workers))))
         list(ex.map(lambda w: prove_parent(0, 1, 0, w, w), warm))
+        decode(warm[0].to_postcard())
     for v in stats.values():
         v.clear()
     times = []
@@ -386,13 +394,14 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
         node_done.clear()
         t0 = time.perf_counter()
         if args.tree_level_barriers:
-            r = run_aggregation_tree(plans[0], rank, lambda i: prove_leaf(0, i), lambda lv, nd, lb, rb: prove_parent(0, lv, nd, lb, rb),
+            r = run_aggregation_tree(plans[0], rank, lambda i: prove_leaf(0, i).to_postcard(),
+                                     lambda lv, nd, lb, rb: prove_parent(0, lv, nd, lb, rb).to_postcard(),
                                      dist=dist, device=coll_device, on_level=on_level, level_barrier=barrier,
                                      workers=len(all_workers))
             roots = [r] if rank == 0 else None
         else:
             roots = run_aggregation_forest(plans, rank, prove_leaf, prove_parent, dist=dist, device=coll_device,
-                                           workers=len(all_workers),
+                                           workers=len(all_workers), encode=lambda pr: pr.to_postcard(), decode=decode,
                                            on_node=lambda t, lv, nd, sec: node_done.append((lv, sec * 1e3)))
         barrier()
         times.append(time.perf_counter() - t0)
@@ -408,8 +417,9 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
     ok = True
     if rank == 0:
         import hashlib
+        roots = [r.to_postcard() if isinstance(r, p3r.BatchStarkProof) else r for r in roots]
         for root in roots:
-            rp = p3r.BatchStarkProof.from_postcard(root, field)
+            rp = p3r.BatchStarkProof.from_postcard(root, field)    # the root is checked from its wire form
             try:
                 p3r.verify_all_tables(ctx.cfg, rp)
             except Exception as e:

@@ -142,14 +142,19 @@ def _run_levels(plan, rank, prove_leaf, prove_parent, dist, device, on_level, le
 
 def run_aggregation_forest(plans, rank: int, prove_leaf: Callable[[int, int], bytes],
                            prove_parent: Callable[[int, int, int, bytes, bytes], bytes], dist=None, device="cpu",
-                           workers: int = 1, on_node: Optional[Callable[[int, int, int, float], None]] = None) -> Optional[List[bytes]]:
+                           workers: int = 1, on_node: Optional[Callable[[int, int, int, float], None]] = None,
+                           encode: Callable = lambda proof: proof, decode: Callable = lambda data: data) -> Optional[List[bytes]]:
     """Dependency-driven scheduler for one or more 2-to-1 trees in flight (`plans`: one TreePlan per tree, all
     over the same world).  A parent is proved as soon as ITS two children are on its rank - there is no level
     barrier - by a pool of `workers` host threads (callbacks must be thread-safe for workers > 1: one p3r_ctx
     = one HIP stream per thread).  The reference's driver is the serial pair loop of
     recursive_aggregation.rs:447-475; the nodes it proves one after the other are independent.
 
-    prove_leaf(tree, i) -> proof bytes; prove_parent(tree, level, node, left, right) -> proof bytes.
+    prove_leaf(tree, i) -> proof; prove_parent(tree, level, node, left, right) -> proof.  A proof is whatever the
+    callbacks exchange (bytes by default).  `encode(proof) -> bytes` / `decode(bytes) -> proof` are applied only to
+    proofs that change rank, by the communication thread: a child proved on this rank reaches its parent as the
+    object its prover returned (the reference's driver never serialises a child either), a child that arrives over
+    the wire is parsed on receipt, while the parent is still waiting for its other child or for a prover.
     Child proofs that must change rank, and each tree's root on its way to rank 0, are moved by ONE
     communication thread per rank that walks the (level, tree, node)-sorted list of this rank's messages:
     both ends of a message reach it after the same earlier messages, so blocking send/recv pairs match
@@ -224,9 +229,9 @@ def run_aggregation_forest(plans, rank: int, prove_leaf: Callable[[int, int], by
                 torch.cuda.set_device(device)
             for _, _, _, src, dst, key in mine:
                 if src == rank:
-                    _send_bytes(dist, future_of(key).result(), dst, device)
+                    _send_bytes(dist, encode(future_of(key).result()), dst, device)
                 else:
-                    future_of(key).set_result(_recv_bytes(dist, src, device))
+                    future_of(key).set_result(decode(_recv_bytes(dist, src, device)))
                 done += 1
         except BaseException as e:  # noqa: BLE001
             errors.append(e)

@@ -146,6 +146,20 @@ inline std::shared_ptr<DevPool>& tls_pool() {
   return p;
 }
 
+// Development knobs (tile sizes, the pre-round-2 NTT passes, copy-engine fetches, Merkle partition): environment
+// variables that select equality-tested alternatives of the shipped path.  They exist in the `knobs` build of the
+// library only (-DP3R_TUNING_KNOBS: plonky3_recursion_amd/knobs/libp3r_hip.so, what tests/test_gpu_cpp_host.py and the
+// tuning tools load); in the product build every knob reads as unset and the alternatives are dead code the
+// compiler drops.
+inline const char* tuning_knob(const char* name) {
+#ifdef P3R_TUNING_KNOBS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // Blocking host->device / device->host copy ordered on the ctx stream.
 inline hipError_t copy_sync(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
@@ -253,7 +267,7 @@ struct HostPost {
     if (host) (void)hipHostFree(host);
   }
   static bool enabled() {
-    static const bool off = getenv("P3R_NO_POLLED_FETCH") != nullptr;
+    static const bool off = tuning_knob("P3R_NO_POLLED_FETCH") != nullptr;
     return !off;
   }
   // `words` <= kWords cells from `src` (device) -> *out (valid until the next post)

@@ -262,7 +262,7 @@ struct NttJob {
 template <class PP>
 void launch_ntt(p3r_ctx* ctx, std::vector<NttJob>& jobs, const char* name) {
   if (jobs.empty()) return;
-  static const int log_tile = getenv("P3R_NTT_LOG_TILE") ? atoi(getenv("P3R_NTT_LOG_TILE")) : 13;  // 2^13 cells, 512 lanes: 4 tiles per CU overlap their phases
+  static const int log_tile = tuning_knob("P3R_NTT_LOG_TILE") ? atoi(tuning_knob("P3R_NTT_LOG_TILE")) : 13;  // 2^13 cells, 512 lanes: 4 tiles per CU overlap their phases
   std::vector<NttPass> passes;
   size_t lds_max = 0;
   unsigned threads_max = 64;
@@ -315,7 +315,7 @@ constexpr int kNtt2MinLogR = 5, kNtt2MaxLogR = 12, kNtt2MaxLineLogR = 13;
 // layer): one launch of the mixed-size kernel instead of one per size.
 template <class JOB>
 bool merge_small_launches(std::map<int, std::pair<std::vector<JOB>, uint64_t>>& by_r, std::vector<JOB>& all, uint32_t& blocks) {
-  static const bool off = getenv("P3R_NTT_NO_MIXED") != nullptr;
+  static const bool off = tuning_knob("P3R_NTT_NO_MIXED") != nullptr;
   if (off || by_r.size() < 2) return false;
   uint64_t total = 0;
   for (auto& kv : by_r) {
@@ -425,8 +425,8 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
   std::map<int, std::pair<std::vector<NttColJob>, uint64_t>> fwd_col;    // sub-transform size -> (jobs, blocks)
   std::map<int, std::pair<std::vector<NttLineJob>, uint64_t>> fwd_line;
   std::map<int, std::pair<std::vector<NttColJob>, uint64_t>> inv1, inv2;
-  static const bool lean_fwd = !getenv("P3R_NTT_OLD");
-  static const int fwd_la_cap = getenv("P3R_NTT_FWD_LOG_N1") ? atoi(getenv("P3R_NTT_FWD_LOG_N1")) : 8;
+  static const bool lean_fwd = !tuning_knob("P3R_NTT_OLD");
+  static const int fwd_la_cap = tuning_knob("P3R_NTT_FWD_LOG_N1") ? atoi(tuning_knob("P3R_NTT_FWD_LOG_N1")) : 8;
   for (const LdeItem& it : items) {
     const p3r_dmat* in = it.in;
     const uint32_t shift = it.shift;
@@ -537,7 +537,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       auto& fc = fwd_col[la_f * 2 + bigf];
       cj.block0 = (uint32_t)fc.second;
       {
-        static const bool no_xcd = getenv("P3R_NTT_NO_XCD_MAP") != nullptr;
+        static const bool no_xcd = tuning_knob("P3R_NTT_NO_XCD_MAP") != nullptr;
         const uint64_t tiles = (uint64_t)w << (lb_f - (kNtt2LogTile + bigf - la_f));
         cj.xcd_map = (!no_xcd && added_bits > 0 && (cj.block0 & 7) == 0 && (tiles & 7) == 0) ? 1 : 0;
       }
@@ -550,7 +550,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
       // lines of up to 2^12 cells on 2^12-cell tiles (256 lanes, six workgroups per CU): measured 10 % faster
       // than 2^13-cell tiles at the same waves per CU - the pass is VALU-bound (it does not slow down with
       // a third fewer waves) and smaller workgroups wait less at their barriers.  P3R_NTT_LINE_LOG_TILE=13: tuning
-      static const int line_log_tile = getenv("P3R_NTT_LINE_LOG_TILE") ? atoi(getenv("P3R_NTT_LINE_LOG_TILE")) : 12;
+      static const int line_log_tile = tuning_knob("P3R_NTT_LINE_LOG_TILE") ? atoi(tuning_knob("P3R_NTT_LINE_LOG_TILE")) : 12;
       const int small = (line_log_tile == 12 && lb_f <= 12) ? 1 : 0;
       auto& fl = fwd_line[lb_f * 2 + small];
       lj.block0 = (uint32_t)fl.second;
@@ -632,7 +632,7 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
 // one-permutation-per-lane kernel ~11 us whatever its size).  P3R_COOP_MAX_NODES / _LEAF_ROWS: tuning.
 // (tuning knobs are rounded down to a power of two: the kernels index by shifts and halvings)
 inline size_t env_pow2(const char* name, size_t dflt, size_t lo, size_t hi) {
-  const char* e = getenv(name);
+  const char* e = tuning_knob(name);
   size_t v = e ? (size_t)atol(e) : dflt;
   v = std::min(std::max(v, lo), hi);
   while (v & (v - 1)) v &= v - 1;

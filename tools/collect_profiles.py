@@ -107,7 +107,12 @@ for f in ("bench_line_babybear_2p22.json", "bench_line_tree_1gpu.json", "bench_l
           "bench_line_forest_1gpu_4trees.json", "bench_line_2ranks_gloo.json", "bench_line_forest_2ranks_gloo.json", "spans.txt"):
     src = os.path.join(SRC, f)
     if os.path.exists(src) and os.path.getsize(src):
-        shutil.copy(src, os.path.join(OUT, f))
+        if f.endswith(".json"):   # the ranks' collective layer may print banner lines next to the bench line
+            lines = [ln for ln in open(src) if ln.startswith("{")]
+            if lines:
+                json.dump(json.loads(lines[-1]), open(os.path.join(OUT, f), "w"), indent=1)
+        else:
+            shutil.copy(src, os.path.join(OUT, f))
 
 h = kern.get("k_mmcs_hash_rows", {})
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(OUT, "prove_next_layer_final_kernel_stats.csv")))}
