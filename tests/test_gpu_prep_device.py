@@ -63,6 +63,9 @@ PACKINGS = [None, dict(public_lanes=2, alu_lanes=1, horner_packed_steps=2, recom
     ("koala-bear", 10, 0, PACKINGS[2], dict(horner_chain_len=300, sponge_chain_len=70, merkle_depth=9)),
     ("koala-bear", 12, harness_lib.INDEPENDENT_SPONGES, None, dict(horner_chain_len=2600, sponge_chain_len=330, merkle_depth=20)),
     ("baby-bear", 13, 0, PACKINGS[3], dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)),
+    # many workgroups per scan / sort / histogram: the bench's knobs at 2^17 rows (0.6 M ops), and config 2's at 2^16
+    ("koala-bear", 17, 0, None, dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)),
+    ("baby-bear", 16, harness_lib.INDEPENDENT_SPONGES, None, dict(horner_chain_len=2600, sponge_chain_len=330, merkle_depth=20)),
 ])
 def test_device_preparation_equals_host_preparation(field, log_h, flags, packing, gen):
     import harness_adapters as wl
