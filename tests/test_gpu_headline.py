@@ -25,8 +25,10 @@ def test_headline_layer_proves_and_both_verifiers_accept(oracle, field, log_h):
     arrs = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN)   # the bench workload
     ctx = p3r.Context(field=field, **FRI)
     tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
-    cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(arrs), p3r.FriRecursionBackend(),
+    circuit = wl.circuit_from_arrays(arrs)
+    cache = p3r.build_next_layer_prep(ctx, circuit, p3r.FriRecursionBackend(),
                                       p3r.ProveNextLayerParams(table_packing=tp))
+    assert cache.prepared_circuit.prepared_on_device
     inputs = wl.circuit_inputs_from_arrays(arrs)
     del arrs
     out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=inputs), ctx, p3r.FriRecursionBackend(),
@@ -35,6 +37,20 @@ def test_headline_layer_proves_and_both_verifiers_accept(oracle, field, log_h):
     assert max(cpd.table_heights) == 1 << log_h
     # a second prove of the same inputs gives the same bytes (no stale pooled memory at this size)
     assert cache.prepared_circuit.prove(inputs) == out.proof.proof
+    # the host restatement of the preparation (csrc/circuit_impl.cuh) agrees with the device pass at this size:
+    # same preprocessed commitment, same schedule depth, same proof
+    import os
+    os.environ["P3R_PREP_HOST"] = "1"
+    try:
+        host_pc = p3r.PreparedCircuit(ctx, circuit, tp)
+    finally:
+        os.environ.pop("P3R_PREP_HOST", None)
+    assert not host_pc.prepared_on_device
+    assert np.array_equal(host_pc.circuit_prover_data.preprocessed_commitment, cpd.preprocessed_commitment)
+    assert host_pc.levels == cache.prepared_circuit.levels
+    assert host_pc.prove(inputs) == out.proof.proof
+    host_pc.free()
+    del circuit
     # 1. native verifier (host code of the C-ABI library), through the reference's entry point
     cache.prover.verify_all_tables(out.proof)
     # 2. oracle verifier, from the statement the proof metadata rebuilds
