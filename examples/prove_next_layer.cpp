@@ -92,6 +92,15 @@ int main(int argc, char** argv) {
       std::printf("layer %d: prove_next_layer %.1f ms, proof %zu bytes (%zu with metadata), verify_all_tables ok\n", l, ms,
                   out.proof.proof.size(), out.proof.to_postcard().size());
     }
+    {
+      // the wire form and back (what moves between the processes of an aggregation tree): native parser, same bytes again,
+      // and the parsed proof verifies from its own metadata
+      const std::vector<uint8_t> wire = out.proof.to_postcard();
+      const p3r::BatchStarkProof back = p3r::BatchStarkProof::from_postcard(wire, field);
+      if (back.proof != out.proof.proof || back.to_postcard() != wire) throw p3r::Error(P3R_EINVAL, "postcard round trip differs");
+      p3r::verify_all_tables(ctx.config(), back);
+      std::printf("BatchStarkProof postcard round trip ok (%zu bytes)\n", wire.size());
+    }
     // prove_aggregation_layer (recursion.rs:656-762): the circuit's inputs arrive as the shares of the two
     // proofs it verifies; the AggregationPrepCache slot is filled by the first call and reused by the second
     {

@@ -224,6 +224,40 @@ struct BatchStarkProof {
     }
     return a;
   }
+  // Inverse of to_postcard: one pass of the native parser (p3r_batch_stark_proof_parse: framing of the inner
+  // BatchProof, every field element in range, the metadata fields and the rules of validate()) - what a node of the
+  // aggregation tree runs on a child that arrived from another process.
+  static BatchStarkProof from_postcard(const std::vector<uint8_t>& data, Field field, bool montgomery_field_encoding = true) {
+    p3r_batch_stark_meta m;
+    char err[256] = {0};
+    const int rc = p3r_batch_stark_proof_parse((uint32_t)field, data.data(), data.size(),
+                                               montgomery_field_encoding ? 0 : P3R_PROVE_CANONICAL_FIELD_ENCODING, nullptr, &m, err, sizeof err);
+    if (rc != P3R_OK) throw Error(rc, err);
+    BatchStarkProof p;
+    p.proof.assign(data.begin(), data.begin() + m.proof_len);
+    p.table_packing.public_lanes = m.public_lanes; p.table_packing.alu_lanes = m.alu_lanes;
+    p.table_packing.min_trace_height = m.min_trace_height; p.table_packing.horner_packed_steps = m.horner_packed_steps;
+    for (int i = 0; i < 3; ++i) p.rows[i] = (size_t)m.rows[i];
+    p.alu_variant = m.alu_variant; p.ext_degree = m.ext_degree;
+    if (m.has_w_binomial) p.w_binomial = m.w_binomial;
+    p.alu_quintic_trinomial = m.alu_quintic_trinomial != 0;
+    for (uint32_t i = 0; i < m.n_non_primitives; ++i) {
+      const p3r_npo_table_entry& e = m.non_primitives[i];
+      NonPrimitiveTableEntry n;
+      n.op_type = e.op_type; n.rows = (size_t)e.rows; n.lanes = e.lanes; n.air_variant = e.air_variant;
+      n.public_values.assign(e.public_values, e.public_values + e.n_public_values);
+      if (n.op_type == "recompose") p.table_packing.recompose_lanes = e.lanes;
+      p.non_primitives.push_back(std::move(n));
+    }
+    if (m.has_stark_common) {
+      p.preprocessed_commitment.assign(m.commitment, m.commitment + 8 * m.cap_len);
+      p.preprocessed_widths.assign(m.preprocessed_widths, m.preprocessed_widths + m.n_instances);
+      p.degree_bits.assign(m.degree_bits, m.degree_bits + m.n_instances);
+    }
+    p.montgomery_field_encoding = montgomery_field_encoding;
+    p.modulus = field == Field::KoalaBear ? 0x7f000001u : 0x78000001u;
+    return p;
+  }
   // postcard bytes of the whole BatchStarkProof<SC> (serde derives of :610-636, packing.rs:9-27,
   // RowCounts :459-460, NonPrimitiveTableEntry :272-290, SerializedStarkCommon :495-511)
   std::vector<uint8_t> to_postcard() const {
