@@ -379,9 +379,25 @@ void parse_batch_stark_meta(const uint8_t* bytes, size_t len, bool canonical, co
     if (v >= PP::P) vfail("field element out of range");
     return canonical ? (uint32_t)v : Fp<PP>::raw((uint32_t)v).to_canonical();
   };
-  auto str = [&](char (&dst)[64]) {
+  auto str = [&](char (&dst)[64]) {  // NpoTypeId(String): valid UTF-8 (serde rejects anything else), no NUL (the C struct ends there)
     const size_t k = R.len(63);
     if ((size_t)(R.end - R.p) < k) vfail("proof metadata truncated");
+    for (size_t i = 0; i < k;) {
+      const uint8_t b = R.p[i];
+      size_t n = b < 0x80 ? 1 : (b >> 5) == 6 ? 2 : (b >> 4) == 14 ? 3 : (b >> 3) == 30 ? 4 : 0;
+      bool ok = n != 0 && b != 0 && i + n <= k;
+      uint32_t cp = n == 1 ? b : n == 2 ? (b & 0x1F) : n == 3 ? (b & 0x0F) : (b & 0x07);
+      for (size_t j = 1; ok && j < n; ++j) {
+        ok = (R.p[i + j] >> 6) == 2;
+        cp = (cp << 6) | (R.p[i + j] & 0x3F);
+      }
+      // shortest form only, no surrogates, nothing beyond U+10FFFF
+      if (ok && ((n == 2 && cp < 0x80) || (n == 3 && (cp < 0x800 || (cp >= 0xD800 && cp < 0xE000))) ||
+                 (n == 4 && (cp < 0x10000 || cp > 0x10FFFF))))
+        ok = false;
+      if (!ok) vfail("invalid UTF-8 in an operation type name");
+      i += n;
+    }
     std::memcpy(dst, R.p, k);
     dst[k] = 0;
     R.p += k;

@@ -96,3 +96,58 @@ def test_span_report_uses_reference_span_names_and_parses_like_benchmark_sh():
     total = sum(v[0] for k, v in prof.items() if k.startswith("stage:") and k != "stage:build_traces") / 2 \
         + (0.24 + 0.06 + 0.04 + 0.24) / 2
     assert m and m.group(2) == "ms" and abs(float(m.group(1)) - total) < 0.01
+
+
+def test_native_parser_survives_mutated_wire_bytes(oracle):
+    """p3r_batch_stark_proof_parse reads bytes that crossed a process boundary: truncations, bit flips, length
+    bombs and trailing garbage must come back as P3rError (or as a proof that re-serialises to the same bytes),
+    never as a crash or an over-read."""
+    import harness_lib
+    import layer_lib
+    import plonky3_recursion_amd.prover as pv
+    from plonky3_recursion_amd.device import P3rError
+    field = "koala-bear"
+    arrs = harness_lib.generate(field, 6, seed=77, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+    prm = layer_lib.params(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+    inner = layer_lib.OracleLayer(oracle, field, arrs, prm).prove()
+    tp = pv.TablePacking(min_trace_height=8)
+    good = pv.BatchStarkProof(
+        proof=inner, table_packing=tp, rows=(3, 5, 7), w_binomial=3,
+        non_primitives=(pv.NonPrimitiveTableEntry("poseidon2_perm/koala_bear_d4_w16", 32, 1, public_values=(1, 2)),
+                        pv.NonPrimitiveTableEntry("recompose", 9, 2)),
+        preprocessed_commitment=np.arange(8, dtype=np.uint32).reshape(1, 8), preprocessed_widths=(2, 2, 60, 24, 4),
+        degree_bits=(3, 4, 5, 5, 3), monty_r=1, modulus=0x7F000001).to_postcard()
+    back = pv.BatchStarkProof.from_postcard(good, field)
+    assert back.to_postcard() == good and back.non_primitives[0].public_values == (1, 2)
+    rng = np.random.default_rng(5)
+    accepted = rejected = 0
+    meta_at = len(inner)
+
+    def attempt(data):
+        nonlocal accepted, rejected
+        try:
+            p = pv.BatchStarkProof.from_postcard(bytes(data), field)
+        except P3rError:
+            rejected += 1
+            return
+        accepted += 1
+        # whatever is accepted is understood: its own wire form is a fixed point (TablePacking.npo_lanes is derived
+        # from the table entries on the way out, so a flipped name there is not reproduced byte for byte)
+        again = p.to_postcard()
+        assert pv.BatchStarkProof.from_postcard(again, field).to_postcard() == again
+        assert p.proof == bytes(data)[:len(p.proof)]
+
+    for n in list(range(0, 64)) + [int(x) for x in rng.integers(0, len(good), 200)]:
+        attempt(good[:n])                                                  # truncations
+    for _ in range(1500):                                                  # bit flips, biased towards the metadata tail
+        data = bytearray(good)
+        pos = int(rng.integers(meta_at, len(good))) if rng.random() < 0.6 else int(rng.integers(0, len(good)))
+        data[pos] ^= 1 << int(rng.integers(0, 8))
+        attempt(data)
+    for pos in [int(x) for x in rng.integers(0, len(good), 200)]:          # length bombs: a run of 0xFF continuation bytes
+        data = bytearray(good)
+        data[pos:pos + 4] = b"\\xff\\xff\\xff\\xff"
+        attempt(data)
+    attempt(good + b"\\x00")
+    attempt(b"")
+    assert rejected > 500 and accepted > 0, (accepted, rejected)
