@@ -49,6 +49,7 @@ struct Fp {
 template <class PP>
 struct Fp4 {
   using F = Fp<PP>;
+  static constexpr int DEG = 4;
   F c[4];
   static Fp4 zero() { return Fp4(); }
   static Fp4 one() { Fp4 r; r.c[0] = F::one(); return r; }
@@ -74,6 +75,64 @@ struct Fp4 {
     Fp4 r = one(), b = *this;
     for (; e; e >>= 1, b = b * b)
       if (e & 1) r = r * b;
+    return r;
+  }
+};
+
+// The degree-5 extension F[x] / (x^5 + x^2 - 1) of KoalaBear (QuinticTrinomialExtensionField; the circuit
+// field of the reference's D = 5 unit tests, circuit-prover/src/batch_stark_prover.rs tests.rs:844-1029 and
+// air/alu_air.rs:735-760): schoolbook product of degree 8, then x^5 = 1 - x^2 applied from the top.
+template <class PP>
+struct Fp5 {
+  using F = Fp<PP>;
+  static constexpr int DEG = 5;
+  F c[5];
+  static Fp5 zero() { return Fp5(); }
+  static Fp5 one() { Fp5 r; r.c[0] = F::one(); return r; }
+  static Fp5 from_base(F b) { Fp5 r; r.c[0] = b; return r; }
+  friend Fp5 operator+(Fp5 a, const Fp5& b) { for (int i = 0; i < 5; ++i) a.c[i] = a.c[i] + b.c[i]; return a; }
+  friend Fp5 operator-(Fp5 a, const Fp5& b) { for (int i = 0; i < 5; ++i) a.c[i] = a.c[i] - b.c[i]; return a; }
+  friend Fp5 operator*(const Fp5& a, const Fp5& b) {
+    F t[9];
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j) t[i + j] = t[i + j] + a.c[i] * b.c[j];
+    for (int k = 8; k >= 5; --k) {  // x^k = x^(k-5) - x^(k-3)
+      t[k - 5] = t[k - 5] + t[k];
+      t[k - 3] = t[k - 3] - t[k];
+    }
+    Fp5 r;
+    for (int i = 0; i < 5; ++i) r.c[i] = t[i];
+    return r;
+  }
+  bool operator==(const Fp5& o) const {
+    for (int i = 0; i < 5; ++i) if (!(c[i] == o.c[i])) return false;
+    return true;
+  }
+  // a^-1 by solving (multiplication-by-a matrix) * x = 1 over the base field (Gauss-Jordan, 5 x 6)
+  Fp5 inv() const {
+    F m[5][6];
+    Fp5 col = *this, xgen;
+    xgen.c[1] = F::one();
+    for (int j = 0; j < 5; ++j) {
+      for (int i = 0; i < 5; ++i) m[i][j] = col.c[i];
+      col = col * xgen;
+    }
+    for (int i = 0; i < 5; ++i) m[i][5] = i == 0 ? F::one() : F::zero();
+    for (int k = 0; k < 5; ++k) {
+      int piv = k;
+      while (piv < 5 && m[piv][k] == F::zero()) ++piv;
+      if (piv == 5) return zero();  // a = 0
+      for (int j = 0; j < 6; ++j) { F t = m[k][j]; m[k][j] = m[piv][j]; m[piv][j] = t; }
+      const F s = m[k][k].inv();
+      for (int j = 0; j < 6; ++j) m[k][j] = m[k][j] * s;
+      for (int i = 0; i < 5; ++i) {
+        if (i == k) continue;
+        const F f = m[i][k];
+        for (int j = 0; j < 6; ++j) m[i][j] = m[i][j] - f * m[k][j];
+      }
+    }
+    Fp5 r;
+    for (int i = 0; i < 5; ++i) r.c[i] = m[i][5];
     return r;
   }
 };

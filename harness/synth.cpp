@@ -58,16 +58,18 @@ enum : uint32_t { C_CONST = 0, C_PUBLIC = 1, C_ADD = 2, C_MUL = 3, C_BOOL = 4, C
                   C_HINT_EXT = 7, C_HINT_BIN = 8, C_P2 = 9, C_RECOMPOSE = 10 };
 constexpr uint32_t NO_W = 0xFFFFFFFFu;
 
-template <class PP>
+template <class PP, class E>
 void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int sponge_chain_len,
               int merkle_depth, const uint32_t* rc_canonical, uint32_t flags) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  constexpr int D = E::DEG;  // circuit extension degree: witness indices on the bus are scaled by D
   const uint32_t P = PP::P;
+  if (D != 4 && (flags & (SYN_NO_POSEIDON2 | SYN_NO_RECOMPOSE)) != (SYN_NO_POSEIDON2 | SYN_NO_RECOMPOSE))
+    throw std::runtime_error("ext_degree 5 covers the primitive tables: pass SYN_NO_POSEIDON2 | SYN_NO_RECOMPOSE");
   const size_t H = size_t(1) << log_h;
   Rng rng(seed);
   auto rf = [&]() { return F::from_canonical((uint32_t)(rng.next() % P)); };
-  auto re = [&]() { E e; for (int i = 0; i < 4; ++i) e.c[i] = rf(); return e; };
+  auto re = [&]() { E e; for (int i = 0; i < D; ++i) e.c[i] = rf(); return e; };
 
 
   // ---- the circuit being built (flattened Circuit<EF>, include/p3r.h) ----
@@ -87,7 +89,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   std::vector<uint32_t> reads;
   auto create = [&](const E& v) { wval.push_back(v); reads.push_back(0); return (uint32_t)(wval.size() - 1); };
   auto pick = [&]() { uint32_t w = rng.below((uint32_t)wval.size()); reads[w]++; return w; };
-  auto put_e = [&](std::vector<uint32_t>& dst, const E& e) { for (int i = 0; i < 4; ++i) dst.push_back(e.c[i].to_canonical()); };
+  auto put_e = [&](std::vector<uint32_t>& dst, const E& e) { for (int i = 0; i < D; ++i) dst.push_back(e.c[i].to_canonical()); };
   auto canon4 = [&](const E& e) { std::vector<uint32_t> v; put_e(v, e); return v; };
 
   // ---- Const (H/16 rows) and Public (H/2 ops) ----
@@ -303,7 +305,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   // backwards (the runner solves for b, runner.rs:341-385), claim a private input or consume
   // hint outputs.  Only the LAST output of a Horner run is ever read by another op:
   // intermediate outputs of packed rows never reach the bus (alu_air.rs:630-667).
-  auto& alu_values = W.arr["alu_values"];  // n x 16 (a,b,c,out)
+  auto& alu_values = W.arr["alu_values"];  // n x 4D (a,b,c,out)
   // a_state / c_state: 0 skip, 1 reader, 2 creator (circuit.rs:341-379)
   struct AluOp { int kind; uint32_t a, b, c, out; uint8_t a_state, c_state; bool b_creator, out_creator, has_c; };
   std::vector<AluOp> ops;
@@ -394,12 +396,12 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
         emit(mul ? OP_MUL : OP_ADD, a, b, NO_W, o, NO_W, 1, 0, true, false);
         pickable.push_back(b);
       } else if (v < 0.07) {
-        // ExtDecompositionHint: 4 hint outputs, each claimed by the Add that first uses it
+        // ExtDecompositionHint: D hint outputs, each claimed by the Add that first uses it
         uint32_t src = pickp_noread();
-        std::vector<uint32_t> outs(4);
-        for (int i = 0; i < 4; ++i) outs[i] = create(E::from_base(wval[src].c[i]));
+        std::vector<uint32_t> outs(D);
+        for (int i = 0; i < D; ++i) outs[i] = create(E::from_base(wval[src].c[i]));
         push_op(C_HINT_EXT, src, 0, 0, 0, 0, outs);
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < D; ++i) {
           uint32_t b = pickp_noread();
           uint32_t o = create(wval[outs[i]] + wval[b]);
           emit(OP_ADD, outs[i], b, NO_W, o, NO_W, 2, 0, false, true);
@@ -467,9 +469,9 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
 
   // ---- emit tables ----
   auto& const_values = W.arr["const_values"]; auto& const_prep = W.arr["const_prep"];
-  for (uint32_t w : const_w) { put_e(const_values, wval[w]); const_prep.push_back(reads[w]); const_prep.push_back(w * 4); }
+  for (uint32_t w : const_w) { put_e(const_values, wval[w]); const_prep.push_back(reads[w]); const_prep.push_back(w * D); }
   auto& public_values = W.arr["public_values"]; auto& public_prep = W.arr["public_prep"];
-  for (uint32_t w : public_w) { put_e(public_values, wval[w]); public_prep.push_back(reads[w]); public_prep.push_back(w * 4); }
+  for (uint32_t w : public_w) { put_e(public_values, wval[w]); public_prep.push_back(reads[w]); public_prep.push_back(w * D); }
   auto& rec_prep = W.arr["recompose_prep"];
   for (uint32_t w : rec_w) { rec_prep.push_back(w * 4); rec_prep.push_back(reads[w]); }
   for (auto& f : out_fix) p2_out_ctl[f.row * 2 + f.limb] = reads[f.wid];
@@ -481,7 +483,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     const uint32_t a_col = o.a_state == 1 ? 1u : o.a_state == 2 ? neg(reads[o.a]) : 0u;
     const uint32_t c_col = o.c_state == 1 ? 1u : o.c_state == 2 ? neg(reads[o.c]) : 0u;
     uint32_t row[13] = {neg1, o.kind == OP_ADD, o.kind == OP_BOOL, o.kind == OP_MULADD, o.kind == OP_HORNER,
-                        o.a * 4, o.b * 4, o.c * 4, o.out * 4,
+                        o.a * D, o.b * D, o.c * D, o.out * D,
                         o.b_creator ? reads[o.b] % P : neg1, o.out_creator ? reads[o.out] % P : neg1, a_col, c_col};
     alu_prep.insert(alu_prep.end(), row, row + 13);
   }
@@ -489,7 +491,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     // AluTrace::from_records / get_airs_and_degrees_with_prep add one all-zero dummy op
     // (tables/alu.rs:69-73, common.rs:283-286)
     alu_prep.insert(alu_prep.end(), 13, 0u);
-    alu_values.insert(alu_values.end(), 16, 0u);
+    alu_values.insert(alu_values.end(), 4 * D, 0u);
   }
   W.arr["counts"] = {(uint32_t)const_w.size(), (uint32_t)public_w.size(), (uint32_t)std::max<size_t>(ops.size(), 1),
                      (uint32_t)n_p2, (uint32_t)rec_w.size(), (uint32_t)wval.size()};
@@ -499,12 +501,17 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
 
 extern "C" {
 
+// flags bits 8..11: circuit extension degree (0 = 4).  5 = the KoalaBear quintic trinomial extension.
 void* syn_generate(int field, int log_h, uint64_t seed, int horner_chain_len, int sponge_chain_len,
                    int merkle_depth, const uint32_t* rc_canonical, uint32_t flags) {
   auto* W = new Workload();
+  const uint32_t ext_degree = (flags >> 8) & 15u ? (flags >> 8) & 15u : 4u;
+  flags &= 0xFFu;
   try {
-    if (field == 0) generate<KoalaBearParams>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
-    else if (field == 1) generate<BabyBearParams>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    if (ext_degree == 5 && field == 0) generate<KoalaBearParams, Fp5<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (ext_degree != 4) throw std::runtime_error("ext_degree must be 4, or 5 over KoalaBear");
+    else if (field == 0) generate<KoalaBearParams, Fp4<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (field == 1) generate<BabyBearParams, Fp4<BabyBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else throw std::runtime_error("unknown field");
   } catch (const std::exception& e) {
     W->err = e.what();

@@ -15,13 +15,18 @@
 namespace orc {
 
 enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4 };
-constexpr int D = 4;  // circuit extension degree handled by this restatement
+// Circuit extension degree: 4 (binomial x^4 = W) or 5 (KoalaBear quintic trinomial x^5 + x^2 - 1,
+// alu_air.rs:115-134; primitive tables only: the D = 5 backend's Poseidon2 table is the compact D1 one, not restated).
+// The STARK's own challenge field stays the degree-4 binomial extension, as in the reference's D = 5 unit tests
+// (batch_stark_prover/tests.rs:844-1029: QuinticTrinomialExtensionField traces under config::koala_bear()).
+constexpr int kMaxD = 5;
 
 struct AirDesc {
   int kind = AIR_CONST;
   int lanes = 1;
   int horner_k = 2;          // ALU: TablePacking::horner_packed_steps (packing.rs:10-27)
   int coeff_lookups = 0;     // Recompose: challenger.d() != D (backend/fri.rs:693-721)
+  int D = 4;                 // extension degree of the circuit's element field
 };
 
 // ---- widths (shape_golden.rs:32-68 pins the ALU formula) ----
@@ -29,6 +34,7 @@ inline int alu_num_int(int k) { return (k - 1) / 2; }                        // 
 inline int alu_extra_prep_width(int k) { return (k - 1) + 6 * (k - 1); }     // alu_columns.rs
 template <class FP>
 int air_width(const AirDesc& a) {
+  const int D = a.D;
   switch (a.kind) {
     case AIR_CONST: return D;                                                // const_air.rs:88-127
     case AIR_PUBLIC: return a.lanes * D;                                     // public_air.rs:127-169
@@ -39,6 +45,7 @@ int air_width(const AirDesc& a) {
   throw std::runtime_error("bad air kind");
 }
 inline int air_prep_width(const AirDesc& a) {
+  const int D = a.D;
   switch (a.kind) {
     case AIR_CONST: return 2;
     case AIR_PUBLIC: return a.lanes * 2;
@@ -80,6 +87,7 @@ template <class FP> inline Fe<FP> lift_to(const Fe<FP>& f, Fe<FP>*) { return f; 
 // ---- WitnessSendAir (Const / Public): public_air.rs:209-239 ----
 template <class FP, class V>
 void eval_witness_send(const AirDesc& a, EvalCtx<FP, V>& b) {
+  const int D = a.D;
   for (int lane = 0; lane < a.lanes; ++lane) {
     V mult = b.prep_local[lane * 2 + 0];
     V idx = b.prep_local[lane * 2 + 1];
@@ -92,6 +100,7 @@ void eval_witness_send(const AirDesc& a, EvalCtx<FP, V>& b) {
 // ---- RecomposeAir: recompose_air.rs:141-198 ----
 template <class FP, class V>
 void eval_recompose(const AirDesc& a, EvalCtx<FP, V>& b) {
+  const int D = a.D;
   const int plw = 2 + (a.coeff_lookups ? 2 * D : 0);
   for (int lane = 0; lane < a.lanes; ++lane) {
     const V* p = b.prep_local + lane * plw;
@@ -108,11 +117,26 @@ void eval_recompose(const AirDesc& a, EvalCtx<FP, V>& b) {
   }
 }
 
-// x*y in F[x]/(x^4 - W) on D-coefficient slices (alu_air.rs:715-733)
+// x*y on D-coefficient slices: F[x]/(x^4 - W) (ext_mul_binomial, alu_air.rs:715-733) or, for D = 5,
+// F[x]/(x^5 + x^2 - 1) (ext_mul_quintic_trinomial, alu_air.rs:737-765: x^5 = 1 - x^2, x^6 = x - x^3,
+// x^7 = x^2 - x^4, x^8 = x^3 + x^2 - 1)
 template <class FP, class V>
-std::array<V, D> ext_mul(const V* x, const V* y) {
-  std::array<V, D> acc;
+std::array<V, kMaxD> ext_mul(int D, const V* x, const V* y) {
+  std::array<V, kMaxD> acc;
   for (auto& e : acc) e = EvalCtx<FP, V>::K(0);
+  if (D == 5) {
+    V c[9];
+    for (auto& e : c) e = EvalCtx<FP, V>::K(0);
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j) c[i + j] = c[i + j] + x[i] * y[j];
+    V c5_minus_c8 = c[5] - c[8];
+    acc[0] = c[0] + c5_minus_c8;
+    acc[1] = c[1] + c[6];
+    acc[2] = c[2] - c5_minus_c8 + c[7];
+    acc[3] = c[3] - c[6] + c[8];
+    acc[4] = c[4] - c[7];
+    return acc;
+  }
   const V w = EvalCtx<FP, V>::K(FP::W);
   for (int i = 0; i < D; ++i)
     for (int j = 0; j < D; ++j) {
@@ -127,6 +151,7 @@ std::array<V, D> ext_mul(const V* x, const V* y) {
 // ---- AluAir: interactions alu_air.rs:1000-1085, constraints alu_air.rs:764-996 ----
 template <class FP, class V>
 void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
+  const int D = a.D;
   const int lanes = a.lanes, LW = 4 * D, PW = 13, k_max = a.horner_k;
   const int extra_main = lanes * LW, extra_prep = lanes * PW;
   const int num_int = alu_num_int(k_max);
@@ -166,7 +191,7 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
     V active = zero - mult_a;
     V sel_mul = active - sel_bool - sel_muladd - sel_horner - sel_add;
     for (int i = 0; i < D; ++i) b.assert_zero(sel_add * (A[i] + B[i] - O[i]));                 // ADD
-    auto ab = ext_mul<FP, V>(A, B);
+    auto ab = ext_mul<FP, V>(D, A, B);
     for (int i = 0; i < D; ++i) b.assert_zero(sel_mul * (ab[i] - O[i]));                        // MUL
     b.assert_zero(sel_bool * A[0] * (A[0] - one));                                              // BOOL
     for (int i = 1; i < D; ++i) b.assert_zero(sel_bool * A[i]);
@@ -174,7 +199,7 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
     // HORNER_ACC
     V next_sel_horner = pn[4];
     const V *NA = ln, *NB = ln + D, *NC = ln + 2 * D, *NO = ln + 3 * D;
-    auto out_next_b = ext_mul<FP, V>(O, NB);
+    auto out_next_b = ext_mul<FP, V>(D, O, NB);
     if (lane == 0) {
       const V* next_int0 = N + extra_main;
       V any_cur = zero, any_next = zero, sel_ge3_next = zero;
@@ -184,11 +209,11 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
       for (int kk = 3; kk <= k_max; ++kk) sel_ge3_next = sel_ge3_next + PN[extra_prep + sel_k_idx(kk)];
       const int b_sq_base = ac_base + 2 * (k_max - 1) * D;
       const V* b_sq = L + b_sq_base; const V* b_sq_next = N + b_sq_base;
-      auto bb = ext_mul<FP, V>(B, B);
+      auto bb = ext_mul<FP, V>(D, B, B);
       for (int i = 0; i < D; ++i) b.assert_zero(any_cur * (b_sq[i] - bb[i]));
-      auto out_b_sq = ext_mul<FP, V>(O, b_sq_next);
-      auto c0_b_next = ext_mul<FP, V>(NC, NB);
-      auto a0_b_next = ext_mul<FP, V>(NA, NB);
+      auto out_b_sq = ext_mul<FP, V>(D, O, b_sq_next);
+      auto c0_b_next = ext_mul<FP, V>(D, NC, NB);
+      auto a0_b_next = ext_mul<FP, V>(D, NA, NB);
       const V* a1_next = N + ac_base; const V* c1_next = N + ac_base + D;
       for (int i = 0; i < D; ++i) {                                                              // 1) packed inter-row
         V poly = out_b_sq[i] + c0_b_next[i] - a0_b_next[i] + c1_next[i] - a1_next[i];
@@ -207,9 +232,9 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
           if (s + 1 < kk) {
             int off_sp1 = ac_base + 2 * s * D;
             const V* a_sp1 = L + off_sp1; const V* c_sp1 = L + off_sp1 + D;
-            auto int_b_sq = ext_mul<FP, V>(int_curr, b_sq);
-            auto c_s_b = ext_mul<FP, V>(c_s, B);
-            auto a_s_b = ext_mul<FP, V>(a_s, B);
+            auto int_b_sq = ext_mul<FP, V>(D, int_curr, b_sq);
+            auto c_s_b = ext_mul<FP, V>(D, c_s, B);
+            auto a_s_b = ext_mul<FP, V>(D, a_s, B);
             const V* target = (s + 2 >= kk) ? O : (L + extra_main + (slot + 1) * D);
             for (int i = 0; i < D; ++i) {
               V prod = int_b_sq[i] + c_s_b[i] - a_s_b[i] + c_sp1[i] - a_sp1[i];
@@ -218,7 +243,7 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
             if (!(s + 2 >= kk)) slot += 1;
             s += 2;
           } else {
-            auto int_b = ext_mul<FP, V>(int_curr, B);
+            auto int_b = ext_mul<FP, V>(D, int_curr, B);
             for (int i = 0; i < D; ++i) b.assert_zero(sel_kk * (int_b[i] + c_s[i] - a_s[i] - O[i]));
             s += 1;
           }
@@ -236,6 +261,7 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
 // the Poseidon2Cols semantics (SURVEY.md appendix A "Inner perm-AIR constraints").
 template <class FP, class V>
 void eval_poseidon2(const Poseidon2<FP>& p2, EvalCtx<FP, V>& b) {
+  constexpr int D = 4;  // the D = 4 width-16 arity-2 table (the D = 5 backend's compact-D1 table is not restated)
   constexpr int WE = 4, RE = 2, R = FP::SBOX_REGS;
   const int pc = Poseidon2<FP>::perm_cols();
   const V* L = b.local; const V* N = b.next; const V* PL = b.prep_local; const V* PN = b.prep_next;

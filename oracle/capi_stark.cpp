@@ -31,6 +31,9 @@ typedef struct orc_workload {
   size_t n_recompose; const uint32_t* recompose_values; /* n x 4 */ const uint32_t* recompose_prep; /* n x 2: idx, mult */
   /* TablePacking (circuit-prover/src/batch_stark_prover/packing.rs:10-27) */
   uint32_t public_lanes, alu_lanes, horner_packed_steps, recompose_lanes, min_trace_height;
+  /* extension degree D of the circuit's element field: 0 or 4 = binomial x^4 = W (every "x 4" above), 5 = KoalaBear
+   * quintic trinomial (values are n x 5 / n x 20; primitive tables only: n_p2 = n_recompose = 0) */
+  uint32_t ext_degree;
 } orc_workload;
 
 typedef struct orc_params {
@@ -104,26 +107,30 @@ struct Layer : LayerBase {
   // rows is not part of the batch (batch_stark_prover/poseidon2.rs:1089-1092, recompose.rs:77-80).
   void build(const orc_workload& w) {
     const size_t mh = w.min_trace_height;
+    const int D = w.ext_degree ? (int)w.ext_degree : 4;
+    if (D != 4 && D != 5) throw std::runtime_error("UnsupportedDegree");
+    if (D == 5 && (FP::P != KoalaBear::P || w.n_p2 || w.n_recompose))
+      throw std::runtime_error("D = 5: KoalaBear, primitive tables only (the compact-D1 Poseidon2 table is not restated)");
     const int public_lanes = w.n_public <= 1 ? 1 : (int)w.public_lanes;
     const int alu_lanes = w.n_alu <= 1 ? 1 : (int)w.alu_lanes;
     {
       Instance<FP> in;
-      in.air.kind = AIR_CONST; in.air.lanes = 1;
-      in.main = lanes_trace_to_matrix<FP>(vec(w.const_values, w.n_const * 4), 1, mh);
+      in.air.kind = AIR_CONST; in.air.lanes = 1; in.air.D = D;
+      in.main = lanes_trace_to_matrix<FP>(vec(w.const_values, w.n_const * D), 1, mh, D);
       in.prep = lanes_prep_to_matrix<FP>(vec(w.const_prep, w.n_const * 2), 2, 1, mh);
       insts.push_back(std::move(in));
     }
     {
       Instance<FP> in;
-      in.air.kind = AIR_PUBLIC; in.air.lanes = public_lanes;
-      in.main = lanes_trace_to_matrix<FP>(vec(w.public_values, w.n_public * 4), in.air.lanes, mh);
+      in.air.kind = AIR_PUBLIC; in.air.lanes = public_lanes; in.air.D = D;
+      in.main = lanes_trace_to_matrix<FP>(vec(w.public_values, w.n_public * D), in.air.lanes, mh, D);
       in.prep = lanes_prep_to_matrix<FP>(vec(w.public_prep, w.n_public * 2), 2, in.air.lanes, mh);
       insts.push_back(std::move(in));
     }
     {
       Instance<FP> in;
-      in.air.kind = AIR_ALU; in.air.lanes = alu_lanes; in.air.horner_k = (int)w.horner_packed_steps;
-      auto values = vec(w.alu_values, w.n_alu * 16);
+      in.air.kind = AIR_ALU; in.air.lanes = alu_lanes; in.air.horner_k = (int)w.horner_packed_steps; in.air.D = D;
+      auto values = vec(w.alu_values, w.n_alu * 4 * D);
       auto prep = vec(w.alu_prep13, w.n_alu * 13);
       in.main = alu_trace_to_matrix<FP>(in.air, values, prep, mh);
       in.prep = alu_preprocessed_trace<FP>(in.air, prep, mh);
@@ -262,7 +269,8 @@ int orc_verify_batch(int field, const uint32_t* rc, const orc_params* p, size_t 
       for (size_t i = 0; i < n_airs; ++i) {
         AirDesc a;
         a.kind = (int)airs4[4 * i]; a.lanes = (int)airs4[4 * i + 1]; a.horner_k = (int)airs4[4 * i + 2];
-        a.coeff_lookups = (int)airs4[4 * i + 3];
+        a.coeff_lookups = (int)(airs4[4 * i + 3] & 0xFF);
+        a.D = (airs4[4 * i + 3] >> 8) ? (int)(airs4[4 * i + 3] >> 8) : 4;   // bits 8..: extension degree of the circuit (0 = 4)
         shapes.push_back({a});
       }
       typename BatchProof<FP>::Cap cap(size_t(1) << p->cap_height);

@@ -157,6 +157,43 @@ struct Fe4 {
   }
 };
 
+// Element of the CIRCUIT's extension field with the degree chosen at run time: F[x]/(x^4 - W) or, for D = 5,
+// F[x]/(x^5 + x^2 - 1) (p3's QuinticTrinomialExtensionField; reduction as in alu_air.rs:737-765).  Used by the
+// trace builders; the STARK's challenge field is Fe4 whatever the circuit's degree.
+template <class FP>
+struct FeX {
+  using F = Fe<FP>;
+  int D = 4;
+  std::array<F, 5> c{};
+  explicit FeX(int d = 4) : D(d) {}
+  static FeX zero(int d) { return FeX(d); }
+  friend FeX operator+(FeX a, const FeX& b) { for (int i = 0; i < a.D; ++i) a.c[i] += b.c[i]; return a; }
+  friend FeX operator-(FeX a, const FeX& b) { for (int i = 0; i < a.D; ++i) a.c[i] -= b.c[i]; return a; }
+  friend FeX operator*(const FeX& a, const FeX& b) {
+    FeX r(a.D);
+    if (a.D == 5) {
+      F t[9];
+      for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j) t[i + j] += a.c[i] * b.c[j];
+      // x^5 = 1 - x^2, x^6 = x - x^3, x^7 = x^2 - x^4, x^8 = x^3 + x^2 - 1
+      r.c[0] = t[0] + t[5] - t[8];
+      r.c[1] = t[1] + t[6];
+      r.c[2] = t[2] - t[5] + t[7] + t[8];
+      r.c[3] = t[3] - t[6] + t[8];
+      r.c[4] = t[4] - t[7];
+      return r;
+    }
+    const F w(FP::W);
+    for (int i = 0; i < a.D; ++i)
+      for (int j = 0; j < a.D; ++j) {
+        F t = a.c[i] * b.c[j];
+        if (i + j >= a.D) r.c[i + j - a.D] += w * t;
+        else r.c[i + j] += t;
+      }
+    return r;
+  }
+};
+
 inline uint32_t bitrev(uint32_t x, int bits) {
   uint32_t r = 0;
   for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1u) << (bits - 1 - i);

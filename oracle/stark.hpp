@@ -96,7 +96,7 @@ inline std::vector<int> interaction_mult_degrees(const AirDesc& a) {
   switch (a.kind) {
     case AIR_CONST: d = {1}; break;
     case AIR_PUBLIC: d.assign(a.lanes, 1); break;
-    case AIR_RECOMPOSE: d.assign(a.lanes * (1 + (a.coeff_lookups ? D : 0)), 1); break;
+    case AIR_RECOMPOSE: d.assign(a.lanes * (1 + (a.coeff_lookups ? a.D : 0)), 1); break;
     case AIR_ALU:
       for (int l = 0; l < a.lanes; ++l) { d.push_back(2); d.push_back(1); d.push_back(2); d.push_back(1); }
       for (int t = 1; t < a.horner_k; ++t) { d.push_back(1); d.push_back(1); }
@@ -162,7 +162,7 @@ struct LookupChallenges {
 // get_perm_challenges (verifier/batch_stark.rs:1026-1112): one (alpha, beta) pair; every
 // lookup is on the single global bus "WitnessChecks" (bus id 0); W = widest tuple = 1 + D.
 template <class FP>
-LookupChallenges<FP> sample_lookup_challenges(Challenger<FP>& ch) {
+LookupChallenges<FP> sample_lookup_challenges(Challenger<FP>& ch, int D) {
   Fe4<FP> alpha = ch.sample_ext(), beta = ch.sample_ext();
   Fe4<FP> gamma = beta;
   for (int i = 1; i < 1 + D; ++i) gamma *= beta;
@@ -466,7 +466,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   bool any_lookup = false;
   for (auto& L : layouts) any_lookup |= !L.groups.empty();
   LookupChallenges<FP> lc{};
-  if (any_lookup) lc = sample_lookup_challenges<FP>(ch);
+  if (any_lookup) lc = sample_lookup_challenges<FP>(ch, insts[0].air.D);
   std::vector<AuxTrace<FP>> aux(ni);
   proof.has_terminal.assign(ni, false);
   proof.lookup_terminals.assign(ni, EF::zero());
@@ -747,7 +747,7 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
   for (auto& d : prep_commit) ch.observe_arr(d);
   LookupChallenges<FP> lc{};
   if (any_lookup) {
-    lc = sample_lookup_challenges<FP>(ch);
+    lc = sample_lookup_challenges<FP>(ch, shapes[0].air.D);
     for (auto& d : proof.permutation_commit) ch.observe_arr(d);
     for (size_t i = 0; i < ni; ++i) if (proof.has_terminal[i]) ch.observe_ext(proof.lookup_terminals[i]);
   }

@@ -68,7 +68,7 @@ void pad_rows(Matrix<FP>& m, size_t min_height) {
 // (public_air.rs:127-169) / RecomposeAir::trace_to_matrix (recompose_air.rs:96-119):
 // values: n_ops x D, laid out `lanes` ops per row, zero padded.
 template <class FP>
-Matrix<FP> lanes_trace_to_matrix(const std::vector<Fe<FP>>& values, int lanes, size_t min_height) {
+Matrix<FP> lanes_trace_to_matrix(const std::vector<Fe<FP>>& values, int lanes, size_t min_height, int D = 4) {
   size_t n_ops = values.size() / D;
   size_t rows = std::max<size_t>((n_ops + lanes - 1) / lanes, 1);
   Matrix<FP> m(rows, (size_t)lanes * D);
@@ -144,8 +144,8 @@ bool alu_compute_schedule(const std::vector<Fe<FP>>& prep13, int lanes, int pack
 }
 
 template <class FP>
-Fe4<FP> e4_at(const std::vector<Fe<FP>>& values, size_t op, int operand) {
-  Fe4<FP> e;
+FeX<FP> e4_at(const std::vector<Fe<FP>>& values, size_t op, int operand, int D) {
+  FeX<FP> e(D);
   for (int d = 0; d < D; ++d) e.c[d] = values[(op * 4 + operand) * D + d];
   return e;
 }
@@ -154,7 +154,8 @@ Fe4<FP> e4_at(const std::vector<Fe<FP>>& values, size_t op, int operand) {
 template <class FP>
 Matrix<FP> alu_trace_to_matrix(const AirDesc& a, const std::vector<Fe<FP>>& values,
                                const std::vector<Fe<FP>>& prep13, size_t min_height) {
-  using EF = Fe4<FP>;
+  using EF = FeX<FP>;
+  const int D = a.D;
   const int lanes = a.lanes, LW = 4 * D, k_max = a.horner_k;
   const int width = air_width<FP>(a), num_int = alu_num_int(k_max);
   std::vector<AluEntry> sched;
@@ -165,49 +166,49 @@ Matrix<FP> alu_trace_to_matrix(const AirDesc& a, const std::vector<Fe<FP>>& valu
   Matrix<FP> m(rows, width);
   auto put = [&](size_t off, const EF& e) { for (int d = 0; d < D; ++d) m.v[off + d] = e.c[d]; };
   if (has) {
-    EF prev = EF::zero();
+    EF prev = EF::zero(D);
     for (size_t pos = 0; pos < sched.size(); ++pos) {
       size_t row = pos / lanes, lane = pos % lanes;
       const auto& en = sched[pos];
       size_t base = row * width + lane * LW;
       if (en.kind == 0) {
-        for (int o = 0; o < 4; ++o) put(base + o * D, e4_at<FP>(values, en.first, o));
-        if (lane == 0) prev = e4_at<FP>(values, en.first, 3);
+        for (int o = 0; o < 4; ++o) put(base + o * D, e4_at<FP>(values, en.first, o, D));
+        if (lane == 0) prev = e4_at<FP>(values, en.first, 3, D);
       } else if (en.kind == 1) {
         int k = en.k;
-        for (int o = 0; o < 3; ++o) put(base + o * D, e4_at<FP>(values, en.first, o));
-        put(base + 3 * D, e4_at<FP>(values, en.first + k - 1, 3));
+        for (int o = 0; o < 3; ++o) put(base + o * D, e4_at<FP>(values, en.first, o, D));
+        put(base + 3 * D, e4_at<FP>(values, en.first + k - 1, 3, D));
         if (lane == 0) {
           size_t extra = row * width + (size_t)lanes * LW;
-          EF b = e4_at<FP>(values, en.first, 1), acc = prev;
+          EF b = e4_at<FP>(values, en.first, 1, D), acc = prev;
           int step = 0;
           for (int s = 0; s < num_int; ++s) {
             size_t i0 = en.first + step, i1 = i0 + 1;
             if (i1 < en.first + k) {
-              EF o0 = acc * b + e4_at<FP>(values, i0, 2) - e4_at<FP>(values, i0, 0);
-              acc = o0 * b + e4_at<FP>(values, i1, 2) - e4_at<FP>(values, i1, 0);
+              EF o0 = acc * b + e4_at<FP>(values, i0, 2, D) - e4_at<FP>(values, i0, 0, D);
+              acc = o0 * b + e4_at<FP>(values, i1, 2, D) - e4_at<FP>(values, i1, 0, D);
               step += 2;
             } else {
-              acc = acc * b + e4_at<FP>(values, i0, 2) - e4_at<FP>(values, i0, 0);
+              acc = acc * b + e4_at<FP>(values, i0, 2, D) - e4_at<FP>(values, i0, 0, D);
               step += 1;
             }
             put(extra + s * D, acc);
           }
           size_t ac_base = extra + num_int * D;
           for (int t = 1; t < k; ++t) {
-            put(ac_base + 2 * (t - 1) * D, e4_at<FP>(values, en.first + t, 0));
-            put(ac_base + 2 * (t - 1) * D + D, e4_at<FP>(values, en.first + t, 2));
+            put(ac_base + 2 * (t - 1) * D, e4_at<FP>(values, en.first + t, 0, D));
+            put(ac_base + 2 * (t - 1) * D + D, e4_at<FP>(values, en.first + t, 2, D));
           }
           put(ac_base + 2 * (k_max - 1) * D, b * b);
-          prev = e4_at<FP>(values, en.first + k - 1, 3);
+          prev = e4_at<FP>(values, en.first + k - 1, 3, D);
         }
       } else if (lane == 0) {
-        prev = EF::zero();
+        prev = EF::zero(D);
       }
     }
   } else {
     for (size_t op = 0; op < n_ops; ++op)
-      for (int o = 0; o < 4; ++o) put((op / lanes) * width + (op % lanes) * LW + o * D, e4_at<FP>(values, op, o));
+      for (int o = 0; o < 4; ++o) put((op / lanes) * width + (op % lanes) * LW + o * D, e4_at<FP>(values, op, o, D));
   }
   pad_rows(m, min_height);
   return m;
@@ -271,6 +272,7 @@ struct P2CtlRow {
 template <class FP>
 Matrix<FP> p2_preprocessed_trace(const std::vector<P2CtlRow<FP>>& rows, size_t min_height) {
   using F = Fe<FP>;
+  constexpr int D = 4;  // the non-compact layout is the D = 4 one
   const size_t w = 24, n = rows.size();
   Matrix<FP> m(std::max<size_t>(n, 1), w);
   for (size_t r = 0; r < n; ++r) {

@@ -30,8 +30,9 @@ NO_POSEIDON2, NO_RECOMPOSE, SINGLE_PUBLIC, NO_ALU, INDEPENDENT_SPONGES = 1, 2, 4
 
 
 def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None,
-             flags=0):
-    """Returns dict name -> np.uint32 array (see harness/synth.cpp)."""
+             flags=0, ext_degree=4):
+    """Returns dict name -> np.uint32 array (see harness/synth.cpp).  ext_degree=5: KoalaBear circuits over the
+    quintic trinomial extension, primitive tables only (flags must hold NO_POSEIDON2 | NO_RECOMPOSE)."""
     build()
     lib = C.CDLL(LIB)
     lib.syn_generate.restype = C.c_void_p
@@ -45,7 +46,7 @@ def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_le
         rc = oracle_lib.default_rc(field)
     rc = np.ascontiguousarray(rc, dtype=np.uint32)
     h = lib.syn_generate(FIELD_IDS[field], log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth,
-                         rc.ctypes.data_as(u32p), flags)
+                         rc.ctypes.data_as(u32p), flags | (ext_degree << 8 if ext_degree != 4 else 0))
     try:
         err = lib.syn_error(h)
         if err:

@@ -1,0 +1,114 @@
+"""CPU: circuits over the KoalaBear quintic trinomial extension (D = 5, x^5 + x^2 - 1) through the oracle.
+The reference proves such circuits under the D = 4 STARK configuration - the circuit field only changes the
+width of the witness tuples on the bus (D + 1), the table widths and the ALU multiplication rule
+(circuit-prover/src/batch_stark_prover/tests.rs:844-1029, air/alu_air.rs:735-760)."""
+import numpy as np
+import pytest
+
+import harness_lib
+import layer_lib
+
+P = 0x7F000001
+PRIMITIVE = harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE
+
+
+def quintic_mul(x, y):
+    t = [0] * 9
+    for i in range(5):
+        for j in range(5):
+            t[i + j] = (t[i + j] + int(x[i]) * int(y[j])) % P
+    for k in range(8, 4, -1):   # x^k = x^(k-5) - x^(k-3)
+        t[k - 5] = (t[k - 5] + t[k]) % P
+        t[k - 3] = (t[k - 3] - t[k]) % P
+    return t[:5]
+
+
+def layer(oracle, log_h, seed, prm, packing=None, **kw):
+    arrs = harness_lib.generate("koala-bear", log_h, seed=seed, horner_chain_len=kw.pop("horner_chain_len", 12),
+                                flags=PRIMITIVE, ext_degree=5, **kw)
+    packing = dict(packing or {}, ext_degree=5)
+    return arrs, layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=packing)
+
+
+def test_generator_values_follow_the_trinomial_rule():
+    arrs = harness_lib.generate("koala-bear", 5, seed=1, horner_chain_len=6, flags=PRIMITIVE, ext_degree=5)
+    v = arrs["alu_values"].reshape(-1, 20)
+    kinds = arrs["alu_prep13"].reshape(-1, 13)
+    seen = 0
+    for row, k in zip(v, kinds):
+        a, b, c, out = row[0:5], row[5:10], row[10:15], row[15:20]
+        if not (k[1] or k[2] or k[3] or k[4]):      # Mul: a * b = out
+            assert quintic_mul(a, b) == [int(x) for x in out]
+            seen += 1
+    assert seen > 10
+    # x^5 = 1 - x^2 on the generator's arithmetic via a known product: (x^4) * (x) = 1 - x^2
+    assert quintic_mul([0, 0, 0, 0, 1], [0, 1, 0, 0, 0]) == [1, 0, P - 1, 0, 0]
+
+
+@pytest.mark.parametrize("log_h,kw", [
+    (5, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=0)),
+    (7, dict(log_blowup=2, max_log_arity=3, log_final_poly_len=2)),
+    (7, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, cap_height=2)),
+])
+def test_prove_verify_roundtrip(oracle, log_h, kw):
+    prm = layer_lib.params(query_pow_bits=3, num_queries=5, **kw)
+    arrs, L = layer(oracle, log_h, log_h, prm)
+    pf = L.prove()
+    L.verify(pf)
+    assert L.prove() == pf
+    for pos in range(7, len(pf), max(len(pf) // 40, 1)):
+        bad = bytearray(pf)
+        bad[pos] ^= 1
+        with pytest.raises(RuntimeError):
+            L.verify(bytes(bad))
+
+
+def test_table_shapes(oracle):
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=3)
+    arrs, L = layer(oracle, 6, 2, prm)
+    t = {x["kind"]: x for x in L.tables()}
+    assert set(t) == {"const", "public", "alu"}
+    # D = 5: Const / Public carry 5 value columns per lane; ALU 4 operands x 5 per lane + (1 + 6 + 1) x 5 for the
+    # packed Horner steps (alu_columns.rs:52-127)
+    assert t["const"]["main"].shape[1] == 5 and t["const"]["prep"].shape[1] == 2
+    assert t["public"]["main"].shape[1] == 5
+    assert t["alu"]["main"].shape[1] == 3 * 20 + (1 + 6 + 1) * 5
+    assert t["alu"]["prep"].shape[1] == 3 * 13 + 7 * 3
+    # witness indices are scaled by D on the bus (circuit.rs:237-510 with D = 5)
+    assert (arrs["const_prep"].reshape(-1, 2)[:, 1] % 5 == 0).all()
+
+
+@pytest.mark.parametrize("packing", [dict(alu_lanes=1, horner_packed_steps=2), dict(alu_lanes=2, horner_packed_steps=3, public_lanes=2)])
+def test_lane_and_pack_variants(oracle, packing):
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=3)
+    _, L = layer(oracle, 6, 3, prm, packing=packing, horner_chain_len=17)
+    L.verify(L.prove())
+
+
+def test_unsatisfied_trace_is_rejected(oracle):
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=4)
+    arrs = harness_lib.generate("koala-bear", 6, seed=4, horner_chain_len=12, flags=PRIMITIVE, ext_degree=5)
+    # the top coefficient of an operand: invisible to a D = 4 rule
+    arrs["alu_values"][4] = (int(arrs["alu_values"][4]) + 1) % P
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(ext_degree=5))
+    with pytest.raises(RuntimeError, match="constraints do not match|final polynomial|terminals"):
+        L.verify(L.prove())
+
+
+def test_degree_four_rule_does_not_verify_a_quintic_layer(oracle):
+    """The same proof checked as a D = 4 statement is rejected (the verifier's AIR list carries D)."""
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=3)
+    arrs, L = layer(oracle, 6, 5, prm)
+    pf = L.prove()
+    airs5 = [dict(kind=x["kind_id"], lanes=x["lanes"], horner_packed_steps=x["horner_k"], ext_degree=5) for x in L.tables()]
+    layer_lib.oracle_verify_statement(oracle, "koala-bear", prm, airs5, L.prep_commit(), pf)
+    airs4 = [dict(a, ext_degree=4) for a in airs5]
+    with pytest.raises(RuntimeError):
+        layer_lib.oracle_verify_statement(oracle, "koala-bear", prm, airs4, L.prep_commit(), pf)
+
+
+def test_refused_shapes(oracle):
+    with pytest.raises(RuntimeError, match="primitive tables"):
+        harness_lib.generate("koala-bear", 5, ext_degree=5)
+    with pytest.raises(RuntimeError, match="ext_degree"):
+        harness_lib.generate("baby-bear", 5, flags=PRIMITIVE, ext_degree=5)
