@@ -60,7 +60,13 @@ enum { P3R_FIELD_KOALA_BEAR = 0, P3R_FIELD_BABY_BEAR = 1 };
 typedef struct p3r_config {
   uint32_t abi_version;        /* P3R_ABI_VERSION */
   uint32_t field;              /* P3R_FIELD_* */
-  uint32_t ext_degree;         /* 4 (binomial x^4 = W) */
+  uint32_t ext_degree;         /* circuit extension degree D of the traces: 4 (binomial x^4 = W), or 5 over KoalaBear
+                                * (quintic trinomial x^5 + x^2 - 1: QuinticTrinomialExtensionField, proved under the
+                                * same D = 4 STARK configuration as in circuit-prover/src/batch_stark_prover/
+                                * tests.rs:844-1029).  D = 5 covers the primitive tables (Const, Public, ALU) at the
+                                * prove_all_tables boundary: values are n x 5 / n x 20, witness indices in the
+                                * preprocessed columns are scaled by 5; p3r_circuit_create and layers with Poseidon2
+                                * or Recompose rows return P3R_EUNSUPPORTED. */
   uint32_t log_blowup;
   uint32_t max_log_arity;
   uint32_t cap_height;
@@ -276,11 +282,11 @@ typedef struct p3r_layer_desc {
   const uint32_t* p2_mmcs_index_sum_idx; /* n_p2 */
 } p3r_layer_desc;
 
-/* Flattened Traces<EF> (circuit/src/tables/mod.rs:49-62), D = 4, canonical. */
+/* Flattened Traces<EF> (circuit/src/tables/mod.rs:49-62), canonical; D = p3r_config.ext_degree. */
 typedef struct p3r_traces {
-  size_t n_const;     const uint32_t* const_values;     /* n x 4 */
-  size_t n_public;    const uint32_t* public_values;    /* n x 4 */
-  size_t n_alu;       const uint32_t* alu_values;       /* n x 16: AluTrace.values [a,b,c,out] */
+  size_t n_const;     const uint32_t* const_values;     /* n x D (D = p3r_config.ext_degree) */
+  size_t n_public;    const uint32_t* public_values;    /* n x D */
+  size_t n_alu;       const uint32_t* alu_values;       /* n x 4D: AluTrace.values [a,b,c,out] */
   p3r_p2_rows p2;     /* n = un-padded Poseidon2 row count (any n, padding is done here) */
   size_t n_recompose; const uint32_t* recompose_values; /* n x 4 */
 } p3r_traces;

@@ -43,11 +43,14 @@ struct FriParams {
            query_pow_bits = 15, num_queries = 54;
 };
 
-inline p3r_config make_config(Field field, const FriParams& p, int device = 0, const std::vector<uint32_t>* rc = nullptr) {
+// ext_degree: the circuit extension degree of the traces - 4, or 5 for KoalaBear circuits over the quintic trinomial
+// extension (primitive tables, at the prove_all_tables boundary; include/p3r.h)
+inline p3r_config make_config(Field field, const FriParams& p, int device = 0, const std::vector<uint32_t>* rc = nullptr,
+                              uint32_t ext_degree = 4) {
   p3r_config c{};
   c.abi_version = P3R_ABI_VERSION;
   c.field = (uint32_t)field;
-  c.ext_degree = 4;
+  c.ext_degree = ext_degree;
   c.log_blowup = p.log_blowup; c.max_log_arity = p.max_log_arity; c.cap_height = p.cap_height;
   c.log_final_poly_len = p.log_final_poly_len; c.commit_pow_bits = p.commit_pow_bits;
   c.query_pow_bits = p.query_pow_bits; c.num_queries = p.num_queries;
@@ -59,9 +62,9 @@ inline p3r_config make_config(Field field, const FriParams& p, int device = 0, c
 // One per GPU, not thread-safe, one call in flight (the reference's RecursionOutput is !Send).
 class Context {
  public:
-  Context(Field field, const FriParams& fri, int device = 0, std::vector<uint32_t> poseidon2_rc = {})
+  Context(Field field, const FriParams& fri, int device = 0, std::vector<uint32_t> poseidon2_rc = {}, uint32_t ext_degree = 4)
       : field_(field), fri_(fri), rc_(std::move(poseidon2_rc)) {
-    cfg_ = make_config(field, fri, device, rc_.empty() ? nullptr : &rc_);
+    cfg_ = make_config(field, fri, device, rc_.empty() ? nullptr : &rc_, ext_degree);
     h_ = p3r_create(&cfg_);
     if (!h_) throw Error(P3R_ENODEV, p3r_last_error(nullptr));
   }
@@ -71,6 +74,7 @@ class Context {
   p3r_ctx* raw() const { return h_; }
   const p3r_config& config() const { return cfg_; }
   Field field() const { return field_; }
+  uint32_t ext_degree() const { return cfg_.ext_degree; }
   const FriParams& fri() const { return fri_; }
   void check(int rc) const { if (rc != P3R_OK) throw Error(rc, p3r_last_error(h_)); }
   template <class T> T* ptr(T* p) const { if (!p) throw Error(P3R_EINVAL, p3r_last_error(h_)); return p; }
@@ -108,8 +112,8 @@ struct TablePacking {
 
 // Flattened Traces<EF>, D = 4, canonical u32.
 struct Traces {
-  std::vector<uint32_t> const_values, public_values;  // n x 4
-  std::vector<uint32_t> alu_values;                   // n x 16: [a, b, c, out]
+  std::vector<uint32_t> const_values, public_values;  // n x D (D = the context's ext_degree)
+  std::vector<uint32_t> alu_values;                   // n x 4D: [a, b, c, out]
   std::vector<uint32_t> p2_input_values;              // n x 16
   std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_bit;
   std::vector<uint32_t> p2_mmcs_index_sum;
@@ -299,11 +303,15 @@ inline void verify_all_tables(const p3r_config& cfg, const BatchStarkProof& proo
   proof.validate();
   if (proof.preprocessed_commitment.empty()) throw Error(P3R_EINVAL, "proof carries no preprocessed commitment (stark_common)");
   // the proof's extension metadata must be the verifier's (batch_stark_prover.rs:1245-1263)
-  if (proof.ext_degree != 4)
-    throw Error(P3R_EINVAL, "ExtDegreeMismatch: proof has ext_degree " + std::to_string(proof.ext_degree) + ", the verifier expects 4");
+  if (proof.ext_degree != cfg.ext_degree)
+    throw Error(P3R_EINVAL, "ExtDegreeMismatch: proof has ext_degree " + std::to_string(proof.ext_degree) +
+                                ", the verifier expects " + std::to_string(cfg.ext_degree));
+  // EF = BinomialExtensionField<F, 4>: the field's W; EF = QuinticTrinomialExtensionField<F>: no W, the trinomial flag
+  const bool quintic = cfg.ext_degree == 5;
   const uint32_t want_w = cfg.field == P3R_FIELD_KOALA_BEAR ? 3u : 11u;
-  if (!proof.w_binomial || *proof.w_binomial != want_w) throw Error(P3R_EINVAL, "BinomialWMismatch");
-  if (proof.alu_quintic_trinomial) throw Error(P3R_EINVAL, "QuinticReductionMismatch");
+  if (quintic ? proof.w_binomial.has_value() : (!proof.w_binomial || *proof.w_binomial != want_w))
+    throw Error(P3R_EINVAL, "BinomialWMismatch");
+  if (proof.alu_quintic_trinomial != quintic) throw Error(P3R_EINVAL, "QuinticReductionMismatch");
   auto airs = proof.airs();
   if (proof.degree_bits.size() != airs.size() || proof.preprocessed_widths.size() != airs.size())
     throw Error(P3R_EINVAL, "InvalidProofShape: AIR list and stark_common metadata differ in length");
@@ -327,11 +335,13 @@ std::vector<uint8_t> proof_call(const Context& ctx, Fn&& fn) {
   buf.resize(n);
   return buf;
 }
-inline p3r_traces traces_struct(const Traces& t) {
+inline p3r_traces traces_struct(const Traces& t, uint32_t d = 4) {
   p3r_traces s{};
-  s.n_const = t.const_values.size() / 4; s.const_values = t.const_values.data();
-  s.n_public = t.public_values.size() / 4; s.public_values = t.public_values.data();
-  s.n_alu = t.alu_values.size() / 16; s.alu_values = t.alu_values.data();
+  if (t.const_values.size() % d || t.public_values.size() % d || t.alu_values.size() % (4 * d))
+    throw Error(P3R_EINVAL, "Traces values are not n x D / n x 4D for ext_degree " + std::to_string(d));
+  s.n_const = t.const_values.size() / d; s.const_values = t.const_values.data();
+  s.n_public = t.public_values.size() / d; s.public_values = t.public_values.data();
+  s.n_alu = t.alu_values.size() / (4 * d); s.alu_values = t.alu_values.data();
   s.p2.n = t.p2_input_values.size() / 16; s.p2.input_values = t.p2_input_values.data();
   s.p2.new_start = t.p2_new_start.data(); s.p2.merkle_path = t.p2_merkle_path.data(); s.p2.mmcs_bit = t.p2_mmcs_bit.data();
   s.p2.mmcs_index_sum = t.p2_mmcs_index_sum.data();
@@ -345,7 +355,7 @@ class ResidentTraces {
  public:
   ResidentTraces(const Context& ctx, p3r_dtraces* h) : ctx_(&ctx), h_(h) {}
   ResidentTraces(const Context& ctx, const CircuitProverData& cpd, const Traces& t) : ctx_(&ctx) {
-    p3r_traces s = detail::traces_struct(t);
+    p3r_traces s = detail::traces_struct(t, ctx.ext_degree());
     h_ = ctx.ptr(p3r_traces_upload(ctx.raw(), cpd.raw(), &s));
   }
   ~ResidentTraces() { if (h_) p3r_traces_free(ctx_->raw(), h_); }
@@ -428,7 +438,7 @@ class BatchStarkProver {
  public:
   BatchStarkProver(const Context& ctx, const TablePacking& packing) : ctx_(&ctx), table_packing_(packing) {}
   BatchStarkProof prove_all_tables(const Traces& traces, const CircuitProverData& cpd, bool canonical_field_encoding = false) const {
-    p3r_traces s = detail::traces_struct(traces);
+    p3r_traces s = detail::traces_struct(traces, ctx_->ext_degree());
     const uint32_t flags = canonical_field_encoding ? P3R_PROVE_CANONICAL_FIELD_ENCODING : 0;
     auto bytes = detail::proof_call(*ctx_, [&](uint8_t* b, size_t cap, size_t* n) { return p3r_prove_all_tables(ctx_->raw(), cpd.raw(), &s, flags, b, cap, n); });
     return wrap(std::move(bytes), cpd, canonical_field_encoding);
@@ -448,7 +458,9 @@ class BatchStarkProver {
     const TablePacking& tp = cpd.effective_packing();
     p.table_packing = tp;
     p.rows = {cpd.rows().n_const, cpd.rows().n_public, cpd.rows().n_alu};
-    p.w_binomial = binomial_w(ctx_->field());
+    p.ext_degree = ctx_->ext_degree();
+    if (p.ext_degree == 4) p.w_binomial = binomial_w(ctx_->field());
+    p.alu_quintic_trinomial = p.ext_degree == 5;
     const uint32_t k = tp.horner_packed_steps;
     const uint32_t widths[5] = {2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24, 2 * tp.recompose_lanes};
     for (int i = 0; i < 5; ++i) {
@@ -474,9 +486,8 @@ class BatchStarkProver {
 
 // ---- recursion API (recursion/src/recursion.rs)
 struct FriRecursionBackend {  // registers the Poseidon2 + Recompose table provers for D = 4 (backend/fri.rs:693-721)
-  void non_primitive_provers(size_t ext_degree) const {
-    if (ext_degree != 4) throw Error(P3R_EUNSUPPORTED, "UnsupportedDegree(" + std::to_string(ext_degree) + ")");
-  }
+  // and none for any other degree (`else { Vec::new() }`): a D = 5 layer is proved from its primitive tables
+  size_t non_primitive_provers(size_t ext_degree) const { return ext_degree == 4 ? 2 : 0; }
 };
 struct ProveNextLayerParams { TablePacking table_packing; };
 
@@ -489,7 +500,7 @@ struct NextLayerPrepCache {
 
 inline NextLayerPrepCache build_next_layer_prep(const Context& ctx, Circuit circuit, const FriRecursionBackend& backend,
                                                 const ProveNextLayerParams& params) {
-  backend.non_primitive_provers(4);
+  backend.non_primitive_provers(ctx.ext_degree());
   NextLayerPrepCache c;
   c.prover = std::make_unique<BatchStarkProver>(ctx, params.table_packing);
   c.prepared_circuit = std::make_unique<PreparedCircuit>(ctx, std::move(circuit), params.table_packing);
@@ -497,7 +508,7 @@ inline NextLayerPrepCache build_next_layer_prep(const Context& ctx, Circuit circ
 }
 inline NextLayerPrepCache build_next_layer_prep(const Context& ctx, const CircuitPrep& prep, const FriRecursionBackend& backend,
                                                 const ProveNextLayerParams& params) {
-  backend.non_primitive_provers(4);
+  backend.non_primitive_provers(ctx.ext_degree());
   NextLayerPrepCache c;
   c.prover = std::make_unique<BatchStarkProver>(ctx, params.table_packing);
   c.owned_prover_data = std::make_unique<CircuitProverData>(ctx, prep, params.table_packing);
@@ -515,7 +526,7 @@ struct RecursionOutput {
 
 inline RecursionOutput prove_next_layer(const RecursionInput& input, const Context& ctx, const FriRecursionBackend& backend,
                                         const ProveNextLayerParams&, const NextLayerPrepCache& prep) {
-  backend.non_primitive_provers(4);
+  backend.non_primitive_provers(ctx.ext_degree());
   (void)ctx;
   if (input.traces) return {prep.prover->prove_all_tables(*input.traces, prep.circuit_prover_data())};
   if (!input.circuit_inputs || !prep.prepared_circuit)
@@ -581,7 +592,7 @@ inline RecursionOutput prove_aggregation_layer(const RecursionInput& left, const
                                                uint32_t left_non_primitive_ops = 0) {
   if (!left.circuit_inputs || !right.circuit_inputs)
     throw Error(P3R_EINVAL, "prove_aggregation_layer needs the circuit inputs of both sides");
-  backend.non_primitive_provers(4);
+  backend.non_primitive_provers(ctx.ext_degree());
   const AggregationCircuitFingerprint fp = aggregation_circuit_fingerprint(verification_circuit);
   const CircuitInputs inputs = pack_aggregation_inputs(*left.circuit_inputs, *right.circuit_inputs, left_non_primitive_ops);
   if (prep_cache && *prep_cache && (*prep_cache)->circuit_fingerprint == fp) {

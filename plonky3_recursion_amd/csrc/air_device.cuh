@@ -20,12 +20,17 @@ namespace p3r {
 
 enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4 };
 
+constexpr int kMaxExtD = 5;  // widest circuit extension: bus tuples hold at most 1 + kMaxExtD fields
+
 struct AirParams {
   int kind;
   int lanes;
   int horner_k;
   int coeff_lookups;
   int lookup_unpacked = 0;  // p3r_config.ext_choices & P3R_EXT_LOOKUP_UNPACKED
+  // Circuit extension degree D of the table's witness values (p3r_config.ext_degree): 4 = binomial x^4 = W,
+  // 5 = KoalaBear quintic trinomial x^5 + x^2 - 1 (primitive tables only).  Bus tuples are (idx, v_0..v_{D-1}).
+  int ext_d = 4;
 };
 
 // Row window over column-major main / preprocessed matrices of a common height.
@@ -43,32 +48,55 @@ struct RowView {
   __device__ __forceinline__ F PN(int c) const { return F::raw(prep[(size_t)c * h + nxt]); }
 };
 
-template <class F>
-struct V4 {
-  F c[4];
+template <class F, int D>
+struct VD {
+  F c[D];
 };
-template <class V, class G>
-P3R_HD V4<V> load4(G&& get, int col) {
-  V4<V> r;
+template <class F>
+using V4 = VD<F, 4>;
+template <int D, class V, class G>
+P3R_HD VD<V, D> loadD(G&& get, int col) {
+  VD<V, D> r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r.c[i] = get(col + i);
+  for (int i = 0; i < D; ++i) r.c[i] = get(col + i);
   return r;
 }
-// x*y in F[x]/(x^4 - W) (alu_air.rs:715-733)
+template <class V, class G>
+P3R_HD V4<V> load4(G&& get, int col) { return loadD<4, V>(get, col); }
+// x*y in the circuit's extension: F[x]/(x^4 - W) (alu_air.rs:715-733) or, for D = 5, F[x]/(x^5 + x^2 - 1)
+// (ext_mul_quintic_trinomial, alu_air.rs:735-762: x^5 = 1 - x^2, x^6 = x - x^3, x^7 = x^2 - x^4,
+// x^8 = x^3 + x^2 - 1)
+template <class PP, int D, class V>
+P3R_HD VD<V, D> mulD(const VD<V, D>& a, const VD<V, D>& b) {
+  VD<V, D> r;
+  if constexpr (D == 4) {
+    const V W = Lift<V>::of(Fp<PP>::from_canonical(PP::EXT_W));
+    r.c[0] = a.c[0] * b.c[0] + W * (a.c[1] * b.c[3] + a.c[2] * b.c[2] + a.c[3] * b.c[1]);
+    r.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0] + W * (a.c[2] * b.c[3] + a.c[3] * b.c[2]);
+    r.c[2] = a.c[0] * b.c[2] + a.c[1] * b.c[1] + a.c[2] * b.c[0] + W * (a.c[3] * b.c[3]);
+    r.c[3] = a.c[0] * b.c[3] + a.c[1] * b.c[2] + a.c[2] * b.c[1] + a.c[3] * b.c[0];
+  } else {
+    static_assert(D == 5, "circuit extension degree must be 4 or 5");
+    const V c5 = a.c[1] * b.c[4] + a.c[2] * b.c[3] + a.c[3] * b.c[2] + a.c[4] * b.c[1];
+    const V c6 = a.c[2] * b.c[4] + a.c[3] * b.c[3] + a.c[4] * b.c[2];
+    const V c7 = a.c[3] * b.c[4] + a.c[4] * b.c[3];
+    const V c8 = a.c[4] * b.c[4];
+    const V c58 = c5 - c8;
+    r.c[0] = a.c[0] * b.c[0] + c58;
+    r.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0] + c6;
+    r.c[2] = a.c[0] * b.c[2] + a.c[1] * b.c[1] + a.c[2] * b.c[0] - c58 + c7;
+    r.c[3] = a.c[0] * b.c[3] + a.c[1] * b.c[2] + a.c[2] * b.c[1] + a.c[3] * b.c[0] - c6 + c8;
+    r.c[4] = a.c[0] * b.c[4] + a.c[1] * b.c[3] + a.c[2] * b.c[2] + a.c[3] * b.c[1] + a.c[4] * b.c[0] - c7;
+  }
+  return r;
+}
 template <class PP, class V>
-P3R_HD V4<V> mul4(const V4<V>& a, const V4<V>& b) {
-  const V W = Lift<V>::of(Fp<PP>::from_canonical(PP::EXT_W));
-  V4<V> r;
-  r.c[0] = a.c[0] * b.c[0] + W * (a.c[1] * b.c[3] + a.c[2] * b.c[2] + a.c[3] * b.c[1]);
-  r.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0] + W * (a.c[2] * b.c[3] + a.c[3] * b.c[2]);
-  r.c[2] = a.c[0] * b.c[2] + a.c[1] * b.c[1] + a.c[2] * b.c[0] + W * (a.c[3] * b.c[3]);
-  r.c[3] = a.c[0] * b.c[3] + a.c[1] * b.c[2] + a.c[2] * b.c[1] + a.c[3] * b.c[0];
-  return r;
-}
+P3R_HD V4<V> mul4(const V4<V>& a, const V4<V>& b) { return mulD<PP, 4, V>(a, b); }
 
 // ---------------------------------------------------------------- interactions (push order)
-// sink.add(idx, v, mult): one bus tuple (idx, v0..v3) with signed multiplicity.
-template <class PP, class View, class Sink>
+// sink.add(idx, v, mult): one bus tuple (idx, v_0..v_{D-1}) with signed multiplicity.  D is the circuit
+// extension degree of the primitive tables (a.ext_d); the Poseidon2 and Recompose tables exist for D = 4 only.
+template <class PP, int D = 4, class View, class Sink>
 P3R_HD void air_interactions(const AirParams& a, const View& v, Sink& sink) {
   using F = typename View::V;  // value type of the view
   auto L = [&](int c) { return v.L(c); };
@@ -76,140 +104,142 @@ P3R_HD void air_interactions(const AirParams& a, const View& v, Sink& sink) {
     case AIR_CONST:
     case AIR_PUBLIC:
       for (int lane = 0; lane < a.lanes; ++lane)
-        sink.add(v.PL(lane * 2 + 1), load4<F>(L, lane * 4), v.PL(lane * 2));
+        sink.add(v.PL(lane * 2 + 1), loadD<D, F>(L, lane * D), v.PL(lane * 2));
       break;
-    case AIR_RECOMPOSE: {
-      const int plw = 2 + (a.coeff_lookups ? 8 : 0);
-      for (int lane = 0; lane < a.lanes; ++lane) {
-        sink.add(v.PL(lane * plw), load4<F>(L, lane * 4), v.PL(lane * plw + 1));
-        if (a.coeff_lookups)
-          for (int i = 0; i < 4; ++i) {
-            V4<F> t;
-            t.c[0] = v.L(lane * 4 + i);
-            t.c[1] = t.c[2] = t.c[3] = F::zero();
-            sink.add(v.PL(lane * plw + 2 + 2 * i), t, v.PL(lane * plw + 3 + 2 * i));
-          }
+    case AIR_RECOMPOSE:
+      if constexpr (D == 4) {
+        const int plw = 2 + (a.coeff_lookups ? 8 : 0);
+        for (int lane = 0; lane < a.lanes; ++lane) {
+          sink.add(v.PL(lane * plw), load4<F>(L, lane * 4), v.PL(lane * plw + 1));
+          if (a.coeff_lookups)
+            for (int i = 0; i < 4; ++i) {
+              V4<F> t;
+              t.c[0] = v.L(lane * 4 + i);
+              t.c[1] = t.c[2] = t.c[3] = F::zero();
+              sink.add(v.PL(lane * plw + 2 + 2 * i), t, v.PL(lane * plw + 3 + 2 * i));
+            }
+        }
       }
-    } break;
+      break;
     case AIR_ALU: {
       const int lanes = a.lanes, k_max = a.horner_k;
       for (int lane = 0; lane < lanes; ++lane) {
-        const int m = lane * 16, p = lane * 13;
+        const int m = lane * 4 * D, p = lane * 13;
         F mult_a = v.PL(p), a_rd = v.PL(p + 11), c_rd = v.PL(p + 12);
-        sink.add(v.PL(p + 5), load4<F>(L, m), mult_a * a_rd);
-        sink.add(v.PL(p + 6), load4<F>(L, m + 4), v.PL(p + 9));
-        sink.add(v.PL(p + 7), load4<F>(L, m + 8), mult_a * c_rd);
-        sink.add(v.PL(p + 8), load4<F>(L, m + 12), v.PL(p + 10));
+        sink.add(v.PL(p + 5), loadD<D, F>(L, m), mult_a * a_rd);
+        sink.add(v.PL(p + 6), loadD<D, F>(L, m + D), v.PL(p + 9));
+        sink.add(v.PL(p + 7), loadD<D, F>(L, m + 2 * D), mult_a * c_rd);
+        sink.add(v.PL(p + 8), loadD<D, F>(L, m + 3 * D), v.PL(p + 10));
       }
-      const int extra_main = lanes * 16, extra_prep = lanes * 13;
-      const int ac_base = extra_main + ((k_max - 1) / 2) * 4;
+      const int extra_main = lanes * 4 * D, extra_prep = lanes * 13;
+      const int ac_base = extra_main + ((k_max - 1) / 2) * D;
       for (int t = 1; t < k_max; ++t) {
         const int sp = extra_prep + (k_max - 1) + 6 * (t - 1);
-        const int off = ac_base + 8 * (t - 1);
-        sink.add(v.PL(sp), load4<F>(L, off), v.PL(sp + 4));
-        sink.add(v.PL(sp + 1), load4<F>(L, off + 4), v.PL(sp + 5));
+        const int off = ac_base + 2 * D * (t - 1);
+        sink.add(v.PL(sp), loadD<D, F>(L, off), v.PL(sp + 4));
+        sink.add(v.PL(sp + 1), loadD<D, F>(L, off + D), v.PL(sp + 5));
       }
     } break;
-    case AIR_POSEIDON2: {
-      constexpr int R = PP::SBOX_REGISTERS;
-      constexpr int pc = p2_perm_cols<PP>();
-      constexpr int out_col = pc - P2_WIDTH;  // ending_full_rounds[3].post
-      (void)R;
-      F not_merkle = F::one() - v.PL(23);
-      for (int l = 0; l < 4; ++l)
-        sink.add(v.PL(l * 4), load4<F>(L, l * 4), -(v.PL(l * 4 + 1) * not_merkle));
-      for (int l = 0; l < 2; ++l)
-        sink.add(v.PL(16 + l * 2), load4<F>(L, out_col + l * 4), v.PL(16 + l * 2 + 1));
-      V4<F> t;
-      t.c[0] = v.L(pc + 1);
-      t.c[1] = t.c[2] = t.c[3] = F::zero();
-      sink.add(v.PL(20), t, -(v.PL(21) * v.PN(22)));
-    } break;
+    case AIR_POSEIDON2:
+      if constexpr (D == 4) {
+        constexpr int pc = p2_perm_cols<PP>();
+        constexpr int out_col = pc - P2_WIDTH;  // ending_full_rounds[3].post
+        F not_merkle = F::one() - v.PL(23);
+        for (int l = 0; l < 4; ++l)
+          sink.add(v.PL(l * 4), load4<F>(L, l * 4), -(v.PL(l * 4 + 1) * not_merkle));
+        for (int l = 0; l < 2; ++l)
+          sink.add(v.PL(16 + l * 2), load4<F>(L, out_col + l * 4), v.PL(16 + l * 2 + 1));
+        V4<F> t;
+        t.c[0] = v.L(pc + 1);
+        t.c[1] = t.c[2] = t.c[3] = F::zero();
+        sink.add(v.PL(20), t, -(v.PL(21) * v.PN(22)));
+      }
+      break;
   }
 }
 
 // ---------------------------------------------------------------- constraints
 // fold.base(c): the next base-field constraint value, in declaration order.
-template <class PP, class View, class Fold>
+template <class PP, int D = 4, class View, class Fold>
 P3R_HD void alu_constraints(const AirParams& a, const View& v, Fold& fold) {
   using F = typename View::V;
   auto L = [&](int c) { return v.L(c); };
   auto N = [&](int c) { return v.N(c); };
   const int lanes = a.lanes, k_max = a.horner_k;
-  const int extra_main = lanes * 16, extra_prep = lanes * 13;
+  const int extra_main = lanes * 4 * D, extra_prep = lanes * 13;
   const int num_int = (k_max - 1) / 2;
-  const int ac_base = extra_main + num_int * 4;
+  const int ac_base = extra_main + num_int * D;
   const F one = F::one();
   for (int lane = 0; lane < lanes; ++lane) {
-    const int m = lane * 16, p = lane * 13;
-    V4<F> A = load4<F>(L, m), B = load4<F>(L, m + 4), C = load4<F>(L, m + 8), O = load4<F>(L, m + 12);
+    const int m = lane * 4 * D, p = lane * 13;
+    VD<F, D> A = loadD<D, F>(L, m), B = loadD<D, F>(L, m + D), C = loadD<D, F>(L, m + 2 * D), O = loadD<D, F>(L, m + 3 * D);
     F mult_a = v.PL(p), sel_add = v.PL(p + 1), sel_bool = v.PL(p + 2), sel_muladd = v.PL(p + 3),
       sel_horner = v.PL(p + 4);
     F sel_mul = -mult_a - sel_bool - sel_muladd - sel_horner - sel_add;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fold.base(sel_add * (A.c[i] + B.c[i] - O.c[i]));
-    V4<F> ab = mul4<PP, F>(A, B);
+    for (int i = 0; i < D; ++i) fold.base(sel_add * (A.c[i] + B.c[i] - O.c[i]));
+    VD<F, D> ab = mulD<PP, D, F>(A, B);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fold.base(sel_mul * (ab.c[i] - O.c[i]));
+    for (int i = 0; i < D; ++i) fold.base(sel_mul * (ab.c[i] - O.c[i]));
     fold.base(sel_bool * A.c[0] * (A.c[0] - one));
 #pragma unroll
-    for (int i = 1; i < 4; ++i) fold.base(sel_bool * A.c[i]);
+    for (int i = 1; i < D; ++i) fold.base(sel_bool * A.c[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fold.base(sel_muladd * (ab.c[i] + C.c[i] - O.c[i]));
+    for (int i = 0; i < D; ++i) fold.base(sel_muladd * (ab.c[i] + C.c[i] - O.c[i]));
     F next_sel_horner = v.PN(p + 4);
-    V4<F> NA = load4<F>(N, m), NB = load4<F>(N, m + 4), NC = load4<F>(N, m + 8), NO = load4<F>(N, m + 12);
-    V4<F> out_next_b = mul4<PP, F>(O, NB);
+    VD<F, D> NA = loadD<D, F>(N, m), NB = loadD<D, F>(N, m + D), NC = loadD<D, F>(N, m + 2 * D), NO = loadD<D, F>(N, m + 3 * D);
+    VD<F, D> out_next_b = mulD<PP, D, F>(O, NB);
     if (lane == 0) {
       F any_cur = F::zero(), any_next = F::zero(), sel_ge3_next = F::zero();
       for (int kk = 2; kk <= k_max; ++kk) any_cur += v.PL(extra_prep + kk - 2);
       for (int kk = 2; kk <= k_max; ++kk) any_next += v.PN(extra_prep + kk - 2);
       F next_sel_k2 = v.PN(extra_prep);
       for (int kk = 3; kk <= k_max; ++kk) sel_ge3_next += v.PN(extra_prep + kk - 2);
-      const int b_sq_base = ac_base + 8 * (k_max - 1);
-      V4<F> b_sq = load4<F>(L, b_sq_base), b_sq_next = load4<F>(N, b_sq_base);
-      V4<F> bb = mul4<PP, F>(B, B);
+      const int b_sq_base = ac_base + 2 * D * (k_max - 1);
+      VD<F, D> b_sq = loadD<D, F>(L, b_sq_base), b_sq_next = loadD<D, F>(N, b_sq_base);
+      VD<F, D> bb = mulD<PP, D, F>(B, B);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fold.base(any_cur * (b_sq.c[i] - bb.c[i]));
-      V4<F> out_b_sq = mul4<PP, F>(O, b_sq_next), c0b = mul4<PP, F>(NC, NB), a0b = mul4<PP, F>(NA, NB);
-      V4<F> a1n = load4<F>(N, ac_base), c1n = load4<F>(N, ac_base + 4), int0n = load4<F>(N, extra_main);
+      for (int i = 0; i < D; ++i) fold.base(any_cur * (b_sq.c[i] - bb.c[i]));
+      VD<F, D> out_b_sq = mulD<PP, D, F>(O, b_sq_next), c0b = mulD<PP, D, F>(NC, NB), a0b = mulD<PP, D, F>(NA, NB);
+      VD<F, D> a1n = loadD<D, F>(N, ac_base), c1n = loadD<D, F>(N, ac_base + D), int0n = loadD<D, F>(N, extra_main);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < D; ++i) {
         F poly = out_b_sq.c[i] + c0b.c[i] - a0b.c[i] + c1n.c[i] - a1n.c[i];
         fold.base(next_sel_k2 * (poly - NO.c[i]));
         fold.base(sel_ge3_next * (poly - int0n.c[i]));
       }
       F next_sel_single = next_sel_horner - any_next;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fold.base(next_sel_single * (out_next_b.c[i] + NC.c[i] - NA.c[i] - NO.c[i]));
+      for (int i = 0; i < D; ++i) fold.base(next_sel_single * (out_next_b.c[i] + NC.c[i] - NA.c[i] - NO.c[i]));
       for (int kk = 3; kk <= k_max; ++kk) {
         F sel_kk = v.PL(extra_prep + kk - 2);
         int s = 2, slot = 0;
         while (s < kk) {
-          V4<F> int_curr = load4<F>(L, extra_main + slot * 4);
-          const int off_s = ac_base + 8 * (s - 1);
-          V4<F> a_s = load4<F>(L, off_s), c_s = load4<F>(L, off_s + 4);
+          VD<F, D> int_curr = loadD<D, F>(L, extra_main + slot * D);
+          const int off_s = ac_base + 2 * D * (s - 1);
+          VD<F, D> a_s = loadD<D, F>(L, off_s), c_s = loadD<D, F>(L, off_s + D);
           if (s + 1 < kk) {
-            const int off_sp1 = ac_base + 8 * s;
-            V4<F> a_sp1 = load4<F>(L, off_sp1), c_sp1 = load4<F>(L, off_sp1 + 4);
-            V4<F> int_b_sq = mul4<PP, F>(int_curr, b_sq), c_s_b = mul4<PP, F>(c_s, B), a_s_b = mul4<PP, F>(a_s, B);
+            const int off_sp1 = ac_base + 2 * D * s;
+            VD<F, D> a_sp1 = loadD<D, F>(L, off_sp1), c_sp1 = loadD<D, F>(L, off_sp1 + D);
+            VD<F, D> int_b_sq = mulD<PP, D, F>(int_curr, b_sq), c_s_b = mulD<PP, D, F>(c_s, B), a_s_b = mulD<PP, D, F>(a_s, B);
             const bool to_out = s + 2 >= kk;
-            V4<F> target = to_out ? O : load4<F>(L, extra_main + (slot + 1) * 4);
+            VD<F, D> target = to_out ? O : loadD<D, F>(L, extra_main + (slot + 1) * D);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < D; ++i)
               fold.base(sel_kk * (int_b_sq.c[i] + c_s_b.c[i] - a_s_b.c[i] + c_sp1.c[i] - a_sp1.c[i] - target.c[i]));
             if (!to_out) slot += 1;
             s += 2;
           } else {
-            V4<F> int_b = mul4<PP, F>(int_curr, B);
+            VD<F, D> int_b = mulD<PP, D, F>(int_curr, B);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fold.base(sel_kk * (int_b.c[i] + c_s.c[i] - a_s.c[i] - O.c[i]));
+            for (int i = 0; i < D; ++i) fold.base(sel_kk * (int_b.c[i] + c_s.c[i] - a_s.c[i] - O.c[i]));
             s += 1;
           }
         }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fold.base(next_sel_horner * (out_next_b.c[i] + NC.c[i] - NA.c[i] - NO.c[i]));
+      for (int i = 0; i < D; ++i) fold.base(next_sel_horner * (out_next_b.c[i] + NC.c[i] - NA.c[i] - NO.c[i]));
     }
   }
 }
@@ -301,16 +331,17 @@ __host__ __device__ inline int air_num_base_constraints(const AirParams& a) {
   switch (a.kind) {
     case AIR_ALU: {
       int n = 0;
+      const int D = a.ext_d;
       for (int lane = 0; lane < a.lanes; ++lane) {
-        n += 4 + 4 + 4 + 4;
+        n += 4 * D;
         if (lane == 0) {
-          n += 4 + 8 + 4;
+          n += 4 * D;
           for (int kk = 3; kk <= a.horner_k; ++kk) {
             int s = 2;
-            while (s < kk) { n += 4; s += (s + 1 < kk) ? 2 : 1; }
+            while (s < kk) { n += D; s += (s + 1 < kk) ? 2 : 1; }
           }
         } else {
-          n += 4;
+          n += D;
         }
       }
       return n;

@@ -295,6 +295,36 @@ struct Fp4 {
   }
 };
 
+// Degree-5 extension F[x]/(x^5 + x^2 - 1) of KoalaBear (p3-field's QuinticTrinomialExtensionField): the field of
+// D = 5 circuits.  Only what trace generation needs (the ALU table's packed-Horner intermediates): ring
+// operations; the STARK's challenge field stays Fp4.
+template <class PP>
+inline constexpr bool kHasQuintic = PP::P == 0x7f000001u;
+template <class PP>
+struct Fp5 {
+  using F = Fp<PP>;
+  F c[5];
+  static P3R_HD Fp5 zero() { Fp5 r; for (int i = 0; i < 5; ++i) r.c[i] = F::zero(); return r; }
+  friend P3R_HD Fp5 operator+(Fp5 a, Fp5 b) { Fp5 r; for (int i = 0; i < 5; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+  friend P3R_HD Fp5 operator-(Fp5 a, Fp5 b) { Fp5 r; for (int i = 0; i < 5; ++i) r.c[i] = a.c[i] - b.c[i]; return r; }
+  friend P3R_HD Fp5 operator*(Fp5 a, Fp5 b) {
+    // schoolbook coefficients c0..c8 (paired products share a reduction), then x^5 = 1 - x^2 from the top:
+    // r0 = c0 + c5 - c8, r1 = c1 + c6, r2 = c2 - c5 + c7 + c8, r3 = c3 - c6 + c8, r4 = c4 - c7
+    const F c5 = F::dot2(a.c[1], b.c[4], a.c[2], b.c[3]) + F::dot2(a.c[3], b.c[2], a.c[4], b.c[1]);
+    const F c6 = F::dot2(a.c[2], b.c[4], a.c[3], b.c[3]) + a.c[4] * b.c[2];
+    const F c7 = F::dot2(a.c[3], b.c[4], a.c[4], b.c[3]);
+    const F c8 = a.c[4] * b.c[4];
+    const F c58 = c5 - c8;
+    Fp5 r;
+    r.c[0] = a.c[0] * b.c[0] + c58;
+    r.c[1] = F::dot2(a.c[0], b.c[1], a.c[1], b.c[0]) + c6;
+    r.c[2] = F::dot2(a.c[0], b.c[2], a.c[1], b.c[1]) + a.c[2] * b.c[0] - c58 + c7;
+    r.c[3] = F::dot2(a.c[0], b.c[3], a.c[1], b.c[2]) + F::dot2(a.c[2], b.c[1], a.c[3], b.c[0]) - c6 + c8;
+    r.c[4] = F::dot2(a.c[0], b.c[4], a.c[1], b.c[3]) + F::dot2(a.c[2], b.c[2], a.c[3], b.c[1]) + a.c[4] * b.c[0] - c7;
+    return r;
+  }
+};
+
 // Embedding of a base-field constant into the value type a generic routine computes in
 // (the base field itself for the prover's kernels, the extension for evaluations at zeta).
 template <class V> struct Lift;

@@ -136,9 +136,9 @@ inline int fri_log_arity(const std::vector<uint8_t>& schedule, size_t phase, int
 
 inline int air_width_of(const AirParams& a, int p2_width) {
   switch (a.kind) {
-    case AIR_CONST: return 4;
-    case AIR_PUBLIC: return a.lanes * 4;
-    case AIR_ALU: return a.lanes * 16 + ((a.horner_k - 1) / 2 + 2 * (a.horner_k - 1) + 1) * 4;
+    case AIR_CONST: return a.ext_d;
+    case AIR_PUBLIC: return a.lanes * a.ext_d;
+    case AIR_ALU: return (a.lanes * 4 + (a.horner_k - 1) / 2 + 2 * (a.horner_k - 1) + 1) * a.ext_d;
     case AIR_POSEIDON2: return p2_width;
     case AIR_RECOMPOSE: return a.lanes * 4;
   }

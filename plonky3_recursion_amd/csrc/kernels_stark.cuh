@@ -28,17 +28,17 @@ __host__ __device__ __forceinline__ E4 e4_store(const Fp4<PP>& e) {
   return r;
 }
 
-// LogUp challenges: denominator = prefix + sum_j beta^j * field_j, tuple = (idx, v0..v3)
-// (recursion/src/verifier/batch_stark.rs:1086-1100).
+// LogUp challenges: denominator = prefix + sum_j beta^j * field_j, tuple = (idx, v_0..v_{D-1}) for circuit
+// extension degree D, prefix = alpha + beta^(D+1) (recursion/src/verifier/batch_stark.rs:1086-1100).
 struct LookupCh {
   E4 prefix;
-  E4 beta_pow[5];
+  E4 beta_pow[kMaxExtD + 1];
 };
-template <class PP>
-__device__ __forceinline__ Fp4<PP> lookup_denom(const LookupCh& lc, Fp<PP> idx, const V4<Fp<PP>>& v) {
+template <class PP, int D>
+__device__ __forceinline__ Fp4<PP> lookup_denom(const LookupCh& lc, Fp<PP> idx, const VD<Fp<PP>, D>& v) {
   Fp4<PP> d = e4_load<PP>(lc.prefix) + e4_load<PP>(lc.beta_pow[0]) * idx;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) d += e4_load<PP>(lc.beta_pow[j + 1]) * v.c[j];
+  for (int j = 0; j < D; ++j) d += e4_load<PP>(lc.beta_pow[j + 1]) * v.c[j];
   return d;
 }
 
@@ -65,8 +65,9 @@ struct AuxSink {
     total += cur;
     cur = E::zero();
   }
-  __device__ __forceinline__ void add(F idx, const V4<F>& v, F mult) {
-    if (mult.v != 0) cur += lookup_denom<PP>(lc, idx, v).inv() * mult;
+  template <int D>
+  __device__ __forceinline__ void add(F idx, const VD<F, D>& v, F mult) {
+    if (mult.v != 0) cur += lookup_denom<PP, D>(lc, idx, v).inv() * mult;
     ++cnt;
     if (!pair || (cnt & 1) == 0) flush();
   }
@@ -91,7 +92,7 @@ struct LogupJob {
   uint32_t tile0;        // first block in the tile launches (k_ef_scan modes 0 and 2)
 };
 
-template <class PP>
+template <class PP, int D = 4>
 __global__ void __launch_bounds__(kBlock)
 k_logup_aux(const LogupJob* __restrict__ jobs, int n_jobs, LookupCh lc) {
   int jb = 0;
@@ -101,7 +102,7 @@ k_logup_aux(const LogupJob* __restrict__ jobs, int n_jobs, LookupCh lc) {
   if (r >= n) return;
   RowView<PP> v{as_global(job.main), as_global(job.prep), n, r, r + 1 == n ? 0 : r + 1};
   AuxSink<PP> sink(lc, as_global(job.aux), n, r, job.pair);
-  air_interactions<PP>(job.air, v, sink);
+  air_interactions<PP, D>(job.air, v, sink);
   sink.finish();
   const gptr<uint32_t> rowsum = as_global(job.rowsum);
 #pragma unroll
@@ -263,8 +264,9 @@ struct QuotSink {
     for (int k = 0; k < 4; ++k) e.c[k] = F::raw(aux[(size_t)(col * 4 + k) * q.lde_h + r]);
     return e;
   }
-  __device__ __forceinline__ void add(F idx, const V4<F>& v, F mult) {
-    E d = lookup_denom<PP>(lc, idx, v);
+  template <int D>
+  __device__ __forceinline__ void add(F idx, const VD<F, D>& v, F mult) {
+    E d = lookup_denom<PP, D>(lc, idx, v);
     ++cnt;
     if (!q.pair) {
       E f = aux_at(cnt, row);
@@ -290,7 +292,7 @@ struct QuotSink {
 
 // One launch for all tables of a proof: `jobs` lists them, a block finds its table by walking the
 // first-block indices.  The LogUp challenges and the round constants are the same for every table.
-template <class PP>
+template <class PP, int D = 4>
 __global__ void __launch_bounds__(kBlock)
 k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const uint32_t* __restrict__ rc) {
   using F = Fp<PP>;
@@ -310,13 +312,14 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const
   const F zh = F::raw(q.zh[c]), g_inv = F::raw(q.g_inv);
   const F is_transition = x - g_inv;
   BaseFold<PP> fold(as_global(q.apow), q.n_constraints);
-  if (q.air.kind == AIR_ALU) alu_constraints<PP>(q.air, v, fold);
-  else if (q.air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc, fold);
+  if (q.air.kind == AIR_ALU) alu_constraints<PP, D>(q.air, v, fold);
+  if constexpr (D == 4)
+    if (q.air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc, fold);
   if (q.aux) {
     const F is_first = zh * (x - F::one()).inv();
     const F is_last = zh * is_transition.inv();
     QuotSink<PP> sink(q, lc, fold, j);
-    air_interactions<PP>(q.air, v, sink);
+    air_interactions<PP, D>(q.air, v, sink);
     sink.finish();
     E s = sink.aux_at(0, j), s_next = sink.aux_at(0, v.nxt);
     fold.ext(s * is_first);

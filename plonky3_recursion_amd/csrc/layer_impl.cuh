@@ -20,38 +20,37 @@ namespace {
 
 // (AluPlanEntry / PLAN_*: run_schedule.h)
 
-// K1: one lane per trace row.
-template <class PP>
+// K1: one lane per trace row.  E = the circuit's extension field (Fp4, or Fp5 for D = 5 circuits), D its degree.
+template <class PP, class E, int D>
 __global__ void __launch_bounds__(kBlock)
 k_alu_trace(const AluPlanEntry* __restrict__ plan, const uint32_t* __restrict__ prev_src /* per row */,
-            const uint32_t* __restrict__ values /* [n_ops][16] Montgomery */, size_t rows, size_t h, int lanes,
+            const uint32_t* __restrict__ values /* [n_ops][4 D] Montgomery */, size_t rows, size_t h, int lanes,
             int k_max, uint32_t* __restrict__ out /* [width][h] */) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
   size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (row >= rows) return;
   auto val = [&](uint32_t op, int operand) {
     E e;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) e.c[d] = F::raw(values[(size_t)op * 16 + operand * 4 + d]);
+    for (int d = 0; d < D; ++d) e.c[d] = F::raw(values[(size_t)op * (4 * D) + operand * D + d]);
     return e;
   };
   auto put = [&](int col, const E& e) {
 #pragma unroll
-    for (int d = 0; d < 4; ++d) out[(size_t)(col + d) * h + row] = e.c[d].v;
+    for (int d = 0; d < D; ++d) out[(size_t)(col + d) * h + row] = e.c[d].v;
   };
   const int num_int = (k_max - 1) / 2;
   for (int lane = 0; lane < lanes; ++lane) {
     AluPlanEntry en = plan[row * lanes + lane];
-    const int base = lane * 16;
+    const int base = lane * 4 * D;
     if (en.kind == PLAN_OP) {
-      for (int o = 0; o < 4; ++o) put(base + o * 4, val(en.first, o));
+      for (int o = 0; o < 4; ++o) put(base + o * D, val(en.first, o));
     } else if (en.kind == PLAN_PACKED) {
       const int k = en.k;
-      for (int o = 0; o < 3; ++o) put(base + o * 4, val(en.first, o));
-      put(base + 12, val(en.first + k - 1, 3));
+      for (int o = 0; o < 3; ++o) put(base + o * D, val(en.first, o));
+      put(base + 3 * D, val(en.first + k - 1, 3));
       if (lane == 0) {
-        const int extra = lanes * 16;
+        const int extra = lanes * 4 * D;
         const uint32_t ps = prev_src[row];
         E acc = ps == 0xFFFFFFFFu ? E::zero() : val(ps, 3);
         const E b = val(en.first, 1);
@@ -66,14 +65,14 @@ k_alu_trace(const AluPlanEntry* __restrict__ plan, const uint32_t* __restrict__ 
             acc = acc * b + val(i0, 2) - val(i0, 0);
             step += 1;
           }
-          put(extra + s * 4, acc);
+          put(extra + s * D, acc);
         }
-        const int ac_base = extra + num_int * 4;
+        const int ac_base = extra + num_int * D;
         for (int t = 1; t < k; ++t) {
-          put(ac_base + 8 * (t - 1), val(en.first + t, 0));
-          put(ac_base + 8 * (t - 1) + 4, val(en.first + t, 2));
+          put(ac_base + 2 * D * (t - 1), val(en.first + t, 0));
+          put(ac_base + 2 * D * (t - 1) + D, val(en.first + t, 2));
         }
-        put(ac_base + 8 * (k_max - 1), b * b);
+        put(ac_base + 2 * D * (k_max - 1), b * b);
       }
     }
   }
@@ -211,6 +210,9 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   L->has_p2 = d->counts.n_p2 > 0;
   L->has_recompose = d->counts.n_recompose > 0;
   if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
+  if (ctx->cfg.ext_degree != 4 && (L->has_p2 || L->has_recompose))
+    fail(P3R_EUNSUPPORTED, "UnsupportedDegree(%u): D = 5 layers hold the primitive tables (Const, Public, ALU) only",
+         ctx->cfg.ext_degree);
   const auto& c = d->counts;
   auto check = [&](const uint32_t* p, size_t n, const char* what) {
     if (n && !p) fail(P3R_EINVAL, "%s is NULL", what);
@@ -381,9 +383,10 @@ std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, con
     fail(P3R_EINVAL, "trace row counts do not match the prepared circuit shape");
   auto d = std::make_unique<p3r_dtraces>();
   d->n_const = c.n_const; d->n_public = c.n_public; d->n_alu = c.n_alu; d->n_recompose = c.n_recompose;
-  d->const_values = upload_mont<PP>(ctx, t->const_values, c.n_const * 4, "const_values");
-  d->public_values = upload_mont<PP>(ctx, t->public_values, c.n_public * 4, "public_values");
-  d->alu_values = upload_mont<PP>(ctx, t->alu_values, c.n_alu * 16, "alu_values");
+  const size_t D = ctx->cfg.ext_degree;  // values are n x D (Const, Public), n x 4D (ALU: a, b, c, out)
+  d->const_values = upload_mont<PP>(ctx, t->const_values, c.n_const * D, "const_values");
+  d->public_values = upload_mont<PP>(ctx, t->public_values, c.n_public * D, "public_values");
+  d->alu_values = upload_mont<PP>(ctx, t->alu_values, c.n_alu * 4 * D, "alu_values");
   d->recompose_values = upload_mont<PP>(ctx, t->recompose_values, c.n_recompose * 4, "recompose_values");
   if (!L->has_p2) return d;
   // Poseidon2 rows padded with fillers: new_start = true, zero state (poseidon2.rs:1125-1140)
@@ -408,27 +411,35 @@ std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, con
 template <class PP>
 std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t) {
   std::vector<std::unique_ptr<p3r_dmat>> m(5);
-  auto flat = [&](const DevBuf& src, size_t n_ops, size_t h, int w) {
+  const int D = (int)ctx->cfg.ext_degree;
+  auto flat = [&](const DevBuf& src, size_t n_ops, size_t h, int w, int per_op) {
     auto out = dmat_alloc(h, (size_t)w);
     ProfScope ps(ctx, "trace_to_matrix");
     hipLaunchKernelGGL(k_flat_to_colmajor<PP>, dim3(blocks_for(h * w)), dim3(kBlock), 0, ctx->stream, src.p,
-                       n_ops * 4, out->d, h, w);
+                       n_ops * per_op, out->d, h, w);
     return out;
   };
-  m[0] = flat(t->const_values, t->n_const, L->h_const, 4);
-  m[1] = flat(t->public_values, t->n_public, L->h_public, (int)L->public_lanes * 4);
+  m[0] = flat(t->const_values, t->n_const, L->h_const, D, D);
+  m[1] = flat(t->public_values, t->n_public, L->h_public, (int)L->public_lanes * D, D);
   {
     const int lanes = (int)L->alu_lanes, k = (int)L->horner_k;
-    const int width = lanes * 16 + ((k - 1) / 2 + 2 * (k - 1) + 1) * 4;
+    const int width = (lanes * 4 + (k - 1) / 2 + 2 * (k - 1) + 1) * D;
     m[2] = dmat_alloc(L->h_alu, (size_t)width);
     P3R_HIP(hipMemsetAsync(m[2]->d, 0, L->h_alu * (size_t)width * 4, ctx->stream));
     ProfScope ps(ctx, "alu_trace");
-    hipLaunchKernelGGL(k_alu_trace<PP>, dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream,
-                       reinterpret_cast<const AluPlanEntry*>(L->alu_plan.p), L->alu_prev_src.p, t->alu_values.p,
-                       L->alu_rows, L->h_alu, lanes, k, m[2]->d);
+    const auto* plan = reinterpret_cast<const AluPlanEntry*>(L->alu_plan.p);
+    if (D == 5) {
+      if constexpr (kHasQuintic<PP>)
+        hipLaunchKernelGGL((k_alu_trace<PP, Fp5<PP>, 5>), dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream, plan,
+                           L->alu_prev_src.p, t->alu_values.p, L->alu_rows, L->h_alu, lanes, k, m[2]->d);
+    } else {
+      hipLaunchKernelGGL((k_alu_trace<PP, Fp4<PP>, 4>), dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream, plan,
+                         L->alu_prev_src.p, t->alu_values.p, L->alu_rows, L->h_alu, lanes, k, m[2]->d);
+    }
   }
   if (L->has_p2) m[3] = trace_fill<PP>(ctx, t->p2.get());
-  if (L->has_recompose) m[4] = flat(t->recompose_values, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * 4);
+  if (L->has_recompose)
+    m[4] = flat(t->recompose_values, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * 4, 4);
   P3R_HIP(hipGetLastError());
   return m;
 }

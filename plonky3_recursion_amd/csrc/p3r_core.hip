@@ -866,8 +866,10 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
       fail(P3R_EINVAL, "abi_version %u != %u", cfg->abi_version, P3R_ABI_VERSION);
     if (cfg->field != P3R_FIELD_KOALA_BEAR && cfg->field != P3R_FIELD_BABY_BEAR)
       fail(P3R_EUNSUPPORTED, "unsupported field id %u", cfg->field);
-    if (cfg->ext_degree != 4)
-      fail(P3R_EUNSUPPORTED, "unsupported extension degree %u (only D=4)", cfg->ext_degree);
+    // circuit extension degree: 4 (binomial) on both fields; 5 = the KoalaBear quintic trinomial extension, proved
+    // under the same D = 4 STARK configuration (batch_stark_prover/tests.rs:844-1029), primitive tables only
+    if (cfg->ext_degree != 4 && !(cfg->ext_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR))
+      fail(P3R_EUNSUPPORTED, "unsupported extension degree %u (D = 4, or D = 5 over KoalaBear)", cfg->ext_degree);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -1244,7 +1246,7 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
   try {
     if (!cfg || !airs || !preprocessed_commitment || !degree_bits || (!proof && proof_len)) { report("NULL argument"); return P3R_EINVAL; }
     if (cfg->abi_version != P3R_ABI_VERSION) { report("ABI version mismatch"); return P3R_EINVAL; }
-    if (cfg->ext_degree != 4) { report("UnsupportedDegree"); return P3R_EUNSUPPORTED; }
+    if (cfg->ext_degree != 4 && !(cfg->ext_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR)) { report("UnsupportedDegree"); return P3R_EUNSUPPORTED; }
     p3r::VerifyParams prm{(int)cfg->log_blowup, (int)cfg->max_log_arity, (int)cfg->cap_height, (int)cfg->log_final_poly_len,
                           (int)cfg->commit_pow_bits, (int)cfg->query_pow_bits, (int)cfg->num_queries, {}};
     if (cfg->fri_log_arities) prm.fri_log_arities.assign(cfg->fri_log_arities, cfg->fri_log_arities + cfg->fri_log_arities_len);
@@ -1253,7 +1255,8 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     for (size_t i = 0; i < n_airs; ++i) {
       if (airs[i].kind > P3R_AIR_RECOMPOSE || !airs[i].lanes) { report("bad AIR descriptor"); return P3R_EINVAL; }
       a[i] = {(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
-              (cfg->ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0};
+              (cfg->ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)cfg->ext_degree};
+      if (cfg->ext_degree != 4 && airs[i].kind > P3R_AIR_ALU) { report("UnsupportedDegree: D = 5 covers the primitive tables"); return P3R_EUNSUPPORTED; }
     }
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     std::vector<uint32_t> cap(preprocessed_commitment, preprocessed_commitment + ((size_t)P2_DIGEST << cfg->cap_height));
@@ -1325,6 +1328,9 @@ p3r_circuit* p3r_circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* desc, uint
   p3r_circuit* out = nullptr;
   guard(ctx, [&] {
     if (!desc || !commit_out) fail(P3R_EINVAL, "NULL argument");
+    // the device CircuitRunner computes in the D = 4 binomial extension; D = 5 layers enter at prove_all_tables
+    if (ctx->cfg.ext_degree != 4)
+      fail(P3R_EUNSUPPORTED, "UnsupportedDegree(%u): the circuit boundary runs D = 4 circuits", ctx->cfg.ext_degree);
     out = P3R_FIELD_CALL(ctx, circuit_create, ctx, desc, commit_out).release();
   });
   return out;

@@ -128,8 +128,10 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
   std::vector<LdeItem> items;
   for (size_t i = 0; i < n; ++i) {
     AirParams a{(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
-                (ctx->cfg.ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0};
+                (ctx->cfg.ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)ctx->cfg.ext_degree};
     if (a.kind < 0 || a.kind > AIR_RECOMPOSE) fail(P3R_EINVAL, "instance %zu: unknown AIR kind %d", i, a.kind);
+    if (a.ext_d != 4 && (a.kind == AIR_POSEIDON2 || a.kind == AIR_RECOMPOSE))
+      fail(P3R_EUNSUPPORTED, "instance %zu: ext_degree %d covers the primitive tables (Const, Public, ALU) only", i, a.ext_d);
     if (a.lanes < 1) fail(P3R_EINVAL, "instance %zu: lanes must be positive", i);
     if (a.kind == AIR_ALU && (a.horner_k < 2 || a.horner_k > 8))
       fail(P3R_EINVAL, "instance %zu: horner_packed_steps must be in 2..8", i);
@@ -216,8 +218,10 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   if (any_lookup) {
     E alpha_l = ch.sample_ext(), beta_l = ch.sample_ext();
     E bp = E::one();
-    for (int j = 0; j < 5; ++j) { lc.beta_pow[j] = to_e4<PP>(bp); bp *= beta_l; }
-    lc.prefix = to_e4<PP>(alpha_l + bp);  // alpha + beta^5, bus id 0
+    // the widest tuple on the bus is (idx, v_0..v_{D-1}): gamma = beta^(D+1)
+    const int tuple_w = (int)ctx->cfg.ext_degree + 1;
+    for (int j = 0; j < tuple_w; ++j) { lc.beta_pow[j] = to_e4<PP>(bp); bp *= beta_l; }
+    lc.prefix = to_e4<PP>(alpha_l + bp);  // alpha + beta^(D+1), bus id 0
   }
   std::vector<std::unique_ptr<p3r_dmat>> aux(ni), aux_lde(ni);
   std::vector<E> terminals(ni, E::zero());
@@ -262,7 +266,12 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       P3R_HIP(ctx->stage.upload(ctx->stream, scratch.back().p, jobs.data(), jobs.size() * sizeof(LogupJob)));
       const int nj = (int)jobs.size();
       ProfScope ps(ctx, "logup_aux");
-      hipLaunchKernelGGL(k_logup_aux<PP>, dim3(row_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, nj, lc);
+      if (ctx->cfg.ext_degree == 5) {
+        if constexpr (kHasQuintic<PP>)
+          hipLaunchKernelGGL((k_logup_aux<PP, 5>), dim3(row_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, nj, lc);
+      } else {
+        hipLaunchKernelGGL(k_logup_aux<PP>, dim3(row_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, nj, lc);
+      }
       hipLaunchKernelGGL(k_ef_scan<PP>, dim3(tiles), dim3(kBlock), 0, ctx->stream, 0, d_jobs, nj);
       hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)nj), dim3(kBlock), 0, ctx->stream, 1, d_jobs, nj);
       hipLaunchKernelGGL(k_ef_scan<PP>, dim3(tiles), dim3(kBlock), 0, ctx->stream, 2, d_jobs, nj);
@@ -359,8 +368,14 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     DevBuf d_quot((quot_jobs.size() * sizeof(QuotientArgs) + 3) / 4);
     P3R_HIP(ctx->stage.upload(ctx->stream, d_quot.p, quot_jobs.data(), quot_jobs.size() * sizeof(QuotientArgs)));
     ProfScope ps(ctx, "quotient");
-    hipLaunchKernelGGL(k_quotient<PP>, dim3(quot_blocks), dim3(kBlock), 0, ctx->stream,
-                       reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc, ctx->rc.p);
+    if (ctx->cfg.ext_degree == 5) {
+      if constexpr (kHasQuintic<PP>)
+        hipLaunchKernelGGL((k_quotient<PP, 5>), dim3(quot_blocks), dim3(kBlock), 0, ctx->stream,
+                           reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc, ctx->rc.p);
+    } else {
+      hipLaunchKernelGGL(k_quotient<PP>, dim3(quot_blocks), dim3(kBlock), 0, ctx->stream,
+                         reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc, ctx->rc.p);
+    }
     P3R_HIP(hipGetLastError());
   }
   {
@@ -461,8 +476,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   // the counterpart of prove_batch's internal constraint check (include/p3r.h).  Host work of a few
   // extension-field evaluations per table, done while the device computes the 1/(z - x) vectors.
   {
-    E l_beta_pow[5];
-    for (int j = 0; j < 5; ++j) l_beta_pow[j] = e4_load<PP>(lc.beta_pow[j]);
+    E l_beta_pow[kMaxExtD + 1];
+    for (int j = 0; j <= kMaxExtD; ++j) l_beta_pow[j] = e4_load<PP>(lc.beta_pow[j]);
     const E l_prefix = e4_load<PP>(lc.prefix);
     std::vector<std::vector<std::vector<E>>> inst_chunks(ni);
     for (size_t k = 0; k < chunks.size(); ++k) inst_chunks[chunks[k].inst].push_back(o_chunks[k]);

@@ -482,17 +482,19 @@ template <class PP>
 struct ZetaLookupSink {
   using E = Fp4<PP>;
   E prefix;
-  E beta_pow[5];
+  E beta_pow[kMaxExtD + 1];
   const std::vector<E>& aux;  // EF aux columns at zeta: [0] running sum, [g + 1] fraction of group g
   ZetaFold<PP>& fold;
   int pair, cnt = 0;
   E d0 = E::zero(), m0 = E::zero(), sum_f = E::zero();
-  E denom(const E& idx, const V4<E>& v) const {
+  template <int D>
+  E denom(const E& idx, const VD<E, D>& v) const {
     E d = prefix + beta_pow[0] * idx;
-    for (int j = 0; j < 4; ++j) d += beta_pow[j + 1] * v.c[j];
+    for (int j = 0; j < D; ++j) d += beta_pow[j + 1] * v.c[j];
     return d;
   }
-  void add(const E& idx, const V4<E>& v, const E& mult) {
+  template <int D>
+  void add(const E& idx, const VD<E, D>& v, const E& mult) {
     const E d = denom(idx, v);
     ++cnt;
     if (!pair) {
@@ -613,8 +615,13 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     ZetaView<PP> v{in.main_local, in.main_next ? in.main_next : &none, in.prep_local, in.prep_next};
     ZetaFold<PP> fold;
     fold.alpha = alpha;
-    if (air.kind == AIR_ALU) alu_constraints<PP>(air, v, fold);
-    else if (air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc_mont, fold);
+    const bool quintic = air.ext_d == 5;
+    if (air.ext_d != 4 && !(quintic && kHasQuintic<PP> && air.kind <= AIR_ALU))
+      vfail("instance %zu: no AIR of kind %d for circuit extension degree %d", i, air.kind, air.ext_d);
+    if (air.kind == AIR_ALU) {
+      if (quintic) alu_constraints<PP, 5>(air, v, fold);
+      else alu_constraints<PP>(air, v, fold);
+    } else if (air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc_mont, fold);
     if (fold.count != air_num_base_constraints<PP>(air)) vfail("instance %zu: constraint count mismatch", i);
     if (L.n_groups) {
       // EF aux columns from their 4 base-column openings: sum_k x^k * col_k(zeta)
@@ -629,9 +636,11 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
         return out;
       };
       const std::vector<E> aux_l = ef_cols(*in.perm_local), aux_n = ef_cols(*in.perm_next);
-      ZetaLookupSink<PP> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4]},
+      ZetaLookupSink<PP> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4],
+                                         l_beta_pow[5]},
                               aux_l, fold, L.pair};
-      air_interactions<PP>(air, v, sink);
+      if (quintic) air_interactions<PP, 5>(air, v, sink);
+      else air_interactions<PP>(air, v, sink);
       sink.finish();
       if (sink.cnt != L.n_interactions) vfail("instance %zu: interaction count mismatch", i);
       const E s = aux_l[0], s_next = aux_n[0], terminal = *in.terminal;
@@ -738,12 +747,16 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   observe_cap(P.main_cap);
   for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(prep_w[i]);
   observe_cap(prep_cap);
-  E l_prefix = E::zero(), l_beta_pow[5];
+  E l_prefix = E::zero(), l_beta_pow[kMaxExtD + 1];
   for (auto& b : l_beta_pow) b = E::zero();
   if (any_lookup) {
     const E alpha_l = ch.sample_ext(), beta_l = ch.sample_ext();
     E bp = E::one();
-    for (int j = 0; j < 5; ++j) { l_beta_pow[j] = bp; bp *= beta_l; }
+    // gamma = beta^W, W = the widest bus tuple = 1 + circuit extension degree (get_perm_challenges,
+    // recursion/src/verifier/batch_stark.rs:1086-1100)
+    int tuple_w = 5;
+    for (auto& a : airs) tuple_w = std::max(tuple_w, std::min(a.ext_d, kMaxExtD) + 1);
+    for (int j = 0; j < tuple_w; ++j) { l_beta_pow[j] = bp; bp *= beta_l; }
     l_prefix = alpha_l + bp;
     observe_cap(*P.perm_cap);
     for (int i : perm_insts) ch.observe_ext(*P.terminals[i]);

@@ -58,9 +58,9 @@ class TablePacking:
 @dataclass
 class Traces:
     """Flattened `Traces<EF>`: every array is canonical uint32."""
-    const_values: np.ndarray        # (n_const, 4)
-    public_values: np.ndarray       # (n_public, 4)
-    alu_values: np.ndarray          # (n_alu, 16): [a, b, c, out] x 4 coefficients
+    const_values: np.ndarray        # (n_const, D)      D = the context's ext_degree (4, or 5 for quintic circuits)
+    public_values: np.ndarray       # (n_public, D)
+    alu_values: np.ndarray          # (n_alu, 4 D): [a, b, c, out] x D coefficients
     p2_input_values: np.ndarray     # (n_p2, 16)
     p2_new_start: np.ndarray        # (n_p2,) bool
     p2_merkle_path: np.ndarray
@@ -170,7 +170,7 @@ class ResidentTraces:
 
     def __init__(self, ctx: Context, cpd: CircuitProverData, traces: Traces):
         self.ctx, self.cpd = ctx, cpd
-        t, self._keep = _traces_struct(traces)
+        t, self._keep = _traces_struct(traces, ctx.ext_degree)
         self.h = ctx.ptr(ctx.lib.p3r_traces_upload(ctx.h, cpd.h, C.byref(t)))
 
     @classmethod
@@ -182,6 +182,8 @@ class ResidentTraces:
     def download(self, name: str) -> np.ndarray:
         """One array of the device-resident Traces, canonical (see TRACES_ARRAYS)."""
         which, table, width = TRACES_ARRAYS[name]
+        if table in ("const", "public", "alu"):
+            width = width // 4 * self.ctx.ext_degree
         out = np.empty((self.cpd.rows[table], width), dtype=np.uint32)
         self.ctx.check(self.ctx.lib.p3r_dtraces_get(self.ctx.h, self.cpd.h, self.h, which,
                                                     out.ctypes.data_as(_lib.u32p), out.size))
@@ -199,9 +201,13 @@ class ResidentTraces:
             pass
 
 
-def _traces_struct(tr: Traces):
+def _traces_struct(tr: Traces, ext_degree=4):
     t = _lib.P3rTraces()
     keep = []
+    for name, w in (("const_values", ext_degree), ("public_values", ext_degree), ("alu_values", 4 * ext_degree)):
+        a = np.asarray(getattr(tr, name))
+        if a.ndim != 2 or a.shape[1] != w:
+            raise P3rError(-1, "%s must have shape (n, %d) for ext_degree %d, got %r" % (name, w, ext_degree, a.shape))
 
     def p32(a):
         x, p = _u32(a)
@@ -400,13 +406,18 @@ def verify_all_tables(cfg, proof: BatchStarkProof, canonical_field_encoding=None
     ExtDegreeMismatch, BinomialWMismatch, QuinticReductionMismatch)."""
     if proof.preprocessed_commitment is None:
         raise P3rError(-1, "proof carries no preprocessed commitment (stark_common)")
-    if proof.ext_degree != 4:
-        raise P3rError(-1, "ExtDegreeMismatch: proof has ext_degree %d, the verifier expects 4" % proof.ext_degree)
+    want_d = int(cfg.ext_degree)   # the verifier's expected trace element field EF
+    if proof.ext_degree != want_d:
+        raise P3rError(-1, "ExtDegreeMismatch: proof has ext_degree %d, the verifier expects %d" % (proof.ext_degree, want_d))
     field = field or {0: "koala-bear", 1: "baby-bear"}[int(cfg.field)]
-    if proof.w_binomial != W_BINOMIAL[field]:
-        raise P3rError(-1, "BinomialWMismatch: proof has W = %r, the verifier expects %d" % (proof.w_binomial, W_BINOMIAL[field]))
-    if proof.alu_quintic_trinomial:
-        raise P3rError(-1, "QuinticReductionMismatch: the D = 4 verifier has no quintic reduction")
+    # EF = BinomialExtensionField<F, 4>: W = the field's; EF = QuinticTrinomialExtensionField<F>: no binomial W
+    # and the trinomial reduction flag (field_params.rs:54-66)
+    want_w = W_BINOMIAL[field] if want_d == 4 else None
+    if proof.w_binomial != want_w:
+        raise P3rError(-1, "BinomialWMismatch: proof has W = %r, the verifier expects %r" % (proof.w_binomial, want_w))
+    if bool(proof.alu_quintic_trinomial) != (want_d == 5):
+        raise P3rError(-1, "QuinticReductionMismatch: proof quintic-trinomial flag %s does not match the verifier's expected "
+                       "trace field (%s)" % (bool(proof.alu_quintic_trinomial), want_d == 5))
     airs = proof.airs()
     if len(proof.preprocessed_widths) != len(airs) or len(proof.degree_bits) != len(airs):
         raise P3rError(-1, "InvalidProofShape: %d AIRs, %d preprocessed widths, %d degree_bits"
@@ -432,7 +443,7 @@ class BatchStarkProver:
         if isinstance(traces, ResidentTraces):
             raw = self._call(ctx.lib.p3r_prove_all_tables_resident, ctx.h, circuit_prover_data.h, traces.h, flags)
         else:
-            t, keep = _traces_struct(traces)
+            t, keep = _traces_struct(traces, ctx.ext_degree)
             raw = self._call(ctx.lib.p3r_prove_all_tables, ctx.h, circuit_prover_data.h, C.byref(t), flags)
         return self.wrap_proof(raw, circuit_prover_data, canonical_field_encoding)
 
@@ -456,7 +467,9 @@ class BatchStarkProver:
         return BatchStarkProof(
             proof=raw, table_packing=tp,
             rows=(cpd.rows["const"], cpd.rows["public"], cpd.rows["alu"]),
-            w_binomial=W_BINOMIAL[ctx.field],
+            ext_degree=ctx.ext_degree,
+            w_binomial=W_BINOMIAL[ctx.field] if ctx.ext_degree == 4 else None,
+            alu_quintic_trinomial=ctx.ext_degree == 5,
             non_primitives=tuple(npo),
             preprocessed_commitment=cpd.preprocessed_commitment,
             preprocessed_widths=tuple(w for w, ok in zip(prep_widths, present) if ok),
@@ -686,9 +699,9 @@ class FriRecursionBackend:
         self.config = config or FriRecursionConfig()
 
     def non_primitive_provers(self, ext_degree: int):
-        if ext_degree != 4:
-            raise P3rError(_lib_code("UNSUPPORTED"), f"UnsupportedDegree({ext_degree})")
-        return ["poseidon2_perm", "recompose"]
+        # the D = 4 backend registers its table provers for D = 4 circuits and none for any other degree
+        # (fri.rs:693-721: `else { Vec::new() }`): a D = 5 layer is proved from its primitive tables
+        return ["poseidon2_perm", "recompose"] if ext_degree == 4 else []
 
 
 def _lib_code(name):
@@ -730,7 +743,7 @@ def build_next_layer_prep(ctx: Context, circuit, backend: FriRecursionBackend,
                           params: ProveNextLayerParams) -> NextLayerPrepCache:
     """recursion.rs:342-394.  `circuit` is a `Circuit` (preprocessed columns are derived here, as
     get_airs_and_degrees_with_prep does) or an already-flattened `CircuitPrep`."""
-    backend.non_primitive_provers(4)
+    backend.non_primitive_provers(ctx.ext_degree)
     prover = BatchStarkProver(ctx, params.table_packing)
     if isinstance(circuit, Circuit):
         pc = PreparedCircuit(ctx, circuit, params.table_packing)

@@ -4,12 +4,13 @@ import numpy as np
 from plonky3_recursion_amd.prover import Circuit, CircuitInputs, CircuitPrep, Traces
 
 
-def traces_from_arrays(a) -> Traces:
+def traces_from_arrays(a, ext_degree=4) -> Traces:
     fl = a["p2_flags"].reshape(-1, 4)
+    d = ext_degree
     return Traces(
-        const_values=a["const_values"].reshape(-1, 4),
-        public_values=a["public_values"].reshape(-1, 4),
-        alu_values=a["alu_values"].reshape(-1, 16),
+        const_values=a["const_values"].reshape(-1, d),
+        public_values=a["public_values"].reshape(-1, d),
+        alu_values=a["alu_values"].reshape(-1, 4 * d),
         p2_input_values=a["p2_inputs"].reshape(-1, 16),
         p2_new_start=fl[:, 0].astype(np.uint8),
         p2_merkle_path=fl[:, 1].astype(np.uint8),

@@ -1,0 +1,147 @@
+"""GPU parity for D = 5 layers: KoalaBear circuits over the quintic trinomial extension x^5 + x^2 - 1, primitive
+tables (Const, Public, ALU), proved under the D = 4 STARK configuration as the reference's unit tests do
+(circuit-prover/src/batch_stark_prover/tests.rs:844-1029).  Matrices, preprocessed commitment and proof bytes
+against the CPU oracle; the proof's metadata; what the D = 5 context refuses."""
+import numpy as np
+import pytest
+
+import harness_lib
+import layer_lib
+
+pytestmark = pytest.mark.gpu
+
+PRIMITIVE = harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE
+
+
+def setup(oracle, log_h, kw, packing=None, flags=PRIMITIVE, **gen):
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    import harness_adapters as wl
+    gen.setdefault("horner_chain_len", 20)
+    arrs = harness_lib.generate("koala-bear", log_h, seed=11 + log_h, flags=flags, ext_degree=5, **gen)
+    prm = layer_lib.params(**kw)
+    packing = packing or {}
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(packing, ext_degree=5))
+    ctx = p3r.Context(field="koala-bear", log_blowup=prm.log_blowup, max_log_arity=prm.max_log_arity,
+                      cap_height=prm.cap_height, log_final_poly_len=prm.log_final_poly_len,
+                      commit_pow_bits=prm.commit_pow_bits, query_pow_bits=prm.query_pow_bits,
+                      num_queries=prm.num_queries, ext_degree=5)
+    tp = pv.TablePacking(public_lanes=packing.get("public_lanes", 1), alu_lanes=packing.get("alu_lanes", 3),
+                         horner_packed_steps=packing.get("horner_packed_steps", 4))
+    tp.with_fri_params(prm.log_final_poly_len, prm.log_blowup)
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), pv.FriRecursionBackend(),
+                                     pv.ProveNextLayerParams(table_packing=tp))
+    return arrs, L, ctx, cache, wl.traces_from_arrays(arrs, ext_degree=5)
+
+
+CASES = [
+    (6, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=4, num_queries=5), None),
+    (8, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=5, num_queries=5),
+     dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3)),
+    (7, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=1, query_pow_bits=4, num_queries=6),
+     dict(alu_lanes=1, horner_packed_steps=2)),
+    (9, dict(log_blowup=2, max_log_arity=3, log_final_poly_len=3, cap_height=2, commit_pow_bits=2, query_pow_bits=6,
+             num_queries=6), dict(alu_lanes=4, horner_packed_steps=5)),
+    (10, dict(log_blowup=1, max_log_arity=2, log_final_poly_len=2, query_pow_bits=4, num_queries=8),
+     dict(alu_lanes=3, horner_packed_steps=8)),
+]
+
+
+@pytest.mark.parametrize("log_h,kw,packing", CASES)
+def test_quintic_layer_matrices_commitment_and_proof(oracle, log_h, kw, packing):
+    from plonky3_recursion_amd import prover as pv
+    arrs, L, ctx, cache, traces = setup(oracle, log_h, kw, packing)
+    tables = L.tables()
+    cpd = cache.circuit_prover_data
+    assert [t["kind"] for t in tables] == ["const", "public", "alu"]
+    assert cpd.table_heights[:3] == [t["main"].shape[0] for t in tables]
+    assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
+    res = pv.ResidentTraces(ctx, cpd, traces)
+    for i, t in enumerate(tables):
+        got = cache.prover.build_main_trace(res, cpd, i).download()
+        assert got.shape == t["main"].shape, t["kind"]
+        assert np.array_equal(got, t["main"]), t["kind"]
+    assert np.array_equal(res.download("alu_values"), traces.alu_values)
+    out = pv.prove_next_layer(pv.RecursionInput(traces=traces), ctx, pv.FriRecursionBackend(),
+                              pv.ProveNextLayerParams(table_packing=cpd.packing), prep=cache)
+    want = L.prove()
+    assert out.proof.proof == want
+    L.verify(out.proof.proof)
+    assert cache.prover.prove_all_tables(res, cpd).proof == want
+    assert cache.prover.prove_all_tables(traces, cpd, canonical_field_encoding=True).proof == L.prove(field_encoding=1)
+    # the metadata the reference writes next to the proof (batch_stark_prover.rs:1597-1641)
+    p = out.proof
+    assert p.ext_degree == 5 and p.w_binomial is None and p.alu_quintic_trinomial and p.non_primitives == ()
+    cache.prover.verify_all_tables(p)
+    back = pv.BatchStarkProof.from_postcard(p.to_postcard(), "koala-bear")
+    assert back.to_postcard() == p.to_postcard() and back.ext_degree == 5 and back.alu_quintic_trinomial
+    cache.prover.verify_all_tables(back)
+    res.free()
+    cpd.free()
+    ctx.close()
+
+
+def test_quintic_unsatisfied_trace_is_reported(oracle):
+    """The prover's self-check at zeta applies the trinomial rule: a product reduced the binomial way is refused."""
+    import plonky3_recursion_amd as p3r
+    arrs, L, ctx, cache, traces = setup(oracle, 6, dict(log_final_poly_len=1, query_pow_bits=3, num_queries=4))
+    v = traces.alu_values.copy()
+    v[3, 19] = (int(v[3, 19]) + 1) % 0x7F000001     # top coefficient of an output
+    traces.alu_values = v
+    with pytest.raises(p3r.P3rError, match="do not satisfy"):
+        cache.prover.prove_all_tables(traces, cache.circuit_prover_data)
+    cache.circuit_prover_data.free()
+    ctx.close()
+
+
+def test_what_a_quintic_context_refuses(oracle):
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    import harness_adapters as wl
+    with pytest.raises(p3r.P3rError, match="extension degree"):
+        p3r.Context(field="baby-bear", ext_degree=5)
+    with pytest.raises(p3r.P3rError, match="extension degree"):
+        p3r.Context(field="koala-bear", ext_degree=8)
+    ctx = p3r.Context(field="koala-bear", log_final_poly_len=1, query_pow_bits=3, num_queries=4, ext_degree=5)
+    tp = pv.TablePacking().with_fri_params(1, 2)
+    # a layer with Poseidon2 / Recompose rows is a D = 4 layer
+    arrs4 = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+    with pytest.raises(p3r.P3rError, match="UnsupportedDegree"):
+        pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs4), pv.FriRecursionBackend(),
+                                 pv.ProveNextLayerParams(table_packing=tp))
+    # the circuit boundary runs D = 4 circuits
+    arrs5 = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, flags=PRIMITIVE, ext_degree=5)
+    with pytest.raises(p3r.P3rError, match="UnsupportedDegree"):
+        pv.PreparedCircuit(ctx, wl.circuit_from_arrays(arrs5), tp)
+    # D = 4 shaped values under a D = 5 context
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs5), pv.FriRecursionBackend(),
+                                     pv.ProveNextLayerParams(table_packing=tp))
+    bad = wl.traces_from_arrays(harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, flags=PRIMITIVE))
+    with pytest.raises(p3r.P3rError, match="shape"):
+        cache.prover.prove_all_tables(bad, cache.circuit_prover_data)
+    cache.circuit_prover_data.free()
+    ctx.close()
+
+
+def test_quintic_layer_at_2_16_rows_verifies(oracle):
+    """Past the sizes the oracle's prover finishes in seconds: the GPU proof of a 2^16-row D = 5 layer is accepted by
+    the oracle's verifier (from the statement alone) and by the native verifier."""
+    from plonky3_recursion_amd import prover as pv
+    import plonky3_recursion_amd as p3r
+    import harness_adapters as wl
+    prm = layer_lib.params(query_pow_bits=8, num_queries=20)
+    arrs = harness_lib.generate("koala-bear", 16, seed=5, horner_chain_len=64, flags=PRIMITIVE, ext_degree=5)
+    ctx = p3r.Context(field="koala-bear", query_pow_bits=8, num_queries=20, ext_degree=5)
+    tp = pv.TablePacking().with_fri_params(prm.log_final_poly_len, prm.log_blowup)
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), pv.FriRecursionBackend(),
+                                     pv.ProveNextLayerParams(table_packing=tp))
+    proof = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs, ext_degree=5), cache.circuit_prover_data)
+    cache.prover.verify_all_tables(proof)
+    airs = [dict(a, ext_degree=5) for a in proof.airs()]
+    layer_lib.oracle_verify_statement(oracle, "koala-bear", prm, airs, proof.preprocessed_commitment, proof.proof)
+    bad = bytearray(proof.proof)
+    bad[len(bad) // 2] ^= 4
+    with pytest.raises(RuntimeError):
+        layer_lib.oracle_verify_statement(oracle, "koala-bear", prm, airs, proof.preprocessed_commitment, bytes(bad))
+    cache.circuit_prover_data.free()
+    ctx.close()

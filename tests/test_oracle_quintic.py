@@ -112,3 +112,94 @@ def test_refused_shapes(oracle):
         harness_lib.generate("koala-bear", 5, ext_degree=5)
     with pytest.raises(RuntimeError, match="ext_degree"):
         harness_lib.generate("baby-bear", 5, flags=PRIMITIVE, ext_degree=5)
+
+
+# ---------------------------------------------------------------- the product's native verifier (host code, no GPU)
+def native_verify(prm, tables, cap, proof, ext_degree=5, field="koala-bear", canonical=False):
+    import plonky3_recursion_amd as p3r
+    degree_bits = [int(t["main"].shape[0]).bit_length() - 1 for t in tables]
+    cfg, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, ext_degree=ext_degree)
+    airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
+    p3r.verify_batch(cfg, airs, cap, degree_bits, proof, canonical)
+
+
+@pytest.mark.parametrize("log_h,kw,packing", [
+    (5, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=0, query_pow_bits=3, num_queries=4), None),
+    (7, dict(log_blowup=2, max_log_arity=3, log_final_poly_len=2, query_pow_bits=5, num_queries=6), None),
+    (7, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, cap_height=2, query_pow_bits=4, num_queries=5),
+     dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3)),
+    (6, dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, commit_pow_bits=3, query_pow_bits=3, num_queries=4),
+     dict(alu_lanes=4, horner_packed_steps=6)),
+])
+def test_native_verifier_accepts_quintic_oracle_proofs(oracle, log_h, kw, packing):
+    import plonky3_recursion_amd as p3r
+    prm = layer_lib.params(**kw)
+    arrs, L = layer(oracle, log_h, 70 + log_h, prm, packing=packing, horner_chain_len=17)
+    tables, cap = L.tables(), L.prep_commit()
+    proof = L.prove()
+    native_verify(prm, tables, cap, proof)
+    native_verify(prm, tables, cap, L.prove(field_encoding=1), canonical=True)
+    for frac in (0.02, 0.3, 0.55, 0.8, 0.97):
+        bad = bytearray(proof)
+        bad[int(len(bad) * frac)] ^= 1
+        with pytest.raises(p3r.P3rError):
+            native_verify(prm, tables, cap, bytes(bad))
+    # the statement carries the circuit field: the D = 4 verifier rejects (table widths differ), and D = 5 is
+    # KoalaBear's
+    with pytest.raises(p3r.P3rError):
+        native_verify(prm, tables, cap, proof, ext_degree=4)
+    with pytest.raises(p3r.P3rError, match="UnsupportedDegree"):
+        native_verify(prm, tables, cap, proof, field="baby-bear")
+
+
+def test_native_verifier_rejects_unsatisfied_quintic_trace(oracle):
+    import plonky3_recursion_amd as p3r
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=4)
+    arrs = harness_lib.generate("koala-bear", 6, seed=4, horner_chain_len=12, flags=PRIMITIVE, ext_degree=5)
+    v = arrs["alu_values"].reshape(-1, 20)
+    kinds = arrs["alu_prep13"].reshape(-1, 13)
+    mul = next(i for i, k in enumerate(kinds) if not (k[1] or k[2] or k[3] or k[4]) and v[i, 4] and v[i, 9])
+    # out = a * b under the BINOMIAL-like wrap x^5 = 1 (no - x^2 term): a product a D = 5 rule must refuse
+    a, b = v[mul, 0:5], v[mul, 5:10]
+    t = [0] * 9
+    for i in range(5):
+        for j in range(5):
+            t[i + j] = (t[i + j] + int(a[i]) * int(b[j])) % P
+    v[mul, 15:20] = [(t[k] + (t[k + 5] if k + 5 < 9 else 0)) % P for k in range(5)]
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(ext_degree=5))
+    with pytest.raises(p3r.P3rError, match="quotient|final polynomial|lookup sum"):
+        native_verify(prm, L.tables(), L.prep_commit(), L.prove())
+
+
+def test_quintic_metadata_on_the_wire(oracle):
+    """BatchStarkProof of a D = 5 layer: ext_degree 5, no binomial W, the trinomial flag
+    (batch_stark_prover.rs:610-636, 1245-1263)."""
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd.prover import BatchStarkProof, TablePacking, verify_all_tables
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=3)
+    arrs, L = layer(oracle, 6, 9, prm)
+    tables, cap = L.tables(), L.prep_commit()
+    tp = TablePacking(public_lanes=1, alu_lanes=3, horner_packed_steps=4, min_trace_height=layer_lib.min_trace_height(prm))
+    c = arrs["counts"]
+    bsp = BatchStarkProof(proof=L.prove(), table_packing=tp, rows=(int(c[0]), int(c[1]), int(c[2])), ext_degree=5,
+                          w_binomial=None, alu_quintic_trinomial=True, preprocessed_commitment=cap,
+                          preprocessed_widths=tuple(t["prep"].shape[1] for t in tables),
+                          degree_bits=tuple(int(t["main"].shape[0]).bit_length() - 1 for t in tables),
+                          monty_r=1, modulus=P)
+    wire = bsp.to_postcard()
+    back = BatchStarkProof.from_postcard(wire, "koala-bear")
+    assert back.ext_degree == 5 and back.w_binomial is None and back.alu_quintic_trinomial
+    assert back.to_postcard() == wire
+    cfg5, keep5 = p3r.make_config("koala-bear", prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                  prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, ext_degree=5)
+    verify_all_tables(cfg5, back)
+    cfg4, keep4 = p3r.make_config("koala-bear", prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                  prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries)
+    with pytest.raises(p3r.P3rError, match="ExtDegreeMismatch"):
+        verify_all_tables(cfg4, back)
+    import dataclasses
+    with pytest.raises(p3r.P3rError, match="BinomialWMismatch"):
+        verify_all_tables(cfg5, dataclasses.replace(back, w_binomial=3))
+    with pytest.raises(p3r.P3rError, match="QuinticReductionMismatch"):
+        verify_all_tables(cfg5, dataclasses.replace(back, alu_quintic_trinomial=False))
