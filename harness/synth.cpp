@@ -64,8 +64,8 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   using F = Fp<PP>;
   constexpr int D = E::DEG;  // circuit extension degree: witness indices on the bus are scaled by D
   const uint32_t P = PP::P;
-  if (D != 4 && (flags & (SYN_NO_POSEIDON2 | SYN_NO_RECOMPOSE)) != (SYN_NO_POSEIDON2 | SYN_NO_RECOMPOSE))
-    throw std::runtime_error("ext_degree 5 covers the primitive tables: pass SYN_NO_POSEIDON2 | SYN_NO_RECOMPOSE");
+  if (D != 4 && !(flags & SYN_NO_RECOMPOSE))
+    throw std::runtime_error("ext_degree 5 has no Recompose table here: pass SYN_NO_RECOMPOSE (Poseidon2 rows are the compact-D1 ones)");
   const size_t H = size_t(1) << log_h;
   Rng rng(seed);
   auto rf = [&]() { return F::from_canonical((uint32_t)(rng.next() % P)); };
@@ -208,7 +208,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   auto& pd_ids = W.arr["pd_op_ids"]; auto& pd_sib = W.arr["pd_siblings"];
   struct OutFix { size_t row; int limb; uint32_t wid; };
   std::vector<OutFix> out_fix;
-  {
+  if constexpr (D == 4) {
     F state[16];
     for (auto& x : state) x = F::zero();
     const uint32_t sponge_pick_limit = (uint32_t)pickable.size();
@@ -296,6 +296,89 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
       }
       p2_acc_idx.push_back(en ? (uint32_t)acc_wid[r] : 0u);
       push_op(C_P2, next_npo_id++, 0, 0, 0, (p.new_start ? 1u : 0u) | (p.merkle ? 2u : 0u), ext);
+    }
+  } else {
+    // ---- compact-D1 Poseidon2 rows of a D = 5 circuit (KOALA_BEAR_D1_W16 on the 5-slot witness bus): every state
+    // element is its own witness, holding a base-field value (tuples (idx, v, 0, 0, 0, 0)).  Row semantics follow the
+    // AIR (poseidon2-circuit-air/src/air.rs:937-1031) and the base-mode executor
+    // (circuit/src/ops/poseidon_perm/executor.rs:600-700): sponge rows take CTL inputs on the rate only, the capacity
+    // chains (first capacity element += the length tag); Merkle rows carry digest | sibling, swapped by the direction
+    // bit, and never read the bus.
+    auto& p2_absorb = W.arr["p2_absorb_len"];
+    std::vector<uint32_t> base_w;   // base-valued witnesses a sponge may read
+    for (uint32_t w : base_valued) base_w.push_back(w);
+    for (size_t i = 0; i < std::max<size_t>(H / 8, 4); ++i) {
+      // base-valued public inputs
+      uint32_t w = create(E::from_base(rf()));
+      push_op(C_PUBLIC, 0, 0, 0, w, (uint32_t)public_w.size(), {});
+      public_w.push_back(w); public_rows.push_back(w); put_e(in_public, wval[w]);
+      pickable.push_back(w); base_w.push_back(w); base_valued.push_back(w);
+    }
+    F state[16];
+    for (auto& x : state) x = F::zero();
+    for (size_t r = 0; r < n_p2; ++r) {
+      const auto& p = plan[r];
+      const bool last_of_chain = (r + 1 == n_p2) || plan[r + 1].new_start;
+      F in[16];
+      uint32_t in_ctl[16] = {0}, in_idx[16] = {0};
+      uint32_t tag = 0;
+      if (!p.merkle) {
+        tag = rng.below(4) == 0 ? 0u : 1u + rng.below(8);
+        for (int i = 0; i < 16; ++i) in[i] = p.new_start ? F::zero() : state[i];
+        for (int i = 0; i < 8; ++i)
+          if (rng.unit() < (p.new_start ? 0.75 : 0.5)) {
+            const uint32_t w = base_w[rng.below((uint32_t)base_w.size())];
+            reads[w]++;
+            in_ctl[i] = 1; in_idx[i] = w; in[i] = wval[w].c[0];
+          }
+        in[8] = in[8] + F::from_canonical(tag);
+      } else {
+        F digest[8];
+        for (int i = 0; i < 8; ++i) {
+          if (p.new_start) {
+            // the leaf digest is named by witness index, without a bus read (Merkle rows send nothing)
+            const uint32_t w = base_w[rng.below((uint32_t)base_w.size())];
+            in_ctl[i] = 1; in_idx[i] = w; digest[i] = wval[w].c[0];
+          } else {
+            digest[i] = state[i];
+          }
+        }
+        for (int i = 0; i < 8; ++i) {
+          in[p.bit ? 8 + i : i] = digest[i];
+          in[p.bit ? i : 8 + i] = rf();   // sibling: private data
+        }
+        if (p.new_start && p.bit)
+          for (int i = 0; i < 8; ++i) { in_ctl[8 + i] = in_ctl[i]; in_idx[8 + i] = in_idx[i]; in_ctl[i] = 0; in_idx[i] = 0; }
+      }
+      for (int i = 0; i < 16; ++i) { p2_inputs.push_back(in[i].to_canonical()); state[i] = in[i]; }
+      p2_permute<PP>(state, rc_canonical);
+      const bool en = acc_wid[r] >= 0;
+      p2_flags.push_back(p.new_start); p2_flags.push_back(p.merkle); p2_flags.push_back(p.bit); p2_flags.push_back(en);
+      p2_index_sum.push_back(en ? p.acc : 0u);
+      p2_absorb.push_back(tag);
+      for (int i = 0; i < 16; ++i) { p2_in_ctl.push_back(in_ctl[i]); p2_in_idx.push_back(in_idx[i]); }
+      const bool onto_public = !p.merkle && last_of_chain && rng.unit() < 0.2;
+      for (int l = 0; l < 8; ++l) {
+        if (last_of_chain && rng.unit() < 0.6) {
+          const uint32_t w = create(E::from_base(state[l]));
+          if (onto_public) {
+            // a Public op already defined this witness with the same value: the output is a reader on the bus
+            push_op(C_PUBLIC, 0, 0, 0, w, (uint32_t)public_w.size(), {});
+            public_w.push_back(w); public_rows.push_back(w); put_e(in_public, wval[w]);
+            reads[w]++;
+            p2_out_ctl.push_back(P - 1);
+          } else {
+            out_fix.push_back({r, l, w});
+            p2_out_ctl.push_back(0);  // patched below once read counts are known
+          }
+          pickable.push_back(w); base_valued.push_back(w);
+          p2_out_idx.push_back(w);
+        } else {
+          p2_out_idx.push_back(0);
+          p2_out_ctl.push_back(0);
+        }
+      }
+      p2_acc_idx.push_back(en ? (uint32_t)acc_wid[r] : 0u);
     }
   }
 
@@ -474,7 +557,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   for (uint32_t w : public_w) { put_e(public_values, wval[w]); public_prep.push_back(reads[w]); public_prep.push_back(w * D); }
   auto& rec_prep = W.arr["recompose_prep"];
   for (uint32_t w : rec_w) { rec_prep.push_back(w * 4); rec_prep.push_back(reads[w]); }
-  for (auto& f : out_fix) p2_out_ctl[f.row * 2 + f.limb] = reads[f.wid];
+  for (auto& f : out_fix) p2_out_ctl[f.row * (D == 4 ? 2 : 8) + f.limb] = reads[f.wid];
   // ALU per-op preprocessed, 13 columns (AluPrepLaneCols, alu_columns.rs:9-46; common.rs:198-281)
   auto& alu_prep = W.arr["alu_prep13"];
   const uint32_t neg1 = P - 1;

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3R_ABI_VERSION 3
+#define P3R_ABI_VERSION 4
 
 enum {
   P3R_OK = 0,
@@ -275,11 +275,17 @@ typedef struct p3r_layer_desc {
   const uint8_t* p2_new_start;        /* n_p2 */
   const uint8_t* p2_merkle_path;      /* n_p2 */
   const uint8_t* p2_mmcs_ctl_enabled; /* n_p2 */
-  const uint8_t* p2_in_ctl;           /* n_p2 x 4 */
-  const uint32_t* p2_input_indices;   /* n_p2 x 4 */
-  const uint32_t* p2_out_ctl;         /* n_p2 x 2, multiplicity as a canonical field element */
-  const uint32_t* p2_output_indices;  /* n_p2 x 2 */
+  const uint8_t* p2_in_ctl;           /* n_p2 x IL */
+  const uint32_t* p2_input_indices;   /* n_p2 x IL */
+  const uint32_t* p2_out_ctl;         /* n_p2 x OL, multiplicity as a canonical field element */
+  const uint32_t* p2_output_indices;  /* n_p2 x OL */
   const uint32_t* p2_mmcs_index_sum_idx; /* n_p2 */
+  /* IL x OL = 4 x 2 limbs of four base elements for ext_degree 4 (the D4 width-16 table).  Under ext_degree 5 the
+   * table is the compact-D1 one, KOALA_BEAR_D1_W16 on the 5-slot witness bus (poseidon2-circuit-air/src/air.rs:730-763,
+   * circuit-prover/src/batch_stark_prover/poseidon2.rs:1244-1285): IL x OL = 16 x 8, one witness per state element,
+   * and p2_absorb_len (n_p2, NULL = zeros) is the prefix-free sponge length tag the executor writes into the header
+   * (circuit/src/ops/poseidon_perm/executor.rs:720-741).  Since ABI version 4. */
+  const uint8_t* p2_absorb_len;
 } p3r_layer_desc;
 
 /* Flattened Traces<EF> (circuit/src/tables/mod.rs:49-62), canonical; D = p3r_config.ext_degree. */

@@ -125,6 +125,9 @@ struct CircuitPrep {
   std::vector<uint32_t> const_prep, public_prep, alu_prep13, recompose_prep;
   std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_ctl_enabled, p2_in_ctl;
   std::vector<uint32_t> p2_input_indices, p2_out_ctl, p2_output_indices, p2_mmcs_index_sum_idx;
+  // IL x OL = 4 x 2 limbs per row under ext_degree 4; 16 x 8 elements (the compact-D1 table) under ext_degree 5,
+  // where p2_absorb_len holds the sponge length tags (empty: zeros); include/p3r.h
+  std::vector<uint8_t> p2_absorb_len;
 };
 
 struct Circuit {  // flattened Circuit<EF>
@@ -155,6 +158,12 @@ class CircuitProverData {
     d.p2_mmcs_ctl_enabled = prep.p2_mmcs_ctl_enabled.data(); d.p2_in_ctl = prep.p2_in_ctl.data();
     d.p2_input_indices = prep.p2_input_indices.data(); d.p2_out_ctl = prep.p2_out_ctl.data();
     d.p2_output_indices = prep.p2_output_indices.data(); d.p2_mmcs_index_sum_idx = prep.p2_mmcs_index_sum_idx.data();
+    const size_t il = ctx.ext_degree() == 4 ? 4 : 16, ol = il / 2;
+    if (prep.p2_in_ctl.size() != d.counts.n_p2 * il || prep.p2_input_indices.size() != d.counts.n_p2 * il ||
+        prep.p2_out_ctl.size() != d.counts.n_p2 * ol || prep.p2_output_indices.size() != d.counts.n_p2 * ol ||
+        (!prep.p2_absorb_len.empty() && prep.p2_absorb_len.size() != d.counts.n_p2))
+      throw Error(P3R_EINVAL, "Poseidon2 CTL arrays do not match the row count for ext_degree " + std::to_string(ctx.ext_degree()));
+    if (!prep.p2_absorb_len.empty()) d.p2_absorb_len = prep.p2_absorb_len.data();
     rows_ = d.counts;
     preprocessed_commitment.resize(size_t(8) << ctx.fri().cap_height);
     owned_ = ctx.ptr(p3r_layer_create(ctx.raw(), &d, preprocessed_commitment.data()));
@@ -222,7 +231,9 @@ struct BatchStarkProof {
     std::vector<p3r_air_desc> a = {{P3R_AIR_CONST, 1, 2, 0}, {P3R_AIR_PUBLIC, table_packing.public_lanes, 2, 0},
                                    {P3R_AIR_ALU, table_packing.alu_lanes, table_packing.horner_packed_steps, 0}};
     for (auto& e : non_primitives) {
-      if (e.op_type.rfind("poseidon2_perm/", 0) == 0) a.push_back({P3R_AIR_POSEIDON2, 1, 2, 0});
+      const bool p2 = e.op_type.rfind("poseidon2_perm/", 0) == 0;
+      const bool d1 = e.op_type.size() >= 7 && e.op_type.compare(e.op_type.size() - 7, 7, "_d1_w16") == 0;
+      if (p2 && (ext_degree == 4 || d1)) a.push_back({P3R_AIR_POSEIDON2, 1, 2, 0});
       else if (e.op_type == "recompose") a.push_back({P3R_AIR_RECOMPOSE, (uint32_t)e.lanes, 2, 0});
       else throw Error(P3R_EUNSUPPORTED, "MissingTableProver(" + e.op_type + ")");
     }
@@ -462,7 +473,8 @@ class BatchStarkProver {
     if (p.ext_degree == 4) p.w_binomial = binomial_w(ctx_->field());
     p.alu_quintic_trinomial = p.ext_degree == 5;
     const uint32_t k = tp.horner_packed_steps;
-    const uint32_t widths[5] = {2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24, 2 * tp.recompose_lanes};
+    const bool d4 = p.ext_degree == 4;   // D = 5 circuits carry the compact-D1 Poseidon2 table (62 preprocessed columns)
+    const uint32_t widths[5] = {2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), d4 ? 24u : 62u, 2 * tp.recompose_lanes};
     for (int i = 0; i < 5; ++i) {
       if (!cpd.table_heights[i]) continue;
       p.preprocessed_widths.push_back(widths[i]);
@@ -471,7 +483,8 @@ class BatchStarkProver {
       p.degree_bits.push_back(db);
     }
     if (cpd.table_heights[3])  // Poseidon2Prover reports the PADDED row count (poseidon2.rs:1449)
-      p.non_primitives.push_back({ctx_->field() == Field::KoalaBear ? "poseidon2_perm/koala_bear_d4_w16" : "poseidon2_perm/baby_bear_d4_w16",
+      p.non_primitives.push_back({!d4 ? "poseidon2_perm/koala_bear_d1_w16"
+                                  : ctx_->field() == Field::KoalaBear ? "poseidon2_perm/koala_bear_d4_w16" : "poseidon2_perm/baby_bear_d4_w16",
                                   cpd.table_heights[3], 1, {}, 0});
     if (cpd.table_heights[4])  // RecomposeProver reports the op count (recompose.rs:125)
       p.non_primitives.push_back({"recompose", cpd.rows().n_recompose, tp.recompose_lanes, {}, 0});

@@ -16,7 +16,7 @@ namespace orc {
 
 enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4 };
 // Circuit extension degree: 4 (binomial x^4 = W) or 5 (KoalaBear quintic trinomial x^5 + x^2 - 1,
-// alu_air.rs:115-134; primitive tables only: the D = 5 backend's Poseidon2 table is the compact D1 one, not restated).
+// alu_air.rs:115-134; its Poseidon2 table is the compact-D1 width-16 one, eval_poseidon2_d1 below; Recompose is D = 4 only).
 // The STARK's own challenge field stays the degree-4 binomial extension, as in the reference's D = 5 unit tests
 // (batch_stark_prover/tests.rs:844-1029: QuinticTrinomialExtensionField traces under config::koala_bear()).
 constexpr int kMaxD = 5;
@@ -50,7 +50,7 @@ inline int air_prep_width(const AirDesc& a) {
     case AIR_CONST: return 2;
     case AIR_PUBLIC: return a.lanes * 2;
     case AIR_ALU: return a.lanes * 13 + alu_extra_prep_width(a.horner_k);    // alu_air.rs:333-335
-    case AIR_POSEIDON2: return 4 * 4 + 2 * 2 + 4;                            // preprocessed.rs:104-108
+    case AIR_POSEIDON2: return D == 4 ? 4 * 4 + 2 * 2 + 4 : 26 + 16 + 8 + 8 + 4;  // preprocessed.rs:104-108, :127-145 (compact D1)
     case AIR_RECOMPOSE: return a.lanes * (2 + (a.coeff_lookups ? 2 * D : 0));
   }
   throw std::runtime_error("bad air kind");
@@ -255,6 +255,67 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
   }
 }
 
+// p3_poseidon2_air::eval through the SubAirBuilder over the permutation columns (air.rs:1137-1158), restated
+// from the Poseidon2Cols semantics (SURVEY.md appendix A "Inner perm-AIR constraints").
+template <class FP, class V>
+void eval_poseidon2_perm(const Poseidon2<FP>& p2, EvalCtx<FP, V>& b) {
+  constexpr int R = FP::SBOX_REGS;
+  const V* L = b.local;
+  const V zero = b.K(0);
+  auto full_off = [&](int r) { return WIDTH + r * (WIDTH * R + WIDTH); };
+  const int partial_off = full_off(HALF_FULL);
+  const int ending_off = partial_off + FP::PARTIAL * (R + 1);
+  auto end_off = [&](int r) { return ending_off + r * (WIDTH * R + WIDTH); };
+  std::array<V, WIDTH> s;
+  for (int i = 0; i < WIDTH; ++i) s[i] = L[i];
+  auto external = [&](std::array<V, WIDTH>& st) {
+    std::array<V, WIDTH> o;
+    for (int i = 0; i < WIDTH; ++i) {
+      V acc = zero;
+      for (int j = 0; j < WIDTH; ++j) acc = acc + st[j] * b.KF(p2.ext[i][j]);
+      o[i] = acc;
+    }
+    st = o;
+  };
+  auto internal = [&](std::array<V, WIDTH>& st) {
+    V sum = zero;
+    for (auto& x : st) sum = sum + x;
+    for (int i = 0; i < WIDTH; ++i) st[i] = st[i] * b.KF(p2.diag[i]) + sum;
+  };
+  auto sbox = [&](V x, const V* reg) -> V {
+    if (FP::SBOX_DEGREE == 3) return x * x * x;
+    // (7,1): committed x^3 register, then x^7 = (x^3)^2 * x
+    V c3 = reg[0];
+    b.assert_zero(c3 - x * x * x);
+    return c3 * c3 * x;
+  };
+  external(s);
+  int k = 0;
+  auto full_round = [&](int col) {
+    for (int i = 0; i < WIDTH; ++i) {
+      V x = s[i] + b.KF(p2.rc[k + i]);
+      s[i] = sbox(x, L + col + i * R);
+    }
+    k += WIDTH;
+    external(s);
+    const V* post = L + col + WIDTH * R;
+    for (int i = 0; i < WIDTH; ++i) {
+      b.assert_zero(s[i] - post[i]);
+      s[i] = post[i];
+    }
+  };
+  for (int r = 0; r < HALF_FULL; ++r) full_round(full_off(r));
+  for (int r = 0; r < FP::PARTIAL; ++r) {
+    int col = partial_off + r * (R + 1);
+    V x = s[0] + b.KF(p2.rc[k++]);
+    s[0] = sbox(x, L + col);
+    b.assert_zero(s[0] - L[col + R]);
+    s[0] = L[col + R];
+    internal(s);
+  }
+  for (int r = 0; r < HALF_FULL; ++r) full_round(end_off(r));
+}
+
 // ---- Poseidon2CircuitAir (D=4, width 16, arity-2 shape) ----
 // interactions poseidon2-circuit-air/src/air.rs:1790-1893; circuit constraints :937,:1049-1122;
 // inner permutation AIR p3_poseidon2_air::eval via SubAirBuilder (:1137-1158) restated from
@@ -320,55 +381,71 @@ void eval_poseidon2(const Poseidon2<FP>& p2, EvalCtx<FP, V>& b) {
                   (next_index_sum - (mmcs_index_sum * b.K(2) + next_bit)));
   }
 
-  // --- inner permutation AIR ---
-  std::array<V, WIDTH> s;
-  for (int i = 0; i < WIDTH; ++i) s[i] = L[i];
-  auto external = [&](std::array<V, WIDTH>& st) {
-    std::array<V, WIDTH> o;
-    for (int i = 0; i < WIDTH; ++i) {
-      V acc = zero;
-      for (int j = 0; j < WIDTH; ++j) acc = acc + st[j] * b.KF(p2.ext[i][j]);
-      o[i] = acc;
+  eval_poseidon2_perm<FP, V>(p2, b);
+}
+
+// ---- Poseidon2CircuitAir, compact D1 layout (width 16, rate 8, one witness per state element) on a witness bus of
+// WB = D value slots (KoalaBearD1Width16WitnessBus5 for D = 5 circuits: batch_stark_prover/poseidon2.rs:1244-1285) ----
+// preprocessed row (air.rs:730-763, poseidon-circuit-cols preprocessed.rs:121-145), 62 columns:
+//   [0..8) in_ctl | 8 cap_tag | 9 cap_chain_enable | [10..18) rate sponge-chain sel | [18..26) rate Merkle-chain sel
+//   | [26..42) input idx | [42..50) output idx | [50..58) out_ctl | 58 mmcs idx | 59 mmcs_merkle_flag | 60 new_start
+//   | 61 merkle_path
+// constraints air.rs:937-1031, interactions :1721-1785.
+template <class FP, class V>
+void eval_poseidon2_d1(const AirDesc& a, const Poseidon2<FP>& p2, EvalCtx<FP, V>& b) {
+  constexpr int WE = 16, RE = 8, R = FP::SBOX_REGS, HDR = 26, TAIL = HDR + WE + RE + RE;
+  const int WB = a.D;
+  const int pc = Poseidon2<FP>::perm_cols();
+  const V* L = b.local; const V* N = b.next; const V* PL = b.prep_local; const V* PN = b.prep_next;
+  const int ending_off = WIDTH + HALF_FULL * (WIDTH * R + WIDTH) + FP::PARTIAL * (R + 1);
+  const V* local_out = L + ending_off + (HALF_FULL - 1) * (WIDTH * R + WIDTH) + WIDTH * R;
+  const V* next_in = N;
+  const V mmcs_bit = L[pc], mmcs_index_sum = L[pc + 1];
+  const V next_bit = N[pc], next_index_sum = N[pc + 1];
+  const V one = b.K(1), zero = b.K(0);
+
+  // --- interactions ---
+  {
+    const V not_merkle = one - PL[TAIL + 3];
+    for (int l = 0; l < RE; ++l) {
+      std::vector<V> f{PL[HDR + l], L[l]};
+      for (int d = 1; d < WB; ++d) f.push_back(zero);
+      b.push_interaction(std::move(f), zero - PL[l] * not_merkle);
     }
-    st = o;
-  };
-  auto internal = [&](std::array<V, WIDTH>& st) {
-    V sum = zero;
-    for (auto& x : st) sum = sum + x;
-    for (int i = 0; i < WIDTH; ++i) st[i] = st[i] * b.KF(p2.diag[i]) + sum;
-  };
-  auto sbox = [&](V x, const V* reg) -> V {
-    if (FP::SBOX_DEGREE == 3) return x * x * x;
-    // (7,1): committed x^3 register, then x^7 = (x^3)^2 * x
-    V c3 = reg[0];
-    b.assert_zero(c3 - x * x * x);
-    return c3 * c3 * x;
-  };
-  external(s);
-  int k = 0;
-  auto full_round = [&](int col) {
-    for (int i = 0; i < WIDTH; ++i) {
-      V x = s[i] + b.KF(p2.rc[k + i]);
-      s[i] = sbox(x, L + col + i * R);
+    for (int l = 0; l < RE; ++l) {
+      std::vector<V> f{PL[HDR + WE + l], local_out[l]};
+      for (int d = 1; d < WB; ++d) f.push_back(zero);
+      b.push_interaction(std::move(f), PL[HDR + WE + RE + l]);
     }
-    k += WIDTH;
-    external(s);
-    const V* post = L + col + WIDTH * R;
-    for (int i = 0; i < WIDTH; ++i) {
-      b.assert_zero(s[i] - post[i]);
-      s[i] = post[i];
-    }
-  };
-  for (int r = 0; r < HALF_FULL; ++r) full_round(full_off(r));
-  for (int r = 0; r < FP::PARTIAL; ++r) {
-    int col = partial_off + r * (R + 1);
-    V x = s[0] + b.KF(p2.rc[k++]);
-    s[0] = sbox(x, L + col);
-    b.assert_zero(s[0] - L[col + R]);
-    s[0] = L[col + R];
-    internal(s);
+    std::vector<V> f{PL[TAIL], mmcs_index_sum};
+    for (int d = 1; d < WB; ++d) f.push_back(zero);
+    b.push_interaction(std::move(f), zero - PL[TAIL + 1] * PN[TAIL + 2]);
   }
-  for (int r = 0; r < HALF_FULL; ++r) full_round(end_off(r));
+
+  // --- circuit constraints ---
+  b.assert_zero(mmcs_bit * (one - mmcs_bit));
+  const V cap_chain_enable = PN[RE + 1], cap_tag = PN[RE];
+  const V next_new_start = PN[TAIL + 2], next_merkle_path = PN[TAIL + 3];
+  const V not_merkle = one - next_merkle_path;
+  for (int l = 0; l < RE; ++l)
+    b.assert_zero(b.is_transition * PN[RE + 2 + l] * (next_in[l] - local_out[l]));
+  for (int l = RE; l < WE; ++l) {
+    const V tag = l == RE ? cap_tag : zero;
+    b.assert_zero(b.is_transition * (cap_chain_enable * not_merkle) * (next_in[l] - local_out[l] - tag));
+  }
+  const V is_left = one - next_bit;
+  for (int i = 0; i < RE; ++i) {
+    const V sel = PN[RE + 2 + RE + i];
+    b.assert_zero(b.is_transition * (sel * is_left) * (next_in[i] - local_out[i]));
+    b.assert_zero(b.is_transition * (sel * next_bit) * (next_in[RE + i] - local_out[i]));
+  }
+  for (int l = RE; l < WE; ++l) {
+    const V tag = l == RE ? cap_tag : zero;
+    b.assert_zero(b.is_transition * next_new_start * not_merkle * (next_in[l] - tag));
+  }
+  b.assert_zero(b.is_transition * (one - next_new_start) * next_merkle_path *
+                (next_index_sum - (mmcs_index_sum * b.K(2) + next_bit)));
+  eval_poseidon2_perm<FP, V>(p2, b);
 }
 
 template <class FP, class V>
@@ -377,7 +454,10 @@ void eval_air(const AirDesc& a, const Poseidon2<FP>& p2, EvalCtx<FP, V>& b) {
     case AIR_CONST:
     case AIR_PUBLIC: eval_witness_send<FP, V>(a, b); break;
     case AIR_ALU: eval_alu<FP, V>(a, b); break;
-    case AIR_POSEIDON2: eval_poseidon2<FP, V>(p2, b); break;
+    case AIR_POSEIDON2:
+      if (a.D == 4) eval_poseidon2<FP, V>(p2, b);
+      else eval_poseidon2_d1<FP, V>(a, p2, b);
+      break;
     case AIR_RECOMPOSE: eval_recompose<FP, V>(a, b); break;
     default: throw std::runtime_error("bad air kind");
   }

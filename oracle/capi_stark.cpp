@@ -32,8 +32,10 @@ typedef struct orc_workload {
   /* TablePacking (circuit-prover/src/batch_stark_prover/packing.rs:10-27) */
   uint32_t public_lanes, alu_lanes, horner_packed_steps, recompose_lanes, min_trace_height;
   /* extension degree D of the circuit's element field: 0 or 4 = binomial x^4 = W (every "x 4" above), 5 = KoalaBear
-   * quintic trinomial (values are n x 5 / n x 20; primitive tables only: n_p2 = n_recompose = 0) */
+   * quintic trinomial: values are n x 5 / n x 20, n_recompose = 0, and the Poseidon2 table is the compact-D1 one -
+   * p2_in_ctl / p2_input_indices are n x 16, p2_out_ctl / p2_output_indices n x 8, p2_absorb_len n (nullable: zeros) */
   uint32_t ext_degree;
+  const uint32_t* p2_absorb_len;
 } orc_workload;
 
 typedef struct orc_params {
@@ -109,8 +111,8 @@ struct Layer : LayerBase {
     const size_t mh = w.min_trace_height;
     const int D = w.ext_degree ? (int)w.ext_degree : 4;
     if (D != 4 && D != 5) throw std::runtime_error("UnsupportedDegree");
-    if (D == 5 && (FP::P != KoalaBear::P || w.n_p2 || w.n_recompose))
-      throw std::runtime_error("D = 5: KoalaBear, primitive tables only (the compact-D1 Poseidon2 table is not restated)");
+    if (D == 5 && (FP::P != KoalaBear::P || w.n_recompose))
+      throw std::runtime_error("D = 5: KoalaBear; Const / Public / ALU / compact-D1 Poseidon2 tables (no Recompose)");
     const int public_lanes = w.n_public <= 1 ? 1 : (int)w.public_lanes;
     const int alu_lanes = w.n_alu <= 1 ? 1 : (int)w.alu_lanes;
     {
@@ -139,19 +141,30 @@ struct Layer : LayerBase {
     }
     if (w.n_p2 > 0) {
       Instance<FP> in;
-      in.air.kind = AIR_POSEIDON2;
+      in.air.kind = AIR_POSEIDON2; in.air.D = D;
       // pad the op list to a power of two >= min height with filler rows
       // (new_start = true, zero state: batch_stark_prover/poseidon2.rs:1125-1140)
       size_t n = 1;
       while (n < std::max(w.n_p2, mh)) n <<= 1;
       std::vector<P2Row<FP>> rows(n);
-      std::vector<P2CtlRow<FP>> ctl(w.n_p2);
+      std::vector<P2CtlRow<FP>> ctl(D == 4 ? w.n_p2 : 0);
+      std::vector<P2CtlRowD1<FP>> ctl1(D == 4 ? 0 : w.n_p2);
       for (size_t r = 0; r < n; ++r) {
         if (r < w.n_p2) {
           rows[r].new_start = w.p2_flags[r * 4 + 0]; rows[r].merkle_path = w.p2_flags[r * 4 + 1];
           rows[r].mmcs_bit = w.p2_flags[r * 4 + 2];
           rows[r].mmcs_index_sum = F(w.p2_mmcs_index_sum[r]);
           for (int k = 0; k < 16; ++k) rows[r].input[k] = F(w.p2_inputs[r * 16 + k]);
+          if (D != 4) {
+            auto& c = ctl1[r];
+            c.new_start = rows[r].new_start; c.merkle_path = rows[r].merkle_path;
+            c.mmcs_ctl_enabled = w.p2_flags[r * 4 + 3];
+            for (int l = 0; l < 16; ++l) { c.in_ctl[l] = w.p2_in_ctl[r * 16 + l]; c.input_indices[l] = w.p2_input_indices[r * 16 + l]; }
+            for (int l = 0; l < 8; ++l) { c.out_ctl[l] = F(w.p2_out_ctl[r * 8 + l]); c.output_indices[l] = w.p2_output_indices[r * 8 + l]; }
+            c.mmcs_index_sum_idx = w.p2_mmcs_index_sum_idx[r];
+            c.absorb_len = w.p2_absorb_len ? w.p2_absorb_len[r] : 0;
+            continue;
+          }
           auto& c = ctl[r];
           c.new_start = rows[r].new_start; c.merkle_path = rows[r].merkle_path;
           c.mmcs_ctl_enabled = w.p2_flags[r * 4 + 3];
@@ -163,7 +176,7 @@ struct Layer : LayerBase {
         }
       }
       in.main = p2_generate_trace_rows<FP>(p2, rows);
-      in.prep = p2_preprocessed_trace<FP>(ctl, n);
+      in.prep = D == 4 ? p2_preprocessed_trace<FP>(ctl, n) : p2_preprocessed_trace_d1<FP>(ctl1, n, D);
       insts.push_back(std::move(in));
     }
     if (w.n_recompose > 0) {

@@ -101,7 +101,11 @@ inline std::vector<int> interaction_mult_degrees(const AirDesc& a) {
       for (int l = 0; l < a.lanes; ++l) { d.push_back(2); d.push_back(1); d.push_back(2); d.push_back(1); }
       for (int t = 1; t < a.horner_k; ++t) { d.push_back(1); d.push_back(1); }
       break;
-    case AIR_POSEIDON2: d = {2, 2, 2, 2, 1, 1, 2}; break;
+    case AIR_POSEIDON2:
+      if (a.D == 4) { d = {2, 2, 2, 2, 1, 1, 2}; break; }
+      // compact D1: 8 rate sends (in_ctl * not_merkle), 8 output receives, the accumulator send (air.rs:1721-1785)
+      d.assign(8, 2); d.insert(d.end(), 8, 1); d.push_back(2);
+      break;
   }
   return d;
 }

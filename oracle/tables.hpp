@@ -301,4 +301,44 @@ Matrix<FP> p2_preprocessed_trace(const std::vector<P2CtlRow<FP>>& rows, size_t m
   return m;
 }
 
+// Compact D1 layout of the same table (IL = 16, OL = 8: one witness per state element; air.rs:730-763 for the
+// CTL fields, circuit/src/ops/poseidon_perm/executor.rs:720-741 for the header incl. the length tag in slot 8),
+// witness indices scaled by the circuit's extension degree d; padding as above (air.rs:613-649).
+template <class FP>
+struct P2CtlRowD1 {
+  bool new_start, merkle_path, mmcs_ctl_enabled;
+  uint32_t in_ctl[16], input_indices[16], output_indices[8], mmcs_index_sum_idx, absorb_len;
+  Fe<FP> out_ctl[8];
+};
+template <class FP>
+Matrix<FP> p2_preprocessed_trace_d1(const std::vector<P2CtlRowD1<FP>>& rows, size_t min_height, int d) {
+  using F = Fe<FP>;
+  const size_t w = 62, n = rows.size();
+  Matrix<FP> m(std::max<size_t>(n, 1), w);
+  for (size_t r = 0; r < n; ++r) {
+    const auto& op = rows[r];
+    F* o = &m.v[r * w];
+    if (!op.merkle_path)
+      for (int l = 8; l < 16; ++l)
+        if (op.in_ctl[l]) throw std::runtime_error("compact D=1 Poseidon2: capacity must not be witness-fed on sponge rows");
+    for (int l = 0; l < 8; ++l) o[l] = F(op.in_ctl[l] ? 1 : 0);
+    o[8] = F(op.absorb_len);
+    o[9] = F(op.new_start ? 0 : 1);
+    for (int l = 0; l < 8; ++l) o[10 + l] = F((!op.new_start && !op.merkle_path && !op.in_ctl[l]) ? 1 : 0);
+    for (int l = 0; l < 8; ++l) o[18 + l] = F((!op.new_start && op.merkle_path && !op.in_ctl[l]) ? 1 : 0);
+    for (int l = 0; l < 16; ++l) o[26 + l] = F((uint64_t)op.input_indices[l] * d);
+    for (int l = 0; l < 8; ++l) o[42 + l] = F((uint64_t)op.output_indices[l] * d);
+    for (int l = 0; l < 8; ++l) o[50 + l] = op.out_ctl[l];
+    o[58] = F((uint64_t)op.mmcs_index_sum_idx * d);
+    o[59] = F((op.mmcs_ctl_enabled && op.merkle_path) ? 1 : 0);
+    o[60] = F(op.new_start ? 1 : 0);
+    o[61] = F(op.merkle_path ? 1 : 0);
+  }
+  size_t natural = n;
+  if (n == 0) m.h = 0;
+  pad_rows(m, min_height);
+  if (m.h > natural) m.v[natural * w + w - 2] = F::one();
+  return m;
+}
+
 }  // namespace orc

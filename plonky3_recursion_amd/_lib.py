@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # P3R_LIB_PATH: A/B runs of two builds of the library on one box (development only)
 LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so")
 
-P3R_ABI_VERSION = 3
+P3R_ABI_VERSION = 4
 P3R_EXT_LOOKUP_UNPACKED = 1
 FIELD_KOALA_BEAR = 0
 FIELD_BABY_BEAR = 1
@@ -73,6 +73,7 @@ class P3rLayerDesc(C.Structure):
         ("p2_mmcs_ctl_enabled", C.POINTER(C.c_uint8)), ("p2_in_ctl", C.POINTER(C.c_uint8)),
         ("p2_input_indices", C.POINTER(C.c_uint32)), ("p2_out_ctl", C.POINTER(C.c_uint32)),
         ("p2_output_indices", C.POINTER(C.c_uint32)), ("p2_mmcs_index_sum_idx", C.POINTER(C.c_uint32)),
+        ("p2_absorb_len", C.POINTER(C.c_uint8)),
     ]
 
 

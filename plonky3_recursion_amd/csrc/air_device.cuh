@@ -20,7 +20,12 @@ namespace p3r {
 
 enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4 };
 
-constexpr int kMaxExtD = 5;  // widest circuit extension: bus tuples hold at most 1 + kMaxExtD fields
+constexpr int kMaxExtD = 5;
+// compact-D1 Poseidon2 preprocessed row (poseidon-circuit-cols/src/preprocessed.rs:121-145), 62 columns:
+//   [0..8) in_ctl | 8 length tag | 9 cap_chain_enable | [10..18) rate sponge-chain sel | [18..26) rate Merkle-chain sel
+//   | [26..42) input idx | [42..50) output idx | [50..58) out_ctl | 58 mmcs idx | 59 mmcs_merkle_flag | 60 new_start
+//   | 61 merkle_path
+constexpr int kP2D1Hdr = 26, kP2D1Tail = 58, kP2D1PrepWidth = 62;  // widest circuit extension: bus tuples hold at most 1 + kMaxExtD fields
 
 struct AirParams {
   int kind;
@@ -153,6 +158,25 @@ P3R_HD void air_interactions(const AirParams& a, const View& v, Sink& sink) {
         t.c[0] = v.L(pc + 1);
         t.c[1] = t.c[2] = t.c[3] = F::zero();
         sink.add(v.PL(20), t, -(v.PL(21) * v.PN(22)));
+      } else {
+        // compact-D1 table on the D-slot witness bus (KoalaBearD1Width16WitnessBus5; air.rs:1721-1785): 8 rate
+        // sends, 8 output receives, the accumulator send; tuples (idx, v, 0, ..)
+        constexpr int pc = p2_perm_cols<PP>();
+        constexpr int out_col = pc - P2_WIDTH;
+        const F not_merkle = F::one() - v.PL(kP2D1Tail + 3);
+        VD<F, D> t;
+#pragma unroll
+        for (int i = 1; i < D; ++i) t.c[i] = F::zero();
+        for (int l = 0; l < 8; ++l) {
+          t.c[0] = v.L(l);
+          sink.add(v.PL(kP2D1Hdr + l), t, -(v.PL(l) * not_merkle));
+        }
+        for (int l = 0; l < 8; ++l) {
+          t.c[0] = v.L(out_col + l);
+          sink.add(v.PL(kP2D1Hdr + 16 + l), t, v.PL(kP2D1Hdr + 24 + l));
+        }
+        t.c[0] = v.L(pc + 1);
+        sink.add(v.PL(kP2D1Tail), t, -(v.PL(kP2D1Tail + 1) * v.PN(kP2D1Tail + 2)));
       }
       break;
   }
@@ -244,38 +268,12 @@ P3R_HD void alu_constraints(const AirParams& a, const View& v, Fold& fold) {
   }
 }
 
+// p3_poseidon2_air::eval over the permutation columns (poseidon2-circuit-air/src/air.rs:1137-1158)
 template <class PP, class View, class Fold>
-P3R_HD void poseidon2_constraints(const View& v, typename View::V is_transition, const uint32_t* __restrict__ rc,
-                                  Fold& fold) {
+P3R_HD void poseidon2_perm_constraints(const View& v, const uint32_t* __restrict__ rc, Fold& fold) {
   using F = typename View::V;
   using B = Fp<PP>;
   constexpr int R = PP::SBOX_REGISTERS;
-  constexpr int pc = p2_perm_cols<PP>();
-  constexpr int out_col = pc - P2_WIDTH;
-  const F one = F::one();
-  const F mmcs_bit = v.L(pc), index_sum = v.L(pc + 1), next_bit = v.N(pc), next_index_sum = v.N(pc + 1);
-  fold.base(mmcs_bit * (one - mmcs_bit));
-  // sponge chaining
-  for (int l = 0; l < 4; ++l) {
-    F gate = is_transition * v.PN(l * 4 + 2);
-#pragma unroll
-    for (int d = 0; d < 4; d += 2)
-      fold.base2(gate * (v.N(l * 4 + d) - v.L(out_col + l * 4 + d)), gate * (v.N(l * 4 + d + 1) - v.L(out_col + l * 4 + d + 1)));
-  }
-  // Merkle chaining, left then right placement
-  F is_left = one - next_bit;
-  for (int i = 0; i < 2; ++i) {
-    F gate = is_transition * (v.PN(i * 4 + 3) * is_left);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) fold.base(gate * (v.N(i * 4 + d) - v.L(out_col + i * 4 + d)));
-  }
-  for (int i = 0; i < 2; ++i) {
-    F gate = is_transition * (v.PN(i * 4 + 3) * next_bit);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) fold.base(gate * (v.N((2 + i) * 4 + d) - v.L(out_col + i * 4 + d)));
-  }
-  fold.base(is_transition * (one - v.PN(22)) * v.PN(23) * (next_index_sum - (index_sum.dbl() + next_bit)));
-  // inner permutation AIR
   F s[P2_WIDTH];
 #pragma unroll
   for (int i = 0; i < P2_WIDTH; ++i) s[i] = v.L(i);
@@ -325,6 +323,74 @@ P3R_HD void poseidon2_constraints(const View& v, typename View::V is_transition,
   for (int r = 0; r < P2_HALF_FULL; ++r) full_round();
 }
 
+template <class PP, class View, class Fold>
+P3R_HD void poseidon2_constraints(const View& v, typename View::V is_transition, const uint32_t* __restrict__ rc,
+                                  Fold& fold) {
+  using F = typename View::V;
+  constexpr int pc = p2_perm_cols<PP>();
+  constexpr int out_col = pc - P2_WIDTH;
+  const F one = F::one();
+  const F mmcs_bit = v.L(pc), index_sum = v.L(pc + 1), next_bit = v.N(pc), next_index_sum = v.N(pc + 1);
+  fold.base(mmcs_bit * (one - mmcs_bit));
+  // sponge chaining
+  for (int l = 0; l < 4; ++l) {
+    F gate = is_transition * v.PN(l * 4 + 2);
+#pragma unroll
+    for (int d = 0; d < 4; d += 2)
+      fold.base2(gate * (v.N(l * 4 + d) - v.L(out_col + l * 4 + d)), gate * (v.N(l * 4 + d + 1) - v.L(out_col + l * 4 + d + 1)));
+  }
+  // Merkle chaining, left then right placement
+  F is_left = one - next_bit;
+  for (int i = 0; i < 2; ++i) {
+    F gate = is_transition * (v.PN(i * 4 + 3) * is_left);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) fold.base(gate * (v.N(i * 4 + d) - v.L(out_col + i * 4 + d)));
+  }
+  for (int i = 0; i < 2; ++i) {
+    F gate = is_transition * (v.PN(i * 4 + 3) * next_bit);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) fold.base(gate * (v.N((2 + i) * 4 + d) - v.L(out_col + i * 4 + d)));
+  }
+  fold.base(is_transition * (one - v.PN(22)) * v.PN(23) * (next_index_sum - (index_sum.dbl() + next_bit)));
+  poseidon2_perm_constraints<PP>(v, rc, fold);
+}
+
+// The compact-D1 table (one witness per state element): air.rs:937-1031.
+template <class PP, class View, class Fold>
+P3R_HD void poseidon2_d1_constraints(const View& v, typename View::V is_transition, const uint32_t* __restrict__ rc,
+                                     Fold& fold) {
+  using F = typename View::V;
+  constexpr int pc = p2_perm_cols<PP>();
+  constexpr int out_col = pc - P2_WIDTH;
+  const F one = F::one();
+  const F mmcs_bit = v.L(pc), index_sum = v.L(pc + 1), next_bit = v.N(pc), next_index_sum = v.N(pc + 1);
+  fold.base(mmcs_bit * (one - mmcs_bit));
+  const F cap_tag = v.PN(8), next_new_start = v.PN(kP2D1Tail + 2), next_merkle = v.PN(kP2D1Tail + 3);
+  const F not_merkle = one - next_merkle;
+  // sponge chaining: rate limbs by their own selector, capacity by cap_chain_enable (first element += the length tag)
+  for (int l = 0; l < 8; ++l) fold.base(is_transition * v.PN(10 + l) * (v.N(l) - v.L(out_col + l)));
+  {
+    const F gate = is_transition * (v.PN(9) * not_merkle);
+    fold.base(gate * (v.N(8) - v.L(out_col + 8) - cap_tag));
+    for (int l = 9; l < 16; ++l) fold.base(gate * (v.N(l) - v.L(out_col + l)));
+  }
+  // Merkle chaining: the running digest goes left or right by the next row's direction bit
+  const F is_left = one - next_bit;
+  for (int i = 0; i < 8; ++i) {
+    const F sel = v.PN(18 + i), d = v.L(out_col + i);
+    fold.base(is_transition * (sel * is_left) * (v.N(i) - d));
+    fold.base(is_transition * (sel * next_bit) * (v.N(8 + i) - d));
+  }
+  // sponge chain starts: the capacity is the length tag, then zeros
+  {
+    const F gate = is_transition * next_new_start * not_merkle;
+    fold.base(gate * (v.N(8) - cap_tag));
+    for (int l = 9; l < 16; ++l) fold.base(gate * v.N(l));
+  }
+  fold.base(is_transition * (one - next_new_start) * next_merkle * (next_index_sum - (index_sum.dbl() + next_bit)));
+  poseidon2_perm_constraints<PP>(v, rc, fold);
+}
+
 // Number of base constraints of an AIR (host side needs it to size the alpha-power table).
 template <class PP>
 __host__ __device__ inline int air_num_base_constraints(const AirParams& a) {
@@ -348,7 +414,8 @@ __host__ __device__ inline int air_num_base_constraints(const AirParams& a) {
     }
     case AIR_POSEIDON2: {
       constexpr int R = PP::SBOX_REGISTERS;
-      return 1 + 16 + 8 + 8 + 1 + 2 * P2_HALF_FULL * (P2_WIDTH * R + P2_WIDTH) + PP::PARTIAL_ROUNDS * (R + 1);
+      return (a.ext_d == 4 ? 1 + 16 + 8 + 8 + 1 : 1 + 8 + 8 + 16 + 8 + 1) +
+             2 * P2_HALF_FULL * (P2_WIDTH * R + P2_WIDTH) + PP::PARTIAL_ROUNDS * (R + 1);
     }
     default: return 0;
   }

@@ -79,7 +79,11 @@ inline std::vector<int> interaction_mult_degrees(const AirParams& a) {
       for (int l = 0; l < a.lanes; ++l) { d.push_back(2); d.push_back(1); d.push_back(2); d.push_back(1); }
       for (int t = 1; t < a.horner_k; ++t) { d.push_back(1); d.push_back(1); }
       break;
-    case AIR_POSEIDON2: d = {2, 2, 2, 2, 1, 1, 2}; break;
+    case AIR_POSEIDON2:
+      if (a.ext_d == 4) { d = {2, 2, 2, 2, 1, 1, 2}; break; }
+      // compact D1: 8 rate sends (in_ctl * not_merkle), 8 output receives, the accumulator send
+      d.assign(8, 2); d.insert(d.end(), 8, 1); d.push_back(2);
+      break;
   }
   return d;
 }
@@ -149,7 +153,7 @@ inline int air_prep_width_of(const AirParams& a) {
     case AIR_CONST: return 2;
     case AIR_PUBLIC: return a.lanes * 2;
     case AIR_ALU: return a.lanes * 13 + 7 * (a.horner_k - 1);
-    case AIR_POSEIDON2: return 24;
+    case AIR_POSEIDON2: return a.ext_d == 4 ? 24 : kP2D1PrepWidth;
     case AIR_RECOMPOSE: return a.lanes * (2 + (a.coeff_lookups ? 8 : 0));
   }
   return 0;

@@ -313,8 +313,10 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const
   const F is_transition = x - g_inv;
   BaseFold<PP> fold(as_global(q.apow), q.n_constraints);
   if (q.air.kind == AIR_ALU) alu_constraints<PP, D>(q.air, v, fold);
-  if constexpr (D == 4)
-    if (q.air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc, fold);
+  if (q.air.kind == AIR_POSEIDON2) {
+    if constexpr (D == 4) poseidon2_constraints<PP>(v, is_transition, rc, fold);
+    else poseidon2_d1_constraints<PP>(v, is_transition, rc, fold);
+  }
   if (q.aux) {
     const F is_first = zh * (x - F::one()).inv();
     const F is_last = zh * is_transition.inv();

@@ -210,9 +210,10 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   L->has_p2 = d->counts.n_p2 > 0;
   L->has_recompose = d->counts.n_recompose > 0;
   if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
-  if (ctx->cfg.ext_degree != 4 && (L->has_p2 || L->has_recompose))
-    fail(P3R_EUNSUPPORTED, "UnsupportedDegree(%u): D = 5 layers hold the primitive tables (Const, Public, ALU) only",
-         ctx->cfg.ext_degree);
+  const uint32_t ext_d = ctx->cfg.ext_degree;
+  if (ext_d != 4 && L->has_recompose)
+    fail(P3R_EUNSUPPORTED, "UnsupportedDegree(%u): D = 5 layers have no Recompose table (Const, Public, ALU, compact-D1 Poseidon2)",
+         ext_d);
   const auto& c = d->counts;
   auto check = [&](const uint32_t* p, size_t n, const char* what) {
     if (n && !p) fail(P3R_EINVAL, "%s is NULL", what);
@@ -239,11 +240,39 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     check(d->const_prep, c.n_const * 2, "const_prep");
     check(d->public_prep, c.n_public * 2, "public_prep");
     check(d->recompose_prep, c.n_recompose * 2, "recompose_prep");
-    check(d->p2_out_ctl, c.n_p2 * 2, "p2_out_ctl");
+    check(d->p2_out_ctl, c.n_p2 * (ext_d == 4 ? 2 : 8), "p2_out_ctl");
     mats[0] = lanes_prep(d->const_prep, c.n_const, 2, 1, L->h_const);
     mats[1] = lanes_prep(d->public_prep, c.n_public, 2, (int)L->public_lanes, L->h_public);
     // Poseidon2 preprocessed rows (air.rs:697-794, non-compact D=4 layout) + padding (:613-649)
-    if (L->has_p2) {
+    if (L->has_p2 && ext_d != 4) {
+      // compact-D1 rows (air.rs:730-763; header executor.rs:720-741) + the same padding rule
+      L->h_p2 = padded_height(c.n_p2, mh);
+      std::vector<uint32_t>& m = mats[3];
+      constexpr size_t W = kP2D1PrepWidth;
+      m.assign(L->h_p2 * W, 0);
+      auto scaled = [&](uint32_t wid) { return (uint32_t)((uint64_t)wid * ext_d % P); };
+      for (size_t r = 0; r < c.n_p2; ++r) {
+        uint32_t* o = &m[r * W];
+        const bool ns = d->p2_new_start[r], mp = d->p2_merkle_path[r], en = d->p2_mmcs_ctl_enabled[r];
+        const uint8_t* ctl = d->p2_in_ctl + r * 16;
+        if (!mp)
+          for (int l = 8; l < 16; ++l)
+            if (ctl[l]) fail(P3R_EINVAL, "Poseidon2 row %zu: capacity input slots must be empty on compact D=1 sponge rows", r);
+        for (int l = 0; l < 8; ++l) o[l] = ctl[l] != 0;
+        o[8] = d->p2_absorb_len ? d->p2_absorb_len[r] : 0u;
+        o[9] = !ns;
+        for (int l = 0; l < 8; ++l) o[10 + l] = !ns && !mp && !ctl[l];
+        for (int l = 0; l < 8; ++l) o[18 + l] = !ns && mp && !ctl[l];
+        for (int l = 0; l < 16; ++l) o[kP2D1Hdr + l] = scaled(d->p2_input_indices[r * 16 + l]);
+        for (int l = 0; l < 8; ++l) o[kP2D1Hdr + 16 + l] = scaled(d->p2_output_indices[r * 8 + l]);
+        for (int l = 0; l < 8; ++l) o[kP2D1Hdr + 24 + l] = d->p2_out_ctl[r * 8 + l];
+        o[kP2D1Tail] = scaled(d->p2_mmcs_index_sum_idx[r]);
+        o[kP2D1Tail + 1] = en && mp;
+        o[kP2D1Tail + 2] = ns;
+        o[kP2D1Tail + 3] = mp;
+      }
+      if (L->h_p2 > c.n_p2) m[c.n_p2 * W + kP2D1Tail + 2] = 1;
+    } else if (L->has_p2) {
       L->h_p2 = padded_height(c.n_p2, mh);
       std::vector<uint32_t>& m = mats[3];
       m.assign(L->h_p2 * 24, 0);
@@ -312,8 +341,8 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     P3R_HIP(copy_sync(ctx->stream, L->alu_prev_src.p, S.prev_src.data(), S.prev_src.size() * 4, hipMemcpyHostToDevice));
   }
   other_tables.get();
-  const int widths[5] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1), 24,
-                         (int)L->recompose_lanes * 2};
+  const int widths[5] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1),
+                         ext_d == 4 ? 24 : kP2D1PrepWidth, (int)L->recompose_lanes * 2};
   const size_t heights[5] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose};
   p3r_matrix pm[5];
   p3r_air_desc present_airs[5];

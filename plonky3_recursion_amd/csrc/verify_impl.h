@@ -616,12 +616,15 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     ZetaFold<PP> fold;
     fold.alpha = alpha;
     const bool quintic = air.ext_d == 5;
-    if (air.ext_d != 4 && !(quintic && kHasQuintic<PP> && air.kind <= AIR_ALU))
+    if (air.ext_d != 4 && !(quintic && kHasQuintic<PP> && air.kind <= AIR_POSEIDON2))
       vfail("instance %zu: no AIR of kind %d for circuit extension degree %d", i, air.kind, air.ext_d);
     if (air.kind == AIR_ALU) {
       if (quintic) alu_constraints<PP, 5>(air, v, fold);
       else alu_constraints<PP>(air, v, fold);
-    } else if (air.kind == AIR_POSEIDON2) poseidon2_constraints<PP>(v, is_transition, rc_mont, fold);
+    } else if (air.kind == AIR_POSEIDON2) {
+      if (quintic) poseidon2_d1_constraints<PP>(v, is_transition, rc_mont, fold);
+      else poseidon2_constraints<PP>(v, is_transition, rc_mont, fold);
+    }
     if (fold.count != air_num_base_constraints<PP>(air)) vfail("instance %zu: constraint count mismatch", i);
     if (L.n_groups) {
       // EF aux columns from their 4 base-column openings: sum_k x^k * col_k(zeta)

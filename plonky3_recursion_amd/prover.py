@@ -79,11 +79,12 @@ class CircuitPrep:
     p2_new_start: np.ndarray
     p2_merkle_path: np.ndarray
     p2_mmcs_ctl_enabled: np.ndarray
-    p2_in_ctl: np.ndarray           # (n_p2, 4)
-    p2_input_indices: np.ndarray    # (n_p2, 4)
-    p2_out_ctl: np.ndarray          # (n_p2, 2) multiplicities
-    p2_output_indices: np.ndarray   # (n_p2, 2)
+    p2_in_ctl: np.ndarray           # (n_p2, IL)   IL x OL = 4 x 2 limbs (D = 4), 16 x 8 elements (the compact-D1
+    p2_input_indices: np.ndarray    # (n_p2, IL)   table of a D = 5 circuit: include/p3r.h)
+    p2_out_ctl: np.ndarray          # (n_p2, OL) multiplicities
+    p2_output_indices: np.ndarray   # (n_p2, OL)
     p2_mmcs_index_sum_idx: np.ndarray
+    p2_absorb_len: Optional[np.ndarray] = None   # (n_p2,) sponge length tags of compact-D1 rows (None: zeros)
 
 
 class CircuitProverData:
@@ -120,6 +121,15 @@ class CircuitProverData:
         d.p2_mmcs_ctl_enabled, d.p2_in_ctl = p8(prep.p2_mmcs_ctl_enabled), p8(prep.p2_in_ctl)
         d.p2_input_indices, d.p2_out_ctl = p32(prep.p2_input_indices), p32(prep.p2_out_ctl)
         d.p2_output_indices, d.p2_mmcs_index_sum_idx = p32(prep.p2_output_indices), p32(prep.p2_mmcs_index_sum_idx)
+        il, ol = (4, 2) if ctx.ext_degree == 4 else (16, 8)
+        n_p2 = len(prep.p2_new_start)
+        for name, w in (("p2_in_ctl", il), ("p2_input_indices", il), ("p2_out_ctl", ol), ("p2_output_indices", ol)):
+            if np.asarray(getattr(prep, name)).size != n_p2 * w:
+                raise P3rError(-1, "%s must hold %d x %d entries for ext_degree %d" % (name, n_p2, w, ctx.ext_degree))
+        if prep.p2_absorb_len is not None and len(prep.p2_absorb_len):
+            if len(prep.p2_absorb_len) != n_p2:
+                raise P3rError(-1, "p2_absorb_len must hold one entry per Poseidon2 row")
+            d.p2_absorb_len = p8(prep.p2_absorb_len)
         self.rows = dict(const=d.counts.n_const, public=d.counts.n_public, alu=d.counts.n_alu,
                          poseidon2=d.counts.n_p2, recompose=d.counts.n_recompose)
         self.preprocessed_commitment = np.empty((1 << ctx.cap_height, 8), dtype=np.uint32)
@@ -309,7 +319,7 @@ class BatchStarkProof:
         out = [dict(kind=0, lanes=1), dict(kind=1, lanes=tp.public_lanes),
                dict(kind=2, lanes=tp.alu_lanes, horner_packed_steps=tp.horner_packed_steps)]
         for e in self.non_primitives:
-            if e.op_type.startswith("poseidon2_perm/"):
+            if e.op_type.startswith("poseidon2_perm/") and (self.ext_degree == 4 or e.op_type.endswith("_d1_w16")):
                 out.append(dict(kind=3, lanes=1))
             elif e.op_type == "recompose":
                 out.append(dict(kind=4, lanes=e.lanes))
@@ -452,10 +462,12 @@ class BatchStarkProver:
         reference fills next to `proof` (batch_stark_prover.rs:610-636, 1597-1641)."""
         ctx = self.ctx
         tp = cpd.effective_packing
-        p2_name = "poseidon2_perm/%s_d4_w16" % ctx.field.replace("-", "_")   # circuit/src/ops/npo.rs:38
+        # circuit/src/ops/npo.rs:38, poseidon2_perm/config.rs:413-427: the D4 table, or the compact-D1 one of a D = 5 circuit
+        p2_name = "poseidon2_perm/%s_%s_w16" % (ctx.field.replace("-", "_"), "d4" if ctx.ext_degree == 4 else "d1")
         k = tp.horner_packed_steps
         present = [h > 0 for h in cpd.table_heights]
-        prep_widths = (2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24, 2 * tp.recompose_lanes)
+        prep_widths = (2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24 if ctx.ext_degree == 4 else 62,
+                       2 * tp.recompose_lanes)
         # non-primitive tables without rows are not proved (poseidon2.rs:1089-1092, recompose.rs:77-80)
         npo = []
         if present[3]:

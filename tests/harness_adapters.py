@@ -20,8 +20,9 @@ def traces_from_arrays(a, ext_degree=4) -> Traces:
     )
 
 
-def circuit_prep_from_arrays(a) -> CircuitPrep:
+def circuit_prep_from_arrays(a, ext_degree=4) -> CircuitPrep:
     fl = a["p2_flags"].reshape(-1, 4)
+    il, ol = (4, 2) if ext_degree == 4 else (16, 8)
     return CircuitPrep(
         const_prep=a["const_prep"].reshape(-1, 2),
         public_prep=a["public_prep"].reshape(-1, 2),
@@ -30,11 +31,12 @@ def circuit_prep_from_arrays(a) -> CircuitPrep:
         p2_new_start=fl[:, 0].astype(np.uint8),
         p2_merkle_path=fl[:, 1].astype(np.uint8),
         p2_mmcs_ctl_enabled=fl[:, 3].astype(np.uint8),
-        p2_in_ctl=a["p2_in_ctl"].reshape(-1, 4).astype(np.uint8),
-        p2_input_indices=a["p2_input_indices"].reshape(-1, 4),
-        p2_out_ctl=a["p2_out_ctl"].reshape(-1, 2),
-        p2_output_indices=a["p2_output_indices"].reshape(-1, 2),
+        p2_in_ctl=a["p2_in_ctl"].reshape(-1, il).astype(np.uint8),
+        p2_input_indices=a["p2_input_indices"].reshape(-1, il),
+        p2_out_ctl=a["p2_out_ctl"].reshape(-1, ol),
+        p2_output_indices=a["p2_output_indices"].reshape(-1, ol),
         p2_mmcs_index_sum_idx=a["p2_mmcs_index_sum_idx"],
+        p2_absorb_len=a["p2_absorb_len"].astype(np.uint8) if ext_degree != 4 and "p2_absorb_len" in a else None,
     )
 
 

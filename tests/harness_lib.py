@@ -16,7 +16,7 @@ ARRAYS = ["const_values", "const_prep", "public_values", "public_prep", "alu_val
           "p2_output_indices", "p2_mmcs_index_sum_idx", "recompose_values", "recompose_prep", "counts",
           # the circuit the arrays above were derived from (flattened Circuit<EF>, include/p3r.h) and its inputs
           "ops", "ext", "public_rows", "in_public_values", "private_rows", "in_private_values", "pd_op_ids",
-          "pd_siblings", "rewrite"]
+          "pd_siblings", "rewrite", "p2_absorb_len"]
 
 
 def build():

@@ -1,5 +1,6 @@
-"""GPU parity for D = 5 layers: KoalaBear circuits over the quintic trinomial extension x^5 + x^2 - 1, primitive
-tables (Const, Public, ALU), proved under the D = 4 STARK configuration as the reference's unit tests do
+"""GPU parity for D = 5 layers: KoalaBear circuits over the quintic trinomial extension x^5 + x^2 - 1 - the
+primitive tables (Const, Public, ALU) and the compact-D1 Poseidon2 table - proved under the D = 4 STARK
+configuration as the reference's unit tests do
 (circuit-prover/src/batch_stark_prover/tests.rs:844-1029).  Matrices, preprocessed commitment and proof bytes
 against the CPU oracle; the proof's metadata; what the D = 5 context refuses."""
 import numpy as np
@@ -18,6 +19,8 @@ def setup(oracle, log_h, kw, packing=None, flags=PRIMITIVE, **gen):
     from plonky3_recursion_amd import prover as pv
     import harness_adapters as wl
     gen.setdefault("horner_chain_len", 20)
+    gen.setdefault("sponge_chain_len", 3)
+    gen.setdefault("merkle_depth", 5)
     arrs = harness_lib.generate("koala-bear", log_h, seed=11 + log_h, flags=flags, ext_degree=5, **gen)
     prm = layer_lib.params(**kw)
     packing = packing or {}
@@ -29,7 +32,7 @@ def setup(oracle, log_h, kw, packing=None, flags=PRIMITIVE, **gen):
     tp = pv.TablePacking(public_lanes=packing.get("public_lanes", 1), alu_lanes=packing.get("alu_lanes", 3),
                          horner_packed_steps=packing.get("horner_packed_steps", 4))
     tp.with_fri_params(prm.log_final_poly_len, prm.log_blowup)
-    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), pv.FriRecursionBackend(),
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=5), pv.FriRecursionBackend(),
                                      pv.ProveNextLayerParams(table_packing=tp))
     return arrs, L, ctx, cache, wl.traces_from_arrays(arrs, ext_degree=5)
 
@@ -47,14 +50,18 @@ CASES = [
 ]
 
 
+WITH_P2 = harness_lib.NO_RECOMPOSE   # + the compact-D1 Poseidon2 table (KOALA_BEAR_D1_W16 on the 5-slot witness bus)
+
+
+@pytest.mark.parametrize("flags", [PRIMITIVE, WITH_P2])
 @pytest.mark.parametrize("log_h,kw,packing", CASES)
-def test_quintic_layer_matrices_commitment_and_proof(oracle, log_h, kw, packing):
+def test_quintic_layer_matrices_commitment_and_proof(oracle, log_h, kw, packing, flags):
     from plonky3_recursion_amd import prover as pv
-    arrs, L, ctx, cache, traces = setup(oracle, log_h, kw, packing)
+    arrs, L, ctx, cache, traces = setup(oracle, log_h, kw, packing, flags=flags)
     tables = L.tables()
     cpd = cache.circuit_prover_data
-    assert [t["kind"] for t in tables] == ["const", "public", "alu"]
-    assert cpd.table_heights[:3] == [t["main"].shape[0] for t in tables]
+    assert [t["kind"] for t in tables] == ["const", "public", "alu"] + (["poseidon2"] if flags == WITH_P2 else [])
+    assert [h for h in cpd.table_heights if h] == [t["main"].shape[0] for t in tables]
     assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
     res = pv.ResidentTraces(ctx, cpd, traces)
     for i, t in enumerate(tables):
@@ -71,7 +78,8 @@ def test_quintic_layer_matrices_commitment_and_proof(oracle, log_h, kw, packing)
     assert cache.prover.prove_all_tables(traces, cpd, canonical_field_encoding=True).proof == L.prove(field_encoding=1)
     # the metadata the reference writes next to the proof (batch_stark_prover.rs:1597-1641)
     p = out.proof
-    assert p.ext_degree == 5 and p.w_binomial is None and p.alu_quintic_trinomial and p.non_primitives == ()
+    assert p.ext_degree == 5 and p.w_binomial is None and p.alu_quintic_trinomial
+    assert [e.op_type for e in p.non_primitives] == (["poseidon2_perm/koala_bear_d1_w16"] if flags == WITH_P2 else [])
     cache.prover.verify_all_tables(p)
     back = pv.BatchStarkProof.from_postcard(p.to_postcard(), "koala-bear")
     assert back.to_postcard() == p.to_postcard() and back.ext_degree == 5 and back.alu_quintic_trinomial
@@ -94,6 +102,21 @@ def test_quintic_unsatisfied_trace_is_reported(oracle):
     ctx.close()
 
 
+def test_compact_d1_chain_break_is_reported(oracle):
+    """A chained capacity element of a sponge continuation row changed: the prover's self-check at zeta refuses."""
+    import plonky3_recursion_amd as p3r
+    arrs, L, ctx, cache, traces = setup(oracle, 6, dict(log_final_poly_len=1, query_pow_bits=3, num_queries=4), flags=WITH_P2)
+    fl = arrs["p2_flags"].reshape(-1, 4)
+    r = next(r for r in range(1, len(fl)) if not fl[r, 0] and not fl[r, 1])
+    v = traces.p2_input_values.copy()
+    v[r, 12] = (int(v[r, 12]) + 1) % 0x7F000001
+    traces.p2_input_values = v
+    with pytest.raises(p3r.P3rError, match="do not satisfy"):
+        cache.prover.prove_all_tables(traces, cache.circuit_prover_data)
+    cache.circuit_prover_data.free()
+    ctx.close()
+
+
 def test_what_a_quintic_context_refuses(oracle):
     import plonky3_recursion_amd as p3r
     from plonky3_recursion_amd import prover as pv
@@ -104,17 +127,21 @@ def test_what_a_quintic_context_refuses(oracle):
         p3r.Context(field="koala-bear", ext_degree=8)
     ctx = p3r.Context(field="koala-bear", log_final_poly_len=1, query_pow_bits=3, num_queries=4, ext_degree=5)
     tp = pv.TablePacking().with_fri_params(1, 2)
-    # a layer with Poseidon2 / Recompose rows is a D = 4 layer
+    # a layer with Recompose rows is a D = 4 layer, and so are 4 x 2-limb Poseidon2 rows
     arrs4 = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+    prep4 = wl.circuit_prep_from_arrays(arrs4)
+    with pytest.raises(p3r.P3rError, match="ext_degree 5"):
+        pv.build_next_layer_prep(ctx, prep4, pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
+    arrs5r = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, flags=harness_lib.NO_POSEIDON2)
     with pytest.raises(p3r.P3rError, match="UnsupportedDegree"):
-        pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs4), pv.FriRecursionBackend(),
+        pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs5r, ext_degree=5), pv.FriRecursionBackend(),
                                  pv.ProveNextLayerParams(table_packing=tp))
     # the circuit boundary runs D = 4 circuits
     arrs5 = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, flags=PRIMITIVE, ext_degree=5)
     with pytest.raises(p3r.P3rError, match="UnsupportedDegree"):
         pv.PreparedCircuit(ctx, wl.circuit_from_arrays(arrs5), tp)
     # D = 4 shaped values under a D = 5 context
-    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs5), pv.FriRecursionBackend(),
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs5, ext_degree=5), pv.FriRecursionBackend(),
                                      pv.ProveNextLayerParams(table_packing=tp))
     bad = wl.traces_from_arrays(harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, flags=PRIMITIVE))
     with pytest.raises(p3r.P3rError, match="shape"):
@@ -130,10 +157,11 @@ def test_quintic_layer_at_2_16_rows_verifies(oracle):
     import plonky3_recursion_amd as p3r
     import harness_adapters as wl
     prm = layer_lib.params(query_pow_bits=8, num_queries=20)
-    arrs = harness_lib.generate("koala-bear", 16, seed=5, horner_chain_len=64, flags=PRIMITIVE, ext_degree=5)
+    arrs = harness_lib.generate("koala-bear", 16, seed=5, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20,
+                                flags=WITH_P2, ext_degree=5)
     ctx = p3r.Context(field="koala-bear", query_pow_bits=8, num_queries=20, ext_degree=5)
     tp = pv.TablePacking().with_fri_params(prm.log_final_poly_len, prm.log_blowup)
-    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), pv.FriRecursionBackend(),
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=5), pv.FriRecursionBackend(),
                                      pv.ProveNextLayerParams(table_packing=tp))
     proof = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs, ext_degree=5), cache.circuit_prover_data)
     cache.prover.verify_all_tables(proof)

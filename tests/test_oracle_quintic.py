@@ -108,7 +108,7 @@ def test_degree_four_rule_does_not_verify_a_quintic_layer(oracle):
 
 
 def test_refused_shapes(oracle):
-    with pytest.raises(RuntimeError, match="primitive tables"):
+    with pytest.raises(RuntimeError, match="no Recompose table"):
         harness_lib.generate("koala-bear", 5, ext_degree=5)
     with pytest.raises(RuntimeError, match="ext_degree"):
         harness_lib.generate("baby-bear", 5, flags=PRIMITIVE, ext_degree=5)
@@ -203,3 +203,88 @@ def test_quintic_metadata_on_the_wire(oracle):
         verify_all_tables(cfg5, dataclasses.replace(back, w_binomial=3))
     with pytest.raises(p3r.P3rError, match="QuinticReductionMismatch"):
         verify_all_tables(cfg5, dataclasses.replace(back, alu_quintic_trinomial=False))
+
+
+# ---------------------------------------------------------------- compact-D1 Poseidon2 table of a D = 5 circuit
+D1 = dict(horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+
+
+def layer_d1(oracle, log_h, seed, prm, packing=None, mutate=None):
+    arrs = harness_lib.generate("koala-bear", log_h, seed=seed, flags=harness_lib.NO_RECOMPOSE, ext_degree=5, **D1)
+    if mutate:
+        mutate(arrs)
+    return arrs, layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(packing or {}, ext_degree=5))
+
+
+@pytest.mark.parametrize("log_h,kw", [
+    (5, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=0)),
+    (7, dict(log_blowup=2, max_log_arity=3, log_final_poly_len=2)),
+    (7, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, cap_height=2)),
+])
+def test_compact_d1_poseidon2_roundtrip(oracle, log_h, kw):
+    prm = layer_lib.params(query_pow_bits=3, num_queries=5, **kw)
+    arrs, L = layer_d1(oracle, log_h, log_h, prm)
+    t = {x["kind"]: x for x in L.tables()}
+    # KoalaBearD1Width16: the same 166 main columns as the D = 4 table, 62 preprocessed ones
+    # (poseidon-circuit-cols/src/preprocessed.rs:137-145: 26 header + 16 + 8 + 8 + 4)
+    assert t["poseidon2"]["main"].shape[1] == 166 and t["poseidon2"]["prep"].shape[1] == 62
+    n = int(arrs["counts"][3])
+    prep = t["poseidon2"]["prep"]
+    assert (prep[:n, 26:42] % 5 == 0).all()                       # witness indices scaled by D = 5
+    assert np.array_equal(prep[:n, 8], arrs["p2_absorb_len"]) and (log_h < 7 or arrs["p2_absorb_len"].any())
+    if prep.shape[0] > n:
+        assert prep[n, 60] == 1 and not prep[n + 1:].any()        # first padding row: chain boundary
+    pf = L.prove()
+    L.verify(pf)
+    assert L.prove() == pf
+    for pos in range(7, len(pf), max(len(pf) // 40, 1)):
+        bad = bytearray(pf)
+        bad[pos] ^= 1
+        with pytest.raises(RuntimeError):
+            L.verify(bytes(bad))
+    # the product's native verifier agrees
+    native_verify(prm, L.tables(), L.prep_commit(), pf)
+
+
+def sponge_continuation_rows(arrs):
+    fl = arrs["p2_flags"].reshape(-1, 4)
+    return [r for r in range(1, len(fl)) if not fl[r, 0] and not fl[r, 1]]
+
+
+@pytest.mark.parametrize("what", ["capacity", "rate", "tag", "merkle", "accumulator", "bus"])
+def test_compact_d1_poseidon2_rejects(oracle, what):
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=4)
+
+    def mutate(arrs):
+        fl = arrs["p2_flags"].reshape(-1, 4)
+        inp = arrs["p2_inputs"].reshape(-1, 16)
+        ctl = arrs["p2_in_ctl"].reshape(-1, 16)
+        if what == "capacity":      # a chained capacity element (never witness-fed)
+            r = sponge_continuation_rows(arrs)[0]
+            inp[r, 12] = (int(inp[r, 12]) + 1) % P
+        elif what == "rate":        # a chained rate element
+            r, i = next((r, i) for r in sponge_continuation_rows(arrs) for i in range(8) if not ctl[r, i])
+            inp[r, i] = (int(inp[r, i]) + 1) % P
+        elif what == "tag":         # the length tag bound into the first capacity element
+            # (row 0 is nobody's "next" row under when_transition: its tag is not bound)
+            r = next(r for r in range(1, len(fl)) if not fl[r, 1] and arrs["p2_absorb_len"][r])
+            arrs["p2_absorb_len"][r] = int(arrs["p2_absorb_len"][r]) + 1
+        elif what == "merkle":      # the running digest of a Merkle continuation row
+            r = next(r for r in range(1, len(fl)) if fl[r, 1] and not fl[r, 0])
+            side = 8 if fl[r, 2] else 0
+            inp[r, side + 3] = (int(inp[r, side + 3]) + 1) % P
+        elif what == "accumulator":  # the public witness the path's mmcs_index_sum is sent to
+            r = next(r for r in range(len(fl)) if fl[r, 3])
+            w = int(arrs["p2_mmcs_index_sum_idx"][r])
+            pos = int(np.nonzero(arrs["public_prep"].reshape(-1, 2)[:, 1] == 5 * w)[0][0])
+            pv = arrs["public_values"].reshape(-1, 5)
+            assert pv[pos, 0] == arrs["p2_mmcs_index_sum"][r]
+            pv[pos, 0] = (int(pv[pos, 0]) + 1) % P
+        else:                        # an output multiplicity
+            oc = arrs["p2_out_ctl"]
+            k = next(k for k in range(len(oc)) if 0 < oc[k] < P - 1)
+            oc[k] = int(oc[k]) + 1
+
+    arrs, L = layer_d1(oracle, 6, 21, prm, mutate=mutate)
+    with pytest.raises(RuntimeError, match="constraints do not match|final polynomial|terminals do not sum"):
+        L.verify(L.prove())
