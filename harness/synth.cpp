@@ -49,7 +49,9 @@ enum { SYN_NO_POSEIDON2 = 1, SYN_NO_RECOMPOSE = 2, SYN_SINGLE_PUBLIC = 4, SYN_NO
        // sponge rows read only witnesses that no permutation produced: the sponge chains are independent of each
        // other (the leaf hashes of a verifier circuit: one chain per opened row), Merkle chains may still start
        // from a sponge's digest
-       SYN_INDEPENDENT_SPONGES = 16 };
+       SYN_INDEPENDENT_SPONGES = 16,
+       // the Recompose table is the "recompose/coeff" variant (per-coefficient bus tuples)
+       SYN_RECOMPOSE_COEFF = 32 };
 
 enum { OP_ADD = 0, OP_MUL = 1, OP_BOOL = 2, OP_MULADD = 3, OP_HORNER = 4 };
 
@@ -64,8 +66,6 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   using F = Fp<PP>;
   constexpr int D = E::DEG;  // circuit extension degree: witness indices on the bus are scaled by D
   const uint32_t P = PP::P;
-  if (D != 4 && !(flags & SYN_NO_RECOMPOSE))
-    throw std::runtime_error("ext_degree 5 has no Recompose table here: pass SYN_NO_RECOMPOSE (Poseidon2 rows are the compact-D1 ones)");
   const size_t H = size_t(1) << log_h;
   Rng rng(seed);
   auto rf = [&]() { return F::from_canonical((uint32_t)(rng.next() % P)); };
@@ -177,24 +177,38 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   auto pickp_noread = [&]() { return pickable[rng.below((uint32_t)pickable.size())]; };
   auto pickp = [&]() { uint32_t w = pickp_noread(); reads[w]++; return w; };
 
-  // ---- Recompose (H/4 rows): packs 4 base-field witnesses into one extension witness
-  // (ops/recompose.rs:115-170; the coefficient witnesses are not looked up without coeff_lookups) ----
+  // ---- Recompose (H/4 rows): packs D base-field witnesses into one extension witness
+  // (ops/recompose.rs:115-170).  Plain table: the coefficient witnesses are not looked up.  SYN_RECOMPOSE_COEFF: the
+  // "recompose/coeff" variant (recompose_air.rs:196-226, batch_stark_prover/recompose.rs:341-352) - every coefficient
+  // is a bus tuple (D*idx, c, 0, ..) whose multiplicity is the read count of a coefficient no other table defines
+  // (a hint output in the reference) and 0 otherwise ----
   const size_t n_rec = (flags & SYN_NO_RECOMPOSE) ? 0 : std::max<size_t>(H / 4, 2);
+  const bool rec_coeff = (flags & SYN_RECOMPOSE_COEFF) != 0;
   std::vector<uint32_t> rec_w;
+  std::vector<std::vector<uint32_t>> rec_ins;
+  std::vector<uint32_t> rec_owned;   // coefficient witnesses whose only creator is a recompose/coeff row
   auto& rec_values = W.arr["recompose_values"];
   for (size_t i = 0; i < n_rec; ++i) {
-    std::vector<uint32_t> ins(4);
+    std::vector<uint32_t> ins(D);
     E v;
-    for (int k = 0; k < 4; ++k) {
-      ins[k] = base_valued[rng.below((uint32_t)base_valued.size())];
+    for (int k = 0; k < D; ++k) {
+      if (rec_coeff && rng.unit() < 0.3) {
+        ins[k] = create(E::from_base(rf()));
+        rec_owned.push_back(ins[k]);
+      } else {
+        ins[k] = base_valued[rng.below((uint32_t)base_valued.size())];
+      }
       v.c[k] = wval[ins[k]].c[0];
       rec_values.push_back(v.c[k].to_canonical());
     }
     uint32_t w = create(v);
     rec_w.push_back(w);
     pickable.push_back(w);
-    push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, 0, ins);
+    rec_ins.push_back(ins);
+    if (D == 4 && !rec_coeff) push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, 0, ins);
   }
+  // the owned coefficients are ordinary witnesses for everything after them
+  for (uint32_t w : rec_owned) { pickable.push_back(w); base_valued.push_back(w); }
 
   // ---- Poseidon2 rows (executor semantics: ops/poseidon_perm/executor.rs:921-972) ----
   auto& p2_inputs = W.arr["p2_inputs"];      // n x 16
@@ -556,7 +570,19 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   auto& public_values = W.arr["public_values"]; auto& public_prep = W.arr["public_prep"];
   for (uint32_t w : public_w) { put_e(public_values, wval[w]); public_prep.push_back(reads[w]); public_prep.push_back(w * D); }
   auto& rec_prep = W.arr["recompose_prep"];
-  for (uint32_t w : rec_w) { rec_prep.push_back(w * 4); rec_prep.push_back(reads[w]); }
+  {
+    std::vector<char> owned(wval.size(), 0);
+    for (uint32_t w : rec_owned) owned[w] = 1;
+    for (size_t i = 0; i < rec_w.size(); ++i) {
+      rec_prep.push_back(rec_w[i] * D); rec_prep.push_back(reads[rec_w[i]]);
+      if (rec_coeff)
+        for (int k = 0; k < D; ++k) {
+          const uint32_t c = rec_ins[i][k];
+          rec_prep.push_back(c * D);
+          rec_prep.push_back(owned[c] ? reads[c] : 0u);
+        }
+    }
+  }
   for (auto& f : out_fix) p2_out_ctl[f.row * (D == 4 ? 2 : 8) + f.limb] = reads[f.wid];
   // ALU per-op preprocessed, 13 columns (AluPrepLaneCols, alu_columns.rs:9-46; common.rs:198-281)
   auto& alu_prep = W.arr["alu_prep13"];

@@ -269,7 +269,8 @@ typedef struct p3r_layer_desc {
   const uint32_t* const_prep;     /* n_const x 2: [ext_mult, D*witness_idx]   (common.rs:353-368) */
   const uint32_t* public_prep;    /* n_public x 2                              (common.rs:324-351) */
   const uint32_t* alu_prep13;     /* n_alu x 13: AluPrepLaneCols               (common.rs:198-323) */
-  const uint32_t* recompose_prep; /* n_recompose x 2: [D*output_idx, out_mult] */
+  const uint32_t* recompose_prep; /* n_recompose x 2: [D*output_idx, out_mult]; with recompose_coeff_lookups (below)
+                                   * n_recompose x (2 + 2D): ... then (D*coeff_idx_i, coeff_mult_i) for i < D */
   /* Poseidon2CircuitRow CTL fields after poseidon_preprocess_for_prover
    * (circuit-prover/src/batch_stark_prover.rs:97-246); witness ids are NOT yet D-scaled */
   const uint8_t* p2_new_start;        /* n_p2 */
@@ -286,6 +287,12 @@ typedef struct p3r_layer_desc {
    * and p2_absorb_len (n_p2, NULL = zeros) is the prefix-free sponge length tag the executor writes into the header
    * (circuit/src/ops/poseidon_perm/executor.rs:720-741).  Since ABI version 4. */
   const uint8_t* p2_absorb_len;
+  /* 1: the Recompose table is the "recompose/coeff" variant (NpoTypeId::recompose_with_coeff_lookups, circuit/src/ops/
+   * npo.rs:53-60; circuit-prover/src/air/recompose_air.rs:196-226): each coefficient is also a bus tuple
+   * (D*coeff_idx, c, 0, ..) with the multiplicity batch_stark_prover/recompose.rs:341-352 computes.  It is what a backend
+   * registers when the permutation's degree differs from the circuit's (backend/fri.rs:693-721, :741-852: always under
+   * ext_degree 5, where the permutation is the D1 one).  Since ABI version 4. */
+  uint32_t recompose_coeff_lookups;
 } p3r_layer_desc;
 
 /* Flattened Traces<EF> (circuit/src/tables/mod.rs:49-62), canonical; D = p3r_config.ext_degree. */
@@ -294,7 +301,7 @@ typedef struct p3r_traces {
   size_t n_public;    const uint32_t* public_values;    /* n x D */
   size_t n_alu;       const uint32_t* alu_values;       /* n x 4D: AluTrace.values [a,b,c,out] */
   p3r_p2_rows p2;     /* n = un-padded Poseidon2 row count (any n, padding is done here) */
-  size_t n_recompose; const uint32_t* recompose_values; /* n x 4 */
+  size_t n_recompose; const uint32_t* recompose_values; /* n x D */
 } p3r_traces;
 
 typedef struct p3r_layer p3r_layer;

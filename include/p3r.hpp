@@ -117,7 +117,7 @@ struct Traces {
   std::vector<uint32_t> p2_input_values;              // n x 16
   std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_bit;
   std::vector<uint32_t> p2_mmcs_index_sum;
-  std::vector<uint32_t> recompose_values;             // n x 4
+  std::vector<uint32_t> recompose_values;             // n x D
 };
 
 // Per-op preprocessed data as get_airs_and_degrees_with_prep leaves it (see p3r_layer_desc).
@@ -128,6 +128,8 @@ struct CircuitPrep {
   // IL x OL = 4 x 2 limbs per row under ext_degree 4; 16 x 8 elements (the compact-D1 table) under ext_degree 5,
   // where p2_absorb_len holds the sponge length tags (empty: zeros); include/p3r.h
   std::vector<uint8_t> p2_absorb_len;
+  // the "recompose/coeff" table (per-coefficient bus tuples): recompose_prep is n x (2 + 2 D)
+  bool recompose_coeff_lookups = false;
 };
 
 struct Circuit {  // flattened Circuit<EF>
@@ -148,7 +150,11 @@ class CircuitProverData {
     p3r_layer_desc d{};
     d.counts.n_const = prep.const_prep.size() / 2; d.counts.n_public = prep.public_prep.size() / 2;
     d.counts.n_alu = prep.alu_prep13.size() / 13; d.counts.n_p2 = prep.p2_new_start.size();
-    d.counts.n_recompose = prep.recompose_prep.size() / 2;
+    const size_t rec_w = 2 + (prep.recompose_coeff_lookups ? 2 * ctx.ext_degree() : 0);
+    if (prep.recompose_prep.size() % rec_w) throw Error(P3R_EINVAL, "recompose_prep must be n x " + std::to_string(rec_w));
+    d.counts.n_recompose = prep.recompose_prep.size() / rec_w;
+    d.recompose_coeff_lookups = prep.recompose_coeff_lookups;
+    recompose_coeff_lookups = prep.recompose_coeff_lookups;
     d.public_lanes = packing.public_lanes; d.alu_lanes = packing.alu_lanes;
     d.horner_packed_steps = packing.horner_packed_steps; d.recompose_lanes = packing.recompose_lanes;
     d.min_trace_height = packing.min_trace_height;
@@ -180,6 +186,7 @@ class CircuitProverData {
   CircuitProverData(const CircuitProverData&) = delete;
   CircuitProverData& operator=(const CircuitProverData&) = delete;
   const p3r_layer* raw() const { return layer_; }
+  bool recompose_coeff_lookups = false;
   const TablePacking& packing() const { return packing_; }
   const TablePacking& effective_packing() const { return effective_; }  // reduce_lanes_if_dummy applied
   const p3r_layer_desc_counts& rows() const { return rows_; }
@@ -235,6 +242,7 @@ struct BatchStarkProof {
       const bool d1 = e.op_type.size() >= 7 && e.op_type.compare(e.op_type.size() - 7, 7, "_d1_w16") == 0;
       if (p2 && (ext_degree == 4 || d1)) a.push_back({P3R_AIR_POSEIDON2, 1, 2, 0});
       else if (e.op_type == "recompose") a.push_back({P3R_AIR_RECOMPOSE, (uint32_t)e.lanes, 2, 0});
+      else if (e.op_type == "recompose/coeff") a.push_back({P3R_AIR_RECOMPOSE, (uint32_t)e.lanes, 2, 1});
       else throw Error(P3R_EUNSUPPORTED, "MissingTableProver(" + e.op_type + ")");
     }
     return a;
@@ -348,7 +356,7 @@ std::vector<uint8_t> proof_call(const Context& ctx, Fn&& fn) {
 }
 inline p3r_traces traces_struct(const Traces& t, uint32_t d = 4) {
   p3r_traces s{};
-  if (t.const_values.size() % d || t.public_values.size() % d || t.alu_values.size() % (4 * d))
+  if (t.const_values.size() % d || t.public_values.size() % d || t.alu_values.size() % (4 * d) || t.recompose_values.size() % d)
     throw Error(P3R_EINVAL, "Traces values are not n x D / n x 4D for ext_degree " + std::to_string(d));
   s.n_const = t.const_values.size() / d; s.const_values = t.const_values.data();
   s.n_public = t.public_values.size() / d; s.public_values = t.public_values.data();
@@ -356,7 +364,7 @@ inline p3r_traces traces_struct(const Traces& t, uint32_t d = 4) {
   s.p2.n = t.p2_input_values.size() / 16; s.p2.input_values = t.p2_input_values.data();
   s.p2.new_start = t.p2_new_start.data(); s.p2.merkle_path = t.p2_merkle_path.data(); s.p2.mmcs_bit = t.p2_mmcs_bit.data();
   s.p2.mmcs_index_sum = t.p2_mmcs_index_sum.data();
-  s.n_recompose = t.recompose_values.size() / 4; s.recompose_values = t.recompose_values.data();
+  s.n_recompose = t.recompose_values.size() / d; s.recompose_values = t.recompose_values.data();
   return s;
 }
 }  // namespace detail
@@ -474,7 +482,9 @@ class BatchStarkProver {
     p.alu_quintic_trinomial = p.ext_degree == 5;
     const uint32_t k = tp.horner_packed_steps;
     const bool d4 = p.ext_degree == 4;   // D = 5 circuits carry the compact-D1 Poseidon2 table (62 preprocessed columns)
-    const uint32_t widths[5] = {2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), d4 ? 24u : 62u, 2 * tp.recompose_lanes};
+    const bool coeff = cpd.recompose_coeff_lookups;
+    const uint32_t widths[5] = {2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), d4 ? 24u : 62u,
+                                (2 + (coeff ? 2 * p.ext_degree : 0)) * tp.recompose_lanes};
     for (int i = 0; i < 5; ++i) {
       if (!cpd.table_heights[i]) continue;
       p.preprocessed_widths.push_back(widths[i]);
@@ -487,7 +497,7 @@ class BatchStarkProver {
                                   : ctx_->field() == Field::KoalaBear ? "poseidon2_perm/koala_bear_d4_w16" : "poseidon2_perm/baby_bear_d4_w16",
                                   cpd.table_heights[3], 1, {}, 0});
     if (cpd.table_heights[4])  // RecomposeProver reports the op count (recompose.rs:125)
-      p.non_primitives.push_back({"recompose", cpd.rows().n_recompose, tp.recompose_lanes, {}, 0});
+      p.non_primitives.push_back({coeff ? "recompose/coeff" : "recompose", cpd.rows().n_recompose, tp.recompose_lanes, {}, 0});
     p.preprocessed_commitment = cpd.preprocessed_commitment;
     p.montgomery_field_encoding = !canonical;
     p.modulus = modulus(ctx_->field());

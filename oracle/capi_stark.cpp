@@ -36,6 +36,9 @@ typedef struct orc_workload {
    * p2_in_ctl / p2_input_indices are n x 16, p2_out_ctl / p2_output_indices n x 8, p2_absorb_len n (nullable: zeros) */
   uint32_t ext_degree;
   const uint32_t* p2_absorb_len;
+  /* 1: the Recompose table is the "recompose/coeff" variant (recompose_air.rs:196-226) - recompose_prep is
+   * n x (2 + 2 D): [D*output_idx, out_mult, (D*coeff_idx_i, coeff_mult_i) x D]; recompose_values are n x D either way */
+  uint32_t recompose_coeff_lookups;
 } orc_workload;
 
 typedef struct orc_params {
@@ -111,8 +114,7 @@ struct Layer : LayerBase {
     const size_t mh = w.min_trace_height;
     const int D = w.ext_degree ? (int)w.ext_degree : 4;
     if (D != 4 && D != 5) throw std::runtime_error("UnsupportedDegree");
-    if (D == 5 && (FP::P != KoalaBear::P || w.n_recompose))
-      throw std::runtime_error("D = 5: KoalaBear; Const / Public / ALU / compact-D1 Poseidon2 tables (no Recompose)");
+    if (D == 5 && FP::P != KoalaBear::P) throw std::runtime_error("D = 5 is KoalaBear's quintic extension");
     const int public_lanes = w.n_public <= 1 ? 1 : (int)w.public_lanes;
     const int alu_lanes = w.n_alu <= 1 ? 1 : (int)w.alu_lanes;
     {
@@ -181,9 +183,11 @@ struct Layer : LayerBase {
     }
     if (w.n_recompose > 0) {
       Instance<FP> in;
-      in.air.kind = AIR_RECOMPOSE; in.air.lanes = (int)w.recompose_lanes; in.air.coeff_lookups = 0;
-      in.main = lanes_trace_to_matrix<FP>(vec(w.recompose_values, w.n_recompose * 4), in.air.lanes, mh);
-      in.prep = lanes_prep_to_matrix<FP>(vec(w.recompose_prep, w.n_recompose * 2), 2, in.air.lanes, mh);
+      in.air.kind = AIR_RECOMPOSE; in.air.lanes = (int)w.recompose_lanes; in.air.D = D;
+      in.air.coeff_lookups = w.recompose_coeff_lookups ? 1 : 0;
+      const int plw = 2 + (in.air.coeff_lookups ? 2 * D : 0);
+      in.main = lanes_trace_to_matrix<FP>(vec(w.recompose_values, w.n_recompose * D), in.air.lanes, mh, D);
+      in.prep = lanes_prep_to_matrix<FP>(vec(w.recompose_prep, w.n_recompose * plw), plw, in.air.lanes, mh);
       // RecomposeAir::trace_to_matrix pads only to a power of two; the prover then pads dynamic
       // tables to min_height (batch_stark_prover.rs:1515): same result as padding here.
       insts.push_back(std::move(in));

@@ -73,7 +73,7 @@ class P3rLayerDesc(C.Structure):
         ("p2_mmcs_ctl_enabled", C.POINTER(C.c_uint8)), ("p2_in_ctl", C.POINTER(C.c_uint8)),
         ("p2_input_indices", C.POINTER(C.c_uint32)), ("p2_out_ctl", C.POINTER(C.c_uint32)),
         ("p2_output_indices", C.POINTER(C.c_uint32)), ("p2_mmcs_index_sum_idx", C.POINTER(C.c_uint32)),
-        ("p2_absorb_len", C.POINTER(C.c_uint8)),
+        ("p2_absorb_len", C.POINTER(C.c_uint8)), ("recompose_coeff_lookups", C.c_uint32),
     ]
 
 

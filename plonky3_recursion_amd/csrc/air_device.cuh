@@ -111,21 +111,22 @@ P3R_HD void air_interactions(const AirParams& a, const View& v, Sink& sink) {
       for (int lane = 0; lane < a.lanes; ++lane)
         sink.add(v.PL(lane * 2 + 1), loadD<D, F>(L, lane * D), v.PL(lane * 2));
       break;
-    case AIR_RECOMPOSE:
-      if constexpr (D == 4) {
-        const int plw = 2 + (a.coeff_lookups ? 8 : 0);
-        for (int lane = 0; lane < a.lanes; ++lane) {
-          sink.add(v.PL(lane * plw), load4<F>(L, lane * 4), v.PL(lane * plw + 1));
-          if (a.coeff_lookups)
-            for (int i = 0; i < 4; ++i) {
-              V4<F> t;
-              t.c[0] = v.L(lane * 4 + i);
-              t.c[1] = t.c[2] = t.c[3] = F::zero();
-              sink.add(v.PL(lane * plw + 2 + 2 * i), t, v.PL(lane * plw + 3 + 2 * i));
-            }
-        }
+    case AIR_RECOMPOSE: {
+      // output tuple (idx, v_0..v_{D-1}); the "recompose/coeff" variant adds one tuple (idx_i, v_i, 0, ..) per
+      // coefficient (recompose_air.rs:196-226)
+      const int plw = 2 + (a.coeff_lookups ? 2 * D : 0);
+      for (int lane = 0; lane < a.lanes; ++lane) {
+        sink.add(v.PL(lane * plw), loadD<D, F>(L, lane * D), v.PL(lane * plw + 1));
+        if (a.coeff_lookups)
+          for (int i = 0; i < D; ++i) {
+            VD<F, D> t;
+            t.c[0] = v.L(lane * D + i);
+#pragma unroll
+            for (int j = 1; j < D; ++j) t.c[j] = F::zero();
+            sink.add(v.PL(lane * plw + 2 + 2 * i), t, v.PL(lane * plw + 3 + 2 * i));
+          }
       }
-      break;
+    } break;
     case AIR_ALU: {
       const int lanes = a.lanes, k_max = a.horner_k;
       for (int lane = 0; lane < lanes; ++lane) {

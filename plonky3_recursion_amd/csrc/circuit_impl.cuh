@@ -1257,7 +1257,7 @@ void dtraces_get(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, uint32_
     case P3R_TRACES_CONST_VALUES: plain(t->const_values, c.n_const * ctx->cfg.ext_degree); break;
     case P3R_TRACES_PUBLIC_VALUES: plain(t->public_values, c.n_public * ctx->cfg.ext_degree); break;
     case P3R_TRACES_ALU_VALUES: plain(t->alu_values, c.n_alu * 4 * ctx->cfg.ext_degree); break;
-    case P3R_TRACES_RECOMPOSE_VALUES: plain(t->recompose_values, c.n_recompose * 4); break;
+    case P3R_TRACES_RECOMPOSE_VALUES: plain(t->recompose_values, c.n_recompose * ctx->cfg.ext_degree); break;
     case P3R_TRACES_P2_INPUT_VALUES: {
       if (out_len != c.n_p2 * 16) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2 * 16, out_len);
       if (!c.n_p2) break;

@@ -74,7 +74,7 @@ inline std::vector<int> interaction_mult_degrees(const AirParams& a) {
   switch (a.kind) {
     case AIR_CONST: d = {1}; break;
     case AIR_PUBLIC: d.assign(a.lanes, 1); break;
-    case AIR_RECOMPOSE: d.assign(a.lanes * (1 + (a.coeff_lookups ? 4 : 0)), 1); break;
+    case AIR_RECOMPOSE: d.assign(a.lanes * (1 + (a.coeff_lookups ? a.ext_d : 0)), 1); break;
     case AIR_ALU:
       for (int l = 0; l < a.lanes; ++l) { d.push_back(2); d.push_back(1); d.push_back(2); d.push_back(1); }
       for (int t = 1; t < a.horner_k; ++t) { d.push_back(1); d.push_back(1); }
@@ -144,7 +144,7 @@ inline int air_width_of(const AirParams& a, int p2_width) {
     case AIR_PUBLIC: return a.lanes * a.ext_d;
     case AIR_ALU: return (a.lanes * 4 + (a.horner_k - 1) / 2 + 2 * (a.horner_k - 1) + 1) * a.ext_d;
     case AIR_POSEIDON2: return p2_width;
-    case AIR_RECOMPOSE: return a.lanes * 4;
+    case AIR_RECOMPOSE: return a.lanes * a.ext_d;
   }
   return 0;
 }
@@ -154,7 +154,7 @@ inline int air_prep_width_of(const AirParams& a) {
     case AIR_PUBLIC: return a.lanes * 2;
     case AIR_ALU: return a.lanes * 13 + 7 * (a.horner_k - 1);
     case AIR_POSEIDON2: return a.ext_d == 4 ? 24 : kP2D1PrepWidth;
-    case AIR_RECOMPOSE: return a.lanes * (2 + (a.coeff_lookups ? 8 : 0));
+    case AIR_RECOMPOSE: return a.lanes * (2 + (a.coeff_lookups ? 2 * a.ext_d : 0));
   }
   return 0;
 }

@@ -177,6 +177,7 @@ struct p3r_layer {
   // A non-primitive table with no rows is not part of the batch (poseidon2.rs:1089-1092,
   // recompose.rs:77-80: `batch_instance_*` returns None); the primitive three always are.
   bool has_p2 = true, has_recompose = true;
+  bool recompose_coeff = false;  // the "recompose/coeff" variant: per-coefficient bus tuples (recompose_air.rs:196-226)
   int slot_of(int table) const {  // position of table 0..4 among the proved instances, -1 if absent
     if (table < 3) return table;
     if (table == 3) return has_p2 ? 3 : -1;
@@ -211,9 +212,8 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   L->has_recompose = d->counts.n_recompose > 0;
   if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
   const uint32_t ext_d = ctx->cfg.ext_degree;
-  if (ext_d != 4 && L->has_recompose)
-    fail(P3R_EUNSUPPORTED, "UnsupportedDegree(%u): D = 5 layers have no Recompose table (Const, Public, ALU, compact-D1 Poseidon2)",
-         ext_d);
+  L->recompose_coeff = d->recompose_coeff_lookups != 0;
+  const int rec_plw = 2 + (L->recompose_coeff ? 2 * (int)ext_d : 0);
   const auto& c = d->counts;
   auto check = [&](const uint32_t* p, size_t n, const char* what) {
     if (n && !p) fail(P3R_EINVAL, "%s is NULL", what);
@@ -234,12 +234,12 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
                           {P3R_AIR_PUBLIC, L->public_lanes, 2, 0},
                           {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
                           {P3R_AIR_POSEIDON2, 1, 2, 0},
-                          {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 0}};
+                          {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, L->recompose_coeff ? 1u : 0u}};
   // every table but the ALU one on a second host thread (they share nothing with it)
   auto other_tables = std::async(std::launch::async, [&] {
     check(d->const_prep, c.n_const * 2, "const_prep");
     check(d->public_prep, c.n_public * 2, "public_prep");
-    check(d->recompose_prep, c.n_recompose * 2, "recompose_prep");
+    check(d->recompose_prep, c.n_recompose * rec_plw, "recompose_prep");
     check(d->p2_out_ctl, c.n_p2 * (ext_d == 4 ? 2 : 8), "p2_out_ctl");
     mats[0] = lanes_prep(d->const_prep, c.n_const, 2, 1, L->h_const);
     mats[1] = lanes_prep(d->public_prep, c.n_public, 2, (int)L->public_lanes, L->h_public);
@@ -299,7 +299,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
       if (L->h_p2 > c.n_p2) m[c.n_p2 * 24 + 22] = 1;
     }
     if (L->has_recompose)
-      mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, 2, (int)L->recompose_lanes, L->h_recompose);
+      mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, rec_plw, (int)L->recompose_lanes, L->h_recompose);
   });
   // ALU: schedule + scheduled preprocessed trace (alu_air.rs:613-677)
   {
@@ -342,7 +342,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   }
   other_tables.get();
   const int widths[5] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1),
-                         ext_d == 4 ? 24 : kP2D1PrepWidth, (int)L->recompose_lanes * 2};
+                         ext_d == 4 ? 24 : kP2D1PrepWidth, (int)L->recompose_lanes * rec_plw};
   const size_t heights[5] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose};
   p3r_matrix pm[5];
   p3r_air_desc present_airs[5];
@@ -416,7 +416,7 @@ std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, con
   d->const_values = upload_mont<PP>(ctx, t->const_values, c.n_const * D, "const_values");
   d->public_values = upload_mont<PP>(ctx, t->public_values, c.n_public * D, "public_values");
   d->alu_values = upload_mont<PP>(ctx, t->alu_values, c.n_alu * 4 * D, "alu_values");
-  d->recompose_values = upload_mont<PP>(ctx, t->recompose_values, c.n_recompose * 4, "recompose_values");
+  d->recompose_values = upload_mont<PP>(ctx, t->recompose_values, c.n_recompose * D, "recompose_values");
   if (!L->has_p2) return d;
   // Poseidon2 rows padded with fillers: new_start = true, zero state (poseidon2.rs:1125-1140)
   const size_t h = L->h_p2, n = c.n_p2;
@@ -468,7 +468,7 @@ std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r
   }
   if (L->has_p2) m[3] = trace_fill<PP>(ctx, t->p2.get());
   if (L->has_recompose)
-    m[4] = flat(t->recompose_values, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * 4, 4);
+    m[4] = flat(t->recompose_values, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * D, D);
   P3R_HIP(hipGetLastError());
   return m;
 }

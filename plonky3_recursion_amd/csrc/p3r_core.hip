@@ -1256,7 +1256,6 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
       if (airs[i].kind > P3R_AIR_RECOMPOSE || !airs[i].lanes) { report("bad AIR descriptor"); return P3R_EINVAL; }
       a[i] = {(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
               (cfg->ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)cfg->ext_degree};
-      if (cfg->ext_degree != 4 && airs[i].kind > P3R_AIR_POSEIDON2) { report("UnsupportedDegree: D = 5 has no Recompose table"); return P3R_EUNSUPPORTED; }
     }
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     std::vector<uint32_t> cap(preprocessed_commitment, preprocessed_commitment + ((size_t)P2_DIGEST << cfg->cap_height));

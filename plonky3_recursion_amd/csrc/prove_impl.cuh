@@ -130,8 +130,6 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
     AirParams a{(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
                 (ctx->cfg.ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)ctx->cfg.ext_degree};
     if (a.kind < 0 || a.kind > AIR_RECOMPOSE) fail(P3R_EINVAL, "instance %zu: unknown AIR kind %d", i, a.kind);
-    if (a.ext_d != 4 && a.kind == AIR_RECOMPOSE)
-      fail(P3R_EUNSUPPORTED, "instance %zu: ext_degree %d has no Recompose table (Const, Public, ALU, compact-D1 Poseidon2)", i, a.ext_d);
     if (a.lanes < 1) fail(P3R_EINVAL, "instance %zu: lanes must be positive", i);
     if (a.kind == AIR_ALU && (a.horner_k < 2 || a.horner_k > 8))
       fail(P3R_EINVAL, "instance %zu: horner_packed_steps must be in 2..8", i);

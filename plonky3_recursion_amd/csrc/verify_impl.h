@@ -616,7 +616,7 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     ZetaFold<PP> fold;
     fold.alpha = alpha;
     const bool quintic = air.ext_d == 5;
-    if (air.ext_d != 4 && !(quintic && kHasQuintic<PP> && air.kind <= AIR_POSEIDON2))
+    if (air.ext_d != 4 && !(quintic && kHasQuintic<PP> && air.kind <= AIR_RECOMPOSE))
       vfail("instance %zu: no AIR of kind %d for circuit extension degree %d", i, air.kind, air.ext_d);
     if (air.kind == AIR_ALU) {
       if (quintic) alu_constraints<PP, 5>(air, v, fold);

@@ -85,6 +85,8 @@ class CircuitPrep:
     p2_output_indices: np.ndarray   # (n_p2, OL)
     p2_mmcs_index_sum_idx: np.ndarray
     p2_absorb_len: Optional[np.ndarray] = None   # (n_p2,) sponge length tags of compact-D1 rows (None: zeros)
+    # the "recompose/coeff" table (per-coefficient bus tuples): recompose_prep is (n_recompose, 2 + 2 D)
+    recompose_coeff_lookups: bool = False
 
 
 class CircuitProverData:
@@ -111,7 +113,13 @@ class CircuitProverData:
         d.counts.n_public = len(prep.public_prep)
         d.counts.n_alu = len(prep.alu_prep13)
         d.counts.n_p2 = len(prep.p2_new_start)
-        d.counts.n_recompose = len(prep.recompose_prep)
+        rec_w = 2 + (2 * ctx.ext_degree if prep.recompose_coeff_lookups else 0)
+        rec = np.asarray(prep.recompose_prep)
+        if rec.size % rec_w:
+            raise P3rError(-1, "recompose_prep must be (n, %d)" % rec_w)
+        d.counts.n_recompose = rec.size // rec_w
+        d.recompose_coeff_lookups = 1 if prep.recompose_coeff_lookups else 0
+        self.recompose_coeff_lookups = bool(prep.recompose_coeff_lookups)
         d.public_lanes, d.alu_lanes = packing.public_lanes, packing.alu_lanes
         d.horner_packed_steps, d.recompose_lanes = packing.horner_packed_steps, packing.recompose_lanes
         d.min_trace_height = packing.min_trace_height
@@ -192,7 +200,7 @@ class ResidentTraces:
     def download(self, name: str) -> np.ndarray:
         """One array of the device-resident Traces, canonical (see TRACES_ARRAYS)."""
         which, table, width = TRACES_ARRAYS[name]
-        if table in ("const", "public", "alu"):
+        if table in ("const", "public", "alu", "recompose"):
             width = width // 4 * self.ctx.ext_degree
         out = np.empty((self.cpd.rows[table], width), dtype=np.uint32)
         self.ctx.check(self.ctx.lib.p3r_dtraces_get(self.ctx.h, self.cpd.h, self.h, which,
@@ -214,7 +222,8 @@ class ResidentTraces:
 def _traces_struct(tr: Traces, ext_degree=4):
     t = _lib.P3rTraces()
     keep = []
-    for name, w in (("const_values", ext_degree), ("public_values", ext_degree), ("alu_values", 4 * ext_degree)):
+    for name, w in (("const_values", ext_degree), ("public_values", ext_degree), ("alu_values", 4 * ext_degree),
+                    ("recompose_values", ext_degree)):
         a = np.asarray(getattr(tr, name))
         if a.ndim != 2 or a.shape[1] != w:
             raise P3rError(-1, "%s must have shape (n, %d) for ext_degree %d, got %r" % (name, w, ext_degree, a.shape))
@@ -321,8 +330,8 @@ class BatchStarkProof:
         for e in self.non_primitives:
             if e.op_type.startswith("poseidon2_perm/") and (self.ext_degree == 4 or e.op_type.endswith("_d1_w16")):
                 out.append(dict(kind=3, lanes=1))
-            elif e.op_type == "recompose":
-                out.append(dict(kind=4, lanes=e.lanes))
+            elif e.op_type in ("recompose", "recompose/coeff"):
+                out.append(dict(kind=4, lanes=e.lanes, coeff_lookups=1 if e.op_type == "recompose/coeff" else 0))
             else:
                 raise P3rError(-5, "MissingTableProver(%s)" % e.op_type)
         return out
@@ -347,7 +356,8 @@ class BatchStarkProof:
                                                air_variant=int(e.air_variant))
                         for e in m.non_primitives[:m.n_non_primitives])
         npo_lanes = {e.op_type.decode(): int(e.lanes) for e in m.npo_lanes[:m.n_npo_lanes]}
-        recompose_lanes = next((e.lanes for e in entries if e.op_type == "recompose"), npo_lanes.get("recompose", 1))
+        recompose_lanes = next((e.lanes for e in entries if e.op_type in ("recompose", "recompose/coeff")),
+                               npo_lanes.get("recompose", npo_lanes.get("recompose/coeff", 1)))
         commitment = None
         if m.has_stark_common:
             commitment = np.frombuffer(m, dtype=np.uint32, count=8 * m.cap_len,
@@ -466,8 +476,9 @@ class BatchStarkProver:
         p2_name = "poseidon2_perm/%s_%s_w16" % (ctx.field.replace("-", "_"), "d4" if ctx.ext_degree == 4 else "d1")
         k = tp.horner_packed_steps
         present = [h > 0 for h in cpd.table_heights]
+        coeff = getattr(cpd, "recompose_coeff_lookups", False)
         prep_widths = (2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24 if ctx.ext_degree == 4 else 62,
-                       2 * tp.recompose_lanes)
+                       (2 + (2 * ctx.ext_degree if coeff else 0)) * tp.recompose_lanes)
         # non-primitive tables without rows are not proved (poseidon2.rs:1089-1092, recompose.rs:77-80)
         npo = []
         if present[3]:
@@ -475,7 +486,9 @@ class BatchStarkProver:
             npo.append(NonPrimitiveTableEntry(op_type=p2_name, rows=cpd.table_heights[3], lanes=1))
         if present[4]:
             # RecomposeProver reports the op count (recompose.rs:125)
-            npo.append(NonPrimitiveTableEntry(op_type="recompose", rows=cpd.rows["recompose"], lanes=tp.recompose_lanes))
+            # circuit/src/ops/npo.rs:48-60: "recompose", or "recompose/coeff" for the per-coefficient variant
+            npo.append(NonPrimitiveTableEntry(op_type="recompose/coeff" if coeff else "recompose",
+                                              rows=cpd.rows["recompose"], lanes=tp.recompose_lanes))
         return BatchStarkProof(
             proof=raw, table_packing=tp,
             rows=(cpd.rows["const"], cpd.rows["public"], cpd.rows["alu"]),

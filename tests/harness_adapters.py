@@ -16,18 +16,19 @@ def traces_from_arrays(a, ext_degree=4) -> Traces:
         p2_merkle_path=fl[:, 1].astype(np.uint8),
         p2_mmcs_bit=fl[:, 2].astype(np.uint8),
         p2_mmcs_index_sum=a["p2_mmcs_index_sum"],
-        recompose_values=a["recompose_values"].reshape(-1, 4),
+        recompose_values=a["recompose_values"].reshape(-1, d),
     )
 
 
-def circuit_prep_from_arrays(a, ext_degree=4) -> CircuitPrep:
+def circuit_prep_from_arrays(a, ext_degree=4, recompose_coeff_lookups=False) -> CircuitPrep:
     fl = a["p2_flags"].reshape(-1, 4)
     il, ol = (4, 2) if ext_degree == 4 else (16, 8)
     return CircuitPrep(
         const_prep=a["const_prep"].reshape(-1, 2),
         public_prep=a["public_prep"].reshape(-1, 2),
         alu_prep13=a["alu_prep13"].reshape(-1, 13),
-        recompose_prep=a["recompose_prep"].reshape(-1, 2),
+        recompose_prep=a["recompose_prep"].reshape(-1, 2 + (2 * ext_degree if recompose_coeff_lookups else 0)),
+        recompose_coeff_lookups=recompose_coeff_lookups,
         p2_new_start=fl[:, 0].astype(np.uint8),
         p2_merkle_path=fl[:, 1].astype(np.uint8),
         p2_mmcs_ctl_enabled=fl[:, 3].astype(np.uint8),

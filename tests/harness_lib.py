@@ -26,13 +26,14 @@ def build():
     subprocess.run(["make", "-C", HDIR], check=True, capture_output=True)
 
 
-NO_POSEIDON2, NO_RECOMPOSE, SINGLE_PUBLIC, NO_ALU, INDEPENDENT_SPONGES = 1, 2, 4, 8, 16
+NO_POSEIDON2, NO_RECOMPOSE, SINGLE_PUBLIC, NO_ALU, INDEPENDENT_SPONGES, RECOMPOSE_COEFF = 1, 2, 4, 8, 16, 32
 
 
 def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None,
              flags=0, ext_degree=4):
     """Returns dict name -> np.uint32 array (see harness/synth.cpp).  ext_degree=5: KoalaBear circuits over the
-    quintic trinomial extension, primitive tables only (flags must hold NO_POSEIDON2 | NO_RECOMPOSE)."""
+    quintic trinomial extension (Poseidon2 rows are then the compact-D1 ones).  flags | RECOMPOSE_COEFF: the Recompose
+    table is the "recompose/coeff" variant (recompose_prep is n x (2 + 2 D))."""
     build()
     lib = C.CDLL(LIB)
     lib.syn_generate.restype = C.c_void_p

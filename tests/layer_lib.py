@@ -20,7 +20,7 @@ class OrcWorkload(C.Structure):
         ("n_recompose", C.c_size_t), ("recompose_values", u32p), ("recompose_prep", u32p),
         ("public_lanes", C.c_uint32), ("alu_lanes", C.c_uint32), ("horner_packed_steps", C.c_uint32),
         ("recompose_lanes", C.c_uint32), ("min_trace_height", C.c_uint32), ("ext_degree", C.c_uint32),
-        ("p2_absorb_len", u32p),
+        ("p2_absorb_len", u32p), ("recompose_coeff_lookups", C.c_uint32),
     ]
 
 
@@ -68,6 +68,7 @@ def fill_workload(wl_struct, arrays, packing, keep):
     wl_struct.recompose_lanes = packing.get("recompose_lanes", 1)
     wl_struct.min_trace_height = packing["min_trace_height"]
     wl_struct.ext_degree = packing.get("ext_degree", 4)   # 5: KoalaBear quintic circuits (compact-D1 Poseidon2 rows)
+    wl_struct.recompose_coeff_lookups = packing.get("recompose_coeff_lookups", 0)
     if "p2_absorb_len" in arrays and len(arrays["p2_absorb_len"]):
         wl_struct.p2_absorb_len = ptr("p2_absorb_len")
 

@@ -14,27 +14,30 @@ pytestmark = pytest.mark.gpu
 PRIMITIVE = harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE
 
 
-def setup(oracle, log_h, kw, packing=None, flags=PRIMITIVE, **gen):
+def setup(oracle, log_h, kw, packing=None, flags=PRIMITIVE, ext_degree=5, **gen):
     import plonky3_recursion_amd as p3r
     from plonky3_recursion_amd import prover as pv
     import harness_adapters as wl
     gen.setdefault("horner_chain_len", 20)
     gen.setdefault("sponge_chain_len", 3)
     gen.setdefault("merkle_depth", 5)
-    arrs = harness_lib.generate("koala-bear", log_h, seed=11 + log_h, flags=flags, ext_degree=5, **gen)
+    arrs = harness_lib.generate("koala-bear", log_h, seed=11 + log_h, flags=flags, ext_degree=ext_degree, **gen)
     prm = layer_lib.params(**kw)
     packing = packing or {}
-    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(packing, ext_degree=5))
+    coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm,
+                              packing=dict(packing, ext_degree=ext_degree, recompose_coeff_lookups=int(coeff)))
     ctx = p3r.Context(field="koala-bear", log_blowup=prm.log_blowup, max_log_arity=prm.max_log_arity,
                       cap_height=prm.cap_height, log_final_poly_len=prm.log_final_poly_len,
                       commit_pow_bits=prm.commit_pow_bits, query_pow_bits=prm.query_pow_bits,
-                      num_queries=prm.num_queries, ext_degree=5)
+                      num_queries=prm.num_queries, ext_degree=ext_degree)
     tp = pv.TablePacking(public_lanes=packing.get("public_lanes", 1), alu_lanes=packing.get("alu_lanes", 3),
-                         horner_packed_steps=packing.get("horner_packed_steps", 4))
+                         horner_packed_steps=packing.get("horner_packed_steps", 4),
+                         recompose_lanes=packing.get("recompose_lanes", 1))
     tp.with_fri_params(prm.log_final_poly_len, prm.log_blowup)
-    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=5), pv.FriRecursionBackend(),
-                                     pv.ProveNextLayerParams(table_packing=tp))
-    return arrs, L, ctx, cache, wl.traces_from_arrays(arrs, ext_degree=5)
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree, recompose_coeff_lookups=coeff),
+                                     pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
+    return arrs, L, ctx, cache, wl.traces_from_arrays(arrs, ext_degree=ext_degree)
 
 
 CASES = [
@@ -51,16 +54,19 @@ CASES = [
 
 
 WITH_P2 = harness_lib.NO_RECOMPOSE   # + the compact-D1 Poseidon2 table (KOALA_BEAR_D1_W16 on the 5-slot witness bus)
+BACKEND_D5 = harness_lib.RECOMPOSE_COEFF   # + Recompose with coefficient lookups: the D = 5 backend's mix (fri.rs:741-852)
+KINDS = {PRIMITIVE: [], WITH_P2: ["poseidon2"], BACKEND_D5: ["poseidon2", "recompose"], 0: ["poseidon2", "recompose"]}
+NPO_NAMES = {"poseidon2": "poseidon2_perm/koala_bear_d1_w16"}
 
 
-@pytest.mark.parametrize("flags", [PRIMITIVE, WITH_P2])
+@pytest.mark.parametrize("flags", [PRIMITIVE, WITH_P2, BACKEND_D5, 0])
 @pytest.mark.parametrize("log_h,kw,packing", CASES)
 def test_quintic_layer_matrices_commitment_and_proof(oracle, log_h, kw, packing, flags):
     from plonky3_recursion_amd import prover as pv
     arrs, L, ctx, cache, traces = setup(oracle, log_h, kw, packing, flags=flags)
     tables = L.tables()
     cpd = cache.circuit_prover_data
-    assert [t["kind"] for t in tables] == ["const", "public", "alu"] + (["poseidon2"] if flags == WITH_P2 else [])
+    assert [t["kind"] for t in tables] == ["const", "public", "alu"] + KINDS[flags]
     assert [h for h in cpd.table_heights if h] == [t["main"].shape[0] for t in tables]
     assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
     res = pv.ResidentTraces(ctx, cpd, traces)
@@ -79,7 +85,8 @@ def test_quintic_layer_matrices_commitment_and_proof(oracle, log_h, kw, packing,
     # the metadata the reference writes next to the proof (batch_stark_prover.rs:1597-1641)
     p = out.proof
     assert p.ext_degree == 5 and p.w_binomial is None and p.alu_quintic_trinomial
-    assert [e.op_type for e in p.non_primitives] == (["poseidon2_perm/koala_bear_d1_w16"] if flags == WITH_P2 else [])
+    rec_name = "recompose/coeff" if flags == BACKEND_D5 else "recompose"
+    assert [e.op_type for e in p.non_primitives] == [NPO_NAMES.get(k, rec_name) for k in KINDS[flags]]
     cache.prover.verify_all_tables(p)
     back = pv.BatchStarkProof.from_postcard(p.to_postcard(), "koala-bear")
     assert back.to_postcard() == p.to_postcard() and back.ext_degree == 5 and back.alu_quintic_trinomial
@@ -127,15 +134,11 @@ def test_what_a_quintic_context_refuses(oracle):
         p3r.Context(field="koala-bear", ext_degree=8)
     ctx = p3r.Context(field="koala-bear", log_final_poly_len=1, query_pow_bits=3, num_queries=4, ext_degree=5)
     tp = pv.TablePacking().with_fri_params(1, 2)
-    # a layer with Recompose rows is a D = 4 layer, and so are 4 x 2-limb Poseidon2 rows
+    # 4 x 2-limb Poseidon2 rows are a D = 4 layer's
     arrs4 = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
     prep4 = wl.circuit_prep_from_arrays(arrs4)
     with pytest.raises(p3r.P3rError, match="ext_degree 5"):
         pv.build_next_layer_prep(ctx, prep4, pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
-    arrs5r = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, flags=harness_lib.NO_POSEIDON2)
-    with pytest.raises(p3r.P3rError, match="UnsupportedDegree"):
-        pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs5r, ext_degree=5), pv.FriRecursionBackend(),
-                                 pv.ProveNextLayerParams(table_packing=tp))
     # the circuit boundary runs D = 4 circuits
     arrs5 = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, flags=PRIMITIVE, ext_degree=5)
     with pytest.raises(p3r.P3rError, match="UnsupportedDegree"):
@@ -158,18 +161,37 @@ def test_quintic_layer_at_2_16_rows_verifies(oracle):
     import harness_adapters as wl
     prm = layer_lib.params(query_pow_bits=8, num_queries=20)
     arrs = harness_lib.generate("koala-bear", 16, seed=5, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20,
-                                flags=WITH_P2, ext_degree=5)
+                                flags=BACKEND_D5, ext_degree=5)
     ctx = p3r.Context(field="koala-bear", query_pow_bits=8, num_queries=20, ext_degree=5)
     tp = pv.TablePacking().with_fri_params(prm.log_final_poly_len, prm.log_blowup)
-    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=5), pv.FriRecursionBackend(),
-                                     pv.ProveNextLayerParams(table_packing=tp))
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=5, recompose_coeff_lookups=True),
+                                     pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
     proof = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs, ext_degree=5), cache.circuit_prover_data)
     cache.prover.verify_all_tables(proof)
     airs = [dict(a, ext_degree=5) for a in proof.airs()]
+    assert [a["kind"] for a in airs] == [0, 1, 2, 3, 4] and airs[4]["coeff_lookups"] == 1
     layer_lib.oracle_verify_statement(oracle, "koala-bear", prm, airs, proof.preprocessed_commitment, proof.proof)
     bad = bytearray(proof.proof)
     bad[len(bad) // 2] ^= 4
     with pytest.raises(RuntimeError):
         layer_lib.oracle_verify_statement(oracle, "koala-bear", prm, airs, proof.preprocessed_commitment, bytes(bad))
     cache.circuit_prover_data.free()
+    ctx.close()
+
+
+def test_recompose_coeff_variant_under_degree_four(oracle):
+    """"recompose/coeff" is not tied to D = 5: a D = 4 backend registers it when its permutation is a D1 one
+    (backend/fri.rs:693-721).  Same bytes as the oracle, metadata names the variant, native verifier accepts."""
+    from plonky3_recursion_amd import prover as pv
+    kw = dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=5, num_queries=5)
+    arrs, L, ctx, cache, traces = setup(oracle, 8, kw, dict(recompose_lanes=2), flags=harness_lib.RECOMPOSE_COEFF,
+                                        ext_degree=4)
+    cpd = cache.circuit_prover_data
+    assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
+    proof = cache.prover.prove_all_tables(traces, cpd)
+    assert proof.proof == L.prove()
+    assert [e.op_type for e in proof.non_primitives] == ["poseidon2_perm/koala_bear_d4_w16", "recompose/coeff"]
+    assert proof.preprocessed_widths[-1] == 2 * (2 + 8)
+    cache.prover.verify_all_tables(pv.BatchStarkProof.from_postcard(proof.to_postcard(), "koala-bear"))
+    cpd.free()
     ctx.close()

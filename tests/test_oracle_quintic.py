@@ -108,8 +108,6 @@ def test_degree_four_rule_does_not_verify_a_quintic_layer(oracle):
 
 
 def test_refused_shapes(oracle):
-    with pytest.raises(RuntimeError, match="no Recompose table"):
-        harness_lib.generate("koala-bear", 5, ext_degree=5)
     with pytest.raises(RuntimeError, match="ext_degree"):
         harness_lib.generate("baby-bear", 5, flags=PRIMITIVE, ext_degree=5)
 
@@ -287,4 +285,54 @@ def test_compact_d1_poseidon2_rejects(oracle, what):
 
     arrs, L = layer_d1(oracle, 6, 21, prm, mutate=mutate)
     with pytest.raises(RuntimeError, match="constraints do not match|final polynomial|terminals do not sum"):
+        L.verify(L.prove())
+
+
+# ---------------------------------------------------------------- Recompose over D coefficients, "recompose/coeff"
+@pytest.mark.parametrize("ext_degree,coeff", [(5, 0), (5, 1), (4, 1)])
+def test_recompose_variants_roundtrip_and_native_verifier(oracle, ext_degree, coeff):
+    """The D = 5 backend's table mix (backend/fri.rs:741-852): Const / Public / ALU / compact-D1 Poseidon2 /
+    Recompose with coefficient lookups; and the coefficient variant under D = 4 (what a D = 4 circuit with a D1
+    permutation registers, fri.rs:693-721)."""
+    import plonky3_recursion_amd as p3r
+    prm = layer_lib.params(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=3, num_queries=5)
+    arrs = harness_lib.generate("koala-bear", 7, seed=31, flags=harness_lib.RECOMPOSE_COEFF if coeff else 0,
+                                ext_degree=ext_degree, **D1)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm,
+                              packing=dict(ext_degree=ext_degree, recompose_coeff_lookups=coeff, recompose_lanes=2))
+    tables = L.tables()
+    t = {x["kind"]: x for x in tables}
+    assert set(t) == {"const", "public", "alu", "poseidon2", "recompose"}
+    d = ext_degree
+    assert t["recompose"]["main"].shape[1] == 2 * d and t["recompose"]["prep"].shape[1] == 2 * (2 + (2 * d if coeff else 0))
+    if coeff:
+        assert arrs["recompose_prep"].reshape(-1, 2 + 2 * d)[:, 3::2].any()     # some coefficient multiplicities
+    pf = L.prove()
+    L.verify(pf)
+    cfg, keep = p3r.make_config("koala-bear", prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, ext_degree=ext_degree)
+    airs = [dict(kind=x["kind_id"], lanes=x["lanes"], horner_packed_steps=x["horner_k"],
+                 coeff_lookups=coeff if x["kind"] == "recompose" else 0) for x in tables]
+    db = [int(x["main"].shape[0]).bit_length() - 1 for x in tables]
+    p3r.verify_batch(cfg, airs, L.prep_commit(), db, pf)
+    for frac in (0.1, 0.5, 0.9):
+        bad = bytearray(pf)
+        bad[int(len(bad) * frac)] ^= 1
+        with pytest.raises(p3r.P3rError):
+            p3r.verify_batch(cfg, airs, L.prep_commit(), db, bytes(bad))
+    if coeff:
+        # without the coefficient tuples it is another statement
+        plain = [dict(a, coeff_lookups=0) for a in airs]
+        with pytest.raises(p3r.P3rError):
+            p3r.verify_batch(cfg, plain, L.prep_commit(), db, pf)
+
+
+def test_recompose_coeff_unbalanced_is_rejected(oracle):
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=4)
+    arrs = harness_lib.generate("koala-bear", 6, seed=33, flags=harness_lib.RECOMPOSE_COEFF, ext_degree=5, **D1)
+    rp = arrs["recompose_prep"].reshape(-1, 12)
+    r, i = next((r, i) for r in range(len(rp)) for i in range(5) if rp[r, 3 + 2 * i])
+    rp[r, 3 + 2 * i] += 1
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(ext_degree=5, recompose_coeff_lookups=1))
+    with pytest.raises(RuntimeError, match="terminals do not sum"):
         L.verify(L.prove())
