@@ -513,6 +513,8 @@ def main():
     ap.add_argument("--spans", action="store_true",
                     help="print the per-stage timers as tracing-forest spans under the reference's span names (stderr)")
     ap.add_argument("--no-small-layers", action="store_true", help="skip the 2^14/2^15/2^16-row layers")
+    ap.add_argument("--no-quintic", action="store_true",
+                    help="skip the D = 5 layer (KoalaBear quintic circuits: ALU, compact-D1 Poseidon2, recompose/coeff)")
     ap.add_argument("--no-config2", action="store_true",
                     help="skip the secondary measurement with BASELINE config 2's chain-length knobs")
     ap.add_argument("--trees", type=int, default=1,
@@ -851,6 +853,53 @@ def main():
             res2.free()
             pc2.free()
             resident = pc = None
+        if not args.no_quintic and world == 1 and field == "koala-bear":
+            # SURVEY 8(f).4, D = 5: the table mix FriRecursionBackendD5 registers (backend/fri.rs:741-852) - Const, Public,
+            # ALU over the quintic trinomial extension, compact-D1 Poseidon2, Recompose with coefficient lookups - at the
+            # prove_all_tables boundary with Traces resident in HBM, same height, same FRI parameters, proof verified.
+            if resident is not None:
+                resident.free()
+                pc.free()
+                resident = pc = None
+            ctx5 = p3r.Context(field=field, ext_degree=5, **FRI)
+            arrs5 = harness_lib.generate(field, log_h, seed=0x5EED0005, flags=harness_lib.RECOMPOSE_COEFF, ext_degree=5, **GEN_KNOBS)
+            counts5 = [int(x) for x in arrs5["counts"]]
+            cache5 = p3r.build_next_layer_prep(ctx5, wl.circuit_prep_from_arrays(arrs5, ext_degree=5, recompose_coeff_lookups=True),
+                                               p3r.FriRecursionBackend(), p3r.ProveNextLayerParams(table_packing=packing))
+            cpd5 = cache5.circuit_prover_data
+            res5 = p3r.ResidentTraces(ctx5, cpd5, wl.traces_from_arrays(arrs5, ext_degree=5))
+            del arrs5
+            proof5 = cache5.prover.prove_all_tables(res5, cpd5)
+            ctx5.sync()
+            t5 = time.perf_counter()
+            for _ in range(3):
+                cache5.prover.prove_all_tables(res5, cpd5)
+            ctx5.sync()
+            ms5 = (time.perf_counter() - t5) / 3 * 1e3
+            try:
+                cache5.prover.verify_all_tables(proof5)
+                ok5 = True
+            except Exception as e:
+                print(f"bench: D = 5 layer: proof rejected: {e}", file=sys.stderr)
+                ok5 = False
+            ctx5.profile_enable(True)
+            cache5.prover.prove_all_tables(res5, cpd5)
+            prof5 = ctx5.profile_read()
+            ctx5.profile_enable(False)
+            line["quintic_backend_layer"] = {
+                "ms_per_step": ms5, "steps": 3, "proof_verified": ok5, "proof_bytes": len(proof5.proof),
+                "ext_degree": 5, "tables": [e.op_type for e in proof5.non_primitives],
+                "table_heights": cpd5.table_heights,
+                "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose"], counts5)),
+                "kernel_ms": {k: v[0] for k, v in prof5.items() if not k.startswith("stage:")},
+                "workload": f"prove_all_tables (Traces resident in HBM) of the synthetic {field} 2^{log_h}-row D = 5 layer: "
+                            f"const / public / alu over F[x]/(x^5 + x^2 - 1) / compact-D1 poseidon2 / recompose with "
+                            f"coefficient lookups, the D = 4 STARK configuration, same FRI parameters"}
+            proof_verified = proof_verified and ok5
+            line["proof_verified"] = proof_verified
+            res5.free()
+            cpd5.free()
+            ctx5.close()
         print(json.dumps(line))
     if resident is not None:
         resident.free()
