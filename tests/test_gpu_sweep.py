@@ -1,6 +1,6 @@
 """GPU: a slice of tools/prove_sweep.py in the suite - random layer sizes, table packings, FRI
 parameters, cap heights, proof-of-work bits, folding schedules (fitting and blind), proof layouts and
-the LogUp packing switch, both fields.  Per draw: preprocessed commitment and proof bytes equal the
+the LogUp packing switch, both fields, D = 4 and D = 5 circuits with their table variants.  Per draw: preprocessed commitment and proof bytes equal the
 oracle's and both verifiers accept - or both sides refuse the configuration."""
 import importlib.util
 import os

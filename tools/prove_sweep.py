@@ -76,12 +76,25 @@ def fitting_schedule(rng, oracle, field, arrs, kw, packing):
 def one(oracle, seed, max_log_h, min_log_h=5):
     rng = random.Random(seed)
     field, log_h, kw, packing, gen = draw(rng, max_log_h, min_log_h)
-    arrs = harness_lib.generate(field, log_h, seed=seed, **gen)
+    # circuit extension degree and table variants, from a second stream so that the draws above keep their seeds:
+    # D = 5 (KoalaBear quintic circuits: primitive tables, + compact-D1 Poseidon2, + Recompose, + recompose/coeff) in
+    # a third of the KoalaBear draws; recompose/coeff under D = 4 now and then
+    rng2 = random.Random(seed * 7919 + 1)
+    ext_degree, flags = 4, 0
+    if field == "koala-bear" and rng2.random() < 0.33:
+        ext_degree = 5
+        flags = rng2.choice([harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE, harness_lib.NO_RECOMPOSE, 0,
+                             harness_lib.RECOMPOSE_COEFF])
+    elif rng2.random() < 0.15:
+        flags = harness_lib.RECOMPOSE_COEFF
+    coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
+    arrs = harness_lib.generate(field, log_h, seed=seed, flags=flags, ext_degree=ext_degree, **gen)
+    packing_o = dict(packing, ext_degree=ext_degree, recompose_coeff_lookups=int(coeff))
     if kw.get("fri_log_arities") == "fitting":
-        kw["fri_log_arities"] = fitting_schedule(rng, oracle, field, arrs, kw, packing)
+        kw["fri_log_arities"] = fitting_schedule(rng, oracle, field, arrs, kw, packing_o)
     prm = layer_lib.params(**kw)
-    desc = f"seed {seed}: {field} 2^{log_h} {kw} {packing} {gen}"
-    L = layer_lib.OracleLayer(oracle, field, arrs, prm, packing=dict(packing))
+    desc = f"seed {seed}: {field} D={ext_degree} flags={flags} 2^{log_h} {kw} {packing} {gen}"
+    L = layer_lib.OracleLayer(oracle, field, arrs, prm, packing=dict(packing_o))
     try:
         want_cap, want = L.prep_commit(), L.prove()
     except RuntimeError as e:       # a configuration the protocol has no proof for: the prover must refuse it too
@@ -90,11 +103,11 @@ def one(oracle, seed, max_log_h, min_log_h=5):
     tp.with_fri_params(prm.log_final_poly_len, prm.log_blowup)
     ctx = None
     try:
-        ctx = p3r.Context(field=field, **kw)
-        cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), pv.FriRecursionBackend(),
-                                         pv.ProveNextLayerParams(table_packing=tp))
+        ctx = p3r.Context(field=field, ext_degree=ext_degree, **kw)
+        cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree, recompose_coeff_lookups=coeff),
+                                         pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
         cpd = cache.circuit_prover_data
-        out = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs), cpd)
+        out = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs, ext_degree=ext_degree), cpd)
     except p3r.P3rError as e:
         assert want_cap is None, "prover refused (%s) what the oracle proves: %s" % (e, desc)
         if ctx is not None:
