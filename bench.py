@@ -657,18 +657,27 @@ def main():
     # prep-cache miss (recursion.rs:452-501, prep=None): preprocessed columns + LDE + commitment are
     # rebuilt from the circuit before the proof; once, on rank 0 at N = 1
     prep_miss_ms = None
+    prep_miss_runs = None
     prep_breakdown = None
     small = {}
     if rank == 0 and world == 1:
         circ = wl.circuit_from_arrays(arrs)
         hin = wl.circuit_inputs_from_arrays(arrs)
-        ctx.sync()
-        m0 = time.perf_counter()
-        cache2 = p3r.build_next_layer_prep(ctx, circ, p3r.FriRecursionBackend(),
-                                           p3r.ProveNextLayerParams(table_packing=packing))
-        miss_proof = cache2.prepared_circuit.prove(hin)
-        ctx.sync()
-        prep_miss_ms = (time.perf_counter() - m0) * 1e3
+        # two complete misses (nothing of the first survives into the second but the allocator's pool); the line
+        # carries both and quotes the smaller: a single sample is exposed to whatever else the host does in those 50 ms
+        prep_miss_runs = []
+        cache2 = None
+        for _ in range(2):
+            if cache2 is not None:
+                cache2.prepared_circuit.free()
+            ctx.sync()
+            m0 = time.perf_counter()
+            cache2 = p3r.build_next_layer_prep(ctx, circ, p3r.FriRecursionBackend(),
+                                               p3r.ProveNextLayerParams(table_packing=packing))
+            miss_proof = cache2.prepared_circuit.prove(hin)
+            ctx.sync()
+            prep_miss_runs.append((time.perf_counter() - m0) * 1e3)
+        prep_miss_ms = min(prep_miss_runs)
         # where the preparation spends it (a second, bracketed build; not part of prep_miss_ms)
         ctx.profile_enable(True)
         cache3 = p3r.build_next_layer_prep(ctx, circ, p3r.FriRecursionBackend(),
@@ -732,6 +741,7 @@ def main():
             "proof_verify_ms": verify_ms,
             "value_incl_h2d_ms": incl_h2d_ms,
             "prep_miss_ms": prep_miss_ms,
+            "prep_miss_ms_runs": prep_miss_runs,
             "prep_miss_breakdown_ms": prep_breakdown,
             "small_layers": small or None,
             "small_layer_throughput": small_tput,
