@@ -79,6 +79,22 @@ struct Fp4 {
   }
 };
 
+// The base field as a "degree-1 extension": the element type of base-field circuits (CircuitBuilder<F>).
+template <class PP>
+struct Fp1 {
+  using F = Fp<PP>;
+  static constexpr int DEG = 1;
+  F c[1];
+  static Fp1 zero() { return Fp1(); }
+  static Fp1 one() { Fp1 r; r.c[0] = F::one(); return r; }
+  static Fp1 from_base(F b) { Fp1 r; r.c[0] = b; return r; }
+  friend Fp1 operator+(Fp1 a, const Fp1& b) { a.c[0] = a.c[0] + b.c[0]; return a; }
+  friend Fp1 operator-(Fp1 a, const Fp1& b) { a.c[0] = a.c[0] - b.c[0]; return a; }
+  friend Fp1 operator*(const Fp1& a, const Fp1& b) { Fp1 r; r.c[0] = a.c[0] * b.c[0]; return r; }
+  bool operator==(const Fp1& o) const { return c[0] == o.c[0]; }
+  Fp1 inv() const { Fp1 r; r.c[0] = c[0].inv(); return r; }
+};
+
 // The degree-5 extension F[x] / (x^5 + x^2 - 1) of KoalaBear (QuinticTrinomialExtensionField; the circuit
 // field of the reference's D = 5 unit tests, circuit-prover/src/batch_stark_prover.rs tests.rs:844-1029 and
 // air/alu_air.rs:735-760): schoolbook product of degree 8, then x^5 = 1 - x^2 applied from the top.

@@ -610,7 +610,8 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
 
 extern "C" {
 
-// flags bits 8..11: circuit extension degree (0 = 4).  5 = the KoalaBear quintic trinomial extension.
+// flags bits 8..11: circuit extension degree (0 = 4).  5 = the KoalaBear quintic trinomial extension, 1 = base-field
+// circuits (Poseidon2 rows are the compact-D1 ones in both).
 void* syn_generate(int field, int log_h, uint64_t seed, int horner_chain_len, int sponge_chain_len,
                    int merkle_depth, const uint32_t* rc_canonical, uint32_t flags) {
   auto* W = new Workload();
@@ -618,7 +619,9 @@ void* syn_generate(int field, int log_h, uint64_t seed, int horner_chain_len, in
   flags &= 0xFFu;
   try {
     if (ext_degree == 5 && field == 0) generate<KoalaBearParams, Fp5<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
-    else if (ext_degree != 4) throw std::runtime_error("ext_degree must be 4, or 5 over KoalaBear");
+    else if (ext_degree == 1 && field == 0) generate<KoalaBearParams, Fp1<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (ext_degree == 1 && field == 1) generate<BabyBearParams, Fp1<BabyBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (ext_degree != 4) throw std::runtime_error("ext_degree must be 1, 4, or 5 over KoalaBear");
     else if (field == 0) generate<KoalaBearParams, Fp4<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else if (field == 1) generate<BabyBearParams, Fp4<BabyBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else throw std::runtime_error("unknown field");

@@ -60,13 +60,15 @@ enum { P3R_FIELD_KOALA_BEAR = 0, P3R_FIELD_BABY_BEAR = 1 };
 typedef struct p3r_config {
   uint32_t abi_version;        /* P3R_ABI_VERSION */
   uint32_t field;              /* P3R_FIELD_* */
-  uint32_t ext_degree;         /* circuit extension degree D of the traces: 4 (binomial x^4 = W), or 5 over KoalaBear
+  uint32_t ext_degree;         /* circuit extension degree D of the traces: 1 (base-field circuits, CircuitBuilder<F>: the
+                                * base proof of recursive_fibonacci.rs:315-331; bus tuples (idx, v)), 4 (binomial
+                                * x^4 = W), or 5 over KoalaBear
                                 * (quintic trinomial x^5 + x^2 - 1: QuinticTrinomialExtensionField, proved under the
                                 * same D = 4 STARK configuration as in circuit-prover/src/batch_stark_prover/
-                                * tests.rs:844-1029).  D = 5 covers the primitive tables (Const, Public, ALU) at the
-                                * prove_all_tables boundary: values are n x 5 / n x 20, witness indices in the
-                                * preprocessed columns are scaled by 5; p3r_circuit_create and layers with Poseidon2
-                                * or Recompose rows return P3R_EUNSUPPORTED. */
+                                * tests.rs:844-1029).  D = 1 and D = 5 layers enter at the prove_all_tables boundary:
+                                * values are n x D / n x 4D, witness indices in the preprocessed columns are scaled
+                                * by D, the Poseidon2 table is the compact-D1 one (p3r_layer_desc); p3r_circuit_create
+                                * runs D = 4 circuits and returns P3R_EUNSUPPORTED otherwise. */
   uint32_t log_blowup;
   uint32_t max_log_arity;
   uint32_t cap_height;

@@ -15,7 +15,7 @@
 namespace orc {
 
 enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4 };
-// Circuit extension degree: 4 (binomial x^4 = W) or 5 (KoalaBear quintic trinomial x^5 + x^2 - 1,
+// Circuit extension degree: 1 (base-field circuits), 4 (binomial x^4 = W) or 5 (KoalaBear quintic trinomial x^5 + x^2 - 1,
 // alu_air.rs:115-134; its Poseidon2 table is the compact-D1 width-16 one, eval_poseidon2_d1 below; Recompose is D = 4 only).
 // The STARK's own challenge field stays the degree-4 binomial extension, as in the reference's D = 5 unit tests
 // (batch_stark_prover/tests.rs:844-1029: QuinticTrinomialExtensionField traces under config::koala_bear()).

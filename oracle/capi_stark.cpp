@@ -113,7 +113,8 @@ struct Layer : LayerBase {
   void build(const orc_workload& w) {
     const size_t mh = w.min_trace_height;
     const int D = w.ext_degree ? (int)w.ext_degree : 4;
-    if (D != 4 && D != 5) throw std::runtime_error("UnsupportedDegree");
+    // 1 = base-field circuits (the base proof of recursive_fibonacci: CircuitBuilder<F>, tests.rs:433), 4, 5
+    if (D != 1 && D != 4 && D != 5) throw std::runtime_error("UnsupportedDegree");
     if (D == 5 && FP::P != KoalaBear::P) throw std::runtime_error("D = 5 is KoalaBear's quintic extension");
     const int public_lanes = w.n_public <= 1 ? 1 : (int)w.public_lanes;
     const int alu_lanes = w.n_alu <= 1 ? 1 : (int)w.alu_lanes;

@@ -33,8 +33,9 @@ struct AirParams {
   int horner_k;
   int coeff_lookups;
   int lookup_unpacked = 0;  // p3r_config.ext_choices & P3R_EXT_LOOKUP_UNPACKED
-  // Circuit extension degree D of the table's witness values (p3r_config.ext_degree): 4 = binomial x^4 = W,
-  // 5 = KoalaBear quintic trinomial x^5 + x^2 - 1 (primitive tables only).  Bus tuples are (idx, v_0..v_{D-1}).
+  // Circuit extension degree D of the table's witness values (p3r_config.ext_degree): 1 = base-field circuits,
+  // 4 = binomial x^4 = W, 5 = KoalaBear quintic trinomial x^5 + x^2 - 1.  Bus tuples are (idx, v_0..v_{D-1}); the
+  // Poseidon2 table is the D4 width-16 one for D = 4 and the compact-D1 one (on a D-slot bus) otherwise.
   int ext_d = 4;
 };
 
@@ -74,14 +75,16 @@ P3R_HD V4<V> load4(G&& get, int col) { return loadD<4, V>(get, col); }
 template <class PP, int D, class V>
 P3R_HD VD<V, D> mulD(const VD<V, D>& a, const VD<V, D>& b) {
   VD<V, D> r;
-  if constexpr (D == 4) {
+  if constexpr (D == 1) {
+    r.c[0] = a.c[0] * b.c[0];   // base-field circuits
+  } else if constexpr (D == 4) {
     const V W = Lift<V>::of(Fp<PP>::from_canonical(PP::EXT_W));
     r.c[0] = a.c[0] * b.c[0] + W * (a.c[1] * b.c[3] + a.c[2] * b.c[2] + a.c[3] * b.c[1]);
     r.c[1] = a.c[0] * b.c[1] + a.c[1] * b.c[0] + W * (a.c[2] * b.c[3] + a.c[3] * b.c[2]);
     r.c[2] = a.c[0] * b.c[2] + a.c[1] * b.c[1] + a.c[2] * b.c[0] + W * (a.c[3] * b.c[3]);
     r.c[3] = a.c[0] * b.c[3] + a.c[1] * b.c[2] + a.c[2] * b.c[1] + a.c[3] * b.c[0];
   } else {
-    static_assert(D == 5, "circuit extension degree must be 4 or 5");
+    static_assert(D == 5, "circuit extension degree must be 1, 4 or 5");
     const V c5 = a.c[1] * b.c[4] + a.c[2] * b.c[3] + a.c[3] * b.c[2] + a.c[4] * b.c[1];
     const V c6 = a.c[2] * b.c[4] + a.c[3] * b.c[3] + a.c[4] * b.c[2];
     const V c7 = a.c[3] * b.c[4] + a.c[4] * b.c[3];

@@ -11,6 +11,7 @@
 // Device representation: Montgomery form x*2^32 mod P held in a u32 in [0, P).
 // Everything that crosses the C ABI is canonical (see include/p3r.h).
 #pragma once
+#include <type_traits>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -300,6 +301,24 @@ struct Fp4 {
 // operations; the STARK's challenge field stays Fp4.
 template <class PP>
 inline constexpr bool kHasQuintic = PP::P == 0x7f000001u;
+// The base field as the element type of base-field circuits (D = 1: CircuitBuilder<F>).
+template <class PP>
+struct Fp1 {
+  using F = Fp<PP>;
+  F c[1];
+  static P3R_HD Fp1 zero() { Fp1 r; r.c[0] = F::zero(); return r; }
+  friend P3R_HD Fp1 operator+(Fp1 a, Fp1 b) { Fp1 r; r.c[0] = a.c[0] + b.c[0]; return r; }
+  friend P3R_HD Fp1 operator-(Fp1 a, Fp1 b) { Fp1 r; r.c[0] = a.c[0] - b.c[0]; return r; }
+  friend P3R_HD Fp1 operator*(Fp1 a, Fp1 b) { Fp1 r; r.c[0] = a.c[0] * b.c[0]; return r; }
+};
+// Calls fn(std::integral_constant<int, D>) for the circuit extension degree d of a context: 1, 4, or 5 (KoalaBear).
+template <class PP, class Fn>
+inline void dispatch_ext_degree(int d, Fn&& fn) {
+  if (d == 1) fn(std::integral_constant<int, 1>{});
+  else if (d == 5) { if constexpr (kHasQuintic<PP>) fn(std::integral_constant<int, 5>{}); }
+  else fn(std::integral_constant<int, 4>{});
+}
+
 template <class PP>
 struct Fp5 {
   using F = Fp<PP>;
@@ -324,6 +343,12 @@ struct Fp5 {
     return r;
   }
 };
+
+// element type of a circuit of extension degree D
+template <class PP, int D> struct CircuitExt;
+template <class PP> struct CircuitExt<PP, 1> { using type = Fp1<PP>; };
+template <class PP> struct CircuitExt<PP, 4> { using type = Fp4<PP>; };
+template <class PP> struct CircuitExt<PP, 5> { using type = Fp5<PP>; };
 
 // Embedding of a base-field constant into the value type a generic routine computes in
 // (the base field itself for the prover's kernels, the extension for evaluations at zeta).

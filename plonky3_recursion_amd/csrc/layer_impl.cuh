@@ -457,14 +457,11 @@ std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r
     P3R_HIP(hipMemsetAsync(m[2]->d, 0, L->h_alu * (size_t)width * 4, ctx->stream));
     ProfScope ps(ctx, "alu_trace");
     const auto* plan = reinterpret_cast<const AluPlanEntry*>(L->alu_plan.p);
-    if (D == 5) {
-      if constexpr (kHasQuintic<PP>)
-        hipLaunchKernelGGL((k_alu_trace<PP, Fp5<PP>, 5>), dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream, plan,
-                           L->alu_prev_src.p, t->alu_values.p, L->alu_rows, L->h_alu, lanes, k, m[2]->d);
-    } else {
-      hipLaunchKernelGGL((k_alu_trace<PP, Fp4<PP>, 4>), dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream, plan,
+    dispatch_ext_degree<PP>(D, [&](auto dc) {
+      using E = typename CircuitExt<PP, decltype(dc)::value>::type;
+      hipLaunchKernelGGL((k_alu_trace<PP, E, decltype(dc)::value>), dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream, plan,
                          L->alu_prev_src.p, t->alu_values.p, L->alu_rows, L->h_alu, lanes, k, m[2]->d);
-    }
+    });
   }
   if (L->has_p2) m[3] = trace_fill<PP>(ctx, t->p2.get());
   if (L->has_recompose)

@@ -615,14 +615,12 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     ZetaView<PP> v{in.main_local, in.main_next ? in.main_next : &none, in.prep_local, in.prep_next};
     ZetaFold<PP> fold;
     fold.alpha = alpha;
-    const bool quintic = air.ext_d == 5;
-    if (air.ext_d != 4 && !(quintic && kHasQuintic<PP> && air.kind <= AIR_RECOMPOSE))
+    if (!(air.ext_d == 1 || air.ext_d == 4 || (air.ext_d == 5 && kHasQuintic<PP>)))
       vfail("instance %zu: no AIR of kind %d for circuit extension degree %d", i, air.kind, air.ext_d);
     if (air.kind == AIR_ALU) {
-      if (quintic) alu_constraints<PP, 5>(air, v, fold);
-      else alu_constraints<PP>(air, v, fold);
+      dispatch_ext_degree<PP>(air.ext_d, [&](auto dc) { alu_constraints<PP, decltype(dc)::value>(air, v, fold); });
     } else if (air.kind == AIR_POSEIDON2) {
-      if (quintic) poseidon2_d1_constraints<PP>(v, is_transition, rc_mont, fold);
+      if (air.ext_d != 4) poseidon2_d1_constraints<PP>(v, is_transition, rc_mont, fold);
       else poseidon2_constraints<PP>(v, is_transition, rc_mont, fold);
     }
     if (fold.count != air_num_base_constraints<PP>(air)) vfail("instance %zu: constraint count mismatch", i);
@@ -642,8 +640,7 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
       ZetaLookupSink<PP> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4],
                                          l_beta_pow[5]},
                               aux_l, fold, L.pair};
-      if (quintic) air_interactions<PP, 5>(air, v, sink);
-      else air_interactions<PP>(air, v, sink);
+      dispatch_ext_degree<PP>(air.ext_d, [&](auto dc) { air_interactions<PP, decltype(dc)::value>(air, v, sink); });
       sink.finish();
       if (sink.cnt != L.n_interactions) vfail("instance %zu: interaction count mismatch", i);
       const E s = aux_l[0], s_next = aux_n[0], terminal = *in.terminal;
@@ -757,7 +754,7 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
     E bp = E::one();
     // gamma = beta^W, W = the widest bus tuple = 1 + circuit extension degree (get_perm_challenges,
     // recursion/src/verifier/batch_stark.rs:1086-1100)
-    int tuple_w = 5;
+    int tuple_w = 2;
     for (auto& a : airs) tuple_w = std::max(tuple_w, std::min(a.ext_d, kMaxExtD) + 1);
     for (int j = 0; j < tuple_w; ++j) { l_beta_pow[j] = bp; bp *= beta_l; }
     l_prefix = alpha_l + bp;

@@ -432,7 +432,7 @@ def verify_all_tables(cfg, proof: BatchStarkProof, canonical_field_encoding=None
     field = field or {0: "koala-bear", 1: "baby-bear"}[int(cfg.field)]
     # EF = BinomialExtensionField<F, 4>: W = the field's; EF = QuinticTrinomialExtensionField<F>: no binomial W
     # and the trinomial reduction flag (field_params.rs:54-66)
-    want_w = W_BINOMIAL[field] if want_d == 4 else None
+    want_w = W_BINOMIAL[field] if want_d == 4 else None    # D = 1: the base field has no W either
     if proof.w_binomial != want_w:
         raise P3rError(-1, "BinomialWMismatch: proof has W = %r, the verifier expects %r" % (proof.w_binomial, want_w))
     if bool(proof.alu_quintic_trinomial) != (want_d == 5):
@@ -473,7 +473,7 @@ class BatchStarkProver:
         ctx = self.ctx
         tp = cpd.effective_packing
         # circuit/src/ops/npo.rs:38, poseidon2_perm/config.rs:413-427: the D4 table, or the compact-D1 one of a D = 5 circuit
-        p2_name = "poseidon2_perm/%s_%s_w16" % (ctx.field.replace("-", "_"), "d4" if ctx.ext_degree == 4 else "d1")
+        p2_name = "poseidon2_perm/%s_%s_w16" % (ctx.field.replace("-", "_"), "d4" if ctx.ext_degree == 4 else "d1")   # D = 1, 5: D1
         k = tp.horner_packed_steps
         present = [h > 0 for h in cpd.table_heights]
         coeff = getattr(cpd, "recompose_coeff_lookups", False)

@@ -11,7 +11,7 @@ import oracle_lib
 
 FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15,
            num_queries=54)   # recursive_fibonacci.rs:71-147
-PACKING = dict(public_lanes=1, alu_lanes=1)
+PACKING = dict(public_lanes=1, alu_lanes=1, horner_packed_steps=2)   # TablePacking::new(1, 1): K keeps its default 2
 
 
 def oracle_run(oracle, field, n=1000):
@@ -56,7 +56,7 @@ def test_fibonacci_base_circuit_on_device(oracle, field):
     circuit, inputs, fib, oc = oracle_run(oracle, field)
     w = oc.workload_arrays()
     ctx = p3r.Context(field=field, **FRI)
-    tp = p3r.TablePacking(public_lanes=1, alu_lanes=1).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    tp = p3r.TablePacking(public_lanes=1, alu_lanes=1, horner_packed_steps=2).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
     pcirc = p3r.Circuit(circuit.witness_count, circuit.ops, circuit.ext, circuit.public_rows)
     cache = p3r.build_next_layer_prep(ctx, pcirc, p3r.FriRecursionBackend(), p3r.ProveNextLayerParams(table_packing=tp))
     pc = cache.prepared_circuit

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 (cd tools/microbench && ./int_rates > ../../gpurun_out/final/int_rates.txt 2>&1; ./perm_f64 > ../../gpurun_out/final/perm_f64.txt 2>&1)
 timeout 1200 python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench_err.log
-ARGS="bench.py --no-cpu-baseline --no-config2 --no-small-layers"
+ARGS="bench.py --no-cpu-baseline --no-config2 --no-small-layers --no-quintic"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 $ARGS > gpurun_out/final/stats_run.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/final/pmc_$C -- python3 $ARGS --steps 1 --warmup 0 > gpurun_out/final/pmc_$C.log 2>&1
@@ -20,11 +20,11 @@ find gpurun_out/final -name "*kernel_trace.csv" -delete
 find gpurun_out/final -name "*agent_info.csv" -delete
 du -sh gpurun_out/final
 # BASELINE config 5 (BabyBear, 2^22 rows) and config 4 (aggregation tree on one GPU): builder-run lines
-timeout 900 python bench.py --field baby-bear --log-height 22 --steps 3 --no-cpu-baseline --no-config2 --no-small-layers > gpurun_out/final/bench_line_babybear_2p22.json 2> gpurun_out/final/bench_babybear_err.log
+timeout 900 python bench.py --field baby-bear --log-height 22 --steps 3 --no-cpu-baseline --no-config2 --no-small-layers --no-quintic > gpurun_out/final/bench_line_babybear_2p22.json 2> gpurun_out/final/bench_babybear_err.log
 timeout 600 python bench.py --tree --steps 3 --warmup 1 > gpurun_out/final/bench_line_tree_1gpu.json 2> gpurun_out/final/bench_tree_err.log
 timeout 600 python bench.py --tree --tree-workers 4 --steps 3 --warmup 1 > gpurun_out/final/bench_line_tree_1gpu_4workers.json 2>> gpurun_out/final/bench_tree_err.log
 timeout 600 python bench.py --tree --tree-workers 4 --trees 4 --steps 3 --warmup 1 > gpurun_out/final/bench_line_forest_1gpu_4trees.json 2>> gpurun_out/final/bench_tree_err.log
 # the plain multi-rank entry (the parent spawns the ranks; two ranks share the box's one GPU over gloo)
-P3R_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 3 --no-cpu-baseline --no-config2 --no-small-layers > gpurun_out/final/bench_line_2ranks_gloo.json 2> gpurun_out/final/bench_2ranks_err.log
+P3R_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 3 --no-cpu-baseline --no-config2 --no-small-layers --no-quintic > gpurun_out/final/bench_line_2ranks_gloo.json 2> gpurun_out/final/bench_2ranks_err.log
 P3R_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --tree --trees 0 --tree-workers 2 --steps 3 > gpurun_out/final/bench_line_forest_2ranks_gloo.json 2>> gpurun_out/final/bench_2ranks_err.log
-timeout 300 python bench.py --steps 3 --no-cpu-baseline --no-config2 --no-small-layers --spans > /dev/null 2> gpurun_out/final/spans.txt
+timeout 300 python bench.py --steps 3 --no-cpu-baseline --no-config2 --no-small-layers --no-quintic --spans > /dev/null 2> gpurun_out/final/spans.txt

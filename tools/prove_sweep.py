@@ -85,6 +85,11 @@ def one(oracle, seed, max_log_h, min_log_h=5):
         ext_degree = 5
         flags = rng2.choice([harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE, harness_lib.NO_RECOMPOSE, 0,
                              harness_lib.RECOMPOSE_COEFF])
+    elif rng2.random() < 0.25:
+        # base-field circuits (D = 1, both fields), the same table variants
+        ext_degree = 1
+        flags = rng2.choice([harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE, harness_lib.NO_RECOMPOSE, 0,
+                             harness_lib.RECOMPOSE_COEFF])
     elif rng2.random() < 0.15:
         flags = harness_lib.RECOMPOSE_COEFF
     coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
