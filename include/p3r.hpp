@@ -328,7 +328,8 @@ inline void verify_all_tables(const p3r_config& cfg, const BatchStarkProof& proo
   // EF = BinomialExtensionField<F, 4>: the field's W; EF = QuinticTrinomialExtensionField<F>: no W, the trinomial flag
   const bool quintic = cfg.ext_degree == 5;
   const uint32_t want_w = cfg.field == P3R_FIELD_KOALA_BEAR ? 3u : 11u;
-  if (quintic ? proof.w_binomial.has_value() : (!proof.w_binomial || *proof.w_binomial != want_w))
+  const bool has_w = cfg.ext_degree == 4;   // D = 1 (the base field) and the quintic trinomial extension have none
+  if (has_w ? (!proof.w_binomial || *proof.w_binomial != want_w) : proof.w_binomial.has_value())
     throw Error(P3R_EINVAL, "BinomialWMismatch");
   if (proof.alu_quintic_trinomial != quintic) throw Error(P3R_EINVAL, "QuinticReductionMismatch");
   auto airs = proof.airs();
