@@ -76,7 +76,9 @@ def _fib_layer(oracle, field, key):
     oc = cl.OracleCircuit(oracle, circuit).preprocess(oracle_lib.MODULUS[field])
     oc.run(field, inputs)
     prm = layer_lib.params(**g["fri"])
-    L = layer_lib.OracleLayer(oracle, field, oc.workload_arrays(), prm, packing=dict(g["packing"]), rc=rc)
+    packing = dict(g["packing"])
+    packing.setdefault("horner_packed_steps", 2)      # TablePacking::new(1, 1) keeps K = 2 (packing.rs:36-47)
+    L = layer_lib.OracleLayer(oracle, field, oc.workload_arrays(), prm, packing=packing, rc=rc)
     return g, rc, circuit, inputs, prm, L
 
 
@@ -107,7 +109,8 @@ def test_hip_prover_reproduces_the_rust_proof(oracle, field, key):
     import plonky3_recursion_amd as p3r
     g, rc, circuit, inputs, prm, L = _fib_layer(oracle, field, key)
     ctx = p3r.Context(field=field, poseidon2_rc=rc, **g["fri"])
-    tp = p3r.TablePacking(public_lanes=1, alu_lanes=1).with_fri_params(g["fri"]["log_final_poly_len"], g["fri"]["log_blowup"])
+    tp = p3r.TablePacking(public_lanes=1, alu_lanes=1, horner_packed_steps=g["packing"].get("horner_packed_steps", 2))
+    tp.with_fri_params(g["fri"]["log_final_poly_len"], g["fri"]["log_blowup"])
     pc = p3r.PreparedCircuit(ctx, p3r.Circuit(circuit.witness_count, circuit.ops, circuit.ext, circuit.public_rows), tp)
     got = pc.prove(p3r.CircuitInputs(public_values=inputs.public_values.reshape(-1, 4)))
     assert got == bytes.fromhex(g["batch_proof_postcard_hex"])
@@ -187,4 +190,129 @@ def test_hip_prover_reproduces_the_rust_npo_proof(oracle, field, key):
                                      private_data_siblings=inputs.pd_siblings.reshape(-1, 8)))
     assert got == bytes.fromhex(g["batch_proof_postcard_hex"])
     pc.free()
+    ctx.close()
+
+
+# ---- D = 1: the example's base proof (CircuitBuilder<F>) --------------------------------------------------------------
+def _base_layer(oracle, field, key):
+    import layer_lib
+    g = load(f"rust_fibonacci_base_layer_{key}.json")
+    rc = np.array(g["rc"], dtype=np.uint32)
+    prep = [np.array(c, dtype=np.uint32) for c in g["preprocessed_columns"]]      # [Const, Public, Alu] (PrimitiveOpType order)
+    w = dict(const_values=np.array(g["const_values"], np.uint32), const_prep=prep[0],
+             public_values=np.array(g["public_values"], np.uint32), public_prep=prep[1],
+             alu_values=np.array(g["alu_values"], np.uint32), alu_prep13=prep[2])
+    for name in ("p2_inputs", "p2_flags", "p2_mmcs_index_sum", "p2_in_ctl", "p2_input_indices", "p2_out_ctl",
+                 "p2_output_indices", "p2_mmcs_index_sum_idx", "recompose_values", "recompose_prep"):
+        w[name] = np.zeros(0, np.uint32)
+    w["counts"] = np.array([len(w["const_values"]), len(w["public_values"]), len(w["alu_values"]) // 4, 0, 0, 0], np.uint32)
+    prm = layer_lib.params(**g["fri"])
+    L = layer_lib.OracleLayer(oracle, field, w, prm, packing=dict(g["packing"], ext_degree=1), rc=rc)
+    return g, rc, w, prm, L
+
+
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_rust_base_field_proof_is_accepted_and_reproduced(oracle, field, key):
+    """`prove_all_tables` over D = 1 traces (recursive_fibonacci.rs:315-337): the reference's preprocessed columns and
+    Traces go into the oracle as they are; bus tuples (idx, v), prefix alpha + beta^2."""
+    import plonky3_recursion_amd as p3r
+    g, rc, w, prm, L = _base_layer(oracle, field, key)
+    inner, outer = bytes.fromhex(g["batch_proof_postcard_hex"]), bytes.fromhex(g["batch_stark_proof_postcard_hex"])
+    proof = p3r.BatchStarkProof.from_postcard(outer, field)
+    assert proof.ext_degree == 1 and proof.w_binomial is None and proof.proof == inner and proof.to_postcard() == outer
+    assert np.array_equal(proof.preprocessed_commitment, L.prep_commit()), "D = 1 table layout / preprocessed commitment"
+    cfg, keep = p3r.make_config(field, poseidon2_rc=rc, ext_degree=1, **g["fri"])
+    p3r.verify_all_tables(cfg, proof)
+    L.verify(inner)
+    assert L.prove() == inner, "prove_batch bytes (D = 1)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_hip_prover_reproduces_the_rust_base_field_proof(oracle, field, key):
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    import harness_adapters as wl
+    g, rc, w, prm, L = _base_layer(oracle, field, key)
+    ctx = p3r.Context(field=field, poseidon2_rc=rc, ext_degree=1, **g["fri"])
+    tp = pv.TablePacking(**g["packing"]).with_fri_params(g["fri"]["log_final_poly_len"], g["fri"]["log_blowup"])
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(w, ext_degree=1), pv.FriRecursionBackend(),
+                                     pv.ProveNextLayerParams(table_packing=tp))
+    got = cache.prover.prove_all_tables(wl.traces_from_arrays(w, ext_degree=1), cache.circuit_prover_data)
+    assert got.proof == bytes.fromhex(g["batch_proof_postcard_hex"])
+    assert got.to_postcard() == bytes.fromhex(g["batch_stark_proof_postcard_hex"])
+    cache.circuit_prover_data.free()
+    ctx.close()
+
+
+# ---- D = 5: quintic ALU + the compact-D1 Poseidon2 table ---------------------------------------------------------------
+def _quintic_layer(oracle):
+    import layer_lib
+    g = load("rust_quintic_layer_koala_bear.json")
+    rc = np.array(g["rc"], dtype=np.uint32)
+    prim = [np.array(c, dtype=np.uint32) for c in g["preprocessed_columns"]["primitive"]]
+    p2 = np.array(g["preprocessed_columns"]["non_primitive"]["poseidon2_perm/koala_bear_d1_w16"], np.uint32).reshape(-1, 62)
+    main_p2 = next(np.array(m["values"], np.uint32).reshape(-1, m["width"]) for m in g["main_traces"]
+                   if m["table"].startswith("poseidon2_perm/"))
+    n = len(p2)
+    # the committed 62-column rows back to p3r_layer_desc's fields (include/p3r.h; indices are stored scaled by 5)
+    in_ctl = np.zeros((n, 16), np.uint32)
+    in_ctl[:, :8] = p2[:, 0:8]
+    w = dict(const_values=np.array(g["const_values"], np.uint32), const_prep=prim[0],
+             public_values=np.array(g["public_values"], np.uint32), public_prep=prim[1],
+             alu_values=np.array(g["alu_values"], np.uint32), alu_prep13=prim[2],
+             p2_inputs=main_p2[:n, :16].reshape(-1), p2_in_ctl=in_ctl.reshape(-1), p2_absorb_len=p2[:, 8].copy(),
+             p2_input_indices=(p2[:, 26:42] // 5).reshape(-1), p2_output_indices=(p2[:, 42:50] // 5).reshape(-1),
+             p2_out_ctl=p2[:, 50:58].reshape(-1), p2_mmcs_index_sum_idx=p2[:, 58] // 5,
+             p2_flags=np.stack([p2[:, 60], p2[:, 61], main_p2[:n, -2], p2[:, 59]], axis=1).reshape(-1),
+             p2_mmcs_index_sum=main_p2[:n, -1].copy(),
+             recompose_values=np.zeros(0, np.uint32), recompose_prep=np.zeros(0, np.uint32))
+    w["counts"] = np.array([len(w["const_values"]) // 5, len(w["public_values"]) // 5, len(w["alu_values"]) // 20, n, 0, 0], np.uint32)
+    return g, rc, w
+
+
+def test_rust_quintic_layer_tables_and_proof(oracle):
+    """The D = 5 tables against the reference: per-table main traces (quintic ALU incl. the packed-Horner columns,
+    the 166-column permutation rows), the preprocessed commitment (62-column compact-D1 rows), acceptance, bytes."""
+    import layer_lib
+    import plonky3_recursion_amd as p3r
+    g, rc, w = _quintic_layer(oracle)
+    pk = g["packing"]
+    fri = g["fri"]
+    prm = layer_lib.params(**fri)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", w, prm, rc=rc,
+                              packing=dict(public_lanes=pk["public_lanes"], alu_lanes=pk["alu_lanes"],
+                                           horner_packed_steps=pk["horner_packed_steps"], min_trace_height=pk["min_trace_height"],
+                                           ext_degree=5))
+    tables = {t["kind"]: t for t in L.tables()}
+    for m in g["main_traces"]:
+        kind = "poseidon2" if m["table"].startswith("poseidon2_perm/") else m["table"].lower()
+        want = np.array(m["values"], np.uint32).reshape(-1, m["width"])
+        assert np.array_equal(tables[kind]["main"], want), f"main trace of {m['table']}"
+    outer = bytes.fromhex(g["batch_stark_proof_postcard_hex"])
+    proof = p3r.BatchStarkProof.from_postcard(outer, "koala-bear")
+    assert proof.ext_degree == 5 and proof.w_binomial is None and proof.alu_quintic_trinomial
+    assert [e.op_type for e in proof.non_primitives] == ["poseidon2_perm/koala_bear_d1_w16"]
+    assert np.array_equal(proof.preprocessed_commitment, L.prep_commit()), "compact-D1 preprocessed rows / commitment"
+    cfg, keep = p3r.make_config("koala-bear", poseidon2_rc=rc, ext_degree=5, **fri)
+    p3r.verify_all_tables(cfg, proof)
+    assert L.prove() == proof.proof, "prove_batch bytes (D = 5)"
+
+
+@pytest.mark.gpu
+def test_hip_prover_reproduces_the_rust_quintic_proof(oracle):
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    import harness_adapters as wl
+    g, rc, w = _quintic_layer(oracle)
+    pk = g["packing"]
+    fri = g["fri"]
+    ctx = p3r.Context(field="koala-bear", poseidon2_rc=rc, ext_degree=5, **fri)
+    tp = pv.TablePacking(public_lanes=pk["public_lanes"], alu_lanes=pk["alu_lanes"], horner_packed_steps=pk["horner_packed_steps"],
+                         min_trace_height=pk["min_trace_height"])
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(w, ext_degree=5), pv.FriRecursionBackend(),
+                                     pv.ProveNextLayerParams(table_packing=tp))
+    got = cache.prover.prove_all_tables(wl.traces_from_arrays(w, ext_degree=5), cache.circuit_prover_data)
+    assert got.to_postcard() == bytes.fromhex(g["batch_stark_proof_postcard_hex"])
+    cache.circuit_prover_data.free()
     ctx.close()

@@ -23,6 +23,13 @@
 //!       registered TableProvers build - a mismatch localises to
 //!       (bus roles / multiplicities | runner | Poseidon2Cols interior order | constraint order | LogUp packing).
 //!
+//!   tests/golden/rust_fibonacci_base_layer_<field>.json
+//!       the Fibonacci circuit as the example proves it first: CircuitBuilder<F>, D = 1 traces (p3r_config.ext_degree = 1).
+//!   tests/golden/rust_quintic_layer_koala_bear.json
+//!       a QuinticTrinomialExtensionField<KoalaBear> circuit (quintic Mul / MulAdd, a chained base-mode Poseidon2 sponge
+//!       on the compact-D1 table) under the ordinary KoalaBear configuration: the D = 5 tables of this repo
+//!       (ext_degree = 5), with preprocessed columns, Traces, per-table main traces and proof bytes.
+//!
 //! Written against the API the reference itself uses (recursion/examples/common/mod.rs:192-207,
 //! 464-486; circuit-prover/src/batch_stark_prover/tests.rs:1031-1099).  It has NOT been compiled in
 //! this repo's build image (no cargo there): expect to fix an import or two on first use.
@@ -169,7 +176,7 @@ macro_rules! field_module {
                 })
             }
 
-            fn config() -> MyConfig {
+            pub fn config() -> MyConfig {
                 let perm: Perm = $default_perm();
                 let hash = MyHash::new(perm.clone());
                 let compress = MyCompress::new(perm.clone());
@@ -224,11 +231,58 @@ macro_rules! field_module {
                     "fri": {"log_blowup": LOG_BLOWUP, "max_log_arity": MAX_LOG_ARITY, "cap_height": CAP_HEIGHT,
                             "log_final_poly_len": LOG_FINAL_POLY_LEN, "commit_pow_bits": COMMIT_POW_BITS,
                             "query_pow_bits": QUERY_POW_BITS, "num_queries": NUM_QUERIES},
-                    "packing": {"public_lanes": 1, "alu_lanes": 1},
+                    "packing": {"public_lanes": 1, "alu_lanes": 1, "horner_packed_steps": 2},   // TablePacking::new keeps K = 2
                     "rc": round_constants(),
                     "degree_bits": log_degrees,
                     "batch_stark_proof_postcard_hex": hex(&outer),
                     "batch_proof_postcard_hex": hex(&inner),
+                })
+            }
+
+            /// The same circuit the way the example proves it FIRST: over the base field (`CircuitBuilder<F>`, D = 1 traces,
+            /// recursive_fibonacci.rs:315-337; batch_stark_prover/tests.rs:433).  p3r_config.ext_degree = 1.
+            pub fn fibonacci_base_layer() -> Value {
+                let mut builder = CircuitBuilder::<F>::new();
+                let expected = builder.alloc_public_input("expected_result");
+                let mut a = builder.alloc_const(F::ZERO, "F(0)");
+                let mut b = builder.alloc_const(F::ONE, "F(1)");
+                for _ in 2..=FIB_N {
+                    let next = builder.add(a, b);
+                    a = b;
+                    b = next;
+                }
+                builder.connect(b, expected);
+                let circuit = builder.build().unwrap();
+                let (mut fa, mut fb) = (F::ZERO, F::ONE);
+                for _ in 2..=FIB_N { let t = fa + fb; fa = fb; fb = t; }
+                let packing = TablePacking::new(1, 1).with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
+                let cfg = config();
+                let (airs_degrees, primitive_columns, non_primitive_columns) =
+                    get_airs_and_degrees_with_prep::<MyConfig, F, 1>(&circuit, &packing, &[], &[], ConstraintProfile::Standard).unwrap();
+                let prep_json: Vec<Vec<u32>> = primitive_columns.iter().map(|c| u32s(c)).collect();
+                let (airs, log_degrees): (Vec<_>, Vec<usize>) = airs_degrees.into_iter().unzip();
+                let prover_data = ProverData::from_airs_and_degrees(&cfg, &airs, &log_degrees);
+                let cpd = CircuitProverData::new(prover_data, primitive_columns, non_primitive_columns);
+                let mut runner = circuit.runner();
+                runner.set_public_inputs(&[fb]).unwrap();
+                let traces = runner.run().unwrap();
+                let prover = BatchStarkProver::new(cfg).with_table_packing(packing);
+                let proof: BatchStarkProof<MyConfig> = prover.prove_all_tables(&traces, &cpd).unwrap();
+                assert_eq!(proof.ext_degree, 1);
+                prover.verify_all_tables::<F>(&proof).unwrap();
+                json!({
+                    "field": $key, "n": FIB_N, "fib": fb.as_canonical_u32(), "ext_degree": 1,
+                    "fri": {"log_blowup": LOG_BLOWUP, "max_log_arity": MAX_LOG_ARITY, "cap_height": CAP_HEIGHT,
+                            "log_final_poly_len": LOG_FINAL_POLY_LEN, "commit_pow_bits": COMMIT_POW_BITS,
+                            "query_pow_bits": QUERY_POW_BITS, "num_queries": NUM_QUERIES},
+                    "packing": {"public_lanes": 1, "alu_lanes": 1, "horner_packed_steps": 2},
+                    "rc": round_constants(),
+                    "preprocessed_columns": prep_json,
+                    "const_values": u32s(&traces.const_trace.values), "public_values": u32s(&traces.public_trace.values),
+                    "alu_values": traces.alu_trace.values.iter().flat_map(|r| u32s(r)).collect::<Vec<u32>>(),
+                    "degree_bits": log_degrees,
+                    "batch_stark_proof_postcard_hex": hex(&postcard::to_allocvec(&proof).unwrap()),
+                    "batch_proof_postcard_hex": hex(&postcard::to_allocvec(&proof.proof).unwrap()),
                 })
             }
 
@@ -329,7 +383,7 @@ macro_rules! field_module {
                 let limb = |k: usize| Challenge::from_basis_coefficients_slice(&out[4 * k..4 * k + 4]).unwrap();
                 let publics = vec![xv, yv, av, ef(2), limb(0), limb(1)];
 
-                let packing = TablePacking::new(1, 3).with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
+                let packing = TablePacking::new(1, 3).with_horner_pack_k(4).with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
                 let cfg = config();
                 let npo_prep: Vec<Box<dyn NpoPreprocessor<F>>> = vec![Box::new(Poseidon2Preprocessor), Box::new(RecomposePreprocessor::default())];
                 let mut air_builders = poseidon2_air_builders::<_, 4>();
@@ -446,6 +500,105 @@ field_module!(baby, p3_baby_bear::BabyBear, p3_baby_bear::Poseidon2BabyBear<16>,
               p3_baby_bear::BABYBEAR_POSEIDON2_RC_16_EXTERNAL_FINAL, "baby_bear",
               p3_poseidon2_circuit_air::BabyBearD4Width16, p3_circuit::ops::Poseidon2Config::BABY_BEAR_D4_W16);
 
+/// D = 5: a `QuinticTrinomialExtensionField<KoalaBear>` circuit under the ordinary KoalaBear configuration, the shape of
+/// circuit-prover/src/batch_stark_prover/tests.rs:844-1029: a quintic Mul / MulAdd, and a two-row base-mode Poseidon2
+/// sponge chain (KOALA_BEAR_D1_W16, compact-D1 preprocessed layout) whose rate outputs are exposed.  Emits the traces
+/// and preprocessed columns in the layout of include/p3r.h under ext_degree = 5 (values n x 5 / n x 20, Poseidon2 CTL
+/// 16 x 8 per row, absorb_len), the per-table main traces and the proof bytes.
+fn quintic_layer() -> Value {
+    use koala::{config, round_constants, MyConfig};
+    use p3_circuit::ops::{generate_poseidon2_trace, KoalaBearD1Width16, Poseidon2Config, Poseidon2PermCallBase};
+    use p3_circuit_prover::batch_stark_prover::{poseidon2_air_builders_d5, poseidon2_table_provers_d5, Poseidon2Preprocessor};
+    use p3_circuit_prover::common::NpoPreprocessor;
+    use p3_field::extension::QuinticTrinomialExtensionField;
+    use p3_koala_bear::{default_koalabear_poseidon2_16, KoalaBear};
+    use p3_test_utils::LiftPermToQuintic;
+    type EF5 = QuinticTrinomialExtensionField<KoalaBear>;
+    const D: usize = 5;
+    let lift = |v: u64| EF5::from(KoalaBear::from_u64(v));
+    let ef5 = |a: u64| EF5::from_basis_coefficients_fn(|i| KoalaBear::from_u64(a + 3 * i as u64));
+    let inner_perm = default_koalabear_poseidon2_16();
+    let mut st = [KoalaBear::ZERO; 16];
+    st[0] = KoalaBear::from_u64(11);
+    st[1] = KoalaBear::from_u64(13);
+    let out0 = inner_perm.permute(st);
+    let out1 = inner_perm.permute(out0);
+
+    let mut builder = CircuitBuilder::<EF5>::new();
+    builder.enable_poseidon2_perm_base::<KoalaBearD1Width16, _>(generate_poseidon2_trace::<EF5, KoalaBearD1Width16>,
+                                                                 LiftPermToQuintic::new(inner_perm));
+    // quintic arithmetic: the trinomial reduction is what a D = 4 rule cannot satisfy
+    let x = builder.public_input();
+    let y = builder.public_input();
+    let m = builder.mul(x, y);
+    let ma = builder.mul_add(m, x, y);
+    let expected_ma = builder.public_input();
+    builder.connect(ma, expected_ma);
+    // base-mode sponge: two rows, the second chained (new_start = false), rate outputs exposed
+    let in_a = builder.public_input();
+    let in_b = builder.public_input();
+    let mut inputs0: [Option<_>; 16] = [None; 16];
+    inputs0[0] = Some(in_a);
+    inputs0[1] = Some(in_b);
+    builder.add_poseidon2_perm_base(&Poseidon2PermCallBase { config: Poseidon2Config::KOALA_BEAR_D1_W16, new_start: true,
+        inputs: inputs0, out_ctl: [false; 8], return_all_outputs: false, absorb_len: 0 }).unwrap();
+    let (_, outs) = builder.add_poseidon2_perm_base(&Poseidon2PermCallBase { config: Poseidon2Config::KOALA_BEAR_D1_W16,
+        new_start: false, inputs: [None; 16], out_ctl: [true; 8], return_all_outputs: false, absorb_len: 0 }).unwrap();
+    let e0 = builder.public_input();
+    let e1 = builder.public_input();
+    let d0 = builder.sub(outs[0].unwrap(), e0);
+    let d1 = builder.sub(outs[1].unwrap(), e1);
+    builder.assert_zero(d0);
+    builder.assert_zero(d1);
+    let circuit = builder.build().unwrap();
+
+    let (xv, yv) = (ef5(5), ef5(9));
+    let mav = xv * yv * xv + yv;
+    let publics = vec![xv, yv, mav, lift(11), lift(13), EF5::from(out1[0]), EF5::from(out1[1])];
+    let cfg: MyConfig = config();
+    let packing = TablePacking::default().with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
+    let npo_prep: Vec<Box<dyn NpoPreprocessor<KoalaBear>>> = vec![Box::new(Poseidon2Preprocessor)];
+    let air_builders = poseidon2_air_builders_d5::<MyConfig>();
+    let (airs_degrees, primitive_columns, non_primitive_columns) =
+        get_airs_and_degrees_with_prep::<MyConfig, _, D>(&circuit, &packing, &npo_prep, &air_builders, ConstraintProfile::Standard).unwrap();
+    let prep_json = json!({
+        "primitive": primitive_columns.iter().map(|c| u32s(c)).collect::<Vec<_>>(),
+        "non_primitive": non_primitive_columns.iter().map(|(k, c)| (k.to_string(), u32s(c))).collect::<std::collections::BTreeMap<_, _>>(),
+    });
+    let (airs, log_degrees): (Vec<_>, Vec<usize>) = airs_degrees.into_iter().unzip();
+    let mut runner = circuit.runner();
+    runner.set_public_inputs(&publics).unwrap();
+    let traces = runner.run().unwrap();
+    let prover_data = ProverData::from_airs_and_degrees(&cfg, &airs, &log_degrees);
+    let cpd = CircuitProverData::new(prover_data, primitive_columns, non_primitive_columns);
+    let mut prover = BatchStarkProver::new(cfg);
+    for p in poseidon2_table_provers_d5(Poseidon2Config::KOALA_BEAR_D1_W16) { prover.register_table_prover(p); }
+    let mains: Vec<Value> = prover.main_traces_for_pinning::<EF5, D>(&traces, &cpd).into_iter()
+        .map(|(name, m)| json!({"table": name, "width": m.width(), "values": u32s(&m.values)})).collect();
+    let proof: BatchStarkProof<MyConfig> = prover.prove_all_tables(&traces, &cpd).unwrap();
+    assert_eq!(proof.ext_degree, D);
+    assert!(proof.w_binomial.is_none() && proof.alu_quintic_trinomial);
+    prover.verify_all_tables::<EF5>(&proof).unwrap();
+    let flat5 = |v: &[EF5]| -> Vec<u32> { v.iter().flat_map(|e| u32s(e.as_basis_coefficients_slice())).collect() };
+    json!({
+        "field": "koala_bear", "ext_degree": 5,
+        "fri": {"log_blowup": LOG_BLOWUP, "max_log_arity": MAX_LOG_ARITY, "cap_height": CAP_HEIGHT,
+                "log_final_poly_len": LOG_FINAL_POLY_LEN, "commit_pow_bits": COMMIT_POW_BITS,
+                "query_pow_bits": QUERY_POW_BITS, "num_queries": NUM_QUERIES},
+        "packing": {"public_lanes": packing.public_lanes(), "alu_lanes": packing.alu_lanes(),
+                    "horner_packed_steps": packing.horner_packed_steps(), "min_trace_height": packing.min_trace_height()},
+        "rc": round_constants(),
+        "public_inputs": flat5(&publics),
+        "preprocessed_columns": prep_json,
+        "const_values": flat5(&traces.const_trace.values), "public_values": flat5(&traces.public_trace.values),
+        "alu_values": traces.alu_trace.values.iter().flat_map(|r| flat5(r)).collect::<Vec<u32>>(),
+        "main_traces": mains,
+        "degree_bits": log_degrees,
+        "batch_stark_proof_postcard_hex": hex(&postcard::to_allocvec(&proof).unwrap()),
+        "batch_proof_postcard_hex": hex(&postcard::to_allocvec(&proof.proof).unwrap()),
+    })
+}
+
 fn main() {
     let golden = concat!(env!("CARGO_MANIFEST_DIR"), "/../../tests/golden");
     let inp: Value = serde_json::from_str(&fs::read_to_string(format!("{golden}/primitives.json")).unwrap()).unwrap();
@@ -461,5 +614,8 @@ fn main() {
     fs::write(format!("{golden}/rust_fibonacci_layer_baby_bear.json"), serde_json::to_string(&baby::fibonacci_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_npo_layer_koala_bear.json"), serde_json::to_string(&koala::npo_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_npo_layer_baby_bear.json"), serde_json::to_string(&baby::npo_layer()).unwrap()).unwrap();
-    println!("wrote rust_primitives.json, rust_fibonacci_layer_*.json and rust_npo_layer_*.json under {golden}");
+    fs::write(format!("{golden}/rust_fibonacci_base_layer_koala_bear.json"), serde_json::to_string(&koala::fibonacci_base_layer()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_fibonacci_base_layer_baby_bear.json"), serde_json::to_string(&baby::fibonacci_base_layer()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_quintic_layer_koala_bear.json"), serde_json::to_string(&quintic_layer()).unwrap()).unwrap();
+    println!("wrote rust_primitives.json, rust_fibonacci_layer_*.json, rust_fibonacci_base_layer_*.json, rust_npo_layer_*.json and rust_quintic_layer_koala_bear.json under {golden}");
 }
