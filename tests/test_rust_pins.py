@@ -246,9 +246,9 @@ def test_hip_prover_reproduces_the_rust_base_field_proof(oracle, field, key):
 
 
 # ---- D = 5: quintic ALU + the compact-D1 Poseidon2 table ---------------------------------------------------------------
-def _quintic_layer(oracle):
+def _quintic_layer(oracle, g=None):
     import layer_lib
-    g = load("rust_quintic_layer_koala_bear.json")
+    g = g or load("rust_quintic_layer_koala_bear.json")
     rc = np.array(g["rc"], dtype=np.uint32)
     prim = [np.array(c, dtype=np.uint32) for c in g["preprocessed_columns"]["primitive"]]
     p2 = np.array(g["preprocessed_columns"]["non_primitive"]["poseidon2_perm/koala_bear_d1_w16"], np.uint32).reshape(-1, 62)
@@ -316,3 +316,31 @@ def test_hip_prover_reproduces_the_rust_quintic_proof(oracle):
     assert got.to_postcard() == bytes.fromhex(g["batch_stark_proof_postcard_hex"])
     cache.circuit_prover_data.free()
     ctx.close()
+
+
+def test_quintic_fixture_mapping_inverts_the_table_builder(oracle):
+    """No Rust file needed: a fixture of the same schema made from this repo's own D = 5 layer (the oracle's committed
+    62-column rows and main traces) maps back to p3r_layer_desc fields that rebuild the same tables and commitment -
+    so that, when the real fixture arrives, a failure of test_rust_quintic_layer_tables_and_proof is about the
+    tables, not about the test's own unpacking."""
+    import harness_lib
+    import layer_lib
+    import oracle_lib
+    arrs = harness_lib.generate("koala-bear", 6, seed=77, flags=harness_lib.NO_RECOMPOSE, ext_degree=5, horner_chain_len=12,
+                                sponge_chain_len=3, merkle_depth=4)
+    prm = layer_lib.params(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=6, num_queries=8)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(ext_degree=5))
+    tables = {t["kind"]: t for t in L.tables()}
+    n = int(arrs["counts"][3])
+    g = dict(rc=oracle_lib.default_rc("koala-bear").tolist(),
+             preprocessed_columns=dict(primitive=[arrs["const_prep"].tolist(), arrs["public_prep"].tolist(), arrs["alu_prep13"].tolist()],
+                                       non_primitive={"poseidon2_perm/koala_bear_d1_w16": tables["poseidon2"]["prep"][:n].reshape(-1).tolist()}),
+             const_values=arrs["const_values"].tolist(), public_values=arrs["public_values"].tolist(),
+             alu_values=arrs["alu_values"].tolist(),
+             main_traces=[dict(table="poseidon2_perm/koala_bear_d1_w16", width=int(tables["poseidon2"]["main"].shape[1]),
+                               values=tables["poseidon2"]["main"].reshape(-1).tolist())])
+    _, rc, w = _quintic_layer(oracle, g)
+    L2 = layer_lib.OracleLayer(oracle, "koala-bear", w, prm, packing=dict(ext_degree=5), rc=rc)
+    for a, b in zip(L.tables(), L2.tables()):
+        assert a["kind"] == b["kind"] and np.array_equal(a["main"], b["main"]) and np.array_equal(a["prep"], b["prep"]), a["kind"]
+    assert np.array_equal(L.prep_commit(), L2.prep_commit())
