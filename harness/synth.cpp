@@ -205,7 +205,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     rec_w.push_back(w);
     pickable.push_back(w);
     rec_ins.push_back(ins);
-    if (D == 4 && !rec_coeff) push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, 0, ins);
+    if (!rec_coeff) push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, 0, ins);
   }
   // the owned coefficients are ordinary witnesses for everything after them
   for (uint32_t w : rec_owned) { pickable.push_back(w); base_valued.push_back(w); }

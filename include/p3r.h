@@ -65,10 +65,12 @@ typedef struct p3r_config {
                                 * x^4 = W), or 5 over KoalaBear
                                 * (quintic trinomial x^5 + x^2 - 1: QuinticTrinomialExtensionField, proved under the
                                 * same D = 4 STARK configuration as in circuit-prover/src/batch_stark_prover/
-                                * tests.rs:844-1029).  D = 1 and D = 5 layers enter at the prove_all_tables boundary:
-                                * values are n x D / n x 4D, witness indices in the preprocessed columns are scaled
-                                * by D, the Poseidon2 table is the compact-D1 one (p3r_layer_desc); p3r_circuit_create
-                                * runs D = 4 circuits and returns P3R_EUNSUPPORTED otherwise. */
+                                * tests.rs:844-1029).  Under D = 1 / D = 5 values are n x D / n x 4D, witness indices in
+                                * the preprocessed columns are scaled by D and the Poseidon2 table is the compact-D1
+                                * one (p3r_layer_desc).  The circuit boundary (p3r_circuit_create ...) runs such
+                                * circuits too - constants carry D coefficients, inputs are n x D - except for
+                                * Poseidon2 ops, which it refuses with P3R_EUNSUPPORTED (base-mode rows: hand the
+                                * layer over as Traces). */
   uint32_t log_blowup;
   uint32_t max_log_arity;
   uint32_t cap_height;

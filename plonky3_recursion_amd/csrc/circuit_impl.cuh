@@ -44,7 +44,9 @@ struct HostCircuit {
 
 inline bool op_is_alu(uint32_t k) { return k >= P3R_OP_ALU_ADD && k <= P3R_OP_ALU_HORNER_ACC; }
 
-inline void validate_circuit(const HostCircuit& c) {
+// D: the circuit's extension degree (p3r_config.ext_degree): constants carry D coefficients, an ExtDecompositionHint
+// has D outputs, Recompose packs D coefficients.
+inline void validate_circuit(const HostCircuit& c, uint32_t D = 4) {
   const uint32_t nw = c.witness_count;
   // bit 31 of a stored witness id and the top bits of the error word are used as flags
   if (nw >= (1u << 31)) fail(P3R_EINVAL, "witness_count %u is too large", nw);
@@ -60,7 +62,7 @@ inline void validate_circuit(const HostCircuit& c) {
     switch (op.kind) {
       case P3R_OP_CONST:
         wid(op.out, i, "out");
-        if (op.ext_len != 4) fail(P3R_EINVAL, "op %zu: a constant carries 4 coefficients", i);
+        if (op.ext_len != D) fail(P3R_EINVAL, "op %zu: a constant carries %u coefficients", i, D);
         break;
       case P3R_OP_PUBLIC: wid(op.out, i, "out"); break;
       case P3R_OP_ALU_ADD: case P3R_OP_ALU_MUL: case P3R_OP_ALU_BOOL_CHECK: case P3R_OP_ALU_MUL_ADD:
@@ -71,15 +73,19 @@ inline void validate_circuit(const HostCircuit& c) {
         break;
       case P3R_OP_HINT_EXT_DECOMPOSITION:
         wid(op.a, i, "input");
-        if (op.ext_len != 4) fail(P3R_EINVAL, "op %zu: ExtDecompositionHint expects 4 outputs, got %u", i, op.ext_len);
+        if (op.ext_len != D) fail(P3R_EINVAL, "op %zu: ExtDecompositionHint expects %u outputs, got %u", i, D, op.ext_len);
         for (uint32_t k = 0; k < op.ext_len; ++k) wid(e[k], i, "hint output");
         break;
       case P3R_OP_HINT_BINARY_DECOMPOSITION:
         wid(op.a, i, "input");
-        if (op.ext_len > 31 * 4) fail(P3R_EINVAL, "op %zu: BinaryDecompositionTooManyBits (%u > 124)", i, op.ext_len);
+        if (op.ext_len > 31 * D) fail(P3R_EINVAL, "op %zu: BinaryDecompositionTooManyBits (%u > %u)", i, op.ext_len, 31 * D);
         for (uint32_t k = 0; k < op.ext_len; ++k) wid(e[k], i, "hint output");
         break;
       case P3R_OP_POSEIDON2_PERM: {
+        // the permutation rows of a D = 1 / D = 5 circuit are base-mode rows (one witness per state element,
+        // executor.rs:600-700): their layers enter at the prove_all_tables boundary, the device runner has no executor
+        if (D != 4)
+          fail(P3R_EUNSUPPORTED, "op %zu: UnsupportedDegree(%u): the device runner executes Poseidon2 rows of D = 4 circuits", i, D);
         if (op.ext_len < 7 || (e[6] != 2 && e[6] != 4) || op.ext_len != 7 + e[6])
           fail(P3R_EINVAL, "op %zu: Poseidon2 perm expects 4 input limbs, mmcs_index_sum, mmcs_bit and 2 or 4 outputs", i);
         for (uint32_t k = 0; k < 6; ++k) opt(e[k], i, "poseidon2 input");
@@ -92,8 +98,8 @@ inline void validate_circuit(const HostCircuit& c) {
       case P3R_OP_RECOMPOSE:
         wid(op.out, i, "out");
         if (op.a >= c.ops.size()) fail(P3R_EINVAL, "op %zu: NonPrimitiveOpId(%u) out of range", i, op.a);
-        if (op.ext_len != 4) fail(P3R_EINVAL, "op %zu: recompose expects 1 input group with 4 witnesses", i);
-        for (uint32_t k = 0; k < 4; ++k) wid(e[k], i, "coefficient");
+        if (op.ext_len != D) fail(P3R_EINVAL, "op %zu: recompose expects 1 input group with %u witnesses", i, D);
+        for (uint32_t k = 0; k < D; ++k) wid(e[k], i, "coefficient");
         break;
       default: fail(P3R_EUNSUPPORTED, "op %zu: kind %u has no table in this backend", i, op.kind);
     }
@@ -107,8 +113,8 @@ inline void validate_circuit(const HostCircuit& c) {
 struct AluRoles { uint8_t a_state, c_state, b_creator, out_creator; };
 
 template <class PP>
-CircuitTables circuit_tables(const HostCircuit& c) {
-  constexpr uint32_t P = PP::P, D = 4, NEG1 = P - 1;
+CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
+  constexpr uint32_t P = PP::P, NEG1 = P - 1;
   auto scaled = [&](uint32_t w) { return (uint32_t)(((uint64_t)w * D) % P); };
   CircuitTables T;
   std::vector<uint32_t> reads(c.witness_count, 0);
@@ -310,7 +316,7 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
       case P3R_OP_CONST:
         S.const_rows.push_back(op.out);
         r.ext_off = (uint32_t)S.dev_ext.size();
-        S.dev_ext.insert(S.dev_ext.end(), e, e + 4);
+        S.dev_ext.insert(S.dev_ext.end(), e, e + op.ext_len);
         if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
         break;
       case P3R_OP_PUBLIC:
@@ -384,9 +390,9 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
         }
         break;
       case P3R_OP_RECOMPOSE:
-        for (int k = 0; k < 4; ++k) need(e[k]);
+        for (uint32_t k = 0; k < op.ext_len; ++k) need(e[k]);
         r.ext_off = (uint32_t)S.dev_ext.size();
-        S.dev_ext.insert(S.dev_ext.end(), e, e + 4);
+        S.dev_ext.insert(S.dev_ext.end(), e, e + op.ext_len);
         if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
         r.rec = n_rec++;
         break;
@@ -500,28 +506,51 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
 }
 
 // ---------------------------------------------------------------- kernels
-template <class PP>
-__device__ __forceinline__ Fp4<PP> w_load(const uint32_t* __restrict__ w, uint32_t id) {
-  const uint4 v = *reinterpret_cast<const uint4*>(w + (size_t)id * 4);
-  Fp4<PP> e;
-  e.c[0] = Fp<PP>::raw(v.x); e.c[1] = Fp<PP>::raw(v.y); e.c[2] = Fp<PP>::raw(v.z); e.c[3] = Fp<PP>::raw(v.w);
+// The witness table holds D Montgomery words per witness (row-major, [witness_count][D]); E = the circuit's element
+// type (Fp1 / Fp4 / Fp5, field.h).  A D = 4 row is one 16-byte access.
+template <class PP, int D = 4>
+__device__ __forceinline__ typename CircuitExt<PP, D>::type w_load(const uint32_t* __restrict__ w, uint32_t id) {
+  typename CircuitExt<PP, D>::type e;
+  if constexpr (D == 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(w + (size_t)id * 4);
+    e.c[0] = Fp<PP>::raw(v.x); e.c[1] = Fp<PP>::raw(v.y); e.c[2] = Fp<PP>::raw(v.z); e.c[3] = Fp<PP>::raw(v.w);
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; ++k) e.c[k] = Fp<PP>::raw(w[(size_t)id * D + k]);
+  }
   return e;
 }
-template <class PP>
-__device__ __forceinline__ void w_store(uint32_t* __restrict__ w, uint32_t id, const Fp4<PP>& e) {
-  *reinterpret_cast<uint4*>(w + (size_t)id * 4) = make_uint4(e.c[0].v, e.c[1].v, e.c[2].v, e.c[3].v);
+template <class PP, int D = 4>
+__device__ __forceinline__ void w_store(uint32_t* __restrict__ w, uint32_t id, const typename CircuitExt<PP, D>::type& e) {
+  if constexpr (D == 4) {
+    *reinterpret_cast<uint4*>(w + (size_t)id * 4) = make_uint4(e.c[0].v, e.c[1].v, e.c[2].v, e.c[3].v);
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; ++k) w[(size_t)id * D + k] = e.c[k].v;
+  }
+}
+// one AluOpRecord operand ([a, b, c, out] x D words per op)
+template <class PP, int D, class E>
+__device__ __forceinline__ void rec_store(uint32_t* __restrict__ alu_values, uint32_t rec, int operand, const E& e) {
+  uint32_t* dst = alu_values + ((size_t)rec * 4 + operand) * D;
+  if constexpr (D == 4) {
+    *reinterpret_cast<uint4*>(dst) = make_uint4(e.c[0].v, e.c[1].v, e.c[2].v, e.c[3].v);
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; ++k) dst[k] = e.c[k].v;
+  }
 }
 __device__ __forceinline__ void run_error(uint32_t* err, uint32_t op_idx, uint32_t code) {
   // the runner stops at the FIRST failing op of the sequence: keep the smallest op index
   atomicMin(err, (op_idx << 3) | code);
 }
-template <class PP>
-__device__ __forceinline__ void w_put(uint32_t* __restrict__ w, uint32_t id, const Fp4<PP>& e, bool check, uint32_t* err,
-                                      uint32_t op_idx) {
+template <class PP, int D = 4>
+__device__ __forceinline__ void w_put(uint32_t* __restrict__ w, uint32_t id, const typename CircuitExt<PP, D>::type& e,
+                                      bool check, uint32_t* err, uint32_t op_idx) {
   if (check) {
-    if (!(w_load<PP>(w, id) == e)) run_error(err, op_idx, RUN_ERR_CONFLICT);
+    if (!(w_load<PP, D>(w, id) == e)) run_error(err, op_idx, RUN_ERR_CONFLICT);
   } else {
-    w_store<PP>(w, id, e);
+    w_store<PP, D>(w, id, e);
   }
 }
 
@@ -548,100 +577,99 @@ struct RunArgs {
 };
 
 // One ALU / hint / recompose / const op.
-template <class PP>
+template <class PP, int D = 4>
 __device__ __forceinline__ void run_light_op(const RunArgs& A, const RunOp& op) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename CircuitExt<PP, D>::type;
   uint32_t* __restrict__ w = A.w;
   const uint32_t* __restrict__ ext = A.ext;
   uint32_t* err = A.err;
   const uint32_t kind = op.kind_flags & 0xFF;
   const bool chk_out = op.kind_flags & RUN_CHECK_OUT;
   auto record = [&](const E& a, const E& b, const E& c, const E& o) {  // AluOpRecord (runner.rs:317-453)
-    uint4* dst = reinterpret_cast<uint4*>(A.alu_values + (size_t)op.rec * 16);
-    dst[0] = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
-    dst[1] = make_uint4(b.c[0].v, b.c[1].v, b.c[2].v, b.c[3].v);
-    dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
-    dst[3] = make_uint4(o.c[0].v, o.c[1].v, o.c[2].v, o.c[3].v);
+    rec_store<PP, D>(A.alu_values, op.rec, 0, a);
+    rec_store<PP, D>(A.alu_values, op.rec, 1, b);
+    rec_store<PP, D>(A.alu_values, op.rec, 2, c);
+    rec_store<PP, D>(A.alu_values, op.rec, 3, o);
   };
   switch (kind) {
     case P3R_OP_CONST: {
       E v;
-      for (int k = 0; k < 4; ++k) v.c[k] = F::raw(ext[op.ext_off + k]);  // stored in Montgomery form
-      w_put<PP>(w, op.out, v, chk_out, err, op.op_idx);
+      for (int k = 0; k < D; ++k) v.c[k] = F::raw(ext[op.ext_off + k]);  // stored in Montgomery form
+      w_put<PP, D>(w, op.out, v, chk_out, err, op.op_idx);
       break;
     }
     case P3R_OP_ALU_ADD: case P3R_OP_ALU_MUL: {
-      const E a = w_load<PP>(w, op.a);
+      const E a = w_load<PP, D>(w, op.a);
       E b, o;
       if (op.kind_flags & RUN_BACKWARD) {
-        o = w_load<PP>(w, op.out);
+        o = w_load<PP, D>(w, op.out);
         if (kind == P3R_OP_ALU_ADD) b = o - a;
         else {
           if (a == E::zero()) { run_error(err, op.op_idx, RUN_ERR_DIV0); b = E::zero(); }
           else b = o * a.inv();
         }
-        w_store<PP>(w, op.b, b);
+        w_store<PP, D>(w, op.b, b);
       } else {
-        b = w_load<PP>(w, op.b);
+        b = w_load<PP, D>(w, op.b);
         o = kind == P3R_OP_ALU_ADD ? a + b : a * b;
-        w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+        w_put<PP, D>(w, op.out, o, chk_out, err, op.op_idx);
       }
       record(a, b, E::zero(), o);
       break;
     }
     case P3R_OP_ALU_BOOL_CHECK: {
-      const E a = w_load<PP>(w, op.a);
-      w_put<PP>(w, op.out, a, chk_out, err, op.op_idx);
+      const E a = w_load<PP, D>(w, op.a);
+      w_put<PP, D>(w, op.out, a, chk_out, err, op.op_idx);
       record(a, E::zero(), a, a);
       break;
     }
     case P3R_OP_ALU_MUL_ADD: {
-      const E a = w_load<PP>(w, op.a), b = w_load<PP>(w, op.b), ab = a * b;
-      if (op.aux != kNoW) w_put<PP>(w, op.aux, ab, op.kind_flags & RUN_CHECK_AUX, err, op.op_idx);
-      const E c = op.c != kNoW ? (op.c == op.aux ? ab : w_load<PP>(w, op.c)) : E::zero();
+      const E a = w_load<PP, D>(w, op.a), b = w_load<PP, D>(w, op.b), ab = a * b;
+      if (op.aux != kNoW) w_put<PP, D>(w, op.aux, ab, op.kind_flags & RUN_CHECK_AUX, err, op.op_idx);
+      const E c = op.c != kNoW ? (op.c == op.aux ? ab : w_load<PP, D>(w, op.c)) : E::zero();
       const E o = ab + c;
       if (op.aux != kNoW && op.out == op.aux) { if (!(o == ab)) run_error(err, op.op_idx, RUN_ERR_CONFLICT); }
-      else w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+      else w_put<PP, D>(w, op.out, o, chk_out, err, op.op_idx);
       record(a, b, c, o);
       break;
     }
     case P3R_OP_ALU_HORNER_ACC: {
-      const E acc = w_load<PP>(w, op.aux), a = w_load<PP>(w, op.a), b = w_load<PP>(w, op.b), c = w_load<PP>(w, op.c);
+      const E acc = w_load<PP, D>(w, op.aux), a = w_load<PP, D>(w, op.a), b = w_load<PP, D>(w, op.b), c = w_load<PP, D>(w, op.c);
       const E o = acc * b + c - a;
-      w_put<PP>(w, op.out, o, chk_out, err, op.op_idx);
+      w_put<PP, D>(w, op.out, o, chk_out, err, op.op_idx);
       record(a, b, c, o);
       break;
     }
     case P3R_OP_HINT_EXT_DECOMPOSITION: {
-      const E v = w_load<PP>(w, op.a);
-      for (int k = 0; k < 4; ++k) {
+      const E v = w_load<PP, D>(w, op.a);
+      for (int k = 0; k < D; ++k) {
         const uint32_t t = ext[op.ext_off + k];
-        w_put<PP>(w, t & ~RUN_CHECK_BIT, E::from_base(v.c[k]), t & RUN_CHECK_BIT, err, op.op_idx);
+        w_put<PP, D>(w, t & ~RUN_CHECK_BIT, E::from_base(v.c[k]), t & RUN_CHECK_BIT, err, op.op_idx);
       }
       break;
     }
     case P3R_OP_HINT_BINARY_DECOMPOSITION: {
-      const E v = w_load<PP>(w, op.a);
+      const E v = w_load<PP, D>(w, op.a);
       const uint32_t n_out = (op.kind_flags >> 16) & 0xFF;
       uint32_t o = 0;
-      for (int k = 0; k < 4 && o < n_out; ++k) {
+      for (int k = 0; k < D && o < n_out; ++k) {
         const uint32_t val = v.c[k].to_canonical();
         for (int bit = 0; bit < 31 && o < n_out; ++bit, ++o) {
           const uint32_t t = ext[op.ext_off + o];
           const E e = ((val >> bit) & 1) ? E::one() : E::zero();
-          w_put<PP>(w, t & ~RUN_CHECK_BIT, e, t & RUN_CHECK_BIT, err, op.op_idx);
+          w_put<PP, D>(w, t & ~RUN_CHECK_BIT, e, t & RUN_CHECK_BIT, err, op.op_idx);
         }
       }
       break;
     }
     case P3R_OP_RECOMPOSE: {
       E v;
-      for (int k = 0; k < 4; ++k) {
-        v.c[k] = w_load<PP>(w, ext[op.ext_off + k]).c[0];
-        A.rec_values[(size_t)op.rec * 4 + k] = v.c[k].v;
+      for (int k = 0; k < D; ++k) {
+        v.c[k] = w_load<PP, D>(w, ext[op.ext_off + k]).c[0];
+        A.rec_values[(size_t)op.rec * D + k] = v.c[k].v;
       }
-      w_put<PP>(w, op.out, v, chk_out, err, op.op_idx);
+      w_put<PP, D>(w, op.out, v, chk_out, err, op.op_idx);
       break;
     }
     default: break;
@@ -719,28 +747,28 @@ __device__ __forceinline__ void run_p2_segment(const RunArgs& A, RunSchedule::P2
 // with a shuffle scan across the wave, then every lane replays its slice from its incoming
 // accumulator, writing the outputs and the AluOpRecords (runner.rs:430-453).
 // `block`: index among the chain blocks of the launch, four chains (waves) per block.
-template <class PP>
+template <class PP, int D = 4>
 __device__ __forceinline__ void run_chains(const RunArgs& A, const RunOp* __restrict__ steps,
                                            const RunSchedule::ChainSeg* __restrict__ segs, uint32_t n_segs,
                                            uint32_t block) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename CircuitExt<PP, D>::type;
   const uint32_t chain = block * (kBlock / 64) + (threadIdx.x >> 6);
   if (chain >= n_segs) return;  // whole waves leave together
   const RunSchedule::ChainSeg seg = segs[chain];
   const uint32_t t = threadIdx.x & 63;
   uint32_t* __restrict__ w = A.w;
-  const E b = w_load<PP>(w, seg.b_w);
+  const E b = w_load<PP, D>(w, seg.b_w);
   const uint32_t per = (seg.n + 63) / 64;
   const uint32_t i0 = min(t * per, seg.n), i1 = min(i0 + per, seg.n);
   // local fold from a zero accumulator: value V, multiplier M = b^(i1 - i0)
   E M = E::one(), V = E::zero();
   for (uint32_t i = i0; i < i1; ++i) {
     const RunOp op = steps[seg.first + i];
-    V = V * b + w_load<PP>(w, op.c) - w_load<PP>(w, op.a);
+    V = V * b + w_load<PP, D>(w, op.c) - w_load<PP, D>(w, op.a);
     M = M * b;
   }
-  auto up = [&](const E& e, int d) { E r; for (int k = 0; k < 4; ++k) r.c[k] = F::raw(__shfl_up(e.c[k].v, d)); return r; };
+  auto up = [&](const E& e, int d) { E r; for (int k = 0; k < D; ++k) r.c[k] = F::raw(__shfl_up(e.c[k].v, d)); return r; };
   // inclusive scan of the maps x -> x*M + V (composition: the earlier slice is applied first)
   for (int d = 1; d < 64; d <<= 1) {
     const E pm = up(M, d), pv = up(V, d);
@@ -750,110 +778,110 @@ __device__ __forceinline__ void run_chains(const RunArgs& A, const RunOp* __rest
     }
   }
   // incoming accumulator of this slice = (maps of all earlier slices)(acc0)
-  E acc = w_load<PP>(w, seg.acc_w);
+  E acc = w_load<PP, D>(w, seg.acc_w);
   {
     const E pm = up(M, 1), pv = up(V, 1);
     if (t > 0) acc = acc * pm + pv;
   }
   for (uint32_t i = i0; i < i1; ++i) {
     const RunOp op = steps[seg.first + i];
-    const E a = w_load<PP>(w, op.a), c = w_load<PP>(w, op.c);
+    const E a = w_load<PP, D>(w, op.a), c = w_load<PP, D>(w, op.c);
     acc = acc * b + c - a;
-    w_store<PP>(w, op.out, acc);
-    uint4* dst = reinterpret_cast<uint4*>(A.alu_values + (size_t)op.rec * 16);
-    dst[0] = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
-    dst[1] = make_uint4(b.c[0].v, b.c[1].v, b.c[2].v, b.c[3].v);
-    dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
-    dst[3] = make_uint4(acc.c[0].v, acc.c[1].v, acc.c[2].v, acc.c[3].v);
+    w_store<PP, D>(w, op.out, acc);
+    rec_store<PP, D>(A.alu_values, op.rec, 0, a);
+    rec_store<PP, D>(A.alu_values, op.rec, 1, b);
+    rec_store<PP, D>(A.alu_values, op.rec, 2, c);
+    rec_store<PP, D>(A.alu_values, op.rec, 3, acc);
   }
 }
 
 // One WIDE level of the schedule in one launch, longest-running blocks first: a Poseidon2
 // permutation segment per 16 lanes, then a short Horner chain per wave, then one light op per lane.
-template <class PP>
+template <class PP, int D = 4>
 __global__ void __launch_bounds__(kBlock)
 k_run_level(RunArgs A, uint32_t p2_begin, uint32_t n_p2, uint32_t p2_blocks, const RunOp* __restrict__ chain_steps,
             const RunSchedule::ChainSeg* __restrict__ chains, uint32_t n_chains, uint32_t chain_blocks,
             uint32_t light_begin, uint32_t n_light) {
   if (blockIdx.x < p2_blocks) {
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    const bool live = (g >> 4) < n_p2;
-    run_p2_segment<PP>(A, live ? A.p2segs[p2_begin + (g >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(g & 15), live);
+    if constexpr (D == 4) {  // permutation rows exist in D = 4 circuits only (validate_circuit)
+      const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+      const bool live = (g >> 4) < n_p2;
+      run_p2_segment<PP>(A, live ? A.p2segs[p2_begin + (g >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(g & 15), live);
+    }
     return;
   }
   if (blockIdx.x < p2_blocks + chain_blocks) {
-    run_chains<PP>(A, chain_steps, chains, n_chains, blockIdx.x - p2_blocks);
+    run_chains<PP, D>(A, chain_steps, chains, n_chains, blockIdx.x - p2_blocks);
     return;
   }
   const uint32_t i = (blockIdx.x - p2_blocks - chain_blocks) * kBlock + threadIdx.x;
-  if (i < n_light) run_light_op<PP>(A, A.light[light_begin + i]);
+  if (i < n_light) run_light_op<PP, D>(A, A.light[light_begin + i]);
 }
 
 // Long chains: the same scan with a whole workgroup per chain - slices are folded per lane, combined
 // by a shuffle scan inside each wave, the sixteen wave totals by one more shuffle scan through LDS.
 constexpr int kLongChainBlock = 1024;
-template <class PP>
+template <class PP, int D = 4>
 __global__ void __launch_bounds__(kLongChainBlock)
 k_run_chains_block(RunArgs A, const RunOp* __restrict__ steps, const RunSchedule::ChainSeg* __restrict__ segs) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename CircuitExt<PP, D>::type;
   constexpr int kWaves = kLongChainBlock / 64;
-  __shared__ uint32_t s_m[kWaves][4], s_v[kWaves][4];
+  __shared__ uint32_t s_m[kWaves][D], s_v[kWaves][D];
   const RunSchedule::ChainSeg seg = segs[blockIdx.x];
   const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
   uint32_t* __restrict__ w = A.w;
-  const E b = w_load<PP>(w, seg.b_w);
+  const E b = w_load<PP, D>(w, seg.b_w);
   const uint32_t per = (seg.n + kLongChainBlock - 1) / kLongChainBlock;
   const uint32_t i0 = min(t * per, seg.n), i1 = min(i0 + per, seg.n);
   E M = E::one(), V = E::zero();
   for (uint32_t i = i0; i < i1; ++i) {
     const RunOp op = steps[seg.first + i];
-    V = V * b + w_load<PP>(w, op.c) - w_load<PP>(w, op.a);
+    V = V * b + w_load<PP, D>(w, op.c) - w_load<PP, D>(w, op.a);
     M = M * b;
   }
-  auto up = [&](const E& e, int d) { E r; for (int k = 0; k < 4; ++k) r.c[k] = F::raw(__shfl_up(e.c[k].v, d)); return r; };
+  auto up = [&](const E& e, int d) { E r; for (int k = 0; k < D; ++k) r.c[k] = F::raw(__shfl_up(e.c[k].v, d)); return r; };
   for (int d = 1; d < 64; d <<= 1) {  // inclusive scan inside the wave
     const E pm = up(M, d), pv = up(V, d);
     if ((int)lane >= d) { V = pv * M + V; M = pm * M; }
   }
   if (lane == 63)
-    for (int k = 0; k < 4; ++k) { s_m[wave][k] = M.c[k].v; s_v[wave][k] = V.c[k].v; }
+    for (int k = 0; k < D; ++k) { s_m[wave][k] = M.c[k].v; s_v[wave][k] = V.c[k].v; }
   __syncthreads();
   if (wave == 0) {  // inclusive scan of the wave totals, kept as EXCLUSIVE prefixes per wave
     E tm = E::one(), tv = E::zero();
     if (lane < kWaves)
-      for (int k = 0; k < 4; ++k) { tm.c[k] = F::raw(s_m[lane][k]); tv.c[k] = F::raw(s_v[lane][k]); }
+      for (int k = 0; k < D; ++k) { tm.c[k] = F::raw(s_m[lane][k]); tv.c[k] = F::raw(s_v[lane][k]); }
     for (int d = 1; d < kWaves; d <<= 1) {
       const E pm = up(tm, d), pv = up(tv, d);
       if ((int)lane >= d) { tv = pv * tm + tv; tm = pm * tm; }
     }
     const E em = up(tm, 1), ev = up(tv, 1);
     if (lane < kWaves)
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < D; ++k) {
         s_m[lane][k] = lane ? em.c[k].v : E::one().c[k].v;
         s_v[lane][k] = lane ? ev.c[k].v : 0u;
       }
   }
   __syncthreads();
   // incoming accumulator: acc0 through the earlier waves, then through the earlier lanes of this wave
-  E acc = w_load<PP>(w, seg.acc_w);
+  E acc = w_load<PP, D>(w, seg.acc_w);
   {
     E wm, wv;
-    for (int k = 0; k < 4; ++k) { wm.c[k] = F::raw(s_m[wave][k]); wv.c[k] = F::raw(s_v[wave][k]); }
+    for (int k = 0; k < D; ++k) { wm.c[k] = F::raw(s_m[wave][k]); wv.c[k] = F::raw(s_v[wave][k]); }
     acc = acc * wm + wv;
     const E pm = up(M, 1), pv = up(V, 1);
     if (lane > 0) acc = acc * pm + pv;
   }
   for (uint32_t i = i0; i < i1; ++i) {
     const RunOp op = steps[seg.first + i];
-    const E a = w_load<PP>(w, op.a), c = w_load<PP>(w, op.c);
+    const E a = w_load<PP, D>(w, op.a), c = w_load<PP, D>(w, op.c);
     acc = acc * b + c - a;
-    w_store<PP>(w, op.out, acc);
-    uint4* dst = reinterpret_cast<uint4*>(A.alu_values + (size_t)op.rec * 16);
-    dst[0] = make_uint4(a.c[0].v, a.c[1].v, a.c[2].v, a.c[3].v);
-    dst[1] = make_uint4(b.c[0].v, b.c[1].v, b.c[2].v, b.c[3].v);
-    dst[2] = make_uint4(c.c[0].v, c.c[1].v, c.c[2].v, c.c[3].v);
-    dst[3] = make_uint4(acc.c[0].v, acc.c[1].v, acc.c[2].v, acc.c[3].v);
+    w_store<PP, D>(w, op.out, acc);
+    rec_store<PP, D>(A.alu_values, op.rec, 0, a);
+    rec_store<PP, D>(A.alu_values, op.rec, 1, b);
+    rec_store<PP, D>(A.alu_values, op.rec, 2, c);
+    rec_store<PP, D>(A.alu_values, op.rec, 3, acc);
   }
 }
 
@@ -865,7 +893,7 @@ k_run_chains_block(RunArgs A, const RunOp* __restrict__ steps, const RunSchedule
 // one coalesced copy, so a level does not start with a cold HBM read of its own ops.
 constexpr int kNarrowBlock = 1024;
 constexpr uint32_t kNarrowLightCap = 1400;  // light-op records per chunk (56 KB of LDS)
-template <class PP>
+template <class PP, int D = 4>
 __global__ void __launch_bounds__(kNarrowBlock)
 k_run_levels_narrow(RunArgs A, const uint32_t* __restrict__ chunk_bounds, uint32_t n_chunks) {
   __shared__ RunOp s_light[kNarrowLightCap];
@@ -883,9 +911,13 @@ k_run_levels_narrow(RunArgs A, const uint32_t* __restrict__ chunk_bounds, uint32
     for (uint32_t l = l0; l < l1; ++l) {
       const uint32_t lb = A.light_off[l], nl = A.light_off[l + 1] - lb;
       const uint32_t pb = A.p2seg_off[l], np = A.p2seg_off[l + 1] - pb;
-      if (t < nl) run_light_op<PP>(A, s_light[lb - lb0 + t]);
-      const bool live = (t >> 4) < np;
-      if (__any(live)) run_p2_segment<PP>(A, live ? A.p2segs[pb + (t >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(t & 15), live);
+      if (t < nl) run_light_op<PP, D>(A, s_light[lb - lb0 + t]);
+      if constexpr (D == 4) {
+        const bool live = (t >> 4) < np;
+        if (__any(live)) run_p2_segment<PP>(A, live ? A.p2segs[pb + (t >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(t & 15), live);
+      } else {
+        (void)pb; (void)np;
+      }
       __syncthreads();
     }
   }
@@ -894,27 +926,29 @@ k_run_levels_narrow(RunArgs A, const uint32_t* __restrict__ chunk_bounds, uint32
 // witness[rows[i]] = values[i]  (set_public_inputs / set_private_inputs, runner.rs:83-122)
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
-k_run_scatter(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ values, size_t n, uint32_t* __restrict__ w) {
+k_run_scatter(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ values, size_t n, uint32_t* __restrict__ w,
+              uint32_t D) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n * 4) return;
-  w[(size_t)rows[i >> 2] * 4 + (i & 3)] = values[i];
+  if (i >= n * D) return;
+  w[(size_t)rows[i / D] * D + (i % D)] = values[i];
 }
 // out[i] = witness[rows[i]]  (PublicTraceBuilder, tables/public.rs:44-62)
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
-k_run_gather(const uint32_t* __restrict__ rows, size_t n, const uint32_t* __restrict__ w, uint32_t* __restrict__ out) {
+k_run_gather(const uint32_t* __restrict__ rows, size_t n, const uint32_t* __restrict__ w, uint32_t* __restrict__ out,
+             uint32_t D) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n * 4) return;
-  out[i] = w[(size_t)rows[i >> 2] * 4 + (i & 3)];
+  if (i >= n * D) return;
+  out[i] = w[(size_t)rows[i / D] * D + (i % D)];
 }
 // duplicates left behind by ALU deduplication take the value of their canonical witness
-template <class PP>
+template <class PP, int D = 4>
 __global__ void __launch_bounds__(kBlock)
 k_run_rewrite(const uint32_t* __restrict__ triples, size_t n, uint32_t* __restrict__ w, uint32_t* __restrict__ err) {
   size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const uint32_t dst = triples[3 * i], src = triples[3 * i + 1];
-  w_put<PP>(w, dst, w_load<PP>(w, src), triples[3 * i + 2] != 0, err, 0x1FFFFFFFu);
+  w_put<PP, D>(w, dst, w_load<PP, D>(w, src), triples[3 * i + 2] != 0, err, 0x1FFFFFFFu);
 }
 
 }  // namespace
@@ -955,7 +989,9 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   // Device-side preparation (prep_device.hip): the op list crosses PCIe once; preprocessed columns, ALU lane
   // schedule and execution schedule are built in HBM.  A circuit it flags (malformed, unclaimed private input,
   // a witness nobody sets ...) goes through the host restatement below, which raises the reference's error.
-  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr;  // read per call: the equality tests flip it
+  // (circuits of extension degree 1 / 5 take the host restatement: the device pass is written for D = 4)
+  const uint32_t ext_d = ctx->cfg.ext_degree;
+  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr || ext_d != 4;  // read per call: the equality tests flip it
   if (!host_prep) {
     prof_stage(ctx, "prep_device");
     DevPrep R;
@@ -985,10 +1021,10 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   h.public_rows.assign(d->public_rows, d->public_rows + d->n_public);
   h.private_rows.assign(d->private_input_rows, d->private_input_rows + d->n_private);
   h.rewrite.assign(d->witness_rewrite, d->witness_rewrite + 2 * d->n_rewrite);
-  validate_circuit(h);
+  validate_circuit(h, ext_d);
   for (auto& op : h.ops)
     if (op.kind == P3R_OP_CONST)
-      for (int k = 0; k < 4; ++k)
+      for (uint32_t k = 0; k < ext_d; ++k)
         if (h.ext_of(op)[k] >= PP::P) fail(P3R_EINVAL, "constant of witness %u is not canonical", op.out);
 
   // the execution schedule depends on the circuit alone (host vectors only, no device work): it is built
@@ -1001,7 +1037,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
 
   // CircuitProverData: preprocessed columns -> LDE + commitment (build_next_layer_prep)
   prof_stage(ctx, "prep_circuit_tables");
-  CircuitTables T = circuit_tables<PP>(h);
+  CircuitTables T = circuit_tables<PP>(h, ext_d);
   C->counts = T.counts;
   p3r_layer_desc ld{};
   ld.counts = T.counts;
@@ -1026,10 +1062,10 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   std::vector<uint32_t> const_vals;
   for (auto& r : S.light)
     if ((r.kind_flags & 0xFF) == P3R_OP_CONST)
-      for (int k = 0; k < 4; ++k) ext_m[r.ext_off + k] = Fp<PP>::from_canonical(S.dev_ext[r.ext_off + k]).v;
+      for (uint32_t k = 0; k < ext_d; ++k) ext_m[r.ext_off + k] = Fp<PP>::from_canonical(S.dev_ext[r.ext_off + k]).v;
   for (auto& op : h.ops)
     if (op.kind == P3R_OP_CONST)
-      for (int k = 0; k < 4; ++k) const_vals.push_back(Fp<PP>::from_canonical(h.ext_of(op)[k]).v);
+      for (uint32_t k = 0; k < ext_d; ++k) const_vals.push_back(Fp<PP>::from_canonical(h.ext_of(op)[k]).v);
   auto up = [&](DevBuf& b, const void* src, size_t bytes) {
     b.alloc(std::max<size_t>((bytes + 3) / 4, 1));
     if (bytes) P3R_HIP(copy_sync(ctx->stream, b.p, src, bytes, hipMemcpyHostToDevice));
@@ -1106,8 +1142,8 @@ std::unique_ptr<p3r_dinputs> circuit_inputs_upload(p3r_ctx* ctx, const p3r_circu
   const size_t n_p2 = C->counts.n_p2, n_pd = in->n_private_data;
   if (n_pd && (!in->private_data_op_ids || !in->private_data_siblings)) fail(P3R_EINVAL, "private data arrays are NULL");
   auto D = std::make_unique<p3r_dinputs>();
-  D->pub = upload_mont<PP>(ctx, in->public_values, C->n_public_rows * 4, "public_values");
-  D->priv = upload_mont<PP>(ctx, in->private_values, C->n_private_rows * 4, "private_values");
+  D->pub = upload_mont<PP>(ctx, in->public_values, C->n_public_rows * ctx->cfg.ext_degree, "public_values");
+  D->priv = upload_mont<PP>(ctx, in->private_values, C->n_private_rows * ctx->cfg.ext_degree, "private_values");
   D->sib = upload_mont<PP>(ctx, in->private_data_siblings, n_pd * 8, "private_data_siblings");
   D->slot.alloc(std::max<size_t>(n_p2, 1));
   P3R_HIP(hipMemsetAsync(D->slot.p, 0xFF, std::max<size_t>(n_p2, 1) * 4, ctx->stream));  // -1: no private data
@@ -1156,25 +1192,26 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
   auto T = std::make_unique<p3r_dtraces>();
   const auto& cn = C->counts;
   T->n_const = cn.n_const; T->n_public = cn.n_public; T->n_alu = cn.n_alu; T->n_recompose = cn.n_recompose;
-  DevBuf w((size_t)std::max<uint32_t>(C->witness_count, 1) * 4);
+  const uint32_t ext_d = ctx->cfg.ext_degree;
+  DevBuf w((size_t)std::max<uint32_t>(C->witness_count, 1) * ext_d);
   DevBuf err(1), p2_out(std::max<size_t>(n_p2, 1) * 16);
   const DevBuf &d_pub = in->pub, &d_priv = in->priv, &d_sib = in->sib, &d_slot = in->slot;
   P3R_HIP(hipMemsetAsync(err.p, 0xFF, 4, ctx->stream));
   if (C->n_public_rows)
-    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(C->n_public_rows * 4)), dim3(kBlock), 0, ctx->stream,
-                       C->d_public_rows.p, d_pub.p, C->n_public_rows, w.p);
+    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(C->n_public_rows * ext_d)), dim3(kBlock), 0, ctx->stream,
+                       C->d_public_rows.p, d_pub.p, C->n_public_rows, w.p, ext_d);
   if (C->n_private_rows)
-    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(C->n_private_rows * 4)), dim3(kBlock), 0, ctx->stream,
-                       C->d_private_rows.p, d_priv.p, C->n_private_rows, w.p);
+    hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(C->n_private_rows * ext_d)), dim3(kBlock), 0, ctx->stream,
+                       C->d_private_rows.p, d_priv.p, C->n_private_rows, w.p, ext_d);
   // trace buffers
-  T->const_values.alloc(std::max<size_t>(cn.n_const * 4, 1));
+  T->const_values.alloc(std::max<size_t>(cn.n_const * ext_d, 1));
   if (cn.n_const)
-    P3R_HIP(hipMemcpyAsync(T->const_values.p, C->d_const_values.p, cn.n_const * 16, hipMemcpyDeviceToDevice, ctx->stream));
-  T->public_values.alloc(std::max<size_t>(cn.n_public * 4, 1));
-  T->alu_values.alloc(std::max<size_t>(cn.n_alu * 16, 1));
+    P3R_HIP(hipMemcpyAsync(T->const_values.p, C->d_const_values.p, cn.n_const * ext_d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  T->public_values.alloc(std::max<size_t>(cn.n_public * ext_d, 1));
+  T->alu_values.alloc(std::max<size_t>(cn.n_alu * 4 * ext_d, 1));
   if (S.n_alu_records == 0)  // the dummy op of an empty table; otherwise every record is written by its op
     P3R_HIP(hipMemsetAsync(T->alu_values.p, 0, T->alu_values.n * 4, ctx->stream));
-  T->recompose_values.alloc(std::max<size_t>(cn.n_recompose * 4, 1));
+  T->recompose_values.alloc(std::max<size_t>(cn.n_recompose * ext_d, 1));
   uint32_t* p2_inputs = nullptr; uint8_t* p2_flags = nullptr; uint32_t* p2_seed = nullptr;
   size_t p2_h = 0;
   if (L->has_p2) {
@@ -1204,9 +1241,11 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     A.rc = ctx->rc.p; A.diag = ctx->p2_diag.p; A.err = err.p;
     A.light_off = C->d_light_off.p; A.p2seg_off = C->d_p2seg_off.p;
     A.p2segs = reinterpret_cast<const RunSchedule::P2Seg*>(C->d_p2segs.p);
+    dispatch_ext_degree<PP>((int)ext_d, [&](auto dc) {
+    constexpr int DD = decltype(dc)::value;
     for (const auto& seg : S.segments) {
       if (seg.narrow) {
-        hipLaunchKernelGGL(k_run_levels_narrow<PP>, dim3(1), dim3(kNarrowBlock), 0, ctx->stream, A,
+        hipLaunchKernelGGL((k_run_levels_narrow<PP, DD>), dim3(1), dim3(kNarrowBlock), 0, ctx->stream, A,
                            C->d_chunk_bounds.p + seg.chunk_begin, seg.n_chunks);
         continue;
       }
@@ -1219,17 +1258,18 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
       const uint32_t n_short = nc - n_long, cb = (n_short + kBlock / 64 - 1) / (kBlock / 64);
       // chains only read operands of lower levels, so they share the launch with the level's other ops
       if (lb + pb + cb)
-        hipLaunchKernelGGL(k_run_level<PP>, dim3(pb + cb + lb), dim3(kBlock), 0, ctx->stream, A, S.p2seg_off[l], np, pb,
+        hipLaunchKernelGGL((k_run_level<PP, DD>), dim3(pb + cb + lb), dim3(kBlock), 0, ctx->stream, A, S.p2seg_off[l], np, pb,
                            steps, segs + n_long, n_short, cb, S.light_off[l], nl);
       if (n_long)
-        hipLaunchKernelGGL(k_run_chains_block<PP>, dim3(n_long), dim3(kLongChainBlock), 0, ctx->stream, A, steps, segs);
+        hipLaunchKernelGGL((k_run_chains_block<PP, DD>), dim3(n_long), dim3(kLongChainBlock), 0, ctx->stream, A, steps, segs);
     }
     if (C->n_rewrite)
-      hipLaunchKernelGGL(k_run_rewrite<PP>, dim3(blocks_for(C->n_rewrite)), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((k_run_rewrite<PP, DD>), dim3(blocks_for(C->n_rewrite)), dim3(kBlock), 0, ctx->stream,
                          C->d_rewrite.p, C->n_rewrite, w.p, err.p);
+    });
     if (cn.n_public)
-      hipLaunchKernelGGL(k_run_gather<PP>, dim3(blocks_for(cn.n_public * 4)), dim3(kBlock), 0, ctx->stream,
-                         C->d_public_out.p, cn.n_public, w.p, T->public_values.p);
+      hipLaunchKernelGGL(k_run_gather<PP>, dim3(blocks_for(cn.n_public * ext_d)), dim3(kBlock), 0, ctx->stream,
+                         C->d_public_out.p, cn.n_public, w.p, T->public_values.p, ext_d);
     P3R_HIP(hipGetLastError());
   }
   if (deferred_err) {

@@ -310,6 +310,10 @@ struct Fp1 {
   friend P3R_HD Fp1 operator+(Fp1 a, Fp1 b) { Fp1 r; r.c[0] = a.c[0] + b.c[0]; return r; }
   friend P3R_HD Fp1 operator-(Fp1 a, Fp1 b) { Fp1 r; r.c[0] = a.c[0] - b.c[0]; return r; }
   friend P3R_HD Fp1 operator*(Fp1 a, Fp1 b) { Fp1 r; r.c[0] = a.c[0] * b.c[0]; return r; }
+  static P3R_HD Fp1 one() { Fp1 r; r.c[0] = F::one(); return r; }
+  static P3R_HD Fp1 from_base(F b) { Fp1 r; r.c[0] = b; return r; }
+  P3R_HD bool operator==(const Fp1& o) const { return c[0] == o.c[0]; }
+  P3R_HD Fp1 inv() const { Fp1 r; r.c[0] = c[0].inv(); return r; }
 };
 // Calls fn(std::integral_constant<int, D>) for the circuit extension degree d of a context: 1, 4, or 5 (KoalaBear).
 template <class PP, class Fn>
@@ -340,6 +344,38 @@ struct Fp5 {
     r.c[2] = F::dot2(a.c[0], b.c[2], a.c[1], b.c[1]) + a.c[2] * b.c[0] - c58 + c7;
     r.c[3] = F::dot2(a.c[0], b.c[3], a.c[1], b.c[2]) + F::dot2(a.c[2], b.c[1], a.c[3], b.c[0]) - c6 + c8;
     r.c[4] = F::dot2(a.c[0], b.c[4], a.c[1], b.c[3]) + F::dot2(a.c[2], b.c[2], a.c[3], b.c[1]) + a.c[4] * b.c[0] - c7;
+    return r;
+  }
+  static P3R_HD Fp5 one() { Fp5 r = zero(); r.c[0] = F::one(); return r; }
+  static P3R_HD Fp5 from_base(F b) { Fp5 r = zero(); r.c[0] = b; return r; }
+  P3R_HD bool operator==(const Fp5& o) const {
+    return c[0] == o.c[0] && c[1] == o.c[1] && c[2] == o.c[2] && c[3] == o.c[3] && c[4] == o.c[4];
+  }
+  // a^-1 (the circuit runner's backward Mul: rare): the columns of the multiplication-by-a matrix are a * x^j;
+  // Gauss-Jordan on [M | e_0] over the base field.  Zero has no inverse: the caller checks first.
+  P3R_HD Fp5 inv() const {
+    F m[5][6];
+    Fp5 col = *this, x = zero();
+    x.c[1] = F::one();
+    for (int j = 0; j < 5; ++j) {
+      for (int i = 0; i < 5; ++i) m[i][j] = col.c[i];
+      col = col * x;
+    }
+    for (int i = 0; i < 5; ++i) m[i][5] = i == 0 ? F::one() : F::zero();
+    for (int k = 0; k < 5; ++k) {
+      int piv = k;
+      while (piv < 4 && m[piv][k] == F::zero()) ++piv;
+      for (int j = 0; j < 6; ++j) { const F t = m[k][j]; m[k][j] = m[piv][j]; m[piv][j] = t; }
+      const F s = m[k][k].inv();
+      for (int j = 0; j < 6; ++j) m[k][j] = m[k][j] * s;
+      for (int i = 0; i < 5; ++i) {
+        if (i == k) continue;
+        const F f = m[i][k];
+        for (int j = 0; j < 6; ++j) m[i][j] = m[i][j] - f * m[k][j];
+      }
+    }
+    Fp5 r;
+    for (int i = 0; i < 5; ++i) r.c[i] = m[i][5];
     return r;
   }
 };

@@ -1327,9 +1327,6 @@ p3r_circuit* p3r_circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* desc, uint
   p3r_circuit* out = nullptr;
   guard(ctx, [&] {
     if (!desc || !commit_out) fail(P3R_EINVAL, "NULL argument");
-    // the device CircuitRunner computes in the D = 4 binomial extension; D = 5 layers enter at prove_all_tables
-    if (ctx->cfg.ext_degree != 4)
-      fail(P3R_EUNSUPPORTED, "UnsupportedDegree(%u): the circuit boundary runs D = 4 circuits", ctx->cfg.ext_degree);
     out = P3R_FIELD_CALL(ctx, circuit_create, ctx, desc, commit_out).release();
   });
   return out;

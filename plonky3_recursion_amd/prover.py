@@ -607,15 +607,15 @@ class PreparedCircuit:
         return view
 
     @staticmethod
-    def _inputs_struct(circuit: Circuit, inputs: CircuitInputs):
+    def _inputs_struct(circuit: Circuit, inputs: CircuitInputs, d: int = 4):
         t = _lib.P3rCircuitInputs()
         pub, t.public_values = _flat32(inputs.public_values)
         prv, t.private_values = _flat32(inputs.private_values)
-        # set_public_inputs / set_private_inputs length checks (runner.rs:84-90,107-113)
-        if pub.size != 4 * circuit.public_flat_len:
-            raise P3rError(-1, "PublicInputLengthMismatch { expected: %d, got: %d }" % (circuit.public_flat_len, pub.size // 4))
-        if prv.size != 4 * circuit.private_flat_len:
-            raise P3rError(-1, "PrivateInputLengthMismatch { expected: %d, got: %d }" % (circuit.private_flat_len, prv.size // 4))
+        # set_public_inputs / set_private_inputs length checks (runner.rs:84-90,107-113); d coefficients per input
+        if pub.size != d * circuit.public_flat_len:
+            raise P3rError(-1, "PublicInputLengthMismatch { expected: %d, got: %d }" % (circuit.public_flat_len, pub.size // d))
+        if prv.size != d * circuit.private_flat_len:
+            raise P3rError(-1, "PrivateInputLengthMismatch { expected: %d, got: %d }" % (circuit.private_flat_len, prv.size // d))
         ids, t.private_data_op_ids = _flat32(inputs.private_data_op_ids)
         sib, t.private_data_siblings = _flat32(inputs.private_data_siblings)
         if sib.size != 8 * ids.size:
@@ -632,7 +632,7 @@ class PreparedCircuit:
         if isinstance(inputs, ResidentInputs):
             h = self.ctx.ptr(self.ctx.lib.p3r_circuit_run_resident(self.ctx.h, self.h, inputs.h))
         else:
-            t, keep = self._inputs_struct(self.circuit, inputs)
+            t, keep = self._inputs_struct(self.circuit, inputs, self.ctx.ext_degree)
             h = self.ctx.ptr(self.ctx.lib.p3r_circuit_run(self.ctx.h, self.h, C.byref(t)))
         return ResidentTraces._adopt(self.ctx, self.circuit_prover_data, h)
 
@@ -641,7 +641,7 @@ class PreparedCircuit:
         flags = 1 if canonical_field_encoding else 0
         if isinstance(inputs, ResidentInputs):
             return self.ctx._proof_call(self.ctx.lib.p3r_prove_next_layer_resident, self.ctx.h, self.h, inputs.h, flags)
-        t, keep = self._inputs_struct(self.circuit, inputs)
+        t, keep = self._inputs_struct(self.circuit, inputs, self.ctx.ext_degree)
         return self.ctx._proof_call(self.ctx.lib.p3r_prove_next_layer, self.ctx.h, self.h, C.byref(t), flags)
 
     def free(self):
@@ -665,7 +665,7 @@ class ResidentInputs:
 
     def __init__(self, prepared: PreparedCircuit, inputs: CircuitInputs):
         self.ctx = prepared.ctx
-        t, keep = PreparedCircuit._inputs_struct(prepared.circuit, inputs)
+        t, keep = PreparedCircuit._inputs_struct(prepared.circuit, inputs, prepared.ctx.ext_degree)
         self.h = self.ctx.ptr(self.ctx.lib.p3r_circuit_inputs_upload(self.ctx.h, prepared.h, C.byref(t)))
 
     def free(self):
@@ -689,10 +689,10 @@ class CircuitRunner:
         self._pd = {}
 
     def set_public_inputs(self, values):
-        self._inputs.public_values = np.asarray(values, dtype=np.uint32).reshape(-1, 4)
+        self._inputs.public_values = np.asarray(values, dtype=np.uint32).reshape(-1, self.prepared.ctx.ext_degree)
 
     def set_private_inputs(self, values):
-        self._inputs.private_values = np.asarray(values, dtype=np.uint32).reshape(-1, 4)
+        self._inputs.private_values = np.asarray(values, dtype=np.uint32).reshape(-1, self.prepared.ctx.ext_degree)
 
     def set_private_data(self, op_id: int, sibling):
         if op_id in self._pd:

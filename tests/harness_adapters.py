@@ -47,9 +47,9 @@ def circuit_from_arrays(a) -> Circuit:
                    witness_rewrite=a["rewrite"].reshape(-1, 2))
 
 
-def circuit_inputs_from_arrays(a) -> CircuitInputs:
-    return CircuitInputs(public_values=a["in_public_values"].reshape(-1, 4),
-                         private_values=a["in_private_values"].reshape(-1, 4),
+def circuit_inputs_from_arrays(a, ext_degree=4) -> CircuitInputs:
+    return CircuitInputs(public_values=a["in_public_values"].reshape(-1, ext_degree),
+                         private_values=a["in_private_values"].reshape(-1, ext_degree),
                          private_data_op_ids=a["pd_op_ids"], private_data_siblings=a["pd_siblings"].reshape(-1, 8))
 
 

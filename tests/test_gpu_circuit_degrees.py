@@ -1,0 +1,101 @@
+"""GPU: the circuit boundary (prepare -> run on the device -> prove) for circuits of extension degree 1 and 5 -
+`CircuitBuilder<F>` and `CircuitBuilder<QuinticTrinomialExtensionField<KoalaBear>>` circuits over the primitive ops,
+the hints and Recompose.  The synthetic generator (its own arithmetic, harness/arith.h) supplies the op list AND the
+traces and preprocessed columns a sequential run must produce; the device's run, its preprocessed commitment and
+the proof bytes are compared with those and with the oracle proving the generator's traces.  Poseidon2 rows of such
+circuits are base-mode rows: their layers enter at the prove_all_tables boundary (tests/test_gpu_quintic.py,
+tests/test_base_field_circuits.py) and the circuit boundary refuses them."""
+import numpy as np
+import pytest
+
+import harness_lib
+import layer_lib
+
+pytestmark = pytest.mark.gpu
+
+FRI = dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+NO_P2 = harness_lib.NO_POSEIDON2
+
+
+def setup(oracle, field, ext_degree, log_h, flags, packing=None, **gen):
+    import plonky3_recursion_amd as p3r
+    import harness_adapters as wl
+    gen.setdefault("horner_chain_len", 16)
+    a = harness_lib.generate(field, log_h, seed=57 + log_h, flags=flags, ext_degree=ext_degree, **gen)
+    prm = layer_lib.params(**FRI)
+    ctx = p3r.Context(field=field, ext_degree=ext_degree, **FRI)
+    tp = p3r.TablePacking(**(packing or {})).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(a), p3r.FriRecursionBackend(),
+                                      p3r.ProveNextLayerParams(table_packing=tp))
+    return a, prm, ctx, cache, wl.circuit_inputs_from_arrays(a, ext_degree)
+
+
+CASES = [("koala-bear", 5, 7, NO_P2 | harness_lib.NO_RECOMPOSE, None),
+         ("koala-bear", 5, 9, NO_P2 | harness_lib.NO_RECOMPOSE, dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3)),
+         ("koala-bear", 5, 10, NO_P2 | harness_lib.NO_RECOMPOSE, dict(alu_lanes=4, horner_packed_steps=5)),
+         ("koala-bear", 1, 8, NO_P2 | harness_lib.NO_RECOMPOSE, None),
+         ("baby-bear", 1, 9, NO_P2 | harness_lib.NO_RECOMPOSE, dict(alu_lanes=1, horner_packed_steps=2)),
+         ("koala-bear", 5, 7, NO_P2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC, None),
+         # + Recompose ops (D base-field witnesses packed into one element)
+         ("koala-bear", 5, 8, NO_P2, dict(recompose_lanes=2)),
+         ("baby-bear", 1, 7, NO_P2, None)]
+
+
+@pytest.mark.parametrize("field,ext_degree,log_h,flags,packing", CASES)
+def test_device_runner_for_base_field_and_quintic_circuits(oracle, field, ext_degree, log_h, flags, packing):
+    import plonky3_recursion_amd as p3r
+    a, prm, ctx, cache, inputs = setup(oracle, field, ext_degree, log_h, flags, packing, horner_chain_len=200 if log_h >= 10 else 16)
+    pc = cache.prepared_circuit
+    assert not pc.prepared_on_device       # circuits of degree 1 / 5 take the host restatement of the preparation
+    assert [pc.circuit_prover_data.rows[k] for k in ("const", "public", "alu", "poseidon2", "recompose")] == \
+        [int(x) for x in a["counts"][:5]]
+    res = pc.run(inputs)
+    assert np.array_equal(res.download("const_values").reshape(-1), a["const_values"])
+    assert np.array_equal(res.download("public_values").reshape(-1), a["public_values"])
+    got = res.download("alu_values")
+    assert np.array_equal(got.reshape(-1), a["alu_values"]), np.argwhere(got.reshape(-1) != a["alu_values"])[:4]
+    assert np.array_equal(res.download("recompose_values").reshape(-1), a["recompose_values"])
+    # the commitment binds the preprocessed columns derived from the op list: bus roles, multiplicities, indices x D
+    L = layer_lib.OracleLayer(oracle, field, a, prm, packing=dict(packing or {}, ext_degree=ext_degree))
+    assert np.array_equal(pc.circuit_prover_data.preprocessed_commitment, L.prep_commit())
+    out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=inputs), ctx, p3r.FriRecursionBackend(),
+                               p3r.ProveNextLayerParams(table_packing=pc.packing), prep=cache)
+    proof = L.prove()
+    assert out.proof.proof == proof and pc.prove(inputs) == proof
+    assert out.proof.ext_degree == ext_degree and out.proof.alu_quintic_trinomial == (ext_degree == 5)
+    cache.prover.verify_all_tables(out.proof)
+    res.free()
+    pc.free()
+    ctx.close()
+
+
+def test_quintic_division_by_zero_and_conflict_are_reported(oracle):
+    """The runner's error paths over Fp5: a backward Mul through a zero divisor, and a public input that contradicts
+    what an op computes (WitnessConflict)."""
+    import plonky3_recursion_amd as p3r
+    a, prm, ctx, cache, inputs = setup(oracle, "koala-bear", 5, 7, NO_P2 | harness_lib.NO_RECOMPOSE)
+    pc = cache.prepared_circuit
+    pub = inputs.public_values.copy()
+    pub[:, 4] = (pub[:, 4].astype(np.uint64) + 1) % 0x7F000001     # the top coefficient of every public input
+    bad = p3r.CircuitInputs(public_values=pub, private_values=inputs.private_values)
+    try:
+        res = pc.run(bad)
+    except p3r.P3rError as e:
+        assert "WitnessConflict" in str(e) or "DivisionByZero" in str(e)
+    else:
+        # no op re-derives a public input in this draw: the run goes through, with different traces
+        assert not np.array_equal(res.download("alu_values").reshape(-1), a["alu_values"])
+        res.free()
+    pc.free()
+    ctx.close()
+
+
+def test_poseidon2_rows_of_a_quintic_circuit_are_refused(oracle):
+    import plonky3_recursion_amd as p3r
+    import harness_adapters as wl
+    a4 = harness_lib.generate("koala-bear", 6, seed=3, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+    ctx = p3r.Context(field="koala-bear", ext_degree=5, **FRI)
+    tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    with pytest.raises(p3r.P3rError):
+        p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a4), tp)
+    ctx.close()

@@ -139,10 +139,7 @@ def test_what_a_quintic_context_refuses(oracle):
     prep4 = wl.circuit_prep_from_arrays(arrs4)
     with pytest.raises(p3r.P3rError, match="ext_degree 5"):
         pv.build_next_layer_prep(ctx, prep4, pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
-    # the circuit boundary runs D = 4 circuits
     arrs5 = harness_lib.generate("koala-bear", 6, seed=1, horner_chain_len=12, flags=PRIMITIVE, ext_degree=5)
-    with pytest.raises(p3r.P3rError, match="UnsupportedDegree"):
-        pv.PreparedCircuit(ctx, wl.circuit_from_arrays(arrs5), tp)
     # D = 4 shaped values under a D = 5 context
     cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs5, ext_degree=5), pv.FriRecursionBackend(),
                                      pv.ProveNextLayerParams(table_packing=tp))
