@@ -361,8 +361,10 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
           in[p.bit ? 8 + i : i] = digest[i];
           in[p.bit ? i : 8 + i] = rf();   // sibling: private data
         }
-        if (p.new_start && p.bit)
-          for (int i = 0; i < 8; ++i) { in_ctl[8 + i] = in_ctl[i]; in_idx[8 + i] = in_idx[i]; in_ctl[i] = 0; in_idx[i] = 0; }
+        // (the preprocessed row names the op's input SLOTS, 0..7 for the leaf digest, whatever the direction bit:
+        // executor.rs preprocess_inputs; the swap happens on the values)
+        pd_ids.push_back(next_npo_id);
+        for (int i = 0; i < 8; ++i) pd_sib.push_back(in[p.bit ? i : 8 + i].to_canonical());
       }
       for (int i = 0; i < 16; ++i) { p2_inputs.push_back(in[i].to_canonical()); state[i] = in[i]; }
       p2_permute<PP>(state, rc_canonical);
@@ -372,9 +374,12 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
       p2_absorb.push_back(tag);
       for (int i = 0; i < 16; ++i) { p2_in_ctl.push_back(in_ctl[i]); p2_in_idx.push_back(in_idx[i]); }
       const bool onto_public = !p.merkle && last_of_chain && rng.unit() < 0.2;
+      uint32_t row_out[8];
       for (int l = 0; l < 8; ++l) {
+        row_out[l] = NO_W;
         if (last_of_chain && rng.unit() < 0.6) {
           const uint32_t w = create(E::from_base(state[l]));
+          row_out[l] = w;
           if (onto_public) {
             // a Public op already defined this witness with the same value: the output is a reader on the bus
             push_op(C_PUBLIC, 0, 0, 0, w, (uint32_t)public_w.size(), {});
@@ -393,6 +398,14 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
         }
       }
       p2_acc_idx.push_back(en ? (uint32_t)acc_wid[r] : 0u);
+      // the op: ext = [in0..in15, mmcs_index_sum, mmcs_bit, n_out = 8, out0..out7], b = absorb_len (include/p3r.h)
+      std::vector<uint32_t> ext(19 + 8, NO_W);
+      for (int i = 0; i < 16; ++i) if (in_ctl[i]) ext[i] = in_idx[i];
+      if (en) ext[16] = (uint32_t)acc_wid[r];
+      if (p.merkle) ext[17] = p.bit ? 1u : 0u;   // the zero / one constant witnesses
+      ext[18] = 8;
+      for (int l = 0; l < 8; ++l) ext[19 + l] = row_out[l];
+      push_op(C_P2, next_npo_id++, tag, 0, 0, (p.new_start ? 1u : 0u) | (p.merkle ? 2u : 0u), ext);
     }
   }
 

@@ -68,9 +68,8 @@ typedef struct p3r_config {
                                 * tests.rs:844-1029).  Under D = 1 / D = 5 values are n x D / n x 4D, witness indices in
                                 * the preprocessed columns are scaled by D and the Poseidon2 table is the compact-D1
                                 * one (p3r_layer_desc).  The circuit boundary (p3r_circuit_create ...) runs such
-                                * circuits too - constants carry D coefficients, inputs are n x D - except for
-                                * Poseidon2 ops, which it refuses with P3R_EUNSUPPORTED (base-mode rows: hand the
-                                * layer over as Traces). */
+                                * circuits too: constants carry D coefficients, inputs are n x D, Poseidon2 ops are
+                                * base-mode permutations (p3r_op_kind). */
   uint32_t log_blowup;
   uint32_t max_log_arity;
   uint32_t cap_height;
@@ -429,7 +428,11 @@ enum p3r_op_kind {               /* circuit/src/ops/op.rs `Op`, AluOpKind */
   P3R_OP_HINT_BINARY_DECOMPOSITION = 8, /* a = input; ext = ext_len output witnesses (:1750-1810) */
   P3R_OP_POSEIDON2_PERM = 9,     /* a = NonPrimitiveOpId; aux = flags (bit 0 new_start, bit 1 merkle_path);
                                     ext = [in0..in3, mmcs_index_sum, mmcs_bit, n_out (2 or 4), out0..];
-                                    empty slots are P3R_NO_WITNESS (poseidon_perm/executor.rs:921-972) */
+                                    empty slots are P3R_NO_WITNESS (poseidon_perm/executor.rs:921-972).
+                                    Under ext_degree 1 / 5 the op is a base-mode permutation (KOALA_BEAR_D1_W16 /
+                                    BABY_BEAR_D1_W16, one witness per state element, executor.rs:600-700):
+                                    ext = [in0..in15, mmcs_index_sum, mmcs_bit, n_out (8 or 16), out0..],
+                                    b = absorb_len (the sponge length tag) */
   P3R_OP_RECOMPOSE = 10          /* a = NonPrimitiveOpId; out; ext = 4 coefficient witnesses
                                     (circuit/src/ops/recompose.rs:115-170) */
 };

@@ -33,6 +33,14 @@ struct CircuitTables {
   std::vector<uint32_t> const_prep, public_prep, alu_prep13, recompose_prep;
   std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_ctl_enabled, p2_in_ctl;
   std::vector<uint32_t> p2_input_indices, p2_out_ctl, p2_output_indices, p2_mmcs_index_sum_idx;
+  std::vector<uint8_t> p2_absorb_len;   // base-mode rows (circuits of degree 1 / 5)
+};
+
+// Poseidon2 op layout by circuit degree: D = 4 -> four input limbs of four elements, two (or four) output limbs;
+// otherwise base mode -> sixteen one-element slots, eight (or sixteen) outputs.  ext = [in.., index_sum, bit, n_out, out..]
+struct P2Shape {
+  uint32_t il, ol, ol_full;
+  explicit P2Shape(uint32_t D) : il(D == 4 ? 4 : 16), ol(D == 4 ? 2 : 8), ol_full(D == 4 ? 4 : 16) {}
 };
 
 struct HostCircuit {
@@ -82,16 +90,20 @@ inline void validate_circuit(const HostCircuit& c, uint32_t D = 4) {
         for (uint32_t k = 0; k < op.ext_len; ++k) wid(e[k], i, "hint output");
         break;
       case P3R_OP_POSEIDON2_PERM: {
-        // the permutation rows of a D = 1 / D = 5 circuit are base-mode rows (one witness per state element,
-        // executor.rs:600-700): their layers enter at the prove_all_tables boundary, the device runner has no executor
-        if (D != 4)
-          fail(P3R_EUNSUPPORTED, "op %zu: UnsupportedDegree(%u): the device runner executes Poseidon2 rows of D = 4 circuits", i, D);
-        if (op.ext_len < 7 || (e[6] != 2 && e[6] != 4) || op.ext_len != 7 + e[6])
-          fail(P3R_EINVAL, "op %zu: Poseidon2 perm expects 4 input limbs, mmcs_index_sum, mmcs_bit and 2 or 4 outputs", i);
-        for (uint32_t k = 0; k < 6; ++k) opt(e[k], i, "poseidon2 input");
-        for (uint32_t k = 0; k < e[6]; ++k) opt(e[7 + k], i, "poseidon2 output");
-        if ((op.aux & 2) && e[5] == kNoW)
+        const P2Shape sh(D);
+        const uint32_t hdr = sh.il + 3;   // inputs, mmcs_index_sum, mmcs_bit, n_out
+        if (op.ext_len < hdr || (e[hdr - 1] != sh.ol && e[hdr - 1] != sh.ol_full) || op.ext_len != hdr + e[hdr - 1])
+          fail(P3R_EINVAL, "op %zu: Poseidon2 perm expects %u input limbs, mmcs_index_sum, mmcs_bit and %u or %u outputs", i,
+               sh.il, sh.ol, sh.ol_full);
+        for (uint32_t k = 0; k < sh.il + 2; ++k) opt(e[k], i, "poseidon2 input");
+        for (uint32_t k = 0; k < e[hdr - 1]; ++k) opt(e[hdr + k], i, "poseidon2 output");
+        if ((op.aux & 2) && e[sh.il + 1] == kNoW)
           fail(P3R_EINVAL, "op %zu: mmcs_bit must be provided when merkle_path=true", i);
+        if (D != 4 && !(op.aux & 2))   // executor.rs:712-725
+          for (uint32_t k = sh.ol; k < sh.il; ++k)
+            if (e[k] != kNoW)
+              fail(P3R_EINVAL, "op %zu: NonPrimitiveOpLayoutMismatch: capacity input slots must be empty on compact D=1 sponge rows", i);
+        if (D != 4 && op.b > 255) fail(P3R_EINVAL, "op %zu: absorb_len %u does not fit the length tag", i, op.b);
         if (op.a >= c.ops.size()) fail(P3R_EINVAL, "op %zu: NonPrimitiveOpId(%u) out of range", i, op.a);
         break;
       }
@@ -133,6 +145,7 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
           if (!cp[w]) is_hint[w] = 1;
         }
   }
+  const P2Shape sh(D);
   // pass 1: who creates, who reads
   std::vector<AluRoles> roles;
   std::vector<const p3r_op*> consts, publics, alus, p2s, recs;
@@ -144,10 +157,10 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
       case P3R_OP_POSEIDON2_PERM: {
         const uint32_t* e = c.ext_of(op);
         const bool merkle = op.aux & 2;
-        for (int l = 0; l < 4; ++l)
+        for (uint32_t l = 0; l < sh.il; ++l)
           if (e[l] != kNoW && !merkle) reads[e[l]]++;  // Merkle rows name the limb without a bus read
-        for (int l = 0; l < 2; ++l) {
-          const uint32_t w = e[7 + l];
+        for (uint32_t l = 0; l < sh.ol; ++l) {
+          const uint32_t w = e[sh.il + 3 + l];
           if (w == kNoW) continue;
           if (defined[w]) { dup_p2[w] = 1; reads[w]++; } else defined[w] = 1;
         }
@@ -193,9 +206,9 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
     while (h < n) h <<= 1;
     for (size_t r = 0; r < n; ++r) {
       const uint32_t* e = c.ext_of(*p2s[r]);
-      if (e[4] == kNoW || !(p2s[r]->aux & 2)) continue;
+      if (e[sh.il] == kNoW || !(p2s[r]->aux & 2)) continue;
       const bool next_ns = r + 1 < n ? (p2s[r + 1]->aux & 1) : (h > n ? true : (p2s[0]->aux & 1));
-      if (next_ns) reads[e[4]]++;
+      if (next_ns) reads[e[sh.il]]++;
     }
   }
   // pass 2: signed multiplicities.  The tables are independent of each other once the read counts are
@@ -214,24 +227,27 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
     for (auto* op : publics) { T.public_prep.push_back(mult(op->out)); T.public_prep.push_back(scaled(op->out)); }
     const size_t np = p2s.size();
     T.p2_new_start.resize(np); T.p2_merkle_path.resize(np); T.p2_mmcs_ctl_enabled.resize(np);
-    T.p2_in_ctl.resize(4 * np); T.p2_input_indices.resize(4 * np);
-    T.p2_output_indices.resize(2 * np); T.p2_out_ctl.resize(2 * np); T.p2_mmcs_index_sum_idx.resize(np);
+    const uint32_t il = sh.il, ol = sh.ol;
+    T.p2_in_ctl.resize(il * np); T.p2_input_indices.resize(il * np);
+    T.p2_output_indices.resize(ol * np); T.p2_out_ctl.resize(ol * np); T.p2_mmcs_index_sum_idx.resize(np);
+    if (D != 4) T.p2_absorb_len.resize(np);
     for (size_t r = 0; r < np; ++r) {
       const p3r_op* op = p2s[r];
       const uint32_t* e = c.ext_of(*op);
       T.p2_new_start[r] = op->aux & 1;
       T.p2_merkle_path[r] = (op->aux >> 1) & 1;
-      T.p2_mmcs_ctl_enabled[r] = e[4] != kNoW;
-      for (int l = 0; l < 4; ++l) {
-        T.p2_in_ctl[4 * r + l] = e[l] != kNoW;
-        T.p2_input_indices[4 * r + l] = e[l] != kNoW ? e[l] : 0;
+      T.p2_mmcs_ctl_enabled[r] = e[il] != kNoW;
+      for (uint32_t l = 0; l < il; ++l) {
+        T.p2_in_ctl[il * r + l] = e[l] != kNoW;
+        T.p2_input_indices[il * r + l] = e[l] != kNoW ? e[l] : 0;
       }
-      for (int l = 0; l < 2; ++l) {
-        const uint32_t w = e[7 + l];
-        T.p2_output_indices[2 * r + l] = w != kNoW ? w : 0;
-        T.p2_out_ctl[2 * r + l] = w == kNoW ? 0 : dup_p2[w] ? NEG1 : mult(w);
+      for (uint32_t l = 0; l < ol; ++l) {
+        const uint32_t w = e[il + 3 + l];
+        T.p2_output_indices[ol * r + l] = w != kNoW ? w : 0;
+        T.p2_out_ctl[ol * r + l] = w == kNoW ? 0 : dup_p2[w] ? NEG1 : mult(w);
       }
-      T.p2_mmcs_index_sum_idx[r] = e[4] != kNoW ? e[4] : 0;
+      T.p2_mmcs_index_sum_idx[r] = e[il] != kNoW ? e[il] : 0;
+      if (D != 4) T.p2_absorb_len[r] = (uint8_t)op->b;
     }
     T.recompose_prep.reserve(2 * recs.size());
     for (auto* op : recs) {
@@ -260,7 +276,8 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
 
 // ---------------------------------------------------------------- execution schedule (host, once)
 // (RunOp / RunP2 / RunSchedule: run_schedule.h, shared with the device-side preparation)
-inline RunSchedule build_schedule(const HostCircuit& c) {
+inline RunSchedule build_schedule(const HostCircuit& c, uint32_t D = 4) {
+  const P2Shape sh(D);
   RunSchedule S;
   const uint32_t nw = c.witness_count;
   std::vector<uint8_t> set(nw, 0);
@@ -275,7 +292,7 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
   };
   struct Tmp { uint32_t level; bool is_p2; uint32_t idx; };
   std::vector<Tmp> order;
-  struct OpenP2 { uint32_t level; std::vector<RunP2> rows; };
+  struct OpenP2 { uint32_t level; std::vector<RunP2> rows; std::vector<RunP2B> rows_b; };
   std::vector<OpenP2> p2open;        // every segment; open_normal / open_merkle index the growing ones
   int open_normal = -1, open_merkle = -1;
   uint32_t n_p2_rows = 0;
@@ -397,41 +414,53 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
         r.rec = n_rec++;
         break;
       case P3R_OP_POSEIDON2_PERM: {
-        RunP2 q{};
         const bool new_start = op.aux & 1, merkle = op.aux & 2;
-        q.flags = (op.aux & 3) | (e[6] << 8);
-        q.op_idx = (uint32_t)i;
-        q.row = n_p2_rows++;
-        for (int l = 0; l < 4; ++l) { q.in[l] = e[l]; if (e[l] != kNoW) need(e[l]); }
-        q.idx_w = e[4]; if (e[4] != kNoW) need(e[4]);
-        q.bit_w = e[5]; if (e[5] != kNoW) need(e[5]);
-        q.prev_row = kNoW;
+        const uint32_t il = sh.il, n_out = e[il + 2];
+        RunP2 q{};
+        RunP2B qb{};
+        const uint32_t row = n_p2_rows++;
+        if (D == 4) {
+          q.flags = (op.aux & 3) | (n_out << 8);
+          q.op_idx = (uint32_t)i; q.row = row; q.prev_row = kNoW;
+          for (uint32_t l = 0; l < 4; ++l) q.in[l] = e[l];
+          q.idx_w = e[4]; q.bit_w = e[5];
+        } else {
+          qb.flags = (op.aux & 3) | (n_out << 8);
+          qb.op_idx = (uint32_t)i; qb.row = row; qb.prev_row = kNoW; qb.absorb_len = op.b;
+          for (uint32_t l = 0; l < 16; ++l) qb.in[l] = e[l];
+          qb.idx_w = e[16]; qb.bit_w = e[17];
+        }
+        for (uint32_t l = 0; l < il + 2; ++l) if (e[l] != kNoW) need(e[l]);
         int& open = merkle ? open_merkle : open_normal;
         if (!new_start) {
           const uint32_t prev = merkle ? last_merkle : last_normal;
           if (prev == kNoW) defer("Poseidon2ChainMissingPreviousState { operation_index: NonPrimitiveOpId(%u) }", op.a);
-          q.prev_row = prev;
+          q.prev_row = qb.prev_row = prev;
         }
-        for (uint32_t l = 0; l < 4; ++l) {
-          q.out[l] = l < e[6] ? e[7 + l] : kNoW;
-          if (q.out[l] == kNoW) continue;
+        for (uint32_t l = 0; l < sh.ol_full; ++l) {
+          const uint32_t ow = l < n_out ? e[il + 3 + l] : kNoW;
+          if (D == 4) q.out[l] = ow; else qb.out[l] = ow;
+          if (ow == kNoW) continue;
           bool earlier = false;
-          for (uint32_t j = 0; j < l; ++j) earlier |= q.out[j] == q.out[l];
-          if (earlier || put(q.out[l])) q.flags |= 1u << (4 + l); else written.push_back(q.out[l]);
+          for (uint32_t j = 0; j < l; ++j) earlier |= e[il + 3 + j] == ow;
+          if (earlier || put(ow)) { if (D == 4) q.flags |= 1u << (4 + l); else qb.check_mask |= 1u << l; }
+          else written.push_back(ow);
         }
         if (S.p2_row_of_op_id[op.a] != kNoW) fail(P3R_EINVAL, "duplicate NonPrimitiveOpId(%u)", op.a);
-        S.p2_row_of_op_id[op.a] = q.row;
+        S.p2_row_of_op_id[op.a] = row;
         S.p2_row_merkle.push_back(merkle);
         // `lvl` = highest level among the witnesses this row reads (or compares against)
-        if (!new_start && open >= 0 && q.prev_row != kNoW && lvl < p2open[open].level) {
-          p2open[open].rows.push_back(q);  // continues the open run of its mode
+        const bool chained = !new_start && open >= 0 && (D == 4 ? q.prev_row : qb.prev_row) != kNoW;
+        if (chained && lvl < p2open[open].level) {
+          if (D == 4) p2open[open].rows.push_back(q); else p2open[open].rows_b.push_back(qb);  // continues the open run of its mode
         } else {
           uint32_t seg_level = lvl + 1;
           if (!new_start && open >= 0) seg_level = std::max(seg_level, p2open[open].level + 1);
-          p2open.push_back({seg_level, {q}});
+          p2open.push_back({seg_level, {}, {}});
+          if (D == 4) p2open.back().rows.push_back(q); else p2open.back().rows_b.push_back(qb);
           open = (int)p2open.size() - 1;
         }
-        if (merkle) last_merkle = q.row; else last_normal = q.row;
+        if (merkle) last_merkle = row; else last_normal = row;
         for (uint32_t w : written) { set[w] = 1; wlevel[w] = p2open[open].level; }
         continue;
       }
@@ -482,8 +511,13 @@ inline RunSchedule build_schedule(const HostCircuit& c) {
     std::iota(by_level.begin(), by_level.end(), 0u);
     std::stable_sort(by_level.begin(), by_level.end(), [&](uint32_t x, uint32_t y) { return p2open[x].level < p2open[y].level; });
     for (uint32_t k : by_level) {
-      S.p2segs.push_back({(uint32_t)S.p2.size(), (uint32_t)p2open[k].rows.size()});
-      S.p2.insert(S.p2.end(), p2open[k].rows.begin(), p2open[k].rows.end());
+      if (D == 4) {
+        S.p2segs.push_back({(uint32_t)S.p2.size(), (uint32_t)p2open[k].rows.size()});
+        S.p2.insert(S.p2.end(), p2open[k].rows.begin(), p2open[k].rows.end());
+      } else {
+        S.p2segs.push_back({(uint32_t)S.p2b.size(), (uint32_t)p2open[k].rows_b.size()});
+        S.p2b.insert(S.p2b.end(), p2open[k].rows_b.begin(), p2open[k].rows_b.end());
+      }
     }
   }
   (void)n_pub;
@@ -557,6 +591,7 @@ __device__ __forceinline__ void w_put(uint32_t* __restrict__ w, uint32_t id, con
 struct RunArgs {
   const RunOp* light;   // sorted by level
   const RunP2* p2;
+  const RunP2B* p2b;    // base-mode rows (circuits of degree 1 / 5) instead
   uint32_t* w;          // witness table, [witness_count][4] Montgomery
   const uint32_t* ext;
   uint32_t* alu_values;
@@ -742,6 +777,76 @@ __device__ __forceinline__ void run_p2_segment(const RunArgs& A, RunSchedule::P2
   }
 }
 
+// The same for the base-mode permutation rows of a circuit of degree D = 1 / 5 (one witness per state element,
+// poseidon_perm/executor.rs:600-700 for sponge rows - the chained state, CTL inputs on any slot the op names, the
+// length tag added to the first capacity element - and :924-970 for Merkle rows, sixteen one-element limbs).
+// A witness is a D-word element; the permutation acts on its constant term (LiftPermToQuintic) and an output is
+// written back as a base-field element of the circuit's field.
+template <class PP, int D>
+__device__ __forceinline__ void run_p2_segment_base(const RunArgs& A, RunSchedule::P2Seg seg, int j, bool live) {
+  using F = Fp<PP>;
+  uint32_t* __restrict__ w = A.w;
+  uint32_t* err = A.err;
+  if (!live) seg.n = 0;
+  const CoopRc<PP> rcs = coop_load_rc<PP>(A.rc, j);
+  const F diag_j = F::raw(A.diag[j]);
+  F carried = F::zero();
+  for (uint32_t k = 0; k < seg.n; ++k) {
+    const RunP2B& q = A.p2b[seg.first + k];
+    const uint32_t flags = q.flags;
+    const bool new_start = flags & 1, merkle = flags & 2;
+    F s = F::zero();
+    if (!new_start && (!merkle || j < 8)) s = k ? carried : F::raw(A.p2_out[(size_t)q.prev_row * 16 + j]);
+    const int32_t slot = A.pd_slot[q.row];
+    if (merkle && slot >= 0 && j >= 8) s = F::raw(A.siblings[(size_t)slot * 8 + (j - 8)]);
+    const uint32_t in_w = q.in[j];
+    if (in_w != kNoW) s = F::raw(w[(size_t)in_w * D]);
+    // the prefix-free length tag of a sponge row (executor.rs:681-683)
+    if (!merkle && j == 8 && q.absorb_len) s = s + F::from_canonical(q.absorb_len);
+    bool bit = false;
+    if (q.bit_w != kNoW) {
+      const auto v = w_load<PP, D>(w, q.bit_w);
+      using E = typename CircuitExt<PP, D>::type;
+      if (v == E::one()) bit = true;
+      else if (!(v == E::zero()) && j == 0) run_error(err, q.op_idx, RUN_ERR_MMCS_BIT);
+    }
+    {
+      const uint32_t other = __shfl_xor(s.v, 8);
+      if (merkle && bit) s = F::raw(other);
+    }
+    A.p2_inputs[(size_t)j * A.p2_h + q.row] = s.v;
+    if (j == 0) {
+      A.p2_flags[q.row] = flags & 1;
+      A.p2_flags[A.p2_h + q.row] = (flags >> 1) & 1;
+      A.p2_flags[2 * A.p2_h + q.row] = bit;
+      uint32_t seed = 0;
+      if (q.idx_w != kNoW) {
+        const auto v = w_load<PP, D>(w, q.idx_w);
+        uint32_t high = 0;
+        for (int c = 1; c < D; ++c) high |= v.c[c].v;
+        if (high) run_error(err, q.op_idx, RUN_ERR_INDEX_SUM);
+        seed = v.c[0].v;
+      }
+      A.p2_seed[q.row] = seed;
+    }
+    s = coop_permute<PP>(s, j, diag_j, rcs);
+    carried = s;
+    A.p2_out[(size_t)q.row * 16 + j] = s.v;
+    const uint32_t n_out = (flags >> 8) & 31;
+    if ((uint32_t)j < n_out && q.out[j] != kNoW) {
+      uint32_t* slot_w = w + (size_t)q.out[j] * D;
+      if (q.check_mask & (1u << j)) {
+        bool same = slot_w[0] == s.v;
+        for (int c = 1; c < D; ++c) same = same && slot_w[c] == 0;
+        if (!same) run_error(err, q.op_idx, RUN_ERR_CONFLICT);
+      } else {
+        slot_w[0] = s.v;
+        for (int c = 1; c < D; ++c) slot_w[c] = 0;
+      }
+    }
+  }
+}
+
 // Horner chains of one level: one WAVE per chain evaluates acc_j = acc_{j-1}*b + (c_j - a_j) as an
 // affine scan - every lane folds its slice locally, the slice maps (b^len, value) are combined
 // with a shuffle scan across the wave, then every lane replays its slice from its incoming
@@ -803,11 +908,11 @@ k_run_level(RunArgs A, uint32_t p2_begin, uint32_t n_p2, uint32_t p2_blocks, con
             const RunSchedule::ChainSeg* __restrict__ chains, uint32_t n_chains, uint32_t chain_blocks,
             uint32_t light_begin, uint32_t n_light) {
   if (blockIdx.x < p2_blocks) {
-    if constexpr (D == 4) {  // permutation rows exist in D = 4 circuits only (validate_circuit)
-      const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-      const bool live = (g >> 4) < n_p2;
-      run_p2_segment<PP>(A, live ? A.p2segs[p2_begin + (g >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(g & 15), live);
-    }
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = (g >> 4) < n_p2;
+    const RunSchedule::P2Seg sg = live ? A.p2segs[p2_begin + (g >> 4)] : RunSchedule::P2Seg{0, 0};
+    if constexpr (D == 4) run_p2_segment<PP>(A, sg, (int)(g & 15), live);
+    else run_p2_segment_base<PP, D>(A, sg, (int)(g & 15), live);
     return;
   }
   if (blockIdx.x < p2_blocks + chain_blocks) {
@@ -912,11 +1017,11 @@ k_run_levels_narrow(RunArgs A, const uint32_t* __restrict__ chunk_bounds, uint32
       const uint32_t lb = A.light_off[l], nl = A.light_off[l + 1] - lb;
       const uint32_t pb = A.p2seg_off[l], np = A.p2seg_off[l + 1] - pb;
       if (t < nl) run_light_op<PP, D>(A, s_light[lb - lb0 + t]);
-      if constexpr (D == 4) {
-        const bool live = (t >> 4) < np;
-        if (__any(live)) run_p2_segment<PP>(A, live ? A.p2segs[pb + (t >> 4)] : RunSchedule::P2Seg{0, 0}, (int)(t & 15), live);
-      } else {
-        (void)pb; (void)np;
+      const bool live = (t >> 4) < np;
+      if (__any(live)) {
+        const RunSchedule::P2Seg sg = live ? A.p2segs[pb + (t >> 4)] : RunSchedule::P2Seg{0, 0};
+        if constexpr (D == 4) run_p2_segment<PP>(A, sg, (int)(t & 15), live);
+        else run_p2_segment_base<PP, D>(A, sg, (int)(t & 15), live);
       }
       __syncthreads();
     }
@@ -1029,7 +1134,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
 
   // the execution schedule depends on the circuit alone (host vectors only, no device work): it is built
   // on a second host thread while this one builds and commits the preprocessed columns
-  std::future<RunSchedule> sched_job = std::async(std::launch::async, [&h] { return build_schedule(h); });
+  std::future<RunSchedule> sched_job = std::async(std::launch::async, [&h, ext_d] { return build_schedule(h, ext_d); });
   struct JoinOnUnwind {  // an error below must not leave the worker reading `h` after it is gone
     std::future<RunSchedule>& f;
     ~JoinOnUnwind() { if (f.valid()) f.wait(); }
@@ -1049,6 +1154,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   ld.p2_mmcs_ctl_enabled = T.p2_mmcs_ctl_enabled.data(); ld.p2_in_ctl = T.p2_in_ctl.data();
   ld.p2_input_indices = T.p2_input_indices.data(); ld.p2_out_ctl = T.p2_out_ctl.data();
   ld.p2_output_indices = T.p2_output_indices.data(); ld.p2_mmcs_index_sum_idx = T.p2_mmcs_index_sum_idx.data();
+  if (ext_d != 4 && !T.p2_absorb_len.empty()) ld.p2_absorb_len = T.p2_absorb_len.data();
   prof_stage(ctx, "prep_layer_create");
   C->layer = layer_create<PP>(ctx, &ld, commit_out);
 
@@ -1071,7 +1177,8 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
     if (bytes) P3R_HIP(copy_sync(ctx->stream, b.p, src, bytes, hipMemcpyHostToDevice));
   };
   up(C->d_light, S.light.data(), S.light.size() * sizeof(RunOp));
-  up(C->d_p2, S.p2.data(), S.p2.size() * sizeof(RunP2));
+  if (ext_d == 4) up(C->d_p2, S.p2.data(), S.p2.size() * sizeof(RunP2));
+  else up(C->d_p2, S.p2b.data(), S.p2b.size() * sizeof(RunP2B));
   up(C->d_ext, ext_m.data(), ext_m.size() * 4);
   up(C->d_const_values, const_vals.data(), const_vals.size() * 4);
   up(C->d_public_rows, h.public_rows.data(), h.public_rows.size() * 4);
@@ -1093,7 +1200,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   }
   C->n_rewrite = S.rewrite_pairs.size() / 3;
   // the large host arrays are on the device now
-  S.light = {}; S.p2 = {}; S.chain_ops = {}; S.dev_ext = {}; S.p2_row_of_op_id = {}; S.p2_row_merkle = {};
+  S.light = {}; S.p2 = {}; S.p2b = {}; S.chain_ops = {}; S.dev_ext = {}; S.p2_row_of_op_id = {}; S.p2_row_merkle = {};
   prof_stage(ctx, nullptr);
   return C;
 }
@@ -1235,6 +1342,7 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     RunArgs A{};
     A.light = reinterpret_cast<const RunOp*>(C->d_light.p);
     A.p2 = reinterpret_cast<const RunP2*>(C->d_p2.p);
+    A.p2b = reinterpret_cast<const RunP2B*>(C->d_p2.p);
     A.w = w.p; A.ext = C->d_ext.p; A.alu_values = T->alu_values.p; A.rec_values = T->recompose_values.p;
     A.p2_inputs = p2_inputs; A.p2_h = p2_h; A.p2_flags = p2_flags; A.p2_seed = p2_seed; A.p2_out = p2_out.p;
     A.pd_slot = reinterpret_cast<const int32_t*>(d_slot.p); A.siblings = d_sib.p;

@@ -44,6 +44,16 @@ struct RunP2 {  // one Poseidon2 permutation, sixteen lanes
   uint32_t row, prev_row, op_idx;
 };
 
+// The same for a circuit of extension degree 1 / 5: a base-mode permutation (Poseidon2Config::*_D1_W16) has one
+// witness per state element - sixteen input slots, eight or sixteen outputs - and a sponge length tag
+// (circuit/src/ops/poseidon_perm/executor.rs:600-700).
+struct RunP2B {
+  uint32_t in[16], out[16], idx_w, bit_w;
+  uint32_t flags;       // bit 0 new_start, 1 merkle_path, 8-12 number of outputs
+  uint32_t check_mask;  // bit l: output l lands on a witness that already holds a value (compare)
+  uint32_t row, prev_row, op_idx, absorb_len;
+};
+
 enum : uint32_t { RUN_ERR_CONFLICT = 1, RUN_ERR_DIV0 = 2, RUN_ERR_MMCS_BIT = 3, RUN_ERR_INDEX_SUM = 4 };
 
 struct RunSchedule {
@@ -54,6 +64,7 @@ struct RunSchedule {
   // group with the state kept in registers (no launch, barrier or memory round trip per row)
   struct P2Seg { uint32_t first, n; };
   std::vector<RunP2> p2;                    // rows, segment by segment
+  std::vector<RunP2B> p2b;                  // the same for base-mode rows (circuits of degree 1 / 5): one of the two is empty
   std::vector<P2Seg> p2segs;                // sorted by level
   std::vector<uint32_t> light_off, p2seg_off;  // per level, size levels + 1
   std::vector<uint32_t> dev_ext;

@@ -1,10 +1,10 @@
 """GPU: the circuit boundary (prepare -> run on the device -> prove) for circuits of extension degree 1 and 5 -
-`CircuitBuilder<F>` and `CircuitBuilder<QuinticTrinomialExtensionField<KoalaBear>>` circuits over the primitive ops,
-the hints and Recompose.  The synthetic generator (its own arithmetic, harness/arith.h) supplies the op list AND the
-traces and preprocessed columns a sequential run must produce; the device's run, its preprocessed commitment and
-the proof bytes are compared with those and with the oracle proving the generator's traces.  Poseidon2 rows of such
-circuits are base-mode rows: their layers enter at the prove_all_tables boundary (tests/test_gpu_quintic.py,
-tests/test_base_field_circuits.py) and the circuit boundary refuses them."""
+`CircuitBuilder<F>` and `CircuitBuilder<QuinticTrinomialExtensionField<KoalaBear>>` circuits: the primitive ops, the
+hints, Recompose and base-mode Poseidon2 permutations (one witness per state element: sponge chains with their
+length tags, Merkle paths with private siblings).  The synthetic generator (its own arithmetic, harness/arith.h)
+supplies the op list AND the traces and preprocessed columns a sequential run must produce; the device's run, its
+preprocessed commitment and the proof bytes are compared with those and with the oracle proving the generator's
+traces."""
 import numpy as np
 import pytest
 
@@ -21,6 +21,8 @@ def setup(oracle, field, ext_degree, log_h, flags, packing=None, **gen):
     import plonky3_recursion_amd as p3r
     import harness_adapters as wl
     gen.setdefault("horner_chain_len", 16)
+    gen.setdefault("sponge_chain_len", 3)
+    gen.setdefault("merkle_depth", 5)
     a = harness_lib.generate(field, log_h, seed=57 + log_h, flags=flags, ext_degree=ext_degree, **gen)
     prm = layer_lib.params(**FRI)
     ctx = p3r.Context(field=field, ext_degree=ext_degree, **FRI)
@@ -38,7 +40,13 @@ CASES = [("koala-bear", 5, 7, NO_P2 | harness_lib.NO_RECOMPOSE, None),
          ("koala-bear", 5, 7, NO_P2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC, None),
          # + Recompose ops (D base-field witnesses packed into one element)
          ("koala-bear", 5, 8, NO_P2, dict(recompose_lanes=2)),
-         ("baby-bear", 1, 7, NO_P2, None)]
+         ("baby-bear", 1, 7, NO_P2, None),
+         # + base-mode Poseidon2 permutations
+         ("koala-bear", 5, 7, harness_lib.NO_RECOMPOSE, None),
+         ("koala-bear", 5, 9, 0, dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3)),
+         ("koala-bear", 1, 8, 0, None),
+         ("baby-bear", 1, 8, harness_lib.NO_RECOMPOSE, dict(alu_lanes=4, horner_packed_steps=6)),
+         ("koala-bear", 5, 10, harness_lib.INDEPENDENT_SPONGES, None)]
 
 
 @pytest.mark.parametrize("field,ext_degree,log_h,flags,packing", CASES)
@@ -55,6 +63,10 @@ def test_device_runner_for_base_field_and_quintic_circuits(oracle, field, ext_de
     got = res.download("alu_values")
     assert np.array_equal(got.reshape(-1), a["alu_values"]), np.argwhere(got.reshape(-1) != a["alu_values"])[:4]
     assert np.array_equal(res.download("recompose_values").reshape(-1), a["recompose_values"])
+    if a["counts"][3]:
+        assert np.array_equal(res.download("p2_input_values").reshape(-1), a["p2_inputs"])
+        assert np.array_equal(res.download("p2_flags"), a["p2_flags"].reshape(-1, 4)[:, :3])
+        assert np.array_equal(res.download("p2_mmcs_index_sum").reshape(-1), a["p2_mmcs_index_sum"])
     # the commitment binds the preprocessed columns derived from the op list: bus roles, multiplicities, indices x D
     L = layer_lib.OracleLayer(oracle, field, a, prm, packing=dict(packing or {}, ext_degree=ext_degree))
     assert np.array_equal(pc.circuit_prover_data.preprocessed_commitment, L.prep_commit())
@@ -90,7 +102,9 @@ def test_quintic_division_by_zero_and_conflict_are_reported(oracle):
     ctx.close()
 
 
-def test_poseidon2_rows_of_a_quintic_circuit_are_refused(oracle):
+def test_layouts_of_the_other_degree_are_refused(oracle):
+    """A D = 4 op list (four-limb permutations, four-coefficient constants) under a D = 5 context, and a sponge row
+    that feeds its capacity from a witness (NonPrimitiveOpLayoutMismatch, executor.rs:712-725)."""
     import plonky3_recursion_amd as p3r
     import harness_adapters as wl
     a4 = harness_lib.generate("koala-bear", 6, seed=3, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
@@ -98,4 +112,11 @@ def test_poseidon2_rows_of_a_quintic_circuit_are_refused(oracle):
     tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
     with pytest.raises(p3r.P3rError):
         p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a4), tp)
+    a5 = harness_lib.generate("koala-bear", 6, seed=3, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4,
+                              flags=harness_lib.NO_RECOMPOSE, ext_degree=5)
+    ops = a5["ops"].reshape(-1, 8)
+    r = next(i for i in range(len(ops)) if ops[i, 0] == 9 and not (ops[i, 5] & 2))      # a sponge permutation
+    a5["ext"][ops[r, 6] + 12] = 0                                                          # capacity slot 12 <- witness 0
+    with pytest.raises(p3r.P3rError, match="capacity input slots must be empty"):
+        p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a5), tp)
     ctx.close()
