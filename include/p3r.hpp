@@ -139,7 +139,7 @@ struct Circuit {  // flattened Circuit<EF>
 };
 
 struct CircuitInputs {
-  std::vector<uint32_t> public_values, private_values;                  // x 4 each
+  std::vector<uint32_t> public_values, private_values;                  // x D each (the context's ext_degree)
   std::vector<uint32_t> private_data_op_ids, private_data_siblings;     // siblings x 8
 };
 
@@ -433,12 +433,13 @@ class PreparedCircuit {
  private:
   p3r_circuit_inputs inputs_struct(const CircuitInputs& in) const {
     // set_public_inputs / set_private_inputs length checks (runner.rs:84-90,107-113)
-    if (in.public_values.size() != 4 * circuit_.public_rows.size())
+    const size_t d = ctx_->ext_degree();   // D coefficients per input
+    if (in.public_values.size() != d * circuit_.public_rows.size())
       throw Error(P3R_EINVAL, "PublicInputLengthMismatch { expected: " + std::to_string(circuit_.public_rows.size()) + ", got: " +
-                                  std::to_string(in.public_values.size() / 4) + " }");
-    if (in.private_values.size() != 4 * circuit_.private_input_rows.size())
+                                  std::to_string(in.public_values.size() / d) + " }");
+    if (in.private_values.size() != d * circuit_.private_input_rows.size())
       throw Error(P3R_EINVAL, "PrivateInputLengthMismatch { expected: " + std::to_string(circuit_.private_input_rows.size()) +
-                                  ", got: " + std::to_string(in.private_values.size() / 4) + " }");
+                                  ", got: " + std::to_string(in.private_values.size() / d) + " }");
     if (in.private_data_siblings.size() != 8 * in.private_data_op_ids.size())
       throw Error(P3R_EINVAL, "private_data_siblings must hold two extension limbs per op id");
     p3r_circuit_inputs s{};
