@@ -184,3 +184,39 @@ def test_gpu_base_field_layers_match_the_oracle(oracle, field, log_h, kw, packin
     res.free()
     cpd.free()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field", ["koala-bear", "baby-bear"])
+def test_gpu_config_0_base_layer_end_to_end(oracle, field):
+    """BASELINE config 0's base layer the way the example runs it, on the device: the `CircuitBuilder<F>` Fibonacci
+    circuit (n = 1000) is prepared (get_airs_and_degrees_with_prep::<_, F, 1>), RUN (runner.run()) and proved
+    (prove_all_tables) in one prove_next_layer call under ext_degree = 1; the proof is byte-identical to the oracle's
+    proof of the same D = 1 traces and the native verifier accepts it."""
+    import plonky3_recursion_amd as p3r
+    w, fib = fibonacci_base_workload(oracle, field)
+    circuit, inputs, fib2 = fib_lib.fibonacci_circuit(1000, oracle_lib.MODULUS[field], ext_degree=1)
+    assert fib == fib2
+    prm = layer_lib.params(**FRI)
+    packing = dict(public_lanes=1, alu_lanes=1, horner_packed_steps=2)   # TablePacking::new(1, 1)
+    L = layer_lib.OracleLayer(oracle, field, w, prm, packing=dict(packing, ext_degree=1))
+    ctx = p3r.Context(field=field, ext_degree=1, **FRI)
+    tp = p3r.TablePacking(**packing).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    pcirc = p3r.Circuit(circuit.witness_count, circuit.ops, circuit.ext, circuit.public_rows)
+    cache = p3r.build_next_layer_prep(ctx, pcirc, p3r.FriRecursionBackend(), p3r.ProveNextLayerParams(table_packing=tp))
+    pc = cache.prepared_circuit
+    assert np.array_equal(pc.circuit_prover_data.preprocessed_commitment, L.prep_commit())
+    pin = p3r.CircuitInputs(public_values=np.array([[fib]], dtype=np.uint32))
+    res = pc.run(pin)
+    assert np.array_equal(res.download("alu_values").reshape(-1), w["alu_values"])
+    res.free()
+    out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=pin), ctx, p3r.FriRecursionBackend(),
+                               p3r.ProveNextLayerParams(table_packing=tp), prep=cache)
+    assert out.proof.proof == L.prove()
+    assert out.proof.ext_degree == 1 and out.proof.rows == (2, 1, 999)
+    cache.prover.verify_all_tables(out.proof)
+    # the wrong expected_result is a WitnessConflict at run time
+    with pytest.raises(p3r.P3rError, match="WitnessConflict"):
+        pc.run(p3r.CircuitInputs(public_values=np.array([[(fib + 1) % oracle_lib.MODULUS[field]]], dtype=np.uint32)))
+    pc.free()
+    ctx.close()
