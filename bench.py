@@ -863,6 +863,51 @@ def main():
             res2.free()
             pc2.free()
             resident = pc = None
+        if not args.no_quintic and world == 1:
+            # BASELINE config 0's base layer (recursive_fibonacci --n 1000: CircuitBuilder<F>, D = 1 traces,
+            # TablePacking::new(1, 1)): prepare + run + prove on the device under ext_degree = 1, proof verified
+            if resident is not None:
+                resident.free()
+                pc.free()
+                resident = pc = None
+            P = p3r.MODULUS[field] if hasattr(p3r, "MODULUS") else {"koala-bear": 0x7F000001, "baby-bear": 0x78000001}[field]
+            NOW, n_fib = 0xFFFFFFFF, 1000
+            ops0, ext0 = [[0, 0, 0, NOW, 0, NOW, 0, 1], [1, 0, 0, NOW, 1, 0, 0, 0], [0, 0, 0, NOW, 2, NOW, 1, 1]], [0, 1]
+            fa, fb, a_w, b_w, nxt = 0, 1, 0, 2, 3
+            for i in range(2, n_fib + 1):
+                out_w = 1 if i == n_fib else nxt
+                ops0.append([2, a_w, b_w, NOW, out_w, NOW, 0, 0])
+                a_w, b_w, fa, fb, nxt = b_w, out_w, fb, (fa + fb) % P, nxt + 1
+            ctx0 = p3r.Context(field=field, ext_degree=1, **FRI)
+            tp0 = p3r.TablePacking(public_lanes=1, alu_lanes=1, horner_packed_steps=2).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+            circ0 = p3r.Circuit(nxt - 1, np.array(ops0, dtype=np.uint32), np.array(ext0, dtype=np.uint32), np.array([1], dtype=np.uint32))
+            t0 = time.perf_counter()
+            cache0 = p3r.build_next_layer_prep(ctx0, circ0, p3r.FriRecursionBackend(), p3r.ProveNextLayerParams(table_packing=tp0))
+            in0 = p3r.CircuitInputs(public_values=np.array([[fb]], dtype=np.uint32))
+            proof0 = cache0.prepared_circuit.prove(in0)
+            ctx0.sync()
+            first_ms = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            for _ in range(10):
+                cache0.prepared_circuit.prove(in0)
+            ctx0.sync()
+            ms0 = (time.perf_counter() - t0) / 10 * 1e3
+            try:
+                cache0.prover.verify_all_tables(cache0.prover.wrap_proof(proof0, cache0.prepared_circuit.circuit_prover_data))
+                ok0 = True
+            except Exception as e:
+                print(f"bench: config 0 base layer: proof rejected: {e}", file=sys.stderr)
+                ok0 = False
+            line["config0_fibonacci_base_layer"] = {
+                "ms_per_step": ms0, "steps": 10, "build_and_prove_ms": first_ms, "proof_verified": ok0, "proof_bytes": len(proof0),
+                "ext_degree": 1, "table_heights": cache0.prepared_circuit.circuit_prover_data.table_heights,
+                "workload": f"BASELINE config 0's base layer: the Fibonacci(n = {n_fib}) circuit over the base field (CircuitBuilder<F>, "
+                            f"Const 2 / Public 1 / ALU 999 Adds, TablePacking::new(1, 1)) prepared, run and proved on the device "
+                            f"(prove_next_layer, ext_degree = 1), {field}, the headline FRI parameters"}
+            proof_verified = proof_verified and ok0
+            line["proof_verified"] = proof_verified
+            cache0.prepared_circuit.free()
+            ctx0.close()
         if not args.no_quintic and world == 1 and field == "koala-bear":
             # SURVEY 8(f).4, D = 5: the table mix FriRecursionBackendD5 registers (backend/fri.rs:741-852) - Const, Public,
             # ALU over the quintic trinomial extension, compact-D1 Poseidon2, Recompose with coefficient lookups - at the
