@@ -46,13 +46,16 @@ CASES = [("koala-bear", 5, 7, NO_P2 | harness_lib.NO_RECOMPOSE, None),
          ("koala-bear", 5, 9, 0, dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3)),
          ("koala-bear", 1, 8, 0, None),
          ("baby-bear", 1, 8, harness_lib.NO_RECOMPOSE, dict(alu_lanes=4, horner_packed_steps=6)),
-         ("koala-bear", 5, 10, harness_lib.INDEPENDENT_SPONGES, None)]
+         ("koala-bear", 5, 10, harness_lib.INDEPENDENT_SPONGES, None),
+         # wide levels, long Horner chains (the workgroup scan), deep Merkle paths
+         ("koala-bear", 5, 13, 0, None)]
 
 
 @pytest.mark.parametrize("field,ext_degree,log_h,flags,packing", CASES)
 def test_device_runner_for_base_field_and_quintic_circuits(oracle, field, ext_degree, log_h, flags, packing):
     import plonky3_recursion_amd as p3r
-    a, prm, ctx, cache, inputs = setup(oracle, field, ext_degree, log_h, flags, packing, horner_chain_len=200 if log_h >= 10 else 16)
+    a, prm, ctx, cache, inputs = setup(oracle, field, ext_degree, log_h, flags, packing, horner_chain_len=200 if log_h >= 10 else 16,
+                                       merkle_depth=12 if log_h >= 13 else 5)
     pc = cache.prepared_circuit
     assert not pc.prepared_on_device       # circuits of degree 1 / 5 take the host restatement of the preparation
     assert [pc.circuit_prover_data.rows[k] for k in ("const", "public", "alu", "poseidon2", "recompose")] == \
