@@ -95,6 +95,62 @@ struct Fp1 {
   Fp1 inv() const { Fp1 r; r.c[0] = c[0].inv(); return r; }
 };
 
+// A binomial extension F[x] / (x^D - W) of any degree (the reference's circuit degrees 2, 6, 8:
+// batch_stark_prover/tests.rs:486 runs D = 8 over KoalaBear).  Inverse by Gauss-Jordan on the multiplication matrix.
+template <class PP, int D_, uint32_t W_>
+struct FpBin {
+  using F = Fp<PP>;
+  static constexpr int DEG = D_;
+  static constexpr uint32_t W = W_;
+  F c[D_];
+  static FpBin zero() { return FpBin(); }
+  static FpBin one() { FpBin r; r.c[0] = F::one(); return r; }
+  static FpBin from_base(F b) { FpBin r; r.c[0] = b; return r; }
+  friend FpBin operator+(FpBin a, const FpBin& b) { for (int i = 0; i < D_; ++i) a.c[i] = a.c[i] + b.c[i]; return a; }
+  friend FpBin operator-(FpBin a, const FpBin& b) { for (int i = 0; i < D_; ++i) a.c[i] = a.c[i] - b.c[i]; return a; }
+  friend FpBin operator*(const FpBin& a, const FpBin& b) {
+    FpBin r;
+    const F w = F::from_canonical(W_);
+    for (int i = 0; i < D_; ++i)
+      for (int j = 0; j < D_; ++j) {
+        const F t = a.c[i] * b.c[j];
+        if (i + j >= D_) r.c[i + j - D_] = r.c[i + j - D_] + w * t;
+        else r.c[i + j] = r.c[i + j] + t;
+      }
+    return r;
+  }
+  bool operator==(const FpBin& o) const {
+    for (int i = 0; i < D_; ++i) if (!(c[i] == o.c[i])) return false;
+    return true;
+  }
+  FpBin inv() const {
+    F m[D_][D_ + 1];
+    FpBin col = *this, xgen;
+    xgen.c[1] = F::one();
+    for (int j = 0; j < D_; ++j) {
+      for (int i = 0; i < D_; ++i) m[i][j] = col.c[i];
+      col = col * xgen;
+    }
+    for (int i = 0; i < D_; ++i) m[i][D_] = i == 0 ? F::one() : F::zero();
+    for (int k = 0; k < D_; ++k) {
+      int piv = k;
+      while (piv < D_ && m[piv][k] == F::zero()) ++piv;
+      if (piv == D_) return zero();  // zero, or a zero divisor when x^D - W is reducible
+      for (int j = 0; j <= D_; ++j) { F t = m[k][j]; m[k][j] = m[piv][j]; m[piv][j] = t; }
+      const F s = m[k][k].inv();
+      for (int j = 0; j <= D_; ++j) m[k][j] = m[k][j] * s;
+      for (int i = 0; i < D_; ++i) {
+        if (i == k) continue;
+        const F f = m[i][k];
+        for (int j = 0; j <= D_; ++j) m[i][j] = m[i][j] - f * m[k][j];
+      }
+    }
+    FpBin r;
+    for (int i = 0; i < D_; ++i) r.c[i] = m[i][D_];
+    return r;
+  }
+};
+
 // The degree-5 extension F[x] / (x^5 + x^2 - 1) of KoalaBear (QuinticTrinomialExtensionField; the circuit
 // field of the reference's D = 5 unit tests, circuit-prover/src/batch_stark_prover.rs tests.rs:844-1029 and
 // air/alu_air.rs:735-760): schoolbook product of degree 8, then x^5 = 1 - x^2 applied from the top.

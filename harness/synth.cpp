@@ -65,6 +65,8 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
               int merkle_depth, const uint32_t* rc_canonical, uint32_t flags) {
   using F = Fp<PP>;
   constexpr int D = E::DEG;  // circuit extension degree: witness indices on the bus are scaled by D
+  if ((D == 2 || D == 6 || D == 8) && !(flags & SYN_NO_POSEIDON2))
+    throw std::runtime_error("ext_degree 2 / 6 / 8: no Poseidon2 table, pass SYN_NO_POSEIDON2");
   const uint32_t P = PP::P;
   const size_t H = size_t(1) << log_h;
   Rng rng(seed);
@@ -634,7 +636,13 @@ void* syn_generate(int field, int log_h, uint64_t seed, int horner_chain_len, in
     if (ext_degree == 5 && field == 0) generate<KoalaBearParams, Fp5<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else if (ext_degree == 1 && field == 0) generate<KoalaBearParams, Fp1<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else if (ext_degree == 1 && field == 1) generate<BabyBearParams, Fp1<BabyBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
-    else if (ext_degree != 4) throw std::runtime_error("ext_degree must be 1, 4, or 5 over KoalaBear");
+    // binomial extensions of degree 2 / 6 / 8 with W = 3 (KoalaBear) / 11 (BabyBear): the W is data (tests pass the same
+    // value to the prover and the oracle); primitive tables and Recompose
+    else if (ext_degree == 8 && field == 0) generate<KoalaBearParams, FpBin<KoalaBearParams, 8, 3>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (ext_degree == 2 && field == 0) generate<KoalaBearParams, FpBin<KoalaBearParams, 2, 3>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (ext_degree == 6 && field == 1) generate<BabyBearParams, FpBin<BabyBearParams, 6, 11>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (ext_degree == 8 && field == 1) generate<BabyBearParams, FpBin<BabyBearParams, 8, 11>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
+    else if (ext_degree != 4) throw std::runtime_error("ext_degree must be 1, 4, 5 over KoalaBear, or 2 / 6 / 8 (koala-bear: 2, 8; baby-bear: 6, 8)");
     else if (field == 0) generate<KoalaBearParams, Fp4<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else if (field == 1) generate<BabyBearParams, Fp4<BabyBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else throw std::runtime_error("unknown field");

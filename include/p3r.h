@@ -62,7 +62,7 @@ typedef struct p3r_config {
   uint32_t field;              /* P3R_FIELD_* */
   uint32_t ext_degree;         /* circuit extension degree D of the traces: 1 (base-field circuits, CircuitBuilder<F>: the
                                 * base proof of recursive_fibonacci.rs:315-331; bus tuples (idx, v)), 4 (binomial
-                                * x^4 = W), or 5 over KoalaBear
+                                * x^4 = W), 2 / 6 / 8 (binomial x^D = ext_w, below), or 5 over KoalaBear
                                 * (quintic trinomial x^5 + x^2 - 1: QuinticTrinomialExtensionField, proved under the
                                 * same D = 4 STARK configuration as in circuit-prover/src/batch_stark_prover/
                                 * tests.rs:844-1029).  Under D = 1 / D = 5 values are n x D / n x 4D, witness indices in
@@ -102,6 +102,11 @@ typedef struct p3r_config {
    *                    lists the fields); NULL = the order read off the in-tree destructuring patterns. */
   const uint8_t* proof_layout;
   uint32_t proof_layout_len;
+  /* ABI version 4.  W of the binomial extension x^D = W for ext_degree 2, 6, 8 (canonical; BinomiallyExtendable<D>::W
+   * of the caller's field crate - the value the proof carries as w_binomial).  Such layers hold the primitive tables
+   * and Recompose (batch_stark_prover/tests.rs:486: test_koalabear_batch_stark_extension_field_d8) and enter at the
+   * prove_all_tables boundary.  0 for the other degrees: 4 uses the field's W (3 / 11), 1 and 5 have none. */
+  uint32_t ext_w;
 } p3r_config;
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */

@@ -46,11 +46,12 @@ struct FriParams {
 // ext_degree: the circuit extension degree of the traces - 4, or 5 for KoalaBear circuits over the quintic trinomial
 // extension (primitive tables, at the prove_all_tables boundary; include/p3r.h)
 inline p3r_config make_config(Field field, const FriParams& p, int device = 0, const std::vector<uint32_t>* rc = nullptr,
-                              uint32_t ext_degree = 4) {
+                              uint32_t ext_degree = 4, uint32_t ext_w = 0 /* W of x^D = W for ext_degree 2 / 6 / 8 */) {
   p3r_config c{};
   c.abi_version = P3R_ABI_VERSION;
   c.field = (uint32_t)field;
   c.ext_degree = ext_degree;
+  c.ext_w = ext_w;
   c.log_blowup = p.log_blowup; c.max_log_arity = p.max_log_arity; c.cap_height = p.cap_height;
   c.log_final_poly_len = p.log_final_poly_len; c.commit_pow_bits = p.commit_pow_bits;
   c.query_pow_bits = p.query_pow_bits; c.num_queries = p.num_queries;
@@ -62,9 +63,10 @@ inline p3r_config make_config(Field field, const FriParams& p, int device = 0, c
 // One per GPU, not thread-safe, one call in flight (the reference's RecursionOutput is !Send).
 class Context {
  public:
-  Context(Field field, const FriParams& fri, int device = 0, std::vector<uint32_t> poseidon2_rc = {}, uint32_t ext_degree = 4)
+  Context(Field field, const FriParams& fri, int device = 0, std::vector<uint32_t> poseidon2_rc = {}, uint32_t ext_degree = 4,
+          uint32_t ext_w = 0)
       : field_(field), fri_(fri), rc_(std::move(poseidon2_rc)) {
-    cfg_ = make_config(field, fri, device, rc_.empty() ? nullptr : &rc_, ext_degree);
+    cfg_ = make_config(field, fri, device, rc_.empty() ? nullptr : &rc_, ext_degree, ext_w);
     h_ = p3r_create(&cfg_);
     if (!h_) throw Error(P3R_ENODEV, p3r_last_error(nullptr));
   }
@@ -328,8 +330,10 @@ inline void verify_all_tables(const p3r_config& cfg, const BatchStarkProof& proo
   // EF = BinomialExtensionField<F, 4>: the field's W; EF = QuinticTrinomialExtensionField<F>: no W, the trinomial flag
   const bool quintic = cfg.ext_degree == 5;
   const uint32_t want_w = cfg.field == P3R_FIELD_KOALA_BEAR ? 3u : 11u;
-  const bool has_w = cfg.ext_degree == 4;   // D = 1 (the base field) and the quintic trinomial extension have none
-  if (has_w ? (!proof.w_binomial || *proof.w_binomial != want_w) : proof.w_binomial.has_value())
+  // D = 1 (the base field) and the quintic trinomial extension have no W; D = 2 / 6 / 8 carry the verifier's ext_w
+  const bool generic = cfg.ext_degree == 2 || cfg.ext_degree == 6 || cfg.ext_degree == 8;
+  const bool has_w = cfg.ext_degree == 4 || generic;
+  if (has_w ? (!proof.w_binomial || *proof.w_binomial != (generic ? cfg.ext_w : want_w)) : proof.w_binomial.has_value())
     throw Error(P3R_EINVAL, "BinomialWMismatch");
   if (proof.alu_quintic_trinomial != quintic) throw Error(P3R_EINVAL, "QuinticReductionMismatch");
   auto airs = proof.airs();
@@ -481,6 +485,7 @@ class BatchStarkProver {
     p.rows = {cpd.rows().n_const, cpd.rows().n_public, cpd.rows().n_alu};
     p.ext_degree = ctx_->ext_degree();
     if (p.ext_degree == 4) p.w_binomial = binomial_w(ctx_->field());
+    else if (p.ext_degree == 2 || p.ext_degree == 6 || p.ext_degree == 8) p.w_binomial = ctx_->config().ext_w;
     p.alu_quintic_trinomial = p.ext_degree == 5;
     const uint32_t k = tp.horner_packed_steps;
     const bool d4 = p.ext_degree == 4;   // D = 5 circuits carry the compact-D1 Poseidon2 table (62 preprocessed columns)

@@ -19,7 +19,7 @@ enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AI
 // alu_air.rs:115-134; its Poseidon2 table is the compact-D1 width-16 one, eval_poseidon2_d1 below; Recompose is D = 4 only).
 // The STARK's own challenge field stays the degree-4 binomial extension, as in the reference's D = 5 unit tests
 // (batch_stark_prover/tests.rs:844-1029: QuinticTrinomialExtensionField traces under config::koala_bear()).
-constexpr int kMaxD = 5;
+constexpr int kMaxD = 8;
 
 struct AirDesc {
   int kind = AIR_CONST;
@@ -27,6 +27,7 @@ struct AirDesc {
   int horner_k = 2;          // ALU: TablePacking::horner_packed_steps (packing.rs:10-27)
   int coeff_lookups = 0;     // Recompose: challenger.d() != D (backend/fri.rs:693-721)
   int D = 4;                 // extension degree of the circuit's element field
+  uint32_t W = 0;            // W of a binomial extension x^D = W; 0: the field's W of its degree-4 extension
 };
 
 // ---- widths (shape_golden.rs:32-68 pins the ALU formula) ----
@@ -121,10 +122,10 @@ void eval_recompose(const AirDesc& a, EvalCtx<FP, V>& b) {
 // F[x]/(x^5 + x^2 - 1) (ext_mul_quintic_trinomial, alu_air.rs:737-765: x^5 = 1 - x^2, x^6 = x - x^3,
 // x^7 = x^2 - x^4, x^8 = x^3 + x^2 - 1)
 template <class FP, class V>
-std::array<V, kMaxD> ext_mul(int D, const V* x, const V* y) {
+std::array<V, kMaxD> ext_mul(int D, const V* x, const V* y, uint32_t W = 0) {
   std::array<V, kMaxD> acc;
   for (auto& e : acc) e = EvalCtx<FP, V>::K(0);
-  if (D == 5) {
+  if (D == 5 && W == 0) {
     V c[9];
     for (auto& e : c) e = EvalCtx<FP, V>::K(0);
     for (int i = 0; i < 5; ++i)
@@ -137,7 +138,7 @@ std::array<V, kMaxD> ext_mul(int D, const V* x, const V* y) {
     acc[4] = c[4] - c[7];
     return acc;
   }
-  const V w = EvalCtx<FP, V>::K(FP::W);
+  const V w = EvalCtx<FP, V>::K(W ? W : FP::W);
   for (int i = 0; i < D; ++i)
     for (int j = 0; j < D; ++j) {
       V term = x[i] * y[j];
@@ -191,7 +192,7 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
     V active = zero - mult_a;
     V sel_mul = active - sel_bool - sel_muladd - sel_horner - sel_add;
     for (int i = 0; i < D; ++i) b.assert_zero(sel_add * (A[i] + B[i] - O[i]));                 // ADD
-    auto ab = ext_mul<FP, V>(D, A, B);
+    auto ab = ext_mul<FP, V>(D, A, B, a.W);
     for (int i = 0; i < D; ++i) b.assert_zero(sel_mul * (ab[i] - O[i]));                        // MUL
     b.assert_zero(sel_bool * A[0] * (A[0] - one));                                              // BOOL
     for (int i = 1; i < D; ++i) b.assert_zero(sel_bool * A[i]);
@@ -199,7 +200,7 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
     // HORNER_ACC
     V next_sel_horner = pn[4];
     const V *NA = ln, *NB = ln + D, *NC = ln + 2 * D, *NO = ln + 3 * D;
-    auto out_next_b = ext_mul<FP, V>(D, O, NB);
+    auto out_next_b = ext_mul<FP, V>(D, O, NB, a.W);
     if (lane == 0) {
       const V* next_int0 = N + extra_main;
       V any_cur = zero, any_next = zero, sel_ge3_next = zero;
@@ -209,11 +210,11 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
       for (int kk = 3; kk <= k_max; ++kk) sel_ge3_next = sel_ge3_next + PN[extra_prep + sel_k_idx(kk)];
       const int b_sq_base = ac_base + 2 * (k_max - 1) * D;
       const V* b_sq = L + b_sq_base; const V* b_sq_next = N + b_sq_base;
-      auto bb = ext_mul<FP, V>(D, B, B);
+      auto bb = ext_mul<FP, V>(D, B, B, a.W);
       for (int i = 0; i < D; ++i) b.assert_zero(any_cur * (b_sq[i] - bb[i]));
-      auto out_b_sq = ext_mul<FP, V>(D, O, b_sq_next);
-      auto c0_b_next = ext_mul<FP, V>(D, NC, NB);
-      auto a0_b_next = ext_mul<FP, V>(D, NA, NB);
+      auto out_b_sq = ext_mul<FP, V>(D, O, b_sq_next, a.W);
+      auto c0_b_next = ext_mul<FP, V>(D, NC, NB, a.W);
+      auto a0_b_next = ext_mul<FP, V>(D, NA, NB, a.W);
       const V* a1_next = N + ac_base; const V* c1_next = N + ac_base + D;
       for (int i = 0; i < D; ++i) {                                                              // 1) packed inter-row
         V poly = out_b_sq[i] + c0_b_next[i] - a0_b_next[i] + c1_next[i] - a1_next[i];
@@ -232,9 +233,9 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
           if (s + 1 < kk) {
             int off_sp1 = ac_base + 2 * s * D;
             const V* a_sp1 = L + off_sp1; const V* c_sp1 = L + off_sp1 + D;
-            auto int_b_sq = ext_mul<FP, V>(D, int_curr, b_sq);
-            auto c_s_b = ext_mul<FP, V>(D, c_s, B);
-            auto a_s_b = ext_mul<FP, V>(D, a_s, B);
+            auto int_b_sq = ext_mul<FP, V>(D, int_curr, b_sq, a.W);
+            auto c_s_b = ext_mul<FP, V>(D, c_s, B, a.W);
+            auto a_s_b = ext_mul<FP, V>(D, a_s, B, a.W);
             const V* target = (s + 2 >= kk) ? O : (L + extra_main + (slot + 1) * D);
             for (int i = 0; i < D; ++i) {
               V prod = int_b_sq[i] + c_s_b[i] - a_s_b[i] + c_sp1[i] - a_sp1[i];
@@ -243,7 +244,7 @@ void eval_alu(const AirDesc& a, EvalCtx<FP, V>& b) {
             if (!(s + 2 >= kk)) slot += 1;
             s += 2;
           } else {
-            auto int_b = ext_mul<FP, V>(D, int_curr, B);
+            auto int_b = ext_mul<FP, V>(D, int_curr, B, a.W);
             for (int i = 0; i < D; ++i) b.assert_zero(sel_kk * (int_b[i] + c_s[i] - a_s[i] - O[i]));
             s += 1;
           }

@@ -39,6 +39,8 @@ typedef struct orc_workload {
   /* 1: the Recompose table is the "recompose/coeff" variant (recompose_air.rs:196-226) - recompose_prep is
    * n x (2 + 2 D): [D*output_idx, out_mult, (D*coeff_idx_i, coeff_mult_i) x D]; recompose_values are n x D either way */
   uint32_t recompose_coeff_lookups;
+  /* W of the binomial extension x^D = W for ext_degree 2, 6, 8 (0 otherwise) */
+  uint32_t ext_w;
 } orc_workload;
 
 typedef struct orc_params {
@@ -114,27 +116,30 @@ struct Layer : LayerBase {
     const size_t mh = w.min_trace_height;
     const int D = w.ext_degree ? (int)w.ext_degree : 4;
     // 1 = base-field circuits (the base proof of recursive_fibonacci: CircuitBuilder<F>, tests.rs:433), 4, 5
-    if (D != 1 && D != 4 && D != 5) throw std::runtime_error("UnsupportedDegree");
+    const bool generic = D == 2 || D == 6 || D == 8;   // binomial x^D = ext_w: primitive tables + Recompose (tests.rs:486)
+    if (D != 1 && D != 4 && D != 5 && !generic) throw std::runtime_error("UnsupportedExtDegree");
+    if (generic && (w.ext_w == 0 || w.n_p2)) throw std::runtime_error("MissingWForExtension / no Poseidon2 table for this degree");
+    const uint32_t W = generic ? w.ext_w : 0;
     if (D == 5 && FP::P != KoalaBear::P) throw std::runtime_error("D = 5 is KoalaBear's quintic extension");
     const int public_lanes = w.n_public <= 1 ? 1 : (int)w.public_lanes;
     const int alu_lanes = w.n_alu <= 1 ? 1 : (int)w.alu_lanes;
     {
       Instance<FP> in;
-      in.air.kind = AIR_CONST; in.air.lanes = 1; in.air.D = D;
+      in.air.kind = AIR_CONST; in.air.lanes = 1; in.air.D = D; in.air.W = W;
       in.main = lanes_trace_to_matrix<FP>(vec(w.const_values, w.n_const * D), 1, mh, D);
       in.prep = lanes_prep_to_matrix<FP>(vec(w.const_prep, w.n_const * 2), 2, 1, mh);
       insts.push_back(std::move(in));
     }
     {
       Instance<FP> in;
-      in.air.kind = AIR_PUBLIC; in.air.lanes = public_lanes; in.air.D = D;
+      in.air.kind = AIR_PUBLIC; in.air.lanes = public_lanes; in.air.D = D; in.air.W = W;
       in.main = lanes_trace_to_matrix<FP>(vec(w.public_values, w.n_public * D), in.air.lanes, mh, D);
       in.prep = lanes_prep_to_matrix<FP>(vec(w.public_prep, w.n_public * 2), 2, in.air.lanes, mh);
       insts.push_back(std::move(in));
     }
     {
       Instance<FP> in;
-      in.air.kind = AIR_ALU; in.air.lanes = alu_lanes; in.air.horner_k = (int)w.horner_packed_steps; in.air.D = D;
+      in.air.kind = AIR_ALU; in.air.lanes = alu_lanes; in.air.horner_k = (int)w.horner_packed_steps; in.air.D = D; in.air.W = W;
       auto values = vec(w.alu_values, w.n_alu * 4 * D);
       auto prep = vec(w.alu_prep13, w.n_alu * 13);
       in.main = alu_trace_to_matrix<FP>(in.air, values, prep, mh);
@@ -184,7 +189,7 @@ struct Layer : LayerBase {
     }
     if (w.n_recompose > 0) {
       Instance<FP> in;
-      in.air.kind = AIR_RECOMPOSE; in.air.lanes = (int)w.recompose_lanes; in.air.D = D;
+      in.air.kind = AIR_RECOMPOSE; in.air.lanes = (int)w.recompose_lanes; in.air.D = D; in.air.W = W;
       in.air.coeff_lookups = w.recompose_coeff_lookups ? 1 : 0;
       const int plw = 2 + (in.air.coeff_lookups ? 2 * D : 0);
       in.main = lanes_trace_to_matrix<FP>(vec(w.recompose_values, w.n_recompose * D), in.air.lanes, mh, D);
@@ -288,7 +293,8 @@ int orc_verify_batch(int field, const uint32_t* rc, const orc_params* p, size_t 
         AirDesc a;
         a.kind = (int)airs4[4 * i]; a.lanes = (int)airs4[4 * i + 1]; a.horner_k = (int)airs4[4 * i + 2];
         a.coeff_lookups = (int)(airs4[4 * i + 3] & 0xFF);
-        a.D = (airs4[4 * i + 3] >> 8) ? (int)(airs4[4 * i + 3] >> 8) : 4;   // bits 8..: extension degree of the circuit (0 = 4)
+        a.D = ((airs4[4 * i + 3] >> 8) & 0xFF) ? (int)((airs4[4 * i + 3] >> 8) & 0xFF) : 4;   // bits 8..15: extension degree of the circuit (0 = 4)
+        a.W = a.D == 2 || a.D == 6 || a.D == 8 ? airs4[4 * i + 3] >> 16 : 0;                   // bits 16..: W of a generic binomial (small W only)
         shapes.push_back({a});
       }
       typename BatchProof<FP>::Cap cap(size_t(1) << p->cap_height);

@@ -164,14 +164,15 @@ template <class FP>
 struct FeX {
   using F = Fe<FP>;
   int D = 4;
-  std::array<F, 5> c{};
-  explicit FeX(int d = 4) : D(d) {}
+  uint32_t W = 0;   // binomial x^D = W; 0: the field's own rule for the degree (W of the quartic, the quintic trinomial)
+  std::array<F, 8> c{};
+  explicit FeX(int d = 4, uint32_t w = 0) : D(d), W(w) {}
   static FeX zero(int d) { return FeX(d); }
   friend FeX operator+(FeX a, const FeX& b) { for (int i = 0; i < a.D; ++i) a.c[i] += b.c[i]; return a; }
   friend FeX operator-(FeX a, const FeX& b) { for (int i = 0; i < a.D; ++i) a.c[i] -= b.c[i]; return a; }
   friend FeX operator*(const FeX& a, const FeX& b) {
-    FeX r(a.D);
-    if (a.D == 5) {
+    FeX r(a.D, a.W);
+    if (a.D == 5 && a.W == 0) {
       F t[9];
       for (int i = 0; i < 5; ++i)
         for (int j = 0; j < 5; ++j) t[i + j] += a.c[i] * b.c[j];
@@ -183,7 +184,7 @@ struct FeX {
       r.c[4] = t[4] - t[7];
       return r;
     }
-    const F w(FP::W);
+    const F w(a.W ? a.W : FP::W);
     for (int i = 0; i < a.D; ++i)
       for (int j = 0; j < a.D; ++j) {
         F t = a.c[i] * b.c[j];

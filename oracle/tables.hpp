@@ -144,8 +144,8 @@ bool alu_compute_schedule(const std::vector<Fe<FP>>& prep13, int lanes, int pack
 }
 
 template <class FP>
-FeX<FP> e4_at(const std::vector<Fe<FP>>& values, size_t op, int operand, int D) {
-  FeX<FP> e(D);
+FeX<FP> e4_at(const std::vector<Fe<FP>>& values, size_t op, int operand, int D, uint32_t W = 0) {
+  FeX<FP> e(D, W);
   for (int d = 0; d < D; ++d) e.c[d] = values[(op * 4 + operand) * D + d];
   return e;
 }
@@ -172,35 +172,35 @@ Matrix<FP> alu_trace_to_matrix(const AirDesc& a, const std::vector<Fe<FP>>& valu
       const auto& en = sched[pos];
       size_t base = row * width + lane * LW;
       if (en.kind == 0) {
-        for (int o = 0; o < 4; ++o) put(base + o * D, e4_at<FP>(values, en.first, o, D));
-        if (lane == 0) prev = e4_at<FP>(values, en.first, 3, D);
+        for (int o = 0; o < 4; ++o) put(base + o * D, e4_at<FP>(values, en.first, o, D, a.W));
+        if (lane == 0) prev = e4_at<FP>(values, en.first, 3, D, a.W);
       } else if (en.kind == 1) {
         int k = en.k;
-        for (int o = 0; o < 3; ++o) put(base + o * D, e4_at<FP>(values, en.first, o, D));
-        put(base + 3 * D, e4_at<FP>(values, en.first + k - 1, 3, D));
+        for (int o = 0; o < 3; ++o) put(base + o * D, e4_at<FP>(values, en.first, o, D, a.W));
+        put(base + 3 * D, e4_at<FP>(values, en.first + k - 1, 3, D, a.W));
         if (lane == 0) {
           size_t extra = row * width + (size_t)lanes * LW;
-          EF b = e4_at<FP>(values, en.first, 1, D), acc = prev;
+          EF b = e4_at<FP>(values, en.first, 1, D, a.W), acc = prev;
           int step = 0;
           for (int s = 0; s < num_int; ++s) {
             size_t i0 = en.first + step, i1 = i0 + 1;
             if (i1 < en.first + k) {
-              EF o0 = acc * b + e4_at<FP>(values, i0, 2, D) - e4_at<FP>(values, i0, 0, D);
-              acc = o0 * b + e4_at<FP>(values, i1, 2, D) - e4_at<FP>(values, i1, 0, D);
+              EF o0 = acc * b + e4_at<FP>(values, i0, 2, D, a.W) - e4_at<FP>(values, i0, 0, D, a.W);
+              acc = o0 * b + e4_at<FP>(values, i1, 2, D, a.W) - e4_at<FP>(values, i1, 0, D, a.W);
               step += 2;
             } else {
-              acc = acc * b + e4_at<FP>(values, i0, 2, D) - e4_at<FP>(values, i0, 0, D);
+              acc = acc * b + e4_at<FP>(values, i0, 2, D, a.W) - e4_at<FP>(values, i0, 0, D, a.W);
               step += 1;
             }
             put(extra + s * D, acc);
           }
           size_t ac_base = extra + num_int * D;
           for (int t = 1; t < k; ++t) {
-            put(ac_base + 2 * (t - 1) * D, e4_at<FP>(values, en.first + t, 0, D));
-            put(ac_base + 2 * (t - 1) * D + D, e4_at<FP>(values, en.first + t, 2, D));
+            put(ac_base + 2 * (t - 1) * D, e4_at<FP>(values, en.first + t, 0, D, a.W));
+            put(ac_base + 2 * (t - 1) * D + D, e4_at<FP>(values, en.first + t, 2, D, a.W));
           }
           put(ac_base + 2 * (k_max - 1) * D, b * b);
-          prev = e4_at<FP>(values, en.first + k - 1, 3, D);
+          prev = e4_at<FP>(values, en.first + k - 1, 3, D, a.W);
         }
       } else if (lane == 0) {
         prev = EF::zero(D);
@@ -208,7 +208,7 @@ Matrix<FP> alu_trace_to_matrix(const AirDesc& a, const std::vector<Fe<FP>>& valu
     }
   } else {
     for (size_t op = 0; op < n_ops; ++op)
-      for (int o = 0; o < 4; ++o) put((op / lanes) * width + (op % lanes) * LW + o * D, e4_at<FP>(values, op, o, D));
+      for (int o = 0; o < 4; ++o) put((op / lanes) * width + (op % lanes) * LW + o * D, e4_at<FP>(values, op, o, D, a.W));
   }
   pad_rows(m, min_height);
   return m;

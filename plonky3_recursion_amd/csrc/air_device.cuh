@@ -20,12 +20,12 @@ namespace p3r {
 
 enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4 };
 
-constexpr int kMaxExtD = 5;
+constexpr int kMaxExtD = 8;  // widest circuit extension: bus tuples hold at most 1 + kMaxExtD fields
 // compact-D1 Poseidon2 preprocessed row (poseidon-circuit-cols/src/preprocessed.rs:121-145), 62 columns:
 //   [0..8) in_ctl | 8 length tag | 9 cap_chain_enable | [10..18) rate sponge-chain sel | [18..26) rate Merkle-chain sel
 //   | [26..42) input idx | [42..50) output idx | [50..58) out_ctl | 58 mmcs idx | 59 mmcs_merkle_flag | 60 new_start
 //   | 61 merkle_path
-constexpr int kP2D1Hdr = 26, kP2D1Tail = 58, kP2D1PrepWidth = 62;  // widest circuit extension: bus tuples hold at most 1 + kMaxExtD fields
+constexpr int kP2D1Hdr = 26, kP2D1Tail = 58, kP2D1PrepWidth = 62;
 
 struct AirParams {
   int kind;
@@ -35,8 +35,11 @@ struct AirParams {
   int lookup_unpacked = 0;  // p3r_config.ext_choices & P3R_EXT_LOOKUP_UNPACKED
   // Circuit extension degree D of the table's witness values (p3r_config.ext_degree): 1 = base-field circuits,
   // 4 = binomial x^4 = W, 5 = KoalaBear quintic trinomial x^5 + x^2 - 1.  Bus tuples are (idx, v_0..v_{D-1}); the
-  // Poseidon2 table is the D4 width-16 one for D = 4 and the compact-D1 one (on a D-slot bus) otherwise.
+  // Poseidon2 table is the D4 width-16 one for D = 4 and the compact-D1 one (on a D-slot bus) for D = 1 / 5.
+  // D = 2, 6, 8: the binomial extension x^D = W with W = ext_w_mont (Montgomery word; p3r_config.ext_w), the
+  // primitive tables and Recompose.
   int ext_d = 4;
+  uint32_t ext_w_mont = 0;
 };
 
 // Row window over column-major main / preprocessed matrices of a common height.
@@ -73,9 +76,24 @@ P3R_HD V4<V> load4(G&& get, int col) { return loadD<4, V>(get, col); }
 // (ext_mul_quintic_trinomial, alu_air.rs:735-762: x^5 = 1 - x^2, x^6 = x - x^3, x^7 = x^2 - x^4,
 // x^8 = x^3 + x^2 - 1)
 template <class PP, int D, class V>
-P3R_HD VD<V, D> mulD(const VD<V, D>& a, const VD<V, D>& b) {
+P3R_HD VD<V, D> mulD(const VD<V, D>& a, const VD<V, D>& b, uint32_t w_mont = 0) {
   VD<V, D> r;
-  if constexpr (D == 1) {
+  if constexpr (D == 2 || D == 6 || D == 8) {
+    // generic binomial x^D = W (ext_mul_binomial, alu_air.rs:715-733), W a run-time value
+    const V W = Lift<V>::of(Fp<PP>::raw(w_mont));
+    V lo[D], hi[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { lo[k] = V::zero(); hi[k] = V::zero(); }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        if (i + j < D) lo[i + j] = lo[i + j] + a.c[i] * b.c[j];
+        else hi[i + j - D] = hi[i + j - D] + a.c[i] * b.c[j];
+      }
+#pragma unroll
+    for (int k = 0; k < D; ++k) r.c[k] = lo[k] + W * hi[k];
+  } else if constexpr (D == 1) {
     r.c[0] = a.c[0] * b.c[0];   // base-field circuits
   } else if constexpr (D == 4) {
     const V W = Lift<V>::of(Fp<PP>::from_canonical(PP::EXT_W));
@@ -162,7 +180,7 @@ P3R_HD void air_interactions(const AirParams& a, const View& v, Sink& sink) {
         t.c[0] = v.L(pc + 1);
         t.c[1] = t.c[2] = t.c[3] = F::zero();
         sink.add(v.PL(20), t, -(v.PL(21) * v.PN(22)));
-      } else {
+      } else if constexpr (D == 1 || D == 5) {
         // compact-D1 table on the D-slot witness bus (KoalaBearD1Width16WitnessBus5; air.rs:1721-1785): 8 rate
         // sends, 8 output receives, the accumulator send; tuples (idx, v, 0, ..)
         constexpr int pc = p2_perm_cols<PP>();
@@ -206,7 +224,7 @@ P3R_HD void alu_constraints(const AirParams& a, const View& v, Fold& fold) {
     F sel_mul = -mult_a - sel_bool - sel_muladd - sel_horner - sel_add;
 #pragma unroll
     for (int i = 0; i < D; ++i) fold.base(sel_add * (A.c[i] + B.c[i] - O.c[i]));
-    VD<F, D> ab = mulD<PP, D, F>(A, B);
+    VD<F, D> ab = mulD<PP, D, F>(A, B, a.ext_w_mont);
 #pragma unroll
     for (int i = 0; i < D; ++i) fold.base(sel_mul * (ab.c[i] - O.c[i]));
     fold.base(sel_bool * A.c[0] * (A.c[0] - one));
@@ -216,7 +234,7 @@ P3R_HD void alu_constraints(const AirParams& a, const View& v, Fold& fold) {
     for (int i = 0; i < D; ++i) fold.base(sel_muladd * (ab.c[i] + C.c[i] - O.c[i]));
     F next_sel_horner = v.PN(p + 4);
     VD<F, D> NA = loadD<D, F>(N, m), NB = loadD<D, F>(N, m + D), NC = loadD<D, F>(N, m + 2 * D), NO = loadD<D, F>(N, m + 3 * D);
-    VD<F, D> out_next_b = mulD<PP, D, F>(O, NB);
+    VD<F, D> out_next_b = mulD<PP, D, F>(O, NB, a.ext_w_mont);
     if (lane == 0) {
       F any_cur = F::zero(), any_next = F::zero(), sel_ge3_next = F::zero();
       for (int kk = 2; kk <= k_max; ++kk) any_cur += v.PL(extra_prep + kk - 2);
@@ -225,10 +243,10 @@ P3R_HD void alu_constraints(const AirParams& a, const View& v, Fold& fold) {
       for (int kk = 3; kk <= k_max; ++kk) sel_ge3_next += v.PN(extra_prep + kk - 2);
       const int b_sq_base = ac_base + 2 * D * (k_max - 1);
       VD<F, D> b_sq = loadD<D, F>(L, b_sq_base), b_sq_next = loadD<D, F>(N, b_sq_base);
-      VD<F, D> bb = mulD<PP, D, F>(B, B);
+      VD<F, D> bb = mulD<PP, D, F>(B, B, a.ext_w_mont);
 #pragma unroll
       for (int i = 0; i < D; ++i) fold.base(any_cur * (b_sq.c[i] - bb.c[i]));
-      VD<F, D> out_b_sq = mulD<PP, D, F>(O, b_sq_next), c0b = mulD<PP, D, F>(NC, NB), a0b = mulD<PP, D, F>(NA, NB);
+      VD<F, D> out_b_sq = mulD<PP, D, F>(O, b_sq_next, a.ext_w_mont), c0b = mulD<PP, D, F>(NC, NB, a.ext_w_mont), a0b = mulD<PP, D, F>(NA, NB, a.ext_w_mont);
       VD<F, D> a1n = loadD<D, F>(N, ac_base), c1n = loadD<D, F>(N, ac_base + D), int0n = loadD<D, F>(N, extra_main);
 #pragma unroll
       for (int i = 0; i < D; ++i) {
@@ -249,7 +267,7 @@ P3R_HD void alu_constraints(const AirParams& a, const View& v, Fold& fold) {
           if (s + 1 < kk) {
             const int off_sp1 = ac_base + 2 * D * s;
             VD<F, D> a_sp1 = loadD<D, F>(L, off_sp1), c_sp1 = loadD<D, F>(L, off_sp1 + D);
-            VD<F, D> int_b_sq = mulD<PP, D, F>(int_curr, b_sq), c_s_b = mulD<PP, D, F>(c_s, B), a_s_b = mulD<PP, D, F>(a_s, B);
+            VD<F, D> int_b_sq = mulD<PP, D, F>(int_curr, b_sq, a.ext_w_mont), c_s_b = mulD<PP, D, F>(c_s, B, a.ext_w_mont), a_s_b = mulD<PP, D, F>(a_s, B, a.ext_w_mont);
             const bool to_out = s + 2 >= kk;
             VD<F, D> target = to_out ? O : loadD<D, F>(L, extra_main + (slot + 1) * D);
 #pragma unroll
@@ -258,7 +276,7 @@ P3R_HD void alu_constraints(const AirParams& a, const View& v, Fold& fold) {
             if (!to_out) slot += 1;
             s += 2;
           } else {
-            VD<F, D> int_b = mulD<PP, D, F>(int_curr, B);
+            VD<F, D> int_b = mulD<PP, D, F>(int_curr, B, a.ext_w_mont);
 #pragma unroll
             for (int i = 0; i < D; ++i) fold.base(sel_kk * (int_b.c[i] + c_s.c[i] - a_s.c[i] - O.c[i]));
             s += 1;

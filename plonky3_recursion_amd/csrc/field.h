@@ -315,13 +315,24 @@ struct Fp1 {
   P3R_HD bool operator==(const Fp1& o) const { return c[0] == o.c[0]; }
   P3R_HD Fp1 inv() const { Fp1 r; r.c[0] = c[0].inv(); return r; }
 };
-// Calls fn(std::integral_constant<int, D>) for the circuit extension degree d of a context: 1, 4, or 5 (KoalaBear).
+// Calls fn(std::integral_constant<int, D>) for the circuit extension degree d of a context: 1, 4, or 5 (KoalaBear) -
+// the degrees the device runner computes in.
 template <class PP, class Fn>
 inline void dispatch_ext_degree(int d, Fn&& fn) {
   if (d == 1) fn(std::integral_constant<int, 1>{});
   else if (d == 5) { if constexpr (kHasQuintic<PP>) fn(std::integral_constant<int, 5>{}); }
   else fn(std::integral_constant<int, 4>{});
 }
+// The same over every degree the AIR statements are written for: + the binomial extensions of degree 2, 6, 8
+// (W at run time).
+template <class PP, class Fn>
+inline void dispatch_air_degree(int d, Fn&& fn) {
+  if (d == 2) fn(std::integral_constant<int, 2>{});
+  else if (d == 6) fn(std::integral_constant<int, 6>{});
+  else if (d == 8) fn(std::integral_constant<int, 8>{});
+  else dispatch_ext_degree<PP>(d, fn);
+}
+inline bool ext_degree_is_binomial_generic(uint32_t d) { return d == 2 || d == 6 || d == 8; }
 
 template <class PP>
 struct Fp5 {

@@ -315,7 +315,7 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const
   if (q.air.kind == AIR_ALU) alu_constraints<PP, D>(q.air, v, fold);
   if (q.air.kind == AIR_POSEIDON2) {
     if constexpr (D == 4) poseidon2_constraints<PP>(v, is_transition, rc, fold);
-    else poseidon2_d1_constraints<PP>(v, is_transition, rc, fold);
+    else if constexpr (D == 1 || D == 5) poseidon2_d1_constraints<PP>(v, is_transition, rc, fold);
   }
   if (q.aux) {
     const F is_first = zh * (x - F::one()).inv();

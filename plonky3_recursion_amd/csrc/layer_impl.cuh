@@ -20,13 +20,27 @@ namespace {
 
 // (AluPlanEntry / PLAN_*: run_schedule.h)
 
-// K1: one lane per trace row.  E = the circuit's extension field (Fp4, or Fp5 for D = 5 circuits), D its degree.
-template <class PP, class E, int D>
+// K1: one lane per trace row.  D = the circuit's extension degree; elements are VD<F, D> and products go through
+// mulD (the same rule the AIR states: Fp1 / x^4 = W / quintic trinomial / generic binomial with W = w_mont).
+template <class PP, int D>
+struct AluElem {
+  Fp<PP> c[D];
+  static __device__ __forceinline__ AluElem zero() { AluElem r; for (int i = 0; i < D; ++i) r.c[i] = Fp<PP>::zero(); return r; }
+};
+template <class PP, int D>
 __global__ void __launch_bounds__(kBlock)
 k_alu_trace(const AluPlanEntry* __restrict__ plan, const uint32_t* __restrict__ prev_src /* per row */,
             const uint32_t* __restrict__ values /* [n_ops][4 D] Montgomery */, size_t rows, size_t h, int lanes,
-            int k_max, uint32_t* __restrict__ out /* [width][h] */) {
+            int k_max, uint32_t* __restrict__ out /* [width][h] */, uint32_t w_mont) {
   using F = Fp<PP>;
+  using E = VD<F, D>;
+  auto zero = [] { E r; for (int i = 0; i < D; ++i) r.c[i] = F::zero(); return r; };
+  auto mul = [&](const E& x, const E& y) { return mulD<PP, D, F>(x, y, w_mont); };
+  auto fma = [&](const E& x, const E& y, const E& p, const E& m) {   // x * y + p - m
+    E r = mul(x, y);
+    for (int i = 0; i < D; ++i) r.c[i] = r.c[i] + p.c[i] - m.c[i];
+    return r;
+  };
   size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (row >= rows) return;
   auto val = [&](uint32_t op, int operand) {
@@ -52,17 +66,17 @@ k_alu_trace(const AluPlanEntry* __restrict__ plan, const uint32_t* __restrict__ 
       if (lane == 0) {
         const int extra = lanes * 4 * D;
         const uint32_t ps = prev_src[row];
-        E acc = ps == 0xFFFFFFFFu ? E::zero() : val(ps, 3);
+        E acc = ps == 0xFFFFFFFFu ? zero() : val(ps, 3);
         const E b = val(en.first, 1);
         int step = 0;
         for (int s = 0; s < num_int; ++s) {
           uint32_t i0 = en.first + step;
           if (step + 1 < k) {
-            E o0 = acc * b + val(i0, 2) - val(i0, 0);
-            acc = o0 * b + val(i0 + 1, 2) - val(i0 + 1, 0);
+            E o0 = fma(acc, b, val(i0, 2), val(i0, 0));
+            acc = fma(o0, b, val(i0 + 1, 2), val(i0 + 1, 0));
             step += 2;
           } else {
-            acc = acc * b + val(i0, 2) - val(i0, 0);
+            acc = fma(acc, b, val(i0, 2), val(i0, 0));
             step += 1;
           }
           put(extra + s * D, acc);
@@ -72,7 +86,7 @@ k_alu_trace(const AluPlanEntry* __restrict__ plan, const uint32_t* __restrict__ 
           put(ac_base + 2 * D * (t - 1), val(en.first + t, 0));
           put(ac_base + 2 * D * (t - 1) + D, val(en.first + t, 2));
         }
-        put(ac_base + 2 * D * (k_max - 1), b * b);
+        put(ac_base + 2 * D * (k_max - 1), mul(b, b));
       }
     }
   }
@@ -212,6 +226,8 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   L->has_recompose = d->counts.n_recompose > 0;
   if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
   const uint32_t ext_d = ctx->cfg.ext_degree;
+  if (ext_degree_is_binomial_generic(ext_d) && L->has_p2)
+    fail(P3R_EUNSUPPORTED, "UnsupportedDegree(%u): no Poseidon2 table for this circuit degree (Const, Public, ALU, Recompose)", ext_d);
   L->recompose_coeff = d->recompose_coeff_lookups != 0;
   const int rec_plw = 2 + (L->recompose_coeff ? 2 * (int)ext_d : 0);
   const auto& c = d->counts;
@@ -457,10 +473,10 @@ std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r
     P3R_HIP(hipMemsetAsync(m[2]->d, 0, L->h_alu * (size_t)width * 4, ctx->stream));
     ProfScope ps(ctx, "alu_trace");
     const auto* plan = reinterpret_cast<const AluPlanEntry*>(L->alu_plan.p);
-    dispatch_ext_degree<PP>(D, [&](auto dc) {
-      using E = typename CircuitExt<PP, decltype(dc)::value>::type;
-      hipLaunchKernelGGL((k_alu_trace<PP, E, decltype(dc)::value>), dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream, plan,
-                         L->alu_prev_src.p, t->alu_values.p, L->alu_rows, L->h_alu, lanes, k, m[2]->d);
+    const uint32_t w_mont = ext_degree_is_binomial_generic((uint32_t)D) ? Fp<PP>::from_canonical(ctx->cfg.ext_w).v : 0u;
+    dispatch_air_degree<PP>(D, [&](auto dc) {
+      hipLaunchKernelGGL((k_alu_trace<PP, decltype(dc)::value>), dim3(blocks_for(L->alu_rows)), dim3(kBlock), 0, ctx->stream, plan,
+                         L->alu_prev_src.p, t->alu_values.p, L->alu_rows, L->h_alu, lanes, k, m[2]->d, w_mont);
     });
   }
   if (L->has_p2) m[3] = trace_fill<PP>(ctx, t->p2.get());

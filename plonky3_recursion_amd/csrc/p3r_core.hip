@@ -868,8 +868,13 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
       fail(P3R_EUNSUPPORTED, "unsupported field id %u", cfg->field);
     // circuit extension degree: 4 (binomial) on both fields; 5 = the KoalaBear quintic trinomial extension, proved
     // under the same D = 4 STARK configuration (batch_stark_prover/tests.rs:844-1029), primitive tables only
-    if (cfg->ext_degree != 1 && cfg->ext_degree != 4 && !(cfg->ext_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR))
-      fail(P3R_EUNSUPPORTED, "unsupported extension degree %u (D = 1, D = 4, or D = 5 over KoalaBear)", cfg->ext_degree);
+    if (p3r::ext_degree_is_binomial_generic(cfg->ext_degree)) {
+      // binomial extension x^D = W of degree 2 / 6 / 8: W is the caller's (BinomiallyExtendable<D>::W of its field
+      // crate; the proof carries it as w_binomial)
+      const uint32_t P = cfg->field == P3R_FIELD_KOALA_BEAR ? p3r::KoalaBearParams::P : p3r::BabyBearParams::P;
+      if (cfg->ext_w == 0 || cfg->ext_w >= P) fail(P3R_EINVAL, "MissingWForExtension: ext_degree %u needs ext_w in 1..p-1", cfg->ext_degree);
+    } else if (cfg->ext_degree != 1 && cfg->ext_degree != 4 && !(cfg->ext_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR))
+      fail(P3R_EUNSUPPORTED, "UnsupportedExtDegree(%u): 1, 2, 4, 6, 8, or 5 over KoalaBear", cfg->ext_degree);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -1246,7 +1251,9 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
   try {
     if (!cfg || !airs || !preprocessed_commitment || !degree_bits || (!proof && proof_len)) { report("NULL argument"); return P3R_EINVAL; }
     if (cfg->abi_version != P3R_ABI_VERSION) { report("ABI version mismatch"); return P3R_EINVAL; }
-    if (cfg->ext_degree != 1 && cfg->ext_degree != 4 && !(cfg->ext_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR)) { report("UnsupportedDegree"); return P3R_EUNSUPPORTED; }
+    const bool generic_d = p3r::ext_degree_is_binomial_generic(cfg->ext_degree);
+    if (generic_d && cfg->ext_w == 0) { report("MissingWForExtension"); return P3R_EINVAL; }
+    if (!generic_d && cfg->ext_degree != 1 && cfg->ext_degree != 4 && !(cfg->ext_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR)) { report("UnsupportedDegree"); return P3R_EUNSUPPORTED; }
     p3r::VerifyParams prm{(int)cfg->log_blowup, (int)cfg->max_log_arity, (int)cfg->cap_height, (int)cfg->log_final_poly_len,
                           (int)cfg->commit_pow_bits, (int)cfg->query_pow_bits, (int)cfg->num_queries, {}};
     if (cfg->fri_log_arities) prm.fri_log_arities.assign(cfg->fri_log_arities, cfg->fri_log_arities + cfg->fri_log_arities_len);
@@ -1255,7 +1262,7 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     for (size_t i = 0; i < n_airs; ++i) {
       if (airs[i].kind > P3R_AIR_RECOMPOSE || !airs[i].lanes) { report("bad AIR descriptor"); return P3R_EINVAL; }
       a[i] = {(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
-              (cfg->ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)cfg->ext_degree};
+              (cfg->ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)cfg->ext_degree, 0u};
     }
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     std::vector<uint32_t> cap(preprocessed_commitment, preprocessed_commitment + ((size_t)P2_DIGEST << cfg->cap_height));
@@ -1266,7 +1273,9 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
       const uint32_t* src = cfg->poseidon2_rc;
       if (src && cfg->poseidon2_rc_len != nrc) p3r::vfail("poseidon2_rc_len is %u, the field needs %zu constants", cfg->poseidon2_rc_len, nrc);
       if (!src) src = PP::FIELD_ID == 0 ? kDefaultRc_koala_bear : kDefaultRc_baby_bear;
-      p3r::verify_batch<PP>(prm, std::vector<uint32_t>(src, src + nrc), a, cap, want_db, proof, proof_len, canonical);
+      auto airs_pp = a;
+      for (auto& x : airs_pp) x.ext_w_mont = generic_d ? p3r::Fp<PP>::from_canonical(cfg->ext_w).v : 0u;
+      p3r::verify_batch<PP>(prm, std::vector<uint32_t>(src, src + nrc), airs_pp, cap, want_db, proof, proof_len, canonical);
     };
     if (cfg->field == P3R_FIELD_KOALA_BEAR) run(p3r::KoalaBearParams{});
     else if (cfg->field == P3R_FIELD_BABY_BEAR) run(p3r::BabyBearParams{});
@@ -1327,6 +1336,9 @@ p3r_circuit* p3r_circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* desc, uint
   p3r_circuit* out = nullptr;
   guard(ctx, [&] {
     if (!desc || !commit_out) fail(P3R_EINVAL, "NULL argument");
+    if (p3r::ext_degree_is_binomial_generic(ctx->cfg.ext_degree))
+      fail(P3R_EUNSUPPORTED, "UnsupportedDegree(%u): the device runner computes in degree 1, 4 and 5; hand the layer over as Traces",
+           ctx->cfg.ext_degree);
     out = P3R_FIELD_CALL(ctx, circuit_create, ctx, desc, commit_out).release();
   });
   return out;

@@ -128,7 +128,10 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
   std::vector<LdeItem> items;
   for (size_t i = 0; i < n; ++i) {
     AirParams a{(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
-                (ctx->cfg.ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)ctx->cfg.ext_degree};
+                (ctx->cfg.ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)ctx->cfg.ext_degree,
+                ext_degree_is_binomial_generic(ctx->cfg.ext_degree) ? Fp<PP>::from_canonical(ctx->cfg.ext_w).v : 0u};
+    if (ext_degree_is_binomial_generic(ctx->cfg.ext_degree) && a.kind == AIR_POSEIDON2)
+      fail(P3R_EUNSUPPORTED, "instance %zu: UnsupportedDegree(%d): no Poseidon2 table for this circuit degree", i, a.ext_d);
     if (a.kind < 0 || a.kind > AIR_RECOMPOSE) fail(P3R_EINVAL, "instance %zu: unknown AIR kind %d", i, a.kind);
     if (a.lanes < 1) fail(P3R_EINVAL, "instance %zu: lanes must be positive", i);
     if (a.kind == AIR_ALU && (a.horner_k < 2 || a.horner_k > 8))
@@ -264,7 +267,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       P3R_HIP(ctx->stage.upload(ctx->stream, scratch.back().p, jobs.data(), jobs.size() * sizeof(LogupJob)));
       const int nj = (int)jobs.size();
       ProfScope ps(ctx, "logup_aux");
-      dispatch_ext_degree<PP>((int)ctx->cfg.ext_degree, [&](auto dc) {
+      dispatch_air_degree<PP>((int)ctx->cfg.ext_degree, [&](auto dc) {
         hipLaunchKernelGGL((k_logup_aux<PP, decltype(dc)::value>), dim3(row_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, nj, lc);
       });
       hipLaunchKernelGGL(k_ef_scan<PP>, dim3(tiles), dim3(kBlock), 0, ctx->stream, 0, d_jobs, nj);
@@ -363,7 +366,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     DevBuf d_quot((quot_jobs.size() * sizeof(QuotientArgs) + 3) / 4);
     P3R_HIP(ctx->stage.upload(ctx->stream, d_quot.p, quot_jobs.data(), quot_jobs.size() * sizeof(QuotientArgs)));
     ProfScope ps(ctx, "quotient");
-    dispatch_ext_degree<PP>((int)ctx->cfg.ext_degree, [&](auto dc) {
+    dispatch_air_degree<PP>((int)ctx->cfg.ext_degree, [&](auto dc) {
       hipLaunchKernelGGL((k_quotient<PP, decltype(dc)::value>), dim3(quot_blocks), dim3(kBlock), 0, ctx->stream,
                          reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc, ctx->rc.p);
     });

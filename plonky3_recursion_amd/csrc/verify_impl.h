@@ -615,10 +615,11 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     ZetaView<PP> v{in.main_local, in.main_next ? in.main_next : &none, in.prep_local, in.prep_next};
     ZetaFold<PP> fold;
     fold.alpha = alpha;
-    if (!(air.ext_d == 1 || air.ext_d == 4 || (air.ext_d == 5 && kHasQuintic<PP>)))
+    const bool generic = ext_degree_is_binomial_generic((uint32_t)air.ext_d);
+    if (!(air.ext_d == 1 || air.ext_d == 4 || (air.ext_d == 5 && kHasQuintic<PP>) || (generic && air.kind != AIR_POSEIDON2)))
       vfail("instance %zu: no AIR of kind %d for circuit extension degree %d", i, air.kind, air.ext_d);
     if (air.kind == AIR_ALU) {
-      dispatch_ext_degree<PP>(air.ext_d, [&](auto dc) { alu_constraints<PP, decltype(dc)::value>(air, v, fold); });
+      dispatch_air_degree<PP>(air.ext_d, [&](auto dc) { alu_constraints<PP, decltype(dc)::value>(air, v, fold); });
     } else if (air.kind == AIR_POSEIDON2) {
       if (air.ext_d != 4) poseidon2_d1_constraints<PP>(v, is_transition, rc_mont, fold);
       else poseidon2_constraints<PP>(v, is_transition, rc_mont, fold);
@@ -638,9 +639,9 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
       };
       const std::vector<E> aux_l = ef_cols(*in.perm_local), aux_n = ef_cols(*in.perm_next);
       ZetaLookupSink<PP> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4],
-                                         l_beta_pow[5]},
+                                         l_beta_pow[5], l_beta_pow[6], l_beta_pow[7], l_beta_pow[8]},
                               aux_l, fold, L.pair};
-      dispatch_ext_degree<PP>(air.ext_d, [&](auto dc) { air_interactions<PP, decltype(dc)::value>(air, v, sink); });
+      dispatch_air_degree<PP>(air.ext_d, [&](auto dc) { air_interactions<PP, decltype(dc)::value>(air, v, sink); });
       sink.finish();
       if (sink.cnt != L.n_interactions) vfail("instance %zu: interaction count mismatch", i);
       const E s = aux_l[0], s_next = aux_n[0], terminal = *in.terminal;

@@ -432,7 +432,8 @@ def verify_all_tables(cfg, proof: BatchStarkProof, canonical_field_encoding=None
     field = field or {0: "koala-bear", 1: "baby-bear"}[int(cfg.field)]
     # EF = BinomialExtensionField<F, 4>: W = the field's; EF = QuinticTrinomialExtensionField<F>: no binomial W
     # and the trinomial reduction flag (field_params.rs:54-66)
-    want_w = W_BINOMIAL[field] if want_d == 4 else None    # D = 1: the base field has no W either
+    # D = 1: the base field has no W either; D = 2 / 6 / 8: the verifier's own W (p3r_config.ext_w)
+    want_w = W_BINOMIAL[field] if want_d == 4 else int(cfg.ext_w) if want_d in (2, 6, 8) else None
     if proof.w_binomial != want_w:
         raise P3rError(-1, "BinomialWMismatch: proof has W = %r, the verifier expects %r" % (proof.w_binomial, want_w))
     if bool(proof.alu_quintic_trinomial) != (want_d == 5):
@@ -493,7 +494,7 @@ class BatchStarkProver:
             proof=raw, table_packing=tp,
             rows=(cpd.rows["const"], cpd.rows["public"], cpd.rows["alu"]),
             ext_degree=ctx.ext_degree,
-            w_binomial=W_BINOMIAL[ctx.field] if ctx.ext_degree == 4 else None,
+            w_binomial=W_BINOMIAL[ctx.field] if ctx.ext_degree == 4 else ctx.ext_w if ctx.ext_degree in (2, 6, 8) else None,
             alu_quintic_trinomial=ctx.ext_degree == 5,
             non_primitives=tuple(npo),
             preprocessed_commitment=cpd.preprocessed_commitment,

@@ -20,7 +20,7 @@ class OrcWorkload(C.Structure):
         ("n_recompose", C.c_size_t), ("recompose_values", u32p), ("recompose_prep", u32p),
         ("public_lanes", C.c_uint32), ("alu_lanes", C.c_uint32), ("horner_packed_steps", C.c_uint32),
         ("recompose_lanes", C.c_uint32), ("min_trace_height", C.c_uint32), ("ext_degree", C.c_uint32),
-        ("p2_absorb_len", u32p), ("recompose_coeff_lookups", C.c_uint32),
+        ("p2_absorb_len", u32p), ("recompose_coeff_lookups", C.c_uint32), ("ext_w", C.c_uint32),
     ]
 
 
@@ -69,6 +69,7 @@ def fill_workload(wl_struct, arrays, packing, keep):
     wl_struct.min_trace_height = packing["min_trace_height"]
     wl_struct.ext_degree = packing.get("ext_degree", 4)   # 5: KoalaBear quintic circuits (compact-D1 Poseidon2 rows)
     wl_struct.recompose_coeff_lookups = packing.get("recompose_coeff_lookups", 0)
+    wl_struct.ext_w = packing.get("ext_w", 0)
     if "p2_absorb_len" in arrays and len(arrays["p2_absorb_len"]):
         wl_struct.p2_absorb_len = ptr("p2_absorb_len")
 
@@ -82,7 +83,7 @@ def oracle_verify_statement(orc, field, prm, airs, prep_cap, proof_bytes, rc=Non
                                      C.POINTER(C.c_uint8), C.c_size_t, C.c_int]
     rc = oracle_lib.default_rc(field) if rc is None else np.ascontiguousarray(rc, dtype=np.uint32)
     a4 = np.array([[a["kind"], a.get("lanes", 1), a.get("horner_packed_steps", 2),
-                    a.get("coeff_lookups", 0) | (a.get("ext_degree", 4) << 8)] for a in airs], dtype=np.uint32)
+                    a.get("coeff_lookups", 0) | (a.get("ext_degree", 4) << 8) | (a.get("ext_w", 0) << 16)] for a in airs], dtype=np.uint32)
     cap = np.ascontiguousarray(prep_cap, dtype=np.uint32)
     b = (C.c_uint8 * len(proof_bytes)).from_buffer_copy(proof_bytes)
     orc._ck(lib.orc_verify_batch(oracle_lib.FIELD_IDS[field], rc.ctypes.data_as(u32p), C.byref(prm), len(airs),
