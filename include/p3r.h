@@ -107,6 +107,11 @@ typedef struct p3r_config {
    * and Recompose (batch_stark_prover/tests.rs:486: test_koalabear_batch_stark_extension_field_d8) and enter at the
    * prove_all_tables boundary.  0 for the other degrees: 4 uses the field's W (3 / 11), 1 and 5 have none. */
   uint32_t ext_w;
+  /* ABI version 4.  Degree of the STARK's CHALLENGE field (SC::Challenge): 0 / 4 = the quartic binomial extension
+   * (every BASELINE configuration); 5 = KoalaBear's quintic trinomial extension, the configuration of
+   * koala_bear_quintic_params (test-utils/src/lib.rs:414-460; recursive_fibonacci --quintic;
+   * recursion/tests/fibonacci_batch_stark_prover_quintic.rs).  Extension elements of the proof then hold five words. */
+  uint32_t challenge_degree;
 } p3r_config;
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
@@ -237,6 +242,8 @@ p3r_prep* p3r_prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, const p3r_matr
                           size_t n_instances, uint32_t* commit_out);
 void p3r_prep_free(p3r_ctx* ctx, p3r_prep* prep);
 
+#define P3R_PROOF_QUINTIC_CHALLENGE 2u /* flags of the proof PARSERS (p3r_batch_proof_len*, p3r_batch_stark_proof_parse):
+                                        * extension elements are five words (p3r_config.challenge_degree = 5) */
 #define P3R_PROVE_CANONICAL_FIELD_ENCODING 1u /* flags: write canonical u32 instead of the
                                                * Montgomery word p3-monty-31's serde emits */
 

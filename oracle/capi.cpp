@@ -154,7 +154,7 @@ void do_challenger_script(const uint32_t* rc, const int32_t* ops, size_t n_ops, 
     switch (ops[i]) {
       case 0: ch.observe(Fe<FP>(args[i])); break;
       case 1: out[o++] = ch.sample().v; break;
-      case 2: { auto e = ch.sample_ext(); for (auto c : e.c) out[o++] = c.v; break; }
+      case 2: { auto e = ch.sample_ext(); for (int k = 0; k < 4; ++k) out[o++] = e.c[k].v; break; }
       case 3: out[o++] = ch.sample_bits((int)args[i]); break;
       case 4: out[o++] = ch.grind((int)args[i]).v; break;
       case 5: ch.observe_base_as_ext(Fe<FP>(args[i])); break;

@@ -51,6 +51,7 @@ typedef struct orc_params {
   uint32_t n_fri_log_arities;
   uint8_t fri_log_arities[32];
   uint8_t proof_layout[18];   // twin of p3r_config.proof_layout; all zero = identity
+  uint32_t challenge_degree;  // 0 / 4: the quartic challenge field; 5: KoalaBear's quintic trinomial extension
 } orc_params;
 
 const char* orc_last_error();
@@ -70,7 +71,11 @@ struct LayerBase {
   virtual void verify(const orc_params& p, const uint32_t* prep_cap, const uint8_t* bytes, size_t n, int enc) const = 0;
 };
 
+// the challenge field of the calls that follow (field.hpp: a process-wide setting of this test oracle)
+void set_challenge_degree(const orc_params& p) { challenge_degree() = p.challenge_degree == 5 ? 5 : 4; }
+
 Layout to_layout(const orc_params& p) {
+  set_challenge_degree(p);
   Layout L;
   bool any = false;
   for (int i = 0; i < 18; ++i) any |= p.proof_layout[i] != 0;
@@ -81,6 +86,7 @@ Layout to_layout(const orc_params& p) {
   return L;
 }
 StarkParams to_sp(const orc_params& p) {
+  set_challenge_degree(p);
   StarkParams s;
   s.log_blowup = p.log_blowup; s.max_log_arity = p.max_log_arity; s.cap_height = p.cap_height;
   s.log_final_poly_len = p.log_final_poly_len; s.commit_pow_bits = p.commit_pow_bits;

@@ -82,32 +82,53 @@ struct Fe {
   }
 };
 
-// F[x]/(x^4 - W); coefficient order 1, x, x^2, x^3.
+// The STARK's CHALLENGE field.  Degree 4: F[x]/(x^4 - W), coefficient order 1, x, x^2, x^3 (every BASELINE
+// configuration).  Degree 5: F[x]/(x^5 + x^2 - 1), p3's QuinticTrinomialExtensionField, the challenge field of
+// `koala_bear_quintic_params` (test-utils/src/lib.rs:414-460; recursive_fibonacci.rs --quintic).  The degree is a
+// process-wide setting of this test oracle (challenge_degree(), set by the C entry points from orc_params before a
+// prove / verify); the name Fe4 stays.
+inline int& challenge_degree() {
+  static int d = 4;
+  return d;
+}
 template <class FP>
 struct Fe4 {
   using F = Fe<FP>;
-  std::array<F, 4> c{};
+  std::array<F, 5> c{};
+  static int deg() { return challenge_degree(); }
   Fe4() = default;
   explicit Fe4(F b) { c[0] = b; }
-  Fe4(F a, F b, F cc, F d) { c = {a, b, cc, d}; }
+  Fe4(F a, F b, F cc, F d) { c = {a, b, cc, d, F::zero()}; }
   static Fe4 zero() { return Fe4(); }
   static Fe4 one() { return Fe4(F::one()); }
   friend Fe4 operator+(Fe4 a, const Fe4& b) {
-    for (int i = 0; i < 4; ++i) a.c[i] += b.c[i];
+    for (int i = 0; i < 5; ++i) a.c[i] += b.c[i];
     return a;
   }
   friend Fe4 operator-(Fe4 a, const Fe4& b) {
-    for (int i = 0; i < 4; ++i) a.c[i] -= b.c[i];
+    for (int i = 0; i < 5; ++i) a.c[i] -= b.c[i];
     return a;
   }
   Fe4 operator-() const {
     Fe4 r;
-    for (int i = 0; i < 4; ++i) r.c[i] = -c[i];
+    for (int i = 0; i < 5; ++i) r.c[i] = -c[i];
     return r;
   }
-  // schoolbook with wrap-around x^4 -> W
   friend Fe4 operator*(const Fe4& a, const Fe4& b) {
     Fe4 r;
+    if (deg() == 5) {
+      F t[9];
+      for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j) t[i + j] += a.c[i] * b.c[j];
+      // x^5 = 1 - x^2, x^6 = x - x^3, x^7 = x^2 - x^4, x^8 = x^3 + x^2 - 1
+      r.c[0] = t[0] + t[5] - t[8];
+      r.c[1] = t[1] + t[6];
+      r.c[2] = t[2] - t[5] + t[7] + t[8];
+      r.c[3] = t[3] - t[6] + t[8];
+      r.c[4] = t[4] - t[7];
+      return r;
+    }
+    // schoolbook with wrap-around x^4 -> W
     const F w(FP::W);
     for (int i = 0; i < 4; ++i)
       for (int j = 0; j < 4; ++j) {
@@ -118,7 +139,7 @@ struct Fe4 {
     return r;
   }
   friend Fe4 operator*(Fe4 a, F b) {
-    for (int i = 0; i < 4; ++i) a.c[i] *= b;
+    for (int i = 0; i < 5; ++i) a.c[i] *= b;
     return a;
   }
   Fe4& operator+=(const Fe4& o) { return *this = *this + o; }
@@ -126,7 +147,7 @@ struct Fe4 {
   Fe4& operator*=(const Fe4& o) { return *this = *this * o; }
   bool operator==(const Fe4& o) const { return c == o.c; }
   bool operator!=(const Fe4& o) const { return !(c == o.c); }
-  bool is_zero() const { return c[0].v == 0 && c[1].v == 0 && c[2].v == 0 && c[3].v == 0; }
+  bool is_zero() const { return c[0].v == 0 && c[1].v == 0 && c[2].v == 0 && c[3].v == 0 && c[4].v == 0; }
   Fe4 pow(uint64_t e) const {
     Fe4 r = one(), b = *this;
     for (; e; e >>= 1) {
@@ -135,16 +156,42 @@ struct Fe4 {
     }
     return r;
   }
-  // a^-1 = a^(p^4 - 2) computed through the Frobenius norm: a^-1 = a^(r-1) / N(a),
-  // r = 1 + p + p^2 + p^3, N(a) = a^r in the base field.
+  // Degree 4: a^-1 = a^(p^4 - 2) through the Frobenius norm: a^-1 = a^(r-1) / N(a), r = 1 + p + p^2 + p^3.
+  // Degree 5: the solution of (multiplication-by-a matrix) x = 1 over the base field (Gauss-Jordan).
   Fe4 inv() const {
     if (is_zero()) throw std::runtime_error("inverse of zero");
+    if (deg() == 5) {
+      F m[5][6];
+      Fe4 col = *this, x;
+      x.c[1] = F::one();
+      for (int j = 0; j < 5; ++j) {
+        for (int i = 0; i < 5; ++i) m[i][j] = col.c[i];
+        col = col * x;
+      }
+      for (int i = 0; i < 5; ++i) m[i][5] = i == 0 ? F::one() : F::zero();
+      for (int k = 0; k < 5; ++k) {
+        int piv = k;
+        while (piv < 5 && m[piv][k].v == 0) ++piv;
+        if (piv == 5) throw std::runtime_error("singular multiplication matrix");
+        for (int j = 0; j < 6; ++j) std::swap(m[k][j], m[piv][j]);
+        const F s = m[k][k].inv();
+        for (int j = 0; j < 6; ++j) m[k][j] *= s;
+        for (int i = 0; i < 5; ++i) {
+          if (i == k) continue;
+          const F f = m[i][k];
+          for (int j = 0; j < 6; ++j) m[i][j] -= f * m[k][j];
+        }
+      }
+      Fe4 r;
+      for (int i = 0; i < 5; ++i) r.c[i] = m[i][5];
+      return r;
+    }
     Fe4 f1 = frobenius(), f2 = f1.frobenius(), f3 = f2.frobenius();
     Fe4 prod = f1 * f2 * f3;  // a^(r-1)
     Fe4 norm = *this * prod;  // in the base field
     return prod * norm.c[0].inv();
   }
-  // x -> x^p : coefficient i is multiplied by (W^((p-1)/4))^i
+  // x -> x^p : coefficient i is multiplied by (W^((p-1)/4))^i  (degree 4 only)
   Fe4 frobenius() const {
     const F z = F(FP::W).pow(((uint64_t)FP::P - 1) / 4);
     Fe4 r;

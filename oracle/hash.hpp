@@ -144,8 +144,8 @@ struct Challenger {
   }
   void observe_slice(const std::vector<F>& xs) { for (auto x : xs) observe(x); }
   template <size_t N> void observe_arr(const std::array<F, N>& xs) { for (auto x : xs) observe(x); }
-  void observe_ext(const EF& x) { for (auto c : x.c) observe(c); }
-  // observe_base_as_algebra_element: [v,0,0,0] (recursion/src/verifier/batch_stark.rs:521-523)
+  void observe_ext(const EF& x) { for (int i = 0; i < EF::deg(); ++i) observe(x.c[i]); }
+  // observe_base_as_algebra_element: [v,0,0,0(,0)] (recursion/src/verifier/batch_stark.rs:521-523)
   void observe_base_as_ext(F v) { observe_ext(EF(v)); }
   F sample() {
     if (!in_buf.empty() || out_buf.empty()) duplexing();
@@ -155,7 +155,7 @@ struct Challenger {
   }
   EF sample_ext() {
     EF e;
-    for (int i = 0; i < 4; ++i) e.c[i] = sample();
+    for (int i = 0; i < EF::deg(); ++i) e.c[i] = sample();
     return e;
   }
   uint32_t sample_bits(int bits) { return sample().v & ((bits >= 32) ? ~0u : ((1u << bits) - 1)); }

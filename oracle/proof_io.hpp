@@ -29,7 +29,7 @@ struct Writer {
     if (enc == FIELD_ENCODING_MONTY) v = ((uint64_t)x.v << 32) % FP::P;
     varint(v);
   }
-  void ef(const Fe4<FP>& x) { for (auto c : x.c) fe(c); }
+  void ef(const Fe4<FP>& x) { for (int i = 0; i < Fe4<FP>::deg(); ++i) fe(x.c[i]); }
   void digest(const std::array<Fe<FP>, DIGEST>& d) { for (auto c : d) fe(c); }
   void cap(const std::vector<std::array<Fe<FP>, DIGEST>>& c) { varint(c.size()); for (auto& d : c) digest(d); }
   void vec_fe(const std::vector<Fe<FP>>& v) { varint(v.size()); for (auto x : v) fe(x); }
@@ -153,7 +153,7 @@ struct Reader {
     }
     return Fe<FP>(v);
   }
-  Fe4<FP> ef() { Fe4<FP> e; for (auto& c : e.c) c = fe(); return e; }
+  Fe4<FP> ef() { Fe4<FP> e; for (int i = 0; i < Fe4<FP>::deg(); ++i) e.c[i] = fe(); return e; }
   std::array<Fe<FP>, DIGEST> digest() { std::array<Fe<FP>, DIGEST> d; for (auto& c : d) c = fe(); return d; }
   std::vector<std::array<Fe<FP>, DIGEST>> cap() { size_t n = len(); std::vector<std::array<Fe<FP>, DIGEST>> c(n); for (auto& d : c) d = digest(); return c; }
   std::vector<Fe<FP>> vec_fe() { size_t n = len(); std::vector<Fe<FP>> v(n); for (auto& x : v) x = fe(); return v; }

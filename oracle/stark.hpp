@@ -371,10 +371,11 @@ void fri_commit_phase(const Poseidon2<FP>& p2, const StarkParams& sp, std::vecto
       la = sp.fri_log_arities[ph];
     }
     size_t arity = size_t(1) << la, rows = folded.size() >> la;
-    Matrix<FP> leaves(rows, arity * 4);
+    const int DC = EF::deg();   // ExtensionMmcs: a leaf is `arity` extension elements flattened to base words
+    Matrix<FP> leaves(rows, arity * DC);
     for (size_t r = 0; r < rows; ++r)
       for (size_t j = 0; j < arity; ++j)
-        for (int k = 0; k < 4; ++k) leaves.at(r, j * 4 + k) = folded[r * arity + j].c[k];
+        for (int k = 0; k < DC; ++k) leaves.at(r, j * DC + k) = folded[r * arity + j].c[k];
     st.leaves.push_back(leaves);
     std::vector<const Matrix<FP>*> ptr{&st.leaves.back()};
     st.trees.push_back(MerkleTree<FP>::commit(p2, ptr, sp.cap_height));
@@ -407,7 +408,7 @@ void fri_commit_phase(const Poseidon2<FP>& p2, const StarkParams& sp, std::vecto
   for (size_t i = 0; i < m; ++i) nat[bitrev((uint32_t)i, lm)] = folded[i];
   // inverse DFT coefficient-wise on the 4 base coordinates
   std::vector<EF> coeffs(m);
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < EF::deg(); ++k) {
     std::vector<F> col(m);
     for (size_t i = 0; i < m; ++i) col[i] = nat[i].c[k];
     auto cc = idft<FP>(col);
@@ -481,7 +482,8 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     const auto& in = insts[i];
     const size_t n = in.main.h;
     const int aw = L.aux_width();
-    aux[i].flat = Matrix<FP>(n, aw * 4);
+    const int DC = EF::deg();
+    aux[i].flat = Matrix<FP>(n, aw * DC);
     // the fractions of a row depend on that row only (parallel); the running sum is a serial prefix
 #pragma omp parallel for schedule(static) if (n >= 1024)
     for (size_t r = 0; r < n; ++r) {
@@ -498,15 +500,15 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
           const auto& it = b.interactions[m];
           if (it.mult.v != 0) f += lookup_denom_f<FP>(lc, it.fields).inv() * it.mult;
         }
-        for (int k = 0; k < 4; ++k) aux[i].flat.at(r, (g + 1) * 4 + k) = f.c[k];
+        for (int k = 0; k < DC; ++k) aux[i].flat.at(r, (g + 1) * DC + k) = f.c[k];
       }
     }
     EF run = EF::zero();
     for (size_t r = 0; r < n; ++r) {
-      for (int k = 0; k < 4; ++k) aux[i].flat.at(r, k) = run.c[k];
+      for (int k = 0; k < DC; ++k) aux[i].flat.at(r, k) = run.c[k];
       for (size_t g = 0; g < L.groups.size(); ++g) {
         EF f;
-        for (int k = 0; k < 4; ++k) f.c[k] = aux[i].flat.at(r, (g + 1) * 4 + k);
+        for (int k = 0; k < DC; ++k) f.c[k] = aux[i].flat.at(r, (g + 1) * DC + k);
         run += f;
       }
     }
@@ -548,7 +550,8 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     int perm_pos = -1;
     for (size_t k = 0; k < perm_insts.size(); ++k) if (perm_insts[k] == (int)i) perm_pos = (int)k;
     if (perm_pos >= 0) aq = on_q(perm_c.ldes[perm_pos]);
-    Matrix<FP> qflat(qn, 4);
+    const int DC = EF::deg();
+    Matrix<FP> qflat(qn, DC);
     const F wq = F::two_adic_generator(log_n[i] + lq);
     const int aw = L.aux_width();
     std::vector<F> xs(qn);
@@ -570,7 +573,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
       if (aw) {
         std::vector<EF> al(aw), an(aw), den, mul;
         for (int c = 0; c < aw; ++c)
-          for (int k = 0; k < 4; ++k) { al[c].c[k] = aq.at(r, c * 4 + k); an[c].c[k] = aq.at(rn, c * 4 + k); }
+          for (int k = 0; k < DC; ++k) { al[c].c[k] = aq.at(r, c * DC + k); an[c].c[k] = aq.at(rn, c * DC + k); }
         for (auto& it : b.interactions) { den.push_back(lookup_denom_f<FP>(lc, it.fields)); mul.push_back(EF(it.mult)); }
         logup_constraints<FP>(L, den, mul, al, an, sel.is_first, sel.is_last, sel.is_transition,
                               proof.lookup_terminals[i], ext_cons);
@@ -579,13 +582,13 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
       for (auto& c : b.constraints) acc = acc * alpha + EF(c);
       for (auto& c : ext_cons) acc = acc * alpha + c;
       EF q = acc * sel.inv_vanishing;
-      for (int k = 0; k < 4; ++k) qflat.at(r, k) = q.c[k];
+      for (int k = 0; k < DC; ++k) qflat.at(r, k) = q.c[k];
     }
     // split_evals: chunk c = rows c, c+C, ... ; split_domains: shift gen * wq^c
     for (int c = 0; c < C; ++c) {
-      Matrix<FP> ce(n, 4);
+      Matrix<FP> ce(n, DC);
       for (size_t r = 0; r < n; ++r)
-        for (int k = 0; k < 4; ++k) ce.at(r, k) = qflat.at(r * C + c, k);
+        for (int k = 0; k < DC; ++k) ce.at(r, k) = qflat.at(r * C + c, k);
       q_chunk_evals.push_back(ce);
       q_chunk_shift.push_back(gen * wq.pow(c));
       q_chunk_owner.emplace_back((int)i, c);
@@ -690,7 +693,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
       for (size_t j = 0; j < (size_t(1) << la); ++j) {
         if (j == pos) continue;
         EF e;
-        for (int k = 0; k < 4; ++k) e.c[k] = st.leaves[p].at(row, j * 4 + k);
+        for (int k = 0; k < EF::deg(); ++k) e.c[k] = st.leaves[p].at(row, j * EF::deg() + k);
         step.sibling_values.push_back(e);
       }
       std::vector<std::vector<F>> ov;
@@ -732,8 +735,8 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
     if (ov.has_trace_next && (int)ov.trace_next.size() != w) fail("trace_next width");
     if ((int)ov.preprocessed_local.size() != pw || (int)ov.preprocessed_next.size() != pw) fail("prep width");
     if ((int)ov.quotient_chunks.size() != (1 << layouts[i].log_quotient_chunks)) fail("chunk count");
-    for (auto& c : ov.quotient_chunks) if (c.size() != 4) fail("chunk width");
-    const size_t aflat = (size_t)layouts[i].aux_width() * 4;
+    for (auto& c : ov.quotient_chunks) if (c.size() != (size_t)EF::deg()) fail("chunk width");
+    const size_t aflat = (size_t)layouts[i].aux_width() * EF::deg();
     if (ov.permutation_local.size() != aflat || ov.permutation_next.size() != aflat) fail("permutation width");
     if (proof.has_terminal[i] != !layouts[i].groups.empty()) fail("terminal presence");
   }
@@ -871,8 +874,8 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
       size_t s = 0;
       for (size_t j = 0; j < arity; ++j) evals[j] = (j == pos) ? folded : step.sibling_values[s++];
       std::vector<F> flat;
-      for (auto& e : evals) for (auto c : e.c) flat.push_back(c);
-      std::vector<std::pair<size_t, size_t>> dims{{size_t(1) << (log_cur - la), arity * 4}};
+      for (auto& e : evals) for (int k = 0; k < EF::deg(); ++k) flat.push_back(e.c[k]);
+      std::vector<std::pair<size_t, size_t>> dims{{size_t(1) << (log_cur - la), arity * (size_t)EF::deg()}};
       if (!MerkleTree<FP>::verify(p2, fp.commit_phase_commits[p], sp.cap_height, dims, row, {flat}, step.opening_proof))
         fail("commit-phase MMCS opening");
       folded = fold_row<FP>(evals, row, log_cur - la, la, betas[p]);
@@ -908,7 +911,7 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
         zp *= zh_coset(shifts[j], zeta) * zh_coset(shifts[j], EF(shifts[c])).inv();
       }
       EF val = EF::zero();
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < EF::deg(); ++e) {
         EF basis = EF::zero();
         basis.c[e] = F::one();
         val += basis * ov.quotient_chunks[c][e];
@@ -930,10 +933,10 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
       auto recompose = [&](const std::vector<EF>& flat) {
         std::vector<EF> out(aw, EF::zero());
         for (int c = 0; c < aw; ++c)
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < EF::deg(); ++e) {
             EF basis = EF::zero();
             basis.c[e] = F::one();
-            out[c] += basis * flat[c * 4 + e];
+            out[c] += basis * flat[c * EF::deg() + e];
           }
         return out;
       };

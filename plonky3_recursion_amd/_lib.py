@@ -34,7 +34,7 @@ class P3rConfig(C.Structure):
         ("fri_log_arities", C.POINTER(C.c_uint8)),
         ("fri_log_arities_len", C.c_uint32),
         ("proof_layout", C.POINTER(C.c_uint8)),
-        ("proof_layout_len", C.c_uint32), ("ext_w", C.c_uint32),
+        ("proof_layout_len", C.c_uint32), ("ext_w", C.c_uint32), ("challenge_degree", C.c_uint32),
     ]
 
 

@@ -357,35 +357,74 @@ struct Fp5 {
     r.c[4] = F::dot2(a.c[0], b.c[4], a.c[1], b.c[3]) + F::dot2(a.c[2], b.c[2], a.c[3], b.c[1]) + a.c[4] * b.c[0] - c7;
     return r;
   }
+  friend P3R_HD Fp5 operator*(Fp5 a, F b) { Fp5 r; for (int i = 0; i < 5; ++i) r.c[i] = a.c[i] * b; return r; }
+  P3R_HD Fp5 operator-() const { Fp5 r; for (int i = 0; i < 5; ++i) r.c[i] = -c[i]; return r; }
+  P3R_HD Fp5& operator+=(Fp5 o) { *this = *this + o; return *this; }
+  P3R_HD Fp5& operator-=(Fp5 o) { *this = *this - o; return *this; }
+  P3R_HD Fp5& operator*=(Fp5 o) { *this = *this * o; return *this; }
+  P3R_HD bool is_zero() const { return (c[0].v | c[1].v | c[2].v | c[3].v | c[4].v) == 0; }
+  P3R_HD Fp5 sqr() const { return *this * *this; }
+  P3R_HD Fp5 dbl() const { Fp5 r; for (int i = 0; i < 5; ++i) r.c[i] = c[i].dbl(); return r; }
+  P3R_HD Fp5 halve() const { Fp5 r; for (int i = 0; i < 5; ++i) r.c[i] = c[i].halve(); return r; }
+  P3R_HD Fp5 pow(uint64_t e) const {
+    Fp5 r = one(), b = *this;
+    while (e) {
+      if (e & 1) r *= b;
+      b = b.sqr();
+      e >>= 1;
+    }
+    return r;
+  }
+  static P3R_HD Fp5 dot2_base(const Fp5& a1, F b1, const Fp5& a2, F b2) {
+    Fp5 r;
+    for (int i = 0; i < 5; ++i) r.c[i] = F::dot2(a1.c[i], b1, a2.c[i], b2);
+    return r;
+  }
   static P3R_HD Fp5 one() { Fp5 r = zero(); r.c[0] = F::one(); return r; }
   static P3R_HD Fp5 from_base(F b) { Fp5 r = zero(); r.c[0] = b; return r; }
   P3R_HD bool operator==(const Fp5& o) const {
     return c[0] == o.c[0] && c[1] == o.c[1] && c[2] == o.c[2] && c[3] == o.c[3] && c[4] == o.c[4];
   }
-  // a^-1 (the circuit runner's backward Mul: rare): the columns of the multiplication-by-a matrix are a * x^j;
-  // Gauss-Jordan on [M | e_0] over the base field.  Zero has no inverse: the caller checks first.
+  // a^-1: the columns of the multiplication-by-a matrix are a * x^j; Gauss-Jordan on [M | e_0] over the base field.
+  // Every index is a compile-time constant once unrolled (the matrix stays in registers on the device): pivoting is
+  // a conditional row swap.  Zero has no inverse: callers check first (the result is then zero).
   P3R_HD Fp5 inv() const {
     F m[5][6];
     Fp5 col = *this, x = zero();
     x.c[1] = F::one();
+#pragma unroll
     for (int j = 0; j < 5; ++j) {
+#pragma unroll
       for (int i = 0; i < 5; ++i) m[i][j] = col.c[i];
       col = col * x;
     }
+#pragma unroll
     for (int i = 0; i < 5; ++i) m[i][5] = i == 0 ? F::one() : F::zero();
+#pragma unroll
     for (int k = 0; k < 5; ++k) {
-      int piv = k;
-      while (piv < 4 && m[piv][k] == F::zero()) ++piv;
-      for (int j = 0; j < 6; ++j) { const F t = m[k][j]; m[k][j] = m[piv][j]; m[piv][j] = t; }
+#pragma unroll
+      for (int i = k + 1; i < 5; ++i) {
+        const bool sw = m[k][k].v == 0 && m[i][k].v != 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const F a = m[k][j], b = m[i][j];
+          m[k][j] = sw ? b : a;
+          m[i][j] = sw ? a : b;
+        }
+      }
       const F s = m[k][k].inv();
+#pragma unroll
       for (int j = 0; j < 6; ++j) m[k][j] = m[k][j] * s;
+#pragma unroll
       for (int i = 0; i < 5; ++i) {
         if (i == k) continue;
         const F f = m[i][k];
+#pragma unroll
         for (int j = 0; j < 6; ++j) m[i][j] = m[i][j] - f * m[k][j];
       }
     }
     Fp5 r;
+#pragma unroll
     for (int i = 0; i < 5; ++i) r.c[i] = m[i][5];
     return r;
   }
@@ -402,6 +441,12 @@ template <class PP> struct CircuitExt<PP, 5> { using type = Fp5<PP>; };
 template <class V> struct Lift;
 template <class PP> struct Lift<Fp<PP>> { static P3R_HD Fp<PP> of(Fp<PP> x) { return x; } };
 template <class PP> struct Lift<Fp4<PP>> { static P3R_HD Fp4<PP> of(Fp<PP> x) { return Fp4<PP>::from_base(x); } };
+template <class PP> struct Lift<Fp5<PP>> { static P3R_HD Fp5<PP> of(Fp<PP> x) { return Fp5<PP>::from_base(x); } };
+// The STARK's challenge field: the quartic binomial extension (every BASELINE configuration), or - DC = 5 -
+// KoalaBear's quintic trinomial extension (test-utils koala_bear_quintic_params, recursive_fibonacci --quintic).
+template <class PP, int DC> struct Chal;
+template <class PP> struct Chal<PP, 4> { using type = Fp4<PP>; };
+template <class PP> struct Chal<PP, 5> { using type = Fp5<PP>; };
 
 P3R_HD uint32_t bit_reverse(uint32_t x, int bits) {
   if (bits == 0) return 0;

@@ -19,10 +19,10 @@
 
 namespace p3r {
 
-template <class PP>
+template <class PP, int DC = 4>
 struct HostChallenger {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;   // the challenge field: DC sampled / observed coefficients per element
   const uint32_t* rc;  // Montgomery
   F state[P2_WIDTH];
   std::vector<F> in_buf, out_buf;
@@ -45,7 +45,7 @@ struct HostChallenger {
     in_buf.push_back(x);
     if (in_buf.size() == (size_t)P2_RATE) duplexing();
   }
-  void observe_ext(const E& e) { for (int i = 0; i < 4; ++i) observe(e.c[i]); }
+  void observe_ext(const E& e) { for (int i = 0; i < DC; ++i) observe(e.c[i]); }
   void observe_base_as_ext(uint64_t v) { observe_ext(E::from_base(F::from_u64(v))); }
   void observe_digest_canonical(const uint32_t* d) { for (int i = 0; i < P2_DIGEST; ++i) observe(F::from_canonical(d[i])); }
   F sample() {
@@ -56,7 +56,7 @@ struct HostChallenger {
   }
   E sample_ext() {
     E e;
-    for (int i = 0; i < 4; ++i) e.c[i] = sample();
+    for (int i = 0; i < DC; ++i) e.c[i] = sample();
     return e;
   }
   uint32_t sample_bits(int bits) { return sample().to_canonical() & ((1u << bits) - 1); }
@@ -162,10 +162,10 @@ inline bool air_uses_next(const AirParams& a) { return a.kind == AIR_ALU || a.ki
 
 // ---- postcard writer. Field elements are written as the Montgomery word by default
 // (p3-monty-31's serde form), or canonical when `canonical` is set.
-template <class PP>
+template <class PP, int DC = 4>
 struct ProofWriter {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   // `out` is grown in large steps and written through a cursor (a proof is ~10^5 varints; a
   // push_back per byte made serialisation a visible part of small proofs); take() trims it.
   std::vector<uint8_t> out;
@@ -226,11 +226,11 @@ struct ProofWriter {
     return (size_t)(p - p0);
   }
 #endif
-  static_assert(sizeof(E) == 16 && sizeof(F) == 4, "extension elements are four contiguous words");
-  void ef(const E& e) { words(&e.c[0].v, 4); }
+  static_assert(sizeof(E) == 4 * DC && sizeof(F) == 4, "extension elements are DC contiguous words");
+  void ef(const E& e) { words(&e.c[0].v, DC); }
   void vec_ef(const std::vector<E>& v) {
     varint(v.size());
-    if (!v.empty()) words(&v[0].c[0].v, 4 * v.size());
+    if (!v.empty()) words(&v[0].c[0].v, DC * v.size());
   }
   void digest_mont(const uint32_t* d) { words(d, P2_DIGEST); }
   void cap_mont(const std::vector<uint32_t>& cap) {

@@ -1251,6 +1251,7 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
   try {
     if (!cfg || !airs || !preprocessed_commitment || !degree_bits || (!proof && proof_len)) { report("NULL argument"); return P3R_EINVAL; }
     if (cfg->abi_version != P3R_ABI_VERSION) { report("ABI version mismatch"); return P3R_EINVAL; }
+    if (cfg->challenge_degree != 0 && cfg->challenge_degree != 4 && cfg->challenge_degree != 5) { report("UnsupportedChallengeDegree"); return P3R_EUNSUPPORTED; }
     const bool generic_d = p3r::ext_degree_is_binomial_generic(cfg->ext_degree);
     if (generic_d && cfg->ext_w == 0) { report("MissingWForExtension"); return P3R_EINVAL; }
     if (!generic_d && cfg->ext_degree != 1 && cfg->ext_degree != 4 && !(cfg->ext_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR)) { report("UnsupportedDegree"); return P3R_EUNSUPPORTED; }
@@ -1275,7 +1276,14 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
       if (!src) src = PP::FIELD_ID == 0 ? kDefaultRc_koala_bear : kDefaultRc_baby_bear;
       auto airs_pp = a;
       for (auto& x : airs_pp) x.ext_w_mont = generic_d ? p3r::Fp<PP>::from_canonical(cfg->ext_w).v : 0u;
-      p3r::verify_batch<PP>(prm, std::vector<uint32_t>(src, src + nrc), airs_pp, cap, want_db, proof, proof_len, canonical);
+      if (cfg->challenge_degree == 5) {
+        if constexpr (p3r::kHasQuintic<PP>)
+          p3r::verify_batch<PP, 5>(prm, std::vector<uint32_t>(src, src + nrc), airs_pp, cap, want_db, proof, proof_len, canonical);
+        else
+          p3r::vfail("UnsupportedChallengeDegree: the quintic challenge field is KoalaBear's");
+      } else {
+        p3r::verify_batch<PP>(prm, std::vector<uint32_t>(src, src + nrc), airs_pp, cap, want_db, proof, proof_len, canonical);
+      }
     };
     if (cfg->field == P3R_FIELD_KOALA_BEAR) run(p3r::KoalaBearParams{});
     else if (cfg->field == P3R_FIELD_BABY_BEAR) run(p3r::BabyBearParams{});
@@ -1301,7 +1309,9 @@ int p3r_batch_proof_len_layout(uint32_t field, const uint8_t* bytes, size_t len,
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     p3r::ProofLayout PL;
     if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
-    if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len, PL);
+    if (field == P3R_FIELD_KOALA_BEAR && (flags & P3R_PROOF_QUINTIC_CHALLENGE))
+      (void)p3r::parse_proof<p3r::KoalaBearParams, 5>(bytes, len, canonical, proof_len, PL);
+    else if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len, PL);
     else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len, PL);
     else throw std::runtime_error("unknown field");
     return P3R_OK;
@@ -1320,8 +1330,9 @@ int p3r_batch_stark_proof_parse(uint32_t field, const uint8_t* bytes, size_t len
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     p3r::ProofLayout PL;
     if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
-    if (field == P3R_FIELD_KOALA_BEAR) p3r::parse_batch_stark_meta<p3r::KoalaBearParams>(bytes, len, canonical, PL, out);
-    else if (field == P3R_FIELD_BABY_BEAR) p3r::parse_batch_stark_meta<p3r::BabyBearParams>(bytes, len, canonical, PL, out);
+    const int dc = (flags & P3R_PROOF_QUINTIC_CHALLENGE) ? 5 : 4;
+    if (field == P3R_FIELD_KOALA_BEAR) p3r::parse_batch_stark_meta<p3r::KoalaBearParams>(bytes, len, canonical, PL, dc, out);
+    else if (field == P3R_FIELD_BABY_BEAR) p3r::parse_batch_stark_meta<p3r::BabyBearParams>(bytes, len, canonical, PL, dc, out);
     else throw std::runtime_error("unknown field");
     out->parse_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return P3R_OK;

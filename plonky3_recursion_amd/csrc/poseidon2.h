@@ -85,6 +85,12 @@ P3R_HD Fp4<PP> p2_div_2exp(Fp4<PP> x, int k) {
   for (int i = 0; i < 4; ++i) r.c[i] = p2_div_2exp(x.c[i], k);
   return r;
 }
+template <class PP>
+P3R_HD Fp5<PP> p2_div_2exp(Fp5<PP> x, int k) {
+  Fp5<PP> r;
+  for (int i = 0; i < 5; ++i) r.c[i] = p2_div_2exp(x.c[i], k);
+  return r;
+}
 
 // s_i <- v_i * s_i + sum(s), diagonal v per field:
 //  KoalaBear: [-2, 1, 2, 1/2, 3, 4, -1/2, -3, -4, 1/2^8, 1/8, 1/2^24, -1/2^8, -1/8, -1/16, -1/2^24]

@@ -39,10 +39,10 @@ struct VerifyFailure : std::runtime_error {
 }
 
 // ---- postcard reader (mirror of ProofWriter)
-template <class PP>
+template <class PP, int DC = 4>
 struct ProofReader {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   const uint8_t* p;
   const uint8_t* end;
   bool canonical;
@@ -77,7 +77,7 @@ struct ProofReader {
     if (v >= PP::P) vfail("field element out of range");
     return canonical ? F::from_canonical((uint32_t)v) : F::raw((uint32_t)v);
   }
-  E ef() { E e; for (int i = 0; i < 4; ++i) e.c[i] = fe(); return e; }
+  E ef() { E e; for (int i = 0; i < DC; ++i) e.c[i] = fe(); return e; }
   std::vector<E> vec_ef(size_t max = 1u << 16) {
     std::vector<E> v(len(max));
     for (auto& e : v) e = ef();
@@ -92,10 +92,10 @@ struct ProofReader {
   }
 };
 
-template <class PP>
+template <class PP, int DC = 4>
 struct ParsedProof {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   using Digest = std::array<F, P2_DIGEST>;
   using Cap = std::vector<Digest>;
   Cap main_cap, quot_cap;
@@ -120,11 +120,11 @@ struct ParsedProof {
 
 // `consumed`: when given, trailing bytes are allowed and the length of the BatchProof is returned
 // (the outer BatchStarkProof appends its metadata after it, batch_stark_prover.rs:610-636).
-template <class PP>
-ParsedProof<PP> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size_t* consumed = nullptr,
+template <class PP, int DC = 4>
+ParsedProof<PP, DC> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size_t* consumed = nullptr,
                             const ProofLayout& PL = ProofLayout{}) {
-  ProofReader<PP> R{bytes, bytes + n, canonical};
-  ParsedProof<PP> P;
+  ProofReader<PP, DC> R{bytes, bytes + n, canonical};
+  ParsedProof<PP, DC> P;
   auto read_commitments = [&] {
     P.main_cap = R.cap();
     if (R.flag()) P.perm_cap = R.cap();
@@ -294,14 +294,16 @@ struct ProofSkimmer {
 #endif
     fes_scalar(k);
   }
-  void vec_ef(size_t max = 1u << 16) { fes(4 * len(max)); }
+  int dc = 4;   // words per extension element (the challenge degree)
+  void vec_ef(size_t max = 1u << 16) { fes((size_t)dc * len(max)); }
   void cap() { fes(P2_DIGEST * len(1u << 16)); }
 };
 
 // Same grammar as parse_proof; returns the length of the BatchProof at the head of `bytes`.
 template <class PP>
-size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofLayout{}) {
+size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofLayout{}, int dc = 4) {
   ProofSkimmer<PP> R{bytes, bytes + n};
+  R.dc = dc;
   auto opened = [&] {
     const size_t ni = R.len(64);
     for (size_t i = 0; i < ni; ++i)
@@ -329,7 +331,7 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
       const size_t nph = R.len(64);
       for (size_t k = 0; k < nph; ++k) {
         (void)R.byte();
-        R.fes(4 * R.len(16));
+        R.fes((size_t)dc * R.len(16));
         R.fes(P2_DIGEST * R.len(64));
       }
     }
@@ -355,7 +357,7 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
         break;
       case 1: opened(); break;
       case 2: fri(); break;
-      case 3: { const size_t nt = R.len(64); for (size_t t = 0; t < nt; ++t) if (R.flag()) R.fes(4); break; }
+      case 3: { const size_t nt = R.len(64); for (size_t t = 0; t < nt; ++t) if (R.flag()) R.fes(dc); break; }
       default: { const size_t nd = R.len(64); for (size_t d = 0; d < nd; ++d) (void)R.len(40); break; }
     }
   }
@@ -364,10 +366,10 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
 
 // The metadata fields that follow the inner BatchProof (BatchStarkProof, batch_stark_prover.rs:610-636).
 template <class PP>
-void parse_batch_stark_meta(const uint8_t* bytes, size_t len, bool canonical, const ProofLayout& PL,
+void parse_batch_stark_meta(const uint8_t* bytes, size_t len, bool canonical, const ProofLayout& PL, int dc,
                             p3r_batch_stark_meta* M) {
   std::memset(M, 0, sizeof *M);
-  M->proof_len = skim_proof<PP>(bytes, len, PL);
+  M->proof_len = skim_proof<PP>(bytes, len, PL, dc);
   ProofSkimmer<PP> R{bytes + M->proof_len, bytes + len};
   auto u32 = [&](const char* what) {
     const uint64_t v = R.varint();
@@ -455,9 +457,9 @@ void parse_batch_stark_meta(const uint8_t* bytes, size_t len, bool canonical, co
 }
 
 // ---- the opened values of one instance as an AIR view over the extension field
-template <class PP>
+template <class PP, int DC = 4>
 struct ZetaView {
-  using V = Fp4<PP>;
+  using V = typename Chal<PP, DC>::type;
   const std::vector<V>*ml, *mn, *pl, *pn;
   V L(int c) const { return (*ml).at(c); }
   V N(int c) const { return (*mn).at(c); }
@@ -467,9 +469,9 @@ struct ZetaView {
 
 // acc <- acc * alpha + c over every constraint, base-field constraints first
 // (recursion/src/traits/air.rs:162-182)
-template <class PP>
+template <class PP, int DC = 4>
 struct ZetaFold {
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   E alpha, acc = E::zero();
   int count = 0;
   void base(const E& c) { acc = acc * alpha + c; ++count; }
@@ -478,13 +480,13 @@ struct ZetaFold {
 };
 
 // LogUp group constraints at zeta: f_g * prod d_k - sum_k m_k prod_{l != k} d_l (same grouping as QuotSink)
-template <class PP>
+template <class PP, int DC = 4>
 struct ZetaLookupSink {
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   E prefix;
   E beta_pow[kMaxExtD + 1];
   const std::vector<E>& aux;  // EF aux columns at zeta: [0] running sum, [g + 1] fraction of group g
-  ZetaFold<PP>& fold;
+  ZetaFold<PP, DC>& fold;
   int pair, cnt = 0;
   E d0 = E::zero(), m0 = E::zero(), sum_f = E::zero();
   template <int D>
@@ -583,9 +585,9 @@ void mmcs_verify(const std::vector<std::array<Fp<PP>, P2_DIGEST>>& cap, int cap_
 // (recursion/src/verifier/batch_stark.rs:886-1017, verifier/quotient.rs:60-140).  Shared by the
 // verifier and by the prover's self-check before it serialises a proof (prove_impl.cuh): the
 // counterpart of prove_batch's debug constraint check, at the cost of one evaluation per table.
-template <class PP>
+template <class PP, int DC = 4>
 struct ZetaInstance {
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   const std::vector<E>* main_local;
   const std::vector<E>* main_next;  // null when the AIR reads no next row
   const std::vector<E>* prep_local;
@@ -595,12 +597,13 @@ struct ZetaInstance {
   const std::vector<std::vector<E>>* chunks;
   const E* terminal;  // null without lookups
 };
-template <class PP>
-void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log_n_i, const ZetaInstance<PP>& in,
-                            Fp4<PP> alpha, Fp4<PP> zeta, Fp4<PP> l_prefix, const Fp4<PP>* l_beta_pow,
+template <class PP, int DC = 4>
+void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log_n_i, const ZetaInstance<PP, DC>& in,
+                            typename Chal<PP, DC>::type alpha, typename Chal<PP, DC>::type zeta,
+                            typename Chal<PP, DC>::type l_prefix, const typename Chal<PP, DC>::type* l_beta_pow,
                             const uint32_t* rc_mont, size_t i) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   const F gen = F::generator();
   {
     const size_t n = size_t(1) << log_n_i;
@@ -612,8 +615,8 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     const E is_first = zh * (zeta - E::one()).inv();
     const E is_last = zh * is_transition.inv();
     static const std::vector<E> none;
-    ZetaView<PP> v{in.main_local, in.main_next ? in.main_next : &none, in.prep_local, in.prep_next};
-    ZetaFold<PP> fold;
+    ZetaView<PP, DC> v{in.main_local, in.main_next ? in.main_next : &none, in.prep_local, in.prep_next};
+    ZetaFold<PP, DC> fold;
     fold.alpha = alpha;
     const bool generic = ext_degree_is_binomial_generic((uint32_t)air.ext_d);
     if (!(air.ext_d == 1 || air.ext_d == 4 || (air.ext_d == 5 && kHasQuintic<PP>) || (generic && air.kind != AIR_POSEIDON2)))
@@ -628,17 +631,17 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     if (L.n_groups) {
       // EF aux columns from their 4 base-column openings: sum_k x^k * col_k(zeta)
       auto ef_cols = [&](const std::vector<E>& flat) {
-        std::vector<E> out(flat.size() / 4, E::zero());
+        std::vector<E> out(flat.size() / DC, E::zero());
         for (size_t c = 0; c < out.size(); ++c)
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < DC; ++k) {
             E basis = E::zero();
             basis.c[k] = F::one();
-            out[c] += basis * flat[c * 4 + k];
+            out[c] += basis * flat[c * DC + k];
           }
         return out;
       };
       const std::vector<E> aux_l = ef_cols(*in.perm_local), aux_n = ef_cols(*in.perm_next);
-      ZetaLookupSink<PP> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4],
+      ZetaLookupSink<PP, DC> sink{l_prefix, {l_beta_pow[0], l_beta_pow[1], l_beta_pow[2], l_beta_pow[3], l_beta_pow[4],
                                          l_beta_pow[5], l_beta_pow[6], l_beta_pow[7], l_beta_pow[8]},
                               aux_l, fold, L.pair};
       dispatch_air_degree<PP>(air.ext_d, [&](auto dc) { air_interactions<PP, decltype(dc)::value>(air, v, sink); });
@@ -667,7 +670,7 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
         den *= (shifts[c] * shifts[o].inv()).pow(n) - F::one();
       }
       E qc = E::zero();
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < DC; ++k) {
         E basis = E::zero();
         basis.c[k] = F::one();
         qc += basis * (*in.chunks)[c][k];
@@ -685,14 +688,14 @@ struct VerifyParams {
   ProofLayout layout;                    // field order of the serialised structs (p3r_config.proof_layout)
 };
 
-template <class PP>
+template <class PP, int DC = 4>
 void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canonical, const std::vector<AirParams>& airs,
                   const std::vector<uint32_t>& prep_cap_canonical, const std::vector<uint32_t>& expected_degree_bits,
                   const uint8_t* bytes, size_t n_bytes, bool canonical) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   using Digest = std::array<F, P2_DIGEST>;
-  const ParsedProof<PP> P = parse_proof<PP>(bytes, n_bytes, canonical, nullptr, prm.layout);
+  const ParsedProof<PP, DC> P = parse_proof<PP, DC>(bytes, n_bytes, canonical, nullptr, prm.layout);
   const size_t ni = airs.size();
   if (rc_canonical.size() != (size_t)p2_num_constants<PP>()) vfail("wrong number of round constants");
   std::vector<uint32_t> rc(rc_canonical.size());
@@ -722,21 +725,21 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
     if (log_n[i] + lb > PP::TWO_ADICITY) vfail("instance %zu: degree too large", i);
     width[i] = air_width_of(airs[i], p2w);
     prep_w[i] = air_prep_width_of(airs[i]);
-    const size_t aw = (size_t)layouts[i].aux_width() * 4, C = size_t(1) << layouts[i].log_chunks;
+    const size_t aw = (size_t)layouts[i].aux_width() * DC, C = size_t(1) << layouts[i].log_chunks;
     if (in.main_local.size() != (size_t)width[i]) vfail("instance %zu: %zu main openings, the AIR has %d columns", i, in.main_local.size(), width[i]);
     if (air_uses_next(airs[i]) != in.main_next.has_value()) vfail("instance %zu: main next-row openings do not match the AIR", i);
     if (in.main_next && in.main_next->size() != (size_t)width[i]) vfail("instance %zu: bad main next width", i);
     if (in.prep_local.size() != (size_t)prep_w[i] || in.prep_next.size() != (size_t)prep_w[i]) vfail("instance %zu: bad preprocessed opening width", i);
     if (in.perm_local.size() != aw || in.perm_next.size() != aw) vfail("instance %zu: bad permutation opening width", i);
     if (in.chunks.size() != C) vfail("instance %zu: %zu quotient chunks, expected %zu", i, in.chunks.size(), C);
-    for (auto& c : in.chunks) if (c.size() != 4) vfail("instance %zu: bad quotient chunk width", i);
+    for (auto& c : in.chunks) if (c.size() != (size_t)DC) vfail("instance %zu: bad quotient chunk width", i);
     if ((layouts[i].n_groups > 0) != P.terminals[i].has_value()) vfail("instance %zu: lookup terminal presence mismatch", i);
     if (layouts[i].n_groups) { any_lookup = true; perm_insts.push_back((int)i); }
   }
   if (any_lookup != P.perm_cap.has_value()) vfail("permutation commitment presence mismatch");
 
   // ---- transcript (same order as prove_batch)
-  HostChallenger<PP> ch(rc.data());
+  HostChallenger<PP, DC> ch(rc.data());
   auto observe_cap = [&](const std::vector<Digest>& cap) { for (auto& d : cap) for (auto x : d) ch.observe(x); };
   ch.observe_base_as_ext(ni);
   for (size_t i = 0; i < ni; ++i) {
@@ -785,9 +788,9 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   E terminal_sum = E::zero();
   for (size_t i = 0; i < ni; ++i) {
     const auto& in = P.insts[i];
-    ZetaInstance<PP> zi{&in.main_local, in.main_next ? &*in.main_next : nullptr, &in.prep_local, &in.prep_next,
+    ZetaInstance<PP, DC> zi{&in.main_local, in.main_next ? &*in.main_next : nullptr, &in.prep_local, &in.prep_next,
                         &in.perm_local, &in.perm_next, &in.chunks, P.terminals[i] ? &*P.terminals[i] : nullptr};
-    check_instance_at_zeta<PP>(airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow, rc.data(), i);
+    check_instance_at_zeta<PP, DC>(airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow, rc.data(), i);
     if (layouts[i].n_groups) terminal_sum += *P.terminals[i];
   }
   if (any_lookup && !terminal_sum.is_zero()) vfail("global lookup sum is not zero");
@@ -803,12 +806,12 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
     rounds[0].push_back(m);
   }
   for (size_t i = 0; i < ni; ++i)
-    for (auto& c : P.insts[i].chunks) rounds[1].push_back({log_n[i] + lb, 4, {zeta}, {&c}});
+    for (auto& c : P.insts[i].chunks) rounds[1].push_back({log_n[i] + lb, DC, {zeta}, {&c}});
   for (size_t i = 0; i < ni; ++i)
     rounds[2].push_back({log_n[i] + lb, prep_w[i], {zeta, zeta * F::two_adic_generator(log_n[i])},
                          {&P.insts[i].prep_local, &P.insts[i].prep_next}});
   for (int i : perm_insts)
-    rounds[3].push_back({log_n[i] + lb, layouts[i].aux_width() * 4, {zeta, zeta * F::two_adic_generator(log_n[i])},
+    rounds[3].push_back({log_n[i] + lb, layouts[i].aux_width() * DC, {zeta, zeta * F::two_adic_generator(log_n[i])},
                          {&P.insts[i].perm_local, &P.insts[i].perm_next}});
   const std::vector<Digest>* round_caps[4] = {&P.main_cap, &P.quot_cap, &prep_cap, any_lookup ? &*P.perm_cap : nullptr};
   int log_max = 0;
@@ -900,7 +903,7 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
       for (size_t j = 0, s = 0; j < arity; ++j) e[j] = j == pos ? folded : ph.sibs[s++];
       // the leaf is the row of 2^la sibling evaluations, extension elements flattened
       std::vector<F> leaf;
-      for (auto& x : e) for (int k = 0; k < 4; ++k) leaf.push_back(x.c[k]);
+      for (auto& x : e) for (int k = 0; k < DC; ++k) leaf.push_back(x.c[k]);
       mmcs_verify<PP>(P.commit_caps[p], cap_h, {cur - la}, {leaf}, row, ph.path, rc.data(), "FRI commit phase");
       F ss_inv = F::two_adic_generator(cur).inv().pow(bit_reverse((uint32_t)row, cur - la));
       E b = betas[p];

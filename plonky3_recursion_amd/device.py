@@ -37,7 +37,7 @@ def _u8(a):
 
 def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5,
                 commit_pow_bits=0, query_pow_bits=15, num_queries=54, device=0, poseidon2_rc=None, ext_choices=0,
-                fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0):
+                fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0, challenge_degree=4):
     """A `p3r_config` (+ the arrays it points into, which must stay alive with it).  `ext_choices` /
     `fri_log_arities`: the selectable protocol details of include/p3r.h.
     `ext_degree`: the circuit extension degree D of the traces - 4, or 5 for KoalaBear circuits over the quintic
@@ -47,6 +47,7 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
     cfg.field = FIELD_IDS[field]
     cfg.ext_degree = ext_degree
     cfg.ext_w = ext_w     # W of x^D = W for ext_degree 2 / 6 / 8 (include/p3r.h)
+    cfg.challenge_degree = challenge_degree   # 5: KoalaBear's quintic challenge field
     cfg.log_blowup = log_blowup
     cfg.max_log_arity = max_log_arity
     cfg.cap_height = cap_height
@@ -104,15 +105,17 @@ class Context:
 
     def __init__(self, field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
                  log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
-                 device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0):
+                 device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0,
+                 challenge_degree=4):
         self.lib = _lib.load()
         self.field = field
         self.ext_degree = ext_degree
         self.ext_w = ext_w
+        self.challenge_degree = challenge_degree
         self.p = MODULUS[field]
         cfg, self._rc_keep = make_config(field, log_blowup, max_log_arity, cap_height, log_final_poly_len,
                                          commit_pow_bits, query_pow_bits, num_queries, device, poseidon2_rc, ext_choices,
-                                         fri_log_arities, proof_layout, ext_degree, ext_w)
+                                         fri_log_arities, proof_layout, ext_degree, ext_w, challenge_degree)
         self.cfg = cfg
         self.cap_height = cap_height
         self.log_blowup = log_blowup

@@ -28,13 +28,15 @@ class OrcParams(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("log_blowup", "max_log_arity", "cap_height", "log_final_poly_len",
                                           "commit_pow_bits", "query_pow_bits", "num_queries", "ext_choices",
                                           "n_fri_log_arities")] + [("fri_log_arities", C.c_uint8 * 32),
-                                                                   ("proof_layout", C.c_uint8 * 18)]
+                                                                   ("proof_layout", C.c_uint8 * 18),
+                                                                   ("challenge_degree", C.c_uint32)]
 
 
 def params(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0,
-           query_pow_bits=15, num_queries=54, ext_choices=0, fri_log_arities=None, proof_layout=None):
+           query_pow_bits=15, num_queries=54, ext_choices=0, fri_log_arities=None, proof_layout=None, challenge_degree=4):
     p = OrcParams(log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits,
                   num_queries, ext_choices, 0)
+    p.challenge_degree = challenge_degree
     if fri_log_arities is not None:
         p.n_fri_log_arities = len(fri_log_arities)
         for i, la in enumerate(fri_log_arities):

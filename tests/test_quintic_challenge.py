@@ -1,0 +1,73 @@
+"""The STARK over KoalaBear's quintic CHALLENGE field (`Challenge = QuinticTrinomialExtensionField<KoalaBear>`,
+test-utils koala_bear_quintic_params; recursive_fibonacci --quintic; recursion/tests/
+fibonacci_batch_stark_prover_quintic.rs): LogUp fractions, constraint folding, openings, FRI and the transcript run
+over five-coefficient elements; the base-field side (traces, LDE, MMCS) is unchanged.
+CPU: the oracle's prover against its verifier and the product's native verifier.  GPU: proof bytes."""
+import numpy as np
+import pytest
+
+import harness_lib
+import layer_lib
+
+FIELD = "koala-bear"
+SMALL = dict(horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+# circuit degree x table mix: the quintic recursion backend's own (D = 5), the base proof (D = 1), and D = 4 tables
+MIXES = [(5, harness_lib.RECOMPOSE_COEFF, 1), (1, harness_lib.NO_RECOMPOSE, 0), (4, 0, 0)]
+
+
+def native_verify(prm, tables, cap, proof, d, coeff=0, challenge_degree=5, canonical=False):
+    import plonky3_recursion_amd as p3r
+    cfg, keep = p3r.make_config(FIELD, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, ext_degree=d,
+                                challenge_degree=challenge_degree)
+    airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"],
+                 coeff_lookups=coeff if t["kind"] == "recompose" else 0) for t in tables]
+    p3r.verify_batch(cfg, airs, cap, [int(t["main"].shape[0]).bit_length() - 1 for t in tables], proof, canonical)
+
+
+@pytest.mark.parametrize("d,flags,coeff", MIXES)
+@pytest.mark.parametrize("log_h,kw", [
+    (5, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=0)),
+    (7, dict(log_blowup=2, max_log_arity=3, log_final_poly_len=2)),
+    (7, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, cap_height=2, commit_pow_bits=2)),
+])
+def test_oracle_and_native_verifier_over_the_quintic_challenge_field(oracle, d, flags, coeff, log_h, kw):
+    import plonky3_recursion_amd as p3r
+    prm = layer_lib.params(query_pow_bits=3, num_queries=5, challenge_degree=5, **kw)
+    arrs = harness_lib.generate(FIELD, log_h, seed=90 + log_h, flags=flags, ext_degree=d, **SMALL)
+    packing = dict(ext_degree=d, recompose_coeff_lookups=coeff)
+    L = layer_lib.OracleLayer(oracle, FIELD, arrs, prm, packing=packing)
+    pf = L.prove()
+    L.verify(pf)
+    assert L.prove() == pf
+    tables, cap = L.tables(), L.prep_commit()
+    native_verify(prm, tables, cap, pf, d, coeff)
+    native_verify(prm, tables, cap, L.prove(field_encoding=1), d, coeff, canonical=True)
+    # five words per extension element: the quartic verifier cannot even frame it, and vice versa
+    with pytest.raises(p3r.P3rError):
+        native_verify(prm, tables, cap, pf, d, coeff, challenge_degree=4)
+    prm4 = layer_lib.params(query_pow_bits=3, num_queries=5, **kw)
+    pf4 = layer_lib.OracleLayer(oracle, FIELD, arrs, prm4, packing=packing).prove()
+    assert len(pf) > len(pf4)
+    with pytest.raises(p3r.P3rError):
+        native_verify(prm, tables, cap, pf4, d, coeff)
+    for pos in range(7, len(pf), max(len(pf) // 25, 1)):
+        bad = bytearray(pf)
+        bad[pos] ^= 1
+        with pytest.raises(RuntimeError):
+            L.verify(bytes(bad))
+        with pytest.raises(p3r.P3rError):
+            native_verify(prm, tables, cap, bytes(bad), d, coeff)
+
+
+def test_quintic_challenge_is_koala_bears(oracle):
+    import plonky3_recursion_amd as p3r
+    prm = layer_lib.params(log_final_poly_len=1, query_pow_bits=2, num_queries=3)
+    arrs = harness_lib.generate("baby-bear", 6, seed=1, **SMALL)
+    L = layer_lib.OracleLayer(oracle, "baby-bear", arrs, prm)
+    cfg, keep = p3r.make_config("baby-bear", prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, challenge_degree=5)
+    tables = L.tables()
+    airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
+    with pytest.raises(p3r.P3rError, match="UnsupportedChallengeDegree"):
+        p3r.verify_batch(cfg, airs, L.prep_commit(), [int(t["main"].shape[0]).bit_length() - 1 for t in tables], L.prove())
