@@ -144,28 +144,29 @@ struct SubtreeArgs {
   // Optional (FRI commit phase, single-workgroup launch that ends at the root): the transcript step
   // of fri_transcript_step below runs right behind the root instead of in a launch of its own.
   uint32_t* t_state;  // [16] sponge state, or null
-  uint32_t* t_beta;   // [4]
+  uint32_t* t_beta;   // [DC]
   uint32_t* t_cap;    // [8]
+  int t_dc;           // words of the folding challenge (the challenge degree); 0 = 4
 };
 
 // One step of the FRI commit-phase transcript on the device (DuplexChallenger<F, Perm, 16, 8>,
 // recursion/src/challenger/circuit.rs:97-156,337-386) for cap_height 0 and no commit-phase proof
 // of work: observe the 8 words of the phase's Merkle root (a full rate block: overwrite
 // state[0..8], state[8] += 8, permute), then sample the folding challenge (an extension element
-// pops state[7], [6], [5], [4]).  Keeps the commit phase free of host round trips; the host
+// pops state[7], [6], [5], [4](, [3] over the quintic challenge field)).  Keeps the commit phase free of host round trips; the host
 // replays the same steps on its own transcript afterwards from `cap_out`.
 // Called by the 16 lanes of one DPP row; `root_word` = lane j's word of the root (j < 8).
 template <class PP>
 __device__ __forceinline__ void fri_transcript_step(int j, uint32_t root_word, uint32_t* __restrict__ state,
                                                     uint32_t* __restrict__ beta_out, uint32_t* __restrict__ cap_out,
-                                                    const CoopRc<PP>& rc, const uint32_t* __restrict__ diag) {
+                                                    const CoopRc<PP>& rc, const uint32_t* __restrict__ diag, int dc = 4) {
   using F = Fp<PP>;
   F s = j < P2_RATE ? F::raw(root_word) : F::raw(state[j]);
   if (j < P2_RATE) cap_out[j] = s.v;
   if (j == P2_RATE) s += F::from_canonical(P2_RATE);
   s = coop_permute<PP>(s, j, F::raw(diag[j]), rc);
   state[j] = s.v;
-  if (j >= 4 && j < P2_RATE) beta_out[7 - j] = s.v;
+  if (j >= P2_RATE - dc && j < P2_RATE) beta_out[7 - j] = s.v;
 }
 template <class PP>
 __global__ void __launch_bounds__(kSubtreeBlock)
@@ -208,7 +209,7 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
     // the root is the single node of the last level: word k at buf[(n_levels - 1) & 1][k]
     const uint32_t* root = buf[(a.n_levels - 1) & 1];
     fri_transcript_step<PP>((int)threadIdx.x, threadIdx.x < P2_RATE ? root[threadIdx.x] : 0u, a.t_state, a.t_beta,
-                            a.t_cap, rcs, diag);
+                            a.t_cap, rcs, diag, a.t_dc ? a.t_dc : 4);
   }
 }
 
@@ -217,11 +218,11 @@ k_mmcs_subtree(SubtreeArgs a, const uint32_t* __restrict__ rc, const uint32_t* _
 template <class PP>
 __global__ void __launch_bounds__(64)
 k_fri_transcript_step(const uint32_t* __restrict__ root /* [8] */, uint32_t* __restrict__ state /* [16] */,
-                      uint32_t* __restrict__ beta_out /* [4] */, uint32_t* __restrict__ cap_out /* [8] */,
-                      const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+                      uint32_t* __restrict__ beta_out /* [DC] */, uint32_t* __restrict__ cap_out /* [8] */,
+                      const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag, int dc) {
   const int j = threadIdx.x;
   if (j >= P2_WIDTH) return;  // one 16-lane row
-  fri_transcript_step<PP>(j, j < P2_RATE ? root[j] : 0u, state, beta_out, cap_out, coop_load_rc<PP>(rc, j), diag);
+  fri_transcript_step<PP>(j, j < P2_RATE ? root[j] : 0u, state, beta_out, cap_out, coop_load_rc<PP>(rc, j), diag, dc);
 }
 
 }  // namespace p3r

@@ -10,27 +10,29 @@ namespace p3r {
 
 // Both kernels run once per proof over job lists (one job per distinct (height, point), resp. per
 // height); a block finds its job by walking the list of first-block indices.
-struct FriInvJob {
-  uint32_t* inv;  // [4][h]
+template <int DC>
+struct FriInvJobT {
+  uint32_t* inv;  // [DC][h]
   uint64_t h;
   int log_h;
   uint32_t w_h;
   uint32_t w_4;     // primitive 4th root of unity w_h^(h/4) (h >= 4)
-  E4 z;
+  EW<DC> z;
   uint32_t block0;  // first block; a lane owns four consecutive rows
 };
-template <class PP>
+using FriInvJob = FriInvJobT<4>;
+template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock)
-k_fri_inv_points(const FriInvJob* __restrict__ jobs, int n_jobs, uint32_t gen) {
+k_fri_inv_points(const FriInvJobT<DC>* __restrict__ jobs, int n_jobs, uint32_t gen) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   int j = 0;
   while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
-  const FriInvJob& job = jobs[j];
+  const FriInvJobT<DC>& job = jobs[j];
   // four consecutive rows per lane: their inversions share one base-field inversion (inv4)
   const size_t h = job.h, r0 = ((size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x) * 4;
   if (r0 >= h) return;
-  const E z = e4_load<PP>(job.z);
+  const E z = e4_load<PP, DC>(job.z);
   E x[4], v[4];
   // rows r0..r0+3 differ in their two low bits, i.e. in the two HIGH bits of the bit-reversed
   // exponent: x, -x, ix, -ix with i = w_h^(h/4)   (h >= 4, r0 a multiple of 4)
@@ -46,7 +48,7 @@ k_fri_inv_points(const FriInvJob* __restrict__ jobs, int n_jobs, uint32_t gen) {
   for (int m = 0; m < 4; ++m)
     if (r0 + m < h)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) inv[(size_t)k * h + r0 + m] = v[m].c[k].v;
+      for (int k = 0; k < DC; ++k) inv[(size_t)k * h + r0 + m] = v[m].c[k].v;
 }
 
 // V = sum_c alpha^c * value_c over the opened values of one (matrix, point): one workgroup per
@@ -56,34 +58,34 @@ struct FriVsumJob {
   uint32_t* out;         // [4]
   int w;
 };
-template <class PP>
+template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock)
-k_fri_vsum(const FriVsumJob* __restrict__ jobs, const uint32_t* __restrict__ apow_tab /* alpha^c, 4 words each */) {
+k_fri_vsum(const FriVsumJob* __restrict__ jobs, const uint32_t* __restrict__ apow_tab /* alpha^c, DC words each */) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
-  __shared__ uint32_t sh[kBlock / 64][4];
+  using E = typename Chal<PP, DC>::type;
+  __shared__ uint32_t sh[kBlock / 64][DC];
   const FriVsumJob job = jobs[blockIdx.x];
   const gptr<const uint32_t> vals = as_global(job.vals);
   E acc = E::zero();
   for (int c = threadIdx.x; c < job.w; c += kBlock) {
     E ap, v;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      ap.c[k] = F::raw(apow_tab[4 * c + k]);
-      v.c[k] = F::raw(vals[4 * c + k]);
+    for (int k = 0; k < DC; ++k) {
+      ap.c[k] = F::raw(apow_tab[DC * c + k]);
+      v.c[k] = F::raw(vals[DC * c + k]);
     }
     acc += ap * v;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < DC; ++k) {
     F x = acc.c[k];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += F::raw(__shfl_down(x.v, off));
     if (lane == 0) sh[wave][k] = x.v;
   }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < DC) {
     F x = F::zero();
 #pragma unroll
     for (int wv = 0; wv < kBlock / 64; ++wv) x += F::raw(sh[wv][threadIdx.x]);
@@ -92,13 +94,15 @@ k_fri_vsum(const FriVsumJob* __restrict__ jobs, const uint32_t* __restrict__ apo
 }
 
 // One committed matrix and its opening points.
-struct FriReduceMat {
+template <int DC>
+struct FriReduceMatT {
   const uint32_t* mat;  // bit-reversed LDE [w][h]
   int w, n_points;
-  const uint32_t* inv[2];  // [4][h] each
-  const uint32_t* v[2];    // [4]: the k_fri_vsum result of this matrix and point
-  E4 off[2];
+  const uint32_t* inv[2];  // [DC][h] each
+  const uint32_t* v[2];    // [DC]: the k_fri_vsum result of this matrix and point
+  EW<DC> off[2];
 };
+using FriReduceMat = FriReduceMatT<4>;
 // All matrices of one height: lane r owns ro[r] and adds every matrix's term to it, so ro is
 // written once and needs no zero fill.
 struct FriReduceJob {
@@ -107,12 +111,12 @@ struct FriReduceJob {
   uint32_t mat0, n_mats;  // range in the matrix list
   uint32_t block0;
 };
-template <class PP>
+template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock)
-k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriReduceMat* __restrict__ mats,
-                 const uint32_t* __restrict__ apow_tab /* alpha^c, 4 words each */) {
+k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriReduceMatT<DC>* __restrict__ mats,
+                 const uint32_t* __restrict__ apow_tab /* alpha^c, DC words each */) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   int j = 0;
   while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
   const FriReduceJob job = jobs[j];
@@ -121,12 +125,12 @@ k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriRed
   auto apow = [&](int c) {
     E ap;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ap.c[k] = F::raw(apow_tab[4 * c + k]);
+    for (int k = 0; k < DC; ++k) ap.c[k] = F::raw(apow_tab[DC * c + k]);
     return ap;
   };
   E acc = E::zero();
   for (uint32_t m = 0; m < job.n_mats; ++m) {
-    const FriReduceMat& a = mats[job.mat0 + m];
+    const FriReduceMatT<DC>& a = mats[job.mat0 + m];
     const gptr<const uint32_t> mat = as_global(a.mat);
     const int w = a.w;
     E S = E::zero();
@@ -137,15 +141,15 @@ k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriRed
     for (int p = 0; p < a.n_points; ++p) {
       E inv;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) inv.c[k] = F::raw(as_global(a.inv[p])[(size_t)k * h + r]);
+      for (int k = 0; k < DC; ++k) inv.c[k] = F::raw(as_global(a.inv[p])[(size_t)k * h + r]);
       E V;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) V.c[k] = F::raw(as_global(a.v[p])[k]);
-      acc += e4_load<PP>(a.off[p]) * (V - S) * inv;
+      for (int k = 0; k < DC; ++k) V.c[k] = F::raw(as_global(a.v[p])[k]);
+      acc += e4_load<PP, DC>(a.off[p]) * (V - S) * inv;
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) as_global(job.ro)[(size_t)k * h + r] = acc.c[k].v;
+  for (int k = 0; k < DC; ++k) as_global(job.ro)[(size_t)k * h + r] = acc.c[k].v;
 }
 
 }  // namespace p3r

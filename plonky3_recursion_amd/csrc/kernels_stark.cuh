@@ -11,34 +11,38 @@
 
 namespace p3r {
 
-// Extension elements travel to kernels by value as 4 Montgomery words.
-struct E4 {
-  uint32_t c[4];
+// Extension elements (the challenge field, DC = 4 or 5 coefficients) travel to kernels by value as Montgomery words.
+template <int DC>
+struct EW {
+  uint32_t c[DC];
 };
-template <class PP>
-__host__ __device__ __forceinline__ Fp4<PP> e4_load(const E4& e) {
-  Fp4<PP> r;
-  for (int i = 0; i < 4; ++i) r.c[i] = Fp<PP>::raw(e.c[i]);
+using E4 = EW<4>;
+template <class PP, int DC = 4>
+__host__ __device__ __forceinline__ typename Chal<PP, DC>::type e4_load(const EW<DC>& e) {
+  typename Chal<PP, DC>::type r;
+  for (int i = 0; i < DC; ++i) r.c[i] = Fp<PP>::raw(e.c[i]);
   return r;
 }
-template <class PP>
-__host__ __device__ __forceinline__ E4 e4_store(const Fp4<PP>& e) {
-  E4 r;
-  for (int i = 0; i < 4; ++i) r.c[i] = e.c[i].v;
+template <class PP, int DC = 4>
+__host__ __device__ __forceinline__ EW<DC> e4_store(const typename Chal<PP, DC>::type& e) {
+  EW<DC> r;
+  for (int i = 0; i < DC; ++i) r.c[i] = e.c[i].v;
   return r;
 }
 
 // LogUp challenges: denominator = prefix + sum_j beta^j * field_j, tuple = (idx, v_0..v_{D-1}) for circuit
 // extension degree D, prefix = alpha + beta^(D+1) (recursion/src/verifier/batch_stark.rs:1086-1100).
-struct LookupCh {
-  E4 prefix;
-  E4 beta_pow[kMaxExtD + 1];
+template <int DC>
+struct LookupChT {
+  EW<DC> prefix;
+  EW<DC> beta_pow[kMaxExtD + 1];
 };
-template <class PP, int D>
-__device__ __forceinline__ Fp4<PP> lookup_denom(const LookupCh& lc, Fp<PP> idx, const VD<Fp<PP>, D>& v) {
-  Fp4<PP> d = e4_load<PP>(lc.prefix) + e4_load<PP>(lc.beta_pow[0]) * idx;
+using LookupCh = LookupChT<4>;
+template <class PP, int D, int DC>
+__device__ __forceinline__ typename Chal<PP, DC>::type lookup_denom(const LookupChT<DC>& lc, Fp<PP> idx, const VD<Fp<PP>, D>& v) {
+  typename Chal<PP, DC>::type d = e4_load<PP, DC>(lc.prefix) + e4_load<PP, DC>(lc.beta_pow[0]) * idx;
 #pragma unroll
-  for (int j = 0; j < D; ++j) d += e4_load<PP>(lc.beta_pow[j + 1]) * v.c[j];
+  for (int j = 0; j < D; ++j) d += e4_load<PP, DC>(lc.beta_pow[j + 1]) * v.c[j];
   return d;
 }
 
@@ -46,28 +50,28 @@ __device__ __forceinline__ Fp4<PP> lookup_denom(const LookupCh& lc, Fp<PP> idx, 
 // One lane per trace row: fraction columns f_g = sum_{k in g} m_k / d_k for each packed
 // lookup group (groups are consecutive pairs when `pair` else singletons - the host checks
 // that the packing computed from the degree budget has this shape), plus the row total.
-template <class PP>
+template <class PP, int DC = 4>
 struct AuxSink {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
-  const LookupCh& lc;
-  gptr<uint32_t> aux;  // [4*aw][n]
+  using E = typename Chal<PP, DC>::type;
+  const LookupChT<DC>& lc;
+  gptr<uint32_t> aux;  // [DC*aw][n]
   size_t n, row;
   int pair;
   int cnt = 0;
   E cur, total;
-  __device__ AuxSink(const LookupCh& l, gptr<uint32_t> a, size_t n_, size_t r, int p)
+  __device__ AuxSink(const LookupChT<DC>& l, gptr<uint32_t> a, size_t n_, size_t r, int p)
       : lc(l), aux(a), n(n_), row(r), pair(p), cur(E::zero()), total(E::zero()) {}
   __device__ __forceinline__ void flush() {
     int g = pair ? (cnt - 1) / 2 : cnt - 1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) aux[(size_t)((g + 1) * 4 + k) * n + row] = cur.c[k].v;
+    for (int k = 0; k < DC; ++k) aux[(size_t)((g + 1) * DC + k) * n + row] = cur.c[k].v;
     total += cur;
     cur = E::zero();
   }
   template <int D>
   __device__ __forceinline__ void add(F idx, const VD<F, D>& v, F mult) {
-    if (mult.v != 0) cur += lookup_denom<PP, D>(lc, idx, v).inv() * mult;
+    if (mult.v != 0) cur += lookup_denom<PP, D, DC>(lc, idx, v).inv() * mult;
     ++cnt;
     if (!pair || (cnt & 1) == 0) flush();
   }
@@ -77,6 +81,7 @@ struct AuxSink {
 };
 
 // The LogUp pass of every table of a proof is one launch of each kernel below over this job list.
+constexpr int kMaxChalD = 5;   // widest challenge field (words per extension element)
 struct LogupJob {
   AirParams air;
   const uint32_t* main;  // trace [w][n]
@@ -92,31 +97,31 @@ struct LogupJob {
   uint32_t tile0;        // first block in the tile launches (k_ef_scan modes 0 and 2)
 };
 
-template <class PP, int D = 4>
+template <class PP, int D = 4, int DC = 4>
 __global__ void __launch_bounds__(kBlock)
-k_logup_aux(const LogupJob* __restrict__ jobs, int n_jobs, LookupCh lc) {
+k_logup_aux(const LogupJob* __restrict__ jobs, int n_jobs, LookupChT<DC> lc) {
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
   const LogupJob& job = jobs[jb];
   const size_t n = job.n, r = (size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x;
   if (r >= n) return;
   RowView<PP> v{as_global(job.main), as_global(job.prep), n, r, r + 1 == n ? 0 : r + 1};
-  AuxSink<PP> sink(lc, as_global(job.aux), n, r, job.pair);
+  AuxSink<PP, DC> sink(lc, as_global(job.aux), n, r, job.pair);
   air_interactions<PP, D>(job.air, v, sink);
   sink.finish();
   const gptr<uint32_t> rowsum = as_global(job.rowsum);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) rowsum[(size_t)k * n + r] = sink.total.c[k].v;
+  for (int k = 0; k < DC; ++k) rowsum[(size_t)k * n + r] = sink.total.c[k].v;
 }
 
 // Exclusive prefix sum of extension elements (running LogUp sum, aux column 0) per job.
 // mode 0: tile totals -> agg; mode 1: exclusive scan of agg (one block per job), grand total ->
 // total; mode 2: write exclusive prefixes.
-template <class PP>
+template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock) k_ef_scan(int mode, const LogupJob* __restrict__ jobs, int n_jobs) {
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   using F = Fp<PP>;
-  __shared__ uint32_t sh[4][kBlock];
+  __shared__ uint32_t sh[DC][kBlock];
   const int tid = threadIdx.x;
   int jb = 0;
   if (mode == 1) jb = blockIdx.x;
@@ -134,7 +139,7 @@ __global__ void __launch_bounds__(kBlock) k_ef_scan(int mode, const LogupJob* __
     size_t lo = (size_t)tid * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
     for (size_t j = lo; j < hi; ++j) {
       E m;
-      for (int k = 0; k < 4; ++k) m.c[k] = F::raw(agg[4 * j + k]);
+      for (int k = 0; k < DC; ++k) m.c[k] = F::raw(agg[DC * j + k]);
       run += m;
     }
   } else {
@@ -144,54 +149,54 @@ __global__ void __launch_bounds__(kBlock) k_ef_scan(int mode, const LogupJob* __
       size_t i = base + q;
       loc[q] = E::zero();
       if (i < n)
-        for (int k = 0; k < 4; ++k) loc[q].c[k] = F::raw(in[(size_t)k * n + i]);
+        for (int k = 0; k < DC; ++k) loc[q].c[k] = F::raw(in[(size_t)k * n + i]);
       run += loc[q];
     }
   }
-  for (int k = 0; k < 4; ++k) sh[k][tid] = run.c[k].v;
+  for (int k = 0; k < DC; ++k) sh[k][tid] = run.c[k].v;
   __syncthreads();
   for (int off = 1; off < kBlock; off <<= 1) {
     E prev = E::zero(), cur;
     bool has = tid >= off;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < DC; ++k) {
       if (has) prev.c[k] = F::raw(sh[k][tid - off]);
       cur.c[k] = F::raw(sh[k][tid]);
     }
     __syncthreads();
     if (has) {
       cur += prev;
-      for (int k = 0; k < 4; ++k) sh[k][tid] = cur.c[k].v;
+      for (int k = 0; k < DC; ++k) sh[k][tid] = cur.c[k].v;
     }
     __syncthreads();
   }
   E excl = E::zero();
   if (tid > 0)
-    for (int k = 0; k < 4; ++k) excl.c[k] = F::raw(sh[k][tid - 1]);
+    for (int k = 0; k < DC; ++k) excl.c[k] = F::raw(sh[k][tid - 1]);
   if (mode == 0) {
     if (tid == kBlock - 1)
-      for (int k = 0; k < 4; ++k) agg[4 * (size_t)tile + k] = sh[k][tid];
+      for (int k = 0; k < DC; ++k) agg[DC * (size_t)tile + k] = sh[k][tid];
   } else if (mode == 1) {
     size_t per = (n_blocks + kBlock - 1) / kBlock;
     size_t lo = (size_t)tid * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
     E p = excl;
     for (size_t j = lo; j < hi; ++j) {
       E m;
-      for (int k = 0; k < 4; ++k) m.c[k] = F::raw(agg[4 * j + k]);
-      for (int k = 0; k < 4; ++k) agg[4 * j + k] = p.c[k].v;
+      for (int k = 0; k < DC; ++k) m.c[k] = F::raw(agg[DC * j + k]);
+      for (int k = 0; k < DC; ++k) agg[DC * j + k] = p.c[k].v;
       p += m;
     }
     if (tid == kBlock - 1)
-      for (int k = 0; k < 4; ++k) total[k] = sh[k][tid];
+      for (int k = 0; k < DC; ++k) total[k] = sh[k][tid];
   } else {
     E p;
-    for (int k = 0; k < 4; ++k) p.c[k] = F::raw(agg[4 * (size_t)tile + k]);
+    for (int k = 0; k < DC; ++k) p.c[k] = F::raw(agg[DC * (size_t)tile + k]);
     p += excl;
     size_t base = (size_t)tile * kScanTile + (size_t)tid * kScanItems;
 #pragma unroll
     for (int q = 0; q < kScanItems; ++q) {
       size_t i = base + q;
       if (i < n)
-        for (int k = 0; k < 4; ++k) out[(size_t)k * n + i] = p.c[k].v;
+        for (int k = 0; k < DC; ++k) out[(size_t)k * n + i] = p.c[k].v;
       p += loc[q];
     }
   }
@@ -209,20 +214,20 @@ struct QuotientArgs {
   const uint32_t* apow;   // alpha^j as 4 words each, j = 0..: one table for all AIRs of a proof
   int n_constraints;      // N: constraint k (base constraints first) is weighted alpha^(N-1-k)
   int n_base, n_groups, pair;
-  E4 terminal;
+  uint32_t terminal[kMaxChalD];   // the instance's LogUp terminal, DC words
   uint32_t gen;           // coset shift (Montgomery)
   uint32_t w_q;           // generator of the quotient domain (size n*C)
   uint32_t g_inv;         // inverse trace-domain generator
   uint32_t zh[4];         // Z_H on the C cosets:  gen^n * w_C^c - 1
   uint32_t zh_inv[4];
-  uint32_t* out;          // [C][4][n] chunk evaluations, natural order
+  uint32_t* out;          // [C][DC][n] chunk evaluations, natural order
   uint32_t block0;        // first block of this table in the launch (all tables of a proof share it)
 };
 
-template <class PP>
+template <class PP, int DC = 4>
 struct BaseFold {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   gptr<const uint32_t> apow;  // alpha^j, ascending
   int k;                      // exponent of the next constraint's weight: N-1, N-2, ...
   E acc;
@@ -230,7 +235,7 @@ struct BaseFold {
   __device__ __forceinline__ E pw() {
     E p;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p.c[i] = F::raw(apow[4 * k + i]);
+    for (int i = 0; i < DC; ++i) p.c[i] = F::raw(apow[DC * k + i]);
     --k;
     return p;
   }
@@ -244,29 +249,29 @@ struct BaseFold {
 };
 
 // Collects the LogUp group constraints:  f_g * prod d_k - sum_k m_k prod_{l!=k} d_l.
-template <class PP>
+template <class PP, int DC = 4>
 struct QuotSink {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   const QuotientArgs& q;
-  const LookupCh& lc;
+  const LookupChT<DC>& lc;
   gptr<const uint32_t> aux;
-  BaseFold<PP>& fold;
+  BaseFold<PP, DC>& fold;
   size_t row;
   int cnt = 0;
   E d0, sum_f;
   F m0;
-  __device__ QuotSink(const QuotientArgs& q_, const LookupCh& lc_, BaseFold<PP>& f, size_t r)
+  __device__ QuotSink(const QuotientArgs& q_, const LookupChT<DC>& lc_, BaseFold<PP, DC>& f, size_t r)
       : q(q_), lc(lc_), aux(as_global(q_.aux)), fold(f), row(r), d0(E::zero()), sum_f(E::zero()), m0(F::zero()) {}
   __device__ __forceinline__ E aux_at(int col, size_t r) const {
     E e;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e.c[k] = F::raw(aux[(size_t)(col * 4 + k) * q.lde_h + r]);
+    for (int k = 0; k < DC; ++k) e.c[k] = F::raw(aux[(size_t)(col * DC + k) * q.lde_h + r]);
     return e;
   }
   template <int D>
   __device__ __forceinline__ void add(F idx, const VD<F, D>& v, F mult) {
-    E d = lookup_denom<PP, D>(lc, idx, v);
+    E d = lookup_denom<PP, D, DC>(lc, idx, v);
     ++cnt;
     if (!q.pair) {
       E f = aux_at(cnt, row);
@@ -292,11 +297,11 @@ struct QuotSink {
 
 // One launch for all tables of a proof: `jobs` lists them, a block finds its table by walking the
 // first-block indices.  The LogUp challenges and the round constants are the same for every table.
-template <class PP, int D = 4>
+template <class PP, int D = 4, int DC = 4>
 __global__ void __launch_bounds__(kBlock)
-k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const uint32_t* __restrict__ rc) {
+k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupChT<DC> lc, const uint32_t* __restrict__ rc) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
   const QuotientArgs& q = jobs[jb];
@@ -311,7 +316,7 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const
   const uint32_t c = i & (uint32_t)(C - 1);
   const F zh = F::raw(q.zh[c]), g_inv = F::raw(q.g_inv);
   const F is_transition = x - g_inv;
-  BaseFold<PP> fold(as_global(q.apow), q.n_constraints);
+  BaseFold<PP, DC> fold(as_global(q.apow), q.n_constraints);
   if (q.air.kind == AIR_ALU) alu_constraints<PP, D>(q.air, v, fold);
   if (q.air.kind == AIR_POSEIDON2) {
     if constexpr (D == 4) poseidon2_constraints<PP>(v, is_transition, rc, fold);
@@ -320,18 +325,21 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const
   if (q.aux) {
     const F is_first = zh * (x - F::one()).inv();
     const F is_last = zh * is_transition.inv();
-    QuotSink<PP> sink(q, lc, fold, j);
+    QuotSink<PP, DC> sink(q, lc, fold, j);
     air_interactions<PP, D>(q.air, v, sink);
     sink.finish();
     E s = sink.aux_at(0, j), s_next = sink.aux_at(0, v.nxt);
     fold.ext(s * is_first);
     fold.ext((s_next - s - sink.sum_f) * is_transition);
-    fold.ext((s + sink.sum_f - e4_load<PP>(q.terminal)) * is_last);
+    E terminal;
+#pragma unroll
+    for (int k = 0; k < DC; ++k) terminal.c[k] = F::raw(q.terminal[k]);
+    fold.ext((s + sink.sum_f - terminal) * is_last);
   }
   E quot = fold.acc * F::raw(q.zh_inv[c]);
   const size_t n = size_t(1) << q.log_n, r = i >> q.log_chunks;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) as_global(q.out)[((size_t)c * 4 + k) * n + r] = quot.c[k].v;
+  for (int k = 0; k < DC; ++k) as_global(q.out)[((size_t)c * DC + k) * n + r] = quot.c[k].v;
 }
 
 // ------------------------------------------------------------------ K9: openings
@@ -343,6 +351,12 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupCh lc, const
 // norms): the tower inverse costs ~25 products plus a ~56-product exponentiation in the base
 // field, and the latter is what the four share.  A zero among them (never, for z outside the base
 // field) falls back to separate inversions so that it cannot poison its neighbours.
+template <class PP>
+__device__ __forceinline__ void inv4(const Fp5<PP> (&x)[4], Fp5<PP> (&out)[4]) {
+  // the quintic field has no cheap norm tower: four separate inversions
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = x[i].inv();
+}
 template <class PP>
 __device__ __forceinline__ void inv4(const Fp4<PP> (&x)[4], Fp4<PP> (&out)[4]) {
   using F = Fp<PP>;
@@ -369,25 +383,27 @@ __device__ __forceinline__ void inv4(const Fp4<PP> (&x)[4], Fp4<PP> (&out)[4]) {
 
 // Barycentric weights over the trace subgroup:  L_i(z) = w^i (z^n - 1) / (n (z - w^i)).
 // `scale` = (z^n - 1)/n is supplied by the host.
-struct BaryJob {
-  uint32_t* out;  // [4][n]
+template <int DC>
+struct BaryJobT {
+  uint32_t* out;  // [DC][n]
   uint64_t n;
   uint32_t w_n;
-  E4 z, scale;
+  EW<DC> z, scale;
   uint32_t block0;  // first block of this job
 };
-template <class PP>
-__global__ void __launch_bounds__(kBlock) k_bary_weights(const BaryJob* __restrict__ jobs, int n_jobs) {
+using BaryJob = BaryJobT<4>;
+template <class PP, int DC = 4>
+__global__ void __launch_bounds__(kBlock) k_bary_weights(const BaryJobT<DC>* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   int j = 0;
   while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
-  const BaryJob& b = jobs[j];
+  const BaryJobT<DC>& b = jobs[j];
   // four consecutive points per lane: their inversions share one base-field inversion (inv4)
   const size_t i0 = ((size_t)(blockIdx.x - b.block0) * kBlock + threadIdx.x) * 4;
   if (i0 >= b.n) return;
   const F w1 = F::raw(b.w_n);
-  const E z = e4_load<PP>(b.z), scale = e4_load<PP>(b.scale);
+  const E z = e4_load<PP, DC>(b.z), scale = e4_load<PP, DC>(b.scale);
   F wi[4];
   E x[4], inv[4];
   wi[0] = w1.pow(i0);
@@ -402,7 +418,7 @@ __global__ void __launch_bounds__(kBlock) k_bary_weights(const BaryJob* __restri
     if (i0 + m < b.n) {
       const E r = inv[m] * scale * wi[m];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) out[(size_t)k * b.n + i0 + m] = r.c[k].v;
+      for (int k = 0; k < DC; ++k) out[(size_t)k * b.n + i0 + m] = r.c[k].v;
     }
   }
 }
@@ -411,22 +427,22 @@ constexpr int kOpenCols = 8;      // matrix columns sharing one pass over the we
 constexpr int kOpenRows = 8192;   // rows per block for tall matrices (the host shrinks it for short ones)
 struct OpenJob {
   const uint32_t* mat;  // [w][n] column-major, natural order
-  const uint32_t *wt0, *wt1;  // weights per point ([4][n]); wt1 null for a single point
-  uint32_t* partial;    // [P][n_chunks][w][4]
+  const uint32_t *wt0, *wt1;  // weights per point ([DC][n]); wt1 null for a single point
+  uint32_t* partial;    // [P][n_chunks][w][DC]
   uint64_t n;
   int w, n_chunks, rows_per_block, col_groups;
   uint32_t block0;      // first block of this job in the dot launch
-  uint32_t out0;        // first output word of this job ([P][w][4]) in the reduce launch
+  uint32_t out0;        // first output word of this job ([P][w][DC]) in the reduce launch
 };
 // partial[p][chunk][col] = sum over the chunk's rows of weights_p[row] * M[col][row].
 // All accumulator indexing is compile-time (register resident); the block reduction is a
 // wave shuffle tree followed by a 4-wave LDS combine.
-template <class PP, int P>
+template <class PP, int P, int DC>
 __device__ __forceinline__ void open_dot_block(const OpenJob& job, int col_group, int chunk,
-                                               uint32_t (*sh)[2 * kOpenCols * 4]) {
+                                               uint32_t (*sh)[2 * kOpenCols * DC]) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
-  constexpr int NV = P * kOpenCols * 4;
+  using E = typename Chal<PP, DC>::type;
+  constexpr int NV = P * kOpenCols * DC;
   const gptr<const uint32_t> mat = as_global(job.mat);
   const gptr<const uint32_t> wt0 = as_global(job.wt0);
   const gptr<const uint32_t> wt1 = as_global(job.wt1);
@@ -444,13 +460,13 @@ __device__ __forceinline__ void open_dot_block(const OpenJob& job, int col_group
     const bool has_b = rb < r1;
     E wa[P], wb[P];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < DC; ++k) {
       wa[0].c[k] = F::raw(wt0[(size_t)k * n + r]);
       wb[0].c[k] = has_b ? F::raw(wt0[(size_t)k * n + rb]) : F::zero();
     }
     if (P == 2)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < DC; ++k) {
         wa[P - 1].c[k] = F::raw(wt1[(size_t)k * n + r]);
         wb[P - 1].c[k] = has_b ? F::raw(wt1[(size_t)k * n + rb]) : F::zero();
       }
@@ -469,34 +485,34 @@ __device__ __forceinline__ void open_dot_block(const OpenJob& job, int col_group
 #pragma unroll
     for (int c = 0; c < kOpenCols; ++c)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < DC; ++k) {
         F v = acc[p][c].c[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += F::raw(__shfl_down(v.v, off));
-        if (lane == 0) sh[wave][(p * kOpenCols + c) * 4 + k] = v.v;
+        if (lane == 0) sh[wave][(p * kOpenCols + c) * DC + k] = v.v;
       }
   __syncthreads();
   if ((int)threadIdx.x < NV) {
     F s = F::zero();
 #pragma unroll
     for (int wv = 0; wv < kBlock / 64; ++wv) s += F::raw(sh[wv][threadIdx.x]);
-    const int p = threadIdx.x / (kOpenCols * 4), rem = threadIdx.x % (kOpenCols * 4), c = rem / 4, k = rem % 4;
-    if (c0 + c < w) as_global(job.partial)[(((size_t)p * job.n_chunks + chunk) * w + c0 + c) * 4 + k] = s.v;
+    const int p = threadIdx.x / (kOpenCols * DC), rem = threadIdx.x % (kOpenCols * DC), c = rem / DC, k = rem % DC;
+    if (c0 + c < w) as_global(job.partial)[(((size_t)p * job.n_chunks + chunk) * w + c0 + c) * DC + k] = s.v;
   }
 }
-template <class PP>
+template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock) k_open_dot(const OpenJob* __restrict__ jobs, int n_jobs) {
-  __shared__ uint32_t sh[kBlock / 64][2 * kOpenCols * 4];
+  __shared__ uint32_t sh[kBlock / 64][2 * kOpenCols * DC];
   int j = 0;
   while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
   const OpenJob job = jobs[j];
   const int local = (int)(blockIdx.x - job.block0);
   const int col_group = local % job.col_groups, chunk = local / job.col_groups;
-  if (job.wt1) open_dot_block<PP, 2>(job, col_group, chunk, sh);
-  else open_dot_block<PP, 1>(job, col_group, chunk, sh);
+  if (job.wt1) open_dot_block<PP, 2, DC>(job, col_group, chunk, sh);
+  else open_dot_block<PP, 1, DC>(job, col_group, chunk, sh);
 }
-// out[out0 + (p*w + c)*4 + k] = sum over chunks of partial[p][chunk][c][k]
-template <class PP>
+// out[out0 + (p*w + c)*DC + k] = sum over chunks of partial[p][chunk][c][k]
+template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock)
 k_open_reduce(const OpenJob* __restrict__ jobs, int n_jobs, uint32_t total, uint32_t* __restrict__ out) {
   using F = Fp<PP>;
@@ -506,7 +522,7 @@ k_open_reduce(const OpenJob* __restrict__ jobs, int n_jobs, uint32_t total, uint
   while (j + 1 < n_jobs && t >= jobs[j + 1].out0) ++j;
   const OpenJob& job = jobs[j];
   const uint32_t local = t - job.out0;
-  const uint32_t per_point = (uint32_t)job.w * 4, p = local / per_point, rem = local % per_point;
+  const uint32_t per_point = (uint32_t)job.w * DC, p = local / per_point, rem = local % per_point;
   F s = F::zero();
   const gptr<const uint32_t> partial = as_global(job.partial);
   for (int ch = 0; ch < job.n_chunks; ++ch)
@@ -529,10 +545,10 @@ struct FriFoldArgs {
   uint32_t tw_inv[3][4];  // tw_inv[s][j] = (w_arity^{2^s})^{-bitrev(2j, la - s)}
   uint32_t neg_half;
 };
-template <class PP>
+template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock) k_fri_fold(FriFoldArgs a) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   size_t r = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= a.rows) return;
   const size_t n_in = a.rows << a.la;
@@ -540,11 +556,11 @@ __global__ void __launch_bounds__(kBlock) k_fri_fold(FriFoldArgs a) {
   const int arity = 1 << a.la;
   for (int j = 0; j < arity; ++j)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e[j].c[k] = F::raw(a.in[(size_t)k * n_in + (r << a.la) + j]);
+    for (int k = 0; k < DC; ++k) e[j].c[k] = F::raw(a.in[(size_t)k * n_in + (r << a.la) + j]);
   F ss_inv = F::raw(a.w_inv).pow(bit_reverse((uint32_t)r, a.log_rows));
   E b;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) b.c[k] = F::raw(a.beta[k]);
+  for (int k = 0; k < DC; ++k) b.c[k] = F::raw(a.beta[k]);
   const F nh = F::raw(a.neg_half);
   int len = arity;
   for (int s = 0; s < a.la; ++s) {
@@ -562,11 +578,11 @@ __global__ void __launch_bounds__(kBlock) k_fri_fold(FriFoldArgs a) {
   if (a.roll) {
     E ro;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ro.c[k] = F::raw(a.roll[(size_t)k * a.rows + r]);
+    for (int k = 0; k < DC; ++k) ro.c[k] = F::raw(a.roll[(size_t)k * a.rows + r]);
     res += b * ro;  // b is beta^(2^la) after the la squarings above
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) a.out[(size_t)k * a.rows + r] = res.c[k].v;
+  for (int k = 0; k < DC; ++k) a.out[(size_t)k * a.rows + r] = res.c[k].v;
 }
 
 // Leaf hashing for column sets that are strided views (FRI commit-phase leaves are the

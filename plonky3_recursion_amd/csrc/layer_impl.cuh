@@ -494,7 +494,7 @@ std::vector<uint8_t> prove_all_tables(p3r_ctx* ctx, const p3r_layer* L, const p3
   size_t n = 0;
   for (int i = 0; i < 5; ++i)
     if (mains[i]) ptrs[n++] = mains[i].get();
-  return prove_batch<PP>(ctx, L->prep.get(), ptrs, n, canonical);
+  return prove_batch_any<PP>(ctx, L->prep.get(), ptrs, n, canonical);
 }
 
 }  // namespace

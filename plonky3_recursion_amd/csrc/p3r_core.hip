@@ -670,6 +670,7 @@ void launch_compress(p3r_ctx* ctx, const uint32_t* prev, const uint32_t* inj, ui
 struct TranscriptStep {
   uint32_t *state, *beta, *cap;
   bool done = false;
+  int dc = 4;   // words of the folding challenge (the challenge degree)
 };
 template <class PP>
 size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_t, DevBuf>* inject,
@@ -697,6 +698,7 @@ size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_
     a.t_state = step->state;
     a.t_beta = step->beta;
     a.t_cap = step->cap;
+    a.t_dc = step->dc;
     step->done = true;
   }
   ProfScope ps(ctx, "mmcs_compress");
@@ -868,6 +870,9 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
       fail(P3R_EUNSUPPORTED, "unsupported field id %u", cfg->field);
     // circuit extension degree: 4 (binomial) on both fields; 5 = the KoalaBear quintic trinomial extension, proved
     // under the same D = 4 STARK configuration (batch_stark_prover/tests.rs:844-1029), primitive tables only
+    if (cfg->challenge_degree != 0 && cfg->challenge_degree != 4 &&
+        !(cfg->challenge_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR))
+      fail(P3R_EUNSUPPORTED, "UnsupportedChallengeDegree(%u): 4, or 5 over KoalaBear", cfg->challenge_degree);
     if (p3r::ext_degree_is_binomial_generic(cfg->ext_degree)) {
       // binomial extension x^D = W of degree 2 / 6 / 8: W is the caller's (BinomiallyExtendable<D>::W of its field
       // crate; the proof carries it as w_binomial)
@@ -1149,7 +1154,7 @@ int p3r_prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* m
     if (!prep || !main_traces || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
     for (size_t i = 0; i < n_instances; ++i)
       if (!main_traces[i]) fail(P3R_EINVAL, "main trace %zu is NULL", i);
-    auto bytes = P3R_FIELD_CALL(ctx, prove_batch, ctx, prep, main_traces, n_instances,
+    auto bytes = P3R_FIELD_CALL(ctx, prove_batch_any, ctx, prep, main_traces, n_instances,
                                 (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
     emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
   });
@@ -1168,7 +1173,7 @@ int p3r_prove_batch_host(p3r_ctx* ctx, const p3r_prep* prep, const p3r_matrix* m
                                      main_traces[i].width));
       ptrs.push_back(owned.back().get());
     }
-    auto bytes = P3R_FIELD_CALL(ctx, prove_batch, ctx, prep, ptrs.data(), n_instances,
+    auto bytes = P3R_FIELD_CALL(ctx, prove_batch_any, ctx, prep, ptrs.data(), n_instances,
                                 (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
     emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
   });

@@ -27,16 +27,16 @@ struct p3r_prep {
 
 namespace {
 
-template <class PP>
-E4 to_e4(const Fp4<PP>& e) { return e4_store<PP>(e); }
+template <class PP, int DC = 4>
+EW<DC> to_e4(const typename Chal<PP, DC>::type& e) { return e4_store<PP, DC>(e); }
 
-template <class PP>
-std::vector<Fp4<PP>> download_ef(p3r_ctx* ctx, const uint32_t* dev, size_t count) {
-  std::vector<uint32_t> raw(count * 4);
+template <class PP, int DC = 4>
+std::vector<typename Chal<PP, DC>::type> download_ef(p3r_ctx* ctx, const uint32_t* dev, size_t count) {
+  std::vector<uint32_t> raw(count * DC);
   P3R_HIP(fetch_small(ctx, dev, raw.size(), raw.data()));
-  std::vector<Fp4<PP>> out(count);
+  std::vector<typename Chal<PP, DC>::type> out(count);
   for (size_t i = 0; i < count; ++i)
-    for (int k = 0; k < 4; ++k) out[i].c[k] = Fp<PP>::raw(raw[i * 4 + k]);
+    for (int k = 0; k < DC; ++k) out[i].c[k] = Fp<PP>::raw(raw[i * DC + k]);
   return out;
 }
 
@@ -85,8 +85,8 @@ std::unique_ptr<p3r_tree> commit_dmats(p3r_ctx* ctx, const std::vector<const p3r
 // Proof-of-work grinding on the device: the smallest witness w such that, after observing w, the
 // low `bits` bits of the next sample are zero (recursion/src/challenger/circuit.rs:409-430).
 // Leaves the host challenger in the post-check state.  bits == 0: witness 0, transcript untouched.
-template <class PP>
-Fp<PP> grind_witness(p3r_ctx* ctx, HostChallenger<PP>& ch, int bits) {
+template <class PP, class Challenger>
+Fp<PP> grind_witness(p3r_ctx* ctx, Challenger& ch, int bits) {
   using F = Fp<PP>;
   if (bits == 0) return F::zero();
   if (bits > 30) fail(P3R_EINVAL, "proof-of-work bits must be <= 30");
@@ -159,11 +159,13 @@ struct RoundTrees {
   const p3r_tree* tree;
 };
 
-template <class PP>
+// DC: the degree of the challenge field (p3r_config.challenge_degree): 4, or 5 = KoalaBear's quintic trinomial
+// extension.  Extension vectors on the device are DC planes ([DC][n]); the proof writes DC words per element.
+template <class PP, int DC = 4>
 std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* mains, size_t ni,
                                  bool canonical_encoding) {
   using F = Fp<PP>;
-  using E = Fp4<PP>;
+  using E = typename Chal<PP, DC>::type;
   const p3r_config& cfg = ctx->cfg;
   const int log_blowup = (int)cfg.log_blowup;
   if (ni != prep->airs.size()) fail(P3R_EINVAL, "%zu traces for %zu preprocessed instances", ni, prep->airs.size());
@@ -184,8 +186,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<F> rc_host(ctx->rc_canonical.size());
   std::vector<uint32_t> rc_mont(ctx->rc_canonical.size());
   for (size_t i = 0; i < rc_mont.size(); ++i) rc_mont[i] = F::from_canonical(ctx->rc_canonical[i]).v;
-  HostChallenger<PP> ch(rc_mont.data());
-  ProofWriter<PP> W;
+  HostChallenger<PP, DC> ch(rc_mont.data());
+  ProofWriter<PP, DC> W;
   W.canonical = canonical_encoding;
 
   prof_stage(ctx, "main_lde_commit");
@@ -215,22 +217,22 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   // ---- 3. LogUp: challenges, aux traces, commitment, terminals
   bool any_lookup = false;
   for (auto& L : layouts) any_lookup |= L.n_groups > 0;
-  LookupCh lc{};
+  LookupChT<DC> lc{};
   if (any_lookup) {
     E alpha_l = ch.sample_ext(), beta_l = ch.sample_ext();
     E bp = E::one();
     // the widest tuple on the bus is (idx, v_0..v_{D-1}): gamma = beta^(D+1)
     const int tuple_w = (int)ctx->cfg.ext_degree + 1;
-    for (int j = 0; j < tuple_w; ++j) { lc.beta_pow[j] = to_e4<PP>(bp); bp *= beta_l; }
-    lc.prefix = to_e4<PP>(alpha_l + bp);  // alpha + beta^(D+1), bus id 0
+    for (int j = 0; j < tuple_w; ++j) { lc.beta_pow[j] = to_e4<PP, DC>(bp); bp *= beta_l; }
+    lc.prefix = to_e4<PP, DC>(alpha_l + bp);  // alpha + beta^(D+1), bus id 0
   }
   std::vector<std::unique_ptr<p3r_dmat>> aux(ni), aux_lde(ni);
   std::vector<E> terminals(ni, E::zero());
   std::vector<int> perm_insts;
   std::unique_ptr<p3r_tree> perm_tree;
   if (any_lookup) {
-    DevBuf totals(4 * ni);
-    P3R_HIP(hipMemsetAsync(totals.p, 0, 16 * ni, ctx->stream));
+    DevBuf totals(DC * ni);
+    P3R_HIP(hipMemsetAsync(totals.p, 0, 4 * DC * ni, ctx->stream));
     // aux traces of all tables: fractions per row, then the running sum as a three-phase scan
     std::vector<LogupJob> jobs;
     std::vector<DevBuf> scratch;
@@ -239,7 +241,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       const auto& L = layouts[i];
       if (!L.n_groups) continue;
       const size_t n = mains[i]->h;
-      aux[i] = dmat_alloc(n, (size_t)L.aux_width() * 4);
+      aux[i] = dmat_alloc(n, (size_t)L.aux_width() * DC);
       LogupJob j{};
       j.air = prep->airs[i];
       j.main = mains[i]->d;
@@ -249,11 +251,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       j.n = n;
       j.pair = L.pair;
       j.n_tiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
-      scratch.emplace_back(4 * n);
+      scratch.emplace_back(DC * n);
       j.rowsum = scratch.back().p;
-      scratch.emplace_back(4 * (size_t)j.n_tiles);
+      scratch.emplace_back(DC * (size_t)j.n_tiles);
       j.agg = scratch.back().p;
-      j.total = totals.p + 4 * i;
+      j.total = totals.p + DC * i;
       j.block0 = row_blocks;
       j.tile0 = tiles;
       row_blocks += blocks_for(n);
@@ -268,11 +270,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       const int nj = (int)jobs.size();
       ProfScope ps(ctx, "logup_aux");
       dispatch_air_degree<PP>((int)ctx->cfg.ext_degree, [&](auto dc) {
-        hipLaunchKernelGGL((k_logup_aux<PP, decltype(dc)::value>), dim3(row_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, nj, lc);
+        hipLaunchKernelGGL((k_logup_aux<PP, decltype(dc)::value, DC>), dim3(row_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, nj, lc);
       });
-      hipLaunchKernelGGL(k_ef_scan<PP>, dim3(tiles), dim3(kBlock), 0, ctx->stream, 0, d_jobs, nj);
-      hipLaunchKernelGGL(k_ef_scan<PP>, dim3((unsigned)nj), dim3(kBlock), 0, ctx->stream, 1, d_jobs, nj);
-      hipLaunchKernelGGL(k_ef_scan<PP>, dim3(tiles), dim3(kBlock), 0, ctx->stream, 2, d_jobs, nj);
+      hipLaunchKernelGGL((k_ef_scan<PP, DC>), dim3(tiles), dim3(kBlock), 0, ctx->stream, 0, d_jobs, nj);
+      hipLaunchKernelGGL((k_ef_scan<PP, DC>), dim3((unsigned)nj), dim3(kBlock), 0, ctx->stream, 1, d_jobs, nj);
+      hipLaunchKernelGGL((k_ef_scan<PP, DC>), dim3(tiles), dim3(kBlock), 0, ctx->stream, 2, d_jobs, nj);
       P3R_HIP(hipGetLastError());
     }
     lde_items.clear();
@@ -286,7 +288,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     perm_tree = commit_dmats<PP>(ctx, ptrs, perm_cap);
     {
       // every table's global sum in one transfer
-      auto all = download_ef<PP>(ctx, totals.p, ni);
+      auto all = download_ef<PP, DC>(ctx, totals.p, ni);
       for (int i : perm_insts) terminals[i] = all[i];
     }
     for (uint32_t v : perm_cap) ch.observe(F::raw(v));
@@ -305,12 +307,12 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   };
   int n_max = 1;
   for (size_t i = 0; i < ni; ++i) n_max = std::max(n_max, n_constraints(i));
-  DevBuf d_apow((size_t)n_max * 4);
+  DevBuf d_apow((size_t)n_max * DC);
   {
-    std::vector<uint32_t> apow((size_t)n_max * 4);
+    std::vector<uint32_t> apow((size_t)n_max * DC);
     E p = E::one();
     for (int k = 0; k < n_max; ++k) {
-      for (int c = 0; c < 4; ++c) apow[4 * k + c] = p.c[c].v;
+      for (int c = 0; c < DC; ++c) apow[DC * k + c] = p.c[c].v;
       p *= alpha;
     }
     P3R_HIP(ctx->stage.upload(ctx->stream, d_apow.p, apow.data(), apow.size() * 4));
@@ -334,7 +336,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     q.log_chunks = lq;
     q.apow = d_apow.p;
     q.n_base = n_base; q.n_groups = L.n_groups; q.pair = L.pair;
-    q.terminal = to_e4<PP>(terminals[i]);
+    for (int k = 0; k < DC; ++k) q.terminal[k] = terminals[i].c[k].v;
     q.gen = gen.v;
     const F wq = F::two_adic_generator(log_n[i] + lq);
     q.w_q = wq.v;
@@ -345,7 +347,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       q.zh[c] = zh.v;
       q.zh_inv[c] = zh.inv().v;
     }
-    auto chunk_buf = dmat_alloc(n, (size_t)4 * C);  // [C][4][n]
+    auto chunk_buf = dmat_alloc(n, (size_t)DC * C);  // [C][DC][n]
     q.out = chunk_buf->d;
     q.block0 = quot_blocks;
     quot_blocks += blocks_for(n << lq);
@@ -355,9 +357,9 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       ck.inst = (int)i;
       ck.shift = gen * wq.pow(c);
       ck.evals = std::make_unique<p3r_dmat>();
-      ck.evals->d = chunk_buf->d + (size_t)c * 4 * n;  // view: n x 4 column-major
+      ck.evals->d = chunk_buf->d + (size_t)c * DC * n;  // view: n x DC column-major
       ck.evals->h = n;
-      ck.evals->w = 4;
+      ck.evals->w = DC;
       chunks.push_back(std::move(ck));
     }
     chunk_bufs_keep.push_back(std::move(chunk_buf));
@@ -367,7 +369,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     P3R_HIP(ctx->stage.upload(ctx->stream, d_quot.p, quot_jobs.data(), quot_jobs.size() * sizeof(QuotientArgs)));
     ProfScope ps(ctx, "quotient");
     dispatch_air_degree<PP>((int)ctx->cfg.ext_degree, [&](auto dc) {
-      hipLaunchKernelGGL((k_quotient<PP, decltype(dc)::value>), dim3(quot_blocks), dim3(kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL((k_quotient<PP, decltype(dc)::value, DC>), dim3(quot_blocks), dim3(kBlock), 0, ctx->stream,
                          reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc, ctx->rc.p);
     });
     P3R_HIP(hipGetLastError());
@@ -391,7 +393,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<Item> items;
   std::vector<std::vector<std::vector<E>>> o_main(ni), o_prep(ni), o_perm(ni);
   std::vector<std::vector<E>> o_chunks(chunks.size());
-  Opener<PP> op(ctx);  // keeps the opened values on the device for the reduced openings
+  Opener<PP, DC> op(ctx);  // keeps the opened values on the device for the reduced openings
   {
     for (size_t i = 0; i < ni; ++i) {
       std::vector<E> pts{zeta};
@@ -401,7 +403,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     }
     for (size_t k = 0; k < chunks.size(); ++k) {
       auto& ck = chunks[k];
-      size_t j = op.open(ck.evals->d, ck.evals->h, 4, ck.shift, {zeta});
+      size_t j = op.open(ck.evals->d, ck.evals->h, DC, ck.shift, {zeta});
       items.push_back({1, (int)k, ck.lde.get(), log_n[ck.inst], {zeta}, {}, j});
     }
     for (size_t i = 0; i < ni; ++i) {
@@ -427,37 +429,41 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   }
   // 1/(zeta - x) vectors of the reduced openings depend on the opening points only: the device
   // computes them while the host absorbs the opened values into the transcript
-  std::map<std::array<uint64_t, 3>, uint32_t*> inv_cache;  // (log_height, z) -> 1/(z - x_r)
+  std::map<std::array<uint64_t, 6>, uint32_t*> inv_cache;  // (log_height, z) -> 1/(z - x_r)
+  auto inv_key = [](int lh, const E& z) {
+    std::array<uint64_t, 6> key{(uint64_t)lh, 0, 0, 0, 0, 0};
+    for (int k = 0; k < DC; ++k) key[1 + k] = z.c[k].v;
+    return key;
+  };
   std::vector<DevBuf> inv_keep;
   {
-    std::vector<FriInvJob> inv_jobs;
+    std::vector<FriInvJobT<DC>> inv_jobs;
     uint32_t inv_blocks = 0;
     for (auto& it : items) {
       const int lh = it.log_h + log_blowup;
       for (size_t p = 0; p < it.z.size(); ++p) {
-        std::array<uint64_t, 3> key{(uint64_t)lh, ((uint64_t)it.z[p].c[0].v << 32) | it.z[p].c[1].v,
-                                    ((uint64_t)it.z[p].c[2].v << 32) | it.z[p].c[3].v};
+        const auto key = inv_key(lh, it.z[p]);
         if (inv_cache.count(key)) continue;
-        inv_keep.emplace_back((size_t)4 << lh);
-        FriInvJob j{};
+        inv_keep.emplace_back((size_t)DC << lh);
+        FriInvJobT<DC> j{};
         j.inv = inv_keep.back().p;
         j.h = uint64_t(1) << lh;
         j.log_h = lh;
         if (lh < 2) fail(P3R_EINVAL, "FRI: an LDE of fewer than four rows");
         j.w_h = F::two_adic_generator(lh).v;
         j.w_4 = F::two_adic_generator(2).v;
-        j.z = to_e4<PP>(it.z[p]);
+        j.z = to_e4<PP, DC>(it.z[p]);
         j.block0 = inv_blocks;
         inv_blocks += blocks_for((size_t(1) << lh) / 4);
         inv_jobs.push_back(j);
         inv_cache.emplace(key, j.inv);
       }
     }
-    inv_keep.emplace_back((inv_jobs.size() * sizeof(FriInvJob) + 3) / 4);
-    P3R_HIP(ctx->stage.upload(ctx->stream, inv_keep.back().p, inv_jobs.data(), inv_jobs.size() * sizeof(FriInvJob)));
+    inv_keep.emplace_back((inv_jobs.size() * sizeof(FriInvJobT<DC>) + 3) / 4);
+    P3R_HIP(ctx->stage.upload(ctx->stream, inv_keep.back().p, inv_jobs.data(), inv_jobs.size() * sizeof(FriInvJobT<DC>)));
     ProfScope ps(ctx, "fri_inv_points");
-    hipLaunchKernelGGL(k_fri_inv_points<PP>, dim3(inv_blocks), dim3(kBlock), 0, ctx->stream,
-                       reinterpret_cast<const FriInvJob*>(inv_keep.back().p), (int)inv_jobs.size(), gen.v);
+    hipLaunchKernelGGL((k_fri_inv_points<PP, DC>), dim3(inv_blocks), dim3(kBlock), 0, ctx->stream,
+                       reinterpret_cast<const FriInvJobT<DC>*>(inv_keep.back().p), (int)inv_jobs.size(), gen.v);
     P3R_HIP(hipGetLastError());
   }
   for (auto& it : items)
@@ -471,18 +477,18 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   // extension-field evaluations per table, done while the device computes the 1/(z - x) vectors.
   {
     E l_beta_pow[kMaxExtD + 1];
-    for (int j = 0; j <= kMaxExtD; ++j) l_beta_pow[j] = e4_load<PP>(lc.beta_pow[j]);
-    const E l_prefix = e4_load<PP>(lc.prefix);
+    for (int j = 0; j <= kMaxExtD; ++j) l_beta_pow[j] = e4_load<PP, DC>(lc.beta_pow[j]);
+    const E l_prefix = e4_load<PP, DC>(lc.prefix);
     std::vector<std::vector<std::vector<E>>> inst_chunks(ni);
     for (size_t k = 0; k < chunks.size(); ++k) inst_chunks[chunks[k].inst].push_back(o_chunks[k]);
     static const std::vector<E> empty;
     for (size_t i = 0; i < ni; ++i) {
       const bool lk = layouts[i].n_groups > 0;
-      ZetaInstance<PP> zi{&o_main[i][0], o_main[i].size() > 1 ? &o_main[i][1] : nullptr, &o_prep[i][0], &o_prep[i][1],
+      ZetaInstance<PP, DC> zi{&o_main[i][0], o_main[i].size() > 1 ? &o_main[i][1] : nullptr, &o_prep[i][0], &o_prep[i][1],
                           lk ? &o_perm[i][0] : &empty, lk ? &o_perm[i][1] : &empty, &inst_chunks[i],
                           lk ? &terminals[i] : nullptr};
       try {
-        check_instance_at_zeta<PP>(prep->airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow,
+        check_instance_at_zeta<PP, DC>(prep->airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow,
                                    ctx->rc_mont_host.data(), i);
       } catch (const VerifyFailure& e) {
         fail(P3R_EINVAL, "the traces do not satisfy the constraints (%s)", e.what());
@@ -501,44 +507,42 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<E> fa_pow(max_w + 1);
   fa_pow[0] = E::one();
   for (size_t c = 1; c <= max_w; ++c) fa_pow[c] = fa_pow[c - 1] * fri_alpha;
-  DevBuf d_fapow(max_w * 4);
+  DevBuf d_fapow(max_w * DC);
   {
-    std::vector<uint32_t> h(max_w * 4);
+    std::vector<uint32_t> h(max_w * DC);
     for (size_t c = 0; c < max_w; ++c)
-      for (int k = 0; k < 4; ++k) h[c * 4 + k] = fa_pow[c].c[k].v;
+      for (int k = 0; k < DC; ++k) h[c * DC + k] = fa_pow[c].c[k].v;
     P3R_HIP(ctx->stage.upload(ctx->stream, d_fapow.p, h.data(), h.size() * 4));
   }
   // One pass per height over all its matrices (kernels_fri_reduce.cuh); alpha powers restart per
   // height and run on across that height's matrices and points in `items` order.
-  std::map<int, std::pair<E, DevBuf>> ros;  // log_height -> (alpha power, ro planes [4][h])
+  std::map<int, std::pair<E, DevBuf>> ros;  // log_height -> (alpha power, ro planes [DC][h])
   {
-    std::map<int, std::vector<FriReduceMat>> by_height;
+    std::map<int, std::vector<FriReduceMatT<DC>>> by_height;
     std::vector<DevBuf> keep;
     std::vector<FriVsumJob> vsum_jobs;
-    DevBuf vsums(8 * items.size());
+    DevBuf vsums(2 * DC * items.size());
     for (auto& it : items) {
       const int lh = it.log_h + log_blowup;
       auto f = ros.find(lh);
-      if (f == ros.end()) f = ros.emplace(lh, std::make_pair(E::one(), DevBuf((size_t)4 << lh))).first;
-      FriReduceMat a{};
+      if (f == ros.end()) f = ros.emplace(lh, std::make_pair(E::one(), DevBuf((size_t)DC << lh))).first;
+      FriReduceMatT<DC> a{};
       a.mat = it.lde->d;
       a.w = (int)it.lde->w;
       a.n_points = (int)it.z.size();
       E ap = f->second.first;
       for (size_t p = 0; p < it.z.size(); ++p) {
-        std::array<uint64_t, 3> key{(uint64_t)lh, ((uint64_t)it.z[p].c[0].v << 32) | it.z[p].c[1].v,
-                                    ((uint64_t)it.z[p].c[2].v << 32) | it.z[p].c[3].v};
-        a.inv[p] = inv_cache.at(key);
+        a.inv[p] = inv_cache.at(inv_key(lh, it.z[p]));
         // V = sum_c alpha^c * opened value c, formed on the device (k_fri_vsum)
-        a.v[p] = vsums.p + 4 * vsum_jobs.size();
-        vsum_jobs.push_back({op.values_dev(it.job, (int)p), vsums.p + 4 * vsum_jobs.size(), (int)it.vals[p].size()});
-        a.off[p] = to_e4<PP>(ap);
+        a.v[p] = vsums.p + DC * vsum_jobs.size();
+        vsum_jobs.push_back({op.values_dev(it.job, (int)p), vsums.p + DC * vsum_jobs.size(), (int)it.vals[p].size()});
+        a.off[p] = to_e4<PP, DC>(ap);
         ap *= fa_pow[it.lde->w];
       }
       f->second.first = ap;
       by_height[lh].push_back(a);
     }
-    std::vector<FriReduceMat> mats;
+    std::vector<FriReduceMatT<DC>> mats;
     std::vector<FriReduceJob> jobs;
     uint32_t blocks = 0;
     for (auto& kv : by_height) {
@@ -553,7 +557,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       mats.insert(mats.end(), kv.second.begin(), kv.second.end());
     }
     // the three job lists travel in one transfer
-    const size_t b_mats = mats.size() * sizeof(FriReduceMat), b_jobs = jobs.size() * sizeof(FriReduceJob),
+    const size_t b_mats = mats.size() * sizeof(FriReduceMatT<DC>), b_jobs = jobs.size() * sizeof(FriReduceJob),
                  b_vsum = vsum_jobs.size() * sizeof(FriVsumJob);
     const size_t o_jobs = (b_mats + 15) & ~size_t(15), o_vsum = (o_jobs + b_jobs + 15) & ~size_t(15);
     std::vector<unsigned char> blob(o_vsum + b_vsum);
@@ -563,14 +567,14 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     keep.emplace_back((blob.size() + 3) / 4);
     unsigned char* d_blob = reinterpret_cast<unsigned char*>(keep.back().p);
     P3R_HIP(ctx->stage.upload(ctx->stream, d_blob, blob.data(), blob.size()));
-    const auto* d_mats = reinterpret_cast<const FriReduceMat*>(d_blob);
+    const auto* d_mats = reinterpret_cast<const FriReduceMatT<DC>*>(d_blob);
     const auto* d_jobs = reinterpret_cast<const FriReduceJob*>(d_blob + o_jobs);
     const auto* d_vsum = reinterpret_cast<const FriVsumJob*>(d_blob + o_vsum);
     {
       ProfScope ps(ctx, "fri_reduce");
-      hipLaunchKernelGGL(k_fri_vsum<PP>, dim3((unsigned)vsum_jobs.size()), dim3(kBlock), 0, ctx->stream, d_vsum,
+      hipLaunchKernelGGL((k_fri_vsum<PP, DC>), dim3((unsigned)vsum_jobs.size()), dim3(kBlock), 0, ctx->stream, d_vsum,
                          d_fapow.p);
-      hipLaunchKernelGGL(k_fri_reduce_pre<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(),
+      hipLaunchKernelGGL((k_fri_reduce_pre<PP, DC>), dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(),
                          d_mats, d_fapow.p);
     }
     P3R_HIP(hipGetLastError());
@@ -594,9 +598,9 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   // commit phase is enqueued without a host round trip; the host replays them afterwards.
   const bool device_transcript = cfg.cap_height == 0 && cfg.commit_pow_bits == 0 && ch.in_buf.empty();
   constexpr size_t kMaxPhases = 32;
-  DevBuf d_tstate(P2_WIDTH), d_phase((4 + P2_DIGEST) * kMaxPhases);  // challenges, then roots
+  DevBuf d_tstate(P2_WIDTH), d_phase((DC + P2_DIGEST) * kMaxPhases);  // challenges, then roots
   uint32_t* const d_betas = d_phase.p;
-  uint32_t* const d_caps = d_phase.p + 4 * kMaxPhases;
+  uint32_t* const d_caps = d_phase.p + DC * kMaxPhases;
   if (device_transcript) {
     uint32_t st[P2_WIDTH];
     for (int k = 0; k < P2_WIDTH; ++k) st[k] = ch.state[k].v;
@@ -611,7 +615,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     Phase ph;
     ph.la = la;
     ph.rows = rows;
-    // leaves: row r = the 2^la sibling evaluations, EF flattened -> column (j*4+k) = plane k, offset j, stride arity
+    // leaves: row r = the 2^la sibling evaluations, EF flattened -> column (j*DC+k) = plane k, offset j, stride arity
     ph.tree = std::make_unique<p3r_tree>();
     ph.tree->cap_height = (int)cfg.cap_height;
     ph.tree->log_max_h = log_cur - la;
@@ -622,7 +626,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     {
       std::vector<const uint32_t*> cols;
       for (size_t j = 0; j < arity; ++j)
-        for (int k = 0; k < 4; ++k) cols.push_back(folded.p + (size_t)k * n_in + j);
+        for (int k = 0; k < DC; ++k) cols.push_back(folded.p + (size_t)k * n_in + j);
       const uint32_t* const* dcols = col_table(ctx, cols);
       {
         ProfScope ps(ctx, "mmcs_hash_rows_strided");
@@ -638,25 +642,26 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     }
     const size_t pi = phases.size();
     if (pi >= kMaxPhases) fail(P3R_EUNSUPPORTED, "more than %zu FRI commit phases", kMaxPhases);
-    TranscriptStep step{d_tstate.p, d_betas + 4 * pi, d_caps + P2_DIGEST * pi};
+    TranscriptStep step{d_tstate.p, d_betas + DC * pi, d_caps + P2_DIGEST * pi};
+    step.dc = DC;
     build_plain_layers<PP>(ctx, ph.tree.get(), rows, device_transcript ? &step : nullptr);
     if (device_transcript) {
       if (!step.done)  // a tree whose root is not produced by a single-workgroup launch (one leaf)
         hipLaunchKernelGGL(k_fri_transcript_step<PP>, dim3(1), dim3(64), 0, ctx->stream, ph.tree->layers.back().p,
-                           step.state, step.beta, step.cap, ctx->rc.p, ctx->p2_diag.p);
+                           step.state, step.beta, step.cap, ctx->rc.p, ctx->p2_diag.p, DC);
     } else {
       ph.cap = download_cap_mont<PP>(ctx, ph.tree.get());
       for (uint32_t v : ph.cap) ch.observe(F::raw(v));
       commit_pow_witnesses.push_back(grind_witness<PP>(ctx, ch, (int)cfg.commit_pow_bits));
       const E beta = ch.sample_ext();
-      uint32_t bw[4];
-      for (int k = 0; k < 4; ++k) bw[k] = beta.c[k].v;
-      P3R_HIP(ctx->stage.upload(ctx->stream, d_betas + 4 * pi, bw, sizeof bw));
+      uint32_t bw[DC];
+      for (int k = 0; k < DC; ++k) bw[k] = beta.c[k].v;
+      P3R_HIP(ctx->stage.upload(ctx->stream, d_betas + DC * pi, bw, sizeof bw));
     }
-    DevBuf out(4 * rows);
+    DevBuf out(DC * rows);
     FriFoldArgs fa{};
     fa.in = folded.p; fa.out = out.p; fa.rows = rows; fa.la = la; fa.log_rows = log_cur - la;
-    fa.beta = d_betas + 4 * pi;
+    fa.beta = d_betas + DC * pi;
     const bool roll = next_h < heights.size() && heights[next_h] == log_cur - la;
     fa.roll = roll ? ros[heights[next_h]].second.p : nullptr;
     fa.w_inv = F::two_adic_generator(log_cur).inv().v;
@@ -669,7 +674,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     fa.neg_half = (-(F::from_canonical(2).inv())).v;
     {
       ProfScope ps(ctx, "fri_fold");
-      hipLaunchKernelGGL(k_fri_fold<PP>, dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream, fa);
+      hipLaunchKernelGGL((k_fri_fold<PP, DC>), dim3(blocks_for(rows)), dim3(kBlock), 0, ctx->stream, fa);
     }
     P3R_HIP(hipGetLastError());
     if (roll) ++next_h;
@@ -683,11 +688,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<E> final_poly;
   {
     const size_t m = size_t(1) << log_cur;
-    std::vector<uint32_t> raw(4 * m), phase_words(d_phase.n);
+    std::vector<uint32_t> raw(DC * m), phase_words(d_phase.n);
     if (device_transcript && !phases.empty()) P3R_HIP(fetch_small(ctx, d_phase.p, phase_words.size(), phase_words.data()));
     P3R_HIP(fetch_small(ctx, folded.p, raw.size(), raw.data()));
     const uint32_t* betas = phase_words.data();
-    const uint32_t* caps = betas + 4 * kMaxPhases;
+    const uint32_t* caps = betas + DC * kMaxPhases;
     if (device_transcript) {
       // replay the commit phase on the host transcript; the challenges must be the device's
       for (size_t pi = 0; pi < phases.size(); ++pi) {
@@ -695,15 +700,15 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         for (uint32_t v : phases[pi].cap) ch.observe(F::raw(v));
         commit_pow_witnesses.push_back(grind_witness<PP>(ctx, ch, 0));
         const E beta = ch.sample_ext();
-        for (int k = 0; k < 4; ++k)
-          if (beta.c[k].v != betas[4 * pi + k]) fail(P3R_EHIP, "internal: device and host FRI transcripts disagree");
+        for (int k = 0; k < DC; ++k)
+          if (beta.c[k].v != betas[DC * pi + k]) fail(P3R_EHIP, "internal: device and host FRI transcripts disagree");
       }
     }
     // inverse DFT, decimation in time: the rows are already in bit-reversed order, the
     // coefficients come out in natural order
     std::vector<E> coeffs(m);
     for (size_t i = 0; i < m; ++i)
-      for (int k = 0; k < 4; ++k) coeffs[i].c[k] = F::raw(raw[(size_t)k * m + i]);
+      for (int k = 0; k < DC; ++k) coeffs[i].c[k] = F::raw(raw[(size_t)k * m + i]);
     const F w_inv = F::two_adic_generator(log_cur).inv(), m_inv = F::from_u64(m).inv();
     for (size_t len = 2; len <= m; len <<= 1) {
       const F w_len = w_inv.pow(m / len);
@@ -770,9 +775,9 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       const size_t arity = size_t(1) << ph.la, n_in = ph.rows << ph.la;
       QPhase qp;
       qp.shift = shift;
-      // sibling j of the row: the four planes of one extension element, at row * arity + j
+      // sibling j of the row: the DC planes of one extension element, at row * arity + j
       for (size_t j = 0; j < arity; ++j)
-        qp.sib_at[j] = push(ph.folded_in.p + j, n_in, 4, (uint32_t)(shift + ph.la), 0, (uint32_t)arity);
+        qp.sib_at[j] = push(ph.folded_in.p + j, n_in, DC, (uint32_t)(shift + ph.la), 0, (uint32_t)arity);
       qp.depth = ph.tree->log_max_h - ph.tree->cap_height;
       qp.proof_at = cursor;
       for (int l = 0; l < qp.depth; ++l)
@@ -852,7 +857,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         W.byte((uint8_t)phases[p].la);
         W.varint(arity - 1);
         for (size_t j = 0; j < arity; ++j)
-          if (j != pos) W.words(g + qp.sib_at[j], 4);
+          if (j != pos) W.words(g + qp.sib_at[j], DC);
         W.varint(qp.depth);
         W.words(g + qp.proof_at, (size_t)qp.depth * P2_DIGEST);
       }
@@ -895,6 +900,17 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   P3R_HIP(hipStreamSynchronize(ctx->stream));
   prof_stage(ctx, nullptr);
   return W.take();
+}
+
+// prove_batch over the context's challenge field (p3r_config.challenge_degree)
+template <class PP>
+std::vector<uint8_t> prove_batch_any(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* mains, size_t ni,
+                                     bool canonical_encoding) {
+  if (ctx->cfg.challenge_degree == 5) {
+    if constexpr (kHasQuintic<PP>) return prove_batch<PP, 5>(ctx, prep, mains, ni, canonical_encoding);
+    else fail(P3R_EUNSUPPORTED, "UnsupportedChallengeDegree: the quintic challenge field is KoalaBear's");
+  }
+  return prove_batch<PP, 4>(ctx, prep, mains, ni, canonical_encoding);
 }
 
 }  // namespace

@@ -337,18 +337,21 @@ class BatchStarkProof:
         return out
 
     @classmethod
-    def from_postcard(cls, data: bytes, field: str, canonical_field_encoding=False, proof_layout=None) -> "BatchStarkProof":
+    def from_postcard(cls, data: bytes, field: str, canonical_field_encoding=False, proof_layout=None,
+                      challenge_degree=4) -> "BatchStarkProof":
         """Inverse of `to_postcard`: one pass of the C-ABI parser (p3r_batch_stark_proof_parse: framing of the
         inner `BatchProof`, the metadata that follows it, and the `validate()` rules) - a parent node of the
         aggregation tree runs this on each child, so it is native host code, not a Python loop.
-        `proof_layout`: the 18 bytes of `p3r_config.proof_layout` when the proof was written with one."""
+        `proof_layout`: the 18 bytes of `p3r_config.proof_layout` when the proof was written with one.
+        `challenge_degree`: 5 for a proof over KoalaBear's quintic challenge field (five words per extension
+        element; P3R_PROOF_QUINTIC_CHALLENGE)."""
         from .device import FIELD_IDS, MODULUS
         lib = _lib.load()
         m, err = _lib.P3rBatchStarkMeta(), C.create_string_buffer(256)
         lay = None if proof_layout is None else (C.c_uint8 * 18)(*[int(v) for v in proof_layout])
         data = bytes(data)
-        rc = lib.p3r_batch_stark_proof_parse(FIELD_IDS[field], data, len(data), 1 if canonical_field_encoding else 0, lay,
-                                             C.byref(m), err, len(err))
+        flags = (1 if canonical_field_encoding else 0) | (2 if challenge_degree == 5 else 0)
+        rc = lib.p3r_batch_stark_proof_parse(FIELD_IDS[field], data, len(data), flags, lay, C.byref(m), err, len(err))
         if rc != 0:
             raise P3rError(rc, err.value.decode())
         entries = tuple(NonPrimitiveTableEntry(op_type=e.op_type.decode(), rows=int(e.rows), lanes=int(e.lanes),

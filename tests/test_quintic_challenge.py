@@ -71,3 +71,92 @@ def test_quintic_challenge_is_koala_bears(oracle):
     airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
     with pytest.raises(p3r.P3rError, match="UnsupportedChallengeDegree"):
         p3r.verify_batch(cfg, airs, L.prep_commit(), [int(t["main"].shape[0]).bit_length() - 1 for t in tables], L.prove())
+
+
+# ---- GPU: the device prover over the quintic challenge field ------------------------------------------------------
+GPU_CASES = [
+    (6, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=4, num_queries=5), None),
+    (8, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=5, num_queries=5),
+     dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3)),
+    (7, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=1, query_pow_bits=4, num_queries=6),
+     dict(alu_lanes=1, horner_packed_steps=2)),
+    (9, dict(log_blowup=2, max_log_arity=3, log_final_poly_len=3, cap_height=2, commit_pow_bits=2, query_pow_bits=6,
+             num_queries=6), dict(alu_lanes=4, horner_packed_steps=5)),
+    (11, dict(log_blowup=1, max_log_arity=2, log_final_poly_len=2, query_pow_bits=4, num_queries=8),
+     dict(alu_lanes=3, horner_packed_steps=8)),
+    (13, dict(log_blowup=3, max_log_arity=3, log_final_poly_len=0, query_pow_bits=3, num_queries=4),
+     dict(alu_lanes=2, horner_packed_steps=4, recompose_lanes=2)),
+]
+
+
+def gpu_setup(oracle, d, flags, coeff, log_h, kw, packing):
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    import harness_adapters as wl
+    arrs = harness_lib.generate(FIELD, log_h, seed=31 + log_h, flags=flags, ext_degree=d, horner_chain_len=20,
+                                sponge_chain_len=3, merkle_depth=5)
+    prm = layer_lib.params(challenge_degree=5, **kw)
+    packing = packing or {}
+    L = layer_lib.OracleLayer(oracle, FIELD, arrs, prm, packing=dict(packing, ext_degree=d, recompose_coeff_lookups=coeff))
+    ctx = p3r.Context(field=FIELD, log_blowup=prm.log_blowup, max_log_arity=prm.max_log_arity,
+                      cap_height=prm.cap_height, log_final_poly_len=prm.log_final_poly_len,
+                      commit_pow_bits=prm.commit_pow_bits, query_pow_bits=prm.query_pow_bits,
+                      num_queries=prm.num_queries, ext_degree=d, challenge_degree=5)
+    tp = pv.TablePacking(public_lanes=packing.get("public_lanes", 1), alu_lanes=packing.get("alu_lanes", 3),
+                         horner_packed_steps=packing.get("horner_packed_steps", 4),
+                         recompose_lanes=packing.get("recompose_lanes", 1))
+    tp.with_fri_params(prm.log_final_poly_len, prm.log_blowup)
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=d, recompose_coeff_lookups=bool(coeff)),
+                                     pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
+    return arrs, L, ctx, cache, wl.traces_from_arrays(arrs, ext_degree=d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,flags,coeff", MIXES)
+@pytest.mark.parametrize("log_h,kw,packing", GPU_CASES)
+def test_device_proof_bytes_over_the_quintic_challenge_field(oracle, d, flags, coeff, log_h, kw, packing):
+    from plonky3_recursion_amd import prover as pv
+    arrs, L, ctx, cache, traces = gpu_setup(oracle, d, flags, coeff, log_h, kw, packing)
+    cpd = cache.circuit_prover_data
+    assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
+    out = pv.prove_next_layer(pv.RecursionInput(traces=traces), ctx, pv.FriRecursionBackend(),
+                              pv.ProveNextLayerParams(table_packing=cpd.packing), prep=cache)
+    want = L.prove()
+    assert out.proof.proof == want
+    res = pv.ResidentTraces(ctx, cpd, traces)
+    assert cache.prover.prove_all_tables(res, cpd).proof == want
+    assert cache.prover.prove_all_tables(traces, cpd, canonical_field_encoding=True).proof == L.prove(field_encoding=1)
+    p = out.proof
+    assert p.ext_degree == d
+    cache.prover.verify_all_tables(p)
+    back = pv.BatchStarkProof.from_postcard(p.to_postcard(), FIELD, challenge_degree=5)
+    assert back.to_postcard() == p.to_postcard()
+    cache.prover.verify_all_tables(back)
+    with pytest.raises(Exception):   # five-word elements do not frame as a quartic proof
+        pv.BatchStarkProof.from_postcard(p.to_postcard(), FIELD)
+    res.free()
+    cpd.free()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_quintic_challenge_self_check_refuses_a_broken_trace(oracle):
+    import plonky3_recursion_amd as p3r
+    arrs, L, ctx, cache, traces = gpu_setup(oracle, 5, harness_lib.RECOMPOSE_COEFF, 1, 6,
+                                            dict(log_final_poly_len=1, query_pow_bits=3, num_queries=4), None)
+    v = traces.alu_values.copy()
+    v[3, 19] = (int(v[3, 19]) + 1) % 0x7F000001
+    traces.alu_values = v
+    with pytest.raises(p3r.P3rError, match="do not satisfy"):
+        cache.prover.prove_all_tables(traces, cache.circuit_prover_data)
+    cache.circuit_prover_data.free()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_quintic_challenge_context_is_koala_bears():
+    import plonky3_recursion_amd as p3r
+    with pytest.raises(p3r.P3rError, match="UnsupportedChallengeDegree"):
+        p3r.Context(field="baby-bear", challenge_degree=5)
+    with pytest.raises(p3r.P3rError, match="UnsupportedChallengeDegree"):
+        p3r.Context(field="koala-bear", challenge_degree=3)
