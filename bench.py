@@ -916,45 +916,52 @@ def main():
                 resident.free()
                 pc.free()
                 resident = pc = None
-            ctx5 = p3r.Context(field=field, ext_degree=5, **FRI)
             arrs5 = harness_lib.generate(field, log_h, seed=0x5EED0005, flags=harness_lib.RECOMPOSE_COEFF, ext_degree=5, **GEN_KNOBS)
             counts5 = [int(x) for x in arrs5["counts"]]
-            cache5 = p3r.build_next_layer_prep(ctx5, wl.circuit_prep_from_arrays(arrs5, ext_degree=5, recompose_coeff_lookups=True),
-                                               p3r.FriRecursionBackend(), p3r.ProveNextLayerParams(table_packing=packing))
-            cpd5 = cache5.circuit_prover_data
-            res5 = p3r.ResidentTraces(ctx5, cpd5, wl.traces_from_arrays(arrs5, ext_degree=5))
+            prep5 = wl.circuit_prep_from_arrays(arrs5, ext_degree=5, recompose_coeff_lookups=True)
+            traces5 = wl.traces_from_arrays(arrs5, ext_degree=5)
             del arrs5
-            proof5 = cache5.prover.prove_all_tables(res5, cpd5)
-            ctx5.sync()
-            t5 = time.perf_counter()
-            for _ in range(3):
+            # challenge degree 4: the D = 4 STARK configuration the reference's D = 5 unit tests prove under
+            # (batch_stark_prover/tests.rs:844-1029); 5: koala_bear_quintic_params, the configuration of
+            # recursive_fibonacci --quintic (LogUp, quotient, openings, FRI and transcript over five-word elements)
+            for dc, key in ((4, "quintic_backend_layer"), (5, "quintic_challenge_layer")):
+                ctx5 = p3r.Context(field=field, ext_degree=5, challenge_degree=dc, **FRI)
+                cache5 = p3r.build_next_layer_prep(ctx5, prep5, p3r.FriRecursionBackend(),
+                                                   p3r.ProveNextLayerParams(table_packing=packing))
+                cpd5 = cache5.circuit_prover_data
+                res5 = p3r.ResidentTraces(ctx5, cpd5, traces5)
+                proof5 = cache5.prover.prove_all_tables(res5, cpd5)
+                ctx5.sync()
+                t5 = time.perf_counter()
+                for _ in range(3):
+                    cache5.prover.prove_all_tables(res5, cpd5)
+                ctx5.sync()
+                ms5 = (time.perf_counter() - t5) / 3 * 1e3
+                try:
+                    cache5.prover.verify_all_tables(proof5)
+                    ok5 = True
+                except Exception as e:
+                    print(f"bench: D = 5 layer, challenge degree {dc}: proof rejected: {e}", file=sys.stderr)
+                    ok5 = False
+                ctx5.profile_enable(True)
                 cache5.prover.prove_all_tables(res5, cpd5)
-            ctx5.sync()
-            ms5 = (time.perf_counter() - t5) / 3 * 1e3
-            try:
-                cache5.prover.verify_all_tables(proof5)
-                ok5 = True
-            except Exception as e:
-                print(f"bench: D = 5 layer: proof rejected: {e}", file=sys.stderr)
-                ok5 = False
-            ctx5.profile_enable(True)
-            cache5.prover.prove_all_tables(res5, cpd5)
-            prof5 = ctx5.profile_read()
-            ctx5.profile_enable(False)
-            line["quintic_backend_layer"] = {
-                "ms_per_step": ms5, "steps": 3, "proof_verified": ok5, "proof_bytes": len(proof5.proof),
-                "ext_degree": 5, "tables": [e.op_type for e in proof5.non_primitives],
-                "table_heights": cpd5.table_heights,
-                "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose"], counts5)),
-                "kernel_ms": {k: v[0] for k, v in prof5.items() if not k.startswith("stage:")},
-                "workload": f"prove_all_tables (Traces resident in HBM) of the synthetic {field} 2^{log_h}-row D = 5 layer: "
-                            f"const / public / alu over F[x]/(x^5 + x^2 - 1) / compact-D1 poseidon2 / recompose with "
-                            f"coefficient lookups, the D = 4 STARK configuration, same FRI parameters"}
-            proof_verified = proof_verified and ok5
-            line["proof_verified"] = proof_verified
-            res5.free()
-            cpd5.free()
-            ctx5.close()
+                prof5 = ctx5.profile_read()
+                ctx5.profile_enable(False)
+                line[key] = {
+                    "ms_per_step": ms5, "steps": 3, "proof_verified": ok5, "proof_bytes": len(proof5.proof),
+                    "ext_degree": 5, "challenge_degree": dc, "tables": [e.op_type for e in proof5.non_primitives],
+                    "table_heights": cpd5.table_heights,
+                    "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose"], counts5)),
+                    "kernel_ms": {k: v[0] for k, v in prof5.items() if not k.startswith("stage:")},
+                    "workload": f"prove_all_tables (Traces resident in HBM) of the synthetic {field} 2^{log_h}-row D = 5 layer: "
+                                f"const / public / alu over F[x]/(x^5 + x^2 - 1) / compact-D1 poseidon2 / recompose with "
+                                f"coefficient lookups, " + ("the D = 4 STARK configuration" if dc == 4 else
+                                "the quintic STARK configuration (Challenge = F[x]/(x^5 + x^2 - 1))") + ", same FRI parameters"}
+                proof_verified = proof_verified and ok5
+                line["proof_verified"] = proof_verified
+                res5.free()
+                cpd5.free()
+                ctx5.close()
         print(json.dumps(line))
     if resident is not None:
         resident.free()

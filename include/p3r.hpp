@@ -46,12 +46,14 @@ struct FriParams {
 // ext_degree: the circuit extension degree of the traces - 4, or 5 for KoalaBear circuits over the quintic trinomial
 // extension (primitive tables, at the prove_all_tables boundary; include/p3r.h)
 inline p3r_config make_config(Field field, const FriParams& p, int device = 0, const std::vector<uint32_t>* rc = nullptr,
-                              uint32_t ext_degree = 4, uint32_t ext_w = 0 /* W of x^D = W for ext_degree 2 / 6 / 8 */) {
+                              uint32_t ext_degree = 4, uint32_t ext_w = 0 /* W of x^D = W for ext_degree 2 / 6 / 8 */,
+                              uint32_t challenge_degree = 4 /* 5: KoalaBear's quintic challenge field */) {
   p3r_config c{};
   c.abi_version = P3R_ABI_VERSION;
   c.field = (uint32_t)field;
   c.ext_degree = ext_degree;
   c.ext_w = ext_w;
+  c.challenge_degree = challenge_degree;
   c.log_blowup = p.log_blowup; c.max_log_arity = p.max_log_arity; c.cap_height = p.cap_height;
   c.log_final_poly_len = p.log_final_poly_len; c.commit_pow_bits = p.commit_pow_bits;
   c.query_pow_bits = p.query_pow_bits; c.num_queries = p.num_queries;
@@ -64,9 +66,9 @@ inline p3r_config make_config(Field field, const FriParams& p, int device = 0, c
 class Context {
  public:
   Context(Field field, const FriParams& fri, int device = 0, std::vector<uint32_t> poseidon2_rc = {}, uint32_t ext_degree = 4,
-          uint32_t ext_w = 0)
+          uint32_t ext_w = 0, uint32_t challenge_degree = 4)
       : field_(field), fri_(fri), rc_(std::move(poseidon2_rc)) {
-    cfg_ = make_config(field, fri, device, rc_.empty() ? nullptr : &rc_, ext_degree, ext_w);
+    cfg_ = make_config(field, fri, device, rc_.empty() ? nullptr : &rc_, ext_degree, ext_w, challenge_degree);
     h_ = p3r_create(&cfg_);
     if (!h_) throw Error(P3R_ENODEV, p3r_last_error(nullptr));
   }
@@ -252,11 +254,15 @@ struct BatchStarkProof {
   // Inverse of to_postcard: one pass of the native parser (p3r_batch_stark_proof_parse: framing of the inner
   // BatchProof, every field element in range, the metadata fields and the rules of validate()) - what a node of the
   // aggregation tree runs on a child that arrived from another process.
-  static BatchStarkProof from_postcard(const std::vector<uint8_t>& data, Field field, bool montgomery_field_encoding = true) {
+  // challenge_degree 5: a proof over KoalaBear's quintic challenge field (five words per extension element).
+  static BatchStarkProof from_postcard(const std::vector<uint8_t>& data, Field field, bool montgomery_field_encoding = true,
+                                       uint32_t challenge_degree = 4) {
     p3r_batch_stark_meta m;
     char err[256] = {0};
     const int rc = p3r_batch_stark_proof_parse((uint32_t)field, data.data(), data.size(),
-                                               montgomery_field_encoding ? 0 : P3R_PROVE_CANONICAL_FIELD_ENCODING, nullptr, &m, err, sizeof err);
+                                               (montgomery_field_encoding ? 0 : P3R_PROVE_CANONICAL_FIELD_ENCODING) |
+                                                   (challenge_degree == 5 ? P3R_PROOF_QUINTIC_CHALLENGE : 0),
+                                               nullptr, &m, err, sizeof err);
     if (rc != P3R_OK) throw Error(rc, err);
     BatchStarkProof p;
     p.proof.assign(data.begin(), data.begin() + m.proof_len);

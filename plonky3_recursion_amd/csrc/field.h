@@ -334,6 +334,39 @@ inline void dispatch_air_degree(int d, Fn&& fn) {
 }
 inline bool ext_degree_is_binomial_generic(uint32_t d) { return d == 2 || d == 6 || d == 8; }
 
+// Frobenius constants of F[x]/(x^5 + x^2 - 1): coefficient J of x^(I * p^K) in Montgomery form, evaluated at compile
+// time (the map a -> a^(p^K) is F-linear, so it is a 5 x 5 matrix over the base field whose column I is this power).
+namespace quintic {
+struct Q5 { uint64_t c[5]; };
+constexpr Q5 q5_mul(Q5 a, Q5 b, uint64_t p) {
+  uint64_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 5; ++j) t[i + j] = (t[i + j] + a.c[i] * b.c[j] % p) % p;
+  for (int k = 8; k >= 5; --k) {  // x^k = x^(k-5) - x^(k-3)
+    t[k - 5] = (t[k - 5] + t[k]) % p;
+    t[k - 3] = (t[k - 3] + p - t[k]) % p;
+  }
+  return Q5{{t[0], t[1], t[2], t[3], t[4]}};
+}
+constexpr Q5 q5_pow(Q5 b, uint64_t e, uint64_t p) {
+  Q5 r{{1, 0, 0, 0, 0}};
+  while (e) {
+    if (e & 1) r = q5_mul(r, b, p);
+    b = q5_mul(b, b, p);
+    e >>= 1;
+  }
+  return r;
+}
+constexpr uint32_t frob_entry(uint32_t p, int k, int i, int j) {
+  Q5 x{{0, 1, 0, 0, 0}};
+  for (int s = 0; s < k; ++s) x = q5_pow(x, p, p);   // x^(p^k)
+  const Q5 xi = q5_pow(x, (uint64_t)i, p);
+  return (uint32_t)((xi.c[j] << 32) % p);              // Montgomery form
+}
+}  // namespace quintic
+template <class PP, int K, int I, int J>
+inline constexpr uint32_t kFrob5 = quintic::frob_entry(PP::P, K, I, J);
+
 template <class PP>
 struct Fp5 {
   using F = Fp<PP>;
@@ -385,48 +418,39 @@ struct Fp5 {
   P3R_HD bool operator==(const Fp5& o) const {
     return c[0] == o.c[0] && c[1] == o.c[1] && c[2] == o.c[2] && c[3] == o.c[3] && c[4] == o.c[4];
   }
-  // a^-1: the columns of the multiplication-by-a matrix are a * x^j; Gauss-Jordan on [M | e_0] over the base field.
-  // Every index is a compile-time constant once unrolled (the matrix stays in registers on the device): pivoting is
-  // a conditional row swap.  Zero has no inverse: callers check first (the result is then zero).
-  P3R_HD Fp5 inv() const {
-    F m[5][6];
-    Fp5 col = *this, x = zero();
-    x.c[1] = F::one();
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-#pragma unroll
-      for (int i = 0; i < 5; ++i) m[i][j] = col.c[i];
-      col = col * x;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) m[i][5] = i == 0 ? F::one() : F::zero();
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-#pragma unroll
-      for (int i = k + 1; i < 5; ++i) {
-        const bool sw = m[k][k].v == 0 && m[i][k].v != 0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const F a = m[k][j], b = m[i][j];
-          m[k][j] = sw ? b : a;
-          m[i][j] = sw ? a : b;
-        }
-      }
-      const F s = m[k][k].inv();
-#pragma unroll
-      for (int j = 0; j < 6; ++j) m[k][j] = m[k][j] * s;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        if (i == k) continue;
-        const F f = m[i][k];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) m[i][j] = m[i][j] - f * m[k][j];
-      }
-    }
+  // a^(p^K), K = 1, 2: the Frobenius map as a matrix-vector product with compile-time constants.
+  template <int K, int J>
+  P3R_HD F frobenius_coeff() const {
+    const F t = F::dot2(c[1], F::raw(kFrob5<PP, K, 1, J>), c[2], F::raw(kFrob5<PP, K, 2, J>)) +
+                F::dot2(c[3], F::raw(kFrob5<PP, K, 3, J>), c[4], F::raw(kFrob5<PP, K, 4, J>));
+    return J == 0 ? c[0] + t : t;
+  }
+  template <int K>
+  P3R_HD Fp5 frobenius() const {
     Fp5 r;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) r.c[i] = m[i][5];
+    r.c[0] = frobenius_coeff<K, 0>();
+    r.c[1] = frobenius_coeff<K, 1>();
+    r.c[2] = frobenius_coeff<K, 2>();
+    r.c[3] = frobenius_coeff<K, 3>();
+    r.c[4] = frobenius_coeff<K, 4>();
     return r;
+  }
+  // Constant coefficient of a * b (all that is needed of a product known to lie in the base field).
+  static P3R_HD F mul_c0(const Fp5& a, const Fp5& b) {
+    return a.c[0] * b.c[0] + F::dot2(a.c[1], b.c[4], a.c[2], b.c[3]) + F::dot2(a.c[3], b.c[2], a.c[4], b.c[1]) -
+           a.c[4] * b.c[4];
+  }
+  // Itoh-Tsujii: with r = 1 + p + p^2 + p^3 + p^4, a^r = N(a) lies in the base field and a^-1 = a^(r-1) / N(a).
+  // a^(r-1) = a^(p + p^2 + p^3 + p^4) = t * t^(p^2) with t = a^p * a^(p^2): three Frobenius maps, two products.
+  // norm_cofactor() returns a^(r-1); norm = mul_c0(a, cofactor).  Zero maps to zero (callers check first).
+  P3R_HD Fp5 norm_cofactor() const {
+    const Fp5 a1 = frobenius<1>();
+    const Fp5 t = a1 * a1.template frobenius<1>();
+    return t * t.template frobenius<2>();
+  }
+  P3R_HD Fp5 inv() const {
+    const Fp5 co = norm_cofactor();
+    return co * mul_c0(*this, co).inv();
   }
 };
 

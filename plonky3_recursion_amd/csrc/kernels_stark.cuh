@@ -353,9 +353,31 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupChT<DC> lc, 
 // field) falls back to separate inversions so that it cannot poison its neighbours.
 template <class PP>
 __device__ __forceinline__ void inv4(const Fp5<PP> (&x)[4], Fp5<PP> (&out)[4]) {
-  // the quintic field has no cheap norm tower: four separate inversions
+  // the quintic field's norm is N(a) = a * a^(r-1) (field.h: norm_cofactor); the four norms share the inversion
+  using F = Fp<PP>;
+  Fp5<PP> co[4];
+  F nm[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) out[i] = x[i].inv();
+  for (int i = 0; i < 4; ++i) {
+    co[i] = x[i].norm_cofactor();
+    nm[i] = Fp5<PP>::mul_c0(x[i], co[i]);
+  }
+  const F p01 = nm[0] * nm[1], p012 = p01 * nm[2], p0123 = p012 * nm[3];
+  if (p0123.v == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = x[i].inv();
+    return;
+  }
+  F t = p0123.inv();
+  const F i3 = t * p012;
+  t = t * nm[3];
+  const F i2 = t * p01;
+  t = t * nm[2];
+  const F i1 = t * nm[0], i0 = t * nm[1];
+  out[0] = co[0] * i0;
+  out[1] = co[1] * i1;
+  out[2] = co[2] * i2;
+  out[3] = co[3] * i3;
 }
 template <class PP>
 __device__ __forceinline__ void inv4(const Fp4<PP> (&x)[4], Fp4<PP> (&out)[4]) {
