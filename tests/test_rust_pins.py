@@ -246,9 +246,12 @@ def test_hip_prover_reproduces_the_rust_base_field_proof(oracle, field, key):
 
 
 # ---- D = 5: quintic ALU + the compact-D1 Poseidon2 table ---------------------------------------------------------------
-def _quintic_layer(oracle, g=None):
+QUINTIC_FIXTURES = ["rust_quintic_layer_koala_bear.json", "rust_quintic_challenge_layer_koala_bear.json"]
+
+
+def _quintic_layer(oracle, g=None, name=QUINTIC_FIXTURES[0]):
     import layer_lib
-    g = g or load("rust_quintic_layer_koala_bear.json")
+    g = g or load(name)
     rc = np.array(g["rc"], dtype=np.uint32)
     prim = [np.array(c, dtype=np.uint32) for c in g["preprocessed_columns"]["primitive"]]
     p2 = np.array(g["preprocessed_columns"]["non_primitive"]["poseidon2_perm/koala_bear_d1_w16"], np.uint32).reshape(-1, 62)
@@ -271,15 +274,18 @@ def _quintic_layer(oracle, g=None):
     return g, rc, w
 
 
-def test_rust_quintic_layer_tables_and_proof(oracle):
+@pytest.mark.parametrize("name", QUINTIC_FIXTURES)
+def test_rust_quintic_layer_tables_and_proof(oracle, name):
     """The D = 5 tables against the reference: per-table main traces (quintic ALU incl. the packed-Horner columns,
-    the 166-column permutation rows), the preprocessed commitment (62-column compact-D1 rows), acceptance, bytes."""
+    the 166-column permutation rows), the preprocessed commitment (62-column compact-D1 rows), acceptance, bytes -
+    under the ordinary configuration and under koala_bear_quintic_params (challenge_degree = 5)."""
     import layer_lib
     import plonky3_recursion_amd as p3r
-    g, rc, w = _quintic_layer(oracle)
+    g, rc, w = _quintic_layer(oracle, name=name)
     pk = g["packing"]
     fri = g["fri"]
-    prm = layer_lib.params(**fri)
+    dc = int(g.get("challenge_degree", 4))
+    prm = layer_lib.params(challenge_degree=dc, **fri)
     L = layer_lib.OracleLayer(oracle, "koala-bear", w, prm, rc=rc,
                               packing=dict(public_lanes=pk["public_lanes"], alu_lanes=pk["alu_lanes"],
                                            horner_packed_steps=pk["horner_packed_steps"], min_trace_height=pk["min_trace_height"],
@@ -290,24 +296,25 @@ def test_rust_quintic_layer_tables_and_proof(oracle):
         want = np.array(m["values"], np.uint32).reshape(-1, m["width"])
         assert np.array_equal(tables[kind]["main"], want), f"main trace of {m['table']}"
     outer = bytes.fromhex(g["batch_stark_proof_postcard_hex"])
-    proof = p3r.BatchStarkProof.from_postcard(outer, "koala-bear")
+    proof = p3r.BatchStarkProof.from_postcard(outer, "koala-bear", challenge_degree=dc)
     assert proof.ext_degree == 5 and proof.w_binomial is None and proof.alu_quintic_trinomial
     assert [e.op_type for e in proof.non_primitives] == ["poseidon2_perm/koala_bear_d1_w16"]
     assert np.array_equal(proof.preprocessed_commitment, L.prep_commit()), "compact-D1 preprocessed rows / commitment"
-    cfg, keep = p3r.make_config("koala-bear", poseidon2_rc=rc, ext_degree=5, **fri)
+    cfg, keep = p3r.make_config("koala-bear", poseidon2_rc=rc, ext_degree=5, challenge_degree=dc, **fri)
     p3r.verify_all_tables(cfg, proof)
     assert L.prove() == proof.proof, "prove_batch bytes (D = 5)"
 
 
 @pytest.mark.gpu
-def test_hip_prover_reproduces_the_rust_quintic_proof(oracle):
+@pytest.mark.parametrize("name", QUINTIC_FIXTURES)
+def test_hip_prover_reproduces_the_rust_quintic_proof(oracle, name):
     import plonky3_recursion_amd as p3r
     from plonky3_recursion_amd import prover as pv
     import harness_adapters as wl
-    g, rc, w = _quintic_layer(oracle)
+    g, rc, w = _quintic_layer(oracle, name=name)
     pk = g["packing"]
     fri = g["fri"]
-    ctx = p3r.Context(field="koala-bear", poseidon2_rc=rc, ext_degree=5, **fri)
+    ctx = p3r.Context(field="koala-bear", poseidon2_rc=rc, ext_degree=5, challenge_degree=int(g.get("challenge_degree", 4)), **fri)
     tp = pv.TablePacking(public_lanes=pk["public_lanes"], alu_lanes=pk["alu_lanes"], horner_packed_steps=pk["horner_packed_steps"],
                          min_trace_height=pk["min_trace_height"])
     cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(w, ext_degree=5), pv.FriRecursionBackend(),

@@ -25,6 +25,8 @@
 //!
 //!   tests/golden/rust_fibonacci_base_layer_<field>.json
 //!       the Fibonacci circuit as the example proves it first: CircuitBuilder<F>, D = 1 traces (p3r_config.ext_degree = 1).
+//!   tests/golden/rust_quintic_challenge_layer_koala_bear.json
+//!       the same D = 5 layer proved under koala_bear_quintic_params (quintic CHALLENGE field)
 //!   tests/golden/rust_quintic_layer_koala_bear.json
 //!       a QuinticTrinomialExtensionField<KoalaBear> circuit (quintic Mul / MulAdd, a chained base-mode Poseidon2 sponge
 //!       on the compact-D1 table) under the ordinary KoalaBear configuration: the D = 5 tables of this repo
@@ -505,8 +507,10 @@ field_module!(baby, p3_baby_bear::BabyBear, p3_baby_bear::Poseidon2BabyBear<16>,
 /// sponge chain (KOALA_BEAR_D1_W16, compact-D1 preprocessed layout) whose rate outputs are exposed.  Emits the traces
 /// and preprocessed columns in the layout of include/p3r.h under ext_degree = 5 (values n x 5 / n x 20, Poseidon2 CTL
 /// 16 x 8 per row, absorb_len), the per-table main traces and the proof bytes.
-fn quintic_layer() -> Value {
-    use koala::{config, round_constants, MyConfig};
+macro_rules! quintic_layer_body {
+    ($Cfg:ty, $cfg:expr, $dc:expr) => {{
+    use koala::round_constants;
+    type MyConfig = $Cfg;
     use p3_circuit::ops::{generate_poseidon2_trace, KoalaBearD1Width16, Poseidon2Config, Poseidon2PermCallBase};
     use p3_circuit_prover::batch_stark_prover::{poseidon2_air_builders_d5, poseidon2_table_provers_d5, Poseidon2Preprocessor};
     use p3_circuit_prover::common::NpoPreprocessor;
@@ -555,7 +559,7 @@ fn quintic_layer() -> Value {
     let (xv, yv) = (ef5(5), ef5(9));
     let mav = xv * yv * xv + yv;
     let publics = vec![xv, yv, mav, lift(11), lift(13), EF5::from(out1[0]), EF5::from(out1[1])];
-    let cfg: MyConfig = config();
+    let cfg: MyConfig = $cfg;
     let packing = TablePacking::default().with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
     let npo_prep: Vec<Box<dyn NpoPreprocessor<KoalaBear>>> = vec![Box::new(Poseidon2Preprocessor)];
     let air_builders = poseidon2_air_builders_d5::<MyConfig>();
@@ -581,7 +585,7 @@ fn quintic_layer() -> Value {
     prover.verify_all_tables::<EF5>(&proof).unwrap();
     let flat5 = |v: &[EF5]| -> Vec<u32> { v.iter().flat_map(|e| u32s(e.as_basis_coefficients_slice())).collect() };
     json!({
-        "field": "koala_bear", "ext_degree": 5,
+        "field": "koala_bear", "ext_degree": 5, "challenge_degree": $dc,
         "fri": {"log_blowup": LOG_BLOWUP, "max_log_arity": MAX_LOG_ARITY, "cap_height": CAP_HEIGHT,
                 "log_final_poly_len": LOG_FINAL_POLY_LEN, "commit_pow_bits": COMMIT_POW_BITS,
                 "query_pow_bits": QUERY_POW_BITS, "num_queries": NUM_QUERIES},
@@ -597,6 +601,39 @@ fn quintic_layer() -> Value {
         "batch_stark_proof_postcard_hex": hex(&postcard::to_allocvec(&proof).unwrap()),
         "batch_proof_postcard_hex": hex(&postcard::to_allocvec(&proof.proof).unwrap()),
     })
+    }};
+}
+
+/// The layer under the ordinary KoalaBear configuration (quartic challenge field): batch_stark_prover/tests.rs:844-1029.
+fn quintic_layer() -> Value {
+    quintic_layer_body!(koala::MyConfig, koala::config(), 4)
+}
+
+/// The same layer under `koala_bear_quintic_params` (test-utils/src/lib.rs:414-460: `Challenge =
+/// QuinticTrinomialExtensionField<KoalaBear>`, the configuration of recursive_fibonacci --quintic and of
+/// recursion/tests/fibonacci_batch_stark_prover_quintic.rs) with this tool's FRI parameters: every extension element of
+/// the proof holds five words (p3r_config.challenge_degree = 5).
+fn quintic_challenge_layer() -> Value {
+    use p3_test_utils::koala_bear_quintic_params as q;
+    fn config() -> q::MyConfig {
+        let perm = q::default_koalabear_poseidon2_16();
+        let hash = q::MyHash::new(perm.clone());
+        let compress = q::MyCompress::new(perm.clone());
+        let val_mmcs = q::MyMmcs::new(hash, compress, CAP_HEIGHT);
+        let challenge_mmcs = q::ChallengeMmcs::new(val_mmcs.clone());
+        let fri_params = FriParameters {
+            max_log_arity: MAX_LOG_ARITY,
+            log_blowup: LOG_BLOWUP,
+            log_final_poly_len: LOG_FINAL_POLY_LEN,
+            num_queries: NUM_QUERIES,
+            commit_proof_of_work_bits: COMMIT_POW_BITS,
+            query_proof_of_work_bits: QUERY_POW_BITS,
+            mmcs: challenge_mmcs,
+        };
+        let pcs = q::MyPcs::new(q::Dft::default(), val_mmcs, fri_params);
+        q::MyConfig::new(pcs, q::Challenger::new(perm))
+    }
+    quintic_layer_body!(q::MyConfig, config(), 5)
 }
 
 fn main() {
@@ -617,5 +654,6 @@ fn main() {
     fs::write(format!("{golden}/rust_fibonacci_base_layer_koala_bear.json"), serde_json::to_string(&koala::fibonacci_base_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_fibonacci_base_layer_baby_bear.json"), serde_json::to_string(&baby::fibonacci_base_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_quintic_layer_koala_bear.json"), serde_json::to_string(&quintic_layer()).unwrap()).unwrap();
-    println!("wrote rust_primitives.json, rust_fibonacci_layer_*.json, rust_fibonacci_base_layer_*.json, rust_npo_layer_*.json and rust_quintic_layer_koala_bear.json under {golden}");
+    fs::write(format!("{golden}/rust_quintic_challenge_layer_koala_bear.json"), serde_json::to_string(&quintic_challenge_layer()).unwrap()).unwrap();
+    println!("wrote rust_primitives.json, rust_fibonacci_layer_*.json, rust_fibonacci_base_layer_*.json, rust_npo_layer_*.json, rust_quintic_layer_koala_bear.json and rust_quintic_challenge_layer_koala_bear.json under {golden}");
 }
