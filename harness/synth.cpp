@@ -187,30 +187,53 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   const size_t n_rec = (flags & SYN_NO_RECOMPOSE) ? 0 : std::max<size_t>(H / 4, 2);
   const bool rec_coeff = (flags & SYN_RECOMPOSE_COEFF) != 0;
   std::vector<uint32_t> rec_w;
+  std::vector<uint8_t> rec_dup;      // the output lands on a witness another table already defined: a reader (-1)
   std::vector<std::vector<uint32_t>> rec_ins;
-  std::vector<uint32_t> rec_owned;   // coefficient witnesses whose only creator is a recompose/coeff row
+  // coefficient witnesses whose only creator is a recompose/coeff row: the outputs of an ExtDecompositionHint
+  // (circuit_builder.rs:1438-1463: decompose -> recompose/coeff -> connect).  Only Poseidon2 sponge inputs read them
+  // afterwards: an ALU op would claim an undefined hint output as ITS creation (circuit.rs:351-359), and the
+  // recompose/coeff preprocessing does not mark them defined (ops/recompose.rs:174-192)
+  std::vector<uint32_t> rec_owned;
+  std::vector<uint8_t> is_rec_out;
   auto& rec_values = W.arr["recompose_values"];
   for (size_t i = 0; i < n_rec; ++i) {
     std::vector<uint32_t> ins(D);
     E v;
-    for (int k = 0; k < D; ++k) {
-      if (rec_coeff && rng.unit() < 0.3) {
-        ins[k] = create(E::from_base(rf()));
+    uint32_t w;
+    bool dup = false;
+    if (rec_coeff && rng.unit() < 0.4) {
+      const uint32_t src = pickp_noread();
+      v = wval[src];
+      for (int k = 0; k < D; ++k) {
+        ins[k] = create(E::from_base(v.c[k]));
         rec_owned.push_back(ins[k]);
-      } else {
-        ins[k] = base_valued[rng.below((uint32_t)base_valued.size())];
       }
-      v.c[k] = wval[ins[k]].c[0];
-      rec_values.push_back(v.c[k].to_canonical());
+      push_op(C_HINT_EXT, src, 0, 0, 0, 0, ins);
+      // connect(x, reconstructed): the op's output IS the decomposed witness - unless another row of this table
+      // made it (dup_npo_outputs is kept per witness: both rows would become readers, circuit.rs:464-491)
+      dup = rng.unit() < 0.5 && !(src < is_rec_out.size() && is_rec_out[src]);
+      if (dup) { w = src; reads[src]++; } else w = create(v);
+    } else {
+      for (int k = 0; k < D; ++k) {
+        ins[k] = base_valued[rng.below((uint32_t)base_valued.size())];
+        v.c[k] = wval[ins[k]].c[0];
+      }
+      w = create(v);
     }
-    uint32_t w = create(v);
+    for (int k = 0; k < D; ++k) rec_values.push_back(v.c[k].to_canonical());
     rec_w.push_back(w);
-    pickable.push_back(w);
+    if (!dup) { is_rec_out.resize(wval.size(), 0); is_rec_out[w] = 1; }
+    rec_dup.push_back(dup);
+    if (!dup) pickable.push_back(w);
     rec_ins.push_back(ins);
-    if (!rec_coeff) push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, 0, ins);
+    push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, rec_coeff ? 1u : 0u, ins);
   }
-  // the owned coefficients are ordinary witnesses for everything after them
-  for (uint32_t w : rec_owned) { pickable.push_back(w); base_valued.push_back(w); }
+  // a sponge row may absorb an owned coefficient instead of an ordinary witness
+  auto sponge_owned = [&](uint32_t& w) {
+    if (rec_owned.empty() || rng.unit() >= 0.25) return false;
+    w = rec_owned[rng.below((uint32_t)rec_owned.size())];
+    return true;
+  };
 
   // ---- Poseidon2 rows (executor semantics: ops/poseidon_perm/executor.rs:921-972) ----
   auto& p2_inputs = W.arr["p2_inputs"];      // n x 16
@@ -229,7 +252,9 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     for (auto& x : state) x = F::zero();
     const uint32_t sponge_pick_limit = (uint32_t)pickable.size();
     auto sponge_pick = [&](bool count_read) {
-      const uint32_t w = (flags & SYN_INDEPENDENT_SPONGES) ? pickable[rng.below(sponge_pick_limit)] : pickp_noread();
+      uint32_t w;
+      if (!(count_read && sponge_owned(w)))
+        w = (flags & SYN_INDEPENDENT_SPONGES) ? pickable[rng.below(sponge_pick_limit)] : pickp_noread();
       if (count_read) reads[w]++;
       return w;
     };
@@ -343,7 +368,8 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
         for (int i = 0; i < 16; ++i) in[i] = p.new_start ? F::zero() : state[i];
         for (int i = 0; i < 8; ++i)
           if (rng.unit() < (p.new_start ? 0.75 : 0.5)) {
-            const uint32_t w = base_w[rng.below((uint32_t)base_w.size())];
+            uint32_t w;
+            if (!sponge_owned(w)) w = base_w[rng.below((uint32_t)base_w.size())];
             reads[w]++;
             in_ctl[i] = 1; in_idx[i] = w; in[i] = wval[w].c[0];
           }
@@ -589,7 +615,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     std::vector<char> owned(wval.size(), 0);
     for (uint32_t w : rec_owned) owned[w] = 1;
     for (size_t i = 0; i < rec_w.size(); ++i) {
-      rec_prep.push_back(rec_w[i] * D); rec_prep.push_back(reads[rec_w[i]]);
+      rec_prep.push_back(rec_w[i] * D); rec_prep.push_back(rec_dup[i] ? P - 1 : reads[rec_w[i]]);
       if (rec_coeff)
         for (int k = 0; k < D; ++k) {
           const uint32_t c = rec_ins[i][k];

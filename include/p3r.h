@@ -445,8 +445,13 @@ enum p3r_op_kind {               /* circuit/src/ops/op.rs `Op`, AluOpKind */
                                     BABY_BEAR_D1_W16, one witness per state element, executor.rs:600-700):
                                     ext = [in0..in15, mmcs_index_sum, mmcs_bit, n_out (8 or 16), out0..],
                                     b = absorb_len (the sponge length tag) */
-  P3R_OP_RECOMPOSE = 10          /* a = NonPrimitiveOpId; out; ext = 4 coefficient witnesses
-                                    (circuit/src/ops/recompose.rs:115-170) */
+  P3R_OP_RECOMPOSE = 10          /* a = NonPrimitiveOpId; out; ext = D coefficient witnesses
+                                    (circuit/src/ops/recompose.rs:115-170); aux = 0 (or P3R_NO_WITNESS): the `recompose` table,
+                                    aux = 1: `recompose/coeff` (NpoTypeId::recompose_with_coeff_lookups,
+                                    ops/npo.rs:48-60: every coefficient is a bus tuple too; a coefficient that is a
+                                    hint output is created by this row with its read count, any other is named with
+                                    multiplicity 0 - batch_stark_prover/recompose.rs:341-352).  The Recompose ops of
+                                    one circuit are of one kind (a layer holds one Recompose table). */
 };
 
 typedef struct p3r_op {

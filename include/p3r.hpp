@@ -423,6 +423,9 @@ class PreparedCircuit {
     ctx.check(p3r_circuit_counts(h_, &counts));
     ctx.check(p3r_circuit_levels(h_, &levels_));
     cpd_ = std::make_unique<CircuitProverData>(ctx, p3r_circuit_layer(h_), packing, counts, std::move(commit));
+    // Recompose ops of the "recompose/coeff" kind (aux = 1): the table the wrapped proof names
+    for (const p3r_op& op : circuit_.ops)
+      if (op.kind == P3R_OP_RECOMPOSE && op.aux == 1u) cpd_->recompose_coeff_lookups = true;
   }
   ~PreparedCircuit() { cpd_.reset(); if (h_) p3r_circuit_free(ctx_->raw(), h_); }
   PreparedCircuit(const PreparedCircuit&) = delete;

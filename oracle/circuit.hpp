@@ -57,7 +57,9 @@ struct Preprocessed {
   int D = 4;
   std::vector<uint32_t> prim_const, prim_public, prim_alu12;  // primitive[Const|Public|Alu]
   std::vector<uint32_t> p2_rows;     // non_primitive[poseidon2_perm/..]: 24 values per op
-  std::vector<uint32_t> recompose;   // non_primitive[recompose]: [output idx, 1] per op
+  std::vector<uint32_t> recompose;   // non_primitive[recompose]: [output idx, 1] per op; the "recompose/coeff" kind
+                                     // (aux = 1) appends [coefficient idx, 1] per coefficient (ops/recompose.rs:174-192)
+  bool recompose_coeff = false;
   std::vector<uint32_t> ext_reads;
   std::vector<bool> dup_p2, dup_recompose;  // dup_npo_outputs[op_type][wid]
   std::set<uint32_t> hint_output_wids;
@@ -168,6 +170,16 @@ inline Preprocessed generate_preprocessed_columns(const CircuitDesc& c, uint32_t
         if (op.ext_len != 4) throw std::runtime_error("recompose op: needs 4 coefficient witnesses");
         pp.recompose.push_back(pp.idx(op.out));
         pp.recompose.push_back(1);
+        if (op.aux == 1) {
+          // register_non_primitive_output_index per coefficient: named, not marked defined, no read counted
+          pp.recompose_coeff = true;
+          for (uint32_t k = 0; k < op.ext_len; ++k) {
+            pp.recompose.push_back(pp.idx(c.ext[op.ext_off + k]));
+            pp.recompose.push_back(1);
+          }
+        } else if (pp.recompose_coeff) {
+          throw std::runtime_error("recompose and recompose/coeff ops in one circuit");
+        }
         if (is_def(op.out)) {
           if (op.out >= pp.dup_recompose.size()) pp.dup_recompose.resize((size_t)op.out + 1, false);
           pp.dup_recompose[op.out] = true;
@@ -226,10 +238,17 @@ inline CircuitPrep get_airs_and_degrees_with_prep(Preprocessed pp) {
     }
   // ---- recompose_preprocess_for_op (recompose.rs:294-358)
   out.recompose_prep = pp.recompose;
-  for (size_t r = 0; r < out.recompose_prep.size() / 2; ++r) {
-    const uint32_t wid = out.recompose_prep[2 * r] / D;
+  const size_t rec_w = pp.recompose_coeff ? 2 + 2 * D : 2;
+  for (size_t r = 0; r < out.recompose_prep.size() / rec_w; ++r) {
+    uint32_t* row = &out.recompose_prep[rec_w * r];
+    const uint32_t wid = row[0] / D;
     const bool dup = wid < pp.dup_recompose.size() && pp.dup_recompose[wid];
-    out.recompose_prep[2 * r + 1] = dup ? neg1 : reads(wid);
+    row[1] = dup ? neg1 : reads(wid);
+    // coefficient tuples: a hint output is created here with its read count, anything else is named with 0 (:341-352)
+    for (size_t k = 2; k < rec_w; k += 2) {
+      const uint32_t cw = row[k] / D;
+      row[k + 1] = pp.hint_output_wids.count(cw) ? reads(cw) : 0u;
+    }
   }
   // ---- primitive tables (common.rs:186-368)
   for (uint32_t idx : pp.prim_const) { out.const_prep.push_back(reads(idx / D)); out.const_prep.push_back(idx); }

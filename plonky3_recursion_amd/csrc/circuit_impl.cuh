@@ -34,7 +34,22 @@ struct CircuitTables {
   std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_ctl_enabled, p2_in_ctl;
   std::vector<uint32_t> p2_input_indices, p2_out_ctl, p2_output_indices, p2_mmcs_index_sum_idx;
   std::vector<uint8_t> p2_absorb_len;   // base-mode rows (circuits of degree 1 / 5)
+  bool recompose_coeff = false;         // the circuit's Recompose ops are the "recompose/coeff" kind (aux = 1)
 };
+
+// The Recompose ops of a circuit are of one kind here: "recompose" (aux = 0) or "recompose/coeff" (aux = 1:
+// NpoTypeId::recompose_with_coeff_lookups, circuit/src/ops/npo.rs:48-60).  A layer holds one Recompose table.
+inline bool circuit_recompose_coeff(const p3r_op* ops, size_t n) {
+  int kind = -1;
+  for (size_t i = 0; i < n; ++i)
+    if (ops[i].kind == P3R_OP_RECOMPOSE) {
+      const int k = ops[i].aux == 1u;
+      if (kind >= 0 && kind != k)
+        fail(P3R_EUNSUPPORTED, "op %zu: `recompose` and `recompose/coeff` ops in one circuit: a layer holds one Recompose table", i);
+      kind = k;
+    }
+  return kind == 1;
+}
 
 // Poseidon2 op layout by circuit degree: D = 4 -> four input limbs of four elements, two (or four) output limbs;
 // otherwise base mode -> sixteen one-element slots, eight (or sixteen) outputs.  ext = [in.., index_sum, bit, n_out, out..]
@@ -111,6 +126,8 @@ inline void validate_circuit(const HostCircuit& c, uint32_t D = 4) {
         wid(op.out, i, "out");
         if (op.a >= c.ops.size()) fail(P3R_EINVAL, "op %zu: NonPrimitiveOpId(%u) out of range", i, op.a);
         if (op.ext_len != D) fail(P3R_EINVAL, "op %zu: recompose expects 1 input group with %u witnesses", i, D);
+        if (op.aux > 1 && op.aux != kNoW)
+          fail(P3R_EINVAL, "op %zu: recompose aux %u (0 or P3R_NO_WITNESS = `recompose`, 1 = `recompose/coeff`)", i, op.aux);
         for (uint32_t k = 0; k < D; ++k) wid(e[k], i, "coefficient");
         break;
       default: fail(P3R_EUNSUPPORTED, "op %zu: kind %u has no table in this backend", i, op.kind);
@@ -249,10 +266,19 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
       T.p2_mmcs_index_sum_idx[r] = e[il] != kNoW ? e[il] : 0;
       if (D != 4) T.p2_absorb_len[r] = (uint8_t)op->b;
     }
-    T.recompose_prep.reserve(2 * recs.size());
+    // recompose.rs:293-356: [D * out, mult]; the coefficient variant appends (D * coeff, mult) per coefficient, where
+    // only a hint output is created here (its reads), any other coefficient is named with multiplicity 0
+    T.recompose_coeff = circuit_recompose_coeff(c.ops.data(), c.ops.size());
+    T.recompose_prep.reserve((T.recompose_coeff ? 2 + 2 * D : 2) * recs.size());
     for (auto* op : recs) {
       T.recompose_prep.push_back(scaled(op->out));
       T.recompose_prep.push_back(dup_rec[op->out] ? NEG1 : mult(op->out));
+      if (T.recompose_coeff)
+        for (uint32_t k = 0; k < D; ++k) {
+          const uint32_t w = c.ext_of(*op)[k];
+          T.recompose_prep.push_back(scaled(w));
+          T.recompose_prep.push_back(is_hint[w] ? mult(w) : 0u);
+        }
     }
   });
   T.alu_prep13.resize(13 * alus.size());
@@ -1096,7 +1122,9 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   // a witness nobody sets ...) goes through the host restatement below, which raises the reference's error.
   // (circuits of extension degree 1 / 5 take the host restatement: the device pass is written for D = 4)
   const uint32_t ext_d = ctx->cfg.ext_degree;
-  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr || ext_d != 4;  // read per call: the equality tests flip it
+  // (so do circuits whose Recompose ops are the coefficient-lookup kind)
+  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr || ext_d != 4 ||   // read per call: the equality tests flip it
+                         (d->ops && circuit_recompose_coeff(d->ops, d->n_ops));
   if (!host_prep) {
     prof_stage(ctx, "prep_device");
     DevPrep R;
@@ -1155,6 +1183,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   ld.p2_input_indices = T.p2_input_indices.data(); ld.p2_out_ctl = T.p2_out_ctl.data();
   ld.p2_output_indices = T.p2_output_indices.data(); ld.p2_mmcs_index_sum_idx = T.p2_mmcs_index_sum_idx.data();
   if (ext_d != 4 && !T.p2_absorb_len.empty()) ld.p2_absorb_len = T.p2_absorb_len.data();
+  ld.recompose_coeff_lookups = T.recompose_coeff ? 1u : 0u;
   prof_stage(ctx, "prep_layer_create");
   C->layer = layer_create<PP>(ctx, &ld, commit_out);
 

@@ -595,6 +595,9 @@ class PreparedCircuit:
         self.prepared_on_device = bool(ctx.lib.p3r_circuit_prepared_on_device(self.h))
         self._cpd_args = (ctx.lib.p3r_circuit_layer(self.h), packing, rows, commit)
         self._cpd_view = None
+        # Recompose ops of the "recompose/coeff" kind (aux = 1; include/p3r.h): the table the proof names
+        o2 = ops.reshape(-1, 8)
+        self.recompose_coeff_lookups = bool(np.any((o2[:, 0] == 10) & (o2[:, 5] == 1)))
 
     @property
     def circuit_prover_data(self) -> CircuitProverData:
@@ -607,6 +610,7 @@ class PreparedCircuit:
             if not self.h:
                 raise P3rError(-1, "the prepared circuit has been freed")
             view = CircuitProverData._borrow(self.ctx, *self._cpd_args, owner=self)
+            view.recompose_coeff_lookups = self.recompose_coeff_lookups
             self._cpd_view = weakref.ref(view)
         return view
 

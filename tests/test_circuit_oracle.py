@@ -55,7 +55,8 @@ def test_runner_matches_reference_unit_tests(oracle, case):
     assert not alu[:, :, 1:].any()
 
 
-SHAPES = [0, harness_lib.NO_POSEIDON2, harness_lib.NO_RECOMPOSE,
+SHAPES = [0, harness_lib.NO_POSEIDON2, harness_lib.NO_RECOMPOSE, harness_lib.RECOMPOSE_COEFF,
+          harness_lib.RECOMPOSE_COEFF | harness_lib.NO_POSEIDON2,
           harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC,
           harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU]
 
@@ -75,15 +76,23 @@ def test_circuit_path_reproduces_harness_bookkeeping(oracle, field, flags):
         assert len(a["private_rows"]) and len(a["rewrite"]) and (a["p2_out_ctl"] == oracle_lib.MODULUS[field] - 1).any()
 
 
-def test_circuit_path_proof_verifies(oracle):
+@pytest.mark.parametrize("flags", [0, harness_lib.RECOMPOSE_COEFF])
+def test_circuit_path_proof_verifies(oracle, flags):
     """Traces + preprocessed columns derived from the circuit prove and verify (LogUp balanced
-    under the reference's creator / reader multiplicity rules, every AIR satisfied)."""
+    under the reference's creator / reader multiplicity rules, every AIR satisfied).  RECOMPOSE_COEFF: the Recompose
+    ops are the `recompose/coeff` kind - decomposition-hint outputs are created on the bus by the recompose rows and
+    read by sponge inputs (circuit_builder.rs:1438-1463)."""
     field = "koala-bear"
-    a = harness_lib.generate(field, 7, seed=4, horner_chain_len=10, sponge_chain_len=3, merkle_depth=4)
+    a = harness_lib.generate(field, 7, seed=4, horner_chain_len=10, sponge_chain_len=3, merkle_depth=4, flags=flags)
     oc = cl.OracleCircuit(oracle, cl.Circuit.from_arrays(a)).preprocess(oracle_lib.MODULUS[field])
     oc.run(field, cl.Inputs.from_arrays(a))
     prm = layer_lib.params(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
-    L = layer_lib.OracleLayer(oracle, field, oc.workload_arrays(), prm)
+    coeff = int(bool(flags & harness_lib.RECOMPOSE_COEFF))
+    w = oc.workload_arrays()
+    if coeff:
+        rp = w["recompose_prep"].reshape(-1, 10)
+        assert (rp[:, 3::2] > 0).any() and (rp[:, 1] == oracle_lib.MODULUS[field] - 1).any()   # owned coefficients that are read; outputs connected back
+    L = layer_lib.OracleLayer(oracle, field, w, prm, packing=dict(recompose_coeff_lookups=coeff))
     L.verify(L.prove())
 
 

@@ -47,6 +47,11 @@ CASES = [("koala-bear", 5, 7, NO_P2 | harness_lib.NO_RECOMPOSE, None),
          ("koala-bear", 1, 8, 0, None),
          ("baby-bear", 1, 8, harness_lib.NO_RECOMPOSE, dict(alu_lanes=4, horner_packed_steps=6)),
          ("koala-bear", 5, 10, harness_lib.INDEPENDENT_SPONGES, None),
+         # Recompose ops of the `recompose/coeff` kind: hint outputs created by the recompose rows, read by sponge inputs
+         ("koala-bear", 5, 8, harness_lib.RECOMPOSE_COEFF, None),
+         ("koala-bear", 5, 10, harness_lib.RECOMPOSE_COEFF, dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3, recompose_lanes=2)),
+         ("baby-bear", 1, 8, harness_lib.RECOMPOSE_COEFF, None),
+         ("koala-bear", 5, 7, harness_lib.RECOMPOSE_COEFF | NO_P2, None),
          # wide levels, long Horner chains (the workgroup scan), deep Merkle paths
          ("koala-bear", 5, 13, 0, None)]
 
@@ -71,13 +76,16 @@ def test_device_runner_for_base_field_and_quintic_circuits(oracle, field, ext_de
         assert np.array_equal(res.download("p2_flags"), a["p2_flags"].reshape(-1, 4)[:, :3])
         assert np.array_equal(res.download("p2_mmcs_index_sum").reshape(-1), a["p2_mmcs_index_sum"])
     # the commitment binds the preprocessed columns derived from the op list: bus roles, multiplicities, indices x D
-    L = layer_lib.OracleLayer(oracle, field, a, prm, packing=dict(packing or {}, ext_degree=ext_degree))
+    coeff = int(bool(flags & harness_lib.RECOMPOSE_COEFF))
+    L = layer_lib.OracleLayer(oracle, field, a, prm, packing=dict(packing or {}, ext_degree=ext_degree, recompose_coeff_lookups=coeff))
     assert np.array_equal(pc.circuit_prover_data.preprocessed_commitment, L.prep_commit())
     out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=inputs), ctx, p3r.FriRecursionBackend(),
                                p3r.ProveNextLayerParams(table_packing=pc.packing), prep=cache)
     proof = L.prove()
     assert out.proof.proof == proof and pc.prove(inputs) == proof
     assert out.proof.ext_degree == ext_degree and out.proof.alu_quintic_trinomial == (ext_degree == 5)
+    if a["counts"][4]:
+        assert out.proof.non_primitives[-1].op_type == ("recompose/coeff" if coeff else "recompose")
     cache.prover.verify_all_tables(out.proof)
     res.free()
     pc.free()
