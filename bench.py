@@ -920,6 +920,7 @@ def main():
             counts5 = [int(x) for x in arrs5["counts"]]
             prep5 = wl.circuit_prep_from_arrays(arrs5, ext_degree=5, recompose_coeff_lookups=True)
             traces5 = wl.traces_from_arrays(arrs5, ext_degree=5)
+            circ5, hin5 = wl.circuit_from_arrays(arrs5), wl.circuit_inputs_from_arrays(arrs5, 5)
             del arrs5
             # challenge degree 4: the D = 4 STARK configuration the reference's D = 5 unit tests prove under
             # (batch_stark_prover/tests.rs:844-1029); 5: koala_bear_quintic_params, the configuration of
@@ -961,6 +962,28 @@ def main():
                 line["proof_verified"] = proof_verified
                 res5.free()
                 cpd5.free()
+                if dc == 5:
+                    # the same layer from the circuit boundary: the D = 5 verifier circuit (quintic ALU ops, base-mode
+                    # Poseidon2 permutations, recompose/coeff ops fed by decomposition hints) prepared once, then run on
+                    # the device and proved per step - prove_next_layer of a `--quintic` recursion layer
+                    t5 = time.perf_counter()
+                    pc5 = p3r.PreparedCircuit(ctx5, circ5, packing)
+                    prep_ms5 = (time.perf_counter() - t5) * 1e3
+                    rin5 = pc5.upload_inputs(hin5)
+                    same5 = pc5.prove(rin5) == proof5.proof
+                    ctx5.sync()
+                    t5 = time.perf_counter()
+                    for _ in range(3):
+                        pc5.prove(rin5)
+                    ctx5.sync()
+                    line[key]["prove_next_layer_ms"] = (time.perf_counter() - t5) / 3 * 1e3
+                    line[key]["circuit_prep_ms"] = prep_ms5
+                    line[key]["circuit_levels"] = pc5.levels
+                    line[key]["same_proof_as_from_traces"] = same5
+                    proof_verified = proof_verified and same5
+                    line["proof_verified"] = proof_verified
+                    rin5.free()
+                    pc5.free()
                 ctx5.close()
         print(json.dumps(line))
     if resident is not None:

@@ -51,7 +51,10 @@ enum { SYN_NO_POSEIDON2 = 1, SYN_NO_RECOMPOSE = 2, SYN_SINGLE_PUBLIC = 4, SYN_NO
        // from a sponge's digest
        SYN_INDEPENDENT_SPONGES = 16,
        // the Recompose table is the "recompose/coeff" variant (per-coefficient bus tuples)
-       SYN_RECOMPOSE_COEFF = 32 };
+       SYN_RECOMPOSE_COEFF = 32,
+       // both Recompose tables in one layer: every op is drawn `recompose` or `recompose/coeff`; the rows of the second
+       // kind go to recompose_coeff_values / recompose_coeff_prep and counts[6]
+       SYN_RECOMPOSE_BOTH = 64 };
 
 enum { OP_ADD = 0, OP_MUL = 1, OP_BOOL = 2, OP_MULADD = 3, OP_HORNER = 4 };
 
@@ -185,7 +188,8 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   // is a bus tuple (D*idx, c, 0, ..) whose multiplicity is the read count of a coefficient no other table defines
   // (a hint output in the reference) and 0 otherwise ----
   const size_t n_rec = (flags & SYN_NO_RECOMPOSE) ? 0 : std::max<size_t>(H / 4, 2);
-  const bool rec_coeff = (flags & SYN_RECOMPOSE_COEFF) != 0;
+  const bool rec_both = (flags & SYN_RECOMPOSE_BOTH) != 0;
+  const bool rec_coeff = (flags & SYN_RECOMPOSE_COEFF) != 0 || rec_both;
   std::vector<uint32_t> rec_w;
   std::vector<uint8_t> rec_dup;      // the output lands on a witness another table already defined: a reader (-1)
   std::vector<std::vector<uint32_t>> rec_ins;
@@ -195,13 +199,18 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   // recompose/coeff preprocessing does not mark them defined (ops/recompose.rs:174-192)
   std::vector<uint32_t> rec_owned;
   std::vector<uint8_t> is_rec_out;
+  std::vector<uint8_t> rec_kind;     // 1: the row belongs to the `recompose/coeff` table
   auto& rec_values = W.arr["recompose_values"];
+  auto& rec2_values = W.arr["recompose_coeff_values"];
   for (size_t i = 0; i < n_rec; ++i) {
     std::vector<uint32_t> ins(D);
     E v;
     uint32_t w;
     bool dup = false;
-    if (rec_coeff && rng.unit() < 0.4) {
+    // RECOMPOSE_BOTH: about half the ops are the plain kind (their coefficients are never hint outputs: a plain row
+    // does not put them on the bus)
+    const bool coeff_row = rec_coeff && !(rec_both && rng.unit() < 0.5);
+    if (coeff_row && rng.unit() < 0.4) {
       const uint32_t src = pickp_noread();
       v = wval[src];
       for (int k = 0; k < D; ++k) {
@@ -211,6 +220,8 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
       push_op(C_HINT_EXT, src, 0, 0, 0, 0, ins);
       // connect(x, reconstructed): the op's output IS the decomposed witness - unless another row of this table
       // made it (dup_npo_outputs is kept per witness: both rows would become readers, circuit.rs:464-491)
+      // (dup_npo_outputs is per op type: with two tables only an output of the SAME table is excluded - kept simple
+      // here by excluding every recompose output)
       dup = rng.unit() < 0.5 && !(src < is_rec_out.size() && is_rec_out[src]);
       if (dup) { w = src; reads[src]++; } else w = create(v);
     } else {
@@ -220,13 +231,15 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
       }
       w = create(v);
     }
-    for (int k = 0; k < D; ++k) rec_values.push_back(v.c[k].to_canonical());
+    const bool second = rec_both && coeff_row;
+    for (int k = 0; k < D; ++k) (second ? rec2_values : rec_values).push_back(v.c[k].to_canonical());
+    rec_kind.push_back(second);
     rec_w.push_back(w);
     if (!dup) { is_rec_out.resize(wval.size(), 0); is_rec_out[w] = 1; }
     rec_dup.push_back(dup);
     if (!dup) pickable.push_back(w);
     rec_ins.push_back(ins);
-    push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, rec_coeff ? 1u : 0u, ins);
+    push_op(C_RECOMPOSE, next_npo_id++, 0, 0, w, coeff_row ? 1u : 0u, ins);
   }
   // a sponge row may absorb an owned coefficient instead of an ordinary witness
   auto sponge_owned = [&](uint32_t& w) {
@@ -611,16 +624,20 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   auto& public_values = W.arr["public_values"]; auto& public_prep = W.arr["public_prep"];
   for (uint32_t w : public_w) { put_e(public_values, wval[w]); public_prep.push_back(reads[w]); public_prep.push_back(w * D); }
   auto& rec_prep = W.arr["recompose_prep"];
+  auto& rec2_prep = W.arr["recompose_coeff_prep"];
+  size_t n_rec_second = 0;
   {
     std::vector<char> owned(wval.size(), 0);
     for (uint32_t w : rec_owned) owned[w] = 1;
     for (size_t i = 0; i < rec_w.size(); ++i) {
-      rec_prep.push_back(rec_w[i] * D); rec_prep.push_back(rec_dup[i] ? P - 1 : reads[rec_w[i]]);
-      if (rec_coeff)
+      auto& dst = rec_kind[i] ? rec2_prep : rec_prep;
+      n_rec_second += rec_kind[i];
+      dst.push_back(rec_w[i] * D); dst.push_back(rec_dup[i] ? P - 1 : reads[rec_w[i]]);
+      if (rec_both ? rec_kind[i] != 0 : rec_coeff)
         for (int k = 0; k < D; ++k) {
           const uint32_t c = rec_ins[i][k];
-          rec_prep.push_back(c * D);
-          rec_prep.push_back(owned[c] ? reads[c] : 0u);
+          dst.push_back(c * D);
+          dst.push_back(owned[c] ? reads[c] : 0u);
         }
     }
   }
@@ -644,7 +661,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     alu_values.insert(alu_values.end(), 4 * D, 0u);
   }
   W.arr["counts"] = {(uint32_t)const_w.size(), (uint32_t)public_w.size(), (uint32_t)std::max<size_t>(ops.size(), 1),
-                     (uint32_t)n_p2, (uint32_t)rec_w.size(), (uint32_t)wval.size()};
+                     (uint32_t)n_p2, (uint32_t)(rec_w.size() - n_rec_second), (uint32_t)wval.size(), (uint32_t)n_rec_second};
 }
 
 }  // namespace

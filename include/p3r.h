@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3R_ABI_VERSION 4
+#define P3R_ABI_VERSION 5
 
 enum {
   P3R_OK = 0,
@@ -274,6 +274,13 @@ int p3r_prove_batch_host(p3r_ctx* ctx, const p3r_prep* prep, const p3r_matrix* m
  */
 typedef struct p3r_layer_desc_counts {
   size_t n_const, n_public, n_alu, n_p2, n_recompose; /* ops / rows before padding */
+  /* ABI version 5.  Rows of the SECOND Recompose table, `recompose/coeff`, of a layer that holds both kinds: a
+   * backend created with coefficient lookups registers the two table provers side by side
+   * (recompose_table_provers(lanes, true), batch_stark_prover.rs:1914-1932: [`recompose`, `recompose/coeff`]) and a
+   * verifier circuit uses both - plain recomposition in the challenger and the MMCS gadgets
+   * (recursion/src/challenger/circuit.rs:206-384, pcs/mmcs.rs:106-140), the coefficient kind for decomposition links
+   * (circuit_builder.rs:1438-1477).  0: one Recompose table, of the kind recompose_coeff_lookups names. */
+  size_t n_recompose_coeff;
 } p3r_layer_desc_counts;
 
 typedef struct p3r_layer_desc {
@@ -308,6 +315,9 @@ typedef struct p3r_layer_desc {
    * registers when the permutation's degree differs from the circuit's (backend/fri.rs:693-721, :741-852: always under
    * ext_degree 5, where the permutation is the D1 one).  Since ABI version 4. */
   uint32_t recompose_coeff_lookups;
+  /* ABI version 5.  n_recompose_coeff x (2 + 2D): the rows of the second Recompose table (then recompose_prep holds
+   * the plain kind and recompose_coeff_lookups must be 0).  The batch lists `recompose` before `recompose/coeff`. */
+  const uint32_t* recompose_coeff_prep;
 } p3r_layer_desc;
 
 /* Flattened Traces<EF> (circuit/src/tables/mod.rs:49-62), canonical; D = p3r_config.ext_degree. */
@@ -317,6 +327,7 @@ typedef struct p3r_traces {
   size_t n_alu;       const uint32_t* alu_values;       /* n x 4D: AluTrace.values [a,b,c,out] */
   p3r_p2_rows p2;     /* n = un-padded Poseidon2 row count (any n, padding is done here) */
   size_t n_recompose; const uint32_t* recompose_values; /* n x D */
+  size_t n_recompose_coeff; const uint32_t* recompose_coeff_values; /* n x D: rows of the second Recompose table (ABI 5) */
 } p3r_traces;
 
 typedef struct p3r_layer p3r_layer;
@@ -328,6 +339,8 @@ void p3r_layer_free(p3r_ctx* ctx, p3r_layer* layer);
  * batch: a non-primitive table with no rows is left out, as `batch_instance_*` returning None does
  * (batch_stark_prover/poseidon2.rs:1089-1092, recompose.rs:77-80). */
 int p3r_layer_table_heights(const p3r_layer* layer, size_t heights_out[5]);
+/* Padded height of the second Recompose table (`recompose/coeff` next to `recompose`, ABI version 5); 0 = absent. */
+int p3r_layer_recompose_coeff_height(const p3r_layer* layer, size_t* height_out);
 /* The packing the proof was made with: Public / ALU lanes fall back to 1 when the table holds at
  * most the dummy op (reduce_lanes_if_dummy, batch_stark_prover.rs:1305-1318); BatchStarkProof
  * stores this effective packing (:1617-1622). */
@@ -450,8 +463,9 @@ enum p3r_op_kind {               /* circuit/src/ops/op.rs `Op`, AluOpKind */
                                     aux = 1: `recompose/coeff` (NpoTypeId::recompose_with_coeff_lookups,
                                     ops/npo.rs:48-60: every coefficient is a bus tuple too; a coefficient that is a
                                     hint output is created by this row with its read count, any other is named with
-                                    multiplicity 0 - batch_stark_prover/recompose.rs:341-352).  The Recompose ops of
-                                    one circuit are of one kind (a layer holds one Recompose table). */
+                                    multiplicity 0 - batch_stark_prover/recompose.rs:341-352).  A circuit may hold both kinds:
+                                    the layer then proves two Recompose tables, `recompose` before `recompose/coeff`
+                                    (p3r_layer_desc_counts.n_recompose_coeff). */
 };
 
 typedef struct p3r_op {
@@ -521,7 +535,8 @@ enum p3r_traces_array {
   P3R_TRACES_P2_INPUT_VALUES = 3, /* n_p2 x 16 */
   P3R_TRACES_P2_FLAGS = 4,        /* n_p2 x 3: new_start, merkle_path, mmcs_bit */
   P3R_TRACES_P2_MMCS_INDEX_SUM = 5, /* n_p2 */
-  P3R_TRACES_RECOMPOSE_VALUES = 6 /* n_recompose x 4 */
+  P3R_TRACES_RECOMPOSE_VALUES = 6, /* n_recompose x D */
+  P3R_TRACES_RECOMPOSE_COEFF_VALUES = 7 /* n_recompose_coeff x D: the second Recompose table */
 };
 int p3r_dtraces_get(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces, uint32_t which,
                     uint32_t* out, size_t out_len);

@@ -122,6 +122,7 @@ struct Traces {
   std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_bit;
   std::vector<uint32_t> p2_mmcs_index_sum;
   std::vector<uint32_t> recompose_values;             // n x D
+  std::vector<uint32_t> recompose_coeff_values;       // n x D: rows of the second Recompose table (`recompose/coeff`)
 };
 
 // Per-op preprocessed data as get_airs_and_degrees_with_prep leaves it (see p3r_layer_desc).
@@ -134,6 +135,9 @@ struct CircuitPrep {
   std::vector<uint8_t> p2_absorb_len;
   // the "recompose/coeff" table (per-coefficient bus tuples): recompose_prep is n x (2 + 2 D)
   bool recompose_coeff_lookups = false;
+  // a layer holding BOTH Recompose tables (recompose_table_provers(lanes, true)): recompose_prep is the plain kind,
+  // this the `recompose/coeff` table, n x (2 + 2 D)
+  std::vector<uint32_t> recompose_coeff_prep;
 };
 
 struct Circuit {  // flattened Circuit<EF>
@@ -159,6 +163,10 @@ class CircuitProverData {
     d.counts.n_recompose = prep.recompose_prep.size() / rec_w;
     d.recompose_coeff_lookups = prep.recompose_coeff_lookups;
     recompose_coeff_lookups = prep.recompose_coeff_lookups;
+    const size_t rec2_w = 2 + 2 * ctx.ext_degree();
+    if (prep.recompose_coeff_prep.size() % rec2_w) throw Error(P3R_EINVAL, "recompose_coeff_prep must be n x " + std::to_string(rec2_w));
+    d.counts.n_recompose_coeff = prep.recompose_coeff_prep.size() / rec2_w;
+    d.recompose_coeff_prep = prep.recompose_coeff_prep.data();
     d.public_lanes = packing.public_lanes; d.alu_lanes = packing.alu_lanes;
     d.horner_packed_steps = packing.horner_packed_steps; d.recompose_lanes = packing.recompose_lanes;
     d.min_trace_height = packing.min_trace_height;
@@ -196,10 +204,12 @@ class CircuitProverData {
   const p3r_layer_desc_counts& rows() const { return rows_; }
   std::vector<uint32_t> preprocessed_commitment;  // (1 << cap_height) x 8, canonical
   std::array<size_t, 5> table_heights{};          // 0 = table absent from the batch
+  size_t recompose_coeff_height = 0;              // the second Recompose table (`recompose/coeff` next to `recompose`)
 
  private:
   void read_shape() {
     ctx_->check(p3r_layer_table_heights(layer_, table_heights.data()));
+    ctx_->check(p3r_layer_recompose_coeff_height(layer_, &recompose_coeff_height));
     effective_ = packing_;
     ctx_->check(p3r_layer_effective_lanes(layer_, &effective_.public_lanes, &effective_.alu_lanes));
   }
@@ -376,6 +386,8 @@ inline p3r_traces traces_struct(const Traces& t, uint32_t d = 4) {
   s.p2.new_start = t.p2_new_start.data(); s.p2.merkle_path = t.p2_merkle_path.data(); s.p2.mmcs_bit = t.p2_mmcs_bit.data();
   s.p2.mmcs_index_sum = t.p2_mmcs_index_sum.data();
   s.n_recompose = t.recompose_values.size() / d; s.recompose_values = t.recompose_values.data();
+  if (t.recompose_coeff_values.size() % d) throw Error(P3R_EINVAL, "recompose_coeff_values must hold n x D values");
+  s.n_recompose_coeff = t.recompose_coeff_values.size() / d; s.recompose_coeff_values = t.recompose_coeff_values.data();
   return s;
 }
 }  // namespace detail
@@ -423,9 +435,12 @@ class PreparedCircuit {
     ctx.check(p3r_circuit_counts(h_, &counts));
     ctx.check(p3r_circuit_levels(h_, &levels_));
     cpd_ = std::make_unique<CircuitProverData>(ctx, p3r_circuit_layer(h_), packing, counts, std::move(commit));
-    // Recompose ops of the "recompose/coeff" kind (aux = 1): the table the wrapped proof names
+    // Recompose ops of the "recompose/coeff" kind (aux = 1): the layer's one Recompose table when every Recompose op
+    // is of that kind, its second table next to `recompose` otherwise
+    bool any_rec = false, all_coeff = true;
     for (const p3r_op& op : circuit_.ops)
-      if (op.kind == P3R_OP_RECOMPOSE && op.aux == 1u) cpd_->recompose_coeff_lookups = true;
+      if (op.kind == P3R_OP_RECOMPOSE) { any_rec = true; all_coeff = all_coeff && op.aux == 1u; }
+    cpd_->recompose_coeff_lookups = any_rec && all_coeff;
   }
   ~PreparedCircuit() { cpd_.reset(); if (h_) p3r_circuit_free(ctx_->raw(), h_); }
   PreparedCircuit(const PreparedCircuit&) = delete;
@@ -499,13 +514,16 @@ class BatchStarkProver {
     const uint32_t k = tp.horner_packed_steps;
     const bool d4 = p.ext_degree == 4;   // D = 5 circuits carry the compact-D1 Poseidon2 table (62 preprocessed columns)
     const bool coeff = cpd.recompose_coeff_lookups;
-    const uint32_t widths[5] = {2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), d4 ? 24u : 62u,
-                                (2 + (coeff ? 2 * p.ext_degree : 0)) * tp.recompose_lanes};
-    for (int i = 0; i < 5; ++i) {
-      if (!cpd.table_heights[i]) continue;
+    const uint32_t widths[6] = {2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), d4 ? 24u : 62u,
+                                (2 + (coeff ? 2 * p.ext_degree : 0)) * tp.recompose_lanes,
+                                (2 + 2 * p.ext_degree) * tp.recompose_lanes};
+    const size_t heights[6] = {cpd.table_heights[0], cpd.table_heights[1], cpd.table_heights[2], cpd.table_heights[3],
+                               cpd.table_heights[4], cpd.recompose_coeff_height};
+    for (int i = 0; i < 6; ++i) {
+      if (!heights[i]) continue;
       p.preprocessed_widths.push_back(widths[i]);
       uint32_t db = 0;
-      while ((size_t(1) << db) < cpd.table_heights[i]) ++db;
+      while ((size_t(1) << db) < heights[i]) ++db;
       p.degree_bits.push_back(db);
     }
     if (cpd.table_heights[3])  // Poseidon2Prover reports the PADDED row count (poseidon2.rs:1449)
@@ -514,6 +532,8 @@ class BatchStarkProver {
                                   cpd.table_heights[3], 1, {}, 0});
     if (cpd.table_heights[4])  // RecomposeProver reports the op count (recompose.rs:125)
       p.non_primitives.push_back({coeff ? "recompose/coeff" : "recompose", cpd.rows().n_recompose, tp.recompose_lanes, {}, 0});
+    if (cpd.recompose_coeff_height)  // both table provers registered: `recompose`, then `recompose/coeff`
+      p.non_primitives.push_back({"recompose/coeff", cpd.rows().n_recompose_coeff, tp.recompose_lanes, {}, 0});
     p.preprocessed_commitment = cpd.preprocessed_commitment;
     p.montgomery_field_encoding = !canonical;
     p.modulus = modulus(ctx_->field());

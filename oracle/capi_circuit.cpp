@@ -52,7 +52,7 @@ void do_run(CircuitHandle& H, const uint32_t* rc, const uint32_t* pub, const uin
   auto put_e = [](std::vector<uint32_t>& d, const E& e) { for (int i = 0; i < 4; ++i) d.push_back(e.c[i].v); };
   auto& A = H.arr;
   for (const char* k : {"witness", "const_values", "public_values", "alu_values", "p2_inputs", "p2_flags",
-                        "p2_mmcs_index_sum", "recompose_values"}) A[k].clear();
+                        "p2_mmcs_index_sum", "recompose_values", "recompose_coeff_values"}) A[k].clear();
   for (auto& e : T.witness) put_e(A["witness"], e);
   for (auto& e : T.const_values) put_e(A["const_values"], e);
   for (auto& e : T.public_values) put_e(A["public_values"], e);
@@ -63,6 +63,7 @@ void do_run(CircuitHandle& H, const uint32_t* rc, const uint32_t* pub, const uin
     A["p2_mmcs_index_sum"].push_back(r.mmcs_index_sum.v);
   }
   for (auto& r : T.recompose_values) for (auto x : r) A["recompose_values"].push_back(x.v);
+  for (auto& r : T.recompose_coeff_values) for (auto x : r) A["recompose_coeff_values"].push_back(x.v);
 }
 }  // namespace
 
@@ -96,6 +97,7 @@ int orc_circuit_preprocess(void* h, uint32_t modulus, int D) {
     CircuitPrep cp = get_airs_and_degrees_with_prep(pp);
     A["const_prep"] = cp.const_prep; A["public_prep"] = cp.public_prep; A["alu_prep13"] = cp.alu_prep13;
     A["p2_prep_rows"] = cp.p2_rows; A["recompose_prep"] = cp.recompose_prep; A["ext_reads"] = cp.ext_reads;
+    A["recompose_coeff_prep"] = cp.recompose_coeff_prep;
     for (const char* k : {"p2_in_ctl", "p2_input_indices", "p2_out_ctl", "p2_output_indices",
                           "p2_mmcs_index_sum_idx", "p2_prep_flags"}) A[k].clear();
     const uint32_t d = (uint32_t)D;

@@ -41,6 +41,10 @@ typedef struct orc_workload {
   uint32_t recompose_coeff_lookups;
   /* W of the binomial extension x^D = W for ext_degree 2, 6, 8 (0 otherwise) */
   uint32_t ext_w;
+  /* the SECOND Recompose table of a layer holding both kinds (recompose_table_provers(lanes, true),
+   * batch_stark_prover.rs:1914-1932: `recompose`, then `recompose/coeff`): n x D values, n x (2 + 2 D) preprocessed;
+   * recompose_prep is then the plain table and recompose_coeff_lookups is 0 */
+  size_t n_recompose_coeff; const uint32_t* recompose_coeff_values; const uint32_t* recompose_coeff_prep;
 } orc_workload;
 
 typedef struct orc_params {
@@ -202,6 +206,16 @@ struct Layer : LayerBase {
       in.prep = lanes_prep_to_matrix<FP>(vec(w.recompose_prep, w.n_recompose * plw), plw, in.air.lanes, mh);
       // RecomposeAir::trace_to_matrix pads only to a power of two; the prover then pads dynamic
       // tables to min_height (batch_stark_prover.rs:1515): same result as padding here.
+      insts.push_back(std::move(in));
+    }
+    if (w.n_recompose_coeff > 0) {
+      if (w.recompose_coeff_lookups) throw std::runtime_error("two Recompose tables: the first is the plain kind");
+      Instance<FP> in;
+      in.air.kind = AIR_RECOMPOSE; in.air.lanes = (int)w.recompose_lanes; in.air.D = D; in.air.W = W;
+      in.air.coeff_lookups = 1;
+      const int plw = 2 + 2 * D;
+      in.main = lanes_trace_to_matrix<FP>(vec(w.recompose_coeff_values, w.n_recompose_coeff * D), in.air.lanes, mh, D);
+      in.prep = lanes_prep_to_matrix<FP>(vec(w.recompose_coeff_prep, w.n_recompose_coeff * plw), plw, in.air.lanes, mh);
       insts.push_back(std::move(in));
     }
     for (auto& in : insts)

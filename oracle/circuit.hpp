@@ -57,11 +57,12 @@ struct Preprocessed {
   int D = 4;
   std::vector<uint32_t> prim_const, prim_public, prim_alu12;  // primitive[Const|Public|Alu]
   std::vector<uint32_t> p2_rows;     // non_primitive[poseidon2_perm/..]: 24 values per op
-  std::vector<uint32_t> recompose;   // non_primitive[recompose]: [output idx, 1] per op; the "recompose/coeff" kind
-                                     // (aux = 1) appends [coefficient idx, 1] per coefficient (ops/recompose.rs:174-192)
-  bool recompose_coeff = false;
+  std::vector<uint32_t> recompose;   // non_primitive[recompose]: [output idx, 1] per op
+  // non_primitive[recompose/coeff] (ops with aux = 1): [output idx, 1] then [coefficient idx, 1] per coefficient
+  // (ops/recompose.rs:174-192) - a separate op type, hence a separate table and a separate duplicate map
+  std::vector<uint32_t> recompose_coeff;
   std::vector<uint32_t> ext_reads;
-  std::vector<bool> dup_p2, dup_recompose;  // dup_npo_outputs[op_type][wid]
+  std::vector<bool> dup_p2, dup_recompose, dup_recompose_coeff;  // dup_npo_outputs[op_type][wid]
   std::set<uint32_t> hint_output_wids;
   uint32_t idx(uint32_t wid) const { return (uint32_t)(((uint64_t)wid * (uint64_t)D) % P); }  // base_field_index
   void read(uint32_t wid) {  // increment_ext_reads
@@ -168,21 +169,19 @@ inline Preprocessed generate_preprocessed_columns(const CircuitDesc& c, uint32_t
       }
       case COP_RECOMPOSE: {
         if (op.ext_len != 4) throw std::runtime_error("recompose op: needs 4 coefficient witnesses");
-        pp.recompose.push_back(pp.idx(op.out));
-        pp.recompose.push_back(1);
-        if (op.aux == 1) {
-          // register_non_primitive_output_index per coefficient: named, not marked defined, no read counted
-          pp.recompose_coeff = true;
+        const bool coeff = op.aux == 1;
+        auto& rows = coeff ? pp.recompose_coeff : pp.recompose;
+        auto& dups = coeff ? pp.dup_recompose_coeff : pp.dup_recompose;
+        rows.push_back(pp.idx(op.out));
+        rows.push_back(1);
+        if (coeff)   // register_non_primitive_output_index per coefficient: named, not marked defined, no read counted
           for (uint32_t k = 0; k < op.ext_len; ++k) {
-            pp.recompose.push_back(pp.idx(c.ext[op.ext_off + k]));
-            pp.recompose.push_back(1);
+            rows.push_back(pp.idx(c.ext[op.ext_off + k]));
+            rows.push_back(1);
           }
-        } else if (pp.recompose_coeff) {
-          throw std::runtime_error("recompose and recompose/coeff ops in one circuit");
-        }
         if (is_def(op.out)) {
-          if (op.out >= pp.dup_recompose.size()) pp.dup_recompose.resize((size_t)op.out + 1, false);
-          pp.dup_recompose[op.out] = true;
+          if (op.out >= dups.size()) dups.resize((size_t)op.out + 1, false);
+          dups[op.out] = true;
           pp.read(op.out);
         } else {
           define(op.out);
@@ -203,6 +202,10 @@ inline Preprocessed generate_preprocessed_columns(const CircuitDesc& c, uint32_t
 // conventions), from the generic columns.
 struct CircuitPrep {
   std::vector<uint32_t> const_prep, public_prep, alu_prep13, recompose_prep;
+  // the `recompose/coeff` rows: the layer's second Recompose table - or, when the circuit has no plain Recompose op,
+  // its only one (a table without rows is not proved): then they are in recompose_prep and this flag is set
+  std::vector<uint32_t> recompose_coeff_prep;
+  bool recompose_coeff_only = false;
   std::vector<uint32_t> p2_rows;  // 24 per row, out_ctl replaced by the multiplicity
   std::vector<uint32_t> ext_reads;
 };
@@ -237,18 +240,25 @@ inline CircuitPrep get_airs_and_degrees_with_prep(Preprocessed pp) {
       ctl = dup ? neg1 : reads(wid);
     }
   // ---- recompose_preprocess_for_op (recompose.rs:294-358)
-  out.recompose_prep = pp.recompose;
-  const size_t rec_w = pp.recompose_coeff ? 2 + 2 * D : 2;
-  for (size_t r = 0; r < out.recompose_prep.size() / rec_w; ++r) {
-    uint32_t* row = &out.recompose_prep[rec_w * r];
-    const uint32_t wid = row[0] / D;
-    const bool dup = wid < pp.dup_recompose.size() && pp.dup_recompose[wid];
-    row[1] = dup ? neg1 : reads(wid);
-    // coefficient tuples: a hint output is created here with its read count, anything else is named with 0 (:341-352)
-    for (size_t k = 2; k < rec_w; k += 2) {
-      const uint32_t cw = row[k] / D;
-      row[k + 1] = pp.hint_output_wids.count(cw) ? reads(cw) : 0u;
+  auto recompose_for_op = [&](std::vector<uint32_t> rows, const std::vector<bool>& dups, size_t rec_w) {
+    for (size_t r = 0; r < rows.size() / rec_w; ++r) {
+      uint32_t* row = &rows[rec_w * r];
+      const uint32_t wid = row[0] / D;
+      const bool dup = wid < dups.size() && dups[wid];
+      row[1] = dup ? neg1 : reads(wid);
+      // coefficient tuples: a hint output is created here with its read count, anything else is named with 0 (:341-352)
+      for (size_t k = 2; k < rec_w; k += 2) {
+        const uint32_t cw = row[k] / D;
+        row[k + 1] = pp.hint_output_wids.count(cw) ? reads(cw) : 0u;
+      }
     }
+    return rows;
+  };
+  out.recompose_prep = recompose_for_op(pp.recompose, pp.dup_recompose, 2);
+  out.recompose_coeff_prep = recompose_for_op(pp.recompose_coeff, pp.dup_recompose_coeff, 2 + 2 * D);
+  if (out.recompose_prep.empty() && !out.recompose_coeff_prep.empty()) {
+    out.recompose_prep.swap(out.recompose_coeff_prep);
+    out.recompose_coeff_only = true;
   }
   // ---- primitive tables (common.rs:186-368)
   for (uint32_t idx : pp.prim_const) { out.const_prep.push_back(reads(idx / D)); out.const_prep.push_back(idx); }
@@ -288,6 +298,7 @@ struct RunTraces {
   struct P2Row { bool new_start, merkle_path, mmcs_bit, mmcs_ctl_enabled; F mmcs_index_sum; std::array<F, 16> input; };
   std::vector<P2Row> p2_rows;
   std::vector<std::array<F, 4>> recompose_values;
+  std::vector<std::array<F, 4>> recompose_coeff_values;   // rows of the ops with aux = 1 when the circuit has both kinds
 };
 
 // CircuitRunner::run (runner.rs:195-253) for D = 4.
@@ -296,6 +307,8 @@ RunTraces<FP> run_circuit(const CircuitDesc& c, const Poseidon2<FP>& p2, const R
   using F = Fe<FP>;
   using E = Fe4<FP>;
   RunTraces<FP> T;
+  bool has_plain_recompose = false;   // the rows of `recompose/coeff` ops form a second table only next to a first one
+  for (auto& op : c.ops) has_plain_recompose = has_plain_recompose || (op.kind == COP_RECOMPOSE && op.aux != 1);
   std::vector<E> w(c.witness_count);
   std::vector<bool> set(c.witness_count, false);
   auto wid_str = [](uint32_t x) { return "WitnessId(" + std::to_string(x) + ")"; };
@@ -451,7 +464,7 @@ RunTraces<FP> run_circuit(const CircuitDesc& c, const Poseidon2<FP>& p2, const R
         std::array<F, 4> co;
         for (int i = 0; i < 4; ++i) co[i] = get(ins[i]).c[0];
         put(op.out, E(co[0], co[1], co[2], co[3]));
-        T.recompose_values.push_back(co);
+        (op.aux == 1 && has_plain_recompose ? T.recompose_coeff_values : T.recompose_values).push_back(co);
         break;
       }
       default: throw std::runtime_error("unknown op kind");

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # P3R_LIB_PATH: A/B runs of two builds of the library on one box (development only)
 LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so")
 
-P3R_ABI_VERSION = 4
+P3R_ABI_VERSION = 5
 P3R_EXT_LOOKUP_UNPACKED = 1
 FIELD_KOALA_BEAR = 0
 FIELD_BABY_BEAR = 1
@@ -59,7 +59,7 @@ class P3rAirDesc(C.Structure):
 
 
 class P3rLayerCounts(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("n_const", "n_public", "n_alu", "n_p2", "n_recompose")]
+    _fields_ = [(n, C.c_size_t) for n in ("n_const", "n_public", "n_alu", "n_p2", "n_recompose", "n_recompose_coeff")]
 
 
 class P3rLayerDesc(C.Structure):
@@ -74,6 +74,7 @@ class P3rLayerDesc(C.Structure):
         ("p2_input_indices", C.POINTER(C.c_uint32)), ("p2_out_ctl", C.POINTER(C.c_uint32)),
         ("p2_output_indices", C.POINTER(C.c_uint32)), ("p2_mmcs_index_sum_idx", C.POINTER(C.c_uint32)),
         ("p2_absorb_len", C.POINTER(C.c_uint8)), ("recompose_coeff_lookups", C.c_uint32),
+        ("recompose_coeff_prep", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -84,6 +85,7 @@ class P3rTraces(C.Structure):
         ("n_alu", C.c_size_t), ("alu_values", C.POINTER(C.c_uint32)),
         ("p2", P3rP2Rows),
         ("n_recompose", C.c_size_t), ("recompose_values", C.POINTER(C.c_uint32)),
+        ("n_recompose_coeff", C.c_size_t), ("recompose_coeff_values", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -184,6 +186,7 @@ SIGNATURES = {
     "p3r_layer_create": (vp, [vp, C.POINTER(P3rLayerDesc), u32p]),
     "p3r_layer_free": (None, [vp, vp]),
     "p3r_layer_table_heights": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "p3r_layer_recompose_coeff_height": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "p3r_layer_effective_lanes": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "p3r_verify_batch": (C.c_int, [C.POINTER(P3rConfig), C.POINTER(P3rAirDesc), C.c_size_t, u32p, u32p,
                                    C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, C.c_char_p, C.c_size_t]),

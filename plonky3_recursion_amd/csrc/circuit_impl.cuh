@@ -31,24 +31,22 @@ namespace {
 struct CircuitTables {
   p3r_layer_desc_counts counts{};
   std::vector<uint32_t> const_prep, public_prep, alu_prep13, recompose_prep;
+  // ops of the "recompose/coeff" kind (aux = 1): the layer's ONE Recompose table when the circuit has no plain
+  // Recompose op (recompose_coeff: recompose_prep holds them), its second table otherwise
+  std::vector<uint32_t> recompose_coeff_prep;
+  bool recompose_coeff = false;
   std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_ctl_enabled, p2_in_ctl;
   std::vector<uint32_t> p2_input_indices, p2_out_ctl, p2_output_indices, p2_mmcs_index_sum_idx;
   std::vector<uint8_t> p2_absorb_len;   // base-mode rows (circuits of degree 1 / 5)
-  bool recompose_coeff = false;         // the circuit's Recompose ops are the "recompose/coeff" kind (aux = 1)
 };
 
-// The Recompose ops of a circuit are of one kind here: "recompose" (aux = 0) or "recompose/coeff" (aux = 1:
-// NpoTypeId::recompose_with_coeff_lookups, circuit/src/ops/npo.rs:48-60).  A layer holds one Recompose table.
+// Recompose ops come in two kinds: "recompose" (aux = 0) and "recompose/coeff" (aux = 1:
+// NpoTypeId::recompose_with_coeff_lookups, circuit/src/ops/npo.rs:48-60).  Each kind is its own table
+// (recompose_table_provers(lanes, true), batch_stark_prover.rs:1914-1932).
 inline bool circuit_recompose_coeff(const p3r_op* ops, size_t n) {
-  int kind = -1;
   for (size_t i = 0; i < n; ++i)
-    if (ops[i].kind == P3R_OP_RECOMPOSE) {
-      const int k = ops[i].aux == 1u;
-      if (kind >= 0 && kind != k)
-        fail(P3R_EUNSUPPORTED, "op %zu: `recompose` and `recompose/coeff` ops in one circuit: a layer holds one Recompose table", i);
-      kind = k;
-    }
-  return kind == 1;
+    if (ops[i].kind == P3R_OP_RECOMPOSE && ops[i].aux == 1u) return true;
+  return false;
 }
 
 // Poseidon2 op layout by circuit degree: D = 4 -> four input limbs of four elements, two (or four) output limbs;
@@ -148,7 +146,8 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
   CircuitTables T;
   std::vector<uint32_t> reads(c.witness_count, 0);
   std::vector<uint8_t> defined(c.witness_count, 0), is_private(c.witness_count, 0), is_hint(c.witness_count, 0);
-  std::vector<uint8_t> dup_p2(c.witness_count, 0), dup_rec(c.witness_count, 0);
+  // dup_npo_outputs is kept per op type (circuit.rs:464-491): one map per Recompose kind
+  std::vector<uint8_t> dup_p2(c.witness_count, 0), dup_rec(c.witness_count, 0), dup_rec_coeff(c.witness_count, 0);
   for (uint32_t w : c.private_rows) is_private[w] = 1;
   {
     // hint outputs not also produced by a Const / Public op (circuit.rs:263-284)
@@ -165,7 +164,7 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
   const P2Shape sh(D);
   // pass 1: who creates, who reads
   std::vector<AluRoles> roles;
-  std::vector<const p3r_op*> consts, publics, alus, p2s, recs;
+  std::vector<const p3r_op*> consts, publics, alus, p2s, recs, recs_coeff;
   for (auto& op : c.ops) {
     switch (op.kind) {
       case P3R_OP_CONST: consts.push_back(&op); defined[op.out] = 1; break;
@@ -184,10 +183,12 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
         p2s.push_back(&op);
         break;
       }
-      case P3R_OP_RECOMPOSE:
-        if (defined[op.out]) { dup_rec[op.out] = 1; reads[op.out]++; } else defined[op.out] = 1;
-        recs.push_back(&op);
+      case P3R_OP_RECOMPOSE: {
+        const bool coeff = op.aux == 1u;
+        if (defined[op.out]) { (coeff ? dup_rec_coeff : dup_rec)[op.out] = 1; reads[op.out]++; } else defined[op.out] = 1;
+        (coeff ? recs_coeff : recs).push_back(&op);
         break;
+      }
       default: {  // ALU
         const bool out_def = defined[op.out], b_def = defined[op.b];
         auto state_of = [&](uint32_t w) -> uint8_t {
@@ -236,7 +237,12 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
   T.counts.n_public = publics.size();
   T.counts.n_alu = std::max<size_t>(alus.size(), 1);
   T.counts.n_p2 = p2s.size();
+  // a table without rows is not proved: a circuit whose Recompose ops are all of the coefficient kind has ONE
+  // Recompose table, `recompose/coeff`, in the first slot (p3r_layer_desc.recompose_coeff_lookups)
+  T.recompose_coeff = recs.empty() && !recs_coeff.empty();
+  if (T.recompose_coeff) recs.swap(recs_coeff);
   T.counts.n_recompose = recs.size();
+  T.counts.n_recompose_coeff = recs_coeff.size();
   auto small_tables = std::async(std::launch::async, [&] {
     T.const_prep.reserve(2 * consts.size());
     for (auto* op : consts) { T.const_prep.push_back(mult(op->out)); T.const_prep.push_back(scaled(op->out)); }
@@ -268,18 +274,21 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
     }
     // recompose.rs:293-356: [D * out, mult]; the coefficient variant appends (D * coeff, mult) per coefficient, where
     // only a hint output is created here (its reads), any other coefficient is named with multiplicity 0
-    T.recompose_coeff = circuit_recompose_coeff(c.ops.data(), c.ops.size());
-    T.recompose_prep.reserve((T.recompose_coeff ? 2 + 2 * D : 2) * recs.size());
-    for (auto* op : recs) {
-      T.recompose_prep.push_back(scaled(op->out));
-      T.recompose_prep.push_back(dup_rec[op->out] ? NEG1 : mult(op->out));
-      if (T.recompose_coeff)
+    auto rows_of = [&](const std::vector<const p3r_op*>& list, std::vector<uint32_t>& dst) {
+      for (auto* op : list) {
+        const bool coeff = op->aux == 1u;
+        dst.push_back(scaled(op->out));
+        dst.push_back((coeff ? dup_rec_coeff : dup_rec)[op->out] ? NEG1 : mult(op->out));
+        if (!coeff) continue;
         for (uint32_t k = 0; k < D; ++k) {
           const uint32_t w = c.ext_of(*op)[k];
-          T.recompose_prep.push_back(scaled(w));
-          T.recompose_prep.push_back(is_hint[w] ? mult(w) : 0u);
+          dst.push_back(scaled(w));
+          dst.push_back(is_hint[w] ? mult(w) : 0u);
         }
-    }
+      }
+    };
+    rows_of(recs, T.recompose_prep);
+    rows_of(recs_coeff, T.recompose_coeff_prep);
   });
   T.alu_prep13.resize(13 * alus.size());
   for (size_t i = 0; i < alus.size(); ++i) {
@@ -327,6 +336,9 @@ inline RunSchedule build_schedule(const HostCircuit& c, uint32_t D = 4) {
   bool chain_open = false;
   std::vector<RunOp> light;
   uint32_t n_alu = 0, n_rec = 0, n_pub = 0;
+  // trace rows of the "recompose/coeff" ops follow those of the plain ops in the one recompose_values array
+  uint32_t n_rec_plain_total = 0, n_rec_coeff = 0;
+  for (auto& op : c.ops) n_rec_plain_total += op.kind == P3R_OP_RECOMPOSE && op.aux != 1u;
   uint32_t last_normal = kNoW, last_merkle = kNoW;
   uint32_t max_op_id = 0;
   bool any_npo = false;
@@ -437,7 +449,7 @@ inline RunSchedule build_schedule(const HostCircuit& c, uint32_t D = 4) {
         r.ext_off = (uint32_t)S.dev_ext.size();
         S.dev_ext.insert(S.dev_ext.end(), e, e + op.ext_len);
         if (put(op.out)) r.kind_flags |= RUN_CHECK_OUT; else written.push_back(op.out);
-        r.rec = n_rec++;
+        r.rec = op.aux == 1u ? n_rec_plain_total + n_rec_coeff++ : n_rec++;
         break;
       case P3R_OP_POSEIDON2_PERM: {
         const bool new_start = op.aux & 1, merkle = op.aux & 2;
@@ -1183,6 +1195,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   ld.p2_input_indices = T.p2_input_indices.data(); ld.p2_out_ctl = T.p2_out_ctl.data();
   ld.p2_output_indices = T.p2_output_indices.data(); ld.p2_mmcs_index_sum_idx = T.p2_mmcs_index_sum_idx.data();
   if (ext_d != 4 && !T.p2_absorb_len.empty()) ld.p2_absorb_len = T.p2_absorb_len.data();
+  ld.recompose_coeff_prep = T.recompose_coeff_prep.data();
   ld.recompose_coeff_lookups = T.recompose_coeff ? 1u : 0u;
   prof_stage(ctx, "prep_layer_create");
   C->layer = layer_create<PP>(ctx, &ld, commit_out);
@@ -1347,7 +1360,8 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
   T->alu_values.alloc(std::max<size_t>(cn.n_alu * 4 * ext_d, 1));
   if (S.n_alu_records == 0)  // the dummy op of an empty table; otherwise every record is written by its op
     P3R_HIP(hipMemsetAsync(T->alu_values.p, 0, T->alu_values.n * 4, ctx->stream));
-  T->recompose_values.alloc(std::max<size_t>(cn.n_recompose * ext_d, 1));
+  T->recompose_values.alloc(std::max<size_t>((cn.n_recompose + cn.n_recompose_coeff) * ext_d, 1));
+  T->n_recompose_coeff = cn.n_recompose_coeff;
   uint32_t* p2_inputs = nullptr; uint8_t* p2_flags = nullptr; uint32_t* p2_seed = nullptr;
   size_t p2_h = 0;
   if (L->has_p2) {
@@ -1422,19 +1436,22 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
 template <class PP>
 void dtraces_get(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, uint32_t which, uint32_t* out, size_t out_len) {
   const auto& c = L->counts;
-  auto plain = [&](const DevBuf& src, size_t n) {
+  auto plain_at = [&](const uint32_t* src, size_t n) {
     if (out_len != n) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", n, out_len);
     if (!n) return;
     DevBuf tmp(n);
-    P3R_HIP(hipMemcpyAsync(tmp.p, src.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    P3R_HIP(hipMemcpyAsync(tmp.p, src, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_convert_inplace<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, tmp.p, n, 0);
     P3R_HIP(copy_sync(ctx->stream, out, tmp.p, n * 4, hipMemcpyDeviceToHost));
   };
   switch (which) {
-    case P3R_TRACES_CONST_VALUES: plain(t->const_values, c.n_const * ctx->cfg.ext_degree); break;
-    case P3R_TRACES_PUBLIC_VALUES: plain(t->public_values, c.n_public * ctx->cfg.ext_degree); break;
-    case P3R_TRACES_ALU_VALUES: plain(t->alu_values, c.n_alu * 4 * ctx->cfg.ext_degree); break;
-    case P3R_TRACES_RECOMPOSE_VALUES: plain(t->recompose_values, c.n_recompose * ctx->cfg.ext_degree); break;
+    case P3R_TRACES_CONST_VALUES: plain_at(t->const_values.p, c.n_const * ctx->cfg.ext_degree); break;
+    case P3R_TRACES_PUBLIC_VALUES: plain_at(t->public_values.p, c.n_public * ctx->cfg.ext_degree); break;
+    case P3R_TRACES_ALU_VALUES: plain_at(t->alu_values.p, c.n_alu * 4 * ctx->cfg.ext_degree); break;
+    case P3R_TRACES_RECOMPOSE_VALUES: plain_at(t->recompose_values.p, c.n_recompose * ctx->cfg.ext_degree); break;
+    case P3R_TRACES_RECOMPOSE_COEFF_VALUES:   // the rows of the second table follow those of the first
+      plain_at(t->recompose_values.p + c.n_recompose * ctx->cfg.ext_degree, c.n_recompose_coeff * ctx->cfg.ext_degree);
+      break;
     case P3R_TRACES_P2_INPUT_VALUES: {
       if (out_len != c.n_p2 * 16) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2 * 16, out_len);
       if (!c.n_p2) break;
@@ -1456,7 +1473,7 @@ void dtraces_get(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, uint32_
     case P3R_TRACES_P2_MMCS_INDEX_SUM: {
       if (out_len != c.n_p2) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2, out_len);
       if (!c.n_p2) break;
-      plain(t->p2->seed, c.n_p2);
+      plain_at(t->p2->seed.p, c.n_p2);
       break;
     }
     default: fail(P3R_EINVAL, "unknown traces array %u", which);

@@ -188,14 +188,17 @@ struct p3r_layer {
   p3r_layer_desc_counts counts{};
   uint32_t public_lanes = 1, alu_lanes = 1, horner_k = 2, recompose_lanes = 1, min_height = 1;
   size_t h_const = 0, h_public = 0, h_alu = 0, h_p2 = 0, h_recompose = 0, alu_rows = 0;
+  size_t h_recompose_coeff = 0;   // table 5: the `recompose/coeff` table of a layer that holds both kinds
   // A non-primitive table with no rows is not part of the batch (poseidon2.rs:1089-1092,
   // recompose.rs:77-80: `batch_instance_*` returns None); the primitive three always are.
-  bool has_p2 = true, has_recompose = true;
-  bool recompose_coeff = false;  // the "recompose/coeff" variant: per-coefficient bus tuples (recompose_air.rs:196-226)
-  int slot_of(int table) const {  // position of table 0..4 among the proved instances, -1 if absent
+  bool has_p2 = true, has_recompose = true, has_recompose_coeff = false;
+  bool recompose_coeff = false;  // table 4 is the "recompose/coeff" variant: per-coefficient bus tuples (recompose_air.rs:196-226)
+  int slot_of(int table) const {  // position of table 0..5 among the proved instances, -1 if absent
     if (table < 3) return table;
     if (table == 3) return has_p2 ? 3 : -1;
-    return has_recompose ? (has_p2 ? 4 : 3) : -1;
+    const int base = has_p2 ? 4 : 3;
+    if (table == 4) return has_recompose ? base : -1;
+    return has_recompose_coeff ? base + (has_recompose ? 1 : 0) : -1;
   }
   std::unique_ptr<p3r_prep> prep;
   p3r::DevBuf alu_plan, alu_prev_src;
@@ -205,6 +208,7 @@ struct p3r_layer {
 struct p3r_dtraces {
   p3r::DevBuf const_values, public_values, alu_values, recompose_values;  // Montgomery, row-major
   size_t n_const = 0, n_public = 0, n_alu = 0, n_recompose = 0;
+  size_t n_recompose_coeff = 0;   // rows of table 5: they follow the n_recompose rows of table 4 in recompose_values
   std::unique_ptr<p3r_p2_dev> p2;  // padded to the table height with filler rows
 };
 
@@ -224,6 +228,9 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   if (d->counts.n_alu <= 1) L->alu_lanes = 1;
   L->has_p2 = d->counts.n_p2 > 0;
   L->has_recompose = d->counts.n_recompose > 0;
+  L->has_recompose_coeff = d->counts.n_recompose_coeff > 0;
+  if (L->has_recompose_coeff && d->recompose_coeff_lookups)
+    fail(P3R_EINVAL, "recompose_coeff_lookups = 1 names the ONE Recompose table; with a second table (n_recompose_coeff) recompose_prep is the plain kind");
   if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
   const uint32_t ext_d = ctx->cfg.ext_degree;
   if (ext_degree_is_binomial_generic(ext_d) && L->has_p2)
@@ -245,17 +252,20 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     std::copy(prep, prep + n_ops * per_op, m.begin());
     return m;
   };
-  std::vector<std::vector<uint32_t>> mats(5);
-  p3r_air_desc airs[5] = {{P3R_AIR_CONST, 1, 2, 0},
+  const int rec2_plw = 2 + 2 * (int)ext_d;
+  std::vector<std::vector<uint32_t>> mats(6);
+  p3r_air_desc airs[6] = {{P3R_AIR_CONST, 1, 2, 0},
                           {P3R_AIR_PUBLIC, L->public_lanes, 2, 0},
                           {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
                           {P3R_AIR_POSEIDON2, 1, 2, 0},
-                          {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, L->recompose_coeff ? 1u : 0u}};
+                          {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, L->recompose_coeff ? 1u : 0u},
+                          {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 1u}};
   // every table but the ALU one on a second host thread (they share nothing with it)
   auto other_tables = std::async(std::launch::async, [&] {
     check(d->const_prep, c.n_const * 2, "const_prep");
     check(d->public_prep, c.n_public * 2, "public_prep");
     check(d->recompose_prep, c.n_recompose * rec_plw, "recompose_prep");
+    check(d->recompose_coeff_prep, c.n_recompose_coeff * rec2_plw, "recompose_coeff_prep");
     check(d->p2_out_ctl, c.n_p2 * (ext_d == 4 ? 2 : 8), "p2_out_ctl");
     mats[0] = lanes_prep(d->const_prep, c.n_const, 2, 1, L->h_const);
     mats[1] = lanes_prep(d->public_prep, c.n_public, 2, (int)L->public_lanes, L->h_public);
@@ -316,6 +326,8 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     }
     if (L->has_recompose)
       mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, rec_plw, (int)L->recompose_lanes, L->h_recompose);
+    if (L->has_recompose_coeff)
+      mats[5] = lanes_prep(d->recompose_coeff_prep, c.n_recompose_coeff, rec2_plw, (int)L->recompose_lanes, L->h_recompose_coeff);
   });
   // ALU: schedule + scheduled preprocessed trace (alu_air.rs:613-677)
   {
@@ -357,13 +369,13 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     P3R_HIP(copy_sync(ctx->stream, L->alu_prev_src.p, S.prev_src.data(), S.prev_src.size() * 4, hipMemcpyHostToDevice));
   }
   other_tables.get();
-  const int widths[5] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1),
-                         ext_d == 4 ? 24 : kP2D1PrepWidth, (int)L->recompose_lanes * rec_plw};
-  const size_t heights[5] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose};
-  p3r_matrix pm[5];
-  p3r_air_desc present_airs[5];
+  const int widths[6] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1),
+                         ext_d == 4 ? 24 : kP2D1PrepWidth, (int)L->recompose_lanes * rec_plw, (int)L->recompose_lanes * rec2_plw};
+  const size_t heights[6] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose, L->h_recompose_coeff};
+  p3r_matrix pm[6];
+  p3r_air_desc present_airs[6];
   size_t n_present = 0;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 6; ++i) {
     if (L->slot_of(i) < 0) continue;
     present_airs[n_present] = airs[i];
     pm[n_present++] = {mats[i].data(), heights[i], (size_t)widths[i]};
@@ -424,15 +436,25 @@ template <class PP>
 std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, const p3r_traces* t) {
   const auto& c = L->counts;
   if (t->n_const != c.n_const || t->n_public != c.n_public || t->n_alu != c.n_alu || t->p2.n != c.n_p2 ||
-      t->n_recompose != c.n_recompose)
+      t->n_recompose != c.n_recompose || t->n_recompose_coeff != c.n_recompose_coeff)
     fail(P3R_EINVAL, "trace row counts do not match the prepared circuit shape");
   auto d = std::make_unique<p3r_dtraces>();
   d->n_const = c.n_const; d->n_public = c.n_public; d->n_alu = c.n_alu; d->n_recompose = c.n_recompose;
+  d->n_recompose_coeff = c.n_recompose_coeff;
   const size_t D = ctx->cfg.ext_degree;  // values are n x D (Const, Public), n x 4D (ALU: a, b, c, out)
   d->const_values = upload_mont<PP>(ctx, t->const_values, c.n_const * D, "const_values");
   d->public_values = upload_mont<PP>(ctx, t->public_values, c.n_public * D, "public_values");
   d->alu_values = upload_mont<PP>(ctx, t->alu_values, c.n_alu * 4 * D, "alu_values");
-  d->recompose_values = upload_mont<PP>(ctx, t->recompose_values, c.n_recompose * D, "recompose_values");
+  if (!c.n_recompose_coeff) {
+    d->recompose_values = upload_mont<PP>(ctx, t->recompose_values, c.n_recompose * D, "recompose_values");
+  } else {
+    // one device array: the rows of table 4, then those of table 5
+    if (!t->recompose_coeff_values || (c.n_recompose && !t->recompose_values)) fail(P3R_EINVAL, "recompose values are NULL");
+    std::vector<uint32_t> both((c.n_recompose + c.n_recompose_coeff) * D);
+    std::copy(t->recompose_values, t->recompose_values + c.n_recompose * D, both.begin());
+    std::copy(t->recompose_coeff_values, t->recompose_coeff_values + c.n_recompose_coeff * D, both.begin() + c.n_recompose * D);
+    d->recompose_values = upload_mont<PP>(ctx, both.data(), both.size(), "recompose_values");
+  }
   if (!L->has_p2) return d;
   // Poseidon2 rows padded with fillers: new_start = true, zero state (poseidon2.rs:1125-1140)
   const size_t h = L->h_p2, n = c.n_p2;
@@ -455,17 +477,17 @@ std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, con
 // K1 + K2 + K3: the main-trace matrices, indexed by table 0..4 (absent tables stay null).
 template <class PP>
 std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t) {
-  std::vector<std::unique_ptr<p3r_dmat>> m(5);
+  std::vector<std::unique_ptr<p3r_dmat>> m(6);
   const int D = (int)ctx->cfg.ext_degree;
-  auto flat = [&](const DevBuf& src, size_t n_ops, size_t h, int w, int per_op) {
+  auto flat = [&](const uint32_t* src, size_t n_ops, size_t h, int w, int per_op) {
     auto out = dmat_alloc(h, (size_t)w);
     ProfScope ps(ctx, "trace_to_matrix");
-    hipLaunchKernelGGL(k_flat_to_colmajor<PP>, dim3(blocks_for(h * w)), dim3(kBlock), 0, ctx->stream, src.p,
+    hipLaunchKernelGGL(k_flat_to_colmajor<PP>, dim3(blocks_for(h * w)), dim3(kBlock), 0, ctx->stream, src,
                        n_ops * per_op, out->d, h, w);
     return out;
   };
-  m[0] = flat(t->const_values, t->n_const, L->h_const, D, D);
-  m[1] = flat(t->public_values, t->n_public, L->h_public, (int)L->public_lanes * D, D);
+  m[0] = flat(t->const_values.p, t->n_const, L->h_const, D, D);
+  m[1] = flat(t->public_values.p, t->n_public, L->h_public, (int)L->public_lanes * D, D);
   {
     const int lanes = (int)L->alu_lanes, k = (int)L->horner_k;
     const int width = (lanes * 4 + (k - 1) / 2 + 2 * (k - 1) + 1) * D;
@@ -481,7 +503,10 @@ std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r
   }
   if (L->has_p2) m[3] = trace_fill<PP>(ctx, t->p2.get());
   if (L->has_recompose)
-    m[4] = flat(t->recompose_values, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * D, D);
+    m[4] = flat(t->recompose_values.p, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * D, D);
+  if (L->has_recompose_coeff)
+    m[5] = flat(t->recompose_values.p + t->n_recompose * (size_t)D, t->n_recompose_coeff, L->h_recompose_coeff,
+                (int)L->recompose_lanes * D, D);
   P3R_HIP(hipGetLastError());
   return m;
 }
@@ -490,9 +515,9 @@ template <class PP>
 std::vector<uint8_t> prove_all_tables(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, bool canonical) {
   prof_stage(ctx, "build_traces");
   auto mains = build_main_traces<PP>(ctx, L, t);
-  const p3r_dmat* ptrs[5];
+  const p3r_dmat* ptrs[6];
   size_t n = 0;
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 6; ++i)
     if (mains[i]) ptrs[n++] = mains[i].get();
   return prove_batch_any<PP>(ctx, L->prep.get(), ptrs, n, canonical);
 }

@@ -1196,6 +1196,11 @@ int p3r_layer_table_heights(const p3r_layer* L, size_t h[5]) {
   h[0] = L->h_const; h[1] = L->h_public; h[2] = L->h_alu; h[3] = L->h_p2; h[4] = L->h_recompose;
   return P3R_OK;
 }
+int p3r_layer_recompose_coeff_height(const p3r_layer* L, size_t* h) {
+  if (!L || !h) return P3R_EINVAL;
+  *h = L->h_recompose_coeff;
+  return P3R_OK;
+}
 int p3r_layer_effective_lanes(const p3r_layer* L, uint32_t* public_lanes, uint32_t* alu_lanes) {
   if (!L || !public_lanes || !alu_lanes) return P3R_EINVAL;
   *public_lanes = L->public_lanes;
@@ -1237,7 +1242,7 @@ p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const
                                      uint32_t table) {
   p3r_dmat* out = nullptr;
   guard(ctx, [&] {
-    if (!layer || !traces || table > 4) fail(P3R_EINVAL, "bad arguments");
+    if (!layer || !traces || table > 5) fail(P3R_EINVAL, "bad arguments");
     if (layer->slot_of((int)table) < 0) fail(P3R_EINVAL, "table %u has no rows and is not part of the batch", table);
     auto m = P3R_FIELD_CALL(ctx, build_main_traces, ctx, layer, traces);
     P3R_HIP(hipStreamSynchronize(ctx->stream));

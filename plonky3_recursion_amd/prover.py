@@ -66,7 +66,9 @@ class Traces:
     p2_merkle_path: np.ndarray
     p2_mmcs_bit: np.ndarray
     p2_mmcs_index_sum: np.ndarray   # (n_p2,)
-    recompose_values: np.ndarray    # (n_recompose, 4)
+    recompose_values: np.ndarray    # (n_recompose, D)
+    # rows of the second Recompose table (`recompose/coeff` next to `recompose`; include/p3r.h, ABI version 5)
+    recompose_coeff_values: Optional[np.ndarray] = None   # (n_recompose_coeff, D)
 
 
 @dataclass
@@ -87,6 +89,9 @@ class CircuitPrep:
     p2_absorb_len: Optional[np.ndarray] = None   # (n_p2,) sponge length tags of compact-D1 rows (None: zeros)
     # the "recompose/coeff" table (per-coefficient bus tuples): recompose_prep is (n_recompose, 2 + 2 D)
     recompose_coeff_lookups: bool = False
+    # a layer holding BOTH Recompose tables (recompose_table_provers(lanes, true), batch_stark_prover.rs:1914-1932):
+    # recompose_prep is then the plain kind and this is the `recompose/coeff` table, (n, 2 + 2 D)
+    recompose_coeff_prep: Optional[np.ndarray] = None
 
 
 class CircuitProverData:
@@ -120,6 +125,12 @@ class CircuitProverData:
         d.counts.n_recompose = rec.size // rec_w
         d.recompose_coeff_lookups = 1 if prep.recompose_coeff_lookups else 0
         self.recompose_coeff_lookups = bool(prep.recompose_coeff_lookups)
+        rec2 = np.zeros(0, np.uint32) if prep.recompose_coeff_prep is None else np.asarray(prep.recompose_coeff_prep)
+        if rec2.size % (2 + 2 * ctx.ext_degree):
+            raise P3rError(-1, "recompose_coeff_prep must be (n, %d)" % (2 + 2 * ctx.ext_degree))
+        d.counts.n_recompose_coeff = rec2.size // (2 + 2 * ctx.ext_degree)
+        if d.counts.n_recompose_coeff:
+            d.recompose_coeff_prep = p32(rec2)
         d.public_lanes, d.alu_lanes = packing.public_lanes, packing.alu_lanes
         d.horner_packed_steps, d.recompose_lanes = packing.horner_packed_steps, packing.recompose_lanes
         d.min_trace_height = packing.min_trace_height
@@ -139,7 +150,8 @@ class CircuitProverData:
                 raise P3rError(-1, "p2_absorb_len must hold one entry per Poseidon2 row")
             d.p2_absorb_len = p8(prep.p2_absorb_len)
         self.rows = dict(const=d.counts.n_const, public=d.counts.n_public, alu=d.counts.n_alu,
-                         poseidon2=d.counts.n_p2, recompose=d.counts.n_recompose)
+                         poseidon2=d.counts.n_p2, recompose=d.counts.n_recompose,
+                         recompose_coeff=d.counts.n_recompose_coeff)
         self.preprocessed_commitment = np.empty((1 << ctx.cap_height, 8), dtype=np.uint32)
         self.h = ctx.ptr(ctx.lib.p3r_layer_create(ctx.h, C.byref(d),
                                                   self.preprocessed_commitment.ctypes.data_as(_lib.u32p)))
@@ -161,6 +173,9 @@ class CircuitProverData:
         hs = (C.c_size_t * 5)()
         ctx.check(ctx.lib.p3r_layer_table_heights(self.h, hs))
         self.table_heights = [int(x) for x in hs]   # 0 = table absent from the batch
+        h5 = C.c_size_t()
+        ctx.check(ctx.lib.p3r_layer_recompose_coeff_height(self.h, C.byref(h5)))
+        self.recompose_coeff_height = int(h5.value)   # the second Recompose table (0 = absent)
         pl, al = C.c_uint32(), C.c_uint32()
         ctx.check(ctx.lib.p3r_layer_effective_lanes(self.h, C.byref(pl), C.byref(al)))
         # reduce_lanes_if_dummy (batch_stark_prover.rs:1305-1318): what the proof records (:1617-1622)
@@ -180,7 +195,8 @@ class CircuitProverData:
 
 TRACES_ARRAYS = dict(const_values=(0, "const", 4), public_values=(1, "public", 4), alu_values=(2, "alu", 16),
                      p2_input_values=(3, "poseidon2", 16), p2_flags=(4, "poseidon2", 3),
-                     p2_mmcs_index_sum=(5, "poseidon2", 1), recompose_values=(6, "recompose", 4))
+                     p2_mmcs_index_sum=(5, "poseidon2", 1), recompose_values=(6, "recompose", 4),
+                     recompose_coeff_values=(7, "recompose_coeff", 4))
 
 
 class ResidentTraces:
@@ -200,9 +216,9 @@ class ResidentTraces:
     def download(self, name: str) -> np.ndarray:
         """One array of the device-resident Traces, canonical (see TRACES_ARRAYS)."""
         which, table, width = TRACES_ARRAYS[name]
-        if table in ("const", "public", "alu", "recompose"):
+        if table in ("const", "public", "alu", "recompose", "recompose_coeff"):
             width = width // 4 * self.ctx.ext_degree
-        out = np.empty((self.cpd.rows[table], width), dtype=np.uint32)
+        out = np.empty((self.cpd.rows.get(table, 0), width), dtype=np.uint32)
         self.ctx.check(self.ctx.lib.p3r_dtraces_get(self.ctx.h, self.cpd.h, self.h, which,
                                                     out.ctypes.data_as(_lib.u32p), out.size))
         return out
@@ -248,6 +264,13 @@ def _traces_struct(tr: Traces, ext_degree=4):
     x, t.p2.mmcs_index_sum = p32(tr.p2_mmcs_index_sum)
     x, t.recompose_values = p32(tr.recompose_values)
     t.n_recompose = x.shape[0]
+    rc = getattr(tr, "recompose_coeff_values", None)
+    if rc is not None and np.asarray(rc).size:
+        rc = np.asarray(rc)
+        if rc.ndim != 2 or rc.shape[1] != ext_degree:
+            raise P3rError(-1, "recompose_coeff_values must have shape (n, %d), got %r" % (ext_degree, rc.shape))
+        x, t.recompose_coeff_values = p32(rc)
+        t.n_recompose_coeff = x.shape[0]
     return t, keep
 
 
@@ -479,10 +502,12 @@ class BatchStarkProver:
         # circuit/src/ops/npo.rs:38, poseidon2_perm/config.rs:413-427: the D4 table, or the compact-D1 one of a D = 5 circuit
         p2_name = "poseidon2_perm/%s_%s_w16" % (ctx.field.replace("-", "_"), "d4" if ctx.ext_degree == 4 else "d1")   # D = 1, 5: D1
         k = tp.horner_packed_steps
-        present = [h > 0 for h in cpd.table_heights]
+        heights = list(cpd.table_heights) + [getattr(cpd, "recompose_coeff_height", 0)]   # + the second Recompose table
+        present = [h > 0 for h in heights]
         coeff = getattr(cpd, "recompose_coeff_lookups", False)
         prep_widths = (2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24 if ctx.ext_degree == 4 else 62,
-                       (2 + (2 * ctx.ext_degree if coeff else 0)) * tp.recompose_lanes)
+                       (2 + (2 * ctx.ext_degree if coeff else 0)) * tp.recompose_lanes,
+                       (2 + 2 * ctx.ext_degree) * tp.recompose_lanes)
         # non-primitive tables without rows are not proved (poseidon2.rs:1089-1092, recompose.rs:77-80)
         npo = []
         if present[3]:
@@ -493,6 +518,10 @@ class BatchStarkProver:
             # circuit/src/ops/npo.rs:48-60: "recompose", or "recompose/coeff" for the per-coefficient variant
             npo.append(NonPrimitiveTableEntry(op_type="recompose/coeff" if coeff else "recompose",
                                               rows=cpd.rows["recompose"], lanes=tp.recompose_lanes))
+        if present[5]:
+            # both table provers are registered: `recompose`, then `recompose/coeff` (batch_stark_prover.rs:1924-1928)
+            npo.append(NonPrimitiveTableEntry(op_type="recompose/coeff", rows=cpd.rows["recompose_coeff"],
+                                              lanes=tp.recompose_lanes))
         return BatchStarkProof(
             proof=raw, table_packing=tp,
             rows=(cpd.rows["const"], cpd.rows["public"], cpd.rows["alu"]),
@@ -502,7 +531,7 @@ class BatchStarkProver:
             non_primitives=tuple(npo),
             preprocessed_commitment=cpd.preprocessed_commitment,
             preprocessed_widths=tuple(w for w, ok in zip(prep_widths, present) if ok),
-            degree_bits=tuple(int(h).bit_length() - 1 for h in cpd.table_heights if h > 0),
+            degree_bits=tuple(int(h).bit_length() - 1 for h in heights if h > 0),
             monty_r=0 if canonical_field_encoding else 1, modulus=ctx.p)
 
     def verify_all_tables(self, proof: BatchStarkProof, canonical_field_encoding=None):
@@ -588,16 +617,19 @@ class PreparedCircuit:
         self.h = ctx.ptr(ctx.lib.p3r_circuit_create(ctx.h, C.byref(d), commit.ctypes.data_as(_lib.u32p)))
         cn = _lib.P3rLayerCounts()
         ctx.check(ctx.lib.p3r_circuit_counts(self.h, C.byref(cn)))
-        rows = dict(const=cn.n_const, public=cn.n_public, alu=cn.n_alu, poseidon2=cn.n_p2, recompose=cn.n_recompose)
+        rows = dict(const=cn.n_const, public=cn.n_public, alu=cn.n_alu, poseidon2=cn.n_p2, recompose=cn.n_recompose,
+                    recompose_coeff=cn.n_recompose_coeff)
         lv = C.c_size_t()
         ctx.check(ctx.lib.p3r_circuit_levels(self.h, C.byref(lv)))
         self.levels = lv.value
         self.prepared_on_device = bool(ctx.lib.p3r_circuit_prepared_on_device(self.h))
         self._cpd_args = (ctx.lib.p3r_circuit_layer(self.h), packing, rows, commit)
         self._cpd_view = None
-        # Recompose ops of the "recompose/coeff" kind (aux = 1; include/p3r.h): the table the proof names
+        # Recompose ops of the "recompose/coeff" kind (aux = 1; include/p3r.h): the layer's one Recompose table when
+        # every Recompose op is of that kind, its second table next to `recompose` otherwise
         o2 = ops.reshape(-1, 8)
-        self.recompose_coeff_lookups = bool(np.any((o2[:, 0] == 10) & (o2[:, 5] == 1)))
+        rec = o2[o2[:, 0] == 10]
+        self.recompose_coeff_lookups = bool(len(rec)) and bool(np.all(rec[:, 5] == 1))
 
     @property
     def circuit_prover_data(self) -> CircuitProverData:

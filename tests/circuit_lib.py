@@ -11,9 +11,10 @@ NO_W = 0xFFFFFFFF
 (OP_CONST, OP_PUBLIC, OP_ADD, OP_MUL, OP_BOOL, OP_MULADD, OP_HORNER, OP_HINT_EXT, OP_HINT_BIN, OP_P2,
  OP_RECOMPOSE) = range(11)
 
-PREP_ARRAYS = ["const_prep", "public_prep", "alu_prep13", "recompose_prep", "p2_in_ctl", "p2_input_indices",
+PREP_ARRAYS = ["const_prep", "public_prep", "alu_prep13", "recompose_prep", "recompose_coeff_prep", "p2_in_ctl", "p2_input_indices",
                "p2_out_ctl", "p2_output_indices", "p2_mmcs_index_sum_idx"]
-RUN_ARRAYS = ["const_values", "public_values", "alu_values", "p2_inputs", "p2_mmcs_index_sum", "recompose_values"]
+RUN_ARRAYS = ["const_values", "public_values", "alu_values", "p2_inputs", "p2_mmcs_index_sum", "recompose_values",
+              "recompose_coeff_values"]
 
 
 class OrcCircuitDesc(C.Structure):
@@ -99,7 +100,7 @@ class OracleCircuit:
         assert np.array_equal(pf[:, :2], rf[:, :2])
         out["p2_flags"] = rf.reshape(-1)
         n = [len(out["const_values"]) // 4, len(out["public_values"]) // 4, len(out["alu_values"]) // 16,
-             len(rf), len(out["recompose_values"]) // 4, self.circuit.witness_count]
+             len(rf), len(out["recompose_values"]) // 4, self.circuit.witness_count, len(out["recompose_coeff_values"]) // 4]
         out["counts"] = np.array(n, dtype=np.uint32)
         return out
 

@@ -17,6 +17,8 @@ def traces_from_arrays(a, ext_degree=4) -> Traces:
         p2_mmcs_bit=fl[:, 2].astype(np.uint8),
         p2_mmcs_index_sum=a["p2_mmcs_index_sum"],
         recompose_values=a["recompose_values"].reshape(-1, d),
+        # RECOMPOSE_BOTH: the rows of the second Recompose table (`recompose/coeff`)
+        recompose_coeff_values=a["recompose_coeff_values"].reshape(-1, d) if len(a.get("recompose_coeff_values", ())) else None,
     )
 
 
@@ -38,6 +40,7 @@ def circuit_prep_from_arrays(a, ext_degree=4, recompose_coeff_lookups=False) -> 
         p2_output_indices=a["p2_output_indices"].reshape(-1, ol),
         p2_mmcs_index_sum_idx=a["p2_mmcs_index_sum_idx"],
         p2_absorb_len=a["p2_absorb_len"].astype(np.uint8) if ext_degree != 4 and "p2_absorb_len" in a else None,
+        recompose_coeff_prep=a["recompose_coeff_prep"].reshape(-1, 2 + 2 * ext_degree) if len(a.get("recompose_coeff_prep", ())) else None,
     )
 
 

@@ -16,7 +16,7 @@ ARRAYS = ["const_values", "const_prep", "public_values", "public_prep", "alu_val
           "p2_output_indices", "p2_mmcs_index_sum_idx", "recompose_values", "recompose_prep", "counts",
           # the circuit the arrays above were derived from (flattened Circuit<EF>, include/p3r.h) and its inputs
           "ops", "ext", "public_rows", "in_public_values", "private_rows", "in_private_values", "pd_op_ids",
-          "pd_siblings", "rewrite", "p2_absorb_len"]
+          "pd_siblings", "rewrite", "p2_absorb_len", "recompose_coeff_values", "recompose_coeff_prep"]
 
 
 def build():
@@ -27,6 +27,9 @@ def build():
 
 
 NO_POSEIDON2, NO_RECOMPOSE, SINGLE_PUBLIC, NO_ALU, INDEPENDENT_SPONGES, RECOMPOSE_COEFF = 1, 2, 4, 8, 16, 32
+# both Recompose tables in one layer: each op is `recompose` or `recompose/coeff` (arrays recompose_* and recompose_coeff_*;
+# counts[6] = rows of the second table) - what a backend with coefficient lookups registers (batch_stark_prover.rs:1914-1932)
+RECOMPOSE_BOTH = 64
 
 
 def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None,

@@ -21,6 +21,7 @@ class OrcWorkload(C.Structure):
         ("public_lanes", C.c_uint32), ("alu_lanes", C.c_uint32), ("horner_packed_steps", C.c_uint32),
         ("recompose_lanes", C.c_uint32), ("min_trace_height", C.c_uint32), ("ext_degree", C.c_uint32),
         ("p2_absorb_len", u32p), ("recompose_coeff_lookups", C.c_uint32), ("ext_w", C.c_uint32),
+        ("n_recompose_coeff", C.c_size_t), ("recompose_coeff_values", u32p), ("recompose_coeff_prep", u32p),
     ]
 
 
@@ -74,6 +75,11 @@ def fill_workload(wl_struct, arrays, packing, keep):
     wl_struct.ext_w = packing.get("ext_w", 0)
     if "p2_absorb_len" in arrays and len(arrays["p2_absorb_len"]):
         wl_struct.p2_absorb_len = ptr("p2_absorb_len")
+    # a layer with both Recompose tables (harness flag RECOMPOSE_BOTH): the second one is `recompose/coeff`
+    if len(c) > 6 and int(c[6]):
+        wl_struct.n_recompose_coeff = int(c[6])
+        wl_struct.recompose_coeff_values = ptr("recompose_coeff_values")
+        wl_struct.recompose_coeff_prep = ptr("recompose_coeff_prep")
 
 
 def oracle_verify_statement(orc, field, prm, airs, prep_cap, proof_bytes, rc=None, field_encoding=0):

@@ -56,7 +56,8 @@ def test_runner_matches_reference_unit_tests(oracle, case):
 
 
 SHAPES = [0, harness_lib.NO_POSEIDON2, harness_lib.NO_RECOMPOSE, harness_lib.RECOMPOSE_COEFF,
-          harness_lib.RECOMPOSE_COEFF | harness_lib.NO_POSEIDON2,
+          harness_lib.RECOMPOSE_COEFF | harness_lib.NO_POSEIDON2, harness_lib.RECOMPOSE_BOTH,
+          harness_lib.RECOMPOSE_BOTH | harness_lib.NO_POSEIDON2,
           harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC,
           harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU]
 
@@ -76,7 +77,7 @@ def test_circuit_path_reproduces_harness_bookkeeping(oracle, field, flags):
         assert len(a["private_rows"]) and len(a["rewrite"]) and (a["p2_out_ctl"] == oracle_lib.MODULUS[field] - 1).any()
 
 
-@pytest.mark.parametrize("flags", [0, harness_lib.RECOMPOSE_COEFF])
+@pytest.mark.parametrize("flags", [0, harness_lib.RECOMPOSE_COEFF, harness_lib.RECOMPOSE_BOTH])
 def test_circuit_path_proof_verifies(oracle, flags):
     """Traces + preprocessed columns derived from the circuit prove and verify (LogUp balanced
     under the reference's creator / reader multiplicity rules, every AIR satisfied).  RECOMPOSE_COEFF: the Recompose
@@ -92,7 +93,13 @@ def test_circuit_path_proof_verifies(oracle, flags):
     if coeff:
         rp = w["recompose_prep"].reshape(-1, 10)
         assert (rp[:, 3::2] > 0).any() and (rp[:, 1] == oracle_lib.MODULUS[field] - 1).any()   # owned coefficients that are read; outputs connected back
+    if flags & harness_lib.RECOMPOSE_BOTH:
+        # both Recompose tables (recompose_table_provers(lanes, true)): `recompose`, then `recompose/coeff`
+        assert w["counts"][4] and w["counts"][6]
     L = layer_lib.OracleLayer(oracle, field, w, prm, packing=dict(recompose_coeff_lookups=coeff))
+    if flags & harness_lib.RECOMPOSE_BOTH:
+        t = L.tables()
+        assert [x["kind"] for x in t[-2:]] == ["recompose", "recompose"] and t[-2]["prep"].shape[1] == 2 and t[-1]["prep"].shape[1] == 10
     L.verify(L.prove())
 
 

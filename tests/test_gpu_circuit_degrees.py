@@ -52,6 +52,13 @@ CASES = [("koala-bear", 5, 7, NO_P2 | harness_lib.NO_RECOMPOSE, None),
          ("koala-bear", 5, 10, harness_lib.RECOMPOSE_COEFF, dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3, recompose_lanes=2)),
          ("baby-bear", 1, 8, harness_lib.RECOMPOSE_COEFF, None),
          ("koala-bear", 5, 7, harness_lib.RECOMPOSE_COEFF | NO_P2, None),
+         # both kinds in one circuit: two Recompose tables, `recompose` then `recompose/coeff` (what a verifier circuit
+         # of the D = 5 backend holds: plain recomposition in the challenger, the coefficient kind for decomposition links)
+         ("koala-bear", 5, 8, harness_lib.RECOMPOSE_BOTH, None),
+         ("koala-bear", 5, 10, harness_lib.RECOMPOSE_BOTH, dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3, recompose_lanes=2)),
+         ("baby-bear", 1, 8, harness_lib.RECOMPOSE_BOTH, None),
+         ("koala-bear", 4, 8, harness_lib.RECOMPOSE_BOTH, None),
+         ("baby-bear", 4, 7, harness_lib.RECOMPOSE_BOTH | NO_P2, None),
          # wide levels, long Horner chains (the workgroup scan), deep Merkle paths
          ("koala-bear", 5, 13, 0, None)]
 
@@ -71,6 +78,10 @@ def test_device_runner_for_base_field_and_quintic_circuits(oracle, field, ext_de
     got = res.download("alu_values")
     assert np.array_equal(got.reshape(-1), a["alu_values"]), np.argwhere(got.reshape(-1) != a["alu_values"])[:4]
     assert np.array_equal(res.download("recompose_values").reshape(-1), a["recompose_values"])
+    both = bool(flags & harness_lib.RECOMPOSE_BOTH)
+    if both:
+        assert pc.circuit_prover_data.rows["recompose_coeff"] == int(a["counts"][6]) > 0
+        assert np.array_equal(res.download("recompose_coeff_values").reshape(-1), a["recompose_coeff_values"])
     if a["counts"][3]:
         assert np.array_equal(res.download("p2_input_values").reshape(-1), a["p2_inputs"])
         assert np.array_equal(res.download("p2_flags"), a["p2_flags"].reshape(-1, 4)[:, :3])
@@ -84,7 +95,13 @@ def test_device_runner_for_base_field_and_quintic_circuits(oracle, field, ext_de
     proof = L.prove()
     assert out.proof.proof == proof and pc.prove(inputs) == proof
     assert out.proof.ext_degree == ext_degree and out.proof.alu_quintic_trinomial == (ext_degree == 5)
-    if a["counts"][4]:
+    if both:
+        assert [e.op_type for e in out.proof.non_primitives[-2:]] == ["recompose", "recompose/coeff"]
+        assert [e.rows for e in out.proof.non_primitives[-2:]] == [int(a["counts"][4]), int(a["counts"][6])]
+        back = p3r.BatchStarkProof.from_postcard(out.proof.to_postcard(), field)
+        assert back.to_postcard() == out.proof.to_postcard()
+        cache.prover.verify_all_tables(back)
+    elif a["counts"][4]:
         assert out.proof.non_primitives[-1].op_type == ("recompose/coeff" if coeff else "recompose")
     cache.prover.verify_all_tables(out.proof)
     res.free()

@@ -192,3 +192,43 @@ def test_recompose_coeff_variant_under_degree_four(oracle):
     cache.prover.verify_all_tables(pv.BatchStarkProof.from_postcard(proof.to_postcard(), "koala-bear"))
     cpd.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("ext_degree", [5, 4, 1])
+@pytest.mark.parametrize("log_h,kw,packing", CASES[:3])
+def test_layer_with_both_recompose_tables(oracle, log_h, kw, packing, ext_degree):
+    """`recompose` and `recompose/coeff` in one layer (recompose_table_provers(lanes, true), batch_stark_prover.rs:
+    1914-1932): six tables at the prove_all_tables boundary - matrices, commitment, proof bytes, metadata."""
+    from plonky3_recursion_amd import prover as pv
+    arrs, L, ctx, cache, traces = setup(oracle, log_h, kw, packing, flags=harness_lib.RECOMPOSE_BOTH, ext_degree=ext_degree)
+    tables = L.tables()
+    cpd = cache.circuit_prover_data
+    assert [t["kind"] for t in tables] == ["const", "public", "alu", "poseidon2", "recompose", "recompose"]
+    assert cpd.rows["recompose"] == int(arrs["counts"][4]) and cpd.rows["recompose_coeff"] == int(arrs["counts"][6]) > 0
+    assert cpd.table_heights + [cpd.recompose_coeff_height] == [t["main"].shape[0] for t in tables]
+    assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
+    res = pv.ResidentTraces(ctx, cpd, traces)
+    for i, t in enumerate(tables):
+        got = cache.prover.build_main_trace(res, cpd, i).download()
+        assert np.array_equal(got, t["main"]), (i, t["kind"])
+    want = L.prove()
+    p = cache.prover.prove_all_tables(res, cpd)
+    assert p.proof == want
+    assert cache.prover.prove_all_tables(traces, cpd, canonical_field_encoding=True).proof == L.prove(field_encoding=1)
+    assert [e.op_type for e in p.non_primitives[-2:]] == ["recompose", "recompose/coeff"]
+    cache.prover.verify_all_tables(p)
+    back = pv.BatchStarkProof.from_postcard(p.to_postcard(), "koala-bear")
+    assert back.to_postcard() == p.to_postcard()
+    cache.prover.verify_all_tables(back)
+    L.verify(p.proof)
+    # a second table next to one that already is the coefficient kind is refused
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    prep = wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree)
+    prep.recompose_coeff_lookups = True
+    prep.recompose_prep = np.zeros((len(prep.recompose_prep), 2 + 2 * ext_degree), np.uint32)
+    with pytest.raises(p3r.P3rError, match="plain kind"):
+        pv.CircuitProverData(ctx, prep, cpd.packing)
+    res.free()
+    cpd.free()
+    ctx.close()
