@@ -910,15 +910,15 @@ def main():
             ctx0.close()
         if not args.no_quintic and world == 1 and field == "koala-bear":
             # SURVEY 8(f).4, D = 5: the table mix FriRecursionBackendD5 registers (backend/fri.rs:741-852) - Const, Public,
-            # ALU over the quintic trinomial extension, compact-D1 Poseidon2, Recompose with coefficient lookups - at the
+            # ALU over the quintic trinomial extension, compact-D1 Poseidon2, Recompose and Recompose with coefficient lookups - at the
             # prove_all_tables boundary with Traces resident in HBM, same height, same FRI parameters, proof verified.
             if resident is not None:
                 resident.free()
                 pc.free()
                 resident = pc = None
-            arrs5 = harness_lib.generate(field, log_h, seed=0x5EED0005, flags=harness_lib.RECOMPOSE_COEFF, ext_degree=5, **GEN_KNOBS)
+            arrs5 = harness_lib.generate(field, log_h, seed=0x5EED0005, flags=harness_lib.RECOMPOSE_BOTH, ext_degree=5, **GEN_KNOBS)
             counts5 = [int(x) for x in arrs5["counts"]]
-            prep5 = wl.circuit_prep_from_arrays(arrs5, ext_degree=5, recompose_coeff_lookups=True)
+            prep5 = wl.circuit_prep_from_arrays(arrs5, ext_degree=5)   # both Recompose tables: `recompose`, `recompose/coeff`
             traces5 = wl.traces_from_arrays(arrs5, ext_degree=5)
             circ5, hin5 = wl.circuit_from_arrays(arrs5), wl.circuit_inputs_from_arrays(arrs5, 5)
             del arrs5
@@ -951,12 +951,12 @@ def main():
                 line[key] = {
                     "ms_per_step": ms5, "steps": 3, "proof_verified": ok5, "proof_bytes": len(proof5.proof),
                     "ext_degree": 5, "challenge_degree": dc, "tables": [e.op_type for e in proof5.non_primitives],
-                    "table_heights": cpd5.table_heights,
-                    "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose"], counts5)),
+                    "table_heights": cpd5.table_heights + [cpd5.recompose_coeff_height],
+                    "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose", "witnesses", "recompose/coeff"], counts5)),
                     "kernel_ms": {k: v[0] for k, v in prof5.items() if not k.startswith("stage:")},
                     "workload": f"prove_all_tables (Traces resident in HBM) of the synthetic {field} 2^{log_h}-row D = 5 layer: "
-                                f"const / public / alu over F[x]/(x^5 + x^2 - 1) / compact-D1 poseidon2 / recompose with "
-                                f"coefficient lookups, " + ("the D = 4 STARK configuration" if dc == 4 else
+                                f"const / public / alu over F[x]/(x^5 + x^2 - 1) / compact-D1 poseidon2 / recompose / recompose with "
+                                f"coefficient lookups (the six tables a verifier circuit of FriRecursionBackendD5 fills), " + ("the D = 4 STARK configuration" if dc == 4 else
                                 "the quintic STARK configuration (Challenge = F[x]/(x^5 + x^2 - 1))") + ", same FRI parameters"}
                 proof_verified = proof_verified and ok5
                 line["proof_verified"] = proof_verified

@@ -92,13 +92,19 @@ def one(oracle, seed, max_log_h, min_log_h=5):
                              harness_lib.RECOMPOSE_COEFF])
     elif rng2.random() < 0.15:
         flags = harness_lib.RECOMPOSE_COEFF
+    # third stream: both Recompose tables in one layer (any degree), and KoalaBear's quintic CHALLENGE field
+    rng3 = random.Random(seed * 104729 + 2)
+    if not (flags & harness_lib.NO_RECOMPOSE) and rng3.random() < 0.3:
+        flags = (flags & ~harness_lib.RECOMPOSE_COEFF) | harness_lib.RECOMPOSE_BOTH
+    challenge_degree = 5 if field == "koala-bear" and rng3.random() < 0.3 else 4
+    kw["challenge_degree"] = challenge_degree
     coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
     arrs = harness_lib.generate(field, log_h, seed=seed, flags=flags, ext_degree=ext_degree, **gen)
     packing_o = dict(packing, ext_degree=ext_degree, recompose_coeff_lookups=int(coeff))
     if kw.get("fri_log_arities") == "fitting":
         kw["fri_log_arities"] = fitting_schedule(rng, oracle, field, arrs, kw, packing_o)
     prm = layer_lib.params(**kw)
-    desc = f"seed {seed}: {field} D={ext_degree} flags={flags} 2^{log_h} {kw} {packing} {gen}"
+    desc = f"seed {seed}: {field} D={ext_degree} DC={challenge_degree} flags={flags} 2^{log_h} {kw} {packing} {gen}"
     L = layer_lib.OracleLayer(oracle, field, arrs, prm, packing=dict(packing_o))
     try:
         want_cap, want = L.prep_commit(), L.prove()
