@@ -354,7 +354,7 @@ int p3r_prove_all_tables(p3r_ctx* ctx, const p3r_layer* layer, const p3r_traces*
                          uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
 int p3r_prove_all_tables_resident(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
                                   uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
-/* K1-K3 only: the main trace of table `table` (0..4) as a device matrix (parity tests). */
+/* K1-K3 only: the main trace of table `table` (0..4; 5 = the second Recompose table) as a device matrix (parity tests). */
 p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
                                      uint32_t table);
 
@@ -500,7 +500,7 @@ p3r_circuit* p3r_circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* desc, uint
 void p3r_circuit_free(p3r_ctx* ctx, p3r_circuit* circuit);
 /* The CircuitProverData the circuit was prepared into (owned by the circuit). */
 const p3r_layer* p3r_circuit_layer(const p3r_circuit* circuit);
-/* Op counts of the five tables, i.e. the sizes of the arrays p3r_dtraces_get returns. */
+/* Op counts of the tables (five, or six with a second Recompose table), i.e. the sizes of the arrays p3r_dtraces_get returns. */
 int p3r_circuit_counts(const p3r_circuit* circuit, p3r_layer_desc_counts* out);
 /* Levels of the execution schedule (ops of one level have no dependencies on each other). */
 int p3r_circuit_levels(const p3r_circuit* circuit, size_t* n_levels);
