@@ -341,6 +341,9 @@ void p3r_layer_free(p3r_ctx* ctx, p3r_layer* layer);
 int p3r_layer_table_heights(const p3r_layer* layer, size_t heights_out[5]);
 /* Padded height of the second Recompose table (`recompose/coeff` next to `recompose`, ABI version 5); 0 = absent. */
 int p3r_layer_recompose_coeff_height(const p3r_layer* layer, size_t* height_out);
+/* 1: the table at position 4 is the `recompose/coeff` kind (p3r_layer_desc.recompose_coeff_lookups, or a circuit whose
+ * Recompose ops all carry aux = 1) - the name the proof's metadata gives it. */
+int p3r_layer_recompose_kind(const p3r_layer* layer, uint32_t* coeff_lookups_out);
 /* The packing the proof was made with: Public / ALU lanes fall back to 1 when the table holds at
  * most the dummy op (reduce_lanes_if_dummy, batch_stark_prover.rs:1305-1318); BatchStarkProof
  * stores this effective packing (:1617-1622). */

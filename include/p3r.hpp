@@ -162,7 +162,6 @@ class CircuitProverData {
     if (prep.recompose_prep.size() % rec_w) throw Error(P3R_EINVAL, "recompose_prep must be n x " + std::to_string(rec_w));
     d.counts.n_recompose = prep.recompose_prep.size() / rec_w;
     d.recompose_coeff_lookups = prep.recompose_coeff_lookups;
-    recompose_coeff_lookups = prep.recompose_coeff_lookups;
     const size_t rec2_w = 2 + 2 * ctx.ext_degree();
     if (prep.recompose_coeff_prep.size() % rec2_w) throw Error(P3R_EINVAL, "recompose_coeff_prep must be n x " + std::to_string(rec2_w));
     d.counts.n_recompose_coeff = prep.recompose_coeff_prep.size() / rec2_w;
@@ -210,6 +209,9 @@ class CircuitProverData {
   void read_shape() {
     ctx_->check(p3r_layer_table_heights(layer_, table_heights.data()));
     ctx_->check(p3r_layer_recompose_coeff_height(layer_, &recompose_coeff_height));
+    uint32_t kind = 0;
+    ctx_->check(p3r_layer_recompose_kind(layer_, &kind));
+    recompose_coeff_lookups = kind != 0;   // the table at position 4 is `recompose/coeff`
     effective_ = packing_;
     ctx_->check(p3r_layer_effective_lanes(layer_, &effective_.public_lanes, &effective_.alu_lanes));
   }
@@ -435,12 +437,6 @@ class PreparedCircuit {
     ctx.check(p3r_circuit_counts(h_, &counts));
     ctx.check(p3r_circuit_levels(h_, &levels_));
     cpd_ = std::make_unique<CircuitProverData>(ctx, p3r_circuit_layer(h_), packing, counts, std::move(commit));
-    // Recompose ops of the "recompose/coeff" kind (aux = 1): the layer's one Recompose table when every Recompose op
-    // is of that kind, its second table next to `recompose` otherwise
-    bool any_rec = false, all_coeff = true;
-    for (const p3r_op& op : circuit_.ops)
-      if (op.kind == P3R_OP_RECOMPOSE) { any_rec = true; all_coeff = all_coeff && op.aux == 1u; }
-    cpd_->recompose_coeff_lookups = any_rec && all_coeff;
   }
   ~PreparedCircuit() { cpd_.reset(); if (h_) p3r_circuit_free(ctx_->raw(), h_); }
   PreparedCircuit(const PreparedCircuit&) = delete;

@@ -187,6 +187,7 @@ SIGNATURES = {
     "p3r_layer_free": (None, [vp, vp]),
     "p3r_layer_table_heights": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "p3r_layer_recompose_coeff_height": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "p3r_layer_recompose_kind": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "p3r_layer_effective_lanes": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "p3r_verify_batch": (C.c_int, [C.POINTER(P3rConfig), C.POINTER(P3rAirDesc), C.c_size_t, u32p, u32p,
                                    C.POINTER(C.c_uint8), C.c_size_t, C.c_uint32, C.c_char_p, C.c_size_t]),

@@ -43,11 +43,6 @@ struct CircuitTables {
 // Recompose ops come in two kinds: "recompose" (aux = 0) and "recompose/coeff" (aux = 1:
 // NpoTypeId::recompose_with_coeff_lookups, circuit/src/ops/npo.rs:48-60).  Each kind is its own table
 // (recompose_table_provers(lanes, true), batch_stark_prover.rs:1914-1932).
-inline bool circuit_recompose_coeff(const p3r_op* ops, size_t n) {
-  for (size_t i = 0; i < n; ++i)
-    if (ops[i].kind == P3R_OP_RECOMPOSE && ops[i].aux == 1u) return true;
-  return false;
-}
 
 // Poseidon2 op layout by circuit degree: D = 4 -> four input limbs of four elements, two (or four) output limbs;
 // otherwise base mode -> sixteen one-element slots, eight (or sixteen) outputs.  ext = [in.., index_sum, bit, n_out, out..]
@@ -1134,9 +1129,8 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   // a witness nobody sets ...) goes through the host restatement below, which raises the reference's error.
   // (circuits of extension degree 1 / 5 take the host restatement: the device pass is written for D = 4)
   const uint32_t ext_d = ctx->cfg.ext_degree;
-  // (so do circuits whose Recompose ops are the coefficient-lookup kind)
-  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr || ext_d != 4 ||   // read per call: the equality tests flip it
-                         (d->ops && circuit_recompose_coeff(d->ops, d->n_ops));
+  // (so do circuits with Recompose ops of the coefficient-lookup kind: the device pass flags them)
+  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr || ext_d != 4;   // read per call: the equality tests flip it
   if (!host_prep) {
     prof_stage(ctx, "prep_device");
     DevPrep R;

@@ -1201,6 +1201,11 @@ int p3r_layer_recompose_coeff_height(const p3r_layer* L, size_t* h) {
   *h = L->h_recompose_coeff;
   return P3R_OK;
 }
+int p3r_layer_recompose_kind(const p3r_layer* L, uint32_t* coeff_lookups) {
+  if (!L || !coeff_lookups) return P3R_EINVAL;
+  *coeff_lookups = L->recompose_coeff ? 1u : 0u;
+  return P3R_OK;
+}
 int p3r_layer_effective_lanes(const p3r_layer* L, uint32_t* public_lanes, uint32_t* alu_lanes) {
   if (!L || !public_lanes || !alu_lanes) return P3R_EINVAL;
   *public_lanes = L->public_lanes;

@@ -124,7 +124,6 @@ class CircuitProverData:
             raise P3rError(-1, "recompose_prep must be (n, %d)" % rec_w)
         d.counts.n_recompose = rec.size // rec_w
         d.recompose_coeff_lookups = 1 if prep.recompose_coeff_lookups else 0
-        self.recompose_coeff_lookups = bool(prep.recompose_coeff_lookups)
         rec2 = np.zeros(0, np.uint32) if prep.recompose_coeff_prep is None else np.asarray(prep.recompose_coeff_prep)
         if rec2.size % (2 + 2 * ctx.ext_degree):
             raise P3rError(-1, "recompose_coeff_prep must be (n, %d)" % (2 + 2 * ctx.ext_degree))
@@ -176,6 +175,9 @@ class CircuitProverData:
         h5 = C.c_size_t()
         ctx.check(ctx.lib.p3r_layer_recompose_coeff_height(self.h, C.byref(h5)))
         self.recompose_coeff_height = int(h5.value)   # the second Recompose table (0 = absent)
+        kind = C.c_uint32()
+        ctx.check(ctx.lib.p3r_layer_recompose_kind(self.h, C.byref(kind)))
+        self.recompose_coeff_lookups = bool(kind.value)   # the table at position 4 is `recompose/coeff`
         pl, al = C.c_uint32(), C.c_uint32()
         ctx.check(ctx.lib.p3r_layer_effective_lanes(self.h, C.byref(pl), C.byref(al)))
         # reduce_lanes_if_dummy (batch_stark_prover.rs:1305-1318): what the proof records (:1617-1622)
@@ -625,11 +627,7 @@ class PreparedCircuit:
         self.prepared_on_device = bool(ctx.lib.p3r_circuit_prepared_on_device(self.h))
         self._cpd_args = (ctx.lib.p3r_circuit_layer(self.h), packing, rows, commit)
         self._cpd_view = None
-        # Recompose ops of the "recompose/coeff" kind (aux = 1; include/p3r.h): the layer's one Recompose table when
-        # every Recompose op is of that kind, its second table next to `recompose` otherwise
-        o2 = ops.reshape(-1, 8)
-        rec = o2[o2[:, 0] == 10]
-        self.recompose_coeff_lookups = bool(len(rec)) and bool(np.all(rec[:, 5] == 1))
+
 
     @property
     def circuit_prover_data(self) -> CircuitProverData:
@@ -642,7 +640,6 @@ class PreparedCircuit:
             if not self.h:
                 raise P3rError(-1, "the prepared circuit has been freed")
             view = CircuitProverData._borrow(self.ctx, *self._cpd_args, owner=self)
-            view.recompose_coeff_lookups = self.recompose_coeff_lookups
             self._cpd_view = weakref.ref(view)
         return view
 
