@@ -243,6 +243,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     for (size_t i = 0; i < n; ++i)
       if (p[i] >= P) fail(P3R_EINVAL, "%s[%zu] is not canonical", what, i);
   };
+  prof_stage(ctx, "prep_lc_checks");
   check(d->alu_prep13, c.n_alu * 13, "alu_prep13");
   const size_t mh = L->min_height;
   auto lanes_prep = [&](const uint32_t* prep, size_t n_ops, int per_op, int lanes, size_t& h_out) {
@@ -332,7 +333,9 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   // ALU: schedule + scheduled preprocessed trace (alu_air.rs:613-677)
   {
     const int lanes = (int)L->alu_lanes, k_max = (int)L->horner_k, pw = lanes * 13 + 7 * (k_max - 1);
+    prof_stage(ctx, "prep_lc_alu_schedule");
     HostAluSchedule S = alu_schedule(d->alu_prep13, c.n_alu, lanes, k_max);
+    prof_stage(ctx, "prep_lc_alu_matrix");
     L->alu_rows = S.rows;
     L->h_alu = padded_height(S.rows, mh);
     std::vector<uint32_t>& m = mats[2];
@@ -363,12 +366,15 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
         }
       }
     }
+    prof_stage(ctx, "prep_lc_plan_upload");
     L->alu_plan.alloc((S.entries.size() * sizeof(AluPlanEntry) + 3) / 4);
     P3R_HIP(copy_sync(ctx->stream, L->alu_plan.p, S.entries.data(), S.entries.size() * sizeof(AluPlanEntry), hipMemcpyHostToDevice));
     L->alu_prev_src.alloc(S.prev_src.size());
     P3R_HIP(copy_sync(ctx->stream, L->alu_prev_src.p, S.prev_src.data(), S.prev_src.size() * 4, hipMemcpyHostToDevice));
   }
+  prof_stage(ctx, "prep_lc_other_tables_wait");
   other_tables.get();
+  prof_stage(ctx, "prep_lc_upload_lde_commit");
   const int widths[6] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1),
                          ext_d == 4 ? 24 : kP2D1PrepWidth, (int)L->recompose_lanes * rec_plw, (int)L->recompose_lanes * rec2_plw};
   const size_t heights[6] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose, L->h_recompose_coeff};
