@@ -160,3 +160,33 @@ def test_quintic_challenge_context_is_koala_bears():
         p3r.Context(field="baby-bear", challenge_degree=5)
     with pytest.raises(p3r.P3rError, match="UnsupportedChallengeDegree"):
         p3r.Context(field="koala-bear", challenge_degree=3)
+
+
+# ---- CPU: six-table layers (`recompose` next to `recompose/coeff`) through the oracle and the native verifier ------
+@pytest.mark.parametrize("d,dc", [(5, 5), (5, 4), (4, 4), (1, 4)])
+def test_six_table_layer_oracle_and_native_verifier(oracle, d, dc):
+    """A backend with coefficient lookups registers both Recompose table provers (batch_stark_prover.rs:1914-1932);
+    the statement the native verifier rebuilds lists `recompose` before `recompose/coeff`.  Declaring the second
+    table as the plain kind, or swapping the two, is a different statement."""
+    import plonky3_recursion_amd as p3r
+    prm = layer_lib.params(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=5,
+                           challenge_degree=dc)
+    arrs = harness_lib.generate(FIELD, 7, seed=404, flags=harness_lib.RECOMPOSE_BOTH, ext_degree=d, **SMALL)
+    L = layer_lib.OracleLayer(oracle, FIELD, arrs, prm, packing=dict(ext_degree=d))
+    tables, cap = L.tables(), L.prep_commit()
+    assert [t["kind"] for t in tables[-2:]] == ["recompose", "recompose"]
+    assert tables[-2]["prep"].shape[1] == 2 and tables[-1]["prep"].shape[1] == 2 + 2 * d
+    pf = L.prove()
+    L.verify(pf)
+    cfg, keep = p3r.make_config(FIELD, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, ext_degree=d, challenge_degree=dc)
+    db = [int(t["main"].shape[0]).bit_length() - 1 for t in tables]
+
+    def airs(kinds):
+        out = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"], coeff_lookups=0) for t in tables]
+        out[-2]["coeff_lookups"], out[-1]["coeff_lookups"] = kinds
+        return out
+    p3r.verify_batch(cfg, airs((0, 1)), cap, db, pf)
+    for wrong in ((0, 0), (1, 1), (1, 0)):
+        with pytest.raises(p3r.P3rError):
+            p3r.verify_batch(cfg, airs(wrong), cap, db, pf)
