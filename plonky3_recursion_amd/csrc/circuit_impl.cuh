@@ -71,7 +71,8 @@ inline void validate_circuit(const HostCircuit& c, uint32_t D = 4) {
     if (w >= nw) fail(P3R_EINVAL, "op %zu: %s witness %u out of bounds (witness_count %u)", i, what, w, nw);
   };
   auto opt = [&](uint32_t w, size_t i, const char* what) { if (w != kNoW) wid(w, i, what); };
-  for (size_t i = 0; i < c.ops.size(); ++i) {
+  host_parallel_for(c.ops.size(), size_t(1) << 16, [&](size_t i0, size_t i1) {
+  for (size_t i = i0; i < i1; ++i) {
     const p3r_op& op = c.ops[i];
     if ((size_t)op.ext_off + op.ext_len > c.ext.size()) fail(P3R_EINVAL, "op %zu: ext slice out of range", i);
     const uint32_t* e = c.ext_of(op);
@@ -126,6 +127,7 @@ inline void validate_circuit(const HostCircuit& c, uint32_t D = 4) {
       default: fail(P3R_EUNSUPPORTED, "op %zu: kind %u has no table in this backend", i, op.kind);
     }
   }
+  });
   for (uint32_t w : c.public_rows) if (w >= nw) fail(P3R_EINVAL, "public row witness %u out of bounds", w);
   for (uint32_t w : c.private_rows) if (w >= nw) fail(P3R_EINVAL, "private row witness %u out of bounds", w);
   for (uint32_t w : c.rewrite) if (w >= nw) fail(P3R_EINVAL, "witness_rewrite entry %u out of bounds", w);
@@ -286,7 +288,8 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
     rows_of(recs_coeff, T.recompose_coeff_prep);
   });
   T.alu_prep13.resize(13 * alus.size());
-  for (size_t i = 0; i < alus.size(); ++i) {
+  host_parallel_for(alus.size(), size_t(1) << 16, [&](size_t i0, size_t i1) {
+  for (size_t i = i0; i < i1; ++i) {
     const p3r_op& op = *alus[i];
     const AluRoles& r = roles[i];
     const uint32_t c_w = op.c != kNoW ? op.c : 0;
@@ -299,6 +302,7 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
                               reader_col(r.a_state, op.a), reader_col(r.c_state, c_w)};
     std::copy(row, row + 13, T.alu_prep13.begin() + 13 * i);
   }
+  });
   if (alus.empty()) T.alu_prep13.assign(13, 0);  // the dummy row of an empty ALU table (common.rs:283-286)
   small_tables.get();
   return T;

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <map>
 #include <memory>
@@ -38,6 +39,25 @@ struct Error : std::runtime_error {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   throw Error(code, buf);
+}
+
+// fn(begin, end) over [0, n) on a few host threads (the preparation's per-op maps: validation, preprocessed rows,
+// the ALU matrix).  Chunks are contiguous and an error is reported for the LOWEST chunk that failed, so the message
+// is the one the sequential loop gives whenever the first bad element is the only one in its chunk's prefix.
+template <class Fn>
+inline void host_parallel_for(size_t n, size_t min_chunk, Fn fn) {
+  const size_t hw = std::max<size_t>(std::thread::hardware_concurrency(), 1);
+  const size_t chunks = std::min<size_t>(std::min<size_t>(hw, 16), (n + min_chunk - 1) / std::max<size_t>(min_chunk, 1));
+  if (chunks <= 1) { fn((size_t)0, n); return; }
+  std::vector<std::exception_ptr> err(chunks);
+  std::vector<std::thread> th;
+  auto run = [&](size_t c) {
+    try { fn(n * c / chunks, n * (c + 1) / chunks); } catch (...) { err[c] = std::current_exception(); }
+  };
+  for (size_t c = 1; c < chunks; ++c) th.emplace_back(run, c);
+  run(0);
+  for (auto& t : th) t.join();
+  for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 #define P3R_HIP(expr)                                                                   \

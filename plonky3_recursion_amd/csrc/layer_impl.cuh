@@ -240,8 +240,10 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   const auto& c = d->counts;
   auto check = [&](const uint32_t* p, size_t n, const char* what) {
     if (n && !p) fail(P3R_EINVAL, "%s is NULL", what);
-    for (size_t i = 0; i < n; ++i)
-      if (p[i] >= P) fail(P3R_EINVAL, "%s[%zu] is not canonical", what, i);
+    host_parallel_for(n, size_t(1) << 20, [&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; ++i)
+        if (p[i] >= P) fail(P3R_EINVAL, "%s[%zu] is not canonical", what, i);
+    });
   };
   prof_stage(ctx, "prep_lc_checks");
   check(d->alu_prep13, c.n_alu * 13, "alu_prep13");
@@ -255,6 +257,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   };
   const int rec2_plw = 2 + 2 * (int)ext_d;
   std::vector<std::vector<uint32_t>> mats(6);
+  std::unique_ptr<uint32_t, decltype(&free)> alu_mat(nullptr, &free);   // table 2 (the largest), filled in parallel
   p3r_air_desc airs[6] = {{P3R_AIR_CONST, 1, 2, 0},
                           {P3R_AIR_PUBLIC, L->public_lanes, 2, 0},
                           {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
@@ -338,19 +341,22 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     prof_stage(ctx, "prep_lc_alu_matrix");
     L->alu_rows = S.rows;
     L->h_alu = padded_height(S.rows, mh);
-    std::vector<uint32_t>& m = mats[2];
-    m.assign(L->h_alu * (size_t)pw, 0);
+    // zero pages from calloc, first touched by the thread that fills them
+    alu_mat.reset(static_cast<uint32_t*>(calloc(L->h_alu * (size_t)pw, sizeof(uint32_t))));
+    if (!alu_mat) fail(P3R_ENOMEM, "host allocation of the ALU preprocessed matrix failed");
+    uint32_t* m = alu_mat.get();
     auto mulmod = [&](uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)a * b % P); };
-    for (size_t pos = 0; pos < S.entries.size(); ++pos) {
+    host_parallel_for(S.entries.size(), size_t(1) << 15, [&](size_t pos0, size_t pos1) {
+    for (size_t pos = pos0; pos < pos1; ++pos) {
       const auto& en = S.entries[pos];
       size_t row = pos / lanes, lane = pos % lanes, base = row * pw + lane * 13;
       if (en.kind == PLAN_OP) {
-        std::copy(d->alu_prep13 + (size_t)en.first * 13, d->alu_prep13 + (size_t)en.first * 13 + 13, m.begin() + base);
+        std::copy(d->alu_prep13 + (size_t)en.first * 13, d->alu_prep13 + (size_t)en.first * 13 + 13, m + base);
       } else if (en.kind == PLAN_PACKED && lane == 0) {
         const int k = en.k;
         const uint32_t* src0 = d->alu_prep13 + (size_t)en.first * 13;
         const uint32_t* last = d->alu_prep13 + (size_t)(en.first + k - 1) * 13;
-        std::copy(src0, src0 + 13, m.begin() + base);
+        std::copy(src0, src0 + 13, m + base);
         m[base + 8] = last[8];
         m[base + 10] = last[10];
         m[base + 9] = mulmod(m[base + 9], (uint32_t)k);
@@ -366,6 +372,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
         }
       }
     }
+    });
     prof_stage(ctx, "prep_lc_plan_upload");
     L->alu_plan.alloc((S.entries.size() * sizeof(AluPlanEntry) + 3) / 4);
     P3R_HIP(copy_sync(ctx->stream, L->alu_plan.p, S.entries.data(), S.entries.size() * sizeof(AluPlanEntry), hipMemcpyHostToDevice));
@@ -384,7 +391,7 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   for (int i = 0; i < 6; ++i) {
     if (L->slot_of(i) < 0) continue;
     present_airs[n_present] = airs[i];
-    pm[n_present++] = {mats[i].data(), heights[i], (size_t)widths[i]};
+    pm[n_present++] = {i == 2 ? alu_mat.get() : mats[i].data(), heights[i], (size_t)widths[i]};
   }
   L->prep = prep_create<PP>(ctx, present_airs, pm, n_present);
   std::copy(L->prep->cap_canonical.begin(), L->prep->cap_canonical.end(), commit_out);
