@@ -190,3 +190,70 @@ def test_six_table_layer_oracle_and_native_verifier(oracle, d, dc):
     for wrong in ((0, 0), (1, 1), (1, 0)):
         with pytest.raises(p3r.P3rError):
             p3r.verify_batch(cfg, airs(wrong), cap, db, pf)
+
+
+# ---- the reference's own quintic test, first half (recursion/tests/fibonacci_batch_stark_prover_quintic.rs:62-113) ----
+def fibonacci_quintic_workload(oracle, n):
+    """Fibonacci(n) built with CircuitBuilder<Challenge> (Challenge = the quintic field): D = 5 arrays derived from the
+    oracle's circuit runner, which computes in the D = 4 embedding - values are base-field elements either way."""
+    import circuit_lib as cl
+    import fib_lib
+    import oracle_lib
+    circuit, inputs, fib = fib_lib.fibonacci_circuit(n, oracle_lib.MODULUS[FIELD])
+    oc = cl.OracleCircuit(oracle, circuit).preprocess(oracle_lib.MODULUS[FIELD])
+    oc.run(FIELD, inputs)
+    w = {k: np.array(v, dtype=np.uint32) for k, v in oc.workload_arrays().items()}
+    for name, per in (("const_values", 1), ("public_values", 1), ("alu_values", 4)):
+        v = w[name].reshape(-1, per, 4)
+        assert not v[:, :, 1:].any()
+        out = np.zeros((v.shape[0], per, 5), np.uint32)
+        out[:, :, 0] = v[:, :, 0]
+        w[name] = out.reshape(-1)
+    for name in ("const_prep", "public_prep"):
+        p = w[name].reshape(-1, 2)
+        p[:, 1] = p[:, 1] // 4 * 5
+    p13 = w["alu_prep13"].reshape(-1, 13)
+    p13[:, 5:9] = p13[:, 5:9] // 4 * 5
+    return w, fib
+
+
+@pytest.mark.gpu
+def test_fibonacci_batch_verifier_quintic_koala_inner_proof(oracle):
+    """`test_fibonacci_batch_verifier_quintic_koala`: n = 48, `CircuitBuilder::<Challenge>`, TablePacking::new(2, 4),
+    get_airs_and_degrees_with_prep::<MyConfig, _, 5>, runner.run(), prove_all_tables, verify_all_tables::<Challenge>
+    under koala_bear_quintic_params - here as one prove_next_layer call on the device (ext_degree = 5,
+    challenge_degree = 5), proof bytes against the oracle.  (FriParameters::new_testing's scalars are upstream's;
+    small test parameters of the same kind are used.)"""
+    import fib_lib
+    import oracle_lib
+    import plonky3_recursion_amd as p3r
+    fri = dict(log_blowup=2, max_log_arity=1, cap_height=0, log_final_poly_len=0, commit_pow_bits=1, query_pow_bits=1,
+               num_queries=2)
+    w, fib = fibonacci_quintic_workload(oracle, 48)
+    assert [int(x) for x in w["counts"][:5]] == [2, 1, 47, 0, 0]
+    prm = layer_lib.params(challenge_degree=5, **fri)
+    packing = dict(public_lanes=2, alu_lanes=4, horner_packed_steps=2)   # TablePacking::new(2, 4)
+    L = layer_lib.OracleLayer(oracle, FIELD, w, prm, packing=dict(packing, ext_degree=5))
+    circuit, inputs, fib2 = fib_lib.fibonacci_circuit(48, oracle_lib.MODULUS[FIELD], ext_degree=5)
+    assert fib == fib2 == 4807526976 % oracle_lib.MODULUS[FIELD]
+    ctx = p3r.Context(field=FIELD, ext_degree=5, challenge_degree=5, **fri)
+    tp = p3r.TablePacking(**packing).with_fri_params(fri["log_final_poly_len"], fri["log_blowup"])
+    pcirc = p3r.Circuit(circuit.witness_count, circuit.ops, circuit.ext, circuit.public_rows)
+    cache = p3r.build_next_layer_prep(ctx, pcirc, p3r.FriRecursionBackend(), p3r.ProveNextLayerParams(table_packing=tp))
+    assert np.array_equal(cache.prepared_circuit.circuit_prover_data.preprocessed_commitment, L.prep_commit())
+    pin = p3r.CircuitInputs(public_values=np.array([[fib, 0, 0, 0, 0]], dtype=np.uint32))
+    out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=pin), ctx, p3r.FriRecursionBackend(),
+                               p3r.ProveNextLayerParams(table_packing=tp), prep=cache)
+    want = L.prove()
+    assert out.proof.proof == want
+    L.verify(want)
+    p = out.proof
+    assert p.ext_degree == 5 and p.alu_quintic_trinomial and p.w_binomial is None and p.rows == (2, 1, 47)
+    assert p.non_primitives == ()
+    cache.prover.verify_all_tables(p)
+    back = p3r.BatchStarkProof.from_postcard(p.to_postcard(), FIELD, challenge_degree=5)
+    cache.prover.verify_all_tables(back)
+    with pytest.raises(p3r.P3rError, match="WitnessConflict"):
+        cache.prepared_circuit.run(p3r.CircuitInputs(public_values=np.array([[fib + 1, 0, 0, 0, 0]], dtype=np.uint32)))
+    cache.prepared_circuit.free()
+    ctx.close()
