@@ -232,3 +232,35 @@ def test_layer_with_both_recompose_tables(oracle, log_h, kw, packing, ext_degree
     res.free()
     cpd.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("d,dc,packing", [
+    (5, 5, dict(public_lanes=1, alu_lanes=8, horner_packed_steps=2)),                      # TablePacking::new(1, 8)
+    (4, 4, dict(public_lanes=1, alu_lanes=8, horner_packed_steps=2, recompose_lanes=2)),
+    (5, 5, dict(public_lanes=3, alu_lanes=6, horner_packed_steps=3, recompose_lanes=2)),
+    (1, 4, dict(public_lanes=4, alu_lanes=8, horner_packed_steps=8)),
+])
+def test_wide_packings_of_a_six_table_layer(oracle, d, dc, packing):
+    """The verifier circuit of the reference's quintic test is proved with `TablePacking::new(1, 8)` - eight ALU lanes -
+    and both Recompose tables (fibonacci_batch_stark_prover_quintic.rs:173-181, :236-238): wide rows, six tables, the
+    quintic configuration; proof bytes against the oracle."""
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    kw = dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+    arrs = harness_lib.generate("koala-bear", 9, seed=5, flags=harness_lib.RECOMPOSE_BOTH, ext_degree=d, horner_chain_len=20,
+                                sponge_chain_len=3, merkle_depth=5)
+    prm = layer_lib.params(challenge_degree=dc, **kw)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(packing, ext_degree=d))
+    ctx = p3r.Context(field="koala-bear", ext_degree=d, challenge_degree=dc, **kw)
+    tp = pv.TablePacking(**packing).with_fri_params(kw["log_final_poly_len"], kw["log_blowup"])
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=d), pv.FriRecursionBackend(),
+                                     pv.ProveNextLayerParams(table_packing=tp))
+    cpd = cache.circuit_prover_data
+    assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
+    p = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs, ext_degree=d), cpd)
+    assert p.proof == L.prove()
+    assert p.table_packing.alu_lanes == packing["alu_lanes"]
+    cache.prover.verify_all_tables(p)
+    cpd.free()
+    ctx.close()
