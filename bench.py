@@ -984,6 +984,33 @@ def main():
                     line["proof_verified"] = proof_verified
                     rin5.free()
                     pc5.free()
+                    # the size of a real verifier circuit (2^15 rows) under the same configuration: what one steady-state
+                    # layer of `recursive_fibonacci --quintic` costs here
+                    a15 = harness_lib.generate(field, 15, seed=0x5EED0015, flags=harness_lib.RECOMPOSE_BOTH, ext_degree=5, **GEN_KNOBS)
+                    t5 = time.perf_counter()
+                    pc15 = p3r.PreparedCircuit(ctx5, wl.circuit_from_arrays(a15), packing)
+                    prep15 = (time.perf_counter() - t5) * 1e3
+                    rin15 = pc15.upload_inputs(wl.circuit_inputs_from_arrays(a15, 5))
+                    raw15 = pc15.prove(rin15)
+                    ctx5.sync()
+                    t5 = time.perf_counter()
+                    for _ in range(10):
+                        pc15.prove(rin15)
+                    ctx5.sync()
+                    ms15 = (time.perf_counter() - t5) / 10 * 1e3
+                    try:
+                        cache15 = pc15.circuit_prover_data
+                        p3r.BatchStarkProver(ctx5).verify_all_tables(p3r.BatchStarkProver(ctx5).wrap_proof(raw15, cache15))
+                        ok15 = True
+                    except Exception as e:
+                        print(f"bench: 2^15-row quintic layer: proof rejected: {e}", file=sys.stderr)
+                        ok15 = False
+                    line[key]["small_layer_2p15"] = {"prove_next_layer_ms": ms15, "steps": 10, "proof_bytes": len(raw15),
+                                                     "proof_verified": ok15, "circuit_prep_ms": prep15}
+                    proof_verified = proof_verified and ok15
+                    line["proof_verified"] = proof_verified
+                    rin15.free()
+                    pc15.free()
                 ctx5.close()
         print(json.dumps(line))
     if resident is not None:
