@@ -40,22 +40,26 @@ std::vector<uint32_t> arr(const Synth& s, void* h, const char* name) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: %s <field> <log_height> <proof_out> [layers]\n", argv[0]); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: %s <field> <log_height> <proof_out> [layers] [--quintic]\n", argv[0]); return 2; }
   try {
     const p3r::Field field = std::string(argv[1]) == "baby-bear" ? p3r::Field::BabyBear : p3r::Field::KoalaBear;
     const int log_h = std::atoi(argv[2]);
     const int layers = argc > 4 ? std::atoi(argv[4]) : 2;
+    // --quintic (recursive_fibonacci.rs:515): KoalaBear, a D = 5 verifier circuit (base-mode Poseidon2 permutations,
+    // both Recompose kinds) under koala_bear_quintic_params, i.e. Challenge = the quintic field as well
+    const bool quintic = argc > 5 && std::string(argv[5]) == "--quintic";
+    const uint32_t D = quintic ? 5 : 4;
     std::string self = argv[0];
     const std::string root = self.substr(0, self.rfind('/')) + "/..";
 
     p3r::FriParams fri;  // the examples' defaults: blow-up 4, 54 queries, 15 bits of query PoW
-    p3r::Context ctx(field, fri);
+    p3r::Context ctx(field, fri, 0, {}, D, 0, quintic ? 5 : 4);
     std::vector<uint32_t> rc(p3r_poseidon2_num_constants(ctx.raw()));
     ctx.check(p3r_poseidon2_round_constants(ctx.raw(), rc.data()));
 
     // the verifier circuit + its inputs
     Synth synth(root + "/harness/libp3r_synth.so");
-    void* w = synth.generate((int)field, log_h, 0x5EED0000, 64, 8, 20, rc.data(), 0);
+    void* w = synth.generate((int)field, log_h, 0x5EED0000, 64, 8, 20, rc.data(), quintic ? (64u /* both Recompose kinds */ | 5u << 8) : 0u);
     if (*synth.error(w)) throw std::runtime_error(synth.error(w));
     p3r::Circuit circuit;
     circuit.witness_count = arr(synth, w, "counts")[5];
@@ -96,7 +100,7 @@ int main(int argc, char** argv) {
       // the wire form and back (what moves between the processes of an aggregation tree): native parser, same bytes again,
       // and the parsed proof verifies from its own metadata
       const std::vector<uint8_t> wire = out.proof.to_postcard();
-      const p3r::BatchStarkProof back = p3r::BatchStarkProof::from_postcard(wire, field);
+      const p3r::BatchStarkProof back = p3r::BatchStarkProof::from_postcard(wire, field, true, quintic ? 5 : 4);
       if (back.proof != out.proof.proof || back.to_postcard() != wire) throw p3r::Error(P3R_EINVAL, "postcard round trip differs");
       p3r::verify_all_tables(ctx.config(), back);
       std::printf("BatchStarkProof postcard round trip ok (%zu bytes)\n", wire.size());
@@ -104,7 +108,7 @@ int main(int argc, char** argv) {
     // prove_aggregation_layer (recursion.rs:656-762): the circuit's inputs arrive as the shares of the two
     // proofs it verifies; the AggregationPrepCache slot is filled by the first call and reused by the second
     {
-      const size_t hp = inputs.public_values.size() / 8 * 4, hv = inputs.private_values.size() / 8 * 4;
+      const size_t hp = inputs.public_values.size() / (2 * D) * D, hv = inputs.private_values.size() / (2 * D) * D;
       const size_t hs = inputs.private_data_op_ids.size() / 2;
       const uint32_t n_left = hs < inputs.private_data_op_ids.size() ? inputs.private_data_op_ids[hs] : 0;
       size_t cut = 0;

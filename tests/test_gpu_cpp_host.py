@@ -45,6 +45,33 @@ def test_cpp_host_matches_python_binding(oracle, tmp_path, field, log_h):
     ctx.close()
 
 
+def test_cpp_host_quintic_layer(oracle, tmp_path):
+    """`prove_next_layer <field> <log_h> <out> <layers> --quintic`: the compiled caller under koala_bear_quintic_params -
+    a D = 5 verifier circuit with base-mode Poseidon2 permutations and both Recompose kinds, Challenge = the quintic
+    field - gives the bytes of the Python binding; the oracle proves the same bytes from the generator's tables."""
+    import plonky3_recursion_amd as p3r
+    import harness_adapters as wl
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    out_file = str(tmp_path / "proof5.bin")
+    r = subprocess.run([EXE, "koala-bear", "11", out_file, "2", "--quintic"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verify_all_tables ok" in r.stdout and "prove_aggregation_layer (cached prep)" in r.stdout
+    got = open(out_file, "rb").read()
+    a = harness_lib.generate("koala-bear", 11, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=8, merkle_depth=20,
+                             flags=harness_lib.RECOMPOSE_BOTH, ext_degree=5)
+    fri = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15,
+               num_queries=54)
+    ctx = p3r.Context(field="koala-bear", ext_degree=5, challenge_degree=5, **fri)
+    tp = p3r.TablePacking().with_fri_params(5, 2)
+    pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
+    assert pc.prove(wl.circuit_inputs_from_arrays(a, 5)) == got
+    L = layer_lib.OracleLayer(oracle, "koala-bear", a, layer_lib.params(challenge_degree=5, **fri), packing=dict(ext_degree=5))
+    assert np.array_equal(pc.circuit_prover_data.preprocessed_commitment, L.prep_commit())
+    assert L.prove() == got
+    pc.free()
+    ctx.close()
+
+
 def test_fallback_paths_give_the_same_proof(tmp_path):
     """The tuning knobs exist in the `knobs` build of the library only (plonky3_recursion_amd/knobs/libp3r_hip.so,
     -DP3R_TUNING_KNOBS; the product build compiles them out).  The paths they select (copy-engine fetches instead
