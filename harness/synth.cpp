@@ -198,7 +198,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
   // afterwards: an ALU op would claim an undefined hint output as ITS creation (circuit.rs:351-359), and the
   // recompose/coeff preprocessing does not mark them defined (ops/recompose.rs:174-192)
   std::vector<uint32_t> rec_owned;
-  std::vector<uint8_t> is_rec_out;
+  std::vector<uint8_t> is_rec_out;   // 1: made by a plain `recompose` row, 2: by a `recompose/coeff` row
   std::vector<uint8_t> rec_kind;     // 1: the row belongs to the `recompose/coeff` table
   auto& rec_values = W.arr["recompose_values"];
   auto& rec2_values = W.arr["recompose_coeff_values"];
@@ -220,9 +220,11 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
       push_op(C_HINT_EXT, src, 0, 0, 0, 0, ins);
       // connect(x, reconstructed): the op's output IS the decomposed witness - unless another row of this table
       // made it (dup_npo_outputs is kept per witness: both rows would become readers, circuit.rs:464-491)
-      // (dup_npo_outputs is per op type: with two tables only an output of the SAME table is excluded - kept simple
-      // here by excluding every recompose output)
-      dup = rng.unit() < 0.5 && !(src < is_rec_out.size() && is_rec_out[src]);
+      // (dup_npo_outputs is per op type: with two tables only an output of the SAME table - this row is of the
+      // coefficient kind - is excluded; decomposing what a plain `recompose` row made and connecting back is the
+      // builder's own pattern, circuit_builder.rs:1438-1463)
+      const uint8_t made_by = src < is_rec_out.size() ? is_rec_out[src] : 0;
+      dup = rng.unit() < 0.5 && (made_by == 0 || (rec_both && made_by == 1));
       if (dup) { w = src; reads[src]++; } else w = create(v);
     } else {
       for (int k = 0; k < D; ++k) {
@@ -235,7 +237,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     for (int k = 0; k < D; ++k) (second ? rec2_values : rec_values).push_back(v.c[k].to_canonical());
     rec_kind.push_back(second);
     rec_w.push_back(w);
-    if (!dup) { is_rec_out.resize(wval.size(), 0); is_rec_out[w] = 1; }
+    if (!dup) { is_rec_out.resize(wval.size(), 0); is_rec_out[w] = coeff_row ? 2 : 1; }
     rec_dup.push_back(dup);
     if (!dup) pickable.push_back(w);
     rec_ins.push_back(ins);
