@@ -927,7 +927,7 @@ def main():
             # recursive_fibonacci --quintic (LogUp, quotient, openings, FRI and transcript over five-word elements)
             for dc, key in ((4, "quintic_backend_layer"), (5, "quintic_challenge_layer")):
                 ctx5 = p3r.Context(field=field, ext_degree=5, challenge_degree=dc, **FRI)
-                cache5 = p3r.build_next_layer_prep(ctx5, prep5, p3r.FriRecursionBackend(),
+                cache5 = p3r.build_next_layer_prep(ctx5, prep5, p3r.FriRecursionBackendD5(),
                                                    p3r.ProveNextLayerParams(table_packing=packing))
                 cpd5 = cache5.circuit_prover_data
                 res5 = p3r.ResidentTraces(ctx5, cpd5, traces5)

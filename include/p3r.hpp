@@ -544,6 +544,12 @@ struct FriRecursionBackend {  // registers the Poseidon2 + Recompose table prove
   // and none for any other degree (`else { Vec::new() }`): a D = 5 layer is proved from its primitive tables
   size_t non_primitive_provers(size_t ext_degree) const { return ext_degree == 4 ? 2 : 0; }
 };
+// recursion/src/backend/fri.rs:741-852: the backend of KoalaBear quintic circuits.  With the D1 permutation (`cl = true`,
+// :816-835) it registers the compact-D1 Poseidon2 table and BOTH Recompose tables for D = 5 circuits, nothing otherwise;
+// all three are built in, so a Context with ext_degree = 5 proves whatever tables the circuit fills (five or six).
+struct FriRecursionBackendD5 : FriRecursionBackend {
+  size_t non_primitive_provers(size_t ext_degree) const { return ext_degree == 5 ? 3 : 0; }
+};
 struct ProveNextLayerParams { TablePacking table_packing; };
 
 struct NextLayerPrepCache {

@@ -6,7 +6,7 @@ raises if `libp3r_hip.so` has not been built (no CPU fallback).
 """
 from .device import Context, DeviceMatrix, MerkleTree, P3rError, make_config, verify_batch  # noqa: F401
 from .prover import (AggregationCircuitFingerprint, AggregationPrepCache, BatchStarkProof, BatchStarkProver, Circuit, CircuitInputs, CircuitPrep,  # noqa: F401
-                     CircuitProverData, CircuitRunner, PreparedCircuit, FriRecursionBackend, FriRecursionConfig, NextLayerPrepCache, ProveNextLayerParams,
+                     CircuitProverData, CircuitRunner, PreparedCircuit, FriRecursionBackend, FriRecursionBackendD5, FriRecursionConfig, NextLayerPrepCache, ProveNextLayerParams,
                      RecursionInput, RecursionOutput, ResidentTraces, TablePacking, Traces,
                      aggregation_circuit_fingerprint, build_next_layer_prep, pack_aggregation_inputs, prove_aggregation_layer,
                      prove_next_layer, span_report, verify_all_tables)

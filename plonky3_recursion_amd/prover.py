@@ -766,6 +766,16 @@ class FriRecursionBackend:
         return ["poseidon2_perm", "recompose"] if ext_degree == 4 else []
 
 
+class FriRecursionBackendD5(FriRecursionBackend):
+    """recursion/src/backend/fri.rs:741-852: the backend of KoalaBear quintic circuits.  With the D1 permutation
+    (`challenger_perm_config.extension_degree() != 5`, hence `cl = true`) it registers the compact-D1 Poseidon2 table and
+    BOTH Recompose tables for D = 5 circuits (:816-835), and nothing for any other degree; all three are built in to this
+    prover, so a context with ext_degree = 5 proves whatever tables the circuit fills (five or six)."""
+
+    def non_primitive_provers(self, ext_degree: int):
+        return ["poseidon2_perm/koala_bear_d1_w16", "recompose", "recompose/coeff"] if ext_degree == 5 else []
+
+
 def _lib_code(name):
     return {"UNSUPPORTED": -5}[name]
 

@@ -239,10 +239,10 @@ def test_fibonacci_batch_verifier_quintic_koala_inner_proof(oracle):
     ctx = p3r.Context(field=FIELD, ext_degree=5, challenge_degree=5, **fri)
     tp = p3r.TablePacking(**packing).with_fri_params(fri["log_final_poly_len"], fri["log_blowup"])
     pcirc = p3r.Circuit(circuit.witness_count, circuit.ops, circuit.ext, circuit.public_rows)
-    cache = p3r.build_next_layer_prep(ctx, pcirc, p3r.FriRecursionBackend(), p3r.ProveNextLayerParams(table_packing=tp))
+    cache = p3r.build_next_layer_prep(ctx, pcirc, p3r.FriRecursionBackendD5(), p3r.ProveNextLayerParams(table_packing=tp))
     assert np.array_equal(cache.prepared_circuit.circuit_prover_data.preprocessed_commitment, L.prep_commit())
     pin = p3r.CircuitInputs(public_values=np.array([[fib, 0, 0, 0, 0]], dtype=np.uint32))
-    out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=pin), ctx, p3r.FriRecursionBackend(),
+    out = p3r.prove_next_layer(p3r.RecursionInput(circuit_inputs=pin), ctx, p3r.FriRecursionBackendD5(),
                                p3r.ProveNextLayerParams(table_packing=tp), prep=cache)
     want = L.prove()
     assert out.proof.proof == want
