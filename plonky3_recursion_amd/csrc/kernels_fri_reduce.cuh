@@ -133,11 +133,20 @@ k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriRed
     const FriReduceMatT<DC>& a = mats[job.mat0 + m];
     const gptr<const uint32_t> mat = as_global(a.mat);
     const int w = a.w;
-    E S = E::zero();
+    E S = E::zero(), S2 = E::zero();
     int c = 0;
-    for (; c + 1 < w; c += 2)  // two columns per reduction
+    // four column loads in flight, two columns per reduction, two accumulators: the pass is bound by HBM latency x
+    // occupancy, not by issue (1.22 -> 1.10 ms at 2^20 rows; eight in flight: 1.14 ms)
+    for (; c + 3 < w; c += 4) {
+      const F m0 = F::raw(mat[(size_t)c * h + r]), m1 = F::raw(mat[(size_t)(c + 1) * h + r]);
+      const F m2 = F::raw(mat[(size_t)(c + 2) * h + r]), m3 = F::raw(mat[(size_t)(c + 3) * h + r]);
+      S += E::dot2_base(apow(c), m0, apow(c + 1), m1);
+      S2 += E::dot2_base(apow(c + 2), m2, apow(c + 3), m3);
+    }
+    for (; c + 1 < w; c += 2)
       S += E::dot2_base(apow(c), F::raw(mat[(size_t)c * h + r]), apow(c + 1), F::raw(mat[(size_t)(c + 1) * h + r]));
     if (c < w) S += apow(c) * F::raw(mat[(size_t)c * h + r]);
+    S += S2;
     for (int p = 0; p < a.n_points; ++p) {
       E inv;
 #pragma unroll
