@@ -289,9 +289,21 @@ struct BatchStarkProof {
       NonPrimitiveTableEntry n;
       n.op_type = e.op_type; n.rows = (size_t)e.rows; n.lanes = e.lanes; n.air_variant = e.air_variant;
       n.public_values.assign(e.public_values, e.public_values + e.n_public_values);
-      if (n.op_type == "recompose") p.table_packing.recompose_lanes = e.lanes;
       p.non_primitives.push_back(std::move(n));
     }
+    // recompose lanes: the first Recompose entry of either kind, else TablePacking.npo_lanes (the rule of prover.py)
+    bool have_lanes = false;
+    for (const auto& n : p.non_primitives)
+      if (!have_lanes && (n.op_type == "recompose" || n.op_type == "recompose/coeff")) {
+        p.table_packing.recompose_lanes = n.lanes;
+        have_lanes = true;
+      }
+    for (const char* name : {"recompose", "recompose/coeff"})
+      for (uint32_t i = 0; i < m.n_npo_lanes && !have_lanes; ++i)
+        if (std::string(m.npo_lanes[i].op_type) == name) {
+          p.table_packing.recompose_lanes = m.npo_lanes[i].lanes;
+          have_lanes = true;
+        }
     if (m.has_stark_common) {
       p.preprocessed_commitment.assign(m.commitment, m.commitment + 8 * m.cap_len);
       p.preprocessed_widths.assign(m.preprocessed_widths, m.preprocessed_widths + m.n_instances);

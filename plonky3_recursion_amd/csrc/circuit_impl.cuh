@@ -1128,6 +1128,9 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   C->witness_count = d->witness_count;
   C->n_public_rows = d->n_public;
   C->n_private_rows = d->n_private;
+  // packing parameters first: both preparations divide by them (TablePacking::validate, packing.rs:140-161)
+  if (!d->public_lanes || !d->alu_lanes || !d->recompose_lanes) fail(P3R_EINVAL, "lane counts must be positive");
+  if (d->horner_packed_steps < 2 || d->horner_packed_steps > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
   // Device-side preparation (prep_device.hip): the op list crosses PCIe once; preprocessed columns, ALU lane
   // schedule and execution schedule are built in HBM.  A circuit it flags (malformed, unclaimed private input,
   // a witness nobody sets ...) goes through the host restatement below, which raises the reference's error.

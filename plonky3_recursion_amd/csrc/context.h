@@ -171,7 +171,7 @@ inline std::shared_ptr<DevPool>& tls_pool() {
 // library only (-DP3R_TUNING_KNOBS: plonky3_recursion_amd/knobs/libp3r_hip.so, what tests/test_gpu_cpp_host.py and the
 // tuning tools load); in the product build every knob reads as unset and the alternatives are dead code the
 // compiler drops.
-inline const char* tuning_knob(const char* name) {
+static inline const char* tuning_knob(const char* name) {
 #ifdef P3R_TUNING_KNOBS
   return getenv(name);
 #else

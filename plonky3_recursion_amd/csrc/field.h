@@ -298,7 +298,7 @@ struct Fp4 {
 
 // Degree-5 extension F[x]/(x^5 + x^2 - 1) of KoalaBear (p3-field's QuinticTrinomialExtensionField): the field of
 // D = 5 circuits.  Only what trace generation needs (the ALU table's packed-Horner intermediates): ring
-// operations; the STARK's challenge field stays Fp4.
+// operations plus inv (Itoh-Tsujii) - also the STARK's challenge field under challenge_degree = 5 (Chal<PP, 5>).
 template <class PP>
 inline constexpr bool kHasQuintic = PP::P == 0x7f000001u;
 // The base field as the element type of base-field circuits (D = 1: CircuitBuilder<F>).

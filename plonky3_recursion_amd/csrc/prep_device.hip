@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(kB) k_validate(const uint32_t* __restrict__ op
       break;
     case P3R_OP_RECOMPOSE:
       // a `recompose/coeff` op (aux = 1) hands the circuit over to the host restatement, like a malformed one
-      ok = wid(op.out) && op.a < n_ops && op.ext_len == 4 && op.aux != 1u;
+      ok = wid(op.out) && op.a < n_ops && op.ext_len == 4 && (op.aux == 0u || op.aux == kNoW);  // any other aux: the host path rejects it
       if (ok) for (uint32_t k = 0; k < 4; ++k) ok = ok && wid(e[k]);
       break;
     default: ok = false;

@@ -269,9 +269,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       P3R_HIP(ctx->stage.upload(ctx->stream, scratch.back().p, jobs.data(), jobs.size() * sizeof(LogupJob)));
       const int nj = (int)jobs.size();
       ProfScope ps(ctx, "logup_aux");
-      dispatch_air_degree<PP>((int)ctx->cfg.ext_degree, [&](auto dc) {
-        hipLaunchKernelGGL((k_logup_aux<PP, decltype(dc)::value, DC>), dim3(row_blocks), dim3(kBlock), 0, ctx->stream, d_jobs, nj, lc);
-      });
+      launch_logup_aux<PP, DC>(ctx, row_blocks, d_jobs, nj, lc);
       hipLaunchKernelGGL((k_ef_scan<PP, DC>), dim3(tiles), dim3(kBlock), 0, ctx->stream, 0, d_jobs, nj);
       hipLaunchKernelGGL((k_ef_scan<PP, DC>), dim3((unsigned)nj), dim3(kBlock), 0, ctx->stream, 1, d_jobs, nj);
       hipLaunchKernelGGL((k_ef_scan<PP, DC>), dim3(tiles), dim3(kBlock), 0, ctx->stream, 2, d_jobs, nj);
@@ -368,10 +366,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     DevBuf d_quot((quot_jobs.size() * sizeof(QuotientArgs) + 3) / 4);
     P3R_HIP(ctx->stage.upload(ctx->stream, d_quot.p, quot_jobs.data(), quot_jobs.size() * sizeof(QuotientArgs)));
     ProfScope ps(ctx, "quotient");
-    dispatch_air_degree<PP>((int)ctx->cfg.ext_degree, [&](auto dc) {
-      hipLaunchKernelGGL((k_quotient<PP, decltype(dc)::value, DC>), dim3(quot_blocks), dim3(kBlock), 0, ctx->stream,
-                         reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc, ctx->rc.p);
-    });
+    launch_quotient<PP, DC>(ctx, quot_blocks, reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc);
     P3R_HIP(hipGetLastError());
   }
   {

@@ -59,6 +59,7 @@ struct ProofReader {
     uint64_t v = 0;
     for (int shift = 0; shift < 64; shift += 7) {
       uint8_t b = byte();
+      if (shift == 63 && b > 1) vfail("varint overflows 64 bits");  // postcard: the tenth byte carries one bit
       v |= (uint64_t)(b & 0x7F) << shift;
       if (!(b & 0x80)) {
         if (b == 0 && shift > 0) vfail("non-canonical varint");
@@ -233,6 +234,7 @@ struct ProofSkimmer {
     uint64_t v = 0;
     for (int shift = 0; shift < 64; shift += 7) {
       uint8_t b = byte();
+      if (shift == 63 && b > 1) vfail("varint overflows 64 bits");  // postcard: the tenth byte carries one bit
       v |= (uint64_t)(b & 0x7F) << shift;
       if (!(b & 0x80)) {
         if (b == 0 && shift > 0) vfail("non-canonical varint");
@@ -448,12 +450,18 @@ void parse_batch_stark_meta(const uint8_t* bytes, size_t len, bool canonical, co
   // structural invariants a derived Deserialize bypasses (batch_stark_prover.rs:666-681, packing.rs:140-161)
   const uint32_t d = M->ext_degree;
   if (!(d == 1 || d == 2 || d == 4 || d == 5 || d == 6 || d == 8)) vfail("UnsupportedExtDegree(%u)", d);
+  for (int i = 0; i < 3; ++i)
+    if (!M->rows[i]) vfail("ZeroRowCount");  // RowCounts::validate, batch_stark_prover.rs:475-479
+  // TablePacking::validate, packing.rs:140-161
   if (!M->public_lanes) vfail("ZeroLanes(\"public_lanes\")");
   if (!M->alu_lanes) vfail("ZeroLanes(\"alu_lanes\")");
-  for (uint32_t i = 0; i < M->n_non_primitives; ++i)
-    if (!M->non_primitives[i].lanes) vfail("ZeroNpoLanes(%s)", M->non_primitives[i].op_type);
+  for (uint32_t i = 0; i < M->n_npo_lanes; ++i)
+    if (!M->npo_lanes[i].lanes) vfail("ZeroNpoLanes(%s)", M->npo_lanes[i].op_type);
   if (!M->min_trace_height || (M->min_trace_height & (M->min_trace_height - 1))) vfail("BadMinTraceHeight(%u)", M->min_trace_height);
   if (M->horner_packed_steps < 2) vfail("BadHornerPackedSteps(%u)", M->horner_packed_steps);
+  // NonPrimitiveTableEntry::validate, batch_stark_prover.rs:292-300
+  for (uint32_t i = 0; i < M->n_non_primitives; ++i)
+    if (!M->non_primitives[i].lanes) vfail("ZeroNpoLanes(%s)", M->non_primitives[i].op_type);
 }
 
 // ---- the opened values of one instance as an AIR view over the extension field

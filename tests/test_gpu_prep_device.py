@@ -162,3 +162,29 @@ def test_flagged_circuits_get_the_host_paths_error():
     c.witness_count = good.witness_count + 1
     assert "UnclaimedPrivateInput" in messages(c)
     ctx.close()
+
+
+def test_bad_packing_is_refused_before_either_preparation(monkeypatch):
+    """Lane counts of 0 and a Horner pack size outside 2..8 reach the C ABI unvalidated when a caller skips
+    TablePacking::validate: both preparations divide by them, so p3r_circuit_create checks first (P3R_EINVAL,
+    not a SIGFPE) - on the device path and on the host path."""
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    field = "koala-bear"
+    ctx = p3r.Context(field=field, **FRI)
+    a = harness_lib.generate(field, 7, seed=5, horner_chain_len=16, sponge_chain_len=3, merkle_depth=5)
+    circuit = wl.circuit_from_arrays(a)
+    monkeypatch.setattr(p3r.TablePacking, "validate", lambda self: None)
+    bad = [dict(public_lanes=0), dict(alu_lanes=0), dict(recompose_lanes=0), dict(horner_packed_steps=0),
+           dict(horner_packed_steps=1), dict(horner_packed_steps=9)]
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("P3R_PREP_HOST", "1")
+        for kw in bad:
+            tp = p3r.TablePacking(min_trace_height=8)
+            for k, v in kw.items():
+                setattr(tp, k, v)
+            with pytest.raises(p3r.P3rError, match="lane counts must be positive|horner_packed_steps must be in 2..8") as e:
+                p3r.PreparedCircuit(ctx, circuit, tp)
+            assert e.value.code == -1   # P3R_EINVAL
+    ctx.close()

@@ -146,8 +146,48 @@ def test_native_parser_survives_mutated_wire_bytes(oracle):
         attempt(data)
     for pos in [int(x) for x in rng.integers(0, len(good), 200)]:          # length bombs: a run of 0xFF continuation bytes
         data = bytearray(good)
-        data[pos:pos + 4] = b"\\xff\\xff\\xff\\xff"
+        data[pos:pos + 4] = b"\xff\xff\xff\xff"
         attempt(data)
-    attempt(good + b"\\x00")
+    attempt(good + b"\x00")
     attempt(b"")
     assert rejected > 500 and accepted > 0, (accepted, rejected)
+
+
+def test_native_parser_applies_row_count_npo_lane_and_varint_rules(oracle):
+    """What `BatchStarkProof::validate()` enforces and a derived Deserialize bypasses: RowCounts::validate
+    (batch_stark_prover.rs:475-479), TablePacking::validate over npo_lanes (packing.rs:147-151), and postcard's
+    rule that the tenth byte of a varint carries one bit."""
+    import pytest
+    import harness_lib
+    import layer_lib
+    from plonky3_recursion_amd.device import P3rError
+    field = "koala-bear"
+    arrs = harness_lib.generate(field, 6, seed=78, horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
+    prm = layer_lib.params(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+    inner = layer_lib.OracleLayer(oracle, field, arrs, prm).prove()
+    tp = pv.TablePacking(min_trace_height=8)
+    good = pv.BatchStarkProof(
+        proof=inner, table_packing=tp, rows=(3, 5, 7), w_binomial=3,
+        non_primitives=(pv.NonPrimitiveTableEntry("recompose", 9, 2),), monty_r=1, modulus=0x7F000001).to_postcard()
+    assert pv.BatchStarkProof.from_postcard(good, field).rows == (3, 5, 7)
+    tail = good[len(inner):]
+    # public_lanes alu_lanes n_npo=1 len "recompose" lanes=2 min_h horner rows[3] ...
+    assert tail[:3] == bytes([1, 3, 1]) and tail[3] == 9 and tail[4:13] == b"recompose" and tail[13] == 2
+    lanes_at, rows_at = len(inner) + 13, len(inner) + 16
+    assert good[rows_at:rows_at + 3] == bytes([3, 5, 7])
+
+    def mutated(pos, new, width=1):
+        d = bytearray(good)
+        d[pos:pos + width] = new
+        return bytes(d)
+    for k in range(3):
+        with pytest.raises(P3rError, match="ZeroRowCount"):
+            pv.BatchStarkProof.from_postcard(mutated(rows_at + k, b"\x00"), field)
+    with pytest.raises(P3rError, match="ZeroNpoLanes"):
+        pv.BatchStarkProof.from_postcard(mutated(lanes_at, b"\x00"), field)
+    # a ten-byte varint for rows[0]: ...0x01 in the tenth byte is 2^63 (fits usize), 0x7E overflows 64 bits
+    ok10 = mutated(rows_at, b"\x83" + b"\x80" * 8 + b"\x01")
+    assert pv.BatchStarkProof.from_postcard(ok10, field).rows[0] == 3 + (1 << 63)
+    for last in (b"\x02", b"\x7e", b"\x7f"):
+        with pytest.raises(P3rError, match="varint"):
+            pv.BatchStarkProof.from_postcard(mutated(rows_at, b"\xff" * 9 + last), field)
