@@ -419,6 +419,7 @@ struct p3r_ctx {
   double cur_stage_t0 = 0;
   int partial_rounds = 0;
   hipStream_t stream = nullptr;
+  int n_cus = 256;  // compute units of the device (grids of the persistent kernels)
   p3r::DevBuf rc;  // Poseidon2 constants, Montgomery
   p3r::DevBuf rc_f64;  // the same constants as canonical doubles (poseidon2_f64.cuh)
   const double* rcd() const { return reinterpret_cast<const double*>(rc_f64.p); }

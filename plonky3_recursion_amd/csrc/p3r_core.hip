@@ -451,6 +451,10 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
     c->cfg = *cfg;
     tls_pool() = c->pool;
     P3R_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
+    }
     P3R_FIELD_CALL(c, init_ctx, c.get());
     ctx = c.release();
   });
