@@ -115,13 +115,28 @@ def hbm_families(heights, widths, packing, kernel_ms):
             out[fam] = {"algorithmic_bytes": nbytes, "ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS}
             if fam == "ntt":   # the four-pass model above (68 B per cell) next to the one-read-one-write minimum
+                bf, prod = ntt_arithmetic(heights, widths, packing)
+                arith_ms = (bf / NTT_BUTTERFLY_RATE + prod / MONT_PRODUCT_RATE) * 1e3
                 out[fam].update({"model_bytes_per_cell": 16 + 4 + 4 * B + 8 * B, "min_bytes_per_cell": 4 + 4 * B,
                                  "min_bytes": ntt_min, "achieved_vs_min": ntt_min / (ms * 1e-3) / 1e9,
-                                 "frac_vs_min": ntt_min / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                                 "frac_vs_min": ntt_min / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "arithmetic": {"butterflies": bf, "products": prod, "butterfly_rate": NTT_BUTTERFLY_RATE,
+                                                "product_rate": MONT_PRODUCT_RATE, "floor_ms": arith_ms, "frac": arith_ms / ms,
+                                                "source": "profiles/r04/ntt_bound.txt: the passes are bound by the butterflies "
+                                                          "they issue plus their memory phases, not by HBM bytes"}})
     return out
 
 
-PROFILE_ROUND = "r03"   # profiles/<round>/ holds the rocprofv3 summaries the roofline numbers refer to
+PROFILE_ROUND = "r04"   # profiles/<round>/ holds the rocprofv3 summaries the roofline numbers refer to
+
+
+def profile_file(name):
+    """Path of a committed summary: this round's, else the newest earlier round's (the line names what it read)."""
+    for rnd in (PROFILE_ROUND, "r03", "r02"):
+        p = os.path.join(ROOT, "profiles", rnd, name)
+        if os.path.exists(p):
+            return p, f"profiles/{rnd}/{name}"
+    return None, None
 FP64_FMA_SPEC = 39.3e12  # /opt/skills/guides/MI355X_MICROARCH.md: 78.6 TFLOP/s FP64 vector = 39.3 T FMA lane-ops/s
 PUBLISHED_CPU_MS = 109.0  # BASELINE.md: prove_next_layer of a real (~2^15-row) verifier circuit, Apple M4 Pro, 14 cores
 
@@ -132,21 +147,83 @@ def committed_valu_model(field):
       pmc_hash_rows.json      rocprofv3 --pmc SQ_INSTS_VALU over tools/pmc_hash_rows.py (N commits of one matrix of
                               known shape): valu_insts_per_perm = SQ_INSTS_VALU x 64 lanes / permutations
       microbench_int_rates.txt  the `v_fma_f64` line of tools/microbench/int_rates on the same box."""
-    base = os.path.join(ROOT, "profiles", PROFILE_ROUND)
     insts = rate = None
+    src = {}
     try:
-        with open(os.path.join(base, "pmc_hash_rows.json")) as fh:
+        p, src["valu_insts_per_perm"] = profile_file("pmc_hash_rows.json")
+        with open(p) as fh:
             insts = float(json.load(fh)["fields"][field]["valu_insts_per_perm"])
     except Exception:
         pass
     try:
-        with open(os.path.join(base, "microbench_int_rates.txt")) as fh:
+        p, src["peak_measured_lane_ops_per_s"] = profile_file("microbench_int_rates.txt")
+        with open(p) as fh:
             for ln in fh:
                 if ln.startswith("v_fma_f64"):
                     rate = float(ln.split()[1]) * 1e12
     except Exception:
         pass
-    return insts, rate
+    return insts, rate, src
+
+
+# Arithmetic of the LDE passes (profiles/r04/ntt_bound.txt, tools/microbench/ntt_valu on one MI355X): the radix-2
+# butterfly of csrc/kernels_ntt2.cuh (ten integer instructions, two of them v_mad_u64_u32) issues at 3.9 T/s with no
+# memory in the loop, a Montgomery product at 7.7 T/s (profiles/r03/microbench_int_rates.txt).
+NTT_BUTTERFLY_RATE = 3.9e12
+MONT_PRODUCT_RATE = 7.68e12
+
+
+def ntt_arithmetic(heights, widths, packing):
+    """Butterflies and twiddle / shift products of a proof's coset LDEs: per input cell of a 2^n-row column,
+    n/2 butterflies for the inverse transform and 4 x n/2 for the four cosets; 2 products for the four-step twiddle of
+    the inverse transform and 3 per coset (coset shift power, four-step twiddle chain) for the forward one."""
+    names = ["const", "public", "alu", "poseidon2", "recompose"]
+    aux = lookup_aux_widths(packing.alu_lanes, packing.horner_packed_steps)
+    B = 1 << FRI["log_blowup"]
+    bf = prod = 0
+    for i, n in enumerate(names):
+        h = heights[i]
+        if not h:
+            continue
+        cells = h * (widths[i] + aux[n][0] * 4 + aux[n][1] * 4)
+        bf += cells * (h.bit_length() - 1) / 2 * (1 + B)
+        prod += cells * (2 + 3 * B)
+    return bf, prod
+
+
+def proof_roofline(field, heights, widths, packing, perms, insts_per_perm, hash_bytes, ms_per_step, fams):
+    """The whole proof against its two roofs (reported separately and summed): every Poseidon2
+    permutation of the proof (workload_model: trace fill, leaf hashing, compressions, FRI leaves) at the dominant
+    kernel's instructions per permutation against the FP64 vector peak; every streaming kernel at its MINIMUM
+    algorithmic bytes against the HBM peak - the LDE as one read of the trace and one write of the four cosets
+    (20 B per cell, not the 68 B the four passes move), the hash kernel's read of the committed LDEs, the quotient's
+    read of main / preprocessed / aux LDEs on the quotient domain (local + next row), openings and reduced openings.
+    frac = floor_ms / ms_per_step."""
+    names = ["const", "public", "alu", "poseidon2", "recompose"]
+    aux = lookup_aux_widths(packing.alu_lanes, packing.horner_packed_steps)
+    prep_w = [2, 2 * packing.public_lanes, 13 * packing.alu_lanes + 7 * (packing.horner_packed_steps - 1), 24,
+              2 * packing.recompose_lanes]
+    quot = 0
+    for i, n in enumerate(names):
+        if heights[i]:   # quotient domain = chunks x h rows; local + next of every column; 16 B per chunk row written
+            c = aux[n][1]
+            quot += heights[i] * c * (2 * 4 * (widths[i] + prep_w[i] + 4 * aux[n][0]) + 16)
+    hbm = {"lde_min": fams.get("ntt", {}).get("min_bytes", 0), "leaf_hash_read": hash_bytes, "quotient": quot,
+           "reduced_openings": fams.get("fri_reduced_openings", {}).get("algorithmic_bytes", 0),
+           "openings": fams.get("openings", {}).get("algorithmic_bytes", 0)}
+    hbm_bytes = sum(hbm.values())
+    valu_ms = perms * insts_per_perm / FP64_FMA_SPEC * 1e3 if insts_per_perm else None
+    hbm_ms = hbm_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
+    floor = (valu_ms or 0.0) + hbm_ms
+    ntt_arith = fams.get("ntt", {}).get("arithmetic", {}).get("floor_ms")
+    out = {"valu_floor_ms": valu_ms, "hbm_floor_ms": hbm_ms, "floor_ms": floor, "frac": floor / ms_per_step,
+           "poseidon2_perms": perms, "valu_insts_per_perm": insts_per_perm, "valu_peak_lane_ops_per_s": FP64_FMA_SPEC,
+           "hbm_min_bytes": hbm_bytes, "hbm_min_bytes_by_family": hbm, "hbm_peak_GBps": HBM_PEAK_GBS}
+    if ntt_arith and valu_ms:
+        # the LDE passes priced by their butterflies (what binds them, profiles/r04/ntt_bound.txt) instead of by 20 B per cell
+        f2 = valu_ms + ntt_arith + (hbm_bytes - hbm["lde_min"]) / (HBM_PEAK_GBS * 1e9) * 1e3
+        out["with_lde_arithmetic"] = {"lde_arithmetic_floor_ms": ntt_arith, "floor_ms": f2, "frac": f2 / ms_per_step}
+    return out
 
 
 def pmc_traffic_bytes(kernel):
@@ -155,7 +232,7 @@ def pmc_traffic_bytes(kernel):
     The kernel's HBM traffic is its input cells and output digests whatever arithmetic hashes them, so
     the figure only goes stale when the table mix changes - `traffic_source` names the file."""
     try:
-        with open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")) as fh:
+        with open(profile_file("pmc_traffic.json")[0]) as fh:
             k = json.load(fh)["kernels"][kernel]
         # gfx950: FETCH_SIZE tallies the 128-B requests of a coalesced streaming read at 64 B
         # (/opt/skills/guides/MI355X_MICROARCH.md, HBM section) - doubled before comparing with bytes.
@@ -409,11 +486,12 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
         level_ms = [max((ms for lv, ms in node_done if lv == l), default=None) for l in range(plans[0].levels)]
     times = times[args.warmup:]
     dt = sum(times)
+    own_dt = dt
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ranks = rank_report(torch, dist, world, backend_name, local_rank, coll_device)
+    ranks = rank_report(torch, dist, world, backend_name, local_rank, coll_device, rank_ms=own_dt / max(len(times), 1) * 1e3)
     ok = True
     if rank == 0:
         import hashlib
@@ -475,19 +553,36 @@ def self_launch(n):
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    # the ranks set up side by side (workload generation, the host halves of preparation and verification): their
+    # OpenMP teams share the host's cores instead of each taking all of them
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def rank_report(torch, dist, world, backend, local_rank, coll_device):
-    """What the collective layer saw: world size, backend, the device ordinal of every rank."""
+def rank_report(torch, dist, world, backend, local_rank, coll_device, rank_ms=None):
+    """What the collective layer saw: world size and backend as it reports them, and per rank the device ordinal, its PCI
+    address (two ranks on one GPU show the same one) and the rank's own time for the timed region."""
+    def pci(i):
+        try:
+            p = torch.cuda.get_device_properties(i)
+            return [int(getattr(p, "pci_domain_id", 0)), int(getattr(p, "pci_bus_id", -1)), int(getattr(p, "pci_device_id", -1))]
+        except Exception:
+            return [0, -1, -1]
+    mine = [local_rank] + pci(local_rank) + [int(round((rank_ms or 0.0) * 1000.0))]
     if dist is None:
-        return {"world_size": 1, "backend": None, "devices": [local_rank]}
-    t = torch.tensor([local_rank], dtype=torch.int64, device=coll_device)
-    got = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(got, t)
-    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": [int(g.item()) for g in got]}
+        rows, ws, be = [mine], 1, None
+    else:
+        t = torch.tensor(mine, dtype=torch.int64, device=coll_device)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        rows, ws, be = [[int(v) for v in g.tolist()] for g in got], dist.get_world_size(), dist.get_backend()
+    per_rank = [{"rank": r, "device": row[0], "pci": "%04x:%02x:%02x" % (row[1], row[2] & 0xFF, row[3] & 0xFF) if row[2] >= 0 else None,
+                 "ms": row[4] / 1000.0 if rank_ms is not None else None} for r, row in enumerate(rows)]
+    return {"world_size": ws, "backend": be, "devices": [row[0] for row in rows], "per_rank": per_rank,
+            "distinct_gpus": len({(p["device"], p["pci"]) for p in per_rank}),
+            "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}
 
 
 def main():
@@ -545,8 +640,25 @@ def main():
     # P3R_BENCH_BACKEND=gloo exercises the multi-rank path where the ranks cannot have a GPU each
     # (several ranks share device 0); the driver's runs use nccl (= RCCL), one GPU per rank.
     backend = os.environ.get("P3R_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if ndev == 0:
+        print("bench: no GPU visible to this process (torch.cuda.device_count() == 0); this benchmark has no CPU path",
+              file=sys.stderr)
+        sys.exit(2)
+    if backend == "nccl" and world > 1 and ndev < world:
+        # one rank per GPU over RCCL: a rank without a device of its own would share one and deadlock or fail inside
+        # ncclCommInitRank with an error that does not say why
+        print(f"bench: --gpus {world} under the nccl backend needs {world} visible GPUs, this node shows {ndev} "
+              f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); P3R_BENCH_BACKEND=gloo runs the ranks on shared devices",
+              file=sys.stderr)
+        sys.exit(2)
+    if world > 1:
+        cap = max(1, (os.cpu_count() or world) // world)
+        cur = os.environ.get("OMP_NUM_THREADS")
+        if cur is None or not cur.isdigit() or int(cur) > cap:
+            os.environ["OMP_NUM_THREADS"] = str(cap)   # before the OpenMP users (harness, oracle) are loaded
     if backend != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        local_rank = local_rank % max(ndev, 1)
     coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
@@ -646,13 +758,14 @@ def main():
         # the reference's tracing-forest view of the same step (scripts/benchmark.sh:87-101 parses it)
         print(p3r.span_report(prof, prof_steps), file=sys.stderr)
 
+    own_dt = dt
     if dist is not None:
         t = torch.tensor([dt, 0.0 if proof_verified else 1.0], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
         proof_verified = proof_verified and float(t[1].item()) == 0.0
+    ranks = rank_report(torch, dist, world, backend, local_rank, coll_device, rank_ms=own_dt / args.steps * 1e3)
     ms_per_step = dt / args.steps * 1e3
-    ranks = rank_report(torch, dist, world, backend, local_rank, coll_device)
 
     # prep-cache miss (recursion.rs:452-501, prep=None): preprocessed columns + LDE + commitment are
     # rebuilt from the circuit before the proof; once, on rank 0 at N = 1
@@ -751,48 +864,49 @@ def main():
             "kernel_ms_per_step": kernel_ms,
             "stage_wall_ms_per_step": stage_ms,
             "dominant_kernel_family": dominant,
-            "roofline": {
-                "kernel": "k_mmcs_hash_rows",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": pmc_traffic_bytes("k_mmcs_hash_rows") if (field, log_h) == ("koala-bear", 20) else None,
-                "traffic_source": f"profiles/{PROFILE_ROUND}/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "same command, tools/profile_round.sh; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, the "
-                                  "gfx950 correction of the microarchitecture guide - the factor 2 for 4-B-per-lane reads is "
-                                  "calibrated on this kernel's known byte count)",
-                "avg_launch_ms": avg_launch_ms,
-                "algorithmic_bytes_per_launch": hash_bytes / launches_per_step if launches_per_step else None,
-                "note": "MMCS leaf hashing is VALU bound (one Poseidon2 permutation per 32 B absorbed), not HBM bound; "
-                        "valu_roofline prices it against the FP64 issue rate",
-            },
         }
-        # The dominant kernel is VALU bound: the permutation runs in FP64 (exact integer arithmetic in doubles,
-        # csrc/poseidon2_f64.cuh), so its price is FP64 instructions per permutation x the FP64 issue rate.
-        # Headline `frac` is against the guide's FP64 vector peak (78.6 TFLOP/s = 39.3 T FMA lane-ops/s); both
-        # inputs of the measured variant come from named files of profiles/<round>/ (committed_valu_model).
+        # `roofline`: the dominant kernel against the roof that binds it.  MMCS leaf hashing is one Poseidon2 permutation
+        # per 32 B absorbed: it is bound by VALU issue - the permutation runs in FP64 (exact integer arithmetic in
+        # doubles, csrc/poseidon2_f64.cuh), so its price is FP64 instructions per permutation x the FP64 issue rate
+        # (guide: 78.6 TFLOP/s FP64 vector = 39.3 T FMA lane-ops/s).  Instructions per permutation and the measured
+        # v_fma_f64 rate come from named files of profiles/<round>/ (committed_valu_model); the kernel's HBM side
+        # (algorithmic bytes, PMC traffic) is the sub-object `hbm`.
         hash_total_ms = kernel_ms.get("mmcs_hash_rows", 0.0)
-        if hash_total_ms:
-            insts, fma_rate = committed_valu_model(field)
-            ach = hash_perms / (hash_total_ms * 1e-3)
-            line["valu_roofline"] = {"kernel": "k_mmcs_hash_rows", "bound": "fp64-valu",
-                                     "achieved": ach, "unit": "Poseidon2 perms/s",
-                                     "valu_insts_per_perm": insts,
-                                     "peak": (FP64_FMA_SPEC / insts) if insts else None,
-                                     "frac": (ach * insts / FP64_FMA_SPEC) if insts else None,
-                                     "peak_lane_ops_per_s": FP64_FMA_SPEC,
-                                     "peak_measured_lane_ops_per_s": fma_rate,
-                                     "frac_measured": (ach * insts / fma_rate) if insts and fma_rate else None,
-                                     "perms_per_step_in_kernel": hash_perms,
-                                     "sources": {"valu_insts_per_perm": f"profiles/{PROFILE_ROUND}/pmc_hash_rows.json "
-                                                                        "(SQ_INSTS_VALU x 64 / permutations, tools/pmc_hash_rows.py)",
-                                                 "peak_measured_lane_ops_per_s": f"profiles/{PROFILE_ROUND}/microbench_int_rates.txt "
-                                                                                 "(v_fma_f64 line, tools/microbench/int_rates)",
-                                                 "peak_lane_ops_per_s": "MI355X_MICROARCH.md: 78.6 TFLOP/s FP64 vector"}}
+        insts, fma_rate, vsrc = committed_valu_model(field)
+        ach = hash_perms / (hash_total_ms * 1e-3) if hash_total_ms else None
+        traffic = pmc_traffic_bytes("k_mmcs_hash_rows") if (field, log_h) == ("koala-bear", 20) else None
+        line["roofline"] = {
+            "kernel": "k_mmcs_hash_rows",
+            "bound": "valu-issue",
+            "achieved": (ach * insts / 1e12) if ach and insts else None,
+            "peak": FP64_FMA_SPEC / 1e12,
+            "unit": "T FP64 lane-ops/s (MI355X_MICROARCH.md: 78.6 TFLOP/s FP64 vector = 39.3 T FMA lane-ops/s)",
+            "frac": (ach * insts / FP64_FMA_SPEC) if ach and insts else None,
+            "traffic": traffic,
+            "avg_launch_ms": avg_launch_ms,
+            "perms_per_s": ach,
+            "perms_per_step_in_kernel": hash_perms,
+            "valu_insts_per_perm": insts,
+            "peak_perms_per_s": (FP64_FMA_SPEC / insts) if insts else None,
+            "peak_measured_lane_ops_per_s": fma_rate,
+            "frac_measured": (ach * insts / fma_rate) if ach and insts and fma_rate else None,
+            "sources": {"valu_insts_per_perm": f"{vsrc.get('valu_insts_per_perm')} (SQ_INSTS_VALU x 64 / permutations, "
+                                               "tools/pmc_hash_rows.py)",
+                        "peak_measured_lane_ops_per_s": f"{vsrc.get('peak_measured_lane_ops_per_s')} (v_fma_f64 line, "
+                                                        "tools/microbench/int_rates)",
+                        "traffic": f"{profile_file('pmc_traffic.json')[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "same command, tools/profile_round.sh; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 "
+                                   "correction of the microarchitecture guide - the factor 2 for 4-B-per-lane reads is calibrated on "
+                                   "this kernel's known byte count)"},
+            "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                    "algorithmic_bytes_per_launch": hash_bytes / launches_per_step if launches_per_step else None,
+                    "traffic_vs_algorithmic": (traffic / (hash_bytes / launches_per_step)) if traffic and launches_per_step else None,
+                    "note": "4 w + 32 B per LDE row; not the binding roof of this kernel"},
+        }
         # The streaming families against HBM, from the same algorithmic byte counts as DESIGN.md §3/§7.
         line["hbm_families"] = hbm_families(cpd.table_heights, widths, packing, kernel_ms)
+        line["proof_roofline"] = proof_roofline(field, cpd.table_heights, widths, packing, perms, insts, hash_bytes, ms_per_step,
+                                                line["hbm_families"])
         if not args.no_cpu_baseline and world == 1:
             lh = args.cpu_baseline_log_height
             cdt, crun, cores = cpu_baseline(field, lh)

@@ -13,6 +13,7 @@
 //                                  constraints), :1137-1158 (inner permutation AIR),
 //                                  :1790-1893 (interactions); prep row preprocessed.rs:160-
 #pragma once
+#include "run_schedule.h"
 #include "field.h"
 #include "poseidon2.h"
 
@@ -25,7 +26,7 @@ constexpr int kMaxExtD = 8;  // widest circuit extension: bus tuples hold at mos
 //   [0..8) in_ctl | 8 length tag | 9 cap_chain_enable | [10..18) rate sponge-chain sel | [18..26) rate Merkle-chain sel
 //   | [26..42) input idx | [42..50) output idx | [50..58) out_ctl | 58 mmcs idx | 59 mmcs_merkle_flag | 60 new_start
 //   | 61 merkle_path
-constexpr int kP2D1Hdr = 26, kP2D1Tail = 58, kP2D1PrepWidth = 62;
+// (kP2D1Hdr, kP2D1Tail, kP2D1PrepWidth: run_schedule.h - the device-side preparation writes the same rows)
 
 struct AirParams {
   int kind;

@@ -1134,10 +1134,9 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   // Device-side preparation (prep_device.hip): the op list crosses PCIe once; preprocessed columns, ALU lane
   // schedule and execution schedule are built in HBM.  A circuit it flags (malformed, unclaimed private input,
   // a witness nobody sets ...) goes through the host restatement below, which raises the reference's error.
-  // (circuits of extension degree 1 / 5 take the host restatement: the device pass is written for D = 4)
+  // (circuit degrees 1, 4 and 5 - the degrees the runner computes in - and both Recompose kinds)
   const uint32_t ext_d = ctx->cfg.ext_degree;
-  // (so do circuits with Recompose ops of the coefficient-lookup kind: the device pass flags them)
-  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr || ext_d != 4;   // read per call: the equality tests flip it
+  const bool host_prep = getenv("P3R_PREP_HOST") != nullptr;   // read per call: the equality tests flip it
   if (!host_prep) {
     prof_stage(ctx, "prep_device");
     DevPrep R;

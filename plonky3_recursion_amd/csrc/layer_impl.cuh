@@ -410,19 +410,23 @@ std::unique_ptr<p3r_layer> layer_from_device(p3r_ctx* ctx, DevPrep& R, const p3r
   if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
   L->has_p2 = R.counts.n_p2 > 0;
   L->has_recompose = R.counts.n_recompose > 0;
+  L->has_recompose_coeff = R.counts.n_recompose_coeff > 0;
+  L->recompose_coeff = R.recompose_coeff;
   L->h_const = R.h[0]; L->h_public = R.h[1]; L->h_alu = R.h[2]; L->h_p2 = R.h[3]; L->h_recompose = R.h[4];
+  L->h_recompose_coeff = R.h[5];
   L->alu_rows = R.alu_rows;
   L->alu_plan = std::move(R.alu_plan);
   L->alu_prev_src = std::move(R.alu_prev_src);
-  const p3r_air_desc airs[5] = {{P3R_AIR_CONST, 1, 2, 0},
+  const p3r_air_desc airs[6] = {{P3R_AIR_CONST, 1, 2, 0},
                                 {P3R_AIR_PUBLIC, L->public_lanes, 2, 0},
                                 {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
                                 {P3R_AIR_POSEIDON2, 1, 2, 0},
-                                {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 0}};
-  p3r_air_desc present[5];
+                                {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, L->recompose_coeff ? 1u : 0u},
+                                {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 1u}};
+  p3r_air_desc present[6];
   std::vector<std::unique_ptr<p3r_dmat>> traces;
   size_t n = 0;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 6; ++i) {
     if (L->slot_of(i) < 0) continue;
     present[n++] = airs[i];
     traces.push_back(std::move(R.prep[i]));

@@ -1,6 +1,6 @@
 // Device-side preparation of a verifier circuit: what `prove_next_layer` pays with prep = None
 // (recursion/src/recursion.rs:452-501) before the proof itself -
-//   Circuit::generate_preprocessed_columns::<4>      circuit/src/circuit.rs:237-510
+//   Circuit::generate_preprocessed_columns::<D>      circuit/src/circuit.rs:237-510   (D = 1, 4, 5: the context's ext_degree)
 //   get_airs_and_degrees_with_prep                   circuit-prover/src/common.rs:127-390
 //   poseidon_preprocess_for_prover                   circuit-prover/src/batch_stark_prover.rs:97-246
 //   AluAir::compute_schedule + build_scheduled_preprocessed_trace
@@ -22,9 +22,10 @@ struct DevPrep {
   // ---- CircuitProverData inputs: per-table preprocessed traces (column-major, Montgomery, padded)
   p3r_layer_desc_counts counts{};
   uint32_t public_lanes = 1, alu_lanes = 1;  // effective (reduce_lanes_if_dummy, batch_stark_prover.rs:1305-1318)
-  size_t h[5] = {0, 0, 0, 0, 0};             // padded heights, 0 = table absent
+  size_t h[6] = {0, 0, 0, 0, 0, 0};          // padded heights, 0 = table absent; [5] = the second Recompose table
   size_t alu_rows = 0;
-  std::unique_ptr<p3r_dmat> prep[5];
+  std::unique_ptr<p3r_dmat> prep[6];
+  bool recompose_coeff = false;              // slot 4 holds the `recompose/coeff` kind (the circuit has no plain Recompose op)
   DevBuf alu_plan, alu_prev_src;
   // ---- execution schedule: the large arrays stay on the device, `sched` carries the per-level offsets,
   // the launch plan and the counts the runner needs on the host

@@ -23,8 +23,16 @@ constexpr int kB = 256;
 constexpr uint32_t kUnset = 0xFFFFFFFFu;
 inline unsigned nblk(size_t n) { return (unsigned)((n + kB - 1) / kB); }
 
+// The circuit's extension degree D and the layout of its Poseidon2 ops (circuit_impl.cuh::P2Shape): D = 4 -> four
+// input limbs, two CTL-exposed output limbs; otherwise base mode -> sixteen one-element slots, eight exposed outputs.
+// ext = [in[il].., mmcs_index_sum, mmcs_bit, n_out, out..].
+struct Shape {
+  uint32_t D, il, ol, ol_full;
+};
+inline Shape shape_of(uint32_t D) { return D == 4 ? Shape{4, 4, 2, 4} : Shape{D, 16, 8, 16}; }
+
 // witness flag bits
-enum : uint32_t { WF_PRIVATE = 1, WF_CP = 2, WF_HINT = 4, WF_DUP_P2 = 8, WF_DUP_REC = 16 };
+enum : uint32_t { WF_PRIVATE = 1, WF_CP = 2, WF_HINT = 4, WF_DUP_P2 = 8, WF_DUP_REC = 16, WF_DUP_REC_COEFF = 32 };
 // static per-op flags (beyond RUN_*): bits 12..
 enum : uint32_t { OF_READY = 1u << 12, OF_LINK = 1u << 13, OF_LIGHT = 1u << 14 };
 // why the device pass gives up (any bit set: the host path reports)
@@ -46,7 +54,7 @@ __device__ __forceinline__ bool is_hint(uint32_t k) {
 // validate_circuit (circuit_impl.cuh) + the canonical check of constants, as a yes / no per op
 template <class PP>
 __global__ void __launch_bounds__(kB) k_validate(const uint32_t* __restrict__ ops, size_t n_ops, const uint32_t* __restrict__ ext,
-                                                 size_t n_ext, uint32_t nw, uint32_t* __restrict__ bad) {
+                                                 size_t n_ext, uint32_t nw, Shape sh, uint32_t* __restrict__ bad) {
   const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
   if (i >= n_ops) return;
   const Op op = load_op(ops, i);
@@ -56,8 +64,8 @@ __global__ void __launch_bounds__(kB) k_validate(const uint32_t* __restrict__ op
   auto opt = [&](uint32_t w) { return w == kNoW || w < nw; };
   if (ok) switch (op.kind) {
     case P3R_OP_CONST:
-      ok = wid(op.out) && op.ext_len == 4;
-      if (ok) for (int k = 0; k < 4; ++k) ok = ok && e[k] < PP::P;
+      ok = wid(op.out) && op.ext_len == sh.D;
+      if (ok) for (uint32_t k = 0; k < sh.D; ++k) ok = ok && e[k] < PP::P;
       break;
     case P3R_OP_PUBLIC: ok = wid(op.out); break;
     case P3R_OP_ALU_ADD: case P3R_OP_ALU_MUL: case P3R_OP_ALU_BOOL_CHECK: case P3R_OP_ALU_MUL_ADD: case P3R_OP_ALU_HORNER_ACC:
@@ -65,26 +73,31 @@ __global__ void __launch_bounds__(kB) k_validate(const uint32_t* __restrict__ op
       if (op.kind == P3R_OP_ALU_HORNER_ACC && (op.c == kNoW || op.aux == kNoW)) ok = false;
       break;
     case P3R_OP_HINT_EXT_DECOMPOSITION:
-      ok = wid(op.a) && op.ext_len == 4;
-      if (ok) for (uint32_t k = 0; k < 4; ++k) ok = ok && wid(e[k]);
+      ok = wid(op.a) && op.ext_len == sh.D;
+      if (ok) for (uint32_t k = 0; k < sh.D; ++k) ok = ok && wid(e[k]);
       break;
     case P3R_OP_HINT_BINARY_DECOMPOSITION:
-      ok = wid(op.a) && op.ext_len <= 31 * 4;
+      ok = wid(op.a) && op.ext_len <= 31 * sh.D;
       if (ok) for (uint32_t k = 0; k < op.ext_len; ++k) ok = ok && wid(e[k]);
       break;
-    case P3R_OP_POSEIDON2_PERM:
-      ok = op.ext_len >= 7 && (e[6] == 2 || e[6] == 4) && op.ext_len == 7 + e[6];
+    case P3R_OP_POSEIDON2_PERM: {
+      const uint32_t hdr = sh.il + 3;
+      ok = op.ext_len >= hdr && (e[hdr - 1] == sh.ol || e[hdr - 1] == sh.ol_full) && op.ext_len == hdr + e[hdr - 1];
       if (ok) {
-        for (uint32_t k = 0; k < 6; ++k) ok = ok && opt(e[k]);
-        for (uint32_t k = 0; k < e[6]; ++k) ok = ok && opt(e[7 + k]);
-        if ((op.aux & 2) && e[5] == kNoW) ok = false;
+        for (uint32_t k = 0; k < sh.il + 2; ++k) ok = ok && opt(e[k]);
+        for (uint32_t k = 0; k < e[hdr - 1]; ++k) ok = ok && opt(e[hdr + k]);
+        if ((op.aux & 2) && e[sh.il + 1] == kNoW) ok = false;
+        if (sh.D != 4 && !(op.aux & 2))   // compact D = 1 sponge rows: the capacity slots stay empty (executor.rs:712-725)
+          for (uint32_t k = sh.ol; k < sh.il; ++k) ok = ok && e[k] == kNoW;
+        if (sh.D != 4 && op.b > 255) ok = false;   // absorb_len is the length tag
         if (op.a >= n_ops) ok = false;
       }
       break;
+    }
     case P3R_OP_RECOMPOSE:
-      // a `recompose/coeff` op (aux = 1) hands the circuit over to the host restatement, like a malformed one
-      ok = wid(op.out) && op.a < n_ops && op.ext_len == 4 && (op.aux == 0u || op.aux == kNoW);  // any other aux: the host path rejects it
-      if (ok) for (uint32_t k = 0; k < 4; ++k) ok = ok && wid(e[k]);
+      // aux: 0 / P3R_NO_WITNESS = `recompose`, 1 = `recompose/coeff`; anything else the host path rejects
+      ok = wid(op.out) && op.a < n_ops && op.ext_len == sh.D && (op.aux == 0u || op.aux == 1u || op.aux == kNoW);
+      if (ok) for (uint32_t k = 0; k < sh.D; ++k) ok = ok && wid(e[k]);
       break;
     default: ok = false;
   }
@@ -119,13 +132,18 @@ struct PairAluP2 {
     return (uint64_t)is_alu(k) | ((uint64_t)(k == P3R_OP_POSEIDON2_PERM) << 32);
   }
 };
-struct PairRecExt {  // recompose rows | cells this op appends to the device ext array
+struct PairRecExt {  // plain recompose rows | cells this op appends to the device ext array
   const uint32_t* ops;
+  uint32_t D;
   __device__ uint64_t operator()(size_t i) const {
     const uint32_t k = ops[8 * i];
-    const uint32_t cells = (k == P3R_OP_CONST || k == P3R_OP_RECOMPOSE) ? 4u : is_hint(k) ? ops[8 * i + 7] : 0u;
-    return (uint64_t)(k == P3R_OP_RECOMPOSE) | ((uint64_t)cells << 32);
+    const uint32_t cells = (k == P3R_OP_CONST || k == P3R_OP_RECOMPOSE) ? D : is_hint(k) ? ops[8 * i + 7] : 0u;
+    return (uint64_t)(k == P3R_OP_RECOMPOSE && ops[8 * i + 5] != 1u) | ((uint64_t)cells << 32);
   }
+};
+struct FlagRecCoeff {  // rows of the `recompose/coeff` kind (aux = 1)
+  const uint32_t* ops;
+  __device__ uint32_t operator()(size_t i) const { return (ops[8 * i] == P3R_OP_RECOMPOSE && ops[8 * i + 5] == 1u) ? 1u : 0u; }
 };
 
 template <class Fn>
@@ -159,7 +177,8 @@ __global__ void __launch_bounds__(kB) k_table_lists(const uint32_t* __restrict__
                                                     const uint64_t* __restrict__ s_ap, const uint64_t* __restrict__ s_re,
                                                     uint32_t* __restrict__ const_ops, uint32_t* __restrict__ public_ops,
                                                     uint32_t* __restrict__ alu_ops, uint32_t* __restrict__ p2_ops,
-                                                    uint32_t* __restrict__ rec_ops) {
+                                                    uint32_t* __restrict__ rec_ops, const uint32_t* __restrict__ s_rc,
+                                                    uint32_t* __restrict__ rec_coeff_ops) {
   const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
   if (i >= n_ops) return;
   const uint32_t k = ops[8 * i];
@@ -167,7 +186,10 @@ __global__ void __launch_bounds__(kB) k_table_lists(const uint32_t* __restrict__
   else if (k == P3R_OP_PUBLIC) public_ops[(uint32_t)(s_cp[i] >> 32)] = (uint32_t)i;
   else if (is_alu(k)) alu_ops[(uint32_t)s_ap[i]] = (uint32_t)i;
   else if (k == P3R_OP_POSEIDON2_PERM) p2_ops[(uint32_t)(s_ap[i] >> 32)] = (uint32_t)i;
-  else if (k == P3R_OP_RECOMPOSE) rec_ops[(uint32_t)s_re[i]] = (uint32_t)i;
+  else if (k == P3R_OP_RECOMPOSE) {
+    if (ops[8 * i + 5] == 1u) rec_coeff_ops[s_rc[i]] = (uint32_t)i;
+    else rec_ops[(uint32_t)s_re[i]] = (uint32_t)i;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ first touches
@@ -193,7 +215,7 @@ __global__ void __launch_bounds__(kB) k_mark_hint(const uint32_t* __restrict__ o
 // tdef[w]: time (op index + 1) of the op that DEFINES w on the bus; stime[w]: time of the op that SETS w at run time.
 // This pass takes every role that defines / sets unconditionally; k_times_fix adds the two conditional roles.
 __global__ void __launch_bounds__(kB) k_times(const uint32_t* __restrict__ ops, size_t n_ops, const uint32_t* __restrict__ ext,
-                                              const uint32_t* __restrict__ wflags, uint32_t* __restrict__ tdef,
+                                              const uint32_t* __restrict__ wflags, Shape sh, uint32_t* __restrict__ tdef,
                                               uint32_t* __restrict__ stime) {
   const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
   if (i >= n_ops) return;
@@ -204,10 +226,10 @@ __global__ void __launch_bounds__(kB) k_times(const uint32_t* __restrict__ ops, 
     case P3R_OP_CONST: atomicMin(&tdef[op.out], t); atomicMin(&stime[op.out], t); break;
     case P3R_OP_PUBLIC: atomicMin(&tdef[op.out], t); break;
     case P3R_OP_POSEIDON2_PERM:
-      for (uint32_t l = 0; l < e[6]; ++l) {
-        const uint32_t w = e[7 + l];
+      for (uint32_t l = 0; l < e[sh.il + 2]; ++l) {
+        const uint32_t w = e[sh.il + 3 + l];
         if (w == kNoW) continue;
-        if (l < 2) atomicMin(&tdef[w], t);   // the CTL-exposed outputs (circuit.rs:464-491)
+        if (l < sh.ol) atomicMin(&tdef[w], t);   // the CTL-exposed outputs (circuit.rs:464-491)
         atomicMin(&stime[w], t);
       }
       break;
@@ -251,7 +273,7 @@ __global__ void __launch_bounds__(kB) k_times_fix(const uint32_t* __restrict__ o
 // ------------------------------------------------------------------------------------------------ bus roles + read counts
 // generate_preprocessed_columns pass 1 (circuit_impl.cuh::circuit_tables): who reads what
 __global__ void __launch_bounds__(kB) k_roles(const uint32_t* __restrict__ ops, size_t n_ops, const uint32_t* __restrict__ ext,
-                                              uint32_t* __restrict__ wflags, const uint32_t* __restrict__ tdef,
+                                              uint32_t* __restrict__ wflags, const uint32_t* __restrict__ tdef, Shape sh,
                                               const uint64_t* __restrict__ s_ap, uint32_t* __restrict__ reads,
                                               uint32_t* __restrict__ roles /* per ALU row: a_state | c_state<<8 | b_creator<<16 | out_creator<<24 */) {
   const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
@@ -264,17 +286,20 @@ __global__ void __launch_bounds__(kB) k_roles(const uint32_t* __restrict__ ops, 
     case P3R_OP_CONST: case P3R_OP_PUBLIC: case P3R_OP_HINT_EXT_DECOMPOSITION: case P3R_OP_HINT_BINARY_DECOMPOSITION: break;
     case P3R_OP_POSEIDON2_PERM: {
       const bool merkle = op.aux & 2;
-      for (int l = 0; l < 4; ++l)
+      for (uint32_t l = 0; l < sh.il; ++l)
         if (e[l] != kNoW && !merkle) atomicAdd(&reads[e[l]], 1u);  // Merkle rows name the limb without a bus read
-      for (int l = 0; l < 2; ++l) {
-        const uint32_t w = e[7 + l];
+      for (uint32_t l = 0; l < sh.ol; ++l) {
+        const uint32_t w = e[sh.il + 3 + l];
         if (w == kNoW) continue;
-        if (def(w) || (l == 1 && e[7] == w)) { atomicOr(&wflags[w], WF_DUP_P2); atomicAdd(&reads[w], 1u); }
+        bool earlier = false;   // an earlier output of this same row already defined it
+        for (uint32_t j = 0; j < l; ++j) earlier |= e[sh.il + 3 + j] == w;
+        if (def(w) || earlier) { atomicOr(&wflags[w], WF_DUP_P2); atomicAdd(&reads[w], 1u); }
       }
       break;
     }
     case P3R_OP_RECOMPOSE:
-      if (def(op.out)) { atomicOr(&wflags[op.out], WF_DUP_REC); atomicAdd(&reads[op.out], 1u); }
+      // dup_npo_outputs is kept per op type: one flag per Recompose kind
+      if (def(op.out)) { atomicOr(&wflags[op.out], op.aux == 1u ? WF_DUP_REC_COEFF : WF_DUP_REC); atomicAdd(&reads[op.out], 1u); }
       break;
     default: {
       const bool out_def = def(op.out), b_def = def(op.b);
@@ -297,11 +322,12 @@ __global__ void __launch_bounds__(kB) k_roles(const uint32_t* __restrict__ ops, 
 // the accumulator of a Merkle chain is read when the row is followed by a chain boundary; the first padding row
 // counts as one (batch_stark_prover.rs:149-176)
 __global__ void __launch_bounds__(kB) k_acc_reads(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
-                                                  const uint32_t* __restrict__ p2_ops, size_t n, size_t h, uint32_t* __restrict__ reads) {
+                                                  const uint32_t* __restrict__ p2_ops, size_t n, size_t h, Shape sh,
+                                                  uint32_t* __restrict__ reads) {
   const size_t r = (size_t)blockIdx.x * kB + threadIdx.x;
   if (r >= n) return;
   const Op op = load_op(ops, p2_ops[r]);
-  const uint32_t acc = ext[op.ext_off + 4];
+  const uint32_t acc = ext[op.ext_off + sh.il];
   if (acc == kNoW || !(op.aux & 2)) return;
   const bool next_ns = r + 1 < n ? (ops[8 * (size_t)p2_ops[r + 1] + 5] & 1) : (h > n ? true : (ops[8 * (size_t)p2_ops[0] + 5] & 1));
   if (next_ns) atomicAdd(&reads[acc], 1u);
@@ -317,7 +343,7 @@ template <class PP>
 struct Cells {  // canonical -> the Montgomery cells the traces hold
   using F = Fp<PP>;
   static __device__ __forceinline__ uint32_t mont(uint32_t canonical) { return F::from_canonical(canonical).v; }
-  static __device__ __forceinline__ uint32_t scaled(uint32_t w) { return mont((uint32_t)(((uint64_t)w * 4) % PP::P)); }
+  static __device__ __forceinline__ uint32_t scaled(uint32_t w, uint32_t D) { return mont((uint32_t)(((uint64_t)w * D) % PP::P)); }
   static __device__ __forceinline__ uint32_t mult(const uint32_t* reads, uint32_t w) { return mont(reads[w] % PP::P); }
   static __device__ __forceinline__ uint32_t neg_mult(const uint32_t* reads, uint32_t w) {
     const uint32_t m = reads[w] % PP::P;
@@ -331,7 +357,7 @@ struct Cells {  // canonical -> the Montgomery cells the traces hold
 template <class PP>
 __global__ void __launch_bounds__(kB) k_prep_simple(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ list, size_t n, int lanes,
                                                     int recompose, const uint32_t* __restrict__ reads, const uint32_t* __restrict__ wflags,
-                                                    size_t h, uint32_t* __restrict__ out) {
+                                                    uint32_t D, size_t h, uint32_t* __restrict__ out) {
   const size_t j = (size_t)blockIdx.x * kB + threadIdx.x;
   if (j >= n) return;
   using C = Cells<PP>;
@@ -339,9 +365,30 @@ __global__ void __launch_bounds__(kB) k_prep_simple(const uint32_t* __restrict__
   const size_t row = j / lanes, lane = j % lanes;
   uint32_t m = C::mult(reads, w);
   if (recompose && (wflags[w] & WF_DUP_REC)) m = C::neg1();
-  const uint32_t idx = C::scaled(w);
+  const uint32_t idx = C::scaled(w, D);
   out[(lane * 2 + 0) * h + row] = recompose ? idx : m;
   out[(lane * 2 + 1) * h + row] = recompose ? m : idx;
+}
+// Recompose rows of the coefficient-lookup kind (recompose.rs:293-356): [D * out, mult, (D * coeff_k, mult_k) x D] per lane -
+// a coefficient that is a hint output is created by this row with its read count, any other is named with multiplicity 0
+template <class PP>
+__global__ void __launch_bounds__(kB) k_prep_rec_coeff(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
+                                                       const uint32_t* __restrict__ list, size_t n, int lanes,
+                                                       const uint32_t* __restrict__ reads, const uint32_t* __restrict__ wflags, uint32_t D,
+                                                       size_t h, uint32_t* __restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (j >= n) return;
+  using C = Cells<PP>;
+  const Op op = load_op(ops, list[j]);
+  const size_t row = j / lanes, lane = j % lanes, plw = 2 + 2 * (size_t)D;
+  auto put = [&](size_t c, uint32_t v) { out[(lane * plw + c) * h + row] = v; };
+  put(0, C::scaled(op.out, D));
+  put(1, (wflags[op.out] & WF_DUP_REC_COEFF) ? C::neg1() : C::mult(reads, op.out));
+  for (uint32_t k = 0; k < D; ++k) {
+    const uint32_t w = ext[op.ext_off + k];
+    put(2 + 2 * k, C::scaled(w, D));
+    put(3 + 2 * k, (wflags[w] & WF_HINT) ? C::mult(reads, w) : 0u);
+  }
 }
 
 // Poseidon2 preprocessed rows (poseidon2-circuit-air/src/air.rs:697-794, non-compact D = 4 layout) + padding (:613-649)
@@ -363,27 +410,64 @@ __global__ void __launch_bounds__(kB) k_prep_p2(const uint32_t* __restrict__ ops
   const uint32_t one = C::one();
   for (int l = 0; l < 4; ++l) {
     const bool ctl = e[l] != kNoW;
-    put(l * 4, C::scaled(ctl ? e[l] : 0));
+    put(l * 4, C::scaled(ctl ? e[l] : 0, 4));
     put(l * 4 + 1, ctl ? one : 0);
     put(l * 4 + 2, (!ns && !mp && !ctl) ? one : 0);
     put(l * 4 + 3, (!ns && mp && !ctl) ? one : 0);
   }
   for (int l = 0; l < 2; ++l) {
     const uint32_t w = e[7 + l];
-    put(16 + 2 * l, C::scaled(w != kNoW ? w : 0));
+    put(16 + 2 * l, C::scaled(w != kNoW ? w : 0, 4));
     put(17 + 2 * l, w == kNoW ? 0u : (wflags[w] & WF_DUP_P2) ? C::neg1() : C::mult(reads, w));
   }
-  put(20, C::scaled(en ? e[4] : 0));
+  put(20, C::scaled(en ? e[4] : 0, 4));
   put(21, (en && mp) ? one : 0);
   put(22, ns ? one : 0);
   put(23, mp ? one : 0);
+}
+// the compact D = 1 rows of circuits of degree 1 / 5 (air.rs:730-763, executor.rs:720-741; layer_impl.cuh::layer_create):
+// [in_ctl x 8, length tag, cap_chain_enable, 8 + 8 chain selectors | 16 + 8 indices, 8 out_ctl | index_sum idx, 3 flags]
+template <class PP>
+__global__ void __launch_bounds__(kB) k_prep_p2_d1(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
+                                                   const uint32_t* __restrict__ p2_ops, size_t n, const uint32_t* __restrict__ reads,
+                                                   const uint32_t* __restrict__ wflags, uint32_t D, size_t h, uint32_t* __restrict__ out) {
+  const size_t r = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (r >= h) return;
+  using C = Cells<PP>;
+  if (r >= n) {
+    for (int c = 0; c < kP2D1PrepWidth; ++c) out[(size_t)c * h + r] = (c == kP2D1Tail + 2 && r == n) ? C::one() : 0u;
+    return;
+  }
+  const Op op = load_op(ops, p2_ops[r]);
+  const uint32_t* e = ext + op.ext_off;
+  const bool ns = op.aux & 1, mp = op.aux & 2, en = e[16] != kNoW;
+  auto put = [&](int c, uint32_t v) { out[(size_t)c * h + r] = v; };
+  const uint32_t one = C::one();
+  for (int l = 0; l < 8; ++l) {
+    const bool ctl = e[l] != kNoW;
+    put(l, ctl ? one : 0);
+    put(10 + l, (!ns && !mp && !ctl) ? one : 0);
+    put(18 + l, (!ns && mp && !ctl) ? one : 0);
+  }
+  put(8, C::mont(op.b));   // absorb_len (<= 255: validated)
+  put(9, !ns ? one : 0);
+  for (int l = 0; l < 16; ++l) put(kP2D1Hdr + l, C::scaled(e[l] != kNoW ? e[l] : 0, D));
+  for (int l = 0; l < 8; ++l) {
+    const uint32_t w = e[19 + l];
+    put(kP2D1Hdr + 16 + l, C::scaled(w != kNoW ? w : 0, D));
+    put(kP2D1Hdr + 24 + l, w == kNoW ? 0u : (wflags[w] & WF_DUP_P2) ? C::neg1() : C::mult(reads, w));
+  }
+  put(kP2D1Tail, C::scaled(en ? e[16] : 0, D));
+  put(kP2D1Tail + 1, (en && mp) ? one : 0);
+  put(kP2D1Tail + 2, ns ? one : 0);
+  put(kP2D1Tail + 3, mp ? one : 0);
 }
 
 // AluPrepLaneCols of ALU row j (common.rs:198-323), Montgomery
 template <class PP>
 __device__ __forceinline__ void alu_prep13(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ alu_ops,
                                            const uint32_t* __restrict__ roles, const uint32_t* __restrict__ reads, uint32_t j,
-                                           uint32_t row[13]) {
+                                           uint32_t D, uint32_t row[13]) {
   using C = Cells<PP>;
   const Op op = load_op(ops, alu_ops[j]);
   const uint32_t r = roles[j];
@@ -396,10 +480,10 @@ __device__ __forceinline__ void alu_prep13(const uint32_t* __restrict__ ops, con
   row[2] = op.kind == P3R_OP_ALU_BOOL_CHECK ? one : 0;
   row[3] = op.kind == P3R_OP_ALU_MUL_ADD ? one : 0;
   row[4] = op.kind == P3R_OP_ALU_HORNER_ACC ? one : 0;
-  row[5] = C::scaled(op.a);
-  row[6] = C::scaled(op.b);
-  row[7] = C::scaled(c_w);
-  row[8] = C::scaled(op.out);
+  row[5] = C::scaled(op.a, D);
+  row[6] = C::scaled(op.b, D);
+  row[7] = C::scaled(c_w, D);
+  row[8] = C::scaled(op.out, D);
   row[9] = b_creator ? C::mult(reads, op.b) : C::neg1();
   row[10] = out_creator ? C::mult(reads, op.out) : C::neg1();
   row[11] = reader_col(a_state, op.a);
@@ -488,8 +572,8 @@ __global__ void __launch_bounds__(kB) k_alu_prev(const AluPlanEntry* __restrict_
 template <class PP>
 __global__ void __launch_bounds__(kB) k_prep_alu(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ alu_ops,
                                                  const uint32_t* __restrict__ roles, const uint32_t* __restrict__ reads,
-                                                 const AluPlanEntry* __restrict__ plan, size_t rows, int lanes, int k_max, size_t h,
-                                                 uint32_t* __restrict__ out) {
+                                                 const AluPlanEntry* __restrict__ plan, size_t rows, int lanes, int k_max, uint32_t D,
+                                                 size_t h, uint32_t* __restrict__ out) {
   const size_t s = (size_t)blockIdx.x * kB + threadIdx.x;
   if (s >= rows * (size_t)lanes) return;
   using F = Fp<PP>;
@@ -498,13 +582,13 @@ __global__ void __launch_bounds__(kB) k_prep_alu(const uint32_t* __restrict__ op
   auto put = [&](size_t c, uint32_t v) { out[c * h + row] = v; };
   uint32_t p[13];
   if (en.kind == PLAN_OP) {
-    alu_prep13<PP>(ops, alu_ops, roles, reads, en.first, p);
+    alu_prep13<PP>(ops, alu_ops, roles, reads, en.first, D, p);
     for (int c = 0; c < 13; ++c) put(lane * 13 + c, p[c]);
   } else if (en.kind == PLAN_PACKED && lane == 0) {
     const int k = en.k;
     uint32_t last[13];
-    alu_prep13<PP>(ops, alu_ops, roles, reads, en.first, p);
-    alu_prep13<PP>(ops, alu_ops, roles, reads, en.first + k - 1, last);
+    alu_prep13<PP>(ops, alu_ops, roles, reads, en.first, D, p);
+    alu_prep13<PP>(ops, alu_ops, roles, reads, en.first + k - 1, D, last);
     p[8] = last[8];
     p[10] = last[10];
     p[9] = (F::raw(p[9]) * F::from_canonical((uint32_t)k)).v;
@@ -514,7 +598,7 @@ __global__ void __launch_bounds__(kB) k_prep_alu(const uint32_t* __restrict__ op
     put(extra + (k - 2), F::one().v);
     for (int t = 1; t < k; ++t) {
       uint32_t st[13];
-      alu_prep13<PP>(ops, alu_ops, roles, reads, en.first + t, st);
+      alu_prep13<PP>(ops, alu_ops, roles, reads, en.first + t, D, st);
       const size_t q = extra + (k_max - 1) + 6 * (t - 1);
       put(q, st[5]); put(q + 1, st[7]); put(q + 2, st[11]); put(q + 3, st[12]);
       put(q + 4, (mult_a * F::raw(st[11])).v);
@@ -544,7 +628,7 @@ inline std::unique_ptr<p3r_dmat> zero_mat(p3r_ctx* ctx, size_t h, size_t w) {
 // static facts of every op given stime (what the sequential builder reads off its `set` array): direction of an
 // Add / Mul, writes that are comparisons, HornerAcc steps that can join a scan, reads of witnesses nobody sets
 __global__ void __launch_bounds__(kB) k_sched_static(const uint32_t* __restrict__ ops, size_t n_ops, const uint32_t* __restrict__ ext,
-                                                     const uint32_t* __restrict__ stime, uint32_t* __restrict__ oflags,
+                                                     const uint32_t* __restrict__ stime, Shape sh, uint32_t* __restrict__ oflags,
                                                      uint32_t* __restrict__ bad) {
   const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
   if (i >= n_ops) return;
@@ -586,10 +670,10 @@ __global__ void __launch_bounds__(kB) k_sched_static(const uint32_t* __restrict_
     case P3R_OP_HINT_EXT_DECOMPOSITION: case P3R_OP_HINT_BINARY_DECOMPOSITION: f = OF_LIGHT; need(op.a); break;
     case P3R_OP_RECOMPOSE:
       f = OF_LIGHT | (set(op.out) ? RUN_CHECK_OUT : 0);
-      for (int k = 0; k < 4; ++k) need(e[k]);
+      for (uint32_t k = 0; k < sh.D; ++k) need(e[k]);
       break;
     case P3R_OP_POSEIDON2_PERM:
-      for (int l = 0; l < 6; ++l) if (e[l] != kNoW) need(e[l]);
+      for (uint32_t l = 0; l < sh.il + 2; ++l) if (e[l] != kNoW) need(e[l]);
       break;
     default: break;
   }
@@ -682,7 +766,7 @@ struct MaxNpoId {
 // light ops: one thread each
 __global__ void __launch_bounds__(kB) k_level_light(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
                                                     const uint32_t* __restrict__ light_ops, size_t n_light, const uint32_t* __restrict__ oflags,
-                                                    const uint32_t* __restrict__ stime, uint32_t* __restrict__ wlevel,
+                                                    const uint32_t* __restrict__ stime, uint32_t D, uint32_t* __restrict__ wlevel,
                                                     uint32_t* __restrict__ olevel, uint32_t* __restrict__ changed) {
   const size_t k = (size_t)blockIdx.x * kB + threadIdx.x;
   if (k >= n_light) return;
@@ -717,7 +801,7 @@ __global__ void __launch_bounds__(kB) k_level_light(const uint32_t* __restrict__
         if (!dup && stime[w] < t) dep(w);
       }
       break;
-    case P3R_OP_RECOMPOSE: for (int q = 0; q < 4; ++q) dep(e[q]); if (chk_out) dep(op.out); break;
+    case P3R_OP_RECOMPOSE: for (uint32_t q = 0; q < D; ++q) dep(e[q]); if (chk_out) dep(op.out); break;
     default: break;
   }
   lvl += 1;
@@ -788,7 +872,7 @@ __global__ void __launch_bounds__(kB) k_level_chains(const uint32_t* __restrict_
 __global__ void __launch_bounds__(kB) k_level_p2(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
                                                  const uint32_t* __restrict__ p2_ops, const uint32_t* __restrict__ mlist,
                                                  const uint32_t* __restrict__ runs, size_t n_runs, size_t n_rows,
-                                                 const uint32_t* __restrict__ stime, uint32_t* __restrict__ wlevel,
+                                                 const uint32_t* __restrict__ stime, Shape sh, uint32_t* __restrict__ wlevel,
                                                  uint32_t* __restrict__ plevel /* per mode position */, uint32_t* __restrict__ phead,
                                                  uint32_t* __restrict__ changed) {
   const size_t run = ((size_t)blockIdx.x * kB + threadIdx.x) >> 6;
@@ -799,21 +883,24 @@ __global__ void __launch_bounds__(kB) k_level_p2(const uint32_t* __restrict__ op
   bool ch = false;
   for (uint32_t base = m0; base < m1; base += 64) {
     const uint32_t m = base + lane;
-    uint32_t need = 0, outs[4] = {kNoW, kNoW, kNoW, kNoW};
+    uint32_t need = 0;
+    uint32_t outs_mask = 0;            // bit l: output l is written by this row
+    const uint32_t* eo = nullptr;      // its output list
     if (m < m1) {
       const uint32_t i = p2_ops[mlist[m]], t = i + 1;
       const Op op = load_op(ops, i);
       const uint32_t* e = ext + op.ext_off;
+      eo = e + sh.il + 3;
       uint32_t lvl = 0;
-      for (int l = 0; l < 6; ++l) if (e[l] != kNoW) lvl = max(lvl, wlevel[e[l]]);
-      for (uint32_t l = 0; l < e[6]; ++l) {
-        const uint32_t w = e[7 + l];
+      for (uint32_t l = 0; l < sh.il + 2; ++l) if (e[l] != kNoW) lvl = max(lvl, wlevel[e[l]]);
+      for (uint32_t l = 0; l < e[sh.il + 2]; ++l) {
+        const uint32_t w = eo[l];
         if (w == kNoW) continue;
         bool earlier = false;
-        for (uint32_t j = 0; j < l; ++j) earlier |= e[7 + j] == w;
+        for (uint32_t j = 0; j < l; ++j) earlier |= eo[j] == w;
         if (earlier) continue;
         if (stime[w] < t) lvl = max(lvl, wlevel[w]);  // a comparison: the row waits for the value
-        else outs[l] = w;                             // written by this row
+        else outs_mask |= 1u << l;                    // written by this row
       }
       need = lvl + 1;
     }
@@ -824,7 +911,7 @@ __global__ void __launch_bounds__(kB) k_level_p2(const uint32_t* __restrict__ op
       const uint32_t head = (m == m0 || lvl > prev) ? 1u : 0u;
       if (plevel[m] != lvl || phead[m] != head) {
         plevel[m] = lvl; phead[m] = head; ch = true;
-        for (int l = 0; l < 4; ++l) if (outs[l] != kNoW) wlevel[outs[l]] = lvl;
+        for (uint32_t l = 0; l < 16; ++l) if (outs_mask & (1u << l)) wlevel[eo[l]] = lvl;
       }
     }
     carry = __shfl(lvl, 63);
@@ -857,15 +944,15 @@ __global__ void __launch_bounds__(kB) k_iota(uint32_t* __restrict__ v, size_t n)
 // the device ext array: constants (Montgomery), hint output lists (bit 31: compare instead of write), recompose inputs
 template <class PP>
 __global__ void __launch_bounds__(kB) k_emit_ext(const uint32_t* __restrict__ ops, size_t n_ops, const uint32_t* __restrict__ ext,
-                                                 const uint64_t* __restrict__ s_re, const uint32_t* __restrict__ stime,
+                                                 const uint64_t* __restrict__ s_re, const uint32_t* __restrict__ stime, uint32_t D,
                                                  uint32_t* __restrict__ dev_ext) {
   const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
   if (i >= n_ops) return;
   const Op op = load_op(ops, i);
   const uint32_t off = (uint32_t)(s_re[i] >> 32), t = (uint32_t)i + 1;
   const uint32_t* e = ext + op.ext_off;
-  if (op.kind == P3R_OP_CONST) for (int k = 0; k < 4; ++k) dev_ext[off + k] = Fp<PP>::from_canonical(e[k]).v;
-  else if (op.kind == P3R_OP_RECOMPOSE) for (int k = 0; k < 4; ++k) dev_ext[off + k] = e[k];
+  if (op.kind == P3R_OP_CONST) for (uint32_t k = 0; k < D; ++k) dev_ext[off + k] = Fp<PP>::from_canonical(e[k]).v;
+  else if (op.kind == P3R_OP_RECOMPOSE) for (uint32_t k = 0; k < D; ++k) dev_ext[off + k] = e[k];
   else if (is_hint(op.kind))
     for (uint32_t k = 0; k < op.ext_len; ++k) {
       const uint32_t w = e[k];
@@ -874,25 +961,27 @@ __global__ void __launch_bounds__(kB) k_emit_ext(const uint32_t* __restrict__ op
       dev_ext[off + k] = (dup || stime[w] < t) ? (w | RUN_CHECK_BIT) : w;
     }
 }
+// (s_rc / n_rec_plain: the trace rows of the `recompose/coeff` ops follow those of the plain ops in the one array)
 __device__ __forceinline__ RunOp make_run_op(const Op& op, uint32_t i, uint32_t f, const uint64_t* __restrict__ s_ap,
-                                              const uint64_t* __restrict__ s_re) {
+                                              const uint64_t* __restrict__ s_re, const uint32_t* __restrict__ s_rc, uint32_t n_rec_plain) {
   RunOp r{};
   r.kind_flags = op.kind | (f & (RUN_BACKWARD | RUN_CHECK_OUT | RUN_CHECK_AUX));
   if (is_hint(op.kind)) r.kind_flags |= op.ext_len << 16;
   r.a = op.a; r.b = op.b; r.c = op.c; r.out = op.out; r.aux = op.aux;
   r.op_idx = i;
   if (is_alu(op.kind)) r.rec = (uint32_t)s_ap[i];
-  else if (op.kind == P3R_OP_RECOMPOSE) r.rec = (uint32_t)s_re[i];
+  else if (op.kind == P3R_OP_RECOMPOSE) r.rec = op.aux == 1u ? n_rec_plain + s_rc[i] : (uint32_t)s_re[i];
   if (op.kind == P3R_OP_CONST || op.kind == P3R_OP_RECOMPOSE || is_hint(op.kind)) r.ext_off = (uint32_t)(s_re[i] >> 32);
   return r;
 }
 __global__ void __launch_bounds__(kB) k_emit_light(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ sorted_ops, size_t n,
                                                    const uint32_t* __restrict__ oflags, const uint64_t* __restrict__ s_ap,
-                                                   const uint64_t* __restrict__ s_re, RunOp* __restrict__ out) {
+                                                   const uint64_t* __restrict__ s_re, const uint32_t* __restrict__ s_rc, uint32_t n_rec_plain,
+                                                   RunOp* __restrict__ out) {
   const size_t k = (size_t)blockIdx.x * kB + threadIdx.x;
   if (k >= n) return;
   const uint32_t i = sorted_ops[k];
-  out[k] = make_run_op(load_op(ops, i), i, oflags[i], s_ap, s_re);
+  out[k] = make_run_op(load_op(ops, i), i, oflags[i], s_ap, s_re, s_rc, n_rec_plain);
 }
 __global__ void __launch_bounds__(kB) k_emit_chain_ops(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ hmem, size_t n,
                                                        const uint64_t* __restrict__ s_ap, const uint64_t* __restrict__ s_re,
@@ -900,7 +989,7 @@ __global__ void __launch_bounds__(kB) k_emit_chain_ops(const uint32_t* __restric
   const size_t k = (size_t)blockIdx.x * kB + threadIdx.x;
   if (k >= n) return;
   const uint32_t i = hmem[k];
-  out[k] = make_run_op(load_op(ops, i), i, 0, s_ap, s_re);
+  out[k] = make_run_op(load_op(ops, i), i, 0, s_ap, s_re, nullptr, 0);   // HornerAcc steps only
 }
 // chains in creation order: {first member, length, acc witness, b witness}, sort key = level * 2 + (short ? 1 : 0)
 __global__ void __launch_bounds__(kB) k_chain_records(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ hmem,
@@ -977,12 +1066,48 @@ __global__ void __launch_bounds__(kB) k_emit_p2(const uint32_t* __restrict__ ops
     out[f0 + k] = q;
   }
 }
+__global__ void __launch_bounds__(kB) k_emit_p2_base(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
+                                                const uint32_t* __restrict__ p2_ops, const uint32_t* __restrict__ mlist,
+                                                const uint32_t* __restrict__ order, const uint32_t* __restrict__ seg_pos,
+                                                const uint32_t* __restrict__ seg_len, const uint32_t* __restrict__ first /* per sorted segment */,
+                                                size_t n_segs, size_t n_normal, const uint32_t* __restrict__ stime,
+                                                RunP2B* __restrict__ out, RunSchedule::P2Seg* __restrict__ segs) {
+  const size_t s = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (s >= n_segs) return;
+  const uint32_t c = order[s], m0 = seg_pos[c], len = seg_len[c], f0 = first[s];
+  segs[s] = RunSchedule::P2Seg{f0, len};
+  for (uint32_t k = 0; k < len; ++k) {
+    const uint32_t m = m0 + k, row = mlist[m], i = p2_ops[row], t = i + 1;
+    const Op op = load_op(ops, i);
+    const uint32_t* e = ext + op.ext_off;
+    RunP2B q{};
+    const uint32_t n_out = e[18];
+    q.flags = (op.aux & 3) | (n_out << 8);
+    q.op_idx = i;
+    q.row = row;
+    q.absorb_len = op.b;
+    for (int l = 0; l < 16; ++l) q.in[l] = e[l];
+    q.idx_w = e[16];
+    q.bit_w = e[17];
+    // the previous permutation of the same mode (last_output_normal / last_output_merkle, executor.rs:340-355)
+    q.prev_row = kNoW;
+    if (!(op.aux & 1)) q.prev_row = (m == 0 || m == n_normal) ? kNoW : mlist[m - 1];
+    for (uint32_t l = 0; l < 16; ++l) {
+      q.out[l] = l < n_out ? e[19 + l] : kNoW;
+      if (q.out[l] == kNoW) continue;
+      bool earlier = false;
+      for (uint32_t j = 0; j < l; ++j) earlier |= q.out[j] == q.out[l];
+      if (earlier || stime[q.out[l]] < t) q.check_mask |= 1u << l;
+    }
+    out[f0 + k] = q;
+  }
+}
 template <class PP>
 __global__ void __launch_bounds__(kB) k_const_values(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
-                                                     const uint32_t* __restrict__ const_ops, size_t n, uint32_t* __restrict__ out) {
+                                                     const uint32_t* __restrict__ const_ops, size_t n, uint32_t D, uint32_t* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
-  if (i >= n * 4) return;
-  out[i] = Fp<PP>::from_canonical(ext[ops[8 * (size_t)const_ops[i >> 2] + 6] + (i & 3)]).v;
+  if (i >= n * D) return;
+  out[i] = Fp<PP>::from_canonical(ext[ops[8 * (size_t)const_ops[i / D] + 6] + (uint32_t)(i % D)]).v;
 }
 __global__ void __launch_bounds__(kB) k_outs_of(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ list, size_t n,
                                                 uint32_t* __restrict__ out) {
@@ -1026,6 +1151,9 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   const size_t n_ops = d->n_ops;
   const uint32_t nw = d->witness_count;
   if (nw >= (1u << 31) || n_ops >= (size_t(1) << 28) || n_ops == 0 || nw == 0) return false;  // host path: limits, degenerate circuits
+  const uint32_t D = ctx->cfg.ext_degree;
+  if (D != 1 && D != 4 && D != 5) return false;   // (the runner computes in these degrees)
+  const Shape sh = shape_of(D);
   hipStream_t s = ctx->stream;
   prof_stage(ctx, "prep_upload");
   // ---- the circuit crosses PCIe once
@@ -1051,7 +1179,7 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   P3R_HIP(hipMemsetAsync(wlevel.p, 0, (size_t)nw * 4, s));
   P3R_HIP(hipMemsetAsync(tdef.p, 0xFF, (size_t)nw * 4, s));
   P3R_HIP(hipMemsetAsync(stime.p, 0xFF, (size_t)nw * 4, s));
-  LAUNCH(k_validate<PP>, n_ops, ops.p, n_ops, ext.p, d->n_ext, nw, bad.p);
+  LAUNCH(k_validate<PP>, n_ops, ops.p, n_ops, ext.p, d->n_ext, nw, sh, bad.p);
   LAUNCH(k_mark_rows, d->n_public, R.d_public_rows.p, d->n_public, nw, 0u, wflags.p, stime.p, bad.p);
   LAUNCH(k_mark_rows, d->n_private, R.d_private_rows.p, d->n_private, nw, (uint32_t)WF_PRIVATE, wflags.p, stime.p, bad.p);
   {
@@ -1064,27 +1192,34 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   DevBuf s_cp, s_ap, s_re;
   scan_pairs(ctx, PairConstPublic{ops.p}, n_ops, s_cp);
   scan_pairs(ctx, PairAluP2{ops.p}, n_ops, s_ap);
-  scan_pairs(ctx, PairRecExt{ops.p}, n_ops, s_re);
+  scan_pairs(ctx, PairRecExt{ops.p, D}, n_ops, s_re);
+  DevBuf s_rc(n_ops + 1);   // rank among the `recompose/coeff` ops
+  scan_flags(ctx, FlagRecCoeff{ops.p}, n_ops, s_rc.p);
+  hipLaunchKernelGGL(k_flags_total<FlagRecCoeff>, dim3(1), dim3(64), 0, s, FlagRecCoeff{ops.p}, n_ops, s_rc.p);
   uint64_t* S_cp = reinterpret_cast<uint64_t*>(s_cp.p);
   uint64_t* S_ap = reinterpret_cast<uint64_t*>(s_ap.p);
   uint64_t* S_re = reinterpret_cast<uint64_t*>(s_re.p);
   hipLaunchKernelGGL(k_scan_total<PairConstPublic>, dim3(1), dim3(64), 0, s, PairConstPublic{ops.p}, n_ops, S_cp);
   hipLaunchKernelGGL(k_scan_total<PairAluP2>, dim3(1), dim3(64), 0, s, PairAluP2{ops.p}, n_ops, S_ap);
-  hipLaunchKernelGGL(k_scan_total<PairRecExt>, dim3(1), dim3(64), 0, s, PairRecExt{ops.p}, n_ops, S_re);
+  hipLaunchKernelGGL(k_scan_total<PairRecExt>, dim3(1), dim3(64), 0, s, PairRecExt{ops.p, D}, n_ops, S_re);
   uint64_t tot[3];
+  uint32_t n_rec_coeff_u32 = 0;
+  P3R_HIP(hipMemcpyAsync(&n_rec_coeff_u32, s_rc.p + n_ops, 4, hipMemcpyDeviceToHost, s));
   P3R_HIP(hipMemcpyAsync(&tot[0], S_cp + n_ops, 8, hipMemcpyDeviceToHost, s));
   P3R_HIP(hipMemcpyAsync(&tot[1], S_ap + n_ops, 8, hipMemcpyDeviceToHost, s));
   P3R_HIP(copy_sync(s, &tot[2], S_re + n_ops, 8, hipMemcpyDeviceToHost));
   const size_t n_const = (uint32_t)tot[0], n_public = tot[0] >> 32, n_alu_ops = (uint32_t)tot[1], n_p2 = tot[1] >> 32;
-  const size_t n_rec = (uint32_t)tot[2], n_dev_ext = tot[2] >> 32;
+  // plain / coefficient-kind Recompose ops; their trace rows share one array, the plain ones first
+  const size_t n_rec_plain = (uint32_t)tot[2], n_rec_coeff = n_rec_coeff_u32, n_dev_ext = tot[2] >> 32;
   DevBuf const_ops(std::max<size_t>(n_const, 1)), public_ops(std::max<size_t>(n_public, 1)), alu_ops(std::max<size_t>(n_alu_ops, 1)),
-      p2_ops(std::max<size_t>(n_p2, 1)), rec_ops(std::max<size_t>(n_rec, 1));
-  LAUNCH(k_table_lists, n_ops, ops.p, n_ops, S_cp, S_ap, S_re, const_ops.p, public_ops.p, alu_ops.p, p2_ops.p, rec_ops.p);
+      p2_ops(std::max<size_t>(n_p2, 1)), rec_ops(std::max<size_t>(n_rec_plain, 1)), rec_coeff_ops(std::max<size_t>(n_rec_coeff, 1));
+  LAUNCH(k_table_lists, n_ops, ops.p, n_ops, S_cp, S_ap, S_re, const_ops.p, public_ops.p, alu_ops.p, p2_ops.p, rec_ops.p, s_rc.p,
+         rec_coeff_ops.p);
 
   // ---- first touches
   LAUNCH(k_mark_cp, n_ops, ops.p, n_ops, wflags.p);
   LAUNCH(k_mark_hint, n_ops, ops.p, n_ops, ext.p, wflags.p);
-  LAUNCH(k_times, n_ops, ops.p, n_ops, ext.p, wflags.p, tdef.p, stime.p);
+  LAUNCH(k_times, n_ops, ops.p, n_ops, ext.p, wflags.p, sh, tdef.p, stime.p);
   for (int round = 0;; ++round) {
     P3R_HIP(hipMemsetAsync(changed.p, 0, 4, s));
     for (int k = 0; k < 4; ++k) LAUNCH(k_times_fix, n_ops, ops.p, n_ops, wflags.p, tdef.p, stime.p, changed.p);
@@ -1096,14 +1231,19 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
 
   // ---- bus roles, read counts
   DevBuf roles(std::max<size_t>(n_alu_ops, 1));
-  LAUNCH(k_roles, n_ops, ops.p, n_ops, ext.p, wflags.p, tdef.p, S_ap, reads.p, roles.p);
+  LAUNCH(k_roles, n_ops, ops.p, n_ops, ext.p, wflags.p, tdef.p, sh, S_ap, reads.p, roles.p);
   const size_t mh = d->min_trace_height;
   R.counts.n_const = n_const; R.counts.n_public = n_public; R.counts.n_alu = std::max<size_t>(n_alu_ops, 1);
-  R.counts.n_p2 = n_p2; R.counts.n_recompose = n_rec;
+  R.counts.n_p2 = n_p2;
+  // a table without rows is not proved: a circuit whose Recompose ops are all of the coefficient kind has ONE Recompose
+  // table, `recompose/coeff`, in the first slot (circuit_impl.cuh::circuit_tables)
+  R.recompose_coeff = n_rec_plain == 0 && n_rec_coeff > 0;
+  R.counts.n_recompose = R.recompose_coeff ? n_rec_coeff : n_rec_plain;
+  R.counts.n_recompose_coeff = R.recompose_coeff ? 0 : n_rec_coeff;
   R.public_lanes = n_public <= 1 ? 1 : d->public_lanes;
   R.alu_lanes = R.counts.n_alu <= 1 ? 1 : d->alu_lanes;
   const size_t h_p2 = n_p2 ? padded_h(n_p2, mh) : 0;
-  LAUNCH(k_acc_reads, n_p2, ops.p, ext.p, p2_ops.p, n_p2, h_p2, reads.p);
+  LAUNCH(k_acc_reads, n_p2, ops.p, ext.p, p2_ops.p, n_p2, h_p2, sh, reads.p);
   LAUNCH(k_unclaimed, d->n_private, R.d_private_rows.p, d->n_private, tdef.p, bad.p);
 
   prof_stage(ctx, "prep_traces");
@@ -1111,19 +1251,31 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   const int lanes = (int)R.alu_lanes, k_max = (int)d->horner_packed_steps, rl = (int)d->recompose_lanes, pl = (int)R.public_lanes;
   R.h[0] = padded_h(std::max<size_t>(n_const, 1), mh);
   R.prep[0] = zero_mat(ctx, R.h[0], 2);
-  LAUNCH(k_prep_simple<PP>, n_const, ops.p, const_ops.p, n_const, 1, 0, reads.p, wflags.p, R.h[0], R.prep[0]->d);
+  LAUNCH(k_prep_simple<PP>, n_const, ops.p, const_ops.p, n_const, 1, 0, reads.p, wflags.p, D, R.h[0], R.prep[0]->d);
   R.h[1] = padded_h(std::max<size_t>((n_public + pl - 1) / pl, 1), mh);
   R.prep[1] = zero_mat(ctx, R.h[1], 2 * (size_t)pl);
-  LAUNCH(k_prep_simple<PP>, n_public, ops.p, public_ops.p, n_public, pl, 0, reads.p, wflags.p, R.h[1], R.prep[1]->d);
+  LAUNCH(k_prep_simple<PP>, n_public, ops.p, public_ops.p, n_public, pl, 0, reads.p, wflags.p, D, R.h[1], R.prep[1]->d);
   if (n_p2) {
     R.h[3] = h_p2;
-    R.prep[3] = zero_mat(ctx, h_p2, 24);
-    LAUNCH(k_prep_p2<PP>, h_p2, ops.p, ext.p, p2_ops.p, n_p2, reads.p, wflags.p, h_p2, R.prep[3]->d);
+    if (D == 4) {
+      R.prep[3] = zero_mat(ctx, h_p2, 24);
+      LAUNCH(k_prep_p2<PP>, h_p2, ops.p, ext.p, p2_ops.p, n_p2, reads.p, wflags.p, h_p2, R.prep[3]->d);
+    } else {
+      R.prep[3] = zero_mat(ctx, h_p2, kP2D1PrepWidth);
+      LAUNCH(k_prep_p2_d1<PP>, h_p2, ops.p, ext.p, p2_ops.p, n_p2, reads.p, wflags.p, D, h_p2, R.prep[3]->d);
+    }
   }
-  if (n_rec) {
-    R.h[4] = padded_h(std::max<size_t>((n_rec + rl - 1) / rl, 1), mh);
+  if (n_rec_plain) {
+    R.h[4] = padded_h(std::max<size_t>((n_rec_plain + rl - 1) / rl, 1), mh);
     R.prep[4] = zero_mat(ctx, R.h[4], 2 * (size_t)rl);
-    LAUNCH(k_prep_simple<PP>, n_rec, ops.p, rec_ops.p, n_rec, rl, 1, reads.p, wflags.p, R.h[4], R.prep[4]->d);
+    LAUNCH(k_prep_simple<PP>, n_rec_plain, ops.p, rec_ops.p, n_rec_plain, rl, 1, reads.p, wflags.p, D, R.h[4], R.prep[4]->d);
+  }
+  if (n_rec_coeff) {
+    const int slot = R.recompose_coeff ? 4 : 5;
+    R.h[slot] = padded_h(std::max<size_t>((n_rec_coeff + rl - 1) / rl, 1), mh);
+    R.prep[slot] = zero_mat(ctx, R.h[slot], (2 + 2 * (size_t)D) * rl);
+    LAUNCH(k_prep_rec_coeff<PP>, n_rec_coeff, ops.p, ext.p, rec_coeff_ops.p, n_rec_coeff, rl, reads.p, wflags.p, D, R.h[slot],
+           R.prep[slot]->d);
   }
   {
     // ALU lane schedule
@@ -1171,7 +1323,7 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
     }
     R.alu_prev_src.alloc(rows);
     LAUNCH(k_alu_prev, rows, plan, rows, lanes, any ? 1 : 0, R.alu_prev_src.p);
-    if (n) LAUNCH(k_prep_alu<PP>, rows * lanes, ops.p, alu_ops.p, roles.p, reads.p, plan, rows, lanes, k_max, R.h[2], R.prep[2]->d);
+    if (n) LAUNCH(k_prep_alu<PP>, rows * lanes, ops.p, alu_ops.p, roles.p, reads.p, plan, rows, lanes, k_max, D, R.h[2], R.prep[2]->d);
   }
 
   prof_stage(ctx, "prep_schedule_static");
@@ -1179,7 +1331,7 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   RunSchedule& S = R.sched;
   DevBuf oflags(n_ops), olevel(n_ops);
   P3R_HIP(hipMemsetAsync(olevel.p, 0, n_ops * 4, s));
-  LAUNCH(k_sched_static, n_ops, ops.p, n_ops, ext.p, stime.p, oflags.p, bad.p);
+  LAUNCH(k_sched_static, n_ops, ops.p, n_ops, ext.p, stime.p, sh, oflags.p, bad.p);
   LAUNCH(k_chain_link, n_ops, ops.p, n_ops, oflags.p);
   DevBuf ready_rank(n_ops + 1), light_rank(n_ops + 1);
   scan_flags(ctx, FlagReady{oflags.p}, n_ops, ready_rank.p);
@@ -1254,9 +1406,9 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
     for (int round = 0;; ++round) {
       P3R_HIP(hipMemsetAsync(changed.p, 0, 4, s));
       for (int k = 0; k < 4; ++k) {
-        LAUNCH(k_level_light, n_light, ops.p, ext.p, light_ops.p, n_light, oflags.p, stime.p, wlevel.p, olevel.p, changed.p);
+        LAUNCH(k_level_light, n_light, ops.p, ext.p, light_ops.p, n_light, oflags.p, stime.p, D, wlevel.p, olevel.p, changed.p);
         LAUNCH(k_level_chains, n_runs * 64, ops.p, hmem.p, runs.p, n_runs, n_members, wlevel.p, olevel.p, chead.p, changed.p);
-        LAUNCH(k_level_p2, n_p2_runs * 64, ops.p, ext.p, p2_ops.p, mlist.p, p2_runs.p, n_p2_runs, n_p2, stime.p, wlevel.p, plevel.p,
+        LAUNCH(k_level_p2, n_p2_runs * 64, ops.p, ext.p, p2_ops.p, mlist.p, p2_runs.p, n_p2_runs, n_p2, stime.p, sh, wlevel.p, plevel.p,
                phead.p, changed.p);
       }
       uint32_t c = 0;
@@ -1334,9 +1486,10 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
     sort_by_key(ctx, light_keys.p, light_keys2.p, light_ops.p, light_sorted.p, n_light, lbits);
     LAUNCH(k_first_index, n_light, light_keys2.p, n_light, f_light);
     R.d_light.alloc(std::max<size_t>(n_light * (sizeof(RunOp) / 4), 1));
-    LAUNCH(k_emit_light, n_light, ops.p, light_sorted.p, n_light, oflags.p, S_ap, S_re, reinterpret_cast<RunOp*>(R.d_light.p));
+    LAUNCH(k_emit_light, n_light, ops.p, light_sorted.p, n_light, oflags.p, S_ap, S_re, s_rc.p, (uint32_t)n_rec_plain,
+           reinterpret_cast<RunOp*>(R.d_light.p));
     R.d_ext.alloc(std::max<size_t>(n_dev_ext, 1));
-    LAUNCH(k_emit_ext<PP>, n_ops, ops.p, n_ops, ext.p, S_re, stime.p, R.d_ext.p);
+    LAUNCH(k_emit_ext<PP>, n_ops, ops.p, n_ops, ext.p, S_re, stime.p, D, R.d_ext.p);
     prof_stage(ctx, "prep_emit_chains");
     // Horner chains
     size_t n_chains = 0;
@@ -1363,7 +1516,7 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
     prof_stage(ctx, "prep_emit_p2");
     // Poseidon2 segments
     size_t n_segs = 0;
-    R.d_p2.alloc(std::max<size_t>(n_p2 * (sizeof(RunP2) / 4), 1));
+    R.d_p2.alloc(std::max<size_t>(n_p2 * ((D == 4 ? sizeof(RunP2) : sizeof(RunP2B)) / 4), 1));
     R.d_p2segs.alloc(1);
     if (n_p2) {
       DevBuf head_by_row(n_p2 + 2), head_rank(n_p2 + 2), head_rows(n_p2);
@@ -1383,13 +1536,17 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
       LAUNCH(k_gather_u32, n_segs, seg_len.p, order.p, n_segs, len_sorted.p);
       scan_u32(ctx, len_sorted.p, first.p, n_segs);
       R.d_p2segs.alloc(n_segs * 2);
-      LAUNCH(k_emit_p2, n_segs, ops.p, ext.p, p2_ops.p, mlist.p, order.p, seg_pos.p, seg_len.p, first.p, n_segs, n_normal, stime.p,
-             reinterpret_cast<RunP2*>(R.d_p2.p), reinterpret_cast<RunSchedule::P2Seg*>(R.d_p2segs.p));
+      if (D == 4)
+        LAUNCH(k_emit_p2, n_segs, ops.p, ext.p, p2_ops.p, mlist.p, order.p, seg_pos.p, seg_len.p, first.p, n_segs, n_normal, stime.p,
+               reinterpret_cast<RunP2*>(R.d_p2.p), reinterpret_cast<RunSchedule::P2Seg*>(R.d_p2segs.p));
+      else
+        LAUNCH(k_emit_p2_base, n_segs, ops.p, ext.p, p2_ops.p, mlist.p, order.p, seg_pos.p, seg_len.p, first.p, n_segs, n_normal, stime.p,
+               reinterpret_cast<RunP2B*>(R.d_p2.p), reinterpret_cast<RunSchedule::P2Seg*>(R.d_p2segs.p));
     }
     prof_stage(ctx, "prep_emit_rest");
     // static Const trace, Public gather list
-    R.d_const_values.alloc(std::max<size_t>(n_const * 4, 1));
-    LAUNCH(k_const_values<PP>, n_const * 4, ops.p, ext.p, const_ops.p, n_const, R.d_const_values.p);
+    R.d_const_values.alloc(std::max<size_t>(n_const * D, 1));
+    LAUNCH(k_const_values<PP>, n_const * D, ops.p, ext.p, const_ops.p, n_const, D, R.d_const_values.p);
     R.d_public_out.alloc(std::max<size_t>(n_public, 1));
     LAUNCH(k_outs_of, n_public, ops.p, public_ops.p, n_public, R.d_public_out.p);
     // per-level offsets on the host, launch plan

@@ -13,6 +13,11 @@ namespace p3r {
 
 constexpr uint32_t kNoW = P3R_NO_WITNESS;
 
+// Preprocessed row of the compact D = 1 Poseidon2 table (poseidon2-circuit-air/src/air.rs:730-763): 8 in_ctl, the
+// length tag, cap_chain_enable, 8 + 8 chain selectors | at kP2D1Hdr: 16 input indices, 8 output indices, 8 out_ctl |
+// at kP2D1Tail: mmcs_index_sum index, mmcs_ctl_enabled, new_start, merkle_path
+constexpr int kP2D1Hdr = 26, kP2D1Tail = 58, kP2D1PrepWidth = 62;
+
 // ALU plan entry kinds
 enum { PLAN_SEP = 0, PLAN_OP = 1, PLAN_PACKED = 2 };
 

@@ -173,6 +173,18 @@ def test_plain_bench_entry_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], capture_output=True, text=True, timeout=120, cwd=ROOT,
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
+    # ranks[]: what the collective layer reports, the device and PCI address of every rank, its own time
+    rk = line["ranks"]
+    assert rk["backend"] == "gloo" and len(rk["per_rank"]) == 2 and rk["distinct_gpus"] == 1
+    assert all(p["pci"] and p["ms"] is not None and p["ms"] > 0 for p in rk["per_rank"])
+    assert rk["omp_num_threads"] and int(rk["omp_num_threads"]) <= max(1, (os.cpu_count() or 2) // 2)
+    # one rank per GPU over RCCL needs as many GPUs as ranks: refused with a message, not a hang inside ncclCommInitRank
+    import torch
+    if torch.cuda.device_count() < 2:
+        nccl_env = {k: v for k, v in env.items() if k != "P3R_BENCH_BACKEND"}
+        few = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--log-height", "10"],
+                             capture_output=True, text=True, timeout=300, cwd=ROOT, env=nccl_env)
+        assert few.returncode != 0 and "visible GPUs" in few.stderr, few.stderr[-2000:]
 
 
 def test_default_bench_line_two_ranks_over_gloo():

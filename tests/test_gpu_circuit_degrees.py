@@ -69,7 +69,7 @@ def test_device_runner_for_base_field_and_quintic_circuits(oracle, field, ext_de
     a, prm, ctx, cache, inputs = setup(oracle, field, ext_degree, log_h, flags, packing, horner_chain_len=200 if log_h >= 10 else 16,
                                        merkle_depth=12 if log_h >= 13 else 5)
     pc = cache.prepared_circuit
-    assert not pc.prepared_on_device       # circuits of degree 1 / 5 take the host restatement of the preparation
+    assert pc.prepared_on_device           # every circuit degree the runner computes in is prepared on the device (round 4)
     assert [pc.circuit_prover_data.rows[k] for k in ("const", "public", "alu", "poseidon2", "recompose")] == \
         [int(x) for x in a["counts"][:5]]
     res = pc.run(inputs)

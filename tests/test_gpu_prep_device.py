@@ -14,7 +14,19 @@ import oracle_lib
 
 pytestmark = pytest.mark.gpu
 FRI = dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
-ARRAYS = ("const_values", "public_values", "alu_values", "recompose_values", "p2_input_values", "p2_flags", "p2_mmcs_index_sum")
+ARRAYS = ("const_values", "public_values", "alu_values", "recompose_values", "recompose_coeff_values", "p2_input_values", "p2_flags",
+          "p2_mmcs_index_sum")
+
+
+DEGREE_CASES = [("koala-bear", 5, 8, 0, None), ("koala-bear", 1, 8, 0, None), ("baby-bear", 1, 9, 0, dict(alu_lanes=2, horner_packed_steps=3)),
+                ("koala-bear", 5, 9, harness_lib.RECOMPOSE_COEFF, dict(public_lanes=2, alu_lanes=2, horner_packed_steps=3, recompose_lanes=2)),
+                ("koala-bear", 5, 10, harness_lib.RECOMPOSE_BOTH, dict(recompose_lanes=2)),
+                ("baby-bear", 1, 8, harness_lib.RECOMPOSE_BOTH, None),
+                ("koala-bear", 4, 9, harness_lib.RECOMPOSE_BOTH, dict(public_lanes=3, alu_lanes=4, horner_packed_steps=5)),
+                ("baby-bear", 4, 8, harness_lib.RECOMPOSE_COEFF | harness_lib.NO_POSEIDON2, None),
+                ("koala-bear", 5, 8, harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE, None),
+                ("koala-bear", 5, 12, harness_lib.INDEPENDENT_SPONGES | harness_lib.RECOMPOSE_BOTH,
+                 dict(public_lanes=2, alu_lanes=3, horner_packed_steps=4))]
 
 
 def both_ways(ctx, circuit, tp, inputs):
@@ -76,6 +88,23 @@ def test_device_preparation_equals_host_preparation(field, log_h, flags, packing
     tp = p3r.TablePacking(**(packing or {})).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
     dev, host = both_ways(ctx, wl.circuit_from_arrays(a), tp, wl.circuit_inputs_from_arrays(a))
     check_same(dev, host, (field, log_h, flags, packing))
+    ctx.close()
+
+
+@pytest.mark.parametrize("field,ext_degree,log_h,flags,packing", DEGREE_CASES)
+def test_device_preparation_for_circuit_degrees_1_and_5_and_both_recompose_kinds(field, ext_degree, log_h, flags, packing):
+    """Round 4: the device pass covers the circuit degrees 1 / 4 / 5 (base-mode Poseidon2 rows with their 62-column
+    compact preprocessed layout, D-scaled witness indices, D-coefficient constants / hints / Recompose inputs) and
+    Recompose ops of the coefficient-lookup kind (one table, or the second of two): same commitment, schedule, run
+    traces and proof bytes as the host restatement (backend/fri.rs:741-852, common.rs:127-390, air.rs:730-763)."""
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    a = harness_lib.generate(field, log_h, seed=91 + log_h, flags=flags, ext_degree=ext_degree,
+                             horner_chain_len=200 if log_h >= 10 else 16, sponge_chain_len=3, merkle_depth=5)
+    ctx = p3r.Context(field=field, ext_degree=ext_degree, **FRI)
+    tp = p3r.TablePacking(**(packing or {})).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    dev, host = both_ways(ctx, wl.circuit_from_arrays(a), tp, wl.circuit_inputs_from_arrays(a, ext_degree))
+    check_same(dev, host, (field, ext_degree, log_h, flags, packing))
     ctx.close()
 
 

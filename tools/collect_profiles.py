@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC, OUT = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(OUT, exist_ok=True)
 
@@ -83,8 +83,9 @@ json.dump({"provenance": "rocprofv3 --pmc <counter> --kernel-trace, one pass per
 # FP64 / VALU instructions per Poseidon2 permutation of k_mmcs_hash_rows: counter total over the launches of
 # tools/pmc_hash_rows.py (matrix of known shape) x 64 lanes / permutations of those launches
 hr = {"provenance": "rocprofv3 --pmc SQ_INSTS_VALU (and SQ_WAVES) --kernel-trace over `python3 tools/pmc_hash_rows.py <field>` "
-                    "(tools/profile_round.sh): `launches` commits of one rows x width matrix, every launch is one "
-                    "k_mmcs_hash_rows over it; valu_insts_per_perm = SQ_INSTS_VALU x 64 / (launches x rows x ceil(width / 8))",
+                    "bench` (tools/profile_round.sh): the three commits (main, LogUp aux, quotient chunks) of bench.py's 2^20-row "
+                    "layer, every commit one job-list launch of k_mmcs_hash_rows over all its height classes; "
+                    "valu_insts_per_perm = SQ_INSTS_VALU x 64 / permutations of those launches",
       "fields": {}}
 for fld in ("koala-bear", "baby-bear"):
     try:
@@ -120,8 +121,9 @@ hs = next(v for k, v in stats.items() if "k_mmcs_hash_rows<" in k and "strided" 
 print("value ms", line["value"], "| hash PMC MB/launch (2*FETCH + WRITE)",
       (2 * h.get("fetch_kb_per_launch", 0) + h.get("write_kb_per_launch", 0)) * 1024 / 1e6,
       "| bench avg_launch_ms", line["roofline"]["avg_launch_ms"], "| rocprof avg ms", float(hs["AverageNs"]) / 1e6, "calls", hs["Calls"])
-print("roofline", {k: line["roofline"].get(k) for k in ("achieved", "frac", "traffic", "algorithmic_bytes_per_launch")})
-print("valu", line.get("valu_roofline"))
+print("roofline", {k: line["roofline"].get(k) for k in ("bound", "achieved", "frac", "traffic", "valu_insts_per_perm")})
+print("hbm side", line["roofline"].get("hbm"))
+print("proof_roofline", {k: line.get("proof_roofline", {}).get(k) for k in ("valu_floor_ms", "hbm_floor_ms", "floor_ms", "frac")})
 print("kernel_ms", {k: round(v, 2) for k, v in line["kernel_ms_per_step"].items()})
 print("stage_ms", {k: round(v, 2) for k, v in line["stage_wall_ms_per_step"].items()})
 print("cpu", line.get("cpu_baseline"))

@@ -16,16 +16,47 @@ sys.path.insert(0, ROOT)
 import plonky3_recursion_amd as p3r  # noqa: E402
 
 field = sys.argv[1] if len(sys.argv) > 1 else "koala-bear"
-log_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 22
-width = int(sys.argv[3]) if len(sys.argv) > 3 else 80
-launches = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 ctx = p3r.Context(field=field)
 rng = np.random.default_rng(1)
-m = ctx.upload(rng.integers(0, ctx.p, size=(1 << log_rows, width), dtype=np.uint32))
-for _ in range(launches):
-    cap, tree = ctx.commit_device([m])
-    tree.free()
-ctx.sync()
-print(json.dumps({"field": field, "rows": 1 << log_rows, "width": width, "launches": launches,
-                  "perms_per_launch": (1 << log_rows) * ((width + 7) // 8)}))
+if len(sys.argv) > 2 and sys.argv[2] == "bench":
+    # the three commits of bench.py's 2^20-row layer (main, LogUp aux, quotient chunks; default packing): one job-list
+    # launch per commit over every height class, as in a proof
+    import bench
+    launches = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    packing = p3r.TablePacking()
+    k, B = packing.horner_packed_steps, 4
+    heights = [1 << 16, 1 << 19, 1 << 20, 1 << 19, 1 << 18]
+    widths = [4, 4 * packing.public_lanes, 16 * packing.alu_lanes + ((k - 1) // 2 + 2 * (k - 1) + 1) * 4,
+              166 if field == "koala-bear" else 300, 4 * packing.recompose_lanes]
+    names = ["const", "public", "alu", "poseidon2", "recompose"]
+    aux = bench.lookup_aux_widths(packing.alu_lanes, k)
+    commits = [[(heights[i] * B, widths[i]) for i in range(5)],
+               [(heights[i] * B, aux[n][0] * 4) for i, n in enumerate(names)],
+               [(heights[i] * B, 4) for i, n in enumerate(names) for _ in range(aux[n][1])]]
+    perms = 0
+    for mats in commits:
+        by_h = {}
+        for h, w in mats:
+            by_h[h] = by_h.get(h, 0) + w
+        perms += sum(h * ((w + 7) // 8) for h, w in by_h.items())
+        dm = [ctx.upload(rng.integers(0, ctx.p, size=(h, w), dtype=np.uint32)) for h, w in mats]
+        for _ in range(launches):
+            cap, tree = ctx.commit_device(dm)
+            tree.free()
+        ctx.sync()
+        for m in dm:
+            m.free()
+    print(json.dumps({"field": field, "shapes": "bench.py 2^20-row layer: main / aux / quotient commits", "commits": commits,
+                      "launches": 3 * launches, "perms_per_launch": perms / 3.0}))
+else:
+    log_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 22
+    width = int(sys.argv[3]) if len(sys.argv) > 3 else 80
+    launches = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+    m = ctx.upload(rng.integers(0, ctx.p, size=(1 << log_rows, width), dtype=np.uint32))
+    for _ in range(launches):
+        cap, tree = ctx.commit_device([m])
+        tree.free()
+    ctx.sync()
+    print(json.dumps({"field": field, "rows": 1 << log_rows, "width": width, "launches": launches,
+                      "perms_per_launch": (1 << log_rows) * ((width + 7) // 8)}))
 ctx.close()

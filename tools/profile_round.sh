@@ -12,7 +12,7 @@ done
 # instructions per permutation of the dominant kernel: N launches over a matrix of known shape (tools/pmc_hash_rows.py)
 for F in koala-bear baby-bear; do
   for C in SQ_INSTS_VALU SQ_WAVES; do
-    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/final/hashrows_${F}_$C -- python3 tools/pmc_hash_rows.py $F > gpurun_out/final/hashrows_${F}_$C.log 2>&1
+    timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/final/hashrows_${F}_$C -- python3 tools/pmc_hash_rows.py $F bench > gpurun_out/final/hashrows_${F}_$C.log 2>&1
   done
 done
 # keep the merge small: drop the per-dispatch traces except counter collection + stats
