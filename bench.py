@@ -167,7 +167,7 @@ def committed_valu_model(field):
 
 
 # Arithmetic of the LDE passes (profiles/r04/ntt_bound.txt, tools/microbench/ntt_valu on one MI355X): the radix-2
-# butterfly of csrc/kernels_ntt2.cuh (ten integer instructions, two of them v_mad_u64_u32) issues at 3.9 T/s with no
+# butterfly of csrc/kernels_ntt2.hip.h (ten integer instructions, two of them v_mad_u64_u32) issues at 3.9 T/s with no
 # memory in the loop, a Montgomery product at 7.7 T/s (profiles/r03/microbench_int_rates.txt).
 NTT_BUTTERFLY_RATE = 3.9e12
 MONT_PRODUCT_RATE = 7.68e12
@@ -867,7 +867,7 @@ def main():
         }
         # `roofline`: the dominant kernel against the roof that binds it.  MMCS leaf hashing is one Poseidon2 permutation
         # per 32 B absorbed: it is bound by VALU issue - the permutation runs in FP64 (exact integer arithmetic in
-        # doubles, csrc/poseidon2_f64.cuh), so its price is FP64 instructions per permutation x the FP64 issue rate
+        # doubles, csrc/poseidon2_f64.hip.h), so its price is FP64 instructions per permutation x the FP64 issue rate
         # (guide: 78.6 TFLOP/s FP64 vector = 39.3 T FMA lane-ops/s).  Instructions per permutation and the measured
         # v_fma_f64 rate come from named files of profiles/<round>/ (committed_valu_model); the kernel's HBM side
         # (algorithmic bytes, PMC traffic) is the sub-object `hbm`.

@@ -21,7 +21,7 @@
 // setup.  Ops are then levelised (an op's level = 1 + the highest level among the ops that
 // produce what it reads, including the Poseidon2 chaining through the previous permutation of
 // the same mode) and every level runs as one launch: one lane per ALU / hint / recompose op,
-// sixteen lanes per Poseidon2 permutation (kernels_coop.cuh).  Ops write their trace records
+// sixteen lanes per Poseidon2 permutation (kernels_coop.hip.h).  Ops write their trace records
 // (AluOpRecord, Poseidon2CircuitRow, RecomposeCircuitRow) as they execute.
 
 namespace {

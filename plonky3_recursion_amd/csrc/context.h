@@ -421,7 +421,7 @@ struct p3r_ctx {
   hipStream_t stream = nullptr;
   int n_cus = 256;  // compute units of the device (grids of the persistent kernels)
   p3r::DevBuf rc;  // Poseidon2 constants, Montgomery
-  p3r::DevBuf rc_f64;  // the same constants as canonical doubles (poseidon2_f64.cuh)
+  p3r::DevBuf rc_f64;  // the same constants as canonical doubles (poseidon2_f64.hip.h)
   const double* rcd() const { return reinterpret_cast<const double*>(rc_f64.p); }
   p3r::DevBuf p2_diag;  // internal-layer diagonal, Montgomery (lane-cooperative kernels)
   std::vector<uint32_t> rc_canonical;

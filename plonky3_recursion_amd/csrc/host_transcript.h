@@ -13,7 +13,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "air_device.cuh"
+#include "air_device.hip.h"
 #include "context.h"
 #include "host_poseidon2_simd.h"
 

@@ -10,8 +10,8 @@
 #pragma once
 #include "field.h"
 #include "poseidon2.h"
-#include "poseidon2_f64.cuh"
-#include "kernels_ntt.cuh"
+#include "poseidon2_f64.hip.h"
+#include "kernels_ntt.hip.h"
 
 namespace p3r {
 
@@ -78,7 +78,7 @@ k_convert_inplace(uint32_t* __restrict__ d, size_t n, int to_monty) {
 // ---------------------------------------------------------------------------------
 
 // Plain batch permutation: states column-major [16][n] in and out (the perms/s metric).
-// FP64 form (poseidon2_f64.cuh): `rcd` = the constants as canonical doubles.
+// FP64 form (poseidon2_f64.hip.h): `rcd` = the constants as canonical doubles.
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
 k_p2_permute_batch(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
@@ -290,7 +290,7 @@ k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const double*
   const int wtot = jobs[jb].wtot;
   size_t i = (size_t)(blockIdx.x - jobs[jb].block0) * kBlock + threadIdx.x;
   if (i >= h) return;
-  // the sponge state lives in FP64 between permutations (poseidon2_f64.cuh): absorbed cells are
+  // the sponge state lives in FP64 between permutations (poseidon2_f64.hip.h): absorbed cells are
   // converted on the way in, the capacity half is carried unreduced, the digest is reduced once
   double s[P2_WIDTH];
 #pragma unroll

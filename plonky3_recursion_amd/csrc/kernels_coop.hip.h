@@ -1,6 +1,6 @@
 // Lane-cooperative Poseidon2 for LATENCY-bound work (small Merkle layers): one state element per
 // lane, 16 lanes (one DPP "row") per permutation, 4 permutations per wavefront.  The one-state-
-// per-lane kernels of kernels.cuh are ~9 k dependent instructions (~25 us) per layer however few
+// per-lane kernels of kernels.hip.h are ~9 k dependent instructions (~25 us) per layer however few
 // nodes the layer has; here a permutation is ~1.3 k dependent instructions because the S-boxes of
 // a round run in parallel and the linear layers are DPP rotations:
 //   external:  M4 is circulant, y_i = 2 x_i + 3 x_{i+1} + x_{i+2} + x_{i+3} inside a quad
@@ -8,7 +8,7 @@
 //   internal:  sum over the row with row_ror:8,4,2,1, then s_i <- d_i * s_i + sum.
 // Same arithmetic as poseidon2.h (Montgomery form), so results are bit-identical.
 #pragma once
-#include "kernels.cuh"
+#include "kernels.hip.h"
 
 namespace p3r {
 
@@ -101,7 +101,7 @@ __device__ __forceinline__ Fp<PP> coop_permute(Fp<PP> s, int elem, Fp<PP> diag, 
 // lanes per row: a row is only 1-4 permutations, so with one row per lane the launch is one
 // permutation latency of the 7.8 k-instruction kind (25 us) however few rows there are; the
 // lane-cooperative permutation brings it to a few microseconds.  Same overwrite-mode sponge as
-// k_mmcs_hash_rows_strided (kernels_stark.cuh).
+// k_mmcs_hash_rows_strided (kernels_stark.hip.h).
 template <class PP>
 __global__ void __launch_bounds__(kBlock)
 k_mmcs_hash_rows_strided_coop(const uint32_t* const* __restrict__ cols, int wtot, size_t h, size_t stride,

@@ -4,7 +4,7 @@
 // One inverse vector per distinct (height, point) serves every matrix committed at that height
 // (recursion/src/pcs/fri/verifier.rs:1122-1345 caches the same quantity per (height, z)).
 #pragma once
-#include "kernels_stark.cuh"
+#include "kernels_stark.hip.h"
 
 namespace p3r {
 

@@ -3,7 +3,7 @@
 //                   vector, all cosets, input scaled by the coset shift powers, output multiplied
 //                   by the four-step twiddles, rows left in bit-reversed order;
 //   k_ntt_fwd_line  pass 2: contiguous size-R2 transforms in place, rows left in bit-reversed order.
-// Same arithmetic and data movement as k_ntt_tile (kernels_ntt.cuh) - identical outputs - but the
+// Same arithmetic and data movement as k_ntt_tile (kernels_ntt.hip.h) - identical outputs - but the
 // geometry is a template parameter: one 16-cell item per lane and stage group, every shift and
 // stride a compile-time constant, the twiddles of the last stage group immediates, no per-cell
 // 64-bit address arithmetic.  (rocprof, round 2: k_ntt_tile spends 10.7 VALU instructions per cell
@@ -11,7 +11,7 @@
 //
 // Tile: 2^13 cells = 512 lanes x 16 cells, four tiles per CU.
 #pragma once
-#include "kernels_ntt.cuh"
+#include "kernels_ntt.hip.h"
 
 namespace p3r {
 

@@ -2,12 +2,12 @@
 //   K7  LogUp auxiliary (permutation) trace       k_logup_aux, k_ef_scan
 //   K8  quotient evaluation                        k_quotient
 //   K9  openings at zeta / zeta*g                   k_bary_weights, k_open_dot, k_open_reduce
-//   K10 FRI reduced openings, folds, grinding       k_fri_fold, k_grind (reduced openings: kernels_fri_reduce.cuh)
+//   K10 FRI reduced openings, folds, grinding       k_fri_fold, k_grind (reduced openings: kernels_fri_reduce.hip.h)
 //   query answers                                   k_gather
 // Protocol anchors are listed in p3r_prove.hip next to the host code that sequences them.
 #pragma once
-#include "air_device.cuh"
-#include "kernels.cuh"
+#include "air_device.hip.h"
+#include "kernels.hip.h"
 
 namespace p3r {
 

@@ -1,9 +1,9 @@
 // C ABI (include/p3r.h): context, device matrices, Poseidon2 (K3), coset LDE (K5), MMCS (K6).
-// Host orchestration only; all arithmetic on data runs in the gfx950 kernels of kernels.cuh.
+// Host orchestration only; all arithmetic on data runs in the gfx950 kernels of kernels.hip.h.
 #include "context.h"
-#include "kernels.cuh"
-#include "kernels_stark.cuh"
-#include "kernels_coop.cuh"
+#include "kernels.hip.h"
+#include "kernels_stark.hip.h"
+#include "kernels_coop.hip.h"
 #include "tu_api.h"
 #include "poseidon2_rc_default.inc"
 #include "profile.h"
@@ -412,9 +412,9 @@ void init_ctx(p3r_ctx* ctx) {
 }  // namespace
 
 #include "verify_impl.h"
-#include "prove_impl.cuh"
-#include "layer_impl.cuh"
-#include "circuit_impl.cuh"
+#include "prove_impl.hip.h"
+#include "layer_impl.hip.h"
+#include "circuit_impl.hip.h"
 
 // =============================================================================== C ABI
 extern "C" {
@@ -920,7 +920,7 @@ int p3r_batch_stark_proof_parse(uint32_t field, const uint8_t* bytes, size_t len
   }
 }
 
-// ---- circuit boundary (circuit_impl.cuh) ----
+// ---- circuit boundary (circuit_impl.hip.h) ----
 p3r_circuit* p3r_circuit_create(p3r_ctx* ctx, const p3r_circuit_desc* desc, uint32_t* commit_out) {
   p3r_circuit* out = nullptr;
   guard(ctx, [&] {

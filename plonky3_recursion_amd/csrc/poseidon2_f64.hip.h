@@ -29,7 +29,7 @@
 #include "poseidon2.h"
 
 #if defined(__FAST_MATH__) || defined(__FINITE_MATH_ONLY__) && __FINITE_MATH_ONLY__
-#error "poseidon2_f64.cuh relies on exact IEEE-754 double arithmetic (error-free products, magic-number rounding): do not build with -ffast-math / -Ofast"
+#error "poseidon2_f64.hip.h relies on exact IEEE-754 double arithmetic (error-free products, magic-number rounding): do not build with -ffast-math / -Ofast"
 #endif
 
 namespace p3r {

@@ -5,8 +5,8 @@
 //   poseidon_preprocess_for_prover                   circuit-prover/src/batch_stark_prover.rs:97-246
 //   AluAir::compute_schedule + build_scheduled_preprocessed_trace
 //                                                    circuit-prover/src/air/alu_air.rs:349-463,613-677
-// and the static execution schedule of the device CircuitRunner (circuit_impl.cuh).  The host restatement of
-// the same steps (circuit_impl.cuh::circuit_tables / build_schedule, layer_impl.cuh::layer_create) walks the
+// and the static execution schedule of the device CircuitRunner (circuit_impl.hip.h).  The host restatement of
+// the same steps (circuit_impl.hip.h::circuit_tables / build_schedule, layer_impl.hip.h::layer_create) walks the
 // 4.8 M ops of a 2^20-row layer on one or two host threads (400 ms); here every step is a map, a scan, a
 // histogram or a short fixed-point iteration over the op list in HBM, and the preprocessed traces are
 // written where their LDE and commitment read them - nothing but the op list crosses PCIe.

@@ -23,7 +23,7 @@ constexpr int kB = 256;
 constexpr uint32_t kUnset = 0xFFFFFFFFu;
 inline unsigned nblk(size_t n) { return (unsigned)((n + kB - 1) / kB); }
 
-// The circuit's extension degree D and the layout of its Poseidon2 ops (circuit_impl.cuh::P2Shape): D = 4 -> four
+// The circuit's extension degree D and the layout of its Poseidon2 ops (circuit_impl.hip.h::P2Shape): D = 4 -> four
 // input limbs, two CTL-exposed output limbs; otherwise base mode -> sixteen one-element slots, eight exposed outputs.
 // ext = [in[il].., mmcs_index_sum, mmcs_bit, n_out, out..].
 struct Shape {
@@ -51,7 +51,7 @@ __device__ __forceinline__ bool is_hint(uint32_t k) {
 }
 
 // ------------------------------------------------------------------------------------------------ validation
-// validate_circuit (circuit_impl.cuh) + the canonical check of constants, as a yes / no per op
+// validate_circuit (circuit_impl.hip.h) + the canonical check of constants, as a yes / no per op
 template <class PP>
 __global__ void __launch_bounds__(kB) k_validate(const uint32_t* __restrict__ ops, size_t n_ops, const uint32_t* __restrict__ ext,
                                                  size_t n_ext, uint32_t nw, Shape sh, uint32_t* __restrict__ bad) {
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(kB) k_times_fix(const uint32_t* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------------ bus roles + read counts
-// generate_preprocessed_columns pass 1 (circuit_impl.cuh::circuit_tables): who reads what
+// generate_preprocessed_columns pass 1 (circuit_impl.hip.h::circuit_tables): who reads what
 __global__ void __launch_bounds__(kB) k_roles(const uint32_t* __restrict__ ops, size_t n_ops, const uint32_t* __restrict__ ext,
                                               uint32_t* __restrict__ wflags, const uint32_t* __restrict__ tdef, Shape sh,
                                               const uint64_t* __restrict__ s_ap, uint32_t* __restrict__ reads,
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(kB) k_prep_p2(const uint32_t* __restrict__ ops
   put(22, ns ? one : 0);
   put(23, mp ? one : 0);
 }
-// the compact D = 1 rows of circuits of degree 1 / 5 (air.rs:730-763, executor.rs:720-741; layer_impl.cuh::layer_create):
+// the compact D = 1 rows of circuits of degree 1 / 5 (air.rs:730-763, executor.rs:720-741; layer_impl.hip.h::layer_create):
 // [in_ctl x 8, length tag, cap_chain_enable, 8 + 8 chain selectors | 16 + 8 indices, 8 out_ctl | index_sum idx, 3 flags]
 template <class PP>
 __global__ void __launch_bounds__(kB) k_prep_p2_d1(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
@@ -1236,7 +1236,7 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   R.counts.n_const = n_const; R.counts.n_public = n_public; R.counts.n_alu = std::max<size_t>(n_alu_ops, 1);
   R.counts.n_p2 = n_p2;
   // a table without rows is not proved: a circuit whose Recompose ops are all of the coefficient kind has ONE Recompose
-  // table, `recompose/coeff`, in the first slot (circuit_impl.cuh::circuit_tables)
+  // table, `recompose/coeff`, in the first slot (circuit_impl.hip.h::circuit_tables)
   R.recompose_coeff = n_rec_plain == 0 && n_rec_coeff > 0;
   R.counts.n_recompose = R.recompose_coeff ? n_rec_coeff : n_rec_plain;
   R.counts.n_recompose_coeff = R.recompose_coeff ? 0 : n_rec_coeff;

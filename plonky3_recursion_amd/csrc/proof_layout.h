@@ -1,5 +1,5 @@
 // Field order of the postcard-serialised proof structs (p3r_config.proof_layout): shared by the
-// prover's writer (prove_impl.cuh), the native verifier's reader (verify_impl.h) and the ctx.
+// prover's writer (prove_impl.hip.h), the native verifier's reader (verify_impl.h) and the ctx.
 #pragma once
 #include <cstddef>
 #include <cstdint>

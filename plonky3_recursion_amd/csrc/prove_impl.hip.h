@@ -12,9 +12,9 @@
 // All matrices stay resident in HBM; only commitments, opened values, the final polynomial
 // and the query answers cross to the host.
 #include "host_transcript.h"
-#include "kernels_stark.cuh"
-#include "kernels_fri_reduce.cuh"
-#include "open_impl.cuh"
+#include "kernels_stark.hip.h"
+#include "kernels_fri_reduce.hip.h"
+#include "open_impl.hip.h"
 
 struct p3r_prep {
   std::vector<p3r::AirParams> airs;
@@ -509,7 +509,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       for (int k = 0; k < DC; ++k) h[c * DC + k] = fa_pow[c].c[k].v;
     P3R_HIP(ctx->stage.upload(ctx->stream, d_fapow.p, h.data(), h.size() * 4));
   }
-  // One pass per height over all its matrices (kernels_fri_reduce.cuh); alpha powers restart per
+  // One pass per height over all its matrices (kernels_fri_reduce.hip.h); alpha powers restart per
   // height and run on across that height's matrices and points in `items` order.
   std::map<int, std::pair<E, DevBuf>> ros;  // log_height -> (alpha power, ro planes [DC][h])
   {
@@ -736,7 +736,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   const int n_rounds = any_lookup ? 4 : 3;
   std::vector<size_t> indices(cfg.num_queries);
   for (auto& ix : indices) ix = ch.sample_bits(log_max);
-  // the item list is the same for every query (kernels_stark.cuh, k_gather); offsets are relative
+  // the item list is the same for every query (kernels_stark.hip.h, k_gather); offsets are relative
   // to a query's block of `words_per_query` words in the output
   std::vector<QueryItem> q_items;
   uint32_t cursor = 0;

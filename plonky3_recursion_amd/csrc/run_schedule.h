@@ -1,4 +1,4 @@
-// Structures of the prepared circuit shared by the host-side preparation (circuit_impl.cuh, layer_impl.cuh)
+// Structures of the prepared circuit shared by the host-side preparation (circuit_impl.hip.h, layer_impl.hip.h)
 // and the device-side one (prep_device.hip): the execution schedule of the verifier circuit
 // (CircuitRunner::run, circuit/src/tables/runner.rs:195-253, as a static levelised plan) and the ALU lane
 // schedule (AluAir::compute_schedule, circuit-prover/src/air/alu_air.rs:349-463, as a scatter plan).

@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "context.h"
-#include "kernels_stark.cuh"
+#include "kernels_stark.hip.h"
 
 namespace p3r {
 

@@ -1,8 +1,8 @@
-// K5: NTT tables, the passes of kernels_ntt.cuh / kernels_ntt2.cuh and the coset LDE of a batch of matrices
+// K5: NTT tables, the passes of kernels_ntt.hip.h / kernels_ntt2.hip.h and the coset LDE of a batch of matrices
 // (TwoAdicSubgroupDft::coset_lde_batch as TwoAdicFriPcs::commit uses it, circuit-prover/src/config.rs:55,131).
 // Own translation unit (tu_api.h).
 #include "tu_api.h"
-#include "kernels_ntt2.cuh"
+#include "kernels_ntt2.hip.h"
 #include "profile.h"
 
 #include <algorithm>
@@ -137,7 +137,7 @@ void launch_ntt(p3r_ctx* ctx, std::vector<NttJob>& jobs, const char* name) {
   P3R_HIP(hipGetLastError());
 }
 
-// The lean forward passes (kernels_ntt2.cuh): jobs grouped by the compile-time sub-transform size.
+// The lean forward passes (kernels_ntt2.hip.h): jobs grouped by the compile-time sub-transform size.
 template <class PP, int LOG_R, int MODE, int LOG_TILE>
 void launch_col_r(p3r_ctx* ctx, std::vector<NttColJob>& jobs, uint32_t blocks) {
   const auto* d = static_cast<const NttColJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(NttColJob)));
@@ -364,7 +364,7 @@ std::vector<std::unique_ptr<p3r_dmat>> coset_lde_batch(p3r_ctx* ctx, const std::
     auto tw4f = get_tw4<PP>(ctx, log_n, 0);
     if (lean_fwd && la_f >= kNtt2MinLogR && la_f <= kNtt2MaxLogR && lb_f >= kNtt2MinLogR && lb_f <= kNtt2MaxLineLogR &&
         lb_f >= kNtt2LogTile - la_f) {
-      // lean kernels (kernels_ntt2.cuh): the same two passes with compile-time geometry
+      // lean kernels (kernels_ntt2.hip.h): the same two passes with compile-time geometry
       NttColJob cj{};
       cj.in = coef; cj.out = out->d;
       cj.tw = get_tw_sub<PP>(ctx, la_f, 0);

@@ -1,4 +1,4 @@
-// Native verifier for the proofs prove_impl.cuh produces: `verify_batch` behind
+// Native verifier for the proofs prove_impl.hip.h produces: `verify_batch` behind
 // `BatchStarkProver::verify_all_tables` (circuit-prover/src/batch_stark_prover.rs:1230-1268,
 // 1649-1727).  Host code: verification is a few thousand permutations and is serial in the
 // reference too.  It replays the prover's transcript and checks, following the in-tree circuit
@@ -10,7 +10,7 @@
 //   MMCS openings (mixed heights, injection, cap)   recursion/src/pcs/mmcs.rs:319-426, circuit/src/ops/mmcs.rs:81-209
 //   FRI: reduced openings, folds, roll-ins, final polynomial, proofs of work
 //                                                   recursion/src/pcs/fri/verifier.rs:424-465,562-781,887-981,1068-1356
-// The AIR statements are the ones the quotient kernel evaluates (air_device.cuh), instantiated
+// The AIR statements are the ones the quotient kernel evaluates (air_device.hip.h), instantiated
 // over the extension field at zeta.
 #pragma once
 #include <array>
@@ -591,7 +591,7 @@ void mmcs_verify(const std::vector<std::array<Fp<PP>, P2_DIGEST>>& cap, int cap_
 
 // ---- the out-of-domain identity of one instance: folded constraints(zeta) / Z_H(zeta) == quotient(zeta)
 // (recursion/src/verifier/batch_stark.rs:886-1017, verifier/quotient.rs:60-140).  Shared by the
-// verifier and by the prover's self-check before it serialises a proof (prove_impl.cuh): the
+// verifier and by the prover's self-check before it serialises a proof (prove_impl.hip.h): the
 // counterpart of prove_batch's debug constraint check, at the cost of one evaluation per table.
 template <class PP, int DC = 4>
 struct ZetaInstance {
@@ -828,7 +828,7 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   std::sort(heights.rbegin(), heights.rend());
   heights.erase(std::unique(heights.begin(), heights.end()), heights.end());
   const int log_final = prm.log_final_poly_len + lb;
-  // the arity schedule the prover must have used (the FRI prover's rule, prove_impl.cuh step 7)
+  // the arity schedule the prover must have used (the FRI prover's rule, prove_impl.hip.h step 7)
   std::vector<int> las;
   {
     size_t next_h = 1;

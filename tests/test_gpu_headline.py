@@ -37,7 +37,7 @@ def test_headline_layer_proves_and_both_verifiers_accept(oracle, field, log_h):
     assert max(cpd.table_heights) == 1 << log_h
     # a second prove of the same inputs gives the same bytes (no stale pooled memory at this size)
     assert cache.prepared_circuit.prove(inputs) == out.proof.proof
-    # the host restatement of the preparation (csrc/circuit_impl.cuh) agrees with the device pass at this size:
+    # the host restatement of the preparation (csrc/circuit_impl.hip.h) agrees with the device pass at this size:
     # same preprocessed commitment, same schedule depth, same proof
     import os
     os.environ["P3R_PREP_HOST"] = "1"

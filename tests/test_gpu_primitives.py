@@ -96,7 +96,7 @@ def test_lde_golden(ctx, golden):
 
 @pytest.mark.parametrize("log_h,w,added", [(1, 1, 1), (2, 3, 2), (5, 4, 2), (8, 7, 1), (10, 3, 2), (11, 2, 2),
                                             (12, 3, 2), (13, 2, 1), (14, 2, 2), (15, 1, 2),
-                                            # every sub-transform size of the lean NTT kernels (kernels_ntt2.cuh): forward
+                                            # every sub-transform size of the lean NTT kernels (kernels_ntt2.hip.h): forward
                                             # 2^6..2^8 x 2^6..2^11, inverse 2^6..2^10 column passes; 1, 2, 4, 8 cosets
                                             (12, 2, 0), (13, 3, 3), (16, 2, 2), (16, 1, 3), (17, 1, 2), (18, 1, 2), (19, 1, 1), (20, 1, 1),
                                             (21, 1, 2)])

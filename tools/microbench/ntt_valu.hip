@@ -1,4 +1,4 @@
-// Is the forward line pass of the LDE (k_ntt_fwd_line, csrc/kernels_ntt2.cuh) bound by the arithmetic it issues, or by
+// Is the forward line pass of the LDE (k_ntt_fwd_line, csrc/kernels_ntt2.hip.h) bound by the arithmetic it issues, or by
 // what surrounds it (LDS exchange, barriers, the load / store phases of a workgroup)?
 //   line      the shipped kernel: 2^12-cell lines, three stage groups, two LDS exchanges + the copy-out exchange
 //   regs      the same butterflies and twiddle reads (twelve stages on the sixteen registers of a lane, the twiddle
@@ -10,8 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "kernels_ntt2.cuh"
-#include "poseidon2_f64.cuh"
+#include "kernels_ntt2.hip.h"
+#include "poseidon2_f64.hip.h"
 using namespace p3r;
 using PP = KoalaBearParams;
 using F = Fp<PP>;

@@ -1,4 +1,4 @@
-// FP64 issue rates on gfx950 and the FP64 Poseidon2 permutation (csrc/poseidon2_f64.cuh) against the
+// FP64 issue rates on gfx950 and the FP64 Poseidon2 permutation (csrc/poseidon2_f64.hip.h) against the
 // integer Montgomery one (csrc/poseidon2.h): bit-equality on random and edge-case states, and
 // permutations per second of both.  Output is committed under profiles/.
 #include <hip/hip_runtime.h>
@@ -6,7 +6,7 @@
 #include <cstdint>
 #include <vector>
 #include <random>
-#include "../../plonky3_recursion_amd/csrc/poseidon2_f64.cuh"
+#include "../../plonky3_recursion_amd/csrc/poseidon2_f64.hip.h"
 using namespace p3r;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 constexpr int ITER = 2048, UNROLL = 16;
