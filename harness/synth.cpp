@@ -54,7 +54,47 @@ enum { SYN_NO_POSEIDON2 = 1, SYN_NO_RECOMPOSE = 2, SYN_SINGLE_PUBLIC = 4, SYN_NO
        SYN_RECOMPOSE_COEFF = 32,
        // both Recompose tables in one layer: every op is drawn `recompose` or `recompose/coeff`; the rows of the second
        // kind go to recompose_coeff_values / recompose_coeff_prep and counts[6]
-       SYN_RECOMPOSE_BOTH = 64 };
+       SYN_RECOMPOSE_BOTH = 64,
+       // a width-32 Poseidon2 table next to the width-16 one (Poseidon2Config::*_D4_W32: the permutation of the arity-4
+       // MMCS, circuit-prover/tests/arity4_mmcs.rs): arity-4 Merkle chains (4-to-1 compressions, injection levels with
+       // zero pads, bridge levels) and rate-24 sponge chains.  D = 4 only; arrays p2w_*, counts[7].  The rows enter at
+       // the prove_all_tables boundary (they are not ops of the flattened circuit)
+       SYN_P2_W32 = 128 };
+
+// constants of the width-32 permutation (syn_set_w32): rc = [4][32] | partial | [4][32], diag = [32], canonical
+static const uint32_t* g_w32_rc = nullptr;
+static const uint32_t* g_w32_diag = nullptr;
+template <class PP, class F>
+void p2w_permute(F* s, const uint32_t* rc, const uint32_t* diag) {
+  constexpr int W = 32;
+  constexpr int PARTIAL = PP::P == 0x7f000001u ? 31 : 30;   // config.rs:88-100, :164-172
+  static const int M4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+  auto external = [&]() {
+    F o[W];
+    for (int i = 0; i < W; ++i) {
+      F acc = F::zero();
+      for (int j = 0; j < W; ++j) acc = acc + F::from_canonical((uint32_t)(M4[i % 4][j % 4] * (i / 4 == j / 4 ? 2 : 1))) * s[j];
+      o[i] = acc;
+    }
+    for (int i = 0; i < W; ++i) s[i] = o[i];
+  };
+  auto sbox = [&](F x) { const F x3 = x * x * x; return PP::SBOX_DEGREE == 3 ? x3 : x3 * x3 * x; };
+  external();
+  int k = 0;
+  auto full = [&]() {
+    for (int i = 0; i < W; ++i) s[i] = sbox(s[i] + F::from_canonical(rc[k + i]));
+    k += W;
+    external();
+  };
+  for (int r = 0; r < 4; ++r) full();
+  for (int r = 0; r < PARTIAL; ++r) {
+    s[0] = sbox(s[0] + F::from_canonical(rc[k++]));
+    F sum = F::zero();
+    for (int i = 0; i < W; ++i) sum = sum + s[i];
+    for (int i = 0; i < W; ++i) s[i] = s[i] * F::from_canonical(diag[i]) + sum;
+  }
+  for (int r = 0; r < 4; ++r) full();
+}
 
 enum { OP_ADD = 0, OP_MUL = 1, OP_BOOL = 2, OP_MULADD = 3, OP_HORNER = 4 };
 
@@ -452,6 +492,105 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     }
   }
 
+  // ---- the width-32 Poseidon2 table (SYN_P2_W32): H/4 rows of arity-4 Merkle chains and rate-24 sponge chains ----
+  // Row semantics (poseidon2-circuit-air/src/air.rs:1178-1342, recursion/src/pcs/mmcs.rs:1013-1075): the state is 8
+  // limbs of 4 elements, a chunk is CAPACITY_EXT = 2 limbs.  A Merkle continuation row carries the previous digest
+  // (output limbs 0, 1) in chunk pos = bit + 2 * bit2; the other chunks are free siblings, or - on an injection
+  // level (pos = 0) - chunk 1 an injected digest and chunks 2, 3 zero pads, all three CTL-loaded (in_ctl = 1); the
+  // two direction bits are read from the zero / one constant witnesses on every Merkle row.  A sponge row overwrites
+  // the six rate limbs from the bus and chains the capacity limbs.  The last row of a chain exposes its six rate
+  // output limbs (out_ctl).
+  size_t n_p2w = 0;
+  if (flags & SYN_P2_W32) {
+    if constexpr (D != 4) throw std::runtime_error("SYN_P2_W32: the width-32 table belongs to D = 4 circuits");
+    else {
+    if (!g_w32_rc || !g_w32_diag) throw std::runtime_error("SYN_P2_W32: call syn_set_w32 first");
+    n_p2w = std::max<size_t>(H / 4, 4);
+    auto& w_inputs = W.arr["p2w_inputs"];   // n x 32
+    auto& w_flags = W.arr["p2w_flags"];     // n x 4: new_start, merkle_path, mmcs_bit, mmcs_bit2
+    auto& w_sum = W.arr["p2w_mmcs_index_sum"];
+    auto& w_prep = W.arr["p2w_prep"];       // n x 48, assembled Poseidon2PreprocessedRow<8, 6>
+    struct WFix { size_t cell; uint32_t wid; };
+    std::vector<WFix> w_out_fix;            // out_ctl cells patched with the final read counts
+    F st[32];
+    for (auto& x : st) x = F::zero();
+    size_t r = 0;
+    const uint32_t ZERO_W = const_w[0], ONE_W = const_w[1];
+    while (r < n_p2w) {
+      const bool merkle = rng.unit() < 0.7;
+      size_t len = std::min<size_t>(merkle ? std::max(2, merkle_depth / 2) : std::max(1, sponge_chain_len), n_p2w - r);
+      uint32_t acc = 0;
+      for (size_t j = 0; j < len; ++j, ++r) {
+        const bool ns = j == 0, last = j + 1 == len;
+        F in[32];
+        uint32_t in_ctl[8] = {0}, in_idx[8] = {0};
+        bool bit = false, bit2 = false;
+        auto load = [&](int limb, uint32_t w) {   // CTL-loaded limb: a bus read of witness w
+          in_ctl[limb] = 1; in_idx[limb] = w; reads[w]++;
+          for (int d = 0; d < 4; ++d) in[limb * 4 + d] = wval[w].c[d];
+        };
+        if (merkle) {
+          const bool inject = !ns && rng.unit() < 0.3, bridge = !ns && !inject && rng.unit() < 0.2;
+          uint32_t pos = (inject || bridge) ? (bridge ? rng.below(2) : 0u) : rng.below(4);
+          bit = pos & 1; bit2 = pos & 2;
+          for (int i = 0; i < 32; ++i) in[i] = rf();          // free siblings (private data)
+          if (ns) {
+            // the leaf digest enters chunk pos from the bus
+            load(2 * pos, pickp_noread());
+            load(2 * pos + 1, pickp_noread());
+          } else {
+            for (int i = 0; i < 8; ++i) in[8 * pos + i] = st[i];   // running digest, bound by the placement constraint
+          }
+          if (inject) {
+            load(2, pickp_noread()); load(3, pickp_noread());   // injected digest in chunk 1
+            for (int l = 4; l < 8; ++l) load(l, ZERO_W);         // zero pads
+          } else if (bridge) {
+            for (int l = 4; l < 8; ++l) load(l, ZERO_W);         // a step-2 level: chunks 2, 3 are pads
+          }
+          reads[bit ? ONE_W : ZERO_W]++;
+          reads[bit2 ? ONE_W : ZERO_W]++;
+          acc = ns ? pos : (uint32_t)(((uint64_t)acc * 4 + pos) % P);
+        } else {
+          if (ns) for (int i = 0; i < 32; ++i) in[i] = F::zero();
+          else for (int i = 0; i < 32; ++i) in[i] = st[i];      // capacity (and un-overwritten rate) limbs chain
+          const int take = ns ? 6 : 1 + (int)rng.below(6);
+          for (int l = 0; l < take; ++l) load(l, pickp_noread());
+        }
+        for (int i = 0; i < 32; ++i) { w_inputs.push_back(in[i].to_canonical()); st[i] = in[i]; }
+        p2w_permute<PP>(st, g_w32_rc, g_w32_diag);
+        w_flags.push_back(ns); w_flags.push_back(merkle); w_flags.push_back(bit); w_flags.push_back(bit2);
+        w_sum.push_back(merkle ? acc : 0u);
+        // preprocessed row
+        for (int l = 0; l < 8; ++l) {
+          w_prep.push_back(in_idx[l] * D);
+          w_prep.push_back(in_ctl[l]);
+          w_prep.push_back((!ns && !merkle && !in_ctl[l]) ? 1u : 0u);
+          w_prep.push_back((!ns && merkle && !in_ctl[l]) ? 1u : 0u);
+        }
+        for (int l = 0; l < 6; ++l) {
+          if (last) {
+            E v; for (int d = 0; d < 4; ++d) v.c[d] = st[l * 4 + d];
+            const uint32_t w = create(v);
+            pickable.push_back(w);
+            w_prep.push_back(w * D);
+            w_out_fix.push_back({w_prep.size(), w});
+            w_prep.push_back(0);
+          } else {
+            w_prep.push_back(0); w_prep.push_back(0);
+          }
+        }
+        // arity-4: the accumulator slots carry the witnesses of the two direction bits (air.rs:1848-1870)
+        w_prep.push_back((merkle ? (bit ? ONE_W : ZERO_W) : 0u) * D);
+        w_prep.push_back((merkle ? (bit2 ? ONE_W : ZERO_W) : 0u) * D);
+        w_prep.push_back(ns);
+        w_prep.push_back(merkle);
+      }
+    }
+    W.arr["p2w_out_fix"].clear();
+    for (auto& f : w_out_fix) { W.arr["p2w_out_fix"].push_back((uint32_t)f.cell); W.arr["p2w_out_fix"].push_back(f.wid); }
+    }
+  }
+
   // ---- ALU ops: 3 lanes x ~H rows; Horner chains ride lane 0 (alu_air.rs:349-463) ----
   // Op mix: 45% Add, 30% Mul, 10% MulAdd, 14% HornerAcc (chains of
   // length U{4..horner_chain_len}), 1% BoolCheck; a few percent of the Add / Mul ops run
@@ -644,6 +783,12 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     }
   }
   for (auto& f : out_fix) p2_out_ctl[f.row * (D == 4 ? 2 : 8) + f.limb] = reads[f.wid];
+  if (n_p2w) {
+    auto& fix = W.arr["p2w_out_fix"];
+    auto& w_prep = W.arr["p2w_prep"];
+    for (size_t i = 0; i + 1 < fix.size(); i += 2) w_prep[fix[i]] = reads[fix[i + 1]] % P;
+    W.arr.erase("p2w_out_fix");
+  }
   // ALU per-op preprocessed, 13 columns (AluPrepLaneCols, alu_columns.rs:9-46; common.rs:198-281)
   auto& alu_prep = W.arr["alu_prep13"];
   const uint32_t neg1 = P - 1;
@@ -663,7 +808,8 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     alu_values.insert(alu_values.end(), 4 * D, 0u);
   }
   W.arr["counts"] = {(uint32_t)const_w.size(), (uint32_t)public_w.size(), (uint32_t)std::max<size_t>(ops.size(), 1),
-                     (uint32_t)n_p2, (uint32_t)(rec_w.size() - n_rec_second), (uint32_t)wval.size(), (uint32_t)n_rec_second};
+                     (uint32_t)n_p2, (uint32_t)(rec_w.size() - n_rec_second), (uint32_t)wval.size(), (uint32_t)n_rec_second,
+                     (uint32_t)n_p2w};
 }
 
 }  // namespace
@@ -696,6 +842,8 @@ void* syn_generate(int field, int log_h, uint64_t seed, int horner_chain_len, in
   }
   return W;
 }
+// constants of the width-32 permutation for SYN_P2_W32 (the pointers must stay valid during syn_generate)
+void syn_set_w32(const uint32_t* rc_canonical, const uint32_t* diag_canonical) { g_w32_rc = rc_canonical; g_w32_diag = diag_canonical; }
 const char* syn_error(void* h) { return static_cast<Workload*>(h)->err.c_str(); }
 int syn_get(void* h, const char* name, const uint32_t** ptr, size_t* len) {
   auto* W = static_cast<Workload*>(h);

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3R_ABI_VERSION 5
+#define P3R_ABI_VERSION 6
 
 enum {
   P3R_OK = 0,
@@ -112,6 +112,18 @@ typedef struct p3r_config {
    * koala_bear_quintic_params (test-utils/src/lib.rs:414-460; recursive_fibonacci --quintic;
    * recursion/tests/fibonacci_batch_stark_prover_quintic.rs).  Extension elements of the proof then hold five words. */
   uint32_t challenge_degree;
+  /* ABI version 6.  Constants of the WIDTH-32 Poseidon2 permutation (Poseidon2{Koala,Baby}Bear<32>, the permutation of
+   * the arity-4 MMCS: Poseidon2Config::{KOALA,BABY}_BEAR_D4_W32, circuit/src/ops/poseidon2_perm/config.rs:88-100,
+   * :164-172; 31 / 30 partial rounds).  poseidon2_w32_rc: [4][32] external-initial | [partial] internal | [4][32]
+   * external-final, canonical (p3_{koala,baby}_bear::*_POSEIDON2_RC_32_*, poseidon2-circuit-air/src/public_types.rs:
+   * 179-187,396-404); poseidon2_w32_diag: the 32 entries of the internal layer's diagonal
+   * (GenericPoseidon2LinearLayers<32> of the field crate).  Both live in un-vendored crates, so - like the width-16
+   * round constants - they are the caller's DATA; NULL selects self-generated defaults (tools/
+   * gen_poseidon2_constants.py: Grain LFSR constants, a diagonal of small integers and inverse powers of two), which
+   * are NOT pinned to upstream.  Used by the width-32 Poseidon2 table (P3R_AIR_POSEIDON2_W32). */
+  const uint32_t* poseidon2_w32_rc;
+  uint32_t poseidon2_w32_rc_len;
+  const uint32_t* poseidon2_w32_diag;   /* 32 canonical values, or NULL */
 } p3r_config;
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
@@ -168,6 +180,19 @@ typedef struct p3r_p2_rows {
   const uint8_t* mmcs_bit;        /* n */
   const uint32_t* mmcs_index_sum; /* n */
 } p3r_p2_rows;
+/* ABI version 6.  Rows of the WIDTH-32 table (arity-4 compression shape, 4 * CAPACITY_EXT == WIDTH_EXT:
+ * Poseidon2CircuitRow with mmcs_bit2; poseidon2-circuit-air/src/air.rs:370-432).  The main trace is
+ * [Poseidon2Cols<32> | mmcs_bit | mmcs_bit2 | mmcs_bit * mmcs_bit2 | mmcs_index_sum]; the index accumulator of a
+ * Merkle continuation row is 4 * previous + mmcs_bit + 2 * mmcs_bit2. */
+typedef struct p3r_p2w_rows {
+  size_t n;                       /* un-padded row count (0: the layer has no width-32 table) */
+  const uint32_t* input_values;   /* n x 32 row-major */
+  const uint8_t* new_start;       /* n */
+  const uint8_t* merkle_path;     /* n */
+  const uint8_t* mmcs_bit;        /* n: low bit of the position pos = mmcs_bit + 2 * mmcs_bit2 */
+  const uint8_t* mmcs_bit2;       /* n: high bit */
+  const uint32_t* mmcs_index_sum; /* n */
+} p3r_p2w_rows;
 
 /* Poseidon2CircuitAir::generate_trace_rows: trace_out is n x p3r_poseidon2_trace_width(). */
 int p3r_poseidon2_trace_fill(p3r_ctx* ctx, const p3r_p2_rows* rows, uint32_t* trace_out);
@@ -224,7 +249,9 @@ void p3r_tree_free(p3r_ctx* ctx, p3r_tree* tree);
  *                     (batch_stark_prover.rs:1493-1519) and writes the postcard bytes of
  *                     BatchProof (recursion/src/types/proof.rs:403-409).
  */
-enum { P3R_AIR_CONST = 0, P3R_AIR_PUBLIC = 1, P3R_AIR_ALU = 2, P3R_AIR_POSEIDON2 = 3, P3R_AIR_RECOMPOSE = 4 };
+/* P3R_AIR_POSEIDON2_W32 (ABI 6): Poseidon2CircuitAir{Koala,Baby}BearD4Width32, the table of the arity-4 MMCS rows -
+ * eval_arity4 (poseidon2-circuit-air/src/air.rs:1178-1342), 48 preprocessed columns, 16 bus interactions. */
+enum { P3R_AIR_CONST = 0, P3R_AIR_PUBLIC = 1, P3R_AIR_ALU = 2, P3R_AIR_POSEIDON2 = 3, P3R_AIR_RECOMPOSE = 4, P3R_AIR_POSEIDON2_W32 = 5 };
 
 /* One CircuitTableAir (circuit-prover/src/common.rs:90-100) of extension degree D = 4. */
 typedef struct p3r_air_desc {
@@ -281,6 +308,10 @@ typedef struct p3r_layer_desc_counts {
    * (recursion/src/challenger/circuit.rs:206-384, pcs/mmcs.rs:106-140), the coefficient kind for decomposition links
    * (circuit_builder.rs:1438-1477).  0: one Recompose table, of the kind recompose_coeff_lookups names. */
   size_t n_recompose_coeff;
+  /* ABI version 6.  Rows of the width-32 Poseidon2 table (`poseidon2_perm/<field>_d4_w32`), proved right after the
+   * width-16 one - the order a mixed-config verifier circuit enables them in (W16 challenger, W32 MMCS:
+   * recursion/examples/recursive_aggregation.rs:902-1000).  D = 4 circuits; 0: no such table. */
+  size_t n_p2w;
 } p3r_layer_desc_counts;
 
 typedef struct p3r_layer_desc {
@@ -318,6 +349,12 @@ typedef struct p3r_layer_desc {
   /* ABI version 5.  n_recompose_coeff x (2 + 2D): the rows of the second Recompose table (then recompose_prep holds
    * the plain kind and recompose_coeff_lookups must be 0).  The batch lists `recompose` before `recompose/coeff`. */
   const uint32_t* recompose_coeff_prep;
+  /* ABI version 6.  n_p2w x 48: the ASSEMBLED preprocessed rows of the width-32 table, Poseidon2PreprocessedRow<8, 6>
+   * as extract_preprocessed_from_operations + the prover's multiplicity pass leave them (poseidon-circuit-cols/src/
+   * preprocessed.rs; witness indices already D-scaled, canonical): 8 x {idx, in_ctl, normal_chain_sel,
+   * merkle_chain_sel} | 6 x {idx, out_ctl} | witness idx of mmcs_bit | witness idx of mmcs_bit2 | new_start |
+   * merkle_path.  Padding rows are added here (air.rs:613-649). */
+  const uint32_t* p2w_prep;
 } p3r_layer_desc;
 
 /* Flattened Traces<EF> (circuit/src/tables/mod.rs:49-62), canonical; D = p3r_config.ext_degree. */
@@ -328,6 +365,7 @@ typedef struct p3r_traces {
   p3r_p2_rows p2;     /* n = un-padded Poseidon2 row count (any n, padding is done here) */
   size_t n_recompose; const uint32_t* recompose_values; /* n x D */
   size_t n_recompose_coeff; const uint32_t* recompose_coeff_values; /* n x D: rows of the second Recompose table (ABI 5) */
+  p3r_p2w_rows p2w;   /* rows of the width-32 Poseidon2 table (ABI 6; n = 0 without one) */
 } p3r_traces;
 
 typedef struct p3r_layer p3r_layer;
@@ -339,6 +377,8 @@ void p3r_layer_free(p3r_ctx* ctx, p3r_layer* layer);
  * batch: a non-primitive table with no rows is left out, as `batch_instance_*` returning None does
  * (batch_stark_prover/poseidon2.rs:1089-1092, recompose.rs:77-80). */
 int p3r_layer_table_heights(const p3r_layer* layer, size_t heights_out[5]);
+/* Padded height of the width-32 Poseidon2 table (ABI version 6); 0 = absent. */
+int p3r_layer_p2w_height(const p3r_layer* layer, size_t* height_out);
 /* Padded height of the second Recompose table (`recompose/coeff` next to `recompose`, ABI version 5); 0 = absent. */
 int p3r_layer_recompose_coeff_height(const p3r_layer* layer, size_t* height_out);
 /* 1: the table at position 4 is the `recompose/coeff` kind (p3r_layer_desc.recompose_coeff_lookups, or a circuit whose

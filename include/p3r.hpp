@@ -256,7 +256,9 @@ struct BatchStarkProof {
     for (auto& e : non_primitives) {
       const bool p2 = e.op_type.rfind("poseidon2_perm/", 0) == 0;
       const bool d1 = e.op_type.size() >= 7 && e.op_type.compare(e.op_type.size() - 7, 7, "_d1_w16") == 0;
-      if (p2 && (ext_degree == 4 || d1)) a.push_back({P3R_AIR_POSEIDON2, 1, 2, 0});
+      const bool w32 = e.op_type.size() >= 7 && e.op_type.compare(e.op_type.size() - 7, 7, "_d4_w32") == 0;
+      if (p2 && w32 && ext_degree == 4) a.push_back({P3R_AIR_POSEIDON2_W32, 1, 2, 0});   // the table of the arity-4 MMCS rows
+      else if (p2 && (ext_degree == 4 || d1)) a.push_back({P3R_AIR_POSEIDON2, 1, 2, 0});
       else if (e.op_type == "recompose") a.push_back({P3R_AIR_RECOMPOSE, (uint32_t)e.lanes, 2, 0});
       else if (e.op_type == "recompose/coeff") a.push_back({P3R_AIR_RECOMPOSE, (uint32_t)e.lanes, 2, 1});
       else throw Error(P3R_EUNSUPPORTED, "MissingTableProver(" + e.op_type + ")");

@@ -14,7 +14,8 @@
 
 namespace orc {
 
-enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4 };
+// AIR_POSEIDON2_W32: the width-32 D = 4 table of the arity-4 MMCS (Poseidon2CircuitAir{Koala,Baby}BearD4Width32)
+enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4, AIR_POSEIDON2_W32 = 5 };
 // Circuit extension degree: 1 (base-field circuits), 4 (binomial x^4 = W) or 5 (KoalaBear quintic trinomial x^5 + x^2 - 1,
 // alu_air.rs:115-134; its Poseidon2 table is the compact-D1 width-16 one, eval_poseidon2_d1 below; Recompose is D = 4 only).
 // The STARK's own challenge field stays the degree-4 binomial extension, as in the reference's D = 5 unit tests
@@ -42,6 +43,7 @@ int air_width(const AirDesc& a) {
     case AIR_ALU: return a.lanes * 4 * D + (alu_num_int(a.horner_k) + 2 * (a.horner_k - 1) + 1) * D;  // alu_air.rs:320-325
     case AIR_POSEIDON2: return Poseidon2<FP>::perm_cols() + 2;               // air.rs:561-585
     case AIR_RECOMPOSE: return a.lanes * D;                                  // recompose_air.rs:96-119
+    case AIR_POSEIDON2_W32: return Poseidon2W32<FP>::perm_cols() + 4;        // num_cols_arity4 (cols.rs:122-130)
   }
   throw std::runtime_error("bad air kind");
 }
@@ -53,11 +55,12 @@ inline int air_prep_width(const AirDesc& a) {
     case AIR_ALU: return a.lanes * 13 + alu_extra_prep_width(a.horner_k);    // alu_air.rs:333-335
     case AIR_POSEIDON2: return D == 4 ? 4 * 4 + 2 * 2 + 4 : 26 + 16 + 8 + 8 + 4;  // preprocessed.rs:104-108, :127-145 (compact D1)
     case AIR_RECOMPOSE: return a.lanes * (2 + (a.coeff_lookups ? 2 * D : 0));
+    case AIR_POSEIDON2_W32: return 8 * 4 + 6 * 2 + 4;   // poseidon_preprocessed_row_width(WIDTH_EXT = 8, RATE_EXT = 6), preprocessed.rs:104-108
   }
   throw std::runtime_error("bad air kind");
 }
 // BaseAir::main_next_row_columns non-empty? (traits/air.rs:106-112: const/public/recompose omit it)
-inline bool air_uses_next(const AirDesc& a) { return a.kind == AIR_ALU || a.kind == AIR_POSEIDON2; }
+inline bool air_uses_next(const AirDesc& a) { return a.kind == AIR_ALU || a.kind == AIR_POSEIDON2 || a.kind == AIR_POSEIDON2_W32; }
 
 // ---- evaluation context ----
 template <class FP, class V>
@@ -449,6 +452,127 @@ void eval_poseidon2_d1(const AirDesc& a, const Poseidon2<FP>& p2, EvalCtx<FP, V>
   eval_poseidon2_perm<FP, V>(p2, b);
 }
 
+// ---- Poseidon2CircuitAir, arity-4 compression shape (D = 4, width 32: WIDTH_EXT = 8, RATE_EXT = 6, CAPACITY_EXT = 2) ----
+// interactions poseidon2-circuit-air/src/air.rs:1790-1870 (non-compact branch, is_arity4); circuit constraints
+// eval_arity4 :1178-1342; the inner permutation AIR over the first perm_cols columns as for width 16.
+template <class FP, class V>
+void eval_poseidon2_w32_perm(const Poseidon2W32<FP>& p2, EvalCtx<FP, V>& b) {
+  constexpr int R = FP::SBOX_REGS, W = WIDTH32;
+  const V* L = b.local;
+  const V zero = b.K(0);
+  auto full_off = [&](int r) { return W + r * (W * R + W); };
+  const int partial_off = full_off(HALF_FULL);
+  const int ending_off = partial_off + FP::PARTIAL_W32 * (R + 1);
+  auto end_off = [&](int r) { return ending_off + r * (W * R + W); };
+  std::array<V, W> s;
+  for (int i = 0; i < W; ++i) s[i] = L[i];
+  auto external = [&](std::array<V, W>& st) {
+    std::array<V, W> o;
+    for (int i = 0; i < W; ++i) {
+      V acc = zero;
+      for (int j = 0; j < W; ++j) acc = acc + st[j] * b.KF(Poseidon2W32<FP>::ext_entry(i, j));
+      o[i] = acc;
+    }
+    st = o;
+  };
+  auto internal = [&](std::array<V, W>& st) {
+    V sum = zero;
+    for (auto& x : st) sum = sum + x;
+    for (int i = 0; i < W; ++i) st[i] = st[i] * b.KF(p2.diag[i]) + sum;
+  };
+  auto sbox = [&](V x, const V* reg) -> V {
+    if (FP::SBOX_DEGREE == 3) return x * x * x;
+    V c3 = reg[0];
+    b.assert_zero(c3 - x * x * x);
+    return c3 * c3 * x;
+  };
+  external(s);
+  int k = 0;
+  auto full_round = [&](int col) {
+    for (int i = 0; i < W; ++i) {
+      V x = s[i] + b.KF(p2.rc[k + i]);
+      s[i] = sbox(x, L + col + i * R);
+    }
+    k += W;
+    external(s);
+    const V* post = L + col + W * R;
+    for (int i = 0; i < W; ++i) {
+      b.assert_zero(s[i] - post[i]);
+      s[i] = post[i];
+    }
+  };
+  for (int r = 0; r < HALF_FULL; ++r) full_round(full_off(r));
+  for (int r = 0; r < FP::PARTIAL_W32; ++r) {
+    int col = partial_off + r * (R + 1);
+    V x = s[0] + b.KF(p2.rc[k++]);
+    s[0] = sbox(x, L + col);
+    b.assert_zero(s[0] - L[col + R]);
+    s[0] = L[col + R];
+    internal(s);
+  }
+  for (int r = 0; r < HALF_FULL; ++r) full_round(end_off(r));
+}
+
+template <class FP, class V>
+void eval_poseidon2_w32(const Poseidon2W32<FP>& p2, EvalCtx<FP, V>& b) {
+  constexpr int D = 4, WE = 8, RE = 6, CE = 2, R = FP::SBOX_REGS, W = WIDTH32;
+  const int pc = Poseidon2W32<FP>::perm_cols();
+  const V* L = b.local; const V* N = b.next; const V* PL = b.prep_local; const V* PN = b.prep_next;
+  const int out_off = pc - W;   // ending_full_rounds[3].post: the last W columns of Poseidon2Cols
+  const V* local_out = L + out_off;
+  const V* next_in = N;
+  const V bit = L[pc], bit2 = L[pc + 1], bit_x_bit2 = L[pc + 2], index_sum = L[pc + 3];
+  const V next_bit = N[pc], next_bit2 = N[pc + 1], next_bit_x_bit2 = N[pc + 2], next_index_sum = N[pc + 3];
+  (void)R;
+  // prep row: input_limbs[8]{idx, in_ctl, normal_chain_sel, merkle_chain_sel} | output_limbs[6]{idx, out_ctl}
+  //           | mmcs_index_sum_ctl_idx (here: witness of bit 0) | mmcs_merkle_flag (here: witness of bit 1) | new_start | merkle_path
+  auto in_limb = [&](const V* P, int l, int f) { return P[l * 4 + f]; };
+  auto out_limb = [&](const V* P, int l, int f) { return P[WE * 4 + l * 2 + f]; };
+  const int tail = WE * 4 + RE * 2;
+  const V one = b.K(1), zero = b.K(0);
+
+  // --- interactions (air.rs:1790-1870) ---
+  for (int l = 0; l < WE; ++l) {
+    std::vector<V> f{in_limb(PL, l, 0)};
+    for (int d = 0; d < D; ++d) f.push_back(L[l * D + d]);
+    b.push_interaction(std::move(f), zero - in_limb(PL, l, 1));   // arity-4: the bare in_ctl (pads and injected slots only)
+  }
+  for (int l = 0; l < RE; ++l) {
+    std::vector<V> f{out_limb(PL, l, 0)};
+    for (int d = 0; d < D; ++d) f.push_back(local_out[l * D + d]);
+    b.push_interaction(std::move(f), out_limb(PL, l, 1));
+  }
+  {
+    const V merkle = PL[tail + 3];
+    std::vector<V> f0{PL[tail], bit};
+    for (int d = 1; d < D; ++d) f0.push_back(zero);
+    b.push_interaction(std::move(f0), zero - merkle);
+    std::vector<V> f1{PL[tail + 1], bit2};
+    for (int d = 1; d < D; ++d) f1.push_back(zero);
+    b.push_interaction(std::move(f1), zero - merkle);
+  }
+
+  // --- circuit constraints (eval_arity4) ---
+  b.assert_zero(bit * (one - bit));
+  b.assert_zero(bit2 * (one - bit2));
+  b.assert_zero(bit_x_bit2 - bit * bit2);
+  for (int l = 0; l < WE; ++l)
+    for (int d = 0; d < D; ++d)
+      b.assert_zero(b.is_transition * in_limb(PN, l, 2) * (next_in[l * D + d] - local_out[l * D + d]));
+  const V h[4] = {one - next_bit - next_bit2 + next_bit_x_bit2, next_bit - next_bit_x_bit2, next_bit2 - next_bit_x_bit2, next_bit_x_bit2};
+  for (int chunk = 0; chunk < 4; ++chunk)
+    for (int slot = 0; slot < CE; ++slot) {
+      const int g = chunk * CE + slot;
+      const V gate = in_limb(PN, g, 3) * h[chunk];
+      for (int d = 0; d < D; ++d)
+        b.assert_zero(b.is_transition * gate * (next_in[g * D + d] - local_out[slot * D + d]));
+    }
+  b.assert_zero(b.is_transition * (one - PN[tail + 2]) * PN[tail + 3] *
+                (next_index_sum - (index_sum * b.K(4) + next_bit + b.K(2) * next_bit2)));
+
+  eval_poseidon2_w32_perm<FP, V>(p2, b);
+}
+
 template <class FP, class V>
 void eval_air(const AirDesc& a, const Poseidon2<FP>& p2, EvalCtx<FP, V>& b) {
   switch (a.kind) {
@@ -460,6 +584,10 @@ void eval_air(const AirDesc& a, const Poseidon2<FP>& p2, EvalCtx<FP, V>& b) {
       else eval_poseidon2_d1<FP, V>(a, p2, b);
       break;
     case AIR_RECOMPOSE: eval_recompose<FP, V>(a, b); break;
+    case AIR_POSEIDON2_W32:
+      if (a.D != 4 || !p2.w32) throw std::runtime_error("the width-32 Poseidon2 table is the D = 4 one and needs its constants");
+      eval_poseidon2_w32<FP, V>(*p2.w32, b);
+      break;
     default: throw std::runtime_error("bad air kind");
   }
 }

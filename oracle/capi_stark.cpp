@@ -45,6 +45,13 @@ typedef struct orc_workload {
    * batch_stark_prover.rs:1914-1932: `recompose`, then `recompose/coeff`): n x D values, n x (2 + 2 D) preprocessed;
    * recompose_prep is then the plain table and recompose_coeff_lookups is 0 */
   size_t n_recompose_coeff; const uint32_t* recompose_coeff_values; const uint32_t* recompose_coeff_prep;
+  /* the width-32 Poseidon2 table of the arity-4 MMCS (Poseidon2Config::*_D4_W32; D = 4 circuits), proved right after the
+   * width-16 one: n x 32 inputs, n x 4 flags (new_start, merkle_path, mmcs_bit, mmcs_bit2), n index sums, and the
+   * ASSEMBLED preprocessed rows n x 48 (Poseidon2PreprocessedRow<8, 6>: 8 x {idx, in_ctl, normal_chain_sel,
+   * merkle_chain_sel} | 6 x {idx, out_ctl} | bit-0 witness idx | bit-1 witness idx | new_start | merkle_path);
+   * w32_rc / w32_diag: the permutation's constants (canonical; 8 * 32 + partial rounds, 32) */
+  size_t n_p2w; const uint32_t* p2w_inputs; const uint32_t* p2w_flags; const uint32_t* p2w_mmcs_index_sum; const uint32_t* p2w_prep;
+  const uint32_t* w32_rc; const uint32_t* w32_diag;
 } orc_workload;
 
 typedef struct orc_params {
@@ -197,6 +204,31 @@ struct Layer : LayerBase {
       in.prep = D == 4 ? p2_preprocessed_trace<FP>(ctl, n) : p2_preprocessed_trace_d1<FP>(ctl1, n, D);
       insts.push_back(std::move(in));
     }
+    if (w.n_p2w > 0) {
+      if (D != 4) throw std::runtime_error("the width-32 Poseidon2 table belongs to D = 4 circuits");
+      if (!w.w32_rc || !w.w32_diag) throw std::runtime_error("the width-32 Poseidon2 table needs its constants");
+      p2.w32 = std::make_shared<Poseidon2W32<FP>>(w.w32_rc, w.w32_diag);
+      Instance<FP> in;
+      in.air.kind = AIR_POSEIDON2_W32; in.air.D = 4;
+      size_t n = 1;
+      while (n < std::max(w.n_p2w, mh)) n <<= 1;
+      std::vector<P2WRow<FP>> rows(n);
+      for (size_t r = 0; r < n; ++r) {
+        if (r >= w.n_p2w) { rows[r].new_start = true; continue; }   // filler rows: new_start, zero state
+        rows[r].new_start = w.p2w_flags[r * 4 + 0]; rows[r].merkle_path = w.p2w_flags[r * 4 + 1];
+        rows[r].mmcs_bit = w.p2w_flags[r * 4 + 2]; rows[r].mmcs_bit2 = w.p2w_flags[r * 4 + 3];
+        rows[r].mmcs_index_sum = F(w.p2w_mmcs_index_sum[r]);
+        for (int k = 0; k < 32; ++k) rows[r].input[k] = F(w.p2w_inputs[r * 32 + k]);
+      }
+      in.main = p2w_generate_trace_rows<FP>(*p2.w32, rows);
+      // BaseAir::preprocessed_trace padding (air.rs:613-649): zero rows, the first one with new_start = 1 at width - 2
+      const size_t pw = 48;
+      in.prep = Matrix<FP>(n, pw);
+      auto cells = vec(w.p2w_prep, w.n_p2w * pw);
+      std::copy(cells.begin(), cells.end(), in.prep.v.begin());
+      if (n > w.n_p2w) in.prep.v[w.n_p2w * pw + pw - 2] = F::one();
+      insts.push_back(std::move(in));
+    }
     if (w.n_recompose > 0) {
       Instance<FP> in;
       in.air.kind = AIR_RECOMPOSE; in.air.lanes = (int)w.recompose_lanes; in.air.D = D; in.air.W = W;
@@ -315,6 +347,36 @@ int orc_verify_batch(int field, const uint32_t* rc, const orc_params* p, size_t 
         a.coeff_lookups = (int)(airs4[4 * i + 3] & 0xFF);
         a.D = ((airs4[4 * i + 3] >> 8) & 0xFF) ? (int)((airs4[4 * i + 3] >> 8) & 0xFF) : 4;   // bits 8..15: extension degree of the circuit (0 = 4)
         a.W = a.D == 2 || a.D == 6 || a.D == 8 ? airs4[4 * i + 3] >> 16 : 0;                   // bits 16..: W of a generic binomial (small W only)
+        shapes.push_back({a});
+      }
+      typename BatchProof<FP>::Cap cap(size_t(1) << p->cap_height);
+      const uint32_t* c = prep_cap;
+      for (auto& d : cap) for (auto& x : d) x = F(*c++);
+      verify_batch<FP>(p2, to_sp(*p), shapes, cap, proof);
+    };
+    if (field == 0) run(KoalaBear{});
+    else if (field == 1) run(BabyBear{});
+    else throw std::runtime_error("unknown field id");
+  });
+}
+
+// the same with the constants of the width-32 permutation, for statements that hold an AIR_POSEIDON2_W32 instance
+int orc_verify_batch_w32(int field, const uint32_t* rc, const uint32_t* w32_rc, const uint32_t* w32_diag, const orc_params* p,
+                         size_t n_airs, const uint32_t* airs4, const uint32_t* prep_cap, const uint8_t* bytes, size_t len,
+                         int field_encoding) {
+  return guard2([&] {
+    auto run = [&](auto tag) {
+      using FP = decltype(tag);
+      using F = Fe<FP>;
+      Poseidon2<FP> p2(rc);
+      p2.w32 = std::make_shared<Poseidon2W32<FP>>(w32_rc, w32_diag);
+      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p));
+      std::vector<InstanceShape> shapes;
+      for (size_t i = 0; i < n_airs; ++i) {
+        AirDesc a;
+        a.kind = (int)airs4[4 * i]; a.lanes = (int)airs4[4 * i + 1]; a.horner_k = (int)airs4[4 * i + 2];
+        a.coeff_lookups = (int)(airs4[4 * i + 3] & 0xFF);
+        a.D = ((airs4[4 * i + 3] >> 8) & 0xFF) ? (int)((airs4[4 * i + 3] >> 8) & 0xFF) : 4;
         shapes.push_back({a});
       }
       typename BatchProof<FP>::Cap cap(size_t(1) << p->cap_height);

@@ -28,6 +28,7 @@ struct KoalaBear {
   static constexpr int SBOX_DEGREE = 3;
   static constexpr int SBOX_REGS = 0;
   static constexpr int PARTIAL = 20;
+  static constexpr int PARTIAL_W32 = 31;   // Poseidon2Config::KOALA_BEAR_D4_W32 (circuit/src/ops/poseidon2_perm/config.rs:164-172)
 };
 struct BabyBear {
   static constexpr uint32_t P = 0x78000001u;
@@ -37,6 +38,7 @@ struct BabyBear {
   static constexpr int SBOX_DEGREE = 7;
   static constexpr int SBOX_REGS = 1;
   static constexpr int PARTIAL = 13;
+  static constexpr int PARTIAL_W32 = 30;   // Poseidon2Config::BABY_BEAR_D4_W32 (config.rs:88-100)
 };
 
 template <class FP>

@@ -3,6 +3,7 @@
 // PARITY UNPINNED (see field.hpp).  Each function cites the in-tree restatement it follows.
 #pragma once
 #include <algorithm>
+#include <memory>
 #include <numeric>
 
 #include "field.hpp"
@@ -11,9 +12,70 @@ namespace orc {
 
 constexpr int WIDTH = 16, RATE = 8, DIGEST = 8, HALF_FULL = 4;
 
+// Poseidon2 width 32 (Poseidon2{Koala,Baby}Bear<32>: the permutation of the arity-4 MMCS, circuit-prover/tests/arity4_mmcs.rs:42-47):
+// same round structure as width 16 - external layer circ(2 M4, M4, .., M4) over eight blocks, internal layer
+// diag + all-ones - with 31 / 30 partial rounds.  Round constants AND the internal diagonal are the caller's data
+// (upstream's live in un-vendored crates and are not restated in-tree).
+constexpr int WIDTH32 = 32;
+template <class FP>
+struct Poseidon2W32 {
+  using F = Fe<FP>;
+  std::vector<F> rc;                       // [4][32] | [PARTIAL_W32] | [4][32]
+  std::array<F, WIDTH32> diag;
+  static constexpr int num_constants() { return 2 * HALF_FULL * WIDTH32 + FP::PARTIAL_W32; }
+  static constexpr int perm_cols() {
+    return WIDTH32 + 2 * HALF_FULL * (WIDTH32 * FP::SBOX_REGS + WIDTH32) + FP::PARTIAL_W32 * (FP::SBOX_REGS + 1);
+  }
+  Poseidon2W32(const uint32_t* rc_canonical, const uint32_t* diag_canonical) {
+    rc.resize(num_constants());
+    for (int i = 0; i < num_constants(); ++i) rc[i] = F(rc_canonical[i]);
+    for (int i = 0; i < WIDTH32; ++i) diag[i] = F(diag_canonical[i]);
+  }
+  static F ext_entry(int i, int j) {
+    static const int M4[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+    return F((uint64_t)M4[i % 4][j % 4] * ((i / 4 == j / 4) ? 2 : 1));
+  }
+  void external(std::array<F, WIDTH32>& s) const {
+    std::array<F, WIDTH32> o{};
+    for (int i = 0; i < WIDTH32; ++i)
+      for (int j = 0; j < WIDTH32; ++j) o[i] += ext_entry(i, j) * s[j];
+    s = o;
+  }
+  void internal(std::array<F, WIDTH32>& s) const {
+    F sum = F::zero();
+    for (auto& x : s) sum += x;
+    for (int i = 0; i < WIDTH32; ++i) s[i] = s[i] * diag[i] + sum;
+  }
+  void permute(std::array<F, WIDTH32>& s, std::vector<F>* cells = nullptr) const {
+    if (cells) for (auto& x : s) cells->push_back(x);
+    external(s);
+    int k = 0;
+    auto full = [&]() {
+      for (int i = 0; i < WIDTH32; ++i) {
+        F x = s[i] + rc[k + i];
+        if (FP::SBOX_REGS == 1 && cells) cells->push_back(x * x * x);
+        s[i] = x.pow(FP::SBOX_DEGREE);
+      }
+      k += WIDTH32;
+      external(s);
+      if (cells) for (auto& x : s) cells->push_back(x);
+    };
+    for (int r = 0; r < HALF_FULL; ++r) full();
+    for (int r = 0; r < FP::PARTIAL_W32; ++r) {
+      F x = s[0] + rc[k++];
+      if (FP::SBOX_REGS == 1 && cells) cells->push_back(x * x * x);
+      s[0] = x.pow(FP::SBOX_DEGREE);
+      if (cells) cells->push_back(s[0]);
+      internal(s);
+    }
+    for (int r = 0; r < HALF_FULL; ++r) full();
+  }
+};
+
 template <class FP>
 struct Poseidon2 {
   using F = Fe<FP>;
+  std::shared_ptr<Poseidon2W32<FP>> w32;   // set when the layer holds a width-32 table (AIR_POSEIDON2_W32)
   // flat: [4][16] external-initial | [PARTIAL] internal | [4][16] external-final
   // (poseidon2-circuit-air/src/public_types.rs:48-54,220-226 name the upstream statics)
   std::vector<F> rc;

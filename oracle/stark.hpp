@@ -106,6 +106,7 @@ inline std::vector<int> interaction_mult_degrees(const AirDesc& a) {
       // compact D1: 8 rate sends (in_ctl * not_merkle), 8 output receives, the accumulator send (air.rs:1721-1785)
       d.assign(8, 2); d.insert(d.end(), 8, 1); d.push_back(2);
       break;
+    case AIR_POSEIDON2_W32: d.assign(8 + 6 + 2, 1); break;   // in_ctl sends, out_ctl receives, the two direction-bit reads (-merkle_path)
   }
   return d;
 }
@@ -116,6 +117,7 @@ int air_base_constraint_degree(const AirDesc& a) {
   switch (a.kind) {
     case AIR_ALU: return 3;
     case AIR_POSEIDON2: return 3;
+    case AIR_POSEIDON2_W32: return 3;   // eval_arity4's degree notes, air.rs:1168-1176
     default: return 0;
   }
 }

@@ -44,6 +44,42 @@ Matrix<FP> p2_generate_trace_rows(const Poseidon2<FP>& p2, const std::vector<P2R
   return m;
 }
 
+// The width-32 table (arity-4 compression shape, 4 * CAPACITY_EXT == WIDTH_EXT): same two passes, the arity-4 layout
+// [Poseidon2Cols | mmcs_bit | mmcs_bit2 | mmcs_bit * mmcs_bit2 | mmcs_index_sum] and a base-four accumulator
+// (air.rs:370-432: continuation Merkle rows use 4 * acc + bit + 2 * bit2).
+template <class FP>
+struct P2WRow {
+  bool new_start = false, merkle_path = false, mmcs_bit = false, mmcs_bit2 = false;
+  Fe<FP> mmcs_index_sum;
+  std::array<Fe<FP>, WIDTH32> input{};
+};
+template <class FP>
+Matrix<FP> p2w_generate_trace_rows(const Poseidon2W32<FP>& p2, const std::vector<P2WRow<FP>>& rows) {
+  using F = Fe<FP>;
+  const size_t n = rows.size();
+  log2_strict(n);
+  const size_t pc = Poseidon2W32<FP>::perm_cols(), ncols = pc + 4;
+  Matrix<FP> m(n, ncols);
+  F prev = F::zero();
+  for (size_t i = 0; i < n; ++i) {
+    const auto& op = rows[i];
+    if (i > 0 && op.merkle_path && !op.new_start)
+      prev = prev * F(4) + (op.mmcs_bit ? F::one() : F::zero()) + (op.mmcs_bit2 ? F(2) : F::zero());
+    else
+      prev = op.mmcs_index_sum;
+    std::vector<F> cells;
+    auto s = op.input;
+    p2.permute(s, &cells);
+    if (cells.size() != pc) throw std::runtime_error("Poseidon2Cols<32> width mismatch");
+    for (size_t c = 0; c < cells.size(); ++c) m.at(i, c) = cells[c];
+    m.at(i, pc) = op.mmcs_bit ? F::one() : F::zero();
+    m.at(i, pc + 1) = op.mmcs_bit2 ? F::one() : F::zero();
+    m.at(i, pc + 2) = (op.mmcs_bit && op.mmcs_bit2) ? F::one() : F::zero();
+    m.at(i, pc + 3) = prev;
+  }
+  return m;
+}
+
 }  // namespace orc
 
 // ===========================================================================================

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # P3R_LIB_PATH: A/B runs of two builds of the library on one box (development only)
 LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so")
 
-P3R_ABI_VERSION = 5
+P3R_ABI_VERSION = 6
 P3R_EXT_LOOKUP_UNPACKED = 1
 FIELD_KOALA_BEAR = 0
 FIELD_BABY_BEAR = 1
@@ -35,6 +35,9 @@ class P3rConfig(C.Structure):
         ("fri_log_arities_len", C.c_uint32),
         ("proof_layout", C.POINTER(C.c_uint8)),
         ("proof_layout_len", C.c_uint32), ("ext_w", C.c_uint32), ("challenge_degree", C.c_uint32),
+        # ABI 6: constants of the width-32 permutation (NULL = the self-generated defaults)
+        ("poseidon2_w32_rc", C.POINTER(C.c_uint32)), ("poseidon2_w32_rc_len", C.c_uint32),
+        ("poseidon2_w32_diag", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -49,6 +52,18 @@ class P3rP2Rows(C.Structure):
     ]
 
 
+class P3rP2wRows(C.Structure):   # rows of the width-32 Poseidon2 table (ABI 6)
+    _fields_ = [
+        ("n", C.c_size_t),
+        ("input_values", C.POINTER(C.c_uint32)),
+        ("new_start", C.POINTER(C.c_uint8)),
+        ("merkle_path", C.POINTER(C.c_uint8)),
+        ("mmcs_bit", C.POINTER(C.c_uint8)),
+        ("mmcs_bit2", C.POINTER(C.c_uint8)),
+        ("mmcs_index_sum", C.POINTER(C.c_uint32)),
+    ]
+
+
 class P3rMatrix(C.Structure):
     _fields_ = [("values", C.POINTER(C.c_uint32)), ("height", C.c_size_t), ("width", C.c_size_t)]
 
@@ -59,7 +74,7 @@ class P3rAirDesc(C.Structure):
 
 
 class P3rLayerCounts(C.Structure):
-    _fields_ = [(n, C.c_size_t) for n in ("n_const", "n_public", "n_alu", "n_p2", "n_recompose", "n_recompose_coeff")]
+    _fields_ = [(n, C.c_size_t) for n in ("n_const", "n_public", "n_alu", "n_p2", "n_recompose", "n_recompose_coeff", "n_p2w")]
 
 
 class P3rLayerDesc(C.Structure):
@@ -75,6 +90,7 @@ class P3rLayerDesc(C.Structure):
         ("p2_output_indices", C.POINTER(C.c_uint32)), ("p2_mmcs_index_sum_idx", C.POINTER(C.c_uint32)),
         ("p2_absorb_len", C.POINTER(C.c_uint8)), ("recompose_coeff_lookups", C.c_uint32),
         ("recompose_coeff_prep", C.POINTER(C.c_uint32)),
+        ("p2w_prep", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -86,6 +102,7 @@ class P3rTraces(C.Structure):
         ("p2", P3rP2Rows),
         ("n_recompose", C.c_size_t), ("recompose_values", C.POINTER(C.c_uint32)),
         ("n_recompose_coeff", C.c_size_t), ("recompose_coeff_values", C.POINTER(C.c_uint32)),
+        ("p2w", P3rP2wRows),
     ]
 
 
@@ -187,6 +204,7 @@ SIGNATURES = {
     "p3r_layer_free": (None, [vp, vp]),
     "p3r_layer_table_heights": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "p3r_layer_recompose_coeff_height": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "p3r_layer_p2w_height": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "p3r_layer_recompose_kind": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "p3r_layer_effective_lanes": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "p3r_verify_batch": (C.c_int, [C.POINTER(P3rConfig), C.POINTER(P3rAirDesc), C.c_size_t, u32p, u32p,

@@ -19,7 +19,12 @@
 
 namespace p3r {
 
-enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4 };
+// AIR_POSEIDON2_W32: the width-32 D = 4 table of the arity-4 MMCS (Poseidon2CircuitAir{Koala,Baby}BearD4Width32,
+// poseidon2-circuit-air/src/public_types.rs:179-187,396-404)
+enum AirKind { AIR_CONST = 0, AIR_PUBLIC = 1, AIR_ALU = 2, AIR_POSEIDON2 = 3, AIR_RECOMPOSE = 4, AIR_POSEIDON2_W32 = 5 };
+// its preprocessed row (Poseidon2PreprocessedRow<WIDTH_EXT = 8, RATE_EXT = 6>, poseidon-circuit-cols/src/preprocessed.rs):
+//   8 x {idx, in_ctl, normal_chain_sel, merkle_chain_sel} | 6 x {idx, out_ctl} | bit-0 witness | bit-1 witness | new_start | merkle_path
+constexpr int kP2WPrepWidth = 48, kP2WOutLimbs = 32, kP2WTail = 44;
 
 constexpr int kMaxExtD = 8;  // widest circuit extension: bus tuples hold at most 1 + kMaxExtD fields
 // compact-D1 Poseidon2 preprocessed row (poseidon-circuit-cols/src/preprocessed.rs:121-145), 62 columns:
@@ -200,6 +205,23 @@ P3R_HD void air_interactions(const AirParams& a, const View& v, Sink& sink) {
         }
         t.c[0] = v.L(pc + 1);
         sink.add(v.PL(kP2D1Tail), t, -(v.PL(kP2D1Tail + 1) * v.PN(kP2D1Tail + 2)));
+      }
+      break;
+    case AIR_POSEIDON2_W32:
+      // non-compact branch with is_arity4 (air.rs:1790-1870): 8 input sends with the bare in_ctl (pads and injected
+      // slots only), 6 output receives, and the two direction bits read from their witnesses on Merkle rows
+      if constexpr (D == 4) {
+        constexpr int pc = p2w_perm_cols<PP>();
+        constexpr int out_col = pc - P2W_WIDTH;
+        for (int l = 0; l < 8; ++l) sink.add(v.PL(l * 4), load4<F>(L, l * 4), -v.PL(l * 4 + 1));
+        for (int l = 0; l < 6; ++l) sink.add(v.PL(kP2WOutLimbs + l * 2), load4<F>(L, out_col + l * 4), v.PL(kP2WOutLimbs + l * 2 + 1));
+        const F neg_merkle = -v.PL(kP2WTail + 3);
+        V4<F> t;
+        t.c[1] = t.c[2] = t.c[3] = F::zero();
+        t.c[0] = v.L(pc);
+        sink.add(v.PL(kP2WTail), t, neg_merkle);
+        t.c[0] = v.L(pc + 1);
+        sink.add(v.PL(kP2WTail + 1), t, neg_merkle);
       }
       break;
   }
@@ -414,6 +436,91 @@ P3R_HD void poseidon2_d1_constraints(const View& v, typename View::V is_transiti
   poseidon2_perm_constraints<PP>(v, rc, fold);
 }
 
+// The width-32 table: p3_poseidon2_air::eval over Poseidon2Cols<32> (rcw = the width-32 constant table, poseidon2.h)
+template <class PP, class View, class Fold>
+P3R_HD void poseidon2w_perm_constraints(const View& v, const uint32_t* __restrict__ rcw, Fold& fold) {
+  using F = typename View::V;
+  using B = Fp<PP>;
+  constexpr int R = PP::SBOX_REGISTERS, W = P2W_WIDTH;
+  const uint32_t* diag = rcw + p2w_num_rc<PP>();
+  F s[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) s[i] = v.L(i);
+  p2w_external_linear(s);
+  int k = 0, col = W;
+  auto full_round = [&]() {
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      F x = s[i] + Lift<F>::of(B::raw(rcw[k + i]));
+      if (R == 1) {
+        F c3 = v.L(col + i);
+        fold.base(c3 - x.sqr() * x);
+        s[i] = c3.sqr() * x;
+      } else {
+        s[i] = x.sqr() * x;
+      }
+    }
+    k += W;
+    col += W * R;
+    p2w_external_linear(s);
+#pragma unroll
+    for (int i = 0; i < W; ++i) {
+      F post = v.L(col + i);
+      fold.base(s[i] - post);
+      s[i] = post;
+    }
+    col += W;
+  };
+  for (int r = 0; r < P2_HALF_FULL; ++r) full_round();
+  for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) {
+    F x = s[0] + Lift<F>::of(B::raw(rcw[k++]));
+    if (R == 1) {
+      F c3 = v.L(col);
+      fold.base(c3 - x.sqr() * x);
+      s[0] = c3.sqr() * x;
+      col += 1;
+    } else {
+      s[0] = x.sqr() * x;
+    }
+    F post = v.L(col);
+    fold.base(s[0] - post);
+    s[0] = post;
+    col += 1;
+    p2w_internal_linear<PP, F>(s, diag);
+  }
+  for (int r = 0; r < P2_HALF_FULL; ++r) full_round();
+}
+// eval_arity4 (poseidon2-circuit-air/src/air.rs:1178-1342): booleanity of both direction bits, the product column,
+// sponge chaining, the running-hash placement into chunk pos = bit + 2 * bit2, the base-four index accumulator
+template <class PP, class View, class Fold>
+P3R_HD void poseidon2w_constraints(const View& v, typename View::V is_transition, const uint32_t* __restrict__ rcw, Fold& fold) {
+  using F = typename View::V;
+  constexpr int pc = p2w_perm_cols<PP>();
+  constexpr int out_col = pc - P2W_WIDTH;
+  const F one = F::one();
+  const F bit = v.L(pc), bit2 = v.L(pc + 1), bxb = v.L(pc + 2), index_sum = v.L(pc + 3);
+  const F nbit = v.N(pc), nbit2 = v.N(pc + 1), nbxb = v.N(pc + 2), next_index_sum = v.N(pc + 3);
+  fold.base(bit * (one - bit));
+  fold.base(bit2 * (one - bit2));
+  fold.base(bxb - bit * bit2);
+  for (int l = 0; l < 8; ++l) {
+    const F gate = is_transition * v.PN(l * 4 + 2);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) fold.base(gate * (v.N(l * 4 + d) - v.L(out_col + l * 4 + d)));
+  }
+  const F h[4] = {one - nbit - nbit2 + nbxb, nbit - nbxb, nbit2 - nbxb, nbxb};
+  for (int chunk = 0; chunk < 4; ++chunk)
+    for (int slot = 0; slot < 2; ++slot) {
+      const int g = chunk * 2 + slot;
+      const F gate = is_transition * (v.PN(g * 4 + 3) * h[chunk]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) fold.base(gate * (v.N(g * 4 + d) - v.L(out_col + slot * 4 + d)));
+    }
+  fold.base(is_transition * (one - v.PN(kP2WTail + 2)) * v.PN(kP2WTail + 3) *
+            (next_index_sum - (index_sum.dbl().dbl() + nbit + nbit2.dbl())));
+  poseidon2w_perm_constraints<PP>(v, rcw, fold);
+}
+
 // Number of base constraints of an AIR (host side needs it to size the alpha-power table).
 template <class PP>
 __host__ __device__ inline int air_num_base_constraints(const AirParams& a) {
@@ -439,6 +546,10 @@ __host__ __device__ inline int air_num_base_constraints(const AirParams& a) {
       constexpr int R = PP::SBOX_REGISTERS;
       return (a.ext_d == 4 ? 1 + 16 + 8 + 8 + 1 : 1 + 8 + 8 + 16 + 8 + 1) +
              2 * P2_HALF_FULL * (P2_WIDTH * R + P2_WIDTH) + PP::PARTIAL_ROUNDS * (R + 1);
+    }
+    case AIR_POSEIDON2_W32: {
+      constexpr int R = PP::SBOX_REGISTERS;
+      return 3 + 32 + 32 + 1 + 2 * P2_HALF_FULL * (P2W_WIDTH * R + P2W_WIDTH) + PP::PARTIAL_ROUNDS_W32 * (R + 1);
     }
     default: return 0;
   }

@@ -63,6 +63,7 @@ struct KoalaBearParams {
   static constexpr int SBOX_DEGREE = 3;
   static constexpr int SBOX_REGISTERS = 0;
   static constexpr int PARTIAL_ROUNDS = 20;
+  static constexpr int PARTIAL_ROUNDS_W32 = 31;  // Poseidon2Config::KOALA_BEAR_D4_W32 (circuit/src/ops/poseidon2_perm/config.rs:164-172)
   static constexpr int FIELD_ID = 0;
 };
 struct BabyBearParams {
@@ -73,6 +74,7 @@ struct BabyBearParams {
   static constexpr int SBOX_DEGREE = 7;
   static constexpr int SBOX_REGISTERS = 1;
   static constexpr int PARTIAL_ROUNDS = 13;
+  static constexpr int PARTIAL_ROUNDS_W32 = 30;  // Poseidon2Config::BABY_BEAR_D4_W32 (config.rs:88-100)
   static constexpr int FIELD_ID = 1;
 };
 

@@ -84,6 +84,7 @@ inline std::vector<int> interaction_mult_degrees(const AirParams& a) {
       // compact D1: 8 rate sends (in_ctl * not_merkle), 8 output receives, the accumulator send
       d.assign(8, 2); d.insert(d.end(), 8, 1); d.push_back(2);
       break;
+    case AIR_POSEIDON2_W32: d.assign(8 + 6 + 2, 1); break;   // in_ctl sends, out_ctl receives, the two direction-bit reads
   }
   return d;
 }
@@ -99,7 +100,7 @@ inline LookupLayout lookup_layout(const AirParams& a) {
     return deg;
   };
   int max_deg = 2;
-  if (a.kind == AIR_ALU || a.kind == AIR_POSEIDON2) max_deg = 3;
+  if (a.kind == AIR_ALU || a.kind == AIR_POSEIDON2 || a.kind == AIR_POSEIDON2_W32) max_deg = 3;
   for (size_t i = 0; i < md.size(); ++i) max_deg = std::max(max_deg, gdeg((int)i, 1));
   LookupLayout L;
   L.n_interactions = (int)md.size();
@@ -138,13 +139,15 @@ inline int fri_log_arity(const std::vector<uint8_t>& schedule, size_t phase, int
   return (la >= 1 && la <= limit && la <= max_log_arity) ? la : -1;
 }
 
-inline int air_width_of(const AirParams& a, int p2_width) {
+// p2_width: the field's width-16 Poseidon2 table (perm columns + 2); its width-32 table has p2w_width columns
+inline int air_width_of(const AirParams& a, int p2_width, int p2w_width = 0) {
   switch (a.kind) {
     case AIR_CONST: return a.ext_d;
     case AIR_PUBLIC: return a.lanes * a.ext_d;
     case AIR_ALU: return (a.lanes * 4 + (a.horner_k - 1) / 2 + 2 * (a.horner_k - 1) + 1) * a.ext_d;
     case AIR_POSEIDON2: return p2_width;
     case AIR_RECOMPOSE: return a.lanes * a.ext_d;
+    case AIR_POSEIDON2_W32: return p2w_width;
   }
   return 0;
 }
@@ -155,10 +158,11 @@ inline int air_prep_width_of(const AirParams& a) {
     case AIR_ALU: return a.lanes * 13 + 7 * (a.horner_k - 1);
     case AIR_POSEIDON2: return a.ext_d == 4 ? 24 : kP2D1PrepWidth;
     case AIR_RECOMPOSE: return a.lanes * (2 + (a.coeff_lookups ? 2 * a.ext_d : 0));
+    case AIR_POSEIDON2_W32: return kP2WPrepWidth;
   }
   return 0;
 }
-inline bool air_uses_next(const AirParams& a) { return a.kind == AIR_ALU || a.kind == AIR_POSEIDON2; }
+inline bool air_uses_next(const AirParams& a) { return a.kind == AIR_ALU || a.kind == AIR_POSEIDON2 || a.kind == AIR_POSEIDON2_W32; }
 
 // ---- postcard writer. Field elements are written as the Montgomery word by default
 // (p3-monty-31's serde form), or canonical when `canonical` is set.

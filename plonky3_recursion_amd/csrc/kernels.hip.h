@@ -112,12 +112,19 @@ template <class PP>
 __device__ __forceinline__ Affine<PP> p2_row_affine(size_t i, const uint8_t* new_start,
                                                     const uint8_t* merkle_path,
                                                     const uint8_t* mmcs_bit,
-                                                    const uint32_t* mmcs_index_sum_mont) {
+                                                    const uint32_t* mmcs_index_sum_mont,
+                                                    const uint8_t* mmcs_bit2 = nullptr) {
   using F = Fp<PP>;
   Affine<PP> m;
   if (i > 0 && merkle_path[i] && !new_start[i]) {
-    m.a = F::one().dbl();
-    m.b = mmcs_bit[i] ? F::one() : F::zero();
+    if (mmcs_bit2) {
+      // arity-4 rows (the width-32 table): base four, acc <- 4 acc + bit + 2 bit2 (air.rs:401-412)
+      m.a = F::one().dbl().dbl();
+      m.b = F::from_canonical((uint32_t)(mmcs_bit[i] ? 1 : 0) + (mmcs_bit2[i] ? 2u : 0u));
+    } else {
+      m.a = F::one().dbl();
+      m.b = mmcs_bit[i] ? F::one() : F::zero();
+    }
   } else {
     m.a = F::zero();
     m.b = F::raw(mmcs_index_sum_mont[i]);
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(kBlock)
 k_p2_acc_scan(int mode, size_t n, const uint8_t* __restrict__ new_start,
               const uint8_t* __restrict__ merkle_path, const uint8_t* __restrict__ mmcs_bit,
               const uint32_t* __restrict__ index_sum_mont, uint32_t* __restrict__ agg,
-              size_t n_blocks, uint32_t* __restrict__ acc_out) {
+              size_t n_blocks, uint32_t* __restrict__ acc_out, const uint8_t* __restrict__ mmcs_bit2 = nullptr) {
   using F = Fp<PP>;
   __shared__ uint32_t sa[kBlock], sb[kBlock];
   const int tid = threadIdx.x;
@@ -159,7 +166,7 @@ k_p2_acc_scan(int mode, size_t n, const uint8_t* __restrict__ new_start,
     for (int k = 0; k < kScanItems; ++k) {
       size_t i = base + k;
       if (i < n) {
-        loc[k] = p2_row_affine<PP>(i, new_start, merkle_path, mmcs_bit, index_sum_mont);
+        loc[k] = p2_row_affine<PP>(i, new_start, merkle_path, mmcs_bit, index_sum_mont, mmcs_bit2);
       } else {
         loc[k].a = F::one();
         loc[k].b = F::zero();
@@ -261,6 +268,30 @@ k_p2_trace_fill(const uint32_t* __restrict__ inputs /* [16][n] mont */,
   }
   p2_permute_traced<PP>(s, rc, sink);
   sink.put(mmcs_bit[i] ? F::one() : F::zero());
+  sink.put(F::raw(acc[i]));
+}
+// the width-32 table: [Poseidon2Cols<32> | mmcs_bit | mmcs_bit2 | mmcs_bit * mmcs_bit2 | mmcs_index_sum]
+// (poseidon2-circuit-air/src/air.rs:414-434 arity-4 branch); rcw = the width-32 constant table
+template <class PP>
+__global__ void __launch_bounds__(kBlock)
+k_p2w_trace_fill(const uint32_t* __restrict__ inputs /* [32][n] mont */, const uint8_t* __restrict__ mmcs_bit,
+                 const uint8_t* __restrict__ mmcs_bit2, const uint32_t* __restrict__ acc /* [n] mont */,
+                 uint32_t* __restrict__ trace /* [cols][n] */, size_t n, const uint32_t* __restrict__ rcw) {
+  using F = Fp<PP>;
+  size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  F s[P2W_WIDTH];
+  P2ColSink<F> sink{trace + i, n};
+#pragma unroll
+  for (int k = 0; k < P2W_WIDTH; ++k) {
+    s[k] = F::raw(inputs[(size_t)k * n + i]);
+    sink.put(s[k]);
+  }
+  p2w_permute_traced<PP>(s, rcw, sink);
+  const bool b0 = mmcs_bit[i], b1 = mmcs_bit2[i];
+  sink.put(b0 ? F::one() : F::zero());
+  sink.put(b1 ? F::one() : F::zero());
+  sink.put((b0 && b1) ? F::one() : F::zero());
   sink.put(F::raw(acc[i]));
 }
 

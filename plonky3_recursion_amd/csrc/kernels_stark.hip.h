@@ -322,6 +322,10 @@ k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupChT<DC> lc, 
     if constexpr (D == 4) poseidon2_constraints<PP>(v, is_transition, rc, fold);
     else if constexpr (D == 1 || D == 5) poseidon2_d1_constraints<PP>(v, is_transition, rc, fold);
   }
+  if (q.air.kind == AIR_POSEIDON2_W32) {
+    // (the width-32 constant table follows the width-16 one in p3r_ctx::rc)
+    if constexpr (D == 4) poseidon2w_constraints<PP>(v, is_transition, rc + p2_num_constants<PP>(), fold);
+  }
   if (q.aux) {
     const F is_first = zh * (x - F::one()).inv();
     const F is_last = zh * is_transition.inv();

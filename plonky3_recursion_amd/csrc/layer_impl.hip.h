@@ -193,10 +193,15 @@ struct p3r_layer {
   // recompose.rs:77-80: `batch_instance_*` returns None); the primitive three always are.
   bool has_p2 = true, has_recompose = true, has_recompose_coeff = false;
   bool recompose_coeff = false;  // table 4 is the "recompose/coeff" variant: per-coefficient bus tuples (recompose_air.rs:196-226)
-  int slot_of(int table) const {  // position of table 0..5 among the proved instances, -1 if absent
+  // table 6: the width-32 Poseidon2 table (arity-4 MMCS rows), proved right after the width-16 one
+  bool has_p2w = false;
+  size_t h_p2w = 0;
+  int slot_of(int table) const {  // position of table 0..6 among the proved instances, -1 if absent
     if (table < 3) return table;
     if (table == 3) return has_p2 ? 3 : -1;
-    const int base = has_p2 ? 4 : 3;
+    int base = has_p2 ? 4 : 3;
+    if (table == 6) return has_p2w ? base : -1;
+    if (has_p2w) base += 1;
     if (table == 4) return has_recompose ? base : -1;
     return has_recompose_coeff ? base + (has_recompose ? 1 : 0) : -1;
   }
@@ -210,7 +215,10 @@ struct p3r_dtraces {
   size_t n_const = 0, n_public = 0, n_alu = 0, n_recompose = 0;
   size_t n_recompose_coeff = 0;   // rows of table 5: they follow the n_recompose rows of table 4 in recompose_values
   std::unique_ptr<p3r_p2_dev> p2;  // padded to the table height with filler rows
+  std::unique_ptr<p3r_p2_dev> p2w; // rows of the width-32 table (flags: new_start | merkle_path | mmcs_bit | mmcs_bit2)
 };
+// tables in PROOF order: [Const, Public, Alu, Poseidon2, Poseidon2-W32, Recompose, Recompose/coeff]
+constexpr int kTableOrder[7] = {0, 1, 2, 3, 6, 4, 5};
 
 namespace {
 
@@ -229,6 +237,9 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   L->has_p2 = d->counts.n_p2 > 0;
   L->has_recompose = d->counts.n_recompose > 0;
   L->has_recompose_coeff = d->counts.n_recompose_coeff > 0;
+  L->has_p2w = d->counts.n_p2w > 0;
+  if (L->has_p2w && ctx->cfg.ext_degree != 4) fail(P3R_EUNSUPPORTED, "the width-32 Poseidon2 table belongs to D = 4 circuits");
+  if (L->has_p2w && !d->p2w_prep) fail(P3R_EINVAL, "p2w_prep is NULL");
   if (L->has_recompose_coeff && d->recompose_coeff_lookups)
     fail(P3R_EINVAL, "recompose_coeff_lookups = 1 names the ONE Recompose table; with a second table (n_recompose_coeff) recompose_prep is the plain kind");
   if (L->horner_k < 2 || L->horner_k > 8) fail(P3R_EINVAL, "horner_packed_steps must be in 2..8");
@@ -256,14 +267,15 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
     return m;
   };
   const int rec2_plw = 2 + 2 * (int)ext_d;
-  std::vector<std::vector<uint32_t>> mats(6);
+  std::vector<std::vector<uint32_t>> mats(7);
   std::unique_ptr<uint32_t, decltype(&free)> alu_mat(nullptr, &free);   // table 2 (the largest), filled in parallel
-  p3r_air_desc airs[6] = {{P3R_AIR_CONST, 1, 2, 0},
+  p3r_air_desc airs[7] = {{P3R_AIR_CONST, 1, 2, 0},
                           {P3R_AIR_PUBLIC, L->public_lanes, 2, 0},
                           {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
                           {P3R_AIR_POSEIDON2, 1, 2, 0},
                           {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, L->recompose_coeff ? 1u : 0u},
-                          {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 1u}};
+                          {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 1u},
+                          {P3R_AIR_POSEIDON2_W32, 1, 2, 0}};
   // every table but the ALU one on a second host thread (they share nothing with it)
   auto other_tables = std::async(std::launch::async, [&] {
     check(d->const_prep, c.n_const * 2, "const_prep");
@@ -332,6 +344,15 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
       mats[4] = lanes_prep(d->recompose_prep, c.n_recompose, rec_plw, (int)L->recompose_lanes, L->h_recompose);
     if (L->has_recompose_coeff)
       mats[5] = lanes_prep(d->recompose_coeff_prep, c.n_recompose_coeff, rec2_plw, (int)L->recompose_lanes, L->h_recompose_coeff);
+    if (L->has_p2w) {
+      // the caller's assembled rows + BaseAir::preprocessed_trace padding (air.rs:613-649): zero rows, the first one
+      // with new_start = 1 at width - 2
+      check(d->p2w_prep, c.n_p2w * (size_t)kP2WPrepWidth, "p2w_prep");
+      L->h_p2w = padded_height(c.n_p2w, mh);
+      mats[6].assign(L->h_p2w * (size_t)kP2WPrepWidth, 0);
+      std::copy(d->p2w_prep, d->p2w_prep + c.n_p2w * (size_t)kP2WPrepWidth, mats[6].begin());
+      if (L->h_p2w > c.n_p2w) mats[6][c.n_p2w * (size_t)kP2WPrepWidth + kP2WTail + 2] = 1;
+    }
   });
   // ALU: schedule + scheduled preprocessed trace (alu_air.rs:613-677)
   {
@@ -382,13 +403,14 @@ std::unique_ptr<p3r_layer> layer_create(p3r_ctx* ctx, const p3r_layer_desc* d, u
   prof_stage(ctx, "prep_lc_other_tables_wait");
   other_tables.get();
   prof_stage(ctx, "prep_lc_upload_lde_commit");
-  const int widths[6] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1),
-                         ext_d == 4 ? 24 : kP2D1PrepWidth, (int)L->recompose_lanes * rec_plw, (int)L->recompose_lanes * rec2_plw};
-  const size_t heights[6] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose, L->h_recompose_coeff};
-  p3r_matrix pm[6];
-  p3r_air_desc present_airs[6];
+  const int widths[7] = {2, (int)L->public_lanes * 2, (int)L->alu_lanes * 13 + 7 * ((int)L->horner_k - 1),
+                         ext_d == 4 ? 24 : kP2D1PrepWidth, (int)L->recompose_lanes * rec_plw, (int)L->recompose_lanes * rec2_plw,
+                         kP2WPrepWidth};
+  const size_t heights[7] = {L->h_const, L->h_public, L->h_alu, L->h_p2, L->h_recompose, L->h_recompose_coeff, L->h_p2w};
+  p3r_matrix pm[7];
+  p3r_air_desc present_airs[7];
   size_t n_present = 0;
-  for (int i = 0; i < 6; ++i) {
+  for (int i : kTableOrder) {
     if (L->slot_of(i) < 0) continue;
     present_airs[n_present] = airs[i];
     pm[n_present++] = {i == 2 ? alu_mat.get() : mats[i].data(), heights[i], (size_t)widths[i]};
@@ -488,13 +510,66 @@ std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, con
   }
   p3r_p2_rows rows{h, in.data(), ns.data(), mp.data(), bit.data(), idx.data()};
   d->p2 = p2_rows_upload<PP>(ctx, &rows);
+  if (L->has_p2w) {
+    // rows of the width-32 table, padded with the same fillers
+    const size_t hw = L->h_p2w, nw = c.n_p2w;
+    const p3r_p2w_rows& w = t->p2w;
+    if (w.n != nw) fail(P3R_EINVAL, "trace row counts do not match the prepared circuit shape (width-32 Poseidon2 table)");
+    if (!w.input_values || !w.new_start || !w.merkle_path || !w.mmcs_bit || !w.mmcs_bit2 || !w.mmcs_index_sum)
+      fail(P3R_EINVAL, "width-32 Poseidon2 rows have a NULL field");
+    std::vector<uint32_t> win(hw * 32, 0), widx(hw, 0);
+    std::vector<uint8_t> f(4 * hw, 0);
+    std::fill(f.begin(), f.begin() + hw, 1);   // new_start = 1 on fillers
+    std::copy(w.input_values, w.input_values + nw * 32, win.begin());
+    std::copy(w.mmcs_index_sum, w.mmcs_index_sum + nw, widx.begin());
+    std::copy(w.new_start, w.new_start + nw, f.begin());
+    std::copy(w.merkle_path, w.merkle_path + nw, f.begin() + hw);
+    std::copy(w.mmcs_bit, w.mmcs_bit + nw, f.begin() + 2 * hw);
+    std::copy(w.mmcs_bit2, w.mmcs_bit2 + nw, f.begin() + 3 * hw);
+    for (size_t i = 0; i < nw * 32; ++i) if (win[i] >= PP::P) fail(P3R_EINVAL, "p2w.input_values[%zu] is not canonical", i);
+    for (size_t i = 0; i < nw; ++i) if (widx[i] >= PP::P) fail(P3R_EINVAL, "p2w.mmcs_index_sum[%zu] is not canonical", i);
+    auto dw = std::make_unique<p3r_p2_dev>();
+    dw->n = hw;
+    dw->flags.alloc(hw + 1);
+    P3R_HIP(hipMemcpyAsync(dw->flags.p, f.data(), 4 * hw, hipMemcpyHostToDevice, ctx->stream));
+    dw->seed.alloc(hw);
+    P3R_HIP(hipMemcpyAsync(dw->seed.p, widx.data(), hw * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_convert_inplace<PP>, dim3(blocks_for(hw)), dim3(kBlock), 0, ctx->stream, dw->seed.p, hw, 1);
+    P3R_HIP(hipGetLastError());
+    dw->inputs = upload<PP>(ctx, win.data(), hw, P2W_WIDTH);  // syncs the stream
+    d->p2w = std::move(dw);
+  }
   return d;
+}
+
+// K3 for the width-32 table: base-four accumulator scan, then one permutation per row
+template <class PP>
+std::unique_ptr<p3r_dmat> trace_fill_w32(p3r_ctx* ctx, const p3r_p2_dev* rows) {
+  const size_t n = rows->n;
+  const uint8_t* f8 = reinterpret_cast<const uint8_t*>(rows->flags.p);
+  DevBuf acc(n);
+  const size_t n_blocks = (n + kScanTile - 1) / kScanTile;
+  DevBuf agg(2 * n_blocks);
+  {
+    ProfScope ps(ctx, "p2_acc_scan");
+    for (int mode = 0; mode < 3; ++mode)
+      hipLaunchKernelGGL(k_p2_acc_scan<PP>, dim3(mode == 1 ? 1u : (unsigned)n_blocks), dim3(kBlock), 0, ctx->stream, mode, n, f8, f8 + n,
+                         f8 + 2 * n, rows->seed.p, agg.p, n_blocks, acc.p, f8 + 3 * n);
+  }
+  auto trace = dmat_alloc(n, (size_t)p2w_perm_cols<PP>() + 4);
+  {
+    ProfScope ps(ctx, "p2_trace_fill");
+    hipLaunchKernelGGL(k_p2w_trace_fill<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, rows->inputs->d, f8 + 2 * n, f8 + 3 * n,
+                       acc.p, trace->d, n, ctx->rc.p + p2_num_constants<PP>());
+  }
+  P3R_HIP(hipGetLastError());
+  return trace;
 }
 
 // K1 + K2 + K3: the main-trace matrices, indexed by table 0..4 (absent tables stay null).
 template <class PP>
 std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t) {
-  std::vector<std::unique_ptr<p3r_dmat>> m(6);
+  std::vector<std::unique_ptr<p3r_dmat>> m(7);
   const int D = (int)ctx->cfg.ext_degree;
   auto flat = [&](const uint32_t* src, size_t n_ops, size_t h, int w, int per_op) {
     auto out = dmat_alloc(h, (size_t)w);
@@ -519,6 +594,7 @@ std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r
     });
   }
   if (L->has_p2) m[3] = trace_fill<PP>(ctx, t->p2.get());
+  if (L->has_p2w) m[6] = trace_fill_w32<PP>(ctx, t->p2w.get());
   if (L->has_recompose)
     m[4] = flat(t->recompose_values.p, t->n_recompose, L->h_recompose, (int)L->recompose_lanes * D, D);
   if (L->has_recompose_coeff)
@@ -532,9 +608,9 @@ template <class PP>
 std::vector<uint8_t> prove_all_tables(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, bool canonical) {
   prof_stage(ctx, "build_traces");
   auto mains = build_main_traces<PP>(ctx, L, t);
-  const p3r_dmat* ptrs[6];
+  const p3r_dmat* ptrs[7];
   size_t n = 0;
-  for (int i = 0; i < 6; ++i)
+  for (int i : kTableOrder)
     if (mains[i]) ptrs[n++] = mains[i].get();
   return prove_batch_any<PP>(ctx, L->prep.get(), ptrs, n, canonical);
 }

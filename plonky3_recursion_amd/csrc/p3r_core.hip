@@ -6,6 +6,7 @@
 #include "kernels_coop.hip.h"
 #include "tu_api.h"
 #include "poseidon2_rc_default.inc"
+#include "poseidon2_w32_default.inc"
 #include "profile.h"
 #include "run_schedule.h"
 #include "prep_device.h"
@@ -360,27 +361,42 @@ void mmcs_open(p3r_ctx* ctx, const p3r_tree* tree, size_t index, uint32_t* opene
   for (size_t i = 0; i < (size_t)depth * P2_DIGEST; ++i) proof[i] = F::raw(proof[i]).to_canonical();
 }
 
+// The permutation constants of a configuration, canonical: the width-16 round constants, then the width-32 table
+// (round constants | diagonal, poseidon2.h) - the layout of p3r_ctx::rc and of the verifier's table.  NULL pointers
+// select the self-generated defaults.  `bad`: reports a length mismatch.
+template <class PP, class Bad>
+std::vector<uint32_t> constants_table(const p3r_config& cfg, Bad&& bad) {
+  const size_t nrc = p2_num_constants<PP>(), nrcw = p2w_num_rc<PP>();
+  const uint32_t* src = cfg.poseidon2_rc;
+  if (src && cfg.poseidon2_rc_len != nrc) bad("poseidon2_rc_len", cfg.poseidon2_rc_len, nrc);
+  if (!src) src = PP::FIELD_ID == 0 ? kDefaultRc_koala_bear : kDefaultRc_baby_bear;
+  const uint32_t* w = cfg.poseidon2_w32_rc;
+  if (w && cfg.poseidon2_w32_rc_len != nrcw) bad("poseidon2_w32_rc_len", cfg.poseidon2_w32_rc_len, nrcw);
+  if (!w) w = PP::FIELD_ID == 0 ? kDefaultRcW32_koala_bear : kDefaultRcW32_baby_bear;
+  const uint32_t* dg = cfg.poseidon2_w32_diag ? cfg.poseidon2_w32_diag : (PP::FIELD_ID == 0 ? kDefaultDiagW32_koala_bear : kDefaultDiagW32_baby_bear);
+  std::vector<uint32_t> t(src, src + nrc);
+  t.insert(t.end(), w, w + nrcw);
+  t.insert(t.end(), dg, dg + P2W_WIDTH);
+  return t;
+}
+
 template <class PP>
 void init_ctx(p3r_ctx* ctx) {
   using F = Fp<PP>;
   const size_t nrc = p2_num_constants<PP>();
-  const uint32_t* src = ctx->cfg.poseidon2_rc;
-  if (src) {
-    if (ctx->cfg.poseidon2_rc_len != nrc)
-      fail(P3R_EINVAL, "poseidon2_rc_len is %u, the field needs %zu constants",
-           ctx->cfg.poseidon2_rc_len, nrc);
-  } else {
-    src = PP::FIELD_ID == 0 ? kDefaultRc_koala_bear : kDefaultRc_baby_bear;
-  }
-  ctx->rc_canonical.assign(src, src + nrc);
-  std::vector<uint32_t> mont(nrc);
-  for (size_t i = 0; i < nrc; ++i) {
-    if (src[i] >= PP::P) fail(P3R_EINVAL, "round constant %zu is not canonical", i);
-    mont[i] = F::from_canonical(src[i]).v;
+  const std::vector<uint32_t> table = constants_table<PP>(ctx->cfg, [](const char* what, uint32_t got, size_t want) {
+    fail(P3R_EINVAL, "%s is %u, the field needs %zu constants", what, got, want);
+  });
+  const uint32_t* src = table.data();
+  ctx->rc_canonical = table;   // width-16 constants first (nrc of them), then the width-32 table
+  std::vector<uint32_t> mont(table.size());
+  for (size_t i = 0; i < table.size(); ++i) {
+    if (table[i] >= PP::P) fail(P3R_EINVAL, "permutation constant %zu is not canonical", i);
+    mont[i] = F::from_canonical(table[i]).v;
   }
   ctx->rc_mont_host = mont;
-  ctx->rc.alloc(nrc);
-  P3R_HIP(copy_sync(ctx->stream, ctx->rc.p, mont.data(), nrc * 4, hipMemcpyHostToDevice));
+  ctx->rc.alloc(mont.size());
+  P3R_HIP(copy_sync(ctx->stream, ctx->rc.p, mont.data(), mont.size() * 4, hipMemcpyHostToDevice));
   std::vector<double> rcd(src, src + nrc);
   ctx->rc_f64.alloc(2 * nrc);
   P3R_HIP(copy_sync(ctx->stream, ctx->rc_f64.p, rcd.data(), nrc * 8, hipMemcpyHostToDevice));
@@ -400,7 +416,9 @@ void init_ctx(p3r_ctx* ctx) {
     P3R_HIP(copy_sync(ctx->stream, ctx->p2_diag.p, dm, sizeof dm, hipMemcpyHostToDevice));
   }
   ctx->partial_rounds = PP::PARTIAL_ROUNDS;
-  ctx->cfg.poseidon2_rc = nullptr;  // caller's pointer is not retained
+  ctx->cfg.poseidon2_rc = nullptr;  // caller's pointers are not retained
+  ctx->cfg.poseidon2_w32_rc = nullptr;
+  ctx->cfg.poseidon2_w32_diag = nullptr;
   if (ctx->cfg.fri_log_arities) ctx->fri_log_arities.assign(ctx->cfg.fri_log_arities, ctx->cfg.fri_log_arities + ctx->cfg.fri_log_arities_len);
   ctx->cfg.fri_log_arities = nullptr;
   if (!ctx->proof_layout.set(ctx->cfg.proof_layout, ctx->cfg.proof_layout_len))
@@ -487,7 +505,7 @@ uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx) {
 }
 int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out) {
   if (!ctx || !out) return P3R_EINVAL;
-  std::copy(ctx->rc_canonical.begin(), ctx->rc_canonical.end(), out);
+  std::copy(ctx->rc_canonical.begin(), ctx->rc_canonical.begin() + p3r_poseidon2_num_constants(ctx), out);   // the width-16 table
   return P3R_OK;
 }
 
@@ -759,6 +777,11 @@ int p3r_layer_table_heights(const p3r_layer* L, size_t h[5]) {
   h[0] = L->h_const; h[1] = L->h_public; h[2] = L->h_alu; h[3] = L->h_p2; h[4] = L->h_recompose;
   return P3R_OK;
 }
+int p3r_layer_p2w_height(const p3r_layer* L, size_t* h) {
+  if (!L || !h) return P3R_EINVAL;
+  *h = L->h_p2w;
+  return P3R_OK;
+}
 int p3r_layer_recompose_coeff_height(const p3r_layer* L, size_t* h) {
   if (!L || !h) return P3R_EINVAL;
   *h = L->h_recompose_coeff;
@@ -810,7 +833,7 @@ p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const
                                      uint32_t table) {
   p3r_dmat* out = nullptr;
   guard(ctx, [&] {
-    if (!layer || !traces || table > 5) fail(P3R_EINVAL, "bad arguments");
+    if (!layer || !traces || table > 6) fail(P3R_EINVAL, "bad arguments");
     if (layer->slot_of((int)table) < 0) fail(P3R_EINVAL, "table %u has no rows and is not part of the batch", table);
     auto m = P3R_FIELD_CALL(ctx, build_main_traces, ctx, layer, traces);
     P3R_HIP(hipStreamSynchronize(ctx->stream));
@@ -839,7 +862,7 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     if (!prm.layout.set(cfg->proof_layout, cfg->proof_layout_len)) { report("proof_layout must be 18 bytes: three permutations"); return P3R_EINVAL; }
     std::vector<p3r::AirParams> a(n_airs);
     for (size_t i = 0; i < n_airs; ++i) {
-      if (airs[i].kind > P3R_AIR_RECOMPOSE || !airs[i].lanes) { report("bad AIR descriptor"); return P3R_EINVAL; }
+      if (airs[i].kind > P3R_AIR_POSEIDON2_W32 || !airs[i].lanes) { report("bad AIR descriptor"); return P3R_EINVAL; }
       a[i] = {(int)airs[i].kind, (int)airs[i].lanes, (int)airs[i].horner_packed_steps, (int)airs[i].coeff_lookups,
               (cfg->ext_choices & P3R_EXT_LOOKUP_UNPACKED) ? 1 : 0, (int)cfg->ext_degree, 0u};
     }
@@ -848,19 +871,18 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     const std::vector<uint32_t> want_db(degree_bits, degree_bits + n_airs);
     auto run = [&](auto tag) {
       using PP = decltype(tag);
-      const size_t nrc = p2_num_constants<PP>();
-      const uint32_t* src = cfg->poseidon2_rc;
-      if (src && cfg->poseidon2_rc_len != nrc) p3r::vfail("poseidon2_rc_len is %u, the field needs %zu constants", cfg->poseidon2_rc_len, nrc);
-      if (!src) src = PP::FIELD_ID == 0 ? kDefaultRc_koala_bear : kDefaultRc_baby_bear;
+      const std::vector<uint32_t> table = constants_table<PP>(*cfg, [](const char* what, uint32_t got, size_t want) {
+        p3r::vfail("%s is %u, the field needs %zu constants", what, got, want);
+      });
       auto airs_pp = a;
       for (auto& x : airs_pp) x.ext_w_mont = generic_d ? p3r::Fp<PP>::from_canonical(cfg->ext_w).v : 0u;
       if (cfg->challenge_degree == 5) {
         if constexpr (p3r::kHasQuintic<PP>)
-          p3r::verify_batch<PP, 5>(prm, std::vector<uint32_t>(src, src + nrc), airs_pp, cap, want_db, proof, proof_len, canonical);
+          p3r::verify_batch<PP, 5>(prm, table, airs_pp, cap, want_db, proof, proof_len, canonical);
         else
           p3r::vfail("UnsupportedChallengeDegree: the quintic challenge field is KoalaBear's");
       } else {
-        p3r::verify_batch<PP>(prm, std::vector<uint32_t>(src, src + nrc), airs_pp, cap, want_db, proof, proof_len, canonical);
+        p3r::verify_batch<PP>(prm, table, airs_pp, cap, want_db, proof, proof_len, canonical);
       }
     };
     if (cfg->field == P3R_FIELD_KOALA_BEAR) run(p3r::KoalaBearParams{});

@@ -203,4 +203,81 @@ P3R_HD void p2_permute(F* s, const uint32_t* __restrict__ rc) {
   p2_permute_traced<PP>(s, rc, sink);
 }
 
+// ---- width 32: the permutation of the arity-4 MMCS (Poseidon2{Koala,Baby}Bear<32>, Poseidon2Config::*_D4_W32;
+// circuit-prover/tests/arity4_mmcs.rs:42-47).  Same round structure; the external layer runs over eight M4 blocks;
+// the internal diagonal is DATA like the round constants (upstream's GenericPoseidon2LinearLayers<32> lives in
+// un-vendored crates): the constant table is [4][32] external-initial | [PARTIAL_W32] internal | [4][32]
+// external-final | [32] diagonal, Montgomery on the device, and follows the width-16 table in p3r_ctx::rc.
+constexpr int P2W_WIDTH = 32;
+template <class PP>
+constexpr int p2w_num_rc() { return 2 * P2_HALF_FULL * P2W_WIDTH + PP::PARTIAL_ROUNDS_W32; }
+template <class PP>
+constexpr int p2w_num_constants() { return p2w_num_rc<PP>() + P2W_WIDTH; }
+template <class PP>
+constexpr int p2w_perm_cols() {
+  return P2W_WIDTH + 2 * P2_HALF_FULL * (P2W_WIDTH * PP::SBOX_REGISTERS + P2W_WIDTH) + PP::PARTIAL_ROUNDS_W32 * (PP::SBOX_REGISTERS + 1);
+}
+template <class F>
+P3R_HD void p2w_external_linear(F* s) {
+#pragma unroll
+  for (int i = 0; i < P2W_WIDTH; i += 4) p2_mat4(s[i], s[i + 1], s[i + 2], s[i + 3]);
+  F sum[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sum[k] = s[k];
+#pragma unroll
+    for (int b = 1; b < P2W_WIDTH / 4; ++b) sum[k] += s[4 * b + k];
+  }
+#pragma unroll
+  for (int i = 0; i < P2W_WIDTH; ++i) s[i] += sum[i & 3];
+}
+// s_i <- d_i * s_i + sum(s), d = the diagonal of the constant table (base-field words lifted into F)
+template <class PP, class F>
+P3R_HD void p2w_internal_linear(F* s, const uint32_t* __restrict__ diag) {
+  F sum = s[0];
+#pragma unroll
+  for (int i = 1; i < P2W_WIDTH; ++i) sum += s[i];
+#pragma unroll
+  for (int i = 0; i < P2W_WIDTH; ++i) s[i] = s[i] * Lift<F>::of(Fp<PP>::raw(diag[i])) + sum;
+}
+// Full permutation; `rcw` = the width-32 constant table.  Cells in Poseidon2Cols order, as p2_permute_traced.
+template <class PP, class F, class Sink>
+P3R_HD void p2w_permute_traced(F* s, const uint32_t* __restrict__ rcw, Sink& sink) {
+  const uint32_t* diag = rcw + p2w_num_rc<PP>();
+  p2w_external_linear(s);
+  int k = 0;
+  auto full_round = [&]() {
+#pragma unroll
+    for (int i = 0; i < P2W_WIDTH; ++i) {
+      F x = s[i] + F::raw(rcw[k + i]);
+      if (PP::SBOX_REGISTERS == 1) {
+        F x3 = x.cube();
+        sink.put(x3);
+        s[i] = x3.sqr_times(x);
+      } else {
+        s[i] = p2_sbox<PP>(x);
+      }
+    }
+    k += P2W_WIDTH;
+    p2w_external_linear(s);
+#pragma unroll
+    for (int i = 0; i < P2W_WIDTH; ++i) sink.put(s[i]);
+  };
+  for (int r = 0; r < P2_HALF_FULL; ++r) full_round();
+  for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) {
+    F x = s[0] + F::raw(rcw[k + r]);
+    if (PP::SBOX_REGISTERS == 1) {
+      F x3 = x.cube();
+      sink.put(x3);
+      s[0] = x3.sqr_times(x);
+    } else {
+      s[0] = p2_sbox<PP>(x);
+    }
+    sink.put(s[0]);
+    p2w_internal_linear<PP>(s, diag);
+  }
+  k += PP::PARTIAL_ROUNDS_W32;
+  for (int r = 0; r < P2_HALF_FULL; ++r) full_round();
+}
+
 }  // namespace p3r

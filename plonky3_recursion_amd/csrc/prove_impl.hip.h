@@ -132,7 +132,9 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
                 ext_degree_is_binomial_generic(ctx->cfg.ext_degree) ? Fp<PP>::from_canonical(ctx->cfg.ext_w).v : 0u};
     if (ext_degree_is_binomial_generic(ctx->cfg.ext_degree) && a.kind == AIR_POSEIDON2)
       fail(P3R_EUNSUPPORTED, "instance %zu: UnsupportedDegree(%d): no Poseidon2 table for this circuit degree", i, a.ext_d);
-    if (a.kind < 0 || a.kind > AIR_RECOMPOSE) fail(P3R_EINVAL, "instance %zu: unknown AIR kind %d", i, a.kind);
+    if (a.kind < 0 || a.kind > AIR_POSEIDON2_W32) fail(P3R_EINVAL, "instance %zu: unknown AIR kind %d", i, a.kind);
+    if (a.kind == AIR_POSEIDON2_W32 && ctx->cfg.ext_degree != 4)
+      fail(P3R_EUNSUPPORTED, "instance %zu: the width-32 Poseidon2 table belongs to D = 4 circuits", i);
     if (a.lanes < 1) fail(P3R_EINVAL, "instance %zu: lanes must be positive", i);
     if (a.kind == AIR_ALU && (a.horner_k < 2 || a.horner_k > 8))
       fail(P3R_EINVAL, "instance %zu: horner_packed_steps must be in 2..8", i);
@@ -176,8 +178,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     const AirParams& a = prep->airs[i];
     if (mains[i]->h != prep->heights[i])
       fail(P3R_EINVAL, "instance %zu: trace height %zu != preprocessed height %zu", i, mains[i]->h, prep->heights[i]);
-    if ((int)mains[i]->w != air_width_of(a, p2w))
-      fail(P3R_EINVAL, "instance %zu: trace width %zu, the AIR expects %d", i, mains[i]->w, air_width_of(a, p2w));
+    if ((int)mains[i]->w != air_width_of(a, p2w, p2w_perm_cols<PP>() + 4))
+      fail(P3R_EINVAL, "instance %zu: trace width %zu, the AIR expects %d", i, mains[i]->w, air_width_of(a, p2w, p2w_perm_cols<PP>() + 4));
     log_n[i] = log2_exact(mains[i]->h, "trace height");
     layouts[i] = lookup_layout(a);
     if (layouts[i].log_chunks > log_blowup) fail(P3R_EINVAL, "quotient domain larger than the LDE");

@@ -634,6 +634,9 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     } else if (air.kind == AIR_POSEIDON2) {
       if (air.ext_d != 4) poseidon2_d1_constraints<PP>(v, is_transition, rc_mont, fold);
       else poseidon2_constraints<PP>(v, is_transition, rc_mont, fold);
+    } else if (air.kind == AIR_POSEIDON2_W32) {
+      if (air.ext_d != 4) vfail("instance %zu: the width-32 Poseidon2 table belongs to D = 4 circuits", i);
+      poseidon2w_constraints<PP>(v, is_transition, rc_mont + p2_num_constants<PP>(), fold);
     }
     if (fold.count != air_num_base_constraints<PP>(air)) vfail("instance %zu: constraint count mismatch", i);
     if (L.n_groups) {
@@ -705,7 +708,8 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   using Digest = std::array<F, P2_DIGEST>;
   const ParsedProof<PP, DC> P = parse_proof<PP, DC>(bytes, n_bytes, canonical, nullptr, prm.layout);
   const size_t ni = airs.size();
-  if (rc_canonical.size() != (size_t)p2_num_constants<PP>()) vfail("wrong number of round constants");
+  // the width-16 round constants, followed by the width-32 table (poseidon2.h; csrc/p3r_core.hip::constants_table)
+  if (rc_canonical.size() != (size_t)p2_num_constants<PP>() + (size_t)p2w_num_constants<PP>()) vfail("wrong number of permutation constants");
   std::vector<uint32_t> rc(rc_canonical.size());
   for (size_t i = 0; i < rc.size(); ++i) rc[i] = F::from_canonical(rc_canonical[i]).v;
   const int p2w = p2_perm_cols<PP>() + 2;
@@ -731,7 +735,7 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
       vfail("InvalidProofShape: instance %zu declares degree_bits %d, the preprocessed metadata has %u", i, log_n[i],
             i < expected_degree_bits.size() ? expected_degree_bits[i] : 0u);
     if (log_n[i] + lb > PP::TWO_ADICITY) vfail("instance %zu: degree too large", i);
-    width[i] = air_width_of(airs[i], p2w);
+    width[i] = air_width_of(airs[i], p2w, p2w_perm_cols<PP>() + 4);
     prep_w[i] = air_prep_width_of(airs[i]);
     const size_t aw = (size_t)layouts[i].aux_width() * DC, C = size_t(1) << layouts[i].log_chunks;
     if (in.main_local.size() != (size_t)width[i]) vfail("instance %zu: %zu main openings, the AIR has %d columns", i, in.main_local.size(), width[i]);

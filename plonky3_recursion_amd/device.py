@@ -37,7 +37,8 @@ def _u8(a):
 
 def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5,
                 commit_pow_bits=0, query_pow_bits=15, num_queries=54, device=0, poseidon2_rc=None, ext_choices=0,
-                fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0, challenge_degree=4):
+                fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0, challenge_degree=4,
+                poseidon2_w32_rc=None, poseidon2_w32_diag=None):
     """A `p3r_config` (+ the arrays it points into, which must stay alive with it).  `ext_choices` /
     `fri_log_arities`: the selectable protocol details of include/p3r.h.
     `ext_degree`: the circuit extension degree D of the traces - 4, or 5 for KoalaBear circuits over the quintic
@@ -72,7 +73,18 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
         pl, pptr = _u8(proof_layout)
         cfg.proof_layout = pptr
         cfg.proof_layout_len = pl.size
-    return cfg, (rc, ar, pl)
+    # constants of the width-32 permutation (the table of the arity-4 MMCS rows); None = the library's defaults
+    w_rc = w_dg = None
+    if poseidon2_w32_rc is not None:
+        w_rc, wptr = _u32(poseidon2_w32_rc)
+        cfg.poseidon2_w32_rc = wptr
+        cfg.poseidon2_w32_rc_len = w_rc.size
+    if poseidon2_w32_diag is not None:
+        w_dg, dptr = _u32(poseidon2_w32_diag)
+        if w_dg.size != 32:
+            raise P3rError(-1, "poseidon2_w32_diag must hold 32 values")
+        cfg.poseidon2_w32_diag = dptr
+    return cfg, (rc, ar, pl, w_rc, w_dg)
 
 
 def verify_batch(cfg, airs, preprocessed_commitment, degree_bits, proof: bytes, canonical_field_encoding=False):
@@ -106,7 +118,7 @@ class Context:
     def __init__(self, field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
                  log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
                  device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0,
-                 challenge_degree=4):
+                 challenge_degree=4, poseidon2_w32_rc=None, poseidon2_w32_diag=None):
         self.lib = _lib.load()
         self.field = field
         self.ext_degree = ext_degree
@@ -115,7 +127,8 @@ class Context:
         self.p = MODULUS[field]
         cfg, self._rc_keep = make_config(field, log_blowup, max_log_arity, cap_height, log_final_poly_len,
                                          commit_pow_bits, query_pow_bits, num_queries, device, poseidon2_rc, ext_choices,
-                                         fri_log_arities, proof_layout, ext_degree, ext_w, challenge_degree)
+                                         fri_log_arities, proof_layout, ext_degree, ext_w, challenge_degree,
+                                         poseidon2_w32_rc, poseidon2_w32_diag)
         self.cfg = cfg
         self.cap_height = cap_height
         self.log_blowup = log_blowup

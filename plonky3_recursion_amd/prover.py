@@ -69,6 +69,13 @@ class Traces:
     recompose_values: np.ndarray    # (n_recompose, D)
     # rows of the second Recompose table (`recompose/coeff` next to `recompose`; include/p3r.h, ABI version 5)
     recompose_coeff_values: Optional[np.ndarray] = None   # (n_recompose_coeff, D)
+    # rows of the width-32 Poseidon2 table (arity-4 MMCS rows; include/p3r.h p3r_p2w_rows, ABI version 6)
+    p2w_input_values: Optional[np.ndarray] = None         # (n_p2w, 32)
+    p2w_new_start: Optional[np.ndarray] = None
+    p2w_merkle_path: Optional[np.ndarray] = None
+    p2w_mmcs_bit: Optional[np.ndarray] = None
+    p2w_mmcs_bit2: Optional[np.ndarray] = None
+    p2w_mmcs_index_sum: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -92,6 +99,8 @@ class CircuitPrep:
     # a layer holding BOTH Recompose tables (recompose_table_provers(lanes, true), batch_stark_prover.rs:1914-1932):
     # recompose_prep is then the plain kind and this is the `recompose/coeff` table, (n, 2 + 2 D)
     recompose_coeff_prep: Optional[np.ndarray] = None
+    # the width-32 Poseidon2 table: assembled preprocessed rows (n_p2w, 48), Poseidon2PreprocessedRow<8, 6>
+    p2w_prep: Optional[np.ndarray] = None
 
 
 class CircuitProverData:
@@ -130,6 +139,12 @@ class CircuitProverData:
         d.counts.n_recompose_coeff = rec2.size // (2 + 2 * ctx.ext_degree)
         if d.counts.n_recompose_coeff:
             d.recompose_coeff_prep = p32(rec2)
+        pw = np.zeros(0, np.uint32) if prep.p2w_prep is None else np.asarray(prep.p2w_prep)
+        if pw.size % 48:
+            raise P3rError(-1, "p2w_prep must be (n, 48)")
+        d.counts.n_p2w = pw.size // 48
+        if d.counts.n_p2w:
+            d.p2w_prep = p32(pw)
         d.public_lanes, d.alu_lanes = packing.public_lanes, packing.alu_lanes
         d.horner_packed_steps, d.recompose_lanes = packing.horner_packed_steps, packing.recompose_lanes
         d.min_trace_height = packing.min_trace_height
@@ -150,7 +165,7 @@ class CircuitProverData:
             d.p2_absorb_len = p8(prep.p2_absorb_len)
         self.rows = dict(const=d.counts.n_const, public=d.counts.n_public, alu=d.counts.n_alu,
                          poseidon2=d.counts.n_p2, recompose=d.counts.n_recompose,
-                         recompose_coeff=d.counts.n_recompose_coeff)
+                         recompose_coeff=d.counts.n_recompose_coeff, poseidon2_w32=d.counts.n_p2w)
         self.preprocessed_commitment = np.empty((1 << ctx.cap_height, 8), dtype=np.uint32)
         self.h = ctx.ptr(ctx.lib.p3r_layer_create(ctx.h, C.byref(d),
                                                   self.preprocessed_commitment.ctypes.data_as(_lib.u32p)))
@@ -175,6 +190,8 @@ class CircuitProverData:
         h5 = C.c_size_t()
         ctx.check(ctx.lib.p3r_layer_recompose_coeff_height(self.h, C.byref(h5)))
         self.recompose_coeff_height = int(h5.value)   # the second Recompose table (0 = absent)
+        ctx.check(ctx.lib.p3r_layer_p2w_height(self.h, C.byref(h5)))
+        self.p2w_height = int(h5.value)               # the width-32 Poseidon2 table (0 = absent)
         kind = C.c_uint32()
         ctx.check(ctx.lib.p3r_layer_recompose_kind(self.h, C.byref(kind)))
         self.recompose_coeff_lookups = bool(kind.value)   # the table at position 4 is `recompose/coeff`
@@ -273,6 +290,20 @@ def _traces_struct(tr: Traces, ext_degree=4):
             raise P3rError(-1, "recompose_coeff_values must have shape (n, %d), got %r" % (ext_degree, rc.shape))
         x, t.recompose_coeff_values = p32(rc)
         t.n_recompose_coeff = x.shape[0]
+    pw = getattr(tr, "p2w_input_values", None)
+    if pw is not None and np.asarray(pw).size:
+        pw = np.asarray(pw)
+        if pw.ndim != 2 or pw.shape[1] != 32:
+            raise P3rError(-1, "p2w_input_values must have shape (n, 32), got %r" % (pw.shape,))
+        x, t.p2w.input_values = p32(pw)
+        t.p2w.n = x.shape[0]
+        for name in ("new_start", "merkle_path", "mmcs_bit", "mmcs_bit2"):
+            b, p = _u8(getattr(tr, "p2w_" + name))
+            if b.shape[0] != t.p2w.n:
+                raise P3rError(-1, "p2w_%s must hold one entry per row" % name)
+            keep.append(b)
+            setattr(t.p2w, name, p)
+        x, t.p2w.mmcs_index_sum = p32(tr.p2w_mmcs_index_sum)
     return t, keep
 
 
@@ -353,7 +384,9 @@ class BatchStarkProof:
         out = [dict(kind=0, lanes=1), dict(kind=1, lanes=tp.public_lanes),
                dict(kind=2, lanes=tp.alu_lanes, horner_packed_steps=tp.horner_packed_steps)]
         for e in self.non_primitives:
-            if e.op_type.startswith("poseidon2_perm/") and (self.ext_degree == 4 or e.op_type.endswith("_d1_w16")):
+            if e.op_type.startswith("poseidon2_perm/") and e.op_type.endswith("_d4_w32") and self.ext_degree == 4:
+                out.append(dict(kind=5, lanes=1))   # the width-32 table of the arity-4 MMCS (P3R_AIR_POSEIDON2_W32)
+            elif e.op_type.startswith("poseidon2_perm/") and (self.ext_degree == 4 or e.op_type.endswith("_d1_w16")):
                 out.append(dict(kind=3, lanes=1))
             elif e.op_type in ("recompose", "recompose/coeff"):
                 out.append(dict(kind=4, lanes=e.lanes, coeff_lookups=1 if e.op_type == "recompose/coeff" else 0))
@@ -504,10 +537,12 @@ class BatchStarkProver:
         # circuit/src/ops/npo.rs:38, poseidon2_perm/config.rs:413-427: the D4 table, or the compact-D1 one of a D = 5 circuit
         p2_name = "poseidon2_perm/%s_%s_w16" % (ctx.field.replace("-", "_"), "d4" if ctx.ext_degree == 4 else "d1")   # D = 1, 5: D1
         k = tp.horner_packed_steps
-        heights = list(cpd.table_heights) + [getattr(cpd, "recompose_coeff_height", 0)]   # + the second Recompose table
+        # proof order: [Const, Public, Alu, Poseidon2, Poseidon2-W32, Recompose, Recompose/coeff]
+        heights = list(cpd.table_heights[:4]) + [getattr(cpd, "p2w_height", 0)] + [cpd.table_heights[4]] + \
+            [getattr(cpd, "recompose_coeff_height", 0)]
         present = [h > 0 for h in heights]
         coeff = getattr(cpd, "recompose_coeff_lookups", False)
-        prep_widths = (2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24 if ctx.ext_degree == 4 else 62,
+        prep_widths = (2, 2 * tp.public_lanes, 13 * tp.alu_lanes + 7 * (k - 1), 24 if ctx.ext_degree == 4 else 62, 48,
                        (2 + (2 * ctx.ext_degree if coeff else 0)) * tp.recompose_lanes,
                        (2 + 2 * ctx.ext_degree) * tp.recompose_lanes)
         # non-primitive tables without rows are not proved (poseidon2.rs:1089-1092, recompose.rs:77-80)
@@ -516,11 +551,15 @@ class BatchStarkProver:
             # Poseidon2Prover reports the PADDED row count (poseidon2.rs:1449)
             npo.append(NonPrimitiveTableEntry(op_type=p2_name, rows=cpd.table_heights[3], lanes=1))
         if present[4]:
+            # the width-32 table of the arity-4 MMCS (Poseidon2Config::*_D4_W32; NpoTypeId poseidon2_perm/<field>_d4_w32)
+            npo.append(NonPrimitiveTableEntry(op_type="poseidon2_perm/%s_d4_w32" % ctx.field.replace("-", "_"),
+                                              rows=cpd.p2w_height, lanes=1))
+        if present[5]:
             # RecomposeProver reports the op count (recompose.rs:125)
             # circuit/src/ops/npo.rs:48-60: "recompose", or "recompose/coeff" for the per-coefficient variant
             npo.append(NonPrimitiveTableEntry(op_type="recompose/coeff" if coeff else "recompose",
                                               rows=cpd.rows["recompose"], lanes=tp.recompose_lanes))
-        if present[5]:
+        if present[6]:
             # both table provers are registered: `recompose`, then `recompose/coeff` (batch_stark_prover.rs:1924-1928)
             npo.append(NonPrimitiveTableEntry(op_type="recompose/coeff", rows=cpd.rows["recompose_coeff"],
                                               lanes=tp.recompose_lanes))

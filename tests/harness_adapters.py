@@ -19,7 +19,16 @@ def traces_from_arrays(a, ext_degree=4) -> Traces:
         recompose_values=a["recompose_values"].reshape(-1, d),
         # RECOMPOSE_BOTH: the rows of the second Recompose table (`recompose/coeff`)
         recompose_coeff_values=a["recompose_coeff_values"].reshape(-1, d) if len(a.get("recompose_coeff_values", ())) else None,
+        # P2_W32: the rows of the width-32 Poseidon2 table
+        **(_p2w_traces(a) if len(a.get("p2w_inputs", ())) else {}),
     )
+
+
+def _p2w_traces(a):
+    fl = a["p2w_flags"].reshape(-1, 4)
+    return dict(p2w_input_values=a["p2w_inputs"].reshape(-1, 32), p2w_new_start=fl[:, 0].astype(np.uint8),
+                p2w_merkle_path=fl[:, 1].astype(np.uint8), p2w_mmcs_bit=fl[:, 2].astype(np.uint8),
+                p2w_mmcs_bit2=fl[:, 3].astype(np.uint8), p2w_mmcs_index_sum=a["p2w_mmcs_index_sum"])
 
 
 def circuit_prep_from_arrays(a, ext_degree=4, recompose_coeff_lookups=False) -> CircuitPrep:
@@ -41,6 +50,7 @@ def circuit_prep_from_arrays(a, ext_degree=4, recompose_coeff_lookups=False) -> 
         p2_mmcs_index_sum_idx=a["p2_mmcs_index_sum_idx"],
         p2_absorb_len=a["p2_absorb_len"].astype(np.uint8) if ext_degree != 4 and "p2_absorb_len" in a else None,
         recompose_coeff_prep=a["recompose_coeff_prep"].reshape(-1, 2 + 2 * ext_degree) if len(a.get("recompose_coeff_prep", ())) else None,
+        p2w_prep=a["p2w_prep"].reshape(-1, 48) if len(a.get("p2w_prep", ())) else None,
     )
 
 

@@ -16,7 +16,9 @@ ARRAYS = ["const_values", "const_prep", "public_values", "public_prep", "alu_val
           "p2_output_indices", "p2_mmcs_index_sum_idx", "recompose_values", "recompose_prep", "counts",
           # the circuit the arrays above were derived from (flattened Circuit<EF>, include/p3r.h) and its inputs
           "ops", "ext", "public_rows", "in_public_values", "private_rows", "in_private_values", "pd_op_ids",
-          "pd_siblings", "rewrite", "p2_absorb_len", "recompose_coeff_values", "recompose_coeff_prep"]
+          "pd_siblings", "rewrite", "p2_absorb_len", "recompose_coeff_values", "recompose_coeff_prep",
+          # the width-32 Poseidon2 table (flag P2_W32; counts[7] rows): inputs n x 32, flags n x 4, index sums, assembled prep n x 48
+          "p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep"]
 
 
 def build():
@@ -30,6 +32,9 @@ NO_POSEIDON2, NO_RECOMPOSE, SINGLE_PUBLIC, NO_ALU, INDEPENDENT_SPONGES, RECOMPOS
 # both Recompose tables in one layer: each op is `recompose` or `recompose/coeff` (arrays recompose_* and recompose_coeff_*;
 # counts[6] = rows of the second table) - what a backend with coefficient lookups registers (batch_stark_prover.rs:1914-1932)
 RECOMPOSE_BOTH = 64
+# a width-32 Poseidon2 table next to the width-16 one: arity-4 Merkle chains and rate-24 sponges (Poseidon2Config::*_D4_W32);
+# D = 4 only, at the prove_all_tables boundary (arrays p2w_*, counts[7])
+P2_W32 = 128
 
 
 def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None,
@@ -49,6 +54,11 @@ def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_le
         import oracle_lib
         rc = oracle_lib.default_rc(field)
     rc = np.ascontiguousarray(rc, dtype=np.uint32)
+    if flags & P2_W32:
+        import oracle_lib
+        w32 = [np.ascontiguousarray(a, dtype=np.uint32) for a in oracle_lib.default_w32(field)]
+        lib.syn_set_w32.argtypes = [u32p, u32p]
+        lib.syn_set_w32(w32[0].ctypes.data_as(u32p), w32[1].ctypes.data_as(u32p))
     h = lib.syn_generate(FIELD_IDS[field], log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth,
                          rc.ctypes.data_as(u32p), flags | (ext_degree << 8 if ext_degree != 4 else 0))
     try:

@@ -6,7 +6,7 @@ import numpy as np
 import oracle_lib
 
 u32p = C.POINTER(C.c_uint32)
-KINDS = ["const", "public", "alu", "poseidon2", "recompose"]
+KINDS = ["const", "public", "alu", "poseidon2", "recompose", "poseidon2_w32"]
 
 
 class OrcWorkload(C.Structure):
@@ -22,6 +22,9 @@ class OrcWorkload(C.Structure):
         ("recompose_lanes", C.c_uint32), ("min_trace_height", C.c_uint32), ("ext_degree", C.c_uint32),
         ("p2_absorb_len", u32p), ("recompose_coeff_lookups", C.c_uint32), ("ext_w", C.c_uint32),
         ("n_recompose_coeff", C.c_size_t), ("recompose_coeff_values", u32p), ("recompose_coeff_prep", u32p),
+        # the width-32 Poseidon2 table (arity-4 MMCS rows) and the constants of its permutation
+        ("n_p2w", C.c_size_t), ("p2w_inputs", u32p), ("p2w_flags", u32p), ("p2w_mmcs_index_sum", u32p), ("p2w_prep", u32p),
+        ("w32_rc", u32p), ("w32_diag", u32p),
     ]
 
 
@@ -75,6 +78,13 @@ def fill_workload(wl_struct, arrays, packing, keep):
     wl_struct.ext_w = packing.get("ext_w", 0)
     if "p2_absorb_len" in arrays and len(arrays["p2_absorb_len"]):
         wl_struct.p2_absorb_len = ptr("p2_absorb_len")
+    if len(c) > 7 and int(c[7]):   # rows of the width-32 Poseidon2 table (harness flag P2_W32)
+        wl_struct.n_p2w = int(c[7])
+        for name in ("p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep"):
+            setattr(wl_struct, name, ptr(name))
+        w32 = oracle_lib.default_w32(packing["field"])
+        keep.extend(w32)
+        wl_struct.w32_rc, wl_struct.w32_diag = w32[0].ctypes.data_as(u32p), w32[1].ctypes.data_as(u32p)
     # a layer with both Recompose tables (harness flag RECOMPOSE_BOTH): the second one is `recompose/coeff`
     if len(c) > 6 and int(c[6]):
         wl_struct.n_recompose_coeff = int(c[6])
@@ -119,6 +129,7 @@ class OracleLayer:
                                          C.c_int]
         packing = dict(packing or {})
         packing.setdefault("min_trace_height", min_trace_height(prm))
+        packing["field"] = field
         self.packing = packing
         wl = OrcWorkload()
         self._keep = []

@@ -36,6 +36,13 @@ def default_rc(field):
         return np.array(json.load(fh)[FIELD_NAMES[field]], dtype=np.uint32)
 
 
+def default_w32(field):
+    """(round constants, internal diagonal) of the DEFAULT width-32 permutation (tools/gen_poseidon2_constants.py; unpinned)."""
+    with open(os.path.join(ROOT, "tests/golden/poseidon2_w32_default.json")) as fh:
+        d = json.load(fh)[FIELD_NAMES[field]]
+    return np.array(d["rc"], dtype=np.uint32), np.array(d["diag"], dtype=np.uint32)
+
+
 class Oracle:
     def __init__(self):
         build()

@@ -70,6 +70,9 @@ def test_circuit_path_reproduces_harness_bookkeeping(oracle, field, flags):
     oc.run(field, cl.Inputs.from_arrays(a))
     w = oc.workload_arrays()
     for k in w:
+        if k == "counts":   # counts[7]: rows of the width-32 Poseidon2 table, which is not part of the flattened circuit
+            assert np.array_equal(w[k], a[k][:len(w[k])]) and not a[k][len(w[k]):].any(), k
+            continue
         assert np.array_equal(w[k], a[k]), k
     if flags == 0:
         kinds = np.bincount(a["ops"].reshape(-1, 8)[:, 0], minlength=11)

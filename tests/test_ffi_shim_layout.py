@@ -65,8 +65,9 @@ def norm_c(base, ptr, const, dim):
 
 def rust_structs(md):
     out = {}
+    md = strip_c_comments(md)   # comments may hold braces (type names like Poseidon2{Koala,Baby}Bear<32>)
     for m in re.finditer(r"#\[repr\(C\)\]\s*pub struct (\w+)\s*\{(.*?)\}", md, flags=re.S):
-        body = strip_c_comments(m.group(2))
+        body = m.group(2)
         fields = []
         # split on commas that are not inside brackets
         depth, cur, parts = 0, "", []

@@ -1,0 +1,99 @@
+"""GPU: the width-32 Poseidon2 table (arity-4 MMCS rows; P3R_AIR_POSEIDON2_W32, ABI version 6) at the prove_all_tables
+boundary - the device's trace fill (base-four accumulator scan + width-32 permutation), preprocessed commitment and
+proof BYTES against the oracle on three parameter sets x both fields; the native verifier and the oracle's verifier
+both accept and both reject tampered statements; the proof's metadata names the table `poseidon2_perm/<field>_d4_w32`."""
+import numpy as np
+import pytest
+
+import harness_lib
+import layer_lib
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+GEN = dict(horner_chain_len=16, sponge_chain_len=3, merkle_depth=6)
+SETS = [dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4),
+        dict(log_blowup=2, max_log_arity=3, log_final_poly_len=2, cap_height=1, query_pow_bits=5, num_queries=6),
+        dict(log_blowup=2, max_log_arity=2, log_final_poly_len=5, query_pow_bits=8, num_queries=8)]
+
+
+def setup(oracle, field, log_h, kw, flags=0, packing=None):
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    a = harness_lib.generate(field, log_h, seed=40 + log_h, flags=harness_lib.P2_W32 | flags, **GEN)
+    prm = layer_lib.params(**kw)
+    L = layer_lib.OracleLayer(oracle, field, a, prm, packing=packing)
+    ctx = p3r.Context(field=field, **kw)
+    tp = p3r.TablePacking(**(packing or {})).with_fri_params(kw["log_final_poly_len"], kw["log_blowup"])
+    cpd = p3r.CircuitProverData(ctx, wl.circuit_prep_from_arrays(a), tp)
+    return a, L, ctx, cpd, wl.traces_from_arrays(a)
+
+
+@pytest.mark.parametrize("field", ["koala-bear", "baby-bear"])
+@pytest.mark.parametrize("k,log_h", [(0, 7), (1, 9), (2, 10)])
+def test_proof_bytes_equal_oracle(oracle, field, k, log_h):
+    import plonky3_recursion_amd as p3r
+    a, L, ctx, cpd, traces = setup(oracle, field, log_h, SETS[k])
+    assert cpd.rows["poseidon2_w32"] == int(a["counts"][7]) and cpd.p2w_height > 0
+    assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
+    prover = p3r.BatchStarkProver(ctx)
+    res = p3r.ResidentTraces(ctx, cpd, traces)
+    # the device's main trace of the table (kernels k_p2_acc_scan with the base-four map, k_p2w_trace_fill)
+    got_main = prover.build_main_trace(res, cpd, 6).download()
+    want = [t for t in L.tables() if t["kind"] == "poseidon2_w32"][0]["main"]
+    assert got_main.shape == want.shape and np.array_equal(got_main, want)
+    proof = prover.prove_all_tables(res, cpd)
+    assert proof.proof == L.prove()
+    names = [e.op_type for e in proof.non_primitives]
+    f = field.replace("-", "_")
+    assert names[:2] == ["poseidon2_perm/%s_d4_w16" % f, "poseidon2_perm/%s_d4_w32" % f]
+    assert [x["kind"] for x in proof.airs()] == [0, 1, 2, 3, 5, 4]
+    prover.verify_all_tables(proof)      # native verifier
+    L.verify(proof.proof)                # the oracle's verifier
+    back = p3r.BatchStarkProof.from_postcard(proof.to_postcard(), field)
+    assert [e.op_type for e in back.non_primitives] == names
+    prover.verify_all_tables(back)
+    # a tampered byte is rejected by both
+    bad = bytearray(proof.proof)
+    bad[len(bad) // 3] ^= 4
+    with pytest.raises(p3r.P3rError):
+        prover.verify_all_tables(p3r.BatchStarkProof(**{**proof.__dict__, "proof": bytes(bad)}))
+    with pytest.raises(RuntimeError):
+        L.verify(bytes(bad))
+    res.free(); cpd.free(); ctx.close()
+
+
+def test_broken_row_is_refused_by_the_prover(oracle):
+    """The prover checks the verifier's identity at zeta on its own openings before it serialises anything."""
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    field, kw = "koala-bear", SETS[0]
+    a = harness_lib.generate(field, 7, seed=47, flags=harness_lib.P2_W32, **GEN)
+    fl = a["p2w_flags"].reshape(-1, 4)
+    r = next(r for r in range(len(fl)) if fl[r, 1] and not fl[r, 0])
+    a["p2w_inputs"].reshape(-1, 32)[r, 8 * int(fl[r, 2] + 2 * fl[r, 3])] ^= 1   # chunk `pos` is no longer the running hash
+    ctx = p3r.Context(field=field, **kw)
+    tp = p3r.TablePacking().with_fri_params(kw["log_final_poly_len"], kw["log_blowup"])
+    cpd = p3r.CircuitProverData(ctx, wl.circuit_prep_from_arrays(a), tp)
+    with pytest.raises(p3r.P3rError, match="constraints"):
+        p3r.BatchStarkProver(ctx).prove_all_tables(wl.traces_from_arrays(a), cpd)
+    cpd.free(); ctx.close()
+
+
+def test_custom_width32_constants_are_data(oracle):
+    """p3r_config.poseidon2_w32_rc / _diag: another diagonal gives another (still verifying) proof; a wrong length is refused."""
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    field, kw = "koala-bear", SETS[0]
+    rc, diag = oracle_lib.default_w32(field)
+    with pytest.raises(p3r.P3rError, match="poseidon2_w32_rc_len"):
+        p3r.Context(field=field, poseidon2_w32_rc=rc[:-1], **kw)
+    ctx = p3r.Context(field=field, poseidon2_w32_rc=rc, poseidon2_w32_diag=diag, **kw)   # the defaults, passed explicitly
+    a = harness_lib.generate(field, 7, seed=47, flags=harness_lib.P2_W32, **GEN)
+    tp = p3r.TablePacking().with_fri_params(kw["log_final_poly_len"], kw["log_blowup"])
+    cpd = p3r.CircuitProverData(ctx, wl.circuit_prep_from_arrays(a), tp)
+    prover = p3r.BatchStarkProver(ctx)
+    proof = prover.prove_all_tables(wl.traces_from_arrays(a), cpd)
+    prover.verify_all_tables(proof)
+    L = layer_lib.OracleLayer(oracle, field, a, layer_lib.params(**kw))
+    assert proof.proof == L.prove()
+    cpd.free(); ctx.close()

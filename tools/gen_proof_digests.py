@@ -39,10 +39,19 @@ def layer(oracle, case):
 
 
 def workload_digest(arrs):
+    """sha256 over the generator's arrays.  Arrays added after the pins were made (the width-32 Poseidon2 table's,
+    round 4) are left out while they are empty, and `counts` is hashed without its trailing zero entries for such
+    tables - so the pins of the older layers keep telling a generator change apart from a layout extension."""
+    late = ("p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep")
     h = hashlib.sha256()
     for k in sorted(arrs):
+        a = arrs[k]
+        if k in late and not len(a):
+            continue
+        if k == "counts" and len(a) > 7 and not a[7:].any():
+            a = a[:7]
         h.update(k.encode())
-        h.update(arrs[k].tobytes())
+        h.update(a.tobytes())
     return h.hexdigest()
 
 
