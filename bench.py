@@ -1101,8 +1101,12 @@ def main():
                     # the size of a real verifier circuit (2^15 rows) under the same configuration: what one steady-state
                     # layer of `recursive_fibonacci --quintic` costs here
                     a15 = harness_lib.generate(field, 15, seed=0x5EED0015, flags=harness_lib.RECOMPOSE_BOTH, ext_degree=5, **GEN_KNOBS)
+                    c15 = wl.circuit_from_arrays(a15)
+                    p3r.PreparedCircuit(ctx5, c15, packing).free()   # first preparation of this size: allocator pool, table caches
+                    ctx5.sync()
                     t5 = time.perf_counter()
-                    pc15 = p3r.PreparedCircuit(ctx5, wl.circuit_from_arrays(a15), packing)
+                    pc15 = p3r.PreparedCircuit(ctx5, c15, packing)
+                    ctx5.sync()
                     prep15 = (time.perf_counter() - t5) * 1e3
                     rin15 = pc15.upload_inputs(wl.circuit_inputs_from_arrays(a15, 5))
                     raw15 = pc15.prove(rin15)
@@ -1126,6 +1130,54 @@ def main():
                     rin15.free()
                     pc15.free()
                 ctx5.close()
+        if not args.no_quintic and world == 1:
+            # SURVEY 8(f).4, arity-4 width-32: a layer that holds the width-32 Poseidon2 table (the arity-4 MMCS rows of a
+            # mixed-config verifier circuit: W16 challenger + W32 MMCS, recursive_aggregation.rs:902-1000) next to the five
+            # tables of the headline layer, at the prove_all_tables boundary with Traces resident in HBM; proof verified
+            if resident is not None:
+                resident.free()
+                pc.free()
+                resident = pc = None
+            arrsw = harness_lib.generate(field, log_h, seed=0x5EED0032, flags=harness_lib.P2_W32, **GEN_KNOBS)
+            countsw = [int(x) for x in arrsw["counts"]]
+            ctxw = p3r.Context(field=field, **FRI)
+            cpdw = p3r.CircuitProverData(ctxw, wl.circuit_prep_from_arrays(arrsw), packing)
+            resw = p3r.ResidentTraces(ctxw, cpdw, wl.traces_from_arrays(arrsw))
+            del arrsw
+            proverw = p3r.BatchStarkProver(ctxw)
+            proofw = proverw.prove_all_tables(resw, cpdw)
+            ctxw.sync()
+            tw = time.perf_counter()
+            for _ in range(3):
+                proverw.prove_all_tables(resw, cpdw)
+            ctxw.sync()
+            msw = (time.perf_counter() - tw) / 3 * 1e3
+            try:
+                proverw.verify_all_tables(proofw)
+                okw = True
+            except Exception as e:
+                print(f"bench: width-32 layer: proof rejected: {e}", file=sys.stderr)
+                okw = False
+            ctxw.profile_enable(True)
+            proverw.prove_all_tables(resw, cpdw)
+            profw = ctxw.profile_read()
+            ctxw.profile_enable(False)
+            line["width32_table_layer"] = {
+                "ms_per_step": msw, "steps": 3, "proof_verified": okw, "proof_bytes": len(proofw.proof),
+                "tables": [e.op_type for e in proofw.non_primitives],
+                "table_heights": cpdw.table_heights + [cpdw.p2w_height],
+                "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose", "witnesses", "recompose/coeff", "poseidon2_w32"], countsw)),
+                "width32_table": {"main_columns": (319 if field == "koala-bear" else 604) + 4, "preprocessed_columns": 48, "bus_interactions": 16,
+                                  "constants": "self-generated defaults (p3r_config.poseidon2_w32_rc / _diag = NULL): unpinned"},
+                "kernel_ms": {k: v[0] for k, v in profw.items() if not k.startswith("stage:")},
+                "workload": f"prove_all_tables (Traces resident in HBM) of the synthetic {field} 2^{log_h}-row layer with a sixth table: "
+                            f"const / public / alu / poseidon2 (width 16) / poseidon2 width 32 (arity-4 Merkle chains with injection and "
+                            f"bridge levels, rate-24 sponge chains: 2^{log_h - 2} rows) / recompose, same FRI parameters"}
+            proof_verified = proof_verified and okw
+            line["proof_verified"] = proof_verified
+            resw.free()
+            cpdw.free()
+            ctxw.close()
         print(json.dumps(line))
     if resident is not None:
         resident.free()
