@@ -194,6 +194,13 @@ typedef struct p3r_p2w_rows {
   const uint32_t* mmcs_index_sum; /* n */
 } p3r_p2w_rows;
 
+/* Unit seams of the width-32 permutation and its table (ABI 6): Poseidon2{Koala,Baby}Bear<32> on n row-major
+ * canonical states; generate_trace_rows of the arity-4 layout (trace_out is n x p3r_poseidon2_w32_trace_width(),
+ * n a power of two). */
+int p3r_poseidon2_w32_permute_batch(p3r_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n);
+int p3r_poseidon2_w32_trace_fill(p3r_ctx* ctx, const p3r_p2w_rows* rows, uint32_t* trace_out);
+uint32_t p3r_poseidon2_w32_trace_width(const p3r_ctx* ctx);
+
 /* Poseidon2CircuitAir::generate_trace_rows: trace_out is n x p3r_poseidon2_trace_width(). */
 int p3r_poseidon2_trace_fill(p3r_ctx* ctx, const p3r_p2_rows* rows, uint32_t* trace_out);
 /* Same, leaving the trace in HBM. */

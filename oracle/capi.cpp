@@ -192,6 +192,40 @@ int orc_p2_trace_rows(int field, const uint32_t* rc, size_t n, const uint32_t* i
                       const uint32_t* index_sum, uint32_t* out) {
   return guard([&] { FIELD_SWITCH(field, do_trace_rows, rc, n, inputs, new_start, merkle_path, mmcs_bit, index_sum, out); });
 }
+// the width-32 permutation and its table's trace rows (constants as data: rc = 8 * 32 + partial rounds, diag = 32)
+int orc_p2w_permute(int field, const uint32_t* rc, const uint32_t* diag, const uint32_t* in, uint32_t* out, size_t n) {
+  return guard([&] {
+    auto run = [&](auto tag) {
+      using FP = decltype(tag);
+      Poseidon2W32<FP> p2(rc, diag);
+      for (size_t i = 0; i < n; ++i) {
+        std::array<Fe<FP>, WIDTH32> s;
+        for (int k = 0; k < WIDTH32; ++k) s[k] = Fe<FP>(in[i * WIDTH32 + k]);
+        p2.permute(s);
+        for (int k = 0; k < WIDTH32; ++k) out[i * WIDTH32 + k] = s[k].v;
+      }
+    };
+    if (field == 0) run(KoalaBear{}); else run(BabyBear{});
+  });
+}
+int orc_p2w_trace_rows(int field, const uint32_t* rc, const uint32_t* diag, size_t n, const uint32_t* inputs, const uint32_t* flags4,
+                       const uint32_t* index_sum, uint32_t* out) {
+  return guard([&] {
+    auto run = [&](auto tag) {
+      using FP = decltype(tag);
+      Poseidon2W32<FP> p2(rc, diag);
+      std::vector<P2WRow<FP>> rows(n);
+      for (size_t i = 0; i < n; ++i) {
+        rows[i].new_start = flags4[4 * i]; rows[i].merkle_path = flags4[4 * i + 1];
+        rows[i].mmcs_bit = flags4[4 * i + 2]; rows[i].mmcs_bit2 = flags4[4 * i + 3];
+        rows[i].mmcs_index_sum = Fe<FP>(index_sum[i]);
+        for (int k = 0; k < WIDTH32; ++k) rows[i].input[k] = Fe<FP>(inputs[i * WIDTH32 + k]);
+      }
+      mat_to(p2w_generate_trace_rows<FP>(p2, rows), out);
+    };
+    if (field == 0) run(KoalaBear{}); else run(BabyBear{});
+  });
+}
 int orc_coset_lde(int field, const uint32_t* evals, size_t h, size_t w, uint32_t added_bits,
                   uint32_t shift, uint32_t* out) {
   return guard([&] { FIELD_SWITCH(field, do_lde, evals, h, w, added_bits, shift, out); });

@@ -205,6 +205,9 @@ SIGNATURES = {
     "p3r_layer_table_heights": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "p3r_layer_recompose_coeff_height": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "p3r_layer_p2w_height": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "p3r_poseidon2_w32_permute_batch": (C.c_int, [vp, u32p, u32p, C.c_size_t]),
+    "p3r_poseidon2_w32_trace_fill": (C.c_int, [vp, C.POINTER(P3rP2wRows), u32p]),
+    "p3r_poseidon2_w32_trace_width": (C.c_uint32, [vp]),
     "p3r_layer_recompose_kind": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
     "p3r_layer_effective_lanes": (C.c_int, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "p3r_verify_batch": (C.c_int, [C.POINTER(P3rConfig), C.POINTER(P3rAirDesc), C.c_size_t, u32p, u32p,

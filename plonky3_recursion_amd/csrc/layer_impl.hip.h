@@ -471,6 +471,26 @@ DevBuf upload_mont(p3r_ctx* ctx, const uint32_t* host, size_t n, const char* wha
   return b;
 }
 
+// rows of the width-32 table on the device: h padded rows of which the first n carry data; flags = new_start[h] |
+// merkle_path[h] | mmcs_bit[h] | mmcs_bit2[h]
+template <class PP>
+std::unique_ptr<p3r_p2_dev> p2w_rows_upload(p3r_ctx* ctx, size_t h, size_t n, const uint32_t* inputs /* h x 32 */, const uint8_t* flags /* 4 h */,
+                                            const uint32_t* index_sum /* h */) {
+  log2_exact(h, "width-32 Poseidon2 row count (padded)");
+  for (size_t i = 0; i < n * 32; ++i) if (inputs[i] >= PP::P) fail(P3R_EINVAL, "p2w.input_values[%zu] is not canonical", i);
+  for (size_t i = 0; i < n; ++i) if (index_sum[i] >= PP::P) fail(P3R_EINVAL, "p2w.mmcs_index_sum[%zu] is not canonical", i);
+  auto dw = std::make_unique<p3r_p2_dev>();
+  dw->n = h;
+  dw->flags.alloc(h + 1);
+  P3R_HIP(hipMemcpyAsync(dw->flags.p, flags, 4 * h, hipMemcpyHostToDevice, ctx->stream));
+  dw->seed.alloc(h);
+  P3R_HIP(hipMemcpyAsync(dw->seed.p, index_sum, h * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_convert_inplace<PP>, dim3(blocks_for(h)), dim3(kBlock), 0, ctx->stream, dw->seed.p, h, 1);
+  P3R_HIP(hipGetLastError());
+  dw->inputs = upload<PP>(ctx, inputs, h, P2W_WIDTH);  // syncs the stream
+  return dw;
+}
+
 template <class PP>
 std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, const p3r_traces* t) {
   const auto& c = L->counts;
@@ -526,18 +546,7 @@ std::unique_ptr<p3r_dtraces> traces_upload(p3r_ctx* ctx, const p3r_layer* L, con
     std::copy(w.merkle_path, w.merkle_path + nw, f.begin() + hw);
     std::copy(w.mmcs_bit, w.mmcs_bit + nw, f.begin() + 2 * hw);
     std::copy(w.mmcs_bit2, w.mmcs_bit2 + nw, f.begin() + 3 * hw);
-    for (size_t i = 0; i < nw * 32; ++i) if (win[i] >= PP::P) fail(P3R_EINVAL, "p2w.input_values[%zu] is not canonical", i);
-    for (size_t i = 0; i < nw; ++i) if (widx[i] >= PP::P) fail(P3R_EINVAL, "p2w.mmcs_index_sum[%zu] is not canonical", i);
-    auto dw = std::make_unique<p3r_p2_dev>();
-    dw->n = hw;
-    dw->flags.alloc(hw + 1);
-    P3R_HIP(hipMemcpyAsync(dw->flags.p, f.data(), 4 * hw, hipMemcpyHostToDevice, ctx->stream));
-    dw->seed.alloc(hw);
-    P3R_HIP(hipMemcpyAsync(dw->seed.p, widx.data(), hw * 4, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_convert_inplace<PP>, dim3(blocks_for(hw)), dim3(kBlock), 0, ctx->stream, dw->seed.p, hw, 1);
-    P3R_HIP(hipGetLastError());
-    dw->inputs = upload<PP>(ctx, win.data(), hw, P2W_WIDTH);  // syncs the stream
-    d->p2w = std::move(dw);
+    d->p2w = p2w_rows_upload<PP>(ctx, hw, nw, win.data(), f.data(), widx.data());
   }
   return d;
 }

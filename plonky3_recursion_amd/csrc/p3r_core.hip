@@ -145,6 +145,26 @@ std::unique_ptr<p3r_dmat> trace_fill(p3r_ctx* ctx, const p3r_p2_dev* rows) {
   return trace;
 }
 
+// width-32 permutation over n row-major states (canonical in / out): the unit seam of p3r_poseidon2_w32_permute_batch
+template <class PP>
+__global__ void __launch_bounds__(kBlock) k_p2w_permute_rows(uint32_t* __restrict__ s, size_t n, const uint32_t* __restrict__ rcw) {
+  using F = Fp<PP>;
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  F x[P2W_WIDTH];
+#pragma unroll
+  for (int k = 0; k < P2W_WIDTH; ++k) x[k] = F::from_canonical(s[i * P2W_WIDTH + k]);
+  P2NullSink sink;
+  p2w_permute_traced<PP>(x, rcw, sink);
+#pragma unroll
+  for (int k = 0; k < P2W_WIDTH; ++k) s[i * P2W_WIDTH + k] = x[k].to_canonical();
+}
+template <class PP>
+void permute_w32_rows(p3r_ctx* ctx, uint32_t* d, size_t n) {
+  hipLaunchKernelGGL(k_p2w_permute_rows<PP>, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, d, n, ctx->rc.p + p2_num_constants<PP>());
+  P3R_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------ coset LDE (tu_lde.hip)
 template <class PP>
 std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_bits, uint32_t shift) {
@@ -621,6 +641,42 @@ int p3r_poseidon2_trace_fill(p3r_ctx* ctx, const p3r_p2_rows* rows, uint32_t* tr
     auto t = P3R_FIELD_CALL(ctx, trace_fill, ctx, d.get());
     P3R_FIELD_CALL(ctx, download, ctx, t.get(), trace_out);
   });
+}
+
+// unit seams of the width-32 permutation (ABI 6): the permutation itself, and the table's trace fill
+int p3r_poseidon2_w32_permute_batch(p3r_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n) {
+  return guard(ctx, [&] {
+    if (!in || !out) fail(P3R_EINVAL, "NULL argument");
+    if (n == 0) return;
+    DevBuf d(n * P2W_WIDTH);
+    P3R_HIP(hipMemcpyAsync(d.p, in, n * P2W_WIDTH * 4, hipMemcpyHostToDevice, ctx->stream));
+    P3R_FIELD_CALL(ctx, permute_w32_rows, ctx, d.p, n);
+    P3R_HIP(copy_sync(ctx->stream, out, d.p, n * P2W_WIDTH * 4, hipMemcpyDeviceToHost));
+  });
+}
+int p3r_poseidon2_w32_trace_fill(p3r_ctx* ctx, const p3r_p2w_rows* rows, uint32_t* trace_out) {
+  return guard(ctx, [&] {
+    if (!rows || !trace_out || !rows->input_values || !rows->new_start || !rows->merkle_path || !rows->mmcs_bit || !rows->mmcs_bit2 ||
+        !rows->mmcs_index_sum)
+      fail(P3R_EINVAL, "NULL argument");
+    const size_t n = rows->n;
+    log2_exact(n, "width-32 Poseidon2 row count (callers pad to a power of two)");
+    std::vector<uint8_t> f(4 * n);
+    std::copy(rows->new_start, rows->new_start + n, f.begin());
+    std::copy(rows->merkle_path, rows->merkle_path + n, f.begin() + n);
+    std::copy(rows->mmcs_bit, rows->mmcs_bit + n, f.begin() + 2 * n);
+    std::copy(rows->mmcs_bit2, rows->mmcs_bit2 + n, f.begin() + 3 * n);
+    auto run = [&](auto tag) {
+      using PP = decltype(tag);
+      auto d = p2w_rows_upload<PP>(ctx, n, n, rows->input_values, f.data(), rows->mmcs_index_sum);
+      auto t = trace_fill_w32<PP>(ctx, d.get());
+      download<PP>(ctx, t.get(), trace_out);
+    };
+    if (ctx->cfg.field == P3R_FIELD_KOALA_BEAR) run(KoalaBearParams{}); else run(BabyBearParams{});
+  });
+}
+uint32_t p3r_poseidon2_w32_trace_width(const p3r_ctx* ctx) {
+  return (ctx->cfg.field == P3R_FIELD_KOALA_BEAR ? p2w_perm_cols<KoalaBearParams>() : p2w_perm_cols<BabyBearParams>()) + 4;
 }
 
 p3r_dmat* p3r_coset_lde_dmat(p3r_ctx* ctx, const p3r_dmat* evals, uint32_t added_bits,

@@ -201,6 +201,40 @@ class Context:
         rows, keep = self._p2_rows(inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum)
         return DeviceMatrix(self, self.ptr(self.lib.p3r_poseidon2_trace_fill_dmat(self.h, C.byref(rows))))
 
+    # ---- the width-32 permutation (the arity-4 MMCS) and its table's trace rows (include/p3r.h, ABI 6)
+    def poseidon2_w32_permute_batch(self, states):
+        a, p = _u32(states)
+        if a.ndim != 2 or a.shape[1] != 32:
+            raise P3rError(-1, "states must have shape (n, 32)")
+        out = np.empty_like(a)
+        self.check(self.lib.p3r_poseidon2_w32_permute_batch(self.h, p, out.ctypes.data_as(_lib.u32p), a.shape[0]))
+        return out
+
+    def generate_w32_trace_rows(self, inputs, new_start, merkle_path, mmcs_bit, mmcs_bit2, mmcs_index_sum, height=None):
+        """Poseidon2CircuitAir::generate_trace_rows of the arity-4 layout; rows are padded to `height` (a power of two)
+        with filler rows (new_start = 1, zero state)."""
+        a = np.ascontiguousarray(inputs, dtype=np.uint32)
+        n = a.shape[0]
+        h = height or (1 << max(n - 1, 0).bit_length())
+        pad = lambda x, fill, dt: np.concatenate([np.asarray(x, dt).reshape(n, -1), np.full((h - n, np.asarray(x, dt).reshape(n, -1).shape[1]), fill, dt)])
+        rows = _lib.P3rP2wRows()
+        keep = []
+
+        def put(name, arr, ptr_of):
+            x, p = ptr_of(np.ascontiguousarray(arr))
+            keep.append(x)
+            setattr(rows, name, p)
+        rows.n = h
+        put("input_values", pad(a, 0, np.uint32), _u32)
+        put("new_start", pad(new_start, 1, np.uint8).reshape(-1), _u8)
+        put("merkle_path", pad(merkle_path, 0, np.uint8).reshape(-1), _u8)
+        put("mmcs_bit", pad(mmcs_bit, 0, np.uint8).reshape(-1), _u8)
+        put("mmcs_bit2", pad(mmcs_bit2, 0, np.uint8).reshape(-1), _u8)
+        put("mmcs_index_sum", pad(mmcs_index_sum, 0, np.uint32).reshape(-1), _u32)
+        out = np.empty((h, int(self.lib.p3r_poseidon2_w32_trace_width(self.h))), dtype=np.uint32)
+        self.check(self.lib.p3r_poseidon2_w32_trace_fill(self.h, C.byref(rows), out.ctypes.data_as(_lib.u32p)))
+        return out
+
     def upload_p2_rows(self, inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum):
         rows, keep = self._p2_rows(inputs, new_start, merkle_path, mmcs_bit, mmcs_index_sum)
         return DeviceP2Rows(self, self.ptr(self.lib.p3r_p2_rows_upload(self.h, C.byref(rows))))

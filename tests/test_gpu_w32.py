@@ -97,3 +97,40 @@ def test_custom_width32_constants_are_data(oracle):
     L = layer_lib.OracleLayer(oracle, field, a, layer_lib.params(**kw))
     assert proof.proof == L.prove()
     cpd.free(); ctx.close()
+
+
+@pytest.mark.parametrize("field", ["koala-bear", "baby-bear"])
+def test_width32_permutation_and_trace_rows_vs_oracle(oracle, field):
+    """The unit seams: Poseidon2<field><32> on random and edge-case states, and the table's trace rows (base-four
+    accumulator scan across blocks + one permutation per row) on 2^13 random rows, against the oracle."""
+    import ctypes as C
+    import plonky3_recursion_amd as p3r
+    P = oracle_lib.MODULUS[field]
+    rc, diag = oracle_lib.default_w32(field)
+    lib, u32p = oracle.lib, C.POINTER(C.c_uint32)
+    lib.orc_p2w_permute.argtypes = [C.c_int, u32p, u32p, u32p, u32p, C.c_size_t]
+    lib.orc_p2w_trace_rows.argtypes = [C.c_int, u32p, u32p, C.c_size_t, u32p, u32p, u32p, u32p]
+    rng = np.random.default_rng(9)
+    ctx = p3r.Context(field=field)
+    st = rng.integers(0, P, size=(300, 32), dtype=np.uint32)
+    st[0] = 0
+    st[1] = P - 1
+    st[2, ::2] = 0
+    want = np.empty_like(st)
+    fid = oracle_lib.FIELD_IDS[field]
+    oracle._ck(lib.orc_p2w_permute(fid, rc.ctypes.data_as(u32p), diag.ctypes.data_as(u32p), st.ctypes.data_as(u32p), want.ctypes.data_as(u32p), len(st)))
+    assert np.array_equal(ctx.poseidon2_w32_permute_batch(st), want)
+    n = 1 << 13
+    inputs = rng.integers(0, P, size=(n, 32), dtype=np.uint32)
+    ns = (rng.random(n) < 0.15).astype(np.uint8)
+    ns[0] = 1
+    mp = (rng.random(n) < 0.7).astype(np.uint8)
+    b0, b1 = rng.integers(0, 2, size=n, dtype=np.uint8), rng.integers(0, 2, size=n, dtype=np.uint8)
+    idx = rng.integers(0, P, size=n, dtype=np.uint32)
+    got = ctx.generate_w32_trace_rows(inputs, ns, mp, b0, b1, idx)
+    flags = np.stack([ns, mp, b0, b1], axis=1).astype(np.uint32)
+    want = np.empty_like(got)
+    oracle._ck(lib.orc_p2w_trace_rows(fid, rc.ctypes.data_as(u32p), diag.ctypes.data_as(u32p), n, inputs.ctypes.data_as(u32p),
+                                      np.ascontiguousarray(flags).ctypes.data_as(u32p), idx.ctypes.data_as(u32p), want.ctypes.data_as(u32p)))
+    assert got.shape == want.shape and np.array_equal(got, want)
+    ctx.close()

@@ -351,3 +351,77 @@ def test_quintic_fixture_mapping_inverts_the_table_builder(oracle):
     for a, b in zip(L.tables(), L2.tables()):
         assert a["kind"] == b["kind"] and np.array_equal(a["main"], b["main"]) and np.array_equal(a["prep"], b["prep"]), a["kind"]
     assert np.array_equal(L.prep_commit(), L2.prep_commit())
+
+
+# ---- the width-32 Poseidon2 table of the arity-4 MMCS (circuit-prover/tests/arity4_mmcs.rs as a fixture) ----
+def _arity4_fixture():
+    g = load("rust_arity4_layer_koala_bear.json")
+    return g, np.array(g["w32_rc"], np.uint32), np.array(g["w32_diag"], np.uint32)
+
+
+def test_rust_arity4_layer_constants_and_table(oracle):
+    """With the DUMPED constants (round constants and internal diagonal of Poseidon2KoalaBear<32>): the harness permutation
+    reproduces upstream's KATs; the oracle's width-32 trace rows equal the Rust prover's main trace of the table; the
+    native verifier accepts the Rust proof.  A failure of the first assertion means the external layer (M4 blocks) or the
+    round structure differs; of the second, the Poseidon2Cols<32> interior order or the arity-4 circuit columns."""
+    import ctypes as C
+    import layer_lib
+    import plonky3_recursion_amd as p3r
+    g, rc, diag = _arity4_fixture()
+    assert len(rc) == 8 * 32 + 31 and len(diag) == 32
+    lib = oracle.lib
+    u32p = C.POINTER(C.c_uint32)
+    lib.orc_p2w_permute.argtypes = [C.c_int, u32p, u32p, u32p, u32p, C.c_size_t]
+    for kat in g["perm32_kats"]:
+        x = np.array(kat["in"], np.uint32)
+        y = np.empty(32, np.uint32)
+        oracle._ck(lib.orc_p2w_permute(0, rc.ctypes.data_as(u32p), diag.ctypes.data_as(u32p), x.ctypes.data_as(u32p), y.ctypes.data_as(u32p), 1))
+        assert y.tolist() == kat["out"], "Poseidon2KoalaBear<32>: external layer / round structure"
+    rows = g["p2w_rows"]
+    n = len(rows)
+    main = next(m for m in g["main_traces"] if m["table"].endswith("_d4_w32"))
+    want = np.array(main["values"], np.uint32).reshape(-1, main["width"])
+    assert main["width"] == 32 + 8 * 32 + 31 + 4
+    lib.orc_p2w_trace_rows.argtypes = [C.c_int, u32p, u32p, C.c_size_t, u32p, u32p, u32p, u32p]
+    h = want.shape[0]
+    inputs = np.zeros((h, 32), np.uint32)
+    flags = np.zeros((h, 4), np.uint32)
+    flags[:, 0] = 1
+    sums = np.zeros(h, np.uint32)
+    for r, row in enumerate(rows):
+        inputs[r] = row["input_values"]
+        flags[r] = [row["new_start"], row["merkle_path"], row["mmcs_bit"], row["mmcs_bit2"]]
+        sums[r] = row["mmcs_index_sum"]
+    got = np.empty_like(want)
+    oracle._ck(lib.orc_p2w_trace_rows(0, rc.ctypes.data_as(u32p), diag.ctypes.data_as(u32p), h, inputs.ctypes.data_as(u32p),
+                                      flags.ctypes.data_as(u32p), sums.ctypes.data_as(u32p), got.ctypes.data_as(u32p)))
+    assert np.array_equal(got[:n], want[:n]), "Poseidon2Cols<32> interior order / arity-4 circuit columns"
+    # the Rust proof under the native verifier (the table's constants passed as data)
+    proof = bytes.fromhex(g["batch_stark_proof_postcard_hex"])
+    bsp = p3r.BatchStarkProof.from_postcard(proof, "koala-bear")
+    assert any(e.op_type == "poseidon2_perm/koala_bear_d4_w32" for e in bsp.non_primitives)
+    cfg, keep = p3r.make_config("koala-bear", poseidon2_rc=np.array(g["rc"], np.uint32), poseidon2_w32_rc=rc, poseidon2_w32_diag=diag,
+                                **layer_lib_fri_of_config_koala_bear())
+    p3r.verify_all_tables(cfg, bsp)
+
+
+def layer_lib_fri_of_config_koala_bear():
+    """FRI parameters of circuit-prover's `config::koala_bear()` (config.rs:42-84, :126-136): what arity4_mmcs.rs proves under."""
+    return dict(log_blowup=1, max_log_arity=1, cap_height=0, log_final_poly_len=0, commit_pow_bits=0, query_pow_bits=16,
+                num_queries=100)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_rust_arity4_table(oracle):
+    """The device's trace fill of the width-32 table on the Rust run's rows, with the dumped constants."""
+    import plonky3_recursion_amd as p3r
+    g, rc, diag = _arity4_fixture()
+    main = next(m for m in g["main_traces"] if m["table"].endswith("_d4_w32"))
+    want = np.array(main["values"], np.uint32).reshape(-1, main["width"])
+    rows = g["p2w_rows"]
+    ctx = p3r.Context(field="koala-bear", poseidon2_rc=np.array(g["rc"], np.uint32), poseidon2_w32_rc=rc, poseidon2_w32_diag=diag)
+    got = ctx.generate_w32_trace_rows(np.array([r["input_values"] for r in rows], np.uint32),
+                                      *[np.array([r[k] for r in rows], np.uint8) for k in ("new_start", "merkle_path", "mmcs_bit", "mmcs_bit2")],
+                                      np.array([r["mmcs_index_sum"] for r in rows], np.uint32), height=want.shape[0])
+    assert np.array_equal(got[:len(rows)], want[:len(rows)])
+    ctx.close()

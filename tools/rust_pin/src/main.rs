@@ -32,6 +32,12 @@
 //!       on the compact-D1 table) under the ordinary KoalaBear configuration: the D = 5 tables of this repo
 //!       (ext_degree = 5), with preprocessed columns, Traces, per-table main traces and proof bytes.
 //!
+//!   tests/golden/rust_arity4_layer_koala_bear.json
+//!       circuit-prover/tests/arity4_mmcs.rs as a fixture: the constants of Poseidon2KoalaBear<32> (round constants AND the
+//!       internal diagonal, read off the linear layer), permutation KATs, a native arity-4 tree's root and sibling list, the
+//!       rows, preprocessed columns and main trace of the width-32 Poseidon2 table, the proof bytes (tests/test_rust_pins.py::
+//!       test_rust_arity4_layer_*).
+//!
 //! Written against the API the reference itself uses (recursion/examples/common/mod.rs:192-207,
 //! 464-486; circuit-prover/src/batch_stark_prover/tests.rs:1031-1099).  It has NOT been compiled in
 //! this repo's build image (no cargo there): expect to fix an import or two on first use.
@@ -636,6 +642,123 @@ fn quintic_challenge_layer() -> Value {
     quintic_layer_body!(q::MyConfig, config(), 5)
 }
 
+/// The width-32 Poseidon2 table of the arity-4 MMCS, as circuit-prover/tests/arity4_mmcs.rs proves it: a native arity-4
+/// tree (`MerkleTreeMmcs<F, F, PaddingFreeSponge<Perm32, 32, 24, 8>, TruncatedPermutation<Perm32, 4, 8, 32>, 4, 8>`) over a
+/// 64 x 4 matrix, one opening driven through `add_mmcs_verify_arity4`, the circuit proved with the W32 table under the
+/// ordinary KoalaBear configuration.  Dumps what this repo's width-32 path takes as DATA or has to reproduce:
+///   w32_rc / w32_diag   the permutation's constants (the diagonal read off the internal layer on the unit vectors:
+///                       internal(e_i)[i] = d_i + 1) -> p3r_config.poseidon2_w32_rc / poseidon2_w32_diag
+///   perm32_kats         Poseidon2KoalaBear<32> on a few states
+///   native_commit / native_opening_proof   the arity-4 tree's root and the sibling list (3 per level, ascending)
+///   p2w_rows            the Poseidon2CircuitRow list of the run (inputs, new_start, merkle_path, mmcs_bit, mmcs_bit2, mmcs_index_sum)
+///   preprocessed_columns, main_traces, proof bytes      as in the other layer fixtures
+fn arity4_layer() -> Value {
+    use p3_circuit::ops::{Poseidon2Config, generate_poseidon2_trace, generate_recompose_trace, perm_private_data};
+    use p3_circuit_prover::batch_stark_prover::{poseidon2_air_builders, recompose_air_builders};
+    use p3_circuit_prover::common::NpoPreprocessor;
+    use p3_circuit_prover::config::KoalaBearConfig;
+    use p3_circuit_prover::{Poseidon2Preprocessor, RecomposePreprocessor, config};
+    use p3_koala_bear::{GenericPoseidon2LinearLayersKoalaBear, KoalaBear, Poseidon2KoalaBear, default_koalabear_poseidon2_32};
+    use p3_poseidon2::GenericPoseidon2LinearLayers;
+    use p3_poseidon2_circuit_air::KoalaBearD4Width32;
+    type F = KoalaBear;
+    type EF = BinomialExtensionField<F, 4>;
+    type Perm32 = Poseidon2KoalaBear<32>;
+    type LeafHash = PaddingFreeSponge<Perm32, 32, 24, 8>;
+    type Compress4 = TruncatedPermutation<Perm32, 4, 8, 32>;
+    type Mmcs4 = MerkleTreeMmcs<F, F, LeafHash, Compress4, 4, 8>;
+    const INDEX: usize = 27;   // pos 3, 2, 1 at the three levels
+
+    let perm = default_koalabear_poseidon2_32();
+    // constants: the round constants through the AIR's own accessor, the diagonal off the unit vectors
+    let rcs = KoalaBearD4Width32::round_constants();
+    let mut w32_rc: Vec<u32> = Vec::new();
+    for r in rcs.beginning_full_round_constants.iter() { w32_rc.extend(u32s(r)); }
+    w32_rc.extend(u32s(&rcs.partial_round_constants));
+    for r in rcs.ending_full_round_constants.iter() { w32_rc.extend(u32s(r)); }
+    let w32_diag: Vec<u32> = (0..32).map(|i| {
+        let mut e = [F::ZERO; 32];
+        e[i] = F::ONE;
+        <GenericPoseidon2LinearLayersKoalaBear as GenericPoseidon2LinearLayers<32>>::internal_linear_layer(&mut e);
+        (e[i] - F::ONE).as_canonical_u32()
+    }).collect();
+    let kats: Vec<Value> = (0..4u64).map(|k| {
+        let mut st: [F; 32] = core::array::from_fn(|i| F::from_u64(k * 1000 + 7 * i as u64 + 1));
+        let input = u32s(&st);
+        perm.permute_mut(&mut st);
+        json!({"in": input, "out": u32s(&st)})
+    }).collect();
+
+    let mmcs = Mmcs4::new(LeafHash::new(perm.clone()), Compress4::new(perm.clone()), 0);
+    let values: Vec<F> = (0..(64 * 4) as u64).map(F::from_u64).collect();
+    let (commit, pdata) = mmcs.commit(vec![RowMajorMatrix::new(values, 4)]);
+    let opening = mmcs.open_batch(INDEX, &pdata);
+    let pack = |digest: &[F]| -> Vec<EF> { digest.chunks(4).map(|c| EF::from_basis_coefficients_slice(c).unwrap()).collect() };
+
+    let mut builder = CircuitBuilder::<EF>::new();
+    builder.enable_poseidon2_perm_width_32::<KoalaBearD4Width32, _>(generate_poseidon2_trace::<EF, KoalaBearD4Width32>, perm);
+    builder.enable_recompose::<F>(generate_recompose_trace::<F, EF>);
+    let cfg32 = Poseidon2Config::KOALA_BEAR_D4_W32;
+    let leaf = vec![builder.alloc_const(EF::from_basis_coefficients_slice(&opening.opened_values[0]).unwrap(), "leaf")];
+    let zero = builder.alloc_const(EF::ZERO, "dir_bit_0");
+    let one = builder.alloc_const(EF::ONE, "dir_bit_1");
+    let levels = opening.opening_proof.len() / 3;
+    let dirs: Vec<[_; 2]> = (0..levels).map(|l| { let pos = (INDEX >> (2 * l)) & 3; [if pos & 1 == 1 { one } else { zero }, if pos >> 1 == 1 { one } else { zero }] }).collect();
+    let root: Vec<_> = pack(&commit.roots()[0]).iter().map(|&v| builder.alloc_const(v, "root")).collect();
+    let op_ids = builder.add_mmcs_verify_arity4(cfg32, &leaf, &dirs, &root).unwrap();
+    let circuit = builder.build().unwrap();
+    let mut runner = circuit.runner();
+    runner.set_public_inputs(&[]).unwrap();
+    for (level, &op_id) in op_ids.iter().skip(1).enumerate() {
+        let sib: Vec<EF> = opening.opening_proof[level * 3..(level + 1) * 3].iter().flat_map(|d| pack(d)).collect();
+        runner.set_private_data(op_id, perm_private_data(cfg32, sib)).unwrap();
+    }
+    let traces = runner.run().unwrap();
+
+    let packing = TablePacking::new(4, 4);
+    let cfg = config::koala_bear();
+    let npo_prep: Vec<Box<dyn NpoPreprocessor<F>>> = vec![Box::new(Poseidon2Preprocessor), Box::new(RecomposePreprocessor::default())];
+    let mut air_builders = poseidon2_air_builders::<_, 4>();
+    air_builders.extend(recompose_air_builders(1, false));
+    let (airs_degrees, primitive_columns, non_primitive_columns) =
+        get_airs_and_degrees_with_prep::<KoalaBearConfig, _, 4>(&circuit, &packing, &npo_prep, &air_builders, ConstraintProfile::Standard).unwrap();
+    let prep_json = json!({
+        "primitive": primitive_columns.iter().map(|c| u32s(c)).collect::<Vec<_>>(),
+        "non_primitive": non_primitive_columns.iter().map(|(k, c)| (k.to_string(), u32s(c))).collect::<std::collections::BTreeMap<_, _>>(),
+    });
+    let (airs, log_degrees): (Vec<_>, Vec<usize>) = airs_degrees.into_iter().unzip();
+    let prover_data = ProverData::from_airs_and_degrees(&cfg, &airs, &log_degrees);
+    let cpd = CircuitProverData::new(prover_data, primitive_columns, non_primitive_columns);
+    let mut prover = BatchStarkProver::new(cfg).with_table_packing(packing.clone());
+    prover.register_poseidon2_table::<4>(cfg32);
+    prover.register_recompose_table::<4>(false);
+    let mains: Vec<Value> = prover.main_traces_for_pinning::<EF, 4>(&traces, &cpd).into_iter()
+        .map(|(name, m)| json!({"table": name, "width": m.width(), "values": u32s(&m.values)})).collect();
+    // the rows of the width-32 table as the executor recorded them (ops/poseidon2_perm/trace.rs:94-133)
+    let p2w_rows: Vec<Value> = traces.non_primitive_trace::<p3_circuit::ops::Poseidon2Trace<F>>(&cfg32.npo_type_id()).map(|t| t.operations.iter().map(|r| json!({
+        "new_start": r.new_start, "merkle_path": r.merkle_path, "mmcs_bit": r.mmcs_bit, "mmcs_bit2": r.mmcs_bit2,
+        "mmcs_index_sum": r.mmcs_index_sum.as_canonical_u32(), "input_values": u32s(&r.input_values)})).collect()).unwrap_or_default();
+    let proof: BatchStarkProof<KoalaBearConfig> = prover.prove_all_tables(&traces, &cpd).unwrap();
+    prover.verify_all_tables::<EF>(&proof).unwrap();
+    json!({
+        "field": "koala_bear", "ext_degree": 4, "index": INDEX,
+        "w32_rc": w32_rc, "w32_diag": w32_diag, "perm32_kats": kats,
+        "native_commit": u32s(&commit.roots()[0]),
+        "native_opened_row": u32s(&opening.opened_values[0]),
+        "native_opening_proof": opening.opening_proof.iter().map(|d| u32s(d)).collect::<Vec<_>>(),
+        "packing": {"public_lanes": packing.public_lanes(), "alu_lanes": packing.alu_lanes(),
+                    "horner_packed_steps": packing.horner_packed_steps(), "min_trace_height": packing.min_trace_height()},
+        "rc": koala::round_constants(),
+        "preprocessed_columns": prep_json,
+        "p2w_rows": p2w_rows,
+        "main_traces": mains,
+        "degree_bits": log_degrees,
+        "non_primitives": proof.non_primitives.iter().map(|e| e.op_type.to_string()).collect::<Vec<_>>(),
+        "batch_stark_proof_postcard_hex": hex(&postcard::to_allocvec(&proof).unwrap()),
+        "batch_proof_postcard_hex": hex(&postcard::to_allocvec(&proof.proof).unwrap()),
+    })
+}
+
 fn main() {
     let golden = concat!(env!("CARGO_MANIFEST_DIR"), "/../../tests/golden");
     let inp: Value = serde_json::from_str(&fs::read_to_string(format!("{golden}/primitives.json")).unwrap()).unwrap();
@@ -655,5 +778,6 @@ fn main() {
     fs::write(format!("{golden}/rust_fibonacci_base_layer_baby_bear.json"), serde_json::to_string(&baby::fibonacci_base_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_quintic_layer_koala_bear.json"), serde_json::to_string(&quintic_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_quintic_challenge_layer_koala_bear.json"), serde_json::to_string(&quintic_challenge_layer()).unwrap()).unwrap();
-    println!("wrote rust_primitives.json, rust_fibonacci_layer_*.json, rust_fibonacci_base_layer_*.json, rust_npo_layer_*.json, rust_quintic_layer_koala_bear.json and rust_quintic_challenge_layer_koala_bear.json under {golden}");
+    fs::write(format!("{golden}/rust_arity4_layer_koala_bear.json"), serde_json::to_string(&arity4_layer()).unwrap()).unwrap();
+    println!("wrote rust_arity4_layer_koala_bear.json and rust_primitives.json, rust_fibonacci_layer_*.json, rust_fibonacci_base_layer_*.json, rust_npo_layer_*.json, rust_quintic_layer_koala_bear.json and rust_quintic_challenge_layer_koala_bear.json under {golden}");
 }
