@@ -121,6 +121,53 @@ void do_commit(const uint32_t* rc, size_t n_mats, const uint32_t* const* values,
   if (tree_out) *tree_out = static_cast<TreeBase*>(t.release());
 }
 
+// arity-4 MMCS over the width-32 permutation (hash.hpp: MerkleTree::commit4 / verify4)
+template <class FP>
+void do_commit4(const uint32_t* rc, const uint32_t* w32_rc, const uint32_t* w32_diag, size_t n_mats,
+                const uint32_t* const* values, const size_t* heights, const size_t* widths, uint32_t* cap_out,
+                size_t* proof_len, void** tree_out) {
+  Poseidon2<FP> p2(rc);
+  p2.w32 = std::make_shared<Poseidon2W32<FP>>(w32_rc, w32_diag);
+  auto t = std::make_unique<TreeImpl<FP>>();
+  std::vector<const Matrix<FP>*> ptrs;
+  for (size_t i = 0; i < n_mats; ++i) {
+    t->owned.push_back(std::make_unique<Matrix<FP>>(mat_from<FP>(values[i], heights[i], widths[i])));
+    ptrs.push_back(t->owned.back().get());
+  }
+  t->tree = MerkleTree<FP>::commit(p2, ptrs, 0, 4);
+  for (auto& d : t->tree.cap()) for (auto x : d) *cap_out++ = x.v;
+  *proof_len = 0;
+  for (auto& st : t->tree.sched) *proof_len += st.step - 1;
+  if (tree_out) *tree_out = static_cast<TreeBase*>(t.release());
+}
+template <class FP>
+void do_verify4(const uint32_t* rc, const uint32_t* w32_rc, const uint32_t* w32_diag, const uint32_t* cap, size_t n_mats,
+                const size_t* heights, const size_t* widths, size_t index, const uint32_t* opened,
+                const uint32_t* proof, size_t proof_len, int* ok) {
+  Poseidon2<FP> p2(rc);
+  p2.w32 = std::make_shared<Poseidon2W32<FP>>(w32_rc, w32_diag);
+  using Digest = typename MerkleTree<FP>::Digest;
+  std::vector<Digest> capd(1);
+  for (auto& d : capd) for (auto& x : d) x = Fe<FP>(*cap++);
+  std::vector<std::pair<size_t, size_t>> dims;
+  std::vector<std::vector<Fe<FP>>> ov;
+  for (size_t i = 0; i < n_mats; ++i) {
+    dims.emplace_back(heights[i], widths[i]);
+    std::vector<Fe<FP>> r(widths[i]);
+    for (auto& x : r) x = Fe<FP>(*opened++);
+    ov.push_back(r);
+  }
+  std::vector<Digest> pf(proof_len);
+  for (auto& d : pf) for (auto& x : d) x = Fe<FP>(*proof++);
+  *ok = MerkleTree<FP>::verify(p2, capd, 0, dims, index, ov, pf, 4) ? 1 : 0;
+}
+// the schedule alone: steps[l] (2 or 4) and the heights injected after each level; returns the number of levels
+inline size_t do_schedule4(size_t n_mats, const size_t* heights, uint32_t* steps, size_t* inject, size_t cap) {
+  auto sc = arity4_schedule(std::vector<size_t>(heights, heights + n_mats), 1);
+  for (size_t l = 0; l < sc.size() && l < cap; ++l) { steps[l] = (uint32_t)sc[l].step; inject[l] = sc[l].inject_h; }
+  return sc.size();
+}
+
 template <class FP>
 void do_verify(const uint32_t* rc, const uint32_t* cap, int cap_height, size_t n_mats,
                const size_t* heights, const size_t* widths, size_t index, const uint32_t* opened,
@@ -234,6 +281,19 @@ int orc_mmcs_commit(int field, const uint32_t* rc, size_t n_mats, const uint32_t
                     const size_t* heights, const size_t* widths, int cap_height, uint32_t* cap_out,
                     void** tree_out) {
   return guard([&] { FIELD_SWITCH(field, do_commit, rc, n_mats, values, heights, widths, cap_height, cap_out, tree_out); });
+}
+int orc_mmcs_commit4(int field, const uint32_t* rc, const uint32_t* w32_rc, const uint32_t* w32_diag, size_t n_mats,
+                     const uint32_t* const* values, const size_t* heights, const size_t* widths, uint32_t* cap_out,
+                     size_t* proof_len, void** tree_out) {
+  return guard([&] { FIELD_SWITCH(field, do_commit4, rc, w32_rc, w32_diag, n_mats, values, heights, widths, cap_out, proof_len, tree_out); });
+}
+int orc_mmcs_verify4(int field, const uint32_t* rc, const uint32_t* w32_rc, const uint32_t* w32_diag, const uint32_t* cap,
+                     size_t n_mats, const size_t* heights, const size_t* widths, size_t index, const uint32_t* opened,
+                     const uint32_t* proof, size_t proof_len, int* ok) {
+  return guard([&] { FIELD_SWITCH(field, do_verify4, rc, w32_rc, w32_diag, cap, n_mats, heights, widths, index, opened, proof, proof_len, ok); });
+}
+int orc_mmcs_schedule4(size_t n_mats, const size_t* heights, uint32_t* steps, size_t* inject, size_t cap, size_t* n_levels) {
+  return guard([&] { *n_levels = do_schedule4(n_mats, heights, steps, inject, cap); });
 }
 int orc_mmcs_open(const void* tree, size_t index, uint32_t* opened, uint32_t* proof) {
   return guard([&] { static_cast<const TreeBase*>(tree)->open(index, opened, proof); });

@@ -63,6 +63,7 @@ typedef struct orc_params {
   uint8_t fri_log_arities[32];
   uint8_t proof_layout[18];   // twin of p3r_config.proof_layout; all zero = identity
   uint32_t challenge_degree;  // 0 / 4: the quartic challenge field; 5: KoalaBear's quintic trinomial extension
+  uint32_t mmcs_arity;        // 0 / 2: binary trees over the width-16 permutation; 4: the arity-4 MMCS (width 32)
 } orc_params;
 
 const char* orc_last_error();
@@ -103,6 +104,7 @@ StarkParams to_sp(const orc_params& p) {
   s.log_final_poly_len = p.log_final_poly_len; s.commit_pow_bits = p.commit_pow_bits;
   s.query_pow_bits = p.query_pow_bits; s.num_queries = p.num_queries;
   s.lookup_unpacked = (p.ext_choices & 1u) != 0;
+  s.mmcs_arity = p.mmcs_arity == 4 ? 4 : 2;
   for (uint32_t i = 0; i < p.n_fri_log_arities && i < 32; ++i) s.fri_log_arities.push_back(p.fri_log_arities[i]);
   return s;
 }
@@ -140,6 +142,8 @@ struct Layer : LayerBase {
     if (D == 5 && FP::P != KoalaBear::P) throw std::runtime_error("D = 5 is KoalaBear's quintic extension");
     const int public_lanes = w.n_public <= 1 ? 1 : (int)w.public_lanes;
     const int alu_lanes = w.n_alu <= 1 ? 1 : (int)w.alu_lanes;
+    // the width-32 permutation: of the width-32 table below, and of the arity-4 MMCS (orc_params.mmcs_arity)
+    if (w.w32_rc && w.w32_diag) p2.w32 = std::make_shared<Poseidon2W32<FP>>(w.w32_rc, w.w32_diag);
     {
       Instance<FP> in;
       in.air.kind = AIR_CONST; in.air.lanes = 1; in.air.D = D; in.air.W = W;

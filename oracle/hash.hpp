@@ -70,7 +70,72 @@ struct Poseidon2W32 {
     }
     for (int r = 0; r < HALF_FULL; ++r) full();
   }
+  // PaddingFreeSponge<Perm32, 32, 24, 8>, overwrite mode: the leaf hash of the arity-4 MMCS
+  // (`MyHashArity4`, recursion/examples/recursive_aggregation.rs:1026-1029; in-circuit restatement
+  // add_hash_base_coeffs_overwrite called from recursion/src/pcs/mmcs.rs:963-985)
+  static constexpr int RATE32 = 24;
+  std::array<F, DIGEST> hash(const std::vector<F>& in) const {
+    std::array<F, WIDTH32> s{};
+    for (size_t i = 0; i < in.size();) {
+      const size_t take = std::min<size_t>(RATE32, in.size() - i);
+      for (size_t j = 0; j < take; ++j) s[j] = in[i + j];
+      permute(s);
+      i += take;
+    }
+    std::array<F, DIGEST> d;
+    std::copy(s.begin(), s.begin() + DIGEST, d.begin());
+    return d;
+  }
+  // TruncatedPermutation<Perm32, 4, 8, 32>: perm(c0 || c1 || c2 || c3)[0..8] (recursion/src/pcs/mmcs.rs:1010-1075: chunk k
+  // spans lanes [8k, 8k + 8))
+  std::array<F, DIGEST> compress4(const std::array<std::array<F, DIGEST>, 4>& c) const {
+    std::array<F, WIDTH32> s;
+    for (int k = 0; k < 4; ++k) std::copy(c[k].begin(), c[k].end(), s.begin() + DIGEST * k);
+    permute(s);
+    std::array<F, DIGEST> d;
+    std::copy(s.begin(), s.begin() + DIGEST, d.begin());
+    return d;
+  }
 };
+
+// Level schedule of an arity-4 Merkle tree over mixed-height matrices (recursion/src/pcs/mmcs.rs:866-960:
+// padded_len, arity4_path_schedule - "matching native arity_schedule").  A level compresses `step` children: 4, or 2
+// (a bridge) when a shorter matrix has to be injected half way to the next quaternary layer; a layer of 2 logical
+// nodes is padded to 4 with zero digests.  `inject_h`: the height of the matrices whose row digests are folded in
+// after the level (0: none).
+struct Arity4Step {
+  int step;
+  size_t logical_next, padded_next, inject_h;
+};
+inline size_t npt(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+inline size_t padded_len(size_t raw, size_t n) { return raw <= 1 ? raw : (raw >= n ? (raw + n - 1) / n * n : n); }
+inline std::vector<Arity4Step> arity4_schedule(std::vector<size_t> heights, size_t num_roots) {
+  std::stable_sort(heights.begin(), heights.end(), [](size_t a, size_t b) { return a > b; });
+  const size_t max_height = heights.at(0), leaf_npt = npt(max_height);
+  size_t at = 0;   // the leaf hash consumes every matrix of the tallest class
+  while (at < heights.size() && npt(heights[at]) == leaf_npt) ++at;
+  std::vector<Arity4Step> steps;
+  size_t curr = padded_len(max_height, 4);
+  while (curr > num_roots) {
+    int step;
+    if (curr < 4) step = 2;
+    else {
+      const size_t target = npt(curr / 4);
+      bool intermediate = false;
+      for (size_t k = at; k < heights.size(); ++k) intermediate |= npt(heights[k]) > target;
+      step = intermediate ? 2 : 4;
+    }
+    const size_t logical_next = curr / step;
+    curr = padded_len(logical_next, 4);
+    size_t inject = 0;
+    if (at < heights.size() && npt(heights[at]) == npt(logical_next)) {
+      inject = heights[at];
+      while (at < heights.size() && heights[at] == inject) ++at;
+    }
+    steps.push_back({step, logical_next, curr, inject});
+  }
+  return steps;
+}
 
 template <class FP>
 struct Poseidon2 {
@@ -265,11 +330,114 @@ struct MerkleTree {
   std::vector<const Matrix<FP>*> mats;  // commit order
   std::vector<std::vector<Digest>> layers;
   int log_max_h = 0, cap_height = 0;
+  int arity = 2;                    // 4: MerkleTreeMmcs<.., 4, 8> over the width-32 permutation
+  std::vector<Arity4Step> sched;    // arity 4: one entry per level
 
   std::vector<Digest> cap() const { return layers.back(); }
 
+  static const Poseidon2W32<FP>& wide(const Poseidon2<FP>& p2) {
+    if (!p2.w32) throw std::runtime_error("the arity-4 MMCS needs the constants of the width-32 permutation");
+    return *p2.w32;
+  }
+  static Digest zero_digest() { Digest d; d.fill(F::zero()); return d; }
+
+  // Arity 4 (recursion/src/pcs/mmcs.rs:866-1316 is the in-tree statement of what such a tree is: leaf = W32 sponge
+  // over the rows of the tallest matrices; a level compresses 4 (or 2, zero-padded to 4) children; an injected
+  // matrix enters as one more compression (node, its row digest, 0, 0); logical layers of 2 are padded to 4).
+  static MerkleTree commit4(const Poseidon2<FP>& p2, const std::vector<const Matrix<FP>*>& mats, int cap_height) {
+    if (cap_height != 0) throw std::runtime_error("arity-4 MMCS: cap_height must be 0");
+    const auto& w = wide(p2);
+    MerkleTree t;
+    t.mats = mats;
+    t.arity = 4;
+    std::vector<size_t> order(mats.size()), heights;
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return mats[a]->h > mats[b]->h; });
+    for (auto* m : mats) heights.push_back(m->h);
+    const size_t hmax = mats[order[0]]->h;
+    t.log_max_h = log2_strict(hmax);
+    t.sched = arity4_schedule(heights, 1);
+    auto rows_at = [&](size_t h, size_t i) {
+      std::vector<F> cat;
+      for (size_t k : order)
+        if (mats[k]->h == h) {
+          auto r = mats[k]->row(i);
+          cat.insert(cat.end(), r.begin(), r.end());
+        }
+      return cat;
+    };
+    std::vector<Digest> cur(padded_len(hmax, 4), zero_digest());
+#pragma omp parallel for schedule(static) if (hmax >= 1024)
+    for (size_t i = 0; i < hmax; ++i) cur[i] = w.hash(rows_at(hmax, i));
+    t.layers.push_back(cur);
+    for (const Arity4Step& st : t.sched) {
+      std::vector<Digest> nxt(st.padded_next, zero_digest());
+#pragma omp parallel for schedule(static) if (st.logical_next >= 1024)
+      for (size_t i = 0; i < st.logical_next; ++i) {
+        std::array<Digest, 4> c{zero_digest(), zero_digest(), zero_digest(), zero_digest()};
+        for (int k = 0; k < st.step; ++k) c[k] = cur[(size_t)st.step * i + k];
+        nxt[i] = w.compress4(c);
+        if (st.inject_h) nxt[i] = w.compress4({nxt[i], w.hash(rows_at(st.inject_h, i)), zero_digest(), zero_digest()});
+      }
+      t.layers.push_back(nxt);
+      cur = nxt;
+    }
+    return t;
+  }
+  // siblings of one level in ascending position, the opened node's own position left out
+  // (`Proof = Vec<[F; 8]>`, grouped per level by set_arity4_opening_private_data, recursion/src/pcs/mmcs.rs:1413-1461)
+  void open4(size_t index, std::vector<std::vector<F>>& opened, std::vector<Digest>& proof) const {
+    opened.clear();
+    proof.clear();
+    for (auto* m : mats) opened.push_back(m->row(index >> (log_max_h - log2_strict(m->h))));
+    size_t idx = index;
+    for (size_t l = 0; l < sched.size(); ++l) {
+      const size_t step = sched[l].step, pos = idx % step, base = idx - pos;
+      for (size_t j = 0; j < step; ++j)
+        if (j != pos) proof.push_back(layers[l][base + j]);
+      idx /= step;
+    }
+  }
+  static bool verify4(const Poseidon2<FP>& p2, const std::vector<Digest>& cap, int cap_height,
+                      const std::vector<std::pair<size_t, size_t>>& dims, size_t index,
+                      const std::vector<std::vector<F>>& opened, const std::vector<Digest>& proof) {
+    if (cap_height != 0 || cap.size() != 1) return false;
+    const auto& w = wide(p2);
+    std::vector<size_t> order(dims.size()), heights;
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dims[a].first > dims[b].first; });
+    for (auto& d : dims) heights.push_back(d.first);
+    const size_t hmax = dims[order[0]].first;
+    if (index >= hmax) return false;
+    const auto sched = arity4_schedule(heights, 1);
+    auto cat_at = [&](size_t h) {
+      std::vector<F> cat;
+      for (size_t k : order)
+        if (dims[k].first == h) {
+          if (opened[k].size() != dims[k].second) throw std::runtime_error("opened width mismatch");
+          cat.insert(cat.end(), opened[k].begin(), opened[k].end());
+        }
+      return cat;
+    };
+    size_t want = 0;
+    for (auto& st : sched) want += st.step - 1;
+    if (proof.size() != want) return false;
+    Digest d = w.hash(cat_at(hmax));
+    size_t idx = index, at = 0;
+    for (auto& st : sched) {
+      const size_t pos = idx % st.step;
+      std::array<Digest, 4> c{zero_digest(), zero_digest(), zero_digest(), zero_digest()};
+      for (size_t j = 0; j < (size_t)st.step; ++j) c[j] = j == pos ? d : proof[at++];
+      d = w.compress4(c);
+      idx /= st.step;
+      if (st.inject_h) d = w.compress4({d, w.hash(cat_at(st.inject_h)), zero_digest(), zero_digest()});
+    }
+    return idx == 0 && cap[0] == d;
+  }
+
   static MerkleTree commit(const Poseidon2<FP>& p2, const std::vector<const Matrix<FP>*>& mats,
-                           int cap_height) {
+                           int cap_height, int arity = 2) {
+    if (arity == 4) return commit4(p2, mats, cap_height);
     MerkleTree t;
     t.mats = mats;
     t.cap_height = cap_height;
@@ -316,6 +484,7 @@ struct MerkleTree {
   // open_batch(index): rows (index >> (log_max_h - log_h)) of every matrix in commit order,
   // sibling digests bottom-up.
   void open(size_t index, std::vector<std::vector<F>>& opened, std::vector<Digest>& proof) const {
+    if (arity == 4) return open4(index, opened, proof);
     opened.clear();
     proof.clear();
     for (auto* m : mats) opened.push_back(m->row(index >> (log_max_h - log2_strict(m->h))));
@@ -326,7 +495,8 @@ struct MerkleTree {
   // commit order.
   static bool verify(const Poseidon2<FP>& p2, const std::vector<Digest>& cap, int cap_height,
                      const std::vector<std::pair<size_t, size_t>>& dims, size_t index,
-                     const std::vector<std::vector<F>>& opened, const std::vector<Digest>& proof) {
+                     const std::vector<std::vector<F>>& opened, const std::vector<Digest>& proof, int arity = 2) {
+    if (arity == 4) return verify4(p2, cap, cap_height, dims, index, opened, proof);
     std::vector<size_t> order(dims.size());
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(),

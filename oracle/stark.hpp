@@ -27,6 +27,7 @@ namespace orc {
 
 struct StarkParams {
   int log_blowup = 2, max_log_arity = 2, cap_height = 0, log_final_poly_len = 5;
+  int mmcs_arity = 2;   // 4: the arity-4 MMCS over the width-32 permutation (MyMmcsArity4, recursive_aggregation.rs:1024-1046)
   int commit_pow_bits = 0, query_pow_bits = 15, num_queries = 54;
   // selectable details the in-tree reference does not pin (twins of p3r_config.ext_choices /
   // fri_log_arities, include/p3r.h)
@@ -276,12 +277,12 @@ struct Committed {
   typename BatchProof<FP>::Cap cap;
 };
 template <class FP>
-Committed<FP> commit_ldes(const Poseidon2<FP>& p2, std::vector<Matrix<FP>> ldes, int cap_height) {
+Committed<FP> commit_ldes(const Poseidon2<FP>& p2, std::vector<Matrix<FP>> ldes, int cap_height, int arity = 2) {
   Committed<FP> c;
   c.ldes = std::move(ldes);
   std::vector<const Matrix<FP>*> ptrs;
   for (auto& m : c.ldes) ptrs.push_back(&m);
-  c.tree = MerkleTree<FP>::commit(p2, ptrs, cap_height);
+  c.tree = MerkleTree<FP>::commit(p2, ptrs, cap_height, arity);
   c.cap = c.tree.cap();
   return c;
 }
@@ -297,7 +298,7 @@ ProverData<FP> make_prover_data(const Poseidon2<FP>& p2, const StarkParams& sp,
                                 const std::vector<Instance<FP>>& insts) {
   std::vector<Matrix<FP>> ldes;
   for (auto& in : insts) ldes.push_back(coset_lde_bitrev<FP>(in.prep, sp.log_blowup, Fe<FP>::generator()));
-  return {commit_ldes<FP>(p2, std::move(ldes), sp.cap_height)};
+  return {commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity)};
 }
 
 // ------------------------------------------------------------------ FRI
@@ -380,7 +381,7 @@ void fri_commit_phase(const Poseidon2<FP>& p2, const StarkParams& sp, std::vecto
         for (int k = 0; k < DC; ++k) leaves.at(r, j * DC + k) = folded[r * arity + j].c[k];
     st.leaves.push_back(leaves);
     std::vector<const Matrix<FP>*> ptr{&st.leaves.back()};
-    st.trees.push_back(MerkleTree<FP>::commit(p2, ptr, sp.cap_height));
+    st.trees.push_back(MerkleTree<FP>::commit(p2, ptr, sp.cap_height, sp.mmcs_arity));
     // the tree keeps a pointer to the matrix: re-point it at the stored copy after push_back moves
     st.log_arities.push_back(la);
     auto cap = st.trees.back().cap();
@@ -455,7 +456,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   // 1. commit main traces (one MMCS over all instances)
   std::vector<Matrix<FP>> main_ldes;
   for (auto& in : insts) main_ldes.push_back(coset_lde_bitrev<FP>(in.main, sp.log_blowup, gen));
-  auto main_c = commit_ldes<FP>(p2, std::move(main_ldes), sp.cap_height);
+  auto main_c = commit_ldes<FP>(p2, std::move(main_ldes), sp.cap_height, sp.mmcs_arity);
   proof.main_commit = main_c.cap;
   // 2. transcript head (batch_stark.rs:521-578)
   ch.observe_base_as_ext(F((uint64_t)ni));
@@ -523,7 +524,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   if (any_lookup) {
     std::vector<Matrix<FP>> ldes;
     for (int i : perm_insts) ldes.push_back(coset_lde_bitrev<FP>(aux[i].flat, sp.log_blowup, gen));
-    perm_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height);
+    perm_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity);
     proof.has_permutation = true;
     proof.permutation_commit = perm_c.cap;
     for (auto& d : perm_c.cap) ch.observe_arr(d);
@@ -599,7 +600,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   std::vector<Matrix<FP>> q_ldes;
   for (size_t k = 0; k < q_chunk_evals.size(); ++k)
     q_ldes.push_back(coset_lde_bitrev<FP>(q_chunk_evals[k], sp.log_blowup, gen * q_chunk_shift[k].inv()));
-  auto quot_c = commit_ldes<FP>(p2, std::move(q_ldes), sp.cap_height);
+  auto quot_c = commit_ldes<FP>(p2, std::move(q_ldes), sp.cap_height, sp.mmcs_arity);
   proof.quotient_commit = quot_c.cap;
   for (auto& d : quot_c.cap) ch.observe_arr(d);
   EF zeta = ch.sample_ext();
@@ -841,7 +842,7 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
         dims.emplace_back(size_t(1) << (rd.mats[m].log_h + sp.log_blowup), bo.opened_values[m].size());
       }
       size_t ridx = index >> (log_max - batch_max);
-      if (!MerkleTree<FP>::verify(p2, *rd.cap, sp.cap_height, dims, ridx, bo.opened_values, bo.opening_proof))
+      if (!MerkleTree<FP>::verify(p2, *rd.cap, sp.cap_height, dims, ridx, bo.opened_values, bo.opening_proof, sp.mmcs_arity))
         fail("input MMCS opening");
       for (size_t m = 0; m < rd.mats.size(); ++m) {
         int lh = rd.mats[m].log_h + sp.log_blowup;
@@ -878,7 +879,7 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
       std::vector<F> flat;
       for (auto& e : evals) for (int k = 0; k < EF::deg(); ++k) flat.push_back(e.c[k]);
       std::vector<std::pair<size_t, size_t>> dims{{size_t(1) << (log_cur - la), arity * (size_t)EF::deg()}};
-      if (!MerkleTree<FP>::verify(p2, fp.commit_phase_commits[p], sp.cap_height, dims, row, {flat}, step.opening_proof))
+      if (!MerkleTree<FP>::verify(p2, fp.commit_phase_commits[p], sp.cap_height, dims, row, {flat}, step.opening_proof, sp.mmcs_arity))
         fail("commit-phase MMCS opening");
       folded = fold_row<FP>(evals, row, log_cur - la, la, betas[p]);
       log_cur -= la;

@@ -33,14 +33,17 @@ class OrcParams(C.Structure):
                                           "commit_pow_bits", "query_pow_bits", "num_queries", "ext_choices",
                                           "n_fri_log_arities")] + [("fri_log_arities", C.c_uint8 * 32),
                                                                    ("proof_layout", C.c_uint8 * 18),
-                                                                   ("challenge_degree", C.c_uint32)]
+                                                                   ("challenge_degree", C.c_uint32),
+                                                                   ("mmcs_arity", C.c_uint32)]
 
 
 def params(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0,
-           query_pow_bits=15, num_queries=54, ext_choices=0, fri_log_arities=None, proof_layout=None, challenge_degree=4):
+           query_pow_bits=15, num_queries=54, ext_choices=0, fri_log_arities=None, proof_layout=None, challenge_degree=4,
+           mmcs_arity=2):
     p = OrcParams(log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits,
                   num_queries, ext_choices, 0)
     p.challenge_degree = challenge_degree
+    p.mmcs_arity = mmcs_arity   # 4: the arity-4 MMCS over the width-32 permutation
     if fri_log_arities is not None:
         p.n_fri_log_arities = len(fri_log_arities)
         for i, la in enumerate(fri_log_arities):
@@ -78,13 +81,14 @@ def fill_workload(wl_struct, arrays, packing, keep):
     wl_struct.ext_w = packing.get("ext_w", 0)
     if "p2_absorb_len" in arrays and len(arrays["p2_absorb_len"]):
         wl_struct.p2_absorb_len = ptr("p2_absorb_len")
+    # the constants of the width-32 permutation: its table's (below) and the arity-4 MMCS's (params(mmcs_arity=4))
+    w32 = packing.get("w32") or oracle_lib.default_w32(packing["field"])
+    keep.extend(w32)
+    wl_struct.w32_rc, wl_struct.w32_diag = w32[0].ctypes.data_as(u32p), w32[1].ctypes.data_as(u32p)
     if len(c) > 7 and int(c[7]):   # rows of the width-32 Poseidon2 table (harness flag P2_W32)
         wl_struct.n_p2w = int(c[7])
         for name in ("p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep"):
             setattr(wl_struct, name, ptr(name))
-        w32 = oracle_lib.default_w32(packing["field"])
-        keep.extend(w32)
-        wl_struct.w32_rc, wl_struct.w32_diag = w32[0].ctypes.data_as(u32p), w32[1].ctypes.data_as(u32p)
     # a layer with both Recompose tables (harness flag RECOMPOSE_BOTH): the second one is `recompose/coeff`
     if len(c) > 6 and int(c[6]):
         wl_struct.n_recompose_coeff = int(c[6])

@@ -98,6 +98,50 @@ class Oracle:
                                           cap.ctypes.data_as(u32p), C.byref(tree)))
         return cap, OracleTree(self, tree, arrs, cap_height)
 
+    # ---- arity-4 MMCS over the width-32 permutation (oracle/hash.hpp: MerkleTree::commit4 / open4 / verify4)
+    def commit4(self, field, mats, rc=None, w32=None):
+        rc = default_rc(field) if rc is None else rc
+        w32 = default_w32(field) if w32 is None else w32
+        arrs = [np.ascontiguousarray(m, dtype=np.uint32) for m in mats]
+        n = len(arrs)
+        vals = (u32p * n)(*[a.ctypes.data_as(u32p) for a in arrs])
+        hs = (C.c_size_t * n)(*[a.shape[0] for a in arrs])
+        ws = (C.c_size_t * n)(*[a.shape[1] for a in arrs])
+        cap = np.empty((1, 8), dtype=np.uint32)
+        tree, plen = C.c_void_p(), C.c_size_t()
+        r, rp = _u32(rc)
+        self._ck(self.lib.orc_mmcs_commit4(FIELD_IDS[field], rp, w32[0].ctypes.data_as(u32p), w32[1].ctypes.data_as(u32p),
+                                           C.c_size_t(n), vals, hs, ws, cap.ctypes.data_as(u32p), C.byref(plen), C.byref(tree)))
+        t = OracleTree(self, tree, arrs, 0)
+        t.proof_len = plen.value
+        return cap, t
+
+    def verify4(self, field, cap, dims, index, opened, proof, rc=None, w32=None):
+        rc = default_rc(field) if rc is None else rc
+        w32 = default_w32(field) if w32 is None else w32
+        n = len(dims)
+        hs = (C.c_size_t * n)(*[d[0] for d in dims])
+        ws = (C.c_size_t * n)(*[d[1] for d in dims])
+        c, cp = _u32(cap)
+        o, op = _u32(opened)
+        pf, pp = _u32(np.asarray(proof, dtype=np.uint32).reshape(-1, 8))
+        r, rp = _u32(rc)
+        ok = C.c_int()
+        self._ck(self.lib.orc_mmcs_verify4(FIELD_IDS[field], rp, w32[0].ctypes.data_as(u32p), w32[1].ctypes.data_as(u32p), cp,
+                                           C.c_size_t(n), hs, ws, C.c_size_t(index), op, pp, C.c_size_t(pf.shape[0]),
+                                           C.byref(ok)))
+        return bool(ok.value)
+
+    def schedule4(self, heights):
+        """[(step, height of the matrices injected after the level or 0)] of an arity-4 tree over `heights`."""
+        n = len(heights)
+        hs = (C.c_size_t * n)(*heights)
+        steps = (C.c_uint32 * 64)()
+        inj = (C.c_size_t * 64)()
+        nl = C.c_size_t()
+        self._ck(self.lib.orc_mmcs_schedule4(C.c_size_t(n), hs, steps, inj, C.c_size_t(64), C.byref(nl)))
+        return [(int(steps[i]), int(inj[i])) for i in range(nl.value)]
+
     def verify(self, field, cap, dims, index, opened, proof, rc=None):
         rc = default_rc(field) if rc is None else rc
         n = len(dims)
@@ -141,7 +185,7 @@ class OracleTree:
     def open(self, index):
         w = sum(a.shape[1] for a in self.arrs)
         opened = np.empty(w, dtype=np.uint32)
-        proof = np.empty((self.log_max_h - self.cap_height, 8), dtype=np.uint32)
+        proof = np.empty((getattr(self, "proof_len", self.log_max_h - self.cap_height), 8), dtype=np.uint32)
         self.orc._ck(self.orc.lib.orc_mmcs_open(self.h, C.c_size_t(index), opened.ctypes.data_as(u32p),
                                                 proof.ctypes.data_as(u32p)))
         return opened, proof
