@@ -1178,6 +1178,44 @@ def main():
             resw.free()
             cpdw.free()
             ctxw.close()
+            # SURVEY 8(f).4, arity-4: the headline layer proved under the prover's OWN arity-4 MMCS (p3r_config.mmcs_arity = 4:
+            # MyMmcsArity4 of `recursive_aggregation --arity4` - width-32 sponge leaves of rate 24, 4-to-1 levels, W16
+            # challenger): same circuit, same inputs, same FRI parameters as the headline; prove_next_layer with a cache
+            arrs4 = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN_KNOBS)
+            ctx4 = p3r.Context(field=field, mmcs_arity=4, **FRI)
+            pc4 = p3r.PreparedCircuit(ctx4, wl.circuit_from_arrays(arrs4), packing)
+            rin4 = pc4.upload_inputs(wl.circuit_inputs_from_arrays(arrs4))
+            del arrs4
+            raw4 = pc4.prove(rin4)
+            ctx4.sync()
+            t4 = time.perf_counter()
+            for _ in range(5):
+                pc4.prove(rin4)
+            ctx4.sync()
+            ms4 = (time.perf_counter() - t4) / 5 * 1e3
+            try:
+                prover4 = p3r.BatchStarkProver(ctx4)
+                prover4.verify_all_tables(prover4.wrap_proof(raw4, pc4.circuit_prover_data))
+                ok4 = True
+            except Exception as e:
+                print(f"bench: arity-4 MMCS layer: proof rejected: {e}", file=sys.stderr)
+                ok4 = False
+            ctx4.profile_enable(True)
+            pc4.prove(rin4)
+            prof4 = ctx4.profile_read()
+            ctx4.profile_enable(False)
+            line["arity4_mmcs_layer"] = {
+                "ms_per_step": ms4, "steps": 5, "proof_verified": ok4, "proof_bytes": len(raw4),
+                "kernel_ms": {k: v[0] for k, v in prof4.items() if not k.startswith("stage:")},
+                "constants": "self-generated defaults (p3r_config.poseidon2_w32_rc / _diag = NULL): unpinned",
+                "workload": f"the headline prove_next_layer (same circuit, inputs, tables and FRI parameters) with every commitment - "
+                            f"traces, LogUp columns, quotient chunks, FRI commit phases - under the arity-4 MMCS over the width-32 "
+                            f"permutation; challenger on the width-16 permutation"}
+            proof_verified = proof_verified and ok4
+            line["proof_verified"] = proof_verified
+            rin4.free()
+            pc4.free()
+            ctx4.close()
         print(json.dumps(line))
     if resident is not None:
         resident.free()

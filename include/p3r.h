@@ -124,6 +124,14 @@ typedef struct p3r_config {
   const uint32_t* poseidon2_w32_rc;
   uint32_t poseidon2_w32_rc_len;
   const uint32_t* poseidon2_w32_diag;   /* 32 canonical values, or NULL */
+  /* ABI version 6.  Arity of the prover's own MMCS: 0 / 2 = binary trees over the width-16 permutation
+   * (PaddingFreeSponge<Perm16, 16, 8, 8>, TruncatedPermutation<Perm16, 2, 8, 16>: every BASELINE configuration);
+   * 4 = the arity-4 MMCS of `recursive_aggregation --arity4` (recursion/examples/recursive_aggregation.rs:1024-1046:
+   * MerkleTreeMmcs<.., 4, 8> with PaddingFreeSponge<Perm32, 32, 24, 8> leaves and TruncatedPermutation<Perm32, 4, 8, 32>
+   * levels over the width-32 permutation above; the challenger keeps the width-16 permutation).  Trace, quotient and
+   * FRI commit-phase trees, their opening proofs (step - 1 sibling digests per level, recursion/src/pcs/mmcs.rs:
+   * 866-1316) and both verifiers follow.  cap_height must be 0 with arity 4. */
+  uint32_t mmcs_arity;
 } p3r_config;
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
@@ -238,9 +246,19 @@ int p3r_mmcs_commit_dmat(p3r_ctx* ctx, const p3r_dmat* const* mats, size_t n_mat
 /* Mmcs::open_batch(index): writes, for each committed matrix in commit order, its row
  * (index >> (log_max_height - log_height)) into opened_values (concatenated, sum of widths
  * elements), and the sibling digests bottom-up into proof_out
- * ((log_max_height - cap_height) x 8 elements). */
+ * (p3r_tree_proof_len(tree) x 8 elements: log_max_height - cap_height digests for a binary tree; for an arity-4 tree
+ * step - 1 digests per level in ascending position, the opened node's own left out). */
 int p3r_mmcs_open(p3r_ctx* ctx, const p3r_tree* tree, size_t index, uint32_t* opened_values,
                   uint32_t* proof_out);
+/* Digests of one opening proof of this tree (`Mmcs::Proof = Vec<[F; 8]>`). */
+size_t p3r_tree_proof_len(const p3r_tree* tree);
+/* Mmcs::verify_batch on the host, no context: heights / widths of the committed matrices in commit order, the opened
+ * rows concatenated in that order, `proof` = proof_len digests.  Honours cfg->mmcs_arity (and, for arity 4, the
+ * width-32 constants of cfg).  Returns P3R_OK when the opening is accepted, P3R_EINVAL with the reason in err_buf
+ * otherwise. */
+int p3r_mmcs_verify(const p3r_config* cfg, const uint32_t* cap, size_t n_mats, const size_t* heights, const size_t* widths,
+                    size_t index, const uint32_t* opened_values, const uint32_t* proof, size_t proof_len, char* err_buf,
+                    size_t err_cap);
 size_t p3r_tree_log_max_height(const p3r_tree* tree);
 size_t p3r_tree_total_width(const p3r_tree* tree);
 void p3r_tree_free(p3r_ctx* ctx, p3r_tree* tree);

@@ -41,6 +41,9 @@ inline uint32_t binomial_w(Field f) { return f == Field::KoalaBear ? 3u : 11u; }
 struct FriParams {
   uint32_t log_blowup = 2, max_log_arity = 2, cap_height = 0, log_final_poly_len = 5, commit_pow_bits = 0,
            query_pow_bits = 15, num_queries = 54;
+  // arity of the PCS's MMCS: 2 = MyMmcs (width-16 permutation), 4 = MyMmcsArity4 (width-32 permutation, W16 challenger:
+  // recursion/examples/recursive_aggregation.rs:902-1046; cap_height must be 0)
+  uint32_t mmcs_arity = 2;
 };
 
 // ext_degree: the circuit extension degree of the traces - 4, or 5 for KoalaBear circuits over the quintic trinomial
@@ -57,6 +60,7 @@ inline p3r_config make_config(Field field, const FriParams& p, int device = 0, c
   c.log_blowup = p.log_blowup; c.max_log_arity = p.max_log_arity; c.cap_height = p.cap_height;
   c.log_final_poly_len = p.log_final_poly_len; c.commit_pow_bits = p.commit_pow_bits;
   c.query_pow_bits = p.query_pow_bits; c.num_queries = p.num_queries;
+  c.mmcs_arity = p.mmcs_arity;
   c.device = device;
   if (rc) { c.poseidon2_rc = rc->data(); c.poseidon2_rc_len = (uint32_t)rc->size(); }
   return c;

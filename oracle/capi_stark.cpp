@@ -381,6 +381,7 @@ int orc_verify_batch_w32(int field, const uint32_t* rc, const uint32_t* w32_rc, 
         a.kind = (int)airs4[4 * i]; a.lanes = (int)airs4[4 * i + 1]; a.horner_k = (int)airs4[4 * i + 2];
         a.coeff_lookups = (int)(airs4[4 * i + 3] & 0xFF);
         a.D = ((airs4[4 * i + 3] >> 8) & 0xFF) ? (int)((airs4[4 * i + 3] >> 8) & 0xFF) : 4;
+        a.W = a.D == 2 || a.D == 6 || a.D == 8 ? airs4[4 * i + 3] >> 16 : 0;
         shapes.push_back({a});
       }
       typename BatchProof<FP>::Cap cap(size_t(1) << p->cap_height);

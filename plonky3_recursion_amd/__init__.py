@@ -4,7 +4,7 @@ Host-side mirror of the reference's interface for this path over the C ABI in in
 The HIP library is mandatory: importing the package is cheap, but any compute entry point
 raises if `libp3r_hip.so` has not been built (no CPU fallback).
 """
-from .device import Context, DeviceMatrix, MerkleTree, P3rError, make_config, verify_batch  # noqa: F401
+from .device import Context, DeviceMatrix, MerkleTree, P3rError, make_config, mmcs_verify, verify_batch  # noqa: F401
 from .prover import (AggregationCircuitFingerprint, AggregationPrepCache, BatchStarkProof, BatchStarkProver, Circuit, CircuitInputs, CircuitPrep,  # noqa: F401
                      CircuitProverData, CircuitRunner, PreparedCircuit, FriRecursionBackend, FriRecursionBackendD5, FriRecursionConfig, NextLayerPrepCache, ProveNextLayerParams,
                      RecursionInput, RecursionOutput, ResidentTraces, TablePacking, Traces,

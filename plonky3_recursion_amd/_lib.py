@@ -38,6 +38,7 @@ class P3rConfig(C.Structure):
         # ABI 6: constants of the width-32 permutation (NULL = the self-generated defaults)
         ("poseidon2_w32_rc", C.POINTER(C.c_uint32)), ("poseidon2_w32_rc_len", C.c_uint32),
         ("poseidon2_w32_diag", C.POINTER(C.c_uint32)),
+        ("mmcs_arity", C.c_uint32),   # 0 / 2: binary MMCS over the width-16 permutation; 4: the arity-4 MMCS (width 32)
     ]
 
 
@@ -193,6 +194,9 @@ SIGNATURES = {
     "p3r_mmcs_open": (C.c_int, [vp, vp, C.c_size_t, u32p, u32p]),
     "p3r_tree_log_max_height": (C.c_size_t, [vp]),
     "p3r_tree_total_width": (C.c_size_t, [vp]),
+    "p3r_tree_proof_len": (C.c_size_t, [vp]),
+    "p3r_mmcs_verify": (C.c_int, [C.POINTER(P3rConfig), u32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t,
+                                  u32p, u32p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "p3r_tree_free": (None, [vp, vp]),
     "p3r_prep_create": (vp, [vp, C.POINTER(P3rAirDesc), C.POINTER(P3rMatrix), C.c_size_t, u32p]),
     "p3r_prep_free": (None, [vp, vp]),

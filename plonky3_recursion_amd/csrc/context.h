@@ -24,6 +24,7 @@
 #include "field.h"
 #include "poseidon2.h"
 #include "proof_layout.h"
+#include "mmcs4.h"
 
 namespace p3r {
 
@@ -399,6 +400,11 @@ struct p3r_tree {
   size_t total_width = 0;
   // layers[l]: digests of layer l (layer 0 = leaves), SoA [8][n_l], n_l = 2^(log_max_h - l)
   std::vector<p3r::DevBuf> layers;
+  // arity-4 MMCS (p3r_config.mmcs_arity = 4; mmcs4.h): levels[l] produces layers[l + 1]; n_l = layer_n[l] (a layer
+  // of 2 is padded to 4 with zero digests).  Empty for the binary tree.
+  int arity = 2;
+  std::vector<p3r::Mmcs4Level> levels;
+  std::vector<size_t> layer_n;
 };
 
 namespace p3r {
@@ -423,6 +429,9 @@ struct p3r_ctx {
   p3r::DevBuf rc;  // Poseidon2 constants, Montgomery
   p3r::DevBuf rc_f64;  // the same constants as canonical doubles (poseidon2_f64.hip.h)
   const double* rcd() const { return reinterpret_cast<const double*>(rc_f64.p); }
+  // the FP64 table of the width-32 permutation (poseidon2_w32_f64.hip.h), after the width-16 constants
+  size_t rcd_w32_at = 0;
+  const double* rcd_w32() const { return rcd() + rcd_w32_at; }
   p3r::DevBuf p2_diag;  // internal-layer diagonal, Montgomery (lane-cooperative kernels)
   std::vector<uint32_t> rc_canonical;
   std::vector<uint8_t> fri_log_arities;  // copy of p3r_config.fri_log_arities (empty: the rule)

@@ -290,11 +290,78 @@ size_t mmcs_subtree(p3r_ctx* ctx, p3r_tree* tree, size_t n, const std::map<size_
   return nn;
 }
 
+// The levels of an arity-4 tree above its leaf-digest layer (tree->layers[0], tree->levels set): one launch each.
+// `inject`: height -> row digests of the matrices of that height (null: none, the FRI commit-phase trees).
+template <class PP>
+void mmcs4_build_levels(p3r_ctx* ctx, p3r_tree* tree, const std::map<size_t, DevBuf>* inject) {
+  for (const Mmcs4Level& lv : tree->levels) {
+    DevBuf next(P2_DIGEST * lv.padded_next);
+    const uint32_t* inj = nullptr;
+    if (lv.inject_h) {
+      auto it = inject ? inject->find(lv.inject_h) : decltype(inject->end()){};
+      if (!inject || it == inject->end() || lv.inject_h != lv.logical_next)
+        fail(P3R_EINVAL, "arity-4 MMCS: matrix heights must be powers of two");
+      inj = it->second.p;
+    }
+    mmcs4_compress<PP>(ctx, tree->layers.back().p, tree->layer_n.back(), lv.step, inj, next.p, lv.logical_next, lv.padded_next);
+    tree->layers.push_back(std::move(next));
+    tree->layer_n.push_back(lv.padded_next);
+  }
+}
+
+// The arity-4 tree (mmcs4.h; kernels_mmcs4.hip.h): leaf digests of every height class in one launch, then one launch
+// per level.  tree->layers[l] is [8][tree->layer_n[l]].
+template <class PP>
+void mmcs_commit4(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
+  using F = Fp<PP>;
+  const auto& mats = tree->mats;
+  std::vector<size_t> heights, class_h;
+  for (auto* m : mats) heights.push_back(m->h);
+  std::vector<size_t> order(mats.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return mats[a]->h > mats[b]->h; });
+  const size_t hmax = mats[order[0]]->h;
+  tree->arity = 4;
+  tree->log_max_h = log2_exact(hmax, "matrix height");
+  tree->cap_height = 0;
+  tree->total_width = 0;
+  for (auto* m : mats) tree->total_width += m->w;
+  tree->levels = mmcs4_schedule(heights);
+  for (size_t i : order)
+    if (class_h.empty() || class_h.back() != mats[i]->h) class_h.push_back(mats[i]->h);
+  tree->layers.clear();
+  tree->layer_n.clear();
+  const size_t n0 = mmcs4_padded_len(hmax);
+  tree->layers.emplace_back(P2_DIGEST * n0);
+  tree->layer_n.push_back(n0);
+  if (n0 != hmax) P3R_HIP(hipMemsetAsync(tree->layers[0].p, 0, P2_DIGEST * n0 * 4, ctx->stream));
+  std::map<size_t, DevBuf> inject;
+  {
+    std::vector<std::vector<const p3r_dmat*>> classes;
+    std::vector<uint32_t*> digs;
+    std::vector<size_t> allocs;
+    for (size_t h : class_h) {
+      std::vector<const p3r_dmat*> v;
+      for (size_t i : order)
+        if (mats[i]->h == h) v.push_back(mats[i]);
+      classes.push_back(std::move(v));
+      if (h == hmax) { digs.push_back(tree->layers[0].p); allocs.push_back(n0); }
+      else { digs.push_back(inject.emplace(h, DevBuf(P2_DIGEST * h)).first->second.p); allocs.push_back(h); }
+    }
+    mmcs4_hash_rows<PP>(ctx, classes, digs, allocs);
+  }
+  mmcs4_build_levels<PP>(ctx, tree, &inject);
+  uint32_t root[P2_DIGEST];
+  P3R_HIP(fetch_small(ctx, tree->layers.back().p, P2_DIGEST, root));
+  for (int k = 0; k < P2_DIGEST; ++k) cap_out[k] = F::raw(root[k]).to_canonical();
+}
+
 template <class PP>
 void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   using F = Fp<PP>;
   const auto& mats = tree->mats;
   if (mats.empty()) fail(P3R_EINVAL, "MMCS commit needs at least one matrix");
+  if (ctx->cfg.mmcs_arity == 4) return mmcs_commit4<PP>(ctx, tree, cap_out);
   // tallest first, stable (recursion/src/pcs/mmcs.rs:355-425)
   std::vector<size_t> order(mats.size());
   std::iota(order.begin(), order.end(), 0);
@@ -369,16 +436,30 @@ void mmcs_open(p3r_ctx* ctx, const p3r_tree* tree, size_t index, uint32_t* opene
                              ctx->stream));
     off += m->w;
   }
-  const int depth = tree->log_max_h - tree->cap_height;
-  for (int l = 0; l < depth; ++l) {
-    size_t n = size_t(1) << (tree->log_max_h - l);
-    size_t sib = (index >> l) ^ 1;
-    P3R_HIP(hipMemcpy2DAsync(proof + (size_t)l * P2_DIGEST, 4, tree->layers[l].p + sib, n * 4, 4,
-                             P2_DIGEST, hipMemcpyDeviceToHost, ctx->stream));
+  size_t depth = (size_t)(tree->log_max_h - tree->cap_height);
+  if (tree->arity == 4) {
+    // step - 1 siblings per level, ascending position, the node's own left out (recursion/src/pcs/mmcs.rs:1413-1461)
+    depth = 0;
+    for (size_t l = 0; l < tree->levels.size(); ++l) {
+      const size_t step = tree->levels[l].step, idx = index >> tree->levels[l].bits, pos = idx & (step - 1);
+      for (size_t j = 0; j < step; ++j) {
+        if (j == pos) continue;
+        P3R_HIP(hipMemcpy2DAsync(proof + depth * P2_DIGEST, 4, tree->layers[l].p + (idx - pos + j), tree->layer_n[l] * 4, 4,
+                                 P2_DIGEST, hipMemcpyDeviceToHost, ctx->stream));
+        ++depth;
+      }
+    }
+  } else {
+    for (size_t l = 0; l < depth; ++l) {
+      size_t n = size_t(1) << (tree->log_max_h - l);
+      size_t sib = (index >> l) ^ 1;
+      P3R_HIP(hipMemcpy2DAsync(proof + l * P2_DIGEST, 4, tree->layers[l].p + sib, n * 4, 4,
+                               P2_DIGEST, hipMemcpyDeviceToHost, ctx->stream));
+    }
   }
   P3R_HIP(hipStreamSynchronize(ctx->stream));
   for (size_t i = 0; i < off; ++i) opened[i] = F::raw(opened[i]).to_canonical();
-  for (size_t i = 0; i < (size_t)depth * P2_DIGEST; ++i) proof[i] = F::raw(proof[i]).to_canonical();
+  for (size_t i = 0; i < depth * P2_DIGEST; ++i) proof[i] = F::raw(proof[i]).to_canonical();
 }
 
 // The permutation constants of a configuration, canonical: the width-16 round constants, then the width-32 table
@@ -417,9 +498,23 @@ void init_ctx(p3r_ctx* ctx) {
   ctx->rc_mont_host = mont;
   ctx->rc.alloc(mont.size());
   P3R_HIP(copy_sync(ctx->stream, ctx->rc.p, mont.data(), mont.size() * 4, hipMemcpyHostToDevice));
+  // FP64 tables: the width-16 round constants, then the width-32 table of poseidon2_w32_f64.hip.h (round constants |
+  // the diagonal as centred integers | diagonal / P)
   std::vector<double> rcd(src, src + nrc);
-  ctx->rc_f64.alloc(2 * nrc);
-  P3R_HIP(copy_sync(ctx->stream, ctx->rc_f64.p, rcd.data(), nrc * 8, hipMemcpyHostToDevice));
+  ctx->rcd_w32_at = nrc;
+  {
+    const size_t nrcw = p2w_num_rc<PP>();
+    const uint32_t* w = src + nrc;
+    rcd.insert(rcd.end(), w, w + nrcw);
+    for (int pass = 0; pass < 2; ++pass)
+      for (int i = 0; i < P2W_WIDTH; ++i) {
+        const uint32_t d = w[nrcw + i];
+        const double centred = d > PP::P / 2 ? (double)d - (double)PP::P : (double)d;
+        rcd.push_back(pass == 0 ? centred : centred / (double)PP::P);
+      }
+  }
+  ctx->rc_f64.alloc(2 * rcd.size());
+  P3R_HIP(copy_sync(ctx->stream, ctx->rc_f64.p, rcd.data(), rcd.size() * 8, hipMemcpyHostToDevice));
   {
     auto inv2k = [](int k) { return F::from_u64(uint64_t(1) << k).inv(); };
     const F two = F::from_canonical(2), three = F::from_canonical(3), four = F::from_canonical(4);
@@ -467,6 +562,11 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
       fail(P3R_EUNSUPPORTED, "unsupported field id %u", cfg->field);
     // circuit extension degree: 4 (binomial) on both fields; 5 = the KoalaBear quintic trinomial extension, proved
     // under the same D = 4 STARK configuration (batch_stark_prover/tests.rs:844-1029), primitive tables only
+    if (cfg->mmcs_arity != 0 && cfg->mmcs_arity != 2 && cfg->mmcs_arity != 4)
+      fail(P3R_EINVAL, "mmcs_arity must be 2 or 4 (got %u)", cfg->mmcs_arity);
+    // the cap of an arity-4 tree strips whole compression steps (recursion/src/pcs/mmcs.rs:1143-1156); the reference's
+    // arity-4 configurations run with the default cap_height 0 (recursive_aggregation.rs:77), and only that is built
+    if (cfg->mmcs_arity == 4 && cfg->cap_height != 0) fail(P3R_EUNSUPPORTED, "arity-4 MMCS: cap_height must be 0");
     if (cfg->challenge_degree != 0 && cfg->challenge_degree != 4 &&
         !(cfg->challenge_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR))
       fail(P3R_EUNSUPPORTED, "UnsupportedChallengeDegree(%u): 4, or 5 over KoalaBear", cfg->challenge_degree);
@@ -735,6 +835,58 @@ int p3r_mmcs_open(p3r_ctx* ctx, const p3r_tree* tree, size_t index, uint32_t* op
 }
 size_t p3r_tree_log_max_height(const p3r_tree* t) { return (size_t)t->log_max_h; }
 size_t p3r_tree_total_width(const p3r_tree* t) { return t->total_width; }
+size_t p3r_tree_proof_len(const p3r_tree* t) {
+  return t->arity == 4 ? p3r::mmcs4_proof_len(t->levels) : (size_t)(t->log_max_h - t->cap_height);
+}
+int p3r_mmcs_verify(const p3r_config* cfg, const uint32_t* cap, size_t n_mats, const size_t* heights, const size_t* widths,
+                    size_t index, const uint32_t* opened_values, const uint32_t* proof, size_t proof_len, char* err_buf,
+                    size_t err_cap) {
+  auto report = [&](const char* msg) {
+    if (err_buf && err_cap) snprintf(err_buf, err_cap, "%s", msg);
+  };
+  try {
+    if (!cfg || !cap || !heights || !widths || !opened_values || (!proof && proof_len) || !n_mats) { report("NULL argument"); return P3R_EINVAL; }
+    if (cfg->abi_version != P3R_ABI_VERSION) { report("ABI version mismatch"); return P3R_EINVAL; }
+    if (cfg->mmcs_arity == 4 && cfg->cap_height != 0) { report("arity-4 MMCS: cap_height must be 0"); return P3R_EUNSUPPORTED; }
+    auto run = [&](auto tag) {
+      using PP = decltype(tag);
+      using F = p3r::Fp<PP>;
+      using Digest = std::array<F, P2_DIGEST>;
+      const std::vector<uint32_t> table = constants_table<PP>(*cfg, [](const char* what, uint32_t got, size_t want) {
+        p3r::vfail("%s is %u, the field needs %zu constants", what, got, want);
+      });
+      std::vector<uint32_t> rc(table.size());
+      for (size_t i = 0; i < rc.size(); ++i) rc[i] = F::from_canonical(table[i]).v;
+      auto fe = [](uint32_t v) {
+        if (v >= PP::P) p3r::vfail("non-canonical field element");
+        return F::from_canonical(v);
+      };
+      std::vector<Digest> capd(size_t(1) << cfg->cap_height), path(proof_len);
+      for (auto& d : capd) for (auto& x : d) x = fe(*cap++);
+      const uint32_t* pf = proof;
+      for (auto& d : path) for (auto& x : d) x = fe(*pf++);
+      std::vector<int> lhs;
+      std::vector<std::vector<F>> rows;
+      const uint32_t* ov = opened_values;
+      for (size_t m = 0; m < n_mats; ++m) {
+        if (!heights[m] || (heights[m] & (heights[m] - 1))) p3r::vfail("matrix heights must be powers of two");
+        lhs.push_back(p3r::log2_exact(heights[m], "matrix height"));
+        std::vector<F> r(widths[m]);
+        for (auto& x : r) x = fe(*ov++);
+        rows.push_back(std::move(r));
+      }
+      if (cfg->mmcs_arity == 4) p3r::mmcs_verify4<PP>(capd, (int)cfg->cap_height, lhs, rows, index, path, rc.data() + p3r::p2_num_constants<PP>(), "opening");
+      else p3r::mmcs_verify<PP>(capd, (int)cfg->cap_height, lhs, rows, index, path, rc.data(), "opening");
+    };
+    if (cfg->field == P3R_FIELD_KOALA_BEAR) run(p3r::KoalaBearParams{});
+    else if (cfg->field == P3R_FIELD_BABY_BEAR) run(p3r::BabyBearParams{});
+    else { report("unknown field"); return P3R_EINVAL; }
+    return P3R_OK;
+  } catch (const std::exception& e) {
+    report(e.what());
+    return P3R_EINVAL;
+  }
+}
 void p3r_tree_free(p3r_ctx* ctx, p3r_tree* tree) {
   if (ctx) (void)hipStreamSynchronize(ctx->stream);
   delete tree;
@@ -915,6 +1067,9 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     p3r::VerifyParams prm{(int)cfg->log_blowup, (int)cfg->max_log_arity, (int)cfg->cap_height, (int)cfg->log_final_poly_len,
                           (int)cfg->commit_pow_bits, (int)cfg->query_pow_bits, (int)cfg->num_queries, {}};
     if (cfg->fri_log_arities) prm.fri_log_arities.assign(cfg->fri_log_arities, cfg->fri_log_arities + cfg->fri_log_arities_len);
+    if (cfg->mmcs_arity != 0 && cfg->mmcs_arity != 2 && cfg->mmcs_arity != 4) { report("mmcs_arity must be 2 or 4"); return P3R_EINVAL; }
+    if (cfg->mmcs_arity == 4 && cfg->cap_height != 0) { report("arity-4 MMCS: cap_height must be 0"); return P3R_EUNSUPPORTED; }
+    prm.mmcs_arity = cfg->mmcs_arity == 4 ? 4 : 2;
     if (!prm.layout.set(cfg->proof_layout, cfg->proof_layout_len)) { report("proof_layout must be 18 bytes: three permutations"); return P3R_EINVAL; }
     std::vector<p3r::AirParams> a(n_airs);
     for (size_t i = 0; i < n_airs; ++i) {

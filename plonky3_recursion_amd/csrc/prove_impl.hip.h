@@ -619,13 +619,22 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     if (ph.tree->cap_height > ph.tree->log_max_h)
       fail(P3R_EINVAL, "cap_height %d exceeds the height of FRI commit phase %zu (2^%d rows)", ph.tree->cap_height,
            phases.size(), ph.tree->log_max_h);
-    ph.tree->layers.emplace_back(P2_DIGEST * rows);
+    const bool arity4 = cfg.mmcs_arity == 4;
+    const size_t n_leaf = arity4 ? mmcs4_padded_len(rows) : rows;
+    ph.tree->layers.emplace_back(P2_DIGEST * n_leaf);
     {
       std::vector<const uint32_t*> cols;
       for (size_t j = 0; j < arity; ++j)
         for (int k = 0; k < DC; ++k) cols.push_back(folded.p + (size_t)k * n_in + j);
       const uint32_t* const* dcols = col_table(ctx, cols);
-      {
+      if (arity4) {
+        // ExtensionMmcs over the arity-4 MMCS: the same flattened rows under the width-32 sponge
+        ph.tree->arity = 4;
+        ph.tree->levels = mmcs4_schedule({rows});
+        ph.tree->layer_n.assign(1, n_leaf);
+        if (n_leaf != rows) P3R_HIP(hipMemsetAsync(ph.tree->layers[0].p, 0, P2_DIGEST * n_leaf * 4, ctx->stream));
+        mmcs4_hash_rows_strided<PP>(ctx, dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p, n_leaf);
+      } else {
         ProfScope ps(ctx, "mmcs_hash_rows_strided");
         if (rows <= coop_max_leaf_rows())  // latency-bound: sixteen lanes per row
           hipLaunchKernelGGL(k_mmcs_hash_rows_strided_coop<PP>, dim3(blocks_for(rows * 16)), dim3(kBlock), 0,
@@ -641,7 +650,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     if (pi >= kMaxPhases) fail(P3R_EUNSUPPORTED, "more than %zu FRI commit phases", kMaxPhases);
     TranscriptStep step{d_tstate.p, d_betas + DC * pi, d_caps + P2_DIGEST * pi};
     step.dc = DC;
-    build_plain_layers<PP>(ctx, ph.tree.get(), rows, device_transcript ? &step : nullptr);
+    if (arity4) mmcs4_build_levels<PP>(ctx, ph.tree.get(), nullptr);
+    else build_plain_layers<PP>(ctx, ph.tree.get(), rows, device_transcript ? &step : nullptr);
     if (device_transcript) {
       if (!step.done)  // a tree whose root is not produced by a single-workgroup launch (one leaf)
         hipLaunchKernelGGL(k_fri_transcript_step<PP>, dim3(1), dim3(64), 0, ctx->stream, ph.tree->layers.back().p,
@@ -748,8 +758,35 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     cursor += count;
     return at;
   };
-  struct QRound { std::vector<std::pair<uint32_t, uint32_t>> rows; uint32_t proof_at; int depth; };
-  struct QPhase { uint32_t sib_at[8]; uint32_t proof_at; int depth; int shift; };
+  // an opening proof inside a query's block: binary tree - `depth` sibling digests in a row at proof_at; arity-4 tree
+  // (mmcs4.h) - per level the siblings at positions pos ^ 1 .. pos ^ (step - 1), written out in ascending position
+  struct QPath {
+    uint32_t proof_at = 0;
+    int depth = 0;
+    std::vector<uint32_t> lv_at;
+    const p3r_tree* t = nullptr;
+  };
+  struct QRound { std::vector<std::pair<uint32_t, uint32_t>> rows; QPath path; uint32_t tree_shift; };
+  struct QPhase { uint32_t sib_at[8]; QPath path; int shift; };
+  // `base_shift`: the tree's index = query index >> base_shift
+  auto push_path = [&](const p3r_tree* t, uint32_t base_shift) {
+    QPath qp;
+    qp.t = t;
+    qp.proof_at = cursor;
+    if (t->arity == 4) {
+      for (size_t l = 0; l < t->levels.size(); ++l) {
+        qp.lv_at.push_back(cursor);
+        for (int f = 1; f < t->levels[l].step; ++f)
+          push(t->layers[l].p, t->layer_n[l], P2_DIGEST, base_shift + (uint32_t)t->levels[l].bits, (uint32_t)f, 1);
+      }
+      qp.depth = (int)mmcs4_proof_len(t->levels);
+    } else {
+      qp.depth = t->log_max_h - t->cap_height;
+      for (int l = 0; l < qp.depth; ++l)
+        push(t->layers[l].p, size_t(1) << (t->log_max_h - l), P2_DIGEST, base_shift + l, 1, 1);
+    }
+    return qp;
+  };
   std::vector<QRound> qrounds;
   std::vector<QPhase> qphases;
   for (int r = 0; r < n_rounds; ++r) {
@@ -760,10 +797,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       const int lh = log2_exact(m->h, "height");
       qr.rows.emplace_back(push(m->d, m->h, (uint32_t)m->w, (uint32_t)(log_max - lh), 0, 1), (uint32_t)m->w);
     }
-    qr.depth = t->log_max_h - t->cap_height;
-    qr.proof_at = cursor;
-    for (int l = 0; l < qr.depth; ++l)
-      push(t->layers[l].p, size_t(1) << (t->log_max_h - l), P2_DIGEST, tree_shift + l, 1, 1);
+    qr.tree_shift = tree_shift;
+    qr.path = push_path(t, tree_shift);
     qrounds.push_back(std::move(qr));
   }
   {
@@ -775,11 +810,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       // sibling j of the row: the DC planes of one extension element, at row * arity + j
       for (size_t j = 0; j < arity; ++j)
         qp.sib_at[j] = push(ph.folded_in.p + j, n_in, DC, (uint32_t)(shift + ph.la), 0, (uint32_t)arity);
-      qp.depth = ph.tree->log_max_h - ph.tree->cap_height;
-      qp.proof_at = cursor;
-      for (int l = 0; l < qp.depth; ++l)
-        push(ph.tree->layers[l].p, size_t(1) << (ph.tree->log_max_h - l), P2_DIGEST, (uint32_t)(shift + ph.la + l), 1, 1);
-      qphases.push_back(qp);
+      qp.path = push_path(ph.tree.get(), (uint32_t)(shift + ph.la));
+      qphases.push_back(std::move(qp));
       shift += ph.la;
     }
   }
@@ -832,6 +864,18 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       }
     }
   };
+  auto write_path = [&](const QPath& qp, const uint32_t* g, size_t tree_index) {
+    W.varint(qp.depth);
+    if (qp.t->arity != 4) {
+      W.words(g + qp.proof_at, (size_t)qp.depth * P2_DIGEST);
+      return;
+    }
+    for (size_t l = 0; l < qp.t->levels.size(); ++l) {
+      const size_t step = qp.t->levels[l].step, pos = (tree_index >> qp.t->levels[l].bits) & (step - 1);
+      for (size_t j = 0; j < step; ++j)
+        if (j != pos) W.words(g + qp.lv_at[l] + ((j ^ pos) - 1) * P2_DIGEST, P2_DIGEST);
+    }
+  };
   auto write_queries = [&] {
     W.varint(indices.size());
     for (size_t qi = 0; qi < indices.size(); ++qi) {
@@ -843,8 +887,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
           W.varint(rw.second);
           W.words(g + rw.first, rw.second);
         }
-        W.varint(qr.depth);
-        W.words(g + qr.proof_at, (size_t)qr.depth * P2_DIGEST);
+        write_path(qr.path, g, indices[qi] >> qr.tree_shift);
       }
       W.varint(qphases.size());
       for (size_t p = 0; p < phases.size(); ++p) {
@@ -855,8 +898,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         W.varint(arity - 1);
         for (size_t j = 0; j < arity; ++j)
           if (j != pos) W.words(g + qp.sib_at[j], DC);
-        W.varint(qp.depth);
-        W.words(g + qp.proof_at, (size_t)qp.depth * P2_DIGEST);
+        write_path(qp.path, g, indices[qi] >> (qp.shift + phases[p].la));
       }
     }
   };

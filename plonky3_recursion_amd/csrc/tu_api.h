@@ -55,4 +55,16 @@ void launch_logup_aux(p3r_ctx* ctx, unsigned blocks, const LogupJob* d_jobs, int
 template <class PP, int DC>
 void launch_quotient(p3r_ctx* ctx, unsigned blocks, const QuotientArgs* d_jobs, int n_jobs, const LookupChT<DC>& lc);
 
+// K6 of the arity-4 MMCS (tu_mmcs4.hip; kernels_mmcs4.hip.h).  classes[c] = the matrices of one height, digs[c] =
+// [8][allocs[c]] with allocs[c] >= that height.
+template <class PP>
+void mmcs4_hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& classes, const std::vector<uint32_t*>& digs,
+                     const std::vector<size_t>& allocs);
+template <class PP>
+void mmcs4_hash_rows_strided(p3r_ctx* ctx, const uint32_t* const* dcols, int wtot, size_t rows, size_t stride, uint32_t* dig,
+                             size_t alloc);
+template <class PP>
+void mmcs4_compress(p3r_ctx* ctx, const uint32_t* prev, size_t n_prev, int step, const uint32_t* inj, uint32_t* out,
+                    size_t n_logical, size_t n_out);
+
 }  // namespace p3r

@@ -1,0 +1,64 @@
+// K6 of the arity-4 MMCS: the three kernels over the width-32 FP64 permutation and their launches.  Own translation
+// unit (tu_api.h): the permutation is 11 k instructions of straight-line code per instance.
+#include "tu_api.h"
+#include "kernels_mmcs4.hip.h"
+#include "profile.h"
+
+namespace p3r {
+
+template <class PP>
+void mmcs4_hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& classes, const std::vector<uint32_t*>& digs,
+                     const std::vector<size_t>& allocs) {
+  std::vector<HashRowsJob4> jobs;
+  for (size_t c = 0; c < classes.size(); ++c) {
+    std::vector<const uint32_t*> cols;
+    for (const p3r_dmat* m : classes[c])
+      for (size_t k = 0; k < m->w; ++k) cols.push_back(m->d + k * m->h);
+    HashRowsJob4 j{};
+    j.cols = col_table(ctx, cols);
+    j.dig = digs[c];
+    j.h = classes[c][0]->h;
+    j.h_alloc = allocs[c];
+    j.wtot = (int)cols.size();
+    jobs.push_back(j);
+  }
+  // widest rows first: their blocks run longest
+  std::stable_sort(jobs.begin(), jobs.end(), [](const HashRowsJob4& a, const HashRowsJob4& b) { return a.wtot > b.wtot; });
+  uint32_t blocks = 0;
+  for (auto& j : jobs) {
+    j.block0 = blocks;
+    blocks += (uint32_t)((j.h + kBlock - 1) / kBlock);
+  }
+  const auto* d_jobs = static_cast<const HashRowsJob4*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(HashRowsJob4)));
+  ProfScope ps(ctx, "mmcs_hash_rows");
+  hipLaunchKernelGGL(k_mmcs4_hash_rows<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(), ctx->rcd_w32());
+  P3R_HIP(hipGetLastError());
+}
+
+template <class PP>
+void mmcs4_hash_rows_strided(p3r_ctx* ctx, const uint32_t* const* dcols, int wtot, size_t rows, size_t stride, uint32_t* dig,
+                             size_t alloc) {
+  ProfScope ps(ctx, "mmcs_hash_rows_strided");
+  hipLaunchKernelGGL(k_mmcs4_hash_rows_strided<PP>, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, dcols,
+                     wtot, rows, stride, dig, alloc, ctx->rcd_w32());
+  P3R_HIP(hipGetLastError());
+}
+
+template <class PP>
+void mmcs4_compress(p3r_ctx* ctx, const uint32_t* prev, size_t n_prev, int step, const uint32_t* inj, uint32_t* out,
+                    size_t n_logical, size_t n_out) {
+  ProfScope ps(ctx, "mmcs_compress");
+  hipLaunchKernelGGL(k_mmcs4_compress<PP>, dim3((unsigned)((n_out + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, prev, n_prev,
+                     step, inj, out, n_logical, n_out, ctx->rcd_w32());
+  P3R_HIP(hipGetLastError());
+}
+
+#define P3R_MMCS4_INSTANCES(PP)                                                                                              \
+  template void mmcs4_hash_rows<PP>(p3r_ctx*, const std::vector<std::vector<const p3r_dmat*>>&, const std::vector<uint32_t*>&, \
+                                    const std::vector<size_t>&);                                                              \
+  template void mmcs4_hash_rows_strided<PP>(p3r_ctx*, const uint32_t* const*, int, size_t, size_t, uint32_t*, size_t);        \
+  template void mmcs4_compress<PP>(p3r_ctx*, const uint32_t*, size_t, int, const uint32_t*, uint32_t*, size_t, size_t);
+P3R_MMCS4_INSTANCES(KoalaBearParams)
+P3R_MMCS4_INSTANCES(BabyBearParams)
+
+}  // namespace p3r

@@ -589,6 +589,77 @@ void mmcs_verify(const std::vector<std::array<Fp<PP>, P2_DIGEST>>& cap, int cap_
   if (node != cap.at(idx)) vfail("%s: Merkle root mismatch", what);
 }
 
+// Arity-4 MMCS (mmcs4.h): leaf = width-32 sponge of rate 24 over the rows of the tallest matrices; per level step - 1
+// siblings in ascending position around the running digest at `pos = index mod step`, chunks above `step` zero; an
+// injected class as one more compression (node, digest of its rows, 0, 0).  recursion/src/pcs/mmcs.rs:1165-1316 is
+// the same walk in circuit form.  `rcw`: the width-32 constant table (Montgomery), rc + p2_num_constants.
+template <class PP>
+std::array<Fp<PP>, P2_DIGEST> sponge_hash_w32(const std::vector<Fp<PP>>& row, const uint32_t* rcw) {
+  using F = Fp<PP>;
+  F s[P2W_WIDTH];
+  for (auto& x : s) x = F::zero();
+  struct { void put(F) {} } sink;
+  for (size_t g = 0; g < row.size(); g += 24) {
+    for (size_t j = 0; j < 24 && g + j < row.size(); ++j) s[j] = row[g + j];
+    p2w_permute_traced<PP>(s, rcw, sink);
+  }
+  std::array<F, P2_DIGEST> d;
+  for (int k = 0; k < P2_DIGEST; ++k) d[k] = s[k];
+  return d;
+}
+template <class PP>
+std::array<Fp<PP>, P2_DIGEST> compress4(const std::array<Fp<PP>, P2_DIGEST>* c, const uint32_t* rcw) {
+  using F = Fp<PP>;
+  F s[P2W_WIDTH];
+  for (int j = 0; j < 4; ++j)
+    for (int k = 0; k < P2_DIGEST; ++k) s[j * P2_DIGEST + k] = c[j][k];
+  struct { void put(F) {} } sink;
+  p2w_permute_traced<PP>(s, rcw, sink);
+  std::array<F, P2_DIGEST> d;
+  for (int k = 0; k < P2_DIGEST; ++k) d[k] = s[k];
+  return d;
+}
+template <class PP>
+void mmcs_verify4(const std::vector<std::array<Fp<PP>, P2_DIGEST>>& cap, int cap_height, const std::vector<int>& log_heights,
+                  const std::vector<std::vector<Fp<PP>>>& rows, size_t index,
+                  const std::vector<std::array<Fp<PP>, P2_DIGEST>>& path, const uint32_t* rcw, const char* what) {
+  using F = Fp<PP>;
+  using Digest = std::array<F, P2_DIGEST>;
+  if (rows.size() != log_heights.size() || rows.empty()) vfail("%s: %zu opened rows for %zu matrices", what, rows.size(), log_heights.size());
+  if (cap_height != 0 || cap.size() != 1) vfail("%s: bad cap (the arity-4 MMCS has a one-digest cap)", what);
+  int log_max = 0;
+  std::vector<size_t> heights;
+  for (int lh : log_heights) {
+    log_max = std::max(log_max, lh);
+    heights.push_back(size_t(1) << lh);
+  }
+  if (index >> log_max) vfail("%s: index out of range", what);
+  const std::vector<Mmcs4Level> levels = mmcs4_schedule(heights);
+  if (path.size() != mmcs4_proof_len(levels))
+    vfail("%s: opening proof has %zu siblings, expected %zu", what, path.size(), mmcs4_proof_len(levels));
+  auto concat = [&](size_t h) {
+    std::vector<F> r;
+    for (size_t m = 0; m < rows.size(); ++m)
+      if (heights[m] == h) r.insert(r.end(), rows[m].begin(), rows[m].end());
+    return r;
+  };
+  Digest zero;
+  zero.fill(F::zero());
+  Digest node = sponge_hash_w32<PP>(concat(size_t(1) << log_max), rcw);
+  size_t at = 0;
+  for (const Mmcs4Level& lv : levels) {
+    const size_t pos = (index >> lv.bits) & (size_t)(lv.step - 1);
+    Digest c[4] = {zero, zero, zero, zero};
+    for (size_t j = 0; j < (size_t)lv.step; ++j) c[j] = j == pos ? node : path[at++];
+    node = compress4<PP>(c, rcw);
+    if (lv.inject_h) {
+      Digest in[4] = {node, sponge_hash_w32<PP>(concat(lv.inject_h), rcw), zero, zero};
+      node = compress4<PP>(in, rcw);
+    }
+  }
+  if (node != cap[0]) vfail("%s: Merkle root mismatch", what);
+}
+
 // ---- the out-of-domain identity of one instance: folded constraints(zeta) / Z_H(zeta) == quotient(zeta)
 // (recursion/src/verifier/batch_stark.rs:886-1017, verifier/quotient.rs:60-140).  Shared by the
 // verifier and by the prover's self-check before it serialises a proof (prove_impl.hip.h): the
@@ -697,6 +768,7 @@ struct VerifyParams {
   int log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits, num_queries;
   std::vector<uint8_t> fri_log_arities;  // explicit folding schedule (p3r_config), empty: the rule
   ProofLayout layout;                    // field order of the serialised structs (p3r_config.proof_layout)
+  int mmcs_arity = 2;                    // 4: the arity-4 MMCS over the width-32 permutation (p3r_config.mmcs_arity)
 };
 
 template <class PP, int DC = 4>
@@ -882,7 +954,8 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
       if (qr.rows.size() != rounds[r].size()) vfail("query %zu: batch %zu opens %zu matrices, expected %zu", qi, r, qr.rows.size(), rounds[r].size());
       for (size_t m = 0; m < rounds[r].size(); ++m)
         if (qr.rows[m].size() != (size_t)rounds[r][m].w) vfail("query %zu: batch %zu matrix %zu has the wrong width", qi, r, m);
-      mmcs_verify<PP>(*round_caps[r], cap_h, lhs, qr.rows, index >> (log_max - r_max), qr.path, rc.data(), "input batch");
+      if (prm.mmcs_arity == 4) mmcs_verify4<PP>(*round_caps[r], cap_h, lhs, qr.rows, index >> (log_max - r_max), qr.path, rc.data() + p2_num_constants<PP>(), "input batch");
+      else mmcs_verify<PP>(*round_caps[r], cap_h, lhs, qr.rows, index >> (log_max - r_max), qr.path, rc.data(), "input batch");
       for (size_t m = 0; m < rounds[r].size(); ++m) {
         const Mat& M = rounds[r][m];
         auto it = ro.find(M.log_h);
@@ -916,7 +989,8 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
       // the leaf is the row of 2^la sibling evaluations, extension elements flattened
       std::vector<F> leaf;
       for (auto& x : e) for (int k = 0; k < DC; ++k) leaf.push_back(x.c[k]);
-      mmcs_verify<PP>(P.commit_caps[p], cap_h, {cur - la}, {leaf}, row, ph.path, rc.data(), "FRI commit phase");
+      if (prm.mmcs_arity == 4) mmcs_verify4<PP>(P.commit_caps[p], cap_h, {cur - la}, {leaf}, row, ph.path, rc.data() + p2_num_constants<PP>(), "FRI commit phase");
+      else mmcs_verify<PP>(P.commit_caps[p], cap_h, {cur - la}, {leaf}, row, ph.path, rc.data(), "FRI commit phase");
       F ss_inv = F::two_adic_generator(cur).inv().pow(bit_reverse((uint32_t)row, cur - la));
       E b = betas[p];
       const F omega = F::two_adic_generator(la);

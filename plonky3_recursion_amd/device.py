@@ -38,7 +38,7 @@ def _u8(a):
 def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5,
                 commit_pow_bits=0, query_pow_bits=15, num_queries=54, device=0, poseidon2_rc=None, ext_choices=0,
                 fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0, challenge_degree=4,
-                poseidon2_w32_rc=None, poseidon2_w32_diag=None):
+                poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2):
     """A `p3r_config` (+ the arrays it points into, which must stay alive with it).  `ext_choices` /
     `fri_log_arities`: the selectable protocol details of include/p3r.h.
     `ext_degree`: the circuit extension degree D of the traces - 4, or 5 for KoalaBear circuits over the quintic
@@ -49,6 +49,7 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
     cfg.ext_degree = ext_degree
     cfg.ext_w = ext_w     # W of x^D = W for ext_degree 2 / 6 / 8 (include/p3r.h)
     cfg.challenge_degree = challenge_degree   # 5: KoalaBear's quintic challenge field
+    cfg.mmcs_arity = mmcs_arity               # 4: the arity-4 MMCS over the width-32 permutation (recursive_aggregation --arity4)
     cfg.log_blowup = log_blowup
     cfg.max_log_arity = max_log_arity
     cfg.cap_height = cap_height
@@ -112,14 +113,32 @@ def verify_batch(cfg, airs, preprocessed_commitment, degree_bits, proof: bytes, 
         raise P3rError(rc, err.value.decode())
 
 
+def mmcs_verify(cfg, cap, dims, index, opened_values, proof):
+    """`Mmcs::verify_batch` on the host (p3r_mmcs_verify; no GPU): `dims` = (height, width) of the committed matrices in
+    commit order, `opened_values` their opened rows concatenated, `proof` the sibling digests.  Honours cfg.mmcs_arity.
+    Raises P3rError with the reason when the opening is rejected."""
+    lib = _lib.load()
+    c, cp = _u32(cap)
+    o, op = _u32(opened_values)
+    pf, pp = _u32(np.asarray(proof, dtype=np.uint32).reshape(-1, 8))
+    n = len(dims)
+    hs = (C.c_size_t * n)(*[int(d[0]) for d in dims])
+    ws = (C.c_size_t * n)(*[int(d[1]) for d in dims])
+    err = C.create_string_buffer(512)
+    rc = lib.p3r_mmcs_verify(C.byref(cfg), cp, n, hs, ws, int(index), op, pp, pf.shape[0], err, len(err))
+    if rc != 0:
+        raise P3rError(rc, err.value.decode())
+
+
 class Context:
     """One per GPU; not thread-safe; one call in flight (include/p3r.h)."""
 
     def __init__(self, field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
                  log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
                  device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0,
-                 challenge_degree=4, poseidon2_w32_rc=None, poseidon2_w32_diag=None):
+                 challenge_degree=4, poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2):
         self.lib = _lib.load()
+        self.mmcs_arity = mmcs_arity
         self.field = field
         self.ext_degree = ext_degree
         self.ext_w = ext_w
@@ -128,7 +147,7 @@ class Context:
         cfg, self._rc_keep = make_config(field, log_blowup, max_log_arity, cap_height, log_final_poly_len,
                                          commit_pow_bits, query_pow_bits, num_queries, device, poseidon2_rc, ext_choices,
                                          fri_log_arities, proof_layout, ext_degree, ext_w, challenge_degree,
-                                         poseidon2_w32_rc, poseidon2_w32_diag)
+                                         poseidon2_w32_rc, poseidon2_w32_diag, mmcs_arity)
         self.cfg = cfg
         self.cap_height = cap_height
         self.log_blowup = log_blowup
@@ -414,7 +433,7 @@ class MerkleTree:
     def open_batch(self, index):
         """Returns (opened_values concatenated in commit order, proof[(depth, 8)])."""
         w = self.ctx.lib.p3r_tree_total_width(self.h)
-        depth = self.log_max_height - self.ctx.cap_height
+        depth = self.ctx.lib.p3r_tree_proof_len(self.h)   # binary: log_max_height - cap_height; arity 4: sum of (step - 1)
         opened = np.empty(w, dtype=np.uint32)
         proof = np.empty((depth, 8), dtype=np.uint32)
         self.ctx.check(self.ctx.lib.p3r_mmcs_open(self.ctx.h, self.h, index, opened.ctypes.data_as(_lib.u32p),

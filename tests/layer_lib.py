@@ -96,20 +96,22 @@ def fill_workload(wl_struct, arrays, packing, keep):
         wl_struct.recompose_coeff_prep = ptr("recompose_coeff_prep")
 
 
-def oracle_verify_statement(orc, field, prm, airs, prep_cap, proof_bytes, rc=None, field_encoding=0):
+def oracle_verify_statement(orc, field, prm, airs, prep_cap, proof_bytes, rc=None, field_encoding=0, w32=None):
     """The oracle verifier from the statement alone: `airs` = dicts(kind, lanes, horner_packed_steps,
     coeff_lookups) in instance order (what `BatchStarkProof.airs()` rebuilds from the proof metadata).
     For layers whose tables the CPU would take minutes to rebuild.  Raises RuntimeError on rejection."""
     lib = orc.lib
-    lib.orc_verify_batch.argtypes = [C.c_int, u32p, C.POINTER(OrcParams), C.c_size_t, u32p, u32p,
-                                     C.POINTER(C.c_uint8), C.c_size_t, C.c_int]
+    lib.orc_verify_batch_w32.argtypes = [C.c_int, u32p, u32p, u32p, C.POINTER(OrcParams), C.c_size_t, u32p, u32p,
+                                         C.POINTER(C.c_uint8), C.c_size_t, C.c_int]
     rc = oracle_lib.default_rc(field) if rc is None else np.ascontiguousarray(rc, dtype=np.uint32)
+    w32 = oracle_lib.default_w32(field) if w32 is None else w32   # of a width-32 table / the arity-4 MMCS
     a4 = np.array([[a["kind"], a.get("lanes", 1), a.get("horner_packed_steps", 2),
                     a.get("coeff_lookups", 0) | (a.get("ext_degree", 4) << 8) | (a.get("ext_w", 0) << 16)] for a in airs], dtype=np.uint32)
     cap = np.ascontiguousarray(prep_cap, dtype=np.uint32)
     b = (C.c_uint8 * len(proof_bytes)).from_buffer_copy(proof_bytes)
-    orc._ck(lib.orc_verify_batch(oracle_lib.FIELD_IDS[field], rc.ctypes.data_as(u32p), C.byref(prm), len(airs),
-                                 a4.ctypes.data_as(u32p), cap.ctypes.data_as(u32p), b, len(proof_bytes), field_encoding))
+    orc._ck(lib.orc_verify_batch_w32(oracle_lib.FIELD_IDS[field], rc.ctypes.data_as(u32p), w32[0].ctypes.data_as(u32p),
+                                     w32[1].ctypes.data_as(u32p), C.byref(prm), len(airs), a4.ctypes.data_as(u32p),
+                                     cap.ctypes.data_as(u32p), b, len(proof_bytes), field_encoding))
 
 
 class OracleLayer:

@@ -98,6 +98,16 @@ class Oracle:
                                           cap.ctypes.data_as(u32p), C.byref(tree)))
         return cap, OracleTree(self, tree, arrs, cap_height)
 
+    def p2w_permute(self, field, states, w32=None):
+        """The width-32 permutation on n x 32 canonical states (orc_p2w_permute)."""
+        w32 = default_w32(field) if w32 is None else w32
+        a, p = _u32(np.asarray(states, dtype=np.uint32).reshape(-1, 32))
+        out = np.empty_like(a)
+        self.lib.orc_p2w_permute.argtypes = [C.c_int, u32p, u32p, u32p, u32p, C.c_size_t]
+        self._ck(self.lib.orc_p2w_permute(FIELD_IDS[field], w32[0].ctypes.data_as(u32p), w32[1].ctypes.data_as(u32p), p,
+                                          out.ctypes.data_as(u32p), C.c_size_t(a.shape[0])))
+        return out
+
     # ---- arity-4 MMCS over the width-32 permutation (oracle/hash.hpp: MerkleTree::commit4 / open4 / verify4)
     def commit4(self, field, mats, rc=None, w32=None):
         rc = default_rc(field) if rc is None else rc
