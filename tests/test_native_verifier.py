@@ -18,7 +18,7 @@ def verify(field, prm, tables, cap, proof, canonical=False, degree_bits=None):
     if degree_bits is None:  # the verifier's own metadata: log2 of every table's (padded) height
         degree_bits = [int(t["main"].shape[0]).bit_length() - 1 for t in tables]
     cfg, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
-                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries)
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, mmcs_arity=prm.mmcs_arity or 2)
     airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
     p3r.verify_batch(cfg, airs, cap, degree_bits, proof, canonical)
 
@@ -35,6 +35,12 @@ CASES = [
      harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC),
     ("koala-bear", 6, dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4),
      dict(alu_lanes=4, horner_packed_steps=5), harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU),
+    # the arity-4 MMCS over the width-32 permutation (p3r_config.mmcs_arity = 4): oracle prover, native verifier
+    ("koala-bear", 7, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=4, num_queries=5, mmcs_arity=4), None, 0),
+    ("baby-bear", 6, dict(log_blowup=1, max_log_arity=3, log_final_poly_len=0, commit_pow_bits=3, query_pow_bits=3, num_queries=4, mmcs_arity=4),
+     dict(alu_lanes=2, horner_packed_steps=3), 0),
+    ("koala-bear", 7, dict(log_blowup=1, max_log_arity=1, log_final_poly_len=1, query_pow_bits=3, num_queries=4, mmcs_arity=4), None,
+     harness_lib.P2_W32),
 ]
 
 

@@ -166,3 +166,45 @@ def test_arity4_layer_proof_round_trip(oracle, field):
     bad[len(bad) // 2] ^= 1
     with pytest.raises(RuntimeError):
         L4.verify(bytes(bad))
+
+
+@pytest.mark.parametrize("field", FIELDS)
+@pytest.mark.parametrize("arity", [2, 4])
+def test_native_host_verifier_accepts_the_oracles_openings(oracle, field, arity):
+    """p3r_mmcs_verify (host code of the C-ABI library, no GPU) against trees built by the oracle: two implementations
+    of verify_batch agree on acceptance and on every rejection."""
+    import plonky3_recursion_amd as p3r
+    rng = np.random.default_rng(21 + arity)
+    cfg, keep = p3r.make_config(field, mmcs_arity=arity)
+    for shapes in SHAPES:
+        mats = mats_of(rng, field, shapes)
+        cap, tree = oracle.commit4(field, mats) if arity == 4 else oracle.commit(field, mats)
+        hmax = max(s[0] for s in shapes)
+        for index in sorted({0, hmax - 1, int(rng.integers(0, hmax))}):
+            opened, proof = tree.open(index)
+            p3r.mmcs_verify(cfg, cap, shapes, index, opened, proof)
+            if proof.shape[0]:
+                bad = proof.copy()
+                bad[int(rng.integers(0, bad.shape[0])), int(rng.integers(0, 8))] ^= 1
+                with pytest.raises(p3r.P3rError, match="root mismatch"):
+                    p3r.mmcs_verify(cfg, cap, shapes, index, opened, bad)
+                with pytest.raises(p3r.P3rError, match="siblings"):
+                    p3r.mmcs_verify(cfg, cap, shapes, index, opened, proof[1:])
+            bad = opened.copy()
+            bad[-1] ^= 2
+            with pytest.raises(p3r.P3rError, match="root mismatch"):
+                p3r.mmcs_verify(cfg, cap, shapes, index, bad, proof)
+            with pytest.raises(p3r.P3rError, match="out of range"):
+                p3r.mmcs_verify(cfg, cap, shapes, hmax, opened, proof)
+    # and the other arity's verifier refuses the same opening
+    other, keep2 = p3r.make_config(field, mmcs_arity=6 - arity)
+    with pytest.raises(p3r.P3rError):
+        p3r.mmcs_verify(other, cap, shapes, index, opened, proof)
+
+
+def test_native_verifier_config_rules():
+    import plonky3_recursion_amd as p3r
+    cfg, keep = p3r.make_config("koala-bear", mmcs_arity=4, cap_height=1)
+    z = np.zeros((2, 8), dtype=np.uint32)
+    with pytest.raises(p3r.P3rError, match="cap_height must be 0"):
+        p3r.mmcs_verify(cfg, z, [(4, 1)], 0, np.zeros(1, dtype=np.uint32), z)

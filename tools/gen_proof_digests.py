@@ -23,6 +23,8 @@ CASES = [
     ("d5_quintic_challenge", "koala-bear", 8, 16, 64, 5, 5, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=4, num_queries=5),
      dict(public_lanes=1, alu_lanes=8, horner_packed_steps=2)),
     ("d1_quintic_challenge", "koala-bear", 7, 17, 2, 1, 5, dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4), {}),
+    ("d4_arity4_mmcs", "koala-bear", 7, 19, 0, 4, 4, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4, mmcs_arity=4), {}),
+    ("d4_arity4_mmcs_w32_table", "baby-bear", 7, 20, 128, 4, 4, dict(log_blowup=1, max_log_arity=3, log_final_poly_len=1, query_pow_bits=3, num_queries=4, mmcs_arity=4), {}),
     ("d8_binomial", "koala-bear", 7, 18, 1, 8, 4, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4), dict(ext_w=3)),
 ]
 GEN = dict(horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
