@@ -143,3 +143,28 @@ def test_extern_functions_of_the_shim_exist_with_the_same_arity():
         assert cfn[name] == n, "%s: %d parameters in the shim, %d in the header" % (name, n, cfn[name])
         seen += 1
     assert seen >= 8
+
+
+def test_shim_literals_name_the_headers_abi_version_and_every_config_field():
+    """The `p3r_config { .. }` literals of the shim text: `abi_version: N` is p3r.h's P3R_ABI_VERSION, and a literal
+    that is not built with `..` names every field of the struct (a Rust struct literal with a missing field does not
+    compile - the round-3 literal silently lacked the ABI-6 fields)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    hdr = open(os.path.join(root, "include", "p3r.h")).read()
+    abi = int(re.search(r"#define\s+P3R_ABI_VERSION\s+(\d+)", hdr).group(1))
+    for m in re.finditer(r"abi_version:\s*(\d+)", md):
+        assert int(m.group(1)) == abi, "INTEGRATION.md names ABI version %s, p3r.h has %d" % (m.group(1), abi)
+    body = re.search(r"typedef struct p3r_config \{(.*?)\} p3r_config;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [re.split(r"[\s\*]+", d.strip())[-1] for d in body.split(";") if d.strip()]
+    lits = re.findall(r"let cfg = p3r_config \{(.*?)\};", md, re.S)
+    assert lits, "no p3r_config literal found in INTEGRATION.md"
+    for lit in lits:
+        lit = re.sub(r"//[^\n]*", "", lit)
+        if ".." in lit:
+            continue
+        named = set(re.findall(r"(\w+)\s*:", lit)) | set(re.findall(r"[{,]\s*(\w+)\s*(?=[,}])", "{" + lit + "}"))
+        missing = [f for f in fields if f not in named]
+        assert not missing, "p3r_config literal in INTEGRATION.md lacks %s" % missing

@@ -54,7 +54,7 @@ def draw(rng, max_log_h, min_log_h=5):
 def fitting_schedule(rng, oracle, field, arrs, kw, packing):
     """A random folding schedule that reaches every roll-in height and the final height (the rule of
     include/p3r.h: each step at most max_log_arity, the distance to the next input height and to the end)."""
-    base = {k: v for k, v in kw.items() if k not in ("fri_log_arities", "proof_layout")}
+    base = {k: v for k, v in kw.items() if k not in ("fri_log_arities", "proof_layout", "mmcs_arity")}
     L = layer_lib.OracleLayer(oracle, field, arrs, layer_lib.params(**base), packing=dict(packing))
     lb = kw["log_blowup"]
     # FRI inputs: the LDEs of the trace domains and of the quotient chunks all live at log2(h) + log_blowup
@@ -98,6 +98,16 @@ def one(oracle, seed, max_log_h, min_log_h=5):
         flags = (flags & ~harness_lib.RECOMPOSE_COEFF) | harness_lib.RECOMPOSE_BOTH
     challenge_degree = 5 if field == "koala-bear" and rng3.random() < 0.3 else 4
     kw["challenge_degree"] = challenge_degree
+    # fourth stream (round 4): the prover's own arity-4 MMCS in a third of the draws (a one-digest cap: cap_height 0 in four
+    # of five of them, otherwise the drawn cap - which both sides must refuse), and the width-32 Poseidon2 table in a
+    # quarter of the D = 4 layers that hold a width-16 one
+    rng4 = random.Random(seed * 15485863 + 3)
+    if rng4.random() < 0.33:
+        kw["mmcs_arity"] = 4
+        if rng4.random() < 0.8:
+            kw["cap_height"] = 0
+    if ext_degree == 4 and not (flags & harness_lib.NO_POSEIDON2) and rng4.random() < 0.25:
+        flags |= harness_lib.P2_W32
     coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
     arrs = harness_lib.generate(field, log_h, seed=seed, flags=flags, ext_degree=ext_degree, **gen)
     packing_o = dict(packing, ext_degree=ext_degree, recompose_coeff_lookups=int(coeff))
