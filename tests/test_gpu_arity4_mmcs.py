@@ -64,6 +64,29 @@ def test_commit_and_open_vs_oracle(oracle, field, shapes):
     c.close()
 
 
+def test_reference_round_trip_pattern_on_the_device(oracle):
+    """circuit-prover/tests/arity4_mmcs.rs: a 64 x 4 matrix (three quaternary levels, three siblings a level), indices
+    0, 1, 2, 3, 27, 63; the openings must be the ones the W32 TABLE's rows then consume - checked here by feeding the
+    device's opening into the synthetic table rows' own recomputation of the root (the oracle's permutation seam)."""
+    import plonky3_recursion_amd as p3r
+    from test_oracle_arity4_mmcs import REF_HEIGHT, REF_INDICES, REF_WIDTH, compress4, w32_hash
+    for field in FIELDS:
+        c = p3r.Context(field=field, mmcs_arity=4)
+        mat = rand(np.random.default_rng(64), field, (REF_HEIGHT, REF_WIDTH))
+        cap, tree = c.commit([mat])
+        for index in REF_INDICES:
+            opened, proof = tree.open_batch(index)
+            assert proof.shape == (9, 8)
+            node = w32_hash(oracle, field, opened)
+            for level in range(3):
+                pos = (index >> (2 * level)) & 3
+                sibs = list(proof[3 * level:3 * level + 3])
+                node = compress4(oracle, field, [node if k == pos else sibs.pop(0) for k in range(4)])
+            assert np.array_equal(node, cap[0])
+        tree.free()
+        c.close()
+
+
 def test_tall_tree_every_level_kind(oracle):
     """2^17 leaves: a bridge level at the bottom (2^16 injected), a second bridge 2^14 -> 2^13 (injected), a plain
     injection at 2^9 = 2^13 / 4^2, and a padded top (2^9 -> 128 -> 32 -> 8 -> 2: the last level compresses a layer of 2

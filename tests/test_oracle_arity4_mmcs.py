@@ -208,3 +208,37 @@ def test_native_verifier_config_rules():
     z = np.zeros((2, 8), dtype=np.uint32)
     with pytest.raises(p3r.P3rError, match="cap_height must be 0"):
         p3r.mmcs_verify(cfg, z, [(4, 1)], 0, np.zeros(1, dtype=np.uint32), z)
+
+
+# ---- the reference's own test of this path, as data: circuit-prover/tests/arity4_mmcs.rs:49-55 (a 64 x 4 matrix: three
+# full quaternary levels 64 -> 16 -> 4 -> 1, three siblings per level), :131-137 (pos = (index >> 2 level) & 3, the three
+# native siblings fill the remaining chunks in ascending order), :222-228 (indices 0, 1, 2, 3, 27, 63), :235-238
+# (siblings[0][0] += 1 at index 27 must break the root)
+REF_HEIGHT, REF_WIDTH, REF_INDICES = 64, 4, [0, 1, 2, 3, 27, 63]
+
+
+@pytest.mark.parametrize("field", FIELDS)
+def test_reference_round_trip_pattern(oracle, field):
+    import plonky3_recursion_amd as p3r
+    rng = np.random.default_rng(64)
+    mat = rng.integers(0, P[field], size=(REF_HEIGHT, REF_WIDTH), dtype=np.uint32)
+    cap, tree = oracle.commit4(field, [mat])
+    cfg, keep = p3r.make_config(field, mmcs_arity=4)
+    for index in REF_INDICES:
+        opened, proof = tree.open(index)
+        assert proof.shape[0] % 3 == 0 and proof.shape[0] // 3 == 3      # arity4_mmcs.rs:99-104
+        node = w32_hash(oracle, field, opened)
+        for level in range(3):
+            pos = (index >> (2 * level)) & 3
+            sibs = list(proof[3 * level:3 * level + 3])
+            chunks = [node if k == pos else sibs.pop(0) for k in range(4)]
+            node = compress4(oracle, field, chunks)
+        assert np.array_equal(node, cap[0])
+        assert oracle.verify4(field, cap, [(REF_HEIGHT, REF_WIDTH)], index, opened, proof)
+        p3r.mmcs_verify(cfg, cap, [(REF_HEIGHT, REF_WIDTH)], index, opened, proof)
+    opened, proof = tree.open(27)
+    bad = proof.copy()
+    bad[0, 0] = (int(bad[0, 0]) + 1) % P[field]
+    assert not oracle.verify4(field, cap, [(REF_HEIGHT, REF_WIDTH)], 27, opened, bad)
+    with pytest.raises(p3r.P3rError, match="root mismatch"):
+        p3r.mmcs_verify(cfg, cap, [(REF_HEIGHT, REF_WIDTH)], 27, opened, bad)
