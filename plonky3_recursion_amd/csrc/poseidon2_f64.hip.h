@@ -135,10 +135,30 @@ __device__ __forceinline__ void p2f_external_linear(double* s) {
   for (int i = 0; i < P2_WIDTH; ++i) s[i] += sum[i & 3];
 }
 
+// The diagonal's factors that are not inline constants of the ISA (3 and the inverse powers of two below 1/2), as
+// SCALAR REGISTER values.  Written as literals they are only encodable in the two-address v_fmac_f64 form, whose
+// addend register is overwritten: every `x * m + sum` then starts with a copy of `sum` (v_mov_b64), 7 extra
+// instructions in an 80-instruction partial round.  From a register the three-address v_fma_f64 takes them.
+template <class PP>
+struct P2FDiag {
+  double three, a, b, c, d;   // KoalaBear: 2^-8, 2^-3, 2^-4, 2^-24;  BabyBear: 2^-8, 2^-2, 2^-3, 2^-4 (2^-27 has no addend form)
+};
+template <class PP>
+__device__ __forceinline__ P2FDiag<PP> p2f_diag_consts() {
+  P2FDiag<PP> k;
+  k.three = 3.0;
+  k.a = 0x1p-8;
+  k.b = PP::FIELD_ID == 0 ? 0x1p-3 : 0x1p-2;
+  k.c = PP::FIELD_ID == 0 ? 0x1p-4 : 0x1p-3;
+  k.d = PP::FIELD_ID == 0 ? 0x1p-24 : 0x1p-4;
+  asm volatile("" : "+s"(k.three), "+s"(k.a), "+s"(k.b), "+s"(k.c), "+s"(k.d));
+  return k;
+}
+
 // Diagonal of the internal layer as FP64 factors (poseidon2.h: p2_internal_linear); entries that
 // are integers are applied by one FMA, the 2^-k ones by p2f_mul_2exp_neg.
 template <class PP>
-__device__ __forceinline__ void p2f_internal_linear(double* s, bool reduce_wide) {
+__device__ __forceinline__ void p2f_internal_linear(double* s, bool reduce_wide, const P2FDiag<PP>& K) {
   if (reduce_wide) {
     s[2] = p2f_reduce<PP>(s[2]);
     s[4] = p2f_reduce<PP>(s[4]);
@@ -153,25 +173,25 @@ __device__ __forceinline__ void p2f_internal_linear(double* s, bool reduce_wide)
   s[1] = s[1] + sum;
   s[2] = __builtin_fma(s[2], 2.0, sum);
   s[3] = p2f_mul_2exp_neg_add<PP>(s[3], 0.5, sum);
-  s[4] = __builtin_fma(s[4], 3.0, sum);
+  s[4] = __builtin_fma(s[4], K.three, sum);
   s[5] = __builtin_fma(s[5], 4.0, sum);
   s[6] = p2f_mul_2exp_neg_add<PP>(s[6], -0.5, sum);
-  s[7] = __builtin_fma(s[7], -3.0, sum);
+  s[7] = __builtin_fma(s[7], -K.three, sum);
   s[8] = __builtin_fma(s[8], -4.0, sum);
-  s[9] = p2f_mul_2exp_neg_add<PP>(s[9], 0x1p-8, sum);
+  s[9] = p2f_mul_2exp_neg_add<PP>(s[9], K.a, sum);          // 2^-8
   if (PP::FIELD_ID == 0) {
-    s[10] = p2f_mul_2exp_neg_add<PP>(s[10], 0x1p-3, sum);
-    s[11] = p2f_mul_2exp_neg<PP>(s[11], 0x1p-24) + sum;
-    s[12] = p2f_mul_2exp_neg_add<PP>(s[12], -0x1p-8, sum);
-    s[13] = p2f_mul_2exp_neg_add<PP>(s[13], -0x1p-3, sum);
-    s[14] = p2f_mul_2exp_neg_add<PP>(s[14], -0x1p-4, sum);
-    s[15] = p2f_mul_2exp_neg<PP>(s[15], -0x1p-24) + sum;
+    s[10] = p2f_mul_2exp_neg_add<PP>(s[10], K.b, sum);      // 2^-3
+    s[11] = p2f_mul_2exp_neg<PP>(s[11], K.d) + sum;         // 2^-24
+    s[12] = p2f_mul_2exp_neg_add<PP>(s[12], -K.a, sum);     // -2^-8
+    s[13] = p2f_mul_2exp_neg_add<PP>(s[13], -K.b, sum);     // -2^-3
+    s[14] = p2f_mul_2exp_neg_add<PP>(s[14], -K.c, sum);     // -2^-4
+    s[15] = p2f_mul_2exp_neg<PP>(s[15], -K.d) + sum;        // -2^-24
   } else {
-    s[10] = p2f_mul_2exp_neg_add<PP>(s[10], 0x1p-2, sum);
-    s[11] = p2f_mul_2exp_neg_add<PP>(s[11], 0x1p-3, sum);
+    s[10] = p2f_mul_2exp_neg_add<PP>(s[10], K.b, sum);      // 2^-2
+    s[11] = p2f_mul_2exp_neg_add<PP>(s[11], K.c, sum);      // 2^-3
     s[12] = p2f_mul_2exp_neg<PP>(s[12], 0x1p-27) + sum;
-    s[13] = p2f_mul_2exp_neg_add<PP>(s[13], -0x1p-8, sum);
-    s[14] = p2f_mul_2exp_neg_add<PP>(s[14], -0x1p-4, sum);
+    s[13] = p2f_mul_2exp_neg_add<PP>(s[13], -K.a, sum);     // -2^-8
+    s[14] = p2f_mul_2exp_neg_add<PP>(s[14], -K.d, sum);     // -2^-4
     s[15] = p2f_mul_2exp_neg<PP>(s[15], -0x1p-27) + sum;
   }
 }
@@ -193,9 +213,10 @@ __device__ __forceinline__ void p2f_permute(double* s, const double* __restrict_
     k += P2_WIDTH;
     p2f_external_linear(s);
   }
+  const P2FDiag<PP> K = p2f_diag_consts<PP>();
   for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
     s[0] = p2f_sbox<PP>(s[0] + rc[k + r]);
-    p2f_internal_linear<PP>(s, r % 5 == 0);
+    p2f_internal_linear<PP>(s, r % 5 == 0, K);
   }
   k += PP::PARTIAL_ROUNDS;
   // the lanes with |d| >= 2 leave the partial rounds unreduced (up to 4^5 * 2^31): wide S-box once

@@ -37,16 +37,35 @@ __device__ __forceinline__ void p2wf_external_linear(double* s) {
   for (int i = 0; i < P2W_WIDTH; ++i) s[i] += sum[i & 3];
 }
 
+// a * b + add mod P given c = b / P, in FIVE instructions including the addition (p2f_mulmod_c + one add is six): the
+// rounding constant stays inside the quotient.
+//   qm = fma(a, c, MAGIC)              = MAGIC + q exactly, q = rint(a c)           (|q| < 2^46)
+//   t  = fma(qm, P_HI, -MAGIC * P_HI)  = q * P_HI exactly: one rounding of a value that is representable (46 + 7 bits);
+//                                        MAGIC * P_HI is itself a 9-bit constant
+//   e  = fma(a, b, -t)                 = (a b - q P) + q exactly
+//   (e + addM) - qm                    = a b - q P + add, addM = add + MAGIC: both steps are integer sums below 2^53
+// `neg_c` = -MAGIC * P_HI, handed in as a live register value: as a literal the compiler re-materialises it in front of
+// every use (two v_mov_b32 feeding a v_fmac_f64), which costs more than the instruction the form saves; `p_hi` = P_HI in
+// a scalar register pair for the same reason (as a literal it is only encodable in the two-address v_fmac form).
+template <class PP>
+__device__ __forceinline__ double p2f_mulmod_c_add(double a, double b, double c, double addM, double neg_c, double p_hi) {
+  const double qm = __builtin_fma(a, c, P2F64<PP>::MAGIC);
+  const double t = __builtin_fma(qm, p_hi, neg_c);
+  const double e = __builtin_fma(a, b, -t);
+  return (e + addM) - qm;
+}
+
 // s_i <- d_i s_i + sum(s)
 template <class PP>
-__device__ __forceinline__ void p2wf_internal_linear(double* s, const double* __restrict__ d, const double* __restrict__ c) {
+__device__ __forceinline__ void p2wf_internal_linear(double* s, const double* __restrict__ d, const double* __restrict__ c, double neg_c, double p_hi) {
   double part[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     part[k] = ((s[k] + s[4 + k]) + (s[8 + k] + s[12 + k])) + ((s[16 + k] + s[20 + k]) + (s[24 + k] + s[28 + k]));
   const double sum = p2f_reduce<PP>((part[0] + part[1]) + (part[2] + part[3]));
+  const double sumM = sum + P2F64<PP>::MAGIC;
 #pragma unroll
-  for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_mulmod_c<PP>(s[i], d[i], c[i]) + sum;
+  for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_mulmod_c_add<PP>(s[i], d[i], c[i], sumM, neg_c, p_hi);
 }
 
 // In: integers |x| <= 0.5 P + slack.  Out: the same (reduced, not canonical: either sign).
@@ -73,9 +92,12 @@ __device__ __forceinline__ void p2wf_permute(double* s, const double* __restrict
       cv[i] = d[P2W_WIDTH + i];
       asm volatile("" : "+v"(dv[i]), "+v"(cv[i]));
     }
+    double neg_c = -(P2F64<PP>::MAGIC * P2F64<PP>::P_HI);
+    double p_hi = P2F64<PP>::P_HI;
+    asm volatile("" : "+v"(neg_c), "+s"(p_hi));
     for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) {
       s[0] = p2f_sbox<PP>(s[0] + tab[k + r]);
-      p2wf_internal_linear<PP>(s, dv, cv);
+      p2wf_internal_linear<PP>(s, dv, cv, neg_c, p_hi);
     }
   }
   k += PP::PARTIAL_ROUNDS_W32;
