@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ROUND = next((a for a in sys.argv[1:] if not a.startswith("--")), "r04")
 SRC, OUT = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(OUT, exist_ok=True)
 
@@ -24,6 +24,40 @@ def newest(pattern):
 def kname(full):
     m = re.search(r"(k_[a-z0-9_]+)", full)
     return m.group(1) if m else full[:40]
+
+
+def hash_rows_summary():
+    """pmc_hash_rows.json from the hashrows_* passes; bench.py reads the instruction count from it, so
+    tools/profile_round.sh runs this (`--hash-rows-only`) BEFORE the bench of the same call."""
+    # FP64 / VALU instructions per Poseidon2 permutation of k_mmcs_hash_rows: counter total over the launches of
+    # tools/pmc_hash_rows.py (matrix of known shape) x 64 lanes / permutations of those launches
+    hr = {"provenance": "rocprofv3 --pmc SQ_INSTS_VALU (and SQ_WAVES) --kernel-trace over `python3 tools/pmc_hash_rows.py <field>` "
+                        "bench` (tools/profile_round.sh): the three commits (main, LogUp aux, quotient chunks) of bench.py's 2^20-row "
+                        "layer, every commit one job-list launch of k_mmcs_hash_rows over all its height classes; "
+                        "valu_insts_per_perm = SQ_INSTS_VALU x 64 / permutations of those launches",
+          "fields": {}}
+    for fld in ("koala-bear", "baby-bear"):
+        try:
+            meta = json.loads([ln for ln in open(os.path.join(SRC, "hashrows_%s_SQ_INSTS_VALU.log" % fld)) if ln.startswith("{")][-1])
+            def total(counter):
+                path = newest(SRC + "/hashrows_%s_%s/*/*_counter_collection.csv" % (fld, counter))
+                vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                        if r["Counter_Name"] == counter and "k_mmcs_hash_rows<" in r["Kernel_Name"] and "strided" not in r["Kernel_Name"]]
+                return sum(vals), len(vals)
+            insts, n = total("SQ_INSTS_VALU")
+            waves, _ = total("SQ_WAVES")
+            perms = n * meta["perms_per_launch"]
+            hr["fields"][fld] = dict(meta, launches_counted=n, SQ_INSTS_VALU=insts, SQ_WAVES=waves, permutations=perms,
+                                     valu_insts_per_perm=insts * 64.0 / perms)
+        except Exception as e:  # a missing pass must not lose the rest of the summaries
+            print("pmc_hash_rows: %s: %r" % (fld, e))
+    if hr["fields"]:
+        json.dump(hr, open(os.path.join(OUT, "pmc_hash_rows.json"), "w"), indent=1)
+
+
+if "--hash-rows-only" in sys.argv:
+    hash_rows_summary()
+    sys.exit(0)
 
 
 def pmc(counter):
@@ -80,30 +114,7 @@ json.dump({"provenance": "rocprofv3 --pmc <counter> --kernel-trace, one pass per
                          "sums over every launch of the kernel in the run (1 preparation + 3 prove_next_layer)",
            "kernels": table}, open(os.path.join(OUT, "pmc_sq.json"), "w"), indent=1)
 
-# FP64 / VALU instructions per Poseidon2 permutation of k_mmcs_hash_rows: counter total over the launches of
-# tools/pmc_hash_rows.py (matrix of known shape) x 64 lanes / permutations of those launches
-hr = {"provenance": "rocprofv3 --pmc SQ_INSTS_VALU (and SQ_WAVES) --kernel-trace over `python3 tools/pmc_hash_rows.py <field>` "
-                    "bench` (tools/profile_round.sh): the three commits (main, LogUp aux, quotient chunks) of bench.py's 2^20-row "
-                    "layer, every commit one job-list launch of k_mmcs_hash_rows over all its height classes; "
-                    "valu_insts_per_perm = SQ_INSTS_VALU x 64 / permutations of those launches",
-      "fields": {}}
-for fld in ("koala-bear", "baby-bear"):
-    try:
-        meta = json.loads([ln for ln in open(os.path.join(SRC, "hashrows_%s_SQ_INSTS_VALU.log" % fld)) if ln.startswith("{")][-1])
-        def total(counter):
-            path = newest(SRC + "/hashrows_%s_%s/*/*_counter_collection.csv" % (fld, counter))
-            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                    if r["Counter_Name"] == counter and "k_mmcs_hash_rows<" in r["Kernel_Name"] and "strided" not in r["Kernel_Name"]]
-            return sum(vals), len(vals)
-        insts, n = total("SQ_INSTS_VALU")
-        waves, _ = total("SQ_WAVES")
-        perms = n * meta["perms_per_launch"]
-        hr["fields"][fld] = dict(meta, launches_counted=n, SQ_INSTS_VALU=insts, SQ_WAVES=waves, permutations=perms,
-                                 valu_insts_per_perm=insts * 64.0 / perms)
-    except Exception as e:  # a missing pass must not lose the rest of the summaries
-        print("pmc_hash_rows: %s: %r" % (fld, e))
-if hr["fields"]:
-    json.dump(hr, open(os.path.join(OUT, "pmc_hash_rows.json"), "w"), indent=1)
+hash_rows_summary()
 for f in ("bench_line_babybear_2p22.json", "bench_line_tree_1gpu.json", "bench_line_tree_1gpu_4workers.json",
           "bench_line_forest_1gpu_4trees.json", "bench_line_2ranks_gloo.json", "bench_line_forest_2ranks_gloo.json", "spans.txt"):
     src = os.path.join(SRC, f)
