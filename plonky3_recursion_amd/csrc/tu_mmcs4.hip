@@ -6,6 +6,12 @@
 
 namespace p3r {
 
+// Up to this many nodes / rows the lane-cooperative form wins: a launch of the one-permutation-per-lane form is one
+// permutation latency (19 us) whatever its size up to ~64 K nodes, the cooperative one ~5 us per pass of 16 K nodes;
+// above, the FP64 form's throughput wins (a lane-cooperative permutation is 32 lanes x ~1.7 k integer instructions
+// against 11.5 k FP64 instructions of one lane).
+constexpr size_t kCoop4MaxNodes = 32768, kCoop4MaxRows = 32768;
+
 template <class PP>
 void mmcs4_hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& classes, const std::vector<uint32_t*>& digs,
                      const std::vector<size_t>& allocs) {
@@ -39,6 +45,12 @@ template <class PP>
 void mmcs4_hash_rows_strided(p3r_ctx* ctx, const uint32_t* const* dcols, int wtot, size_t rows, size_t stride, uint32_t* dig,
                              size_t alloc) {
   ProfScope ps(ctx, "mmcs_hash_rows_strided");
+  if (rows <= kCoop4MaxRows) {   // latency-bound: 32 lanes per row
+    hipLaunchKernelGGL(k_mmcs4_hash_rows_strided_coop<PP>, dim3((unsigned)((rows * 32 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       ctx->stream, dcols, wtot, rows, stride, dig, alloc, ctx->rc.p + p2_num_constants<PP>());
+    P3R_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(k_mmcs4_hash_rows_strided<PP>, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, dcols,
                      wtot, rows, stride, dig, alloc, ctx->rcd_w32());
   P3R_HIP(hipGetLastError());
@@ -48,6 +60,12 @@ template <class PP>
 void mmcs4_compress(p3r_ctx* ctx, const uint32_t* prev, size_t n_prev, int step, const uint32_t* inj, uint32_t* out,
                     size_t n_logical, size_t n_out) {
   ProfScope ps(ctx, "mmcs_compress");
+  if (n_out <= kCoop4MaxNodes) {   // latency-bound: 32 lanes per node
+    hipLaunchKernelGGL(k_mmcs4_compress_coop<PP>, dim3((unsigned)((n_out * 32 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                       prev, n_prev, step, inj, out, n_logical, n_out, ctx->rc.p + p2_num_constants<PP>());
+    P3R_HIP(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(k_mmcs4_compress<PP>, dim3((unsigned)((n_out + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, prev, n_prev,
                      step, inj, out, n_logical, n_out, ctx->rcd_w32());
   P3R_HIP(hipGetLastError());

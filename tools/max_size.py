@@ -2,7 +2,8 @@
 with the default FRI parameters, the proof checked by the native verifier and by the oracle's verifier
 (from the statement alone - the oracle PROVER would need hours at these sizes).
 
-usage: python tools/max_size.py [field] [log_h ...] [--quintic]
+usage: python tools/max_size.py [field] [log_h ...] [--quintic] [--arity4]
+--arity4: the prover's own arity-4 MMCS over the width-32 permutation (p3r_config.mmcs_arity = 4).
 --quintic: a D = 5 circuit (base-mode Poseidon2, both Recompose kinds: six tables) under KoalaBear's quintic
 challenge field.
 """
@@ -25,6 +26,10 @@ GEN = dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
 QUINTIC = "--quintic" in sys.argv
 if QUINTIC:
     sys.argv.remove("--quintic")
+ARITY4 = "--arity4" in sys.argv
+if ARITY4:
+    sys.argv.remove("--arity4")
+    FRI["mmcs_arity"] = 4
 D, DC = (5, 5) if QUINTIC else (4, 4)
 field = sys.argv[1] if len(sys.argv) > 1 else "koala-bear"
 oracle = oracle_lib.Oracle()
