@@ -1,6 +1,8 @@
 // ORACLE (test infrastructure): Poseidon2 width-16, PaddingFreeSponge<_,16,8,8>,
-// TruncatedPermutation<_,2,8,16>, DuplexChallenger<_,_,16,8> and MerkleTreeMmcs.
-// PARITY UNPINNED (see field.hpp).  Each function cites the in-tree restatement it follows.
+// TruncatedPermutation<_,2,8,16>, DuplexChallenger<_,_,16,8> and MerkleTreeMmcs; Poseidon2 width-32 with
+// PaddingFreeSponge<_,32,24,8>, TruncatedPermutation<_,4,8,32> and the arity-4 MerkleTreeMmcs<..,4,8>.
+// PARITY UNPINNED (see field.hpp).  Each function cites the in-tree restatement it follows; for the arity-4 tree
+// that is its in-circuit verifier (recursion/src/pcs/mmcs.rs:866-1316) - the native builder is an un-vendored crate.
 #pragma once
 #include <algorithm>
 #include <memory>
