@@ -425,3 +425,45 @@ def test_hip_reproduces_the_rust_arity4_table(oracle):
                                       np.array([r["mmcs_index_sum"] for r in rows], np.uint32), height=want.shape[0])
     assert np.array_equal(got[:len(rows)], want[:len(rows)])
     ctx.close()
+
+
+# ---- the NATIVE arity-4 MMCS (tools/rust_pin: arity4_mmcs()) - pins p3r_config.mmcs_arity = 4
+def _arity4_mmcs_cases():
+    g = load("rust_arity4_mmcs_koala_bear.json")
+    _, rc, diag = _arity4_fixture()       # the width-32 constants come from the layer fixture of the same run
+    from test_mmcs_reference_shapes import iota_matrix, mixed_height_matrices
+    mats = {"single_height": [iota_matrix(1024, 4)], "wide_leaf_multi_chunk": [iota_matrix(1024, 40)],
+            "odd_log2_height": [iota_matrix(512, 4)], "mixed_heights_with_injection": mixed_height_matrices()}
+    for name, case in g.items():
+        assert [list(m.shape) for m in mats[name]] == case["dims"], name
+        yield name, mats[name], case, (rc, diag)
+
+
+def test_rust_arity4_mmcs_oracle_tree(oracle):
+    """The oracle's arity-4 tree (oracle/hash.hpp::commit4) under upstream's width-32 constants against the native
+    MerkleTreeMmcs<.., 4, 8>: same root, same sibling list at every dumped index.  A root mismatch on `single_height`
+    alone means the leaf sponge or the 4-to-1 compression; on `odd_log2_height` only, the content of the padded
+    positions of a 2-node layer (this repo: zero digests) or a step-2 top level; on `mixed_heights_with_injection`
+    only, the bridge / injection rule."""
+    for name, mats, case, w32 in _arity4_mmcs_cases():
+        cap, tree = oracle.commit4("koala-bear", mats, w32=w32)
+        assert cap[0].tolist() == case["root"], name
+        for o in case["openings"]:
+            opened, proof = tree.open(o["index"])
+            assert opened.tolist() == [v for row in o["opened_values"] for v in row], name
+            assert proof.tolist() == o["opening_proof"], (name, o["index"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_the_rust_arity4_mmcs(oracle):
+    import plonky3_recursion_amd as p3r
+    for name, mats, case, (rc, diag) in _arity4_mmcs_cases():
+        ctx = p3r.Context(field="koala-bear", mmcs_arity=4, poseidon2_w32_rc=rc, poseidon2_w32_diag=diag)
+        cap, tree = ctx.commit(mats)
+        assert cap[0].tolist() == case["root"], name
+        for o in case["openings"]:
+            opened, proof = tree.open_batch(o["index"])
+            assert proof.tolist() == o["opening_proof"], (name, o["index"])
+            p3r.mmcs_verify(ctx.cfg, cap, [m.shape for m in mats], o["index"], opened, proof)
+        tree.free()
+        ctx.close()

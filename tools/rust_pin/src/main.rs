@@ -37,6 +37,9 @@
 //!       internal diagonal, read off the linear layer), permutation KATs, a native arity-4 tree's root and sibling list, the
 //!       rows, preprocessed columns and main trace of the width-32 Poseidon2 table, the proof bytes (tests/test_rust_pins.py::
 //!       test_rust_arity4_layer_*).
+//!   tests/golden/rust_arity4_mmcs_koala_bear.json
+//!       the NATIVE arity-4 MerkleTreeMmcs over the deterministic matrices of recursion/tests/recursive_arity4_mmcs.rs: roots and
+//!       openings (pins p3r_config.mmcs_arity = 4: schedule, sibling order, the content of padded positions).
 //!
 //! Written against the API the reference itself uses (recursion/examples/common/mod.rs:192-207,
 //! 464-486; circuit-prover/src/batch_stark_prover/tests.rs:1031-1099).  It has NOT been compiled in
@@ -642,6 +645,49 @@ fn quintic_challenge_layer() -> Value {
     quintic_layer_body!(q::MyConfig, config(), 5)
 }
 
+/// The NATIVE arity-4 MMCS (`MerkleTreeMmcs<F, F, LeafHash, Compress4, 4, 8>`, p3-merkle-tree) over the deterministic
+/// matrices of recursion/tests/recursive_arity4_mmcs.rs - a single 1024 x 4 and 512 x 4 matrix (cell i = i), the wide
+/// 1024 x 40 leaf, and `mixed_height_matrices()` (heights [512 x4, 4096 x2, 2048 x2, 8192 x2], bridge + injection
+/// levels) - with, per case, the root and the openings at the reference's indices.  This is what pins
+/// p3r_config.mmcs_arity = 4 (csrc/mmcs4.h, oracle/hash.hpp::commit4): the level schedule, the order of the siblings
+/// and - the one thing the in-tree circuit verifier cannot tell - what the native tree holds in the padding positions
+/// of a 2-node layer (this repo writes zero digests).  tests/test_rust_pins.py::test_rust_arity4_mmcs_*.
+fn arity4_mmcs() -> Value {
+    use p3_koala_bear::{KoalaBear, Poseidon2KoalaBear, default_koalabear_poseidon2_32};
+    type F = KoalaBear;
+    type Perm32 = Poseidon2KoalaBear<32>;
+    type LeafHash = PaddingFreeSponge<Perm32, 32, 24, 8>;
+    type Compress4 = TruncatedPermutation<Perm32, 4, 8, 32>;
+    type Mmcs4 = MerkleTreeMmcs<F, F, LeafHash, Compress4, 4, 8>;
+    let perm = default_koalabear_poseidon2_32();
+    let mmcs = Mmcs4::new(LeafHash::new(perm.clone()), Compress4::new(perm), 0);
+    let iota = |h: usize, w: usize| RowMajorMatrix::new((0..(h * w) as u64).map(F::from_u64).collect::<Vec<F>>(), w);
+    let mixed = || -> Vec<RowMajorMatrix<F>> {
+        [512usize, 512, 512, 512, 4096, 4096, 2048, 2048, 8192, 8192].iter().enumerate()
+            .map(|(m, &h)| RowMajorMatrix::new((0..h).map(|i| F::from_u64((m as u64 + 1) * 100_000 + i as u64)).collect::<Vec<F>>(), 1))
+            .collect()
+    };
+    let cases: Vec<(&str, Vec<RowMajorMatrix<F>>, Vec<usize>)> = vec![
+        ("single_height", vec![iota(1024, 4)], vec![0, 1, 2, 3, 5, 1023]),
+        ("wide_leaf_multi_chunk", vec![iota(1024, 40)], vec![0, 1, 2, 3, 5, 1023]),
+        ("odd_log2_height", vec![iota(512, 4)], vec![0, 1, 2, 3, 5, 27, 511]),
+        ("mixed_heights_with_injection", mixed(), vec![0, 1, 5, 8191]),
+    ];
+    let mut out = serde_json::Map::new();
+    for (name, mats, indices) in cases {
+        let dims: Vec<Vec<usize>> = mats.iter().map(|m| vec![m.height(), m.width()]).collect();
+        let (commit, pdata) = mmcs.commit(mats);
+        let openings: Vec<Value> = indices.iter().map(|&index| {
+            let o = mmcs.open_batch(index, &pdata);
+            json!({"index": index,
+                   "opened_values": o.opened_values.iter().map(|r| u32s(r)).collect::<Vec<_>>(),
+                   "opening_proof": o.opening_proof.iter().map(|d| u32s(d)).collect::<Vec<_>>()})
+        }).collect();
+        out.insert(name.to_string(), json!({"dims": dims, "root": u32s(&commit.roots()[0]), "openings": openings}));
+    }
+    Value::Object(out)
+}
+
 /// The width-32 Poseidon2 table of the arity-4 MMCS, as circuit-prover/tests/arity4_mmcs.rs proves it: a native arity-4
 /// tree (`MerkleTreeMmcs<F, F, PaddingFreeSponge<Perm32, 32, 24, 8>, TruncatedPermutation<Perm32, 4, 8, 32>, 4, 8>`) over a
 /// 64 x 4 matrix, one opening driven through `add_mmcs_verify_arity4`, the circuit proved with the W32 table under the
@@ -779,5 +825,6 @@ fn main() {
     fs::write(format!("{golden}/rust_quintic_layer_koala_bear.json"), serde_json::to_string(&quintic_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_quintic_challenge_layer_koala_bear.json"), serde_json::to_string(&quintic_challenge_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_arity4_layer_koala_bear.json"), serde_json::to_string(&arity4_layer()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_arity4_mmcs_koala_bear.json"), serde_json::to_string(&arity4_mmcs()).unwrap()).unwrap();
     println!("wrote rust_arity4_layer_koala_bear.json and rust_primitives.json, rust_fibonacci_layer_*.json, rust_fibonacci_base_layer_*.json, rust_npo_layer_*.json, rust_quintic_layer_koala_bear.json and rust_quintic_challenge_layer_koala_bear.json under {golden}");
 }
