@@ -139,6 +139,44 @@ __global__ void __launch_bounds__(256) k_copy(uint32_t* __restrict__ data) {
   for (int j = 0; j < 16; ++j) d[threadIdx.x + 256 * j] = x[j] + 1;
 }
 
+// `regs` as PERSISTENT workgroups whose NEXT tile streams from HBM straight into LDS (global_load_lds_dwordx4: no
+// destination registers, so the bytes in flight are not bounded by the register file) while the current tile is
+// transformed: does decoupling the loads from the lanes close the gap between a pass and max(arithmetic, copy)?
+//   wait vmcnt(0) (the tile issued one iteration ago + the previous stores) -> barrier -> issue the next tile into the
+//   other buffer -> read this lane's 16 cells from LDS -> barrier -> 12 stages -> 16 stores
+__global__ void __launch_bounds__(256) k_regs_glds(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, uint32_t n_tiles) {
+  __shared__ uint32_t tws[(1u << LOG_R) / 2];
+  __shared__ __attribute__((aligned(16))) uint32_t buf[2][1u << LOG_R];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6;
+  for (uint32_t i = tid; i < (1u << LOG_R) / 2; i += 256) tws[i] = tw[i];
+  auto issue = [&](uint32_t tile, int b) {
+    const uint32_t* src = data + ((size_t)tile << LOG_R);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)   // 256 lanes x 16 B = 4 KB per step; a wave's 64 lanes land in 1 KB of consecutive LDS
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (j * 256 + tid) * 4),
+                                       (__attribute__((address_space(3))) void*)(&buf[b][(j * 256 + wave * 64) * 4]), 16, 0, 0);
+  };
+  uint32_t tile = blockIdx.x;
+  if (tile < n_tiles) issue(tile, 0);
+  int cur = 0;
+  for (; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this tile is in LDS
+    __builtin_amdgcn_s_barrier();
+    if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x, cur ^ 1);
+    F x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = F::raw(buf[cur][tid + 256 * j]);
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the reads above are done before anyone refills this buffer
+    __builtin_amdgcn_s_barrier();
+    ntt2_stages<PP, LOG_R, 0, 4, false>(x, tws, tid);
+    ntt2_stages<PP, LOG_R, 4, 4, false>(x, tws, tid & 15);
+    ntt2_stages<PP, LOG_R, 8, 4, true>(x, (const uint32_t*)nullptr, 0);
+    uint32_t* d = data + ((size_t)tile << LOG_R);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d[tid + 256 * j] = x[j].v;
+  }
+}
+
 template <class Fn>
 float time_ms(Fn&& launch, int reps = 5) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -172,6 +210,10 @@ int main(int argc, char** argv) {
   printf("line      %.3f ms  %.2f T butterflies/s  %.0f GB/s\n", t, bf / t / 1e9, cells * 8.0 / t / 1e6);
   t = time_ms([&] { hipLaunchKernelGGL(k_regs, dim3(blocks), dim3(256), 0, 0, data, dtw); });
   printf("regs      %.3f ms  %.2f T butterflies/s  %.0f GB/s\n", t, bf / t / 1e9, cells * 8.0 / t / 1e6);
+  for (unsigned per_cu : {2u, 3u, 4u}) {
+    t = time_ms([&] { hipLaunchKernelGGL(k_regs_glds, dim3(256 * per_cu), dim3(256), 0, 0, data, dtw, blocks); });
+    printf("regs_glds %.3f ms  %.2f T butterflies/s  %.0f GB/s   (%u persistent workgroups per CU)\n", t, bf / t / 1e9, cells * 8.0 / t / 1e6, per_cu);
+  }
   t = time_ms([&] { hipLaunchKernelGGL(k_regs_f64, dim3(blocks), dim3(256), 0, 0, data, dtwd); });
   printf("regs_f64  %.3f ms  %.2f T butterflies/s  %.0f GB/s\n", t, bf / t / 1e9, cells * 8.0 / t / 1e6);
   t = time_ms([&] { hipLaunchKernelGGL(k_regs_rep<2>, dim3(blocks), dim3(256), 0, 0, data, dtw); });
