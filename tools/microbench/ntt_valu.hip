@@ -144,7 +144,14 @@ __global__ void __launch_bounds__(256) k_copy(uint32_t* __restrict__ data) {
 // transformed: does decoupling the loads from the lanes close the gap between a pass and max(arithmetic, copy)?
 //   wait vmcnt(0) (the tile issued one iteration ago + the previous stores) -> barrier -> issue the next tile into the
 //   other buffer -> read this lane's 16 cells from LDS -> barrier -> 12 stages -> 16 stores
+template <int SKEW>
 __global__ void __launch_bounds__(256) k_regs_glds(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, uint32_t n_tiles) {
+  // SKEW: the persistent workgroups of a CU start a fraction of a tile period apart (blockIdx / 256 is the slot on
+  // the CU under round-robin placement), so that they do not all load, then all compute, then all store together
+  if (SKEW) {
+    const int slot = blockIdx.x / 256;
+    for (int k = 0; k < slot; ++k) __builtin_amdgcn_s_sleep(SKEW);
+  }
   __shared__ uint32_t tws[(1u << LOG_R) / 2];
   __shared__ __attribute__((aligned(16))) uint32_t buf[2][1u << LOG_R];
   const uint32_t tid = threadIdx.x, wave = tid >> 6;
@@ -211,8 +218,12 @@ int main(int argc, char** argv) {
   t = time_ms([&] { hipLaunchKernelGGL(k_regs, dim3(blocks), dim3(256), 0, 0, data, dtw); });
   printf("regs      %.3f ms  %.2f T butterflies/s  %.0f GB/s\n", t, bf / t / 1e9, cells * 8.0 / t / 1e6);
   for (unsigned per_cu : {2u, 3u, 4u}) {
-    t = time_ms([&] { hipLaunchKernelGGL(k_regs_glds, dim3(256 * per_cu), dim3(256), 0, 0, data, dtw, blocks); });
+    t = time_ms([&] { hipLaunchKernelGGL(k_regs_glds<0>, dim3(256 * per_cu), dim3(256), 0, 0, data, dtw, blocks); });
     printf("regs_glds %.3f ms  %.2f T butterflies/s  %.0f GB/s   (%u persistent workgroups per CU)\n", t, bf / t / 1e9, cells * 8.0 / t / 1e6, per_cu);
+    t = time_ms([&] { hipLaunchKernelGGL(k_regs_glds<40>, dim3(256 * per_cu), dim3(256), 0, 0, data, dtw, blocks); });
+    printf("  skewed  %.3f ms   (slot k starts k x 1.1 us late)\n", t);
+    t = time_ms([&] { hipLaunchKernelGGL(k_regs_glds<100>, dim3(256 * per_cu), dim3(256), 0, 0, data, dtw, blocks); });
+    printf("  skewed  %.3f ms   (slot k starts k x 2.7 us late)\n", t);
   }
   t = time_ms([&] { hipLaunchKernelGGL(k_regs_f64, dim3(blocks), dim3(256), 0, 0, data, dtwd); });
   printf("regs_f64  %.3f ms  %.2f T butterflies/s  %.0f GB/s\n", t, bf / t / 1e9, cells * 8.0 / t / 1e6);
