@@ -40,7 +40,7 @@ std::vector<uint32_t> arr(const Synth& s, void* h, const char* name) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: %s <field> <log_height> <proof_out> [layers] [--quintic]\n", argv[0]); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: %s <field> <log_height> <proof_out> [layers] [--quintic | --arity4]\n", argv[0]); return 2; }
   try {
     const p3r::Field field = std::string(argv[1]) == "baby-bear" ? p3r::Field::BabyBear : p3r::Field::KoalaBear;
     const int log_h = std::atoi(argv[2]);
@@ -48,11 +48,15 @@ int main(int argc, char** argv) {
     // --quintic (recursive_fibonacci.rs:515): KoalaBear, a D = 5 verifier circuit (base-mode Poseidon2 permutations,
     // both Recompose kinds) under koala_bear_quintic_params, i.e. Challenge = the quintic field as well
     const bool quintic = argc > 5 && std::string(argv[5]) == "--quintic";
+    // --arity4 (recursive_aggregation.rs:902-1046 `--arity4`): the PCS commits with MyMmcsArity4 - 4-to-1 trees over the
+    // width-32 permutation, the challenger stays on width 16
+    const bool arity4 = argc > 5 && std::string(argv[5]) == "--arity4";
     const uint32_t D = quintic ? 5 : 4;
     std::string self = argv[0];
     const std::string root = self.substr(0, self.rfind('/')) + "/..";
 
     p3r::FriParams fri;  // the examples' defaults: blow-up 4, 54 queries, 15 bits of query PoW
+    if (arity4) fri.mmcs_arity = 4;
     p3r::Context ctx(field, fri, 0, {}, D, 0, quintic ? 5 : 4);
     std::vector<uint32_t> rc(p3r_poseidon2_num_constants(ctx.raw()));
     ctx.check(p3r_poseidon2_round_constants(ctx.raw(), rc.data()));

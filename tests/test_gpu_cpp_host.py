@@ -72,6 +72,31 @@ def test_cpp_host_quintic_layer(oracle, tmp_path):
     ctx.close()
 
 
+def test_cpp_host_arity4_layer(oracle, tmp_path):
+    """`prove_next_layer <field> <log_h> <out> <layers> --arity4`: the compiled caller with `FriParams::mmcs_arity = 4`
+    (MyMmcsArity4: 4-to-1 trees over the width-32 permutation) gives the bytes of the Python binding and of the oracle."""
+    import plonky3_recursion_amd as p3r
+    import harness_adapters as wl
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    out_file = str(tmp_path / "proof4.bin")
+    r = subprocess.run([EXE, "baby-bear", "10", out_file, "2", "--arity4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verify_all_tables ok" in r.stdout
+    got = open(out_file, "rb").read()
+    a = harness_lib.generate("baby-bear", 10, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
+    fri = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15,
+               num_queries=54, mmcs_arity=4)
+    ctx = p3r.Context(field="baby-bear", **fri)
+    tp = p3r.TablePacking().with_fri_params(5, 2)
+    pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
+    assert pc.prove(wl.circuit_inputs_from_arrays(a)) == got
+    L = layer_lib.OracleLayer(oracle, "baby-bear", a, layer_lib.params(**fri))
+    assert np.array_equal(pc.circuit_prover_data.preprocessed_commitment, L.prep_commit())
+    assert L.prove() == got
+    pc.free()
+    ctx.close()
+
+
 def test_fallback_paths_give_the_same_proof(tmp_path):
     """The tuning knobs exist in the `knobs` build of the library only (plonky3_recursion_amd/knobs/libp3r_hip.so,
     -DP3R_TUNING_KNOBS; the product build compiles them out).  The paths they select (copy-engine fetches instead
