@@ -64,6 +64,9 @@ typedef struct orc_params {
   uint8_t proof_layout[18];   // twin of p3r_config.proof_layout; all zero = identity
   uint32_t challenge_degree;  // 0 / 4: the quartic challenge field; 5: KoalaBear's quintic trinomial extension
   uint32_t mmcs_arity;        // 0 / 2: binary trees over the width-16 permutation; 4: the arity-4 MMCS (width 32)
+  // ZK: HidingFriPcs (create_config_zk, recursion/examples/common/mod.rs:511-553); twins of p3r_config.zk*
+  uint32_t zk, num_random_codewords;
+  uint64_t zk_seed, zk_nonce;
 } orc_params;
 
 const char* orc_last_error();
@@ -105,6 +108,10 @@ StarkParams to_sp(const orc_params& p) {
   s.query_pow_bits = p.query_pow_bits; s.num_queries = p.num_queries;
   s.lookup_unpacked = (p.ext_choices & 1u) != 0;
   s.mmcs_arity = p.mmcs_arity == 4 ? 4 : 2;
+  s.zk = p.zk != 0;
+  s.num_random_codewords = p.zk ? (p.num_random_codewords ? (int)p.num_random_codewords : 2) : 0;
+  if (s.zk && (s.num_random_codewords < 1 || s.num_random_codewords > 8)) throw std::runtime_error("num_random_codewords must be in 1..8");
+  s.zk_seed = p.zk_seed; s.zk_nonce = p.zk_nonce;
   for (uint32_t i = 0; i < p.n_fri_log_arities && i < 32; ++i) s.fri_log_arities.push_back(p.fri_log_arities[i]);
   return s;
 }
@@ -268,8 +275,11 @@ struct Layer : LayerBase {
     const auto& m = which == 0 ? insts.at(i).main : insts.at(i).prep;
     for (size_t k = 0; k < m.v.size(); ++k) out[k] = m.v[k].v;
   }
+  int pd_zk = -1;
   void ensure_pd(const orc_params& p) {
-    if (!pd) pd = std::make_unique<ProverData<FP>>(make_prover_data<FP>(p2, to_sp(p), insts));
+    const int z = p.zk ? (int)to_sp(p).num_random_codewords : 0;
+    if (!pd || pd_zk != z) pd = std::make_unique<ProverData<FP>>(make_prover_data<FP>(p2, to_sp(p), insts));
+    pd_zk = z;
   }
   void prep_commit(const orc_params& p, uint32_t* cap_out) override {
     ensure_pd(p);
@@ -281,7 +291,7 @@ struct Layer : LayerBase {
     return serialize_proof<FP>(proof, enc, to_layout(p));
   }
   void verify(const orc_params& p, const uint32_t* prep_cap, const uint8_t* bytes, size_t n, int enc) const override {
-    auto proof = deserialize_proof<FP>(bytes, n, enc, to_layout(p));
+    auto proof = deserialize_proof<FP>(bytes, n, enc, to_layout(p), p.zk != 0);
     std::vector<InstanceShape> shapes;
     for (auto& in : insts) shapes.push_back({in.air});
     typename BatchProof<FP>::Cap cap(size_t(1) << p.cap_height);
@@ -343,7 +353,7 @@ int orc_verify_batch(int field, const uint32_t* rc, const orc_params* p, size_t 
       using FP = decltype(tag);
       using F = Fe<FP>;
       Poseidon2<FP> p2(rc);
-      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p));
+      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p), p->zk != 0);
       std::vector<InstanceShape> shapes;
       for (size_t i = 0; i < n_airs; ++i) {
         AirDesc a;
@@ -374,7 +384,7 @@ int orc_verify_batch_w32(int field, const uint32_t* rc, const uint32_t* w32_rc, 
       using F = Fe<FP>;
       Poseidon2<FP> p2(rc);
       p2.w32 = std::make_shared<Poseidon2W32<FP>>(w32_rc, w32_diag);
-      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p));
+      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p), p->zk != 0);
       std::vector<InstanceShape> shapes;
       for (size_t i = 0; i < n_airs; ++i) {
         AirDesc a;

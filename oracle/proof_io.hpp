@@ -58,7 +58,7 @@ std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_EN
     w.cap(p.main_commit);
     if (p.has_permutation) { w.some(); w.cap(p.permutation_commit); } else w.none();
     w.cap(p.quotient_commit);
-    w.none();
+    if (p.has_random) { w.some(); w.cap(p.random_commit); } else w.none();
   };
   auto opened = [&] {  // { instances: Vec<OpenedValuesWithLookups> }
     w.varint(p.opened.size());
@@ -72,7 +72,7 @@ std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_EN
           w.varint(ov.quotient_chunks.size());
           for (auto& c : ov.quotient_chunks) w.vec_ef(c);
           break;
-        case 5: w.none(); break;  // random
+        case 5: if (ov.has_random) { w.some(); w.vec_ef(ov.random); } else w.none(); break;  // random: Option<Vec<Challenge>>
         case 6: w.vec_ef(ov.permutation_local); break;
         default: w.vec_ef(ov.permutation_next); break;
       }
@@ -97,7 +97,17 @@ std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_EN
       }
     }
   };
-  auto fri = [&] {  // opening_proof: FriProof
+  auto fri = [&] {  // opening_proof: FriProof; HidingFriPcs::Proof = (OpenedValues<Challenge>, FriProof) - a tuple, no framing
+    if (p.has_random) {
+      w.varint(p.fri_random.size());
+      for (auto& rd : p.fri_random) {
+        w.varint(rd.size());
+        for (auto& m : rd) {
+          w.varint(m.size());
+          for (auto& pt : m) w.vec_ef(pt);
+        }
+      }
+    }
     for (int k = 0; k < 5; ++k) switch (L.fri[k]) {
       case 0:
         w.varint(f.commit_phase_commits.size());
@@ -162,7 +172,10 @@ struct Reader {
 };
 
 template <class FP>
-BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_ENCODING_MONTY, const Layout& L = Layout{}) {
+// `zk`: the proof type is the hiding PCS's (the opening proof is the tuple above): a property of the configuration, as
+// SC::Pcs is in the reference - not something the bytes announce.
+BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_ENCODING_MONTY, const Layout& L = Layout{},
+                                 bool zk = false) {
   Reader<FP> r{data, data + n, enc};
   BatchProof<FP> p;
   auto commitments = [&] {
@@ -170,7 +183,8 @@ BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_
     p.has_permutation = r.option();
     if (p.has_permutation) p.permutation_commit = r.cap();
     p.quotient_commit = r.cap();
-    if (r.option()) throw std::runtime_error("random commitment present (ZK unsupported)");
+    p.has_random = r.option();
+    if (p.has_random) p.random_commit = r.cap();
   };
   auto opened = [&] {
     size_t ni = r.len();
@@ -187,7 +201,7 @@ BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_
           for (auto& c : ov.quotient_chunks) c = r.vec_ef();
           break;
         }
-        case 5: if (r.option()) throw std::runtime_error("random opened values present (ZK unsupported)"); break;
+        case 5: ov.has_random = r.option(); if (ov.has_random) ov.random = r.vec_ef(); break;
         case 6: ov.permutation_local = r.vec_ef(); break;
         default: ov.permutation_next = r.vec_ef(); break;
       }
@@ -219,6 +233,16 @@ BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_
     }
   };
   auto fri = [&] {
+    if (zk) {
+      p.fri_random.resize(r.len());
+      for (auto& rd : p.fri_random) {
+        rd.resize(r.len());
+        for (auto& m : rd) {
+          m.resize(r.len());
+          for (auto& pt : m) pt = r.vec_ef();
+        }
+      }
+    }
     for (int k = 0; k < 5; ++k) switch (L.fri[k]) {
       case 0: {
         size_t np = r.len();

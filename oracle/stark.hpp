@@ -13,6 +13,9 @@
 //   selectors                   recursion/src/pcs/fri/targets.rs:868-908
 //   constraint folding          recursion/src/traits/air.rs:162-182
 //   FRI                         recursion/src/pcs/fri/targets.rs:748-866, verifier.rs:424-1838
+//   ZK (HidingFriPcs)           recursion/src/verifier/batch_stark.rs:424-428 (presence), :487-490,536 (degrees),
+//                               :623-661 (random commitment / round), :701-735 (quotient domains), :855-864 and
+//                               :1116-1260 (FRI random opened values), pcs/fri/targets.rs:1076-1130 (merge)
 //
 // Choices that upstream leaves un-pinned and that DESIGN.md section "EXT choices" lists:
 // LogUp per-row constraint polynomials and same-bus packing rule, FRI arity schedule rule,
@@ -33,7 +36,33 @@ struct StarkParams {
   // fri_log_arities, include/p3r.h)
   bool lookup_unpacked = false;
   std::vector<int> fri_log_arities;
+  // ZK: the configuration of create_config_zk (recursion/examples/common/mod.rs:511-553): HidingFriPcs with
+  // `num_random_codewords` = 2 over the SAME (non-hiding) MMCS.  The prover side of HidingFriPcs lives in the
+  // un-vendored p3-fri crate and its proofs are randomised, so byte parity with upstream is undefined: the
+  // construction below is written from the acceptance conditions of the in-tree verifier (cited at each step) and
+  // shared with the HIP prover, random values included (zk_rand below), so that HIP == oracle stays a byte check.
+  bool zk = false;
+  int num_random_codewords = 2;
+  uint64_t zk_seed = 0;    // SmallRng::seed_from_u64(rng_seed)'s counterpart
+  uint64_t zk_nonce = 0;   // proofs made so far under this configuration (the PCS's RNG state advances per commit)
 };
+
+// ------------------------------------------------------------------ ZK randomness
+// Counter-based generator shared with the device (csrc/zk_rand.h): cell `idx` of stream `stream` of proof `nonce`.
+// Streams: (round << 20) | matrix, rounds 0 random, 1 main, 2 quotient, 4 permutation, 5 quotient masks.
+inline uint64_t zk_mix64(uint64_t z) {
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return z;
+}
+inline uint64_t zk_stream_key(uint64_t seed, uint64_t nonce, uint32_t stream) {
+  return zk_mix64(seed ^ zk_mix64(nonce * 0x9E3779B97F4A7C15ull + (uint64_t)stream + 1));
+}
+template <class FP>
+Fe<FP> zk_rand(uint64_t key, uint64_t idx) { return Fe<FP>(zk_mix64(key + idx * 0x9E3779B97F4A7C15ull) % FP::P); }
+enum { ZK_ROUND_RANDOM = 0, ZK_ROUND_MAIN = 1, ZK_ROUND_QUOTIENT = 2, ZK_ROUND_PREP = 3, ZK_ROUND_PERM = 4, ZK_ROUND_QMASK = 5 };
+inline uint32_t zk_stream(int round, size_t mat) { return ((uint32_t)round << 20) | (uint32_t)mat; }
 
 template <class FP>
 struct Instance {
@@ -77,6 +106,8 @@ struct OpenedValues {
   std::vector<EF> preprocessed_local, preprocessed_next;   // always present for circuit tables
   std::vector<std::vector<EF>> quotient_chunks;
   std::vector<EF> permutation_local, permutation_next;     // flattened aux columns (aux_width * 4)
+  bool has_random = false;
+  std::vector<EF> random;                                  // ZK: the random polynomial at zeta, Challenge::DIMENSION values
 };
 template <class FP>
 struct BatchProof {
@@ -87,7 +118,12 @@ struct BatchProof {
   FriProof<FP> fri;
   std::vector<bool> has_terminal;
   std::vector<Fe4<FP>> lookup_terminals;                   // per instance (valid iff has_terminal)
-  std::vector<size_t> degree_bits;
+  std::vector<size_t> degree_bits;                         // ZK: EXTENDED degree bits (base + 1)
+  // ZK (HidingFriPcs): commitment of the random round; opening_proof = (OpenedValues, FriProof) whose first item are
+  // the values of the random codeword columns, rounds -> matrices -> points -> num_random_codewords values
+  bool has_random = false;
+  Cap random_commit;
+  std::vector<std::vector<std::vector<std::vector<Fe4<FP>>>>> fri_random;
 };
 
 // ------------------------------------------------------------------ LogUp
@@ -138,14 +174,17 @@ struct LookupLayout {
 // Lookups::from_air + get_log_num_quotient_chunks + pack_same_bus(budget = 2^log_chunks + 1)
 // (circuit-prover/src/batch_stark_prover.rs:925-941).  Packing rule: greedy in declaration
 // order while the packed constraint degree stays within the budget.
+// is_zk: get_log_num_quotient_chunks(.., is_zk) = log2_ceil(max(degree + is_zk, 2) - 1) and
+// budget = 2^log_chunks + 1 - is_zk (batch_stark_prover.rs:931-939).
 template <class FP>
-LookupLayout lookup_layout(const AirDesc& a, bool unpacked = false) {
+LookupLayout lookup_layout(const AirDesc& a, bool unpacked = false, int is_zk = 0) {
   LookupLayout L;
   auto md = interaction_mult_degrees(a);
-  int max_deg = std::max(air_base_constraint_degree<FP>(a), 2);
+  int max_deg = air_base_constraint_degree<FP>(a);
   for (size_t i = 0; i < md.size(); ++i) max_deg = std::max(max_deg, group_degree(md, {(int)i}));
+  max_deg = std::max(max_deg + is_zk, 2);
   L.log_quotient_chunks = log2_ceil(max_deg - 1);
-  const int budget = (1 << L.log_quotient_chunks) + 1;
+  const int budget = (1 << L.log_quotient_chunks) + 1 - is_zk;
   std::vector<int> cur;
   for (size_t i = 0; i < md.size(); ++i) {
     auto trial = cur;
@@ -287,18 +326,43 @@ Committed<FP> commit_ldes(const Poseidon2<FP>& p2, std::vector<Matrix<FP>> ldes,
   return c;
 }
 
+// HidingFriPcs::commit on one matrix (p3-fri, un-vendored; the acceptance side is batch_stark.rs:629-661: the matrix
+// is opened over the EXTENDED trace domain of size 2h, and its first w columns at zeta / zeta * g_h must be the trace
+// polynomial's): the h x w evaluations become 2h x (w + R) - row 2i = [row i | R random values], row 2i + 1 all
+// random - i.e. the interpolant over <g_2h> agrees with the trace on <g_h> = even powers of g_2h, and the last R
+// columns are the random codewords FRI batches in.  zero_fill: the preprocessed round (public data, committed once
+// per circuit shape: its padding is zeros so that the commitment does not depend on the seed).
+template <class FP>
+Matrix<FP> zk_randomize(const Matrix<FP>& m, int R, uint64_t key, bool zero_fill) {
+  using F = Fe<FP>;
+  const size_t w2 = m.w + (size_t)R;
+  Matrix<FP> o(2 * m.h, w2);
+  for (size_t r = 0; r < 2 * m.h; ++r)
+    for (size_t c = 0; c < w2; ++c) {
+      if (!(r & 1) && c < m.w) o.at(r, c) = m.at(r / 2, c);
+      else o.at(r, c) = zero_fill ? F::zero() : zk_rand<FP>(key, r * w2 + c);
+    }
+  return o;
+}
+
 // Preprocessed commitment shared by every proof of a circuit shape
 // (ProverData::from_airs_and_degrees; recursion/src/recursion.rs:376).
 template <class FP>
 struct ProverData {
   Committed<FP> prep;
+  std::vector<Matrix<FP>> evals;   // the committed evaluations over the (ZK: extended) trace domain
 };
 template <class FP>
 ProverData<FP> make_prover_data(const Poseidon2<FP>& p2, const StarkParams& sp,
                                 const std::vector<Instance<FP>>& insts) {
+  ProverData<FP> pd;
   std::vector<Matrix<FP>> ldes;
-  for (auto& in : insts) ldes.push_back(coset_lde_bitrev<FP>(in.prep, sp.log_blowup, Fe<FP>::generator()));
-  return {commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity)};
+  for (auto& in : insts) {
+    pd.evals.push_back(sp.zk ? zk_randomize<FP>(in.prep, sp.num_random_codewords, 0, true) : in.prep);
+    ldes.push_back(coset_lde_bitrev<FP>(pd.evals.back(), sp.log_blowup, Fe<FP>::generator()));
+  }
+  pd.prep = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity);
+  return pd;
 }
 
 // ------------------------------------------------------------------ FRI
@@ -434,6 +498,12 @@ struct AuxTrace {
   Fe4<FP> terminal;
 };
 
+// Evaluations of a polynomial of degree < h, given over a * <w_h> (natural order), over b * <w_h>.
+template <class FP>
+std::vector<Fe<FP>> coset_move(const std::vector<Fe<FP>>& evals, Fe<FP> a, Fe<FP> b) {
+  return coset_dft<FP>(idft<FP>(evals), 0, b * a.inv());
+}
+
 template <class FP>
 BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
                            const std::vector<Instance<FP>>& insts, const ProverData<FP>& pd) {
@@ -441,30 +511,38 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   using EF = Fe4<FP>;
   const size_t ni = insts.size();
   const F gen = F::generator();
+  const int zk = sp.zk ? 1 : 0, R = zk ? sp.num_random_codewords : 0;
+  const int DC = EF::deg();
+  auto key = [&](int round, size_t mat) { return zk_stream_key(sp.zk_seed, sp.zk_nonce, zk_stream(round, mat)); };
   BatchProof<FP> proof;
   Challenger<FP> ch(&p2);
-  std::vector<int> log_n(ni);
+  std::vector<int> log_n(ni), log_e(ni);   // base / extended (committed) trace degree bits
   std::vector<LookupLayout> layouts(ni);
   for (size_t i = 0; i < ni; ++i) {
     log_n[i] = log2_strict(insts[i].main.h);
+    log_e[i] = log_n[i] + zk;
     if ((int)insts[i].main.w != air_width<FP>(insts[i].air)) throw std::runtime_error("main width mismatch");
     if ((int)insts[i].prep.w != air_prep_width(insts[i].air) || insts[i].prep.h != insts[i].main.h)
       throw std::runtime_error("preprocessed shape mismatch");
-    layouts[i] = lookup_layout<FP>(insts[i].air, sp.lookup_unpacked);
-    proof.degree_bits.push_back(log_n[i]);
+    layouts[i] = lookup_layout<FP>(insts[i].air, sp.lookup_unpacked, zk);
+    proof.degree_bits.push_back(log_e[i]);
   }
-  // 1. commit main traces (one MMCS over all instances)
-  std::vector<Matrix<FP>> main_ldes;
-  for (auto& in : insts) main_ldes.push_back(coset_lde_bitrev<FP>(in.main, sp.log_blowup, gen));
+  if (pd.evals.size() != ni) throw std::runtime_error("prover data of another batch");
+  // 1. commit main traces (one MMCS over all instances); ZK: randomised over the extended domain
+  std::vector<Matrix<FP>> main_ev(ni), main_ldes;
+  for (size_t i = 0; i < ni; ++i) {
+    main_ev[i] = zk ? zk_randomize<FP>(insts[i].main, R, key(ZK_ROUND_MAIN, i), false) : insts[i].main;
+    main_ldes.push_back(coset_lde_bitrev<FP>(main_ev[i], sp.log_blowup, gen));
+  }
   auto main_c = commit_ldes<FP>(p2, std::move(main_ldes), sp.cap_height, sp.mmcs_arity);
   proof.main_commit = main_c.cap;
-  // 2. transcript head (batch_stark.rs:521-578)
+  // 2. transcript head (batch_stark.rs:521-578): extended degree bits, base degree bits, width, chunk count
   ch.observe_base_as_ext(F((uint64_t)ni));
   for (size_t i = 0; i < ni; ++i) {
-    ch.observe_base_as_ext(F((uint64_t)log_n[i]));  // ext degree bits (no ZK)
-    ch.observe_base_as_ext(F((uint64_t)log_n[i]));  // base degree bits
+    ch.observe_base_as_ext(F((uint64_t)log_e[i]));
+    ch.observe_base_as_ext(F((uint64_t)log_n[i]));
     ch.observe_base_as_ext(F((uint64_t)insts[i].main.w));
-    ch.observe_base_as_ext(F(uint64_t(1) << layouts[i].log_quotient_chunks));
+    ch.observe_base_as_ext(F(uint64_t(1) << (layouts[i].log_quotient_chunks + zk)));   // :490
   }
   for (auto& d : proof.main_commit) ch.observe_arr(d);
   // (public values: the circuit tables have none)
@@ -476,6 +554,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   LookupChallenges<FP> lc{};
   if (any_lookup) lc = sample_lookup_challenges<FP>(ch, insts[0].air.D);
   std::vector<AuxTrace<FP>> aux(ni);
+  std::vector<Matrix<FP>> aux_ev(ni);
   proof.has_terminal.assign(ni, false);
   proof.lookup_terminals.assign(ni, EF::zero());
   std::vector<int> perm_insts;
@@ -485,7 +564,6 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     const auto& in = insts[i];
     const size_t n = in.main.h;
     const int aw = L.aux_width();
-    const int DC = EF::deg();
     aux[i].flat = Matrix<FP>(n, aw * DC);
     // the fractions of a row depend on that row only (parallel); the running sum is a serial prefix
 #pragma omp parallel for schedule(static) if (n >= 1024)
@@ -523,7 +601,11 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   Committed<FP> perm_c;
   if (any_lookup) {
     std::vector<Matrix<FP>> ldes;
-    for (int i : perm_insts) ldes.push_back(coset_lde_bitrev<FP>(aux[i].flat, sp.log_blowup, gen));
+    for (size_t k = 0; k < perm_insts.size(); ++k) {
+      const int i = perm_insts[k];
+      aux_ev[i] = zk ? zk_randomize<FP>(aux[i].flat, R, key(ZK_ROUND_PERM, k), false) : aux[i].flat;
+      ldes.push_back(coset_lde_bitrev<FP>(aux_ev[i], sp.log_blowup, gen));
+    }
     perm_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity);
     proof.has_permutation = true;
     proof.permutation_commit = perm_c.cap;
@@ -533,15 +615,17 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   }
   // 4. constraint-folding challenge, quotients
   EF alpha = ch.sample_ext();
-  std::vector<Matrix<FP>> q_chunk_evals;   // per (instance, chunk): n x 4 over its chunk coset
+  std::vector<Matrix<FP>> q_chunk_evals;   // per (instance, chunk): the committed evaluations over its chunk coset
   std::vector<F> q_chunk_shift;
   std::vector<std::pair<int, int>> q_chunk_owner;
   for (size_t i = 0; i < ni; ++i) {
     const auto& in = insts[i];
     const auto& L = layouts[i];
-    const int lq = L.log_quotient_chunks, C = 1 << lq;
+    // quotient domain: ext_dom.create_disjoint_domain(1 << (base_db + log_qd + is_zk)), 2^(log_qd + is_zk) chunks
+    // (batch_stark.rs:701-717)
+    const int lq = L.log_quotient_chunks + zk, C = 1 << lq;
     const size_t n = in.main.h, qn = n << lq;
-    if (lq > sp.log_blowup) throw std::runtime_error("quotient domain larger than the LDE");
+    if (L.log_quotient_chunks > sp.log_blowup) throw std::runtime_error("quotient domain larger than the LDE");
     // evaluations on the quotient coset gen*<w_qn>, natural order = first qn rows of the
     // bit-reversed LDE, un-reversed (Pcs::get_evaluations_on_domain)
     auto on_q = [&](const Matrix<FP>& lde) {
@@ -553,7 +637,6 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     int perm_pos = -1;
     for (size_t k = 0; k < perm_insts.size(); ++k) if (perm_insts[k] == (int)i) perm_pos = (int)k;
     if (perm_pos >= 0) aq = on_q(perm_c.ldes[perm_pos]);
-    const int DC = EF::deg();
     Matrix<FP> qflat(qn, DC);
     const F wq = F::two_adic_generator(log_n[i] + lq);
     const int aw = L.aux_width();
@@ -565,7 +648,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
 #pragma omp parallel for schedule(static) if (qn >= 1024)
     for (size_t r = 0; r < qn; ++r) {
       const F x = xs[r];
-      size_t rn = (r + C) % qn;
+      size_t rn = (r + C) % qn;   // x * g_n: the next row of the BASE trace domain
       EvalCtx<FP, F> b;
       b.local = &mq.v[r * mq.w]; b.next = &mq.v[rn * mq.w];
       b.prep_local = &pq.v[r * pq.w]; b.prep_next = &pq.v[rn * pq.w];
@@ -588,12 +671,65 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
       for (int k = 0; k < DC; ++k) qflat.at(r, k) = q.c[k];
     }
     // split_evals: chunk c = rows c, c+C, ... ; split_domains: shift gen * wq^c
+    std::vector<Matrix<FP>> ce(C, Matrix<FP>(n, DC));
+    std::vector<F> sh(C);
     for (int c = 0; c < C; ++c) {
-      Matrix<FP> ce(n, DC);
       for (size_t r = 0; r < n; ++r)
-        for (int k = 0; k < DC; ++k) ce.at(r, k) = qflat.at(r * C + c, k);
-      q_chunk_evals.push_back(ce);
-      q_chunk_shift.push_back(gen * wq.pow(c));
+        for (int k = 0; k < DC; ++k) ce[c].at(r, k) = qflat.at(r * C + c, k);
+      sh[c] = gen * wq.pow(c);
+    }
+    if (zk) {
+      // HidingFriPcs::commit_quotient, from the acceptance side: the verifier opens chunk c over
+      // natural_domain_for_degree(2n) (batch_stark.rs:719-727) and recomposes quotient(zeta) = sum_c zp_c(zeta) q'_c(zeta),
+      // zp_c(x) = prod_{j != c} Z_j(x) / Z_j(s_c), Z_j(x) = (x / s_j)^n - 1 (verifier/quotient.rs).  q'_c = q_c + Z_c t_c
+      // leaves the sum unchanged iff sum_c k_c t_c = 0 with k_c = prod_{j != c} 1 / Z_j(s_c): C - 1 independent random
+      // t_c of degree < n and t_{C-1} = -(1 / k_{C-1}) sum_{c < C-1} k_c t_c (eprint 2024/1037's chunk masking).
+      // Each t_c (c < C - 1) is given by n random evaluations over U = u * <g_n>, u = s_{C-1} * g_2n; the committed matrix
+      // of chunk c is q'_c over s_c * <g_2n>: even rows q_c (the chunk evaluations), odd rows q_c - 2 t_c on
+      // s_c g_2n <g_n> (Z_c = g_2n^n - 1 = -2 there), plus R fully random codeword columns.
+      const F g2 = F::two_adic_generator(log_n[i] + 1);
+      const F u = sh[C - 1] * g2;
+      std::vector<F> kc(C);
+      for (int c = 0; c < C; ++c) {
+        F d = F::one();
+        for (int j = 0; j < C; ++j)
+          if (j != c) d *= (sh[c] * sh[j].inv()).pow(uint64_t(1) << log_n[i]) - F::one();
+        kc[c] = d.inv();
+      }
+      std::vector<Matrix<FP>> tU(C, Matrix<FP>(n, DC));   // t_c over U
+      for (int c = 0; c + 1 < C; ++c) {
+        const uint64_t tk = key(ZK_ROUND_QMASK, q_chunk_evals.size() + c);
+        for (size_t r = 0; r < n; ++r)
+          for (int k = 0; k < DC; ++k) tU[c].at(r, k) = zk_rand<FP>(tk, r * DC + k);
+      }
+      const F neg_inv_last = -(kc[C - 1].inv());
+      for (size_t r = 0; r < n; ++r)
+        for (int k = 0; k < DC; ++k) {
+          F acc = F::zero();
+          for (int c = 0; c + 1 < C; ++c) acc += kc[c] * tU[c].at(r, k);
+          tU[C - 1].at(r, k) = acc * neg_inv_last;
+        }
+      for (int c = 0; c < C; ++c) {
+        const uint64_t ck = key(ZK_ROUND_QUOTIENT, q_chunk_evals.size() + c);
+        const size_t w2 = (size_t)DC + R;
+        Matrix<FP> m(2 * n, w2);
+        for (int k = 0; k < DC; ++k) {
+          std::vector<F> qc(n), tc(n);
+          for (size_t r = 0; r < n; ++r) { qc[r] = ce[c].at(r, k); tc[r] = tU[c].at(r, k); }
+          auto q_odd = coset_move<FP>(qc, sh[c], sh[c] * g2), t_odd = coset_move<FP>(tc, u, sh[c] * g2);
+          for (size_t r = 0; r < n; ++r) {
+            m.at(2 * r, k) = qc[r];
+            m.at(2 * r + 1, k) = q_odd[r] - t_odd[r] - t_odd[r];
+          }
+        }
+        for (size_t r = 0; r < 2 * n; ++r)
+          for (size_t k = DC; k < w2; ++k) m.at(r, k) = zk_rand<FP>(ck, r * w2 + k);
+        ce[c] = std::move(m);
+      }
+    }
+    for (int c = 0; c < C; ++c) {
+      q_chunk_evals.push_back(std::move(ce[c]));
+      q_chunk_shift.push_back(sh[c]);
       q_chunk_owner.emplace_back((int)i, c);
     }
   }
@@ -603,55 +739,97 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   auto quot_c = commit_ldes<FP>(p2, std::move(q_ldes), sp.cap_height, sp.mmcs_arity);
   proof.quotient_commit = quot_c.cap;
   for (auto& d : quot_c.cap) ch.observe_arr(d);
+  // ZK: the random round - per instance a fully random matrix of Challenge::DIMENSION (+ R) columns over the extended
+  // trace domain; its commitment is observed after the quotient's (batch_stark.rs:623-625), its round comes first (:645-661)
+  Committed<FP> rand_c;
+  std::vector<Matrix<FP>> rand_ev(ni);
+  if (zk) {
+    std::vector<Matrix<FP>> ldes;
+    for (size_t i = 0; i < ni; ++i) {
+      const uint64_t rk = key(ZK_ROUND_RANDOM, i);
+      const size_t w2 = (size_t)DC + R, h2 = insts[i].main.h * 2;
+      rand_ev[i] = Matrix<FP>(h2, w2);
+      for (size_t r = 0; r < h2; ++r)
+        for (size_t c = 0; c < w2; ++c) rand_ev[i].at(r, c) = zk_rand<FP>(rk, r * w2 + c);
+      ldes.push_back(coset_lde_bitrev<FP>(rand_ev[i], sp.log_blowup, gen));
+    }
+    rand_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity);
+    proof.has_random = true;
+    proof.random_commit = rand_c.cap;
+    for (auto& d : rand_c.cap) ch.observe_arr(d);
+  }
   EF zeta = ch.sample_ext();
 
-  // 5. open (rounds: main, quotient, preprocessed, permutation); observe in round/matrix/point order
+  // 5. open (rounds: [random,] main, quotient, preprocessed, permutation); observe in round/matrix/point order.  Every
+  // committed matrix is opened in full (ZK: its R random codeword columns included - the values HidingFriPcs splits off
+  // into the opening proof's first item and the verifier merges back, batch_stark.rs:855-864, :1116-1260)
   proof.opened.resize(ni);
   struct OpenItem { int round, mat, log_h; EF z; std::vector<EF> vals; };
   std::vector<OpenItem> items;  // in reduced-opening order
+  const int r0 = zk;            // index of the main round
+  if (zk)
+    for (size_t i = 0; i < ni; ++i)
+      items.push_back({0, (int)i, log_e[i], zeta, open_matrix<FP>(rand_ev[i], F::one(), zeta)});
   for (size_t i = 0; i < ni; ++i) {
-    EF zn = zeta * F::two_adic_generator(log_n[i]);
-    auto& ov = proof.opened[i];
-    ov.trace_local = open_matrix<FP>(insts[i].main, F::one(), zeta);
-    items.push_back({0, (int)i, log_n[i], zeta, ov.trace_local});
-    ov.has_trace_next = air_uses_next(insts[i].air);
-    if (ov.has_trace_next) {
-      ov.trace_next = open_matrix<FP>(insts[i].main, F::one(), zn);
-      items.push_back({0, (int)i, log_n[i], zn, ov.trace_next});
-    }
+    EF zn = zeta * F::two_adic_generator(log_n[i]);   // zeta * g of the BASE trace domain (:663-700)
+    items.push_back({r0, (int)i, log_e[i], zeta, open_matrix<FP>(main_ev[i], F::one(), zeta)});
+    if (air_uses_next(insts[i].air)) items.push_back({r0, (int)i, log_e[i], zn, open_matrix<FP>(main_ev[i], F::one(), zn)});
   }
   for (size_t k = 0; k < q_chunk_evals.size(); ++k) {
     int i = q_chunk_owner[k].first;
-    auto v = open_matrix<FP>(q_chunk_evals[k], q_chunk_shift[k], zeta);
-    proof.opened[i].quotient_chunks.push_back(v);
-    items.push_back({1, (int)k, log_n[i], zeta, v});
+    items.push_back({r0 + 1, (int)k, log_e[i], zeta, open_matrix<FP>(q_chunk_evals[k], q_chunk_shift[k], zeta)});
   }
   for (size_t i = 0; i < ni; ++i) {
     EF zn = zeta * F::two_adic_generator(log_n[i]);
-    auto& ov = proof.opened[i];
-    ov.preprocessed_local = open_matrix<FP>(insts[i].prep, F::one(), zeta);
-    ov.preprocessed_next = open_matrix<FP>(insts[i].prep, F::one(), zn);
-    items.push_back({2, (int)i, log_n[i], zeta, ov.preprocessed_local});
-    items.push_back({2, (int)i, log_n[i], zn, ov.preprocessed_next});
+    items.push_back({r0 + 2, (int)i, log_e[i], zeta, open_matrix<FP>(pd.evals[i], F::one(), zeta)});
+    items.push_back({r0 + 2, (int)i, log_e[i], zn, open_matrix<FP>(pd.evals[i], F::one(), zn)});
   }
   for (size_t k = 0; k < perm_insts.size(); ++k) {
     int i = perm_insts[k];
     EF zn = zeta * F::two_adic_generator(log_n[i]);
-    auto& ov = proof.opened[i];
-    ov.permutation_local = open_matrix<FP>(aux[i].flat, F::one(), zeta);
-    ov.permutation_next = open_matrix<FP>(aux[i].flat, F::one(), zn);
-    items.push_back({3, (int)k, log_n[i], zeta, ov.permutation_local});
-    items.push_back({3, (int)k, log_n[i], zn, ov.permutation_next});
+    items.push_back({r0 + 3, (int)k, log_e[i], zeta, open_matrix<FP>(aux_ev[i], F::one(), zeta)});
+    items.push_back({r0 + 3, (int)k, log_e[i], zn, open_matrix<FP>(aux_ev[i], F::one(), zn)});
   }
   for (auto& it : items) for (auto& v : it.vals) ch.observe_ext(v);
+  // the proof's fields: the first w values of each opening; ZK: the trailing R per (round, matrix, point)
+  {
+    const int n_rounds = (zk ? 1 : 0) + 3 + (any_lookup ? 1 : 0);
+    if (zk) proof.fri_random.resize(n_rounds);
+    for (auto& it : items) {
+      std::vector<EF> head(it.vals.begin(), it.vals.end() - R), tail(it.vals.end() - R, it.vals.end());
+      if (zk) {
+        auto& rd = proof.fri_random[it.round];
+        if ((int)rd.size() <= it.mat) rd.resize(it.mat + 1);
+        rd[it.mat].push_back(tail);
+      }
+      const int rr = it.round - r0;
+      if (rr == -1) { proof.opened[it.mat].has_random = true; proof.opened[it.mat].random = head; }
+      else if (rr == 0) {
+        auto& ov = proof.opened[it.mat];
+        if (ov.trace_local.empty()) ov.trace_local = head;
+        else { ov.has_trace_next = true; ov.trace_next = head; }
+      } else if (rr == 1) proof.opened[q_chunk_owner[it.mat].first].quotient_chunks.push_back(head);
+      else if (rr == 2) {
+        auto& ov = proof.opened[it.mat];
+        if (ov.preprocessed_local.empty()) ov.preprocessed_local = head; else ov.preprocessed_next = head;
+      } else {
+        auto& ov = proof.opened[perm_insts[it.mat]];
+        if (ov.permutation_local.empty()) ov.permutation_local = head; else ov.permutation_next = head;
+      }
+    }
+  }
 
   // 6. FRI: batching challenge, per-height reduced openings
   EF fri_alpha = ch.sample_ext();
-  const Committed<FP>* rounds[4] = {&main_c, &quot_c, &pd.prep, &perm_c};
+  std::vector<const Committed<FP>*> rounds;
+  if (zk) rounds.push_back(&rand_c);
+  rounds.push_back(&main_c); rounds.push_back(&quot_c); rounds.push_back(&pd.prep);
+  if (any_lookup) rounds.push_back(&perm_c);
   std::map<int, std::pair<EF, std::vector<EF>>> ros;  // log_height -> (alpha_pow, ro)
   for (auto& it : items) {
     const Matrix<FP>& lde = rounds[it.round]->ldes[it.mat];
     int lh = it.log_h + sp.log_blowup;
+    if (lde.h != (size_t(1) << lh) || lde.w != it.vals.size()) throw std::runtime_error("internal: opening shape");
     auto& e = ros[lh];
     if (e.second.empty()) { e.first = EF::one(); e.second.assign(lde.h, EF::zero()); }
     const F wl = F::two_adic_generator(lh);
@@ -679,9 +857,8 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   for (int q = 0; q < sp.num_queries; ++q) {
     size_t index = ch.sample_bits(log_max);
     QueryProof<FP> qp;
-    for (int r = 0; r < 4; ++r) {
-      if (r == 3 && !any_lookup) continue;
-      const auto& cm = *rounds[r];
+    for (const Committed<FP>* cmp : rounds) {
+      const auto& cm = *cmp;
       BatchOpening<FP> bo;
       size_t ridx = index >> (log_max - cm.tree.log_max_h);
       cm.tree.open(ridx, bo.opened_values, bo.opening_proof);
@@ -723,13 +900,24 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
   auto fail = [](const std::string& m) { throw std::runtime_error("verify: " + m); };
   const size_t ni = shapes.size();
   if (proof.opened.size() != ni || proof.degree_bits.size() != ni) fail("instance count mismatch");
+  if (proof.has_terminal.size() != ni || proof.lookup_terminals.size() != ni) fail("terminal count mismatch");
   const F gen = F::generator();
+  const int zk = sp.zk ? 1 : 0, R = zk ? sp.num_random_codewords : 0;
+  const int DC = EF::deg();
+  // randomisation must match the PCS's ZK setting (batch_stark.rs:424-428: RandomizationError)
+  if (proof.has_random != (zk != 0)) fail("RandomizationError: random commitment presence does not match the ZK setting");
+  for (auto& ov : proof.opened)
+    if (ov.has_random != (zk != 0)) fail("RandomizationError: random opened values presence does not match the ZK setting");
   std::vector<LookupLayout> layouts(ni);
-  std::vector<int> log_n(ni);
+  std::vector<int> log_n(ni), log_e(ni);
   bool any_lookup = false;
   for (size_t i = 0; i < ni; ++i) {
-    layouts[i] = lookup_layout<FP>(shapes[i].air, sp.lookup_unpacked);
-    log_n[i] = (int)proof.degree_bits[i];
+    layouts[i] = lookup_layout<FP>(shapes[i].air, sp.lookup_unpacked, zk);
+    log_e[i] = (int)proof.degree_bits[i];
+    // base_db = ext_db - is_zk (:536): "Extended degree bits smaller than ZK adjustment"
+    if (log_e[i] < zk) fail("extended degree bits smaller than the ZK adjustment");
+    log_n[i] = log_e[i] - zk;
+    if (log_e[i] + sp.log_blowup > FP::TWO_ADICITY) fail("degree too large");
     any_lookup |= !layouts[i].groups.empty();
     const auto& ov = proof.opened[i];
     const int w = air_width<FP>(shapes[i].air), pw = air_prep_width(shapes[i].air);
@@ -737,9 +925,11 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
     if (ov.has_trace_next != air_uses_next(shapes[i].air)) fail("trace_next presence");
     if (ov.has_trace_next && (int)ov.trace_next.size() != w) fail("trace_next width");
     if ((int)ov.preprocessed_local.size() != pw || (int)ov.preprocessed_next.size() != pw) fail("prep width");
-    if ((int)ov.quotient_chunks.size() != (1 << layouts[i].log_quotient_chunks)) fail("chunk count");
-    for (auto& c : ov.quotient_chunks) if (c.size() != (size_t)EF::deg()) fail("chunk width");
-    const size_t aflat = (size_t)layouts[i].aux_width() * EF::deg();
+    // quotient_degree = 1 << (log_qd + is_zk) (:487-496)
+    if ((int)ov.quotient_chunks.size() != (1 << (layouts[i].log_quotient_chunks + zk))) fail("chunk count");
+    for (auto& c : ov.quotient_chunks) if (c.size() != (size_t)DC) fail("chunk width");
+    if (zk && ov.random.size() != (size_t)DC) fail("RandomizationError: random opened values length");   // :506-511
+    const size_t aflat = (size_t)layouts[i].aux_width() * DC;
     if (ov.permutation_local.size() != aflat || ov.permutation_next.size() != aflat) fail("permutation width");
     if (proof.has_terminal[i] != !layouts[i].groups.empty()) fail("terminal presence");
   }
@@ -747,10 +937,10 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
   Challenger<FP> ch(&p2);
   ch.observe_base_as_ext(F((uint64_t)ni));
   for (size_t i = 0; i < ni; ++i) {
-    ch.observe_base_as_ext(F((uint64_t)log_n[i]));
+    ch.observe_base_as_ext(F((uint64_t)log_e[i]));
     ch.observe_base_as_ext(F((uint64_t)log_n[i]));
     ch.observe_base_as_ext(F((uint64_t)air_width<FP>(shapes[i].air)));
-    ch.observe_base_as_ext(F(uint64_t(1) << layouts[i].log_quotient_chunks));
+    ch.observe_base_as_ext(F(uint64_t(1) << (layouts[i].log_quotient_chunks + zk)));
   }
   for (auto& d : proof.main_commit) ch.observe_arr(d);
   for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(F((uint64_t)air_prep_width(shapes[i].air)));
@@ -763,33 +953,42 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
   }
   EF alpha = ch.sample_ext();
   for (auto& d : proof.quotient_commit) ch.observe_arr(d);
+  if (zk) for (auto& d : proof.random_commit) ch.observe_arr(d);   // :623-625
   EF zeta = ch.sample_ext();
 
-  // rounds: (commitment cap, matrices (log_height, points(z, values)))
-  struct MatOpen { int log_h; std::vector<std::pair<EF, const std::vector<EF>*>> pts; };
+  // rounds: (commitment cap, matrices (log_height, width, points(z, values)))
+  // ZK: every matrix carries R more columns, whose values at each point come from the opening proof's first item
+  // (merge_hiding_random_openings, pcs/fri/targets.rs:1076-1130: round / matrix / point counts must match)
+  struct MatOpen { int log_h; std::vector<std::pair<EF, std::vector<EF>>> pts; };
   struct Round { const typename BatchProof<FP>::Cap* cap; std::vector<MatOpen> mats; };
   std::vector<Round> rounds;
+  if (zk) {
+    Round r{&proof.random_commit, {}};
+    for (size_t i = 0; i < ni; ++i) r.mats.push_back({log_e[i], {{zeta, proof.opened[i].random}}});   // :645-661
+    rounds.push_back(r);
+  }
   {
     Round r{&proof.main_commit, {}};
     for (size_t i = 0; i < ni; ++i) {
-      MatOpen m{log_n[i], {{zeta, &proof.opened[i].trace_local}}};
+      MatOpen m{log_e[i], {{zeta, proof.opened[i].trace_local}}};
       if (proof.opened[i].has_trace_next)
-        m.pts.push_back({zeta * F::two_adic_generator(log_n[i]), &proof.opened[i].trace_next});
+        m.pts.push_back({zeta * F::two_adic_generator(log_n[i]), proof.opened[i].trace_next});   // base-domain generator
       r.mats.push_back(m);
     }
     rounds.push_back(r);
   }
   {
+    // randomized_quotient_domains: natural_domain_for_degree(size << is_zk) (:719-727)
     Round r{&proof.quotient_commit, {}};
     for (size_t i = 0; i < ni; ++i)
-      for (auto& c : proof.opened[i].quotient_chunks) r.mats.push_back({log_n[i], {{zeta, &c}}});
+      for (auto& c : proof.opened[i].quotient_chunks) r.mats.push_back({log_e[i], {{zeta, c}}});
     rounds.push_back(r);
   }
   {
     Round r{&prep_commit, {}};
     for (size_t i = 0; i < ni; ++i) {
       EF zn = zeta * F::two_adic_generator(log_n[i]);
-      r.mats.push_back({log_n[i], {{zeta, &proof.opened[i].preprocessed_local}, {zn, &proof.opened[i].preprocessed_next}}});
+      r.mats.push_back({log_e[i], {{zeta, proof.opened[i].preprocessed_local}, {zn, proof.opened[i].preprocessed_next}}});
     }
     rounds.push_back(r);
   }
@@ -798,11 +997,26 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
     for (size_t i = 0; i < ni; ++i) {
       if (proof.opened[i].permutation_local.empty()) continue;
       EF zn = zeta * F::two_adic_generator(log_n[i]);
-      r.mats.push_back({log_n[i], {{zeta, &proof.opened[i].permutation_local}, {zn, &proof.opened[i].permutation_next}}});
+      r.mats.push_back({log_e[i], {{zeta, proof.opened[i].permutation_local}, {zn, proof.opened[i].permutation_next}}});
     }
     rounds.push_back(r);
   }
-  for (auto& r : rounds) for (auto& m : r.mats) for (auto& pt : m.pts) for (auto& v : *pt.second) ch.observe_ext(v);
+  if (zk) {
+    if (proof.fri_random.size() != rounds.size()) fail("hiding FRI proof shape: random rounds count does not match commitments");
+    for (size_t r = 0; r < rounds.size(); ++r) {
+      if (proof.fri_random[r].size() != rounds[r].mats.size()) fail("hiding FRI proof shape: random matrices count does not match");
+      for (size_t m = 0; m < rounds[r].mats.size(); ++m) {
+        auto& pts = rounds[r].mats[m].pts;
+        if (proof.fri_random[r][m].size() != pts.size()) fail("hiding FRI proof shape: random points count does not match");
+        for (size_t p = 0; p < pts.size(); ++p) {
+          const auto& extra = proof.fri_random[r][m][p];
+          if ((int)extra.size() != R) fail("hiding FRI proof shape: random codeword count");
+          pts[p].second.insert(pts[p].second.end(), extra.begin(), extra.end());
+        }
+      }
+    }
+  } else if (!proof.fri_random.empty()) fail("random opened values in a non-ZK proof");
+  for (auto& r : rounds) for (auto& m : r.mats) for (auto& pt : m.pts) for (auto& v : pt.second) ch.observe_ext(v);
 
   // FRI challenges (fri/targets.rs:748-814)
   const auto& fp = proof.fri;
@@ -841,6 +1055,7 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
         batch_max = std::max(batch_max, rd.mats[m].log_h + sp.log_blowup);
         dims.emplace_back(size_t(1) << (rd.mats[m].log_h + sp.log_blowup), bo.opened_values[m].size());
       }
+      if (batch_max > log_max) fail("a committed matrix taller than the FRI domain");
       size_t ridx = index >> (log_max - batch_max);
       if (!MerkleTree<FP>::verify(p2, *rd.cap, sp.cap_height, dims, ridx, bo.opened_values, bo.opening_proof, sp.mmcs_arity))
         fail("input MMCS opening");
@@ -852,10 +1067,10 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
         auto it = ro.find(lh);
         if (it == ro.end()) it = ro.emplace(lh, std::make_pair(EF::one(), EF::zero())).first;
         for (auto& pt : rd.mats[m].pts) {
-          if (pt.second->size() != bo.opened_values[m].size()) fail("opened width vs point values");
+          if (pt.second.size() != bo.opened_values[m].size()) fail("opened width vs point values");
           EF inv = (pt.first - EF(x)).inv();
-          for (size_t c = 0; c < pt.second->size(); ++c) {
-            it->second.second += it->second.first * ((*pt.second)[c] - EF(bo.opened_values[m][c])) * inv;
+          for (size_t c = 0; c < pt.second.size(); ++c) {
+            it->second.second += it->second.first * (pt.second[c] - EF(bo.opened_values[m][c])) * inv;
             it->second.first *= fri_alpha;
           }
         }
@@ -900,7 +1115,9 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
   for (size_t i = 0; i < ni; ++i) {
     const auto& L = layouts[i];
     const auto& ov = proof.opened[i];
-    const int lq = L.log_quotient_chunks, C = 1 << lq;
+    // quotient domain of size 2^(base_db + log_qd + is_zk) split into 2^(log_qd + is_zk) chunk domains of the BASE
+    // trace size (:701-717): the chunks are recomposed over those, not over the randomised opening domains
+    const int lq = L.log_quotient_chunks + zk, C = 1 << lq;
     // recompose quotient(zeta) from chunks (verifier/quotient.rs:60-140)
     const F wq = F::two_adic_generator(log_n[i] + lq);
     std::vector<F> shifts(C);
