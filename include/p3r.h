@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3R_ABI_VERSION 6
+#define P3R_ABI_VERSION 7
 
 enum {
   P3R_OK = 0,
@@ -132,6 +132,29 @@ typedef struct p3r_config {
    * FRI commit-phase trees, their opening proofs (step - 1 sibling digests per level, recursion/src/pcs/mmcs.rs:
    * 866-1316) and both verifiers follow.  cap_height must be 0 with arity 4. */
   uint32_t mmcs_arity;
+  /* ABI version 7.  ZK: the PCS is HidingFriPcs (create_config_zk, recursion/examples/common/mod.rs:511-553:
+   * `MyPcsZk::new(dft, val_mmcs, fri_params, 2, SmallRng::seed_from_u64(rng_seed))` over the SAME non-hiding MMCS;
+   * `recursive_fibonacci --zk`, `recursive_aggregation --zk`, recursion/tests/fibonacci_batch_stark_prover_zk.rs).
+   *   zk = 1: every committed matrix (preprocessed, main, permutation, quotient chunks) is committed over the EXTENDED
+   *     trace domain of twice the height - original rows interleaved with random rows - with `num_random_codewords`
+   *     random columns appended; a random round (Challenge::DIMENSION + num_random_codewords columns per instance) is
+   *     committed and opened at zeta; the quotient has 2^(log_chunks + 1) chunks, each masked by a random multiple of
+   *     its vanishing polynomial; degree_bits in the proof and in the preprocessed metadata are the extended ones
+   *     (recursion.rs:374); the opening proof is HidingFriPcs's tuple (random opened values, FriProof).  What the
+   *     verifiers enforce is recursion/src/verifier/batch_stark.rs:424-428,487-490,536,623-661,701-735,855-864,1116-1260;
+   *     the prover side of HidingFriPcs lives in the un-vendored p3-fri crate and its proofs are randomised, so byte
+   *     parity with upstream is undefined by construction - the construction is written from those acceptance
+   *     conditions.  The preprocessed round is padded with zeros, not random values: its commitment
+   *     depends on the circuit shape only.
+   *   num_random_codewords: 0 selects 2 (the examples' value); 1..8.
+   *   zk_seed: seed of the random values (rng_seed).  They come from a counter-based generator keyed by (zk_seed, proofs
+   *     made so far by the ctx, round, matrix, cell) - csrc/zk_rand.h - so two proofs of one ctx differ (as the
+   *     RefCell<SmallRng> of the reference advances), and a fresh ctx with the same seed repeats the sequence
+   *     (p3r_zk_nonce / p3r_zk_set_nonce).  NOT a cryptographic generator (neither is SmallRng): a deployment that needs
+   *     the zero-knowledge property must supply an unpredictable seed per ctx. */
+  uint32_t zk;
+  uint32_t num_random_codewords;
+  uint64_t zk_seed;
 } p3r_config;
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
@@ -153,6 +176,10 @@ uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx);
 /* The round constants in use (canonical, the flat layout of p3r_config.poseidon2_rc); `out` holds
  * p3r_poseidon2_num_constants values. */
 int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out);
+/* ABI version 7.  Proofs made so far under a ZK configuration (the state of the hiding PCS's RNG): read it, or set it
+ * to replay / skip ahead (parity tests set it so that the CPU oracle can be given the same value). */
+uint64_t p3r_zk_nonce(const p3r_ctx* ctx);
+int p3r_zk_set_nonce(p3r_ctx* ctx, uint64_t nonce);
 /* Blocks until all work queued on the ctx's stream has completed. */
 int p3r_sync(p3r_ctx* ctx);
 /* Device memory a ctx has released stays in its pool for reuse (a 2^20-row prove keeps several GB
@@ -296,6 +323,8 @@ void p3r_prep_free(p3r_ctx* ctx, p3r_prep* prep);
 
 #define P3R_PROOF_QUINTIC_CHALLENGE 2u /* flags of the proof PARSERS (p3r_batch_proof_len*, p3r_batch_stark_proof_parse):
                                         * extension elements are five words (p3r_config.challenge_degree = 5) */
+#define P3R_PROOF_ZK 4u /* flags of the proof PARSERS: the proof is a hiding PCS's (p3r_config.zk = 1): its opening proof
+                        * is the tuple (random opened values, FriProof) - the proof TYPE, which the bytes do not announce */
 #define P3R_PROVE_CANONICAL_FIELD_ENCODING 1u /* flags: write canonical u32 instead of the
                                                * Montgomery word p3-monty-31's serde emits */
 

@@ -44,6 +44,11 @@ struct FriParams {
   // arity of the PCS's MMCS: 2 = MyMmcs (width-16 permutation), 4 = MyMmcsArity4 (width-32 permutation, W16 challenger:
   // recursion/examples/recursive_aggregation.rs:902-1046; cap_height must be 0)
   uint32_t mmcs_arity = 2;
+  // ZK: the PCS is HidingFriPcs with `num_random_codewords` random codewords and an RNG seeded with `zk_seed`
+  // (create_config_zk, recursion/examples/common/mod.rs:511-553: two codewords)
+  bool zk = false;
+  uint32_t num_random_codewords = 2;
+  uint64_t zk_seed = 0;
 };
 
 // ext_degree: the circuit extension degree of the traces - 4, or 5 for KoalaBear circuits over the quintic trinomial
@@ -61,6 +66,9 @@ inline p3r_config make_config(Field field, const FriParams& p, int device = 0, c
   c.log_final_poly_len = p.log_final_poly_len; c.commit_pow_bits = p.commit_pow_bits;
   c.query_pow_bits = p.query_pow_bits; c.num_queries = p.num_queries;
   c.mmcs_arity = p.mmcs_arity;
+  c.zk = p.zk ? 1u : 0u;
+  c.num_random_codewords = p.zk ? p.num_random_codewords : 0u;
+  c.zk_seed = p.zk_seed;
   c.device = device;
   if (rc) { c.poseidon2_rc = rc->data(); c.poseidon2_rc_len = (uint32_t)rc->size(); }
   return c;
@@ -273,13 +281,14 @@ struct BatchStarkProof {
   // BatchProof, every field element in range, the metadata fields and the rules of validate()) - what a node of the
   // aggregation tree runs on a child that arrived from another process.
   // challenge_degree 5: a proof over KoalaBear's quintic challenge field (five words per extension element).
+  // zk: the proof is a hiding PCS's (FriParams::zk; P3R_PROOF_ZK): its opening proof is the tuple (random opened values, FriProof).
   static BatchStarkProof from_postcard(const std::vector<uint8_t>& data, Field field, bool montgomery_field_encoding = true,
-                                       uint32_t challenge_degree = 4) {
+                                       uint32_t challenge_degree = 4, bool zk = false) {
     p3r_batch_stark_meta m;
     char err[256] = {0};
     const int rc = p3r_batch_stark_proof_parse((uint32_t)field, data.data(), data.size(),
                                                (montgomery_field_encoding ? 0 : P3R_PROVE_CANONICAL_FIELD_ENCODING) |
-                                                   (challenge_degree == 5 ? P3R_PROOF_QUINTIC_CHALLENGE : 0),
+                                                   (challenge_degree == 5 ? P3R_PROOF_QUINTIC_CHALLENGE : 0) | (zk ? P3R_PROOF_ZK : 0),
                                                nullptr, &m, err, sizeof err);
     if (rc != P3R_OK) throw Error(rc, err);
     BatchStarkProof p;
@@ -538,7 +547,7 @@ class BatchStarkProver {
       p.preprocessed_widths.push_back(widths[i]);
       uint32_t db = 0;
       while ((size_t(1) << db) < heights[i]) ++db;
-      p.degree_bits.push_back(db);
+      p.degree_bits.push_back(db + (ctx_->config().zk ? 1u : 0u));   // ZK: the extended degree bits (recursion.rs:374)
     }
     if (cpd.table_heights[3])  // Poseidon2Prover reports the PADDED row count (poseidon2.rs:1449)
       p.non_primitives.push_back({!d4 ? "poseidon2_perm/koala_bear_d1_w16"

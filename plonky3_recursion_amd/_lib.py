@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # P3R_LIB_PATH: A/B runs of two builds of the library on one box (development only)
 LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so")
 
-P3R_ABI_VERSION = 6
+P3R_ABI_VERSION = 7
 P3R_EXT_LOOKUP_UNPACKED = 1
 FIELD_KOALA_BEAR = 0
 FIELD_BABY_BEAR = 1
@@ -39,6 +39,8 @@ class P3rConfig(C.Structure):
         ("poseidon2_w32_rc", C.POINTER(C.c_uint32)), ("poseidon2_w32_rc_len", C.c_uint32),
         ("poseidon2_w32_diag", C.POINTER(C.c_uint32)),
         ("mmcs_arity", C.c_uint32),   # 0 / 2: binary MMCS over the width-16 permutation; 4: the arity-4 MMCS (width 32)
+        # ABI 7: ZK = HidingFriPcs (create_config_zk, recursion/examples/common/mod.rs:511-553)
+        ("zk", C.c_uint32), ("num_random_codewords", C.c_uint32), ("zk_seed", C.c_uint64),
     ]
 
 
@@ -173,6 +175,8 @@ SIGNATURES = {
     "p3r_poseidon2_num_constants": (C.c_uint32, [vp]),
     "p3r_poseidon2_round_constants": (C.c_int, [vp, u32p]),
     "p3r_sync": (C.c_int, [vp]),
+    "p3r_zk_nonce": (C.c_uint64, [vp]),
+    "p3r_zk_set_nonce": (C.c_int, [vp, C.c_uint64]),
     "p3r_trim": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     "p3r_dmat_upload": (vp, [vp, u32p, C.c_size_t, C.c_size_t]),
     "p3r_dmat_alloc": (vp, [vp, C.c_size_t, C.c_size_t]),

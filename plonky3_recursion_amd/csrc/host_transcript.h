@@ -68,7 +68,8 @@ struct HostChallenger {
 };
 
 // ---- lookup layout (same rule as DESIGN.md "LogUp"): greedy same-bus packing under the
-// degree budget 2^log_chunks + 1.
+// degree budget 2^log_chunks + 1 - is_zk; log_chunks = log2_ceil(max(degree + is_zk, 2) - 1)
+// (circuit-prover/src/batch_stark_prover.rs:931-939).
 inline std::vector<int> interaction_mult_degrees(const AirParams& a) {
   std::vector<int> d;
   switch (a.kind) {
@@ -89,23 +90,26 @@ inline std::vector<int> interaction_mult_degrees(const AirParams& a) {
   return d;
 }
 struct LookupLayout {
+  // pair: interactions per packed group minus one (0 singletons, 1 pairs, 2 triples - the budget of a ZK configuration);
+  // the last group may be smaller
   int n_interactions = 0, n_groups = 0, pair = 0, log_chunks = 0;
   int aux_width() const { return n_groups ? n_groups + 1 : 0; }
 };
-inline LookupLayout lookup_layout(const AirParams& a) {
+inline LookupLayout lookup_layout(const AirParams& a, int is_zk = 0) {
   auto md = interaction_mult_degrees(a);
   auto gdeg = [&](int first, int K) {
     int deg = 1 + K;
     for (int k = 0; k < K; ++k) deg = std::max(deg, md[first + k] + K - 1);
     return deg;
   };
-  int max_deg = 2;
+  int max_deg = 0;
   if (a.kind == AIR_ALU || a.kind == AIR_POSEIDON2 || a.kind == AIR_POSEIDON2_W32) max_deg = 3;
   for (size_t i = 0; i < md.size(); ++i) max_deg = std::max(max_deg, gdeg((int)i, 1));
+  max_deg = std::max(max_deg + is_zk, 2);
   LookupLayout L;
   L.n_interactions = (int)md.size();
   while ((1 << L.log_chunks) < max_deg - 1) ++L.log_chunks;
-  const int budget = (1 << L.log_chunks) + 1;
+  const int budget = (1 << L.log_chunks) + 1 - is_zk;
   // greedy packing; the device kernels support the two shapes it produces for these AIRs
   std::vector<int> sizes;
   int first = 0, K = 0;
@@ -115,14 +119,14 @@ inline LookupLayout lookup_layout(const AirParams& a) {
   }
   if (K) sizes.push_back(K);
   L.n_groups = (int)sizes.size();
-  bool all1 = true, pairs = true;
-  for (size_t g = 0; g < sizes.size(); ++g) {
-    all1 = all1 && sizes[g] == 1;
-    pairs = pairs && (sizes[g] == 2 || (g + 1 == sizes.size() && sizes[g] == 1));
-  }
-  if (all1) L.pair = 0;
-  else if (pairs) L.pair = 1;
-  else fail(P3R_EUNSUPPORTED, "lookup packing shape not supported by the device kernels");
+  // uniform groups of G = 1, 2 or 3 interactions, the last one possibly smaller: the shapes the greedy rule
+  // produces for these AIRs, and the ones the device kernels take
+  const int G = sizes.empty() ? 1 : sizes[0];
+  bool uniform = G >= 1 && G <= 3;
+  for (size_t g = 0; g < sizes.size(); ++g)
+    uniform = uniform && (sizes[g] == G || (g + 1 == sizes.size() && sizes[g] >= 1 && sizes[g] < G));
+  if (!uniform) fail(P3R_EUNSUPPORTED, "lookup packing shape not supported by the device kernels");
+  L.pair = G - 1;
   return L;
 }
 

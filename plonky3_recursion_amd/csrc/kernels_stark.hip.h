@@ -48,8 +48,8 @@ __device__ __forceinline__ typename Chal<PP, DC>::type lookup_denom(const Lookup
 
 // ------------------------------------------------------------------ K7: aux trace
 // One lane per trace row: fraction columns f_g = sum_{k in g} m_k / d_k for each packed
-// lookup group (groups are consecutive pairs when `pair` else singletons - the host checks
-// that the packing computed from the degree budget has this shape), plus the row total.
+// lookup group (groups are `pair` + 1 consecutive interactions: singletons, pairs, or - under a ZK configuration's
+// budget - triples; the host checks that the packing computed from the degree budget has this shape), plus the row total.
 template <class PP, int DC = 4>
 struct AuxSink {
   using F = Fp<PP>;
@@ -63,7 +63,7 @@ struct AuxSink {
   __device__ AuxSink(const LookupChT<DC>& l, gptr<uint32_t> a, size_t n_, size_t r, int p)
       : lc(l), aux(a), n(n_), row(r), pair(p), cur(E::zero()), total(E::zero()) {}
   __device__ __forceinline__ void flush() {
-    int g = pair ? (cnt - 1) / 2 : cnt - 1;
+    int g = pair == 1 ? (cnt - 1) / 2 : pair == 2 ? (cnt - 1) / 3 : cnt - 1;
 #pragma unroll
     for (int k = 0; k < DC; ++k) aux[(size_t)((g + 1) * DC + k) * n + row] = cur.c[k].v;
     total += cur;
@@ -73,10 +73,10 @@ struct AuxSink {
   __device__ __forceinline__ void add(F idx, const VD<F, D>& v, F mult) {
     if (mult.v != 0) cur += lookup_denom<PP, D, DC>(lc, idx, v).inv() * mult;
     ++cnt;
-    if (!pair || (cnt & 1) == 0) flush();
+    if (!pair || (pair == 1 ? (cnt & 1) == 0 : cnt % 3 == 0)) flush();
   }
   __device__ __forceinline__ void finish() {
-    if (pair && (cnt & 1)) flush();
+    if (pair == 1 ? (cnt & 1) != 0 : pair == 2 && cnt % 3 != 0) flush();
   }
 };
 
@@ -210,7 +210,7 @@ struct QuotientArgs {
   const uint32_t* aux;    // nullable
   size_t lde_h;
   int log_n;              // trace height
-  int log_chunks;         // log2 of quotient chunks C
+  int log_chunks;         // log2 of quotient chunks C (ZK: one more than the AIR's log_quotient_chunks, batch_stark.rs:701-717)
   const uint32_t* apow;   // alpha^j as 4 words each, j = 0..: one table for all AIRs of a proof
   int n_constraints;      // N: constraint k (base constraints first) is weighted alpha^(N-1-k)
   int n_base, n_groups, pair;
@@ -218,8 +218,8 @@ struct QuotientArgs {
   uint32_t gen;           // coset shift (Montgomery)
   uint32_t w_q;           // generator of the quotient domain (size n*C)
   uint32_t g_inv;         // inverse trace-domain generator
-  uint32_t zh[4];         // Z_H on the C cosets:  gen^n * w_C^c - 1
-  uint32_t zh_inv[4];
+  uint32_t zh[8];         // Z_H on the C cosets:  gen^n * w_C^c - 1
+  uint32_t zh_inv[8];
   uint32_t* out;          // [C][DC][n] chunk evaluations, natural order
   uint32_t block0;        // first block of this table in the launch (all tables of a proof share it)
 };
@@ -258,11 +258,12 @@ struct QuotSink {
   gptr<const uint32_t> aux;
   BaseFold<PP, DC>& fold;
   size_t row;
-  int cnt = 0;
-  E d0, sum_f;
-  F m0;
+  int cnt = 0, held = 0;   // held: interactions of the open group (pairs / triples)
+  E d0, d1, sum_f;
+  F m0, m1;
   __device__ QuotSink(const QuotientArgs& q_, const LookupChT<DC>& lc_, BaseFold<PP, DC>& f, size_t r)
-      : q(q_), lc(lc_), aux(as_global(q_.aux)), fold(f), row(r), d0(E::zero()), sum_f(E::zero()), m0(F::zero()) {}
+      : q(q_), lc(lc_), aux(as_global(q_.aux)), fold(f), row(r), d0(E::zero()), d1(E::zero()), sum_f(E::zero()),
+        m0(F::zero()), m1(F::zero()) {}
   __device__ __forceinline__ E aux_at(int col, size_t r) const {
     E e;
 #pragma unroll
@@ -277,21 +278,38 @@ struct QuotSink {
       E f = aux_at(cnt, row);
       fold.ext(f * d - E::from_base(mult));
       sum_f += f;
-    } else if (cnt & 1) {
-      d0 = d;
-      m0 = mult;
-    } else {
-      E f = aux_at(cnt / 2, row);
-      fold.ext(f * d0 * d - (d * m0 + d0 * mult));
-      sum_f += f;
+    } else if (q.pair == 1) {
+      if (cnt & 1) {
+        d0 = d;
+        m0 = mult;
+        held = 1;
+      } else {
+        E f = aux_at(cnt / 2, row);
+        fold.ext(f * d0 * d - (d * m0 + d0 * mult));
+        sum_f += f;
+        held = 0;
+      }
+    } else {   // triples: f d0 d1 d2 - (m0 d1 d2 + m1 d0 d2 + m2 d0 d1)
+      if (held == 0) {
+        d0 = d; m0 = mult; held = 1;
+      } else if (held == 1) {
+        d1 = d; m1 = mult; held = 2;
+      } else {
+        E f = aux_at(cnt / 3, row);
+        const E d01 = d0 * d1;
+        fold.ext(f * d01 * d - ((d1 * m0 + d0 * m1) * d + d01 * mult));
+        sum_f += f;
+        held = 0;
+      }
     }
   }
   __device__ __forceinline__ void finish() {
-    if (q.pair && (cnt & 1)) {
-      E f = aux_at((cnt + 1) / 2, row);
-      fold.ext(f * d0 - E::from_base(m0));
-      sum_f += f;
-    }
+    if (!held) return;
+    const int G = q.pair + 1;
+    E f = aux_at((cnt + G - 1) / G, row);
+    if (held == 1) fold.ext(f * d0 - E::from_base(m0));
+    else fold.ext(f * d0 * d1 - (d1 * m0 + d0 * m1));
+    sum_f += f;
   }
 };
 

@@ -567,6 +567,8 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
     // the cap of an arity-4 tree strips whole compression steps (recursion/src/pcs/mmcs.rs:1143-1156); the reference's
     // arity-4 configurations run with the default cap_height 0 (recursive_aggregation.rs:77), and only that is built
     if (cfg->mmcs_arity == 4 && cfg->cap_height != 0) fail(P3R_EUNSUPPORTED, "arity-4 MMCS: cap_height must be 0");
+    if (cfg->zk > 1) fail(P3R_EINVAL, "zk must be 0 or 1 (got %u)", cfg->zk);
+    if (cfg->zk && cfg->num_random_codewords > 8) fail(P3R_EINVAL, "num_random_codewords must be in 1..8 (0 selects 2)");
     if (cfg->challenge_degree != 0 && cfg->challenge_degree != 4 &&
         !(cfg->challenge_degree == 5 && cfg->field == P3R_FIELD_KOALA_BEAR))
       fail(P3R_EUNSUPPORTED, "UnsupportedChallengeDegree(%u): 4, or 5 over KoalaBear", cfg->challenge_degree);
@@ -626,6 +628,13 @@ uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx) {
 int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out) {
   if (!ctx || !out) return P3R_EINVAL;
   std::copy(ctx->rc_canonical.begin(), ctx->rc_canonical.begin() + p3r_poseidon2_num_constants(ctx), out);   // the width-16 table
+  return P3R_OK;
+}
+
+uint64_t p3r_zk_nonce(const p3r_ctx* ctx) { return ctx ? ctx->zk_nonce : 0; }
+int p3r_zk_set_nonce(p3r_ctx* ctx, uint64_t nonce) {
+  if (!ctx) return P3R_EINVAL;
+  ctx->zk_nonce = nonce;
   return P3R_OK;
 }
 
@@ -1070,6 +1079,9 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
     if (cfg->mmcs_arity != 0 && cfg->mmcs_arity != 2 && cfg->mmcs_arity != 4) { report("mmcs_arity must be 2 or 4"); return P3R_EINVAL; }
     if (cfg->mmcs_arity == 4 && cfg->cap_height != 0) { report("arity-4 MMCS: cap_height must be 0"); return P3R_EUNSUPPORTED; }
     prm.mmcs_arity = cfg->mmcs_arity == 4 ? 4 : 2;
+    if (cfg->zk > 1 || cfg->num_random_codewords > 8) { report("zk must be 0 or 1, num_random_codewords at most 8"); return P3R_EINVAL; }
+    prm.zk = (int)cfg->zk;
+    prm.num_random_codewords = cfg->zk ? (cfg->num_random_codewords ? (int)cfg->num_random_codewords : 2) : 0;
     if (!prm.layout.set(cfg->proof_layout, cfg->proof_layout_len)) { report("proof_layout must be 18 bytes: three permutations"); return P3R_EINVAL; }
     std::vector<p3r::AirParams> a(n_airs);
     for (size_t i = 0; i < n_airs; ++i) {
@@ -1120,10 +1132,11 @@ int p3r_batch_proof_len_layout(uint32_t field, const uint8_t* bytes, size_t len,
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     p3r::ProofLayout PL;
     if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
+    const bool zk = (flags & P3R_PROOF_ZK) != 0;
     if (field == P3R_FIELD_KOALA_BEAR && (flags & P3R_PROOF_QUINTIC_CHALLENGE))
-      (void)p3r::parse_proof<p3r::KoalaBearParams, 5>(bytes, len, canonical, proof_len, PL);
-    else if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len, PL);
-    else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len, PL);
+      (void)p3r::parse_proof<p3r::KoalaBearParams, 5>(bytes, len, canonical, proof_len, PL, zk);
+    else if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len, PL, zk);
+    else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len, PL, zk);
     else throw std::runtime_error("unknown field");
     return P3R_OK;
   } catch (const std::exception& e) {
@@ -1142,8 +1155,9 @@ int p3r_batch_stark_proof_parse(uint32_t field, const uint8_t* bytes, size_t len
     p3r::ProofLayout PL;
     if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
     const int dc = (flags & P3R_PROOF_QUINTIC_CHALLENGE) ? 5 : 4;
-    if (field == P3R_FIELD_KOALA_BEAR) p3r::parse_batch_stark_meta<p3r::KoalaBearParams>(bytes, len, canonical, PL, dc, out);
-    else if (field == P3R_FIELD_BABY_BEAR) p3r::parse_batch_stark_meta<p3r::BabyBearParams>(bytes, len, canonical, PL, dc, out);
+    const bool zk = (flags & P3R_PROOF_ZK) != 0;
+    if (field == P3R_FIELD_KOALA_BEAR) p3r::parse_batch_stark_meta<p3r::KoalaBearParams>(bytes, len, canonical, PL, dc, out, zk);
+    else if (field == P3R_FIELD_BABY_BEAR) p3r::parse_batch_stark_meta<p3r::BabyBearParams>(bytes, len, canonical, PL, dc, out, zk);
     else throw std::runtime_error("unknown field");
     out->parse_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return P3R_OK;

@@ -9,18 +9,25 @@
 //                                               recursion/src/verifier/quotient.rs:60-140
 //   FRI challenges, arities, PoW, queries       recursion/src/pcs/fri/targets.rs:748-866
 //   reduced openings / folding / final poly     recursion/src/pcs/fri/verifier.rs:562-781,887-915,1068-1356
+//   ZK (p3r_config.zk, HidingFriPcs)            recursion/src/verifier/batch_stark.rs:424-428,487-490,536,623-661,701-735,
+//                                               855-864,1116-1260; pcs/fri/targets.rs:1076-1130 - the prover side is
+//                                               un-vendored and randomised: written from those acceptance conditions
 // All matrices stay resident in HBM; only commitments, opened values, the final polynomial
 // and the query answers cross to the host.
 #include "host_transcript.h"
 #include "kernels_stark.hip.h"
 #include "kernels_fri_reduce.hip.h"
+#include "kernels_zk.hip.h"
 #include "open_impl.hip.h"
 
 struct p3r_prep {
   std::vector<p3r::AirParams> airs;
   std::vector<std::unique_ptr<p3r_dmat>> traces;  // preprocessed traces (K7 and openings read them)
+  std::vector<std::unique_ptr<p3r_dmat>> evals;   // ZK: the committed evaluations, 2h x (w + R), zero-padded (else empty)
   std::vector<std::unique_ptr<p3r_dmat>> ldes;    // their bit-reversed LDEs (K8, FRI)
-  std::vector<size_t> heights;
+  std::vector<size_t> heights;                    // BASE trace heights
+  int zk_codewords = -1;                          // R the preparation was committed with (0: not ZK)
+  const p3r_dmat* committed(size_t i) const { return evals.empty() ? traces[i].get() : evals[i].get(); }
   std::unique_ptr<p3r_tree> tree;
   std::vector<uint32_t> cap_canonical;
 };
@@ -117,6 +124,41 @@ Fp<PP> grind_witness(p3r_ctx* ctx, Challenger& ch, int bits) {
   return w;
 }
 
+inline int zk_codewords(const p3r_config& cfg) { return cfg.zk ? (cfg.num_random_codewords ? (int)cfg.num_random_codewords : 2) : 0; }
+
+// HidingFriPcs::commit on a batch of matrices (kernels_zk.hip.h): h x w -> 2h x (w + R) each, one launch.
+// src[i] == nullptr: a fully random 2 * h[i] x (w[i] + R) matrix (w[i] = the width before the codeword columns).
+template <class PP>
+std::vector<std::unique_ptr<p3r_dmat>> zk_randomize(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& src, const std::vector<size_t>& h,
+                                                    const std::vector<size_t>& w, int R, const std::vector<uint64_t>& keys, bool zero_fill) {
+  std::vector<std::unique_ptr<p3r_dmat>> out;
+  std::vector<ZkRandomizeJob> jobs;
+  uint64_t blocks = 0;
+  for (size_t i = 0; i < h.size(); ++i) {
+    out.push_back(dmat_alloc(2 * h[i], w[i] + (size_t)R));
+    ZkRandomizeJob j{};
+    j.src = src[i] ? src[i]->d : nullptr;
+    j.dst = out.back()->d;
+    j.h2 = 2 * h[i];
+    j.w = src[i] ? (uint32_t)w[i] : 0u;
+    j.w2 = (uint32_t)(w[i] + (size_t)R);
+    j.zero_fill = zero_fill ? 1u : 0u;
+    j.key = keys[i];
+    j.block0 = (uint32_t)blocks;
+    blocks += (uint64_t)j.w2 * ((j.h2 + kBlock - 1) / kBlock);
+    jobs.push_back(j);
+  }
+  if (blocks >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "ZK randomisation launch of %llu tiles", (unsigned long long)blocks);
+  if (jobs.empty()) return out;
+  DevBuf d_jobs((jobs.size() * sizeof(ZkRandomizeJob) + 3) / 4);
+  P3R_HIP(ctx->stage.upload(ctx->stream, d_jobs.p, jobs.data(), jobs.size() * sizeof(ZkRandomizeJob)));
+  ProfScope ps(ctx, "zk_randomize");
+  hipLaunchKernelGGL(k_zk_randomize<PP>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                     reinterpret_cast<const ZkRandomizeJob*>(d_jobs.p), (int)jobs.size());
+  P3R_HIP(hipGetLastError());
+  return out;
+}
+
 // `dev_traces`: the preprocessed traces already in HBM (column-major, Montgomery: the device-side preparation
 // writes them there); otherwise they are uploaded from the host matrices `mats`.
 template <class PP>
@@ -141,12 +183,22 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
     const size_t width = dev_traces ? (*dev_traces)[i]->w : mats[i].width, height = dev_traces ? (*dev_traces)[i]->h : mats[i].height;
     if ((int)width != air_prep_width_of(a))
       fail(P3R_EINVAL, "instance %zu: preprocessed width %zu, the AIR expects %d", i, width, air_prep_width_of(a));
-    (void)lookup_layout(a);
+    (void)lookup_layout(a, ctx->cfg.zk ? 1 : 0);
     prep->airs.push_back(a);
     prep->heights.push_back(height);
     auto m = dev_traces ? std::move((*dev_traces)[i]) : upload<PP>(ctx, mats[i].values, mats[i].height, mats[i].width);
     items.push_back({m.get(), PP::GEN});
     prep->traces.push_back(std::move(m));
+  }
+  prep->zk_codewords = zk_codewords(ctx->cfg);
+  if (ctx->cfg.zk) {
+    // commit_preprocessing of a hiding PCS: the same extended domain and codeword columns, padded with ZEROS - public
+    // data, and the commitment stays a function of the circuit shape (p3r.h: p3r_config.zk)
+    std::vector<const p3r_dmat*> src;
+    std::vector<size_t> hs, ws;
+    for (auto& t : prep->traces) { src.push_back(t.get()); hs.push_back(t->h); ws.push_back(t->w); }
+    prep->evals = zk_randomize<PP>(ctx, src, hs, ws, prep->zk_codewords, std::vector<uint64_t>(n, 0), true);
+    for (size_t i = 0; i < n; ++i) items[i].in = prep->evals[i].get();
   }
   prep->ldes = coset_lde_batch<PP>(ctx, items, (int)ctx->cfg.log_blowup);
   for (auto& l : prep->ldes) ptrs.push_back(l.get());
@@ -172,8 +224,14 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   const int log_blowup = (int)cfg.log_blowup;
   if (ni != prep->airs.size()) fail(P3R_EINVAL, "%zu traces for %zu preprocessed instances", ni, prep->airs.size());
   const int p2w = p2_perm_cols<PP>() + 2;
+  // ZK (HidingFriPcs): every committed matrix lives over the extended trace domain (log_e = log_n + 1) with R random
+  // codeword columns; `nonce` keys this proof's random values (zk_rand.h)
+  const int zk = cfg.zk ? 1 : 0, R = zk_codewords(cfg);
+  if (prep->zk_codewords != R) fail(P3R_EINVAL, "the preprocessed data was committed under another ZK setting");
+  const uint64_t nonce = zk ? ctx->zk_nonce++ : 0;
+  auto zkey = [&](int round, size_t mat) { return zk_stream_key(cfg.zk_seed, nonce, round, mat); };
   std::vector<LookupLayout> layouts(ni);
-  std::vector<int> log_n(ni);
+  std::vector<int> log_n(ni), log_e(ni);
   for (size_t i = 0; i < ni; ++i) {
     const AirParams& a = prep->airs[i];
     if (mains[i]->h != prep->heights[i])
@@ -181,8 +239,10 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     if ((int)mains[i]->w != air_width_of(a, p2w, p2w_perm_cols<PP>() + 4))
       fail(P3R_EINVAL, "instance %zu: trace width %zu, the AIR expects %d", i, mains[i]->w, air_width_of(a, p2w, p2w_perm_cols<PP>() + 4));
     log_n[i] = log2_exact(mains[i]->h, "trace height");
-    layouts[i] = lookup_layout(a);
+    log_e[i] = log_n[i] + zk;
+    layouts[i] = lookup_layout(a, zk);
     if (layouts[i].log_chunks > log_blowup) fail(P3R_EINVAL, "quotient domain larger than the LDE");
+    if ((1 << (layouts[i].log_chunks + zk)) > 8) fail(P3R_EUNSUPPORTED, "more than 8 quotient chunks");
   }
   const F gen = F::generator();
   std::vector<F> rc_host(ctx->rc_canonical.size());
@@ -195,21 +255,30 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   prof_stage(ctx, "main_lde_commit");
   // ---- 1. main LDEs + commitment
   std::vector<LdeItem> lde_items;
-  for (size_t i = 0; i < ni; ++i) lde_items.push_back({mains[i], PP::GEN});
+  std::vector<std::unique_ptr<p3r_dmat>> main_r;   // ZK: the randomised traces (what is committed and opened)
+  std::vector<const p3r_dmat*> main_ev(mains, mains + ni);
+  if (zk) {
+    std::vector<size_t> hs, ws;
+    std::vector<uint64_t> keys;
+    for (size_t i = 0; i < ni; ++i) { hs.push_back(mains[i]->h); ws.push_back(mains[i]->w); keys.push_back(zkey(ZK_ROUND_MAIN, i)); }
+    main_r = zk_randomize<PP>(ctx, main_ev, hs, ws, R, keys, false);
+    for (size_t i = 0; i < ni; ++i) main_ev[i] = main_r[i].get();
+  }
+  for (size_t i = 0; i < ni; ++i) lde_items.push_back({main_ev[i], PP::GEN});
   std::vector<std::unique_ptr<p3r_dmat>> main_lde = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
   std::vector<const p3r_dmat*> ptrs;
   for (size_t i = 0; i < ni; ++i) ptrs.push_back(main_lde[i].get());
-  std::vector<uint32_t> main_cap, perm_cap, quot_cap;
+  std::vector<uint32_t> main_cap, perm_cap, quot_cap, rand_cap;
   auto main_tree = commit_dmats<PP>(ctx, ptrs, main_cap);
 
   prof_stage(ctx, "transcript_head");
   // ---- 2. transcript head
   ch.observe_base_as_ext(ni);
   for (size_t i = 0; i < ni; ++i) {
-    ch.observe_base_as_ext(log_n[i]);
+    ch.observe_base_as_ext(log_e[i]);   // extended degree bits, base degree bits, width, chunk count (:538-558)
     ch.observe_base_as_ext(log_n[i]);
     ch.observe_base_as_ext(mains[i]->w);
-    ch.observe_base_as_ext(uint64_t(1) << layouts[i].log_chunks);
+    ch.observe_base_as_ext(uint64_t(1) << (layouts[i].log_chunks + zk));
   }
   for (uint32_t v : main_cap) ch.observe(F::raw(v));
   for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(air_prep_width_of(prep->airs[i]));
@@ -228,7 +297,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     for (int j = 0; j < tuple_w; ++j) { lc.beta_pow[j] = to_e4<PP, DC>(bp); bp *= beta_l; }
     lc.prefix = to_e4<PP, DC>(alpha_l + bp);  // alpha + beta^(D+1), bus id 0
   }
-  std::vector<std::unique_ptr<p3r_dmat>> aux(ni), aux_lde(ni);
+  std::vector<std::unique_ptr<p3r_dmat>> aux(ni), aux_lde(ni), aux_r(ni);
+  std::vector<const p3r_dmat*> aux_ev(ni, nullptr);   // the committed permutation evaluations (ZK: randomised)
   std::vector<E> terminals(ni, E::zero());
   std::vector<int> perm_insts;
   std::unique_ptr<p3r_tree> perm_tree;
@@ -277,8 +347,23 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       hipLaunchKernelGGL((k_ef_scan<PP, DC>), dim3(tiles), dim3(kBlock), 0, ctx->stream, 2, d_jobs, nj);
       P3R_HIP(hipGetLastError());
     }
+    for (int i : perm_insts) aux_ev[i] = aux[i].get();
+    if (zk) {
+      std::vector<const p3r_dmat*> src;
+      std::vector<size_t> hs, ws;
+      std::vector<uint64_t> keys;
+      for (size_t k = 0; k < perm_insts.size(); ++k) {
+        const p3r_dmat* a = aux[perm_insts[k]].get();
+        src.push_back(a); hs.push_back(a->h); ws.push_back(a->w); keys.push_back(zkey(ZK_ROUND_PERM, k));
+      }
+      auto rs = zk_randomize<PP>(ctx, src, hs, ws, R, keys, false);
+      for (size_t k = 0; k < perm_insts.size(); ++k) {
+        aux_r[perm_insts[k]] = std::move(rs[k]);
+        aux_ev[perm_insts[k]] = aux_r[perm_insts[k]].get();
+      }
+    }
     lde_items.clear();
-    for (int i : perm_insts) lde_items.push_back({aux[i].get(), PP::GEN});
+    for (int i : perm_insts) lde_items.push_back({aux_ev[i], PP::GEN});
     auto ldes = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
     ptrs.clear();
     for (size_t k = 0; k < perm_insts.size(); ++k) {
@@ -322,7 +407,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   for (size_t i = 0; i < ni; ++i) {
     const AirParams& a = prep->airs[i];
     const auto& L = layouts[i];
-    const int lq = L.log_chunks, C = 1 << lq;
+    // quotient domain of 2^(log_qd + is_zk) chunk cosets of the BASE trace size (batch_stark.rs:701-717)
+    const int lq = L.log_chunks + zk, C = 1 << lq;
     const size_t n = mains[i]->h;
     const int n_base = air_num_base_constraints<PP>(a);
     QuotientArgs q{};
@@ -371,6 +457,75 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     launch_quotient<PP, DC>(ctx, quot_blocks, reinterpret_cast<const QuotientArgs*>(d_quot.p), (int)quot_jobs.size(), lc);
     P3R_HIP(hipGetLastError());
   }
+  std::vector<std::unique_ptr<p3r_dmat>> zk_keep;   // masks, coset moves and the randomised chunk matrices
+  if (zk) {
+    // HidingFriPcs::commit_quotient from the acceptance side.  The verifier opens chunk c over
+    // natural_domain_for_degree(2n) (batch_stark.rs:719-727) and recomposes quotient(zeta) = sum_c zp_c(zeta) q'_c(zeta),
+    // zp_c(x) = prod_{j != c} Z_j(x) / Z_j(s_c), Z_j(x) = (x / s_j)^n - 1 (verifier/quotient.rs).  q'_c = q_c + Z_c t_c
+    // leaves the sum unchanged iff sum_c k_c t_c = 0, k_c = prod_{j != c} 1 / Z_j(s_c): C - 1 independent random masks
+    // t_c of degree < n and t_{C-1} = -(1 / k_{C-1}) sum_{c < C-1} k_c t_c.  Each mask is n random evaluations over the
+    // common coset U = u <g_n>, u = s_{C-1} g_2n; the committed matrix of chunk c is q'_c over s_c <g_2n>: even rows
+    // the chunk evaluations, odd rows q_c - 2 t_c on s_c g_2n <g_n> (Z_c = g_2n^n - 1 = -2 there), plus R random
+    // codeword columns.  q_c and t_c reach the odd coset by a coset move (the LDE with no added bits).
+    std::vector<LdeItem> q_moves, t_moves;
+    size_t k0 = 0;
+    for (size_t i = 0; i < ni; ++i) {
+      const int lq = layouts[i].log_chunks + zk, C = 1 << lq;
+      const size_t n = mains[i]->h;
+      const F wq = F::two_adic_generator(log_n[i] + lq), g2 = F::two_adic_generator(log_n[i] + 1);
+      std::vector<F> sh(C), kc(C);
+      for (int c = 0; c < C; ++c) sh[c] = gen * wq.pow(c);
+      for (int c = 0; c < C; ++c) {
+        F d = F::one();
+        for (int j = 0; j < C; ++j)
+          if (j != c) d *= (sh[c] * sh[j].inv()).pow(n) - F::one();
+        kc[c] = d.inv();
+      }
+      const F u = sh[C - 1] * g2, neg_inv_last = -(kc[C - 1].inv());
+      ZkMaskArgs ma{};
+      ma.n = n; ma.C = C; ma.DC = DC;
+      for (int c = 0; c < C; ++c) {
+        zk_keep.push_back(dmat_alloc(n, DC));
+        ma.t[c] = zk_keep.back()->d;
+        ma.key[c] = zkey(ZK_ROUND_QMASK, k0 + c);
+        ma.coef[c] = (kc[c] * neg_inv_last).v;
+        t_moves.push_back({zk_keep.back().get(), (sh[c] * g2 * u.inv()).to_canonical()});
+        q_moves.push_back({chunks[k0 + c].evals.get(), g2.to_canonical()});
+      }
+      {
+        ProfScope ps(ctx, "zk_masks");
+        hipLaunchKernelGGL(k_zk_masks<PP>, dim3(blocks_for(n * DC)), dim3(kBlock), 0, ctx->stream, ma);
+      }
+      P3R_HIP(hipGetLastError());
+      k0 += C;
+    }
+    auto q_odd = coset_lde_batch<PP>(ctx, q_moves, 0), t_odd = coset_lde_batch<PP>(ctx, t_moves, 0);
+    std::vector<ZkChunkJob> jobs;
+    uint64_t blocks = 0;
+    for (size_t k = 0; k < chunks.size(); ++k) {
+      const size_t n = chunks[k].evals->h;
+      auto m = dmat_alloc(2 * n, (size_t)DC + R);
+      ZkChunkJob j{};
+      j.q = chunks[k].evals->d; j.q_odd = q_odd[k]->d; j.t_odd = t_odd[k]->d; j.dst = m->d;
+      j.n = n; j.log_n = log_n[chunks[k].inst]; j.DC = DC; j.R = R;
+      j.key = zkey(ZK_ROUND_QUOTIENT, k);
+      j.block0 = (uint32_t)blocks;
+      blocks += (uint64_t)(DC + R) * ((2 * n + kBlock - 1) / kBlock);
+      jobs.push_back(j);
+      chunks[k].evals = std::move(m);   // the committed evaluations: 2n x (DC + R) over s_c <g_2n>
+    }
+    if (blocks >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "ZK chunk launch of %llu tiles", (unsigned long long)blocks);
+    DevBuf d_jobs((jobs.size() * sizeof(ZkChunkJob) + 3) / 4);
+    P3R_HIP(ctx->stage.upload(ctx->stream, d_jobs.p, jobs.data(), jobs.size() * sizeof(ZkChunkJob)));
+    {
+      ProfScope ps(ctx, "zk_chunks");
+      hipLaunchKernelGGL(k_zk_chunk<PP>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                         reinterpret_cast<const ZkChunkJob*>(d_jobs.p), (int)jobs.size());
+    }
+    P3R_HIP(hipGetLastError());
+    for (auto& m : q_odd) zk_keep.push_back(std::move(m));   // the stream still reads them
+    for (auto& m : t_odd) zk_keep.push_back(std::move(m));
+  }
   {
     // commit evaluates each chunk polynomial on gen*<w>: shift = GENERATOR / domain shift
     lde_items.clear();
@@ -382,46 +537,81 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   for (auto& ck : chunks) ptrs.push_back(ck.lde.get());
   auto quot_tree = commit_dmats<PP>(ctx, ptrs, quot_cap);
   for (uint32_t v : quot_cap) ch.observe(F::raw(v));
+  // ZK: the random round - per instance a fully random matrix of Challenge::DIMENSION (+ R) columns over the extended
+  // trace domain, opened at zeta; its commitment is observed after the quotient's (batch_stark.rs:623-625)
+  std::vector<std::unique_ptr<p3r_dmat>> rand_ev, rand_lde;
+  std::unique_ptr<p3r_tree> rand_tree;
+  if (zk) {
+    std::vector<const p3r_dmat*> src(ni, nullptr);
+    std::vector<size_t> hs, ws(ni, (size_t)DC);
+    std::vector<uint64_t> keys;
+    for (size_t i = 0; i < ni; ++i) { hs.push_back(mains[i]->h); keys.push_back(zkey(ZK_ROUND_RANDOM, i)); }
+    rand_ev = zk_randomize<PP>(ctx, src, hs, ws, R, keys, false);
+    lde_items.clear();
+    for (auto& m : rand_ev) lde_items.push_back({m.get(), PP::GEN});
+    rand_lde = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
+    ptrs.clear();
+    for (auto& m : rand_lde) ptrs.push_back(m.get());
+    rand_tree = commit_dmats<PP>(ctx, ptrs, rand_cap);
+    for (uint32_t v : rand_cap) ch.observe(F::raw(v));
+  }
   const E zeta = ch.sample_ext();
 
   prof_stage(ctx, "openings");
   // ---- 5. openings, observed in round / matrix / point order
+  // Rounds: [random,] main, quotient, preprocessed, permutation (batch_stark.rs:645-852).  Every committed matrix is
+  // opened in full; under ZK the last R values of each opening are the random codewords' - HidingFriPcs splits them off
+  // into the opening proof's first item and the verifier merges them back before observing (:855-864, :1116-1260).
   struct Item { int round, mat; const p3r_dmat* lde; int log_h; std::vector<E> z; std::vector<std::vector<E>> vals; size_t job; };
   std::vector<Item> items;
   std::vector<std::vector<std::vector<E>>> o_main(ni), o_prep(ni), o_perm(ni);
-  std::vector<std::vector<E>> o_chunks(chunks.size());
+  std::vector<std::vector<E>> o_chunks(chunks.size()), o_rand(ni);
+  const int r_main = zk, r_quot = zk + 1, r_prep = zk + 2, r_perm = zk + 3;
   Opener<PP, DC> op(ctx);  // keeps the opened values on the device for the reduced openings
   {
+    if (zk)
+      for (size_t i = 0; i < ni; ++i) {
+        size_t j = op.open(rand_ev[i]->d, rand_ev[i]->h, (int)rand_ev[i]->w, F::one(), {zeta});
+        items.push_back({0, (int)i, rand_lde[i].get(), log_e[i], {zeta}, {}, j});
+      }
     for (size_t i = 0; i < ni; ++i) {
       std::vector<E> pts{zeta};
+      // zeta * g of the BASE trace domain (:663-700)
       if (air_uses_next(prep->airs[i])) pts.push_back(zeta * F::two_adic_generator(log_n[i]));
-      size_t j = op.open(mains[i]->d, mains[i]->h, (int)mains[i]->w, F::one(), pts);
-      items.push_back({0, (int)i, main_lde[i].get(), log_n[i], pts, {}, j});
+      size_t j = op.open(main_ev[i]->d, main_ev[i]->h, (int)main_ev[i]->w, F::one(), pts);
+      items.push_back({r_main, (int)i, main_lde[i].get(), log_e[i], pts, {}, j});
     }
     for (size_t k = 0; k < chunks.size(); ++k) {
       auto& ck = chunks[k];
-      size_t j = op.open(ck.evals->d, ck.evals->h, DC, ck.shift, {zeta});
-      items.push_back({1, (int)k, ck.lde.get(), log_n[ck.inst], {zeta}, {}, j});
+      size_t j = op.open(ck.evals->d, ck.evals->h, (int)ck.evals->w, ck.shift, {zeta});
+      items.push_back({r_quot, (int)k, ck.lde.get(), log_e[ck.inst], {zeta}, {}, j});
     }
     for (size_t i = 0; i < ni; ++i) {
       std::vector<E> pts{zeta, zeta * F::two_adic_generator(log_n[i])};
-      const p3r_dmat* pt = prep->traces[i].get();
+      const p3r_dmat* pt = prep->committed(i);
       size_t j = op.open(pt->d, pt->h, (int)pt->w, F::one(), pts);
-      items.push_back({2, (int)i, prep->ldes[i].get(), log_n[i], pts, {}, j});
+      items.push_back({r_prep, (int)i, prep->ldes[i].get(), log_e[i], pts, {}, j});
     }
     for (size_t k = 0; k < perm_insts.size(); ++k) {
       int i = perm_insts[k];
       std::vector<E> pts{zeta, zeta * F::two_adic_generator(log_n[i])};
-      size_t j = op.open(aux[i]->d, aux[i]->h, (int)aux[i]->w, F::one(), pts);
-      items.push_back({3, (int)k, aux_lde[i].get(), log_n[i], pts, {}, j});
+      size_t j = op.open(aux_ev[i]->d, aux_ev[i]->h, (int)aux_ev[i]->w, F::one(), pts);
+      items.push_back({r_perm, (int)k, aux_lde[i].get(), log_e[i], pts, {}, j});
     }
     auto all = op.finish();
+    // the proof's own fields hold the values of the AIR's columns: the openings without their R codeword values
+    auto head = [&](const std::vector<std::vector<E>>& v) {
+      std::vector<std::vector<E>> o;
+      for (auto& pv : v) o.emplace_back(pv.begin(), pv.end() - R);
+      return o;
+    };
     for (auto& it : items) {
       it.vals = all[it.job];
-      if (it.round == 0) o_main[it.mat] = it.vals;
-      else if (it.round == 1) o_chunks[it.mat] = it.vals[0];
-      else if (it.round == 2) o_prep[it.mat] = it.vals;
-      else o_perm[perm_insts[it.mat]] = it.vals;
+      if (it.round == r_main) o_main[it.mat] = head(it.vals);
+      else if (it.round == r_quot) o_chunks[it.mat] = head(it.vals)[0];
+      else if (it.round == r_prep) o_prep[it.mat] = head(it.vals);
+      else if (it.round == r_perm) o_perm[perm_insts[it.mat]] = head(it.vals);
+      else o_rand[it.mat] = head(it.vals)[0];
     }
   }
   // 1/(zeta - x) vectors of the reduced openings depend on the opening points only: the device
@@ -486,7 +676,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
                           lk ? &terminals[i] : nullptr};
       try {
         check_instance_at_zeta<PP, DC>(prep->airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow,
-                                   ctx->rc_mont_host.data(), i);
+                                   ctx->rc_mont_host.data(), i, zk);
       } catch (const VerifyFailure& e) {
         fail(P3R_EINVAL, "the traces do not satisfy the constraints (%s)", e.what());
       }
@@ -744,8 +934,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
 
   prof_stage(ctx, "queries");
   // ---- 8. queries: one gather launch for every opened row / sibling of every query
-  const p3r_tree* round_trees[4] = {main_tree.get(), quot_tree.get(), prep->tree.get(), perm_tree.get()};
-  const int n_rounds = any_lookup ? 4 : 3;
+  std::vector<const p3r_tree*> round_trees;
+  if (zk) round_trees.push_back(rand_tree.get());
+  round_trees.push_back(main_tree.get()); round_trees.push_back(quot_tree.get()); round_trees.push_back(prep->tree.get());
+  if (any_lookup) round_trees.push_back(perm_tree.get());
+  const int n_rounds = (int)round_trees.size();
   std::vector<size_t> indices(cfg.num_queries);
   for (auto& ix : indices) ix = ch.sample_bits(log_max);
   // the item list is the same for every query (kernels_stark.hip.h, k_gather); offsets are relative
@@ -840,13 +1033,13 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     W.cap_mont(main_cap);
     if (any_lookup) { W.byte(1); W.cap_mont(perm_cap); } else W.byte(0);
     W.cap_mont(quot_cap);
-    W.byte(0);  // random commitment (ZK): none
+    if (zk) { W.byte(1); W.cap_mont(rand_cap); } else W.byte(0);  // random commitment: Some iff Pcs::ZK (batch_stark.rs:424-428)
   };
   auto write_opened = [&] {
     W.varint(ni);
     size_t ck = 0;
     for (size_t i = 0; i < ni; ++i) {
-      const size_t C = size_t(1) << layouts[i].log_chunks;
+      const size_t C = size_t(1) << (layouts[i].log_chunks + zk);
       for (int f = 0; f < 8; ++f) {
         switch (PL.opened[f]) {
           case 0: W.vec_ef(o_main[i][0]); break;
@@ -857,7 +1050,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
             W.varint(C);
             for (size_t c = 0; c < C; ++c) W.vec_ef(o_chunks[ck++]);
             break;
-          case 5: W.byte(0); break;  // random opened values: none
+          case 5: if (zk) { W.byte(1); W.vec_ef(o_rand[i]); } else W.byte(0); break;  // random: Option<Vec<Challenge>>
           case 6: if (!o_perm[i].empty()) W.vec_ef(o_perm[i][0]); else W.varint(0); break;
           default: if (!o_perm[i].empty()) W.vec_ef(o_perm[i][1]); else W.varint(0); break;
         }
@@ -903,6 +1096,23 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     }
   };
   auto write_fri = [&] {
+    if (zk) {
+      // HidingFriPcs::Proof = (OpenedValues<Challenge>, FriProof): rounds -> matrices -> points -> the R codeword values
+      // (pcs/fri/targets.rs:956-1005); a tuple has no framing of its own
+      W.varint((size_t)n_rounds);
+      size_t at = 0;
+      for (int r = 0; r < n_rounds; ++r) {
+        size_t n_m = 0;
+        while (at + n_m < items.size() && items[at + n_m].round == r) ++n_m;
+        W.varint(n_m);
+        for (size_t m = 0; m < n_m; ++m) {
+          const Item& it = items[at + m];
+          W.varint(it.vals.size());
+          for (auto& pv : it.vals) W.vec_ef(std::vector<E>(pv.end() - R, pv.end()));
+        }
+        at += n_m;
+      }
+    }
     for (int f = 0; f < 5; ++f) {
       switch (PL.fri[f]) {
         case 0:
@@ -932,7 +1142,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         break;
       default:
         W.varint(ni);
-        for (size_t i = 0; i < ni; ++i) W.varint(log_n[i]);
+        for (size_t i = 0; i < ni; ++i) W.varint(log_e[i]);   // ZK: the extended degree bits
         break;
     }
   }

@@ -10,6 +10,10 @@
 //   MMCS openings (mixed heights, injection, cap)   recursion/src/pcs/mmcs.rs:319-426, circuit/src/ops/mmcs.rs:81-209
 //   FRI: reduced openings, folds, roll-ins, final polynomial, proofs of work
 //                                                   recursion/src/pcs/fri/verifier.rs:424-465,562-781,887-981,1068-1356
+//   ZK (HidingFriPcs, p3r_config.zk)                batch_stark.rs:424-428 (randomisation presence), :487-490,536 (degree
+//                                                   bits), :623-661 (random commitment, its round), :701-735 (quotient
+//                                                   domains), :855-864,1116-1260 and pcs/fri/targets.rs:1076-1130 (the
+//                                                   opening proof's random opened values, merged into every point)
 // The AIR statements are the ones the quotient kernel evaluates (air_device.hip.h), instantiated
 // over the extension field at zeta.
 #pragma once
@@ -100,12 +104,14 @@ struct ParsedProof {
   using Digest = std::array<F, P2_DIGEST>;
   using Cap = std::vector<Digest>;
   Cap main_cap, quot_cap;
-  std::optional<Cap> perm_cap;
+  std::optional<Cap> perm_cap, rand_cap;
   struct Inst {
     std::vector<E> main_local, prep_local, prep_next, perm_local, perm_next;
-    std::optional<std::vector<E>> main_next;
+    std::optional<std::vector<E>> main_next, random;
     std::vector<std::vector<E>> chunks;
   };
+  // HidingFriPcs::Proof = (OpenedValues<Challenge>, FriProof): rounds -> matrices -> points -> random codeword values
+  std::vector<std::vector<std::vector<std::vector<E>>>> fri_random;
   std::vector<Inst> insts;
   std::vector<Cap> commit_caps;
   std::vector<F> commit_pow;
@@ -122,15 +128,16 @@ struct ParsedProof {
 // `consumed`: when given, trailing bytes are allowed and the length of the BatchProof is returned
 // (the outer BatchStarkProof appends its metadata after it, batch_stark_prover.rs:610-636).
 template <class PP, int DC = 4>
+// `zk`: the proof type is the hiding PCS's - a property of the configuration (SC::Pcs in the reference), not of the bytes.
 ParsedProof<PP, DC> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size_t* consumed = nullptr,
-                            const ProofLayout& PL = ProofLayout{}) {
+                            const ProofLayout& PL = ProofLayout{}, bool zk = false) {
   ProofReader<PP, DC> R{bytes, bytes + n, canonical};
   ParsedProof<PP, DC> P;
   auto read_commitments = [&] {
     P.main_cap = R.cap();
     if (R.flag()) P.perm_cap = R.cap();
     P.quot_cap = R.cap();
-    if (R.flag()) vfail("proof carries a random (ZK) commitment: not supported");
+    if (R.flag()) P.rand_cap = R.cap();
   };
   auto read_opened = [&] {
     P.insts.resize(R.len(64));
@@ -145,7 +152,7 @@ ParsedProof<PP, DC> parse_proof(const uint8_t* bytes, size_t n, bool canonical, 
             in.chunks.resize(R.len(8));
             for (auto& c : in.chunks) c = R.vec_ef();
             break;
-          case 5: if (R.flag()) vfail("proof carries random opened values: not supported"); break;
+          case 5: if (R.flag()) in.random = R.vec_ef(); break;
           case 6: in.perm_local = R.vec_ef(); break;
           default: in.perm_next = R.vec_ef(); break;
         }
@@ -176,6 +183,16 @@ ParsedProof<PP, DC> parse_proof(const uint8_t* bytes, size_t n, bool canonical, 
     }
   };
   auto read_fri = [&] {
+    if (zk) {
+      P.fri_random.resize(R.len(8));
+      for (auto& rd : P.fri_random) {
+        rd.resize(R.len(256));
+        for (auto& m : rd) {
+          m.resize(R.len(2));
+          for (auto& pt : m) pt = R.vec_ef(16);
+        }
+      }
+    }
     for (int f = 0; f < 5; ++f) {
       switch (PL.fri[f]) {
         case 0:
@@ -303,7 +320,7 @@ struct ProofSkimmer {
 
 // Same grammar as parse_proof; returns the length of the BatchProof at the head of `bytes`.
 template <class PP>
-size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofLayout{}, int dc = 4) {
+size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofLayout{}, int dc = 4, bool zk = false) {
   ProofSkimmer<PP> R{bytes, bytes + n};
   R.dc = dc;
   auto opened = [&] {
@@ -316,7 +333,7 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
           case 2: if (!R.flag()) vfail("preprocessed_local missing"); R.vec_ef(); break;
           case 3: if (!R.flag()) vfail("preprocessed_next missing"); R.vec_ef(); break;
           case 4: { const size_t nc = R.len(8); for (size_t c = 0; c < nc; ++c) R.vec_ef(); break; }
-          case 5: if (R.flag()) vfail("proof carries random opened values: not supported"); break;
+          case 5: if (R.flag()) R.vec_ef(); break;
           default: R.vec_ef(); break;
         }
       }
@@ -339,6 +356,16 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
     }
   };
   auto fri = [&] {
+    if (zk) {
+      const size_t nr = R.len(8);
+      for (size_t r = 0; r < nr; ++r) {
+        const size_t nm = R.len(256);
+        for (size_t m = 0; m < nm; ++m) {
+          const size_t np = R.len(2);
+          for (size_t k = 0; k < np; ++k) R.vec_ef(16);
+        }
+      }
+    }
     for (int f = 0; f < 5; ++f) {
       switch (PL.fri[f]) {
         case 0: { const size_t nc = R.len(64); for (size_t c = 0; c < nc; ++c) R.cap(); break; }
@@ -355,7 +382,7 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
         R.cap();
         if (R.flag()) R.cap();
         R.cap();
-        if (R.flag()) vfail("proof carries a random (ZK) commitment: not supported");
+        if (R.flag()) R.cap();
         break;
       case 1: opened(); break;
       case 2: fri(); break;
@@ -369,9 +396,9 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
 // The metadata fields that follow the inner BatchProof (BatchStarkProof, batch_stark_prover.rs:610-636).
 template <class PP>
 void parse_batch_stark_meta(const uint8_t* bytes, size_t len, bool canonical, const ProofLayout& PL, int dc,
-                            p3r_batch_stark_meta* M) {
+                            p3r_batch_stark_meta* M, bool zk = false) {
   std::memset(M, 0, sizeof *M);
-  M->proof_len = skim_proof<PP>(bytes, len, PL, dc);
+  M->proof_len = skim_proof<PP>(bytes, len, PL, dc, zk);
   ProofSkimmer<PP> R{bytes + M->proof_len, bytes + len};
   auto u32 = [&](const char* what) {
     const uint64_t v = R.varint();
@@ -495,8 +522,8 @@ struct ZetaLookupSink {
   E beta_pow[kMaxExtD + 1];
   const std::vector<E>& aux;  // EF aux columns at zeta: [0] running sum, [g + 1] fraction of group g
   ZetaFold<PP, DC>& fold;
-  int pair, cnt = 0;
-  E d0 = E::zero(), m0 = E::zero(), sum_f = E::zero();
+  int pair, cnt = 0, held = 0;
+  E d0 = E::zero(), m0 = E::zero(), d1 = E::zero(), m1 = E::zero(), sum_f = E::zero();
   template <int D>
   E denom(const E& idx, const VD<E, D>& v) const {
     E d = prefix + beta_pow[0] * idx;
@@ -511,20 +538,29 @@ struct ZetaLookupSink {
       const E f = aux.at(cnt);
       fold.ext(f * d - mult);
       sum_f += f;
-    } else if (cnt & 1) {
-      d0 = d; m0 = mult;
-    } else {
+    } else if (held == 0) {
+      d0 = d; m0 = mult; held = 1;
+    } else if (pair == 1) {
       const E f = aux.at(cnt / 2);
       fold.ext(f * d0 * d - (d * m0 + d0 * mult));
       sum_f += f;
+      held = 0;
+    } else if (held == 1) {
+      d1 = d; m1 = mult; held = 2;
+    } else {   // triples (the budget of a ZK configuration)
+      const E f = aux.at(cnt / 3);
+      fold.ext(f * d0 * d1 * d - (m0 * d1 * d + m1 * d0 * d + mult * d0 * d1));
+      sum_f += f;
+      held = 0;
     }
   }
   void finish() {
-    if (pair && (cnt & 1)) {
-      const E f = aux.at((cnt + 1) / 2);
-      fold.ext(f * d0 - m0);
-      sum_f += f;
-    }
+    if (!held) return;
+    const int G = pair + 1;
+    const E f = aux.at((cnt + G - 1) / G);
+    if (held == 1) fold.ext(f * d0 - m0);
+    else fold.ext(f * d0 * d1 - (m0 * d1 + m1 * d0));
+    sum_f += f;
   }
 };
 
@@ -676,11 +712,13 @@ struct ZetaInstance {
   const std::vector<std::vector<E>>* chunks;
   const E* terminal;  // null without lookups
 };
+// log_n_i: the BASE trace degree bits; is_zk: the quotient domain has 2^(log_chunks + is_zk) chunk cosets of the base
+// trace size (batch_stark.rs:701-717).
 template <class PP, int DC = 4>
 void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log_n_i, const ZetaInstance<PP, DC>& in,
                             typename Chal<PP, DC>::type alpha, typename Chal<PP, DC>::type zeta,
                             typename Chal<PP, DC>::type l_prefix, const typename Chal<PP, DC>::type* l_beta_pow,
-                            const uint32_t* rc_mont, size_t i) {
+                            const uint32_t* rc_mont, size_t i, int is_zk = 0) {
   using F = Fp<PP>;
   using E = typename Chal<PP, DC>::type;
   const F gen = F::generator();
@@ -736,8 +774,9 @@ void check_instance_at_zeta(const AirParams& air, const LookupLayout& L, int log
     }
     // quotient(zeta) = sum_c L_c(zeta) * Q_c(zeta) over the 2^log_chunks cosets of the quotient domain
     // (recursion/src/verifier/quotient.rs:60-)
-    const int lq = L.log_chunks;
+    const int lq = L.log_chunks + is_zk;
     const size_t C = size_t(1) << lq;
+    if (in.chunks->size() != C) vfail("instance %zu: %zu quotient chunks, expected %zu", i, in.chunks->size(), C);
     const F wq = F::two_adic_generator(log_n_i + lq);
     std::vector<F> shifts(C);
     for (size_t c = 0; c < C; ++c) shifts[c] = gen * wq.pow(c);
@@ -769,6 +808,8 @@ struct VerifyParams {
   std::vector<uint8_t> fri_log_arities;  // explicit folding schedule (p3r_config), empty: the rule
   ProofLayout layout;                    // field order of the serialised structs (p3r_config.proof_layout)
   int mmcs_arity = 2;                    // 4: the arity-4 MMCS over the width-32 permutation (p3r_config.mmcs_arity)
+  int zk = 0;                            // HidingFriPcs (p3r_config.zk)
+  int num_random_codewords = 0;          // random codeword columns per committed matrix (p3r_config.num_random_codewords)
 };
 
 template <class PP, int DC = 4>
@@ -778,7 +819,9 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   using F = Fp<PP>;
   using E = typename Chal<PP, DC>::type;
   using Digest = std::array<F, P2_DIGEST>;
-  const ParsedProof<PP, DC> P = parse_proof<PP, DC>(bytes, n_bytes, canonical, nullptr, prm.layout);
+  const int zk = prm.zk ? 1 : 0, R = zk ? prm.num_random_codewords : 0;
+  if (zk && (R < 1 || R > 8)) vfail("num_random_codewords must be in 1..8");
+  const ParsedProof<PP, DC> P = parse_proof<PP, DC>(bytes, n_bytes, canonical, nullptr, prm.layout, zk != 0);
   const size_t ni = airs.size();
   // the width-16 round constants, followed by the width-32 table (poseidon2.h; csrc/p3r_core.hip::constants_table)
   if (rc_canonical.size() != (size_t)p2_num_constants<PP>() + (size_t)p2w_num_constants<PP>()) vfail("wrong number of permutation constants");
@@ -794,22 +837,31 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
     for (int k = 0; k < P2_DIGEST; ++k) prep_cap[j][k] = F::from_canonical(prep_cap_canonical[j * P2_DIGEST + k]);
 
   // ---- shapes
+  // randomisation must match the PCS's ZK setting (batch_stark.rs:424-428: RandomizationError)
+  if (P.rand_cap.has_value() != (zk != 0)) vfail("RandomizationError: random commitment presence does not match the ZK setting");
+  for (auto& in : P.insts)
+    if (in.random.has_value() != (zk != 0)) vfail("RandomizationError: random opened values presence does not match the ZK setting");
   std::vector<LookupLayout> layouts(ni);
-  std::vector<int> log_n(ni), width(ni), prep_w(ni);
+  std::vector<int> log_n(ni), log_e(ni), width(ni), prep_w(ni);   // base / extended (committed) degree bits
   bool any_lookup = false;
   std::vector<int> perm_insts;
   for (size_t i = 0; i < ni; ++i) {
     const auto& in = P.insts[i];
-    layouts[i] = lookup_layout(airs[i]);
-    log_n[i] = P.degree_bits[i];
-    // the domains are the verifier's, not the prover's: recursion/src/verifier/batch_stark.rs:793
-    if (expected_degree_bits.size() != ni || (uint32_t)log_n[i] != expected_degree_bits[i])
-      vfail("InvalidProofShape: instance %zu declares degree_bits %d, the preprocessed metadata has %u", i, log_n[i],
+    layouts[i] = lookup_layout(airs[i], zk);
+    log_e[i] = P.degree_bits[i];
+    // the domains are the verifier's, not the prover's: recursion/src/verifier/batch_stark.rs:793 (ZK: the preprocessed
+    // metadata holds the EXTENDED degree bits, recursion.rs:374)
+    if (expected_degree_bits.size() != ni || (uint32_t)log_e[i] != expected_degree_bits[i])
+      vfail("InvalidProofShape: instance %zu declares degree_bits %d, the preprocessed metadata has %u", i, log_e[i],
             i < expected_degree_bits.size() ? expected_degree_bits[i] : 0u);
-    if (log_n[i] + lb > PP::TWO_ADICITY) vfail("instance %zu: degree too large", i);
+    if (log_e[i] < zk) vfail("InvalidProofShape: extended degree bits smaller than the ZK adjustment");   // :536
+    log_n[i] = log_e[i] - zk;
+    if (log_e[i] + lb > PP::TWO_ADICITY) vfail("instance %zu: degree too large", i);
     width[i] = air_width_of(airs[i], p2w, p2w_perm_cols<PP>() + 4);
     prep_w[i] = air_prep_width_of(airs[i]);
-    const size_t aw = (size_t)layouts[i].aux_width() * DC, C = size_t(1) << layouts[i].log_chunks;
+    // quotient_degree = 1 << (log_qd + is_zk) (:487-496)
+    const size_t aw = (size_t)layouts[i].aux_width() * DC, C = size_t(1) << (layouts[i].log_chunks + zk);
+    if (in.random && in.random->size() != (size_t)DC) vfail("RandomizationError: instance %zu: %zu random opened values", i, in.random->size());
     if (in.main_local.size() != (size_t)width[i]) vfail("instance %zu: %zu main openings, the AIR has %d columns", i, in.main_local.size(), width[i]);
     if (air_uses_next(airs[i]) != in.main_next.has_value()) vfail("instance %zu: main next-row openings do not match the AIR", i);
     if (in.main_next && in.main_next->size() != (size_t)width[i]) vfail("instance %zu: bad main next width", i);
@@ -827,10 +879,10 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   auto observe_cap = [&](const std::vector<Digest>& cap) { for (auto& d : cap) for (auto x : d) ch.observe(x); };
   ch.observe_base_as_ext(ni);
   for (size_t i = 0; i < ni; ++i) {
-    ch.observe_base_as_ext(log_n[i]);
+    ch.observe_base_as_ext(log_e[i]);
     ch.observe_base_as_ext(log_n[i]);
     ch.observe_base_as_ext(width[i]);
-    ch.observe_base_as_ext(uint64_t(1) << layouts[i].log_chunks);
+    ch.observe_base_as_ext(uint64_t(1) << (layouts[i].log_chunks + zk));
   }
   observe_cap(P.main_cap);
   for (size_t i = 0; i < ni; ++i) ch.observe_base_as_ext(prep_w[i]);
@@ -851,21 +903,55 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   }
   const E alpha = ch.sample_ext();
   observe_cap(P.quot_cap);
+  if (zk) observe_cap(*P.rand_cap);   // :623-625
   const E zeta = ch.sample_ext();
-  for (size_t i = 0; i < ni; ++i) {
-    for (auto& v : P.insts[i].main_local) ch.observe_ext(v);
-    if (P.insts[i].main_next) for (auto& v : *P.insts[i].main_next) ch.observe_ext(v);
+  // input batches in round order ([random,] main, quotient, preprocessed, permutation): matrices (log LDE height,
+  // width), points and claimed values.  ZK: every committed matrix has R more columns - the random codewords - whose
+  // values at each point are the opening proof's first item; they are appended to the point's values before anything
+  // is observed or reduced (merge_hiding_random_openings, pcs/fri/targets.rs:1076-1130; batch_stark.rs:1116-1260).
+  struct Mat { int log_h; int w; std::vector<E> z; std::vector<std::vector<E>> vals; };
+  std::vector<std::vector<Mat>> rounds;
+  if (zk) {
+    rounds.emplace_back();
+    for (size_t i = 0; i < ni; ++i) rounds.back().push_back({log_e[i] + lb, DC, {zeta}, {*P.insts[i].random}});   // :645-661
   }
+  rounds.emplace_back();
+  for (size_t i = 0; i < ni; ++i) {
+    Mat m{log_e[i] + lb, width[i], {zeta}, {P.insts[i].main_local}};
+    // zeta * g of the BASE trace domain (:663-700)
+    if (P.insts[i].main_next) { m.z.push_back(zeta * F::two_adic_generator(log_n[i])); m.vals.push_back(*P.insts[i].main_next); }
+    rounds.back().push_back(m);
+  }
+  rounds.emplace_back();
+  for (size_t i = 0; i < ni; ++i)   // randomized_quotient_domains: natural_domain_for_degree(size << is_zk) (:719-727)
+    for (auto& c : P.insts[i].chunks) rounds.back().push_back({log_e[i] + lb, DC, {zeta}, {c}});
+  rounds.emplace_back();
   for (size_t i = 0; i < ni; ++i)
-    for (auto& c : P.insts[i].chunks) for (auto& v : c) ch.observe_ext(v);
-  for (size_t i = 0; i < ni; ++i) {
-    for (auto& v : P.insts[i].prep_local) ch.observe_ext(v);
-    for (auto& v : P.insts[i].prep_next) ch.observe_ext(v);
+    rounds.back().push_back({log_e[i] + lb, prep_w[i], {zeta, zeta * F::two_adic_generator(log_n[i])},
+                             {P.insts[i].prep_local, P.insts[i].prep_next}});
+  if (any_lookup) {
+    rounds.emplace_back();
+    for (int i : perm_insts)
+      rounds.back().push_back({log_e[i] + lb, layouts[i].aux_width() * DC, {zeta, zeta * F::two_adic_generator(log_n[i])},
+                               {P.insts[i].perm_local, P.insts[i].perm_next}});
   }
-  for (int i : perm_insts) {
-    for (auto& v : P.insts[i].perm_local) ch.observe_ext(v);
-    for (auto& v : P.insts[i].perm_next) ch.observe_ext(v);
+  if (zk) {
+    if (P.fri_random.size() != rounds.size()) vfail("InvalidProofShape: hiding FRI proof: random rounds count does not match commitments");
+    for (size_t r = 0; r < rounds.size(); ++r) {
+      if (P.fri_random[r].size() != rounds[r].size()) vfail("InvalidProofShape: hiding FRI proof: random matrices count does not match (round %zu)", r);
+      for (size_t m = 0; m < rounds[r].size(); ++m) {
+        Mat& M = rounds[r][m];
+        if (P.fri_random[r][m].size() != M.z.size()) vfail("InvalidProofShape: hiding FRI proof: random points count does not match (round %zu matrix %zu)", r, m);
+        for (size_t p = 0; p < M.z.size(); ++p) {
+          const auto& extra = P.fri_random[r][m][p];
+          if (extra.size() != (size_t)R) vfail("InvalidProofShape: hiding FRI proof: %zu random codeword values, expected %d", extra.size(), R);
+          M.vals[p].insert(M.vals[p].end(), extra.begin(), extra.end());
+        }
+        M.w += R;
+      }
+    }
   }
+  for (auto& r : rounds) for (auto& m : r) for (auto& pv : m.vals) for (auto& v : pv) ch.observe_ext(v);
 
   // ---- constraints at zeta
   const F gen = F::generator();
@@ -874,30 +960,17 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
     const auto& in = P.insts[i];
     ZetaInstance<PP, DC> zi{&in.main_local, in.main_next ? &*in.main_next : nullptr, &in.prep_local, &in.prep_next,
                         &in.perm_local, &in.perm_next, &in.chunks, P.terminals[i] ? &*P.terminals[i] : nullptr};
-    check_instance_at_zeta<PP, DC>(airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow, rc.data(), i);
+    check_instance_at_zeta<PP, DC>(airs[i], layouts[i], log_n[i], zi, alpha, zeta, l_prefix, l_beta_pow, rc.data(), i, zk);
     if (layouts[i].n_groups) terminal_sum += *P.terminals[i];
   }
   if (any_lookup && !terminal_sum.is_zero()) vfail("global lookup sum is not zero");
 
   // ---- FRI transcript
   const E fri_alpha = ch.sample_ext();
-  // input batches in round order: matrices (log LDE height, width), points and claimed values
-  struct Mat { int log_h; int w; std::vector<E> z; std::vector<const std::vector<E>*> vals; };
-  std::vector<std::vector<Mat>> rounds(any_lookup ? 4 : 3);
-  for (size_t i = 0; i < ni; ++i) {
-    Mat m{log_n[i] + lb, width[i], {zeta}, {&P.insts[i].main_local}};
-    if (P.insts[i].main_next) { m.z.push_back(zeta * F::two_adic_generator(log_n[i])); m.vals.push_back(&*P.insts[i].main_next); }
-    rounds[0].push_back(m);
-  }
-  for (size_t i = 0; i < ni; ++i)
-    for (auto& c : P.insts[i].chunks) rounds[1].push_back({log_n[i] + lb, DC, {zeta}, {&c}});
-  for (size_t i = 0; i < ni; ++i)
-    rounds[2].push_back({log_n[i] + lb, prep_w[i], {zeta, zeta * F::two_adic_generator(log_n[i])},
-                         {&P.insts[i].prep_local, &P.insts[i].prep_next}});
-  for (int i : perm_insts)
-    rounds[3].push_back({log_n[i] + lb, layouts[i].aux_width() * DC, {zeta, zeta * F::two_adic_generator(log_n[i])},
-                         {&P.insts[i].perm_local, &P.insts[i].perm_next}});
-  const std::vector<Digest>* round_caps[4] = {&P.main_cap, &P.quot_cap, &prep_cap, any_lookup ? &*P.perm_cap : nullptr};
+  std::vector<const std::vector<Digest>*> round_caps;
+  if (zk) round_caps.push_back(&*P.rand_cap);
+  round_caps.push_back(&P.main_cap); round_caps.push_back(&P.quot_cap); round_caps.push_back(&prep_cap);
+  if (any_lookup) round_caps.push_back(&*P.perm_cap);
   int log_max = 0;
   std::vector<int> heights;
   for (auto& r : rounds) for (auto& m : r) { log_max = std::max(log_max, m.log_h); heights.push_back(m.log_h); }
@@ -966,7 +1039,7 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
         for (int c = 0; c < M.w; ++c) S += fa_pow[c] * qr.rows[m][c];
         for (size_t p = 0; p < M.z.size(); ++p) {
           E Vp = E::zero();
-          for (int c = 0; c < M.w; ++c) Vp += fa_pow[c] * (*M.vals[p])[c];
+          for (int c = 0; c < M.w; ++c) Vp += fa_pow[c] * M.vals[p][c];
           it->second.second += it->second.first * (Vp - S) * (M.z[p] - E::from_base(x)).inv();
           it->second.first *= fa_pow[M.w];
         }

@@ -38,7 +38,7 @@ def _u8(a):
 def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5,
                 commit_pow_bits=0, query_pow_bits=15, num_queries=54, device=0, poseidon2_rc=None, ext_choices=0,
                 fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0, challenge_degree=4,
-                poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2):
+                poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2, zk=0, num_random_codewords=2, zk_seed=0):
     """A `p3r_config` (+ the arrays it points into, which must stay alive with it).  `ext_choices` /
     `fri_log_arities`: the selectable protocol details of include/p3r.h.
     `ext_degree`: the circuit extension degree D of the traces - 4, or 5 for KoalaBear circuits over the quintic
@@ -50,6 +50,8 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
     cfg.ext_w = ext_w     # W of x^D = W for ext_degree 2 / 6 / 8 (include/p3r.h)
     cfg.challenge_degree = challenge_degree   # 5: KoalaBear's quintic challenge field
     cfg.mmcs_arity = mmcs_arity               # 4: the arity-4 MMCS over the width-32 permutation (recursive_aggregation --arity4)
+    # ZK: HidingFriPcs with `num_random_codewords` random codewords and a seeded RNG (create_config_zk)
+    cfg.zk, cfg.num_random_codewords, cfg.zk_seed = int(zk), int(num_random_codewords) if zk else 0, int(zk_seed)
     cfg.log_blowup = log_blowup
     cfg.max_log_arity = max_log_arity
     cfg.cap_height = cap_height
@@ -136,9 +138,11 @@ class Context:
     def __init__(self, field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
                  log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
                  device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0,
-                 challenge_degree=4, poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2):
+                 challenge_degree=4, poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2, zk=0,
+                 num_random_codewords=2, zk_seed=0):
         self.lib = _lib.load()
         self.mmcs_arity = mmcs_arity
+        self.zk = int(zk)
         self.field = field
         self.ext_degree = ext_degree
         self.ext_w = ext_w
@@ -147,7 +151,7 @@ class Context:
         cfg, self._rc_keep = make_config(field, log_blowup, max_log_arity, cap_height, log_final_poly_len,
                                          commit_pow_bits, query_pow_bits, num_queries, device, poseidon2_rc, ext_choices,
                                          fri_log_arities, proof_layout, ext_degree, ext_w, challenge_degree,
-                                         poseidon2_w32_rc, poseidon2_w32_diag, mmcs_arity)
+                                         poseidon2_w32_rc, poseidon2_w32_diag, mmcs_arity, zk, num_random_codewords, zk_seed)
         self.cfg = cfg
         self.cap_height = cap_height
         self.log_blowup = log_blowup
@@ -159,6 +163,15 @@ class Context:
         if getattr(self, "h", None):
             self.lib.p3r_destroy(self.h)
             self.h = None
+
+    @property
+    def zk_nonce(self):
+        """Proofs made so far under a ZK configuration (the hiding PCS's RNG state: p3r_zk_nonce)."""
+        return int(self.lib.p3r_zk_nonce(self.h))
+
+    @zk_nonce.setter
+    def zk_nonce(self, v):
+        self.check(self.lib.p3r_zk_set_nonce(self.h, C.c_uint64(int(v))))
 
     def __del__(self):
         try:
