@@ -1216,6 +1216,53 @@ def main():
             rin4.free()
             pc4.free()
             ctx4.close()
+            # SURVEY 8(f).4, ZK: the headline layer under HidingFriPcs (p3r_config.zk = 1: create_config_zk of
+            # recursion/examples/common/mod.rs:511-553 - two random codewords, seeded RNG): every commitment over the
+            # extended trace domain (twice the rows, two more columns), a random round, eight masked quotient chunks per
+            # constrained table instead of two, LogUp packed in triples.  Same circuit, inputs and FRI parameters;
+            # prove_next_layer with a cache; every timed proof is a different proof, the first and the last are verified
+            arrsz = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN_KNOBS)
+            ctxz = p3r.Context(field=field, zk=1, num_random_codewords=2, zk_seed=0x5EED, **FRI)
+            pcz = p3r.PreparedCircuit(ctxz, wl.circuit_from_arrays(arrsz), packing)
+            rinz = pcz.upload_inputs(wl.circuit_inputs_from_arrays(arrsz))
+            del arrsz
+            rawz = pcz.prove(rinz)
+            ctxz.sync()
+            tz = time.perf_counter()
+            for _ in range(5):
+                lastz = pcz.prove(rinz)
+            ctxz.sync()
+            msz = (time.perf_counter() - tz) / 5 * 1e3
+            try:
+                proverz = p3r.BatchStarkProver(ctxz)
+                for rz in (rawz, lastz):
+                    proverz.verify_all_tables(proverz.wrap_proof(rz, pcz.circuit_prover_data))
+                okz = rawz != lastz
+                if not okz:
+                    print("bench: ZK layer: two proofs of one input are identical", file=sys.stderr)
+            except Exception as e:
+                print(f"bench: ZK layer: proof rejected: {e}", file=sys.stderr)
+                okz = False
+            ctxz.profile_enable(True)
+            pcz.prove(rinz)
+            profz = ctxz.profile_read()
+            ctxz.profile_enable(False)
+            line["zk_layer"] = {
+                "ms_per_step": msz, "steps": 5, "proof_verified": okz, "proof_bytes": len(rawz),
+                "vs_headline": msz / ms_per_step,
+                "num_random_codewords": 2, "proofs_made": ctxz.zk_nonce,
+                "kernel_ms": {k: v[0] for k, v in profz.items() if not k.startswith("stage:")},
+                "parity": "byte parity with upstream is undefined for a randomised proof (the prover side of HidingFriPcs is un-vendored): "
+                          "accepted by the native verifier here, by both verifiers and byte-identical to the oracle under the shared "
+                          "counter-based randomness in tests/test_gpu_zk.py",
+                "workload": f"the headline prove_next_layer (same circuit, inputs, tables and FRI parameters) under the ZK configuration: "
+                            f"traces, LogUp columns and preprocessed columns committed over 2^{log_h + 1}-row extended domains with two "
+                            f"random codeword columns each, a random round, 2^(log_qd + 1) masked quotient chunks"}
+            proof_verified = proof_verified and okz
+            line["proof_verified"] = proof_verified
+            rinz.free()
+            pcz.free()
+            ctxz.close()
         print(json.dumps(line))
     if resident is not None:
         resident.free()

@@ -467,3 +467,73 @@ def test_hip_reproduces_the_rust_arity4_mmcs(oracle):
             p3r.mmcs_verify(ctx.cfg, cap, [m.shape for m in mats], o["index"], opened, proof)
         tree.free()
         ctx.close()
+
+
+# ---- ZK (HidingFriPcs): acceptance in both directions - a randomised proof has no byte parity to pin ------------------
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_rust_zk_proof_is_accepted(oracle, field, key):
+    """A NATIVE ZK proof (the reference's prove_all_tables under create_config_zk, recursion/examples/common/mod.rs:511-553)
+    fed to this repo's verifiers: p3r_verify_batch under p3r_config.zk = 1 and the oracle's verify_batch must accept it,
+    the BatchStarkProof wire format must round-trip under P3R_PROOF_ZK, and the non-ZK configuration must refuse it.
+    A rejection names the verifier rule that differs from upstream's (csrc/verify_impl.h cites each one)."""
+    import fib_lib
+    import circuit_lib as cl
+    import layer_lib
+    import oracle_lib
+    import plonky3_recursion_amd as p3r
+    g = load(f"rust_fibonacci_zk_layer_{key}.json")
+    rc = np.array(g["rc"], dtype=np.uint32)
+    inner, outer = bytes.fromhex(g["batch_proof_postcard_hex"]), bytes.fromhex(g["batch_stark_proof_postcard_hex"])
+    zk = dict(zk=1, num_random_codewords=g["zk"]["num_random_codewords"])
+    proof = p3r.BatchStarkProof.from_postcard(outer, field, zk=True)
+    assert proof.proof == inner and proof.to_postcard() == outer, "BatchStarkProof postcard layout of a hiding PCS's proof"
+    assert list(proof.degree_bits) == g["degree_bits"], "extended degree bits in the preprocessed metadata"
+    cfg, keep = p3r.make_config(field, poseidon2_rc=rc, **g["fri"], **zk)
+    p3r.verify_all_tables(cfg, proof)
+    cfg0, keep0 = p3r.make_config(field, poseidon2_rc=rc, **g["fri"])
+    with pytest.raises(p3r.P3rError):
+        p3r.verify_all_tables(cfg0, p3r.BatchStarkProof.from_postcard(outer, field, zk=True))
+    # the oracle's verifier, against the statement alone (commitment and AIRs from the proof's own metadata)
+    prm = layer_lib.params(**g["fri"], **zk)
+    layer_lib.oracle_verify_statement(oracle, field, prm, proof.airs(), proof.preprocessed_commitment, inner, rc=rc)
+    # how far the un-pinned prover-side choices are from upstream's, as information (no assertion): does upstream pad the
+    # preprocessed round with zeros (commitment equality), are its quotient masks of the same shape (lengths only)
+    circuit, inputs, fib = fib_lib.fibonacci_circuit(g["n"], oracle_lib.MODULUS[field])
+    oc = cl.OracleCircuit(oracle, circuit).preprocess(oracle_lib.MODULUS[field])
+    oc.run(field, inputs, rc=rc)
+    L = layer_lib.OracleLayer(oracle, field, oc.workload_arrays(), prm, packing=dict(g["packing"]), rc=rc)
+    same_prep = np.array_equal(proof.preprocessed_commitment, L.prep_commit())
+    print(f"{field}: upstream's ZK preprocessed commitment {'equals' if same_prep else 'differs from'} the zero-padded one here")
+
+
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_rust_accepts_our_zk_proof(field, key):
+    """The other direction: `cargo run -- zk-accept` (tools/rust_pin) ran the reference's verify_all_tables on the ZK proof
+    this repo made (tests/golden/zk_fibonacci_layer_for_rust_<field>.json, tools/gen_zk_fixture.py)."""
+    import hashlib
+    acc = load("rust_zk_acceptance.json")[key]
+    fx = load(f"zk_fibonacci_layer_for_rust_{key}.json")
+    assert hashlib.sha256(bytes.fromhex(fx["batch_stark_proof_postcard_hex"])).hexdigest() == fx["sha256"] == acc["fixture_sha256"], \
+        "the acceptance record is about another fixture: re-run `cargo run -- zk-accept`"
+    assert acc["fixture_round_constants_are_upstream"], "regenerate the fixture after rust_primitives.json exists (tools/gen_zk_fixture.py)"
+    assert acc["deserialised"], acc["verdict"]
+    assert acc["verdict"] == "accepted", acc["verdict"]
+
+
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_our_zk_fixture_is_current(oracle, field, key):
+    """The committed fixture is what the prover makes today and both verifiers here accept it (runs without cargo)."""
+    import hashlib
+    import sys
+    import plonky3_recursion_amd as p3r
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_zk_fixture
+    fx = load(f"zk_fibonacci_layer_for_rust_{key}.json")
+    outer = bytes.fromhex(fx["batch_stark_proof_postcard_hex"])
+    assert hashlib.sha256(outer).hexdigest() == fx["sha256"]
+    if not os.path.exists(os.path.join(GOLDEN, "rust_primitives.json")):
+        assert gen_zk_fixture.make(field, key)["sha256"] == fx["sha256"], "prover output drifted: python tools/gen_zk_fixture.py"
+    proof = p3r.BatchStarkProof.from_postcard(outer, field, zk=True)
+    assert len(proof.proof) == fx["batch_proof_len"]
+    cfg, keep = p3r.make_config(field, poseidon2_rc=np.array(fx["rc"], dtype=np.uint32), zk=1, num_random_codewords=2, **fx["fri"])
+    p3r.verify_all_tables(cfg, proof)

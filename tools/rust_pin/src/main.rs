@@ -41,6 +41,17 @@
 //!       the NATIVE arity-4 MerkleTreeMmcs over the deterministic matrices of recursion/tests/recursive_arity4_mmcs.rs: roots and
 //!       openings (pins p3r_config.mmcs_arity = 4: schedule, sibling order, the content of padded positions).
 //!
+//!   tests/golden/rust_fibonacci_zk_layer_<field>.json
+//!       the Fibonacci layer under create_config_zk (recursion/examples/common/mod.rs:511-553: HidingFriPcs, two random
+//!       codewords, SmallRng::seed_from_u64(1)), prover data built with the EXTENDED degrees (recursion.rs:374).  A ZK proof
+//!       is randomised and the prover side of HidingFriPcs draws from a sequential RNG, so nothing here pins bytes: the
+//!       fixture feeds a NATIVE ZK proof to this repo's verifiers (tests/test_rust_pins.py::test_rust_zk_proof_is_accepted:
+//!       p3r_verify_batch under p3r_config.zk = 1 and the oracle's verify_batch must both accept it).
+//!   `cargo run --release -- zk-accept`  ->  tests/golden/rust_zk_acceptance.json
+//!       the other direction: reads tests/golden/zk_fibonacci_layer_for_rust_<field>.json (a ZK proof made by THIS repo's
+//!       prover, tools/gen_zk_fixture.py - regenerate it after the first run so that it uses upstream's round constants),
+//!       deserialises it as BatchStarkProof<MyConfigZk> and runs the reference's verify_all_tables on it.
+//!
 //! Written against the API the reference itself uses (recursion/examples/common/mod.rs:192-207,
 //! 464-486; circuit-prover/src/batch_stark_prover/tests.rs:1031-1099).  It has NOT been compiled in
 //! this repo's build image (no cargo there): expect to fix an import or two on first use.
@@ -56,7 +67,9 @@ use p3_commit::{ExtensionMmcs, Mmcs};
 use p3_dft::{Radix2DitParallel, TwoAdicSubgroupDft};
 use p3_field::extension::BinomialExtensionField;
 use p3_field::{BasedVectorSpace, Field, PrimeCharacteristicRing, PrimeField32, TwoAdicField};
-use p3_fri::{FriParameters, TwoAdicFriPcs};
+use p3_fri::{FriParameters, HidingFriPcs, TwoAdicFriPcs};
+use rand::SeedableRng;
+use rand::rngs::SmallRng;
 use p3_matrix::Matrix;
 use p3_matrix::bitrev::BitReversibleMatrix;
 use p3_matrix::dense::RowMajorMatrix;
@@ -78,6 +91,9 @@ const COMMIT_POW_BITS: usize = 0;
 const QUERY_POW_BITS: usize = 6;
 const NUM_QUERIES: usize = 8;
 const FIB_N: usize = 100;
+// create_config_zk (recursion/examples/common/mod.rs:536-542)
+const ZK_CODEWORDS: usize = 2;
+const ZK_SEED: u64 = 1;
 
 fn u32s<F: PrimeField32>(xs: &[F]) -> Vec<u32> {
     xs.iter().map(|x| x.as_canonical_u32()).collect()
@@ -248,6 +264,96 @@ macro_rules! field_module {
                     "batch_stark_proof_postcard_hex": hex(&outer),
                     "batch_proof_postcard_hex": hex(&inner),
                 })
+            }
+
+            pub type MyPcsZk = HidingFriPcs<F, Dft, MyMmcs, ChallengeMmcs, SmallRng>;
+            pub type MyConfigZk = StarkConfig<MyPcsZk, Challenge, Challenger>;
+            /// create_config_zk (recursion/examples/common/mod.rs:511-553): the same (non-hiding) MMCS, HidingFriPcs with two
+            /// random codewords and a seeded SmallRng
+            pub fn config_zk(seed: u64) -> MyConfigZk {
+                let perm: Perm = $default_perm();
+                let hash = MyHash::new(perm.clone());
+                let compress = MyCompress::new(perm.clone());
+                let val_mmcs = MyMmcs::new(hash, compress, CAP_HEIGHT);
+                let challenge_mmcs = ChallengeMmcs::new(val_mmcs.clone());
+                let fri_params = FriParameters {
+                    max_log_arity: MAX_LOG_ARITY,
+                    log_blowup: LOG_BLOWUP,
+                    log_final_poly_len: LOG_FINAL_POLY_LEN,
+                    num_queries: NUM_QUERIES,
+                    commit_proof_of_work_bits: COMMIT_POW_BITS,
+                    query_proof_of_work_bits: QUERY_POW_BITS,
+                    mmcs: challenge_mmcs,
+                };
+                let pcs = MyPcsZk::new(Dft::default(), val_mmcs, fri_params, ZK_CODEWORDS, SmallRng::seed_from_u64(seed));
+                MyConfigZk::new(pcs, Challenger::new(perm))
+            }
+
+            /// The Fibonacci layer under the ZK configuration: the proof this repo's verifiers must accept
+            /// (p3r_config.zk = 1; recursion/src/verifier/batch_stark.rs:424-428,487-490,536,623-661,701-735,855-864).
+            pub fn fibonacci_zk_layer() -> Value {
+                let mut builder = CircuitBuilder::<Challenge>::new();
+                let expected = builder.alloc_public_input("expected_result");
+                let mut a = builder.alloc_const(Challenge::ZERO, "F(0)");
+                let mut b = builder.alloc_const(Challenge::ONE, "F(1)");
+                for _ in 2..=FIB_N {
+                    let next = builder.add(a, b);
+                    a = b;
+                    b = next;
+                }
+                builder.connect(b, expected);
+                let circuit = builder.build().unwrap();
+                let (mut fa, mut fb) = (F::ZERO, F::ONE);
+                for _ in 2..=FIB_N { let t = fa + fb; fa = fb; fb = t; }
+                let packing = TablePacking::new(1, 1).with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
+                let cfg = config_zk(ZK_SEED);
+                let (airs_degrees, primitive_columns, non_primitive_columns) =
+                    get_airs_and_degrees_with_prep::<MyConfigZk, Challenge, 4>(&circuit, &packing, &[], &[], ConstraintProfile::Standard).unwrap();
+                let (airs, log_degrees): (Vec<_>, Vec<usize>) = airs_degrees.into_iter().unzip();
+                // the EXTENDED degrees (recursion.rs:374: `d + config.is_zk()`)
+                let ext_degrees: Vec<usize> = log_degrees.iter().map(|&d| d + cfg.is_zk()).collect();
+                let prover_data = ProverData::from_airs_and_degrees(&cfg, &airs, &ext_degrees);
+                let cpd = CircuitProverData::new(prover_data, primitive_columns, non_primitive_columns);
+                let mut runner = circuit.runner();
+                runner.set_public_inputs(&[Challenge::from(fb)]).unwrap();
+                let traces = runner.run().unwrap();
+                let prover = BatchStarkProver::new(cfg).with_table_packing(packing);
+                let proof: BatchStarkProof<MyConfigZk> = prover.prove_all_tables(&traces, &cpd).unwrap();
+                prover.verify_all_tables::<Challenge>(&proof).unwrap();
+                let outer = postcard::to_allocvec(&proof).unwrap();
+                let inner = postcard::to_allocvec(&proof.proof).unwrap();
+                json!({
+                    "field": $key, "n": FIB_N, "fib": fb.as_canonical_u32(),
+                    "fri": {"log_blowup": LOG_BLOWUP, "max_log_arity": MAX_LOG_ARITY, "cap_height": CAP_HEIGHT,
+                            "log_final_poly_len": LOG_FINAL_POLY_LEN, "commit_pow_bits": COMMIT_POW_BITS,
+                            "query_pow_bits": QUERY_POW_BITS, "num_queries": NUM_QUERIES},
+                    "zk": {"num_random_codewords": ZK_CODEWORDS, "seed": ZK_SEED},
+                    "packing": {"public_lanes": 1, "alu_lanes": 1, "horner_packed_steps": 2},
+                    "rc": round_constants(),
+                    "degree_bits": ext_degrees,
+                    "batch_stark_proof_postcard_hex": hex(&outer),
+                    "batch_proof_postcard_hex": hex(&inner),
+                })
+            }
+
+            /// The other direction: a ZK proof made by this repo's prover (tests/golden/zk_fibonacci_layer_for_rust_<field>.json),
+            /// judged by the reference's verify_all_tables.
+            pub fn zk_accept(golden: &str) -> Value {
+                let path = format!("{golden}/zk_fibonacci_layer_for_rust_{}.json", $key);
+                let fx: Value = serde_json::from_str(&fs::read_to_string(&path).unwrap()).unwrap();
+                let bytes = unhex(fx["batch_stark_proof_postcard_hex"].as_str().unwrap());
+                let same_rc = fx["rc"].as_array().unwrap().iter().map(|v| v.as_u64().unwrap() as u32).collect::<Vec<_>>() == round_constants();
+                let packing = TablePacking::new(1, 1).with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
+                let prover = BatchStarkProver::new(config_zk(0)).with_table_packing(packing);
+                let (parsed, verdict) = match postcard::from_bytes::<BatchStarkProof<MyConfigZk>>(&bytes) {
+                    Err(e) => (false, format!("postcard: {e}")),
+                    Ok(proof) => match prover.verify_all_tables::<Challenge>(&proof) {
+                        Ok(()) => (true, "accepted".to_string()),
+                        Err(e) => (true, format!("rejected: {e}")),
+                    },
+                };
+                json!({"field": $key, "fixture_sha256": fx["sha256"], "fixture_round_constants_are_upstream": same_rc,
+                       "deserialised": parsed, "verdict": verdict})
             }
 
             /// The same circuit the way the example proves it FIRST: over the base field (`CircuitBuilder<F>`, D = 1 traces,
@@ -498,6 +604,9 @@ fn flatten_circuit<F: PrimeField32, EF: BasedVectorSpace<F> + Field>(c: &p3_circ
     (ops, ext)
 }
 
+fn unhex(s: &str) -> Vec<u8> {
+    (0..s.len() / 2).map(|i| u8::from_str_radix(&s[2 * i..2 * i + 2], 16).unwrap()).collect()
+}
 fn hex(b: &[u8]) -> String {
     b.iter().map(|x| format!("{x:02x}")).collect()
 }
@@ -807,6 +916,15 @@ fn arity4_layer() -> Value {
 
 fn main() {
     let golden = concat!(env!("CARGO_MANIFEST_DIR"), "/../../tests/golden");
+    if std::env::args().nth(1).as_deref() == Some("zk-accept") {
+        let out = json!({
+            "provenance": "tools/rust_pin zk-accept: the reference's verify_all_tables on tests/golden/zk_fibonacci_layer_for_rust_<field>.json",
+            "koala_bear": koala::zk_accept(golden), "baby_bear": baby::zk_accept(golden),
+        });
+        fs::write(format!("{golden}/rust_zk_acceptance.json"), serde_json::to_string(&out).unwrap()).unwrap();
+        println!("{out}");
+        return;
+    }
     let inp: Value = serde_json::from_str(&fs::read_to_string(format!("{golden}/primitives.json")).unwrap()).unwrap();
     let out = json!({
         "provenance": "tools/rust_pin: upstream p3-* 0.6 + the reference's circuit-prover, run on the inputs of primitives.json",
@@ -826,5 +944,7 @@ fn main() {
     fs::write(format!("{golden}/rust_quintic_challenge_layer_koala_bear.json"), serde_json::to_string(&quintic_challenge_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_arity4_layer_koala_bear.json"), serde_json::to_string(&arity4_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_arity4_mmcs_koala_bear.json"), serde_json::to_string(&arity4_mmcs()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_fibonacci_zk_layer_koala_bear.json"), serde_json::to_string(&koala::fibonacci_zk_layer()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_fibonacci_zk_layer_baby_bear.json"), serde_json::to_string(&baby::fibonacci_zk_layer()).unwrap()).unwrap();
     println!("wrote rust_arity4_layer_koala_bear.json and rust_primitives.json, rust_fibonacci_layer_*.json, rust_fibonacci_base_layer_*.json, rust_npo_layer_*.json, rust_quintic_layer_koala_bear.json and rust_quintic_challenge_layer_koala_bear.json under {golden}");
 }
