@@ -127,18 +127,32 @@ def hbm_families(heights, widths, packing, kernel_ms):
     return out
 
 
-PROFILE_ROUND = "r04"   # profiles/<round>/ holds the rocprofv3 summaries the roofline numbers refer to
+PROFILE_ROUND = "r05"   # profiles/<round>/ holds the rocprofv3 summaries the roofline numbers refer to
 
 
 def profile_file(name):
     """Path of a committed summary: this round's, else the newest earlier round's (the line names what it read)."""
-    for rnd in (PROFILE_ROUND, "r03", "r02"):
+    for rnd in (PROFILE_ROUND, "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(p):
             return p, f"profiles/{rnd}/{name}"
     return None, None
 FP64_FMA_SPEC = 39.3e12  # /opt/skills/guides/MI355X_MICROARCH.md: 78.6 TFLOP/s FP64 vector = 39.3 T FMA lane-ops/s
 PUBLISHED_CPU_MS = 109.0  # BASELINE.md: prove_next_layer of a real (~2^15-row) verifier circuit, Apple M4 Pro, 14 cores
+
+
+HASH_KERNEL_SOURCES = ("poseidon2_f64.hip.h", "kernels.hip.h")   # what k_mmcs_hash_rows is compiled from
+
+
+def kernel_source_digest(names=HASH_KERNEL_SOURCES):
+    """sha256 over the sources of the dominant kernel: tools/collect_profiles.py stores it next to the instruction count
+    it measured, committed_valu_model refuses a count taken from other sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(ROOT, "plonky3_recursion_amd", "csrc", n), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def committed_valu_model(field):
@@ -152,7 +166,14 @@ def committed_valu_model(field):
     try:
         p, src["valu_insts_per_perm"] = profile_file("pmc_hash_rows.json")
         with open(p) as fh:
-            insts = float(json.load(fh)["fields"][field]["valu_insts_per_perm"])
+            rec = json.load(fh)
+        # the count is a property of the kernel's code: a file measured on other sources is refused, not quoted
+        want, have = rec.get("kernel_sources_sha256"), kernel_source_digest()
+        if want != have:
+            src["refused"] = (f"{src['valu_insts_per_perm']} was measured on other kernel sources (sha256 of "
+                              f"{' + '.join(HASH_KERNEL_SOURCES)}: file {str(want)[:12]}, built {have[:12]}): re-run tools/profile_round.sh")
+        else:
+            insts = float(rec["fields"][field]["valu_insts_per_perm"])
     except Exception:
         pass
     try:
@@ -171,6 +192,48 @@ def committed_valu_model(field):
 # memory in the loop, a Montgomery product at 7.7 T/s (profiles/r03/microbench_int_rates.txt).
 NTT_BUTTERFLY_RATE = 3.9e12
 MONT_PRODUCT_RATE = 7.68e12
+MONT_PRODUCT_RATE_PLAIN = 5.82e12   # "Montgomery product" line of microbench_int_rates.txt (mul_lo / mul_hi / borrow form)
+VALU_ISSUE_SPEC = 39.3e12           # full-rate VALU lane-instructions/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (the guide's FP64 FMA figure)
+
+# kernels (names as rocprofv3 reports them, tools/collect_profiles.py::kname) behind the families of kernel_ms_per_step
+VALU_FAMILY_KERNELS = {
+    "ntt": (("ntt_inverse_1", "ntt_inverse_2", "ntt_forward_1", "ntt_forward_2"),
+            ("k_ntt_col", "k_ntt_col_mixed", "k_ntt_fwd_line", "k_ntt_fwd_line_mixed", "k_ntt_tile")),
+    "quotient": (("quotient",), ("k_quotient",)),
+    "mmcs_compress": (("mmcs_compress",), ("k_mmcs_compress", "k_mmcs_compress_f64", "k_mmcs_subtree", "k_mmcs_top")),
+    "run_levels": (("run_levels",), ("k_run_level", "k_run_levels_narrow", "k_run_chains_block", "k_run_chains_wave")),
+    "logup_aux": (("logup_aux",), ("k_logup_aux", "k_ef_scan")),
+    "fri_reduce": (("fri_reduce",), ("k_fri_reduce_pre", "k_fri_vsum")),
+    "open_dot": (("open_dot",), ("k_open_dot", "k_open_reduce")),
+}
+
+
+def valu_families(kernel_ms):
+    """What binds the families that are not HBM-bound: VALU lane-instructions per proof (SQ_INSTS_VALU x 64 from the
+    committed PMC pass, profiles/<round>/pmc_sq.json, divided by the proofs of that run) over the family's measured time,
+    against the full-rate issue peak.  A lower bound on issue-slot use: v_mad_u64_u32 / v_mul_hi_u32 occupy more than one
+    slot (13.2 / 19.8 T/s in microbench_int_rates.txt), so an integer family at 0.8 is at its roof."""
+    p, name = profile_file("pmc_sq.json")
+    if not p:
+        return None
+    try:
+        with open(p) as fh:
+            rec = json.load(fh)
+        ks = rec["kernels"]
+        proofs = rec.get("proofs_in_run") or ks.get("k_quotient", {}).get("launches")   # one quotient launch per proof
+        out = {"source": f"{name}: SQ_INSTS_VALU x 64 lanes / {proofs} proofs of that run; times: this run's kernel_ms_per_step",
+               "peak_lane_insts_per_s": VALU_ISSUE_SPEC}
+        for fam, (time_keys, kernels) in VALU_FAMILY_KERNELS.items():
+            insts = sum(ks[k]["SQ_INSTS_VALU"] for k in kernels if k in ks and "SQ_INSTS_VALU" in ks[k]) * 64.0 / proofs
+            ms = sum(kernel_ms.get(k, 0.0) for k in time_keys)
+            if insts and ms:
+                rate = insts / (ms * 1e-3)
+                out[fam] = {"valu_lane_insts_per_step": insts, "ms": ms, "achieved_lane_insts_per_s": rate,
+                            "frac": rate / VALU_ISSUE_SPEC, "bound": "valu-issue" if rate / VALU_ISSUE_SPEC >= 0.6 else "latency / memory phases",
+                            "kernels": [k for k in kernels if k in ks]}
+        return out
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def ntt_arithmetic(heights, widths, packing):
@@ -561,6 +624,18 @@ def self_launch(n):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def omp_team_size():
+    """The OpenMP team the harness / oracle libraries actually get in this process (not the environment string)."""
+    try:
+        import ctypes
+        import oracle_lib
+        lib = ctypes.CDLL(oracle_lib.LIB)
+        lib.orc_num_threads.restype = ctypes.c_int
+        return int(lib.orc_num_threads())
+    except Exception:
+        return None
+
+
 def rank_report(torch, dist, world, backend, local_rank, coll_device, rank_ms=None):
     """What the collective layer saw: world size and backend as it reports them, and per rank the device ordinal, its PCI
     address (two ranks on one GPU show the same one) and the rank's own time for the timed region."""
@@ -582,7 +657,7 @@ def rank_report(torch, dist, world, backend, local_rank, coll_device, rank_ms=No
                  "ms": row[4] / 1000.0 if rank_ms is not None else None} for r, row in enumerate(rows)]
     return {"world_size": ws, "backend": be, "devices": [row[0] for row in rows], "per_rank": per_rank,
             "distinct_gpus": len({(p["device"], p["pci"]) for p in per_rank}),
-            "omp_num_threads": os.environ.get("OMP_NUM_THREADS")}
+            "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "omp_team_size": omp_team_size()}
 
 
 def main():
@@ -628,14 +703,22 @@ def main():
         print(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks", file=sys.stderr)
         sys.exit(2)
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        # the ranks set up side by side: cap their OpenMP teams BEFORE torch is imported - torch loads an OpenMP runtime,
+        # and libgomp reads OMP_NUM_THREADS when it is loaded, not when a team starts
+        cap = max(1, (os.cpu_count() or world) // world)
+        cur = os.environ.get("OMP_NUM_THREADS")
+        if cur is None or not cur.isdigit() or int(cur) > cap:
+            os.environ["OMP_NUM_THREADS"] = str(cap)
+
     import torch
     import harness_lib
     import plonky3_recursion_amd as p3r
     import harness_adapters as wl
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     # P3R_BENCH_BACKEND=gloo exercises the multi-rank path where the ranks cannot have a GPU each
     # (several ranks share device 0); the driver's runs use nccl (= RCCL), one GPU per rank.
@@ -652,11 +735,6 @@ def main():
               f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); P3R_BENCH_BACKEND=gloo runs the ranks on shared devices",
               file=sys.stderr)
         sys.exit(2)
-    if world > 1:
-        cap = max(1, (os.cpu_count() or world) // world)
-        cur = os.environ.get("OMP_NUM_THREADS")
-        if cur is None or not cur.isdigit() or int(cur) > cap:
-            os.environ["OMP_NUM_THREADS"] = str(cap)   # before the OpenMP users (harness, oracle) are loaded
     if backend != "nccl":
         local_rank = local_rank % max(ndev, 1)
     coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
@@ -890,6 +968,12 @@ def main():
             "peak_perms_per_s": (FP64_FMA_SPEC / insts) if insts else None,
             "peak_measured_lane_ops_per_s": fma_rate,
             "frac_measured": (ach * insts / fma_rate) if ach and insts and fma_rate else None,
+            "frac_null_reason": vsrc.get("refused"),
+            # SURVEY 8d's own yardstick for this kernel: 616 modular products per permutation at the chip's measured
+            # Montgomery rate (mul_lo / mul_hi form, microbench_int_rates.txt) - the FP64 formulation is measured against
+            # the INTEGER roof the survey proposed
+            "vs_survey_integer_roof": (ach / (MONT_PRODUCT_RATE_PLAIN / 616.0)) if ach else None,
+            "survey_integer_roof_perms_per_s": MONT_PRODUCT_RATE_PLAIN / 616.0,
             "sources": {"valu_insts_per_perm": f"{vsrc.get('valu_insts_per_perm')} (SQ_INSTS_VALU x 64 / permutations, "
                                                "tools/pmc_hash_rows.py)",
                         "peak_measured_lane_ops_per_s": f"{vsrc.get('peak_measured_lane_ops_per_s')} (v_fma_f64 line, "
@@ -905,11 +989,15 @@ def main():
         }
         # The streaming families against HBM, from the same algorithmic byte counts as DESIGN.md §3/§7.
         line["hbm_families"] = hbm_families(cpd.table_heights, widths, packing, kernel_ms)
+        # ... and against VALU issue: what binds the quotient, the NTT passes, the Merkle levels and the circuit run
+        line["valu_families"] = valu_families(kernel_ms) if (field, log_h) == ("koala-bear", 20) else None
         line["proof_roofline"] = proof_roofline(field, cpd.table_heights, widths, packing, perms, insts, hash_bytes, ms_per_step,
                                                 line["hbm_families"])
         if not args.no_cpu_baseline and world == 1:
             lh = args.cpu_baseline_log_height
             cdt, crun, cores = cpu_baseline(field, lh)
+            # a second, four times larger sample: how the port scales (the line's own comparator stays the first)
+            cdt2, crun2, _ = cpu_baseline(field, lh + 2)
             line["cpu_baseline"] = {
                 "value": cdt * 1e3, "unit": "ms", "cores": cores, "kind": "port",
                 "sample": f"same prove_next_layer (circuit run + prove, same table mix, same FRI parameters, same "
@@ -917,6 +1005,11 @@ def main():
                           f"restatement, OpenMP on {cores} threads (the circuit run is sequential, as in the reference)",
                 "circuit_run_ms": crun * 1e3,
                 "gpu_ms_same_sample": small.get(str(lh), {}).get("ms_per_step") if small else None,
+                "samples": [{"log_height": lh, "ms": cdt * 1e3, "circuit_run_ms": crun * 1e3,
+                             "gpu_ms": small.get(str(lh), {}).get("ms_per_step") if small else None},
+                            {"log_height": lh + 2, "ms": cdt2 * 1e3, "circuit_run_ms": crun2 * 1e3,
+                             "gpu_ms": small.get(str(lh + 2), {}).get("ms_per_step") if small else None}],
+                "scaling_4x_rows": cdt2 / cdt,
                 "note": "a label, not a comparator: the oracle is a deliberately plain restatement (u64 % arithmetic, textbook "
                         "NTT).  The reference's own published figure is `published_reference_ms`.",
                 "published_reference_ms": PUBLISHED_CPU_MS,
@@ -1173,8 +1266,10 @@ def main():
                 "workload": f"prove_all_tables (Traces resident in HBM) of the synthetic {field} 2^{log_h}-row layer with a sixth table: "
                             f"const / public / alu / poseidon2 (width 16) / poseidon2 width 32 (arity-4 Merkle chains with injection and "
                             f"bridge levels, rate-24 sponge chains: 2^{log_h - 2} rows) / recompose, same FRI parameters"}
-            proof_verified = proof_verified and okw
-            line["proof_verified"] = proof_verified
+            # the width-32 legs run on SELF-GENERATED constants (P3R_EXT_UNPINNED_W32_DEFAULTS): their self-verification says
+            # prover and verifier agree with each other, not with upstream - it is reported here and does not feed the
+            # headline `proof_verified`
+            line.setdefault("unpinned_legs_self_verified", {})["width32_table_layer"] = okw
             resw.free()
             cpdw.free()
             ctxw.close()
@@ -1211,8 +1306,7 @@ def main():
                 "workload": f"the headline prove_next_layer (same circuit, inputs, tables and FRI parameters) with every commitment - "
                             f"traces, LogUp columns, quotient chunks, FRI commit phases - under the arity-4 MMCS over the width-32 "
                             f"permutation; challenger on the width-16 permutation"}
-            proof_verified = proof_verified and ok4
-            line["proof_verified"] = proof_verified
+            line.setdefault("unpinned_legs_self_verified", {})["arity4_mmcs_layer"] = ok4
             rin4.free()
             pc4.free()
             ctx4.close()
@@ -1270,7 +1364,7 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
-    if not proof_verified:
+    if not proof_verified or (rank == 0 and not all(line.get("unpinned_legs_self_verified", {}).values())):
         sys.exit(3)
 
 

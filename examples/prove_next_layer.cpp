@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     const std::string root = self.substr(0, self.rfind('/')) + "/..";
 
     p3r::FriParams fri;  // the examples' defaults: blow-up 4, 54 queries, 15 bits of query PoW
-    if (arity4) fri.mmcs_arity = 4;
+    if (arity4) { fri.mmcs_arity = 4; fri.allow_unpinned_w32_defaults = true; }   // this example has no upstream statics to pass: the built-in width-32 constants, acknowledged as unpinned
     p3r::Context ctx(field, fri, 0, {}, D, 0, quintic ? 5 : 4);
     std::vector<uint32_t> rc(p3r_poseidon2_num_constants(ctx.raw()));
     ctx.check(p3r_poseidon2_round_constants(ctx.raw(), rc.data()));

@@ -159,6 +159,13 @@ typedef struct p3r_config {
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
 #define P3R_EXT_LOOKUP_UNPACKED 1u
+/* ABI version 7.  The width-32 permutation - the one of the arity-4 MMCS (mmcs_arity = 4) and of the width-32 Poseidon2
+ * table - has its constants in un-vendored crates, and the library's built-in defaults for them are SELF-GENERATED: a
+ * proof made with them verifies nowhere else.  Using that permutation with poseidon2_w32_rc or poseidon2_w32_diag NULL
+ * therefore needs this acknowledgement in ext_choices; without it p3r_create (mmcs_arity = 4), the width-32 entry points,
+ * p3r_prep_create / p3r_layer_create of a batch holding P3R_AIR_POSEIDON2_W32, p3r_verify_batch and p3r_mmcs_verify
+ * refuse with P3R_EINVAL.  (The width-16 defaults are believed to be upstream's; the width-32 ones are known not to be.) */
+#define P3R_EXT_UNPINNED_W32_DEFAULTS 2u
 
 typedef struct p3r_ctx p3r_ctx;
 typedef struct p3r_dmat p3r_dmat; /* device-resident matrix (power-of-two height) */

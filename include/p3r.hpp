@@ -46,6 +46,9 @@ struct FriParams {
   uint32_t mmcs_arity = 2;
   // ZK: the PCS is HidingFriPcs with `num_random_codewords` random codewords and an RNG seeded with `zk_seed`
   // (create_config_zk, recursion/examples/common/mod.rs:511-553: two codewords)
+  // the library's built-in width-32 constants are self-generated (P3R_EXT_UNPINNED_W32_DEFAULTS, p3r.h): using the
+  // arity-4 MMCS / the width-32 table without the caller's constants must be asked for
+  bool allow_unpinned_w32_defaults = false;
   bool zk = false;
   uint32_t num_random_codewords = 2;
   uint64_t zk_seed = 0;
@@ -66,6 +69,7 @@ inline p3r_config make_config(Field field, const FriParams& p, int device = 0, c
   c.log_final_poly_len = p.log_final_poly_len; c.commit_pow_bits = p.commit_pow_bits;
   c.query_pow_bits = p.query_pow_bits; c.num_queries = p.num_queries;
   c.mmcs_arity = p.mmcs_arity;
+  if (p.allow_unpinned_w32_defaults) c.ext_choices |= P3R_EXT_UNPINNED_W32_DEFAULTS;
   c.zk = p.zk ? 1u : 0u;
   c.num_random_codewords = p.zk ? p.num_random_codewords : 0u;
   c.zk_seed = p.zk_seed;

@@ -295,8 +295,17 @@ struct Challenger {
   }
   // Deterministic grind: smallest canonical witness (upstream searches in parallel and may
   // return any valid witness - SURVEY.md appendix A "PoW"; DESIGN.md states this choice).
+  // `forced`: witnesses to use instead of searching, in grind order (tools/resolve_pins.py: a proof made elsewhere may
+  // carry any valid witness - upstream searches in parallel -, and the rest of its transcript hangs off that choice)
+  const std::vector<uint32_t>* forced = nullptr;
+  size_t forced_at = 0;
   F grind(int bits) {
     if (bits == 0) return F::zero();
+    if (forced && forced_at < forced->size()) {
+      const F w((*forced)[forced_at++]);
+      if (!check_witness(bits, w)) throw std::runtime_error("forced proof-of-work witness is not valid at this point of the transcript");
+      return w;
+    }
     for (uint32_t w = 0; w < FP::P; ++w) {
       Challenger c = *this;
       if (c.check_witness(bits, F(w))) {

@@ -41,6 +41,7 @@ struct StarkParams {
   // un-vendored p3-fri crate and its proofs are randomised, so byte parity with upstream is undefined: the
   // construction below is written from the acceptance conditions of the in-tree verifier (cited at each step) and
   // shared with the HIP prover, random values included (zk_rand below), so that HIP == oracle stays a byte check.
+  std::vector<uint32_t> forced_pow;   // proof-of-work witnesses to use instead of the smallest ones (Challenger::forced)
   bool zk = false;
   int num_random_codewords = 2;
   uint64_t zk_seed = 0;    // SmallRng::seed_from_u64(rng_seed)'s counterpart
@@ -516,6 +517,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   auto key = [&](int round, size_t mat) { return zk_stream_key(sp.zk_seed, sp.zk_nonce, zk_stream(round, mat)); };
   BatchProof<FP> proof;
   Challenger<FP> ch(&p2);
+  if (!sp.forced_pow.empty()) ch.forced = &sp.forced_pow;
   std::vector<int> log_n(ni), log_e(ni);   // base / extended (committed) trace degree bits
   std::vector<LookupLayout> layouts(ni);
   for (size_t i = 0; i < ni; ++i) {

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so"
 
 P3R_ABI_VERSION = 7
 P3R_EXT_LOOKUP_UNPACKED = 1
+P3R_EXT_UNPINNED_W32_DEFAULTS = 2   # the built-in width-32 constants are self-generated: using them is an explicit choice (p3r.h)
 FIELD_KOALA_BEAR = 0
 FIELD_BABY_BEAR = 1
 

@@ -175,6 +175,7 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
     if (ext_degree_is_binomial_generic(ctx->cfg.ext_degree) && a.kind == AIR_POSEIDON2)
       fail(P3R_EUNSUPPORTED, "instance %zu: UnsupportedDegree(%d): no Poseidon2 table for this circuit degree", i, a.ext_d);
     if (a.kind < 0 || a.kind > AIR_POSEIDON2_W32) fail(P3R_EINVAL, "instance %zu: unknown AIR kind %d", i, a.kind);
+    if (a.kind == AIR_POSEIDON2_W32) require_w32_constants(ctx);
     if (a.kind == AIR_POSEIDON2_W32 && ctx->cfg.ext_degree != 4)
       fail(P3R_EUNSUPPORTED, "instance %zu: the width-32 Poseidon2 table belongs to D = 4 circuits", i);
     if (a.lanes < 1) fail(P3R_EINVAL, "instance %zu: lanes must be positive", i);

@@ -65,6 +65,12 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
         rc, ptr = _u32(poseidon2_rc)
         cfg.poseidon2_rc = ptr
         cfg.poseidon2_rc_len = rc.size
+    # The width-32 permutation's constants live in un-vendored crates; the library's defaults for them are self-generated
+    # and the C ABI wants that acknowledged (P3R_EXT_UNPINNED_W32_DEFAULTS).  This mirror is the test / bench harness,
+    # where the defaults are the deliberate choice: the bit is set whenever they would be used, and bench.py labels every
+    # such leg "unpinned".  A Rust / C++ caller passes upstream's statics instead.
+    if poseidon2_w32_rc is None or poseidon2_w32_diag is None:
+        ext_choices |= _lib.P3R_EXT_UNPINNED_W32_DEFAULTS
     cfg.ext_choices = ext_choices
     ar = None
     if fri_log_arities is not None:

@@ -12,7 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = next((a for a in sys.argv[1:] if not a.startswith("--")), "r04")
+ROUND = next((a for a in sys.argv[1:] if not a.startswith("--")), "r05")
 SRC, OUT = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(OUT, exist_ok=True)
 
@@ -52,6 +52,11 @@ def hash_rows_summary():
         except Exception as e:  # a missing pass must not lose the rest of the summaries
             print("pmc_hash_rows: %s: %r" % (fld, e))
     if hr["fields"]:
+        # bench.py::committed_valu_model refuses the count when the kernel's sources are not the ones it was measured on
+        sys.path.insert(0, ROOT)
+        import bench
+        hr["kernel_sources"] = list(bench.HASH_KERNEL_SOURCES)
+        hr["kernel_sources_sha256"] = bench.kernel_source_digest()
         json.dump(hr, open(os.path.join(OUT, "pmc_hash_rows.json"), "w"), indent=1)
 
 
@@ -112,6 +117,7 @@ for k in kernels:
     table[k] = row
 json.dump({"provenance": "rocprofv3 --pmc <counter> --kernel-trace, one pass per counter, same command as pmc_traffic.json; "
                          "sums over every launch of the kernel in the run (1 preparation + 3 prove_next_layer)",
+           "proofs_in_run": table.get("k_quotient", {}).get("launches"),   # one k_quotient launch per prove_next_layer
            "kernels": table}, open(os.path.join(OUT, "pmc_sq.json"), "w"), indent=1)
 
 hash_rows_summary()

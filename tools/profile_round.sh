@@ -10,7 +10,7 @@ for F in koala-bear baby-bear; do
   done
 done
 # the bench line reads the instruction count just measured (profiles/<round>/pmc_hash_rows.json)
-python3 tools/collect_profiles.py ${1:-r04} --hash-rows-only
+python3 tools/collect_profiles.py ${1:-r05} --hash-rows-only
 timeout 1200 python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench_err.log
 ARGS="bench.py --no-cpu-baseline --no-config2 --no-small-layers --no-quintic"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 $ARGS > gpurun_out/final/stats_run.log 2>&1
