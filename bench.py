@@ -428,7 +428,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
     import harness_lib
     import harness_adapters as wl
     import plonky3_recursion_amd as p3r
-    from plonky3_recursion_amd.aggregation import TreePlan, run_aggregation_forest, run_aggregation_tree
+    from plonky3_recursion_amd.aggregation import TreePlan, predict_forest_wall_ms, run_aggregation_forest, run_aggregation_tree
     field, lh = args.field, args.leaf_log_height
     import queue
     packing = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
@@ -524,6 +524,100 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
         warm = list(ex.map(lambda i: prove_leaf(0, i), range(len(all_workers))))
         list(ex.map(lambda w: prove_parent(0, 1, 0, w, w), warm))
         decode(warm[0].to_postcard())
+    # ---- the inputs of the wall-time prediction (aggregation.predict_forest_wall_ms), measured on an idle GPU before the
+    # timed region: SOLO latency of a leaf and of a node (one prover, nothing else in flight), the GPU's capacity for
+    # concurrent proofs (this rank's provers all proving leaves at once), and what a child proof costs when it changes
+    # rank (serialise + native parse here; + one send/recv of that size when there is a peer)
+    def solo(fn, reps=3):
+        best = None
+        for _ in range(reps):
+            barrier_local()
+            t1 = time.perf_counter()
+            fn()
+            barrier_local()
+            best = min(best or 1e9, (time.perf_counter() - t1) * 1e3)
+        return best
+
+    def barrier_local():
+        for wk in all_workers:
+            wk["ctx"].sync()
+
+    def measure():
+        leaf = solo(lambda: prove_leaf(0, 0))
+        node = solo(lambda: prove_parent(0, 1, 0, warm[0], warm[0]))
+        caps = [1.0, 1.0]
+        # capacity: as many provers as can share this GPU in the run (this rank's, times the ranks on the same device)
+        k = len(all_workers) * max(1, sum(1 for d in local_devices if d == local_devices[rank]))
+        if k > 1:
+            extra = []
+            for _ in range(k - len(all_workers)):   # stand-ins for the other ranks' provers, for the measurement only
+                wctx = p3r.Context(field=field, device=local_rank, **FRI)
+                lc = p3r.build_next_layer_prep(wctx, leaf_circuit, backend, params)
+                wk = dict(ctx=wctx, leaf_cache=lc, leaf_inputs=lc.prepared_circuit.upload_inputs(leaf_host_inputs), agg_cache=[None])
+                workers.put(wk)
+                all_workers.append(wk)
+                extra.append(wk)
+            with ThreadPoolExecutor(max_workers=k) as ex:
+                if extra:
+                    list(ex.map(lambda i: prove_parent(0, 1, 0, warm[0], warm[0]), range(k)))   # their caches
+                for which, fn, alone in ((0, lambda i: [prove_leaf(0, i) for _ in range(4)], leaf),
+                                         (1, lambda i: [prove_parent(0, 1, 0, warm[0], warm[0]) for _ in range(4)], node)):
+                    barrier_local()
+                    t1 = time.perf_counter()
+                    list(ex.map(fn, range(k)))
+                    barrier_local()
+                    caps[which] = min(float(k), 4 * k * alone / ((time.perf_counter() - t1) * 1e3))
+            for wk in extra:   # drained: nobody else holds a worker now
+                got = [workers.get() for _ in range(len(all_workers))]
+                for g in got:
+                    if g is not wk:
+                        workers.put(g)
+                all_workers.remove(wk)
+                wk["leaf_inputs"].free()
+                wk["leaf_cache"].prepared_circuit.free()
+                if wk["agg_cache"][0] is not None:
+                    wk["agg_cache"][0].prepared_circuit.free()
+                wk["ctx"].close()
+        return leaf, node, caps
+
+    # ranks that share a GPU (the gloo test runs) measure one after the other: a solo latency is a solo latency
+    local_devices = [local_rank] * world
+    if dist is not None and world > 1:
+        t = torch.tensor([local_rank], dtype=torch.int64, device=coll_device)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        local_devices = [int(g.item()) for g in got]
+    solo_leaf_ms = solo_node_ms = None
+    gpu_capacity = [1.0, 1.0]
+    for r in range(world):
+        if r == rank:
+            solo_leaf_ms, solo_node_ms, gpu_capacity = measure()
+        if dist is not None:
+            dist.barrier()
+    if dist is not None and world > 1:   # rank 0's measurements are the ones the prediction uses
+        t = torch.tensor([solo_leaf_ms, solo_node_ms] + gpu_capacity, dtype=torch.float64, device=coll_device)
+        dist.broadcast(t, 0)
+        solo_leaf_ms, solo_node_ms, gpu_capacity = float(t[0]), float(t[1]), [float(t[2]), float(t[3])]
+    wire = warm[0].to_postcard()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        decode(warm[0].to_postcard())
+    codec_ms = (time.perf_counter() - t1) / 5 * 1e3
+    link_ms = 0.0
+    if dist is not None and world > 1:   # one proof-sized message rank 0 -> rank 1 -> rank 0 (the collective layer's own latency)
+        from plonky3_recursion_amd.aggregation import _recv_bytes, _send_bytes
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            if rank == 0:
+                _send_bytes(dist, wire, 1, coll_device)
+                _recv_bytes(dist, 1, coll_device)
+            elif rank == 1:
+                _send_bytes(dist, _recv_bytes(dist, 0, coll_device), 0, coll_device)
+        link_ms = (time.perf_counter() - t1) / 6 * 1e3
+        t = torch.tensor([link_ms], dtype=torch.float64, device=coll_device)
+        dist.broadcast(t, 0)
+        link_ms = float(t.item())
     for v in stats.values():
         v.clear()
     times = []
@@ -570,6 +664,31 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
         n_nodes = (2 * args.tree_leaves - 1) * n_trees
         ms_tree = dt / args.steps * 1e3
         mean = lambda v: (sum(v) / len(v)) if v else None
+        # prediction: the scheduler's own event model on the solo measurements above - for THIS run (ranks that share a GPU
+        # share its capacity) and for one GPU per rank at 1 / 2 / 4 / 8 ranks, which is what a multi-GPU run is compared with
+        message_ms = codec_ms + link_ms
+        gpu_ids = {p["rank"]: (p["device"], p["pci"]) for p in ranks["per_rank"]}
+        here = predict_forest_wall_ms(plans, solo_leaf_ms, solo_node_ms, message_ms, workers=len(all_workers), gpu_of_rank=gpu_ids,
+                                      gpu_capacity=gpu_capacity)
+        worlds = {}
+        for w in (1, 2, 4, 8):
+            pl = [TreePlan(args.tree_leaves, w, offset=t) for t in range(args.trees if args.trees > 0 else w)]
+            pr = predict_forest_wall_ms(pl, solo_leaf_ms, solo_node_ms, message_ms, workers=len(all_workers), gpu_capacity=gpu_capacity)
+            worlds[str(w)] = {"predicted_wall_ms": pr["wall_ms"], "critical_path_ms": pr["critical_path_ms"], "trees": len(pl),
+                              "proofs_per_s": pr["nodes"] / (pr["wall_ms"] * 1e-3)}
+        prediction = {
+            "model": "aggregation.predict_forest_wall_ms: dependency-driven schedule replayed on solo times; proofs in flight on one "
+                     "GPU share it above `gpu_capacity`; one communication thread per rank",
+            "inputs": {"solo_leaf_ms": solo_leaf_ms, "solo_node_ms": solo_node_ms,
+                       "gpu_capacity_concurrent_proofs": {"leaves": gpu_capacity[0], "nodes": gpu_capacity[1]},
+                       "message_ms": message_ms, "serialise_plus_parse_ms": codec_ms, "link_ms": link_ms, "proof_bytes": len(wire),
+                       "workers_per_rank": len(all_workers)},
+            "this_run": {"predicted_wall_ms": here["wall_ms"], "measured_wall_ms": ms_tree, "measured_over_predicted": ms_tree / here["wall_ms"],
+                         "critical_path_ms": here["critical_path_ms"], "busy_ms_per_rank": here["busy_ms_per_rank"]},
+            "one_gpu_per_rank": worlds,
+            "note": "a tree is log2(leaves) + 1 dependent proofs deep: beyond `leaves` / 2 GPUs its wall time is the critical path "
+                    "(solo latencies + one message per level), whatever the GPU count; --trees 0 is the form that scales",
+        }
         what = f"{n_trees} independent 2-to-1 aggregation trees in flight" if n_trees > 1 else "2-to-1 aggregation tree"
         print(json.dumps({
             "metric": f"aggregation tree wall ms ({args.tree_leaves} leaf proofs -> 1 root, prove_aggregation_layer per node), KoalaBear",
@@ -588,6 +707,8 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
                                       f"send/recv of child proofs only"},
             "ranks": ranks,
             "proofs_per_s": n_nodes / (ms_tree * 1e-3), "trees_per_s": n_trees / (ms_tree * 1e-3),
+            "critical_path_ms": here["critical_path_ms"],
+            "prediction": prediction,
             "root_verified": ok, "roots_verified": len(roots) if ok else 0,
             "root_sha256": hashlib.sha256(root).hexdigest(), "root_bytes": len(root),
             "rank0": {"leaf_ms": mean(stats["leaf_ms"]), "node_ms": mean(stats["node_ms"]),
@@ -1305,7 +1426,9 @@ def main():
                 "constants": "self-generated defaults (p3r_config.poseidon2_w32_rc / _diag = NULL): unpinned",
                 "workload": f"the headline prove_next_layer (same circuit, inputs, tables and FRI parameters) with every commitment - "
                             f"traces, LogUp columns, quotient chunks, FRI commit phases - under the arity-4 MMCS over the width-32 "
-                            f"permutation; challenger on the width-16 permutation"}
+                            f"permutation; challenger on the width-16 permutation.  NOT a layer of `recursive_aggregation "
+                            f"--arity4`: that recursion's verifier circuit fills the width-32 table, for which the circuit seam has "
+                            f"no op kind (INTEGRATION.md section 3a''); see width32_table_layer for the table itself"}
             line.setdefault("unpinned_legs_self_verified", {})["arity4_mmcs_layer"] = ok4
             rin4.free()
             pc4.free()

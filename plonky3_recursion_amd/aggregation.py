@@ -275,3 +275,122 @@ def gather_proofs_to_root(proof: bytes, dist, rank: int, world: int, device="cpu
         return out
     _send_bytes(dist, proof, 0, device)
     return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# What a run should cost: the schedule of run_aggregation_forest replayed on measured per-proof and per-message times.
+def predict_forest_wall_ms(plans, leaf_ms: float, node_ms: float, message_ms: float = 0.0, workers: int = 1,
+                           gpu_of_rank=None, gpu_capacity: float = 1.0, handoff_ms: Optional[float] = None):
+    """Wall time of `run_aggregation_forest(plans, ..)` predicted from solo measurements - the number a first multi-GPU run
+    is compared with (recursion/examples/recursive_aggregation.rs:447-475 is the serial loop being parallelised).
+
+      leaf_ms / node_ms   one prove_next_layer / prove_aggregation_layer alone on an idle GPU (latency, not throughput)
+      message_ms          one child proof changing rank: serialise + send/recv + native parse (the receiving side's decode
+                          overlaps its other work but not the parent that waits for it)
+      workers             concurrent provers per rank
+      gpu_of_rank         rank -> GPU identity (ranks sharing a GPU share its capacity); default: one GPU per rank
+      gpu_capacity        how many solo-speed proofs a GPU sustains at once (measured: concurrent throughput x solo
+                          latency) - a number, or (for leaves, for nodes): a proof alone uses 1 / capacity of the GPU, the
+                          proofs in flight on one GPU run at full speed while their shares sum to at most 1 and are all
+                          slowed by that sum beyond it
+      handoff_ms          the root's trip to rank 0 (default: message_ms)
+
+    The model is the scheduler's own: a node becomes ready when both children are on its rank (the left one is there when
+    it finishes, the right one message_ms after it finishes unless it was proved on the same rank; one communication
+    thread per rank moves messages in (level, tree, node) order), ready nodes take the first free prover of their rank in
+    ready order, and the proofs in flight on one GPU share it (processor sharing above `gpu_capacity`).
+    Returns dict(wall_ms, critical_path_ms, busy_ms_per_rank, nodes)."""
+    import heapq
+    world = plans[0].world
+    L = plans[0].levels
+    gpu_of_rank = gpu_of_rank or {r: r for r in range(world)}
+    handoff_ms = message_ms if handoff_ms is None else handoff_ms
+    work = lambda lv: leaf_ms if lv == 0 else node_ms   # noqa: E731
+    caps = gpu_capacity if isinstance(gpu_capacity, (tuple, list)) else (gpu_capacity, gpu_capacity)
+    share = lambda k: 1.0 / max(caps[0 if k[1] == 0 else 1], 1e-9)   # noqa: E731
+    keys = [(t, lv, i) for t, p in enumerate(plans) for lv in range(L) for i in range(p.nodes(lv))]
+    owner = {(t, lv, i): plans[t].owner(lv, i) for t, lv, i in keys}
+    # critical path (no contention, no queueing): longest dependent chain including the messages on it
+    cp = {}
+    for t, lv, i in sorted(keys, key=lambda k: k[1]):
+        if lv == 0:
+            cp[(t, lv, i)] = leaf_ms
+        else:
+            l, r = (t, lv - 1, 2 * i), (t, lv - 1, 2 * i + 1)
+            cp[(t, lv, i)] = node_ms + max(cp[l], cp[r] + (message_ms if owner[r] != owner[(t, lv, i)] else 0.0))
+    critical = max(cp[(t, L - 1, 0)] + (handoff_ms if owner[(t, L - 1, 0)] != 0 else 0.0) for t in range(len(plans)))
+    # event simulation
+    arrived = {}                                  # child key -> time it is available on its parent's rank
+    missing = {k: 2 for k in keys if k[1] > 0}
+    ready = {r: [] for r in range(world)}         # per rank: heap of (ready time, seq, key)
+    running = {}                                  # key -> remaining solo-ms
+    free = {r: workers for r in range(world)}
+    comm_free = {r: 0.0 for r in range(world)}    # when the rank's communication thread is next idle
+    finish = {}
+    busy = {r: 0.0 for r in range(world)}
+    seq = 0
+    for k in keys:
+        if k[1] == 0:
+            heapq.heappush(ready[owner[k]], (0.0, seq, k))
+            seq += 1
+    now = 0.0
+    pending_arrivals = []                         # heap of (time, seq, parent key)
+
+    def rate(k):
+        g = gpu_of_rank[owner[k]]
+        load = sum(share(q) for q in running if gpu_of_rank[owner[q]] == g)
+        return min(1.0, 1.0 / load) if load else 1.0
+
+    def start_ready():
+        for r in range(world):
+            while free[r] and ready[r] and ready[r][0][0] <= now + 1e-12:
+                _, _, k = heapq.heappop(ready[r])
+                running[k] = work(k[1])
+                free[r] -= 1
+
+    roots_at_0 = {}
+    while len(finish) < len(keys) or pending_arrivals:
+        start_ready()
+        # next event: a running proof finishes, a message arrives, or a queued node becomes ready
+        t_next, what = None, None
+        for k, rem in running.items():
+            tf = now + rem / rate(k)
+            if t_next is None or tf < t_next:
+                t_next, what = tf, ("finish", k)
+        if pending_arrivals and (t_next is None or pending_arrivals[0][0] < t_next):
+            t_next, what = pending_arrivals[0][0], ("arrive", None)
+        for r in range(world):
+            if free[r] and ready[r] and (t_next is None or ready[r][0][0] < t_next):
+                t_next, what = ready[r][0][0], ("ready", None)
+        if t_next is None:
+            break
+        dt = max(t_next - now, 0.0)
+        for k in list(running):
+            running[k] -= dt * rate(k)
+            busy[owner[k]] += dt
+        now = t_next
+        if what[0] == "finish":
+            k = what[1]
+            del running[k]
+            free[owner[k]] += 1
+            finish[k] = now
+            t, lv, i = k
+            if lv == L - 1:
+                roots_at_0[t] = now + (handoff_ms if owner[k] != 0 else 0.0)
+                continue
+            parent = (t, lv + 1, i // 2)
+            if owner[parent] == owner[k]:
+                at = now
+            else:   # through both ranks' communication threads, in order
+                at = max(now, comm_free[owner[k]], comm_free[owner[parent]]) + message_ms
+                comm_free[owner[k]] = comm_free[owner[parent]] = at
+            heapq.heappush(pending_arrivals, (at, seq, parent))
+            seq += 1
+        elif what[0] == "arrive":
+            at, _, parent = heapq.heappop(pending_arrivals)
+            missing[parent] -= 1
+            if missing[parent] == 0:
+                heapq.heappush(ready[owner[parent]], (at, seq, parent))
+                seq += 1
+    wall = max(list(roots_at_0.values()) + [now])
+    return {"wall_ms": wall, "critical_path_ms": critical, "busy_ms_per_rank": [busy[r] for r in range(world)], "nodes": len(keys)}

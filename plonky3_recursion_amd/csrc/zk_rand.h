@@ -15,7 +15,7 @@
 namespace p3r {
 
 constexpr uint64_t kZkGold = 0x9E3779B97F4A7C15ull;
-P3R_HD inline uint64_t zk_mix64(uint64_t z) {
+P3R_HD uint64_t zk_mix64(uint64_t z) {
   z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
   z ^= z >> 27; z *= 0x94D049BB133111EBull;
   z ^= z >> 31;
@@ -28,7 +28,7 @@ inline uint64_t zk_stream_key(uint64_t seed, uint64_t nonce, int round, size_t m
 }
 // the value as a Montgomery word
 template <class PP>
-P3R_HD inline uint32_t zk_rand_mont(uint64_t key, uint64_t idx) {
+P3R_HD uint32_t zk_rand_mont(uint64_t key, uint64_t idx) {
   return Fp<PP>::from_canonical((uint32_t)(zk_mix64(key + idx * kZkGold) % PP::P)).v;
 }
 

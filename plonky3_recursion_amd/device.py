@@ -251,10 +251,14 @@ class Context:
     def generate_w32_trace_rows(self, inputs, new_start, merkle_path, mmcs_bit, mmcs_bit2, mmcs_index_sum, height=None):
         """Poseidon2CircuitAir::generate_trace_rows of the arity-4 layout; rows are padded to `height` (a power of two)
         with filler rows (new_start = 1, zero state)."""
-        a = np.ascontiguousarray(inputs, dtype=np.uint32)
+        a = np.ascontiguousarray(inputs, dtype=np.uint32).reshape(-1, 32)
         n = a.shape[0]
         h = height or (1 << max(n - 1, 0).bit_length())
-        pad = lambda x, fill, dt: np.concatenate([np.asarray(x, dt).reshape(n, -1), np.full((h - n, np.asarray(x, dt).reshape(n, -1).shape[1]), fill, dt)])
+
+        def pad(x, fill, dt):   # explicit shapes: n == 0 (a table of filler rows only) has no rows to take the width from
+            x = np.asarray(x, dt)
+            w = 32 if x.ndim == 2 else 1
+            return np.concatenate([x.reshape(n, w), np.full((h - n, w), fill, dt)])
         rows = _lib.P3rP2wRows()
         keep = []
 

@@ -303,7 +303,11 @@ def _traces_struct(tr: Traces, ext_degree=4):
                 raise P3rError(-1, "p2w_%s must hold one entry per row" % name)
             keep.append(b)
             setattr(t.p2w, name, p)
-        x, t.p2w.mmcs_index_sum = p32(tr.p2w_mmcs_index_sum)
+        # the C side copies n words from this array too: a missing or short one must not reach it
+        idx = getattr(tr, "p2w_mmcs_index_sum", None)
+        if idx is None or np.asarray(idx).reshape(-1).shape[0] != t.p2w.n:
+            raise P3rError(-1, "p2w_mmcs_index_sum must hold one entry per row (%d)" % t.p2w.n)
+        x, t.p2w.mmcs_index_sum = p32(np.asarray(idx).reshape(-1))
     return t, keep
 
 

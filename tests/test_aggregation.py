@@ -157,3 +157,30 @@ def test_single_process_tree():
     leaf = lambda i: (b"leaf%d|" % i) * (1000 + i)
     parent = lambda lvl, node, l, r: hashlib.sha256(l).digest() + hashlib.sha256(r).digest() + b"|%d.%d" % (lvl, node)
     assert run_aggregation_tree(TreePlan(8, 1), 0, leaf, parent).hex() == expected_root(8)
+
+
+def test_wall_time_prediction_model():
+    """aggregation.predict_forest_wall_ms: the scheduler's own event model on solo times - what `bench.py --tree` prints as the
+    number a multi-GPU run is to be compared with."""
+    from plonky3_recursion_amd.aggregation import TreePlan, predict_forest_wall_ms as predict
+    leaf, node, msg = 3.0, 5.0, 1.0
+    # one rank, one prover: the serial loop of recursive_aggregation.rs:447-475
+    one = predict([TreePlan(8, 1)], leaf, node)
+    assert one["wall_ms"] == pytest.approx(8 * leaf + 7 * node) and one["nodes"] == 15
+    assert one["critical_path_ms"] == pytest.approx(leaf + 3 * node)
+    # a GPU per leaf: the critical path - a leaf, then one node and one message per level
+    eight = predict([TreePlan(8, 8)], leaf, node, msg)
+    assert eight["wall_ms"] == pytest.approx(leaf + 3 * (node + msg)) == pytest.approx(eight["critical_path_ms"])
+    # fewer GPUs than leaves/2: between the two, never better than the critical path
+    walls = [predict([TreePlan(8, w)], leaf, node, msg)["wall_ms"] for w in (1, 2, 4, 8)]
+    assert walls == sorted(walls, reverse=True) and walls[-1] >= eight["critical_path_ms"] - 1e-9
+    # concurrent provers on one GPU: bounded by its capacity (2 proofs at once at full speed: half the serial time at best)
+    shared = predict([TreePlan(8, 1)], leaf, node, workers=4, gpu_capacity=2.0)
+    assert (8 * leaf + 7 * node) / 2 - 1e-9 <= shared["wall_ms"] < 8 * leaf + 7 * node
+    # two ranks on ONE GPU share it; on two GPUs they do not
+    same = predict([TreePlan(8, 2)], leaf, node, msg, gpu_of_rank={0: "g", 1: "g"}, gpu_capacity=1.0)
+    apart = predict([TreePlan(8, 2)], leaf, node, msg)
+    assert same["wall_ms"] > apart["wall_ms"]
+    # K trees with rotated placement keep every rank busy: per-tree cost falls
+    forest = predict([TreePlan(8, 4, offset=t) for t in range(4)], leaf, node, msg)
+    assert forest["wall_ms"] / 4 < predict([TreePlan(8, 4)], leaf, node, msg)["wall_ms"]
