@@ -542,45 +542,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
         for wk in all_workers:
             wk["ctx"].sync()
 
-    def measure():
-        leaf = solo(lambda: prove_leaf(0, 0))
-        node = solo(lambda: prove_parent(0, 1, 0, warm[0], warm[0]))
-        caps = [1.0, 1.0]
-        # capacity: as many provers as can share this GPU in the run (this rank's, times the ranks on the same device)
-        k = len(all_workers) * max(1, sum(1 for d in local_devices if d == local_devices[rank]))
-        if k > 1:
-            extra = []
-            for _ in range(k - len(all_workers)):   # stand-ins for the other ranks' provers, for the measurement only
-                wctx = p3r.Context(field=field, device=local_rank, **FRI)
-                lc = p3r.build_next_layer_prep(wctx, leaf_circuit, backend, params)
-                wk = dict(ctx=wctx, leaf_cache=lc, leaf_inputs=lc.prepared_circuit.upload_inputs(leaf_host_inputs), agg_cache=[None])
-                workers.put(wk)
-                all_workers.append(wk)
-                extra.append(wk)
-            with ThreadPoolExecutor(max_workers=k) as ex:
-                if extra:
-                    list(ex.map(lambda i: prove_parent(0, 1, 0, warm[0], warm[0]), range(k)))   # their caches
-                for which, fn, alone in ((0, lambda i: [prove_leaf(0, i) for _ in range(4)], leaf),
-                                         (1, lambda i: [prove_parent(0, 1, 0, warm[0], warm[0]) for _ in range(4)], node)):
-                    barrier_local()
-                    t1 = time.perf_counter()
-                    list(ex.map(fn, range(k)))
-                    barrier_local()
-                    caps[which] = min(float(k), 4 * k * alone / ((time.perf_counter() - t1) * 1e3))
-            for wk in extra:   # drained: nobody else holds a worker now
-                got = [workers.get() for _ in range(len(all_workers))]
-                for g in got:
-                    if g is not wk:
-                        workers.put(g)
-                all_workers.remove(wk)
-                wk["leaf_inputs"].free()
-                wk["leaf_cache"].prepared_circuit.free()
-                if wk["agg_cache"][0] is not None:
-                    wk["agg_cache"][0].prepared_circuit.free()
-                wk["ctx"].close()
-        return leaf, node, caps
-
-    # ranks that share a GPU (the gloo test runs) measure one after the other: a solo latency is a solo latency
+    # ranks that share a GPU (the gloo test runs) take their SOLO latencies one after the other ...
     local_devices = [local_rank] * world
     if dist is not None and world > 1:
         t = torch.tensor([local_rank], dtype=torch.int64, device=coll_device)
@@ -588,12 +550,27 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
         dist.all_gather(got, t)
         local_devices = [int(g.item()) for g in got]
     solo_leaf_ms = solo_node_ms = None
-    gpu_capacity = [1.0, 1.0]
     for r in range(world):
         if r == rank:
-            solo_leaf_ms, solo_node_ms, gpu_capacity = measure()
+            solo_leaf_ms = solo(lambda: prove_leaf(0, 0))
+            solo_node_ms = solo(lambda: prove_parent(0, 1, 0, warm[0], warm[0]))
         if dist is not None:
             dist.barrier()
+    # ... and measure the GPU's capacity TOGETHER: every prover of every rank proves four leaves (then four nodes) at
+    # once; capacity = solo-milliseconds of work done on this rank's GPU per millisecond of wall time.  (Provers of two
+    # processes share a GPU less well than provers of one: the measurement has to be made in the run's own form.)
+    sharers = max(1, sum(1 for d in local_devices if d == local_devices[rank])) if backend_name != "nccl" else 1
+    gpu_capacity = [1.0, 1.0]
+    if len(all_workers) * sharers > 1:
+        with ThreadPoolExecutor(max_workers=len(all_workers)) as ex:
+            for which, fn, alone in ((0, lambda i: [prove_leaf(0, i) for _ in range(4)], solo_leaf_ms),
+                                     (1, lambda i: [prove_parent(0, 1, 0, warm[0], warm[0]) for _ in range(4)], solo_node_ms)):
+                barrier()
+                t1 = time.perf_counter()
+                list(ex.map(fn, range(len(all_workers))))
+                barrier()
+                gpu_capacity[which] = min(float(len(all_workers) * sharers),
+                                          4 * len(all_workers) * sharers * alone / ((time.perf_counter() - t1) * 1e3))
     if dist is not None and world > 1:   # rank 0's measurements are the ones the prediction uses
         t = torch.tensor([solo_leaf_ms, solo_node_ms] + gpu_capacity, dtype=torch.float64, device=coll_device)
         dist.broadcast(t, 0)
