@@ -425,6 +425,11 @@ struct p3r_ctx {
   double cur_stage_t0 = 0;
   int partial_rounds = 0;
   hipStream_t stream = nullptr;
+  // second stream of the commits (prove_impl.hip.h::lde_and_commit): the leaf hashing of one height class runs on it
+  // while the main stream extends the next class; joined before the Merkle levels.  Nothing else uses it.
+  hipStream_t stream2 = nullptr;
+  hipStream_t stream2_low = nullptr;   // the same at the lowest priority (A/B: P3R_COMMIT_OVERLAP_MODE = 2)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int n_cus = 256;  // compute units of the device (grids of the persistent kernels)
   p3r::DevBuf rc;  // Poseidon2 constants, Montgomery
   p3r::DevBuf rc_f64;  // the same constants as canonical doubles (poseidon2_f64.hip.h)

@@ -180,9 +180,11 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
 // ------------------------------------------------------------------ MMCS
 // Row digests of several height classes in one launch: classes[c] = the matrices of one height
 // (their rows are concatenated in the given order), digs[c] = [8][h_c].
+// `side`: launch on the ctx's second stream, after everything the main stream has queued so far (the job tables go up
+// through the main stream); the caller joins with hash_rows_join before anything reads the digests.
 template <class PP>
 void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& classes,
-               const std::vector<uint32_t*>& digs) {
+               const std::vector<uint32_t*>& digs, int side = 0) {
   std::vector<HashRowsJob> jobs;
   for (size_t c = 0; c < classes.size(); ++c) {
     std::vector<const uint32_t*> cols;
@@ -205,11 +207,21 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
   }
   const auto* d_jobs =
       static_cast<const HashRowsJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(HashRowsJob)));
+  if (side) {
+    hipStream_t s2 = side == 2 ? ctx->stream2_low : ctx->stream2;
+    P3R_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    P3R_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks), dim3(kBlock), 0, s2, d_jobs, (int)jobs.size(), ctx->rcd());
+    P3R_HIP(hipGetLastError());
+    P3R_HIP(hipEventRecord(ctx->ev_join, s2));
+    return;
+  }
   ProfScope ps(ctx, "mmcs_hash_rows");
   hipLaunchKernelGGL(k_mmcs_hash_rows<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(),
                      ctx->rcd());
   P3R_HIP(hipGetLastError());
 }
+inline void hash_rows_join(p3r_ctx* ctx) { P3R_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0)); }
 
 // One 2-to-1 layer, one permutation per lane: for layers large enough to fill the chip.  Smaller
 // ones are latency-bound and go through mmcs_subtree below (16 lanes per node, several levels per launch).
@@ -362,12 +374,17 @@ void mmcs_commit4(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   for (int k = 0; k < P2_DIGEST; ++k) cap_out[k] = F::raw(root[k]).to_canonical();
 }
 
+// `pre`: leaf digests of some height classes computed already (height -> [8][h] digests; hash_rows on the side stream,
+// joined by the caller): those classes are not hashed again.
 template <class PP>
-void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
+void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out, std::map<size_t, DevBuf>* pre = nullptr) {
   using F = Fp<PP>;
   const auto& mats = tree->mats;
   if (mats.empty()) fail(P3R_EINVAL, "MMCS commit needs at least one matrix");
-  if (ctx->cfg.mmcs_arity == 4) return mmcs_commit4<PP>(ctx, tree, cap_out);
+  if (ctx->cfg.mmcs_arity == 4) {
+    if (pre && !pre->empty()) fail(P3R_EHIP, "internal: pre-hashed classes under the arity-4 MMCS");
+    return mmcs_commit4<PP>(ctx, tree, cap_out);
+  }
   // tallest first, stable (recursion/src/pcs/mmcs.rs:355-425)
   std::vector<size_t> order(mats.size());
   std::iota(order.begin(), order.end(), 0);
@@ -393,17 +410,25 @@ void mmcs_commit(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   for (size_t i : order)
     if (class_h.empty() || class_h.back() != mats[i]->h) class_h.push_back(mats[i]->h);
   tree->layers.clear();
-  tree->layers.emplace_back(P2_DIGEST * hmax);
   std::map<size_t, DevBuf> inject;  // height -> digests of the matrices of that height
   {
     std::vector<std::vector<const p3r_dmat*>> classes;
     std::vector<uint32_t*> digs;
     for (size_t h : class_h) {
+      auto done = pre ? pre->find(h) : decltype(pre->end()){};
+      const bool have = pre && done != pre->end();
+      if (h == hmax) {
+        if (have) tree->layers.push_back(std::move(done->second));
+        else tree->layers.emplace_back(P2_DIGEST * hmax);
+      } else if (have) {
+        inject.emplace(h, std::move(done->second));
+      }
+      if (have) continue;
       classes.push_back(at_height(h));
       if (h == hmax) digs.push_back(tree->layers[0].p);
       else digs.push_back(inject.emplace(h, DevBuf(P2_DIGEST * h)).first->second.p);
     }
-    hash_rows<PP>(ctx, classes, digs);
+    if (!classes.empty()) hash_rows<PP>(ctx, classes, digs);
   }
   size_t n = hmax;
   const size_t cap_n = size_t(1) << tree->cap_height;
@@ -581,6 +606,14 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
     c->cfg = *cfg;
     tls_pool() = c->pool;
     P3R_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    P3R_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {
+      int lo = 0, hi = 0;
+      P3R_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = the numerically greatest = lowest priority
+      P3R_HIP(hipStreamCreateWithPriority(&c->stream2_low, hipStreamNonBlocking, lo));
+    }
+    P3R_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    P3R_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     {
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
@@ -596,6 +629,10 @@ void p3r_destroy(p3r_ctx* ctx) {
   (void)hipSetDevice(ctx->cfg.device);
   (void)hipStreamSynchronize(ctx->stream);
   prof_clear(ctx);
+  if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+  if (ctx->stream2_low) { (void)hipStreamSynchronize(ctx->stream2_low); (void)hipStreamDestroy(ctx->stream2_low); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   (void)hipStreamDestroy(ctx->stream);
   std::shared_ptr<DevPool> pool = ctx->pool;
   delete ctx;

@@ -79,14 +79,77 @@ std::vector<uint32_t> download_cap_mont(p3r_ctx* ctx, const p3r_tree* tree) {
 
 template <class PP>
 std::unique_ptr<p3r_tree> commit_dmats(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats,
-                                       std::vector<uint32_t>& cap_mont) {
+                                       std::vector<uint32_t>& cap_mont, std::map<size_t, DevBuf>* pre = nullptr) {
   auto tree = std::make_unique<p3r_tree>();
   tree->mats = mats;
   std::vector<uint32_t> cap_canon((size_t)P2_DIGEST << ctx->cfg.cap_height);
-  mmcs_commit<PP>(ctx, tree.get(), cap_canon.data());
+  mmcs_commit<PP>(ctx, tree.get(), cap_canon.data(), pre);
   cap_mont.resize(cap_canon.size());
   for (size_t i = 0; i < cap_canon.size(); ++i) cap_mont[i] = Fp<PP>::from_canonical(cap_canon[i]).v;
   return tree;
+}
+
+// Coset LDE + MMCS commitment of one round's matrices (TwoAdicFriPcs::commit), with the leaf hashing of ONE height class
+// taken off the critical path: the class with the most permutations is extended first and hashed on the ctx's second
+// stream while the main stream extends the other classes - the hash is VALU-bound (0.96 busy), the LDE passes leave a
+// third of their time to memory phases, and the two kernels share the CUs (tools/overlap_ab.py: 0.55 ms of a 1.9 ms LDE
+// hidden; profiles/r05/overlap_ab.txt).  Same digests, same tree, same bytes.  Falls back to the plain sequence for
+// small layers (nothing to hide: they are latency-bound), one height class, the arity-4 MMCS, and while the per-family
+// timers are on (two kernels at once would be timed as one).
+template <class PP>
+std::unique_ptr<p3r_tree> lde_and_commit(p3r_ctx* ctx, const std::vector<LdeItem>& items, int log_blowup,
+                                         std::vector<std::unique_ptr<p3r_dmat>>& ldes, std::vector<uint32_t>& cap_mont) {
+  // (read per call, not once: tools/ab_commit_overlap.py alternates the forms proof by proof inside one process)
+  const bool off = tuning_knob("P3R_NO_COMMIT_OVERLAP") != nullptr;
+  // A/B forms (knobs build): 1 = the same split of the LDE and of the hash launch on ONE stream (what the split costs by
+  // itself), 2 = the hash on a lowest-priority stream (the LDE's workgroups go first wherever both are waiting)
+  const int mode = tuning_knob("P3R_COMMIT_OVERLAP_MODE") ? atoi(tuning_knob("P3R_COMMIT_OVERLAP_MODE")) : 0;
+  std::map<size_t, uint64_t> perms, cells;   // per height class of the LDEs
+  for (auto& it : items) {
+    cells[it.in->h] += (uint64_t)it.in->h * it.in->w;
+    perms[it.in->h] += it.in->w;             // columns for now
+  }
+  size_t pick = 0;
+  uint64_t best = 0, total_cells = 0;
+  for (auto& kv : perms) {
+    kv.second = (uint64_t)kv.first * ((kv.second + P2_RATE - 1) / P2_RATE);
+    if (kv.second > best) { best = kv.second; pick = kv.first; }
+    total_cells += cells[kv.first];
+  }
+  const bool overlap = !off && !ctx->prof_enabled && ctx->cfg.mmcs_arity != 4 && perms.size() >= 2 &&
+                       total_cells - cells[pick] >= (uint64_t(1) << 22) && best >= (uint64_t(1) << 20);
+  ldes.clear();
+  ldes.resize(items.size());
+  std::vector<const p3r_dmat*> ptrs(items.size());
+  if (!overlap) {
+    auto out = coset_lde_batch<PP>(ctx, items, log_blowup);
+    for (size_t i = 0; i < items.size(); ++i) { ldes[i] = std::move(out[i]); ptrs[i] = ldes[i].get(); }
+    return commit_dmats<PP>(ctx, ptrs, cap_mont);
+  }
+  std::vector<LdeItem> first, rest;
+  std::vector<size_t> first_at, rest_at;
+  for (size_t i = 0; i < items.size(); ++i) {
+    (items[i].in->h == pick ? first : rest).push_back(items[i]);
+    (items[i].in->h == pick ? first_at : rest_at).push_back(i);
+  }
+  {
+    auto out = coset_lde_batch<PP>(ctx, first, log_blowup);
+    for (size_t k = 0; k < first.size(); ++k) { ldes[first_at[k]] = std::move(out[k]); ptrs[first_at[k]] = ldes[first_at[k]].get(); }
+  }
+  std::map<size_t, DevBuf> pre;
+  {
+    std::vector<const p3r_dmat*> cls;   // commit order within the class = the caller's order (stable)
+    for (size_t i : first_at) cls.push_back(ptrs[i]);
+    const size_t h = cls[0]->h;
+    uint32_t* dig = pre.emplace(h, DevBuf(P2_DIGEST * h)).first->second.p;
+    hash_rows<PP>(ctx, {cls}, {dig}, /*side=*/mode == 1 ? 0 : mode == 2 ? 2 : 1);
+  }
+  {
+    auto out = coset_lde_batch<PP>(ctx, rest, log_blowup);
+    for (size_t k = 0; k < rest.size(); ++k) { ldes[rest_at[k]] = std::move(out[k]); ptrs[rest_at[k]] = ldes[rest_at[k]].get(); }
+  }
+  if (mode != 1) hash_rows_join(ctx);
+  return commit_dmats<PP>(ctx, ptrs, cap_mont, &pre);
 }
 
 // Proof-of-work grinding on the device: the smallest witness w such that, after observing w, the
@@ -266,11 +329,10 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     for (size_t i = 0; i < ni; ++i) main_ev[i] = main_r[i].get();
   }
   for (size_t i = 0; i < ni; ++i) lde_items.push_back({main_ev[i], PP::GEN});
-  std::vector<std::unique_ptr<p3r_dmat>> main_lde = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
+  std::vector<std::unique_ptr<p3r_dmat>> main_lde;
   std::vector<const p3r_dmat*> ptrs;
-  for (size_t i = 0; i < ni; ++i) ptrs.push_back(main_lde[i].get());
   std::vector<uint32_t> main_cap, perm_cap, quot_cap, rand_cap;
-  auto main_tree = commit_dmats<PP>(ctx, ptrs, main_cap);
+  auto main_tree = lde_and_commit<PP>(ctx, lde_items, log_blowup, main_lde, main_cap);
 
   prof_stage(ctx, "transcript_head");
   // ---- 2. transcript head
@@ -365,13 +427,9 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     }
     lde_items.clear();
     for (int i : perm_insts) lde_items.push_back({aux_ev[i], PP::GEN});
-    auto ldes = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
-    ptrs.clear();
-    for (size_t k = 0; k < perm_insts.size(); ++k) {
-      aux_lde[perm_insts[k]] = std::move(ldes[k]);
-      ptrs.push_back(aux_lde[perm_insts[k]].get());
-    }
-    perm_tree = commit_dmats<PP>(ctx, ptrs, perm_cap);
+    std::vector<std::unique_ptr<p3r_dmat>> ldes;
+    perm_tree = lde_and_commit<PP>(ctx, lde_items, log_blowup, ldes, perm_cap);
+    for (size_t k = 0; k < perm_insts.size(); ++k) aux_lde[perm_insts[k]] = std::move(ldes[k]);
     {
       // every table's global sum in one transfer
       auto all = download_ef<PP, DC>(ctx, totals.p, ni);

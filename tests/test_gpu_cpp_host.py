@@ -126,3 +126,33 @@ def test_fallback_paths_give_the_same_proof(tmp_path):
     assert proof("wide_subtrees", P3R_SUBTREE_NODES="256", P3R_COOP_MAX_NODES="32768",
                  P3R_COOP_MAX_LEAF_ROWS="32768") == want
     assert proof("old_ntt", P3R_NTT_OLD="1") == want
+
+
+def test_two_stream_commit_gives_the_same_proof(tmp_path):
+    """Layers large enough to have something to hide hash one height class of each commit on a second stream while the
+    main stream extends the next (prove_impl.hip.h::lde_and_commit).  The knobs build can switch that off
+    (P3R_NO_COMMIT_OVERLAP): same bytes, with and without ZK commitments."""
+    import hashlib
+    import sys
+    knobs_lib = os.path.join(ROOT, "plonky3_recursion_amd", "knobs", "libp3r_hip.so")
+    if not os.path.exists(knobs_lib):
+        pytest.skip("knobs build of the library is absent (__graft_entry__.build() makes it)")
+    script = (
+        "import sys, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import harness_lib, harness_adapters as wl, plonky3_recursion_amd as p3r\n"
+        "a = harness_lib.generate('koala-bear', 17, seed=5, horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)\n"
+        "for zk in (0, 1):\n"
+        "    ctx = p3r.Context(field='koala-bear', zk=zk, zk_seed=3)\n"
+        "    pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), p3r.TablePacking().with_fri_params(5, 2))\n"
+        "    print(hashlib.sha256(pc.prove(wl.circuit_inputs_from_arrays(a))).hexdigest())\n"
+        "    pc.free(); ctx.close()\n" % (ROOT, os.path.join(ROOT, "tests")))
+
+    def digests(**env):
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env={**os.environ, **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout.split()
+
+    want = digests()
+    assert len(want) == 2 and want[0] != want[1]
+    assert digests(P3R_LIB_PATH=knobs_lib) == want
+    assert digests(P3R_LIB_PATH=knobs_lib, P3R_NO_COMMIT_OVERLAP="1") == want

@@ -133,3 +133,37 @@ def test_zk_prove_next_layer_and_wire_round_trip(oracle, field, log_h):
     cache.prover.verify_all_tables(out2.proof)
     cpd.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("d,flags,coeff,cd", [(5, harness_lib.RECOMPOSE_COEFF, 1, 5), (5, harness_lib.RECOMPOSE_BOTH, 0, 4),
+                                              (1, harness_lib.NO_RECOMPOSE, 0, 4)])
+def test_zk_circuit_degrees_and_quintic_challenge_on_the_device(oracle, d, flags, coeff, cd):
+    """ZK proofs of D = 5 / D = 1 layers, under the quartic and the quintic challenge field, through prove_next_layer:
+    the oracle's bytes (same seed and proof number), both verifiers."""
+    import plonky3_recursion_amd as p3r
+    from plonky3_recursion_amd import prover as pv
+    import harness_adapters as wl
+    from test_zk import native_verify_d
+    kw = dict(log_blowup=2, max_log_arity=2, log_final_poly_len=2, query_pow_bits=4, num_queries=5)
+    prm = layer_lib.params(zk=1, zk_seed=8, challenge_degree=cd, **kw)
+    arrs = harness_lib.generate("koala-bear", 8, seed=30 + d + cd, flags=flags, ext_degree=d, horner_chain_len=12, sponge_chain_len=3,
+                                merkle_depth=4)
+    both = bool(flags & harness_lib.RECOMPOSE_BOTH) and not coeff
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=dict(ext_degree=d, recompose_coeff_lookups=coeff))
+    ctx = make_ctx("koala-bear", prm, ext_degree=d, challenge_degree=cd)
+    tp = pv.TablePacking().with_fri_params(prm.log_final_poly_len, prm.log_blowup)
+    cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=d, recompose_coeff_lookups=bool(coeff)),
+                                     pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
+    cpd = cache.circuit_prover_data
+    assert np.array_equal(cpd.preprocessed_commitment, L.prep_commit())
+    out = pv.prove_next_layer(pv.RecursionInput(traces=wl.traces_from_arrays(arrs, d)), ctx, pv.FriRecursionBackend(),
+                              pv.ProveNextLayerParams(table_packing=cpd.packing), prep=cache)
+    assert out.proof.proof == L.prove()
+    L.verify(out.proof.proof)
+    cache.prover.verify_all_tables(out.proof)
+    if not both:
+        native_verify_d(prm, L.tables(), L.prep_commit(), out.proof.proof, d, coeff, cd)
+    back = pv.BatchStarkProof.from_postcard(out.proof.to_postcard(), "koala-bear", challenge_degree=cd, zk=True)
+    cache.prover.verify_all_tables(back)
+    cpd.free()
+    ctx.close()

@@ -199,3 +199,47 @@ def test_zk_parameter_checks(oracle):
     cfg, keep = p3r.make_config("koala-bear", zk=1, num_random_codewords=9)
     with pytest.raises(p3r.P3rError, match="num_random_codewords"):
         p3r.verify_batch(cfg, [dict(kind=0)], np.zeros((1, 8), np.uint32), [5], b"\x00")
+
+
+# circuit degree x table mix x challenge degree: the quintic recursion backend's own tables (D = 5, recompose/coeff) under the
+# quartic and the quintic challenge field, and the base proof (D = 1)
+DEGREE_MIXES = [(5, harness_lib.RECOMPOSE_COEFF, 1, 4), (5, harness_lib.RECOMPOSE_COEFF, 1, 5), (1, harness_lib.NO_RECOMPOSE, 0, 4),
+                (4, 0, 0, 5)]
+
+
+def native_verify_d(prm, tables, cap, proof, d, coeff, cd):
+    import plonky3_recursion_amd as p3r
+    cfg, keep = p3r.make_config("koala-bear", prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, ext_degree=d, challenge_degree=cd,
+                                zk=prm.zk, num_random_codewords=prm.num_random_codewords)
+    airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"],
+                 coeff_lookups=coeff if t["kind"] == "recompose" else 0) for t in tables]
+    p3r.verify_batch(cfg, airs, cap, [int(t["main"].shape[0]).bit_length() - 1 + prm.zk for t in tables], proof)
+
+
+@pytest.mark.parametrize("d,flags,coeff,cd", DEGREE_MIXES)
+def test_zk_over_the_other_circuit_degrees_and_the_quintic_challenge_field(oracle, d, flags, coeff, cd):
+    """`random` opened vectors have Challenge::DIMENSION = 5 entries under the quintic challenge field, the random round
+    has 5 + R columns, the masked chunks 5 + R; compact-D1 Poseidon2 rows pack their 17 interactions in triples."""
+    import plonky3_recursion_amd as p3r
+    kw = dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4)
+    prm = layer_lib.params(zk=1, zk_seed=21, challenge_degree=cd, **kw)
+    arrs = harness_lib.generate("koala-bear", 6, seed=60 + d + cd, flags=flags, ext_degree=d, **SMALL)
+    packing = dict(ext_degree=d, recompose_coeff_lookups=coeff)
+    L = layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm, packing=packing)
+    tables, cap, proof = L.tables(), L.prep_commit(), L.prove()
+    L.verify(proof)
+    native_verify_d(prm, tables, cap, proof, d, coeff, cd)
+    dec = proof_codec.decode(proof, dc=cd, zk=True)
+    assert dec["_consumed"] == len(proof)
+    assert all(len(o["random"]) == cd and all(len(v) == cd for v in o["random"]) for o in dec["opened"])
+    for frac in (0.1, 0.45, 0.9):
+        bad = bytearray(proof)
+        bad[int(len(bad) * frac)] ^= 1
+        with pytest.raises(RuntimeError):
+            L.verify(bytes(bad))
+        with pytest.raises(p3r.P3rError):
+            native_verify_d(prm, tables, cap, bytes(bad), d, coeff, cd)
+    prm0 = layer_lib.params(challenge_degree=cd, **kw)
+    with pytest.raises(p3r.P3rError):
+        native_verify_d(prm0, tables, cap, proof, d, coeff, cd)
