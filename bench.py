@@ -451,7 +451,10 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
     workers = queue.Queue()
     all_workers = []
     for _ in range(max(1, args.tree_workers)):
-        wctx = p3r.Context(field=field, device=local_rank, **FRI)
+        # --zk: `config_with_fri_params_zk(.., rng_seed)` per prover (recursive_aggregation.rs:711-721); distinct seeds, as
+        # distinct PCS objects have distinct RNG states
+        zk_kw = dict(zk=1, num_random_codewords=2, zk_seed=0x5EED0000 + 977 * rank + len(all_workers)) if args.zk else {}
+        wctx = p3r.Context(field=field, device=local_rank, **FRI, **zk_kw)
         lc = p3r.build_next_layer_prep(wctx, leaf_circuit, backend, params)
         wk = dict(ctx=wctx, leaf_cache=lc, leaf_inputs=lc.prepared_circuit.upload_inputs(leaf_host_inputs), agg_cache=[None])
         workers.put(wk)
@@ -479,7 +482,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
     def decode(data):
         """A child proof off the wire (or, in the level-synchronous mode, any child): native parse + metadata rules."""
         t0 = time.perf_counter()
-        proof = p3r.BatchStarkProof.from_postcard(data, field)
+        proof = p3r.BatchStarkProof.from_postcard(data, field, zk=args.zk)
         note("child_parse_ms", (time.perf_counter() - t0) * 1e3)
         note("child_parse_native_ms", proof.parse_ns * 1e-6)
         return proof
@@ -631,7 +634,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
         import hashlib
         roots = [r.to_postcard() if isinstance(r, p3r.BatchStarkProof) else r for r in roots]
         for root in roots:
-            rp = p3r.BatchStarkProof.from_postcard(root, field)    # the root is checked from its wire form
+            rp = p3r.BatchStarkProof.from_postcard(root, field, zk=args.zk)    # the root is checked from its wire form
             try:
                 p3r.verify_all_tables(ctx.cfg, rp)
             except Exception as e:
@@ -677,6 +680,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
                                    f"2^{lh}-row layer) -> {args.tree_leaves - 1} nodes (prove_aggregation_layer, 2^{lh + 1}-row "
                                    f"layer = twice the Poseidon2 / ALU counts), one rank per GPU, parent on its left child's rank, "
                                    f"tree t placed with rank offset t",
+                       "zk": bool(args.zk),
                        "field": field, "leaf_log_height": lh, "node_log_height": lh + 1, "leaves": args.tree_leaves,
                        "trees": n_trees, "nodes": n_nodes, "fri": FRI, "workers_per_rank": len(all_workers),
                        "scheduler": "level-synchronous" if args.tree_level_barriers else "dependency-driven",
@@ -785,6 +789,8 @@ def main():
                     help="skip the D = 5 layer (KoalaBear quintic circuits: ALU, compact-D1 Poseidon2, recompose/coeff)")
     ap.add_argument("--no-config2", action="store_true",
                     help="skip the secondary measurement with BASELINE config 2's chain-length knobs")
+    ap.add_argument("--zk", action="store_true",
+                    help="--tree: every proof of the tree under the ZK configuration (HidingFriPcs: `recursive_aggregation --zk`)")
     ap.add_argument("--trees", type=int, default=1,
                     help="--tree: independent trees in flight (0 = one per rank: the throughput form, weak scaling); tree t "
                          "is placed with rank offset t, so every rank proves the same number of nodes")

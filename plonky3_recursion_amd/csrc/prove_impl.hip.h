@@ -89,18 +89,19 @@ std::unique_ptr<p3r_tree> commit_dmats(p3r_ctx* ctx, const std::vector<const p3r
   return tree;
 }
 
-// Coset LDE + MMCS commitment of one round's matrices (TwoAdicFriPcs::commit), with the leaf hashing of ONE height class
-// taken off the critical path: the class with the most permutations is extended first and hashed on the ctx's second
-// stream while the main stream extends the other classes - the hash is VALU-bound (0.96 busy), the LDE passes leave a
-// third of their time to memory phases, and the two kernels share the CUs (tools/overlap_ab.py: 0.55 ms of a 1.9 ms LDE
-// hidden; profiles/r05/overlap_ab.txt).  Same digests, same tree, same bytes.  Falls back to the plain sequence for
-// small layers (nothing to hide: they are latency-bound), one height class, the arity-4 MMCS, and while the per-family
-// timers are on (two kernels at once would be timed as one).
+// Coset LDE + MMCS commitment of one round's matrices (TwoAdicFriPcs::commit).  The product runs them back to back on the
+// ctx's stream.  The `knobs` build can take the leaf hashing of ONE height class off the critical path instead
+// (P3R_COMMIT_OVERLAP=1): the class with the most permutations is extended first and hashed on the ctx's second stream
+// while the main stream extends the other classes - the hash is VALU-bound (0.96 busy), the LDE passes leave a third of
+// their time to memory phases.  Measured (profiles/r05/commit_overlap_ab.txt): between two contexts the pair gains
+// 0.55 ms of a 1.9 ms LDE, inside the prover 0.0 - 0.2 ms of 28 (paired, 40 proofs per form alternating in one
+// process): below the 0.3 ms a change has to earn, so it is not the product's path.  Same digests, same tree, same bytes
+// (tests/test_gpu_cpp_host.py::test_two_stream_commit_gives_the_same_proof).
 template <class PP>
 std::unique_ptr<p3r_tree> lde_and_commit(p3r_ctx* ctx, const std::vector<LdeItem>& items, int log_blowup,
                                          std::vector<std::unique_ptr<p3r_dmat>>& ldes, std::vector<uint32_t>& cap_mont) {
   // (read per call, not once: tools/ab_commit_overlap.py alternates the forms proof by proof inside one process)
-  const bool off = tuning_knob("P3R_NO_COMMIT_OVERLAP") != nullptr;
+  const bool off = tuning_knob("P3R_COMMIT_OVERLAP") == nullptr;
   // A/B forms (knobs build): 1 = the same split of the LDE and of the hash launch on ONE stream (what the split costs by
   // itself), 2 = the hash on a lowest-priority stream (the LDE's workgroups go first wherever both are waiting)
   const int mode = tuning_knob("P3R_COMMIT_OVERLAP_MODE") ? atoi(tuning_knob("P3R_COMMIT_OVERLAP_MODE")) : 0;

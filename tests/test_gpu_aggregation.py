@@ -127,13 +127,14 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,leaves", [(2, 4), (1, 8)])
-def test_tree_of_real_proofs_root_verifies(world, leaves):
+@pytest.mark.parametrize("world,leaves,zk", [(2, 4, False), (1, 8, False), (2, 4, True)])
+def test_tree_of_real_proofs_root_verifies(world, leaves, zk):
     """bench.py --tree: leaves -> root with prove_next_layer / prove_aggregation_layer on every node,
-    children parsed and natively verified before their parent is proved, the root verified on rank 0."""
+    children parsed and natively verified before their parent is proved, the root verified on rank 0.
+    --zk: every proof under the hiding PCS (`recursive_aggregation --zk`): children cross ranks as ZK proofs."""
     env = dict(os.environ, P3R_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     args = ["bench.py", "--tree", "--gpus", str(world), "--tree-leaves", str(leaves), "--leaf-log-height", "10", "--steps", "1",
-            "--warmup", "0", "--tree-verify-children", "--tree-level-barriers"]
+            "--warmup", "0", "--tree-verify-children", "--tree-level-barriers"] + (["--zk"] if zk else [])
     if world == 1:
         cmd = [sys.executable] + args
     else:
@@ -146,6 +147,11 @@ def test_tree_of_real_proofs_root_verifies(world, leaves):
     assert line["config"]["nodes"] == 2 * leaves - 1
     assert len(line["rank0"]["level_wall_ms_last_step"]) == leaves.bit_length()
     assert line["rank0"]["child_verify_ms"] is not None
+    assert line["config"]["zk"] is zk
+    # the comparison a multi-GPU run gets: critical path and predicted walls from solo measurements
+    pr = line["prediction"]
+    assert line["critical_path_ms"] > 0 and set(pr["one_gpu_per_rank"]) == {"1", "2", "4", "8"}
+    assert pr["one_gpu_per_rank"]["8"]["predicted_wall_ms"] <= pr["one_gpu_per_rank"]["1"]["predicted_wall_ms"]
 
 
 def test_plain_bench_entry_launches_its_own_ranks():

@@ -129,9 +129,9 @@ def test_fallback_paths_give_the_same_proof(tmp_path):
 
 
 def test_two_stream_commit_gives_the_same_proof(tmp_path):
-    """Layers large enough to have something to hide hash one height class of each commit on a second stream while the
-    main stream extends the next (prove_impl.hip.h::lde_and_commit).  The knobs build can switch that off
-    (P3R_NO_COMMIT_OVERLAP): same bytes, with and without ZK commitments."""
+    """The knobs build can hash one height class of each commit on a second stream while the main stream extends the next
+    (prove_impl.hip.h::lde_and_commit, P3R_COMMIT_OVERLAP; measured, not the product's path: profiles/r05/
+    commit_overlap_ab.txt): same bytes in every form, with and without ZK commitments."""
     import hashlib
     import sys
     knobs_lib = os.path.join(ROOT, "plonky3_recursion_amd", "knobs", "libp3r_hip.so")
@@ -155,4 +155,5 @@ def test_two_stream_commit_gives_the_same_proof(tmp_path):
     want = digests()
     assert len(want) == 2 and want[0] != want[1]
     assert digests(P3R_LIB_PATH=knobs_lib) == want
-    assert digests(P3R_LIB_PATH=knobs_lib, P3R_NO_COMMIT_OVERLAP="1") == want
+    assert digests(P3R_LIB_PATH=knobs_lib, P3R_COMMIT_OVERLAP="1") == want
+    assert digests(P3R_LIB_PATH=knobs_lib, P3R_COMMIT_OVERLAP="1", P3R_COMMIT_OVERLAP_MODE="2") == want

@@ -2,10 +2,10 @@
 """Paired A/B of the two-stream commit (prove_impl.hip.h::lde_and_commit) on the headline layer, inside ONE process of the
 `knobs` build: the forms alternate proof by proof on the same context, inputs and memory, so box-to-box and run-to-run
 drift (+- 0.5 ms between processes on these boxes) cancels.
-    plain      P3R_NO_COMMIT_OVERLAP=1        one LDE batch, one hash launch per commit (rounds 1 - 4)
-    overlap    (default)                      biggest hash class on the second stream while the rest is extended
-    split      P3R_COMMIT_OVERLAP_MODE=1      the same split of LDE and hash on ONE stream: what the split costs
-    lowprio    P3R_COMMIT_OVERLAP_MODE=2      the side stream at the lowest priority
+    plain      (default, the product's path)  one LDE batch, one hash launch per commit
+    overlap    P3R_COMMIT_OVERLAP=1           biggest hash class on the second stream while the rest is extended
+    split      + P3R_COMMIT_OVERLAP_MODE=1    the same split of LDE and hash on ONE stream: what the split costs
+    lowprio    + P3R_COMMIT_OVERLAP_MODE=2    the side stream at the lowest priority
 usage (GPU box): P3R_LIB_PATH=plonky3_recursion_amd/knobs/libp3r_hip.so python tools/ab_commit_overlap.py [reps=30] [log_h=20]"""
 import hashlib
 import os
@@ -23,7 +23,8 @@ import bench  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 log_h = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-FORMS = {"plain": {"P3R_NO_COMMIT_OVERLAP": "1"}, "overlap": {}, "split": {"P3R_COMMIT_OVERLAP_MODE": "1"}, "lowprio": {"P3R_COMMIT_OVERLAP_MODE": "2"}}
+FORMS = {"plain": {}, "overlap": {"P3R_COMMIT_OVERLAP": "1"}, "split": {"P3R_COMMIT_OVERLAP": "1", "P3R_COMMIT_OVERLAP_MODE": "1"},
+         "lowprio": {"P3R_COMMIT_OVERLAP": "1", "P3R_COMMIT_OVERLAP_MODE": "2"}}
 ctx = p3r.Context(field="koala-bear", **bench.FRI)
 packing = p3r.TablePacking().with_fri_params(bench.FRI["log_final_poly_len"], bench.FRI["log_blowup"])
 arrs = harness_lib.generate("koala-bear", log_h, seed=0x5EED0000, **bench.GEN_KNOBS)
@@ -33,7 +34,7 @@ del arrs
 
 
 def set_form(env):
-    for k in ("P3R_NO_COMMIT_OVERLAP", "P3R_COMMIT_OVERLAP_MODE"):
+    for k in ("P3R_COMMIT_OVERLAP", "P3R_COMMIT_OVERLAP_MODE"):
         os.environ.pop(k, None)
     os.environ.update(env)
 

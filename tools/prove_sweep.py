@@ -58,7 +58,8 @@ def fitting_schedule(rng, oracle, field, arrs, kw, packing):
     L = layer_lib.OracleLayer(oracle, field, arrs, layer_lib.params(**base), packing=dict(packing))
     lb = kw["log_blowup"]
     # FRI inputs: the LDEs of the trace domains and of the quotient chunks all live at log2(h) + log_blowup
-    hs = sorted({int(np.log2(t["main"].shape[0])) + lb for t in L.tables()}, reverse=True)
+    # (ZK: over the extended domains, one bit taller)
+    hs = sorted({int(np.log2(t["main"].shape[0])) + lb + int(kw.get("zk", 0)) for t in L.tables()}, reverse=True)
     log_final = kw["log_final_poly_len"] + lb
     cur, out, nxt = hs[0], [], 1
     while cur > log_final:
@@ -108,12 +109,20 @@ def one(oracle, seed, max_log_h, min_log_h=5):
             kw["cap_height"] = 0
     if ext_degree == 4 and not (flags & harness_lib.NO_POSEIDON2) and rng4.random() < 0.25:
         flags |= harness_lib.P2_W32
+    # fifth stream (round 5): the ZK configuration (HidingFriPcs: p3r_config.zk) in a third of the draws, with 1 - 3 random
+    # codewords, a random seed and a random proof number - the oracle is given the same three, so the bytes must agree;
+    # degree-3 constraints need log_blowup >= 2 under ZK, the other draws must be refused by both sides
+    rng5 = random.Random(seed * 32452843 + 4)
+    zk_nonce = 0
+    if rng5.random() < 0.33:
+        kw["zk"], kw["num_random_codewords"], kw["zk_seed"] = 1, rng5.randint(1, 3), rng5.getrandbits(48)
+        zk_nonce = rng5.randint(0, 5)
     coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
     arrs = harness_lib.generate(field, log_h, seed=seed, flags=flags, ext_degree=ext_degree, **gen)
     packing_o = dict(packing, ext_degree=ext_degree, recompose_coeff_lookups=int(coeff))
     if kw.get("fri_log_arities") == "fitting":
         kw["fri_log_arities"] = fitting_schedule(rng, oracle, field, arrs, kw, packing_o)
-    prm = layer_lib.params(**kw)
+    prm = layer_lib.params(zk_nonce=zk_nonce, **kw)
     desc = f"seed {seed}: {field} D={ext_degree} DC={challenge_degree} flags={flags} 2^{log_h} {kw} {packing} {gen}"
     L = layer_lib.OracleLayer(oracle, field, arrs, prm, packing=dict(packing_o))
     try:
@@ -125,6 +134,7 @@ def one(oracle, seed, max_log_h, min_log_h=5):
     ctx = None
     try:
         ctx = p3r.Context(field=field, ext_degree=ext_degree, **kw)
+        ctx.zk_nonce = zk_nonce
         cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree, recompose_coeff_lookups=coeff),
                                          pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
         cpd = cache.circuit_prover_data
