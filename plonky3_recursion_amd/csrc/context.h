@@ -443,6 +443,7 @@ struct p3r_ctx {
   p3r::ProofLayout proof_layout;         // from p3r_config.proof_layout (identity by default)
   std::vector<uint32_t> rc_mont_host;  // Montgomery copy on the host (the prover's out-of-domain self-check)
   std::string err;
+  bool w32_diag_builtin = false;  // the width-32 diagonal takes the per-lane forms (poseidon2_w32_f64.hip.h)
   bool w32_unacknowledged = false;  // width-32 constants defaulted without P3R_EXT_UNPINNED_W32_DEFAULTS (p3r.h)
   uint64_t zk_nonce = 0;  // proofs made so far under a ZK configuration (p3r_zk_nonce; zk_rand.h)
   p3r::HostStage stage;  // small uploads that do not wait (see HostStage)

@@ -9,7 +9,7 @@ namespace p3r {
 constexpr int P2W_RATE = 24;   // PaddingFreeSponge<Perm32, 32, 24, 8>
 
 // One absorb loop for both leaf kernels: cell (g, i) of the concatenated row is load(g).
-template <class PP, class Load>
+template <class PP, bool BUILTIN, class Load>
 __device__ __forceinline__ void p2wf_sponge(double* s, int wtot, const double* __restrict__ tab, Load&& load) {
 #pragma unroll
   for (int k = 0; k < P2W_WIDTH; ++k) s[k] = 0.0;
@@ -17,14 +17,14 @@ __device__ __forceinline__ void p2wf_sponge(double* s, int wtot, const double* _
   for (; g + P2W_RATE <= wtot; g += P2W_RATE) {
 #pragma unroll
     for (int j = 0; j < P2W_RATE; ++j) s[j] = load(g + j);
-    p2wf_permute<PP>(s, tab);
+    p2wf_permute<PP, BUILTIN>(s, tab);
   }
   const int rem = wtot - g;
   if (rem > 0) {
 #pragma unroll
     for (int j = 0; j < P2W_RATE; ++j)
       if (j < rem) s[j] = load(g + j);
-    p2wf_permute<PP>(s, tab);
+    p2wf_permute<PP, BUILTIN>(s, tab);
   }
 }
 
@@ -38,7 +38,8 @@ struct HashRowsJob4 {
 };
 // Leaf digests of several height classes in one launch (the job list of k_mmcs_hash_rows): overwrite-mode sponge of
 // rate 24 over the concatenated row (recursion/src/pcs/mmcs.rs:963-985 add_arity4_leaf_digest_from_base).
-template <class PP>
+// BUILTIN: the instance for the built-in diagonal (poseidon2_w32_f64.hip.h).
+template <class PP, bool BUILTIN>
 __global__ void __launch_bounds__(kBlock)
 k_mmcs4_hash_rows(const HashRowsJob4* __restrict__ jobs, int n_jobs, const double* __restrict__ tab) {
   int jb = 0;
@@ -49,20 +50,20 @@ k_mmcs4_hash_rows(const HashRowsJob4* __restrict__ jobs, int n_jobs, const doubl
   const size_t i = (size_t)(blockIdx.x - jobs[jb].block0) * kBlock + threadIdx.x;
   if (i >= h) return;
   double s[P2W_WIDTH];
-  p2wf_sponge<PP>(s, jobs[jb].wtot, tab, [&](int g) { return p2f_load<PP>(as_global(cols[g])[i]); });
+  p2wf_sponge<PP, BUILTIN>(s, jobs[jb].wtot, tab, [&](int g) { return p2f_load<PP>(as_global(cols[g])[i]); });
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * stride + i] = p2f_store<PP>(s[k]);
 }
 
 // FRI commit-phase leaves: strided views over the folded vector (k_mmcs_hash_rows_strided).  dig: [8][h_alloc].
-template <class PP>
+template <class PP, bool BUILTIN>
 __global__ void __launch_bounds__(kBlock)
 k_mmcs4_hash_rows_strided(const uint32_t* const* __restrict__ cols, int wtot, size_t h, size_t stride, uint32_t* __restrict__ dig,
                           size_t h_alloc, const double* __restrict__ tab) {
   const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= h) return;
   double s[P2W_WIDTH];
-  p2wf_sponge<PP>(s, wtot, tab, [&](int g) { return p2f_load<PP>(cols[g][i * stride]); });
+  p2wf_sponge<PP, BUILTIN>(s, wtot, tab, [&](int g) { return p2f_load<PP>(cols[g][i * stride]); });
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * h_alloc + i] = p2f_store<PP>(s[k]);
 }
@@ -72,7 +73,7 @@ k_mmcs4_hash_rows_strided(const uint32_t* const* __restrict__ cols, int wtot, si
 // the matrices of the new layer's height enter as one more compression (node, inj[i], 0, 0) in the same lane.
 // Nodes n_logical .. n_out of the new layer are the zero digests that pad a layer of 2 to 4.
 // prev: [8][n_prev], inj: [8][n_logical] or null, out: [8][n_out].
-template <class PP>
+template <class PP, bool BUILTIN>
 __global__ void __launch_bounds__(kBlock)
 k_mmcs4_compress(const uint32_t* __restrict__ prev, size_t n_prev, int step, const uint32_t* __restrict__ inj,
                  uint32_t* __restrict__ out, size_t n_logical, size_t n_out, const double* __restrict__ tab) {
@@ -103,7 +104,7 @@ k_mmcs4_compress(const uint32_t* __restrict__ prev, size_t n_prev, int step, con
       s[3 * P2_DIGEST + k] = 0.0;
     }
   }
-  p2wf_permute<PP>(s, tab);
+  p2wf_permute<PP, BUILTIN>(s, tab);
   if (inj) {
 #pragma unroll
     for (int k = 0; k < P2_DIGEST; ++k) {
@@ -111,7 +112,7 @@ k_mmcs4_compress(const uint32_t* __restrict__ prev, size_t n_prev, int step, con
       s[2 * P2_DIGEST + k] = 0.0;
       s[3 * P2_DIGEST + k] = 0.0;
     }
-    p2wf_permute<PP>(s, tab);
+    p2wf_permute<PP, BUILTIN>(s, tab);
   }
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) out[(size_t)k * n_out + i] = p2f_store<PP>(s[k]);

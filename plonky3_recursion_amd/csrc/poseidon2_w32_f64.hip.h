@@ -10,21 +10,34 @@
 // (width 16: 3.9 k) for three times the rate - the same cost per absorbed cell.
 //
 // Constant table `tab` (doubles, p3r_ctx::rcd_w32()): [4][32] | [partial] | [4][32] round constants (canonical),
-// then the diagonal as CENTRED integers (|d| <= P / 2), then d_i / P.
+// then the diagonal as CENTRED integers (|d| <= P / 2), then d_i / P, then the STRUCTURED form (below): 32 factors,
+// and as raw 64-bit words: a flag, the lanes' form codes (2 bits each), one reduction mask per partial round.
+//
+// The built-in diagonal (round 5).  The diagonal is data, so in general every lane pays the five-instruction product.  The
+// library's OWN default diagonal, however, is known at compile time (poseidon2_w32_default.inc): small integers and
+// inverse powers of two, like the width-16 one.  When the configured diagonal IS the built-in one (p3r_create compares
+// the 32 entries and launches the BUILTIN kernel instances) the partial rounds run per-lane forms fixed at compile time - one FMA for |d| <= 16, the
+// three-instruction p2f_mul_2exp_neg_add for +-2^-k with k <= 12, p2f_mul_2exp_neg and an add for larger k - with the
+// small-integer lanes reduced every 3 - 5 rounds (three wave-uniform branches per round, as in the width-16 kernel):
+// ~95 instead of ~160 instructions per partial round.  Any other diagonal takes the general path.
+// (Tried first, as the round-4 review proposed: forms selected at RUN time by wave-uniform branches on per-lane code words,
+// for any structured diagonal.  Byte-exact and 2.3 x SLOWER - a commit of 2^22 x 64 in 16.1 ms against 7.0 ms: each lane's
+// form becomes its own basic block, so the scheduler can no longer interleave the 32 independent dependency chains of a
+// round and every chain runs at FP64 latency.  profiles/r05/w32_diag_ab.txt.)
 //
 // Magnitudes: inputs |x| <= 0.5 P + slack (p2wf_permute reduces its outputs).  External layer: rows of
 // circ(2 M4, M4, ..) sum to 7 * 9 = 63, so a full round's S-box sees |x| < 63 * 1.3 P + P < 2^38 - inside the domain
 // of the narrow S-box (p2f_mulmod_c needs |a b| < 2^76).  Partial rounds: d_i * s_i reduced to < 0.7 P, the lane sum
 // reduced to <= 0.5 P: no growth.
 #pragma once
+#include <utility>
+
 #include "poseidon2_f64.hip.h"
+#include "poseidon2_w32_default.inc"   // the built-in diagonal: its lane forms are compile-time facts here
 
 namespace p3r {
 
 #pragma clang fp contract(off)
-
-template <class PP>
-constexpr int p2wf_table_len() { return p2w_num_rc<PP>() + 2 * P2W_WIDTH; }
 
 __device__ __forceinline__ void p2wf_external_linear(double* s) {
 #pragma unroll
@@ -68,8 +81,98 @@ __device__ __forceinline__ void p2wf_internal_linear(double* s, const double* __
   for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_mulmod_c_add<PP>(s[i], d[i], c[i], sumM, neg_c, p_hi);
 }
 
-// In: integers |x| <= 0.5 P + slack.  Out: the same (reduced, not canonical: either sign).
+// ---- the built-in diagonal: lane forms as compile-time facts
+struct P2WLaneForm { int form; int period; };   // form 0: small integer, 1: +-2^-k (addend form), 2: +-2^-k then add, 3: general
 template <class PP>
+constexpr P2WLaneForm p2w_default_form(int i) {
+  const uint32_t d = PP::FIELD_ID == 0 ? kDefaultDiagW32_koala_bear[i] : kDefaultDiagW32_baby_bear[i];
+  const int64_t c = d > PP::P / 2 ? (int64_t)d - (int64_t)PP::P : (int64_t)d;
+  if (c != 0 && c >= -16 && c <= 16) {
+    const int64_t a = c < 0 ? -c : c;
+    return {0, a < 2 ? 0 : a <= 4 ? 5 : a <= 7 ? 4 : 3};
+  }
+  for (int k = 1; k <= PP::TWO_ADICITY; ++k) {
+    const uint64_t t = ((uint64_t)d << k) % PP::P;
+    if (t == 1 || t == PP::P - 1) return {k <= 12 ? 1 : 2, 0};
+  }
+  return {3, 0};
+}
+// the lane's factor as an FP64 value (the integer itself, or +-2^-k), and the first lane with the same magnitude: the
+// magnitudes that are not inline constants of the ISA live in SCALAR registers (one pair per distinct magnitude, ~17; the
+// sign is a source modifier), see P2FDiag in poseidon2_f64.hip.h for why not literals
+template <class PP>
+constexpr double p2w_default_factor(int i) {
+  const uint32_t d = PP::FIELD_ID == 0 ? kDefaultDiagW32_koala_bear[i] : kDefaultDiagW32_baby_bear[i];
+  const int64_t c = d > PP::P / 2 ? (int64_t)d - (int64_t)PP::P : (int64_t)d;
+  if (c >= -16 && c <= 16) return (double)c;
+  double m = 1.0;
+  for (int k = 1; k <= PP::TWO_ADICITY; ++k) {
+    m *= 0.5;
+    const uint64_t t = ((uint64_t)d << k) % PP::P;
+    if (t == 1) return m;
+    if (t == PP::P - 1) return -m;
+  }
+  return 0.0;
+}
+constexpr double p2w_abs(double x) { return x < 0 ? -x : x; }
+template <class PP>
+constexpr int p2w_default_rep(int i) {
+  for (int j = 0; j < i; ++j)
+    if (p2w_abs(p2w_default_factor<PP>(j)) == p2w_abs(p2w_default_factor<PP>(i))) return j;
+  return i;
+}
+template <class PP>
+constexpr bool p2w_default_inline(int i) {
+  const double a = p2w_abs(p2w_default_factor<PP>(i));
+  return a == 0.5 || a == 1.0 || a == 2.0 || a == 4.0;
+}
+template <class PP, int I>
+__device__ __forceinline__ void p2wf_pin_default(double* mk) {
+  if constexpr (p2w_default_rep<PP>(I) == I && !p2w_default_inline<PP>(I)) {
+    constexpr double mag = p2w_abs(p2w_default_factor<PP>(I));
+    mk[I] = mag;
+    asm volatile("" : "+s"(mk[I]));
+  }
+}
+template <class PP, int... I>
+__device__ __forceinline__ void p2wf_pin_defaults(double* mk, std::integer_sequence<int, I...>) { (p2wf_pin_default<PP, I>(mk), ...); }
+
+template <class PP, int I>
+__device__ __forceinline__ void p2wf_lane_default(double* s, const double* mk, double sum) {
+  constexpr P2WLaneForm f = p2w_default_form<PP>(I);
+  static_assert(f.form != 3, "the built-in width-32 diagonal is made of small integers and inverse powers of two");
+  // (constexpr variables, not calls: a call outside a constant expression is compiled, and the 64-bit `%` loops of these
+  // functions then run on the scalar unit every round)
+  constexpr double lit = p2w_default_factor<PP>(I);
+  constexpr bool inl = p2w_default_inline<PP>(I);
+  constexpr int rep = p2w_default_rep<PP>(I);
+  const double m = inl ? lit : lit < 0 ? -mk[rep] : mk[rep];
+  if constexpr (f.form == 0) s[I] = __builtin_fma(s[I], m, sum);
+  else if constexpr (f.form == 1) s[I] = p2f_mul_2exp_neg_add<PP>(s[I], m, sum);
+  else s[I] = p2f_mul_2exp_neg<PP>(s[I], m) + sum;
+}
+template <class PP, int PERIOD, int I>
+__device__ __forceinline__ void p2wf_lane_reduce(double* s) {
+  if constexpr (I > 0 && p2w_default_form<PP>(I).period == PERIOD) s[I] = p2f_reduce<PP>(s[I]);   // lane 0: the S-box reduces it
+}
+template <class PP, int... I>
+__device__ __forceinline__ void p2wf_internal_linear_default(double* s, const double* mk, int r, std::integer_sequence<int, I...>) {
+  // a lane multiplied by a small integer grows by that factor every round: reduced every 5 / 4 / 3 rounds (|d| <= 4 / 7 / 16)
+  if (r % 5 == 0) (p2wf_lane_reduce<PP, 5, I>(s), ...);
+  if (r % 4 == 0) (p2wf_lane_reduce<PP, 4, I>(s), ...);
+  if (r % 3 == 0) (p2wf_lane_reduce<PP, 3, I>(s), ...);
+  double part[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    part[k] = ((s[k] + s[4 + k]) + (s[8 + k] + s[12 + k])) + ((s[16 + k] + s[20 + k]) + (s[24 + k] + s[28 + k]));
+  const double sum = p2f_reduce<PP>((part[0] + part[1]) + (part[2] + part[3]));
+  (p2wf_lane_default<PP, I>(s, mk, sum), ...);
+}
+
+// In: integers |x| <= 0.5 P + slack.  Out: the same (reduced, not canonical: either sign).
+// BUILTIN: the configured diagonal is the built-in one (its own kernel instance: the general path keeps 64 constants in
+// vector registers and runs at one wave per SIMD; this one needs none)
+template <class PP, bool BUILTIN>
 __device__ __forceinline__ void p2wf_permute(double* s, const double* __restrict__ tab) {
   const double* d = tab + p2w_num_rc<PP>();
   p2wf_external_linear(s);
@@ -80,7 +183,18 @@ __device__ __forceinline__ void p2wf_permute(double* s, const double* __restrict
     k += P2W_WIDTH;
     p2wf_external_linear(s);
   }
-  {
+  if constexpr (BUILTIN) {
+    double mk[P2W_WIDTH];
+    p2wf_pin_defaults<PP>(mk, std::make_integer_sequence<int, P2W_WIDTH>{});
+#pragma unroll 1
+    for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) {
+      s[0] = p2f_sbox<PP>(s[0] + tab[k + r]);
+      p2wf_internal_linear_default<PP>(s, mk, r, std::make_integer_sequence<int, P2W_WIDTH>{});
+    }
+    // whatever the small-integer lanes accumulated since their last reduction: back inside the full rounds' domain
+#pragma unroll
+    for (int i = 1; i < P2W_WIDTH; ++i) s[i] = p2f_reduce<PP>(s[i]);
+  } else {
     // The 64 diagonal constants stay in VECTOR registers through the partial rounds.  As scalars they need 128 SGPRs at
     // once: hoisted out of the loop they spill into vector lanes (v_readlane per use: +50 % instructions, measured 0.39
     // ns per permutation), loaded inside the round the waves wait on the scalar cache every round (0.60 ns).  One wave

@@ -37,7 +37,8 @@ void mmcs4_hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*
   }
   const auto* d_jobs = static_cast<const HashRowsJob4*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(HashRowsJob4)));
   ProfScope ps(ctx, "mmcs_hash_rows");
-  hipLaunchKernelGGL(k_mmcs4_hash_rows<PP>, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(), ctx->rcd_w32());
+  const auto kern = ctx->w32_diag_builtin ? &k_mmcs4_hash_rows<PP, true> : &k_mmcs4_hash_rows<PP, false>;   // poseidon2_w32_f64.hip.h
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_jobs, (int)jobs.size(), ctx->rcd_w32());
   P3R_HIP(hipGetLastError());
 }
 
@@ -51,7 +52,8 @@ void mmcs4_hash_rows_strided(p3r_ctx* ctx, const uint32_t* const* dcols, int wto
     P3R_HIP(hipGetLastError());
     return;
   }
-  hipLaunchKernelGGL(k_mmcs4_hash_rows_strided<PP>, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, dcols,
+  const auto kern = ctx->w32_diag_builtin ? &k_mmcs4_hash_rows_strided<PP, true> : &k_mmcs4_hash_rows_strided<PP, false>;   // poseidon2_w32_f64.hip.h
+  hipLaunchKernelGGL(kern, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, dcols,
                      wtot, rows, stride, dig, alloc, ctx->rcd_w32());
   P3R_HIP(hipGetLastError());
 }
@@ -66,7 +68,8 @@ void mmcs4_compress(p3r_ctx* ctx, const uint32_t* prev, size_t n_prev, int step,
     P3R_HIP(hipGetLastError());
     return;
   }
-  hipLaunchKernelGGL(k_mmcs4_compress<PP>, dim3((unsigned)((n_out + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, prev, n_prev,
+  const auto kern = ctx->w32_diag_builtin ? &k_mmcs4_compress<PP, true> : &k_mmcs4_compress<PP, false>;   // poseidon2_w32_f64.hip.h
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n_out + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, prev, n_prev,
                      step, inj, out, n_logical, n_out, ctx->rcd_w32());
   P3R_HIP(hipGetLastError());
 }

@@ -51,6 +51,21 @@ def hash_rows_summary():
                                      valu_insts_per_perm=insts * 64.0 / perms)
         except Exception as e:  # a missing pass must not lose the rest of the summaries
             print("pmc_hash_rows: %s: %r" % (fld, e))
+    # width-32 permutation (arity-4 MMCS leaf kernel): instructions per permutation of the built-in-diagonal instance and
+    # of the general one
+    w32 = {}
+    for which in ("builtin", "general"):
+        try:
+            meta = json.loads([ln for ln in open(os.path.join(SRC, "hashrows_w32_%s.log" % which)) if ln.startswith("{")][-1])
+            path = newest(SRC + "/hashrows_w32_%s/*/*_counter_collection.csv" % which)
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                    if r["Counter_Name"] == "SQ_INSTS_VALU" and "k_mmcs4_hash_rows<" in r["Kernel_Name"]]
+            w32[which] = dict(meta, launches_counted=len(vals), SQ_INSTS_VALU=sum(vals),
+                              valu_insts_per_perm=sum(vals) * 64.0 / (len(vals) * meta["perms_per_launch"]))
+        except Exception as e:
+            print("pmc_hash_rows w32: %s: %r" % (which, e))
+    if w32:
+        hr["width32"] = w32
     if hr["fields"]:
         # bench.py::committed_valu_model refuses the count when the kernel's sources are not the ones it was measured on
         sys.path.insert(0, ROOT)

@@ -4,7 +4,9 @@
 exact (rows x ceil(width / 8) per launch), so SQ_INSTS_VALU x 64 lanes / permutations is the kernel's FP64 /
 VALU instruction count per Poseidon2 permutation - the figure bench.py's `valu_roofline` prices.
 tools/collect_profiles.py turns the counter file into profiles/<round>/pmc_hash_rows.json.
-usage: python3 tools/pmc_hash_rows.py <field> [log_rows] [width] [launches]"""
+usage: python3 tools/pmc_hash_rows.py <field> [log_rows] [width] [launches]
+       python3 tools/pmc_hash_rows.py <field> w32 builtin|general    (the arity-4 leaf kernel over the width-32 permutation: the
+           built-in diagonal's instance, or the general one, reached by configuring a random diagonal)"""
 import json
 import os
 import sys
@@ -16,8 +18,26 @@ sys.path.insert(0, ROOT)
 import plonky3_recursion_amd as p3r  # noqa: E402
 
 field = sys.argv[1] if len(sys.argv) > 1 else "koala-bear"
-ctx = p3r.Context(field=field)
 rng = np.random.default_rng(1)
+if len(sys.argv) > 2 and sys.argv[2] == "w32":
+    which = sys.argv[3] if len(sys.argv) > 3 else "builtin"
+    kw = {}
+    if which == "general":   # any diagonal that is not the built-in one takes the general kernel
+        dflt = json.load(open(os.path.join(ROOT, "tests", "golden", "poseidon2_w32_default.json")))[field.replace("-", "_")]
+        kw = dict(poseidon2_w32_rc=np.array(dflt["rc"], dtype=np.uint32).reshape(-1),
+                  poseidon2_w32_diag=rng.integers(1, 0x78000001, size=32, dtype=np.uint32))
+    ctx = p3r.Context(field=field, mmcs_arity=4, **kw)
+    log_rows, width, launches = 22, 96, 3
+    m = ctx.upload(rng.integers(0, ctx.p, size=(1 << log_rows, width), dtype=np.uint32))
+    for _ in range(launches):
+        cap, tree = ctx.commit_device([m])
+        tree.free()
+    ctx.sync()
+    print(json.dumps({"field": field, "kernel": "k_mmcs4_hash_rows", "diagonal": which, "rows": 1 << log_rows, "width": width,
+                      "launches": launches, "perms_per_launch": (1 << log_rows) * ((width + 23) // 24)}))
+    ctx.close()
+    sys.exit(0)
+ctx = p3r.Context(field=field)
 if len(sys.argv) > 2 and sys.argv[2] == "bench":
     # the three commits of bench.py's 2^20-row layer (main, LogUp aux, quotient chunks; default packing): one job-list
     # launch per commit over every height class, as in a proof

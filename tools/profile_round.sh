@@ -9,6 +9,10 @@ for F in koala-bear baby-bear; do
     timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/final/hashrows_${F}_$C -- python3 tools/pmc_hash_rows.py $F bench > gpurun_out/final/hashrows_${F}_$C.log 2>&1
   done
 done
+# the same for the arity-4 leaf kernel over the width-32 permutation, both instances (round-4 review item 5)
+for W in builtin general; do
+  timeout 300 rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/final/hashrows_w32_$W -- python3 tools/pmc_hash_rows.py koala-bear w32 $W > gpurun_out/final/hashrows_w32_$W.log 2>&1
+done
 # the bench line reads the instruction count just measured (profiles/<round>/pmc_hash_rows.json)
 python3 tools/collect_profiles.py ${1:-r05} --hash-rows-only
 timeout 1200 python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench_err.log
