@@ -50,27 +50,30 @@ __device__ __forceinline__ void p2wf_external_linear(double* s) {
   for (int i = 0; i < P2W_WIDTH; ++i) s[i] += sum[i & 3];
 }
 
-// a * b + add mod P given c = b / P, in FIVE instructions including the addition (p2f_mulmod_c + one add is six): the
-// rounding constant stays inside the quotient.
-//   qm = fma(a, c, MAGIC)              = MAGIC + q exactly, q = rint(a c)           (|q| < 2^46)
+// Exact product a * d + add mod P with a quotient kept together with its rounding constant (qm = MAGIC + q):
+//   qm = fma(a / P, d, MAGIC)          = MAGIC + q exactly, q = rint(a d / P)       (|q| < 2^46)
 //   t  = fma(qm, P_HI, -MAGIC * P_HI)  = q * P_HI exactly: one rounding of a value that is representable (46 + 7 bits);
 //                                        MAGIC * P_HI is itself a 9-bit constant
-//   e  = fma(a, b, -t)                 = (a b - q P) + q exactly
-//   (e + addM) - qm                    = a b - q P + add, addM = add + MAGIC: both steps are integer sums below 2^53
-// `neg_c` = -MAGIC * P_HI, handed in as a live register value: as a literal the compiler re-materialises it in front of
-// every use (two v_mov_b32 feeding a v_fmac_f64), which costs more than the instruction the form saves; `p_hi` = P_HI in
-// a scalar register pair for the same reason (as a literal it is only encodable in the two-address v_fmac form).
+//   e  = fma(a, d, -t)                 = (a d - q P) + q exactly
+//   (e + addM) - qm                    = a d - q P + add, addM = add + MAGIC: both steps are integer sums below 2^53
+// `neg_c` = -MAGIC * P_HI and `magic` are handed in as live vector registers (as literals the compiler re-materialises
+// them in front of every use), `p_hi` = P_HI and the diagonal entry in scalar register pairs (one scalar operand per
+// instruction on gfx9).
+// No per-entry d / P: the quotient comes from (a / P) * d - one more multiplication (six instructions) and 64 fewer
+// vector registers than round 4's five-instruction form with c = d / P per entry.  (a * INVP) * d carries two roundings instead of one: an error
+// below 2^-20 on a quotient below 2^32, so q is still within one of the exact quotient's rounding and |result| < 0.7 P.
 template <class PP>
-__device__ __forceinline__ double p2f_mulmod_c_add(double a, double b, double c, double addM, double neg_c, double p_hi) {
-  const double qm = __builtin_fma(a, c, P2F64<PP>::MAGIC);
+__device__ __forceinline__ double p2f_mulmod_s_add(double a, double d, double addM, double magic, double neg_c, double p_hi) {
+  const double ai = a * P2F64<PP>::INVP;
+  const double qm = __builtin_fma(ai, d, magic);
   const double t = __builtin_fma(qm, p_hi, neg_c);
-  const double e = __builtin_fma(a, b, -t);
+  const double e = __builtin_fma(a, d, -t);
   return (e + addM) - qm;
 }
 
 // s_i <- d_i s_i + sum(s)
 template <class PP>
-__device__ __forceinline__ void p2wf_internal_linear(double* s, const double* __restrict__ d, const double* __restrict__ c, double neg_c, double p_hi) {
+__device__ __forceinline__ void p2wf_internal_linear(double* s, const double* d, double magic, double neg_c, double p_hi) {
   double part[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -78,7 +81,7 @@ __device__ __forceinline__ void p2wf_internal_linear(double* s, const double* __
   const double sum = p2f_reduce<PP>((part[0] + part[1]) + (part[2] + part[3]));
   const double sumM = sum + P2F64<PP>::MAGIC;
 #pragma unroll
-  for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_mulmod_c_add<PP>(s[i], d[i], c[i], sumM, neg_c, p_hi);
+  for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_mulmod_s_add<PP>(s[i], d[i], sumM, magic, neg_c, p_hi);
 }
 
 // ---- the built-in diagonal: lane forms as compile-time facts
@@ -195,23 +198,24 @@ __device__ __forceinline__ void p2wf_permute(double* s, const double* __restrict
 #pragma unroll
     for (int i = 1; i < P2W_WIDTH; ++i) s[i] = p2f_reduce<PP>(s[i]);
   } else {
-    // The 64 diagonal constants stay in VECTOR registers through the partial rounds.  As scalars they need 128 SGPRs at
-    // once: hoisted out of the loop they spill into vector lanes (v_readlane per use: +50 % instructions, measured 0.39
-    // ns per permutation), loaded inside the round the waves wait on the scalar cache every round (0.60 ns).  One wave
-    // has 32 independent lanes of work in flight, so the lower occupancy costs nothing.
-    double dv[P2W_WIDTH], cv[P2W_WIDTH];
+    // The 32 diagonal entries stay in SCALAR registers through the partial rounds (64 SGPRs) and the vector registers
+    // hold the state and its temporaries only: four waves per SIMD.  (Round 4 kept d AND d / P, 64 constants, in vector
+    // registers - as scalars they would have needed 128 SGPRs - and ran at one wave per SIMD on the argument that a
+    // wave has 32 independent lanes in flight; the built-in diagonal's instance showed what that occupancy costs.)
+    double dv[P2W_WIDTH];
 #pragma unroll
     for (int i = 0; i < P2W_WIDTH; ++i) {
       dv[i] = d[i];
-      cv[i] = d[P2W_WIDTH + i];
-      asm volatile("" : "+v"(dv[i]), "+v"(cv[i]));
+      asm volatile("" : "+s"(dv[i]));
     }
     double neg_c = -(P2F64<PP>::MAGIC * P2F64<PP>::P_HI);
+    double magic = P2F64<PP>::MAGIC;
     double p_hi = P2F64<PP>::P_HI;
-    asm volatile("" : "+v"(neg_c), "+s"(p_hi));
+    asm volatile("" : "+v"(neg_c), "+v"(magic), "+s"(p_hi));
+#pragma unroll 1
     for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) {
       s[0] = p2f_sbox<PP>(s[0] + tab[k + r]);
-      p2wf_internal_linear<PP>(s, dv, cv, neg_c, p_hi);
+      p2wf_internal_linear<PP>(s, dv, magic, neg_c, p_hi);
     }
   }
   k += PP::PARTIAL_ROUNDS_W32;
