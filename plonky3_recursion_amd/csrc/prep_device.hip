@@ -7,11 +7,11 @@
 // graph an op can run - is a function of "the first op that touches a witness in a given role".  So the
 // walk becomes: atomicMin of the op index per witness (plus a short fixed-point loop for the two roles that
 // depend on another witness's state), then maps over the ops.  Ranks inside a table, offsets into the
-// packed arrays and the level-sorted order of the schedule are scans and one stable radix sort (hipCUB).
+// packed arrays and the level-sorted order of the schedule are scans and one stable radix sort (device_prims.hip.h).
 #include "prep_device.h"
 #include "profile.h"
 
-#include <hipcub/hipcub.hpp>
+#include "device_prims.hip.h"
 
 #include <algorithm>
 #include <unordered_map>
@@ -149,15 +149,7 @@ struct FlagRecCoeff {  // rows of the `recompose/coeff` kind (aux = 1)
 template <class Fn>
 void scan_pairs(p3r_ctx* ctx, Fn fn, size_t n, DevBuf& out /* n + 1 u64: exclusive sums, total at [n] */) {
   out.alloc(2 * (n + 1));
-  uint64_t* o = reinterpret_cast<uint64_t*>(out.p);
-  hipcub::CountingInputIterator<size_t> idx(0);
-  hipcub::TransformInputIterator<uint64_t, Fn, hipcub::CountingInputIterator<size_t>> in(idx, fn);
-  size_t bytes = 0;
-  // n + 1 items: the value past the end is never consumed by an exclusive sum, but it is read - give it a
-  // harmless index by scanning n items and producing the total with a second, inclusive element
-  P3R_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, o, (int)n, ctx->stream));
-  DevBuf tmp((bytes + 3) / 4 + 1);
-  P3R_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, o, (int)n, ctx->stream));
+  prims::exclusive_sum<uint64_t>(ctx->stream, fn, n, reinterpret_cast<uint64_t*>(out.p));   // the total: k_scan_total
 }
 // total = excl[n-1] + fn(n-1)
 template <class Fn>
@@ -166,10 +158,7 @@ __global__ void k_scan_total(Fn fn, size_t n, uint64_t* __restrict__ excl) {
 }
 
 void scan_u32(p3r_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n) {
-  size_t bytes = 0;
-  P3R_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
-  DevBuf tmp((bytes + 3) / 4 + 1);
-  P3R_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, ctx->stream));
+  prims::exclusive_sum<uint32_t>(ctx->stream, prims::LoadU32{in}, n, out);
 }
 
 // op -> its row in its table; the tables' op lists
@@ -692,12 +681,7 @@ struct FlagReady { const uint32_t* f; __device__ uint32_t operator()(size_t i) c
 struct FlagLight { const uint32_t* f; __device__ uint32_t operator()(size_t i) const { return (f[i] & OF_LIGHT) ? 1u : 0u; } };
 template <class Fn>
 void scan_flags(p3r_ctx* ctx, Fn fn, size_t n, uint32_t* out /* n + 1 */) {
-  hipcub::CountingInputIterator<size_t> idx(0);
-  hipcub::TransformInputIterator<uint32_t, Fn, hipcub::CountingInputIterator<size_t>> in(idx, fn);
-  size_t bytes = 0;
-  P3R_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, ctx->stream));
-  DevBuf tmp((bytes + 3) / 4 + 1);
-  P3R_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, ctx->stream));
+  prims::exclusive_sum<uint32_t>(ctx->stream, fn, n, out);   // the total: k_flags_total
 }
 template <class Fn>
 __global__ void k_flags_total(Fn fn, size_t n, uint32_t* __restrict__ excl) {
@@ -1125,10 +1109,7 @@ __global__ void __launch_bounds__(kB) k_set_zero_at(const uint32_t* __restrict__
 
 void sort_by_key(p3r_ctx* ctx, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n, int bits) {
   if (!n) return;
-  size_t bytes = 0;
-  P3R_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, bits, ctx->stream));
-  DevBuf tmp((bytes + 3) / 4 + 1);
-  P3R_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, bits, ctx->stream));
+  prims::sort_pairs(ctx->stream, keys_in, keys_out, vals_in, vals_out, n, bits);
 }
 inline int bits_for(uint32_t max_value) {
   int b = 1;
@@ -1340,13 +1321,8 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   hipLaunchKernelGGL(k_flags_total<FlagLight>, dim3(1), dim3(64), 0, s, FlagLight{oflags.p}, n_ops, light_rank.p);
   // NonPrimitiveOpId -> row
   {
-    hipcub::CountingInputIterator<size_t> idx(0);
-    hipcub::TransformInputIterator<uint32_t, MaxNpoId, hipcub::CountingInputIterator<size_t>> in(idx, MaxNpoId{ops.p});
     DevBuf mx(1);
-    size_t bytes = 0;
-    P3R_HIP(hipcub::DeviceReduce::Max(nullptr, bytes, in, mx.p, (int)n_ops, s));
-    DevBuf tmp((bytes + 3) / 4 + 1);
-    P3R_HIP(hipcub::DeviceReduce::Max(tmp.p, bytes, in, mx.p, (int)n_ops, s));
+    prims::reduce_max(s, MaxNpoId{ops.p}, n_ops, mx.p);
     uint32_t t3[3];
     P3R_HIP(hipMemcpyAsync(&t3[0], mx.p, 4, hipMemcpyDeviceToHost, s));
     P3R_HIP(hipMemcpyAsync(&t3[1], ready_rank.p + n_ops, 4, hipMemcpyDeviceToHost, s));
