@@ -134,8 +134,8 @@ void reduce_max(hipStream_t s, Fn fn, size_t n, uint32_t* out) {
 }
 
 // counts[digit][block]
-static __global__ void __launch_bounds__(kPB) k_sort_hist(const uint32_t* __restrict__ keys, size_t n, int shift, uint32_t* __restrict__ counts,
-                                                   uint32_t n_blocks) {
+static __global__ void __launch_bounds__(kPB) k_sort_hist(const uint32_t* __restrict__ keys, size_t n, int shift, uint32_t mask,
+                                                          uint32_t* __restrict__ counts, uint32_t n_blocks) {
   __shared__ uint32_t h[kRadix];
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -143,7 +143,7 @@ static __global__ void __launch_bounds__(kPB) k_sort_hist(const uint32_t* __rest
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const size_t i = t0 + (size_t)j * kPB + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (kRadix - 1)], 1u);
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
   }
   __syncthreads();
   counts[(size_t)threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
@@ -151,7 +151,7 @@ static __global__ void __launch_bounds__(kPB) k_sort_hist(const uint32_t* __rest
 // offs: the exclusive sums of counts, i.e. where the first key of (digit, block) goes
 static __global__ void __launch_bounds__(kPB) k_sort_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, size_t n, int shift,
-                                                      const uint32_t* __restrict__ offs, uint32_t n_blocks) {
+                                                             uint32_t mask, const uint32_t* __restrict__ offs, uint32_t n_blocks) {
   __shared__ uint32_t wh[kWaves][kRadix];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -161,7 +161,7 @@ static __global__ void __launch_bounds__(kPB) k_sort_scatter(const uint32_t* __r
 #pragma unroll
   for (int j = 0; j < kSortItems; ++j) {
     const size_t i = w0 + (size_t)j * 64 + lane;
-    if (i < n) atomicAdd(&wh[w][(keys_in[i] >> shift) & (kRadix - 1)], 1u);
+    if (i < n) atomicAdd(&wh[w][(keys_in[i] >> shift) & mask], 1u);
   }
   __syncthreads();
   {  // counts -> where each wave's first key of digit `threadIdx.x` goes
@@ -179,7 +179,7 @@ static __global__ void __launch_bounds__(kPB) k_sort_scatter(const uint32_t* __r
     const size_t i = w0 + (size_t)j * 64 + lane;
     const bool act = i < n;
     const uint32_t key = act ? keys_in[i] : 0u, val = act ? vals_in[i] : 0u;
-    const uint32_t d = (key >> shift) & (kRadix - 1);
+    const uint32_t d = (key >> shift) & mask;
     uint64_t peers = __ballot(act);   // the active lanes of this step whose digit is d
 #pragma unroll
     for (int b = 0; b < kRadixBits; ++b) {
@@ -203,7 +203,8 @@ static __global__ void __launch_bounds__(kPB) k_sort_scatter(const uint32_t* __r
 inline void sort_pairs(hipStream_t s, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
                        int bits) {
   if (!n) return;
-  const int passes = std::max(1, (bits + kRadixBits - 1) / kRadixBits);
+  if (bits < 1 || bits > 32) fail(P3R_EINVAL, "sort_pairs: 1 <= bits <= 32");
+  const int passes = (bits + kRadixBits - 1) / kRadixBits;
   const uint32_t n_blocks = (uint32_t)((n + kSortTile - 1) / kSortTile);
   DevBuf counts((size_t)kRadix * n_blocks), tk, tv;
   if (passes > 1) {
@@ -215,9 +216,10 @@ inline void sort_pairs(hipStream_t s, const uint32_t* keys_in, uint32_t* keys_ou
     const bool to_out = ((passes - 1 - p) & 1) == 0;   // the last pass lands in the caller's arrays
     uint32_t *dst_k = to_out ? keys_out : tk.p, *dst_v = to_out ? vals_out : tv.p;
     const int shift = p * kRadixBits;
-    hipLaunchKernelGGL(k_sort_hist, dim3(n_blocks), dim3(kPB), 0, s, src_k, n, shift, counts.p, n_blocks);
+    const uint32_t mask = (1u << std::min(kRadixBits, bits - shift)) - 1u;   // key bits at and above `bits` are not part of the order
+    hipLaunchKernelGGL(k_sort_hist, dim3(n_blocks), dim3(kPB), 0, s, src_k, n, shift, mask, counts.p, n_blocks);
     exclusive_sum<uint32_t>(s, LoadU32{counts.p}, (size_t)kRadix * n_blocks, counts.p);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(n_blocks), dim3(kPB), 0, s, src_k, src_v, dst_k, dst_v, n, shift, counts.p, n_blocks);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(n_blocks), dim3(kPB), 0, s, src_k, src_v, dst_k, dst_v, n, shift, mask, counts.p, n_blocks);
     src_k = dst_k;
     src_v = dst_v;
   }
