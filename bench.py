@@ -155,6 +155,47 @@ def kernel_source_digest(names=HASH_KERNEL_SOURCES):
     return h.hexdigest()
 
 
+W32_KERNEL_SOURCES = ("poseidon2_f64.hip.h", "poseidon2_w32_f64.hip.h", "kernels_mmcs4.hip.h")   # k_mmcs4_hash_rows
+
+
+def w32_leaf_roofline(field, heights, widths, packing, hash_rows_ms):
+    """The arity-4 MMCS's leaf kernel against the FP64 issue peak: width-32 permutations per proof (rate-24 sponge over
+    the concatenated row of every height class of the three commits) x instructions per permutation of the built-in
+    diagonal's kernel instance (profiles/<round>/pmc_hash_rows.json::width32, measured on KoalaBear; refused when the
+    kernel's sources are not the ones it was measured on) / the measured time of mmcs_hash_rows."""
+    names = ["const", "public", "alu", "poseidon2", "recompose"]
+    aux = lookup_aux_widths(packing.alu_lanes, packing.horner_packed_steps)
+    B = 1 << FRI["log_blowup"]
+    perms = 0
+    for mats in ([(heights[i] * B, widths[i]) for i in range(5)], [(heights[i] * B, aux[n][0] * 4) for i, n in enumerate(names)],
+                 [(heights[i] * B, 4) for i, n in enumerate(names) for _ in range(aux[n][1])]):
+        by_h = {}
+        for h, w in mats:
+            by_h[h] = by_h.get(h, 0) + w
+        perms += sum(h * ((w + 23) // 24) for h, w in by_h.items())
+    out = {"kernel": "k_mmcs4_hash_rows<PP, BUILTIN = true>", "bound": "valu-issue", "width32_perms_per_step_in_kernel": perms,
+           "peak": VALU_ISSUE_SPEC / 1e12, "unit": "T FP64 lane-ops/s", "valu_insts_per_perm": None, "achieved": None, "frac": None}
+    try:
+        path, src = profile_file("pmc_hash_rows.json")
+        with open(path) as fh:
+            rec = json.load(fh)
+        have = kernel_source_digest(W32_KERNEL_SOURCES)
+        if rec.get("width32_sources_sha256") != have:
+            out["frac_null_reason"] = f"{src}::width32 was measured on other kernel sources: re-run tools/profile_round.sh"
+        elif field != "koala-bear":
+            out["frac_null_reason"] = "the width-32 instruction count is measured on KoalaBear only"
+        else:
+            insts = float(rec["width32"]["builtin"]["valu_insts_per_perm"])
+            out["valu_insts_per_perm"] = insts
+            out["source"] = f"{src}::width32.builtin (general instance: {rec['width32']['general']['valu_insts_per_perm']:.0f})"
+            if hash_rows_ms:
+                out["achieved"] = perms * insts / (hash_rows_ms * 1e-3) / 1e12
+                out["frac"] = out["achieved"] / out["peak"]
+    except Exception as e:
+        out["frac_null_reason"] = f"no committed width-32 instruction count ({e!r})"
+    return out
+
+
 def committed_valu_model(field):
     """FP64 instructions per Poseidon2 permutation of k_mmcs_hash_rows and the measured v_fma_f64 rate, both read
     from files under profiles/<round>/ so that every number of `valu_roofline` can be recomputed:
@@ -1407,6 +1448,7 @@ def main():
                 "ms_per_step": ms4, "steps": 5, "proof_verified": ok4, "proof_bytes": len(raw4),
                 "kernel_ms": {k: v[0] for k, v in prof4.items() if not k.startswith("stage:")},
                 "constants": "self-generated defaults (p3r_config.poseidon2_w32_rc / _diag = NULL): unpinned",
+                "leaf_roofline": w32_leaf_roofline(field, cpd.table_heights, widths, packing, prof4.get("mmcs_hash_rows", (0.0,))[0]),
                 "workload": f"the headline prove_next_layer (same circuit, inputs, tables and FRI parameters) with every commitment - "
                             f"traces, LogUp columns, quotient chunks, FRI commit phases - under the arity-4 MMCS over the width-32 "
                             f"permutation; challenger on the width-16 permutation.  NOT a layer of `recursive_aggregation "

@@ -65,7 +65,11 @@ def hash_rows_summary():
         except Exception as e:
             print("pmc_hash_rows w32: %s: %r" % (which, e))
     if w32:
+        sys.path.insert(0, ROOT)
+        import bench
         hr["width32"] = w32
+        hr["width32_sources"] = list(bench.W32_KERNEL_SOURCES)
+        hr["width32_sources_sha256"] = bench.kernel_source_digest(bench.W32_KERNEL_SOURCES)
     if hr["fields"]:
         # bench.py::committed_valu_model refuses the count when the kernel's sources are not the ones it was measured on
         sys.path.insert(0, ROOT)
