@@ -40,7 +40,7 @@ std::vector<uint32_t> arr(const Synth& s, void* h, const char* name) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: %s <field> <log_height> <proof_out> [layers] [--quintic | --arity4]\n", argv[0]); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: %s <field> <log_height> <proof_out> [layers] [--quintic | --arity4 | --zk]\n", argv[0]); return 2; }
   try {
     const p3r::Field field = std::string(argv[1]) == "baby-bear" ? p3r::Field::BabyBear : p3r::Field::KoalaBear;
     const int log_h = std::atoi(argv[2]);
@@ -51,12 +51,17 @@ int main(int argc, char** argv) {
     // --arity4 (recursive_aggregation.rs:902-1046 `--arity4`): the PCS commits with MyMmcsArity4 - 4-to-1 trees over the
     // width-32 permutation, the challenger stays on width 16
     const bool arity4 = argc > 5 && std::string(argv[5]) == "--arity4";
+    // --zk (create_config_zk, recursion/examples/common/mod.rs:511-553): the PCS is HidingFriPcs with two random codewords.
+    // Every proof draws fresh randomness (the context counts its proofs); p3r_zk_set_nonce replays one.
+    const bool zk = argc > 5 && std::string(argv[5]) == "--zk";
+    constexpr uint64_t kReplayNonce = 7;
     const uint32_t D = quintic ? 5 : 4;
     std::string self = argv[0];
     const std::string root = self.substr(0, self.rfind('/')) + "/..";
 
     p3r::FriParams fri;  // the examples' defaults: blow-up 4, 54 queries, 15 bits of query PoW
     if (arity4) { fri.mmcs_arity = 4; fri.allow_unpinned_w32_defaults = true; }   // this example has no upstream statics to pass: the built-in width-32 constants, acknowledged as unpinned
+    if (zk) { fri.zk = true; fri.num_random_codewords = 2; fri.zk_seed = 3; }
     p3r::Context ctx(field, fri, 0, {}, D, 0, quintic ? 5 : 4);
     std::vector<uint32_t> rc(p3r_poseidon2_num_constants(ctx.raw()));
     ctx.check(p3r_poseidon2_round_constants(ctx.raw(), rc.data()));
@@ -93,6 +98,7 @@ int main(int argc, char** argv) {
     input.circuit_inputs = &inputs;
     p3r::RecursionOutput out;
     for (int l = 0; l < layers; ++l) {
+      if (zk && l == layers - 1) ctx.check(p3r_zk_set_nonce(ctx.raw(), kReplayNonce));   // the written proof is proof number 7
       t0 = std::chrono::steady_clock::now();
       out = p3r::prove_next_layer(input, ctx, backend, params, prep);
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -104,7 +110,7 @@ int main(int argc, char** argv) {
       // the wire form and back (what moves between the processes of an aggregation tree): native parser, same bytes again,
       // and the parsed proof verifies from its own metadata
       const std::vector<uint8_t> wire = out.proof.to_postcard();
-      const p3r::BatchStarkProof back = p3r::BatchStarkProof::from_postcard(wire, field, true, quintic ? 5 : 4);
+      const p3r::BatchStarkProof back = p3r::BatchStarkProof::from_postcard(wire, field, true, quintic ? 5 : 4, zk);
       if (back.proof != out.proof.proof || back.to_postcard() != wire) throw p3r::Error(P3R_EINVAL, "postcard round trip differs");
       p3r::verify_all_tables(ctx.config(), back);
       std::printf("BatchStarkProof postcard round trip ok (%zu bytes)\n", wire.size());
@@ -130,8 +136,15 @@ int main(int argc, char** argv) {
       li.circuit_inputs = &l;
       ri.circuit_inputs = &r;
       std::unique_ptr<p3r::AggregationPrepCache> slot;
+      if (zk) {   // two proofs of one input differ under ZK ...
+        p3r::RecursionOutput fresh = p3r::prove_next_layer(input, ctx, backend, params, prep);
+        if (fresh.proof.proof == out.proof.proof) throw std::runtime_error("two ZK proofs of one input are identical");
+        prep.prover->verify_all_tables(fresh.proof);
+        ctx.check(p3r_zk_set_nonce(ctx.raw(), kReplayNonce));   // ... and a replayed proof number gives the same bytes
+      }
       p3r::RecursionOutput a1 = p3r::prove_aggregation_layer(li, ri, node_circuit, ctx, backend, params, &slot, n_left);
       const p3r::AggregationPrepCache* filled = slot.get();
+      if (zk) ctx.check(p3r_zk_set_nonce(ctx.raw(), kReplayNonce));
       t0 = std::chrono::steady_clock::now();
       p3r::RecursionOutput a2 = p3r::prove_aggregation_layer(li, ri, node_circuit, ctx, backend, params, &slot, n_left);
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -97,6 +97,34 @@ def test_cpp_host_arity4_layer(oracle, tmp_path):
     ctx.close()
 
 
+def test_cpp_host_zk_layer(oracle, tmp_path):
+    """`prove_next_layer <field> <log_h> <out> <layers> --zk`: the compiled caller with `FriParams::zk` (HidingFriPcs, two
+    random codewords, seed 3).  The example checks that two proofs of one input differ and that `p3r_zk_set_nonce` replays
+    one; the proof it writes is proof number 7, which the Python binding and the oracle reproduce byte for byte."""
+    import plonky3_recursion_amd as p3r
+    import harness_adapters as wl
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    out_file = str(tmp_path / "proofz.bin")
+    r = subprocess.run([EXE, "koala-bear", "10", out_file, "2", "--zk"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "verify_all_tables ok" in r.stdout and "postcard round trip ok" in r.stdout and r.stdout.strip().endswith("ok")
+    got = open(out_file, "rb").read()
+    a = harness_lib.generate("koala-bear", 10, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
+    fri = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15,
+               num_queries=54)
+    ctx = p3r.Context(field="koala-bear", zk=1, num_random_codewords=2, zk_seed=3, **fri)
+    tp = p3r.TablePacking().with_fri_params(5, 2)
+    pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
+    ctx.zk_nonce = 7
+    assert pc.prove(wl.circuit_inputs_from_arrays(a)) == got
+    L = layer_lib.OracleLayer(oracle, "koala-bear", a, layer_lib.params(zk=1, num_random_codewords=2, zk_seed=3, zk_nonce=7, **fri))
+    assert np.array_equal(pc.circuit_prover_data.preprocessed_commitment, L.prep_commit())
+    L.verify(got)
+    assert L.prove() == got
+    pc.free()
+    ctx.close()
+
+
 def test_fallback_paths_give_the_same_proof(tmp_path):
     """The tuning knobs exist in the `knobs` build of the library only (plonky3_recursion_amd/knobs/libp3r_hip.so,
     -DP3R_TUNING_KNOBS; the product build compiles them out).  The paths they select (copy-engine fetches instead
