@@ -88,7 +88,7 @@ k_p2_permute_batch(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, 
   double s[P2_WIDTH];
 #pragma unroll
   for (int k = 0; k < P2_WIDTH; ++k) s[k] = p2f_load<PP>(in[(size_t)k * n + i]);
-  p2f_permute<PP>(s, rcd);
+  p2f_permute<PP, 0u>(s, rcd);
 #pragma unroll
   for (int k = 0; k < P2_WIDTH; ++k) out[(size_t)k * n + i] = p2f_store<PP>(s[k]);
 }
@@ -330,14 +330,14 @@ k_mmcs_hash_rows(const HashRowsJob* __restrict__ jobs, int n_jobs, const double*
   for (; g + P2_RATE <= wtot; g += P2_RATE) {
 #pragma unroll
     for (int j = 0; j < P2_RATE; ++j) s[j] = p2f_load<PP>(as_global(cols[g + j])[i]);
-    p2f_permute<PP>(s, rcd);
+    p2f_permute<PP, 0xFF00u>(s, rcd);   // the capacity half is carried
   }
   int rem = wtot - g;
   if (rem > 0) {
 #pragma unroll
     for (int j = 0; j < P2_RATE; ++j)
       if (j < rem) s[j] = p2f_load<PP>(as_global(cols[g + j])[i]);
-    p2f_permute<PP>(s, rcd);
+    p2f_permute<PP, 0xFFFFu>(s, rcd);   // and the rate lanes past `rem` (reducing a fresh cell is harmless)
   }
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * h + i] = p2f_store<PP>(s[k]);
@@ -361,11 +361,11 @@ k_mmcs_compress(const uint32_t* __restrict__ prev, const uint32_t* __restrict__ 
     s[k] = p2f_load<PP>(lr.x);
     s[P2_DIGEST + k] = p2f_load<PP>(lr.y);
   }
-  p2f_permute<PP>(s, rcd);
+  p2f_permute<PP, 0u>(s, rcd);
   if (inj) {
 #pragma unroll
     for (int k = 0; k < P2_DIGEST; ++k) s[P2_DIGEST + k] = p2f_load<PP>(inj[(size_t)k * n + i]);
-    p2f_permute<PP>(s, rcd);
+    p2f_permute<PP, 0x00FFu>(s, rcd);   // the node's own digest is carried
   }
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) out[(size_t)k * n + i] = p2f_store<PP>(s[k]);

@@ -17,14 +17,14 @@ __device__ __forceinline__ void p2wf_sponge(double* s, int wtot, const double* _
   for (; g + P2W_RATE <= wtot; g += P2W_RATE) {
 #pragma unroll
     for (int j = 0; j < P2W_RATE; ++j) s[j] = load(g + j);
-    p2wf_permute<PP, BUILTIN>(s, tab);
+    p2wf_permute<PP, BUILTIN, 0xFF000000u>(s, tab);   // the capacity lanes are carried
   }
   const int rem = wtot - g;
   if (rem > 0) {
 #pragma unroll
     for (int j = 0; j < P2W_RATE; ++j)
       if (j < rem) s[j] = load(g + j);
-    p2wf_permute<PP, BUILTIN>(s, tab);
+    p2wf_permute<PP, BUILTIN, 0xFFFFFFFFu>(s, tab);   // and the rate lanes past `rem`
   }
 }
 
@@ -104,7 +104,7 @@ k_mmcs4_compress(const uint32_t* __restrict__ prev, size_t n_prev, int step, con
       s[3 * P2_DIGEST + k] = 0.0;
     }
   }
-  p2wf_permute<PP, BUILTIN>(s, tab);
+  p2wf_permute<PP, BUILTIN, 0u>(s, tab);
   if (inj) {
 #pragma unroll
     for (int k = 0; k < P2_DIGEST; ++k) {
@@ -112,7 +112,7 @@ k_mmcs4_compress(const uint32_t* __restrict__ prev, size_t n_prev, int step, con
       s[2 * P2_DIGEST + k] = 0.0;
       s[3 * P2_DIGEST + k] = 0.0;
     }
-    p2wf_permute<PP, BUILTIN>(s, tab);
+    p2wf_permute<PP, BUILTIN, 0x000000FFu>(s, tab);   // the node's own digest is carried
   }
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) out[(size_t)k * n_out + i] = p2f_store<PP>(s[k]);

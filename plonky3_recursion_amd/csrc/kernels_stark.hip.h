@@ -644,14 +644,14 @@ k_mmcs_hash_rows_strided(const uint32_t* const* __restrict__ cols, int wtot, siz
   for (; g + P2_RATE <= wtot; g += P2_RATE) {
 #pragma unroll
     for (int j = 0; j < P2_RATE; ++j) s[j] = p2f_load<PP>(cols[g + j][i * stride]);
-    p2f_permute<PP>(s, rcd);
+    p2f_permute<PP, 0xFF00u>(s, rcd);
   }
   int rem = wtot - g;
   if (rem > 0) {
 #pragma unroll
     for (int j = 0; j < P2_RATE; ++j)
       if (j < rem) s[j] = p2f_load<PP>(cols[g + j][i * stride]);
-    p2f_permute<PP>(s, rcd);
+    p2f_permute<PP, 0xFFFFu>(s, rcd);
   }
 #pragma unroll
   for (int k = 0; k < P2_DIGEST; ++k) dig[(size_t)k * h + i] = p2f_store<PP>(s[k]);

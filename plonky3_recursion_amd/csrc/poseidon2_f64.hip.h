@@ -38,8 +38,9 @@ template <class PP>
 struct P2F64 {
   static constexpr double P = (double)PP::P;
   static constexpr double INVP = 1.0 / (double)PP::P;
-  // x + MAGIC - MAGIC = x rounded to the nearest integer for |x| < 2^51: two full-rate instructions
-  // (the first one fused with the product that forms x); v_rndne_f64 issues at half the DP rate.
+  // x + MAGIC - MAGIC = x rounded to the nearest integer for |x| < 2^51: two instructions, the first one fused with the
+  // product that forms x (v_rndne_f64 is full-rate on gfx950 too - tools/microbench/int_rates - and would be the same
+  // count: v_mul_f64 + v_rndne_f64); p2f_mulmod_k never subtracts it back.
   static constexpr double MAGIC = 0x1.8p52;
   // P = P_HI + 1 with P_HI = c * 2^m (127 * 2^24, 15 * 2^27): q * P_HI is an exact double for q < 2^46
   static constexpr double P_HI = (double)(PP::P - 1);
@@ -94,10 +95,42 @@ __device__ __forceinline__ double p2f_mulmod_c(double a, double b, double c) {
   return e - q;
 }
 
+// The same product in FOUR instructions (round 5): the rounding constant is never subtracted from the quotient, it rides
+// through the chain and cancels in the last step.
+//   qm = fma(a, c, MAGIC)            = MAGIC + q exactly, q = rint(a c)                        (|q| < 2^46)
+//   t  = fma(qm, P_HI, -MAGIC * P)   = q P_HI - MAGIC exactly: qm P_HI = MAGIC P_HI + q P_HI, and MAGIC P = MAGIC P_HI + MAGIC;
+//                                      the result is a multiple of 2^24 below 2^77, 53 significant bits
+//   e  = fma(a, b, -t)               = (a b - q P) + q + MAGIC exactly: an integer below 2^47 on top of MAGIC, inside [2^52, 2^53)
+//   e - qm                           = a b - q P
+// MAGIC P = 3 P 2^51 is a 33-bit constant.  The three constants must sit in registers (one scalar operand per instruction
+// on gfx9, no 64-bit literals in the three-address forms): `k` = -MAGIC P in a vector register pair, P_HI and MAGIC in scalar
+// ones, pinned by p2f_sbox_consts so that the compiler does not fold them back into literals (see P2FDiag below for what
+// that costs).  Two instructions fewer per S-box of degree 3, four per S-box of degree 7.
+template <class PP>
+struct P2FSboxK {
+  double k, p_hi, magic;
+};
+template <class PP>
+__device__ __forceinline__ P2FSboxK<PP> p2f_sbox_consts() {
+  P2FSboxK<PP> K;
+  K.k = -(P2F64<PP>::MAGIC * P2F64<PP>::P);
+  K.p_hi = P2F64<PP>::P_HI;
+  K.magic = P2F64<PP>::MAGIC;
+  asm volatile("" : "+v"(K.k), "+s"(K.p_hi), "+s"(K.magic));
+  return K;
+}
+template <class PP>
+__device__ __forceinline__ double p2f_mulmod_k(double a, double b, double c, const P2FSboxK<PP>& K) {
+  const double qm = __builtin_fma(a, c, K.magic);
+  const double t = __builtin_fma(qm, K.p_hi, K.k);
+  const double e = __builtin_fma(a, b, -t);
+  return e - qm;
+}
+
 // WIDE: |x| may reach 2^41 (first full round of a sponge permutation: unreduced capacity carried
 // through the initial linear layer); otherwise |x| < 2^37.
 template <class PP, bool WIDE = false>
-__device__ __forceinline__ double p2f_sbox(double x) {
+__device__ __forceinline__ double p2f_sbox(double x, const P2FSboxK<PP>& K) {
   if (WIDE) {
     const double x2 = p2f_mulmod<PP>(x, x);
     const double x3 = p2f_mulmod<PP>(x2, x);
@@ -106,11 +139,11 @@ __device__ __forceinline__ double p2f_sbox(double x) {
     return p2f_mulmod<PP>(x6, x);
   }
   const double c = x * P2F64<PP>::INVP;
-  const double x2 = p2f_mulmod_c<PP>(x, x, c);
-  const double x3 = p2f_mulmod_c<PP>(x2, x, c);
+  const double x2 = p2f_mulmod_k<PP>(x, x, c, K);
+  const double x3 = p2f_mulmod_k<PP>(x2, x, c, K);
   if (PP::SBOX_DEGREE == 3) return x3;
-  const double x6 = p2f_mulmod_c<PP>(x3, x3, x3 * P2F64<PP>::INVP);
-  return p2f_mulmod_c<PP>(x6, x, c);
+  const double x6 = p2f_mulmod_k<PP>(x3, x3, x3 * P2F64<PP>::INVP, K);
+  return p2f_mulmod_k<PP>(x6, x, c, K);
 }
 
 __device__ __forceinline__ void p2f_mat4(double& x0, double& x1, double& x2, double& x3) {
@@ -197,25 +230,28 @@ __device__ __forceinline__ void p2f_internal_linear(double* s, bool reduce_wide,
 }
 
 // `rc`: the flat constant table of poseidon2.h as CANONICAL doubles.
-// In: integers of magnitude < 2^36.  Out: integers of magnitude < 2^36 (35 * 0.7 P), not reduced.
-template <class PP>
+// In: integers in [0, P] (p2f_load: a lazy REDC of one word), except the lanes of CARRIED (bit i = lane i), which may hold the unreduced outputs of
+// a previous permutation (< 2^36) and are reduced first: three instructions per carried lane, after which EVERY S-box of
+// the first full round is the narrow one (four instructions fewer per lane than the wide form that an unreduced lane,
+// spread over the state by the first linear layer, used to force on all sixteen).
+// Out: integers of magnitude < 2^36 (35 * 0.7 P), not reduced.
+template <class PP, unsigned CARRIED = 0xFFFFu>
 __device__ __forceinline__ void p2f_permute(double* s, const double* __restrict__ rc) {
-  p2f_external_linear(s);
+  const P2FSboxK<PP> SK = p2f_sbox_consts<PP>();
+#pragma unroll
+  for (int i = 0; i < P2_WIDTH; ++i)
+    if (CARRIED >> i & 1u) s[i] = p2f_reduce<PP>(s[i]);
+  p2f_external_linear(s);   // |.| <= 35 P: inside the narrow S-box's 2^38 with the round constant added
   int k = 0;
-  // the first full round sees the widest inputs (see p2f_sbox)
+  for (int r = 0; r < P2_HALF_FULL; ++r) {
 #pragma unroll
-  for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP, true>(s[i] + rc[k + i]);
-  k += P2_WIDTH;
-  p2f_external_linear(s);
-  for (int r = 1; r < P2_HALF_FULL; ++r) {
-#pragma unroll
-    for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i]);
+    for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i], SK);
     k += P2_WIDTH;
     p2f_external_linear(s);
   }
   const P2FDiag<PP> K = p2f_diag_consts<PP>();
   for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
-    s[0] = p2f_sbox<PP>(s[0] + rc[k + r]);
+    s[0] = p2f_sbox<PP>(s[0] + rc[k + r], SK);
     p2f_internal_linear<PP>(s, r % 5 == 0, K);
   }
   k += PP::PARTIAL_ROUNDS;
@@ -223,13 +259,13 @@ __device__ __forceinline__ void p2f_permute(double* s, const double* __restrict_
 #pragma unroll
   for (int i = 0; i < P2_WIDTH; ++i) {
     const bool wide = i == 2 || i == 4 || i == 5 || i == 7 || i == 8;
-    s[i] = wide ? p2f_sbox<PP, true>(s[i] + rc[k + i]) : p2f_sbox<PP>(s[i] + rc[k + i]);
+    s[i] = wide ? p2f_sbox<PP, true>(s[i] + rc[k + i], SK) : p2f_sbox<PP>(s[i] + rc[k + i], SK);
   }
   k += P2_WIDTH;
   p2f_external_linear(s);
   for (int r = 1; r < P2_HALF_FULL; ++r) {
 #pragma unroll
-    for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i]);
+    for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i], SK);
     k += P2_WIDTH;
     p2f_external_linear(s);
   }

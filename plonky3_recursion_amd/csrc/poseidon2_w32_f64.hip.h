@@ -25,7 +25,7 @@
 // form becomes its own basic block, so the scheduler can no longer interleave the 32 independent dependency chains of a
 // round and every chain runs at FP64 latency.  profiles/r05/w32_diag_ab.txt.)
 //
-// Magnitudes: inputs |x| <= 0.5 P + slack (p2wf_permute reduces its outputs).  External layer: rows of
+// Magnitudes: inputs |x| <= P (fresh cells, or carried lanes that p2wf_permute reduces on the way in).  External layer: rows of
 // circ(2 M4, M4, ..) sum to 7 * 9 = 63, so a full round's S-box sees |x| < 63 * 1.3 P + P < 2^38 - inside the domain
 // of the narrow S-box (p2f_mulmod_c needs |a b| < 2^76).  Partial rounds: d_i * s_i reduced to < 0.7 P, the lane sum
 // reduced to <= 0.5 P: no growth.
@@ -172,17 +172,24 @@ __device__ __forceinline__ void p2wf_internal_linear_default(double* s, const do
   (p2wf_lane_default<PP, I>(s, mk, sum), ...);
 }
 
-// In: integers |x| <= 0.5 P + slack.  Out: the same (reduced, not canonical: either sign).
 // BUILTIN: the configured diagonal is the built-in one (its own kernel instance: the general path keeps 64 constants in
 // vector registers and runs at one wave per SIMD; this one needs none)
-template <class PP, bool BUILTIN>
+// In: integers in [0, P] (p2f_load), except the lanes of CARRIED (bit i = lane i): unreduced outputs of a previous
+// permutation, reduced here (poseidon2_f64.hip.h: p2f_permute).  Out: |.| < 63 * 1.3 P, NOT reduced: a digest goes through
+// p2f_store, which reduces; a carried lane is reduced by the next permutation.  (Until round 5 all 32 outputs were reduced
+// on the way out: 96 instructions, 72 of them on lanes that were overwritten or dropped.)
+template <class PP, bool BUILTIN, unsigned CARRIED = 0xFFFFFFFFu>
 __device__ __forceinline__ void p2wf_permute(double* s, const double* __restrict__ tab) {
+#pragma unroll
+  for (int i = 0; i < P2W_WIDTH; ++i)
+    if (CARRIED >> i & 1u) s[i] = p2f_reduce<PP>(s[i]);
   const double* d = tab + p2w_num_rc<PP>();
+  const P2FSboxK<PP> SK = p2f_sbox_consts<PP>();
   p2wf_external_linear(s);
   int k = 0;
   for (int r = 0; r < P2_HALF_FULL; ++r) {
 #pragma unroll
-    for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + tab[k + i]);
+    for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + tab[k + i], SK);
     k += P2W_WIDTH;
     p2wf_external_linear(s);
   }
@@ -191,7 +198,7 @@ __device__ __forceinline__ void p2wf_permute(double* s, const double* __restrict
     p2wf_pin_defaults<PP>(mk, std::make_integer_sequence<int, P2W_WIDTH>{});
 #pragma unroll 1
     for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) {
-      s[0] = p2f_sbox<PP>(s[0] + tab[k + r]);
+      s[0] = p2f_sbox<PP>(s[0] + tab[k + r], SK);
       p2wf_internal_linear_default<PP>(s, mk, r, std::make_integer_sequence<int, P2W_WIDTH>{});
     }
     // whatever the small-integer lanes accumulated since their last reduction: back inside the full rounds' domain
@@ -214,19 +221,17 @@ __device__ __forceinline__ void p2wf_permute(double* s, const double* __restrict
     asm volatile("" : "+v"(neg_c), "+v"(magic), "+s"(p_hi));
 #pragma unroll 1
     for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) {
-      s[0] = p2f_sbox<PP>(s[0] + tab[k + r]);
+      s[0] = p2f_sbox<PP>(s[0] + tab[k + r], SK);
       p2wf_internal_linear<PP>(s, dv, magic, neg_c, p_hi);
     }
   }
   k += PP::PARTIAL_ROUNDS_W32;
   for (int r = 0; r < P2_HALF_FULL; ++r) {
 #pragma unroll
-    for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + tab[k + i]);
+    for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + tab[k + i], SK);
     k += P2W_WIDTH;
     p2wf_external_linear(s);
   }
-#pragma unroll
-  for (int i = 0; i < P2W_WIDTH; ++i) s[i] = p2f_reduce<PP>(s[i]);
 }
 
 #pragma clang fp contract(fast)

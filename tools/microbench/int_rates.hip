@@ -11,6 +11,8 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed) {
   uint32_t a[UNROLL];
   double d[UNROLL];
   uint32_t b = seed | 1u;
+  double kmagic = 0x1.8p52, kphi = 2130706432.0, kk = -(0x1.8p52 * 2130706433.0);
+  asm volatile("" : "+s"(kmagic), "+s"(kphi), "+v"(kk));
   for (int i = 0; i < UNROLL; ++i) { a[i] = threadIdx.x * 2654435761u + i + seed; d[i] = (double)a[i]; }
   for (int it = 0; it < ITER; ++it) {
 #pragma unroll
@@ -27,6 +29,22 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, uint32_t seed) {
         uint32_t q = __umulhi(a[i], 0x9A3C5E71u);
         uint32_t r = a[i] * b - q * 0x7f000001u;
         a[i] = min(r, r - 0x7f000001u) + i;
+      }
+      if (OP == 10) d[i] = d[i] + d[(i + 1) & 15];                                  // v_add_f64
+      if (OP == 11) d[i] = d[i] * 1.0000001;                                        // v_mul_f64
+      if (OP == 12) d[i] = __builtin_amdgcn_fract(d[i]) + 1.5;                      // v_fract_f64 (+ v_add_f64)
+      if (OP == 13) d[i] = __builtin_rint(d[i]) * 1.0000001;                        // v_rndne_f64 (+ v_mul_f64)
+      if (OP == 14) {  // FP64 product mod P, five instructions (poseidon2_f64.hip.h: p2f_mulmod_c), c = x / P given
+        const double x = d[i], c = d[(i + 1) & 15];
+        const double q = __builtin_fma(x, c, 0x1.8p52) - 0x1.8p52;
+        const double t = q * 2130706432.0;
+        d[i] = __builtin_fma(x, x, -t) - q;
+      }
+      if (OP == 15) {  // the same in four (p2f_mulmod_k): the rounding constant rides through the chain
+        const double x = d[i], c = d[(i + 1) & 15];
+        const double qm = __builtin_fma(x, c, kmagic);
+        const double t = __builtin_fma(qm, kphi, kk);
+        d[i] = __builtin_fma(x, x, -t) - qm;
       }
       if (OP == 8) {  // Montgomery product through two 64-bit multiply-adds: x = a*b; y = q*P + x; r = y >> 32
         uint64_t x = (uint64_t)a[i] * b;
@@ -72,5 +90,11 @@ int main() {
   run<7>(out, "Montgomery product", 1);
   run<8>(out, "Montgomery via mad_u64_u32", 1);
   run<9>(out, "Shoup product (+add)", 1);
+  run<10>(out, "v_add_f64", 1);
+  run<11>(out, "v_mul_f64", 1);
+  run<12>(out, "v_fract_f64 + v_add_f64", 2);
+  run<13>(out, "v_rndne_f64 + v_mul_f64", 2);
+  run<14>(out, "FP64 product mod P, 5 instr.", 1);
+  run<15>(out, "FP64 product mod P, 4 instr.", 1);
   return 0;
 }
