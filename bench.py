@@ -600,21 +600,25 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
             solo_node_ms = solo(lambda: prove_parent(0, 1, 0, warm[0], warm[0]))
         if dist is not None:
             dist.barrier()
-    # ... and measure the GPU's capacity TOGETHER: every prover of every rank proves four leaves (then four nodes) at
+    # ... and measure the GPU's capacity TOGETHER: every prover of every rank proves twelve leaves (then twelve nodes) at
     # once; capacity = solo-milliseconds of work done on this rank's GPU per millisecond of wall time.  (Provers of two
     # processes share a GPU less well than provers of one: the measurement has to be made in the run's own form.)
     sharers = max(1, sum(1 for d in local_devices if d == local_devices[rank])) if backend_name != "nccl" else 1
     gpu_capacity = [1.0, 1.0]
     if len(all_workers) * sharers > 1:
         with ThreadPoolExecutor(max_workers=len(all_workers)) as ex:
-            for which, fn, alone in ((0, lambda i: [prove_leaf(0, i) for _ in range(4)], solo_leaf_ms),
-                                     (1, lambda i: [prove_parent(0, 1, 0, warm[0], warm[0]) for _ in range(4)], solo_node_ms)):
-                barrier()
-                t1 = time.perf_counter()
-                list(ex.map(fn, range(len(all_workers))))
-                barrier()
-                gpu_capacity[which] = min(float(len(all_workers) * sharers),
-                                          4 * len(all_workers) * sharers * alone / ((time.perf_counter() - t1) * 1e3))
+            reps = 12   # proofs per prover and sample; the better of two samples (a 30 ms sample of four proofs each
+            #             varied between 1.5 and 2.0 from run to run and took the four-tree prediction with it)
+            for which, fn, alone in ((0, lambda i: [prove_leaf(0, i) for _ in range(reps)], solo_leaf_ms),
+                                     (1, lambda i: [prove_parent(0, 1, 0, warm[0], warm[0]) for _ in range(reps)], solo_node_ms)):
+                best = 0.0
+                for _ in range(2):
+                    barrier()
+                    t1 = time.perf_counter()
+                    list(ex.map(fn, range(len(all_workers))))
+                    barrier()
+                    best = max(best, reps * len(all_workers) * sharers * alone / ((time.perf_counter() - t1) * 1e3))
+                gpu_capacity[which] = min(float(len(all_workers) * sharers), best)
     if dist is not None and world > 1:   # rank 0's measurements are the ones the prediction uses
         t = torch.tensor([solo_leaf_ms, solo_node_ms] + gpu_capacity, dtype=torch.float64, device=coll_device)
         dist.broadcast(t, 0)
