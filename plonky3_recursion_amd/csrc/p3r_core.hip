@@ -518,26 +518,14 @@ void init_ctx(p3r_ctx* ctx) {
     const size_t nrcw = p2w_num_rc<PP>();
     const uint32_t* w = src + nrc;
     rcd.insert(rcd.end(), w, w + nrcw);
-    for (int pass = 0; pass < 2; ++pass)
-      for (int i = 0; i < P2W_WIDTH; ++i) {
-        const uint32_t d = w[nrcw + i];
-        const double centred = d > PP::P / 2 ? (double)d - (double)PP::P : (double)d;
-        rcd.push_back(pass == 0 ? centred : centred / (double)PP::P);
-      }
-    // the structured form of the diagonal (poseidon2_w32_f64.hip.h): factors, then flag | codes | masks as raw words
-    double factor[P2W_WIDTH] = {0};
-    uint64_t codes = 0, red[32] = {0};
-    static_assert(PP::PARTIAL_ROUNDS_W32 <= 32, "reduction masks of the width-32 partial rounds");
-    const bool structured = p2w_classify_diag<PP>(w + nrcw, factor, codes, red, PP::PARTIAL_ROUNDS_W32);
-    // the kernels have the lane forms of the BUILT-IN diagonal compiled in: that path is taken when the configured
-    // diagonal is the built-in one, entry by entry (poseidon2_w32_f64.hip.h)
+    for (int i = 0; i < P2W_WIDTH; ++i) {
+      const uint32_t d = w[nrcw + i];
+      rcd.push_back(d > PP::P / 2 ? (double)d - (double)PP::P : (double)d);
+    }
+    // the kernels have the lane forms of the BUILT-IN diagonal compiled in: those instances are launched when the
+    // configured diagonal is the built-in one, entry by entry (poseidon2_w32_f64.hip.h); any other diagonal is data
     const uint32_t* builtin = PP::FIELD_ID == 0 ? kDefaultDiagW32_koala_bear : kDefaultDiagW32_baby_bear;
-    const bool is_builtin = structured && std::equal(builtin, builtin + P2W_WIDTH, w + nrcw) && !tuning_knob("P3R_W32_GENERAL_DIAG");
-    rcd.insert(rcd.end(), factor, factor + P2W_WIDTH);
-    auto raw = [](uint64_t v) { double d; std::memcpy(&d, &v, 8); return d; };
-    rcd.push_back(raw(is_builtin ? 2 : 0));
-    rcd.push_back(raw(codes));
-    for (int r = 0; r < 32; ++r) rcd.push_back(raw(red[r]));
+    const bool is_builtin = std::equal(builtin, builtin + P2W_WIDTH, w + nrcw) && !tuning_knob("P3R_W32_GENERAL_DIAG");
     ctx->w32_diag_builtin = is_builtin;
   }
   ctx->rc_f64.alloc(2 * rcd.size());

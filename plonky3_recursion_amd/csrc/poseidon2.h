@@ -280,52 +280,6 @@ P3R_HD void p2w_permute_traced(F* s, const uint32_t* __restrict__ rcw, Sink& sin
   for (int r = 0; r < P2_HALF_FULL; ++r) full_round();
 }
 
-// ---- the FP64 table of the width-32 permutation (poseidon2_w32_f64.hip.h describes it): lengths, offsets and the host-side
-// classification of the internal diagonal
-template <class PP>
-constexpr int p2wf_table_len() { return p2w_num_rc<PP>() + 3 * P2W_WIDTH + 2 + 32; }
-// offsets of the structured form inside the table (doubles)
-template <class PP> constexpr int p2wf_off_factor() { return p2w_num_rc<PP>() + 2 * P2W_WIDTH; }
-template <class PP> constexpr int p2wf_off_words() { return p2w_num_rc<PP>() + 3 * P2W_WIDTH; }   // [0] flag, [1] codes, [2 + r] masks
-
-// Host: the structured form of a diagonal (canonical entries).  Returns false if an entry is general.
-// factor[i]: the small integer, or +-2^-k; codes: 2 bits per lane (0 small, 1 = 2^-k with addend form, 2 = 2^-k without);
-// red[r]: lanes to reduce at the start of partial round r.
-template <class PP>
-inline bool p2w_classify_diag(const uint32_t* diag, double* factor, uint64_t& codes, uint64_t* red, int rounds) {
-  codes = 0;
-  int period[P2W_WIDTH];
-  for (int i = 0; i < P2W_WIDTH; ++i) {
-    const uint32_t d = diag[i];
-    const int64_t c = d > PP::P / 2 ? (int64_t)d - (int64_t)PP::P : (int64_t)d;
-    period[i] = 0;
-    if (c != 0 && c >= -16 && c <= 16) {
-      factor[i] = (double)c;
-      const int64_t a = c < 0 ? -c : c;
-      period[i] = a < 2 ? 0 : a <= 4 ? 5 : a <= 7 ? 4 : 3;
-      continue;
-    }
-    int form = -1;
-    for (int k = 1; k <= PP::TWO_ADICITY && form < 0; ++k) {
-      const uint64_t t = ((uint64_t)d << k) % PP::P;
-      if (t == 1 || t == PP::P - 1) {
-        double m = 1.0;
-        for (int j = 0; j < k; ++j) m *= 0.5;
-        factor[i] = t == 1 ? m : -m;
-        form = k <= 12 ? 1 : 2;
-      }
-    }
-    if (form < 0) return false;
-    codes |= (uint64_t)form << (2 * i);
-  }
-  for (int r = 0; r < rounds; ++r) {
-    red[r] = 0;
-    // lane 0 goes through the S-box every round, which reduces it
-    for (int i = 1; i < P2W_WIDTH; ++i)
-      if (period[i] && r > 0 && r % period[i] == 0) red[r] |= uint64_t(1) << i;
-  }
-  return true;
-}
-
-
+// ---- the FP64 table of the width-32 permutation (poseidon2_w32_f64.hip.h): the round constants, then the 32 entries of
+// the internal diagonal, as doubles (centred: entries above P / 2 as negative numbers)
 }  // namespace p3r

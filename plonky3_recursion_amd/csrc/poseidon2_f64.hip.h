@@ -83,20 +83,12 @@ __device__ __forceinline__ double p2f_mul_2exp_neg_add(double x, double m, doubl
   return __builtin_fma(-f, P2F64<PP>::P, t);
 }
 
-// a * b mod P given c = b / P (rounded): five instructions, and c is shared by every product with
-// the same b (the S-box multiplies by x twice or three times).
-//   q = rint(a * c);  e = fma(a, b, -q * P_HI) = (a b - q P) + q exactly (an integer below 2^47, because
-//   q * P_HI is exact);  result = e - q.  Needs |a b| < 2^76 (q < 2^46); |result| < 0.7 P.
-template <class PP>
-__device__ __forceinline__ double p2f_mulmod_c(double a, double b, double c) {
-  const double q = __builtin_fma(a, c, P2F64<PP>::MAGIC) - P2F64<PP>::MAGIC;
-  const double t = q * P2F64<PP>::P_HI;
-  const double e = __builtin_fma(a, b, -t);
-  return e - q;
-}
-
-// The same product in FOUR instructions (round 5): the rounding constant is never subtracted from the quotient, it rides
-// through the chain and cancels in the last step.
+// a * b mod P given c = b / P (rounded; c is shared by every product with the same b: the S-box multiplies by x twice or
+// three times).  Until round 5 in five instructions:
+//   q = fma(a, c, MAGIC) - MAGIC = rint(a c);  t = q * P_HI;  e = fma(a, b, -t) = (a b - q P) + q exactly (an integer below
+//   2^47, because q * P_HI is exact);  result = e - q.  Needs |a b| < 2^76 (q < 2^46); |result| < 0.7 P.
+// Now in FOUR: the rounding constant is never subtracted from the quotient, it rides through the chain and cancels in the
+// last step.
 //   qm = fma(a, c, MAGIC)            = MAGIC + q exactly, q = rint(a c)                        (|q| < 2^46)
 //   t  = fma(qm, P_HI, -MAGIC * P)   = q P_HI - MAGIC exactly: qm P_HI = MAGIC P_HI + q P_HI, and MAGIC P = MAGIC P_HI + MAGIC;
 //                                      the result is a multiple of 2^24 below 2^77, 53 significant bits

@@ -4,16 +4,15 @@
 // double holding an integer congruent to the canonical value, only the S-box reduces in the full rounds).
 //
 // What differs from width 16: the internal diagonal is the caller's DATA (p3r_config.poseidon2_w32_diag), so its
-// entries are general field elements and a partial round multiplies every lane by its entry with the five-instruction
-// product p2f_mulmod_c (the quotient factor d_i / P is part of the constant table), instead of the one-to-three
-// instruction forms the known width-16 diagonal allows.  That makes a permutation ~11.5 k FP64 instructions
-// (width 16: 3.9 k) for three times the rate - the same cost per absorbed cell.
+// entries are general field elements and, in general, a partial round multiplies every lane by its entry with a full
+// modular product (p2f_mulmod_s_add below: six instructions, the entry in a scalar register pair) instead of the
+// one-to-three instruction forms a known diagonal allows: 11.3 k FP64 instructions per permutation (width 16: 3.3 k) for
+// three times the rate.  The library's own diagonal gets those forms (next paragraph): 7.9 k.
 //
 // Constant table `tab` (doubles, p3r_ctx::rcd_w32()): [4][32] | [partial] | [4][32] round constants (canonical),
-// then the diagonal as CENTRED integers (|d| <= P / 2), then d_i / P, then the STRUCTURED form (below): 32 factors,
-// and as raw 64-bit words: a flag, the lanes' form codes (2 bits each), one reduction mask per partial round.
+// then the diagonal as CENTRED integers (|d| <= P / 2).
 //
-// The built-in diagonal (round 5).  The diagonal is data, so in general every lane pays the five-instruction product.  The
+// The built-in diagonal (round 5).  The diagonal is data, so in general every lane pays the full product.  The
 // library's OWN default diagonal, however, is known at compile time (poseidon2_w32_default.inc): small integers and
 // inverse powers of two, like the width-16 one.  When the configured diagonal IS the built-in one (p3r_create compares
 // the 32 entries and launches the BUILTIN kernel instances) the partial rounds run per-lane forms fixed at compile time - one FMA for |d| <= 16, the
@@ -27,7 +26,7 @@
 //
 // Magnitudes: inputs |x| <= P (fresh cells, or carried lanes that p2wf_permute reduces on the way in).  External layer: rows of
 // circ(2 M4, M4, ..) sum to 7 * 9 = 63, so a full round's S-box sees |x| < 63 * 1.3 P + P < 2^38 - inside the domain
-// of the narrow S-box (p2f_mulmod_c needs |a b| < 2^76).  Partial rounds: d_i * s_i reduced to < 0.7 P, the lane sum
+// of the narrow S-box (p2f_mulmod_k needs |a b| < 2^76).  Partial rounds: d_i * s_i reduced to < 0.7 P, the lane sum
 // reduced to <= 0.5 P: no growth.
 #pragma once
 #include <utility>
