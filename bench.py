@@ -783,6 +783,20 @@ def omp_team_size():
         return None
 
 
+def weak_scaling_prediction(solo_ms, sigma=0.015):
+    """The plain multi-GPU entry shards nothing: every rank proves its own layer on its own GPU, inputs resident, and the
+    only collectives are the barrier and the MAX of the timings outside the timed steps.  So the step of N ranks is the
+    slowest rank's solo step: solo x (1 + sigma x E[max of N standard normals]), sigma = the GPU-to-GPU spread seen across
+    the boxes of profiles/r03 - r05 (1.5 %); the aggregate rate is N proofs per that step.  What the run cannot show on
+    one GPU and a shared node may add: host cores (each rank's launch loop and transcript take one core; the workload
+    generator before the timed region takes `omp_team_size` threads per rank, capped by OMP_NUM_THREADS)."""
+    emax = {1: 0.0, 2: 0.5642, 4: 1.0294, 8: 1.4236}
+    return {"model": "independent proofs, one per GPU: step(N) = slowest rank's solo step = solo x (1 + 0.015 x E[max of N normals]); "
+                     "no data-path collective", "solo_ms": solo_ms,
+            "one_gpu_per_rank": {str(n): {"predicted_ms_per_step": solo_ms * (1 + sigma * e), "predicted_proofs_per_s": n / (solo_ms * (1 + sigma * e)) * 1e3}
+                                 for n, e in emax.items()}}
+
+
 def rank_report(torch, dist, world, backend, local_rank, coll_device, rank_ms=None):
     """What the collective layer saw: world size and backend as it reports them, and per rank the device ordinal, its PCI
     address (two ranks on one GPU show the same one) and the rank's own time for the timed region."""
@@ -1076,6 +1090,9 @@ def main():
                 "parallelism": f"{world} independent proofs, one per GPU, no data-path collective",
             },
             "ranks": ranks,
+            # what an N-GPU run of this entry is to be compared with (the tree entry has its own: run_tree)
+            # (ranks that share a GPU - the gloo run on a one-GPU box - split it: solo = step x GPUs / ranks)
+            "scaling_prediction": weak_scaling_prediction(ms_per_step * max(1, ranks.get("distinct_gpus") or world) / world),
             "proof_verified": proof_verified,
             "proof_sha256": proof_sha256,
             "proof_verify_ms": verify_ms,
