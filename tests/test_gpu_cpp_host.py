@@ -156,6 +156,31 @@ def test_fallback_paths_give_the_same_proof(tmp_path):
     assert proof("old_ntt", P3R_NTT_OLD="1") == want
 
 
+def test_both_width32_kernel_instances_give_the_same_proof(tmp_path):
+    """The arity-4 MMCS launches the kernel instances that hold the built-in diagonal's lane forms at compile time when the
+    configured diagonal is the built-in one (csrc/poseidon2_w32_f64.hip.h), the general instances (diagonal in scalar
+    registers, six-instruction product) otherwise; the knobs build can force the general ones for the built-in diagonal
+    (P3R_W32_GENERAL_DIAG): same proof bytes, large enough for the one-permutation-per-lane kernels to run."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    knobs_dir = os.path.join(ROOT, "plonky3_recursion_amd", "knobs")
+    if not os.path.exists(os.path.join(knobs_dir, "libp3r_hip.so")):
+        pytest.skip("knobs build of the library is absent (__graft_entry__.build() makes it)")
+    got = {}
+    for name, env in (("product", {}), ("knobs_builtin", {"LD_LIBRARY_PATH": knobs_dir}),
+                      ("knobs_general", {"LD_LIBRARY_PATH": knobs_dir, "P3R_W32_GENERAL_DIAG": "1"})):
+        out_file = str(tmp_path / (name + ".bin"))
+        e = dict(os.environ)
+        if "LD_LIBRARY_PATH" in env:
+            e["LD_LIBRARY_PATH"] = env["LD_LIBRARY_PATH"] + os.pathsep + e.get("LD_LIBRARY_PATH", "")
+        e.update({k: v for k, v in env.items() if k != "LD_LIBRARY_PATH"})
+        for field, log_h in (("koala-bear", 16), ("baby-bear", 15)):
+            r = subprocess.run([EXE, field, str(log_h), out_file, "1", "--arity4"], capture_output=True, text=True, timeout=300, env=e)
+            assert r.returncode == 0, r.stdout + r.stderr
+            got[(name, field)] = open(out_file, "rb").read()
+    for field in ("koala-bear", "baby-bear"):
+        assert got[("product", field)] == got[("knobs_builtin", field)] == got[("knobs_general", field)], field
+
+
 def test_two_stream_commit_gives_the_same_proof(tmp_path):
     """The knobs build can hash one height class of each commit on a second stream while the main stream extends the next
     (prove_impl.hip.h::lde_and_commit, P3R_COMMIT_OVERLAP; measured, not the product's path: profiles/r05/
