@@ -372,7 +372,7 @@ int run_proofs(const char* path, uint64_t iters, uint64_t seed) {
     if (m == c.outer) continue;
     // exact-size heap copy: ASan then sees any read past the end
     uint8_t* buf = (uint8_t*)malloc(m.size() ? m.size() : 1);
-    memcpy(buf, m.data(), m.size());
+    if (!m.empty()) memcpy(buf, m.data(), m.size());   // (an empty mutant has a null data(): memcpy's arguments must not be - UBSan, at 10 x the default volume)
     size_t plen = 0;
     (void)p3r_batch_proof_len_layout(c.cfg.field, buf, m.size(), c.flags, nullptr, &plen, err, sizeof err);
     const int rc = p3r_batch_stark_proof_parse(c.cfg.field, buf, m.size(), c.flags, nullptr, &meta, err, sizeof err);
@@ -472,7 +472,7 @@ int run_circuit(const char* path, uint64_t iters, uint64_t seed) {
   auto run = [&](const p3r_circuit_desc& d, const std::vector<uint32_t>& o, const std::vector<uint32_t>& e, const std::vector<uint32_t>& pu,
                  const std::vector<uint32_t>& pr, const std::vector<uint32_t>& rw, uint32_t dg) {
     // exact-size heap copies: an over-read is a sanitizer report
-    auto dup = [](const std::vector<uint32_t>& v) { uint32_t* p = (uint32_t*)malloc(v.size() * 4 + (v.empty() ? 4 : 0)); memcpy(p, v.data(), v.size() * 4); return p; };
+    auto dup = [](const std::vector<uint32_t>& v) { uint32_t* p = (uint32_t*)malloc(v.size() * 4 + (v.empty() ? 4 : 0)); if (!v.empty()) memcpy(p, v.data(), v.size() * 4); return p; };
     uint32_t *po = dup(o), *pe = dup(e), *ppu = dup(pu), *ppr = dup(pr), *prw = dup(rw);
     p3r_circuit_desc x = d;
     x.n_ops = o.size() / 8; x.ops = (const p3r_op*)po; x.n_ext = e.size(); x.ext = pe; x.n_public = pu.size(); x.public_rows = ppu;
