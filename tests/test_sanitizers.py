@@ -9,7 +9,7 @@ them are circuit-prover/src/batch_stark_prover.rs:459-488,666-681 and packing.rs
 the driver; an accepted mutant with different proof bytes fails it.
 
 P3R_SAN_ITERS: mutants per proof case under AddressSanitizer (default 25000; four cases per field = 10^5 mutants per
-field); the UBSan build (-O0: twenty times slower per mutant) sees a twenty-fifth of that."""
+field); the UBSan build (-O0: twenty times slower per mutant) sees a tenth of that."""
 import json
 import os
 import struct
@@ -101,7 +101,7 @@ CASES = [
 def test_mutated_proofs_under_sanitizers(drivers, oracle, tmp_path, field, name, kw, packing, flags):
     case = str(tmp_path / f"{name}.case")
     n = write_proof_case(case, oracle, field, layer_lib.params(**kw), packing, flags)
-    for san, iters in (("asan", ITERS), ("ubsan", max(ITERS // 25, 200))):
+    for san, iters in (("asan", ITERS), ("ubsan", max(ITERS // 10, 200))):
         res = run(drivers[san], "proofs", case, iters, seed=sum(map(ord, field + name + san)))
         total = {k: sum(r[k] for r in res) for k in res[0] if k != "mode"}
         print(san, field, name, n, "bytes:", total)
@@ -127,7 +127,7 @@ def test_mutated_circuits_under_sanitizers(drivers, tmp_path, field, ext_degree)
         for key, per in (("ops", 8), ("ext", 1), ("public_rows", 1), ("private_rows", 1), ("rewrite", 2)):
             a = np.ascontiguousarray(arrs[key], dtype=np.uint32).reshape(-1)
             fh.write(struct.pack("<Q", a.size // per) + a.tobytes())
-    for san, iters in (("asan", max(ITERS // 2, 4000)), ("ubsan", max(ITERS // 25, 400))):
+    for san, iters in (("asan", max(ITERS // 2, 4000)), ("ubsan", max(ITERS // 10, 400))):
         res = run(drivers[san], "circuit", case, iters, seed=11)
         total = {k: sum(r[k] for r in res) for k in res[0] if k != "mode"}
         print(san, field, len(ops), "ops:", total)
