@@ -15,16 +15,16 @@
 // magnitude < 2^53.  p2f_load / p2f_store convert from / to the Montgomery u32 of field.h.
 //
 // Exactness (every step below is exact integer arithmetic, |.| < 2^53):
-//   mulmod(a, b):   h = fl(a*b); l = fma(a, b, -h) is the exact residual (an integer);
-//                   q = rint(h / P) (as h/P + 1.5 2^52 - 1.5 2^52); r = fma(-q, P, h) is exact because h - q*P is an integer of
-//                   magnitude < P; r + l is the product reduced to |.| < 0.7 P.  Holds for
-//                   |a*b| < 2^82 (the error of q stays below 1/4).
+//   a * b mod P:    p2f_mulmod_k below: the quotient from a * (b / P), the remainder through P = P_HI + 1 with P_HI a
+//                   7-bit (4-bit) multiple of 2^24 (2^27), so q * P_HI is exact; needs |a b| < 2^76.
+//   x mod P:        q = rint(x / P) (as x / P + 1.5 2^52 - 1.5 2^52); r = fma(-q, P, x) is exact because x - q P is an
+//                   integer of magnitude <= P / 2 + slack.  Holds for |x| < 2^51.
 //   x / 2^k:        for 2^k | P - 1 and ANY integer x:  x / 2^k  =  t - frac(t) * P  with t = x * 2^-k
 //                   (x = 2^k F + low  =>  x / 2^k = F - low (P-1) / 2^k  mod P,  frac(t) = low / 2^k):
 //                   v_mul_f64, v_fract_f64, v_fma_f64.  |result| <= |x| / 2^k + P.
 //   growth:         the sum of a partial round is reduced (3 instructions), so a round adds at most
 //                   0.7 P to a lane after its diagonal factor (|d| <= 4); the lanes with |d| >= 2 are
-//                   reduced every 5 partial rounds (4^5 = 2^10 on top of 2^36).
+//                   reduced twice inside the partial rounds and once after them (p2f_permute).
 #pragma once
 #include "poseidon2.h"
 
@@ -52,15 +52,6 @@ __device__ __forceinline__ double p2f_quot(double x) {
   return __builtin_fma(x, P2F64<PP>::INVP, P2F64<PP>::MAGIC) - P2F64<PP>::MAGIC;
 }
 
-// a * b mod P, |result| < 0.7 P
-template <class PP>
-__device__ __forceinline__ double p2f_mulmod(double a, double b) {
-  const double h = a * b;
-  const double l = __builtin_fma(a, b, -h);
-  const double q = p2f_quot<PP>(h);
-  const double r = __builtin_fma(-q, P2F64<PP>::P, h);
-  return r + l;
-}
 // x mod P, |result| <= 0.5 P (+ rounding slack)
 template <class PP>
 __device__ __forceinline__ double p2f_reduce(double x) {
@@ -119,17 +110,10 @@ __device__ __forceinline__ double p2f_mulmod_k(double a, double b, double c, con
   return e - qm;
 }
 
-// WIDE: |x| may reach 2^41 (first full round of a sponge permutation: unreduced capacity carried
-// through the initial linear layer); otherwise |x| < 2^37.
-template <class PP, bool WIDE = false>
+// |x| < 2^38 (p2f_mulmod_k needs |a b| < 2^76).  (Until round 5 there was a second, "wide" form on the two-product
+// p2f_mulmod for lanes that arrived unreduced; every caller reduces such lanes first now, which is cheaper.)
+template <class PP>
 __device__ __forceinline__ double p2f_sbox(double x, const P2FSboxK<PP>& K) {
-  if (WIDE) {
-    const double x2 = p2f_mulmod<PP>(x, x);
-    const double x3 = p2f_mulmod<PP>(x2, x);
-    if (PP::SBOX_DEGREE == 3) return x3;
-    const double x6 = p2f_mulmod<PP>(x3, x3);
-    return p2f_mulmod<PP>(x6, x);
-  }
   const double c = x * P2F64<PP>::INVP;
   const double x2 = p2f_mulmod_k<PP>(x, x, c, K);
   const double x3 = p2f_mulmod_k<PP>(x2, x, c, K);
@@ -242,20 +226,21 @@ __device__ __forceinline__ void p2f_permute(double* s, const double* __restrict_
     p2f_external_linear(s);
   }
   const P2FDiag<PP> K = p2f_diag_consts<PP>();
+  // The five lanes with |d| >= 2 (2, 3, 4, -3, -4) grow by up to four times a round from < 2^36: reduced at the start of
+  // rounds 6 and 15 (2^36 * 4^6 and 2^30 * 4^9 stay below 2^49, so the lane sum stays below 2^52) and once after the last
+  // round, after which every S-box of the last four full rounds is the narrow one.  (Until round 5: every fifth round
+  // and a wide S-box for the five lanes, 80 instructions where this takes 45.)
   for (int r = 0; r < PP::PARTIAL_ROUNDS; ++r) {
     s[0] = p2f_sbox<PP>(s[0] + rc[k + r], SK);
-    p2f_internal_linear<PP>(s, r % 5 == 0, K);
+    p2f_internal_linear<PP>(s, r == 6 || r == 15, K);
   }
   k += PP::PARTIAL_ROUNDS;
-  // the lanes with |d| >= 2 leave the partial rounds unreduced (up to 4^5 * 2^31): wide S-box once
-#pragma unroll
-  for (int i = 0; i < P2_WIDTH; ++i) {
-    const bool wide = i == 2 || i == 4 || i == 5 || i == 7 || i == 8;
-    s[i] = wide ? p2f_sbox<PP, true>(s[i] + rc[k + i], SK) : p2f_sbox<PP>(s[i] + rc[k + i], SK);
-  }
-  k += P2_WIDTH;
-  p2f_external_linear(s);
-  for (int r = 1; r < P2_HALF_FULL; ++r) {
+  s[2] = p2f_reduce<PP>(s[2]);
+  s[4] = p2f_reduce<PP>(s[4]);
+  s[5] = p2f_reduce<PP>(s[5]);
+  s[7] = p2f_reduce<PP>(s[7]);
+  s[8] = p2f_reduce<PP>(s[8]);
+  for (int r = 0; r < P2_HALF_FULL; ++r) {
 #pragma unroll
     for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i], SK);
     k += P2_WIDTH;

@@ -153,16 +153,26 @@ __device__ __forceinline__ void p2wf_lane_default(double* s, const double* mk, d
   else if constexpr (f.form == 1) s[I] = p2f_mul_2exp_neg_add<PP>(s[I], m, sum);
   else s[I] = p2f_mul_2exp_neg<PP>(s[I], m) + sum;
 }
+// `period` names the growth class of a small-integer lane: 5 = |d| in 2..4, 4 = |d| in 5..7, 3 = |d| in 8..16
 template <class PP, int PERIOD, int I>
 __device__ __forceinline__ void p2wf_lane_reduce(double* s) {
   if constexpr (I > 0 && p2w_default_form<PP>(I).period == PERIOD) s[I] = p2f_reduce<PP>(s[I]);   // lane 0: the S-box reduces it
 }
+template <class PP, int I>
+__device__ __forceinline__ void p2wf_lane_reduce_grown(double* s) {
+  if constexpr (I > 0 && p2w_default_form<PP>(I).period > 0) s[I] = p2f_reduce<PP>(s[I]);
+}
+template <class PP, int... I>
+__device__ __forceinline__ void p2wf_reduce_grown(double* s, std::integer_sequence<int, I...>) { (p2wf_lane_reduce_grown<PP, I>(s), ...); }
 template <class PP, int... I>
 __device__ __forceinline__ void p2wf_internal_linear_default(double* s, const double* mk, int r, std::integer_sequence<int, I...>) {
-  // a lane multiplied by a small integer grows by that factor every round: reduced every 5 / 4 / 3 rounds (|d| <= 4 / 7 / 16)
-  if (r % 5 == 0) (p2wf_lane_reduce<PP, 5, I>(s), ...);
-  if (r % 4 == 0) (p2wf_lane_reduce<PP, 4, I>(s), ...);
-  if (r % 3 == 0) (p2wf_lane_reduce<PP, 3, I>(s), ...);
+  // A lane multiplied by a small integer grows by that factor every round, from < 2^37 (63 * 0.7 P) at the first round and
+  // from 2^30 after a reduction; kept below 2^47, so that the sum of all of them stays below 2^51: |d| <= 4 reduced at the
+  // start of rounds 5, 13, 21, 29 (4^5 2^36.4, then 4^8 2^30), |d| <= 7 at 3, 8, 13, .. (7^3, then 7^5), |d| <= 16 at 2, 5, 8, ..
+  // (16^2, then 16^3).  (Until this change: every 5 / 4 / 3 rounds from round 0.)
+  if (r >= 5 && (r - 5) % 8 == 0) (p2wf_lane_reduce<PP, 5, I>(s), ...);
+  if (r >= 3 && (r - 3) % 5 == 0) (p2wf_lane_reduce<PP, 4, I>(s), ...);
+  if (r >= 2 && (r - 2) % 3 == 0) (p2wf_lane_reduce<PP, 3, I>(s), ...);
   double part[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -200,9 +210,9 @@ __device__ __forceinline__ void p2wf_permute(double* s, const double* __restrict
       s[0] = p2f_sbox<PP>(s[0] + tab[k + r], SK);
       p2wf_internal_linear_default<PP>(s, mk, r, std::make_integer_sequence<int, P2W_WIDTH>{});
     }
-    // whatever the small-integer lanes accumulated since their last reduction: back inside the full rounds' domain
-#pragma unroll
-    for (int i = 1; i < P2W_WIDTH; ++i) s[i] = p2f_reduce<PP>(s[i]);
+    // whatever the small-integer lanes accumulated since their last reduction: back inside the full rounds' domain (the
+    // other lanes are there already: +-2^-k lanes leave every round below 2^32, the d = 1 lane adds a reduced sum a round)
+    p2wf_reduce_grown<PP>(s, std::make_integer_sequence<int, P2W_WIDTH>{});
   } else {
     // The 32 diagonal entries stay in SCALAR registers through the partial rounds (64 SGPRs) and the vector registers
     // hold the state and its temporaries only: four waves per SIMD.  (Round 4 kept d AND d / P, 64 constants, in vector
