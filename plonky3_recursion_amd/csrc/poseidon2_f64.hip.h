@@ -219,6 +219,8 @@ __device__ __forceinline__ void p2f_permute(double* s, const double* __restrict_
     if (CARRIED >> i & 1u) s[i] = p2f_reduce<PP>(s[i]);
   p2f_external_linear(s);   // |.| <= 35 P: inside the narrow S-box's 2^38 with the round constant added
   int k = 0;
+  // (two rounds per iteration: the scalar loads of the second round's constants are in flight while the first one runs)
+#pragma unroll 2
   for (int r = 0; r < P2_HALF_FULL; ++r) {
 #pragma unroll
     for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i], SK);
@@ -240,6 +242,8 @@ __device__ __forceinline__ void p2f_permute(double* s, const double* __restrict_
   s[5] = p2f_reduce<PP>(s[5]);
   s[7] = p2f_reduce<PP>(s[7]);
   s[8] = p2f_reduce<PP>(s[8]);
+  // (two rounds per iteration: the scalar loads of the second round's constants are in flight while the first one runs)
+#pragma unroll 2
   for (int r = 0; r < P2_HALF_FULL; ++r) {
 #pragma unroll
     for (int i = 0; i < P2_WIDTH; ++i) s[i] = p2f_sbox<PP>(s[i] + rc[k + i], SK);
