@@ -184,3 +184,18 @@ def test_wall_time_prediction_model():
     # K trees with rotated placement keep every rank busy: per-tree cost falls
     forest = predict([TreePlan(8, 4, offset=t) for t in range(4)], leaf, node, msg)
     assert forest["wall_ms"] / 4 < predict([TreePlan(8, 4)], leaf, node, msg)["wall_ms"]
+
+
+def test_weak_scaling_prediction_of_the_plain_entry():
+    """bench.py's `scaling_prediction`: independent proofs, so the step of N ranks is the slowest rank's solo step - equal
+    to the solo step at N = 1, growing by less than 3 % to N = 8, and the aggregate rate is N proofs per step."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    p = bench.weak_scaling_prediction(28.0)["one_gpu_per_rank"]
+    assert p["1"]["predicted_ms_per_step"] == 28.0
+    steps = [p[str(n)]["predicted_ms_per_step"] for n in (1, 2, 4, 8)]
+    assert steps == sorted(steps) and steps[-1] < 28.0 * 1.03
+    for n in (1, 2, 4, 8):
+        assert abs(p[str(n)]["predicted_proofs_per_s"] - n / p[str(n)]["predicted_ms_per_step"] * 1e3) < 1e-9
