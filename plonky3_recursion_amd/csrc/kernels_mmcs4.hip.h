@@ -122,7 +122,7 @@ k_mmcs4_compress(const uint32_t* __restrict__ prev, size_t n_prev, int step, con
 
 // ---- lane-cooperative width-32 permutation for LATENCY-bound levels (kernels_coop.hip.h is the width-16 form): one
 // state element per lane, 32 lanes (two DPP rows) per permutation, two permutations per wavefront.  With one
-// permutation per lane a level of an arity-4 tree costs one 11.5 k-instruction permutation (19 us) however few nodes
+// permutation per lane a level of an arity-4 tree costs one 7.8 - 11.3 k-instruction permutation (13 - 19 us) however few nodes
 // it has; here the 32 S-boxes of a round run side by side and the linear layers are DPP rotations plus ONE cross-row
 // step (v_permlane16_swap, new on gfx950: it exchanges the odd rows of one register with the even rows of another,
 // so swap(t, t) yields (row0, row0, row2, row2) and (row1, row1, row3, row3), whose sum is the pair sum in every row).

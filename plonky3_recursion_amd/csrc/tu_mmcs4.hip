@@ -7,9 +7,9 @@
 namespace p3r {
 
 // Up to this many nodes / rows the lane-cooperative form wins: a launch of the one-permutation-per-lane form is one
-// permutation latency (19 us) whatever its size up to ~64 K nodes, the cooperative one ~5 us per pass of 16 K nodes;
-// above, the FP64 form's throughput wins (a lane-cooperative permutation is 32 lanes x ~1.7 k integer instructions
-// against 11.5 k FP64 instructions of one lane).
+// permutation latency (13 us with the built-in diagonal's 7.8 k instructions, 19 us with the general 11.3 k) whatever its
+// size up to ~64 K nodes, the cooperative one ~5 us per pass of 16 K nodes; above, the FP64 form's throughput wins (a
+// lane-cooperative permutation is 32 lanes x ~1.7 k integer instructions against 7.8 - 11.3 k FP64 instructions of one lane).
 constexpr size_t kCoop4MaxNodes = 32768, kCoop4MaxRows = 32768;
 
 template <class PP>
