@@ -127,12 +127,12 @@ def hbm_families(heights, widths, packing, kernel_ms):
     return out
 
 
-PROFILE_ROUND = "r05"   # profiles/<round>/ holds the rocprofv3 summaries the roofline numbers refer to
+PROFILE_ROUND = "r06"   # profiles/<round>/ holds the rocprofv3 summaries the roofline numbers refer to
 
 
 def profile_file(name):
     """Path of a committed summary: this round's, else the newest earlier round's (the line names what it read)."""
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(p):
             return p, f"profiles/{rnd}/{name}"
@@ -715,7 +715,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
                     "(solo latencies + one message per level), whatever the GPU count; --trees 0 is the form that scales",
         }
         what = f"{n_trees} independent 2-to-1 aggregation trees in flight" if n_trees > 1 else "2-to-1 aggregation tree"
-        print(json.dumps({
+        emit({
             "metric": f"aggregation tree wall ms ({args.tree_leaves} leaf proofs -> 1 root, prove_aggregation_layer per node), KoalaBear",
             "value": ms_tree, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_tree, "higher_is_better": False,
@@ -741,7 +741,8 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
                       "child_parse_ms": mean(stats["child_parse_ms"]), "child_parse_native_ms": mean(stats["child_parse_native_ms"]),
                       "child_verify_ms": mean(stats["child_verify_ms"]),
                       "level_wall_ms_last_step": list(level_ms)},
-        }))
+            "proof_verified": ok, "proof_sha256": hashlib.sha256(root).hexdigest(),
+        }, args)
     for wk in all_workers:
         wk["leaf_inputs"].free()
         wk["leaf_cache"].prepared_circuit.free()
@@ -771,25 +772,13 @@ def self_launch(n):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def omp_team_size():
-    """The OpenMP team the harness / oracle libraries actually get in this process (not the environment string)."""
-    try:
-        import ctypes
-        import oracle_lib
-        lib = ctypes.CDLL(oracle_lib.LIB)
-        lib.orc_num_threads.restype = ctypes.c_int
-        return int(lib.orc_num_threads())
-    except Exception:
-        return None
-
-
 def weak_scaling_prediction(solo_ms, sigma=0.015):
     """The plain multi-GPU entry shards nothing: every rank proves its own layer on its own GPU, inputs resident, and the
     only collectives are the barrier and the MAX of the timings outside the timed steps.  So the step of N ranks is the
     slowest rank's solo step: solo x (1 + sigma x E[max of N standard normals]), sigma = the GPU-to-GPU spread seen across
     the boxes of profiles/r03 - r05 (1.5 %); the aggregate rate is N proofs per that step.  What the run cannot show on
     one GPU and a shared node may add: host cores (each rank's launch loop and transcript take one core; the workload
-    generator before the timed region takes `omp_team_size` threads per rank, capped by OMP_NUM_THREADS)."""
+    generator before the timed region is single-threaded)."""
     emax = {1: 0.0, 2: 0.5642, 4: 1.0294, 8: 1.4236}
     return {"model": "independent proofs, one per GPU: step(N) = slowest rank's solo step = solo x (1 + 0.015 x E[max of N normals]); "
                      "no data-path collective", "solo_ms": solo_ms,
@@ -818,7 +807,105 @@ def rank_report(torch, dist, world, backend, local_rank, coll_device, rank_ms=No
                  "ms": row[4] / 1000.0 if rank_ms is not None else None} for r, row in enumerate(rows)]
     return {"world_size": ws, "backend": be, "devices": [row[0] for row in rows], "per_rank": per_rank,
             "distinct_gpus": len({(p["device"], p["pci"]) for p in per_rank}),
-            "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "omp_team_size": omp_team_size()}
+            "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "host_cpus": os.cpu_count()}
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "proof_verified", "proof_sha256")
+CONTRACT_MAX_CHARS = 6000   # the driver keeps an ~8 KB tail of stdout: the final line must fit whole inside it
+
+
+def _round_floats(x, digits=6):
+    """Floats to `digits` significant figures (the final line is read by people and by a size-limited record)."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _round_floats(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round_floats(v, digits) for v in x]
+    return x
+
+
+def contract_line(full, detail_path=None):
+    """The ONE line the driver parses: exactly the contract fields of a full result dict (everything else - kernel
+    families, secondary legs, predictions - lives in the detail file).  Pure function of `full`; tests/test_bench_line_contract.py
+    holds it to CONTRACT_MAX_CHARS on canned results."""
+    cfg = full.get("config") or {}
+    out = {k: full.get(k) for k in CONTRACT_KEYS if k not in ("config", "roofline", "cpu_baseline")}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "field", "log_height", "table_heights", "table_widths", "fri",
+                                            "independent_proofs", "proof_bytes", "parallelism", "tree", "leaves", "trees",
+                                            "leaf_log_height", "workers_per_rank", "zk") if k in cfg}
+    r = full.get("roofline")
+    if r:
+        hbm = r.get("hbm") or {}
+        out["roofline"] = {
+            "kernel": r.get("kernel"), "bound": r.get("bound"), "achieved": r.get("achieved"), "peak": r.get("peak"),
+            "unit": "T FP64 lane-ops/s" if r.get("bound") == "valu-issue" else r.get("unit"),
+            "frac": r.get("frac"), "traffic": r.get("traffic"), "avg_launch_ms": r.get("avg_launch_ms"),
+            "perms_per_s": r.get("perms_per_s"), "valu_insts_per_perm": r.get("valu_insts_per_perm"),
+            "frac_measured_fma_rate": r.get("frac_measured"), "vs_survey_integer_roof": r.get("vs_survey_integer_roof"),
+            "frac_null_reason": r.get("frac_null_reason"),
+            "hbm": {k: hbm.get(k) for k in ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch",
+                                            "traffic_vs_algorithmic")},
+            "sources": r.get("source_files"),
+        }
+    else:
+        out["roofline"] = None
+    c = full.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "sample", "circuit_run_ms",
+                                                     "gpu_ms_same_sample", "published_reference_ms")}
+    else:
+        out["cpu_baseline"] = None
+    for k in ("poseidon2_perms_per_s", "dominant_kernel_family", "value_incl_h2d_ms", "prep_miss_ms", "proof_verify_ms",
+              "root_handoff_ms", "proofs_per_s", "trees_per_s", "critical_path_ms", "roots_verified"):
+        if full.get(k) is not None:
+            out[k] = full[k]
+    pr = full.get("proof_roofline")
+    if pr and pr.get("frac") is not None:
+        out["proof_roofline_frac"] = pr["frac"]
+    if full.get("ranks"):
+        rk = full["ranks"]
+        out["ranks"] = {k: rk.get(k) for k in ("backend", "world_size", "distinct_gpus") if k in rk}
+    if detail_path:
+        out["detail"] = detail_path
+    out = _round_floats(out)
+    text = json.dumps(out, separators=(", ", ": "), allow_nan=False)
+    if len(text) > CONTRACT_MAX_CHARS:
+        # never let prose push the line over the record's tail: drop the optional extras, then shorten the strings
+        for k in ("ranks", "proof_roofline_frac", "root_handoff_ms", "proof_verify_ms", "prep_miss_ms", "value_incl_h2d_ms"):
+            out.pop(k, None)
+        if out.get("cpu_baseline"):
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:200]
+        out["config"]["workload"] = out["config"]["workload"][:300]
+        text = json.dumps(out, separators=(", ", ": "), allow_nan=False)
+    assert len(text) <= CONTRACT_MAX_CHARS, f"final bench line is {len(text)} characters"
+    return text
+
+
+def write_detail(full, path):
+    """Everything measured, next to the final line: <path> (and gpurun_out/ when that scratch directory exists, so a
+    gpurun call brings it back)."""
+    text = json.dumps(full, indent=1)
+    paths = [path]
+    scratch = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(scratch) and os.path.abspath(path) == os.path.join(ROOT, "bench_detail.json"):
+        paths.append(os.path.join(scratch, os.path.basename(path)))
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                f.write(text + "\n")
+        except OSError as e:   # a read-only checkout must not cost the run its number
+            print(f"bench: could not write {p}: {e}", file=sys.stderr)
+
+
+def emit(full, args):
+    """Detail to its file, then the one contract line as the LAST line of stdout."""
+    write_detail(full, args.detail_out)
+    sys.stdout.flush()
+    print(contract_line(full, os.path.basename(args.detail_out)), flush=True)
 
 
 def main():
@@ -843,6 +930,16 @@ def main():
     ap.add_argument("--tree-level-barriers", action="store_true", help="barrier between levels (per-level wall times)")
     ap.add_argument("--spans", action="store_true",
                     help="print the per-stage timers as tracing-forest spans under the reference's span names (stderr)")
+    ap.add_argument("--full", action="store_true",
+                    help="also run the secondary legs (config 2 knobs, config 0 base layer, D = 5, width-32 table, arity-4 MMCS, "
+                         "ZK) and the second, 4x larger CPU sample: the profile rounds' form; the default run is the headline "
+                         "with its roofline and cpu_baseline and finishes in well under a minute")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where everything that is not a contract field goes (the final stdout line stays under "
+                         f"{CONTRACT_MAX_CHARS} characters)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (nccl = RCCL unless P3R_BENCH_BACKEND says otherwise) also at world size 1: "
+                         "barrier, all_reduce(MAX) of the timings and the root hand-off run through the collective library on one GPU")
     ap.add_argument("--no-small-layers", action="store_true", help="skip the 2^14/2^15/2^16-row layers")
     ap.add_argument("--no-quintic", action="store_true",
                     help="skip the D = 5 layer (KoalaBear quintic circuits: ALU, compact-D1 Poseidon2, recompose/coeff)")
@@ -854,6 +951,8 @@ def main():
                     help="--tree: independent trees in flight (0 = one per rank: the throughput form, weak scaling); tree t "
                          "is placed with rank offset t, so every rank proves the same number of nodes")
     args = ap.parse_args()
+    if not args.full:
+        args.no_quintic = args.no_config2 = True
 
     # `python bench.py --gpus N` on its own starts the N ranks itself: the parent spawns
     # `python -m torch.distributed.run` BEFORE it has imported torch or touched a device (a process that has
@@ -901,7 +1000,16 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % max(ndev, 1)
     coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if world > 1 or args.force_dist:
+        if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:   # --force-dist without a launcher
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         import datetime
@@ -1140,14 +1248,13 @@ def main():
             # the INTEGER roof the survey proposed
             "vs_survey_integer_roof": (ach / (MONT_PRODUCT_RATE_PLAIN / 616.0)) if ach else None,
             "survey_integer_roof_perms_per_s": MONT_PRODUCT_RATE_PLAIN / 616.0,
-            "sources": {"valu_insts_per_perm": f"{vsrc.get('valu_insts_per_perm')} (SQ_INSTS_VALU x 64 / permutations, "
-                                               "tools/pmc_hash_rows.py)",
-                        "peak_measured_lane_ops_per_s": f"{vsrc.get('peak_measured_lane_ops_per_s')} (v_fma_f64 line, "
-                                                        "tools/microbench/int_rates)",
-                        "traffic": f"{profile_file('pmc_traffic.json')[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                   "same command, tools/profile_round.sh; bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 "
-                                   "correction of the microarchitecture guide - the factor 2 for 4-B-per-lane reads is calibrated on "
-                                   "this kernel's known byte count)"},
+            # how each was obtained: tools/profile_round.sh (rocprofv3 --pmc SQ_INSTS_VALU over tools/pmc_hash_rows.py;
+            # the v_fma_f64 line of tools/microbench/int_rates; --pmc FETCH_SIZE / WRITE_SIZE passes of this command with
+            # bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)
+            "source_files": {"valu_insts_per_perm": vsrc.get("valu_insts_per_perm"),
+                             "peak_measured_lane_ops_per_s": vsrc.get("peak_measured_lane_ops_per_s"),
+                             "traffic": profile_file("pmc_traffic.json")[1],
+                             "kernel_stats": profile_file("prove_next_layer_final_kernel_stats.csv")[1]},
             "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                     "algorithmic_bytes_per_launch": hash_bytes / launches_per_step if launches_per_step else None,
                     "traffic_vs_algorithmic": (traffic / (hash_bytes / launches_per_step)) if traffic and launches_per_step else None,
@@ -1163,7 +1270,7 @@ def main():
             lh = args.cpu_baseline_log_height
             cdt, crun, cores = cpu_baseline(field, lh)
             # a second, four times larger sample: how the port scales (the line's own comparator stays the first)
-            cdt2, crun2, _ = cpu_baseline(field, lh + 2)
+            cdt2, crun2 = (cpu_baseline(field, lh + 2)[:2]) if args.full else (None, None)
             line["cpu_baseline"] = {
                 "value": cdt * 1e3, "unit": "ms", "cores": cores, "kind": "port",
                 "sample": f"same prove_next_layer (circuit run + prove, same table mix, same FRI parameters, same "
@@ -1172,10 +1279,10 @@ def main():
                 "circuit_run_ms": crun * 1e3,
                 "gpu_ms_same_sample": small.get(str(lh), {}).get("ms_per_step") if small else None,
                 "samples": [{"log_height": lh, "ms": cdt * 1e3, "circuit_run_ms": crun * 1e3,
-                             "gpu_ms": small.get(str(lh), {}).get("ms_per_step") if small else None},
-                            {"log_height": lh + 2, "ms": cdt2 * 1e3, "circuit_run_ms": crun2 * 1e3,
-                             "gpu_ms": small.get(str(lh + 2), {}).get("ms_per_step") if small else None}],
-                "scaling_4x_rows": cdt2 / cdt,
+                             "gpu_ms": small.get(str(lh), {}).get("ms_per_step") if small else None}] +
+                           ([{"log_height": lh + 2, "ms": cdt2 * 1e3, "circuit_run_ms": crun2 * 1e3,
+                              "gpu_ms": small.get(str(lh + 2), {}).get("ms_per_step") if small else None}] if cdt2 else []),
+                "scaling_4x_rows": (cdt2 / cdt) if cdt2 else None,
                 "note": "a label, not a comparator: the oracle is a deliberately plain restatement (u64 % arithmetic, textbook "
                         "NTT).  The reference's own published figure is `published_reference_ms`.",
                 "published_reference_ms": PUBLISHED_CPU_MS,
@@ -1526,7 +1633,7 @@ def main():
             rinz.free()
             pcz.free()
             ctxz.close()
-        print(json.dumps(line))
+        emit(line, args)
     if resident is not None:
         resident.free()
         pc.free()

@@ -266,8 +266,17 @@ def run_aggregation_forest(plans, rank: int, prove_leaf: Callable[[int, int], by
 
 def gather_proofs_to_root(proof: bytes, dist, rank: int, world: int, device="cpu") -> Optional[List[bytes]]:
     """Independent proofs (one per rank) handed to rank 0: used by bench.py's weak-scaling run."""
-    if dist is None or world == 1:
+    if dist is None:
         return [proof]
+    if world == 1:
+        # a process group of one (bench.py --force-dist): the proof still makes the trip through the collective library -
+        # length and payload as device tensors, broadcast from rank 0 - so that a one-GPU box exercises the same path
+        import torch
+        n = torch.tensor([len(proof)], dtype=torch.int64, device=device)
+        dist.broadcast(n, 0)
+        buf = torch.frombuffer(bytearray(proof), dtype=torch.uint8).to(device)
+        dist.broadcast(buf, 0)
+        return [bytes(buf[: int(n.item())].cpu().numpy().tobytes())]
     if rank == 0:
         out = [proof]
         for src in range(1, world):

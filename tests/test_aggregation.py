@@ -73,7 +73,7 @@ def expected_forest_root(t, n_leaves):
     return level[0].hex()
 
 
-@pytest.mark.parametrize("world,n_leaves,n_trees,workers", [(2, 8, 1, 1), (4, 8, 4, 2), (2, 4, 3, 3), (3, 4, 2, 1)])
+@pytest.mark.parametrize("world,n_leaves,n_trees,workers", [(2, 8, 1, 1), (4, 8, 4, 2), (2, 4, 3, 3), (3, 4, 2, 1), (8, 8, 8, 1)])
 def test_forest_over_gloo(tmp_path, world, n_leaves, n_trees, workers):
     """Dependency-driven scheduler: K trees in flight with rotated placement, no level barrier, one comm
     thread per rank; every tree's root reaches rank 0 and equals the serial evaluation."""
@@ -82,7 +82,7 @@ def test_forest_over_gloo(tmp_path, world, n_leaves, n_trees, workers):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(n_leaves), str(n_trees),
            str(workers)]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert out.returncode == 0, out.stderr[-2000:]
     for t in range(n_trees):
         assert f"ROOT {t} {expected_forest_root(t, n_leaves)}" in out.stdout
@@ -128,13 +128,15 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n_leaves", [(2, 8), (4, 8), (2, 2), (3, 4)])
+# world 8: BASELINE config 4's placement (one leaf per rank, root on rank 0); world 1: a process group of one - the
+# hand-off still goes through the collective library (bench.py --force-dist)
+@pytest.mark.parametrize("world,n_leaves", [(2, 8), (4, 8), (2, 2), (3, 4), (8, 8), (1, 4)])
 def test_tree_over_gloo(tmp_path, world, n_leaves):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script), str(n_leaves)]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert out.returncode == 0, out.stderr[-2000:]
     assert f"ROOT {expected_root(n_leaves)}" in out.stdout
     assert "GATHER True" in out.stdout

@@ -5,6 +5,7 @@ import json
 import os
 import socket
 import subprocess
+import tempfile
 import sys
 
 import numpy as np
@@ -121,6 +122,24 @@ def test_aggregation_output_outlives_its_cache_slot_and_content_is_part_of_the_k
     ctx.close()
 
 
+DETAIL = os.path.join(tempfile.gettempdir(), f"p3r_bench_detail_{os.getpid()}.json")
+
+
+def bench_result(out):
+    """The full result of a bench.py run: the LAST stdout line is the driver's contract line (compact, every contract
+    key, names its detail file); everything else is in the detail file rank 0 wrote."""
+    last = out.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert len(last) < 6000 and {"metric", "value", "unit", "n_gpus", "roofline", "cpu_baseline", "proof_verified",
+                                 "proof_sha256", "config"} <= set(line), last[:300]
+    with open(DETAIL) as fh:
+        full = json.load(fh)
+    os.remove(DETAIL)
+    assert full["value"] == pytest.approx(line["value"], rel=1e-5) and full["n_gpus"] == line["n_gpus"]
+    return full
+
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -140,9 +159,9 @@ def test_tree_of_real_proofs_root_verifies(world, leaves, zk):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                "127.0.0.1", "--master-port", str(free_port())] + args
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    out = subprocess.run(cmd + ["--detail-out", DETAIL], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    line = bench_result(out)
     assert line["root_verified"] is True and line["n_gpus"] == world and line["scaling"] == "strong"
     assert line["config"]["nodes"] == 2 * leaves - 1
     assert len(line["rank0"]["level_wall_ms_last_step"]) == leaves.bit_length()
@@ -162,17 +181,17 @@ def test_plain_bench_entry_launches_its_own_ranks():
         env.pop(k, None)
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-height", "12",
            "--no-cpu-baseline", "--no-config2", "--no-small-layers"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    out = subprocess.run(cmd + ["--detail-out", DETAIL], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    line = bench_result(out)
     assert line["n_gpus"] == 2 and line["proof_verified"] is True
     assert line["ranks"]["world_size"] == 2 and line["ranks"]["backend"] == "gloo" and len(line["ranks"]["devices"]) == 2
     # the forest form through the same plain entry: one tree per rank, rotated placement, every root verified
     cmd = [sys.executable, "bench.py", "--gpus", "2", "--tree", "--trees", "0", "--tree-leaves", "4", "--leaf-log-height", "10",
            "--steps", "1", "--warmup", "0", "--tree-workers", "2"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    out = subprocess.run(cmd + ["--detail-out", DETAIL], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    line = bench_result(out)
     assert line["n_gpus"] == 2 and line["config"]["trees"] == 2 and line["roots_verified"] == 2 and line["scaling"] == "weak"
     assert line["config"]["scheduler"] == "dependency-driven" and line["ranks"]["world_size"] == 2
     assert line["rank0"]["child_parse_ms"] is not None
@@ -201,9 +220,35 @@ def test_default_bench_line_two_ranks_over_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-height", "12",
            "--no-cpu-baseline", "--no-config2", "--no-small-layers"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    out = subprocess.run(cmd + ["--detail-out", DETAIL], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    line = bench_result(out)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["proof_verified"] is True
     assert line["config"]["independent_proofs"] == 2
     assert isinstance(line["root_handoff_ms"], float)
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "plain"])
+def test_rccl_process_group_of_one(launcher):
+    """First contact with RCCL on an MI355X before the driver's scaling run: world size 1 under the **nccl** backend -
+    init_process_group("nccl", device_id=...), the barrier and the all_reduce(MAX) that bracket the timed region, the
+    proof's hand-off as device tensors through the collective library, destroy_process_group - with the environment
+    (HSA_ENABLE_IPC_MODE_LEGACY=0) and the launcher line the driver uses, and once through `--force-dist` alone.
+    Nothing about scaling is claimed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("P3R_BENCH_BACKEND", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--log-height", "12", "--no-cpu-baseline",
+            "--no-small-layers", "--force-dist"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port())] + args
+    else:
+        env.pop("MASTER_ADDR")
+        cmd = [sys.executable] + args
+    out = subprocess.run(cmd + ["--detail-out", DETAIL], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = bench_result(out)
+    assert line["n_gpus"] == 1 and line["proof_verified"] is True
+    rk = line["ranks"]
+    assert rk["backend"] == "nccl" and rk["world_size"] == 1 and rk["distinct_gpus"] == 1
+    assert isinstance(line["root_handoff_ms"], float), line["root_handoff_ms"]    # "failed: ..." would be a string

@@ -99,6 +99,9 @@ def pmc(counter):
 
 line = json.load(open(os.path.join(SRC, "bench_line.json")))
 json.dump(line, open(os.path.join(OUT, "bench_line_final.json"), "w"), indent=1)
+for f in ("bench_default_line.json", "bench_default_detail.json", "bench_default_time.txt", "bench_contract_line.json"):
+    if os.path.exists(os.path.join(SRC, f)):
+        shutil.copy(os.path.join(SRC, f), os.path.join(OUT, f))
 shutil.copy(newest(SRC + "/stats/*/*_kernel_stats.csv"), os.path.join(OUT, "prove_next_layer_final_kernel_stats.csv"))
 for f in ("int_rates.txt", "perm_f64.txt"):
     if os.path.exists(os.path.join(SRC, f)):
@@ -145,9 +148,7 @@ for f in ("bench_line_babybear_2p22.json", "bench_line_tree_1gpu.json", "bench_l
     src = os.path.join(SRC, f)
     if os.path.exists(src) and os.path.getsize(src):
         if f.endswith(".json"):   # the ranks' collective layer may print banner lines next to the bench line
-            lines = [ln for ln in open(src) if ln.startswith("{")]
-            if lines:
-                json.dump(json.loads(lines[-1]), open(os.path.join(OUT, f), "w"), indent=1)
+            shutil.copy(src, os.path.join(OUT, f))   # bench.py --detail-out: the full result dict
         else:
             shutil.copy(src, os.path.join(OUT, f))
 
