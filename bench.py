@@ -751,6 +751,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
         wk["ctx"].close()
     if dist is not None:
         dist.destroy_process_group()
+    flush_final_line()
     if not ok:
         sys.exit(3)
 
@@ -901,11 +902,22 @@ def write_detail(full, path):
             print(f"bench: could not write {p}: {e}", file=sys.stderr)
 
 
+_FINAL_LINE = []
+
+
 def emit(full, args):
-    """Detail to its file, then the one contract line as the LAST line of stdout."""
+    """Detail to its file now; the one contract line is printed by flush_final_line() as the process's LAST output - after
+    the contexts are closed and the process group is destroyed, so that nothing a library prints on the way out follows it."""
     write_detail(full, args.detail_out)
+    _FINAL_LINE.append(contract_line(full, os.path.basename(args.detail_out)))
+
+
+def flush_final_line():
+    sys.stderr.flush()
     sys.stdout.flush()
-    print(contract_line(full, os.path.basename(args.detail_out)), flush=True)
+    for text in _FINAL_LINE:
+        print(text, flush=True)
+    _FINAL_LINE.clear()
 
 
 def main():
@@ -1640,6 +1652,7 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    flush_final_line()
     if not proof_verified or (rank == 0 and not all(line.get("unpinned_legs_self_verified", {}).values())):
         sys.exit(3)
 

@@ -129,6 +129,7 @@ def bench_result(out):
     """The full result of a bench.py run: the LAST stdout line is the driver's contract line (compact, every contract
     key, names its detail file); everything else is in the detail file rank 0 wrote."""
     last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("{"), "the contract line must be the last line of stdout, got: " + repr(out.stdout[-600:])
     line = json.loads(last)
     assert len(last) < 6000 and {"metric", "value", "unit", "n_gpus", "roofline", "cpu_baseline", "proof_verified",
                                  "proof_sha256", "config"} <= set(line), last[:300]
