@@ -494,7 +494,7 @@ def run_tree(args, torch, dist, rank, world, local_rank, coll_device, backend_na
     for _ in range(max(1, args.tree_workers)):
         # --zk: `config_with_fri_params_zk(.., rng_seed)` per prover (recursive_aggregation.rs:711-721); distinct seeds, as
         # distinct PCS objects have distinct RNG states
-        zk_kw = dict(zk=1, num_random_codewords=2, zk_seed=0x5EED0000 + 977 * rank + len(all_workers)) if args.zk else {}
+        zk_kw = dict(zk=1, num_random_codewords=2) if args.zk else {}   # (the library keys every context from the operating system)
         wctx = p3r.Context(field=field, device=local_rank, **FRI, **zk_kw)
         lc = p3r.build_next_layer_prep(wctx, leaf_circuit, backend, params)
         wk = dict(ctx=wctx, leaf_cache=lc, leaf_inputs=lc.prepared_circuit.upload_inputs(leaf_host_inputs), agg_cache=[None])
@@ -1518,7 +1518,7 @@ def main():
                 resident = pc = None
             arrsw = harness_lib.generate(field, log_h, seed=0x5EED0032, flags=harness_lib.P2_W32, **GEN_KNOBS)
             countsw = [int(x) for x in arrsw["counts"]]
-            ctxw = p3r.Context(field=field, **FRI)
+            ctxw = p3r.Context(field=field, **FRI, allow_unpinned_w32_defaults=True)
             cpdw = p3r.CircuitProverData(ctxw, wl.circuit_prep_from_arrays(arrsw), packing)
             resw = p3r.ResidentTraces(ctxw, cpdw, wl.traces_from_arrays(arrsw))
             del arrsw
@@ -1562,7 +1562,7 @@ def main():
             # MyMmcsArity4 of `recursive_aggregation --arity4` - width-32 sponge leaves of rate 24, 4-to-1 levels, W16
             # challenger): same circuit, same inputs, same FRI parameters as the headline; prove_next_layer with a cache
             arrs4 = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN_KNOBS)
-            ctx4 = p3r.Context(field=field, mmcs_arity=4, **FRI)
+            ctx4 = p3r.Context(field=field, mmcs_arity=4, **FRI, allow_unpinned_w32_defaults=True)
             pc4 = p3r.PreparedCircuit(ctx4, wl.circuit_from_arrays(arrs4), packing)
             rin4 = pc4.upload_inputs(wl.circuit_inputs_from_arrays(arrs4))
             del arrs4
@@ -1591,12 +1591,55 @@ def main():
                 "leaf_roofline": w32_leaf_roofline(field, cpd.table_heights, widths, packing, prof4.get("mmcs_hash_rows", (0.0,))[0]),
                 "workload": f"the headline prove_next_layer (same circuit, inputs, tables and FRI parameters) with every commitment - "
                             f"traces, LogUp columns, quotient chunks, FRI commit phases - under the arity-4 MMCS over the width-32 "
-                            f"permutation; challenger on the width-16 permutation.  NOT a layer of `recursive_aggregation "
-                            f"--arity4`: that recursion's verifier circuit fills the width-32 table, for which the circuit seam has "
-                            f"no op kind (INTEGRATION.md section 3a''); see width32_table_layer for the table itself"}
+                            f"permutation; challenger on the width-16 permutation.  The circuit itself holds width-16 rows only: "
+                            f"arity4_recursion_layer is the layer whose verifier circuit fills the width-32 table"}
             line.setdefault("unpinned_legs_self_verified", {})["arity4_mmcs_layer"] = ok4
             rin4.free()
             pc4.free()
+            # ... and the layer `recursive_aggregation --arity4` proves (recursive_aggregation.rs:902-1046): the verifier circuit
+            # of an arity-4 proof - width-16 challenger rows AND width-32 MMCS rows (P3R_OP_POSEIDON2_W32_PERM: leaf sponges of
+            # rate 24 that seed 4-to-1 compression chains with injection and bridge levels) - run on the device and proved
+            # under the arity-4 MMCS, from the circuit boundary with a cache
+            arrsr = harness_lib.generate(field, log_h, seed=0x5EED0032, flags=harness_lib.P2_W32_OPS, **GEN_KNOBS)
+            countsr = [int(x) for x in arrsr["counts"]]
+            tr = time.perf_counter()
+            pcr = p3r.PreparedCircuit(ctx4, wl.circuit_from_arrays(arrsr), packing)
+            ctx4.sync()
+            prepr_ms = (time.perf_counter() - tr) * 1e3
+            rinr = pcr.upload_inputs(wl.circuit_inputs_from_arrays(arrsr))
+            del arrsr
+            rawr = pcr.prove(rinr)
+            ctx4.sync()
+            tr = time.perf_counter()
+            for _ in range(5):
+                pcr.prove(rinr)
+            ctx4.sync()
+            msr = (time.perf_counter() - tr) / 5 * 1e3
+            try:
+                prover4.verify_all_tables(prover4.wrap_proof(rawr, pcr.circuit_prover_data))
+                okr = True
+            except Exception as e:
+                print(f"bench: arity-4 recursion layer: proof rejected: {e}", file=sys.stderr)
+                okr = False
+            ctx4.profile_enable(True)
+            pcr.prove(rinr)
+            profr = ctx4.profile_read()
+            ctx4.profile_enable(False)
+            line["arity4_recursion_layer"] = {
+                "ms_per_step": msr, "steps": 5, "proof_verified": okr, "proof_bytes": len(rawr), "circuit_prep_ms": prepr_ms,
+                "prepared_on_device": pcr.prepared_on_device, "circuit_levels": pcr.levels,
+                "table_heights": pcr.circuit_prover_data.table_heights + [pcr.circuit_prover_data.p2w_height],
+                "ops": dict(zip(["const", "public", "alu", "poseidon2", "recompose", "witnesses", "recompose/coeff", "poseidon2_w32"], countsr)),
+                "kernel_ms": {k: v[0] for k, v in profr.items() if not k.startswith("stage:")},
+                "run_circuit_ms": profr.get("stage:run_circuit", (None,))[0],
+                "constants": "self-generated defaults (p3r_config.poseidon2_w32_rc / _diag = NULL): unpinned",
+                "workload": f"prove_next_layer (verifier-circuit run on the device + prove_all_tables, cached preparation) of the synthetic "
+                            f"{field} 2^{log_h}-row layer of an arity-4 recursion: six tables - const / public / alu / poseidon2 width 16 "
+                            f"(challenger) / poseidon2 width 32 (MMCS: 2^{log_h - 2} rows run from P3R_OP_POSEIDON2_W32_PERM ops) / recompose - "
+                            f"every commitment under the arity-4 MMCS, same FRI parameters"}
+            line.setdefault("unpinned_legs_self_verified", {})["arity4_recursion_layer"] = okr
+            rinr.free()
+            pcr.free()
             ctx4.close()
             # SURVEY 8(f).4, ZK: the headline layer under HidingFriPcs (p3r_config.zk = 1: create_config_zk of
             # recursion/examples/common/mod.rs:511-553 - two random codewords, seeded RNG): every commitment over the
@@ -1604,7 +1647,7 @@ def main():
             # constrained table instead of two, LogUp packed in triples.  Same circuit, inputs and FRI parameters;
             # prove_next_layer with a cache; every timed proof is a different proof, the first and the last are verified
             arrsz = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN_KNOBS)
-            ctxz = p3r.Context(field=field, zk=1, num_random_codewords=2, zk_seed=0x5EED, **FRI)
+            ctxz = p3r.Context(field=field, zk=1, num_random_codewords=2, **FRI)   # keyed from the operating system: the production form
             pcz = p3r.PreparedCircuit(ctxz, wl.circuit_from_arrays(arrsz), packing)
             rinz = pcz.upload_inputs(wl.circuit_inputs_from_arrays(arrsz))
             del arrsz

@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
 
     p3r::FriParams fri;  // the examples' defaults: blow-up 4, 54 queries, 15 bits of query PoW
     if (arity4) { fri.mmcs_arity = 4; fri.allow_unpinned_w32_defaults = true; }   // this example has no upstream statics to pass: the built-in width-32 constants, acknowledged as unpinned
-    if (zk) { fri.zk = true; fri.num_random_codewords = 2; fri.zk_seed = 3; }
+    if (zk) { fri.zk = true; fri.num_random_codewords = 2; fri.zk_key = {3, 0, 0, 0, 0, 0, 0, 0}; fri.zk_deterministic = true; }   // (the test replays this proof on the CPU oracle)
     p3r::Context ctx(field, fri, 0, {}, D, 0, quintic ? 5 : 4);
     std::vector<uint32_t> rc(p3r_poseidon2_num_constants(ctx.raw()));
     ctx.check(p3r_poseidon2_round_constants(ctx.raw(), rc.data()));

@@ -59,7 +59,14 @@ enum { SYN_NO_POSEIDON2 = 1, SYN_NO_RECOMPOSE = 2, SYN_SINGLE_PUBLIC = 4, SYN_NO
        // MMCS, circuit-prover/tests/arity4_mmcs.rs): arity-4 Merkle chains (4-to-1 compressions, injection levels with
        // zero pads, bridge levels) and rate-24 sponge chains.  D = 4 only; arrays p2w_*, counts[7].  The rows enter at
        // the prove_all_tables boundary (they are not ops of the flattened circuit)
-       SYN_P2_W32 = 128 };
+       SYN_P2_W32 = 128,
+       // with SYN_P2_W32: the width-32 rows ARE ops of the flattened circuit (P3R_OP_POSEIDON2_W32_PERM, kind 11), with the
+       // executor's exact row semantics (poseidon_perm/executor.rs:92-235,947-966): no index-accumulator value, Merkle
+       // chains that continue a leaf sponge (new_start = 0 on every compression row, the shape add_arity4_compression_row
+       // emits, recursion/src/pcs/mmcs.rs:1013-1075) next to chains that start from a CTL-loaded digest; arrays
+       // pdw_op_ids / pdw_siblings hold the private data (three sibling digests per Merkle row).  Bit 12: the bits 8-11
+       // carry the extension degree
+       SYN_P2_W32_OPS = 4096 };
 
 // constants of the width-32 permutation (syn_set_w32): rc = [4][32] | partial | [4][32], diag = [32], canonical
 static const uint32_t* g_w32_rc = nullptr;
@@ -100,7 +107,7 @@ enum { OP_ADD = 0, OP_MUL = 1, OP_BOOL = 2, OP_MULADD = 3, OP_HORNER = 4 };
 
 // circuit op kinds of include/p3r.h (p3r_op_kind)
 enum : uint32_t { C_CONST = 0, C_PUBLIC = 1, C_ADD = 2, C_MUL = 3, C_BOOL = 4, C_MULADD = 5, C_HORNER = 6,
-                  C_HINT_EXT = 7, C_HINT_BIN = 8, C_P2 = 9, C_RECOMPOSE = 10 };
+                  C_HINT_EXT = 7, C_HINT_BIN = 8, C_P2 = 9, C_RECOMPOSE = 10, C_P2W = 11 };
 constexpr uint32_t NO_W = 0xFFFFFFFFu;
 
 template <class PP, class E>
@@ -516,11 +523,16 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
     for (auto& x : st) x = F::zero();
     size_t r = 0;
     const uint32_t ZERO_W = const_w[0], ONE_W = const_w[1];
+    const bool as_ops = flags & SYN_P2_W32_OPS;
+    auto& pdw_ids = W.arr["pdw_op_ids"]; auto& pdw_sib = W.arr["pdw_siblings"];
     while (r < n_p2w) {
-      const bool merkle = rng.unit() < 0.7;
-      size_t len = std::min<size_t>(merkle ? std::max(2, merkle_depth / 2) : std::max(1, sponge_chain_len), n_p2w - r);
+      const bool merkle_chain = rng.unit() < 0.7;
+      // as ops: half of the Merkle chains continue a leaf sponge of 1-3 rows (new_start only on its first row)
+      const size_t prefix = (as_ops && merkle_chain && rng.unit() < 0.5) ? 1 + rng.below(3) : 0;
+      size_t len = std::min<size_t>((merkle_chain ? std::max(2, merkle_depth / 2) : std::max(1, sponge_chain_len)) + prefix, n_p2w - r);
       uint32_t acc = 0;
       for (size_t j = 0; j < len; ++j, ++r) {
+        const bool merkle = merkle_chain && j >= prefix;
         const bool ns = j == 0, last = j + 1 == len;
         F in[32];
         uint32_t in_ctl[8] = {0}, in_idx[8] = {0};
@@ -534,6 +546,11 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
           uint32_t pos = (inject || bridge) ? (bridge ? rng.below(2) : 0u) : rng.below(4);
           bit = pos & 1; bit2 = pos & 2;
           for (int i = 0; i < 32; ++i) in[i] = rf();          // free siblings (private data)
+          if (as_ops) {   // set_private_data: the three chunks other than pos, ascending (fill_sibling_data)
+            pdw_ids.push_back(next_npo_id);
+            for (uint32_t chunk = 0; chunk < 4; ++chunk)
+              if (chunk != pos) for (int i = 0; i < 8; ++i) pdw_sib.push_back(in[8 * chunk + i].to_canonical());
+          }
           if (ns) {
             // the leaf digest enters chunk pos from the bus
             load(2 * pos, pickp_noread());
@@ -559,7 +576,11 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
         for (int i = 0; i < 32; ++i) { w_inputs.push_back(in[i].to_canonical()); st[i] = in[i]; }
         p2w_permute<PP>(st, g_w32_rc, g_w32_diag);
         w_flags.push_back(ns); w_flags.push_back(merkle); w_flags.push_back(bit); w_flags.push_back(bit2);
-        w_sum.push_back(merkle ? acc : 0u);
+        w_sum.push_back(merkle && !as_ops ? acc : 0u);   // the executor's row carries no accumulator value
+        std::vector<uint32_t> ext(12 + 6, NO_W);         // [in0..7, mmcs_index_sum, bit, bit2, n_out, out0..5]
+        for (int l = 0; l < 8; ++l) if (in_ctl[l]) ext[l] = in_idx[l];
+        if (merkle) { ext[9] = bit ? ONE_W : ZERO_W; ext[10] = bit2 ? ONE_W : ZERO_W; }
+        ext[11] = 6;
         // preprocessed row
         for (int l = 0; l < 8; ++l) {
           w_prep.push_back(in_idx[l] * D);
@@ -572,6 +593,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
             E v; for (int d = 0; d < 4; ++d) v.c[d] = st[l * 4 + d];
             const uint32_t w = create(v);
             pickable.push_back(w);
+            ext[12 + l] = w;
             w_prep.push_back(w * D);
             w_out_fix.push_back({w_prep.size(), w});
             w_prep.push_back(0);
@@ -584,6 +606,7 @@ void generate(Workload& W, int log_h, uint64_t seed, int horner_chain_len, int s
         w_prep.push_back((merkle ? (bit2 ? ONE_W : ZERO_W) : 0u) * D);
         w_prep.push_back(ns);
         w_prep.push_back(merkle);
+        if (as_ops) push_op(C_P2W, next_npo_id++, 0, 0, 0, (ns ? 1u : 0u) | (merkle ? 2u : 0u), ext);
       }
     }
     W.arr["p2w_out_fix"].clear();
@@ -822,7 +845,8 @@ void* syn_generate(int field, int log_h, uint64_t seed, int horner_chain_len, in
                    int merkle_depth, const uint32_t* rc_canonical, uint32_t flags) {
   auto* W = new Workload();
   const uint32_t ext_degree = (flags >> 8) & 15u ? (flags >> 8) & 15u : 4u;
-  flags &= 0xFFu;
+  flags = (flags & 0xFFu) | (flags & SYN_P2_W32_OPS);
+  if (flags & SYN_P2_W32_OPS) flags |= SYN_P2_W32;
   try {
     if (ext_degree == 5 && field == 0) generate<KoalaBearParams, Fp5<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);
     else if (ext_degree == 1 && field == 0) generate<KoalaBearParams, Fp1<KoalaBearParams>>(*W, log_h, seed, horner_chain_len, sponge_chain_len, merkle_depth, rc_canonical, flags);

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define P3R_ABI_VERSION 7
+#define P3R_ABI_VERSION 8
 
 enum {
   P3R_OK = 0,
@@ -147,14 +147,17 @@ typedef struct p3r_config {
    *     conditions.  The preprocessed round is padded with zeros, not random values: its commitment
    *     depends on the circuit shape only.
    *   num_random_codewords: 0 selects 2 (the examples' value); 1..8.
-   *   zk_seed: seed of the random values (rng_seed).  They come from a counter-based generator keyed by (zk_seed, proofs
-   *     made so far by the ctx, round, matrix, cell) - csrc/zk_rand.h - so two proofs of one ctx differ (as the
-   *     RefCell<SmallRng> of the reference advances), and a fresh ctx with the same seed repeats the sequence
-   *     (p3r_zk_nonce / p3r_zk_set_nonce).  NOT a cryptographic generator (neither is SmallRng): a deployment that needs
-   *     the zero-knowledge property must supply an unpredictable seed per ctx. */
+   *   zk_key (ABI version 8; versions up to 7 had a 64-bit `zk_seed` here): 256-bit key of the random values - the
+   *     counterpart of HidingFriPcs's `rng: R`, which is the caller's to choose (common/mod.rs:536-542).  The values come
+   *     from a keyed counter-based generator, ChaCha with 8 rounds over (key, proofs made so far by the ctx, round,
+   *     matrix, cell), field elements by rejection sampling (csrc/zk_rand.h).  By default p3r_create mixes 128 bits of
+   *     operating-system entropy (getrandom) into the key: two contexts, or two runs, never mask different witnesses with
+   *     the same values, whatever the caller passes - an all-zero key is fine.  P3R_EXT_ZK_DETERMINISTIC in ext_choices
+   *     takes the key as it is and lets p3r_zk_set_nonce move the proof counter: reproducible proofs for tests and
+   *     replay, and NO hiding if a (key, nonce) pair is ever used for two witnesses. */
   uint32_t zk;
   uint32_t num_random_codewords;
-  uint64_t zk_seed;
+  uint32_t zk_key[8];
 } p3r_config;
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
@@ -166,6 +169,10 @@ typedef struct p3r_config {
  * p3r_prep_create / p3r_layer_create of a batch holding P3R_AIR_POSEIDON2_W32, p3r_verify_batch and p3r_mmcs_verify
  * refuse with P3R_EINVAL.  (The width-16 defaults are believed to be upstream's; the width-32 ones are known not to be.) */
 #define P3R_EXT_UNPINNED_W32_DEFAULTS 2u
+/* ABI version 8.  ZK: use p3r_config.zk_key as it is (no operating-system entropy mixed in) and allow p3r_zk_set_nonce:
+ * the proofs of a context are then a function of (key, nonce, inputs) - what the parity tests against the CPU oracle
+ * need, and what a deployment must NOT set (see zk_key). */
+#define P3R_EXT_ZK_DETERMINISTIC 4u
 
 typedef struct p3r_ctx p3r_ctx;
 typedef struct p3r_dmat p3r_dmat; /* device-resident matrix (power-of-two height) */
@@ -183,8 +190,9 @@ uint32_t p3r_poseidon2_num_constants(const p3r_ctx* ctx);
 /* The round constants in use (canonical, the flat layout of p3r_config.poseidon2_rc); `out` holds
  * p3r_poseidon2_num_constants values. */
 int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out);
-/* ABI version 7.  Proofs made so far under a ZK configuration (the state of the hiding PCS's RNG): read it, or set it
- * to replay / skip ahead (parity tests set it so that the CPU oracle can be given the same value). */
+/* ABI version 7.  Proofs made so far under a ZK configuration (the state of the hiding PCS's RNG): read it, or - under
+ * P3R_EXT_ZK_DETERMINISTIC only (ABI version 8; P3R_EINVAL otherwise: replaying a nonce repeats the masks) - set it to
+ * replay / skip ahead (parity tests set it so that the CPU oracle can be given the same value). */
 uint64_t p3r_zk_nonce(const p3r_ctx* ctx);
 int p3r_zk_set_nonce(p3r_ctx* ctx, uint64_t nonce);
 /* Blocks until all work queued on the ctx's stream has completed. */
@@ -541,7 +549,8 @@ int p3r_batch_stark_proof_parse(uint32_t field, const uint8_t* bytes, size_t len
  *                          (runner.rs:83-253) with the witness table and the Traces kept in HBM
  *   p3r_prove_next_layer== run + prove_all_tables
  * D = 4 (extension-field witnesses), Poseidon2 D4 width 16, Recompose without coefficient lookups:
- * the tables FriRecursionBackend registers (recursion/src/backend/fri.rs:693-721). */
+ * the tables FriRecursionBackend registers (recursion/src/backend/fri.rs:693-721) - and, since ABI version 8, the
+ * width-32 Poseidon2 table of a mixed-config verifier circuit (P3R_OP_POSEIDON2_W32_PERM). */
 #define P3R_NO_WITNESS 0xFFFFFFFFu
 
 enum p3r_op_kind {               /* circuit/src/ops/op.rs `Op`, AluOpKind */
@@ -562,7 +571,7 @@ enum p3r_op_kind {               /* circuit/src/ops/op.rs `Op`, AluOpKind */
                                     BABY_BEAR_D1_W16, one witness per state element, executor.rs:600-700):
                                     ext = [in0..in15, mmcs_index_sum, mmcs_bit, n_out (8 or 16), out0..],
                                     b = absorb_len (the sponge length tag) */
-  P3R_OP_RECOMPOSE = 10          /* a = NonPrimitiveOpId; out; ext = D coefficient witnesses
+  P3R_OP_RECOMPOSE = 10,         /* a = NonPrimitiveOpId; out; ext = D coefficient witnesses
                                     (circuit/src/ops/recompose.rs:115-170); aux = 0 (or P3R_NO_WITNESS): the `recompose` table,
                                     aux = 1: `recompose/coeff` (NpoTypeId::recompose_with_coeff_lookups,
                                     ops/npo.rs:48-60: every coefficient is a bus tuple too; a coefficient that is a
@@ -570,6 +579,22 @@ enum p3r_op_kind {               /* circuit/src/ops/op.rs `Op`, AluOpKind */
                                     multiplicity 0 - batch_stark_prover/recompose.rs:341-352).  A circuit may hold both kinds:
                                     the layer then proves two Recompose tables, `recompose` before `recompose/coeff`
                                     (p3r_layer_desc_counts.n_recompose_coeff). */
+  P3R_OP_POSEIDON2_W32_PERM = 11 /* ABI version 8.  A permutation of the width-32 table (`poseidon2_perm/<field>_d4_w32`, the arity-4
+                                    compression shape 4 * CAPACITY_EXT == WIDTH_EXT: eight input limbs, rate six, digests of two
+                                    limbs) in a D = 4 circuit - the MMCS rows of a verifier circuit built under `--arity4`
+                                    (recursion/examples/recursive_aggregation.rs:902-1046; W16 challenger rows stay
+                                    P3R_OP_POSEIDON2_PERM).  a = NonPrimitiveOpId; aux = flags (bit 0 new_start, bit 1
+                                    merkle_path); ext = [in0..in7, mmcs_index_sum (must be P3R_NO_WITNESS: the arity-4 table has
+                                    no index accumulator bus), mmcs_bit, mmcs_bit2, n_out (6 or 8), out0..].  Semantics of
+                                    PoseidonPermExecutor::execute for `is_arity4()` (circuit/src/ops/poseidon_perm/
+                                    executor.rs:92-235,290-303,493-561,947-966): a sponge row chains the whole previous normal
+                                    output and mirrors its own output into the Merkle chain state; a Merkle row places the
+                                    previous Merkle-state digest (output limbs 0, 1) into chunk pos = mmcs_bit + 2 * mmcs_bit2,
+                                    fills the other three chunks from its private data in ascending order, then overwrites
+                                    every limb that names a witness.  Both direction bits are required on a Merkle row.  The
+                                    preprocessed rows are Poseidon2PreprocessedRow<8, 6> (executor.rs:777-884: every named input
+                                    limb is a bus read, Merkle rows included; the accumulator slots carry the two bit
+                                    witnesses, both read). */
 };
 
 typedef struct p3r_op {
@@ -594,6 +619,12 @@ typedef struct p3r_circuit_inputs {
   size_t n_private_data;                 /* set_private_data: Poseidon2PermPrivateData { sibling } */
   const uint32_t* private_data_op_ids;   /* n_private_data NonPrimitiveOpIds */
   const uint32_t* private_data_siblings; /* n_private_data x 8: two extension limbs */
+  /* ABI version 8.  Private data of P3R_OP_POSEIDON2_W32_PERM Merkle rows: the three sibling digests of an arity-4
+   * level, chunk by chunk in ascending chunk order with the running-hash chunk skipped (fill_sibling_data,
+   * executor.rs:166-201).  An op id of the other width in either list is an error. */
+  size_t n_private_data_w32;
+  const uint32_t* private_data_w32_op_ids;   /* n_private_data_w32 NonPrimitiveOpIds */
+  const uint32_t* private_data_w32_siblings; /* n_private_data_w32 x 24: three chunks of two extension limbs */
 } p3r_circuit_inputs;
 
 typedef struct p3r_circuit p3r_circuit;
@@ -640,7 +671,10 @@ enum p3r_traces_array {
   P3R_TRACES_P2_FLAGS = 4,        /* n_p2 x 3: new_start, merkle_path, mmcs_bit */
   P3R_TRACES_P2_MMCS_INDEX_SUM = 5, /* n_p2 */
   P3R_TRACES_RECOMPOSE_VALUES = 6, /* n_recompose x D */
-  P3R_TRACES_RECOMPOSE_COEFF_VALUES = 7 /* n_recompose_coeff x D: the second Recompose table */
+  P3R_TRACES_RECOMPOSE_COEFF_VALUES = 7, /* n_recompose_coeff x D: the second Recompose table */
+  P3R_TRACES_P2W_INPUT_VALUES = 8,   /* n_p2w x 32 (ABI 8: rows of the width-32 Poseidon2 table) */
+  P3R_TRACES_P2W_FLAGS = 9,          /* n_p2w x 4: new_start, merkle_path, mmcs_bit, mmcs_bit2 */
+  P3R_TRACES_P2W_MMCS_INDEX_SUM = 10 /* n_p2w */
 };
 int p3r_dtraces_get(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces, uint32_t which,
                     uint32_t* out, size_t out_len);

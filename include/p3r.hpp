@@ -44,14 +44,16 @@ struct FriParams {
   // arity of the PCS's MMCS: 2 = MyMmcs (width-16 permutation), 4 = MyMmcsArity4 (width-32 permutation, W16 challenger:
   // recursion/examples/recursive_aggregation.rs:902-1046; cap_height must be 0)
   uint32_t mmcs_arity = 2;
-  // ZK: the PCS is HidingFriPcs with `num_random_codewords` random codewords and an RNG seeded with `zk_seed`
-  // (create_config_zk, recursion/examples/common/mod.rs:511-553: two codewords)
+  // ZK: the PCS is HidingFriPcs with `num_random_codewords` random codewords (create_config_zk,
+  // recursion/examples/common/mod.rs:511-553: two codewords); `zk_key` is the 256-bit key of its generator (the library
+  // mixes operating-system entropy into it unless `zk_deterministic` asks for reproducible proofs: tests, replay)
   // the library's built-in width-32 constants are self-generated (P3R_EXT_UNPINNED_W32_DEFAULTS, p3r.h): using the
   // arity-4 MMCS / the width-32 table without the caller's constants must be asked for
   bool allow_unpinned_w32_defaults = false;
   bool zk = false;
   uint32_t num_random_codewords = 2;
-  uint64_t zk_seed = 0;
+  std::array<uint32_t, 8> zk_key{};
+  bool zk_deterministic = false;
 };
 
 // ext_degree: the circuit extension degree of the traces - 4, or 5 for KoalaBear circuits over the quintic trinomial
@@ -72,7 +74,8 @@ inline p3r_config make_config(Field field, const FriParams& p, int device = 0, c
   if (p.allow_unpinned_w32_defaults) c.ext_choices |= P3R_EXT_UNPINNED_W32_DEFAULTS;
   c.zk = p.zk ? 1u : 0u;
   c.num_random_codewords = p.zk ? p.num_random_codewords : 0u;
-  c.zk_seed = p.zk_seed;
+  for (int i = 0; i < 8; ++i) c.zk_key[i] = p.zk_key[i];
+  if (p.zk_deterministic) c.ext_choices |= P3R_EXT_ZK_DETERMINISTIC;
   c.device = device;
   if (rc) { c.poseidon2_rc = rc->data(); c.poseidon2_rc_len = (uint32_t)rc->size(); }
   return c;
@@ -165,6 +168,8 @@ struct Circuit {  // flattened Circuit<EF>
 struct CircuitInputs {
   std::vector<uint32_t> public_values, private_values;                  // x D each (the context's ext_degree)
   std::vector<uint32_t> private_data_op_ids, private_data_siblings;     // siblings x 8
+  // private data of width-32 Merkle rows (P3R_OP_POSEIDON2_W32_PERM): three sibling digests, siblings x 24
+  std::vector<uint32_t> private_data_w32_op_ids, private_data_w32_siblings;
 };
 
 class CircuitProverData {
@@ -501,6 +506,10 @@ class PreparedCircuit {
     s.public_values = in.public_values.data(); s.private_values = in.private_values.data();
     s.n_private_data = in.private_data_op_ids.size(); s.private_data_op_ids = in.private_data_op_ids.data();
     s.private_data_siblings = in.private_data_siblings.data();
+    if (in.private_data_w32_siblings.size() != 24 * in.private_data_w32_op_ids.size())
+      throw Error(P3R_EINVAL, "private_data_w32_siblings must hold three digests of two extension limbs per op id");
+    s.n_private_data_w32 = in.private_data_w32_op_ids.size(); s.private_data_w32_op_ids = in.private_data_w32_op_ids.data();
+    s.private_data_w32_siblings = in.private_data_w32_siblings.data();
     return s;
   }
   const Context* ctx_;
@@ -673,6 +682,8 @@ inline CircuitInputs pack_aggregation_inputs(const CircuitInputs& l, const Circu
   o.private_values.insert(o.private_values.end(), r.private_values.begin(), r.private_values.end());
   for (uint32_t id : r.private_data_op_ids) o.private_data_op_ids.push_back(id + left_non_primitive_ops);
   o.private_data_siblings.insert(o.private_data_siblings.end(), r.private_data_siblings.begin(), r.private_data_siblings.end());
+  for (uint32_t id : r.private_data_w32_op_ids) o.private_data_w32_op_ids.push_back(id + left_non_primitive_ops);
+  o.private_data_w32_siblings.insert(o.private_data_w32_siblings.end(), r.private_data_w32_siblings.begin(), r.private_data_w32_siblings.end());
   return o;
 }
 // `prep_cache` is the reference's Option<&mut Option<AggregationPrepCache>>: null = no caching; an

@@ -35,7 +35,8 @@ int guard3(Fn&& fn) {
 
 template <class FP>
 void do_run(CircuitHandle& H, const uint32_t* rc, const uint32_t* pub, const uint32_t* priv, size_t n_pd,
-            const uint32_t* pd_ids, const uint32_t* pd_sib) {
+            const uint32_t* pd_ids, const uint32_t* pd_sib, const uint32_t* w32_rc = nullptr, const uint32_t* w32_diag = nullptr,
+            size_t n_pdw = 0, const uint32_t* pdw_ids = nullptr, const uint32_t* pdw_sib = nullptr) {
   using F = Fe<FP>;
   using E = Fe4<FP>;
   auto ef = [](const uint32_t* p) {
@@ -48,11 +49,19 @@ void do_run(CircuitHandle& H, const uint32_t* rc, const uint32_t* pub, const uin
   for (size_t i = 0; i < H.c.public_rows.size(); ++i) in.public_values.push_back(ef(pub + 4 * i));
   for (size_t i = 0; i < H.c.private_rows.size(); ++i) in.private_values.push_back(ef(priv + 4 * i));
   for (size_t i = 0; i < n_pd; ++i) in.private_data[pd_ids[i]] = {ef(pd_sib + 8 * i), ef(pd_sib + 8 * i + 4)};
-  auto T = run_circuit<FP>(H.c, p2, in);
+  for (size_t i = 0; i < n_pdw; ++i) {
+    std::array<E, 6> sib;
+    for (int l = 0; l < 6; ++l) sib[l] = ef(pdw_sib + 24 * i + 4 * l);
+    in.private_data_w32[pdw_ids[i]] = sib;
+  }
+  std::unique_ptr<Poseidon2W32<FP>> p2w;
+  if (w32_rc && w32_diag) p2w = std::make_unique<Poseidon2W32<FP>>(w32_rc, w32_diag);
+  auto T = run_circuit<FP>(H.c, p2, in, p2w.get());
   auto put_e = [](std::vector<uint32_t>& d, const E& e) { for (int i = 0; i < 4; ++i) d.push_back(e.c[i].v); };
   auto& A = H.arr;
   for (const char* k : {"witness", "const_values", "public_values", "alu_values", "p2_inputs", "p2_flags",
-                        "p2_mmcs_index_sum", "recompose_values", "recompose_coeff_values"}) A[k].clear();
+                        "p2_mmcs_index_sum", "recompose_values", "recompose_coeff_values", "p2w_inputs", "p2w_flags",
+                        "p2w_mmcs_index_sum"}) A[k].clear();
   for (auto& e : T.witness) put_e(A["witness"], e);
   for (auto& e : T.const_values) put_e(A["const_values"], e);
   for (auto& e : T.public_values) put_e(A["public_values"], e);
@@ -61,6 +70,11 @@ void do_run(CircuitHandle& H, const uint32_t* rc, const uint32_t* pub, const uin
     for (auto x : r.input) A["p2_inputs"].push_back(x.v);
     A["p2_flags"].insert(A["p2_flags"].end(), {r.new_start, r.merkle_path, r.mmcs_bit, r.mmcs_ctl_enabled});
     A["p2_mmcs_index_sum"].push_back(r.mmcs_index_sum.v);
+  }
+  for (auto& r : T.p2w_rows) {
+    for (auto x : r.input) A["p2w_inputs"].push_back(x.v);
+    A["p2w_flags"].insert(A["p2w_flags"].end(), {r.new_start, r.merkle_path, r.mmcs_bit, r.mmcs_bit2});
+    A["p2w_mmcs_index_sum"].push_back(r.mmcs_index_sum.v);
   }
   for (auto& r : T.recompose_values) for (auto x : r) A["recompose_values"].push_back(x.v);
   for (auto& r : T.recompose_coeff_values) for (auto x : r) A["recompose_coeff_values"].push_back(x.v);
@@ -98,6 +112,7 @@ int orc_circuit_preprocess(void* h, uint32_t modulus, int D) {
     A["const_prep"] = cp.const_prep; A["public_prep"] = cp.public_prep; A["alu_prep13"] = cp.alu_prep13;
     A["p2_prep_rows"] = cp.p2_rows; A["recompose_prep"] = cp.recompose_prep; A["ext_reads"] = cp.ext_reads;
     A["recompose_coeff_prep"] = cp.recompose_coeff_prep;
+    A["p2w_rows_raw"] = pp.p2w_rows; A["p2w_prep"] = cp.p2w_rows;
     for (const char* k : {"p2_in_ctl", "p2_input_indices", "p2_out_ctl", "p2_output_indices",
                           "p2_mmcs_index_sum_idx", "p2_prep_flags"}) A[k].clear();
     const uint32_t d = (uint32_t)D;
@@ -118,6 +133,22 @@ int orc_circuit_run(void* h, int field, const uint32_t* rc, const uint32_t* publ
     auto& H = *static_cast<CircuitHandle*>(h);
     if (field == 0) do_run<KoalaBear>(H, rc, public_values, private_values, n_private_data, pd_op_ids, pd_siblings);
     else if (field == 1) do_run<BabyBear>(H, rc, public_values, private_values, n_private_data, pd_op_ids, pd_siblings);
+    else throw std::runtime_error("unknown field id");
+  });
+}
+
+// the same for a circuit that holds width-32 Poseidon2 ops (COP_P2W): the constants of the width-32 permutation and the
+// private data of its Merkle rows (24 values = three sibling digests per op id)
+int orc_circuit_run_w32(void* h, int field, const uint32_t* rc, const uint32_t* w32_rc, const uint32_t* w32_diag,
+                        const uint32_t* public_values, const uint32_t* private_values, size_t n_private_data,
+                        const uint32_t* pd_op_ids, const uint32_t* pd_siblings, size_t n_private_data_w32,
+                        const uint32_t* pdw_op_ids, const uint32_t* pdw_siblings) {
+  return guard3([&] {
+    auto& H = *static_cast<CircuitHandle*>(h);
+    if (field == 0) do_run<KoalaBear>(H, rc, public_values, private_values, n_private_data, pd_op_ids, pd_siblings, w32_rc, w32_diag,
+                                      n_private_data_w32, pdw_op_ids, pdw_siblings);
+    else if (field == 1) do_run<BabyBear>(H, rc, public_values, private_values, n_private_data, pd_op_ids, pd_siblings, w32_rc, w32_diag,
+                                          n_private_data_w32, pdw_op_ids, pdw_siblings);
     else throw std::runtime_error("unknown field id");
   });
 }

@@ -66,7 +66,8 @@ typedef struct orc_params {
   uint32_t mmcs_arity;        // 0 / 2: binary trees over the width-16 permutation; 4: the arity-4 MMCS (width 32)
   // ZK: HidingFriPcs (create_config_zk, recursion/examples/common/mod.rs:511-553); twins of p3r_config.zk*
   uint32_t zk, num_random_codewords;
-  uint64_t zk_seed, zk_nonce;
+  uint32_t zk_key[8];   // p3r_config.zk_key, taken as it is (the P3R_EXT_ZK_DETERMINISTIC reading)
+  uint64_t zk_nonce;
   // proof-of-work witnesses to use instead of the smallest ones, in grind order (commit phases, then queries); canonical
   uint32_t n_forced_pow;
   uint32_t forced_pow[40];
@@ -114,7 +115,8 @@ StarkParams to_sp(const orc_params& p) {
   s.zk = p.zk != 0;
   s.num_random_codewords = p.zk ? (p.num_random_codewords ? (int)p.num_random_codewords : 2) : 0;
   if (s.zk && (s.num_random_codewords < 1 || s.num_random_codewords > 8)) throw std::runtime_error("num_random_codewords must be in 1..8");
-  s.zk_seed = p.zk_seed; s.zk_nonce = p.zk_nonce;
+  for (int i = 0; i < 8; ++i) s.zk_key[i] = p.zk_key[i];
+  s.zk_nonce = p.zk_nonce;
   for (uint32_t i = 0; i < p.n_forced_pow && i < 40; ++i) s.forced_pow.push_back(p.forced_pow[i]);
   for (uint32_t i = 0; i < p.n_fri_log_arities && i < 32; ++i) s.fri_log_arities.push_back(p.fri_log_arities[i]);
   return s;

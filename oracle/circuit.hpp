@@ -8,7 +8,10 @@
 //   recompose_preprocess_for_op     circuit-prover/src/batch_stark_prover/recompose.rs:294-358
 //   get_airs_and_degrees_with_prep  circuit-prover/src/common.rs:127-390 (primitive-table part)
 //   CircuitRunner::{execute_all, run} circuit/src/tables/runner.rs:195-510
-//   PoseidonPermExecutor::execute   circuit/src/ops/poseidon_perm/executor.rs:921-972 (+ helpers :103-520)
+//   PoseidonPermExecutor::execute   circuit/src/ops/poseidon_perm/executor.rs:921-972 (+ helpers :103-520); the arity-4
+//                                   shape of the width-32 table (COP_P2W): is_arity4 :92-95, place_arity4_running_hash
+//                                   :141-160, fill_sibling_data :166-201, resolve_mmcs_bit2 :290-303, update_chain_state
+//                                   :462-491, validate_ext_inputs :493-545, preprocess_* :770-893
 //   RecomposeExecutor::execute      circuit/src/ops/recompose.rs:115-170
 //   Ext/BinaryDecompositionHint     circuit/src/builder/circuit_builder.rs:1659-1810
 //
@@ -31,7 +34,10 @@ namespace orc {
 constexpr uint32_t NO_W = 0xFFFFFFFFu;
 enum : uint32_t {
   COP_CONST = 0, COP_PUBLIC = 1, COP_ADD = 2, COP_MUL = 3, COP_BOOL = 4, COP_MULADD = 5, COP_HORNER = 6,
-  COP_HINT_EXT = 7, COP_HINT_BIN = 8, COP_P2 = 9, COP_RECOMPOSE = 10
+  COP_HINT_EXT = 7, COP_HINT_BIN = 8, COP_P2 = 9, COP_RECOMPOSE = 10,
+  // a permutation of the width-32 table (D4_W32: width_ext 8, rate_ext 6, capacity_ext 2 - the arity-4 compression shape):
+  // ext = [in0..in7, mmcs_index_sum, mmcs_bit, mmcs_bit2, n_out, out0..]
+  COP_P2W = 11
 };
 inline bool is_alu(uint32_t k) { return k >= COP_ADD && k <= COP_HORNER; }
 
@@ -62,7 +68,8 @@ struct Preprocessed {
   // (ops/recompose.rs:174-192) - a separate op type, hence a separate table and a separate duplicate map
   std::vector<uint32_t> recompose_coeff;
   std::vector<uint32_t> ext_reads;
-  std::vector<bool> dup_p2, dup_recompose, dup_recompose_coeff;  // dup_npo_outputs[op_type][wid]
+  std::vector<uint32_t> p2w_rows;    // non_primitive[poseidon2_perm/.._d4_w32]: 48 values per op
+  std::vector<bool> dup_p2, dup_recompose, dup_recompose_coeff, dup_p2w;  // dup_npo_outputs[op_type][wid]
   std::set<uint32_t> hint_output_wids;
   uint32_t idx(uint32_t wid) const { return (uint32_t)(((uint64_t)wid * (uint64_t)D) % P); }  // base_field_index
   void read(uint32_t wid) {  // increment_ext_reads
@@ -167,6 +174,53 @@ inline Preprocessed generate_preprocessed_columns(const CircuitDesc& c, uint32_t
         }
         break;
       }
+      case COP_P2W: {
+        // executor.rs:770-893 for is_arity4_shape(): 8 x [idx, in_ctl, normal_chain_sel, merkle_chain_sel] where EVERY named
+        // limb is a witness read (Merkle rows included: their AIR sends a bare in_ctl), 6 x [out idx, out_ctl], then on a
+        // Merkle row the witness indices of the two direction bits (both read) in the accumulator / flag slots
+        const uint32_t* e = c.ext_of(op);
+        if (D != 4) throw std::runtime_error("width-32 poseidon2 op: D = 4 circuits only");
+        if (op.ext_len < 12) throw std::runtime_error("width-32 poseidon2 op: ext too short");
+        const uint32_t n_out = e[11];
+        if ((n_out != 6 && n_out != 8) || op.ext_len != 12 + n_out) throw std::runtime_error("width-32 poseidon2 op: bad output count");
+        const bool new_start = op.aux & 1, merkle = (op.aux >> 1) & 1;
+        if (e[8] != NO_W) throw std::runtime_error("width-32 poseidon2 op: mmcs_index_sum is not supported on this table");
+        if (merkle && (e[9] == NO_W || e[10] == NO_W)) throw std::runtime_error("width-32 poseidon2 op: a Merkle row needs both direction bits");
+        if (!merkle && (e[9] != NO_W || e[10] != NO_W)) throw std::runtime_error("width-32 poseidon2 op: a direction bit on a sponge row");
+        for (int l = 0; l < 8; ++l) {
+          const bool empty = e[l] == NO_W;
+          if (empty) { pp.p2w_rows.push_back(0); pp.p2w_rows.push_back(0); }
+          else { pp.p2w_rows.push_back(pp.idx(e[l])); pp.read(e[l]); pp.p2w_rows.push_back(1); }
+          pp.p2w_rows.push_back(!new_start && !merkle && empty);
+          pp.p2w_rows.push_back(!new_start && merkle && empty);
+        }
+        for (int l = 0; l < 6; ++l) {
+          const uint32_t w = e[12 + l];
+          if (w == NO_W) { pp.p2w_rows.push_back(0); pp.p2w_rows.push_back(0); }
+          else { pp.p2w_rows.push_back(pp.idx(w)); pp.p2w_rows.push_back(1); }
+        }
+        if (merkle) {
+          pp.p2w_rows.push_back(pp.idx(e[9])); pp.read(e[9]);
+          pp.p2w_rows.push_back(pp.idx(e[10])); pp.read(e[10]);
+        } else {
+          pp.p2w_rows.push_back(0);   // no mmcs_index_sum witness
+          pp.p2w_rows.push_back(0);   // mmcs_merkle_flag = ctl && merkle
+        }
+        pp.p2w_rows.push_back(new_start);
+        pp.p2w_rows.push_back(merkle);
+        for (int l = 0; l < 6; ++l) {   // circuit.rs:464-491 over the num_exposed_outputs() = rate_ext outputs
+          const uint32_t w = e[12 + l];
+          if (w == NO_W) continue;
+          if (is_def(w)) {
+            if (w >= pp.dup_p2w.size()) pp.dup_p2w.resize((size_t)w + 1, false);
+            pp.dup_p2w[w] = true;
+            pp.read(w);
+          } else {
+            define(w);
+          }
+        }
+        break;
+      }
       case COP_RECOMPOSE: {
         if (op.ext_len != 4) throw std::runtime_error("recompose op: needs 4 coefficient witnesses");
         const bool coeff = op.aux == 1;
@@ -207,6 +261,7 @@ struct CircuitPrep {
   std::vector<uint32_t> recompose_coeff_prep;
   bool recompose_coeff_only = false;
   std::vector<uint32_t> p2_rows;  // 24 per row, out_ctl replaced by the multiplicity
+  std::vector<uint32_t> p2w_rows; // 48 per row (the width-32 table), out_ctl replaced by the multiplicity
   std::vector<uint32_t> ext_reads;
 };
 
@@ -237,6 +292,16 @@ inline CircuitPrep get_airs_and_degrees_with_prep(Preprocessed pp) {
       if (!ctl) continue;
       const uint32_t wid = out.p2_rows[r * 24 + 16 + 2 * j] / D;
       const bool dup = wid < pp.dup_p2.size() && pp.dup_p2[wid];
+      ctl = dup ? neg1 : reads(wid);
+    }
+  // the width-32 table: phase 1 skips the arity-4 op types (batch_stark_prover.rs:121-127), phase 2 is the same
+  out.p2w_rows = pp.p2w_rows;
+  for (size_t r = 0; r < out.p2w_rows.size() / 48; ++r)
+    for (int j = 0; j < 6; ++j) {
+      uint32_t& ctl = out.p2w_rows[r * 48 + 33 + 2 * j];
+      if (!ctl) continue;
+      const uint32_t wid = out.p2w_rows[r * 48 + 32 + 2 * j] / D;
+      const bool dup = wid < pp.dup_p2w.size() && pp.dup_p2w[wid];
       ctl = dup ? neg1 : reads(wid);
     }
   // ---- recompose_preprocess_for_op (recompose.rs:294-358)
@@ -286,6 +351,7 @@ template <class FP>
 struct RunInputs {
   std::vector<Fe4<FP>> public_values, private_values;
   std::map<uint32_t, std::array<Fe4<FP>, 2>> private_data;  // NonPrimitiveOpId -> sibling limbs
+  std::map<uint32_t, std::array<Fe4<FP>, 6>> private_data_w32;  // width-32 Merkle rows: three sibling digests
 };
 
 template <class FP>
@@ -297,13 +363,16 @@ struct RunTraces {
   std::vector<std::array<E, 4>> alu_values;  // a, b, c, out
   struct P2Row { bool new_start, merkle_path, mmcs_bit, mmcs_ctl_enabled; F mmcs_index_sum; std::array<F, 16> input; };
   std::vector<P2Row> p2_rows;
+  struct P2WRow { bool new_start, merkle_path, mmcs_bit, mmcs_bit2; F mmcs_index_sum; std::array<F, 32> input; };
+  std::vector<P2WRow> p2w_rows;
   std::vector<std::array<F, 4>> recompose_values;
   std::vector<std::array<F, 4>> recompose_coeff_values;   // rows of the ops with aux = 1 when the circuit has both kinds
 };
 
 // CircuitRunner::run (runner.rs:195-253) for D = 4.
+// p2w: the width-32 permutation (needed only by a circuit that holds COP_P2W ops)
 template <class FP>
-RunTraces<FP> run_circuit(const CircuitDesc& c, const Poseidon2<FP>& p2, const RunInputs<FP>& in) {
+RunTraces<FP> run_circuit(const CircuitDesc& c, const Poseidon2<FP>& p2, const RunInputs<FP>& in, const Poseidon2W32<FP>* p2w = nullptr) {
   using F = Fe<FP>;
   using E = Fe4<FP>;
   RunTraces<FP> T;
@@ -331,6 +400,9 @@ RunTraces<FP> run_circuit(const CircuitDesc& c, const Poseidon2<FP>& p2, const R
 
   bool have_normal = false, have_merkle = false;
   std::array<E, 4> last_normal{}, last_merkle{};
+  // PoseidonExecutionState is per op type: the width-32 table has its own chain state
+  bool w_have_normal = false, w_have_merkle = false;
+  std::array<E, 8> w_last_normal{}, w_last_merkle{};
   for (auto& op : c.ops) {
     switch (op.kind) {
       case COP_CONST: {
@@ -457,6 +529,64 @@ RunTraces<FP> run_circuit(const CircuitDesc& c, const Poseidon2<FP>& p2, const R
         if (merkle) { last_merkle = outv; have_merkle = true; }
         else { last_normal = outv; have_normal = true; }
         T.p2_rows.push_back(row);
+        break;
+      }
+      case COP_P2W: {
+        if (!p2w) throw std::runtime_error("the circuit holds width-32 Poseidon2 ops: the width-32 permutation is needed");
+        const uint32_t* e = c.ext_of(op);
+        const uint32_t n_out = e[11];
+        const bool new_start = op.aux & 1, merkle = (op.aux >> 1) & 1;
+        auto pd = in.private_data_w32.find(op.a);
+        if (pd != in.private_data_w32.end() && !merkle)
+          throw std::runtime_error("IncorrectNonPrimitiveOpPrivateData: private data provided for non-Merkle operation");
+        auto boolean = [&](uint32_t wid, const char* label) {   // resolve_boolean_witness (:305-338)
+          if (wid == NO_W) {
+            if (merkle) throw std::runtime_error(std::string("IncorrectNonPrimitiveOpPrivateData: ") + label + " must be provided when merkle_path=true");
+            return false;
+          }
+          const E v = get(wid);
+          if (v == E::zero()) return false;
+          if (v == E::one()) return true;
+          throw std::runtime_error(std::string("IncorrectNonPrimitiveOpPrivateData: boolean ") + label + " (0 or 1)");
+        };
+        const bool bit = boolean(e[9], "mmcs_bit"), bit2 = boolean(e[10], "mmcs_bit2");
+        const int pos = (int)bit + 2 * (int)bit2;
+        // init_chain_state (:103-139): a Merkle row of the arity-4 shape starts from zeros ...
+        std::array<E, 8> st{};
+        const bool have_prev = merkle ? w_have_merkle : w_have_normal;
+        if (!new_start) {
+          if (!have_prev) throw std::runtime_error("Poseidon2ChainMissingPreviousState");
+          if (!merkle) st = w_last_normal;
+        }
+        // ... and place_arity4_running_hash (:141-160) writes the previous digest (capacity_ext = 2 limbs) into chunk pos
+        if (merkle && !new_start) { st[2 * pos] = w_last_merkle[0]; st[2 * pos + 1] = w_last_merkle[1]; }
+        // fill_sibling_data (:166-201): the chunks other than pos, ascending
+        if (merkle && pd != in.private_data_w32.end()) {
+          int written = 0;
+          for (int chunk = 0; chunk < 4; ++chunk) {
+            if (chunk == pos) continue;
+            st[2 * chunk] = pd->second[written]; st[2 * chunk + 1] = pd->second[written + 1];
+            written += 2;
+          }
+        }
+        // apply_witness_values (:207-219); no swap on this shape (:227-234)
+        for (int l = 0; l < 8; ++l)
+          if (e[l] != NO_W) st[l] = get(e[l]);
+        typename RunTraces<FP>::P2WRow row{};
+        row.new_start = new_start; row.merkle_path = merkle; row.mmcs_bit = bit; row.mmcs_bit2 = bit2;
+        row.mmcs_index_sum = F(0);   // inputs[width_ext] is empty (build_trace_row :389-397)
+        for (int l = 0; l < 8; ++l)
+          for (int k = 0; k < 4; ++k) row.input[l * 4 + k] = st[l].c[k];
+        std::array<F, 32> state = row.input;
+        p2w->permute(state);
+        std::array<E, 8> outv;
+        for (int l = 0; l < 8; ++l) outv[l] = E(state[l * 4], state[l * 4 + 1], state[l * 4 + 2], state[l * 4 + 3]);
+        for (uint32_t l = 0; l < n_out; ++l)
+          if (e[12 + l] != NO_W) put(e[12 + l], outv[l]);
+        // update_chain_state (:462-491): a sponge row of the arity-4 shape seeds the Merkle chain too
+        if (merkle) { w_last_merkle = outv; w_have_merkle = true; }
+        else { w_last_normal = outv; w_have_normal = true; w_last_merkle = outv; w_have_merkle = true; }
+        T.p2w_rows.push_back(row);
         break;
       }
       case COP_RECOMPOSE: {

@@ -44,24 +44,59 @@ struct StarkParams {
   std::vector<uint32_t> forced_pow;   // proof-of-work witnesses to use instead of the smallest ones (Challenger::forced)
   bool zk = false;
   int num_random_codewords = 2;
-  uint64_t zk_seed = 0;    // SmallRng::seed_from_u64(rng_seed)'s counterpart
+  std::array<uint32_t, 8> zk_key{};   // the key of the hiding PCS's generator (`rng: R`'s counterpart; p3r_config.zk_key taken as it is)
   uint64_t zk_nonce = 0;   // proofs made so far under this configuration (the PCS's RNG state advances per commit)
 };
 
 // ------------------------------------------------------------------ ZK randomness
-// Counter-based generator shared with the device (csrc/zk_rand.h): cell `idx` of stream `stream` of proof `nonce`.
-// Streams: (round << 20) | matrix, rounds 0 random, 1 main, 2 quotient, 4 permutation, 5 quotient masks.
-inline uint64_t zk_mix64(uint64_t z) {
-  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-  z ^= z >> 27; z *= 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return z;
-}
-inline uint64_t zk_stream_key(uint64_t seed, uint64_t nonce, uint32_t stream) {
-  return zk_mix64(seed ^ zk_mix64(nonce * 0x9E3779B97F4A7C15ull + (uint64_t)stream + 1));
+// Keyed counter-based generator shared with the device (csrc/zk_rand.h is the device's statement of it): ChaCha with 8
+// rounds (RFC 8439's block function with four double rounds) under a 256-bit key; input words 12..15 of a block are
+// [counter, stream, nonce_lo, nonce_hi], nonce = proofs made so far.  Streams: (round << 20) | matrix, rounds 0 random,
+// 1 main, 2 quotient, 4 permutation, 5 quotient masks.  Cell idx of a stream: rejection sampling on 31-bit words -
+// words 2j, 2j + 1 (j = idx mod 8) of block idx / 8, then the words of fallback blocks
+// [idx mod 2^32, stream | f << 24 | (idx >> 32) << 27], f = 1..7, the first value below p.
+struct ZkStream {
+  std::array<uint32_t, 8> key{};
+  uint64_t nonce = 0;
+  uint32_t stream = 0;
+};
+inline std::array<uint32_t, 16> zk_chacha8(const std::array<uint32_t, 8>& key, uint32_t w12, uint32_t w13, uint64_t nonce) {
+  std::array<uint32_t, 16> in = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+  for (int i = 0; i < 8; ++i) in[4 + i] = key[i];
+  in[12] = w12; in[13] = w13; in[14] = (uint32_t)nonce; in[15] = (uint32_t)(nonce >> 32);
+  std::array<uint32_t, 16> x = in;
+  auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+  auto quarter = [&](int a, int b, int c, int d) {
+    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+    x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+    x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+  };
+  for (int dr = 0; dr < 4; ++dr) {
+    for (int c = 0; c < 4; ++c) quarter(c, 4 + c, 8 + c, 12 + c);                                   // columns
+    for (int c = 0; c < 4; ++c) quarter(c, 4 + (c + 1) % 4, 8 + (c + 2) % 4, 12 + (c + 3) % 4);     // diagonals
+  }
+  for (int i = 0; i < 16; ++i) x[i] += in[i];
+  return x;
 }
 template <class FP>
-Fe<FP> zk_rand(uint64_t key, uint64_t idx) { return Fe<FP>(zk_mix64(key + idx * 0x9E3779B97F4A7C15ull) % FP::P); }
+Fe<FP> zk_rand(const ZkStream& s, uint64_t idx) {
+  const auto first = zk_chacha8(s.key, (uint32_t)(idx >> 3), s.stream, s.nonce);
+  const size_t j = idx & 7;
+  for (size_t t = 0; t < 2; ++t) {
+    const uint32_t v = first[2 * j + t] & 0x7FFFFFFFu;
+    if (v < FP::P) return Fe<FP>(v);
+  }
+  uint32_t last = 0;
+  for (uint32_t f = 1; f <= 7; ++f) {
+    const auto more = zk_chacha8(s.key, (uint32_t)idx, s.stream | (f << 24) | ((uint32_t)(idx >> 32) << 27), s.nonce);
+    for (uint32_t w : more) {
+      last = w & 0x7FFFFFFFu;
+      if (last < FP::P) return Fe<FP>(last);
+    }
+  }
+  return Fe<FP>(last % FP::P);
+}
 enum { ZK_ROUND_RANDOM = 0, ZK_ROUND_MAIN = 1, ZK_ROUND_QUOTIENT = 2, ZK_ROUND_PREP = 3, ZK_ROUND_PERM = 4, ZK_ROUND_QMASK = 5 };
 inline uint32_t zk_stream(int round, size_t mat) { return ((uint32_t)round << 20) | (uint32_t)mat; }
 
@@ -334,7 +369,7 @@ Committed<FP> commit_ldes(const Poseidon2<FP>& p2, std::vector<Matrix<FP>> ldes,
 // columns are the random codewords FRI batches in.  zero_fill: the preprocessed round (public data, committed once
 // per circuit shape: its padding is zeros so that the commitment does not depend on the seed).
 template <class FP>
-Matrix<FP> zk_randomize(const Matrix<FP>& m, int R, uint64_t key, bool zero_fill) {
+Matrix<FP> zk_randomize(const Matrix<FP>& m, int R, const ZkStream& key, bool zero_fill) {
   using F = Fe<FP>;
   const size_t w2 = m.w + (size_t)R;
   Matrix<FP> o(2 * m.h, w2);
@@ -359,7 +394,7 @@ ProverData<FP> make_prover_data(const Poseidon2<FP>& p2, const StarkParams& sp,
   ProverData<FP> pd;
   std::vector<Matrix<FP>> ldes;
   for (auto& in : insts) {
-    pd.evals.push_back(sp.zk ? zk_randomize<FP>(in.prep, sp.num_random_codewords, 0, true) : in.prep);
+    pd.evals.push_back(sp.zk ? zk_randomize<FP>(in.prep, sp.num_random_codewords, ZkStream{}, true) : in.prep);
     ldes.push_back(coset_lde_bitrev<FP>(pd.evals.back(), sp.log_blowup, Fe<FP>::generator()));
   }
   pd.prep = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity);
@@ -514,7 +549,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   const F gen = F::generator();
   const int zk = sp.zk ? 1 : 0, R = zk ? sp.num_random_codewords : 0;
   const int DC = EF::deg();
-  auto key = [&](int round, size_t mat) { return zk_stream_key(sp.zk_seed, sp.zk_nonce, zk_stream(round, mat)); };
+  auto key = [&](int round, size_t mat) { return ZkStream{sp.zk_key, sp.zk_nonce, zk_stream(round, mat)}; };
   BatchProof<FP> proof;
   Challenger<FP> ch(&p2);
   if (!sp.forced_pow.empty()) ch.forced = &sp.forced_pow;
@@ -700,7 +735,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
       }
       std::vector<Matrix<FP>> tU(C, Matrix<FP>(n, DC));   // t_c over U
       for (int c = 0; c + 1 < C; ++c) {
-        const uint64_t tk = key(ZK_ROUND_QMASK, q_chunk_evals.size() + c);
+        const ZkStream tk = key(ZK_ROUND_QMASK, q_chunk_evals.size() + c);
         for (size_t r = 0; r < n; ++r)
           for (int k = 0; k < DC; ++k) tU[c].at(r, k) = zk_rand<FP>(tk, r * DC + k);
       }
@@ -712,7 +747,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
           tU[C - 1].at(r, k) = acc * neg_inv_last;
         }
       for (int c = 0; c < C; ++c) {
-        const uint64_t ck = key(ZK_ROUND_QUOTIENT, q_chunk_evals.size() + c);
+        const ZkStream ck = key(ZK_ROUND_QUOTIENT, q_chunk_evals.size() + c);
         const size_t w2 = (size_t)DC + R;
         Matrix<FP> m(2 * n, w2);
         for (int k = 0; k < DC; ++k) {
@@ -748,7 +783,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   if (zk) {
     std::vector<Matrix<FP>> ldes;
     for (size_t i = 0; i < ni; ++i) {
-      const uint64_t rk = key(ZK_ROUND_RANDOM, i);
+      const ZkStream rk = key(ZK_ROUND_RANDOM, i);
       const size_t w2 = (size_t)DC + R, h2 = insts[i].main.h * 2;
       rand_ev[i] = Matrix<FP>(h2, w2);
       for (size_t r = 0; r < h2; ++r)

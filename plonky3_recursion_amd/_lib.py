@@ -9,9 +9,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # P3R_LIB_PATH: A/B runs of two builds of the library on one box (development only)
 LIB_PATH = os.environ.get("P3R_LIB_PATH") or os.path.join(_HERE, "libp3r_hip.so")
 
-P3R_ABI_VERSION = 7
+P3R_ABI_VERSION = 8
 P3R_EXT_LOOKUP_UNPACKED = 1
 P3R_EXT_UNPINNED_W32_DEFAULTS = 2   # the built-in width-32 constants are self-generated: using them is an explicit choice (p3r.h)
+P3R_EXT_ZK_DETERMINISTIC = 4        # ZK key taken as it is, p3r_zk_set_nonce allowed: reproducible proofs (tests, replay)
 FIELD_KOALA_BEAR = 0
 FIELD_BABY_BEAR = 1
 
@@ -41,7 +42,7 @@ class P3rConfig(C.Structure):
         ("poseidon2_w32_diag", C.POINTER(C.c_uint32)),
         ("mmcs_arity", C.c_uint32),   # 0 / 2: binary MMCS over the width-16 permutation; 4: the arity-4 MMCS (width 32)
         # ABI 7: ZK = HidingFriPcs (create_config_zk, recursion/examples/common/mod.rs:511-553)
-        ("zk", C.c_uint32), ("num_random_codewords", C.c_uint32), ("zk_seed", C.c_uint64),
+        ("zk", C.c_uint32), ("num_random_codewords", C.c_uint32), ("zk_key", C.c_uint32 * 8),
     ]
 
 
@@ -132,6 +133,9 @@ class P3rCircuitInputs(C.Structure):
         ("public_values", C.POINTER(C.c_uint32)), ("private_values", C.POINTER(C.c_uint32)),
         ("n_private_data", C.c_size_t), ("private_data_op_ids", C.POINTER(C.c_uint32)),
         ("private_data_siblings", C.POINTER(C.c_uint32)),
+        # ABI 8: private data of the width-32 Merkle rows (three sibling digests = 24 values per op id)
+        ("n_private_data_w32", C.c_size_t), ("private_data_w32_op_ids", C.POINTER(C.c_uint32)),
+        ("private_data_w32_siblings", C.POINTER(C.c_uint32)),
     ]
 
 

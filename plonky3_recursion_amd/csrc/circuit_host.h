@@ -29,7 +29,12 @@ struct CircuitTables {
   std::vector<uint8_t> p2_new_start, p2_merkle_path, p2_mmcs_ctl_enabled, p2_in_ctl;
   std::vector<uint32_t> p2_input_indices, p2_out_ctl, p2_output_indices, p2_mmcs_index_sum_idx;
   std::vector<uint8_t> p2_absorb_len;   // base-mode rows (circuits of degree 1 / 5)
+  // rows of the width-32 table (P3R_OP_POSEIDON2_W32_PERM), assembled: Poseidon2PreprocessedRow<8, 6>, 48 columns
+  std::vector<uint32_t> p2w_prep;
 };
+
+// ext layout of a width-32 permutation op: [in0..in7, mmcs_index_sum, mmcs_bit, mmcs_bit2, n_out, out0..]
+constexpr uint32_t kW32In = 8, kW32Rate = 6, kW32IdxSlot = 8, kW32BitSlot = 9, kW32Bit2Slot = 10, kW32NOutSlot = 11, kW32Hdr = 12;
 
 // Recompose ops come in two kinds: "recompose" (aux = 0) and "recompose/coeff" (aux = 1:
 // NpoTypeId::recompose_with_coeff_lookups, circuit/src/ops/npo.rs:48-60).  Each kind is its own table
@@ -119,6 +124,22 @@ inline void validate_circuit(const HostCircuit& c, uint32_t D = 4) {
         if (op.a >= c.ops.size()) fail(P3R_EINVAL, "op %zu: NonPrimitiveOpId(%u) out of range", i, op.a);
         break;
       }
+      case P3R_OP_POSEIDON2_W32_PERM: {
+        // validate_ext_inputs / validate_ext_outputs for the arity-4 shape (executor.rs:493-577)
+        if (D != 4) fail(P3R_EUNSUPPORTED, "op %zu: the width-32 Poseidon2 table belongs to D = 4 circuits", i);
+        if (op.ext_len < kW32Hdr || (e[kW32NOutSlot] != kW32Rate && e[kW32NOutSlot] != kW32In) || op.ext_len != kW32Hdr + e[kW32NOutSlot])
+          fail(P3R_EINVAL, "op %zu: width-32 Poseidon2 perm expects 8 input limbs, mmcs_index_sum, mmcs_bit, mmcs_bit2 and 6 or 8 outputs", i);
+        for (uint32_t k = 0; k < kW32NOutSlot; ++k) opt(e[k], i, "poseidon2 input");
+        for (uint32_t k = 0; k < e[kW32NOutSlot]; ++k) opt(e[kW32Hdr + k], i, "poseidon2 output");
+        if (e[kW32IdxSlot] != kNoW)
+          fail(P3R_EUNSUPPORTED, "op %zu: mmcs_index_sum on a width-32 row (the arity-4 table has no index accumulator bus)", i);
+        if ((op.aux & 2) && e[kW32BitSlot] == kNoW) fail(P3R_EINVAL, "op %zu: mmcs_bit must be provided when merkle_path=true", i);
+        if ((op.aux & 2) && e[kW32Bit2Slot] == kNoW) fail(P3R_EINVAL, "op %zu: mmcs_bit2 must be provided when merkle_path=true", i);
+        if (!(op.aux & 2) && (e[kW32BitSlot] != kNoW || e[kW32Bit2Slot] != kNoW))
+          fail(P3R_EUNSUPPORTED, "op %zu: a direction bit on a width-32 sponge row", i);
+        if (op.a >= c.ops.size()) fail(P3R_EINVAL, "op %zu: NonPrimitiveOpId(%u) out of range", i, op.a);
+        break;
+      }
       case P3R_OP_RECOMPOSE:
         wid(op.out, i, "out");
         if (op.a >= c.ops.size()) fail(P3R_EINVAL, "op %zu: NonPrimitiveOpId(%u) out of range", i, op.a);
@@ -148,6 +169,8 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
   std::vector<uint8_t> defined(c.witness_count, 0), is_private(c.witness_count, 0), is_hint(c.witness_count, 0);
   // dup_npo_outputs is kept per op type (circuit.rs:464-491): one map per Recompose kind
   std::vector<uint8_t> dup_p2(c.witness_count, 0), dup_rec(c.witness_count, 0), dup_rec_coeff(c.witness_count, 0);
+  std::vector<uint8_t> dup_p2w;   // the width-32 table is its own op type
+  std::vector<const p3r_op*> p2ws;
   for (uint32_t w : c.private_rows) is_private[w] = 1;
   {
     // hint outputs not also produced by a Const / Public op (circuit.rs:263-284)
@@ -181,6 +204,22 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
           if (defined[w]) { dup_p2[w] = 1; reads[w]++; } else defined[w] = 1;
         }
         p2s.push_back(&op);
+        break;
+      }
+      case P3R_OP_POSEIDON2_W32_PERM: {
+        // arity-4 shape (executor.rs:777-793,880-893): every named input limb is a bus read - Merkle rows too (their
+        // AIR sends a bare in_ctl) - and a Merkle row reads the witnesses of its two direction bits
+        const uint32_t* e = c.ext_of(op);
+        if (dup_p2w.empty()) dup_p2w.assign(c.witness_count, 0);
+        for (uint32_t l = 0; l < kW32In; ++l)
+          if (e[l] != kNoW) reads[e[l]]++;
+        for (uint32_t l = 0; l < kW32Rate; ++l) {
+          const uint32_t w = e[kW32Hdr + l];
+          if (w == kNoW) continue;
+          if (defined[w]) { dup_p2w[w] = 1; reads[w]++; } else defined[w] = 1;
+        }
+        if (op.aux & 2) { reads[e[kW32BitSlot]]++; reads[e[kW32Bit2Slot]]++; }
+        p2ws.push_back(&op);
         break;
       }
       case P3R_OP_RECOMPOSE: {
@@ -237,6 +276,7 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
   T.counts.n_public = publics.size();
   T.counts.n_alu = std::max<size_t>(alus.size(), 1);
   T.counts.n_p2 = p2s.size();
+  T.counts.n_p2w = p2ws.size();
   // a table without rows is not proved: a circuit whose Recompose ops are all of the coefficient kind has ONE
   // Recompose table, `recompose/coeff`, in the first slot (p3r_layer_desc.recompose_coeff_lookups)
   T.recompose_coeff = recs.empty() && !recs_coeff.empty();
@@ -271,6 +311,37 @@ CircuitTables circuit_tables(const HostCircuit& c, uint32_t D = 4) {
       }
       T.p2_mmcs_index_sum_idx[r] = e[il] != kNoW ? e[il] : 0;
       if (D != 4) T.p2_absorb_len[r] = (uint8_t)op->b;
+    }
+    // the width-32 table: Poseidon2PreprocessedRow<8, 6> assembled (preprocess_inputs / _outputs / _flags for
+    // is_arity4_shape, executor.rs:770-893, then phase 2 of poseidon_preprocess_for_prover, batch_stark_prover.rs:177-243;
+    // phase 1 skips the arity-4 op types, :121-127)
+    T.p2w_prep.resize(48 * p2ws.size());
+    for (size_t r = 0; r < p2ws.size(); ++r) {
+      const p3r_op* op = p2ws[r];
+      const uint32_t* e = c.ext_of(*op);
+      const bool ns = op->aux & 1, merkle = op->aux & 2;
+      uint32_t* row = &T.p2w_prep[48 * r];
+      for (uint32_t l = 0; l < kW32In; ++l) {
+        const bool named = e[l] != kNoW;
+        row[4 * l] = named ? scaled(e[l]) : 0;
+        row[4 * l + 1] = named;
+        row[4 * l + 2] = !ns && !merkle && !named;
+        row[4 * l + 3] = !ns && merkle && !named;
+      }
+      for (uint32_t l = 0; l < kW32Rate; ++l) {
+        const uint32_t w = e[kW32Hdr + l];
+        row[32 + 2 * l] = w != kNoW ? scaled(w) : 0;
+        row[33 + 2 * l] = w == kNoW ? 0 : dup_p2w[w] ? NEG1 : mult(w);
+      }
+      if (merkle) {   // the accumulator slots carry the two bit witnesses
+        row[44] = scaled(e[kW32BitSlot]);
+        row[45] = scaled(e[kW32Bit2Slot]);
+      } else {
+        row[44] = 0;   // mmcs_index_sum is refused on width-32 rows (validate_circuit): idx 0, mmcs_merkle_flag 0
+        row[45] = 0;
+      }
+      row[46] = ns;
+      row[47] = merkle;
     }
     // recompose.rs:293-356: [D * out, mult]; the coefficient variant appends (D * coeff, mult) per coefficient, where
     // only a hint output is created here (its reads), any other coefficient is named with multiplicity 0
@@ -342,11 +413,21 @@ inline RunSchedule build_schedule(const HostCircuit& c, uint32_t D = 4) {
   uint32_t n_rec_plain_total = 0, n_rec_coeff = 0;
   for (auto& op : c.ops) n_rec_plain_total += op.kind == P3R_OP_RECOMPOSE && op.aux != 1u;
   uint32_t last_normal = kNoW, last_merkle = kNoW;
+  // the width-32 table is its own op type with its own chain state (PoseidonExecutionState per op_type); an arity-4
+  // sponge row seeds the Merkle state too (update_chain_state, executor.rs:462-491)
+  struct OpenP2W { uint32_t level; std::vector<RunP2W> rows; };
+  std::vector<OpenP2W> p2wopen;
+  std::vector<uint32_t> p2w_seg_of_row;
+  uint32_t w_last_normal = kNoW, w_last_merkle = kNoW, n_p2w_rows = 0;
   uint32_t max_op_id = 0;
-  bool any_npo = false;
+  bool any_npo = false, any_w32 = false;
   for (auto& op : c.ops)
-    if (op.kind == P3R_OP_POSEIDON2_PERM || op.kind == P3R_OP_RECOMPOSE) { max_op_id = std::max(max_op_id, op.a); any_npo = true; }
+    if (op.kind == P3R_OP_POSEIDON2_PERM || op.kind == P3R_OP_RECOMPOSE || op.kind == P3R_OP_POSEIDON2_W32_PERM) {
+      max_op_id = std::max(max_op_id, op.a); any_npo = true;
+      any_w32 = any_w32 || op.kind == P3R_OP_POSEIDON2_W32_PERM;
+    }
   if (any_npo) S.p2_row_of_op_id.assign((size_t)max_op_id + 1, kNoW);
+  if (any_w32) S.p2w_row_of_op_id.assign((size_t)max_op_id + 1, kNoW);
 
   std::vector<uint32_t> written;
   light.reserve(c.ops.size());
@@ -486,7 +567,8 @@ inline RunSchedule build_schedule(const HostCircuit& c, uint32_t D = 4) {
           if (earlier || put(ow)) { if (D == 4) q.flags |= 1u << (4 + l); else qb.check_mask |= 1u << l; }
           else written.push_back(ow);
         }
-        if (S.p2_row_of_op_id[op.a] != kNoW) fail(P3R_EINVAL, "duplicate NonPrimitiveOpId(%u)", op.a);
+        if (S.p2_row_of_op_id[op.a] != kNoW || (!S.p2w_row_of_op_id.empty() && S.p2w_row_of_op_id[op.a] != kNoW))
+          fail(P3R_EINVAL, "duplicate NonPrimitiveOpId(%u)", op.a);
         S.p2_row_of_op_id[op.a] = row;
         S.p2_row_merkle.push_back(merkle);
         // `lvl` = highest level among the witnesses this row reads (or compares against)
@@ -504,6 +586,52 @@ inline RunSchedule build_schedule(const HostCircuit& c, uint32_t D = 4) {
         for (uint32_t w : written) { set[w] = 1; wlevel[w] = p2open[open].level; }
         continue;
       }
+      case P3R_OP_POSEIDON2_W32_PERM: {
+        const bool new_start = op.aux & 1, merkle = op.aux & 2;
+        const uint32_t n_out = e[kW32NOutSlot];
+        RunP2W q{};
+        const uint32_t row = n_p2w_rows++;
+        q.flags = (op.aux & 3) | (n_out << 8);
+        q.op_idx = (uint32_t)i; q.row = row; q.prev_row = kNoW;
+        for (uint32_t l = 0; l < kW32In; ++l) { q.in[l] = e[l]; if (e[l] != kNoW) need(e[l]); }
+        q.bit_w = e[kW32BitSlot]; q.bit2_w = e[kW32Bit2Slot];
+        if (q.bit_w != kNoW) need(q.bit_w);
+        if (q.bit2_w != kNoW) need(q.bit2_w);
+        if (!new_start) {
+          const uint32_t prev = merkle ? w_last_merkle : w_last_normal;
+          if (prev == kNoW) defer("Poseidon2ChainMissingPreviousState { operation_index: NonPrimitiveOpId(%u) }", op.a);
+          q.prev_row = prev;
+        }
+        for (uint32_t l = 0; l < kW32In; ++l) {
+          const uint32_t ow = l < n_out ? e[kW32Hdr + l] : kNoW;
+          q.out[l] = ow;
+          if (ow == kNoW) continue;
+          bool earlier = false;
+          for (uint32_t j = 0; j < l; ++j) earlier |= e[kW32Hdr + j] == ow;
+          if (earlier || put(ow)) q.flags |= 1u << (16 + l);
+          else written.push_back(ow);
+        }
+        if (S.p2_row_of_op_id[op.a] != kNoW || S.p2w_row_of_op_id[op.a] != kNoW) fail(P3R_EINVAL, "duplicate NonPrimitiveOpId(%u)", op.a);
+        S.p2w_row_of_op_id[op.a] = row;
+        S.p2w_row_merkle.push_back(merkle);
+        // joins the segment that ends in its predecessor when everything it reads is ready before that segment starts
+        int seg = -1;
+        if (q.prev_row != kNoW) {
+          const uint32_t ps = p2w_seg_of_row[q.prev_row];
+          if (p2wopen[ps].rows.back().row == q.prev_row && lvl < p2wopen[ps].level) { seg = (int)ps; q.prev_in_seg = 1; }
+        }
+        if (seg < 0) {
+          uint32_t seg_level = lvl + 1;
+          if (q.prev_row != kNoW) seg_level = std::max(seg_level, p2wopen[p2w_seg_of_row[q.prev_row]].level + 1);
+          p2wopen.push_back({seg_level, {}});
+          seg = (int)p2wopen.size() - 1;
+        }
+        p2wopen[seg].rows.push_back(q);
+        p2w_seg_of_row.push_back((uint32_t)seg);
+        if (merkle) w_last_merkle = row; else w_last_normal = w_last_merkle = row;
+        for (uint32_t w : written) { set[w] = 1; wlevel[w] = p2wopen[seg].level; }
+        continue;
+      }
       default: fail(P3R_EUNSUPPORTED, "op %zu: unsupported kind %u", i, op.kind);
     }
     lvl += 1;
@@ -516,6 +644,7 @@ inline RunSchedule build_schedule(const HostCircuit& c, uint32_t D = 4) {
   for (auto& t : order) max_level = std::max(max_level, t.level);
   for (auto& ch : chains) max_level = std::max(max_level, ch.level);
   for (auto& sg : p2open) max_level = std::max(max_level, sg.level);
+  for (auto& sg : p2wopen) max_level = std::max(max_level, sg.level);
   std::unordered_map<uint32_t, uint32_t> canon_of;
   for (size_t k = 0; k + 1 < c.rewrite.size(); k += 2) canon_of.emplace(c.rewrite[k], c.rewrite[k + 1]);
   for (size_t k = 0; k + 1 < c.rewrite.size(); k += 2) {
@@ -558,6 +687,18 @@ inline RunSchedule build_schedule(const HostCircuit& c, uint32_t D = 4) {
         S.p2segs.push_back({(uint32_t)S.p2b.size(), (uint32_t)p2open[k].rows_b.size()});
         S.p2b.insert(S.p2b.end(), p2open[k].rows_b.begin(), p2open[k].rows_b.end());
       }
+    }
+  }
+  if (!p2wopen.empty()) {
+    S.p2wseg_off.assign(max_level + 2, 0);
+    for (auto& sg : p2wopen) S.p2wseg_off[sg.level + 1]++;
+    for (size_t l = 1; l < S.p2wseg_off.size(); ++l) S.p2wseg_off[l] += S.p2wseg_off[l - 1];
+    std::vector<uint32_t> by_level(p2wopen.size());
+    std::iota(by_level.begin(), by_level.end(), 0u);
+    std::stable_sort(by_level.begin(), by_level.end(), [&](uint32_t x, uint32_t y) { return p2wopen[x].level < p2wopen[y].level; });
+    for (uint32_t k : by_level) {
+      S.p2wsegs.push_back({(uint32_t)S.p2w.size(), (uint32_t)p2wopen[k].rows.size()});
+      S.p2w.insert(S.p2w.end(), p2wopen[k].rows.begin(), p2wopen[k].rows.end());
     }
   }
   (void)n_pub;

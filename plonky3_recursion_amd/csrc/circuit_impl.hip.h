@@ -98,6 +98,17 @@ struct RunArgs {
   const uint32_t* light_off;  // per level, device copies of the schedule offsets
   const RunSchedule::P2Seg* p2segs;
   const uint32_t* p2seg_off;
+  // rows of the width-32 table (P3R_OP_POSEIDON2_W32_PERM); p2wseg_off == nullptr: the circuit has none
+  const RunP2W* p2w;
+  uint32_t* p2w_inputs;   // [32][p2w_h]
+  size_t p2w_h;
+  uint8_t* p2w_flags;     // new_start[h] | merkle_path[h] | mmcs_bit[h] | mmcs_bit2[h]
+  uint32_t* p2w_out;      // permutation outputs by row (chain state)
+  const int32_t* pdw_slot;
+  const uint32_t* siblings_w;   // [n][24]
+  const uint32_t* rcw;    // constants of the width-32 permutation (round constants | diagonal), Montgomery
+  const RunSchedule::P2Seg* p2wsegs;
+  const uint32_t* p2wseg_off;
 };
 
 // One ALU / hint / recompose / const op.
@@ -266,6 +277,72 @@ __device__ __forceinline__ void run_p2_segment(const RunArgs& A, RunSchedule::P2
   }
 }
 
+// One segment of width-32 permutations (P3R_OP_POSEIDON2_W32_PERM): lane j of a 32-lane group owns state element j
+// (limb j/4, coefficient j%4; chunk j/8 of the arity-4 shape).  PoseidonPermExecutor::execute for is_arity4()
+// (poseidon_perm/executor.rs:92-235,947-966): no swap - the running digest is PLACED into chunk pos = bit + 2 bit2.
+template <class PP>
+__device__ __forceinline__ void run_p2w_segment(const RunArgs& A, RunSchedule::P2Seg seg, int j, bool live) {
+  using F = Fp<PP>;
+  using E = Fp4<PP>;
+  uint32_t* __restrict__ w = A.w;
+  uint32_t* err = A.err;
+  if (!live) seg.n = 0;
+  const Coop32Rc<PP> rcs = coop32_load_rc<PP>(A.rcw, j);
+  F carried = F::zero();  // output of the previous row of this segment
+  for (uint32_t k = 0; k < seg.n; ++k) {
+    const RunP2W q = A.p2w[seg.first + k];
+    const bool new_start = q.flags & 1, merkle = q.flags & 2;
+    // resolve_mmcs_bit / resolve_mmcs_bit2 (:283-338)
+    bool bit = false, bit2 = false;
+    if (q.bit_w != kNoW) {
+      const E v = w_load<PP>(w, q.bit_w);
+      if (v == E::one()) bit = true;
+      else if (!(v == E::zero()) && j == 0) run_error(err, q.op_idx, RUN_ERR_MMCS_BIT);
+    }
+    if (q.bit2_w != kNoW) {
+      const E v = w_load<PP>(w, q.bit2_w);
+      if (v == E::one()) bit2 = true;
+      else if (!(v == E::zero()) && j == 0) run_error(err, q.op_idx, RUN_ERR_MMCS_BIT);
+    }
+    const int pos = (int)bit + 2 * (int)bit2, chunk = j >> 3;
+    // previous output of this row's chain: still in registers when the predecessor is the row before, else in memory
+    // (it was written by an earlier level); the digest = its first eight elements goes to the lanes of chunk `pos`
+    F prev = F::zero();
+    if (!new_start) {
+      if (q.prev_in_seg) prev = merkle ? F::raw(__shfl(carried.v, j & 7, 32)) : carried;
+      else prev = F::raw(A.p2w_out[(size_t)q.prev_row * 32 + (merkle ? (j & 7) : j)]);
+    }
+    // init_chain_state + place_arity4_running_hash (:103-160)
+    F s = F::zero();
+    if (!new_start && (!merkle || chunk == pos)) s = prev;
+    // fill_sibling_data (:166-201): the three other chunks in ascending order
+    const int32_t slot = A.pdw_slot[q.row];
+    if (merkle && slot >= 0 && chunk != pos)
+      s = F::raw(A.siblings_w[(size_t)slot * 24 + (size_t)(chunk - (chunk > pos ? 1 : 0)) * 8 + (j & 7)]);
+    // apply_witness_values (:207-219)
+    const uint32_t in_w = q.in[j >> 2];
+    if (in_w != kNoW) s = F::raw(w[(size_t)in_w * 4 + (j & 3)]);
+    // Poseidon2CircuitRow (build_trace_row :364-417): mmcs_index_sum stays zero (no accumulator witness on this table)
+    A.p2w_inputs[(size_t)j * A.p2w_h + q.row] = s.v;
+    if (j == 0) {
+      A.p2w_flags[q.row] = new_start;
+      A.p2w_flags[A.p2w_h + q.row] = merkle;
+      A.p2w_flags[2 * A.p2w_h + q.row] = bit;
+      A.p2w_flags[3 * A.p2w_h + q.row] = bit2;
+    }
+    s = coop32_permute<PP>(s, j, rcs);
+    carried = s;
+    A.p2w_out[(size_t)q.row * 32 + j] = s.v;
+    const uint32_t n_out = (q.flags >> 8) & 15;
+    const uint32_t l = (uint32_t)j >> 2;
+    if (l < n_out && q.out[l] != kNoW) {
+      uint32_t* slot_w = w + (size_t)q.out[l] * 4 + (j & 3);
+      if (q.flags & (1u << (16 + l))) { if (*slot_w != s.v) run_error(err, q.op_idx, RUN_ERR_CONFLICT); }
+      else *slot_w = s.v;
+    }
+  }
+}
+
 // The same for the base-mode permutation rows of a circuit of degree D = 1 / 5 (one witness per state element,
 // poseidon_perm/executor.rs:600-700 for sponge rows - the chained state, CTL inputs on any slot the op names, the
 // length tag added to the first capacity element - and :924-970 for Merkle rows, sixteen one-element limbs).
@@ -395,7 +472,17 @@ template <class PP, int D = 4>
 __global__ void __launch_bounds__(kBlock)
 k_run_level(RunArgs A, uint32_t p2_begin, uint32_t n_p2, uint32_t p2_blocks, const RunOp* __restrict__ chain_steps,
             const RunSchedule::ChainSeg* __restrict__ chains, uint32_t n_chains, uint32_t chain_blocks,
-            uint32_t light_begin, uint32_t n_light) {
+            uint32_t light_begin, uint32_t n_light, uint32_t p2w_begin = 0, uint32_t n_p2w = 0, uint32_t p2w_blocks = 0) {
+  if constexpr (D == 4) {
+    // width-32 permutation segments ride at the END of the grid (the existing block ranges keep their indices)
+    if (p2w_blocks && blockIdx.x >= gridDim.x - p2w_blocks) {
+      const uint32_t g = (blockIdx.x - (gridDim.x - p2w_blocks)) * kBlock + threadIdx.x;
+      const bool live = (g >> 5) < n_p2w;
+      const RunSchedule::P2Seg sg = live ? A.p2wsegs[p2w_begin + (g >> 5)] : RunSchedule::P2Seg{0, 0};
+      run_p2w_segment<PP>(A, sg, (int)(g & 31), live);
+      return;
+    }
+  }
   if (blockIdx.x < p2_blocks) {
     const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
     const bool live = (g >> 4) < n_p2;
@@ -409,7 +496,7 @@ k_run_level(RunArgs A, uint32_t p2_begin, uint32_t n_p2, uint32_t p2_blocks, con
     return;
   }
   const uint32_t i = (blockIdx.x - p2_blocks - chain_blocks) * kBlock + threadIdx.x;
-  if (i < n_light) run_light_op<PP, D>(A, A.light[light_begin + i]);
+  if (i < n_light) run_light_op<PP, D>(A, A.light[light_begin + i]);   // (a trailing width-32 block returned above)
 }
 
 // Long chains: the same scan with a whole workgroup per chain - slices are folded per lane, combined
@@ -512,6 +599,16 @@ k_run_levels_narrow(RunArgs A, const uint32_t* __restrict__ chunk_bounds, uint32
         if constexpr (D == 4) run_p2_segment<PP>(A, sg, (int)(t & 15), live);
         else run_p2_segment_base<PP, D>(A, sg, (int)(t & 15), live);
       }
+      if constexpr (D == 4) {
+        if (A.p2wseg_off) {
+          const uint32_t wb = A.p2wseg_off[l], nwseg = A.p2wseg_off[l + 1] - wb;
+          const bool wlive = (t >> 5) < nwseg;
+          if (__any(wlive)) {
+            const RunSchedule::P2Seg sg = wlive ? A.p2wsegs[wb + (t >> 5)] : RunSchedule::P2Seg{0, 0};
+            run_p2w_segment<PP>(A, sg, (int)(t & 31), wlive);
+          }
+        }
+      }
       __syncthreads();
     }
   }
@@ -561,11 +658,15 @@ struct p3r_circuit {
   p3r::DevBuf d_light, d_p2, d_ext, d_const_values, d_public_rows, d_private_rows, d_public_out, d_rewrite;
   p3r::DevBuf d_light_off, d_p2seg_off, d_p2segs, d_chunk_bounds, d_chain_ops, d_chains;
   p3r::DevBuf d_row_of_op_id;  // NonPrimitiveOpId -> Poseidon2 row, bit 31 = Merkle row; kNoW: no permutation
+  // rows of the width-32 table (P3R_OP_POSEIDON2_W32_PERM; host-side preparation only)
+  p3r::DevBuf d_p2w, d_p2wsegs, d_p2wseg_off;
+  p3r::DevBuf d_roww_of_op_id; // NonPrimitiveOpId -> width-32 row, bit 31 = Merkle row
 };
 
 // Inputs of one run made resident in HBM (public / private values, Merkle siblings).
 struct p3r_dinputs {
   p3r::DevBuf pub, priv, sib, slot;
+  p3r::DevBuf sib_w, slot_w;   // private data of the width-32 Merkle rows: [n][24], row -> position
 };
 
 namespace {
@@ -650,6 +751,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   if (ext_d != 4 && !T.p2_absorb_len.empty()) ld.p2_absorb_len = T.p2_absorb_len.data();
   ld.recompose_coeff_prep = T.recompose_coeff_prep.data();
   ld.recompose_coeff_lookups = T.recompose_coeff ? 1u : 0u;
+  if (T.counts.n_p2w) ld.p2w_prep = T.p2w_prep.data();
   prof_stage(ctx, "prep_layer_create");
   C->layer = layer_create<PP>(ctx, &ld, commit_out);
 
@@ -686,6 +788,15 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   up(C->d_chunk_bounds, S.chunk_bounds.data(), S.chunk_bounds.size() * 4);
   up(C->d_chain_ops, S.chain_ops.data(), S.chain_ops.size() * sizeof(RunOp));
   up(C->d_chains, S.chains.data(), S.chains.size() * sizeof(RunSchedule::ChainSeg));
+  if (!S.p2wseg_off.empty()) {
+    up(C->d_p2w, S.p2w.data(), S.p2w.size() * sizeof(RunP2W));
+    up(C->d_p2wsegs, S.p2wsegs.data(), S.p2wsegs.size() * sizeof(RunSchedule::P2Seg));
+    up(C->d_p2wseg_off, S.p2wseg_off.data(), S.p2wseg_off.size() * 4);
+    std::vector<uint32_t> ids(S.p2w_row_of_op_id);
+    for (auto& v : ids)
+      if (v != kNoW && S.p2w_row_merkle[v]) v |= 1u << 31;
+    up(C->d_roww_of_op_id, ids.data(), ids.size() * 4);
+  }
   {
     std::vector<uint32_t> ids(S.p2_row_of_op_id);
     for (auto& v : ids)
@@ -696,6 +807,7 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
   C->n_rewrite = S.rewrite_pairs.size() / 3;
   // the large host arrays are on the device now
   S.light = {}; S.p2 = {}; S.p2b = {}; S.chain_ops = {}; S.dev_ext = {}; S.p2_row_of_op_id = {}; S.p2_row_merkle = {};
+  S.p2w = {}; S.p2w_row_of_op_id = {}; S.p2w_row_merkle = {};
   prof_stage(ctx, nullptr);
   return C;
 }
@@ -746,27 +858,43 @@ std::unique_ptr<p3r_dinputs> circuit_inputs_upload(p3r_ctx* ctx, const p3r_circu
   auto D = std::make_unique<p3r_dinputs>();
   D->pub = upload_mont<PP>(ctx, in->public_values, C->n_public_rows * ctx->cfg.ext_degree, "public_values");
   D->priv = upload_mont<PP>(ctx, in->private_values, C->n_private_rows * ctx->cfg.ext_degree, "private_values");
-  D->sib = upload_mont<PP>(ctx, in->private_data_siblings, n_pd * 8, "private_data_siblings");
-  D->slot.alloc(std::max<size_t>(n_p2, 1));
-  P3R_HIP(hipMemsetAsync(D->slot.p, 0xFF, std::max<size_t>(n_p2, 1) * 4, ctx->stream));  // -1: no private data
-  if (n_pd) {
+  // the two widths are two op types with their own row tables: the same claim / check passes per list
+  auto private_data = [&](size_t n_pd, const uint32_t* ids_host, const uint32_t* sib_host, size_t per_op, size_t n_rows,
+                          const DevBuf& row_of_id, const DevBuf& other_row_of_id, DevBuf& sib, DevBuf& slot, const char* what) {
+    sib = upload_mont<PP>(ctx, sib_host, n_pd * per_op, what);
+    slot.alloc(std::max<size_t>(n_rows, 1));
+    P3R_HIP(hipMemsetAsync(slot.p, 0xFF, std::max<size_t>(n_rows, 1) * 4, ctx->stream));  // -1: no private data
+    if (!n_pd) return;
+    if (!row_of_id.p)   // the circuit has no permutation of this width at all
+      fail(P3R_EINVAL, "NonPrimitiveOpIdOutOfRange { op_id: %u, max_ops: %zu } (%s)", ids_host[0], C->n_op_ids, what);
     DevBuf ids(n_pd), err(1);
-    P3R_HIP(hipMemcpyAsync(ids.p, in->private_data_op_ids, n_pd * 4, hipMemcpyHostToDevice, ctx->stream));
+    P3R_HIP(hipMemcpyAsync(ids.p, ids_host, n_pd * 4, hipMemcpyHostToDevice, ctx->stream));
     P3R_HIP(hipMemsetAsync(err.p, 0xFF, 4, ctx->stream));
-    hipLaunchKernelGGL(k_pd_claim, dim3(blocks_for(n_pd)), dim3(kBlock), 0, ctx->stream, ids.p, n_pd, C->d_row_of_op_id.p, C->n_op_ids, D->slot.p);
-    hipLaunchKernelGGL(k_pd_check, dim3(blocks_for(n_pd)), dim3(kBlock), 0, ctx->stream, ids.p, n_pd, C->d_row_of_op_id.p, C->n_op_ids, D->slot.p,
-                       err.p);
+    hipLaunchKernelGGL(k_pd_claim, dim3(blocks_for(n_pd)), dim3(kBlock), 0, ctx->stream, ids.p, n_pd, row_of_id.p, C->n_op_ids, slot.p);
+    hipLaunchKernelGGL(k_pd_check, dim3(blocks_for(n_pd)), dim3(kBlock), 0, ctx->stream, ids.p, n_pd, row_of_id.p, C->n_op_ids, slot.p, err.p);
     uint32_t e = 0;
     P3R_HIP(copy_sync(ctx->stream, &e, err.p, 4, hipMemcpyDeviceToHost));
     if (e != 0xFFFFFFFFu) {
-      const uint32_t id = in->private_data_op_ids[e >> 2];
+      const uint32_t id = ids_host[e >> 2];
       switch (e & 3) {
-        case 1: fail(P3R_EINVAL, "NonPrimitiveOpIdOutOfRange { op_id: %u, max_ops: %zu }", id, C->n_op_ids);
+        case 1: {
+          uint32_t other = kNoW;
+          if (other_row_of_id.p && id < C->n_op_ids) P3R_HIP(copy_sync(ctx->stream, &other, other_row_of_id.p + id, 4, hipMemcpyDeviceToHost));
+          if (other != kNoW)
+            fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: NonPrimitiveOpId(%u) is a permutation of the other width (%s)", id, what);
+          fail(P3R_EINVAL, "NonPrimitiveOpIdOutOfRange { op_id: %u, max_ops: %zu }", id, C->n_op_ids);
+        }
         case 2: fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data already set for NonPrimitiveOpId(%u)", id);
         default: fail(P3R_EINVAL, "IncorrectNonPrimitiveOpPrivateData: private data provided for non-Merkle operation NonPrimitiveOpId(%u)", id);
       }
     }
-  }
+  };
+  private_data(n_pd, in->private_data_op_ids, in->private_data_siblings, 8, n_p2, C->d_row_of_op_id, C->d_roww_of_op_id, D->sib, D->slot,
+               "private_data_siblings");
+  const size_t n_pdw = in->n_private_data_w32;
+  if (n_pdw && (!in->private_data_w32_op_ids || !in->private_data_w32_siblings)) fail(P3R_EINVAL, "width-32 private data arrays are NULL");
+  private_data(n_pdw, in->private_data_w32_op_ids, in->private_data_w32_siblings, 24, C->counts.n_p2w, C->d_roww_of_op_id, C->d_row_of_op_id,
+               D->sib_w, D->slot_w, "private_data_w32_siblings");
   return D;
 }
 
@@ -833,6 +961,25 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     p2_inputs = d->inputs->d; p2_seed = d->seed.p;
     T->p2 = std::move(d);
   }
+  // rows of the width-32 table: the same fillers
+  uint32_t* p2w_inputs = nullptr; uint8_t* p2w_flags = nullptr;
+  size_t p2w_h = 0;
+  DevBuf p2w_out(std::max<size_t>(cn.n_p2w, 1) * 32);
+  if (L->has_p2w) {
+    p2w_h = L->h_p2w;
+    auto d = std::make_unique<p3r_p2_dev>();
+    d->n = p2w_h;
+    d->inputs = dmat_alloc(p2w_h, P2W_WIDTH);
+    P3R_HIP(hipMemsetAsync(d->inputs->d, 0, p2w_h * P2W_WIDTH * 4, ctx->stream));
+    d->flags.alloc(p2w_h + 1);
+    p2w_flags = reinterpret_cast<uint8_t*>(d->flags.p);
+    P3R_HIP(hipMemsetAsync(p2w_flags, 1, p2w_h, ctx->stream));
+    P3R_HIP(hipMemsetAsync(p2w_flags + p2w_h, 0, 3 * p2w_h, ctx->stream));
+    d->seed.alloc(p2w_h);
+    P3R_HIP(hipMemsetAsync(d->seed.p, 0, p2w_h * 4, ctx->stream));   // no accumulator witness on this table
+    p2w_inputs = d->inputs->d;
+    T->p2w = std::move(d);
+  }
   {
     ProfScope ps(ctx, "run_levels");
     RunArgs A{};
@@ -845,6 +992,15 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     A.rc = ctx->rc.p; A.diag = ctx->p2_diag.p; A.err = err.p;
     A.light_off = C->d_light_off.p; A.p2seg_off = C->d_p2seg_off.p;
     A.p2segs = reinterpret_cast<const RunSchedule::P2Seg*>(C->d_p2segs.p);
+    const bool has_w32 = !S.p2wseg_off.empty();
+    if (has_w32) {
+      A.p2w = reinterpret_cast<const RunP2W*>(C->d_p2w.p);
+      A.p2w_inputs = p2w_inputs; A.p2w_h = p2w_h; A.p2w_flags = p2w_flags; A.p2w_out = p2w_out.p;
+      A.pdw_slot = reinterpret_cast<const int32_t*>(in->slot_w.p); A.siblings_w = in->sib_w.p;
+      A.rcw = ctx->rc.p + p2_num_constants<PP>();
+      A.p2wsegs = reinterpret_cast<const RunSchedule::P2Seg*>(C->d_p2wsegs.p);
+      A.p2wseg_off = C->d_p2wseg_off.p;
+    }
     dispatch_ext_degree<PP>((int)ext_d, [&](auto dc) {
     constexpr int DD = decltype(dc)::value;
     for (const auto& seg : S.segments) {
@@ -860,10 +1016,11 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
       const RunOp* steps = reinterpret_cast<const RunOp*>(C->d_chain_ops.p);
       const RunSchedule::ChainSeg* segs = reinterpret_cast<const RunSchedule::ChainSeg*>(C->d_chains.p) + S.chain_off[l];
       const uint32_t n_short = nc - n_long, cb = (n_short + kBlock / 64 - 1) / (kBlock / 64);
+      const uint32_t npw = has_w32 ? S.p2wseg_off[l + 1] - S.p2wseg_off[l] : 0u, pwb = (npw * 32 + kBlock - 1) / kBlock;
       // chains only read operands of lower levels, so they share the launch with the level's other ops
-      if (lb + pb + cb)
-        hipLaunchKernelGGL((k_run_level<PP, DD>), dim3(pb + cb + lb), dim3(kBlock), 0, ctx->stream, A, S.p2seg_off[l], np, pb,
-                           steps, segs + n_long, n_short, cb, S.light_off[l], nl);
+      if (lb + pb + cb + pwb)
+        hipLaunchKernelGGL((k_run_level<PP, DD>), dim3(pb + cb + lb + pwb), dim3(kBlock), 0, ctx->stream, A, S.p2seg_off[l], np, pb,
+                           steps, segs + n_long, n_short, cb, S.light_off[l], nl, has_w32 ? S.p2wseg_off[l] : 0u, npw, pwb);
       if (n_long)
         hipLaunchKernelGGL((k_run_chains_block<PP, DD>), dim3(n_long), dim3(kLongChainBlock), 0, ctx->stream, A, steps, segs);
     }
@@ -927,6 +1084,30 @@ void dtraces_get(p3r_ctx* ctx, const p3r_layer* L, const p3r_dtraces* t, uint32_
       if (out_len != c.n_p2) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2, out_len);
       if (!c.n_p2) break;
       plain_at(t->p2->seed.p, c.n_p2);
+      break;
+    }
+    case P3R_TRACES_P2W_INPUT_VALUES: {
+      if (out_len != c.n_p2w * 32) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2w * 32, out_len);
+      if (!c.n_p2w) break;
+      std::vector<uint32_t> full(t->p2w->n * 32);
+      download<PP>(ctx, t->p2w->inputs.get(), full.data());  // row-major [h][32], canonical
+      std::copy(full.begin(), full.begin() + c.n_p2w * 32, out);
+      break;
+    }
+    case P3R_TRACES_P2W_FLAGS: {
+      if (out_len != c.n_p2w * 4) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2w * 4, out_len);
+      if (!c.n_p2w) break;
+      const size_t h = t->p2w->n;
+      std::vector<uint8_t> f(4 * h);
+      P3R_HIP(copy_sync(ctx->stream, f.data(), t->p2w->flags.p, 4 * h, hipMemcpyDeviceToHost));
+      for (size_t r = 0; r < c.n_p2w; ++r)
+        for (int k = 0; k < 4; ++k) out[r * 4 + k] = f[k * h + r];
+      break;
+    }
+    case P3R_TRACES_P2W_MMCS_INDEX_SUM: {
+      if (out_len != c.n_p2w) fail(P3R_EBUFFER, "array holds %zu values, caller asked for %zu", c.n_p2w, out_len);
+      if (!c.n_p2w) break;
+      plain_at(t->p2w->seed.p, c.n_p2w);
       break;
     }
     default: fail(P3R_EINVAL, "unknown traces array %u", which);

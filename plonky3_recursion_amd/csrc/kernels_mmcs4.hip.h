@@ -120,84 +120,10 @@ k_mmcs4_compress(const uint32_t* __restrict__ prev, size_t n_prev, int step, con
 
 }  // namespace p3r
 
-// ---- lane-cooperative width-32 permutation for LATENCY-bound levels (kernels_coop.hip.h is the width-16 form): one
-// state element per lane, 32 lanes (two DPP rows) per permutation, two permutations per wavefront.  With one
-// permutation per lane a level of an arity-4 tree costs one 7.8 - 11.3 k-instruction permutation (13 - 19 us) however few nodes
-// it has; here the 32 S-boxes of a round run side by side and the linear layers are DPP rotations plus ONE cross-row
-// step (v_permlane16_swap, new on gfx950: it exchanges the odd rows of one register with the even rows of another,
-// so swap(t, t) yields (row0, row0, row2, row2) and (row1, row1, row3, row3), whose sum is the pair sum in every row).
+// (the lane-cooperative width-32 permutation coop32_permute lives in kernels_coop.hip.h, next to the width-16 form)
 #include "kernels_coop.hip.h"
 
 namespace p3r {
-
-template <class F>
-__device__ __forceinline__ F coop32_pair_sum(F t) {
-  const auto r = __builtin_amdgcn_permlane16_swap(t.v, t.v, false, false);
-  return F::raw(r[0]) + F::raw(r[1]);
-}
-// external layer circ(2 M4, M4, .., M4) over eight quads: M4 inside the quad, then the sum of the eight quads
-template <class F>
-__device__ __forceinline__ F coop32_external(F x) {
-  const F b = F::raw(dpp<DPP_QUAD_NEXT1>(x.v)), c = F::raw(dpp<DPP_QUAD_NEXT2>(x.v)), d = F::raw(dpp<DPP_QUAD_NEXT3>(x.v));
-  const F ab = x + b;
-  const F y = ab.dbl() + b + (c + d);  // 2x + 3b + c + d
-  F t = y + F::raw(dpp<DPP_ROW_ROR4>(y.v));
-  t = t + F::raw(dpp<DPP_ROW_ROR8>(t.v));
-  return y + coop32_pair_sum(t);
-}
-template <class F>
-__device__ __forceinline__ F coop32_sum(F x) { return coop32_pair_sum(coop_row_sum(x)); }
-// the value of lane 0 of the group on all 32 lanes; `x0` is zero on the other 31
-__device__ __forceinline__ uint32_t coop32_bcast0(uint32_t x0) {
-  const uint32_t q = coop_bcast0(x0);
-  const auto r = __builtin_amdgcn_permlane16_swap(q, q, false, false);
-  return r[0] | r[1];
-}
-
-template <class PP>
-struct Coop32Rc {
-  uint32_t full[2 * P2_HALF_FULL];
-  uint32_t part[PP::PARTIAL_ROUNDS_W32];
-  uint32_t diag;
-};
-// `rcw`: the width-32 constant table in Montgomery form (p3r_ctx::rc + p2_num_constants: round constants | diagonal)
-template <class PP>
-__device__ __forceinline__ Coop32Rc<PP> coop32_load_rc(const uint32_t* __restrict__ rcw, int elem) {
-  Coop32Rc<PP> c;
-#pragma unroll
-  for (int r = 0; r < P2_HALF_FULL; ++r) c.full[r] = rcw[r * P2W_WIDTH + elem];
-#pragma unroll
-  for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) c.part[r] = rcw[P2_HALF_FULL * P2W_WIDTH + r];
-#pragma unroll
-  for (int r = 0; r < P2_HALF_FULL; ++r)
-    c.full[P2_HALF_FULL + r] = rcw[P2_HALF_FULL * P2W_WIDTH + PP::PARTIAL_ROUNDS_W32 + r * P2W_WIDTH + elem];
-  c.diag = rcw[p2w_num_rc<PP>() + elem];
-  return c;
-}
-template <class PP>
-__device__ __forceinline__ Fp<PP> coop32_permute(Fp<PP> s, int elem, const Coop32Rc<PP>& rc) {
-  using F = Fp<PP>;
-  const F diag = F::raw(rc.diag);
-  s = coop32_external(s);
-#pragma unroll
-  for (int r = 0; r < P2_HALF_FULL; ++r) {
-    s = p2_sbox<PP>(s + F::raw(rc.full[r]));
-    s = coop32_external(s);
-  }
-#pragma unroll 1
-  for (int r = 0; r < PP::PARTIAL_ROUNDS_W32; ++r) {
-    const F rest = coop32_sum(elem == 0 ? F::zero() : s);
-    const F sb = p2_sbox<PP>(s + F::raw(rc.part[r]));
-    const F sum = rest + F::raw(coop32_bcast0(elem == 0 ? sb.v : 0u));
-    s = (elem == 0 ? sb : s) * diag + sum;
-  }
-#pragma unroll
-  for (int r = 0; r < P2_HALF_FULL; ++r) {
-    s = p2_sbox<PP>(s + F::raw(rc.full[P2_HALF_FULL + r]));
-    s = coop32_external(s);
-  }
-  return s;
-}
 
 // One level, 32 lanes per node (k_mmcs4_compress is the one-node-per-lane form): lane e holds word e & 7 of child
 // e >> 3.  For the levels small enough to be latency-bound.

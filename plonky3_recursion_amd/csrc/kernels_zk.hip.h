@@ -19,11 +19,11 @@ struct ZkRandomizeJob {
   uint64_t h2;          // 2h
   uint32_t w, w2;       // original / randomised width
   uint32_t zero_fill;
-  uint64_t key;
+  uint32_t stream;      // zk_stream_id(round, matrix): which stream of the proof's generator (zk_rand.h)
   uint32_t block0;      // first block of this job: blocks cover (column, 256 rows) tiles, rows fastest
 };
 template <class PP>
-__global__ void __launch_bounds__(kBlock) k_zk_randomize(const ZkRandomizeJob* __restrict__ jobs, int n_jobs) {
+__global__ void __launch_bounds__(kBlock) k_zk_randomize(const ZkRandomizeJob* __restrict__ jobs, int n_jobs, ZkKey key) {
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
   const ZkRandomizeJob& j = jobs[jb];
@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(kBlock) k_zk_randomize(const ZkRandomizeJob* _
   if (r >= j.h2) return;
   uint32_t v;
   if (!(r & 1) && c < j.w) v = as_global(j.src)[(uint64_t)c * (j.h2 >> 1) + (r >> 1)];
-  else v = j.zero_fill ? 0u : zk_rand_mont<PP>(j.key, r * j.w2 + c);
+  else v = j.zero_fill ? 0u : zk_rand_mont<PP>(key, j.stream, r * j.w2 + c);
   as_global(j.dst)[(uint64_t)c * j.h2 + r] = v;
 }
 
@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(kBlock) k_zk_randomize(const ZkRandomizeJob* _
 constexpr int kZkMaxChunks = 8;
 struct ZkMaskArgs {
   uint32_t* t[kZkMaxChunks];    // [DC][n] each; t[C - 1] is written
-  uint64_t key[kZkMaxChunks];
+  uint32_t stream[kZkMaxChunks];
+  ZkKey key;
   uint32_t coef[kZkMaxChunks];  // -(k_c / k_{C-1}), Montgomery
   uint64_t n;
   int C, DC;
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(kBlock) k_zk_masks(ZkMaskArgs a) {
   const uint64_t k = i / a.n, r = i % a.n;
   F acc = F::zero();
   for (int c = 0; c + 1 < a.C; ++c) {
-    const F v = F::raw(zk_rand_mont<PP>(a.key[c], r * a.DC + k));
+    const F v = F::raw(zk_rand_mont<PP>(a.key, a.stream[c], r * a.DC + k));
     as_global(a.t[c])[i] = v.v;
     acc += v * F::raw(a.coef[c]);
   }
@@ -73,11 +74,11 @@ struct ZkChunkJob {
   uint32_t* dst;           // [DC + R][2n]
   uint64_t n;
   int log_n, DC, R;
-  uint64_t key;
+  uint32_t stream;
   uint32_t block0;
 };
 template <class PP>
-__global__ void __launch_bounds__(kBlock) k_zk_chunk(const ZkChunkJob* __restrict__ jobs, int n_jobs) {
+__global__ void __launch_bounds__(kBlock) k_zk_chunk(const ZkChunkJob* __restrict__ jobs, int n_jobs, ZkKey key) {
   using F = Fp<PP>;
   int jb = 0;
   while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(kBlock) k_zk_chunk(const ZkChunkJob* __restric
   if (r >= h2) return;
   uint32_t v;
   if ((int)c >= j.DC) {
-    v = zk_rand_mont<PP>(j.key, r * (uint64_t)(j.DC + j.R) + c);
+    v = zk_rand_mont<PP>(key, j.stream, r * (uint64_t)(j.DC + j.R) + c);
   } else if (!(r & 1)) {
     v = as_global(j.q)[(uint64_t)c * j.n + (r >> 1)];
   } else {

@@ -10,7 +10,10 @@
 #include "prep_device.h"
 #include "host_abi.h"
 
+#include <sys/random.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <future>
 #include <numeric>
 #include <unordered_map>
@@ -621,6 +624,21 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
     }
+    if (cfg->zk) {
+      // the key the context draws its masks with (zk_rand.h): the caller's, mixed with 128 bits of operating-system
+      // entropy unless reproducible proofs were asked for
+      uint32_t entropy[4] = {0, 0, 0, 0};
+      const bool deterministic = cfg->ext_choices & P3R_EXT_ZK_DETERMINISTIC;
+      if (!deterministic) {
+        size_t got = 0;
+        while (got < sizeof entropy) {
+          const ssize_t r = getrandom(reinterpret_cast<uint8_t*>(entropy) + got, sizeof entropy - got, 0);
+          if (r < 0) { if (errno == EINTR) continue; fail(P3R_EHIP, "getrandom failed (errno %d): no entropy for the ZK key", errno); }
+          got += (size_t)r;
+        }
+      }
+      zk_context_key(cfg->zk_key, entropy, deterministic, c->zk_key);
+    }
     P3R_FIELD_CALL(c, init_ctx, c.get());
     ctx = c.release();
   });
@@ -664,6 +682,10 @@ int p3r_poseidon2_round_constants(const p3r_ctx* ctx, uint32_t* out) {
 uint64_t p3r_zk_nonce(const p3r_ctx* ctx) { return ctx ? ctx->zk_nonce : 0; }
 int p3r_zk_set_nonce(p3r_ctx* ctx, uint64_t nonce) {
   if (!ctx) return P3R_EINVAL;
+  if (!(ctx->cfg.ext_choices & P3R_EXT_ZK_DETERMINISTIC)) {
+    ctx->err = "p3r_zk_set_nonce needs P3R_EXT_ZK_DETERMINISTIC: replaying a nonce repeats the masks of an earlier proof";
+    return P3R_EINVAL;
+  }
   ctx->zk_nonce = nonce;
   return P3R_OK;
 }

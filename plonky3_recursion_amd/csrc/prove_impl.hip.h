@@ -194,7 +194,8 @@ inline int zk_codewords(const p3r_config& cfg) { return cfg.zk ? (cfg.num_random
 // src[i] == nullptr: a fully random 2 * h[i] x (w[i] + R) matrix (w[i] = the width before the codeword columns).
 template <class PP>
 std::vector<std::unique_ptr<p3r_dmat>> zk_randomize(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& src, const std::vector<size_t>& h,
-                                                    const std::vector<size_t>& w, int R, const std::vector<uint64_t>& keys, bool zero_fill) {
+                                                    const std::vector<size_t>& w, int R, const std::vector<uint32_t>& streams, const ZkKey& key,
+                                                    bool zero_fill) {
   std::vector<std::unique_ptr<p3r_dmat>> out;
   std::vector<ZkRandomizeJob> jobs;
   uint64_t blocks = 0;
@@ -207,7 +208,8 @@ std::vector<std::unique_ptr<p3r_dmat>> zk_randomize(p3r_ctx* ctx, const std::vec
     j.w = src[i] ? (uint32_t)w[i] : 0u;
     j.w2 = (uint32_t)(w[i] + (size_t)R);
     j.zero_fill = zero_fill ? 1u : 0u;
-    j.key = keys[i];
+    j.stream = streams[i];
+    if ((uint64_t)j.h2 * j.w2 >= (uint64_t(1) << 35)) fail(P3R_EUNSUPPORTED, "ZK: a matrix of 2^35 cells or more");
     j.block0 = (uint32_t)blocks;
     blocks += (uint64_t)j.w2 * ((j.h2 + kBlock - 1) / kBlock);
     jobs.push_back(j);
@@ -218,7 +220,7 @@ std::vector<std::unique_ptr<p3r_dmat>> zk_randomize(p3r_ctx* ctx, const std::vec
   P3R_HIP(ctx->stage.upload(ctx->stream, d_jobs.p, jobs.data(), jobs.size() * sizeof(ZkRandomizeJob)));
   ProfScope ps(ctx, "zk_randomize");
   hipLaunchKernelGGL(k_zk_randomize<PP>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
-                     reinterpret_cast<const ZkRandomizeJob*>(d_jobs.p), (int)jobs.size());
+                     reinterpret_cast<const ZkRandomizeJob*>(d_jobs.p), (int)jobs.size(), key);
   P3R_HIP(hipGetLastError());
   return out;
 }
@@ -262,7 +264,7 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
     std::vector<const p3r_dmat*> src;
     std::vector<size_t> hs, ws;
     for (auto& t : prep->traces) { src.push_back(t.get()); hs.push_back(t->h); ws.push_back(t->w); }
-    prep->evals = zk_randomize<PP>(ctx, src, hs, ws, prep->zk_codewords, std::vector<uint64_t>(n, 0), true);
+    prep->evals = zk_randomize<PP>(ctx, src, hs, ws, prep->zk_codewords, std::vector<uint32_t>(n, 0), ZkKey{}, true);
     for (size_t i = 0; i < n; ++i) items[i].in = prep->evals[i].get();
   }
   prep->ldes = coset_lde_batch<PP>(ctx, items, (int)ctx->cfg.log_blowup);
@@ -294,7 +296,10 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   const int zk = cfg.zk ? 1 : 0, R = zk_codewords(cfg);
   if (prep->zk_codewords != R) fail(P3R_EINVAL, "the preprocessed data was committed under another ZK setting");
   const uint64_t nonce = zk ? ctx->zk_nonce++ : 0;
-  auto zkey = [&](int round, size_t mat) { return zk_stream_key(cfg.zk_seed, nonce, round, mat); };
+  ZkKey zk_key{};
+  for (int i = 0; i < 8; ++i) zk_key.k[i] = ctx->zk_key[i];
+  zk_key.nonce_lo = (uint32_t)nonce; zk_key.nonce_hi = (uint32_t)(nonce >> 32);
+  auto zkey = [&](int round, size_t mat) { return zk_stream_id(round, mat); };
   std::vector<LookupLayout> layouts(ni);
   std::vector<int> log_n(ni), log_e(ni);
   for (size_t i = 0; i < ni; ++i) {
@@ -324,9 +329,9 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<const p3r_dmat*> main_ev(mains, mains + ni);
   if (zk) {
     std::vector<size_t> hs, ws;
-    std::vector<uint64_t> keys;
+    std::vector<uint32_t> keys;
     for (size_t i = 0; i < ni; ++i) { hs.push_back(mains[i]->h); ws.push_back(mains[i]->w); keys.push_back(zkey(ZK_ROUND_MAIN, i)); }
-    main_r = zk_randomize<PP>(ctx, main_ev, hs, ws, R, keys, false);
+    main_r = zk_randomize<PP>(ctx, main_ev, hs, ws, R, keys, zk_key, false);
     for (size_t i = 0; i < ni; ++i) main_ev[i] = main_r[i].get();
   }
   for (size_t i = 0; i < ni; ++i) lde_items.push_back({main_ev[i], PP::GEN});
@@ -415,12 +420,12 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     if (zk) {
       std::vector<const p3r_dmat*> src;
       std::vector<size_t> hs, ws;
-      std::vector<uint64_t> keys;
+      std::vector<uint32_t> keys;
       for (size_t k = 0; k < perm_insts.size(); ++k) {
         const p3r_dmat* a = aux[perm_insts[k]].get();
         src.push_back(a); hs.push_back(a->h); ws.push_back(a->w); keys.push_back(zkey(ZK_ROUND_PERM, k));
       }
-      auto rs = zk_randomize<PP>(ctx, src, hs, ws, R, keys, false);
+      auto rs = zk_randomize<PP>(ctx, src, hs, ws, R, keys, zk_key, false);
       for (size_t k = 0; k < perm_insts.size(); ++k) {
         aux_r[perm_insts[k]] = std::move(rs[k]);
         aux_ev[perm_insts[k]] = aux_r[perm_insts[k]].get();
@@ -543,11 +548,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       }
       const F u = sh[C - 1] * g2, neg_inv_last = -(kc[C - 1].inv());
       ZkMaskArgs ma{};
-      ma.n = n; ma.C = C; ma.DC = DC;
+      ma.n = n; ma.C = C; ma.DC = DC; ma.key = zk_key;
       for (int c = 0; c < C; ++c) {
         zk_keep.push_back(dmat_alloc(n, DC));
         ma.t[c] = zk_keep.back()->d;
-        ma.key[c] = zkey(ZK_ROUND_QMASK, k0 + c);
+        ma.stream[c] = zkey(ZK_ROUND_QMASK, k0 + c);
         ma.coef[c] = (kc[c] * neg_inv_last).v;
         t_moves.push_back({zk_keep.back().get(), (sh[c] * g2 * u.inv()).to_canonical()});
         q_moves.push_back({chunks[k0 + c].evals.get(), g2.to_canonical()});
@@ -568,7 +573,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       ZkChunkJob j{};
       j.q = chunks[k].evals->d; j.q_odd = q_odd[k]->d; j.t_odd = t_odd[k]->d; j.dst = m->d;
       j.n = n; j.log_n = log_n[chunks[k].inst]; j.DC = DC; j.R = R;
-      j.key = zkey(ZK_ROUND_QUOTIENT, k);
+      j.stream = zkey(ZK_ROUND_QUOTIENT, k);
       j.block0 = (uint32_t)blocks;
       blocks += (uint64_t)(DC + R) * ((2 * n + kBlock - 1) / kBlock);
       jobs.push_back(j);
@@ -580,7 +585,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     {
       ProfScope ps(ctx, "zk_chunks");
       hipLaunchKernelGGL(k_zk_chunk<PP>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
-                         reinterpret_cast<const ZkChunkJob*>(d_jobs.p), (int)jobs.size());
+                         reinterpret_cast<const ZkChunkJob*>(d_jobs.p), (int)jobs.size(), zk_key);
     }
     P3R_HIP(hipGetLastError());
     for (auto& m : q_odd) zk_keep.push_back(std::move(m));   // the stream still reads them
@@ -604,9 +609,9 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   if (zk) {
     std::vector<const p3r_dmat*> src(ni, nullptr);
     std::vector<size_t> hs, ws(ni, (size_t)DC);
-    std::vector<uint64_t> keys;
+    std::vector<uint32_t> keys;
     for (size_t i = 0; i < ni; ++i) { hs.push_back(mains[i]->h); keys.push_back(zkey(ZK_ROUND_RANDOM, i)); }
-    rand_ev = zk_randomize<PP>(ctx, src, hs, ws, R, keys, false);
+    rand_ev = zk_randomize<PP>(ctx, src, hs, ws, R, keys, zk_key, false);
     lde_items.clear();
     for (auto& m : rand_ev) lde_items.push_back({m.get(), PP::GEN});
     rand_lde = coset_lde_batch<PP>(ctx, lde_items, log_blowup);

@@ -59,6 +59,15 @@ struct RunP2B {
   uint32_t row, prev_row, op_idx, absorb_len;
 };
 
+// A permutation of the WIDTH-32 table in a D = 4 circuit (P3R_OP_POSEIDON2_W32_PERM: the arity-4 compression shape,
+// poseidon_perm/executor.rs:92-235): eight input limbs, two direction bits, up to eight output limbs; thirty-two lanes.
+struct RunP2W {
+  uint32_t in[8], bit_w, bit2_w, out[8];
+  uint32_t flags;       // bit 0 new_start, 1 merkle_path, 8-11 number of outputs, 16-23 output l is a check
+  uint32_t row, prev_row, op_idx;
+  uint32_t prev_in_seg; // 1: prev_row is the row just before this one in its segment (the state is still in registers)
+};
+
 enum : uint32_t { RUN_ERR_CONFLICT = 1, RUN_ERR_DIV0 = 2, RUN_ERR_MMCS_BIT = 3, RUN_ERR_INDEX_SUM = 4 };
 
 struct RunSchedule {
@@ -72,6 +81,13 @@ struct RunSchedule {
   std::vector<RunP2B> p2b;                  // the same for base-mode rows (circuits of degree 1 / 5): one of the two is empty
   std::vector<P2Seg> p2segs;                // sorted by level
   std::vector<uint32_t> light_off, p2seg_off;  // per level, size levels + 1
+  // rows of the width-32 table (D = 4 circuits that hold P3R_OP_POSEIDON2_W32_PERM ops): same segment rule - a row
+  // joins the segment whose last row is its predecessor when its witnesses are ready in time
+  std::vector<RunP2W> p2w;
+  std::vector<P2Seg> p2wsegs;
+  std::vector<uint32_t> p2wseg_off;         // per level, size levels + 1 (empty: no width-32 rows)
+  std::vector<uint32_t> p2w_row_of_op_id;   // NonPrimitiveOpId -> width-32 row (or kNoW)
+  std::vector<uint8_t> p2w_row_merkle;
   std::vector<uint32_t> dev_ext;
   std::vector<uint32_t> const_rows;         // const op -> witness, in table order (static Const trace)
   std::vector<uint32_t> public_out;         // public table row -> witness
@@ -100,8 +116,9 @@ inline void finish_segments(RunSchedule& S) {
   for (uint32_t l = 1; l <= S.levels; ++l) {
     const uint32_t nl = S.light_off[l + 1] - S.light_off[l], np = S.p2seg_off[l + 1] - S.p2seg_off[l];
     const uint32_t nc = S.chain_off[l + 1] - S.chain_off[l];
-    if (!nl && !np && !nc) continue;
-    const bool narrow = nl <= 1024 && np <= 64 && !nc;
+    const uint32_t npw = S.p2wseg_off.empty() ? 0u : S.p2wseg_off[l + 1] - S.p2wseg_off[l];
+    if (!nl && !np && !nc && !npw) continue;
+    const bool narrow = nl <= 1024 && np <= 64 && npw <= 32 && !nc;
     if (narrow && !S.segments.empty() && S.segments.back().narrow && S.segments.back().l1 == l) S.segments.back().l1 = l + 1;
     else S.segments.push_back({l, l + 1, narrow, 0, 0});
   }

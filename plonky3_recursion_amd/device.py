@@ -38,7 +38,8 @@ def _u8(a):
 def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5,
                 commit_pow_bits=0, query_pow_bits=15, num_queries=54, device=0, poseidon2_rc=None, ext_choices=0,
                 fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0, challenge_degree=4,
-                poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2, zk=0, num_random_codewords=2, zk_seed=0):
+                poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2, zk=0, num_random_codewords=2, zk_seed=None,
+                zk_key=None, zk_deterministic=None, allow_unpinned_w32_defaults=False):
     """A `p3r_config` (+ the arrays it points into, which must stay alive with it).  `ext_choices` /
     `fri_log_arities`: the selectable protocol details of include/p3r.h.
     `ext_degree`: the circuit extension degree D of the traces - 4, or 5 for KoalaBear circuits over the quintic
@@ -51,7 +52,23 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
     cfg.challenge_degree = challenge_degree   # 5: KoalaBear's quintic challenge field
     cfg.mmcs_arity = mmcs_arity               # 4: the arity-4 MMCS over the width-32 permutation (recursive_aggregation --arity4)
     # ZK: HidingFriPcs with `num_random_codewords` random codewords and a seeded RNG (create_config_zk)
-    cfg.zk, cfg.num_random_codewords, cfg.zk_seed = int(zk), int(num_random_codewords) if zk else 0, int(zk_seed)
+    # `zk_key`: the 256-bit key of its generator (eight u32 words, or 32 bytes); the library mixes operating-system
+    # entropy into it unless `zk_deterministic`.  `zk_seed` is the test harness's shorthand: key = (seed, 0, ..) taken
+    # as it is - reproducible proofs, which is what a comparison with the CPU oracle needs and a deployment must not use.
+    cfg.zk, cfg.num_random_codewords = int(zk), int(num_random_codewords) if zk else 0
+    if zk_seed is not None and zk_key is not None:
+        raise P3rError(-1, "pass zk_key or zk_seed, not both")
+    if zk_seed is not None:
+        zk_key = [int(zk_seed) & 0xFFFFFFFF, (int(zk_seed) >> 32) & 0xFFFFFFFF, 0, 0, 0, 0, 0, 0]
+        zk_deterministic = True if zk_deterministic is None else zk_deterministic
+    if zk_key is not None:
+        words = np.frombuffer(bytes(zk_key), dtype="<u4") if isinstance(zk_key, (bytes, bytearray)) else np.asarray(zk_key, dtype=np.uint32)
+        if words.size != 8:
+            raise P3rError(-1, "zk_key must hold 256 bits (eight u32 words or 32 bytes)")
+        for i in range(8):
+            cfg.zk_key[i] = int(words[i])
+    if zk_deterministic:
+        ext_choices |= _lib.P3R_EXT_ZK_DETERMINISTIC
     cfg.log_blowup = log_blowup
     cfg.max_log_arity = max_log_arity
     cfg.cap_height = cap_height
@@ -66,10 +83,10 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
         cfg.poseidon2_rc = ptr
         cfg.poseidon2_rc_len = rc.size
     # The width-32 permutation's constants live in un-vendored crates; the library's defaults for them are self-generated
-    # and the C ABI wants that acknowledged (P3R_EXT_UNPINNED_W32_DEFAULTS).  This mirror is the test / bench harness,
-    # where the defaults are the deliberate choice: the bit is set whenever they would be used, and bench.py labels every
-    # such leg "unpinned".  A Rust / C++ caller passes upstream's statics instead.
-    if poseidon2_w32_rc is None or poseidon2_w32_diag is None:
+    # and the C ABI wants that acknowledged (P3R_EXT_UNPINNED_W32_DEFAULTS): so does this mirror - a caller that uses
+    # the arity-4 MMCS or the width-32 table without upstream's statics says `allow_unpinned_w32_defaults=True` (the
+    # tests, bench.py's "unpinned" legs and the profiling tools do), as p3r.hpp's FriParams has it.
+    if allow_unpinned_w32_defaults and (poseidon2_w32_rc is None or poseidon2_w32_diag is None):
         ext_choices |= _lib.P3R_EXT_UNPINNED_W32_DEFAULTS
     cfg.ext_choices = ext_choices
     ar = None
@@ -145,7 +162,7 @@ class Context:
                  log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
                  device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0,
                  challenge_degree=4, poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2, zk=0,
-                 num_random_codewords=2, zk_seed=0):
+                 num_random_codewords=2, zk_seed=None, zk_key=None, zk_deterministic=None, allow_unpinned_w32_defaults=False):
         self.lib = _lib.load()
         self.mmcs_arity = mmcs_arity
         self.zk = int(zk)
@@ -157,7 +174,8 @@ class Context:
         cfg, self._rc_keep = make_config(field, log_blowup, max_log_arity, cap_height, log_final_poly_len,
                                          commit_pow_bits, query_pow_bits, num_queries, device, poseidon2_rc, ext_choices,
                                          fri_log_arities, proof_layout, ext_degree, ext_w, challenge_degree,
-                                         poseidon2_w32_rc, poseidon2_w32_diag, mmcs_arity, zk, num_random_codewords, zk_seed)
+                                         poseidon2_w32_rc, poseidon2_w32_diag, mmcs_arity, zk, num_random_codewords, zk_seed,
+                                         zk_key, zk_deterministic, allow_unpinned_w32_defaults)
         self.cfg = cfg
         self.cap_height = cap_height
         self.log_blowup = log_blowup

@@ -215,7 +215,9 @@ class CircuitProverData:
 TRACES_ARRAYS = dict(const_values=(0, "const", 4), public_values=(1, "public", 4), alu_values=(2, "alu", 16),
                      p2_input_values=(3, "poseidon2", 16), p2_flags=(4, "poseidon2", 3),
                      p2_mmcs_index_sum=(5, "poseidon2", 1), recompose_values=(6, "recompose", 4),
-                     recompose_coeff_values=(7, "recompose_coeff", 4))
+                     recompose_coeff_values=(7, "recompose_coeff", 4),
+                     p2w_input_values=(8, "poseidon2_w32", 32), p2w_flags=(9, "poseidon2_w32", 4),
+                     p2w_mmcs_index_sum=(10, "poseidon2_w32", 1))
 
 
 class ResidentTraces:
@@ -628,6 +630,9 @@ class CircuitInputs:
     private_values: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.uint32))
     private_data_op_ids: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
     private_data_siblings: np.ndarray = field(default_factory=lambda: np.zeros((0, 8), np.uint32))
+    # private data of width-32 Merkle rows (P3R_OP_POSEIDON2_W32_PERM): the three sibling digests of an arity-4 level
+    private_data_w32_op_ids: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
+    private_data_w32_siblings: np.ndarray = field(default_factory=lambda: np.zeros((0, 24), np.uint32))
 
 
 def _flat32(a):
@@ -665,7 +670,7 @@ class PreparedCircuit:
         cn = _lib.P3rLayerCounts()
         ctx.check(ctx.lib.p3r_circuit_counts(self.h, C.byref(cn)))
         rows = dict(const=cn.n_const, public=cn.n_public, alu=cn.n_alu, poseidon2=cn.n_p2, recompose=cn.n_recompose,
-                    recompose_coeff=cn.n_recompose_coeff)
+                    recompose_coeff=cn.n_recompose_coeff, poseidon2_w32=cn.n_p2w)
         lv = C.c_size_t()
         ctx.check(ctx.lib.p3r_circuit_levels(self.h, C.byref(lv)))
         self.levels = lv.value
@@ -703,7 +708,12 @@ class PreparedCircuit:
         if sib.size != 8 * ids.size:
             raise ValueError("private_data_siblings must hold two extension limbs (8 values) per op id")
         t.n_private_data = ids.size
-        return t, (pub, prv, ids, sib)
+        idw, t.private_data_w32_op_ids = _flat32(inputs.private_data_w32_op_ids)
+        sibw, t.private_data_w32_siblings = _flat32(inputs.private_data_w32_siblings)
+        if sibw.size != 24 * idw.size:
+            raise ValueError("private_data_w32_siblings must hold three digests of two extension limbs (24 values) per op id")
+        t.n_private_data_w32 = idw.size
+        return t, (pub, prv, ids, sib, idw, sibw)
 
     def upload_inputs(self, inputs: CircuitInputs) -> "ResidentInputs":
         return ResidentInputs(self, inputs)
@@ -963,7 +973,11 @@ def pack_aggregation_inputs(left: CircuitInputs, right: CircuitInputs, left_non_
     return CircuitInputs(public_values=cat(left.public_values, right.public_values, 4),
                          private_values=cat(left.private_values, right.private_values, 4),
                          private_data_op_ids=ids,
-                         private_data_siblings=cat(left.private_data_siblings, right.private_data_siblings, 8))
+                         private_data_siblings=cat(left.private_data_siblings, right.private_data_siblings, 8),
+                         private_data_w32_op_ids=np.concatenate([
+                             np.asarray(left.private_data_w32_op_ids, np.uint32).reshape(-1),
+                             np.asarray(right.private_data_w32_op_ids, np.uint32).reshape(-1) + np.uint32(left_non_primitive_ops)]),
+                         private_data_w32_siblings=cat(left.private_data_w32_siblings, right.private_data_w32_siblings, 24))
 
 
 def prove_aggregation_layer(left: RecursionInput, right: RecursionInput, verification_circuit: Circuit, ctx: Context,

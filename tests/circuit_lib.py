@@ -9,7 +9,7 @@ import oracle_lib
 u32p = C.POINTER(C.c_uint32)
 NO_W = 0xFFFFFFFF
 (OP_CONST, OP_PUBLIC, OP_ADD, OP_MUL, OP_BOOL, OP_MULADD, OP_HORNER, OP_HINT_EXT, OP_HINT_BIN, OP_P2,
- OP_RECOMPOSE) = range(11)
+ OP_RECOMPOSE, OP_P2W) = range(12)
 
 PREP_ARRAYS = ["const_prep", "public_prep", "alu_prep13", "recompose_prep", "recompose_coeff_prep", "p2_in_ctl", "p2_input_indices",
                "p2_out_ctl", "p2_output_indices", "p2_mmcs_index_sum_idx"]
@@ -43,13 +43,15 @@ class Circuit:
 
 
 class Inputs:
-    def __init__(self, public_values=(), private_values=(), pd_op_ids=(), pd_siblings=()):
+    def __init__(self, public_values=(), private_values=(), pd_op_ids=(), pd_siblings=(), pdw_op_ids=(), pdw_siblings=()):
         self.public_values, self.private_values = _arr(public_values), _arr(private_values)
         self.pd_op_ids, self.pd_siblings = _arr(pd_op_ids), _arr(pd_siblings)
+        self.pdw_op_ids, self.pdw_siblings = _arr(pdw_op_ids), _arr(pdw_siblings)   # width-32 Merkle rows: 24 values per id
 
     @classmethod
     def from_arrays(cls, a):
-        return cls(a["in_public_values"], a["in_private_values"], a["pd_op_ids"], a["pd_siblings"])
+        return cls(a["in_public_values"], a["in_private_values"], a["pd_op_ids"], a["pd_siblings"],
+                   a.get("pdw_op_ids", ()), a.get("pdw_siblings", ()))
 
 
 class OracleCircuit:
@@ -61,6 +63,7 @@ class OracleCircuit:
         lib.orc_circuit_free.argtypes = [C.c_void_p]
         lib.orc_circuit_preprocess.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         lib.orc_circuit_run.argtypes = [C.c_void_p, C.c_int, u32p, u32p, u32p, C.c_size_t, u32p, u32p]
+        lib.orc_circuit_run_w32.argtypes = [C.c_void_p, C.c_int, u32p, u32p, u32p, u32p, u32p, C.c_size_t, u32p, u32p, C.c_size_t, u32p, u32p]
         lib.orc_circuit_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(u32p), C.POINTER(C.c_size_t)]
         d = OrcCircuitDesc()
         c = circuit
@@ -82,9 +85,18 @@ class OracleCircuit:
         self.orc._ck(self.orc.lib.orc_circuit_preprocess(self.h, modulus, d))
         return self
 
-    def run(self, field, inputs: Inputs, rc=None):
+    def run(self, field, inputs: Inputs, rc=None, w32=None):
         rc = oracle_lib.default_rc(field) if rc is None else np.ascontiguousarray(rc, dtype=np.uint32)
         i = inputs
+        if (self.circuit.ops[:, 0] == OP_P2W).any():
+            w32 = oracle_lib.default_w32(field) if w32 is None else w32
+            wrc, wdiag = (np.ascontiguousarray(x, dtype=np.uint32) for x in w32)
+            self.orc._ck(self.orc.lib.orc_circuit_run_w32(
+                self.h, oracle_lib.FIELD_IDS[field], rc.ctypes.data_as(u32p), wrc.ctypes.data_as(u32p), wdiag.ctypes.data_as(u32p),
+                i.public_values.ctypes.data_as(u32p), i.private_values.ctypes.data_as(u32p), len(i.pd_op_ids),
+                i.pd_op_ids.ctypes.data_as(u32p), i.pd_siblings.ctypes.data_as(u32p), len(i.pdw_op_ids),
+                i.pdw_op_ids.ctypes.data_as(u32p), i.pdw_siblings.ctypes.data_as(u32p)))
+            return self
         self.orc._ck(self.orc.lib.orc_circuit_run(
             self.h, oracle_lib.FIELD_IDS[field], rc.ctypes.data_as(u32p), i.public_values.ctypes.data_as(u32p),
             i.private_values.ctypes.data_as(u32p), len(i.pd_op_ids), i.pd_op_ids.ctypes.data_as(u32p),
@@ -99,8 +111,11 @@ class OracleCircuit:
         rf = self.get("p2_flags").reshape(-1, 4)        # new_start, merkle_path, mmcs_bit, mmcs_ctl_enabled
         assert np.array_equal(pf[:, :2], rf[:, :2])
         out["p2_flags"] = rf.reshape(-1)
+        for k in ("p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep"):   # the width-32 table (OP_P2W ops)
+            out[k] = self.get(k)
         n = [len(out["const_values"]) // 4, len(out["public_values"]) // 4, len(out["alu_values"]) // 16,
-             len(rf), len(out["recompose_values"]) // 4, self.circuit.witness_count, len(out["recompose_coeff_values"]) // 4]
+             len(rf), len(out["recompose_values"]) // 4, self.circuit.witness_count, len(out["recompose_coeff_values"]) // 4,
+             len(out["p2w_mmcs_index_sum"])]
         out["counts"] = np.array(n, dtype=np.uint32)
         return out
 

@@ -63,7 +63,9 @@ def circuit_from_arrays(a) -> Circuit:
 def circuit_inputs_from_arrays(a, ext_degree=4) -> CircuitInputs:
     return CircuitInputs(public_values=a["in_public_values"].reshape(-1, ext_degree),
                          private_values=a["in_private_values"].reshape(-1, ext_degree),
-                         private_data_op_ids=a["pd_op_ids"], private_data_siblings=a["pd_siblings"].reshape(-1, 8))
+                         private_data_op_ids=a["pd_op_ids"], private_data_siblings=a["pd_siblings"].reshape(-1, 8),
+                         private_data_w32_op_ids=a.get("pdw_op_ids", np.zeros(0, np.uint32)),
+                         private_data_w32_siblings=np.asarray(a.get("pdw_siblings", np.zeros(0, np.uint32))).reshape(-1, 24))
 
 
 def split_aggregation_inputs(inputs: CircuitInputs):

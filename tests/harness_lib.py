@@ -18,7 +18,9 @@ ARRAYS = ["const_values", "const_prep", "public_values", "public_prep", "alu_val
           "ops", "ext", "public_rows", "in_public_values", "private_rows", "in_private_values", "pd_op_ids",
           "pd_siblings", "rewrite", "p2_absorb_len", "recompose_coeff_values", "recompose_coeff_prep",
           # the width-32 Poseidon2 table (flag P2_W32; counts[7] rows): inputs n x 32, flags n x 4, index sums, assembled prep n x 48
-          "p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep"]
+          "p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep",
+          # P2_W32_OPS: private data of the width-32 Merkle rows (op ids; 24 values = three sibling digests each)
+          "pdw_op_ids", "pdw_siblings"]
 
 
 def build():
@@ -35,6 +37,9 @@ RECOMPOSE_BOTH = 64
 # a width-32 Poseidon2 table next to the width-16 one: arity-4 Merkle chains and rate-24 sponges (Poseidon2Config::*_D4_W32);
 # D = 4 only, at the prove_all_tables boundary (arrays p2w_*, counts[7])
 P2_W32 = 128
+# the width-32 rows as ops of the circuit (P3R_OP_POSEIDON2_W32_PERM) with the executor's exact row semantics, leaf sponges
+# that seed Merkle chains, and their private data (arrays pdw_*): what a verifier circuit built under `--arity4` holds
+P2_W32_OPS = 4096 | P2_W32
 
 
 def generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=6, merkle_depth=20, rc=None,

@@ -59,7 +59,9 @@ SHAPES = [0, harness_lib.NO_POSEIDON2, harness_lib.NO_RECOMPOSE, harness_lib.REC
           harness_lib.RECOMPOSE_COEFF | harness_lib.NO_POSEIDON2, harness_lib.RECOMPOSE_BOTH,
           harness_lib.RECOMPOSE_BOTH | harness_lib.NO_POSEIDON2,
           harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE | harness_lib.SINGLE_PUBLIC,
-          harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU]
+          harness_lib.NO_POSEIDON2 | harness_lib.NO_ALU,
+          # the width-32 Poseidon2 rows as ops of the circuit (arity-4 Merkle verification chains: kind 11)
+          harness_lib.P2_W32_OPS]
 
 
 @pytest.mark.parametrize("field", ["koala-bear", "baby-bear"])
@@ -74,13 +76,26 @@ def test_circuit_path_reproduces_harness_bookkeeping(oracle, field, flags):
             assert np.array_equal(w[k], a[k][:len(w[k])]) and not a[k][len(w[k]):].any(), k
             continue
         assert np.array_equal(w[k], a[k]), k
+    if flags == harness_lib.P2_W32_OPS:
+        # the generator keeps its own books (its rows follow the AIR, poseidon2-circuit-air/src/air.rs:1178-1342); the
+        # oracle restates the executor: both reach the same 48-column rows, inputs, flags and multiplicities
+        ops = a["ops"].reshape(-1, 8)
+        w32 = ops[ops[:, 0] == cl.OP_P2W]
+        fl = a["p2w_flags"].reshape(-1, 4)
+        assert len(w32) == a["counts"][7] == len(fl) and len(a["pdw_op_ids"]) == int(fl[:, 1].sum())
+        seeded = [r for r in range(1, len(fl)) if fl[r, 1] and not fl[r, 0] and not fl[r - 1, 1]]
+        assert seeded, "a Merkle chain that continues a leaf sponge (update_chain_state's seed, executor.rs:462-491)"
+        assert (fl[:, 1] & fl[:, 0]).any(), "a Merkle chain that starts from a CTL-loaded digest"
+        prep = a["p2w_prep"].reshape(-1, 48)
+        assert (prep[fl[:, 1] == 1][:, 1:32:4].sum(axis=1) >= 4).any(), "an injection / bridge level with CTL-loaded pads"
+        assert not a["p2w_mmcs_index_sum"].any()
     if flags == 0:
         kinds = np.bincount(a["ops"].reshape(-1, 8)[:, 0], minlength=11)
         assert kinds.all()   # every op kind is exercised
         assert len(a["private_rows"]) and len(a["rewrite"]) and (a["p2_out_ctl"] == oracle_lib.MODULUS[field] - 1).any()
 
 
-@pytest.mark.parametrize("flags", [0, harness_lib.RECOMPOSE_COEFF, harness_lib.RECOMPOSE_BOTH])
+@pytest.mark.parametrize("flags", [0, harness_lib.RECOMPOSE_COEFF, harness_lib.RECOMPOSE_BOTH, harness_lib.P2_W32_OPS])
 def test_circuit_path_proof_verifies(oracle, flags):
     """Traces + preprocessed columns derived from the circuit prove and verify (LogUp balanced
     under the reference's creator / reader multiplicity rules, every AIR satisfied).  RECOMPOSE_COEFF: the Recompose
@@ -100,6 +115,9 @@ def test_circuit_path_proof_verifies(oracle, flags):
         # both Recompose tables (recompose_table_provers(lanes, true)): `recompose`, then `recompose/coeff`
         assert w["counts"][4] and w["counts"][6]
     L = layer_lib.OracleLayer(oracle, field, w, prm, packing=dict(recompose_coeff_lookups=coeff))
+    if flags == harness_lib.P2_W32_OPS:
+        # six tables: the width-32 one right after the width-16 one (W16 challenger rows, W32 MMCS rows)
+        assert [x["kind"] for x in L.tables()] == ["const", "public", "alu", "poseidon2", "poseidon2_w32", "recompose"]
     if flags & harness_lib.RECOMPOSE_BOTH:
         t = L.tables()
         assert [x["kind"] for x in t[-2:]] == ["recompose", "recompose"] and t[-2]["prep"].shape[1] == 2 and t[-1]["prep"].shape[1] == 10

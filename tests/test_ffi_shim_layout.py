@@ -158,7 +158,7 @@ def test_shim_literals_name_the_headers_abi_version_and_every_config_field():
         assert int(m.group(1)) == abi, "INTEGRATION.md names ABI version %s, p3r.h has %d" % (m.group(1), abi)
     body = re.search(r"typedef struct p3r_config \{(.*?)\} p3r_config;", hdr, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = [re.split(r"[\s\*]+", d.strip())[-1] for d in body.split(";") if d.strip()]
+    fields = [re.sub(r"\[.*\]$", "", re.split(r"[\s\*]+", d.strip())[-1]) for d in body.split(";") if d.strip()]   # (zk_key[8] -> zk_key)
     lits = re.findall(r"let cfg = p3r_config \{(.*?)\};", md, re.S)
     assert lits, "no p3r_config literal found in INTEGRATION.md"
     for lit in lits:

@@ -36,7 +36,7 @@ SHAPES = [
 @pytest.mark.parametrize("shapes", SHAPES)
 def test_commit_and_open_vs_oracle(oracle, field, shapes):
     import plonky3_recursion_amd as p3r
-    c = p3r.Context(field=field, mmcs_arity=4)
+    c = p3r.Context(field=field, mmcs_arity=4, allow_unpinned_w32_defaults=True)
     rng = np.random.default_rng(11)
     mats = [rand(rng, field, s) for s in shapes]
     cap, tree = c.commit(mats)
@@ -71,7 +71,7 @@ def test_reference_round_trip_pattern_on_the_device(oracle):
     import plonky3_recursion_amd as p3r
     from test_oracle_arity4_mmcs import REF_HEIGHT, REF_INDICES, REF_WIDTH, compress4, w32_hash
     for field in FIELDS:
-        c = p3r.Context(field=field, mmcs_arity=4)
+        c = p3r.Context(field=field, mmcs_arity=4, allow_unpinned_w32_defaults=True)
         mat = rand(np.random.default_rng(64), field, (REF_HEIGHT, REF_WIDTH))
         cap, tree = c.commit([mat])
         for index in REF_INDICES:
@@ -93,7 +93,7 @@ def test_tall_tree_every_level_kind(oracle):
     padded to 4)."""
     import plonky3_recursion_amd as p3r
     field = "koala-bear"
-    c = p3r.Context(field=field, mmcs_arity=4)
+    c = p3r.Context(field=field, mmcs_arity=4, allow_unpinned_w32_defaults=True)
     rng = np.random.default_rng(12)
     shapes = [(1 << 17, 3), (1 << 16, 9), (1 << 13, 2), (1 << 17, 30), (1 << 9, 5), (1 << 13, 8)]
     mats = [rand(rng, field, s) for s in shapes]
@@ -117,7 +117,7 @@ def test_binary_and_arity4_verifiers_do_not_accept_each_other(oracle):
     rng = np.random.default_rng(13)
     shapes = [(64, 5), (16, 3)]
     mats = [rand(rng, field, s) for s in shapes]
-    c4, c2 = p3r.Context(field=field, mmcs_arity=4), p3r.Context(field=field)
+    c4, c2 = p3r.Context(field=field, mmcs_arity=4, allow_unpinned_w32_defaults=True), p3r.Context(field=field)
     cap4, t4 = c4.commit(mats)
     cap2, t2 = c2.commit(mats)
     assert not np.array_equal(cap4, cap2)
@@ -138,9 +138,9 @@ def test_binary_and_arity4_verifiers_do_not_accept_each_other(oracle):
 def test_arity4_refuses_a_cap(oracle):
     import plonky3_recursion_amd as p3r
     with pytest.raises(p3r.P3rError, match="cap_height must be 0"):
-        p3r.Context(field="koala-bear", mmcs_arity=4, cap_height=1)
+        p3r.Context(field="koala-bear", mmcs_arity=4, cap_height=1, allow_unpinned_w32_defaults=True)
     with pytest.raises(p3r.P3rError, match="mmcs_arity"):
-        p3r.Context(field="koala-bear", mmcs_arity=3)
+        p3r.Context(field="koala-bear", mmcs_arity=3, allow_unpinned_w32_defaults=True)
 
 
 def test_custom_width32_constants_change_the_tree(oracle):
@@ -154,7 +154,7 @@ def test_custom_width32_constants_change_the_tree(oracle):
     diag2 = rand(rng, field, diag.shape)     # a general diagonal: every entry a full field element
     shapes = [(32, 29), (8, 3)]
     mats = [rand(rng, field, s) for s in shapes]
-    c = p3r.Context(field=field, mmcs_arity=4, poseidon2_w32_rc=rc2, poseidon2_w32_diag=diag2)
+    c = p3r.Context(field=field, mmcs_arity=4, poseidon2_w32_rc=rc2, poseidon2_w32_diag=diag2, allow_unpinned_w32_defaults=True)
     cap, tree = c.commit(mats)
     ocap, otree = oracle.commit4(field, mats, w32=(rc2, diag2))
     dcap, _ = oracle.commit4(field, mats)
@@ -172,7 +172,7 @@ def make_ctx(field, prm, **kw):
     return p3r.Context(field=field, log_blowup=prm.log_blowup, max_log_arity=prm.max_log_arity,
                        cap_height=prm.cap_height, log_final_poly_len=prm.log_final_poly_len,
                        commit_pow_bits=prm.commit_pow_bits, query_pow_bits=prm.query_pow_bits,
-                       num_queries=prm.num_queries, mmcs_arity=prm.mmcs_arity, **kw)
+                       num_queries=prm.num_queries, mmcs_arity=prm.mmcs_arity, **kw, allow_unpinned_w32_defaults=True)
 
 
 def airs_of(tables):
@@ -211,7 +211,7 @@ def test_prove_batch_bytes_equal_oracle(oracle, field, log_h, flags, kw):
     db = [int(np.log2(t["main"].shape[0])) for t in tables]
     p3r.verify_batch(ctx.cfg, airs_of(tables), cap, db, got)
     cfg2, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, 0, prm.log_final_poly_len, prm.commit_pow_bits,
-                                 prm.query_pow_bits, prm.num_queries)
+                                 prm.query_pow_bits, prm.num_queries, allow_unpinned_w32_defaults=True)
     with pytest.raises(p3r.P3rError):
         p3r.verify_batch(cfg2, airs_of(tables), cap, db, got)
     bad = bytearray(got)

@@ -32,7 +32,7 @@ def test_cpp_host_matches_python_binding(oracle, tmp_path, field, log_h):
     a = harness_lib.generate(field, log_h, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
     fri = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15,
                num_queries=54)
-    ctx = p3r.Context(field=field, **fri)
+    ctx = p3r.Context(field=field, **fri, allow_unpinned_w32_defaults=True)
     tp = p3r.TablePacking().with_fri_params(5, 2)
     pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
     assert pc.prove(wl.circuit_inputs_from_arrays(a)) == got
@@ -61,7 +61,7 @@ def test_cpp_host_quintic_layer(oracle, tmp_path):
                              flags=harness_lib.RECOMPOSE_BOTH, ext_degree=5)
     fri = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15,
                num_queries=54)
-    ctx = p3r.Context(field="koala-bear", ext_degree=5, challenge_degree=5, **fri)
+    ctx = p3r.Context(field="koala-bear", ext_degree=5, challenge_degree=5, **fri, allow_unpinned_w32_defaults=True)
     tp = p3r.TablePacking().with_fri_params(5, 2)
     pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
     assert pc.prove(wl.circuit_inputs_from_arrays(a, 5)) == got
@@ -86,7 +86,7 @@ def test_cpp_host_arity4_layer(oracle, tmp_path):
     a = harness_lib.generate("baby-bear", 10, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
     fri = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15,
                num_queries=54, mmcs_arity=4)
-    ctx = p3r.Context(field="baby-bear", **fri)
+    ctx = p3r.Context(field="baby-bear", **fri, allow_unpinned_w32_defaults=True)
     tp = p3r.TablePacking().with_fri_params(5, 2)
     pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
     assert pc.prove(wl.circuit_inputs_from_arrays(a)) == got
@@ -112,7 +112,7 @@ def test_cpp_host_zk_layer(oracle, tmp_path):
     a = harness_lib.generate("koala-bear", 10, seed=0x5EED0000, horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)
     fri = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15,
                num_queries=54)
-    ctx = p3r.Context(field="koala-bear", zk=1, num_random_codewords=2, zk_seed=3, **fri)
+    ctx = p3r.Context(field="koala-bear", zk=1, num_random_codewords=2, zk_seed=3, **fri, allow_unpinned_w32_defaults=True)
     tp = p3r.TablePacking().with_fri_params(5, 2)
     pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
     ctx.zk_nonce = 7
@@ -195,7 +195,7 @@ def test_two_stream_commit_gives_the_same_proof(tmp_path):
         "import harness_lib, harness_adapters as wl, plonky3_recursion_amd as p3r\n"
         "a = harness_lib.generate('koala-bear', 17, seed=5, horner_chain_len=64, sponge_chain_len=8, merkle_depth=20)\n"
         "for zk in (0, 1):\n"
-        "    ctx = p3r.Context(field='koala-bear', zk=zk, zk_seed=3)\n"
+        "    ctx = p3r.Context(field='koala-bear', zk=zk, zk_seed=3, allow_unpinned_w32_defaults=True)\n"
         "    pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), p3r.TablePacking().with_fri_params(5, 2))\n"
         "    print(hashlib.sha256(pc.prove(wl.circuit_inputs_from_arrays(a))).hexdigest())\n"
         "    pc.free(); ctx.close()\n" % (ROOT, os.path.join(ROOT, "tests")))

@@ -23,7 +23,7 @@ def test_headline_layer_proves_and_both_verifiers_accept(oracle, field, log_h):
     import plonky3_recursion_amd as p3r
     import harness_adapters as wl
     arrs = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN)   # the bench workload
-    ctx = p3r.Context(field=field, **FRI)
+    ctx = p3r.Context(field=field, **FRI, allow_unpinned_w32_defaults=True)
     tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
     circuit = wl.circuit_from_arrays(arrs)
     cache = p3r.build_next_layer_prep(ctx, circuit, p3r.FriRecursionBackend(),
@@ -84,7 +84,7 @@ def test_headline_lde_and_commit_bit_exact(oracle, field, log_h, width):
     m = rng.integers(0, p, size=(1 << log_h, width), dtype=np.uint32)
     m[0, :] = p - 1
     m[-1, :] = 0
-    ctx = p3r.Context(field=field, **FRI)
+    ctx = p3r.Context(field=field, **FRI, allow_unpinned_w32_defaults=True)
     dm = ctx.upload(m)
     lde = ctx.coset_lde_batch_device(dm, 2, g)
     cap, tree = ctx.commit_device([lde])

@@ -22,7 +22,7 @@ def setup(oracle, field, log_h, kw, flags=0, packing=None):
     a = harness_lib.generate(field, log_h, seed=40 + log_h, flags=harness_lib.P2_W32 | flags, **GEN)
     prm = layer_lib.params(**kw)
     L = layer_lib.OracleLayer(oracle, field, a, prm, packing=packing)
-    ctx = p3r.Context(field=field, **kw)
+    ctx = p3r.Context(field=field, **kw, allow_unpinned_w32_defaults=True)
     tp = p3r.TablePacking(**(packing or {})).with_fri_params(kw["log_final_poly_len"], kw["log_blowup"])
     cpd = p3r.CircuitProverData(ctx, wl.circuit_prep_from_arrays(a), tp)
     return a, L, ctx, cpd, wl.traces_from_arrays(a)
@@ -71,7 +71,7 @@ def test_broken_row_is_refused_by_the_prover(oracle):
     fl = a["p2w_flags"].reshape(-1, 4)
     r = next(r for r in range(len(fl)) if fl[r, 1] and not fl[r, 0])
     a["p2w_inputs"].reshape(-1, 32)[r, 8 * int(fl[r, 2] + 2 * fl[r, 3])] ^= 1   # chunk `pos` is no longer the running hash
-    ctx = p3r.Context(field=field, **kw)
+    ctx = p3r.Context(field=field, **kw, allow_unpinned_w32_defaults=True)
     tp = p3r.TablePacking().with_fri_params(kw["log_final_poly_len"], kw["log_blowup"])
     cpd = p3r.CircuitProverData(ctx, wl.circuit_prep_from_arrays(a), tp)
     with pytest.raises(p3r.P3rError, match="constraints"):
@@ -86,8 +86,8 @@ def test_custom_width32_constants_are_data(oracle):
     field, kw = "koala-bear", SETS[0]
     rc, diag = oracle_lib.default_w32(field)
     with pytest.raises(p3r.P3rError, match="poseidon2_w32_rc_len"):
-        p3r.Context(field=field, poseidon2_w32_rc=rc[:-1], **kw)
-    ctx = p3r.Context(field=field, poseidon2_w32_rc=rc, poseidon2_w32_diag=diag, **kw)   # the defaults, passed explicitly
+        p3r.Context(field=field, poseidon2_w32_rc=rc[:-1], **kw, allow_unpinned_w32_defaults=True)
+    ctx = p3r.Context(field=field, poseidon2_w32_rc=rc, poseidon2_w32_diag=diag, **kw, allow_unpinned_w32_defaults=True)   # the defaults, passed explicitly
     a = harness_lib.generate(field, 7, seed=47, flags=harness_lib.P2_W32, **GEN)
     tp = p3r.TablePacking().with_fri_params(kw["log_final_poly_len"], kw["log_blowup"])
     cpd = p3r.CircuitProverData(ctx, wl.circuit_prep_from_arrays(a), tp)
@@ -111,7 +111,7 @@ def test_width32_permutation_and_trace_rows_vs_oracle(oracle, field):
     lib.orc_p2w_permute.argtypes = [C.c_int, u32p, u32p, u32p, u32p, C.c_size_t]
     lib.orc_p2w_trace_rows.argtypes = [C.c_int, u32p, u32p, C.c_size_t, u32p, u32p, u32p, u32p]
     rng = np.random.default_rng(9)
-    ctx = p3r.Context(field=field)
+    ctx = p3r.Context(field=field, allow_unpinned_w32_defaults=True)
     st = rng.integers(0, P, size=(300, 32), dtype=np.uint32)
     st[0] = 0
     st[1] = P - 1

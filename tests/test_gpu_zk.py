@@ -23,7 +23,8 @@ def make_ctx(field, prm, **extra):
                        cap_height=prm.cap_height, log_final_poly_len=prm.log_final_poly_len,
                        commit_pow_bits=prm.commit_pow_bits, query_pow_bits=prm.query_pow_bits,
                        num_queries=prm.num_queries, mmcs_arity=prm.mmcs_arity or 2, zk=prm.zk,
-                       num_random_codewords=prm.num_random_codewords, zk_seed=prm.zk_seed, **extra)
+                       num_random_codewords=prm.num_random_codewords, zk_key=list(prm.zk_key), zk_deterministic=True,
+                       allow_unpinned_w32_defaults=True, **extra)
 
 
 def airs_of(tables):

@@ -51,7 +51,7 @@ def test_all_openings_oracle_tree_native_verifier(oracle, field, name, shapes, c
     for arity in (2, 4):
         if arity == 4 and cap_height:
             continue   # a one-digest cap only
-        cfg, keep = p3r.make_config(field, cap_height=cap_height, mmcs_arity=arity)
+        cfg, keep = p3r.make_config(field, cap_height=cap_height, mmcs_arity=arity, allow_unpinned_w32_defaults=True)
         cap, tree = oracle.commit4(field, mats) if arity == 4 else oracle.commit(field, mats, cap_height)
         for index in range(hmax):
             opened, proof = tree.open(index)
@@ -88,7 +88,7 @@ def test_all_openings_device_tree(oracle, field, name, shapes, cap_height):
     for arity in (2, 4):
         if arity == 4 and cap_height:
             continue
-        c = p3r.Context(field=field, cap_height=cap_height, mmcs_arity=arity)
+        c = p3r.Context(field=field, cap_height=cap_height, mmcs_arity=arity, allow_unpinned_w32_defaults=True)
         cap, tree = c.commit(mats)
         ocap, otree = oracle.commit4(field, mats) if arity == 4 else oracle.commit(field, mats, cap_height)
         assert np.array_equal(cap, ocap)
@@ -164,7 +164,7 @@ def check_arity4_reference_case(oracle, field, tree, cap, mats, indices, steps, 
 def test_arity4_reference_patterns_oracle_tree(oracle, name, mats, indices, steps):
     import plonky3_recursion_amd as p3r
     field = "koala-bear"
-    cfg, keep = p3r.make_config(field, mmcs_arity=4)
+    cfg, keep = p3r.make_config(field, mmcs_arity=4, allow_unpinned_w32_defaults=True)
     cap, tree = oracle.commit4(field, mats)
 
     def native(shapes, index, opened, proof, ok):
@@ -181,7 +181,7 @@ def test_arity4_reference_patterns_oracle_tree(oracle, name, mats, indices, step
 def test_arity4_reference_patterns_device_tree(oracle, name, mats, indices, steps):
     import plonky3_recursion_amd as p3r
     field = "koala-bear"
-    c = p3r.Context(field=field, mmcs_arity=4)
+    c = p3r.Context(field=field, mmcs_arity=4, allow_unpinned_w32_defaults=True)
     cap, tree = c.commit(mats)
     ocap, otree = oracle.commit4(field, mats)
     assert np.array_equal(cap, ocap)

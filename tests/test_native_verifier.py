@@ -18,7 +18,7 @@ def verify(field, prm, tables, cap, proof, canonical=False, degree_bits=None):
     if degree_bits is None:  # the verifier's own metadata: log2 of every table's (padded) height
         degree_bits = [int(t["main"].shape[0]).bit_length() - 1 for t in tables]
     cfg, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
-                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, mmcs_arity=prm.mmcs_arity or 2)
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, mmcs_arity=prm.mmcs_arity or 2, allow_unpinned_w32_defaults=True)
     airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
     p3r.verify_batch(cfg, airs, cap, degree_bits, proof, canonical)
 
@@ -141,7 +141,7 @@ def test_batch_stark_proof_wire_round_trip_and_verify(oracle, canonical):
     assert back.table_packing == tp and back.rows == proof.rows and back.non_primitives == proof.non_primitives
     assert np.array_equal(back.preprocessed_commitment, cap)
     cfg, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
-                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries)
+                                prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, allow_unpinned_w32_defaults=True)
     p3r.verify_all_tables(cfg, back)
     # the extension metadata must be the verifier's (batch_stark_prover.rs:1245-1263) and the
     # stark_common degree_bits are what the inner proof has to declare
@@ -220,7 +220,7 @@ def test_selectable_protocol_details_oracle_and_native_verifier_agree(oracle, ex
     def native(ext, ar, lay=layout):
         cfg, keep = p3r.make_config(field, base.log_blowup, base.max_log_arity, base.cap_height, base.log_final_poly_len,
                                     base.commit_pow_bits, base.query_pow_bits, base.num_queries, ext_choices=ext,
-                                    fri_log_arities=ar, proof_layout=lay)
+                                    fri_log_arities=ar, proof_layout=lay, allow_unpinned_w32_defaults=True)
         p3r.verify_batch(cfg, airs, cap, db, proof)
 
     native(ext_choices, arities)

@@ -175,7 +175,7 @@ def test_native_host_verifier_accepts_the_oracles_openings(oracle, field, arity)
     of verify_batch agree on acceptance and on every rejection."""
     import plonky3_recursion_amd as p3r
     rng = np.random.default_rng(21 + arity)
-    cfg, keep = p3r.make_config(field, mmcs_arity=arity)
+    cfg, keep = p3r.make_config(field, mmcs_arity=arity, allow_unpinned_w32_defaults=True)
     for shapes in SHAPES:
         mats = mats_of(rng, field, shapes)
         cap, tree = oracle.commit4(field, mats) if arity == 4 else oracle.commit(field, mats)
@@ -197,14 +197,14 @@ def test_native_host_verifier_accepts_the_oracles_openings(oracle, field, arity)
             with pytest.raises(p3r.P3rError, match="out of range"):
                 p3r.mmcs_verify(cfg, cap, shapes, hmax, opened, proof)
     # and the other arity's verifier refuses the same opening
-    other, keep2 = p3r.make_config(field, mmcs_arity=6 - arity)
+    other, keep2 = p3r.make_config(field, mmcs_arity=6 - arity, allow_unpinned_w32_defaults=True)
     with pytest.raises(p3r.P3rError):
         p3r.mmcs_verify(other, cap, shapes, index, opened, proof)
 
 
 def test_native_verifier_config_rules():
     import plonky3_recursion_amd as p3r
-    cfg, keep = p3r.make_config("koala-bear", mmcs_arity=4, cap_height=1)
+    cfg, keep = p3r.make_config("koala-bear", mmcs_arity=4, cap_height=1, allow_unpinned_w32_defaults=True)
     z = np.zeros((2, 8), dtype=np.uint32)
     with pytest.raises(p3r.P3rError, match="cap_height must be 0"):
         p3r.mmcs_verify(cfg, z, [(4, 1)], 0, np.zeros(1, dtype=np.uint32), z)
@@ -223,7 +223,7 @@ def test_reference_round_trip_pattern(oracle, field):
     rng = np.random.default_rng(64)
     mat = rng.integers(0, P[field], size=(REF_HEIGHT, REF_WIDTH), dtype=np.uint32)
     cap, tree = oracle.commit4(field, [mat])
-    cfg, keep = p3r.make_config(field, mmcs_arity=4)
+    cfg, keep = p3r.make_config(field, mmcs_arity=4, allow_unpinned_w32_defaults=True)
     for index in REF_INDICES:
         opened, proof = tree.open(index)
         assert proof.shape[0] % 3 == 0 and proof.shape[0] // 3 == 3      # arity4_mmcs.rs:99-104

@@ -116,7 +116,7 @@ def test_native_verifier_agrees_with_the_oracle_on_width32_layers(oracle, field,
     def native(L, proof):
         t = L.tables()
         cfg, keep = p3r.make_config(field, **{k: getattr(L.prm, k) for k in ("log_blowup", "max_log_arity", "cap_height", "log_final_poly_len",
-                                                                            "commit_pow_bits", "query_pow_bits", "num_queries")})
+                                                                            "commit_pow_bits", "query_pow_bits", "num_queries")}, allow_unpinned_w32_defaults=True)
         airs = [dict(kind=x["kind_id"], lanes=x["lanes"], horner_packed_steps=x["horner_k"]) for x in t]
         assert 5 in [a["kind"] for a in airs]
         p3r.verify_batch(cfg, airs, L.prep_commit(), [int(x["main"].shape[0]).bit_length() - 1 for x in t], proof)

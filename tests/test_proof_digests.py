@@ -46,7 +46,7 @@ def test_device_reproduces_the_committed_digests(oracle, case):
     assert gpd.workload_digest(arrs) == pin["workload"]
     pk = dict(packing)
     ext_w = pk.pop("ext_w", 0)
-    ctx = p3r.Context(field=field, ext_degree=d, ext_w=ext_w, challenge_degree=dc, **fri)
+    ctx = p3r.Context(field=field, ext_degree=d, ext_w=ext_w, challenge_degree=dc, **fri, allow_unpinned_w32_defaults=True)
     tp = pv.TablePacking(**pk).with_fri_params(fri["log_final_poly_len"], fri["log_blowup"])
     coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
     cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=d, recompose_coeff_lookups=coeff),

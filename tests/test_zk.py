@@ -26,7 +26,7 @@ def native_verify(field, prm, tables, cap, proof, degree_bits=None, zk=None, cod
     cfg, keep = p3r.make_config(field, prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
                                 prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, mmcs_arity=prm.mmcs_arity or 2,
                                 zk=zk, num_random_codewords=prm.num_random_codewords if codewords is None else codewords,
-                                challenge_degree=prm.challenge_degree or 4)
+                                challenge_degree=prm.challenge_degree or 4, allow_unpinned_w32_defaults=True)
     airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"]) for t in tables]
     p3r.verify_batch(cfg, airs, cap, degree_bits, proof)
 
@@ -196,7 +196,7 @@ def test_zk_parameter_checks(oracle):
         layer_lib.OracleLayer(oracle, "koala-bear", arrs, prm).prove()
     with pytest.raises(RuntimeError, match="num_random_codewords"):
         layer_lib.OracleLayer(oracle, "koala-bear", arrs, layer_lib.params(zk=1, num_random_codewords=9)).prove()
-    cfg, keep = p3r.make_config("koala-bear", zk=1, num_random_codewords=9)
+    cfg, keep = p3r.make_config("koala-bear", zk=1, num_random_codewords=9, allow_unpinned_w32_defaults=True)
     with pytest.raises(p3r.P3rError, match="num_random_codewords"):
         p3r.verify_batch(cfg, [dict(kind=0)], np.zeros((1, 8), np.uint32), [5], b"\x00")
 
@@ -211,7 +211,7 @@ def native_verify_d(prm, tables, cap, proof, d, coeff, cd):
     import plonky3_recursion_amd as p3r
     cfg, keep = p3r.make_config("koala-bear", prm.log_blowup, prm.max_log_arity, prm.cap_height, prm.log_final_poly_len,
                                 prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, ext_degree=d, challenge_degree=cd,
-                                zk=prm.zk, num_random_codewords=prm.num_random_codewords)
+                                zk=prm.zk, num_random_codewords=prm.num_random_codewords, allow_unpinned_w32_defaults=True)
     airs = [dict(kind=t["kind_id"], lanes=t["lanes"], horner_packed_steps=t["horner_k"],
                  coeff_lookups=coeff if t["kind"] == "recompose" else 0) for t in tables]
     p3r.verify_batch(cfg, airs, cap, [int(t["main"].shape[0]).bit_length() - 1 + prm.zk for t in tables], proof)

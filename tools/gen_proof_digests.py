@@ -25,6 +25,8 @@ CASES = [
     ("d1_quintic_challenge", "koala-bear", 7, 17, 2, 1, 5, dict(log_blowup=1, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4), {}),
     ("d4_arity4_mmcs", "koala-bear", 7, 19, 0, 4, 4, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4, mmcs_arity=4), {}),
     ("d4_arity4_mmcs_w32_table", "baby-bear", 7, 20, 128, 4, 4, dict(log_blowup=1, max_log_arity=3, log_final_poly_len=1, query_pow_bits=3, num_queries=4, mmcs_arity=4), {}),
+    # round 6: the width-32 rows as ops of the circuit (flag 4096 | 128), under the arity-4 MMCS: the arrays are the generator's own books
+    ("d4_arity4_w32_ops", "koala-bear", 7, 21, 4096 | 128, 4, 4, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4, mmcs_arity=4), {}),
     ("d8_binomial", "koala-bear", 7, 18, 1, 8, 4, dict(log_blowup=2, max_log_arity=2, log_final_poly_len=1, query_pow_bits=3, num_queries=4), dict(ext_w=3)),
 ]
 GEN = dict(horner_chain_len=12, sponge_chain_len=3, merkle_depth=4)
@@ -44,7 +46,7 @@ def workload_digest(arrs):
     """sha256 over the generator's arrays.  Arrays added after the pins were made (the width-32 Poseidon2 table's,
     round 4) are left out while they are empty, and `counts` is hashed without its trailing zero entries for such
     tables - so the pins of the older layers keep telling a generator change apart from a layout extension."""
-    late = ("p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep")
+    late = ("p2w_inputs", "p2w_flags", "p2w_mmcs_index_sum", "p2w_prep", "pdw_op_ids", "pdw_siblings")   # (pdw_*: round 6)
     h = hashlib.sha256()
     for k in sorted(arrs):
         a = arrs[k]

@@ -26,7 +26,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "w32":
         dflt = json.load(open(os.path.join(ROOT, "tests", "golden", "poseidon2_w32_default.json")))[field.replace("-", "_")]
         kw = dict(poseidon2_w32_rc=np.array(dflt["rc"], dtype=np.uint32).reshape(-1),
                   poseidon2_w32_diag=rng.integers(1, 0x78000001, size=32, dtype=np.uint32))
-    ctx = p3r.Context(field=field, mmcs_arity=4, **kw)
+    ctx = p3r.Context(field=field, mmcs_arity=4, **kw, allow_unpinned_w32_defaults=True)
     log_rows, width, launches = 22, 96, 3
     m = ctx.upload(rng.integers(0, ctx.p, size=(1 << log_rows, width), dtype=np.uint32))
     for _ in range(launches):

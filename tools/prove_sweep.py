@@ -133,7 +133,7 @@ def one(oracle, seed, max_log_h, min_log_h=5):
     tp.with_fri_params(prm.log_final_poly_len, prm.log_blowup)
     ctx = None
     try:
-        ctx = p3r.Context(field=field, ext_degree=ext_degree, **kw)
+        ctx = p3r.Context(field=field, ext_degree=ext_degree, **kw, allow_unpinned_w32_defaults=True)
         ctx.zk_nonce = zk_nonce
         cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree, recompose_coeff_lookups=coeff),
                                          pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))

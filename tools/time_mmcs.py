@@ -14,7 +14,7 @@ width = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 rng = np.random.default_rng(1)
 base = rng.integers(0, 0x7F000001, size=(1 << (log_rows - 2), width), dtype=np.uint32)
 for arity in (2, 4):
-    ctx = p3r.Context(field="koala-bear", mmcs_arity=arity)
+    ctx = p3r.Context(field="koala-bear", mmcs_arity=arity, allow_unpinned_w32_defaults=True)
     lde = ctx.coset_lde_batch_device(ctx.upload(base), 2, 3)
     cap, tree = ctx.commit_device([lde])
     tree.free()
