@@ -913,10 +913,24 @@ def emit(full, args):
 
 
 def flush_final_line():
+    """The contract line as the LAST line of stdout.  Libraries write to the C-level stdout too and, behind a pipe, only
+    when their buffer is flushed at exit: RCCL's version banner ("RCCL version : .. Librccl path : ..", five lines) came out
+    AFTER the JSON line on the first run under nccl.  So: flush every C stream first, print the line, then point file
+    descriptor 1 at stderr - whatever is written to stdout from here on cannot follow the line."""
     sys.stderr.flush()
     sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     for text in _FINAL_LINE:
         print(text, flush=True)
+    if _FINAL_LINE:
+        try:
+            os.dup2(2, 1)
+        except OSError:
+            pass
     _FINAL_LINE.clear()
 
 
@@ -980,6 +994,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:
+        # only rank 0 speaks on stdout (one JSON line): whatever a library of another rank prints there goes to stderr
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if world > 1:
         # the ranks set up side by side: cap their OpenMP teams BEFORE torch is imported - torch loads an OpenMP runtime,
         # and libgomp reads OMP_NUM_THREADS when it is loaded, not when a team starts
