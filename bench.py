@@ -145,13 +145,19 @@ HASH_KERNEL_SOURCES = ("poseidon2_f64.hip.h", "kernels.hip.h")   # what k_mmcs_h
 
 
 def kernel_source_digest(names=HASH_KERNEL_SOURCES):
-    """sha256 over the sources of the dominant kernel: tools/collect_profiles.py stores it next to the instruction count
-    it measured, committed_valu_model refuses a count taken from other sources."""
+    """sha256 of the CODE of the named kernel sources: comments and blank space are stripped first, so that editing a comment
+    does not invalidate an instruction count (and nobody is tempted to re-stamp a measurement file by hand - the count is
+    a property of the code the compiler saw)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for n in names:
-        with open(os.path.join(ROOT, "plonky3_recursion_amd", "csrc", n), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "plonky3_recursion_amd", "csrc", n), "r") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)      # block comments
+        text = re.sub(r"//[^\n]*", "", text)                    # line comments (no string literal of these files holds //)
+        text = "\n".join(ln.strip() for ln in text.split("\n") if ln.strip())
+        h.update(n.encode() + b"\0" + text.encode() + b"\0")
     return h.hexdigest()
 
 
@@ -249,11 +255,18 @@ VALU_FAMILY_KERNELS = {
 }
 
 
+FP64_FAMILIES = ("mmcs_compress",)   # (and the dominant kernel, priced in `roofline`): FP64 arithmetic, FP64 issue rate
+
+
 def valu_families(kernel_ms):
     """What binds the families that are not HBM-bound: VALU lane-instructions per proof (SQ_INSTS_VALU x 64 from the
-    committed PMC pass, profiles/<round>/pmc_sq.json, divided by the proofs of that run) over the family's measured time,
-    against the full-rate issue peak.  A lower bound on issue-slot use: v_mad_u64_u32 / v_mul_hi_u32 occupy more than one
-    slot (13.2 / 19.8 T/s in microbench_int_rates.txt), so an integer family at 0.8 is at its roof."""
+    committed PMC pass, profiles/<round>/pmc_sq.json, divided by the proofs of that run) against an issue floor that
+    follows the family's INSTRUCTION MIX: floor_ms = N x sum_opcode share / rate, shares from the disassembly of the
+    launched kernel instances and measured per-opcode rates (tools/valu_mix.py -> profiles/<round>/valu_mix.json: a gfx950
+    SIMD retires 32-bit adds faster than the FP64 FMA rate and v_mad_u64_u32 / v_mul_hi_u32 at a half / a third of it, so
+    one divisor for all families - the 39.3 T/s of round 5 - was wrong for the integer ones in both directions).
+    frac = floor_ms / ms.  The FP64 families keep the FP64 issue rate.  `frac_fp64_rate` is the old reading, for
+    comparison across rounds."""
     p, name = profile_file("pmc_sq.json")
     if not p:
         return None
@@ -262,15 +275,26 @@ def valu_families(kernel_ms):
             rec = json.load(fh)
         ks = rec["kernels"]
         proofs = rec.get("proofs_in_run") or ks.get("k_quotient", {}).get("launches")   # one quotient launch per proof
-        out = {"source": f"{name}: SQ_INSTS_VALU x 64 lanes / {proofs} proofs of that run; times: this run's kernel_ms_per_step",
-               "peak_lane_insts_per_s": VALU_ISSUE_SPEC}
+        mix, mix_name = {}, None
+        mp, mix_name = profile_file("valu_mix.json")
+        if mp:
+            with open(mp) as fh:
+                mix = json.load(fh).get("families", {})
+        out = {"source": f"{name}: SQ_INSTS_VALU x 64 lanes / {proofs} proofs of that run; times: this run's kernel_ms_per_step; "
+                         f"mix and rates: {mix_name}",
+               "fp64_lane_insts_per_s": VALU_ISSUE_SPEC}
         for fam, (time_keys, kernels) in VALU_FAMILY_KERNELS.items():
             insts = sum(ks[k]["SQ_INSTS_VALU"] for k in kernels if k in ks and "SQ_INSTS_VALU" in ks[k]) * 64.0 / proofs
             ms = sum(kernel_ms.get(k, 0.0) for k in time_keys)
             if insts and ms:
                 rate = insts / (ms * 1e-3)
+                eff = VALU_ISSUE_SPEC if fam in FP64_FAMILIES or fam not in mix else mix[fam]["effective_rate_T_per_s"] * 1e12
+                floor_ms = insts / eff * 1e3
                 out[fam] = {"valu_lane_insts_per_step": insts, "ms": ms, "achieved_lane_insts_per_s": rate,
-                            "frac": rate / VALU_ISSUE_SPEC, "bound": "valu-issue" if rate / VALU_ISSUE_SPEC >= 0.6 else "latency / memory phases",
+                            "mix_rate_lane_insts_per_s": eff, "floor_ms": floor_ms, "frac": floor_ms / ms,
+                            "frac_fp64_rate": rate / VALU_ISSUE_SPEC,
+                            "mix": None if fam in FP64_FAMILIES or fam not in mix else mix[fam]["share_by_priced_opcode"],
+                            "bound": "valu-issue" if floor_ms / ms >= 0.6 else "latency / memory phases",
                             "kernels": [k for k in kernels if k in ks]}
         return out
     except Exception as e:

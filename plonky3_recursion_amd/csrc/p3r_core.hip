@@ -180,6 +180,18 @@ std::unique_ptr<p3r_dmat> coset_lde(p3r_ctx* ctx, const p3r_dmat* in, int added_
   return std::move(coset_lde_batch<PP>(ctx, {{in, shift}}, added_bits)[0]);
 }
 
+// The second stream of the two-stream commit experiment (knobs build only: P3R_COMMIT_OVERLAP, prove_impl.hip.h): created
+// on first use, so that a product context owns one stream and no idle events.
+inline void ensure_side_streams(p3r_ctx* ctx) {
+  if (ctx->stream2) return;
+  P3R_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  int lo = 0, hi = 0;
+  P3R_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = the numerically greatest = lowest priority
+  P3R_HIP(hipStreamCreateWithPriority(&ctx->stream2_low, hipStreamNonBlocking, lo));
+  P3R_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  P3R_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+}
+
 // ------------------------------------------------------------------ MMCS
 // Row digests of several height classes in one launch: classes[c] = the matrices of one height
 // (their rows are concatenated in the given order), digs[c] = [8][h_c].
@@ -211,6 +223,7 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
   const auto* d_jobs =
       static_cast<const HashRowsJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(HashRowsJob)));
   if (side) {
+    ensure_side_streams(ctx);
     hipStream_t s2 = side == 2 ? ctx->stream2_low : ctx->stream2;
     P3R_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     P3R_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
@@ -612,14 +625,7 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
     c->cfg = *cfg;
     tls_pool() = c->pool;
     P3R_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    P3R_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    {
-      int lo = 0, hi = 0;
-      P3R_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = the numerically greatest = lowest priority
-      P3R_HIP(hipStreamCreateWithPriority(&c->stream2_low, hipStreamNonBlocking, lo));
-    }
-    P3R_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    P3R_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    // (the side streams of the two-stream commit experiment are created on first use: ensure_side_streams)
     {
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;

@@ -138,19 +138,32 @@ std::unique_ptr<p3r_tree> lde_and_commit(p3r_ctx* ctx, const std::vector<LdeItem
     for (size_t k = 0; k < first.size(); ++k) { ldes[first_at[k]] = std::move(out[k]); ptrs[first_at[k]] = ldes[first_at[k]].get(); }
   }
   std::map<size_t, DevBuf> pre;
+  // `pre` is written by the side stream: an exception below must not release it while that kernel still runs
+  struct DrainSideStream {
+    p3r_ctx* ctx;
+    bool armed = false;
+    ~DrainSideStream() {
+      if (!armed) return;
+      if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+      if (ctx->stream2_low) (void)hipStreamSynchronize(ctx->stream2_low);
+    }
+  } drain_on_unwind{ctx};
   {
     std::vector<const p3r_dmat*> cls;   // commit order within the class = the caller's order (stable)
     for (size_t i : first_at) cls.push_back(ptrs[i]);
     const size_t h = cls[0]->h;
     uint32_t* dig = pre.emplace(h, DevBuf(P2_DIGEST * h)).first->second.p;
     hash_rows<PP>(ctx, {cls}, {dig}, /*side=*/mode == 1 ? 0 : mode == 2 ? 2 : 1);
+    drain_on_unwind.armed = mode != 1;
   }
   {
     auto out = coset_lde_batch<PP>(ctx, rest, log_blowup);
     for (size_t k = 0; k < rest.size(); ++k) { ldes[rest_at[k]] = std::move(out[k]); ptrs[rest_at[k]] = ldes[rest_at[k]].get(); }
   }
   if (mode != 1) hash_rows_join(ctx);
-  return commit_dmats<PP>(ctx, ptrs, cap_mont, &pre);
+  auto tree = commit_dmats<PP>(ctx, ptrs, cap_mont, &pre);
+  drain_on_unwind.armed = false;   // joined on the main stream: `pre` is released in stream order from here on
+  return tree;
 }
 
 // Proof-of-work grinding on the device: the smallest witness w such that, after observing w, the
@@ -250,7 +263,16 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
     const size_t width = dev_traces ? (*dev_traces)[i]->w : mats[i].width, height = dev_traces ? (*dev_traces)[i]->h : mats[i].height;
     if ((int)width != air_prep_width_of(a))
       fail(P3R_EINVAL, "instance %zu: preprocessed width %zu, the AIR expects %d", i, width, air_prep_width_of(a));
-    (void)lookup_layout(a, ctx->cfg.zk ? 1 : 0);
+    {
+      // known at preparation time: a quotient of 2^(log_chunks) cosets (twice as many under ZK) is evaluated ON the
+      // committed LDE here, so log_chunks must not exceed log_blowup.  Upstream re-evaluates on the larger domain
+      // instead; that is a capability this prover lacks, not a caller error - said so, and said early
+      const LookupLayout lay = lookup_layout(a, ctx->cfg.zk ? 1 : 0);
+      if (lay.log_chunks > (int)ctx->cfg.log_blowup)
+        fail(P3R_EUNSUPPORTED, "instance %zu: quotient domain larger than the LDE: constraint degree needs log_blowup >= %d%s, log_blowup is %u "
+             "(upstream extends the traces to the quotient domain in this case; this prover does not)", i, lay.log_chunks,
+             ctx->cfg.zk ? " under zk = 1" : "", ctx->cfg.log_blowup);
+    }
     prep->airs.push_back(a);
     prep->heights.push_back(height);
     auto m = dev_traces ? std::move((*dev_traces)[i]) : upload<PP>(ctx, mats[i].values, mats[i].height, mats[i].width);
@@ -311,7 +333,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     log_n[i] = log2_exact(mains[i]->h, "trace height");
     log_e[i] = log_n[i] + zk;
     layouts[i] = lookup_layout(a, zk);
-    if (layouts[i].log_chunks > log_blowup) fail(P3R_EINVAL, "quotient domain larger than the LDE");
+    if (layouts[i].log_chunks > log_blowup) fail(P3R_EUNSUPPORTED, "quotient domain larger than the LDE (zk %d, log_blowup %d)", zk, log_blowup);
     if ((1 << (layouts[i].log_chunks + zk)) > 8) fail(P3R_EUNSUPPORTED, "more than 8 quotient chunks");
   }
   const F gen = F::generator();

@@ -23,7 +23,7 @@ def test_headline_layer_proves_and_both_verifiers_accept(oracle, field, log_h):
     import plonky3_recursion_amd as p3r
     import harness_adapters as wl
     arrs = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN)   # the bench workload
-    ctx = p3r.Context(field=field, **FRI, allow_unpinned_w32_defaults=True)
+    ctx = p3r.Context(field=field, **FRI)
     tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
     circuit = wl.circuit_from_arrays(arrs)
     cache = p3r.build_next_layer_prep(ctx, circuit, p3r.FriRecursionBackend(),
@@ -73,6 +73,52 @@ def test_headline_layer_proves_and_both_verifiers_accept(oracle, field, log_h):
     ctx.close()
 
 
+def test_headline_zk_layer_proves_and_both_verifiers_accept(oracle):
+    """The headline layer (KoalaBear, 2^20 rows, the bench workload) under the ZK configuration - HidingFriPcs, two random
+    codewords, every commitment over 2^21-row extended domains (2^23-row LDEs), eight masked quotient chunks - keyed the way a
+    deployment keys it: no key given, the library draws one from the operating system (so no byte can be compared with the
+    CPU oracle's prover; tests/test_gpu_zk.py does that under P3R_EXT_ZK_DETERMINISTIC at sizes the oracle finishes).
+    Both verifiers accept, two proofs of one input differ, tampering is rejected, a non-ZK verifier refuses the proof."""
+    import dataclasses
+    import plonky3_recursion_amd as p3r
+    import harness_adapters as wl
+    field, log_h = "koala-bear", 20
+    arrs = harness_lib.generate(field, log_h, seed=0x5EED0000, **GEN)
+    ctx = p3r.Context(field=field, zk=1, num_random_codewords=2, **FRI)
+    tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(arrs), p3r.FriRecursionBackend(),
+                                      p3r.ProveNextLayerParams(table_packing=tp))
+    pc = cache.prepared_circuit
+    inputs = pc.upload_inputs(wl.circuit_inputs_from_arrays(arrs))
+    del arrs
+    first, second = pc.prove(inputs), pc.prove(inputs)
+    assert first != second and len(first) == len(second) and ctx.zk_nonce == 2
+    with pytest.raises(p3r.P3rError, match="DETERMINISTIC"):
+        ctx.zk_nonce = 0          # replaying a proof counter repeats the masks: refused outside the deterministic mode
+    cpd = pc.circuit_prover_data
+    prover = p3r.BatchStarkProver(ctx)
+    prm = layer_lib.params(zk=1, num_random_codewords=2, **FRI)
+    for raw in (first, second):
+        proof = prover.wrap_proof(raw, cpd)
+        prover.verify_all_tables(proof)                                                                   # native verifier
+        layer_lib.oracle_verify_statement(oracle, field, prm, proof.airs(), cpd.preprocessed_commitment, raw)   # the oracle's
+    proof = prover.wrap_proof(first, cpd)
+    assert max(proof.degree_bits) == log_h + 1            # the EXTENDED degree bits (recursion.rs:374)
+    for at in (len(first) // 5, (len(first) * 2) // 3):
+        bad = bytearray(first)
+        bad[at] ^= 4
+        with pytest.raises(p3r.P3rError):
+            prover.verify_all_tables(dataclasses.replace(proof, proof=bytes(bad)))
+        with pytest.raises(RuntimeError):
+            layer_lib.oracle_verify_statement(oracle, field, prm, proof.airs(), cpd.preprocessed_commitment, bytes(bad))
+    # the PCS types refuse each other: a verifier of the non-hiding configuration cannot read this proof
+    with pytest.raises(RuntimeError):
+        layer_lib.oracle_verify_statement(oracle, field, layer_lib.params(**FRI), proof.airs(), cpd.preprocessed_commitment, first)
+    inputs.free()
+    pc.free()
+    ctx.close()
+
+
 @pytest.mark.parametrize("field,log_h,width", [("koala-bear", 20, 8), ("baby-bear", 22, 2)])
 def test_headline_lde_and_commit_bit_exact(oracle, field, log_h, width):
     """coset_lde_batch (blow-up 4) + MerkleTreeMmcs::commit of a 2^log_h x width matrix: every LDE cell,
@@ -84,7 +130,7 @@ def test_headline_lde_and_commit_bit_exact(oracle, field, log_h, width):
     m = rng.integers(0, p, size=(1 << log_h, width), dtype=np.uint32)
     m[0, :] = p - 1
     m[-1, :] = 0
-    ctx = p3r.Context(field=field, **FRI, allow_unpinned_w32_defaults=True)
+    ctx = p3r.Context(field=field, **FRI)
     dm = ctx.upload(m)
     lde = ctx.coset_lde_batch_device(dm, 2, g)
     cap, tree = ctx.commit_device([lde])

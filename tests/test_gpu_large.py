@@ -20,7 +20,7 @@ def prove_on_gpu(field, log_h, seed=11, **gen):
     gen.setdefault("sponge_chain_len", 8)
     gen.setdefault("merkle_depth", 20)
     arrs = harness_lib.generate(field, log_h, seed=seed, **gen)
-    ctx = p3r.Context(field=field, **FRI, allow_unpinned_w32_defaults=True)
+    ctx = p3r.Context(field=field, **FRI)
     tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
     cache = p3r.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs), p3r.FriRecursionBackend(),
                                       p3r.ProveNextLayerParams(table_packing=tp))
@@ -93,7 +93,7 @@ def test_circuit_run_and_prove_at_scale(oracle, field, log_h, gen):
     oc = cl.OracleCircuit(oracle, cl.Circuit.from_arrays(a)).preprocess(oracle_lib.MODULUS[field])
     oc.run(field, cl.Inputs.from_arrays(a))
     want = oc.workload_arrays()
-    ctx = p3r.Context(field=field, **FRI, allow_unpinned_w32_defaults=True)
+    ctx = p3r.Context(field=field, **FRI)
     tp = p3r.TablePacking().with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
     cache = p3r.build_next_layer_prep(ctx, wl.circuit_from_arrays(a), p3r.FriRecursionBackend(),
                                       p3r.ProveNextLayerParams(table_packing=tp))
