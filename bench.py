@@ -202,6 +202,29 @@ def w32_leaf_roofline(field, heights, widths, packing, hash_rows_ms):
     return out
 
 
+def measured_leaf_roofline(field, prof, steps=1):
+    """Leaf hashing of ANY configuration against the FP64 issue peak, from what the launches actually absorbed: the library
+    counts the permutations of its k_mmcs_hash_rows launches while profiling is on (csrc/profile.h::prof_count, entry
+    `stage:count:hash_rows_perms`), so no table-mix model is needed - used for the ZK leg (twice the rows, codeword columns,
+    a random round, eight masked chunks).  Instructions per permutation: the committed count of the same kernel
+    (committed_valu_model).  prof: Context.profile_read() of `steps` proofs."""
+    perms = prof.get("stage:count:hash_rows_perms", (None,))[0]
+    ms = prof.get("mmcs_hash_rows", (0.0, 0))[0]
+    insts, fma_rate, vsrc = committed_valu_model(field)
+    out = {"kernel": "k_mmcs_hash_rows", "bound": "valu-issue", "perms_per_step_in_kernel": (perms / steps) if perms else None,
+           "ms_per_step": ms / steps if ms else None, "launches_per_step": prof.get("mmcs_hash_rows", (0.0, 0))[1] / steps,
+           "valu_insts_per_perm": insts, "peak": FP64_FMA_SPEC / 1e12, "unit": "T FP64 lane-ops/s", "achieved": None, "frac": None,
+           "frac_null_reason": vsrc.get("refused")}
+    if perms and ms and insts:
+        out["perms_per_s"] = perms / (ms * 1e-3)
+        out["achieved"] = out["perms_per_s"] * insts / 1e12
+        out["frac"] = out["achieved"] / out["peak"]
+        out["frac_measured_fma_rate"] = (out["achieved"] * 1e12 / fma_rate) if fma_rate else None
+    elif not perms:
+        out["frac_null_reason"] = out["frac_null_reason"] or "the library did not report stage:count:hash_rows_perms"
+    return out
+
+
 def committed_valu_model(field):
     """FP64 instructions per Poseidon2 permutation of k_mmcs_hash_rows and the measured v_fma_f64 rate, both read
     from files under profiles/<round>/ so that every number of `valu_roofline` can be recomputed:
@@ -1218,7 +1241,11 @@ def main():
                   4 * packing.recompose_lanes]
         perms, hash_perms, hash_bytes, model_launches = workload_model(field, cpd.table_heights, widths, packing)
         kernel_ms = {kk: v[0] / prof_steps for kk, v in prof.items() if not kk.startswith("stage:")}
-        stage_ms = {kk[6:]: v[0] / prof_steps for kk, v in prof.items() if kk.startswith("stage:")}
+        stage_ms = {kk[6:]: v[0] / prof_steps for kk, v in prof.items() if kk.startswith("stage:") and not kk.startswith("stage:count:")}
+        counted_perms = prof.get("stage:count:hash_rows_perms", (None,))[0]   # what the launches absorbed (csrc/profile.h::prof_count)
+        if counted_perms is not None and counted_perms / prof_steps != workload_model(field, cpd.table_heights, widths, packing)[1]:
+            print(f"bench: the leaf-hash launches absorbed {counted_perms / prof_steps:.0f} permutations per step, the model says "
+                  f"{workload_model(field, cpd.table_heights, widths, packing)[1]}", file=sys.stderr)
         dominant = max(kernel_ms, key=kernel_ms.get) if kernel_ms else None
         hash_ms, hash_launches = prof.get("mmcs_hash_rows", (0.0, 0))
         launches_per_step = hash_launches / prof_steps
@@ -1292,6 +1319,7 @@ def main():
             "avg_launch_ms": avg_launch_ms,
             "perms_per_s": ach,
             "perms_per_step_in_kernel": hash_perms,
+            "perms_per_step_counted_by_the_library": (counted_perms / prof_steps) if counted_perms is not None else None,
             "valu_insts_per_perm": insts,
             "peak_perms_per_s": (FP64_FMA_SPEC / insts) if insts else None,
             "peak_measured_lane_ops_per_s": fma_rate,
@@ -1719,6 +1747,7 @@ def main():
                 "vs_headline": msz / ms_per_step,
                 "num_random_codewords": 2, "proofs_made": ctxz.zk_nonce,
                 "kernel_ms": {k: v[0] for k, v in profz.items() if not k.startswith("stage:")},
+                "leaf_roofline": measured_leaf_roofline(field, profz),
                 "parity": "byte parity with upstream is undefined for a randomised proof (the prover side of HidingFriPcs is un-vendored): "
                           "accepted by the native verifier here, by both verifiers and byte-identical to the oracle under the shared "
                           "counter-based randomness in tests/test_gpu_zk.py",

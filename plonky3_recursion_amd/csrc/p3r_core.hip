@@ -216,10 +216,13 @@ void hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*>>& cl
   std::stable_sort(jobs.begin(), jobs.end(),
                    [](const HashRowsJob& a, const HashRowsJob& b) { return a.wtot > b.wtot; });
   uint32_t blocks = 0;
+  double perms = 0;
   for (auto& j : jobs) {
     j.block0 = blocks;
     blocks += blocks_for(j.h);
+    perms += (double)j.h * ((j.wtot + P2_RATE - 1) / P2_RATE);
   }
+  prof_count(ctx, "hash_rows_perms", perms);
   const auto* d_jobs =
       static_cast<const HashRowsJob*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(HashRowsJob)));
   if (side) {

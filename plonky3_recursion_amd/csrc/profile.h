@@ -33,6 +33,17 @@ inline void prof_stage(p3r_ctx* ctx, const char* name) {
   ctx->cur_stage_t0 = now;
 }
 
+// A counter next to the timers (read back as the profile entry "stage:count:<name>", its value in total_ms): what a family
+// processed while profiling was on - e.g. the permutations the leaf-hash launches absorbed, which bench.py prices
+// against the issue peak without modelling the table mix of every configuration.
+inline void prof_count(p3r_ctx* ctx, const char* name, double v) {
+  if (!ctx->prof_enabled) return;
+  const std::string key = std::string("count:") + name;
+  for (auto& kv : ctx->stage_ms)
+    if (kv.first == key) { kv.second += v; return; }
+  ctx->stage_ms.emplace_back(key, v);
+}
+
 struct ProfScope {
   p3r_ctx* ctx;
   hipEvent_t a = nullptr, b = nullptr;

@@ -31,10 +31,13 @@ void mmcs4_hash_rows(p3r_ctx* ctx, const std::vector<std::vector<const p3r_dmat*
   // widest rows first: their blocks run longest
   std::stable_sort(jobs.begin(), jobs.end(), [](const HashRowsJob4& a, const HashRowsJob4& b) { return a.wtot > b.wtot; });
   uint32_t blocks = 0;
+  double perms = 0;
   for (auto& j : jobs) {
     j.block0 = blocks;
     blocks += (uint32_t)((j.h + kBlock - 1) / kBlock);
+    perms += (double)j.h * ((j.wtot + P2W_RATE - 1) / P2W_RATE);   // width-32 permutations of the rate-24 sponge
   }
+  prof_count(ctx, "hash_rows_perms", perms);
   const auto* d_jobs = static_cast<const HashRowsJob4*>(const_table(ctx, jobs.data(), jobs.size() * sizeof(HashRowsJob4)));
   ProfScope ps(ctx, "mmcs_hash_rows");
   const auto kern = ctx->w32_diag_builtin ? &k_mmcs4_hash_rows<PP, true> : &k_mmcs4_hash_rows<PP, false>;   // poseidon2_w32_f64.hip.h

@@ -134,7 +134,8 @@ def one(oracle, seed, max_log_h, min_log_h=5):
     ctx = None
     try:
         ctx = p3r.Context(field=field, ext_degree=ext_degree, **kw, allow_unpinned_w32_defaults=True)
-        ctx.zk_nonce = zk_nonce
+        if kw.get("zk"):
+            ctx.zk_nonce = zk_nonce   # (zk_seed makes the context deterministic: the oracle is given the same key and nonce)
         cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree, recompose_coeff_lookups=coeff),
                                          pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
         cpd = cache.circuit_prover_data
