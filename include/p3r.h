@@ -158,6 +158,14 @@ typedef struct p3r_config {
   uint32_t zk;
   uint32_t num_random_codewords;
   uint32_t zk_key[8];
+  /* ABI version 8.  MerkleTreeHidingMmcs for the input MMCS and (through ExtensionMmcs) the FRI commit-phase MMCS -
+   * "the upstream-recommended ZK setup" of recursion/tests/zk_hiding_mmcs.rs (SALT_ELEMS = 4 there): every committed
+   * matrix gets mmcs_salt_elems random elements per row, a leaf preimage is the concatenation of [row | salt] over the
+   * matrices of its height class (recursion/src/pcs/mmcs.rs:315-413, :430-510), and an MMCS opening proof is the tuple
+   * (per-matrix salts, sibling digests) (:763-790).  0: the plain MerkleTreeMmcs; 1..16.  The salts come from the
+   * generator of zk_key (which is therefore keyed also when zk = 0); both arities; independent of zk, as the MMCS type is
+   * independent of the PCS type upstream.  The preprocessed commitment is salted too (it is made once per circuit). */
+  uint32_t mmcs_salt_elems;
 } p3r_config;
 /* LogUp: one auxiliary column per interaction instead of packing same-bus interactions greedily up to
  * the degree budget 2^log_chunks + 1 (batch_stark_prover.rs:925-941 `pack_same_bus`). */
@@ -301,6 +309,12 @@ size_t p3r_tree_proof_len(const p3r_tree* tree);
 int p3r_mmcs_verify(const p3r_config* cfg, const uint32_t* cap, size_t n_mats, const size_t* heights, const size_t* widths,
                     size_t index, const uint32_t* opened_values, const uint32_t* proof, size_t proof_len, char* err_buf,
                     size_t err_cap);
+/* ABI version 8.  The same for a hiding MMCS (cfg->mmcs_salt_elems > 0: MerkleTreeHidingMmcs::verify_batch,
+ * recursion/src/pcs/mmcs.rs:315-413): `salts` = n_mats x mmcs_salt_elems, the first half of the opening proof
+ * `(salts, siblings)`; every leaf preimage is the concatenation of [row | salt] per matrix of its height class. */
+int p3r_mmcs_verify_salted(const p3r_config* cfg, const uint32_t* cap, size_t n_mats, const size_t* heights, const size_t* widths,
+                           size_t index, const uint32_t* opened_values, const uint32_t* salts, const uint32_t* proof,
+                           size_t proof_len, char* err_buf, size_t err_cap);
 size_t p3r_tree_log_max_height(const p3r_tree* tree);
 size_t p3r_tree_total_width(const p3r_tree* tree);
 void p3r_tree_free(p3r_ctx* ctx, p3r_tree* tree);
@@ -340,6 +354,8 @@ void p3r_prep_free(p3r_ctx* ctx, p3r_prep* prep);
                                         * extension elements are five words (p3r_config.challenge_degree = 5) */
 #define P3R_PROOF_ZK 4u /* flags of the proof PARSERS: the proof is a hiding PCS's (p3r_config.zk = 1): its opening proof
                         * is the tuple (random opened values, FriProof) - the proof TYPE, which the bytes do not announce */
+#define P3R_PROOF_SALTED 8u /* flags of the proof PARSERS (ABI 8): the MMCSs are hiding ones (p3r_config.mmcs_salt_elems > 0):
+                            * every MMCS opening proof is the tuple (per-matrix salts, sibling digests) */
 #define P3R_PROVE_CANONICAL_FIELD_ENCODING 1u /* flags: write canonical u32 instead of the
                                                * Montgomery word p3-monty-31's serde emits */
 

@@ -54,6 +54,8 @@ struct FriParams {
   uint32_t num_random_codewords = 2;
   std::array<uint32_t, 8> zk_key{};
   bool zk_deterministic = false;
+  // MerkleTreeHidingMmcs for the input and FRI commit-phase MMCSs (recursion/tests/zk_hiding_mmcs.rs: 4); 0 = the plain MMCS
+  uint32_t mmcs_salt_elems = 0;
 };
 
 // ext_degree: the circuit extension degree of the traces - 4, or 5 for KoalaBear circuits over the quintic trinomial
@@ -76,6 +78,7 @@ inline p3r_config make_config(Field field, const FriParams& p, int device = 0, c
   c.num_random_codewords = p.zk ? p.num_random_codewords : 0u;
   for (int i = 0; i < 8; ++i) c.zk_key[i] = p.zk_key[i];
   if (p.zk_deterministic) c.ext_choices |= P3R_EXT_ZK_DETERMINISTIC;
+  c.mmcs_salt_elems = p.mmcs_salt_elems;
   c.device = device;
   if (rc) { c.poseidon2_rc = rc->data(); c.poseidon2_rc_len = (uint32_t)rc->size(); }
   return c;
@@ -292,12 +295,13 @@ struct BatchStarkProof {
   // challenge_degree 5: a proof over KoalaBear's quintic challenge field (five words per extension element).
   // zk: the proof is a hiding PCS's (FriParams::zk; P3R_PROOF_ZK): its opening proof is the tuple (random opened values, FriProof).
   static BatchStarkProof from_postcard(const std::vector<uint8_t>& data, Field field, bool montgomery_field_encoding = true,
-                                       uint32_t challenge_degree = 4, bool zk = false) {
+                                       uint32_t challenge_degree = 4, bool zk = false, bool salted = false) {
     p3r_batch_stark_meta m;
     char err[256] = {0};
     const int rc = p3r_batch_stark_proof_parse((uint32_t)field, data.data(), data.size(),
                                                (montgomery_field_encoding ? 0 : P3R_PROVE_CANONICAL_FIELD_ENCODING) |
-                                                   (challenge_degree == 5 ? P3R_PROOF_QUINTIC_CHALLENGE : 0) | (zk ? P3R_PROOF_ZK : 0),
+                                                   (challenge_degree == 5 ? P3R_PROOF_QUINTIC_CHALLENGE : 0) | (zk ? P3R_PROOF_ZK : 0) |
+                                                   (salted ? P3R_PROOF_SALTED : 0),
                                                nullptr, &m, err, sizeof err);
     if (rc != P3R_OK) throw Error(rc, err);
     BatchStarkProof p;

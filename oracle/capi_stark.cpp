@@ -71,6 +71,7 @@ typedef struct orc_params {
   // proof-of-work witnesses to use instead of the smallest ones, in grind order (commit phases, then queries); canonical
   uint32_t n_forced_pow;
   uint32_t forced_pow[40];
+  uint32_t mmcs_salt_elems;   // twin of p3r_config.mmcs_salt_elems: MerkleTreeHidingMmcs with that many salt elements per row (0: plain)
 } orc_params;
 
 const char* orc_last_error();
@@ -117,6 +118,8 @@ StarkParams to_sp(const orc_params& p) {
   if (s.zk && (s.num_random_codewords < 1 || s.num_random_codewords > 8)) throw std::runtime_error("num_random_codewords must be in 1..8");
   for (int i = 0; i < 8; ++i) s.zk_key[i] = p.zk_key[i];
   s.zk_nonce = p.zk_nonce;
+  s.mmcs_salt_elems = (int)p.mmcs_salt_elems;
+  if (s.mmcs_salt_elems < 0 || s.mmcs_salt_elems > 16) throw std::runtime_error("mmcs_salt_elems must be in 0..16");
   for (uint32_t i = 0; i < p.n_forced_pow && i < 40; ++i) s.forced_pow.push_back(p.forced_pow[i]);
   for (uint32_t i = 0; i < p.n_fri_log_arities && i < 32; ++i) s.fri_log_arities.push_back(p.fri_log_arities[i]);
   return s;
@@ -294,10 +297,10 @@ struct Layer : LayerBase {
   std::vector<uint8_t> prove(const orc_params& p, int enc) override {
     ensure_pd(p);
     auto proof = prove_batch<FP>(p2, to_sp(p), insts, *pd);
-    return serialize_proof<FP>(proof, enc, to_layout(p));
+    return serialize_proof<FP>(proof, enc, to_layout(p), p.mmcs_salt_elems != 0);
   }
   void verify(const orc_params& p, const uint32_t* prep_cap, const uint8_t* bytes, size_t n, int enc) const override {
-    auto proof = deserialize_proof<FP>(bytes, n, enc, to_layout(p), p.zk != 0);
+    auto proof = deserialize_proof<FP>(bytes, n, enc, to_layout(p), p.zk != 0, p.mmcs_salt_elems != 0);
     std::vector<InstanceShape> shapes;
     for (auto& in : insts) shapes.push_back({in.air});
     typename BatchProof<FP>::Cap cap(size_t(1) << p.cap_height);
@@ -359,7 +362,7 @@ int orc_verify_batch(int field, const uint32_t* rc, const orc_params* p, size_t 
       using FP = decltype(tag);
       using F = Fe<FP>;
       Poseidon2<FP> p2(rc);
-      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p), p->zk != 0);
+      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p), p->zk != 0, p->mmcs_salt_elems != 0);
       std::vector<InstanceShape> shapes;
       for (size_t i = 0; i < n_airs; ++i) {
         AirDesc a;
@@ -390,7 +393,7 @@ int orc_verify_batch_w32(int field, const uint32_t* rc, const uint32_t* w32_rc, 
       using F = Fe<FP>;
       Poseidon2<FP> p2(rc);
       p2.w32 = std::make_shared<Poseidon2W32<FP>>(w32_rc, w32_diag);
-      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p), p->zk != 0);
+      auto proof = deserialize_proof<FP>(bytes, len, field_encoding, to_layout(*p), p->zk != 0, p->mmcs_salt_elems != 0);
       std::vector<InstanceShape> shapes;
       for (size_t i = 0; i < n_airs; ++i) {
         AirDesc a;

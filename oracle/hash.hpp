@@ -317,6 +317,56 @@ struct Challenger {
   }
 };
 
+// ------------------------------------------------------------------ ZK randomness
+// Keyed counter-based generator shared with the device (csrc/zk_rand.h is the device's statement of it): ChaCha with 8
+// rounds (RFC 8439's block function with four double rounds) under a 256-bit key; input words 12..15 of a block are
+// [counter, stream, nonce_lo, nonce_hi], nonce = proofs made so far.  Streams: (round << 20) | matrix, rounds 0 random,
+// 1 main, 2 quotient, 4 permutation, 5 quotient masks.  Cell idx of a stream: rejection sampling on 31-bit words -
+// words 2j, 2j + 1 (j = idx mod 8) of block idx / 8, then the words of fallback blocks
+// [idx mod 2^32, stream | f << 24 | (idx >> 32) << 27], f = 1..7, the first value below p.
+struct ZkStream {
+  std::array<uint32_t, 8> key{};
+  uint64_t nonce = 0;
+  uint32_t stream = 0;
+};
+inline std::array<uint32_t, 16> zk_chacha8(const std::array<uint32_t, 8>& key, uint32_t w12, uint32_t w13, uint64_t nonce) {
+  std::array<uint32_t, 16> in = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+  for (int i = 0; i < 8; ++i) in[4 + i] = key[i];
+  in[12] = w12; in[13] = w13; in[14] = (uint32_t)nonce; in[15] = (uint32_t)(nonce >> 32);
+  std::array<uint32_t, 16> x = in;
+  auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+  auto quarter = [&](int a, int b, int c, int d) {
+    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+    x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+    x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+  };
+  for (int dr = 0; dr < 4; ++dr) {
+    for (int c = 0; c < 4; ++c) quarter(c, 4 + c, 8 + c, 12 + c);                                   // columns
+    for (int c = 0; c < 4; ++c) quarter(c, 4 + (c + 1) % 4, 8 + (c + 2) % 4, 12 + (c + 3) % 4);     // diagonals
+  }
+  for (int i = 0; i < 16; ++i) x[i] += in[i];
+  return x;
+}
+template <class FP>
+Fe<FP> zk_rand(const ZkStream& s, uint64_t idx) {
+  const auto first = zk_chacha8(s.key, (uint32_t)(idx >> 3), s.stream, s.nonce);
+  const size_t j = idx & 7;
+  for (size_t t = 0; t < 2; ++t) {
+    const uint32_t v = first[2 * j + t] & 0x7FFFFFFFu;
+    if (v < FP::P) return Fe<FP>(v);
+  }
+  uint32_t last = 0;
+  for (uint32_t f = 1; f <= 7; ++f) {
+    const auto more = zk_chacha8(s.key, (uint32_t)idx, s.stream | (f << 24) | ((uint32_t)(idx >> 32) << 27), s.nonce);
+    for (uint32_t w : more) {
+      last = w & 0x7FFFFFFFu;
+      if (last < FP::P) return Fe<FP>(last);
+    }
+  }
+  return Fe<FP>(last % FP::P);
+}
+
 // Row-major matrix of base elements.
 template <class FP>
 struct Matrix {
@@ -343,6 +393,30 @@ struct MerkleTree {
   int log_max_h = 0, cap_height = 0;
   int arity = 2;                    // 4: MerkleTreeMmcs<.., 4, 8> over the width-32 permutation
   std::vector<Arity4Step> sched;    // arity 4: one entry per level
+  // MerkleTreeHidingMmcs (recursion/src/pcs/mmcs.rs:315-413,430-510: "commits [row | salt] per matrix"): one salt matrix
+  // (height x SALT_ELEMS) per committed matrix, in commit order; a leaf preimage is the concatenation, over the matrices of
+  // the height class in tallest-first stable order, of [row | salt].  Empty: the plain MerkleTreeMmcs.
+  std::vector<Matrix<FP>> salts;
+  // cell (r, c) of the salt matrix of matrix k: cell r * elems + c of the stream (round << 20 | first_mat + k) of the
+  // keyed generator above (the device's salts are the same values: csrc/zk_rand.h)
+  struct SaltSpec { int elems = 0; ZkStream base; int round = 0; size_t first_mat = 0; };
+  void draw_salts(const SaltSpec* sp) {
+    salts.clear();
+    if (!sp || sp->elems <= 0) return;
+    for (size_t k = 0; k < mats.size(); ++k) {
+      Matrix<FP> m(mats[k]->h, (size_t)sp->elems);
+      ZkStream st = sp->base;
+      st.stream = ((uint32_t)sp->round << 20) | (uint32_t)(sp->first_mat + k);
+      for (size_t r = 0; r < m.h; ++r)
+        for (size_t c = 0; c < m.w; ++c) m.at(r, c) = zk_rand<FP>(st, r * m.w + c);
+      salts.push_back(std::move(m));
+    }
+  }
+  std::vector<F> salted_row(size_t k, size_t i) const {
+    auto r = mats[k]->row(i);
+    if (!salts.empty()) { auto s = salts[k].row(i); r.insert(r.end(), s.begin(), s.end()); }
+    return r;
+  }
 
   std::vector<Digest> cap() const { return layers.back(); }
 
@@ -355,12 +429,14 @@ struct MerkleTree {
   // Arity 4 (recursion/src/pcs/mmcs.rs:866-1316 is the in-tree statement of what such a tree is: leaf = W32 sponge
   // over the rows of the tallest matrices; a level compresses 4 (or 2, zero-padded to 4) children; an injected
   // matrix enters as one more compression (node, its row digest, 0, 0); logical layers of 2 are padded to 4).
-  static MerkleTree commit4(const Poseidon2<FP>& p2, const std::vector<const Matrix<FP>*>& mats, int cap_height) {
+  static MerkleTree commit4(const Poseidon2<FP>& p2, const std::vector<const Matrix<FP>*>& mats, int cap_height,
+                            const SaltSpec* salt = nullptr) {
     if (cap_height != 0) throw std::runtime_error("arity-4 MMCS: cap_height must be 0");
     const auto& w = wide(p2);
     MerkleTree t;
     t.mats = mats;
     t.arity = 4;
+    t.draw_salts(salt);
     std::vector<size_t> order(mats.size()), heights;
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return mats[a]->h > mats[b]->h; });
@@ -372,7 +448,7 @@ struct MerkleTree {
       std::vector<F> cat;
       for (size_t k : order)
         if (mats[k]->h == h) {
-          auto r = mats[k]->row(i);
+          auto r = t.salted_row(k, i);
           cat.insert(cat.end(), r.begin(), r.end());
         }
       return cat;
@@ -397,10 +473,12 @@ struct MerkleTree {
   }
   // siblings of one level in ascending position, the opened node's own position left out
   // (`Proof = Vec<[F; 8]>`, grouped per level by set_arity4_opening_private_data, recursion/src/pcs/mmcs.rs:1413-1461)
-  void open4(size_t index, std::vector<std::vector<F>>& opened, std::vector<Digest>& proof) const {
+  void open4(size_t index, std::vector<std::vector<F>>& opened, std::vector<Digest>& proof,
+             std::vector<std::vector<F>>* salts_out = nullptr) const {
     opened.clear();
     proof.clear();
     for (auto* m : mats) opened.push_back(m->row(index >> (log_max_h - log2_strict(m->h))));
+    open_salts(index, salts_out);
     size_t idx = index;
     for (size_t l = 0; l < sched.size(); ++l) {
       const size_t step = sched[l].step, pos = idx % step, base = idx - pos;
@@ -411,8 +489,10 @@ struct MerkleTree {
   }
   static bool verify4(const Poseidon2<FP>& p2, const std::vector<Digest>& cap, int cap_height,
                       const std::vector<std::pair<size_t, size_t>>& dims, size_t index,
-                      const std::vector<std::vector<F>>& opened, const std::vector<Digest>& proof) {
+                      const std::vector<std::vector<F>>& opened, const std::vector<Digest>& proof,
+                      const std::vector<std::vector<F>>* salts = nullptr) {
     if (cap_height != 0 || cap.size() != 1) return false;
+    if (salts && salts->size() != dims.size()) return false;
     const auto& w = wide(p2);
     std::vector<size_t> order(dims.size()), heights;
     std::iota(order.begin(), order.end(), 0);
@@ -427,6 +507,7 @@ struct MerkleTree {
         if (dims[k].first == h) {
           if (opened[k].size() != dims[k].second) throw std::runtime_error("opened width mismatch");
           cat.insert(cat.end(), opened[k].begin(), opened[k].end());
+          if (salts) cat.insert(cat.end(), (*salts)[k].begin(), (*salts)[k].end());   // [row | salt] per matrix
         }
       return cat;
     };
@@ -447,11 +528,12 @@ struct MerkleTree {
   }
 
   static MerkleTree commit(const Poseidon2<FP>& p2, const std::vector<const Matrix<FP>*>& mats,
-                           int cap_height, int arity = 2) {
-    if (arity == 4) return commit4(p2, mats, cap_height);
+                           int cap_height, int arity = 2, const SaltSpec* salt = nullptr) {
+    if (arity == 4) return commit4(p2, mats, cap_height, salt);
     MerkleTree t;
     t.mats = mats;
     t.cap_height = cap_height;
+    t.draw_salts(salt);
     std::vector<size_t> order(mats.size());
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(),
@@ -463,7 +545,7 @@ struct MerkleTree {
       std::vector<F> cat;
       for (size_t k : order)
         if (mats[k]->h == h) {
-          auto r = mats[k]->row(i);
+          auto r = t.salted_row(k, i);
           cat.insert(cat.end(), r.begin(), r.end());
         }
       return cat;
@@ -494,10 +576,19 @@ struct MerkleTree {
 
   // open_batch(index): rows (index >> (log_max_h - log_h)) of every matrix in commit order,
   // sibling digests bottom-up.
-  void open(size_t index, std::vector<std::vector<F>>& opened, std::vector<Digest>& proof) const {
-    if (arity == 4) return open4(index, opened, proof);
+  // the salt rows of the opened rows, per matrix in commit order (the first half of `Proof = (salts, siblings)`,
+  // recursion/src/pcs/mmcs.rs:763-790)
+  void open_salts(size_t index, std::vector<std::vector<F>>* salts_out) const {
+    if (!salts_out) return;
+    salts_out->clear();
+    for (size_t k = 0; k < salts.size(); ++k) salts_out->push_back(salts[k].row(index >> (log_max_h - log2_strict(mats[k]->h))));
+  }
+  void open(size_t index, std::vector<std::vector<F>>& opened, std::vector<Digest>& proof,
+            std::vector<std::vector<F>>* salts_out = nullptr) const {
+    if (arity == 4) return open4(index, opened, proof, salts_out);
     opened.clear();
     proof.clear();
+    open_salts(index, salts_out);
     for (auto* m : mats) opened.push_back(m->row(index >> (log_max_h - log2_strict(m->h))));
     for (int l = 0; l < log_max_h - cap_height; ++l) proof.push_back(layers[l][(index >> l) ^ 1]);
   }
@@ -506,8 +597,10 @@ struct MerkleTree {
   // commit order.
   static bool verify(const Poseidon2<FP>& p2, const std::vector<Digest>& cap, int cap_height,
                      const std::vector<std::pair<size_t, size_t>>& dims, size_t index,
-                     const std::vector<std::vector<F>>& opened, const std::vector<Digest>& proof, int arity = 2) {
-    if (arity == 4) return verify4(p2, cap, cap_height, dims, index, opened, proof);
+                     const std::vector<std::vector<F>>& opened, const std::vector<Digest>& proof, int arity = 2,
+                     const std::vector<std::vector<F>>* salts = nullptr) {
+    if (arity == 4) return verify4(p2, cap, cap_height, dims, index, opened, proof, salts);
+    if (salts && salts->size() != dims.size()) return false;
     std::vector<size_t> order(dims.size());
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(),
@@ -523,6 +616,7 @@ struct MerkleTree {
           any = true;
           if (opened[k].size() != dims[k].second) throw std::runtime_error("opened width mismatch");
           cat.insert(cat.end(), opened[k].begin(), opened[k].end());
+          if (salts) cat.insert(cat.end(), (*salts)[k].begin(), (*salts)[k].end());   // [row | salt] per matrix (mmcs.rs:375-389)
         }
       return cat;
     };

@@ -51,7 +51,10 @@ struct Layout {
 };
 
 template <class FP>
-std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_ENCODING_MONTY, const Layout& L = Layout{}) {
+// `salted`: the MMCSs are MerkleTreeHidingMmcs - an opening proof is the tuple (Vec<Vec<F>> salts, Vec<[F; 8]> siblings)
+// (`SaltedMmcsProof`, recursion/src/pcs/mmcs.rs:763-768); like `zk` a property of the configuration, not of the bytes
+std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_ENCODING_MONTY, const Layout& L = Layout{},
+                                     bool salted = false) {
   Writer<FP> w;
   w.enc = enc;
   auto commitments = [&] {  // { main, permutation?, quotient_chunks, random? }
@@ -85,6 +88,7 @@ std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_EN
       for (auto& bo : q.input_proof) {
         w.varint(bo.opened_values.size());
         for (auto& r : bo.opened_values) w.vec_fe(r);
+        if (salted) { w.varint(bo.salts.size()); for (auto& sl : bo.salts) w.vec_fe(sl); }
         w.varint(bo.opening_proof.size());
         for (auto& d : bo.opening_proof) w.digest(d);
       }
@@ -92,6 +96,7 @@ std::vector<uint8_t> serialize_proof(const BatchProof<FP>& p, int enc = FIELD_EN
       for (auto& s : q.commit_phase_openings) {
         w.byte(s.log_arity);
         w.vec_ef(s.sibling_values);
+        if (salted) { w.varint(s.salts.size()); for (auto& sl : s.salts) w.vec_fe(sl); }
         w.varint(s.opening_proof.size());
         for (auto& d : s.opening_proof) w.digest(d);
       }
@@ -175,7 +180,7 @@ template <class FP>
 // `zk`: the proof type is the hiding PCS's (the opening proof is the tuple above): a property of the configuration, as
 // SC::Pcs is in the reference - not something the bytes announce.
 BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_ENCODING_MONTY, const Layout& L = Layout{},
-                                 bool zk = false) {
+                                 bool zk = false, bool salted = false) {
   Reader<FP> r{data, data + n, enc};
   BatchProof<FP> p;
   auto commitments = [&] {
@@ -217,6 +222,7 @@ BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_
         size_t nm = r.len();
         bo.opened_values.resize(nm);
         for (auto& row : bo.opened_values) row = r.vec_fe();
+        if (salted) { bo.salts.resize(r.len()); for (auto& sl : bo.salts) sl = r.vec_fe(); }
         size_t nd = r.len();
         bo.opening_proof.resize(nd);
         for (auto& d : bo.opening_proof) d = r.digest();
@@ -226,6 +232,7 @@ BatchProof<FP> deserialize_proof(const uint8_t* data, size_t n, int enc = FIELD_
       for (auto& s : q.commit_phase_openings) {
         s.log_arity = r.byte();
         s.sibling_values = r.vec_ef();
+        if (salted) { s.salts.resize(r.len()); for (auto& sl : s.salts) sl = r.vec_fe(); }
         size_t nd = r.len();
         s.opening_proof.resize(nd);
         for (auto& d : s.opening_proof) d = r.digest();

@@ -46,57 +46,26 @@ struct StarkParams {
   int num_random_codewords = 2;
   std::array<uint32_t, 8> zk_key{};   // the key of the hiding PCS's generator (`rng: R`'s counterpart; p3r_config.zk_key taken as it is)
   uint64_t zk_nonce = 0;   // proofs made so far under this configuration (the PCS's RNG state advances per commit)
+  // MerkleTreeHidingMmcs for the input AND the FRI commit-phase MMCS (recursion/tests/zk_hiding_mmcs.rs: "the
+  // upstream-recommended ZK setup", SALT_ELEMS = 4 there): every committed matrix gets mmcs_salt_elems random elements
+  // per row appended to its leaf preimage; an opening proof is (per-matrix salts, sibling digests).  0: MerkleTreeMmcs.
+  int mmcs_salt_elems = 0;
 };
-
-// ------------------------------------------------------------------ ZK randomness
-// Keyed counter-based generator shared with the device (csrc/zk_rand.h is the device's statement of it): ChaCha with 8
-// rounds (RFC 8439's block function with four double rounds) under a 256-bit key; input words 12..15 of a block are
-// [counter, stream, nonce_lo, nonce_hi], nonce = proofs made so far.  Streams: (round << 20) | matrix, rounds 0 random,
-// 1 main, 2 quotient, 4 permutation, 5 quotient masks.  Cell idx of a stream: rejection sampling on 31-bit words -
-// words 2j, 2j + 1 (j = idx mod 8) of block idx / 8, then the words of fallback blocks
-// [idx mod 2^32, stream | f << 24 | (idx >> 32) << 27], f = 1..7, the first value below p.
-struct ZkStream {
-  std::array<uint32_t, 8> key{};
-  uint64_t nonce = 0;
-  uint32_t stream = 0;
-};
-inline std::array<uint32_t, 16> zk_chacha8(const std::array<uint32_t, 8>& key, uint32_t w12, uint32_t w13, uint64_t nonce) {
-  std::array<uint32_t, 16> in = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
-  for (int i = 0; i < 8; ++i) in[4 + i] = key[i];
-  in[12] = w12; in[13] = w13; in[14] = (uint32_t)nonce; in[15] = (uint32_t)(nonce >> 32);
-  std::array<uint32_t, 16> x = in;
-  auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
-  auto quarter = [&](int a, int b, int c, int d) {
-    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
-    x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
-    x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
-    x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
-  };
-  for (int dr = 0; dr < 4; ++dr) {
-    for (int c = 0; c < 4; ++c) quarter(c, 4 + c, 8 + c, 12 + c);                                   // columns
-    for (int c = 0; c < 4; ++c) quarter(c, 4 + (c + 1) % 4, 8 + (c + 2) % 4, 12 + (c + 3) % 4);     // diagonals
-  }
-  for (int i = 0; i < 16; ++i) x[i] += in[i];
-  return x;
-}
+// salts are drawn from the configuration's keyed generator: stream round = kSaltRound + the round of the committed batch
+// (ZK_ROUND_* below), kSaltRoundFri for the commit-phase trees (matrix = phase)
+constexpr int kSaltRound = 8, kSaltRoundFri = 14;
 template <class FP>
-Fe<FP> zk_rand(const ZkStream& s, uint64_t idx) {
-  const auto first = zk_chacha8(s.key, (uint32_t)(idx >> 3), s.stream, s.nonce);
-  const size_t j = idx & 7;
-  for (size_t t = 0; t < 2; ++t) {
-    const uint32_t v = first[2 * j + t] & 0x7FFFFFFFu;
-    if (v < FP::P) return Fe<FP>(v);
-  }
-  uint32_t last = 0;
-  for (uint32_t f = 1; f <= 7; ++f) {
-    const auto more = zk_chacha8(s.key, (uint32_t)idx, s.stream | (f << 24) | ((uint32_t)(idx >> 32) << 27), s.nonce);
-    for (uint32_t w : more) {
-      last = w & 0x7FFFFFFFu;
-      if (last < FP::P) return Fe<FP>(last);
-    }
-  }
-  return Fe<FP>(last % FP::P);
+typename MerkleTree<FP>::SaltSpec salt_spec(const StarkParams& sp, int round, size_t first_mat = 0, bool prep = false) {
+  typename MerkleTree<FP>::SaltSpec s;
+  s.elems = sp.mmcs_salt_elems;
+  s.base.key = sp.zk_key;
+  s.base.nonce = prep ? 0 : sp.zk_nonce;   // the preprocessed commitment is made once per circuit, before any proof
+  s.round = round;
+  s.first_mat = first_mat;
+  return s;
 }
+
+// (the keyed generator of the ZK configuration - ZkStream, zk_rand - lives in hash.hpp: the hiding MMCS draws its salts from it)
 enum { ZK_ROUND_RANDOM = 0, ZK_ROUND_MAIN = 1, ZK_ROUND_QUOTIENT = 2, ZK_ROUND_PREP = 3, ZK_ROUND_PERM = 4, ZK_ROUND_QMASK = 5 };
 inline uint32_t zk_stream(int round, size_t mat) { return ((uint32_t)round << 20) | (uint32_t)mat; }
 
@@ -112,12 +81,14 @@ template <class FP>
 struct BatchOpening {
   std::vector<std::vector<Fe<FP>>> opened_values;          // per matrix of the batch
   std::vector<std::array<Fe<FP>, DIGEST>> opening_proof;   // sibling digests bottom-up
+  std::vector<std::vector<Fe<FP>>> salts;                  // hiding MMCS: per matrix; Proof = (salts, siblings)
 };
 template <class FP>
 struct CommitPhaseStep {
   uint8_t log_arity = 1;
   std::vector<Fe4<FP>> sibling_values;
   std::vector<std::array<Fe<FP>, DIGEST>> opening_proof;
+  std::vector<std::vector<Fe<FP>>> salts;                  // hiding MMCS: one entry (the phase's single matrix)
 };
 template <class FP>
 struct QueryProof {
@@ -352,12 +323,13 @@ struct Committed {
   typename BatchProof<FP>::Cap cap;
 };
 template <class FP>
-Committed<FP> commit_ldes(const Poseidon2<FP>& p2, std::vector<Matrix<FP>> ldes, int cap_height, int arity = 2) {
+Committed<FP> commit_ldes(const Poseidon2<FP>& p2, std::vector<Matrix<FP>> ldes, int cap_height, int arity = 2,
+                          const typename MerkleTree<FP>::SaltSpec* salt = nullptr) {
   Committed<FP> c;
   c.ldes = std::move(ldes);
   std::vector<const Matrix<FP>*> ptrs;
   for (auto& m : c.ldes) ptrs.push_back(&m);
-  c.tree = MerkleTree<FP>::commit(p2, ptrs, cap_height, arity);
+  c.tree = MerkleTree<FP>::commit(p2, ptrs, cap_height, arity, salt);
   c.cap = c.tree.cap();
   return c;
 }
@@ -397,7 +369,8 @@ ProverData<FP> make_prover_data(const Poseidon2<FP>& p2, const StarkParams& sp,
     pd.evals.push_back(sp.zk ? zk_randomize<FP>(in.prep, sp.num_random_codewords, ZkStream{}, true) : in.prep);
     ldes.push_back(coset_lde_bitrev<FP>(pd.evals.back(), sp.log_blowup, Fe<FP>::generator()));
   }
-  pd.prep = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity);
+  const auto prep_salt = salt_spec<FP>(sp, kSaltRound + ZK_ROUND_PREP, 0, true);
+  pd.prep = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity, &prep_salt);
   return pd;
 }
 
@@ -481,7 +454,8 @@ void fri_commit_phase(const Poseidon2<FP>& p2, const StarkParams& sp, std::vecto
         for (int k = 0; k < DC; ++k) leaves.at(r, j * DC + k) = folded[r * arity + j].c[k];
     st.leaves.push_back(leaves);
     std::vector<const Matrix<FP>*> ptr{&st.leaves.back()};
-    st.trees.push_back(MerkleTree<FP>::commit(p2, ptr, sp.cap_height, sp.mmcs_arity));
+    const auto fri_salt = salt_spec<FP>(sp, kSaltRoundFri, st.trees.size());   // ExtensionMmcs over the hiding MMCS: the flattened row, then its salt
+    st.trees.push_back(MerkleTree<FP>::commit(p2, ptr, sp.cap_height, sp.mmcs_arity, &fri_salt));
     // the tree keeps a pointer to the matrix: re-point it at the stored copy after push_back moves
     st.log_arities.push_back(la);
     auto cap = st.trees.back().cap();
@@ -571,7 +545,8 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
     main_ev[i] = zk ? zk_randomize<FP>(insts[i].main, R, key(ZK_ROUND_MAIN, i), false) : insts[i].main;
     main_ldes.push_back(coset_lde_bitrev<FP>(main_ev[i], sp.log_blowup, gen));
   }
-  auto main_c = commit_ldes<FP>(p2, std::move(main_ldes), sp.cap_height, sp.mmcs_arity);
+  const auto main_salt = salt_spec<FP>(sp, kSaltRound + ZK_ROUND_MAIN);
+  auto main_c = commit_ldes<FP>(p2, std::move(main_ldes), sp.cap_height, sp.mmcs_arity, &main_salt);
   proof.main_commit = main_c.cap;
   // 2. transcript head (batch_stark.rs:521-578): extended degree bits, base degree bits, width, chunk count
   ch.observe_base_as_ext(F((uint64_t)ni));
@@ -643,7 +618,8 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
       aux_ev[i] = zk ? zk_randomize<FP>(aux[i].flat, R, key(ZK_ROUND_PERM, k), false) : aux[i].flat;
       ldes.push_back(coset_lde_bitrev<FP>(aux_ev[i], sp.log_blowup, gen));
     }
-    perm_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity);
+    const auto perm_salt = salt_spec<FP>(sp, kSaltRound + ZK_ROUND_PERM);
+    perm_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity, &perm_salt);
     proof.has_permutation = true;
     proof.permutation_commit = perm_c.cap;
     for (auto& d : perm_c.cap) ch.observe_arr(d);
@@ -773,7 +749,8 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
   std::vector<Matrix<FP>> q_ldes;
   for (size_t k = 0; k < q_chunk_evals.size(); ++k)
     q_ldes.push_back(coset_lde_bitrev<FP>(q_chunk_evals[k], sp.log_blowup, gen * q_chunk_shift[k].inv()));
-  auto quot_c = commit_ldes<FP>(p2, std::move(q_ldes), sp.cap_height, sp.mmcs_arity);
+  const auto quot_salt = salt_spec<FP>(sp, kSaltRound + ZK_ROUND_QUOTIENT);
+  auto quot_c = commit_ldes<FP>(p2, std::move(q_ldes), sp.cap_height, sp.mmcs_arity, &quot_salt);
   proof.quotient_commit = quot_c.cap;
   for (auto& d : quot_c.cap) ch.observe_arr(d);
   // ZK: the random round - per instance a fully random matrix of Challenge::DIMENSION (+ R) columns over the extended
@@ -790,7 +767,8 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
         for (size_t c = 0; c < w2; ++c) rand_ev[i].at(r, c) = zk_rand<FP>(rk, r * w2 + c);
       ldes.push_back(coset_lde_bitrev<FP>(rand_ev[i], sp.log_blowup, gen));
     }
-    rand_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity);
+    const auto rand_salt = salt_spec<FP>(sp, kSaltRound + ZK_ROUND_RANDOM);
+    rand_c = commit_ldes<FP>(p2, std::move(ldes), sp.cap_height, sp.mmcs_arity, &rand_salt);
     proof.has_random = true;
     proof.random_commit = rand_c.cap;
     for (auto& d : rand_c.cap) ch.observe_arr(d);
@@ -898,7 +876,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
       const auto& cm = *cmp;
       BatchOpening<FP> bo;
       size_t ridx = index >> (log_max - cm.tree.log_max_h);
-      cm.tree.open(ridx, bo.opened_values, bo.opening_proof);
+      cm.tree.open(ridx, bo.opened_values, bo.opening_proof, sp.mmcs_salt_elems ? &bo.salts : nullptr);
       qp.input_proof.push_back(bo);
     }
     size_t idx = index;
@@ -914,7 +892,7 @@ BatchProof<FP> prove_batch(const Poseidon2<FP>& p2, const StarkParams& sp,
         step.sibling_values.push_back(e);
       }
       std::vector<std::vector<F>> ov;
-      st.trees[p].open(row, ov, step.opening_proof);
+      st.trees[p].open(row, ov, step.opening_proof, sp.mmcs_salt_elems ? &step.salts : nullptr);
       qp.commit_phase_openings.push_back(step);
       idx = row;
     }
@@ -1094,7 +1072,12 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
       }
       if (batch_max > log_max) fail("a committed matrix taller than the FRI domain");
       size_t ridx = index >> (log_max - batch_max);
-      if (!MerkleTree<FP>::verify(p2, *rd.cap, sp.cap_height, dims, ridx, bo.opened_values, bo.opening_proof, sp.mmcs_arity))
+      if (sp.mmcs_salt_elems) {   // `(salts, siblings)`: one salt of SALT_ELEMS per matrix of the batch (mmcs.rs:339-347)
+        if (bo.salts.size() != dims.size()) fail("input MMCS opening: salt count");
+        for (auto& sl : bo.salts) if ((int)sl.size() != sp.mmcs_salt_elems) fail("input MMCS opening: salt length");
+      } else if (!bo.salts.empty()) fail("input MMCS opening: salts under a non-hiding MMCS");
+      if (!MerkleTree<FP>::verify(p2, *rd.cap, sp.cap_height, dims, ridx, bo.opened_values, bo.opening_proof, sp.mmcs_arity,
+                                  sp.mmcs_salt_elems ? &bo.salts : nullptr))
         fail("input MMCS opening");
       for (size_t m = 0; m < rd.mats.size(); ++m) {
         int lh = rd.mats[m].log_h + sp.log_blowup;
@@ -1131,7 +1114,11 @@ void verify_batch(const Poseidon2<FP>& p2, const StarkParams& sp, const std::vec
       std::vector<F> flat;
       for (auto& e : evals) for (int k = 0; k < EF::deg(); ++k) flat.push_back(e.c[k]);
       std::vector<std::pair<size_t, size_t>> dims{{size_t(1) << (log_cur - la), arity * (size_t)EF::deg()}};
-      if (!MerkleTree<FP>::verify(p2, fp.commit_phase_commits[p], sp.cap_height, dims, row, {flat}, step.opening_proof, sp.mmcs_arity))
+      if (sp.mmcs_salt_elems) {
+        if (step.salts.size() != 1 || (int)step.salts[0].size() != sp.mmcs_salt_elems) fail("commit-phase MMCS opening: salt shape");
+      } else if (!step.salts.empty()) fail("commit-phase MMCS opening: salts under a non-hiding MMCS");
+      if (!MerkleTree<FP>::verify(p2, fp.commit_phase_commits[p], sp.cap_height, dims, row, {flat}, step.opening_proof, sp.mmcs_arity,
+                                  sp.mmcs_salt_elems ? &step.salts : nullptr))
         fail("commit-phase MMCS opening");
       folded = fold_row<FP>(evals, row, log_cur - la, la, betas[p]);
       log_cur -= la;

@@ -43,6 +43,7 @@ class P3rConfig(C.Structure):
         ("mmcs_arity", C.c_uint32),   # 0 / 2: binary MMCS over the width-16 permutation; 4: the arity-4 MMCS (width 32)
         # ABI 7: ZK = HidingFriPcs (create_config_zk, recursion/examples/common/mod.rs:511-553)
         ("zk", C.c_uint32), ("num_random_codewords", C.c_uint32), ("zk_key", C.c_uint32 * 8),
+        ("mmcs_salt_elems", C.c_uint32),   # MerkleTreeHidingMmcs: salt elements per committed row (0: plain MMCS)
     ]
 
 
@@ -206,6 +207,8 @@ SIGNATURES = {
     "p3r_tree_proof_len": (C.c_size_t, [vp]),
     "p3r_mmcs_verify": (C.c_int, [C.POINTER(P3rConfig), u32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t,
                                   u32p, u32p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "p3r_mmcs_verify_salted": (C.c_int, [C.POINTER(P3rConfig), u32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_size_t,
+                                         u32p, u32p, u32p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "p3r_tree_free": (None, [vp, vp]),
     "p3r_prep_create": (vp, [vp, C.POINTER(P3rAirDesc), C.POINTER(P3rMatrix), C.c_size_t, u32p]),
     "p3r_prep_free": (None, [vp, vp]),

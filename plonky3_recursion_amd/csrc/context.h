@@ -395,6 +395,16 @@ struct p3r_tree {
   // matrices in COMMIT order (as passed by the caller)
   std::vector<const p3r_dmat*> mats;
   std::vector<std::unique_ptr<p3r_dmat>> owned;  // when committed from host matrices
+  // MerkleTreeHidingMmcs (p3r_config.mmcs_salt_elems > 0): `mats` then holds every committed matrix FOLLOWED by its salt
+  // matrix (height x salt_elems, owned) - [M0, S0, M1, S1, ..] - so that the leaf preimage of a height class, built by the
+  // plain commit in tallest-first stable order, is the concatenation of [row | salt] per matrix
+  // (recursion/src/pcs/mmcs.rs:375-389); an opening is (rows of the even entries, salts = rows of the odd ones, siblings).
+  int salt_elems = 0;
+  std::vector<std::unique_ptr<p3r_dmat>> salt_owned;
+  // FRI commit-phase tree of a hiding ExtensionMmcs: the salts of its one (strided) leaf matrix, column c of row r at
+  // [c * salt_stride * rows + r * salt_stride] (the layout of the strided leaf kernels)
+  p3r::DevBuf phase_salts;
+  size_t phase_salt_stride = 0, phase_rows = 0;
   int log_max_h = 0;
   int cap_height = 0;
   size_t total_width = 0;

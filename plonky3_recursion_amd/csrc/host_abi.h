@@ -113,6 +113,36 @@ int p3r_mmcs_verify(const p3r_config* cfg, const uint32_t* cap, size_t n_mats, c
 }
 
 // ---- native verifier (verify_impl.h): host code, no device needed ----
+// MerkleTreeHidingMmcs::verify_batch: the leaf preimage of a height class is the concatenation of [row | salt] per matrix
+// (recursion/src/pcs/mmcs.rs:375-389), i.e. the plain walk over the matrices widened by cfg->mmcs_salt_elems columns.
+int p3r_mmcs_verify_salted(const p3r_config* cfg, const uint32_t* cap, size_t n_mats, const size_t* heights, const size_t* widths,
+                           size_t index, const uint32_t* opened_values, const uint32_t* salts, const uint32_t* proof,
+                           size_t proof_len, char* err_buf, size_t err_cap) {
+  if (!cfg || !widths || !opened_values || !n_mats || (cfg->mmcs_salt_elems && !salts)) {
+    if (err_buf && err_cap) snprintf(err_buf, err_cap, "NULL argument");
+    return P3R_EINVAL;
+  }
+  const size_t S = cfg->mmcs_salt_elems;
+  if (S > 16) {
+    if (err_buf && err_cap) snprintf(err_buf, err_cap, "mmcs_salt_elems must be in 0..16");
+    return P3R_EINVAL;
+  }
+  std::vector<size_t> wide(widths, widths + n_mats);
+  std::vector<uint32_t> rows;
+  const uint32_t* ov = opened_values;
+  for (size_t m = 0; m < n_mats; ++m) {
+    if (widths[m] > (size_t(1) << 24)) {
+      if (err_buf && err_cap) snprintf(err_buf, err_cap, "matrix width out of range");
+      return P3R_EINVAL;
+    }
+    rows.insert(rows.end(), ov, ov + widths[m]);
+    ov += widths[m];
+    if (S) rows.insert(rows.end(), salts + m * S, salts + (m + 1) * S);
+    wide[m] += S;
+  }
+  return p3r_mmcs_verify(cfg, cap, n_mats, heights, wide.data(), index, rows.data(), proof, proof_len, err_buf, err_cap);
+}
+
 int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_airs,
                      const uint32_t* preprocessed_commitment, const uint32_t* degree_bits, const uint8_t* proof,
                      size_t proof_len, uint32_t flags, char* err_buf, size_t err_cap) {
@@ -138,6 +168,8 @@ int p3r_verify_batch(const p3r_config* cfg, const p3r_air_desc* airs, size_t n_a
       if (uses_w32) { report(kW32Unpinned); return P3R_EINVAL; }
     }
     if (cfg->zk > 1 || cfg->num_random_codewords > 8) { report("zk must be 0 or 1, num_random_codewords at most 8"); return P3R_EINVAL; }
+    if (cfg->mmcs_salt_elems > 16) { report("mmcs_salt_elems must be in 0..16"); return P3R_EINVAL; }
+    prm.mmcs_salt_elems = (int)cfg->mmcs_salt_elems;
     prm.zk = (int)cfg->zk;
     prm.num_random_codewords = cfg->zk ? (cfg->num_random_codewords ? (int)cfg->num_random_codewords : 2) : 0;
     if (!prm.layout.set(cfg->proof_layout, cfg->proof_layout_len)) { report("proof_layout must be 18 bytes: three permutations"); return P3R_EINVAL; }
@@ -190,11 +222,11 @@ int p3r_batch_proof_len_layout(uint32_t field, const uint8_t* bytes, size_t len,
     const bool canonical = (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0;
     p3r::ProofLayout PL;
     if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
-    const bool zk = (flags & P3R_PROOF_ZK) != 0;
+    const bool zk = (flags & P3R_PROOF_ZK) != 0, salted = (flags & P3R_PROOF_SALTED) != 0;
     if (field == P3R_FIELD_KOALA_BEAR && (flags & P3R_PROOF_QUINTIC_CHALLENGE))
-      (void)p3r::parse_proof<p3r::KoalaBearParams, 5>(bytes, len, canonical, proof_len, PL, zk);
-    else if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len, PL, zk);
-    else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len, PL, zk);
+      (void)p3r::parse_proof<p3r::KoalaBearParams, 5>(bytes, len, canonical, proof_len, PL, zk, salted);
+    else if (field == P3R_FIELD_KOALA_BEAR) (void)p3r::parse_proof<p3r::KoalaBearParams>(bytes, len, canonical, proof_len, PL, zk, salted);
+    else if (field == P3R_FIELD_BABY_BEAR) (void)p3r::parse_proof<p3r::BabyBearParams>(bytes, len, canonical, proof_len, PL, zk, salted);
     else throw std::runtime_error("unknown field");
     return P3R_OK;
   } catch (const std::exception& e) {
@@ -213,9 +245,9 @@ int p3r_batch_stark_proof_parse(uint32_t field, const uint8_t* bytes, size_t len
     p3r::ProofLayout PL;
     if (!PL.set(proof_layout, 18)) throw std::runtime_error("proof_layout must be three permutations batch[5] | fri[5] | opened[8]");
     const int dc = (flags & P3R_PROOF_QUINTIC_CHALLENGE) ? 5 : 4;
-    const bool zk = (flags & P3R_PROOF_ZK) != 0;
-    if (field == P3R_FIELD_KOALA_BEAR) p3r::parse_batch_stark_meta<p3r::KoalaBearParams>(bytes, len, canonical, PL, dc, out, zk);
-    else if (field == P3R_FIELD_BABY_BEAR) p3r::parse_batch_stark_meta<p3r::BabyBearParams>(bytes, len, canonical, PL, dc, out, zk);
+    const bool zk = (flags & P3R_PROOF_ZK) != 0, salted = (flags & P3R_PROOF_SALTED) != 0;
+    if (field == P3R_FIELD_KOALA_BEAR) p3r::parse_batch_stark_meta<p3r::KoalaBearParams>(bytes, len, canonical, PL, dc, out, zk, salted);
+    else if (field == P3R_FIELD_BABY_BEAR) p3r::parse_batch_stark_meta<p3r::BabyBearParams>(bytes, len, canonical, PL, dc, out, zk, salted);
     else throw std::runtime_error("unknown field");
     out->parse_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     return P3R_OK;

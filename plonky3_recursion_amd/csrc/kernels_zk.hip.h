@@ -101,4 +101,27 @@ __global__ void __launch_bounds__(kBlock) k_zk_chunk(const ZkChunkJob* __restric
   as_global(j.dst)[(uint64_t)c * h2 + r] = v;
 }
 
+// Salts of a hiding MMCS (p3r_config.mmcs_salt_elems): cell (r, c) of the h x S salt matrix of one committed matrix is
+// cell r * S + c of its stream.  Plain column-major matrices [S][h] (stride 1), or the strided layout of a FRI
+// commit-phase leaf matrix: dst[c * h * stride + r * stride].
+struct ZkSaltJob {
+  uint32_t* dst;
+  uint64_t h;
+  uint32_t S, stride;
+  uint32_t stream;
+  uint32_t block0;
+};
+template <class PP>
+__global__ void __launch_bounds__(kBlock) k_zk_salts(const ZkSaltJob* __restrict__ jobs, int n_jobs, ZkKey key) {
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const ZkSaltJob& j = jobs[jb];
+  const uint64_t tiles_per_col = (j.h + kBlock - 1) / kBlock;
+  const uint64_t t = blockIdx.x - j.block0;
+  const uint32_t c = (uint32_t)(t / tiles_per_col);
+  const uint64_t r = (t % tiles_per_col) * kBlock + threadIdx.x;
+  if (r >= j.h) return;
+  as_global(j.dst)[((uint64_t)c * j.h + r) * j.stride] = zk_rand_mont<PP>(key, j.stream, r * j.S + c);
+}
+
 }  // namespace p3r

@@ -628,13 +628,16 @@ p3r_ctx* p3r_create(const p3r_config* cfg) {
     c->cfg = *cfg;
     tls_pool() = c->pool;
     P3R_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    // (the side streams of the two-stream commit experiment are created on first use: ensure_side_streams)
+    // (the side streams of the two-stream commit experiment are created on first use: ensure_side_streams; the knobs build
+    // can create them with the context, as round 5 did - the A/B of profiles/r06/README.md on small-layer throughput)
+    if (tuning_knob("P3R_FORCE_SIDE_STREAMS")) ensure_side_streams(c.get());
     {
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) c->n_cus = cus;
     }
-    if (cfg->zk) {
-      // the key the context draws its masks with (zk_rand.h): the caller's, mixed with 128 bits of operating-system
+    if (cfg->mmcs_salt_elems > 16) fail(P3R_EINVAL, "mmcs_salt_elems must be in 0..16 (got %u)", cfg->mmcs_salt_elems);
+    if (cfg->zk || cfg->mmcs_salt_elems) {
+      // the key the context draws its masks (and the salts of a hiding MMCS) with (zk_rand.h): the caller's, mixed with 128 bits of operating-system
       // entropy unless reproducible proofs were asked for
       uint32_t entropy[4] = {0, 0, 0, 0};
       const bool deterministic = cfg->ext_choices & P3R_EXT_ZK_DETERMINISTIC;

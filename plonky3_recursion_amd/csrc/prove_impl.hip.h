@@ -77,11 +77,55 @@ std::vector<uint32_t> download_cap_mont(p3r_ctx* ctx, const p3r_tree* tree) {
   return cap;
 }
 
+// The context's generator key with a proof's nonce (zk_rand.h).
+inline ZkKey zk_key_of(const p3r_ctx* ctx, uint64_t nonce) {
+  ZkKey k{};
+  for (int i = 0; i < 8; ++i) k.k[i] = ctx->zk_key[i];
+  k.nonce_lo = (uint32_t)nonce; k.nonce_hi = (uint32_t)(nonce >> 32);
+  return k;
+}
+
+// Salt matrices of a hiding MMCS for the matrices of one batch (commit order): h x S each, one launch.
+template <class PP>
+std::vector<std::unique_ptr<p3r_dmat>> draw_salts(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats, int salt_round, const ZkKey& key) {
+  const uint32_t S = ctx->cfg.mmcs_salt_elems;
+  std::vector<std::unique_ptr<p3r_dmat>> out;
+  std::vector<ZkSaltJob> jobs;
+  uint64_t blocks = 0;
+  for (size_t i = 0; i < mats.size(); ++i) {
+    out.push_back(dmat_alloc(mats[i]->h, S));
+    ZkSaltJob j{};
+    j.dst = out.back()->d; j.h = mats[i]->h; j.S = S; j.stride = 1;
+    j.stream = zk_stream_id(salt_round, i);
+    j.block0 = (uint32_t)blocks;
+    blocks += (uint64_t)S * ((j.h + kBlock - 1) / kBlock);
+    jobs.push_back(j);
+  }
+  if (blocks >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "salt launch of %llu tiles", (unsigned long long)blocks);
+  DevBuf d_jobs((jobs.size() * sizeof(ZkSaltJob) + 3) / 4);
+  P3R_HIP(ctx->stage.upload(ctx->stream, d_jobs.p, jobs.data(), jobs.size() * sizeof(ZkSaltJob)));
+  ProfScope ps(ctx, "mmcs_salts");
+  hipLaunchKernelGGL(k_zk_salts<PP>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, reinterpret_cast<const ZkSaltJob*>(d_jobs.p),
+                     (int)jobs.size(), key);
+  P3R_HIP(hipGetLastError());
+  return out;
+}
+
+// `salt_round` >= 0 under a hiding MMCS (p3r_config.mmcs_salt_elems > 0): the stream round of this batch's salts.
 template <class PP>
 std::unique_ptr<p3r_tree> commit_dmats(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats,
-                                       std::vector<uint32_t>& cap_mont, std::map<size_t, DevBuf>* pre = nullptr) {
+                                       std::vector<uint32_t>& cap_mont, std::map<size_t, DevBuf>* pre = nullptr,
+                                       int salt_round = -1, const ZkKey* key = nullptr) {
   auto tree = std::make_unique<p3r_tree>();
   tree->mats = mats;
+  if (ctx->cfg.mmcs_salt_elems) {
+    if (salt_round < 0 || !key) fail(P3R_EHIP, "internal: a commit without its salt stream under a hiding MMCS");
+    if (pre && !pre->empty()) fail(P3R_EHIP, "internal: pre-hashed classes under a hiding MMCS");
+    tree->salt_elems = (int)ctx->cfg.mmcs_salt_elems;
+    tree->salt_owned = draw_salts<PP>(ctx, mats, salt_round, *key);
+    tree->mats.clear();
+    for (size_t i = 0; i < mats.size(); ++i) { tree->mats.push_back(mats[i]); tree->mats.push_back(tree->salt_owned[i].get()); }
+  }
   std::vector<uint32_t> cap_canon((size_t)P2_DIGEST << ctx->cfg.cap_height);
   mmcs_commit<PP>(ctx, tree.get(), cap_canon.data(), pre);
   cap_mont.resize(cap_canon.size());
@@ -99,7 +143,8 @@ std::unique_ptr<p3r_tree> commit_dmats(p3r_ctx* ctx, const std::vector<const p3r
 // (tests/test_gpu_cpp_host.py::test_two_stream_commit_gives_the_same_proof).
 template <class PP>
 std::unique_ptr<p3r_tree> lde_and_commit(p3r_ctx* ctx, const std::vector<LdeItem>& items, int log_blowup,
-                                         std::vector<std::unique_ptr<p3r_dmat>>& ldes, std::vector<uint32_t>& cap_mont) {
+                                         std::vector<std::unique_ptr<p3r_dmat>>& ldes, std::vector<uint32_t>& cap_mont,
+                                         int salt_round = -1, const ZkKey* key = nullptr) {
   // (read per call, not once: tools/ab_commit_overlap.py alternates the forms proof by proof inside one process)
   const bool off = tuning_knob("P3R_COMMIT_OVERLAP") == nullptr;
   // A/B forms (knobs build): 1 = the same split of the LDE and of the hash launch on ONE stream (what the split costs by
@@ -117,7 +162,7 @@ std::unique_ptr<p3r_tree> lde_and_commit(p3r_ctx* ctx, const std::vector<LdeItem
     if (kv.second > best) { best = kv.second; pick = kv.first; }
     total_cells += cells[kv.first];
   }
-  const bool overlap = !off && !ctx->prof_enabled && ctx->cfg.mmcs_arity != 4 && perms.size() >= 2 &&
+  const bool overlap = !off && !ctx->prof_enabled && ctx->cfg.mmcs_arity != 4 && !ctx->cfg.mmcs_salt_elems && perms.size() >= 2 &&
                        total_cells - cells[pick] >= (uint64_t(1) << 22) && best >= (uint64_t(1) << 20);
   ldes.clear();
   ldes.resize(items.size());
@@ -125,7 +170,7 @@ std::unique_ptr<p3r_tree> lde_and_commit(p3r_ctx* ctx, const std::vector<LdeItem
   if (!overlap) {
     auto out = coset_lde_batch<PP>(ctx, items, log_blowup);
     for (size_t i = 0; i < items.size(); ++i) { ldes[i] = std::move(out[i]); ptrs[i] = ldes[i].get(); }
-    return commit_dmats<PP>(ctx, ptrs, cap_mont);
+    return commit_dmats<PP>(ctx, ptrs, cap_mont, nullptr, salt_round, key);
   }
   std::vector<LdeItem> first, rest;
   std::vector<size_t> first_at, rest_at;
@@ -292,7 +337,11 @@ std::unique_ptr<p3r_prep> prep_create(p3r_ctx* ctx, const p3r_air_desc* airs, co
   prep->ldes = coset_lde_batch<PP>(ctx, items, (int)ctx->cfg.log_blowup);
   for (auto& l : prep->ldes) ptrs.push_back(l.get());
   std::vector<uint32_t> cap_mont;
-  prep->tree = commit_dmats<PP>(ctx, ptrs, cap_mont);
+  {
+    // a hiding MMCS salts the preprocessed commitment too; it is made once per circuit: the nonce of `proof 0`
+    const ZkKey prep_key = zk_key_of(ctx, 0);
+    prep->tree = commit_dmats<PP>(ctx, ptrs, cap_mont, nullptr, kSaltRound + ZK_ROUND_PREP, &prep_key);
+  }
   prep->cap_canonical.resize(cap_mont.size());
   for (size_t i = 0; i < cap_mont.size(); ++i) prep->cap_canonical[i] = F::raw(cap_mont[i]).to_canonical();
   return prep;
@@ -317,7 +366,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   // codeword columns; `nonce` keys this proof's random values (zk_rand.h)
   const int zk = cfg.zk ? 1 : 0, R = zk_codewords(cfg);
   if (prep->zk_codewords != R) fail(P3R_EINVAL, "the preprocessed data was committed under another ZK setting");
-  const uint64_t nonce = zk ? ctx->zk_nonce++ : 0;
+  const uint64_t nonce = (zk || cfg.mmcs_salt_elems) ? ctx->zk_nonce++ : 0;   // (the salts of a hiding MMCS are per proof too)
   ZkKey zk_key{};
   for (int i = 0; i < 8; ++i) zk_key.k[i] = ctx->zk_key[i];
   zk_key.nonce_lo = (uint32_t)nonce; zk_key.nonce_hi = (uint32_t)(nonce >> 32);
@@ -360,7 +409,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::vector<std::unique_ptr<p3r_dmat>> main_lde;
   std::vector<const p3r_dmat*> ptrs;
   std::vector<uint32_t> main_cap, perm_cap, quot_cap, rand_cap;
-  auto main_tree = lde_and_commit<PP>(ctx, lde_items, log_blowup, main_lde, main_cap);
+  auto main_tree = lde_and_commit<PP>(ctx, lde_items, log_blowup, main_lde, main_cap, kSaltRound + ZK_ROUND_MAIN, &zk_key);
 
   prof_stage(ctx, "transcript_head");
   // ---- 2. transcript head
@@ -456,7 +505,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     lde_items.clear();
     for (int i : perm_insts) lde_items.push_back({aux_ev[i], PP::GEN});
     std::vector<std::unique_ptr<p3r_dmat>> ldes;
-    perm_tree = lde_and_commit<PP>(ctx, lde_items, log_blowup, ldes, perm_cap);
+    perm_tree = lde_and_commit<PP>(ctx, lde_items, log_blowup, ldes, perm_cap, kSaltRound + ZK_ROUND_PERM, &zk_key);
     for (size_t k = 0; k < perm_insts.size(); ++k) aux_lde[perm_insts[k]] = std::move(ldes[k]);
     {
       // every table's global sum in one transfer
@@ -622,7 +671,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   }
   ptrs.clear();
   for (auto& ck : chunks) ptrs.push_back(ck.lde.get());
-  auto quot_tree = commit_dmats<PP>(ctx, ptrs, quot_cap);
+  auto quot_tree = commit_dmats<PP>(ctx, ptrs, quot_cap, nullptr, kSaltRound + ZK_ROUND_QUOTIENT, &zk_key);
   for (uint32_t v : quot_cap) ch.observe(F::raw(v));
   // ZK: the random round - per instance a fully random matrix of Challenge::DIMENSION (+ R) columns over the extended
   // trace domain, opened at zeta; its commitment is observed after the quotient's (batch_stark.rs:623-625)
@@ -639,7 +688,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     rand_lde = coset_lde_batch<PP>(ctx, lde_items, log_blowup);
     ptrs.clear();
     for (auto& m : rand_lde) ptrs.push_back(m.get());
-    rand_tree = commit_dmats<PP>(ctx, ptrs, rand_cap);
+    rand_tree = commit_dmats<PP>(ctx, ptrs, rand_cap, nullptr, kSaltRound + ZK_ROUND_RANDOM, &zk_key);
     for (uint32_t v : rand_cap) ch.observe(F::raw(v));
   }
   const E zeta = ch.sample_ext();
@@ -903,6 +952,27 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       std::vector<const uint32_t*> cols;
       for (size_t j = 0; j < arity; ++j)
         for (int k = 0; k < DC; ++k) cols.push_back(folded.p + (size_t)k * n_in + j);
+      if (cfg.mmcs_salt_elems) {
+        // ExtensionMmcs over a hiding MMCS: the flattened row, then its salt (recursion/src/pcs/mmcs.rs:470-486).  The salt
+        // columns take the leaf kernels' strided layout: column c of row r at [c * n_in + r * arity]
+        const uint32_t S = cfg.mmcs_salt_elems;
+        p3r_tree& T = *ph.tree;
+        T.salt_elems = (int)S; T.phase_salt_stride = arity; T.phase_rows = rows;
+        T.phase_salts.alloc((size_t)S * n_in);
+        ZkSaltJob j{};
+        j.dst = T.phase_salts.p; j.h = rows; j.S = S; j.stride = (uint32_t)arity;
+        j.stream = zk_stream_id(kSaltRoundFri, phases.size());
+        j.block0 = 0;
+        DevBuf d_job((sizeof(ZkSaltJob) + 3) / 4);
+        P3R_HIP(ctx->stage.upload(ctx->stream, d_job.p, &j, sizeof j));
+        {
+          ProfScope ps(ctx, "mmcs_salts");
+          hipLaunchKernelGGL(k_zk_salts<PP>, dim3((unsigned)(S * ((rows + kBlock - 1) / kBlock))), dim3(kBlock), 0, ctx->stream,
+                             reinterpret_cast<const ZkSaltJob*>(d_job.p), 1, zk_key);
+        }
+        P3R_HIP(hipGetLastError());
+        for (uint32_t c = 0; c < S; ++c) cols.push_back(T.phase_salts.p + (size_t)c * n_in);
+      }
       const uint32_t* const* dcols = col_table(ctx, cols);
       if (arity4) {
         // ExtensionMmcs over the arity-4 MMCS: the same flattened rows under the width-32 sponge
@@ -1047,7 +1117,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
     const p3r_tree* t = nullptr;
   };
   struct QRound { std::vector<std::pair<uint32_t, uint32_t>> rows; QPath path; uint32_t tree_shift; };
-  struct QPhase { uint32_t sib_at[8]; QPath path; int shift; };
+  struct QPhase { uint32_t sib_at[8]; QPath path; int shift; uint32_t salt_at = 0; };
   // `base_shift`: the tree's index = query index >> base_shift
   auto push_path = [&](const p3r_tree* t, uint32_t base_shift) {
     QPath qp;
@@ -1090,6 +1160,8 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       // sibling j of the row: the DC planes of one extension element, at row * arity + j
       for (size_t j = 0; j < arity; ++j)
         qp.sib_at[j] = push(ph.folded_in.p + j, n_in, DC, (uint32_t)(shift + ph.la), 0, (uint32_t)arity);
+      if (ph.tree->salt_elems)   // the salt of the opened row (strided layout: fri commit phase above)
+        qp.salt_at = push(ph.tree->phase_salts.p, n_in, (uint32_t)ph.tree->salt_elems, (uint32_t)(shift + ph.la), 0, (uint32_t)arity);
       qp.path = push_path(ph.tree.get(), (uint32_t)(shift + ph.la));
       qphases.push_back(std::move(qp));
       shift += ph.la;
@@ -1162,10 +1234,20 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
       const uint32_t* g = gathered + (size_t)qi * words_per_query;  // this query's answers
       W.varint(qrounds.size());
       for (auto& qr : qrounds) {
-        W.varint(qr.rows.size());
-        for (auto& rw : qr.rows) {
-          W.varint(rw.second);
-          W.words(g + rw.first, rw.second);
+        // a hiding MMCS's tree lists [M0, S0, M1, S1, ..]: opened values are the rows of the even entries, and the opening
+        // proof is the tuple (salts = rows of the odd entries, siblings) (SaltedMmcsProof, mmcs.rs:763-768)
+        const size_t step = qr.path.t->salt_elems ? 2 : 1;
+        W.varint(qr.rows.size() / step);
+        for (size_t k = 0; k < qr.rows.size(); k += step) {
+          W.varint(qr.rows[k].second);
+          W.words(g + qr.rows[k].first, qr.rows[k].second);
+        }
+        if (step == 2) {
+          W.varint(qr.rows.size() / 2);
+          for (size_t k = 1; k < qr.rows.size(); k += 2) {
+            W.varint(qr.rows[k].second);
+            W.words(g + qr.rows[k].first, qr.rows[k].second);
+          }
         }
         write_path(qr.path, g, indices[qi] >> qr.tree_shift);
       }
@@ -1178,6 +1260,11 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         W.varint(arity - 1);
         for (size_t j = 0; j < arity; ++j)
           if (j != pos) W.words(g + qp.sib_at[j], DC);
+        if (qp.path.t->salt_elems) {   // (salts of the phase's one matrix, siblings)
+          W.varint(1);
+          W.varint((size_t)qp.path.t->salt_elems);
+          W.words(g + qp.salt_at, (size_t)qp.path.t->salt_elems);
+        }
         write_path(qp.path, g, indices[qi] >> (qp.shift + phases[p].la));
       }
     }

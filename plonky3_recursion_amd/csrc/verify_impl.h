@@ -115,8 +115,10 @@ struct ParsedProof {
   std::vector<Inst> insts;
   std::vector<Cap> commit_caps;
   std::vector<F> commit_pow;
-  struct QRound { std::vector<std::vector<F>> rows; std::vector<Digest> path; };
-  struct QPhase { int la; std::vector<E> sibs; std::vector<Digest> path; };
+  // `salts`: MerkleTreeHidingMmcs - the opening proof is the tuple (per-matrix salts, sibling digests)
+  // (SaltedMmcsProof, recursion/src/pcs/mmcs.rs:763-768); empty under the plain MMCS
+  struct QRound { std::vector<std::vector<F>> rows; std::vector<Digest> path; std::vector<std::vector<F>> salts; };
+  struct QPhase { int la; std::vector<E> sibs; std::vector<Digest> path; std::vector<std::vector<F>> salts; };
   struct Query { std::vector<QRound> rounds; std::vector<QPhase> phases; };
   std::vector<Query> queries;
   std::vector<E> final_poly;
@@ -129,8 +131,9 @@ struct ParsedProof {
 // (the outer BatchStarkProof appends its metadata after it, batch_stark_prover.rs:610-636).
 template <class PP, int DC = 4>
 // `zk`: the proof type is the hiding PCS's - a property of the configuration (SC::Pcs in the reference), not of the bytes.
+// `salted`: the MMCSs are hiding ones (p3r_config.mmcs_salt_elems > 0): every opening proof carries its salts first.
 ParsedProof<PP, DC> parse_proof(const uint8_t* bytes, size_t n, bool canonical, size_t* consumed = nullptr,
-                            const ProofLayout& PL = ProofLayout{}, bool zk = false) {
+                            const ProofLayout& PL = ProofLayout{}, bool zk = false, bool salted = false) {
   ProofReader<PP, DC> R{bytes, bytes + n, canonical};
   ParsedProof<PP, DC> P;
   auto read_commitments = [&] {
@@ -169,6 +172,10 @@ ParsedProof<PP, DC> parse_proof(const uint8_t* bytes, size_t n, bool canonical, 
           row.resize(R.len(1u << 16));
           for (auto& x : row) x = R.fe();
         }
+        if (salted) {
+          r.salts.resize(R.len(256));
+          for (auto& sl : r.salts) { sl.resize(R.len(64)); for (auto& x : sl) x = R.fe(); }
+        }
         r.path.resize(R.len(64));
         for (auto& d : r.path) d = R.digest();
       }
@@ -177,6 +184,10 @@ ParsedProof<PP, DC> parse_proof(const uint8_t* bytes, size_t n, bool canonical, 
         ph.la = R.byte();
         ph.sibs.resize(R.len(16));
         for (auto& e : ph.sibs) e = R.ef();
+        if (salted) {
+          ph.salts.resize(R.len(4));
+          for (auto& sl : ph.salts) { sl.resize(R.len(64)); for (auto& x : sl) x = R.fe(); }
+        }
         ph.path.resize(R.len(64));
         for (auto& d : ph.path) d = R.digest();
       }
@@ -320,7 +331,7 @@ struct ProofSkimmer {
 
 // Same grammar as parse_proof; returns the length of the BatchProof at the head of `bytes`.
 template <class PP>
-size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofLayout{}, int dc = 4, bool zk = false) {
+size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofLayout{}, int dc = 4, bool zk = false, bool salted = false) {
   ProofSkimmer<PP> R{bytes, bytes + n};
   R.dc = dc;
   auto opened = [&] {
@@ -345,12 +356,14 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
       for (size_t r = 0; r < nr; ++r) {
         const size_t rows = R.len(256);
         for (size_t k = 0; k < rows; ++k) R.fes(R.len(1u << 16));
+        if (salted) { const size_t ns = R.len(256); for (size_t k = 0; k < ns; ++k) R.fes(R.len(64)); }
         R.fes(P2_DIGEST * R.len(64));
       }
       const size_t nph = R.len(64);
       for (size_t k = 0; k < nph; ++k) {
         (void)R.byte();
         R.fes((size_t)dc * R.len(16));
+        if (salted) { const size_t ns = R.len(4); for (size_t k = 0; k < ns; ++k) R.fes(R.len(64)); }
         R.fes(P2_DIGEST * R.len(64));
       }
     }
@@ -396,9 +409,9 @@ size_t skim_proof(const uint8_t* bytes, size_t n, const ProofLayout& PL = ProofL
 // The metadata fields that follow the inner BatchProof (BatchStarkProof, batch_stark_prover.rs:610-636).
 template <class PP>
 void parse_batch_stark_meta(const uint8_t* bytes, size_t len, bool canonical, const ProofLayout& PL, int dc,
-                            p3r_batch_stark_meta* M, bool zk = false) {
+                            p3r_batch_stark_meta* M, bool zk = false, bool salted = false) {
   std::memset(M, 0, sizeof *M);
-  M->proof_len = skim_proof<PP>(bytes, len, PL, dc, zk);
+  M->proof_len = skim_proof<PP>(bytes, len, PL, dc, zk, salted);
   ProofSkimmer<PP> R{bytes + M->proof_len, bytes + len};
   auto u32 = [&](const char* what) {
     const uint64_t v = R.varint();
@@ -810,7 +823,27 @@ struct VerifyParams {
   int mmcs_arity = 2;                    // 4: the arity-4 MMCS over the width-32 permutation (p3r_config.mmcs_arity)
   int zk = 0;                            // HidingFriPcs (p3r_config.zk)
   int num_random_codewords = 0;          // random codeword columns per committed matrix (p3r_config.num_random_codewords)
+  int mmcs_salt_elems = 0;               // MerkleTreeHidingMmcs: salt elements per committed row (p3r_config.mmcs_salt_elems)
 };
+
+// MerkleTreeHidingMmcs::verify_batch through the plain walk: the leaf preimage of a height class is the concatenation of
+// [row | salt] per matrix (recursion/src/pcs/mmcs.rs:375-389 for base rows, :470-486 for flattened extension rows), i.e.
+// the plain preimage of the matrices widened by their salts.
+template <class F>
+std::vector<std::vector<F>> salted_rows(const std::vector<std::vector<F>>& rows, const std::vector<std::vector<F>>& salts, int salt_elems,
+                                        const char* what) {
+  if (!salt_elems) {
+    if (!salts.empty()) vfail("%s: salts under a non-hiding MMCS", what);
+    return rows;
+  }
+  if (salts.size() != rows.size()) vfail("%s: %zu salts for %zu matrices", what, salts.size(), rows.size());
+  std::vector<std::vector<F>> out(rows);
+  for (size_t m = 0; m < rows.size(); ++m) {
+    if ((int)salts[m].size() != salt_elems) vfail("%s: a salt of %zu elements, expected %d", what, salts[m].size(), salt_elems);
+    out[m].insert(out[m].end(), salts[m].begin(), salts[m].end());
+  }
+  return out;
+}
 
 template <class PP, int DC = 4>
 void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canonical, const std::vector<AirParams>& airs,
@@ -821,7 +854,8 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
   using Digest = std::array<F, P2_DIGEST>;
   const int zk = prm.zk ? 1 : 0, R = zk ? prm.num_random_codewords : 0;
   if (zk && (R < 1 || R > 8)) vfail("num_random_codewords must be in 1..8");
-  const ParsedProof<PP, DC> P = parse_proof<PP, DC>(bytes, n_bytes, canonical, nullptr, prm.layout, zk != 0);
+  if (prm.mmcs_salt_elems < 0 || prm.mmcs_salt_elems > 16) vfail("mmcs_salt_elems must be in 0..16");
+  const ParsedProof<PP, DC> P = parse_proof<PP, DC>(bytes, n_bytes, canonical, nullptr, prm.layout, zk != 0, prm.mmcs_salt_elems != 0);
   const size_t ni = airs.size();
   // the width-16 round constants, followed by the width-32 table (poseidon2.h; csrc/p3r_core.hip::constants_table)
   if (rc_canonical.size() != (size_t)p2_num_constants<PP>() + (size_t)p2w_num_constants<PP>()) vfail("wrong number of permutation constants");
@@ -1027,8 +1061,9 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
       if (qr.rows.size() != rounds[r].size()) vfail("query %zu: batch %zu opens %zu matrices, expected %zu", qi, r, qr.rows.size(), rounds[r].size());
       for (size_t m = 0; m < rounds[r].size(); ++m)
         if (qr.rows[m].size() != (size_t)rounds[r][m].w) vfail("query %zu: batch %zu matrix %zu has the wrong width", qi, r, m);
-      if (prm.mmcs_arity == 4) mmcs_verify4<PP>(*round_caps[r], cap_h, lhs, qr.rows, index >> (log_max - r_max), qr.path, rc.data() + p2_num_constants<PP>(), "input batch");
-      else mmcs_verify<PP>(*round_caps[r], cap_h, lhs, qr.rows, index >> (log_max - r_max), qr.path, rc.data(), "input batch");
+      const auto leaf_rows = salted_rows<F>(qr.rows, qr.salts, prm.mmcs_salt_elems, "input batch");
+      if (prm.mmcs_arity == 4) mmcs_verify4<PP>(*round_caps[r], cap_h, lhs, leaf_rows, index >> (log_max - r_max), qr.path, rc.data() + p2_num_constants<PP>(), "input batch");
+      else mmcs_verify<PP>(*round_caps[r], cap_h, lhs, leaf_rows, index >> (log_max - r_max), qr.path, rc.data(), "input batch");
       for (size_t m = 0; m < rounds[r].size(); ++m) {
         const Mat& M = rounds[r][m];
         auto it = ro.find(M.log_h);
@@ -1062,8 +1097,9 @@ void verify_batch(const VerifyParams& prm, const std::vector<uint32_t>& rc_canon
       // the leaf is the row of 2^la sibling evaluations, extension elements flattened
       std::vector<F> leaf;
       for (auto& x : e) for (int k = 0; k < DC; ++k) leaf.push_back(x.c[k]);
-      if (prm.mmcs_arity == 4) mmcs_verify4<PP>(P.commit_caps[p], cap_h, {cur - la}, {leaf}, row, ph.path, rc.data() + p2_num_constants<PP>(), "FRI commit phase");
-      else mmcs_verify<PP>(P.commit_caps[p], cap_h, {cur - la}, {leaf}, row, ph.path, rc.data(), "FRI commit phase");
+      const auto leaf_rows = salted_rows<F>({leaf}, ph.salts, prm.mmcs_salt_elems, "FRI commit phase");
+      if (prm.mmcs_arity == 4) mmcs_verify4<PP>(P.commit_caps[p], cap_h, {cur - la}, leaf_rows, row, ph.path, rc.data() + p2_num_constants<PP>(), "FRI commit phase");
+      else mmcs_verify<PP>(P.commit_caps[p], cap_h, {cur - la}, leaf_rows, row, ph.path, rc.data(), "FRI commit phase");
       F ss_inv = F::two_adic_generator(cur).inv().pow(bit_reverse((uint32_t)row, cur - la));
       E b = betas[p];
       const F omega = F::two_adic_generator(la);

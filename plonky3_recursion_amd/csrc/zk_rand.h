@@ -23,6 +23,9 @@
 namespace p3r {
 
 enum { ZK_ROUND_RANDOM = 0, ZK_ROUND_MAIN = 1, ZK_ROUND_QUOTIENT = 2, ZK_ROUND_PREP = 3, ZK_ROUND_PERM = 4, ZK_ROUND_QMASK = 5 };
+// salts of a hiding MMCS (p3r_config.mmcs_salt_elems): stream round kSaltRound + the round of the committed batch, matrix =
+// its position in the batch; kSaltRoundFri for the FRI commit-phase trees (matrix = phase)
+constexpr int kSaltRound = 8, kSaltRoundFri = 14;
 
 // what a kernel needs besides the stream id: the context's key and the proof's nonce (passed by value)
 struct ZkKey {

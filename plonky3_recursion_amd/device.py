@@ -39,7 +39,7 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
                 commit_pow_bits=0, query_pow_bits=15, num_queries=54, device=0, poseidon2_rc=None, ext_choices=0,
                 fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0, challenge_degree=4,
                 poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2, zk=0, num_random_codewords=2, zk_seed=None,
-                zk_key=None, zk_deterministic=None, allow_unpinned_w32_defaults=False):
+                zk_key=None, zk_deterministic=None, allow_unpinned_w32_defaults=False, mmcs_salt_elems=0):
     """A `p3r_config` (+ the arrays it points into, which must stay alive with it).  `ext_choices` /
     `fri_log_arities`: the selectable protocol details of include/p3r.h.
     `ext_degree`: the circuit extension degree D of the traces - 4, or 5 for KoalaBear circuits over the quintic
@@ -56,6 +56,7 @@ def make_config(field="koala-bear", log_blowup=2, max_log_arity=2, cap_height=0,
     # entropy into it unless `zk_deterministic`.  `zk_seed` is the test harness's shorthand: key = (seed, 0, ..) taken
     # as it is - reproducible proofs, which is what a comparison with the CPU oracle needs and a deployment must not use.
     cfg.zk, cfg.num_random_codewords = int(zk), int(num_random_codewords) if zk else 0
+    cfg.mmcs_salt_elems = int(mmcs_salt_elems)   # MerkleTreeHidingMmcs (recursion/tests/zk_hiding_mmcs.rs: 4); 0 = plain
     if zk_seed is not None and zk_key is not None:
         raise P3rError(-1, "pass zk_key or zk_seed, not both")
     if zk_seed is not None:
@@ -138,9 +139,10 @@ def verify_batch(cfg, airs, preprocessed_commitment, degree_bits, proof: bytes, 
         raise P3rError(rc, err.value.decode())
 
 
-def mmcs_verify(cfg, cap, dims, index, opened_values, proof):
+def mmcs_verify(cfg, cap, dims, index, opened_values, proof, salts=None):
     """`Mmcs::verify_batch` on the host (p3r_mmcs_verify; no GPU): `dims` = (height, width) of the committed matrices in
     commit order, `opened_values` their opened rows concatenated, `proof` the sibling digests.  Honours cfg.mmcs_arity.
+    `salts` (n_mats x cfg.mmcs_salt_elems): the hiding MMCS's opening (p3r_mmcs_verify_salted).
     Raises P3rError with the reason when the opening is rejected."""
     lib = _lib.load()
     c, cp = _u32(cap)
@@ -150,7 +152,13 @@ def mmcs_verify(cfg, cap, dims, index, opened_values, proof):
     hs = (C.c_size_t * n)(*[int(d[0]) for d in dims])
     ws = (C.c_size_t * n)(*[int(d[1]) for d in dims])
     err = C.create_string_buffer(512)
-    rc = lib.p3r_mmcs_verify(C.byref(cfg), cp, n, hs, ws, int(index), op, pp, pf.shape[0], err, len(err))
+    if salts is not None:
+        sl, sp = _u32(np.asarray(salts, dtype=np.uint32).reshape(-1))
+        if sl.size != n * cfg.mmcs_salt_elems:
+            raise P3rError(-1, "salts must hold %d x %d values" % (n, cfg.mmcs_salt_elems))
+        rc = lib.p3r_mmcs_verify_salted(C.byref(cfg), cp, n, hs, ws, int(index), op, sp, pp, pf.shape[0], err, len(err))
+    else:
+        rc = lib.p3r_mmcs_verify(C.byref(cfg), cp, n, hs, ws, int(index), op, pp, pf.shape[0], err, len(err))
     if rc != 0:
         raise P3rError(rc, err.value.decode())
 
@@ -162,7 +170,8 @@ class Context:
                  log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
                  device=0, poseidon2_rc=None, ext_choices=0, fri_log_arities=None, proof_layout=None, ext_degree=4, ext_w=0,
                  challenge_degree=4, poseidon2_w32_rc=None, poseidon2_w32_diag=None, mmcs_arity=2, zk=0,
-                 num_random_codewords=2, zk_seed=None, zk_key=None, zk_deterministic=None, allow_unpinned_w32_defaults=False):
+                 num_random_codewords=2, zk_seed=None, zk_key=None, zk_deterministic=None, allow_unpinned_w32_defaults=False,
+                 mmcs_salt_elems=0):
         self.lib = _lib.load()
         self.mmcs_arity = mmcs_arity
         self.zk = int(zk)
@@ -175,7 +184,7 @@ class Context:
                                          commit_pow_bits, query_pow_bits, num_queries, device, poseidon2_rc, ext_choices,
                                          fri_log_arities, proof_layout, ext_degree, ext_w, challenge_degree,
                                          poseidon2_w32_rc, poseidon2_w32_diag, mmcs_arity, zk, num_random_codewords, zk_seed,
-                                         zk_key, zk_deterministic, allow_unpinned_w32_defaults)
+                                         zk_key, zk_deterministic, allow_unpinned_w32_defaults, mmcs_salt_elems)
         self.cfg = cfg
         self.cap_height = cap_height
         self.log_blowup = log_blowup

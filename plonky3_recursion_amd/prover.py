@@ -402,20 +402,21 @@ class BatchStarkProof:
 
     @classmethod
     def from_postcard(cls, data: bytes, field: str, canonical_field_encoding=False, proof_layout=None,
-                      challenge_degree=4, zk=False) -> "BatchStarkProof":
+                      challenge_degree=4, zk=False, salted=False) -> "BatchStarkProof":
         """Inverse of `to_postcard`: one pass of the C-ABI parser (p3r_batch_stark_proof_parse: framing of the
         inner `BatchProof`, the metadata that follows it, and the `validate()` rules) - a parent node of the
         aggregation tree runs this on each child, so it is native host code, not a Python loop.
         `proof_layout`: the 18 bytes of `p3r_config.proof_layout` when the proof was written with one.
         `challenge_degree`: 5 for a proof over KoalaBear's quintic challenge field (five words per extension
         element; P3R_PROOF_QUINTIC_CHALLENGE).  `zk`: the proof is a hiding PCS's (p3r_config.zk; P3R_PROOF_ZK) - its
-        opening proof is the tuple (random opened values, FriProof), which the bytes do not announce."""
+        opening proof is the tuple (random opened values, FriProof), which the bytes do not announce.  `salted`: the MMCSs are
+        hiding ones (p3r_config.mmcs_salt_elems > 0; P3R_PROOF_SALTED): every MMCS opening proof is (salts, siblings)."""
         from .device import FIELD_IDS, MODULUS
         lib = _lib.load()
         m, err = _lib.P3rBatchStarkMeta(), C.create_string_buffer(256)
         lay = None if proof_layout is None else (C.c_uint8 * 18)(*[int(v) for v in proof_layout])
         data = bytes(data)
-        flags = (1 if canonical_field_encoding else 0) | (2 if challenge_degree == 5 else 0) | (4 if zk else 0)
+        flags = (1 if canonical_field_encoding else 0) | (2 if challenge_degree == 5 else 0) | (4 if zk else 0) | (8 if salted else 0)
         rc = lib.p3r_batch_stark_proof_parse(FIELD_IDS[field], data, len(data), flags, lay, C.byref(m), err, len(err))
         if rc != 0:
             raise P3rError(rc, err.value.decode())

@@ -39,12 +39,15 @@ class OrcParams(C.Structure):
                                                                    ("zk", C.c_uint32), ("num_random_codewords", C.c_uint32),
                                                                    ("zk_key", C.c_uint32 * 8), ("zk_nonce", C.c_uint64),
                                                                    # forced proof-of-work witnesses (tools/resolve_pins.py)
-                                                                   ("n_forced_pow", C.c_uint32), ("forced_pow", C.c_uint32 * 40)]
+                                                                   ("n_forced_pow", C.c_uint32), ("forced_pow", C.c_uint32 * 40),
+                                                                   # MerkleTreeHidingMmcs: salt elements per committed row (0: plain MMCS)
+                                                                   ("mmcs_salt_elems", C.c_uint32)]
 
 
 def params(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0,
            query_pow_bits=15, num_queries=54, ext_choices=0, fri_log_arities=None, proof_layout=None, challenge_degree=4,
-           mmcs_arity=2, zk=0, num_random_codewords=2, zk_seed=0, zk_nonce=0, forced_pow=None, zk_key=None):
+           mmcs_arity=2, zk=0, num_random_codewords=2, zk_seed=0, zk_nonce=0, forced_pow=None, zk_key=None,
+           mmcs_salt_elems=0):
     p = OrcParams(log_blowup, max_log_arity, cap_height, log_final_poly_len, commit_pow_bits, query_pow_bits,
                   num_queries, ext_choices, 0)
     p.challenge_degree = challenge_degree
@@ -53,6 +56,7 @@ def params(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, co
     # zk_nonce = proofs already made under the configuration (its RNG state)
     # zk_seed: the harness's shorthand for the key (seed, 0, ..) - the same mapping as plonky3_recursion_amd.make_config
     p.zk, p.num_random_codewords, p.zk_nonce = zk, num_random_codewords, zk_nonce
+    p.mmcs_salt_elems = mmcs_salt_elems
     key = list(zk_key) if zk_key is not None else [int(zk_seed) & 0xFFFFFFFF, (int(zk_seed) >> 32) & 0xFFFFFFFF, 0, 0, 0, 0, 0, 0]
     for i in range(8):
         p.zk_key[i] = int(key[i])

@@ -39,7 +39,9 @@ def _varint(v):
     return bytes(out)
 
 
-def decode(data, dc=4, zk=False):
+def decode(data, dc=4, zk=False, salted=False):
+    """`salted`: the MMCSs are hiding ones - every MMCS opening proof is the tuple (salts: Vec<Vec<F>>, siblings)
+    (SaltedMmcsProof, recursion/src/pcs/mmcs.rs:763-768); decoded as `salts` next to `opening_proof`."""
     r = Reader(bytes(data))
     fe = r.varint
     ef = lambda: [fe() for _ in range(dc)]                 # noqa: E731
@@ -57,8 +59,11 @@ def decode(data, dc=4, zk=False):
     fri["commit_phase_commits"] = r.vec(cap)
     fri["commit_pow_witnesses"] = r.vec(fe)
     fri["query_proofs"] = r.vec(lambda: dict(
-        input_proof=r.vec(lambda: dict(opened_values=r.vec(lambda: r.vec(fe)), opening_proof=r.vec(digest))),
-        commit_phase_openings=r.vec(lambda: dict(log_arity=r.byte(), sibling_values=vec_ef(), opening_proof=r.vec(digest)))))
+        input_proof=r.vec(lambda: dict(opened_values=r.vec(lambda: r.vec(fe)),
+                                       **(dict(salts=r.vec(lambda: r.vec(fe))) if salted else {}), opening_proof=r.vec(digest))),
+        commit_phase_openings=r.vec(lambda: dict(log_arity=r.byte(), sibling_values=vec_ef(),
+                                                 **(dict(salts=r.vec(lambda: r.vec(fe))) if salted else {}),
+                                                 opening_proof=r.vec(digest)))))
     fri["final_poly"] = vec_ef()
     fri["query_pow_witness"] = fe()
     p["opening_proof"] = fri
@@ -107,12 +112,16 @@ def encode(p, zk=None):
     def query(q):
         def batch(b):
             vec(b["opened_values"], lambda row: vec(row, V))
+            if "salts" in b:
+                vec(b["salts"], lambda row: vec(row, V))
             vec(b["opening_proof"], fes)
         vec(q["input_proof"], batch)
 
         def step(s):
             out.append(s["log_arity"])
             vec_ef(s["sibling_values"])
+            if "salts" in s:
+                vec(s["salts"], lambda row: vec(row, V))
             vec(s["opening_proof"], fes)
         vec(q["commit_phase_openings"], step)
     vec(f["query_proofs"], query)
