@@ -118,7 +118,7 @@ struct Tree {
   void add(int parent, int kid) { n[parent].kids.push_back(kid); }   // `kid` is evaluated by the caller BEFORE this call: pass a value, not T.leaf(..) inline with n[..]
 };
 
-int parse_outer(Tree& T, int dc, bool zk) {
+int parse_outer(Tree& T, int dc, bool zk, bool salted = false) {
   auto fe = [&] { return T.leaf(K_FE); };
   auto ef = [&] { return T.strct([&](int id) { for (int i = 0; i < dc && T.ok; ++i) T.add(id, fe()); }); };
   auto vec_ef = [&] { return T.vec(ef); };
@@ -148,8 +148,15 @@ int parse_outer(Tree& T, int dc, bool zk) {
       T.add(f, T.commit_pow);
       T.add(f, T.vec([&] {
         return T.strct([&](int q) {
-          T.add(q, T.vec([&] { return T.strct([&](int b) { T.add(b, T.vec([&] { return T.vec(fe); })); T.add(b, T.vec(digest)); }); }));
-          T.add(q, T.vec([&] { return T.strct([&](int s) { T.add(s, T.leaf(K_BYTE)); T.add(s, vec_ef()); T.add(s, T.vec(digest)); }); }));
+          // a hiding MMCS's opening proof is the tuple (salts, siblings): one more Vec<Vec<F>> in front of the digests
+          T.add(q, T.vec([&] { return T.strct([&](int b) {
+            T.add(b, T.vec([&] { return T.vec(fe); }));
+            if (salted) T.add(b, T.vec([&] { return T.vec(fe); }));
+            T.add(b, T.vec(digest)); }); }));
+          T.add(q, T.vec([&] { return T.strct([&](int s) {
+            T.add(s, T.leaf(K_BYTE)); T.add(s, vec_ef());
+            if (salted) T.add(s, T.vec([&] { return T.vec(fe); }));
+            T.add(s, T.vec(digest)); }); }));
         });
       }));
       T.add(f, vec_ef());
@@ -201,6 +208,7 @@ Case load_case(const char* path) {
   c.cfg.commit_pow_bits = in.get<uint32_t>(); c.cfg.query_pow_bits = in.get<uint32_t>(); c.cfg.num_queries = in.get<uint32_t>();
   c.cfg.challenge_degree = in.get<uint32_t>(); c.cfg.mmcs_arity = in.get<uint32_t>(); c.cfg.zk = in.get<uint32_t>();
   c.cfg.num_random_codewords = in.get<uint32_t>();
+  c.cfg.mmcs_salt_elems = in.get<uint32_t>();
   c.cfg.ext_choices = P3R_EXT_UNPINNED_W32_DEFAULTS;   // the cases are made with the library's built-in width-32 constants
   const uint32_t na = in.get<uint32_t>();
   for (uint32_t i = 0; i < na; ++i) { p3r_air_desc a{}; a.kind = in.get<uint32_t>(); a.lanes = in.get<uint32_t>(); a.horner_packed_steps = in.get<uint32_t>(); a.coeff_lookups = in.get<uint32_t>(); c.airs.push_back(a); }
@@ -210,7 +218,7 @@ Case load_case(const char* path) {
   if ((uint64_t)(in.e - in.p) < len) { fprintf(stderr, "case file truncated\n"); exit(2); }
   c.outer.assign(in.p, in.p + len);
   c.dc = c.cfg.challenge_degree == 5 ? 5 : 4;
-  c.flags = (c.dc == 5 ? P3R_PROOF_QUINTIC_CHALLENGE : 0) | (c.cfg.zk ? P3R_PROOF_ZK : 0);
+  c.flags = (c.dc == 5 ? P3R_PROOF_QUINTIC_CHALLENGE : 0) | (c.cfg.zk ? P3R_PROOF_ZK : 0) | (c.cfg.mmcs_salt_elems ? P3R_PROOF_SALTED : 0);
   return c;
 }
 
@@ -331,9 +339,9 @@ std::vector<uint8_t> mutate(const std::vector<uint8_t>& d, const Tree& T, Rng& r
 // unchanged when no proof of work is required (recursion/src/challenger/circuit.rs:409-430: "When no PoW is required, keep
 // challenger state unchanged"), so such a witness is not bound by the proof - in the reference as here.  Any other accepted
 // difference is a finding.
-bool normalised_inner(const std::vector<uint8_t>& d, int dc, bool zk, bool blank_commit, bool blank_query, std::vector<uint8_t>& out) {
+bool normalised_inner(const std::vector<uint8_t>& d, int dc, bool zk, bool salted, bool blank_commit, bool blank_query, std::vector<uint8_t>& out) {
   Tree T(d);
-  parse_outer(T, dc, zk);
+  parse_outer(T, dc, zk, salted);
   if (!T.ok || T.commit_pow < 0 || T.query_pow < 0 || T.inner_end < 0) return false;
   out.clear();
   size_t at = 0;
@@ -359,16 +367,16 @@ int run_proofs(const char* path, uint64_t iters, uint64_t seed) {
     return 1;
   }
   Tree T(c.outer);
-  parse_outer(T, c.dc, c.cfg.zk != 0);
+  parse_outer(T, c.dc, c.cfg.zk != 0, c.cfg.mmcs_salt_elems != 0);
   if (!T.ok || T.at != c.outer.size()) { fprintf(stderr, "the mutator's grammar does not cover the seed proof (%zu of %zu bytes)\n", T.at, c.outer.size()); return 1; }
   Rng r{seed};
   uint64_t parsed = 0, verified_same = 0, rejected_parse = 0, rejected_verify = 0, hpp_ok = 0, unbound_pow = 0;
   const bool blank_c = c.cfg.commit_pow_bits == 0, blank_q = c.cfg.query_pow_bits == 0;
   std::vector<uint8_t> seed_norm;
-  if (!normalised_inner(c.outer, c.dc, c.cfg.zk != 0, blank_c, blank_q, seed_norm)) { fprintf(stderr, "cannot normalise the seed proof\n"); return 1; }
+  if (!normalised_inner(c.outer, c.dc, c.cfg.zk != 0, c.cfg.mmcs_salt_elems != 0, blank_c, blank_q, seed_norm)) { fprintf(stderr, "cannot normalise the seed proof\n"); return 1; }
   for (uint64_t it = 0; it < iters; ++it) {
     std::vector<uint8_t> m = mutate(c.outer, T, r);
-    if (r.below(16) == 0) { Tree T2(m); parse_outer(T2, c.dc, c.cfg.zk != 0); if (T2.ok) m = mutate(m, T2, r); }   // two edits
+    if (r.below(16) == 0) { Tree T2(m); parse_outer(T2, c.dc, c.cfg.zk != 0, c.cfg.mmcs_salt_elems != 0); if (T2.ok) m = mutate(m, T2, r); }   // two edits
     if (m == c.outer) continue;
     // exact-size heap copy: ASan then sees any read past the end
     uint8_t* buf = (uint8_t*)malloc(m.size() ? m.size() : 1);
@@ -380,7 +388,7 @@ int run_proofs(const char* path, uint64_t iters, uint64_t seed) {
     ++parsed;
     // the C++ mirror (include/p3r.hpp): parse -> object -> bytes must reproduce what was parsed
     try {
-      auto p = p3r::BatchStarkProof::from_postcard(std::vector<uint8_t>(buf, buf + m.size()), (p3r::Field)c.cfg.field, true, (uint32_t)c.dc, c.cfg.zk != 0);
+      auto p = p3r::BatchStarkProof::from_postcard(std::vector<uint8_t>(buf, buf + m.size()), (p3r::Field)c.cfg.field, true, (uint32_t)c.dc, c.cfg.zk != 0, c.cfg.mmcs_salt_elems != 0);
       (void)p.airs();
       ++hpp_ok;
     } catch (const std::exception&) {}
@@ -392,7 +400,7 @@ int run_proofs(const char* path, uint64_t iters, uint64_t seed) {
     free(buf);
     if (vrc == P3R_OK) {
       std::vector<uint8_t> mn;
-      if (!same_inner && (blank_c || blank_q) && normalised_inner(m, c.dc, c.cfg.zk != 0, blank_c, blank_q, mn) && mn == seed_norm) {
+      if (!same_inner && (blank_c || blank_q) && normalised_inner(m, c.dc, c.cfg.zk != 0, c.cfg.mmcs_salt_elems != 0, blank_c, blank_q, mn) && mn == seed_norm) {
         ++unbound_pow;   // differs only in a witness of a zero-bit grind
       } else if (!same_inner) {
         fprintf(stderr, "iteration %llu (seed %llu): a mutant with different proof bytes was ACCEPTED\n", (unsigned long long)it, (unsigned long long)seed);

@@ -72,9 +72,9 @@ def write_proof_case(path, oracle, field, prm, packing, flags=0, log_h=5):
     outer = proof.to_postcard()
     with open(path, "wb") as fh:
         fh.write(b"P3RSAN1\0")
-        fh.write(struct.pack("<13I", oracle_lib.FIELD_IDS[field], 4, prm.log_blowup, prm.max_log_arity, prm.cap_height,
+        fh.write(struct.pack("<14I", oracle_lib.FIELD_IDS[field], 4, prm.log_blowup, prm.max_log_arity, prm.cap_height,
                              prm.log_final_poly_len, prm.commit_pow_bits, prm.query_pow_bits, prm.num_queries, prm.challenge_degree or 4,
-                             prm.mmcs_arity or 2, prm.zk, prm.num_random_codewords if prm.zk else 0))
+                             prm.mmcs_arity or 2, prm.zk, prm.num_random_codewords if prm.zk else 0, prm.mmcs_salt_elems))
         fh.write(struct.pack("<I", len(tables)))
         for t in tables:
             fh.write(struct.pack("<4I", t["kind_id"], t["lanes"], t["horner_k"], 0))
@@ -91,6 +91,8 @@ CASES = [
     ("cap_pow", dict(log_blowup=1, max_log_arity=1, cap_height=2, log_final_poly_len=1, commit_pow_bits=2, query_pow_bits=2, num_queries=2),
      dict(public_lanes=1, alu_lanes=3, horner_packed_steps=4, recompose_lanes=1), 0),
     ("zk", dict(log_blowup=2, max_log_arity=2, log_final_poly_len=0, query_pow_bits=2, num_queries=2, zk=1, zk_seed=5), dict(PACK), 0),
+    # the hiding MMCS under HidingFriPcs (recursion/tests/zk_hiding_mmcs.rs): opening proofs are (salts, siblings)
+    ("zk_salted", dict(log_blowup=2, max_log_arity=2, log_final_poly_len=0, query_pow_bits=2, num_queries=2, zk=1, zk_seed=6, mmcs_salt_elems=4), dict(PACK), 0),
     ("arity4_no_npo", dict(log_blowup=1, max_log_arity=3, log_final_poly_len=0, query_pow_bits=2, num_queries=2, mmcs_arity=4),
      dict(PACK), harness_lib.NO_POSEIDON2 | harness_lib.NO_RECOMPOSE),
 ]
