@@ -103,7 +103,7 @@ for f in ("bench_default_line.json", "bench_default_detail.json", "bench_default
     if os.path.exists(os.path.join(SRC, f)):
         shutil.copy(os.path.join(SRC, f), os.path.join(OUT, f))
 shutil.copy(newest(SRC + "/stats/*/*_kernel_stats.csv"), os.path.join(OUT, "prove_next_layer_final_kernel_stats.csv"))
-for f in ("int_rates.txt", "perm_f64.txt"):
+for f in ("int_rates.txt", "perm_f64.txt", "valu_classes.txt"):
     if os.path.exists(os.path.join(SRC, f)):
         shutil.copy(os.path.join(SRC, f), os.path.join(OUT, "microbench_" + f))
 fe, wr = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
@@ -124,7 +124,8 @@ json.dump({
     "kernels": kern}, open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
 
 # SQ counters: totals per kernel over the run (one pass per counter)
-sq_names = ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+sq_names = ["SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+            "SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
             "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INST_CYCLES_VMEM",
             "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT"]
 sq = {c: pmc(c) for c in sq_names}

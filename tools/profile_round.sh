@@ -2,7 +2,7 @@
 # Raw output goes to gpurun_out/final/; tools/collect_profiles.py <round> turns it into profiles/<round>/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
-(cd tools/microbench && ./int_rates > ../../gpurun_out/final/int_rates.txt 2>&1; ./perm_f64 > ../../gpurun_out/final/perm_f64.txt 2>&1)
+(cd tools/microbench && ./int_rates > ../../gpurun_out/final/int_rates.txt 2>&1; ./perm_f64 > ../../gpurun_out/final/perm_f64.txt 2>&1; ./valu_classes > ../../gpurun_out/final/valu_classes.txt 2>&1)
 # instructions per permutation of the dominant kernel: N launches over a matrix of known shape (tools/pmc_hash_rows.py)
 for F in koala-bear baby-bear; do
   for C in SQ_INSTS_VALU SQ_WAVES; do
@@ -21,7 +21,7 @@ python3 tools/collect_profiles.py ${1:-r06} --hash-rows-only
 timeout 1200 python bench.py --full --detail-out gpurun_out/final/bench_line.json > gpurun_out/final/bench_contract_line.json 2> gpurun_out/final/bench_err.log
 ARGS="bench.py --no-cpu-baseline --no-config2 --no-small-layers --no-quintic"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -- python3 $ARGS > gpurun_out/final/stats_run.log 2>&1
-for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT; do
+for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/final/pmc_$C -- python3 $ARGS --steps 1 --warmup 0 > gpurun_out/final/pmc_$C.log 2>&1
 done
 # keep the merge small: drop the per-dispatch traces except counter collection + stats
