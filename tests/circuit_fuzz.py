@@ -11,7 +11,11 @@ import circuit_lib as cl
 N = cl.NO_W
 
 
-def random_circuit(seed, n_ops=300, modulus=0x7F000001):
+def random_circuit(seed, n_ops=300, modulus=0x7F000001, w32=False):
+    """w32: a fifth of the permutation chains are chains of the WIDTH-32 table (cl.OP_P2W: sponge and Merkle rows freely
+    mixed - a Merkle row continues whatever width-32 row came last, a sponge row the last SPONGE row, as the executor's two
+    chain states have it; named limbs anywhere, bits from the constants, three sibling digests as private data on most
+    Merkle rows).  Off by default: the draws of the existing seeds do not change."""
     rng = random.Random(seed)
     ops, ext = [], []
     ws = []            # witnesses that are set when the next op runs
@@ -19,6 +23,8 @@ def random_circuit(seed, n_ops=300, modulus=0x7F000001):
     n_w = 0
     public_rows, public_values, private_rows, private_values = [], [], [], []
     pd_ids, pd_sibs = [], []
+    pdw_ids, pdw_sibs = [], []
+    have_w = {False: False, True: False}   # width-32 op type: normal / Merkle chain state exists
     npo_id = 0
     rewrite = []
 
@@ -123,6 +129,24 @@ def random_circuit(seed, n_ops=300, modulus=0x7F000001):
             op(cl.OP_RECOMPOSE, a=npo_id, out=o, e=[rng.choice(base_ws) for _ in range(4)])
             npo_id += 1
             ws.append(o)
+        elif w32 and k < 0.86:
+            for j in range(rng.randint(1, 10)):
+                merkle = rng.random() < 0.6
+                new_start = not have_w[merkle] or rng.random() < 0.15
+                e = [pick() if rng.random() < (0.5 if new_start else 0.2) else N for _ in range(8)]
+                e.append(N)                                                             # no mmcs_index_sum on this table
+                e += [rng.choice([zero, one]), rng.choice([zero, one])] if merkle else [N, N]
+                n_out = rng.choice([6, 8])
+                outs = [fresh() if rng.random() < 0.5 else N for _ in range(n_out)]
+                op(cl.OP_P2W, a=npo_id, aux=(1 if new_start else 0) | (2 if merkle else 0), e=e + [n_out] + outs)
+                if merkle and rng.random() < 0.8:
+                    pdw_ids.append(npo_id)
+                    pdw_sibs.append([rng.randrange(modulus) for _ in range(24)])
+                npo_id += 1
+                have_w[merkle] = True
+                if not merkle:
+                    have_w[True] = True        # a sponge row seeds the Merkle state (executor.rs:462-491)
+                ws += [o for o in outs if o != N]
         else:
             merkle = rng.random() < 0.5
             for j in range(rng.randint(1, 9)):
@@ -146,5 +170,5 @@ def random_circuit(seed, n_ops=300, modulus=0x7F000001):
         rewrite += [fresh(), pick()]
     circuit = cl.Circuit(n_w, ops, ext, public_rows, private_rows, rewrite)
     inputs = cl.Inputs(np.array(public_values, np.uint32), np.array(private_values, np.uint32), pd_ids,
-                       np.array(pd_sibs, np.uint32) if pd_sibs else ())
+                       np.array(pd_sibs, np.uint32) if pd_sibs else (), pdw_ids, np.array(pdw_sibs, np.uint32) if pdw_sibs else ())
     return circuit, inputs

@@ -117,6 +117,15 @@ def one(oracle, seed, max_log_h, min_log_h=5):
     if rng5.random() < 0.33:
         kw["zk"], kw["num_random_codewords"], kw["zk_seed"] = 1, rng5.randint(1, 3), rng5.getrandbits(48)
         zk_nonce = rng5.randint(0, 5)
+    # sixth stream (round 6): the hiding MMCS (p3r_config.mmcs_salt_elems: MerkleTreeHidingMmcs for input and commit-phase
+    # trees) in a quarter of the draws, 1 - 5 salt elements, with or without ZK, under either arity; the oracle is given the
+    # same key and proof number
+    rng6 = random.Random(seed * 49979687 + 5)
+    if rng6.random() < 0.25:
+        kw["mmcs_salt_elems"] = rng6.randint(1, 5)
+        if "zk_seed" not in kw:
+            kw["zk_seed"] = rng6.getrandbits(48)
+            zk_nonce = rng6.randint(0, 3)
     coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
     arrs = harness_lib.generate(field, log_h, seed=seed, flags=flags, ext_degree=ext_degree, **gen)
     packing_o = dict(packing, ext_degree=ext_degree, recompose_coeff_lookups=int(coeff))
@@ -134,7 +143,7 @@ def one(oracle, seed, max_log_h, min_log_h=5):
     ctx = None
     try:
         ctx = p3r.Context(field=field, ext_degree=ext_degree, **kw, allow_unpinned_w32_defaults=True)
-        if kw.get("zk"):
+        if kw.get("zk") or kw.get("mmcs_salt_elems"):
             ctx.zk_nonce = zk_nonce   # (zk_seed makes the context deterministic: the oracle is given the same key and nonce)
         cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree, recompose_coeff_lookups=coeff),
                                          pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
