@@ -289,8 +289,10 @@ __device__ __forceinline__ void run_p2w_segment(const RunArgs& A, RunSchedule::P
   if (!live) seg.n = 0;
   const Coop32Rc<PP> rcs = coop32_load_rc<PP>(A.rcw, j);
   F carried = F::zero();  // output of the previous row of this segment
+  RunP2W next = seg.n ? A.p2w[seg.first] : RunP2W{};
   for (uint32_t k = 0; k < seg.n; ++k) {
-    const RunP2W q = A.p2w[seg.first + k];
+    const RunP2W q = next;
+    if (k + 1 < seg.n) next = A.p2w[seg.first + k + 1];  // in flight while this row is permuted
     const bool new_start = q.flags & 1, merkle = q.flags & 2;
     // resolve_mmcs_bit / resolve_mmcs_bit2 (:283-338)
     bool bit = false, bit2 = false;
