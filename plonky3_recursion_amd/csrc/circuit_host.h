@@ -33,8 +33,6 @@ struct CircuitTables {
   std::vector<uint32_t> p2w_prep;
 };
 
-// ext layout of a width-32 permutation op: [in0..in7, mmcs_index_sum, mmcs_bit, mmcs_bit2, n_out, out0..]
-constexpr uint32_t kW32In = 8, kW32Rate = 6, kW32IdxSlot = 8, kW32BitSlot = 9, kW32Bit2Slot = 10, kW32NOutSlot = 11, kW32Hdr = 12;
 
 // Recompose ops come in two kinds: "recompose" (aux = 0) and "recompose/coeff" (aux = 1:
 // NpoTypeId::recompose_with_coeff_lookups, circuit/src/ops/npo.rs:48-60).  Each kind is its own table

@@ -710,6 +710,8 @@ std::unique_ptr<p3r_circuit> circuit_create(p3r_ctx* ctx, const p3r_circuit_desc
       C->d_p2seg_off = std::move(R.d_p2seg_off); C->d_p2segs = std::move(R.d_p2segs);
       C->d_chunk_bounds = std::move(R.d_chunk_bounds); C->d_chain_ops = std::move(R.d_chain_ops);
       C->d_chains = std::move(R.d_chains); C->d_row_of_op_id = std::move(R.d_row_of_op_id);
+      C->d_p2w = std::move(R.d_p2w); C->d_p2wsegs = std::move(R.d_p2wsegs); C->d_p2wseg_off = std::move(R.d_p2wseg_off);
+      C->d_roww_of_op_id = std::move(R.d_roww_of_op_id);
       C->prepared_on_device = true;
       prof_stage(ctx, nullptr);
       return C;

@@ -434,21 +434,24 @@ std::unique_ptr<p3r_layer> layer_from_device(p3r_ctx* ctx, DevPrep& R, const p3r
   L->has_recompose = R.counts.n_recompose > 0;
   L->has_recompose_coeff = R.counts.n_recompose_coeff > 0;
   L->recompose_coeff = R.recompose_coeff;
+  L->has_p2w = R.counts.n_p2w > 0;
+  L->h_p2w = R.h[6];
   L->h_const = R.h[0]; L->h_public = R.h[1]; L->h_alu = R.h[2]; L->h_p2 = R.h[3]; L->h_recompose = R.h[4];
   L->h_recompose_coeff = R.h[5];
   L->alu_rows = R.alu_rows;
   L->alu_plan = std::move(R.alu_plan);
   L->alu_prev_src = std::move(R.alu_prev_src);
-  const p3r_air_desc airs[6] = {{P3R_AIR_CONST, 1, 2, 0},
+  const p3r_air_desc airs[7] = {{P3R_AIR_CONST, 1, 2, 0},
                                 {P3R_AIR_PUBLIC, L->public_lanes, 2, 0},
                                 {P3R_AIR_ALU, L->alu_lanes, L->horner_k, 0},
                                 {P3R_AIR_POSEIDON2, 1, 2, 0},
                                 {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, L->recompose_coeff ? 1u : 0u},
-                                {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 1u}};
-  p3r_air_desc present[6];
+                                {P3R_AIR_RECOMPOSE, L->recompose_lanes, 2, 1u},
+                                {P3R_AIR_POSEIDON2_W32, 1, 2, 0}};
+  p3r_air_desc present[7];
   std::vector<std::unique_ptr<p3r_dmat>> traces;
   size_t n = 0;
-  for (int i = 0; i < 6; ++i) {
+  for (int i : kTableOrder) {
     if (L->slot_of(i) < 0) continue;
     present[n++] = airs[i];
     traces.push_back(std::move(R.prep[i]));

@@ -22,9 +22,9 @@ struct DevPrep {
   // ---- CircuitProverData inputs: per-table preprocessed traces (column-major, Montgomery, padded)
   p3r_layer_desc_counts counts{};
   uint32_t public_lanes = 1, alu_lanes = 1;  // effective (reduce_lanes_if_dummy, batch_stark_prover.rs:1305-1318)
-  size_t h[6] = {0, 0, 0, 0, 0, 0};          // padded heights, 0 = table absent; [5] = the second Recompose table
+  size_t h[7] = {0, 0, 0, 0, 0, 0, 0};       // padded heights, 0 = table absent; [5] = the second Recompose table, [6] = width-32 Poseidon2
   size_t alu_rows = 0;
-  std::unique_ptr<p3r_dmat> prep[6];
+  std::unique_ptr<p3r_dmat> prep[7];
   bool recompose_coeff = false;              // slot 4 holds the `recompose/coeff` kind (the circuit has no plain Recompose op)
   DevBuf alu_plan, alu_prev_src;
   // ---- execution schedule: the large arrays stay on the device, `sched` carries the per-level offsets,
@@ -33,6 +33,7 @@ struct DevPrep {
   DevBuf d_light, d_p2, d_ext, d_const_values, d_public_rows, d_private_rows, d_public_out, d_rewrite;
   DevBuf d_light_off, d_p2seg_off, d_p2segs, d_chunk_bounds, d_chain_ops, d_chains;
   DevBuf d_row_of_op_id;  // NonPrimitiveOpId -> Poseidon2 row, bit 31 = Merkle row; kNoW: not a permutation
+  DevBuf d_p2w, d_p2wsegs, d_p2wseg_off, d_roww_of_op_id;  // the same for the rows of the width-32 table (empty: the circuit has none)
   size_t n_op_ids = 0, n_public_rows = 0, n_private_rows = 0, n_rewrite = 0;
 };
 

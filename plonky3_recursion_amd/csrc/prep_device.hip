@@ -32,7 +32,7 @@ struct Shape {
 inline Shape shape_of(uint32_t D) { return D == 4 ? Shape{4, 4, 2, 4} : Shape{D, 16, 8, 16}; }
 
 // witness flag bits
-enum : uint32_t { WF_PRIVATE = 1, WF_CP = 2, WF_HINT = 4, WF_DUP_P2 = 8, WF_DUP_REC = 16, WF_DUP_REC_COEFF = 32 };
+enum : uint32_t { WF_PRIVATE = 1, WF_CP = 2, WF_HINT = 4, WF_DUP_P2 = 8, WF_DUP_REC = 16, WF_DUP_REC_COEFF = 32, WF_DUP_P2W = 64 };
 // static per-op flags (beyond RUN_*): bits 12..
 enum : uint32_t { OF_READY = 1u << 12, OF_LINK = 1u << 13, OF_LIGHT = 1u << 14 };
 // why the device pass gives up (any bit set: the host path reports)
@@ -94,6 +94,20 @@ __global__ void __launch_bounds__(kB) k_validate(const uint32_t* __restrict__ op
       }
       break;
     }
+    case P3R_OP_POSEIDON2_W32_PERM:
+      // the arity-4 shape (circuit_host.h::validate_circuit): D = 4 circuits only, no index accumulator, both direction
+      // bits on a Merkle row and none on a sponge row
+      ok = sh.D == 4 && op.ext_len >= kW32Hdr && (e[kW32NOutSlot] == kW32Rate || e[kW32NOutSlot] == kW32In) &&
+           op.ext_len == kW32Hdr + e[kW32NOutSlot];
+      if (ok) {
+        for (uint32_t k = 0; k < kW32NOutSlot; ++k) ok = ok && opt(e[k]);
+        for (uint32_t k = 0; k < e[kW32NOutSlot]; ++k) ok = ok && opt(e[kW32Hdr + k]);
+        if (e[kW32IdxSlot] != kNoW) ok = false;
+        const bool b1 = e[kW32BitSlot] != kNoW, b2 = e[kW32Bit2Slot] != kNoW;
+        if ((op.aux & 2) ? !(b1 && b2) : (b1 || b2)) ok = false;
+        if (op.a >= n_ops) ok = false;
+      }
+      break;
     case P3R_OP_RECOMPOSE:
       // aux: 0 / P3R_NO_WITNESS = `recompose`, 1 = `recompose/coeff`; anything else the host path rejects
       ok = wid(op.out) && op.a < n_ops && op.ext_len == sh.D && (op.aux == 0u || op.aux == 1u || op.aux == kNoW);
@@ -144,6 +158,11 @@ struct PairRecExt {  // plain recompose rows | cells this op appends to the devi
 struct FlagRecCoeff {  // rows of the `recompose/coeff` kind (aux = 1)
   const uint32_t* ops;
   __device__ uint32_t operator()(size_t i) const { return (ops[8 * i] == P3R_OP_RECOMPOSE && ops[8 * i + 5] == 1u) ? 1u : 0u; }
+};
+
+struct FlagP2W {  // rows of the width-32 Poseidon2 table
+  const uint32_t* ops;
+  __device__ uint32_t operator()(size_t i) const { return ops[8 * i] == P3R_OP_POSEIDON2_W32_PERM ? 1u : 0u; }
 };
 
 template <class Fn>
@@ -222,6 +241,14 @@ __global__ void __launch_bounds__(kB) k_times(const uint32_t* __restrict__ ops, 
         atomicMin(&stime[w], t);
       }
       break;
+    case P3R_OP_POSEIDON2_W32_PERM:
+      for (uint32_t l = 0; l < e[kW32NOutSlot]; ++l) {
+        const uint32_t w = e[kW32Hdr + l];
+        if (w == kNoW) continue;
+        if (l < kW32Rate) atomicMin(&tdef[w], t);   // the six rate limbs are on the bus
+        atomicMin(&stime[w], t);
+      }
+      break;
     case P3R_OP_RECOMPOSE: atomicMin(&tdef[op.out], t); atomicMin(&stime[op.out], t); break;
     case P3R_OP_HINT_EXT_DECOMPOSITION: case P3R_OP_HINT_BINARY_DECOMPOSITION:
       for (uint32_t k = 0; k < op.ext_len; ++k) atomicMin(&stime[e[k]], t);
@@ -284,6 +311,21 @@ __global__ void __launch_bounds__(kB) k_roles(const uint32_t* __restrict__ ops, 
         for (uint32_t j = 0; j < l; ++j) earlier |= e[sh.il + 3 + j] == w;
         if (def(w) || earlier) { atomicOr(&wflags[w], WF_DUP_P2); atomicAdd(&reads[w], 1u); }
       }
+      break;
+    }
+    case P3R_OP_POSEIDON2_W32_PERM: {
+      // every named input limb is a bus read - Merkle rows too - and a Merkle row reads its two direction bits
+      // (circuit_host.h::circuit_tables; executor.rs:777-793,880-893)
+      for (uint32_t l = 0; l < kW32In; ++l)
+        if (e[l] != kNoW) atomicAdd(&reads[e[l]], 1u);
+      for (uint32_t l = 0; l < kW32Rate; ++l) {
+        const uint32_t w = e[kW32Hdr + l];
+        if (w == kNoW) continue;
+        bool earlier = false;
+        for (uint32_t j = 0; j < l; ++j) earlier |= e[kW32Hdr + j] == w;
+        if (def(w) || earlier) { atomicOr(&wflags[w], WF_DUP_P2W); atomicAdd(&reads[w], 1u); }
+      }
+      if (op.aux & 2) { atomicAdd(&reads[e[kW32BitSlot]], 1u); atomicAdd(&reads[e[kW32Bit2Slot]], 1u); }
       break;
     }
     case P3R_OP_RECOMPOSE:
@@ -413,6 +455,42 @@ __global__ void __launch_bounds__(kB) k_prep_p2(const uint32_t* __restrict__ ops
   put(21, (en && mp) ? one : 0);
   put(22, ns ? one : 0);
   put(23, mp ? one : 0);
+}
+// Rows of the width-32 table, Poseidon2PreprocessedRow<8, 6> (circuit_host.h::circuit_tables; executor.rs:770-893,
+// batch_stark_prover.rs:177-243): [idx, in_ctl, normal_chain_sel, merkle_chain_sel] x 8, [idx, out_ctl] x 6, the two bit
+// witnesses of a Merkle row in the accumulator slots, new_start, merkle_path; padding as above
+template <class PP>
+__global__ void __launch_bounds__(kB) k_prep_p2w(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
+                                                 const uint32_t* __restrict__ pw_ops, size_t n, const uint32_t* __restrict__ reads,
+                                                 const uint32_t* __restrict__ wflags, size_t h, uint32_t* __restrict__ out) {
+  const size_t r = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (r >= h) return;
+  using C = Cells<PP>;
+  if (r >= n) {
+    for (int c = 0; c < kP2WPrepCols; ++c) out[(size_t)c * h + r] = (c == kP2WPrepCols - 2 && r == n) ? C::one() : 0u;
+    return;
+  }
+  const Op op = load_op(ops, pw_ops[r]);
+  const uint32_t* e = ext + op.ext_off;
+  const bool ns = op.aux & 1, mp = op.aux & 2;
+  auto put = [&](int c, uint32_t v) { out[(size_t)c * h + r] = v; };
+  const uint32_t one = C::one();
+  for (int l = 0; l < (int)kW32In; ++l) {
+    const bool named = e[l] != kNoW;
+    put(4 * l, C::scaled(named ? e[l] : 0, 4));
+    put(4 * l + 1, named ? one : 0);
+    put(4 * l + 2, (!ns && !mp && !named) ? one : 0);
+    put(4 * l + 3, (!ns && mp && !named) ? one : 0);
+  }
+  for (int l = 0; l < (int)kW32Rate; ++l) {
+    const uint32_t w = e[kW32Hdr + l];
+    put(32 + 2 * l, C::scaled(w != kNoW ? w : 0, 4));
+    put(33 + 2 * l, w == kNoW ? 0u : (wflags[w] & WF_DUP_P2W) ? C::neg1() : C::mult(reads, w));
+  }
+  put(44, mp ? C::scaled(e[kW32BitSlot], 4) : 0u);
+  put(45, mp ? C::scaled(e[kW32Bit2Slot], 4) : 0u);
+  put(46, ns ? one : 0);
+  put(47, mp ? one : 0);
 }
 // the compact D = 1 rows of circuits of degree 1 / 5 (air.rs:730-763, executor.rs:720-741; layer_impl.hip.h::layer_create):
 // [in_ctl x 8, length tag, cap_chain_enable, 8 + 8 chain selectors | 16 + 8 indices, 8 out_ctl | index_sum idx, 3 flags]
@@ -664,6 +742,9 @@ __global__ void __launch_bounds__(kB) k_sched_static(const uint32_t* __restrict_
     case P3R_OP_POSEIDON2_PERM:
       for (uint32_t l = 0; l < sh.il + 2; ++l) if (e[l] != kNoW) need(e[l]);
       break;
+    case P3R_OP_POSEIDON2_W32_PERM:
+      for (uint32_t l = 0; l < kW32NOutSlot; ++l) if (e[l] != kNoW) need(e[l]);
+      break;
     default: break;
   }
   oflags[i] = f;
@@ -742,7 +823,7 @@ struct MaxNpoId {
   const uint32_t* ops;
   __device__ uint32_t operator()(size_t i) const {
     const uint32_t k = ops[8 * i];
-    return (k == P3R_OP_POSEIDON2_PERM || k == P3R_OP_RECOMPOSE) ? ops[8 * i + 1] + 1 : 0u;
+    return (k == P3R_OP_POSEIDON2_PERM || k == P3R_OP_RECOMPOSE || k == P3R_OP_POSEIDON2_W32_PERM) ? ops[8 * i + 1] + 1 : 0u;
   }
 };
 
@@ -901,6 +982,148 @@ __global__ void __launch_bounds__(kB) k_level_p2(const uint32_t* __restrict__ op
     carry = __shfl(lvl, 63);
   }
   if (ch) *changed = 1;
+}
+
+// ---- the width-32 table (P3R_OP_POSEIDON2_W32_PERM): its own op type with its own chain state (circuit_host.h::build_schedule,
+// update_chain_state executor.rs:462-491).  Every row updates the Merkle state and a sponge row the sponge state too, so a chained
+// Merkle row continues the row just before it and a chained sponge row the sponge row before it: one predecessor per row, at
+// most two successors - row p + 1 and the next sponge row - and the FIRST of them in circuit order whose witnesses are ready
+// before p's segment runs extends that segment; any other opens a segment above it.
+__global__ void __launch_bounds__(kB) k_pw_modes(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ pw_ops, size_t n,
+                                                 uint32_t* __restrict__ is_sponge) {
+  const size_t r = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (r < n) is_sponge[r] = ((ops[8 * (size_t)pw_ops[r] + 5] >> 1) & 1) ^ 1u;
+}
+__global__ void __launch_bounds__(kB) k_pw_links(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ pw_ops, size_t n,
+                                                 const uint32_t* __restrict__ sponge_rank, const uint32_t* __restrict__ sponge_list,
+                                                 uint32_t* __restrict__ prev, uint32_t* __restrict__ bad) {
+  const size_t r = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t aux = ops[8 * (size_t)pw_ops[r] + 5];
+  uint32_t p = kNoW;
+  if (!(aux & 1)) {
+    if (aux & 2) p = r ? (uint32_t)r - 1 : kNoW;
+    else p = sponge_rank[r] ? sponge_list[sponge_rank[r] - 1] : kNoW;
+    if (p == kNoW) atomicOr(bad, BAD_DEFERRED);   // Poseidon2ChainMissingPreviousState
+  }
+  prev[r] = p;
+}
+// the successor of row p that shares its segment, or kNoW
+__device__ __forceinline__ uint32_t pw_next_in_segment(uint32_t p, size_t n, const uint32_t* __restrict__ prev,
+                                                       const uint32_t* __restrict__ joined, const uint32_t* __restrict__ is_sponge,
+                                                       const uint32_t* __restrict__ sponge_rank, const uint32_t* __restrict__ sponge_list,
+                                                       size_t n_sponge) {
+  if ((size_t)p + 1 < n && prev[p + 1] == p && joined[p + 1]) return p + 1;
+  if (is_sponge[p] && (size_t)sponge_rank[p] + 1 < n_sponge) {
+    const uint32_t c = sponge_list[sponge_rank[p] + 1];
+    if (c != p + 1 && prev[c] == p && joined[c]) return c;
+  }
+  return kNoW;
+}
+// one thread per row; the fixed point of "level = the segment's level" over rows that depend on earlier rows only
+__global__ void __launch_bounds__(kB) k_level_p2w(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
+                                                  const uint32_t* __restrict__ pw_ops, size_t n, const uint32_t* __restrict__ prev,
+                                                  const uint32_t* __restrict__ is_sponge, const uint32_t* __restrict__ stime,
+                                                  uint32_t* __restrict__ wlevel, uint32_t* __restrict__ pwlevel,
+                                                  uint32_t* __restrict__ joined, uint32_t* __restrict__ changed) {
+  const size_t r = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t i = pw_ops[r], t = i + 1;
+  const Op op = load_op(ops, i);
+  const uint32_t* e = ext + op.ext_off;
+  const uint32_t* eo = e + kW32Hdr;
+  uint32_t lvl = 0, outs_mask = 0;
+  for (uint32_t l = 0; l < kW32NOutSlot; ++l) if (e[l] != kNoW) lvl = max(lvl, wlevel[e[l]]);
+  for (uint32_t l = 0; l < e[kW32NOutSlot]; ++l) {
+    const uint32_t w = eo[l];
+    if (w == kNoW) continue;
+    bool earlier = false;
+    for (uint32_t j = 0; j < l; ++j) earlier |= eo[j] == w;
+    if (earlier) continue;
+    if (stime[w] < t) lvl = max(lvl, wlevel[w]);  // a comparison: the row waits for the value
+    else outs_mask |= 1u << l;                    // written by this row
+  }
+  const uint32_t need = lvl + 1, p = prev[r];
+  uint32_t level = need, join = 0;
+  if (p != kNoW) {
+    const uint32_t lp = pwlevel[p];
+    bool can = need <= lp;
+    // a sponge row's predecessor may have a Merkle successor, row p + 1, which comes first in circuit order
+    if (can && is_sponge[r] && p + 1 < r && prev[p + 1] == p && joined[p + 1]) can = false;
+    level = can ? lp : max(need, lp + 1);
+    join = can;
+  }
+  if (pwlevel[r] == level && joined[r] == join) return;
+  pwlevel[r] = level;
+  joined[r] = join;
+  *changed = 1;
+  for (uint32_t l = 0; l < kW32In; ++l) if (outs_mask & (1u << l)) wlevel[eo[l]] = level;
+}
+__global__ void __launch_bounds__(kB) k_pw_heads(const uint32_t* __restrict__ joined, size_t n, uint32_t* __restrict__ is_head) {
+  const size_t r = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (r < n) is_head[r] = joined[r] ^ 1u;
+}
+__global__ void __launch_bounds__(kB) k_pw_seg_records(const uint32_t* __restrict__ head_rows, size_t n_segs, size_t n,
+                                                       const uint32_t* __restrict__ prev, const uint32_t* __restrict__ joined,
+                                                       const uint32_t* __restrict__ is_sponge, const uint32_t* __restrict__ sponge_rank,
+                                                       const uint32_t* __restrict__ sponge_list, size_t n_sponge,
+                                                       const uint32_t* __restrict__ pwlevel, uint32_t* __restrict__ seg_len,
+                                                       uint32_t* __restrict__ seg_level) {
+  const size_t s = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (s >= n_segs) return;
+  uint32_t r = head_rows[s], len = 0;
+  seg_level[s] = pwlevel[r];
+  for (; r != kNoW; r = pw_next_in_segment(r, n, prev, joined, is_sponge, sponge_rank, sponge_list, n_sponge)) ++len;
+  seg_len[s] = len;
+}
+__global__ void __launch_bounds__(kB) k_emit_p2w(const uint32_t* __restrict__ ops, const uint32_t* __restrict__ ext,
+                                                 const uint32_t* __restrict__ pw_ops, size_t n, const uint32_t* __restrict__ prev,
+                                                 const uint32_t* __restrict__ joined, const uint32_t* __restrict__ is_sponge,
+                                                 const uint32_t* __restrict__ sponge_rank, const uint32_t* __restrict__ sponge_list,
+                                                 size_t n_sponge, const uint32_t* __restrict__ order, const uint32_t* __restrict__ head_rows,
+                                                 const uint32_t* __restrict__ seg_len, const uint32_t* __restrict__ first /* per sorted segment */,
+                                                 size_t n_segs, const uint32_t* __restrict__ stime, RunP2W* __restrict__ out,
+                                                 RunSchedule::P2Seg* __restrict__ segs) {
+  const size_t s = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (s >= n_segs) return;
+  const uint32_t c = order[s], len = seg_len[c], f0 = first[s];
+  segs[s] = RunSchedule::P2Seg{f0, len};
+  uint32_t row = head_rows[c];
+  for (uint32_t k = 0; k < len; ++k) {
+    const uint32_t i = pw_ops[row], t = i + 1;
+    const Op op = load_op(ops, i);
+    const uint32_t* e = ext + op.ext_off;
+    const uint32_t n_out = e[kW32NOutSlot];
+    RunP2W q{};
+    q.flags = (op.aux & 3) | (n_out << 8);
+    q.op_idx = i;
+    q.row = row;
+    q.prev_row = prev[row];
+    q.prev_in_seg = k ? 1u : 0u;
+    for (uint32_t l = 0; l < kW32In; ++l) q.in[l] = e[l];
+    q.bit_w = e[kW32BitSlot];
+    q.bit2_w = e[kW32Bit2Slot];
+    for (uint32_t l = 0; l < kW32In; ++l) {
+      q.out[l] = l < n_out ? e[kW32Hdr + l] : kNoW;
+      if (q.out[l] == kNoW) continue;
+      bool earlier = false;
+      for (uint32_t j = 0; j < l; ++j) earlier |= q.out[j] == q.out[l];
+      if (earlier || stime[q.out[l]] < t) q.flags |= 1u << (16 + l);
+    }
+    out[f0 + k] = q;
+    row = pw_next_in_segment(row, n, prev, joined, is_sponge, sponge_rank, sponge_list, n_sponge);
+  }
+}
+// the two widths share the NonPrimitiveOpId space: one id, one row
+__global__ void __launch_bounds__(kB) k_ids_cross(const uint32_t* __restrict__ row_of_id, const uint32_t* __restrict__ roww_of_id,
+                                                  size_t n_ids, uint32_t* __restrict__ bad) {
+  const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (i < n_ids && row_of_id[i] != kNoW && roww_of_id[i] != kNoW) atomicOr(bad, BAD_DUP_ID);
+}
+__global__ void __launch_bounds__(kB) k_list_kind(const uint32_t* __restrict__ ops, size_t n_ops, uint32_t kind,
+                                                  const uint32_t* __restrict__ rank, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * kB + threadIdx.x;
+  if (i < n_ops && ops[8 * i] == kind) out[rank[i]] = (uint32_t)i;
 }
 
 // ---- emission ----------------------------------------------------------------------------------------------
@@ -1183,8 +1406,12 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   hipLaunchKernelGGL(k_scan_total<PairConstPublic>, dim3(1), dim3(64), 0, s, PairConstPublic{ops.p}, n_ops, S_cp);
   hipLaunchKernelGGL(k_scan_total<PairAluP2>, dim3(1), dim3(64), 0, s, PairAluP2{ops.p}, n_ops, S_ap);
   hipLaunchKernelGGL(k_scan_total<PairRecExt>, dim3(1), dim3(64), 0, s, PairRecExt{ops.p, D}, n_ops, S_re);
+  DevBuf s_pw(n_ops + 1);   // rank among the width-32 Poseidon2 ops
+  scan_flags(ctx, FlagP2W{ops.p}, n_ops, s_pw.p);
+  hipLaunchKernelGGL(k_flags_total<FlagP2W>, dim3(1), dim3(64), 0, s, FlagP2W{ops.p}, n_ops, s_pw.p);
   uint64_t tot[3];
-  uint32_t n_rec_coeff_u32 = 0;
+  uint32_t n_rec_coeff_u32 = 0, n_pw_u32 = 0;
+  P3R_HIP(hipMemcpyAsync(&n_pw_u32, s_pw.p + n_ops, 4, hipMemcpyDeviceToHost, s));
   P3R_HIP(hipMemcpyAsync(&n_rec_coeff_u32, s_rc.p + n_ops, 4, hipMemcpyDeviceToHost, s));
   P3R_HIP(hipMemcpyAsync(&tot[0], S_cp + n_ops, 8, hipMemcpyDeviceToHost, s));
   P3R_HIP(hipMemcpyAsync(&tot[1], S_ap + n_ops, 8, hipMemcpyDeviceToHost, s));
@@ -1196,6 +1423,9 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
       p2_ops(std::max<size_t>(n_p2, 1)), rec_ops(std::max<size_t>(n_rec_plain, 1)), rec_coeff_ops(std::max<size_t>(n_rec_coeff, 1));
   LAUNCH(k_table_lists, n_ops, ops.p, n_ops, S_cp, S_ap, S_re, const_ops.p, public_ops.p, alu_ops.p, p2_ops.p, rec_ops.p, s_rc.p,
          rec_coeff_ops.p);
+  const size_t n_pw = n_pw_u32;
+  DevBuf pw_ops(std::max<size_t>(n_pw, 1));
+  if (n_pw) LAUNCH(k_list_kind, n_ops, ops.p, n_ops, (uint32_t)P3R_OP_POSEIDON2_W32_PERM, s_pw.p, pw_ops.p);
 
   // ---- first touches
   LAUNCH(k_mark_cp, n_ops, ops.p, n_ops, wflags.p);
@@ -1216,6 +1446,7 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
   const size_t mh = d->min_trace_height;
   R.counts.n_const = n_const; R.counts.n_public = n_public; R.counts.n_alu = std::max<size_t>(n_alu_ops, 1);
   R.counts.n_p2 = n_p2;
+  R.counts.n_p2w = n_pw;
   // a table without rows is not proved: a circuit whose Recompose ops are all of the coefficient kind has ONE Recompose
   // table, `recompose/coeff`, in the first slot (circuit_impl.hip.h::circuit_tables)
   R.recompose_coeff = n_rec_plain == 0 && n_rec_coeff > 0;
@@ -1245,6 +1476,11 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
       R.prep[3] = zero_mat(ctx, h_p2, kP2D1PrepWidth);
       LAUNCH(k_prep_p2_d1<PP>, h_p2, ops.p, ext.p, p2_ops.p, n_p2, reads.p, wflags.p, D, h_p2, R.prep[3]->d);
     }
+  }
+  if (n_pw) {
+    R.h[6] = padded_h(n_pw, mh);
+    R.prep[6] = zero_mat(ctx, R.h[6], kP2WPrepCols);
+    LAUNCH(k_prep_p2w<PP>, R.h[6], ops.p, ext.p, pw_ops.p, n_pw, reads.p, wflags.p, R.h[6], R.prep[6]->d);
   }
   if (n_rec_plain) {
     R.h[4] = padded_h(std::max<size_t>((n_rec_plain + rl - 1) / rl, 1), mh);
@@ -1336,6 +1572,12 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
     R.d_row_of_op_id.alloc(std::max<size_t>(R.n_op_ids, 1));
     P3R_HIP(hipMemsetAsync(R.d_row_of_op_id.p, 0xFF, std::max<size_t>(R.n_op_ids, 1) * 4, s));
     LAUNCH(k_op_ids, n_p2, ops.p, p2_ops.p, n_p2, R.n_op_ids, R.d_row_of_op_id.p, bad.p);
+    if (n_pw) {
+      R.d_roww_of_op_id.alloc(std::max<size_t>(R.n_op_ids, 1));
+      P3R_HIP(hipMemsetAsync(R.d_roww_of_op_id.p, 0xFF, std::max<size_t>(R.n_op_ids, 1) * 4, s));
+      LAUNCH(k_op_ids, n_pw, ops.p, pw_ops.p, n_pw, R.n_op_ids, R.d_roww_of_op_id.p, bad.p);
+      LAUNCH(k_ids_cross, R.n_op_ids, R.d_row_of_op_id.p, R.d_roww_of_op_id.p, R.n_op_ids, bad.p);
+    }
 
     DevBuf hmem(std::max<size_t>(n_members, 1)), run_start(n_members + 2), light_ops(std::max<size_t>(n_light, 1));
     LAUNCH(k_compact_ops, n_ops, oflags.p, n_ops, ready_rank.p, light_rank.p, hmem.p, run_start.p, light_ops.p);
@@ -1372,6 +1614,22 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
       P3R_HIP(hipMemsetAsync(plevel.p, 0, n_p2 * 4, s));
       P3R_HIP(hipMemsetAsync(phead.p, 0, (n_p2 + 1) * 4, s));
     }
+    // rows of the width-32 table: predecessor links
+    DevBuf pw_sponge(n_pw + 2), pw_srank(n_pw + 2), pw_slist(std::max<size_t>(n_pw, 1)), pw_prev(std::max<size_t>(n_pw, 1)),
+        pw_level(std::max<size_t>(n_pw, 1)), pw_joined(std::max<size_t>(n_pw, 1));
+    size_t n_pw_sponge = 0;
+    if (n_pw) {
+      LAUNCH(k_pw_modes, n_pw, ops.p, pw_ops.p, n_pw, pw_sponge.p);
+      P3R_HIP(hipMemsetAsync(pw_sponge.p + n_pw, 0, 4, s));
+      scan_u32(ctx, pw_sponge.p, pw_srank.p, n_pw + 1);
+      uint32_t v = 0;
+      P3R_HIP(copy_sync(s, &v, pw_srank.p + n_pw, 4, hipMemcpyDeviceToHost));
+      n_pw_sponge = v;
+      LAUNCH(k_compact_marked, n_pw, pw_sponge.p, pw_srank.p, n_pw, pw_slist.p);
+      LAUNCH(k_pw_links, n_pw, ops.p, pw_ops.p, n_pw, pw_srank.p, pw_slist.p, pw_prev.p, bad.p);
+      P3R_HIP(hipMemsetAsync(pw_level.p, 0, n_pw * 4, s));
+      P3R_HIP(hipMemsetAsync(pw_joined.p, 0, n_pw * 4, s));
+    }
     {
       uint32_t b0 = 0;
       P3R_HIP(copy_sync(s, &b0, bad.p, 4, hipMemcpyDeviceToHost));
@@ -1386,6 +1644,8 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
         LAUNCH(k_level_chains, n_runs * 64, ops.p, hmem.p, runs.p, n_runs, n_members, wlevel.p, olevel.p, chead.p, changed.p);
         LAUNCH(k_level_p2, n_p2_runs * 64, ops.p, ext.p, p2_ops.p, mlist.p, p2_runs.p, n_p2_runs, n_p2, stime.p, sh, wlevel.p, plevel.p,
                phead.p, changed.p);
+        LAUNCH(k_level_p2w, n_pw, ops.p, ext.p, pw_ops.p, n_pw, pw_prev.p, pw_sponge.p, stime.p, wlevel.p, pw_level.p, pw_joined.p,
+               changed.p);
       }
       uint32_t c = 0;
       P3R_HIP(copy_sync(s, &c, changed.p, 4, hipMemcpyDeviceToHost));
@@ -1441,6 +1701,7 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
     P3R_HIP(hipMemsetAsync(mxl.p, 0, 4, s));
     LAUNCH(k_max_u32, n_ops, olevel.p, n_ops, mxl.p);
     LAUNCH(k_max_u32, n_p2, plevel.p, n_p2, mxl.p);
+    LAUNCH(k_max_u32, n_pw, pw_level.p, n_pw, mxl.p);
     uint32_t max_level = 0;
     {
       uint32_t v2[2];
@@ -1519,6 +1780,33 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
         LAUNCH(k_emit_p2_base, n_segs, ops.p, ext.p, p2_ops.p, mlist.p, order.p, seg_pos.p, seg_len.p, first.p, n_segs, n_normal, stime.p,
                reinterpret_cast<RunP2B*>(R.d_p2.p), reinterpret_cast<RunSchedule::P2Seg*>(R.d_p2segs.p));
     }
+    // segments of the width-32 table: heads in row order (= the order the sequential walk opens them in), stable sort by level
+    size_t n_wsegs = 0;
+    DevBuf histw(nl1);
+    P3R_HIP(hipMemsetAsync(histw.p, 0xFF, nl1 * 4, s));
+    if (n_pw) {
+      DevBuf is_head(n_pw + 2), head_rank(n_pw + 2), head_rows(n_pw);
+      LAUNCH(k_pw_heads, n_pw, pw_joined.p, n_pw, is_head.p);
+      P3R_HIP(hipMemsetAsync(is_head.p + n_pw, 0, 4, s));
+      scan_u32(ctx, is_head.p, head_rank.p, n_pw + 1);
+      uint32_t v = 0;
+      P3R_HIP(copy_sync(s, &v, head_rank.p + n_pw, 4, hipMemcpyDeviceToHost));
+      n_wsegs = v;
+      LAUNCH(k_compact_marked, n_pw, is_head.p, head_rank.p, n_pw, head_rows.p);
+      DevBuf seg_len(n_wsegs), seg_level(n_wsegs), keys2(n_wsegs), iota(n_wsegs), order(n_wsegs), len_sorted(n_wsegs + 1), first(n_wsegs + 1);
+      LAUNCH(k_pw_seg_records, n_wsegs, head_rows.p, n_wsegs, n_pw, pw_prev.p, pw_joined.p, pw_sponge.p, pw_srank.p, pw_slist.p, n_pw_sponge,
+             pw_level.p, seg_len.p, seg_level.p);
+      LAUNCH(k_iota, n_wsegs, iota.p, n_wsegs);
+      sort_by_key(ctx, seg_level.p, keys2.p, iota.p, order.p, n_wsegs, lbits);
+      LAUNCH(k_first_index, n_wsegs, keys2.p, n_wsegs, histw.p);
+      LAUNCH(k_gather_u32, n_wsegs, seg_len.p, order.p, n_wsegs, len_sorted.p);
+      scan_u32(ctx, len_sorted.p, first.p, n_wsegs);
+      R.d_p2w.alloc(n_pw * (sizeof(RunP2W) / 4));
+      R.d_p2wsegs.alloc(n_wsegs * 2);
+      LAUNCH(k_emit_p2w, n_wsegs, ops.p, ext.p, pw_ops.p, n_pw, pw_prev.p, pw_joined.p, pw_sponge.p, pw_srank.p, pw_slist.p, n_pw_sponge,
+             order.p, head_rows.p, seg_len.p, first.p, n_wsegs, stime.p, reinterpret_cast<RunP2W*>(R.d_p2w.p),
+             reinterpret_cast<RunSchedule::P2Seg*>(R.d_p2wsegs.p));
+    }
     prof_stage(ctx, "prep_emit_rest");
     // static Const trace, Public gather list
     R.d_const_values.alloc(std::max<size_t>(n_const * D, 1));
@@ -1545,6 +1833,13 @@ bool devprep_impl(p3r_ctx* ctx, const p3r_circuit_desc* d, DevPrep& R) {
     if (S.light_off.back() != n_light || S.p2seg_off.back() != n_segs || S.chain_off.back() != n_chains)
       fail(P3R_EINVAL, "circuit schedule: level histogram does not add up (%u/%zu light, %u/%zu segments, %u/%zu chains)",
            S.light_off.back(), n_light, S.p2seg_off.back(), n_segs, S.chain_off.back(), n_chains);
+    if (n_pw) {
+      const std::vector<uint32_t> hw = fetch<uint32_t>(ctx, histw.p, nl1);
+      S.p2wseg_off = offsets(hw.data(), nl1 - 1, n_wsegs);
+      if (S.p2wseg_off.back() != n_wsegs)
+        fail(P3R_EINVAL, "circuit schedule: level histogram does not add up (%u/%zu width-32 segments)", S.p2wseg_off.back(), n_wsegs);
+      up(R.d_p2wseg_off, S.p2wseg_off.data(), S.p2wseg_off.size());
+    }
     finish_segments(S);
     up(R.d_light_off, S.light_off.data(), S.light_off.size());
     up(R.d_p2seg_off, S.p2seg_off.data(), S.p2seg_off.size());

@@ -18,6 +18,11 @@ constexpr uint32_t kNoW = P3R_NO_WITNESS;
 // at kP2D1Tail: mmcs_index_sum index, mmcs_ctl_enabled, new_start, merkle_path
 constexpr int kP2D1Hdr = 26, kP2D1Tail = 58, kP2D1PrepWidth = 62;
 
+// ext layout of a width-32 permutation op: [in0..in7, mmcs_index_sum, mmcs_bit, mmcs_bit2, n_out, out0..]
+constexpr uint32_t kW32In = 8, kW32Rate = 6, kW32IdxSlot = 8, kW32BitSlot = 9, kW32Bit2Slot = 10, kW32NOutSlot = 11, kW32Hdr = 12;
+// preprocessed row of that table: Poseidon2PreprocessedRow<8, 6> (= air_device.hip.h::kP2WPrepWidth, tail at 44)
+constexpr int kP2WPrepCols = 48;
+
 // ALU plan entry kinds
 enum { PLAN_SEP = 0, PLAN_OP = 1, PLAN_PACKED = 2 };
 

@@ -29,7 +29,7 @@ DEGREE_CASES = [("koala-bear", 5, 8, 0, None), ("koala-bear", 1, 8, 0, None), ("
                  dict(public_lanes=2, alu_lanes=3, horner_packed_steps=4))]
 
 
-def both_ways(ctx, circuit, tp, inputs):
+def both_ways(ctx, circuit, tp, inputs, arrays=ARRAYS):
     """(commitment, levels, traces, proof) with the device-side and with the host-side preparation."""
     import plonky3_recursion_amd as p3r
     out = []
@@ -43,7 +43,7 @@ def both_ways(ctx, circuit, tp, inputs):
         assert pc.prepared_on_device == (not host)
         res = pc.run(inputs)
         cpd = pc.circuit_prover_data
-        traces = {k: res.download(k) for k in ARRAYS if cpd.rows[p3r.prover.TRACES_ARRAYS[k][1]]}
+        traces = {k: res.download(k) for k in arrays if cpd.rows[p3r.prover.TRACES_ARRAYS[k][1]]}
         out.append((cpd.preprocessed_commitment.copy(), pc.levels, traces, pc.prove(inputs), list(cpd.table_heights),
                     cpd.effective_packing))
         res.free()
@@ -143,6 +143,77 @@ def test_device_preparation_on_random_circuits(field, seeds, n_ops):
         assert dev[1] == host[1] and dev[2] == host[2], (seed, dev[1], host[1], dev[2], host[2])
         for n in host[3]:
             assert np.array_equal(dev[3][n], host[3][n]), (seed, n)
+    ctx.close()
+
+
+W32_ARRAYS = ARRAYS + ("p2w_input_values", "p2w_flags", "p2w_mmcs_index_sum")
+
+
+@pytest.mark.parametrize("field,log_h,packing,gen,ctx_kw", [
+    ("koala-bear", 7, None, {}, {}),
+    ("baby-bear", 8, PACKINGS[1], {}, dict(mmcs_arity=4)),
+    ("koala-bear", 10, PACKINGS[2], dict(horner_chain_len=300, sponge_chain_len=40, merkle_depth=11), dict(mmcs_arity=4)),
+    ("baby-bear", 13, PACKINGS[3], dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20), {}),
+    ("koala-bear", 16, None, dict(horner_chain_len=64, sponge_chain_len=8, merkle_depth=20), dict(mmcs_arity=4)),
+])
+def test_device_preparation_of_width32_rows(field, log_h, packing, gen, ctx_kw):
+    """Round 6: circuits that hold P3R_OP_POSEIDON2_W32_PERM ops (the MMCS rows of an `--arity4` verifier circuit) are
+    prepared on the device too: the 48-column Poseidon2PreprocessedRow<8, 6> rows with their multiplicities
+    (executor.rs:770-893, batch_stark_prover.rs:177-243), the op type's own chain state (sponge rows seed the Merkle
+    state, executor.rs:462-491) as segments of the static schedule, the NonPrimitiveOpId -> row table for the private
+    data of the Merkle rows - same commitment, schedule depth, run traces and proof bytes as the host restatement."""
+    import harness_adapters as wl
+    import plonky3_recursion_amd as p3r
+    gen = dict(dict(horner_chain_len=16, sponge_chain_len=3, merkle_depth=5), **gen)
+    a = harness_lib.generate(field, log_h, seed=177 + log_h, flags=harness_lib.P2_W32_OPS, **gen)
+    assert len(a["pdw_op_ids"]) > 0
+    ctx = p3r.Context(field=field, allow_unpinned_w32_defaults=True, **FRI, **ctx_kw)
+    tp = p3r.TablePacking(**(packing or {})).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+    dev, host = both_ways(ctx, wl.circuit_from_arrays(a), tp, wl.circuit_inputs_from_arrays(a), W32_ARRAYS)
+    assert "p2w_input_values" in host[2] and len(host[2]["p2w_input_values"])
+    check_same(dev, host, (field, log_h, packing))
+    ctx.close()
+
+
+@pytest.mark.parametrize("field,seeds,n_ops", [("koala-bear", range(600, 640), 400), ("baby-bear", range(700, 710), 400),
+                                               ("koala-bear", range(800, 804), 3000)])
+def test_device_preparation_on_random_circuits_with_width32_rows(field, seeds, n_ops):
+    """Sponge and Merkle rows of the width-32 table in any order, rows that wait for witnesses of later levels (a successor
+    that opens its own segment, the other successor of the same row joining instead), outputs that land on set witnesses."""
+    import plonky3_recursion_amd as p3r
+    import plonky3_recursion_amd.prover as pv
+    ctx = p3r.Context(field=field, allow_unpinned_w32_defaults=True, **FRI)
+    P = oracle_lib.MODULUS[field]
+    saw = 0
+    for k, seed in enumerate(seeds):
+        tp = p3r.TablePacking(public_lanes=1 + k % 3, alu_lanes=1 + k % 4, horner_packed_steps=2 + k % 4,
+                              recompose_lanes=1 + k % 2).with_fri_params(FRI["log_final_poly_len"], FRI["log_blowup"])
+        c, i = circuit_fuzz.random_circuit(seed, n_ops=n_ops, modulus=P, w32=True)
+        circuit = p3r.Circuit(c.witness_count, c.ops, c.ext, c.public_rows, c.private_rows, c.rewrite.reshape(-1, 2))
+        inputs = p3r.CircuitInputs(i.public_values.reshape(-1, 4), i.private_values.reshape(-1, 4), i.pd_op_ids,
+                                   i.pd_siblings.reshape(-1, 8), i.pdw_op_ids, i.pdw_siblings.reshape(-1, 24))
+        res = []
+        for host in (False, True):
+            if host:
+                os.environ["P3R_PREP_HOST"] = "1"
+            try:
+                pc = p3r.PreparedCircuit(ctx, circuit, tp)
+            finally:
+                os.environ.pop("P3R_PREP_HOST", None)
+            assert pc.prepared_on_device == (not host), seed
+            r = pc.run(inputs)
+            cpd = pc.circuit_prover_data
+            res.append((cpd.preprocessed_commitment.copy(), pc.levels, list(cpd.table_heights),
+                        {n: r.download(n) for n in W32_ARRAYS if cpd.rows[pv.TRACES_ARRAYS[n][1]]}))
+            r.free()
+            pc.free()
+        dev, host = res
+        saw += int("p2w_input_values" in host[3])
+        assert np.array_equal(dev[0], host[0]), (seed, "preprocessed commitment")
+        assert dev[1] == host[1] and dev[2] == host[2], (seed, dev[1], host[1], dev[2], host[2])
+        for n in host[3]:
+            assert np.array_equal(dev[3][n], host[3][n]), (seed, n)
+    assert saw > len(seeds) // 2
     ctx.close()
 
 

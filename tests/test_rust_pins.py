@@ -506,6 +506,62 @@ def test_rust_zk_proof_is_accepted(oracle, field, key):
     print(f"{field}: upstream's ZK preprocessed commitment {'equals' if same_prep else 'differs from'} the zero-padded one here")
 
 
+# ---- the hiding MMCS (MerkleTreeHidingMmcs: recursion/tests/zk_hiding_mmcs.rs) - pins p3r_config.mmcs_salt_elems ----------
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_rust_hiding_mmcs_openings_are_accepted(oracle, field, key):
+    """A NATIVE salted tree (tools/rust_pin: hiding_mmcs()): every opening `(salts, siblings)` must be accepted by
+    p3r_mmcs_verify_salted and by the oracle's verify - leaf preimage `[row | salt]` per matrix of a height class in matrix
+    order (recursion/src/pcs/mmcs.rs:315-413), opening-proof layout (:763-790) - and refused with one salt element or one
+    opened value changed.  (The salts are the fixture's data: upstream draws them from the MMCS's own SmallRng.)"""
+    import plonky3_recursion_amd as p3r
+    g = load(f"rust_hiding_mmcs_{key}.json")
+    rc = np.array(g["rc"], dtype=np.uint32)
+    S = g["salt_elems"]
+    cfg, keep = p3r.make_config(field, poseidon2_rc=rc, cap_height=g["cap_height"], mmcs_salt_elems=S, zk_seed=1)
+    dims = [(m["height"], m["width"]) for m in g["matrices"]]
+    cap = np.array(g["root"], dtype=np.uint32)
+    for o in g["openings"]:
+        opened = np.array([v for row in o["opened_values"] for v in row], dtype=np.uint32)
+        salts = np.array(o["salts"], dtype=np.uint32).reshape(len(dims), S)
+        proof = np.array(o["siblings"], dtype=np.uint32).reshape(-1, 8)
+        p3r.mmcs_verify(cfg, cap, dims, o["index"], opened, proof, salts=salts)
+        # the oracle: a hiding commitment of [M0, M1] with salts [S0, S1] is the plain one of [M0 | S0], [M1 | S1]
+        wide = np.concatenate([np.concatenate([np.array(r, dtype=np.uint32), salts[k]]) for k, r in enumerate(o["opened_values"])])
+        oracle.verify(field, cap, [(h, w + S) for h, w in dims], o["index"], wide, proof, rc=rc)
+        bad = salts.copy()
+        bad[1, S - 1] ^= 1
+        with pytest.raises(p3r.P3rError):
+            p3r.mmcs_verify(cfg, cap, dims, o["index"], opened, proof, salts=bad)
+        bad = opened.copy()
+        bad[0] ^= 1
+        with pytest.raises(p3r.P3rError):
+            p3r.mmcs_verify(cfg, cap, dims, o["index"], bad, proof, salts=salts)
+
+
+@pytest.mark.parametrize("field,key", FIELDS)
+def test_rust_hiding_mmcs_proof_is_accepted(oracle, field, key):
+    """A NATIVE proof under HidingFriPcs WITH the hiding MMCS for the input and the commit-phase trees (tools/rust_pin:
+    fibonacci_hiding_layer(), the configuration of recursion/tests/zk_hiding_mmcs.rs:41-58,120-131): the wire format must
+    round-trip under P3R_PROOF_ZK | P3R_PROOF_SALTED, p3r_verify_batch under zk = 1, mmcs_salt_elems = 4 and the oracle's
+    verify_batch must accept it, and the configuration without salts must refuse it."""
+    import layer_lib
+    import plonky3_recursion_amd as p3r
+    g = load(f"rust_fibonacci_hiding_layer_{key}.json")
+    rc = np.array(g["rc"], dtype=np.uint32)
+    inner, outer = bytes.fromhex(g["batch_proof_postcard_hex"]), bytes.fromhex(g["batch_stark_proof_postcard_hex"])
+    zk = dict(zk=1, num_random_codewords=g["zk"]["num_random_codewords"], mmcs_salt_elems=g["mmcs_salt_elems"])
+    proof = p3r.BatchStarkProof.from_postcard(outer, field, zk=True, salted=True)
+    assert proof.proof == inner and proof.to_postcard() == outer, "BatchStarkProof postcard layout under the hiding MMCS"
+    assert list(proof.degree_bits) == g["degree_bits"]
+    cfg, keep = p3r.make_config(field, poseidon2_rc=rc, zk_seed=1, **g["fri"], **zk)
+    p3r.verify_all_tables(cfg, proof)
+    cfg0, keep0 = p3r.make_config(field, poseidon2_rc=rc, zk=1, num_random_codewords=g["zk"]["num_random_codewords"], **g["fri"])
+    with pytest.raises(p3r.P3rError):
+        p3r.verify_all_tables(cfg0, p3r.BatchStarkProof.from_postcard(outer, field, zk=True, salted=True))
+    prm = layer_lib.params(zk_key=(1, 0, 0, 0, 0, 0, 0, 0), **g["fri"], **zk)
+    layer_lib.oracle_verify_statement(oracle, field, prm, proof.airs(), proof.preprocessed_commitment, inner, rc=rc)
+
+
 @pytest.mark.parametrize("field,key", FIELDS)
 def test_rust_accepts_our_zk_proof(field, key):
     """The other direction: `cargo run -- zk-accept` (tools/rust_pin) ran the reference's verify_all_tables on the ZK proof

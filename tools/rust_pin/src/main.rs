@@ -47,6 +47,11 @@
 //!       is randomised and the prover side of HidingFriPcs draws from a sequential RNG, so nothing here pins bytes: the
 //!       fixture feeds a NATIVE ZK proof to this repo's verifiers (tests/test_rust_pins.py::test_rust_zk_proof_is_accepted:
 //!       p3r_verify_batch under p3r_config.zk = 1 and the oracle's verify_batch must both accept it).
+//!   tests/golden/rust_hiding_mmcs_<field>.json, tests/golden/rust_fibonacci_hiding_layer_<field>.json
+//!       MerkleTreeHidingMmcs (recursion/tests/zk_hiding_mmcs.rs: SALT_ELEMS = 4, SmallRng::seed_from_u64(11)): a native salted
+//!       tree with every opening `(salts, siblings)`, and the Fibonacci layer under HidingFriPcs + the hiding MMCS for input and
+//!       commit-phase trees.  Pins p3r_config.mmcs_salt_elems: leaf preimage `[row | salt]`, the opening-proof layout, the
+//!       verifier (tests/test_rust_pins.py::test_rust_hiding_mmcs_*).
 //!   `cargo run --release -- zk-accept`  ->  tests/golden/rust_zk_acceptance.json
 //!       the other direction: reads tests/golden/zk_fibonacci_layer_for_rust_<field>.json (a ZK proof made by THIS repo's
 //!       prover, tools/gen_zk_fixture.py - regenerate it after the first run so that it uses upstream's round constants),
@@ -73,7 +78,7 @@ use rand::rngs::SmallRng;
 use p3_matrix::Matrix;
 use p3_matrix::bitrev::BitReversibleMatrix;
 use p3_matrix::dense::RowMajorMatrix;
-use p3_merkle_tree::MerkleTreeMmcs;
+use p3_merkle_tree::{MerkleTreeHidingMmcs, MerkleTreeMmcs};
 use p3_symmetric::{CryptographicHasher, PaddingFreeSponge, Permutation, PseudoCompressionFunction, TruncatedPermutation};
 use p3_uni_stark::StarkConfig;
 use serde_json::{Value, json};
@@ -94,6 +99,9 @@ const FIB_N: usize = 100;
 // create_config_zk (recursion/examples/common/mod.rs:536-542)
 const ZK_CODEWORDS: usize = 2;
 const ZK_SEED: u64 = 1;
+// the hiding MMCS of recursion/tests/zk_hiding_mmcs.rs:41-58 (p3r_config.mmcs_salt_elems)
+const SALT_ELEMS: usize = 4;
+const SALT_SEED: u64 = 11;
 
 fn u32s<F: PrimeField32>(xs: &[F]) -> Vec<u32> {
     xs.iter().map(|x| x.as_canonical_u32()).collect()
@@ -328,6 +336,110 @@ macro_rules! field_module {
                             "log_final_poly_len": LOG_FINAL_POLY_LEN, "commit_pow_bits": COMMIT_POW_BITS,
                             "query_pow_bits": QUERY_POW_BITS, "num_queries": NUM_QUERIES},
                     "zk": {"num_random_codewords": ZK_CODEWORDS, "seed": ZK_SEED},
+                    "packing": {"public_lanes": 1, "alu_lanes": 1, "horner_packed_steps": 2},
+                    "rc": round_constants(),
+                    "degree_bits": ext_degrees,
+                    "batch_stark_proof_postcard_hex": hex(&outer),
+                    "batch_proof_postcard_hex": hex(&inner),
+                })
+            }
+
+            // ---- the hiding MMCS: MerkleTreeHidingMmcs for the input trees AND the FRI commit-phase trees
+            // (recursion/tests/zk_hiding_mmcs.rs:41-58,120-131: "the upstream-recommended ZK setup")
+            pub type HidingValMmcs =
+                MerkleTreeHidingMmcs<<F as Field>::Packing, <F as Field>::Packing, MyHash, MyCompress, SmallRng, 2, DIGEST, SALT_ELEMS>;
+            pub type HidingChallengeMmcs = ExtensionMmcs<F, Challenge, HidingValMmcs>;
+            pub type MyPcsHiding = HidingFriPcs<F, Dft, HidingValMmcs, HidingChallengeMmcs, SmallRng>;
+            pub type MyConfigHiding = StarkConfig<MyPcsHiding, Challenge, Challenger>;
+            pub fn config_hiding(salt_seed: u64, seed: u64) -> MyConfigHiding {
+                let perm: Perm = $default_perm();
+                let hash = MyHash::new(perm.clone());
+                let compress = MyCompress::new(perm.clone());
+                let val_mmcs = HidingValMmcs::new(hash, compress, CAP_HEIGHT, SmallRng::seed_from_u64(salt_seed));
+                let challenge_mmcs = HidingChallengeMmcs::new(val_mmcs.clone());
+                let fri_params = FriParameters {
+                    max_log_arity: MAX_LOG_ARITY,
+                    log_blowup: LOG_BLOWUP,
+                    log_final_poly_len: LOG_FINAL_POLY_LEN,
+                    num_queries: NUM_QUERIES,
+                    commit_proof_of_work_bits: COMMIT_POW_BITS,
+                    query_proof_of_work_bits: QUERY_POW_BITS,
+                    mmcs: challenge_mmcs,
+                };
+                let pcs = MyPcsHiding::new(Dft::default(), val_mmcs, fri_params, ZK_CODEWORDS, SmallRng::seed_from_u64(seed));
+                MyConfigHiding::new(pcs, Challenger::new(perm))
+            }
+
+            /// A NATIVE hiding tree over two deterministic matrices of two heights (8 x 3, 4 x 5): root, and for every leaf index
+            /// the opened rows with the opening proof `(salts, siblings)` (recursion/src/pcs/mmcs.rs:763-790).  The salts come
+            /// from the MMCS's own SmallRng, so they are DATA of the fixture: p3r_mmcs_verify_salted and the oracle's verify
+            /// must accept every opening - which pins the leaf preimage `[row | salt]` per matrix of a height class, in
+            /// matrix order (mmcs.rs:315-413) - and reject it with one salt element changed.
+            pub fn hiding_mmcs() -> Value {
+                let perm: Perm = $default_perm();
+                let mmcs = HidingValMmcs::new(MyHash::new(perm.clone()), MyCompress::new(perm), CAP_HEIGHT, SmallRng::seed_from_u64(SALT_SEED));
+                let m0 = RowMajorMatrix::new((0..24u32).map(|i| F::from_u32(3 * i + 1)).collect::<Vec<_>>(), 3);
+                let m1 = RowMajorMatrix::new((0..20u32).map(|i| F::from_u32(7 * i + 2)).collect::<Vec<_>>(), 5);
+                let dims = vec![m0.dimensions(), m1.dimensions()];
+                let (commit, data) = mmcs.commit(vec![m0.clone(), m1.clone()]);
+                let root: Vec<Vec<u32>> = commit.clone().into_iter().map(|d| u32s(&d)).collect();
+                let mut openings = Vec::new();
+                for index in 0..8usize {
+                    let opening = mmcs.open_batch(index, &data);
+                    mmcs.verify_batch(&commit, &dims, index, (&opening).into()).unwrap();
+                    let (salts, siblings) = &opening.opening_proof;
+                    openings.push(json!({
+                        "index": index,
+                        "opened_values": opening.opened_values.iter().map(|r| u32s(r)).collect::<Vec<_>>(),
+                        "salts": salts.iter().map(|r| u32s(r)).collect::<Vec<_>>(),
+                        "siblings": siblings.iter().map(|d| u32s(d)).collect::<Vec<_>>(),
+                    }));
+                }
+                json!({"field": $key, "salt_elems": SALT_ELEMS, "cap_height": CAP_HEIGHT, "rc": round_constants(),
+                       "matrices": [{"height": 8, "width": 3, "values": u32s(&m0.values)}, {"height": 4, "width": 5, "values": u32s(&m1.values)}],
+                       "root": root, "openings": openings})
+            }
+
+            /// The Fibonacci layer proved under HidingFriPcs WITH the hiding MMCS (every input tree and every commit-phase tree
+            /// salted; opening proofs carry the salts): the proof this repo's verifiers must accept under
+            /// p3r_config.zk = 1, mmcs_salt_elems = 4 (tests/test_rust_pins.py::test_rust_hiding_mmcs_proof_is_accepted).
+            pub fn fibonacci_hiding_layer() -> Value {
+                let mut builder = CircuitBuilder::<Challenge>::new();
+                let expected = builder.alloc_public_input("expected_result");
+                let mut a = builder.alloc_const(Challenge::ZERO, "F(0)");
+                let mut b = builder.alloc_const(Challenge::ONE, "F(1)");
+                for _ in 2..=FIB_N {
+                    let next = builder.add(a, b);
+                    a = b;
+                    b = next;
+                }
+                builder.connect(b, expected);
+                let circuit = builder.build().unwrap();
+                let (mut fa, mut fb) = (F::ZERO, F::ONE);
+                for _ in 2..=FIB_N { let t = fa + fb; fa = fb; fb = t; }
+                let packing = TablePacking::new(1, 1).with_fri_params(LOG_FINAL_POLY_LEN, LOG_BLOWUP);
+                let cfg = config_hiding(SALT_SEED, ZK_SEED);
+                let (airs_degrees, primitive_columns, non_primitive_columns) =
+                    get_airs_and_degrees_with_prep::<MyConfigHiding, Challenge, 4>(&circuit, &packing, &[], &[], ConstraintProfile::Standard).unwrap();
+                let (airs, log_degrees): (Vec<_>, Vec<usize>) = airs_degrees.into_iter().unzip();
+                let ext_degrees: Vec<usize> = log_degrees.iter().map(|&d| d + cfg.is_zk()).collect();
+                let prover_data = ProverData::from_airs_and_degrees(&cfg, &airs, &ext_degrees);
+                let cpd = CircuitProverData::new(prover_data, primitive_columns, non_primitive_columns);
+                let mut runner = circuit.runner();
+                runner.set_public_inputs(&[Challenge::from(fb)]).unwrap();
+                let traces = runner.run().unwrap();
+                let prover = BatchStarkProver::new(cfg).with_table_packing(packing);
+                let proof: BatchStarkProof<MyConfigHiding> = prover.prove_all_tables(&traces, &cpd).unwrap();
+                prover.verify_all_tables::<Challenge>(&proof).unwrap();
+                let outer = postcard::to_allocvec(&proof).unwrap();
+                let inner = postcard::to_allocvec(&proof.proof).unwrap();
+                json!({
+                    "field": $key, "n": FIB_N, "fib": fb.as_canonical_u32(),
+                    "fri": {"log_blowup": LOG_BLOWUP, "max_log_arity": MAX_LOG_ARITY, "cap_height": CAP_HEIGHT,
+                            "log_final_poly_len": LOG_FINAL_POLY_LEN, "commit_pow_bits": COMMIT_POW_BITS,
+                            "query_pow_bits": QUERY_POW_BITS, "num_queries": NUM_QUERIES},
+                    "zk": {"num_random_codewords": ZK_CODEWORDS, "seed": ZK_SEED},
+                    "mmcs_salt_elems": SALT_ELEMS, "salt_seed": SALT_SEED,
                     "packing": {"public_lanes": 1, "alu_lanes": 1, "horner_packed_steps": 2},
                     "rc": round_constants(),
                     "degree_bits": ext_degrees,
@@ -946,5 +1058,9 @@ fn main() {
     fs::write(format!("{golden}/rust_arity4_mmcs_koala_bear.json"), serde_json::to_string(&arity4_mmcs()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_fibonacci_zk_layer_koala_bear.json"), serde_json::to_string(&koala::fibonacci_zk_layer()).unwrap()).unwrap();
     fs::write(format!("{golden}/rust_fibonacci_zk_layer_baby_bear.json"), serde_json::to_string(&baby::fibonacci_zk_layer()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_hiding_mmcs_koala_bear.json"), serde_json::to_string(&koala::hiding_mmcs()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_hiding_mmcs_baby_bear.json"), serde_json::to_string(&baby::hiding_mmcs()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_fibonacci_hiding_layer_koala_bear.json"), serde_json::to_string(&koala::fibonacci_hiding_layer()).unwrap()).unwrap();
+    fs::write(format!("{golden}/rust_fibonacci_hiding_layer_baby_bear.json"), serde_json::to_string(&baby::fibonacci_hiding_layer()).unwrap()).unwrap();
     println!("wrote rust_arity4_layer_koala_bear.json and rust_primitives.json, rust_fibonacci_layer_*.json, rust_fibonacci_base_layer_*.json, rust_npo_layer_*.json, rust_quintic_layer_koala_bear.json and rust_quintic_challenge_layer_koala_bear.json under {golden}");
 }
