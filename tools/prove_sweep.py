@@ -126,13 +126,23 @@ def one(oracle, seed, max_log_h, min_log_h=5):
         if "zk_seed" not in kw:
             kw["zk_seed"] = rng6.getrandbits(48)
             zk_nonce = rng6.randint(0, 3)
+    # seventh stream (round 6): the CIRCUIT seam in a third of the draws - the flattened circuit prepared on the device
+    # (csrc/prep_device.hip), run by the device runner and proved in one call (p3r_prove_next_layer) instead of
+    # prove_all_tables over the generator's traces - and, in a third of the D = 4 layers that hold a width-16 table, the
+    # width-32 rows as OPS of that circuit (P3R_OP_POSEIDON2_W32_PERM: leaf sponges seeding 4-to-1 chains)
+    rng7 = random.Random(seed * 67867967 + 6)
+    via_circuit = rng7.random() < 0.33
+    if ext_degree == 4 and not (flags & harness_lib.NO_POSEIDON2) and rng7.random() < 0.33:
+        flags |= harness_lib.P2_W32_OPS
+    if via_circuit and (flags & harness_lib.P2_W32):
+        flags |= harness_lib.P2_W32_OPS      # (a table-only width-32 layer has no circuit that fills it)
     coeff = bool(flags & harness_lib.RECOMPOSE_COEFF)
     arrs = harness_lib.generate(field, log_h, seed=seed, flags=flags, ext_degree=ext_degree, **gen)
     packing_o = dict(packing, ext_degree=ext_degree, recompose_coeff_lookups=int(coeff))
     if kw.get("fri_log_arities") == "fitting":
         kw["fri_log_arities"] = fitting_schedule(rng, oracle, field, arrs, kw, packing_o)
     prm = layer_lib.params(zk_nonce=zk_nonce, **kw)
-    desc = f"seed {seed}: {field} D={ext_degree} DC={challenge_degree} flags={flags} 2^{log_h} {kw} {packing} {gen}"
+    desc = f"seed {seed}: {field} D={ext_degree} DC={challenge_degree} flags={flags}{' via-circuit' if via_circuit else ''} 2^{log_h} {kw} {packing} {gen}"
     L = layer_lib.OracleLayer(oracle, field, arrs, prm, packing=dict(packing_o))
     try:
         want_cap, want = L.prep_commit(), L.prove()
@@ -145,10 +155,18 @@ def one(oracle, seed, max_log_h, min_log_h=5):
         ctx = p3r.Context(field=field, ext_degree=ext_degree, **kw, allow_unpinned_w32_defaults=True)
         if kw.get("zk") or kw.get("mmcs_salt_elems"):
             ctx.zk_nonce = zk_nonce   # (zk_seed makes the context deterministic: the oracle is given the same key and nonce)
-        cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree, recompose_coeff_lookups=coeff),
-                                         pv.FriRecursionBackend(), pv.ProveNextLayerParams(table_packing=tp))
-        cpd = cache.circuit_prover_data
-        out = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs, ext_degree=ext_degree), cpd)
+        backend = pv.FriRecursionBackendD5() if ext_degree == 5 else pv.FriRecursionBackend()
+        if via_circuit:
+            cache = pv.build_next_layer_prep(ctx, wl.circuit_from_arrays(arrs), backend, pv.ProveNextLayerParams(table_packing=tp))
+            assert cache.prepared_circuit.prepared_on_device, "device preparation handed over: " + desc
+            cpd = cache.circuit_prover_data
+            out = pv.prove_next_layer(pv.RecursionInput(circuit_inputs=wl.circuit_inputs_from_arrays(arrs, ext_degree)), ctx, backend,
+                                      pv.ProveNextLayerParams(table_packing=tp), prep=cache).proof
+        else:
+            cache = pv.build_next_layer_prep(ctx, wl.circuit_prep_from_arrays(arrs, ext_degree=ext_degree, recompose_coeff_lookups=coeff),
+                                             backend, pv.ProveNextLayerParams(table_packing=tp))
+            cpd = cache.circuit_prover_data
+            out = cache.prover.prove_all_tables(wl.traces_from_arrays(arrs, ext_degree=ext_degree), cpd)
     except p3r.P3rError as e:
         assert want_cap is None, "prover refused (%s) what the oracle proves: %s" % (e, desc)
         if ctx is not None:
@@ -159,7 +177,10 @@ def one(oracle, seed, max_log_h, min_log_h=5):
     assert out.proof == want, "proof bytes: " + desc
     L.verify(out.proof)
     cache.prover.verify_all_tables(out)
-    cpd.free()
+    if cache.prepared_circuit is not None:
+        cache.prepared_circuit.free()
+    else:
+        cpd.free()
     ctx.close()
     return desc, len(want)
 
