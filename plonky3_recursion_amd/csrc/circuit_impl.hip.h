@@ -867,13 +867,13 @@ std::unique_ptr<p3r_dinputs> circuit_inputs_upload(p3r_ctx* ctx, const p3r_circu
                           const DevBuf& row_of_id, const DevBuf& other_row_of_id, DevBuf& sib, DevBuf& slot, const char* what) {
     sib = upload_mont<PP>(ctx, sib_host, n_pd * per_op, what);
     slot.alloc(std::max<size_t>(n_rows, 1));
-    P3R_HIP(hipMemsetAsync(slot.p, 0xFF, std::max<size_t>(n_rows, 1) * 4, ctx->stream));  // -1: no private data
+    P3R_HIP(fill_async(ctx->stream, slot.p, 0xFF, std::max<size_t>(n_rows, 1) * 4));  // -1: no private data
     if (!n_pd) return;
     if (!row_of_id.p)   // the circuit has no permutation of this width at all
       fail(P3R_EINVAL, "NonPrimitiveOpIdOutOfRange { op_id: %u, max_ops: %zu } (%s)", ids_host[0], C->n_op_ids, what);
     DevBuf ids(n_pd), err(1);
     P3R_HIP(hipMemcpyAsync(ids.p, ids_host, n_pd * 4, hipMemcpyHostToDevice, ctx->stream));
-    P3R_HIP(hipMemsetAsync(err.p, 0xFF, 4, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, err.p, 0xFF, 4));
     hipLaunchKernelGGL(k_pd_claim, dim3(blocks_for(n_pd)), dim3(kBlock), 0, ctx->stream, ids.p, n_pd, row_of_id.p, C->n_op_ids, slot.p);
     hipLaunchKernelGGL(k_pd_check, dim3(blocks_for(n_pd)), dim3(kBlock), 0, ctx->stream, ids.p, n_pd, row_of_id.p, C->n_op_ids, slot.p, err.p);
     uint32_t e = 0;
@@ -930,7 +930,7 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
   DevBuf w((size_t)std::max<uint32_t>(C->witness_count, 1) * ext_d);
   DevBuf err(1), p2_out(std::max<size_t>(n_p2, 1) * 16);
   const DevBuf &d_pub = in->pub, &d_priv = in->priv, &d_sib = in->sib, &d_slot = in->slot;
-  P3R_HIP(hipMemsetAsync(err.p, 0xFF, 4, ctx->stream));
+  P3R_HIP(fill_async(ctx->stream, err.p, 0xFF, 4));
   if (C->n_public_rows)
     hipLaunchKernelGGL(k_run_scatter<PP>, dim3(blocks_for(C->n_public_rows * ext_d)), dim3(kBlock), 0, ctx->stream,
                        C->d_public_rows.p, d_pub.p, C->n_public_rows, w.p, ext_d);
@@ -940,11 +940,11 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
   // trace buffers
   T->const_values.alloc(std::max<size_t>(cn.n_const * ext_d, 1));
   if (cn.n_const)
-    P3R_HIP(hipMemcpyAsync(T->const_values.p, C->d_const_values.p, cn.n_const * ext_d * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    P3R_HIP(copy_async_kernel(ctx->stream, T->const_values.p, C->d_const_values.p, cn.n_const * ext_d * 4));
   T->public_values.alloc(std::max<size_t>(cn.n_public * ext_d, 1));
   T->alu_values.alloc(std::max<size_t>(cn.n_alu * 4 * ext_d, 1));
   if (S.n_alu_records == 0)  // the dummy op of an empty table; otherwise every record is written by its op
-    P3R_HIP(hipMemsetAsync(T->alu_values.p, 0, T->alu_values.n * 4, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, T->alu_values.p, 0, T->alu_values.n * 4));
   T->recompose_values.alloc(std::max<size_t>((cn.n_recompose + cn.n_recompose_coeff) * ext_d, 1));
   T->n_recompose_coeff = cn.n_recompose_coeff;
   uint32_t* p2_inputs = nullptr; uint8_t* p2_flags = nullptr; uint32_t* p2_seed = nullptr;
@@ -955,13 +955,13 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     auto d = std::make_unique<p3r_p2_dev>();
     d->n = p2_h;
     d->inputs = dmat_alloc(p2_h, P2_WIDTH);
-    P3R_HIP(hipMemsetAsync(d->inputs->d, 0, p2_h * P2_WIDTH * 4, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, d->inputs->d, 0, p2_h * P2_WIDTH * 4));
     d->flags.alloc((3 * p2_h + 3) / 4 + 1);
     p2_flags = reinterpret_cast<uint8_t*>(d->flags.p);
-    P3R_HIP(hipMemsetAsync(p2_flags, 1, p2_h, ctx->stream));
-    P3R_HIP(hipMemsetAsync(p2_flags + p2_h, 0, 2 * p2_h, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, p2_flags, 1, p2_h));
+    P3R_HIP(fill_async(ctx->stream, p2_flags + p2_h, 0, 2 * p2_h));
     d->seed.alloc(p2_h);
-    P3R_HIP(hipMemsetAsync(d->seed.p, 0, p2_h * 4, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, d->seed.p, 0, p2_h * 4));
     p2_inputs = d->inputs->d; p2_seed = d->seed.p;
     T->p2 = std::move(d);
   }
@@ -974,13 +974,13 @@ std::unique_ptr<p3r_dtraces> circuit_run(p3r_ctx* ctx, const p3r_circuit* C, con
     auto d = std::make_unique<p3r_p2_dev>();
     d->n = p2w_h;
     d->inputs = dmat_alloc(p2w_h, P2W_WIDTH);
-    P3R_HIP(hipMemsetAsync(d->inputs->d, 0, p2w_h * P2W_WIDTH * 4, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, d->inputs->d, 0, p2w_h * P2W_WIDTH * 4));
     d->flags.alloc(p2w_h + 1);
     p2w_flags = reinterpret_cast<uint8_t*>(d->flags.p);
-    P3R_HIP(hipMemsetAsync(p2w_flags, 1, p2w_h, ctx->stream));
-    P3R_HIP(hipMemsetAsync(p2w_flags + p2w_h, 0, 3 * p2w_h, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, p2w_flags, 1, p2w_h));
+    P3R_HIP(fill_async(ctx->stream, p2w_flags + p2w_h, 0, 3 * p2w_h));
     d->seed.alloc(p2w_h);
-    P3R_HIP(hipMemsetAsync(d->seed.p, 0, p2w_h * 4, ctx->stream));   // no accumulator witness on this table
+    P3R_HIP(fill_async(ctx->stream, d->seed.p, 0, p2w_h * 4));   // no accumulator witness on this table
     p2w_inputs = d->inputs->d;
     T->p2w = std::move(d);
   }

@@ -181,11 +181,95 @@ static inline const char* tuning_knob(const char* name) {
 #endif
 }
 
+// Host-side timeline of one proof (knobs build, P3R_HOST_TIMELINE=1): what the HOST does between a transcript round trip
+// and the next launch - the part of a proof the GPU spends idle (tools/host_gaps.py shows the gaps, this shows their cause).
+struct HostTimeline {
+  std::vector<std::pair<const char*, int64_t>> marks;
+  bool on = false;
+};
+inline HostTimeline& host_timeline() {
+  static thread_local HostTimeline t;
+  return t;
+}
+inline void host_mark(const char* tag) {
+  HostTimeline& t = host_timeline();
+  if (t.on) t.marks.emplace_back(tag, (int64_t)std::chrono::steady_clock::now().time_since_epoch().count());
+}
+inline void host_timeline_begin() {
+  HostTimeline& t = host_timeline();
+  t.on = tuning_knob("P3R_HOST_TIMELINE") != nullptr;
+  t.marks.clear();
+  host_mark("begin");
+}
+inline void host_timeline_dump() {
+  HostTimeline& t = host_timeline();
+  if (!t.on || t.marks.empty()) return;
+  fprintf(stderr, "host timeline (us since begin, us since the mark before):\n");
+  for (size_t i = 0; i < t.marks.size(); ++i)
+    fprintf(stderr, "  %9.1f %8.1f  %s\n", (t.marks[i].second - t.marks[0].second) / 1e3,
+            i ? (t.marks[i].second - t.marks[i - 1].second) / 1e3 : 0.0, t.marks[i].first);
+  t.marks.clear();
+}
+
 // Blocking host->device / device->host copy ordered on the ctx stream.
 inline hipError_t copy_sync(hipStream_t s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, s);
   if (e != hipSuccess) return e;
   return hipStreamSynchronize(s);
+}
+
+// Fills and small copies of the proof path as kernels of our own instead of hipMemsetAsync / hipMemcpyAsync: the runtime's
+// blit path costs more on the host per call than a kernel launch, which shows where the GPU has nothing queued - the first
+// operation after a transcript round trip, the dozen memsets that open a circuit run.  Same-box A/B
+// (profiles/r06/host_gaps.txt): headline 27.16 -> 27.07 ms, 2^16-row layer 4.09 -> 3.92 ms.  P3R_RUNTIME_COPIES=1 (knobs
+// build) restores the runtime calls.
+static __global__ void __launch_bounds__(256) k_fill_bytes(uint8_t* __restrict__ p, uint32_t pattern, size_t n) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+  const size_t mis = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15, head = mis < n ? mis : n;
+  if (tid < head) p[tid] = (uint8_t)pattern;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  const size_t nq = (n - head) >> 4;
+  for (size_t i = tid; i < nq; i += nt) q[i] = make_uint4(pattern, pattern, pattern, pattern);
+  const size_t done = head + (nq << 4);
+  if (tid < n - done) p[done + tid] = (uint8_t)pattern;
+}
+// W: bytes per element (16 / 4 / 1, what the alignment of both ends allows)
+template <class T>
+static __global__ void __launch_bounds__(256) k_copy_small(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t n) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+  const size_t nq = n / sizeof(T);
+  T* d = reinterpret_cast<T*>(dst);
+  const T* q = reinterpret_cast<const T*>(src);
+  for (size_t i = tid; i < nq; i += nt) d[i] = q[i];
+  const size_t done = nq * sizeof(T);
+  if (tid < n - done) dst[done + tid] = src[done + tid];
+}
+inline bool runtime_copies() {
+  static const bool on = tuning_knob("P3R_RUNTIME_COPIES") != nullptr;
+  return on;
+}
+inline hipError_t fill_async(hipStream_t s, void* p, int byte, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  host_mark("launch: fill");
+  if (runtime_copies()) return hipMemsetAsync(p, byte, bytes, s);
+  const uint32_t b = (uint32_t)byte & 0xFFu, pattern = b * 0x01010101u;
+  const size_t blocks = std::min<size_t>((bytes / 16 + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(k_fill_bytes, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint8_t*>(p), pattern, bytes);
+  return hipGetLastError();
+}
+// device-visible source (device memory, or pinned host memory by its device pointer) -> device memory
+inline hipError_t copy_async_kernel(hipStream_t s, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  host_mark("launch: copy");
+  const uintptr_t both = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src);
+  const size_t w = (both & 15) == 0 ? 16 : (both & 3) == 0 ? 4 : 1;
+  const size_t blocks = std::min<size_t>((bytes / w + 255) / 256 + 1, 4096);
+  uint8_t* d = static_cast<uint8_t*>(dst);
+  const uint8_t* q = static_cast<const uint8_t*>(src);
+  if (w == 16) hipLaunchKernelGGL(k_copy_small<uint4>, dim3((unsigned)blocks), dim3(256), 0, s, d, q, bytes);
+  else if (w == 4) hipLaunchKernelGGL(k_copy_small<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, d, q, bytes);
+  else hipLaunchKernelGGL(k_copy_small<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, d, q, bytes);
+  return hipGetLastError();
 }
 
 // Pinned staging ring for small host->device uploads (pointer tables, challenge powers, job
@@ -195,6 +279,7 @@ inline hipError_t copy_sync(hipStream_t s, void* dst, const void* src, size_t by
 struct HostStage {
   static constexpr size_t kBytes = size_t(4) << 20;  // the largest client is the query gather list (~0.4 MB)
   char* base = nullptr;
+  char* base_dev = nullptr;  // the ring as the device sees it (the upload kernel reads it in place)
   size_t off = 0;
   HostStage() = default;
   HostStage(const HostStage&) = delete;
@@ -206,7 +291,9 @@ struct HostStage {
   hipError_t ensure() {
     if (base) return hipSuccess;
     off = kWordBytes;
-    return hipHostMalloc(reinterpret_cast<void**>(&base), kBytes, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&base), kBytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return e;
+    return hipHostGetDevicePointer(reinterpret_cast<void**>(&base_dev), base, 0);
   }
   // A few pinned words for small device->host results that are fetched asynchronously and read
   // after a later synchronisation of the stream (the circuit run's error word).
@@ -229,7 +316,9 @@ struct HostStage {
       off = kWordBytes;
     }
     std::memcpy(base + off, src, bytes);
-    hipError_t e = hipMemcpyAsync(dst, base + off, bytes, hipMemcpyHostToDevice, s);
+    // (the launch publishes the host's stores: the ring is coherent memory, read over the link by one small kernel)
+    hipError_t e = runtime_copies() ? hipMemcpyAsync(dst, base + off, bytes, hipMemcpyHostToDevice, s)
+                                    : copy_async_kernel(s, dst, base_dev + off, bytes);
     off += need;
     return e;
   }
@@ -281,6 +370,19 @@ struct HostPost {
   uint32_t* host = nullptr;
   uint32_t* dev = nullptr;
   uint32_t seq = 0;
+  // how long the k-th fetch of a proof waited the last time (see post()); begin_proof() resets k and, when the proof's
+  // shape is another one, the predictions
+  static constexpr int kSlots = 48;
+  int slot = 0;
+  bool in_proof = false;   // fetches outside a proof (commit / open API calls, preparation) are not predicted
+  uint64_t shape = 0;
+  int64_t expect_ns[kSlots] = {};
+  void begin_proof(uint64_t shape_key) {
+    slot = 0;
+    in_proof = true;
+    if (shape_key != shape) { shape = shape_key; std::fill(expect_ns, expect_ns + kSlots, 0); }
+  }
+  void end_proof() { in_proof = false; }
   HostPost() = default;
   HostPost(const HostPost&) = delete;
   HostPost& operator=(const HostPost&) = delete;
@@ -312,12 +414,30 @@ struct HostPost {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     volatile uint32_t* flag = host + kWords;
+    // How to wait.  The store normally lands within microseconds (small layers: the host spins).  A 2^20-row proof waits
+    // 3 - 15 ms per round trip; a thread that sleeps through that in short naps is woken from an idle core when the result
+    // arrives, and the GPU sits idle for the 50 - 100 us that takes - six times per proof (profiles/r06/host_gaps.txt).
+    // The k-th round trip of a proof takes what it took in the proof before (same shape, same kernels): sleep through
+    // most of THAT, then poll awake.  A wait that outlasts its prediction (another shape, sibling provers on the GPU)
+    // falls back to naps; the first proof of a shape has no prediction and naps as before.
+    static const int mode = tuning_knob("P3R_POST_MODE") ? atoi(tuning_knob("P3R_POST_MODE")) : 0;  // 1: naps only, 2: spin only
+    const int sl = slot < kSlots ? slot : kSlots - 1;
+    if (in_proof) ++slot;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed_ns = [&] { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); };
+    const int64_t expect = mode == 0 && in_proof ? expect_ns[sl] : 0;
+    if (expect > 400000) {
+      // asleep for the first three quarters (in pieces, so that a result that comes early is not slept through for long)
+      const int64_t until = expect - std::max<int64_t>(expect / 4, 200000);
+      for (int64_t now = elapsed_ns(); now < until && *flag != seq; now = elapsed_ns())
+        std::this_thread::sleep_for(std::chrono::nanoseconds(std::min<int64_t>(until - now, 500000)));
+    }
+    const int64_t awake_until = expect > 400000 ? expect + expect / 2 + 500000 : 0;   // then: naps
     for (uint64_t spins = 0;; ++spins) {
       if (*flag == seq) break;
-      // the store normally lands within a few microseconds; past ~50 us of polling there are kernels queued ahead
-      // (large layers, or sibling provers on the same GPU): stop burning the core - yield, then sleep in short naps
-      if (spins > (uint64_t(1) << 14) && (spins & 0x3F) == 0x3F) {
-        if (spins > (uint64_t(1) << 17)) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      if (mode != 2 && spins > (uint64_t(1) << 14) && (spins & 0x3F) == 0x3F) {
+        if (awake_until && elapsed_ns() < awake_until) std::this_thread::yield();
+        else if (spins > (uint64_t(1) << 17)) std::this_thread::sleep_for(std::chrono::microseconds(20));
         else std::this_thread::yield();
       }
       if ((spins & 0xFFF) == 0xFFF) {
@@ -330,6 +450,7 @@ struct HostPost {
         }
       }
     }
+    if (in_proof) expect_ns[sl] = elapsed_ns();
     std::atomic_thread_fence(std::memory_order_acquire);
     return hipSuccess;
   }
@@ -476,7 +597,9 @@ inline hipError_t fetch_small(p3r_ctx* ctx, const uint32_t* src, size_t words, u
   if (words == 0) return hipSuccess;
   if (p3r::HostPost::enabled() && words <= p3r::HostPost::kWords) {
     const uint32_t* got = nullptr;
+    p3r::host_mark("fetch: posted, waiting for the GPU");
     hipError_t e = ctx->post.post(ctx->stream, src, words, &got);
+    p3r::host_mark("fetch: arrived");
     if (e != hipSuccess) return e;
     std::memcpy(dst, got, words * 4);
     return hipSuccess;

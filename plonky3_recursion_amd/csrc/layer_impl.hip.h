@@ -596,7 +596,7 @@ std::vector<std::unique_ptr<p3r_dmat>> build_main_traces(p3r_ctx* ctx, const p3r
     const int lanes = (int)L->alu_lanes, k = (int)L->horner_k;
     const int width = (lanes * 4 + (k - 1) / 2 + 2 * (k - 1) + 1) * D;
     m[2] = dmat_alloc(L->h_alu, (size_t)width);
-    P3R_HIP(hipMemsetAsync(m[2]->d, 0, L->h_alu * (size_t)width * 4, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, m[2]->d, 0, L->h_alu * (size_t)width * 4));
     ProfScope ps(ctx, "alu_trace");
     const auto* plan = reinterpret_cast<const AluPlanEntry*>(L->alu_plan.p);
     const uint32_t w_mont = ext_degree_is_binomial_generic((uint32_t)D) ? Fp<PP>::from_canonical(ctx->cfg.ext_w).v : 0u;

@@ -371,7 +371,7 @@ void mmcs_commit4(p3r_ctx* ctx, p3r_tree* tree, uint32_t* cap_out) {
   const size_t n0 = mmcs4_padded_len(hmax);
   tree->layers.emplace_back(P2_DIGEST * n0);
   tree->layer_n.push_back(n0);
-  if (n0 != hmax) P3R_HIP(hipMemsetAsync(tree->layers[0].p, 0, P2_DIGEST * n0 * 4, ctx->stream));
+  if (n0 != hmax) P3R_HIP(fill_async(ctx->stream, tree->layers[0].p, 0, P2_DIGEST * n0 * 4));
   std::map<size_t, DevBuf> inject;
   {
     std::vector<std::vector<const p3r_dmat*>> classes;

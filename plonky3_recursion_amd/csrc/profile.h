@@ -20,6 +20,7 @@ inline void prof_clear(p3r_ctx* ctx) {
 // Stage marks: `prof_stage(ctx, "name")` closes the previous stage and opens a new one;
 // `prof_stage(ctx, nullptr)` closes the last.  No-ops unless profiling is enabled.
 inline void prof_stage(p3r_ctx* ctx, const char* name) {
+  p3r::host_mark(name ? name : "stage end");
   if (!ctx->prof_enabled) return;
   (void)hipStreamSynchronize(ctx->stream);
   const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();

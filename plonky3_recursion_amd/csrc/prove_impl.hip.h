@@ -168,7 +168,9 @@ std::unique_ptr<p3r_tree> lde_and_commit(p3r_ctx* ctx, const std::vector<LdeItem
   ldes.resize(items.size());
   std::vector<const p3r_dmat*> ptrs(items.size());
   if (!overlap) {
+    host_mark("lde: enqueue");
     auto out = coset_lde_batch<PP>(ctx, items, log_blowup);
+    host_mark("lde: enqueued; commit: enqueue");
     for (size_t i = 0; i < items.size(); ++i) { ldes[i] = std::move(out[i]); ptrs[i] = ldes[i].get(); }
     return commit_dmats<PP>(ctx, ptrs, cap_mont, nullptr, salt_round, key);
   }
@@ -234,7 +236,7 @@ Fp<PP> grind_witness(p3r_ctx* ctx, Challenger& ch, int bits) {
   // 2^(bits+10) candidates all miss with probability e^-1024; stop there instead of sweeping the field
   const uint64_t limit = std::min<uint64_t>(PP::P, (uint64_t(1) << std::min<uint32_t>(bits + 10, 31)) + batch);
   for (uint64_t base = 0; base < limit && found == 0xFFFFFFFFu; base += batch) {
-    P3R_HIP(hipMemsetAsync(res.p, 0xFF, 4, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, res.p, 0xFF, 4));
     g.base = (uint32_t)base;
     ProfScope ps(ctx, "grind");
     hipLaunchKernelGGL(k_grind<PP>, dim3(batch / kBlock), dim3(kBlock), 0, ctx->stream, g);
@@ -360,6 +362,17 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   using E = typename Chal<PP, DC>::type;
   const p3r_config& cfg = ctx->cfg;
   const int log_blowup = (int)cfg.log_blowup;
+  host_timeline_begin();
+  {
+    // the waits of this proof repeat those of the last proof of the same shape (HostPost::post)
+    uint64_t shape = 0x9E3779B97F4A7C15ull ^ ni;
+    for (size_t i = 0; i < ni; ++i) shape = (shape ^ (mains[i]->h * 31 + mains[i]->w)) * 0x100000001B3ull;
+    ctx->post.begin_proof(shape);
+  }
+  struct EndProofWaits {
+    HostPost& p;
+    ~EndProofWaits() { p.end_proof(); }
+  } end_proof_waits{ctx->post};
   if (ni != prep->airs.size()) fail(P3R_EINVAL, "%zu traces for %zu preprocessed instances", ni, prep->airs.size());
   const int p2w = p2_perm_cols<PP>() + 2;
   // ZK (HidingFriPcs): every committed matrix lives over the extended trace domain (log_e = log_n + 1) with R random
@@ -444,7 +457,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   std::unique_ptr<p3r_tree> perm_tree;
   if (any_lookup) {
     DevBuf totals(DC * ni);
-    P3R_HIP(hipMemsetAsync(totals.p, 0, 4 * DC * ni, ctx->stream));
+    P3R_HIP(fill_async(ctx->stream, totals.p, 0, 4 * DC * ni));
     // aux traces of all tables: fractions per row, then the running sum as a three-phase scan
     std::vector<LogupJob> jobs;
     std::vector<DevBuf> scratch;
@@ -979,7 +992,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         ph.tree->arity = 4;
         ph.tree->levels = mmcs4_schedule({rows});
         ph.tree->layer_n.assign(1, n_leaf);
-        if (n_leaf != rows) P3R_HIP(hipMemsetAsync(ph.tree->layers[0].p, 0, P2_DIGEST * n_leaf * 4, ctx->stream));
+        if (n_leaf != rows) P3R_HIP(fill_async(ctx->stream, ph.tree->layers[0].p, 0, P2_DIGEST * n_leaf * 4));
         mmcs4_hash_rows_strided<PP>(ctx, dcols, (int)cols.size(), rows, arity, ph.tree->layers[0].p, n_leaf);
       } else {
         ProfScope ps(ctx, "mmcs_hash_rows_strided");
@@ -1322,6 +1335,7 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
   }
   P3R_HIP(hipStreamSynchronize(ctx->stream));
   prof_stage(ctx, nullptr);
+  host_timeline_dump();
   return W.take();
 }
 
