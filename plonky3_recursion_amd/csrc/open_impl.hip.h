@@ -105,8 +105,12 @@ struct Opener {
                          (int)dot_jobs.size(), (uint32_t)(used * DC), out.p);
       P3R_HIP(hipGetLastError());
     }
+    // the opened values (4 800 words for a recursion layer) travel like a commitment root: posted by a one-workgroup
+    // kernel and polled for - the copy engine's round trip is 30 - 40 us longer (profiles/r06/host_gaps.txt); read in
+    // place, before the next post
     const uint32_t* raw = nullptr;
-    P3R_HIP(ctx->landing.fetch(ctx->stream, out.p, used * DC * 4, &raw));
+    if (HostPost::enabled() && used * DC <= HostPost::kWords) P3R_HIP(ctx->post.post(ctx->stream, out.p, used * DC, &raw));
+    else P3R_HIP(ctx->landing.fetch(ctx->stream, out.p, used * DC * 4, &raw));
     keep.clear();  // `out` stays for the reduced openings (values_dev)
     std::vector<std::vector<std::vector<E>>> res(jobs.size());
     for (size_t j = 0; j < jobs.size(); ++j) {
