@@ -366,6 +366,13 @@ void p3r_prep_free(p3r_ctx* ctx, p3r_prep* prep);
 int p3r_prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* main_traces,
                     size_t n_instances, uint32_t flags, uint8_t* proof_buf, size_t proof_cap,
                     size_t* proof_len);
+/* The proof of the last prove call on this context that returned P3R_EBUFFER (any of p3r_prove_batch[_host],
+ * p3r_prove_all_tables[_resident], p3r_prove_next_layer[_resident]): the bytes are KEPT, not recomputed - a second prove
+ * call costs a second proof, and under zk = 1 or a hiding MMCS it IS another proof, of another length, so retrying with
+ * the reported size can fail again.  The binding of a growable byte vector (Vec<u8>): call, on P3R_EBUFFER resize to
+ * *proof_len and take.  The bytes are dropped by the next prove call and by a successful take; P3R_EINVAL when none is
+ * waiting, P3R_EBUFFER (size in *proof_len) when proof_cap is still too small. */
+int p3r_take_proof(p3r_ctx* ctx, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len);
 /* Same from host matrices (row-major canonical). */
 int p3r_prove_batch_host(p3r_ctx* ctx, const p3r_prep* prep, const p3r_matrix* main_traces,
                          size_t n_instances, uint32_t flags, uint8_t* proof_buf, size_t proof_cap,

@@ -412,7 +412,8 @@ std::vector<uint8_t> proof_call(const Context& ctx, Fn&& fn) {
   std::vector<uint8_t> buf(size_t(1) << 20);
   size_t n = 0;
   int rc = fn(buf.data(), buf.size(), &n);
-  if (rc == P3R_EBUFFER && n > buf.size()) { buf.resize(n); rc = fn(buf.data(), buf.size(), &n); }
+  // the library keeps a proof that did not fit (it is not recomputed: under zk a second call makes ANOTHER proof)
+  if (rc == P3R_EBUFFER && n > buf.size()) { buf.resize(n); rc = p3r_take_proof(ctx.raw(), buf.data(), buf.size(), &n); }
   ctx.check(rc);
   buf.resize(n);
   return buf;

@@ -246,6 +246,7 @@ SIGNATURES = {
     "p3r_circuit_inputs_upload": (vp, [vp, vp, C.POINTER(P3rCircuitInputs)]),
     "p3r_circuit_inputs_free": (None, [vp, vp]),
     "p3r_circuit_run_resident": (vp, [vp, vp, vp]),
+    "p3r_take_proof": (C.c_int, [vp, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]),
     "p3r_prove_next_layer_resident": (C.c_int, [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint8), C.c_size_t,
                                                 C.POINTER(C.c_size_t)]),
     "p3r_dtraces_get": (C.c_int, [vp, vp, vp, C.c_uint32, u32p, C.c_size_t]),

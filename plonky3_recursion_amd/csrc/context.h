@@ -578,6 +578,7 @@ struct p3r_ctx {
   bool w32_unacknowledged = false;  // width-32 constants defaulted without P3R_EXT_UNPINNED_W32_DEFAULTS (p3r.h)
   uint64_t zk_nonce = 0;  // proofs made so far under a ZK configuration (p3r_zk_nonce; zk_rand.h)
   uint32_t zk_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // the key the context draws with (zk_rand.h::zk_context_key)
+  std::vector<uint8_t> pending_proof;  // the proof of a prove call whose buffer was too small (p3r_take_proof)
   p3r::HostStage stage;  // small uploads that do not wait (see HostStage)
   p3r::HostLanding landing;  // device->host results read in place (see HostLanding)
   p3r::HostPost post;        // small device->host results the host polls for (see HostPost)

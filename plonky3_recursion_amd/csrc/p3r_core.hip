@@ -955,11 +955,30 @@ void p3r_prep_free(p3r_ctx* ctx, p3r_prep* prep) {
   delete prep;
 }
 
-static int emit_proof(std::vector<uint8_t>&& bytes, uint8_t* buf, size_t cap, size_t* len) {
+// A proof that does not fit the caller's buffer is KEPT (p3r_take_proof): proving again to learn nothing but the size
+// would double the call's cost, and under zk = 1 - or a hiding MMCS - the second proof is another one, of another length.
+static int emit_proof(p3r_ctx* ctx, std::vector<uint8_t>&& bytes, uint8_t* buf, size_t cap, size_t* len) {
   *len = bytes.size();
-  if (bytes.size() > cap) fail(P3R_EBUFFER, "proof needs %zu bytes, buffer holds %zu", bytes.size(), cap);
+  ctx->pending_proof.clear();
+  if (bytes.size() > cap) {
+    const size_t need = bytes.size();
+    ctx->pending_proof = std::move(bytes);
+    fail(P3R_EBUFFER, "proof needs %zu bytes, buffer holds %zu (p3r_take_proof hands it over)", need, cap);
+  }
   memcpy(buf, bytes.data(), bytes.size());
   return 0;
+}
+
+int p3r_take_proof(p3r_ctx* ctx, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {
+  return guard(ctx, [&] {
+    if (!proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
+    if (ctx->pending_proof.empty()) fail(P3R_EINVAL, "no proof is waiting: the last prove call on this context did not return P3R_EBUFFER");
+    *proof_len = ctx->pending_proof.size();
+    if (ctx->pending_proof.size() > proof_cap)
+      fail(P3R_EBUFFER, "proof needs %zu bytes, buffer holds %zu", ctx->pending_proof.size(), proof_cap);
+    memcpy(proof_buf, ctx->pending_proof.data(), ctx->pending_proof.size());
+    std::vector<uint8_t>().swap(ctx->pending_proof);
+  });
 }
 
 int p3r_prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* main_traces,
@@ -971,7 +990,7 @@ int p3r_prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_dmat* const* m
       if (!main_traces[i]) fail(P3R_EINVAL, "main trace %zu is NULL", i);
     auto bytes = P3R_FIELD_CALL(ctx, prove_batch_any, ctx, prep, main_traces, n_instances,
                                 (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
-    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+    emit_proof(ctx, std::move(bytes), proof_buf, proof_cap, proof_len);
   });
 }
 
@@ -990,7 +1009,7 @@ int p3r_prove_batch_host(p3r_ctx* ctx, const p3r_prep* prep, const p3r_matrix* m
     }
     auto bytes = P3R_FIELD_CALL(ctx, prove_batch_any, ctx, prep, ptrs.data(), n_instances,
                                 (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
-    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+    emit_proof(ctx, std::move(bytes), proof_buf, proof_cap, proof_len);
   });
 }
 
@@ -1050,7 +1069,7 @@ int p3r_prove_all_tables_resident(p3r_ctx* ctx, const p3r_layer* layer, const p3
     if (!layer || !traces || !proof_len || (!proof_buf && proof_cap)) fail(P3R_EINVAL, "bad arguments");
     auto bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, layer, traces,
                                 (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
-    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+    emit_proof(ctx, std::move(bytes), proof_buf, proof_cap, proof_len);
   });
 }
 int p3r_prove_all_tables(p3r_ctx* ctx, const p3r_layer* layer, const p3r_traces* traces, uint32_t flags,
@@ -1060,7 +1079,7 @@ int p3r_prove_all_tables(p3r_ctx* ctx, const p3r_layer* layer, const p3r_traces*
     auto d = P3R_FIELD_CALL(ctx, traces_upload, ctx, layer, traces);
     auto bytes = P3R_FIELD_CALL(ctx, prove_all_tables, ctx, layer, d.get(),
                                 (flags & P3R_PROVE_CANONICAL_FIELD_ENCODING) != 0);
-    emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+    emit_proof(ctx, std::move(bytes), proof_buf, proof_cap, proof_len);
   });
 }
 p3r_dmat* p3r_layer_build_main_trace(p3r_ctx* ctx, const p3r_layer* layer, const p3r_dtraces* traces,
@@ -1152,7 +1171,7 @@ static void prove_next_layer_impl(p3r_ctx* ctx, const p3r_circuit* circuit, cons
     throw;
   }
   run_raise_error(*run_err);  // prove_all_tables returns with the stream drained
-  emit_proof(std::move(bytes), proof_buf, proof_cap, proof_len);
+  emit_proof(ctx, std::move(bytes), proof_buf, proof_cap, proof_len);
 }
 int p3r_prove_next_layer(p3r_ctx* ctx, const p3r_circuit* circuit, const p3r_circuit_inputs* inputs,
                          uint32_t flags, uint8_t* proof_buf, size_t proof_cap, size_t* proof_len) {

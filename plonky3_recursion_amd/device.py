@@ -367,14 +367,13 @@ class Context:
         buf = getattr(self, "_proof_buf", None)
         if buf is None:
             buf = self._proof_buf = C.create_string_buffer(1 << 20)
-        while True:
-            n = C.c_size_t()
-            rc = fn(*args, C.cast(buf, C.POINTER(C.c_uint8)), len(buf), C.byref(n))
-            if rc == -6 and n.value > len(buf):  # P3R_EBUFFER
-                buf = self._proof_buf = C.create_string_buffer(n.value)
-                continue
-            self.check(rc)
-            return C.string_at(buf, n.value)   # one memcpy (slicing a ctypes array builds a list first)
+        n = C.c_size_t()
+        rc = fn(*args, C.cast(buf, C.POINTER(C.c_uint8)), len(buf), C.byref(n))
+        if rc == -6 and n.value > len(buf):  # P3R_EBUFFER: the library kept the proof (p3r_take_proof) - it is not made again
+            buf = self._proof_buf = C.create_string_buffer(max(n.value + n.value // 4, 2 * len(buf)))
+            rc = self.lib.p3r_take_proof(self.h, C.cast(buf, C.POINTER(C.c_uint8)), len(buf), C.byref(n))
+        self.check(rc)
+        return C.string_at(buf, n.value)   # one memcpy (slicing a ctypes array builds a list first)
 
     def prove_batch(self, prover_data, main_traces, canonical_field_encoding=False):
         """main_traces: DeviceMatrix list (resident) or 2-D uint32 arrays (host)."""

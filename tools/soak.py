@@ -8,7 +8,7 @@ ARITY = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54,
            mmcs_arity=ARITY)
 a = harness_lib.generate("koala-bear", 16, seed=3)
-ctx = p3r.Context(field="koala-bear", **FRI)
+ctx = p3r.Context(field="koala-bear", allow_unpinned_w32_defaults=True, **FRI)
 tp = p3r.TablePacking().with_fri_params(5, 2)
 pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
 res = pc.upload_inputs(wl.circuit_inputs_from_arrays(a))

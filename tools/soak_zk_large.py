@@ -4,7 +4,8 @@ import harness_lib, torch
 import plonky3_recursion_amd as p3r
 import harness_adapters as wl
 FRI = dict(log_blowup=2, max_log_arity=2, cap_height=0, log_final_poly_len=5, commit_pow_bits=0, query_pow_bits=15, num_queries=54)
-for field, lh, kw in (("koala-bear", 21, dict(zk=1, num_random_codewords=2, zk_seed=9)), ("koala-bear", 21, dict(zk=1, num_random_codewords=2, zk_seed=9, mmcs_arity=4))):
+for field, lh, kw in (("koala-bear", 21, dict(zk=1, num_random_codewords=2, zk_seed=9)), ("koala-bear", 21, dict(zk=1, num_random_codewords=2, zk_seed=9, mmcs_arity=4)),
+                      ("koala-bear", 21, dict(zk=1, num_random_codewords=2, mmcs_salt_elems=4))):   # the hiding MMCS, keyed by the OS
     a = harness_lib.generate(field, lh, seed=3)
     ctx = p3r.Context(field=field, **FRI, **kw, allow_unpinned_w32_defaults=True)
     tp = p3r.TablePacking().with_fri_params(5, 2)
