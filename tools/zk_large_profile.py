@@ -1,3 +1,5 @@
+"""Per-proof times and the per-kernel / per-stage profile of a large ZK layer under the binary and the arity-4 MMCS.
+   python tools/zk_large_profile.py [log_rows=21]"""
 import sys, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import harness_lib, torch
