@@ -860,7 +860,8 @@ def rank_report(torch, dist, world, backend, local_rank, coll_device, rank_ms=No
 
 CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "proof_verified", "proof_sha256")
-CONTRACT_MAX_CHARS = 6000   # the driver keeps an ~8 KB tail of stdout: the final line must fit whole inside it
+CONTRACT_MAX_CHARS = 6000
+SUSTAINED_S = 6.0   # seconds of back-to-back headline proofs after the timed region (default run, one GPU)   # the driver keeps an ~8 KB tail of stdout: the final line must fit whole inside it
 
 
 def _round_floats(x, digits=6):
@@ -1014,6 +1015,7 @@ def main():
                     help="initialise the process group (nccl = RCCL unless P3R_BENCH_BACKEND says otherwise) also at world size 1: "
                          "barrier, all_reduce(MAX) of the timings and the root hand-off run through the collective library on one GPU")
     ap.add_argument("--no-small-layers", action="store_true", help="skip the 2^14/2^15/2^16-row layers")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the sustained leg (SUSTAINED_S seconds of back-to-back proofs after the timed region)")
     ap.add_argument("--no-quintic", action="store_true",
                     help="skip the D = 5 layer (KoalaBear quintic circuits: ALU, compact-D1 Poseidon2, recompose/coeff)")
     ap.add_argument("--no-config2", action="store_true",
@@ -1172,6 +1174,22 @@ def main():
         print("bench: host-input proof differs from the resident-input proof", file=sys.stderr)
         proof_verified = False
     del host_inputs
+    # the same step back to back for SUSTAINED_S seconds (rank 0 of a one-GPU run): the timed region above is K steps -
+    # half a second at the driver's K = 20 - and a utilisation sampler that looks at the GPU every five seconds can miss
+    # it altogether; this leg is long enough to be seen, and says whether the rate holds once clocks and HBM have settled
+    sustained = None
+    if rank == 0 and world == 1 and not args.no_sustained and not args.no_small_layers:   # (profiling runs pass --no-small-layers)
+        s0 = time.perf_counter()
+        n_sus, all_same = 0, True
+        while time.perf_counter() - s0 < SUSTAINED_S:
+            all_same = (pc.prove(resident) == last_proof) and all_same
+            n_sus += 1
+        sus_s = time.perf_counter() - s0
+        sustained = {"seconds": sus_s, "proofs": n_sus, "ms_per_step": sus_s / n_sus * 1e3, "vs_timed_region": (sus_s / n_sus) / (dt / args.steps),
+                     "every_proof_identical_to_the_timed_one": all_same}
+        if not all_same:
+            print("bench: a proof of the sustained leg differs from the timed region's", file=sys.stderr)
+            proof_verified = False
     # per-kernel-family times come from two EXTRA steps with HIP-event bracketing switched on, so
     # the event overhead is not inside `value`
     prof_steps = 2
@@ -1291,6 +1309,7 @@ def main():
             "prep_miss_breakdown_ms": prep_breakdown,
             "small_layers": small or None,
             "small_layer_throughput": small_tput,
+            "sustained": sustained,
             "root_handoff_ms": handoff_ms,
             "poseidon2_perms_per_s": perms * world / (ms_per_step * 1e-3),
             "poseidon2_perms_per_step": perms,
