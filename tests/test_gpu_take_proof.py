@@ -70,3 +70,30 @@ def test_the_python_wrapper_takes_instead_of_proving_twice_under_zk():
     second = pc.prove(rin)                         # the grown buffer now fits: no detour
     assert ctx.zk_nonce == before + 2 and second != proof
     rin.free(); pc.free(); ctx.close()
+
+
+def test_predicted_waits_leave_the_bytes_alone_when_shapes_alternate():
+    """The host sleeps through most of what a transcript round trip took in the previous proof of the same shape
+    (csrc/context.h::HostPost::post).  Two shapes alternating on one context, and a profiled proof in between (no
+    prediction there: the stage marks drain the stream), must keep giving the same bytes - a misprediction may cost time,
+    never a result."""
+    import plonky3_recursion_amd as p3r
+    ctx = p3r.Context(field="koala-bear")      # the headline FRI parameters: waits of a millisecond and more at 2^16 rows
+    tp = p3r.TablePacking().with_fri_params(5, 2)
+    made = []
+    for log_h in (16, 17):
+        a = harness_lib.generate("koala-bear", log_h, seed=7 + log_h)
+        pc = p3r.PreparedCircuit(ctx, wl.circuit_from_arrays(a), tp)
+        rin = pc.upload_inputs(wl.circuit_inputs_from_arrays(a))
+        made.append((pc, rin, pc.prove(rin)))
+    for k in range(3):
+        for pc, rin, want in made:
+            assert pc.prove(rin) == want
+        if k == 1:
+            ctx.profile_enable(True)
+            assert made[1][0].prove(made[1][1]) == made[1][2]
+            assert any(name.startswith("stage:") for name in ctx.profile_read())
+            ctx.profile_enable(False)
+    for pc, rin, _ in made:
+        rin.free(); pc.free()
+    ctx.close()
