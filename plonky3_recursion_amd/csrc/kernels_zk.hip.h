@@ -124,4 +124,99 @@ __global__ void __launch_bounds__(kBlock) k_zk_salts(const ZkSaltJob* __restrict
   as_global(j.dst)[((uint64_t)c * j.h + r) * j.stride] = zk_rand_mont<PP>(key, j.stream, r * j.S + c);
 }
 
+
+// ---- the same fills, one ChaCha block per EIGHT cells (round 6) ---------------------------------------------------------
+// k_zk_randomize / k_zk_salts compute cell (r, c) in the lane that stores it - lanes run along a column, the cells of a
+// ChaCha block along a row - so every random cell pays for a whole block (~ 400 instructions, 5.7 ms of randomisation and
+// 9.0 ms of salts per 2^20-row proof).  Here a workgroup owns a tile of 2^log_tr rows x all columns: each lane computes
+// whole blocks, draws their eight cells by static index and parks them in LDS by (row, column); the tile is then written
+// out column by column, lanes along the rows.  Same values, same bytes (zk_rand_canonical remains the definition and the
+// slow path of a cell whose two candidates are refused).
+constexpr uint32_t kZkTileWords = 12288;   // 48 KB of LDS per workgroup
+struct ZkTileJob {
+  const uint32_t* src;   // mode 0: the matrix being randomised, [w][rows / 2]
+  uint32_t* dst;
+  uint64_t rows;         // rows of the index space: 2h (randomise), h (salts)
+  uint32_t w, w2;        // mode 0: original / randomised width; otherwise 0 / number of columns
+  uint32_t mode;         // 0: even rows keep src for c < w, everything else random; 1: every cell random
+                         // (the zero fill of the preprocessed round draws nothing: it stays with k_zk_randomize)
+  uint32_t stride;       // element stride of dst inside a column (1: plain column-major; FRI commit-phase salts: the arity)
+  uint32_t stream;
+  uint32_t log_tr;       // rows per tile
+  uint32_t block0;
+};
+// rows per tile: as many as the LDS budget holds at this width (row pitch odd: the write-out reads a column of the tile)
+inline uint32_t zk_tile_log_rows(uint64_t rows, uint32_t w2) {
+  const uint32_t pitch = w2 | 1u;
+  uint32_t log_tr = rows >= 2 ? 1 : 0;
+  while (log_tr >= 1 && log_tr < 11 && (uint64_t(2) << log_tr) * pitch <= kZkTileWords && (uint64_t(2) << log_tr) <= rows) ++log_tr;
+  return log_tr;
+}
+// (out of line: the slow path of a cell would otherwise be inlined eight times into every fill loop)
+template <class PP>
+__device__ __noinline__ uint32_t zk_rand_canonical_slow(const ZkKey& key, uint32_t stream, uint64_t idx) {
+  return zk_rand_canonical<PP>(key, stream, idx);
+}
+// the eight cells of block b of a stream that fall in [lo, hi): emit(idx, Montgomery value)
+template <class PP, class Emit>
+__device__ __forceinline__ void zk_block_cells(const ZkKey& key, uint32_t stream, uint64_t b, uint64_t lo, uint64_t hi, Emit&& emit) {
+  uint32_t blk[16];
+  zk_chacha8_block(key.k, (uint32_t)b, stream, key.nonce_lo, key.nonce_hi, blk);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint64_t idx = 8 * b + k;
+    if (idx < lo || idx >= hi) continue;
+    uint32_t v = blk[2 * k] & 0x7FFFFFFFu;
+    if (v >= PP::P) {
+      v = blk[2 * k + 1] & 0x7FFFFFFFu;
+      if (v >= PP::P) v = zk_rand_canonical_slow<PP>(key, stream, idx);   // (both refused: 2^-14 KoalaBear, 2^-8 BabyBear)
+    }
+    emit(idx, Fp<PP>::from_canonical(v).v);
+  }
+}
+template <class PP>
+__global__ void __launch_bounds__(kBlock) k_zk_fill_tiles(const ZkTileJob* __restrict__ jobs, int n_jobs, ZkKey key) {
+  __shared__ uint32_t tile[kZkTileWords];
+  int jb = 0;
+  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const ZkTileJob& j = jobs[jb];
+  const uint32_t w2 = j.w2, pitch = w2 | 1u, tr = 1u << j.log_tr, tid = threadIdx.x;
+  const uint64_t r0 = (uint64_t)(blockIdx.x - j.block0) << j.log_tr;
+  if (j.mode == 1) {
+    // one contiguous range of the stream
+    const uint64_t lo = r0 * w2, hi = lo + (uint64_t)tr * w2;
+    for (uint64_t b = (lo >> 3) + tid; b <= ((hi - 1) >> 3); b += kBlock)
+      zk_block_cells<PP>(key, j.stream, b, lo, hi, [&](uint64_t idx, uint32_t v) {
+        const uint32_t off = (uint32_t)(idx - lo), rr = off / w2;
+        tile[rr * pitch + (off - rr * w2)] = v;
+      });
+  } else {
+    // odd rows: all w2 cells; even rows: the codeword columns [w, w2).  Items (block of the row, row), rows fastest:
+    // the lanes of a wave work on the same block position of neighbouring rows
+    const uint32_t half = tr >> 1;
+    for (uint32_t par = 0; par < 2; ++par) {
+      const uint32_t c_lo = par ? j.w : 0u;
+      if (c_lo >= w2) continue;
+      const uint32_t kb_n = (w2 - c_lo + 7) / 8 + 1;
+      for (uint32_t it = tid; it < kb_n * half; it += kBlock) {
+        const uint32_t kb = it / half, q = it - kb * half, rr = 2 * q + (par ? 0u : 1u);
+        const uint64_t lo = (r0 + rr) * w2 + c_lo, hi = (r0 + rr + 1) * w2, b = (lo >> 3) + kb;
+        if (8 * b >= hi) continue;
+        zk_block_cells<PP>(key, j.stream, b, lo, hi, [&](uint64_t idx, uint32_t v) { tile[rr * pitch + c_lo + (uint32_t)(idx - lo)] = v; });
+      }
+    }
+  }
+  __syncthreads();
+  // write-out: column by column, lanes along the rows of the tile
+  const uint64_t total = (uint64_t)w2 << j.log_tr;
+  for (uint64_t i = tid; i < total; i += kBlock) {
+    const uint32_t c = (uint32_t)(i >> j.log_tr), rr = (uint32_t)i & (tr - 1);
+    const uint64_t r = r0 + rr;
+    uint32_t v;
+    if (j.mode == 0 && !(r & 1) && c < j.w) v = as_global(j.src)[(uint64_t)c * (j.rows >> 1) + (r >> 1)];
+    else v = tile[rr * pitch + c];
+    as_global(j.dst)[((uint64_t)c * j.rows + r) * j.stride] = v;
+  }
+}
+
 }  // namespace p3r

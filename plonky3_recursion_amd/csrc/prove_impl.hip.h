@@ -85,11 +85,47 @@ inline ZkKey zk_key_of(const p3r_ctx* ctx, uint64_t nonce) {
   return k;
 }
 
+// the tiled fills of kernels_zk.hip.h (one ChaCha block per eight cells); P3R_ZK_CELL_FILL=1 (knobs build): the per-cell kernels
+inline bool zk_cell_fill() {
+  static const bool on = tuning_knob("P3R_ZK_CELL_FILL") != nullptr;
+  return on;
+}
+template <class PP>
+void launch_zk_tiles(p3r_ctx* ctx, std::vector<ZkTileJob>& jobs, const ZkKey& key, const char* family) {
+  uint64_t blocks = 0;
+  for (auto& j : jobs) {
+    if (2 * (uint64_t)(j.w2 | 1u) > kZkTileWords) fail(P3R_EUNSUPPORTED, "ZK fill of a matrix of %u columns", j.w2);
+    j.log_tr = zk_tile_log_rows(j.rows, j.w2);
+    j.block0 = (uint32_t)blocks;
+    blocks += j.rows >> j.log_tr;
+  }
+  if (blocks >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "ZK fill launch of %llu tiles", (unsigned long long)blocks);
+  if (!blocks) return;
+  DevBuf d_jobs((jobs.size() * sizeof(ZkTileJob) + 3) / 4);
+  P3R_HIP(ctx->stage.upload(ctx->stream, d_jobs.p, jobs.data(), jobs.size() * sizeof(ZkTileJob)));
+  ProfScope ps(ctx, family);
+  hipLaunchKernelGGL(k_zk_fill_tiles<PP>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, reinterpret_cast<const ZkTileJob*>(d_jobs.p),
+                     (int)jobs.size(), key);
+  P3R_HIP(hipGetLastError());
+}
+
 // Salt matrices of a hiding MMCS for the matrices of one batch (commit order): h x S each, one launch.
 template <class PP>
 std::vector<std::unique_ptr<p3r_dmat>> draw_salts(p3r_ctx* ctx, const std::vector<const p3r_dmat*>& mats, int salt_round, const ZkKey& key) {
   const uint32_t S = ctx->cfg.mmcs_salt_elems;
   std::vector<std::unique_ptr<p3r_dmat>> out;
+  if (!zk_cell_fill()) {
+    std::vector<ZkTileJob> tj;
+    for (size_t i = 0; i < mats.size(); ++i) {
+      out.push_back(dmat_alloc(mats[i]->h, S));
+      ZkTileJob j{};
+      j.dst = out.back()->d; j.rows = mats[i]->h; j.w2 = S; j.mode = 1; j.stride = 1;
+      j.stream = zk_stream_id(salt_round, i);
+      tj.push_back(j);
+    }
+    launch_zk_tiles<PP>(ctx, tj, key, "mmcs_salts");
+    return out;
+  }
   std::vector<ZkSaltJob> jobs;
   uint64_t blocks = 0;
   for (size_t i = 0; i < mats.size(); ++i) {
@@ -276,6 +312,17 @@ std::vector<std::unique_ptr<p3r_dmat>> zk_randomize(p3r_ctx* ctx, const std::vec
   }
   if (blocks >= (uint64_t(1) << 31)) fail(P3R_EUNSUPPORTED, "ZK randomisation launch of %llu tiles", (unsigned long long)blocks);
   if (jobs.empty()) return out;
+  if (!zk_cell_fill() && !zero_fill) {   // (a zero fill draws nothing: the per-cell kernel is the cheap one there)
+    std::vector<ZkTileJob> tj;
+    for (auto& j : jobs) {
+      ZkTileJob t{};
+      t.src = j.src; t.dst = j.dst; t.rows = j.h2; t.w = j.w; t.w2 = j.w2; t.stride = 1; t.stream = j.stream;
+      t.mode = j.src ? 0u : 1u;   // no source matrix (the random round): every cell is random
+      tj.push_back(t);
+    }
+    launch_zk_tiles<PP>(ctx, tj, key, "zk_randomize");
+    return out;
+  }
   DevBuf d_jobs((jobs.size() * sizeof(ZkRandomizeJob) + 3) / 4);
   P3R_HIP(ctx->stage.upload(ctx->stream, d_jobs.p, jobs.data(), jobs.size() * sizeof(ZkRandomizeJob)));
   ProfScope ps(ctx, "zk_randomize");
@@ -978,8 +1025,12 @@ std::vector<uint8_t> prove_batch(p3r_ctx* ctx, const p3r_prep* prep, const p3r_d
         j.stream = zk_stream_id(kSaltRoundFri, phases.size());
         j.block0 = 0;
         DevBuf d_job((sizeof(ZkSaltJob) + 3) / 4);
-        P3R_HIP(ctx->stage.upload(ctx->stream, d_job.p, &j, sizeof j));
-        {
+        if (!zk_cell_fill()) {
+          std::vector<ZkTileJob> tj(1);
+          tj[0].dst = j.dst; tj[0].rows = rows; tj[0].w2 = S; tj[0].mode = 1; tj[0].stride = (uint32_t)arity; tj[0].stream = j.stream;
+          launch_zk_tiles<PP>(ctx, tj, zk_key, "mmcs_salts");
+        } else {
+          P3R_HIP(ctx->stage.upload(ctx->stream, d_job.p, &j, sizeof j));
           ProfScope ps(ctx, "mmcs_salts");
           hipLaunchKernelGGL(k_zk_salts<PP>, dim3((unsigned)(S * ((rows + kBlock - 1) / kBlock))), dim3(kBlock), 0, ctx->stream,
                              reinterpret_cast<const ZkSaltJob*>(d_job.p), 1, zk_key);
