@@ -132,7 +132,10 @@ __global__ void __launch_bounds__(kBlock) k_zk_salts(const ZkSaltJob* __restrict
 // whole blocks, draws their eight cells by static index and parks them in LDS by (row, column); the tile is then written
 // out column by column, lanes along the rows.  Same values, same bytes (zk_rand_canonical remains the definition and the
 // slow path of a cell whose two candidates are refused).
-constexpr uint32_t kZkTileWords = 12288;   // 48 KB of LDS per workgroup
+#ifndef P3R_ZK_TILE_WORDS
+#define P3R_ZK_TILE_WORDS 12288   // 48 KB of LDS per workgroup (tools/microbench/zk_fill_check.hip times other sizes)
+#endif
+constexpr uint32_t kZkTileWords = P3R_ZK_TILE_WORDS;
 struct ZkTileJob {
   const uint32_t* src;   // mode 0: the matrix being randomised, [w][rows / 2]
   uint32_t* dst;
