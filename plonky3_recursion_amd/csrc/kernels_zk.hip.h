@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(kBlock) k_zk_salts(const ZkSaltJob* __restrict
 // out column by column, lanes along the rows.  Same values, same bytes (zk_rand_canonical remains the definition and the
 // slow path of a cell whose two candidates are refused).
 #ifndef P3R_ZK_TILE_WORDS
-#define P3R_ZK_TILE_WORDS 12288   // 48 KB of LDS per workgroup (tools/microbench/zk_fill_check.hip times other sizes)
+#define P3R_ZK_TILE_WORDS 6144   // 24 KB of LDS per workgroup: six workgroups per CU (tools/microbench/zk_fill_check.hip: 48 KB tiles
+                                // take 1.10 / 0.74 ms for 2^22 x 64 / 2^20 x 168 cells, 24 KB 0.75 / 0.52, 16 KB 0.82 / 0.64)
 #endif
 constexpr uint32_t kZkTileWords = P3R_ZK_TILE_WORDS;
 struct ZkTileJob {
@@ -155,26 +156,27 @@ inline uint32_t zk_tile_log_rows(uint64_t rows, uint32_t w2) {
   while (log_tr >= 1 && log_tr < 11 && (uint64_t(2) << log_tr) * pitch <= kZkTileWords && (uint64_t(2) << log_tr) <= rows) ++log_tr;
   return log_tr;
 }
-// (out of line: the slow path of a cell would otherwise be inlined eight times into every fill loop)
-template <class PP>
-__device__ __noinline__ uint32_t zk_rand_canonical_slow(const ZkKey& key, uint32_t stream, uint64_t idx) {
-  return zk_rand_canonical<PP>(key, stream, idx);
-}
-// the eight cells of block b of a stream that fall in [lo, hi): emit(idx, Montgomery value)
+// the eight cells of block b of a stream that fall in [lo, hi): emit(idx, Montgomery value).  A cell whose two candidates
+// are refused (2^-14 KoalaBear, 2^-8 BabyBear) is drawn again by the definition, in ONE loop behind the eight (a call in
+// each of them would be inlined eight times, or cost every lane the calling convention's spills)
 template <class PP, class Emit>
 __device__ __forceinline__ void zk_block_cells(const ZkKey& key, uint32_t stream, uint64_t b, uint64_t lo, uint64_t hi, Emit&& emit) {
   uint32_t blk[16];
   zk_chacha8_block(key.k, (uint32_t)b, stream, key.nonce_lo, key.nonce_hi, blk);
+  uint32_t refused = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const uint64_t idx = 8 * b + k;
     if (idx < lo || idx >= hi) continue;
     uint32_t v = blk[2 * k] & 0x7FFFFFFFu;
-    if (v >= PP::P) {
-      v = blk[2 * k + 1] & 0x7FFFFFFFu;
-      if (v >= PP::P) v = zk_rand_canonical_slow<PP>(key, stream, idx);   // (both refused: 2^-14 KoalaBear, 2^-8 BabyBear)
-    }
+    if (v >= PP::P) v = blk[2 * k + 1] & 0x7FFFFFFFu;
+    if (v >= PP::P) { refused |= 1u << k; continue; }
     emit(idx, Fp<PP>::from_canonical(v).v);
+  }
+  while (refused) {
+    const int k = __ffs(refused) - 1;
+    refused &= refused - 1;
+    emit(8 * b + k, Fp<PP>::from_canonical(zk_rand_canonical<PP>(key, stream, 8 * b + k)).v);
   }
 }
 template <class PP>

@@ -53,8 +53,8 @@ int run(const char* name) {
     hipFree(src); hipFree(a); hipFree(b);
   }
   // times
-  {
-    const uint64_t h = 1 << 21; const uint32_t w = 62, R = 2, w2 = w + R; const uint64_t rows = 2 * h;
+  for (int shape = 0; shape < 2; ++shape) {
+    const uint64_t h = shape ? (1 << 19) : (1 << 21); const uint32_t w = shape ? 166 : 62, R = 2, w2 = w + R; const uint64_t rows = 2 * h;
     uint32_t *src, *a; CK(hipMalloc(&src, h * w * 4)); CK(hipMalloc(&a, rows * w2 * 4)); CK(hipMemset(src, 1, h * w * 4));
     ZkTileJob t{}; t.src = src; t.dst = a; t.rows = rows; t.w = w; t.w2 = w2; t.mode = 0; t.stride = 1; t.stream = 5; t.log_tr = zk_tile_log_rows(rows, w2);
     ZkTileJob* dt; CK(hipMalloc(&dt, sizeof t)); CK(hipMemcpy(dt, &t, sizeof t, hipMemcpyHostToDevice));
@@ -70,7 +70,7 @@ int run(const char* name) {
       hipLaunchKernelGGL(k_zk_randomize<PP>, dim3((unsigned)(w2 * ((rows + kBlock - 1) / kBlock))), dim3(kBlock), 0, 0, dj, 1, key);
       hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_old, e0, e1);
     }
-    printf("%s randomise 2^21 x 62 -> 2^22 x 64: tiled %.3f ms, per cell %.3f ms\n", name, ms_new, ms_old);
+    printf("%s randomise %llu x %u -> %llu x %u: tiled %.3f ms, per cell %.3f ms\n", name, (unsigned long long)h, w, (unsigned long long)rows, w2, ms_new, ms_old);
     const uint32_t S = 4;
     ZkTileJob ts{}; ts.dst = a; ts.rows = rows; ts.w2 = S; ts.mode = 1; ts.stride = 1; ts.stream = 6; ts.log_tr = zk_tile_log_rows(rows, S);
     CK(hipMemcpy(dt, &ts, sizeof ts, hipMemcpyHostToDevice));
@@ -84,7 +84,7 @@ int run(const char* name) {
       hipLaunchKernelGGL(k_zk_salts<PP>, dim3((unsigned)(S * ((rows + kBlock - 1) / kBlock))), dim3(kBlock), 0, 0, dsj, 1, key);
       hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_old, e0, e1);
     }
-    printf("%s salts 2^22 x 4: tiled %.3f ms, per cell %.3f ms\n", name, ms_new, ms_old);
+    printf("%s salts %llu x 4: tiled %.3f ms, per cell %.3f ms\n", name, (unsigned long long)rows, ms_new, ms_old);
   }
   return bad;
 }
