@@ -21,3 +21,12 @@ def test_tiled_fills_equal_the_per_cell_kernels():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all shapes identical" in r.stdout and "MISMATCH" not in r.stdout
     assert r.stdout.count("0 of ") >= 38
+
+
+def test_tiled_fills_with_cell_indices_beyond_2_to_the_32():
+    """2^24 rows x 300 / 330 columns of one stream (5 x 10^9 cells, 40 GB for the two copies): the 64-bit index paths of
+    the tiled kernel against the per-cell kernels (launched in two halves: a grid holds fewer than 2^32 threads), compared
+    on the device."""
+    r = subprocess.run([EXE, "--big"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count(": 0 cells differ") == 4 and "all shapes identical" in r.stdout

@@ -3,10 +3,67 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I plonky3_recursion_amd/csrc -o tools/microbench/zk_fill_check tools/microbench/zk_fill_check.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <string>
 #include <vector>
 #include "kernels_zk.hip.h"
 using namespace p3r;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ void k_count_diff(const uint32_t* a, const uint32_t* b, size_t n, unsigned long long* count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long local = 0;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) local += a[i] != b[i];
+  if (local) atomicAdd(count, local);
+}
+// `--big`: cell indices beyond 2^32 (2^24 rows x 300 columns of one stream, 2^23 x 330 randomised), compared on the device
+template <class PP>
+int run_big(const char* name) {
+  ZkKey key{};
+  for (int i = 0; i < 8; ++i) key.k[i] = 0x85EBCA6Bu * (i + 3);
+  int bad = 0;
+  for (int mode = 1; mode >= 0; --mode) {
+    const uint64_t rows = mode ? (uint64_t(1) << 24) : (uint64_t(1) << 24);
+    const uint32_t w = mode ? 0 : 328, w2 = mode ? 300 : 330;
+    const size_t cells = (size_t)rows * w2;
+    uint32_t *src = nullptr, *a, *b;
+    if (!mode) { CK(hipMalloc(&src, (rows / 2) * w * 4)); CK(hipMemset(src, 3, (rows / 2) * w * 4)); }
+    CK(hipMalloc(&a, cells * 4)); CK(hipMalloc(&b, cells * 4));
+    ZkTileJob t{}; t.src = src; t.dst = b; t.rows = rows; t.w = w; t.w2 = w2; t.mode = mode; t.stride = 1; t.stream = zk_stream_id(2, 1);
+    t.log_tr = zk_tile_log_rows(rows, w2);
+    ZkTileJob* dt; CK(hipMalloc(&dt, sizeof t)); CK(hipMemcpy(dt, &t, sizeof t, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_zk_fill_tiles<PP>, dim3((unsigned)(rows >> t.log_tr)), dim3(kBlock), 0, 0, dt, 1, key);
+    if (mode) {
+      // the per-cell salts kernel covers (column, 256-row) tiles: 300 x 65536 blocks
+      ZkSaltJob j{}; j.dst = a; j.h = rows; j.S = w2; j.stride = 1; j.stream = t.stream;
+      ZkSaltJob* dj; CK(hipMalloc(&dj, sizeof j)); CK(hipMemcpy(dj, &j, sizeof j, hipMemcpyHostToDevice));
+      // (a grid holds fewer than 2^32 threads: two launches, the second one's block offset carried by a wrapped block0)
+      const uint32_t all = (uint32_t)(w2 * ((rows + kBlock - 1) / kBlock)), g1 = all / 2;
+      hipLaunchKernelGGL(k_zk_salts<PP>, dim3(g1), dim3(kBlock), 0, 0, dj, 1, key);
+      j.block0 = 0u - g1;
+      ZkSaltJob* dj2; CK(hipMalloc(&dj2, sizeof j)); CK(hipMemcpy(dj2, &j, sizeof j, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_zk_salts<PP>, dim3(all - g1), dim3(kBlock), 0, 0, dj2, 1, key);
+    } else {
+      ZkRandomizeJob j{}; j.src = src; j.dst = a; j.h2 = rows; j.w = w; j.w2 = w2; j.stream = t.stream;
+      ZkRandomizeJob* dj; CK(hipMalloc(&dj, sizeof j)); CK(hipMemcpy(dj, &j, sizeof j, hipMemcpyHostToDevice));
+      const uint32_t all = (uint32_t)(w2 * ((rows + kBlock - 1) / kBlock)), g1 = all / 2;
+      hipLaunchKernelGGL(k_zk_randomize<PP>, dim3(g1), dim3(kBlock), 0, 0, dj, 1, key);
+      j.block0 = 0u - g1;
+      ZkRandomizeJob* dj2; CK(hipMalloc(&dj2, sizeof j)); CK(hipMemcpy(dj2, &j, sizeof j, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_zk_randomize<PP>, dim3(all - g1), dim3(kBlock), 0, 0, dj2, 1, key);
+    }
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
+    unsigned long long* dcount; CK(hipMalloc(&dcount, 8)); CK(hipMemset(dcount, 0, 8));
+    hipLaunchKernelGGL(k_count_diff, dim3(8192), dim3(256), 0, 0, a, b, cells, dcount);
+    unsigned long long diff = 0;
+    CK(hipMemcpy(&diff, dcount, 8, hipMemcpyDeviceToHost));
+    printf("%s BIG mode %d: 2^24 rows x %u columns (%zu cells, indices to %.2f x 2^32): %llu cells differ\n", name, mode, w2, cells,
+           (double)cells / 4294967296.0, diff);
+    bad += diff != 0;
+    hipFree(a); hipFree(b); if (src) hipFree(src);
+  }
+  return bad;
+}
 
 template <class PP>
 int run(const char* name) {
@@ -88,8 +145,14 @@ int run(const char* name) {
   }
   return bad;
 }
-int main() {
+int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IONBF, 0);
+  if (argc > 1 && std::string(argv[1]) == "--big") {
+    int b = run_big<KoalaBearParams>("koala-bear");
+    b += run_big<BabyBearParams>("baby-bear");
+    printf(b ? "MISMATCH\n" : "all shapes identical\n");
+    return b != 0;
+  }
   int bad = run<KoalaBearParams>("koala-bear");
   bad += run<BabyBearParams>("baby-bear");
   printf(bad ? "MISMATCH\n" : "all shapes identical\n");
