@@ -34,6 +34,19 @@ template <class T>
 __device__ __forceinline__ gptr<T> as_global(T* p) {
   return (gptr<T>)p;
 }
+
+// The job a workgroup of a job-list launch belongs to: the last one whose first block is not past it.  A ZK commit of
+// quotient chunks is forty matrices, the openings of a proof twenty-five to sixty: a linear walk over their descriptors is
+// that many dependent scalar loads before the workgroup starts; a bisection takes five or six.
+template <class Job>
+__device__ __forceinline__ int find_job(const Job* __restrict__ jobs, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (blockIdx.x >= jobs[mid].block0) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
 #endif
 
 constexpr uint32_t inv_mod_2_32(uint32_t p) {

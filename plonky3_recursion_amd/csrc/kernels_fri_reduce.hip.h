@@ -26,8 +26,7 @@ __global__ void __launch_bounds__(kBlock)
 k_fri_inv_points(const FriInvJobT<DC>* __restrict__ jobs, int n_jobs, uint32_t gen) {
   using F = Fp<PP>;
   using E = typename Chal<PP, DC>::type;
-  int j = 0;
-  while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
+  const int j = find_job(jobs, n_jobs);
   const FriInvJobT<DC>& job = jobs[j];
   // four consecutive rows per lane: their inversions share one base-field inversion (inv4)
   const size_t h = job.h, r0 = ((size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x) * 4;
@@ -117,8 +116,7 @@ k_fri_reduce_pre(const FriReduceJob* __restrict__ jobs, int n_jobs, const FriRed
                  const uint32_t* __restrict__ apow_tab /* alpha^c, DC words each */) {
   using F = Fp<PP>;
   using E = typename Chal<PP, DC>::type;
-  int j = 0;
-  while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
+  const int j = find_job(jobs, n_jobs);
   const FriReduceJob job = jobs[j];
   const size_t h = job.h, r = (size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x;
   if (r >= h) return;

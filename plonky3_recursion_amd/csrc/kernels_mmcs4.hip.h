@@ -42,8 +42,7 @@ struct HashRowsJob4 {
 template <class PP, bool BUILTIN>
 __global__ void __launch_bounds__(kBlock)
 k_mmcs4_hash_rows(const HashRowsJob4* __restrict__ jobs, int n_jobs, const double* __restrict__ tab) {
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const gptr<const uint32_t* const> cols = as_global(jobs[jb].cols);
   const gptr<uint32_t> dig = as_global(jobs[jb].dig);
   const size_t h = jobs[jb].h, stride = jobs[jb].h_alloc;

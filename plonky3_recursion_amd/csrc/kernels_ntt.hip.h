@@ -161,8 +161,7 @@ template <class PP>
 __global__ void __launch_bounds__(kNttBlock, 8) k_ntt_tile(const NttPass* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
   extern __shared__ uint32_t lds[];
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const NttPass a = jobs[jb];
   // tile (x) fastest, then coset (z), then polynomial (y); x and z counts are powers of two
   const uint32_t local = blockIdx.x - a.block0;

@@ -187,8 +187,7 @@ template <class PP, int LOG_R, int LOG_TILE = kNtt2LogTile>
 __global__ void __launch_bounds__(1 << (LOG_TILE - 4)) k_ntt_fwd_line(const NttLineJob* __restrict__ jobs, int n_jobs) {
   __shared__ uint32_t tile[ntt2_line_tile_words(LOG_R, LOG_TILE)];
   __shared__ uint32_t tws[(1u << LOG_R) / 2];  // (reading the table through L1 instead frees LDS for another tile per CU but measured 25 % slower)
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   ntt2_line_body<PP, LOG_R, LOG_TILE>(jobs[jb], blockIdx.x - jobs[jb].block0, tile, tws);
 }
 
@@ -199,8 +198,7 @@ template <class PP>
 __global__ void __launch_bounds__(256) k_ntt_fwd_line_mixed(const NttLineJob* __restrict__ jobs, int n_jobs) {
   __shared__ uint32_t tile[ntt2_line_tile_words(12, 12)];  // the same for every line length
   __shared__ uint32_t tws[(1u << 12) / 2];
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const NttLineJob& job = jobs[jb];
   const uint32_t local = blockIdx.x - job.block0;
   switch (job.log_r) {
@@ -400,8 +398,7 @@ template <class PP, int LOG_R, int MODE, int LOG_TILE = kNtt2LogTile>
 __global__ void __launch_bounds__(kNtt2Lanes, LOG_TILE == 13 ? 8 : 4) k_ntt_col(const NttColJob* __restrict__ jobs, int n_jobs) {
   __shared__ uint32_t tile[ntt2_col_tile_words(LOG_R, LOG_TILE)];
   __shared__ uint32_t tws[(1u << LOG_R) / 2];
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   ntt2_col_body<PP, LOG_R, MODE, LOG_TILE>(jobs[jb], blockIdx.x - jobs[jb].block0, tile, tws);
 }
 
@@ -412,8 +409,7 @@ template <class PP, int MODE>
 __global__ void __launch_bounds__(kNtt2Lanes) k_ntt_col_mixed(const NttColJob* __restrict__ jobs, int n_jobs) {
   __shared__ uint32_t tile[ntt2_col_tile_words(12, 13)];  // the largest: 2^12 rows x 2 columns
   __shared__ uint32_t tws[(1u << 12) / 2];
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const NttColJob& a = jobs[jb];
   const uint32_t local = blockIdx.x - a.block0;
   switch (a.log_r) {

@@ -100,8 +100,7 @@ struct LogupJob {
 template <class PP, int D = 4, int DC = 4>
 __global__ void __launch_bounds__(kBlock)
 k_logup_aux(const LogupJob* __restrict__ jobs, int n_jobs, LookupChT<DC> lc) {
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const LogupJob& job = jobs[jb];
   const size_t n = job.n, r = (size_t)(blockIdx.x - job.block0) * kBlock + threadIdx.x;
   if (r >= n) return;
@@ -320,8 +319,7 @@ __global__ void __launch_bounds__(kBlock)
 k_quotient(const QuotientArgs* __restrict__ jobs, int n_jobs, LookupChT<DC> lc, const uint32_t* __restrict__ rc) {
   using F = Fp<PP>;
   using E = typename Chal<PP, DC>::type;
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const QuotientArgs& q = jobs[jb];
   const int lq = q.log_n + q.log_chunks;
   const size_t qn = size_t(1) << lq, C = size_t(1) << q.log_chunks;
@@ -440,8 +438,7 @@ template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock) k_bary_weights(const BaryJobT<DC>* __restrict__ jobs, int n_jobs) {
   using F = Fp<PP>;
   using E = typename Chal<PP, DC>::type;
-  int j = 0;
-  while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
+  const int j = find_job(jobs, n_jobs);
   const BaryJobT<DC>& b = jobs[j];
   // four consecutive points per lane: their inversions share one base-field inversion (inv4)
   const size_t i0 = ((size_t)(blockIdx.x - b.block0) * kBlock + threadIdx.x) * 4;
@@ -547,8 +544,7 @@ __device__ __forceinline__ void open_dot_block(const OpenJob& job, int col_group
 template <class PP, int DC = 4>
 __global__ void __launch_bounds__(kBlock) k_open_dot(const OpenJob* __restrict__ jobs, int n_jobs) {
   __shared__ uint32_t sh[kBlock / 64][2 * kOpenCols * DC];
-  int j = 0;
-  while (j + 1 < n_jobs && blockIdx.x >= jobs[j + 1].block0) ++j;
+  const int j = find_job(jobs, n_jobs);
   const OpenJob job = jobs[j];
   const int local = (int)(blockIdx.x - job.block0);
   const int col_group = local % job.col_groups, chunk = local / job.col_groups;
@@ -562,8 +558,11 @@ k_open_reduce(const OpenJob* __restrict__ jobs, int n_jobs, uint32_t total, uint
   using F = Fp<PP>;
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= total) return;
-  int j = 0;
-  while (j + 1 < n_jobs && t >= jobs[j + 1].out0) ++j;
+  int j = 0, hi = n_jobs - 1;   // the last job whose first output is not past t (bisection: context.h::find_job)
+  while (j < hi) {
+    const int mid = (j + hi + 1) >> 1;
+    if (t >= jobs[mid].out0) j = mid; else hi = mid - 1;
+  }
   const OpenJob& job = jobs[j];
   const uint32_t local = t - job.out0;
   const uint32_t per_point = (uint32_t)job.w * DC, p = local / per_point, rem = local % per_point;

@@ -24,8 +24,7 @@ struct ZkRandomizeJob {
 };
 template <class PP>
 __global__ void __launch_bounds__(kBlock) k_zk_randomize(const ZkRandomizeJob* __restrict__ jobs, int n_jobs, ZkKey key) {
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const ZkRandomizeJob& j = jobs[jb];
   const uint64_t tiles_per_col = (j.h2 + kBlock - 1) / kBlock;
   const uint64_t t = blockIdx.x - j.block0;
@@ -80,8 +79,7 @@ struct ZkChunkJob {
 template <class PP>
 __global__ void __launch_bounds__(kBlock) k_zk_chunk(const ZkChunkJob* __restrict__ jobs, int n_jobs, ZkKey key) {
   using F = Fp<PP>;
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const ZkChunkJob& j = jobs[jb];
   const uint64_t h2 = 2 * j.n, tiles_per_col = (h2 + kBlock - 1) / kBlock;
   const uint64_t t = blockIdx.x - j.block0;
@@ -113,8 +111,7 @@ struct ZkSaltJob {
 };
 template <class PP>
 __global__ void __launch_bounds__(kBlock) k_zk_salts(const ZkSaltJob* __restrict__ jobs, int n_jobs, ZkKey key) {
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const ZkSaltJob& j = jobs[jb];
   const uint64_t tiles_per_col = (j.h + kBlock - 1) / kBlock;
   const uint64_t t = blockIdx.x - j.block0;
@@ -182,8 +179,7 @@ __device__ __forceinline__ void zk_block_cells(const ZkKey& key, uint32_t stream
 template <class PP>
 __global__ void __launch_bounds__(kBlock) k_zk_fill_tiles(const ZkTileJob* __restrict__ jobs, int n_jobs, ZkKey key) {
   __shared__ uint32_t tile[kZkTileWords];
-  int jb = 0;
-  while (jb + 1 < n_jobs && blockIdx.x >= jobs[jb + 1].block0) ++jb;
+  const int jb = find_job(jobs, n_jobs);
   const ZkTileJob& j = jobs[jb];
   const uint32_t w2 = j.w2, pitch = w2 | 1u, tr = 1u << j.log_tr, tid = threadIdx.x;
   const uint64_t r0 = (uint64_t)(blockIdx.x - j.block0) << j.log_tr;
